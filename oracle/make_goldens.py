@@ -1,0 +1,476 @@
+"""Generate tests/golden/*.npz from the REAL reference and pin the oracle.
+
+Run in the build container only (needs /root/reference):
+
+    python oracle/make_goldens.py
+
+For every hot-path function (goldens G1-G9) this
+script (1) runs the reference implementation imported through ``ref_shim``,
+(2) asserts that ``oracle/sr_oracle.py`` reproduces it on the same inputs,
+(3) stores inputs + reference outputs as small fixtures.  The fixtures are data
+only (inputs / expected outputs); no reference source is copied.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+import ref_shim  # noqa: E402
+ref_shim.install()
+import sr_oracle as O  # noqa: E402
+
+from dlib.models.network_swinir import SwinIR  # noqa: E402  (reference)
+from dlib.models import network_nlsn as ref_nlsn  # noqa: E402
+from dlib.utils import utils_image as ref_ui  # noqa: E402
+from dlib.utils import constants as ref_c  # noqa: E402
+from dlib import loss as ref_loss  # noqa: E402
+from dlib.learning.lr_scheduler import MyStepLR  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def close(a, b, tol, what):
+    err = (a.double() - b.double()).abs().max().item()
+    assert err <= tol, f"oracle != reference for {what}: max err {err:g} > {tol:g}"
+    print(f"  ok {what}: max|oracle-ref| = {err:.3g}")
+
+
+def sd_np(sd, prefix):
+    return {prefix + k: v for k, v in sd.items()}
+
+
+class ForcedDropPath(nn.Module):
+    """Stands in for timm.DropPath with a prescribed per-sample multiplier."""
+
+    def __init__(self, scale):
+        super().__init__()
+        self.scale = scale
+
+    def forward(self, x):
+        return x * self.scale.reshape(-1, *([1] * (x.ndim - 1)))
+
+
+# ---------------------------------------------------------------- G1 / G5
+def g_index():
+    print("G1/G5 index ops")
+    out = {}
+    for r, shp in ((2, (2, 8, 3, 5)), (8, (1, 64, 4, 6)), (3, (1, 18, 2, 2))):
+        x = torch.arange(math.prod(shp), dtype=torch.float32).reshape(shp)
+        ref = F.pixel_shuffle(x, r)
+        assert torch.equal(O.pixel_shuffle(x, r), ref)
+        out[f"ps_r{r}_in"] = x
+        out[f"ps_r{r}_out"] = ref
+    from dlib.models.network_swinir import window_partition, window_reverse, \
+        SwinTransformerBlock, WindowAttention
+    x = torch.arange(2 * 16 * 24 * 3, dtype=torch.float32).reshape(2, 16, 24, 3)
+    wp = window_partition(x, 8)
+    assert torch.equal(O.window_partition(x, 8), wp)
+    assert torch.equal(O.window_reverse(wp, 8, 16, 24), window_reverse(wp, 8, 16, 24))
+    out["wp_in"], out["wp_out"] = x, wp
+    rolled = torch.roll(x, shifts=(-4, -4), dims=(1, 2))
+    out["roll_m4"] = rolled
+    blk = SwinTransformerBlock(dim=12, input_resolution=(16, 24), num_heads=2,
+                               window_size=8, shift_size=4)
+    assert torch.equal(O.shifted_window_mask(16, 24, 8, 4), blk.attn_mask)
+    out["mask_16x24"] = blk.attn_mask
+    out["mask_72x72"] = blk.calculate_mask((72, 72))
+    assert torch.equal(O.shifted_window_mask(72, 72, 8, 4), out["mask_72x72"])
+    wa = WindowAttention(12, (8, 8), 2)
+    assert torch.equal(O.relative_position_index(8), wa.relative_position_index)
+    out["rpi_8"] = wa.relative_position_index
+    npz("g1_index", **out)
+
+
+# ---------------------------------------------------------------- G2 EDSR
+def build_ref_edsr(cfg):
+    """EDSR-baseline wired from the reference's own blocks exactly as
+    NLSN.__init__/forward does minus the attention modules."""
+    conv = ref_nlsn.default_conv
+    nf = cfg["n_feats"]
+    act = nn.ReLU(True)
+
+    class RefEDSR(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.head = nn.Sequential(conv(cfg["in_chans"], nf, 3))
+            body = [ref_nlsn.ResBlock(conv, nf, 3, act=act,
+                                      res_scale=cfg["res_scale"])
+                    for _ in range(cfg["n_resblocks"])]
+            body.append(conv(nf, nf, 3))
+            self.body = nn.Sequential(*body)
+            self.tail = nn.Sequential(
+                ref_nlsn.Upsampler(conv, cfg["upscale"], nf, act=False),
+                nn.Conv2d(nf, cfg["in_chans"], 3, padding=1))
+
+        def forward(self, x):
+            x = self.head(x)
+            res = self.body(x)
+            res = res + x
+            return self.tail(res)
+    return RefEDSR()
+
+
+def g_edsr():
+    print("G2 EDSR-baseline from reference blocks")
+    for scale, shp in ((2, (1, 1, 16, 16)), (4, (1, 1, 24, 40)), (8, (2, 1, 16, 16))):
+        # small nets (16 feats, 2-3 blocks) keep the fixtures small; the
+        # full-size EDSR-baseline is checked forward-only with seeded weights.
+        cfg = O.edsr_config(upscale=scale, n_feats=16,
+                            n_resblocks=3 if scale != 4 else 2,
+                            res_scale=1.0 if scale != 8 else 0.1)
+        sd = O.edsr_init_state_dict(cfg, seed=10 + scale)
+        net = build_ref_edsr(cfg)
+        missing = net.load_state_dict(sd, strict=True)
+        torch.manual_seed(scale)
+        x = torch.rand(shp)
+        y = net(x)
+        loss = y.abs().mean()
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+
+        sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        yo = O.edsr_forward(sdo, x, cfg)
+        close(yo, y, 1e-6, f"edsr x{scale} forward")
+        yo.abs().mean().backward()
+        for k in grads:
+            close(sdo[k].grad, grads[k], 1e-6, f"edsr x{scale} grad {k}") \
+                if k in ("head.0.weight", "tail.1.bias") else None
+            assert (sdo[k].grad - grads[k]).abs().max() < 1e-6, k
+        arrs = dict(x=x, y=y, cfg=np.array([scale, cfg["n_resblocks"],
+                                            cfg["n_feats"]]),
+                    res_scale=np.array(cfg["res_scale"]))
+        arrs.update(sd_np(sd, "sd/"))
+        arrs.update(sd_np(grads, "grad/"))
+        npz(f"g2_edsr_x{scale}", **arrs)
+
+
+def g_edsr_full():
+    print("G2b EDSR-baseline full size (16x64), seeded weights, forward only")
+    out = {}
+    for scale, hw in ((4, 32), (8, 16)):
+        cfg = O.edsr_config(upscale=scale)
+        sd = O.edsr_init_state_dict(cfg, seed=scale)
+        net = build_ref_edsr(cfg)
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(40 + scale)
+        x = torch.rand(1, 1, hw, hw)
+        with torch.no_grad():
+            y = net(x)
+            close(O.edsr_forward(sd, x, cfg), y, 1e-6, f"edsr full x{scale}")
+        out[f"x{scale}/x"], out[f"x{scale}/y"] = x, y
+    npz("g2b_edsr_full", **out)
+
+
+# ---------------------------------------------------------------- G3 SwinIR tiny
+def tiny_cfg(drop_path_rate=0.0):
+    return O.swinir_config(upscale=8, in_chans=1, img_size=16, window_size=8,
+                           depths=(2, 2), embed_dim=60, num_heads=(6, 6),
+                           mlp_ratio=2, upsampler="pixelshuffledirect",
+                           drop_path_rate=drop_path_rate)
+
+
+def build_ref_swinir(cfg):
+    return SwinIR(upscale=cfg["upscale"], in_chans=cfg["in_chans"],
+                  img_size=cfg["img_size"], window_size=cfg["window_size"],
+                  img_range=cfg["img_range"], depths=cfg["depths"],
+                  embed_dim=cfg["embed_dim"], num_heads=cfg["num_heads"],
+                  mlp_ratio=cfg["mlp_ratio"], upsampler=cfg["upsampler"],
+                  resi_connection=cfg["resi_connection"])
+
+
+def perturb(sd, seed):
+    """Make LN affine / Linear bias non-trivial so tests see them."""
+    g = torch.Generator().manual_seed(seed)
+    for k, v in sd.items():
+        if v.dtype != torch.float32 or k.endswith("attn_mask"):
+            continue
+        if "norm" in k or (k.endswith(".bias") and ("qkv" in k or "proj" in k
+                                                      or "fc" in k)):
+            v.add_(0.1 * torch.randn(v.shape, generator=g))
+    return sd
+
+
+def g_swinir_tiny():
+    print("G3 SwinIR tiny")
+    cfg = tiny_cfg()
+    sd = perturb(O.swinir_init_state_dict(cfg, seed=3), 33)
+    net = build_ref_swinir(cfg)
+    net.load_state_dict(sd, strict=True)
+    assert list(net.state_dict().keys()) == list(sd.keys()), "key order"
+    net.eval()
+    torch.manual_seed(5)
+    x = torch.rand(2, 1, 16, 16)
+
+    # eval forward + taps via hooks on the first block
+    taps_ref = {}
+    b0 = net.layers[0].residual_group.blocks[0]
+    def tap(name, first=False):
+        def hook(mod, inp, out):  # must return None (else it replaces out)
+            taps_ref.setdefault(name, (out[0] if first else out).detach().clone())
+        return hook
+    hk = [b0.norm1.register_forward_hook(tap("ln1")),
+          b0.attn.qkv.register_forward_hook(tap("qkv")),
+          b0.attn.softmax.register_forward_hook(tap("attn_probs_w0", True)),
+          b0.register_forward_hook(tap("block0_out"))]
+    with torch.no_grad():
+        y_eval = net(x)
+    for h in hk:
+        h.remove()
+    taps = {}
+    with torch.no_grad():
+        yo = O.swinir_forward(sd, x, cfg, taps=taps)
+    close(yo, y_eval, 2e-6, "swinir tiny eval forward")
+    for k in taps_ref:
+        close(taps[k], taps_ref[k], 2e-6, f"tap {k}")
+
+    # train-mode grads.  The reference always builds SwinIR with
+    # drop_path_rate=0.1 (define_G never overrides it), so stochastic depth is
+    # live in train mode; neutralise it here, the forced-mask case is below.
+    net.train()
+    for l in net.layers:
+        for b in l.residual_group.blocks:
+            b.drop_path = nn.Identity()
+    xg = x.clone().requires_grad_(True)
+    y = net(xg)
+    torch.manual_seed(6)
+    tgt = torch.rand_like(y)
+    (y - tgt).abs().mean().backward()
+    grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask") else v)
+           for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = O.swinir_forward(sdo, xo, cfg)
+    (yo - tgt).abs().mean().backward()
+    close(xo.grad, xg.grad, 1e-7, "swinir tiny dL/dx")
+    for k in grads:
+        e = (sdo[k].grad - grads[k]).abs().max().item()
+        assert e < 2e-7, (k, e)
+    print("  ok swinir tiny param grads")
+
+    # forced drop-path (training semantics with prescribed masks)
+    cfg_dp = tiny_cfg(0.5)
+    rates = O.swinir_drop_path_rates(cfg_dp)
+    torch.manual_seed(7)
+    dp = []
+    blocks = [b for l in net.layers for b in l.residual_group.blocks]
+    for r, b in zip(rates, blocks):
+        keep = 1.0 - r
+        m = torch.bernoulli(torch.full((2, 2), keep)) / keep if r > 0 else torch.ones(2, 2)
+        dp.append(m)
+
+        class TwoCall(nn.Module):
+            def __init__(self, m):
+                super().__init__()
+                self.m, self.i = m, 0
+
+            def forward(self, t):
+                s = self.m[self.i % 2]
+                self.i += 1
+                return t * s.reshape(-1, 1, 1)
+        b.drop_path = TwoCall(m)
+    y_dp = net(x)
+    yo = O.swinir_forward(sd, x, cfg_dp, dp_scales=dp)
+    close(yo, y_dp.detach(), 2e-6, "swinir tiny forced drop-path forward")
+
+    # padded / non-square path (x_size != input_resolution, mask recomputed)
+    net2 = build_ref_swinir(cfg)
+    net2.load_state_dict(sd, strict=True)
+    net2.eval()
+    torch.manual_seed(8)
+    xp = torch.rand(1, 1, 12, 20)
+    with torch.no_grad():
+        y_pad = net2(xp)
+        yo = O.swinir_forward(sd, xp, cfg)
+    close(yo, y_pad, 2e-6, "swinir tiny padded 12x20")
+
+    arrs = dict(x=x, y_eval=y_eval, target=tgt, dx=xg.grad, y_dp=y_dp,
+                dp=torch.stack(dp), x_pad=xp, y_pad=y_pad)
+    arrs.update({"tap/" + k: v for k, v in taps_ref.items()})
+    arrs.update(sd_np(sd, "sd/"))
+    arrs.update(sd_np(grads, "grad/"))
+    npz("g3_swinir_tiny", **arrs)
+
+
+# ---------------------------------------------------------------- G4 README config
+def g_swinir_readme():
+    print("G4 SwinIR README-config forward (seeded weights, output only)")
+    cfg = O.swinir_config()
+    sd = O.swinir_init_state_dict(cfg, seed=0)
+    net = build_ref_swinir(cfg)
+    net.load_state_dict(sd, strict=True)
+    n_params = sum(p.numel() for p in net.parameters())
+    assert n_params == 7865884, n_params
+    assert len(net.state_dict()) == 366
+    net.eval()
+    torch.manual_seed(0)
+    x = torch.rand(1, 1, 64, 64)
+    with torch.no_grad():
+        y = net(x)
+        yo = O.swinir_forward(sd, x, cfg)
+    close(yo, y, 5e-6, "swinir README forward 64x64")
+    keys = np.array(list(net.state_dict().keys()))
+    shapes = np.array([str(tuple(v.shape)) for v in net.state_dict().values()])
+    npz("g4_swinir_readme", x=x, y=y, keys=keys, shapes=shapes,
+        n_params=np.array(n_params))
+
+
+# ---------------------------------------------------------------- G6 losses
+def g_losses():
+    print("G6 MasterLoss")
+    torch.manual_seed(11)
+    pred = torch.rand(2, 1, 64, 64)
+    tgt = torch.rand(2, 1, 64, 64)
+    wgt = torch.rand(2, 1, 64, 64) * 2
+    out = dict(pred=pred, target=tgt, weight=wgt)
+
+    def ref_master(terms, weight=None):
+        m = ref_loss.MasterLoss(cuda_id="cpu")
+        for t in terms:
+            if t[0] == "l1":
+                m.add(ref_loss.L1(cuda_id="cpu", lambda_=t[1]))
+            elif t[0] == "l2":
+                m.add(ref_loss.L2(cuda_id="cpu", lambda_=t[1]))
+            elif t[0] == "ssim":
+                l = ref_loss.NegativeSsim(cuda_id="cpu", lambda_=t[1])
+                l.set_window_size(t[2])
+                m.add(l)
+        p = pred.clone().requires_grad_(True)
+        v = m(epoch=0, y_pred=p, y_target=tgt, trg_per_pixel_weight=weight,
+              model=None)
+        v.backward()
+        return v.detach(), torch.stack([h.detach().reshape(()) for h in m.l_holder]), p.grad, m.n_holder
+
+    cases = {"l1": ([("l1", 1.0)], None),
+             "l2_ssim19": ([("l2", 1.0), ("ssim", 5.0, 19)], None),
+             "l1_weighted": ([("l1", 1.0)], wgt),
+             "ssim11": ([("ssim", 1.0, 11)], None)}
+    for name, (terms, w) in cases.items():
+        v, holder, g, names = ref_master(terms, w)
+        p = pred.clone().requires_grad_(True)
+        vo, ho = O.master_loss(p, tgt, terms, w)
+        vo.backward()
+        close(vo.detach(), v, 1e-6, f"loss {name}")
+        close(torch.stack([h.detach() for h in ho]), holder, 1e-6, f"l_holder {name}")
+        close(p.grad, g, 1e-8, f"dL/dpred {name}")
+        out[name + "/l_holder"] = holder
+        out[name + "/grad"] = g
+        out[name + "/names"] = np.array(names)
+    npz("g6_losses", **out)
+
+
+# ---------------------------------------------------------------- G7 metrics
+def g_metrics():
+    print("G7 metrics")
+    torch.manual_seed(21)
+    hr = (torch.rand(3, 1, 96, 96) * 255).round() / 255
+    hr[2] = hr[2] * 0 + 0.25          # constant image
+    pr = (hr + 0.05 * torch.randn_like(hr))
+    pr[1] = hr[1]                     # identical pair -> mse floor
+    a = ref_ui.tensor2uint82float(pr)
+    b = ref_ui.tensor2uint82float(hr)
+    assert torch.equal(O.tensor2uint82float(pr), a)
+    # rounding corner cases
+    corner = torch.tensor([0.5 / 255, 1.5 / 255, 2.5 / 255, -0.1, 1.2, 0.49999 / 255]).reshape(1, 1, 2, 3)
+    assert torch.equal(O.tensor2uint82float(corner), ref_ui.tensor2uint82float(corner))
+    out = dict(pred=pr, hr=hr, a=a, b=b, corner=corner,
+               corner_out=ref_ui.tensor2uint82float(corner))
+    border = 8
+    for th in (None, 4, 7, 10, 300):
+        roi = None if th is None else (b >= th).float()
+        tag = "noroi" if th is None else f"roi{th}"
+        for nm, rf, of in (("psnr", ref_ui.mbatch_gpu_calculate_psnr, O.metric_psnr),
+                           ("mse", ref_ui.mbatch_gpu_calculate_mse, O.metric_mse),
+                           ("nrmse", ref_ui.mbatch_gpu_calculate_nrmse, O.metric_nrmse),
+                           ("ssim", ref_ui.mbatch_gpu_calculate_ssim, O.metric_ssim)):
+            r = rf(a.clone(), b.clone(), border=border, roi=None if roi is None else roi.clone())
+            o = of(a.clone(), b.clone(), border=border, roi=None if roi is None else roi.clone())
+            close(o, r, 1e-9 if nm != "ssim" else 1e-6, f"{nm} {tag}")
+            out[f"{nm}/{tag}"] = r
+    assert abs(out["psnr/noroi"][1].item() - 498.1308) < 1e-3  # mse floor
+    # PSNR_Y path for gray images
+    def rgb(t):
+        return t.repeat(1, 3, 1, 1)
+    ya = ref_ui.mb_gpu_rgb2ycbcr(rgb(a / 255.0), only_y=True)
+    yb = ref_ui.mb_gpu_rgb2ycbcr(rgb(b / 255.0), only_y=True)
+    close(O.gray_to_y(a / 255.0), ya, 1e-7, "gray->Y")
+    ya8, yb8 = ref_ui.tensor2uint82float(ya), ref_ui.tensor2uint82float(yb)
+    out["psnr_y/noroi"] = ref_ui.mbatch_gpu_calculate_psnr(ya8, yb8, border=border)
+    close(O.metric_psnr(O.tensor2uint82float(O.gray_to_y(a / 255.0)),
+                        O.tensor2uint82float(O.gray_to_y(b / 255.0)), border),
+          out["psnr_y/noroi"], 1e-9, "psnr_y")
+    out["border"] = np.array(border)
+    npz("g7_metrics", **out)
+
+
+# ---------------------------------------------------------------- G8 optim
+def g_optim():
+    print("G8 optimizer + MyStepLR")
+    torch.manual_seed(31)
+    p0 = torch.randn(257)
+    gs = torch.randn(3, 257)
+    out = dict(p0=p0, grads=gs)
+    for name in ("adam", "adam_wd", "sgd"):
+        p = nn.Parameter(p0.clone())
+        if name == "adam":
+            opt = torch.optim.Adam([p], lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+        elif name == "adam_wd":
+            opt = torch.optim.Adam([p], lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+        else:
+            opt = torch.optim.SGD([p], lr=0.01, momentum=0.9, nesterov=True, weight_decay=0.0)
+        po = p0.clone()
+        m, v, buf = torch.zeros(257), torch.zeros(257), torch.zeros(257)
+        traj = []
+        for i in range(3):
+            p.grad = gs[i].clone()
+            opt.step()
+            if name == "sgd":
+                O.sgd_nesterov_step(po, gs[i], buf, i == 0, 0.01)
+            else:
+                O.adam_step(po, gs[i], m, v, i + 1, 2e-4, wd=1e-4 if name == "adam_wd" else 0.0)
+            close(po, p.detach(), 2e-7, f"{name} step {i + 1}")
+            traj.append(p.detach().clone())
+        out[name] = torch.stack(traj)
+    p = nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([p], lr=0.01)
+    sch = MyStepLR(opt, step_size=30, gamma=0.5, last_epoch=-1, min_lr=1e-4)
+    lrs = []
+    for it in range(300):
+        opt.step()
+        sch.step()
+        lrs.append(opt.param_groups[0]["lr"])
+        assert abs(lrs[-1] - O.mysteplr(0.01, it + 1, 30, 0.5, 1e-4)) < 1e-15
+    out["mysteplr"] = np.array(lrs)
+    npz("g8_optim", **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    g_index()
+    g_edsr()
+    g_edsr_full()
+    g_swinir_tiny()
+    g_swinir_readme()
+    g_losses()
+    g_metrics()
+    g_optim()
+    print("all goldens written; oracle pinned against the reference.")

@@ -1,0 +1,555 @@
+"""CPU oracle for the SR-CACO-2 patch-level hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain PyTorch-fp32 (metrics: fp64) restatement of the reference
+algorithms on the hot path.  It is the *checker*: only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import it.  Nothing under ``sr-caco-2_amd/`` imports it; the product path
+runs hand-written HIP kernels and fails loudly when they are missing.
+
+Parity pin: ``oracle/make_goldens.py`` imports the real reference modules from
+``/root/reference`` (through a ``sys.modules`` shim), checks every function
+below against them on seeded inputs, and stores the reference outputs as small
+fixtures in ``tests/golden/``.  ``tests/test_oracle_golden.py`` re-checks the
+oracle against those fixtures wherever the reference tree is absent.
+
+Everything here is *functional*: networks take a ``state_dict`` (same keys and
+shapes as the reference modules) and a config dict.  Citations are
+``file:line`` relative to ``/root/reference``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# ----------------------------------------------------------------------------
+# index-only pieces (bit-exact gates)
+# ----------------------------------------------------------------------------
+def pixel_shuffle(x: Tensor, r: int) -> Tensor:
+    """out[b,c,h*r+i,w*r+j] = in[b,c*r*r+i*r+j,h,w]  (nn.PixelShuffle as used at
+    dlib/models/network_nlsn.py:108 and network_swinir.py:701)."""
+    b, c, h, w = x.shape
+    co = c // (r * r)
+    x = x.reshape(b, co, r, r, h, w)
+    return x.permute(0, 1, 4, 2, 5, 3).reshape(b, co, h * r, w * r)
+
+
+def window_partition(x: Tensor, ws: int) -> Tensor:
+    """(B,H,W,C) -> (B*nW, ws, ws, C); network_swinir.py:48-62."""
+    b, h, w, c = x.shape
+    x = x.reshape(b, h // ws, ws, w // ws, ws, c)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(-1, ws, ws, c)
+
+
+def window_reverse(win: Tensor, ws: int, h: int, w: int) -> Tensor:
+    """(B*nW, ws, ws, C) -> (B,H,W,C); network_swinir.py:65-80."""
+    b = win.shape[0] // ((h // ws) * (w // ws))
+    x = win.reshape(b, h // ws, w // ws, ws, ws, -1)
+    return x.permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, -1)
+
+
+def relative_position_index(ws: int) -> Tensor:
+    """(ws*ws, ws*ws) int64 table index; network_swinir.py:116-128."""
+    ys, xs = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
+    ys, xs = ys.reshape(-1), xs.reshape(-1)
+    dy = ys[:, None] - ys[None, :] + ws - 1
+    dx = xs[:, None] - xs[None, :] + ws - 1
+    return dy * (2 * ws - 1) + dx
+
+
+def shifted_window_mask(h: int, w: int, ws: int, shift: int) -> Tensor:
+    """(nW, ws*ws, ws*ws) in {0,-100}; network_swinir.py:260-285."""
+    region = torch.zeros(h, w)
+    bounds_h = [(0, h - ws), (h - ws, h - shift), (h - shift, h)]
+    bounds_w = [(0, w - ws), (w - ws, w - shift), (w - shift, w)]
+    k = 0
+    for (h0, h1) in bounds_h:
+        for (w0, w1) in bounds_w:
+            region[h0:h1, w0:w1] = k
+            k += 1
+    rw = window_partition(region[None, :, :, None], ws).reshape(-1, ws * ws)
+    diff = rw[:, None, :] - rw[:, :, None]
+    return torch.where(diff != 0, torch.full_like(diff, -100.0),
+                       torch.zeros_like(diff))
+
+
+# ----------------------------------------------------------------------------
+# SwinIR (network_swinir.py:710-970)
+# ----------------------------------------------------------------------------
+def swinir_config(upscale=8, in_chans=1, img_size=64, window_size=8,
+                  img_range=1.0, depths=(6, 6, 6, 6), embed_dim=180,
+                  num_heads=(6, 6, 6, 6), mlp_ratio=2,
+                  upsampler="pixelshuffledirect", resi_connection="1conv",
+                  drop_path_rate=0.1) -> dict:
+    """README.md:120-197 configuration by default."""
+    return dict(upscale=upscale, in_chans=in_chans, img_size=img_size,
+                window_size=window_size, img_range=img_range,
+                depths=list(depths), embed_dim=embed_dim,
+                num_heads=list(num_heads), mlp_ratio=mlp_ratio,
+                upsampler=upsampler, resi_connection=resi_connection,
+                drop_path_rate=drop_path_rate)
+
+
+def swinir_drop_path_rates(cfg: dict) -> List[float]:
+    """network_swinir.py:821 -- linspace(0, rate, sum(depths))."""
+    n = sum(cfg["depths"])
+    return [v.item() for v in torch.linspace(0, cfg["drop_path_rate"], n)]
+
+
+def _wmsa(sd: SD, pre: str, xw: Tensor, heads: int, mask: Optional[Tensor],
+          rpi: Tensor, taps: Optional[dict]) -> Tensor:
+    """WindowAttention.forward, network_swinir.py:140-179."""
+    nb, n, c = xw.shape
+    d = c // heads
+    qkv = F.linear(xw, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"])
+    if taps is not None:
+        taps.setdefault("qkv", qkv.detach().clone())
+    qkv = qkv.reshape(nb, n, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (d ** -0.5), qkv[1], qkv[2]
+    att = q @ k.transpose(-2, -1)
+    bias = sd[pre + "relative_position_bias_table"][rpi.reshape(-1)]
+    att = att + bias.reshape(n, n, heads).permute(2, 0, 1)[None]
+    if mask is not None:
+        nw = mask.shape[0]
+        att = (att.reshape(nb // nw, nw, heads, n, n)
+               + mask[None, :, None]).reshape(nb, heads, n, n)
+    att = att.softmax(dim=-1)
+    if taps is not None:
+        taps.setdefault("attn_probs_w0", att[0].detach().clone())
+    out = (att @ v).transpose(1, 2).reshape(nb, n, c)
+    return F.linear(out, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+
+
+def _swin_block(sd: SD, pre: str, x: Tensor, hw: Tuple[int, int], ws: int,
+                shift: int, heads: int, dp_scale: Optional[Tensor],
+                rpi: Tensor, taps: Optional[dict]) -> Tensor:
+    """SwinTransformerBlock.forward, network_swinir.py:287-337."""
+    h, w = hw
+    b, l, c = x.shape
+    y = F.layer_norm(x, (c,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"])
+    if taps is not None:
+        taps.setdefault("ln1", y.detach().clone())
+    y = y.reshape(b, h, w, c)
+    if shift:
+        y = torch.roll(y, shifts=(-shift, -shift), dims=(1, 2))
+        mask = shifted_window_mask(h, w, ws, shift).to(x)
+    else:
+        mask = None
+    yw = window_partition(y, ws).reshape(-1, ws * ws, c)
+    yw = _wmsa(sd, pre + "attn.", yw, heads, mask, rpi, taps)
+    y = window_reverse(yw.reshape(-1, ws, ws, c), ws, h, w)
+    if shift:
+        y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
+    y = y.reshape(b, l, c)
+    if dp_scale is not None:  # timm DropPath: per-sample mask / keep_prob
+        y = y * dp_scale[0].reshape(b, 1, 1)
+    x = x + y
+    y = F.layer_norm(x, (c,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
+    y = F.linear(y, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])
+    y = F.gelu(y)  # nn.GELU default = exact erf (network_swinir.py:30)
+    y = F.linear(y, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    if dp_scale is not None:
+        y = y * dp_scale[1].reshape(b, 1, 1)
+    x = x + y
+    if taps is not None:
+        taps.setdefault("block0_out", x.detach().clone())
+    return x
+
+
+def swinir_forward(sd: SD, x: Tensor, cfg: dict,
+                   dp_scales: Optional[Sequence[Tensor]] = None,
+                   taps: Optional[dict] = None) -> Tensor:
+    """SwinIR.forward for upsampler 'pixelshuffledirect' / 'pixelshuffle'
+    (network_swinir.py:930-970).  ``dp_scales``: per block a (2,B) tensor of
+    DropPath multipliers (mask/keep_prob) for the attention and MLP branches,
+    or None for eval / drop_path_rate 0.  ``taps`` collects intermediates of
+    the first block for per-stage parity tests."""
+    ws = cfg["window_size"]
+    c = cfg["embed_dim"]
+    s = cfg["upscale"]
+    h0, w0 = x.shape[2:]
+    ph, pw = (ws - h0 % ws) % ws, (ws - w0 % ws) % ws
+    if ph or pw:
+        x = F.pad(x, (0, pw, 0, ph), mode="reflect")  # :908-913
+    mean = torch.zeros(1, 1, 1, 1) if cfg["in_chans"] != 3 else \
+        torch.tensor((0.4488, 0.4371, 0.4040)).reshape(1, 3, 1, 1)
+    mean = mean.to(x)
+    x = (x - mean) * cfg["img_range"]
+    h, w = x.shape[2:]
+    rpi = relative_position_index(ws)
+
+    f0 = F.conv2d(x, sd["conv_first.weight"], sd["conv_first.bias"], padding=1)
+    t = f0.flatten(2).transpose(1, 2)  # PatchEmbed :610-614
+    t = F.layer_norm(t, (c,), sd["patch_embed.norm.weight"],
+                     sd["patch_embed.norm.bias"])
+    bi = 0
+    for li, depth in enumerate(cfg["depths"]):
+        t_in = t
+        for j in range(depth):
+            # a block clamps its window to the image when the image is not
+            # larger than the window (network_swinir.py:232-236)
+            wsj, shift = ws, (0 if j % 2 == 0 else ws // 2)
+            if cfg["img_size"] <= ws:
+                wsj, shift = cfg["img_size"], 0
+            t = _swin_block(sd, f"layers.{li}.residual_group.blocks.{j}.", t,
+                            (h, w), wsj, shift, cfg["num_heads"][li],
+                            None if dp_scales is None else dp_scales[bi],
+                            rpi if wsj == ws else relative_position_index(wsj),
+                            taps if bi == 0 else None)
+            bi += 1
+        img = t.transpose(1, 2).reshape(-1, c, h, w)  # PatchUnEmbed :651-655
+        img = F.conv2d(img, sd[f"layers.{li}.conv.weight"],
+                       sd[f"layers.{li}.conv.bias"], padding=1)
+        t = img.flatten(2).transpose(1, 2) + t_in  # RSTB :562-565
+    t = F.layer_norm(t, (c,), sd["norm.weight"], sd["norm.bias"])
+    img = t.transpose(1, 2).reshape(-1, c, h, w)
+    f = F.conv2d(img, sd["conv_after_body.weight"], sd["conv_after_body.bias"],
+                 padding=1) + f0
+    if cfg["upsampler"] == "pixelshuffledirect":  # :943-947
+        y = F.conv2d(f, sd["upsample.0.weight"], sd["upsample.0.bias"],
+                     padding=1)
+        y = pixel_shuffle(y, s)
+    elif cfg["upsampler"] == "pixelshuffle":  # :937-942
+        y = F.leaky_relu(F.conv2d(f, sd["conv_before_upsample.0.weight"],
+                                  sd["conv_before_upsample.0.bias"], padding=1),
+                         0.01)
+        for i in range(int(math.log2(s))):
+            y = F.conv2d(y, sd[f"upsample.{2 * i}.weight"],
+                         sd[f"upsample.{2 * i}.bias"], padding=1)
+            y = pixel_shuffle(y, 2)
+        y = F.conv2d(y, sd["conv_last.weight"], sd["conv_last.bias"], padding=1)
+    else:
+        raise NotImplementedError(cfg["upsampler"])
+    y = y / cfg["img_range"] + mean
+    return y[:, :, :h0 * s, :w0 * s]
+
+
+def swinir_init_state_dict(cfg: dict, seed: int = 0) -> SD:
+    """Deterministic weights with the reference's shapes/keys.  Values follow
+    the reference's init *distributions* (trunc-normal std .02 for Linear and
+    the bias table, default Conv2d init; network_swinir.py:891-897) but not its
+    RNG stream -- parity tests always load one state_dict into both sides."""
+    g = torch.Generator().manual_seed(seed)
+    c, ws = cfg["embed_dim"], cfg["window_size"]
+    hid = int(c * cfg["mlp_ratio"])
+    sd: SD = {}
+
+    def conv(name, co, ci):
+        bound = 1.0 / math.sqrt(ci * 9)
+        sd[name + ".weight"] = (torch.rand(co, ci, 3, 3, generator=g) * 2 - 1) * bound
+        sd[name + ".bias"] = (torch.rand(co, generator=g) * 2 - 1) * bound
+
+    def lin(name, co, ci):
+        sd[name + ".weight"] = torch.nn.init.trunc_normal_(
+            torch.empty(co, ci), std=0.02, generator=g)
+        sd[name + ".bias"] = torch.zeros(co)
+
+    def ln(name):
+        sd[name + ".weight"] = torch.ones(c)
+        sd[name + ".bias"] = torch.zeros(c)
+
+    conv("conv_first", c, cfg["in_chans"])
+    ln("patch_embed.norm")
+    size = cfg["img_size"]
+    wsb = min(ws, size) if size <= ws else ws
+    for li, depth in enumerate(cfg["depths"]):
+        heads = cfg["num_heads"][li]
+        for j in range(depth):
+            p = f"layers.{li}.residual_group.blocks.{j}."
+            shift = 0 if (j % 2 == 0 or size <= ws) else ws // 2
+            if shift:  # a module's own buffers precede its children
+                sd[p + "attn_mask"] = shifted_window_mask(size, size, ws, shift)
+            ln(p + "norm1")
+            sd[p + "attn.relative_position_bias_table"] = \
+                torch.nn.init.trunc_normal_(
+                    torch.empty((2 * wsb - 1) ** 2, heads), std=0.02, generator=g)
+            sd[p + "attn.relative_position_index"] = relative_position_index(wsb)
+            lin(p + "attn.qkv", 3 * c, c)
+            lin(p + "attn.proj", c, c)
+            ln(p + "norm2")
+            lin(p + "mlp.fc1", hid, c)
+            lin(p + "mlp.fc2", c, hid)
+        conv(f"layers.{li}.conv", c, c)
+    ln("norm")
+    conv("conv_after_body", c, c)
+    s = cfg["upscale"]
+    if cfg["upsampler"] == "pixelshuffledirect":
+        conv("upsample.0", s * s * cfg["in_chans"], c)
+    else:
+        conv("conv_before_upsample.0", 64, c)
+        for i in range(int(math.log2(s))):
+            conv(f"upsample.{2 * i}", 256, 64)
+        conv("conv_last", cfg["in_chans"], 64)
+    return sd
+
+
+# ----------------------------------------------------------------------------
+# EDSR-baseline assembled from the reference's EDSR blocks
+# (network_nlsn.py:38-128 blocks, :355-369 wiring without attention;
+#  sizes utils_init_default_args.py:37-50)
+# ----------------------------------------------------------------------------
+def edsr_config(upscale=4, in_chans=1, n_feats=64, n_resblocks=16,
+                res_scale=1.0) -> dict:
+    return dict(upscale=upscale, in_chans=in_chans, n_feats=n_feats,
+                n_resblocks=n_resblocks, res_scale=res_scale)
+
+
+def edsr_forward(sd: SD, x: Tensor, cfg: dict) -> Tensor:
+    nb = cfg["n_resblocks"]
+    f0 = F.conv2d(x, sd["head.0.weight"], sd["head.0.bias"], padding=1)
+    r = f0
+    for k in range(nb):  # ResBlock: conv-ReLU-conv, *res_scale, +x  (:89-93)
+        y = F.relu(F.conv2d(r, sd[f"body.{k}.body.0.weight"],
+                            sd[f"body.{k}.body.0.bias"], padding=1))
+        y = F.conv2d(y, sd[f"body.{k}.body.2.weight"],
+                     sd[f"body.{k}.body.2.bias"], padding=1)
+        r = y * cfg["res_scale"] + r
+    r = F.conv2d(r, sd[f"body.{nb}.weight"], sd[f"body.{nb}.bias"], padding=1)
+    r = r + f0  # :363-364
+    for i in range(int(math.log2(cfg["upscale"]))):  # Upsampler :100-108
+        r = F.conv2d(r, sd[f"tail.0.{2 * i}.weight"],
+                     sd[f"tail.0.{2 * i}.bias"], padding=1)
+        r = pixel_shuffle(r, 2)
+    return F.conv2d(r, sd["tail.1.weight"], sd["tail.1.bias"], padding=1)
+
+
+def edsr_init_state_dict(cfg: dict, seed: int = 0) -> SD:
+    g = torch.Generator().manual_seed(seed)
+    nf, nb = cfg["n_feats"], cfg["n_resblocks"]
+    sd: SD = {}
+
+    def conv(name, co, ci):
+        bound = 1.0 / math.sqrt(ci * 9)
+        sd[name + ".weight"] = (torch.rand(co, ci, 3, 3, generator=g) * 2 - 1) * bound
+        sd[name + ".bias"] = (torch.rand(co, generator=g) * 2 - 1) * bound
+
+    conv("head.0", nf, cfg["in_chans"])
+    for k in range(nb):
+        conv(f"body.{k}.body.0", nf, nf)
+        conv(f"body.{k}.body.2", nf, nf)
+    conv(f"body.{nb}", nf, nf)
+    for i in range(int(math.log2(cfg["upscale"]))):
+        conv(f"tail.0.{2 * i}", 4 * nf, nf)
+    conv("tail.1", cfg["in_chans"], nf)
+    return sd
+
+
+# ----------------------------------------------------------------------------
+# losses (dlib/loss/main.py, dlib/loss/ssim.py, dlib/loss/master.py)
+# ----------------------------------------------------------------------------
+def loss_l1(pred: Tensor, target: Tensor, lam: float = 1.0,
+            weight: Optional[Tensor] = None) -> Tensor:
+    """loss/main.py:45-76."""
+    e = (pred - target).abs()
+    if weight is not None:
+        e = e * weight
+    return lam * e.mean()
+
+
+def loss_l2(pred: Tensor, target: Tensor, lam: float = 1.0) -> Tensor:
+    """loss/main.py:79-99."""
+    return lam * ((pred - target) ** 2).mean()
+
+
+def gaussian_window_1d(ws: int, sigma: float = 1.5) -> Tensor:
+    """loss/ssim.py:23-27 (float32 taps, normalised)."""
+    g = torch.tensor([math.exp(-(i - ws // 2) ** 2 / float(2 * sigma ** 2))
+                      for i in range(ws)], dtype=torch.float32)
+    return g / g.sum()
+
+
+def ssim_map_same(a: Tensor, b: Tensor, ws: int) -> Tensor:
+    """loss/ssim.py:38-56: zero-padded 'same' depthwise Gaussian, C1=1e-4,
+    C2=9e-4."""
+    ch = a.shape[1]
+    g = gaussian_window_1d(ws)
+    win = (g[:, None] @ g[None, :]).float()[None, None].expand(ch, 1, ws, ws)
+    win = win.contiguous().to(a)
+    pad = ws // 2
+
+    def blur(t):
+        return F.conv2d(t, win, padding=pad, groups=ch)
+    mu1, mu2 = blur(a), blur(b)
+    s11 = blur(a * a) - mu1 * mu1
+    s22 = blur(b * b) - mu2 * mu2
+    s12 = blur(a * b) - mu1 * mu2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / (
+        (mu1 * mu1 + mu2 * mu2 + c1) * (s11 + s22 + c2))
+
+
+def loss_neg_ssim(pred: Tensor, target: Tensor, lam: float = 1.0,
+                  ws: int = 11) -> Tensor:
+    """loss/main.py:154-186: -lambda * mean_b(mean_chw(ssim_map))."""
+    m = ssim_map_same(pred, target, ws)
+    return -lam * m.mean(1).mean(1).mean(1).mean()
+
+
+def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
+                weight: Optional[Tensor] = None) -> Tuple[Tensor, List[Tensor]]:
+    """loss/master.py:46-56.  ``terms``: ('l1',lam) | ('l2',lam) |
+    ('ssim',lam,ws).  Returns (total, l_holder) with l_holder[0] == total."""
+    parts = []
+    for t in terms:
+        if t[0] == "l1":
+            parts.append(loss_l1(pred, target, t[1], weight))
+        elif t[0] == "l2":
+            parts.append(loss_l2(pred, target, t[1]))
+        elif t[0] == "ssim":
+            parts.append(loss_neg_ssim(pred, target, t[1], t[2]))
+        else:
+            raise ValueError(t[0])
+    total = sum(parts)
+    return total, [total] + parts
+
+
+# ----------------------------------------------------------------------------
+# metrics (dlib/utils/utils_image.py)
+# ----------------------------------------------------------------------------
+def tensor2uint82float(img: Tensor) -> Tensor:
+    """utils_image.py:369-372 (round half to even, as torch.round)."""
+    return (img.float().clamp(0, 1) * 255.0).round().clamp(0, 255).float()
+
+
+def _crop(t: Optional[Tensor], border: int) -> Optional[Tensor]:
+    if t is None:
+        return None
+    h, w = t.shape[2:]
+    return t[:, :, border:h - border, border:w - border]
+
+
+def metric_mse(a: Tensor, b: Tensor, border: int = 0,
+               roi: Optional[Tensor] = None) -> Tensor:
+    """utils_image.py:894-934.  NB the ROI branch subtracts in the *input*
+    dtype before promoting (reference behaviour)."""
+    a, b, roi = _crop(a, border), _crop(b, border), _crop(roi, border)
+    n = a.shape[0]
+    if roi is None:
+        return ((a.double() - b.double()) ** 2).reshape(n, -1).mean(-1)
+    roi = roi.double()
+    d = (a - b) * roi
+    cnt = roi.reshape(n, -1).sum(-1)
+    cnt[cnt == 0] = 1.0
+    return (d ** 2).reshape(n, -1).sum(-1) / cnt
+
+
+def metric_psnr(a: Tensor, b: Tensor, border: int = 0,
+                roi: Optional[Tensor] = None) -> Tensor:
+    """utils_image.py:843-891 (fp64; mse floor 1e-45)."""
+    a, b, roi = _crop(a, border), _crop(b, border), _crop(roi, border)
+    n = a.shape[0]
+    a, b = a.double(), b.double()
+    if roi is None:
+        mse = ((a - b) ** 2).reshape(n, -1).mean(-1)
+    else:
+        roi = roi.double()
+        cnt = roi.reshape(n, -1).sum(-1)
+        cnt[cnt == 0] = 1.0
+        mse = (((a - b) * roi) ** 2).reshape(n, -1).sum(-1) / cnt
+    mse = torch.where(mse < 1e-45, torch.full_like(mse, 1e-45), mse)
+    return 20.0 * torch.log10(255.0 / torch.sqrt(mse))
+
+
+def metric_nrmse(img: Tensor, y: Tensor, border: int = 0,
+                 roi: Optional[Tensor] = None) -> Tensor:
+    """utils_image.py:937-1007."""
+    img, y, roi = _crop(img, border), _crop(y, border), _crop(roi, border)
+    n = img.shape[0]
+    img, y = img.double(), y.double()
+    if roi is None:
+        mse = ((img - y) ** 2).reshape(n, -1).mean(-1)
+        yy = y.reshape(n, -1)
+        lo = yy.min(-1)[0]
+    else:
+        roi = roi.double()
+        cnt = roi.reshape(n, -1).sum(-1)
+        cnt[cnt == 0] = 1.0
+        mse = (((img - y) * roi) ** 2).reshape(n, -1).sum(-1) / cnt
+        lo_all = y.reshape(n, -1).min(-1)[0]
+        yy = (y * roi).reshape(n, -1)
+        lo = torch.maximum(lo_all, yy.min(-1)[0])
+    den = yy.max(-1)[0] - lo
+    den[den == 0] = 1.0
+    return torch.sqrt(mse) / den
+
+
+def gaussian_window_2d_metric(ks: int = 11, sigma: float = 1.5) -> Tensor:
+    """utils_image.py:1102-1117."""
+    c = torch.arange(ks, dtype=torch.float32) - (ks - 1) / 2.0
+    g = (-(c[None, :] ** 2 + c[:, None] ** 2) / (2 * sigma ** 2)).exp()
+    return g / g.sum()
+
+
+def metric_ssim(x: Tensor, y: Tensor, border: int = 0,
+                roi: Optional[Tensor] = None) -> Tensor:
+    """utils_image.py:1120-1198 + :1010-1099: inputs in [0,255]; /255;
+    11x11 sigma-1.5 'valid' Gaussian; per-image mean (ROI cropped by 5)."""
+    x, y, roi = _crop(x, border), _crop(y, border), _crop(roi, border)
+    x, y = x / 255.0, y / 255.0
+    ch = x.shape[1]
+    k = gaussian_window_2d_metric()[None, None].repeat(ch, 1, 1, 1).to(x)
+
+    def blur(t):
+        return F.conv2d(t, k, groups=ch)
+    mx, my = blur(x), blur(y)
+    sxx = blur(x ** 2) - mx ** 2
+    syy = blur(y ** 2) - my ** 2
+    sxy = blur(x * y) - mx * my
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    cs = (2.0 * sxy + c2) / (sxx + syy + c2)
+    ss = ((2.0 * mx * my + c1) / (mx ** 2 + my ** 2 + c1)) * cs
+    n = ss.shape[0]
+    if roi is None:
+        return ss.reshape(n, ch, -1).mean(-1).mean(1)
+    r = roi[:, :, 5:roi.shape[2] - 5, 5:roi.shape[3] - 5]
+    cnt = r.reshape(n, -1).sum(-1)
+    cnt[cnt == 0] = 1.0
+    return ((ss * r).reshape(n, ch, -1).sum(-1) / cnt[:, None]).mean(1)
+
+
+def gray_to_y(img01: Tensor) -> Tensor:
+    """_rgb_tensor (utils_trainer.py:865-871) + mb_gpu_rgb2ycbcr(only_y)
+    (utils_image.py:618-653) for a 1-channel float image in [0,1]:
+    repeat to 3ch, Y = ((65.481 r + 128.553 g + 24.966 b)/255 + 16)/255, clamp."""
+    v = img01.float() * 255.0
+    yv = (65.481 * v + 128.553 * v + 24.966 * v) / 255.0 + 16.0
+    return (yv / 255.0).clamp(0.0, 1.0)
+
+
+# ----------------------------------------------------------------------------
+# optimizer / scheduler (utils_instance.py:216-247, learning/lr_scheduler.py:6-35)
+# ----------------------------------------------------------------------------
+def mysteplr(base_lr: float, it: int, step_size: int, gamma: float,
+             min_lr: float) -> float:
+    """LR in effect after ``it`` scheduler.step() calls."""
+    return max(base_lr * gamma ** (it // step_size), min_lr)
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
+              b1=0.9, b2=0.999, eps=1e-8, wd=0.0) -> None:
+    """torch.optim.Adam (non-amsgrad, L2 weight decay), in place; ``step`` is
+    1-based."""
+    if wd:
+        g = g + wd * p
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
+
+
+def sgd_nesterov_step(p: Tensor, g: Tensor, buf: Tensor, first: bool, lr: float,
+                      momentum=0.9, wd=0.0, nesterov=True) -> None:
+    """torch.optim.SGD with momentum (dampening 0), in place."""
+    if wd:
+        g = g + wd * p
+    if first:
+        buf.copy_(g)
+    else:
+        buf.mul_(momentum).add_(g)
+    p.add_(g + momentum * buf if nesterov else buf, alpha=-lr)
