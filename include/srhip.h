@@ -1,0 +1,172 @@
+/* libsrhip -- C-ABI of the MI355X (gfx950) hot path for SR-CACO-2 patch-level
+ * super-resolution: 3x3 residual convolutions, pixel shuffle, SwinIR window
+ * attention + MLP, L1/L2 losses, PSNR-family metrics, optimizers.
+ *
+ * The reference (sbelharbi/sr-caco-2) has no FFI: its hot path is stock aten
+ * calls made from Python.  Each entry point below
+ * therefore names the reference call site(s) it replaces (file:line relative
+ * to the reference root).  INTEGRATION.md shows the ctypes binding a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - Every function returns 0 on success and a negative code on failure;
+ *    srhip_last_error() returns a thread-local message.  Nothing calls exit().
+ *  - All pointers are DEVICE pointers owned by the caller (PyTorch's caching
+ *    allocator in practice).  Kernels never allocate or free; scratch space is
+ *    passed in (sizes from the *_ws / *_plan queries).
+ *  - Every call takes the hipStream_t to launch on (as void*), is asynchronous
+ *    and does not synchronise.  Calls are re-entrant across streams.
+ *  - Activations are fp32, channels-last: an image is [B][H][W][C] = a token
+ *    matrix [B*H*W][C].  1-channel network inputs/outputs are plain [B][H][W].
+ *  - "ld*" arguments are row pitches in floats and must be multiples of 4.
+ */
+#ifndef SRHIP_H
+#define SRHIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* srhip_last_error(void);
+int srhip_abi_version(void);
+
+/* ---- dense contractions on the exact-f32 MFMA ------------------------------ */
+
+/* C[M,N] = epi( pro(A)[M,K] . W[N,K]^T + bias ).
+ * Replaces nn.Linear forward (network_swinir.py:40-43,148,177) and, called with
+ * a transposed weight copy, its data gradient.
+ *   a_mode 0: A as is | 1: (A-mean)*rstd with ln_stats[M][2] (LayerNorm folded
+ *          into W, see srhip_fold_layernorm; network_swinir.py:293,335)
+ *        | 2: gelu(A) (exact erf, network_swinir.py:41)
+ *   epi 0: +bias | 1: relu | 2: R + s*(acc+bias) (residual add with per-sample
+ *          DropPath scale s = alpha*rowscale[row/rows_per_scale];
+ *          network_swinir.py:334-335) | 3: s*acc*gelu'(R) | 4: acc*(R>0) */
+int srhip_gemm_nt(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
+                  long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
+                  const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha,
+                  void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution, NHWC, implicit GEMM.  Wp is the tap-major
+ * pack [9][Cout][Cin] from srhip_pack_conv_weight (forward) or its flipped /
+ * transposed twin (data gradient).  Epilogues as srhip_gemm_nt (0,1,2,4).
+ * Replaces default_conv / nn.Conv2d(.,.,3,1,1): network_nlsn.py:38-41,89-93,
+ * network_swinir.py:544,850,700. */
+int srhip_conv3x3_nhwc(const float* X, long ldx, const float* Wp, const float* bias, float* Y, long ldy,
+                       int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
+                       const float* rowscale, float alpha, void* stream);
+
+/* Weight gradients: out[i][j] = sum_m A[m][i] * pro(B)[m][j], reduce dimension
+ * split in S slices written to part[S][(9)][NI][NJ] (+ column sums of A in
+ * part_colsum[S][NI] for the bias gradient); srhip_reduce_* sums the slices.
+ * srhip_tn_plan returns S and the size of `part` in floats. */
+int srhip_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats);
+int srhip_gemm_tn(const float* A, long lda, const float* B, long ldb, int M, int NI, int NJ,
+                  const float* a_rowscale, int a_rowscale_rows, int b_mode, const float* ln_stats,
+                  float* part, float* part_colsum, int S, void* stream);
+int srhip_conv3x3_wgrad(const float* dY, long lddy, const float* X, long ldx, int B, int H, int W,
+                        int Cout, int Cin, float* part, float* part_colsum, int S, void* stream);
+int srhip_reduce_linear_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
+                              int N, int K, void* stream);
+/* Linear fed by a folded LayerNorm: also emits dgamma / dbeta of that norm. */
+int srhip_reduce_ln_linear_wgrad(const float* part, const float* colsum, int S, const float* W,
+                                 const float* gamma, const float* beta, float* dW, float* db,
+                                 float* dgamma, float* dbeta, int N, int K, void* stream);
+/* dW in torch layout [Cout][Cin][3][3]. */
+int srhip_reduce_conv_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
+                            int Co, int Ci, void* stream);
+
+/* ---- weight preparation (once per optimizer step) --------------------------- */
+/* Wf = W*gamma (per column), bf = b + W.beta: LayerNorm affine folded into the
+ * Linear that consumes it. */
+int srhip_fold_layernorm(const float* W, const float* b, const float* gamma, const float* beta,
+                         float* Wf, float* bf, int N, int K, void* stream);
+int srhip_transpose(const float* in, float* out, int R, int C, void* stream);
+/* torch [Cout][Cin][3][3] -> wp [9][Cout][Cin] and/or wpt [9][Cin][Cout] (taps flipped). */
+int srhip_pack_conv_weight(const float* w, float* wp, float* wpt, int Co, int Ci, void* stream);
+
+/* ---- LayerNorm (nn.LayerNorm(C), eps 1e-5; network_swinir.py:240,248,606,846) - */
+/* stats[M][2] = mean, rstd (optional); y = LN(x)*gamma+beta (optional). */
+int srhip_layernorm_fwd(const float* x, float* stats, float* y, const float* gamma, const float* beta,
+                        long M, int C, void* stream);
+/* out = res + dx.  gamma == NULL: dy is the gradient w.r.t. the normalised
+ * value; else dy is w.r.t. y and dgamma/dbeta are produced. */
+int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* res,
+                        const float* gamma, float* out, float* dgamma, float* dbeta, long M, int C,
+                        void* stream);
+
+/* ---- window attention (network_swinir.py:48-80,140-179,297-331) -------------- */
+/* table (225,heads) -> biasT[h][key][query], biasN[h][query][key]. */
+int srhip_bias_expand(const float* table, float* biasT, float* biasN, int heads, void* stream);
+int srhip_bias_grad(const float* dbiasT, float* dtable, int heads, void* stream);
+/* qkv [B*H*W][3C] in token order -> out [B*H*W][C]; 8x8 windows, shift 0 or 4;
+ * roll, window partition/reverse and the shift mask are address math. */
+int srhip_window_attention_fwd(const float* qkv, float* out, const float* biasT, int B, int H, int W,
+                               int C, int heads, int shift, void* stream);
+/* dbiasT must be zero on entry. */
+int srhip_window_attention_bwd(const float* qkv, const float* dout, float* dqkv, const float* biasT,
+                               const float* biasN, float* dbiasT, int B, int H, int W, int C, int heads,
+                               int shift, void* stream);
+
+/* ---- 1-channel edge convolutions -------------------------------------------- */
+/* x [B][H][W] -> y NHWC [.][Co]; flip=1 uses flipped taps (= data gradient of
+ * a Cout=1 conv).  network_swinir.py:786,945; network_nlsn.py:325. */
+int srhip_conv3x3_cin1_fwd(const float* x, const float* w, const float* bias, float* y, long ldy, int B,
+                           int H, int W, int Co, int flip, void* stream);
+long srhip_conv3x3_cin1_wgrad_ws(int Co);
+int srhip_conv3x3_cin1_wgrad(const float* x, const float* dy, long lddy, float* dw, float* db,
+                             float* workspace, int B, int H, int W, int Co, int flip, void* stream);
+/* x NHWC [.][Ci] -> y [B][H][W]; network_nlsn.py:347-350. */
+int srhip_conv3x3_cout1_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, int B,
+                            int H, int W, int Ci, void* stream);
+
+/* ---- pixel shuffle (index only; network_swinir.py:701, network_nlsn.py:108) -- */
+/* in NHWC [B][h][w][Co*r*r] -> out NCHW [B][Co][h*r][w*r] or NHWC [B][h*r][w*r][Co];
+ * inverse=1 runs the mapping backwards (gradient). */
+int srhip_pixel_shuffle(const float* in, float* out, int B, int h, int w, int Co, int r,
+                        int nhwc_out, int inverse, void* stream);
+
+/* ---- losses (dlib/loss/main.py:45-99; MasterLoss dlib/loss/master.py:46-56) -- */
+/* mode 0: lam*mean(|pred-target| * weight?) ; mode 1: lam*mean((pred-target)^2).
+ * Writes (or accumulates) the value into loss_out[0] and d loss / d pred into
+ * grad.  workspace: 2048 doubles. */
+int srhip_loss_l1l2(const float* pred, const float* target, const float* weight, float* grad,
+                    float* loss_out, double* workspace, long n, int mode, float lam, int grad_accum,
+                    int loss_accum, void* stream);
+/* -lam * mean_b(mean_hw(ssim_map)) with a zero-padded Gaussian window of odd
+ * size ws (sigma 1.5), value and gradient (dlib/loss/ssim.py:38-61,
+ * dlib/loss/main.py:154-186).  workspace floats: srhip_ssim_loss_ws(B,H,W). */
+long srhip_ssim_loss_ws(int B, int H, int W);
+int srhip_ssim_loss(const float* pred, const float* target, float* grad, float* loss_out,
+                    float* workspace, int B, int H, int W, int ws, float lam, int grad_accum,
+                    int loss_accum, void* stream);
+
+/* ---- metrics (dlib/utils/utils_image.py:369-372,843-1007,618-653,1010-1198;
+ *      dlib/utils/utils_trainer.py:961-1032) ----------------------------------- */
+/* One pass: tensor2uint82float on both images (skipped if inputs_are_u8),
+ * border crop, then for "no ROI" (slot 0) and each ROI threshold t (roi = H>=t):
+ * out[b][slot][4] = PSNR, PSNR_Y, MSE, NRMSE in fp64.
+ * workspace doubles: srhip_metrics_ws(B, nth). */
+long srhip_metrics_ws(int B, int nth);
+int srhip_metrics_psnr_family(const float* E, const float* Hh, int B, int H, int W, int border,
+                              const int* thresholds_dev, int nth, int inputs_are_u8, double* workspace,
+                              double* out, void* stream);
+/* SSIM metric (11x11 sigma-1.5 valid window, inputs u8-ised then /255):
+ * out[b][slot] fp32 means (ROI cropped by 5 as the reference does).
+ * workspace doubles: B*(nth+1)*2. */
+int srhip_metrics_ssim(const float* E, const float* Hh, int B, int H, int W, int border,
+                       const int* thresholds_dev, int nth, int inputs_are_u8, double* workspace,
+                       float* out, void* stream);
+
+/* ---- optimizers (dlib/utils/utils_instance.py:216-247) on flat buffers ------- */
+int srhip_adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float b1,
+                    float b2, float eps, float wd, float gscale, void* stream);
+int srhip_sgd_step(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
+                   int nesterov, int first, float gscale, void* stream);
+/* flag[0] |= any(!isfinite(x)): one device flag instead of the reference's
+ * per-tensor host syncs (dlib/utils/tools.py:28-63, model_plain.py:344). */
+int srhip_nonfinite_flag(const float* x, long n, int* flag, void* stream);
+int srhip_axpby(float* y, const float* x, long n, float a, float b, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRHIP_H */

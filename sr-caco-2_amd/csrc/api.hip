@@ -1,0 +1,80 @@
+// C-ABI layer of libsrhip: error plumbing and the entry points of the dense
+// contractions (declared in include/srhip.h).
+#include <stdarg.h>
+#include "common.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+
+int sr_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" {
+
+const char* srhip_last_error(void) { return g_err; }
+int srhip_abi_version(void) { return 1; }
+
+int srhip_gemm_nt(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
+                  long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
+                  const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha,
+                  void* stream) {
+  SR_REQUIRE(a_mode >= 0 && a_mode <= 2, "gemm_nt: a_mode %d", a_mode);
+  SR_REQUIRE(epi >= 0 && epi <= 4, "gemm_nt: epi %d", epi);
+  SR_REQUIRE(a_mode != 1 || ln_stats, "gemm_nt: layernorm prologue without stats");
+  SR_REQUIRE(epi < 3 || R, "gemm_nt: epilogue %d needs R", epi);
+  SR_REQUIRE(!rowscale || rows_per_scale > 0, "gemm_nt: rows_per_scale must be > 0");
+  NtArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.wtap = 0; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.bias = bias; p.a_mode = a_mode; p.ln_stats = ln_stats;
+  p.epi = epi; p.R = R; p.ldr = ldr; p.rowscale = rowscale; p.rows_per_scale = rows_per_scale;
+  p.alpha = alpha;
+  return sr_gemm_nt(p, (hipStream_t)stream);
+}
+
+int srhip_conv3x3_nhwc(const float* X, long ldx, const float* Wp, const float* bias, float* Y, long ldy,
+                       int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
+                       const float* rowscale, float alpha, void* stream) {
+  SR_REQUIRE(epi >= 0 && epi <= 4 && epi != 3, "conv3x3: epi %d", epi);
+  SR_REQUIRE(epi != 4 || R, "conv3x3: relu-mask epilogue needs R");
+  NtArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = X; p.lda = ldx; p.W = Wp; p.ldw = Cin; p.wtap = (long)Cout * Cin; p.C = Y; p.ldc = ldy;
+  p.N = Cout; p.K = Cin; p.bias = bias; p.epi = epi; p.R = R; p.ldr = ldr; p.rowscale = rowscale;
+  p.rows_per_scale = H * W; p.alpha = alpha; p.batch = B; p.H = H; p.Wd = W;
+  return sr_conv3x3_nt(p, (hipStream_t)stream);
+}
+
+int srhip_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
+  return sr_tn_plan(M, NI, NJ, conv, S, part_floats);
+}
+
+int srhip_gemm_tn(const float* A, long lda, const float* B, long ldb, int M, int NI, int NJ,
+                  const float* a_rowscale, int a_rowscale_rows, int b_mode, const float* ln_stats,
+                  float* part, float* part_colsum, int S, void* stream) {
+  SR_REQUIRE(b_mode >= 0 && b_mode <= 2, "gemm_tn: b_mode %d", b_mode);
+  SR_REQUIRE(b_mode != 1 || ln_stats, "gemm_tn: layernorm prologue without stats");
+  SR_REQUIRE(!a_rowscale || a_rowscale_rows > 0, "gemm_tn: a_rowscale_rows must be > 0");
+  TnArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.M = M; p.NI = NI; p.NJ = NJ;
+  p.a_rowscale = a_rowscale; p.a_rowscale_rows = a_rowscale_rows; p.b_mode = b_mode;
+  p.ln_stats = ln_stats; p.part = part; p.part_colsum = part_colsum; p.S = S; p.conv = 0;
+  return sr_gemm_tn(p, (hipStream_t)stream);
+}
+
+int srhip_conv3x3_wgrad(const float* dY, long lddy, const float* X, long ldx, int B, int H, int W,
+                        int Cout, int Cin, float* part, float* part_colsum, int S, void* stream) {
+  TnArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = dY; p.lda = lddy; p.B = X; p.ldb = ldx; p.M = B * H * W; p.NI = Cout; p.NJ = Cin;
+  p.part = part; p.part_colsum = part_colsum; p.S = S; p.conv = 1; p.batch = B; p.H = H; p.Wd = W;
+  return sr_gemm_tn(p, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Shared device/host helpers for libsrhip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SR_WAVE 64
+
+// ---- error plumbing (include/srhip.h: every entry point returns 0 or <0) ----
+extern "C" const char* srhip_last_error(void);
+int sr_fail(int code, const char* fmt, ...);
+#define SR_REQUIRE(cond, ...) \
+  do { if (!(cond)) return sr_fail(-22, __VA_ARGS__); } while (0)
+#define SR_LAUNCH_CHECK(name) \
+  do { hipError_t e_ = hipGetLastError(); \
+       if (e_ != hipSuccess) return sr_fail(-5, "%s: %s", name, hipGetErrorString(e_)); } while (0)
+
+static inline int sr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave-level reductions (wave = 64 lanes) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU and its derivative (nn.GELU default, network_swinir.py:30)
+__device__ __forceinline__ float gelu_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// 32x32x2 f32 MFMA: exact f32 fma chain (MI355X_MICROARCH "Matrix cores").
+// lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
+// D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma_row(int reg, int lane) {
+  return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}

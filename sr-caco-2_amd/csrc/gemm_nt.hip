@@ -1,0 +1,311 @@
+// NT contraction on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32):
+//
+//   GEMM : C[M,N] = epi( pro(A)[M,K] . W[N,K]^T )           (Linear fwd, and Linear
+//          bwd-data through a transposed weight copy)
+//   CONV : 3x3 / stride 1 / pad 1 convolution over an NHWC image as an implicit
+//          GEMM: M = output pixels, N = Cout, K = 9 taps x Cin; weights are the
+//          tap-major packed copy Wp[tap][Cout][Cin] (conv fwd) or the flipped /
+//          transposed copy (conv bwd-data).
+//
+// Replaces aten linear / conv2d calls of dlib/models/network_swinir.py:40-43,
+// 148,177,544,786,850,700 and dlib/models/network_nlsn.py:38-41.
+//
+// Tiling: 256 threads = 4 waves as 2(M) x 2(N); each wave owns WM x WN MFMA
+// tiles of 32x32.  A and W chunks (BK wide in K) are staged through LDS with a
+// row pitch SA = 4*odd floats, so that the ds_read_b128 fragment reads (one
+// row per lane, 4 consecutive k) are bank-conflict free.  Each lane half
+// (lane>>5) owns 4 of every 8 consecutive k, which it feeds to 4 successive
+// MFMAs; A and W use the same k permutation, so products pair up correctly.
+// Global loads for chunk i+1 are issued before the MFMAs of chunk i (register
+// prefetch) and written to LDS after them.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int WM, int WN, int BK, bool CONV>
+__global__ void __launch_bounds__(256) k_nt(NtArgs p) {
+  constexpr int SA = (BK % 8 == 4) ? BK : BK + 4;  // pitch = 4*odd floats
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int TROWS = BM / 16;                   // conv: image rows per tile
+  constexpr int AROWS = CONV ? (TROWS + 2) * 18 : BM;
+  constexpr int KV = BK / 4;                       // float4 per staged row
+  constexpr int A_N = AROWS * KV, B_N = BN * KV;
+  constexpr int A_IT = (A_N + 255) / 256, B_IT = (B_N + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[(AROWS + BN) * SA];
+  float* As = smem;
+  float* Bs = smem + AROWS * SA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * p.n_tile;
+  const int nvalid = min(p.n_tile, p.N - n0);
+
+  // block origin
+  int m0 = 0, img = 0, y0 = 0, x0 = 0;
+  if (CONV) {
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; img = t / p.tiles_y;
+    y0 = ty * TROWS; x0 = tx * 16;
+  } else {
+    m0 = blockIdx.x * BM;
+  }
+
+  f32x4 ra[A_IT], rb[B_IT];
+  float rmu[A_IT], rrs[A_IT];
+
+  auto load_a = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int idx = tid + it * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      rmu[it] = 0.f; rrs[it] = 1.f;
+      if (A_N % 256 == 0 || idx < A_N) {
+        const int row = idx / KV, c4 = idx - row * KV;
+        const int gk = kc * BK + c4 * 4;
+        if (CONV) {
+          const int hy = row / 18, hx = row - hy * 18;
+          const int y = y0 + hy - 1, x = x0 + hx - 1;
+          if (y >= 0 && y < p.H && x >= 0 && x < p.Wd && gk < p.K)
+            v = *(const f32x4*)(p.A + ((long)(img * p.H + y) * p.Wd + x) * p.lda + gk);
+        } else {
+          const int gm = m0 + row;
+          if (gm < p.M && gk < p.K) {
+            v = *(const f32x4*)(p.A + (long)gm * p.lda + gk);
+            if (p.a_mode == 1) { rmu[it] = p.ln_stats[2 * gm]; rrs[it] = p.ln_stats[2 * gm + 1]; }
+          }
+        }
+      }
+      ra[it] = v;
+    }
+  };
+  auto load_b = [&](int kc, int tap) {
+    const float* wb = p.W + (long)tap * p.wtap;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int idx = tid + it * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (B_N % 256 == 0 || idx < B_N) {
+        const int row = idx / KV, c4 = idx - row * KV;
+        const int gk = kc * BK + c4 * 4;
+        if (row < nvalid && gk < p.K)
+          v = *(const f32x4*)(wb + (long)(n0 + row) * p.ldw + gk);
+      }
+      rb[it] = v;
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (A_N % 256 == 0 || idx < A_N) {
+        const int row = idx / KV, c4 = idx - row * KV;
+        f32x4 v = ra[it];
+        if (!CONV) {
+          if (p.a_mode == 1) {          // LayerNorm prologue: (x-mean)*rstd
+            v.x = (v.x - rmu[it]) * rrs[it]; v.y = (v.y - rmu[it]) * rrs[it];
+            v.z = (v.z - rmu[it]) * rrs[it]; v.w = (v.w - rmu[it]) * rrs[it];
+          } else if (p.a_mode == 2) {   // GELU prologue
+            v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+          }
+        }
+        *(f32x4*)(As + row * SA + c4 * 4) = v;
+      }
+    }
+  };
+  auto store_b = [&]() {
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (B_N % 256 == 0 || idx < B_N) {
+        const int row = idx / KV, c4 = idx - row * KV;
+        *(f32x4*)(Bs + row * SA + c4 * 4) = rb[it];
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  // fragment base offsets (floats)
+  int a_off[WM], b_off[WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int mt = wm * WM + i;
+    if (CONV) a_off[i] = ((2 * mt + (r >> 4)) * 18 + (r & 15)) * SA + 4 * h;
+    else a_off[i] = (mt * 32 + r) * SA + 4 * h;
+  }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) b_off[j] = ((wn * WN + j) * 32 + r) * SA + 4 * h;
+
+  const int nkc = (p.K + BK - 1) / BK;
+  const int ntap = CONV ? 9 : 1;
+  const int niter = nkc * ntap;
+
+  load_a(0);
+  load_b(0, 0);
+  for (int it = 0; it < niter; ++it) {
+    const int kc = it / ntap, tap = it - kc * ntap;
+    __syncthreads();                       // everyone done reading LDS
+    if (!CONV || tap == 0) store_a();
+    store_b();
+    __syncthreads();
+    if (it + 1 < niter) {                  // prefetch next chunk into registers
+      const int kc1 = (it + 1) / ntap, tap1 = (it + 1) - kc1 * ntap;
+      if (!CONV || tap1 == 0) load_a(kc1);
+      load_b(kc1, tap1);
+    }
+    const int toff = CONV ? ((tap / 3) * 18 + (tap % 3)) * SA : 0;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 fa[WM], fb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) fa[i] = *(const f32x4*)(As + a_off[i] + toff + g * 8);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) fb[j] = *(const f32x4*)(Bs + b_off[j] + g * 8);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j] = mfma32(fa[i][t], fb[j][t], acc[i][j]);
+    }
+    if (BK % 8 == 4) {                     // 4-wide tail: each lane half owns 2 k
+      float2 fa[WM], fb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+        fa[i] = *(const float2*)(As + a_off[i] - 4 * h + toff + (BK - 4) + 2 * h);
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        fb[j] = *(const float2*)(Bs + b_off[j] - 4 * h + (BK - 4) + 2 * h);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          acc[i][j] = mfma32(fa[i].x, fb[j].x, acc[i][j]);
+          acc[i][j] = mfma32(fa[i].y, fb[j].y, acc[i][j]);
+        }
+    }
+  }
+
+  // ---- epilogue ----
+  // per-sample scale (DropPath): one sample per block whenever the sample's
+  // row count is a multiple of the block's rows, else looked up per row.
+  float blk_s = p.alpha;
+  bool per_row = false;
+  if (p.rowscale) {
+    if (CONV) blk_s *= p.rowscale[img];
+    else if (p.rows_per_scale % BM == 0) blk_s *= p.rowscale[m0 / p.rows_per_scale];
+    else per_row = true;
+  }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = (wn * WN + j) * 32 + r;        // column inside the N block
+    const bool cok = col < nvalid;
+    const int gn = n0 + col;
+    const float bv = (cok && p.bias) ? p.bias[gn] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int mt = wm * WM + i;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int lr = mfma_row(q, lane);          // row inside the 32-row tile
+        long grow;                                 // global row (token / pixel)
+        bool rok;
+        if (CONV) {
+          const int y = y0 + 2 * mt + (lr >> 4), x = x0 + (lr & 15);
+          rok = (y < p.H) && (x < p.Wd);
+          grow = (long)(img * p.H + y) * p.Wd + x;
+        } else {
+          grow = m0 + mt * 32 + lr;
+          rok = grow < p.M;
+        }
+        if (!(rok && cok)) continue;
+        float v = acc[i][j][q] + bv;
+        if (p.epi == 1) {
+          v = fmaxf(v, 0.f);
+        } else if (p.epi == 2) {
+          float s = blk_s;
+          if (per_row) s *= p.rowscale[(int)grow / p.rows_per_scale];
+          v = v * s + (p.R ? p.R[grow * p.ldr + gn] : 0.f);
+        } else if (p.epi == 3) {
+          float s = blk_s;
+          if (per_row) s *= p.rowscale[(int)grow / p.rows_per_scale];
+          v = v * s * dgelu_f(p.R[grow * p.ldr + gn]);
+        } else if (p.epi == 4) {
+          v = (p.R[grow * p.ldr + gn] > 0.f) ? v : 0.f;
+        }
+        p.C[grow * p.ldc + gn] = v;
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int BK, bool CONV>
+int launch_nt(const NtArgs& p, hipStream_t st) {
+  constexpr int BM = 64 * WM;
+  dim3 grid;
+  if (CONV) grid = dim3(p.tiles_x * p.tiles_y * p.batch, sr_cdiv(p.N, p.n_tile));
+  else grid = dim3(sr_cdiv(p.M, BM), sr_cdiv(p.N, p.n_tile));
+  hipLaunchKernelGGL((k_nt<WM, WN, BK, CONV>), grid, dim3(256), 0, st, p);
+  SR_LAUNCH_CHECK("k_nt");
+  return 0;
+}
+
+template <bool CONV>
+int dispatch_nt(NtArgs& p, hipStream_t st) {
+  // N tile: 180-wide problems (SwinIR embed 180 and its multiples) run as
+  // 192-column blocks with 180 valid; everything else in 64/128/192 columns.
+  int wn;
+  if (p.N % 180 == 0) { p.n_tile = 180; wn = 3; }
+  else if (p.N <= 64) { p.n_tile = 64; wn = 1; }
+  else if (p.N <= 128 || p.N % 128 == 0) { p.n_tile = 128; wn = 2; }
+  else { p.n_tile = 192; wn = 3; }
+  const bool bk36 = (p.K % 36 == 0) || (p.K % 32 != 0);
+  // M tile: prefer 128 rows, fall back to 64 when that leaves < 2 blocks per CU
+  long rows = CONV ? 0 : p.M;
+  long blocks128;
+  if (CONV) {
+    const int tx = sr_cdiv(p.Wd, 16);
+    blocks128 = (long)tx * sr_cdiv(p.H, 8) * p.batch;
+  } else {
+    blocks128 = sr_cdiv(rows, 128);
+  }
+  blocks128 *= sr_cdiv(p.N, p.n_tile);
+  const int wm = (blocks128 >= 512) ? 2 : 1;
+  if (CONV) {
+    p.tiles_x = sr_cdiv(p.Wd, 16);
+    p.tiles_y = sr_cdiv(p.H, wm == 2 ? 8 : 4);
+  }
+#define SR_NT_CASE(WM_, WN_, BK_) \
+  if (wm == WM_ && wn == WN_ && bk36 == (BK_ == 36)) return launch_nt<WM_, WN_, BK_, CONV>(p, st);
+  SR_NT_CASE(1, 1, 36) SR_NT_CASE(1, 2, 36) SR_NT_CASE(1, 3, 36)
+  SR_NT_CASE(2, 1, 36) SR_NT_CASE(2, 2, 36) SR_NT_CASE(2, 3, 36)
+  SR_NT_CASE(1, 1, 32) SR_NT_CASE(1, 2, 32) SR_NT_CASE(1, 3, 32)
+  SR_NT_CASE(2, 1, 32) SR_NT_CASE(2, 2, 32) SR_NT_CASE(2, 3, 32)
+#undef SR_NT_CASE
+  return sr_fail(-22, "nt: no kernel for wm=%d wn=%d", wm, wn);
+}
+
+}  // namespace
+
+int sr_gemm_nt(NtArgs& p, hipStream_t st) {
+  SR_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0 && p.ldw % 4 == 0,
+             "gemm_nt: K, lda, ldw must be multiples of 4 (K=%d lda=%ld ldw=%ld)", p.K, p.lda, p.ldw);
+  SR_REQUIRE(p.M > 0 && p.N > 0, "gemm_nt: empty problem");
+  return dispatch_nt<false>(p, st);
+}
+
+int sr_conv3x3_nt(NtArgs& p, hipStream_t st) {
+  SR_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0 && p.ldw % 4 == 0,
+             "conv3x3: Cin, lda, ldw must be multiples of 4 (Cin=%d)", p.K);
+  SR_REQUIRE(p.batch > 0 && p.H > 0 && p.Wd > 0, "conv3x3: empty image");
+  p.M = p.batch * p.H * p.Wd;
+  return dispatch_nt<true>(p, st);
+}

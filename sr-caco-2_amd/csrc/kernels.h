@@ -1,0 +1,43 @@
+// Internal launch descriptors shared between the kernel files and the C-ABI
+// layer (api.hip).  Not part of the public interface (include/srhip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct NtArgs {
+  // A operand.  GEMM: row-major [M][lda].  CONV: NHWC image [batch][H][Wd][lda].
+  const float* A; long lda;
+  // W operand.  GEMM: [N][ldw] (K contiguous).  CONV: [9][N][ldw], tap stride wtap.
+  const float* W; long ldw; long wtap;
+  float* C; long ldc;
+  int M, N, K;
+  int n_tile;                 // set by the dispatcher
+  const float* bias;          // [N] or null
+  int a_mode;                 // 0 plain | 1 (x-mean)*rstd from ln_stats | 2 gelu(x)
+  const float* ln_stats;      // [M][2] = mean, rstd
+  int epi;                    // 0 +bias | 1 relu | 2 R + s*(acc+bias) | 3 s*acc*gelu'(R) | 4 acc*(R>0)
+  const float* R; long ldr;
+  const float* rowscale; int rows_per_scale; float alpha;
+  // conv geometry
+  int batch, H, Wd, tiles_x, tiles_y;
+};
+
+struct TnArgs {
+  // out[i][j] = sum_m pa(A)[m][i] * pb(B)[m'][j]   (m' = m, or the tap-shifted pixel)
+  const float* A; long lda;   // [M][lda]   (dY)
+  const float* B; long ldb;   // [M][ldb]   (X)   / NHWC image for conv
+  int M, NI, NJ;              // reduce length, out rows (dY cols), out cols (X cols)
+  int a_rowscale_rows; const float* a_rowscale;   // optional per-sample scale on A rows
+  int b_mode;                 // 0 plain | 1 (x-mean)*rstd | 2 gelu(x)
+  const float* ln_stats;
+  float* part;                // [S][taps][NI][NJ] partial sums
+  float* part_colsum;         // [S][NI] column sums of A (bias grads) or null
+  int S;                      // number of M slices
+  int conv;                   // 0 | 1: B rows are tap-shifted pixels of a [batch][H][Wd] image
+  int batch, H, Wd;
+  int i_tile, j_tile, rows_per_slice;   // set by the dispatcher
+};
+
+int sr_gemm_nt(NtArgs& p, hipStream_t st);
+int sr_conv3x3_nt(NtArgs& p, hipStream_t st);
+int sr_gemm_tn(TnArgs& p, hipStream_t st);
+int sr_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats);

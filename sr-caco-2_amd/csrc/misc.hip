@@ -1,0 +1,493 @@
+// HBM-bound helpers around the contractions: slice reduction of weight-gradient
+// partials, LayerNorm folding of Linear weights, weight re-layouts, LayerNorm
+// kernels, pixel-shuffle, losses, optimizers.  One wave = 64 lanes throughout.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// weight-gradient finalisation
+// ----------------------------------------------------------------------------
+// out[i] = sum_s part[s][i]           (Linear: out = dW [NI][NJ])
+__global__ void k_reduce_slices(const float* __restrict__ part, float* __restrict__ out,
+                                long n, int S, float beta) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[(long)s * n + i];
+    out[i] = beta != 0.f ? out[i] * beta + a : a;
+  }
+}
+// conv: part [S][9][Co][Ci] -> dW torch layout [Co][Ci][3][3]
+__global__ void k_reduce_conv_w(const float* __restrict__ part, float* __restrict__ dw,
+                                int Co, int Ci, int S) {
+  const long n = (long)Co * Ci * 9;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const int tap = i % 9;
+    const long cc = i / 9;  // co*Ci + ci
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[((long)s * 9 + tap) * Co * Ci + cc];
+    dw[i] = a;
+  }
+}
+// Linear fed by a folded LayerNorm (W_f = W*gamma, b_f = b + W.beta):
+//   G = sum_s part, dbv = sum_s colsum
+//   dW[n][k] = gamma[k]*G[n][k] + beta[k]*dbv[n];  db = dbv
+//   dgamma[k] = sum_n W[n][k]*G[n][k];  dbeta[k] = sum_n W[n][k]*dbv[n]
+// One block per 32 columns k; 8 row lanes walk n.
+__global__ void __launch_bounds__(256) k_fin_ln_linear(
+    const float* __restrict__ part, const float* __restrict__ colsum, int S,
+    const float* __restrict__ W, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ dW, float* __restrict__ db,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int K) {
+  __shared__ float sg[8][32], sb[8][32];
+  const int c = threadIdx.x & 31, rr = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + c;
+  float ag = 0.f, ab = 0.f;
+  if (k < K) {
+    const float g = gamma[k], b = beta[k];
+    for (int n = rr; n < N; n += 8) {
+      float G = 0.f, d = 0.f;
+      for (int s = 0; s < S; ++s) {
+        G += part[((long)s * N + n) * K + k];
+        d += colsum[(long)s * N + n];
+      }
+      const float w = W[(long)n * K + k];
+      dW[(long)n * K + k] = g * G + b * d;
+      ag += w * G;
+      ab += w * d;
+      if (blockIdx.x == 0 && c == 0) db[n] = d;
+    }
+  }
+  sg[rr][c] = ag; sb[rr][c] = ab;
+  __syncthreads();
+  if (rr == 0 && k < K) {
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < 8; ++i) { a += sg[i][c]; b += sb[i][c]; }
+    dgamma[k] = a; dbeta[k] = b;
+  }
+}
+__global__ void k_reduce_colsum(const float* __restrict__ colsum, float* __restrict__ db,
+                                int N, int S) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float d = 0.f;
+  for (int s = 0; s < S; ++s) d += colsum[(long)s * N + n];
+  db[n] = d;
+}
+
+// ----------------------------------------------------------------------------
+// weight preparation (once per optimizer step)
+// ----------------------------------------------------------------------------
+// Wf[n][k] = W[n][k]*gamma[k];  bf[n] = b[n] + sum_k W[n][k]*beta[k]; one wave per row
+__global__ void k_fold_ln(const float* __restrict__ W, const float* __restrict__ b,
+                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                          float* __restrict__ Wf, float* __restrict__ bf, int N, int K) {
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float a = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = W[(long)n * K + k];
+    Wf[(long)n * K + k] = w * gamma[k];
+    a += w * beta[k];
+  }
+  a = wave_sum(a);
+  if (lane == 0) bf[n] = (b ? b[n] : 0.f) + a;
+}
+// out[c][r] = in[r][c]
+__global__ void k_transpose(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < R && c0 + tx < C) t[i][tx] = in[(long)(r0 + i) * C + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < C && r0 + tx < R) out[(long)(c0 + i) * R + r0 + tx] = t[tx][i];
+}
+// torch conv weight [Co][Ci][3][3] -> fwd pack [9][Co][Ci], bwd-data pack [9][Ci][Co] (taps flipped)
+__global__ void k_pack_conv_w(const float* __restrict__ w, float* __restrict__ wp,
+                              float* __restrict__ wpt, int Co, int Ci) {
+  const long n = (long)Co * Ci * 9;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const int tap = i % 9;
+    const long cc = i / 9;
+    const int ci = cc % Ci, co = cc / Ci;
+    const float v = w[i];
+    if (wp) wp[((long)tap * Co + co) * Ci + ci] = v;
+    if (wpt) wpt[((long)(8 - tap) * Ci + ci) * Co + co] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// LayerNorm over the last dim C (<= 256), eps 1e-5, biased variance
+// (nn.LayerNorm at network_swinir.py:240,248,606,846).  One wave per row.
+// ----------------------------------------------------------------------------
+constexpr int LN_MAXV = 4;  // values per lane
+
+__device__ __forceinline__ void ln_row_stats(const float* __restrict__ x, int C, int lane,
+                                             float (&v)[LN_MAXV], float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < C ? x[c] : 0.f;
+    s += v[i];
+  }
+  mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + 64 * i;
+    const float d = c < C ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  rstd = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
+}
+
+// stats only: st[m] = {mean, rstd}; optionally y = (x-mean)*rstd*g + b
+__global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ x, float* __restrict__ st,
+                                                float* __restrict__ y, const float* __restrict__ g,
+                                                const float* __restrict__ b, long M, int C) {
+  const long m = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (m >= M) return;
+  float v[LN_MAXV], mean, rstd;
+  ln_row_stats(x + m * C, C, lane, v, mean, rstd);
+  if (lane == 0 && st) { st[2 * m] = mean; st[2 * m + 1] = rstd; }
+  if (y) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) y[m * C + c] = (v[i] - mean) * rstd * g[c] + b[c];
+    }
+  }
+}
+// dx from the gradient w.r.t. the normalised value (dxh), with the residual
+// gradient added:  out = res + rstd*(dxh - mean(dxh) - xh*mean(dxh*xh)).
+// If g != null the incoming gradient is w.r.t. y = xh*g+b: dxh = dy*g and the
+// per-column sums dgamma += dy*xh, dbeta += dy are accumulated with atomics.
+__global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dyp, const float* __restrict__ x,
+                                                const float* __restrict__ st, const float* __restrict__ res,
+                                                const float* __restrict__ g, float* __restrict__ out,
+                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                long M, int C, int rows_per_wave) {
+  const int lane = threadIdx.x & 63;
+  const long w = blockIdx.x * 4L + (threadIdx.x >> 6);
+  float ag[LN_MAXV] = {0.f, 0.f, 0.f, 0.f}, ab[LN_MAXV] = {0.f, 0.f, 0.f, 0.f};
+  for (long m = w * rows_per_wave; m < M && m < (w + 1) * rows_per_wave; ++m) {
+    const float mean = st[2 * m], rstd = st[2 * m + 1];
+    float dxh[LN_MAXV], xh[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      dxh[i] = 0.f; xh[i] = 0.f;
+      if (c < C) {
+        const float dy = dyp[m * C + c];
+        xh[i] = (x[m * C + c] - mean) * rstd;
+        dxh[i] = g ? dy * g[c] : dy;
+        if (g) { ag[i] += dy * xh[i]; ab[i] += dy; }
+        s1 += dxh[i];
+        s2 += dxh[i] * xh[i];
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) {
+        const float d = rstd * (dxh[i] - s1 - xh[i] * s2);
+        out[m * C + c] = res ? res[m * C + c] + d : d;
+      }
+    }
+  }
+  if (g) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) { atomicAdd(dgamma + c, ag[i]); atomicAdd(dbeta + c, ab[i]); }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// pixel shuffle (index only; nn.PixelShuffle, network_swinir.py:701, network_nlsn.py:108)
+//   in  NHWC [B][h][w][Cout*r*r]
+//   out NCHW [B][Cout][h*r][w*r]                 (nhwc_out = 0)
+//       NHWC [B][h*r][w*r][Cout]                 (nhwc_out = 1)
+//   out[b, c, y*r+i, x*r+j] = in[b, y, x, c*r*r + i*r + j]
+// inverse = the same mapping read the other way (bwd of the shuffle).
+// ----------------------------------------------------------------------------
+__global__ void k_pixel_shuffle(const float* __restrict__ in, float* __restrict__ out, int B, int h,
+                                int w, int Co, int r, int nhwc_out, int inverse) {
+  const long n = (long)B * h * w * Co * r * r;
+  const int H = h * r, W = w * r;
+  for (long o = blockIdx.x * (long)blockDim.x + threadIdx.x; o < n;
+       o += (long)gridDim.x * blockDim.x) {
+    // decode the HIGH-res (shuffled) side index o
+    int c, X, Y, b;
+    long t = o;
+    if (nhwc_out) { c = t % Co; t /= Co; X = t % W; t /= W; Y = t % H; b = t / H; }
+    else { X = t % W; t /= W; Y = t % H; t /= H; c = t % Co; b = t / Co; }
+    const int y = Y / r, i = Y - y * r, x = X / r, j = X - x * r;
+    const long li = (((long)b * h + y) * w + x) * ((long)Co * r * r) + (long)c * r * r + i * r + j;
+    if (inverse) out[li] = in[o];
+    else out[o] = in[li];
+  }
+}
+
+// ----------------------------------------------------------------------------
+// losses (dlib/loss/main.py:45-99): fused value + gradient
+//   mode 0: L1  lam*mean(|e|*w?)    grad = lam*sign(e)*w?/n
+//   mode 1: L2  lam*mean(e^2)       grad = 2*lam*e/n
+// partial sums go to part[gridDim.x] (double); k_sum_partials finishes.
+// ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_loss_l1l2(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                   const float* __restrict__ wgt, float* __restrict__ grad,
+                                                   double* __restrict__ part, long n, int mode, float lam,
+                                                   int grad_accum) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  const float gs = lam / (float)n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const float e = pred[i] - tgt[i];
+    float v, g;
+    if (mode == 0) {
+      v = fabsf(e);
+      g = (e > 0.f) ? gs : (e < 0.f ? -gs : 0.f);
+      if (wgt) { v *= wgt[i]; g *= wgt[i]; }
+    } else {
+      v = e * e;
+      g = 2.f * gs * e;
+    }
+    acc += (double)v;
+    if (grad) grad[i] = grad_accum ? grad[i] + g : g;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// out[0] (+)= scale * sum(part[0..n))  as float
+__global__ void k_sum_partials(const double* __restrict__ part, int n, double scale,
+                               float* __restrict__ out, int accum) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) a += part[i];
+  a = wave_sum_d(a);
+  if (threadIdx.x == 0) out[0] = (accum ? out[0] : 0.f) + (float)(a * scale);
+}
+
+// ----------------------------------------------------------------------------
+// optimizers on the flat parameter buffer (utils_instance.py:216-247)
+// ----------------------------------------------------------------------------
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                       float wd, float bc1, float bc2_sqrt, float gscale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = m[i] * b1 + (1.f - b1) * gi;
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+__global__ void k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                      long n, float lr, float momentum, float wd, int nesterov, int first,
+                      float gscale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    float d = gi;
+    if (momentum != 0.f) {
+      const float bi = first ? gi : buf[i] * momentum + gi;
+      buf[i] = bi;
+      d = nesterov ? gi + momentum * bi : bi;
+    }
+    p[i] = pi - lr * d;
+  }
+}
+// finite check: flag[0] |= any(!isfinite(x))
+__global__ void k_nonfinite(const float* __restrict__ x, long n, int* __restrict__ flag) {
+  int bad = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x)
+    bad |= !isfinite(x[i]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+__global__ void k_axpby(float* __restrict__ y, const float* __restrict__ x, long n, float a, float b) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x)
+    y[i] = a * x[i] + b * y[i];
+}
+
+inline int ew_grid(long n) {
+  long g = (n + 255) / 256;
+  if (g > 2048) g = 2048;   // 256 CUs x 8 blocks, grid-stride the rest
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+// ============================ C-ABI (include/srhip.h) ========================
+extern "C" {
+
+int srhip_reduce_linear_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
+                              int N, int K, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)N * K;
+  hipLaunchKernelGGL(k_reduce_slices, dim3(ew_grid(n)), dim3(256), 0, st, part, dW, n, S, 0.f);
+  if (colsum && db)
+    hipLaunchKernelGGL(k_reduce_colsum, dim3(sr_cdiv(N, 256)), dim3(256), 0, st, colsum, db, N, S);
+  SR_LAUNCH_CHECK("reduce_linear_wgrad");
+  return 0;
+}
+
+int srhip_reduce_ln_linear_wgrad(const float* part, const float* colsum, int S, const float* W,
+                                 const float* gamma, const float* beta, float* dW, float* db,
+                                 float* dgamma, float* dbeta, int N, int K, void* stream) {
+  hipLaunchKernelGGL(k_fin_ln_linear, dim3(sr_cdiv(K, 32)), dim3(256), 0, (hipStream_t)stream, part,
+                     colsum, S, W, gamma, beta, dW, db, dgamma, dbeta, N, K);
+  SR_LAUNCH_CHECK("reduce_ln_linear_wgrad");
+  return 0;
+}
+
+int srhip_reduce_conv_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
+                            int Co, int Ci, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_reduce_conv_w, dim3(ew_grid((long)Co * Ci * 9)), dim3(256), 0, st, part, dW,
+                     Co, Ci, S);
+  if (colsum && db)
+    hipLaunchKernelGGL(k_reduce_colsum, dim3(sr_cdiv(Co, 256)), dim3(256), 0, st, colsum, db, Co, S);
+  SR_LAUNCH_CHECK("reduce_conv_wgrad");
+  return 0;
+}
+
+int srhip_fold_layernorm(const float* W, const float* b, const float* gamma, const float* beta,
+                         float* Wf, float* bf, int N, int K, void* stream) {
+  hipLaunchKernelGGL(k_fold_ln, dim3(sr_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, W, b, gamma,
+                     beta, Wf, bf, N, K);
+  SR_LAUNCH_CHECK("fold_layernorm");
+  return 0;
+}
+
+int srhip_transpose(const float* in, float* out, int R, int C, void* stream) {
+  hipLaunchKernelGGL(k_transpose, dim3(sr_cdiv(C, 32), sr_cdiv(R, 32)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, R, C);
+  SR_LAUNCH_CHECK("transpose");
+  return 0;
+}
+
+int srhip_pack_conv_weight(const float* w, float* wp, float* wpt, int Co, int Ci, void* stream) {
+  hipLaunchKernelGGL(k_pack_conv_w, dim3(ew_grid((long)Co * Ci * 9)), dim3(256), 0,
+                     (hipStream_t)stream, w, wp, wpt, Co, Ci);
+  SR_LAUNCH_CHECK("pack_conv_weight");
+  return 0;
+}
+
+int srhip_layernorm_fwd(const float* x, float* stats, float* y, const float* gamma, const float* beta,
+                        long M, int C, void* stream) {
+  SR_REQUIRE(C <= 64 * LN_MAXV, "layernorm: C=%d > %d unsupported", C, 64 * LN_MAXV);
+  SR_REQUIRE(!y || (gamma && beta), "layernorm_fwd: y requested without gamma/beta");
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(k_ln_fwd, dim3(sr_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, stats, y,
+                     gamma, beta, M, C);
+  SR_LAUNCH_CHECK("layernorm_fwd");
+  return 0;
+}
+
+int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* res,
+                        const float* gamma, float* out, float* dgamma, float* dbeta, long M, int C,
+                        void* stream) {
+  SR_REQUIRE(C <= 64 * LN_MAXV, "layernorm: C=%d > %d unsupported", C, 64 * LN_MAXV);
+  SR_REQUIRE(!gamma || (dgamma && dbeta), "layernorm_bwd: gamma given without dgamma/dbeta");
+  if (M <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int rpw = 1;
+  if (gamma) {  // fewer, longer waves so the column atomics stay cheap
+    rpw = (int)((M + 2047) / 2048);
+    hipMemsetAsync(dgamma, 0, sizeof(float) * C, st);
+    hipMemsetAsync(dbeta, 0, sizeof(float) * C, st);
+  }
+  const long waves = (M + rpw - 1) / rpw;
+  hipLaunchKernelGGL(k_ln_bwd, dim3(sr_cdiv(waves, 4)), dim3(256), 0, st, dy, x, stats, res, gamma,
+                     out, dgamma, dbeta, M, C, rpw);
+  SR_LAUNCH_CHECK("layernorm_bwd");
+  return 0;
+}
+
+int srhip_pixel_shuffle(const float* in, float* out, int B, int h, int w, int Co, int r,
+                        int nhwc_out, int inverse, void* stream) {
+  SR_REQUIRE(r >= 1 && Co >= 1, "pixel_shuffle: bad r/Co");
+  const long n = (long)B * h * w * Co * r * r;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_pixel_shuffle, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     B, h, w, Co, r, nhwc_out, inverse);
+  SR_LAUNCH_CHECK("pixel_shuffle");
+  return 0;
+}
+
+// workspace: 2048 doubles
+int srhip_loss_l1l2(const float* pred, const float* target, const float* weight, float* grad,
+                    float* loss_out, double* workspace, long n, int mode, float lam, int grad_accum,
+                    int loss_accum, void* stream) {
+  SR_REQUIRE(n > 0, "loss: empty input");
+  SR_REQUIRE(mode == 0 || mode == 1, "loss: mode %d", mode);
+  hipStream_t st = (hipStream_t)stream;
+  const int g = ew_grid(n);
+  hipLaunchKernelGGL(k_loss_l1l2, dim3(g), dim3(256), 0, st, pred, target, weight, grad, workspace, n,
+                     mode, lam, grad_accum);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, workspace, g, (double)lam / (double)n,
+                     loss_out, loss_accum);
+  SR_LAUNCH_CHECK("loss_l1l2");
+  return 0;
+}
+
+int srhip_adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float b1,
+                    float b2, float eps, float wd, float gscale, void* stream) {
+  if (n <= 0) return 0;
+  const float bc1 = 1.f - powf(b1, (float)step);
+  const float bc2 = 1.f - powf(b2, (float)step);
+  hipLaunchKernelGGL(k_adam, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
+                     b1, b2, eps, wd, bc1, sqrtf(bc2), gscale);
+  SR_LAUNCH_CHECK("adam_step");
+  return 0;
+}
+
+int srhip_sgd_step(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
+                   int nesterov, int first, float gscale, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_sgd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr,
+                     momentum, wd, nesterov, first, gscale);
+  SR_LAUNCH_CHECK("sgd_step");
+  return 0;
+}
+
+int srhip_nonfinite_flag(const float* x, long n, int* flag, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_nonfinite, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, flag);
+  SR_LAUNCH_CHECK("nonfinite_flag");
+  return 0;
+}
+
+int srhip_axpby(float* y, const float* x, long n, float a, float b, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_axpby, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, y, x, n, a, b);
+  SR_LAUNCH_CHECK("axpby");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+// HBM-bound edge kernels: 1-channel 3x3 convolutions (the network's first and
+// last layers on 1-channel microscopy patches) and the fused PSNR / MSE / NRMSE
+// metric sweep.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int CO_PER_LANE = 4;  // Cout <= 256
+
+// y[p][co] = b[co] + sum_t x[p+t] * w[co][t]     x: [B][H][W] (1 channel), y NHWC
+// flip=1 uses w[co][8-t] (this is then the data-gradient of a Cout=1 conv).
+// conv_first: network_swinir.py:786,945; head conv: network_nlsn.py:325.
+__global__ void __launch_bounds__(256) k_conv_cin1_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       int B, int H, int W, int Co, int flip, long ldy) {
+  const int lane = threadIdx.x & 63;
+  const long wave = blockIdx.x * 4L + (threadIdx.x >> 6), nwave = gridDim.x * 4L;
+  float wr[CO_PER_LANE][9], br[CO_PER_LANE];
+#pragma unroll
+  for (int i = 0; i < CO_PER_LANE; ++i) {
+    const int co = lane + 64 * i;
+    br[i] = (co < Co && bias) ? bias[co] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[i][t] = co < Co ? w[co * 9 + (flip ? 8 - t : t)] : 0.f;
+  }
+  const long npix = (long)B * H * W;
+  for (long p = wave; p < npix; p += nwave) {
+    const int xx = p % W, yy = (p / W) % H;
+    const long b = p / ((long)W * H);
+    float xv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int sy = yy + t / 3 - 1, sx = xx + t % 3 - 1;
+      xv[t] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(b * H + sy) * W + sx] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < CO_PER_LANE; ++i) {
+      const int co = lane + 64 * i;
+      if (co < Co) {
+        float a = br[i];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a += xv[t] * wr[i][t];
+        y[p * ldy + co] = a;
+      }
+    }
+  }
+}
+// part[wave][co][10]: dw[co][t] = sum_p dy[p][co]*x[p+t] (t<9), db[co] (t=9)
+__global__ void __launch_bounds__(256) k_conv_cin1_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ part, int B, int H, int W, int Co,
+                                                         long lddy) {
+  const int lane = threadIdx.x & 63;
+  const long wave = blockIdx.x * 4L + (threadIdx.x >> 6), nwave = gridDim.x * 4L;
+  float acc[CO_PER_LANE][10];
+#pragma unroll
+  for (int i = 0; i < CO_PER_LANE; ++i)
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[i][t] = 0.f;
+  const long npix = (long)B * H * W;
+  for (long p = wave; p < npix; p += nwave) {
+    const int xx = p % W, yy = (p / W) % H;
+    const long b = p / ((long)W * H);
+    float xv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int sy = yy + t / 3 - 1, sx = xx + t % 3 - 1;
+      xv[t] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(b * H + sy) * W + sx] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < CO_PER_LANE; ++i) {
+      const int co = lane + 64 * i;
+      if (co < Co) {
+        const float g = dy[p * lddy + co];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] += g * xv[t];
+        acc[i][9] += g;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CO_PER_LANE; ++i) {
+    const int co = lane + 64 * i;
+    if (co < Co) {
+#pragma unroll
+      for (int t = 0; t < 10; ++t) part[(wave * Co + co) * 10 + t] = acc[i][t];
+    }
+  }
+}
+// dw[co][t] = sum_waves part (flip: written to 8-t), db[co]
+__global__ void k_conv_cin1_wgrad_fin(const float* __restrict__ part, float* __restrict__ dw,
+                                      float* __restrict__ db, int Co, int nwave, int flip) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Co * 10) return;
+  const int co = i / 10, t = i % 10;
+  float a = 0.f;
+  for (int wv = 0; wv < nwave; ++wv) a += part[((long)wv * Co + co) * 10 + t];
+  if (t == 9) { if (db) db[co] = a; }
+  else dw[co * 9 + (flip ? 8 - t : t)] = a;
+}
+// Cout = 1: y[p] = b + sum_t sum_ci x[p+t][ci] * w[ci][t]   (x NHWC, Ci <= 256)
+// tail conv of the EDSR wiring, network_nlsn.py:347-350.  One wave per pixel.
+__global__ void __launch_bounds__(256) k_conv_cout1_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        int B, int H, int W, int Ci, long ldx) {
+  const int lane = threadIdx.x & 63;
+  const long wave = blockIdx.x * 4L + (threadIdx.x >> 6), nwave = gridDim.x * 4L;
+  float wr[CO_PER_LANE][9];
+#pragma unroll
+  for (int i = 0; i < CO_PER_LANE; ++i) {
+    const int ci = lane + 64 * i;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[i][t] = ci < Ci ? w[ci * 9 + t] : 0.f;
+  }
+  const float b0 = bias ? bias[0] : 0.f;
+  const long npix = (long)B * H * W;
+  for (long p = wave; p < npix; p += nwave) {
+    const int xx = p % W, yy = (p / W) % H;
+    const long b = p / ((long)W * H);
+    float a = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int sy = yy + t / 3 - 1, sx = xx + t % 3 - 1;
+      if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+        const float* row = x + ((b * H + sy) * W + sx) * ldx;
+#pragma unroll
+        for (int i = 0; i < CO_PER_LANE; ++i) {
+          const int ci = lane + 64 * i;
+          if (ci < Ci) a += row[ci] * wr[i][t];
+        }
+      }
+    }
+    a = wave_sum(a);
+    if (lane == 0) y[p] = a + b0;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// metrics: tensor2uint82float + PSNR / PSNR_Y / MSE / NRMSE in one pass, for
+// "no ROI" and up to 8 ROI thresholds (utils_trainer.py:961-1032,
+// utils_image.py:369-372,843-1007,618-653).  SSE is a sum of integers in
+// double: exact and order independent.
+// ----------------------------------------------------------------------------
+constexpr int MAXTH = 9;  // slot 0 = no ROI
+struct MetAcc {
+  double sse, ssey;
+  long cnt;
+  float ymax, ymin;
+};
+__device__ __forceinline__ float u8f(float v) {  // (clamp(v,0,1)*255).round().clamp(0,255)
+  v = fminf(fmaxf(v, 0.f), 1.f) * 255.0f;
+  return fminf(fmaxf(rintf(v), 0.f), 255.f);
+}
+__device__ __forceinline__ float ycb(float u8) {  // gray -> Y in [0,255] (float path)
+  const float v255 = (u8 / 255.0f) * 255.0f;        // _rgb_tensor(E)/255 -> ycbcr multiplies back
+  const float y = (65.481f * v255 + 128.553f * v255 + 24.966f * v255) / 255.0f + 16.0f;
+  return fminf(fmaxf(y / 255.0f, 0.f), 1.f) * 255.0f;
+}
+// raw[b][th][blk][8] doubles: sse, ssey, cnt, ymax, ymin_roi, ymin_all
+__global__ void __launch_bounds__(256) k_metrics_pass(const float* __restrict__ E, const float* __restrict__ Hh,
+                                                      double* __restrict__ raw, int H, int W, int border,
+                                                      const int* __restrict__ ths, int nth, int in_is_u8) {
+  const int b = blockIdx.y, nb = gridDim.x;
+  const int h = H - 2 * border, w = W - 2 * border;
+  const long n = (long)h * w;
+  MetAcc acc[MAXTH];
+  float ymin_all = 3.0e38f;
+#pragma unroll
+  for (int k = 0; k < MAXTH; ++k) { acc[k].sse = 0; acc[k].ssey = 0; acc[k].cnt = 0; acc[k].ymax = 0.f; acc[k].ymin = 3.0e38f; }
+  int thv[MAXTH];
+#pragma unroll
+  for (int k = 0; k < MAXTH; ++k) thv[k] = (k >= 1 && k <= nth) ? ths[k - 1] : 0;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += nb * 256L) {
+    const int yy = i / w + border, xx = i % w + border;
+    const long o = ((long)b * H + yy) * W + xx;
+    const float a = in_is_u8 ? E[o] : u8f(E[o]);
+    const float t = in_is_u8 ? Hh[o] : u8f(Hh[o]);
+    const double d = (double)a - (double)t;
+    const double dyv = (double)ycb(a) - (double)ycb(t);
+    ymin_all = fminf(ymin_all, t);
+#pragma unroll
+    for (int k = 0; k < MAXTH; ++k) {
+      if (k <= nth && (k == 0 || t >= (float)thv[k])) {
+        acc[k].sse += d * d; acc[k].ssey += dyv * dyv; acc[k].cnt += 1;
+        acc[k].ymax = fmaxf(acc[k].ymax, t); acc[k].ymin = fminf(acc[k].ymin, t);
+      }
+    }
+  }
+  __shared__ double sh[4][6];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double ya = wave_min_d((double)ymin_all);
+#pragma unroll
+  for (int k = 0; k < MAXTH; ++k) {
+    if (k > nth) break;                            // block-uniform
+    const double s0 = wave_sum_d(acc[k].sse), s1 = wave_sum_d(acc[k].ssey);
+    const double s2 = wave_sum_d((double)acc[k].cnt);
+    const double s3 = wave_max_d((double)acc[k].ymax), s4 = wave_min_d((double)acc[k].ymin);
+    __syncthreads();
+    if (lane == 0) { sh[wv][0] = s0; sh[wv][1] = s1; sh[wv][2] = s2; sh[wv][3] = s3; sh[wv][4] = s4; sh[wv][5] = ya; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double* o = raw + (((long)b * (nth + 1) + k) * nb + blockIdx.x) * 8;
+      o[0] = sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0];
+      o[1] = sh[0][1] + sh[1][1] + sh[2][1] + sh[3][1];
+      o[2] = sh[0][2] + sh[1][2] + sh[2][2] + sh[3][2];
+      o[3] = fmax(fmax(sh[0][3], sh[1][3]), fmax(sh[2][3], sh[3][3]));
+      o[4] = fmin(fmin(sh[0][4], sh[1][4]), fmin(sh[2][4], sh[3][4]));
+      o[5] = fmin(fmin(sh[0][5], sh[1][5]), fmin(sh[2][5], sh[3][5]));
+    }
+  }
+}
+// out[b][th][4] doubles: psnr, psnr_y, mse, nrmse
+__global__ void k_metrics_fin(const double* __restrict__ raw, double* __restrict__ out, int nimg_th, int nb,
+                              int nth1, long npix) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nimg_th) return;
+  const int k = i % nth1;
+  double sse = 0, ssey = 0, cnt = 0, ymax = 0, ymin = 3.0e38, ymin_all = 3.0e38;
+  for (int j = 0; j < nb; ++j) {
+    const double* r = raw + ((long)i * nb + j) * 8;
+    sse += r[0]; ssey += r[1]; cnt += r[2];
+    ymax = fmax(ymax, r[3]); ymin = fmin(ymin, r[4]); ymin_all = fmin(ymin_all, r[5]);
+  }
+  double lo;
+  if (k == 0) lo = ymin_all;
+  else {
+    const double min_masked = (cnt < (double)npix) ? 0.0 : ymin;   // min(y*roi)
+    lo = fmax(ymin_all, min_masked);
+  }
+  const double denom_cnt = (k == 0) ? (double)npix : (cnt == 0 ? 1.0 : cnt);
+  double mse = sse / denom_cnt, msey = ssey / denom_cnt;
+  const double mse_p = mse < 1e-45 ? 1e-45 : mse, msey_p = msey < 1e-45 ? 1e-45 : msey;
+  double den = ymax - lo;
+  if (den == 0) den = 1.0;
+  out[i * 4 + 0] = 20.0 * log10(255.0 / sqrt(mse_p));
+  out[i * 4 + 1] = 20.0 * log10(255.0 / sqrt(msey_p));
+  out[i * 4 + 2] = mse;
+  out[i * 4 + 3] = sqrt(mse) / den;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srhip_conv3x3_cin1_fwd(const float* x, const float* w, const float* bias, float* y, long ldy, int B,
+                           int H, int W, int Co, int flip, void* stream) {
+  SR_REQUIRE(Co <= 64 * CO_PER_LANE, "conv_cin1: Cout=%d > %d", Co, 64 * CO_PER_LANE);
+  const long npix = (long)B * H * W;
+  if (npix <= 0) return 0;
+  long blocks = (npix + 15) / 16;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_conv_cin1_fwd, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                     y, B, H, W, Co, flip, ldy);
+  SR_LAUNCH_CHECK("conv_cin1_fwd");
+  return 0;
+}
+
+long srhip_conv3x3_cin1_wgrad_ws(int Co) { return 1024L * Co * 10; }  // floats
+
+int srhip_conv3x3_cin1_wgrad(const float* x, const float* dy, long lddy, float* dw, float* db,
+                             float* workspace, int B, int H, int W, int Co, int flip, void* stream) {
+  SR_REQUIRE(Co <= 64 * CO_PER_LANE, "conv_cin1: Cout=%d > %d", Co, 64 * CO_PER_LANE);
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = 256;  // 1024 waves
+  hipLaunchKernelGGL(k_conv_cin1_wgrad, dim3(blocks), dim3(256), 0, st, x, dy, workspace, B, H, W, Co,
+                     lddy);
+  hipLaunchKernelGGL(k_conv_cin1_wgrad_fin, dim3(sr_cdiv(Co * 10, 256)), dim3(256), 0, st, workspace,
+                     dw, db, Co, blocks * 4, flip);
+  SR_LAUNCH_CHECK("conv_cin1_wgrad");
+  return 0;
+}
+
+int srhip_conv3x3_cout1_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, int B,
+                            int H, int W, int Ci, void* stream) {
+  SR_REQUIRE(Ci <= 64 * CO_PER_LANE, "conv_cout1: Cin=%d > %d", Ci, 64 * CO_PER_LANE);
+  const long npix = (long)B * H * W;
+  if (npix <= 0) return 0;
+  long blocks = (npix + 15) / 16;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_conv_cout1_fwd, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                     y, B, H, W, Ci, ldx);
+  SR_LAUNCH_CHECK("conv_cout1_fwd");
+  return 0;
+}
+
+// workspace doubles: B*(nth+1)*64*8 ; out doubles: B*(nth+1)*4
+long srhip_metrics_ws(int B, int nth) { return (long)B * (nth + 1) * 64 * 8; }
+
+int srhip_metrics_psnr_family(const float* E, const float* Hh, int B, int H, int W, int border,
+                              const int* thresholds_dev, int nth, int inputs_are_u8, double* workspace,
+                              double* out, void* stream) {
+  SR_REQUIRE(nth >= 0 && nth <= MAXTH - 1, "metrics: at most %d ROI thresholds", MAXTH - 1);
+  SR_REQUIRE(B > 0 && H > 2 * border && W > 2 * border, "metrics: empty image after border crop");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = 64;
+  hipLaunchKernelGGL(k_metrics_pass, dim3(nb, B), dim3(256), 0, st, E, Hh, workspace, H, W, border,
+                     thresholds_dev, nth, inputs_are_u8);
+  const int n = B * (nth + 1);
+  hipLaunchKernelGGL(k_metrics_fin, dim3(sr_cdiv(n, 64)), dim3(64), 0, st, workspace, out, n, nb,
+                     nth + 1, (long)(H - 2 * border) * (W - 2 * border));
+  SR_LAUNCH_CHECK("metrics_psnr_family");
+  return 0;
+}
+
+}  // extern "C"

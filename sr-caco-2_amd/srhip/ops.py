@@ -1,0 +1,307 @@
+"""Thin tensor-level wrappers over the libsrhip C-ABI (include/srhip.h).
+
+PyTorch is used for device memory and streams only: every function here takes
+CUDA(=HIP) tensors, passes raw pointers + sizes + the current stream to the
+library, and returns tensors allocated by torch.  No function computes with
+aten ops and none has a CPU path."""
+import ctypes
+
+import torch
+
+from ._lib import call, lib, SrhipError  # noqa: F401
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise SrhipError("srhip ops need CUDA/HIP tensors (no CPU fallback exists)")
+        if t.dtype not in (torch.float32, torch.float64, torch.int32):
+            raise SrhipError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows(t):
+    """2-D view geometry of a row-major matrix whose last dim is contiguous."""
+    assert t.stride(-1) == 1
+    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+
+
+# ------------------------------------------------------------------ contractions
+def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
+            rowscale=None, rows_per_scale=1, alpha=1.0):
+    """out[M,N] = epi(pro(A)[M,K] @ W[N,K]^T + bias)."""
+    _chk(A, W, bias, out, ln_stats, R, rowscale)
+    M, K = A.shape
+    N = W.shape[0]
+    assert W.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    call("srhip_gemm_nt", _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out),
+         out.stride(0), M, N, K, a_mode, _p(ln_stats), epi, _p(R),
+         0 if R is None else R.stride(0), _p(rowscale), rows_per_scale, float(alpha), _st())
+    return out
+
+
+def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0):
+    """X NHWC [B,H,W,Cin], Wp packed [9,Cout,Cin] -> [B,H,W,Cout]."""
+    _chk(X, Wp, bias, out, R, rowscale)
+    B, H, W, Cin = X.shape
+    if out is None:
+        out = torch.empty(B, H, W, Cout, device=X.device, dtype=torch.float32)
+    call("srhip_conv3x3_nhwc", _p(X), X.stride(2), _p(Wp), _p(bias), _p(out), out.stride(2),
+         B, H, W, Cin, Cout, epi, _p(R), 0 if R is None else R.stride(2), _p(rowscale),
+         float(alpha), _st())
+    return out
+
+
+def tn_plan(M, NI, NJ, conv=False):
+    S = ctypes.c_int(0)
+    n = ctypes.c_long(0)
+    call("srhip_tn_plan", M, NI, NJ, int(conv), ctypes.addressof(S), ctypes.addressof(n))
+    return S.value, n.value
+
+
+class Scratch:
+    """Grow-only device scratch buffers keyed by name (caller-owned workspace of
+    the C-ABI; reused across calls so the hot loop never allocates)."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, name, n, dtype=torch.float32, device="cuda"):
+        b = self.bufs.get(name)
+        if b is None or b.numel() < n or b.dtype != dtype:
+            b = torch.empty(max(int(n), 1), device=device, dtype=dtype)
+            self.bufs[name] = b
+        return b
+
+
+SCRATCH = Scratch()
+
+
+def linear_wgrad(dY, X, dW, db, a_rowscale=None, a_rowscale_rows=1, b_mode=0, ln_stats=None,
+                 ln=None):
+    """dW[N,K] = dY[M,N]^T @ pro(X)[M,K]; db = colsum(dY).  ``ln`` =
+    (W, gamma, beta, dgamma, dbeta) finishes a LayerNorm-folded Linear."""
+    _chk(dY, X, dW, db, a_rowscale, ln_stats)
+    M, N = dY.shape
+    K = X.shape[1]
+    S, n = tn_plan(M, N, K)
+    part = SCRATCH.get("tn_part", n, device=dY.device)
+    cs = SCRATCH.get("tn_colsum", S * N, device=dY.device)
+    call("srhip_gemm_tn", _p(dY), dY.stride(0), _p(X), X.stride(0), M, N, K, _p(a_rowscale),
+         a_rowscale_rows, b_mode, _p(ln_stats), _p(part), _p(cs), S, _st())
+    if ln is None:
+        call("srhip_reduce_linear_wgrad", _p(part), _p(cs), S, _p(dW), _p(db), N, K, _st())
+    else:
+        W, gamma, beta, dgamma, dbeta = ln
+        call("srhip_reduce_ln_linear_wgrad", _p(part), _p(cs), S, _p(W), _p(gamma), _p(beta),
+             _p(dW), _p(db), _p(dgamma), _p(dbeta), N, K, _st())
+
+
+def conv3x3_wgrad(dY, X, dW, db):
+    """dY NHWC [B,H,W,Cout], X NHWC [B,H,W,Cin] -> dW [Cout,Cin,3,3], db [Cout]."""
+    _chk(dY, X, dW, db)
+    B, H, W, Cout = dY.shape
+    Cin = X.shape[3]
+    S, n = tn_plan(B * H * W, Cout, Cin, True)
+    part = SCRATCH.get("tn_part", n, device=dY.device)
+    cs = SCRATCH.get("tn_colsum", S * Cout, device=dY.device)
+    call("srhip_conv3x3_wgrad", _p(dY), dY.stride(2), _p(X), X.stride(2), B, H, W, Cout, Cin,
+         _p(part), _p(cs), S, _st())
+    call("srhip_reduce_conv_wgrad", _p(part), _p(cs), S, _p(dW), _p(db), Cout, Cin, _st())
+
+
+# ------------------------------------------------------------------ weight prep
+def fold_layernorm(W, b, gamma, beta, Wf, bf):
+    _chk(W, b, gamma, beta, Wf, bf)
+    call("srhip_fold_layernorm", _p(W), _p(b), _p(gamma), _p(beta), _p(Wf), _p(bf),
+         W.shape[0], W.shape[1], _st())
+
+
+def transpose(src, dst):
+    _chk(src, dst)
+    call("srhip_transpose", _p(src), _p(dst), src.shape[0], src.shape[1], _st())
+
+
+def pack_conv_weight(w, wp=None, wpt=None):
+    _chk(w, wp, wpt)
+    call("srhip_pack_conv_weight", _p(w), _p(wp), _p(wpt), w.shape[0], w.shape[1], _st())
+
+
+# ------------------------------------------------------------------ layernorm
+def layernorm_fwd(x, stats=None, y=None, gamma=None, beta=None):
+    _chk(x, stats, y, gamma, beta)
+    C = x.shape[-1]
+    M = x.numel() // C
+    call("srhip_layernorm_fwd", _p(x), _p(stats), _p(y), _p(gamma), _p(beta), M, C, _st())
+
+
+def layernorm_bwd(dy, x, stats, out, res=None, gamma=None, dgamma=None, dbeta=None):
+    _chk(dy, x, stats, out, res, gamma, dgamma, dbeta)
+    C = x.shape[-1]
+    M = x.numel() // C
+    call("srhip_layernorm_bwd", _p(dy), _p(x), _p(stats), _p(res), _p(gamma), _p(out),
+         _p(dgamma), _p(dbeta), M, C, _st())
+
+
+# ------------------------------------------------------------------ attention
+def bias_expand(table, biasT, biasN):
+    _chk(table, biasT, biasN)
+    call("srhip_bias_expand", _p(table), _p(biasT), _p(biasN), table.shape[1], _st())
+
+
+def bias_grad(dbiasT, dtable):
+    _chk(dbiasT, dtable)
+    call("srhip_bias_grad", _p(dbiasT), _p(dtable), dtable.shape[1], _st())
+
+
+def window_attention_fwd(qkv, out, biasT, B, H, W, C, heads, shift):
+    _chk(qkv, out, biasT)
+    call("srhip_window_attention_fwd", _p(qkv), _p(out), _p(biasT), B, H, W, C, heads, shift, _st())
+
+
+def window_attention_bwd(qkv, dout, dqkv, biasT, biasN, dbiasT, B, H, W, C, heads, shift):
+    _chk(qkv, dout, dqkv, biasT, biasN, dbiasT)
+    call("srhip_window_attention_bwd", _p(qkv), _p(dout), _p(dqkv), _p(biasT), _p(biasN),
+         _p(dbiasT), B, H, W, C, heads, shift, _st())
+
+
+# ------------------------------------------------------------------ edge convs
+def conv3x3_cin1_fwd(x, w, bias, Co, out=None, flip=False):
+    """x [B,H,W] -> NHWC [B,H,W,Co]; w torch layout [Co,1,3,3] (or [1,Co,3,3] with flip)."""
+    _chk(x, w, bias, out)
+    B, H, W = x.shape
+    if out is None:
+        out = torch.empty(B, H, W, Co, device=x.device, dtype=torch.float32)
+    call("srhip_conv3x3_cin1_fwd", _p(x), _p(w), _p(bias), _p(out), out.stride(2), B, H, W, Co,
+         int(flip), _st())
+    return out
+
+
+def conv3x3_cin1_wgrad(x, dy, dw, db, flip=False):
+    _chk(x, dy, dw, db)
+    B, H, W = x.shape
+    Co = dy.shape[3]
+    ws = SCRATCH.get("cin1_ws", lib.srhip_conv3x3_cin1_wgrad_ws(Co), device=x.device)
+    call("srhip_conv3x3_cin1_wgrad", _p(x), _p(dy), dy.stride(2), _p(dw), _p(db), _p(ws), B, H, W,
+         Co, int(flip), _st())
+
+
+def conv3x3_cout1_fwd(x, w, bias, out=None):
+    """x NHWC [B,H,W,Ci] -> [B,H,W]; w torch layout [1,Ci,3,3]."""
+    _chk(x, w, bias, out)
+    B, H, W, Ci = x.shape
+    if out is None:
+        out = torch.empty(B, H, W, device=x.device, dtype=torch.float32)
+    call("srhip_conv3x3_cout1_fwd", _p(x), x.stride(2), _p(w), _p(bias), _p(out), B, H, W, Ci, _st())
+    return out
+
+
+# ------------------------------------------------------------------ pixel shuffle
+def pixel_shuffle(x, r, nhwc_out=False, inverse=False, out=None):
+    """forward: x NHWC [B,h,w,Co*r*r] -> NCHW [B,Co,h*r,w*r] (or NHWC).  inverse:
+    x is the high-res side and the NHWC low-res tensor is returned."""
+    _chk(x, out)
+    if not inverse:
+        B, h, w, C = x.shape
+        Co = C // (r * r)
+        if out is None:
+            shape = (B, h * r, w * r, Co) if nhwc_out else (B, Co, h * r, w * r)
+            out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    else:
+        if nhwc_out:
+            B, Hh, Ww, Co = x.shape
+        else:
+            B, Co, Hh, Ww = x.shape
+        h, w = Hh // r, Ww // r
+        if out is None:
+            out = torch.empty(B, h, w, Co * r * r, device=x.device, dtype=torch.float32)
+    call("srhip_pixel_shuffle", _p(x), _p(out), B, h, w, Co, r, int(nhwc_out), int(inverse), _st())
+    return out
+
+
+# ------------------------------------------------------------------ losses
+def loss_l1l2(pred, target, mode, lam=1.0, weight=None, grad=None, loss_out=None,
+              grad_accum=False, loss_accum=False):
+    _chk(pred, target, weight, grad, loss_out)
+    if loss_out is None:
+        loss_out = torch.empty(1, device=pred.device, dtype=torch.float32)
+    ws = SCRATCH.get("loss_ws", 2048, torch.float64, pred.device)
+    call("srhip_loss_l1l2", _p(pred), _p(target), _p(weight), _p(grad), _p(loss_out), _p(ws),
+         pred.numel(), mode, float(lam), int(grad_accum), int(loss_accum), _st())
+    return loss_out
+
+
+def ssim_loss(pred, target, ws, lam=1.0, grad=None, loss_out=None, grad_accum=False,
+              loss_accum=False):
+    """pred/target [B,1,H,W] or [B,H,W]."""
+    _chk(pred, target, grad, loss_out)
+    B = pred.shape[0]
+    H, W = pred.shape[-2:]
+    if loss_out is None:
+        loss_out = torch.empty(1, device=pred.device, dtype=torch.float32)
+    wsb = SCRATCH.get("ssim_ws", lib.srhip_ssim_loss_ws(B, H, W), device=pred.device)
+    call("srhip_ssim_loss", _p(pred), _p(target), _p(grad), _p(loss_out), _p(wsb), B, H, W, ws,
+         float(lam), int(grad_accum), int(loss_accum), _st())
+    return loss_out
+
+
+# ------------------------------------------------------------------ metrics
+def metrics_psnr_family(E, Hh, border, thresholds=(), inputs_are_u8=False):
+    """Returns fp64 [B, 1+len(thresholds), 4] = PSNR, PSNR_Y, MSE, NRMSE."""
+    _chk(E, Hh)
+    B = E.shape[0]
+    H, W = E.shape[-2:]
+    nth = len(thresholds)
+    th = torch.tensor(list(thresholds) or [0], dtype=torch.int32, device=E.device)
+    ws = SCRATCH.get("met_ws", lib.srhip_metrics_ws(B, nth), torch.float64, E.device)
+    out = torch.empty(B, nth + 1, 4, dtype=torch.float64, device=E.device)
+    call("srhip_metrics_psnr_family", _p(E), _p(Hh), B, H, W, border, _p(th), nth,
+         int(inputs_are_u8), _p(ws), _p(out), _st())
+    return out
+
+
+def metrics_ssim(E, Hh, border, thresholds=(), inputs_are_u8=False):
+    _chk(E, Hh)
+    B = E.shape[0]
+    H, W = E.shape[-2:]
+    nth = len(thresholds)
+    th = torch.tensor(list(thresholds) or [0], dtype=torch.int32, device=E.device)
+    ws = SCRATCH.get("ssim_met_ws", 2 * B * (nth + 1), torch.float64, E.device)
+    out = torch.empty(B, nth + 1, dtype=torch.float32, device=E.device)
+    call("srhip_metrics_ssim", _p(E), _p(Hh), B, H, W, border, _p(th), nth, int(inputs_are_u8),
+         _p(ws), _p(out), _st())
+    return out
+
+
+# ------------------------------------------------------------------ optimizers
+def adam_step(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0, gscale=1.0):
+    _chk(p, g, m, v)
+    call("srhip_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), step, float(lr), float(b1),
+         float(b2), float(eps), float(wd), float(gscale), _st())
+
+
+def sgd_step(p, g, buf, lr, momentum=0.9, wd=0.0, nesterov=True, first=False, gscale=1.0):
+    _chk(p, g, buf)
+    call("srhip_sgd_step", _p(p), _p(g), _p(buf), p.numel(), float(lr), float(momentum),
+         float(wd), int(nesterov), int(first), float(gscale), _st())
+
+
+def nonfinite_flag(x, flag):
+    _chk(x, flag)
+    call("srhip_nonfinite_flag", _p(x), x.numel(), _p(flag), _st())
+
+
+def axpby(y, x, a, b):
+    _chk(x, y)
+    call("srhip_axpby", _p(y), _p(x), y.numel(), float(a), float(b), _st())

@@ -1,0 +1,420 @@
+"""GPU parity tests, kernel by kernel: every libsrhip entry point (called through
+the C-ABI) against a plain PyTorch-fp32 CPU statement of the same op / the
+oracle.  Tolerances: bit-exact for index ops and integer-valued metrics;
+fp32 contractions within 2e-5 relative to the output scale (different
+summation order than aten; exact-f32 MFMA, no reduced precision anywhere)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import sr_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from srhip import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def check(a, b, tol, what):
+    e = relerr(a, b)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol:g}"
+
+
+G = torch.Generator().manual_seed(1234)
+
+
+def rnd(*shape, scale=1.0):
+    return torch.randn(*shape, generator=G) * scale
+
+
+# ------------------------------------------------------------------ gemm_nt
+@pytest.mark.parametrize("M,N,K", [(300, 180, 180), (4096, 540, 180), (1000, 60, 60),
+                                   (777, 64, 64), (2048, 360, 180), (515, 180, 360),
+                                   (64, 120, 60), (130, 256, 64), (33000, 180, 180)])
+def test_gemm_nt_bias(ops, M, N, K):
+    A, W, b = rnd(M, K), rnd(N, K, scale=0.1), rnd(N)
+    out = ops.gemm_nt(dev(A), dev(W), dev(b))
+    check(out, F.linear(A, W, b), 2e-5, f"gemm_nt {M}x{N}x{K}")
+
+
+def test_gemm_nt_prologues_epilogues(ops):
+    M, N, K = 1024, 180, 180
+    A, W, b = rnd(M, K), rnd(N, K, scale=0.1), rnd(N)
+    R = rnd(M, N)
+    # LayerNorm prologue: (A-mean)*rstd
+    mean = A.mean(1)
+    rstd = 1.0 / torch.sqrt(A.var(1, unbiased=False) + 1e-5)
+    stats = torch.stack([mean, rstd], 1)
+    out = ops.gemm_nt(dev(A), dev(W), dev(b), a_mode=1, ln_stats=dev(stats))
+    check(out, F.linear((A - mean[:, None]) * rstd[:, None], W, b), 2e-5, "ln prologue")
+    # GELU prologue
+    out = ops.gemm_nt(dev(A), dev(W), dev(b), a_mode=2)
+    check(out, F.linear(F.gelu(A), W, b), 2e-5, "gelu prologue")
+    # relu
+    out = ops.gemm_nt(dev(A), dev(W), dev(b), epi=1)
+    check(out, F.relu(F.linear(A, W, b)), 2e-5, "relu epilogue")
+    # residual + per-sample scale (4 samples of 256 rows)
+    rs = torch.tensor([1.0, 0.0, 1.25, 2.0])
+    out = ops.gemm_nt(dev(A), dev(W), dev(b), epi=2, R=dev(R), rowscale=dev(rs),
+                      rows_per_scale=256, alpha=0.5)
+    ref = R + 0.5 * rs.repeat_interleave(256)[:, None] * F.linear(A, W, b)
+    check(out, ref, 2e-5, "residual epilogue")
+    # per-row scale fallback (rows_per_scale not a multiple of the tile)
+    rs2 = torch.rand(M // 8 + 1, generator=G)
+    out = ops.gemm_nt(dev(A), dev(W), dev(b), epi=2, R=dev(R), rowscale=dev(rs2), rows_per_scale=8)
+    ref = R + rs2.repeat_interleave(8)[:M, None] * F.linear(A, W, b)
+    check(out, ref, 2e-5, "residual epilogue per-row scale")
+    # dgelu: s*acc*gelu'(R)
+    Rg = R.clone().requires_grad_(True)
+    F.gelu(Rg).sum().backward()
+    out = ops.gemm_nt(dev(A), dev(W), None, epi=3, R=dev(R), rowscale=dev(rs), rows_per_scale=256)
+    ref = rs.repeat_interleave(256)[:, None] * F.linear(A, W) * Rg.grad
+    check(out, ref, 2e-5, "dgelu epilogue")
+    # relu mask
+    out = ops.gemm_nt(dev(A), dev(W), None, epi=4, R=dev(R))
+    check(out, F.linear(A, W) * (R > 0), 2e-5, "relu-mask epilogue")
+    # strided output / input (column slices of wider buffers)
+    wide = torch.zeros(M, 540).cuda()
+    ops.gemm_nt(dev(A), dev(W), dev(b), out=wide[:, 180:360])
+    check(wide[:, 180:360], F.linear(A, W, b), 2e-5, "strided out")
+    assert wide[:, :180].abs().max() == 0 and wide[:, 360:].abs().max() == 0
+
+
+# ------------------------------------------------------------------ conv3x3
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 16, 180, 180), (1, 24, 40, 60, 60),
+                                         (1, 20, 12, 64, 64), (1, 16, 16, 64, 256),
+                                         (2, 64, 64, 180, 64), (1, 9, 7, 16, 16),
+                                         (8, 64, 64, 180, 180)])
+def test_conv3x3_fwd_bwd(ops, B, H, W, Ci, Co):
+    x = rnd(B, Ci, H, W)
+    w = rnd(Co, Ci, 3, 3, scale=0.05)
+    b = rnd(Co)
+    xh = dev(x.permute(0, 2, 3, 1))
+    wd = dev(w)
+    wp = torch.empty(9, Co, Ci).cuda()
+    wpt = torch.empty(9, Ci, Co).cuda()
+    ops.pack_conv_weight(wd, wp, wpt)
+    y = ops.conv3x3(xh, wp, dev(b), Co)
+    ref = F.conv2d(x, w, b, padding=1)
+    check(y.permute(0, 3, 1, 2), ref, 2e-5, "conv fwd")
+    if B * H * W > 20000:
+        return
+    # data gradient through the flipped/transposed pack
+    dy = rnd(B, Co, H, W)
+    dyh = dev(dy.permute(0, 2, 3, 1))
+    dx = ops.conv3x3(dyh, wpt, None, Ci)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    F.conv2d(xr, wr, br, padding=1).backward(dy)
+    check(dx.permute(0, 3, 1, 2), xr.grad, 2e-5, "conv bwd-data")
+    dw = torch.empty_like(wd)
+    db = torch.empty(Co).cuda()
+    ops.conv3x3_wgrad(dyh, xh, dw, db)
+    check(dw, wr.grad, 2e-5, "conv bwd-weight")
+    check(db, br.grad, 2e-5, "conv bwd-bias")
+
+
+def test_conv3x3_epilogues(ops):
+    B, H, W, C = 2, 16, 24, 64
+    x, w, b, R = rnd(B, C, H, W), rnd(C, C, 3, 3, scale=0.05), rnd(C), rnd(B, C, H, W)
+    xh, Rh = dev(x.permute(0, 2, 3, 1)), dev(R.permute(0, 2, 3, 1))
+    wp = torch.empty(9, C, C).cuda()
+    ops.pack_conv_weight(dev(w), wp, None)
+    ref = F.conv2d(x, w, b, padding=1)
+    y = ops.conv3x3(xh, wp, dev(b), C, epi=1)
+    check(y.permute(0, 3, 1, 2), F.relu(ref), 2e-5, "conv relu")
+    y = ops.conv3x3(xh, wp, dev(b), C, epi=2, R=Rh, alpha=0.1)
+    check(y.permute(0, 3, 1, 2), R + 0.1 * ref, 2e-5, "conv residual")
+    y = ops.conv3x3(xh, wp, None, C, epi=4, R=Rh)
+    check(y.permute(0, 3, 1, 2), F.conv2d(x, w, None, padding=1) * (R > 0), 2e-5, "conv relu-mask")
+
+
+# ------------------------------------------------------------------ gemm_tn
+@pytest.mark.parametrize("M,NI,NJ", [(5000, 180, 180), (4096, 540, 180), (3000, 360, 180),
+                                     (2500, 180, 360), (700, 60, 60), (1234, 64, 256),
+                                     (32768, 180, 180)])
+def test_linear_wgrad(ops, M, NI, NJ):
+    dY, X = rnd(M, NI), rnd(M, NJ)
+    dW = torch.empty(NI, NJ).cuda()
+    db = torch.empty(NI).cuda()
+    ops.linear_wgrad(dev(dY), dev(X), dW, db)
+    check(dW, dY.double().t() @ X.double(), 2e-5, "dW")
+    check(db, dY.double().sum(0), 2e-5, "db")
+
+
+def test_linear_wgrad_modes(ops):
+    M, NI, NJ = 2048, 180, 180
+    dY, X = rnd(M, NI), rnd(M, NJ)
+    rs = torch.tensor([1.0, 0.0, 1.5, 2.0, 1.0, 1.0, 0.5, 1.0])
+    dW = torch.empty(NI, NJ).cuda()
+    db = torch.empty(NI).cuda()
+    # per-sample scale on dY, GELU on X
+    ops.linear_wgrad(dev(dY), dev(X), dW, db, a_rowscale=dev(rs), a_rowscale_rows=256, b_mode=2)
+    dYs = dY * rs.repeat_interleave(256)[:, None]
+    check(dW, dYs.double().t() @ F.gelu(X).double(), 2e-5, "dW scale+gelu")
+    check(db, dYs.double().sum(0), 2e-5, "db scale")
+    # LayerNorm-folded Linear: W_f = W*gamma, b_f = b + W.beta
+    Wt, gamma, beta = rnd(NI, NJ, scale=0.1), 1 + 0.1 * rnd(NJ), 0.1 * rnd(NJ)
+    xr = X.clone()
+    Wr, gr, br = (t.clone().requires_grad_(True) for t in (Wt, gamma, beta))
+    bias = torch.zeros(NI, requires_grad=True)
+    y = F.linear(F.layer_norm(xr, (NJ,), gr, br), Wr, bias)
+    y.backward(dY)
+    mean = X.mean(1)
+    rstd = 1.0 / torch.sqrt(X.var(1, unbiased=False) + 1e-5)
+    stats = dev(torch.stack([mean, rstd], 1))
+    dg, dbt = torch.empty(NJ).cuda(), torch.empty(NJ).cuda()
+    ops.linear_wgrad(dev(dY), dev(X), dW, db, b_mode=1, ln_stats=stats,
+                     ln=(dev(Wt), dev(gamma), dev(beta), dg, dbt))
+    check(dW, Wr.grad, 3e-5, "ln-folded dW")
+    check(db, bias.grad, 3e-5, "ln-folded db")
+    check(dg, gr.grad, 3e-5, "ln-folded dgamma")
+    check(dbt, br.grad, 3e-5, "ln-folded dbeta")
+    # and the fold itself
+    Wf, bf = torch.empty(NI, NJ).cuda(), torch.empty(NI).cuda()
+    b0 = rnd(NI)
+    ops.fold_layernorm(dev(Wt), dev(b0), dev(gamma), dev(beta), Wf, bf)
+    check(Wf, Wt * gamma[None], 1e-6, "fold W")
+    check(bf, b0 + Wt @ beta, 1e-5, "fold b")
+    Tt = torch.empty(NJ, NI).cuda()
+    ops.transpose(dev(Wt), Tt)
+    assert torch.equal(Tt.cpu(), Wt.t().contiguous())
+
+
+# ------------------------------------------------------------------ layernorm
+@pytest.mark.parametrize("M,C", [(1000, 180), (4096, 60), (513, 64), (77, 256)])
+def test_layernorm(ops, M, C):
+    x, g, b, dy, res = rnd(M, C), 1 + 0.1 * rnd(C), 0.1 * rnd(C), rnd(M, C), rnd(M, C)
+    stats = torch.empty(M, 2).cuda()
+    y = torch.empty(M, C).cuda()
+    ops.layernorm_fwd(dev(x), stats, y, dev(g), dev(b))
+    check(y, F.layer_norm(x, (C,), g, b), 1e-5, "ln fwd")
+    check(stats[:, 0], x.mean(1), 1e-5, "ln mean")
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, g, b))
+    F.layer_norm(xr, (C,), gr, br).backward(dy)
+    out = torch.empty(M, C).cuda()
+    dg, dbt = torch.empty(C).cuda(), torch.empty(C).cuda()
+    ops.layernorm_bwd(dev(dy), dev(x), stats, out, res=dev(res), gamma=dev(g), dgamma=dg, dbeta=dbt)
+    check(out, res + xr.grad, 2e-5, "ln bwd dx")
+    check(dg, gr.grad, 2e-5, "ln dgamma")
+    check(dbt, br.grad, 2e-5, "ln dbeta")
+    # gradient w.r.t. the normalised value (gamma folded elsewhere)
+    xr2 = x.clone().requires_grad_(True)
+    F.layer_norm(xr2, (C,)).backward(dy)
+    ops.layernorm_bwd(dev(dy), dev(x), stats, out)
+    check(out, xr2.grad, 2e-5, "ln bwd dxhat")
+
+
+# ------------------------------------------------------------------ attention
+def ref_window_attention(qkv, table, B, H, W, C, heads, shift):
+    """oracle statement: roll + partition + attention + reverse + roll."""
+    d = C // heads
+    x = qkv.reshape(B, H, W, 3 * C)
+    if shift:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    xw = O.window_partition(x, 8).reshape(-1, 64, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = xw[0] * d ** -0.5, xw[1], xw[2]
+    att = q @ k.transpose(-2, -1)
+    rpi = O.relative_position_index(8)
+    att = att + table[rpi.reshape(-1)].reshape(64, 64, heads).permute(2, 0, 1)[None]
+    if shift:
+        m = O.shifted_window_mask(H, W, 8, shift)
+        nw = m.shape[0]
+        att = (att.reshape(B, nw, heads, 64, 64) + m[None, :, None]).reshape(-1, heads, 64, 64)
+    att = att.softmax(-1)
+    o = (att @ v).transpose(1, 2).reshape(-1, 8, 8, C)
+    o = O.window_reverse(o, 8, H, W)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    return o.reshape(B * H * W, C)
+
+
+@pytest.mark.parametrize("B,H,W,C,heads,shift", [(2, 16, 16, 180, 6, 0), (2, 16, 16, 180, 6, 4),
+                                                 (1, 16, 24, 60, 6, 4), (3, 24, 16, 60, 6, 0),
+                                                 (1, 64, 64, 180, 6, 4), (1, 72, 72, 180, 6, 4)])
+def test_window_attention(ops, B, H, W, C, heads, shift):
+    T = B * H * W
+    qkv = rnd(T, 3 * C)
+    table = rnd(225, heads, scale=0.5)
+    dout = rnd(T, C)
+    biasT = torch.empty(heads, 64, 64).cuda()
+    biasN = torch.empty(heads, 64, 64).cuda()
+    ops.bias_expand(dev(table), biasT, biasN)
+    rpi = O.relative_position_index(8)
+    dense = table[rpi.reshape(-1)].reshape(64, 64, heads).permute(2, 0, 1)
+    assert torch.equal(biasN.cpu(), dense.contiguous())
+    assert torch.equal(biasT.cpu(), dense.transpose(1, 2).contiguous())
+    out = torch.empty(T, C).cuda()
+    ops.window_attention_fwd(dev(qkv), out, biasT, B, H, W, C, heads, shift)
+    qr, tr = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    ref = ref_window_attention(qr, tr, B, H, W, C, heads, shift)
+    check(out, ref, 1e-5, "attention fwd")
+    ref.backward(dout)
+    dqkv = torch.empty(T, 3 * C).cuda()
+    dbiasT = torch.zeros(heads, 64, 64).cuda()
+    ops.window_attention_bwd(dev(qkv), dev(dout), dqkv, biasT, biasN, dbiasT, B, H, W, C, heads, shift)
+    check(dqkv[:, :C], qr.grad[:, :C], 2e-5, "attention dq")
+    check(dqkv[:, C:2 * C], qr.grad[:, C:2 * C], 2e-5, "attention dk")
+    check(dqkv[:, 2 * C:], qr.grad[:, 2 * C:], 2e-5, "attention dv")
+    dtable = torch.empty(225, heads).cuda()
+    ops.bias_grad(dbiasT, dtable)
+    check(dtable, tr.grad, 5e-5, "attention dtable")
+
+
+# ------------------------------------------------------------------ edge convs
+def test_conv_cin1_cout1(ops):
+    B, H, W, Co = 2, 20, 28, 180
+    x, w, b = torch.rand(B, 1, H, W, generator=G), rnd(Co, 1, 3, 3, scale=0.3), rnd(Co)
+    y = ops.conv3x3_cin1_fwd(dev(x[:, 0]), dev(w), dev(b), Co)
+    check(y.permute(0, 3, 1, 2), F.conv2d(x, w, b, padding=1), 1e-5, "cin1 fwd")
+    dy = rnd(B, Co, H, W)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.conv2d(x, wr, br, padding=1).backward(dy)
+    dw, db = torch.empty(Co, 1, 3, 3).cuda(), torch.empty(Co).cuda()
+    ops.conv3x3_cin1_wgrad(dev(x[:, 0]), dev(dy.permute(0, 2, 3, 1)), dw, db)
+    check(dw, wr.grad, 2e-5, "cin1 dW")
+    check(db, br.grad, 2e-5, "cin1 db")
+    # Cout = 1 tail: forward, data gradient (cin1 kernel with flipped taps) and
+    # weight gradient (cin1 wgrad with roles swapped + flipped taps)
+    Ci = 64
+    xt, wt, bt = rnd(B, Ci, H, W), rnd(1, Ci, 3, 3, scale=0.1), rnd(1)
+    xth = dev(xt.permute(0, 2, 3, 1))
+    yt = ops.conv3x3_cout1_fwd(xth, dev(wt), dev(bt))
+    check(yt, F.conv2d(xt, wt, bt, padding=1)[:, 0], 2e-5, "cout1 fwd")
+    dyt = rnd(B, 1, H, W)
+    xr, wr2, br2 = (t.clone().requires_grad_(True) for t in (xt, wt, bt))
+    F.conv2d(xr, wr2, br2, padding=1).backward(dyt)
+    dxt = ops.conv3x3_cin1_fwd(dev(dyt[:, 0]), dev(wt), None, Ci, flip=True)
+    check(dxt.permute(0, 3, 1, 2), xr.grad, 2e-5, "cout1 bwd-data")
+    dwt = torch.empty(1, Ci, 3, 3).cuda()
+    ops.conv3x3_cin1_wgrad(dev(dyt[:, 0]), xth, dwt, None, flip=True)
+    check(dwt, wr2.grad, 2e-5, "cout1 dW")
+
+
+# ------------------------------------------------------------------ index ops
+@pytest.mark.parametrize("r,Co,h,w", [(8, 1, 8, 8), (2, 64, 6, 10), (3, 2, 4, 4), (8, 1, 64, 64)])
+def test_pixel_shuffle_bit_exact(ops, r, Co, h, w):
+    B = 2
+    x = torch.arange(B * Co * r * r * h * w, dtype=torch.float32).reshape(B, Co * r * r, h, w)
+    ref = F.pixel_shuffle(x, r)
+    xh = dev(x.permute(0, 2, 3, 1))
+    assert torch.equal(ops.pixel_shuffle(xh, r).cpu(), ref)
+    assert torch.equal(ops.pixel_shuffle(xh, r, nhwc_out=True).cpu(), ref.permute(0, 2, 3, 1))
+    assert torch.equal(ops.pixel_shuffle(dev(ref), r, inverse=True).cpu(), xh.cpu())
+    assert torch.equal(ops.pixel_shuffle(dev(ref.permute(0, 2, 3, 1)), r, nhwc_out=True,
+                                         inverse=True).cpu(), xh.cpu())
+
+
+# ------------------------------------------------------------------ losses
+def test_losses(ops):
+    pred = torch.rand(2, 1, 96, 80, generator=G)
+    tgt = torch.rand(2, 1, 96, 80, generator=G)
+    wgt = torch.rand(2, 1, 96, 80, generator=G) * 2
+    for name, mode, w in (("l1", 0, None), ("l2", 1, None), ("l1w", 0, wgt)):
+        p = pred.clone().requires_grad_(True)
+        ref = O.loss_l1(p, tgt, 2.0, w) if mode == 0 else O.loss_l2(p, tgt, 2.0)
+        ref.backward()
+        grad = torch.empty_like(pred).cuda()
+        val = ops.loss_l1l2(dev(pred), dev(tgt), mode, 2.0, None if w is None else dev(w), grad)
+        check(val, ref.detach().reshape(1), 1e-6, name)
+        check(grad, p.grad, 1e-6, name + " grad")
+    for ws in (11, 19):
+        p = pred.clone().requires_grad_(True)
+        ref = O.loss_neg_ssim(p, tgt, 5.0, ws)
+        ref.backward()
+        grad = torch.empty_like(pred).cuda()
+        val = ops.ssim_loss(dev(pred), dev(tgt), ws, 5.0, grad)
+        check(val, ref.detach().reshape(1), 1e-4, f"ssim{ws}")  # fp32 E[x^2]-mu^2 cancellation
+        check(grad, p.grad, 2e-4, f"ssim{ws} grad")
+    # accumulate: L2 + 5*SSIM(19) as one MasterLoss (README recipe)
+    p = pred.clone().requires_grad_(True)
+    tot, _ = O.master_loss(p, tgt, [("l2", 1.0), ("ssim", 5.0, 19)])
+    tot.backward()
+    grad = torch.empty_like(pred).cuda()
+    val = ops.loss_l1l2(dev(pred), dev(tgt), 1, 1.0, None, grad)
+    ops.ssim_loss(dev(pred), dev(tgt), 19, 5.0, grad, val, grad_accum=True, loss_accum=True)
+    check(val, tot.detach().reshape(1), 1e-4, "master")
+    check(grad, p.grad, 2e-4, "master grad")
+
+
+# ------------------------------------------------------------------ metrics
+def test_metrics(ops):
+    hr = (torch.rand(3, 1, 96, 112, generator=G) * 255).round() / 255
+    hr[2] = hr[2] * 0 + 0.25
+    pr = hr + 0.05 * rnd(3, 1, 96, 112)
+    pr[1] = hr[1]
+    ths = (4, 5, 6, 7, 8, 9, 10, 300)
+    border = 8
+    out = ops.metrics_psnr_family(dev(pr), dev(hr), border, ths).cpu()
+    ssim = ops.metrics_ssim(dev(pr), dev(hr), border, ths).cpu()
+    a, b = O.tensor2uint82float(pr), O.tensor2uint82float(hr)
+    for k, th in enumerate((None,) + ths):
+        roi = None if th is None else (b >= th).float()
+        psnr = O.metric_psnr(a, b, border, roi)
+        mse = O.metric_mse(a, b, border, roi)
+        nrmse = O.metric_nrmse(a, b, border, roi)
+        assert torch.equal(out[:, k, 2], mse), f"mse th={th}"      # integer sums: exact
+        assert (out[:, k, 0] - psnr).abs().max() < 1e-9, f"psnr th={th}"
+        assert (out[:, k, 3] - nrmse).abs().max() < 1e-12, f"nrmse th={th}"
+        ya = O.gray_to_y(a / 255.0) * 255.0
+        yb = O.gray_to_y(b / 255.0) * 255.0
+        psnr_y = O.metric_psnr(ya, yb, border, roi)
+        assert (out[:, k, 1] - psnr_y).abs().max() < 1e-4, f"psnr_y th={th}"
+        s = O.metric_ssim(a, b, border, roi)
+        assert (ssim[:, k] - s).abs().max() < 5e-5, f"ssim th={th}"  # fp32 cancellation
+    assert abs(out[1, 0, 0].item() - 498.1308) < 1e-3
+    # already-u8 inputs take the same path
+    out2 = ops.metrics_psnr_family(dev(a), dev(b), border, ths, inputs_are_u8=True).cpu()
+    assert torch.equal(out2[:, :, 2], out[:, :, 2])
+
+
+# ------------------------------------------------------------------ optimizers
+def test_optimizers(ops):
+    n = 100003
+    p0, gs = rnd(n), rnd(3, n)
+    for name in ("adam", "adam_wd", "sgd"):
+        p, m, v = dev(p0), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+        po, mo, vo = p0.clone(), torch.zeros(n), torch.zeros(n)
+        for i in range(3):
+            if name == "sgd":
+                ops.sgd_step(p, dev(gs[i]), m, 0.01, first=(i == 0))
+                O.sgd_nesterov_step(po, gs[i], mo, i == 0, 0.01)
+            else:
+                wd = 1e-4 if name == "adam_wd" else 0.0
+                ops.adam_step(p, dev(gs[i]), m, v, i + 1, 2e-4, wd=wd)
+                O.adam_step(po, gs[i], mo, vo, i + 1, 2e-4, wd=wd)
+            assert (p.cpu() - po).abs().max() < 5e-7, (name, i)
+    flag = torch.zeros(1, dtype=torch.int32).cuda()
+    ops.nonfinite_flag(dev(p0), flag)
+    assert flag.item() == 0
+    bad = p0.clone()
+    bad[777] = float("nan")
+    ops.nonfinite_flag(dev(bad), flag)
+    assert flag.item() == 1
+
+
+def test_errors_are_loud(ops):
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(torch.zeros(4, 6).cuda(), torch.zeros(4, 6).cuda())       # K % 4 != 0
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(torch.zeros(4, 8), torch.zeros(4, 8))                      # CPU tensors
+    with pytest.raises(RuntimeError):
+        ops.window_attention_fwd(torch.zeros(64, 90).cuda(), torch.zeros(64, 30).cuda(),
+                                 torch.zeros(6, 64, 64).cuda(), 1, 8, 8, 30, 6, 4)  # shift on 8x8
