@@ -1,0 +1,249 @@
+"""SwinIR on libsrhip.
+
+Drop-in for the reference's ``dlib.models.network_swinir.SwinIR``
+(network_swinir.py:710-970): same constructor arguments, same ``state_dict``
+keys / shapes / order (366 entries for the README configuration), same
+``forward(x: (B,C,h,w) in [0,1]) -> (B,C,h*s,w*s)`` contract.  The module only
+*holds* parameters; ``forward`` runs the HIP engine (srhip/swinir_engine.py)
+and there is no PyTorch/CPU execution path: CPU tensors raise.
+
+Supported on the HIP path: window_size 8, 1-channel input, upsampler
+'pixelshuffledirect', resi_connection '1conv' (the configuration the reference
+trains and benchmarks, README.md:120-197).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from dlib.utils import constants
+
+__all__ = ['SwinIR']
+
+
+class _Box(nn.Module):
+    """Parameter container (gives the dotted state_dict names)."""
+
+
+def _trunc_normal_(t, std=.02):
+    return nn.init.trunc_normal_(t, mean=0., std=std, a=-2., b=2.)
+
+
+def _linear(out_f, in_f):
+    m = _Box()
+    m.weight = nn.Parameter(_trunc_normal_(torch.empty(out_f, in_f)))
+    m.bias = nn.Parameter(torch.zeros(out_f))
+    return m
+
+
+def _norm(c):
+    m = _Box()
+    m.weight = nn.Parameter(torch.ones(c))
+    m.bias = nn.Parameter(torch.zeros(c))
+    return m
+
+
+def _conv3(co, ci):
+    m = _Box()
+    bound = 1.0 / math.sqrt(ci * 9)   # nn.Conv2d default (kaiming_uniform, a=sqrt(5))
+    m.weight = nn.Parameter((torch.rand(co, ci, 3, 3) * 2 - 1) * bound)
+    m.bias = nn.Parameter((torch.rand(co) * 2 - 1) * bound)
+    return m
+
+
+def _relative_position_index(ws):
+    ys, xs = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
+    ys, xs = ys.reshape(-1), xs.reshape(-1)
+    return (ys[:, None] - ys[None, :] + ws - 1) * (2 * ws - 1) + (xs[:, None] - xs[None, :] + ws - 1)
+
+
+def _shift_mask(h, w, ws, shift):
+    """{0,-100} mask buffer, kept only for state_dict compatibility
+    (network_swinir.py:260-285); the kernel derives the mask from indices."""
+    region = torch.zeros(h, w)
+    k = 0
+    for (h0, h1) in ((0, h - ws), (h - ws, h - shift), (h - shift, h)):
+        for (w0, w1) in ((0, w - ws), (w - ws, w - shift), (w - shift, w)):
+            region[h0:h1, w0:w1] = k
+            k += 1
+    r = region.reshape(h // ws, ws, w // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+    d = r[:, None, :] - r[:, :, None]
+    return torch.where(d != 0, torch.full_like(d, -100.0), torch.zeros_like(d))
+
+
+class _SwinBlock(_Box):
+    def __init__(self, dim, input_resolution, num_heads, window_size, shift_size, mlp_ratio,
+                 drop_path):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.window_size, self.shift_size = window_size, shift_size
+        if min(input_resolution) <= window_size:
+            self.shift_size, self.window_size = 0, min(input_resolution)
+        self.drop_prob = float(drop_path)
+        if self.shift_size > 0:
+            self.register_buffer("attn_mask", _shift_mask(*input_resolution, window_size, shift_size))
+        else:
+            self.attn_mask = None
+        self.norm1 = _norm(dim)
+        attn = _Box()
+        wsb = self.window_size
+        attn.relative_position_bias_table = nn.Parameter(
+            _trunc_normal_(torch.empty((2 * wsb - 1) ** 2, num_heads)))
+        attn.register_buffer("relative_position_index", _relative_position_index(wsb))
+        attn.qkv = _linear(3 * dim, dim)
+        attn.proj = _linear(dim, dim)
+        self.attn = attn
+        self.norm2 = _norm(dim)
+        mlp = _Box()
+        mlp.fc1 = _linear(int(dim * mlp_ratio), dim)
+        mlp.fc2 = _linear(dim, int(dim * mlp_ratio))
+        self.mlp = mlp
+
+
+class _NetFn(torch.autograd.Function):
+    """One autograd node for the whole network (autograd-compatible path;
+    the training loop in ModelPlain drives the engine directly)."""
+
+    @staticmethod
+    def forward(ctx, x, net, dp, need_grad, *params):
+        ctx.net = net
+        ctx.need_dx = x.requires_grad
+        y = net.engine.forward(x, dp, save=need_grad)
+        return y.clone() if need_grad else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        net = ctx.net
+        names = [k for k, _ in net.named_parameters()]
+        grads = {k: torch.empty_like(p) for k, p in net.named_parameters()}
+        dx = net.engine.backward(dy.contiguous(), grads, need_dx=ctx.need_dx)
+        return (dx, None, None, None) + tuple(grads[k] for k in names)
+
+
+class SwinIR(nn.Module):
+    def __init__(self, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=[6, 6, 6, 6],
+                 num_heads=[6, 6, 6, 6], window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm,
+                 ape=False, patch_norm=True, use_checkpoint=False, upscale=2, img_range=1.,
+                 upsampler='', resi_connection=constants.R_CONNECTION_1CONV, **kwargs):
+        super().__init__()
+        unsupported = []
+        if window_size != 8:
+            unsupported.append(f"window_size={window_size} (HIP path: 8)")
+        if in_chans != 1:
+            unsupported.append(f"in_chans={in_chans} (HIP path: 1-channel microscopy patches)")
+        if upsampler != constants.US_PIXEL_SHUFFLE_DIRECT:
+            unsupported.append(f"upsampler={upsampler!r} (HIP path: 'pixelshuffledirect')")
+        if resi_connection != constants.R_CONNECTION_1CONV:
+            unsupported.append(f"resi_connection={resi_connection!r} (HIP path: '1conv')")
+        if ape or not patch_norm or not qkv_bias or qk_scale is not None or drop_rate or attn_drop_rate:
+            unsupported.append("ape / patch_norm=False / qkv_bias=False / qk_scale / dropout")
+        if embed_dim > 256 or (embed_dim // num_heads[0]) not in (10, 16, 30, 32):
+            unsupported.append(f"embed_dim={embed_dim} / heads={num_heads}")
+        if unsupported:
+            raise NotImplementedError("SwinIR on libsrhip does not support: " + "; ".join(unsupported))
+        size = img_size if isinstance(img_size, (tuple, list)) else (img_size, img_size)
+        self.img_size = tuple(size)
+        self.in_chans, self.embed_dim, self.mlp_ratio = in_chans, embed_dim, mlp_ratio
+        self.depths, self.num_heads = list(depths), list(num_heads)
+        self.window_size, self.upscale, self.img_range = window_size, upscale, img_range
+        self.upsampler = upsampler
+        self.mean = torch.zeros(1, 1, 1, 1)
+
+        self.conv_first = _conv3(embed_dim, in_chans)
+        self.patch_embed = _Box()
+        self.patch_embed.norm = _norm(embed_dim)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for li, depth in enumerate(depths):
+            rstb = _Box()
+            rstb.residual_group = _Box()
+            rstb.residual_group.blocks = nn.ModuleList([
+                _SwinBlock(embed_dim, self.img_size, num_heads[li], window_size,
+                           0 if j % 2 == 0 else window_size // 2, mlp_ratio,
+                           dpr[sum(depths[:li]) + j]) for j in range(depth)])
+            rstb.conv = _conv3(embed_dim, embed_dim)
+            self.layers.append(rstb)
+        self.norm = _norm(embed_dim)
+        self.conv_after_body = _conv3(embed_dim, embed_dim)
+        self.upsample = nn.ModuleList([_conv3(upscale * upscale * in_chans, embed_dim)])
+        self._engine = None
+
+    # -- helpers -------------------------------------------------------------
+    def swin_blocks(self):
+        for layer in self.layers:
+            for b in layer.residual_group.blocks:
+                yield b
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            from srhip.swinir_engine import SwinIREngine
+            self._engine = SwinIREngine(self)
+        return self._engine
+
+    def _apply(self, fn, *a, **k):   # .cuda() / .to(): parameter storage moves
+        out = super()._apply(fn, *a, **k)
+        self._engine = None
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        if self._engine is not None:
+            self._engine.invalidate()
+        return out
+
+    def weights_changed(self):
+        """Call after parameters were modified in place (optimizer step)."""
+        if self._engine is not None:
+            self._engine.invalidate()
+
+    def sample_drop_path(self, batch, device):
+        """timm DropPath semantics (per-sample Bernoulli(keep)/keep), one row per
+        (block, branch); None when nothing is dropped."""
+        probs = [b.drop_prob for b in self.swin_blocks()]
+        if not self.training or max(probs) == 0.0:
+            return None
+        keep = 1.0 - torch.tensor(probs, device=device).repeat_interleave(2)
+        mask = torch.bernoulli(keep[:, None].expand(-1, batch))
+        return (mask / keep[:, None]).contiguous()
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'absolute_pos_embed'}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {'relative_position_bias_table'}
+
+    # -- forward -------------------------------------------------------------
+    def prepare_input(self, x):
+        """check_image_size (network_swinir.py:908-913): reflect-pad to a multiple
+        of the window; (x-mean)*img_range is the identity for 1 channel."""
+        if not x.is_cuda:
+            raise RuntimeError("SwinIR (libsrhip) runs on the GPU only: move the model and the "
+                               "input to cuda; there is no CPU fallback")
+        assert x.dim() == 4 and x.shape[1] == self.in_chans, x.shape
+        _, _, h, w = x.shape
+        ws = self.window_size
+        ph, pw = (ws - h % ws) % ws, (ws - w % ws) % ws
+        if ph or pw:
+            x = F.pad(x, (0, pw, 0, ph), 'reflect')
+        if self.img_range != 1.:
+            x = x * self.img_range
+        return x.float().contiguous()[:, 0], h, w
+
+    def forward(self, x, dp=None):
+        xi, h, w = self.prepare_input(x)
+        if dp is None:
+            dp = self.sample_drop_path(x.shape[0], x.device)
+        if xi.shape[1] <= self.window_size or xi.shape[2] <= self.window_size:
+            raise NotImplementedError("inputs must be larger than one 8x8 window")
+        params = [p for _, p in self.named_parameters()]
+        need_grad = torch.is_grad_enabled() and (xi.requires_grad or any(p.requires_grad for p in params))
+        y = _NetFn.apply(xi, self, dp, need_grad, *params)
+        if self.img_range != 1.:
+            y = y / self.img_range
+        s = self.upscale
+        return y[:, :, :h * s, :w * s]

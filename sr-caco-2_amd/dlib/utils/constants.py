@@ -1,0 +1,39 @@
+"""Registry names used on the SR hot path.  Values equal the reference's
+(dlib/utils/constants.py:32-51,91-96,112-128,139-185,820-828) so that configs,
+CLI flags and checkpoints interchange."""
+SUPER_RES = 'super-resolution'
+
+SWINIR = 'swinir'
+EDSR_LIIF = 'EDSR_LIIF'
+MODELS = [SWINIR, EDSR_LIIF]
+
+SWINIR_MTH = 'SWINIR'
+EDSR_LIIF_MTH = 'EDSR_LIIF'
+NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH}
+
+US_PIXEL_SHUFFLE = 'pixelshuffle'
+US_PIXEL_SHUFFLE_DIRECT = 'pixelshuffledirect'
+US_NEAREST_CONV = 'nearest+conv'
+R_CONNECTION_1CONV = '1conv'
+R_CONNECTION_3CONV = '3conv'
+
+INIT_W_DEFAULT = 'init_w_default'
+INIT_BN_CONSTANT = 'init_bn_constant'
+
+PSNR_MTR = 'psnr'
+SSIM_MTR = 'ssim'
+MSE_MTR = 'mse'
+NRMSE_MTR = 'nrmse'
+PSNR_Y_MTR = 'psnr_y'
+METRICS = [PSNR_MTR, SSIM_MTR, MSE_MTR, NRMSE_MTR, PSNR_Y_MTR]
+BEST_MTR = {PSNR_MTR: max, SSIM_MTR: max, MSE_MTR: min, NRMSE_MTR: min, PSNR_Y_MTR: max}
+
+SGD = 'sgd'
+ADAM = 'adam'
+OPTIMIZERS = [SGD, ADAM]
+MULTISTEPLR = 'MultiStepLR'
+MYSTEPLR = 'MyStepLR'
+STEPSLR = [MULTISTEPLR, MYSTEPLR]
+
+GLOO = 'gloo'
+NCCL = 'nccl'

@@ -1,0 +1,264 @@
+"""SwinIR forward / backward as a fixed sequence of libsrhip launches.
+
+Mirrors SwinIR.forward (reference dlib/models/network_swinir.py:930-970) and the
+autograd graph PyTorch would build for it, for the 'pixelshuffledirect'
+upsampler on 1-channel inputs.  Everything stays in token order
+[B*H*W][C] (= NHWC), so PatchEmbed / PatchUnEmbed transposes (:610-614,
+:651-655), torch.roll and window_partition / window_reverse (:297-331) never
+materialise.  LayerNorm affine parameters in front of a Linear are folded into
+that Linear's weights once per step (W_f = W*gamma, b_f = b + W.beta); the
+normalisation itself is the A-operand prologue of the GEMM, GELU the prologue
+of fc2, residual adds and DropPath scaling the GEMM epilogues.
+
+Per Swin block: forward = 2 stats kernels + 4 GEMMs + 1 attention kernel;
+backward = 4 data-gradient GEMMs + 4 weight-gradient GEMMs (+ slice reducers)
++ 2 LayerNorm-backward kernels + 1 attention kernel.
+"""
+import torch
+
+from . import ops
+
+
+class _Bufs:
+    """Persistent activation / gradient buffers keyed by name (no allocation in
+    the steady-state step; also what makes the step graph-capturable)."""
+
+    def __init__(self):
+        self.d = {}
+
+    def get(self, key, *shape, device="cuda", dtype=torch.float32):
+        t = self.d.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, device=device, dtype=dtype)
+            self.d[key] = t
+        return t
+
+    def clear(self):
+        self.d.clear()
+
+
+class SwinIREngine:
+    def __init__(self, net):
+        self.net = net
+        self.C = net.embed_dim
+        self.hid = int(net.embed_dim * net.mlp_ratio)
+        self.scale = net.upscale
+        self.blocks = list(net.swin_blocks())
+        self.layer_of_block = []
+        for li, layer in enumerate(net.layers):
+            for _ in layer.residual_group.blocks:
+                self.layer_of_block.append(li)
+        self.bufs = _Bufs()
+        self.derived = _Bufs()
+        self.prepared = False
+        self.saved = None
+
+    # ------------------------------------------------------------------ weights
+    def invalidate(self):
+        self.prepared = False
+
+    def prepare(self):
+        """Derived weight copies (folded LayerNorm, transposes, conv packs, dense
+        bias images).  Must be re-run whenever parameters change."""
+        net, C, hid, D = self.net, self.C, self.hid, self.derived
+        dev = net.conv_first.weight.device
+        for i, b in enumerate(self.blocks):
+            heads = b.num_heads
+            wq = D.get(f"{i}.wq", 3 * C, C, device=dev)
+            bq = D.get(f"{i}.bq", 3 * C, device=dev)
+            ops.fold_layernorm(b.attn.qkv.weight.data, b.attn.qkv.bias.data, b.norm1.weight.data,
+                               b.norm1.bias.data, wq, bq)
+            ops.transpose(wq, D.get(f"{i}.wqT", C, 3 * C, device=dev))
+            ops.transpose(b.attn.proj.weight.data, D.get(f"{i}.wpT", C, C, device=dev))
+            w1 = D.get(f"{i}.w1", hid, C, device=dev)
+            b1 = D.get(f"{i}.b1", hid, device=dev)
+            ops.fold_layernorm(b.mlp.fc1.weight.data, b.mlp.fc1.bias.data, b.norm2.weight.data,
+                               b.norm2.bias.data, w1, b1)
+            ops.transpose(w1, D.get(f"{i}.w1T", C, hid, device=dev))
+            ops.transpose(b.mlp.fc2.weight.data, D.get(f"{i}.w2T", hid, C, device=dev))
+            ops.bias_expand(b.attn.relative_position_bias_table.data,
+                            D.get(f"{i}.biasT", heads, 64, 64, device=dev),
+                            D.get(f"{i}.biasN", heads, 64, 64, device=dev))
+        for name, conv in self._convs():
+            co, ci = conv.weight.shape[:2]
+            ops.pack_conv_weight(conv.weight.data, D.get(name + ".wp", 9, co, ci, device=dev),
+                                 D.get(name + ".wpt", 9, ci, co, device=dev))
+        self.prepared = True
+
+    def _convs(self):
+        net = self.net
+        for li, layer in enumerate(net.layers):
+            yield f"l{li}", layer.conv
+        yield "cab", net.conv_after_body
+        yield "up", net.upsample[0]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, dp=None, save=True):
+        """x: [B,H,W] fp32 cuda, H and W multiples of 8 -> [B,1,s*H,s*W].
+        dp: None or a [2*nblocks, B] tensor of DropPath multipliers."""
+        if not self.prepared:
+            self.prepare()
+        net, C, hid, D = self.net, self.C, self.hid, self.derived
+        B, H, W = x.shape
+        T = B * H * W
+        dev = x.device
+        bufs = self.bufs
+        tag = "t" if save else "e"    # eval shares one set of block buffers
+
+        def buf(name, *shape):
+            return bufs.get(f"{tag}.{name}", *shape, device=dev)
+
+        f0 = buf("f0", B, H, W, C)
+        ops.conv3x3_cin1_fwd(x, net.conv_first.weight.data, net.conv_first.bias.data, C, out=f0)
+        st_pe = buf("st_pe", T, 2)
+        t = buf("t0", T, C)
+        ops.layernorm_fwd(f0.view(T, C), st_pe, t, net.patch_embed.norm.weight.data,
+                          net.patch_embed.norm.bias.data)
+        sv = {"x": x, "f0": f0, "st_pe": st_pe, "blocks": [], "layers": [], "B": B, "H": H, "W": W,
+              "dp": dp}
+        bi = 0
+        for li, layer in enumerate(net.layers):
+            t_in = t
+            for blk in layer.residual_group.blocks:
+                k = bi if save else 0
+                heads = blk.num_heads
+                s1 = None if dp is None else dp[2 * bi]
+                s2 = None if dp is None else dp[2 * bi + 1]
+                st1 = buf(f"{k}.st1", T, 2)
+                ops.layernorm_fwd(t, st1)
+                qkv = buf(f"{k}.qkv", T, 3 * C)
+                ops.gemm_nt(t, D.d[f"{bi}.wq"], D.d[f"{bi}.bq"], out=qkv, a_mode=1, ln_stats=st1)
+                a = buf(f"{k}.a", T, C)
+                ops.window_attention_fwd(qkv, a, D.d[f"{bi}.biasT"], B, H, W, C, heads, blk.shift_size)
+                x1 = buf(f"{k}.x1", T, C)
+                ops.gemm_nt(a, blk.attn.proj.weight.data, blk.attn.proj.bias.data, out=x1, epi=2, R=t,
+                            rowscale=s1, rows_per_scale=H * W)
+                st2 = buf(f"{k}.st2", T, 2)
+                ops.layernorm_fwd(x1, st2)
+                h = buf(f"{k}.h", T, hid)
+                ops.gemm_nt(x1, D.d[f"{bi}.w1"], D.d[f"{bi}.b1"], out=h, a_mode=1, ln_stats=st2)
+                # block outputs ping-pong in eval, are kept per block in training
+                x2 = buf(f"{bi if save else bi % 2}.x2", T, C)
+                ops.gemm_nt(h, blk.mlp.fc2.weight.data, blk.mlp.fc2.bias.data, out=x2, a_mode=2, epi=2,
+                            R=x1, rowscale=s2, rows_per_scale=H * W)
+                if save:
+                    sv["blocks"].append((t, st1, qkv, a, x1, st2, h))
+                t = x2
+                bi += 1
+            tl = buf(f"L{li if save else li % 2}.out", T, C)
+            ops.conv3x3(t.view(B, H, W, C), D.d[f"l{li}.wp"], layer.conv.bias.data, C,
+                        out=tl.view(B, H, W, C), epi=2, R=t_in.view(B, H, W, C))
+            if save:
+                sv["layers"].append((t_in, t))
+            t = tl
+        st_n = buf("st_n", T, 2)
+        tn = buf("tn", T, C)
+        ops.layernorm_fwd(t, st_n, tn, net.norm.weight.data, net.norm.bias.data)
+        f = buf("f", B, H, W, C)
+        ops.conv3x3(tn.view(B, H, W, C), D.d["cab.wp"], net.conv_after_body.bias.data, C, out=f, epi=2,
+                    R=f0)
+        r = self.scale
+        cu = r * r * net.in_chans
+        u = buf("u", B, H, W, cu)
+        ops.conv3x3(f, D.d["up.wp"], net.upsample[0].bias.data, cu, out=u)
+        y = torch.empty(B, net.in_chans, H * r, W * r, device=dev) if not save else \
+            buf("y", B, net.in_chans, H * r, W * r)
+        ops.pixel_shuffle(u, r, out=y)
+        if save:
+            sv.update(t_last=t, st_n=st_n, tn=tn, f=f)
+            self.saved = sv
+        return y
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dy, grads, need_dx=False):
+        """dy: [B,1,s*H,s*W]; grads: dict name -> tensor to receive the parameter
+        gradient (overwritten).  Returns d loss / d x [B,H,W] if need_dx."""
+        sv = self.saved
+        assert sv is not None, "backward() without a saved forward"
+        net, C, hid, D = self.net, self.C, self.hid, self.derived
+        B, H, W, dp = sv["B"], sv["H"], sv["W"], sv["dp"]
+        T = B * H * W
+        dev = dy.device
+        bufs = self.bufs
+        r = self.scale
+        cu = r * r * net.in_chans
+
+        def buf(name, *shape):
+            return bufs.get("g." + name, *shape, device=dev)
+
+        def G(name):
+            return grads[name]
+
+        du = buf("du", B, H, W, cu)
+        ops.pixel_shuffle(dy, r, inverse=True, out=du)
+        ops.conv3x3_wgrad(du, sv["f"], G("upsample.0.weight"), G("upsample.0.bias"))
+        df = buf("df", B, H, W, C)
+        ops.conv3x3(du, D.d["up.wpt"], None, C, out=df)
+        ops.conv3x3_wgrad(df, sv["tn"].view(B, H, W, C), G("conv_after_body.weight"),
+                          G("conv_after_body.bias"))
+        dtn = buf("dtn", T, C)
+        ops.conv3x3(df, D.d["cab.wpt"], None, C, out=dtn.view(B, H, W, C))
+        dt = buf("dt", T, C)
+        ops.layernorm_bwd(dtn, sv["t_last"], sv["st_n"], dt, gamma=net.norm.weight.data,
+                          dgamma=G("norm.weight"), dbeta=G("norm.bias"))
+        ga, gb = buf("ga", T, C), buf("gb", T, C)
+        dh, dxh, da = buf("dh", T, hid), buf("dxh", T, C), buf("da", T, C)
+        dqkv = buf("dqkv", T, 3 * C)
+        bi = len(self.blocks)
+        for li in reversed(range(len(net.layers))):
+            layer = net.layers[li]
+            t_in, t_blocks = sv["layers"][li]
+            pre = f"layers.{li}."
+            ops.conv3x3_wgrad(dt.view(B, H, W, C), t_blocks.view(B, H, W, C), G(pre + "conv.weight"),
+                              G(pre + "conv.bias"))
+            g = ga
+            ops.conv3x3(dt.view(B, H, W, C), D.d[f"l{li}.wpt"], None, C, out=g.view(B, H, W, C))
+            nb = len(layer.residual_group.blocks)
+            for j in reversed(range(nb)):
+                bi -= 1
+                blk = layer.residual_group.blocks[j]
+                p = pre + f"residual_group.blocks.{j}."
+                t, st1, qkv, a, x1, st2, h = sv["blocks"][bi]
+                heads = blk.num_heads
+                s1 = None if dp is None else dp[2 * bi]
+                s2 = None if dp is None else dp[2 * bi + 1]
+                other = gb if g is ga else ga
+                # ---- MLP branch: x2 = x1 + s2*(gelu(h) W2^T + b2)
+                ops.gemm_nt(g, D.d[f"{bi}.w2T"], None, out=dh, epi=3, R=h, rowscale=s2,
+                            rows_per_scale=H * W)
+                ops.linear_wgrad(g, h, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), a_rowscale=s2,
+                                 a_rowscale_rows=H * W, b_mode=2)
+                ops.gemm_nt(dh, D.d[f"{bi}.w1T"], None, out=dxh)
+                ops.linear_wgrad(dh, x1, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), b_mode=1,
+                                 ln_stats=st2, ln=(blk.mlp.fc1.weight.data, blk.norm2.weight.data,
+                                                   blk.norm2.bias.data, G(p + "norm2.weight"),
+                                                   G(p + "norm2.bias")))
+                g1 = other
+                ops.layernorm_bwd(dxh, x1, st2, g1, res=g)
+                # ---- attention branch: x1 = t + s1*(a Wp^T + bp)
+                ops.gemm_nt(g1, D.d[f"{bi}.wpT"], None, out=da, epi=2, rowscale=s1, rows_per_scale=H * W)
+                ops.linear_wgrad(g1, a, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"),
+                                 a_rowscale=s1, a_rowscale_rows=H * W)
+                dbT = buf("dbiasT", heads, 64, 64)
+                dbT.zero_()
+                ops.window_attention_bwd(qkv, da, dqkv, D.d[f"{bi}.biasT"], D.d[f"{bi}.biasN"], dbT, B, H,
+                                         W, C, heads, blk.shift_size)
+                ops.bias_grad(dbT, G(p + "attn.relative_position_bias_table"))
+                ops.gemm_nt(dqkv, D.d[f"{bi}.wqT"], None, out=dxh)
+                ops.linear_wgrad(dqkv, t, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"), b_mode=1,
+                                 ln_stats=st1, ln=(blk.attn.qkv.weight.data, blk.norm1.weight.data,
+                                                   blk.norm1.bias.data, G(p + "norm1.weight"),
+                                                   G(p + "norm1.bias")))
+                ops.layernorm_bwd(dxh, t, st1, g, res=g1)   # g (its old value is dead) <- grad wrt t
+            ops.axpby(dt, g, 1.0, 1.0)   # RSTB skip: t_out = conv(blocks(t_in)) + t_in
+        # patch_embed.norm and the conv_after_body skip (f = conv(..) + f0)
+        df0 = buf("df0", T, C)
+        ops.layernorm_bwd(dt, sv["f0"].view(T, C), sv["st_pe"], df0, res=df.view(T, C),
+                          gamma=net.patch_embed.norm.weight.data, dgamma=G("patch_embed.norm.weight"),
+                          dbeta=G("patch_embed.norm.bias"))
+        ops.conv3x3_cin1_wgrad(sv["x"], df0.view(B, H, W, C), G("conv_first.weight"),
+                               G("conv_first.bias"))
+        if need_dx:
+            wflip = net.conv_first.weight.data.flip(2, 3).reshape(1, C, 3, 3).contiguous()
+            return ops.conv3x3_cout1_fwd(df0.view(B, H, W, C), wflip, None)
+        return None

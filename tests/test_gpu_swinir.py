@@ -1,0 +1,142 @@
+"""GPU end-to-end parity of the HIP SwinIR (dlib.models.network_swinir) against
+the golden fixtures generated from the real reference and against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import sr_oracle as O  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiu" else z[k]) for k in z.files}
+
+
+def sub(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+@pytest.fixture(scope="module")
+def SwinIR():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from dlib.models.network_swinir import SwinIR as cls
+    return cls
+
+
+def tiny(SwinIR, dpr=0.0):
+    return SwinIR(upscale=8, in_chans=1, img_size=16, window_size=8, depths=[2, 2], embed_dim=60,
+                  num_heads=[6, 6], mlp_ratio=2, upsampler="pixelshuffledirect", drop_path_rate=dpr)
+
+
+def readme(SwinIR, dpr=0.1):
+    return SwinIR(upscale=8, in_chans=1, img_size=64, window_size=8, depths=[6, 6, 6, 6], embed_dim=180,
+                  num_heads=[6, 6, 6, 6], mlp_ratio=2, upsampler="pixelshuffledirect",
+                  drop_path_rate=dpr)
+
+
+def psnr(a, b):
+    return O.metric_psnr(O.tensor2uint82float(a), O.tensor2uint82float(b), 8)
+
+
+def test_state_dict_layout_matches_reference(SwinIR):
+    g = load("g4_swinir_readme")
+    net = readme(SwinIR)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g["keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
+    assert sum(p.numel() for p in net.parameters()) == 7865884
+
+
+def test_tiny_forward_backward_vs_reference_golden(SwinIR):
+    g = load("g3_swinir_tiny")
+    net = tiny(SwinIR)
+    net.load_state_dict(sub(g, "sd/"), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(g["x"].cuda()).cpu()
+    err = (y - g["y_eval"]).abs().max().item()
+    assert err <= 1e-5, f"eval forward max err {err}"      # gate is pixel MAE 1e-5; max is stricter
+    # training-mode forward + backward, drop path neutralised as in the golden
+    net.train()
+    for b in net.swin_blocks():
+        b.drop_prob = 0.0
+    x = g["x"].cuda().requires_grad_(True)
+    yt = net(x)
+    (yt - g["target"].cuda()).abs().mean().backward()
+    assert (x.grad.cpu() - g["dx"]).abs().max() <= 2e-4 * g["dx"].abs().max()
+    worst = 0.0
+    for k, p in net.named_parameters():
+        ref = g["grad/" + k]
+        e = (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        worst = max(worst, e)
+        assert e <= 2e-3, f"grad {k}: rel err {e:.2e}"
+    print("worst param-grad rel err", worst)
+
+
+def test_tiny_forced_droppath_and_padded(SwinIR):
+    g = load("g3_swinir_tiny")
+    net = tiny(SwinIR, 0.5)
+    net.load_state_dict(sub(g, "sd/"), strict=True)
+    net = net.cuda().train()
+    dp = g["dp"].reshape(-1, 2).cuda().contiguous()      # [blocks,2(branch),B] -> [2*blocks, B]
+    with torch.no_grad():
+        y = net(g["x"].cuda(), dp=dp).cpu()
+    assert (y - g["y_dp"]).abs().max() <= 1e-5
+    net.eval()
+    with torch.no_grad():
+        y = net(g["x_pad"].cuda()).cpu()
+    assert y.shape == g["y_pad"].shape
+    assert (y - g["y_pad"]).abs().max() <= 1e-5
+
+
+def test_readme_config_forward_vs_reference_golden(SwinIR):
+    g = load("g4_swinir_readme")
+    cfg = O.swinir_config()
+    sd = O.swinir_init_state_dict(cfg, seed=0)
+    net = readme(SwinIR)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(g["x"].cuda()).cpu()
+    mae = (y - g["y"]).abs().mean().item()
+    assert mae <= 1e-5, f"pixel MAE {mae}"
+    tgt = torch.rand(1, 1, 512, 512, generator=torch.Generator().manual_seed(1))
+    assert (psnr(y, tgt) - psnr(g["y"], tgt)).abs().max() <= 0.01
+    # padded-eval path of the trainer: 72x72 (81 windows, mask from indices)
+    xp = torch.rand(1, 1, 72, 72, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        yp = net(xp.cuda()).cpu()
+        yo = O.swinir_forward(sd, xp, cfg)
+    assert (yp - yo).abs().mean() <= 1e-5
+
+
+def test_readme_config_train_step_grads_vs_oracle(SwinIR):
+    cfg = O.swinir_config(drop_path_rate=0.0)
+    sd = O.swinir_init_state_dict(cfg, seed=0)
+    net = readme(SwinIR, 0.0)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    gen = torch.Generator().manual_seed(3)
+    x, tgt = torch.rand(2, 1, 64, 64, generator=gen), torch.rand(2, 1, 512, 512, generator=gen)
+    y = net(x.cuda())
+    (y - tgt.cuda()).abs().mean().backward()
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask")
+               else v) for k, v in sd.items()}
+    yo = O.swinir_forward(sdo, x, cfg)
+    (yo - tgt).abs().mean().backward()
+    assert (y.detach().cpu() - yo.detach()).abs().mean() <= 1e-5
+    worst = ("", 0.0)
+    for k, p in net.named_parameters():
+        ref = sdo[k].grad
+        e = (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        if e > worst[1]:
+            worst = (k, e)
+    print("worst grad", worst)
+    assert worst[1] <= 5e-3, worst
