@@ -62,6 +62,20 @@ int srhip_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats);
 int srhip_gemm_tn(const float* A, long lda, const float* B, long ldb, int M, int NI, int NJ,
                   const float* a_rowscale, int a_rowscale_rows, int b_mode, const float* ln_stats,
                   float* part, float* part_colsum, int S, void* stream);
+/* Up to 4 Linear weight-gradient problems over the same M rows in one launch
+ * (the four Linears of a Swin block), each with its own partial buffers. */
+typedef struct srhip_tn_problem {
+  const float* A; long lda;          /* dY [M][NI] */
+  const float* B; long ldb;          /* X  [M][NJ] */
+  int NI, NJ;
+  const float* a_rowscale; int a_rowscale_rows;
+  int b_mode; const float* ln_stats;
+  float* part;                       /* [S][NI][NJ] */
+  float* part_colsum;                /* [S][NI] or NULL */
+} srhip_tn_problem;
+int srhip_tn_tiles(int NI, int NJ);
+int srhip_tn_group_plan(int M, int ntiles, int* S);
+int srhip_gemm_tn_grouped(const srhip_tn_problem* probs, int nprob, int M, int S, void* stream);
 int srhip_conv3x3_wgrad(const float* dY, long lddy, const float* X, long ldx, int B, int H, int W,
                         int Cout, int Cin, float* part, float* part_colsum, int S, void* stream);
 int srhip_reduce_linear_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
@@ -156,11 +170,14 @@ int srhip_metrics_ssim(const float* E, const float* Hh, int B, int H, int W, int
                        const int* thresholds_dev, int nth, int inputs_are_u8, double* workspace,
                        float* out, void* stream);
 
-/* ---- optimizers (dlib/utils/utils_instance.py:216-247) on flat buffers ------- */
+/* ---- optimizers (dlib/utils/utils_instance.py:216-247) on flat buffers -------
+ * g is multiplied by gscale first (1/world_size after a sum all-reduce).  If
+ * skip_flag != NULL and *skip_flag != 0 the update is skipped on the device
+ * (non-finite loss, model_plain.py:344-346) -- no host sync. */
 int srhip_adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float b1,
-                    float b2, float eps, float wd, float gscale, void* stream);
+                    float b2, float eps, float wd, float gscale, const int* skip_flag, void* stream);
 int srhip_sgd_step(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
-                   int nesterov, int first, float gscale, void* stream);
+                   int nesterov, int first, float gscale, const int* skip_flag, void* stream);
 /* flag[0] |= any(!isfinite(x)): one device flag instead of the reference's
  * per-tensor host syncs (dlib/utils/tools.py:28-63, model_plain.py:344). */
 int srhip_nonfinite_flag(const float* x, long n, int* flag, void* stream);

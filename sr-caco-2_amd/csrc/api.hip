@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include "common.h"
 #include "kernels.h"
+#include "../../include/srhip.h"
 
 static thread_local char g_err[512] = "";
 
@@ -66,6 +67,25 @@ int srhip_gemm_tn(const float* A, long lda, const float* B, long ldb, int M, int
   p.a_rowscale = a_rowscale; p.a_rowscale_rows = a_rowscale_rows; p.b_mode = b_mode;
   p.ln_stats = ln_stats; p.part = part; p.part_colsum = part_colsum; p.S = S; p.conv = 0;
   return sr_gemm_tn(p, (hipStream_t)stream);
+}
+
+int srhip_tn_tiles(int NI, int NJ) { return sr_tn_tiles(NI, NJ); }
+int srhip_tn_group_plan(int M, int ntiles, int* S) { return sr_tn_group_plan(M, ntiles, S); }
+
+int srhip_gemm_tn_grouped(const srhip_tn_problem* probs, int nprob, int M, int S, void* stream) {
+  SR_REQUIRE(nprob >= 1 && nprob <= 4, "gemm_tn_grouped: 1..4 problems");
+  TnArgs a[4];
+  memset(a, 0, sizeof(a));
+  for (int k = 0; k < nprob; ++k) {
+    const srhip_tn_problem& q = probs[k];
+    SR_REQUIRE(q.b_mode >= 0 && q.b_mode <= 2, "gemm_tn_grouped: b_mode %d", q.b_mode);
+    SR_REQUIRE(q.b_mode != 1 || q.ln_stats, "gemm_tn_grouped: layernorm prologue without stats");
+    TnArgs& p = a[k];
+    p.A = q.A; p.lda = q.lda; p.B = q.B; p.ldb = q.ldb; p.M = M; p.NI = q.NI; p.NJ = q.NJ;
+    p.a_rowscale = q.a_rowscale; p.a_rowscale_rows = q.a_rowscale_rows; p.b_mode = q.b_mode;
+    p.ln_stats = q.ln_stats; p.part = q.part; p.part_colsum = q.part_colsum; p.S = S;
+  }
+  return sr_gemm_tn_grouped(a, nprob, (hipStream_t)stream);
 }
 
 int srhip_conv3x3_wgrad(const float* dY, long lddy, const float* X, long ldx, int B, int H, int W,

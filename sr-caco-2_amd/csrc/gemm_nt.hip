@@ -18,13 +18,14 @@
 // MFMAs; A and W use the same k permutation, so products pair up correctly.
 // Global loads for chunk i+1 are issued before the MFMAs of chunk i (register
 // prefetch) and written to LDS after them.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
 template <int WM, int WN, int BK, bool CONV>
-__global__ void __launch_bounds__(256) k_nt(NtArgs p) {
+__global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
   constexpr int SA = (BK % 8 == 4) ? BK : BK + 4;  // pitch = 4*odd floats
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int TROWS = BM / 16;                   // conv: image rows per tile
@@ -50,6 +51,13 @@ __global__ void __launch_bounds__(256) k_nt(NtArgs p) {
     y0 = ty * TROWS; x0 = tx * 16;
   } else {
     m0 = blockIdx.x * BM;
+  }
+
+  // Co-resident blocks start in lockstep and would all load, compute and store
+  // at the same moments; delaying every other block by part of a main loop lets
+  // one block's loads / epilogue overlap its neighbour's MFMA phase.
+  if (p.stagger > 0 && (blockIdx.x + blockIdx.y * gridDim.x) >= (gridDim.x * gridDim.y) / 2) {
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
 
   f32x4 ra[A_IT], rb[B_IT];
@@ -153,15 +161,18 @@ __global__ void __launch_bounds__(256) k_nt(NtArgs p) {
   for (int it = 0; it < niter; ++it) {
     const int kc = it / ntap, tap = it - kc * ntap;
     __syncthreads();                       // everyone done reading LDS
-    if (!CONV || tap == 0) store_a();
-    store_b();
+    if (!(p.dbg & 2)) {
+      if (!CONV || tap == 0) store_a();
+      store_b();
+    }
     __syncthreads();
-    if (it + 1 < niter) {                  // prefetch next chunk into registers
+    if (it + 1 < niter && !(p.dbg & 1)) {  // prefetch next chunk into registers
       const int kc1 = (it + 1) / ntap, tap1 = (it + 1) - kc1 * ntap;
       if (!CONV || tap1 == 0) load_a(kc1);
       load_b(kc1, tap1);
     }
     const int toff = CONV ? ((tap / 3) * 18 + (tap % 3)) * SA : 0;
+    if (p.dbg & 4) continue;
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       f32x4 fa[WM], fb[WN];
@@ -195,6 +206,7 @@ __global__ void __launch_bounds__(256) k_nt(NtArgs p) {
   }
 
   // ---- epilogue ----
+  if (p.dbg & 8) return;
   // per-sample scale (DropPath): one sample per block whenever the sample's
   // row count is a multiple of the block's rows, else looked up per row.
   float blk_s = p.alpha;
@@ -204,6 +216,10 @@ __global__ void __launch_bounds__(256) k_nt(NtArgs p) {
     else if (p.rows_per_scale % BM == 0) blk_s *= p.rowscale[m0 / p.rows_per_scale];
     else per_row = true;
   }
+  // The epilogue mode is block-uniform: switch OUTSIDE the element loops, and
+  // batch the 16 loads of a tile ahead of the math (one wait per tile, not one
+  // per element).
+  const bool needR = p.R != nullptr && p.epi >= 2;
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int col = (wn * WN + j) * 32 + r;        // column inside the N block
@@ -213,36 +229,58 @@ __global__ void __launch_bounds__(256) k_nt(NtArgs p) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const int mt = wm * WM + i;
+      int grow[16];                                // global row (token / pixel), -1 = masked
+      float rv[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int lr = mfma_row(q, lane);          // row inside the 32-row tile
-        long grow;                                 // global row (token / pixel)
-        bool rok;
         if (CONV) {
           const int y = y0 + 2 * mt + (lr >> 4), x = x0 + (lr & 15);
-          rok = (y < p.H) && (x < p.Wd);
-          grow = (long)(img * p.H + y) * p.Wd + x;
+          grow[q] = (cok && y < p.H && x < p.Wd) ? (img * p.H + y) * p.Wd + x : -1;
         } else {
-          grow = m0 + mt * 32 + lr;
-          rok = grow < p.M;
+          const int g = m0 + mt * 32 + lr;
+          grow[q] = (cok && g < p.M) ? g : -1;
         }
-        if (!(rok && cok)) continue;
-        float v = acc[i][j][q] + bv;
-        if (p.epi == 1) {
-          v = fmaxf(v, 0.f);
-        } else if (p.epi == 2) {
-          float s = blk_s;
-          if (per_row) s *= p.rowscale[(int)grow / p.rows_per_scale];
-          v = v * s + (p.R ? p.R[grow * p.ldr + gn] : 0.f);
-        } else if (p.epi == 3) {
-          float s = blk_s;
-          if (per_row) s *= p.rowscale[(int)grow / p.rows_per_scale];
-          v = v * s * dgelu_f(p.R[grow * p.ldr + gn]);
-        } else if (p.epi == 4) {
-          v = (p.R[grow * p.ldr + gn] > 0.f) ? v : 0.f;
-        }
-        p.C[grow * p.ldc + gn] = v;
       }
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        rv[q] = (needR && grow[q] >= 0) ? p.R[(long)grow[q] * p.ldr + gn] : 0.f;
+      f32x16& v = acc[i][j];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] += bv;
+      switch (p.epi) {
+        case 1:
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = fmaxf(v[q], 0.f);
+          break;
+        case 2:
+          if (per_row) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (grow[q] >= 0) v[q] *= p.rowscale[grow[q] / p.rows_per_scale];
+          }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = v[q] * blk_s + rv[q];
+          break;
+        case 3:
+          if (per_row) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (grow[q] >= 0) v[q] *= p.rowscale[grow[q] / p.rows_per_scale];
+          }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = v[q] * blk_s * dgelu_f(rv[q]);
+          break;
+        case 4:
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = rv[q] > 0.f ? v[q] : 0.f;
+          break;
+        default:
+          break;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (grow[q] >= 0) p.C[(long)grow[q] * p.ldc + gn] = v[q];
     }
   }
 }
@@ -256,6 +294,11 @@ int launch_nt(const NtArgs& p, hipStream_t st) {
   hipLaunchKernelGGL((k_nt<WM, WN, BK, CONV>), grid, dim3(256), 0, st, p);
   SR_LAUNCH_CHECK("k_nt");
   return 0;
+}
+
+int nt_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
 
 template <bool CONV>
@@ -278,7 +321,10 @@ int dispatch_nt(NtArgs& p, hipStream_t st) {
     blocks128 = sr_cdiv(rows, 128);
   }
   blocks128 *= sr_cdiv(p.N, p.n_tile);
-  const int wm = (blocks128 >= 512) ? 2 : 1;
+  int wm = (blocks128 >= 512) ? 2 : 1;
+  const int force_wm = nt_env("SRHIP_NT_WM", 0);
+  if (force_wm == 1 || force_wm == 2) wm = force_wm;
+  p.stagger = nt_env("SRHIP_NT_STAGGER", 0);
   if (CONV) {
     p.tiles_x = sr_cdiv(p.Wd, 16);
     p.tiles_y = sr_cdiv(p.H, wm == 2 ? 8 : 4);
@@ -295,7 +341,14 @@ int dispatch_nt(NtArgs& p, hipStream_t st) {
 
 }  // namespace
 
+static int nt_dbg() {
+  const char* e = getenv("SRHIP_NT_DBG");
+  return e ? atoi(e) : 0;
+}
+
+
 int sr_gemm_nt(NtArgs& p, hipStream_t st) {
+  p.dbg = nt_dbg();
   SR_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0 && p.ldw % 4 == 0,
              "gemm_nt: K, lda, ldw must be multiples of 4 (K=%d lda=%ld ldw=%ld)", p.K, p.lda, p.ldw);
   SR_REQUIRE(p.M > 0 && p.N > 0, "gemm_nt: empty problem");
@@ -307,5 +360,6 @@ int sr_conv3x3_nt(NtArgs& p, hipStream_t st) {
              "conv3x3: Cin, lda, ldw must be multiples of 4 (Cin=%d)", p.K);
   SR_REQUIRE(p.batch > 0 && p.H > 0 && p.Wd > 0, "conv3x3: empty image");
   p.M = p.batch * p.H * p.Wd;
+  p.dbg = nt_dbg();
   return dispatch_nt<true>(p, st);
 }

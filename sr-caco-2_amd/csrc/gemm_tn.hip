@@ -26,7 +26,7 @@ namespace {
 constexpr int TK = 32;  // tokens per staged chunk
 
 template <int WI, int WJ>
-__global__ void __launch_bounds__(256) k_tn(TnArgs p) {
+__device__ __forceinline__ void tn_body(const TnArgs& p, const int s, const int tile, const int tap) {
   constexpr int BI = 64 * WI, BJ = 64 * WJ;
   constexpr int A_IT = TK * BI / 4 / 256, B_IT = TK * BJ / 4 / 256;
   static_assert(TK * BI / 4 % 256 == 0 && TK * BJ / 4 % 256 == 0, "tile");
@@ -36,10 +36,8 @@ __global__ void __launch_bounds__(256) k_tn(TnArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;
-  const int s = blockIdx.x;
   const int nbj = (p.NJ + p.j_tile - 1) / p.j_tile;
-  const int bi = blockIdx.y / nbj, bj = blockIdx.y - bi * nbj;
-  const int tap = blockIdx.z;
+  const int bi = tile / nbj, bj = tile - bi * nbj;
   const int i0 = bi * p.i_tile, j0 = bj * p.j_tile;
   const int ivalid = min(p.i_tile, p.NI - i0), jvalid = min(p.j_tile, p.NJ - j0);
   const int m_begin = s * p.rows_per_slice;
@@ -169,6 +167,33 @@ __global__ void __launch_bounds__(256) k_tn(TnArgs p) {
   if (do_colsum && tid < ivalid) p.part_colsum[(long)s * p.NI + i0 + tid] = colsum;
 }
 
+template <int WI, int WJ>
+__global__ void __launch_bounds__(256) k_tn(TnArgs p) {
+  tn_body<WI, WJ>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several weight-gradient problems over the same token range in ONE launch
+// (the four Linear layers of a Swin block): enough blocks to fill the chip at a
+// moderate slice count, so the partial-sum traffic stays small.
+struct TnGroup {
+  TnArgs p[4];
+  int tile_start[5];
+  int n;
+};
+template <int WI, int WJ>
+__global__ void __launch_bounds__(256) k_tn_grouped(TnGroup g) {
+  const int t = blockIdx.y;
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < g.n && t >= g.tile_start[i]) k = i;
+  // select with constant indices (a runtime-indexed struct array would go to scratch)
+  if (k == 0) tn_body<WI, WJ>(g.p[0], blockIdx.x, t - g.tile_start[0], 0);
+  else if (k == 1) tn_body<WI, WJ>(g.p[1], blockIdx.x, t - g.tile_start[1], 0);
+  else if (k == 2) tn_body<WI, WJ>(g.p[2], blockIdx.x, t - g.tile_start[2], 0);
+  else tn_body<WI, WJ>(g.p[3], blockIdx.x, t - g.tile_start[3], 0);
+}
+
 int pick_tile(int n, int* w) {
   if (n % 180 == 0) { *w = 3; return 180; }
   if (n <= 64) { *w = 1; return 64; }
@@ -182,14 +207,66 @@ int sr_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
   int wi, wj;
   const int ti = pick_tile(NI, &wi), tj = pick_tile(NJ, &wj);
   const long tiles = (long)sr_cdiv(NI, ti) * sr_cdiv(NJ, tj) * (conv ? 9 : 1);
-  // enough blocks for ~3 per CU, at least 256 tokens each, at most 64 slices
-  long s = (768 + tiles - 1) / tiles;
-  const long smax = (M + 255) / 256;
+  // one block per CU and more (k_tn<3,3> holds 1 block/CU); at least 128 tokens each
+  long s = (512 + tiles - 1) / tiles;
+  const long smax = (M + 127) / 128;
   if (s > smax) s = smax;
-  if (s > 64) s = 64;
+  if (s > 256) s = 256;
   if (s < 1) s = 1;
   *S = (int)s;
   *part_floats = s * (conv ? 9 : 1) * (long)NI * NJ;
+  return 0;
+}
+
+int sr_tn_group_plan(int M, int ntiles, int* S) {
+  // whole rounds of 256 blocks (1 block per CU: k_tn<3,3> needs > 256 registers)
+  long s = 256 / ntiles;
+  if (s * ntiles < 256) s = (256 + ntiles - 1) / ntiles;
+  const long smax = (M + 127) / 128;
+  if (s > smax) s = smax;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  *S = (int)s;
+  return 0;
+}
+
+int sr_tn_tiles(int NI, int NJ) {
+  int wi, wj;
+  return sr_cdiv(NI, pick_tile(NI, &wi)) * sr_cdiv(NJ, pick_tile(NJ, &wj));
+}
+
+int sr_gemm_tn_grouped(TnArgs* probs, int n, hipStream_t st) {
+  SR_REQUIRE(n >= 1 && n <= 4, "gemm_tn_grouped: 1..4 problems (got %d)", n);
+  TnGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  int wi = 1, wj = 1, tiles = 0;
+  for (int k = 0; k < n; ++k) {
+    TnArgs& p = probs[k];
+    SR_REQUIRE(p.NI % 4 == 0 && p.NJ % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0,
+               "gemm_tn_grouped: NI, NJ, lda, ldb must be multiples of 4");
+    SR_REQUIRE(p.M == probs[0].M && p.S == probs[0].S && !p.conv,
+               "gemm_tn_grouped: problems must share M and S");
+    int a, b;
+    p.i_tile = pick_tile(p.NI, &a);
+    p.j_tile = pick_tile(p.NJ, &b);
+    if (a > wi) wi = a;
+    if (b > wj) wj = b;
+    int rps = sr_cdiv(p.M, p.S);
+    p.rows_per_slice = (rps + TK - 1) / TK * TK;
+    g.tile_start[k] = tiles;
+    tiles += sr_cdiv(p.NI, p.i_tile) * sr_cdiv(p.NJ, p.j_tile);
+    g.p[k] = p;
+  }
+  g.tile_start[n] = tiles;
+  // one kernel instantiation for the whole group: the largest wave tile; smaller
+  // problems run with masked columns
+  if (wi != wj) wi = wj = (wi > wj ? wi : wj);
+  dim3 grid(probs[0].S, tiles, 1);
+  if (wi == 1) hipLaunchKernelGGL((k_tn_grouped<1, 1>), grid, dim3(256), 0, st, g);
+  else if (wi == 2) hipLaunchKernelGGL((k_tn_grouped<2, 2>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((k_tn_grouped<3, 3>), grid, dim3(256), 0, st, g);
+  SR_LAUNCH_CHECK("k_tn_grouped");
   return 0;
 }
 

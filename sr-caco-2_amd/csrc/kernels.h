@@ -19,6 +19,8 @@ struct NtArgs {
   const float* rowscale; int rows_per_scale; float alpha;
   // conv geometry
   int batch, H, Wd, tiles_x, tiles_y;
+  int dbg;                    // ablation bits (env SRHIP_NT_DBG; 0 in production)
+  int stagger;                // odd blocks sleep this many x 8128 cycles at start
 };
 
 struct TnArgs {
@@ -41,3 +43,6 @@ int sr_gemm_nt(NtArgs& p, hipStream_t st);
 int sr_conv3x3_nt(NtArgs& p, hipStream_t st);
 int sr_gemm_tn(TnArgs& p, hipStream_t st);
 int sr_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats);
+int sr_gemm_tn_grouped(TnArgs* probs, int n, hipStream_t st);
+int sr_tn_group_plan(int M, int ntiles, int* S);
+int sr_tn_tiles(int NI, int NJ);

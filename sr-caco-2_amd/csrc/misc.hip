@@ -15,7 +15,15 @@ __global__ void k_reduce_slices(const float* __restrict__ part, float* __restric
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
        i += (long)gridDim.x * blockDim.x) {
     float a = 0.f;
-    for (int s = 0; s < S; ++s) a += part[(long)s * n + i];
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(s + u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; s < S; ++s) a += part[(long)s * n + i];
     out[i] = beta != 0.f ? out[i] * beta + a : a;
   }
 }
@@ -36,37 +44,53 @@ __global__ void k_reduce_conv_w(const float* __restrict__ part, float* __restric
 //   G = sum_s part, dbv = sum_s colsum
 //   dW[n][k] = gamma[k]*G[n][k] + beta[k]*dbv[n];  db = dbv
 //   dgamma[k] = sum_n W[n][k]*G[n][k];  dbeta[k] = sum_n W[n][k]*dbv[n]
-// One block per 32 columns k; 8 row lanes walk n.
+// Block = 64 columns x 4 rows (one element per thread, slices unrolled by 8 so
+// the loads overlap); dgamma / dbeta are combined across row blocks with one
+// atomic per column per block (zeroed by the caller).
 __global__ void __launch_bounds__(256) k_fin_ln_linear(
     const float* __restrict__ part, const float* __restrict__ colsum, int S,
     const float* __restrict__ W, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ dW, float* __restrict__ db,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int K) {
-  __shared__ float sg[8][32], sb[8][32];
-  const int c = threadIdx.x & 31, rr = threadIdx.x >> 5;
-  const int k = blockIdx.x * 32 + c;
+  __shared__ float sd[4], sg[4][64], sb[4][64];
+  const int c = threadIdx.x & 63, rr = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + c;
+  const int n0 = blockIdx.y * 4;
+  if (c == 0) {   // one lane per row sums that row's bias-gradient slices
+    const int n = n0 + rr;
+    float d = 0.f;
+    if (n < N)
+      for (int s = 0; s < S; ++s) d += colsum[(long)s * N + n];
+    sd[rr] = d;
+    if (n < N && blockIdx.x == 0) db[n] = d;
+  }
+  __syncthreads();
   float ag = 0.f, ab = 0.f;
-  if (k < K) {
-    const float g = gamma[k], b = beta[k];
-    for (int n = rr; n < N; n += 8) {
-      float G = 0.f, d = 0.f;
-      for (int s = 0; s < S; ++s) {
-        G += part[((long)s * N + n) * K + k];
-        d += colsum[(long)s * N + n];
-      }
-      const float w = W[(long)n * K + k];
-      dW[(long)n * K + k] = g * G + b * d;
-      ag += w * G;
-      ab += w * d;
-      if (blockIdx.x == 0 && c == 0) db[n] = d;
+  const int n = n0 + rr;
+  if (k < K && n < N) {
+    const long sl = (long)N * K;
+    const float* pp = part + (long)n * K + k;
+    float G = 0.f;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pp[(s + u) * sl];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) G += v[u];
     }
+    for (; s < S; ++s) G += pp[s * sl];
+    const float d = sd[rr];
+    const float w = W[(long)n * K + k];
+    dW[(long)n * K + k] = gamma[k] * G + beta[k] * d;
+    ag = w * G;
+    ab = w * d;
   }
   sg[rr][c] = ag; sb[rr][c] = ab;
   __syncthreads();
   if (rr == 0 && k < K) {
-    float a = 0.f, b = 0.f;
-    for (int i = 0; i < 8; ++i) { a += sg[i][c]; b += sb[i][c]; }
-    dgamma[k] = a; dbeta[k] = b;
+    atomicAdd(dgamma + k, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+    atomicAdd(dbeta + k, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
   }
 }
 __global__ void k_reduce_colsum(const float* __restrict__ colsum, float* __restrict__ db,
@@ -289,7 +313,8 @@ __global__ void k_sum_partials(const double* __restrict__ part, int n, double sc
 // ----------------------------------------------------------------------------
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                       float wd, float bc1, float bc2_sqrt, float gscale) {
+                       float wd, float bc1, float bc2_sqrt, float gscale, const int* __restrict__ skip) {
+  if (skip && *skip) return;   // non-finite loss: skip the update (model_plain.py:344-346)
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
        i += (long)gridDim.x * blockDim.x) {
     float gi = g[i] * gscale;
@@ -304,7 +329,8 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 }
 __global__ void k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                       long n, float lr, float momentum, float wd, int nesterov, int first,
-                      float gscale) {
+                      float gscale, const int* __restrict__ skip) {
+  if (skip && *skip) return;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
        i += (long)gridDim.x * blockDim.x) {
     float gi = g[i] * gscale;
@@ -359,7 +385,10 @@ int srhip_reduce_linear_wgrad(const float* part, const float* colsum, int S, flo
 int srhip_reduce_ln_linear_wgrad(const float* part, const float* colsum, int S, const float* W,
                                  const float* gamma, const float* beta, float* dW, float* db,
                                  float* dgamma, float* dbeta, int N, int K, void* stream) {
-  hipLaunchKernelGGL(k_fin_ln_linear, dim3(sr_cdiv(K, 32)), dim3(256), 0, (hipStream_t)stream, part,
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(dgamma, 0, sizeof(float) * K, st);
+  (void)hipMemsetAsync(dbeta, 0, sizeof(float) * K, st);
+  hipLaunchKernelGGL(k_fin_ln_linear, dim3(sr_cdiv(K, 64), sr_cdiv(N, 4)), dim3(256), 0, st, part,
                      colsum, S, W, gamma, beta, dW, db, dgamma, dbeta, N, K);
   SR_LAUNCH_CHECK("reduce_ln_linear_wgrad");
   return 0;
@@ -457,21 +486,21 @@ int srhip_loss_l1l2(const float* pred, const float* target, const float* weight,
 }
 
 int srhip_adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float b1,
-                    float b2, float eps, float wd, float gscale, void* stream) {
+                    float b2, float eps, float wd, float gscale, const int* skip_flag, void* stream) {
   if (n <= 0) return 0;
   const float bc1 = 1.f - powf(b1, (float)step);
   const float bc2 = 1.f - powf(b2, (float)step);
   hipLaunchKernelGGL(k_adam, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
-                     b1, b2, eps, wd, bc1, sqrtf(bc2), gscale);
+                     b1, b2, eps, wd, bc1, sqrtf(bc2), gscale, skip_flag);
   SR_LAUNCH_CHECK("adam_step");
   return 0;
 }
 
 int srhip_sgd_step(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
-                   int nesterov, int first, float gscale, void* stream) {
+                   int nesterov, int first, float gscale, const int* skip_flag, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_sgd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr,
-                     momentum, wd, nesterov, first, gscale);
+                     momentum, wd, nesterov, first, gscale, skip_flag);
   SR_LAUNCH_CHECK("sgd_step");
   return 0;
 }

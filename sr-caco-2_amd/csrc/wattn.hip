@@ -43,26 +43,50 @@ __device__ __forceinline__ int wa_token(const WaGeom& g, int pos, int H, int W, 
   return (g.b * H + y) * W + x;
 }
 
+// Coalesced staging of one [64 tokens][D] matrix (q, k, v or dO of one head)
+// into this wave's LDS region: consecutive lanes take consecutive float2 of a
+// token row, so an instruction touches ~5 cache lines instead of 64.
+template <int D>
+__device__ __forceinline__ void wa_stage(float* __restrict__ lds, const float* __restrict__ gsrc,
+                                         long row_pitch, int mytok, int lane) {
+  constexpr int F2 = D / 2;
+#pragma unroll
+  for (int i = 0; i < F2; ++i) {
+    const int idx = i * 64 + lane;
+    const int tok = idx / F2, c2 = idx - tok * F2;
+    const int t = __shfl(mytok, tok, 64);
+    const float2 v = *(const float2*)(gsrc + (long)t * row_pitch + 2 * c2);
+    *(float2*)(lds + tok * D + 2 * c2) = v;
+  }
+}
+
 template <int D>
 __global__ void __launch_bounds__(256) k_wattn_fwd(const float* __restrict__ qkv, float* __restrict__ out,
                                                    const float* __restrict__ biasT, long total, int H,
                                                    int W, int C, int heads, int shift, float scale) {
   constexpr int HD = D / 2;
-  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const long gid = blockIdx.x * 4L + (threadIdx.x >> 6);
-  if (gid >= total) return;
+  __shared__ __attribute__((aligned(16))) float smem[4][2][64 * D];
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+  const long gid = blockIdx.x * 4L + wv;
+  if (gid >= total) return;               // no block-level barrier below
   const WaGeom g = wa_decode(gid, heads, W / 8, H / 8, shift);
   const int C3 = 3 * C;
   const int mytok = wa_token(g, lane, H, W, shift);
+  float* Ks = smem[wv][0];
+  float* Qs = smem[wv][1];
+  const float* hb = qkv + g.head * D;
+  wa_stage<D>(Qs, hb, C3, mytok, lane);
+  wa_stage<D>(Ks, hb + C, C3, mytok, lane);
+  __builtin_amdgcn_wave_barrier();
 
   float qf[2][HD], kf[2][HD];
 #pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    const int tok = __shfl(mytok, r + 32 * blk, 64);
-    const float* base = qkv + (long)tok * C3 + g.head * D + h * HD;
+  for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-    for (int t = 0; t < HD; ++t) { qf[blk][t] = base[t]; kf[blk][t] = base[C + t]; }
-  }
+    for (int t = 0; t < HD; ++t) {
+      qf[blk][t] = Qs[(r + 32 * blk) * D + h * HD + t];
+      kf[blk][t] = Ks[(r + 32 * blk) * D + h * HD + t];
+    }
   f32x16 T[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -77,15 +101,17 @@ __global__ void __launch_bounds__(256) k_wattn_fwd(const float* __restrict__ qkv
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) T[kb][qb] = mfma32(kf[kb][t], qf[qb][t], T[kb][qb]);
 
+  // V replaces K in LDS (the K fragments are in registers by now)
+  __builtin_amdgcn_wave_barrier();
+  wa_stage<D>(Ks, hb + 2 * C, C3, mytok, lane);
+  __builtin_amdgcn_wave_barrier();
   // V operand of P.V: lane = head-dim index, one value per (key block, reg)
   float vc[2][16];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int tok = __shfl(mytok, mfma_row(q, lane) + 32 * kb, 64);
-      vc[kb][q] = r < D ? qkv[(long)tok * C3 + 2 * C + g.head * D + r] : 0.f;
-    }
+    for (int q = 0; q < 16; ++q)
+      vc[kb][q] = r < D ? Ks[(mfma_row(q, lane) + 32 * kb) * D + r] : 0.f;
 
   const float lane_mask = (g.last_col && h != ((lane >> 2) & 1)) ? -100.f : 0.f;
   const float* bt = biasT + (long)g.head * 4096;
@@ -380,6 +406,7 @@ int srhip_window_attention_fwd(const float* qkv, float* out, const float* biasT,
   return 0;
 }
 
+// dbiasT must be zero on entry (accumulated with atomics).
 // dbiasT must be zero on entry (accumulated with atomics).
 int srhip_window_attention_bwd(const float* qkv, const float* dout, float* dqkv, const float* biasT,
                                const float* biasN, float* dbiasT, int B, int H, int W, int C, int heads,

@@ -8,6 +8,7 @@ import ctypes
 
 import torch
 
+from . import probe
 from ._lib import call, lib, SrhipError  # noqa: F401
 
 
@@ -45,9 +46,14 @@ def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
     assert W.shape[1] == K
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    call("srhip_gemm_nt", _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out),
-         out.stride(0), M, N, K, a_mode, _p(ln_stats), epi, _p(R),
-         0 if R is None else R.stride(0), _p(rowscale), rows_per_scale, float(alpha), _st())
+    args = (_p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+            a_mode, _p(ln_stats), epi, _p(R), 0 if R is None else R.stride(0), _p(rowscale),
+            rows_per_scale, float(alpha), _st())
+    if probe.active == "gemm_nt":
+        with probe.timed(("gemm_nt", M, N, K), 2.0 * M * N * K):
+            call("srhip_gemm_nt", *args)
+    else:
+        call("srhip_gemm_nt", *args)
     return out
 
 
@@ -106,6 +112,55 @@ def linear_wgrad(dY, X, dW, db, a_rowscale=None, a_rowscale_rows=1, b_mode=0, ln
         W, gamma, beta, dgamma, dbeta = ln
         call("srhip_reduce_ln_linear_wgrad", _p(part), _p(cs), S, _p(W), _p(gamma), _p(beta),
              _p(dW), _p(db), _p(dgamma), _p(dbeta), N, K, _st())
+
+
+class _TnProblem(ctypes.Structure):   # srhip_tn_problem (include/srhip.h)
+    _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_long), ("B", ctypes.c_void_p),
+                ("ldb", ctypes.c_long), ("NI", ctypes.c_int), ("NJ", ctypes.c_int),
+                ("a_rowscale", ctypes.c_void_p), ("a_rowscale_rows", ctypes.c_int),
+                ("b_mode", ctypes.c_int), ("ln_stats", ctypes.c_void_p),
+                ("part", ctypes.c_void_p), ("part_colsum", ctypes.c_void_p)]
+
+
+def linear_wgrad_grouped(problems):
+    """Up to 4 Linear weight-gradient problems over the same rows in ONE launch.
+    Each problem: dict(dY, X, dW, db, a_rowscale=None, a_rowscale_rows=1, b_mode=0,
+    ln_stats=None, ln=None) with the meaning of linear_wgrad()."""
+    n = len(problems)
+    M = problems[0]["dY"].shape[0]
+    dev = problems[0]["dY"].device
+    tiles = sum(lib.srhip_tn_tiles(q["dY"].shape[1], q["X"].shape[1]) for q in problems)
+    S = ctypes.c_int(0)
+    call("srhip_tn_group_plan", M, tiles, ctypes.addressof(S))
+    S = S.value
+    sizes = [(q["dY"].shape[1] * q["X"].shape[1], q["dY"].shape[1]) for q in problems]
+    part = SCRATCH.get("tng_part", S * sum(a for a, _ in sizes), device=dev)
+    cs = SCRATCH.get("tng_colsum", S * sum(b for _, b in sizes), device=dev)
+    arr = (_TnProblem * n)()
+    views = []
+    po = co = 0
+    for k, q in enumerate(problems):
+        dY, X = q["dY"], q["X"]
+        _chk(dY, X, q["dW"], q["db"], q.get("a_rowscale"), q.get("ln_stats"))
+        N, K = dY.shape[1], X.shape[1]
+        pk, ck = part[po:po + S * N * K], cs[co:co + S * N]
+        po += S * N * K
+        co += S * N
+        views.append((pk, ck))
+        a = arr[k]
+        a.A, a.lda, a.B, a.ldb, a.NI, a.NJ = _p(dY), dY.stride(0), _p(X), X.stride(0), N, K
+        a.a_rowscale, a.a_rowscale_rows = _p(q.get("a_rowscale")), q.get("a_rowscale_rows", 1)
+        a.b_mode, a.ln_stats = q.get("b_mode", 0), _p(q.get("ln_stats"))
+        a.part, a.part_colsum = _p(pk), _p(ck)
+    call("srhip_gemm_tn_grouped", ctypes.addressof(arr), n, M, S, _st())
+    for q, (pk, ck) in zip(problems, views):
+        N, K = q["dY"].shape[1], q["X"].shape[1]
+        if q.get("ln") is None:
+            call("srhip_reduce_linear_wgrad", _p(pk), _p(ck), S, _p(q["dW"]), _p(q["db"]), N, K, _st())
+        else:
+            W, gamma, beta, dgamma, dbeta = q["ln"]
+            call("srhip_reduce_ln_linear_wgrad", _p(pk), _p(ck), S, _p(W), _p(gamma), _p(beta),
+                 _p(q["dW"]), _p(q["db"]), _p(dgamma), _p(dbeta), N, K, _st())
 
 
 def conv3x3_wgrad(dY, X, dW, db):
@@ -285,16 +340,17 @@ def metrics_ssim(E, Hh, border, thresholds=(), inputs_are_u8=False):
 
 
 # ------------------------------------------------------------------ optimizers
-def adam_step(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0, gscale=1.0):
-    _chk(p, g, m, v)
+def adam_step(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0, gscale=1.0, skip_flag=None):
+    _chk(p, g, m, v, skip_flag)
     call("srhip_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), step, float(lr), float(b1),
-         float(b2), float(eps), float(wd), float(gscale), _st())
+         float(b2), float(eps), float(wd), float(gscale), _p(skip_flag), _st())
 
 
-def sgd_step(p, g, buf, lr, momentum=0.9, wd=0.0, nesterov=True, first=False, gscale=1.0):
-    _chk(p, g, buf)
+def sgd_step(p, g, buf, lr, momentum=0.9, wd=0.0, nesterov=True, first=False, gscale=1.0,
+             skip_flag=None):
+    _chk(p, g, buf, skip_flag)
     call("srhip_sgd_step", _p(p), _p(g), _p(buf), p.numel(), float(lr), float(momentum),
-         float(wd), int(nesterov), int(first), float(gscale), _st())
+         float(wd), int(nesterov), int(first), float(gscale), _p(skip_flag), _st())
 
 
 def nonfinite_flag(x, flag):

@@ -170,7 +170,7 @@ class SwinIREngine:
         return y
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dy, grads, need_dx=False):
+    def backward(self, dy, grads, need_dx=False, on_layer_done=None):
         """dy: [B,1,s*H,s*W]; grads: dict name -> tensor to receive the parameter
         gradient (overwritten).  Returns d loss / d x [B,H,W] if need_dx."""
         sv = self.saved
@@ -201,7 +201,9 @@ class SwinIREngine:
         dt = buf("dt", T, C)
         ops.layernorm_bwd(dtn, sv["t_last"], sv["st_n"], dt, gamma=net.norm.weight.data,
                           dgamma=G("norm.weight"), dbeta=G("norm.bias"))
-        ga, gb = buf("ga", T, C), buf("gb", T, C)
+        # three rotating gradient buffers: a block's incoming gradient g must stay
+        # alive until the block's grouped weight-gradient launch at its end
+        gbufs = [buf("ga", T, C), buf("gb", T, C), buf("gc", T, C)]
         dh, dxh, da = buf("dh", T, hid), buf("dxh", T, C), buf("da", T, C)
         dqkv = buf("dqkv", T, 3 * C)
         bi = len(self.blocks)
@@ -211,7 +213,8 @@ class SwinIREngine:
             pre = f"layers.{li}."
             ops.conv3x3_wgrad(dt.view(B, H, W, C), t_blocks.view(B, H, W, C), G(pre + "conv.weight"),
                               G(pre + "conv.bias"))
-            g = ga
+            gi = 0
+            g = gbufs[gi]
             ops.conv3x3(dt.view(B, H, W, C), D.d[f"l{li}.wpt"], None, C, out=g.view(B, H, W, C))
             nb = len(layer.residual_group.blocks)
             for j in reversed(range(nb)):
@@ -222,35 +225,39 @@ class SwinIREngine:
                 heads = blk.num_heads
                 s1 = None if dp is None else dp[2 * bi]
                 s2 = None if dp is None else dp[2 * bi + 1]
-                other = gb if g is ga else ga
+                g1, gout = gbufs[(gi + 1) % 3], gbufs[(gi + 2) % 3]
                 # ---- MLP branch: x2 = x1 + s2*(gelu(h) W2^T + b2)
                 ops.gemm_nt(g, D.d[f"{bi}.w2T"], None, out=dh, epi=3, R=h, rowscale=s2,
                             rows_per_scale=H * W)
-                ops.linear_wgrad(g, h, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), a_rowscale=s2,
-                                 a_rowscale_rows=H * W, b_mode=2)
                 ops.gemm_nt(dh, D.d[f"{bi}.w1T"], None, out=dxh)
-                ops.linear_wgrad(dh, x1, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), b_mode=1,
-                                 ln_stats=st2, ln=(blk.mlp.fc1.weight.data, blk.norm2.weight.data,
-                                                   blk.norm2.bias.data, G(p + "norm2.weight"),
-                                                   G(p + "norm2.bias")))
-                g1 = other
                 ops.layernorm_bwd(dxh, x1, st2, g1, res=g)
                 # ---- attention branch: x1 = t + s1*(a Wp^T + bp)
                 ops.gemm_nt(g1, D.d[f"{bi}.wpT"], None, out=da, epi=2, rowscale=s1, rows_per_scale=H * W)
-                ops.linear_wgrad(g1, a, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"),
-                                 a_rowscale=s1, a_rowscale_rows=H * W)
                 dbT = buf("dbiasT", heads, 64, 64)
                 dbT.zero_()
                 ops.window_attention_bwd(qkv, da, dqkv, D.d[f"{bi}.biasT"], D.d[f"{bi}.biasN"], dbT, B, H,
                                          W, C, heads, blk.shift_size)
                 ops.bias_grad(dbT, G(p + "attn.relative_position_bias_table"))
                 ops.gemm_nt(dqkv, D.d[f"{bi}.wqT"], None, out=dxh)
-                ops.linear_wgrad(dqkv, t, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"), b_mode=1,
-                                 ln_stats=st1, ln=(blk.attn.qkv.weight.data, blk.norm1.weight.data,
-                                                   blk.norm1.bias.data, G(p + "norm1.weight"),
-                                                   G(p + "norm1.bias")))
-                ops.layernorm_bwd(dxh, t, st1, g, res=g1)   # g (its old value is dead) <- grad wrt t
+                ops.layernorm_bwd(dxh, t, st1, gout, res=g1)
+                # ---- the four weight gradients of the block in ONE launch
+                ops.linear_wgrad_grouped([
+                    dict(dY=dqkv, X=t, dW=G(p + "attn.qkv.weight"), db=G(p + "attn.qkv.bias"), b_mode=1,
+                         ln_stats=st1, ln=(blk.attn.qkv.weight.data, blk.norm1.weight.data,
+                                           blk.norm1.bias.data, G(p + "norm1.weight"), G(p + "norm1.bias"))),
+                    dict(dY=g, X=h, dW=G(p + "mlp.fc2.weight"), db=G(p + "mlp.fc2.bias"), a_rowscale=s2,
+                         a_rowscale_rows=H * W, b_mode=2),
+                    dict(dY=dh, X=x1, dW=G(p + "mlp.fc1.weight"), db=G(p + "mlp.fc1.bias"), b_mode=1,
+                         ln_stats=st2, ln=(blk.mlp.fc1.weight.data, blk.norm2.weight.data,
+                                           blk.norm2.bias.data, G(p + "norm2.weight"), G(p + "norm2.bias"))),
+                    dict(dY=g1, X=a, dW=G(p + "attn.proj.weight"), db=G(p + "attn.proj.bias"),
+                         a_rowscale=s1, a_rowscale_rows=H * W),
+                ])
+                gi = (gi + 2) % 3
+                g = gout
             ops.axpby(dt, g, 1.0, 1.0)   # RSTB skip: t_out = conv(blocks(t_in)) + t_in
+            if on_layer_done is not None:   # this layer's gradients are enqueued
+                on_layer_done(len(net.layers) - 1 - li)
         # patch_embed.norm and the conv_after_body skip (f = conv(..) + f0)
         df0 = buf("df0", T, C)
         ops.layernorm_bwd(dt, sv["f0"].view(T, C), sv["st_pe"], df0, res=df.view(T, C),

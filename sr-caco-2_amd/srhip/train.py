@@ -1,0 +1,190 @@
+"""Fast training step on flat parameter / gradient buffers.
+
+This is what ModelPlain.optimize_parameters (reference
+dlib/models/model_plain.py:318-396) becomes on MI355X: forward, MasterLoss,
+backward, one finite-check flag (instead of ~660 host syncs per step,
+dlib/utils/tools.py:55-63), optional data-parallel gradient all-reduce (RCCL,
+side stream, one bucket per RSTB layer launched as soon as that layer's
+gradients exist; replaces DDP, model_base.py:135-142) and a fused multi-tensor
+Adam / SGD-Nesterov update (dlib/utils/utils_instance.py:216-247) -- with no
+Python-visible tensor math in between.
+"""
+import torch
+
+from . import ops
+
+
+class FlatParams:
+    """All float parameters of a module as views of ONE flat fp32 buffer (and
+    their gradients as views of another), in named_parameters() order, so the
+    optimizer and the gradient all-reduce each touch one contiguous range."""
+
+    def __init__(self, net):
+        named = [(k, p) for k, p in net.named_parameters() if p.requires_grad]
+        dev = named[0][1].device
+        self.names = [k for k, _ in named]
+        self.numel = sum(p.numel() for _, p in named)
+        # pad every tensor to a multiple of 4 floats: keeps 16-B alignment for
+        # the vectorised kernels
+        self.offsets = {}
+        off = 0
+        for k, p in named:
+            self.offsets[k] = off
+            off += (p.numel() + 3) // 4 * 4
+        self.total = off
+        self.flat = torch.zeros(off, device=dev)
+        self.grad = torch.zeros(off, device=dev)
+        self.gviews = {}
+        for k, p in named:
+            o, n = self.offsets[k], p.numel()
+            self.flat[o:o + n].view_as(p).copy_(p.data)
+            p.data = self.flat[o:o + n].view_as(p)
+            self.gviews[k] = self.grad[o:o + n].view_as(p)
+            p.grad = self.gviews[k]
+
+    def range_of(self, prefix_list):
+        """[lo, hi) flat range covering every parameter whose name starts with one
+        of the prefixes (they are contiguous by construction)."""
+        lo, hi = None, None
+        for k in self.names:
+            if any(k.startswith(pf) for pf in prefix_list):
+                o = self.offsets[k]
+                e = o + (self.gviews[k].numel() + 3) // 4 * 4
+                lo = o if lo is None else min(lo, o)
+                hi = e if hi is None else max(hi, e)
+        return lo, hi
+
+
+class Optimizer:
+    """Adam (torch semantics, L2 weight decay) or SGD momentum/Nesterov on the flat
+    buffers, plus MyStepLR / MultiStepLR learning-rate rules stepped per
+    iteration as the reference does (utils_trainer.py:370, lr_scheduler.py:6-35)."""
+
+    def __init__(self, flat: FlatParams, kind="adam", lr=2e-4, betas=(0.9, 0.999), eps=1e-8, wd=0.0,
+                 momentum=0.9, nesterov=True, scheduler=None):
+        self.fp, self.kind, self.base_lr = flat, kind, lr
+        self.betas, self.eps, self.wd = betas, eps, wd
+        self.momentum, self.nesterov = momentum, nesterov
+        self.scheduler = scheduler or {}
+        self.step_count = 0      # optimizer steps taken
+        self.sched_count = 0     # scheduler.step() calls
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat) if kind == "adam" else None
+
+    @property
+    def lr(self):
+        s = self.scheduler
+        if not s:
+            return self.base_lr
+        if s["type"] == "MyStepLR":
+            return max(self.base_lr * s["gamma"] ** (self.sched_count // s["step_size"]), s["min_lr"])
+        if s["type"] == "MultiStepLR":
+            k = sum(1 for m in s["milestones"] if self.sched_count >= m)
+            return self.base_lr * s["gamma"] ** k
+        raise NotImplementedError(s["type"])
+
+    def step(self, gscale=1.0, skip_flag=None):
+        fp = self.fp
+        self.step_count += 1
+        if self.kind == "adam":
+            ops.adam_step(fp.flat, fp.grad, self.m, self.v, self.step_count, self.lr, self.betas[0],
+                          self.betas[1], self.eps, self.wd, gscale, skip_flag)
+        elif self.kind == "sgd":
+            ops.sgd_step(fp.flat, fp.grad, self.m, self.lr, self.momentum, self.wd, self.nesterov,
+                         self.step_count == 1, gscale, skip_flag)
+        else:
+            raise NotImplementedError(self.kind)
+
+    def scheduler_step(self):
+        self.sched_count += 1
+
+
+class TrainStep:
+    """loss_terms: sequence of ('l1', lam) | ('l2', lam) | ('ssim', lam, window)
+    (MasterLoss = their sum, dlib/loss/master.py:46-56)."""
+
+    def __init__(self, net, loss_terms=(("l1", 1.0),), optimizer=None, process_group=None,
+                 world_size=1):
+        self.net = net
+        self.fp = FlatParams(net)
+        net.weights_changed()
+        self.loss_terms = list(loss_terms)
+        self.opt = optimizer if optimizer is not None else Optimizer(self.fp)
+        self.world = world_size
+        self.pg = process_group
+        dev = self.fp.flat.device
+        self.loss_buf = torch.zeros(1 + len(self.loss_terms), device=dev)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
+        self.buckets = self._make_buckets() if world_size > 1 else []
+        self.dy = None
+
+    def _make_buckets(self):
+        """One bucket per RSTB layer, in the order backward finishes them; the
+        tail (norm / conv_after_body / upsample) rides with the last layer, the
+        head (conv_first / patch_embed) is its own final bucket."""
+        n = len(self.net.layers)
+        out = []
+        for li in reversed(range(n)):
+            pf = [f"layers.{li}."]
+            if li == n - 1:
+                pf += ["norm.", "conv_after_body.", "upsample."]
+            out.append(self.fp.range_of(pf))
+        out.append(self.fp.range_of(["conv_first.", "patch_embed."]))
+        return out
+
+    def _allreduce_bucket(self, i):
+        import torch.distributed as dist
+        lo, hi = self.buckets[i]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(self.fp.grad[lo:hi], group=self.pg)
+
+    def loss_and_grad(self, y, target):
+        """MasterLoss value(s) + d loss / d y through the fused loss kernels."""
+        if self.dy is None or self.dy.shape != y.shape:
+            self.dy = torch.empty_like(y)
+        lb = self.loss_buf
+        for i, t in enumerate(self.loss_terms):
+            first = i == 0
+            part = lb[1 + i:2 + i]
+            if t[0] in ("l1", "l2"):
+                ops.loss_l1l2(y, target, 0 if t[0] == "l1" else 1, t[1], None, self.dy, part,
+                              grad_accum=not first)
+            elif t[0] == "ssim":
+                ops.ssim_loss(y, target, t[2], t[1], self.dy, part, grad_accum=not first)
+            else:
+                raise NotImplementedError(t[0])
+        return self.dy
+
+    def step(self, lr_img, hr_img, dp=None):
+        """One optimisation step.  Returns the device tensor [total, term1, ...]
+        (no host sync here; read it when needed)."""
+        net = self.net
+        xi, h, w = net.prepare_input(lr_img)
+        assert (h, w) == tuple(xi.shape[1:]), "training patches must be multiples of the 8x8 window"
+        if dp is None:
+            dp = net.sample_drop_path(xi.shape[0], xi.device)
+        y = net.engine.forward(xi, dp, save=True)
+        dy = self.loss_and_grad(y, hr_img)
+        if self.world > 1:
+            hook = self._allreduce_bucket
+        else:
+            hook = None
+        net.engine.backward(dy, self.fp.gviews, on_layer_done=hook)
+        if self.world > 1:
+            self._allreduce_bucket(len(self.buckets) - 1)
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        # one device flag: non-finite loss -> the optimizer kernel skips the update
+        ops.nonfinite_flag(self.loss_buf, self.flag)
+        self.opt.step(gscale=1.0 / self.world, skip_flag=self.flag)
+        self.opt.scheduler_step()
+        net.weights_changed()
+        return self.loss_buf
+
+    def loss_values(self):
+        """[total, term1, ...] as Python floats (host sync)."""
+        v = self.loss_buf[1:].tolist()
+        return [sum(v)] + v
