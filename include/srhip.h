@@ -155,6 +155,8 @@ int srhip_ssim_loss(const float* pred, const float* target, float* grad, float* 
 
 /* ---- metrics (dlib/utils/utils_image.py:369-372,843-1007,618-653,1010-1198;
  *      dlib/utils/utils_trainer.py:961-1032) ----------------------------------- */
+/* (x.clamp(0,1)*255).round().clamp(0,255), round-half-even (utils_image.py:369-372). */
+int srhip_tensor2uint82float(const float* in, float* out, long n, void* stream);
 /* One pass: tensor2uint82float on both images (skipped if inputs_are_u8),
  * border crop, then for "no ROI" (slot 0) and each ROI threshold t (roi = H>=t):
  * out[b][slot][4] = PSNR, PSNR_Y, MSE, NRMSE in fp64.
@@ -182,6 +184,8 @@ int srhip_sgd_step(float* p, const float* g, float* buf, long n, float lr, float
  * per-tensor host syncs (dlib/utils/tools.py:28-63, model_plain.py:344). */
 int srhip_nonfinite_flag(const float* x, long n, int* flag, void* stream);
 int srhip_axpby(float* y, const float* x, long n, float a, float b, void* stream);
+/* out[0] = sum(x) (fp64 accumulation); workspace: 2048 doubles. */
+int srhip_sum(const float* x, long n, float* out, double* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -299,6 +299,16 @@ __global__ void __launch_bounds__(256) k_loss_l1l2(const float* __restrict__ pre
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
+__global__ void __launch_bounds__(256) k_sum(const float* __restrict__ x, double* __restrict__ part, long n) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    acc += (double)x[i];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
 // out[0] (+)= scale * sum(part[0..n))  as float
 __global__ void k_sum_partials(const double* __restrict__ part, int n, double scale,
                                float* __restrict__ out, int accum) {
@@ -482,6 +492,17 @@ int srhip_loss_l1l2(const float* pred, const float* target, const float* weight,
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, workspace, g, (double)lam / (double)n,
                      loss_out, loss_accum);
   SR_LAUNCH_CHECK("loss_l1l2");
+  return 0;
+}
+
+// workspace: 2048 doubles
+int srhip_sum(const float* x, long n, float* out, double* workspace, void* stream) {
+  SR_REQUIRE(n > 0, "sum: empty input");
+  hipStream_t st = (hipStream_t)stream;
+  const int g = ew_grid(n);
+  hipLaunchKernelGGL(k_sum, dim3(g), dim3(256), 0, st, x, workspace, n);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, workspace, g, 1.0, out, 0);
+  SR_LAUNCH_CHECK("sum");
   return 0;
 }
 

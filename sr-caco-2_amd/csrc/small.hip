@@ -156,6 +156,10 @@ __device__ __forceinline__ float ycb(float u8) {  // gray -> Y in [0,255] (float
   const float y = (65.481f * v255 + 128.553f * v255 + 24.966f * v255) / 255.0f + 16.0f;
   return fminf(fmaxf(y / 255.0f, 0.f), 1.f) * 255.0f;
 }
+__global__ void k_u8ify(const float* __restrict__ in, float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = u8f(in[i]);
+}
 // raw[b][th][blk][8] doubles: sse, ssey, cnt, ymax, ymin_roi, ymin_all
 __global__ void __launch_bounds__(256) k_metrics_pass(const float* __restrict__ E, const float* __restrict__ Hh,
                                                       double* __restrict__ raw, int H, int W, int border,
@@ -280,6 +284,15 @@ int srhip_conv3x3_cout1_fwd(const float* x, long ldx, const float* w, const floa
   hipLaunchKernelGGL(k_conv_cout1_fwd, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                      y, B, H, W, Ci, ldx);
   SR_LAUNCH_CHECK("conv_cout1_fwd");
+  return 0;
+}
+
+int srhip_tensor2uint82float(const float* in, float* out, long n, void* stream) {
+  if (n <= 0) return 0;
+  long g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_u8ify, dim3((int)g), dim3(256), 0, (hipStream_t)stream, in, out, n);
+  SR_LAUNCH_CHECK("tensor2uint82float");
   return 0;
 }
 

@@ -1,0 +1,187 @@
+"""SR losses on libsrhip: MasterLoss + L1 / L2 / NegativeSsim.
+
+Mirrors the reference's ``dlib.loss`` surface on the hot path
+(dlib/loss/master.py:19-56, dlib/loss/core.py:17-127, dlib/loss/main.py:45-99,
+154-186): same class names, constructor keywords, ``forward(epoch=, y_pred=,
+y_target=, trg_per_pixel_weight=, model=)`` call, ``l_holder`` / ``n_holder``
+bookkeeping and ``update_t``.  Each term runs ONE fused HIP kernel sequence that
+produces the value and d loss / d y_pred together; autograd only scales that
+stored gradient.  The other 13 reference terms are off by default
+(utils_config.py:279-374) and not on the hot path.
+"""
+import re
+
+import torch
+import torch.nn as nn
+
+from srhip import ops
+
+__all__ = ['MasterLoss', 'ElementaryLoss', 'L1', 'L2', 'NegativeSsim']
+
+
+def _snake(name):
+    s1 = re.sub('(.)([A-Z][a-z]+)', r'\1_\2', name)
+    return re.sub('([a-z0-9])([A-Z])', r'\1_\2', s1).lower()
+
+
+class _FusedLoss(torch.autograd.Function):
+    """value + gradient computed together by ``kernel(pred, grad_out, value_out)``."""
+
+    @staticmethod
+    def forward(ctx, pred, kernel):
+        if not pred.is_cuda:
+            raise RuntimeError("dlib.loss (libsrhip) runs on the GPU only; there is no CPU fallback")
+        p = pred.detach().float().contiguous()
+        grad = torch.empty_like(p) if pred.requires_grad else None
+        val = torch.empty(1, device=p.device, dtype=torch.float32)
+        kernel(p, grad, val)
+        ctx.save_for_backward(grad)
+        return val.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+class ElementaryLoss(nn.Module):
+    def __init__(self, cuda_id=0, name=None, lambda_=1., elb=nn.Identity(), start_epoch=None,
+                 end_epoch=None, restore_range=False, color_min=0, color_max=255,
+                 use_residuals=False):
+        super().__init__()
+        self._name, self.lambda_, self.elb = name, lambda_, elb
+        self.start_epoch = start_epoch
+        self.end_epoch = None if end_epoch == -1 else end_epoch
+        self.c_epoch = 0
+        self._device = torch.device(cuda_id) if not isinstance(cuda_id, torch.device) else cuda_id
+        assert not use_residuals, "use_residuals is not on the hot path"
+        self.use_residuals = use_residuals
+
+    @property
+    def _zero(self):   # value of a switched-off term (lazy: no device touch at construction)
+        return torch.zeros(1, device=self._device)
+
+    def is_on(self, _epoch=None):
+        e = self.c_epoch if _epoch is None else _epoch
+        s, t = self.start_epoch, self.end_epoch
+        if s is None and t is None:
+            return True
+        if s is not None and t is not None:
+            return s <= e <= t
+        return e <= t if s is None else e >= s
+
+    def update_t(self):
+        if hasattr(self.elb, "update_t"):
+            self.elb.update_t()
+
+    @property
+    def __name__(self):
+        return _snake(self.__class__.__name__) if self._name is None else self._name
+
+    @staticmethod
+    def sanity_check_trg_per_pixel_weight(w, y):
+        assert y.ndim == 4 and w.ndim == 4 and w.shape[1] == 1
+        assert (w.shape[0], w.shape[2], w.shape[3]) == (y.shape[0], y.shape[2], y.shape[3])
+
+    def forward(self, epoch, y_pred=None, y_target=None, trg_per_pixel_weight=None, model=None):
+        self.c_epoch = epoch
+
+
+class L1(ElementaryLoss):
+    """lambda * mean(|y_pred - y_target| (* weight)); dlib/loss/main.py:45-76."""
+
+    def forward(self, epoch, y_pred=None, y_target=None, trg_per_pixel_weight=None, model=None):
+        super().forward(epoch=epoch)
+        if not self.is_on():
+            return self._zero
+        w = trg_per_pixel_weight
+        if w is not None:
+            self.sanity_check_trg_per_pixel_weight(w, y_target)
+            assert y_pred.shape[1] == 1, "per-pixel weights: 1-channel predictions"
+            w = w.float().contiguous()
+        t = y_target.float().contiguous()
+        return _FusedLoss.apply(y_pred, lambda p, g, v: ops.loss_l1l2(p, t, 0, self.lambda_, w, g, v))
+
+
+class L2(ElementaryLoss):
+    """lambda * mean((y_pred - y_target)^2); dlib/loss/main.py:79-99."""
+
+    def forward(self, epoch, y_pred=None, y_target=None, trg_per_pixel_weight=None, model=None):
+        super().forward(epoch=epoch)
+        if not self.is_on():
+            return self._zero
+        t = y_target.float().contiguous()
+        return _FusedLoss.apply(y_pred, lambda p, g, v: ops.loss_l1l2(p, t, 1, self.lambda_, None, g, v))
+
+
+class NegativeSsim(ElementaryLoss):
+    """-lambda * mean_b(mean_hw(ssim_map)), Gaussian sigma-1.5 window (default 11,
+    README recipe 19), zero padding; dlib/loss/main.py:154-186, dlib/loss/ssim.py."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.window_size = 11
+
+    def set_window_size(self, window_size):
+        assert isinstance(window_size, int) and window_size > 0
+        self.window_size = window_size
+
+    def forward(self, epoch, y_pred=None, y_target=None, trg_per_pixel_weight=None, model=None):
+        super().forward(epoch=epoch)
+        if not self.is_on():
+            return self._zero
+        assert y_pred.shape[1] == 1, "SSIM loss kernel: 1-channel images"
+        t = y_target.float().contiguous()
+        ws = self.window_size
+        return _FusedLoss.apply(y_pred, lambda p, g, v: ops.ssim_loss(p, t, ws, self.lambda_, g, v))
+
+
+class MasterLoss(nn.Module):
+    """Sum of elementary losses; l_holder = [total, term1, ...] (master.py:46-56)."""
+
+    def __init__(self, cuda_id=0, name=None):
+        super().__init__()
+        self._name = name
+        self.losses, self.l_holder = [], []
+        self.n_holder = [self.__name__]
+        self._device = torch.device(cuda_id) if not isinstance(cuda_id, torch.device) else cuda_id
+
+    def add(self, loss_):
+        self.losses.append(loss_)
+        self.n_holder.append(loss_.__name__)
+
+    def update_t(self):
+        for loss in self.losses:
+            loss.update_t()
+
+    @property
+    def __name__(self):
+        return _snake(self.__class__.__name__) if self._name is None else self._name
+
+    def terms(self):
+        """('l1', lam) | ('l2', lam) | ('ssim', lam, window) for the fused training
+        step (srhip.train.TrainStep)."""
+        out = []
+        for l in self.losses:
+            if isinstance(l, L1):
+                out.append(("l1", l.lambda_))
+            elif isinstance(l, L2):
+                out.append(("l2", l.lambda_))
+            elif isinstance(l, NegativeSsim):
+                out.append(("ssim", l.lambda_, l.window_size))
+            else:
+                raise NotImplementedError(type(l).__name__)
+        return out
+
+    def forward(self, **kwargs):
+        assert self.losses != []
+        self.l_holder = [loss(**kwargs).reshape(()) for loss in self.losses]
+        total = sum(self.l_holder)
+        self.l_holder = [total] + self.l_holder
+        return total
+
+    def to_device(self):
+        return self
+
+    def __str__(self):
+        return "{}(): {}".format(self.__class__.__name__, ", ".join(self.n_holder))

@@ -1,0 +1,161 @@
+"""ModelPlain: the wrapper protocol the reference's trainer consumes
+(dlib/models/model_plain.py:41-456, dlib/models/model_base.py:26-211), on the
+fused libsrhip training step.
+
+Kept: init_train, feed_data(dict, need_H), optimize_parameters(epoch, step),
+update_learning_rate, test, set_eval_mode / set_train_mode, current_visuals,
+current_log, save / save_best / load_network (raw ``netG.state_dict()`` with
+``torch.save`` -- file-compatible with the reference's ``<iter>_G.pth`` /
+``G-model.pth``), save_current / load_current, loss_fn.{l_holder,n_holder,
+update_t}, attributes L, E, H, netG, save_dir.
+
+Changed on purpose (same observable behaviour): one device flag replaces the
+per-step ``isfinite(...).item()`` + ~660 ``check_corruption`` host syncs
+(model_plain.py:344,396; tools.py:55-63): a non-finite loss skips the update on
+the device; ``check_finite()`` reads the flag when the caller wants the
+reference's log-and-exit.  DDP is replaced by bucketed RCCL all-reduce inside
+TrainStep (model_base.py:135-142).
+"""
+import os
+from collections import OrderedDict
+from copy import deepcopy
+
+import torch
+
+from dlib.models.select_network import define_G
+from dlib.utils.utils_instance import define_loss, optimizer_config
+from srhip.train import TrainStep, Optimizer
+
+
+class ModelPlain:
+    def __init__(self, args):
+        self.args = args
+        self.opt_train = args.train
+        self.is_train = getattr(args, 'is_train', True)
+        self.save_dir = getattr(args, 'outd', '.')
+        dev_id = torch.cuda.current_device() if torch.cuda.is_available() else None
+        if dev_id is None:
+            raise RuntimeError("ModelPlain (libsrhip) needs a GPU; there is no CPU fallback")
+        self.device = torch.device(f'cuda:{dev_id}')
+        self.netG = define_G(args).to(self.device)
+        self.schedulers = []
+        self.log_dict = OrderedDict()
+        self.L = self.E = self.H = self.h_per_pixel_weight = None
+        self._current = None
+        self.step_fn = None
+        self.loss_fn = None
+
+    # ---------------------------------------------------------------- train setup
+    def init_train(self):
+        self.load()
+        self.netG.train()
+        self.loss_fn = define_loss(self.args)
+        world = 1
+        pg = None
+        if getattr(self.args, 'distributed', False):
+            import torch.distributed as dist
+            world, pg = dist.get_world_size(), dist.group.WORLD
+        self.step_fn = TrainStep(self.netG, self.loss_fn.terms(), process_group=pg, world_size=world)
+        self.step_fn.opt = Optimizer(self.step_fn.fp, **optimizer_config(self.args))
+        self.G_optimizer = self.step_fn.opt
+        self.log_dict = OrderedDict()
+
+    def load(self):
+        path = self.opt_train.get('pretrained_netG', None) if hasattr(self.opt_train, 'get') else None
+        if path:
+            self.load_network(path, self.netG, strict=True)
+
+    # ---------------------------------------------------------------- data
+    def feed_data(self, data, need_H=True):
+        self.L = data['l_im'].to(self.device, non_blocking=True)
+        self.H = data['h_im'].to(self.device, non_blocking=True) if need_H else None
+        w = data.get('h_per_pixel_weight', None)
+        self.h_per_pixel_weight = None if w is None else w.to(self.device)
+        if self.h_per_pixel_weight is not None:
+            raise NotImplementedError("per-pixel loss weights (--ppiw) with the fused step: use "
+                                      "dlib.loss.L1 through autograd")
+
+    # ---------------------------------------------------------------- step
+    def optimize_parameters(self, epoch: int, current_step: int):
+        self.step_fn.step(self.L, self.H)
+        self.E = self.netG.engine.bufs.d.get("t.y")
+
+    def update_learning_rate(self):
+        pass   # TrainStep steps the LR rule once per iteration (utils_trainer.py:370)
+
+    def current_learning_rate(self):
+        return self.step_fn.opt.lr
+
+    def check_finite(self):
+        """True if no non-finite loss was seen since the last call (one host sync)."""
+        bad = int(self.step_fn.flag.item())
+        self.step_fn.flag.zero_()
+        return bad == 0
+
+    def current_log(self):
+        vals = self.step_fn.loss_values()
+        self.log_dict['G_loss'] = vals[0]
+        self.loss_fn.l_holder = [torch.tensor(v) for v in vals]
+        return self.log_dict
+
+    # ---------------------------------------------------------------- eval
+    def set_eval_mode(self):
+        self.netG.eval()
+
+    def set_train_mode(self):
+        self.netG.train()
+
+    def test(self):
+        self.netG.eval()
+        with torch.no_grad():
+            self.E = self.netG(self.L)
+        self.netG.train()
+
+    def current_visuals(self, need_H=True):
+        out = OrderedDict()
+        out['L'] = self.L.detach().float()
+        out['E'] = self.E.detach().float()
+        if need_H:
+            out['H'] = self.H.detach().float()
+        return out
+
+    # ---------------------------------------------------------------- checkpoints
+    def save_network(self, save_dir, network, network_label, iter_label):
+        os.makedirs(save_dir, exist_ok=True)
+        path = os.path.join(save_dir, f'{iter_label}_{network_label}.pth')
+        sd = OrderedDict((k, v.detach().cpu().clone()) for k, v in network.state_dict().items())
+        torch.save(sd, path)
+        return path
+
+    def save(self, iter_label):
+        return self.save_network(self.save_dir, self.netG, 'G', iter_label)
+
+    def save_best(self, save_dir, name='G-model'):
+        os.makedirs(save_dir, exist_ok=True)
+        path = os.path.join(save_dir, f'{name}.pth')
+        torch.save(OrderedDict((k, v.detach().cpu().clone())
+                               for k, v in self.netG.state_dict().items()), path)
+        return path
+
+    def load_network(self, load_path, network, strict=True, param_key='params'):
+        sd = torch.load(load_path, map_location='cpu')
+        if param_key in sd:
+            sd = sd[param_key]
+        network.load_state_dict(sd, strict=strict)
+        if self.step_fn is not None:   # parameters are views of the flat buffer: copy_ kept them
+            network.weights_changed()
+
+    def save_current(self):
+        self._current = deepcopy({k: v.detach().clone() for k, v in self.netG.state_dict().items()})
+
+    def load_current(self):
+        assert self._current is not None
+        self.netG.load_state_dict(self._current, strict=True)
+        self.netG.weights_changed()
+
+    def flush(self):
+        self.L = self.E = self.H = None
+
+    def info_network(self):
+        n = sum(p.numel() for p in self.netG.parameters())
+        return f'{self.netG.__class__.__name__}: {n} parameters'

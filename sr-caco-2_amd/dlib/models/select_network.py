@@ -1,0 +1,31 @@
+"""Network registry: ``define_G(args) -> nn.Module`` keyed by
+``args.netG['net_type']`` with per-net options read from
+``args.netG[f'{safe_str_var(net_type)}_<opt>']`` -- the reference's contract
+(dlib/models/select_network.py:19-50) for the two hot-path families."""
+from dlib.utils import constants
+from dlib.utils.shared import safe_str_var
+
+__all__ = ['define_G']
+
+
+def define_G(args):
+    opt_net = args.netG
+    net_type = opt_net['net_type']
+    nt = safe_str_var(net_type)
+    if net_type == constants.SWINIR:
+        from dlib.models.network_swinir import SwinIR as net
+        return net(upscale=opt_net[f'{nt}_upscale'], in_chans=opt_net[f'{nt}_in_chans'],
+                   img_size=opt_net[f'{nt}_img_size'], window_size=opt_net[f'{nt}_window_size'],
+                   img_range=opt_net[f'{nt}_img_range'], depths=opt_net[f'{nt}_depths'],
+                   embed_dim=opt_net[f'{nt}_embed_dim'], num_heads=opt_net[f'{nt}_num_heads'],
+                   mlp_ratio=opt_net[f'{nt}_mlp_ratio'], upsampler=opt_net[f'{nt}_upsampler'],
+                   resi_connection=opt_net[f'{nt}_resi_connection'])
+    if net_type == constants.EDSR_LIIF:
+        from dlib.models.network_edsr_liif import EDSR_LIIF as net
+        return net(in_chans=opt_net[f'{nt}_in_chans'], n_resblocks=opt_net[f'{nt}_n_resblocks'],
+                   n_feats=opt_net[f'{nt}_n_feats'], scale=opt_net[f'{nt}_upscale'],
+                   rgb_range=opt_net[f'{nt}_img_range'], res_scale=opt_net.get(f'{nt}_res_scale', 1.),
+                   local_ensemble=True, feat_unfold=True, cell_decode=True)
+    raise NotImplementedError(
+        f"net_type {net_type!r}: only {constants.MODELS} run on libsrhip (SURVEY.md section 8f lists "
+        f"the remaining 14 reference networks as 'next')")

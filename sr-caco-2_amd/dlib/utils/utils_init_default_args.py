@@ -1,0 +1,27 @@
+"""Per-network default options (reference dlib/utils/utils_init_default_args.py:13-50)."""
+from copy import deepcopy
+
+from dlib.utils import constants
+from dlib.utils.shared import safe_str_var
+
+
+def init_net_g(netG: dict, args: dict) -> dict:
+    out = deepcopy(netG)
+    nt = safe_str_var(netG['net_type'])
+    if netG['net_type'] == constants.SWINIR:
+        out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'],
+                    f'{nt}_img_size': args['h_size'] // args['scale'], f'{nt}_window_size': 8,
+                    f'{nt}_img_range': 1.0, f'{nt}_depths': [6, 6, 6, 6, 6, 6], f'{nt}_embed_dim': 180,
+                    f'{nt}_num_heads': [6, 6, 6, 6, 6, 6], f'{nt}_mlp_ratio': 2,
+                    f'{nt}_upsampler': constants.US_PIXEL_SHUFFLE,
+                    f'{nt}_resi_connection': constants.R_CONNECTION_1CONV})
+    elif netG['net_type'] == constants.EDSR_LIIF:
+        out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'],
+                    f'{nt}_n_feats': 64, f'{nt}_img_range': 1.0, f'{nt}_res_scale': 1.,
+                    f'{nt}_n_resblocks': 16})
+    else:
+        raise NotImplementedError(netG['net_type'])
+    out[f'{nt}_init_type'] = constants.INIT_W_DEFAULT
+    out[f'{nt}_init_bn_type'] = constants.INIT_BN_CONSTANT
+    out[f'{nt}_init_gain'] = 1.
+    return out

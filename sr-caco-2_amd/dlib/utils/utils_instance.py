@@ -1,0 +1,49 @@
+"""Loss / optimizer / scheduler factories (reference dlib/utils/utils_instance.py:23-290)
+for the options that are on by default or in the README recipe."""
+from dlib import loss as losses
+from dlib.utils import constants
+
+
+def define_loss(args):
+    dev = getattr(args, 'c_cudaid', None)
+    dev = 0 if dev is None else dev
+    m = losses.MasterLoss(cuda_id=dev)
+    tr = args.train
+    if tr.get('l1', False):
+        m.add(losses.L1(cuda_id=dev, lambda_=tr.get('l1_lambda', 1.)))
+    if tr.get('l2', False):
+        m.add(losses.L2(cuda_id=dev, lambda_=tr.get('l2_lambda', 1.)))
+    if tr.get('ssim', False):
+        l = losses.NegativeSsim(cuda_id=dev, lambda_=tr.get('ssim_lambda', 1.))
+        l.set_window_size(tr.get('ssim_window_s', 11))
+        m.add(l)
+    for k in ('l2sum', 'charbonnier', 'boundpred', 'local_moments', 'img_grad', 'norm_img_grad',
+              'laplace', 'norm_laplace', 'loc_var', 'norm_loc_var', 'hist', 'kde', 'ce', 'w_sparsity'):
+        if tr.get(k, False):
+            raise NotImplementedError(f"loss term --{k} is outside the libsrhip hot path")
+    assert len(m.n_holder) > 1, "no loss term enabled"
+    return m
+
+
+def optimizer_config(args):
+    """dict for srhip.train.Optimizer from the reference's G_optimizer_* / G_scheduler_* keys."""
+    tr = args.train
+    kind = tr['G_optimizer_type']
+    assert kind in constants.OPTIMIZERS, kind
+    cfg = dict(kind=kind, lr=tr['G_optimizer_lr'], wd=tr.get('G_optimizer_wd', 0.0))
+    if kind == constants.ADAM:
+        assert not tr.get('G_optimizer_amsgrad', False), "amsgrad is not on the hot path"
+        cfg.update(betas=(tr.get('G_optimizer_beta1', 0.9), tr.get('G_optimizer_beta2', 0.999)),
+                   eps=tr.get('G_optimizer_eps_adam', 1e-8))
+    else:
+        cfg.update(momentum=tr.get('G_optimizer_momentum', 0.9),
+                   nesterov=tr.get('G_optimizer_nesterov', True))
+    name = tr['G_scheduler_type']
+    assert name in constants.STEPSLR, name
+    if name == constants.MYSTEPLR:
+        cfg['scheduler'] = dict(type=name, step_size=tr['G_scheduler_step_size'],
+                                gamma=tr['G_scheduler_gamma'], min_lr=tr.get('G_scheduler_min_lr', 1e-4))
+    else:
+        cfg['scheduler'] = dict(type=name, milestones=tr['G_scheduler_milestones'],
+                                gamma=tr['G_scheduler_gamma'])
+    return cfg

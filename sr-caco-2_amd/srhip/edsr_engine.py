@@ -1,0 +1,156 @@
+"""EDSR-baseline forward / backward as a fixed sequence of libsrhip launches.
+
+Wiring of the reference's EDSR blocks (dlib/models/network_nlsn.py:38-128 blocks,
+:355-369 forward without the attention modules; sizes from
+dlib/utils/utils_init_default_args.py:37-50): head conv 1->F, N x ResBlock
+(conv-ReLU-conv, *res_scale, +x), conv + long skip, Upsampler (conv F->4F +
+PixelShuffle(2) per octave), tail conv F->1.  NHWC throughout; ReLU, res_scale
+and both residual adds are conv epilogues, the ReLU mask is the epilogue of the
+data-gradient conv, pixel shuffles are index kernels.
+"""
+import math
+
+import torch
+
+from . import ops
+from .swinir_engine import _Bufs
+
+
+class EDSREngine:
+    def __init__(self, net):
+        self.net = net
+        self.F = net.n_feats
+        self.nb = net.n_resblocks
+        self.stages = int(math.log2(net.scale))
+        self.bufs = _Bufs()
+        self.derived = _Bufs()
+        self.prepared = False
+        self.saved = None
+
+    def invalidate(self):
+        self.prepared = False
+
+    def bucket_prefixes(self):
+        """EDSR-baseline has 1.4-1.7 M parameters (5.5-6.7 MB): one gradient bucket."""
+        return [["head.", "body.", "tail."]]
+
+    def _body_convs(self):
+        net = self.net
+        for k in range(self.nb):
+            yield f"b{k}.0", net.body[k].body[0]
+            yield f"b{k}.2", net.body[k].body[2]
+        yield "bend", net.body[self.nb]
+        for i in range(self.stages):
+            yield f"up{i}", net.tail[0][2 * i]
+
+    def prepare(self):
+        D = self.derived
+        dev = self.net.head[0].weight.device
+        for name, conv in self._body_convs():
+            co, ci = conv.weight.shape[:2]
+            ops.pack_conv_weight(conv.weight.data, D.get(name + ".wp", 9, co, ci, device=dev),
+                                 D.get(name + ".wpt", 9, ci, co, device=dev))
+        self.prepared = True
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, dp=None, save=True):
+        """x [B,H,W] -> [B,1,s*H,s*W]."""
+        if not self.prepared:
+            self.prepare()
+        net, F, D = self.net, self.F, self.derived
+        B, H, W = x.shape
+        dev = x.device
+        tag = "t" if save else "e"
+
+        def buf(name, *shape):
+            return self.bufs.get(f"{tag}.{name}", *shape, device=dev)
+
+        f0 = buf("f0", B, H, W, F)
+        ops.conv3x3_cin1_fwd(x, net.head[0].weight.data, net.head[0].bias.data, F, out=f0)
+        r = f0
+        blocks = []
+        rs = float(net.res_scale)
+        for k in range(self.nb):
+            kk = k if save else k % 2
+            a = buf(f"a{kk if save else 0}", B, H, W, F)
+            ops.conv3x3(r, D.d[f"b{k}.0.wp"], net.body[k].body[0].bias.data, F, out=a, epi=1)
+            rn = buf(f"r{kk}", B, H, W, F)
+            ops.conv3x3(a, D.d[f"b{k}.2.wp"], net.body[k].body[2].bias.data, F, out=rn, epi=2, R=r,
+                        alpha=rs)
+            if save:
+                blocks.append((r, a))
+            r = rn
+        rb = buf("rb", B, H, W, F)
+        ops.conv3x3(r, D.d["bend.wp"], net.body[self.nb].bias.data, F, out=rb, epi=2, R=f0)
+        u, h, w = rb, H, W
+        ups = []
+        for i in range(self.stages):
+            c = buf(f"c{i}", B, h, w, 4 * F)
+            ops.conv3x3(u, D.d[f"up{i}.wp"], net.tail[0][2 * i].bias.data, 4 * F, out=c)
+            un = buf(f"u{i}", B, 2 * h, 2 * w, F)
+            ops.pixel_shuffle(c, 2, nhwc_out=True, out=un)
+            if save:
+                ups.append(u)
+            u, h, w = un, 2 * h, 2 * w
+        y = torch.empty(B, h, w, device=dev) if not save else buf("y", B, h, w)
+        ops.conv3x3_cout1_fwd(u, net.tail[1].weight.data, net.tail[1].bias.data, out=y)
+        if save:
+            self.saved = dict(x=x, f0=f0, blocks=blocks, r_last=r, ups=ups, u_last=u, B=B, H=H, W=W)
+        return y.view(B, 1, h, w)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dy, grads, need_dx=False, on_layer_done=None):
+        sv = self.saved
+        assert sv is not None, "backward() without a saved forward"
+        net, F, D = self.net, self.F, self.derived
+        B, H, W = sv["B"], sv["H"], sv["W"]
+        dev = dy.device
+        rs = float(net.res_scale)
+
+        def buf(name, *shape):
+            return self.bufs.get("g." + name, *shape, device=dev)
+
+        def G(name):
+            return grads[name]
+
+        s = net.scale
+        dy = dy.reshape(B, H * s, W * s).contiguous()
+        # tail conv F->1: weight grad = 1-channel wgrad kernel with the roles of
+        # x / dy swapped and flipped taps; data grad = 1-channel fwd kernel, flipped
+        ops.conv3x3_cin1_wgrad(dy, sv["u_last"], G("tail.1.weight"), None, flip=True)
+        ops.sum_into(dy, G("tail.1.bias"))
+        h, w = H * s, W * s
+        du = buf(f"du{self.stages}", B, h, w, F)
+        ops.conv3x3_cin1_fwd(dy, net.tail[1].weight.data, None, F, out=du, flip=True)
+        for i in reversed(range(self.stages)):
+            h, w = h // 2, w // 2
+            dc = buf(f"dc{i}", B, h, w, 4 * F)
+            ops.pixel_shuffle(du, 2, nhwc_out=True, inverse=True, out=dc)
+            ops.conv3x3_wgrad(dc, sv["ups"][i], G(f"tail.0.{2 * i}.weight"), G(f"tail.0.{2 * i}.bias"))
+            du = buf(f"du{i}", B, h, w, F)
+            ops.conv3x3(dc, D.d[f"up{i}.wpt"], None, F, out=du)
+        drb = du                                             # grad wrt rb (= also grad wrt f0 via the skip)
+        ops.conv3x3_wgrad(drb, sv["r_last"], G(f"body.{self.nb}.weight"), G(f"body.{self.nb}.bias"))
+        ga, gb, da = buf("ga", B, H, W, F), buf("gb", B, H, W, F), buf("da", B, H, W, F)
+        g = ga
+        ops.conv3x3(drb, D.d["bend.wpt"], None, F, out=g)
+        for k in reversed(range(self.nb)):
+            r_in, a = sv["blocks"][k]
+            p = f"body.{k}.body."
+            other = gb if g is ga else ga
+            # r_out = rs*(conv2(a)+b2) + r_in ;  a = relu(conv1(r_in)+b1)
+            ops.conv3x3_wgrad(g, a, G(p + "2.weight"), G(p + "2.bias"))
+            ops.conv3x3(g, D.d[f"b{k}.2.wpt"], None, F, out=da, epi=4, R=a)     # * (a > 0)
+            if rs != 1.0:
+                ops.axpby(G(p + "2.weight"), G(p + "2.weight"), 0.0, rs)
+                ops.axpby(G(p + "2.bias"), G(p + "2.bias"), 0.0, rs)
+                ops.axpby(da, da, 0.0, rs)
+            ops.conv3x3_wgrad(da, r_in, G(p + "0.weight"), G(p + "0.bias"))
+            ops.conv3x3(da, D.d[f"b{k}.0.wpt"], None, F, out=other, epi=2, R=g)  # + skip gradient
+            g = other
+        ops.axpby(g, drb, 1.0, 1.0)                          # long skip: rb = conv(body) + f0
+        ops.conv3x3_cin1_wgrad(sv["x"], g, G("head.0.weight"), G("head.0.bias"))
+        if need_dx:
+            wflip = net.head[0].weight.data.flip(2, 3).reshape(1, F, 3, 3).contiguous()
+            return ops.conv3x3_cout1_fwd(g, wflip, None)
+        return None

@@ -312,6 +312,14 @@ def ssim_loss(pred, target, ws, lam=1.0, grad=None, loss_out=None, grad_accum=Fa
 
 
 # ------------------------------------------------------------------ metrics
+def tensor2uint82float(x):
+    _chk(x)
+    x = x.float().contiguous()
+    out = torch.empty_like(x)
+    call("srhip_tensor2uint82float", _p(x), _p(out), x.numel(), _st())
+    return out
+
+
 def metrics_psnr_family(E, Hh, border, thresholds=(), inputs_are_u8=False):
     """Returns fp64 [B, 1+len(thresholds), 4] = PSNR, PSNR_Y, MSE, NRMSE."""
     _chk(E, Hh)
@@ -361,3 +369,10 @@ def nonfinite_flag(x, flag):
 def axpby(y, x, a, b):
     _chk(x, y)
     call("srhip_axpby", _p(y), _p(x), y.numel(), float(a), float(b), _st())
+
+
+def sum_into(x, out):
+    """out[0] = sum(x)."""
+    _chk(x, out)
+    ws = SCRATCH.get("loss_ws", 2048, torch.float64, x.device)
+    call("srhip_sum", _p(x), x.numel(), _p(out), _p(ws), _st())

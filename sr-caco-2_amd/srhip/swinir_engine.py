@@ -53,6 +53,21 @@ class SwinIREngine:
         self.prepared = False
         self.saved = None
 
+    def bucket_prefixes(self):
+        """Gradient buckets in backward-completion order: one per RSTB layer (the
+        tail -- norm / conv_after_body / upsample -- rides with the last layer), the
+        head (conv_first / patch_embed) last.  backward() calls on_layer_done(i)
+        when bucket i is complete, for every bucket but the last."""
+        n = len(self.net.layers)
+        out = []
+        for li in reversed(range(n)):
+            pf = [f"layers.{li}."]
+            if li == n - 1:
+                pf += ["norm.", "conv_after_body.", "upsample."]
+            out.append(pf)
+        out.append(["conv_first.", "patch_embed."])
+        return out
+
     # ------------------------------------------------------------------ weights
     def invalidate(self):
         self.prepared = False

@@ -99,6 +99,24 @@ class Optimizer:
         self.sched_count += 1
 
 
+def allreduce_range(flat_grad, lo, hi, group=None, comm_stream=None):
+    """Sum-all-reduce flat_grad[lo:hi] over the data-parallel group.  On the GPU
+    the collective (RCCL) is enqueued on ``comm_stream`` behind an event recorded
+    on the compute stream, so it overlaps the rest of backward; the optimizer
+    later waits on the stream.  Averaging is folded into the optimizer's
+    ``gscale``.  (CPU tensors + gloo take the same path without streams: used by
+    the world_size-2 tests.)"""
+    import torch.distributed as dist
+    if comm_stream is None:
+        dist.all_reduce(flat_grad[lo:hi], group=group)
+        return
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    comm_stream.wait_event(ev)
+    with torch.cuda.stream(comm_stream):
+        dist.all_reduce(flat_grad[lo:hi], group=group)
+
+
 class TrainStep:
     """loss_terms: sequence of ('l1', lam) | ('l2', lam) | ('ssim', lam, window)
     (MasterLoss = their sum, dlib/loss/master.py:46-56)."""
@@ -120,27 +138,14 @@ class TrainStep:
         self.dy = None
 
     def _make_buckets(self):
-        """One bucket per RSTB layer, in the order backward finishes them; the
-        tail (norm / conv_after_body / upsample) rides with the last layer, the
-        head (conv_first / patch_embed) is its own final bucket."""
-        n = len(self.net.layers)
-        out = []
-        for li in reversed(range(n)):
-            pf = [f"layers.{li}."]
-            if li == n - 1:
-                pf += ["norm.", "conv_after_body.", "upsample."]
-            out.append(self.fp.range_of(pf))
-        out.append(self.fp.range_of(["conv_first.", "patch_embed."]))
-        return out
+        """Gradient buckets in the order backward completes them (the engine names
+        them by parameter prefix); each is one contiguous range of the flat
+        gradient buffer."""
+        return [self.fp.range_of(pf) for pf in self.net.engine.bucket_prefixes()]
 
     def _allreduce_bucket(self, i):
-        import torch.distributed as dist
         lo, hi = self.buckets[i]
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.comm_stream.wait_event(ev)
-        with torch.cuda.stream(self.comm_stream):
-            dist.all_reduce(self.fp.grad[lo:hi], group=self.pg)
+        allreduce_range(self.fp.grad, lo, hi, self.pg, self.comm_stream)
 
     def loss_and_grad(self, y, target):
         """MasterLoss value(s) + d loss / d y through the fused loss kernels."""

@@ -1,0 +1,216 @@
+"""GPU parity: EDSR-baseline (reference blocks) and the dlib.loss / dlib.metrics /
+ModelPlain surfaces, against the reference goldens and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import sr_oracle as O  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiu" else z[k]) for k in z.files}
+
+
+def sub(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8])
+def test_edsr_small_fwd_bwd_vs_reference_golden(scale):
+    from dlib.models.network_edsr_liif import EDSR_LIIF
+    g = load(f"g2_edsr_x{scale}")
+    s, nb, nf = [int(v) for v in g["cfg"]]
+    net = EDSR_LIIF(scale=s, n_resblocks=nb, n_feats=nf, res_scale=float(g["res_scale"]))
+    net.load_state_dict(sub(g, "sd/"), strict=True)
+    net = net.cuda().train()
+    x = g["x"].cuda().requires_grad_(True)
+    y = net(x)
+    assert (y.detach().cpu() - g["y"]).abs().max() <= 1e-5
+    y.abs().mean().backward()
+    for k, p in net.named_parameters():
+        ref = g["grad/" + k]
+        e = (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        assert e <= 1e-3, f"grad {k}: rel err {e:.2e}"
+    # d loss / d input against the oracle
+    sd = {k: v.clone() for k, v in sub(g, "sd/").items()}
+    xo = g["x"].clone().requires_grad_(True)
+    cfg = O.edsr_config(upscale=s, n_feats=nf, n_resblocks=nb, res_scale=float(g["res_scale"]))
+    O.edsr_forward(sd, xo, cfg).abs().mean().backward()
+    assert (x.grad.cpu() - xo.grad).abs().max() <= 1e-3 * xo.grad.abs().max()
+
+
+def test_edsr_full_size_forward_vs_reference_golden():
+    from dlib.models.network_edsr_liif import EDSR_LIIF
+    g = load("g2b_edsr_full")
+    for scale in (4, 8):
+        cfg = O.edsr_config(upscale=scale)
+        net = EDSR_LIIF(scale=scale)
+        net.load_state_dict(O.edsr_init_state_dict(cfg, seed=scale), strict=True)
+        net = net.cuda().eval()
+        with torch.no_grad():
+            y = net(g[f"x{scale}/x"].cuda()).cpu()
+        assert (y - g[f"x{scale}/y"]).abs().mean() <= 1e-5
+    # config 2 shape: x4, LR 128 -> HR 512, oracle comparison incl. PSNR gate
+    cfg = O.edsr_config(upscale=4)
+    sd = O.edsr_init_state_dict(cfg, seed=4)
+    net = EDSR_LIIF(scale=4)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    x = torch.rand(1, 1, 128, 128, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        y = net(x.cuda()).cpu()
+        yo = O.edsr_forward(sd, x, cfg)
+    assert y.shape == (1, 1, 512, 512)
+    assert (y - yo).abs().mean() <= 1e-5
+    tgt = torch.rand(1, 1, 512, 512, generator=torch.Generator().manual_seed(6))
+    ps = lambda a: O.metric_psnr(O.tensor2uint82float(a), O.tensor2uint82float(tgt), 4)
+    assert (ps(y) - ps(yo)).abs().max() <= 0.01
+
+
+def test_dlib_loss_surface_vs_reference_golden():
+    from dlib import loss as L
+    from dlib import losses as L2mod
+    assert L2mod.MasterLoss is L.MasterLoss
+    g = load("g6_losses")
+    cases = {"l1": ([("l1", 1.0)], None), "l2_ssim19": ([("l2", 1.0), ("ssim", 5.0, 19)], None),
+             "l1_weighted": ([("l1", 1.0)], g["weight"]), "ssim11": ([("ssim", 1.0, 11)], None)}
+    for name, (terms, w) in cases.items():
+        m = L.MasterLoss(cuda_id=0)
+        for t in terms:
+            if t[0] == "l1":
+                m.add(L.L1(cuda_id=0, lambda_=t[1]))
+            elif t[0] == "l2":
+                m.add(L.L2(cuda_id=0, lambda_=t[1]))
+            else:
+                s = L.NegativeSsim(cuda_id=0, lambda_=t[1])
+                s.set_window_size(t[2])
+                m.add(s)
+        p = g["pred"].cuda().requires_grad_(True)
+        v = m(epoch=0, y_pred=p, y_target=g["target"].cuda(),
+              trg_per_pixel_weight=None if w is None else w.cuda(), model=None)
+        v.backward()
+        holder = torch.stack([h.detach().cpu().reshape(()) for h in m.l_holder])
+        assert (holder - g[name + "/l_holder"]).abs().max() <= 2e-4 * g[name + "/l_holder"].abs().max(), name
+        assert (p.grad.cpu() - g[name + "/grad"]).abs().max() <= 3e-4 * g[name + "/grad"].abs().max(), name
+        assert m.n_holder == list(g[name + "/names"])
+
+
+def test_dlib_metrics_surface_vs_reference_golden():
+    from dlib import metrics as M
+    from dlib.utils import utils_image
+    assert utils_image.mbatch_gpu_calculate_psnr is M.mbatch_gpu_calculate_psnr
+    g = load("g7_metrics")
+    a = M.tensor2uint82float(g["pred"].cuda())
+    b = M.tensor2uint82float(g["hr"].cuda())
+    assert torch.equal(a.cpu(), g["a"]) and torch.equal(b.cpu(), g["b"])
+    assert torch.equal(M.tensor2uint82float(g["corner"].cuda()).cpu(), g["corner_out"])
+    border = int(g["border"])
+    for th in (None, 4, 7, 10, 300):
+        roi = None if th is None else (b >= th).float()
+        tag = "noroi" if th is None else f"roi{th}"
+        for nm, fn, tol in (("psnr", M.mbatch_gpu_calculate_psnr, 1e-9), ("mse", M.mbatch_gpu_calculate_mse, 0),
+                            ("nrmse", M.mbatch_gpu_calculate_nrmse, 1e-12),
+                            ("ssim", M.mbatch_gpu_calculate_ssim, 5e-5)):
+            v = fn(a, b, border=border, roi=roi).cpu()
+            assert (v.double() - g[f"{nm}/{tag}"].double()).abs().max() <= tol, (nm, tag)
+    with pytest.raises(NotImplementedError):
+        M.mbatch_gpu_calculate_psnr(a, b, border, roi=(torch.rand_like(b) > 0.5).float())
+    sw = M.sweep(g["pred"].cuda(), g["hr"].cuda(), border, (4, 5, 6, 7, 8, 9, 10))
+    assert sw["psnr"].shape == (3, 8) and torch.equal(sw["mse"][:, 0].cpu(), g["mse/noroi"])
+
+
+class Args(dict):
+    __getattr__ = dict.get
+
+
+def tiny_args(opt="adam"):
+    from dlib.utils import constants
+    netG = {'net_type': constants.SWINIR, 'swinir_upscale': 8, 'swinir_in_chans': 1, 'swinir_img_size': 16,
+            'swinir_window_size': 8, 'swinir_img_range': 1.0, 'swinir_depths': [2, 2], 'swinir_embed_dim': 60,
+            'swinir_num_heads': [6, 6], 'swinir_mlp_ratio': 2,
+            'swinir_upsampler': constants.US_PIXEL_SHUFFLE_DIRECT,
+            'swinir_resi_connection': constants.R_CONNECTION_1CONV}
+    train = {'l1': True, 'G_optimizer_type': opt, 'G_optimizer_lr': 2e-4 if opt == "adam" else 0.01,
+             'G_optimizer_wd': 1e-4 if opt == "adam" else 0.0, 'G_scheduler_type': 'MyStepLR',
+             'G_scheduler_step_size': 30, 'G_scheduler_gamma': 0.5, 'G_scheduler_min_lr': 1e-4}
+    return Args(netG=netG, train=train, is_train=True)
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_model_plain_steps_match_oracle_training(tmp_path, opt):
+    """Two fused optimisation steps == two oracle (autograd + torch-semantics
+    optimizer) steps, parameter for parameter; checkpoint round trip."""
+    from dlib.models.select_model import define_model
+    args = tiny_args(opt)
+    args['outd'] = str(tmp_path)
+    model = define_model(args)
+    cfg = O.swinir_config(upscale=8, in_chans=1, img_size=16, window_size=8, depths=(2, 2), embed_dim=60,
+                          num_heads=(6, 6), mlp_ratio=2, drop_path_rate=0.0)
+    sd0 = O.swinir_init_state_dict(cfg, seed=9)
+    model.netG.load_state_dict(sd0, strict=True)
+    for b in model.netG.swin_blocks():
+        b.drop_prob = 0.0
+    model.init_train()
+    gen = torch.Generator().manual_seed(12)
+    batch = {'l_im': torch.rand(2, 1, 16, 16, generator=gen), 'h_im': torch.rand(2, 1, 128, 128, generator=gen)}
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask")
+               else v) for k, v in sd0.items()}
+    names = [k for k, v in sdo.items() if v.requires_grad]
+    st = {k: (torch.zeros_like(sdo[k]), torch.zeros_like(sdo[k])) for k in names}
+    for step in range(2):
+        model.feed_data(batch)
+        model.optimize_parameters(epoch=0, current_step=step)
+        model.update_learning_rate()
+        lo = O.loss_l1(O.swinir_forward(sdo, batch['l_im'], cfg), batch['h_im'])
+        for k in names:
+            sdo[k].grad = None
+        lo.backward()
+        with torch.no_grad():
+            for k in names:
+                if opt == "adam":
+                    O.adam_step(sdo[k], sdo[k].grad, st[k][0], st[k][1], step + 1, 2e-4, wd=1e-4)
+                else:
+                    O.sgd_nesterov_step(sdo[k], sdo[k].grad, st[k][0], step == 0, 0.01)
+        assert abs(model.current_log()['G_loss'] - lo.item()) <= 1e-5
+    assert model.check_finite()
+    for k, p in model.netG.named_parameters():
+        e = (p.detach().cpu() - sdo[k].detach()).abs().max().item()
+        assert e <= 2e-6, f"{k}: {e}"
+    # reference-format checkpoint round trip
+    path = model.save(2)
+    raw = torch.load(path)
+    assert list(raw.keys()) == list(sd0.keys())
+    model.feed_data(batch)
+    model.test()
+    e1 = model.current_visuals()['E'].clone()
+    model.netG.load_state_dict(sd0)
+    model.load_network(path, model.netG)
+    model.test()
+    assert torch.equal(model.current_visuals()['E'], e1)
+
+
+def test_model_plain_nonfinite_loss_skips_update(tmp_path):
+    from dlib.models.select_model import define_model
+    args = tiny_args("sgd")
+    args['outd'] = str(tmp_path)
+    model = define_model(args)
+    model.init_train()
+    before = model.step_fn.fp.flat.clone()
+    bad = {'l_im': torch.rand(2, 1, 16, 16), 'h_im': torch.full((2, 1, 128, 128), float('nan'))}
+    model.feed_data(bad)
+    model.optimize_parameters(0, 0)
+    assert not model.check_finite()
+    assert torch.equal(model.step_fn.fp.flat, before)        # update skipped on the device
