@@ -115,10 +115,11 @@ int srhip_bias_grad(const float* dbiasT, float* dtable, int heads, void* stream)
  * roll, window partition/reverse and the shift mask are address math. */
 int srhip_window_attention_fwd(const float* qkv, float* out, const float* biasT, int B, int H, int W,
                                int C, int heads, int shift, void* stream);
-/* dbiasT must be zero on entry. */
+/* dbiasT must be zero on entry; workspace floats: srhip_window_attention_bwd_ws(). */
+long srhip_window_attention_bwd_ws(int B, int H, int W, int heads);
 int srhip_window_attention_bwd(const float* qkv, const float* dout, float* dqkv, const float* biasT,
-                               const float* biasN, float* dbiasT, int B, int H, int W, int C, int heads,
-                               int shift, void* stream);
+                               const float* biasN, float* dbiasT, float* workspace, int B, int H, int W,
+                               int C, int heads, int shift, void* stream);
 
 /* ---- 1-channel edge convolutions -------------------------------------------- */
 /* x [B][H][W] -> y NHWC [.][Co]; flip=1 uses flipped taps (= data gradient of

@@ -21,6 +21,13 @@ int sr_fail(int code, const char* fmt, ...);
 
 static inline int sr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Neutral operands for optional per-row prologue data.  A conditional load whose
+// result merges with a constant forces the compiler to wait for the load at the
+// branch join (s_waitcnt vmcnt(0) in the middle of a prefetch); selecting the
+// ADDRESS instead keeps the load unconditional and the prefetch asynchronous.
+//   [0..1] = {mean 0, rstd 1}   [2..3] = {0, 0}   [1] = scale 1
+__device__ const float k_sr_neutral[4] = {0.f, 1.f, 0.f, 0.f};
+
 // ---- wave-level reductions (wave = 64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -61,14 +61,14 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
   }
 
   f32x4 ra[A_IT], rb[B_IT];
-  float rmu[A_IT], rrs[A_IT];
+  float2 rst[A_IT];               // {mean, rstd} of the A row (or the neutral pair)
 
   auto load_a = [&](int kc) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int idx = tid + it * 256;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      rmu[it] = 0.f; rrs[it] = 1.f;
+      const float* sp = k_sr_neutral;
       if (A_N % 256 == 0 || idx < A_N) {
         const int row = idx / KV, c4 = idx - row * KV;
         const int gk = kc * BK + c4 * 4;
@@ -81,10 +81,11 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
           const int gm = m0 + row;
           if (gm < p.M && gk < p.K) {
             v = *(const f32x4*)(p.A + (long)gm * p.lda + gk);
-            if (p.a_mode == 1) { rmu[it] = p.ln_stats[2 * gm]; rrs[it] = p.ln_stats[2 * gm + 1]; }
+            if (p.a_mode == 1) sp = p.ln_stats + 2 * gm;
           }
         }
       }
+      if (!CONV) rst[it] = *(const float2*)sp;   // unconditional load (see k_sr_neutral)
       ra[it] = v;
     }
   };
@@ -112,8 +113,8 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
         f32x4 v = ra[it];
         if (!CONV) {
           if (p.a_mode == 1) {          // LayerNorm prologue: (x-mean)*rstd
-            v.x = (v.x - rmu[it]) * rrs[it]; v.y = (v.y - rmu[it]) * rrs[it];
-            v.z = (v.z - rmu[it]) * rrs[it]; v.w = (v.w - rmu[it]) * rrs[it];
+            const float mu = rst[it].x, rs = rst[it].y;
+            v.x = (v.x - mu) * rs; v.y = (v.y - mu) * rs; v.z = (v.z - mu) * rs; v.w = (v.w - mu) * rs;
           } else if (p.a_mode == 2) {   // GELU prologue
             v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
           }

@@ -18,6 +18,7 @@
 // LDS holds the chunk token-major ([32 tokens][192 cols]) exactly as it lies in
 // HBM; a fragment is then one ds_read_b32 per MFMA with consecutive lanes on
 // consecutive columns (conflict free); lane half h takes token 2s+h.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -45,7 +46,8 @@ __device__ __forceinline__ void tn_body(const TnArgs& p, const int s, const int 
   const int dy = p.conv ? tap / 3 - 1 : 0, dx = p.conv ? tap % 3 - 1 : 0;
 
   f32x4 ra[A_IT], rb[B_IT];
-  float rsa[A_IT], rmu[B_IT], rrs[B_IT];
+  float rsa[A_IT];
+  float2 rst[B_IT];               // {mean, rstd} of the B row (or a neutral pair)
 
   auto load = [&](int mc) {
 #pragma unroll
@@ -54,11 +56,10 @@ __device__ __forceinline__ void tn_body(const TnArgs& p, const int s, const int 
       const int row = idx / (BI / 4), c4 = idx - row * (BI / 4);
       const int gm = mc + row, gc = c4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      rsa[it] = 1.f;
-      if (gm < m_end && gc < ivalid) {
-        v = *(const f32x4*)(p.A + (long)gm * p.lda + i0 + gc);
-        if (p.a_rowscale) rsa[it] = p.a_rowscale[gm / p.a_rowscale_rows];
-      }
+      const bool in = gm < m_end && gc < ivalid;
+      if (in) v = *(const f32x4*)(p.A + (long)gm * p.lda + i0 + gc);
+      const float* sp = (in && p.a_rowscale) ? p.a_rowscale + gm / p.a_rowscale_rows : k_sr_neutral + 1;
+      rsa[it] = *sp;               // unconditional load (see k_sr_neutral)
       ra[it] = v;
     }
 #pragma unroll
@@ -67,7 +68,7 @@ __device__ __forceinline__ void tn_body(const TnArgs& p, const int s, const int 
       const int row = idx / (BJ / 4), c4 = idx - row * (BJ / 4);
       const int gm = mc + row, gc = c4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      rmu[it] = 0.f; rrs[it] = 1.f;
+      const float* sp = k_sr_neutral;
       if (gm < m_end && gc < jvalid) {
         long src = gm;
         bool ok = true;
@@ -80,11 +81,12 @@ __device__ __forceinline__ void tn_body(const TnArgs& p, const int s, const int 
         }
         if (ok) {
           v = *(const f32x4*)(p.B + src * p.ldb + j0 + gc);
-          if (p.b_mode == 1) { rmu[it] = p.ln_stats[2 * src]; rrs[it] = p.ln_stats[2 * src + 1]; }
+          if (p.b_mode == 1) sp = p.ln_stats + 2 * src;
         } else {
-          rrs[it] = 0.f;   // keep padded pixels at exactly 0 under any prologue
+          sp = k_sr_neutral + 2;   // {0,0}: padded pixels stay exactly 0 under any prologue
         }
       }
+      rst[it] = *(const float2*)sp;   // unconditional load (see k_sr_neutral)
       rb[it] = v;
     }
   };
@@ -102,8 +104,8 @@ __device__ __forceinline__ void tn_body(const TnArgs& p, const int s, const int 
       const int row = idx / (BJ / 4);
       f32x4 v = rb[it];
       if (p.b_mode == 1) {
-        v.x = (v.x - rmu[it]) * rrs[it]; v.y = (v.y - rmu[it]) * rrs[it];
-        v.z = (v.z - rmu[it]) * rrs[it]; v.w = (v.w - rmu[it]) * rrs[it];
+        const float mu = rst[it].x, rs = rst[it].y;
+        v.x = (v.x - mu) * rs; v.y = (v.y - mu) * rs; v.z = (v.z - mu) * rs; v.w = (v.w - mu) * rs;
       } else if (p.b_mode == 2) {
         // rows past the slice end hold zeros and gelu(0) = 0
         v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
@@ -135,19 +137,30 @@ __device__ __forceinline__ void tn_body(const TnArgs& p, const int s, const int 
       for (int t = 0; t < TK; ++t) cs += As[t * BI + tid];
       colsum += cs;
     }
-#pragma unroll 4
+    // fragments are fetched one token pair ahead of the MFMAs that use them
+    // (register double buffer), so LDS latency hides behind the matrix pipe
+    float fa[2][WI], fb[2][WJ];
+    const float* ar0 = As + h * BI + wi * WI * 32 + r;
+    const float* br0 = Bs + h * BJ + wj * WJ * 32 + r;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) fa[0][i] = ar0[i * 32];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) fb[0][j] = br0[j * 32];
+#pragma unroll
     for (int sp = 0; sp < TK / 2; ++sp) {
-      float fa[WI], fb[WJ];
-      const float* ar = As + (2 * sp + h) * BI + wi * WI * 32 + r;
-      const float* br = Bs + (2 * sp + h) * BJ + wj * WJ * 32 + r;
+      const int cur = sp & 1, nxt = cur ^ 1;
+      if (sp + 1 < TK / 2) {
 #pragma unroll
-      for (int i = 0; i < WI; ++i) fa[i] = ar[i * 32];
+        for (int i = 0; i < WI; ++i) fa[nxt][i] = ar0[2 * (sp + 1) * BI + i * 32];
 #pragma unroll
-      for (int j = 0; j < WJ; ++j) fb[j] = br[j * 32];
+        for (int j = 0; j < WJ; ++j) fb[nxt][j] = br0[2 * (sp + 1) * BJ + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
 #pragma unroll
       for (int i = 0; i < WI; ++i)
 #pragma unroll
-        for (int j = 0; j < WJ; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < WJ; ++j) acc[i][j] = mfma32(fa[cur][i], fb[cur][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -168,7 +181,7 @@ __device__ __forceinline__ void tn_body(const TnArgs& p, const int s, const int 
 }
 
 template <int WI, int WJ>
-__global__ void __launch_bounds__(256) k_tn(TnArgs p) {
+__global__ void __launch_bounds__(256, 2) k_tn(TnArgs p) {
   tn_body<WI, WJ>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -181,7 +194,7 @@ struct TnGroup {
   int n;
 };
 template <int WI, int WJ>
-__global__ void __launch_bounds__(256) k_tn_grouped(TnGroup g) {
+__global__ void __launch_bounds__(256, 2) k_tn_grouped(TnGroup g) {
   const int t = blockIdx.y;
   int k = 0;
 #pragma unroll
@@ -208,7 +221,7 @@ int sr_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
   const int ti = pick_tile(NI, &wi), tj = pick_tile(NJ, &wj);
   const long tiles = (long)sr_cdiv(NI, ti) * sr_cdiv(NJ, tj) * (conv ? 9 : 1);
   // one block per CU and more (k_tn<3,3> holds 1 block/CU); at least 128 tokens each
-  long s = (512 + tiles - 1) / tiles;
+  long s = 512 / tiles;                  // at most two whole rounds of 256 blocks
   const long smax = (M + 127) / 128;
   if (s > smax) s = smax;
   if (s > 256) s = 256;
@@ -219,9 +232,12 @@ int sr_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
 }
 
 int sr_tn_group_plan(int M, int ntiles, int* S) {
-  // whole rounds of 256 blocks (1 block per CU: k_tn<3,3> needs > 256 registers)
-  long s = 256 / ntiles;
-  if (s * ntiles < 256) s = (256 + ntiles - 1) / ntiles;
+  // one whole round of 512 blocks (2 blocks per CU, so one block's staging and
+  // index math overlap the other's MFMAs); env SRHIP_TN_BLOCKS overrides
+  const char* e = getenv("SRHIP_TN_BLOCKS");
+  const long target = e ? atol(e) : 512;
+  long s = target / ntiles;
+  if (s < 1) s = 1;
   const long smax = (M + 127) / 128;
   if (s > smax) s = smax;
   if (s > 256) s = 256;

@@ -157,41 +157,42 @@ __global__ void __launch_bounds__(256) k_wattn_fwd(const float* __restrict__ qkv
   }
 }
 
-// Backward: recompute P in both orientations (query-on-lane for dQ and the
-// bias gradient, key-on-lane for dK and dV) so that every product reduces
-// over an accumulator-row index and no 64x64 tile is transposed.
+// ---------------------------------------------------------------------------
+// Backward as TWO kernels of <= 256 registers (2 waves per SIMD, inputs staged
+// coalesced through LDS), instead of the single 512-register kernel above:
+//   bwd_q : query on the lane  -> softmax stats (to a workspace), dQ, d(bias)
+//   bwd_kv: key on the lane    -> dK, dV (reads the stats)
+// The four waves of a bwd_q block work on four windows of the SAME head and sum
+// their bias-gradient tiles in LDS: one set of global atomics per block.
+// ---------------------------------------------------------------------------
 template <int D>
-__global__ void __launch_bounds__(256) k_wattn_bwd(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                   float* __restrict__ dqkv, const float* __restrict__ biasT,
-                                                   const float* __restrict__ biasN, float* __restrict__ dbiasT,
-                                                   long total, int H, int W, int C, int heads, int shift,
-                                                   float scale) {
+__global__ void __launch_bounds__(256, 2) k_wattn_bwd_q(
+    const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
+    const float* __restrict__ biasT, float* __restrict__ dbiasT, float* __restrict__ stats, int nwin,
+    int H, int W, int C, int heads, int shift, float scale) {
   constexpr int HD = D / 2;
-  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const long gid = blockIdx.x * 4L + (threadIdx.x >> 6);
-  if (gid >= total) return;
-  const WaGeom g = wa_decode(gid, heads, W / 8, H / 8, shift);
-  const int C3 = 3 * C;
-  const int mytok = wa_token(g, lane, H, W, shift);
-  const float lane_mask = (g.last_col && h != ((lane >> 2) & 1)) ? -100.f : 0.f;
-
-  // row-pattern fragments (row = window position r+32*blk, this lane half's 15 dims)
-  float qf[2][HD], kf[2][HD], vf[2][HD], gf[2][HD];
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    const int tok = __shfl(mytok, r + 32 * blk, 64);
-    const float* base = qkv + (long)tok * C3 + g.head * D + h * HD;
-    const float* gb = dout + (long)tok * C + g.head * D + h * HD;
-#pragma unroll
-    for (int t = 0; t < HD; ++t) {
-      qf[blk][t] = base[t]; kf[blk][t] = base[C + t]; vf[blk][t] = base[2 * C + t];
-      gf[blk][t] = gb[t];
-    }
-  }
-  float mrow[2], lrow[2], drow[2];   // per query (r+32*qb): max, 1/sum, delta
-
-  // ---------------- pass 1: query on the lane ----------------
-  {
+  __shared__ __attribute__((aligned(16))) float smem[4096 + 4 * 2 * 64 * D];
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+  float* dbs = smem;                                   // [64 key][64 query]
+  float* As = smem + 4096 + wv * (2 * 64 * D);
+  float* Bs = As + 64 * D;
+  for (int i = threadIdx.x; i < 4096; i += 256) dbs[i] = 0.f;
+  __syncthreads();
+  const int head = blockIdx.x % heads;
+  const int widx = (blockIdx.x / heads) * 4 + wv;
+  if (widx < nwin) {
+    const int nWx = W / 8, nWy = H / 8;
+    WaGeom g;
+    g.head = head;
+    g.wx = widx % nWx;
+    g.wy = (widx / nWx) % nWy;
+    g.b = widx / (nWx * nWy);
+    g.last_row = shift > 0 && g.wy == nWy - 1;
+    g.last_col = shift > 0 && g.wx == nWx - 1;
+    const int C3 = 3 * C;
+    const int mytok = wa_token(g, lane, H, W, shift);
+    const float lane_mask = (g.last_col && h != ((lane >> 2) & 1)) ? -100.f : 0.f;
+    const int fo0 = r * D + h * HD, fo1 = (r + 32) * D + h * HD;
     f32x16 T[2][2], G[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -199,17 +200,32 @@ __global__ void __launch_bounds__(256) k_wattn_bwd(const float* __restrict__ qkv
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int q = 0; q < 16; ++q) { T[a][b][q] = 0.f; G[a][b][q] = 0.f; }
-#pragma unroll
-    for (int t = 0; t < HD; ++t)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          T[kb][qb] = mfma32(kf[kb][t], qf[qb][t], T[kb][qb]);   // S^T
-          G[kb][qb] = mfma32(vf[kb][t], gf[qb][t], G[kb][qb]);   // dP^T = V.dO^T
-        }
-    const float* bt = biasT + (long)g.head * 4096;
-    float* dbt = dbiasT + (long)g.head * 4096;
+    // S^T = K.Q^T
+    wa_stage<D>(As, qkv + C + head * D, C3, mytok, lane);
+    wa_stage<D>(Bs, qkv + head * D, C3, mytok, lane);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 3
+    for (int t = 0; t < HD; ++t) {
+      const float k0 = As[fo0 + t], k1 = As[fo1 + t], q0 = Bs[fo0 + t], q1 = Bs[fo1 + t];
+      T[0][0] = mfma32(k0, q0, T[0][0]); T[0][1] = mfma32(k0, q1, T[0][1]);
+      T[1][0] = mfma32(k1, q0, T[1][0]); T[1][1] = mfma32(k1, q1, T[1][1]);
+    }
+    // dP^T = V.dO^T
+    __builtin_amdgcn_wave_barrier();
+    wa_stage<D>(As, qkv + 2 * C + head * D, C3, mytok, lane);
+    wa_stage<D>(Bs, dout + head * D, C, mytok, lane);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 3
+    for (int t = 0; t < HD; ++t) {
+      const float v0 = As[fo0 + t], v1 = As[fo1 + t], g0 = Bs[fo0 + t], g1 = Bs[fo1 + t];
+      G[0][0] = mfma32(v0, g0, G[0][0]); G[0][1] = mfma32(v0, g1, G[0][1]);
+      G[1][0] = mfma32(v1, g0, G[1][0]); G[1][1] = mfma32(v1, g1, G[1][1]);
+    }
+    // K again (column pattern for dQ)
+    __builtin_amdgcn_wave_barrier();
+    wa_stage<D>(As, qkv + C + head * D, C3, mytok, lane);
+    __builtin_amdgcn_wave_barrier();
+    const float* bt = biasT + (long)head * 4096;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       float mx = -3.0e38f;
@@ -246,8 +262,11 @@ __global__ void __launch_bounds__(256) k_wattn_bwd(const float* __restrict__ qkv
           dl += T[kb][qb][q] * G[kb][qb][q];
         }
       dl += __shfl_xor(dl, 32, 64);
-      mrow[qb] = mx; lrow[qb] = inv; drow[qb] = dl;
-      // dS^T (w.r.t. the biased, scaled logits), bias gradient, dQ
+      const int qtok = __shfl(mytok, r + 32 * qb, 64);
+      if (h == 0) {                                // softmax statistics of query r+32*qb
+        float* sp = stats + ((long)qtok * heads + head) * 3;
+        sp[0] = mx; sp[1] = inv; sp[2] = dl;
+      }
       f32x16 dQ;
 #pragma unroll
       for (int q = 0; q < 16; ++q) dQ[q] = 0.f;
@@ -257,70 +276,106 @@ __global__ void __launch_bounds__(256) k_wattn_bwd(const float* __restrict__ qkv
         for (int q = 0; q < 16; ++q) {
           const int key = mfma_row(q, lane) + 32 * kb;
           const float ds = T[kb][qb][q] * (G[kb][qb][q] - dl);
-          atomicAdd(dbt + key * 64 + r + 32 * qb, ds);
-          const int tok = __shfl(mytok, key, 64);
-          const float kc = r < D ? qkv[(long)tok * C3 + C + g.head * D + r] : 0.f;
+          atomicAdd(dbs + key * 64 + r + 32 * qb, ds);          // LDS atomic
+          const float kc = r < D ? As[key * D + r] : 0.f;
           dQ = mfma32(ds, kc, dQ);
         }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int tok = __shfl(mytok, mfma_row(q, lane) + 32 * qb, 64);
-        if (r < D) dqkv[(long)tok * C3 + g.head * D + r] = dQ[q] * scale;
+        if (r < D) dqkv[(long)tok * C3 + head * D + r] = dQ[q] * scale;
       }
     }
   }
+  __syncthreads();
+  float* dbt = dbiasT + (long)head * 4096;
+  for (int i = threadIdx.x; i < 4096; i += 256) atomicAdd(dbt + i, dbs[i]);
+}
 
-  // ---------------- pass 2: key on the lane ----------------
+template <int D>
+__global__ void __launch_bounds__(256, 2) k_wattn_bwd_kv(
+    const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
+    const float* __restrict__ biasN, const float* __restrict__ stats, long total, int H, int W, int C,
+    int heads, int shift, float scale) {
+  constexpr int HD = D / 2;
+  __shared__ __attribute__((aligned(16))) float smem[4 * (2 * 64 * D + 192)];
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+  const long gid = blockIdx.x * 4L + wv;
+  if (gid >= total) return;               // no block-level barrier below
+  const WaGeom g = wa_decode(gid, heads, W / 8, H / 8, shift);
+  const int head = g.head;
+  const int C3 = 3 * C;
+  const int mytok = wa_token(g, lane, H, W, shift);
+  const float lane_mask = (g.last_col && h != ((lane >> 2) & 1)) ? -100.f : 0.f;
+  float* As = smem + wv * (2 * 64 * D + 192);
+  float* Bs = As + 64 * D;
+  float* st = Bs + 64 * D;                 // [3][64]: max, 1/sum, delta of query = position
+  const int fo0 = r * D + h * HD, fo1 = (r + 32) * D + h * HD;
+  f32x16 S[2][2], G[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { S[a][b][q] = 0.f; G[a][b][q] = 0.f; }
+  // S = Q.K^T (rows = queries)
+  wa_stage<D>(As, qkv + head * D, C3, mytok, lane);
+  wa_stage<D>(Bs, qkv + C + head * D, C3, mytok, lane);
   {
-    f32x16 S[2][2], G[2][2];
+    const float* sp = stats + ((long)mytok * heads + head) * 3;
+    st[lane] = sp[0]; st[64 + lane] = sp[1]; st[128 + lane] = sp[2];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 3
+  for (int t = 0; t < HD; ++t) {
+    const float q0 = As[fo0 + t], q1 = As[fo1 + t], k0 = Bs[fo0 + t], k1 = Bs[fo1 + t];
+    S[0][0] = mfma32(q0, k0, S[0][0]); S[0][1] = mfma32(q0, k1, S[0][1]);
+    S[1][0] = mfma32(q1, k0, S[1][0]); S[1][1] = mfma32(q1, k1, S[1][1]);
+  }
+  // dP = dO.V^T
+  __builtin_amdgcn_wave_barrier();
+  wa_stage<D>(As, dout + head * D, C, mytok, lane);
+  wa_stage<D>(Bs, qkv + 2 * C + head * D, C3, mytok, lane);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 3
+  for (int t = 0; t < HD; ++t) {
+    const float g0 = As[fo0 + t], g1 = As[fo1 + t], v0 = Bs[fo0 + t], v1 = Bs[fo1 + t];
+    G[0][0] = mfma32(g0, v0, G[0][0]); G[0][1] = mfma32(g0, v1, G[0][1]);
+    G[1][0] = mfma32(g1, v0, G[1][0]); G[1][1] = mfma32(g1, v1, G[1][1]);
+  }
+  // Q again (column pattern for dK); dO stays in As (column pattern for dV)
+  __builtin_amdgcn_wave_barrier();
+  wa_stage<D>(Bs, qkv + head * D, C3, mytok, lane);
+  __builtin_amdgcn_wave_barrier();
+  const float* bn = biasN + (long)head * 4096;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+  for (int kb = 0; kb < 2; ++kb) {
+    f32x16 dK, dV;
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+    for (int q = 0; q < 16; ++q) { dK[q] = 0.f; dV[q] = 0.f; }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { S[a][b][q] = 0.f; G[a][b][q] = 0.f; }
-#pragma unroll
-    for (int t = 0; t < HD; ++t)
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          S[qb][kb] = mfma32(qf[qb][t], kf[kb][t], S[qb][kb]);   // S   (rows = queries)
-          G[qb][kb] = mfma32(gf[qb][t], vf[kb][t], G[qb][kb]);   // dP = dO.V^T
-        }
-    const float* bn = biasN + (long)g.head * 4096;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x16 dK, dV;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) { dK[q] = 0.f; dV[q] = 0.f; }
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const float tile_mask = (g.last_row && kb != qb) ? -100.f : 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int qry = mfma_row(q, lane);       // query index inside block qb
-          const float mx = __shfl(mrow[qb], qry, 64);
-          const float inv = __shfl(lrow[qb], qry, 64);
-          const float dl = __shfl(drow[qb], qry, 64);
-          float s = S[qb][kb][q] * scale + bn[(qry + 32 * qb) * 64 + r + 32 * kb];
-          s += tile_mask; s += lane_mask;          // lane_mask is symmetric in (query,key)
-          const float pv = expf(s - mx) * inv;
-          const float ds = pv * (G[qb][kb][q] - dl);
-          const int tok = __shfl(mytok, qry + 32 * qb, 64);
-          const float qc = r < D ? qkv[(long)tok * C3 + g.head * D + r] : 0.f;
-          const float gc = r < D ? dout[(long)tok * C + g.head * D + r] : 0.f;
-          dV = mfma32(pv, gc, dV);
-          dK = mfma32(ds, qc, dK);
-        }
-      }
+    for (int qb = 0; qb < 2; ++qb) {
+      const float tile_mask = (g.last_row && kb != qb) ? -100.f : 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int tok = __shfl(mytok, mfma_row(q, lane) + 32 * kb, 64);
-        if (r < D) {
-          dqkv[(long)tok * C3 + C + g.head * D + r] = dK[q] * scale;
-          dqkv[(long)tok * C3 + 2 * C + g.head * D + r] = dV[q];
-        }
+        const int qry = mfma_row(q, lane) + 32 * qb;     // window position of the query
+        const float mx = st[qry], inv = st[64 + qry], dl = st[128 + qry];
+        float s = S[qb][kb][q] * scale + bn[qry * 64 + r + 32 * kb];
+        s += tile_mask; s += lane_mask;                  // lane_mask is symmetric in (query,key)
+        const float pv = expf(s - mx) * inv;
+        const float ds = pv * (G[qb][kb][q] - dl);
+        const float qc = r < D ? Bs[qry * D + r] : 0.f;
+        const float gc = r < D ? As[qry * D + r] : 0.f;
+        dV = mfma32(pv, gc, dV);
+        dK = mfma32(ds, qc, dK);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int tok = __shfl(mytok, mfma_row(q, lane) + 32 * kb, 64);
+      if (r < D) {
+        dqkv[(long)tok * C3 + C + head * D + r] = dK[q] * scale;
+        dqkv[(long)tok * C3 + 2 * C + head * D + r] = dV[q];
       }
     }
   }
@@ -407,19 +462,28 @@ int srhip_window_attention_fwd(const float* qkv, float* out, const float* biasT,
 }
 
 // dbiasT must be zero on entry (accumulated with atomics).
+long srhip_window_attention_bwd_ws(int B, int H, int W, int heads) {
+  return 3L * B * H * W * heads;   // floats: softmax max, 1/sum, delta per (token, head)
+}
+
 // dbiasT must be zero on entry (accumulated with atomics).
 int srhip_window_attention_bwd(const float* qkv, const float* dout, float* dqkv, const float* biasT,
-                               const float* biasN, float* dbiasT, int B, int H, int W, int C, int heads,
-                               int shift, void* stream) {
+                               const float* biasN, float* dbiasT, float* workspace, int B, int H, int W,
+                               int C, int heads, int shift, void* stream) {
   int rc = wattn_check(B, H, W, C, heads, shift);
   if (rc) return rc;
+  SR_REQUIRE(workspace != nullptr, "window_attention_bwd: workspace required");
   const int D = C / heads;
-  const long total = (long)B * (H / 8) * (W / 8) * heads;
+  const int nwin = B * (H / 8) * (W / 8);
+  const long total = (long)nwin * heads;
   const float scale = 1.0f / sqrtf((float)D);
-  dim3 grid(sr_cdiv(total, 4)), blk(256);
   hipStream_t st = (hipStream_t)stream;
+  dim3 blk(256), gq(heads * sr_cdiv(nwin, 4)), gkv(sr_cdiv(total, 4));
 #define SR_WA(D_) \
-  if (D == D_) hipLaunchKernelGGL((k_wattn_bwd<D_>), grid, blk, 0, st, qkv, dout, dqkv, biasT, biasN, dbiasT, total, H, W, C, heads, shift, scale);
+  if (D == D_) { \
+    hipLaunchKernelGGL((k_wattn_bwd_q<D_>), gq, blk, 0, st, qkv, dout, dqkv, biasT, dbiasT, workspace, nwin, H, W, C, heads, shift, scale); \
+    hipLaunchKernelGGL((k_wattn_bwd_kv<D_>), gkv, blk, 0, st, qkv, dout, dqkv, biasN, workspace, total, H, W, C, heads, shift, scale); \
+  }
   SR_WA(30) SR_WA(10) SR_WA(16) SR_WA(32)
 #undef SR_WA
   SR_LAUNCH_CHECK("window_attention_bwd");

@@ -227,8 +227,9 @@ def window_attention_fwd(qkv, out, biasT, B, H, W, C, heads, shift):
 
 def window_attention_bwd(qkv, dout, dqkv, biasT, biasN, dbiasT, B, H, W, C, heads, shift):
     _chk(qkv, dout, dqkv, biasT, biasN, dbiasT)
+    ws = SCRATCH.get("wattn_ws", lib.srhip_window_attention_bwd_ws(B, H, W, heads), device=qkv.device)
     call("srhip_window_attention_bwd", _p(qkv), _p(dout), _p(dqkv), _p(biasT), _p(biasN),
-         _p(dbiasT), B, H, W, C, heads, shift, _st())
+         _p(dbiasT), _p(ws), B, H, W, C, heads, shift, _st())
 
 
 # ------------------------------------------------------------------ edge convs
