@@ -95,9 +95,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("SRHIP_FORCE_DDP", "0") == "1":
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL
         pg = dist.group.WORLD
 
     from dlib.models.network_swinir import SwinIR
@@ -117,7 +119,7 @@ def main():
     lr_img, hr_img = synth_batch(args.batch, 8, dev, seed=1000 + rank)
 
     def barrier():
-        if world > 1:
+        if pg is not None:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -135,7 +137,7 @@ def main():
     roof = probe.collect() if not args.no_roofline else None
     probe.disable()
 
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -165,7 +167,7 @@ def main():
             # shapes; oversubscribing a 256-thread host is 10x slower
             out["cpu_baseline"] = cpu_baseline(min(32, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 

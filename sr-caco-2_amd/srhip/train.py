@@ -9,6 +9,8 @@ gradients exist; replaces DDP, model_base.py:135-142) and a fused multi-tensor
 Adam / SGD-Nesterov update (dlib/utils/utils_instance.py:216-247) -- with no
 Python-visible tensor math in between.
 """
+import os
+
 import torch
 
 from . import ops
@@ -130,11 +132,14 @@ class TrainStep:
         self.opt = optimizer if optimizer is not None else Optimizer(self.fp)
         self.world = world_size
         self.pg = process_group
+        # SRHIP_FORCE_DDP=1 takes the bucketed all-reduce path even with one rank
+        # (exercises the RCCL / side-stream plumbing on a single GPU)
+        self.ddp = world_size > 1 or os.environ.get("SRHIP_FORCE_DDP", "0") == "1"
         dev = self.fp.flat.device
         self.loss_buf = torch.zeros(1 + len(self.loss_terms), device=dev)
         self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.comm_stream = torch.cuda.Stream(device=dev) if world_size > 1 else None
-        self.buckets = self._make_buckets() if world_size > 1 else []
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.ddp else None
+        self.buckets = self._make_buckets() if self.ddp else []
         self.dy = None
 
     def _make_buckets(self):
@@ -174,12 +179,9 @@ class TrainStep:
             dp = net.sample_drop_path(xi.shape[0], xi.device)
         y = net.engine.forward(xi, dp, save=True)
         dy = self.loss_and_grad(y, hr_img)
-        if self.world > 1:
-            hook = self._allreduce_bucket
-        else:
-            hook = None
+        hook = self._allreduce_bucket if self.ddp else None
         net.engine.backward(dy, self.fp.gviews, on_layer_done=hook)
-        if self.world > 1:
+        if self.ddp:
             self._allreduce_bucket(len(self.buckets) - 1)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         # one device flag: non-finite loss -> the optimizer kernel skips the update
