@@ -80,10 +80,12 @@ int srhip_conv3x3_wgrad(const float* dY, long lddy, const float* X, long ldx, in
                         int Cout, int Cin, float* part, float* part_colsum, int S, void* stream);
 int srhip_reduce_linear_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
                               int N, int K, void* stream);
-/* Linear fed by a folded LayerNorm: also emits dgamma / dbeta of that norm. */
+/* Linear fed by a folded LayerNorm: also emits dgamma / dbeta of that norm
+ * (accumulated with atomics: zeroed here unless ln_grads_zeroed != 0). */
 int srhip_reduce_ln_linear_wgrad(const float* part, const float* colsum, int S, const float* W,
                                  const float* gamma, const float* beta, float* dW, float* db,
-                                 float* dgamma, float* dbeta, int N, int K, void* stream);
+                                 float* dgamma, float* dbeta, int N, int K, int ln_grads_zeroed,
+                                 void* stream);
 /* dW in torch layout [Cout][Cin][3][3]. */
 int srhip_reduce_conv_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
                             int Co, int Ci, void* stream);

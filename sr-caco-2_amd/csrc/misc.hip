@@ -10,10 +10,19 @@ namespace {
 // weight-gradient finalisation
 // ----------------------------------------------------------------------------
 // out[i] = sum_s part[s][i]           (Linear: out = dW [NI][NJ])
+// ... and db[j] = sum_s colsum[s][j] for the nb extra indices behind n (one launch).
 __global__ void k_reduce_slices(const float* __restrict__ part, float* __restrict__ out,
-                                long n, int S, float beta) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+                                long n, int S, float beta, const float* __restrict__ colsum,
+                                float* __restrict__ db, int nb) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n + nb;
        i += (long)gridDim.x * blockDim.x) {
+    if (i >= n) {
+      const long j = i - n;
+      float d = 0.f;
+      for (int s = 0; s < S; ++s) d += colsum[(long)s * nb + j];
+      db[j] = d;
+      continue;
+    }
     float a = 0.f;
     int s = 0;
     for (; s + 8 <= S; s += 8) {
@@ -385,19 +394,22 @@ int srhip_reduce_linear_wgrad(const float* part, const float* colsum, int S, flo
                               int N, int K, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const long n = (long)N * K;
-  hipLaunchKernelGGL(k_reduce_slices, dim3(ew_grid(n)), dim3(256), 0, st, part, dW, n, S, 0.f);
-  if (colsum && db)
-    hipLaunchKernelGGL(k_reduce_colsum, dim3(sr_cdiv(N, 256)), dim3(256), 0, st, colsum, db, N, S);
+  const int nb = (colsum && db) ? N : 0;
+  hipLaunchKernelGGL(k_reduce_slices, dim3(ew_grid(n + nb)), dim3(256), 0, st, part, dW, n, S, 0.f,
+                     colsum, db, nb);
   SR_LAUNCH_CHECK("reduce_linear_wgrad");
   return 0;
 }
 
 int srhip_reduce_ln_linear_wgrad(const float* part, const float* colsum, int S, const float* W,
                                  const float* gamma, const float* beta, float* dW, float* db,
-                                 float* dgamma, float* dbeta, int N, int K, void* stream) {
+                                 float* dgamma, float* dbeta, int N, int K, int ln_grads_zeroed,
+                                 void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(dgamma, 0, sizeof(float) * K, st);
-  (void)hipMemsetAsync(dbeta, 0, sizeof(float) * K, st);
+  if (!ln_grads_zeroed) {   // dgamma / dbeta are accumulated with atomics
+    (void)hipMemsetAsync(dgamma, 0, sizeof(float) * K, st);
+    (void)hipMemsetAsync(dbeta, 0, sizeof(float) * K, st);
+  }
   hipLaunchKernelGGL(k_fin_ln_linear, dim3(sr_cdiv(K, 64), sr_cdiv(N, 4)), dim3(256), 0, st, part,
                      colsum, S, W, gamma, beta, dW, db, dgamma, dbeta, N, K);
   SR_LAUNCH_CHECK("reduce_ln_linear_wgrad");

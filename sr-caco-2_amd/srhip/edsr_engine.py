@@ -99,7 +99,7 @@ class EDSREngine:
         return y.view(B, 1, h, w)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dy, grads, need_dx=False, on_layer_done=None):
+    def backward(self, dy, grads, need_dx=False, on_layer_done=None, grads_zeroed=False):
         sv = self.saved
         assert sv is not None, "backward() without a saved forward"
         net, F, D = self.net, self.F, self.derived

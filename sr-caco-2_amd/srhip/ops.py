@@ -111,7 +111,7 @@ def linear_wgrad(dY, X, dW, db, a_rowscale=None, a_rowscale_rows=1, b_mode=0, ln
     else:
         W, gamma, beta, dgamma, dbeta = ln
         call("srhip_reduce_ln_linear_wgrad", _p(part), _p(cs), S, _p(W), _p(gamma), _p(beta),
-             _p(dW), _p(db), _p(dgamma), _p(dbeta), N, K, _st())
+             _p(dW), _p(db), _p(dgamma), _p(dbeta), N, K, 0, _st())
 
 
 class _TnProblem(ctypes.Structure):   # srhip_tn_problem (include/srhip.h)
@@ -122,7 +122,7 @@ class _TnProblem(ctypes.Structure):   # srhip_tn_problem (include/srhip.h)
                 ("part", ctypes.c_void_p), ("part_colsum", ctypes.c_void_p)]
 
 
-def linear_wgrad_grouped(problems):
+def linear_wgrad_grouped(problems, ln_grads_zeroed=False):
     """Up to 4 Linear weight-gradient problems over the same rows in ONE launch.
     Each problem: dict(dY, X, dW, db, a_rowscale=None, a_rowscale_rows=1, b_mode=0,
     ln_stats=None, ln=None) with the meaning of linear_wgrad()."""
@@ -160,7 +160,7 @@ def linear_wgrad_grouped(problems):
         else:
             W, gamma, beta, dgamma, dbeta = q["ln"]
             call("srhip_reduce_ln_linear_wgrad", _p(pk), _p(ck), S, _p(W), _p(gamma), _p(beta),
-                 _p(q["dW"]), _p(q["db"]), _p(dgamma), _p(dbeta), N, K, _st())
+                 _p(q["dW"]), _p(q["db"]), _p(dgamma), _p(dbeta), N, K, int(ln_grads_zeroed), _st())
 
 
 def conv3x3_wgrad(dY, X, dW, db):

@@ -185,7 +185,7 @@ class SwinIREngine:
         return y
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dy, grads, need_dx=False, on_layer_done=None):
+    def backward(self, dy, grads, need_dx=False, on_layer_done=None, grads_zeroed=False):
         """dy: [B,1,s*H,s*W]; grads: dict name -> tensor to receive the parameter
         gradient (overwritten).  Returns d loss / d x [B,H,W] if need_dx."""
         sv = self.saved
@@ -267,7 +267,7 @@ class SwinIREngine:
                                            blk.norm2.bias.data, G(p + "norm2.weight"), G(p + "norm2.bias"))),
                     dict(dY=g1, X=a, dW=G(p + "attn.proj.weight"), db=G(p + "attn.proj.bias"),
                          a_rowscale=s1, a_rowscale_rows=H * W),
-                ])
+                ], ln_grads_zeroed=grads_zeroed)
                 gi = (gi + 2) % 3
                 g = gout
             ops.axpby(dt, g, 1.0, 1.0)   # RSTB skip: t_out = conv(blocks(t_in)) + t_in

@@ -180,7 +180,10 @@ class TrainStep:
         y = net.engine.forward(xi, dp, save=True)
         dy = self.loss_and_grad(y, hr_img)
         hook = self._allreduce_bucket if self.ddp else None
-        net.engine.backward(dy, self.fp.gviews, on_layer_done=hook)
+        # ONE memset of the flat gradient buffer per step: the few gradients that are
+        # accumulated with atomics (LayerNorm affine) need no per-tensor zeroing then
+        self.fp.grad.zero_()
+        net.engine.backward(dy, self.fp.gviews, on_layer_done=hook, grads_zeroed=True)
         if self.ddp:
             self._allreduce_bucket(len(self.buckets) - 1)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
