@@ -311,7 +311,11 @@ int dispatch_nt(NtArgs& p, hipStream_t st) {
   else if (p.N <= 64) { p.n_tile = 64; wn = 1; }
   else if (p.N <= 128 || p.N % 128 == 0) { p.n_tile = 128; wn = 2; }
   else { p.n_tile = 192; wn = 3; }
-  const bool bk36 = (p.K % 36 == 0) || (p.K % 32 != 0);
+  // K chunk: 60 when it divides K (SwinIR 180/360/540: 3/6/9 chunks instead of
+  // 5/10/15 -- fewer barrier / staging rounds per block), else 36, or 32 for
+  // power-of-two channel counts (EDSR)
+  int bk = ((p.K % 36 == 0) || (p.K % 32 != 0)) ? 36 : 32;
+  if (!CONV && p.K % 60 == 0 && nt_env("SRHIP_NT_BK60", 1)) bk = 60;   // (64-row tiles only, below)
   // M tile: prefer 128 rows, fall back to 64 when that leaves < 2 blocks per CU
   long rows = CONV ? 0 : p.M;
   long blocks128;
@@ -322,20 +326,31 @@ int dispatch_nt(NtArgs& p, hipStream_t st) {
     blocks128 = sr_cdiv(rows, 128);
   }
   blocks128 *= sr_cdiv(p.N, p.n_tile);
-  int wm = (blocks128 >= 512) ? 2 : 1;
+  // 128-row tiles only for the two-column-block case (N = 360): measured faster
+  // there; with three column blocks (N = 540) 64-row tiles win (88 vs 104 us)
+  int wm = (blocks128 >= 512 && sr_cdiv(p.N, p.n_tile) <= 2) ? 2 : 1;
   const int force_wm = nt_env("SRHIP_NT_WM", 0);
   if (force_wm == 1 || force_wm == 2) wm = force_wm;
   p.stagger = nt_env("SRHIP_NT_STAGGER", 0);
+  if (wm == 2 && bk == 60) bk = 36;      // <2,3,60> spills
   if (CONV) {
     p.tiles_x = sr_cdiv(p.Wd, 16);
     p.tiles_y = sr_cdiv(p.H, wm == 2 ? 8 : 4);
   }
 #define SR_NT_CASE(WM_, WN_, BK_) \
-  if (wm == WM_ && wn == WN_ && bk36 == (BK_ == 36)) return launch_nt<WM_, WN_, BK_, CONV>(p, st);
+  if (wm == WM_ && wn == WN_ && bk == BK_) return launch_nt<WM_, WN_, BK_, CONV>(p, st);
   SR_NT_CASE(1, 1, 36) SR_NT_CASE(1, 2, 36) SR_NT_CASE(1, 3, 36)
   SR_NT_CASE(2, 1, 36) SR_NT_CASE(2, 2, 36) SR_NT_CASE(2, 3, 36)
   SR_NT_CASE(1, 1, 32) SR_NT_CASE(1, 2, 32) SR_NT_CASE(1, 3, 32)
   SR_NT_CASE(2, 1, 32) SR_NT_CASE(2, 2, 32) SR_NT_CASE(2, 3, 32)
+  if (!CONV) {
+    if (wm == 1 && wn == 3 && bk == 60) return launch_nt<1, 3, 60, false>(p, st);
+    if (wm == 2 && wn == 3 && bk == 60) return launch_nt<2, 3, 60, false>(p, st);
+    if (wm == 1 && wn == 1 && bk == 60) return launch_nt<1, 1, 60, false>(p, st);
+    if (wm == 1 && wn == 2 && bk == 60) return launch_nt<1, 2, 60, false>(p, st);
+    if (wm == 2 && wn == 1 && bk == 60) return launch_nt<2, 1, 60, false>(p, st);
+    if (wm == 2 && wn == 2 && bk == 60) return launch_nt<2, 2, 60, false>(p, st);
+  }
 #undef SR_NT_CASE
   return sr_fail(-22, "nt: no kernel for wm=%d wn=%d", wm, wn);
 }

@@ -35,6 +35,31 @@ class timed:
         _records.setdefault(self.key, []).append((self.a, self.b, self.flops))
 
 
+def _kernel_name(n, k):
+    """Instantiation the NT dispatcher (csrc/gemm_nt.hip) picks for (N, K) at M >= 32768."""
+    if n % 180 == 0 and n // 180 == 2:
+        return "k_nt<2, 3, 36, false>"
+    if n % 180 == 0:
+        return "k_nt<1, 3, 60, false>" if k % 60 == 0 else "k_nt<1, 3, 36, false>"
+    return None
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of that kernel from the committed rocprofv3 --pmc run
+    (profiles/r01_hbm_traffic_per_kernel.json; FETCH_SIZE x2 + WRITE_SIZE, separate
+    passes, see tools/collect_traffic.sh).  None if not collected."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                        "profiles", "r01_hbm_traffic_per_kernel.json")
+    if kernel is None or not os.path.isfile(path):
+        return None
+    for name, v in json.load(open(path)).items():
+        if kernel in name:
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def collect():
     """Dominant class (largest summed duration) -> roofline dict."""
     torch.cuda.synchronize()
@@ -48,8 +73,9 @@ def collect():
         return None
     key, ms, fl, n = best
     tf = fl / (ms * 1e-3) / 1e12
+    kname = _kernel_name(key[2], key[3])
     return {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-            "kernel": f"k_nt f32-MFMA NT GEMM M={key[1]} N={key[2]} K={key[3]}",
+            "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": _pmc_traffic(kname),
+            "kernel": f"{kname or 'k_nt'}: f32-MFMA NT GEMM M={key[1]} N={key[2]} K={key[3]}",
             "launches": n, "avg_launch_us": 1000.0 * ms / n,
             "algorithmic_gflop_per_launch": fl / n / 1e9}
