@@ -60,56 +60,80 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
     for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
 
+  // ---- staging invariants, hoisted out of the K loop --------------------------
+  // Each thread moves the same float4 slots of the A and W tiles in every chunk;
+  // only the K offset changes.  Rows outside the problem are CLAMPED to a valid
+  // row instead of zero-filled (an output element depends only on its own A row
+  // and W row, and out-of-range rows/columns are never stored), so a chunk's
+  // loads are base(SGPR, advanced per chunk) + byte offset(VGPR, fixed): no
+  // per-chunk address arithmetic on the vector ALU.
   f32x4 ra[A_IT], rb[B_IT];
   float2 rst[A_IT];               // {mean, rstd} of the A row (or the neutral pair)
+  unsigned offA[A_IT], offB[B_IT];   // byte offsets at k = 0
+  bool inA[A_IT];                    // conv: halo pixel inside the image (else zero)
+  // LDS float offset of staging slot `it`: the image is linear in the slot index
+  // when the pitch equals the chunk width (BK = 36, 60), so it costs no register
+  auto lds_off = [&](int it, int n_slots) -> int {
+    const int idx = min(tid + it * 256, n_slots - 1);
+    if (SA == BK) return idx * 4;
+    const int row = idx / KV;
+    return row * SA + (idx - row * KV) * 4;
+  };
+  auto slot_k = [&](int it, int n_slots) -> int {   // k offset of the slot inside the chunk
+    const int idx = min(tid + it * 256, n_slots - 1);
+    return (idx - (idx / KV) * KV) * 4;
+  };
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int idx = min(tid + it * 256, A_N - 1);
+    const int row = idx / KV, c4 = idx - row * KV;
+    inA[it] = true;
+    const float* sp = k_sr_neutral;
+    if (CONV) {
+      const int hy = row / 18, hx = row - hy * 18;
+      const int y = y0 + hy - 1, x = x0 + hx - 1;
+      inA[it] = y >= 0 && y < p.H && x >= 0 && x < p.Wd;
+      const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.Wd - 1);
+      offA[it] = (unsigned)(((img * p.H + yc) * p.Wd + xc) * (int)p.lda + c4 * 4) * 4u;
+    } else {
+      const int gm = min(m0 + row, p.M - 1);
+      offA[it] = (unsigned)(gm * (int)p.lda + c4 * 4) * 4u;
+      if (p.a_mode == 1) sp = p.ln_stats + 2 * gm;
+    }
+    rst[it] = *(const float2*)sp;
+  }
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int idx = min(tid + it * 256, B_N - 1);
+    const int row = idx / KV, c4 = idx - row * KV;
+    offB[it] = (unsigned)((n0 + min(row, nvalid - 1)) * (int)p.ldw + c4 * 4) * 4u;
+  }
 
   auto load_a = [&](int kc) {
+    const char* base = (const char*)(p.A + kc * BK);
+    const bool ktail = kc * BK + BK > p.K;           // block-uniform
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-      const int idx = tid + it * 256;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const float* sp = k_sr_neutral;
-      if (A_N % 256 == 0 || idx < A_N) {
-        const int row = idx / KV, c4 = idx - row * KV;
-        const int gk = kc * BK + c4 * 4;
-        if (CONV) {
-          const int hy = row / 18, hx = row - hy * 18;
-          const int y = y0 + hy - 1, x = x0 + hx - 1;
-          if (y >= 0 && y < p.H && x >= 0 && x < p.Wd && gk < p.K)
-            v = *(const f32x4*)(p.A + ((long)(img * p.H + y) * p.Wd + x) * p.lda + gk);
-        } else {
-          const int gm = m0 + row;
-          if (gm < p.M && gk < p.K) {
-            v = *(const f32x4*)(p.A + (long)gm * p.lda + gk);
-            if (p.a_mode == 1) sp = p.ln_stats + 2 * gm;
-          }
-        }
-      }
-      if (!CONV) rst[it] = *(const float2*)sp;   // unconditional load (see k_sr_neutral)
+      f32x4 v = *(const f32x4*)(base + offA[it]);
+      if (CONV && !inA[it]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ktail && kc * BK + slot_k(it, A_N) >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};
       ra[it] = v;
     }
   };
   auto load_b = [&](int kc, int tap) {
-    const float* wb = p.W + (long)tap * p.wtap;
+    const char* base = (const char*)(p.W + (long)tap * p.wtap + kc * BK);
+    const bool ktail = kc * BK + BK > p.K;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int idx = tid + it * 256;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (B_N % 256 == 0 || idx < B_N) {
-        const int row = idx / KV, c4 = idx - row * KV;
-        const int gk = kc * BK + c4 * 4;
-        if (row < nvalid && gk < p.K)
-          v = *(const f32x4*)(wb + (long)(n0 + row) * p.ldw + gk);
-      }
+      f32x4 v = *(const f32x4*)(base + offB[it]);
+      if (ktail && kc * BK + slot_k(it, B_N) >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};
       rb[it] = v;
     }
   };
   auto store_a = [&]() {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-      const int idx = tid + it * 256;
-      if (A_N % 256 == 0 || idx < A_N) {
-        const int row = idx / KV, c4 = idx - row * KV;
+      if (A_N % 256 == 0 || tid + it * 256 < A_N) {
         f32x4 v = ra[it];
         if (!CONV) {
           if (p.a_mode == 1) {          // LayerNorm prologue: (x-mean)*rstd
@@ -119,18 +143,14 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
             v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
           }
         }
-        *(f32x4*)(As + row * SA + c4 * 4) = v;
+        *(f32x4*)(As + lds_off(it, A_N)) = v;
       }
     }
   };
   auto store_b = [&]() {
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int idx = tid + it * 256;
-      if (B_N % 256 == 0 || idx < B_N) {
-        const int row = idx / KV, c4 = idx - row * KV;
-        *(f32x4*)(Bs + row * SA + c4 * 4) = rb[it];
-      }
+      if (B_N % 256 == 0 || tid + it * 256 < B_N) *(f32x4*)(Bs + lds_off(it, B_N)) = rb[it];
     }
   };
 
@@ -368,6 +388,8 @@ int sr_gemm_nt(NtArgs& p, hipStream_t st) {
   SR_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0 && p.ldw % 4 == 0,
              "gemm_nt: K, lda, ldw must be multiples of 4 (K=%d lda=%ld ldw=%ld)", p.K, p.lda, p.ldw);
   SR_REQUIRE(p.M > 0 && p.N > 0, "gemm_nt: empty problem");
+  SR_REQUIRE((long)p.M * p.lda < (1L << 29) && (long)p.N * p.ldw < (1L << 29),
+             "gemm_nt: operand larger than 2 GiB (32-bit staging offsets)");
   return dispatch_nt<false>(p, st);
 }
 
@@ -376,6 +398,8 @@ int sr_conv3x3_nt(NtArgs& p, hipStream_t st) {
              "conv3x3: Cin, lda, ldw must be multiples of 4 (Cin=%d)", p.K);
   SR_REQUIRE(p.batch > 0 && p.H > 0 && p.Wd > 0, "conv3x3: empty image");
   p.M = p.batch * p.H * p.Wd;
+  SR_REQUIRE((long)p.M * p.lda < (1L << 29) && 9L * p.N * p.ldw < (1L << 29),
+             "conv3x3: operand larger than 2 GiB (32-bit staging offsets)");
   p.dbg = nt_dbg();
   return dispatch_nt<true>(p, st);
 }
