@@ -114,9 +114,11 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
     const bool ktail = kc * BK + BK > p.K;           // block-uniform
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-      f32x4 v = *(const f32x4*)(base + offA[it]);
-      if (CONV && !inA[it]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ktail && kc * BK + slot_k(it, A_N) >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      // K tail (K not a multiple of BK): out-of-range lanes read k = 0 (always
+      // mapped) and are zeroed -- never touch memory past the end of a row
+      const bool oob = ktail && kc * BK + slot_k(it, A_N) >= p.K;
+      f32x4 v = *(const f32x4*)((oob ? (const char*)p.A : base) + offA[it]);
+      if ((CONV && !inA[it]) || oob) v = f32x4{0.f, 0.f, 0.f, 0.f};
       ra[it] = v;
     }
   };
@@ -125,8 +127,9 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
     const bool ktail = kc * BK + BK > p.K;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      f32x4 v = *(const f32x4*)(base + offB[it]);
-      if (ktail && kc * BK + slot_k(it, B_N) >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool oob = ktail && kc * BK + slot_k(it, B_N) >= p.K;
+      f32x4 v = *(const f32x4*)((oob ? (const char*)(p.W + (long)tap * p.wtap) : base) + offB[it]);
+      if (oob) v = f32x4{0.f, 0.f, 0.f, 0.f};
       rb[it] = v;
     }
   };

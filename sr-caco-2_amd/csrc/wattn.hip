@@ -14,6 +14,7 @@
 // lane: with shift = 4 the region of a token inside the last window row /
 // column depends only on (py>=4) / (px>=4), which are the tile index and the
 // lane bits of the MFMA layout.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -60,6 +61,31 @@ __device__ __forceinline__ void wa_stage(float* __restrict__ lds, const float* _
   }
 }
 
+// Two-phase form: issue the global loads early (registers), write LDS later, so
+// the memory latency hides behind the MFMA loop in between.
+template <int D>
+__device__ __forceinline__ void wa_stage_load(float2 (&regs)[D / 2], const float* __restrict__ gsrc,
+                                              long row_pitch, int mytok, int lane) {
+  constexpr int F2 = D / 2;
+#pragma unroll
+  for (int i = 0; i < F2; ++i) {
+    const int idx = i * 64 + lane;
+    const int tok = idx / F2, c2 = idx - tok * F2;
+    const int t = __shfl(mytok, tok, 64);
+    regs[i] = *(const float2*)(gsrc + (long)t * row_pitch + 2 * c2);
+  }
+}
+template <int D>
+__device__ __forceinline__ void wa_stage_store(float* __restrict__ lds, const float2 (&regs)[D / 2], int lane) {
+  constexpr int F2 = D / 2;
+#pragma unroll
+  for (int i = 0; i < F2; ++i) {
+    const int idx = i * 64 + lane;
+    const int tok = idx / F2, c2 = idx - tok * F2;
+    *(float2*)(lds + tok * D + 2 * c2) = regs[i];
+  }
+}
+
 template <int D>
 __global__ void __launch_bounds__(256) k_wattn_fwd(const float* __restrict__ qkv, float* __restrict__ out,
                                                    const float* __restrict__ biasT, long total, int H,
@@ -79,6 +105,8 @@ __global__ void __launch_bounds__(256) k_wattn_fwd(const float* __restrict__ qkv
   wa_stage<D>(Ks, hb + C, C3, mytok, lane);
   __builtin_amdgcn_wave_barrier();
 
+  float2 vreg[D / 2];                       // V on its way while S^T is computed
+  wa_stage_load<D>(vreg, hb + 2 * C, C3, mytok, lane);
   float qf[2][HD], kf[2][HD];
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk)
@@ -103,7 +131,7 @@ __global__ void __launch_bounds__(256) k_wattn_fwd(const float* __restrict__ qkv
 
   // V replaces K in LDS (the K fragments are in registers by now)
   __builtin_amdgcn_wave_barrier();
-  wa_stage<D>(Ks, hb + 2 * C, C3, mytok, lane);
+  wa_stage_store<D>(Ks, vreg, lane);
   __builtin_amdgcn_wave_barrier();
   // V operand of P.V: lane = head-dim index, one value per (key block, reg)
   float vc[2][16];
@@ -136,7 +164,7 @@ __global__ void __launch_bounds__(256) k_wattn_fwd(const float* __restrict__ qkv
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const float e = expf(T[kb][qb][q] - mx);
+        const float e = __expf(T[kb][qb][q] - mx);
         T[kb][qb][q] = e;
         sum += e;
       }
@@ -162,8 +190,7 @@ __global__ void __launch_bounds__(256) k_wattn_fwd(const float* __restrict__ qkv
 // coalesced through LDS), instead of the single 512-register kernel above:
 //   bwd_q : query on the lane  -> softmax stats (to a workspace), dQ, d(bias)
 //   bwd_kv: key on the lane    -> dK, dV (reads the stats)
-// The four waves of a bwd_q block work on four windows of the SAME head and sum
-// their bias-gradient tiles in LDS: one set of global atomics per block.
+// The bias-gradient tile leaves bwd_q as global float atomics.
 // ---------------------------------------------------------------------------
 template <int D>
 __global__ void __launch_bounds__(256, 2) k_wattn_bwd_q(
@@ -171,13 +198,10 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_q(
     const float* __restrict__ biasT, float* __restrict__ dbiasT, float* __restrict__ stats, int nwin,
     int H, int W, int C, int heads, int shift, float scale) {
   constexpr int HD = D / 2;
-  __shared__ __attribute__((aligned(16))) float smem[4096 + 4 * 2 * 64 * D];
+  __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 64 * D];
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-  float* dbs = smem;                                   // [64 key][64 query]
-  float* As = smem + 4096 + wv * (2 * 64 * D);
+  float* As = smem + wv * (2 * 64 * D);
   float* Bs = As + 64 * D;
-  for (int i = threadIdx.x; i < 4096; i += 256) dbs[i] = 0.f;
-  __syncthreads();
   const int head = blockIdx.x % heads;
   const int widx = (blockIdx.x / heads) * 4 + wv;
   if (widx < nwin) {
@@ -200,32 +224,36 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_q(
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int q = 0; q < 16; ++q) { T[a][b][q] = 0.f; G[a][b][q] = 0.f; }
-    // S^T = K.Q^T
+    // S^T = K.Q^T  (V and dO are fetched into registers meanwhile)
+    float2 ra[D / 2], rb[D / 2];
     wa_stage<D>(As, qkv + C + head * D, C3, mytok, lane);
     wa_stage<D>(Bs, qkv + head * D, C3, mytok, lane);
     __builtin_amdgcn_wave_barrier();
+    wa_stage_load<D>(ra, qkv + 2 * C + head * D, C3, mytok, lane);
+    wa_stage_load<D>(rb, dout + head * D, C, mytok, lane);
 #pragma unroll 3
     for (int t = 0; t < HD; ++t) {
       const float k0 = As[fo0 + t], k1 = As[fo1 + t], q0 = Bs[fo0 + t], q1 = Bs[fo1 + t];
       T[0][0] = mfma32(k0, q0, T[0][0]); T[0][1] = mfma32(k0, q1, T[0][1]);
       T[1][0] = mfma32(k1, q0, T[1][0]); T[1][1] = mfma32(k1, q1, T[1][1]);
     }
-    // dP^T = V.dO^T
+    // dP^T = V.dO^T  (K is fetched again meanwhile: column pattern for dQ)
     __builtin_amdgcn_wave_barrier();
-    wa_stage<D>(As, qkv + 2 * C + head * D, C3, mytok, lane);
-    wa_stage<D>(Bs, dout + head * D, C, mytok, lane);
+    wa_stage_store<D>(As, ra, lane);
+    wa_stage_store<D>(Bs, rb, lane);
     __builtin_amdgcn_wave_barrier();
+    wa_stage_load<D>(ra, qkv + C + head * D, C3, mytok, lane);
 #pragma unroll 3
     for (int t = 0; t < HD; ++t) {
       const float v0 = As[fo0 + t], v1 = As[fo1 + t], g0 = Bs[fo0 + t], g1 = Bs[fo1 + t];
       G[0][0] = mfma32(v0, g0, G[0][0]); G[0][1] = mfma32(v0, g1, G[0][1]);
       G[1][0] = mfma32(v1, g0, G[1][0]); G[1][1] = mfma32(v1, g1, G[1][1]);
     }
-    // K again (column pattern for dQ)
     __builtin_amdgcn_wave_barrier();
-    wa_stage<D>(As, qkv + C + head * D, C3, mytok, lane);
+    wa_stage_store<D>(As, ra, lane);
     __builtin_amdgcn_wave_barrier();
     const float* bt = biasT + (long)head * 4096;
+    float* dbt = dbiasT + (long)head * 4096;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       float mx = -3.0e38f;
@@ -247,7 +275,7 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_q(
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const float e = expf(T[kb][qb][q] - mx);
+          const float e = __expf(T[kb][qb][q] - mx);
           T[kb][qb][q] = e;
           sum += e;
         }
@@ -276,7 +304,10 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_q(
         for (int q = 0; q < 16; ++q) {
           const int key = mfma_row(q, lane) + 32 * kb;
           const float ds = T[kb][qb][q] * (G[kb][qb][q] - dl);
-          atomicAdd(dbs + key * 64 + r + 32 * qb, ds);          // LDS atomic
+          // bias gradient: fire-and-forget global float atomics, 256 contiguous bytes
+          // per wave instruction (measured 3.5x cheaper than summing the block's
+          // four windows through LDS float atomics first)
+          atomicAdd(dbt + key * 64 + r + 32 * qb, ds);
           const float kc = r < D ? As[key * D + r] : 0.f;
           dQ = mfma32(ds, kc, dQ);
         }
@@ -287,9 +318,6 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_q(
       }
     }
   }
-  __syncthreads();
-  float* dbt = dbiasT + (long)head * 4096;
-  for (int i = threadIdx.x; i < 4096; i += 256) atomicAdd(dbt + i, dbs[i]);
 }
 
 template <int D>
@@ -326,26 +354,30 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_kv(
     st[lane] = sp[0]; st[64 + lane] = sp[1]; st[128 + lane] = sp[2];
   }
   __builtin_amdgcn_wave_barrier();
+  float2 ra[D / 2], rb[D / 2];              // dO and V on their way during S
+  wa_stage_load<D>(ra, dout + head * D, C, mytok, lane);
+  wa_stage_load<D>(rb, qkv + 2 * C + head * D, C3, mytok, lane);
 #pragma unroll 3
   for (int t = 0; t < HD; ++t) {
     const float q0 = As[fo0 + t], q1 = As[fo1 + t], k0 = Bs[fo0 + t], k1 = Bs[fo1 + t];
     S[0][0] = mfma32(q0, k0, S[0][0]); S[0][1] = mfma32(q0, k1, S[0][1]);
     S[1][0] = mfma32(q1, k0, S[1][0]); S[1][1] = mfma32(q1, k1, S[1][1]);
   }
-  // dP = dO.V^T
+  // dP = dO.V^T  (Q is fetched again meanwhile: column pattern for dK)
   __builtin_amdgcn_wave_barrier();
-  wa_stage<D>(As, dout + head * D, C, mytok, lane);
-  wa_stage<D>(Bs, qkv + 2 * C + head * D, C3, mytok, lane);
+  wa_stage_store<D>(As, ra, lane);
+  wa_stage_store<D>(Bs, rb, lane);
   __builtin_amdgcn_wave_barrier();
+  wa_stage_load<D>(rb, qkv + head * D, C3, mytok, lane);
 #pragma unroll 3
   for (int t = 0; t < HD; ++t) {
     const float g0 = As[fo0 + t], g1 = As[fo1 + t], v0 = Bs[fo0 + t], v1 = Bs[fo1 + t];
     G[0][0] = mfma32(g0, v0, G[0][0]); G[0][1] = mfma32(g0, v1, G[0][1]);
     G[1][0] = mfma32(g1, v0, G[1][0]); G[1][1] = mfma32(g1, v1, G[1][1]);
   }
-  // Q again (column pattern for dK); dO stays in As (column pattern for dV)
+  // dO stays in As (column pattern for dV)
   __builtin_amdgcn_wave_barrier();
-  wa_stage<D>(Bs, qkv + head * D, C3, mytok, lane);
+  wa_stage_store<D>(Bs, rb, lane);
   __builtin_amdgcn_wave_barrier();
   const float* bn = biasN + (long)head * 4096;
 #pragma unroll
@@ -362,7 +394,7 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_kv(
         const float mx = st[qry], inv = st[64 + qry], dl = st[128 + qry];
         float s = S[qb][kb][q] * scale + bn[qry * 64 + r + 32 * kb];
         s += tile_mask; s += lane_mask;                  // lane_mask is symmetric in (query,key)
-        const float pv = expf(s - mx) * inv;
+        const float pv = __expf(s - mx) * inv;
         const float ds = pv * (G[qb][kb][q] - dl);
         const float qc = r < D ? Bs[qry * D + r] : 0.f;
         const float gc = r < D ? As[qry * D + r] : 0.f;
