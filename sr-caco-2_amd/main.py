@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Entry point with the reference's CLI contract for the hot-path networks.
+
+    python main.py --task super-resolution --scale 8 --method SWINIR --net_type swinir \
+        --n_channels 1 --h_size 512 --batch_size 8 --G_optimizer_type sgd --G_optimizer_lr 0.01 \
+        --G_scheduler_type MyStepLR --G_scheduler_step_size 30 --G_scheduler_gamma 0.5 \
+        --swinir_window_size 8 --swinir_depths 6+6+6+6 --swinir_embed_dim 180 \
+        --swinir_num_heads 6+6+6+6 --swinir_mlp_ratio 2 --swinir_upsampler pixelshuffledirect \
+        --l1 True --max_iters 100 [--distributed True --dist_backend nccl]
+
+Flag names, the ``--net_type`` / ``--method`` pairing check, '+'-separated lists
+and the three-stage config (defaults -> per-net defaults -> CLI overrides of
+non-None values) follow dlib/utils/utils_parser.py:291-339,900-967,1142-1143 and
+dlib/utils/utils_config.py:64-404 for the options this path uses.  The
+reference's datasets (TIFF folds, ROI patch sampling) are callers of the path and
+not reproduced: this entry trains / evaluates on
+synthetic patches of the configured shape -- ``--synthetic True`` is implied --
+through the same ModelPlain protocol the reference trainer drives
+(utils_trainer.py:353-415) and reports patches/sec plus the metric sweep of
+utils_trainer.py:961-1032.
+"""
+import argparse
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from dlib.utils import constants  # noqa: E402
+from dlib.utils.shared import safe_str_var  # noqa: E402
+from dlib.utils.utils_init_default_args import init_net_g  # noqa: E402
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ('true', '1', 'yes'):
+        return True
+    if v.lower() in ('false', '0', 'no'):
+        return False
+    raise argparse.ArgumentTypeError(f'boolean expected, got {v!r}')
+
+
+def plus_list(v):
+    return [int(z) for z in v.split('+')]
+
+
+class Dict2Obj(dict):
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def get_config(net_type):
+    """Defaults for the options on the path (utils_config.py:64-404)."""
+    return {
+        'task': constants.SUPER_RES, 'net_type': net_type, 'method': constants.NETTYPE_METHOD[net_type],
+        'scale': 2, 'n_channels': 1, 'h_size': 96, 'batch_size': 8, 'eval_bsize': 8, 'myseed': 0,
+        'distributed': False, 'dist_backend': constants.GLOO, 'cudaid': '0', 'amp': False,
+        'max_epochs': 1, 'max_iters': 50, 'eval_over_roi_also': False,
+        'eval_over_roi_also_ths': [4, 5, 6, 7, 8, 9, 10], 'outd': './out',
+        'train': {'l1': True, 'l1_lambda': 1., 'l2': False, 'l2_lambda': 1., 'ssim': False,
+                  'ssim_lambda': 1., 'ssim_window_s': 11,
+                  'G_optimizer_type': constants.ADAM, 'G_optimizer_lr': 2e-4, 'G_optimizer_wd': 1e-4,
+                  'G_optimizer_beta1': 0.9, 'G_optimizer_beta2': 0.999, 'G_optimizer_eps_adam': 1e-8,
+                  'G_optimizer_momentum': 0.9, 'G_optimizer_nesterov': True, 'G_optimizer_amsgrad': False,
+                  'G_scheduler_type': constants.MYSTEPLR, 'G_scheduler_step_size': 30,
+                  'G_scheduler_gamma': 0.5, 'G_scheduler_min_lr': 1e-4,
+                  'G_scheduler_milestones': [250000, 400000]},
+    }
+
+
+def parse_input(argv=None):
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument('--net_type', type=str, default=constants.SWINIR)
+    net_type = pre.parse_known_args(argv)[0].net_type          # parsed first (utils_parser.py:1333)
+    if net_type not in constants.MODELS:
+        raise NotImplementedError(f'--net_type {net_type}: libsrhip runs {constants.MODELS}')
+    cfg = get_config(net_type)
+    ap = argparse.ArgumentParser(description='SR-CACO-2 hot path on MI355X (libsrhip)')
+    for k in ('task', 'net_type', 'method', 'dist_backend', 'cudaid', 'outd'):
+        ap.add_argument(f'--{k}', type=str, default=None)
+    for k in ('scale', 'n_channels', 'h_size', 'batch_size', 'eval_bsize', 'myseed', 'max_epochs', 'max_iters'):
+        ap.add_argument(f'--{k}', type=int, default=None)
+    for k in ('distributed', 'amp', 'eval_over_roi_also'):
+        ap.add_argument(f'--{k}', type=str2bool, default=None)
+    for k, v in cfg['train'].items():
+        t = str2bool if isinstance(v, bool) else (type(v) if not isinstance(v, list) else plus_list)
+        ap.add_argument(f'--{k}', type=t, default=None)
+    nt = safe_str_var(net_type)
+    net_opts = {constants.SWINIR: {'window_size': int, 'depths': plus_list, 'embed_dim': int,
+                                   'num_heads': plus_list, 'mlp_ratio': int, 'upsampler': str,
+                                   'resi_connection': str, 'img_range': float},
+                constants.EDSR_LIIF: {'n_feats': int, 'n_resblocks': int, 'res_scale': float,
+                                      'img_range': float}}[net_type]
+    for k, t in net_opts.items():
+        ap.add_argument(f'--{nt}_{k}', type=t, default=None)
+    ns, unknown = ap.parse_known_args(argv)
+    if unknown:   # the reference has ~300 flags; the ones for callers of the path are accepted and ignored
+        print(f'[main] ignoring flags outside the hot path: {unknown[::2]}', file=sys.stderr)
+    # any non-None CLI value overrides the top-level / nested key (utils_parser.py:900-923)
+    for k, v in vars(ns).items():
+        if v is None:
+            continue
+        if k in cfg['train']:
+            cfg['train'][k] = v
+        elif not k.startswith(nt + '_'):
+            cfg[k] = v
+    if cfg['method'] != constants.NETTYPE_METHOD[net_type]:
+        raise ValueError(f"--method {cfg['method']} does not match --net_type {net_type} "
+                         f"({constants.NETTYPE_METHOD[net_type]})")
+    if cfg['amp']:
+        raise NotImplementedError('--amp True: the libsrhip path is fp32 (parity gate)')
+    cfg['netG'] = init_net_g({'net_type': net_type}, cfg)
+    for k in net_opts:
+        v = getattr(ns, f'{nt}_{k}')
+        if v is not None:
+            cfg['netG'][f'{nt}_{k}'] = v
+    return Dict2Obj(cfg)
+
+
+def synth_batch(batch, scale, h_size, device, seed):
+    """dataset_dpsr.py:685-710 on synthetic data: H uint8-quantised, L = clamp(bicubic_down(H))."""
+    g = torch.Generator().manual_seed(seed)
+    hr = (torch.rand(batch, 1, h_size, h_size, generator=g) * 255).round() / 255
+    lr = F.interpolate(hr, scale_factor=1.0 / scale, mode='bicubic').clamp(0, 1)
+    return {'l_im': lr.to(device), 'h_im': hr.to(device)}
+
+
+def main(argv=None):
+    args = parse_input(argv)
+    rank, world = 0, 1
+    if args.distributed:
+        import torch.distributed as dist
+        local = int(os.environ.get('LOCAL_RANK', '0'))          # torchrun contract (utils_parser.py:1087)
+        torch.cuda.set_device(local)
+        dist.init_process_group(args.dist_backend)
+        rank, world = dist.get_rank(), dist.get_world_size()
+    else:
+        torch.cuda.set_device(int(str(args.cudaid).split(',')[0]))
+    torch.manual_seed(args.myseed)
+    from dlib.models.select_model import define_model
+    from dlib import metrics
+    model = define_model(args)
+    model.init_train()
+    if rank == 0:
+        print(model.info_network())
+    batch = synth_batch(args.batch_size, args.scale, args.h_size, model.device, 1000 + rank)
+    t0, seen = time.perf_counter(), 0
+    for step in range(1, args.max_iters + 1):
+        model.feed_data(batch)
+        model.optimize_parameters(epoch=0, current_step=step)
+        model.update_learning_rate()
+        seen += args.batch_size * world
+        if step % 10 == 0 or step == args.max_iters:
+            if not model.check_finite():
+                print('Terminated due to error: non-finite loss')       # tools.py:55-63 semantics
+                sys.exit(1)
+            if rank == 0:
+                torch.cuda.synchronize()
+                log = model.current_log()
+                print(f"iter {step:6d}  G_loss {log['G_loss']:.6f}  lr {model.current_learning_rate():.2e}  "
+                      f"{seen / (time.perf_counter() - t0):8.1f} patches/s")
+    # evaluation sweep (utils_trainer.py:961-1032): PSNR / PSNR_Y / MSE / NRMSE / SSIM, optional ROI thresholds
+    model.feed_data(batch)
+    model.test()
+    vis = model.current_visuals()
+    ths = tuple(args.eval_over_roi_also_ths) if args.eval_over_roi_also else ()
+    sw = metrics.sweep(vis['E'], vis['H'], border=args.scale, thresholds=ths)
+    if rank == 0:
+        for k in (constants.PSNR_MTR, constants.PSNR_Y_MTR, constants.MSE_MTR, constants.NRMSE_MTR,
+                  constants.SSIM_MTR):
+            full = sw[k][:, 0].double().mean().item()
+            msg = f'{k:8s} {full:.4f}'
+            if ths:
+                msg += f'   ROI(avg over th {list(ths)}) {sw[k][:, 1:].double().mean().item():.4f}'
+            print(msg)
+        os.makedirs(args.outd, exist_ok=True)
+        print('saved', model.save(args.max_iters))
+    if args.distributed:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
