@@ -10,19 +10,22 @@ namespace {
 // weight-gradient finalisation
 // ----------------------------------------------------------------------------
 // out[i] = sum_s part[s][i]           (Linear: out = dW [NI][NJ])
-// ... and db[j] = sum_s colsum[s][j] for the nb extra indices behind n (one launch).
+// ... and db[j] = sum_s colsum[s][j] in the same launch: the blocks behind the
+// first `main_blocks` handle the nb bias-gradient entries.
 __global__ void k_reduce_slices(const float* __restrict__ part, float* __restrict__ out,
                                 long n, int S, float beta, const float* __restrict__ colsum,
-                                float* __restrict__ db, int nb) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n + nb;
-       i += (long)gridDim.x * blockDim.x) {
-    if (i >= n) {
-      const long j = i - n;
+                                float* __restrict__ db, int nb, int main_blocks) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const int j = (blockIdx.x - main_blocks) * blockDim.x + threadIdx.x;
+    if (j < nb) {
       float d = 0.f;
       for (int s = 0; s < S; ++s) d += colsum[(long)s * nb + j];
       db[j] = d;
-      continue;
     }
+    return;
+  }
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)main_blocks * blockDim.x) {
     float a = 0.f;
     int s = 0;
     for (; s + 8 <= S; s += 8) {
@@ -395,8 +398,9 @@ int srhip_reduce_linear_wgrad(const float* part, const float* colsum, int S, flo
   hipStream_t st = (hipStream_t)stream;
   const long n = (long)N * K;
   const int nb = (colsum && db) ? N : 0;
-  hipLaunchKernelGGL(k_reduce_slices, dim3(ew_grid(n + nb)), dim3(256), 0, st, part, dW, n, S, 0.f,
-                     colsum, db, nb);
+  const int mb = ew_grid(n);
+  hipLaunchKernelGGL(k_reduce_slices, dim3(mb + sr_cdiv(nb, 256)), dim3(256), 0, st, part, dW, n, S, 0.f,
+                     colsum, db, nb, mb);
   SR_LAUNCH_CHECK("reduce_linear_wgrad");
   return 0;
 }

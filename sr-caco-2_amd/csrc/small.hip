@@ -87,16 +87,20 @@ __global__ void __launch_bounds__(256) k_conv_cin1_wgrad(const float* __restrict
     }
   }
 }
-// dw[co][t] = sum_waves part (flip: written to 8-t), db[co]
+// dw[co][t] = sum_waves part (flip: written to 8-t), db[co]; one wave per output
 __global__ void k_conv_cin1_wgrad_fin(const float* __restrict__ part, float* __restrict__ dw,
                                       float* __restrict__ db, int Co, int nwave, int flip) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= Co * 10) return;
   const int co = i / 10, t = i % 10;
   float a = 0.f;
-  for (int wv = 0; wv < nwave; ++wv) a += part[((long)wv * Co + co) * 10 + t];
-  if (t == 9) { if (db) db[co] = a; }
-  else dw[co * 9 + (flip ? 8 - t : t)] = a;
+  for (int wv = lane; wv < nwave; wv += 64) a += part[((long)wv * Co + co) * 10 + t];
+  a = wave_sum(a);
+  if (lane == 0) {
+    if (t == 9) { if (db) db[co] = a; }
+    else dw[co * 9 + (flip ? 8 - t : t)] = a;
+  }
 }
 // Cout = 1: y[p] = b + sum_t sum_ci x[p+t][ci] * w[ci][t]   (x NHWC, Ci <= 256)
 // tail conv of the EDSR wiring, network_nlsn.py:347-350.  One wave per pixel.
@@ -268,7 +272,7 @@ int srhip_conv3x3_cin1_wgrad(const float* x, const float* dy, long lddy, float* 
   const int blocks = 256;  // 1024 waves
   hipLaunchKernelGGL(k_conv_cin1_wgrad, dim3(blocks), dim3(256), 0, st, x, dy, workspace, B, H, W, Co,
                      lddy);
-  hipLaunchKernelGGL(k_conv_cin1_wgrad_fin, dim3(sr_cdiv(Co * 10, 256)), dim3(256), 0, st, workspace,
+  hipLaunchKernelGGL(k_conv_cin1_wgrad_fin, dim3(sr_cdiv(Co * 10, 4)), dim3(256), 0, st, workspace,
                      dw, db, Co, blocks * 4, flip);
   SR_LAUNCH_CHECK("conv_cin1_wgrad");
   return 0;

@@ -428,23 +428,20 @@ __global__ void k_bias_expand(const float* __restrict__ table, float* __restrict
   const int idxT = ((b >> 3) - (a >> 3) + 7) * 15 + ((b & 7) - (a & 7) + 7);
   biasT[i] = table[idxT * heads + hd];
 }
-// dtable[idx][h] = sum over (query,key) with rpi == idx of dbiasT[h][key][query]
+// dtable[idx][h] = sum over (query,key) with rpi == idx of dbiasT[h][key][query];
+// one wave per table entry, one lane per key position
 __global__ void k_bias_grad(const float* __restrict__ dbiasT, float* __restrict__ dtable, int heads) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= 225 * heads) return;
   const int hd = i % heads, idx = i / heads;
   const int dy = idx / 15 - 7, dx = idx % 15 - 7;   // query - key
+  const int ky = lane >> 3, kx = lane & 7;
+  const int qy = ky + dy, qx = kx + dx;
   float a = 0.f;
-  for (int ky = 0; ky < 8; ++ky) {
-    const int qy = ky + dy;
-    if (qy < 0 || qy > 7) continue;
-    for (int kx = 0; kx < 8; ++kx) {
-      const int qx = kx + dx;
-      if (qx < 0 || qx > 7) continue;
-      a += dbiasT[(long)hd * 4096 + (ky * 8 + kx) * 64 + qy * 8 + qx];
-    }
-  }
-  dtable[i] = a;
+  if (qy >= 0 && qy < 8 && qx >= 0 && qx < 8) a = dbiasT[(long)hd * 4096 + lane * 64 + qy * 8 + qx];
+  a = wave_sum(a);
+  if (lane == 0) dtable[i] = a;
 }
 
 }  // namespace
@@ -459,7 +456,7 @@ int srhip_bias_expand(const float* table, float* biasT, float* biasN, int heads,
 }
 
 int srhip_bias_grad(const float* dbiasT, float* dtable, int heads, void* stream) {
-  hipLaunchKernelGGL(k_bias_grad, dim3(sr_cdiv(225 * heads, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_bias_grad, dim3(sr_cdiv(225 * heads, 4)), dim3(256), 0, (hipStream_t)stream,
                      dbiasT, dtable, heads);
   SR_LAUNCH_CHECK("bias_grad");
   return 0;
