@@ -54,6 +54,37 @@ int srhip_conv3x3_nhwc(const float* X, long ldx, const float* Wp, const float* b
                        int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                        const float* rowscale, float alpha, void* stream);
 
+/* ---- the same contractions on the bf16 MFMA with 3-way split operands -------
+ * x = x_h + x_m + x_l (bf16 each, 3 x 8 = 24 significant bits); a*b is summed
+ * from the six cross products >= 2^-24 relative, in f32: f32-accurate results
+ * at 2.67x the matrix-core rate of the f32 MFMA.  The weight operand is split
+ * ONCE per step: out = planes [3][rows][Kp] bf16, Kp = srhip_bf16x3_kp(K) (K
+ * rounded up to 32, zero filled); rows = N for a Linear weight, 9*Cout for the
+ * tap-major conv pack.  Same prologues / epilogues / reference lines as
+ * srhip_gemm_nt and srhip_conv3x3_nhwc. */
+int srhip_bf16x3_kp(int K);
+int srhip_split_bf16x3(const float* W, long ldw, int rows, int K, void* out, void* stream);
+/* All weights of a network in ONE launch.  The caller builds the table on the host
+ * (blk0 = running sum of srhip_split_blocks(rows, K), ascending), copies it to the
+ * device once, and re-runs the launch after every optimizer step. */
+typedef struct {
+  const float* W;   /* [rows][ldw] f32 */
+  void* out;        /* [3][rows][Kp] bf16 */
+  long ldw;
+  int rows, K;
+  int blk0;         /* first block of this entry */
+  int pad_;
+} srhip_split_entry;
+int srhip_split_blocks(int rows, int K);
+int srhip_split_bf16x3_table(const srhip_split_entry* table_dev, int n, int total_blocks, void* stream);
+int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bias, float* C,
+                      long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
+                      const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha,
+                      void* stream);
+int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
+                           int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
+                           const float* rowscale, float alpha, void* stream);
+
 /* Weight gradients: out[i][j] = sum_m A[m][i] * pro(B)[m][j], reduce dimension
  * split in S slices written to part[S][(9)][NI][NJ] (+ column sums of A in
  * part_colsum[S][NI] for the bias gradient); srhip_reduce_* sums the slices.

@@ -51,6 +51,50 @@ int srhip_conv3x3_nhwc(const float* X, long ldx, const float* Wp, const float* b
   return sr_conv3x3_nt(p, (hipStream_t)stream);
 }
 
+int srhip_bf16x3_kp(int K) { return sr_kp(K); }
+
+int srhip_split_bf16x3(const float* W, long ldw, int rows, int K, void* out, void* stream) {
+  return sr_split3(W, ldw, rows, K, (unsigned short*)out, (hipStream_t)stream);
+}
+
+int srhip_split_blocks(int rows, int K) { return sr_cdiv((long)rows * (sr_kp(K) / 4), 256); }
+
+int srhip_split_bf16x3_table(const srhip_split_entry* table_dev, int n, int total_blocks, void* stream) {
+  static_assert(sizeof(srhip_split_entry) == sizeof(SplitEntry), "split table layout");
+  return sr_split3_table((const SplitEntry*)table_dev, n, total_blocks, (hipStream_t)stream);
+}
+
+int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bias, float* C,
+                      long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
+                      const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha,
+                      void* stream) {
+  SR_REQUIRE(a_mode >= 0 && a_mode <= 2, "gemm_nt_bx3: a_mode %d", a_mode);
+  SR_REQUIRE(epi >= 0 && epi <= 4, "gemm_nt_bx3: epi %d", epi);
+  SR_REQUIRE(a_mode != 1 || ln_stats, "gemm_nt_bx3: layernorm prologue without stats");
+  SR_REQUIRE(epi < 3 || R, "gemm_nt_bx3: epilogue %d needs R", epi);
+  SR_REQUIRE(!rowscale || rows_per_scale > 0, "gemm_nt_bx3: rows_per_scale must be > 0");
+  NtArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.Wb = (const unsigned short*)Wb; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.bias = bias; p.a_mode = a_mode; p.ln_stats = ln_stats;
+  p.epi = epi; p.R = R; p.ldr = ldr; p.rowscale = rowscale; p.rows_per_scale = rows_per_scale;
+  p.alpha = alpha;
+  return sr_gemm_ntb(p, (hipStream_t)stream);
+}
+
+int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
+                           int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
+                           const float* rowscale, float alpha, void* stream) {
+  SR_REQUIRE(epi >= 0 && epi <= 4 && epi != 3, "conv3x3_bx3: epi %d", epi);
+  SR_REQUIRE(epi != 4 || R, "conv3x3_bx3: relu-mask epilogue needs R");
+  NtArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = X; p.lda = ldx; p.Wb = (const unsigned short*)Wb; p.C = Y; p.ldc = ldy;
+  p.N = Cout; p.K = Cin; p.bias = bias; p.epi = epi; p.R = R; p.ldr = ldr; p.rowscale = rowscale;
+  p.rows_per_scale = H * W; p.alpha = alpha; p.batch = B; p.H = H; p.Wd = W;
+  return sr_conv3x3_ntb(p, (hipStream_t)stream);
+}
+
 int srhip_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
   return sr_tn_plan(M, NI, NJ, conv, S, part_floats);
 }

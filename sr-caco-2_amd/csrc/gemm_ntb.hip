@@ -1,0 +1,353 @@
+// NT contraction with f32 operands split three ways into bf16 and multiplied on
+// the bf16 MFMA (v_mfma_f32_32x32x16_bf16, f32 accumulate):
+//
+//   x = x_h + x_m + x_l   (each part the bf16 rounding of the remaining residual:
+//                          3 x 8 significant bits = the 24 bits of an f32)
+//   a*b ~= a_m*b_m + a_h*b_l + a_l*b_h + a_h*b_m + a_m*b_h + a_h*b_h
+//
+// The three dropped cross terms (m*l, l*m, l*l) are below 2^-24 relative, i.e.
+// at the rounding level of the f32 product itself; the products of bf16 pairs
+// are exact in the MFMA and the sums run in f32, so the result carries f32
+// accuracy at 6 bf16 MFMAs (6 x 32 cycles per 32x32x16) instead of 8 f32 MFMAs
+// (8 x 64 cycles): 2.67x the matrix-core rate of gemm_nt.hip.
+//
+// Same two problem shapes and the same prologues / epilogues as gemm_nt.hip
+// (Linear fwd / bwd-data, 3x3 conv as implicit GEMM over an NHWC halo tile).
+// W arrives PRE-SPLIT (k_split3: planes [3][rows][Kp] bf16, Kp = K rounded up
+// to 32 and zero filled) because it is reused by every block; the activation
+// operand is split while it is staged into LDS (once per chunk; for the conv
+// once per 9 taps).
+//
+// LDS: per plane [row][32 k] bf16 with an 80-byte row pitch (20 dwords: the 16
+// lanes of a ds_read_b128 phase hit 16 distinct 4-dword bank groups).
+// Fragment of lane (r = lane&31, h = lane>>5) for k-step s: 8 consecutive k at
+// s*16 + 8*h -- the operand layout of the 32x32x16 MFMA for both A and B.
+#include <stdlib.h>
+#include "common.h"
+#include "kernels.h"
+#include "nt_epi.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BKB = 32;          // k per chunk
+constexpr int PITCH = 80;        // bytes per LDS row (32 bf16 + 16 B pad)
+
+// two floats -> their bf16 parts (packed pairs: element 0 in the low half)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+}
+
+__device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int WM, int WN, bool CONV>
+__global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int TROWS = BM / 16;
+  constexpr int AROWS = CONV ? (TROWS + 2) * 18 : BM;
+  constexpr int A_N = AROWS * 8;                 // float4 slots per chunk
+  constexpr int A_IT = (A_N + 255) / 256;
+  constexpr int B_N = 3 * BN * 4;                // 16-byte slots per chunk (3 planes)
+  constexpr int B_IT = (B_N + 255) / 256;
+  constexpr int A_PLANE = AROWS * PITCH, B_PLANE = BN * PITCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + 3 * A_PLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * p.n_tile;
+  const int nvalid = min(p.n_tile, p.N - n0);
+
+  int m0 = 0, img = 0, y0 = 0, x0 = 0;
+  if (CONV) {
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; img = t / p.tiles_y;
+    y0 = ty * TROWS; x0 = tx * 16;
+  } else {
+    m0 = blockIdx.x * BM;
+  }
+
+  // ---- staging invariants (see gemm_nt.hip: clamped rows, fixed byte offsets) ----
+  f32x4 ra[A_IT];
+  u32x4 rb[B_IT];
+  float2 rst[A_IT];
+  unsigned offA[A_IT], offB[B_IT];
+  bool inA[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int idx = min(tid + it * 256, A_N - 1);
+    const int row = idx >> 3, c4 = idx & 7;
+    inA[it] = true;
+    const float* sp = k_sr_neutral;
+    if (CONV) {
+      const int hy = row / 18, hx = row - hy * 18;
+      const int y = y0 + hy - 1, x = x0 + hx - 1;
+      inA[it] = y >= 0 && y < p.H && x >= 0 && x < p.Wd;
+      const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.Wd - 1);
+      offA[it] = (unsigned)(((img * p.H + yc) * p.Wd + xc) * (int)p.lda + c4 * 4) * 4u;
+    } else {
+      const int gm = min(m0 + row, p.M - 1);
+      offA[it] = (unsigned)(gm * (int)p.lda + c4 * 4) * 4u;
+      if (p.a_mode == 1) sp = p.ln_stats + 2 * gm;
+    }
+    rst[it] = *(const float2*)sp;
+  }
+  const long plane_bytes = (long)(CONV ? 9 : 1) * p.N * p.Kp * 2;   // one bf16 plane of W
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int idx = min(tid + it * 256, B_N - 1);
+    const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
+    const int row = rem >> 2, q = rem & 3;
+    offB[it] = (unsigned)(pl * plane_bytes + ((long)(n0 + min(row, nvalid - 1)) * p.Kp) * 2 + q * 16);
+  }
+
+  auto load_a = [&](int kc) {
+    const char* base = (const char*)(p.A + kc * BKB);
+    const bool ktail = kc * BKB + BKB > p.K;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int c4 = min(tid + it * 256, A_N - 1) & 7;
+      const bool oob = ktail && kc * BKB + c4 * 4 >= p.K;
+      f32x4 v = *(const f32x4*)((oob ? (const char*)(p.A - c4 * 4) : base) + offA[it]);   // oob: k = 0 of the row
+      if ((CONV && !inA[it]) || oob) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      ra[it] = v;
+    }
+  };
+  auto load_b = [&](int kc, int tap) {
+    const char* base = (const char*)p.Wb + ((long)tap * p.N * p.Kp + kc * BKB) * 2;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) rb[it] = *(const u32x4*)(base + offB[it]);
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      if (A_N % 256 == 0 || tid + it * 256 < A_N) {
+        const int idx = tid + it * 256;
+        f32x4 v = ra[it];
+        if (!CONV) {
+          if (p.a_mode == 1) {
+            const float mu = rst[it].x, rs = rst[it].y;
+            v.x = (v.x - mu) * rs; v.y = (v.y - mu) * rs; v.z = (v.z - mu) * rs; v.w = (v.w - mu) * rs;
+          } else if (p.a_mode == 2) {
+            v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+          }
+        }
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pair(v.x, v.y, h0, m0_, l0);
+        split3_pair(v.z, v.w, h1, m1, l1);
+        unsigned char* dst = As + (idx >> 3) * PITCH + (idx & 7) * 8;
+        *(u32x2*)(dst) = u32x2{h0, h1};
+        *(u32x2*)(dst + A_PLANE) = u32x2{m0_, m1};
+        *(u32x2*)(dst + 2 * A_PLANE) = u32x2{l0, l1};
+      }
+    }
+  };
+  auto store_b = [&]() {
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      if (B_N % 256 == 0 || tid + it * 256 < B_N) {
+        const int idx = tid + it * 256;
+        const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
+        *(u32x4*)(Bs + pl * B_PLANE + (rem >> 2) * PITCH + (rem & 3) * 16) = rb[it];
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  int a_off[WM], b_off[WN];      // byte offsets of the lane's fragment rows
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int mt = wm * WM + i;
+    if (CONV) a_off[i] = ((2 * mt + (r >> 4)) * 18 + (r & 15)) * PITCH + 16 * h;
+    else a_off[i] = (mt * 32 + r) * PITCH + 16 * h;
+  }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) b_off[j] = ((wn * WN + j) * 32 + r) * PITCH + 16 * h;
+
+  const int nkc = (p.K + BKB - 1) / BKB;
+  const int ntap = CONV ? 9 : 1;
+  const int niter = nkc * ntap;
+
+  load_a(0);
+  load_b(0, 0);
+  for (int it = 0; it < niter; ++it) {
+    const int kc = it / ntap, tap = it - kc * ntap;
+    __syncthreads();
+    if (!CONV || tap == 0) store_a();
+    store_b();
+    __syncthreads();
+    if (it + 1 < niter) {
+      const int kc1 = (it + 1) / ntap, tap1 = (it + 1) - kc1 * ntap;
+      if (!CONV || tap1 == 0) load_a(kc1);
+      load_b(kc1, tap1);
+    }
+    const int toff = CONV ? ((tap / 3) * 18 + (tap % 3)) * PITCH : 0;
+#pragma unroll
+    for (int s = 0; s < BKB / 16; ++s) {
+      u32x4 fa[WM][3], fb[WN][3];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          fa[i][pl] = *(const u32x4*)(As + pl * A_PLANE + a_off[i] + toff + s * 32);
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          fb[j][pl] = *(const u32x4*)(Bs + pl * B_PLANE + b_off[j] + s * 32);
+      // small terms first; term-outer so that consecutive MFMAs hit different tiles
+#define SR_TERM(PA, PB)                                                              \
+  _Pragma("unroll") for (int i = 0; i < WM; ++i)                                     \
+  _Pragma("unroll") for (int j = 0; j < WN; ++j)                                     \
+    acc[i][j] = mfma_bf(fa[i][PA], fb[j][PB], acc[i][j]);
+      SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+#undef SR_TERM
+    }
+  }
+
+  nt_epilogue<WM, WN, CONV>(p, acc, lane, wm, wn, n0, nvalid, m0, img, y0, x0);
+}
+
+template <int WM, int WN, bool CONV>
+int launch_ntb(const NtArgs& p, hipStream_t st) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int AROWS = CONV ? (BM / 16 + 2) * 18 : BM;
+  constexpr int LDS = 3 * (AROWS + BN) * PITCH;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_ntb<WM, WN, CONV>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return sr_fail(-5, "k_ntb: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid;
+  if (CONV) grid = dim3(p.tiles_x * p.tiles_y * p.batch, sr_cdiv(p.N, p.n_tile));
+  else grid = dim3(sr_cdiv(p.M, BM), sr_cdiv(p.N, p.n_tile));
+  hipLaunchKernelGGL((k_ntb<WM, WN, CONV>), grid, dim3(256), LDS, st, p);
+  SR_LAUNCH_CHECK("k_ntb");
+  return 0;
+}
+
+int ntb_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <bool CONV>
+int dispatch_ntb(NtArgs& p, hipStream_t st) {
+  int wn;
+  if (p.N % 180 == 0) { p.n_tile = 180; wn = 3; }
+  else if (p.N <= 64) { p.n_tile = 64; wn = 1; }
+  else if (p.N <= 128 || p.N % 128 == 0) { p.n_tile = 128; wn = 2; }
+  else { p.n_tile = 192; wn = 3; }
+  long blocks128;
+  if (CONV) blocks128 = (long)sr_cdiv(p.Wd, 16) * sr_cdiv(p.H, 8) * p.batch;
+  else blocks128 = sr_cdiv(p.M, 128);
+  blocks128 *= sr_cdiv(p.N, p.n_tile);
+  int wm = blocks128 >= 1024 ? 2 : 1;
+  if (!CONV && wn == 3) wm = 1;          // <2,3> GEMM tile spills
+  const int force_wm = ntb_env("SRHIP_NTB_WM", 0);
+  if (force_wm == 1 || force_wm == 2) wm = force_wm;
+  if (CONV) {
+    p.tiles_x = sr_cdiv(p.Wd, 16);
+    p.tiles_y = sr_cdiv(p.H, wm == 2 ? 8 : 4);
+  }
+#define SR_NTB_CASE(WM_, WN_) \
+  if (wm == WM_ && wn == WN_) return launch_ntb<WM_, WN_, CONV>(p, st);
+  SR_NTB_CASE(1, 1) SR_NTB_CASE(1, 2) SR_NTB_CASE(1, 3)
+  SR_NTB_CASE(2, 1) SR_NTB_CASE(2, 2) SR_NTB_CASE(2, 3)
+#undef SR_NTB_CASE
+  return sr_fail(-22, "ntb: no kernel for wm=%d wn=%d", wm, wn);
+}
+
+// W[rows][ldw] f32 -> out[3][rows][Kp] bf16 (Kp = K rounded up to 32, zero filled)
+__device__ __forceinline__ void split3_slot(const float* __restrict__ W, long ldw, int rows, int K, int Kp,
+                                            unsigned short* __restrict__ out, long i) {
+  const int kq = Kp >> 2;                                       // one float4 (4 k) per thread
+  if (i >= (long)rows * kq) return;
+  const int row = (int)(i / kq), k = (int)(i - (long)row * kq) * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (k < K) v = *(const f32x4*)(W + (long)row * ldw + k);      // K % 4 == 0
+  unsigned h0, m0, l0, h1, m1, l1;
+  split3_pair(v.x, v.y, h0, m0, l0);
+  split3_pair(v.z, v.w, h1, m1, l1);
+  const long plane = (long)rows * Kp;
+  unsigned short* d = out + (long)row * Kp + k;
+  *(u32x2*)(d) = u32x2{h0, h1};
+  *(u32x2*)(d + plane) = u32x2{m0, m1};
+  *(u32x2*)(d + 2 * plane) = u32x2{l0, l1};
+}
+
+__global__ void k_split3(const float* __restrict__ W, long ldw, int rows, int K, int Kp,
+                         unsigned short* __restrict__ out) {
+  split3_slot(W, ldw, rows, K, Kp, out, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// every weight of the network in one launch: block -> table entry by binary search
+__global__ void k_split3_table(const SplitEntry* __restrict__ tab, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SplitEntry e = tab[lo];
+  split3_slot(e.W, e.ldw, e.rows, e.K, sr_kp(e.K), e.out, (long)(blockIdx.x - e.blk0) * blockDim.x + threadIdx.x);
+}
+
+}  // namespace
+
+int sr_split3(const float* W, long ldw, int rows, int K, unsigned short* out, hipStream_t st) {
+  SR_REQUIRE(K % 4 == 0 && ldw % 4 == 0 && rows > 0, "split_bf16x3: K, ldw multiples of 4 (K=%d)", K);
+  const int Kp = sr_kp(K);
+  const long n = (long)rows * (Kp / 4);
+  hipLaunchKernelGGL(k_split3, dim3(sr_cdiv(n, 256)), dim3(256), 0, st, W, ldw, rows, K, Kp, out);
+  SR_LAUNCH_CHECK("k_split3");
+  return 0;
+}
+
+int sr_split3_table(const SplitEntry* tab_dev, int n, int total_blocks, hipStream_t st) {
+  SR_REQUIRE(n > 0 && total_blocks > 0, "split_bf16x3_table: empty table");
+  hipLaunchKernelGGL(k_split3_table, dim3(total_blocks), dim3(256), 0, st, tab_dev, n);
+  SR_LAUNCH_CHECK("k_split3_table");
+  return 0;
+}
+
+int sr_gemm_ntb(NtArgs& p, hipStream_t st) {
+  SR_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0, "gemm_nt_bx3: K, lda must be multiples of 4 (K=%d)", p.K);
+  SR_REQUIRE(p.M > 0 && p.N > 0, "gemm_nt_bx3: empty problem");
+  p.Kp = sr_kp(p.K);
+  SR_REQUIRE((long)p.M * p.lda < (1L << 29) && 6L * p.N * p.Kp < (1L << 31),
+             "gemm_nt_bx3: operand larger than 2 GiB (32-bit staging offsets)");
+  return dispatch_ntb<false>(p, st);
+}
+
+int sr_conv3x3_ntb(NtArgs& p, hipStream_t st) {
+  SR_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0, "conv3x3_bx3: Cin, lda must be multiples of 4 (Cin=%d)", p.K);
+  SR_REQUIRE(p.batch > 0 && p.H > 0 && p.Wd > 0, "conv3x3_bx3: empty image");
+  p.M = p.batch * p.H * p.Wd;
+  p.Kp = sr_kp(p.K);
+  SR_REQUIRE((long)p.M * p.lda < (1L << 29) && 54L * p.N * p.Kp < (1L << 31),
+             "conv3x3_bx3: operand larger than 2 GiB (32-bit staging offsets)");
+  return dispatch_ntb<true>(p, st);
+}

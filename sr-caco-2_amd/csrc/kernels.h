@@ -21,6 +21,8 @@ struct NtArgs {
   int batch, H, Wd, tiles_x, tiles_y;
   int dbg;                    // ablation bits (env SRHIP_NT_DBG; 0 in production)
   int stagger;                // odd blocks sleep this many x 8128 cycles at start
+  // bf16x3 path (gemm_ntb.hip): W pre-split into planes [3][(9)][N][Kp] bf16
+  const unsigned short* Wb; int Kp;
 };
 
 struct TnArgs {
@@ -41,6 +43,13 @@ struct TnArgs {
 
 int sr_gemm_nt(NtArgs& p, hipStream_t st);
 int sr_conv3x3_nt(NtArgs& p, hipStream_t st);
+// one weight of a grouped split (device table; mirrors srhip_split_entry)
+struct SplitEntry { const float* W; unsigned short* out; long ldw; int rows, K, blk0, pad_; };
+int sr_split3_table(const SplitEntry* tab_dev, int n, int total_blocks, hipStream_t st);
+__host__ __device__ static inline int sr_kp(int K) { return (K + 31) / 32 * 32; }
+int sr_split3(const float* W, long ldw, int rows, int K, unsigned short* out, hipStream_t st);
+int sr_gemm_ntb(NtArgs& p, hipStream_t st);
+int sr_conv3x3_ntb(NtArgs& p, hipStream_t st);
 int sr_gemm_tn(TnArgs& p, hipStream_t st);
 int sr_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats);
 int sr_gemm_tn_grouped(TnArgs* probs, int n, hipStream_t st);

@@ -1,0 +1,90 @@
+// Shared epilogue of the NT kernels (gemm_nt.hip: exact-f32 MFMA; gemm_ntb.hip:
+// 3-way bf16 split MFMA): bias, ReLU, residual + per-sample scale (DropPath),
+// GELU' and ReLU' gating, applied to the 32x32 accumulator tiles of one wave.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+template <int WM, int WN, bool CONV>
+__device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][WN], int lane, int wm,
+                                            int wn, int n0, int nvalid, int m0, int img, int y0,
+                                            int x0) {
+  constexpr int BM = 64 * WM;
+  const int r = lane & 31;
+  // per-sample scale (DropPath): one sample per block whenever the sample's
+  // row count is a multiple of the block's rows, else looked up per row.
+  float blk_s = p.alpha;
+  bool per_row = false;
+  if (p.rowscale) {
+    if (CONV) blk_s *= p.rowscale[img];
+    else if (p.rows_per_scale % BM == 0) blk_s *= p.rowscale[m0 / p.rows_per_scale];
+    else per_row = true;
+  }
+  // The epilogue mode is block-uniform: switch OUTSIDE the element loops, and
+  // batch the 16 loads of a tile ahead of the math (one wait per tile, not one
+  // per element).
+  const bool needR = p.R != nullptr && p.epi >= 2;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = (wn * WN + j) * 32 + r;        // column inside the N block
+    const bool cok = col < nvalid;
+    const int gn = n0 + col;
+    const float bv = (cok && p.bias) ? p.bias[gn] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int mt = wm * WM + i;
+      int grow[16];                                // global row (token / pixel), -1 = masked
+      float rv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int lr = mfma_row(q, lane);          // row inside the 32-row tile
+        if (CONV) {
+          const int y = y0 + 2 * mt + (lr >> 4), x = x0 + (lr & 15);
+          grow[q] = (cok && y < p.H && x < p.Wd) ? (img * p.H + y) * p.Wd + x : -1;
+        } else {
+          const int g = m0 + mt * 32 + lr;
+          grow[q] = (cok && g < p.M) ? g : -1;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        rv[q] = (needR && grow[q] >= 0) ? p.R[(long)grow[q] * p.ldr + gn] : 0.f;
+      f32x16& v = acc[i][j];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] += bv;
+      switch (p.epi) {
+        case 1:
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = fmaxf(v[q], 0.f);
+          break;
+        case 2:
+          if (per_row) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (grow[q] >= 0) v[q] *= p.rowscale[grow[q] / p.rows_per_scale];
+          }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = v[q] * blk_s + rv[q];
+          break;
+        case 3:
+          if (per_row) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (grow[q] >= 0) v[q] *= p.rowscale[grow[q] / p.rows_per_scale];
+          }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = v[q] * blk_s * dgelu_f(rv[q]);
+          break;
+        case 4:
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = rv[q] > 0.f ? v[q] : 0.f;
+          break;
+        default:
+          break;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (grow[q] >= 0) p.C[(long)grow[q] * p.ldc + gn] = v[q];
+    }
+  }
+}

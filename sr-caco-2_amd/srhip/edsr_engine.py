@@ -24,6 +24,7 @@ class EDSREngine:
         self.stages = int(math.log2(net.scale))
         self.bufs = _Bufs()
         self.derived = _Bufs()
+        self.ws = ops.WeightSet()
         self.prepared = False
         self.saved = None
 
@@ -50,6 +51,9 @@ class EDSREngine:
             co, ci = conv.weight.shape[:2]
             ops.pack_conv_weight(conv.weight.data, D.get(name + ".wp", 9, co, ci, device=dev),
                                  D.get(name + ".wpt", 9, ci, co, device=dev))
+            self.ws.register(name + ".wp", D.d[name + ".wp"])
+            self.ws.register(name + ".wpt", D.d[name + ".wpt"])
+        self.ws.refresh()
         self.prepared = True
 
     # ------------------------------------------------------------------ forward
@@ -73,20 +77,20 @@ class EDSREngine:
         for k in range(self.nb):
             kk = k if save else k % 2
             a = buf(f"a{kk if save else 0}", B, H, W, F)
-            ops.conv3x3(r, D.d[f"b{k}.0.wp"], net.body[k].body[0].bias.data, F, out=a, epi=1)
+            ops.conv3x3(r, self.ws[f"b{k}.0.wp"], net.body[k].body[0].bias.data, F, out=a, epi=1)
             rn = buf(f"r{kk}", B, H, W, F)
-            ops.conv3x3(a, D.d[f"b{k}.2.wp"], net.body[k].body[2].bias.data, F, out=rn, epi=2, R=r,
+            ops.conv3x3(a, self.ws[f"b{k}.2.wp"], net.body[k].body[2].bias.data, F, out=rn, epi=2, R=r,
                         alpha=rs)
             if save:
                 blocks.append((r, a))
             r = rn
         rb = buf("rb", B, H, W, F)
-        ops.conv3x3(r, D.d["bend.wp"], net.body[self.nb].bias.data, F, out=rb, epi=2, R=f0)
+        ops.conv3x3(r, self.ws["bend.wp"], net.body[self.nb].bias.data, F, out=rb, epi=2, R=f0)
         u, h, w = rb, H, W
         ups = []
         for i in range(self.stages):
             c = buf(f"c{i}", B, h, w, 4 * F)
-            ops.conv3x3(u, D.d[f"up{i}.wp"], net.tail[0][2 * i].bias.data, 4 * F, out=c)
+            ops.conv3x3(u, self.ws[f"up{i}.wp"], net.tail[0][2 * i].bias.data, 4 * F, out=c)
             un = buf(f"u{i}", B, 2 * h, 2 * w, F)
             ops.pixel_shuffle(c, 2, nhwc_out=True, out=un)
             if save:
@@ -128,25 +132,25 @@ class EDSREngine:
             ops.pixel_shuffle(du, 2, nhwc_out=True, inverse=True, out=dc)
             ops.conv3x3_wgrad(dc, sv["ups"][i], G(f"tail.0.{2 * i}.weight"), G(f"tail.0.{2 * i}.bias"))
             du = buf(f"du{i}", B, h, w, F)
-            ops.conv3x3(dc, D.d[f"up{i}.wpt"], None, F, out=du)
+            ops.conv3x3(dc, self.ws[f"up{i}.wpt"], None, F, out=du)
         drb = du                                             # grad wrt rb (= also grad wrt f0 via the skip)
         ops.conv3x3_wgrad(drb, sv["r_last"], G(f"body.{self.nb}.weight"), G(f"body.{self.nb}.bias"))
         ga, gb, da = buf("ga", B, H, W, F), buf("gb", B, H, W, F), buf("da", B, H, W, F)
         g = ga
-        ops.conv3x3(drb, D.d["bend.wpt"], None, F, out=g)
+        ops.conv3x3(drb, self.ws["bend.wpt"], None, F, out=g)
         for k in reversed(range(self.nb)):
             r_in, a = sv["blocks"][k]
             p = f"body.{k}.body."
             other = gb if g is ga else ga
             # r_out = rs*(conv2(a)+b2) + r_in ;  a = relu(conv1(r_in)+b1)
             ops.conv3x3_wgrad(g, a, G(p + "2.weight"), G(p + "2.bias"))
-            ops.conv3x3(g, D.d[f"b{k}.2.wpt"], None, F, out=da, epi=4, R=a)     # * (a > 0)
+            ops.conv3x3(g, self.ws[f"b{k}.2.wpt"], None, F, out=da, epi=4, R=a)     # * (a > 0)
             if rs != 1.0:
                 ops.axpby(G(p + "2.weight"), G(p + "2.weight"), 0.0, rs)
                 ops.axpby(G(p + "2.bias"), G(p + "2.bias"), 0.0, rs)
                 ops.axpby(da, da, 0.0, rs)
             ops.conv3x3_wgrad(da, r_in, G(p + "0.weight"), G(p + "0.bias"))
-            ops.conv3x3(da, D.d[f"b{k}.0.wpt"], None, F, out=other, epi=2, R=g)  # + skip gradient
+            ops.conv3x3(da, self.ws[f"b{k}.0.wpt"], None, F, out=other, epi=2, R=g)  # + skip gradient
             g = other
         ops.axpby(g, drb, 1.0, 1.0)                          # long skip: rb = conv(body) + f0
         ops.conv3x3_cin1_wgrad(sv["x"], g, G("head.0.weight"), G("head.0.bias"))

@@ -37,33 +37,126 @@ def _rows(t):
 
 
 # ------------------------------------------------------------------ contractions
+class Bx3:
+    """Weight operand pre-split into three bf16 planes [3][rows][Kp] for the bf16x3
+    contractions (srhip_split_bf16x3).  rows = N (Linear) or 9*Cout (conv pack)."""
+    __slots__ = ("planes", "rows", "K")
+
+    def __init__(self, rows, K, device):
+        kp = lib.srhip_bf16x3_kp(K)
+        self.planes = torch.empty(3, rows, kp, device=device, dtype=torch.int16)
+        self.rows, self.K = rows, K
+
+    def fill(self, W2d):
+        """W2d: [rows][K] f32 view (row stride = W2d.stride(0))."""
+        assert W2d.shape == (self.rows, self.K) and W2d.stride(1) == 1 and W2d.dtype == torch.float32
+        call("srhip_split_bf16x3", _p(W2d), W2d.stride(0), self.rows, self.K, _p(self.planes), _st())
+        return self
+
+
+def split_bf16x3(W):
+    """f32 weight [N,K] or conv pack [9,Cout,Cin] -> Bx3."""
+    W2d = W.reshape(-1, W.shape[-1])
+    return Bx3(W2d.shape[0], W2d.shape[1], W.device).fill(W2d)
+
+
+class _SplitEntry(ctypes.Structure):   # srhip_split_entry (include/srhip.h)
+    _fields_ = [("W", ctypes.c_void_p), ("out", ctypes.c_void_p), ("ldw", ctypes.c_long),
+                ("rows", ctypes.c_int), ("K", ctypes.c_int), ("blk0", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+class SplitTable:
+    """(f32 source matrix -> Bx3) pairs refreshed by ONE launch (srhip_split_bf16x3_table).
+    The device table holds raw pointers: sources and planes must stay allocated."""
+
+    def __init__(self, pairs):
+        n = len(pairs)
+        arr = (_SplitEntry * n)()
+        blk = 0
+        self.keep = pairs
+        for e, (src, bx) in zip(arr, pairs):
+            src2 = src.reshape(-1, src.shape[-1]) if src.dim() != 2 else src
+            assert src2.data_ptr() == src.data_ptr() and src2.stride(1) == 1
+            assert src2.shape == (bx.rows, bx.K) and src.dtype == torch.float32 and src.is_cuda
+            e.W, e.out, e.ldw, e.rows, e.K, e.blk0 = src2.data_ptr(), bx.planes.data_ptr(), src2.stride(0), bx.rows, bx.K, blk
+            blk += lib.srhip_split_blocks(bx.rows, bx.K)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = raw.to(pairs[0][0].device)
+        self.n, self.blocks = n, blk
+
+    def run(self):
+        call("srhip_split_bf16x3_table", _p(self.table), self.n, self.blocks, _st())
+
+
+class WeightSet:
+    """Operand form of every matmul / conv weight of a network: the f32 tensor itself
+    (env SRHIP_MM=f32: exact-f32 MFMA kernels) or its Bx3 planes (default: bf16x3 split
+    MFMA kernels), refreshed from the f32 sources by ONE grouped split launch."""
+
+    def __init__(self):
+        import os
+        self.use_bx3 = os.environ.get("SRHIP_MM", "bx3") != "f32"
+        self.src, self.bx, self.table, self.sig = {}, {}, None, None
+
+    def register(self, key, t):
+        self.src[key] = t
+
+    def refresh(self):
+        if not self.use_bx3:
+            return
+        sig = tuple((k, t.data_ptr(), tuple(t.shape)) for k, t in self.src.items())
+        if sig != self.sig:
+            pairs = []
+            for k, t in self.src.items():
+                rows = t.numel() // t.shape[-1]
+                old = self.bx.get(k)
+                if old is None or (old.rows, old.K) != (rows, t.shape[-1]):
+                    self.bx[k] = Bx3(rows, t.shape[-1], t.device)
+                pairs.append((t, self.bx[k]))
+            self.table, self.sig = SplitTable(pairs), sig
+        self.table.run()
+
+    def __getitem__(self, key):
+        return self.bx[key] if self.use_bx3 else self.src[key]
+
+
 def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
             rowscale=None, rows_per_scale=1, alpha=1.0):
-    """out[M,N] = epi(pro(A)[M,K] @ W[N,K]^T + bias)."""
-    _chk(A, W, bias, out, ln_stats, R, rowscale)
+    """out[M,N] = epi(pro(A)[M,K] @ W[N,K]^T + bias).  W: f32 tensor (exact-f32
+    MFMA) or Bx3 (3-way bf16 split MFMA)."""
+    bx = isinstance(W, Bx3)
+    _chk(A, None if bx else W, bias, out, ln_stats, R, rowscale)
     M, K = A.shape
-    N = W.shape[0]
-    assert W.shape[1] == K
+    N = W.rows if bx else W.shape[0]
+    assert (W.K if bx else W.shape[1]) == K
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    args = (_p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+    tail = (_p(bias), _p(out), out.stride(0), M, N, K,
             a_mode, _p(ln_stats), epi, _p(R), 0 if R is None else R.stride(0), _p(rowscale),
             rows_per_scale, float(alpha), _st())
+    if bx:
+        name, args = "srhip_gemm_nt_bx3", (_p(A), A.stride(0), _p(W.planes)) + tail
+    else:
+        name, args = "srhip_gemm_nt", (_p(A), A.stride(0), _p(W), W.stride(0)) + tail
     if probe.active == "gemm_nt":
         with probe.timed(("gemm_nt", M, N, K), 2.0 * M * N * K):
-            call("srhip_gemm_nt", *args)
+            call(name, *args)
     else:
-        call("srhip_gemm_nt", *args)
+        call(name, *args)
     return out
 
 
 def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0):
-    """X NHWC [B,H,W,Cin], Wp packed [9,Cout,Cin] -> [B,H,W,Cout]."""
-    _chk(X, Wp, bias, out, R, rowscale)
+    """X NHWC [B,H,W,Cin], Wp packed [9,Cout,Cin] (f32 tensor or Bx3) -> [B,H,W,Cout]."""
+    bx = isinstance(Wp, Bx3)
+    _chk(X, None if bx else Wp, bias, out, R, rowscale)
     B, H, W, Cin = X.shape
     if out is None:
         out = torch.empty(B, H, W, Cout, device=X.device, dtype=torch.float32)
-    call("srhip_conv3x3_nhwc", _p(X), X.stride(2), _p(Wp), _p(bias), _p(out), out.stride(2),
+    if bx:
+        assert Wp.rows == 9 * Cout and Wp.K == Cin
+    call("srhip_conv3x3_nhwc_bx3" if bx else "srhip_conv3x3_nhwc", _p(X), X.stride(2),
+         _p(Wp.planes if bx else Wp), _p(bias), _p(out), out.stride(2),
          B, H, W, Cin, Cout, epi, _p(R), 0 if R is None else R.stride(2), _p(rowscale),
          float(alpha), _st())
     return out

@@ -50,6 +50,7 @@ class SwinIREngine:
                 self.layer_of_block.append(li)
         self.bufs = _Bufs()
         self.derived = _Bufs()
+        self.ws = ops.WeightSet()      # matmul operands: f32 tensors or bf16x3 planes
         self.prepared = False
         self.saved = None
 
@@ -98,6 +99,16 @@ class SwinIREngine:
             co, ci = conv.weight.shape[:2]
             ops.pack_conv_weight(conv.weight.data, D.get(name + ".wp", 9, co, ci, device=dev),
                                  D.get(name + ".wpt", 9, ci, co, device=dev))
+        ws = self.ws
+        for i, b in enumerate(self.blocks):
+            for k in ("wq", "wqT", "wpT", "w1", "w1T", "w2T"):
+                ws.register(f"{i}.{k}", D.d[f"{i}.{k}"])
+            ws.register(f"{i}.wproj", b.attn.proj.weight.data)
+            ws.register(f"{i}.w2", b.mlp.fc2.weight.data)
+        for name, _ in self._convs():
+            ws.register(name + ".wp", D.d[name + ".wp"])
+            ws.register(name + ".wpt", D.d[name + ".wpt"])
+        ws.refresh()
         self.prepared = True
 
     def _convs(self):
@@ -113,7 +124,7 @@ class SwinIREngine:
         dp: None or a [2*nblocks, B] tensor of DropPath multipliers."""
         if not self.prepared:
             self.prepare()
-        net, C, hid, D = self.net, self.C, self.hid, self.derived
+        net, C, hid, D, ws = self.net, self.C, self.hid, self.derived, self.ws
         B, H, W = x.shape
         T = B * H * W
         dev = x.device
@@ -142,26 +153,26 @@ class SwinIREngine:
                 st1 = buf(f"{k}.st1", T, 2)
                 ops.layernorm_fwd(t, st1)
                 qkv = buf(f"{k}.qkv", T, 3 * C)
-                ops.gemm_nt(t, D.d[f"{bi}.wq"], D.d[f"{bi}.bq"], out=qkv, a_mode=1, ln_stats=st1)
+                ops.gemm_nt(t, ws[f"{bi}.wq"], D.d[f"{bi}.bq"], out=qkv, a_mode=1, ln_stats=st1)
                 a = buf(f"{k}.a", T, C)
                 ops.window_attention_fwd(qkv, a, D.d[f"{bi}.biasT"], B, H, W, C, heads, blk.shift_size)
                 x1 = buf(f"{k}.x1", T, C)
-                ops.gemm_nt(a, blk.attn.proj.weight.data, blk.attn.proj.bias.data, out=x1, epi=2, R=t,
+                ops.gemm_nt(a, ws[f"{bi}.wproj"], blk.attn.proj.bias.data, out=x1, epi=2, R=t,
                             rowscale=s1, rows_per_scale=H * W)
                 st2 = buf(f"{k}.st2", T, 2)
                 ops.layernorm_fwd(x1, st2)
                 h = buf(f"{k}.h", T, hid)
-                ops.gemm_nt(x1, D.d[f"{bi}.w1"], D.d[f"{bi}.b1"], out=h, a_mode=1, ln_stats=st2)
+                ops.gemm_nt(x1, ws[f"{bi}.w1"], D.d[f"{bi}.b1"], out=h, a_mode=1, ln_stats=st2)
                 # block outputs ping-pong in eval, are kept per block in training
                 x2 = buf(f"{bi if save else bi % 2}.x2", T, C)
-                ops.gemm_nt(h, blk.mlp.fc2.weight.data, blk.mlp.fc2.bias.data, out=x2, a_mode=2, epi=2,
+                ops.gemm_nt(h, ws[f"{bi}.w2"], blk.mlp.fc2.bias.data, out=x2, a_mode=2, epi=2,
                             R=x1, rowscale=s2, rows_per_scale=H * W)
                 if save:
                     sv["blocks"].append((t, st1, qkv, a, x1, st2, h))
                 t = x2
                 bi += 1
             tl = buf(f"L{li if save else li % 2}.out", T, C)
-            ops.conv3x3(t.view(B, H, W, C), D.d[f"l{li}.wp"], layer.conv.bias.data, C,
+            ops.conv3x3(t.view(B, H, W, C), ws[f"l{li}.wp"], layer.conv.bias.data, C,
                         out=tl.view(B, H, W, C), epi=2, R=t_in.view(B, H, W, C))
             if save:
                 sv["layers"].append((t_in, t))
@@ -170,12 +181,12 @@ class SwinIREngine:
         tn = buf("tn", T, C)
         ops.layernorm_fwd(t, st_n, tn, net.norm.weight.data, net.norm.bias.data)
         f = buf("f", B, H, W, C)
-        ops.conv3x3(tn.view(B, H, W, C), D.d["cab.wp"], net.conv_after_body.bias.data, C, out=f, epi=2,
+        ops.conv3x3(tn.view(B, H, W, C), ws["cab.wp"], net.conv_after_body.bias.data, C, out=f, epi=2,
                     R=f0)
         r = self.scale
         cu = r * r * net.in_chans
         u = buf("u", B, H, W, cu)
-        ops.conv3x3(f, D.d["up.wp"], net.upsample[0].bias.data, cu, out=u)
+        ops.conv3x3(f, ws["up.wp"], net.upsample[0].bias.data, cu, out=u)
         y = torch.empty(B, net.in_chans, H * r, W * r, device=dev) if not save else \
             buf("y", B, net.in_chans, H * r, W * r)
         ops.pixel_shuffle(u, r, out=y)
@@ -190,7 +201,7 @@ class SwinIREngine:
         gradient (overwritten).  Returns d loss / d x [B,H,W] if need_dx."""
         sv = self.saved
         assert sv is not None, "backward() without a saved forward"
-        net, C, hid, D = self.net, self.C, self.hid, self.derived
+        net, C, hid, D, ws = self.net, self.C, self.hid, self.derived, self.ws
         B, H, W, dp = sv["B"], sv["H"], sv["W"], sv["dp"]
         T = B * H * W
         dev = dy.device
@@ -208,11 +219,11 @@ class SwinIREngine:
         ops.pixel_shuffle(dy, r, inverse=True, out=du)
         ops.conv3x3_wgrad(du, sv["f"], G("upsample.0.weight"), G("upsample.0.bias"))
         df = buf("df", B, H, W, C)
-        ops.conv3x3(du, D.d["up.wpt"], None, C, out=df)
+        ops.conv3x3(du, ws["up.wpt"], None, C, out=df)
         ops.conv3x3_wgrad(df, sv["tn"].view(B, H, W, C), G("conv_after_body.weight"),
                           G("conv_after_body.bias"))
         dtn = buf("dtn", T, C)
-        ops.conv3x3(df, D.d["cab.wpt"], None, C, out=dtn.view(B, H, W, C))
+        ops.conv3x3(df, ws["cab.wpt"], None, C, out=dtn.view(B, H, W, C))
         dt = buf("dt", T, C)
         ops.layernorm_bwd(dtn, sv["t_last"], sv["st_n"], dt, gamma=net.norm.weight.data,
                           dgamma=G("norm.weight"), dbeta=G("norm.bias"))
@@ -230,7 +241,7 @@ class SwinIREngine:
                               G(pre + "conv.bias"))
             gi = 0
             g = gbufs[gi]
-            ops.conv3x3(dt.view(B, H, W, C), D.d[f"l{li}.wpt"], None, C, out=g.view(B, H, W, C))
+            ops.conv3x3(dt.view(B, H, W, C), ws[f"l{li}.wpt"], None, C, out=g.view(B, H, W, C))
             nb = len(layer.residual_group.blocks)
             for j in reversed(range(nb)):
                 bi -= 1
@@ -242,18 +253,18 @@ class SwinIREngine:
                 s2 = None if dp is None else dp[2 * bi + 1]
                 g1, gout = gbufs[(gi + 1) % 3], gbufs[(gi + 2) % 3]
                 # ---- MLP branch: x2 = x1 + s2*(gelu(h) W2^T + b2)
-                ops.gemm_nt(g, D.d[f"{bi}.w2T"], None, out=dh, epi=3, R=h, rowscale=s2,
+                ops.gemm_nt(g, ws[f"{bi}.w2T"], None, out=dh, epi=3, R=h, rowscale=s2,
                             rows_per_scale=H * W)
-                ops.gemm_nt(dh, D.d[f"{bi}.w1T"], None, out=dxh)
+                ops.gemm_nt(dh, ws[f"{bi}.w1T"], None, out=dxh)
                 ops.layernorm_bwd(dxh, x1, st2, g1, res=g)
                 # ---- attention branch: x1 = t + s1*(a Wp^T + bp)
-                ops.gemm_nt(g1, D.d[f"{bi}.wpT"], None, out=da, epi=2, rowscale=s1, rows_per_scale=H * W)
+                ops.gemm_nt(g1, ws[f"{bi}.wpT"], None, out=da, epi=2, rowscale=s1, rows_per_scale=H * W)
                 dbT = buf("dbiasT", heads, 64, 64)
                 dbT.zero_()
                 ops.window_attention_bwd(qkv, da, dqkv, D.d[f"{bi}.biasT"], D.d[f"{bi}.biasN"], dbT, B, H,
                                          W, C, heads, blk.shift_size)
                 ops.bias_grad(dbT, G(p + "attn.relative_position_bias_table"))
-                ops.gemm_nt(dqkv, D.d[f"{bi}.wqT"], None, out=dxh)
+                ops.gemm_nt(dqkv, ws[f"{bi}.wqT"], None, out=dxh)
                 ops.layernorm_bwd(dxh, t, st1, gout, res=g1)
                 # ---- the four weight gradients of the block in ONE launch
                 ops.linear_wgrad_grouped([

@@ -1,0 +1,127 @@
+"""bf16x3 split-MFMA contractions (srhip_gemm_nt_bx3 / srhip_conv3x3_nhwc_bx3) against
+float64 aten and against the exact-f32 MFMA kernels: same prologues / epilogues,
+f32-level accuracy (the split keeps 24 significant bits per operand)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from srhip import ops as o
+    return o
+
+
+G = torch.Generator().manual_seed(4321)
+
+
+def rnd(*shape, scale=1.0):
+    return torch.randn(*shape, generator=G) * scale
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def test_split_is_exact(ops):
+    """h + m + l reproduces the f32 value to <= 1 ulp of the 24-bit mantissa."""
+    W = rnd(180, 180) * torch.exp(rnd(180, 180) * 3)
+    bx = ops.split_bf16x3(W.cuda())
+    kp = bx.planes.shape[-1]
+    assert kp == 192 and bx.planes.shape == (3, 180, 192)
+    parts = (bx.planes.cpu().to(torch.int32) << 16).view(torch.float32).double()  # bf16 bits -> f32
+    rec = parts.sum(0)
+    assert rec[:, 180:].abs().max() == 0
+    err = ((rec[:, :180] - W.double()).abs() / W.double().abs().clamp_min(1e-30)).max().item()
+    assert err <= 2.0 ** -23, err
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 180, 180), (4096, 540, 180), (1000, 60, 60), (777, 64, 64),
+                                   (2048, 360, 180), (515, 180, 360), (64, 120, 60), (130, 256, 64),
+                                   (33000, 180, 180), (999, 180, 540), (100, 48, 20)])
+def test_gemm_bx3_matches_f32(ops, M, N, K):
+    A, W, b = rnd(M, K), rnd(N, K, scale=0.1), rnd(N)
+    ref = F.linear(A.double(), W.double(), b.double())
+    f32 = ops.gemm_nt(A.cuda(), W.cuda(), b.cuda())
+    bx = ops.gemm_nt(A.cuda(), ops.split_bf16x3(W.cuda()), b.cuda())
+    e32, ebx = relerr(f32, ref), relerr(bx, ref)
+    assert ebx <= max(2.0 * e32, 1e-6), f"bx3 {ebx:.3e} vs f32 kernel {e32:.3e}"
+
+
+def test_gemm_bx3_prologues_epilogues(ops):
+    M, N, K = 1024, 180, 180
+    A, W, b, R = rnd(M, K), rnd(N, K, scale=0.1), rnd(N), rnd(M, N)
+    Wb = ops.split_bf16x3(W.cuda())
+    d = lambda t: t.cuda()
+    mean = A.mean(1)
+    rstd = 1.0 / torch.sqrt(A.var(1, unbiased=False) + 1e-5)
+    stats = torch.stack([mean, rstd], 1)
+    tol = 2e-6
+    out = ops.gemm_nt(d(A), Wb, d(b), a_mode=1, ln_stats=d(stats))
+    assert relerr(out, F.linear(((A - mean[:, None]) * rstd[:, None]).double(), W.double(), b.double())) < tol
+    out = ops.gemm_nt(d(A), Wb, d(b), a_mode=2)
+    assert relerr(out, F.linear(F.gelu(A.double()), W.double(), b.double())) < tol
+    out = ops.gemm_nt(d(A), Wb, d(b), epi=1)
+    assert relerr(out, F.relu(F.linear(A.double(), W.double(), b.double()))) < tol
+    rs = torch.tensor([1.0, 0.0, 1.25, 2.0])
+    out = ops.gemm_nt(d(A), Wb, d(b), epi=2, R=d(R), rowscale=d(rs), rows_per_scale=256, alpha=0.5)
+    ref = R.double() + 0.5 * rs.double().repeat_interleave(256)[:, None] * F.linear(A.double(), W.double(), b.double())
+    assert relerr(out, ref) < tol
+    Rg = R.double().clone().requires_grad_(True)
+    F.gelu(Rg).sum().backward()
+    out = ops.gemm_nt(d(A), Wb, None, epi=3, R=d(R), rowscale=d(rs), rows_per_scale=256)
+    ref = rs.double().repeat_interleave(256)[:, None] * F.linear(A.double(), W.double()) * Rg.grad
+    assert relerr(out, ref) < tol
+    out = ops.gemm_nt(d(A), Wb, None, epi=4, R=d(R))
+    assert relerr(out, F.linear(A.double(), W.double()) * (R > 0)) < tol
+    wide = torch.zeros(M, 540).cuda()
+    ops.gemm_nt(d(A), Wb, d(b), out=wide[:, 180:360])
+    assert relerr(wide[:, 180:360], F.linear(A.double(), W.double(), b.double())) < tol
+    assert wide[:, :180].abs().max() == 0 and wide[:, 360:].abs().max() == 0
+    # A as a column slice of a wider buffer (qkv -> q)
+    Aw = rnd(M, 540)
+    out = ops.gemm_nt(d(Aw)[:, 180:360], Wb, d(b))
+    assert relerr(out, F.linear(Aw[:, 180:360].double(), W.double(), b.double())) < tol
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 16, 180, 180), (1, 24, 40, 60, 60), (1, 20, 12, 64, 64),
+                                         (1, 16, 16, 64, 256), (2, 64, 64, 180, 64), (1, 9, 7, 16, 16),
+                                         (8, 64, 64, 180, 180)])
+def test_conv_bx3_matches_f32(ops, B, H, W, Ci, Co):
+    x, w, b = rnd(B, Ci, H, W), rnd(Co, Ci, 3, 3, scale=0.05), rnd(Co)
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = torch.empty(9, Co, Ci).cuda()
+    wpt = torch.empty(9, Ci, Co).cuda()
+    ops.pack_conv_weight(w.cuda(), wp, wpt)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    y32 = ops.conv3x3(xh, wp, b.cuda(), Co)
+    ybx = ops.conv3x3(xh, ops.split_bf16x3(wp), b.cuda(), Co)
+    e32, ebx = relerr(y32.permute(0, 3, 1, 2), ref), relerr(ybx.permute(0, 3, 1, 2), ref)
+    assert ebx <= max(2.0 * e32, 1e-6), f"conv bx3 {ebx:.3e} vs f32 kernel {e32:.3e}"
+    if B * H * W > 20000:
+        return
+    dy = rnd(B, Co, H, W)
+    dyh = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dx = ops.conv3x3(dyh, ops.split_bf16x3(wpt), None, Ci)
+    xr = x.double().clone().requires_grad_(True)
+    F.conv2d(xr, w.double(), b.double(), padding=1).backward(dy.double())
+    assert relerr(dx.permute(0, 3, 1, 2), xr.grad) < 2e-6
+
+
+def test_conv_bx3_epilogues(ops):
+    B, H, W, C = 2, 16, 24, 64
+    x, w, b, R = rnd(B, C, H, W), rnd(C, C, 3, 3, scale=0.05), rnd(C), rnd(B, C, H, W)
+    xh, Rh = x.permute(0, 2, 3, 1).contiguous().cuda(), R.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = torch.empty(9, C, C).cuda()
+    ops.pack_conv_weight(w.cuda(), wp, None)
+    wb = ops.split_bf16x3(wp)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    y = ops.conv3x3(xh, wb, b.cuda(), C, epi=1)
+    assert relerr(y.permute(0, 3, 1, 2), F.relu(ref)) < 2e-6
+    y = ops.conv3x3(xh, wb, b.cuda(), C, epi=2, R=Rh, alpha=0.1)
+    assert relerr(y.permute(0, 3, 1, 2), R.double() + 0.1 * ref) < 2e-6
+    y = ops.conv3x3(xh, wb, None, C, epi=4, R=Rh)
+    assert relerr(y.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), None, padding=1) * (R > 0)) < 2e-6
