@@ -109,6 +109,16 @@ int srhip_tn_group_plan(int M, int ntiles, int* S);
 int srhip_gemm_tn_grouped(const srhip_tn_problem* probs, int nprob, int M, int S, void* stream);
 int srhip_conv3x3_wgrad(const float* dY, long lddy, const float* X, long ldx, int B, int H, int W,
                         int Cout, int Cin, float* part, float* part_colsum, int S, void* stream);
+
+/* The three weight-gradient contractions above on the bf16 MFMA with 3-way split
+ * operands (see srhip_gemm_nt_bx3): same arguments, slicing and reducers; no
+ * alignment requirement on NI / NJ / lda / ldb. */
+int srhip_gemm_tn_bx3(const float* A, long lda, const float* B, long ldb, int M, int NI, int NJ,
+                      const float* a_rowscale, int a_rowscale_rows, int b_mode, const float* ln_stats,
+                      float* part, float* part_colsum, int S, void* stream);
+int srhip_gemm_tn_grouped_bx3(const srhip_tn_problem* probs, int nprob, int M, int S, void* stream);
+int srhip_conv3x3_wgrad_bx3(const float* dY, long lddy, const float* X, long ldx, int B, int H, int W,
+                            int Cout, int Cin, float* part, float* part_colsum, int S, void* stream);
 int srhip_reduce_linear_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
                               int N, int K, void* stream);
 /* Linear fed by a folded LayerNorm: also emits dgamma / dbeta of that norm

@@ -99,9 +99,9 @@ int srhip_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
   return sr_tn_plan(M, NI, NJ, conv, S, part_floats);
 }
 
-int srhip_gemm_tn(const float* A, long lda, const float* B, long ldb, int M, int NI, int NJ,
-                  const float* a_rowscale, int a_rowscale_rows, int b_mode, const float* ln_stats,
-                  float* part, float* part_colsum, int S, void* stream) {
+static int gemm_tn_any(bool bx, const float* A, long lda, const float* B, long ldb, int M, int NI, int NJ,
+                       const float* a_rowscale, int a_rowscale_rows, int b_mode, const float* ln_stats,
+                       float* part, float* part_colsum, int S, void* stream) {
   SR_REQUIRE(b_mode >= 0 && b_mode <= 2, "gemm_tn: b_mode %d", b_mode);
   SR_REQUIRE(b_mode != 1 || ln_stats, "gemm_tn: layernorm prologue without stats");
   SR_REQUIRE(!a_rowscale || a_rowscale_rows > 0, "gemm_tn: a_rowscale_rows must be > 0");
@@ -110,13 +110,25 @@ int srhip_gemm_tn(const float* A, long lda, const float* B, long ldb, int M, int
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.M = M; p.NI = NI; p.NJ = NJ;
   p.a_rowscale = a_rowscale; p.a_rowscale_rows = a_rowscale_rows; p.b_mode = b_mode;
   p.ln_stats = ln_stats; p.part = part; p.part_colsum = part_colsum; p.S = S; p.conv = 0;
-  return sr_gemm_tn(p, (hipStream_t)stream);
+  return bx ? sr_gemm_tnb(p, (hipStream_t)stream) : sr_gemm_tn(p, (hipStream_t)stream);
+}
+int srhip_gemm_tn(const float* A, long lda, const float* B, long ldb, int M, int NI, int NJ,
+                  const float* a_rowscale, int a_rowscale_rows, int b_mode, const float* ln_stats,
+                  float* part, float* part_colsum, int S, void* stream) {
+  return gemm_tn_any(false, A, lda, B, ldb, M, NI, NJ, a_rowscale, a_rowscale_rows, b_mode, ln_stats, part,
+                     part_colsum, S, stream);
+}
+int srhip_gemm_tn_bx3(const float* A, long lda, const float* B, long ldb, int M, int NI, int NJ,
+                      const float* a_rowscale, int a_rowscale_rows, int b_mode, const float* ln_stats,
+                      float* part, float* part_colsum, int S, void* stream) {
+  return gemm_tn_any(true, A, lda, B, ldb, M, NI, NJ, a_rowscale, a_rowscale_rows, b_mode, ln_stats, part,
+                     part_colsum, S, stream);
 }
 
 int srhip_tn_tiles(int NI, int NJ) { return sr_tn_tiles(NI, NJ); }
 int srhip_tn_group_plan(int M, int ntiles, int* S) { return sr_tn_group_plan(M, ntiles, S); }
 
-int srhip_gemm_tn_grouped(const srhip_tn_problem* probs, int nprob, int M, int S, void* stream) {
+static int gemm_tn_grouped_any(bool bx, const srhip_tn_problem* probs, int nprob, int M, int S, void* stream) {
   SR_REQUIRE(nprob >= 1 && nprob <= 4, "gemm_tn_grouped: 1..4 problems");
   TnArgs a[4];
   memset(a, 0, sizeof(a));
@@ -129,16 +141,30 @@ int srhip_gemm_tn_grouped(const srhip_tn_problem* probs, int nprob, int M, int S
     p.a_rowscale = q.a_rowscale; p.a_rowscale_rows = q.a_rowscale_rows; p.b_mode = q.b_mode;
     p.ln_stats = q.ln_stats; p.part = q.part; p.part_colsum = q.part_colsum; p.S = S;
   }
-  return sr_gemm_tn_grouped(a, nprob, (hipStream_t)stream);
+  return bx ? sr_gemm_tnb_grouped(a, nprob, (hipStream_t)stream) : sr_gemm_tn_grouped(a, nprob, (hipStream_t)stream);
+}
+int srhip_gemm_tn_grouped(const srhip_tn_problem* probs, int nprob, int M, int S, void* stream) {
+  return gemm_tn_grouped_any(false, probs, nprob, M, S, stream);
+}
+int srhip_gemm_tn_grouped_bx3(const srhip_tn_problem* probs, int nprob, int M, int S, void* stream) {
+  return gemm_tn_grouped_any(true, probs, nprob, M, S, stream);
 }
 
-int srhip_conv3x3_wgrad(const float* dY, long lddy, const float* X, long ldx, int B, int H, int W,
-                        int Cout, int Cin, float* part, float* part_colsum, int S, void* stream) {
+static int conv_wgrad_any(bool bx, const float* dY, long lddy, const float* X, long ldx, int B, int H, int W,
+                          int Cout, int Cin, float* part, float* part_colsum, int S, void* stream) {
   TnArgs p;
   memset(&p, 0, sizeof(p));
   p.A = dY; p.lda = lddy; p.B = X; p.ldb = ldx; p.M = B * H * W; p.NI = Cout; p.NJ = Cin;
   p.part = part; p.part_colsum = part_colsum; p.S = S; p.conv = 1; p.batch = B; p.H = H; p.Wd = W;
-  return sr_gemm_tn(p, (hipStream_t)stream);
+  return bx ? sr_gemm_tnb(p, (hipStream_t)stream) : sr_gemm_tn(p, (hipStream_t)stream);
+}
+int srhip_conv3x3_wgrad(const float* dY, long lddy, const float* X, long ldx, int B, int H, int W,
+                        int Cout, int Cin, float* part, float* part_colsum, int S, void* stream) {
+  return conv_wgrad_any(false, dY, lddy, X, ldx, B, H, W, Cout, Cin, part, part_colsum, S, stream);
+}
+int srhip_conv3x3_wgrad_bx3(const float* dY, long lddy, const float* X, long ldx, int B, int H, int W,
+                            int Cout, int Cin, float* part, float* part_colsum, int S, void* stream) {
+  return conv_wgrad_any(true, dY, lddy, X, ldx, B, H, W, Cout, Cin, part, part_colsum, S, stream);
 }
 
 }  // extern "C"

@@ -28,6 +28,21 @@ static inline int sr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   [0..1] = {mean 0, rstd 1}   [2..3] = {0, 0}   [1] = scale 1
 __device__ const float k_sr_neutral[4] = {0.f, 1.f, 0.f, 0.f};
 
+// Loads through a pointer the compiler cannot prove global (a select between a
+// kernel-argument pointer and a __device__ constant, a pointer read from a struct
+// passed by reference) compile to FLAT loads, which also count against the LDS
+// counter and serialise with ds_* traffic.  These force the global path.
+typedef const __attribute__((address_space(1))) float* sr_gptr_f;
+typedef float sr_f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) sr_f32x2* sr_gptr_f2;
+typedef const __attribute__((address_space(1))) f32x4* sr_gptr_f4;
+__device__ __forceinline__ float ldg_f(const float* p) { return *(sr_gptr_f)p; }
+__device__ __forceinline__ float2 ldg_f2(const float* p) {
+  const sr_f32x2 v = *(sr_gptr_f2)p;
+  return float2{v.x, v.y};
+}
+__device__ __forceinline__ f32x4 ldg_f4(const void* p) { return *(sr_gptr_f4)p; }
+
 // ---- wave-level reductions (wave = 64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
       // row (always mapped) and are zeroed -- never touch memory past the end of a row
       const int sk = slot_k(it, A_N);
       const bool oob = ktail && kc * BK + sk >= p.K;
-      f32x4 v = *(const f32x4*)((oob ? (const char*)(p.A - sk) : base) + offA[it]);
+      f32x4 v = *(const f32x4*)((oob ? (const char*)p.A : base) + (oob ? offA[it] - sk * 4u : offA[it]));
       if ((CONV && !inA[it]) || oob) v = f32x4{0.f, 0.f, 0.f, 0.f};
       ra[it] = v;
     }
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
     for (int it = 0; it < B_IT; ++it) {
       const int sk = slot_k(it, B_N);
       const bool oob = ktail && kc * BK + sk >= p.K;
-      f32x4 v = *(const f32x4*)((oob ? (const char*)(p.W + (long)tap * p.wtap - sk) : base) + offB[it]);
+      f32x4 v = *(const f32x4*)((oob ? (const char*)(p.W + (long)tap * p.wtap) : base) + (oob ? offB[it] - sk * 4u : offB[it]));
       if (oob) v = f32x4{0.f, 0.f, 0.f, 0.f};
       rb[it] = v;
     }

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
       offA[it] = (unsigned)(gm * (int)p.lda + c4 * 4) * 4u;
       if (p.a_mode == 1) sp = p.ln_stats + 2 * gm;
     }
-    rst[it] = *(const float2*)sp;
+    rst[it] = ldg_f2(sp);
   }
   const long plane_bytes = (long)(CONV ? 9 : 1) * p.N * p.Kp * 2;   // one bf16 plane of W
 #pragma unroll
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     for (int it = 0; it < A_IT; ++it) {
       const int c4 = min(tid + it * 256, A_N - 1) & 7;
       const bool oob = ktail && kc * BKB + c4 * 4 >= p.K;
-      f32x4 v = *(const f32x4*)((oob ? (const char*)(p.A - c4 * 4) : base) + offA[it]);   // oob: k = 0 of the row
+      f32x4 v = *(const f32x4*)((oob ? (const char*)p.A : base) + (oob ? offA[it] - c4 * 16u : offA[it]));   // oob: k = 0 of the row
       if ((CONV && !inA[it]) || oob) v = f32x4{0.f, 0.f, 0.f, 0.f};
       ra[it] = v;
     }
@@ -288,7 +288,7 @@ __device__ __forceinline__ void split3_slot(const float* __restrict__ W, long ld
   if (i >= (long)rows * kq) return;
   const int row = (int)(i / kq), k = (int)(i - (long)row * kq) * 4;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (k < K) v = *(const f32x4*)(W + (long)row * ldw + k);      // K % 4 == 0
+  if (k < K) v = ldg_f4(W + (long)row * ldw + k);      // K % 4 == 0
   unsigned h0, m0, l0, h1, m1, l1;
   split3_pair(v.x, v.y, h0, m0, l0);
   split3_pair(v.z, v.w, h1, m1, l1);

@@ -57,9 +57,9 @@ __device__ __forceinline__ void tn_body(const TnArgs& p, const int s, const int 
       const int gm = mc + row, gc = c4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       const bool in = gm < m_end && gc < ivalid;
-      if (in) v = *(const f32x4*)(p.A + (long)gm * p.lda + i0 + gc);
+      if (in) v = ldg_f4(p.A + (long)gm * p.lda + i0 + gc);
       const float* sp = (in && p.a_rowscale) ? p.a_rowscale + gm / p.a_rowscale_rows : k_sr_neutral + 1;
-      rsa[it] = *sp;               // unconditional load (see k_sr_neutral)
+      rsa[it] = ldg_f(sp);               // unconditional load (see k_sr_neutral)
       ra[it] = v;
     }
 #pragma unroll
@@ -80,13 +80,13 @@ __device__ __forceinline__ void tn_body(const TnArgs& p, const int s, const int 
           src = ((long)b * p.H + yy) * p.Wd + xx;
         }
         if (ok) {
-          v = *(const f32x4*)(p.B + src * p.ldb + j0 + gc);
+          v = ldg_f4(p.B + src * p.ldb + j0 + gc);
           if (p.b_mode == 1) sp = p.ln_stats + 2 * src;
         } else {
           sp = k_sr_neutral + 2;   // {0,0}: padded pixels stay exactly 0 under any prologue
         }
       }
-      rst[it] = *(const float2*)sp;   // unconditional load (see k_sr_neutral)
+      rst[it] = ldg_f2(sp);   // unconditional load (see k_sr_neutral)
       rb[it] = v;
     }
   };

@@ -51,6 +51,8 @@ int sr_split3(const float* W, long ldw, int rows, int K, unsigned short* out, hi
 int sr_gemm_ntb(NtArgs& p, hipStream_t st);
 int sr_conv3x3_ntb(NtArgs& p, hipStream_t st);
 int sr_gemm_tn(TnArgs& p, hipStream_t st);
+int sr_gemm_tnb(TnArgs& p, hipStream_t st);
+int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st);
 int sr_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats);
 int sr_gemm_tn_grouped(TnArgs* probs, int n, hipStream_t st);
 int sr_tn_group_plan(int M, int ntiles, int* S);

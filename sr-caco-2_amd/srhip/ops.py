@@ -37,6 +37,16 @@ def _rows(t):
 
 
 # ------------------------------------------------------------------ contractions
+def use_bx3():
+    """Matrix path: bf16x3 split MFMA (default) or exact-f32 MFMA (env SRHIP_MM=f32)."""
+    import os
+    return os.environ.get("SRHIP_MM", "bx3") != "f32"
+
+
+def _tn_sfx():
+    return "_bx3" if use_bx3() else ""
+
+
 class Bx3:
     """Weight operand pre-split into three bf16 planes [3][rows][Kp] for the bf16x3
     contractions (srhip_split_bf16x3).  rows = N (Linear) or 9*Cout (conv pack)."""
@@ -94,8 +104,7 @@ class WeightSet:
     MFMA kernels), refreshed from the f32 sources by ONE grouped split launch."""
 
     def __init__(self):
-        import os
-        self.use_bx3 = os.environ.get("SRHIP_MM", "bx3") != "f32"
+        self.use_bx3 = use_bx3()
         self.src, self.bx, self.table, self.sig = {}, {}, None, None
 
     def register(self, key, t):
@@ -197,7 +206,7 @@ def linear_wgrad(dY, X, dW, db, a_rowscale=None, a_rowscale_rows=1, b_mode=0, ln
     S, n = tn_plan(M, N, K)
     part = SCRATCH.get("tn_part", n, device=dY.device)
     cs = SCRATCH.get("tn_colsum", S * N, device=dY.device)
-    call("srhip_gemm_tn", _p(dY), dY.stride(0), _p(X), X.stride(0), M, N, K, _p(a_rowscale),
+    call("srhip_gemm_tn" + _tn_sfx(), _p(dY), dY.stride(0), _p(X), X.stride(0), M, N, K, _p(a_rowscale),
          a_rowscale_rows, b_mode, _p(ln_stats), _p(part), _p(cs), S, _st())
     if ln is None:
         call("srhip_reduce_linear_wgrad", _p(part), _p(cs), S, _p(dW), _p(db), N, K, _st())
@@ -245,7 +254,7 @@ def linear_wgrad_grouped(problems, ln_grads_zeroed=False):
         a.a_rowscale, a.a_rowscale_rows = _p(q.get("a_rowscale")), q.get("a_rowscale_rows", 1)
         a.b_mode, a.ln_stats = q.get("b_mode", 0), _p(q.get("ln_stats"))
         a.part, a.part_colsum = _p(pk), _p(ck)
-    call("srhip_gemm_tn_grouped", ctypes.addressof(arr), n, M, S, _st())
+    call("srhip_gemm_tn_grouped" + _tn_sfx(), ctypes.addressof(arr), n, M, S, _st())
     for q, (pk, ck) in zip(problems, views):
         N, K = q["dY"].shape[1], q["X"].shape[1]
         if q.get("ln") is None:
@@ -264,7 +273,7 @@ def conv3x3_wgrad(dY, X, dW, db):
     S, n = tn_plan(B * H * W, Cout, Cin, True)
     part = SCRATCH.get("tn_part", n, device=dY.device)
     cs = SCRATCH.get("tn_colsum", S * Cout, device=dY.device)
-    call("srhip_conv3x3_wgrad", _p(dY), dY.stride(2), _p(X), X.stride(2), B, H, W, Cout, Cin,
+    call("srhip_conv3x3_wgrad" + _tn_sfx(), _p(dY), dY.stride(2), _p(X), X.stride(2), B, H, W, Cout, Cin,
          _p(part), _p(cs), S, _st())
     call("srhip_reduce_conv_wgrad", _p(part), _p(cs), S, _p(dW), _p(db), Cout, Cin, _st())
 
