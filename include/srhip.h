@@ -64,19 +64,29 @@ int srhip_conv3x3_nhwc(const float* X, long ldx, const float* Wp, const float* b
  * srhip_gemm_nt and srhip_conv3x3_nhwc. */
 int srhip_bf16x3_kp(int K);
 int srhip_split_bf16x3(const float* W, long ldw, int rows, int K, void* out, void* stream);
-/* All weights of a network in ONE launch.  The caller builds the table on the host
- * (blk0 = running sum of srhip_split_blocks(rows, K), ascending), copies it to the
- * device once, and re-runs the launch after every optimizer step. */
+/* Per-step weight preparation of a whole network in ONE launch (replaces the
+ * per-weight srhip_fold_layernorm / srhip_transpose / srhip_pack_conv_weight /
+ * srhip_bias_expand / srhip_split_bf16x3 sequence, same results).  The caller
+ * fills the job table on the host (blk0 = running sum of srhip_prep_blocks(),
+ * ascending), copies it to the device once and re-runs the launch after every
+ * optimizer step.
+ *   kind 0  bf16x3 planes: out[3][n1*n0][Kp(n2)] of
+ *           v(tap<n1, r<n0, k<n2) = a[off + tap*s0 + r*s1 + k*s2] * g,
+ *           g = 1 (mode 0) | b[k] (mode 1) | b[r] (mode 2)
+ *           -- a Linear weight, its transpose, LayerNorm gamma folded either
+ *           way, a conv weight as tap-major pack or flipped/transposed twin
+ *   kind 1  folded bias: out[n<n0] = b[n] + sum_k a[n][k<n1] * c[k]
+ *   kind 2  relative-position bias images (srhip_bias_expand): a = table,
+ *           out = biasT, out2 = biasN, n0 = heads */
 typedef struct {
-  const float* W;   /* [rows][ldw] f32 */
-  void* out;        /* [3][rows][Kp] bf16 */
-  long ldw;
-  int rows, K;
-  int blk0;         /* first block of this entry */
-  int pad_;
-} srhip_split_entry;
-int srhip_split_blocks(int rows, int K);
-int srhip_split_bf16x3_table(const srhip_split_entry* table_dev, int n, int total_blocks, void* stream);
+  const float* a; const float* b; const float* c; void* out; void* out2;
+  int kind, blk0;
+  int n0, n1, n2;
+  int s0, s1, s2, off;
+  int mode;
+} srhip_prep_entry;
+int srhip_prep_blocks(const srhip_prep_entry* e);
+int srhip_prep_table(const srhip_prep_entry* table_dev, int n, int total_blocks, void* stream);
 int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bias, float* C,
                       long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
                       const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha,

@@ -57,11 +57,14 @@ int srhip_split_bf16x3(const float* W, long ldw, int rows, int K, void* out, voi
   return sr_split3(W, ldw, rows, K, (unsigned short*)out, (hipStream_t)stream);
 }
 
-int srhip_split_blocks(int rows, int K) { return sr_cdiv((long)rows * (sr_kp(K) / 4), 256); }
+int srhip_prep_blocks(const srhip_prep_entry* e) {
+  static_assert(sizeof(srhip_prep_entry) == sizeof(PrepEntry), "prep table layout");
+  SR_REQUIRE(e && e->kind >= 0 && e->kind <= 2, "prep_blocks: kind");
+  return sr_prep_blocks(*(const PrepEntry*)e);
+}
 
-int srhip_split_bf16x3_table(const srhip_split_entry* table_dev, int n, int total_blocks, void* stream) {
-  static_assert(sizeof(srhip_split_entry) == sizeof(SplitEntry), "split table layout");
-  return sr_split3_table((const SplitEntry*)table_dev, n, total_blocks, (hipStream_t)stream);
+int srhip_prep_table(const srhip_prep_entry* table_dev, int n, int total_blocks, void* stream) {
+  return sr_prep_table((const PrepEntry*)table_dev, n, total_blocks, (hipStream_t)stream);
 }
 
 int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bias, float* C,

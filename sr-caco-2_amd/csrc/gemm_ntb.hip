@@ -194,14 +194,17 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
   for (int it = 0; it < niter; ++it) {
     const int kc = it / ntap, tap = it - kc * ntap;
     __syncthreads();
-    if (!CONV || tap == 0) store_a();
-    store_b();
+    if (!(p.dbg & 2)) {
+      if (!CONV || tap == 0) store_a();
+      store_b();
+    }
     __syncthreads();
     if (it + 1 < niter) {
       const int kc1 = (it + 1) / ntap, tap1 = (it + 1) - kc1 * ntap;
-      if (!CONV || tap1 == 0) load_a(kc1);
-      load_b(kc1, tap1);
+      if ((!CONV || tap1 == 0) && !(p.dbg & 32)) load_a(kc1);
+      if (!(p.dbg & 16)) load_b(kc1, tap1);
     }
+    if (p.dbg & 4) continue;
     const int toff = CONV ? ((tap / 3) * 18 + (tap % 3)) * PITCH : 0;
 #pragma unroll
     for (int s = 0; s < BKB / 16; ++s) {
@@ -226,6 +229,7 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     }
   }
 
+  if (p.dbg & 8) return;
   nt_epilogue<WM, WN, CONV>(p, acc, lane, wm, wn, n0, nvalid, m0, img, y0, x0);
 }
 
@@ -304,17 +308,6 @@ __global__ void k_split3(const float* __restrict__ W, long ldw, int rows, int K,
   split3_slot(W, ldw, rows, K, Kp, out, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// every weight of the network in one launch: block -> table entry by binary search
-__global__ void k_split3_table(const SplitEntry* __restrict__ tab, int n) {
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const SplitEntry e = tab[lo];
-  split3_slot(e.W, e.ldw, e.rows, e.K, sr_kp(e.K), e.out, (long)(blockIdx.x - e.blk0) * blockDim.x + threadIdx.x);
-}
-
 }  // namespace
 
 int sr_split3(const float* W, long ldw, int rows, int K, unsigned short* out, hipStream_t st) {
@@ -326,14 +319,8 @@ int sr_split3(const float* W, long ldw, int rows, int K, unsigned short* out, hi
   return 0;
 }
 
-int sr_split3_table(const SplitEntry* tab_dev, int n, int total_blocks, hipStream_t st) {
-  SR_REQUIRE(n > 0 && total_blocks > 0, "split_bf16x3_table: empty table");
-  hipLaunchKernelGGL(k_split3_table, dim3(total_blocks), dim3(256), 0, st, tab_dev, n);
-  SR_LAUNCH_CHECK("k_split3_table");
-  return 0;
-}
-
 int sr_gemm_ntb(NtArgs& p, hipStream_t st) {
+  p.dbg = ntb_env("SRHIP_NT_DBG", 0);      // ablation bits, 0 in production
   SR_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0, "gemm_nt_bx3: K, lda must be multiples of 4 (K=%d)", p.K);
   SR_REQUIRE(p.M > 0 && p.N > 0, "gemm_nt_bx3: empty problem");
   p.Kp = sr_kp(p.K);

@@ -43,9 +43,16 @@ struct TnArgs {
 
 int sr_gemm_nt(NtArgs& p, hipStream_t st);
 int sr_conv3x3_nt(NtArgs& p, hipStream_t st);
-// one weight of a grouped split (device table; mirrors srhip_split_entry)
-struct SplitEntry { const float* W; unsigned short* out; long ldw; int rows, K, blk0, pad_; };
-int sr_split3_table(const SplitEntry* tab_dev, int n, int total_blocks, hipStream_t st);
+// one job of the per-step weight preparation (device table; mirrors srhip_prep_entry)
+struct PrepEntry {
+  const float* a; const float* b; const float* c; void* out; void* out2;
+  int kind, blk0;
+  int n0, n1, n2;
+  int s0, s1, s2, off;
+  int mode;
+};
+int sr_prep_blocks(const PrepEntry& e);
+int sr_prep_table(const PrepEntry* tab_dev, int n, int total_blocks, hipStream_t st);
 __host__ __device__ static inline int sr_kp(int K) { return (K + 31) / 32 * 32; }
 int sr_split3(const float* W, long ldw, int rows, int K, unsigned short* out, hipStream_t st);
 int sr_gemm_ntb(NtArgs& p, hipStream_t st);

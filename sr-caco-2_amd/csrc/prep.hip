@@ -1,0 +1,111 @@
+// Per-step weight preparation for a whole network in ONE launch.
+//
+// After every optimizer step the matmul operands derived from the parameters
+// must be rebuilt: bf16x3 planes of every Linear / conv weight (plain, transposed
+// for the data gradient, LayerNorm gamma folded in; conv weights tap-major, the
+// data-gradient twin with flipped taps), the LayerNorm-folded biases and the
+// dense relative-position bias images.  Done weight by weight that is ~500 tiny
+// launches per step for SwinIR -- CPU-launch bound.  Here the host builds a job
+// table once (pointers are stable), and one kernel walks it: block -> job by
+// binary search over the running block count.
+//
+// Replaces the per-weight srhip_fold_layernorm / srhip_transpose /
+// srhip_pack_conv_weight / srhip_bias_expand / srhip_split_bf16x3 sequence
+// (same results; those entry points remain for single weights).
+#include "common.h"
+#include "kernels.h"
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+}
+
+// kind 0: out planes [3][ntap*rows][Kp] of  v(tap, r, k) = W[off + tap*s_tap + r*s_row + k*s_k]
+//         * (gamma_mode 1: gamma[k] | 2: gamma[r] | 0: 1)
+__device__ __forceinline__ void job_planes(const PrepEntry& e, int lb) {
+  const int Kp = sr_kp(e.n2), kq = Kp >> 2;
+  const long rows = (long)e.n0 * e.n1;
+  const long i = (long)lb * 256 + threadIdx.x;
+  if (i >= rows * kq) return;
+  const int row = (int)(i / kq), k0 = (int)(i - (long)row * kq) * 4;
+  const int tap = row / e.n0, r = row - tap * e.n0;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + j;
+    float x = 0.f;
+    if (k < e.n2) {
+      x = ldg_f(e.a + (long)e.off + (long)tap * e.s0 + (long)r * e.s1 + (long)k * e.s2);
+      if (e.mode == 1) x *= ldg_f(e.b + k);
+      else if (e.mode == 2) x *= ldg_f(e.b + r);
+    }
+    v[j] = x;
+  }
+  unsigned h0, m0, l0, h1, m1, l1;
+  split3_pair(v[0], v[1], h0, m0, l0);
+  split3_pair(v[2], v[3], h1, m1, l1);
+  const long plane = rows * Kp;
+  unsigned short* d = (unsigned short*)e.out + (long)row * Kp + k0;
+  *(u32x2*)(d) = u32x2{h0, h1};
+  *(u32x2*)(d + plane) = u32x2{m0, m1};
+  *(u32x2*)(d + 2 * plane) = u32x2{l0, l1};
+}
+
+// kind 1: out[n] = bias[n] + sum_k W[n][k] * beta[k]   (LayerNorm shift folded into the Linear bias)
+__device__ __forceinline__ void job_fold_bias(const PrepEntry& e, int lb) {
+  const int n = lb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= e.n0) return;
+  float a = 0.f;
+  for (int k = lane; k < e.n1; k += 64) a += ldg_f(e.a + (long)n * e.n1 + k) * ldg_f(e.c + k);
+  a = wave_sum(a);
+  if (lane == 0) ((float*)e.out)[n] = (e.b ? ldg_f(e.b + n) : 0.f) + a;
+}
+
+// kind 2: dense relative-position bias images of one block (see k_bias_expand, wattn.hip)
+__device__ __forceinline__ void job_bias_expand(const PrepEntry& e, int lb) {
+  const int i = lb * 256 + threadIdx.x, heads = e.n0;
+  if (i >= heads * 4096) return;
+  const int hd = i / 4096, a = (i >> 6) & 63, b = i & 63;
+  const int idxN = ((a >> 3) - (b >> 3) + 7) * 15 + ((a & 7) - (b & 7) + 7);
+  ((float*)e.out2)[i] = ldg_f(e.a + idxN * heads + hd);
+  const int idxT = ((b >> 3) - (a >> 3) + 7) * 15 + ((b & 7) - (a & 7) + 7);
+  ((float*)e.out)[i] = ldg_f(e.a + idxT * heads + hd);
+}
+
+__global__ void __launch_bounds__(256) k_prep_table(const PrepEntry* __restrict__ tab, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PrepEntry e = tab[lo];
+  const int lb = blockIdx.x - e.blk0;
+  if (e.kind == 0) job_planes(e, lb);
+  else if (e.kind == 1) job_fold_bias(e, lb);
+  else job_bias_expand(e, lb);
+}
+
+}  // namespace
+
+int sr_prep_blocks(const PrepEntry& e) {
+  if (e.kind == 0) return sr_cdiv((long)e.n0 * e.n1 * (sr_kp(e.n2) / 4), 256);
+  if (e.kind == 1) return sr_cdiv(e.n0, 4);
+  if (e.kind == 2) return sr_cdiv((long)e.n0 * 4096, 256);
+  return -1;
+}
+
+int sr_prep_table(const PrepEntry* tab_dev, int n, int total_blocks, hipStream_t st) {
+  SR_REQUIRE(n > 0 && total_blocks > 0, "prep_table: empty table");
+  hipLaunchKernelGGL(k_prep_table, dim3(total_blocks), dim3(256), 0, st, tab_dev, n);
+  SR_LAUNCH_CHECK("k_prep_table");
+  return 0;
+}

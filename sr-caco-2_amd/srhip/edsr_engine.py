@@ -25,6 +25,7 @@ class EDSREngine:
         self.bufs = _Bufs()
         self.derived = _Bufs()
         self.ws = ops.WeightSet()
+        self._prep = self._prep_sig = None
         self.prepared = False
         self.saved = None
 
@@ -45,15 +46,25 @@ class EDSREngine:
             yield f"up{i}", net.tail[0][2 * i]
 
     def prepare(self):
-        D = self.derived
+        D, ws = self.derived, self.ws
         dev = self.net.head[0].weight.device
-        for name, conv in self._body_convs():
-            co, ci = conv.weight.shape[:2]
-            ops.pack_conv_weight(conv.weight.data, D.get(name + ".wp", 9, co, ci, device=dev),
-                                 D.get(name + ".wpt", 9, ci, co, device=dev))
-            self.ws.register(name + ".wp", D.d[name + ".wp"])
-            self.ws.register(name + ".wpt", D.d[name + ".wpt"])
-        self.ws.refresh()
+        if ws.use_bx3:      # all conv packs as bf16x3 planes by one launch
+            sig = tuple(p.data_ptr() for p in self.net.parameters())
+            if self._prep is None or sig != self._prep_sig:
+                tb = ops.PrepTable()
+                for name, conv in self._body_convs():
+                    co, ci = conv.weight.shape[:2]
+                    tb.conv(conv.weight.data, ws.planes(name + ".wp", 9 * co, ci, dev))
+                    tb.conv(conv.weight.data, ws.planes(name + ".wpt", 9 * ci, co, dev), data_grad=True)
+                self._prep, self._prep_sig = tb.build(dev), sig
+            self._prep.run()
+        else:
+            for name, conv in self._body_convs():
+                co, ci = conv.weight.shape[:2]
+                ops.pack_conv_weight(conv.weight.data, D.get(name + ".wp", 9, co, ci, device=dev),
+                                     D.get(name + ".wpt", 9, ci, co, device=dev))
+                ws.register(name + ".wp", D.d[name + ".wp"])
+                ws.register(name + ".wpt", D.d[name + ".wpt"])
         self.prepared = True
 
     # ------------------------------------------------------------------ forward

@@ -70,63 +70,98 @@ def split_bf16x3(W):
     return Bx3(W2d.shape[0], W2d.shape[1], W.device).fill(W2d)
 
 
-class _SplitEntry(ctypes.Structure):   # srhip_split_entry (include/srhip.h)
-    _fields_ = [("W", ctypes.c_void_p), ("out", ctypes.c_void_p), ("ldw", ctypes.c_long),
-                ("rows", ctypes.c_int), ("K", ctypes.c_int), ("blk0", ctypes.c_int), ("pad_", ctypes.c_int)]
+class _PrepEntry(ctypes.Structure):   # srhip_prep_entry (include/srhip.h)
+    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("c", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("out2", ctypes.c_void_p),
+                ("kind", ctypes.c_int), ("blk0", ctypes.c_int),
+                ("n0", ctypes.c_int), ("n1", ctypes.c_int), ("n2", ctypes.c_int),
+                ("s0", ctypes.c_int), ("s1", ctypes.c_int), ("s2", ctypes.c_int), ("off", ctypes.c_int),
+                ("mode", ctypes.c_int)]
 
 
-class SplitTable:
-    """(f32 source matrix -> Bx3) pairs refreshed by ONE launch (srhip_split_bf16x3_table).
-    The device table holds raw pointers: sources and planes must stay allocated."""
+class PrepTable:
+    """Job table of the per-step weight preparation (srhip_prep_table): every derived
+    matmul operand of a network rebuilt by ONE launch.  Holds raw pointers: sources
+    and outputs must stay allocated (``keep`` pins them)."""
 
-    def __init__(self, pairs):
-        n = len(pairs)
-        arr = (_SplitEntry * n)()
+    def __init__(self):
+        self.jobs, self.keep, self.table = [], [], None
+
+    def _add(self, **kw):
+        e = _PrepEntry()
+        for k, v in kw.items():
+            setattr(e, k, v)
+        self.jobs.append(e)
+
+    def linear(self, W, out, gamma=None, transpose=False):
+        """planes of W [N,K] (or W^T), optionally times gamma[k] (LayerNorm fold)."""
+        N, K = W.shape
+        assert W.is_contiguous() and W.dtype == torch.float32
+        rows, kd = (K, N) if transpose else (N, K)
+        assert (out.rows, out.K) == (rows, kd)
+        self.keep += [W, out, gamma]
+        self._add(kind=0, a=_p(W), b=_p(gamma), out=_p(out.planes), n0=rows, n1=1, n2=kd, s0=0,
+                  s1=1 if transpose else K, s2=K if transpose else 1, off=0,
+                  mode=0 if gamma is None else (2 if transpose else 1))
+
+    def conv(self, w, out, data_grad=False):
+        """planes of the tap-major pack [9][Co][Ci] of a conv weight [Co,Ci,3,3], or of the
+        flipped / transposed twin [9][Ci][Co] used by the data gradient."""
+        Co, Ci = w.shape[:2]
+        assert w.is_contiguous() and tuple(w.shape[2:]) == (3, 3)
+        rows, kd = (Ci, Co) if data_grad else (Co, Ci)
+        assert (out.rows, out.K) == (9 * rows, kd)
+        self.keep += [w, out]
+        if data_grad:   # out[t][ci][co] = w[co][ci][8 - t]
+            self._add(kind=0, a=_p(w), out=_p(out.planes), n0=Ci, n1=9, n2=Co, s0=-1, s1=9, s2=Ci * 9, off=8, mode=0)
+        else:           # out[t][co][ci] = w[co][ci][t]
+            self._add(kind=0, a=_p(w), out=_p(out.planes), n0=Co, n1=9, n2=Ci, s0=1, s1=Ci * 9, s2=9, off=0, mode=0)
+
+    def fold_bias(self, W, b, beta, out):
+        N, K = W.shape
+        self.keep += [W, b, beta, out]
+        self._add(kind=1, a=_p(W), b=_p(b), c=_p(beta), out=_p(out), n0=N, n1=K)
+
+    def bias_expand(self, table, biasT, biasN, heads):
+        self.keep += [table, biasT, biasN]
+        self._add(kind=2, a=_p(table), out=_p(biasT), out2=_p(biasN), n0=heads)
+
+    def build(self, device):
+        n = len(self.jobs)
+        arr = (_PrepEntry * n)()
         blk = 0
-        self.keep = pairs
-        for e, (src, bx) in zip(arr, pairs):
-            src2 = src.reshape(-1, src.shape[-1]) if src.dim() != 2 else src
-            assert src2.data_ptr() == src.data_ptr() and src2.stride(1) == 1
-            assert src2.shape == (bx.rows, bx.K) and src.dtype == torch.float32 and src.is_cuda
-            e.W, e.out, e.ldw, e.rows, e.K, e.blk0 = src2.data_ptr(), bx.planes.data_ptr(), src2.stride(0), bx.rows, bx.K, blk
-            blk += lib.srhip_split_blocks(bx.rows, bx.K)
-        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        self.table = raw.to(pairs[0][0].device)
+        for i, e in enumerate(self.jobs):
+            e.blk0 = blk
+            blk += lib.srhip_prep_blocks(ctypes.addressof(e))
+            arr[i] = e
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self.n, self.blocks = n, blk
+        return self
 
     def run(self):
-        call("srhip_split_bf16x3_table", _p(self.table), self.n, self.blocks, _st())
+        call("srhip_prep_table", _p(self.table), self.n, self.blocks, _st())
 
 
 class WeightSet:
-    """Operand form of every matmul / conv weight of a network: the f32 tensor itself
+    """Operand form of every matmul / conv weight of a network, by key: the f32 tensor
     (env SRHIP_MM=f32: exact-f32 MFMA kernels) or its Bx3 planes (default: bf16x3 split
-    MFMA kernels), refreshed from the f32 sources by ONE grouped split launch."""
+    MFMA kernels)."""
 
     def __init__(self):
         self.use_bx3 = use_bx3()
-        self.src, self.bx, self.table, self.sig = {}, {}, None, None
+        self.d = {}
 
     def register(self, key, t):
-        self.src[key] = t
+        self.d[key] = t
 
-    def refresh(self):
-        if not self.use_bx3:
-            return
-        sig = tuple((k, t.data_ptr(), tuple(t.shape)) for k, t in self.src.items())
-        if sig != self.sig:
-            pairs = []
-            for k, t in self.src.items():
-                rows = t.numel() // t.shape[-1]
-                old = self.bx.get(k)
-                if old is None or (old.rows, old.K) != (rows, t.shape[-1]):
-                    self.bx[k] = Bx3(rows, t.shape[-1], t.device)
-                pairs.append((t, self.bx[k]))
-            self.table, self.sig = SplitTable(pairs), sig
-        self.table.run()
+    def planes(self, key, rows, K, device):
+        bx = self.d.get(key)
+        if not isinstance(bx, Bx3) or (bx.rows, bx.K) != (rows, K):
+            bx = self.d[key] = Bx3(rows, K, device)
+        return bx
 
     def __getitem__(self, key):
-        return self.bx[key] if self.use_bx3 else self.src[key]
+        return self.d[key]
 
 
 def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,

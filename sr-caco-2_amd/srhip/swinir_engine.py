@@ -51,6 +51,7 @@ class SwinIREngine:
         self.bufs = _Bufs()
         self.derived = _Bufs()
         self.ws = ops.WeightSet()      # matmul operands: f32 tensors or bf16x3 planes
+        self._prep = self._prep_sig = None
         self.prepared = False
         self.saved = None
 
@@ -76,6 +77,45 @@ class SwinIREngine:
     def prepare(self):
         """Derived weight copies (folded LayerNorm, transposes, conv packs, dense
         bias images).  Must be re-run whenever parameters change."""
+        if self.ws.use_bx3:
+            self._prepare_bx3()
+        else:
+            self._prepare_f32()
+        self.prepared = True
+
+    def _prepare_bx3(self):
+        """bf16x3 planes of every matmul operand + folded biases + bias images, by ONE
+        launch over a job table built once (rebuilt if a parameter moved)."""
+        net, C, hid, D, ws = self.net, self.C, self.hid, self.derived, self.ws
+        sig = tuple(p.data_ptr() for p in net.parameters())
+        if self._prep is None or sig != self._prep_sig:
+            dev = net.conv_first.weight.device
+            tb = ops.PrepTable()
+            for i, b in enumerate(self.blocks):
+                g1, g2 = b.norm1.weight.data, b.norm2.weight.data
+                wq, wp = b.attn.qkv.weight.data, b.attn.proj.weight.data
+                w1, w2 = b.mlp.fc1.weight.data, b.mlp.fc2.weight.data
+                tb.linear(wq, ws.planes(f"{i}.wq", 3 * C, C, dev), gamma=g1)
+                tb.linear(wq, ws.planes(f"{i}.wqT", C, 3 * C, dev), gamma=g1, transpose=True)
+                tb.linear(wp, ws.planes(f"{i}.wproj", C, C, dev))
+                tb.linear(wp, ws.planes(f"{i}.wpT", C, C, dev), transpose=True)
+                tb.linear(w1, ws.planes(f"{i}.w1", hid, C, dev), gamma=g2)
+                tb.linear(w1, ws.planes(f"{i}.w1T", C, hid, dev), gamma=g2, transpose=True)
+                tb.linear(w2, ws.planes(f"{i}.w2", C, hid, dev))
+                tb.linear(w2, ws.planes(f"{i}.w2T", hid, C, dev), transpose=True)
+                tb.fold_bias(wq, b.attn.qkv.bias.data, b.norm1.bias.data, D.get(f"{i}.bq", 3 * C, device=dev))
+                tb.fold_bias(w1, b.mlp.fc1.bias.data, b.norm2.bias.data, D.get(f"{i}.b1", hid, device=dev))
+                tb.bias_expand(b.attn.relative_position_bias_table.data,
+                               D.get(f"{i}.biasT", b.num_heads, 64, 64, device=dev),
+                               D.get(f"{i}.biasN", b.num_heads, 64, 64, device=dev), b.num_heads)
+            for name, conv in self._convs():
+                co, ci = conv.weight.shape[:2]
+                tb.conv(conv.weight.data, ws.planes(name + ".wp", 9 * co, ci, dev))
+                tb.conv(conv.weight.data, ws.planes(name + ".wpt", 9 * ci, co, dev), data_grad=True)
+            self._prep, self._prep_sig = tb.build(dev), sig
+        self._prep.run()
+
+    def _prepare_f32(self):
         net, C, hid, D = self.net, self.C, self.hid, self.derived
         dev = net.conv_first.weight.device
         for i, b in enumerate(self.blocks):
@@ -108,8 +148,6 @@ class SwinIREngine:
         for name, _ in self._convs():
             ws.register(name + ".wp", D.d[name + ".wp"])
             ws.register(name + ".wpt", D.d[name + ".wpt"])
-        ws.refresh()
-        self.prepared = True
 
     def _convs(self):
         net = self.net

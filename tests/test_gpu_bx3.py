@@ -125,3 +125,34 @@ def test_conv_bx3_epilogues(ops):
     assert relerr(y.permute(0, 3, 1, 2), R.double() + 0.1 * ref) < 2e-6
     y = ops.conv3x3(xh, wb, None, C, epi=4, R=Rh)
     assert relerr(y.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), None, padding=1) * (R > 0)) < 2e-6
+
+
+def test_prep_table_matches_single_ops(ops):
+    """One-launch weight preparation == fold_layernorm / transpose / pack_conv_weight /
+    bias_expand / split_bf16x3 applied weight by weight (bit-exact)."""
+    N, K, heads = 540, 180, 6
+    W, b, g, be = rnd(N, K, scale=0.1).cuda(), rnd(N).cuda(), (1 + 0.1 * rnd(K)).cuda(), rnd(K, scale=0.1).cuda()
+    cw = rnd(64, 180, 3, 3, scale=0.05).cuda()
+    tab = rnd(225, heads).cuda()
+    tb = ops.PrepTable()
+    o = {k: ops.Bx3(*s, "cuda") for k, s in dict(w=(N, K), wT=(K, N), f=(N, K), fT=(K, N), cp=(9 * 64, 180),
+                                                 cpt=(9 * 180, 64)).items()}
+    bq = torch.empty(N).cuda()
+    bT, bN = torch.empty(heads, 64, 64).cuda(), torch.empty(heads, 64, 64).cuda()
+    tb.linear(W, o["w"]); tb.linear(W, o["wT"], transpose=True)
+    tb.linear(W, o["f"], gamma=g); tb.linear(W, o["fT"], gamma=g, transpose=True)
+    tb.conv(cw, o["cp"]); tb.conv(cw, o["cpt"], data_grad=True)
+    tb.fold_bias(W, b, be, bq); tb.bias_expand(tab, bT, bN, heads)
+    tb.build("cuda").run()
+    Wf, bf = torch.empty(N, K).cuda(), torch.empty(N).cuda()
+    ops.fold_layernorm(W, b, g, be, Wf, bf)
+    WT, WfT = torch.empty(K, N).cuda(), torch.empty(K, N).cuda()
+    ops.transpose(W, WT); ops.transpose(Wf, WfT)
+    wp, wpt = torch.empty(9, 64, 180).cuda(), torch.empty(9, 180, 64).cuda()
+    ops.pack_conv_weight(cw, wp, wpt)
+    rT, rN = torch.empty(heads, 64, 64).cuda(), torch.empty(heads, 64, 64).cuda()
+    ops.bias_expand(tab, rT, rN)
+    for k, ref in dict(w=W, wT=WT, f=Wf, fT=WfT, cp=wp, cpt=wpt).items():
+        assert torch.equal(o[k].planes, ops.split_bf16x3(ref).planes), k
+    assert (bq - bf).abs().max().item() < 1e-6
+    assert torch.equal(bT, rT) and torch.equal(bN, rN)
