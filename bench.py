@@ -104,6 +104,7 @@ def main():
 
     from dlib.models.network_swinir import SwinIR
     from srhip import probe
+    from srhip.ops import use_bx3 as ops_use_bx3
     from srhip.train import TrainStep, Optimizer, FlatParams  # noqa: F401
 
     torch.manual_seed(0)                      # same weights on every rank
@@ -130,7 +131,10 @@ def main():
     if not args.no_roofline:
         probe.enable("gemm_nt")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        # HIP events around every NT-GEMM launch of every 4th step (an event is a
+        # barrier packet on the stream: timing all 192 launches of all steps costs ~4%)
+        probe.active = "gemm_nt" if (not args.no_roofline and i % 4 == 0) else None
         ts.step(lr_img, hr_img)
     barrier()
     dt = time.perf_counter() - t0
@@ -155,7 +159,9 @@ def main():
                                    "window 8, mlp 2, pixelshuffledirect), LR 1x64x64 -> HR 1x512x512, "
                                    f"fwd + {args.loss} + bwd + {args.optimizer}",
                        "global_batch": args.batch * world, "batch_per_gpu": args.batch,
-                       "parallelism": f"dp{world}", "final_loss": loss},
+                       "parallelism": f"dp{world}", "final_loss": loss,
+                       "matmul": ("bf16x3 split MFMA: f32 operands split into 3 bf16 parts, 6 products, "
+                                  "f32 accumulate (f32-accurate)") if ops_use_bx3() else "f32 MFMA"},
         }
         gflop_step = 3.0 * SWINIR_X8_GFLOP_FWD * args.batch
         out["model_flops_frac_of_f32_mfma_peak"] = \

@@ -121,8 +121,10 @@ int srhip_conv3x3_wgrad(const float* dY, long lddy, const float* X, long ldx, in
                         int Cout, int Cin, float* part, float* part_colsum, int S, void* stream);
 
 /* The three weight-gradient contractions above on the bf16 MFMA with 3-way split
- * operands (see srhip_gemm_nt_bx3): same arguments, slicing and reducers; no
- * alignment requirement on NI / NJ / lda / ldb. */
+ * operands (see srhip_gemm_nt_bx3): same arguments, alignment rules, slicing and
+ * reducers; plan S with the _bx3 planners (one 8-wave block per CU). */
+int srhip_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats);
+int srhip_tn_group_plan_bx3(int M, int ntiles, int* S);
 int srhip_gemm_tn_bx3(const float* A, long lda, const float* B, long ldb, int M, int NI, int NJ,
                       const float* a_rowscale, int a_rowscale_rows, int b_mode, const float* ln_stats,
                       float* part, float* part_colsum, int S, void* stream);

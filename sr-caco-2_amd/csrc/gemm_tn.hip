@@ -217,11 +217,15 @@ int pick_tile(int n, int* w) {
 }  // namespace
 
 int sr_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
+  return sr_tn_plan_t(M, NI, NJ, conv, 512, S, part_floats);
+}
+
+int sr_tn_plan_t(int M, int NI, int NJ, int conv, int target, int* S, long* part_floats) {
   int wi, wj;
   const int ti = pick_tile(NI, &wi), tj = pick_tile(NJ, &wj);
   const long tiles = (long)sr_cdiv(NI, ti) * sr_cdiv(NJ, tj) * (conv ? 9 : 1);
   // one block per CU and more (k_tn<3,3> holds 1 block/CU); at least 128 tokens each
-  long s = 512 / tiles;                  // at most two whole rounds of 256 blocks
+  long s = target / tiles;               // f32 kernel: two whole rounds of 256 blocks; bx3: one
   const long smax = (M + 127) / 128;
   if (s > smax) s = smax;
   if (s > 256) s = 256;
@@ -231,11 +235,13 @@ int sr_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
   return 0;
 }
 
-int sr_tn_group_plan(int M, int ntiles, int* S) {
+int sr_tn_group_plan(int M, int ntiles, int* S) { return sr_tn_group_plan_t(M, ntiles, 512, S); }
+
+int sr_tn_group_plan_t(int M, int ntiles, int dflt_target, int* S) {
   // one whole round of 512 blocks (2 blocks per CU, so one block's staging and
   // index math overlap the other's MFMAs); env SRHIP_TN_BLOCKS overrides
   const char* e = getenv("SRHIP_TN_BLOCKS");
-  const long target = e ? atol(e) : 512;
+  const long target = e ? atol(e) : dflt_target;
   long s = target / ntiles;
   if (s < 1) s = 1;
   const long smax = (M + 127) / 128;

@@ -5,19 +5,26 @@
 //
 // The reduce index (tokens / pixels) is the MFMA k, so both operands must reach
 // the matrix core column-major: lane (r, h) of a 32x32x16 MFMA supplies 8
-// consecutive TOKENS of column r.  The transposition happens in the global load
-// itself: a lane owns one column and loads it for 8 consecutive tokens (every
-// load instruction reads 64 consecutive floats of one token row -- coalesced),
-// splits the 8 values into bf16 (h, m, l) and writes one 16-byte unit per plane.
-// Everything that depends on the token only (DropPath row scale, LayerNorm
-// statistics, the tap-shifted source pixel of the conv) is wave-uniform and
-// lives in SGPRs.
+// consecutive TOKENS of column r.  A producer lane owns 4 adjacent columns and
+// loads them for 8 consecutive tokens (8 x global_load_dwordx4, every instruction
+// reads whole 16-byte pieces of one token row -- coalesced like a plain copy);
+// the 8 x 4 register block IS the transpose: column j of it is one 16-byte LDS
+// unit per bf16 plane after the split.  Everything that depends on the token only
+// (DropPath row scale, LayerNorm statistics, the tap-shifted source pixel of the
+// conv) is computed by lane (token & 7) and broadcast with v_readlane.
 //
 // LDS: per plane and column two 16-byte units (tokens 0-7, 8-15 of a 16-token
-// chunk), unit (col, u) at slot 2*col + (u ^ ((col>>3)&1)): the 16 lanes of a
-// ds_read/write_b128 phase (16 consecutive columns, same u) hit 16 distinct
-// slots.  Two chunk buffers (one barrier per chunk): chunk c+1 is split and
-// stored while chunk c feeds the MFMAs.
+// chunk).  Unit (col, u) sits at slot 2*P(col) + (u ^ bit3(col)) where P swaps in
+// column bits so that BOTH access patterns are bank-conflict free: the consumer's
+// ds_read_b128 (16 consecutive columns, same u) and the producer's ds_write_b128
+// (16 lanes = columns 4 apart, same u).  Two chunk buffers, one barrier per chunk.
+//
+// Roles: a block is 8 waves = 4 CONSUMER waves (2x2, each W x W MFMA tiles of 32x32;
+// nothing but ds_read + MFMA) and 4 PRODUCER waves (global loads, prologue, split, LDS
+// stores for the next chunk).  One block per CU puts one consumer and one producer on
+// every SIMD, so the matrix core and the vector ALU / memory pipes work at the same
+// time; with symmetric waves the three phases ran back to back (measured: loads 55 us
+// + split 50 us + MFMA 64 us = the 175 us of the launch).
 //
 // Same slicing / partial-tile output / reducers as gemm_tn.hip.
 #include <stdlib.h>
@@ -48,19 +55,25 @@ __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ int unit_slot(int col, int u) { return 2 * col + (u ^ ((col >> 3) & 1)); }
+// column permutation inside blocks of 64: low three bits (b0^b4, b1^b5, b2); the
+// unit bit is flipped by b3.  16 consecutive columns (b3..b0 vary) and 16 columns 4
+// apart (b5..b2 vary) both map onto 16 distinct slots modulo 16.
+__device__ __forceinline__ int unit_slot(int col, int u) {
+  const int low = ((col ^ (col >> 4)) & 3) | (col & 4);
+  return 2 * ((col & ~7) | low) + (u ^ ((col >> 3) & 1));
+}
 
 template <int W>
 __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int tile, const int tap,
                                          unsigned char* smem) {
   constexpr int BC = 64 * W;                 // columns per operand tile
-  constexpr int NU = 2 * 2 * BC;             // units per chunk (A and B, two token octets each)
-  constexpr int IT = NU / 256;               // = W
   constexpr int PLANE = 2 * BC * 32;         // bytes per plane per chunk buffer (A cols then B cols)
   constexpr int BUF = 3 * PLANE;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave8 >= 4;
+  const int wave = wave8 & 3;                // index inside the role
   const int wi = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;
   const int nbj = (p.NJ + p.j_tile - 1) / p.j_tile;
   const int bi = tile / nbj, bj = tile - bi * nbj;
@@ -71,97 +84,99 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
   const int dy = p.conv ? tap / 3 - 1 : 0, dx = p.conv ? tap % 3 - 1 : 0;
   const bool do_colsum = p.part_colsum && bj == 0 && tap == 0;
 
-  // unit (it): idx = tid + 256*it = u * (2*BC) + c, c < BC: A column c, else B column c - BC.
-  // 2*BC and BC are multiples of 64, so operand and u are uniform per wave.
-  float rv[IT][8];
-  float cs[IT];
-#pragma unroll
-  for (int it = 0; it < IT; ++it) cs[it] = 0.f;
-  // per-token data of the chunk in flight, held by lane (token & 15) and broadcast
-  // with v_readlane: source row of each operand (-1: contributes zeros), DropPath
-  // scale of the A row, LayerNorm statistics of the B row
-  int t_rowA = -1, t_rowB = -1;
-  float t_scale = 1.f;
-  float2 t_stats = {0.f, 1.f};
+  // producer wave pw = wave: operand (pw & 1: 0 = A, 1 = B), token octet u = pw >> 1;
+  // lane < BC/4 owns columns 4*lane .. 4*lane+3 of that operand tile
+  constexpr int NQ = BC / 4;
+  struct Stage {            // one chunk in flight in the producer's registers
+    f32x4 rv[8];            // [token][4 columns]
+    float scale;            // A: DropPath scale of token (lane & 7)
+    float2 stats;           // B: LayerNorm statistics of token (lane & 7)
+  };
+  Stage sg0, sg1;
+  const bool isB = wave & 1;
+  const int u = wave >> 1;
+  const int colq = min(4 * lane, (isB ? jvalid : ivalid) - 4);     // clamped: extra columns are never stored
+  const bool lane_on = lane < NQ;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
-  auto load = [&](int mc) {
-    {
-      const int gm = mc + (lane & 15);
-      const bool in = gm < m_end;
-      t_rowA = in ? gm : -1;
-      int srow = gm;
-      bool ok = in;
-      if (p.conv) {
-        const int x = gm % p.Wd, tq = gm / p.Wd;
-        const int y = tq % p.H, b = tq / p.H;
-        const int yy = y + dy, xx = x + dx;
-        ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
-        srow = (b * p.H + yy) * p.Wd + xx;
-      }
-      t_rowB = ok ? srow : -1;
-      const float* sp = (in && p.a_rowscale) ? p.a_rowscale + gm / p.a_rowscale_rows : k_sr_neutral + 1;
-      t_scale = ldg_f(sp);
-      const float* tp = (ok && p.b_mode == 1) ? p.ln_stats + 2 * (long)srow : k_sr_neutral;
-      t_stats = ldg_f2(tp);
+  auto load = [&](int mc, Stage& sg) {
+    const int gm = mc + 8 * u + (lane & 7);      // token of this lane's per-token data
+    const bool in = gm < m_end;
+    int srow = gm;
+    bool ok = in;
+    if (isB && p.conv) {
+      const int x = gm % p.Wd, tq = gm / p.Wd;
+      const int y = tq % p.H, b = tq / p.H;
+      const int yy = y + dy, xx = x + dx;
+      ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+      srow = (b * p.H + yy) * p.Wd + xx;
     }
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int wbase = __builtin_amdgcn_readfirstlane((wave << 6) + 256 * it);   // idx of lane 0
-      const int u = wbase / (2 * BC), cw = wbase - u * (2 * BC);
-      const bool isB = cw >= BC;
-      const int c = (cw - (isB ? BC : 0)) + lane;
-      const float* P = isB ? p.B + j0 : p.A + i0;          // uniform
-      const long ld = isB ? p.ldb : p.lda;
-      const int cc = min(c, (isB ? jvalid : ivalid) - 1);
-      const int rows = isB ? t_rowB : t_rowA;
+    const int t_row = ok ? srow : -1;
+    if (!isB) {
+      const float* sp = (in && p.a_rowscale) ? p.a_rowscale + gm / p.a_rowscale_rows : k_sr_neutral + 1;
+      sg.scale = ldg_f(sp);
+    } else {
+      const float* tp = (ok && p.b_mode == 1) ? p.ln_stats + 2 * (long)srow : k_sr_neutral;
+      sg.stats = ldg_f2(tp);
+    }
+    const float* P = isB ? p.B + j0 : p.A + i0;            // uniform
+    const long ld = isB ? p.ldb : p.lda;
+    // interior chunk (the common case): all 8 tokens present, source rows consecutive
+    const int row0 = __builtin_amdgcn_readlane(t_row, 0);
+    const bool dense = __all(t_row == row0 + (lane & 7) && row0 >= 0);
+    if (dense) {
+      const float* q = P + (long)row0 * ld;                 // uniform, advanced per token
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const int row = __builtin_amdgcn_readlane(rows, 8 * u + t);
+        sg.rv[t] = ldg_f4(q + colq);
+        q += ld;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int row = __builtin_amdgcn_readlane(t_row, t);
         const float* base = row >= 0 ? P + (long)row * ld : k_tnb_zero_row;   // uniform
-        rv[it][t] = ldg_f(base + cc);
+        sg.rv[t] = ldg_f4(base + (row >= 0 ? colq : 0));
       }
     }
   };
 
-  auto store = [&](unsigned char* buf) {
+  auto store = [&](unsigned char* buf, const Stage& sg) {
+    f32x4 v[8];
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int wbase = __builtin_amdgcn_readfirstlane((wave << 6) + 256 * it);
-      const int u = wbase / (2 * BC), cw = wbase - u * (2 * BC);
-      const bool isB = cw >= BC;
-      const int c = cw + lane;                 // column inside the [A | B] chunk row
-      float v[8];
+    for (int t = 0; t < 8; ++t) v[t] = sg.rv[t];
+    if (!isB) {
+      if (p.a_rowscale) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = rv[it][t];
-      if (!isB) {
-        if (p.a_rowscale) {
-#pragma unroll
-          for (int t = 0; t < 8; ++t)
-            v[t] *= __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_scale), 8 * u + t));
-        }
-        if (do_colsum) {
-          float q = 0.f;
-#pragma unroll
-          for (int t = 0; t < 8; ++t) q += v[t];
-          cs[it] += q;
-        }
-      } else if (p.b_mode == 1) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_stats.x), 8 * u + t));
-          const float rs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_stats.y), 8 * u + t));
-          v[t] = (v[t] - mu) * rs;              // zero-filled tokens carry {0, 1}
-        }
-      } else if (p.b_mode == 2) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = gelu_f(v[t]);        // gelu(0) = 0 for the zero fill
+        for (int t = 0; t < 8; ++t)
+          v[t] *= __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg.scale), t));
       }
+      if (do_colsum) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { cs[0] += v[t].x; cs[1] += v[t].y; cs[2] += v[t].z; cs[3] += v[t].w; }
+      }
+    } else if (p.b_mode == 1) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg.stats.x), t));
+        const float rs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg.stats.y), t));
+        v[t] = (v[t] - mu) * rs;                // zero-filled tokens carry {0, 1}
+      }
+    } else if (p.b_mode == 2) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {             // gelu(0) = 0 for the zero fill
+        v[t].x = gelu_f(v[t].x); v[t].y = gelu_f(v[t].y); v[t].z = gelu_f(v[t].z); v[t].w = gelu_f(v[t].w);
+      }
+    }
+    if (!lane_on) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {               // column j of the 8 x 4 block = one unit per plane
       unsigned qh[4], qm[4], ql[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) split3_pair(v[2 * t], v[2 * t + 1], qh[t], qm[t], ql[t]);
+      for (int t = 0; t < 4; ++t) split3_pair(v[2 * t][j], v[2 * t + 1][j], qh[t], qm[t], ql[t]);
       const u32x4 ph = {qh[0], qh[1], qh[2], qh[3]}, pm = {qm[0], qm[1], qm[2], qm[3]},
                   pl = {ql[0], ql[1], ql[2], ql[3]};
-      unsigned char* dst = buf + unit_slot(c, u) * 16;
+      unsigned char* dst = buf + unit_slot((isB ? BC : 0) + 4 * lane + j, u) * 16;
       *(u32x4*)(dst) = ph;
       *(u32x4*)(dst + PLANE) = pm;
       *(u32x4*)(dst + 2 * PLANE) = pl;
@@ -183,41 +198,59 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
   for (int j = 0; j < W; ++j) b_off[j] = unit_slot(BC + (wj * W + j) * 32 + r, h) * 16;
 
   const int nch = (m_end - m_begin + TKB - 1) / TKB;
-  if (nch > 0) {
-    load(m_begin);
-    store(smem);
-    if (nch > 1) load(m_begin + TKB);
-  }
-  __syncthreads();
-  for (int c = 0; c < nch; ++c) {
-    unsigned char* cur = smem + (c & 1) * BUF;
-    if (c + 1 < nch) store(smem + ((c + 1) & 1) * BUF);
-    if (c + 2 < nch) load(m_begin + (c + 2) * TKB);
-    u32x4 fa[W][3];
-#pragma unroll
-    for (int i = 0; i < W; ++i)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fa[i][pl] = *(const u32x4*)(cur + pl * PLANE + a_off[i]);
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-      u32x4 fb0 = *(const u32x4*)(cur + b_off[j]);
-      u32x4 fb1 = *(const u32x4*)(cur + PLANE + b_off[j]);
-      u32x4 fb2 = *(const u32x4*)(cur + 2 * PLANE + b_off[j]);
-#pragma unroll
-      for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][1], fb1, acc[i][j]);
-#pragma unroll
-      for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][0], fb2, acc[i][j]);
-#pragma unroll
-      for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][2], fb0, acc[i][j]);
-#pragma unroll
-      for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][0], fb1, acc[i][j]);
-#pragma unroll
-      for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][1], fb0, acc[i][j]);
-#pragma unroll
-      for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][0], fb0, acc[i][j]);
+  // both roles execute exactly nch + 1 barriers
+  if (producer) {
+    // two chunks in flight: chunk c+1 is split and stored from one register stage
+    // while the loads of chunk c+3 fill it again (c+2 sits in the other stage), so a
+    // load has two chunk periods to land
+    if (nch > 0) {
+      load(m_begin, sg0);
+      if (nch > 1) load(m_begin + TKB, sg1);
+      store(smem, sg0);
+      if (nch > 2) load(m_begin + 2 * TKB, sg0);
     }
     __syncthreads();
-  }
+    for (int c = 0; c < nch; c += 2) {
+      if (c + 1 < nch && !(p.dbg & 2)) store(smem + BUF, sg1);
+      if (c + 3 < nch && !(p.dbg & 1)) load(m_begin + (c + 3) * TKB, sg1);
+      __syncthreads();
+      if (c + 1 < nch) {
+        if (c + 2 < nch && !(p.dbg & 2)) store(smem, sg0);
+        if (c + 4 < nch && !(p.dbg & 1)) load(m_begin + (c + 4) * TKB, sg0);
+        __syncthreads();
+      }
+    }
+  } else {
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+      const unsigned char* cur = smem + (c & 1) * BUF;
+      if (!(p.dbg & 4)) {
+        u32x4 fa[W][3];
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) fa[i][pl] = *(const u32x4*)(cur + pl * PLANE + a_off[i]);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          u32x4 fb0 = *(const u32x4*)(cur + b_off[j]);
+          u32x4 fb1 = *(const u32x4*)(cur + PLANE + b_off[j]);
+          u32x4 fb2 = *(const u32x4*)(cur + 2 * PLANE + b_off[j]);
+#pragma unroll
+          for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][1], fb1, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][0], fb2, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][2], fb0, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][0], fb1, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][1], fb0, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][0], fb0, acc[i][j]);
+        }
+      }
+      __syncthreads();
+    }
 
   float* out = p.part + ((long)(s * (p.conv ? 9 : 1) + tap) * p.NI) * p.NJ;
 #pragma unroll
@@ -232,14 +265,13 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
         if (row < ivalid) out[(long)(i0 + row) * p.NJ + j0 + col] = acc[i][j][q];
       }
     }
+  }
 
   if (do_colsum) {          // a column's two token octets live in different threads: meet in LDS
     float* red = (float*)smem;               // [2][BC]; the chunk buffers are dead now
+    if (producer && !isB && lane_on) {
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int wbase = __builtin_amdgcn_readfirstlane((wave << 6) + 256 * it);
-      const int u = wbase / (2 * BC), cw = wbase - u * (2 * BC);
-      if (cw < BC) red[u * BC + cw + lane] = cs[it];
+      for (int j = 0; j < 4; ++j) red[u * BC + 4 * lane + j] = cs[j];
     }
     __syncthreads();
     if (tid < ivalid) p.part_colsum[(long)s * p.NI + i0 + tid] = red[tid] + red[BC + tid];
@@ -247,7 +279,7 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
 }
 
 template <int W>
-__global__ void __launch_bounds__(256, 2) k_tnb(TnArgs p) {
+__global__ void __launch_bounds__(512, 1) k_tnb(TnArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   tnb_body<W>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
@@ -258,7 +290,7 @@ struct TnbGroup {
   int n;
 };
 template <int W>
-__global__ void __launch_bounds__(256, 2) k_tnb_grouped(TnbGroup g) {
+__global__ void __launch_bounds__(512, 1) k_tnb_grouped(TnbGroup g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = blockIdx.y;
   int k = 0;
@@ -299,6 +331,8 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
     TnArgs& p = probs[k];
     SR_REQUIRE(p.M == probs[0].M && p.S == probs[0].S && !p.conv,
                "gemm_tn_grouped_bx3: problems must share M and S");
+    SR_REQUIRE(p.NI % 4 == 0 && p.NJ % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0,
+               "gemm_tn_grouped_bx3: NI, NJ, lda, ldb must be multiples of 4");
     int a, b;
     p.i_tile = pick_tile(p.NI, &a);
     p.j_tile = pick_tile(p.NJ, &b);
@@ -306,6 +340,7 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
     if (b > w) w = b;
     const int rps = sr_cdiv(p.M, p.S);
     p.rows_per_slice = (rps + TKB - 1) / TKB * TKB;
+    { const char* e = getenv("SRHIP_TN_DBG"); p.dbg = e ? atoi(e) : 0; }
     g.tile_start[k] = tiles;
     tiles += sr_cdiv(p.NI, p.i_tile) * sr_cdiv(p.NJ, p.j_tile);
     g.p[k] = p;
@@ -319,7 +354,7 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
       if (int rc = reserve_lds(k_tnb_grouped<W_>, lds_bytes(W_), "k_tnb_grouped")) return rc; \
       attr[W_] = true;                                                                    \
     }                                                                                     \
-    hipLaunchKernelGGL((k_tnb_grouped<W_>), grid, dim3(256), lds_bytes(W_), st, g);       \
+    hipLaunchKernelGGL((k_tnb_grouped<W_>), grid, dim3(512), lds_bytes(W_), st, g);       \
   }
   SR_TNB_G(1) SR_TNB_G(2) SR_TNB_G(3)
 #undef SR_TNB_G
@@ -329,6 +364,8 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
 
 int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
   SR_REQUIRE(p.M > 0 && p.S > 0, "gemm_tn_bx3: empty problem");
+  SR_REQUIRE(p.NI % 4 == 0 && p.NJ % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0,
+             "gemm_tn_bx3: NI, NJ, lda, ldb must be multiples of 4");
   int wi, wj;
   p.i_tile = pick_tile(p.NI, &wi);
   p.j_tile = pick_tile(p.NJ, &wj);
@@ -343,7 +380,7 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
       if (int rc = reserve_lds(k_tnb<W_>, lds_bytes(W_), "k_tnb")) return rc;             \
       attr[W_] = true;                                                                    \
     }                                                                                     \
-    hipLaunchKernelGGL((k_tnb<W_>), grid, dim3(256), lds_bytes(W_), st, p);               \
+    hipLaunchKernelGGL((k_tnb<W_>), grid, dim3(512), lds_bytes(W_), st, p);               \
   }
   SR_TNB(1) SR_TNB(2) SR_TNB(3)
 #undef SR_TNB

@@ -39,6 +39,7 @@ struct TnArgs {
   int conv;                   // 0 | 1: B rows are tap-shifted pixels of a [batch][H][Wd] image
   int batch, H, Wd;
   int i_tile, j_tile, rows_per_slice;   // set by the dispatcher
+  int dbg;                              // ablation bits (env SRHIP_TN_DBG; 0 in production)
 };
 
 int sr_gemm_nt(NtArgs& p, hipStream_t st);
@@ -63,4 +64,6 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st);
 int sr_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats);
 int sr_gemm_tn_grouped(TnArgs* probs, int n, hipStream_t st);
 int sr_tn_group_plan(int M, int ntiles, int* S);
+int sr_tn_plan_t(int M, int NI, int NJ, int conv, int target, int* S, long* part_floats);
+int sr_tn_group_plan_t(int M, int ntiles, int dflt_target, int* S);
 int sr_tn_tiles(int NI, int NJ);

@@ -205,7 +205,13 @@ class SwinIR(nn.Module):
         probs = [b.drop_prob for b in self.swin_blocks()]
         if not self.training or max(probs) == 0.0:
             return None
-        keep = 1.0 - torch.tensor(probs, device=device).repeat_interleave(2)
+        # the keep probabilities live on the device (a per-step host->device copy would
+        # synchronise the stream and stop the CPU from running ahead of the GPU)
+        cache = getattr(self, "_dp_keep", None)
+        if cache is None or cache[0] != probs or cache[1].device != torch.device(device):
+            keep = 1.0 - torch.tensor(probs, device=device).repeat_interleave(2)
+            cache = self._dp_keep = (probs, keep)
+        keep = cache[1]
         mask = torch.bernoulli(keep[:, None].expand(-1, batch))
         return (mask / keep[:, None]).contiguous()
 

@@ -209,7 +209,7 @@ def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0
 def tn_plan(M, NI, NJ, conv=False):
     S = ctypes.c_int(0)
     n = ctypes.c_long(0)
-    call("srhip_tn_plan", M, NI, NJ, int(conv), ctypes.addressof(S), ctypes.addressof(n))
+    call("srhip_tn_plan" + _tn_sfx(), M, NI, NJ, int(conv), ctypes.addressof(S), ctypes.addressof(n))
     return S.value, n.value
 
 
@@ -268,7 +268,7 @@ def linear_wgrad_grouped(problems, ln_grads_zeroed=False):
     dev = problems[0]["dY"].device
     tiles = sum(lib.srhip_tn_tiles(q["dY"].shape[1], q["X"].shape[1]) for q in problems)
     S = ctypes.c_int(0)
-    call("srhip_tn_group_plan", M, tiles, ctypes.addressof(S))
+    call("srhip_tn_group_plan" + _tn_sfx(), M, tiles, ctypes.addressof(S))
     S = S.value
     sizes = [(q["dY"].shape[1] * q["X"].shape[1], q["dY"].shape[1]) for q in problems]
     part = SCRATCH.get("tng_part", S * sum(a for a, _ in sizes), device=dev)

@@ -4,6 +4,9 @@ region.  Off by default (zero overhead beyond one attribute check)."""
 import torch
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+# bf16x3 path: every f32 product costs 6 bf16 products on v_mfma_f32_32x32x16_bf16
+# (dense bf16 peak 2.5 PFLOP/s, MI355X_MICROARCH.md) -> ceiling in f32-equivalent flops
+BX3_MFMA_PEAK_TFLOPS = 2500.0 / 6.0
 active = None
 _records = {}
 
@@ -36,7 +39,10 @@ class timed:
 
 
 def _kernel_name(n, k):
-    """Instantiation the NT dispatcher (csrc/gemm_nt.hip) picks for (N, K) at M >= 32768."""
+    """Instantiation the NT dispatcher (csrc/gemm_ntb.hip, gemm_nt.hip) picks for (N, K) at M >= 32768."""
+    from . import ops
+    if ops.use_bx3():
+        return "k_ntb<1, 3, false>" if n % 180 == 0 else None
     if n % 180 == 0 and n // 180 == 2:
         return "k_nt<2, 3, 36, false>"
     if n % 180 == 0:
@@ -61,21 +67,29 @@ def _pmc_traffic(kernel):
 
 
 def collect():
-    """Dominant class (largest summed duration) -> roofline dict."""
+    """Dominant KERNEL (largest summed duration over all the (M, N, K) classes that
+    dispatch to it) -> roofline dict.  avg_launch_us is the mean over all its timed
+    launches, i.e. the figure rocprofv3 --stats reports for that kernel."""
     torch.cuda.synchronize()
-    best = None
+    from . import ops
+    per_kernel = {}
     for key, evs in _records.items():
+        kname = _kernel_name(key[2], key[3]) or f"nt(N={key[2]},K={key[3]})"
         ms = sum(a.elapsed_time(b) for a, b, _ in evs)
         fl = sum(f for _, _, f in evs)
-        if best is None or ms > best[1]:
-            best = (key, ms, fl, len(evs))
-    if best is None:
+        g = per_kernel.setdefault(kname, [0.0, 0.0, 0, {}])
+        g[0] += ms
+        g[1] += fl
+        g[2] += len(evs)
+        g[3][f"M={key[1]} N={key[2]} K={key[3]}"] = {"launches": len(evs), "avg_us": 1000.0 * ms / len(evs)}
+    if not per_kernel:
         return None
-    key, ms, fl, n = best
+    kname, (ms, fl, n, classes) = max(per_kernel.items(), key=lambda kv: kv[1][0])
     tf = fl / (ms * 1e-3) / 1e12
-    kname = _kernel_name(key[2], key[3])
-    return {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": _pmc_traffic(kname),
-            "kernel": f"{kname or 'k_nt'}: f32-MFMA NT GEMM M={key[1]} N={key[2]} K={key[3]}",
-            "launches": n, "avg_launch_us": 1000.0 * ms / n,
-            "algorithmic_gflop_per_launch": fl / n / 1e9}
+    bx = ops.use_bx3()
+    peak = BX3_MFMA_PEAK_TFLOPS if bx else F32_MFMA_PEAK_TFLOPS
+    what = "bf16x3-split MFMA (f32-equivalent flops; peak = bf16 dense / 6)" if bx else "f32-MFMA"
+    return {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+            "frac": tf / peak, "traffic": _pmc_traffic(kname),
+            "kernel": f"{kname}: {what} NT GEMM", "launches": n, "avg_launch_us": 1000.0 * ms / n,
+            "algorithmic_gflop_per_launch": fl / n / 1e9, "classes": classes}
