@@ -39,11 +39,13 @@ int srhip_abi_version(void);
  *        | 2: gelu(A) (exact erf, network_swinir.py:41)
  *   epi 0: +bias | 1: relu | 2: R + s*(acc+bias) (residual add with per-sample
  *          DropPath scale s = alpha*rowscale[row/rows_per_scale];
- *          network_swinir.py:334-335) | 3: s*acc*gelu'(R) | 4: acc*(R>0) */
+ *          network_swinir.py:334-335) | 3: s*acc*gelu'(R) | 4: acc*(R>0)
+ *   aux (epi 3 only, may be NULL): second output gelu(R), the activation the fc2
+ *          weight gradient needs -- erf is evaluated once for both */
 int srhip_gemm_nt(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                   long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
                   const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha,
-                  void* stream);
+                  float* aux, long ldaux, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution, NHWC, implicit GEMM.  Wp is the tap-major
  * pack [9][Cout][Cin] from srhip_pack_conv_weight (forward) or its flipped /
@@ -90,7 +92,7 @@ int srhip_prep_table(const srhip_prep_entry* table_dev, int n, int total_blocks,
 int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bias, float* C,
                       long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
                       const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha,
-                      void* stream);
+                      float* aux, long ldaux, void* stream);
 int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
                            int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                            const float* rowscale, float alpha, void* stream);

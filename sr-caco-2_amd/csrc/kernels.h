@@ -16,6 +16,7 @@ struct NtArgs {
   const float* ln_stats;      // [M][2] = mean, rstd
   int epi;                    // 0 +bias | 1 relu | 2 R + s*(acc+bias) | 3 s*acc*gelu'(R) | 4 acc*(R>0)
   const float* R; long ldr;
+  float* aux; long ldaux;     // epi 3: optional second output gelu(R)
   const float* rowscale; int rows_per_scale; float alpha;
   // conv geometry
   int batch, H, Wd, tiles_x, tiles_y;

@@ -73,7 +73,18 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][W
               if (grow[q] >= 0) v[q] *= p.rowscale[grow[q] / p.rows_per_scale];
           }
 #pragma unroll
-          for (int q = 0; q < 16; ++q) v[q] = v[q] * blk_s * dgelu_f(rv[q]);
+          for (int q = 0; q < 16; ++q) {
+            const float x = rv[q];
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+            v[q] = v[q] * blk_s * (cdf + x * pdf);
+            rv[q] = x * cdf;                     // gelu(R), stored below when aux is given
+          }
+          if (p.aux) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (grow[q] >= 0) p.aux[(long)grow[q] * p.ldaux + gn] = rv[q];
+          }
           break;
         case 4:
 #pragma unroll

@@ -165,11 +165,11 @@ class WeightSet:
 
 
 def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
-            rowscale=None, rows_per_scale=1, alpha=1.0):
+            rowscale=None, rows_per_scale=1, alpha=1.0, aux=None):
     """out[M,N] = epi(pro(A)[M,K] @ W[N,K]^T + bias).  W: f32 tensor (exact-f32
     MFMA) or Bx3 (3-way bf16 split MFMA)."""
     bx = isinstance(W, Bx3)
-    _chk(A, None if bx else W, bias, out, ln_stats, R, rowscale)
+    _chk(A, None if bx else W, bias, out, ln_stats, R, rowscale, aux)
     M, K = A.shape
     N = W.rows if bx else W.shape[0]
     assert (W.K if bx else W.shape[1]) == K
@@ -177,7 +177,7 @@ def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
     tail = (_p(bias), _p(out), out.stride(0), M, N, K,
             a_mode, _p(ln_stats), epi, _p(R), 0 if R is None else R.stride(0), _p(rowscale),
-            rows_per_scale, float(alpha), _st())
+            rows_per_scale, float(alpha), _p(aux), 0 if aux is None else aux.stride(0), _st())
     if bx:
         name, args = "srhip_gemm_nt_bx3", (_p(A), A.stride(0), _p(W.planes)) + tail
     else:

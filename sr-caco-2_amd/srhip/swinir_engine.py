@@ -269,6 +269,7 @@ class SwinIREngine:
         # alive until the block's grouped weight-gradient launch at its end
         gbufs = [buf("ga", T, C), buf("gb", T, C), buf("gc", T, C)]
         dh, dxh, da = buf("dh", T, hid), buf("dxh", T, C), buf("da", T, C)
+        gh = buf("gh", T, hid)        # gelu(h): by-product of the dgelu epilogue, operand of the fc2 weight gradient
         dqkv = buf("dqkv", T, 3 * C)
         bi = len(self.blocks)
         for li in reversed(range(len(net.layers))):
@@ -292,7 +293,7 @@ class SwinIREngine:
                 g1, gout = gbufs[(gi + 1) % 3], gbufs[(gi + 2) % 3]
                 # ---- MLP branch: x2 = x1 + s2*(gelu(h) W2^T + b2)
                 ops.gemm_nt(g, ws[f"{bi}.w2T"], None, out=dh, epi=3, R=h, rowscale=s2,
-                            rows_per_scale=H * W)
+                            rows_per_scale=H * W, aux=gh)
                 ops.gemm_nt(dh, ws[f"{bi}.w1T"], None, out=dxh)
                 ops.layernorm_bwd(dxh, x1, st2, g1, res=g)
                 # ---- attention branch: x1 = t + s1*(a Wp^T + bp)
@@ -309,8 +310,8 @@ class SwinIREngine:
                     dict(dY=dqkv, X=t, dW=G(p + "attn.qkv.weight"), db=G(p + "attn.qkv.bias"), b_mode=1,
                          ln_stats=st1, ln=(blk.attn.qkv.weight.data, blk.norm1.weight.data,
                                            blk.norm1.bias.data, G(p + "norm1.weight"), G(p + "norm1.bias"))),
-                    dict(dY=g, X=h, dW=G(p + "mlp.fc2.weight"), db=G(p + "mlp.fc2.bias"), a_rowscale=s2,
-                         a_rowscale_rows=H * W, b_mode=2),
+                    dict(dY=g, X=gh, dW=G(p + "mlp.fc2.weight"), db=G(p + "mlp.fc2.bias"), a_rowscale=s2,
+                         a_rowscale_rows=H * W),
                     dict(dY=dh, X=x1, dW=G(p + "mlp.fc1.weight"), db=G(p + "mlp.fc1.bias"), b_mode=1,
                          ln_stats=st2, ln=(blk.mlp.fc1.weight.data, blk.norm2.weight.data,
                                            blk.norm2.bias.data, G(p + "norm2.weight"), G(p + "norm2.bias"))),

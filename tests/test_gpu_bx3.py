@@ -75,6 +75,9 @@ def test_gemm_bx3_prologues_epilogues(ops):
     out = ops.gemm_nt(d(A), Wb, None, epi=3, R=d(R), rowscale=d(rs), rows_per_scale=256)
     ref = rs.double().repeat_interleave(256)[:, None] * F.linear(A.double(), W.double()) * Rg.grad
     assert relerr(out, ref) < tol
+    aux = torch.empty(M, N).cuda()
+    out2 = ops.gemm_nt(d(A), Wb, None, epi=3, R=d(R), rowscale=d(rs), rows_per_scale=256, aux=aux)
+    assert torch.equal(out2, out) and relerr(aux, F.gelu(R.double())) < tol
     out = ops.gemm_nt(d(A), Wb, None, epi=4, R=d(R))
     assert relerr(out, F.linear(A.double(), W.double()) * (R > 0)) < tol
     wide = torch.zeros(M, 540).cuda()
