@@ -110,30 +110,30 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
     offB[it] = (unsigned)((n0 + min(row, nvalid - 1)) * (int)p.ldw + c4 * 4) * 4u;
   }
 
+  // Loaded values are not touched here (a select on a fresh load forces an immediate
+  // s_waitcnt and serialises the prefetch): K-tail / halo lanes read a valid address
+  // and are zeroed when the chunk is staged.
+  int kc_a = 0, kc_b = 0;                    // chunk held by ra / rb
   auto load_a = [&](int kc) {
     const char* base = (const char*)(p.A + kc * BK);
     const bool ktail = kc * BK + BK > p.K;           // block-uniform
+    kc_a = kc;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-      // K tail (K not a multiple of BK): out-of-range lanes read k = 0 of their
-      // row (always mapped) and are zeroed -- never touch memory past the end of a row
       const int sk = slot_k(it, A_N);
       const bool oob = ktail && kc * BK + sk >= p.K;
-      f32x4 v = *(const f32x4*)((oob ? (const char*)p.A : base) + (oob ? offA[it] - sk * 4u : offA[it]));
-      if ((CONV && !inA[it]) || oob) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      ra[it] = v;
+      ra[it] = *(const f32x4*)((oob ? (const char*)p.A : base) + (oob ? offA[it] - sk * 4u : offA[it]));
     }
   };
   auto load_b = [&](int kc, int tap) {
     const char* base = (const char*)(p.W + (long)tap * p.wtap + kc * BK);
     const bool ktail = kc * BK + BK > p.K;
+    kc_b = kc;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int sk = slot_k(it, B_N);
       const bool oob = ktail && kc * BK + sk >= p.K;
-      f32x4 v = *(const f32x4*)((oob ? (const char*)(p.W + (long)tap * p.wtap) : base) + (oob ? offB[it] - sk * 4u : offB[it]));
-      if (oob) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      rb[it] = v;
+      rb[it] = *(const f32x4*)((oob ? (const char*)(p.W + (long)tap * p.wtap) : base) + (oob ? offB[it] - sk * 4u : offB[it]));
     }
   };
   auto store_a = [&]() {
@@ -149,6 +149,9 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
             v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
           }
         }
+        // halo pixels outside the image and the K tail contribute exact zeros
+        if ((CONV && !inA[it]) || (kc_a * BK + BK > p.K && kc_a * BK + slot_k(it, A_N) >= p.K))
+          v = f32x4{0.f, 0.f, 0.f, 0.f};
         *(f32x4*)(As + lds_off(it, A_N)) = v;
       }
     }
@@ -156,7 +159,11 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
   auto store_b = [&]() {
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      if (B_N % 256 == 0 || tid + it * 256 < B_N) *(f32x4*)(Bs + lds_off(it, B_N)) = rb[it];
+      if (B_N % 256 == 0 || tid + it * 256 < B_N) {
+        f32x4 v = rb[it];
+        if (kc_b * BK + BK > p.K && kc_b * BK + slot_k(it, B_N) >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(Bs + lds_off(it, B_N)) = v;
+      }
     }
   };
 

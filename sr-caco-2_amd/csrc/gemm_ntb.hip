@@ -81,8 +81,15 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     m0 = blockIdx.x * BM;
   }
 
+  // Co-resident blocks start in lockstep and would load, compute and store at the
+  // same moments; delaying the second half of the grid lets one block's memory
+  // phases overlap its neighbour's MFMA phase (see gemm_nt.hip).
+  if (p.stagger > 0 && (blockIdx.x + blockIdx.y * gridDim.x) >= (gridDim.x * gridDim.y) / 2) {
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  }
+
   // ---- staging invariants (see gemm_nt.hip: clamped rows, fixed byte offsets) ----
-  f32x4 ra[A_IT];
+  f32x4 ra0[A_IT], ra1[A_IT];     // GEMM: A chunks it and it+1 in flight (two register sets)
   u32x4 rb[B_IT];
   float2 rst[A_IT];
   unsigned offA[A_IT], offB[B_IT];
@@ -115,16 +122,17 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     offB[it] = (unsigned)(pl * plane_bytes + ((long)(n0 + min(row, nvalid - 1)) * p.Kp) * 2 + q * 16);
   }
 
-  auto load_a = [&](int kc) {
+  // Loaded values are not touched here (a select on a fresh load would force an
+  // immediate s_waitcnt and serialise the prefetch): K-tail / halo lanes read a valid
+  // address and are zeroed when the chunk is staged (store_a).
+  auto load_a = [&](int kc, f32x4 (&ra)[A_IT]) {
     const char* base = (const char*)(p.A + kc * BKB);
     const bool ktail = kc * BKB + BKB > p.K;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int c4 = min(tid + it * 256, A_N - 1) & 7;
       const bool oob = ktail && kc * BKB + c4 * 4 >= p.K;
-      f32x4 v = *(const f32x4*)((oob ? (const char*)p.A : base) + (oob ? offA[it] - c4 * 16u : offA[it]));   // oob: k = 0 of the row
-      if ((CONV && !inA[it]) || oob) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      ra[it] = v;
+      ra[it] = *(const f32x4*)((oob ? (const char*)p.A : base) + (oob ? offA[it] - c4 * 16u : offA[it]));   // oob: k = 0 of the row
     }
   };
   auto load_b = [&](int kc, int tap) {
@@ -132,7 +140,8 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) rb[it] = *(const u32x4*)(base + offB[it]);
   };
-  auto store_a = [&]() {
+  auto store_a = [&](const f32x4 (&ra)[A_IT], int kc) {
+    const bool ktail = kc * BKB + BKB > p.K;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       if (A_N % 256 == 0 || tid + it * 256 < A_N) {
@@ -146,6 +155,8 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
             v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
           }
         }
+        // halo pixels outside the image and the K tail contribute exact zeros
+        if ((CONV && !inA[it]) || (ktail && kc * BKB + (idx & 7) * 4 >= p.K)) v = f32x4{0.f, 0.f, 0.f, 0.f};
         unsigned h0, m0_, l0, h1, m1, l1;
         split3_pair(v.x, v.y, h0, m0_, l0);
         split3_pair(v.z, v.w, h1, m1, l1);
@@ -189,22 +200,25 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
   const int ntap = CONV ? 9 : 1;
   const int niter = nkc * ntap;
 
-  load_a(0);
-  load_b(0, 0);
-  for (int it = 0; it < niter; ++it) {
+  // The A operand comes from HBM and the loop is latency bound with one chunk in
+  // flight: the GEMM keeps TWO A chunks in flight (W chunks are L2 hits, one is enough)
+  auto iter = [&](int it, f32x4 (&ra)[A_IT]) {
     const int kc = it / ntap, tap = it - kc * ntap;
     __syncthreads();
     if (!(p.dbg & 2)) {
-      if (!CONV || tap == 0) store_a();
+      if (!CONV || tap == 0) store_a(ra, kc);
       store_b();
     }
     __syncthreads();
+    if (!CONV) {
+      if (it + 2 < niter && !(p.dbg & 32)) load_a(it + 2, ra);
+    }
     if (it + 1 < niter) {
       const int kc1 = (it + 1) / ntap, tap1 = (it + 1) - kc1 * ntap;
-      if ((!CONV || tap1 == 0) && !(p.dbg & 32)) load_a(kc1);
+      if (CONV && tap1 == 0 && !(p.dbg & 32)) load_a(kc1, ra);
       if (!(p.dbg & 16)) load_b(kc1, tap1);
     }
-    if (p.dbg & 4) continue;
+    if (p.dbg & 4) return;
     const int toff = CONV ? ((tap / 3) * 18 + (tap % 3)) * PITCH : 0;
 #pragma unroll
     for (int s = 0; s < BKB / 16; ++s) {
@@ -227,6 +241,13 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
       SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
 #undef SR_TERM
     }
+  };
+  load_a(0, ra0);
+  if (!CONV && niter > 1) load_a(1, ra1);
+  load_b(0, 0);
+  for (int it = 0; it < niter; it += 2) {
+    iter(it, ra0);
+    if (it + 1 < niter) iter(it + 1, CONV ? ra0 : ra1);
   }
 
   if (p.dbg & 8) return;
@@ -321,6 +342,7 @@ int sr_split3(const float* W, long ldw, int rows, int K, unsigned short* out, hi
 
 int sr_gemm_ntb(NtArgs& p, hipStream_t st) {
   p.dbg = ntb_env("SRHIP_NT_DBG", 0);      // ablation bits, 0 in production
+  p.stagger = ntb_env("SRHIP_NTB_STAGGER", 0);
   SR_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0, "gemm_nt_bx3: K, lda must be multiples of 4 (K=%d)", p.K);
   SR_REQUIRE(p.M > 0 && p.N > 0, "gemm_nt_bx3: empty problem");
   p.Kp = sr_kp(p.K);

@@ -24,6 +24,34 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][W
   // batch the 16 loads of a tile ahead of the math (one wait per tile, not one
   // per element).
   const bool needR = p.R != nullptr && p.epi >= 2;
+  // pass 1: ALL residual / gate loads of the wave (WM x WN tiles x 16) are issued
+  // before any of them is used: the epilogue is latency bound otherwise (every block
+  // of the launch reaches it at the same moment)
+  constexpr bool BATCH = WM * WN <= 3;             // larger wave tiles would spill: per-tile batches
+  float rvall[BATCH ? WM : 1][BATCH ? WN : 1][16];
+#pragma unroll
+  for (int j = 0; j < (BATCH ? WN : 0); ++j) {
+    const int col = (wn * WN + j) * 32 + r;
+    const bool cok = col < nvalid;
+    const int gn = n0 + col;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int mt = wm * WM + i;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int lr = mfma_row(q, lane);
+        int g;
+        if (CONV) {
+          const int y = y0 + 2 * mt + (lr >> 4), x = x0 + (lr & 15);
+          g = (cok && y < p.H && x < p.Wd) ? (img * p.H + y) * p.Wd + x : -1;
+        } else {
+          const int gg = m0 + mt * 32 + lr;
+          g = (cok && gg < p.M) ? gg : -1;
+        }
+        rvall[i][j][q] = (needR && g >= 0) ? p.R[(long)g * p.ldr + gn] : 0.f;
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int col = (wn * WN + j) * 32 + r;        // column inside the N block
@@ -34,7 +62,7 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][W
     for (int i = 0; i < WM; ++i) {
       const int mt = wm * WM + i;
       int grow[16];                                // global row (token / pixel), -1 = masked
-      float rv[16];
+      float (&rv)[16] = rvall[BATCH ? i : 0][BATCH ? j : 0];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int lr = mfma_row(q, lane);          // row inside the 32-row tile
@@ -46,9 +74,11 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][W
           grow[q] = (cok && g < p.M) ? g : -1;
         }
       }
+      if (!BATCH) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
-        rv[q] = (needR && grow[q] >= 0) ? p.R[(long)grow[q] * p.ldr + gn] : 0.f;
+        for (int q = 0; q < 16; ++q)
+          rv[q] = (needR && grow[q] >= 0) ? p.R[(long)grow[q] * p.ldr + gn] : 0.f;
+      }
       f32x16& v = acc[i][j];
 #pragma unroll
       for (int q = 0; q < 16; ++q) v[q] += bv;
