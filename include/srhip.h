@@ -93,6 +93,16 @@ int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bia
                       long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
                       const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha,
                       float* aux, long ldaux, void* stream);
+/* Data-gradient GEMM with the LayerNorm backward fused into its epilogue:
+ *   dxh = A . W^T                       (W = transposed, gamma-folded weight planes)
+ *   out = res + rstd * (dxh - mean_c(dxh) - xhat * mean_c(dxh * xhat)),  xhat = (x - mean) * rstd
+ * with stats[M][2] = {mean, rstd} of x (srhip_layernorm_fwd), res = gradient arriving
+ * over the residual connection (may be NULL).  N <= 192 (the row must fit one block).
+ * Replaces srhip_gemm_nt_bx3 + srhip_layernorm_bwd for the backward of
+ * network_swinir.py:293,335. */
+int srhip_gemm_nt_bx3_lnbwd(const float* A, long lda, const void* Wb, float* out, long ldo, int M, int N, int K,
+                            const float* x, long ldx, const float* stats, const float* res, long ldres,
+                            void* stream);
 int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
                            int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                            const float* rowscale, float alpha, void* stream);

@@ -87,6 +87,17 @@ int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bia
   return sr_gemm_ntb(p, (hipStream_t)stream);
 }
 
+int srhip_gemm_nt_bx3_lnbwd(const float* A, long lda, const void* Wb, float* out, long ldo, int M, int N, int K,
+                            const float* x, long ldx, const float* stats, const float* res, long ldres,
+                            void* stream) {
+  NtArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.Wb = (const unsigned short*)Wb; p.C = out; p.ldc = ldo;
+  p.M = M; p.N = N; p.K = K; p.R = x; p.ldr = ldx; p.R2 = res; p.ldr2 = ldres; p.ep_stats = stats;
+  p.alpha = 1.f;
+  return sr_gemm_ntb_lnbwd(p, (hipStream_t)stream);
+}
+
 int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
                            int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                            const float* rowscale, float alpha, void* stream) {

@@ -210,13 +210,15 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
       store_b();
     }
     __syncthreads();
-    if (!CONV) {
-      if (it + 2 < niter && !(p.dbg & 32)) load_a(it + 2, ra);
-    }
+    // issue order matters (vmcnt retires in order): W(it+1) first, then A(it+2), so the
+    // next staging waits with vmcnt(#A loads) and leaves the far-ahead A chunk in flight
     if (it + 1 < niter) {
       const int kc1 = (it + 1) / ntap, tap1 = (it + 1) - kc1 * ntap;
-      if (CONV && tap1 == 0 && !(p.dbg & 32)) load_a(kc1, ra);
       if (!(p.dbg & 16)) load_b(kc1, tap1);
+      if (CONV && tap1 == 0 && !(p.dbg & 32)) load_a(kc1, ra);
+    }
+    if (!CONV) {
+      if (it + 2 < niter && !(p.dbg & 32)) load_a(it + 2, ra);
     }
     if (p.dbg & 4) return;
     const int toff = CONV ? ((tap / 3) * 18 + (tap % 3)) * PITCH : 0;
@@ -243,14 +245,20 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     }
   };
   load_a(0, ra0);
-  if (!CONV && niter > 1) load_a(1, ra1);
   load_b(0, 0);
+  if (!CONV && niter > 1) load_a(1, ra1);
   for (int it = 0; it < niter; it += 2) {
     iter(it, ra0);
     if (it + 1 < niter) iter(it + 1, CONV ? ra0 : ra1);
   }
 
   if (p.dbg & 8) return;
+  if constexpr (!CONV && WM == 1) {
+    if (p.epi == 5) {
+      nt_epilogue_lnbwd<WN>(p, acc, lane, wm, wn, m0, nvalid, (float*)smem);
+      return;
+    }
+  }
   nt_epilogue<WM, WN, CONV>(p, acc, lane, wm, wn, n0, nvalid, m0, img, y0, x0);
 }
 
@@ -349,6 +357,20 @@ int sr_gemm_ntb(NtArgs& p, hipStream_t st) {
   SR_REQUIRE((long)p.M * p.lda < (1L << 29) && 6L * p.N * p.Kp < (1L << 31),
              "gemm_nt_bx3: operand larger than 2 GiB (32-bit staging offsets)");
   return dispatch_ntb<false>(p, st);
+}
+
+// out = res + LayerNorm-backward(A . W^T) in one kernel (epilogue 5)
+int sr_gemm_ntb_lnbwd(NtArgs& p, hipStream_t st) {
+  SR_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0, "gemm_nt_bx3_lnbwd: K, lda must be multiples of 4 (K=%d)", p.K);
+  SR_REQUIRE(p.M > 0 && p.N > 0 && p.N <= 192, "gemm_nt_bx3_lnbwd: the row (N=%d) must fit one 192-column block", p.N);
+  SR_REQUIRE(p.R && p.ep_stats, "gemm_nt_bx3_lnbwd: x and its statistics are required");
+  p.Kp = sr_kp(p.K);
+  p.epi = 5;
+  p.dbg = 0; p.stagger = 0;
+  if (p.N % 180 == 0 || p.N > 128) { p.n_tile = (p.N % 180 == 0) ? 180 : 192; return launch_ntb<1, 3, false>(p, st); }
+  if (p.N > 64) { p.n_tile = 128; return launch_ntb<1, 2, false>(p, st); }
+  p.n_tile = 64;
+  return launch_ntb<1, 1, false>(p, st);
 }
 
 int sr_conv3x3_ntb(NtArgs& p, hipStream_t st) {

@@ -17,6 +17,8 @@ struct NtArgs {
   int epi;                    // 0 +bias | 1 relu | 2 R + s*(acc+bias) | 3 s*acc*gelu'(R) | 4 acc*(R>0)
   const float* R; long ldr;
   float* aux; long ldaux;     // epi 3: optional second output gelu(R)
+  // epi 5 (LayerNorm backward, bx3 GEMM only): R = x, R2 = residual gradient, ep_stats = {mean, rstd}[M]
+  const float* R2; long ldr2; const float* ep_stats;
   const float* rowscale; int rows_per_scale; float alpha;
   // conv geometry
   int batch, H, Wd, tiles_x, tiles_y;
@@ -59,6 +61,7 @@ __host__ __device__ static inline int sr_kp(int K) { return (K + 31) / 32 * 32; 
 int sr_split3(const float* W, long ldw, int rows, int K, unsigned short* out, hipStream_t st);
 int sr_gemm_ntb(NtArgs& p, hipStream_t st);
 int sr_conv3x3_ntb(NtArgs& p, hipStream_t st);
+int sr_gemm_ntb_lnbwd(NtArgs& p, hipStream_t st);
 int sr_gemm_tn(TnArgs& p, hipStream_t st);
 int sr_gemm_tnb(TnArgs& p, hipStream_t st);
 int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st);

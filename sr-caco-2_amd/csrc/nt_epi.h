@@ -129,3 +129,101 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][W
     }
   }
 }
+
+// Epilogue 5 -- LayerNorm backward fused into the data-gradient GEMM that produces
+// dxh = d loss / d xhat (the LayerNorm affine is folded into the Linear weight):
+//
+//   out = res + rstd * (dxh - mean_c(dxh) - xhat * mean_c(dxh * xhat)),  xhat = (x - mean) * rstd
+//
+// (network_swinir.py:293,335 backward).  Needs the whole row in the block: one N
+// block (N <= 64*WN), WM = 1.  A row's columns live in two waves (wn = 0, 1) and,
+// inside a wave, in the 32 lanes of a half: per-lane partial sums over the lane's
+// tiles, a halving butterfly over the 32 lanes (16 rows x 2 sums in 16 exchanges
+// each instead of 80), then the two wave halves meet in LDS.
+template <int WN>
+__device__ __forceinline__ void nt_epilogue_lnbwd(const NtArgs& p, f32x16 (&acc)[1][WN], int lane, int wm,
+                                                  int wn, int m0, int nvalid, float* red) {
+  const int r = lane & 31;
+  const int rbase = m0 + wm * 32;
+  float rs[16];
+  float xh[WN][16];
+  {
+    float mu[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int g = min(rbase + mfma_row(q, lane), p.M - 1);      // clamped rows are never stored
+      const float2 st = *(const float2*)(p.ep_stats + 2 * (long)g);
+      mu[q] = st.x; rs[q] = st.y;
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = min((wn * WN + j) * 32 + r, nvalid - 1);    // clamped columns are zeroed below
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int g = min(rbase + mfma_row(q, lane), p.M - 1);
+        xh[j][q] = p.R[(long)g * p.ldr + col];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const bool cok = (wn * WN + j) * 32 + r < nvalid;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        acc[0][j][q] = cok ? acc[0][j][q] : 0.f;                  // padded columns hold garbage
+        xh[j][q] = cok ? (xh[j][q] - mu[q]) * rs[q] : 0.f;
+      }
+    }
+  }
+  float a1[16], a2[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) { s1 += acc[0][j][q]; s2 += acc[0][j][q] * xh[j][q]; }
+    a1[q] = s1; a2[q] = s2;
+  }
+  // halving butterfly over the 32 lanes of the half: slot 0 ends as the total of row
+  // q* = bit4*8 + bit3*4 + bit2*2 + bit1 (bits of the lane index)
+#pragma unroll
+  for (int n = 8, m = 16; n >= 1; n >>= 1, m >>= 1) {
+    const bool up = lane & m;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const float s1 = up ? a1[i] : a1[i + n], k1 = up ? a1[i + n] : a1[i];
+      const float s2 = up ? a2[i] : a2[i + n], k2 = up ? a2[i + n] : a2[i];
+      a1[i] = k1 + __shfl_xor(s1, m, 64);
+      a2[i] = k2 + __shfl_xor(s2, m, 64);
+    }
+  }
+  const float t1 = a1[0] + __shfl_xor(a1[0], 1, 64), t2 = a2[0] + __shfl_xor(a2[0], 1, 64);
+  const int qs = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+  __syncthreads();                                  // staging buffers are dead from here on
+  if (!(lane & 1)) *(float2*)(red + ((wn * 64) + wm * 32 + mfma_row(qs, lane)) * 2) = float2{t1, t2};
+  // the residual gradient is fetched while the two wave halves meet in LDS
+  float rres[WN][16];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = min((wn * WN + j) * 32 + r, nvalid - 1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int g = min(rbase + mfma_row(q, lane), p.M - 1);
+      rres[j][q] = p.R2 ? p.R2[(long)g * p.ldr2 + col] : 0.f;
+    }
+  }
+  __syncthreads();
+  const float inv = 1.0f / (float)p.N;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int lr = wm * 32 + mfma_row(q, lane);
+    const float2 p0 = *(const float2*)(red + lr * 2), p1 = *(const float2*)(red + (64 + lr) * 2);
+    const float m1 = (p0.x + p1.x) * inv, m2 = (p0.y + p1.y) * inv;
+    const bool rok = rbase + mfma_row(q, lane) < p.M;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = (wn * WN + j) * 32 + r;
+      if (rok && col < nvalid)
+        p.C[(long)(rbase + mfma_row(q, lane)) * p.ldc + col] =
+            rres[j][q] + rs[q] * (acc[0][j][q] - m1 - xh[j][q] * m2);
+    }
+  }
+}

@@ -190,6 +190,17 @@ def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
     return out
 
 
+def gemm_nt_lnbwd(A, W, x, stats, res, out):
+    """out = res + LayerNorm_backward(A @ W^T; x, stats) in one kernel (W: Bx3)."""
+    assert isinstance(W, Bx3)
+    _chk(A, x, stats, res, out)
+    M, K = A.shape
+    assert W.K == K and x.shape == (M, W.rows) and out.shape == (M, W.rows)
+    call("srhip_gemm_nt_bx3_lnbwd", _p(A), A.stride(0), _p(W.planes), _p(out), out.stride(0), M, W.rows, K,
+         _p(x), x.stride(0), _p(stats), _p(res), 0 if res is None else res.stride(0), _st())
+    return out
+
+
 def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0):
     """X NHWC [B,H,W,Cin], Wp packed [9,Cout,Cin] (f32 tensor or Bx3) -> [B,H,W,Cout]."""
     bx = isinstance(Wp, Bx3)

@@ -294,8 +294,11 @@ class SwinIREngine:
                 # ---- MLP branch: x2 = x1 + s2*(gelu(h) W2^T + b2)
                 ops.gemm_nt(g, ws[f"{bi}.w2T"], None, out=dh, epi=3, R=h, rowscale=s2,
                             rows_per_scale=H * W, aux=gh)
-                ops.gemm_nt(dh, ws[f"{bi}.w1T"], None, out=dxh)
-                ops.layernorm_bwd(dxh, x1, st2, g1, res=g)
+                if ws.use_bx3:      # LayerNorm backward fused into the GEMM epilogue
+                    ops.gemm_nt_lnbwd(dh, ws[f"{bi}.w1T"], x1, st2, g, g1)
+                else:
+                    ops.gemm_nt(dh, ws[f"{bi}.w1T"], None, out=dxh)
+                    ops.layernorm_bwd(dxh, x1, st2, g1, res=g)
                 # ---- attention branch: x1 = t + s1*(a Wp^T + bp)
                 ops.gemm_nt(g1, ws[f"{bi}.wpT"], None, out=da, epi=2, rowscale=s1, rows_per_scale=H * W)
                 dbT = buf("dbiasT", heads, 64, 64)
@@ -303,8 +306,11 @@ class SwinIREngine:
                 ops.window_attention_bwd(qkv, da, dqkv, D.d[f"{bi}.biasT"], D.d[f"{bi}.biasN"], dbT, B, H,
                                          W, C, heads, blk.shift_size)
                 ops.bias_grad(dbT, G(p + "attn.relative_position_bias_table"))
-                ops.gemm_nt(dqkv, ws[f"{bi}.wqT"], None, out=dxh)
-                ops.layernorm_bwd(dxh, t, st1, gout, res=g1)
+                if ws.use_bx3:
+                    ops.gemm_nt_lnbwd(dqkv, ws[f"{bi}.wqT"], t, st1, g1, gout)
+                else:
+                    ops.gemm_nt(dqkv, ws[f"{bi}.wqT"], None, out=dxh)
+                    ops.layernorm_bwd(dxh, t, st1, gout, res=g1)
                 # ---- the four weight gradients of the block in ONE launch
                 ops.linear_wgrad_grouped([
                     dict(dY=dqkv, X=t, dW=G(p + "attn.qkv.weight"), db=G(p + "attn.qkv.bias"), b_mode=1,

@@ -159,3 +159,24 @@ def test_prep_table_matches_single_ops(ops):
         assert torch.equal(o[k].planes, ops.split_bf16x3(ref).planes), k
     assert (bq - bf).abs().max().item() < 1e-6
     assert torch.equal(bT, rT) and torch.equal(bN, rN)
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 180, 360), (777, 180, 540), (300, 64, 64), (2048, 120, 180), (32768, 180, 360)])
+def test_gemm_lnbwd_fused(ops, M, N, K):
+    """GEMM + LayerNorm backward in one kernel == aten autograd of LayerNorm (no affine) applied to x,
+    upstream gradient dxh = A @ W^T, plus the residual gradient."""
+    A, W = rnd(M, K), rnd(N, K, scale=0.1)
+    x, res = rnd(M, N) * 2 + 0.5, rnd(M, N)
+    xd = x.double().requires_grad_(True)
+    y = F.layer_norm(xd, (N,), eps=1e-5)
+    dxh = F.linear(A.double(), W.double())
+    y.backward(dxh)
+    ref = res.double() + xd.grad
+    stats = torch.empty(M, 2).cuda()
+    ops.layernorm_fwd(x.cuda(), stats)
+    out = torch.empty(M, N).cuda()
+    ops.gemm_nt_lnbwd(A.cuda(), ops.split_bf16x3(W.cuda()), x.cuda(), stats, res.cuda(), out)
+    assert relerr(out, ref) < 5e-6
+    out2 = torch.full((M, N), float("nan")).cuda()
+    ops.gemm_nt_lnbwd(A.cuda(), ops.split_bf16x3(W.cuda()), x.cuda(), stats, None, out2)
+    assert relerr(out2, xd.grad) < 5e-6
