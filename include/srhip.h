@@ -64,6 +64,8 @@ int srhip_conv3x3_nhwc(const float* X, long ldx, const float* Wp, const float* b
  * rounded up to 32, zero filled); rows = N for a Linear weight, 9*Cout for the
  * tap-major conv pack.  Same prologues / epilogues / reference lines as
  * srhip_gemm_nt and srhip_conv3x3_nhwc. */
+/* stats_out (srhip_gemm_nt_bx3 only, may be NULL; needs N <= 192): {mean, rstd}[M] of the
+ * output rows, i.e. srhip_layernorm_fwd of C for the next LayerNorm-prologue GEMM. */
 int srhip_bf16x3_kp(int K);
 int srhip_split_bf16x3(const float* W, long ldw, int rows, int K, void* out, void* stream);
 /* Per-step weight preparation of a whole network in ONE launch (replaces the
@@ -92,7 +94,7 @@ int srhip_prep_table(const srhip_prep_entry* table_dev, int n, int total_blocks,
 int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bias, float* C,
                       long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
                       const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha,
-                      float* aux, long ldaux, void* stream);
+                      float* aux, long ldaux, float* stats_out, void* stream);
 /* Data-gradient GEMM with the LayerNorm backward fused into its epilogue:
  *   dxh = A . W^T                       (W = transposed, gamma-folded weight planes)
  *   out = res + rstd * (dxh - mean_c(dxh) - xhat * mean_c(dxh * xhat)),  xhat = (x - mean) * rstd

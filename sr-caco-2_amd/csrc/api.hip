@@ -18,7 +18,7 @@ int sr_fail(int code, const char* fmt, ...) {
 extern "C" {
 
 const char* srhip_last_error(void) { return g_err; }
-int srhip_abi_version(void) { return 2; }
+int srhip_abi_version(void) { return 3; }
 
 int srhip_gemm_nt(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                   long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
@@ -71,7 +71,7 @@ int srhip_prep_table(const srhip_prep_entry* table_dev, int n, int total_blocks,
 int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bias, float* C,
                       long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
                       const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha, float* aux,
-                      long ldaux, void* stream) {
+                      long ldaux, float* stats_out, void* stream) {
   SR_REQUIRE(a_mode >= 0 && a_mode <= 2, "gemm_nt_bx3: a_mode %d", a_mode);
   SR_REQUIRE(epi >= 0 && epi <= 4, "gemm_nt_bx3: epi %d", epi);
   SR_REQUIRE(a_mode != 1 || ln_stats, "gemm_nt_bx3: layernorm prologue without stats");
@@ -82,7 +82,7 @@ int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bia
   p.A = A; p.lda = lda; p.Wb = (const unsigned short*)Wb; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K; p.bias = bias; p.a_mode = a_mode; p.ln_stats = ln_stats;
   p.epi = epi; p.R = R; p.ldr = ldr; p.rowscale = rowscale; p.rows_per_scale = rows_per_scale;
-  p.alpha = alpha; p.aux = aux; p.ldaux = ldaux;
+  p.alpha = alpha; p.aux = aux; p.ldaux = ldaux; p.stats_out = stats_out;
   SR_REQUIRE(!aux || epi == 3, "gemm_nt_bx3: aux output is produced by epilogue 3 only");
   return sr_gemm_ntb(p, (hipStream_t)stream);
 }

@@ -260,6 +260,9 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     }
   }
   nt_epilogue<WM, WN, CONV>(p, acc, lane, wm, wn, n0, nvalid, m0, img, y0, x0);
+  if constexpr (!CONV && WM == 1) {
+    if (p.stats_out) nt_row_stats<WN>(p, acc, lane, wm, wn, m0, nvalid, (float*)smem);
+  }
 }
 
 template <int WM, int WN, bool CONV>
@@ -300,6 +303,7 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
   blocks128 *= sr_cdiv(p.N, p.n_tile);
   int wm = blocks128 >= 1024 ? 2 : 1;
   if (!CONV && wn == 3) wm = 1;          // <2,3> GEMM tile spills
+  if (!CONV && p.stats_out) wm = 1;      // row statistics: WM = 1 epilogue
   const int force_wm = ntb_env("SRHIP_NTB_WM", 0);
   if (force_wm == 1 || force_wm == 2) wm = force_wm;
   if (CONV) {
@@ -349,6 +353,7 @@ int sr_split3(const float* W, long ldw, int rows, int K, unsigned short* out, hi
 }
 
 int sr_gemm_ntb(NtArgs& p, hipStream_t st) {
+  SR_REQUIRE(!p.stats_out || p.N <= 192, "gemm_nt_bx3: row statistics need the row (N=%d) in one 192-column block", p.N);
   p.dbg = ntb_env("SRHIP_NT_DBG", 0);      // ablation bits, 0 in production
   p.stagger = ntb_env("SRHIP_NTB_STAGGER", 0);
   SR_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0, "gemm_nt_bx3: K, lda must be multiples of 4 (K=%d)", p.K);

@@ -5,6 +5,74 @@
 #include "common.h"
 #include "kernels.h"
 
+// Sum of a[q] over the 32 lanes of a wave half for all 16 q at once (halving
+// butterfly: 8+4+2+1+1 exchanges instead of 16x5).  Returns the total of row
+// q* = bit4*8 + bit3*4 + bit2*2 + bit1 of the lane index; a[] is destroyed.
+__device__ __forceinline__ float half_reduce16(float (&a)[16], int lane) {
+#pragma unroll
+  for (int n = 8, m = 16; n >= 1; n >>= 1, m >>= 1) {
+    const bool up = lane & m;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const float s = up ? a[i] : a[i + n], k = up ? a[i + n] : a[i];
+      a[i] = k + __shfl_xor(s, m, 64);
+    }
+  }
+  return a[0] + __shfl_xor(a[0], 1, 64);
+}
+__device__ __forceinline__ int half_reduce16_row(int lane) {
+  return ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+}
+
+// LayerNorm statistics {mean, rstd} (eps 1e-5, biased variance: nn.LayerNorm,
+// network_swinir.py:240,248) of the rows a block has just produced, for the NEXT
+// LayerNorm-prologue GEMM: saves the separate pass over the activation.  Two-pass
+// like the reference (mean, then squared deviations).  One N block, WM = 1.
+template <int WN>
+__device__ __forceinline__ void nt_row_stats(const NtArgs& p, f32x16 (&acc)[1][WN], int lane, int wm, int wn,
+                                             int m0, int nvalid, float* red) {
+  const int r = lane & 31;
+  const float inv = 1.0f / (float)p.N;
+  float a[16], mean[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) s += ((wn * WN + j) * 32 + r < nvalid) ? acc[0][j][q] : 0.f;
+    a[q] = s;
+  }
+  const float t1 = half_reduce16(a, lane);
+  const int qs = half_reduce16_row(lane);
+  __syncthreads();                                  // staging buffers are dead from here on
+  if (!(lane & 1)) red[wn * 64 + wm * 32 + mfma_row(qs, lane)] = t1;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int lr = wm * 32 + mfma_row(q, lane);
+    mean[q] = (red[lr] + red[64 + lr]) * inv;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const float d = ((wn * WN + j) * 32 + r < nvalid) ? acc[0][j][q] - mean[q] : 0.f;
+      s += d * d;
+    }
+    a[q] = s;
+  }
+  const float t2 = half_reduce16(a, lane);
+  if (!(lane & 1)) red[128 + wn * 64 + wm * 32 + mfma_row(qs, lane)] = t2;
+  __syncthreads();
+  if (wn == 0 && r == 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int lr = wm * 32 + mfma_row(q, lane), g = m0 + lr;
+      if (g < p.M) {
+        const float var = (red[128 + lr] + red[192 + lr]) * inv;
+        *(float2*)(p.stats_out + 2 * (long)g) = float2{mean[q], rsqrtf(var + 1e-5f)};
+      }
+    }
+  }
+}
+
 template <int WM, int WN, bool CONV>
 __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][WN], int lane, int wm,
                                             int wn, int n0, int nvalid, int m0, int img, int y0,
@@ -182,21 +250,8 @@ __device__ __forceinline__ void nt_epilogue_lnbwd(const NtArgs& p, f32x16 (&acc)
     for (int j = 0; j < WN; ++j) { s1 += acc[0][j][q]; s2 += acc[0][j][q] * xh[j][q]; }
     a1[q] = s1; a2[q] = s2;
   }
-  // halving butterfly over the 32 lanes of the half: slot 0 ends as the total of row
-  // q* = bit4*8 + bit3*4 + bit2*2 + bit1 (bits of the lane index)
-#pragma unroll
-  for (int n = 8, m = 16; n >= 1; n >>= 1, m >>= 1) {
-    const bool up = lane & m;
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      const float s1 = up ? a1[i] : a1[i + n], k1 = up ? a1[i + n] : a1[i];
-      const float s2 = up ? a2[i] : a2[i + n], k2 = up ? a2[i + n] : a2[i];
-      a1[i] = k1 + __shfl_xor(s1, m, 64);
-      a2[i] = k2 + __shfl_xor(s2, m, 64);
-    }
-  }
-  const float t1 = a1[0] + __shfl_xor(a1[0], 1, 64), t2 = a2[0] + __shfl_xor(a2[0], 1, 64);
-  const int qs = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+  const float t1 = half_reduce16(a1, lane), t2 = half_reduce16(a2, lane);
+  const int qs = half_reduce16_row(lane);
   __syncthreads();                                  // staging buffers are dead from here on
   if (!(lane & 1)) *(float2*)(red + ((wn * 64) + wm * 32 + mfma_row(qs, lane)) * 2) = float2{t1, t2};
   // the residual gradient is fetched while the two wave halves meet in LDS

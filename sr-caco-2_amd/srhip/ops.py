@@ -165,7 +165,7 @@ class WeightSet:
 
 
 def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
-            rowscale=None, rows_per_scale=1, alpha=1.0, aux=None):
+            rowscale=None, rows_per_scale=1, alpha=1.0, aux=None, stats_out=None):
     """out[M,N] = epi(pro(A)[M,K] @ W[N,K]^T + bias).  W: f32 tensor (exact-f32
     MFMA) or Bx3 (3-way bf16 split MFMA)."""
     bx = isinstance(W, Bx3)
@@ -179,8 +179,9 @@ def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
             a_mode, _p(ln_stats), epi, _p(R), 0 if R is None else R.stride(0), _p(rowscale),
             rows_per_scale, float(alpha), _p(aux), 0 if aux is None else aux.stride(0), _st())
     if bx:
-        name, args = "srhip_gemm_nt_bx3", (_p(A), A.stride(0), _p(W.planes)) + tail
+        name, args = "srhip_gemm_nt_bx3", (_p(A), A.stride(0), _p(W.planes)) + tail[:-1] + (_p(stats_out), tail[-1])
     else:
+        assert stats_out is None, "row statistics are produced by the bx3 kernel only"
         name, args = "srhip_gemm_nt", (_p(A), A.stride(0), _p(W), W.stride(0)) + tail
     if probe.active == "gemm_nt":
         with probe.timed(("gemm_nt", M, N, K), 2.0 * M * N * K):

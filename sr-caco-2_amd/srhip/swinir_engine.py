@@ -14,6 +14,8 @@ Per Swin block: forward = 2 stats kernels + 4 GEMMs + 1 attention kernel;
 backward = 4 data-gradient GEMMs + 4 weight-gradient GEMMs (+ slice reducers)
 + 2 LayerNorm-backward kernels + 1 attention kernel.
 """
+import os
+
 import torch
 
 from . import ops
@@ -181,33 +183,43 @@ class SwinIREngine:
         sv = {"x": x, "f0": f0, "st_pe": st_pe, "blocks": [], "layers": [], "B": B, "H": H, "W": W,
               "dp": dp}
         bi = 0
+        # LayerNorm statistics can come out of the producing GEMM's epilogue (env SRHIP_FUSE_STATS)
+        fuse = ws.use_bx3 and os.environ.get("SRHIP_FUSE_STATS", "1") != "0"
         for li, layer in enumerate(net.layers):
             t_in = t
-            for blk in layer.residual_group.blocks:
+            nblk = len(layer.residual_group.blocks)
+            st1 = None                  # statistics of t, if the previous block's fc2 produced them
+            for j, blk in enumerate(layer.residual_group.blocks):
                 k = bi if save else 0
                 heads = blk.num_heads
                 s1 = None if dp is None else dp[2 * bi]
                 s2 = None if dp is None else dp[2 * bi + 1]
-                st1 = buf(f"{k}.st1", T, 2)
-                ops.layernorm_fwd(t, st1)
+                if st1 is None:
+                    st1 = buf(f"{k}.st1", T, 2)
+                    ops.layernorm_fwd(t, st1)
                 qkv = buf(f"{k}.qkv", T, 3 * C)
                 ops.gemm_nt(t, ws[f"{bi}.wq"], D.d[f"{bi}.bq"], out=qkv, a_mode=1, ln_stats=st1)
                 a = buf(f"{k}.a", T, C)
                 ops.window_attention_fwd(qkv, a, D.d[f"{bi}.biasT"], B, H, W, C, heads, blk.shift_size)
                 x1 = buf(f"{k}.x1", T, C)
-                ops.gemm_nt(a, ws[f"{bi}.wproj"], blk.attn.proj.bias.data, out=x1, epi=2, R=t,
-                            rowscale=s1, rows_per_scale=H * W)
                 st2 = buf(f"{k}.st2", T, 2)
-                ops.layernorm_fwd(x1, st2)
+                ops.gemm_nt(a, ws[f"{bi}.wproj"], blk.attn.proj.bias.data, out=x1, epi=2, R=t,
+                            rowscale=s1, rows_per_scale=H * W, stats_out=st2 if fuse else None)
+                if not fuse:
+                    ops.layernorm_fwd(x1, st2)
                 h = buf(f"{k}.h", T, hid)
                 ops.gemm_nt(x1, ws[f"{bi}.w1"], D.d[f"{bi}.b1"], out=h, a_mode=1, ln_stats=st2)
                 # block outputs ping-pong in eval, are kept per block in training
                 x2 = buf(f"{bi if save else bi % 2}.x2", T, C)
+                st_next = None
+                if fuse and j + 1 < nblk:
+                    st_next = buf(f"{(bi + 1) if save else (bi + 1) % 2}.st1", T, 2)
                 ops.gemm_nt(h, ws[f"{bi}.w2"], blk.mlp.fc2.bias.data, out=x2, a_mode=2, epi=2,
-                            R=x1, rowscale=s2, rows_per_scale=H * W)
+                            R=x1, rowscale=s2, rows_per_scale=H * W, stats_out=st_next)
                 if save:
                     sv["blocks"].append((t, st1, qkv, a, x1, st2, h))
                 t = x2
+                st1 = st_next
                 bi += 1
             tl = buf(f"L{li if save else li % 2}.out", T, C)
             ops.conv3x3(t.view(B, H, W, C), ws[f"l{li}.wp"], layer.conv.bias.data, C,

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert len(protos) >= 38
     for name in protos:
         assert hasattr(_lib.lib, name), name
-    assert _lib.lib.srhip_abi_version() >= 2
+    assert _lib.lib.srhip_abi_version() >= 3
     assert isinstance(_lib.lib.srhip_last_error(), bytes)
 
 

@@ -180,3 +180,20 @@ def test_gemm_lnbwd_fused(ops, M, N, K):
     out2 = torch.full((M, N), float("nan")).cuda()
     ops.gemm_nt_lnbwd(A.cuda(), ops.split_bf16x3(W.cuda()), x.cuda(), stats, None, out2)
     assert relerr(out2, xd.grad) < 5e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 180, 180), (700, 180, 360), (300, 64, 64), (555, 120, 60)])
+def test_gemm_row_stats(ops, M, N, K):
+    """stats_out of the GEMM epilogue == layernorm_fwd statistics of the GEMM output."""
+    A, W, b, R = rnd(M, K), rnd(N, K, scale=0.1), rnd(N), rnd(M, N) * 3 + 1
+    Wb = ops.split_bf16x3(W.cuda())
+    st = torch.full((M, 2), float("nan")).cuda()
+    out = ops.gemm_nt(A.cuda(), Wb, b.cuda(), epi=2, R=R.cuda(), alpha=0.7, stats_out=st)
+    ref = R.double() + 0.7 * F.linear(A.double(), W.double(), b.double())
+    assert relerr(out, ref) < 2e-6
+    mean = ref.mean(1)
+    rstd = 1.0 / torch.sqrt(ref.var(1, unbiased=False) + 1e-5)
+    assert relerr(st[:, 0], mean) < 5e-6 and relerr(st[:, 1], rstd) < 5e-6
+    st2 = torch.empty(M, 2).cuda()
+    ops.layernorm_fwd(out, st2)
+    assert (st - st2).abs().max().item() < 1e-5
