@@ -43,6 +43,21 @@ __device__ __forceinline__ float2 ldg_f2(const float* p) {
 }
 __device__ __forceinline__ f32x4 ldg_f4(const void* p) { return *(sr_gptr_f4)p; }
 
+// ---- 3-way bf16 split of f32 pairs (the operand form of the bf16x3 MFMA kernels) ----
+//   x = h + m + l, each part the bf16 rounding (RNE) of the remaining residual; the
+//   residuals are exact in f32.  Packed pairs: element 0 in the low half.  Written on
+//   2-vectors so that the subtractions compile to v_pk_add_f32.
+typedef __bf16 sr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned sr_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const sr_f32x2 x = {x0, x1};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, sr_bf16x2));
+  const sr_f32x2 r = x - __builtin_bit_cast(sr_f32x2, sr_u32x2{h << 16, h & 0xffff0000u});
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sr_bf16x2));
+  const sr_f32x2 s = r - __builtin_bit_cast(sr_f32x2, sr_u32x2{m << 16, m & 0xffff0000u});
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(s, sr_bf16x2));
+}
+
 // ---- wave-level reductions (wave = 64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

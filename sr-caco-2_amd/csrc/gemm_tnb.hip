@@ -42,14 +42,6 @@ constexpr int TKB = 16;   // tokens per chunk = one k step of the 32x32x16 MFMA
 
 __device__ const float k_tnb_zero_row[256] = {0.f};   // source row of tokens that contribute nothing
 
-__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-  m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
-  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
-}
-
 __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -197,34 +189,33 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
 #pragma unroll
   for (int j = 0; j < W; ++j) b_off[j] = unit_slot(BC + (wj * W + j) * 32 + r, h) * 16;
 
-  const int nch = (m_end - m_begin + TKB - 1) / TKB;
+  // chunk count rounded up to even: the producer loop below is straight-line code per
+  // pair of chunks (no conditional stage updates -- those made the compiler wait for
+  // loads still in flight).  Chunks past the slice end load the zero row.
+  const int nch = ((m_end - m_begin + 2 * TKB - 1) / (2 * TKB)) * 2;
   // both roles execute exactly nch + 1 barriers
   if (producer) {
     // two chunks in flight: chunk c+1 is split and stored from one register stage
     // while the loads of chunk c+3 fill it again (c+2 sits in the other stage), so a
     // load has two chunk periods to land
-    if (nch > 0) {
-      load(m_begin, sg0);
-      if (nch > 1) load(m_begin + TKB, sg1);
-      store(smem, sg0);
-      if (nch > 2) load(m_begin + 2 * TKB, sg0);
-    }
+    load(m_begin, sg0);
+    load(m_begin + TKB, sg1);
+    store(smem, sg0);
+    load(m_begin + 2 * TKB, sg0);
     __syncthreads();
     for (int c = 0; c < nch; c += 2) {
-      if (c + 1 < nch && !(p.dbg & 2)) store(smem + BUF, sg1);
-      if (c + 3 < nch && !(p.dbg & 1)) load(m_begin + (c + 3) * TKB, sg1);
+      store(smem + BUF, sg1);                 // chunk c+1
+      load(m_begin + (c + 3) * TKB, sg1);
       __syncthreads();
-      if (c + 1 < nch) {
-        if (c + 2 < nch && !(p.dbg & 2)) store(smem, sg0);
-        if (c + 4 < nch && !(p.dbg & 1)) load(m_begin + (c + 4) * TKB, sg0);
-        __syncthreads();
-      }
+      store(smem, sg0);                       // chunk c+2
+      load(m_begin + (c + 4) * TKB, sg0);
+      __syncthreads();
     }
   } else {
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
       const unsigned char* cur = smem + (c & 1) * BUF;
-      if (!(p.dbg & 4)) {
+      {
         u32x4 fa[W][3];
 #pragma unroll
         for (int i = 0; i < W; ++i)
@@ -340,7 +331,6 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
     if (b > w) w = b;
     const int rps = sr_cdiv(p.M, p.S);
     p.rows_per_slice = (rps + TKB - 1) / TKB * TKB;
-    { const char* e = getenv("SRHIP_TN_DBG"); p.dbg = e ? atoi(e) : 0; }
     g.tile_start[k] = tiles;
     tiles += sr_cdiv(p.NI, p.i_tile) * sr_cdiv(p.NJ, p.j_tile);
     g.p[k] = p;

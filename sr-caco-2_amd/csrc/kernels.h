@@ -43,7 +43,6 @@ struct TnArgs {
   int conv;                   // 0 | 1: B rows are tap-shifted pixels of a [batch][H][Wd] image
   int batch, H, Wd;
   int i_tile, j_tile, rows_per_slice;   // set by the dispatcher
-  int dbg;                              // ablation bits (env SRHIP_TN_DBG; 0 in production)
 };
 
 int sr_gemm_nt(NtArgs& p, hipStream_t st);

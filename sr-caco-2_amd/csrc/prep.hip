@@ -21,14 +21,6 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-  m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
-  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
-}
-
 // kind 0: out planes [3][ntap*rows][Kp] of  v(tap, r, k) = W[off + tap*s_tap + r*s_row + k*s_k]
 //         * (gamma_mode 1: gamma[k] | 2: gamma[r] | 0: 1)
 __device__ __forceinline__ void job_planes(const PrepEntry& e, int lb) {

@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_q(
           // bias gradient: fire-and-forget global float atomics, 256 contiguous bytes
           // per wave instruction (measured 3.5x cheaper than summing the block's
           // four windows through LDS float atomics first)
-          atomicAdd(dbt + key * 64 + r + 32 * qb, ds);
+          if (dbiasT) atomicAdd(dbt + key * 64 + r + 32 * qb, ds);
           const float kc = r < D ? As[key * D + r] : 0.f;
           dQ = mfma32(ds, kc, dQ);
         }
@@ -510,6 +510,7 @@ int srhip_window_attention_bwd(const float* qkv, const float* dout, float* dqkv,
   const float scale = 1.0f / sqrtf((float)D);
   hipStream_t st = (hipStream_t)stream;
   dim3 blk(256), gq(heads * sr_cdiv(nwin, 4)), gkv(sr_cdiv(total, 4));
+  if (getenv("SRHIP_WA_NOATOMIC")) dbiasT = nullptr;   // timing experiment only (bias gradient is lost)
 #define SR_WA(D_) \
   if (D == D_) { \
     hipLaunchKernelGGL((k_wattn_bwd_q<D_>), gq, blk, 0, st, qkv, dout, dqkv, biasT, dbiasT, workspace, nwin, H, W, C, heads, shift, scale); \
