@@ -25,6 +25,7 @@ class EDSREngine:
         self.bufs = _Bufs()
         self.derived = _Bufs()
         self.ws = ops.WeightSet()
+        self.ws.use_bx3 = ops.bx3_for(self.F)      # 64-feature EDSR stays on the exact-f32 MFMA kernels
         self._prep = self._prep_sig = None
         self.prepared = False
         self.saved = None

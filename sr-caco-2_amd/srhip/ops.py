@@ -43,8 +43,16 @@ def use_bx3():
     return os.environ.get("SRHIP_MM", "bx3") != "f32"
 
 
-def _tn_sfx():
-    return "_bx3" if use_bx3() else ""
+BX3_MIN_CHANNELS = 128   # below this the split / staging overhead outweighs the faster MFMA (EDSR's 64)
+
+
+def bx3_for(*channels):
+    """bf16x3 kernels for this problem?  (mode switch + smallest channel count involved)"""
+    return use_bx3() and min(channels) >= BX3_MIN_CHANNELS
+
+
+def _tn_sfx(bx=None):
+    return "_bx3" if (use_bx3() if bx is None else bx) else ""
 
 
 class Bx3:
@@ -218,10 +226,10 @@ def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0
     return out
 
 
-def tn_plan(M, NI, NJ, conv=False):
+def tn_plan(M, NI, NJ, conv=False, bx=None):
     S = ctypes.c_int(0)
     n = ctypes.c_long(0)
-    call("srhip_tn_plan" + _tn_sfx(), M, NI, NJ, int(conv), ctypes.addressof(S), ctypes.addressof(n))
+    call("srhip_tn_plan" + _tn_sfx(bx), M, NI, NJ, int(conv), ctypes.addressof(S), ctypes.addressof(n))
     return S.value, n.value
 
 
@@ -317,10 +325,11 @@ def conv3x3_wgrad(dY, X, dW, db):
     _chk(dY, X, dW, db)
     B, H, W, Cout = dY.shape
     Cin = X.shape[3]
-    S, n = tn_plan(B * H * W, Cout, Cin, True)
+    bx = bx3_for(Cout, Cin)
+    S, n = tn_plan(B * H * W, Cout, Cin, True, bx)
     part = SCRATCH.get("tn_part", n, device=dY.device)
     cs = SCRATCH.get("tn_colsum", S * Cout, device=dY.device)
-    call("srhip_conv3x3_wgrad" + _tn_sfx(), _p(dY), dY.stride(2), _p(X), X.stride(2), B, H, W, Cout, Cin,
+    call("srhip_conv3x3_wgrad" + _tn_sfx(bx), _p(dY), dY.stride(2), _p(X), X.stride(2), B, H, W, Cout, Cin,
          _p(part), _p(cs), S, _st())
     call("srhip_reduce_conv_wgrad", _p(part), _p(cs), S, _p(dW), _p(db), Cout, Cin, _st())
 
