@@ -154,6 +154,16 @@ int srhip_reduce_ln_linear_wgrad(const float* part, const float* colsum, int S, 
                                  float* dgamma, float* dbeta, int N, int K, int ln_grads_zeroed,
                                  void* stream);
 /* dW in torch layout [Cout][Cin][3][3]. */
+/* The slice reducers of up to four Linear problems (srhip_gemm_tn_grouped) in one launch.
+ * gamma == NULL: plain Linear (srhip_reduce_linear_wgrad); else the LayerNorm-folded form
+ * (srhip_reduce_ln_linear_wgrad; dgamma / dbeta are accumulated with atomics: zero them first). */
+typedef struct {
+  const float* part; const float* colsum;
+  const float* W; const float* gamma; const float* beta;
+  float* dW; float* db; float* dgamma; float* dbeta;
+  int N, K;
+} srhip_reduce_problem;
+int srhip_reduce_wgrad_grouped(const srhip_reduce_problem* probs, int nprob, int S, void* stream);
 int srhip_reduce_conv_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
                             int Co, int Ci, void* stream);
 

@@ -3,6 +3,7 @@
 // kernels, pixel-shuffle, losses, optimizers.  One wave = 64 lanes throughout.
 #include "common.h"
 #include "kernels.h"
+#include "../../include/srhip.h"
 
 namespace {
 
@@ -103,6 +104,72 @@ __global__ void __launch_bounds__(256) k_fin_ln_linear(
   if (rr == 0 && k < K) {
     atomicAdd(dgamma + k, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
     atomicAdd(dbeta + k, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+  }
+}
+// The slice reducers of up to four Linear weight gradients (one Swin block) in ONE
+// launch: k_fin_ln_linear's geometry per problem; gamma == null means a plain Linear
+// (dW = G, db = dbv, no LayerNorm gradients).
+struct ReduceGroup {
+  struct P {
+    const float* part; const float* colsum; const float* W; const float* gamma; const float* beta;
+    float* dW; float* db; float* dgamma; float* dbeta;
+    int N, K, blk0, kblocks;
+  } p[4];
+  int n, S;
+};
+__global__ void __launch_bounds__(256) k_reduce_group(ReduceGroup g) {
+  __shared__ float sd[4], sg[4][64], sb[4][64];
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.p[i].blk0) q = i;
+  // select with constant indices (a runtime-indexed struct array would go to scratch)
+  const ReduceGroup::P P = q == 0 ? g.p[0] : q == 1 ? g.p[1] : q == 2 ? g.p[2] : g.p[3];
+  const int S = g.S, N = P.N, K = P.K;
+  const int lb = blockIdx.x - P.blk0;
+  const int bx = lb % P.kblocks, by = lb / P.kblocks;
+  const int c = threadIdx.x & 63, rr = threadIdx.x >> 6;
+  const int k = bx * 64 + c;
+  const int n = by * 4 + rr;
+  if (c == 0) {   // one lane per row sums that row's bias-gradient slices
+    float d = 0.f;
+    if (n < N)
+      for (int s = 0; s < S; ++s) d += P.colsum[(long)s * N + n];
+    sd[rr] = d;
+    if (n < N && bx == 0) P.db[n] = d;
+  }
+  __syncthreads();
+  float ag = 0.f, ab = 0.f;
+  if (k < K && n < N) {
+    const long sl = (long)N * K;
+    const float* pp = P.part + (long)n * K + k;
+    float G = 0.f;
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pp[(s + u) * sl];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) G += v[u];
+    }
+    for (; s < S; ++s) G += pp[s * sl];
+    if (P.gamma) {
+      const float d = sd[rr];
+      const float w = P.W[(long)n * K + k];
+      P.dW[(long)n * K + k] = P.gamma[k] * G + P.beta[k] * d;
+      ag = w * G;
+      ab = w * d;
+    } else {
+      P.dW[(long)n * K + k] = G;
+    }
+  }
+  if (P.gamma) {          // block-uniform
+    sg[rr][c] = ag; sb[rr][c] = ab;
+    __syncthreads();
+    if (rr == 0 && k < K) {
+      atomicAdd(P.dgamma + k, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+      atomicAdd(P.dbeta + k, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+    }
   }
 }
 __global__ void k_reduce_colsum(const float* __restrict__ colsum, float* __restrict__ db,
@@ -243,11 +310,21 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dyp, c
       }
     }
   }
-  if (g) {
+  if (g) {      // the block's four waves meet in LDS, then one atomic per column and block
+    __shared__ float red[2][4][64 * LN_MAXV];
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = lane + 64 * i;
-      if (c < C) { atomicAdd(dgamma + c, ag[i]); atomicAdd(dbeta + c, ab[i]); }
+    for (int i = 0; i < LN_MAXV; ++i) { red[0][wv][lane + 64 * i] = ag[i]; red[1][wv][lane + 64 * i] = ab[i]; }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) {
+          atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+          atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        }
+      }
     }
   }
 }
@@ -420,6 +497,27 @@ int srhip_reduce_ln_linear_wgrad(const float* part, const float* colsum, int S, 
   return 0;
 }
 
+int srhip_reduce_wgrad_grouped(const srhip_reduce_problem* probs, int nprob, int S, void* stream) {
+  SR_REQUIRE(nprob >= 1 && nprob <= 4 && S > 0, "reduce_wgrad_grouped: 1..4 problems, S > 0");
+  ReduceGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = nprob; g.S = S;
+  int blocks = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const srhip_reduce_problem& q = probs[i];
+    SR_REQUIRE(q.part && q.colsum && q.dW && q.db && q.N > 0 && q.K > 0, "reduce_wgrad_grouped: problem %d incomplete", i);
+    SR_REQUIRE(!q.gamma || (q.W && q.beta && q.dgamma && q.dbeta), "reduce_wgrad_grouped: LayerNorm problem %d incomplete", i);
+    ReduceGroup::P& d = g.p[i];
+    d.part = q.part; d.colsum = q.colsum; d.W = q.W; d.gamma = q.gamma; d.beta = q.beta;
+    d.dW = q.dW; d.db = q.db; d.dgamma = q.dgamma; d.dbeta = q.dbeta; d.N = q.N; d.K = q.K;
+    d.blk0 = blocks; d.kblocks = sr_cdiv(q.K, 64);
+    blocks += d.kblocks * sr_cdiv(q.N, 4);
+  }
+  hipLaunchKernelGGL(k_reduce_group, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+  SR_LAUNCH_CHECK("reduce_wgrad_grouped");
+  return 0;
+}
+
 int srhip_reduce_conv_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
                             int Co, int Ci, void* stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -473,7 +571,7 @@ int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, con
   hipStream_t st = (hipStream_t)stream;
   int rpw = 1;
   if (gamma) {  // fewer, longer waves so the column atomics stay cheap
-    rpw = (int)((M + 2047) / 2048);
+    rpw = (int)((M + 8191) / 8192);      // 4 rows per wave at T = 32768: parallelism over atomics (reduced per block)
     hipMemsetAsync(dgamma, 0, sizeof(float) * C, st);
     hipMemsetAsync(dbeta, 0, sizeof(float) * C, st);
   }

@@ -279,6 +279,13 @@ class _TnProblem(ctypes.Structure):   # srhip_tn_problem (include/srhip.h)
                 ("part", ctypes.c_void_p), ("part_colsum", ctypes.c_void_p)]
 
 
+class _ReduceProblem(ctypes.Structure):   # srhip_reduce_problem (include/srhip.h)
+    _fields_ = [("part", ctypes.c_void_p), ("colsum", ctypes.c_void_p), ("W", ctypes.c_void_p),
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("dW", ctypes.c_void_p),
+                ("db", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
+                ("N", ctypes.c_int), ("K", ctypes.c_int)]
+
+
 def linear_wgrad_grouped(problems, ln_grads_zeroed=False):
     """Up to 4 Linear weight-gradient problems over the same rows in ONE launch.
     Each problem: dict(dY, X, dW, db, a_rowscale=None, a_rowscale_rows=1, b_mode=0,
@@ -310,14 +317,17 @@ def linear_wgrad_grouped(problems, ln_grads_zeroed=False):
         a.b_mode, a.ln_stats = q.get("b_mode", 0), _p(q.get("ln_stats"))
         a.part, a.part_colsum = _p(pk), _p(ck)
     call("srhip_gemm_tn_grouped" + _tn_sfx(), ctypes.addressof(arr), n, M, S, _st())
-    for q, (pk, ck) in zip(problems, views):
-        N, K = q["dY"].shape[1], q["X"].shape[1]
-        if q.get("ln") is None:
-            call("srhip_reduce_linear_wgrad", _p(pk), _p(ck), S, _p(q["dW"]), _p(q["db"]), N, K, _st())
-        else:
+    red = (_ReduceProblem * n)()
+    for r, q, (pk, ck) in zip(red, problems, views):
+        r.part, r.colsum, r.dW, r.db = _p(pk), _p(ck), _p(q["dW"]), _p(q["db"])
+        r.N, r.K = q["dY"].shape[1], q["X"].shape[1]
+        if q.get("ln") is not None:
             W, gamma, beta, dgamma, dbeta = q["ln"]
-            call("srhip_reduce_ln_linear_wgrad", _p(pk), _p(ck), S, _p(W), _p(gamma), _p(beta),
-                 _p(q["dW"]), _p(q["db"]), _p(dgamma), _p(dbeta), N, K, int(ln_grads_zeroed), _st())
+            if not ln_grads_zeroed:      # accumulated with atomics
+                dgamma.zero_()
+                dbeta.zero_()
+            r.W, r.gamma, r.beta, r.dgamma, r.dbeta = _p(W), _p(gamma), _p(beta), _p(dgamma), _p(dbeta)
+    call("srhip_reduce_wgrad_grouped", ctypes.addressof(red), n, S, _st())
 
 
 def conv3x3_wgrad(dY, X, dW, db):
