@@ -187,7 +187,15 @@ int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, con
                         void* stream);
 
 /* ---- window attention (network_swinir.py:48-80,140-179,297-331) -------------- */
-/* table (225,heads) -> biasT[h][key][query], biasN[h][query][key]. */
+/* table (225,heads) -> two bias images of heads*4096 floats each, stored in the order
+ * the attention kernels read them as 32x32 MFMA accumulator tiles:
+ * img[h][a][b][lane][q], row = (q&3) + 8*(q>>2) + 4*(lane>>5), col = lane&31;
+ *   biasT (fwd, bwd query pass): bias[query = col+32b][key = row+32a]
+ *   biasN (bwd key pass)       : bias[query = row+32a][key = col+32b]
+ * The bias-gradient image (dbiasT of srhip_window_attention_bwd, input of
+ * srhip_bias_grad) is biasT's tile set stored [h][a][b][q][lane] (atomics want
+ * consecutive lanes on consecutive addresses).  Opaque to callers: produce with this
+ * function (or a kind-2 job of srhip_prep_table), hand to the attention calls. */
 int srhip_bias_expand(const float* table, float* biasT, float* biasN, int heads, void* stream);
 int srhip_bias_grad(const float* dbiasT, float* dtable, int heads, void* stream);
 /* qkv [B*H*W][3C] in token order -> out [B*H*W][C]; 8x8 windows, shift 0 or 4;

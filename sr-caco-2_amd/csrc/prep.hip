@@ -62,15 +62,16 @@ __device__ __forceinline__ void job_fold_bias(const PrepEntry& e, int lb) {
   if (lane == 0) ((float*)e.out)[n] = (e.b ? ldg_f(e.b + n) : 0.f) + a;
 }
 
-// kind 2: dense relative-position bias images of one block (see k_bias_expand, wattn.hip)
+// kind 2: lane-ordered relative-position bias images of one block (k_bias_expand / wa_img_index, wattn.hip)
 __device__ __forceinline__ void job_bias_expand(const PrepEntry& e, int lb) {
   const int i = lb * 256 + threadIdx.x, heads = e.n0;
   if (i >= heads * 4096) return;
-  const int hd = i / 4096, a = (i >> 6) & 63, b = i & 63;
-  const int idxN = ((a >> 3) - (b >> 3) + 7) * 15 + ((a & 7) - (b & 7) + 7);
-  ((float*)e.out2)[i] = ldg_f(e.a + idxN * heads + hd);
-  const int idxT = ((b >> 3) - (a >> 3) + 7) * 15 + ((b & 7) - (a & 7) + 7);
-  ((float*)e.out)[i] = ldg_f(e.a + idxT * heads + hd);
+  const int hd = i / 4096, el = i & 4095;
+  const int q = el & 15, lane = (el >> 4) & 63, b = (el >> 10) & 1, a = el >> 11;
+  const int row = mfma_row(q, lane), col = lane & 31;
+  auto rpi = [](int query, int key) { return ((query >> 3) - (key >> 3) + 7) * 15 + ((query & 7) - (key & 7) + 7); };
+  ((float*)e.out)[i] = ldg_f(e.a + rpi(col + 32 * b, row + 32 * a) * heads + hd);    // imgT
+  ((float*)e.out2)[i] = ldg_f(e.a + rpi(row + 32 * a, col + 32 * b) * heads + hd);   // imgN
 }
 
 __global__ void __launch_bounds__(256) k_prep_table(const PrepEntry* __restrict__ tab, int n) {

@@ -44,46 +44,51 @@ __device__ __forceinline__ int wa_token(const WaGeom& g, int pos, int H, int W, 
   return (g.b * H + y) * W + x;
 }
 
-// Coalesced staging of one [64 tokens][D] matrix (q, k, v or dO of one head)
-// into this wave's LDS region: consecutive lanes take consecutive float2 of a
-// token row, so an instruction touches ~5 cache lines instead of 64.
-template <int D>
-__device__ __forceinline__ void wa_stage(float* __restrict__ lds, const float* __restrict__ gsrc,
-                                         long row_pitch, int mytok, int lane) {
-  constexpr int F2 = D / 2;
-#pragma unroll
-  for (int i = 0; i < F2; ++i) {
-    const int idx = i * 64 + lane;
-    const int tok = idx / F2, c2 = idx - tok * F2;
-    const int t = __shfl(mytok, tok, 64);
-    const float2 v = *(const float2*)(gsrc + (long)t * row_pitch + 2 * c2);
-    *(float2*)(lds + tok * D + 2 * c2) = v;
-  }
-}
-
-// Two-phase form: issue the global loads early (registers), write LDS later, so
-// the memory latency hides behind the MFMA loop in between.
+// Staging of one [64 tokens][D] matrix (q, k, v or dO of one head) into this wave's
+// LDS region: lane = token.  A lane reads its own row (D floats, 8-byte aligned, 94 %
+// of a 128-byte line for D = 30) with float2 loads at immediate offsets and writes LDS
+// row `lane` -- no per-load address arithmetic and no cross-lane token shuffles (the
+// earlier coalesced mapping spent a third of the kernel's vector instructions on
+// them), and the 30-dword row stride makes the ds_write_b64 conflict free.
 template <int D>
 __device__ __forceinline__ void wa_stage_load(float2 (&regs)[D / 2], const float* __restrict__ gsrc,
                                               long row_pitch, int mytok, int lane) {
-  constexpr int F2 = D / 2;
+  const float* rowp = gsrc + (long)mytok * row_pitch;
 #pragma unroll
-  for (int i = 0; i < F2; ++i) {
-    const int idx = i * 64 + lane;
-    const int tok = idx / F2, c2 = idx - tok * F2;
-    const int t = __shfl(mytok, tok, 64);
-    regs[i] = *(const float2*)(gsrc + (long)t * row_pitch + 2 * c2);
-  }
+  for (int i = 0; i < D / 2; ++i) regs[i] = ldg_f2(rowp + 2 * i);
 }
 template <int D>
 __device__ __forceinline__ void wa_stage_store(float* __restrict__ lds, const float2 (&regs)[D / 2], int lane) {
-  constexpr int F2 = D / 2;
 #pragma unroll
-  for (int i = 0; i < F2; ++i) {
-    const int idx = i * 64 + lane;
-    const int tok = idx / F2, c2 = idx - tok * F2;
-    *(float2*)(lds + tok * D + 2 * c2) = regs[i];
-  }
+  for (int i = 0; i < D / 2; ++i) *(float2*)(lds + lane * D + 2 * i) = regs[i];
+}
+template <int D>
+__device__ __forceinline__ void wa_stage(float* __restrict__ lds, const float* __restrict__ gsrc,
+                                         long row_pitch, int mytok, int lane) {
+  float2 regs[D / 2];
+  wa_stage_load<D>(regs, gsrc, row_pitch, mytok, lane);
+  wa_stage_store<D>(lds, regs, lane);
+}
+
+// Relative-position bias images in LANE ORDER.  The dense images are only ever read
+// as MFMA accumulator tiles: lane l of tile (a, b) needs the 16 values of its
+// accumulator registers.  Stored as img[head][a][b][lane][16] they are four
+// global_load_dwordx4 per tile at immediate offsets instead of sixteen scattered dwords.
+//   imgT (fwd, bwd_q; tile (kb, qb)): value of key = mfma_row(q,l) + 32*kb, query = (l&31) + 32*qb
+//   imgN (bwd_kv;     tile (qb, kb)): value of query = mfma_row(q,l) + 32*qb, key = (l&31) + 32*kb
+// both = table[rpi(query, key)][head], rpi(q,k) = (qy-ky+7)*15 + (qx-kx+7)
+// (network_swinir.py:116-128,156-162).
+__device__ __forceinline__ int wa_img_index(int a, int b, int lane, int q) {
+  return (((a * 2 + b) * 64 + lane) * 16) + q;
+}
+// the bias-GRADIENT image is accumulated with float atomics: register-major order
+// [a][b][q][lane], so that one wave instruction adds to 256 contiguous bytes (lane-major
+// would touch 64 cache lines per instruction: measured 8x slower)
+__device__ __forceinline__ int wa_dimg_index(int a, int b, int lane, int q) {
+  return (((a * 2 + b) * 16 + q) * 64) + lane;
+}
+__device__ __forceinline__ int wa_rpi(int query, int key) {
+  return ((query >> 3) - (key >> 3) + 7) * 15 + ((query & 7) - (key & 7) + 7);
 }
 
 template <int D>
@@ -151,8 +156,7 @@ __global__ void __launch_bounds__(256) k_wattn_fwd(const float* __restrict__ qkv
       const float tile_mask = (g.last_row && kb != qb) ? -100.f : 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int key = mfma_row(q, lane) + 32 * kb;
-        float s = T[kb][qb][q] * scale + bt[key * 64 + r + 32 * qb];
+        float s = T[kb][qb][q] * scale + bt[wa_img_index(kb, qb, lane, q)];
         s += tile_mask; s += lane_mask;
         T[kb][qb][q] = s;
         mx = fmaxf(mx, s);
@@ -262,8 +266,7 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_q(
         const float tile_mask = (g.last_row && kb != qb) ? -100.f : 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int key = mfma_row(q, lane) + 32 * kb;
-          float s = T[kb][qb][q] * scale + bt[key * 64 + r + 32 * qb];
+          float s = T[kb][qb][q] * scale + bt[wa_img_index(kb, qb, lane, q)];
           s += tile_mask; s += lane_mask;
           T[kb][qb][q] = s;
           mx = fmaxf(mx, s);
@@ -307,7 +310,7 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_q(
           // bias gradient: fire-and-forget global float atomics, 256 contiguous bytes
           // per wave instruction (measured 3.5x cheaper than summing the block's
           // four windows through LDS float atomics first)
-          if (dbiasT) atomicAdd(dbt + key * 64 + r + 32 * qb, ds);
+          if (dbiasT) atomicAdd(dbt + wa_dimg_index(kb, qb, lane, q), ds);
           const float kc = r < D ? As[key * D + r] : 0.f;
           dQ = mfma32(ds, kc, dQ);
         }
@@ -392,7 +395,7 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_kv(
       for (int q = 0; q < 16; ++q) {
         const int qry = mfma_row(q, lane) + 32 * qb;     // window position of the query
         const float mx = st[qry], inv = st[64 + qry], dl = st[128 + qry];
-        float s = S[qb][kb][q] * scale + bn[qry * 64 + r + 32 * kb];
+        float s = S[qb][kb][q] * scale + bn[wa_img_index(qb, kb, lane, q)];
         s += tile_mask; s += lane_mask;                  // lane_mask is symmetric in (query,key)
         const float pv = __expf(s - mx) * inv;
         const float ds = pv * (G[qb][kb][q] - dl);
@@ -413,23 +416,21 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_kv(
   }
 }
 
-// dense bias images from the (225, heads) table:
-//   biasT[h][key][query] = biasN[h][query][key] = table[rpi(query,key)][h]
-//   rpi(q,k) = (qy-ky+7)*15 + (qx-kx+7)      (network_swinir.py:116-128,156-162)
+// lane-ordered bias images from the (225, heads) table (see wa_img_index)
 __global__ void k_bias_expand(const float* __restrict__ table, float* __restrict__ biasT,
                               float* __restrict__ biasN, int heads) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= heads * 4096) return;
-  const int hd = i / 4096, a = (i >> 6) & 63, b = i & 63;   // element [hd][a][b]
-  // biasN: a = query, b = key
-  const int idxN = ((a >> 3) - (b >> 3) + 7) * 15 + ((a & 7) - (b & 7) + 7);
-  biasN[i] = table[idxN * heads + hd];
-  // biasT: a = key, b = query
-  const int idxT = ((b >> 3) - (a >> 3) + 7) * 15 + ((b & 7) - (a & 7) + 7);
-  biasT[i] = table[idxT * heads + hd];
+  const int hd = i / 4096, e = i & 4095;
+  const int q = e & 15, lane = (e >> 4) & 63, b = (e >> 10) & 1, a = e >> 11;
+  const int row = mfma_row(q, lane), col = lane & 31;
+  // imgT: tile (kb = a, qb = b): key = row + 32a, query = col + 32b
+  biasT[i] = table[wa_rpi(col + 32 * b, row + 32 * a) * heads + hd];
+  // imgN: tile (qb = a, kb = b): query = row + 32a, key = col + 32b
+  biasN[i] = table[wa_rpi(row + 32 * a, col + 32 * b) * heads + hd];
 }
-// dtable[idx][h] = sum over (query,key) with rpi == idx of dbiasT[h][key][query];
-// one wave per table entry, one lane per key position
+// dtable[idx][h] = sum over (query,key) with rpi == idx of the bias-gradient image
+// (wa_dimg_index order); one wave per table entry, one lane per key position
 __global__ void k_bias_grad(const float* __restrict__ dbiasT, float* __restrict__ dtable, int heads) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -439,7 +440,12 @@ __global__ void k_bias_grad(const float* __restrict__ dbiasT, float* __restrict_
   const int ky = lane >> 3, kx = lane & 7;
   const int qy = ky + dy, qx = kx + dx;
   float a = 0.f;
-  if (qy >= 0 && qy < 8 && qx >= 0 && qx < 8) a = dbiasT[(long)hd * 4096 + lane * 64 + qy * 8 + qx];
+  if (qy >= 0 && qy < 8 && qx >= 0 && qx < 8) {
+    const int key = lane, query = qy * 8 + qx;
+    const int kb = key >> 5, rowin = key & 31, qb = query >> 5;
+    const int h = (rowin >> 2) & 1, q = (rowin & 3) + 4 * (rowin >> 3);     // mfma_row(q, 32h + c) == rowin
+    a = dbiasT[(long)hd * 4096 + wa_dimg_index(kb, qb, (query & 31) + 32 * h, q)];
+  }
   a = wave_sum(a);
   if (lane == 0) dtable[i] = a;
 }

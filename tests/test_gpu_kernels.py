@@ -259,8 +259,20 @@ def test_window_attention(ops, B, H, W, C, heads, shift):
     ops.bias_expand(dev(table), biasT, biasN)
     rpi = O.relative_position_index(8)
     dense = table[rpi.reshape(-1)].reshape(64, 64, heads).permute(2, 0, 1)
-    assert torch.equal(biasN.cpu(), dense.contiguous())
-    assert torch.equal(biasT.cpu(), dense.transpose(1, 2).contiguous())
+    # the images are stored in MFMA-lane order [head][a][b][lane][16] (wattn.hip: wa_img_index):
+    #   row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), col = lane & 31
+    #   imgT tile (kb=a, qb=b): bias[query = col + 32 b][key = row + 32 a]
+    #   imgN tile (qb=a, kb=b): bias[query = row + 32 a][key = col + 32 b]
+    q = torch.arange(16).view(1, 1, 1, 16)
+    lane = torch.arange(64).view(1, 1, 64, 1)
+    a = torch.arange(2).view(2, 1, 1, 1)
+    b = torch.arange(2).view(1, 2, 1, 1)
+    row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)
+    col = lane & 31
+    expT = dense[:, (col + 32 * b).expand(2, 2, 64, 16), (row + 32 * a).expand(2, 2, 64, 16)]
+    expN = dense[:, (row + 32 * a).expand(2, 2, 64, 16), (col + 32 * b).expand(2, 2, 64, 16)]
+    assert torch.equal(biasT.cpu().reshape(heads, 2, 2, 64, 16), expT)
+    assert torch.equal(biasN.cpu().reshape(heads, 2, 2, 64, 16), expN)
     out = torch.empty(T, C).cuda()
     ops.window_attention_fwd(dev(qkv), out, biasT, B, H, W, C, heads, shift)
     qr, tr = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
