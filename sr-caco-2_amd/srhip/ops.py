@@ -205,8 +205,13 @@ def gemm_nt_lnbwd(A, W, x, stats, res, out):
     _chk(A, x, stats, res, out)
     M, K = A.shape
     assert W.K == K and x.shape == (M, W.rows) and out.shape == (M, W.rows)
-    call("srhip_gemm_nt_bx3_lnbwd", _p(A), A.stride(0), _p(W.planes), _p(out), out.stride(0), M, W.rows, K,
-         _p(x), x.stride(0), _p(stats), _p(res), 0 if res is None else res.stride(0), _st())
+    args = (_p(A), A.stride(0), _p(W.planes), _p(out), out.stride(0), M, W.rows, K,
+            _p(x), x.stride(0), _p(stats), _p(res), 0 if res is None else res.stride(0), _st())
+    if probe.active == "gemm_nt":      # same kernel as gemm_nt: belongs to the same roofline entry
+        with probe.timed(("gemm_nt", M, W.rows, K), 2.0 * M * W.rows * K):
+            call("srhip_gemm_nt_bx3_lnbwd", *args)
+    else:
+        call("srhip_gemm_nt_bx3_lnbwd", *args)
     return out
 
 
