@@ -13,8 +13,11 @@
 //
 // Same two problem shapes and the same prologues / epilogues as gemm_nt.hip
 // (Linear fwd / bwd-data, 3x3 conv as implicit GEMM over an NHWC halo tile).
-// W arrives PRE-SPLIT (k_split3: planes [3][rows][Kp] bf16, Kp = K rounded up
-// to 32 and zero filled) because it is reused by every block; the activation
+// W arrives PRE-SPLIT because it is reused by every block: three bf16 planes in
+// CHUNK-MAJOR order [3][Kp/32][rows][32] (Kp = K rounded up to 32, zero filled;
+// rows = N, or 9*Cout tap-major for the conv), so the 64*WN rows x 64 B a block
+// stages per plane and chunk are one contiguous run (every wave-level load
+// instruction reads 1 KB of consecutive bytes instead of sixteen 64-byte pieces); the activation
 // operand is split while it is staged into LDS (once per chunk; for the conv
 // once per 9 taps).
 //
@@ -104,13 +107,14 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     }
     rst[it] = ldg_f2(sp);
   }
-  const long plane_bytes = (long)(CONV ? 9 : 1) * p.N * p.Kp * 2;   // one bf16 plane of W
+  const long wrows = (long)(CONV ? 9 : 1) * p.N;                    // rows of the weight matrix
+  const long plane_bytes = wrows * p.Kp * 2;                        // one bf16 plane of W
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
     const int idx = min(tid + it * 256, B_N - 1);
     const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
     const int row = rem >> 2, q = rem & 3;
-    offB[it] = (unsigned)(pl * plane_bytes + ((long)(n0 + min(row, nvalid - 1)) * p.Kp) * 2 + q * 16);
+    offB[it] = (unsigned)(pl * plane_bytes + (long)(n0 + min(row, nvalid - 1)) * 64 + q * 16);
   }
 
   // Loaded values are not touched here (a select on a fresh load would force an
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     }
   };
   auto load_b = [&](int kc, int tap) {
-    const char* base = (const char*)p.Wb + ((long)tap * p.N * p.Kp + kc * BKB) * 2;
+    const char* base = (const char*)p.Wb + ((long)kc * wrows + (long)tap * p.N) * 64;   // chunk kc, row tap*N
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) rb[it] = *(const u32x4*)(base + offB[it]);
   };
@@ -309,7 +313,7 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
   return sr_fail(-22, "ntb: no kernel for wm=%d wn=%d", wm, wn);
 }
 
-// W[rows][ldw] f32 -> out[3][rows][Kp] bf16 (Kp = K rounded up to 32, zero filled)
+// W[rows][ldw] f32 -> out[3][Kp/32][rows][32] bf16 (Kp = K rounded up to 32, zero filled)
 __device__ __forceinline__ void split3_slot(const float* __restrict__ W, long ldw, int rows, int K, int Kp,
                                             unsigned short* __restrict__ out, long i) {
   const int kq = Kp >> 2;                                       // one float4 (4 k) per thread
@@ -321,7 +325,7 @@ __device__ __forceinline__ void split3_slot(const float* __restrict__ W, long ld
   split3_pair(v.x, v.y, h0, m0, l0);
   split3_pair(v.z, v.w, h1, m1, l1);
   const long plane = (long)rows * Kp;
-  unsigned short* d = out + (long)row * Kp + k;
+  unsigned short* d = out + ((long)(k >> 5) * rows + row) * 32 + (k & 31);      // chunk-major
   *(u32x2*)(d) = u32x2{h0, h1};
   *(u32x2*)(d + plane) = u32x2{m0, m1};
   *(u32x2*)(d + 2 * plane) = u32x2{l0, l1};
