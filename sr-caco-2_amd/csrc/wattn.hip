@@ -190,24 +190,51 @@ __global__ void __launch_bounds__(256) k_wattn_fwd(const float* __restrict__ qkv
 }
 
 // ---------------------------------------------------------------------------
-// Backward as TWO kernels of <= 256 registers (2 waves per SIMD, inputs staged
-// coalesced through LDS), instead of the single 512-register kernel above:
-//   bwd_q : query on the lane  -> softmax stats (to a workspace), dQ, d(bias)
-//   bwd_kv: key on the lane    -> dK, dV (reads the stats)
-// The bias-gradient tile leaves bwd_q as global float atomics.
+// Backward as two kernels, each wave owning HALF a (window, head):
+//   bwd_q : (window, head, query block qb) -> softmax stats (to a workspace), dQ of
+//           its 32 queries, d(bias) tiles (kb, qb) as global float atomics
+//   bwd_kv: (window, head, key block kb)   -> dK, dV of its 32 keys (reads the stats)
+// A wave needs one full and one half [tokens][D] matrix in LDS at a time (11.5 KB)
+// and 2 x 2 accumulator tiles less than a whole-window wave: 12 waves per CU instead
+// of 8, and the 6144 waves of the README shape fill the chip in two even rounds
+// (whole-window waves were 3 per SIMD with 2 resident: the second round ran half
+// empty, and SQ counters showed 57 % of the wave cycles stalled on issue).
 // ---------------------------------------------------------------------------
+// half matrix: rows 32*blk .. 32*blk+31 of a head matrix; lane (r, h) moves float2
+// 8h .. 8h+7 of row r
 template <int D>
-__global__ void __launch_bounds__(256, 2) k_wattn_bwd_q(
+__device__ __forceinline__ void wa_stage_half_load(float2 (&regs)[8], const float* __restrict__ gsrc,
+                                                   long row_pitch, int tok, int h) {
+  const float* rowp = gsrc + (long)tok * row_pitch;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int f = min(h * 8 + i, D / 2 - 1);           // D/2 <= 16 float2 per row
+    regs[i] = ldg_f2(rowp + 2 * f);
+  }
+}
+template <int D>
+__device__ __forceinline__ void wa_stage_half_store(float* __restrict__ lds, const float2 (&regs)[8], int r, int h) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int f = h * 8 + i;
+    if (f < D / 2) *(float2*)(lds + r * D + 2 * f) = regs[i];
+  }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256, 3) k_wattn_bwd_q(
     const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
     const float* __restrict__ biasT, float* __restrict__ dbiasT, float* __restrict__ stats, int nwin,
     int H, int W, int C, int heads, int shift, float scale) {
   constexpr int HD = D / 2;
-  __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 64 * D];
+  static_assert(D <= 32, "head dim");
+  __shared__ __attribute__((aligned(16))) float smem[4 * (64 + 32) * D];
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-  float* As = smem + wv * (2 * 64 * D);
-  float* Bs = As + 64 * D;
+  float* As = smem + wv * ((64 + 32) * D);     // full matrix: K, V, K again
+  float* Bs = As + 64 * D;                     // half matrix: Q, dO rows of this query block
   const int head = blockIdx.x % heads;
-  const int widx = (blockIdx.x / heads) * 4 + wv;
+  const int item = (blockIdx.x / heads) * 4 + wv;
+  const int widx = item >> 1, qb = item & 1;
   if (widx < nwin) {
     const int nWx = W / 8, nWy = H / 8;
     WaGeom g;
@@ -218,200 +245,200 @@ __global__ void __launch_bounds__(256, 2) k_wattn_bwd_q(
     g.last_row = shift > 0 && g.wy == nWy - 1;
     g.last_col = shift > 0 && g.wx == nWx - 1;
     const int C3 = 3 * C;
-    const int mytok = wa_token(g, lane, H, W, shift);
+    const int mytok = wa_token(g, lane, H, W, shift);           // token of key / staging row `lane`
+    const int qtok = wa_token(g, r + 32 * qb, H, W, shift);     // token of this lane's query
     const float lane_mask = (g.last_col && h != ((lane >> 2) & 1)) ? -100.f : 0.f;
     const int fo0 = r * D + h * HD, fo1 = (r + 32) * D + h * HD;
-    f32x16 T[2][2], G[2][2];
+    f32x16 T[2], G[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { T[a][b][q] = 0.f; G[a][b][q] = 0.f; }
+      for (int q = 0; q < 16; ++q) { T[a][q] = 0.f; G[a][q] = 0.f; }
     // S^T = K.Q^T  (V and dO are fetched into registers meanwhile)
-    float2 ra[D / 2], rb[D / 2];
+    float2 ra[D / 2], rb[8];
     wa_stage<D>(As, qkv + C + head * D, C3, mytok, lane);
-    wa_stage<D>(Bs, qkv + head * D, C3, mytok, lane);
+    wa_stage_half_load<D>(rb, qkv + head * D, C3, qtok, h);
+    wa_stage_half_store<D>(Bs, rb, r, h);
     __builtin_amdgcn_wave_barrier();
     wa_stage_load<D>(ra, qkv + 2 * C + head * D, C3, mytok, lane);
-    wa_stage_load<D>(rb, dout + head * D, C, mytok, lane);
+    wa_stage_half_load<D>(rb, dout + head * D, C, qtok, h);
 #pragma unroll 3
     for (int t = 0; t < HD; ++t) {
-      const float k0 = As[fo0 + t], k1 = As[fo1 + t], q0 = Bs[fo0 + t], q1 = Bs[fo1 + t];
-      T[0][0] = mfma32(k0, q0, T[0][0]); T[0][1] = mfma32(k0, q1, T[0][1]);
-      T[1][0] = mfma32(k1, q0, T[1][0]); T[1][1] = mfma32(k1, q1, T[1][1]);
+      const float k0 = As[fo0 + t], k1 = As[fo1 + t], q0 = Bs[fo0 + t];
+      T[0] = mfma32(k0, q0, T[0]);
+      T[1] = mfma32(k1, q0, T[1]);
     }
     // dP^T = V.dO^T  (K is fetched again meanwhile: column pattern for dQ)
     __builtin_amdgcn_wave_barrier();
     wa_stage_store<D>(As, ra, lane);
-    wa_stage_store<D>(Bs, rb, lane);
+    wa_stage_half_store<D>(Bs, rb, r, h);
     __builtin_amdgcn_wave_barrier();
     wa_stage_load<D>(ra, qkv + C + head * D, C3, mytok, lane);
 #pragma unroll 3
     for (int t = 0; t < HD; ++t) {
-      const float v0 = As[fo0 + t], v1 = As[fo1 + t], g0 = Bs[fo0 + t], g1 = Bs[fo1 + t];
-      G[0][0] = mfma32(v0, g0, G[0][0]); G[0][1] = mfma32(v0, g1, G[0][1]);
-      G[1][0] = mfma32(v1, g0, G[1][0]); G[1][1] = mfma32(v1, g1, G[1][1]);
+      const float v0 = As[fo0 + t], v1 = As[fo1 + t], g0 = Bs[fo0 + t];
+      G[0] = mfma32(v0, g0, G[0]);
+      G[1] = mfma32(v1, g0, G[1]);
     }
     __builtin_amdgcn_wave_barrier();
     wa_stage_store<D>(As, ra, lane);
     __builtin_amdgcn_wave_barrier();
     const float* bt = biasT + (long)head * 4096;
     float* dbt = dbiasT + (long)head * 4096;
+    float mx = -3.0e38f;
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      float mx = -3.0e38f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const float tile_mask = (g.last_row && kb != qb) ? -100.f : 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          float s = T[kb][qb][q] * scale + bt[wa_img_index(kb, qb, lane, q)];
-          s += tile_mask; s += lane_mask;
-          T[kb][qb][q] = s;
-          mx = fmaxf(mx, s);
-        }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float e = __expf(T[kb][qb][q] - mx);
-          T[kb][qb][q] = e;
-          sum += e;
-        }
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.f / sum;
-      float dl = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          T[kb][qb][q] *= inv;                     // P^T
-          dl += T[kb][qb][q] * G[kb][qb][q];
-        }
-      dl += __shfl_xor(dl, 32, 64);
-      const int qtok = __shfl(mytok, r + 32 * qb, 64);
-      if (h == 0) {                                // softmax statistics of query r+32*qb
-        float* sp = stats + ((long)qtok * heads + head) * 3;
-        sp[0] = mx; sp[1] = inv; sp[2] = dl;
-      }
-      f32x16 dQ;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) dQ[q] = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int key = mfma_row(q, lane) + 32 * kb;
-          const float ds = T[kb][qb][q] * (G[kb][qb][q] - dl);
-          // bias gradient: fire-and-forget global float atomics, 256 contiguous bytes
-          // per wave instruction (measured 3.5x cheaper than summing the block's
-          // four windows through LDS float atomics first)
-          if (dbiasT) atomicAdd(dbt + wa_dimg_index(kb, qb, lane, q), ds);
-          const float kc = r < D ? As[key * D + r] : 0.f;
-          dQ = mfma32(ds, kc, dQ);
-        }
+    for (int kb = 0; kb < 2; ++kb) {
+      const float tile_mask = (g.last_row && kb != qb) ? -100.f : 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int tok = __shfl(mytok, mfma_row(q, lane) + 32 * qb, 64);
-        if (r < D) dqkv[(long)tok * C3 + head * D + r] = dQ[q] * scale;
+        float s = T[kb][q] * scale + bt[wa_img_index(kb, qb, lane, q)];
+        s += tile_mask; s += lane_mask;
+        T[kb][q] = s;
+        mx = fmaxf(mx, s);
       }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float e = __expf(T[kb][q] - mx);
+        T[kb][q] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    float dl = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        T[kb][q] *= inv;                     // P^T
+        dl += T[kb][q] * G[kb][q];
+      }
+    dl += __shfl_xor(dl, 32, 64);
+    if (h == 0) {                            // softmax statistics of query r + 32*qb
+      float* sp = stats + ((long)qtok * heads + head) * 3;
+      sp[0] = mx; sp[1] = inv; sp[2] = dl;
+    }
+    f32x16 dQ;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dQ[q] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int key = mfma_row(q, lane) + 32 * kb;
+        const float ds = T[kb][q] * (G[kb][q] - dl);
+        // bias gradient: fire-and-forget global float atomics, 256 contiguous bytes per
+        // wave instruction
+        if (dbiasT) atomicAdd(dbt + wa_dimg_index(kb, qb, lane, q), ds);
+        const float kc = r < D ? As[key * D + r] : 0.f;
+        dQ = mfma32(ds, kc, dQ);
+      }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int tok = wa_token(g, mfma_row(q, lane) + 32 * qb, H, W, shift);
+      if (r < D) dqkv[(long)tok * C3 + head * D + r] = dQ[q] * scale;
     }
   }
 }
 
 template <int D>
-__global__ void __launch_bounds__(256, 2) k_wattn_bwd_kv(
+__global__ void __launch_bounds__(256, 3) k_wattn_bwd_kv(
     const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
     const float* __restrict__ biasN, const float* __restrict__ stats, long total, int H, int W, int C,
     int heads, int shift, float scale) {
   constexpr int HD = D / 2;
-  __shared__ __attribute__((aligned(16))) float smem[4 * (2 * 64 * D + 192)];
+  __shared__ __attribute__((aligned(16))) float smem[4 * ((64 + 32) * D + 192)];
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-  const long gid = blockIdx.x * 4L + wv;
-  if (gid >= total) return;               // no block-level barrier below
-  const WaGeom g = wa_decode(gid, heads, W / 8, H / 8, shift);
+  const long item = blockIdx.x * 4L + wv;       // (window, head) x key block
+  if (item >= 2 * total) return;                // no block-level barrier below
+  const int kb = (int)(item & 1);
+  const WaGeom g = wa_decode(item >> 1, heads, W / 8, H / 8, shift);
   const int head = g.head;
   const int C3 = 3 * C;
-  const int mytok = wa_token(g, lane, H, W, shift);
+  const int mytok = wa_token(g, lane, H, W, shift);             // token of query / staging row `lane`
+  const int ktok = wa_token(g, r + 32 * kb, H, W, shift);       // token of this lane's key
   const float lane_mask = (g.last_col && h != ((lane >> 2) & 1)) ? -100.f : 0.f;
-  float* As = smem + wv * (2 * 64 * D + 192);
-  float* Bs = As + 64 * D;
-  float* st = Bs + 64 * D;                 // [3][64]: max, 1/sum, delta of query = position
+  float* As = smem + wv * ((64 + 32) * D + 192);   // full matrix: Q, dO, Q again
+  float* Bs = As + 64 * D;                         // half matrix: K, V rows of this key block
+  float* st = Bs + 32 * D;                         // [3][64]: max, 1/sum, delta of query = position
   const int fo0 = r * D + h * HD, fo1 = (r + 32) * D + h * HD;
-  f32x16 S[2][2], G[2][2];
+  f32x16 S[2], G[2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) { S[a][b][q] = 0.f; G[a][b][q] = 0.f; }
+    for (int q = 0; q < 16; ++q) { S[a][q] = 0.f; G[a][q] = 0.f; }
   // S = Q.K^T (rows = queries)
+  float2 ra[D / 2], rb[8];
   wa_stage<D>(As, qkv + head * D, C3, mytok, lane);
-  wa_stage<D>(Bs, qkv + C + head * D, C3, mytok, lane);
+  wa_stage_half_load<D>(rb, qkv + C + head * D, C3, ktok, h);
+  wa_stage_half_store<D>(Bs, rb, r, h);
   {
     const float* sp = stats + ((long)mytok * heads + head) * 3;
     st[lane] = sp[0]; st[64 + lane] = sp[1]; st[128 + lane] = sp[2];
   }
   __builtin_amdgcn_wave_barrier();
-  float2 ra[D / 2], rb[D / 2];              // dO and V on their way during S
-  wa_stage_load<D>(ra, dout + head * D, C, mytok, lane);
-  wa_stage_load<D>(rb, qkv + 2 * C + head * D, C3, mytok, lane);
+  wa_stage_load<D>(ra, dout + head * D, C, mytok, lane);          // dO and V on their way during S
+  wa_stage_half_load<D>(rb, qkv + 2 * C + head * D, C3, ktok, h);
 #pragma unroll 3
   for (int t = 0; t < HD; ++t) {
-    const float q0 = As[fo0 + t], q1 = As[fo1 + t], k0 = Bs[fo0 + t], k1 = Bs[fo1 + t];
-    S[0][0] = mfma32(q0, k0, S[0][0]); S[0][1] = mfma32(q0, k1, S[0][1]);
-    S[1][0] = mfma32(q1, k0, S[1][0]); S[1][1] = mfma32(q1, k1, S[1][1]);
+    const float q0 = As[fo0 + t], q1 = As[fo1 + t], k0 = Bs[fo0 + t];
+    S[0] = mfma32(q0, k0, S[0]);
+    S[1] = mfma32(q1, k0, S[1]);
   }
   // dP = dO.V^T  (Q is fetched again meanwhile: column pattern for dK)
   __builtin_amdgcn_wave_barrier();
   wa_stage_store<D>(As, ra, lane);
-  wa_stage_store<D>(Bs, rb, lane);
+  wa_stage_half_store<D>(Bs, rb, r, h);
   __builtin_amdgcn_wave_barrier();
-  wa_stage_load<D>(rb, qkv + head * D, C3, mytok, lane);
+  wa_stage_load<D>(ra, qkv + head * D, C3, mytok, lane);
 #pragma unroll 3
   for (int t = 0; t < HD; ++t) {
-    const float g0 = As[fo0 + t], g1 = As[fo1 + t], v0 = Bs[fo0 + t], v1 = Bs[fo1 + t];
-    G[0][0] = mfma32(g0, v0, G[0][0]); G[0][1] = mfma32(g0, v1, G[0][1]);
-    G[1][0] = mfma32(g1, v0, G[1][0]); G[1][1] = mfma32(g1, v1, G[1][1]);
+    const float g0 = As[fo0 + t], g1 = As[fo1 + t], v0 = Bs[fo0 + t];
+    G[0] = mfma32(g0, v0, G[0]);
+    G[1] = mfma32(g1, v0, G[1]);
   }
-  // dO stays in As (column pattern for dV)
-  __builtin_amdgcn_wave_barrier();
-  wa_stage_store<D>(Bs, rb, lane);
-  __builtin_amdgcn_wave_barrier();
+  // P and dS in place (S -> P, G -> dS), then dV = P^T.dO with dO still in LDS
   const float* bn = biasN + (long)head * 4096;
+  f32x16 dK, dV;
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    f32x16 dK, dV;
+  for (int q = 0; q < 16; ++q) { dK[q] = 0.f; dV[q] = 0.f; }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { dK[q] = 0.f; dV[q] = 0.f; }
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const float tile_mask = (g.last_row && kb != qb) ? -100.f : 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int qry = mfma_row(q, lane) + 32 * qb;     // window position of the query
-        const float mx = st[qry], inv = st[64 + qry], dl = st[128 + qry];
-        float s = S[qb][kb][q] * scale + bn[wa_img_index(qb, kb, lane, q)];
-        s += tile_mask; s += lane_mask;                  // lane_mask is symmetric in (query,key)
-        const float pv = __expf(s - mx) * inv;
-        const float ds = pv * (G[qb][kb][q] - dl);
-        const float qc = r < D ? Bs[qry * D + r] : 0.f;
-        const float gc = r < D ? As[qry * D + r] : 0.f;
-        dV = mfma32(pv, gc, dV);
-        dK = mfma32(ds, qc, dK);
-      }
-    }
+  for (int qb = 0; qb < 2; ++qb) {
+    const float tile_mask = (g.last_row && kb != qb) ? -100.f : 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int tok = __shfl(mytok, mfma_row(q, lane) + 32 * kb, 64);
-      if (r < D) {
-        dqkv[(long)tok * C3 + C + head * D + r] = dK[q] * scale;
-        dqkv[(long)tok * C3 + 2 * C + head * D + r] = dV[q];
-      }
+      const int qry = mfma_row(q, lane) + 32 * qb;       // window position of the query
+      const float mx = st[qry], inv = st[64 + qry], dl = st[128 + qry];
+      float s = S[qb][q] * scale + bn[wa_img_index(qb, kb, lane, q)];
+      s += tile_mask; s += lane_mask;                    // lane_mask is symmetric in (query, key)
+      const float pv = __expf(s - mx) * inv;
+      G[qb][q] = pv * (G[qb][q] - dl);
+      const float gc = r < D ? As[qry * D + r] : 0.f;
+      dV = mfma32(pv, gc, dV);
+    }
+  }
+  // dK = dS^T.Q with Q back in LDS
+  __builtin_amdgcn_wave_barrier();
+  wa_stage_store<D>(As, ra, lane);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int qry = mfma_row(q, lane) + 32 * qb;
+      const float qc = r < D ? As[qry * D + r] : 0.f;
+      dK = mfma32(G[qb][q], qc, dK);
+    }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int tok = wa_token(g, mfma_row(q, lane) + 32 * kb, H, W, shift);
+    if (r < D) {
+      dqkv[(long)tok * C3 + C + head * D + r] = dK[q] * scale;
+      dqkv[(long)tok * C3 + 2 * C + head * D + r] = dV[q];
     }
   }
 }
@@ -515,7 +542,7 @@ int srhip_window_attention_bwd(const float* qkv, const float* dout, float* dqkv,
   const long total = (long)nwin * heads;
   const float scale = 1.0f / sqrtf((float)D);
   hipStream_t st = (hipStream_t)stream;
-  dim3 blk(256), gq(heads * sr_cdiv(nwin, 4)), gkv(sr_cdiv(total, 4));
+  dim3 blk(256), gq(heads * sr_cdiv(2 * nwin, 4)), gkv(sr_cdiv(2 * total, 4));   // half a (window, head) per wave
   if (getenv("SRHIP_WA_NOATOMIC")) dbiasT = nullptr;   // timing experiment only (bias gradient is lost)
 #define SR_WA(D_) \
   if (D == D_) { \
