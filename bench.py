@@ -132,9 +132,10 @@ def main():
         probe.enable("gemm_nt")
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # HIP events around every NT-GEMM launch of every 4th step (an event is a
-        # barrier packet on the stream: timing all 192 launches of all steps costs ~4%)
-        probe.active = "gemm_nt" if (not args.no_roofline and i % 4 == 0) else None
+        # HIP events around every NT-GEMM launch of every 10th step (an event is a barrier
+        # packet on the stream: a probed step runs ~18 % slower, so probing all of them
+        # would cost the headline number; 2 of the default 20 steps = 384 timed launches)
+        probe.active = "gemm_nt" if (not args.no_roofline and i % 10 == 0) else None
         ts.step(lr_img, hr_img)
     barrier()
     dt = time.perf_counter() - t0
