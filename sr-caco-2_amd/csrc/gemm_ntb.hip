@@ -254,6 +254,12 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
       return;
     }
   }
+  if constexpr (!CONV && WM == 1) {
+    if (p.wide_epi) {                          // block-uniform (set by the dispatcher)
+      nt_epilogue_wide<WN>(p, acc, lane, wave, wm, wn, n0, nvalid, m0, (float*)smem);
+      return;
+    }
+  }
   nt_epilogue<WM, WN, CONV>(p, acc, lane, wm, wn, n0, nvalid, m0, img, y0, x0);
   if constexpr (!CONV && WM == 1) {
     if (p.stats_out) nt_row_stats<WN>(p, acc, lane, wm, wn, m0, nvalid, (float*)smem);
@@ -356,6 +362,10 @@ int sr_gemm_ntb(NtArgs& p, hipStream_t st) {
   p.Kp = sr_kp(p.K);
   SR_REQUIRE((long)p.M * p.lda < (1L << 29) && 6L * p.N * p.Kp < (1L << 31),
              "gemm_nt_bx3: operand larger than 2 GiB (32-bit staging offsets)");
+  // 16-byte epilogue accesses need 4-float alignment of every matrix it touches
+  const auto al4 = [](const void* q, long ld) { return !q || (((size_t)q & 15) == 0 && ld % 4 == 0); };
+  p.wide_epi = !p.stats_out && p.N % 4 == 0 && al4(p.C, p.ldc) && al4(p.R, p.ldr) && al4(p.aux, p.ldaux) &&
+               ((size_t)p.C & 15) == 0 && ntb_env("SRHIP_NTB_WIDE", 1);
   return dispatch_ntb<false>(p, st);
 }
 

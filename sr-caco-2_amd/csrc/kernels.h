@@ -19,6 +19,7 @@ struct NtArgs {
   float* aux; long ldaux;     // epi 3: optional second output gelu(R)
   // epi 5 (LayerNorm backward, bx3 GEMM only): R = x, R2 = residual gradient, ep_stats = {mean, rstd}[M]
   const float* R2; long ldr2; const float* ep_stats;
+  int wide_epi;               // bx3 GEMM: transpose the tile through LDS, 16-byte epilogue accesses
   float* stats_out;           // bx3 GEMM, one N block: {mean, rstd} of every output row (next LayerNorm)
   const float* rowscale; int rows_per_scale; float alpha;
   // conv geometry

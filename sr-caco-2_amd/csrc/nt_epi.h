@@ -293,3 +293,86 @@ __device__ __forceinline__ void nt_epilogue_lnbwd(const NtArgs& p, f32x16 (&acc)
     }
   }
 }
+
+// Wide epilogue (GEMM, WM = 1, epilogues 0-4): the accumulator layout gives a lane ONE
+// column of 16 rows per tile, i.e. 4-byte global accesses -- 48 loads + 48 stores per
+// lane for a 32 x 96 wave tile, and the store tail is issue bound (every block of a
+// launch reaches it together).  Here the wave transposes its tile through LDS (the
+// staging buffers are dead by now) and finishes in ROW-MAJOR float4 pieces: residual /
+// gate loads and stores are 16 bytes per lane, a quarter of the instructions.
+// LDS row pitch 32*WN + 8 floats: the two lane halves (rows 4 apart) land 32 banks
+// apart, so the transposing ds_write_b32 is conflict free.
+template <int WN>
+__device__ __forceinline__ void nt_epilogue_wide(const NtArgs& p, f32x16 (&acc)[1][WN], int lane, int wave,
+                                                 int wm, int wn, int n0, int nvalid, int m0, float* lds) {
+  constexpr int P = 32 * WN + 8;
+  constexpr int F4 = 8 * WN;                   // float4 per tile row
+  constexpr int NIT = 32 * F4 / 64;            // float4 per lane
+  const int r = lane & 31;
+  float* tile = lds + wave * (32 * P);
+  __syncthreads();                             // all waves are done with the staging buffers
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = (wn * WN + j) * 32 + r;
+    const float bv = (col < nvalid && p.bias) ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tile[mfma_row(q, lane) * P + j * 32 + r] = acc[0][j][q] + bv;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const bool needR = p.R != nullptr && p.epi >= 2;
+  const bool per_row = p.rowscale && (p.rows_per_scale % 64 != 0);
+  float blk_s = p.alpha;
+  if (p.rowscale && !per_row) blk_s *= p.rowscale[m0 / p.rows_per_scale];
+  f32x4 rv[NIT];
+  long goff[NIT];                              // element offset row * ld is per matrix: keep (row, col)
+  int grow[NIT], gcol[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / F4, c4 = idx - row * F4;
+    const int col = wn * (32 * WN) + c4 * 4;
+    const int g = m0 + wm * 32 + row;
+    grow[it] = (g < p.M && col < nvalid) ? g : -1;      // nvalid % 4 == 0 (checked by the dispatcher)
+    gcol[it] = n0 + col;
+    goff[it] = (long)row * P + c4 * 4;
+    rv[it] = (needR && grow[it] >= 0) ? *(const f32x4*)(p.R + (long)g * p.ldr + gcol[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    f32x4 v = *(const f32x4*)(tile + goff[it]);
+    float s = blk_s;
+    if (per_row && grow[it] >= 0) s *= p.rowscale[grow[it] / p.rows_per_scale];
+    switch (p.epi) {
+      case 1:
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        break;
+      case 2:
+        v = v * s + rv[it];
+        break;
+      case 3: {
+        f32x4 gl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {          // Phi / phi as in nt_epilogue (backward-grade erf)
+          const float x = rv[it][e];
+          const float z = fabsf(x) * 0.70710678118654752440f;
+          const float e1 = __expf(-0.5f * x * x);
+          const float t = __frcp_rn(1.0f + 0.3275911f * z);
+          const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f +
+                             t * (-1.453152027f + t * 1.061405429f))));
+          const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e1, x));
+          v[e] = v[e] * s * (cdf + x * 0.39894228040143267794f * e1);
+          gl[e] = x * cdf;
+        }
+        if (p.aux && grow[it] >= 0) *(f32x4*)(p.aux + (long)grow[it] * p.ldaux + gcol[it]) = gl;
+        break;
+      }
+      case 4:
+        v.x = rv[it].x > 0.f ? v.x : 0.f; v.y = rv[it].y > 0.f ? v.y : 0.f;
+        v.z = rv[it].z > 0.f ? v.z : 0.f; v.w = rv[it].w > 0.f ? v.w : 0.f;
+        break;
+      default:
+        break;
+    }
+    if (grow[it] >= 0) *(f32x4*)(p.C + (long)grow[it] * p.ldc + gcol[it]) = v;
+  }
+}
