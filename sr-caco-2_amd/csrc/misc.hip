@@ -355,6 +355,45 @@ __global__ void k_pixel_shuffle(const float* __restrict__ in, float* __restrict_
   }
 }
 
+// r = 2, channels-last on both sides (the EDSR upsampler stages, network_nlsn.py:108):
+// a lane moves the 4 sub-pixel values of channel c of one low-res pixel as ONE float4
+// (in[pix][4c .. 4c+3]) and four coalesced dwords (out[2y+i][2x+j][c]) -- no per-element
+// index decoding.  One wave per low-res pixel and 64 channels; blockIdx.y = image row.
+__global__ void __launch_bounds__(256) k_pixel_shuffle_r2_nhwc(const float* __restrict__ in, float* __restrict__ out,
+                                                               int h, int w, int Co, int inverse) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.y;                  // b * h + y
+  const int b = row / h, y = row - b * h;
+  const int W = 2 * w;
+  const int cgroups = (Co + 63) / 64;
+  for (int item = blockIdx.x * 4 + (threadIdx.x >> 6); item < w * cgroups; item += gridDim.x * 4) {
+    const int x = item / cgroups, c = (item - x * cgroups) * 64 + lane;
+    if (c >= Co) continue;
+    const float* lp = in + ((long)row * w + x) * (4L * Co) + 4 * c;
+    float* hp = out + (((long)b * 2 * h + 2 * y) * W + 2 * x) * Co + c;
+    if (!inverse) {
+      const f32x4 v = *(const f32x4*)lp;
+      hp[0] = v.x; hp[Co] = v.y; hp[(long)W * Co] = v.z; hp[(long)W * Co + Co] = v.w;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_pixel_unshuffle_r2_nhwc(const float* __restrict__ hi, float* __restrict__ lo,
+                                                                 int h, int w, int Co) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.y;
+  const int b = row / h, y = row - b * h;
+  const int W = 2 * w;
+  const int cgroups = (Co + 63) / 64;
+  for (int item = blockIdx.x * 4 + (threadIdx.x >> 6); item < w * cgroups; item += gridDim.x * 4) {
+    const int x = item / cgroups, c = (item - x * cgroups) * 64 + lane;
+    if (c >= Co) continue;
+    const float* hp = hi + (((long)b * 2 * h + 2 * y) * W + 2 * x) * Co + c;
+    f32x4 v;
+    v.x = hp[0]; v.y = hp[Co]; v.z = hp[(long)W * Co]; v.w = hp[(long)W * Co + Co];
+    *(f32x4*)(lo + ((long)row * w + x) * (4L * Co) + 4 * c) = v;
+  }
+}
+
 // ----------------------------------------------------------------------------
 // losses (dlib/loss/main.py:45-99): fused value + gradient
 //   mode 0: L1  lam*mean(|e|*w?)    grad = lam*sign(e)*w?/n
@@ -585,6 +624,15 @@ int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, con
 int srhip_pixel_shuffle(const float* in, float* out, int B, int h, int w, int Co, int r,
                         int nhwc_out, int inverse, void* stream) {
   SR_REQUIRE(r >= 1 && Co >= 1, "pixel_shuffle: bad r/Co");
+  if (r == 2 && nhwc_out && (long)B * h < 65536 && ((size_t)in & 15) == 0 && ((size_t)out & 15) == 0) {
+    // fast path: in = low-res side [B][h][w][4*Co], out = high-res side [B][2h][2w][Co]
+    // (inverse: `in` is the high-res side, `out` the low-res one)
+    dim3 grid(sr_cdiv((long)w * sr_cdiv(Co, 64), 4) < 64 ? sr_cdiv((long)w * sr_cdiv(Co, 64), 4) : 64, B * h);
+    if (inverse) hipLaunchKernelGGL(k_pixel_unshuffle_r2_nhwc, grid, dim3(256), 0, (hipStream_t)stream, in, out, h, w, Co);
+    else hipLaunchKernelGGL(k_pixel_shuffle_r2_nhwc, grid, dim3(256), 0, (hipStream_t)stream, in, out, h, w, Co, 0);
+    SR_LAUNCH_CHECK("pixel_shuffle_r2");
+    return 0;
+  }
   const long n = (long)B * h * w * Co * r * r;
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_pixel_shuffle, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, in, out,

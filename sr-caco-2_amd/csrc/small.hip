@@ -8,14 +8,44 @@ namespace {
 
 constexpr int CO_PER_LANE = 4;  // Cout <= 256
 
+// One wave works on a SEGMENT of 64 consecutive pixels of an image row: the 3 x 66
+// input window sits in a wave-private LDS strip and slides through 9 registers, so a
+// pixel costs 3 broadcast LDS reads + the FMAs + one coalesced access of its channel
+// vector -- no per-pixel index arithmetic or bounds tests (the wave-per-pixel version
+// spent ~60 instructions per pixel on those: 4-10x off the HBM time at 512 x 512).
+constexpr int SEG = 64;
+
+__device__ __forceinline__ void seg_decode(long seg, int H, int nsx, int& b, int& y, int& x0) {
+  const int sx = (int)(seg % nsx);
+  const long t = seg / nsx;
+  y = (int)(t % H);
+  b = (int)(t / H);
+  x0 = sx * SEG;
+}
+// rows y-1..y+1, columns x0-1..x0+64 of the 1-channel image -> strip[3][66] (zero outside)
+__device__ __forceinline__ void seg_stage(float* strip, const float* __restrict__ img, int b, int y, int x0,
+                                          int H, int W, int lane) {
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr) {
+    const int sy = y + rr - 1;
+    const bool rok = sy >= 0 && sy < H;
+    const float* row = img + ((long)b * H + (rok ? sy : 0)) * W;
+    const int c0 = x0 - 1 + lane, c1 = x0 + 63 + lane;           // lanes 0..63, then lanes 0..1
+    strip[rr * 66 + lane] = (rok && c0 >= 0 && c0 < W) ? row[c0] : 0.f;
+    if (lane < 2) strip[rr * 66 + 64 + lane] = (rok && c1 < W) ? row[c1] : 0.f;
+  }
+}
+
 // y[p][co] = b[co] + sum_t x[p+t] * w[co][t]     x: [B][H][W] (1 channel), y NHWC
 // flip=1 uses w[co][8-t] (this is then the data-gradient of a Cout=1 conv).
 // conv_first: network_swinir.py:786,945; head conv: network_nlsn.py:325.
 __global__ void __launch_bounds__(256) k_conv_cin1_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        int B, int H, int W, int Co, int flip, long ldy) {
-  const int lane = threadIdx.x & 63;
-  const long wave = blockIdx.x * 4L + (threadIdx.x >> 6), nwave = gridDim.x * 4L;
+  __shared__ float strips[4][3 * 66];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long wave = blockIdx.x * 4L + wv, nwave = gridDim.x * 4L;
+  float* strip = strips[wv];
   float wr[CO_PER_LANE][9], br[CO_PER_LANE];
 #pragma unroll
   for (int i = 0; i < CO_PER_LANE; ++i) {
@@ -24,25 +54,35 @@ __global__ void __launch_bounds__(256) k_conv_cin1_fwd(const float* __restrict__
 #pragma unroll
     for (int t = 0; t < 9; ++t) wr[i][t] = co < Co ? w[co * 9 + (flip ? 8 - t : t)] : 0.f;
   }
-  const long npix = (long)B * H * W;
-  for (long p = wave; p < npix; p += nwave) {
-    const int xx = p % W, yy = (p / W) % H;
-    const long b = p / ((long)W * H);
-    float xv[9];
+  const int nsx = (W + SEG - 1) / SEG;
+  const long nseg = (long)B * H * nsx;
+  for (long seg = wave; seg < nseg; seg += nwave) {
+    int b, yy, x0;
+    seg_decode(seg, H, nsx, b, yy, x0);
+    __builtin_amdgcn_wave_barrier();
+    seg_stage(strip, x, b, yy, x0, H, W, lane);
+    __builtin_amdgcn_wave_barrier();
+    float xv[3][3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int sy = yy + t / 3 - 1, sx = xx + t % 3 - 1;
-      xv[t] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(b * H + sy) * W + sx] : 0.f;
-    }
+    for (int rr = 0; rr < 3; ++rr) { xv[rr][1] = strip[rr * 66]; xv[rr][2] = strip[rr * 66 + 1]; }
+    const int npx = min(SEG, W - x0);
+    float* yp = y + (((long)b * H + yy) * W + x0) * ldy;
+    for (int px = 0; px < npx; ++px) {
 #pragma unroll
-    for (int i = 0; i < CO_PER_LANE; ++i) {
-      const int co = lane + 64 * i;
-      if (co < Co) {
-        float a = br[i];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) a += xv[t] * wr[i][t];
-        y[p * ldy + co] = a;
+      for (int rr = 0; rr < 3; ++rr) {
+        xv[rr][0] = xv[rr][1]; xv[rr][1] = xv[rr][2]; xv[rr][2] = strip[rr * 66 + px + 2];
       }
+#pragma unroll
+      for (int i = 0; i < CO_PER_LANE; ++i) {
+        const int co = lane + 64 * i;
+        if (co < Co) {
+          float a = br[i];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) a += xv[t / 3][t % 3] * wr[i][t];
+          yp[co] = a;
+        }
+      }
+      yp += ldy;
     }
   }
 }
@@ -50,32 +90,44 @@ __global__ void __launch_bounds__(256) k_conv_cin1_fwd(const float* __restrict__
 __global__ void __launch_bounds__(256) k_conv_cin1_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                          float* __restrict__ part, int B, int H, int W, int Co,
                                                          long lddy) {
-  const int lane = threadIdx.x & 63;
-  const long wave = blockIdx.x * 4L + (threadIdx.x >> 6), nwave = gridDim.x * 4L;
+  __shared__ float strips[4][3 * 66];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long wave = blockIdx.x * 4L + wv, nwave = gridDim.x * 4L;
+  float* strip = strips[wv];
   float acc[CO_PER_LANE][10];
 #pragma unroll
   for (int i = 0; i < CO_PER_LANE; ++i)
 #pragma unroll
     for (int t = 0; t < 10; ++t) acc[i][t] = 0.f;
-  const long npix = (long)B * H * W;
-  for (long p = wave; p < npix; p += nwave) {
-    const int xx = p % W, yy = (p / W) % H;
-    const long b = p / ((long)W * H);
-    float xv[9];
+  const int nsx = (W + SEG - 1) / SEG;
+  const long nseg = (long)B * H * nsx;
+  for (long seg = wave; seg < nseg; seg += nwave) {
+    int b, yy, x0;
+    seg_decode(seg, H, nsx, b, yy, x0);
+    __builtin_amdgcn_wave_barrier();
+    seg_stage(strip, x, b, yy, x0, H, W, lane);
+    __builtin_amdgcn_wave_barrier();
+    float xv[3][3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int sy = yy + t / 3 - 1, sx = xx + t % 3 - 1;
-      xv[t] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(b * H + sy) * W + sx] : 0.f;
-    }
+    for (int rr = 0; rr < 3; ++rr) { xv[rr][1] = strip[rr * 66]; xv[rr][2] = strip[rr * 66 + 1]; }
+    const int npx = min(SEG, W - x0);
+    const float* gp = dy + (((long)b * H + yy) * W + x0) * lddy;
+    for (int px = 0; px < npx; ++px) {
 #pragma unroll
-    for (int i = 0; i < CO_PER_LANE; ++i) {
-      const int co = lane + 64 * i;
-      if (co < Co) {
-        const float g = dy[p * lddy + co];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[i][t] += g * xv[t];
-        acc[i][9] += g;
+      for (int rr = 0; rr < 3; ++rr) {
+        xv[rr][0] = xv[rr][1]; xv[rr][1] = xv[rr][2]; xv[rr][2] = strip[rr * 66 + px + 2];
       }
+#pragma unroll
+      for (int i = 0; i < CO_PER_LANE; ++i) {
+        const int co = lane + 64 * i;
+        if (co < Co) {
+          const float g = gp[co];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[i][t] += g * xv[t / 3][t % 3];
+          acc[i][9] += g;
+        }
+      }
+      gp += lddy;
     }
   }
 #pragma unroll
@@ -102,41 +154,53 @@ __global__ void k_conv_cin1_wgrad_fin(const float* __restrict__ part, float* __r
     else dw[co * 9 + (flip ? 8 - t : t)] = a;
   }
 }
-// Cout = 1: y[p] = b + sum_t sum_ci x[p+t][ci] * w[ci][t]   (x NHWC, Ci <= 256)
-// tail conv of the EDSR wiring, network_nlsn.py:347-350.  One wave per pixel.
+// Cout = 1: y[p] = b + sum_t sum_ci x[p+t][ci] * w[ci][t]   (x NHWC, Ci <= 256, Ci % 4 == 0)
+// tail conv of the EDSR wiring, network_nlsn.py:347-350.
+// Block = 16 x 16 output pixels, one per thread.  The 18 x 18 halo goes through LDS in
+// chunks of 16 channels (pixel pitch 20 floats: conflict-free ds_read_b128), the
+// weights as [tap][channel] so a thread reads 4 channels of a tap with one broadcast
+// b128: every input value is fetched from HBM once (plus the halo) instead of 9 times.
+constexpr int C1_CH = 16, C1_PIT = 20;
 __global__ void __launch_bounds__(256) k_conv_cout1_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                         int B, int H, int W, int Ci, long ldx) {
-  const int lane = threadIdx.x & 63;
-  const long wave = blockIdx.x * 4L + (threadIdx.x >> 6), nwave = gridDim.x * 4L;
-  float wr[CO_PER_LANE][9];
-#pragma unroll
-  for (int i = 0; i < CO_PER_LANE; ++i) {
-    const int ci = lane + 64 * i;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wr[i][t] = ci < Ci ? w[ci * 9 + t] : 0.f;
+  __shared__ __attribute__((aligned(16))) float xs[18 * 18 * C1_PIT];
+  __shared__ __attribute__((aligned(16))) float ws[9 * 64 * CO_PER_LANE];     // [tap][Ci padded to 16]
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+  const int cip = (Ci + C1_CH - 1) / C1_CH * C1_CH;
+  for (int i = tid; i < 9 * cip; i += 256) {
+    const int t = i / cip, c = i - t * cip;
+    ws[i] = c < Ci ? w[c * 9 + t] : 0.f;
   }
-  const float b0 = bias ? bias[0] : 0.f;
-  const long npix = (long)B * H * W;
-  for (long p = wave; p < npix; p += nwave) {
-    const int xx = p % W, yy = (p / W) % H;
-    const long b = p / ((long)W * H);
-    float a = 0.f;
+  const int px = tid & 15, py = tid >> 4;
+  float acc = 0.f;
+  for (int c0 = 0; c0 < Ci; c0 += C1_CH) {
+    __syncthreads();                                   // previous chunk consumed (and ws visible)
+    for (int i = tid; i < 18 * 18 * 4; i += 256) {
+      const int hp = i >> 2, c4 = i & 3;
+      const int hy = hp / 18, hx = hp - hy * 18;
+      const int sy = ty * 16 + hy - 1, sx = tx * 16 + hx - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (sy >= 0 && sy < H && sx >= 0 && sx < W && c0 + c4 * 4 < Ci)
+        v = *(const f32x4*)(x + (((long)b * H + sy) * W + sx) * ldx + c0 + c4 * 4);
+      *(f32x4*)(xs + hp * C1_PIT + c4 * 4) = v;
+    }
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int sy = yy + t / 3 - 1, sx = xx + t % 3 - 1;
-      if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
-        const float* row = x + ((b * H + sy) * W + sx) * ldx;
+      const float* xp = xs + ((py + t / 3) * 18 + px + t % 3) * C1_PIT;
+      const float* wp = ws + t * cip + c0;
 #pragma unroll
-        for (int i = 0; i < CO_PER_LANE; ++i) {
-          const int ci = lane + 64 * i;
-          if (ci < Ci) a += row[ci] * wr[i][t];
-        }
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
+        const f32x4 wv = *(const f32x4*)(wp + c4 * 4);
+        acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
       }
     }
-    a = wave_sum(a);
-    if (lane == 0) y[p] = a + b0;
   }
+  const int oy = ty * 16 + py, ox = tx * 16 + px;
+  if (oy < H && ox < W) y[((long)b * H + oy) * W + ox] = acc + (bias ? bias[0] : 0.f);
 }
 
 // ----------------------------------------------------------------------------
@@ -255,7 +319,7 @@ int srhip_conv3x3_cin1_fwd(const float* x, const float* w, const float* bias, fl
   SR_REQUIRE(Co <= 64 * CO_PER_LANE, "conv_cin1: Cout=%d > %d", Co, 64 * CO_PER_LANE);
   const long npix = (long)B * H * W;
   if (npix <= 0) return 0;
-  long blocks = (npix + 15) / 16;
+  long blocks = ((long)B * H * sr_cdiv(W, SEG) + 3) / 4;          // one segment per wave, at most 2048 blocks
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_conv_cin1_fwd, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                      y, B, H, W, Co, flip, ldy);
@@ -263,13 +327,16 @@ int srhip_conv3x3_cin1_fwd(const float* x, const float* w, const float* bias, fl
   return 0;
 }
 
-long srhip_conv3x3_cin1_wgrad_ws(int Co) { return 1024L * Co * 10; }  // floats
+long srhip_conv3x3_cin1_wgrad_ws(int Co) { return 8192L * Co * 10; }  // floats: [waves][Co][10]
 
 int srhip_conv3x3_cin1_wgrad(const float* x, const float* dy, long lddy, float* dw, float* db,
                              float* workspace, int B, int H, int W, int Co, int flip, void* stream) {
   SR_REQUIRE(Co <= 64 * CO_PER_LANE, "conv_cin1: Cout=%d > %d", Co, 64 * CO_PER_LANE);
   hipStream_t st = (hipStream_t)stream;
-  const int blocks = 256;  // 1024 waves
+  // one 64-pixel row segment per wave and iteration; up to 8192 waves (the loop is a
+  // dependent load -> FMA chain per pixel: parallelism across waves hides its latency)
+  long segs = (long)B * H * sr_cdiv(W, SEG);
+  const int blocks = (int)(segs >= 8192 ? 2048 : (segs + 3) / 4);
   hipLaunchKernelGGL(k_conv_cin1_wgrad, dim3(blocks), dim3(256), 0, st, x, dy, workspace, B, H, W, Co,
                      lddy);
   hipLaunchKernelGGL(k_conv_cin1_wgrad_fin, dim3(sr_cdiv(Co * 10, 4)), dim3(256), 0, st, workspace,
@@ -281,12 +348,10 @@ int srhip_conv3x3_cin1_wgrad(const float* x, const float* dy, long lddy, float* 
 int srhip_conv3x3_cout1_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, int B,
                             int H, int W, int Ci, void* stream) {
   SR_REQUIRE(Ci <= 64 * CO_PER_LANE, "conv_cout1: Cin=%d > %d", Ci, 64 * CO_PER_LANE);
-  const long npix = (long)B * H * W;
-  if (npix <= 0) return 0;
-  long blocks = (npix + 15) / 16;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_conv_cout1_fwd, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias,
-                     y, B, H, W, Ci, ldx);
+  SR_REQUIRE(Ci % 4 == 0 && ldx % 4 == 0, "conv_cout1: Cin and ldx must be multiples of 4 (Cin=%d)", Ci);
+  if ((long)B * H * W <= 0) return 0;
+  hipLaunchKernelGGL(k_conv_cout1_fwd, dim3(sr_cdiv(W, 16), sr_cdiv(H, 16), B), dim3(256), 0,
+                     (hipStream_t)stream, x, w, bias, y, B, H, W, Ci, ldx);
   SR_LAUNCH_CHECK("conv_cout1_fwd");
   return 0;
 }
