@@ -43,7 +43,8 @@ def use_bx3():
     return os.environ.get("SRHIP_MM", "bx3") != "f32"
 
 
-BX3_MIN_CHANNELS = 128   # below this the split / staging overhead outweighs the faster MFMA (EDSR's 64)
+import os as _os
+BX3_MIN_CHANNELS = int(_os.environ.get("SRHIP_BX3_MIN_CH", "128"))   # below this the split / staging overhead outweighs the faster MFMA (EDSR's 64)
 
 
 def bx3_for(*channels):
