@@ -89,7 +89,12 @@ def collect():
     bx = ops.use_bx3()
     peak = BX3_MFMA_PEAK_TFLOPS if bx else F32_MFMA_PEAK_TFLOPS
     what = "bf16x3-split MFMA (f32-equivalent flops; peak = bf16 dense / 6)" if bx else "f32-MFMA"
-    return {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
-            "frac": tf / peak, "traffic": _pmc_traffic(kname),
-            "kernel": f"{kname}: {what} NT GEMM", "launches": n, "avg_launch_us": 1000.0 * ms / n,
-            "algorithmic_gflop_per_launch": fl / n / 1e9, "classes": classes}
+    traffic = _pmc_traffic(kname)
+    out = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+           "frac": tf / peak, "traffic": traffic,
+           "kernel": f"{kname}: {what} NT GEMM", "launches": n, "avg_launch_us": 1000.0 * ms / n,
+           "algorithmic_gflop_per_launch": fl / n / 1e9, "classes": classes}
+    if traffic:      # the kernel sits near the ridge: its HBM side, from the PMC bytes, for reference
+        out["hbm_tb_per_s_from_traffic"] = traffic / (ms / n * 1e-3) / 1e12
+        out["hbm_frac_of_8tb_per_s"] = out["hbm_tb_per_s_from_traffic"] / 8.0
+    return out
