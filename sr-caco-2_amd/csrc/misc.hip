@@ -41,11 +41,21 @@ __global__ void k_reduce_slices(const float* __restrict__ part, float* __restric
   }
 }
 // conv: part [S][9][Co][Ci] -> dW torch layout [Co][Ci][3][3]
+// (the bias gradient, sum_s colsum[s][co], rides in the last block)
 __global__ void k_reduce_conv_w(const float* __restrict__ part, float* __restrict__ dw,
-                                int Co, int Ci, int S) {
+                                int Co, int Ci, int S, const float* __restrict__ colsum,
+                                float* __restrict__ db, int main_blocks) {
+  if ((int)blockIdx.x >= main_blocks) {
+    for (int n = threadIdx.x; n < Co; n += blockDim.x) {
+      float d = 0.f;
+      for (int s = 0; s < S; ++s) d += colsum[(long)s * Co + n];
+      db[n] = d;
+    }
+    return;
+  }
   const long n = (long)Co * Ci * 9;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
-       i += (long)gridDim.x * blockDim.x) {
+       i += (long)main_blocks * blockDim.x) {
     const int tap = i % 9;
     const long cc = i / 9;  // co*Ci + ci
     float a = 0.f;
@@ -560,10 +570,10 @@ int srhip_reduce_wgrad_grouped(const srhip_reduce_problem* probs, int nprob, int
 int srhip_reduce_conv_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
                             int Co, int Ci, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_reduce_conv_w, dim3(ew_grid((long)Co * Ci * 9)), dim3(256), 0, st, part, dW,
-                     Co, Ci, S);
-  if (colsum && db)
-    hipLaunchKernelGGL(k_reduce_colsum, dim3(sr_cdiv(Co, 256)), dim3(256), 0, st, colsum, db, Co, S);
+  const int mb = ew_grid((long)Co * Ci * 9);
+  const bool bias = colsum && db;
+  hipLaunchKernelGGL(k_reduce_conv_w, dim3(mb + (bias ? 1 : 0)), dim3(256), 0, st, part, dW, Co, Ci, S,
+                     colsum, db, mb);
   SR_LAUNCH_CHECK("reduce_conv_wgrad");
   return 0;
 }
