@@ -621,8 +621,9 @@ int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, con
   int rpw = 1;
   if (gamma) {  // fewer, longer waves so the column atomics stay cheap
     rpw = (int)((M + 8191) / 8192);      // 4 rows per wave at T = 32768: parallelism over atomics (reduced per block)
-    hipMemsetAsync(dgamma, 0, sizeof(float) * C, st);
-    hipMemsetAsync(dbeta, 0, sizeof(float) * C, st);
+    if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess ||
+        hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)
+      return sr_fail(-5, "layernorm_bwd: cannot zero dgamma / dbeta");
   }
   const long waves = (M + rpw - 1) / rpw;
   hipLaunchKernelGGL(k_ln_bwd, dim3(sr_cdiv(waves, 4)), dim3(256), 0, st, dy, x, stats, res, gamma,
