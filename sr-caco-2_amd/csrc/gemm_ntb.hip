@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
   // same moments; delaying the second half of the grid lets one block's memory
   // phases overlap its neighbour's MFMA phase (see gemm_nt.hip).
   if (p.stagger > 0 && (blockIdx.x + blockIdx.y * gridDim.x) >= (gridDim.x * gridDim.y) / 2) {
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(8);      // x 512 cycles
   }
 
   // ---- staging invariants (see gemm_nt.hip: clamped rows, fixed byte offsets) ----

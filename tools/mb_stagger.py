@@ -15,7 +15,7 @@ def timeit(fn, n=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
 shapes = [(180, 180, 0, 2), (360, 180, 1, 0), (180, 360, 2, 2), (540, 180, 1, 0), (360, 180, 0, 3), (180, 540, 0, 0)]
-for stg in [0, 1, 2, 3, 4, 6, 8, 12]:
+for stg in [0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 16]:
     os.environ["SRHIP_NTB_STAGGER"] = str(stg)
     row = []
     for (N, K, a_mode, epi) in shapes:
@@ -25,4 +25,4 @@ for stg in [0, 1, 2, 3, 4, 6, 8, 12]:
         Wb = ops.split_bf16x3(W)
         kw = dict(out=out, a_mode=a_mode, ln_stats=st if a_mode == 1 else None, epi=epi, R=R if epi >= 2 else None)
         row.append(timeit(lambda: ops.gemm_nt(A, Wb, b, **kw)))
-    print(f"stagger={stg:3d} (x4096 cyc): " + "  ".join(f"{t:6.1f}" for t in row) + f"   sum {sum(row):6.1f}")
+    print(f"stagger={stg:3d} (x512 cyc): " + "  ".join(f"{t:6.1f}" for t in row) + f"   sum {sum(row):6.1f}")
