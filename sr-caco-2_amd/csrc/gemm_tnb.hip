@@ -13,7 +13,7 @@
 // (DropPath row scale, LayerNorm statistics, the tap-shifted source pixel of the
 // conv) is computed by lane (token & 7) and broadcast with v_readlane.
 //
-// LDS: per plane and column two 16-byte units (tokens 0-7, 8-15 of a 16-token
+// LDS: per plane and column four 16-byte units (token octets 0-3 of a 32-token
 // chunk).  Unit (col, u) sits at slot 2*P(col) + (u ^ bit3(col)) where P swaps in
 // column bits so that BOTH access patterns are bank-conflict free: the consumer's
 // ds_read_b128 (16 consecutive columns, same u) and the producer's ds_write_b128
@@ -38,7 +38,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int TKB = 16;   // tokens per chunk = one k step of the 32x32x16 MFMA
+constexpr int TKB = 32;   // tokens per chunk = two k steps of the 32x32x16 MFMA
 
 __device__ const float k_tnb_zero_row[256] = {0.f};   // source row of tokens that contribute nothing
 
@@ -47,19 +47,21 @@ __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// column permutation inside blocks of 64: low three bits (b0^b4, b1^b5, b2); the
-// unit bit is flipped by b3.  16 consecutive columns (b3..b0 vary) and 16 columns 4
-// apart (b5..b2 vary) both map onto 16 distinct slots modulo 16.
+// A column holds four 16-byte units per plane (token octets 0..3 of a 32-token chunk).
+// Unit (col, u) sits at slot 4*P(col) + (u ^ bits32(col)), P = col with its two low bits
+// replaced by (b0^b4, b1^b5): 16 consecutive columns (consumer ds_read_b128, b3..b0 vary)
+// and 16 columns 4 apart (producer ds_write_b128, b5..b2 vary) both cover 16 distinct
+// slots modulo 16.
 __device__ __forceinline__ int unit_slot(int col, int u) {
-  const int low = ((col ^ (col >> 4)) & 3) | (col & 4);
-  return 2 * ((col & ~7) | low) + (u ^ ((col >> 3) & 1));
+  const int low = (col ^ (col >> 4)) & 3;
+  return 4 * ((col & ~3) | low) + (u ^ ((col >> 2) & 3));
 }
 
-template <int W>
+template <int W, int DBG = 0>     // DBG (timing experiments, env SRHIP_TN_DBG): 1 no MFMA, 2 no producer work
 __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int tile, const int tap,
                                          unsigned char* smem) {
   constexpr int BC = 64 * W;                 // columns per operand tile
-  constexpr int PLANE = 2 * BC * 32;         // bytes per plane per chunk buffer (A cols then B cols)
+  constexpr int PLANE = 2 * BC * 64;         // bytes per plane per chunk buffer (A cols then B cols, 4 units each)
   constexpr int BUF = 3 * PLANE;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -76,23 +78,23 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
   const int dy = p.conv ? tap / 3 - 1 : 0, dx = p.conv ? tap % 3 - 1 : 0;
   const bool do_colsum = p.part_colsum && bj == 0 && tap == 0;
 
-  // producer wave pw = wave: operand (pw & 1: 0 = A, 1 = B), token octet u = pw >> 1;
-  // lane < BC/4 owns columns 4*lane .. 4*lane+3 of that operand tile
+  // producer wave pw = wave: operand (pw & 1: 0 = A, 1 = B), token half hh = pw >> 1
+  // (octets 2*hh and 2*hh+1 of the chunk); lane < BC/4 owns columns 4*lane .. 4*lane+3
   constexpr int NQ = BC / 4;
   struct Stage {            // one chunk in flight in the producer's registers
-    f32x4 rv[8];            // [token][4 columns]
-    float scale;            // A: DropPath scale of token (lane & 7)
-    float2 stats;           // B: LayerNorm statistics of token (lane & 7)
+    f32x4 rv[2][8];         // [octet][token][4 columns]
+    float scale;            // A: DropPath scale of token (lane & 15) of the half
+    float2 stats;           // B: LayerNorm statistics of token (lane & 15)
   };
   Stage sg0, sg1;
   const bool isB = wave & 1;
-  const int u = wave >> 1;
+  const int hh = wave >> 1;
   const int colq = min(4 * lane, (isB ? jvalid : ivalid) - 4);     // clamped: extra columns are never stored
   const bool lane_on = lane < NQ;
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
   auto load = [&](int mc, Stage& sg) {
-    const int gm = mc + 8 * u + (lane & 7);      // token of this lane's per-token data
+    const int gm = mc + 16 * hh + (lane & 15);   // token of this lane's per-token data
     const bool in = gm < m_end;
     int srow = gm;
     bool ok = in;
@@ -113,65 +115,69 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
     }
     const float* P = isB ? p.B + j0 : p.A + i0;            // uniform
     const long ld = isB ? p.ldb : p.lda;
-    // interior chunk (the common case): all 8 tokens present, source rows consecutive
+    // interior chunk (the common case): all 16 tokens present, source rows consecutive
     const int row0 = __builtin_amdgcn_readlane(t_row, 0);
-    const bool dense = __all(t_row == row0 + (lane & 7) && row0 >= 0);
+    const bool dense = __all(t_row == row0 + (lane & 15) && row0 >= 0);
     if (dense) {
       const float* q = P + (long)row0 * ld;                 // uniform, advanced per token
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        sg.rv[t] = ldg_f4(q + colq);
+      for (int t = 0; t < 16; ++t) {
+        sg.rv[t >> 3][t & 7] = ldg_f4(q + colq);
         q += ld;
       }
     } else {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
+      for (int t = 0; t < 16; ++t) {
         const int row = __builtin_amdgcn_readlane(t_row, t);
         const float* base = row >= 0 ? P + (long)row * ld : k_tnb_zero_row;   // uniform
-        sg.rv[t] = ldg_f4(base + (row >= 0 ? colq : 0));
+        sg.rv[t >> 3][t & 7] = ldg_f4(base + (row >= 0 ? colq : 0));
       }
     }
   };
 
   auto store = [&](unsigned char* buf, const Stage& sg) {
-    f32x4 v[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) v[t] = sg.rv[t];
-    if (!isB) {
-      if (p.a_rowscale) {
+    for (int o = 0; o < 2; ++o) {               // the two token octets of this wave's half
+      f32x4 v[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-          v[t] *= __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg.scale), t));
+      for (int t = 0; t < 8; ++t) v[t] = sg.rv[o][t];
+      if (!isB) {
+        if (p.a_rowscale) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            v[t] *= __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg.scale), 8 * o + t));
+        }
+        if (do_colsum) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) { cs[0] += v[t].x; cs[1] += v[t].y; cs[2] += v[t].z; cs[3] += v[t].w; }
+        }
+      } else if (p.b_mode == 1) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg.stats.x), 8 * o + t));
+          const float rs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg.stats.y), 8 * o + t));
+          v[t] = (v[t] - mu) * rs;                // zero-filled tokens carry {0, 1}
+        }
+      } else if (p.b_mode == 2) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {             // gelu(0) = 0 for the zero fill
+          v[t].x = gelu_f(v[t].x); v[t].y = gelu_f(v[t].y); v[t].z = gelu_f(v[t].z); v[t].w = gelu_f(v[t].w);
+        }
       }
-      if (do_colsum) {
+      if (lane_on) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { cs[0] += v[t].x; cs[1] += v[t].y; cs[2] += v[t].z; cs[3] += v[t].w; }
+        for (int j = 0; j < 4; ++j) {             // column j of the 8 x 4 block = one unit per plane
+          unsigned qh[4], qm[4], ql[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) split3_pair(v[2 * t][j], v[2 * t + 1][j], qh[t], qm[t], ql[t]);
+          const u32x4 ph = {qh[0], qh[1], qh[2], qh[3]}, pm = {qm[0], qm[1], qm[2], qm[3]},
+                      pl = {ql[0], ql[1], ql[2], ql[3]};
+          unsigned char* dst = buf + unit_slot((isB ? BC : 0) + 4 * lane + j, 2 * hh + o) * 16;
+          *(u32x4*)(dst) = ph;
+          *(u32x4*)(dst + PLANE) = pm;
+          *(u32x4*)(dst + 2 * PLANE) = pl;
+        }
       }
-    } else if (p.b_mode == 1) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg.stats.x), t));
-        const float rs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg.stats.y), t));
-        v[t] = (v[t] - mu) * rs;                // zero-filled tokens carry {0, 1}
-      }
-    } else if (p.b_mode == 2) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {             // gelu(0) = 0 for the zero fill
-        v[t].x = gelu_f(v[t].x); v[t].y = gelu_f(v[t].y); v[t].z = gelu_f(v[t].z); v[t].w = gelu_f(v[t].w);
-      }
-    }
-    if (!lane_on) return;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {               // column j of the 8 x 4 block = one unit per plane
-      unsigned qh[4], qm[4], ql[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) split3_pair(v[2 * t][j], v[2 * t + 1][j], qh[t], qm[t], ql[t]);
-      const u32x4 ph = {qh[0], qh[1], qh[2], qh[3]}, pm = {qm[0], qm[1], qm[2], qm[3]},
-                  pl = {ql[0], ql[1], ql[2], ql[3]};
-      unsigned char* dst = buf + unit_slot((isB ? BC : 0) + 4 * lane + j, u) * 16;
-      *(u32x4*)(dst) = ph;
-      *(u32x4*)(dst + PLANE) = pm;
-      *(u32x4*)(dst + 2 * PLANE) = pl;
     }
   };
 
@@ -183,11 +189,15 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  int a_off[W], b_off[W];
+  int a_off[W][2], b_off[W][2];      // [tile][k step]: lane half h takes octet 2*step + h
 #pragma unroll
-  for (int i = 0; i < W; ++i) a_off[i] = unit_slot((wi * W + i) * 32 + r, h) * 16;
+  for (int i = 0; i < W; ++i)
 #pragma unroll
-  for (int j = 0; j < W; ++j) b_off[j] = unit_slot(BC + (wj * W + j) * 32 + r, h) * 16;
+    for (int ks = 0; ks < 2; ++ks) a_off[i][ks] = unit_slot((wi * W + i) * 32 + r, 2 * ks + h) * 16;
+#pragma unroll
+  for (int j = 0; j < W; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b_off[j][ks] = unit_slot(BC + (wj * W + j) * 32 + r, 2 * ks + h) * 16;
 
   // chunk count rounded up to even: the producer loop below is straight-line code per
   // pair of chunks (no conditional stage updates -- those made the compiler wait for
@@ -204,40 +214,47 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
     load(m_begin + 2 * TKB, sg0);
     __syncthreads();
     for (int c = 0; c < nch; c += 2) {
-      store(smem + BUF, sg1);                 // chunk c+1
-      load(m_begin + (c + 3) * TKB, sg1);
+      if (DBG != 2) {
+        store(smem + BUF, sg1);                 // chunk c+1
+        load(m_begin + (c + 3) * TKB, sg1);
+      }
       __syncthreads();
-      store(smem, sg0);                       // chunk c+2
-      load(m_begin + (c + 4) * TKB, sg0);
+      if (DBG != 2) {
+        store(smem, sg0);                       // chunk c+2
+        load(m_begin + (c + 4) * TKB, sg0);
+      }
       __syncthreads();
     }
   } else {
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
       const unsigned char* cur = smem + (c & 1) * BUF;
-      {
-        u32x4 fa[W][3];
+      if (DBG != 1) {
 #pragma unroll
-        for (int i = 0; i < W; ++i)
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 fa[W][3];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) fa[i][pl] = *(const u32x4*)(cur + pl * PLANE + a_off[i]);
+          for (int i = 0; i < W; ++i)
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-          u32x4 fb0 = *(const u32x4*)(cur + b_off[j]);
-          u32x4 fb1 = *(const u32x4*)(cur + PLANE + b_off[j]);
-          u32x4 fb2 = *(const u32x4*)(cur + 2 * PLANE + b_off[j]);
+            for (int pl = 0; pl < 3; ++pl) fa[i][pl] = *(const u32x4*)(cur + pl * PLANE + a_off[i][ks]);
 #pragma unroll
-          for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][1], fb1, acc[i][j]);
+          for (int j = 0; j < W; ++j) {
+            u32x4 fb0 = *(const u32x4*)(cur + b_off[j][ks]);
+            u32x4 fb1 = *(const u32x4*)(cur + PLANE + b_off[j][ks]);
+            u32x4 fb2 = *(const u32x4*)(cur + 2 * PLANE + b_off[j][ks]);
 #pragma unroll
-          for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][0], fb2, acc[i][j]);
+            for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][1], fb1, acc[i][j]);
 #pragma unroll
-          for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][2], fb0, acc[i][j]);
+            for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][0], fb2, acc[i][j]);
 #pragma unroll
-          for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][0], fb1, acc[i][j]);
+            for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][2], fb0, acc[i][j]);
 #pragma unroll
-          for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][1], fb0, acc[i][j]);
+            for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][0], fb1, acc[i][j]);
 #pragma unroll
-          for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][0], fb0, acc[i][j]);
+            for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][1], fb0, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < W; ++i) acc[i][j] = mfma_bf(fa[i][0], fb0, acc[i][j]);
+          }
         }
       }
       __syncthreads();
@@ -262,7 +279,7 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
     float* red = (float*)smem;               // [2][BC]; the chunk buffers are dead now
     if (producer && !isB && lane_on) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) red[u * BC + 4 * lane + j] = cs[j];
+      for (int j = 0; j < 4; ++j) red[hh * BC + 4 * lane + j] = cs[j];
     }
     __syncthreads();
     if (tid < ivalid) p.part_colsum[(long)s * p.NI + i0 + tid] = red[tid] + red[BC + tid];
@@ -280,7 +297,7 @@ struct TnbGroup {
   int tile_start[5];
   int n;
 };
-template <int W>
+template <int W, int DBG = 0>
 __global__ void __launch_bounds__(512, 1) k_tnb_grouped(TnbGroup g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = blockIdx.y;
@@ -288,10 +305,10 @@ __global__ void __launch_bounds__(512, 1) k_tnb_grouped(TnbGroup g) {
 #pragma unroll
   for (int i = 1; i < 4; ++i)
     if (i < g.n && t >= g.tile_start[i]) k = i;
-  if (k == 0) tnb_body<W>(g.p[0], blockIdx.x, t - g.tile_start[0], 0, smem);
-  else if (k == 1) tnb_body<W>(g.p[1], blockIdx.x, t - g.tile_start[1], 0, smem);
-  else if (k == 2) tnb_body<W>(g.p[2], blockIdx.x, t - g.tile_start[2], 0, smem);
-  else tnb_body<W>(g.p[3], blockIdx.x, t - g.tile_start[3], 0, smem);
+  if (k == 0) tnb_body<W, DBG>(g.p[0], blockIdx.x, t - g.tile_start[0], 0, smem);
+  else if (k == 1) tnb_body<W, DBG>(g.p[1], blockIdx.x, t - g.tile_start[1], 0, smem);
+  else if (k == 2) tnb_body<W, DBG>(g.p[2], blockIdx.x, t - g.tile_start[2], 0, smem);
+  else tnb_body<W, DBG>(g.p[3], blockIdx.x, t - g.tile_start[3], 0, smem);
 }
 
 int pick_tile(int n, int* w) {
@@ -308,7 +325,7 @@ int reserve_lds(K kern, int bytes, const char* name) {
   return 0;
 }
 
-constexpr int lds_bytes(int w) { return 2 * 3 * 2 * 64 * w * 32; }
+constexpr int lds_bytes(int w) { return 2 * 3 * 2 * 64 * w * 64; }
 
 }  // namespace
 
@@ -346,7 +363,13 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
     }                                                                                     \
     hipLaunchKernelGGL((k_tnb_grouped<W_>), grid, dim3(512), lds_bytes(W_), st, g);       \
   }
+  const char* dbg_env = getenv("SRHIP_TN_DBG");
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  if (w == 3 && dbg == 1) { hipLaunchKernelGGL((k_tnb_grouped<3, 1>), grid, dim3(512), lds_bytes(3), st, g); }
+  else if (w == 3 && dbg == 2) { hipLaunchKernelGGL((k_tnb_grouped<3, 2>), grid, dim3(512), lds_bytes(3), st, g); }
+  else {
   SR_TNB_G(1) SR_TNB_G(2) SR_TNB_G(3)
+  }
 #undef SR_TNB_G
   SR_LAUNCH_CHECK("k_tnb_grouped");
   return 0;
