@@ -213,17 +213,26 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
     store(smem, sg0);
     load(m_begin + 2 * TKB, sg0);
     __syncthreads();
+    long t_store = 0, t_load = 0, t_bar = 0;      // DBG 3: s_memtime stamps of the producer phases
     for (int c = 0; c < nch; c += 2) {
-      if (DBG != 2) {
-        store(smem + BUF, sg1);                 // chunk c+1
-        load(m_begin + (c + 3) * TKB, sg1);
-      }
+      const long s0 = DBG == 3 ? (long)__builtin_amdgcn_s_memtime() : 0;
+      if (DBG != 2) store(smem + BUF, sg1);                 // chunk c+1
+      const long s1 = DBG == 3 ? (long)__builtin_amdgcn_s_memtime() : 0;
+      if (DBG != 2) load(m_begin + (c + 3) * TKB, sg1);
+      const long s2 = DBG == 3 ? (long)__builtin_amdgcn_s_memtime() : 0;
       __syncthreads();
+      const long s3 = DBG == 3 ? (long)__builtin_amdgcn_s_memtime() : 0;
       if (DBG != 2) {
         store(smem, sg0);                       // chunk c+2
         load(m_begin + (c + 4) * TKB, sg0);
       }
       __syncthreads();
+      if (DBG == 3) { t_store += s1 - s0; t_load += s2 - s1; t_bar += s3 - s2; }
+    }
+    if (DBG == 3 && blockIdx.x == 0 && tile == 0 && lane == 0) {   // cycles per chunk, by producer wave
+      float* o = p.part + wave * 4;
+      o[0] = (float)t_store / (nch / 2); o[1] = (float)t_load / (nch / 2); o[2] = (float)t_bar / (nch / 2);
+      o[3] = (float)nch;
     }
   } else {
     __syncthreads();
@@ -261,6 +270,7 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
     }
 
   float* out = p.part + ((long)(s * (p.conv ? 9 : 1) + tap) * p.NI) * p.NJ;
+  if (DBG == 3) return;     // stamp build: keep the stamps in part[]
 #pragma unroll
   for (int i = 0; i < W; ++i)
 #pragma unroll
@@ -367,6 +377,7 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
   if (w == 3 && dbg == 1) { hipLaunchKernelGGL((k_tnb_grouped<3, 1>), grid, dim3(512), lds_bytes(3), st, g); }
   else if (w == 3 && dbg == 2) { hipLaunchKernelGGL((k_tnb_grouped<3, 2>), grid, dim3(512), lds_bytes(3), st, g); }
+  else if (w == 3 && dbg == 3) { hipLaunchKernelGGL((k_tnb_grouped<3, 3>), grid, dim3(512), lds_bytes(3), st, g); }
   else {
   SR_TNB_G(1) SR_TNB_G(2) SR_TNB_G(3)
   }

@@ -26,3 +26,11 @@ pr = [dict(dY=dqkv, X=x, dW=torch.empty(3 * C, C, device=dev), db=torch.empty(3 
 for dbg in ("0", "1", "2"):
     os.environ["SRHIP_TN_DBG"] = dbg
     print(f"SRHIP_TN_DBG={dbg}: {timeit(lambda: ops.linear_wgrad_grouped(pr)):7.1f} us (launch + ~21 us reducer)")
+os.environ["SRHIP_TN_DBG"] = "3"
+ops.linear_wgrad_grouped(pr)
+torch.cuda.synchronize()
+st = ops.SCRATCH.bufs["tng_part"][:16].cpu().tolist()
+for w in range(4):
+    o = st[4 * w:4 * w + 4]
+    print(f"producer wave {w} ({'B' if w & 1 else 'A'} operand, half {w >> 1}): cycles per 32-token chunk: "
+          f"store {o[0]:7.0f}  load-issue {o[1]:7.0f}  barrier wait {o[2]:7.0f}   (chunks {o[3]:.0f})")
