@@ -95,6 +95,19 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
 
   auto load = [&](int mc, Stage& sg) {
     const int gm = mc + 16 * hh + (lane & 15);   // token of this lane's per-token data
+    const float* P = isB ? p.B + j0 : p.A + i0;            // uniform
+    const long ld = isB ? p.ldb : p.lda;
+    if (!p.conv && mc + TKB <= m_end) {          // interior chunk of a Linear problem (uniform): no bookkeeping
+      if (!isB) sg.scale = ldg_f(p.a_rowscale ? p.a_rowscale + gm / p.a_rowscale_rows : k_sr_neutral + 1);
+      else sg.stats = ldg_f2(p.b_mode == 1 ? p.ln_stats + 2 * (long)gm : k_sr_neutral);
+      const float* q = P + (long)(mc + 16 * hh) * ld;       // uniform, advanced per token
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        sg.rv[t >> 3][t & 7] = ldg_f4(q + colq);
+        q += ld;
+      }
+      return;
+    }
     const bool in = gm < m_end;
     int srow = gm;
     bool ok = in;
@@ -113,9 +126,7 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
       const float* tp = (ok && p.b_mode == 1) ? p.ln_stats + 2 * (long)srow : k_sr_neutral;
       sg.stats = ldg_f2(tp);
     }
-    const float* P = isB ? p.B + j0 : p.A + i0;            // uniform
-    const long ld = isB ? p.ldb : p.lda;
-    // interior chunk (the common case): all 16 tokens present, source rows consecutive
+    // all 16 tokens present, source rows consecutive (conv interior)
     const int row0 = __builtin_amdgcn_readlane(t_row, 0);
     const bool dense = __all(t_row == row0 + (lane & 15) && row0 >= 0);
     if (dense) {
