@@ -197,14 +197,23 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
 
   // The A operand comes from HBM and the loop is latency bound with one chunk in
   // flight: the GEMM keeps TWO A chunks in flight (W chunks are L2 hits, one is enough)
+  // timing build (SRHIP_NT_DBG bit 64): s_memtime stamps of the loop phases of one wave
+  long tk_b1 = 0, tk_store = 0, tk_b2 = 0, tk_load = 0, tk_mma = 0, tk_prev = 0;
+  const bool stamp = (p.dbg & 64) != 0;
+  auto tick = [&](long& acc_t) {
+    if (stamp) { const long t = (long)__builtin_amdgcn_s_memtime(); acc_t += t - tk_prev; tk_prev = t; }
+  };
   auto iter = [&](int it, f32x4 (&ra)[A_IT]) {
     const int kc = it / ntap, tap = it - kc * ntap;
     __syncthreads();
+    tick(tk_b1);
     if (!(p.dbg & 2)) {
       if (!CONV || tap == 0) store_a(ra, kc);
       store_b();
     }
+    tick(tk_store);
     __syncthreads();
+    tick(tk_b2);
     // issue order matters (vmcnt retires in order): W(it+1) first, then A(it+2), so the
     // next staging waits with vmcnt(#A loads) and leaves the far-ahead A chunk in flight
     if (it + 1 < niter) {
@@ -215,6 +224,7 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     if (!CONV) {
       if (it + 2 < niter && !(p.dbg & 32)) load_a(it + 2, ra);
     }
+    tick(tk_load);
     if (p.dbg & 4) return;
     const int toff = CONV ? ((tap / 3) * 18 + (tap % 3)) * PITCH : 0;
 #pragma unroll
@@ -238,13 +248,25 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
       SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
 #undef SR_TERM
     }
+    tick(tk_mma);
   };
+  const long tk_begin = stamp ? (long)__builtin_amdgcn_s_memtime() : 0;
   load_a(0, ra0);
   load_b(0, 0);
   if (!CONV && niter > 1) load_a(1, ra1);
+  tk_prev = stamp ? (long)__builtin_amdgcn_s_memtime() : 0;
+  const long tk_prologue = tk_prev - tk_begin;
   for (int it = 0; it < niter; it += 2) {
     iter(it, ra0);
     if (it + 1 < niter) iter(it + 1, CONV ? ra0 : ra1);
+  }
+  if (stamp) {       // cycles per phase, summed over the K loop, of wave 0 of two blocks -> C[0..15] (output is lost)
+    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 + 3) && blockIdx.y == 0 && tid == 0) {
+      float* o = p.C + (blockIdx.x == 0 ? 0 : 8);
+      o[0] = (float)tk_prologue; o[1] = (float)tk_b1; o[2] = (float)tk_store; o[3] = (float)tk_b2;
+      o[4] = (float)tk_load; o[5] = (float)tk_mma; o[6] = (float)niter; o[7] = 0.f;
+    }
+    return;
   }
 
   if (p.dbg & 8) return;
