@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Actual parity margins on the README SwinIR golden (tests/golden/g4): pixel MAE, max error, PSNR shift."""
+"""Actual parity margins on the README SwinIR golden (tests/golden/g4): pixel MAE, max error, PSNR shift.
+Not a pytest file (the gates are asserted in test_gpu_swinir.py); lives under tests/ because it uses the oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path.insert(0, os.path.join(ROOT, "sr-caco-2_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from oracle import sr_oracle as O
