@@ -214,18 +214,26 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     tick(tk_store);
     __syncthreads();
     tick(tk_b2);
-    // issue order matters (vmcnt retires in order): W(it+1) first, then A(it+2), so the
-    // next staging waits with vmcnt(#A loads) and leaves the far-ahead A chunk in flight
-    if (it + 1 < niter) {
-      const int kc1 = (it + 1) / ntap, tap1 = (it + 1) - kc1 * ntap;
-      if (!(p.dbg & 16)) load_b(kc1, tap1);
-      if (CONV && tap1 == 0 && !(p.dbg & 32)) load_a(kc1, ra);
-    }
-    if (!CONV) {
+    // A operand of a later chunk (two ahead for the GEMM; the next channel chunk's halo
+    // for the conv): few loads, their own block
+    if (CONV) {
+      if (it + 1 < niter && (it + 1) % ntap == 0 && !(p.dbg & 32)) load_a((it + 1) / ntap, ra);
+    } else {
       if (it + 2 < niter && !(p.dbg & 32)) load_a(it + 2, ra);
     }
     tick(tk_load);
     if (p.dbg & 4) return;
+    // ---- ONE basic block from here: the W loads of the next chunk and this chunk's MFMAs.
+    // A wave that issues its 9 W loads back to back stalls ~1100 cycles on the full
+    // memory queue (the CU's L1 fills 64 B/clk: 74 KB of W per CU and chunk) BEFORE its
+    // MFMAs start -- measured with s_memtime; interleaved one load per four MFMAs the
+    // queue drains while the matrix core works.  The last iteration reloads its own
+    // chunk (no branch in the block).
+    {
+      const int itn = min(it + 1, niter - 1);
+      const int kcn = itn / ntap;
+      load_b(kcn, itn - kcn * ntap);
+    }
     const int toff = CONV ? ((tap / 3) * 18 + (tap % 3)) * PITCH : 0;
 #pragma unroll
     for (int s = 0; s < BKB / 16; ++s) {
@@ -247,6 +255,15 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     acc[i][j] = mfma_bf(fa[i][PA], fb[j][PB], acc[i][j]);
       SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
 #undef SR_TERM
+    }
+    {
+      constexpr int NMFMA = (BKB / 16) * 6 * WM * WN;
+      constexpr int PER = NMFMA / B_IT > 0 ? NMFMA / B_IT : 1;
+#pragma unroll
+      for (int g = 0; g < B_IT; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);     // PER MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // then one VMEM read
+      }
     }
     tick(tk_mma);
   };
@@ -410,6 +427,7 @@ int sr_conv3x3_ntb(NtArgs& p, hipStream_t st) {
   SR_REQUIRE(p.batch > 0 && p.H > 0 && p.Wd > 0, "conv3x3_bx3: empty image");
   p.M = p.batch * p.H * p.Wd;
   p.Kp = sr_kp(p.K);
+  p.dbg = ntb_env("SRHIP_NT_DBG", 0);      // ablation / stamp bits, 0 in production
   SR_REQUIRE((long)p.M * p.lda < (1L << 29) && 54L * p.N * p.Kp < (1L << 31),
              "conv3x3_bx3: operand larger than 2 GiB (32-bit staging offsets)");
   return dispatch_ntb<true>(p, st);
