@@ -60,8 +60,8 @@ int srhip_conv3x3_nhwc(const float* X, long ldx, const float* Wp, const float* b
  * x = x_h + x_m + x_l (bf16 each, 3 x 8 = 24 significant bits); a*b is summed
  * from the six cross products >= 2^-24 relative, in f32: f32-accurate results
  * at 2.67x the matrix-core rate of the f32 MFMA.  The weight operand is split
- * ONCE per step: out = planes [3][Kp/32][rows][32] bf16 (chunk-major: the rows a
- * block stages per 32-wide K chunk are contiguous), Kp = srhip_bf16x3_kp(K) (K
+ * ONCE per step: out = planes [3][Kp/16][rows][16] bf16 (16-k sub-chunk major: the
+ * rows a block stages per K chunk are contiguous), Kp = srhip_bf16x3_kp(K) (K
  * rounded up to 32, zero filled); rows = N for a Linear weight, 9*Cout for the
  * tap-major conv pack.  Same prologues / epilogues / reference lines as
  * srhip_gemm_nt and srhip_conv3x3_nhwc. */
@@ -75,7 +75,7 @@ int srhip_split_bf16x3(const float* W, long ldw, int rows, int K, void* out, voi
  * fills the job table on the host (blk0 = running sum of srhip_prep_blocks(),
  * ascending), copies it to the device once and re-runs the launch after every
  * optimizer step.
- *   kind 0  bf16x3 planes: out[3][Kp(n2)/32][n1*n0][32] of
+ *   kind 0  bf16x3 planes: out[3][Kp(n2)/16][n1*n0][16] of
  *           v(tap<n1, r<n0, k<n2) = a[off + tap*s0 + r*s1 + k*s2] * g,
  *           g = 1 (mode 0) | b[k] (mode 1) | b[r] (mode 2)
  *           -- a Linear weight, its transpose, LayerNorm gamma folded either

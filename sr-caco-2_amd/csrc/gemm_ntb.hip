@@ -14,7 +14,7 @@
 // Same two problem shapes and the same prologues / epilogues as gemm_nt.hip
 // (Linear fwd / bwd-data, 3x3 conv as implicit GEMM over an NHWC halo tile).
 // W arrives PRE-SPLIT because it is reused by every block: three bf16 planes in
-// CHUNK-MAJOR order [3][Kp/32][rows][32] (Kp = K rounded up to 32, zero filled;
+// SUB-CHUNK-MAJOR order [3][Kp/16][rows][16] (Kp = K rounded up to 32, zero filled;
 // rows = N, or 9*Cout tap-major for the conv), so the 64*WN rows x 64 B a block
 // stages per plane and chunk are one contiguous run (every wave-level load
 // instruction reads 1 KB of consecutive bytes instead of sixteen 64-byte pieces); the activation
@@ -114,7 +114,9 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     const int idx = min(tid + it * 256, B_N - 1);
     const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
     const int row = rem >> 2, q = rem & 3;
-    offB[it] = (unsigned)(pl * plane_bytes + (long)(n0 + min(row, nvalid - 1)) * 64 + q * 16);
+    // planes are stored in 16-k sub-chunks [Kp/16][rows][16]: unit q (8 k) lives in sub-chunk q/2
+    offB[it] = (unsigned)(pl * plane_bytes + (long)(q >> 1) * wrows * 32 +
+                          (long)(n0 + min(row, nvalid - 1)) * 32 + (q & 1) * 16);
   }
 
   // Loaded values are not touched here (a select on a fresh load would force an
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     }
   };
   auto load_b = [&](int kc, int tap) {
-    const char* base = (const char*)p.Wb + ((long)kc * wrows + (long)tap * p.N) * 64;   // chunk kc, row tap*N
+    const char* base = (const char*)p.Wb + ((long)kc * 2 * wrows + (long)tap * p.N) * 32;   // sub-chunk 2*kc, row tap*N
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) rb[it] = *(const u32x4*)(base + offB[it]);
   };
@@ -358,7 +360,7 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
   return sr_fail(-22, "ntb: no kernel for wm=%d wn=%d", wm, wn);
 }
 
-// W[rows][ldw] f32 -> out[3][Kp/32][rows][32] bf16 (Kp = K rounded up to 32, zero filled)
+// W[rows][ldw] f32 -> out[3][Kp/16][rows][16] bf16 (Kp = K rounded up to 32, zero filled)
 __device__ __forceinline__ void split3_slot(const float* __restrict__ W, long ldw, int rows, int K, int Kp,
                                             unsigned short* __restrict__ out, long i) {
   const int kq = Kp >> 2;                                       // one float4 (4 k) per thread
@@ -370,7 +372,7 @@ __device__ __forceinline__ void split3_slot(const float* __restrict__ W, long ld
   split3_pair(v.x, v.y, h0, m0, l0);
   split3_pair(v.z, v.w, h1, m1, l1);
   const long plane = (long)rows * Kp;
-  unsigned short* d = out + ((long)(k >> 5) * rows + row) * 32 + (k & 31);      // chunk-major
+  unsigned short* d = out + ((long)(k >> 4) * rows + row) * 16 + (k & 15);      // 16-k sub-chunk major
   *(u32x2*)(d) = u32x2{h0, h1};
   *(u32x2*)(d + plane) = u32x2{m0, m1};
   *(u32x2*)(d + 2 * plane) = u32x2{l0, l1};

@@ -21,7 +21,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-// kind 0: out planes [3][Kp/32][ntap*rows][32] (chunk-major, see gemm_ntb.hip) of  v(tap, r, k) = W[off + tap*s_tap + r*s_row + k*s_k]
+// kind 0: out planes [3][Kp/16][ntap*rows][16] (sub-chunk major, see gemm_ntb.hip) of  v(tap, r, k) = W[off + tap*s_tap + r*s_row + k*s_k]
 //         * (gamma_mode 1: gamma[k] | 2: gamma[r] | 0: 1)
 __device__ __forceinline__ void job_planes(const PrepEntry& e, int lb) {
   const int Kp = sr_kp(e.n2), kq = Kp >> 2;
@@ -46,7 +46,7 @@ __device__ __forceinline__ void job_planes(const PrepEntry& e, int lb) {
   split3_pair(v[0], v[1], h0, m0, l0);
   split3_pair(v[2], v[3], h1, m1, l1);
   const long plane = rows * Kp;
-  unsigned short* d = (unsigned short*)e.out + ((long)(k0 >> 5) * rows + row) * 32 + (k0 & 31);   // chunk-major
+  unsigned short* d = (unsigned short*)e.out + ((long)(k0 >> 4) * rows + row) * 16 + (k0 & 15);   // 16-k sub-chunk major
   *(u32x2*)(d) = u32x2{h0, h1};
   *(u32x2*)(d + plane) = u32x2{m0, m1};
   *(u32x2*)(d + 2 * plane) = u32x2{l0, l1};

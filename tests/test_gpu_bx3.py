@@ -33,8 +33,8 @@ def test_split_is_exact(ops):
     kp = bx.planes.shape[-1]
     assert kp == 192 and bx.planes.shape == (3, 180, 192)
     parts = (bx.planes.cpu().to(torch.int32) << 16).view(torch.float32).double()  # bf16 bits -> f32
-    # storage is chunk-major [3][Kp/32][rows][32]: back to [3][rows][Kp]
-    parts = parts.reshape(3, kp // 32, 180, 32).permute(0, 2, 1, 3).reshape(3, 180, kp)
+    # storage is 16-k sub-chunk major [3][Kp/16][rows][16]: back to [3][rows][Kp]
+    parts = parts.reshape(3, kp // 16, 180, 16).permute(0, 2, 1, 3).reshape(3, 180, kp)
     rec = parts.sum(0)
     assert rec[:, 180:].abs().max() == 0
     err = ((rec[:, :180] - W.double()).abs() / W.double().abs().clamp_min(1e-30)).max().item()
