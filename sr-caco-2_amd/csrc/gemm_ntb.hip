@@ -407,6 +407,13 @@ int sr_gemm_ntb(NtArgs& p, hipStream_t st) {
   const auto al4 = [](const void* q, long ld) { return !q || (((size_t)q & 15) == 0 && ld % 4 == 0); };
   p.wide_epi = !p.stats_out && p.N % 4 == 0 && al4(p.C, p.ldc) && al4(p.R, p.ldr) && al4(p.aux, p.ldaux) &&
                ((size_t)p.C & 15) == 0 && ntb_env("SRHIP_NTB_WIDE", 1);
+  // 64-row tiles (every case but very tall problems with narrow N, which take the 128-row
+  // tiles of this file): the 16-wide-stage kernel of gemm_ntp.hip
+  {
+    const bool wide = p.N % 180 == 0 || p.N > 128;
+    const long blocks128 = (long)sr_cdiv(p.M, 128) * sr_cdiv(p.N, wide ? 192 : (p.N <= 64 ? 64 : 128));
+    if ((wide || p.stats_out || blocks128 < 1024) && ntb_env("SRHIP_NTP", 1)) return sr_gemm_ntp(p, st);
+  }
   return dispatch_ntb<false>(p, st);
 }
 
@@ -418,6 +425,7 @@ int sr_gemm_ntb_lnbwd(NtArgs& p, hipStream_t st) {
   p.Kp = sr_kp(p.K);
   p.epi = 5;
   p.dbg = 0; p.stagger = 0;
+  if (ntb_env("SRHIP_NTP", 1)) return sr_gemm_ntp(p, st);
   if (p.N % 180 == 0 || p.N > 128) { p.n_tile = (p.N % 180 == 0) ? 180 : 192; return launch_ntb<1, 3, false>(p, st); }
   if (p.N > 64) { p.n_tile = 128; return launch_ntb<1, 2, false>(p, st); }
   p.n_tile = 64;

@@ -63,6 +63,7 @@ int sr_split3(const float* W, long ldw, int rows, int K, unsigned short* out, hi
 int sr_gemm_ntb(NtArgs& p, hipStream_t st);
 int sr_conv3x3_ntb(NtArgs& p, hipStream_t st);
 int sr_gemm_ntb_lnbwd(NtArgs& p, hipStream_t st);
+int sr_gemm_ntp(NtArgs& p, hipStream_t st);
 int sr_gemm_tn(TnArgs& p, hipStream_t st);
 int sr_gemm_tnb(TnArgs& p, hipStream_t st);
 int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st);
