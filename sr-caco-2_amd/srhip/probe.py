@@ -39,10 +39,10 @@ class timed:
 
 
 def _kernel_name(n, k):
-    """Instantiation the NT dispatcher (csrc/gemm_ntb.hip, gemm_nt.hip) picks for (N, K) at M >= 32768."""
+    """Instantiation the NT dispatcher (csrc/gemm_ntb.hip -> gemm_ntp.hip, gemm_nt.hip) picks for (N, K) at M >= 32768."""
     from . import ops
     if ops.use_bx3():
-        return "k_ntb<1, 3, false>" if n % 180 == 0 else None
+        return "k_ntp<3>" if n % 180 == 0 else None
     if n % 180 == 0 and n // 180 == 2:
         return "k_nt<2, 3, 36, false>"
     if n % 180 == 0:
