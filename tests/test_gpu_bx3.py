@@ -43,7 +43,8 @@ def test_split_is_exact(ops):
 
 @pytest.mark.parametrize("M,N,K", [(300, 180, 180), (4096, 540, 180), (1000, 60, 60), (777, 64, 64),
                                    (2048, 360, 180), (515, 180, 360), (64, 120, 60), (130, 256, 64),
-                                   (33000, 180, 180), (999, 180, 540), (100, 48, 20)])
+                                   (33000, 180, 180), (999, 180, 540), (100, 48, 20),
+                                   (140000, 64, 64)])   # tall + narrow: the 128-row tiles of gemm_ntb.hip
 def test_gemm_bx3_matches_f32(ops, M, N, K):
     A, W, b = rnd(M, K), rnd(N, K, scale=0.1), rnd(N)
     ref = F.linear(A.double(), W.double(), b.double())
