@@ -148,12 +148,20 @@ __global__ void __launch_bounds__(256, 2) k_ntp(NtArgs p) {
   store(0, ra0, rb0);
   ra0 = load_a(2); load_b(2, rb0);
   __syncthreads();
+  // timing build (SRHIP_NT_DBG bit 64): s_memtime stamps of the even-stage half of the loop
+  const bool stamp = (p.dbg & 64) != 0;
+  long tk_store = 0, tk_load = 0, tk_mma = 0, tk_bar = 0;
   for (int c = 0; c < nst; c += 2) {
     // stage c (even) is in LDS buffer 0
+    const long s0 = stamp ? (long)__builtin_amdgcn_s_memtime() : 0;
     store(c + 1, ra1, rb1);
+    const long s1 = stamp ? (long)__builtin_amdgcn_s_memtime() : 0;
     ra1 = load_a(c + 3); load_b(c + 3, rb1);
+    const long s2 = stamp ? (long)__builtin_amdgcn_s_memtime() : 0;
     mma(c);
+    const long s3 = stamp ? (long)__builtin_amdgcn_s_memtime() : 0;
     __syncthreads();
+    if (stamp) { tk_store += s1 - s0; tk_load += s2 - s1; tk_mma += s3 - s2; tk_bar += (long)__builtin_amdgcn_s_memtime() - s3; }
     if (c + 1 < nst) {                       // block-uniform
       store(c + 2, ra0, rb0);
       ra0 = load_a(c + 4); load_b(c + 4, rb0);
@@ -162,6 +170,15 @@ __global__ void __launch_bounds__(256, 2) k_ntp(NtArgs p) {
     }
   }
 
+  if (stamp) {       // cycles per phase of wave 0 of two blocks -> C[0..15] (output is lost)
+    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 + 3) && blockIdx.y == 0 && tid == 0) {
+      float* o = p.C + (blockIdx.x == 0 ? 0 : 8);
+      const float n = (float)((nst + 1) / 2);
+      o[0] = 0.f; o[1] = (float)tk_bar / n; o[2] = (float)tk_store / n; o[3] = 0.f;
+      o[4] = (float)tk_load / n; o[5] = (float)tk_mma / n; o[6] = 1.f; o[7] = 0.f;
+    }
+    return;
+  }
   if (p.epi == 5) {
     nt_epilogue_lnbwd<WN>(p, acc, lane, wm, wn, m0, nvalid, (float*)smem);
     return;
