@@ -248,7 +248,9 @@ def ref_window_attention(qkv, table, B, H, W, C, heads, shift):
 
 @pytest.mark.parametrize("B,H,W,C,heads,shift", [(2, 16, 16, 180, 6, 0), (2, 16, 16, 180, 6, 4),
                                                  (1, 16, 24, 60, 6, 4), (3, 24, 16, 60, 6, 0),
-                                                 (1, 64, 64, 180, 6, 4), (1, 72, 72, 180, 6, 4)])
+                                                 (1, 64, 64, 180, 6, 4), (1, 72, 72, 180, 6, 4),
+                                                 (1, 16, 24, 96, 6, 4), (2, 16, 16, 192, 6, 0),    # head dims 16, 32
+                                                 (1, 24, 24, 64, 2, 4)])
 def test_window_attention(ops, B, H, W, C, heads, shift):
     T = B * H * W
     qkv = rnd(T, 3 * C)
