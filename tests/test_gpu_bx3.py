@@ -200,3 +200,35 @@ def test_gemm_row_stats(ops, M, N, K):
     st2 = torch.empty(M, 2).cuda()
     ops.layernorm_fwd(out, st2)
     assert (st - st2).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(1, 12, 20, 128, 128), (2, 9, 7, 128, 192), (1, 16, 16, 256, 128), (3, 8, 8, 180, 180)])
+def test_conv_wgrad_bx3_borders_and_tails(ops, B, H, W, Ci, Co):
+    """bf16x3 conv weight gradient on images whose rows are not multiples of the 32-token chunk
+    (border taps, partial last chunk, ragged slices) against float64 autograd."""
+    assert ops.bx3_for(Co, Ci)
+    x, w, dy = rnd(B, Ci, H, W), rnd(Co, Ci, 3, 3, scale=0.05), rnd(B, Co, H, W)
+    wr = w.double().clone().requires_grad_(True)
+    br = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wr, br, padding=1).backward(dy.double())
+    dW, db = torch.empty(Co, Ci, 3, 3).cuda(), torch.empty(Co).cuda()
+    ops.conv3x3_wgrad(dy.permute(0, 2, 3, 1).contiguous().cuda(), x.permute(0, 2, 3, 1).contiguous().cuda(), dW, db)
+    assert relerr(dW, wr.grad) < 2e-6 and relerr(db, br.grad) < 2e-6
+
+
+@pytest.mark.parametrize("M", [31, 100, 4097, 33000])
+def test_linear_wgrad_bx3_ragged_rows(ops, M):
+    """grouped bf16x3 weight gradient with row counts that are not multiples of the chunk / slice sizes."""
+    NI, NJ = 180, 360
+    dY, X = rnd(M, NI), rnd(M, NJ)
+    rs = torch.rand(M // 16 + 1, generator=G) + 0.5
+    st = torch.stack([X.mean(1), 1 / torch.sqrt(X.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+    dW, db = torch.empty(NI, NJ).cuda(), torch.empty(NI).cuda()
+    dW2, db2 = torch.empty(NI, NJ).cuda(), torch.empty(NI).cuda()
+    ops.linear_wgrad_grouped([
+        dict(dY=dY.cuda(), X=X.cuda(), dW=dW, db=db, a_rowscale=rs.cuda(), a_rowscale_rows=16),
+        dict(dY=dY.cuda(), X=X.cuda(), dW=dW2, db=db2, b_mode=1, ln_stats=st.cuda())])
+    dYs = dY.double() * rs.double().repeat_interleave(16)[:M, None]
+    assert relerr(dW, dYs.t() @ X.double()) < 2e-6 and relerr(db, dYs.sum(0)) < 2e-6
+    Xn = (X.double() - st[:, :1].double()) * st[:, 1:].double()
+    assert relerr(dW2, dY.double().t() @ Xn) < 2e-6 and relerr(db2, dY.double().sum(0)) < 2e-6
