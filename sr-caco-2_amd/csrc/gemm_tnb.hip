@@ -5,19 +5,20 @@
 //
 // The reduce index (tokens / pixels) is the MFMA k, so both operands must reach
 // the matrix core column-major: lane (r, h) of a 32x32x16 MFMA supplies 8
-// consecutive TOKENS of column r.  A producer lane owns 4 adjacent columns and
-// loads them for 8 consecutive tokens (8 x global_load_dwordx4, every instruction
-// reads whole 16-byte pieces of one token row -- coalesced like a plain copy);
-// the 8 x 4 register block IS the transpose: column j of it is one 16-byte LDS
-// unit per bf16 plane after the split.  Everything that depends on the token only
-// (DropPath row scale, LayerNorm statistics, the tap-shifted source pixel of the
-// conv) is computed by lane (token & 7) and broadcast with v_readlane.
+// consecutive TOKENS of column r.  A producer lane owns W adjacent columns (the tile
+// is 64*W columns wide: all 64 lanes work; W = 3 -> global_load_dwordx3, a wave reads
+// 768 contiguous bytes of a token row per instruction) and loads them for 2 x 8
+// consecutive tokens; the 8 x W register block IS the transpose: column j of it is
+// one 16-byte LDS unit per bf16 plane after the split.  Everything that depends on
+// the token only (DropPath row scale, LayerNorm statistics, the tap-shifted source
+// pixel of the conv) is computed by lane (token & 15) and broadcast with v_readlane.
+// (First version: 4 columns per lane on 48 of the 64 lanes -- a third more vector
+// instructions per wave for the same tile: producers 4350 -> 3700 cycles per chunk.)
 //
 // LDS: per plane and column four 16-byte units (token octets 0-3 of a 32-token
-// chunk).  Unit (col, u) sits at slot 2*P(col) + (u ^ bit3(col)) where P swaps in
-// column bits so that BOTH access patterns are bank-conflict free: the consumer's
-// ds_read_b128 (16 consecutive columns, same u) and the producer's ds_write_b128
-// (16 lanes = columns 4 apart, same u).  Two chunk buffers, one barrier per chunk.
+// chunk), swizzled (unit_slot) so that BOTH access patterns are bank-conflict free:
+// the consumer's ds_read_b128 (16 consecutive columns, same octet) and the producer's
+// ds_write_b128 (lanes W columns apart).  Two chunk buffers, one barrier per chunk.
 //
 // Roles: a block is 8 waves = 4 CONSUMER waves (2x2, each W x W MFMA tiles of 32x32;
 // nothing but ds_read + MFMA) and 4 PRODUCER waves (global loads, prologue, split, LDS
@@ -47,15 +48,43 @@ __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// A column holds four 16-byte units per plane (token octets 0..3 of a 32-token chunk).
-// Unit (col, u) sits at slot 4*P(col) + (u ^ bits32(col)), P = col with its two low bits
-// replaced by (b0^b4, b1^b5): 16 consecutive columns (consumer ds_read_b128, b3..b0 vary)
-// and 16 columns 4 apart (producer ds_write_b128, b5..b2 vary) both cover 16 distinct
-// slots modulo 16.
+// A column holds four 16-byte units per plane (token octets 0..3 of a 32-token chunk);
+// unit (col, u) sits at slot 4*P(col) + (u ^ g(col)).  A 16-lane phase of ds_*_b128 is
+// conflict free when its 16 units differ in (P & 3, u ^ g), so that pair must be a
+// bijection of the column bits that vary inside a phase -- for the consumer's reads 16
+// consecutive columns, for the producer's writes 16 columns W apart (a lane owns W
+// adjacent columns).  W odd: (P & 3, g) = col & 15 (W is coprime with 16).  W = 2:
+// (col ^ (col >> 4)) & 15 (b0 fixed, b1..b4 vary).  Both verified exhaustively.
+template <int W>
 __device__ __forceinline__ int unit_slot(int col, int u) {
-  const int low = (col ^ (col >> 4)) & 3;
-  return 4 * ((col & ~3) | low) + (u ^ ((col >> 2) & 3));
+  if (W == 2) {
+    const int x = col ^ (col >> 4);
+    return 4 * ((col & ~3) | (x & 3)) + (u ^ ((x >> 2) & 3));
+  }
+  return 4 * col + (u ^ ((col >> 2) & 3));
 }
+
+// W adjacent f32 columns of one token row as one register vector (4-byte aligned for W = 3)
+typedef float tnb_f32x3 __attribute__((ext_vector_type(3)));
+typedef tnb_f32x3 __attribute__((aligned(4))) tnb_f32x3_u;
+template <int W> struct ColVec;
+template <> struct ColVec<1> {
+  typedef float T;
+  static __device__ __forceinline__ T ldg(const float* p) { return ldg_f(p); }
+  static __device__ __forceinline__ float at(T v, int) { return v; }
+};
+template <> struct ColVec<2> {
+  typedef sr_f32x2 T;
+  static __device__ __forceinline__ T ldg(const float* p) { return *(sr_gptr_f2)p; }
+  static __device__ __forceinline__ float at(T v, int j) { return v[j]; }
+};
+template <> struct ColVec<3> {
+  typedef tnb_f32x3 T;
+  static __device__ __forceinline__ T ldg(const float* p) {
+    return *(const __attribute__((address_space(1))) tnb_f32x3_u*)p;
+  }
+  static __device__ __forceinline__ float at(T v, int j) { return v[j]; }
+};
 
 template <int W, int DBG = 0>     // DBG (timing experiments, env SRHIP_TN_DBG): 1 no MFMA, 2 no producer work
 __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int tile, const int tap,
@@ -79,31 +108,42 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
   const bool do_colsum = p.part_colsum && bj == 0 && tap == 0;
 
   // producer wave pw = wave: operand (pw & 1: 0 = A, 1 = B), token half hh = pw >> 1
-  // (octets 2*hh and 2*hh+1 of the chunk); lane < BC/4 owns columns 4*lane .. 4*lane+3
-  constexpr int NQ = BC / 4;
+  // (octets 2*hh and 2*hh+1 of the chunk); lane owns the W adjacent columns W*lane ..
+  // (64 lanes x W = the whole operand tile: every lane works)
   struct Stage {            // one chunk in flight in the producer's registers
-    f32x4 rv[2][8];         // [octet][token][4 columns]
+    typename ColVec<W>::T rv[2][8];   // [octet][token] x W columns
     float scale;            // A: DropPath scale of token (lane & 15) of the half
     float2 stats;           // B: LayerNorm statistics of token (lane & 15)
   };
   Stage sg0, sg1;
   const bool isB = wave & 1;
   const int hh = wave >> 1;
-  const int colq = min(4 * lane, (isB ? jvalid : ivalid) - 4);     // clamped: extra columns are never stored
-  const bool lane_on = lane < NQ;
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  // clamped: a lane past the valid width re-reads the last W valid columns (its tile columns
+  // are never written out); a lane that straddles it is handled in store()
+  const int opvalid = isB ? jvalid : ivalid;
+  const int colq = max(min(W * lane, opvalid - W), 0);
+  const int dsh = W * lane - colq;             // > 0: this lane's load was shifted left
+  const bool ragged = opvalid % W != 0;        // uniform: some lane straddles the valid width
+  const float* const pA = p.A;
+  const float* const pB = p.B;
+  const long ldA = p.lda, ldB = p.ldb;
+  const float* const opP = isB ? pB + j0 : pA + i0;    // this wave's operand (uniform)
+  const long opLd = isB ? ldB : ldA;
+  float cs[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) cs[j] = 0.f;
 
-  auto load = [&](int mc, Stage& sg) {
+  auto load = [&](int mc, Stage& sg) __attribute__((always_inline)) {
     const int gm = mc + 16 * hh + (lane & 15);   // token of this lane's per-token data
-    const float* P = isB ? p.B + j0 : p.A + i0;            // uniform
-    const long ld = isB ? p.ldb : p.lda;
+    const float* P = opP;                                  // uniform
+    const long ld = opLd;
     if (!p.conv && mc + TKB <= m_end) {          // interior chunk of a Linear problem (uniform): no bookkeeping
       if (!isB) sg.scale = ldg_f(p.a_rowscale ? p.a_rowscale + gm / p.a_rowscale_rows : k_sr_neutral + 1);
       else sg.stats = ldg_f2(p.b_mode == 1 ? p.ln_stats + 2 * (long)gm : k_sr_neutral);
       const float* q = P + (long)(mc + 16 * hh) * ld;       // uniform, advanced per token
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        sg.rv[t >> 3][t & 7] = ldg_f4(q + colq);
+        sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(q + colq);
         q += ld;
       }
       return;
@@ -133,7 +173,7 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
       const float* q = P + (long)row0 * ld;                 // uniform, advanced per token
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        sg.rv[t >> 3][t & 7] = ldg_f4(q + colq);
+        sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(q + colq);
         q += ld;
       }
     } else {
@@ -141,53 +181,83 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
       for (int t = 0; t < 16; ++t) {
         const int row = __builtin_amdgcn_readlane(t_row, t);
         const float* base = row >= 0 ? P + (long)row * ld : k_tnb_zero_row;   // uniform
-        sg.rv[t >> 3][t & 7] = ldg_f4(base + (row >= 0 ? colq : 0));
+        sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(base + (row >= 0 ? colq : 0));
       }
     }
   };
 
+  auto bcast = [&](float v, int t) __attribute__((always_inline)) -> float {          // per-token scalar of token t of the half
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
+  };
   auto store = [&](unsigned char* buf, const Stage& sg) {
 #pragma unroll
     for (int o = 0; o < 2; ++o) {               // the two token octets of this wave's half
-      f32x4 v[8];
+      // (token 2t, 2t+1) pairs of one column: the form the split wants (packed f32 math).
+      // One uniform branch per octet selects the prologue; the loops inside are straight-line.
+      sr_f32x2 x[4][W];
+      if (!ragged) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = sg.rv[o][t];
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < W; ++j)
+            x[t][j] = sr_f32x2{ColVec<W>::at(sg.rv[o][2 * t], j), ColVec<W>::at(sg.rv[o][2 * t + 1], j)};
+      } else {                                  // (uniform) the lane that straddles the valid width loaded
+#pragma unroll                                  // shifted left by dsh columns: move its columns back in place
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            float e0 = ColVec<W>::at(sg.rv[o][2 * t], W - 1), e1 = ColVec<W>::at(sg.rv[o][2 * t + 1], W - 1);
+#pragma unroll
+            for (int d = W - 2; d >= 0; --d)
+              if (j + d < W && dsh == d) {
+                e0 = ColVec<W>::at(sg.rv[o][2 * t], j + d);
+                e1 = ColVec<W>::at(sg.rv[o][2 * t + 1], j + d);
+              }
+            x[t][j] = sr_f32x2{e0, e1};
+          }
+      }
       if (!isB) {
         if (p.a_rowscale) {
 #pragma unroll
-          for (int t = 0; t < 8; ++t)
-            v[t] *= __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg.scale), 8 * o + t));
+          for (int t = 0; t < 4; ++t) {
+            const sr_f32x2 k = {bcast(sg.scale, 8 * o + 2 * t), bcast(sg.scale, 8 * o + 2 * t + 1)};
+#pragma unroll
+            for (int j = 0; j < W; ++j) x[t][j] *= k;
+          }
         }
         if (do_colsum) {
 #pragma unroll
-          for (int t = 0; t < 8; ++t) { cs[0] += v[t].x; cs[1] += v[t].y; cs[2] += v[t].z; cs[3] += v[t].w; }
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < W; ++j) cs[j] += x[t][j].x + x[t][j].y;
         }
       } else if (p.b_mode == 1) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg.stats.x), 8 * o + t));
-          const float rs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg.stats.y), 8 * o + t));
-          v[t] = (v[t] - mu) * rs;                // zero-filled tokens carry {0, 1}
+        for (int t = 0; t < 4; ++t) {
+          const sr_f32x2 mu = {bcast(sg.stats.x, 8 * o + 2 * t), bcast(sg.stats.x, 8 * o + 2 * t + 1)};
+          const sr_f32x2 rs = {bcast(sg.stats.y, 8 * o + 2 * t), bcast(sg.stats.y, 8 * o + 2 * t + 1)};
+#pragma unroll
+          for (int j = 0; j < W; ++j) x[t][j] = (x[t][j] - mu) * rs;     // zero-filled tokens carry {0, 1}
         }
       } else if (p.b_mode == 2) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {             // gelu(0) = 0 for the zero fill
-          v[t].x = gelu_f(v[t].x); v[t].y = gelu_f(v[t].y); v[t].z = gelu_f(v[t].z); v[t].w = gelu_f(v[t].w);
-        }
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < W; ++j) {           // gelu(0) = 0 for the zero fill
+            x[t][j].x = gelu_f(x[t][j].x); x[t][j].y = gelu_f(x[t][j].y);
+          }
       }
-      if (lane_on) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {             // column j of the 8 x 4 block = one unit per plane
-          unsigned qh[4], qm[4], ql[4];
+      for (int j = 0; j < W; ++j) {             // column j of the 8 x W block = one unit per plane
+        unsigned qh[4], qm[4], ql[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) split3_pair(v[2 * t][j], v[2 * t + 1][j], qh[t], qm[t], ql[t]);
-          const u32x4 ph = {qh[0], qh[1], qh[2], qh[3]}, pm = {qm[0], qm[1], qm[2], qm[3]},
-                      pl = {ql[0], ql[1], ql[2], ql[3]};
-          unsigned char* dst = buf + unit_slot((isB ? BC : 0) + 4 * lane + j, 2 * hh + o) * 16;
-          *(u32x4*)(dst) = ph;
-          *(u32x4*)(dst + PLANE) = pm;
-          *(u32x4*)(dst + 2 * PLANE) = pl;
-        }
+        for (int t = 0; t < 4; ++t) split3_pair(x[t][j].x, x[t][j].y, qh[t], qm[t], ql[t]);
+        const u32x4 ph = {qh[0], qh[1], qh[2], qh[3]}, pm = {qm[0], qm[1], qm[2], qm[3]},
+                    pl = {ql[0], ql[1], ql[2], ql[3]};
+        unsigned char* dst = buf + unit_slot<W>((isB ? BC : 0) + W * lane + j, 2 * hh + o) * 16;
+        *(u32x4*)(dst) = ph;
+        *(u32x4*)(dst + PLANE) = pm;
+        *(u32x4*)(dst + 2 * PLANE) = pl;
       }
     }
   };
@@ -204,11 +274,11 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
 #pragma unroll
   for (int i = 0; i < W; ++i)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) a_off[i][ks] = unit_slot((wi * W + i) * 32 + r, 2 * ks + h) * 16;
+    for (int ks = 0; ks < 2; ++ks) a_off[i][ks] = unit_slot<W>((wi * W + i) * 32 + r, 2 * ks + h) * 16;
 #pragma unroll
   for (int j = 0; j < W; ++j)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) b_off[j][ks] = unit_slot(BC + (wj * W + j) * 32 + r, 2 * ks + h) * 16;
+    for (int ks = 0; ks < 2; ++ks) b_off[j][ks] = unit_slot<W>(BC + (wj * W + j) * 32 + r, 2 * ks + h) * 16;
 
   // chunk count rounded up to even: the producer loop below is straight-line code per
   // pair of chunks (no conditional stage updates -- those made the compiler wait for
@@ -298,9 +368,9 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
 
   if (do_colsum) {          // a column's two token octets live in different threads: meet in LDS
     float* red = (float*)smem;               // [2][BC]; the chunk buffers are dead now
-    if (producer && !isB && lane_on) {
+    if (producer && !isB) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) red[hh * BC + 4 * lane + j] = cs[j];
+      for (int j = 0; j < W; ++j) red[hh * BC + W * lane + j] = cs[j];
     }
     __syncthreads();
     if (tid < ivalid) p.part_colsum[(long)s * p.NI + i0 + tid] = red[tid] + red[BC + tid];
