@@ -242,6 +242,25 @@ int srhip_ssim_loss(const float* pred, const float* target, float* grad, float* 
                     float* workspace, int B, int H, int W, int ws, float lam, int grad_accum,
                     int loss_accum, void* stream);
 
+/* ---- optional MasterLoss terms (off by default, utils_config.py:279-374) ---- */
+/* Point-wise terms, value + d loss / d pred in one pass.  mode 0 L1 (optional per-pixel weight),
+ * 1 L2, 2 Charbonnier lam*mean(sqrt((t-p)^2 + eps)) (dlib/loss/main.py:125-151), 3 L2Sum
+ * lam*sum((p-t)^2) (dlib/loss/main.py:102-122).  workspace: 2048 doubles. */
+int srhip_loss_pointwise(const float* pred, const float* target, const float* weight, float* grad, float* loss_out,
+                         double* workspace, long n, int mode, float lam, float eps, int grad_accum, int loss_accum,
+                         void* stream);
+/* Local-variation terms on 1-channel images [B][H][W] (dlib/loss/main.py:328-674 with the operators of
+ * dlib/loss/local_variations.py:18-141, replicate padding): op 0 image gradient (2 stencils), 1 Laplacian
+ * (1), 2 local variation over a ksz x ksz window (ksz^2 - 1 stencils; ksz 3, 5 or 7).  norm 1 | 2 = the
+ * reference's NORM1 / NORM2.  channel_norm 0: lam * mean_{b,k,y,x} nrm(op_k(pred) - op_k(target))
+ * (ImageGradientLoss / LaplacianFilterLoss / LocalVariationLoss); 1: lam * mean_{b,y,x} nrm(|op(pred)|_2 -
+ * |op(target)|_2) (the Norm* classes).  Value into loss_out[0], gradient into grad (deterministic gather, no
+ * atomics).  workspace doubles: srhip_loss_stencil_ws(B,H,W). */
+long srhip_loss_stencil_ws(int B, int H, int W);
+int srhip_loss_stencil(const float* pred, const float* target, float* grad, float* loss_out, double* workspace,
+                       int B, int H, int W, int op, int ksz, int norm, int channel_norm, float lam, int grad_accum,
+                       int loss_accum, void* stream);
+
 /* ---- metrics (dlib/utils/utils_image.py:369-372,843-1007,618-653,1010-1198;
  *      dlib/utils/utils_trainer.py:961-1032) ----------------------------------- */
 /* (x.clamp(0,1)*255).round().clamp(0,255), round-half-even (utils_image.py:369-372). */

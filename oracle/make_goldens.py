@@ -378,6 +378,103 @@ def g_losses():
     npz("g6_losses", **out)
 
 
+# ------------------------------------------------- G9 optional loss terms (f4)
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def cpu_as_cuda():
+    """The reference's local-variation operators build their stencils on
+    ``cuda:{current_device()}`` (loss/local_variations.py:25,66,103): map that
+    device to the CPU while the reference objects are constructed."""
+    oc, od = torch.cuda.current_device, torch.device
+    torch.cuda.current_device = lambda: 0
+    torch.device = lambda x, *a: od("cpu") if isinstance(x, str) and x.startswith("cuda") else od(x, *a)
+    try:
+        yield
+    finally:
+        torch.cuda.current_device, torch.device = oc, od
+
+
+LOSS_EXTRA_CASES = {
+    # name: oracle term tuple
+    "charbonnier": ("charbonnier", 1.0, 1e-9),
+    "charbonnier_eps": ("charbonnier", 0.7, 1e-3),
+    "l2sum": ("l2sum", 0.01),
+    "grad_l2": ("grad", 1.0, 2),
+    "grad_l1": ("grad", 2.0, 1),
+    "laplace_l2": ("laplace", 1.0, 2),
+    "laplace_l1": ("laplace", 0.5, 1),
+    "lv3_l2": ("lv", 1.0, 2, 3),
+    "lv5_l1": ("lv", 1.0, 1, 5),
+    "lv7_l2": ("lv", 3.0, 2, 7),
+    "norm_grad_l2": ("norm_grad", 1.0, 2),
+    "norm_grad_l1": ("norm_grad", 1.0, 1),
+    "norm_laplace_l2": ("norm_laplace", 1.0, 2),
+    "norm_lv3_l1": ("norm_lv", 1.0, 1, 3),
+    "norm_lv5_l2": ("norm_lv", 1.5, 2, 5),
+}
+
+
+def ref_extra_term(t):
+    """The reference object for one oracle term tuple."""
+    kind = t[0]
+    kw = dict(cuda_id="cpu", lambda_=t[1])
+    if kind == "charbonnier":
+        l = ref_loss.Charbonnier(**kw)
+        l.set_eps(t[2])
+    elif kind == "l2sum":
+        l = ref_loss.L2Sum(**kw)
+    else:
+        cls = {"grad": ref_loss.ImageGradientLoss, "laplace": ref_loss.LaplacianFilterLoss,
+               "lv": ref_loss.LocalVariationLoss, "norm_grad": ref_loss.NormImageGradientLoss,
+               "norm_laplace": ref_loss.NormLaplacianFilterLoss,
+               "norm_lv": ref_loss.NormLocalVariationLoss}[kind]
+        l = cls(**kw)
+        norm_str = ref_c.NORM1 if t[2] == 1 else ref_c.NORM2
+        if kind.endswith("lv"):
+            l.set_it(ksz=t[3], norm_str=norm_str)
+        else:
+            l.set_it(norm_str=norm_str)
+    return l
+
+
+def g_losses_extra():
+    print("G9 optional MasterLoss terms (Charbonnier, L2Sum, local-variation family)")
+    torch.manual_seed(17)
+    # two inputs: generic, and one with flat / identical regions (zero operator norm, zero
+    # differences: the sub-gradient conventions of norm / L1Loss) on a 1-pixel-wide edge case
+    sets = {}
+    p, t = torch.rand(2, 1, 24, 40), torch.rand(2, 1, 24, 40)
+    sets["a"] = (p, t)
+    p2, t2 = torch.rand(2, 1, 19, 33), torch.rand(2, 1, 19, 33)
+    p2[0, :, :9, :12] = 0.5
+    t2[0, :, 4:12, 20:] = 0.25
+    p2[1, :, 5:15, 5:25] = t2[1, :, 5:15, 5:25]
+    sets["b"] = (p2, t2)
+    p3, t3 = torch.rand(1, 1, 1, 9), torch.rand(1, 1, 1, 9)          # a single row
+    sets["c"] = (p3, t3)
+    out = {}
+    for sn, (pred, tgt) in sets.items():
+        out[f"{sn}/pred"], out[f"{sn}/target"] = pred, tgt
+        for name, term in LOSS_EXTRA_CASES.items():
+            with cpu_as_cuda():
+                m = ref_loss.MasterLoss(cuda_id="cpu")
+                m.add(ref_extra_term(term))
+            pr = pred.clone().requires_grad_(True)
+            v = m(epoch=0, y_pred=pr, y_target=tgt, trg_per_pixel_weight=None, model=None)
+            v.backward()
+            po = pred.clone().requires_grad_(True)
+            vo, _ = O.master_loss(po, tgt, [term])
+            vo.backward()
+            close(vo.detach(), v.detach(), 1e-6 * max(1.0, abs(float(v))), f"loss {sn}/{name}")
+            close(po.grad, pr.grad, 5e-7 * max(1.0, float(pr.grad.abs().max())), f"dL/dpred {sn}/{name}")
+            out[f"{sn}/{name}/value"] = v.detach()
+            out[f"{sn}/{name}/grad"] = pr.grad
+            out[f"{sn}/{name}/names"] = np.array(m.n_holder)
+    npz("g9_losses_extra", **out)
+
+
 # ---------------------------------------------------------------- G7 metrics
 def g_metrics():
     print("G7 metrics")
@@ -465,12 +562,10 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    g_index()
-    g_edsr()
-    g_edsr_full()
-    g_swinir_tiny()
-    g_swinir_readme()
-    g_losses()
-    g_metrics()
-    g_optim()
+    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra,
+            g_metrics, g_optim]
+    only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
+    for g in gens:
+        if not only or g.__name__ in only:
+            g()
     print("all goldens written; oracle pinned against the reference.")

@@ -391,10 +391,57 @@ def loss_neg_ssim(pred: Tensor, target: Tensor, lam: float = 1.0,
     return -lam * m.mean(1).mean(1).mean(1).mean()
 
 
+def loss_charbonnier(pred: Tensor, target: Tensor, lam: float = 1.0, eps: float = 1e-9) -> Tensor:
+    """loss/main.py:125-151."""
+    d = target - pred
+    return lam * torch.sqrt(d * d + eps).mean()
+
+
+def loss_l2sum(pred: Tensor, target: Tensor, lam: float = 1.0) -> Tensor:
+    """loss/main.py:102-122: MSELoss(reduction='sum') (the trailing .mean() acts on a scalar)."""
+    return lam * ((pred - target) ** 2).sum()
+
+
+def local_variation_op(x: Tensor, kind: str, ksz: int = 3) -> Tensor:
+    """loss/local_variations.py:18-141 on a 1-channel image, replicate padding.
+    'grad': (x(.,+1) - x(.,-1), x(+1,.) - x(-1,.)); 'laplace': 8 x - the 8 neighbours;
+    'lv': x - x(+off) for every off != 0 of a ksz x ksz window (row-major)."""
+    assert x.ndim == 4 and x.shape[1] == 1
+    h, w = x.shape[-2:]
+    r = 1 if kind != "lv" else ksz // 2
+    xp = F.pad(x, (r, r, r, r), mode="replicate")
+
+    def sh(dy, dx):
+        return xp[:, :, r + dy:r + dy + h, r + dx:r + dx + w]
+    if kind == "grad":
+        return torch.cat([sh(0, 1) - sh(0, -1), sh(1, 0) - sh(-1, 0)], 1)
+    if kind == "laplace":
+        nb = sum(sh(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dy, dx) != (0, 0))
+        return 8 * x - nb
+    if kind == "lv":
+        return torch.cat([x - sh(i - r, j - r) for i in range(ksz) for j in range(ksz)
+                          if (i, j) != (r, r)], 1)
+    raise ValueError(kind)
+
+
+def loss_local_variation(pred: Tensor, target: Tensor, kind: str, lam: float = 1.0, norm: int = 2,
+                         ksz: int = 3, channel_norm: bool = False) -> Tensor:
+    """loss/main.py:328-497 (ImageGradientLoss / LaplacianFilterLoss / LocalVariationLoss) and
+    :500-674 (Norm*: 2-norm over the operator's channels first).  norm 1 = L1Loss, 2 = MSELoss,
+    reduction 'none' then .mean()."""
+    a, b = local_variation_op(pred, kind, ksz), local_variation_op(target, kind, ksz)
+    if channel_norm:
+        a, b = a.norm(p=2, dim=1, keepdim=True), b.norm(p=2, dim=1, keepdim=True)
+    e = a - b
+    return lam * (e.abs() if norm == 1 else e * e).mean()
+
+
 def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
                 weight: Optional[Tensor] = None) -> Tuple[Tensor, List[Tensor]]:
     """loss/master.py:46-56.  ``terms``: ('l1',lam) | ('l2',lam) |
-    ('ssim',lam,ws).  Returns (total, l_holder) with l_holder[0] == total."""
+    ('ssim',lam,ws) | ('charbonnier',lam,eps) | ('l2sum',lam) | ('grad'|'laplace'|'lv'|
+    'norm_grad'|'norm_laplace'|'norm_lv', lam, norm[, ksz]).  Returns (total, l_holder) with
+    l_holder[0] == total."""
     parts = []
     for t in terms:
         if t[0] == "l1":
@@ -403,6 +450,14 @@ def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
             parts.append(loss_l2(pred, target, t[1]))
         elif t[0] == "ssim":
             parts.append(loss_neg_ssim(pred, target, t[1], t[2]))
+        elif t[0] == "charbonnier":
+            parts.append(loss_charbonnier(pred, target, t[1], t[2]))
+        elif t[0] == "l2sum":
+            parts.append(loss_l2sum(pred, target, t[1]))
+        elif t[0] in ("grad", "laplace", "lv", "norm_grad", "norm_laplace", "norm_lv"):
+            # (kind, lam, norm[, ksz])
+            parts.append(loss_local_variation(pred, target, t[0].replace("norm_", ""), t[1], t[2],
+                                              t[3] if len(t) > 3 else 3, t[0].startswith("norm_")))
         else:
             raise ValueError(t[0])
     total = sum(parts)

@@ -1,0 +1,298 @@
+// Optional MasterLoss terms beyond L1 / L2 / SSIM: the point-wise Charbonnier
+// and L2Sum terms and the local-variation family -- ImageGradientLoss, LaplacianFilterLoss,
+// LocalVariationLoss and their Norm* variants (dlib/loss/main.py:102-151,328-674 with the
+// operators of dlib/loss/local_variations.py:18-141).  Each term is ONE kernel that produces
+// the value and d loss / d pred together (+ the shared partial-sum reducer).
+//
+// Local-variation terms: op = K 3x3 .. 7x7 stencils on the replicate-padded 1-channel image,
+//   plain:  loss = lam * mean_{b,k,y,x} nrm(op_k(pred) - op_k(target))
+//   Norm*:  loss = lam * mean_{b,y,x}   nrm(|op(pred)|_2 - |op(target)|_2)   (2-norm over k)
+// nrm = square (NORM2) or abs (NORM1).  HBM-bound: pred and target are read once (a tile with
+// a 2R halo in LDS), the gradient is written once.  The gradient is a GATHER -- for output
+// pixel q and tap (k, off, w) it sums g_k(p) over the source pixels p whose padded read
+// clamp(p + off) lands on q (one pixel in the interior, a short run on the image border) --
+// so there are no atomics and the result is deterministic.
+#include "common.h"
+#include "kernels.h"
+#include "../../include/srhip.h"
+
+namespace {
+
+constexpr int TS = 16;     // output tile edge (256 threads, one pixel each)
+
+// point-wise terms: mode 0 L1 (optional weight), 1 L2, 2 Charbonnier sqrt(e^2 + eps), 3 L2Sum
+__global__ void __launch_bounds__(256) k_loss_pointwise(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                        const float* __restrict__ wgt, float* __restrict__ grad,
+                                                        double* __restrict__ part, long n, int mode, float gs,
+                                                        float eps, int grad_accum) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float e = pred[i] - tgt[i];
+    float v, g;
+    if (mode == 0) {
+      v = fabsf(e);
+      g = (e > 0.f) ? gs : (e < 0.f ? -gs : 0.f);
+      if (wgt) { v *= wgt[i]; g *= wgt[i]; }
+    } else if (mode == 2) {
+      v = sqrtf(e * e + eps);
+      g = gs * e / v;
+    } else {
+      v = e * e;
+      g = 2.f * gs * e;
+    }
+    acc += (double)v;
+    if (grad) grad[i] = grad_accum ? grad[i] + g : g;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ void __launch_bounds__(1024) k_sum_partials_d(const double* __restrict__ part, int n, double scale,
+                                                         float* __restrict__ out, int accum) {
+  __shared__ double sh[16];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) a += part[i];
+  a = wave_sum_d(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    out[0] = (accum ? out[0] : 0.f) + (float)(t * scale);
+  }
+}
+
+// source pixels p in [0, n) whose replicate-padded read p + off lands on q
+__device__ __forceinline__ void src_range(int q, int off, int n, int& lo, int& hi) {
+  lo = hi = q - off;
+  if (q == 0) lo = 0;
+  if (q == n - 1) hi = n - 1;
+  lo = max(lo, 0);
+  hi = min(hi, n - 1);
+}
+
+template <int OP, int R> struct Stencil;
+// image gradient: k0 = x(y, x+1) - x(y, x-1), k1 = x(y+1, x) - x(y-1, x)   (local_variations.py:18-55)
+template <> struct Stencil<0, 1> {
+  static constexpr int K = 2, TAPS = 2;
+  static __device__ __forceinline__ void tap(int k, int t, int& dy, int& dx, float& w) {
+    const int s = t ? -1 : 1;
+    dy = k ? s : 0; dx = k ? 0 : s; w = (float)s;
+  }
+};
+// Laplacian: 8 x(p) - the 8 neighbours                                     (local_variations.py:58-91)
+template <> struct Stencil<1, 1> {
+  static constexpr int K = 1, TAPS = 9;
+  static __device__ __forceinline__ void tap(int, int t, int& dy, int& dx, float& w) {
+    dy = t / 3 - 1; dx = t % 3 - 1; w = (t == 4) ? 8.f : -1.f;
+  }
+};
+// local variation: k = (i, j) != centre of a ksz x ksz window: x(p) - x(p + (i-c, j-c))   (:94-141)
+template <int R> struct Stencil<2, R> {
+  static constexpr int KS = 2 * R + 1, K = KS * KS - 1, TAPS = 2;
+  static __device__ __forceinline__ void tap(int k, int t, int& dy, int& dx, float& w) {
+    const int kk = k + (k >= K / 2);        // skip the centre
+    dy = t ? kk / KS - R : 0; dx = t ? kk % KS - R : 0; w = t ? -1.f : 1.f;
+  }
+};
+
+// r_k at LDS position (ly, lx) of image a (row pitch LW).  Explicit fma everywhere: pred and
+// target must go through the SAME operation sequence -- where they are equal the reference's
+// difference is exactly 0 and NORM1's sign(0) = 0 (with compiler-chosen contraction the two
+// sides differed by an ulp and the L1 gradient there became +-1).
+template <int OP, int R>
+__device__ __forceinline__ float stencil_at(const float* a, int LW, int ly, int lx, int k) {
+  typedef Stencil<OP, R> S;
+  float r = 0.f;
+#pragma unroll
+  for (int t = 0; t < S::TAPS; ++t) {
+    int dy, dx; float w;
+    S::tap(k, t, dy, dx, w);
+    r = __builtin_fmaf(w, a[(ly + dy) * LW + lx + dx], r);
+  }
+  return r;
+}
+
+__device__ __forceinline__ float nrm_val(float e, int l1) { return l1 ? fabsf(e) : e * e; }
+__device__ __forceinline__ float nrm_der(float e, int l1) {
+  return l1 ? (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) : 2.f * e;
+}
+
+template <int OP, int R>
+__global__ void __launch_bounds__(256) k_loss_stencil(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                      float* __restrict__ grad, double* __restrict__ part, int H, int W,
+                                                      int l1, int chan_norm, float gs, int grad_accum) {
+  typedef Stencil<OP, R> S;
+  constexpr int LW = TS + 4 * R;            // tile + 2R halo
+  constexpr int CW = TS + 2 * R;            // tile + R halo (coefficients of the Norm* variants)
+  __shared__ float sp[LW * LW], st[LW * LW], sd[LW * LW], coef[CW * CW];
+  __shared__ double sh[4];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
+  const float* P = pred + (long)b * H * W;
+  const float* T = tgt + (long)b * H * W;
+  for (int i = tid; i < LW * LW; i += 256) {
+    const int ly = i / LW, lx = i - ly * LW;
+    const int y = min(max(ty0 + ly - 2 * R, 0), H - 1), x = min(max(tx0 + lx - 2 * R, 0), W - 1);   // replicate pad
+    const float a = P[(long)y * W + x], c = T[(long)y * W + x];
+    sp[i] = a;
+    st[i] = c;
+    sd[i] = a - c;
+  }
+  // block-uniform: every pixel within R of the tile is at least R (>= 1) away from the image border
+  const bool interior = ty0 >= 2 * R && ty0 + TS + 2 * R <= H && tx0 >= 2 * R && tx0 + TS + 2 * R <= W;
+  __syncthreads();
+  if (chan_norm) {
+    // c(p) = nrm'(|op(pred)| - |op(target)|) / |op(pred)|   (0 where the norm is 0, as torch's norm backward)
+    for (int i = tid; i < CW * CW; i += 256) {
+      const int cy = i / CW, cx = i - cy * CW;
+      const int y = ty0 + cy - R, x = tx0 + cx - R;
+      float c = 0.f;
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+        float np = 0.f, nt = 0.f;
+#pragma unroll
+        for (int k = 0; k < S::K; ++k) {
+          const float a = stencil_at<OP, R>(sp, LW, cy + R, cx + R, k), t = stencil_at<OP, R>(st, LW, cy + R, cx + R, k);
+          np = __builtin_fmaf(a, a, np); nt = __builtin_fmaf(t, t, nt);
+        }
+        np = sqrtf(np); nt = sqrtf(nt);
+        c = np > 0.f ? nrm_der(np - nt, l1) / np : 0.f;
+      }
+      coef[i] = c;
+    }
+    __syncthreads();
+  }
+  const int qy = tid / TS, qx = tid % TS;
+  const int y = ty0 + qy, x = tx0 + qx;
+  double val = 0.0;
+  if (y < H && x < W) {
+    const int ly = qy + 2 * R, lx = qx + 2 * R;
+    // value at q
+    if (chan_norm) {
+      float np = 0.f, nt = 0.f;
+#pragma unroll
+      for (int k = 0; k < S::K; ++k) {
+        const float a = stencil_at<OP, R>(sp, LW, ly, lx, k), t = stencil_at<OP, R>(st, LW, ly, lx, k);
+        np = __builtin_fmaf(a, a, np); nt = __builtin_fmaf(t, t, nt);
+      }
+      val = (double)nrm_val(sqrtf(np) - sqrtf(nt), l1);
+    } else {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < S::K; ++k)
+        v += nrm_val(stencil_at<OP, R>(sp, LW, ly, lx, k) - stencil_at<OP, R>(st, LW, ly, lx, k), l1);
+      val = (double)v;
+    }
+    // gradient at q: gather over taps and the source pixels whose padded read lands on q
+    if (grad && interior) {
+      // no pixel of this tile touches the padding: the one source pixel of tap off is q - off;
+      // compile-time taps, straight-line code.  Plain terms are linear in d = pred - target.
+      float g = 0.f;
+#pragma unroll
+      for (int k = 0; k < S::K; ++k) {
+#pragma unroll
+        for (int t = 0; t < S::TAPS; ++t) {
+          int dy, dx; float w;
+          S::tap(k, t, dy, dx, w);
+          const int ply = ly - dy, plx = lx - dx;
+          float gk;
+          if (chan_norm) gk = coef[(ply - R) * CW + plx - R] * stencil_at<OP, R>(sp, LW, ply, plx, k);
+          else gk = nrm_der(stencil_at<OP, R>(sd, LW, ply, plx, k), l1);
+          g = __builtin_fmaf(w, gk, g);
+        }
+      }
+      const long o = ((long)b * H + y) * W + x;
+      grad[o] = grad_accum ? grad[o] + gs * g : gs * g;
+    } else if (grad) {
+      float g = 0.f;
+      for (int k = 0; k < S::K; ++k) {
+#pragma unroll
+        for (int t = 0; t < S::TAPS; ++t) {
+          int dy, dx; float w;
+          S::tap(k, t, dy, dx, w);
+          int ylo, yhi, xlo, xhi;
+          src_range(y, dy, H, ylo, yhi);
+          src_range(x, dx, W, xlo, xhi);
+          for (int py = ylo; py <= yhi; ++py)
+            for (int px = xlo; px <= xhi; ++px) {
+              const int ply = py - ty0 + 2 * R, plx = px - tx0 + 2 * R;
+              const float rp = stencil_at<OP, R>(sp, LW, ply, plx, k);
+              float gk;
+              if (chan_norm) gk = coef[(ply - R) * CW + plx - R] * rp;
+              else gk = nrm_der(rp - stencil_at<OP, R>(st, LW, ply, plx, k), l1);
+              g += w * gk;
+            }
+        }
+      }
+      const long o = ((long)b * H + y) * W + x;
+      grad[o] = grad_accum ? grad[o] + gs * g : gs * g;
+    }
+  }
+  val = wave_sum_d(val);
+  if ((tid & 63) == 0) sh[tid >> 6] = val;
+  __syncthreads();
+  if (tid == 0) part[((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+int ew_blocks(long n) {
+  long g = (n + 255) / 256;
+  return (int)(g < 2048 ? g : 2048);
+}
+
+}  // namespace
+
+extern "C" {
+
+int srhip_loss_pointwise(const float* pred, const float* target, const float* weight, float* grad, float* loss_out,
+                         double* workspace, long n, int mode, float lam, float eps, int grad_accum, int loss_accum,
+                         void* stream) {
+  SR_REQUIRE(n > 0, "loss_pointwise: empty input");
+  SR_REQUIRE(mode >= 0 && mode <= 3, "loss_pointwise: mode %d", mode);
+  SR_REQUIRE(mode != 2 || eps > 0.f, "loss_pointwise: Charbonnier needs eps > 0");
+  SR_REQUIRE(weight == nullptr || mode == 0, "loss_pointwise: per-pixel weights apply to L1 only (loss/main.py:62-72)");
+  hipStream_t st = (hipStream_t)stream;
+  const int g = ew_blocks(n);
+  const double denom = mode == 3 ? 1.0 : (double)n;          // L2Sum: MSELoss(reduction='sum')
+  // Charbonnier: d/dpred sqrt((t-p)^2 + eps) = (p - t) / sqrt(...)
+  hipLaunchKernelGGL(k_loss_pointwise, dim3(g), dim3(256), 0, st, pred, target, weight, grad, workspace, n, mode,
+                     (float)((double)lam / denom), eps, grad_accum);
+  hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(1024), 0, st, workspace, g, (double)lam / denom, loss_out, loss_accum);
+  SR_LAUNCH_CHECK("loss_pointwise");
+  return 0;
+}
+
+long srhip_loss_stencil_ws(int B, int H, int W) { return (long)B * sr_cdiv(H, TS) * sr_cdiv(W, TS); }
+
+int srhip_loss_stencil(const float* pred, const float* target, float* grad, float* loss_out, double* workspace,
+                       int B, int H, int W, int op, int ksz, int norm, int channel_norm, float lam, int grad_accum,
+                       int loss_accum, void* stream) {
+  SR_REQUIRE(B > 0 && H > 0 && W > 0, "loss_stencil: empty input");
+  SR_REQUIRE(op >= 0 && op <= 2, "loss_stencil: op %d (0 image gradient, 1 Laplacian, 2 local variation)", op);
+  SR_REQUIRE(op != 2 || ksz == 3 || ksz == 5 || ksz == 7, "loss_stencil: local variation window %d (3, 5 or 7)", ksz);
+  SR_REQUIRE(norm == 1 || norm == 2, "loss_stencil: norm %d (1 or 2)", norm);
+  SR_REQUIRE(B <= 65535, "loss_stencil: batch %d", B);
+  hipStream_t st = (hipStream_t)stream;
+  const int K = op == 0 ? 2 : (op == 1 ? 1 : ksz * ksz - 1);
+  const double count = (double)B * H * W * (channel_norm ? 1 : K);
+  const float gs = (float)((double)lam / count);
+  dim3 grid(sr_cdiv(W, TS), sr_cdiv(H, TS), B);
+  const int l1 = norm == 1;
+#define SR_STENCIL(OP_, R_) \
+  hipLaunchKernelGGL((k_loss_stencil<OP_, R_>), grid, dim3(256), 0, st, pred, target, grad, workspace, H, W, l1, \
+                     channel_norm, gs, grad_accum)
+  if (op == 0) SR_STENCIL(0, 1);
+  else if (op == 1) SR_STENCIL(1, 1);
+  else if (ksz == 3) SR_STENCIL(2, 1);
+  else if (ksz == 5) SR_STENCIL(2, 2);
+  else SR_STENCIL(2, 3);
+#undef SR_STENCIL
+  hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(1024), 0, st, workspace, (int)srhip_loss_stencil_ws(B, H, W),
+                     (double)lam / count, loss_out, loss_accum);
+  SR_LAUNCH_CHECK("loss_stencil");
+  return 0;
+}
+
+}  // extern "C"

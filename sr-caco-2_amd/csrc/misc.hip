@@ -448,12 +448,19 @@ __global__ void __launch_bounds__(256) k_sum(const float* __restrict__ x, double
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 // out[0] (+)= scale * sum(part[0..n))  as float
-__global__ void k_sum_partials(const double* __restrict__ part, int n, double scale,
+__global__ void __launch_bounds__(1024) k_sum_partials(const double* __restrict__ part, int n, double scale,
                                float* __restrict__ out, int accum) {
+  __shared__ double sh[16];
   double a = 0.0;
-  for (int i = threadIdx.x; i < n; i += 64) a += part[i];
+  for (int i = threadIdx.x; i < n; i += 1024) a += part[i];
   a = wave_sum_d(a);
-  if (threadIdx.x == 0) out[0] = (accum ? out[0] : 0.f) + (float)(a * scale);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    out[0] = (accum ? out[0] : 0.f) + (float)(t * scale);
+  }
 }
 
 // ----------------------------------------------------------------------------
@@ -662,7 +669,7 @@ int srhip_loss_l1l2(const float* pred, const float* target, const float* weight,
   const int g = ew_grid(n);
   hipLaunchKernelGGL(k_loss_l1l2, dim3(g), dim3(256), 0, st, pred, target, weight, grad, workspace, n,
                      mode, lam, grad_accum);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, workspace, g, (double)lam / (double)n,
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st, workspace, g, (double)lam / (double)n,
                      loss_out, loss_accum);
   SR_LAUNCH_CHECK("loss_l1l2");
   return 0;
@@ -674,7 +681,7 @@ int srhip_sum(const float* x, long n, float* out, double* workspace, void* strea
   hipStream_t st = (hipStream_t)stream;
   const int g = ew_grid(n);
   hipLaunchKernelGGL(k_sum, dim3(g), dim3(256), 0, st, x, workspace, n);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, workspace, g, 1.0, out, 0);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, st, workspace, g, 1.0, out, 0);
   SR_LAUNCH_CHECK("sum");
   return 0;
 }

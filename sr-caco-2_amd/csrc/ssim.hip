@@ -147,12 +147,19 @@ __global__ void __launch_bounds__(256) k_ssim_loss_bwd(const float* __restrict__
     }
   }
 }
-__global__ void k_sum_partials_d(const double* __restrict__ part, int n, double scale,
+__global__ void __launch_bounds__(1024) k_sum_partials_d(const double* __restrict__ part, int n, double scale,
                                  float* __restrict__ out, int accum) {
+  __shared__ double sh[16];
   double a = 0.0;
-  for (int i = threadIdx.x; i < n; i += 64) a += part[i];
+  for (int i = threadIdx.x; i < n; i += 1024) a += part[i];
   a = wave_sum_d(a);
-  if (threadIdx.x == 0) out[0] = (accum ? out[0] : 0.f) + (float)(a * scale);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    out[0] = (accum ? out[0] : 0.f) + (float)(t * scale);
+  }
 }
 
 // ---------------- metric -------------------------------------------------------
@@ -264,7 +271,7 @@ int srhip_ssim_loss(const float* pred, const float* target, float* grad, float* 
   const int ntile = grid.x * grid.y * grid.z;
   const double scale = -(double)lam / ((double)B * H * W);
   hipLaunchKernelGGL(k_ssim_loss_fwd, grid, dim3(256), 0, st, pred, target, maps, part, H, W, ws, tp);
-  hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(64), 0, st, part, ntile, scale, loss_out, loss_accum);
+  hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(1024), 0, st, part, ntile, scale, loss_out, loss_accum);
   if (grad)
     hipLaunchKernelGGL(k_ssim_loss_bwd, grid, dim3(256), 0, st, pred, target, maps, grad, H, W, ws, tp,
                        (float)scale, grad_accum);

@@ -1,4 +1,5 @@
-"""SR losses on libsrhip: MasterLoss + L1 / L2 / NegativeSsim.
+"""SR losses on libsrhip: MasterLoss + L1 / L2 / NegativeSsim, and the optional
+Charbonnier / L2Sum / local-variation terms.
 
 Mirrors the reference's ``dlib.loss`` surface on the hot path
 (dlib/loss/master.py:19-56, dlib/loss/core.py:17-127, dlib/loss/main.py:45-99,
@@ -6,8 +7,11 @@ Mirrors the reference's ``dlib.loss`` surface on the hot path
 y_target=, trg_per_pixel_weight=, model=)`` call, ``l_holder`` / ``n_holder``
 bookkeeping and ``update_t``.  Each term runs ONE fused HIP kernel sequence that
 produces the value and d loss / d y_pred together; autograd only scales that
-stored gradient.  The other 13 reference terms are off by default
-(utils_config.py:279-374) and not on the hot path.
+stored gradient.  Of the reference's 13 optional terms (off by default,
+utils_config.py:279-374) Charbonnier, L2Sum, ImageGradientLoss, LaplacianFilterLoss,
+LocalVariationLoss and their three Norm* variants are built the same way
+(dlib/loss/main.py:102-151,328-674); BoundedPrediction, LocalMoments, HistogramMatch,
+KDEMatch, CrossEntropyL and WeightsSparsityLoss are not (NotImplementedError on use).
 """
 import re
 
@@ -16,7 +20,11 @@ import torch.nn as nn
 
 from srhip import ops
 
-__all__ = ['MasterLoss', 'ElementaryLoss', 'L1', 'L2', 'NegativeSsim']
+__all__ = ['MasterLoss', 'ElementaryLoss', 'L1', 'L2', 'NegativeSsim', 'L2Sum', 'Charbonnier',
+           'ImageGradientLoss', 'LaplacianFilterLoss', 'LocalVariationLoss', 'NormImageGradientLoss',
+           'NormLaplacianFilterLoss', 'NormLocalVariationLoss']
+
+NORM1, NORM2 = '1', '2'      # dlib/utils/constants.py:696-697
 
 
 def _snake(name):
@@ -136,6 +144,99 @@ class NegativeSsim(ElementaryLoss):
         return _FusedLoss.apply(y_pred, lambda p, g, v: ops.ssim_loss(p, t, ws, self.lambda_, g, v))
 
 
+class L2Sum(ElementaryLoss):
+    """lambda * sum((y_pred - y_target)^2); dlib/loss/main.py:102-122."""
+
+    def forward(self, epoch, y_pred=None, y_target=None, trg_per_pixel_weight=None, model=None):
+        super().forward(epoch=epoch)
+        if not self.is_on():
+            return self._zero
+        t = y_target.float().contiguous()
+        return _FusedLoss.apply(y_pred, lambda p, g, v: ops.loss_pointwise(p, t, 3, self.lambda_, grad=g, loss_out=v))
+
+
+class Charbonnier(ElementaryLoss):
+    """lambda * mean(sqrt((y_target - y_pred)^2 + eps)), eps 1e-9; dlib/loss/main.py:125-151."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.eps = 1e-9
+
+    def set_eps(self, eps):
+        assert eps > 0
+        self.eps = eps
+
+    def forward(self, epoch, y_pred=None, y_target=None, trg_per_pixel_weight=None, model=None):
+        super().forward(epoch=epoch)
+        if not self.is_on():
+            return self._zero
+        t = y_target.float().contiguous()
+        return _FusedLoss.apply(
+            y_pred, lambda p, g, v: ops.loss_pointwise(p, t, 2, self.lambda_, self.eps, grad=g, loss_out=v))
+
+
+class _LocalVariationTerm(ElementaryLoss):
+    """lambda * mean(nrm(op(y_pred) - op(y_target))) (or, Norm* variants, of the 2-norms over the
+    operator's channels) for a replicate-padded stencil operator; dlib/loss/main.py:328-674,
+    dlib/loss/local_variations.py:18-141.  One fused kernel: value + gradient."""
+    kind, channel_norm, has_ksz = None, False, False
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.ksz = 3
+        self.norm_str = NORM2
+        self.already_set = False
+
+    def _set(self, norm_str, ksz=3):
+        assert isinstance(norm_str, str) and norm_str in (NORM1, NORM2), norm_str
+        assert isinstance(ksz, int) and ksz % 2 == 1 and ksz > 2, ksz
+        self.norm_str, self.ksz, self.already_set = norm_str, ksz, True
+
+    def forward(self, epoch, y_pred=None, y_target=None, trg_per_pixel_weight=None, model=None):
+        super().forward(epoch=epoch)
+        if not self.is_on():
+            return self._zero
+        assert y_target.shape == y_pred.shape, f'{y_target.shape}, {y_pred.shape}'
+        assert y_pred.ndim == 4 and y_pred.shape[1] == 1, "supports only grey (local_variations.py:45)"
+        t = y_target.float().contiguous()
+        norm = 1 if self.norm_str == NORM1 else 2
+        return _FusedLoss.apply(y_pred, lambda p, g, v: ops.loss_stencil(
+            p, t, self.kind, self.lambda_, norm, self.ksz, self.channel_norm, grad=g, loss_out=v))
+
+
+class ImageGradientLoss(_LocalVariationTerm):
+    kind = "grad"
+
+    def set_it(self, norm_str):
+        self._set(norm_str)
+
+
+class LaplacianFilterLoss(_LocalVariationTerm):
+    kind = "laplace"
+
+    def set_it(self, norm_str):
+        self._set(norm_str)
+
+
+class LocalVariationLoss(_LocalVariationTerm):
+    kind, has_ksz = "lv", True
+
+    def set_it(self, ksz, norm_str):
+        self._set(norm_str, ksz)
+
+
+class NormImageGradientLoss(ImageGradientLoss):
+    channel_norm = True
+
+
+class NormLaplacianFilterLoss(LaplacianFilterLoss):
+    channel_norm = True
+
+
+class NormLocalVariationLoss(LocalVariationLoss):
+    channel_norm = True
+
+
 class MasterLoss(nn.Module):
     """Sum of elementary losses; l_holder = [total, term1, ...] (master.py:46-56)."""
 
@@ -159,8 +260,9 @@ class MasterLoss(nn.Module):
         return _snake(self.__class__.__name__) if self._name is None else self._name
 
     def terms(self):
-        """('l1', lam) | ('l2', lam) | ('ssim', lam, window) for the fused training
-        step (srhip.train.TrainStep)."""
+        """('l1', lam) | ('l2', lam) | ('ssim', lam, window) | ('charbonnier', lam, eps) |
+        ('l2sum', lam) | ('grad'|'laplace'|'lv'|'norm_*', lam, norm, ksz) for the fused
+        training step (srhip.train.TrainStep)."""
         out = []
         for l in self.losses:
             if isinstance(l, L1):
@@ -169,6 +271,13 @@ class MasterLoss(nn.Module):
                 out.append(("l2", l.lambda_))
             elif isinstance(l, NegativeSsim):
                 out.append(("ssim", l.lambda_, l.window_size))
+            elif isinstance(l, Charbonnier):
+                out.append(("charbonnier", l.lambda_, l.eps))
+            elif isinstance(l, L2Sum):
+                out.append(("l2sum", l.lambda_))
+            elif isinstance(l, _LocalVariationTerm):
+                out.append((("norm_" if l.channel_norm else "") + l.kind, l.lambda_,
+                            1 if l.norm_str == NORM1 else 2, l.ksz))
             else:
                 raise NotImplementedError(type(l).__name__)
         return out

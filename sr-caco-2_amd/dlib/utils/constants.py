@@ -37,3 +37,8 @@ STEPSLR = [MULTISTEPLR, MYSTEPLR]
 
 GLOO = 'gloo'
 NCCL = 'nccl'
+
+# norms of the optional local-variation loss terms (reference constants.py:696-703)
+NORM1 = '1'
+NORM2 = '2'
+LPNORMS = [NORM1, NORM2]

@@ -13,12 +13,33 @@ def define_loss(args):
         m.add(losses.L1(cuda_id=dev, lambda_=tr.get('l1_lambda', 1.)))
     if tr.get('l2', False):
         m.add(losses.L2(cuda_id=dev, lambda_=tr.get('l2_lambda', 1.)))
+    # same order of addition as the reference (utils_instance.py:47-165): it is the order of l_holder / n_holder
+    if tr.get('l2sum', False):
+        m.add(losses.L2Sum(cuda_id=dev, lambda_=tr.get('l2sum_lambda', 1.)))
     if tr.get('ssim', False):
         l = losses.NegativeSsim(cuda_id=dev, lambda_=tr.get('ssim_lambda', 1.))
         l.set_window_size(tr.get('ssim_window_s', 11))
         m.add(l)
-    for k in ('l2sum', 'charbonnier', 'boundpred', 'local_moments', 'img_grad', 'norm_img_grad',
-              'laplace', 'norm_laplace', 'loc_var', 'norm_loc_var', 'hist', 'kde', 'ce', 'w_sparsity'):
+    # optional terms (keys of utils_config.py:296-357)
+    if tr.get('charbonnier', False):
+        l = losses.Charbonnier(cuda_id=dev, lambda_=tr.get('charbonnier_lambda', 1.))
+        l.set_eps(tr.get('charbonnier_eps', 1e-9))
+        m.add(l)
+    for key, cls, norm_key in (('img_grad', losses.ImageGradientLoss, 'img_grad_norm'),
+                               ('norm_img_grad', losses.NormImageGradientLoss, 'norm_img_grad_type'),
+                               ('laplace', losses.LaplacianFilterLoss, 'laplace_norm'),
+                               ('norm_laplace', losses.NormLaplacianFilterLoss, 'norm_laplace_type'),
+                               ('loc_var', losses.LocalVariationLoss, 'loc_var_norm'),
+                               ('norm_loc_var', losses.NormLocalVariationLoss, 'norm_loc_var_type')):
+        if tr.get(key, False):
+            assert not tr.get(key + '_use_residuals', False), "use_residuals is not on the hot path"
+            l = cls(cuda_id=dev, lambda_=tr.get(key + '_lambda', 1.))
+            if key.endswith('loc_var'):
+                l.set_it(ksz=tr.get(key + '_ksz', 3), norm_str=str(tr.get(norm_key, constants.NORM2)))
+            else:
+                l.set_it(norm_str=str(tr.get(norm_key, constants.NORM2)))
+            m.add(l)
+    for k in ('boundpred', 'local_moments', 'hist', 'kde', 'ce', 'w_sparsity'):
         if tr.get(k, False):
             raise NotImplementedError(f"loss term --{k} is outside the libsrhip hot path")
     assert len(m.n_holder) > 1, "no loss term enabled"

@@ -67,6 +67,16 @@ def get_config(net_type):
         'eval_over_roi_also_ths': [4, 5, 6, 7, 8, 9, 10], 'outd': './out',
         'train': {'l1': True, 'l1_lambda': 1., 'l2': False, 'l2_lambda': 1., 'ssim': False,
                   'ssim_lambda': 1., 'ssim_window_s': 11,
+                  # optional terms (utils_config.py:296-357)
+                  'l2sum': False, 'l2sum_lambda': 1., 'charbonnier': False, 'charbonnier_lambda': 1.,
+                  'charbonnier_eps': 1e-9,
+                  'img_grad': False, 'img_grad_lambda': 1., 'img_grad_norm': constants.NORM2,
+                  'norm_img_grad': False, 'norm_img_grad_lambda': 1., 'norm_img_grad_type': constants.NORM2,
+                  'laplace': False, 'laplace_lambda': 1., 'laplace_norm': constants.NORM2,
+                  'norm_laplace': False, 'norm_laplace_lambda': 1., 'norm_laplace_type': constants.NORM2,
+                  'loc_var': False, 'loc_var_ksz': 3, 'loc_var_lambda': 1., 'loc_var_norm': constants.NORM2,
+                  'norm_loc_var': False, 'norm_loc_var_ksz': 3, 'norm_loc_var_lambda': 1.,
+                  'norm_loc_var_type': constants.NORM2,
                   'G_optimizer_type': constants.ADAM, 'G_optimizer_lr': 2e-4, 'G_optimizer_wd': 1e-4,
                   'G_optimizer_beta1': 0.9, 'G_optimizer_beta2': 0.999, 'G_optimizer_eps_adam': 1e-8,
                   'G_optimizer_momentum': 0.9, 'G_optimizer_nesterov': True, 'G_optimizer_amsgrad': False,

@@ -486,6 +486,38 @@ def ssim_loss(pred, target, ws, lam=1.0, grad=None, loss_out=None, grad_accum=Fa
     return loss_out
 
 
+def loss_pointwise(pred, target, mode, lam=1.0, eps=1e-9, weight=None, grad=None, loss_out=None,
+                   grad_accum=False, loss_accum=False):
+    """mode 0 L1 | 1 L2 | 2 Charbonnier(eps) | 3 L2Sum (dlib/loss/main.py:45-151)."""
+    _chk(pred, target, weight, grad, loss_out)
+    if loss_out is None:
+        loss_out = torch.empty(1, device=pred.device, dtype=torch.float32)
+    ws = SCRATCH.get("loss_ws", 2048, torch.float64, pred.device)
+    call("srhip_loss_pointwise", _p(pred), _p(target), _p(weight), _p(grad), _p(loss_out), _p(ws),
+         pred.numel(), mode, float(lam), float(eps), int(grad_accum), int(loss_accum), _st())
+    return loss_out
+
+
+STENCIL_OPS = {"grad": 0, "laplace": 1, "lv": 2}
+
+
+def loss_stencil(pred, target, kind, lam=1.0, norm=2, ksz=3, channel_norm=False, grad=None,
+                 loss_out=None, grad_accum=False, loss_accum=False):
+    """Local-variation loss family on 1-channel images [B,1,H,W] / [B,H,W]
+    (dlib/loss/main.py:328-674): kind 'grad' | 'laplace' | 'lv'."""
+    _chk(pred, target, grad, loss_out)
+    assert pred.ndim == 3 or pred.shape[1] == 1, "local-variation losses: 1-channel images (local_variations.py:45)"
+    B = pred.shape[0]
+    H, W = pred.shape[-2:]
+    if loss_out is None:
+        loss_out = torch.empty(1, device=pred.device, dtype=torch.float32)
+    ws = SCRATCH.get("stencil_ws", lib.srhip_loss_stencil_ws(B, H, W), torch.float64, pred.device)
+    call("srhip_loss_stencil", _p(pred), _p(target), _p(grad), _p(loss_out), _p(ws), B, H, W,
+         STENCIL_OPS[kind], int(ksz), int(norm), int(channel_norm), float(lam), int(grad_accum),
+         int(loss_accum), _st())
+    return loss_out
+
+
 # ------------------------------------------------------------------ metrics
 def tensor2uint82float(x):
     _chk(x)

@@ -120,8 +120,10 @@ def allreduce_range(flat_grad, lo, hi, group=None, comm_stream=None):
 
 
 class TrainStep:
-    """loss_terms: sequence of ('l1', lam) | ('l2', lam) | ('ssim', lam, window)
-    (MasterLoss = their sum, dlib/loss/master.py:46-56)."""
+    """loss_terms: sequence of ('l1', lam) | ('l2', lam) | ('ssim', lam, window) |
+    ('charbonnier', lam, eps) | ('l2sum', lam) | ('grad'|'laplace'|'lv'|'norm_grad'|
+    'norm_laplace'|'norm_lv', lam, norm, ksz)  (MasterLoss = their sum,
+    dlib/loss/master.py:46-56)."""
 
     def __init__(self, net, loss_terms=(("l1", 1.0),), optimizer=None, process_group=None,
                  world_size=1):
@@ -165,6 +167,13 @@ class TrainStep:
                               grad_accum=not first)
             elif t[0] == "ssim":
                 ops.ssim_loss(y, target, t[2], t[1], self.dy, part, grad_accum=not first)
+            elif t[0] == "charbonnier":
+                ops.loss_pointwise(y, target, 2, t[1], t[2], None, self.dy, part, grad_accum=not first)
+            elif t[0] == "l2sum":
+                ops.loss_pointwise(y, target, 3, t[1], grad=self.dy, loss_out=part, grad_accum=not first)
+            elif t[0].replace("norm_", "") in ops.STENCIL_OPS:
+                ops.loss_stencil(y, target, t[0].replace("norm_", ""), t[1], t[2], t[3] if len(t) > 3 else 3,
+                                 t[0].startswith("norm_"), self.dy, part, grad_accum=not first)
             else:
                 raise NotImplementedError(t[0])
         return self.dy

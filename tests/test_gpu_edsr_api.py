@@ -108,6 +108,89 @@ def test_dlib_loss_surface_vs_reference_golden():
         assert m.n_holder == list(g[name + "/names"])
 
 
+def _extra_term(L, term):
+    kind, kw = term[0], dict(cuda_id=0, lambda_=term[1])
+    if kind == "charbonnier":
+        l = L.Charbonnier(**kw)
+        l.set_eps(term[2])
+    elif kind == "l2sum":
+        l = L.L2Sum(**kw)
+    else:
+        cls = {"grad": L.ImageGradientLoss, "laplace": L.LaplacianFilterLoss, "lv": L.LocalVariationLoss,
+               "norm_grad": L.NormImageGradientLoss, "norm_laplace": L.NormLaplacianFilterLoss,
+               "norm_lv": L.NormLocalVariationLoss}[kind]
+        l = cls(**kw)
+        if kind.endswith("lv"):
+            l.set_it(ksz=term[3], norm_str=L.NORM1 if term[2] == 1 else L.NORM2)
+        else:
+            l.set_it(norm_str=L.NORM1 if term[2] == 1 else L.NORM2)
+    return l
+
+
+def test_dlib_optional_loss_terms_vs_reference_golden():
+    """Charbonnier, L2Sum and the local-variation family through the dlib.loss surface (one fused HIP kernel
+    each) against the reference's values and gradients (tests/golden/g9_losses_extra.npz)."""
+    from dlib import loss as L
+    from test_oracle_golden import LOSS_EXTRA_CASES
+    g = load("g9_losses_extra")
+    for sn in "abc":
+        for name, term in LOSS_EXTRA_CASES.items():
+            m = L.MasterLoss(cuda_id=0)
+            m.add(_extra_term(L, term))
+            p = g[f"{sn}/pred"].cuda().requires_grad_(True)
+            v = m(epoch=0, y_pred=p, y_target=g[f"{sn}/target"].cuda(), trg_per_pixel_weight=None, model=None)
+            v.backward()
+            rv, rg = g[f"{sn}/{name}/value"], g[f"{sn}/{name}/grad"]
+            assert abs(float(v) - float(rv)) <= 2e-6 * max(1.0, abs(float(rv))), (sn, name, float(v), float(rv))
+            err = (p.grad.cpu() - rg).abs().max().item()
+            assert err <= 2e-6 * max(1.0, float(rg.abs().max())), (sn, name, err)
+            assert m.n_holder == list(g[f"{sn}/{name}/names"])
+            assert m.terms()[0][0] == term[0]
+
+
+def test_optional_loss_terms_full_size_properties():
+    """At the benchmark's 8 x 512 x 512: linearity of the plain local-variation terms in the difference
+    (loss(pred, target) == loss(pred - target, 0)), zero loss / zero gradient at pred == target, tile-seam
+    independence (a shifted crop gives the same interior gradient), and the fused step's accumulation."""
+    from srhip import ops
+    gen = torch.Generator().manual_seed(3)
+    p = torch.rand(8, 1, 512, 512, generator=gen).cuda()
+    t = torch.rand(8, 1, 512, 512, generator=gen).cuda()
+    z = torch.zeros_like(p)
+    for kind, ksz in (("grad", 3), ("laplace", 3), ("lv", 5)):
+        for norm in (1, 2):
+            g1, g2 = torch.empty_like(p), torch.empty_like(p)
+            v1 = ops.loss_stencil(p, t, kind, 1.0, norm, ksz, False, g1)
+            v2 = ops.loss_stencil(p - t, z, kind, 1.0, norm, ksz, False, g2)
+            assert abs(float(v1) - float(v2)) <= 1e-5 * abs(float(v2))
+            if norm == 2:
+                assert (g1 - g2).abs().max() <= 1e-5 * g2.abs().max()
+            g0 = torch.empty_like(p)
+            v0 = ops.loss_stencil(p, p.clone(), kind, 1.0, norm, ksz, False, g0)
+            assert float(v0) == 0.0 and float(g0.abs().max()) == 0.0
+    # oracle on a crop whose interior is far from the borders: same gradient up to the mean's denominator
+    pc, tc = p[:1, :, 100:180, 200:296].contiguous(), t[:1, :, 100:180, 200:296].contiguous()
+    for kind, norm, ksz, cn in (("lv", 2, 7, False), ("grad", 1, 3, True), ("lv", 2, 3, True)):
+        gfull = torch.empty_like(p)
+        ops.loss_stencil(p, t, kind, 1.0, norm, ksz, cn, gfull)
+        po = pc.cpu().clone().requires_grad_(True)
+        O.loss_local_variation(po, tc.cpu(), kind, 1.0, norm, ksz, cn).backward()
+        scale = pc.numel() / p.numel()
+        a = gfull[0, 0, 100:180, 200:296].cpu()[8:-8, 8:-8]
+        b = (po.grad[0, 0] * scale)[8:-8, 8:-8]
+        assert (a - b).abs().max() <= 2e-6 * b.abs().max(), (kind, norm, ksz, cn)
+    # accumulation flags (how TrainStep sums MasterLoss terms)
+    g = torch.empty_like(p)
+    out = torch.zeros(1, device="cuda")
+    ops.loss_pointwise(p, t, 2, 0.5, 1e-6, None, g, out)
+    ops.loss_stencil(p, t, "laplace", 2.0, 1, 3, False, g, out, grad_accum=True, loss_accum=True)
+    ga, gb = torch.empty_like(p), torch.empty_like(p)
+    va = ops.loss_pointwise(p, t, 2, 0.5, 1e-6, None, ga)
+    vb = ops.loss_stencil(p, t, "laplace", 2.0, 1, 3, False, gb)
+    assert abs(float(out) - float(va) - float(vb)) <= 1e-6 * abs(float(out))
+    assert (g - ga - gb).abs().max() <= 1e-6 * g.abs().max()
+
+
 def test_dlib_metrics_surface_vs_reference_golden():
     from dlib import metrics as M
     from dlib.utils import utils_image
@@ -200,6 +283,49 @@ def test_model_plain_steps_match_oracle_training(tmp_path, opt):
     model.load_network(path, model.netG)
     model.test()
     assert torch.equal(model.current_visuals()['E'], e1)
+
+
+def test_model_plain_step_with_optional_loss_terms(tmp_path):
+    """MasterLoss = Charbonnier + 0.5 * LocalVariation(5, NORM1) + 2 * NormImageGradient(NORM2) through the
+    fused step (config keys of utils_config.py:301-357): loss values and the updated parameters against the
+    oracle's autograd step."""
+    from dlib.models.select_model import define_model
+    args = tiny_args("sgd")
+    args['outd'] = str(tmp_path)
+    args['train'].update({'l1': False, 'charbonnier': True, 'charbonnier_eps': 1e-6, 'loc_var': True,
+                          'loc_var_ksz': 5, 'loc_var_norm': '1', 'loc_var_lambda': 0.5, 'norm_img_grad': True,
+                          'norm_img_grad_type': '2', 'norm_img_grad_lambda': 2.0})
+    model = define_model(args)
+    cfg = O.swinir_config(upscale=8, in_chans=1, img_size=16, window_size=8, depths=(2, 2), embed_dim=60,
+                          num_heads=(6, 6), mlp_ratio=2, drop_path_rate=0.0)
+    sd0 = O.swinir_init_state_dict(cfg, seed=4)
+    model.netG.load_state_dict(sd0, strict=True)
+    for b in model.netG.swin_blocks():
+        b.drop_prob = 0.0
+    model.init_train()
+    assert model.loss_fn.n_holder == ['master_loss', 'charbonnier', 'norm_image_gradient_loss',
+                                      'local_variation_loss']          # the reference's order of addition
+    terms = model.loss_fn.terms()
+    gen = torch.Generator().manual_seed(2)
+    batch = {'l_im': torch.rand(2, 1, 16, 16, generator=gen), 'h_im': torch.rand(2, 1, 128, 128, generator=gen)}
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask")
+               else v) for k, v in sd0.items()}
+    names = [k for k, v in sdo.items() if v.requires_grad]
+    model.feed_data(batch)
+    model.optimize_parameters(epoch=0, current_step=0)
+    tot, holder = O.master_loss(O.swinir_forward(sdo, batch['l_im'], cfg), batch['h_im'], terms)
+    tot.backward()
+    model.current_log()
+    got = [float(v) for v in model.loss_fn.l_holder]
+    assert len(got) == len(holder) == 4
+    for a, b in zip(got, holder):
+        assert abs(a - float(b)) <= 1e-5 * max(1.0, abs(float(b))), (got, [float(h) for h in holder])
+    with torch.no_grad():
+        for k in names:
+            O.sgd_nesterov_step(sdo[k], sdo[k].grad, torch.zeros_like(sdo[k]), True, 0.01)
+    for k, p in model.netG.named_parameters():
+        e = (p.detach().cpu() - sdo[k].detach()).abs().max().item()
+        assert e <= 2e-6, f"{k}: {e}"
 
 
 def test_model_plain_nonfinite_loss_skips_update(tmp_path):
