@@ -91,14 +91,26 @@ __device__ __forceinline__ int wa_rpi(int query, int key) {
   return ((query >> 3) - (key >> 3) + 7) * 15 + ((query & 7) - (key & 7) + 7);
 }
 
+// Logical block index for XCD locality.  Hardware hands consecutive block indices to the 8
+// XCDs round robin, but the waves that share cache lines -- the heads of one window: a
+// head's 120-byte slice of a 2160-byte token row straddles the lines of its neighbours --
+// have consecutive LOGICAL indices.  Give XCD x the x-th contiguous run of logical indices,
+// so that those waves meet in one L2 instead of fetching the shared lines into several.
+__device__ __forceinline__ int wa_block(int remap) {
+  const int B = blockIdx.x, n = gridDim.x;
+  if (!remap) return B;
+  const int q = n >> 3, rem = n & 7, xcd = B & 7;
+  return xcd * q + min(xcd, rem) + (B >> 3);
+}
+
 template <int D>
 __global__ void __launch_bounds__(256) k_wattn_fwd(const float* __restrict__ qkv, float* __restrict__ out,
                                                    const float* __restrict__ biasT, long total, int H,
-                                                   int W, int C, int heads, int shift, float scale) {
+                                                   int W, int C, int heads, int shift, float scale, int remap) {
   constexpr int HD = D / 2;
   __shared__ __attribute__((aligned(16))) float smem[4][2][64 * D];
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-  const long gid = blockIdx.x * 4L + wv;
+  const long gid = wa_block(remap) * 4L + wv;
   if (gid >= total) return;               // no block-level barrier below
   const WaGeom g = wa_decode(gid, heads, W / 8, H / 8, shift);
   const int C3 = 3 * C;
@@ -227,15 +239,16 @@ template <int D>
 __global__ void __launch_bounds__(256, 3) k_wattn_bwd_q(
     const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
     const float* __restrict__ biasT, float* __restrict__ dbiasT, float* __restrict__ stats, int nwin,
-    int H, int W, int C, int heads, int shift, float scale) {
+    int H, int W, int C, int heads, int shift, float scale, int remap) {
   constexpr int HD = D / 2;
   static_assert(D <= 32, "head dim");
   __shared__ __attribute__((aligned(16))) float smem[4 * (64 + 32) * D];
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
   float* As = smem + wv * ((64 + 32) * D);     // full matrix: K, V, K again
   float* Bs = As + 64 * D;                     // half matrix: Q, dO rows of this query block
-  const int head = blockIdx.x % heads;
-  const int item = (blockIdx.x / heads) * 4 + wv;
+  const int lb = wa_block(remap);
+  const int head = lb % heads;
+  const int item = (lb / heads) * 4 + wv;
   const int qb = item & 1;
   // WA_NW consecutive windows per wave, one after the other: their d(bias) tiles are
   // summed in registers first (half the float atomics: 15 % of this kernel went there)
@@ -370,11 +383,11 @@ template <int D>
 __global__ void __launch_bounds__(256, 3) k_wattn_bwd_kv(
     const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
     const float* __restrict__ biasN, const float* __restrict__ stats, long total, int H, int W, int C,
-    int heads, int shift, float scale) {
+    int heads, int shift, float scale, int remap) {
   constexpr int HD = D / 2;
   __shared__ __attribute__((aligned(16))) float smem[4 * ((64 + 32) * D + 192)];
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-  const long item = blockIdx.x * 4L + wv;       // (window, head) x key block
+  const long item = wa_block(remap) * 4L + wv;       // (window, head) x key block
   if (item >= 2 * total) return;                // no block-level barrier below
   const int kb = (int)(item & 1);
   const WaGeom g = wa_decode(item >> 1, heads, W / 8, H / 8, shift);
@@ -516,6 +529,11 @@ int srhip_bias_grad(const float* dbiasT, float* dtable, int heads, void* stream)
   return 0;
 }
 
+static int wa_remap() {            // SRHIP_WA_XCD=0: plain block order (A/B switch)
+  static const int on = [] { const char* e = getenv("SRHIP_WA_XCD"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 static int wattn_check(int B, int H, int W, int C, int heads, int shift) {
   SR_REQUIRE(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0,
              "window_attention: H, W must be positive multiples of the 8x8 window (H=%d W=%d)", H, W);
@@ -539,7 +557,7 @@ int srhip_window_attention_fwd(const float* qkv, float* out, const float* biasT,
   // (a variant with one wave per 32-query half -- 3 whole rounds of waves instead of
   // 1.5 -- measured 35 % slower: K and V are then staged twice)
 #define SR_WA(D_) \
-  if (D == D_) hipLaunchKernelGGL((k_wattn_fwd<D_>), grid, blk, 0, st, qkv, out, biasT, total, H, W, C, heads, shift, scale);
+  if (D == D_) hipLaunchKernelGGL((k_wattn_fwd<D_>), grid, blk, 0, st, qkv, out, biasT, total, H, W, C, heads, shift, scale, wa_remap());
   SR_WA(30) SR_WA(10) SR_WA(16) SR_WA(32)
 #undef SR_WA
   SR_LAUNCH_CHECK("window_attention_fwd");
@@ -568,8 +586,8 @@ int srhip_window_attention_bwd(const float* qkv, const float* dout, float* dqkv,
   if (getenv("SRHIP_WA_NOATOMIC")) dbiasT = nullptr;   // timing experiment only (bias gradient is lost)
 #define SR_WA(D_) \
   if (D == D_) { \
-    hipLaunchKernelGGL((k_wattn_bwd_q<D_>), gq, blk, 0, st, qkv, dout, dqkv, biasT, dbiasT, workspace, nwin, H, W, C, heads, shift, scale); \
-    hipLaunchKernelGGL((k_wattn_bwd_kv<D_>), gkv, blk, 0, st, qkv, dout, dqkv, biasN, workspace, total, H, W, C, heads, shift, scale); \
+    hipLaunchKernelGGL((k_wattn_bwd_q<D_>), gq, blk, 0, st, qkv, dout, dqkv, biasT, dbiasT, workspace, nwin, H, W, C, heads, shift, scale, wa_remap()); \
+    hipLaunchKernelGGL((k_wattn_bwd_kv<D_>), gkv, blk, 0, st, qkv, dout, dqkv, biasN, workspace, total, H, W, C, heads, shift, scale, wa_remap()); \
   }
   SR_WA(30) SR_WA(10) SR_WA(16) SR_WA(32)
 #undef SR_WA
