@@ -284,6 +284,9 @@ class SwinIREngine:
         gh = buf("gh", T, hid)        # gelu(h): by-product of the dgelu epilogue, operand of the fc2 weight gradient
         dqkv = buf("dqkv", T, 3 * C)
         bi = len(self.blocks)
+        # bias-gradient images of all blocks (accumulated with atomics): ONE memset per step
+        dbT_all = buf("dbiasT_all", len(self.blocks), max(b.num_heads for b in self.blocks), 64, 64)
+        dbT_all.zero_()
         for li in reversed(range(len(net.layers))):
             layer = net.layers[li]
             t_in, t_blocks = sv["layers"][li]
@@ -313,8 +316,7 @@ class SwinIREngine:
                     ops.layernorm_bwd(dxh, x1, st2, g1, res=g)
                 # ---- attention branch: x1 = t + s1*(a Wp^T + bp)
                 ops.gemm_nt(g1, ws[f"{bi}.wpT"], None, out=da, epi=2, rowscale=s1, rows_per_scale=H * W)
-                dbT = buf("dbiasT", heads, 64, 64)
-                dbT.zero_()
+                dbT = dbT_all[bi, :heads]
                 ops.window_attention_bwd(qkv, da, dqkv, D.d[f"{bi}.biasT"], D.d[f"{bi}.biasN"], dbT, B, H,
                                          W, C, heads, blk.shift_size)
                 ops.bias_grad(dbT, G(p + "attn.relative_position_bias_table"))
