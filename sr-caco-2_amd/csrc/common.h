@@ -58,6 +58,16 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
   l = __builtin_bit_cast(unsigned, __builtin_convertvector(s, sr_bf16x2));
 }
 
+// ---- XCD-aware block order ----
+// Hardware deals consecutive block indices to the 8 XCDs (each with its own L2) round robin.
+// Blocks that share data -- neighbouring image tiles and their halos, the heads of one
+// attention window -- have consecutive LOGICAL indices: give XCD x the x-th contiguous run of
+// logical indices, so that they meet in one L2.  Bijection for any grid size n.
+__device__ __forceinline__ int sr_xcd_block(int B, int n) {
+  const int q = n >> 3, rem = n & 7, xcd = B & 7;
+  return xcd * q + min(xcd, rem) + (B >> 3);
+}
+
 // ---- wave-level reductions (wave = 64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

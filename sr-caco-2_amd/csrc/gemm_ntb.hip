@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
 
   int m0 = 0, img = 0, y0 = 0, x0 = 0;
   if (CONV) {
-    int t = blockIdx.x;
+    int t = p.xcd_order ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;   // neighbouring tiles (shared halos) in one L2
     const int tx = t % p.tiles_x; t /= p.tiles_x;
     const int ty = t % p.tiles_y; img = t / p.tiles_y;
     y0 = ty * TROWS; x0 = tx * 16;
@@ -351,6 +351,7 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
   if (CONV) {
     p.tiles_x = sr_cdiv(p.Wd, 16);
     p.tiles_y = sr_cdiv(p.H, wm == 2 ? 8 : 4);
+    p.xcd_order = ntb_env("SRHIP_CONV_XCD", 1);
   }
 #define SR_NTB_CASE(WM_, WN_) \
   if (wm == WM_ && wn == WN_) return launch_ntb<WM_, WN_, CONV>(p, st);

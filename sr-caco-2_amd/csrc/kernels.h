@@ -11,6 +11,7 @@ struct NtArgs {
   float* C; long ldc;
   int M, N, K;
   int n_tile;                 // set by the dispatcher
+  int xcd_order;              // conv: XCD-aware tile order (set by the dispatcher)
   const float* bias;          // [N] or null
   int a_mode;                 // 0 plain | 1 (x-mean)*rstd from ln_stats | 2 gelu(x)
   const float* ln_stats;      // [M][2] = mean, rstd

@@ -91,16 +91,12 @@ __device__ __forceinline__ int wa_rpi(int query, int key) {
   return ((query >> 3) - (key >> 3) + 7) * 15 + ((query & 7) - (key & 7) + 7);
 }
 
-// Logical block index for XCD locality.  Hardware hands consecutive block indices to the 8
-// XCDs round robin, but the waves that share cache lines -- the heads of one window: a
-// head's 120-byte slice of a 2160-byte token row straddles the lines of its neighbours --
-// have consecutive LOGICAL indices.  Give XCD x the x-th contiguous run of logical indices,
-// so that those waves meet in one L2 instead of fetching the shared lines into several.
+// Logical block index for XCD locality (sr_xcd_block, common.h): the waves that share cache
+// lines -- the heads of one window: a head's 120-byte slice of a 2160-byte token row straddles
+// the lines of its neighbours -- have consecutive logical indices and so meet in one L2
+// instead of fetching the shared lines into several.
 __device__ __forceinline__ int wa_block(int remap) {
-  const int B = blockIdx.x, n = gridDim.x;
-  if (!remap) return B;
-  const int q = n >> 3, rem = n & 7, xcd = B & 7;
-  return xcd * q + min(xcd, rem) + (B >> 3);
+  return remap ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
 }
 
 template <int D>
