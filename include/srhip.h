@@ -249,6 +249,16 @@ int srhip_ssim_loss(const float* pred, const float* target, float* grad, float* 
 int srhip_loss_pointwise(const float* pred, const float* target, const float* weight, float* grad, float* loss_out,
                          double* workspace, long n, int mode, float lam, float eps, int grad_accum, int loss_accum,
                          void* stream);
+/* BoundedPrediction (dlib/loss/main.py:189-237) with the extended log barrier of dlib/losses/elb.py:92-122 at
+ * barrier parameter t: lam * (mean elb(s*pred - (s*target + eps)) + mean elb(s*target - eps - s*pred)) / 2,
+ * s = scale (color_max when restore_range, else 1).  Value + gradient.  workspace: 2048 doubles. */
+int srhip_loss_bounded(const float* pred, const float* target, float* grad, float* loss_out, double* workspace,
+                       long n, float lam, float eps, float t, float scale, int grad_accum, int loss_accum,
+                       void* stream);
+/* WeightsSparsityLoss (dlib/loss/main.py:938-959) on a flat parameter range: loss_out (+)= lam * sum|w|,
+ * grad[i] += lam * sign(w[i]) (grad may be null).  workspace: 2048 doubles. */
+int srhip_l1_sparsity(const float* w, float* grad, float* loss_out, double* workspace, long n, float lam,
+                      int loss_accum, void* stream);
 /* Local-variation terms on 1-channel images [B][H][W] (dlib/loss/main.py:328-674 with the operators of
  * dlib/loss/local_variations.py:18-141, replicate padding): op 0 image gradient (2 stencils), 1 Laplacian
  * (1), 2 local variation over a ksz x ksz window (ksz^2 - 1 stencils; ksz 3, 5 or 7).  norm 1 | 2 = the

@@ -475,6 +475,60 @@ def g_losses_extra():
     npz("g9_losses_extra", **out)
 
 
+def g_losses_elb():
+    print("G10 BoundedPrediction (ELB) and WeightsSparsityLoss")
+    from dlib.losses.elb import ELB           # reference
+    torch.manual_seed(23)
+    pred, tgt = torch.rand(2, 1, 24, 40), torch.rand(2, 1, 24, 40)
+    pred[0, :, :4] = tgt[0, :, :4]            # inside the band
+    pred[1, :, :4] = tgt[1, :, :4] + 0.004    # close to the upper bound with restore_range
+    out = dict(pred=pred, target=tgt)
+    cases = {"rr_t1": (1.0, 1.0, True, 0), "rr_t3upd": (0.5, 2.0, True, 3), "raw_t1": (1.0, 0.01, False, 0),
+             "raw_t40upd": (2.0, 0.05, False, 40)}
+    for name, (lam, eps, rr, upd) in cases.items():
+        e = ELB(init_t=1., max_t=10., mulcoef=1.01)
+        l = ref_loss.BoundedPrediction(cuda_id="cpu", lambda_=lam, elb=e, restore_range=rr, color_max=255)
+        l.set_eps(eps)
+        m = ref_loss.MasterLoss(cuda_id="cpu")
+        m.add(l)
+        # MasterLoss.update_t() is a no-op for this term in the reference: core.py:12,80-82 tests
+        # isinstance(self.elb, dlib.loss.elb.ELB) while utils_instance.py:16,44 builds a
+        # dlib.losses.elb.ELB (two copies of the class) -- t stays at init_t through the trainer.
+        m.update_t()
+        assert float(l.elb.get_t()) == 1.0
+        for _ in range(upd):                 # the barrier schedule itself (elb.py:85-90), driven directly
+            l.elb.update_t()
+        t = float(l.elb.get_t())
+        close(torch.tensor(O.elb_t_after(upd)), torch.tensor(t), 0.0, f"t after {upd} updates")
+        pr = pred.clone().requires_grad_(True)
+        v = m(epoch=0, y_pred=pr, y_target=tgt, trg_per_pixel_weight=None, model=None)
+        v.backward()
+        po = pred.clone().requires_grad_(True)
+        vo = O.loss_bounded_prediction(po, tgt, lam, eps, t, rr, 255)
+        vo.backward()
+        close(vo.detach(), v.detach(), 2e-6 * max(1.0, abs(float(v))), f"boundpred {name}")
+        close(po.grad, pr.grad, 5e-7 * max(1.0, float(pr.grad.abs().max())), f"d boundpred {name}")
+        out[f"{name}/value"], out[f"{name}/grad"], out[f"{name}/t"] = v.detach(), pr.grad, np.float32(t)
+        out[f"{name}/cfg"] = np.array([lam, eps, float(rr), upd], dtype=np.float64)
+        out[f"{name}/names"] = np.array(m.n_holder)
+    # weights sparsity on a small module
+    net = nn.Sequential(nn.Conv2d(1, 4, 3), nn.Linear(5, 3))
+    with torch.no_grad():
+        net[1].weight[0, :2] = 0.0            # sign(0) = 0
+    ws = ref_loss.WeightsSparsityLoss(cuda_id="cpu", lambda_=0.3)
+    v = ws(epoch=0, y_pred=None, y_target=None, model=net)
+    v.backward()
+    params = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+    vo = O.loss_weights_sparsity(params, 0.3)
+    vo.backward()
+    close(vo.detach(), v.detach().reshape(()), 1e-6, "w_sparsity")
+    for i, (p, q) in enumerate(zip(net.parameters(), params)):
+        close(q.grad, p.grad, 0.0, f"d w_sparsity {i}")
+        out[f"ws/p{i}"], out[f"ws/g{i}"] = p.detach(), p.grad
+    out["ws/value"] = v.detach().reshape(())
+    npz("g10_losses_elb", **out)
+
+
 # ---------------------------------------------------------------- G7 metrics
 def g_metrics():
     print("G7 metrics")
@@ -562,7 +616,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra,
+    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb,
             g_metrics, g_optim]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

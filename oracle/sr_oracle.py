@@ -436,6 +436,40 @@ def loss_local_variation(pred: Tensor, target: Tensor, kind: str, lam: float = 1
     return lam * (e.abs() if norm == 1 else e * e).mean()
 
 
+def elb(z: Tensor, t: float) -> Tensor:
+    """Extended log barrier, mean over the vector (dlib/losses/elb.py:92-122); ``t`` as the
+    reference's float32 buffer ``t_lb``."""
+    t = torch.tensor(t, dtype=torch.float32)
+    ct = -(1. / (t ** 2))
+    less = z <= ct
+    zs = torch.where(less, z, torch.full_like(z, -1.0))      # keep log() off the other branch
+    v_less = -(1. / t) * torch.log(-zs)
+    v_great = t * z - (1. / t) * torch.log(1. / (t ** 2)) + (1. / t)
+    return torch.where(less, v_less, v_great).mean()
+
+
+def elb_t_after(updates: int, init_t: float = 1., max_t: float = 10., mulcoef: float = 1.01) -> float:
+    """t after ``updates`` calls of ELB.update_t (elb.py:85-90), in float32."""
+    t = torch.tensor([init_t], dtype=torch.float32)
+    for _ in range(updates):
+        t = torch.min(t * torch.tensor([mulcoef], dtype=torch.float32), torch.tensor([max_t], dtype=torch.float32))
+    return float(t)
+
+
+def loss_bounded_prediction(pred: Tensor, target: Tensor, lam: float = 1.0, eps: float = 0.0, t: float = 1.0,
+                            restore_range: bool = False, color_max: int = 255) -> Tensor:
+    """loss/main.py:189-237: y - eps <= y_hat <= y + eps through two ELB terms."""
+    yh, y = pred.reshape(-1), target.reshape(-1)
+    if restore_range:
+        yh, y = yh * color_max, y * color_max
+    return lam * (elb(yh - (y + eps), t) + elb(y - eps - yh, t)) / 2.
+
+
+def loss_weights_sparsity(params: Sequence[Tensor], lam: float = 1.0) -> Tensor:
+    """loss/main.py:938-959: lambda * sum_w ||w||_1."""
+    return lam * sum(p.abs().sum() for p in params)
+
+
 def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
                 weight: Optional[Tensor] = None) -> Tuple[Tensor, List[Tensor]]:
     """loss/master.py:46-56.  ``terms``: ('l1',lam) | ('l2',lam) |
@@ -454,6 +488,8 @@ def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
             parts.append(loss_charbonnier(pred, target, t[1], t[2]))
         elif t[0] == "l2sum":
             parts.append(loss_l2sum(pred, target, t[1]))
+        elif t[0] == "boundpred":          # (kind, lam, eps, t, restore_range, color_max)
+            parts.append(loss_bounded_prediction(pred, target, t[1], t[2], t[3], t[4], t[5]))
         elif t[0] in ("grad", "laplace", "lv", "norm_grad", "norm_laplace", "norm_lv"):
             # (kind, lam, norm[, ksz])
             parts.append(loss_local_variation(pred, target, t[0].replace("norm_", ""), t[1], t[2],

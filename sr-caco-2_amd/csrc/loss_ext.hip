@@ -50,6 +50,54 @@ __global__ void __launch_bounds__(256) k_loss_pointwise(const float* __restrict_
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// BoundedPrediction (dlib/loss/main.py:189-237) through the extended log barrier
+// (dlib/losses/elb.py:92-122):  y - eps <= y_hat <= y + eps  as two inequality constraints
+//   z_r = y_hat - (y + eps) <= 0,  z_l = (y - eps) - y_hat <= 0   (both scaled by color_max if restore_range)
+//   elb(z) = -(1/t) log(-z)                        for z <= -1/t^2
+//          =  t z - (1/t) log(1/t^2) + 1/t         otherwise
+// loss = lam * (mean elb(z_r) + mean elb(z_l)) / 2.  The constants follow the reference's f32 tensor
+// arithmetic (ct = -(1/t^2); 1/t; log(1/t^2)).
+__global__ void __launch_bounds__(256) k_loss_bounded(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                      float* __restrict__ grad, double* __restrict__ part, long n,
+                                                      float eps, float t, float scale, float gs, int grad_accum) {
+  __shared__ double sh[4];
+  const float t2 = t * t, inv_t2 = 1.f / t2, ct = -inv_t2, inv_t = 1.f / t;
+  const float c_great = inv_t * logf(inv_t2);
+  double acc = 0.0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float yh = pred[i] * scale, y = tgt[i] * scale;
+    const float zr = yh - (y + eps), zl = y - eps - yh;
+    float v = 0.f, g = 0.f;
+    if (zr <= ct) { v += -inv_t * logf(-zr); g += -inv_t / zr; }
+    else { v += t * zr - c_great + inv_t; g += t; }
+    if (zl <= ct) { v += -inv_t * logf(-zl); g -= -inv_t / zl; }
+    else { v += t * zl - c_great + inv_t; g -= t; }
+    acc += (double)v;
+    if (grad) grad[i] = grad_accum ? grad[i] + gs * g : gs * g;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// WeightsSparsityLoss (dlib/loss/main.py:938-959): lam * sum |w| over the (flat) parameters;
+// d/dw = lam * sign(w), ACCUMULATED into the parameter gradients.
+__global__ void __launch_bounds__(256) k_l1_sparsity(const float* __restrict__ w, float* __restrict__ grad,
+                                                     double* __restrict__ part, long n, float lam) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = w[i];
+    acc += (double)fabsf(v);
+    if (grad) grad[i] += v > 0.f ? lam : (v < 0.f ? -lam : 0.f);
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 __global__ void __launch_bounds__(1024) k_sum_partials_d(const double* __restrict__ part, int n, double scale,
                                                          float* __restrict__ out, int accum) {
   __shared__ double sh[16];
@@ -261,6 +309,33 @@ int srhip_loss_pointwise(const float* pred, const float* target, const float* we
                      (float)((double)lam / denom), eps, grad_accum);
   hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(1024), 0, st, workspace, g, (double)lam / denom, loss_out, loss_accum);
   SR_LAUNCH_CHECK("loss_pointwise");
+  return 0;
+}
+
+int srhip_loss_bounded(const float* pred, const float* target, float* grad, float* loss_out, double* workspace,
+                       long n, float lam, float eps, float t, float scale, int grad_accum, int loss_accum,
+                       void* stream) {
+  SR_REQUIRE(n > 0, "loss_bounded: empty input");
+  SR_REQUIRE(eps >= 0.f && t > 0.f && scale > 0.f, "loss_bounded: eps >= 0, t > 0, scale > 0 (eps=%g t=%g scale=%g)",
+             (double)eps, (double)t, (double)scale);
+  hipStream_t st = (hipStream_t)stream;
+  const int g = ew_blocks(n);
+  const double k = (double)lam / (2.0 * (double)n);
+  hipLaunchKernelGGL(k_loss_bounded, dim3(g), dim3(256), 0, st, pred, target, grad, workspace, n, eps, t, scale,
+                     (float)(k * (double)scale), grad_accum);
+  hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(1024), 0, st, workspace, g, k, loss_out, loss_accum);
+  SR_LAUNCH_CHECK("loss_bounded");
+  return 0;
+}
+
+int srhip_l1_sparsity(const float* w, float* grad, float* loss_out, double* workspace, long n, float lam,
+                      int loss_accum, void* stream) {
+  SR_REQUIRE(n > 0, "l1_sparsity: empty input");
+  hipStream_t st = (hipStream_t)stream;
+  const int g = ew_blocks(n);
+  hipLaunchKernelGGL(k_l1_sparsity, dim3(g), dim3(256), 0, st, w, grad, workspace, n, lam);
+  hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(1024), 0, st, workspace, g, (double)lam, loss_out, loss_accum);
+  SR_LAUNCH_CHECK("l1_sparsity");
   return 0;
 }
 

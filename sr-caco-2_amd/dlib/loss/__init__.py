@@ -10,8 +10,9 @@ produces the value and d loss / d y_pred together; autograd only scales that
 stored gradient.  Of the reference's 13 optional terms (off by default,
 utils_config.py:279-374) Charbonnier, L2Sum, ImageGradientLoss, LaplacianFilterLoss,
 LocalVariationLoss and their three Norm* variants are built the same way
-(dlib/loss/main.py:102-151,328-674); BoundedPrediction, LocalMoments, HistogramMatch,
-KDEMatch, CrossEntropyL and WeightsSparsityLoss are not (NotImplementedError on use).
+(dlib/loss/main.py:102-151,328-674), as are BoundedPrediction (extended log barrier,
+:189-237 + dlib/losses/elb.py) and WeightsSparsityLoss (:938-959); LocalMoments, HistogramMatch,
+KDEMatch and CrossEntropyL are not (NotImplementedError on use).
 """
 import re
 
@@ -22,7 +23,7 @@ from srhip import ops
 
 __all__ = ['MasterLoss', 'ElementaryLoss', 'L1', 'L2', 'NegativeSsim', 'L2Sum', 'Charbonnier',
            'ImageGradientLoss', 'LaplacianFilterLoss', 'LocalVariationLoss', 'NormImageGradientLoss',
-           'NormLaplacianFilterLoss', 'NormLocalVariationLoss']
+           'NormLaplacianFilterLoss', 'NormLocalVariationLoss', 'BoundedPrediction', 'WeightsSparsityLoss']
 
 NORM1, NORM2 = '1', '2'      # dlib/utils/constants.py:696-697
 
@@ -79,7 +80,10 @@ class ElementaryLoss(nn.Module):
         return e <= t if s is None else e >= s
 
     def update_t(self):
-        if hasattr(self.elb, "update_t"):
+        # core.py:80-82 tests for dlib.loss.elb.ELB -- NOT the dlib.losses.elb.ELB that define_loss
+        # builds (see dlib/loss/elb.py): kept, so the barrier schedule behaves as in the reference
+        from dlib.loss.elb import ELB as _CoreELB
+        if isinstance(self.elb, _CoreELB):
             self.elb.update_t()
 
     @property
@@ -173,6 +177,66 @@ class Charbonnier(ElementaryLoss):
         t = y_target.float().contiguous()
         return _FusedLoss.apply(
             y_pred, lambda p, g, v: ops.loss_pointwise(p, t, 2, self.lambda_, self.eps, grad=g, loss_out=v))
+
+
+class BoundedPrediction(ElementaryLoss):
+    """y - eps <= y_hat <= y + eps as two extended-log-barrier terms: lambda * (ELB(y_hat - y - eps) +
+    ELB(y - eps - y_hat)) / 2, on [0, color_max] when restore_range; dlib/loss/main.py:189-237."""
+
+    def __init__(self, restore_range=False, color_min=0, color_max=255, **kwargs):
+        super().__init__(**kwargs)
+        from dlib.losses.elb import ELB
+        assert isinstance(self.elb, ELB)            # main.py:193 (the dlib.losses copy)
+        assert isinstance(color_max, int) and color_min < color_max
+        self.restore_range, self.color_min, self.color_max = restore_range, color_min, color_max
+        self.eps = 0.0
+        self.eps_already_set = False
+
+    def set_eps(self, eps):
+        assert eps >= 0, eps
+        assert isinstance(eps, float), type(eps)
+        self.eps = eps
+        self.eps_already_set = True
+
+    def forward(self, epoch, y_pred=None, y_target=None, trg_per_pixel_weight=None, model=None):
+        super().forward(epoch=epoch)
+        if not self.is_on():
+            return self._zero
+        assert y_target.shape == y_pred.shape, f'{y_target.shape}, {y_pred.shape}'
+        t = y_target.float().contiguous()
+        tb = float(self.elb.get_t())
+        sc = float(self.color_max) if self.restore_range else 1.0
+        return _FusedLoss.apply(y_pred, lambda p, g, v: ops.loss_bounded(
+            p, t, self.lambda_, self.eps, tb, sc, grad=g, loss_out=v))
+
+
+class _SparsityFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lam, *params):
+        val = torch.zeros(1, device=params[0].device, dtype=torch.float32)
+        for p in params:
+            if not p.is_cuda:
+                raise RuntimeError("dlib.loss (libsrhip) runs on the GPU only; there is no CPU fallback")
+            ops.l1_sparsity(p.detach().contiguous().view(-1), lam, None, val, loss_accum=True)
+        ctx.save_for_backward(*params)
+        ctx.lam = lam
+        return val.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(torch.sign(p) * (ctx.lam * g) for p in ctx.saved_tensors)
+
+
+class WeightsSparsityLoss(ElementaryLoss):
+    """lambda * sum over model.parameters() of ||w||_1; dlib/loss/main.py:938-959.  (In the fused
+    training step the term is one kernel over the flat parameter buffer: srhip.train.TrainStep.)"""
+
+    def forward(self, epoch, y_pred=None, y_target=None, trg_per_pixel_weight=None, model=None):
+        super().forward(epoch=epoch)
+        assert model is not None
+        if not self.is_on():
+            return self._zero
+        return _SparsityFn.apply(self.lambda_, *list(model.parameters()))
 
 
 class _LocalVariationTerm(ElementaryLoss):
@@ -275,6 +339,11 @@ class MasterLoss(nn.Module):
                 out.append(("charbonnier", l.lambda_, l.eps))
             elif isinstance(l, L2Sum):
                 out.append(("l2sum", l.lambda_))
+            elif isinstance(l, BoundedPrediction):
+                # the ELB module itself rides along: its t can change between steps
+                out.append(("boundpred", l.lambda_, l.eps, l.elb, l.restore_range, l.color_max))
+            elif isinstance(l, WeightsSparsityLoss):
+                out.append(("w_sparsity", l.lambda_))
             elif isinstance(l, _LocalVariationTerm):
                 out.append((("norm_" if l.channel_norm else "") + l.kind, l.lambda_,
                             1 if l.norm_str == NORM1 else 2, l.ksz))

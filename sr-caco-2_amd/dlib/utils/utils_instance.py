@@ -25,6 +25,16 @@ def define_loss(args):
         l = losses.Charbonnier(cuda_id=dev, lambda_=tr.get('charbonnier_lambda', 1.))
         l.set_eps(tr.get('charbonnier_eps', 1e-9))
         m.add(l)
+    if tr.get('boundpred', False):
+        from dlib.losses.elb import ELB          # utils_instance.py:16,44-45
+        elb = ELB(init_t=float(tr.get('elb_init_t', 1.)), max_t=float(tr.get('elb_max_t', 10.)),
+                  mulcoef=float(tr.get('elb_mulcoef', 1.01)))
+        assert not tr.get('boundpred_use_residuals', False), "use_residuals is not on the hot path"
+        l = losses.BoundedPrediction(cuda_id=dev, lambda_=tr.get('boundpred_lambda', 1.), elb=elb,
+                                     restore_range=tr.get('boundpred_restore_range', True),
+                                     color_max=int(getattr(args, 'color_max', None) or 255))
+        l.set_eps(float(tr.get('boundpred_eps', 1.)))
+        m.add(l)
     for key, cls, norm_key in (('img_grad', losses.ImageGradientLoss, 'img_grad_norm'),
                                ('norm_img_grad', losses.NormImageGradientLoss, 'norm_img_grad_type'),
                                ('laplace', losses.LaplacianFilterLoss, 'laplace_norm'),
@@ -39,9 +49,11 @@ def define_loss(args):
             else:
                 l.set_it(norm_str=str(tr.get(norm_key, constants.NORM2)))
             m.add(l)
-    for k in ('boundpred', 'local_moments', 'hist', 'kde', 'ce', 'w_sparsity'):
+    for k in ('local_moments', 'hist', 'kde', 'ce'):
         if tr.get(k, False):
             raise NotImplementedError(f"loss term --{k} is outside the libsrhip hot path")
+    if tr.get('w_sparsity', False):               # last, as in the reference (utils_instance.py:202-208)
+        m.add(losses.WeightsSparsityLoss(cuda_id=dev, lambda_=tr.get('w_sparsity_lambda', 1.)))
     assert len(m.n_holder) > 1, "no loss term enabled"
     return m
 

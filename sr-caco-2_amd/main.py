@@ -70,6 +70,9 @@ def get_config(net_type):
                   # optional terms (utils_config.py:296-357)
                   'l2sum': False, 'l2sum_lambda': 1., 'charbonnier': False, 'charbonnier_lambda': 1.,
                   'charbonnier_eps': 1e-9,
+                  'boundpred': False, 'boundpred_lambda': 1., 'boundpred_eps': 1., 'boundpred_restore_range': True,
+                  'elb_init_t': 1., 'elb_max_t': 10., 'elb_mulcoef': 1.01,
+                  'w_sparsity': False, 'w_sparsity_lambda': 1.,
                   'img_grad': False, 'img_grad_lambda': 1., 'img_grad_norm': constants.NORM2,
                   'norm_img_grad': False, 'norm_img_grad_lambda': 1., 'norm_img_grad_type': constants.NORM2,
                   'laplace': False, 'laplace_lambda': 1., 'laplace_norm': constants.NORM2,

@@ -498,6 +498,30 @@ def loss_pointwise(pred, target, mode, lam=1.0, eps=1e-9, weight=None, grad=None
     return loss_out
 
 
+def loss_bounded(pred, target, lam=1.0, eps=0.0, t=1.0, scale=1.0, grad=None, loss_out=None,
+                 grad_accum=False, loss_accum=False):
+    """BoundedPrediction through the extended log barrier at parameter t (dlib/loss/main.py:189-237,
+    dlib/losses/elb.py:92-122); scale = color_max with restore_range."""
+    _chk(pred, target, grad, loss_out)
+    if loss_out is None:
+        loss_out = torch.empty(1, device=pred.device, dtype=torch.float32)
+    ws = SCRATCH.get("loss_ws", 2048, torch.float64, pred.device)
+    call("srhip_loss_bounded", _p(pred), _p(target), _p(grad), _p(loss_out), _p(ws), pred.numel(),
+         float(lam), float(eps), float(t), float(scale), int(grad_accum), int(loss_accum), _st())
+    return loss_out
+
+
+def l1_sparsity(w, lam=1.0, grad=None, loss_out=None, loss_accum=False):
+    """WeightsSparsityLoss on a flat parameter range (dlib/loss/main.py:938-959): loss_out (+)= lam*sum|w|,
+    grad += lam*sign(w)."""
+    _chk(w, grad, loss_out)
+    if loss_out is None:
+        loss_out = torch.empty(1, device=w.device, dtype=torch.float32)
+    ws = SCRATCH.get("loss_ws", 2048, torch.float64, w.device)
+    call("srhip_l1_sparsity", _p(w), _p(grad), _p(loss_out), _p(ws), w.numel(), float(lam), int(loss_accum), _st())
+    return loss_out
+
+
 STENCIL_OPS = {"grad": 0, "laplace": 1, "lv": 2}
 
 

@@ -139,6 +139,7 @@ class TrainStep:
         self.ddp = world_size > 1 or os.environ.get("SRHIP_FORCE_DDP", "0") == "1"
         dev = self.fp.flat.device
         self.loss_buf = torch.zeros(1 + len(self.loss_terms), device=dev)
+        self._sink = torch.zeros(1, device=dev)
         self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.ddp else None
         self.buckets = self._make_buckets() if self.ddp else []
@@ -169,6 +170,14 @@ class TrainStep:
                 ops.ssim_loss(y, target, t[2], t[1], self.dy, part, grad_accum=not first)
             elif t[0] == "charbonnier":
                 ops.loss_pointwise(y, target, 2, t[1], t[2], None, self.dy, part, grad_accum=not first)
+            elif t[0] == "boundpred":       # (kind, lam, eps, ELB module | t, restore_range, color_max)
+                tb = float(t[3].get_t()) if hasattr(t[3], "get_t") else float(t[3])
+                ops.loss_bounded(y, target, t[1], t[2], tb, float(t[5]) if t[4] else 1.0, self.dy, part,
+                                 grad_accum=not first)
+            elif t[0] == "w_sparsity":      # value here; its gradient is added after backward (step())
+                ops.l1_sparsity(self.fp.flat, t[1], None, part)
+                if first:
+                    self.dy.zero_()
             elif t[0] == "l2sum":
                 ops.loss_pointwise(y, target, 3, t[1], grad=self.dy, loss_out=part, grad_accum=not first)
             elif t[0].replace("norm_", "") in ops.STENCIL_OPS:
@@ -196,6 +205,9 @@ class TrainStep:
         if self.ddp:
             self._allreduce_bucket(len(self.buckets) - 1)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        for t in self.loss_terms:            # parameter-space term: lam*sign(w) joins the (summed) gradients;
+            if t[0] == "w_sparsity":         # x world because the optimizer divides the all-reduced sum by it
+                ops.l1_sparsity(self.fp.flat, t[1] * self.world, self.fp.grad, self._sink)
         # one device flag: non-finite loss -> the optimizer kernel skips the update
         ops.nonfinite_flag(self.loss_buf, self.flag)
         self.opt.step(gscale=1.0 / self.world, skip_flag=self.flag)

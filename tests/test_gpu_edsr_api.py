@@ -148,6 +148,44 @@ def test_dlib_optional_loss_terms_vs_reference_golden():
             assert m.terms()[0][0] == term[0]
 
 
+def test_dlib_bounded_prediction_and_sparsity_vs_reference_golden():
+    """BoundedPrediction (ELB) and WeightsSparsityLoss through dlib.loss against the reference goldens; the
+    barrier schedule and the reference's update_t quirk (dlib.loss.elb vs dlib.losses.elb)."""
+    from dlib import loss as L
+    from dlib.losses.elb import ELB
+    g = load("g10_losses_elb")
+    for name in ("rr_t1", "rr_t3upd", "raw_t1", "raw_t40upd"):
+        lam, eps, rr, upd = [float(v) for v in g[name + "/cfg"]]
+        l = L.BoundedPrediction(cuda_id=0, lambda_=lam, elb=ELB(init_t=1., max_t=10., mulcoef=1.01),
+                                restore_range=bool(rr), color_max=255)
+        l.set_eps(eps)
+        m = L.MasterLoss(cuda_id=0)
+        m.add(l)
+        m.update_t()                                   # no-op for this term, as in the reference
+        assert float(l.elb.get_t()) == 1.0
+        for _ in range(int(upd)):
+            l.elb.update_t()
+        assert float(l.elb.get_t()) == float(g[name + "/t"])
+        p = g["pred"].cuda().requires_grad_(True)
+        v = m(epoch=0, y_pred=p, y_target=g["target"].cuda(), trg_per_pixel_weight=None, model=None)
+        v.backward()
+        rv, rg = g[name + "/value"], g[name + "/grad"]
+        assert abs(float(v) - float(rv)) <= 5e-6 * max(1.0, abs(float(rv))), (name, float(v), float(rv))
+        assert (p.grad.cpu() - rg).abs().max() <= 5e-6 * max(1.0, float(rg.abs().max())), name
+        assert m.n_holder == list(g[name + "/names"])
+    net = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.Linear(5, 3))
+    with torch.no_grad():
+        for i, q in enumerate(net.parameters()):
+            q.copy_(g[f"ws/p{i}"])
+    net = net.cuda()
+    ws = L.WeightsSparsityLoss(cuda_id=0, lambda_=0.3)
+    v = ws(epoch=0, y_pred=None, y_target=None, model=net)
+    v.backward()
+    assert abs(float(v) - float(g["ws/value"])) <= 1e-6
+    for i, q in enumerate(net.parameters()):
+        assert torch.equal(q.grad.cpu(), g[f"ws/g{i}"])
+
+
 def test_optional_loss_terms_full_size_properties():
     """At the benchmark's 8 x 512 x 512: linearity of the plain local-variation terms in the difference
     (loss(pred, target) == loss(pred - target, 0)), zero loss / zero gradient at pred == target, tile-seam
@@ -294,7 +332,9 @@ def test_model_plain_step_with_optional_loss_terms(tmp_path):
     args['outd'] = str(tmp_path)
     args['train'].update({'l1': False, 'charbonnier': True, 'charbonnier_eps': 1e-6, 'loc_var': True,
                           'loc_var_ksz': 5, 'loc_var_norm': '1', 'loc_var_lambda': 0.5, 'norm_img_grad': True,
-                          'norm_img_grad_type': '2', 'norm_img_grad_lambda': 2.0})
+                          'norm_img_grad_type': '2', 'norm_img_grad_lambda': 2.0, 'boundpred': True,
+                          'boundpred_eps': 2.0, 'boundpred_lambda': 0.25, 'w_sparsity': True,
+                          'w_sparsity_lambda': 1e-4})
     model = define_model(args)
     cfg = O.swinir_config(upscale=8, in_chans=1, img_size=16, window_size=8, depths=(2, 2), embed_dim=60,
                           num_heads=(6, 6), mlp_ratio=2, drop_path_rate=0.0)
@@ -303,9 +343,11 @@ def test_model_plain_step_with_optional_loss_terms(tmp_path):
     for b in model.netG.swin_blocks():
         b.drop_prob = 0.0
     model.init_train()
-    assert model.loss_fn.n_holder == ['master_loss', 'charbonnier', 'norm_image_gradient_loss',
-                                      'local_variation_loss']          # the reference's order of addition
-    terms = model.loss_fn.terms()
+    assert model.loss_fn.n_holder == ['master_loss', 'charbonnier', 'bounded_prediction',
+                                      'norm_image_gradient_loss', 'local_variation_loss',
+                                      'weights_sparsity_loss']         # the reference's order of addition
+    terms = [(t[0], t[1], t[2], 1.0, t[4], t[5]) if t[0] == "boundpred" else t
+             for t in model.loss_fn.terms() if t[0] != "w_sparsity"]
     gen = torch.Generator().manual_seed(2)
     batch = {'l_im': torch.rand(2, 1, 16, 16, generator=gen), 'h_im': torch.rand(2, 1, 128, 128, generator=gen)}
     sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask")
@@ -314,10 +356,13 @@ def test_model_plain_step_with_optional_loss_terms(tmp_path):
     model.feed_data(batch)
     model.optimize_parameters(epoch=0, current_step=0)
     tot, holder = O.master_loss(O.swinir_forward(sdo, batch['l_im'], cfg), batch['h_im'], terms)
+    wsp = O.loss_weights_sparsity([sdo[k] for k in names], 1e-4)
+    tot = tot + wsp
+    holder = [tot] + holder[1:] + [wsp]
     tot.backward()
     model.current_log()
     got = [float(v) for v in model.loss_fn.l_holder]
-    assert len(got) == len(holder) == 4
+    assert len(got) == len(holder) == 6
     for a, b in zip(got, holder):
         assert abs(a - float(b)) <= 1e-5 * max(1.0, abs(float(b))), (got, [float(h) for h in holder])
     with torch.no_grad():
