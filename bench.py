@@ -132,10 +132,11 @@ def main():
         probe.enable("gemm_nt")
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # HIP events around every NT-GEMM launch of every 10th step (an event is a barrier
+        # HIP events around every NT-GEMM launch of every 20th step (an event is a barrier
         # packet on the stream: a probed step runs ~18 % slower, so probing all of them
-        # would cost the headline number; 2 of the default 20 steps = 384 timed launches)
-        probe.active = "gemm_nt" if (not args.no_roofline and i % 10 == 0) else None
+        # would cost the headline number; 1 of the default 20 steps = 192 timed launches,
+        # taken mid-run)
+        probe.active = "gemm_nt" if (not args.no_roofline and i % 20 == 10 % max(args.steps, 1)) else None
         ts.step(lr_img, hr_img)
     barrier()
     dt = time.perf_counter() - t0

@@ -100,34 +100,41 @@ __device__ __forceinline__ int wa_block(int remap) {
 }
 
 template <int D>
-__global__ void __launch_bounds__(256) k_wattn_fwd(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ void __launch_bounds__(256, 3) k_wattn_fwd(const float* __restrict__ qkv, float* __restrict__ out,
                                                    const float* __restrict__ biasT, long total, int H,
                                                    int W, int C, int heads, int shift, float scale, int remap) {
   constexpr int HD = D / 2;
-  __shared__ __attribute__((aligned(16))) float smem[4][2][64 * D];
+  __shared__ __attribute__((aligned(16))) float smem[4][64 * D];
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
   const long gid = wa_block(remap) * 4L + wv;
   if (gid >= total) return;               // no block-level barrier below
   const WaGeom g = wa_decode(gid, heads, W / 8, H / 8, shift);
   const int C3 = 3 * C;
   const int mytok = wa_token(g, lane, H, W, shift);
-  float* Ks = smem[wv][0];
-  float* Qs = smem[wv][1];
+  // ONE 64 x D staging buffer per wave (7.7 KB at D = 30), used for Q, then K, then V: the MFMA
+  // fragments of Q and K live in registers, so the buffer is free again as soon as they are read.
+  // With two buffers a block held 61 KB -> 8 waves per CU and the 3072 (window, head) waves of the
+  // benchmark ran as 1.5 rounds; with one buffer and <= 168 registers 12 waves per CU = one round.
+  float* Ks = smem[wv];
   const float* hb = qkv + g.head * D;
-  wa_stage<D>(Qs, hb, C3, mytok, lane);
-  wa_stage<D>(Ks, hb + C, C3, mytok, lane);
+  float2 vreg[D / 2], kreg[D / 2];
+  wa_stage_load<D>(vreg, hb, C3, mytok, lane);            // Q
+  wa_stage_load<D>(kreg, hb + C, C3, mytok, lane);        // K
+  wa_stage_store<D>(Ks, vreg, lane);
   __builtin_amdgcn_wave_barrier();
-
-  float2 vreg[D / 2];                       // V on its way while S^T is computed
-  wa_stage_load<D>(vreg, hb + 2 * C, C3, mytok, lane);
   float qf[2][HD], kf[2][HD];
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-    for (int t = 0; t < HD; ++t) {
-      qf[blk][t] = Qs[(r + 32 * blk) * D + h * HD + t];
-      kf[blk][t] = Ks[(r + 32 * blk) * D + h * HD + t];
-    }
+    for (int t = 0; t < HD; ++t) qf[blk][t] = Ks[(r + 32 * blk) * D + h * HD + t];
+  __builtin_amdgcn_wave_barrier();
+  wa_stage_store<D>(Ks, kreg, lane);
+  __builtin_amdgcn_wave_barrier();
+  wa_stage_load<D>(vreg, hb + 2 * C, C3, mytok, lane);    // V on its way while S^T is computed
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int t = 0; t < HD; ++t) kf[blk][t] = Ks[(r + 32 * blk) * D + h * HD + t];
   f32x16 T[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
