@@ -529,6 +529,33 @@ def g_losses_elb():
     npz("g10_losses_elb", **out)
 
 
+def g_interpolate():
+    print("G11 Interpolate (Bicubic baseline)")
+    # utils_trainer.py does not import here (matplotlib style): compile ONLY the reference's
+    # Interpolate class from its source, at generation time, into a namespace with the reference's constants
+    import ast
+    src = open(os.path.join(ref_shim.REF, "dlib/utils/utils_trainer.py")).read()
+    tree = ast.parse(src)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Interpolate"]
+    assert len(cls) == 1
+    ns = {"torch": torch, "F": F, "constants": ref_c}
+    exec(compile(ast.Module(body=cls, type_ignores=[]), "<reference Interpolate>", "exec"), ns)
+    torch.manual_seed(41)
+    out = {}
+    for name, shape in (("a", (1, 1, 8, 8)), ("b", (2, 1, 12, 20))):
+        x = torch.rand(*shape) * 1.2 - 0.1                 # some values outside [0, 1]: the clamp
+        out[f"{name}/x"] = x
+        for s_ in (2, 4, 8):
+            with cpu_as_cuda():
+                m = ns["Interpolate"](task=ref_c.SUPER_RES, scale=s_, scale_mode=ref_c.INTER_BICUBIC)
+            m.feed_data({"l_im": x, "h_im": x}, need_H=False)
+            m.test()
+            e = m.current_visuals(need_H=False)["E"]
+            close(O.interpolate_bicubic(x, s_), e, 0.0, f"interpolate {name} x{s_}")
+            out[f"{name}/x{s_}"] = e
+    npz("g11_interpolate", **out)
+
+
 # ---------------------------------------------------------------- G7 metrics
 def g_metrics():
     print("G7 metrics")
@@ -616,7 +643,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb,
+    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_interpolate,
             g_metrics, g_optim]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

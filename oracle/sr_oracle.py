@@ -500,6 +500,12 @@ def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
     return total, [total] + parts
 
 
+def interpolate_bicubic(x: Tensor, scale: int) -> Tensor:
+    """The Bicubic baseline (dlib/utils/utils_trainer.py:121-148): aten's antialiased bicubic
+    resize, clamped to [0, 1]."""
+    return torch.clamp(F.interpolate(x, scale_factor=scale, mode="bicubic", antialias=True), 0.0, 1.0)
+
+
 # ----------------------------------------------------------------------------
 # metrics (dlib/utils/utils_image.py)
 # ----------------------------------------------------------------------------

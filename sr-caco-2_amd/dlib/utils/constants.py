@@ -42,3 +42,9 @@ NCCL = 'nccl'
 NORM1 = '1'
 NORM2 = '2'
 LPNORMS = [NORM1, NORM2]
+
+# tasks / interpolation modes of the Bicubic baseline row (reference constants.py:1-6,218-220)
+RECONSTRUCT = 'reconstruct'
+TASKS = [SUPER_RES, RECONSTRUCT]
+INTER_BICUBIC = 'bicubic'
+INTERPOLATION_MODES = [INTER_BICUBIC]

@@ -229,6 +229,31 @@ def test_optional_loss_terms_full_size_properties():
     assert (g - ga - gb).abs().max() <= 1e-6 * g.abs().max()
 
 
+def test_interpolate_bicubic_baseline_vs_reference_golden():
+    """the Bicubic baseline object (utils_trainer.py:89-167) on stock PyTorch-ROCm, against the
+    reference's CPU output; PSNR against a target agrees to 0.01 dB."""
+    from dlib.utils.utils_trainer import Interpolate
+    from dlib.utils import constants
+    from dlib import metrics as M
+    g = load("g11_interpolate")
+    for name in "ab":
+        x = g[f"{name}/x"]
+        for s_ in (2, 4, 8):
+            m = Interpolate(task=constants.SUPER_RES, scale=s_, scale_mode=constants.INTER_BICUBIC)
+            m.feed_data({'l_im': x, 'h_im': g[f"{name}/x{s_}"]})
+            m.set_eval_mode()
+            m.test()
+            vis = m.current_visuals()
+            ref = g[f"{name}/x{s_}"]
+            assert vis['E'].shape == ref.shape and vis['E'].is_cuda
+            assert (vis['E'].cpu() - ref).abs().mean() <= 1e-5
+            assert float(vis['E'].min()) >= 0.0 and float(vis['E'].max()) <= 1.0
+            tgt = torch.rand(ref.shape, generator=torch.Generator().manual_seed(s_)).cuda()
+            pa = M.mbatch_gpu_calculate_psnr(M.tensor2uint82float(vis['E']), M.tensor2uint82float(tgt), border=0)
+            pb = M.mbatch_gpu_calculate_psnr(M.tensor2uint82float(ref.cuda()), M.tensor2uint82float(tgt), border=0)
+            assert (pa - pb).abs().max() <= 0.01
+
+
 def test_dlib_metrics_surface_vs_reference_golden():
     from dlib import metrics as M
     from dlib.utils import utils_image
