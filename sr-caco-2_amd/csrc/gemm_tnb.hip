@@ -71,17 +71,28 @@ template <int W> struct ColVec;
 template <> struct ColVec<1> {
   typedef float T;
   static __device__ __forceinline__ T ldg(const float* p) { return ldg_f(p); }
+  static __device__ __forceinline__ T ldg(const float* base, unsigned off) {
+    return *(sr_gptr_f)((const char*)base + off);
+  }
   static __device__ __forceinline__ float at(T v, int) { return v; }
 };
 template <> struct ColVec<2> {
   typedef sr_f32x2 T;
   static __device__ __forceinline__ T ldg(const float* p) { return *(sr_gptr_f2)p; }
+  static __device__ __forceinline__ T ldg(const float* base, unsigned off) {
+    return *(sr_gptr_f2)((const char*)base + off);
+  }
   static __device__ __forceinline__ float at(T v, int j) { return v[j]; }
 };
 template <> struct ColVec<3> {
   typedef tnb_f32x3 T;
   static __device__ __forceinline__ T ldg(const float* p) {
     return *(const __attribute__((address_space(1))) tnb_f32x3_u*)p;
+  }
+  // uniform base (SGPR pair) + 32-bit per-lane byte offset: the global_load saddr form, no 64-bit
+  // vector add per load
+  static __device__ __forceinline__ T ldg(const float* base, unsigned off) {
+    return *(const __attribute__((address_space(1))) tnb_f32x3_u*)((const char*)base + off);
   }
   static __device__ __forceinline__ float at(T v, int j) { return v[j]; }
 };
@@ -122,6 +133,7 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
   // are never written out); a lane that straddles it is handled in store()
   const int opvalid = isB ? jvalid : ivalid;
   const int colq = max(min(W * lane, opvalid - W), 0);
+  const unsigned colb = (unsigned)colq * 4u;   // byte offset of this lane's columns in a token row
   const int dsh = W * lane - colq;             // > 0: this lane's load was shifted left
   const bool ragged = opvalid % W != 0;        // uniform: some lane straddles the valid width
   const float* const pA = p.A;
@@ -143,7 +155,7 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
       const float* q = P + (long)(mc + 16 * hh) * ld;       // uniform, advanced per token
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(q + colq);
+        sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(q, colb);
         q += ld;
       }
       return;
@@ -173,7 +185,7 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
       const float* q = P + (long)row0 * ld;                 // uniform, advanced per token
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(q + colq);
+        sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(q, colb);
         q += ld;
       }
     } else {
@@ -181,7 +193,7 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
       for (int t = 0; t < 16; ++t) {
         const int row = __builtin_amdgcn_readlane(t_row, t);
         const float* base = row >= 0 ? P + (long)row * ld : k_tnb_zero_row;   // uniform
-        sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(base + (row >= 0 ? colq : 0));
+        sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(base, row >= 0 ? colb : 0u);
       }
     }
   };
