@@ -271,6 +271,18 @@ int srhip_loss_stencil(const float* pred, const float* target, float* grad, floa
                        int B, int H, int W, int op, int ksz, int norm, int channel_norm, float lam, int grad_accum,
                        int loss_accum, void* stream);
 
+/* ---- input pipeline, device-side tail -------------------------------------- */
+/* One training patch: crop P x P at (y0, x0) out of a resident uint8 tile [H][W], augment_img
+ * mode 0..7 (dlib/utils/utils_image.py:469-487), uint8 -> float32 = np.float32(v / 255.)
+ * (utils_image.py:322-323), layout [B][1][P][P] (single2tensor3 + batch collate) -- the
+ * per-sample steps of dlib/datasets/dataset_dpsr.py:866-894,914-915.  jobs is a HOST array;
+ * bit-exact. */
+typedef struct {
+  const unsigned char* img;   /* device pointer */
+  int H, W, y0, x0, mode;
+} srhip_patch_job;
+int srhip_patch_gather(const srhip_patch_job* jobs, int B, int P, float* out, void* stream);
+
 /* ---- metrics (dlib/utils/utils_image.py:369-372,843-1007,618-653,1010-1198;
  *      dlib/utils/utils_trainer.py:961-1032) ----------------------------------- */
 /* (x.clamp(0,1)*255).round().clamp(0,255), round-half-even (utils_image.py:369-372). */

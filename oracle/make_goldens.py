@@ -556,6 +556,38 @@ def g_interpolate():
     npz("g11_interpolate", **out)
 
 
+def g_patches():
+    print("G12 training patch assembly (crop + augment_img + uint2single + single2tensor3)")
+    rng = np.random.RandomState(5)
+    sf = 4
+    hr = [rng.randint(0, 256, size=(40, 56), dtype=np.uint8), rng.randint(0, 256, size=(48, 48), dtype=np.uint8)]
+    lr = [rng.randint(0, 256, size=(10, 14), dtype=np.uint8), rng.randint(0, 256, size=(12, 12), dtype=np.uint8)]
+    P, l = 16, 4
+    ids = [0, 1, 0, 1, 0, 1, 0, 1, 1, 0]
+    modes = [0, 1, 2, 3, 4, 5, 6, 7, 3, 5]
+    y0 = [0, 32, 24, 7, 13, 5, 20, 31, 0, 24]
+    x0 = [0, 32, 40, 9, 22, 17, 3, 30, 32, 0]
+    exp_h, exp_l = [], []
+    for t, yy, xx, m in zip(ids, y0, x0, modes):
+        # the reference's own steps (dataset_dpsr.py:866-894): crop, augment, float, tensor
+        img_h = ref_ui.uint2single(np.expand_dims(hr[t], 2))
+        img_l = ref_ui.uint2single(np.expand_dims(lr[t], 2))
+        yl, xl = yy // sf, xx // sf
+        img_l = img_l[yl:yl + l, xl:xl + l, :]
+        img_h = img_h[yy:yy + P, xx:xx + P, :]
+        img_l = ref_ui.augment_img(img_l, m)
+        img_h = ref_ui.augment_img(img_h, m)
+        exp_h.append(ref_ui.single2tensor3(img_h))
+        exp_l.append(ref_ui.single2tensor3(img_l))
+    eh, el = torch.stack(exp_h), torch.stack(exp_l)
+    oh = O.patch_batch(hr, ids, y0, x0, modes, P)
+    ol = O.patch_batch(lr, ids, [v // sf for v in y0], [v // sf for v in x0], modes, l)
+    assert torch.equal(oh, eh) and torch.equal(ol, el), "oracle != reference patch assembly"
+    print("  ok patch assembly: bit-exact")
+    npz("g12_patches", hr0=hr[0], hr1=hr[1], lr0=lr[0], lr1=lr[1], ids=np.array(ids), modes=np.array(modes),
+        y0=np.array(y0), x0=np.array(x0), sf=np.array(sf), h_im=eh, l_im=el)
+
+
 # ---------------------------------------------------------------- G7 metrics
 def g_metrics():
     print("G7 metrics")
@@ -643,7 +675,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_interpolate,
+    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_interpolate, g_patches,
             g_metrics, g_optim]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

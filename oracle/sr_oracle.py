@@ -500,6 +500,27 @@ def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
     return total, [total] + parts
 
 
+def augment_index(mode: int, i, j, P: int):
+    """Source position inside a P x P patch of output position (i, j) under augment_img mode
+    0..7 (utils_image.py:469-487: rot90 = counter-clockwise on axes (0, 1), flipud = rows reversed)."""
+    e = P - 1
+    return [(i, j), (j, i), (e - i, j), (e - j, i), (i, e - j), (j, e - i), (e - i, e - j), (e - j, e - i)][mode]
+
+
+def patch_batch(tiles, ids, y0, x0, modes, P: int) -> Tensor:
+    """The per-sample tail of DatasetDPSR.__getitem__ in training mode
+    (dataset_dpsr.py:866-894,914-915): crop P x P at (y0, x0) from the uint8 tile, augment_img(mode),
+    uint2single (np.float32(v / 255.), the division in float64), single2tensor3 -> [B, 1, P, P]."""
+    import numpy as np
+    out = np.empty((len(ids), 1, P, P), dtype=np.float32)
+    ii, jj = np.meshgrid(np.arange(P), np.arange(P), indexing="ij")
+    for b, (t, yy, xx, m) in enumerate(zip(ids, y0, x0, modes)):
+        crop = np.asarray(tiles[t])[yy:yy + P, xx:xx + P]
+        si, sj = augment_index(int(m), ii, jj, P)
+        out[b, 0] = np.float32(crop[si, sj] / 255.)
+    return torch.from_numpy(out)
+
+
 def interpolate_bicubic(x: Tensor, scale: int) -> Tensor:
     """The Bicubic baseline (dlib/utils/utils_trainer.py:121-148): aten's antialiased bicubic
     resize, clamped to [0, 1]."""

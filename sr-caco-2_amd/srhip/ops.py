@@ -542,6 +542,41 @@ def loss_stencil(pred, target, kind, lam=1.0, norm=2, ksz=3, channel_norm=False,
     return loss_out
 
 
+# ------------------------------------------------------------------ input pipeline (f2)
+class _PatchJob(ctypes.Structure):   # srhip_patch_job (include/srhip.h)
+    _fields_ = [("img", ctypes.c_void_p), ("H", ctypes.c_int), ("W", ctypes.c_int), ("y0", ctypes.c_int),
+                ("x0", ctypes.c_int), ("mode", ctypes.c_int)]
+
+
+def patch_gather(tiles, ids, y0, x0, modes, P, out=None):
+    """[B,1,P,P] float32 batch out of device-resident uint8 tiles: crop at (y0, x0), augment_img mode 0..7,
+    /255 -- the per-sample tail of DatasetDPSR.__getitem__ (dataset_dpsr.py:866-894,914-915).  ``tiles``:
+    sequence of contiguous uint8 CUDA tensors [H, W]; ids / y0 / x0 / modes: per-sample Python ints."""
+    B = len(ids)
+    dev = tiles[ids[0]].device
+    if out is None:
+        out = torch.empty(B, 1, P, P, device=dev, dtype=torch.float32)
+    _chk(out)
+    jobs = (_PatchJob * B)()
+    for b in range(B):
+        t = tiles[ids[b]]
+        if not (t.is_cuda and t.dtype == torch.uint8 and t.dim() == 2 and t.is_contiguous()):
+            raise ValueError("patch_gather: tiles must be contiguous uint8 CUDA tensors [H, W]")
+        jobs[b].img, jobs[b].H, jobs[b].W = t.data_ptr(), t.shape[0], t.shape[1]
+        jobs[b].y0, jobs[b].x0, jobs[b].mode = int(y0[b]), int(x0[b]), int(modes[b])
+    call("srhip_patch_gather", ctypes.addressof(jobs), B, P, _p(out), _st())
+    return out
+
+
+def train_batch(hr_tiles, lr_tiles, ids, y0, x0, modes, patch_size, sf):
+    """The batch dict the reference's trainer feeds ModelPlain (keys l_im, h_im; dataset_dpsr.py:981-1005)
+    from resident tiles: HR crop at (y0, x0), LR crop at (y0 // sf, x0 // sf) of size patch_size // sf,
+    the same augmentation mode on both (dataset_dpsr.py:866-894)."""
+    return {"h_im": patch_gather(hr_tiles, ids, y0, x0, modes, patch_size),
+            "l_im": patch_gather(lr_tiles, ids, [v // sf for v in y0], [v // sf for v in x0], modes,
+                                 patch_size // sf)}
+
+
 # ------------------------------------------------------------------ metrics
 def tensor2uint82float(x):
     _chk(x)

@@ -254,6 +254,36 @@ def test_interpolate_bicubic_baseline_vs_reference_golden():
             assert (pa - pb).abs().max() <= 0.01
 
 
+def test_patch_assembly_bit_exact_vs_reference_golden():
+    """f2: the device-side batch assembly (srhip_patch_gather) against the reference's crop / augment_img /
+    uint2single / single2tensor3 outputs, bit for bit; at the benchmark's size against the oracle; and its
+    error behaviour."""
+    from srhip import ops
+    g = load("g12_patches")
+    hr = [g["hr0"].cuda().contiguous(), g["hr1"].cuda().contiguous()]
+    lr = [g["lr0"].cuda().contiguous(), g["lr1"].cuda().contiguous()]
+    ids, modes = g["ids"].tolist(), g["modes"].tolist()
+    y0, x0, sf = g["y0"].tolist(), g["x0"].tolist(), int(g["sf"])
+    batch = ops.train_batch(hr, lr, ids, y0, x0, modes, 16, sf)
+    assert torch.equal(batch["h_im"].cpu(), g["h_im"]) and torch.equal(batch["l_im"].cpu(), g["l_im"])
+    # benchmark size: 8 patches of 512 x 512 out of 1024 x 1280 tiles, every mode; augmentations are
+    # permutations (sorted values equal) and mode pairs invert each other
+    gen = torch.Generator().manual_seed(8)
+    tiles = [torch.randint(0, 256, (1024, 1280), generator=gen, dtype=torch.uint8) for _ in range(3)]
+    tl = [t.cuda() for t in tiles]
+    ids8, m8 = [0, 1, 2, 0, 1, 2, 0, 1], list(range(8))
+    yy, xx = [0, 512, 100, 37, 511, 256, 3, 400], [768, 0, 5, 700, 123, 64, 767, 333]
+    out = ops.patch_gather(tl, ids8, yy, xx, m8, 512)
+    ref = O.patch_batch([t.numpy() for t in tiles], ids8, yy, xx, m8, 512)
+    assert torch.equal(out.cpu(), ref)
+    base = ops.patch_gather(tl, ids8, yy, xx, [0] * 8, 512)
+    assert torch.equal(out.flatten(1).sort(1).values, base.flatten(1).sort(1).values)
+    with pytest.raises(RuntimeError, match="outside"):
+        ops.patch_gather(tl, [0], [600], [0], [0], 512)
+    with pytest.raises(RuntimeError, match="mode"):
+        ops.patch_gather(tl, [0], [0], [0], [8], 512)
+
+
 def test_dlib_metrics_surface_vs_reference_golden():
     from dlib import metrics as M
     from dlib.utils import utils_image
