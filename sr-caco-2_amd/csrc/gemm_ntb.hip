@@ -406,7 +406,7 @@ int sr_gemm_ntb(NtArgs& p, hipStream_t st) {
              "gemm_nt_bx3: operand larger than 2 GiB (32-bit staging offsets)");
   // 16-byte epilogue accesses need 4-float alignment of every matrix it touches
   const auto al4 = [](const void* q, long ld) { return !q || (((size_t)q & 15) == 0 && ld % 4 == 0); };
-  p.wide_epi = !p.stats_out && p.N % 4 == 0 && al4(p.C, p.ldc) && al4(p.R, p.ldr) && al4(p.aux, p.ldaux) &&
+  p.wide_epi = p.N % 4 == 0 && al4(p.C, p.ldc) && al4(p.R, p.ldr) && al4(p.aux, p.ldaux) &&
                ((size_t)p.C & 15) == 0 && ntb_env("SRHIP_NTB_WIDE", 1);
   // 64-row tiles (every case but very tall problems with narrow N, which take the 128-row
   // tiles of this file): the 16-wide-stage kernel of gemm_ntp.hip

@@ -38,7 +38,7 @@ __device__ __forceinline__ int unit_slot(int row, int u) { return 2 * row + (u ^
 
 constexpr int ntp_lds(int wn) {
   const int stages = 2 * 3 * (BM + 64 * wn) * 32;
-  const int wide = 4 * 32 * (32 * wn + 8) * 4;          // nt_epilogue_wide's transposition tiles
+  const int wide = 4 * 32 * (32 * wn + 8) * 4 + 2 * 2 * 64 * 4;   // nt_epilogue_wide's transposition tiles + row-stat exchange
   return stages > wide ? stages : wide;
 }
 

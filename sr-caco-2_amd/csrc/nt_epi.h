@@ -302,8 +302,8 @@ __device__ __forceinline__ void nt_epilogue_lnbwd(const NtArgs& p, f32x16 (&acc)
 // gate loads and stores are 16 bytes per lane, a quarter of the instructions.
 // LDS row pitch 32*WN + 8 floats: the two lane halves (rows 4 apart) land 32 banks
 // apart, so the transposing ds_write_b32 is conflict free.
-template <int WN>
-__device__ __forceinline__ void nt_epilogue_wide(const NtArgs& p, f32x16 (&acc)[1][WN], int lane, int wave,
+template <int WN, bool STATS>
+__device__ __forceinline__ void nt_epilogue_wide_impl(const NtArgs& p, f32x16 (&acc)[1][WN], int lane, int wave,
                                                  int wm, int wn, int n0, int nvalid, int m0, float* lds) {
   constexpr int P = 32 * WN + 8;
   constexpr int F4 = 8 * WN;                   // float4 per tile row
@@ -374,5 +374,49 @@ __device__ __forceinline__ void nt_epilogue_wide(const NtArgs& p, f32x16 (&acc)[
         break;
     }
     if (grow[it] >= 0) *(f32x4*)(p.C + (long)grow[it] * p.ldc + gcol[it]) = v;
+    if (STATS) *(f32x4*)(tile + goff[it]) = v;            // final values back into the wave's tile
   }
+  if (STATS) {
+    // LayerNorm statistics of the OUTPUT rows (the next LayerNorm's mean / rstd; one N block, so a
+    // row lives in the two column waves of its row group).  The tile is row-major in LDS now: lane
+    // (row = l & 31, half = l >> 5) sums its 48 columns, the halves meet by one shuffle, the two
+    // column waves in LDS.  Two-pass like the reference: mean first, then squared deviations.
+    float* red = lds + 4 * (32 * P);                       // [2][2][64]
+    __builtin_amdgcn_wave_barrier();
+    const int half = lane >> 5;
+    const int cbase = wn * (32 * WN) + half * (16 * WN);
+    f32x4 xv[4 * WN];
+    float s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4 * WN; ++k) {
+      xv[k] = *(const f32x4*)(tile + r * P + half * (16 * WN) + 4 * k);
+      if (cbase + 4 * k < nvalid) s1 += (xv[k].x + xv[k].y) + (xv[k].z + xv[k].w);     // nvalid % 4 == 0
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    if (half == 0) red[wn * 64 + wm * 32 + r] = s1;
+    __syncthreads();
+    const float mean = (red[wm * 32 + r] + red[64 + wm * 32 + r]) * (1.0f / (float)p.N);
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4 * WN; ++k)
+      if (cbase + 4 * k < nvalid) {
+        const f32x4 d = xv[k] - mean;
+        s2 += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+      }
+    s2 += __shfl_xor(s2, 32, 64);
+    if (half == 0) red[128 + wn * 64 + wm * 32 + r] = s2;
+    __syncthreads();
+    const int g = m0 + wm * 32 + r;
+    if (wn == 0 && half == 0 && g < p.M) {
+      const float var = (red[128 + wm * 32 + r] + red[192 + wm * 32 + r]) * (1.0f / (float)p.N);
+      *(float2*)(p.stats_out + 2 * (long)g) = float2{mean, rsqrtf(var + 1e-5f)};
+    }
+  }
+}
+
+template <int WN>
+__device__ __forceinline__ void nt_epilogue_wide(const NtArgs& p, f32x16 (&acc)[1][WN], int lane, int wave,
+                                                 int wm, int wn, int n0, int nvalid, int m0, float* lds) {
+  if (p.stats_out) nt_epilogue_wide_impl<WN, true>(p, acc, lane, wave, wm, wn, n0, nvalid, m0, lds);
+  else nt_epilogue_wide_impl<WN, false>(p, acc, lane, wave, wm, wn, n0, nvalid, m0, lds);
 }
