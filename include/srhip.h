@@ -199,6 +199,10 @@ int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, con
  * function (or a kind-2 job of srhip_prep_table), hand to the attention calls. */
 int srhip_bias_expand(const float* table, float* biasT, float* biasN, int heads, void* stream);
 int srhip_bias_grad(const float* dbiasT, float* dtable, int heads, void* stream);
+/* The same for up to 8 attention blocks in one launch: block i's image at dbiasT + i*image_stride floats,
+ * its table gradient at dtables[i] (HOST array of device pointers). */
+int srhip_bias_grad_batched(const float* dbiasT, long image_stride, float* const* dtables, int nblocks, int heads,
+                            void* stream);
 /* qkv [B*H*W][3C] in token order -> out [B*H*W][C]; 8x8 windows, shift 0 or 4;
  * roll, window partition/reverse and the shift mask are address math. */
 int srhip_window_attention_fwd(const float* qkv, float* out, const float* biasT, int B, int H, int W,

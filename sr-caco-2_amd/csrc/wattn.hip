@@ -495,7 +495,15 @@ __global__ void k_bias_expand(const float* __restrict__ table, float* __restrict
 }
 // dtable[idx][h] = sum over (query,key) with rpi == idx of the bias-gradient image
 // (wa_dimg_index order); one wave per table entry, one lane per key position
-__global__ void k_bias_grad(const float* __restrict__ dbiasT, float* __restrict__ dtable, int heads) {
+struct BiasGradBatch {          // up to 8 attention blocks (images heads*4096 floats apart in one buffer)
+  float* dtable[8];
+};
+__global__ void k_bias_grad(const float* __restrict__ dbiasT, float* __restrict__ dtable, int heads,
+                            BiasGradBatch batch, long img_stride) {
+  if (batch.dtable[0]) {        // batched form: blockIdx.y = attention block
+    dbiasT += blockIdx.y * img_stride;
+    dtable = batch.dtable[blockIdx.y];
+  }
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= 225 * heads) return;
@@ -526,9 +534,26 @@ int srhip_bias_expand(const float* table, float* biasT, float* biasN, int heads,
 }
 
 int srhip_bias_grad(const float* dbiasT, float* dtable, int heads, void* stream) {
+  BiasGradBatch none;
+  memset(&none, 0, sizeof(none));
   hipLaunchKernelGGL(k_bias_grad, dim3(sr_cdiv(225 * heads, 4)), dim3(256), 0, (hipStream_t)stream,
-                     dbiasT, dtable, heads);
+                     dbiasT, dtable, heads, none, 0L);
   SR_LAUNCH_CHECK("bias_grad");
+  return 0;
+}
+
+int srhip_bias_grad_batched(const float* dbiasT, long image_stride, float* const* dtables, int nblocks, int heads,
+                            void* stream) {
+  SR_REQUIRE(nblocks >= 1 && nblocks <= 8, "bias_grad_batched: 1..8 blocks per launch (got %d)", nblocks);
+  BiasGradBatch b;
+  memset(&b, 0, sizeof(b));
+  for (int i = 0; i < nblocks; ++i) {
+    SR_REQUIRE(dtables[i] != nullptr, "bias_grad_batched: table %d missing", i);
+    b.dtable[i] = dtables[i];
+  }
+  hipLaunchKernelGGL(k_bias_grad, dim3(sr_cdiv(225 * heads, 4), nblocks), dim3(256), 0, (hipStream_t)stream,
+                     dbiasT, (float*)nullptr, heads, b, image_stride);
+  SR_LAUNCH_CHECK("bias_grad_batched");
   return 0;
 }
 

@@ -394,6 +394,17 @@ def bias_grad(dbiasT, dtable):
     call("srhip_bias_grad", _p(dbiasT), _p(dtable), dtable.shape[1], _st())
 
 
+def bias_grad_batched(dbiasT_all, first, dtables):
+    """bias_grad for the consecutive attention blocks first .. first+len(dtables)-1 of one image buffer
+    [nblocks, heads, 64, 64] in one launch (<= 8 blocks)."""
+    _chk(dbiasT_all, *dtables)
+    n = len(dtables)
+    arr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in dtables])
+    img = dbiasT_all[first]
+    call("srhip_bias_grad_batched", _p(img), dbiasT_all.stride(0), ctypes.addressof(arr), n,
+         dtables[0].shape[1], _st())
+
+
 def window_attention_fwd(qkv, out, biasT, B, H, W, C, heads, shift):
     _chk(qkv, out, biasT)
     call("srhip_window_attention_fwd", _p(qkv), _p(out), _p(biasT), B, H, W, C, heads, shift, _st())

@@ -319,7 +319,6 @@ class SwinIREngine:
                 dbT = dbT_all[bi, :heads]
                 ops.window_attention_bwd(qkv, da, dqkv, D.d[f"{bi}.biasT"], D.d[f"{bi}.biasN"], dbT, B, H,
                                          W, C, heads, blk.shift_size)
-                ops.bias_grad(dbT, G(p + "attn.relative_position_bias_table"))
                 if ws.use_bx3:
                     ops.gemm_nt_lnbwd(dqkv, ws[f"{bi}.wqT"], t, st1, g1, gout)
                 else:
@@ -340,6 +339,15 @@ class SwinIREngine:
                 ], ln_grads_zeroed=grads_zeroed)
                 gi = (gi + 2) % 3
                 g = gout
+            # relative-position-bias table gradients of the layer's blocks: one launch (<= 8 blocks each)
+            tabs = [G(pre + f"residual_group.blocks.{j}.attn.relative_position_bias_table") for j in range(nb)]
+            same = len({blk.num_heads for blk in layer.residual_group.blocks}) == 1
+            for j0 in range(0, nb, 8):
+                if same:
+                    ops.bias_grad_batched(dbT_all, bi + j0, tabs[j0:j0 + 8])
+                else:
+                    for j in range(j0, min(nb, j0 + 8)):
+                        ops.bias_grad(dbT_all[bi + j, :layer.residual_group.blocks[j].num_heads], tabs[j])
             ops.axpby(dt, g, 1.0, 1.0)   # RSTB skip: t_out = conv(blocks(t_in)) + t_in
             if on_layer_done is not None:   # this layer's gradients are enqueued
                 on_layer_done(len(net.layers) - 1 - li)
