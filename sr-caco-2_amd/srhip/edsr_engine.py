@@ -25,7 +25,9 @@ class EDSREngine:
         self.bufs = _Bufs()
         self.derived = _Bufs()
         self.ws = ops.WeightSet()
-        self.ws.use_bx3 = ops.bx3_for(self.F)      # 64-feature EDSR stays on the exact-f32 MFMA kernels
+        # conv forward / data gradient on the bf16x3 kernels from 64 features on; the weight gradients of a
+        # 64-feature net stay on the exact-f32 MFMA kernels (ops.conv3x3_wgrad decides by ops.bx3_for)
+        self.ws.use_bx3 = ops.bx3_nt_for(self.F)
         self._prep = self._prep_sig = None
         self.prepared = False
         self.saved = None

@@ -47,6 +47,17 @@ import os as _os
 BX3_MIN_CHANNELS = int(_os.environ.get("SRHIP_BX3_MIN_CH", "128"))   # below this the split / staging overhead outweighs the faster MFMA (EDSR's 64)
 
 
+# The NT side (conv / Linear forward and data gradient) pays off much earlier than the weight-gradient side:
+# measured at 64 -> 64 channels, B=8, 128x128 (tools/mb_conv64.py): conv 108.8 -> 65.5 us with the bf16x3 kernel,
+# weight gradient 187.3 -> 212.0 us.  So the two sides have their own thresholds.
+BX3_MIN_CHANNELS_NT = int(_os.environ.get("SRHIP_BX3_MIN_CH_NT", "64"))
+
+
+def bx3_nt_for(*channels):
+    """bf16x3 kernels for the NT side (forward / data gradient) of this problem?"""
+    return use_bx3() and min(channels) >= BX3_MIN_CHANNELS_NT
+
+
 def bx3_for(*channels):
     """bf16x3 kernels for this problem?  (mode switch + smallest channel count involved)"""
     return use_bx3() and min(channels) >= BX3_MIN_CHANNELS
