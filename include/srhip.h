@@ -263,6 +263,11 @@ int srhip_loss_bounded(const float* pred, const float* target, float* grad, floa
  * grad[i] += lam * sign(w[i]) (grad may be null).  workspace: 2048 doubles. */
 int srhip_l1_sparsity(const float* w, float* grad, float* loss_out, double* workspace, long n, float lam,
                       int loss_accum, void* stream);
+/* LocalMoments (dlib/loss/main.py:240-325; PatchMoments dlib/loss/local_terms.py:14-66, the reference's fixed
+ * 3x3 window, reflect padding, unbiased variance): lam * mean_{b,y,x}(KL(target patch || pred patch) * [target
+ * patch variance == 0]) with both variances + 1.  workspace doubles: srhip_loss_stencil_ws(B,H,W). */
+int srhip_loss_local_moments(const float* pred, const float* target, float* grad, float* loss_out, double* workspace,
+                             int B, int H, int W, float lam, int grad_accum, int loss_accum, void* stream);
 /* Local-variation terms on 1-channel images [B][H][W] (dlib/loss/main.py:328-674 with the operators of
  * dlib/loss/local_variations.py:18-141, replicate padding): op 0 image gradient (2 stencils), 1 Laplacian
  * (1), 2 local variation over a ksz x ksz window (ksz^2 - 1 stencils; ksz 3, 5 or 7).  norm 1 | 2 = the

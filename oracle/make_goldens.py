@@ -529,6 +529,34 @@ def g_losses_elb():
     npz("g10_losses_elb", **out)
 
 
+def g_local_moments():
+    print("G13 LocalMoments")
+    torch.manual_seed(29)
+    out = {}
+    for name, shape in (("a", (2, 1, 24, 40)), ("b", (1, 1, 5, 7))):
+        pred = torch.rand(*shape)
+        tgt = torch.round(torch.rand(*shape) * 255) / 255          # the dataset's uint8 grid
+        # flat target regions (background), also touching the image border / corner
+        tgt[0, :, : shape[2] // 2, : shape[3] // 3] = 37.0 / 255
+        tgt[-1, :, -4:, -5:] = 0.0
+        l = ref_loss.LocalMoments(cuda_id="cpu", lambda_=0.7)
+        m = ref_loss.MasterLoss(cuda_id="cpu")
+        m.add(l)
+        pr = pred.clone().requires_grad_(True)
+        v = m(epoch=0, y_pred=pr, y_target=tgt, trg_per_pixel_weight=None, model=None)
+        v.backward()
+        po = pred.clone().requires_grad_(True)
+        vo = O.loss_local_moments(po, tgt, 0.7)
+        vo.backward()
+        assert float(v) > 0 and float(pr.grad.abs().max()) > 0
+        close(vo.detach(), v.detach(), 1e-7, f"local_moments {name}")
+        close(po.grad, pr.grad, 1e-9, f"d local_moments {name}")
+        out[f"{name}/pred"], out[f"{name}/target"] = pred, tgt
+        out[f"{name}/value"], out[f"{name}/grad"] = v.detach(), pr.grad
+        out[f"{name}/names"] = np.array(m.n_holder)
+    npz("g13_local_moments", **out)
+
+
 def g_interpolate():
     print("G11 Interpolate (Bicubic baseline)")
     # utils_trainer.py does not import here (matplotlib style): compile ONLY the reference's
@@ -675,7 +703,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_interpolate, g_patches,
+    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_interpolate, g_patches,
             g_metrics, g_optim]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

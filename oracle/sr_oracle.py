@@ -470,6 +470,26 @@ def loss_weights_sparsity(params: Sequence[Tensor], lam: float = 1.0) -> Tensor:
     return lam * sum(p.abs().sum() for p in params)
 
 
+def patch_moments(x: Tensor, ksz: int = 3) -> Tuple[Tensor, Tensor]:
+    """loss/local_terms.py:34-57: mean and unbiased variance of every ksz x ksz patch (reflect
+    padding), [b, h*w] each."""
+    p = (ksz - 1) // 2
+    z = F.unfold(F.pad(x, (p, p, p, p), mode="reflect"), kernel_size=ksz).permute(0, 2, 1)
+    var, mean = torch.var_mean(z, dim=-1, unbiased=True)
+    return mean, var
+
+
+def loss_local_moments(pred: Tensor, target: Tensor, lam: float = 1.0) -> Tensor:
+    """loss/main.py:240-325.  The operators are built once for ksz = [3] (set_ksz does not rebuild
+    them, :244-263), eps = 1; only patches whose TARGET variance is exactly 0 count."""
+    sm, sv = patch_moments(pred)
+    tm, tv = patch_moments(target)
+    flat = (tv == 0).float()
+    sv1, tv1 = sv + 1.0, tv + 1.0
+    kl = torch.log(torch.sqrt(sv1) / torch.sqrt(tv1)) + (tv1 + (tm - sm) ** 2) / (2 * sv1) - 0.5
+    return lam * (kl * flat).mean()
+
+
 def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
                 weight: Optional[Tensor] = None) -> Tuple[Tensor, List[Tensor]]:
     """loss/master.py:46-56.  ``terms``: ('l1',lam) | ('l2',lam) |
@@ -488,6 +508,8 @@ def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
             parts.append(loss_charbonnier(pred, target, t[1], t[2]))
         elif t[0] == "l2sum":
             parts.append(loss_l2sum(pred, target, t[1]))
+        elif t[0] == "local_moments":
+            parts.append(loss_local_moments(pred, target, t[1]))
         elif t[0] == "boundpred":          # (kind, lam, eps, t, restore_range, color_max)
             parts.append(loss_bounded_prediction(pred, target, t[1], t[2], t[3], t[4], t[5]))
         elif t[0] in ("grad", "laplace", "lv", "norm_grad", "norm_laplace", "norm_lv"):

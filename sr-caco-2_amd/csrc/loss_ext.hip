@@ -285,6 +285,96 @@ __global__ void __launch_bounds__(256) k_loss_stencil(const float* __restrict__ 
   if (tid == 0) part[((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// LocalMoments (dlib/loss/main.py:240-325 with PatchMoments, dlib/loss/local_terms.py:14-66): per pixel
+// the mean / unbiased variance of its 3x3 patch (reflect padding) for pred (m, v) and target (mt, vt);
+//   kl = log(sqrt(v + 1) / sqrt(vt + 1)) + (vt + 1 + (mt - m)^2) / (2 (v + 1)) - 1/2
+// counted ONLY where the target patch is exactly flat (vt == 0); loss = lam * mean_{b,y,x}(kl * [vt == 0]).
+// Mean and variance by Welford's update in row-major patch order: a flat patch gives exactly 0 for any
+// value (sum-then-divide does not), which is what the reference's equality test relies on.
+// The gradient is a gather over the 3x3 centres p around q with the multiplicity of q in p's reflected patch.
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__global__ void __launch_bounds__(256) k_loss_local_moments(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                            float* __restrict__ grad, double* __restrict__ part, int H,
+                                                            int W, float gs, int grad_accum) {
+  constexpr int R = 1, LW = TS + 4 * R, CW = TS + 2 * R;
+  __shared__ float sp[LW * LW], st[LW * LW];
+  __shared__ float cm[CW * CW], cdm[CW * CW], cdv[CW * CW];      // per centre: mean(pred), dL/dm, dL/dv
+  __shared__ double sh[4];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
+  const float* P = pred + (long)b * H * W;
+  const float* T = tgt + (long)b * H * W;
+  for (int i = tid; i < LW * LW; i += 256) {
+    const int ly = i / LW, lx = i - ly * LW;
+    // reflect (H, W >= 2); positions further out than one reflection are never read
+    const int y = min(max(reflect1(ty0 + ly - 2 * R, H), 0), H - 1), x = min(max(reflect1(tx0 + lx - 2 * R, W), 0), W - 1);
+    sp[i] = P[(long)y * W + x];
+    st[i] = T[(long)y * W + x];
+  }
+  __syncthreads();
+  double val = 0.0;
+  for (int i = tid; i < CW * CW; i += 256) {
+    const int cy = i / CW, cx = i - cy * CW;
+    const int y = ty0 + cy - R, x = tx0 + cx - R;
+    float m = 0.f, dm = 0.f, dv = 0.f;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      float mt = 0.f, m2 = 0.f, m2t = 0.f;
+      int k = 0;
+#pragma unroll
+      for (int oy = -1; oy <= 1; ++oy)
+#pragma unroll
+        for (int ox = -1; ox <= 1; ++ox) {
+          ++k;
+          const float a = sp[(cy + R + oy) * LW + cx + R + ox], c = st[(cy + R + oy) * LW + cx + R + ox];
+          const float d1 = a - m;  m += d1 / (float)k;  m2 += d1 * (a - m);
+          const float e1 = c - mt; mt += e1 / (float)k; m2t += e1 * (c - mt);
+        }
+      const float v = m2 / 8.f, vt = m2t / 8.f;
+      if (vt == 0.f) {
+        const float sv = v + 1.f, tv = vt + 1.f, dmu = mt - m;
+        const float kl = logf(sqrtf(sv) / sqrtf(tv)) + (tv + dmu * dmu) / (2.f * sv) - 0.5f;
+        dm = -dmu / sv;
+        dv = 0.5f / sv - (tv + dmu * dmu) / (2.f * sv * sv);
+        // the value counts once: for centres inside the tile proper
+        if (cy >= R && cy < TS + R && cx >= R && cx < TS + R) val += (double)kl;
+      }
+    }
+    cm[i] = m; cdm[i] = dm; cdv[i] = dv;
+  }
+  __syncthreads();
+  const int qy = tid / TS, qx = tid % TS;
+  const int y = ty0 + qy, x = tx0 + qx;
+  if (grad && y < H && x < W) {
+    const float xq = sp[(qy + 2 * R) * LW + qx + 2 * R];
+    float g = 0.f;
+#pragma unroll
+    for (int py = -1; py <= 1; ++py) {
+      const int yy = y + py;
+      if (yy < 0 || yy >= H) continue;
+      int cyn = 0;                                   // how often row y appears in the reflected patch rows of yy
+#pragma unroll
+      for (int o = -1; o <= 1; ++o) cyn += reflect1(yy + o, H) == y;
+#pragma unroll
+      for (int px = -1; px <= 1; ++px) {
+        const int xx = x + px;
+        if (xx < 0 || xx >= W) continue;
+        int cxn = 0;
+#pragma unroll
+        for (int o = -1; o <= 1; ++o) cxn += reflect1(xx + o, W) == x;
+        const int ci = (qy + R + py) * CW + qx + R + px;
+        g += (float)(cyn * cxn) * (cdm[ci] * (1.f / 9.f) + cdv[ci] * (2.f / 8.f) * (xq - cm[ci]));
+      }
+    }
+    const long o = ((long)b * H + y) * W + x;
+    grad[o] = grad_accum ? grad[o] + gs * g : gs * g;
+  }
+  val = wave_sum_d(val);
+  if ((tid & 63) == 0) sh[tid >> 6] = val;
+  __syncthreads();
+  if (tid == 0) part[((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 int ew_blocks(long n) {
   long g = (n + 255) / 256;
   return (int)(g < 2048 ? g : 2048);
@@ -336,6 +426,21 @@ int srhip_l1_sparsity(const float* w, float* grad, float* loss_out, double* work
   hipLaunchKernelGGL(k_l1_sparsity, dim3(g), dim3(256), 0, st, w, grad, workspace, n, lam);
   hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(1024), 0, st, workspace, g, (double)lam, loss_out, loss_accum);
   SR_LAUNCH_CHECK("l1_sparsity");
+  return 0;
+}
+
+int srhip_loss_local_moments(const float* pred, const float* target, float* grad, float* loss_out, double* workspace,
+                             int B, int H, int W, float lam, int grad_accum, int loss_accum, void* stream) {
+  SR_REQUIRE(B > 0 && H >= 2 && W >= 2, "loss_local_moments: H, W >= 2 (reflect padding), got %dx%d", H, W);
+  SR_REQUIRE(B <= 65535, "loss_local_moments: batch %d", B);
+  hipStream_t st = (hipStream_t)stream;
+  const double count = (double)B * H * W;
+  dim3 grid(sr_cdiv(W, TS), sr_cdiv(H, TS), B);
+  hipLaunchKernelGGL(k_loss_local_moments, grid, dim3(256), 0, st, pred, target, grad, workspace, H, W,
+                     (float)((double)lam / count), grad_accum);
+  hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(1024), 0, st, workspace, (int)srhip_loss_stencil_ws(B, H, W),
+                     (double)lam / count, loss_out, loss_accum);
+  SR_LAUNCH_CHECK("loss_local_moments");
   return 0;
 }
 

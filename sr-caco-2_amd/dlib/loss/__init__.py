@@ -11,8 +11,8 @@ stored gradient.  Of the reference's 13 optional terms (off by default,
 utils_config.py:279-374) Charbonnier, L2Sum, ImageGradientLoss, LaplacianFilterLoss,
 LocalVariationLoss and their three Norm* variants are built the same way
 (dlib/loss/main.py:102-151,328-674), as are BoundedPrediction (extended log barrier,
-:189-237 + dlib/losses/elb.py) and WeightsSparsityLoss (:938-959); LocalMoments, HistogramMatch,
-KDEMatch and CrossEntropyL are not (NotImplementedError on use).
+:189-237 + dlib/losses/elb.py), WeightsSparsityLoss (:938-959) and LocalMoments (:240-325);
+HistogramMatch, KDEMatch and CrossEntropyL are not (NotImplementedError on use).
 """
 import re
 
@@ -23,7 +23,8 @@ from srhip import ops
 
 __all__ = ['MasterLoss', 'ElementaryLoss', 'L1', 'L2', 'NegativeSsim', 'L2Sum', 'Charbonnier',
            'ImageGradientLoss', 'LaplacianFilterLoss', 'LocalVariationLoss', 'NormImageGradientLoss',
-           'NormLaplacianFilterLoss', 'NormLocalVariationLoss', 'BoundedPrediction', 'WeightsSparsityLoss']
+           'NormLaplacianFilterLoss', 'NormLocalVariationLoss', 'BoundedPrediction', 'WeightsSparsityLoss',
+           'LocalMoments']
 
 NORM1, NORM2 = '1', '2'      # dlib/utils/constants.py:696-697
 
@@ -210,6 +211,35 @@ class BoundedPrediction(ElementaryLoss):
             p, t, self.lambda_, self.eps, tb, sc, grad=g, loss_out=v))
 
 
+class LocalMoments(ElementaryLoss):
+    """lambda * mean(KL(N(target patch) || N(pred patch)) * [target patch variance == 0]) over 3x3 patches
+    (reflect padding, unbiased variance, both variances + 1); dlib/loss/main.py:240-325.  As in the reference,
+    ``set_ksz`` records the list but the patch operators stay the ones built for ksz = [3] (:244-263)."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.ksz = [3]
+        self.ksz_already_set = False
+        self.eps = 1.
+
+    def set_ksz(self, ksz):
+        assert len(ksz) > 0, len(ksz)
+        for k in ksz:
+            assert isinstance(k, int) and k > 1, k
+        ksz.sort(reverse=False)
+        self.ksz = ksz
+        self.ksz_already_set = True
+
+    def forward(self, epoch, y_pred=None, y_target=None, trg_per_pixel_weight=None, model=None):
+        super().forward(epoch=epoch)
+        if not self.is_on():
+            return self._zero
+        assert y_target.shape == y_pred.shape, f'{y_target.shape}, {y_pred.shape}'
+        assert y_pred.ndim == 4 and y_pred.shape[1] == 1, "supports only one channel (local_terms.py:36)"
+        t = y_target.float().contiguous()
+        return _FusedLoss.apply(y_pred, lambda p, g, v: ops.loss_local_moments(p, t, self.lambda_, grad=g, loss_out=v))
+
+
 class _SparsityFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lam, *params):
@@ -344,6 +374,8 @@ class MasterLoss(nn.Module):
                 out.append(("boundpred", l.lambda_, l.eps, l.elb, l.restore_range, l.color_max))
             elif isinstance(l, WeightsSparsityLoss):
                 out.append(("w_sparsity", l.lambda_))
+            elif isinstance(l, LocalMoments):
+                out.append(("local_moments", l.lambda_))
             elif isinstance(l, _LocalVariationTerm):
                 out.append((("norm_" if l.channel_norm else "") + l.kind, l.lambda_,
                             1 if l.norm_str == NORM1 else 2, l.ksz))

@@ -20,6 +20,11 @@ def define_loss(args):
         l = losses.NegativeSsim(cuda_id=dev, lambda_=tr.get('ssim_lambda', 1.))
         l.set_window_size(tr.get('ssim_window_s', 11))
         m.add(l)
+    if tr.get('local_moments', False):            # utils_instance.py:77-86
+        assert not tr.get('local_moments_use_residuals', False), "use_residuals is not on the hot path"
+        l = losses.LocalMoments(cuda_id=dev, lambda_=tr.get('local_moments_lambda', 1.))
+        l.set_ksz(list(tr.get('local_moments_ksz', [3])))
+        m.add(l)
     # optional terms (keys of utils_config.py:296-357)
     if tr.get('charbonnier', False):
         l = losses.Charbonnier(cuda_id=dev, lambda_=tr.get('charbonnier_lambda', 1.))
@@ -49,7 +54,7 @@ def define_loss(args):
             else:
                 l.set_it(norm_str=str(tr.get(norm_key, constants.NORM2)))
             m.add(l)
-    for k in ('local_moments', 'hist', 'kde', 'ce'):
+    for k in ('hist', 'kde', 'ce'):
         if tr.get(k, False):
             raise NotImplementedError(f"loss term --{k} is outside the libsrhip hot path")
     if tr.get('w_sparsity', False):               # last, as in the reference (utils_instance.py:202-208)

@@ -73,6 +73,7 @@ def get_config(net_type):
                   'boundpred': False, 'boundpred_lambda': 1., 'boundpred_eps': 1., 'boundpred_restore_range': True,
                   'elb_init_t': 1., 'elb_max_t': 10., 'elb_mulcoef': 1.01,
                   'w_sparsity': False, 'w_sparsity_lambda': 1.,
+                  'local_moments': False, 'local_moments_lambda': 1., 'local_moments_ksz': [3],
                   'img_grad': False, 'img_grad_lambda': 1., 'img_grad_norm': constants.NORM2,
                   'norm_img_grad': False, 'norm_img_grad_lambda': 1., 'norm_img_grad_type': constants.NORM2,
                   'laplace': False, 'laplace_lambda': 1., 'laplace_norm': constants.NORM2,

@@ -544,6 +544,20 @@ def l1_sparsity(w, lam=1.0, grad=None, loss_out=None, loss_accum=False):
     return loss_out
 
 
+def loss_local_moments(pred, target, lam=1.0, grad=None, loss_out=None, grad_accum=False, loss_accum=False):
+    """LocalMoments on 1-channel images (dlib/loss/main.py:240-325; fixed 3x3 window, reflect padding)."""
+    _chk(pred, target, grad, loss_out)
+    assert pred.ndim == 3 or pred.shape[1] == 1, "LocalMoments: 1-channel images (local_terms.py:36)"
+    B = pred.shape[0]
+    H, W = pred.shape[-2:]
+    if loss_out is None:
+        loss_out = torch.empty(1, device=pred.device, dtype=torch.float32)
+    ws = SCRATCH.get("stencil_ws", lib.srhip_loss_stencil_ws(B, H, W), torch.float64, pred.device)
+    call("srhip_loss_local_moments", _p(pred), _p(target), _p(grad), _p(loss_out), _p(ws), B, H, W, float(lam),
+         int(grad_accum), int(loss_accum), _st())
+    return loss_out
+
+
 STENCIL_OPS = {"grad": 0, "laplace": 1, "lv": 2}
 
 

@@ -178,6 +178,8 @@ class TrainStep:
                 ops.l1_sparsity(self.fp.flat, t[1], None, part)
                 if first:
                     self.dy.zero_()
+            elif t[0] == "local_moments":
+                ops.loss_local_moments(y, target, t[1], self.dy, part, grad_accum=not first)
             elif t[0] == "l2sum":
                 ops.loss_pointwise(y, target, 3, t[1], grad=self.dy, loss_out=part, grad_accum=not first)
             elif t[0].replace("norm_", "") in ops.STENCIL_OPS:

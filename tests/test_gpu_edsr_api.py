@@ -186,6 +186,38 @@ def test_dlib_bounded_prediction_and_sparsity_vs_reference_golden():
         assert torch.equal(q.grad.cpu(), g[f"ws/g{i}"])
 
 
+def test_dlib_local_moments_vs_reference_golden():
+    """LocalMoments (KL between 3x3 patch Gaussians where the target patch is exactly flat) against the
+    reference, incl. flat regions touching the border / corner and a 5 x 7 image; then at 8 x 512 x 512
+    against the oracle on a crop."""
+    from dlib import loss as L
+    from srhip import ops
+    g = load("g13_local_moments")
+    for name in "ab":
+        m = L.MasterLoss(cuda_id=0)
+        m.add(L.LocalMoments(cuda_id=0, lambda_=0.7))
+        p = g[f"{name}/pred"].cuda().requires_grad_(True)
+        v = m(epoch=0, y_pred=p, y_target=g[f"{name}/target"].cuda(), trg_per_pixel_weight=None, model=None)
+        v.backward()
+        rv, rg = g[f"{name}/value"], g[f"{name}/grad"]
+        assert abs(float(v) - float(rv)) <= 2e-6 * max(1.0, abs(float(rv))), (name, float(v), float(rv))
+        assert (p.grad.cpu() - rg).abs().max() <= 2e-6 * max(1.0, float(rg.abs().max())), name
+        assert m.n_holder == list(g[f"{name}/names"]) and m.terms() == [("local_moments", 0.7)]
+    gen = torch.Generator().manual_seed(13)
+    p = torch.rand(8, 1, 512, 512, generator=gen)
+    t = torch.round(torch.rand(8, 1, 512, 512, generator=gen) * 255) / 255
+    t[:, :, 100:300, 50:400] = 12.0 / 255
+    t[3, :, :, :64] = 0.0
+    gr = torch.empty_like(p).cuda()
+    v = ops.loss_local_moments(p.cuda(), t.cuda(), 1.0, gr)
+    po = p[3:4].clone().requires_grad_(True)
+    vo = O.loss_local_moments(po, t[3:4], 1.0)
+    vo.backward()
+    assert (gr[3:4].cpu() * 8 - po.grad).abs().max() <= 2e-6 * po.grad.abs().max()
+    pa = p.clone().requires_grad_(True)
+    assert abs(float(v) - float(O.loss_local_moments(pa, t, 1.0))) <= 1e-5 * abs(float(v))
+
+
 def test_optional_loss_terms_full_size_properties():
     """At the benchmark's 8 x 512 x 512: linearity of the plain local-variation terms in the difference
     (loss(pred, target) == loss(pred - target, 0)), zero loss / zero gradient at pred == target, tile-seam
