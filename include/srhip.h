@@ -268,6 +268,12 @@ int srhip_l1_sparsity(const float* w, float* grad, float* loss_out, double* work
  * patch variance == 0]) with both variances + 1.  workspace doubles: srhip_loss_stencil_ws(B,H,W). */
 int srhip_loss_local_moments(const float* pred, const float* target, float* grad, float* loss_out, double* workspace,
                              int B, int H, int W, float lam, int grad_accum, int loss_accum, void* stream);
+/* HistogramMatch, NORM1 / NORM2 metrics (dlib/loss/main.py:690-782) over SoftHistogram(bins, 0, 1, sigma)
+ * (dlib/loss/global_terms.py:17-72): lam * mean_{b,k} nrm((h_pred + 1)/sum - (h_target + 1)/sum); n = values
+ * per image.  workspace floats: srhip_loss_hist_ws(B, bins). */
+long srhip_loss_hist_ws(int B, int bins);
+int srhip_loss_hist(const float* pred, const float* target, float* grad, float* loss_out, float* workspace, int B,
+                    long n, int bins, float sigma, int norm, float lam, int grad_accum, int loss_accum, void* stream);
 /* Local-variation terms on 1-channel images [B][H][W] (dlib/loss/main.py:328-674 with the operators of
  * dlib/loss/local_variations.py:18-141, replicate padding): op 0 image gradient (2 stencils), 1 Laplacian
  * (1), 2 local variation over a ksz x ksz window (ksz^2 - 1 stencils; ksz 3, 5 or 7).  norm 1 | 2 = the

@@ -490,6 +490,26 @@ def loss_local_moments(pred: Tensor, target: Tensor, lam: float = 1.0) -> Tensor
     return lam * (kl * flat).mean()
 
 
+def soft_histogram(x: Tensor, bins: int = 256, sigma: float = 1e5) -> Tensor:
+    """loss/global_terms.py:17-72 with min 0, max 1: x [b, n] -> [b, bins]."""
+    delta = float(1.0) / float(bins)
+    centers = 0.0 + delta * (torch.arange(bins).float() + 0.5)
+    d = x.unsqueeze(1) - centers.unsqueeze(1)
+    return (torch.sigmoid(sigma * (d + delta / 2.)) - torch.sigmoid(sigma * (d - delta / 2.))).sum(dim=-1)
+
+
+def loss_histogram_match(pred: Tensor, target: Tensor, lam: float = 1.0, norm: int = 2, sigma: float = 1e5,
+                         bins: int = 256) -> Tensor:
+    """loss/main.py:690-782, NORM1 / NORM2 metrics: histograms + 1, normalised, compared bin by bin."""
+    b = target.shape[0]
+    t = soft_histogram(target.contiguous().view(b, -1), bins, sigma) + 1.
+    t = t / t.sum(dim=-1).view(-1, 1)
+    p = soft_histogram(pred.contiguous().view(b, -1), bins, sigma) + 1.
+    p = p / p.sum(dim=-1).view(-1, 1)
+    e = p - t
+    return lam * (e.abs() if norm == 1 else e * e).mean()
+
+
 def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
                 weight: Optional[Tensor] = None) -> Tuple[Tensor, List[Tensor]]:
     """loss/master.py:46-56.  ``terms``: ('l1',lam) | ('l2',lam) |
@@ -510,6 +530,8 @@ def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
             parts.append(loss_l2sum(pred, target, t[1]))
         elif t[0] == "local_moments":
             parts.append(loss_local_moments(pred, target, t[1]))
+        elif t[0] == "hist":               # (kind, lam, norm, sigma, bins)
+            parts.append(loss_histogram_match(pred, target, t[1], t[2], t[3], t[4]))
         elif t[0] == "boundpred":          # (kind, lam, eps, t, restore_range, color_max)
             parts.append(loss_bounded_prediction(pred, target, t[1], t[2], t[3], t[4], t[5]))
         elif t[0] in ("grad", "laplace", "lv", "norm_grad", "norm_laplace", "norm_lv"):

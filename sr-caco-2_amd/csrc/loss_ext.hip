@@ -375,6 +375,97 @@ __global__ void __launch_bounds__(256) k_loss_local_moments(const float* __restr
   if (tid == 0) part[((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// HistogramMatch (dlib/loss/main.py:690-782) with SoftHistogram (dlib/loss/global_terms.py:17-72):
+//   h[b][k] = sum_px sigmoid(s (x - c_k + d/2)) - sigmoid(s (x - c_k - d/2)),  c_k = d (k + 1/2), d = 1 / bins
+//   p = (h + 1) / sum_k (h + 1)  for pred and target;  loss = lam * mean_{b,k} nrm(p_pred - p_target)
+// The reference evaluates all bins for every pixel (b x bins x n sigmoid pairs).  In float32 a pair is
+// exactly 0 once both arguments are beyond +17 (both sigmoids round to 1) or below -104 (both underflow
+// to 0), i.e. for every bin further than RB = ceil(104 / (s d)) + 1 bins from the pixel's own -- with the
+// default s = 1e5 only the neighbours -- so only those are visited: the same sums, 3 x 2 sigmoids per
+// pixel instead of 256 x 2.
+constexpr int HB = 64;                 // blocks per image
+__device__ __forceinline__ float sigmoid_f(float z) { return 1.f / (1.f + expf(-z)); }
+
+__global__ void __launch_bounds__(256) k_soft_hist(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                   float* __restrict__ part, long n, int bins, float delta,
+                                                   float half, float sigma, int rb) {
+  extern __shared__ float hist[];                 // [2][bins]
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < 2 * bins; i += 256) hist[i] = 0.f;
+  __syncthreads();
+  const long per = (n + HB - 1) / HB, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float x = (a ? tgt : pred)[(long)b * n + i];
+      const int k0 = min(max((int)(x / delta), 0), bins - 1);
+      for (int k = max(k0 - rb, 0); k <= min(k0 + rb, bins - 1); ++k) {
+        const float d = x - delta * ((float)k + 0.5f);
+        const float v = sigmoid_f(sigma * (d + half)) - sigmoid_f(sigma * (d - half));
+        if (v != 0.f) atomicAdd(&hist[a * bins + k], v);
+      }
+    }
+  }
+  __syncthreads();
+  float* o = part + ((long)b * HB + blockIdx.x) * 2 * bins;
+  for (int i = threadIdx.x; i < 2 * bins; i += 256) o[i] = hist[i];
+}
+
+// one block per image: histograms, the normalised difference, its loss share and dL/dh(pred)
+__global__ void __launch_bounds__(256) k_hist_finalize(const float* __restrict__ part, float* __restrict__ dldh,
+                                                       double* __restrict__ lpart, int bins, int l1, float gs) {
+  __shared__ float red[2][4];
+  __shared__ float bc[3];
+  const int b = blockIdx.x, k = threadIdx.x;
+  float hp = 0.f, ht = 0.f;
+  if (k < bins) {
+    for (int j = 0; j < HB; ++j) {
+      const float* o = part + ((long)b * HB + j) * 2 * bins;
+      hp += o[k]; ht += o[bins + k];
+    }
+    hp += 1.f; ht += 1.f;
+  }
+  float s1 = wave_sum(k < bins ? hp : 0.f), s2 = wave_sum(k < bins ? ht : 0.f);
+  if ((k & 63) == 0) { red[0][k >> 6] = s1; red[1][k >> 6] = s2; }
+  __syncthreads();
+  const float Sp = red[0][0] + red[0][1] + red[0][2] + red[0][3], St = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  __syncthreads();
+  const float P = k < bins ? hp / Sp : 0.f, Q = k < bins ? ht / St : 0.f;
+  const float e = P - Q;
+  const float dLdP = k < bins ? gs * nrm_der(e, l1) : 0.f;                 // gs = lam / (B * bins)
+  float lv = wave_sum(k < bins ? nrm_val(e, l1) : 0.f), dp = wave_sum(dLdP * P);
+  if ((k & 63) == 0) { red[0][k >> 6] = lv; red[1][k >> 6] = dp; }
+  __syncthreads();
+  if (k == 0) {
+    bc[0] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    lpart[b] = (double)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+  }
+  __syncthreads();
+  if (k < bins) dldh[(long)b * bins + k] = (dLdP - bc[0]) / Sp;            // d/dh of (h + 1) / sum(h + 1)
+}
+
+__global__ void __launch_bounds__(256) k_soft_hist_grad(const float* __restrict__ pred, const float* __restrict__ dldh,
+                                                        float* __restrict__ grad, long n, int bins, float delta,
+                                                        float half, float sigma, int rb, int grad_accum) {
+  extern __shared__ float dl[];                   // [bins]
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < bins; i += 256) dl[i] = dldh[(long)b * bins + i];
+  __syncthreads();
+  const long per = (n + HB - 1) / HB, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float x = pred[(long)b * n + i];
+    const int k0 = min(max((int)(x / delta), 0), bins - 1);
+    float g = 0.f;
+    for (int k = max(k0 - rb, 0); k <= min(k0 + rb, bins - 1); ++k) {
+      const float d = x - delta * ((float)k + 0.5f);
+      const float sa = sigmoid_f(sigma * (d + half)), sb = sigmoid_f(sigma * (d - half));
+      g += dl[k] * sigma * (sa * (1.f - sa) - sb * (1.f - sb));
+    }
+    const long o = (long)b * n + i;
+    grad[o] = grad_accum ? grad[o] + g : g;
+  }
+}
+
 int ew_blocks(long n) {
   long g = (n + 255) / 256;
   return (int)(g < 2048 ? g : 2048);
@@ -441,6 +532,34 @@ int srhip_loss_local_moments(const float* pred, const float* target, float* grad
   hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(1024), 0, st, workspace, (int)srhip_loss_stencil_ws(B, H, W),
                      (double)lam / count, loss_out, loss_accum);
   SR_LAUNCH_CHECK("loss_local_moments");
+  return 0;
+}
+
+long srhip_loss_hist_ws(int B, int bins) { return (long)B * HB * 2 * bins + (long)B * bins + 2L * B; }
+
+int srhip_loss_hist(const float* pred, const float* target, float* grad, float* loss_out, float* workspace, int B,
+                    long n, int bins, float sigma, int norm, float lam, int grad_accum, int loss_accum, void* stream) {
+  SR_REQUIRE(B > 0 && n > 0 && B <= 65535, "loss_hist: empty input");
+  SR_REQUIRE(bins > 0 && bins <= 256, "loss_hist: 1..256 bins (got %d)", bins);
+  SR_REQUIRE(sigma > 0.f && (norm == 1 || norm == 2), "loss_hist: sigma > 0, norm 1 or 2");
+  hipStream_t st = (hipStream_t)stream;
+  // SoftHistogram(bins, min=0, max=1, sigma): delta = 1/bins as the reference's float32 tensor arithmetic sees it
+  const float delta = (float)(1.0 / (double)bins), half = (float)((1.0 / (double)bins) / 2.0);
+  const double reach = 104.0 / ((double)sigma * (double)delta);
+  const int rb = reach >= (double)bins ? bins : (int)reach + 2;
+  float* part = workspace;
+  float* dldh = part + (long)B * HB * 2 * bins;
+  double* lpart = (double*)(dldh + (long)B * bins + (((long)B * bins) & 1));       // 8-byte aligned
+  hipLaunchKernelGGL(k_soft_hist, dim3(HB, B), dim3(256), 2 * bins * sizeof(float), st, pred, target, part, n, bins,
+                     delta, half, sigma, rb);
+  const double cnt = (double)B * bins;
+  hipLaunchKernelGGL(k_hist_finalize, dim3(B), dim3(256), 0, st, part, dldh, lpart, bins, norm == 1,
+                     (float)((double)lam / cnt));
+  if (grad)
+    hipLaunchKernelGGL(k_soft_hist_grad, dim3(HB, B), dim3(256), bins * sizeof(float), st, pred, dldh, grad, n, bins,
+                       delta, half, sigma, rb, grad_accum);
+  hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(1024), 0, st, lpart, B, (double)lam / cnt, loss_out, loss_accum);
+  SR_LAUNCH_CHECK("loss_hist");
   return 0;
 }
 

@@ -12,7 +12,8 @@ utils_config.py:279-374) Charbonnier, L2Sum, ImageGradientLoss, LaplacianFilterL
 LocalVariationLoss and their three Norm* variants are built the same way
 (dlib/loss/main.py:102-151,328-674), as are BoundedPrediction (extended log barrier,
 :189-237 + dlib/losses/elb.py), WeightsSparsityLoss (:938-959) and LocalMoments (:240-325);
-HistogramMatch, KDEMatch and CrossEntropyL are not (NotImplementedError on use).
+HistogramMatch with its NORM1 / NORM2 metrics (:690-782); its KL / Bhattacharyya metrics, KDEMatch and
+CrossEntropyL are not (NotImplementedError on use).
 """
 import re
 
@@ -24,7 +25,9 @@ from srhip import ops
 __all__ = ['MasterLoss', 'ElementaryLoss', 'L1', 'L2', 'NegativeSsim', 'L2Sum', 'Charbonnier',
            'ImageGradientLoss', 'LaplacianFilterLoss', 'LocalVariationLoss', 'NormImageGradientLoss',
            'NormLaplacianFilterLoss', 'NormLocalVariationLoss', 'BoundedPrediction', 'WeightsSparsityLoss',
-           'LocalMoments']
+           'LocalMoments', 'HistogramMatch']
+
+KL, BH = 'KL', 'BHATTACHARYYA'      # dlib/utils/constants.py:699-700 (HistogramMatch metrics that are not built)
 
 NORM1, NORM2 = '1', '2'      # dlib/utils/constants.py:696-697
 
@@ -240,6 +243,37 @@ class LocalMoments(ElementaryLoss):
         return _FusedLoss.apply(y_pred, lambda p, g, v: ops.loss_local_moments(p, t, self.lambda_, grad=g, loss_out=v))
 
 
+class HistogramMatch(ElementaryLoss):
+    """lambda * mean_{b,bin} nrm(p_pred - p_target), p = (soft histogram + 1) normalised, 256 bins over [0, 1],
+    sigmoid sharpness sigma (1e5); dlib/loss/main.py:690-782.  NORM1 / NORM2 metrics."""
+
+    def __init__(self, color_min=0, color_max=255, **kwargs):
+        super().__init__(**kwargs)
+        self.color_min, self.color_max = color_min, color_max
+        self.norm_str = NORM2
+        self.sigma = 1e5
+        self.already_set = False
+        self.nbins = len(list(range(color_min, color_max))) + 1
+
+    def set_it(self, norm_str, sigma):
+        assert isinstance(sigma, float) and sigma > 0., sigma
+        assert isinstance(norm_str, str) and norm_str in (NORM2, NORM1, KL, BH), norm_str
+        if norm_str in (KL, BH):
+            raise NotImplementedError(f"HistogramMatch metric {norm_str}: only NORM1 / NORM2 run on libsrhip")
+        self.sigma, self.norm_str, self.already_set = sigma, norm_str, True
+        self.nbins = len(list(range(self.color_min, self.color_max))) + 1
+
+    def forward(self, epoch, y_pred=None, y_target=None, trg_per_pixel_weight=None, model=None):
+        super().forward(epoch=epoch)
+        if not self.is_on():
+            return self._zero
+        assert y_target.shape == y_pred.shape, f'{y_target.shape}, {y_pred.shape}'
+        t = y_target.float().contiguous()
+        norm = 1 if self.norm_str == NORM1 else 2
+        return _FusedLoss.apply(y_pred, lambda p, g, v: ops.loss_hist(
+            p, t, self.lambda_, norm, self.sigma, self.nbins, grad=g, loss_out=v))
+
+
 class _SparsityFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lam, *params):
@@ -376,6 +410,8 @@ class MasterLoss(nn.Module):
                 out.append(("w_sparsity", l.lambda_))
             elif isinstance(l, LocalMoments):
                 out.append(("local_moments", l.lambda_))
+            elif isinstance(l, HistogramMatch):
+                out.append(("hist", l.lambda_, 1 if l.norm_str == NORM1 else 2, l.sigma, l.nbins))
             elif isinstance(l, _LocalVariationTerm):
                 out.append((("norm_" if l.channel_norm else "") + l.kind, l.lambda_,
                             1 if l.norm_str == NORM1 else 2, l.ksz))

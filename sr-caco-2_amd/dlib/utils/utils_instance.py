@@ -54,7 +54,11 @@ def define_loss(args):
             else:
                 l.set_it(norm_str=str(tr.get(norm_key, constants.NORM2)))
             m.add(l)
-    for k in ('hist', 'kde', 'ce'):
+    if tr.get('hist', False):                     # utils_instance.py:168-177
+        l = losses.HistogramMatch(cuda_id=dev, lambda_=tr.get('hist_lambda', 1.), color_min=0, color_max=255)
+        l.set_it(norm_str=str(tr.get('hist_metric', constants.NORM2)), sigma=float(tr.get('hist_sigma', 1e5)))
+        m.add(l)
+    for k in ('kde', 'ce'):
         if tr.get(k, False):
             raise NotImplementedError(f"loss term --{k} is outside the libsrhip hot path")
     if tr.get('w_sparsity', False):               # last, as in the reference (utils_instance.py:202-208)

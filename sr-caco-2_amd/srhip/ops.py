@@ -558,6 +558,21 @@ def loss_local_moments(pred, target, lam=1.0, grad=None, loss_out=None, grad_acc
     return loss_out
 
 
+def loss_hist(pred, target, lam=1.0, norm=2, sigma=1e5, bins=256, grad=None, loss_out=None, grad_accum=False,
+              loss_accum=False):
+    """HistogramMatch with the NORM1 / NORM2 metrics over soft histograms of each image of the batch
+    (dlib/loss/main.py:690-782, dlib/loss/global_terms.py:17-72)."""
+    _chk(pred, target, grad, loss_out)
+    B = pred.shape[0]
+    n = pred.numel() // B
+    if loss_out is None:
+        loss_out = torch.empty(1, device=pred.device, dtype=torch.float32)
+    ws = SCRATCH.get("hist_ws", lib.srhip_loss_hist_ws(B, bins), device=pred.device)
+    call("srhip_loss_hist", _p(pred), _p(target), _p(grad), _p(loss_out), _p(ws), B, n, int(bins), float(sigma),
+         int(norm), float(lam), int(grad_accum), int(loss_accum), _st())
+    return loss_out
+
+
 STENCIL_OPS = {"grad": 0, "laplace": 1, "lv": 2}
 
 

@@ -218,6 +218,43 @@ def test_dlib_local_moments_vs_reference_golden():
     assert abs(float(v) - float(O.loss_local_moments(pa, t, 1.0))) <= 1e-5 * abs(float(v))
 
 
+def test_dlib_histogram_match_vs_reference_golden():
+    """HistogramMatch (NORM1 / NORM2) against the reference at the default sigma 1e5 (only the neighbouring bins
+    of a pixel are non-zero in float32 -- the kernel visits just those) and at soft sigmas where many / all
+    bins contribute; then the sparse evaluation against the dense oracle at 8 x 256 x 256."""
+    from dlib import loss as L
+    from dlib.losses.elb import ELB
+    from srhip import ops
+    g = load("g14_hist")
+    for name in ("l2_default", "l1_default", "l2_soft", "l1_wide"):
+        lam, norm, sigma = [float(v) for v in g[name + "/cfg"]]
+        l = L.HistogramMatch(cuda_id=0, lambda_=lam, elb=ELB(), color_min=0, color_max=255)
+        l.set_it(norm_str=L.NORM1 if norm == 1 else L.NORM2, sigma=sigma)
+        m = L.MasterLoss(cuda_id=0)
+        m.add(l)
+        p = g["pred"].cuda().requires_grad_(True)
+        v = m(epoch=0, y_pred=p, y_target=g["target"].cuda(), trg_per_pixel_weight=None, model=None)
+        v.backward()
+        rv, rg = g[name + "/value"], g[name + "/grad"]
+        assert abs(float(v) - float(rv)) <= 2e-5 * abs(float(rv)), (name, float(v), float(rv))
+        assert (p.grad.cpu() - rg).abs().max() <= 2e-4 * float(rg.abs().max()), (name, (p.grad.cpu() - rg).abs().max())
+        assert m.n_holder == list(g[name + "/names"])
+    with pytest.raises(NotImplementedError):
+        L.HistogramMatch(cuda_id=0, elb=ELB()).set_it(norm_str=L.KL, sigma=1e5)
+    gen = torch.Generator().manual_seed(21)
+    p = torch.rand(8, 1, 256, 256, generator=gen)
+    t = torch.round(torch.rand(8, 1, 256, 256, generator=gen) ** 2 * 255) / 255
+    for norm, sigma in ((2, 1e5), (1, 5e3)):
+        gr = torch.empty_like(p).cuda()
+        v = ops.loss_hist(p.cuda(), t.cuda(), 1.0, norm, sigma, 256, gr)
+        po = p[:2].clone().requires_grad_(True)                      # the dense oracle on two images
+        pa = torch.cat([po, p[2:]])
+        vo = O.loss_histogram_match(pa, t, 1.0, norm, sigma, 256)
+        vo.backward()
+        assert abs(float(v) - float(vo)) <= 2e-5 * abs(float(vo)), (norm, sigma, float(v), float(vo))
+        assert (gr[:2].cpu() - po.grad).abs().max() <= 5e-4 * po.grad.abs().max(), (norm, sigma)
+
+
 def test_optional_loss_terms_full_size_properties():
     """At the benchmark's 8 x 512 x 512: linearity of the plain local-variation terms in the difference
     (loss(pred, target) == loss(pred - target, 0)), zero loss / zero gradient at pred == target, tile-seam
