@@ -274,6 +274,11 @@ int srhip_loss_local_moments(const float* pred, const float* target, float* grad
 long srhip_loss_hist_ws(int B, int bins);
 int srhip_loss_hist(const float* pred, const float* target, float* grad, float* loss_out, float* workspace, int B,
                     long n, int bins, float sigma, int norm, float lam, int grad_accum, int loss_accum, void* stream);
+/* KDEMatch, NORM1 / NORM2 metrics (dlib/loss/main.py:785-898) over GaussianKDE(kde_bw, bins, max_color 1, 1 channel)
+ * (dlib/loss/global_terms.py:75-152): lam * mean_{b,k} nrm((p_pred + 1e-4) - (p_target + 1e-4)) / bins,
+ * p[k] = mean_px N(x; linspace(0,1,bins)[k], kde_bw).  workspace floats: srhip_loss_hist_ws(B, bins). */
+int srhip_loss_kde(const float* pred, const float* target, float* grad, float* loss_out, float* workspace, int B,
+                   long n, int bins, float kde_bw, int norm, float lam, int grad_accum, int loss_accum, void* stream);
 /* Local-variation terms on 1-channel images [B][H][W] (dlib/loss/main.py:328-674 with the operators of
  * dlib/loss/local_variations.py:18-141, replicate padding): op 0 image gradient (2 stencils), 1 Laplacian
  * (1), 2 local variation over a ksz x ksz window (ksz^2 - 1 stencils; ksz 3, 5 or 7).  norm 1 | 2 = the

@@ -587,6 +587,36 @@ def g_hist():
     npz("g14_hist", **out)
 
 
+def g_kde():
+    print("G15 KDEMatch (NORM1 / NORM2)")
+    from dlib.losses.elb import ELB
+    torch.manual_seed(43)
+    pred = torch.rand(2, 1, 32, 48) * 1.1 - 0.05
+    tgt = torch.round(torch.rand(2, 1, 32, 48) * 255) / 255
+    tgt[0, :, :16] = (torch.round(torch.rand(16, 48) * 40) + 3) / 255
+    out = dict(pred=pred, target=tgt)
+    for name, (lam, norm, bw) in {"l2_default": (1.0, 2, 1. / 255. ** 2), "l1_default": (3.0, 1, 1. / 255. ** 2),
+                                  "l2_wide": (1.0, 2, 1e-3)}.items():
+        with cpu_as_cuda():
+            l = ref_loss.KDEMatch(cuda_id="cpu", lambda_=lam, elb=ELB(), color_min=0, color_max=1)
+            l.set_it(norm_str=ref_c.NORM1 if norm == 1 else ref_c.NORM2, kde_bw=float(bw), ndim=1, nbins=256)
+        m = ref_loss.MasterLoss(cuda_id="cpu")
+        m.add(l)
+        pr = pred.clone().requires_grad_(True)
+        v = m(epoch=0, y_pred=pr, y_target=tgt, trg_per_pixel_weight=None, model=None)
+        v.backward()
+        po = pred.clone().requires_grad_(True)
+        vo = O.loss_kde_match(po, tgt, lam, norm, bw, 256)
+        vo.backward()
+        close(vo.detach(), v.detach(), 1e-6 * abs(float(v)), f"kde {name}")
+        close(po.grad, pr.grad, 1e-6 * float(pr.grad.abs().max()), f"d kde {name}")
+        out[f"{name}/value"], out[f"{name}/grad"] = v.detach(), pr.grad
+        out[f"{name}/cfg"] = np.array([lam, norm, bw], dtype=np.float64)
+        out[f"{name}/names"] = np.array(m.n_holder)
+        print(f"    value {float(v):.4e}  max|grad| {float(pr.grad.abs().max()):.3e}")
+    npz("g15_kde", **out)
+
+
 def g_interpolate():
     print("G11 Interpolate (Bicubic baseline)")
     # utils_trainer.py does not import here (matplotlib style): compile ONLY the reference's
@@ -733,7 +763,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_interpolate, g_patches,
+    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_interpolate, g_patches,
             g_metrics, g_optim]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

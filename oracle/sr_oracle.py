@@ -510,6 +510,27 @@ def loss_histogram_match(pred: Tensor, target: Tensor, lam: float = 1.0, norm: i
     return lam * (e.abs() if norm == 1 else e * e).mean()
 
 
+def gaussian_kde(images: Tensor, kde_bw: float, bins: int = 256) -> Tensor:
+    """loss/global_terms.py:75-152 for 1-channel images in [0, 1]: [b, 1, h, w] -> [b, bins]."""
+    c1 = torch.tensor((2. * math.pi * kde_bw) ** (-1 / 2.), dtype=torch.float32)
+    c2 = torch.tensor(2. * kde_bw, dtype=torch.float32)
+    cs = torch.linspace(0., 1., bins, dtype=torch.float32).view(-1, 1)
+    out = []
+    for img in images:
+        x = img.contiguous().view(1, 1, -1)
+        out.append((c1 * torch.exp(-((x - cs) ** 2) / c2)).mean(dim=-1).squeeze(0))
+    return torch.stack(out)
+
+
+def loss_kde_match(pred: Tensor, target: Tensor, lam: float = 1.0, norm: int = 2, kde_bw: float = 1. / 255. ** 2,
+                   bins: int = 256) -> Tensor:
+    """loss/main.py:785-898, NORM1 / NORM2 metrics: (kde + 1e-4) compared bin by bin, mean / bins."""
+    t = gaussian_kde(target, kde_bw, bins) + 1e-4
+    p = gaussian_kde(pred, kde_bw, bins) + 1e-4
+    e = p - t
+    return lam * (e.abs() if norm == 1 else e * e).mean() / float(bins)
+
+
 def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
                 weight: Optional[Tensor] = None) -> Tuple[Tensor, List[Tensor]]:
     """loss/master.py:46-56.  ``terms``: ('l1',lam) | ('l2',lam) |
@@ -530,6 +551,8 @@ def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
             parts.append(loss_l2sum(pred, target, t[1]))
         elif t[0] == "local_moments":
             parts.append(loss_local_moments(pred, target, t[1]))
+        elif t[0] == "kde":                # (kind, lam, norm, kde_bw, bins)
+            parts.append(loss_kde_match(pred, target, t[1], t[2], t[3], t[4]))
         elif t[0] == "hist":               # (kind, lam, norm, sigma, bins)
             parts.append(loss_histogram_match(pred, target, t[1], t[2], t[3], t[4]))
         elif t[0] == "boundpred":          # (kind, lam, eps, t, restore_range, color_max)

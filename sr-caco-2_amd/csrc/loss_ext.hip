@@ -386,6 +386,22 @@ __global__ void __launch_bounds__(256) k_loss_local_moments(const float* __restr
 constexpr int HB = 64;                 // blocks per image
 __device__ __forceinline__ float sigmoid_f(float z) { return 1.f / (1.f + expf(-z)); }
 
+// MODE 0: soft histogram (above).  MODE 1: Gaussian KDE of KDEMatch (dlib/loss/global_terms.py:75-152):
+//   p[b][k] = mean_px c1 exp(-(x - cs_k)^2 / c2),  cs = linspace(0, 1, bins), c1 = (2 pi bw)^-1/2, c2 = 2 bw
+// (delta = 1 / (bins - 1), half = c2, sigma = c1 here); exp underflows to exactly 0 beyond
+// |x - cs_k| > sqrt(104 c2), which bounds the bins a pixel touches the same way.
+template <int MODE>
+__device__ __forceinline__ float bin_center(int k, float delta, int bins) {
+  if (MODE == 0) return delta * ((float)k + 0.5f);
+  // torch.linspace(0, 1, bins): from the start below the middle, from the end above it
+  return k < bins / 2 ? delta * (float)k : 1.f - delta * (float)(bins - 1 - k);
+}
+template <int MODE>
+__device__ __forceinline__ int own_bin(float x, float delta, int bins) {
+  return min(max((int)(MODE == 0 ? x / delta : x / delta + 0.5f), 0), bins - 1);
+}
+
+template <int MODE>
 __global__ void __launch_bounds__(256) k_soft_hist(const float* __restrict__ pred, const float* __restrict__ tgt,
                                                    float* __restrict__ part, long n, int bins, float delta,
                                                    float half, float sigma, int rb) {
@@ -398,10 +414,11 @@ __global__ void __launch_bounds__(256) k_soft_hist(const float* __restrict__ pre
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const float x = (a ? tgt : pred)[(long)b * n + i];
-      const int k0 = min(max((int)(x / delta), 0), bins - 1);
+      const int k0 = own_bin<MODE>(x, delta, bins);
       for (int k = max(k0 - rb, 0); k <= min(k0 + rb, bins - 1); ++k) {
-        const float d = x - delta * ((float)k + 0.5f);
-        const float v = sigmoid_f(sigma * (d + half)) - sigmoid_f(sigma * (d - half));
+        const float d = x - bin_center<MODE>(k, delta, bins);
+        const float v = MODE == 0 ? sigmoid_f(sigma * (d + half)) - sigmoid_f(sigma * (d - half))
+                                  : sigma * expf(-(d * d) / half);
         if (v != 0.f) atomicAdd(&hist[a * bins + k], v);
       }
     }
@@ -412,8 +429,10 @@ __global__ void __launch_bounds__(256) k_soft_hist(const float* __restrict__ pre
 }
 
 // one block per image: histograms, the normalised difference, its loss share and dL/dh(pred)
+// kde > 0: KDEMatch's form -- p = mean over the kde pixels + 1e-4 on both sides, no normalisation
 __global__ void __launch_bounds__(256) k_hist_finalize(const float* __restrict__ part, float* __restrict__ dldh,
-                                                       double* __restrict__ lpart, int bins, int l1, float gs) {
+                                                       double* __restrict__ lpart, int bins, int l1, float gs,
+                                                       float kde) {
   __shared__ float red[2][4];
   __shared__ float bc[3];
   const int b = blockIdx.x, k = threadIdx.x;
@@ -423,14 +442,15 @@ __global__ void __launch_bounds__(256) k_hist_finalize(const float* __restrict__
       const float* o = part + ((long)b * HB + j) * 2 * bins;
       hp += o[k]; ht += o[bins + k];
     }
-    hp += 1.f; ht += 1.f;
+    if (kde > 0.f) { hp = hp / kde + 1e-4f; ht = ht / kde + 1e-4f; }
+    else { hp += 1.f; ht += 1.f; }
   }
   float s1 = wave_sum(k < bins ? hp : 0.f), s2 = wave_sum(k < bins ? ht : 0.f);
   if ((k & 63) == 0) { red[0][k >> 6] = s1; red[1][k >> 6] = s2; }
   __syncthreads();
   const float Sp = red[0][0] + red[0][1] + red[0][2] + red[0][3], St = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   __syncthreads();
-  const float P = k < bins ? hp / Sp : 0.f, Q = k < bins ? ht / St : 0.f;
+  const float P = k < bins ? (kde > 0.f ? hp : hp / Sp) : 0.f, Q = k < bins ? (kde > 0.f ? ht : ht / St) : 0.f;
   const float e = P - Q;
   const float dLdP = k < bins ? gs * nrm_der(e, l1) : 0.f;                 // gs = lam / (B * bins)
   float lv = wave_sum(k < bins ? nrm_val(e, l1) : 0.f), dp = wave_sum(dLdP * P);
@@ -441,9 +461,11 @@ __global__ void __launch_bounds__(256) k_hist_finalize(const float* __restrict__
     lpart[b] = (double)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
   }
   __syncthreads();
-  if (k < bins) dldh[(long)b * bins + k] = (dLdP - bc[0]) / Sp;            // d/dh of (h + 1) / sum(h + 1)
+  if (k < bins) dldh[(long)b * bins + k] = kde > 0.f ? dLdP / kde            // d/dh of h / n + eps
+                                                      : (dLdP - bc[0]) / Sp;  // d/dh of (h + 1) / sum(h + 1)
 }
 
+template <int MODE>
 __global__ void __launch_bounds__(256) k_soft_hist_grad(const float* __restrict__ pred, const float* __restrict__ dldh,
                                                         float* __restrict__ grad, long n, int bins, float delta,
                                                         float half, float sigma, int rb, int grad_accum) {
@@ -454,12 +476,16 @@ __global__ void __launch_bounds__(256) k_soft_hist_grad(const float* __restrict_
   const long per = (n + HB - 1) / HB, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
   for (long i = lo + threadIdx.x; i < hi; i += 256) {
     const float x = pred[(long)b * n + i];
-    const int k0 = min(max((int)(x / delta), 0), bins - 1);
+    const int k0 = own_bin<MODE>(x, delta, bins);
     float g = 0.f;
     for (int k = max(k0 - rb, 0); k <= min(k0 + rb, bins - 1); ++k) {
-      const float d = x - delta * ((float)k + 0.5f);
-      const float sa = sigmoid_f(sigma * (d + half)), sb = sigmoid_f(sigma * (d - half));
-      g += dl[k] * sigma * (sa * (1.f - sa) - sb * (1.f - sb));
+      const float d = x - bin_center<MODE>(k, delta, bins);
+      if (MODE == 0) {
+        const float sa = sigmoid_f(sigma * (d + half)), sb = sigmoid_f(sigma * (d - half));
+        g += dl[k] * sigma * (sa * (1.f - sa) - sb * (1.f - sb));
+      } else {
+        g += dl[k] * sigma * expf(-(d * d) / half) * (-2.f * d / half);
+      }
     }
     const long o = (long)b * n + i;
     grad[o] = grad_accum ? grad[o] + g : g;
@@ -550,16 +576,44 @@ int srhip_loss_hist(const float* pred, const float* target, float* grad, float* 
   float* part = workspace;
   float* dldh = part + (long)B * HB * 2 * bins;
   double* lpart = (double*)(dldh + (long)B * bins + (((long)B * bins) & 1));       // 8-byte aligned
-  hipLaunchKernelGGL(k_soft_hist, dim3(HB, B), dim3(256), 2 * bins * sizeof(float), st, pred, target, part, n, bins,
+  hipLaunchKernelGGL(k_soft_hist<0>, dim3(HB, B), dim3(256), 2 * bins * sizeof(float), st, pred, target, part, n, bins,
                      delta, half, sigma, rb);
   const double cnt = (double)B * bins;
   hipLaunchKernelGGL(k_hist_finalize, dim3(B), dim3(256), 0, st, part, dldh, lpart, bins, norm == 1,
-                     (float)((double)lam / cnt));
+                     (float)((double)lam / cnt), 0.f);
   if (grad)
-    hipLaunchKernelGGL(k_soft_hist_grad, dim3(HB, B), dim3(256), bins * sizeof(float), st, pred, dldh, grad, n, bins,
+    hipLaunchKernelGGL(k_soft_hist_grad<0>, dim3(HB, B), dim3(256), bins * sizeof(float), st, pred, dldh, grad, n, bins,
                        delta, half, sigma, rb, grad_accum);
   hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(1024), 0, st, lpart, B, (double)lam / cnt, loss_out, loss_accum);
   SR_LAUNCH_CHECK("loss_hist");
+  return 0;
+}
+
+int srhip_loss_kde(const float* pred, const float* target, float* grad, float* loss_out, float* workspace, int B,
+                   long n, int bins, float kde_bw, int norm, float lam, int grad_accum, int loss_accum, void* stream) {
+  SR_REQUIRE(B > 0 && n > 0 && B <= 65535, "loss_kde: empty input");
+  SR_REQUIRE(bins > 1 && bins <= 256, "loss_kde: 2..256 bins (got %d)", bins);
+  SR_REQUIRE(kde_bw > 0.f && (norm == 1 || norm == 2), "loss_kde: bandwidth > 0, norm 1 or 2");
+  hipStream_t st = (hipStream_t)stream;
+  // GaussianKDE(kde_bw, nbin, max_color = 1, ndim = 1): float32 constants as the reference builds them
+  const float c1 = (float)pow(2.0 * 3.14159265358979323846 * (double)kde_bw, -0.5), c2 = (float)(2.0 * (double)kde_bw);
+  const float delta = (float)(1.0 / (double)(bins - 1));
+  const double reach = sqrt(104.0 * (double)c2) / (double)delta;
+  const int rb = reach >= (double)bins ? bins : (int)reach + 2;
+  float* part = workspace;
+  float* dldh = part + (long)B * HB * 2 * bins;
+  double* lpart = (double*)(dldh + (long)B * bins + (((long)B * bins) & 1));
+  hipLaunchKernelGGL(k_soft_hist<1>, dim3(HB, B), dim3(256), 2 * bins * sizeof(float), st, pred, target, part, n, bins,
+                     delta, c2, c1, rb);
+  // loss = norm(pred, trg).mean() / bins  (dlib/loss/main.py:893-895)
+  const double cnt = (double)B * bins * (double)bins;
+  hipLaunchKernelGGL(k_hist_finalize, dim3(B), dim3(256), 0, st, part, dldh, lpart, bins, norm == 1,
+                     (float)((double)lam / cnt), (float)n);
+  if (grad)
+    hipLaunchKernelGGL(k_soft_hist_grad<1>, dim3(HB, B), dim3(256), bins * sizeof(float), st, pred, dldh, grad, n, bins,
+                       delta, c2, c1, rb, grad_accum);
+  hipLaunchKernelGGL(k_sum_partials_d, dim3(1), dim3(1024), 0, st, lpart, B, (double)lam / cnt, loss_out, loss_accum);
+  SR_LAUNCH_CHECK("loss_kde");
   return 0;
 }
 

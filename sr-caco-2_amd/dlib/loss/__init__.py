@@ -12,8 +12,8 @@ utils_config.py:279-374) Charbonnier, L2Sum, ImageGradientLoss, LaplacianFilterL
 LocalVariationLoss and their three Norm* variants are built the same way
 (dlib/loss/main.py:102-151,328-674), as are BoundedPrediction (extended log barrier,
 :189-237 + dlib/losses/elb.py), WeightsSparsityLoss (:938-959) and LocalMoments (:240-325);
-HistogramMatch with its NORM1 / NORM2 metrics (:690-782); its KL / Bhattacharyya metrics, KDEMatch and
-CrossEntropyL are not (NotImplementedError on use).
+HistogramMatch and KDEMatch with their NORM1 / NORM2 metrics (:690-898); their KL / Bhattacharyya
+metrics and CrossEntropyL (it needs a segmentation head) are not (NotImplementedError on use).
 """
 import re
 
@@ -25,7 +25,7 @@ from srhip import ops
 __all__ = ['MasterLoss', 'ElementaryLoss', 'L1', 'L2', 'NegativeSsim', 'L2Sum', 'Charbonnier',
            'ImageGradientLoss', 'LaplacianFilterLoss', 'LocalVariationLoss', 'NormImageGradientLoss',
            'NormLaplacianFilterLoss', 'NormLocalVariationLoss', 'BoundedPrediction', 'WeightsSparsityLoss',
-           'LocalMoments', 'HistogramMatch']
+           'LocalMoments', 'HistogramMatch', 'KDEMatch']
 
 KL, BH = 'KL', 'BHATTACHARYYA'      # dlib/utils/constants.py:699-700 (HistogramMatch metrics that are not built)
 
@@ -274,6 +274,43 @@ class HistogramMatch(ElementaryLoss):
             p, t, self.lambda_, norm, self.sigma, self.nbins, grad=g, loss_out=v))
 
 
+class KDEMatch(ElementaryLoss):
+    """lambda * mean_{b,bin} nrm((kde_pred + 1e-4) - (kde_target + 1e-4)) / bins over a Gaussian KDE (bandwidth
+    1/255^2, 256 points on [0, 1]) of each 1-channel image; dlib/loss/main.py:785-898.  NORM1 / NORM2 metrics."""
+
+    def __init__(self, color_min=0, color_max=1, **kwargs):
+        super().__init__(**kwargs)
+        assert color_min == 0, color_min              # main.py:793-794
+        assert color_max == 1, color_max
+        self.color_min, self.color_max = color_min, color_max
+        self.kde_bw = 1. / (255. ** 2)
+        self.ndim = 1
+        self.norm_str = NORM2
+        self.already_set = False
+        self.nbins = 256                              # len(np.arange(0, 1, 1/255)) + 1
+
+    def set_it(self, norm_str, kde_bw, ndim, nbins):
+        assert isinstance(kde_bw, float) and kde_bw > 0., kde_bw
+        assert isinstance(norm_str, str) and norm_str in (NORM2, NORM1, BH), norm_str
+        assert isinstance(ndim, int) and ndim == 1, ndim
+        assert isinstance(nbins, int) and nbins > 0, nbins
+        if norm_str == BH:
+            raise NotImplementedError("KDEMatch metric BHATTACHARYYA: only NORM1 / NORM2 run on libsrhip")
+        self.kde_bw, self.norm_str, self.ndim, self.already_set = kde_bw, norm_str, ndim, True
+        self.nbins = 256                              # the reference recomputes it from the colour range (:825)
+
+    def forward(self, epoch, y_pred=None, y_target=None, trg_per_pixel_weight=None, model=None):
+        super().forward(epoch=epoch)
+        if not self.is_on():
+            return self._zero
+        assert y_target.shape == y_pred.shape, f'{y_target.shape}, {y_pred.shape}'
+        assert y_pred.ndim == 4 and y_pred.shape[1] == self.ndim
+        t = y_target.float().contiguous()
+        norm = 1 if self.norm_str == NORM1 else 2
+        return _FusedLoss.apply(y_pred, lambda p, g, v: ops.loss_kde(
+            p, t, self.lambda_, norm, self.kde_bw, self.nbins, grad=g, loss_out=v))
+
+
 class _SparsityFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lam, *params):
@@ -410,6 +447,8 @@ class MasterLoss(nn.Module):
                 out.append(("w_sparsity", l.lambda_))
             elif isinstance(l, LocalMoments):
                 out.append(("local_moments", l.lambda_))
+            elif isinstance(l, KDEMatch):
+                out.append(("kde", l.lambda_, 1 if l.norm_str == NORM1 else 2, l.kde_bw, l.nbins))
             elif isinstance(l, HistogramMatch):
                 out.append(("hist", l.lambda_, 1 if l.norm_str == NORM1 else 2, l.sigma, l.nbins))
             elif isinstance(l, _LocalVariationTerm):

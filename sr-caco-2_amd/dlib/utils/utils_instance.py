@@ -58,7 +58,12 @@ def define_loss(args):
         l = losses.HistogramMatch(cuda_id=dev, lambda_=tr.get('hist_lambda', 1.), color_min=0, color_max=255)
         l.set_it(norm_str=str(tr.get('hist_metric', constants.NORM2)), sigma=float(tr.get('hist_sigma', 1e5)))
         m.add(l)
-    for k in ('kde', 'ce'):
+    if tr.get('kde', False):                      # utils_instance.py:180-190
+        l = losses.KDEMatch(cuda_id=dev, lambda_=tr.get('kde_lambda', 1.), color_min=0, color_max=1)
+        l.set_it(norm_str=str(tr.get('kde_metric', constants.NORM2)), kde_bw=float(tr.get('kde_kde_bw', 1. / 255. ** 2)),
+                 ndim=int(getattr(args, 'n_channels', None) or 1), nbins=int(tr.get('kde_nbins', 256)))
+        m.add(l)
+    for k in ('ce',):
         if tr.get(k, False):
             raise NotImplementedError(f"loss term --{k} is outside the libsrhip hot path")
     if tr.get('w_sparsity', False):               # last, as in the reference (utils_instance.py:202-208)

@@ -75,6 +75,8 @@ def get_config(net_type):
                   'w_sparsity': False, 'w_sparsity_lambda': 1.,
                   'local_moments': False, 'local_moments_lambda': 1., 'local_moments_ksz': [3],
                   'hist': False, 'hist_lambda': 1., 'hist_sigma': 1e5, 'hist_metric': constants.NORM2,
+                  'kde': False, 'kde_lambda': 1., 'kde_nbins': 256, 'kde_kde_bw': 1. / (255. ** 2),
+                  'kde_metric': constants.NORM2,
                   'img_grad': False, 'img_grad_lambda': 1., 'img_grad_norm': constants.NORM2,
                   'norm_img_grad': False, 'norm_img_grad_lambda': 1., 'norm_img_grad_type': constants.NORM2,
                   'laplace': False, 'laplace_lambda': 1., 'laplace_norm': constants.NORM2,

@@ -178,6 +178,8 @@ class TrainStep:
                 ops.l1_sparsity(self.fp.flat, t[1], None, part)
                 if first:
                     self.dy.zero_()
+            elif t[0] == "kde":
+                ops.loss_kde(y, target, t[1], t[2], t[3], t[4], self.dy, part, grad_accum=not first)
             elif t[0] == "hist":
                 ops.loss_hist(y, target, t[1], t[2], t[3], t[4], self.dy, part, grad_accum=not first)
             elif t[0] == "local_moments":

@@ -255,6 +255,38 @@ def test_dlib_histogram_match_vs_reference_golden():
         assert (gr[:2].cpu() - po.grad).abs().max() <= 5e-4 * po.grad.abs().max(), (norm, sigma)
 
 
+def test_dlib_kde_match_vs_reference_golden():
+    """KDEMatch (NORM1 / NORM2) against the reference at the default bandwidth and a wide one; the sparse
+    evaluation (bins within sqrt(104 * 2 bw) of the pixel) against the dense oracle at 8 x 256 x 256."""
+    from dlib import loss as L
+    from dlib.losses.elb import ELB
+    from srhip import ops
+    g = load("g15_kde")
+    for name in ("l2_default", "l1_default", "l2_wide"):
+        lam, norm, bw = [float(v) for v in g[name + "/cfg"]]
+        l = L.KDEMatch(cuda_id=0, lambda_=lam, elb=ELB(), color_min=0, color_max=1)
+        l.set_it(norm_str=L.NORM1 if norm == 1 else L.NORM2, kde_bw=bw, ndim=1, nbins=256)
+        m = L.MasterLoss(cuda_id=0)
+        m.add(l)
+        p = g["pred"].cuda().requires_grad_(True)
+        v = m(epoch=0, y_pred=p, y_target=g["target"].cuda(), trg_per_pixel_weight=None, model=None)
+        v.backward()
+        rv, rg = g[name + "/value"], g[name + "/grad"]
+        assert abs(float(v) - float(rv)) <= 2e-5 * abs(float(rv)), (name, float(v), float(rv))
+        assert (p.grad.cpu() - rg).abs().max() <= 2e-4 * float(rg.abs().max()), (name, (p.grad.cpu() - rg).abs().max())
+        assert m.n_holder == list(g[name + "/names"])
+    gen = torch.Generator().manual_seed(22)
+    p = torch.rand(8, 1, 256, 256, generator=gen)
+    t = torch.round(torch.rand(8, 1, 256, 256, generator=gen) ** 2 * 255) / 255
+    gr = torch.empty_like(p).cuda()
+    v = ops.loss_kde(p.cuda(), t.cuda(), 1.0, 2, 1. / 255. ** 2, 256, gr)
+    po = p[:2].clone().requires_grad_(True)
+    vo = O.loss_kde_match(torch.cat([po, p[2:]]), t, 1.0, 2, 1. / 255. ** 2, 256)
+    vo.backward()
+    assert abs(float(v) - float(vo)) <= 2e-5 * abs(float(vo)), (float(v), float(vo))
+    assert (gr[:2].cpu() - po.grad).abs().max() <= 5e-4 * po.grad.abs().max()
+
+
 def test_optional_loss_terms_full_size_properties():
     """At the benchmark's 8 x 512 x 512: linearity of the plain local-variation terms in the difference
     (loss(pred, target) == loss(pred - target, 0)), zero loss / zero gradient at pred == target, tile-seam
