@@ -144,7 +144,7 @@ int srhip_gemm_tn_bx3(const float* A, long lda, const float* B, long ldb, int M,
 int srhip_tn_tiles(int NI, int NJ) { return sr_tn_tiles(NI, NJ); }
 // bx3 kernels hold one 8-wave block per CU: plan for one round of 256 blocks
 int srhip_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
-  return sr_tn_plan_t(M, NI, NJ, conv, 256, S, part_floats);
+  return sr_tn_plan_bx3(M, NI, NJ, conv, S, part_floats);
 }
 int srhip_tn_group_plan_bx3(int M, int ntiles, int* S) { return sr_tn_group_plan_t(M, ntiles, 256, S); }
 int srhip_tn_group_plan(int M, int ntiles, int* S) { return sr_tn_group_plan(M, ntiles, S); }

@@ -421,6 +421,17 @@ int pick_tile(int n, int* w) {
   *w = 3; return 192;
 }
 
+// Square block tiles of 64*W columns on both operands.  With unequal operand widths the SMALLER class
+// decides (a 256 x 64 problem runs as four 64 x 64 tiles, not as two half-empty 128 x 128 ones).
+int pick_w(int NI, int NJ, int* tile) {
+  int wi, wj;
+  const int ti = pick_tile(NI, &wi), tj = pick_tile(NJ, &wj);
+  const int w = wi < wj ? wi : wj;
+  *tile = wi == wj ? ti : (w == 3 ? 192 : 64 * w);        // equal classes keep 180-wide tiles for 180 / 360 / 540
+  if (wi == wj && ti != tj) *tile = 64 * w;
+  return w;
+}
+
 template <typename K>
 int reserve_lds(K kern, int bytes, const char* name) {
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -483,10 +494,9 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
   SR_REQUIRE(p.M > 0 && p.S > 0, "gemm_tn_bx3: empty problem");
   SR_REQUIRE(p.NI % 4 == 0 && p.NJ % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0,
              "gemm_tn_bx3: NI, NJ, lda, ldb must be multiples of 4");
-  int wi, wj;
-  p.i_tile = pick_tile(p.NI, &wi);
-  p.j_tile = pick_tile(p.NJ, &wj);
-  const int w = wi > wj ? wi : wj;
+  int tile;
+  const int w = pick_w(p.NI, p.NJ, &tile);
+  p.i_tile = p.j_tile = tile;
   const int rps = sr_cdiv(p.M, p.S);
   p.rows_per_slice = (rps + TKB - 1) / TKB * TKB;
   dim3 grid(p.S, sr_cdiv(p.NI, p.i_tile) * sr_cdiv(p.NJ, p.j_tile), p.conv ? 9 : 1);
@@ -502,5 +512,22 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
   SR_TNB(1) SR_TNB(2) SR_TNB(3)
 #undef SR_TNB
   SR_LAUNCH_CHECK("k_tnb");
+  return 0;
+}
+
+// Slice count of the single-problem bx3 launch: one 8-wave block per CU for the 128- and 192-wide tiles
+// (98 / 147 KB of LDS each), THREE per CU for 64-wide tiles (49 KB) -- at 64 channels the launch was
+// short of blocks with the per-CU budget of the wide tiles (28 slices x 9 taps: 212 us; 85 x 9: 147 us).
+int sr_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
+  int tile;
+  const int w = pick_w(NI, NJ, &tile);
+  const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * (conv ? 9 : 1);
+  long s = (w == 1 ? 768 : 256) / tiles;
+  const long smax = (M + 127) / 128;
+  if (s > smax) s = smax;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  *S = (int)s;
+  *part_floats = s * (conv ? 9 : 1) * (long)NI * NJ;
   return 0;
 }

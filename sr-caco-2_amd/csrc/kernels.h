@@ -72,5 +72,6 @@ int sr_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats);
 int sr_gemm_tn_grouped(TnArgs* probs, int n, hipStream_t st);
 int sr_tn_group_plan(int M, int ntiles, int* S);
 int sr_tn_plan_t(int M, int NI, int NJ, int conv, int target, int* S, long* part_floats);
+int sr_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats);
 int sr_tn_group_plan_t(int M, int ntiles, int dflt_target, int* S);
 int sr_tn_tiles(int NI, int NJ);

@@ -44,12 +44,14 @@ def use_bx3():
 
 
 import os as _os
-BX3_MIN_CHANNELS = int(_os.environ.get("SRHIP_BX3_MIN_CH", "128"))   # below this the split / staging overhead outweighs the faster MFMA (EDSR's 64)
+# weight-gradient (TN) side: bf16x3 from 64 channels on, once 64-wide tiles got their own plan (three blocks per
+# CU) and unequal operand widths the smaller tile class -- 64->64 at 8x128x128: 186 us (f32) vs 148 us
+BX3_MIN_CHANNELS = int(_os.environ.get("SRHIP_BX3_MIN_CH", "64"))
 
 
-# The NT side (conv / Linear forward and data gradient) pays off much earlier than the weight-gradient side:
-# measured at 64 -> 64 channels, B=8, 128x128 (tools/mb_conv64.py): conv 108.8 -> 65.5 us with the bf16x3 kernel,
-# weight gradient 187.3 -> 212.0 us.  So the two sides have their own thresholds.
+# The NT side (conv / Linear forward and data gradient) has its own threshold: at 64 -> 64 channels, B=8, 128x128
+# (tools/mb_conv64.py) the conv goes 108.8 -> 65.5 us on the bf16x3 kernel; the weight-gradient side only caught
+# up (186 -> 148 us) after its plan for 64-wide tiles changed -- with the plan of the wide tiles it was slower (212 us).
 BX3_MIN_CHANNELS_NT = int(_os.environ.get("SRHIP_BX3_MIN_CH_NT", "64"))
 
 
