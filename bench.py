@@ -149,6 +149,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss = ts.loss_values()[0]
+    # secondary figure, outside the timed region: forward-only patches/s of the same net and batch
+    eval_pps = None
+    if rank == 0 and world == 1:
+        net.eval()
+        with torch.no_grad():
+            for _ in range(2):
+                net(lr_img)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                net(lr_img)
+            torch.cuda.synchronize()
+            eval_pps = args.batch * 10 / (time.perf_counter() - t1)
+        net.train()
     if rank == 0:
         patches = args.batch * world * args.steps
         out = {
@@ -162,6 +176,7 @@ def main():
                                    f"fwd + {args.loss} + bwd + {args.optimizer}",
                        "global_batch": args.batch * world, "batch_per_gpu": args.batch,
                        "parallelism": f"dp{world}", "final_loss": loss,
+                       "eval_patches_per_s_one_gpu": eval_pps,
                        "matmul": ("bf16x3 split MFMA: f32 operands split into 3 bf16 parts, 6 products, "
                                   "f32 accumulate (f32-accurate)") if ops_use_bx3() else "f32 MFMA"},
         }
