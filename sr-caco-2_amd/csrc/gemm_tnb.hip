@@ -522,7 +522,8 @@ int sr_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
   int tile;
   const int w = pick_w(NI, NJ, &tile);
   const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * (conv ? 9 : 1);
-  long s = (w == 1 ? 768 : 256) / tiles;
+  static const long t1 = [] { const char* e = getenv("SRHIP_TNB_BLOCKS_W1"); return e ? atol(e) : 768L; }();
+  long s = (w == 1 ? t1 : 256) / tiles;
   const long smax = (M + 127) / 128;
   if (s > smax) s = smax;
   if (s > 256) s = 256;
