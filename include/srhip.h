@@ -214,8 +214,9 @@ int srhip_window_attention_bwd(const float* qkv, const float* dout, float* dqkv,
                                int C, int heads, int shift, void* stream);
 
 /* ---- 1-channel edge convolutions -------------------------------------------- */
-/* x [B][H][W] -> y NHWC [.][Co]; flip=1 uses flipped taps (= data gradient of
- * a Cout=1 conv).  network_swinir.py:786,945; network_nlsn.py:325. */
+/* x [B][H][W] -> y NHWC [.][Co]; flip is a flag word: bit 0 = flipped taps (= data gradient of
+ * a Cout=1 conv), bit 1 = ReLU on the output (VDSR's input layer, network_vdsr.py:57-60).
+ * network_swinir.py:786,945; network_nlsn.py:325. */
 int srhip_conv3x3_cin1_fwd(const float* x, const float* w, const float* bias, float* y, long ldy, int B,
                            int H, int W, int Co, int flip, void* stream);
 long srhip_conv3x3_cin1_wgrad_ws(int Co);
@@ -334,6 +335,8 @@ int srhip_sgd_step(float* p, const float* g, float* buf, long n, float lr, float
  * per-tensor host syncs (dlib/utils/tools.py:28-63, model_plain.py:344). */
 int srhip_nonfinite_flag(const float* x, long n, int* flag, void* stream);
 int srhip_axpby(float* y, const float* x, long n, float a, float b, void* stream);
+/* g[i] = a[i] > 0 ? g[i] : 0 -- backward of a ReLU whose OUTPUT a was kept (nn.ReLU, network_vdsr.py:28). */
+int srhip_relu_mask(float* g, const float* a, long n, void* stream);
 /* out[0] = sum(x) (fp64 accumulation); workspace: 2048 doubles. */
 int srhip_sum(const float* x, long n, float* out, double* workspace, void* stream);
 

@@ -617,6 +617,40 @@ def g_kde():
     npz("g15_kde", **out)
 
 
+def g_vdsr():
+    print("G16 VDSR")
+    from dlib.models.network_vdsr import VDSR as RefVDSR
+    out = {}
+    keep = ("conv1.0.weight", "trunk.0.conv.weight", "trunk.17.conv.weight", "conv2.weight")
+    for scale in (2, 4):
+        # weights from the oracle's seeded initialiser (the reference's own N(0, sqrt(2/(9 Cout))) law) loaded
+        # into the reference net: the fixture stays small (no 0.67 M-parameter tensors)
+        sd = O.vdsr_init_state_dict(1, seed=60 + scale)
+        net = RefVDSR(in_chans=1, upscale=scale)
+        assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(50 + scale)
+        x = torch.rand(2, 1, 12, 10)
+        tgt = torch.rand(2, 1, 12 * scale, 10 * scale)
+        y = net(x)
+        (y - tgt).abs().mean().backward()
+        sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        yo = O.vdsr_forward(sdo, x, scale)
+        (yo - tgt).abs().mean().backward()
+        close(yo.detach(), y.detach(), 1e-6, f"vdsr x{scale} forward")
+        pre = f"x{scale}/"
+        sums = []
+        for k, p in net.named_parameters():
+            close(sdo[k].grad, p.grad, 1e-6 * max(1.0, float(p.grad.abs().max())), f"vdsr x{scale} d{k}")
+            if k in keep:
+                out[pre + "grad/" + k] = p.grad
+            sums.append([p.grad.double().sum().item(), p.grad.double().abs().sum().item()])
+        out[pre + "x"], out[pre + "target"], out[pre + "y"] = x, tgt, y.detach()
+        out[pre + "grad_sums"] = np.array(sums)
+        out[pre + "seed"] = np.array(60 + scale)
+    npz("g16_vdsr", **out)
+
+
 def g_interpolate():
     print("G11 Interpolate (Bicubic baseline)")
     # utils_trainer.py does not import here (matplotlib style): compile ONLY the reference's
@@ -763,7 +797,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_interpolate, g_patches,
+    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_interpolate, g_patches,
             g_metrics, g_optim]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

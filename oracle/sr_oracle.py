@@ -341,6 +341,32 @@ def edsr_init_state_dict(cfg: dict, seed: int = 0) -> SD:
 
 
 # ----------------------------------------------------------------------------
+# VDSR (dlib/models/network_vdsr.py)
+# ----------------------------------------------------------------------------
+def vdsr_forward(sd: SD, x: Tensor, upscale: int) -> Tensor:
+    """network_vdsr.py:78-117: bicubic up (align_corners False, clamped), conv1 + ReLU, 18 x (conv + ReLU),
+    conv2, + the interpolated input.  No biases."""
+    xi = torch.clamp(F.interpolate(x, size=(upscale * x.shape[2], upscale * x.shape[3]), mode="bicubic",
+                                   align_corners=False), 0.0, 1.0)
+    out = F.relu(F.conv2d(xi, sd["conv1.0.weight"], padding=1))
+    k = 0
+    while f"trunk.{k}.conv.weight" in sd:
+        out = F.relu(F.conv2d(out, sd[f"trunk.{k}.conv.weight"], padding=1))
+        k += 1
+    return F.conv2d(out, sd["conv2.weight"], padding=1) + xi
+
+
+def vdsr_init_state_dict(in_chans: int = 1, seed: int = 0) -> SD:
+    """network_vdsr.py:121-126: N(0, sqrt(2 / (9 * Cout))) for every conv."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {"conv1.0.weight": torch.randn(64, in_chans, 3, 3, generator=g) * math.sqrt(2 / (9 * 64))}
+    for k in range(18):
+        sd[f"trunk.{k}.conv.weight"] = torch.randn(64, 64, 3, 3, generator=g) * math.sqrt(2 / (9 * 64))
+    sd["conv2.weight"] = torch.randn(in_chans, 64, 3, 3, generator=g) * math.sqrt(2 / (9 * in_chans))
+    return sd
+
+
+# ----------------------------------------------------------------------------
 # losses (dlib/loss/main.py, dlib/loss/ssim.py, dlib/loss/master.py)
 # ----------------------------------------------------------------------------
 def loss_l1(pred: Tensor, target: Tensor, lam: float = 1.0,

@@ -410,6 +410,12 @@ __global__ void __launch_bounds__(256) k_pixel_unshuffle_r2_nhwc(const float* __
 //   mode 1: L2  lam*mean(e^2)       grad = 2*lam*e/n
 // partial sums go to part[gridDim.x] (double); k_sum_partials finishes.
 // ----------------------------------------------------------------------------
+// g *= (a > 0): the backward of a ReLU whose output a is kept (VDSR's last ConvReLU in front of the 64 -> 1 conv)
+__global__ void __launch_bounds__(256) k_relu_mask(float* __restrict__ g, const float* __restrict__ a, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    if (!(a[i] > 0.f)) g[i] = 0.f;
+}
+
 __global__ void __launch_bounds__(256) k_loss_l1l2(const float* __restrict__ pred, const float* __restrict__ tgt,
                                                    const float* __restrict__ wgt, float* __restrict__ grad,
                                                    double* __restrict__ part, long n, int mode, float lam,
@@ -710,6 +716,13 @@ int srhip_nonfinite_flag(const float* x, long n, int* flag, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_nonfinite, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, flag);
   SR_LAUNCH_CHECK("nonfinite_flag");
+  return 0;
+}
+
+int srhip_relu_mask(float* g, const float* a, long n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_relu_mask, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, g, a, n);
+  SR_LAUNCH_CHECK("relu_mask");
   return 0;
 }
 

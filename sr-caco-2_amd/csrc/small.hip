@@ -52,8 +52,9 @@ __global__ void __launch_bounds__(256) k_conv_cin1_fwd(const float* __restrict__
     const int co = lane + 64 * i;
     br[i] = (co < Co && bias) ? bias[co] : 0.f;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wr[i][t] = co < Co ? w[co * 9 + (flip ? 8 - t : t)] : 0.f;
+    for (int t = 0; t < 9; ++t) wr[i][t] = co < Co ? w[co * 9 + ((flip & 1) ? 8 - t : t)] : 0.f;
   }
+  const bool relu = (flip & 2) != 0;          // flags: bit 0 flipped taps, bit 1 ReLU on the output
   const int nsx = (W + SEG - 1) / SEG;
   const long nseg = (long)B * H * nsx;
   for (long seg = wave; seg < nseg; seg += nwave) {
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(256) k_conv_cin1_fwd(const float* __restrict__
           float a = br[i];
 #pragma unroll
           for (int t = 0; t < 9; ++t) a += xv[t / 3][t % 3] * wr[i][t];
-          yp[co] = a;
+          yp[co] = relu ? fmaxf(a, 0.f) : a;
         }
       }
       yp += ldy;

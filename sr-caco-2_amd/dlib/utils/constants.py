@@ -5,11 +5,13 @@ SUPER_RES = 'super-resolution'
 
 SWINIR = 'swinir'
 EDSR_LIIF = 'EDSR_LIIF'
-MODELS = [SWINIR, EDSR_LIIF]
+VDSR = 'VDSR'  # https://arxiv.org/pdf/1511.04587.pdf (reference constants.py:27)
+MODELS = [SWINIR, EDSR_LIIF, VDSR]
 
 SWINIR_MTH = 'SWINIR'
 EDSR_LIIF_MTH = 'EDSR_LIIF'
-NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH}
+VDSR_MTH = 'VDSR'
+NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH}
 
 US_PIXEL_SHUFFLE = 'pixelshuffle'
 US_PIXEL_SHUFFLE_DIRECT = 'pixelshuffledirect'

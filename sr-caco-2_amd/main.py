@@ -114,6 +114,7 @@ def parse_input(argv=None):
     net_opts = {constants.SWINIR: {'window_size': int, 'depths': plus_list, 'embed_dim': int,
                                    'num_heads': plus_list, 'mlp_ratio': int, 'upsampler': str,
                                    'resi_connection': str, 'img_range': float},
+                constants.VDSR: {},
                 constants.EDSR_LIIF: {'n_feats': int, 'n_resblocks': int, 'res_scale': float,
                                       'img_range': float}}[net_type]
     for k, t in net_opts.items():

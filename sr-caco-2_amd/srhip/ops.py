@@ -431,8 +431,16 @@ def window_attention_bwd(qkv, dout, dqkv, biasT, biasN, dbiasT, B, H, W, C, head
 
 
 # ------------------------------------------------------------------ edge convs
-def conv3x3_cin1_fwd(x, w, bias, Co, out=None, flip=False):
+def relu_mask(g, a):
+    """g *= (a > 0) in place (backward of a ReLU whose output a was kept)."""
+    _chk(g, a)
+    call("srhip_relu_mask", _p(g), _p(a), g.numel(), _st())
+    return g
+
+
+def conv3x3_cin1_fwd(x, w, bias, Co, out=None, flip=False, relu=False):
     """x [B,H,W] -> NHWC [B,H,W,Co]; w torch layout [Co,1,3,3] (or [1,Co,3,3] with flip)."""
+    flip = int(bool(flip)) | (2 if relu else 0)
     _chk(x, w, bias, out)
     B, H, W = x.shape
     if out is None:

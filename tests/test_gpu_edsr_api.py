@@ -80,6 +80,72 @@ def test_edsr_full_size_forward_vs_reference_golden():
     assert (ps(y) - ps(yo)).abs().max() <= 0.01
 
 
+@pytest.mark.parametrize("scale", [2, 4])
+def test_vdsr_fwd_bwd_vs_reference_golden(scale):
+    """SURVEY f1, first of the plain CNNs: VDSR (network_vdsr.py) on the libsrhip conv kernels -- forward and
+    every weight gradient against the reference's outputs; registry and state_dict contract."""
+    from dlib.models.select_network import define_G
+    from dlib.utils import constants
+    g = load("g16_vdsr")
+    pre = f"x{scale}/"
+    args = type("A", (), {})()
+    args.netG = {'net_type': constants.VDSR, 'VDSR_upscale': scale, 'VDSR_in_chans': 1}
+    net = define_G(args)
+    sd = O.vdsr_init_state_dict(1, seed=int(g[pre + "seed"]))
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    y = net(g[pre + "x"].cuda())
+    assert (y.detach().cpu() - g[pre + "y"]).abs().mean() <= 1e-5
+    assert (y.detach().cpu() - g[pre + "y"]).abs().max() <= 5e-5
+    (y - g[pre + "target"].cuda()).abs().mean().backward()
+    for i, (k, p) in enumerate(net.named_parameters()):
+        gs = g[pre + "grad_sums"][i]
+        assert abs(p.grad.double().sum().item() - float(gs[0])) <= 2e-4 * max(1e-3, float(gs[1])), k
+        if pre + "grad/" + k in g:
+            ref = g[pre + "grad/" + k]
+            assert (p.grad.cpu() - ref).abs().max() <= 2e-3 * float(ref.abs().max()), k
+    with torch.no_grad():
+        net.eval()
+        y2 = net(g[pre + "x"].cuda())
+    assert (y2.cpu() - g[pre + "y"]).abs().max() <= 5e-5
+    with pytest.raises(RuntimeError, match="GPU only"):
+        net(g[pre + "x"])
+
+
+def test_vdsr_full_size_forward_and_train_step():
+    """VDSR at the benchmark patch (1 x 64 x 64 -> 512 x 512): forward against the oracle (MAE <= 1e-5, PSNR
+    within 0.01 dB) and one fused optimisation step against the oracle's autograd + SGD-Nesterov step."""
+    from dlib.models.network_vdsr import VDSR
+    from srhip.train import TrainStep, Optimizer
+    sd = O.vdsr_init_state_dict(1, seed=7)
+    net = VDSR(in_chans=1, upscale=8)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    gen = torch.Generator().manual_seed(4)
+    x = torch.rand(1, 1, 64, 64, generator=gen)
+    tgt = torch.rand(1, 1, 512, 512, generator=gen)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = O.vdsr_forward(sdo, x, 8)
+    with torch.no_grad():
+        y = net(x.cuda()).cpu()
+    assert (y - yo.detach()).abs().mean() <= 1e-5
+    ps = lambda a: O.metric_psnr(O.tensor2uint82float(a), O.tensor2uint82float(tgt), 8)
+    assert (ps(y) - ps(yo.detach())).abs().max() <= 0.01
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=0.01, momentum=0.9, nesterov=True, wd=0.0)
+    ts.step(x.cuda(), tgt.cuda())
+    lo = O.loss_l1(yo, tgt)
+    lo.backward()
+    assert abs(ts.loss_values()[0] - lo.item()) <= 1e-5
+    with torch.no_grad():
+        for k in sdo:
+            O.sgd_nesterov_step(sdo[k], sdo[k].grad, torch.zeros_like(sdo[k]), True, 0.01)
+    for k, p in net.named_parameters():
+        e = (p.detach().cpu() - sdo[k].detach()).abs().max().item()
+        assert e <= 2e-6, f"{k}: {e}"
+
+
 def test_dlib_loss_surface_vs_reference_golden():
     from dlib import loss as L
     from dlib import losses as L2mod
