@@ -651,6 +651,35 @@ def g_vdsr():
     npz("g16_vdsr", **out)
 
 
+def g_drrn():
+    print("G17 DRRN")
+    from dlib.models.network_drrn import DRRN as RefDRRN
+    out = {}
+    for scale, units in ((2, 3), (4, 25)):
+        sd = O.drrn_init_state_dict(1, seed=70 + scale)
+        net = RefDRRN(in_chans=1, upscale=scale, num_residual_units=units)
+        assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(80 + scale)
+        x = torch.rand(2, 1, 10, 8)
+        tgt = torch.rand(2, 1, 10 * scale, 8 * scale)
+        y = net(x)
+        (y - tgt).abs().mean().backward()
+        sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        yo = O.drrn_forward(sdo, x, scale, units)
+        (yo - tgt).abs().mean().backward()
+        close(yo.detach(), y.detach(), 1e-6 * max(1.0, float(y.abs().max())), f"drrn x{scale} forward")
+        pre = f"x{scale}/"
+        for k, p in net.named_parameters():
+            close(sdo[k].grad, p.grad, 1e-6 * max(1.0, float(p.grad.abs().max())), f"drrn x{scale} d{k}")
+            if scale == 2 or not k.startswith("trunk."):      # the 128x128 gradients once; sums for the other case
+                out[pre + "grad/" + k] = p.grad
+            out[pre + "gsum/" + k] = np.array([p.grad.double().sum().item(), p.grad.double().abs().sum().item()])
+        out[pre + "x"], out[pre + "target"], out[pre + "y"] = x, tgt, y.detach()
+        out[pre + "cfg"] = np.array([70 + scale, units])
+    npz("g17_drrn", **out)
+
+
 def g_interpolate():
     print("G11 Interpolate (Bicubic baseline)")
     # utils_trainer.py does not import here (matplotlib style): compile ONLY the reference's
@@ -797,7 +826,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_interpolate, g_patches,
+    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

@@ -366,6 +366,29 @@ def vdsr_init_state_dict(in_chans: int = 1, seed: int = 0) -> SD:
     return sd
 
 
+def drrn_forward(sd: SD, x: Tensor, upscale: int, num_residual_units: int) -> Tensor:
+    """network_drrn.py:22-126.  The reference's ReLUs are in place: the first ReLU of the first residual unit
+    rectifies the block input itself, so the identity every unit adds is relu(conv1 output)."""
+    xi = torch.clamp(F.interpolate(x, size=(upscale * x.shape[2], upscale * x.shape[3]), mode="bicubic",
+                                   align_corners=False), 0.0, 1.0)
+    x0 = F.relu(F.conv2d(F.relu(xi), sd["conv1.1.weight"], padding=1))
+    out = x0
+    for _ in range(num_residual_units):
+        out = F.conv2d(F.relu(out), sd["trunk.residual_unit.1.weight"], padding=1)
+        out = F.conv2d(F.relu(out), sd["trunk.residual_unit.3.weight"], padding=1)
+        out = out + x0
+    return F.conv2d(F.relu(out), sd["conv2.1.weight"], padding=1) + xi
+
+
+def drrn_init_state_dict(in_chans: int = 1, seed: int = 0) -> SD:
+    """network_drrn.py:128-136: kaiming_normal_(fan_out, relu) = N(0, sqrt(2 / (9 * Cout)))."""
+    g = torch.Generator().manual_seed(seed)
+    return {"conv1.1.weight": torch.randn(128, in_chans, 3, 3, generator=g) * math.sqrt(2 / (9 * 128)),
+            "trunk.residual_unit.1.weight": torch.randn(128, 128, 3, 3, generator=g) * math.sqrt(2 / (9 * 128)),
+            "trunk.residual_unit.3.weight": torch.randn(128, 128, 3, 3, generator=g) * math.sqrt(2 / (9 * 128)),
+            "conv2.1.weight": torch.randn(in_chans, 128, 3, 3, generator=g) * math.sqrt(2 / (9 * in_chans))}
+
+
 # ----------------------------------------------------------------------------
 # losses (dlib/loss/main.py, dlib/loss/ssim.py, dlib/loss/master.py)
 # ----------------------------------------------------------------------------

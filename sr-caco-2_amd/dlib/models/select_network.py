@@ -26,9 +26,13 @@ def define_G(args):
                    n_feats=opt_net[f'{nt}_n_feats'], scale=opt_net[f'{nt}_upscale'],
                    rgb_range=opt_net[f'{nt}_img_range'], res_scale=opt_net.get(f'{nt}_res_scale', 1.),
                    local_ensemble=True, feat_unfold=True, cell_decode=True)
+    if net_type == constants.DRRN:                  # select_network.py:192-198
+        from dlib.models.network_drrn import DRRN as net
+        return net(in_chans=opt_net[f'{nt}_in_chans'], upscale=opt_net[f'{nt}_upscale'],
+                   num_residual_units=opt_net[f'{nt}_num_residual_units'])
     if net_type == constants.VDSR:                  # select_network.py:200-205
         from dlib.models.network_vdsr import VDSR as net
         return net(in_chans=opt_net[f'{nt}_in_chans'], upscale=opt_net[f'{nt}_upscale'])
     raise NotImplementedError(
         f"net_type {net_type!r}: only {constants.MODELS} run on libsrhip (SURVEY.md section 8f lists "
-        f"the remaining 13 reference networks as 'next')")
+        f"the remaining 12 reference networks as 'next')")

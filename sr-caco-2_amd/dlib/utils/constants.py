@@ -6,12 +6,14 @@ SUPER_RES = 'super-resolution'
 SWINIR = 'swinir'
 EDSR_LIIF = 'EDSR_LIIF'
 VDSR = 'VDSR'  # https://arxiv.org/pdf/1511.04587.pdf (reference constants.py:27)
-MODELS = [SWINIR, EDSR_LIIF, VDSR]
+DRRN = 'DRRN'  # https://ieeexplore.ieee.org/document/8099781 (reference constants.py:29)
+MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN]
 
 SWINIR_MTH = 'SWINIR'
 EDSR_LIIF_MTH = 'EDSR_LIIF'
 VDSR_MTH = 'VDSR'
-NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH}
+DRRN_MTH = 'DRRN'
+NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH, DRRN: DRRN_MTH}
 
 US_PIXEL_SHUFFLE = 'pixelshuffle'
 US_PIXEL_SHUFFLE_DIRECT = 'pixelshuffledirect'

@@ -19,6 +19,9 @@ def init_net_g(netG: dict, args: dict) -> dict:
         out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'],
                     f'{nt}_n_feats': 64, f'{nt}_img_range': 1.0, f'{nt}_res_scale': 1.,
                     f'{nt}_n_resblocks': 16})
+    elif netG['net_type'] == constants.DRRN:         # utils_init_default_args.py:231-235
+        out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'],
+                    f'{nt}_num_residual_units': 25})
     elif netG['net_type'] == constants.VDSR:         # utils_init_default_args.py:241
         out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels']})
     else:

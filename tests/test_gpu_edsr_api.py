@@ -113,6 +113,38 @@ def test_vdsr_fwd_bwd_vs_reference_golden(scale):
         net(g[pre + "x"])
 
 
+@pytest.mark.parametrize("scale", [2, 4])
+def test_drrn_fwd_bwd_vs_reference_golden(scale):
+    """DRRN (network_drrn.py; shared-weight recursive block, 3 and 25 units) -- forward and the four
+    weight gradients (the shared ones summed over the applications) against the reference."""
+    from dlib.models.select_network import define_G
+    from dlib.utils import constants
+    g = load("g17_drrn")
+    pre = f"x{scale}/"
+    seed, units = [int(v) for v in g[pre + "cfg"]]
+    args = type("A", (), {})()
+    args.netG = {'net_type': constants.DRRN, 'DRRN_upscale': scale, 'DRRN_in_chans': 1, 'DRRN_num_residual_units': units}
+    net = define_G(args)
+    sd = O.drrn_init_state_dict(1, seed=seed)
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    y = net(g[pre + "x"].cuda())
+    ref = g[pre + "y"]
+    assert (y.detach().cpu() - ref).abs().mean() <= 1e-5 * max(1.0, float(ref.abs().mean()))
+    (y - g[pre + "target"].cuda()).abs().mean().backward()
+    for k, p in net.named_parameters():
+        gs = g[pre + "gsum/" + k]
+        assert abs(p.grad.double().sum().item() - float(gs[0])) <= 2e-4 * max(1e-3, float(gs[1])), k
+        if pre + "grad/" + k in g:
+            r = g[pre + "grad/" + k]
+            assert (p.grad.cpu() - r).abs().max() <= 2e-3 * float(r.abs().max()), k
+    with torch.no_grad():
+        net.eval()
+        y2 = net(g[pre + "x"].cuda())
+    assert (y2.cpu() - ref).abs().mean() <= 1e-5 * max(1.0, float(ref.abs().mean()))
+
+
 def test_vdsr_full_size_forward_and_train_step():
     """VDSR at the benchmark patch (1 x 64 x 64 -> 512 x 512): forward against the oracle (MAE <= 1e-5, PSNR
     within 0.01 dB) and one fused optimisation step against the oracle's autograd + SGD-Nesterov step."""
