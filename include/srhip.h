@@ -331,6 +331,19 @@ int srhip_adam_step(float* p, const float* g, float* m, float* v, long n, int st
                     float b2, float eps, float wd, float gscale, const int* skip_flag, void* stream);
 int srhip_sgd_step(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
                    int nesterov, int first, float gscale, const int* skip_flag, void* stream);
+/* The same updates with the step number kept ON THE DEVICE: srhip_optim_tick does
+ * counter += (skip_flag == 0); the *_dc kernels (launched after it on the same stream) take
+ * Adam's bias corrections 1 - beta^counter and SGD's "first step" (counter == 1) from it.  A step
+ * skipped by the non-finite flag then leaves the optimizer state exactly as the reference does
+ * when it skips backward + optimizer.step() for that batch (model_plain.py:344-346), with no
+ * host sync. */
+int srhip_optim_tick(const int* skip_flag, int* counter, void* stream);
+int srhip_adam_step_dc(float* p, const float* g, float* m, float* v, long n, const int* counter, float lr,
+                       float b1, float b2, float eps, float wd, float gscale, const int* skip_flag,
+                       void* stream);
+int srhip_sgd_step_dc(float* p, const float* g, float* buf, long n, const int* counter, float lr,
+                      float momentum, float wd, int nesterov, float gscale, const int* skip_flag,
+                      void* stream);
 /* flag[0] |= any(!isfinite(x)): one device flag instead of the reference's
  * per-tensor host syncs (dlib/utils/tools.py:28-63, model_plain.py:344). */
 int srhip_nonfinite_flag(const float* x, long n, int* flag, void* stream);

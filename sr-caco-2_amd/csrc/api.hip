@@ -18,7 +18,7 @@ int sr_fail(int code, const char* fmt, ...) {
 extern "C" {
 
 const char* srhip_last_error(void) { return g_err; }
-int srhip_abi_version(void) { return 4; }
+int srhip_abi_version(void) { return 5; }
 
 int srhip_gemm_nt(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                   long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,

@@ -506,6 +506,50 @@ __global__ void k_sgd(float* __restrict__ p, const float* __restrict__ g, float*
     p[i] = pi - lr * d;
   }
 }
+// device-resident step counter: counter += (skip == 0).  The *_dc optimizer kernels read it
+// (they run after this launch on the same stream), so a skipped step advances neither
+// Adam's bias correction nor SGD's first-step momentum initialisation.
+__global__ void k_optim_tick(const int* __restrict__ skip, int* __restrict__ counter) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !(skip && *skip)) *counter += 1;
+}
+__global__ void k_adam_dc(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                          float* __restrict__ v, long n, const int* __restrict__ counter, float lr, float b1,
+                          float b2, float eps, float wd, float gscale, const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const float step = (float)*counter;
+  const float bc1 = 1.f - powf(b1, step);
+  const float bc2_sqrt = sqrtf(1.f - powf(b2, step));
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = m[i] * b1 + (1.f - b1) * gi;
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+__global__ void k_sgd_dc(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                         long n, const int* __restrict__ counter, float lr, float momentum, float wd,
+                         int nesterov, float gscale, const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const int first = *counter == 1;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    float d = gi;
+    if (momentum != 0.f) {
+      const float bi = first ? gi : buf[i] * momentum + gi;
+      buf[i] = bi;
+      d = nesterov ? gi + momentum * bi : bi;
+    }
+    p[i] = pi - lr * d;
+  }
+}
 // finite check: flag[0] |= any(!isfinite(x))
 __global__ void k_nonfinite(const float* __restrict__ x, long n, int* __restrict__ flag) {
   int bad = 0;
@@ -709,6 +753,35 @@ int srhip_sgd_step(float* p, const float* g, float* buf, long n, float lr, float
   hipLaunchKernelGGL(k_sgd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr,
                      momentum, wd, nesterov, first, gscale, skip_flag);
   SR_LAUNCH_CHECK("sgd_step");
+  return 0;
+}
+
+int srhip_optim_tick(const int* skip_flag, int* counter, void* stream) {
+  SR_REQUIRE(counter != nullptr, "optim_tick: counter is NULL");
+  hipLaunchKernelGGL(k_optim_tick, dim3(1), dim3(64), 0, (hipStream_t)stream, skip_flag, counter);
+  SR_LAUNCH_CHECK("optim_tick");
+  return 0;
+}
+
+int srhip_adam_step_dc(float* p, const float* g, float* m, float* v, long n, const int* counter, float lr,
+                       float b1, float b2, float eps, float wd, float gscale, const int* skip_flag,
+                       void* stream) {
+  if (n <= 0) return 0;
+  SR_REQUIRE(counter != nullptr, "adam_step_dc: counter is NULL");
+  hipLaunchKernelGGL(k_adam_dc, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, counter,
+                     lr, b1, b2, eps, wd, gscale, skip_flag);
+  SR_LAUNCH_CHECK("adam_step_dc");
+  return 0;
+}
+
+int srhip_sgd_step_dc(float* p, const float* g, float* buf, long n, const int* counter, float lr,
+                      float momentum, float wd, int nesterov, float gscale, const int* skip_flag,
+                      void* stream) {
+  if (n <= 0) return 0;
+  SR_REQUIRE(counter != nullptr, "sgd_step_dc: counter is NULL");
+  hipLaunchKernelGGL(k_sgd_dc, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, counter,
+                     lr, momentum, wd, nesterov, gscale, skip_flag);
+  SR_LAUNCH_CHECK("sgd_step_dc");
   return 0;
 }
 

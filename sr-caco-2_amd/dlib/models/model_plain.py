@@ -18,7 +18,6 @@ TrainStep (model_base.py:135-142).
 """
 import os
 from collections import OrderedDict
-from copy import deepcopy
 
 import torch
 
@@ -78,7 +77,10 @@ class ModelPlain:
     # ---------------------------------------------------------------- step
     def optimize_parameters(self, epoch: int, current_step: int):
         self.step_fn.step(self.L, self.H)
-        self.E = self.netG.engine.bufs.d.get("t.y")
+        # the engine's output buffer is persistent (overwritten by the next step) and 3-D for the
+        # 1-channel conv nets: hand out a [B,1,H,W] copy, as the reference's self.E is a fresh tensor
+        y = self.netG.engine.bufs.d.get("t.y")
+        self.E = None if y is None else y.reshape(y.shape[0], 1, *y.shape[-2:]).clone()
 
     def update_learning_rate(self):
         pass   # TrainStep steps the LR rule once per iteration (utils_trainer.py:370)
@@ -88,8 +90,8 @@ class ModelPlain:
 
     def check_finite(self):
         """True if no non-finite loss was seen since the last call (one host sync)."""
-        bad = int(self.step_fn.flag.item())
-        self.step_fn.flag.zero_()
+        bad = int(self.step_fn.sticky.item())
+        self.step_fn.sticky.zero_()
         return bad == 0
 
     def current_log(self):
@@ -130,28 +132,40 @@ class ModelPlain:
     def save(self, iter_label):
         return self.save_network(self.save_dir, self.netG, 'G', iter_label)
 
-    def save_best(self, save_dir, name='G-model'):
-        os.makedirs(save_dir, exist_ok=True)
-        path = os.path.join(save_dir, f'{name}.pth')
-        torch.save(OrderedDict((k, v.detach().cpu().clone())
-                               for k, v in self.netG.state_dict().items()), path)
+    def save_network_path(self, network, path: str):
+        """raw state_dict on the CPU, as model_base.py:173-181."""
+        torch.save(OrderedDict((k, v.detach().cpu().clone()) for k, v in network.state_dict().items()), path)
         return path
+
+    def save_best(self, save_dir: str, p_name_file: str = 'model.pth'):
+        """model_plain.py:131-137 (called as save_best(_dir, p_name_file='model.pth'),
+        utils_trainer.py:230): writes <save_dir>/G-<p_name_file>."""
+        os.makedirs(save_dir, exist_ok=True)
+        return self.save_network_path(self.netG, os.path.join(save_dir, f'G-{p_name_file}'))
 
     def load_network(self, load_path, network, strict=True, param_key='params'):
         sd = torch.load(load_path, map_location='cpu')
         if param_key in sd:
             sd = sd[param_key]
-        network.load_state_dict(sd, strict=strict)
-        if self.step_fn is not None:   # parameters are views of the flat buffer: copy_ kept them
-            network.weights_changed()
+        if strict:
+            network.load_state_dict(sd, strict=True)
+        else:   # positional key match of the reference's non-strict branch (model_base.py:193-200)
+            cur = network.state_dict()
+            for (_, v_old), k in zip(sd.items(), list(cur.keys())):
+                cur[k] = v_old
+            network.load_state_dict(cur, strict=True)
+        network.weights_changed()   # parameters are views of the flat buffer: copy_ kept them
 
-    def save_current(self):
-        self._current = deepcopy({k: v.detach().clone() for k, v in self.netG.state_dict().items()})
+    def save_current(self, save_dir: str):
+        """model_plain.py:103-110 (utils_trainer.py:1208): <save_dir>/G-current_model.pth."""
+        os.makedirs(save_dir, exist_ok=True)
+        return self.save_network_path(self.netG, os.path.join(save_dir, 'G-current_model.pth'))
 
-    def load_current(self):
-        assert self._current is not None
-        self.netG.load_state_dict(self._current, strict=True)
-        self.netG.weights_changed()
+    def load_current(self, save_dir: str):
+        """model_plain.py:112-121 (utils_trainer.py:1289): loads G-current_model.pth if present."""
+        path = os.path.join(save_dir, 'G-current_model.pth')
+        if os.path.isfile(path):
+            self.load_network(path, self.netG, strict=True, param_key='params')
 
     def flush(self):
         self.L = self.E = self.H = None

@@ -5,6 +5,8 @@ initialisation; the compute is ``srhip.drrn_engine.DRRNEngine``.  1-channel inpu
 import torch
 import torch.nn as nn
 
+from srhip.module_path import refresh_if_params_changed
+
 __all__ = ['DRRN']
 
 
@@ -101,4 +103,5 @@ class DRRN(nn.Module):
         xi, h, w = self.prepare_input(x)
         params = [p for _, p in self.named_parameters()]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        refresh_if_params_changed(self, params)   # stock torch.optim wrote the weights?
         return _NetFn.apply(xi, self, need_grad, *params)

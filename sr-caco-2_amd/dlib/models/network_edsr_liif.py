@@ -16,6 +16,8 @@ import math
 import torch
 import torch.nn as nn
 
+from srhip.module_path import refresh_if_params_changed
+
 __all__ = ['EDSR_LIIF', 'EDSR']
 
 
@@ -110,6 +112,7 @@ class EDSR_LIIF(nn.Module):
         xi, h, w = self.prepare_input(x)
         params = [p for _, p in self.named_parameters()]
         need_grad = torch.is_grad_enabled() and (xi.requires_grad or any(p.requires_grad for p in params))
+        refresh_if_params_changed(self, params)   # stock torch.optim wrote the weights?
         return _NetFn.apply(xi, self, need_grad, *params)
 
 

@@ -15,6 +15,8 @@ import math
 
 import torch
 import torch.nn as nn
+
+from srhip.module_path import refresh_if_params_changed
 import torch.nn.functional as F
 
 from dlib.utils import constants
@@ -248,6 +250,7 @@ class SwinIR(nn.Module):
             raise NotImplementedError("inputs must be larger than one 8x8 window")
         params = [p for _, p in self.named_parameters()]
         need_grad = torch.is_grad_enabled() and (xi.requires_grad or any(p.requires_grad for p in params))
+        refresh_if_params_changed(self, params)   # stock torch.optim wrote the weights?
         y = _NetFn.apply(xi, self, dp, need_grad, *params)
         if self.img_range != 1.:
             y = y / self.img_range

@@ -139,6 +139,7 @@ class DRRNEngine:
         ops.relu_mask(gx0, sv["x0"])
         ops.axpby(gu, gx0, 1.0, 1.0)                         # d / d conv1 output
         ops.conv3x3_cin1_wgrad(sv["xi"], gu, grads["conv1.1.weight"], None)
-        if on_layer_done is not None:
-            on_layer_done(0)
+        # single bucket = the last one: TrainStep's reducer sends it after backward (announcing it
+        # here too reduced it twice -- the sum instead of the mean -- before the reducer tracked
+        # which buckets were done)
         return None

@@ -68,10 +68,15 @@ class Optimizer:
         self.betas, self.eps, self.wd = betas, eps, wd
         self.momentum, self.nesterov = momentum, nesterov
         self.scheduler = scheduler or {}
-        self.step_count = 0      # optimizer steps taken
+        self.step_count = 0      # optimizer steps requested (host view; skipped ones included)
         self.sched_count = 0     # scheduler.step() calls
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat) if kind == "adam" else None
+        # steps actually APPLIED, kept on the device: a step skipped by the non-finite flag
+        # must not advance Adam's bias correction / SGD's first-step buffer initialisation
+        # (the reference skips backward and optimizer.step() for that batch only,
+        # model_plain.py:344-346) -- and the host must not sync to find out
+        self.applied = torch.zeros(1, dtype=torch.int32, device=flat.flat.device)
 
     @property
     def lr(self):
@@ -88,12 +93,13 @@ class Optimizer:
     def step(self, gscale=1.0, skip_flag=None):
         fp = self.fp
         self.step_count += 1
+        ops.optim_tick(skip_flag, self.applied)          # applied += (flag == 0), on the device
         if self.kind == "adam":
-            ops.adam_step(fp.flat, fp.grad, self.m, self.v, self.step_count, self.lr, self.betas[0],
-                          self.betas[1], self.eps, self.wd, gscale, skip_flag)
+            ops.adam_step_dc(fp.flat, fp.grad, self.m, self.v, self.applied, self.lr, self.betas[0],
+                             self.betas[1], self.eps, self.wd, gscale, skip_flag)
         elif self.kind == "sgd":
-            ops.sgd_step(fp.flat, fp.grad, self.m, self.lr, self.momentum, self.wd, self.nesterov,
-                         self.step_count == 1, gscale, skip_flag)
+            ops.sgd_step_dc(fp.flat, fp.grad, self.m, self.applied, self.lr, self.momentum, self.wd,
+                            self.nesterov, gscale, skip_flag)
         else:
             raise NotImplementedError(self.kind)
 
@@ -119,6 +125,54 @@ def allreduce_range(flat_grad, lo, hi, group=None, comm_stream=None):
         dist.all_reduce(flat_grad[lo:hi], group=group)
 
 
+class GradReducer:
+    """Bucketed data-parallel gradient exchange (replaces DDP's reducer,
+    model_base.py:135-142).  ``buckets``: flat [lo, hi) ranges in the order backward
+    completes them.  The engine calls ``bucket_done(i)`` from inside backward as soon
+    as bucket i's last gradient kernel is enqueued; ``finish()`` reduces whatever the
+    engine did not announce (an engine may announce none, some or all of its buckets)
+    -- every bucket exactly ONCE per step -- and makes the compute stream wait for the
+    side stream.  Works on CPU tensors + gloo without streams (world_size-2 tests)."""
+
+    def __init__(self, flat_grad, buckets, group=None, comm_stream=None):
+        self.grad, self.buckets, self.group, self.comm_stream = flat_grad, list(buckets), group, comm_stream
+        self.done = [True] * len(self.buckets)
+        self.log = []                       # bucket indices in the order they were reduced (tests)
+
+    def begin(self):
+        self.done = [False] * len(self.buckets)
+        self.log = []
+
+    def bucket_done(self, i):
+        if self.done[i]:
+            return
+        self.done[i] = True
+        self.log.append(i)
+        lo, hi = self.buckets[i]
+        allreduce_range(self.grad, lo, hi, self.group, self.comm_stream)
+
+    def reduce_flag(self, flag):
+        """MAX-all-reduce of the per-step non-finite flag: every replica skips (or applies)
+        the same update, so they cannot diverge."""
+        import torch.distributed as dist
+        if self.comm_stream is None:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+
+    def finish(self, flag=None):
+        for i in range(len(self.buckets)):
+            self.bucket_done(i)
+        if flag is not None:
+            self.reduce_flag(flag)
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+
 class TrainStep:
     """loss_terms: sequence of ('l1', lam) | ('l2', lam) | ('ssim', lam, window) |
     ('charbonnier', lam, eps) | ('l2sum', lam) | ('grad'|'laplace'|'lv'|'norm_grad'|
@@ -140,9 +194,18 @@ class TrainStep:
         dev = self.fp.flat.device
         self.loss_buf = torch.zeros(1 + len(self.loss_terms), device=dev)
         self._sink = torch.zeros(1, device=dev)
+        # flag: THIS step's non-finite indicator (cleared at the start of every step, so one bad
+        # batch skips one update, model_plain.py:344-346); sticky: OR over the steps since the
+        # caller last looked (ModelPlain.check_finite)
         self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sticky = torch.zeros(1, dtype=torch.int32, device=dev)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.ddp else None
         self.buckets = self._make_buckets() if self.ddp else []
+        self.reducer = GradReducer(self.fp.grad, self.buckets, self.pg, self.comm_stream) if self.ddp else None
+        if getattr(net, "img_range", 1.) != 1.:
+            # SwinIR.forward divides the output by img_range (network_swinir.py:935,968); the fused
+            # step feeds engine.forward's output straight to the loss
+            raise NotImplementedError("fused training step: img_range != 1 is not supported")
         self.dy = None
 
     def _make_buckets(self):
@@ -150,10 +213,6 @@ class TrainStep:
         them by parameter prefix); each is one contiguous range of the flat
         gradient buffer."""
         return [self.fp.range_of(pf) for pf in self.net.engine.bucket_prefixes()]
-
-    def _allreduce_bucket(self, i):
-        lo, hi = self.buckets[i]
-        allreduce_range(self.fp.grad, lo, hi, self.pg, self.comm_stream)
 
     def loss_and_grad(self, y, target):
         """MasterLoss value(s) + d loss / d y through the fused loss kernels."""
@@ -198,24 +257,29 @@ class TrainStep:
         (no host sync here; read it when needed)."""
         net = self.net
         xi, h, w = net.prepare_input(lr_img)
-        assert (h, w) == tuple(xi.shape[1:]), "training patches must be multiples of the 8x8 window"
+        assert (h, w) == tuple(xi.shape[1:]), \
+            "training patches must not need padding (SwinIR: multiples of the 8x8 window)"
+        self.flag.zero_()
         if dp is None:
             dp = net.sample_drop_path(xi.shape[0], xi.device)
         y = net.engine.forward(xi, dp, save=True)
         dy = self.loss_and_grad(y, hr_img)
-        hook = self._allreduce_bucket if self.ddp else None
+        hook = None
+        if self.ddp:
+            self.reducer.begin()
+            hook = self.reducer.bucket_done
         # ONE memset of the flat gradient buffer per step: the few gradients that are
         # accumulated with atomics (LayerNorm affine) need no per-tensor zeroing then
         self.fp.grad.zero_()
         net.engine.backward(dy, self.fp.gviews, on_layer_done=hook, grads_zeroed=True)
+        # one device flag: non-finite loss -> the optimizer kernel skips the update
+        ops.nonfinite_flag(self.loss_buf, self.flag)
         if self.ddp:
-            self._allreduce_bucket(len(self.buckets) - 1)
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            self.reducer.finish(self.flag)
         for t in self.loss_terms:            # parameter-space term: lam*sign(w) joins the (summed) gradients;
             if t[0] == "w_sparsity":         # x world because the optimizer divides the all-reduced sum by it
                 ops.l1_sparsity(self.fp.flat, t[1] * self.world, self.fp.grad, self._sink)
-        # one device flag: non-finite loss -> the optimizer kernel skips the update
-        ops.nonfinite_flag(self.loss_buf, self.flag)
+        torch.maximum(self.sticky, self.flag, out=self.sticky)
         self.opt.step(gscale=1.0 / self.world, skip_flag=self.flag)
         self.opt.scheduler_step()
         net.weights_changed()

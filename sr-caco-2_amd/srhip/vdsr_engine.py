@@ -117,6 +117,7 @@ class VDSREngine:
             ops.conv3x3(g, self.ws[f"t{k}.wpt"], None, CH, out=other, epi=4, R=acts[k])     # * (a_k > 0)
             g = other
         ops.conv3x3_cin1_wgrad(sv["xi"], g, grads["conv1.0.weight"], None)
-        if on_layer_done is not None:
-            on_layer_done(0)
+        # single bucket = the last one: TrainStep's reducer sends it after backward (announcing it
+        # here too reduced it twice -- the sum instead of the mean -- before the reducer tracked
+        # which buckets were done)
         return None

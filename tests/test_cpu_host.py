@@ -189,3 +189,154 @@ def test_main_cli_contract():
         M.parse_input("--net_type NLSN --method NLSN".split())
     e = M.parse_input("--net_type EDSR_LIIF --method EDSR_LIIF --scale 4 --h_size 512".split())
     assert e.netG['EDSR_LIIF_n_resblocks'] == 16 and e.netG['EDSR_LIIF_upscale'] == 4
+
+
+def test_sharded_sampler_matches_torch_distributed_sampler():
+    """utils_dataloaders.py:138-148 / utils_trainer.py:325-326,382-386: same index lists as torch's
+    DistributedSampler for shuffle+seed+drop_last+set_epoch (train) and the unshuffled padded eval form."""
+    from torch.utils.data.distributed import DistributedSampler
+    from dlib.utils.utils_dataloaders import ShardedSampler, train_sampler, eval_sampler
+    for n in (1, 7, 64, 101, 1000):
+        ds = list(range(n))
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                for drop_last in (True, False):
+                    for shuffle in (True, False):
+                        if drop_last and n < world:
+                            continue
+                        ref = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle, seed=17,
+                                                 drop_last=drop_last)
+                        mine = ShardedSampler(n, world, rank, shuffle=shuffle, seed=17, drop_last=drop_last)
+                        for epoch in (0, 1, 5):
+                            ref.set_epoch(epoch)
+                            mine.set_epoch(epoch)
+                            assert list(ref) == list(mine), (n, world, rank, drop_last, shuffle, epoch)
+                            assert len(ref) == len(mine)
+    s = train_sampler(100, 8, 3, seed=0)
+    s.set_epoch(2)
+    b = s.batches(4)
+    assert len(b) == 3 and all(len(x) == 4 for x in b) and sum(b, []) == s.indices()[:12]
+    # all ranks together cover every sample exactly once per epoch (drop_last trims the tail)
+    cover = sorted(sum((train_sampler(96, 8, r, 5).indices() for r in range(8)), []))
+    assert cover == list(range(96))
+    assert sorted(sum((eval_sampler(10, 4, r).indices() for r in range(4)), [])) == sorted(list(range(10)) + [0, 1])
+
+
+def test_modelplain_checkpoint_protocol_signatures():
+    """The trainer's call sites (utils_trainer.py:230 save_best(_dir, p_name_file='model.pth'), :1208
+    save_current(save_dir=...), :1289 load_current(save_dir=...)) bind against these signatures and the
+    file names are the reference's (model_plain.py:103-137)."""
+    import inspect
+    from dlib.models.model_plain import ModelPlain
+    assert list(inspect.signature(ModelPlain.save_best).parameters) == ['self', 'save_dir', 'p_name_file']
+    assert list(inspect.signature(ModelPlain.save_current).parameters) == ['self', 'save_dir']
+    assert list(inspect.signature(ModelPlain.load_current).parameters) == ['self', 'save_dir']
+    assert list(inspect.signature(ModelPlain.load_network).parameters) == \
+        ['self', 'load_path', 'network', 'strict', 'param_key']
+    inspect.signature(ModelPlain.save_best).bind(None, '/tmp/x', p_name_file='model.pth')
+    inspect.signature(ModelPlain.save_current).bind(None, save_dir='/tmp/x')
+    inspect.signature(ModelPlain.load_current).bind(None, save_dir='/tmp/x')
+    src = inspect.getsource(ModelPlain)
+    assert "f'G-{p_name_file}'" in src and "'G-current_model.pth'" in src
+
+
+WORKER_REDUCER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(sys.argv[1], "sr-caco-2_amd"))
+from srhip.train import FlatParams, GradReducer
+from dlib.utils.utils_parallel import (sync_tensor_across_gpus, sync_non_tensor_value_across_gpus,
+                                       sync_dict_across_gpus, sync_metric_sums)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+
+
+class StubEngine:
+    """Fills the flat gradient views layer by layer in backward order, the way the HIP engines do,
+    and announces buckets through on_layer_done -- `announce` picks which ones: the SwinIR engine
+    announces every bucket but the last, EDSR none, and an engine that announces its only (= last)
+    bucket must not get it reduced twice."""
+    def __init__(self, net, prefixes, announce):
+        self.net, self.prefixes, self.announce = net, prefixes, announce
+    def bucket_prefixes(self):
+        return self.prefixes
+    def backward(self, x, fp, on_layer_done):
+        loss = self.net(x).pow(2).mean()
+        grads = torch.autograd.grad(loss, list(self.net.parameters()))
+        named = dict(zip([k for k, _ in self.net.named_parameters()], grads))
+        for bi, pf in enumerate(self.prefixes):            # backward-completion order
+            for k, g in named.items():
+                if any(k.startswith(p) for p in pf):
+                    fp.gviews[k].copy_(g)
+            if on_layer_done is not None and bi in self.announce:
+                on_layer_done(bi)
+
+
+def run(prefixes, announce):
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 2))
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 2))
+    ref.load_state_dict(net.state_dict())
+    fp = FlatParams(net)
+    eng = StubEngine(net, prefixes, announce)
+    red = GradReducer(fp.grad, [fp.range_of(pf) for pf in eng.bucket_prefixes()])
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(100 + rank))
+    full = torch.cat([torch.randn(8, 6, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)])
+    for step in range(2):                                   # begin() must re-arm every step
+        fp.grad.zero_()
+        red.begin()
+        eng.backward(x, fp, red.bucket_done)
+        flag = torch.tensor([1 if (rank == 1 and step == 1) else 0], dtype=torch.int32)
+        red.finish(flag)
+        assert sorted(red.log) == list(range(len(prefixes))) and len(red.log) == len(prefixes), red.log
+        assert red.log[:len(announce)] == sorted(announce), (red.log, announce)   # hook order = backward order
+        assert int(flag) == (1 if step == 1 else 0)        # MAX over ranks: every replica skips together
+        fp.grad.mul_(1.0 / world)                           # the optimizer's gscale
+        for p in ref.parameters():
+            p.grad = None
+        ref(full).pow(2).mean().backward()                  # the rank-MEAN gradient = 1-rank large batch
+        for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+            assert torch.allclose(fp.gviews[k], q.grad, atol=1e-6), (k, prefixes, announce)
+
+
+run([["2."], ["1."], ["0."]], announce=[0, 1])      # SwinIR style: all but the last
+run([["2."], ["1."], ["0."]], announce=[])          # EDSR style: none announced
+run([["2."], ["1."], ["0."]], announce=[0, 1, 2])   # all announced
+run([["0.", "1.", "2."]], announce=[0])             # one bucket, announced (old VDSR / DRRN engines)
+run([["0.", "1.", "2."]], announce=[])              # one bucket, not announced
+
+# eval-side collectives (utils_parallel.py:13-64 as used at utils_trainer.py:653-674)
+t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+assert sync_tensor_across_gpus(t).tolist() == [1.0, 2.0]
+assert sync_tensor_across_gpus(None) is None
+assert sync_non_tensor_value_across_gpus(3.0 + rank) == 7.0
+d = sync_dict_across_gpus({float(10 * rank): torch.tensor(0.5 + rank), float(10 * rank + 1): torch.tensor(2.5 + rank)})
+assert {k: float(v) for k, v in d.items()} == {0.0: 0.5, 1.0: 2.5, 10.0: 1.5, 11.0: 3.5}
+sums = {"psnr": torch.tensor(30.0 + rank, dtype=torch.float64), "ssim": torch.tensor(0.5 * (rank + 1), dtype=torch.float64)}
+tot, n = sync_metric_sums(sums, 4 + rank)
+assert float(tot["psnr"]) == 61.0 and float(tot["ssim"]) == 1.5 and n == 9.0
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_grad_reducer_hook_order_and_eval_collectives_gloo_world2(tmp_path):
+    """a20 / SURVEY 8e on CPU: the real GradReducer (the object TrainStep hands to engine.backward as
+    on_layer_done) driven by stub engines with every announce pattern the HIP engines use -- each bucket
+    is reduced exactly once per step and the result is the rank-mean gradient; the per-step non-finite
+    flag is MAX-reduced; the eval metric gathers match the reference's semantics."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker_reducer.py"
+    script.write_text(WORKER_REDUCER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
+               OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o
