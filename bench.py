@@ -1,123 +1,214 @@
 #!/usr/bin/env python3
-"""Headline benchmark: SwinIR x8 (64->512, 1 channel) training patches/sec.
+"""Headline benchmark: training patches/sec of the patch-level hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload swinir_x8|edsr_x8|edsr_x4|edsr_x2]
 
-One process per GPU (torchrun supplies RANK / LOCAL_RANK / WORLD_SIZE); a step is
-forward + L1 loss + backward + (RCCL gradient all-reduce) + optimizer on one
-synthetic batch of 8 patches per GPU (README.md:120-197 configuration: embed 180,
-depths 6x4, heads 6, window 8, mlp_ratio 2, pixelshuffledirect; SGD-Nesterov).
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around
-the dominant kernel class inside the timed region; `cpu_baseline` times the
-oracle (PyTorch-fp32 CPU restatement, validated against the reference) on the
-host cores, on a bounded sample.
+One process per GPU.  With --gpus N > 1 and no WORLD_SIZE in the environment the
+script launches itself under ``python -m torch.distributed.run`` (before any GPU
+call is made in this process) and relays rank 0's JSON line, so the documented
+command is one line; under torchrun (RANK / LOCAL_RANK / WORLD_SIZE set) it is the
+worker.  A step is forward + loss + backward + (RCCL gradient all-reduce) +
+optimizer on one synthetic batch of 8 patches per GPU:
+
+  swinir_x8 (default, BASELINE.json's metric): SwinIR README.md:120-197 configuration
+            (embed 180, depths 6x4, heads 6, window 8, mlp 2, pixelshuffledirect), LR 64^2 -> HR 512^2,
+            L1, SGD-Nesterov
+  edsr_x{8,4,2}: EDSR-baseline (16 ResBlocks x 64 features), LR (512/s)^2 -> HR 512^2, L1, Adam
+
+Rank 0 prints ONE JSON line.  ``value`` = patches of all ranks / wall time of exactly K steps between
+barrier + synchronize pairs (max over ranks); ``step_ms`` = median / p10 / p90 of the per-step durations
+from HIP events recorded on the compute stream; ``roofline`` = the dominant kernel class timed live with
+HIP events inside the timed region (two of every twenty steps); ``cpu_baseline`` = the oracle (PyTorch-fp32
+CPU restatement, validated against the reference) timed on the host cores on a bounded sample, B=1 and B=8.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "sr-caco-2_amd"))
 
-import torch  # noqa: E402
-import torch.nn.functional as F  # noqa: E402
-
-# algorithmic work per patch, forward (SURVEY.md 8d / BASELINE.md): fwd+bwd = 3x
-SWINIR_X8_GFLOP_FWD = 68.30
+# algorithmic work per patch, FORWARD (SURVEY.md 8d / BASELINE.md; fwd + bwd = 3x): GFLOP, GB
+WORK = {"swinir_x8": (68.30, 2.853), "edsr_x8": (35.64, 0.518), "edsr_x4": (64.34, 0.976),
+        "edsr_x2": (179.16, 2.809)}
 F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BX3_PEAK_TFLOPS = 2500.0 / 6.0   # bf16 dense / 6 products per f32-accurate product
 HBM_PEAK_GBS = 8000.0
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="swinir_x8", choices=sorted(WORK))
+    ap.add_argument("--batch", type=int, default=8, help="patches per GPU (README --batch_size 8)")
+    ap.add_argument("--loss", default="l1", choices=["l1", "l2ssim"])
+    ap.add_argument("--optimizer", default=None, choices=["sgd", "adam"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------ parent: self-launch
+def launch_workers(args):
+    """--gpus N > 1 outside torchrun: start the N workers as CHILD processes (this process has not
+    touched the GPU and never execs), relay rank 0's JSON line, propagate failure."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    line = None
+    for out in p.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = p.wait()
+    if rc != 0 or line is None:
+        sys.stderr.write(f"bench.py: worker launch failed (exit {rc}, json line {'seen' if line else 'missing'})\n")
+        return rc or 1
+    print(line, flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------ worker
 def synth_batch(batch, scale, device, seed):
     """H = round(rand*255)/255; L = clamp(bicubic_down(H), 0, 1)."""
+    import torch
+    import torch.nn.functional as F
     g = torch.Generator().manual_seed(seed)
     hr = (torch.rand(batch, 1, 512, 512, generator=g) * 255).round() / 255
     lr = F.interpolate(hr, scale_factor=1.0 / scale, mode="bicubic").clamp(0, 1)
     return lr.to(device), hr.to(device)
 
 
-def cpu_baseline(threads):
-    """Oracle fwd + L1 + bwd + SGD-Nesterov on the host: ONE 64x64->512x512 patch,
-    a bounded sample of the same workload."""
+def physical_cores():
+    """sockets x cores per socket from lscpu (hardware threads are reported separately)."""
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":")[0].strip(): l.split(":")[1].strip() for l in out.splitlines() if ":" in l}
+        return int(kv["Socket(s)"]) * int(kv["Core(s) per socket"])
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(workload, optimizer):
+    """Oracle fwd + L1 + bwd + optimizer on the host, the same workload at B=1 and B=8, bounded to
+    ~25 s: B=1 steps for ~8 s, then one warm-up + up to two timed B=8 steps."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import sr_oracle as O
+    cores = physical_cores()
+    threads = min(32, os.cpu_count() or 1)   # a few dozen threads is where torch's CPU kernels peak here
     torch.set_num_threads(threads)
-    cfg = O.swinir_config(drop_path_rate=0.0)
-    sd = O.swinir_init_state_dict(cfg, seed=0)
-    sd = {k: (v.requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask")
-              else v) for k, v in sd.items()}
-    lr, hr = synth_batch(1, 8, "cpu", 0)
+    scale = int(workload.split("_x")[1])
+    if workload.startswith("swinir"):
+        cfg = O.swinir_config(drop_path_rate=0.0)
+        sd = O.swinir_init_state_dict(cfg, seed=0)
+        fwd = lambda x: O.swinir_forward(sd, x, cfg)
+    else:
+        cfg = O.edsr_config(upscale=scale)
+        sd = O.edsr_init_state_dict(cfg, seed=0)
+        fwd = lambda x: O.edsr_forward(sd, x, cfg)
+    for k, v in sd.items():
+        if v.dtype == torch.float32 and not k.endswith("attn_mask"):
+            v.requires_grad_(True)
     params = [v for v in sd.values() if v.requires_grad]
-    bufs = [torch.zeros_like(p) for p in params]
-    def step(first):
+    m = [torch.zeros_like(p) for p in params]
+    v2 = [torch.zeros_like(p) for p in params]
+    count = [0]
+
+    def step(lr, hr):
         for p in params:
             p.grad = None
-        loss = O.loss_l1(O.swinir_forward(sd, lr, cfg), hr)
-        loss.backward()
+        O.loss_l1(fwd(lr), hr).backward()
+        count[0] += 1
         with torch.no_grad():
-            for p, b in zip(params, bufs):
-                O.sgd_nesterov_step(p, p.grad, b, first, 0.01)
+            for i, p in enumerate(params):
+                if optimizer == "sgd":
+                    O.sgd_nesterov_step(p, p.grad, m[i], count[0] == 1, 0.01)
+                else:
+                    O.adam_step(p, p.grad, m[i], v2[i], count[0], 2e-4, wd=1e-4)
 
-    step(True)                                   # untimed warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:                                  # bounded sample: ~12 s of CPU work, 3..12 steps
-        step(False)
-        n += 1
-        dt = time.perf_counter() - t0
-        if (dt >= 12.0 and n >= 3) or n >= 12 or dt >= 60.0:
-            break
-    return {"value": n / dt, "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"{n} steps of batch 1 (1x64x64 -> 1x512x512), fwd+L1+bwd+SGD-Nesterov, fp32, "
-                      f"{dt:.1f} s after 1 warm-up step"}
+    res = {}
+    for B, budget, max_steps in ((1, 8.0, 12), (8, 12.0, 2)):
+        lr, hr = synth_batch(B, scale, "cpu", 0)
+        step(lr, hr)                                   # untimed warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            step(lr, hr)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget or n >= max_steps:
+                break
+        res[B] = {"patches_per_s": B * n / dt, "steps": n, "seconds": dt}
+    best = max(res, key=lambda b: res[b]["patches_per_s"])
+    return {"value": res[best]["patches_per_s"], "unit": "patches/s", "cores": cores, "threads": threads,
+            "kind": "port", "b1": res[1], "b8": res[8],
+            "sample": f"{workload}: oracle fwd+L1+bwd+{optimizer}, fp32, {threads} threads on {cores} physical cores; "
+                      f"B=1: {res[1]['steps']} steps in {res[1]['seconds']:.1f} s, B=8: {res[8]['steps']} steps in "
+                      f"{res[8]['seconds']:.1f} s (each after one warm-up step); value = the better of the two"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="patches per GPU (README --batch_size 8)")
-    ap.add_argument("--loss", default="l1", choices=["l1", "l2ssim"])
-    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
-
+def worker(args):
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run "
-                             "--nproc-per-node N bench.py --gpus N ...")
+    if world != args.gpus and rank == 0:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE\n")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
+    n_ranks_seen = 1
     if world > 1 or os.environ.get("SRHIP_FORCE_DDP", "0") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL
         pg = dist.group.WORLD
+        n_ranks_seen = dist.get_world_size()
 
-    from dlib.models.network_swinir import SwinIR
     from srhip import probe
     from srhip.ops import use_bx3 as ops_use_bx3
-    from srhip.train import TrainStep, Optimizer, FlatParams  # noqa: F401
+    from srhip.train import TrainStep, Optimizer
 
     torch.manual_seed(0)                      # same weights on every rank
-    net = SwinIR(upscale=8, in_chans=1, img_size=64, window_size=8, depths=[6, 6, 6, 6], embed_dim=180,
-                 num_heads=[6, 6, 6, 6], mlp_ratio=2, upsampler="pixelshuffledirect").to(dev).train()
+    scale = int(args.workload.split("_x")[1])
+    if args.workload == "swinir_x8":
+        from dlib.models.network_swinir import SwinIR
+        net = SwinIR(upscale=8, in_chans=1, img_size=64, window_size=8, depths=[6, 6, 6, 6], embed_dim=180,
+                     num_heads=[6, 6, 6, 6], mlp_ratio=2, upsampler="pixelshuffledirect").to(dev).train()
+        desc = ("SwinIR x8 README config (embed 180, depths 6+6+6+6, heads 6, window 8, mlp 2, "
+                "pixelshuffledirect), LR 1x64x64 -> HR 1x512x512")
+        opt_kind = args.optimizer or "sgd"    # README.md:152-159
+        kinds = ("gemm_nt", "linear_tn", "wattn", "conv_nt", "mlp_fused")
+    else:
+        from dlib.models.network_edsr_liif import EDSR_LIIF
+        net = EDSR_LIIF(scale=scale).to(dev).train()
+        desc = (f"EDSR-baseline x{scale} (16 ResBlocks x 64 features, pixel-shuffle tail), "
+                f"LR 1x{512 // scale}x{512 // scale} -> HR 1x512x512")
+        opt_kind = args.optimizer or "adam"   # utils_instance.py:216-247 default
+        kinds = ("conv_nt", "conv_tn")
     terms = [("l1", 1.0)] if args.loss == "l1" else [("l2", 1.0), ("ssim", 5.0, 19)]
     ts = TrainStep(net, terms, process_group=pg, world_size=world)
-    if args.optimizer == "sgd":   # README.md:152-159
+    if opt_kind == "sgd":
         ts.opt = Optimizer(ts.fp, "sgd", lr=0.01, momentum=0.9, nesterov=True, wd=0.0,
                            scheduler={"type": "MyStepLR", "step_size": 30, "gamma": 0.5, "min_lr": 1e-4})
     else:
         ts.opt = Optimizer(ts.fp, "adam", lr=2e-4, wd=1e-4)
-    lr_img, hr_img = synth_batch(args.batch, 8, dev, seed=1000 + rank)
+    lr_img, hr_img = synth_batch(args.batch, scale, dev, seed=1000 + rank)
 
     def barrier():
         if pg is not None:
@@ -129,19 +220,26 @@ def main():
         ts.step(lr_img, hr_img)
     barrier()
     if not args.no_roofline:
-        probe.enable("gemm_nt")
+        probe.enable(kinds)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # HIP events around every NT-GEMM launch of every 20th step (an event is a barrier
-        # packet on the stream: a probed step runs ~18 % slower, so probing all of them
-        # would cost the headline number; 1 of the default 20 steps = 192 timed launches,
-        # taken mid-run)
-        probe.active = "gemm_nt" if (not args.no_roofline and i % 20 == 10 % max(args.steps, 1)) else None
+        # HIP events around every launch of the probed op classes in two of every twenty steps (an
+        # event pair is two barrier packets: a probed step runs ~18 % slower, so probing all of
+        # them would cost the headline number), taken mid-run
+        probe.active = set(kinds) if (not args.no_roofline and i % 10 == 5 % max(args.steps, 1)) else None
+        marks[i].record()
         ts.step(lr_img, hr_img)
+    marks[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
+    probe.active = set(kinds)
     roof = probe.collect() if not args.no_roofline else None
     probe.disable()
+    steps_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+
+    def pct(q):
+        return steps_ms[min(len(steps_ms) - 1, int(round(q * (len(steps_ms) - 1))))]
 
     if pg is not None:
         import torch.distributed as dist
@@ -165,35 +263,47 @@ def main():
         net.train()
     if rank == 0:
         patches = args.batch * world * args.steps
+        pps = patches / dt
+        gflop, gbyte = WORK[args.workload]
+        bx = ops_use_bx3()
         out = {
-            "metric": "train patches/sec, SwinIR x8 64->512 1ch",
-            "value": patches / dt, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "metric": "train patches/sec, SwinIR x8 64->512 1ch" if args.workload == "swinir_x8"
+                      else f"train patches/sec, EDSR-baseline x{scale} {512 // scale}->512 1ch",
+            "value": pps, "unit": "patches/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "timer": "HIP events, rank 0"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "SwinIR x8 README config (embed 180, depths 6+6+6+6, heads 6, "
-                                   "window 8, mlp 2, pixelshuffledirect), LR 1x64x64 -> HR 1x512x512, "
-                                   f"fwd + {args.loss} + bwd + {args.optimizer}",
+            "config": {"workload": f"{desc}, fwd + {args.loss} + bwd + {opt_kind}",
                        "global_batch": args.batch * world, "batch_per_gpu": args.batch,
                        "parallelism": f"dp{world}", "final_loss": loss,
                        "eval_patches_per_s_one_gpu": eval_pps,
                        "matmul": ("bf16x3 split MFMA: f32 operands split into 3 bf16 parts, 6 products, "
-                                  "f32 accumulate (f32-accurate)") if ops_use_bx3() else "f32 MFMA"},
+                                  "f32 accumulate (f32-accurate)") if bx else "f32 MFMA"},
+            # whole step against both rooflines: algorithmic bytes / flops x 3 (fwd + bwd) x patches/s
+            "whole_step": {"hbm_frac": gbyte * 3.0 * pps / world / HBM_PEAK_GBS,
+                           "flop_frac": gflop * 3.0 * pps / world / 1000.0 / (BX3_PEAK_TFLOPS if bx else F32_MFMA_PEAK_TFLOPS),
+                           "flop_frac_of_f32_mfma_peak": gflop * 3.0 * pps / world / 1000.0 / F32_MFMA_PEAK_TFLOPS,
+                           "algorithmic_gflop_per_patch_fwd": gflop, "algorithmic_gbyte_per_patch_fwd": gbyte,
+                           "per_gpu": True},
         }
-        gflop_step = 3.0 * SWINIR_X8_GFLOP_FWD * args.batch
-        out["model_flops_frac_of_f32_mfma_peak"] = \
-            gflop_step / (1000.0 * dt / args.steps) / F32_MFMA_PEAK_TFLOPS
         if roof:
             out["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
-            # a few dozen threads is where torch's CPU kernels peak on these
-            # shapes; oversubscribing a 256-thread host is 10x slower
-            out["cpu_baseline"] = cpu_baseline(min(32, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(args.workload, opt_kind)
         print(json.dumps(out), flush=True)
     if pg is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_workers(args)
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -311,6 +311,80 @@ def g_swinir_tiny():
     npz("g3_swinir_tiny", **arrs)
 
 
+# ---------------------------------------------------------------- G18 trained-like regime
+def g_trained_like():
+    """SwinIR-tiny and a small EDSR with weights moved into a trained-like regime (Linear x10,
+    relative-position tables ~ N(0,1), non-zero biases / LayerNorm affine, EDSR convs x2): the
+    softmax saturates, the -100 shift mask decides probabilities, GELU / ReLU see their tails.
+    Reference forward (eval + train), dL/dx and every parameter gradient."""
+    print("G18 trained-like weights")
+    cfg = tiny_cfg()
+    sd = O.trained_like_(O.swinir_init_state_dict(cfg, seed=21), 210, qk_scale=2.5)
+    net = build_ref_swinir(cfg)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    torch.manual_seed(22)
+    x = torch.rand(2, 1, 16, 16)
+    probs = {}
+    b1 = net.layers[0].residual_group.blocks[1]        # a shifted block
+    hk = b1.attn.softmax.register_forward_hook(lambda m, i, o: probs.setdefault("p", o.detach().clone()))
+    with torch.no_grad():
+        y_eval = net(x)
+        yo = O.swinir_forward(sd, x, cfg)
+    hk.remove()
+    close(yo, y_eval, 2e-5, "trained-like swinir tiny eval forward")
+    pm = probs["p"].max(dim=-1).values
+    print(f"  softmax of the shifted block: mean max-prob {pm.mean():.3f}, rows with max-prob > 0.9: "
+          f"{(pm > 0.9).float().mean():.3f}, exact zeros (masked pairs) {(probs['p'] == 0).float().mean():.3f}")
+    assert pm.mean() > 0.3 and (probs["p"] == 0).float().mean() > 0.1, "regime is not saturated / mask idle"
+    net.train()
+    for l in net.layers:
+        for b in l.residual_group.blocks:
+            b.drop_path = nn.Identity()
+    xg = x.clone().requires_grad_(True)
+    y = net(xg)
+    torch.manual_seed(23)
+    tgt = torch.rand_like(y)
+    (y - tgt).abs().mean().backward()
+    grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask") else v)
+           for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = O.swinir_forward(sdo, xo, cfg)
+    (yo - tgt).abs().mean().backward()
+    close(xo.grad, xg.grad, 1e-5 * float(xg.grad.abs().max()) + 1e-9, "trained-like swinir dL/dx")
+    for k in grads:
+        e = (sdo[k].grad - grads[k]).abs().max().item() / (grads[k].abs().max().item() + 1e-30)
+        assert e < 1e-5, (k, e)
+    print("  ok trained-like swinir param grads")
+    arrs = dict(x=x, y_eval=y_eval, y_train=y.detach(), target=tgt, dx=xg.grad)
+    arrs.update(sd_np(sd, "sd/"))
+    arrs.update(sd_np(grads, "grad/"))
+
+    ecfg = O.edsr_config(upscale=4, n_feats=16, n_resblocks=3, res_scale=1.0)
+    esd = O.trained_like_(O.edsr_init_state_dict(ecfg, seed=24), 240, conv_scale=2.0)
+    enet = build_ref_edsr(ecfg)
+    enet.load_state_dict(esd, strict=True)
+    torch.manual_seed(25)
+    ex = torch.rand(2, 1, 24, 16)
+    ey = enet(ex)
+    etgt = torch.rand_like(ey)
+    (ey - etgt).abs().mean().backward()
+    egr = {k: p.grad.clone() for k, p in enet.named_parameters()}
+    esdo = {k: v.clone().requires_grad_(True) for k, v in esd.items()}
+    eyo = O.edsr_forward(esdo, ex, ecfg)
+    close(eyo, ey, 1e-5 * float(ey.abs().max()), "trained-like edsr forward")
+    (eyo - etgt).abs().mean().backward()
+    for k in egr:
+        e = (esdo[k].grad - egr[k]).abs().max().item() / (egr[k].abs().max().item() + 1e-30)
+        assert e < 1e-5, (k, e)
+    print(f"  ok trained-like edsr (|y| max {float(ey.abs().max()):.2f})")
+    arrs.update(dict(ex=ex, ey=ey.detach(), etarget=etgt, ecfg=np.array([4, 3, 16])))
+    arrs.update(sd_np(esd, "esd/"))
+    arrs.update(sd_np(egr, "egrad/"))
+    npz("g18_trained_like", **arrs)
+
+
 # ---------------------------------------------------------------- G4 README config
 def g_swinir_readme():
     print("G4 SwinIR README-config forward (seeded weights, output only)")
@@ -827,7 +901,7 @@ def g_optim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
-            g_metrics, g_optim]
+            g_metrics, g_optim, g_trained_like]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:
         if not only or g.__name__ in only:

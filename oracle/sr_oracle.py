@@ -289,6 +289,34 @@ def swinir_init_state_dict(cfg: dict, seed: int = 0) -> SD:
     return sd
 
 
+def trained_like_(sd: SD, seed: int, lin_scale: float = 10.0, table_std: float = 1.0,
+                  bias_std: float = 0.1, conv_scale: float = 1.0, qk_scale: float = 1.0) -> SD:
+    """In place: move a freshly initialised state_dict into a trained-like regime (test
+    infrastructure; no reference counterpart -- the reference ships no weights here).  Fresh
+    weights (trunc-normal 0.02, zero biases) leave the net nearly linear and every softmax
+    nearly uniform, so the {0,-100} shift mask, large logits and the GELU tails are never
+    exercised.  Linear weights x lin_scale, relative-position tables ~ N(0, table_std),
+    Linear biases and LayerNorm beta ~ N(0, bias_std), LayerNorm gamma ~ 1 + N(0, bias_std),
+    conv weights x conv_scale."""
+    g = torch.Generator().manual_seed(seed)
+    for k, v in sd.items():
+        if v.dtype != torch.float32 or k.endswith("attn_mask"):
+            continue
+        if k.endswith("relative_position_bias_table"):
+            v.copy_(torch.randn(v.shape, generator=g) * table_std)
+        elif "norm" in k:
+            v.add_(bias_std * torch.randn(v.shape, generator=g))
+        elif v.ndim == 2:
+            v.mul_(lin_scale)
+            if k.endswith("qkv.weight") and qk_scale != 1.0:   # q and k rows only: sharper logits
+                v[:2 * v.shape[0] // 3].mul_(qk_scale)
+        elif v.ndim == 4:
+            v.mul_(conv_scale)
+        elif v.ndim == 1 and ("qkv" in k or "proj" in k or "fc" in k):
+            v.add_(bias_std * torch.randn(v.shape, generator=g))
+    return sd
+
+
 # ----------------------------------------------------------------------------
 # EDSR-baseline assembled from the reference's EDSR blocks
 # (network_nlsn.py:38-128 blocks, :355-369 wiring without attention;

@@ -205,8 +205,8 @@ def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
     else:
         assert stats_out is None, "row statistics are produced by the bx3 kernel only"
         name, args = "srhip_gemm_nt", (_p(A), A.stride(0), _p(W), W.stride(0)) + tail
-    if probe.active == "gemm_nt":
-        with probe.timed(("gemm_nt", M, N, K), 2.0 * M * N * K):
+    if probe.on("gemm_nt"):
+        with probe.timed(("gemm_nt", M, N, K), 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)):
             call(name, *args)
     else:
         call(name, *args)
@@ -221,8 +221,8 @@ def gemm_nt_lnbwd(A, W, x, stats, res, out):
     assert W.K == K and x.shape == (M, W.rows) and out.shape == (M, W.rows)
     args = (_p(A), A.stride(0), _p(W.planes), _p(out), out.stride(0), M, W.rows, K,
             _p(x), x.stride(0), _p(stats), _p(res), 0 if res is None else res.stride(0), _st())
-    if probe.active == "gemm_nt":      # same kernel as gemm_nt: belongs to the same roofline entry
-        with probe.timed(("gemm_nt", M, W.rows, K), 2.0 * M * W.rows * K):
+    if probe.on("gemm_nt"):      # same kernel as gemm_nt: belongs to the same roofline entry
+        with probe.timed(("gemm_nt", M, W.rows, K), 2.0 * M * W.rows * K, 4.0 * (M * K + W.rows * K + 3 * M * W.rows)):
             call("srhip_gemm_nt_bx3_lnbwd", *args)
     else:
         call("srhip_gemm_nt_bx3_lnbwd", *args)
@@ -238,10 +238,17 @@ def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0
         out = torch.empty(B, H, W, Cout, device=X.device, dtype=torch.float32)
     if bx:
         assert Wp.rows == 9 * Cout and Wp.K == Cin
-    call("srhip_conv3x3_nhwc_bx3" if bx else "srhip_conv3x3_nhwc", _p(X), X.stride(2),
-         _p(Wp.planes if bx else Wp), _p(bias), _p(out), out.stride(2),
-         B, H, W, Cin, Cout, epi, _p(R), 0 if R is None else R.stride(2), _p(rowscale),
-         float(alpha), _st())
+    args = (_p(X), X.stride(2), _p(Wp.planes if bx else Wp), _p(bias), _p(out), out.stride(2),
+            B, H, W, Cin, Cout, epi, _p(R), 0 if R is None else R.stride(2), _p(rowscale),
+            float(alpha), _st())
+    name = "srhip_conv3x3_nhwc_bx3" if bx else "srhip_conv3x3_nhwc"
+    if probe.on("conv_nt"):
+        T = B * H * W
+        with probe.timed(("conv_nt", T, Cout, Cin), 18.0 * T * Cout * Cin,
+                         4.0 * (T * Cin + 9 * Cin * Cout + T * Cout * (2 if R is not None else 1))):
+            call(name, *args)
+    else:
+        call(name, *args)
     return out
 
 
@@ -335,7 +342,13 @@ def linear_wgrad_grouped(problems, ln_grads_zeroed=False):
         a.a_rowscale, a.a_rowscale_rows = _p(q.get("a_rowscale")), q.get("a_rowscale_rows", 1)
         a.b_mode, a.ln_stats = q.get("b_mode", 0), _p(q.get("ln_stats"))
         a.part, a.part_colsum = _p(pk), _p(ck)
-    call("srhip_gemm_tn_grouped" + _tn_sfx(), ctypes.addressof(arr), n, M, S, _st())
+    if probe.on("linear_tn"):
+        fl = sum(2.0 * M * q["dY"].shape[1] * q["X"].shape[1] for q in problems)
+        by = sum(4.0 * (M * (q["dY"].shape[1] + q["X"].shape[1]) + q["dY"].shape[1] * q["X"].shape[1]) for q in problems)
+        with probe.timed(("linear_tn", M, n), fl, by):
+            call("srhip_gemm_tn_grouped" + _tn_sfx(), ctypes.addressof(arr), n, M, S, _st())
+    else:
+        call("srhip_gemm_tn_grouped" + _tn_sfx(), ctypes.addressof(arr), n, M, S, _st())
     red = (_ReduceProblem * n)()
     for r, q, (pk, ck) in zip(red, problems, views):
         r.part, r.colsum, r.dW, r.db = _p(pk), _p(ck), _p(q["dW"]), _p(q["db"])
@@ -358,8 +371,15 @@ def conv3x3_wgrad(dY, X, dW, db):
     S, n = tn_plan(B * H * W, Cout, Cin, True, bx)
     part = SCRATCH.get("tn_part", n, device=dY.device)
     cs = SCRATCH.get("tn_colsum", S * Cout, device=dY.device)
-    call("srhip_conv3x3_wgrad" + _tn_sfx(bx), _p(dY), dY.stride(2), _p(X), X.stride(2), B, H, W, Cout, Cin,
-         _p(part), _p(cs), S, _st())
+    def run():
+        call("srhip_conv3x3_wgrad" + _tn_sfx(bx), _p(dY), dY.stride(2), _p(X), X.stride(2), B, H, W, Cout, Cin,
+             _p(part), _p(cs), S, _st())
+    if probe.on("conv_tn"):
+        T = B * H * W
+        with probe.timed(("conv_tn", T, Cout, Cin), 18.0 * T * Cout * Cin, 4.0 * (T * Cin + T * Cout + 9 * Cin * Cout)):
+            run()
+    else:
+        run()
     call("srhip_reduce_conv_wgrad", _p(part), _p(cs), S, _p(dW), _p(db), Cout, Cin, _st())
 
 
@@ -420,14 +440,24 @@ def bias_grad_batched(dbiasT_all, first, dtables):
 
 def window_attention_fwd(qkv, out, biasT, B, H, W, C, heads, shift):
     _chk(qkv, out, biasT)
+    if probe.on("wattn"):
+        T = B * H * W
+        with probe.timed(("wattn", "fwd", T, C), 4.0 * T * 64 * C, 4.0 * T * 4 * C):
+            call("srhip_window_attention_fwd", _p(qkv), _p(out), _p(biasT), B, H, W, C, heads, shift, _st())
+        return
     call("srhip_window_attention_fwd", _p(qkv), _p(out), _p(biasT), B, H, W, C, heads, shift, _st())
 
 
 def window_attention_bwd(qkv, dout, dqkv, biasT, biasN, dbiasT, B, H, W, C, heads, shift):
     _chk(qkv, dout, dqkv, biasT, biasN, dbiasT)
     ws = SCRATCH.get("wattn_ws", lib.srhip_window_attention_bwd_ws(B, H, W, heads), device=qkv.device)
-    call("srhip_window_attention_bwd", _p(qkv), _p(dout), _p(dqkv), _p(biasT), _p(biasN),
-         _p(dbiasT), _p(ws), B, H, W, C, heads, shift, _st())
+    args = (_p(qkv), _p(dout), _p(dqkv), _p(biasT), _p(biasN), _p(dbiasT), _p(ws), B, H, W, C, heads, shift, _st())
+    if probe.on("wattn"):
+        T = B * H * W
+        with probe.timed(("wattn", "bwd", T, C), 10.0 * T * 64 * C, 4.0 * T * 7 * C):
+            call("srhip_window_attention_bwd", *args)
+        return
+    call("srhip_window_attention_bwd", *args)
 
 
 # ------------------------------------------------------------------ edge convs

@@ -1,19 +1,33 @@
 """Live per-kernel timing for bench.py's roofline figure: HIP events recorded
-on the launching stream around every launch of one op class, inside the timed
-region.  Off by default (zero overhead beyond one attribute check)."""
+on the launching stream around every launch of the probed op classes, inside
+the timed region.  Off by default (zero overhead beyond one attribute check).
+
+Op classes ("kinds") and the kernels behind them:
+  gemm_nt    Linear forward / data gradient            k_ntp<WN> / k_ntb (gemm_ntp.hip, gemm_ntb.hip)
+  conv_nt    3x3 conv forward / data gradient          k_ntb<..,true> implicit GEMM (gemm_ntb.hip)
+  conv_tn    3x3 conv weight gradient                  k_tnb<W> conv form (gemm_tnb.hip)
+  linear_tn  Linear weight gradients (grouped launch)  k_tnb_grouped<W> (gemm_tnb.hip)
+  wattn      window attention forward / backward       k_wattn_* (wattn.hip)
+  mlp_fused  fused LN->fc1->GELU->fc2 (+ its backward) k_mlp_* (mlp_fused.hip)
+Every record carries the launch's ALGORITHMIC flops and bytes (SURVEY 8d
+convention: operands read once, result written once, fp32)."""
+import json
+import os
+
 import torch
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 # bf16x3 path: every f32 product costs 6 bf16 products on v_mfma_f32_32x32x16_bf16
 # (dense bf16 peak 2.5 PFLOP/s, MI355X_MICROARCH.md) -> ceiling in f32-equivalent flops
 BX3_MFMA_PEAK_TFLOPS = 2500.0 / 6.0
-active = None
+HBM_PEAK_GBS = 8000.0
+active = None           # None | set of kinds being timed in the current step
 _records = {}
 
 
-def enable(kind):
+def enable(kinds):
     global active
-    active = kind
+    active = set([kinds] if isinstance(kinds, str) else kinds)
     _records.clear()
 
 
@@ -22,11 +36,15 @@ def disable():
     active = None
 
 
-class timed:
-    """with probe.timed(("gemm_nt", M, N, K), flops): launch..."""
+def on(kind):
+    return active is not None and kind in active
 
-    def __init__(self, key, flops):
-        self.key, self.flops = key, flops
+
+class timed:
+    """with probe.timed(("gemm_nt", M, N, K), flops, bytes): launch..."""
+
+    def __init__(self, key, flops, nbytes=0.0):
+        self.key, self.flops, self.nbytes = key, flops, nbytes
 
     def __enter__(self):
         self.a = torch.cuda.Event(enable_timing=True)
@@ -35,66 +53,71 @@ class timed:
 
     def __exit__(self, *exc):
         self.b.record()
-        _records.setdefault(self.key, []).append((self.a, self.b, self.flops))
+        _records.setdefault(self.key, []).append((self.a, self.b, self.flops, self.nbytes))
 
 
-def _kernel_name(n, k):
-    """Instantiation the NT dispatcher (csrc/gemm_ntb.hip -> gemm_ntp.hip, gemm_nt.hip) picks for (N, K) at M >= 32768."""
-    from . import ops
-    if ops.use_bx3():
-        return "k_ntp<3>" if n % 180 == 0 else None
-    if n % 180 == 0 and n // 180 == 2:
-        return "k_nt<2, 3, 36, false>"
-    if n % 180 == 0:
-        return "k_nt<1, 3, 60, false>" if k % 60 == 0 else "k_nt<1, 3, 36, false>"
-    return None
+_KERNEL_OF_KIND = {
+    "gemm_nt": ("k_ntp", "NT GEMM (Linear forward / data gradient)"),
+    "conv_nt": ("k_ntb", "implicit-GEMM 3x3 conv (forward / data gradient)"),
+    "conv_tn": ("k_tnb", "3x3 conv weight gradient"),
+    "linear_tn": ("k_tnb_grouped", "grouped Linear weight gradients"),
+    "wattn": ("k_wattn", "window attention core"),
+    "mlp_fused": ("k_mlp", "fused LayerNorm -> fc1 -> GELU -> fc2 -> residual (and its backward)"),
+}
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch of that kernel from the committed rocprofv3 --pmc run
-    (profiles/r01_hbm_traffic_per_kernel.json; FETCH_SIZE x2 + WRITE_SIZE, separate
-    passes, see tools/collect_traffic.sh).  None if not collected."""
-    import json
-    import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
-                        "profiles", "r01_hbm_traffic_per_kernel.json")
-    if kernel is None or not os.path.isfile(path):
-        return None
-    for name, v in json.load(open(path)).items():
-        if kernel in name:
-            return v["hbm_bytes_per_launch"]
-    return None
+def _pmc_traffic(kernel_stem):
+    """Average HBM bytes per launch of the kernels whose name contains ``kernel_stem``, from the
+    committed rocprofv3 --pmc passes (profiles/r0N_hbm_traffic_per_kernel.json; FETCH_SIZE x2 +
+    WRITE_SIZE, separate passes, tools/collect_traffic.sh).  None if not collected."""
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    want = os.environ.get("SRHIP_TRAFFIC_JSON")
+    cands = [want] if want else [os.path.join(root, "profiles", f"r0{r}_hbm_traffic_per_kernel.json")
+                                 for r in (9, 8, 7, 6, 5, 4, 3, 2, 1)]
+    for path in cands:
+        if path and os.path.isfile(path):
+            tot = n = 0.0
+            for name, v in json.load(open(path)).items():
+                if kernel_stem in name:
+                    tot += v["hbm_bytes_per_launch"] * v["launches"]
+                    n += v["launches"]
+            if n:
+                return tot / n, os.path.basename(path)
+    return None, None
 
 
 def collect():
-    """Dominant KERNEL (largest summed duration over all the (M, N, K) classes that
-    dispatch to it) -> roofline dict.  avg_launch_us is the mean over all its timed
-    launches, i.e. the figure rocprofv3 --stats reports for that kernel."""
+    """Dominant op class (largest summed launch time) -> roofline dict.  avg_launch_us is the
+    mean over all its timed launches, i.e. the figure rocprofv3 --stats reports for its kernel."""
     torch.cuda.synchronize()
     from . import ops
-    per_kernel = {}
+    per_kind = {}
     for key, evs in _records.items():
-        kname = _kernel_name(key[2], key[3]) or f"nt(N={key[2]},K={key[3]})"
-        ms = sum(a.elapsed_time(b) for a, b, _ in evs)
-        fl = sum(f for _, _, f in evs)
-        g = per_kernel.setdefault(kname, [0.0, 0.0, 0, {}])
+        ms = sum(a.elapsed_time(b) for a, b, _, _ in evs)
+        g = per_kind.setdefault(key[0], [0.0, 0.0, 0.0, 0, {}])
         g[0] += ms
-        g[1] += fl
-        g[2] += len(evs)
-        g[3][f"M={key[1]} N={key[2]} K={key[3]}"] = {"launches": len(evs), "avg_us": 1000.0 * ms / len(evs)}
-    if not per_kernel:
+        g[1] += sum(e[2] for e in evs)
+        g[2] += sum(e[3] for e in evs)
+        g[3] += len(evs)
+        g[4][" ".join(str(v) for v in key[1:])] = {"launches": len(evs), "avg_us": 1000.0 * ms / len(evs)}
+    if not per_kind:
         return None
-    kname, (ms, fl, n, classes) = max(per_kernel.items(), key=lambda kv: kv[1][0])
+    kind, (ms, fl, by, n, classes) = max(per_kind.items(), key=lambda kv: kv[1][0])
+    stem, what = _KERNEL_OF_KIND.get(kind, (kind, kind))
     tf = fl / (ms * 1e-3) / 1e12
+    gbs = by / (ms * 1e-3) / 1e9
     bx = ops.use_bx3()
     peak = BX3_MFMA_PEAK_TFLOPS if bx else F32_MFMA_PEAK_TFLOPS
-    what = "bf16x3-split MFMA (f32-equivalent flops; peak = bf16 dense / 6)" if bx else "f32-MFMA"
-    traffic = _pmc_traffic(kname)
-    out = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
-           "frac": tf / peak, "traffic": traffic,
-           "kernel": f"{kname}: {what} NT GEMM", "launches": n, "avg_launch_us": 1000.0 * ms / n,
-           "algorithmic_gflop_per_launch": fl / n / 1e9, "classes": classes}
-    if traffic:      # the kernel sits near the ridge: its HBM side, from the PMC bytes, for reference
-        out["hbm_tb_per_s_from_traffic"] = traffic / (ms / n * 1e-3) / 1e12
-        out["hbm_frac_of_8tb_per_s"] = out["hbm_tb_per_s_from_traffic"] / 8.0
+    arith = "bf16x3-split MFMA (f32-equivalent flops; peak = bf16 dense / 6)" if bx else "f32 MFMA"
+    traffic, src = _pmc_traffic(stem)
+    out = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+           "traffic": traffic, "traffic_source": src,
+           "kernel": f"{stem}*: {what}; {arith}", "launches": n, "avg_launch_us": 1000.0 * ms / n,
+           "algorithmic_gflop_per_launch": fl / n / 1e9,
+           "algorithmic_mbytes_per_launch": by / n / 1e6,
+           "hbm_side": {"achieved_gb_per_s_algorithmic": gbs, "frac_of_8tb_per_s": gbs / HBM_PEAK_GBS},
+           "share_of_probed_time": {k: v[0] / sum(x[0] for x in per_kind.values()) for k, v in per_kind.items()},
+           "classes": classes}
+    if traffic:
+        out["hbm_side"]["measured_gb_per_s_from_pmc_traffic"] = traffic / (ms / n * 1e-3) / 1e9
     return out

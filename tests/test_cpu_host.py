@@ -340,3 +340,19 @@ def test_grad_reducer_hook_order_and_eval_collectives_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert f"rank {r} ok" in o
+
+
+def test_bench_self_launch_relays_worker_failure():
+    """`python bench.py --gpus N` is ONE command: outside torchrun the parent starts the N workers under
+    torch.distributed.run as child processes (it never touches the GPU itself and never execs), relays
+    rank 0's JSON line and propagates failure.  Here there is no GPU: the workers fail, the parent must
+    exit non-zero without printing a result line (no fallback, no hang)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert p.returncode == 0 and '"n_ranks_seen": 2' in p.stdout
+    else:
+        assert p.returncode != 0
+        assert '{"metric"' not in p.stdout
+        assert "worker launch failed" in p.stderr

@@ -95,7 +95,7 @@ def test_gemm_bx3_prologues_epilogues(ops):
 
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 16, 180, 180), (1, 24, 40, 60, 60), (1, 20, 12, 64, 64),
                                          (1, 16, 16, 64, 256), (2, 64, 64, 180, 64), (1, 9, 7, 16, 16),
-                                         (8, 64, 64, 180, 180)])
+                                         (8, 64, 64, 180, 180), (8, 128, 128, 64, 64), (8, 128, 128, 64, 256)])
 def test_conv_bx3_matches_f32(ops, B, H, W, Ci, Co):
     x, w, b = rnd(B, Ci, H, W), rnd(Co, Ci, 3, 3, scale=0.05), rnd(Co)
     xh = x.permute(0, 2, 3, 1).contiguous().cuda()
@@ -107,8 +107,6 @@ def test_conv_bx3_matches_f32(ops, B, H, W, Ci, Co):
     ybx = ops.conv3x3(xh, ops.split_bf16x3(wp), b.cuda(), Co)
     e32, ebx = relerr(y32.permute(0, 3, 1, 2), ref), relerr(ybx.permute(0, 3, 1, 2), ref)
     assert ebx <= max(2.0 * e32, 1e-6), f"conv bx3 {ebx:.3e} vs f32 kernel {e32:.3e}"
-    if B * H * W > 20000:
-        return
     dy = rnd(B, Co, H, W)
     dyh = dy.permute(0, 2, 3, 1).contiguous().cuda()
     dx = ops.conv3x3(dyh, ops.split_bf16x3(wpt), None, Ci)

@@ -43,13 +43,13 @@ def test_edsr_small_fwd_bwd_vs_reference_golden(scale):
     for k, p in net.named_parameters():
         ref = g["grad/" + k]
         e = (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
-        assert e <= 1e-3, f"grad {k}: rel err {e:.2e}"
+        assert e <= 2e-5, f"grad {k}: rel err {e:.2e}"      # <= 10x the measured margin
     # d loss / d input against the oracle
     sd = {k: v.clone() for k, v in sub(g, "sd/").items()}
     xo = g["x"].clone().requires_grad_(True)
     cfg = O.edsr_config(upscale=s, n_feats=nf, n_resblocks=nb, res_scale=float(g["res_scale"]))
     O.edsr_forward(sd, xo, cfg).abs().mean().backward()
-    assert (x.grad.cpu() - xo.grad).abs().max() <= 1e-3 * xo.grad.abs().max()
+    assert (x.grad.cpu() - xo.grad).abs().max() <= 2e-5 * xo.grad.abs().max()
 
 
 def test_edsr_full_size_forward_vs_reference_golden():

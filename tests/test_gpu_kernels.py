@@ -100,8 +100,12 @@ def test_gemm_nt_prologues_epilogues(ops):
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 16, 180, 180), (1, 24, 40, 60, 60),
                                          (1, 20, 12, 64, 64), (1, 16, 16, 64, 256),
                                          (2, 64, 64, 180, 64), (1, 9, 7, 16, 16),
-                                         (8, 64, 64, 180, 180)])
+                                         (8, 64, 64, 180, 180), (8, 128, 128, 64, 64),
+                                         (8, 128, 128, 64, 256), (1, 512, 512, 64, 64)])
 def test_conv3x3_fwd_bwd(ops, B, H, W, Ci, Co):
+    """forward, data gradient and weight gradient at every size, the EDSR training shapes included
+    (8x128^2 and 512^2 at 64 features: the weight gradient there runs the bf16x3 slice plans --
+    three blocks per CU for 64-wide tiles -- that the small cases never reach)."""
     x = rnd(B, Ci, H, W)
     w = rnd(Co, Ci, 3, 3, scale=0.05)
     b = rnd(Co)
@@ -113,8 +117,6 @@ def test_conv3x3_fwd_bwd(ops, B, H, W, Ci, Co):
     y = ops.conv3x3(xh, wp, dev(b), Co)
     ref = F.conv2d(x, w, b, padding=1)
     check(y.permute(0, 3, 1, 2), ref, 2e-5, "conv fwd")
-    if B * H * W > 20000:
-        return
     # data gradient through the flipped/transposed pack
     dy = rnd(B, Co, H, W)
     dyh = dev(dy.permute(0, 2, 3, 1))

@@ -11,6 +11,9 @@ pytestmark = pytest.mark.gpu
 import sr_oracle as O  # noqa: E402
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# parameter / input gradients relative to the tensor's largest entry: <= 10x the margins measured on
+# the MI355X (2.2e-6 on the README configuration, 9e-7 on the tiny net)
+GRAD_GATE = 2e-5
 
 
 def load(name):
@@ -70,13 +73,13 @@ def test_tiny_forward_backward_vs_reference_golden(SwinIR):
     x = g["x"].cuda().requires_grad_(True)
     yt = net(x)
     (yt - g["target"].cuda()).abs().mean().backward()
-    assert (x.grad.cpu() - g["dx"]).abs().max() <= 2e-4 * g["dx"].abs().max()
+    assert (x.grad.cpu() - g["dx"]).abs().max() <= GRAD_GATE * g["dx"].abs().max()
     worst = 0.0
     for k, p in net.named_parameters():
         ref = g["grad/" + k]
         e = (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
         worst = max(worst, e)
-        assert e <= 2e-3, f"grad {k}: rel err {e:.2e}"
+        assert e <= GRAD_GATE, f"grad {k}: rel err {e:.2e}"
     print("worst param-grad rel err", worst)
 
 
@@ -139,4 +142,4 @@ def test_readme_config_train_step_grads_vs_oracle(SwinIR):
         if e > worst[1]:
             worst = (k, e)
     print("worst grad", worst)
-    assert worst[1] <= 5e-3, worst
+    assert worst[1] <= GRAD_GATE, worst
