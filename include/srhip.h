@@ -194,8 +194,8 @@ int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, con
  *   biasT (fwd, bwd query pass): bias[query = col+32b][key = row+32a]
  *   biasN (bwd key pass)       : bias[query = row+32a][key = col+32b]
  * The bias-gradient image (dbiasT of srhip_window_attention_bwd, input of
- * srhip_bias_grad) is biasT's tile set stored [h][a][b][q][lane] (atomics want
- * consecutive lanes on consecutive addresses).  Opaque to callers: produce with this
+ * srhip_bias_grad) is biasT's tile set stored [h][a][b][q][lane] (one wave instruction
+ * touches 256 contiguous bytes).  Opaque to callers: produce with this
  * function (or a kind-2 job of srhip_prep_table), hand to the attention calls. */
 int srhip_bias_expand(const float* table, float* biasT, float* biasN, int heads, void* stream);
 int srhip_bias_grad(const float* dbiasT, float* dtable, int heads, void* stream);
@@ -207,7 +207,9 @@ int srhip_bias_grad_batched(const float* dbiasT, long image_stride, float* const
  * roll, window partition/reverse and the shift mask are address math. */
 int srhip_window_attention_fwd(const float* qkv, float* out, const float* biasT, int B, int H, int W,
                                int C, int heads, int shift, void* stream);
-/* dbiasT must be zero on entry; workspace floats: srhip_window_attention_bwd_ws(). */
+/* dbiasT (may be NULL) is OVERWRITTEN with the bias-gradient image: the query pass stores one
+ * partial tile set per block into the workspace (no atomics), tail blocks of the key pass sum
+ * them in fp64 -- deterministic.  workspace floats: srhip_window_attention_bwd_ws(). */
 long srhip_window_attention_bwd_ws(int B, int H, int W, int heads);
 int srhip_window_attention_bwd(const float* qkv, const float* dout, float* dqkv, const float* biasT,
                                const float* biasN, float* dbiasT, float* workspace, int B, int H, int W,

@@ -385,6 +385,138 @@ def g_trained_like():
     npz("g18_trained_like", **arrs)
 
 
+# ---------------------------------------------------------------- G19 eval.py experiment folder
+def g_eval_fixture():
+    """A reference-format experiment directory + dataset + folds, and what the REFERENCE's own
+    evaluation code writes for it: tests/golden/eval_exp/
+        exp/config_model.yml            yaml dump of the reference's get_config() args (utils_parser.py:1397-1401)
+        exp/best-models/G-model.pth     raw state_dict (model_base.py:173-181)
+        data/caco2/...                  three 8-bit single-channel TIFF pairs (HR 128x136, LR 16x17, x8)
+        folds/<ds>/{l_h,h_l}.txt        utils_dataloaders.py:27-53 format
+        expected/...                    details_*.yml, roi_details_*.yml, <ds>.yaml, roi-<ds>.yaml, tracker.pkl,
+                                        roi_tracker.pkl written by the reference's evaluate_single_ds /
+                                        save_tracker (utils_trainer.py:1102-1181, utils_tracker.py:336) run on
+                                        the CPU with the reference SwinIR behind a ModelPlain-protocol adapter
+                                        (the reference's ModelPlain itself needs CUDA), for the model and for
+                                        the bicubic baseline row.
+    tests/test_gpu_eval.py runs sr-caco-2_amd/eval.py on the same folder and compares file by file."""
+    print("G19 eval.py fixture")
+    import shutil
+    import yaml
+    from PIL import Image
+    import matplotlib.style
+    matplotlib.style.use = lambda *a, **k: None          # utils_tracker.py:25 asks for a style mpl 3.10 dropped
+    from dlib.utils import utils_trainer as ref_tr
+    from dlib.utils import utils_tracker as ref_tk
+    from dlib.utils import utils_config as ref_cfg
+    from dlib.utils.utils_init_default_args import init_net_g as ref_init_net_g
+    import dlib.dllogger as ref_log
+    ref_log.init_arb(backends=[], is_master=True, reset=True)
+
+    base = os.path.join(OUT, "eval_exp")
+    shutil.rmtree(base, ignore_errors=True)
+    ds = ref_c.CACO2_TEST_X8_IN_64_OUT_512_CELL_CELL0
+    exp, data, folds = (os.path.join(base, d) for d in ("exp", "data", "folds"))
+    os.makedirs(os.path.join(exp, "best-models"))
+    os.makedirs(os.path.join(data, ref_c.DS_DIR[ds], "t"))
+    os.makedirs(os.path.join(folds, ds))
+
+    # ---- data: smooth-ish random tiles so that the ROI thresholds 4..10 select real regions
+    rng = np.random.RandomState(5)
+    l_h, h_l = [], []
+    for i in range(3):
+        hr = rng.rand(128 // 8 + 2, 136 // 8 + 2)
+        hr = np.kron(hr, np.ones((8, 8)))[:128, :136] * 40 * (i + 1) / 3 + rng.rand(128, 136) * 6
+        hr = np.clip(np.round(hr), 0, 255).astype(np.uint8)
+        lr = np.clip(np.round(hr.reshape(16, 8, 17, 8).mean(axis=(1, 3)) + rng.randn(16, 17)), 0, 255).astype(np.uint8)
+        kh, kl = f"t/h_{i}.tif", f"t/l_{i}.tif"
+        Image.fromarray(hr).save(os.path.join(data, ref_c.DS_DIR[ds], kh))
+        Image.fromarray(lr).save(os.path.join(data, ref_c.DS_DIR[ds], kl))
+        l_h.append(f"{kl},{kh}")
+        h_l.append(f"{kh},{kl}")
+    open(os.path.join(folds, ds, "l_h.txt"), "w").write("\n".join(l_h) + "\n")
+    open(os.path.join(folds, ds, "h_l.txt"), "w").write("\n".join(h_l) + "\n")
+
+    # ---- config_model.yml from the reference's own defaults
+    args = ref_cfg.get_config(ref_c.SWINIR)
+    args.update(scale=8, n_channels=1, h_size=128, eval_bsize=2, test_dsets=ds, valid_dsets=ds.replace("test", "val"),
+                train_dsets=ds.replace("test", "train"), splits_root="folds", eval_over_roi_also=True,
+                eval_over_roi_also_model_select=False, multi_valid=False, myseed=0, amp=False)
+    args["netG"] = ref_init_net_g(args["netG"], args)
+    nt = "swinir"
+    args["netG"].update({f"{nt}_depths": [2, 2], f"{nt}_embed_dim": 60, f"{nt}_num_heads": [6, 6],
+                         f"{nt}_upsampler": ref_c.US_PIXEL_SHUFFLE_DIRECT, f"{nt}_mlp_ratio": 2})
+    with open(os.path.join(exp, "config_model.yml"), "w") as f:
+        yaml.dump(args, f)
+
+    # ---- weights (trained-like regime) in the reference's checkpoint format
+    from dlib.models.select_network import define_G as ref_define_G
+    A = type("A", (), {})
+    a = A()
+    a.is_train = False
+    a.netG = args["netG"]
+    net = ref_define_G(a)
+    cfg = tiny_cfg()
+    sd = O.trained_like_(O.swinir_init_state_dict(cfg, seed=41), 410, lin_scale=5.0, qk_scale=2.0)
+    net.load_state_dict(sd, strict=True)
+    torch.save(net.eval().state_dict(), os.path.join(exp, "best-models", "G-model.pth"))
+
+    # ---- the reference's evaluation on the CPU
+    class Adapter:     # ModelPlain's protocol as fast_eval / _forward_with_padding consume it
+        def __init__(self, net):
+            self.netG, self.L, self.E, self.H = net, None, None, None
+        def feed_data(self, data, need_H=True):
+            self.L, self.H = data["l_im"], data["h_im"]
+        def test(self):
+            with torch.no_grad():
+                self.E = self.netG(self.L)
+        def set_eval_mode(self):
+            self.netG.eval()
+        def set_train_mode(self):
+            pass
+        def current_visuals(self, need_H=True):
+            return {"L": self.L.float(), "E": self.E.float(), "H": self.H.float()}
+
+    class RefInterp(ref_tr.Interpolate):      # the class proper wants CUDA in __init__ (utils_trainer.py:93)
+        def __init__(self, task, scale, scale_mode):
+            nn.Module.__init__(self)
+            self.device, self.scale, self.task, self.scale_mode = torch.device("cpu"), scale, task, scale_mode
+            self.L = self.E = self.H = None
+
+    def read(p):
+        a8 = np.asarray(Image.open(p), dtype=np.uint8)[:, :, None]
+        return ref_ui.single2tensor3(ref_ui.uint2single(a8))
+    items = [{"l_im": read(os.path.join(data, ref_c.DS_DIR[ds], f"t/l_{i}.tif")), "h_im": read(os.path.join(data, ref_c.DS_DIR[ds], f"t/h_{i}.tif")),
+              "h_id": f"t/h_{i}.tif", "l_id": f"t/l_{i}.tif"} for i in range(3)]
+    loader = [{"l_im": torch.stack([it["l_im"] for it in items[:2]]), "h_im": torch.stack([it["h_im"] for it in items[:2]]),
+               "h_id": [it["h_id"] for it in items[:2]], "l_id": [it["l_id"] for it in items[:2]]},
+              {"l_im": items[2]["l_im"][None], "h_im": items[2]["h_im"][None], "h_id": [items[2]["h_id"]],
+               "l_id": [items[2]["l_id"]]}]
+    from dlib.utils.tools import Dict2Obj as RefDict2Obj
+    ra = RefDict2Obj(args)
+    expd = os.path.join(base, "expected")
+    os.makedirs(expd)
+    ra.outd, ra.outd_backup, ra.is_master, ra.distributed = expd, expd, True, False
+    tracker, roi_tracker = ref_tk.init_tracker(ra), ref_tk.init_tracker(ra)
+    _cuda_empty, _imsave = torch.cuda.empty_cache, ref_ui.cv2_imsave_rgb_in
+    torch.cuda.empty_cache = lambda: None
+    ref_ui.cv2_imsave_rgb_in = lambda img, path: None      # cv2 is a stub here; predictions are not part of the fixture
+    try:
+        for model, name in ((Adapter(net), ds), (RefInterp(ra.task, ra.scale, ra.basic_interpolation),
+                                                  f"{ds}_{ra.basic_interpolation}")):
+            tracker, roi_tracker = ref_tr.evaluate_single_ds(
+                args=ra, model=model, loader=loader, ds_name=name, tracker=tracker, roi_tracker=roi_tracker,
+                current_step=-1, epoch=-1, split=ref_c.TESTSET, nbr_to_plot=0)
+    finally:
+        torch.cuda.empty_cache, ref_ui.cv2_imsave_rgb_in = _cuda_empty, _imsave
+    ref_tk.save_tracker(expd, tracker=tracker, roi_tracker=roi_tracker)
+    shutil.rmtree(os.path.join(expd, ra.save_dir_imgs), ignore_errors=True)
+    for f in sorted(os.listdir(os.path.join(expd, "best-models"))):
+        print("   expected/best-models/" + f)
+    print("   test means:", {m: round(tracker[ref_c.TESTSET][ds][m]["vals"][-1], 4)
+                             for m in (ref_c.PSNR_MTR, ref_c.SSIM_MTR, ref_c.NRMSE_MTR)})
+
+
 # ---------------------------------------------------------------- G4 README config
 def g_swinir_readme():
     print("G4 SwinIR README-config forward (seeded weights, output only)")
@@ -901,7 +1033,7 @@ def g_optim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
-            g_metrics, g_optim, g_trained_like]
+            g_metrics, g_optim, g_trained_like, g_eval_fixture]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:
         if not only or g.__name__ in only:

@@ -241,11 +241,12 @@ constexpr int WA_NW = 2;   // windows per bwd_q wave
 template <int D>
 __global__ void __launch_bounds__(256, 3) k_wattn_bwd_q(
     const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
-    const float* __restrict__ biasT, float* __restrict__ dbiasT, float* __restrict__ stats, int nwin,
+    const float* __restrict__ biasT, float* __restrict__ dbias_part, float* __restrict__ stats, int nwin,
     int H, int W, int C, int heads, int shift, float scale, int remap) {
   constexpr int HD = D / 2;
   static_assert(D <= 32, "head dim");
-  __shared__ __attribute__((aligned(16))) float smem[4 * (64 + 32) * D];
+  constexpr int SM = 4 * (64 + 32) * D > 4096 ? 4 * (64 + 32) * D : 4096;   // >= two d(bias) tile pairs
+  __shared__ __attribute__((aligned(16))) float smem[SM];
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
   float* As = smem + wv * ((64 + 32) * D);     // full matrix: K, V, K again
   float* Bs = As + 64 * D;                     // half matrix: Q, dO rows of this query block
@@ -254,17 +255,15 @@ __global__ void __launch_bounds__(256, 3) k_wattn_bwd_q(
   const int item = (lb / heads) * 4 + wv;
   const int qb = item & 1;
   // WA_NW consecutive windows per wave, one after the other: their d(bias) tiles are
-  // summed in registers first (half the float atomics: 15 % of this kernel went there)
+  // summed in registers first
   f32x16 dsacc[2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int q = 0; q < 16; ++q) dsacc[a][q] = 0.f;
-  bool any = false;
   for (int rep = 0; rep < WA_NW; ++rep) {
   const int widx = (item >> 1) * WA_NW + rep;
   if (widx < nwin) {
-    any = true;
     __builtin_amdgcn_wave_barrier();
     const int nWx = W / 8, nWy = H / 8;
     WaGeom g;
@@ -371,14 +370,29 @@ __global__ void __launch_bounds__(256, 3) k_wattn_bwd_q(
     }
   }
   }
-  // bias gradient: fire-and-forget global float atomics, 256 contiguous bytes per wave
-  // instruction
-  if (dbiasT && any) {
-    float* dbt = dbiasT + (long)head * 4096;
+  // bias gradient: NO atomics.  The block's two window groups (waves wv and wv + 2 own the same
+  // query block) meet in LDS and the block stores ONE partial d(bias) tile pair per query block --
+  // plain 256-byte-per-instruction stores into part[block-in-head][head][4096] -- which the tail
+  // blocks of the key pass sum in fp64 (k_wattn_bwd_kv).  Deterministic, and the sum over all
+  // windows no longer depends on the arrival order of 12.6 M float atomics per launch
+  // (MI355X_MICROARCH.md "Global float atomics": 1.3 TB/s chip-wide, 5x below plain stores).
+  if (dbias_part) {
+    __syncthreads();                                   // every wave is done with its staging region
+    if (wv >= 2) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) atomicAdd(dbt + wa_dimg_index(kb, qb, lane, q), dsacc[kb][q]);
+        for (int q = 0; q < 16; ++q) smem[(wv - 2) * 2048 + (kb * 16 + q) * 64 + lane] = dsacc[kb][q];
+    }
+    __syncthreads();
+    if (wv < 2) {
+      float* dst = dbias_part + ((long)(lb / heads) * heads + head) * 4096;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          dst[wa_dimg_index(kb, qb, lane, q)] = dsacc[kb][q] + smem[wv * 2048 + (kb * 16 + q) * 64 + lane];
+    }
   }
 }
 
@@ -386,11 +400,24 @@ template <int D>
 __global__ void __launch_bounds__(256, 3) k_wattn_bwd_kv(
     const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
     const float* __restrict__ biasN, const float* __restrict__ stats, long total, int H, int W, int C,
-    int heads, int shift, float scale, int remap) {
+    int heads, int shift, float scale, int remap, int nmain, const float* __restrict__ dbias_part,
+    int nparts, float* __restrict__ dbiasT) {
   constexpr int HD = D / 2;
   __shared__ __attribute__((aligned(16))) float smem[4 * ((64 + 32) * D + 192)];
+  if ((int)blockIdx.x >= nmain) {
+    // tail blocks: d(bias) image = sum of the query pass's partial tiles (complete: that launch
+    // precedes this one on the stream), one thread per image element, fp64 accumulation
+    const int e = ((int)blockIdx.x - nmain) * 256 + (int)threadIdx.x;
+    const int img = heads * 4096;
+    if (e < img) {
+      double a = 0.0;
+      for (int p = 0; p < nparts; ++p) a += (double)dbias_part[(long)p * img + e];
+      dbiasT[e] = (float)a;
+    }
+    return;
+  }
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-  const long item = wa_block(remap) * 4L + wv;       // (window, head) x key block
+  const long item = (remap ? sr_xcd_block(blockIdx.x, nmain) : (int)blockIdx.x) * 4L + wv;       // (window, head) x key block
   if (item >= 2 * total) return;                // no block-level barrier below
   const int kb = (int)(item & 1);
   const WaGeom g = wa_decode(item >> 1, heads, W / 8, H / 8, shift);
@@ -518,8 +545,8 @@ __global__ void k_bias_grad(const float* __restrict__ dbiasT, float* __restrict_
     const int h = (rowin >> 2) & 1, q = (rowin & 3) + 4 * (rowin >> 3);     // mfma_row(q, 32h + c) == rowin
     a = dbiasT[(long)hd * 4096 + wa_dimg_index(kb, qb, (query & 31) + 32 * h, q)];
   }
-  a = wave_sum(a);
-  if (lane == 0) dtable[i] = a;
+  const double ad = wave_sum_d((double)a);
+  if (lane == 0) dtable[i] = (float)ad;
 }
 
 }  // namespace
@@ -592,12 +619,17 @@ int srhip_window_attention_fwd(const float* qkv, float* out, const float* biasT,
   return 0;
 }
 
-// dbiasT must be zero on entry (accumulated with atomics).
-long srhip_window_attention_bwd_ws(int B, int H, int W, int heads) {
-  return 3L * B * H * W * heads;   // floats: softmax max, 1/sum, delta per (token, head)
+static int wa_bwd_q_parts(int nwin) {     // query-pass blocks per head = partial d(bias) tile sets per head
+  return sr_cdiv(2 * sr_cdiv(nwin, WA_NW), 4);
 }
 
-// dbiasT must be zero on entry (accumulated with atomics).
+long srhip_window_attention_bwd_ws(int B, int H, int W, int heads) {
+  // floats: softmax max, 1/sum, delta per (token, head) + the query pass's partial d(bias) tiles
+  const int nwin = B * (H / 8) * (W / 8);
+  return 3L * B * H * W * heads + (long)wa_bwd_q_parts(nwin) * heads * 4096;
+}
+
+// dbiasT (may be NULL) is overwritten with the bias-gradient image.
 int srhip_window_attention_bwd(const float* qkv, const float* dout, float* dqkv, const float* biasT,
                                const float* biasN, float* dbiasT, float* workspace, int B, int H, int W,
                                int C, int heads, int shift, void* stream) {
@@ -610,12 +642,14 @@ int srhip_window_attention_bwd(const float* qkv, const float* dout, float* dqkv,
   const float scale = 1.0f / sqrtf((float)D);
   hipStream_t st = (hipStream_t)stream;
   // half a (window, head) per wave; bwd_q waves take WA_NW windows each
-  dim3 blk(256), gq(heads * sr_cdiv(2 * sr_cdiv(nwin, WA_NW), 4)), gkv(sr_cdiv(2 * total, 4));
-  if (getenv("SRHIP_WA_NOATOMIC")) dbiasT = nullptr;   // timing experiment only (bias gradient is lost)
+  const int nparts = wa_bwd_q_parts(nwin), nmain = sr_cdiv(2 * total, 4);
+  const int ntail = dbiasT ? sr_cdiv(heads * 4096, 256) : 0;
+  dim3 blk(256), gq(heads * nparts), gkv(nmain + ntail);
+  float* part = dbiasT ? workspace + 3L * B * H * W * heads : nullptr;
 #define SR_WA(D_) \
   if (D == D_) { \
-    hipLaunchKernelGGL((k_wattn_bwd_q<D_>), gq, blk, 0, st, qkv, dout, dqkv, biasT, dbiasT, workspace, nwin, H, W, C, heads, shift, scale, wa_remap()); \
-    hipLaunchKernelGGL((k_wattn_bwd_kv<D_>), gkv, blk, 0, st, qkv, dout, dqkv, biasN, workspace, total, H, W, C, heads, shift, scale, wa_remap()); \
+    hipLaunchKernelGGL((k_wattn_bwd_q<D_>), gq, blk, 0, st, qkv, dout, dqkv, biasT, part, workspace, nwin, H, W, C, heads, shift, scale, wa_remap()); \
+    hipLaunchKernelGGL((k_wattn_bwd_kv<D_>), gkv, blk, 0, st, qkv, dout, dqkv, biasN, workspace, total, H, W, C, heads, shift, scale, wa_remap(), nmain, part, nparts, dbiasT); \
   }
   SR_WA(30) SR_WA(10) SR_WA(16) SR_WA(32)
 #undef SR_WA

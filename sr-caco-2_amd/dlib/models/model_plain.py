@@ -29,7 +29,7 @@ from srhip.train import TrainStep, Optimizer
 class ModelPlain:
     def __init__(self, args):
         self.args = args
-        self.opt_train = args.train
+        self.opt_train = args.train if getattr(args, 'train', None) is not None else {}
         self.is_train = getattr(args, 'is_train', True)
         self.save_dir = getattr(args, 'outd', '.')
         dev_id = torch.cuda.current_device() if torch.cuda.is_available() else None
@@ -60,9 +60,16 @@ class ModelPlain:
         self.log_dict = OrderedDict()
 
     def load(self):
-        path = self.opt_train.get('pretrained_netG', None) if hasattr(self.opt_train, 'get') else None
-        if path:
-            self.load_network(path, self.netG, strict=True)
+        """model_plain.py:68-73: weights from args.netG['checkpoint_path_netG'] if that file exists
+        (eval.py points it at best-models/G-model.pth); 'pretrained_netG' in the train options is
+        accepted as well."""
+        netg = self.args.netG if hasattr(self.args, 'netG') else {}
+        path = netg.get('checkpoint_path_netG', None) if hasattr(netg, 'get') else None
+        if not path and hasattr(self.opt_train, 'get'):
+            path = self.opt_train.get('pretrained_netG', None)
+        if path and os.path.isfile(path):
+            strict = self.opt_train.get('G_param_strict', True) if hasattr(self.opt_train, 'get') else True
+            self.load_network(path, self.netG, strict=strict, param_key='params')
 
     # ---------------------------------------------------------------- data
     def feed_data(self, data, need_H=True):

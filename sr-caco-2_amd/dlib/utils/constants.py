@@ -29,8 +29,18 @@ SSIM_MTR = 'ssim'
 MSE_MTR = 'mse'
 NRMSE_MTR = 'nrmse'
 PSNR_Y_MTR = 'psnr_y'
-METRICS = [PSNR_MTR, SSIM_MTR, MSE_MTR, NRMSE_MTR, PSNR_Y_MTR]
-BEST_MTR = {PSNR_MTR: max, SSIM_MTR: max, MSE_MTR: min, NRMSE_MTR: min, PSNR_Y_MTR: max}
+SSIM_Y_MTR = 'ssim_y'      # listed by the reference (constants.py:118-131), never computed by its evaluation
+METRICS = [PSNR_MTR, SSIM_MTR, MSE_MTR, NRMSE_MTR, PSNR_Y_MTR, SSIM_Y_MTR]
+BEST_MTR = {PSNR_MTR: max, SSIM_MTR: max, MSE_MTR: min, NRMSE_MTR: min, PSNR_Y_MTR: max, SSIM_Y_MTR: max}
+
+# splits, tracker periods, fold files (reference constants.py:100-136,193,713)
+TRAIN_PHASE, EVAL_PHASE = 'train', 'eval'
+TRAINSET, VALIDSET, TESTSET = 'train', 'val', 'test'
+SPLITS = [TRAINSET, VALIDSET, TESTSET]
+PR_EPOCH, PR_ITER = 'period_epoch', 'period_iter'
+PERIODS = [PR_ITER, PR_EPOCH]
+SEP = '+'
+CODE_IDENTIFIER = 'CODEXXXXXXXIDENTIFIER'
 
 SGD = 'sgd'
 ADAM = 'adam'

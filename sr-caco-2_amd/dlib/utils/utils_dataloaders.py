@@ -73,3 +73,142 @@ def train_sampler(n_samples, world, rank, seed):
 def eval_sampler(n_samples, world, rank):
     """The reference's evaluation sampler (DistributedSampler(shuffle=False), default drop_last=False)."""
     return ShardedSampler(n_samples, world, rank, shuffle=False, drop_last=False)
+
+
+# ----------------------------------------------------------------------------------------------
+# Evaluation sets from the reference's fold files (dlib/utils/utils_dataloaders.py:27-53,196-304,
+# dlib/datasets/dataset_dpsr.py:746-757,826-838,930-947,981-1005).
+# ----------------------------------------------------------------------------------------------
+import os
+from os.path import join
+
+import numpy as np
+
+from dlib.utils import constants
+
+
+def get_pairs(path_file: str) -> dict:
+    """l_h.txt / h_l.txt: one '<key_1>,<key_2>' per line, keys = paths relative to the dataset
+    directory (unique ids), in file order."""
+    assert os.path.isfile(path_file), path_file
+    pairs = {}
+    with open(path_file, 'r') as f:
+        for line in f.readlines():
+            a, b = line.strip('\n').split(',')
+            assert a not in pairs, a
+            pairs[a] = b
+    return pairs
+
+
+def dataset_dir(ds_name: str) -> str:
+    """constants.DS_DIR of the reference (constants.py:472-520): every CACO2 set lives under
+    'caco2', every BioSR set under 'biosr'."""
+    low = ds_name.lower()
+    if low.startswith('caco2'):
+        return 'caco2'
+    if low.startswith('biosr'):
+        return 'biosr'
+    raise ValueError(f'unknown dataset {ds_name!r}')
+
+
+def imread_gray_uint8(path: str) -> np.ndarray:
+    """cv2.imread(path, 0) of utils_image.py:237-243 for the 8-bit single-channel TIFF / PNG tiles of
+    the SR-CACO-2 folds: HxWx1 uint8.  (PIL: cv2 is not part of this build.)"""
+    from PIL import Image
+    with Image.open(path) as im:
+        if im.mode not in ('L', 'P', '1'):
+            if im.mode in ('I;16', 'I', 'F'):
+                raise NotImplementedError(f'{path}: {im.mode} image; the reference reads 8-bit tiles')
+            im = im.convert('L')      # cv2 IMREAD_GRAYSCALE semantics for colour files (not used by the folds)
+        a = np.asarray(im, dtype=np.uint8)
+    return a[:, :, None]
+
+
+class EvalPairs:
+    """EVAL-phase items of DatasetDPSR for sets that ship true low-resolution tiles: per index the
+    dict the evaluation loop consumes (dataset_dpsr.py:981-1005) with l_im / h_im float32 CHW in
+    [0,1] = uint8 / 255 (utils_image.py:322-323,381-382).  The cv2-bicubic 'l_to_h_img' tensors
+    (consumed by SRCNN-style nets only, model_plain.py:184-195) are not produced."""
+
+    def __init__(self, args, pairs_h: dict, pairs_l: dict):
+        self.args, self.pairs_h, self.pairs_l = args, pairs_h, pairs_l
+        self.im_h_ids = list(pairs_h.keys())
+        self.sf = args.scale
+        # ids <-> floats (dataset_dpsr.py:583-590): per-image details travel through all_gather as floats
+        self.im_h_ids_to_float = {k: float(i) for i, k in enumerate(self.im_h_ids)}
+        self.float_to_im_h_ids = {v: k for k, v in self.im_h_ids_to_float.items()}
+
+    def __len__(self):
+        return len(self.im_h_ids)
+
+    def __getitem__(self, index: int) -> dict:
+        import torch
+        h_id = self.im_h_ids[index]
+        l_id = self.pairs_h[h_id]['low_path_key']
+        h_path = self.pairs_h[h_id]['abs_path']
+        l_path = self.pairs_l[l_id]['abs_path']
+        if l_id.startswith('None_') or not os.path.isfile(l_path):
+            raise NotImplementedError(f'{l_id}: synthesised low-resolution inputs (dataset_dpsr.py:713-744, '
+                                      f'cv2 / skimage) are outside this build; ship true LR tiles')
+        img_h = imread_gray_uint8(h_path)
+        hh, ww = img_h.shape[:2]
+        img_h = img_h[:hh - hh % self.sf, :ww - ww % self.sf]            # modcrop (utils_image.py:295-306)
+        img_l = imread_gray_uint8(l_path)
+        to_t = lambda a: torch.from_numpy(np.ascontiguousarray(np.float32(a / 255.))).permute(2, 0, 1).float()
+        return {'l_im': to_t(img_l), 'l_id': l_id, 'l_path': l_path, 'h_im': to_t(img_h), 'h_id': h_id,
+                'h_path': h_path}
+
+
+class EvalLoader:
+    """DataLoader(eval_set, batch_size=eval_bsize, shuffle=False, drop_last=False[, sampler]) without
+    worker processes: batches of stacked tensors + lists of ids (utils_dataloaders.py:262-285)."""
+
+    def __init__(self, dataset, batch_size: int, sampler=None):
+        self.dataset, self.batch_size, self.sampler = dataset, int(batch_size), sampler
+
+    def _indices(self):
+        return list(self.sampler) if self.sampler is not None else list(range(len(self.dataset)))
+
+    def __len__(self):
+        n = len(self._indices())
+        return (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        import torch
+        idx = self._indices()
+        for i in range(0, len(idx), self.batch_size):
+            items = [self.dataset[j] for j in idx[i:i + self.batch_size]]
+            out = {}
+            for k in items[0]:
+                vals = [it[k] for it in items]
+                out[k] = torch.stack(vals) if torch.is_tensor(vals[0]) else vals
+            yield out
+
+
+def get_eval_loader(args, ds_name: str, n: int = -1):
+    assert isinstance(n, int) and (n == -1 or n > 0), n
+    assert f'X_{args.scale}' in ds_name or f'X-{args.scale}' in ds_name, (ds_name, args.scale)
+    fold = join(args.splits_root, ds_name)
+    pairs_l_h = get_pairs(join(fold, 'l_h.txt'))
+    pairs_h_l = get_pairs(join(fold, 'h_l.txt'))
+    if n != -1:
+        keep = list(pairs_l_h.keys())[:n]
+        pairs_l_h = {k: pairs_l_h[k] for k in keep}
+        pairs_h_l = {k: v for k, v in pairs_h_l.items() if v in keep}
+    base = join(args.data_root, dataset_dir(ds_name))
+    strip = lambda k: k.split(constants.CODE_IDENTIFIER)[0]
+    pairs_h = {k: {'low_path_key': v, 'abs_path': join(base, strip(k))} for k, v in pairs_h_l.items()}
+    pairs_l = {k: {'high_path_key': v, 'abs_path': k if k.startswith('None_') else join(base, strip(k))}
+               for k, v in pairs_l_h.items()}
+    ds = EvalPairs(args, pairs_h, pairs_l)
+    sampler = None
+    if getattr(args, 'distributed', False) and args.eval_bsize > 1:
+        import torch.distributed as dist
+        sampler = eval_sampler(len(ds), dist.get_world_size(), dist.get_rank())
+    return EvalLoader(ds, args.eval_bsize, sampler)
+
+
+def get_all_eval_loaders(args, ds_names: str, n: int = -1) -> dict:
+    names = [x for x in ds_names.split(constants.SEP) if x != '']
+    assert names, f'no eval sets in: {ds_names}'
+    return {ds: get_eval_loader(args, ds, n) for ds in names}

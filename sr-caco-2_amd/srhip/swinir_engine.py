@@ -284,9 +284,8 @@ class SwinIREngine:
         gh = buf("gh", T, hid)        # gelu(h): by-product of the dgelu epilogue, operand of the fc2 weight gradient
         dqkv = buf("dqkv", T, 3 * C)
         bi = len(self.blocks)
-        # bias-gradient images of all blocks (accumulated with atomics): ONE memset per step
+        # bias-gradient images of all blocks (each overwritten by its attention backward: no memset)
         dbT_all = buf("dbiasT_all", len(self.blocks), max(b.num_heads for b in self.blocks), 64, 64)
-        dbT_all.zero_()
         for li in reversed(range(len(net.layers))):
             layer = net.layers[li]
             t_in, t_blocks = sv["layers"][li]

@@ -284,7 +284,7 @@ def test_window_attention(ops, B, H, W, C, heads, shift):
     check(out, ref, 1e-5, "attention fwd")
     ref.backward(dout)
     dqkv = torch.empty(T, 3 * C).cuda()
-    dbiasT = torch.zeros(heads, 64, 64).cuda()
+    dbiasT = torch.full((heads, 64, 64), 123.0).cuda()      # overwritten, not accumulated into
     ops.window_attention_bwd(dev(qkv), dev(dout), dqkv, biasT, biasN, dbiasT, B, H, W, C, heads, shift)
     check(dqkv[:, :C], qr.grad[:, :C], 2e-5, "attention dq")
     check(dqkv[:, C:2 * C], qr.grad[:, C:2 * C], 2e-5, "attention dk")
