@@ -325,6 +325,18 @@ int srhip_metrics_ssim(const float* E, const float* Hh, int B, int H, int W, int
                        const int* thresholds_dev, int nth, int inputs_are_u8, double* workspace,
                        float* out, void* stream);
 
+/* Weight (and bias) gradients of up to 40 3x3 convolutions of ONE shape -- the body of an
+ * EDSR-style stack (network_nlsn.py:72-93,325-345 backward) -- in one contraction launch plus one
+ * reducer launch: item k: dW_k[Cout][Cin][3][3] = sum_px dY_k (x) shifted X_k, db_k = sum_px dY_k.
+ * items is a HOST array; part / part_colsum hold n * part_floats_per_item and n * S * Cout floats
+ * (srhip_conv3x3_wgrad_batched_plan).  bf16x3 split MFMA (f32-accurate). */
+typedef struct { const float* dY; const float* X; float* dW; float* db; } srhip_conv_wgrad_item;
+int srhip_conv3x3_wgrad_batched_plan(int n, int B, int H, int W, int Cout, int Cin, int* S,
+                                     long* part_floats_per_item);
+int srhip_conv3x3_wgrad_batched_bx3(const srhip_conv_wgrad_item* items, int n, long lddy, long ldx, int B, int H,
+                                    int W, int Cout, int Cin, float* part, float* part_colsum, int S,
+                                    void* stream);
+
 /* ---- optimizers (dlib/utils/utils_instance.py:216-247) on flat buffers -------
  * g is multiplied by gscale first (1/world_size after a sum all-reduce).  If
  * skip_flag != NULL and *skip_flag != 0 the update is skipped on the device

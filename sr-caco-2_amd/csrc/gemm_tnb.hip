@@ -414,6 +414,31 @@ __global__ void __launch_bounds__(512, 1) k_tnb_grouped(TnbGroup g) {
   else tnb_body<W, DBG>(g.p[3], blockIdx.x, t - g.tile_start[3], 0, smem);
 }
 
+// Up to TNB_BATCH_MAX conv weight-gradient problems of ONE shape (same image geometry and channel
+// counts: the body convs of an EDSR-style net) in one launch.  A single 64 -> 64 problem at 32768
+// pixels is 2.4 GFLOP: alone it needs ~85 reduce slices to fill the chip (13 chunks per block, a
+// 12.5 MB partial buffer and a 24 us reducer per layer); 33 of them together run 2-3 slices of
+// 340+ chunks each.
+constexpr int TNB_BATCH_MAX = 40;
+struct TnbConvBatch {
+  TnArgs base;
+  const float* A[TNB_BATCH_MAX];
+  const float* B[TNB_BATCH_MAX];
+  long part_stride, colsum_stride;     // floats between consecutive problems' partial buffers
+  int n, tiles;
+};
+template <int W>
+__global__ void __launch_bounds__(512, 1) k_tnb_conv_batched(TnbConvBatch g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int k = blockIdx.y / g.tiles, tile = blockIdx.y - k * g.tiles;
+  TnArgs p = g.base;
+  p.A = g.A[k];
+  p.B = g.B[k];
+  p.part = g.base.part + (long)k * g.part_stride;
+  p.part_colsum = g.base.part_colsum ? g.base.part_colsum + (long)k * g.colsum_stride : nullptr;
+  tnb_body<W>(p, blockIdx.x, tile, blockIdx.z, smem);
+}
+
 int pick_tile(int n, int* w) {
   if (n % 180 == 0) { *w = 3; return 180; }
   if (n <= 64) { *w = 1; return 64; }
@@ -512,6 +537,63 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
   SR_TNB(1) SR_TNB(2) SR_TNB(3)
 #undef SR_TNB
   SR_LAUNCH_CHECK("k_tnb");
+  return 0;
+}
+
+int sr_conv_wgrad_batched_plan(int n, int M, int NI, int NJ, int* S, long* part_floats_per_item) {
+  int tile;
+  const int w = pick_w(NI, NJ, &tile);
+  const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * 9 * n;
+  // Blocks in flight: 3 per CU for 64-wide tiles (49 KB of LDS each), else 1.  The slice count is chosen
+  // for WHOLE rounds of blocks -- 33 problems x 9 taps x 3 slices = 891 blocks on 768 slots ran 1.16
+  // rounds, i.e. the second round 16 % full (x4: 5.3 ms for what 1.93 rounds do in 3.1) -- among the
+  // counts that leave a slice at least 1024 rows; ties go to fewer slices (less partial traffic).
+  const long slots = w == 1 ? 768 : 256;
+  long best = 1;
+  double best_eff = 0.0;
+  for (long s = 1; s <= 64; ++s) {
+    if (s > 1 && M / s < 1024) break;
+    const long blocks = tiles * s;
+    const double eff = (double)blocks / (double)(((blocks + slots - 1) / slots) * slots);
+    if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+  }
+  *S = (int)best;
+  *part_floats_per_item = best * 9 * (long)NI * NJ;
+  return 0;
+}
+
+int sr_conv_wgrad_batched_tnb(const TnArgs& base, const float* const* A, const float* const* B, int n,
+                              long part_stride, long colsum_stride, hipStream_t st) {
+  SR_REQUIRE(n >= 1 && n <= TNB_BATCH_MAX, "conv3x3_wgrad_batched: 1..%d problems (got %d)", TNB_BATCH_MAX, n);
+  SR_REQUIRE(base.conv && base.M > 0 && base.S > 0, "conv3x3_wgrad_batched: conv problems only");
+  SR_REQUIRE(base.NI % 4 == 0 && base.NJ % 4 == 0 && base.lda % 4 == 0 && base.ldb % 4 == 0,
+             "conv3x3_wgrad_batched: Cout, Cin and the pixel pitches must be multiples of 4");
+  TnbConvBatch g;
+  memset(&g, 0, sizeof(g));
+  g.base = base;
+  int tile;
+  const int w = pick_w(base.NI, base.NJ, &tile);
+  g.base.i_tile = g.base.j_tile = tile;
+  const int rps = sr_cdiv(base.M, base.S);
+  g.base.rows_per_slice = (rps + TKB - 1) / TKB * TKB;
+  g.n = n;
+  g.tiles = sr_cdiv(base.NI, tile) * sr_cdiv(base.NJ, tile);
+  g.part_stride = part_stride;
+  g.colsum_stride = colsum_stride;
+  for (int k = 0; k < n; ++k) { g.A[k] = A[k]; g.B[k] = B[k]; }
+  dim3 grid(base.S, g.tiles * n, 9);
+  static bool attr[4] = {false, false, false, false};
+#define SR_TNB_CB(W_)                                                                          \
+  if (w == W_) {                                                                               \
+    if (!attr[W_]) {                                                                           \
+      if (int rc = reserve_lds(k_tnb_conv_batched<W_>, lds_bytes(W_), "k_tnb_conv_batched")) return rc; \
+      attr[W_] = true;                                                                         \
+    }                                                                                          \
+    hipLaunchKernelGGL((k_tnb_conv_batched<W_>), grid, dim3(512), lds_bytes(W_), st, g);       \
+  }
+  SR_TNB_CB(1) SR_TNB_CB(2) SR_TNB_CB(3)
+#undef SR_TNB_CB
+  SR_LAUNCH_CHECK("k_tnb_conv_batched");
   return 0;
 }
 

@@ -75,3 +75,6 @@ int sr_tn_plan_t(int M, int NI, int NJ, int conv, int target, int* S, long* part
 int sr_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats);
 int sr_tn_group_plan_t(int M, int ntiles, int dflt_target, int* S);
 int sr_tn_tiles(int NI, int NJ);
+int sr_conv_wgrad_batched_plan(int n, int M, int NI, int NJ, int* S, long* part_floats_per_item);
+int sr_conv_wgrad_batched_tnb(const TnArgs& base, const float* const* A, const float* const* B, int n,
+                              long part_stride, long colsum_stride, hipStream_t st);

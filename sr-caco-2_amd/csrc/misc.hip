@@ -63,6 +63,39 @@ __global__ void k_reduce_conv_w(const float* __restrict__ part, float* __restric
     dw[i] = a;
   }
 }
+// the same for n problems of one shape (blockIdx.y = problem; partial buffers part_stride /
+// colsum_stride floats apart)
+struct ConvReduceBatch {
+  float* dw[40];
+  float* db[40];
+};
+__global__ void k_reduce_conv_w_batched(const float* __restrict__ part, long part_stride,
+                                        const float* __restrict__ colsum, long colsum_stride, int Co, int Ci,
+                                        int S, ConvReduceBatch out, int main_blocks) {
+  const int k = blockIdx.y;
+  part += (long)k * part_stride;
+  float* const dw = out.dw[k];
+  float* const db = out.db[k];
+  if ((int)blockIdx.x >= main_blocks) {
+    if (!colsum || !db) return;
+    colsum += (long)k * colsum_stride;
+    for (int n = threadIdx.x; n < Co; n += blockDim.x) {
+      float d = 0.f;
+      for (int s = 0; s < S; ++s) d += colsum[(long)s * Co + n];
+      db[n] = d;
+    }
+    return;
+  }
+  const long n = (long)Co * Ci * 9;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)main_blocks * blockDim.x) {
+    const int tap = i % 9;
+    const long cc = i / 9;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[((long)s * 9 + tap) * Co * Ci + cc];
+    dw[i] = a;
+  }
+}
 // Linear fed by a folded LayerNorm (W_f = W*gamma, b_f = b + W.beta):
 //   G = sum_s part, dbv = sum_s colsum
 //   dW[n][k] = gamma[k]*G[n][k] + beta[k]*dbv[n];  db = dbv
@@ -632,6 +665,39 @@ int srhip_reduce_conv_wgrad(const float* part, const float* colsum, int S, float
   hipLaunchKernelGGL(k_reduce_conv_w, dim3(mb + (bias ? 1 : 0)), dim3(256), 0, st, part, dW, Co, Ci, S,
                      colsum, db, mb);
   SR_LAUNCH_CHECK("reduce_conv_wgrad");
+  return 0;
+}
+
+int srhip_conv3x3_wgrad_batched_plan(int n, int B, int H, int W, int Cout, int Cin, int* S,
+                                     long* part_floats_per_item) {
+  SR_REQUIRE(n >= 1 && n <= 40, "conv3x3_wgrad_batched_plan: 1..40 problems (got %d)", n);
+  return sr_conv_wgrad_batched_plan(n, B * H * W, Cout, Cin, S, part_floats_per_item);
+}
+
+int srhip_conv3x3_wgrad_batched_bx3(const srhip_conv_wgrad_item* items, int n, long lddy, long ldx, int B, int H,
+                                    int W, int Cout, int Cin, float* part, float* part_colsum, int S,
+                                    void* stream) {
+  SR_REQUIRE(n >= 1 && n <= 40, "conv3x3_wgrad_batched: 1..40 problems (got %d)", n);
+  SR_REQUIRE(items && part && part_colsum, "conv3x3_wgrad_batched: NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  TnArgs p;
+  memset(&p, 0, sizeof(p));
+  p.lda = lddy; p.ldb = ldx; p.M = B * H * W; p.NI = Cout; p.NJ = Cin;
+  p.part = part; p.part_colsum = part_colsum; p.S = S; p.conv = 1; p.batch = B; p.H = H; p.Wd = W;
+  const float* A[40];
+  const float* Bp[40];
+  ConvReduceBatch out;
+  memset(&out, 0, sizeof(out));
+  for (int k = 0; k < n; ++k) {
+    SR_REQUIRE(items[k].dY && items[k].X && items[k].dW, "conv3x3_wgrad_batched: item %d has a NULL pointer", k);
+    A[k] = items[k].dY; Bp[k] = items[k].X; out.dw[k] = items[k].dW; out.db[k] = items[k].db;
+  }
+  const long pstride = (long)S * 9 * Cout * Cin, cstride = (long)S * Cout;
+  if (int rc = sr_conv_wgrad_batched_tnb(p, A, Bp, n, pstride, cstride, st)) return rc;
+  const int mb = ew_grid((long)Cout * Cin * 9) > 64 ? 64 : ew_grid((long)Cout * Cin * 9);
+  hipLaunchKernelGGL(k_reduce_conv_w_batched, dim3(mb + 1, n), dim3(256), 0, st, part, pstride, part_colsum,
+                     cstride, Cout, Cin, S, out, mb);
+  SR_LAUNCH_CHECK("reduce_conv_wgrad_batched");
   return 0;
 }
 

@@ -404,20 +404,32 @@ __global__ void __launch_bounds__(256, 3) k_wattn_bwd_kv(
     int nparts, float* __restrict__ dbiasT) {
   constexpr int HD = D / 2;
   __shared__ __attribute__((aligned(16))) float smem[4 * ((64 + 32) * D + 192)];
-  if ((int)blockIdx.x >= nmain) {
-    // tail blocks: d(bias) image = sum of the query pass's partial tiles (complete: that launch
-    // precedes this one on the stream), one thread per image element, fp64 accumulation
-    const int e = ((int)blockIdx.x - nmain) * 256 + (int)threadIdx.x;
+  const int ntail = (int)gridDim.x - nmain;
+  if ((int)blockIdx.x < ntail) {
+    // the FIRST blocks of the grid (they start at once and overlap the main blocks): d(bias) image =
+    // sum of the query pass's partial tiles (complete: that launch precedes this one on the
+    // stream), one thread per image element, eight loads in flight, fp64 accumulation
+    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
     const int img = heads * 4096;
     if (e < img) {
-      double a = 0.0;
-      for (int p = 0; p < nparts; ++p) a += (double)dbias_part[(long)p * img + e];
-      dbiasT[e] = (float)a;
+      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const float* src = dbias_part + e;
+      int p = 0;
+      for (; p + 8 <= nparts; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ldg_f(src + (long)(p + u) * img);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += (double)v[u];
+      }
+      for (; p < nparts; ++p) a[0] += (double)ldg_f(src + (long)p * img);
+      dbiasT[e] = (float)(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
     }
     return;
   }
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-  const long item = (remap ? sr_xcd_block(blockIdx.x, nmain) : (int)blockIdx.x) * 4L + wv;       // (window, head) x key block
+  const int mb = (int)blockIdx.x - ntail;
+  const long item = (remap ? sr_xcd_block(mb, nmain) : mb) * 4L + wv;       // (window, head) x key block
   if (item >= 2 * total) return;                // no block-level barrier below
   const int kb = (int)(item & 1);
   const WaGeom g = wa_decode(item >> 1, heads, W / 8, H / 8, shift);

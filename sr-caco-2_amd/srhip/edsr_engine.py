@@ -148,24 +148,49 @@ class EDSREngine:
             du = buf(f"du{i}", B, h, w, F)
             ops.conv3x3(dc, self.ws[f"up{i}.wpt"], None, F, out=du)
         drb = du                                             # grad wrt rb (= also grad wrt f0 via the skip)
-        ops.conv3x3_wgrad(drb, sv["r_last"], G(f"body.{self.nb}.weight"), G(f"body.{self.nb}.bias"))
-        ga, gb, da = buf("ga", B, H, W, F), buf("gb", B, H, W, F), buf("da", B, H, W, F)
-        g = ga
+        # The body's weight gradients are DEFERRED: every layer keeps its incoming gradient in a buffer
+        # of its own (2*nb+1 buffers of B*H*W*F floats; sized for 288 GB of HBM) and all 2*nb+1
+        # problems -- one shape -- go through ONE batched contraction + ONE reducer launch after the
+        # data-gradient chain.  Alone, a 64 -> 64 problem at 64x64x8 pixels is 2.4 GFLOP: it was cut in
+        # ~85 reduce slices to fill the chip and paid a 12.5 MB partial buffer + a reducer per layer
+        # (rocprofv3, EDSR x8: 36 x (96 + 24) us of a 9.6 ms step).
+        batched = ops.bx3_for(F, F) and self.nb > 0
+        wg = []                                              # (dY, X, dW, db)
+
+        def wgrad(dY, X, wname, bname):
+            if batched:
+                wg.append((dY, X, G(wname), G(bname)))
+            else:
+                ops.conv3x3_wgrad(dY, X, G(wname), G(bname))
+
+        wgrad(drb, sv["r_last"], f"body.{self.nb}.weight", f"body.{self.nb}.bias")
+        if batched:
+            gs = [buf(f"g{k}", B, H, W, F) for k in range(self.nb + 1)]      # gs[k]: gradient wrt block k's input
+            das = [buf(f"da{k}", B, H, W, F) for k in range(self.nb)]
+        else:
+            ga, gb, da1 = buf("ga", B, H, W, F), buf("gb", B, H, W, F), buf("da", B, H, W, F)
+            gs = [ga if (self.nb - k) % 2 == 0 else gb for k in range(self.nb + 1)]
+            das = [da1] * self.nb
+        g = gs[self.nb]
         ops.conv3x3(drb, self.ws["bend.wpt"], None, F, out=g)
         for k in reversed(range(self.nb)):
             r_in, a = sv["blocks"][k]
             p = f"body.{k}.body."
-            other = gb if g is ga else ga
+            other, da = gs[k], das[k]
             # r_out = rs*(conv2(a)+b2) + r_in ;  a = relu(conv1(r_in)+b1)
-            ops.conv3x3_wgrad(g, a, G(p + "2.weight"), G(p + "2.bias"))
+            wgrad(g, a, p + "2.weight", p + "2.bias")
             ops.conv3x3(g, self.ws[f"b{k}.2.wpt"], None, F, out=da, epi=4, R=a)     # * (a > 0)
             if rs != 1.0:
-                ops.axpby(G(p + "2.weight"), G(p + "2.weight"), 0.0, rs)
-                ops.axpby(G(p + "2.bias"), G(p + "2.bias"), 0.0, rs)
                 ops.axpby(da, da, 0.0, rs)
-            ops.conv3x3_wgrad(da, r_in, G(p + "0.weight"), G(p + "0.bias"))
+            wgrad(da, r_in, p + "0.weight", p + "0.bias")
             ops.conv3x3(da, self.ws[f"b{k}.0.wpt"], None, F, out=other, epi=2, R=g)  # + skip gradient
             g = other
+        if batched:
+            ops.conv3x3_wgrad_batched(wg)
+        if rs != 1.0:                # d(conv2 weights) = rs * (g (x) a): g was used unscaled above
+            for k in range(self.nb):
+                for nm in (f"body.{k}.body.2.weight", f"body.{k}.body.2.bias"):
+                    ops.axpby(G(nm), G(nm), 0.0, rs)
         ops.axpby(g, drb, 1.0, 1.0)                          # long skip: rb = conv(body) + f0
         ops.conv3x3_cin1_wgrad(sv["x"], g, G("head.0.weight"), G("head.0.bias"))
         if need_dx:

@@ -383,6 +383,45 @@ def conv3x3_wgrad(dY, X, dW, db):
     call("srhip_reduce_conv_wgrad", _p(part), _p(cs), S, _p(dW), _p(db), Cout, Cin, _st())
 
 
+class _ConvWgradItem(ctypes.Structure):   # srhip_conv_wgrad_item (include/srhip.h)
+    _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p)]
+
+
+def conv3x3_wgrad_batched(items):
+    """items: sequence of (dY NHWC [B,H,W,Cout], X NHWC [B,H,W,Cin], dW [Cout,Cin,3,3], db [Cout]) of ONE
+    shape and dense NHWC layout -> all weight / bias gradients by one contraction + one reducer launch
+    (bf16x3; up to 40 items per call)."""
+    dY0, X0 = items[0][0], items[0][1]
+    B, H, W, Cout = dY0.shape
+    Cin = X0.shape[3]
+    assert bx3_for(Cout, Cin), "batched conv weight gradients run on the bf16x3 kernels (>= 64 channels)"
+    for j0 in range(0, len(items), 40):
+        chunk = items[j0:j0 + 40]
+        n = len(chunk)
+        S = ctypes.c_int(0)
+        per = ctypes.c_long(0)
+        call("srhip_conv3x3_wgrad_batched_plan", n, B, H, W, Cout, Cin, ctypes.addressof(S), ctypes.addressof(per))
+        part = SCRATCH.get("tnb_part", n * per.value, device=dY0.device)
+        cs = SCRATCH.get("tnb_colsum", n * S.value * Cout, device=dY0.device)
+        arr = (_ConvWgradItem * n)()
+        for k, (dY, X, dW, db) in enumerate(chunk):
+            _chk(dY, X, dW, db)
+            assert dY.shape == dY0.shape and X.shape == X0.shape and dY.stride(2) == dY0.stride(2) \
+                and X.stride(2) == X0.stride(2) and dY.is_contiguous() and X.is_contiguous()
+            arr[k].dY, arr[k].X, arr[k].dW, arr[k].db = _p(dY), _p(X), _p(dW), _p(db)
+
+        def run():
+            call("srhip_conv3x3_wgrad_batched_bx3", ctypes.addressof(arr), n, dY0.stride(2), X0.stride(2), B, H, W,
+                 Cout, Cin, _p(part), _p(cs), S.value, _st())
+        if probe.on("conv_tn"):
+            T = B * H * W
+            with probe.timed(("conv_tn", f"batched x{n}", T, Cout, Cin), 18.0 * T * Cout * Cin * n,
+                             4.0 * n * (T * Cin + T * Cout + 9 * Cin * Cout)):
+                run()
+        else:
+            run()
+
+
 # ------------------------------------------------------------------ weight prep
 def fold_layernorm(W, b, gamma, beta, Wf, bf):
     _chk(W, b, gamma, beta, Wf, bf)

@@ -229,3 +229,22 @@ def test_linear_wgrad_bx3_ragged_rows(ops, M):
     assert relerr(dW, dYs.t() @ X.double()) < 2e-6 and relerr(db, dYs.sum(0)) < 2e-6
     Xn = (X.double() - st[:, :1].double()) * st[:, 1:].double()
     assert relerr(dW2, dY.double().t() @ Xn) < 2e-6 and relerr(db2, dY.double().sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize("n,B,H,W,C", [(3, 2, 16, 16, 64), (5, 1, 20, 12, 64), (33, 1, 24, 40, 64), (2, 1, 9, 7, 128)])
+def test_conv_wgrad_batched_matches_float64(ops, n, B, H, W, C):
+    """srhip_conv3x3_wgrad_batched_bx3: n same-shape problems in one launch (EDSR body, deferred weight
+    gradients) against float64 autograd, ragged borders and odd sizes included; outputs overwritten."""
+    items, refs = [], []
+    for k in range(n):
+        x, dy = rnd(B, C, H, W), rnd(B, C, H, W)
+        xr = x.double()
+        wr = torch.zeros(C, C, 3, 3, dtype=torch.float64, requires_grad=True)
+        br = torch.zeros(C, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xr, wr, br, padding=1).backward(dy.double())
+        refs.append((wr.grad, br.grad))
+        items.append((dy.permute(0, 2, 3, 1).contiguous().cuda(), x.permute(0, 2, 3, 1).contiguous().cuda(),
+                      torch.full((C, C, 3, 3), 7.0).cuda(), torch.full((C,), 7.0).cuda()))
+    ops.conv3x3_wgrad_batched(items)
+    for (_, _, dw, db), (rw, rb) in zip(items, refs):
+        assert relerr(dw, rw) < 2e-6 and relerr(db, rb) < 2e-6

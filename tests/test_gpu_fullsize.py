@@ -22,7 +22,6 @@ import sr_oracle as O  # noqa: E402
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GRAD_GATE = 2e-5          # relative to max|grad| of the tensor; measured margins: see the prints
-GRAD_GATE_CONV_FULL = 5e-5   # EDSR at 512^2: 262144-term sums per weight entry
 
 
 def load(name):
@@ -43,6 +42,17 @@ def need_gpu():
 
 def rel_err(a, ref):
     return (a - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+
+
+def worst_l2(named_grads, ref_grads):
+    """largest relative L2 error over the tensors: ||g - ref|| / ||ref||."""
+    worst = ("", 0.0)
+    for k, g in named_grads.items():
+        r = ref_grads[k].double()
+        e = ((g.detach().cpu().double() - r).norm() / (r.norm() + 1e-300)).item()
+        if e > worst[1]:
+            worst = (k, e)
+    return worst
 
 
 def worst_grad(named_grads, ref_grads):
@@ -88,21 +98,39 @@ def test_edsr_full_size_train_step_vs_oracle(scale, loss):
     y = net.engine.bufs.d["t.y"].detach().reshape(1, 1, 512, 512).cpu()
     grads = {k: v.clone() for k, v in ts.fp.gviews.items()}
 
-    sdo = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
-    yo = O.edsr_forward(sdo, lr_img, cfg)
-    tot, holder = O.master_loss(yo, hr_img, terms)
-    tot.backward()
-    yo = yo.detach()
+    def oracle(dtype):
+        sd = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd0.items()}
+        yo = O.edsr_forward(sd, lr_img.to(dtype), cfg)
+        tot, _ = O.master_loss(yo, hr_img.to(dtype), terms)
+        tot.backward()
+        return sd, yo.detach(), tot
+
+    sdo, yo, tot = oracle(torch.float32)                   # the reference's own arithmetic
+    sd64, _, _ = oracle(torch.float64)                     # the exact answer both fp32 computations approximate
     mae = (y - yo).abs().mean().item()
     gap = psnr_gap(y, yo, hr_img, scale)
     k, e = worst_grad(grads, {k: v.grad for k, v in sdo.items()})
+    k64, e64 = worst_grad(grads, {k: v.grad.float() for k, v in sd64.items()})
+    ko, eo = worst_grad({k: v.grad for k, v in sdo.items()}, {k: v.grad.float() for k, v in sd64.items()})
     lv = ts.loss_values()
-    print(f"\nEDSR x{scale} {loss}: MAE {mae:.2e}, PSNR gap {gap:.2e} dB, loss {lv[0]:.6f} vs {tot.item():.6f}, "
-          f"worst grad {k} {e:.2e}")
+    print(f"\nEDSR x{scale} {loss}: MAE {mae:.2e}, PSNR gap {gap:.2e} dB, loss {lv[0]:.6f} vs {tot.item():.6f}; "
+          f"worst grad vs the fp32 oracle {k} {e:.2e}; vs the fp64 oracle {k64} {e64:.2e}; the fp32 oracle itself "
+          f"vs fp64: {ko} {eo:.2e}")
     assert y.shape == (1, 1, 512, 512)
     assert mae <= 1e-5 and gap <= 0.01
     assert abs(lv[0] - tot.item()) <= 1e-5 * max(1.0, abs(tot.item()))
-    assert e <= GRAD_GATE_CONV_FULL, (k, e)
+    # Gradient gates for a ReLU net.  Tensor-wise relative L2 error against the exact (fp64) gradients
+    # <= GRAD_GATE.  Largest single entry: a ReLU whose pre-activation lies within fp32 rounding of zero
+    # switches on in one computation and off in the other -- ONE pixel of the 4096 .. 65536 of the body's
+    # feature maps then enters or leaves a weight-gradient sum (measured: 1.3e-4 at 64x64, 1.1e-4 at 128x128,
+    # 1.9e-5 at 256x256, while the tensor-wise error stays at 1e-6; the reference's own fp32 result shows the
+    # same against fp64 whenever it has such a pixel: 4.1e-5 at x4) -- so the entry-wise gate allows two such
+    # pixels: 2 / (LR pixels per image).
+    kl, el = worst_l2(grads, {k: v.grad for k, v in sd64.items()})
+    print(f"  worst tensor-wise relative L2 error vs fp64: {kl} {el:.2e}")
+    npix = (512 // scale) ** 2
+    assert el <= GRAD_GATE, (kl, el)
+    assert e64 <= max(GRAD_GATE, 3.0 * eo, 2.0 / npix), (k64, e64, eo)
     # Adam's first update is lr * g / (|g| + eps): where a gradient entry is ~0 its SIGN decides a full
     # +-lr step, so the update is checked from the HIP gradients themselves (the gradients are gated above)
     worst = 0.0
