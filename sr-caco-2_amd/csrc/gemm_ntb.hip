@@ -408,6 +408,9 @@ int sr_gemm_ntb(NtArgs& p, hipStream_t st) {
   const auto al4 = [](const void* q, long ld) { return !q || (((size_t)q & 15) == 0 && ld % 4 == 0); };
   p.wide_epi = p.N % 4 == 0 && al4(p.C, p.ldc) && al4(p.R, p.ldr) && al4(p.aux, p.ldaux) &&
                ((size_t)p.C & 15) == 0 && ntb_env("SRHIP_NTB_WIDE", 1);
+  // K <= 192 at 180-column widths (the K = 180 Linears of a Swin block): weights resident in registers,
+  // persistent blocks, only A through LDS (gemm_ntr.hip)
+  if (sr_gemm_ntr_ok(p)) return sr_gemm_ntr(p, st);
   // 64-row tiles (every case but very tall problems with narrow N, which take the 128-row
   // tiles of this file): the 16-wide-stage kernel of gemm_ntp.hip
   {

@@ -65,6 +65,8 @@ int sr_gemm_ntb(NtArgs& p, hipStream_t st);
 int sr_conv3x3_ntb(NtArgs& p, hipStream_t st);
 int sr_gemm_ntb_lnbwd(NtArgs& p, hipStream_t st);
 int sr_gemm_ntp(NtArgs& p, hipStream_t st);
+bool sr_gemm_ntr_ok(const NtArgs& p);
+int sr_gemm_ntr(NtArgs& p, hipStream_t st);
 int sr_gemm_tn(TnArgs& p, hipStream_t st);
 int sr_gemm_tnb(TnArgs& p, hipStream_t st);
 int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st);

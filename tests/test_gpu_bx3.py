@@ -14,6 +14,15 @@ def ops():
     return o
 
 
+@pytest.fixture(autouse=True, params=["ntp", "ntr"])
+def nt_kernel(request, monkeypatch):
+    """Every test of this file runs twice: with the production NT GEMM (gemm_ntp.hip) and with the
+    register-resident-W kernel switched on for the shapes it takes (gemm_ntr.hip, SRHIP_NTR=1: K <= 192,
+    M >= 4096, widths of 180 or <= 192 -- an experiment kept behind the switch)."""
+    monkeypatch.setenv("SRHIP_NTR", "1" if request.param == "ntr" else "0")
+    return request.param
+
+
 G = torch.Generator().manual_seed(4321)
 
 
@@ -44,7 +53,11 @@ def test_split_is_exact(ops):
 @pytest.mark.parametrize("M,N,K", [(300, 180, 180), (4096, 540, 180), (1000, 60, 60), (777, 64, 64),
                                    (2048, 360, 180), (515, 180, 360), (64, 120, 60), (130, 256, 64),
                                    (33000, 180, 180), (999, 180, 540), (100, 48, 20),
-                                   (140000, 64, 64)])   # tall + narrow: the 128-row tiles of gemm_ntb.hip
+                                   (140000, 64, 64),    # tall + narrow: the 128-row tiles of gemm_ntb.hip
+                                   # register-resident-W kernel (gemm_ntr.hip: K <= 192, M >= 4096): ragged rows,
+                                   # K not a multiple of 32, widths 180 / 360 / 540 and a single <= 192 block
+                                   (4133, 540, 180), (16384, 360, 180), (8200, 180, 168), (5000, 128, 180),
+                                   (4096, 192, 192), (6000, 100, 100)])
 def test_gemm_bx3_matches_f32(ops, M, N, K):
     A, W, b = rnd(M, K), rnd(N, K, scale=0.1), rnd(N)
     ref = F.linear(A.double(), W.double(), b.double())
@@ -54,8 +67,9 @@ def test_gemm_bx3_matches_f32(ops, M, N, K):
     assert ebx <= max(2.0 * e32, 1e-6), f"bx3 {ebx:.3e} vs f32 kernel {e32:.3e}"
 
 
-def test_gemm_bx3_prologues_epilogues(ops):
-    M, N, K = 1024, 180, 180
+@pytest.mark.parametrize("M", [1024, 8192])       # 8192 rows: the register-resident-W kernel (gemm_ntr.hip)
+def test_gemm_bx3_prologues_epilogues(ops, M):
+    N, K = 180, 180
     A, W, b, R = rnd(M, K), rnd(N, K, scale=0.1), rnd(N), rnd(M, N)
     Wb = ops.split_bf16x3(W.cuda())
     d = lambda t: t.cuda()
@@ -70,16 +84,16 @@ def test_gemm_bx3_prologues_epilogues(ops):
     out = ops.gemm_nt(d(A), Wb, d(b), epi=1)
     assert relerr(out, F.relu(F.linear(A.double(), W.double(), b.double()))) < tol
     rs = torch.tensor([1.0, 0.0, 1.25, 2.0])
-    out = ops.gemm_nt(d(A), Wb, d(b), epi=2, R=d(R), rowscale=d(rs), rows_per_scale=256, alpha=0.5)
-    ref = R.double() + 0.5 * rs.double().repeat_interleave(256)[:, None] * F.linear(A.double(), W.double(), b.double())
+    out = ops.gemm_nt(d(A), Wb, d(b), epi=2, R=d(R), rowscale=d(rs), rows_per_scale=M // 4, alpha=0.5)
+    ref = R.double() + 0.5 * rs.double().repeat_interleave(M // 4)[:, None] * F.linear(A.double(), W.double(), b.double())
     assert relerr(out, ref) < tol
     Rg = R.double().clone().requires_grad_(True)
     F.gelu(Rg).sum().backward()
-    out = ops.gemm_nt(d(A), Wb, None, epi=3, R=d(R), rowscale=d(rs), rows_per_scale=256)
-    ref = rs.double().repeat_interleave(256)[:, None] * F.linear(A.double(), W.double()) * Rg.grad
+    out = ops.gemm_nt(d(A), Wb, None, epi=3, R=d(R), rowscale=d(rs), rows_per_scale=M // 4)
+    ref = rs.double().repeat_interleave(M // 4)[:, None] * F.linear(A.double(), W.double()) * Rg.grad
     assert relerr(out, ref) < tol
     aux = torch.empty(M, N).cuda()
-    out2 = ops.gemm_nt(d(A), Wb, None, epi=3, R=d(R), rowscale=d(rs), rows_per_scale=256, aux=aux)
+    out2 = ops.gemm_nt(d(A), Wb, None, epi=3, R=d(R), rowscale=d(rs), rows_per_scale=M // 4, aux=aux)
     assert torch.equal(out2, out) and relerr(aux, F.gelu(R.double())) < tol
     out = ops.gemm_nt(d(A), Wb, None, epi=4, R=d(R))
     assert relerr(out, F.linear(A.double(), W.double()) * (R > 0)) < tol
@@ -183,7 +197,8 @@ def test_gemm_lnbwd_fused(ops, M, N, K):
     assert relerr(out2, xd.grad) < 5e-6
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 180, 180), (700, 180, 360), (300, 64, 64), (555, 120, 60)])
+@pytest.mark.parametrize("M,N,K", [(1024, 180, 180), (700, 180, 360), (300, 64, 64), (555, 120, 60),
+                                   (8192, 180, 180), (4101, 180, 168), (4500, 120, 180)])   # the last three: gemm_ntr.hip
 def test_gemm_row_stats(ops, M, N, K):
     """stats_out of the GEMM epilogue == layernorm_fwd statistics of the GEMM output."""
     A, W, b, R = rnd(M, K), rnd(N, K, scale=0.1), rnd(N), rnd(M, N) * 3 + 1
