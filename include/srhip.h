@@ -49,7 +49,9 @@ int srhip_gemm_nt(const float* A, long lda, const float* W, long ldw, const floa
 
 /* 3x3 / stride 1 / pad 1 convolution, NHWC, implicit GEMM.  Wp is the tap-major
  * pack [9][Cout][Cin] from srhip_pack_conv_weight (forward) or its flipped /
- * transposed twin (data gradient).  Epilogues as srhip_gemm_nt (0,1,2,4).
+ * transposed twin (data gradient).  Epilogues as srhip_gemm_nt (0,1,2,4) plus
+ *   6: LeakyReLU with negative slope alpha (network_swinir.py:857)  7: its backward,
+ *      acc * (R > 0 ? 1 : alpha) with R = the activation's output.
  * Replaces default_conv / nn.Conv2d(.,.,3,1,1): network_nlsn.py:38-41,89-93,
  * network_swinir.py:544,850,700. */
 int srhip_conv3x3_nhwc(const float* X, long ldx, const float* Wp, const float* bias, float* Y, long ldy,

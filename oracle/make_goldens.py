@@ -385,6 +385,51 @@ def g_trained_like():
     npz("g18_trained_like", **arrs)
 
 
+# ---------------------------------------------------------------- G20 SwinIR 'pixelshuffle' upsampler
+def g_swinir_pixelshuffle():
+    """The registry-default reconstruction tail (utils_init_default_args.py:23): conv 180->64 + LeakyReLU,
+    log2(s) x [conv 64->256 + PixelShuffle(2)], conv 64->1 (network_swinir.py:862-868,937-942), x4 on the tiny
+    trunk: reference forward (eval), dL/dx and every parameter gradient."""
+    print("G20 SwinIR tiny, upsampler 'pixelshuffle' x4")
+    cfg = O.swinir_config(upscale=4, in_chans=1, img_size=16, window_size=8, depths=(2, 2), embed_dim=60,
+                          num_heads=(6, 6), mlp_ratio=2, upsampler="pixelshuffle", drop_path_rate=0.0)
+    sd = perturb(O.swinir_init_state_dict(cfg, seed=51), 52)
+    net = build_ref_swinir(cfg)
+    net.load_state_dict(sd, strict=True)
+    assert list(net.state_dict().keys()) == list(sd.keys()), "key order"
+    net.eval()
+    torch.manual_seed(53)
+    x = torch.rand(2, 1, 16, 24)
+    with torch.no_grad():
+        y_eval = net(x)
+        close(O.swinir_forward(sd, x, cfg), y_eval, 2e-6, "pixelshuffle eval forward")
+    net.train()
+    for l in net.layers:
+        for b in l.residual_group.blocks:
+            b.drop_path = nn.Identity()
+    xg = x.clone().requires_grad_(True)
+    y = net(xg)
+    torch.manual_seed(54)
+    tgt = torch.rand_like(y)
+    (y - tgt).abs().mean().backward()
+    grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask") else v)
+           for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    (O.swinir_forward(sdo, xo, cfg) - tgt).abs().mean().backward()
+    close(xo.grad, xg.grad, 1e-7, "pixelshuffle dL/dx")
+    for k in grads:
+        e = (sdo[k].grad - grads[k]).abs().max().item() / (grads[k].abs().max().item() + 1e-30)
+        # bias gradients of the upsampler: fp32 sums over up to 6144 pixels of a gradient that reaches the conv
+        # in a different memory layout (the oracle's reshape/permute shuffle vs nn.PixelShuffle) -> another
+        # summation order inside aten's conv backward
+        assert e < (1e-4 if k.endswith(".bias") else 5e-6), (k, e)
+    arrs = dict(x=x, y_eval=y_eval, target=tgt, dx=xg.grad)
+    arrs.update(sd_np(sd, "sd/"))
+    arrs.update(sd_np(grads, "grad/"))
+    npz("g20_swinir_pixelshuffle", **arrs)
+
+
 # ---------------------------------------------------------------- G19 eval.py experiment folder
 def g_eval_fixture():
     """A reference-format experiment directory + dataset + folds, and what the REFERENCE's own
@@ -1033,7 +1078,7 @@ def g_optim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
-            g_metrics, g_optim, g_trained_like, g_eval_fixture]
+            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:
         if not only or g.__name__ in only:

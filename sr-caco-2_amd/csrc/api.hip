@@ -42,8 +42,8 @@ int srhip_gemm_nt(const float* A, long lda, const float* W, long ldw, const floa
 int srhip_conv3x3_nhwc(const float* X, long ldx, const float* Wp, const float* bias, float* Y, long ldy,
                        int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                        const float* rowscale, float alpha, void* stream) {
-  SR_REQUIRE(epi >= 0 && epi <= 4 && epi != 3, "conv3x3: epi %d", epi);
-  SR_REQUIRE(epi != 4 || R, "conv3x3: relu-mask epilogue needs R");
+  SR_REQUIRE(epi >= 0 && epi <= 7 && epi != 3 && epi != 5, "conv3x3: epi %d", epi);
+  SR_REQUIRE((epi != 4 && epi != 7) || R, "conv3x3: mask epilogue %d needs R", epi);
   NtArgs p;
   memset(&p, 0, sizeof(p));
   p.A = X; p.lda = ldx; p.W = Wp; p.ldw = Cin; p.wtap = (long)Cout * Cin; p.C = Y; p.ldc = ldy;
@@ -101,8 +101,8 @@ int srhip_gemm_nt_bx3_lnbwd(const float* A, long lda, const void* Wb, float* out
 int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
                            int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                            const float* rowscale, float alpha, void* stream) {
-  SR_REQUIRE(epi >= 0 && epi <= 4 && epi != 3, "conv3x3_bx3: epi %d", epi);
-  SR_REQUIRE(epi != 4 || R, "conv3x3_bx3: relu-mask epilogue needs R");
+  SR_REQUIRE(epi >= 0 && epi <= 7 && epi != 3 && epi != 5, "conv3x3_bx3: epi %d", epi);
+  SR_REQUIRE((epi != 4 && epi != 7) || R, "conv3x3_bx3: mask epilogue %d needs R", epi);
   NtArgs p;
   memset(&p, 0, sizeof(p));
   p.A = X; p.lda = ldx; p.Wb = (const unsigned short*)Wb; p.C = Y; p.ldc = ldy;

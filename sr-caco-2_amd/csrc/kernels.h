@@ -15,7 +15,7 @@ struct NtArgs {
   const float* bias;          // [N] or null
   int a_mode;                 // 0 plain | 1 (x-mean)*rstd from ln_stats | 2 gelu(x)
   const float* ln_stats;      // [M][2] = mean, rstd
-  int epi;                    // 0 +bias | 1 relu | 2 R + s*(acc+bias) | 3 s*acc*gelu'(R) | 4 acc*(R>0)
+  int epi;                    // 0 +bias | 1 relu | 2 R + s*(acc+bias) | 3 s*acc*gelu'(R) | 4 acc*(R>0) | 6 leaky relu(alpha) | 7 acc*(R>0 ? 1 : alpha)
   const float* R; long ldr;
   float* aux; long ldaux;     // epi 3: optional second output gelu(R)
   // epi 5 (LayerNorm backward, bx3 GEMM only): R = x, R2 = residual gradient, ep_stats = {mean, rstd}[M]

@@ -199,6 +199,14 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][W
 #pragma unroll
           for (int q = 0; q < 16; ++q) v[q] = rv[q] > 0.f ? v[q] : 0.f;
           break;
+        case 6:            // LeakyReLU(alpha) (network_swinir.py:857,938)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * p.alpha;
+          break;
+        case 7:            // its backward: R = the activation's OUTPUT (same sign as its input)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = rv[q] > 0.f ? v[q] : v[q] * p.alpha;
+          break;
         default:
           break;
       }
@@ -369,6 +377,14 @@ __device__ __forceinline__ void nt_epilogue_wide_impl(const NtArgs& p, f32x16 (&
       case 4:
         v.x = rv[it].x > 0.f ? v.x : 0.f; v.y = rv[it].y > 0.f ? v.y : 0.f;
         v.z = rv[it].z > 0.f ? v.z : 0.f; v.w = rv[it].w > 0.f ? v.w : 0.f;
+        break;
+      case 6:
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+        break;
+      case 7:
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rv[it][e] > 0.f ? v[e] : v[e] * p.alpha;
         break;
       default:
         break;

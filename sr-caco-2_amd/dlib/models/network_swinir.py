@@ -7,9 +7,12 @@ keys / shapes / order (366 entries for the README configuration), same
 *holds* parameters; ``forward`` runs the HIP engine (srhip/swinir_engine.py)
 and there is no PyTorch/CPU execution path: CPU tensors raise.
 
-Supported on the HIP path: window_size 8, 1-channel input, upsampler
-'pixelshuffledirect', resi_connection '1conv' (the configuration the reference
-trains and benchmarks, README.md:120-197).
+Supported on the HIP path: window_size 8, 1-channel input, upsamplers
+'pixelshuffledirect' (the configuration the reference trains and benchmarks,
+README.md:120-197) and 'pixelshuffle' (the registry default,
+utils_init_default_args.py:23; conv 180->64 + LeakyReLU, log2(s) x [conv 64->256 +
+PixelShuffle(2)], conv 64->1: network_swinir.py:862-868,937-942), resi_connection
+'1conv'.
 """
 import math
 
@@ -135,8 +138,10 @@ class SwinIR(nn.Module):
             unsupported.append(f"window_size={window_size} (HIP path: 8)")
         if in_chans != 1:
             unsupported.append(f"in_chans={in_chans} (HIP path: 1-channel microscopy patches)")
-        if upsampler != constants.US_PIXEL_SHUFFLE_DIRECT:
-            unsupported.append(f"upsampler={upsampler!r} (HIP path: 'pixelshuffledirect')")
+        if upsampler not in (constants.US_PIXEL_SHUFFLE_DIRECT, constants.US_PIXEL_SHUFFLE):
+            unsupported.append(f"upsampler={upsampler!r} (HIP path: 'pixelshuffledirect', 'pixelshuffle')")
+        if upsampler == constants.US_PIXEL_SHUFFLE and (upscale & (upscale - 1) or upscale < 2):
+            unsupported.append(f"upscale={upscale} with 'pixelshuffle' (HIP path: powers of two)")
         if resi_connection != constants.R_CONNECTION_1CONV:
             unsupported.append(f"resi_connection={resi_connection!r} (HIP path: '1conv')")
         if ape or not patch_norm or not qkv_bias or qk_scale is not None or drop_rate or attn_drop_rate:
@@ -169,7 +174,17 @@ class SwinIR(nn.Module):
             self.layers.append(rstb)
         self.norm = _norm(embed_dim)
         self.conv_after_body = _conv3(embed_dim, embed_dim)
-        self.upsample = nn.ModuleList([_conv3(upscale * upscale * in_chans, embed_dim)])
+        if upsampler == constants.US_PIXEL_SHUFFLE_DIRECT:
+            self.upsample = nn.ModuleList([_conv3(upscale * upscale * in_chans, embed_dim)])
+        else:       # 'pixelshuffle': same parameter names / order as network_swinir.py:862-868
+            num_feat = 64
+            self.num_feat = num_feat
+            self.conv_before_upsample = nn.ModuleList([_conv3(num_feat, embed_dim)])
+            up = []
+            for _ in range(int(math.log2(upscale))):
+                up += [_conv3(4 * num_feat, num_feat), nn.Identity()]     # upsample.{0,2,4}: conv; odd: PixelShuffle
+            self.upsample = nn.ModuleList(up)
+            self.conv_last = _conv3(in_chans, num_feat)
         self._engine = None
 
     # -- helpers -------------------------------------------------------------

@@ -46,6 +46,8 @@ class SwinIREngine:
         self.hid = int(net.embed_dim * net.mlp_ratio)
         self.scale = net.upscale
         self.blocks = list(net.swin_blocks())
+        self.direct = net.upsampler == "pixelshuffledirect"
+        self.stages = 0 if self.direct else int(round(__import__("math").log2(net.upscale)))
         self.layer_of_block = []
         for li, layer in enumerate(net.layers):
             for _ in layer.residual_group.blocks:
@@ -67,7 +69,7 @@ class SwinIREngine:
         for li in reversed(range(n)):
             pf = [f"layers.{li}."]
             if li == n - 1:
-                pf += ["norm.", "conv_after_body.", "upsample."]
+                pf += ["norm.", "conv_after_body.", "conv_before_upsample.", "upsample.", "conv_last."]
             out.append(pf)
         out.append(["conv_first.", "patch_embed."])
         return out
@@ -156,7 +158,12 @@ class SwinIREngine:
         for li, layer in enumerate(net.layers):
             yield f"l{li}", layer.conv
         yield "cab", net.conv_after_body
-        yield "up", net.upsample[0]
+        if self.direct:
+            yield "up", net.upsample[0]
+        else:
+            yield "cbu", net.conv_before_upsample[0]
+            for i in range(self.stages):
+                yield f"up{i}", net.upsample[2 * i]
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, dp=None, save=True):
@@ -234,12 +241,28 @@ class SwinIREngine:
         ops.conv3x3(tn.view(B, H, W, C), ws["cab.wp"], net.conv_after_body.bias.data, C, out=f, epi=2,
                     R=f0)
         r = self.scale
-        cu = r * r * net.in_chans
-        u = buf("u", B, H, W, cu)
-        ops.conv3x3(f, ws["up.wp"], net.upsample[0].bias.data, cu, out=u)
         y = torch.empty(B, net.in_chans, H * r, W * r, device=dev) if not save else \
             buf("y", B, net.in_chans, H * r, W * r)
-        ops.pixel_shuffle(u, r, out=y)
+        if self.direct:     # conv 180 -> s*s, PixelShuffle(s) (network_swinir.py:943-947)
+            cu = r * r * net.in_chans
+            u = buf("u", B, H, W, cu)
+            ops.conv3x3(f, ws["up.wp"], net.upsample[0].bias.data, cu, out=u)
+            ops.pixel_shuffle(u, r, out=y)
+        else:               # 'pixelshuffle' (network_swinir.py:937-942)
+            nf = net.num_feat
+            u = buf("cbu", B, H, W, nf)
+            ops.conv3x3(f, ws["cbu.wp"], net.conv_before_upsample[0].bias.data, nf, out=u, epi=6, alpha=0.01)
+            h, w, ups = H, W, [u]
+            for i in range(self.stages):
+                c = buf(f"upc{i}", B, h, w, 4 * nf)
+                ops.conv3x3(u, ws[f"up{i}.wp"], net.upsample[2 * i].bias.data, 4 * nf, out=c)
+                u = buf(f"upu{i}", B, 2 * h, 2 * w, nf)
+                ops.pixel_shuffle(c, 2, nhwc_out=True, out=u)
+                h, w = 2 * h, 2 * w
+                ups.append(u)
+            ops.conv3x3_cout1_fwd(u, net.conv_last.weight.data, net.conv_last.bias.data, out=y.view(B, h, w))
+            if save:
+                sv["ups"] = ups
         if save:
             sv.update(t_last=t, st_n=st_n, tn=tn, f=f)
             self.saved = sv
@@ -265,11 +288,33 @@ class SwinIREngine:
         def G(name):
             return grads[name]
 
-        du = buf("du", B, H, W, cu)
-        ops.pixel_shuffle(dy, r, inverse=True, out=du)
-        ops.conv3x3_wgrad(du, sv["f"], G("upsample.0.weight"), G("upsample.0.bias"))
         df = buf("df", B, H, W, C)
-        ops.conv3x3(du, ws["up.wpt"], None, C, out=df)
+        if self.direct:
+            du = buf("du", B, H, W, cu)
+            ops.pixel_shuffle(dy, r, inverse=True, out=du)
+            ops.conv3x3_wgrad(du, sv["f"], G("upsample.0.weight"), G("upsample.0.bias"))
+            ops.conv3x3(du, ws["up.wpt"], None, C, out=df)
+        else:
+            nf, ups = net.num_feat, sv["ups"]
+            h, w = H * r, W * r
+            dyv = dy.reshape(B, h, w).contiguous()
+            # conv_last 64 -> 1: the 1-channel kernels with the roles of x / dy swapped and flipped taps
+            ops.conv3x3_cin1_wgrad(dyv, ups[-1], G("conv_last.weight"), None, flip=True)
+            ops.sum_into(dyv, G("conv_last.bias"))
+            g = buf(f"dupu{self.stages}", B, h, w, nf)
+            ops.conv3x3_cin1_fwd(dyv, net.conv_last.weight.data, None, nf, out=g, flip=True)
+            for i in reversed(range(self.stages)):
+                h, w = h // 2, w // 2
+                dc = buf(f"dupc{i}", B, h, w, 4 * nf)
+                ops.pixel_shuffle(g, 2, nhwc_out=True, inverse=True, out=dc)
+                ops.conv3x3_wgrad(dc, ups[i], G(f"upsample.{2 * i}.weight"), G(f"upsample.{2 * i}.bias"))
+                g = buf(f"dupu{i}", B, h, w, nf)
+                if i == 0:      # LeakyReLU backward rides in the data-gradient conv: * (cbu > 0 ? 1 : 0.01)
+                    ops.conv3x3(dc, ws["up0.wpt"], None, nf, out=g, epi=7, R=ups[0], alpha=0.01)
+                else:
+                    ops.conv3x3(dc, ws[f"up{i}.wpt"], None, nf, out=g)
+            ops.conv3x3_wgrad(g, sv["f"], G("conv_before_upsample.0.weight"), G("conv_before_upsample.0.bias"))
+            ops.conv3x3(g, ws["cbu.wpt"], None, C, out=df)
         ops.conv3x3_wgrad(df, sv["tn"].view(B, H, W, C), G("conv_after_body.weight"),
                           G("conv_after_body.bias"))
         dtn = buf("dtn", T, C)

