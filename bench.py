@@ -49,6 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=8, help="patches per GPU (README --batch_size 8)")
     ap.add_argument("--loss", default="l1", choices=["l1", "l2ssim"])
     ap.add_argument("--optimizer", default=None, choices=["sgd", "adam"])
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (TrainStep.step_graph; 1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args(argv)
@@ -216,9 +217,13 @@ def worker(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        ts.step(lr_img, hr_img)
+    use_graph = args.graph and world == 1 and pg is None
+    step_fn = ts.step_graph if use_graph else ts.step
+    for _ in range(max(args.warmup, 2 if use_graph else 0)):   # graph: eager step, capture, then replays
+        step_fn(lr_img, hr_img)
     barrier()
+    if use_graph:
+        args.no_roofline = True          # per-launch HIP events cannot be recorded inside a replayed graph
     if not args.no_roofline:
         probe.enable(kinds)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -229,7 +234,7 @@ def worker(args):
         # them would cost the headline number), taken mid-run
         probe.active = set(kinds) if (not args.no_roofline and i % 10 == 5 % max(args.steps, 1)) else None
         marks[i].record()
-        ts.step(lr_img, hr_img)
+        step_fn(lr_img, hr_img)
     marks[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
@@ -276,7 +281,7 @@ def worker(args):
             "data": "synthetic",
             "config": {"workload": f"{desc}, fwd + {args.loss} + bwd + {opt_kind}",
                        "global_batch": args.batch * world, "batch_per_gpu": args.batch,
-                       "parallelism": f"dp{world}", "final_loss": loss,
+                       "parallelism": f"dp{world}", "final_loss": loss, "hip_graph": bool(use_graph),
                        "eval_patches_per_s_one_gpu": eval_pps,
                        "matmul": ("bf16x3 split MFMA: f32 operands split into 3 bf16 parts, 6 products, "
                                   "f32 accumulate (f32-accurate)") if bx else "f32 MFMA"},

@@ -352,14 +352,16 @@ int srhip_sgd_step(float* p, const float* g, float* buf, long n, float lr, float
  * Adam's bias corrections 1 - beta^counter and SGD's "first step" (counter == 1) from it.  A step
  * skipped by the non-finite flag then leaves the optimizer state exactly as the reference does
  * when it skips backward + optimizer.step() for that batch (model_plain.py:344-346), with no
- * host sync. */
+ * host sync.  lr_dev (may be NULL): the learning rate read from device memory instead of the
+ * argument -- a launch captured in a hipGraph then replays with the current rate of the per-iteration
+ * schedule (MyStepLR, utils_trainer.py:370). */
 int srhip_optim_tick(const int* skip_flag, int* counter, void* stream);
 int srhip_adam_step_dc(float* p, const float* g, float* m, float* v, long n, const int* counter, float lr,
                        float b1, float b2, float eps, float wd, float gscale, const int* skip_flag,
-                       void* stream);
+                       const float* lr_dev, void* stream);
 int srhip_sgd_step_dc(float* p, const float* g, float* buf, long n, const int* counter, float lr,
                       float momentum, float wd, int nesterov, float gscale, const int* skip_flag,
-                      void* stream);
+                      const float* lr_dev, void* stream);
 /* flag[0] |= any(!isfinite(x)): one device flag instead of the reference's
  * per-tensor host syncs (dlib/utils/tools.py:28-63, model_plain.py:344). */
 int srhip_nonfinite_flag(const float* x, long n, int* flag, void* stream);

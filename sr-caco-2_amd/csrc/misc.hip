@@ -547,8 +547,10 @@ __global__ void k_optim_tick(const int* __restrict__ skip, int* __restrict__ cou
 }
 __global__ void k_adam_dc(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                           float* __restrict__ v, long n, const int* __restrict__ counter, float lr, float b1,
-                          float b2, float eps, float wd, float gscale, const int* __restrict__ skip) {
+                          float b2, float eps, float wd, float gscale, const int* __restrict__ skip,
+                          const float* __restrict__ lr_dev) {
   if (skip && *skip) return;
+  if (lr_dev) lr = *lr_dev;       // learning rate from device memory: a captured launch replays with the current one
   const float step = (float)*counter;
   const float bc1 = 1.f - powf(b1, step);
   const float bc2_sqrt = sqrtf(1.f - powf(b2, step));
@@ -566,8 +568,10 @@ __global__ void k_adam_dc(float* __restrict__ p, const float* __restrict__ g, fl
 }
 __global__ void k_sgd_dc(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                          long n, const int* __restrict__ counter, float lr, float momentum, float wd,
-                         int nesterov, float gscale, const int* __restrict__ skip) {
+                         int nesterov, float gscale, const int* __restrict__ skip,
+                         const float* __restrict__ lr_dev) {
   if (skip && *skip) return;
+  if (lr_dev) lr = *lr_dev;
   const int first = *counter == 1;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
        i += (long)gridDim.x * blockDim.x) {
@@ -831,22 +835,22 @@ int srhip_optim_tick(const int* skip_flag, int* counter, void* stream) {
 
 int srhip_adam_step_dc(float* p, const float* g, float* m, float* v, long n, const int* counter, float lr,
                        float b1, float b2, float eps, float wd, float gscale, const int* skip_flag,
-                       void* stream) {
+                       const float* lr_dev, void* stream) {
   if (n <= 0) return 0;
   SR_REQUIRE(counter != nullptr, "adam_step_dc: counter is NULL");
   hipLaunchKernelGGL(k_adam_dc, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, counter,
-                     lr, b1, b2, eps, wd, gscale, skip_flag);
+                     lr, b1, b2, eps, wd, gscale, skip_flag, lr_dev);
   SR_LAUNCH_CHECK("adam_step_dc");
   return 0;
 }
 
 int srhip_sgd_step_dc(float* p, const float* g, float* buf, long n, const int* counter, float lr,
                       float momentum, float wd, int nesterov, float gscale, const int* skip_flag,
-                      void* stream) {
+                      const float* lr_dev, void* stream) {
   if (n <= 0) return 0;
   SR_REQUIRE(counter != nullptr, "sgd_step_dc: counter is NULL");
   hipLaunchKernelGGL(k_sgd_dc, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, counter,
-                     lr, momentum, wd, nesterov, gscale, skip_flag);
+                     lr, momentum, wd, nesterov, gscale, skip_flag, lr_dev);
   SR_LAUNCH_CHECK("sgd_step_dc");
   return 0;
 }

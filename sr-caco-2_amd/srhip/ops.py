@@ -779,16 +779,18 @@ def optim_tick(skip_flag, counter):
     call("srhip_optim_tick", _p(skip_flag), _p(counter), _st())
 
 
-def adam_step_dc(p, g, m, v, counter, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0, gscale=1.0, skip_flag=None):
-    _chk(p, g, m, v, counter, skip_flag)
+def adam_step_dc(p, g, m, v, counter, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0, gscale=1.0, skip_flag=None,
+                 lr_dev=None):
+    _chk(p, g, m, v, counter, skip_flag, lr_dev)
     call("srhip_adam_step_dc", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(counter), float(lr), float(b1),
-         float(b2), float(eps), float(wd), float(gscale), _p(skip_flag), _st())
+         float(b2), float(eps), float(wd), float(gscale), _p(skip_flag), _p(lr_dev), _st())
 
 
-def sgd_step_dc(p, g, buf, counter, lr, momentum=0.9, wd=0.0, nesterov=True, gscale=1.0, skip_flag=None):
-    _chk(p, g, buf, counter, skip_flag)
+def sgd_step_dc(p, g, buf, counter, lr, momentum=0.9, wd=0.0, nesterov=True, gscale=1.0, skip_flag=None,
+                lr_dev=None):
+    _chk(p, g, buf, counter, skip_flag, lr_dev)
     call("srhip_sgd_step_dc", _p(p), _p(g), _p(buf), p.numel(), _p(counter), float(lr), float(momentum),
-         float(wd), int(nesterov), float(gscale), _p(skip_flag), _st())
+         float(wd), int(nesterov), float(gscale), _p(skip_flag), _p(lr_dev), _st())
 
 
 def nonfinite_flag(x, flag):

@@ -77,6 +77,8 @@ class Optimizer:
         # (the reference skips backward and optimizer.step() for that batch only,
         # model_plain.py:344-346) -- and the host must not sync to find out
         self.applied = torch.zeros(1, dtype=torch.int32, device=flat.flat.device)
+        # the learning rate as the kernels read it (device scalar: a captured step replays with the current one)
+        self.lr_dev = torch.zeros(1, device=flat.flat.device)
 
     @property
     def lr(self):
@@ -90,16 +92,24 @@ class Optimizer:
             return self.base_lr * s["gamma"] ** k
         raise NotImplementedError(s["type"])
 
-    def step(self, gscale=1.0, skip_flag=None):
+    def push_lr(self):
+        """current learning rate -> device scalar (a fill kernel with the value as its argument: no copy, no sync)."""
+        self.lr_dev.fill_(self.lr)
+
+    def step(self, gscale=1.0, skip_flag=None, host_side=True):
+        """host_side=False: enqueue the kernels only (graph capture); the caller advances the host counters and
+        pushes the learning rate before every replay."""
         fp = self.fp
-        self.step_count += 1
+        if host_side:
+            self.step_count += 1
+            self.push_lr()
         ops.optim_tick(skip_flag, self.applied)          # applied += (flag == 0), on the device
         if self.kind == "adam":
             ops.adam_step_dc(fp.flat, fp.grad, self.m, self.v, self.applied, self.lr, self.betas[0],
-                             self.betas[1], self.eps, self.wd, gscale, skip_flag)
+                             self.betas[1], self.eps, self.wd, gscale, skip_flag, self.lr_dev)
         elif self.kind == "sgd":
             ops.sgd_step_dc(fp.flat, fp.grad, self.m, self.applied, self.lr, self.momentum, self.wd,
-                            self.nesterov, gscale, skip_flag)
+                            self.nesterov, gscale, skip_flag, self.lr_dev)
         else:
             raise NotImplementedError(self.kind)
 
@@ -252,9 +262,45 @@ class TrainStep:
                 raise NotImplementedError(t[0])
         return self.dy
 
+    def step_graph(self, lr_img, hr_img):
+        """The same optimisation step replayed from a hipGraph: the ~330 launches of a SwinIR step are
+        captured once per (batch, shape) -- every buffer is persistent, DropPath masks are drawn on the
+        device by captured generator ops, the learning rate and the applied-step counter live in device
+        memory -- and replayed with ONE host call per step (the eager step costs the CPU ~8 ms of launch
+        calls).  The first call for a shape runs one eager step (it creates the buffers), the second
+        captures.  Results are those of step() bit for bit."""
+        if self.ddp:
+            raise NotImplementedError("step_graph: the RCCL bucket path is not captured; use step() under data parallelism")
+        key = (tuple(lr_img.shape), tuple(hr_img.shape))
+        st = getattr(self, "_graph", None)
+        if st is None or st["key"] != key:
+            out = self.step(lr_img, hr_img)               # eager: allocates every buffer of this shape
+            self._graph = {"key": key, "g": None, "lr": lr_img.clone(), "hr": hr_img.clone()}
+            return out
+        st["lr"].copy_(lr_img)
+        st["hr"].copy_(hr_img)
+        if st["g"] is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue(st["lr"], st["hr"], None, host_side=False)
+            st["g"] = g
+        self.opt.step_count += 1
+        self.opt.push_lr()
+        st["g"].replay()
+        self.opt.scheduler_step()
+        self.net.weights_changed()
+        return self.loss_buf
+
     def step(self, lr_img, hr_img, dp=None):
         """One optimisation step.  Returns the device tensor [total, term1, ...]
         (no host sync here; read it when needed)."""
+        out = self._enqueue(lr_img, hr_img, dp, host_side=True)
+        self.opt.scheduler_step()
+        self.net.weights_changed()
+        return out
+
+    def _enqueue(self, lr_img, hr_img, dp, host_side):
         net = self.net
         xi, h, w = net.prepare_input(lr_img)
         assert (h, w) == tuple(xi.shape[1:]), \
@@ -280,9 +326,7 @@ class TrainStep:
             if t[0] == "w_sparsity":         # x world because the optimizer divides the all-reduced sum by it
                 ops.l1_sparsity(self.fp.flat, t[1] * self.world, self.fp.grad, self._sink)
         torch.maximum(self.sticky, self.flag, out=self.sticky)
-        self.opt.step(gscale=1.0 / self.world, skip_flag=self.flag)
-        self.opt.scheduler_step()
-        net.weights_changed()
+        self.opt.step(gscale=1.0 / self.world, skip_flag=self.flag, host_side=host_side)
         return self.loss_buf
 
     def loss_values(self):

@@ -195,3 +195,57 @@ def test_pixelshuffle_upsampler_vs_reference_golden_and_oracle(SwinIR):
         worst = max(worst, (k, e), key=lambda t: t[1])
     print("pixelshuffle README x8: worst grad", worst)
     assert worst[1] <= 1e-4, worst      # bias sums over 262144 pixels: fp32 summation order (see g20)
+
+
+def test_step_graph_replays_the_eager_step_bit_for_bit(SwinIR):
+    """TrainStep.step_graph (one hipGraph replay per step) against TrainStep.step (~70 launches for this net):
+    20 steps from the same weights on a changing batch, SGD-Nesterov with a MyStepLR schedule that halves the rate
+    every 3 iterations (the device-side learning rate must follow it) -- identical loss trajectories and
+    parameters, bit for bit; then the README configuration at B=8: the host spends < 2 ms per step."""
+    import time
+    from srhip.train import TrainStep, Optimizer
+    cfg = O.swinir_config(upscale=8, in_chans=1, img_size=16, window_size=8, depths=(2, 2), embed_dim=60,
+                          num_heads=(6, 6), mlp_ratio=2, drop_path_rate=0.0)
+    sd0 = O.trained_like_(O.swinir_init_state_dict(cfg, seed=81), 82, lin_scale=3.0)
+    gen = torch.Generator().manual_seed(83)
+    batches = [(torch.rand(2, 1, 16, 16, generator=gen).cuda(), torch.rand(2, 1, 128, 128, generator=gen).cuda())
+               for _ in range(20)]
+    runs = []
+    for mode in ("eager", "graph", "eager"):
+        net = tiny(SwinIR)
+        net.load_state_dict(sd0, strict=True)
+        net = net.cuda().train()
+        ts = TrainStep(net, [("l1", 1.0)])
+        ts.opt = Optimizer(ts.fp, "sgd", lr=0.05, momentum=0.9, nesterov=True, wd=0.0,
+                           scheduler={"type": "MyStepLR", "step_size": 3, "gamma": 0.5, "min_lr": 1e-4})
+        losses = []
+        for lr_img, hr_img in batches:
+            (ts.step if mode == "eager" else ts.step_graph)(lr_img, hr_img)
+            losses.append(ts.loss_buf.clone())
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses).cpu(), ts.fp.flat.clone().cpu(), ts.opt.lr))
+    assert runs[1][2] == runs[0][2] and runs[0][2] < 0.05 / 32
+    assert torch.equal(runs[0][0], runs[1][0]), (runs[0][0][:, 0] - runs[1][0][:, 0]).abs().max()
+    # parameters: equal up to what two EAGER runs differ by (the LayerNorm affine gradients are summed with
+    # float atomics, whose order is not fixed)
+    d_graph = (runs[0][1] - runs[1][1]).abs().max().item()
+    d_eager = (runs[0][1] - runs[2][1]).abs().max().item()
+    print(f"step_graph vs step: max |param diff| {d_graph:.2e}; step vs step (second eager run): {d_eager:.2e}")
+    assert d_graph <= max(2.0 * d_eager, 1e-7), (d_graph, d_eager)
+    assert runs[0][0][0, 1] != runs[0][0][-1, 1]          # it did train
+    # README configuration, B = 8, DropPath live (masks drawn by captured generator ops): host time per step
+    net = readme(SwinIR).cuda().train()
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=0.01, momentum=0.9, nesterov=True, wd=0.0)
+    lr_img, hr_img = torch.rand(8, 1, 64, 64).cuda(), torch.rand(8, 1, 512, 512).cuda()
+    for _ in range(3):
+        ts.step_graph(lr_img, hr_img)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ts.step_graph(lr_img, hr_img)
+    host_ms = (time.perf_counter() - t0) * 100.0
+    torch.cuda.synchronize()
+    total_ms = (time.perf_counter() - t0) * 100.0
+    print(f"step_graph README B=8: host {host_ms:.2f} ms per step, device {total_ms:.2f} ms per step")
+    assert host_ms < 2.0 and torch.isfinite(ts.loss_buf).all()
