@@ -307,6 +307,15 @@ typedef struct {
   int H, W, y0, x0, mode;
 } srhip_patch_job;
 int srhip_patch_gather(const srhip_patch_job* jobs, int B, int P, float* out, void* stream);
+/* ROI-weighted patch origins, the 'roi' sampler of the training crops (PatchSampler._roi,
+ * dataset_dpsr.py:330-369): origin (r, c) of the (H-P) x (W-P) candidates has probability
+ * proportional to exp(5*roi) + 1, roi = img[r + P/2][c + P/2] >= threshold.  One uniform in [0,1)
+ * (fp64) per patch selects the origin by the inverse CDF in row-major order; origins[b] = {row, col}
+ * feeds srhip_patch_gather (y0, x0).  jobs[b].{img,H,W} are used; workspace: srhip_roi_sample_ws(B,
+ * max_rows) ints with max_rows >= H - P of every tile. */
+long srhip_roi_sample_ws(int B, int max_rows);
+int srhip_roi_sample(const srhip_patch_job* jobs, int B, int P, int threshold, const double* uniforms,
+                     int* workspace, int max_rows, int* origins, void* stream);
 
 /* ---- metrics (dlib/utils/utils_image.py:369-372,843-1007,618-653,1010-1198;
  *      dlib/utils/utils_trainer.py:961-1032) ----------------------------------- */

@@ -430,6 +430,54 @@ def g_swinir_pixelshuffle():
     npz("g20_swinir_pixelshuffle", **arrs)
 
 
+# ---------------------------------------------------------------- G21 training-crop sampler
+def g_patch_sampler():
+    """PatchSampler (dataset_dpsr.py:293-507): the probabilities the reference hands to
+    np.random.multinomial for the 'roi' style (captured), its seeded draws, and seeded 'uniform' draws."""
+    print("G21 PatchSampler")
+    import random
+    import types
+    import matplotlib.style
+    matplotlib.style.use = lambda *a, **k: None
+    sk, skf = types.ModuleType("skimage"), types.ModuleType("skimage.filters")
+    skf.threshold_otsu = None
+    sk.filters = skf
+    sys.modules.setdefault("skimage", sk)
+    sys.modules.setdefault("skimage.filters", skf)
+    from dlib.datasets.dataset_dpsr import PatchSampler as RefSampler
+    rng = np.random.RandomState(9)
+    out = {}
+    for name, (h, w, P, th) in {"a": (40, 52, 16, 7), "b": (33, 29, 9, 120), "c": (64, 64, 32, 4)}.items():
+        img = np.kron(rng.rand(h // 4 + 1, w // 4 + 1), np.ones((4, 4)))[:h, :w]
+        img = np.clip(np.round(img * (30 if name != "b" else 255)), 0, 255).astype(np.uint8)
+        ref = RefSampler(ref_c.SAMPLE_ROI, P, 256, ref_c.TH_FIX, float(th))
+        seen = []
+        real = np.random.multinomial
+        np.random.multinomial = lambda n, pvals, size=None: (seen.append(np.array(pvals)), real(n, pvals, size))[1]
+        try:
+            np.random.seed(100 + h)
+            draws = np.array([ref(img, False)[:2] for _ in range(40)])
+        finally:
+            np.random.multinomial = real
+        pm = O.roi_origin_pmf(img, th, P)
+        assert pm.shape == (h - P, w - P) and np.array_equal(pm.reshape(-1), seen[0]), "pmf != reference pvals"
+        assert all(np.array_equal(seen[0], q) for q in seen)
+        # the inverse-CDF form draws from the same distribution: its CDF steps are the reference's pvals
+        for u in (0.0, 0.25, 0.5, 0.999999):
+            r0, c0 = O.roi_origin_from_uniform(img, th, P, u)
+            cdf = np.cumsum(pm.reshape(-1))
+            i = r0 * (w - P) + c0
+            assert (cdf[i - 1] if i else 0.0) - 1e-12 <= u <= cdf[i] + 1e-12, (name, u)
+        uni = RefSampler(ref_c.SAMPLE_UNIF, P, 256, ref_c.TH_FIX, float(th))
+        random.seed(200 + h)
+        udraws = np.array([uni(img, False)[:2] for _ in range(40)])
+        out.update({f"{name}/img": img, f"{name}/cfg": np.array([P, th, 100 + h, 200 + h]), f"{name}/roi_draws": draws,
+                    f"{name}/uniform_draws": udraws, f"{name}/pvals": seen[0].astype(np.float64),
+                    f"{name}/roi_u8": ref(img, True)[2]})
+        print(f"  ok {name}: {h}x{w} P={P} th={th}: pmf == reference pvals ({(img >= th).mean():.2f} of the tile is ROI)")
+    npz("g21_patch_sampler", **out)
+
+
 # ---------------------------------------------------------------- G19 eval.py experiment folder
 def g_eval_fixture():
     """A reference-format experiment directory + dataset + folds, and what the REFERENCE's own
@@ -1078,7 +1126,7 @@ def g_optim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
-            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle]
+            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:
         if not only or g.__name__ in only:

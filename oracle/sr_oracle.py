@@ -644,6 +644,35 @@ def master_loss(pred: Tensor, target: Tensor, terms: Sequence[tuple],
     return total, [total] + parts
 
 
+def roi_origin_pmf(img_u8, threshold: int, psize: int):
+    """PatchSampler._roi (dataset_dpsr.py:330-347): probability of every candidate origin, (H-P) x (W-P):
+    proportional to exp(5 * roi) + 1 with roi = img[r + P//2][c + P//2] >= threshold."""
+    import numpy as np
+    h, w = img_u8.shape
+    lo, hi = int(psize / 2), math.ceil(psize / 2)
+    roi = (img_u8 >= threshold).astype(np.float64)[lo:h - hi, lo:w - hi]
+    tmp = np.exp(roi * 5.)
+    return ((tmp.flatten() + 1.) / (tmp + 1.).sum()).reshape(roi.shape)
+
+
+def roi_origin_from_uniform(img_u8, threshold: int, psize: int, u: float):
+    """Inverse CDF of roi_origin_pmf in row-major order: the first origin whose cumulative WEIGHT
+    W1 * (#roi origins so far) + W0 * (#others so far) exceeds u * (total weight), W1 = e^5 + 1, W0 = 2
+    (counts are exact integers, so the device kernel can form the same fp64 numbers)."""
+    import numpy as np
+    h, w = img_u8.shape
+    lo, hi = int(psize / 2), math.ceil(psize / 2)
+    roi = (img_u8 >= threshold)[lo:h - hi, lo:w - hi].reshape(-1)
+    w1, w0 = 149.4131591025766, 2.0
+    assert w1 == math.exp(5.) + 1.
+    c1 = np.cumsum(roi.astype(np.int64))
+    c0 = np.arange(1, roi.size + 1, dtype=np.int64) - c1
+    cum = w1 * c1.astype(np.float64) + w0 * c0.astype(np.float64)
+    i = int(np.searchsorted(cum, u * cum[-1], side="right"))
+    i = min(i, roi.size - 1)
+    return i // (w - psize), i % (w - psize)
+
+
 def augment_index(mode: int, i, j, P: int):
     """Source position inside a P x P patch of output position (i, j) under augment_img mode
     0..7 (utils_image.py:469-487: rot90 = counter-clockwise on axes (0, 1), flipud = rows reversed)."""

@@ -43,7 +43,80 @@ __global__ void __launch_bounds__(256) k_patch_gather(PatchJobs jobs, int P, flo
   }
 }
 
+// ROI-weighted patch origins (PatchSampler._roi, dataset_dpsr.py:330-369): over the (H-P) x (W-P)
+// candidate origins, origin (r, c) has weight exp(5 * roi) + 1 with roi = img[r + P/2][c + P/2] >= th,
+// i.e. e^5 + 1 on the region of interest and 2 elsewhere; the reference draws one multinomial
+// sample from the normalised weights.  Here: inverse CDF of the SAME probabilities in row-major
+// order from one uniform per patch -- cum(i) = W1 * (#roi origins <= i) + W0 * (#others <= i) in
+// fp64, the origin is the first i with cum(i) > u * cum(last).  One block per patch: row counts
+// in parallel, then one lane walks the row prefix and the chosen row.
+constexpr double ROI_W1 = 149.4131591025766, ROI_W0 = 2.0;      // exp(5) + 1, exp(0) + 1
+struct RoiJobs {
+  struct J { const unsigned char* img; int H, W; } j[MAXJOBS];
+};
+__global__ void __launch_bounds__(256) k_roi_sample(RoiJobs jobs, int P, int th, const double* __restrict__ u,
+                                                    int* __restrict__ rowcnt, int max_rows,
+                                                    int* __restrict__ origin) {
+  const RoiJobs::J J = jobs.j[blockIdx.x];
+  const int Hc = J.H - P, Wc = J.W - P, half = P / 2;
+  int* cnt = rowcnt + (long)blockIdx.x * max_rows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < Hc; r += 4) {                      // one wave per row
+    const unsigned char* row = J.img + (long)(r + half) * J.W + half;
+    int n = 0;
+    for (int c = lane; c < Wc; c += 64) n += row[c] >= th;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if (lane == 0) cnt[r] = n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long n1 = 0;
+    for (int r = 0; r < Hc; ++r) n1 += cnt[r];
+    const long n0 = (long)Hc * Wc - n1;
+    const double target = u[blockIdx.x] * (ROI_W1 * (double)n1 + ROI_W0 * (double)n0);
+    long c1 = 0, c0 = 0;
+    int R = Hc - 1;
+    for (int r = 0; r < Hc; ++r) {                           // first row whose cumulative weight exceeds the target
+      const long a1 = c1 + cnt[r], a0 = c0 + (Wc - cnt[r]);
+      if (ROI_W1 * (double)a1 + ROI_W0 * (double)a0 > target) { R = r; break; }
+      c1 = a1; c0 = a0;
+    }
+    const unsigned char* row = J.img + (long)(R + half) * J.W + half;
+    int C = Wc - 1;
+    for (int c = 0; c < Wc; ++c) {
+      if (row[c] >= th) ++c1; else ++c0;
+      if (ROI_W1 * (double)c1 + ROI_W0 * (double)c0 > target) { C = c; break; }
+    }
+    origin[2 * blockIdx.x] = R;
+    origin[2 * blockIdx.x + 1] = C;
+  }
+}
+
 }  // namespace
+
+extern "C" long srhip_roi_sample_ws(int B, int max_rows) { return (long)B * max_rows; }
+
+extern "C" int srhip_roi_sample(const srhip_patch_job* jobs, int B, int P, int threshold, const double* uniforms,
+                                int* workspace, int max_rows, int* origins, void* stream) {
+  SR_REQUIRE(B > 0 && P > 0 && uniforms && workspace && origins, "roi_sample: empty batch / NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (int b0 = 0; b0 < B; b0 += MAXJOBS) {
+    const int nb = B - b0 < MAXJOBS ? B - b0 : MAXJOBS;
+    RoiJobs rj;
+    for (int b = 0; b < nb; ++b) {
+      const srhip_patch_job& q = jobs[b0 + b];
+      SR_REQUIRE(q.img != nullptr && q.H > P && q.W > P, "roi_sample: job %d: tile %dx%d must exceed the patch %d",
+                 b0 + b, q.H, q.W, P);
+      SR_REQUIRE(q.H - P <= max_rows, "roi_sample: job %d: %d candidate rows > workspace rows %d", b0 + b, q.H - P, max_rows);
+      rj.j[b].img = q.img; rj.j[b].H = q.H; rj.j[b].W = q.W;
+    }
+    hipLaunchKernelGGL(k_roi_sample, dim3(nb), dim3(256), 0, st, rj, P, threshold, uniforms + b0,
+                       workspace + (long)b0 * max_rows, max_rows, origins + 2 * b0);
+  }
+  SR_LAUNCH_CHECK("roi_sample");
+  return 0;
+}
 
 extern "C" int srhip_patch_gather(const srhip_patch_job* jobs, int B, int P, float* out, void* stream) {
   SR_REQUIRE(B > 0 && P > 0, "patch_gather: empty batch");

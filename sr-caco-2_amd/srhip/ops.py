@@ -714,6 +714,29 @@ def patch_gather(tiles, ids, y0, x0, modes, P, out=None):
     return out
 
 
+def roi_sample(tiles, ids, P, threshold, uniforms):
+    """Patch origins [B,2] (row, col; int32, on the device) drawn with the reference's ROI weighting
+    (PatchSampler._roi, dataset_dpsr.py:330-369) from ``uniforms`` (float64 [B] in [0,1), e.g. torch.rand on the
+    device): the sampling step of the training crops without a host round trip."""
+    B = len(ids)
+    dev = tiles[ids[0]].device
+    if not (uniforms.is_cuda and uniforms.dtype == torch.float64 and uniforms.numel() == B):
+        raise ValueError("roi_sample: uniforms must be a float64 CUDA tensor with one entry per patch")
+    jobs = (_PatchJob * B)()
+    rows = 1
+    for b in range(B):
+        t = tiles[ids[b]]
+        if not (t.is_cuda and t.dtype == torch.uint8 and t.dim() == 2 and t.is_contiguous()):
+            raise ValueError("roi_sample: tiles must be contiguous uint8 CUDA tensors [H, W]")
+        jobs[b].img, jobs[b].H, jobs[b].W = t.data_ptr(), t.shape[0], t.shape[1]
+        rows = max(rows, t.shape[0] - P)
+    ws = SCRATCH.get("roi_ws", lib.srhip_roi_sample_ws(B, rows), torch.int32, dev)
+    out = torch.empty(B, 2, dtype=torch.int32, device=dev)
+    call("srhip_roi_sample", ctypes.addressof(jobs), B, P, int(threshold), _p(uniforms.contiguous()), _p(ws), rows,
+         _p(out), _st())
+    return out
+
+
 def train_batch(hr_tiles, lr_tiles, ids, y0, x0, modes, patch_size, sf):
     """The batch dict the reference's trainer feeds ModelPlain (keys l_im, h_im; dataset_dpsr.py:981-1005)
     from resident tiles: HR crop at (y0, x0), LR crop at (y0 // sf, x0 // sf) of size patch_size // sf,

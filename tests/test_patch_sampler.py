@@ -1,0 +1,92 @@
+"""Training-crop sampler (reference dlib/datasets/dataset_dpsr.py:293-507) against g21,
+which holds what the REFERENCE's PatchSampler did: the probability vector it handed to
+np.random.multinomial, its seeded 'roi' and 'uniform' draws, its ROI mask.
+
+CPU: the host mirror reproduces the reference's draws from the same seeds; the oracle's probability
+map equals the reference's vector; the inverse-CDF form has those probabilities as its CDF steps.
+GPU: srhip_roi_sample picks, for every uniform, exactly the origin of the oracle's inverse CDF, and
+its empirical distribution over 200k draws is the reference's."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import sr_oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load():
+    z = np.load(os.path.join(G, "g21_patch_sampler.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def test_host_sampler_reproduces_reference_draws():
+    from dlib.datasets.dataset_dpsr import PatchSampler, roi_probabilities, SAMPLE_ROI, SAMPLE_UNIF, TH_FIX, TH_AUTO
+    g = load()
+    for name in "abc":
+        img = g[f"{name}/img"]
+        P, th, seed_np, seed_py = [int(v) for v in g[f"{name}/cfg"]]
+        pm = O.roi_origin_pmf(img, th, P)
+        assert np.array_equal(pm.reshape(-1), g[f"{name}/pvals"])
+        assert np.array_equal(roi_probabilities(img, float(th), P), pm)
+        s = PatchSampler(SAMPLE_ROI, P, 256, TH_FIX, float(th))
+        np.random.seed(seed_np)
+        draws = np.array([s(img, False)[:2] for _ in range(40)])
+        assert np.array_equal(draws, g[f"{name}/roi_draws"])
+        assert np.array_equal(s(img, True)[2], g[f"{name}/roi_u8"])
+        u = PatchSampler(SAMPLE_UNIF, P, 256, TH_FIX, float(th))
+        random.seed(seed_py)
+        assert np.array_equal(np.array([u(img, False)[:2] for _ in range(40)]), g[f"{name}/uniform_draws"])
+        # inverse CDF: origin i is chosen exactly for u in [cdf(i-1), cdf(i))
+        cdf = np.cumsum(pm.reshape(-1))
+        for uu in np.random.RandomState(1).rand(200):
+            r0, c0 = O.roi_origin_from_uniform(img, th, P, float(uu))
+            i = r0 * (img.shape[1] - P) + c0
+            assert (cdf[i - 1] if i else 0.0) - 1e-12 <= uu <= cdf[i] + 1e-12
+    with pytest.raises(NotImplementedError):
+        PatchSampler(SAMPLE_ROI, 8, 256, TH_AUTO, 0.)(g["a/img"], False)
+    with pytest.raises(NotImplementedError):
+        PatchSampler("edt", 8, 256, TH_FIX, 3.)
+
+
+@pytest.mark.gpu
+def test_device_roi_sampler_matches_oracle_and_reference_distribution():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from srhip import ops
+    from dlib.datasets.dataset_dpsr import DeviceRoiSampler
+    g = load()
+    tiles = [torch.from_numpy(g[f"{n}/img"]).cuda() for n in "abc"]
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for k, name in enumerate("abc"):
+        img = g[f"{name}/img"]
+        P, th = int(g[f"{name}/cfg"][0]), int(g[f"{name}/cfg"][1])
+        u = torch.rand(4096, dtype=torch.float64, device="cuda", generator=gen)
+        u[:4] = torch.tensor([0.0, 0.5, 1.0 - 2.0 ** -53, 0.25], dtype=torch.float64)
+        org = ops.roi_sample(tiles, [k] * 4096, P, th, u).cpu().numpy()
+        want = np.array([O.roi_origin_from_uniform(img, th, P, float(v)) for v in u.cpu().numpy()])
+        assert np.array_equal(org, want), name                      # bit-exact against the oracle's inverse CDF
+    # mixed batch through the sampler object, origins stay on the device and feed the gather
+    s = DeviceRoiSampler(tiles, psize=8, threshold=7, seed=3)
+    ids = [0, 2, 1, 0, 2, 2, 1, 0]
+    org, u = s.sample(ids)
+    for b, t in enumerate(ids):
+        assert tuple(org[b].tolist()) == O.roi_origin_from_uniform(g[f"{'abc'[t]}/img"], 7, 8, float(u[b]))
+    o = org.cpu().tolist()
+    patch = ops.patch_gather(tiles, ids, [v[0] for v in o], [v[1] for v in o], [0] * 8, 8)
+    assert patch.shape == (8, 1, 8, 8)
+    # distribution: 200k draws on the small tile against the reference's probability vector
+    img, P, th = g["b/img"], int(g["b/cfg"][0]), int(g["b/cfg"][1])
+    n = 200000
+    u = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen)
+    org = ops.roi_sample(tiles, [1] * n, P, th, u).cpu().numpy()
+    Wc = img.shape[1] - P
+    freq = np.bincount(org[:, 0] * Wc + org[:, 1], minlength=g["b/pvals"].size) / n
+    p = g["b/pvals"]
+    assert np.abs(freq - p).max() <= 6.0 * np.sqrt(p.max() / n)      # 6 sigma of the largest cell
+    roi_mass = p[(O.roi_origin_pmf(img, th, P).reshape(-1) > p.min() * 2)].sum()
+    got = freq[(O.roi_origin_pmf(img, th, P).reshape(-1) > p.min() * 2)].sum()
+    assert abs(got - roi_mass) <= 0.005
