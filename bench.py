@@ -253,7 +253,7 @@ def worker(args):
         dt = t.item()
     loss = ts.loss_values()[0]
     # secondary figure, outside the timed region: forward-only patches/s of the same net and batch
-    eval_pps = None
+    eval_pps = eval_amp_pps = None
     if rank == 0 and world == 1:
         net.eval()
         with torch.no_grad():
@@ -265,6 +265,17 @@ def worker(args):
                 net(lr_img)
             torch.cuda.synchronize()
             eval_pps = args.batch * 10 / (time.perf_counter() - t1)
+            # config 5: reduced-precision inference (one bf16 product; PSNR-gated in tests/test_gpu_amp.py)
+            net.amp = True
+            for _ in range(2):
+                net(lr_img)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                net(lr_img)
+            torch.cuda.synchronize()
+            eval_amp_pps = args.batch * 10 / (time.perf_counter() - t1)
+            net.amp = False
         net.train()
     if rank == 0:
         patches = args.batch * world * args.steps
@@ -282,7 +293,7 @@ def worker(args):
             "config": {"workload": f"{desc}, fwd + {args.loss} + bwd + {opt_kind}",
                        "global_batch": args.batch * world, "batch_per_gpu": args.batch,
                        "parallelism": f"dp{world}", "final_loss": loss, "hip_graph": bool(use_graph),
-                       "eval_patches_per_s_one_gpu": eval_pps,
+                       "eval_patches_per_s_one_gpu": eval_pps, "eval_amp_patches_per_s_one_gpu": eval_amp_pps,
                        "matmul": ("bf16x3 split MFMA: f32 operands split into 3 bf16 parts, 6 products, "
                                   "f32 accumulate (f32-accurate)") if bx else "f32 MFMA"},
             # whole step against both rooflines: algorithmic bytes / flops x 3 (fwd + bwd) x patches/s

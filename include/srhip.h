@@ -28,6 +28,14 @@ extern "C" {
 
 const char* srhip_last_error(void);
 int srhip_abi_version(void);
+/* Arithmetic of the bf16x3 contractions (srhip_gemm_nt_bx3, srhip_conv3x3_nhwc_bx3), process-wide:
+ *   0 (default)  f32-accurate: six bf16 products of the three-way split operands
+ *   1            reduced precision for INFERENCE: one bf16 product of the leading planes, f32
+ *                accumulation -- the role of the reference's --amp autocast at evaluation time
+ *                (model_plain.py:322-327, eval_all.sh); outputs differ from mode 0 at the 1e-3
+ *                relative level (gate: PSNR within 0.01 dB).  Training always runs mode 0. */
+int srhip_set_matmul_mode(int mode);
+int srhip_get_matmul_mode(void);
 
 /* ---- dense contractions on the exact-f32 MFMA ------------------------------ */
 

@@ -18,7 +18,15 @@ int sr_fail(int code, const char* fmt, ...) {
 extern "C" {
 
 const char* srhip_last_error(void) { return g_err; }
-int srhip_abi_version(void) { return 5; }
+int srhip_abi_version(void) { return 6; }
+
+static int g_matmul_mode = 0;
+int srhip_set_matmul_mode(int mode) {
+  if (mode != 0 && mode != 1) return sr_fail(-22, "set_matmul_mode: mode %d (0 = f32-accurate bf16x3, 1 = single bf16 product)", mode);
+  g_matmul_mode = mode;
+  return 0;
+}
+int srhip_get_matmul_mode(void) { return g_matmul_mode; }
 
 int srhip_gemm_nt(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
                   long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
@@ -189,3 +197,5 @@ int srhip_conv3x3_wgrad_bx3(const float* dY, long lddy, const float* X, long ldx
 }
 
 }  // extern "C"
+
+int sr_matmul_mode() { return g_matmul_mode; }

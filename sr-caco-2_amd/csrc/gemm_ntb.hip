@@ -46,14 +46,17 @@ __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int WM, int WN, bool CONV>
+// AMP = true: reduced-precision inference (the reference's --amp autocast, model_plain.py:322-327): ONE bf16
+// product of the leading planes instead of six -- only plane 0 of either operand is staged and read.
+template <int WM, int WN, bool CONV, bool AMP = false>
 __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
+  constexpr int NPL = AMP ? 1 : 3;
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int TROWS = BM / 16;
   constexpr int AROWS = CONV ? (TROWS + 2) * 18 : BM;
   constexpr int A_N = AROWS * 8;                 // float4 slots per chunk
   constexpr int A_IT = (A_N + 255) / 256;
-  constexpr int B_N = 3 * BN * 4;                // 16-byte slots per chunk (3 planes)
+  constexpr int B_N = NPL * BN * 4;              // 16-byte slots per chunk (3 planes; AMP: the leading one)
   constexpr int B_IT = (B_N + 255) / 256;
   constexpr int A_PLANE = AROWS * PITCH, B_PLANE = BN * PITCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -159,8 +162,10 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
         split3_pair(v.z, v.w, h1, m1, l1);
         unsigned char* dst = As + (idx >> 3) * PITCH + (idx & 7) * 8;
         *(u32x2*)(dst) = u32x2{h0, h1};
-        *(u32x2*)(dst + A_PLANE) = u32x2{m0_, m1};
-        *(u32x2*)(dst + 2 * A_PLANE) = u32x2{l0, l1};
+        if (!AMP) {
+          *(u32x2*)(dst + A_PLANE) = u32x2{m0_, m1};
+          *(u32x2*)(dst + 2 * A_PLANE) = u32x2{l0, l1};
+        }
       }
     }
   };
@@ -243,23 +248,27 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
           fa[i][pl] = *(const u32x4*)(As + pl * A_PLANE + a_off[i] + toff + s * 32);
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
           fb[j][pl] = *(const u32x4*)(Bs + pl * B_PLANE + b_off[j] + s * 32);
       // small terms first; term-outer so that consecutive MFMAs hit different tiles
 #define SR_TERM(PA, PB)                                                              \
   _Pragma("unroll") for (int i = 0; i < WM; ++i)                                     \
   _Pragma("unroll") for (int j = 0; j < WN; ++j)                                     \
     acc[i][j] = mfma_bf(fa[i][PA], fb[j][PB], acc[i][j]);
-      SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      if constexpr (AMP) {
+        SR_TERM(0, 0)
+      } else {
+        SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      }
 #undef SR_TERM
     }
     {
-      constexpr int NMFMA = (BKB / 16) * 6 * WM * WN;
+      constexpr int NMFMA = (BKB / 16) * (AMP ? 1 : 6) * WM * WN;
       constexpr int PER = NMFMA / B_IT > 0 ? NMFMA / B_IT : 1;
 #pragma unroll
       for (int g = 0; g < B_IT; ++g) {
@@ -307,14 +316,14 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
   }
 }
 
-template <int WM, int WN, bool CONV>
+template <int WM, int WN, bool CONV, bool AMP = false>
 int launch_ntb(const NtArgs& p, hipStream_t st) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int AROWS = CONV ? (BM / 16 + 2) * 18 : BM;
   constexpr int LDS = 3 * (AROWS + BN) * PITCH;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_ntb<WM, WN, CONV>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_ntb<WM, WN, CONV, AMP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return sr_fail(-5, "k_ntb: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
     attr_set = true;
@@ -322,7 +331,7 @@ int launch_ntb(const NtArgs& p, hipStream_t st) {
   dim3 grid;
   if (CONV) grid = dim3(p.tiles_x * p.tiles_y * p.batch, sr_cdiv(p.N, p.n_tile));
   else grid = dim3(sr_cdiv(p.M, BM), sr_cdiv(p.N, p.n_tile));
-  hipLaunchKernelGGL((k_ntb<WM, WN, CONV>), grid, dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((k_ntb<WM, WN, CONV, AMP>), grid, dim3(256), LDS, st, p);
   SR_LAUNCH_CHECK("k_ntb");
   return 0;
 }
@@ -352,6 +361,15 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
     p.tiles_x = sr_cdiv(p.Wd, 16);
     p.tiles_y = sr_cdiv(p.H, wm == 2 ? 8 : 4);
     p.xcd_order = ntb_env("SRHIP_CONV_XCD", 1);
+  }
+  if constexpr (CONV) {       // reduced-precision inference (srhip_set_matmul_mode(1)): conv kernels only here,
+    if (p.amp) {              // GEMMs take gemm_ntp.hip's AMP instantiation
+#define SR_NTB_AMP(WM_, WN_) \
+  if (wm == WM_ && wn == WN_) return launch_ntb<WM_, WN_, true, true>(p, st);
+      SR_NTB_AMP(1, 1) SR_NTB_AMP(1, 2) SR_NTB_AMP(1, 3)
+      SR_NTB_AMP(2, 1) SR_NTB_AMP(2, 2) SR_NTB_AMP(2, 3)
+#undef SR_NTB_AMP
+    }
   }
 #define SR_NTB_CASE(WM_, WN_) \
   if (wm == WM_ && wn == WN_) return launch_ntb<WM_, WN_, CONV>(p, st);
@@ -410,6 +428,8 @@ int sr_gemm_ntb(NtArgs& p, hipStream_t st) {
                ((size_t)p.C & 15) == 0 && ntb_env("SRHIP_NTB_WIDE", 1);
   // K <= 192 at 180-column widths (the K = 180 Linears of a Swin block): weights resident in registers,
   // persistent blocks, only A through LDS (gemm_ntr.hip)
+  p.amp = sr_matmul_mode();
+  if (p.amp && p.epi != 5) return sr_gemm_ntp(p, st);
   if (sr_gemm_ntr_ok(p)) return sr_gemm_ntr(p, st);
   // 64-row tiles (every case but very tall problems with narrow N, which take the 128-row
   // tiles of this file): the 16-wide-stage kernel of gemm_ntp.hip
@@ -442,6 +462,7 @@ int sr_conv3x3_ntb(NtArgs& p, hipStream_t st) {
   p.M = p.batch * p.H * p.Wd;
   p.Kp = sr_kp(p.K);
   p.dbg = ntb_env("SRHIP_NT_DBG", 0);      // ablation / stamp bits, 0 in production
+  p.amp = sr_matmul_mode();
   SR_REQUIRE((long)p.M * p.lda < (1L << 29) && 54L * p.N * p.Kp < (1L << 31),
              "conv3x3_bx3: operand larger than 2 GiB (32-bit staging offsets)");
   return dispatch_ntb<true>(p, st);

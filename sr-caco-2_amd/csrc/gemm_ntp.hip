@@ -42,10 +42,12 @@ constexpr int ntp_lds(int wn) {
   return stages > wide ? stages : wide;
 }
 
-template <int WN>
+// AMP = true: reduced-precision inference (one bf16 product of the leading planes; see gemm_ntb.hip)
+template <int WN, bool AMP = false>
 __global__ void __launch_bounds__(256, 2) k_ntp(NtArgs p) {
+  constexpr int NPL = AMP ? 1 : 3;
   constexpr int BN = 64 * WN;
-  constexpr int B_N = 3 * BN * 2;                // 16-byte W units per stage (3 planes)
+  constexpr int B_N = NPL * BN * 2;              // 16-byte W units per stage (3 planes; AMP: the leading one)
   constexpr int B_IT = (B_N + 255) / 256;
   constexpr int A_PLANE = BM * 32, B_PLANE = BN * 32;
   constexpr int A_STAGE = 3 * A_PLANE, B_STAGE = 3 * B_PLANE;
@@ -106,8 +108,10 @@ __global__ void __launch_bounds__(256, 2) k_ntp(NtArgs p) {
     split3_pair(v.x, v.y, h0, m0_, l0);
     split3_pair(v.z, v.w, h1, m1, l1);
     *(u32x2*)(sa + a_dst) = u32x2{h0, h1};
-    *(u32x2*)(sa + A_PLANE + a_dst) = u32x2{m0_, m1};
-    *(u32x2*)(sa + 2 * A_PLANE + a_dst) = u32x2{l0, l1};
+    if (!AMP) {
+      *(u32x2*)(sa + A_PLANE + a_dst) = u32x2{m0_, m1};
+      *(u32x2*)(sa + 2 * A_PLANE + a_dst) = u32x2{l0, l1};
+    }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it)
       if (B_N % 256 == 0 || tid + it * 256 < B_N) *(u32x4*)(sb + b_dst[it]) = rb[it];
@@ -128,15 +132,19 @@ __global__ void __launch_bounds__(256, 2) k_ntp(NtArgs p) {
     const unsigned char* sb = Bs + (c & 1) * B_STAGE;
     u32x4 fa[3], fb[WN][3];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) fa[pl] = *(const u32x4*)(sa + pl * A_PLANE + a_off);
+    for (int pl = 0; pl < NPL; ++pl) fa[pl] = *(const u32x4*)(sa + pl * A_PLANE + a_off);
 #pragma unroll
     for (int j = 0; j < WN; ++j)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fb[j][pl] = *(const u32x4*)(sb + pl * B_PLANE + b_off[j]);
+      for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = *(const u32x4*)(sb + pl * B_PLANE + b_off[j]);
     // small terms first; term-outer so that consecutive MFMAs hit different tiles
 #define SR_TERM(PA, PB) \
   _Pragma("unroll") for (int j = 0; j < WN; ++j) acc[0][j] = mfma_bf(fa[PA], fb[j][PB], acc[0][j]);
-    SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+    if constexpr (AMP) {
+      SR_TERM(0, 0)
+    } else {
+      SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+    }
 #undef SR_TERM
   };
 
@@ -195,7 +203,8 @@ template <int WN>
 int launch_ntp(const NtArgs& p, hipStream_t st) {
   constexpr int LDS = ntp_lds(WN);
   dim3 grid(sr_cdiv(p.M, BM), sr_cdiv(p.N, p.n_tile));
-  hipLaunchKernelGGL((k_ntp<WN>), grid, dim3(256), LDS, st, p);
+  if (p.amp) hipLaunchKernelGGL((k_ntp<WN, true>), grid, dim3(256), LDS, st, p);
+  else hipLaunchKernelGGL((k_ntp<WN>), grid, dim3(256), LDS, st, p);
   SR_LAUNCH_CHECK("k_ntp");
   return 0;
 }

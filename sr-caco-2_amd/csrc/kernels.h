@@ -29,6 +29,7 @@ struct NtArgs {
   int stagger;                // odd blocks sleep this many x 8128 cycles at start
   // bf16x3 path (gemm_ntb.hip): W pre-split into planes [3][(9)][N][Kp] bf16
   const unsigned short* Wb; int Kp;
+  int amp;                    // 1: one bf16 product of the leading planes (reduced-precision inference)
 };
 
 struct TnArgs {
@@ -47,6 +48,7 @@ struct TnArgs {
   int i_tile, j_tile, rows_per_slice;   // set by the dispatcher
 };
 
+int sr_matmul_mode();        // 0: f32-accurate bf16x3 | 1: single bf16 product (srhip_set_matmul_mode)
 int sr_gemm_nt(NtArgs& p, hipStream_t st);
 int sr_conv3x3_nt(NtArgs& p, hipStream_t st);
 // one job of the per-step weight preparation (device table; mirrors srhip_prep_entry)

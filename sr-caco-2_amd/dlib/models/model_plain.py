@@ -37,6 +37,9 @@ class ModelPlain:
             raise RuntimeError("ModelPlain (libsrhip) needs a GPU; there is no CPU fallback")
         self.device = torch.device(f'cuda:{dev_id}')
         self.netG = define_G(args).to(self.device)
+        # --amp: the reference trains and evaluates under autocast (model_plain.py:322-327); here training stays
+        # f32-accurate (parity gate) and evaluation takes the single-product bf16 kernels
+        self.netG.amp = bool(getattr(args, 'amp', False))
         self.schedulers = []
         self.log_dict = OrderedDict()
         self.L = self.E = self.H = self.h_per_pixel_weight = None

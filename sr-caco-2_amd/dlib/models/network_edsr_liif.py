@@ -16,6 +16,7 @@ import math
 import torch
 import torch.nn as nn
 
+from srhip import ops
 from srhip.module_path import refresh_if_params_changed
 
 __all__ = ['EDSR_LIIF', 'EDSR']
@@ -38,7 +39,9 @@ class _NetFn(torch.autograd.Function):
     def forward(ctx, x, net, need_grad, *params):
         ctx.net = net
         ctx.need_dx = x.requires_grad
-        y = net.engine.forward(x, None, save=need_grad)
+        # reduced-precision matmuls only for inference (net.amp, set by --amp): training stays f32-accurate
+        with ops.amp_inference(getattr(net, "amp", False) and not need_grad):
+            y = net.engine.forward(x, None, save=need_grad)
         return y.clone() if need_grad else y
 
     @staticmethod

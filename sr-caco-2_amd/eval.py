@@ -72,7 +72,7 @@ def evaluate_pretrained(argv=None):
     args.is_train = False
     args.netG['checkpoint_path_netG'] = join(exp_path, 'best-models/G-model.pth')
     if args.amp:
-        DLLogger.log('config has amp=True: this build evaluates in fp32')
+        DLLogger.log('config has amp=True: evaluating with the reduced-precision (single bf16 product) kernels')
     model = define_model(args)
     model.load()
     model.netG.eval()

@@ -134,8 +134,7 @@ def parse_input(argv=None):
     if cfg['method'] != constants.NETTYPE_METHOD[net_type]:
         raise ValueError(f"--method {cfg['method']} does not match --net_type {net_type} "
                          f"({constants.NETTYPE_METHOD[net_type]})")
-    if cfg['amp']:
-        raise NotImplementedError('--amp True: the libsrhip path is fp32 (parity gate)')
+    # --amp True: evaluation (model.test / eval.py) runs the reduced-precision kernels; training stays fp32-accurate
     cfg['netG'] = init_net_g({'net_type': net_type}, cfg)
     for k in net_opts:
         v = getattr(ns, f'{nt}_{k}')

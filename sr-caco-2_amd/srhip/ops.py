@@ -65,6 +65,27 @@ def bx3_for(*channels):
     return use_bx3() and min(channels) >= BX3_MIN_CHANNELS
 
 
+def set_matmul_mode(mode):
+    """0: f32-accurate bf16x3 (default) | 1: single bf16 product, inference only (srhip_set_matmul_mode)."""
+    call("srhip_set_matmul_mode", int(mode))
+
+
+class amp_inference:
+    """``with ops.amp_inference(on):`` -- reduced-precision matmuls / convs inside the block (the role of
+    torch.cuda.amp.autocast at evaluation time in the reference, model_plain.py:322-327)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = lib.srhip_get_matmul_mode()
+        if self.on:
+            set_matmul_mode(1)
+
+    def __exit__(self, *exc):
+        set_matmul_mode(self.prev)
+
+
 def _tn_sfx(bx=None):
     return "_bx3" if (use_bx3() if bx is None else bx) else ""
 

@@ -1,0 +1,128 @@
+"""Reduced-precision INFERENCE (BASELINE config 5): ``--amp`` runs the GEMMs / convs as one
+bf16 product of the leading planes (srhip_set_matmul_mode(1)) instead of the six of the f32-accurate
+split -- the role of the reference's autocast evaluation (model_plain.py:322-327, eval_all.sh).
+Gate (north_star / VERDICT item 7): PSNR within 0.01 dB of the fp32 path; training is untouched."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import sr_oracle as O  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def psnr(a, b, border):
+    return O.metric_psnr(O.tensor2uint82float(a), O.tensor2uint82float(b), border)
+
+
+def test_mode_switch_changes_the_arithmetic_and_restores():
+    from srhip import ops
+    from srhip._lib import lib
+    g = torch.Generator().manual_seed(1)
+    A, W, b = torch.randn(4096, 180, generator=g), torch.randn(540, 180, generator=g) * 0.1, torch.randn(540, generator=g)
+    ref = F.linear(A.double(), W.double(), b.double())
+    Wb = ops.split_bf16x3(W.cuda())
+    rel = lambda y: ((y.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    e0 = rel(ops.gemm_nt(A.cuda(), Wb, b.cuda()))
+    with ops.amp_inference():
+        assert lib.srhip_get_matmul_mode() == 1
+        e1 = rel(ops.gemm_nt(A.cuda(), Wb, b.cuda()))
+    assert lib.srhip_get_matmul_mode() == 0
+    e2 = rel(ops.gemm_nt(A.cuda(), Wb, b.cuda()))
+    print(f"gemm rel err: f32-accurate {e0:.1e}, single bf16 product {e1:.1e}")
+    assert e0 < 2e-6 and e2 == e0 and 1e-4 < e1 < 2e-2
+    x, w = torch.randn(2, 64, 24, 40, generator=g), torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    wp = torch.empty(9, 64, 64).cuda()
+    ops.pack_conv_weight(w.cuda(), wp, None)
+    cref = F.conv2d(x.double(), w.double(), None, padding=1)
+    crel = lambda y: ((y.permute(0, 3, 1, 2).double().cpu() - cref).abs().max() / cref.abs().max()).item()
+    xh = x.permute(0, 2, 3, 1).contiguous().cuda()
+    c0 = crel(ops.conv3x3(xh, ops.split_bf16x3(wp), None, 64))
+    with ops.amp_inference():
+        c1 = crel(ops.conv3x3(xh, ops.split_bf16x3(wp), None, 64))
+    print(f"conv rel err: f32-accurate {c0:.1e}, single bf16 product {c1:.1e}")
+    assert c0 < 2e-6 and 1e-4 < c1 < 2e-2
+    with pytest.raises(RuntimeError):
+        ops.set_matmul_mode(7)
+
+
+def test_amp_inference_psnr_gate_swinir_edsr_vdsr():
+    from dlib.models.network_swinir import SwinIR
+    from dlib.models.network_edsr_liif import EDSR_LIIF
+    from dlib.models.network_vdsr import VDSR
+    from srhip._lib import lib
+    cases = []
+    cfg = O.swinir_config()
+    sd = O.trained_like_(O.swinir_init_state_dict(cfg, seed=0), 1, lin_scale=3.0)
+    net = SwinIR(upscale=8, in_chans=1, img_size=64, window_size=8, depths=[6, 6, 6, 6], embed_dim=180,
+                 num_heads=[6, 6, 6, 6], mlp_ratio=2, upsampler="pixelshuffledirect")
+    net.load_state_dict(sd, strict=True)
+    cases.append(("SwinIR x8", net, 8, 64))
+    e = EDSR_LIIF(scale=4)
+    e.load_state_dict(O.edsr_init_state_dict(O.edsr_config(upscale=4), seed=4), strict=True)
+    cases.append(("EDSR x4", e, 4, 128))
+    v = VDSR(in_chans=1, upscale=2)
+    v.load_state_dict(O.vdsr_init_state_dict(1, seed=2), strict=True)
+    cases.append(("VDSR x2", v, 2, 256))
+    gen = torch.Generator().manual_seed(11)
+    for name, net, s, lr in cases:
+        net = net.cuda().eval()
+        hr = (torch.rand(8, 1, 512, 512, generator=gen) * 255).round() / 255
+        x = F.interpolate(hr, scale_factor=1.0 / s, mode="bicubic").clamp(0, 1).cuda()
+        with torch.no_grad():
+            y32 = net(x)
+            net.amp = True
+            y16 = net(x)
+            assert lib.srhip_get_matmul_mode() == 0                   # the switch does not leak
+            times = {}
+            for amp in (False, True):
+                net.amp = amp
+                net(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    net(x)
+                torch.cuda.synchronize()
+                times[amp] = 8 * 5 / (time.perf_counter() - t0)
+            net.amp = False
+        y32, y16 = y32.cpu(), y16.cpu()
+        scale_y = max(1.0, float(y32.abs().max()))
+        mae = (y32 - y16).abs().mean().item()
+        gap = (psnr(y32, hr, s) - psnr(y16, hr, s)).abs().max().item()
+        print(f"{name}: amp vs fp32 MAE {mae:.2e} (|y| max {scale_y:.2f}), PSNR gap {gap:.4f} dB; eval patches/s "
+              f"fp32 {times[False]:.0f}, amp {times[True]:.0f} ({times[True] / times[False]:.2f}x)")
+        assert gap <= 0.01, (name, gap)
+        if name.startswith("VDSR"):      # measured 0.023 dB with the single product: the net ignores --amp
+            assert torch.equal(y32, y16)
+        else:
+            assert 1e-7 < mae <= 5e-3 * scale_y, (name, mae)          # really reduced precision, and close
+
+
+def test_amp_flag_leaves_training_untouched():
+    """net.amp only changes no-grad forwards: a training forward/backward under amp=True equals amp=False bit for bit."""
+    from dlib.models.network_edsr_liif import EDSR_LIIF
+    cfg = O.edsr_config(upscale=2, n_feats=64, n_resblocks=2)
+    sd = O.edsr_init_state_dict(cfg, seed=3)
+    x = torch.rand(1, 1, 32, 32, generator=torch.Generator().manual_seed(4)).cuda()
+    outs = []
+    for amp in (False, True):
+        net = EDSR_LIIF(scale=2, n_resblocks=2, n_feats=64)
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        net.amp = amp
+        y = net(x)
+        y.abs().mean().backward()
+        outs.append((y.detach().clone(), net.body[0].body[0].weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
