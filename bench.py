@@ -239,6 +239,10 @@ def worker(args):
     barrier()
     dt = time.perf_counter() - t0
     probe.active = set(kinds)
+    # PMC traffic of THIS workload's kernels (profiles/, collected with tools/refresh_profiles.sh)
+    tj = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_per_kernel_{args.workload.replace('swinir_x8', 'swinir')}_b8.json")
+    if os.path.isfile(tj):
+        os.environ.setdefault("SRHIP_TRAFFIC_JSON", tj)
     roof = probe.collect() if not args.no_roofline else None
     probe.disable()
     steps_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
