@@ -321,6 +321,11 @@ int srhip_patch_gather(const srhip_patch_job* jobs, int B, int P, float* out, vo
  * (fp64) per patch selects the origin by the inverse CDF in row-major order; origins[b] = {row, col}
  * feeds srhip_patch_gather (y0, x0).  jobs[b].{img,H,W} are used; workspace: srhip_roi_sample_ws(B,
  * max_rows) ints with max_rows >= H - P of every tile. */
+/* Patch matrix of a 1-channel image [B][H][W] for a k x k, stride 1, pad k/2 convolution:
+ * out[t][dy*k+dx] = x[b][y+dy-k/2][x+dx-k/2] (zero outside the image), columns k*k .. ldo-1 zero.
+ * With srhip_gemm_nt_bx3 / srhip_gemm_tn_bx3 it is the forward / weight gradient of SRCNN's
+ * nn.Conv2d(1, 1024, 5, 1, 2) (network_srcnn.py:33). */
+int srhip_im2col_c1(const float* x, float* out, long ldo, int B, int H, int W, int ksize, void* stream);
 long srhip_roi_sample_ws(int B, int max_rows);
 int srhip_roi_sample(const srhip_patch_job* jobs, int B, int P, int threshold, const double* uniforms,
                      int* workspace, int max_rows, int* origins, void* stream);

@@ -478,6 +478,36 @@ def g_patch_sampler():
     npz("g21_patch_sampler", **out)
 
 
+# ---------------------------------------------------------------- G22 SRCNN
+def g_srcnn():
+    """The registered SRCNN (network_srcnn.py:23-69): forward and all six parameter gradients of the reference
+    class on a 2 x 1 x 24 x 40 input, weights from the oracle's seeded initialiser (biases perturbed)."""
+    print("G22 SRCNN")
+    from dlib.models.network_srcnn import SRCNN as RefSRCNN
+    sd = O.srcnn_init_state_dict(1, seed=61, bias_std=0.05)
+    sd["reconstruction.weight"] = sd["reconstruction.weight"] * 50.0      # 0.001-scale weights would hide the layer
+    net = RefSRCNN(in_chans=1)
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+    net.load_state_dict(sd, strict=True)
+    torch.manual_seed(62)
+    x = torch.rand(2, 1, 24, 40)
+    y = net(x)
+    tgt = torch.rand_like(y)
+    (y - tgt).abs().mean().backward()
+    grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = O.srcnn_forward(sdo, x)
+    close(yo, y, 1e-6, "srcnn forward")
+    (yo - tgt).abs().mean().backward()
+    for k in grads:
+        e = (sdo[k].grad - grads[k]).abs().max().item() / (grads[k].abs().max().item() + 1e-30)
+        assert e < 1e-5, (k, e)
+    arrs = dict(x=x, y=y.detach(), target=tgt)
+    arrs.update(sd_np({k: v for k, v in sd.items() if k != "map.0.weight"}, "sd/"))   # map.0.weight: from the seed (512 KB)
+    arrs.update(sd_np(grads, "grad/"))
+    npz("g22_srcnn", **arrs)
+
+
 # ---------------------------------------------------------------- G19 eval.py experiment folder
 def g_eval_fixture():
     """A reference-format experiment directory + dataset + folds, and what the REFERENCE's own
@@ -1126,7 +1156,7 @@ def g_optim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
-            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler]
+            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:
         if not only or g.__name__ in only:

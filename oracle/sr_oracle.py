@@ -317,6 +317,26 @@ def trained_like_(sd: SD, seed: int, lin_scale: float = 10.0, table_std: float =
     return sd
 
 
+def srcnn_forward(sd: SD, x: Tensor) -> Tensor:
+    """SRCNN._forward_impl (network_srcnn.py:54-60): conv 5x5 (1 -> 1024) + ReLU, conv 1x1 (-> 128) + ReLU,
+    conv 1x1 (-> 1), on an input already at the target size."""
+    out = F.relu(F.conv2d(x, sd["features.0.weight"], sd["features.0.bias"], padding=2))
+    out = F.relu(F.conv2d(out, sd["map.0.weight"], sd["map.0.bias"]))
+    return F.conv2d(out, sd["reconstruction.weight"], sd["reconstruction.bias"])
+
+
+def srcnn_init_state_dict(in_chans: int = 1, seed: int = 0, bias_std: float = 0.0) -> SD:
+    """network_srcnn.py:63-72 as distributions: N(0, sqrt(2 / (out_channels * k*k))), the reconstruction layer
+    N(0, 0.001), zero biases (bias_std > 0 perturbs them for the tests)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+    for name, co, ci, k in (("features.0", 1024, in_chans, 5), ("map.0", 128, 1024, 1), ("reconstruction", in_chans, 128, 1)):
+        std = 0.001 if name == "reconstruction" else math.sqrt(2 / (co * k * k))
+        sd[name + ".weight"] = torch.randn(co, ci, k, k, generator=g) * std
+        sd[name + ".bias"] = torch.randn(co, generator=g) * bias_std
+    return sd
+
+
 # ----------------------------------------------------------------------------
 # EDSR-baseline assembled from the reference's EDSR blocks
 # (network_nlsn.py:38-128 blocks, :355-369 wiring without attention;

@@ -93,7 +93,41 @@ __global__ void __launch_bounds__(256) k_roi_sample(RoiJobs jobs, int P, int th,
   }
 }
 
+// Patch matrix of a 1-channel image for a k x k / stride 1 / pad k/2 convolution: out[t][dy*k+dx] =
+// x[b][y+dy-k/2][x+dx-k/2] (zero outside), columns k*k .. ldo-1 zero.  Turns the wide first layer of
+// SRCNN (nn.Conv2d(1, 1024, 5, 1, 2), network_srcnn.py:33) into a [T x 28] . [1024 x 28]^T GEMM on the
+// bf16x3 kernels; its weight gradient is the TN contraction against the same matrix.
+__global__ void __launch_bounds__(256) k_im2col_c1(const float* __restrict__ x, float* __restrict__ out, long ldo,
+                                                   int B, int H, int W, int ks) {
+  const long n = (long)B * H * W * ldo;
+  const int half = ks / 2, kk = ks * ks;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long t = i / ldo;
+    const int j = (int)(i - t * ldo);
+    float v = 0.f;
+    if (j < kk) {
+      const int xx = (int)(t % W), yy = (int)((t / W) % H);
+      const long b = t / ((long)W * H);
+      const int sy = yy + j / ks - half, sx = xx + j % ks - half;
+      if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = x[(b * H + sy) * W + sx];
+    }
+    out[i] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int srhip_im2col_c1(const float* x, float* out, long ldo, int B, int H, int W, int ksize, void* stream) {
+  SR_REQUIRE(x && out && B > 0 && H > 0 && W > 0, "im2col_c1: empty image / NULL argument");
+  SR_REQUIRE(ksize >= 1 && ksize % 2 == 1 && ksize * ksize <= ldo && ldo % 4 == 0,
+             "im2col_c1: odd kernel size with ksize^2 <= ldo, ldo %% 4 == 0 (ksize=%d ldo=%ld)", ksize, ldo);
+  const long n = (long)B * H * W * ldo;
+  long g = (n + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(k_im2col_c1, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, out, ldo, B, H, W, ksize);
+  SR_LAUNCH_CHECK("im2col_c1");
+  return 0;
+}
 
 extern "C" long srhip_roi_sample_ws(int B, int max_rows) { return (long)B * max_rows; }
 

@@ -42,7 +42,7 @@ class ModelPlain:
         self.netG.amp = bool(getattr(args, 'amp', False))
         self.schedulers = []
         self.log_dict = OrderedDict()
-        self.L = self.E = self.H = self.h_per_pixel_weight = None
+        self.L = self.E = self.H = self.h_per_pixel_weight = self.L_to_H = None
         self._current = None
         self.step_fn = None
         self.loss_fn = None
@@ -77,6 +77,9 @@ class ModelPlain:
     # ---------------------------------------------------------------- data
     def feed_data(self, data, need_H=True):
         self.L = data['l_im'].to(self.device, non_blocking=True)
+        # SRCNN consumes the low-resolution image already interpolated to the target size (model_plain.py:184-195)
+        l2h = data.get('l_to_h_img', None) if hasattr(data, 'get') else None
+        self.L_to_H = None if l2h is None else l2h.to(self.device, non_blocking=True)
         self.H = data['h_im'].to(self.device, non_blocking=True) if need_H else None
         w = data.get('h_per_pixel_weight', None)
         self.h_per_pixel_weight = None if w is None else w.to(self.device)
@@ -85,8 +88,15 @@ class ModelPlain:
                                       "dlib.loss.L1 through autograd")
 
     # ---------------------------------------------------------------- step
+    def _net_input(self):
+        if getattr(self.args, 'method', None) == 'SRCNN':
+            if self.L_to_H is None:
+                raise KeyError("SRCNN needs the batch key 'l_to_h_img' (the interpolated low-resolution image)")
+            return self.L_to_H
+        return self.L
+
     def optimize_parameters(self, epoch: int, current_step: int):
-        self.step_fn.step(self.L, self.H)
+        self.step_fn.step(self._net_input(), self.H)
         # the engine's output buffer is persistent (overwritten by the next step) and 3-D for the
         # 1-channel conv nets: hand out a [B,1,H,W] copy, as the reference's self.E is a fresh tensor
         y = self.netG.engine.bufs.d.get("t.y")
@@ -120,7 +130,7 @@ class ModelPlain:
     def test(self):
         self.netG.eval()
         with torch.no_grad():
-            self.E = self.netG(self.L)
+            self.E = self.netG(self._net_input())
         self.netG.train()
 
     def current_visuals(self, need_H=True):

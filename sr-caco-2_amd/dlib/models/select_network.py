@@ -33,6 +33,9 @@ def define_G(args):
     if net_type == constants.VDSR:                  # select_network.py:200-205
         from dlib.models.network_vdsr import VDSR as net
         return net(in_chans=opt_net[f'{nt}_in_chans'], upscale=opt_net[f'{nt}_upscale'])
+    if net_type == constants.SRCNN:                 # select_network.py:207-210
+        from dlib.models.network_srcnn import SRCNN as net
+        return net(in_chans=opt_net[f'{nt}_in_chans'])
     raise NotImplementedError(
         f"net_type {net_type!r}: only {constants.MODELS} run on libsrhip (SURVEY.md section 8f lists "
-        f"the remaining 12 reference networks as 'next')")
+        f"the remaining 11 reference networks as 'next')")

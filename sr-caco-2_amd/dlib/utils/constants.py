@@ -7,13 +7,15 @@ SWINIR = 'swinir'
 EDSR_LIIF = 'EDSR_LIIF'
 VDSR = 'VDSR'  # https://arxiv.org/pdf/1511.04587.pdf (reference constants.py:27)
 DRRN = 'DRRN'  # https://ieeexplore.ieee.org/document/8099781 (reference constants.py:29)
-MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN]
+SRCNN = 'SRCNN'  # https://arxiv.org/abs/1501.00092 (reference constants.py)
+MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN]
 
 SWINIR_MTH = 'SWINIR'
 EDSR_LIIF_MTH = 'EDSR_LIIF'
 VDSR_MTH = 'VDSR'
 DRRN_MTH = 'DRRN'
-NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH, DRRN: DRRN_MTH}
+SRCNN_MTH = 'SRCNN'
+NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH, DRRN: DRRN_MTH, SRCNN: SRCNN_MTH}
 
 US_PIXEL_SHUFFLE = 'pixelshuffle'
 US_PIXEL_SHUFFLE_DIRECT = 'pixelshuffledirect'

@@ -735,6 +735,16 @@ def patch_gather(tiles, ids, y0, x0, modes, P, out=None):
     return out
 
 
+def im2col_c1(x, ksize, ldo, out=None):
+    """x [B,H,W] -> patch matrix [B*H*W, ldo] of a ksize x ksize / pad ksize//2 convolution (zero padded)."""
+    _chk(x, out)
+    B, H, W = x.shape
+    if out is None:
+        out = torch.empty(B * H * W, ldo, device=x.device, dtype=torch.float32)
+    call("srhip_im2col_c1", _p(x), _p(out), ldo, B, H, W, int(ksize), _st())
+    return out
+
+
 def roi_sample(tiles, ids, P, threshold, uniforms):
     """Patch origins [B,2] (row, col; int32, on the device) drawn with the reference's ROI weighting
     (PatchSampler._roi, dataset_dpsr.py:330-369) from ``uniforms`` (float64 [B] in [0,1), e.g. torch.rand on the

@@ -1,0 +1,110 @@
+"""SRCNN forward / backward as libsrhip launches.
+
+Reference: dlib/models/network_srcnn.py:23-69 (the registered class, select_network.py:207-210):
+features = Conv2d(1, 1024, 5, 1, 2) + ReLU, map = Conv2d(1024, 128, 1) + ReLU, reconstruction =
+Conv2d(128, 1, 1), applied to the low-resolution image ALREADY interpolated to the target size (the
+batch's 'l_to_h_img', model_plain.py:184-195).  Every layer is a token-matrix GEMM here: the 5x5
+1-channel conv through its patch matrix [T x 28] (srhip_im2col_c1, 25 taps + 3 zero columns), the 1x1
+convs directly on [T x C]; ReLU is the GEMM epilogue, its mask the epilogue of the data-gradient GEMM
+(epi 4), weight gradients run on the grouped TN kernel.  The 1-wide output layer is padded to 4 columns
+(zero rows of W3), so that every matrix meets the 4-float alignment of the kernels."""
+import torch
+
+from . import ops
+from .swinir_engine import _Bufs
+
+C1, C2, KP1 = 1024, 128, 28      # channels; padded taps of the 5x5 layer
+
+
+class SRCNNEngine:
+    def __init__(self, net):
+        self.net = net
+        self.bufs = _Bufs()
+        self.derived = _Bufs()
+        self.ws = ops.WeightSet()
+        self.ws.use_bx3 = True
+        self._prep = self._prep_sig = None
+        self.prepared = False
+        self.saved = None
+
+    def invalidate(self):
+        self.prepared = False
+
+    def bucket_prefixes(self):
+        return [["features.", "map.", "reconstruction."]]
+
+    def prepare(self):
+        net, D, ws = self.net, self.derived, self.ws
+        dev = net.map[0].weight.device
+        w1p = D.get("w1p", C1, KP1, device=dev)          # [1024][25] taps + 3 zero columns
+        w3p = D.get("w3p", 4, C2, device=dev)            # [1][128] + 3 zero rows
+        sig = tuple(p.data_ptr() for p in net.parameters())
+        if self._prep is None or sig != self._prep_sig:
+            w1p.zero_()
+            w3p.zero_()
+            tb = ops.PrepTable()
+            tb.linear(w1p, ws.planes("w1", C1, KP1, dev))
+            tb.linear(net.map[0].weight.data.view(C2, C1), ws.planes("w2", C2, C1, dev))
+            tb.linear(net.map[0].weight.data.view(C2, C1), ws.planes("w2T", C1, C2, dev), transpose=True)
+            tb.linear(w3p, ws.planes("w3", 4, C2, dev))
+            tb.linear(w3p, ws.planes("w3T", C2, 4, dev), transpose=True)
+            self._prep, self._prep_sig = tb.build(dev), sig
+        w1p[:, :25].copy_(net.features[0].weight.data.view(C1, 25))
+        w3p[:1].copy_(net.reconstruction.weight.data.view(1, C2))
+        self._prep.run()
+        self.prepared = True
+
+    def forward(self, x, dp=None, save=True):
+        """x [B,H,W] (already at the target size) -> [B,1,H,W]."""
+        if not self.prepared:
+            self.prepare()
+        net, D, ws = self.net, self.derived, self.ws
+        B, H, W = x.shape
+        T = B * H * W
+        dev = x.device
+        tag = "t" if save else "e"
+
+        def buf(name, *shape):
+            return self.bufs.get(f"{tag}.{name}", *shape, device=dev)
+
+        a0 = ops.im2col_c1(x, 5, KP1, out=buf("a0", T, KP1))
+        h1 = ops.gemm_nt(a0, ws["w1"], net.features[0].bias.data, out=buf("h1", T, C1), epi=1)
+        h2 = ops.gemm_nt(h1, ws["w2"], net.map[0].bias.data, out=buf("h2", T, C2), epi=1)
+        b3 = D.get("b3p", 4, device=dev)
+        b3.zero_()
+        b3[:1].copy_(net.reconstruction.bias.data)
+        y4 = ops.gemm_nt(h2, ws["w3"], b3, out=buf("y4", T, 4))
+        y = torch.empty(B, H, W, device=dev) if not save else buf("y", B, H, W)
+        y.view(T).copy_(y4[:, 0])
+        if save:
+            self.saved = dict(a0=a0, h1=h1, h2=h2, B=B, H=H, W=W)
+        return y.view(B, 1, H, W)
+
+    def backward(self, dy, grads, need_dx=False, on_layer_done=None, grads_zeroed=False):
+        sv = self.saved
+        assert sv is not None, "backward() without a saved forward"
+        assert not need_dx, "SRCNN (libsrhip): no gradient with respect to the interpolated input"
+        net, D, ws = self.net, self.derived, self.ws
+        B, H, W = sv["B"], sv["H"], sv["W"]
+        T = B * H * W
+        dev = dy.device
+
+        def buf(name, *shape):
+            return self.bufs.get("g." + name, *shape, device=dev)
+
+        dy4 = buf("dy4", T, 4)
+        dy4.zero_()
+        dy4[:, 0].copy_(dy.reshape(T))
+        dw3, db3 = buf("dw3", 4, C2), buf("db3", 4)
+        dw1 = buf("dw1", C1, KP1)
+        dh2 = ops.gemm_nt(dy4, ws["w3T"], None, out=buf("dh2", T, C2), epi=4, R=sv["h2"])     # * (h2 > 0)
+        dh1 = ops.gemm_nt(dh2, ws["w2T"], None, out=buf("dh1", T, C1), epi=4, R=sv["h1"])     # * (h1 > 0)
+        ops.linear_wgrad_grouped([
+            dict(dY=dy4, X=sv["h2"], dW=dw3, db=db3),
+            dict(dY=dh2, X=sv["h1"], dW=grads["map.0.weight"].view(C2, C1), db=grads["map.0.bias"]),
+            dict(dY=dh1, X=sv["a0"], dW=dw1, db=grads["features.0.bias"]),
+        ])
+        grads["reconstruction.weight"].view(1, C2).copy_(dw3[:1])
+        grads["reconstruction.bias"].copy_(db3[:1])
+        grads["features.0.weight"].view(C1, 25).copy_(dw1[:, :25])
+        return None

@@ -145,6 +145,54 @@ def test_drrn_fwd_bwd_vs_reference_golden(scale):
     assert (y2.cpu() - ref).abs().mean() <= 1e-5 * max(1.0, float(ref.abs().mean()))
 
 
+def test_srcnn_fwd_bwd_vs_reference_golden_and_full_size_step():
+    """SRCNN (network_srcnn.py:23-69, registry select_network.py:207-210) as token-matrix GEMMs on the
+    bf16x3 kernels (5x5 layer through srhip_im2col_c1): forward and all six parameter gradients against the
+    reference (g22); one fused optimisation step at 512 x 512 against the oracle."""
+    from dlib.models.select_network import define_G
+    from dlib.utils import constants
+    from srhip.train import TrainStep, Optimizer
+    g = load("g22_srcnn")
+    args = type("A", (), {})()
+    args.netG = {'net_type': constants.SRCNN, 'SRCNN_in_chans': 1}
+    net = define_G(args)
+    sd = O.srcnn_init_state_dict(1, seed=61, bias_std=0.05)
+    sd["reconstruction.weight"] = sd["reconstruction.weight"] * 50.0
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    y = net(g["x"].cuda())
+    assert (y.detach().cpu() - g["y"]).abs().max() <= 1e-5
+    (y - g["target"].cuda()).abs().mean().backward()
+    for k, p in net.named_parameters():
+        ref = g["grad/" + k]
+        e = (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+        assert e <= 2e-5, f"grad {k}: rel err {e:.2e}"
+    with torch.no_grad():
+        net.eval()
+        assert (net(g["x"].cuda()).cpu() - g["y"]).abs().max() <= 1e-5
+    with pytest.raises(RuntimeError, match="GPU only"):
+        net(g["x"])
+    # full size: 1 x 512 x 512 (the net runs at the target resolution), L1 + SGD-Nesterov, fused step
+    net2 = define_G(args)
+    sd2 = O.srcnn_init_state_dict(1, seed=63)
+    net2.load_state_dict(sd2, strict=True)
+    net2 = net2.cuda().train()
+    ts = TrainStep(net2, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=0.01, momentum=0.9, nesterov=True, wd=0.0)
+    gen = torch.Generator().manual_seed(64)
+    x, tgt = torch.rand(1, 1, 512, 512, generator=gen), torch.rand(1, 1, 512, 512, generator=gen)
+    ts.step(x.cuda(), tgt.cuda())
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd2.items()}
+    lo = O.loss_l1(O.srcnn_forward(sdo, x), tgt)
+    lo.backward()
+    assert abs(ts.loss_values()[0] - lo.item()) <= 1e-5
+    with torch.no_grad():
+        for k, p in net2.named_parameters():
+            O.sgd_nesterov_step(sdo[k], sdo[k].grad, torch.zeros_like(sdo[k]), True, 0.01)
+            assert (p.detach().cpu() - sdo[k].detach()).abs().max() <= 2e-6, k
+
+
 def test_vdsr_full_size_forward_and_train_step():
     """VDSR at the benchmark patch (1 x 64 x 64 -> 512 x 512): forward against the oracle (MAE <= 1e-5, PSNR
     within 0.01 dB) and one fused optimisation step against the oracle's autograd + SGD-Nesterov step."""
