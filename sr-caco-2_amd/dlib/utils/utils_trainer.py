@@ -12,61 +12,52 @@ from dlib.utils import constants
 __all__ = ['Interpolate']
 
 
+# task -> (batch key of the input, batch key of the target, does the scale factor apply?)
+_TASK_KEYS = {constants.SUPER_RES: ('l_im', 'h_im', True),
+              constants.RECONSTRUCT: ('in_reconstruct', 'trg_reconstruct', False)}
+
+
 class Interpolate(torch.nn.Module):
+    """Bicubic (antialiased) interpolation behind the evaluation protocol; parameter-free."""
+
     def __init__(self, task: str, scale: int, scale_mode: str):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError("Interpolate (libsrhip build) runs on the GPU, like the reference "
                                "(utils_trainer.py:93); there is no CPU path")
-        self.device = torch.device(f'cuda:{torch.cuda.current_device()}')
-        self.scale: int = scale
-        assert task in constants.TASKS, f"{task} | {constants.TASKS}"
-        self.task = task
-        assert scale_mode in [constants.INTER_BICUBIC], scale_mode
-        self.scale_mode: str = scale_mode
+        if task not in _TASK_KEYS:
+            raise AssertionError(f"{task} | {constants.TASKS}")
+        if scale_mode not in constants.INTERPOLATION_MODES:
+            raise AssertionError(scale_mode)
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self.task, self.scale, self.scale_mode = task, scale, scale_mode
         self.L = self.E = self.H = None
 
     def feed_data(self, data, need_H=True):
-        if self.task == constants.SUPER_RES:
-            lk, hk = 'l_im', 'h_im'
-        elif self.task == constants.RECONSTRUCT:
-            lk, hk = 'in_reconstruct', 'trg_reconstruct'
-        else:
-            raise NotImplementedError(self.task)
-        self.L = data[lk].to(self.device)
-        if need_H:
-            self.H = data[hk].to(self.device)
+        key_in, key_trg, _ = _TASK_KEYS[self.task]
+        self.L = data[key_in].to(self.device)
+        self.H = data[key_trg].to(self.device) if need_H else self.H
 
     def forward(self):
-        x = self.L
-        assert x.ndim == 4, x.ndim
-        if self.scale_mode != constants.INTER_BICUBIC:
-            raise NotImplementedError(f'Not supported : {self.scale_mode}')
-        if self.task == constants.SUPER_RES:
-            scale = self.scale
-        elif self.task == constants.RECONSTRUCT:
-            scale = 1
-        else:
-            raise NotImplementedError(self.task)
-        out = F.interpolate(input=x, scale_factor=scale, mode='bicubic', antialias=True)
-        self.E = torch.clamp(out, 0.0, 1.0)       # data in [0, 1] (utils_trainer.py:146-147)
-
-    def set_eval_mode(self):
-        self.eval()
-
-    def set_train_mode(self):
-        pass
+        assert self.L.ndim == 4, self.L.ndim
+        factor = self.scale if _TASK_KEYS[self.task][2] else 1
+        up = F.interpolate(self.L, scale_factor=factor, mode=self.scale_mode, antialias=True)
+        self.E = up.clamp_(0.0, 1.0)              # images live in [0, 1] (utils_trainer.py:146-147)
 
     def test(self):
         self.eval()
         with torch.no_grad():
             self.forward()
 
+    def set_eval_mode(self):
+        self.eval()
+
+    def set_train_mode(self):                     # nothing to train
+        pass
+
     def current_visuals(self, need_H=True):
-        out = {'L': self.L.detach().float(), 'E': self.E.detach().float()}
-        if need_H:
-            out['H'] = self.H.detach().float()
-        return out
+        keys = ('L', 'E', 'H') if need_H else ('L', 'E')
+        return {k: getattr(self, k).detach().float() for k in keys}
 
 
 # ==============================================================================================

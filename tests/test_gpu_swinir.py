@@ -249,3 +249,73 @@ def test_step_graph_replays_the_eager_step_bit_for_bit(SwinIR):
     total_ms = (time.perf_counter() - t0) * 100.0
     print(f"step_graph README B=8: host {host_ms:.2f} ms per step, device {total_ms:.2f} ms per step")
     assert host_ms < 2.0 and torch.isfinite(ts.loss_buf).all()
+
+
+DDP_WORKER = r'''
+import os, sys, socket, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, "sr-caco-2_amd")); sys.path.insert(0, os.path.join(root, "oracle"))
+import sr_oracle as O
+from dlib.models.network_swinir import SwinIR
+from dlib.models.network_vdsr import VDSR
+from srhip.train import TrainStep, Optimizer
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+cfg = O.swinir_config(upscale=8, in_chans=1, img_size=16, window_size=8, depths=(2, 2), embed_dim=60,
+                      num_heads=(6, 6), mlp_ratio=2, drop_path_rate=0.0)
+sd0 = O.trained_like_(O.swinir_init_state_dict(cfg, seed=91), 92, lin_scale=3.0)
+gen = torch.Generator().manual_seed(93)
+batches = [(torch.rand(2, 1, 16, 16, generator=gen).cuda(), torch.rand(2, 1, 128, 128, generator=gen).cuda()) for _ in range(3)]
+out = {}
+for mode in ("plain", "ddp"):
+    os.environ["SRHIP_FORCE_DDP"] = "1" if mode == "ddp" else "0"
+    net = SwinIR(upscale=8, in_chans=1, img_size=16, window_size=8, depths=[2, 2], embed_dim=60, num_heads=[6, 6],
+                 mlp_ratio=2, upsampler="pixelshuffledirect", drop_path_rate=0.0)
+    net.load_state_dict(sd0, strict=True)
+    net = net.cuda().train()
+    ts = TrainStep(net, [("l1", 1.0)], process_group=dist.group.WORLD if mode == "ddp" else None, world_size=1)
+    ts.opt = Optimizer(ts.fp, "adam", lr=2e-4, wd=1e-4)
+    assert ts.ddp == (mode == "ddp")
+    for lr_img, hr_img in batches:
+        ts.step(lr_img, hr_img)
+    if mode == "ddp":      # every bucket went through RCCL exactly once per step, in backward order
+        assert ts.reducer.log == [0, 1, 2] and len(ts.buckets) == 3, ts.reducer.log
+        cover = sorted(ts.buckets)
+        assert cover[0][0] == 0 and cover[-1][1] == ts.fp.total and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    torch.cuda.synchronize()
+    out[mode] = (ts.fp.flat.clone(), ts.loss_buf.clone())
+d = (out["plain"][0] - out["ddp"][0]).abs().max().item()
+assert d <= 1e-7 and torch.equal(out["plain"][1], out["ddp"][1]), d
+# a single-bucket engine (VDSR): the bucket the engine used to announce itself must be reduced once
+v = VDSR(in_chans=1, upscale=2)
+v.load_state_dict(O.vdsr_init_state_dict(1, seed=2), strict=True)
+v = v.cuda().train()
+tv = TrainStep(v, [("l1", 1.0)], process_group=dist.group.WORLD, world_size=1)
+tv.step(torch.rand(1, 1, 16, 16).cuda(), torch.rand(1, 1, 32, 32).cuda())
+assert tv.reducer.log == [0], tv.reducer.log
+dist.destroy_process_group()
+print("ddp ok", d)
+'''
+
+
+def test_forced_ddp_single_rank_rccl_path_matches_plain_step(tmp_path):
+    """a20 on the GPU: SRHIP_FORCE_DDP=1 takes the bucketed RCCL path (side stream, events, per-bucket
+    all-reduce, flag MAX) with a one-rank nccl group; three Adam steps equal the plain step (to the float-atomics
+    noise of the LayerNorm-affine gradients), every bucket is reduced once per step in backward order.  (More
+    than one rank needs more than one GPU: the driver's scaling run.)"""
+    import socket
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(DDP_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, str(script), root, str(port)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0 and "ddp ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
