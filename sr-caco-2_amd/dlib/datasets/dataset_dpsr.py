@@ -89,3 +89,85 @@ class DeviceRoiSampler:
         from srhip import ops
         u = torch.rand(len(ids), dtype=torch.float64, device=self.tiles[0].device, generator=self.gen)
         return ops.roi_sample(self.tiles, ids, self.psize, self.threshold, u), u
+
+
+class ResidentTrainSet:
+    """Training batches assembled ON the GPU from tiles that stay resident in HBM as uint8 (a CACO-2
+    split is a few hundred 8-bit tiles: tens of MB against 288 GB) -- the MI355X form of the TRAIN phase of
+    DatasetDPSR.__getitem__ + DataLoader (dataset_dpsr.py:746-757,826-947, utils_dataloaders.py:138-158) for
+    sets that ship true low-resolution tiles:
+
+      per epoch   ShardedSampler(shuffle, seed + epoch, drop_last) -> this rank's minibatch index lists
+      per batch   crop origins on the device ('uniform': torch.randint; 'roi': srhip_roi_sample on the
+                  low-resolution tile interpolated to the high-resolution size and thresholded, as
+                  :852-857), LR origin = HR origin // scale (:866-867), one augmentation mode 0..7 per
+                  sample (:890), srhip_patch_gather for h_im and l_im (bit-exact crop / flip / rotate /
+                  uint8 -> float32, g12)
+
+    and returns the batch dict the trainer feeds ModelPlain: l_im, h_im, h_id, l_id.  Not produced: the
+    cv2-bicubic 'l_to_h_img' tensors (SRCNN-style nets), per-pixel weights, the LR-only blur / noise
+    augmentations (flags da_blur / da_dot_bin_noise / da_add_gaus_noise must be off).  The ROI image
+    uses torch's bicubic kernel where the reference uses cv2's (both round to uint8): same regions up
+    to boundary pixels of the thresholded mask."""
+
+    def __init__(self, args, pairs_h: dict, pairs_l: dict, device, rank: int = 0, world: int = 1):
+        import torch
+        import torch.nn.functional as F
+        from dlib.utils.utils_dataloaders import imread_gray_uint8, ShardedSampler
+        for flag in ('da_blur', 'da_dot_bin_noise', 'da_add_gaus_noise', 'ppiw', 'augment'):
+            if getattr(args, flag, False):
+                raise NotImplementedError(f"ResidentTrainSet: --{flag} is not part of the device pipeline")
+        self.args, self.device, self.sf = args, torch.device(device), int(args.scale)
+        self.psize, self.batch = int(args.h_size), int(args.batch_size)
+        self.ids_h = list(pairs_h.keys())
+        self.ids_l = [pairs_h[k]['low_path_key'] for k in self.ids_h]
+        self.hr, self.lr, self.roi_src = [], [], []
+        style = getattr(args, 'sample_tr_patch', SAMPLE_UNIF)
+        if style not in (SAMPLE_UNIF, SAMPLE_ROI):
+            raise NotImplementedError(f"sample_tr_patch={style!r}")
+        self.style = style
+        for hk, lk in zip(self.ids_h, self.ids_l):
+            h = torch.from_numpy(imread_gray_uint8(pairs_h[hk]['abs_path'])[:, :, 0].copy())
+            l = torch.from_numpy(imread_gray_uint8(pairs_l[lk]['abs_path'])[:, :, 0].copy())
+            hh, ww = h.shape[0] - h.shape[0] % self.sf, h.shape[1] - h.shape[1] % self.sf      # modcrop
+            h = h[:hh, :ww].contiguous()
+            assert l.shape == (hh // self.sf, ww // self.sf), (hk, tuple(h.shape), tuple(l.shape))
+            assert hh >= self.psize and ww >= self.psize, f"{hk}: tile {hh}x{ww} < patch {self.psize}"
+            self.hr.append(h.to(self.device))
+            self.lr.append(l.to(self.device))
+            if style == SAMPLE_ROI:
+                up = F.interpolate(l[None, None].float(), size=(hh, ww), mode='bicubic', align_corners=False)
+                self.roi_src.append(up.round().clamp(0, 255).to(torch.uint8)[0, 0].contiguous().to(self.device))
+        if style == SAMPLE_ROI:
+            if getattr(args, 'sample_tr_patch_th_style', TH_FIX) != TH_FIX:
+                raise NotImplementedError("ROI sampling needs sample_tr_patch_th_style='fix_threshold' in this build")
+            self.roi = DeviceRoiSampler(self.roi_src, self.psize, int(args.sample_tr_patch_th), seed=int(args.myseed or 0) + rank)
+        self.sampler = ShardedSampler(len(self.ids_h), world, rank, shuffle=True, seed=int(args.myseed or 0), drop_last=True)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(args.myseed or 0) * 1000003 + rank)
+
+    def __len__(self):
+        return len(self.sampler) // self.batch
+
+    def epoch(self, epoch: int):
+        """Iterator over this rank's batch dicts of one epoch (set_epoch semantics of utils_trainer.py:325-326)."""
+        import torch
+        from srhip import ops
+        self.sampler.set_epoch(epoch)
+        P, sf = self.psize, self.sf
+        for ids in self.sampler.batches(self.batch, drop_last=True):
+            B = len(ids)
+            if self.style == SAMPLE_ROI:
+                org, _ = self.roi.sample(ids)
+                org = org.cpu().tolist()                      # B x 2 ints: the only host round trip of the batch
+            else:
+                u = torch.rand(B, 2, device=self.device, generator=self.gen).cpu()
+                org = [[int(u[b, 0] * (self.hr[i].shape[0] - P + 1)), int(u[b, 1] * (self.hr[i].shape[1] - P + 1))]
+                       for b, i in enumerate(ids)]
+            modes = torch.randint(0, 8, (B,), device=self.device, generator=self.gen).cpu().tolist()
+            y0, x0 = [o[0] for o in org], [o[1] for o in org]
+            batch = ops.train_batch(self.hr, self.lr, ids, y0, x0, modes, P, sf)
+            batch['h_id'] = [self.ids_h[i] for i in ids]
+            batch['l_id'] = [self.ids_l[i] for i in ids]
+            batch['origin'], batch['mode'] = org, modes
+            yield batch

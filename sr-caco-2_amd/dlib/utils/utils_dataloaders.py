@@ -208,6 +208,27 @@ def get_eval_loader(args, ds_name: str, n: int = -1):
     return EvalLoader(ds, args.eval_bsize, sampler)
 
 
+def get_train_set(args, device, rank: int = 0, world: int = 1):
+    """The training sets of ``args.train_dsets`` as ONE resident device-side set (get_train_loader,
+    utils_dataloaders.py:56-158: pairs of all listed datasets merged)."""
+    from dlib.datasets.dataset_dpsr import ResidentTrainSet
+    names = [x for x in args.train_dsets.split(constants.SEP) if x != '']
+    assert names, 'no train sets'
+    pairs_h, pairs_l = {}, {}
+    strip = lambda k: k.split(constants.CODE_IDENTIFIER)[0]
+    for ds in names:
+        assert f'X_{args.scale}' in ds or f'X-{args.scale}' in ds, (ds, args.scale)
+        fold = join(args.splits_root, ds)
+        base = join(args.data_root, dataset_dir(ds))
+        for k, v in get_pairs(join(fold, 'h_l.txt')).items():
+            assert k not in pairs_h, k
+            pairs_h[k] = {'low_path_key': v, 'abs_path': join(base, strip(k))}
+        for k, v in get_pairs(join(fold, 'l_h.txt')).items():
+            assert k not in pairs_l, k
+            pairs_l[k] = {'high_path_key': v, 'abs_path': k if k.startswith('None_') else join(base, strip(k))}
+    return ResidentTrainSet(args, pairs_h, pairs_l, device, rank, world)
+
+
 def get_all_eval_loaders(args, ds_names: str, n: int = -1) -> dict:
     names = [x for x in ds_names.split(constants.SEP) if x != '']
     assert names, f'no eval sets in: {ds_names}'

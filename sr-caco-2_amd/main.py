@@ -64,6 +64,8 @@ def get_config(net_type):
         'scale': 2, 'n_channels': 1, 'h_size': 96, 'batch_size': 8, 'eval_bsize': 8, 'myseed': 0,
         'distributed': False, 'dist_backend': constants.GLOO, 'cudaid': '0', 'amp': False,
         'max_epochs': 1, 'max_iters': 50, 'eval_over_roi_also': False,
+        'train_dsets': '', 'valid_dsets': '', 'test_dsets': '', 'data_root': '', 'splits_root': 'folds',
+        'sample_tr_patch': 'uniform', 'sample_tr_patch_th_style': 'fix_threshold', 'sample_tr_patch_th': 7,
         'eval_over_roi_also_ths': [4, 5, 6, 7, 8, 9, 10], 'outd': './out',
         'train': {'l1': True, 'l1_lambda': 1., 'l2': False, 'l2_lambda': 1., 'ssim': False,
                   'ssim_lambda': 1., 'ssim_window_s': 11,
@@ -101,9 +103,11 @@ def parse_input(argv=None):
         raise NotImplementedError(f'--net_type {net_type}: libsrhip runs {constants.MODELS}')
     cfg = get_config(net_type)
     ap = argparse.ArgumentParser(description='SR-CACO-2 hot path on MI355X (libsrhip)')
-    for k in ('task', 'net_type', 'method', 'dist_backend', 'cudaid', 'outd'):
+    for k in ('task', 'net_type', 'method', 'dist_backend', 'cudaid', 'outd', 'train_dsets', 'valid_dsets',
+              'test_dsets', 'data_root', 'splits_root', 'sample_tr_patch', 'sample_tr_patch_th_style'):
         ap.add_argument(f'--{k}', type=str, default=None)
-    for k in ('scale', 'n_channels', 'h_size', 'batch_size', 'eval_bsize', 'myseed', 'max_epochs', 'max_iters'):
+    for k in ('scale', 'n_channels', 'h_size', 'batch_size', 'eval_bsize', 'myseed', 'max_epochs', 'max_iters',
+              'sample_tr_patch_th'):
         ap.add_argument(f'--{k}', type=int, default=None)
     for k in ('distributed', 'amp', 'eval_over_roi_also'):
         ap.add_argument(f'--{k}', type=str2bool, default=None)
@@ -171,8 +175,25 @@ def main(argv=None):
     if rank == 0:
         print(model.info_network())
     batch = synth_batch(args.batch_size, args.scale, args.h_size, model.device, 1000 + rank)
+    stream = None
+    if args.train_dsets:      # real folds: tiles resident in HBM, crops assembled on the device (dataset_dpsr.ResidentTrainSet)
+        from dlib.utils.utils_dataloaders import get_train_set
+        train_set = get_train_set(args, model.device, rank, world)
+
+        def batches():
+            epoch = 0
+            while True:
+                n = 0
+                for b in train_set.epoch(epoch):
+                    n += 1
+                    yield b
+                assert n > 0, "the training split is smaller than one batch per rank"
+                epoch += 1
+        stream = batches()
     t0, seen = time.perf_counter(), 0
     for step in range(1, args.max_iters + 1):
+        if stream is not None:
+            batch = next(stream)
         model.feed_data(batch)
         model.optimize_parameters(epoch=0, current_step=step)
         model.update_learning_rate()
@@ -187,8 +208,8 @@ def main(argv=None):
                 print(f"iter {step:6d}  G_loss {log['G_loss']:.6f}  lr {model.current_learning_rate():.2e}  "
                       f"{seen / (time.perf_counter() - t0):8.1f} patches/s")
     # evaluation sweep (utils_trainer.py:961-1032): PSNR / PSNR_Y / MSE / NRMSE / SSIM, optional ROI thresholds
-    model.feed_data(batch)
-    model.test()
+    from dlib.utils.utils_trainer import _forward_with_padding
+    model = _forward_with_padding(batch, model, args)          # SwinIR: flipped-strip padding to the next window multiple
     vis = model.current_visuals()
     ths = tuple(args.eval_over_roi_also_ths) if args.eval_over_roi_also else ()
     sw = metrics.sweep(vis['E'], vis['H'], border=args.scale, thresholds=ths)

@@ -90,3 +90,42 @@ def test_device_roi_sampler_matches_oracle_and_reference_distribution():
     roi_mass = p[(O.roi_origin_pmf(img, th, P).reshape(-1) > p.min() * 2)].sum()
     got = freq[(O.roi_origin_pmf(img, th, P).reshape(-1) > p.min() * 2)].sum()
     assert abs(got - roi_mass) <= 0.005
+
+
+@pytest.mark.gpu
+def test_resident_train_set_batches_match_numpy_crops():
+    """ResidentTrainSet (TRAIN phase of DatasetDPSR on the device): fold files -> resident uint8 tiles -> per batch
+    origins ('uniform' and 'roi'), LR origin = HR origin // scale, one of the 8 augmentations, uint8 -> float;
+    every returned patch equals the numpy crop + augment_img + /255 of the raw tile (dataset_dpsr.py:866-894,
+    914-915; the oracle's patch_batch is pinned against the reference's functions in g12)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import yaml
+    from PIL import Image
+    from dlib.utils.tools import Dict2Obj
+    from dlib.utils.utils_dataloaders import get_train_set
+    fx = os.path.join(G, "eval_exp")
+    a = Dict2Obj(yaml.safe_load(open(os.path.join(fx, "exp", "config_model.yml"))))
+    ds = a.test_dsets
+    a.train_dsets, a.data_root, a.splits_root = ds, os.path.join(fx, "data"), os.path.join(fx, "folds")
+    a.h_size, a.batch_size, a.myseed = 64, 2, 3
+    raw_h = [np.asarray(Image.open(os.path.join(fx, "data", "caco2", "t", f"h_{i}.tif"))) for i in range(3)]
+    raw_l = [np.asarray(Image.open(os.path.join(fx, "data", "caco2", "t", f"l_{i}.tif"))) for i in range(3)]
+    for style in ("uniform", "roi"):
+        a.sample_tr_patch, a.sample_tr_patch_th_style, a.sample_tr_patch_th = style, "fix_threshold", 12
+        ts = get_train_set(a, "cuda")
+        assert len(ts) == 1 and len(ts.hr) == 3 and ts.hr[0].dtype == torch.uint8 and ts.hr[0].is_cuda
+        seen = set()
+        for epoch in range(4):
+            for b in ts.epoch(epoch):
+                assert b["h_im"].shape == (2, 1, 64, 64) and b["l_im"].shape == (2, 1, 8, 8)
+                for k in range(2):
+                    i = int(b["h_id"][k].split("_")[1].split(".")[0])
+                    assert b["l_id"][k] == f"t/l_{i}.tif"
+                    (r0, c0), mode = b["origin"][k], b["mode"][k]
+                    assert 0 <= r0 <= 128 - 64 and 0 <= c0 <= 136 - 64 and 0 <= mode <= 7
+                    want_h = O.patch_batch([torch.from_numpy(raw_h[i].copy())], [0], [r0], [c0], [mode], 64)
+                    want_l = O.patch_batch([torch.from_numpy(raw_l[i].copy())], [0], [r0 // 8], [c0 // 8], [mode], 8)
+                    assert torch.equal(b["h_im"][k:k + 1].cpu(), want_h) and torch.equal(b["l_im"][k:k + 1].cpu(), want_l)
+                    seen.add(i)
+        assert seen == {0, 1, 2}          # shuffling re-seeded by set_epoch: the dropped sample rotates
