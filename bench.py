@@ -18,7 +18,7 @@ optimizer on one synthetic batch of 8 patches per GPU:
 Rank 0 prints ONE JSON line.  ``value`` = patches of all ranks / wall time of exactly K steps between
 barrier + synchronize pairs (max over ranks); ``step_ms`` = median / p10 / p90 of the per-step durations
 from HIP events recorded on the compute stream; ``roofline`` = the dominant kernel class timed live with
-HIP events inside the timed region (two of every twenty steps); ``cpu_baseline`` = the oracle (PyTorch-fp32
+HIP events inside the timed region (one of every twenty steps); ``cpu_baseline`` = the oracle (PyTorch-fp32
 CPU restatement, validated against the reference) timed on the host cores on a bounded sample, B=1 and B=8.
 """
 import argparse
@@ -229,10 +229,10 @@ def worker(args):
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # HIP events around every launch of the probed op classes in two of every twenty steps (an
+        # HIP events around every launch of the probed op classes in ONE of every twenty steps (an
         # event pair is two barrier packets: a probed step runs ~18 % slower, so probing all of
         # them would cost the headline number), taken mid-run
-        probe.active = set(kinds) if (not args.no_roofline and i % 10 == 5 % max(args.steps, 1)) else None
+        probe.active = set(kinds) if (not args.no_roofline and i % 20 == 10 % max(args.steps, 1)) else None
         marks[i].record()
         step_fn(lr_img, hr_img)
     marks[args.steps].record()
