@@ -116,6 +116,26 @@ int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bia
 int srhip_gemm_nt_bx3_lnbwd(const float* A, long lda, const void* Wb, float* out, long ldo, int M, int N, int K,
                             const float* x, long ldx, const float* stats, const float* res, long ldres,
                             void* stream);
+/* The MLP half of a Swin block in one kernel per direction (mlp_fused.hip): the hidden
+ * activation goes from the first product's accumulators through registers and LDS into
+ * the second product and never returns from HBM.
+ *   forward : h = LN(x) . W1^T + b1 (stats[M][2] = {mean, rstd} of x; W1 gamma-folded, b1 beta-folded),
+ *             out = x + s * (gelu(h) . W2^T + b2), stats_out = {mean, rstd} of the out rows (may be NULL);
+ *             h may be NULL (inference), otherwise it is what the backward reads.
+ *   backward: dh = (s * dy . W2) * gelu'(h), gh = gelu(h)  (both [M][ldh], operands of the weight gradients),
+ *             dx = dy + LayerNorm-backward(dh . W1)  (x, stats as in the forward).
+ * Weight planes in the kernel's own order, built by srhip_prep_table entries of kind 0 with
+ * mode 4 + gamma mode (rows permuted) / 8 + gamma mode (k permuted), s0 = hidden / 2:
+ *   forward  W1p = rows-permuted W1*gamma [2*192][C],      W2p = k-permuted W2 [C][2*192]
+ *   backward W2Tp = rows-permuted W2^T [2*192][C],         W1Tp = k-permuted (W1*gamma)^T [C][2*192]
+ * C <= 192 (multiple of 4), 192 < hidden <= 384 (multiple of 8); rowscale = DropPath multipliers per sample.
+ * Replaces Mlp.forward + residual (dlib/models/network_swinir.py:28-45,335-337) and its autograd. */
+int srhip_mlp_fwd_bx3(const float* x, long ldx, const float* stats, const void* W1p, const float* b1,
+                      const void* W2p, const float* b2, float* h, long ldh, float* out, long ldo, int M, int C,
+                      int hidden, const float* rowscale, int rows_per_scale, float* stats_out, void* stream);
+int srhip_mlp_bwd_bx3(const float* dy, long lddy, const void* W2Tp, const void* W1Tp, const float* h, long ldh,
+                      float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
+                      int M, int C, int hidden, const float* rowscale, int rows_per_scale, void* stream);
 int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
                            int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                            const float* rowscale, float alpha, void* stream);

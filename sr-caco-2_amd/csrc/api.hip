@@ -18,7 +18,7 @@ int sr_fail(int code, const char* fmt, ...) {
 extern "C" {
 
 const char* srhip_last_error(void) { return g_err; }
-int srhip_abi_version(void) { return 6; }
+int srhip_abi_version(void) { return 7; }
 
 static int g_matmul_mode = 0;
 int srhip_set_matmul_mode(int mode) {
@@ -104,6 +104,41 @@ int srhip_gemm_nt_bx3_lnbwd(const float* A, long lda, const void* Wb, float* out
   p.M = M; p.N = N; p.K = K; p.R = x; p.ldr = ldx; p.R2 = res; p.ldr2 = ldres; p.ep_stats = stats;
   p.alpha = 1.f;
   return sr_gemm_ntb_lnbwd(p, (hipStream_t)stream);
+}
+
+int srhip_mlp_fwd_bx3(const float* x, long ldx, const float* stats, const void* W1p, const float* b1,
+                      const void* W2p, const float* b2, float* h, long ldh, float* out, long ldo, int M, int C,
+                      int hidden, const float* rowscale, int rows_per_scale, float* stats_out, void* stream) {
+  SR_REQUIRE(x && stats && W1p && b1 && W2p && out, "mlp_fwd_bx3: null operand");
+  SR_REQUIRE(hidden % 2 == 0, "mlp_fwd_bx3: hidden %d", hidden);
+  SR_REQUIRE(!rowscale || rows_per_scale > 0, "mlp_fwd_bx3: rows_per_scale must be > 0");
+  SR_REQUIRE(sr_matmul_mode() == 0, "mlp_fwd_bx3: f32-accurate matmul mode only");
+  MlpArgs p;
+  memset(&p, 0, sizeof(p));
+  p.o.C = out; p.o.ldc = ldo; p.o.M = M; p.o.N = C; p.o.K = hidden; p.o.bias = b2; p.o.epi = 2;
+  p.o.R = x; p.o.ldr = ldx; p.o.rowscale = rowscale; p.o.rows_per_scale = rows_per_scale; p.o.alpha = 1.f;
+  p.o.stats_out = stats_out;
+  p.X = x; p.ldx = ldx; p.ln_stats = stats; p.K1 = C; p.hs = hidden / 2;
+  p.W1b = (const unsigned short*)W1p; p.W2b = (const unsigned short*)W2p; p.b1 = b1; p.H = h; p.ldh = h ? ldh : 4;
+  return sr_mlp_fused(p, (hipStream_t)stream);
+}
+
+int srhip_mlp_bwd_bx3(const float* dy, long lddy, const void* W2Tp, const void* W1Tp, const float* h, long ldh,
+                      float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
+                      int M, int C, int hidden, const float* rowscale, int rows_per_scale, void* stream) {
+  SR_REQUIRE(dy && W2Tp && W1Tp && h && dh && gh && x && stats && dx, "mlp_bwd_bx3: null operand");
+  SR_REQUIRE(hidden % 2 == 0, "mlp_bwd_bx3: hidden %d", hidden);
+  SR_REQUIRE(!rowscale || rows_per_scale > 0, "mlp_bwd_bx3: rows_per_scale must be > 0");
+  SR_REQUIRE(sr_matmul_mode() == 0, "mlp_bwd_bx3: f32-accurate matmul mode only");
+  MlpArgs p;
+  memset(&p, 0, sizeof(p));
+  p.o.C = dx; p.o.ldc = lddx; p.o.M = M; p.o.N = C; p.o.K = hidden; p.o.epi = 5; p.o.alpha = 1.f;
+  p.o.R = x; p.o.ldr = ldx; p.o.R2 = dy; p.o.ldr2 = lddy; p.o.ep_stats = stats;
+  p.X = dy; p.ldx = lddy; p.K1 = C; p.hs = hidden / 2;
+  p.W1b = (const unsigned short*)W2Tp; p.W2b = (const unsigned short*)W1Tp;
+  p.H = (float*)h; p.ldh = ldh; p.dH = dh; p.GH = gh; p.rowscale1 = rowscale; p.rows_per_scale1 = rows_per_scale;
+  p.bwd = 1;
+  return sr_mlp_fused(p, (hipStream_t)stream);
 }
 
 int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,

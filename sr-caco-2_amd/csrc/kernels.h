@@ -48,6 +48,23 @@ struct TnArgs {
   int i_tile, j_tile, rows_per_slice;   // set by the dispatcher
 };
 
+// fused MLP half of a Swin block (mlp_fused.hip)
+struct MlpArgs {
+  NtArgs o;                    // output side: C, ldc, M, N (= channels), bias, epi (2 forward | 5 backward), R, R2, ep_stats, rowscale, stats_out
+  const float* X; long ldx;    // phase-1 activation rows [M][ldx]: forward x (LayerNorm prologue), backward dY
+  const float* ln_stats;       // forward: {mean, rstd}[M] of the X rows
+  int K1, Kp1;                 // channels (phase-1 reduce length) and its padded plane width
+  int hs;                      // hidden / 2
+  const unsigned short* W1b;   // phase-1 weight planes, rows in (round, half, unit) order   (prep perm 1)
+  const unsigned short* W2b;   // phase-2 weight planes, k in the accumulator-register order (prep perm 2)
+  const float* b1;             // forward: bias of the hidden layer [hidden]
+  float* H; long ldh;          // forward: pre-activation output (may be null) | backward: its input
+  float* dH; float* GH;        // backward outputs [M][ldh]: d loss / d h and gelu(h)
+  const float* rowscale1; int rows_per_scale1;   // backward: per-sample scale of dY (DropPath), null = 1
+  int bwd;
+};
+int sr_mlp_fused(MlpArgs& p, hipStream_t st);
+
 int sr_matmul_mode();        // 0: f32-accurate bf16x3 | 1: single bf16 product (srhip_set_matmul_mode)
 int sr_gemm_nt(NtArgs& p, hipStream_t st);
 int sr_conv3x3_nt(NtArgs& p, hipStream_t st);

@@ -21,24 +21,49 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
+// Index maps of the fused MLP kernel (mlp_fused.hip), hs = hidden / 2, 96 hidden units per wave and round:
+//   perm 1 (rows): plane row  round*192 + half*96 + i            <- hidden unit half*hs + round*96 + i
+//   perm 2 (k)   : plane k    round*192 + t*16 + 8h + 4a + e     <- hidden unit (t&1)*hs + round*96 + 16*(t>>1) + 8a + 4h + e
+//                  (t = stage of the round: its parity is the hidden half; inside a 16-group the order of the
+//                  accumulator registers of the 32x32 MFMA tile that produced the activation)
+// -1 = padding (zero)
+__device__ __forceinline__ int mlp_row_src(int r, int hs) {
+  const int c = r / 192, rem = r - c * 192, half = rem / 96, i = rem - half * 96;
+  const int off = c * 96 + i;
+  return off < hs ? half * hs + off : -1;
+}
+__device__ __forceinline__ int mlp_k_src(int k, int hs) {
+  const int c = k / 192, rem = k - c * 192, t = rem >> 4, pos = rem & 15;
+  const int off = c * 96 + 16 * (t >> 1) + 8 * ((pos >> 2) & 1) + 4 * (pos >> 3) + (pos & 3);
+  return off < hs ? (t & 1) * hs + off : -1;
+}
+
 // kind 0: out planes [3][Kp/16][ntap*rows][16] (sub-chunk major, see gemm_ntb.hip) of  v(tap, r, k) = W[off + tap*s_tap + r*s_row + k*s_k]
-//         * (gamma_mode 1: gamma[k] | 2: gamma[r] | 0: 1)
+//         * (gamma_mode = mode & 3: 1: gamma[k] | 2: gamma[r] | 0: 1);  mode >> 2: 1 = r through mlp_row_src, 2 = k through
+//         mlp_k_src (hs in s0; one tap)
 __device__ __forceinline__ void job_planes(const PrepEntry& e, int lb) {
   const int Kp = sr_kp(e.n2), kq = Kp >> 2;
   const long rows = (long)e.n0 * e.n1;
   const long i = (long)lb * 256 + threadIdx.x;
   if (i >= rows * kq) return;
   const int row = (int)(i / kq), k0 = (int)(i - (long)row * kq) * 4;
-  const int tap = row / e.n0, r = row - tap * e.n0;
+  const int perm = e.mode >> 2, gm = e.mode & 3;
+  int tap = row / e.n0, r = row - tap * e.n0;
+  long tapoff = (long)tap * e.s0;
+  if (perm) { tap = 0; tapoff = 0; }
+  if (perm == 1) r = mlp_row_src(r, e.s0);
   float v[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int k = k0 + j;
+    int k = k0 + j;
     float x = 0.f;
-    if (k < e.n2) {
-      x = ldg_f(e.a + (long)e.off + (long)tap * e.s0 + (long)r * e.s1 + (long)k * e.s2);
-      if (e.mode == 1) x *= ldg_f(e.b + k);
-      else if (e.mode == 2) x *= ldg_f(e.b + r);
+    if (k < e.n2 && r >= 0) {
+      if (perm == 2) k = mlp_k_src(k, e.s0);
+      if (k >= 0) {
+        x = ldg_f(e.a + (long)e.off + tapoff + (long)r * e.s1 + (long)k * e.s2);
+        if (gm == 1) x *= ldg_f(e.b + k);
+        else if (gm == 2) x *= ldg_f(e.b + r);
+      }
     }
     v[j] = x;
   }

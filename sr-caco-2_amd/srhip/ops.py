@@ -147,6 +147,41 @@ class PrepTable:
                   s1=1 if transpose else K, s2=K if transpose else 1, off=0,
                   mode=0 if gamma is None else (2 if transpose else 1))
 
+    def mlp_planes(self, W, out, hidden, which, gamma=None):
+        """Operand planes of the fused MLP kernel (srhip_mlp_fwd_bx3 / srhip_mlp_bwd_bx3) from a
+        Linear weight W, hidden units in the kernel's own order.  which:
+          'rows'   W [hidden, C]: plane rows = hidden units, k = C            (forward, first product)
+          'k'      W [C, hidden]: rows = C, k = hidden units                   (forward, second product)
+          'rowsT'  W [C, hidden] read transposed: rows = hidden units, k = C   (backward, first product)
+          'kT'     W [hidden, C] read transposed: rows = C, k = hidden units   (backward, second product)
+        gamma: LayerNorm weight folded along C ('rows', 'kT')."""
+        assert W.is_contiguous() and W.dtype == torch.float32 and hidden % 2 == 0
+        hp = mlp_hidden_padded(hidden)
+        if which in ("rows", "kT"):
+            assert W.shape[0] == hidden
+            C = W.shape[1]
+        else:
+            assert W.shape[1] == hidden and gamma is None
+            C = W.shape[0]
+        self.keep += [W, out, gamma]
+        g = gamma is not None
+        if which == "rows":
+            assert (out.rows, out.K) == (hp, C)
+            self._add(kind=0, a=_p(W), b=_p(gamma), out=_p(out.planes), n0=hp, n1=1, n2=C, s0=hidden // 2,
+                      s1=C, s2=1, off=0, mode=4 + (1 if g else 0))
+        elif which == "k":
+            assert (out.rows, out.K) == (C, hp)
+            self._add(kind=0, a=_p(W), out=_p(out.planes), n0=C, n1=1, n2=hp, s0=hidden // 2,
+                      s1=hidden, s2=1, off=0, mode=8)
+        elif which == "rowsT":
+            assert (out.rows, out.K) == (hp, C)
+            self._add(kind=0, a=_p(W), out=_p(out.planes), n0=hp, n1=1, n2=C, s0=hidden // 2,
+                      s1=1, s2=hidden, off=0, mode=4)
+        else:
+            assert which == "kT" and (out.rows, out.K) == (C, hp)
+            self._add(kind=0, a=_p(W), b=_p(gamma), out=_p(out.planes), n0=C, n1=1, n2=hp, s0=hidden // 2,
+                      s1=1, s2=C, off=0, mode=8 + (2 if g else 0))
+
     def conv(self, w, out, data_grad=False):
         """planes of the tap-major pack [9][Co][Ci] of a conv weight [Co,Ci,3,3], or of the
         flipped / transposed twin [9][Ci][Co] used by the data gradient."""
@@ -248,6 +283,58 @@ def gemm_nt_lnbwd(A, W, x, stats, res, out):
     else:
         call("srhip_gemm_nt_bx3_lnbwd", *args)
     return out
+
+
+def mlp_hidden_padded(hidden):
+    """Hidden units as the fused MLP kernel lays them out: rounds of 2 halves x 96."""
+    return -(-(hidden // 2) // 96) * 192
+
+
+def mlp_fusable(C, hidden):
+    """Shapes srhip_mlp_fwd_bx3 / srhip_mlp_bwd_bx3 take (the README SwinIR block: 180 -> 360 -> 180)."""
+    return use_bx3() and C % 4 == 0 and C <= 192 and hidden % 8 == 0 and 192 < hidden <= 384
+
+
+def mlp_fwd(x, stats, W1p, b1, W2p, b2, out, h=None, rowscale=None, rows_per_scale=1, stats_out=None):
+    """out = x + s * (gelu(LN(x) @ W1^T + b1) @ W2^T + b2) in ONE kernel; h (optional) receives the
+    pre-activation, stats_out the {mean, rstd} of the out rows.  W1p / W2p: PrepTable.mlp_planes
+    'rows' / 'k'."""
+    _chk(x, stats, b1, b2, out, h, rowscale, stats_out)
+    M, C = x.shape
+    hidden = b1.shape[0]
+    assert (W1p.rows, W1p.K) == (mlp_hidden_padded(hidden), C) and (W2p.rows, W2p.K) == (C, mlp_hidden_padded(hidden))
+    assert out.shape == (M, C) and (h is None or h.shape == (M, hidden))
+    args = (_p(x), x.stride(0), _p(stats), _p(W1p.planes), _p(b1), _p(W2p.planes), _p(b2), _p(h),
+            0 if h is None else h.stride(0), _p(out), out.stride(0), M, C, hidden, _p(rowscale), rows_per_scale,
+            _p(stats_out), _st())
+    if probe.on("mlp_fused"):
+        with probe.timed(("mlp_fused", M, C, hidden, "fwd"), 4.0 * M * C * hidden,
+                         4.0 * (M * (2 * C + (hidden if h is not None else 0)) + 2 * C * hidden)):
+            call("srhip_mlp_fwd_bx3", *args)
+    else:
+        call("srhip_mlp_fwd_bx3", *args)
+    return out
+
+
+def mlp_bwd(dy, W2Tp, W1Tp, h, dh, gh, x, stats, dx, rowscale=None, rows_per_scale=1):
+    """Data gradient of mlp_fwd in ONE kernel: dh = (s * dy @ W2) * gelu'(h), gh = gelu(h) (operands of the
+    weight gradients), dx = dy + LayerNorm_backward(dh @ W1; x, stats).  W2Tp / W1Tp: PrepTable.mlp_planes
+    'rowsT' / 'kT'."""
+    _chk(dy, h, dh, gh, x, stats, dx, rowscale)
+    M, C = dy.shape
+    hidden = h.shape[1]
+    assert (W2Tp.rows, W2Tp.K) == (mlp_hidden_padded(hidden), C) and (W1Tp.rows, W1Tp.K) == (C, mlp_hidden_padded(hidden))
+    assert dh.shape == h.shape == gh.shape and dh.stride(0) == h.stride(0) == gh.stride(0)
+    assert x.shape == (M, C) and dx.shape == (M, C)
+    args = (_p(dy), dy.stride(0), _p(W2Tp.planes), _p(W1Tp.planes), _p(h), h.stride(0), _p(dh), _p(gh), _p(x),
+            x.stride(0), _p(stats), _p(dx), dx.stride(0), M, C, hidden, _p(rowscale), rows_per_scale, _st())
+    if probe.on("mlp_fused"):
+        with probe.timed(("mlp_fused", M, C, hidden, "bwd"), 4.0 * M * C * hidden,
+                         4.0 * (M * (3 * C + 3 * hidden) + 2 * C * hidden)):
+            call("srhip_mlp_bwd_bx3", *args)
+    else:
+        call("srhip_mlp_bwd_bx3", *args)
+    return dx
 
 
 def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0):

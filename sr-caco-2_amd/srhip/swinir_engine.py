@@ -58,6 +58,10 @@ class SwinIREngine:
         self._prep = self._prep_sig = None
         self.prepared = False
         self.saved = None
+        # SRHIP_FUSE_MLP=1: LN -> fc1 -> GELU -> fc2 -> residual (and its data gradient) as one kernel each
+        # (mlp_fused.hip).  Parity-tested, and measured SLOWER in the training step than the separate Linear
+        # launches (413 vs 433 patches/s, same box), so it is not the default.
+        self.fuse_mlp = ops.mlp_fusable(self.C, self.hid) and os.environ.get("SRHIP_FUSE_MLP", "0") != "0"
 
     def bucket_prefixes(self):
         """Gradient buckets in backward-completion order: one per RSTB layer (the
@@ -107,6 +111,12 @@ class SwinIREngine:
                 tb.linear(w1, ws.planes(f"{i}.w1T", C, hid, dev), gamma=g2, transpose=True)
                 tb.linear(w2, ws.planes(f"{i}.w2", C, hid, dev))
                 tb.linear(w2, ws.planes(f"{i}.w2T", hid, C, dev), transpose=True)
+                if self.fuse_mlp:      # operand planes of the fused MLP kernels (hidden units in the kernel's order)
+                    hp = ops.mlp_hidden_padded(hid)
+                    tb.mlp_planes(w1, ws.planes(f"{i}.m1", hp, C, dev), hid, "rows", gamma=g2)
+                    tb.mlp_planes(w2, ws.planes(f"{i}.m2", C, hp, dev), hid, "k")
+                    tb.mlp_planes(w2, ws.planes(f"{i}.m2T", hp, C, dev), hid, "rowsT")
+                    tb.mlp_planes(w1, ws.planes(f"{i}.m1T", C, hp, dev), hid, "kT", gamma=g2)
                 tb.fold_bias(wq, b.attn.qkv.bias.data, b.norm1.bias.data, D.get(f"{i}.bq", 3 * C, device=dev))
                 tb.fold_bias(w1, b.mlp.fc1.bias.data, b.norm2.bias.data, D.get(f"{i}.b1", hid, device=dev))
                 tb.bias_expand(b.attn.relative_position_bias_table.data,
@@ -214,15 +224,20 @@ class SwinIREngine:
                             rowscale=s1, rows_per_scale=H * W, stats_out=st2 if fuse else None)
                 if not fuse:
                     ops.layernorm_fwd(x1, st2)
-                h = buf(f"{k}.h", T, hid)
-                ops.gemm_nt(x1, ws[f"{bi}.w1"], D.d[f"{bi}.b1"], out=h, a_mode=1, ln_stats=st2)
                 # block outputs ping-pong in eval, are kept per block in training
                 x2 = buf(f"{bi if save else bi % 2}.x2", T, C)
                 st_next = None
                 if fuse and j + 1 < nblk:
                     st_next = buf(f"{(bi + 1) if save else (bi + 1) % 2}.st1", T, 2)
-                ops.gemm_nt(h, ws[f"{bi}.w2"], blk.mlp.fc2.bias.data, out=x2, a_mode=2, epi=2,
-                            R=x1, rowscale=s2, rows_per_scale=H * W, stats_out=st_next)
+                if self.fuse_mlp and not ops.lib.srhip_get_matmul_mode():
+                    h = buf(f"{k}.h", T, hid) if save else None       # inference never reads it
+                    ops.mlp_fwd(x1, st2, ws[f"{bi}.m1"], D.d[f"{bi}.b1"], ws[f"{bi}.m2"], blk.mlp.fc2.bias.data,
+                                x2, h=h, rowscale=s2, rows_per_scale=H * W, stats_out=st_next)
+                else:
+                    h = buf(f"{k}.h", T, hid)
+                    ops.gemm_nt(x1, ws[f"{bi}.w1"], D.d[f"{bi}.b1"], out=h, a_mode=1, ln_stats=st2)
+                    ops.gemm_nt(h, ws[f"{bi}.w2"], blk.mlp.fc2.bias.data, out=x2, a_mode=2, epi=2,
+                                R=x1, rowscale=s2, rows_per_scale=H * W, stats_out=st_next)
                 if save:
                     sv["blocks"].append((t, st1, qkv, a, x1, st2, h))
                 t = x2
@@ -351,13 +366,17 @@ class SwinIREngine:
                 s2 = None if dp is None else dp[2 * bi + 1]
                 g1, gout = gbufs[(gi + 1) % 3], gbufs[(gi + 2) % 3]
                 # ---- MLP branch: x2 = x1 + s2*(gelu(h) W2^T + b2)
-                ops.gemm_nt(g, ws[f"{bi}.w2T"], None, out=dh, epi=3, R=h, rowscale=s2,
-                            rows_per_scale=H * W, aux=gh)
-                if ws.use_bx3:      # LayerNorm backward fused into the GEMM epilogue
-                    ops.gemm_nt_lnbwd(dh, ws[f"{bi}.w1T"], x1, st2, g, g1)
+                if self.fuse_mlp:
+                    ops.mlp_bwd(g, ws[f"{bi}.m2T"], ws[f"{bi}.m1T"], h, dh, gh, x1, st2, g1, rowscale=s2,
+                                rows_per_scale=H * W)
                 else:
-                    ops.gemm_nt(dh, ws[f"{bi}.w1T"], None, out=dxh)
-                    ops.layernorm_bwd(dxh, x1, st2, g1, res=g)
+                    ops.gemm_nt(g, ws[f"{bi}.w2T"], None, out=dh, epi=3, R=h, rowscale=s2,
+                                rows_per_scale=H * W, aux=gh)
+                    if ws.use_bx3:      # LayerNorm backward fused into the GEMM epilogue
+                        ops.gemm_nt_lnbwd(dh, ws[f"{bi}.w1T"], x1, st2, g, g1)
+                    else:
+                        ops.gemm_nt(dh, ws[f"{bi}.w1T"], None, out=dxh)
+                        ops.layernorm_bwd(dxh, x1, st2, g1, res=g)
                 # ---- attention branch: x1 = t + s1*(a Wp^T + bp)
                 ops.gemm_nt(g1, ws[f"{bi}.wpT"], None, out=da, epi=2, rowscale=s1, rows_per_scale=H * W)
                 dbT = dbT_all[bi, :heads]

@@ -99,7 +99,15 @@ def test_tiny_forced_droppath_and_padded(SwinIR):
     assert (y - g["y_pad"]).abs().max() <= 1e-5
 
 
-def test_readme_config_forward_vs_reference_golden(SwinIR):
+@pytest.fixture(params=["separate", "fused_mlp"])
+def mlp_path(request, monkeypatch):
+    """README-configuration tests run on both forms of the MLP half of a block: the separate Linear
+    launches (default) and the fused kernels of mlp_fused.hip (SRHIP_FUSE_MLP=1)."""
+    monkeypatch.setenv("SRHIP_FUSE_MLP", "1" if request.param == "fused_mlp" else "0")
+    return request.param
+
+
+def test_readme_config_forward_vs_reference_golden(SwinIR, mlp_path):
     g = load("g4_swinir_readme")
     cfg = O.swinir_config()
     sd = O.swinir_init_state_dict(cfg, seed=0)
@@ -108,6 +116,7 @@ def test_readme_config_forward_vs_reference_golden(SwinIR):
     net = net.cuda().eval()
     with torch.no_grad():
         y = net(g["x"].cuda()).cpu()
+    assert net.engine.fuse_mlp == (mlp_path == "fused_mlp")
     mae = (y - g["y"]).abs().mean().item()
     assert mae <= 1e-5, f"pixel MAE {mae}"
     tgt = torch.rand(1, 1, 512, 512, generator=torch.Generator().manual_seed(1))
@@ -120,7 +129,7 @@ def test_readme_config_forward_vs_reference_golden(SwinIR):
     assert (yp - yo).abs().mean() <= 1e-5
 
 
-def test_readme_config_train_step_grads_vs_oracle(SwinIR):
+def test_readme_config_train_step_grads_vs_oracle(SwinIR, mlp_path):
     cfg = O.swinir_config(drop_path_rate=0.0)
     sd = O.swinir_init_state_dict(cfg, seed=0)
     net = readme(SwinIR, 0.0)
