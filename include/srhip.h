@@ -140,6 +140,24 @@ int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float
                            int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                            const float* rowscale, float alpha, void* stream);
 
+/* 3x3 conv + PixelShuffle(2) as ONE kernel per direction -- the Upsampler stage of EDSR and of SwinIR's
+ * 'pixelshuffle' tail (dlib/models/network_nlsn.py:89-93,103-108; network_swinir.py:857-870): the
+ * [B][H][W][4F] conv result is never materialised.
+ *   srhip_conv3x3_ps2_bx3          Yup [B][2H][2W][F] (ldy = its pixel pitch) = PixelShuffle(2)(conv(X) + bias)
+ *                                  (epi 0 | 1 relu | 6 leaky relu(alpha)); Cout = 4F
+ *   srhip_conv3x3_ps2_bwd_data_bx3 dX [B][H][W][Cin] = data gradient of that conv read from dYup [B][2H][2W][F]
+ *   srhip_conv3x3_ps2_wgrad_bx3    partial weight gradients (as srhip_conv3x3_wgrad_bx3, torch channel order:
+ *                                  srhip_reduce_conv_wgrad applies unchanged) with dY read from dYup
+ * Weight planes with the conv's output channels in sub-pixel-major order sp*F + c <- torch channel c*4 + sp,
+ * sp = 2*i + j: srhip_prep_table kind 0 with mode 12 (rows: forward pack) / 16 (k: data-gradient pack).
+ * F a multiple of 32. */
+int srhip_conv3x3_ps2_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Yup, long ldy,
+                          int B, int H, int W, int Cin, int Cout, int epi, float alpha, void* stream);
+int srhip_conv3x3_ps2_bwd_data_bx3(const float* dYup, long lddy, const void* Wbt, float* dX, long ldx, int B, int H,
+                                   int W, int Cout, int Cin, void* stream);
+int srhip_conv3x3_ps2_wgrad_bx3(const float* dYup, long lddy, const float* X, long ldx, int B, int H, int W,
+                                int Cout, int Cin, float* part, float* part_colsum, int S, void* stream);
+
 /* Weight gradients: out[i][j] = sum_m A[m][i] * pro(B)[m][j], reduce dimension
  * split in S slices written to part[S][(9)][NI][NJ] (+ column sums of A in
  * part_colsum[S][NI] for the bias gradient); srhip_reduce_* sums the slices.

@@ -18,7 +18,7 @@ int sr_fail(int code, const char* fmt, ...) {
 extern "C" {
 
 const char* srhip_last_error(void) { return g_err; }
-int srhip_abi_version(void) { return 7; }
+int srhip_abi_version(void) { return 8; }
 
 static int g_matmul_mode = 0;
 int srhip_set_matmul_mode(int mode) {
@@ -212,6 +212,34 @@ int srhip_gemm_tn_grouped(const srhip_tn_problem* probs, int nprob, int M, int S
 }
 int srhip_gemm_tn_grouped_bx3(const srhip_tn_problem* probs, int nprob, int M, int S, void* stream) {
   return gemm_tn_grouped_any(true, probs, nprob, M, S, stream);
+}
+
+// conv + PixelShuffle(2) as one kernel per direction (NtArgs.ps / TnArgs.ps)
+int srhip_conv3x3_ps2_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Yup, long ldy,
+                          int B, int H, int W, int Cin, int Cout, int epi, float alpha, void* stream) {
+  SR_REQUIRE(epi == 0 || epi == 1 || epi == 6, "conv3x3_ps2_bx3: epi %d (0 bias | 1 relu | 6 leaky relu)", epi);
+  NtArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = X; p.lda = ldx; p.Wb = (const unsigned short*)Wb; p.C = Yup; p.ldc = ldy;
+  p.N = Cout; p.K = Cin; p.bias = bias; p.epi = epi; p.rows_per_scale = H * W; p.alpha = alpha;
+  p.batch = B; p.H = H; p.Wd = W; p.ps = 1;
+  return sr_conv3x3_ntb(p, (hipStream_t)stream);
+}
+int srhip_conv3x3_ps2_bwd_data_bx3(const float* dYup, long lddy, const void* Wbt, float* dX, long ldx, int B, int H,
+                                   int W, int Cout, int Cin, void* stream) {
+  NtArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = dYup; p.lda = lddy; p.Wb = (const unsigned short*)Wbt; p.C = dX; p.ldc = ldx;
+  p.N = Cin; p.K = Cout; p.rows_per_scale = H * W; p.alpha = 1.f; p.batch = B; p.H = H; p.Wd = W; p.ps = 2;
+  return sr_conv3x3_ntb(p, (hipStream_t)stream);
+}
+int srhip_conv3x3_ps2_wgrad_bx3(const float* dYup, long lddy, const float* X, long ldx, int B, int H, int W,
+                                int Cout, int Cin, float* part, float* part_colsum, int S, void* stream) {
+  TnArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = dYup; p.lda = lddy; p.B = X; p.ldb = ldx; p.M = B * H * W; p.NI = Cout; p.NJ = Cin;
+  p.part = part; p.part_colsum = part_colsum; p.S = S; p.conv = 1; p.batch = B; p.H = H; p.Wd = W; p.ps = 1;
+  return sr_gemm_tnb(p, (hipStream_t)stream);
 }
 
 static int conv_wgrad_any(bool bx, const float* dY, long lddy, const float* X, long ldx, int B, int H, int W,

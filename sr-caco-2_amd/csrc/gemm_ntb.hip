@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
       const int y = y0 + hy - 1, x = x0 + hx - 1;
       inA[it] = y >= 0 && y < p.H && x >= 0 && x < p.Wd;
       const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.Wd - 1);
-      offA[it] = (unsigned)(((img * p.H + yc) * p.Wd + xc) * (int)p.lda + c4 * 4) * 4u;
+      if (p.ps == 2) offA[it] = (unsigned)(((img * 2 * p.H + 2 * yc) * 2 * p.Wd + 2 * xc) * (int)p.lda + c4 * 4) * 4u;
+      else offA[it] = (unsigned)(((img * p.H + yc) * p.Wd + xc) * (int)p.lda + c4 * 4) * 4u;
     } else {
       const int gm = min(m0 + row, p.M - 1);
       offA[it] = (unsigned)(gm * (int)p.lda + c4 * 4) * 4u;
@@ -126,7 +127,12 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
   // immediate s_waitcnt and serialise the prefetch): K-tail / halo lanes read a valid
   // address and are zeroed when the chunk is staged (store_a).
   auto load_a = [&](int kc, f32x4 (&ra)[A_IT]) {
-    const char* base = (const char*)(p.A + kc * BKB);
+    long koff = kc * BKB;
+    if (CONV && p.ps == 2) {     // chunk kc = channels c0.. of sub-pixel sp of the shuffled image (K/4 is a multiple of 32)
+      const int fk = p.K >> 2, sp = (kc * BKB) / fk, c0 = kc * BKB - sp * fk;
+      koff = ((long)(sp >> 1) * 2 * p.Wd + (sp & 1)) * p.lda + c0;
+    }
+    const char* base = (const char*)(p.A + koff);
     const bool ktail = kc * BKB + BKB > p.K;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -463,7 +469,9 @@ int sr_conv3x3_ntb(NtArgs& p, hipStream_t st) {
   p.Kp = sr_kp(p.K);
   p.dbg = ntb_env("SRHIP_NT_DBG", 0);      // ablation / stamp bits, 0 in production
   p.amp = sr_matmul_mode();
-  SR_REQUIRE((long)p.M * p.lda < (1L << 29) && 54L * p.N * p.Kp < (1L << 31),
+  SR_REQUIRE((long)p.M * p.lda * (p.ps == 2 ? 4 : 1) < (1L << 29) && 54L * p.N * p.Kp < (1L << 31),
              "conv3x3_bx3: operand larger than 2 GiB (32-bit staging offsets)");
+  SR_REQUIRE(p.ps == 0 || (p.ps == 1 && p.N % 4 == 0 && !p.R) || (p.ps == 2 && p.K % 128 == 0),
+             "conv3x3_bx3 + PixelShuffle(2): Cout %% 4 == 0 and no residual operand (store side), Cin/4 a multiple of 32 (load side)");
   return dispatch_ntb<true>(p, st);
 }

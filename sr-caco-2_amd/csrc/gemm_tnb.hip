@@ -133,13 +133,21 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
   // are never written out); a lane that straddles it is handled in store()
   const int opvalid = isB ? jvalid : ivalid;
   const int colq = max(min(W * lane, opvalid - W), 0);
-  const unsigned colb = (unsigned)colq * 4u;   // byte offset of this lane's columns in a token row
+  const int ps_f = p.NI >> 2;
+  unsigned colb = (unsigned)colq * 4u;         // byte offset of this lane's columns in a token row
+  if (!isB && p.ps) {
+    const int ig = i0 + colq, sp = ig / ps_f, cc = ig - sp * ps_f;
+    colb = (unsigned)((((sp >> 1) * 2 * p.Wd + (sp & 1)) * (int)p.lda + cc) * 4);
+  }
   const int dsh = W * lane - colq;             // > 0: this lane's load was shifted left
   const bool ragged = opvalid % W != 0;        // uniform: some lane straddles the valid width
   const float* const pA = p.A;
   const float* const pB = p.B;
   const long ldA = p.lda, ldB = p.ldb;
-  const float* const opP = isB ? pB + j0 : pA + i0;    // this wave's operand (uniform)
+  // conv + PixelShuffle(2) gradient (p.ps): kernel column i = sp*F + c is channel c of sub-pixel sp of the image
+  // [batch][2H][2Wd][F], F = NI / 4.  A lane's W adjacent columns share one sub-pixel (F % W == 0, checked by the
+  // dispatcher): the token decides the pixel (2y, 2x), the lane's columns a constant byte offset to (i, j) and c
+  const float* const opP = isB ? pB + j0 : (p.ps ? pA : pA + i0);    // this wave's operand (uniform)
   const long opLd = isB ? ldB : ldA;
   float cs[W];
 #pragma unroll
@@ -170,6 +178,11 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
       ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
       srow = (b * p.H + yy) * p.Wd + xx;
     }
+    if (!isB && p.ps) {      // token (b, y, x) of the low-resolution grid -> pixel (2y + i, 2x + j) of the shuffled image
+      const int x = gm % p.Wd, tq = gm / p.Wd;
+      const int y = tq % p.H, b = tq / p.H;
+      srow = (b * 2 * p.H + 2 * y) * 2 * p.Wd + 2 * x;
+    }
     const int t_row = ok ? srow : -1;
     if (!isB) {
       const float* sp = (in && p.a_rowscale) ? p.a_rowscale + gm / p.a_rowscale_rows : k_sr_neutral + 1;
@@ -180,13 +193,15 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
     }
     // all 16 tokens present, source rows consecutive (conv interior)
     const int row0 = __builtin_amdgcn_readlane(t_row, 0);
-    const bool dense = __all(t_row == row0 + (lane & 15) && row0 >= 0);
+    const int step = (!isB && p.ps) ? 2 : 1;            // shuffled gradient image: consecutive tokens are two pixels apart
+    const bool dense = __all(t_row == row0 + step * (lane & 15) && row0 >= 0);
     if (dense) {
       const float* q = P + (long)row0 * ld;                 // uniform, advanced per token
+      const long adv = step * ld;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(q, colb);
-        q += ld;
+        q += adv;
       }
     } else {
 #pragma unroll
@@ -373,7 +388,10 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (wi * W + i) * 32 + mfma_row(q, lane);
-        if (row < ivalid) out[(long)(i0 + row) * p.NJ + j0 + col] = acc[i][j][q];
+        if (row < ivalid) {
+          const int io = i0 + row;               // p.ps: kernel row sp*F + c is torch channel c*4 + sp
+          out[(long)(p.ps ? (io % ps_f) * 4 + io / ps_f : io) * p.NJ + j0 + col] = acc[i][j][q];
+        }
       }
     }
   }
@@ -385,7 +403,10 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
       for (int j = 0; j < W; ++j) red[hh * BC + W * lane + j] = cs[j];
     }
     __syncthreads();
-    if (tid < ivalid) p.part_colsum[(long)s * p.NI + i0 + tid] = red[tid] + red[BC + tid];
+    if (tid < ivalid) {
+      const int io = i0 + tid;
+      p.part_colsum[(long)s * p.NI + (p.ps ? (io % ps_f) * 4 + io / ps_f : io)] = red[tid] + red[BC + tid];
+    }
   }
 }
 
@@ -526,6 +547,8 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
   int tile;
   const int w = pick_w(p.NI, p.NJ, &tile);
   p.i_tile = p.j_tile = tile;
+  SR_REQUIRE(!p.ps || (p.conv && p.NI % 4 == 0 && (p.NI / 4) % w == 0 && p.NI % p.i_tile == 0),
+             "conv3x3_wgrad + PixelShuffle(2): Cout/4 = %d must be a multiple of %d (columns per lane), Cout of the tile", p.NI / 4, w);
   const int rps = sr_cdiv(p.M, p.S);
   p.rows_per_slice = (rps + TKB - 1) / TKB * TKB;
   dim3 grid(p.S, sr_cdiv(p.NI, p.i_tile) * sr_cdiv(p.NJ, p.j_tile), p.conv ? 9 : 1);

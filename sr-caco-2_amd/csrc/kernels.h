@@ -30,6 +30,11 @@ struct NtArgs {
   // bf16x3 path (gemm_ntb.hip): W pre-split into planes [3][(9)][N][Kp] bf16
   const unsigned short* Wb; int Kp;
   int amp;                    // 1: one bf16 product of the leading planes (reduced-precision inference)
+  // conv + PixelShuffle(2) in one kernel (bx3 conv only).  1: the store goes to the shuffled image
+  // C [batch][2H][2Wd][N/4] (ldc = its pixel pitch), kernel column n = sp*(N/4) + c is channel c of
+  // sub-pixel sp = 2*i + j (weight rows in that order: prep perm 3).  2: the A operand is read from the
+  // shuffled image [batch][2H][2Wd][K/4] in the same order, k = sp*(K/4) + c (the data gradient of 1)
+  int ps;
 };
 
 struct TnArgs {
@@ -46,6 +51,8 @@ struct TnArgs {
   int conv;                   // 0 | 1: B rows are tap-shifted pixels of a [batch][H][Wd] image
   int batch, H, Wd;
   int i_tile, j_tile, rows_per_slice;   // set by the dispatcher
+  int ps;                     // conv: A is the shuffled gradient image [batch][2H][2Wd][NI/4] of a conv + PixelShuffle(2)
+                              // (lda = its pixel pitch); out rows are written in torch channel order c*4 + sp
 };
 
 // fused MLP half of a Swin block (mlp_fused.hip)

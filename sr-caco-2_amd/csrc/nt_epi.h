@@ -125,7 +125,10 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][W
     const int col = (wn * WN + j) * 32 + r;        // column inside the N block
     const bool cok = col < nvalid;
     const int gn = n0 + col;
-    const float bv = (cok && p.bias) ? p.bias[gn] : 0.f;
+    // conv + PixelShuffle(2): column gn = sp*(N/4) + cc is channel cc of sub-pixel sp (torch channel cc*4 + sp)
+    const bool shuf = CONV && p.ps == 1;
+    const int fs = p.N >> 2, sp = shuf ? gn / fs : 0, cc = shuf ? gn - sp * fs : gn;
+    const float bv = (cok && p.bias) ? p.bias[shuf ? cc * 4 + sp : gn] : 0.f;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const int mt = wm * WM + i;
@@ -136,7 +139,8 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][W
         const int lr = mfma_row(q, lane);          // row inside the 32-row tile
         if (CONV) {
           const int y = y0 + 2 * mt + (lr >> 4), x = x0 + (lr & 15);
-          grow[q] = (cok && y < p.H && x < p.Wd) ? (img * p.H + y) * p.Wd + x : -1;
+          if (shuf) grow[q] = (cok && y < p.H && x < p.Wd) ? ((img * 2 * p.H + 2 * y + (sp >> 1)) * 2 * p.Wd + 2 * x + (sp & 1)) : -1;
+          else grow[q] = (cok && y < p.H && x < p.Wd) ? (img * p.H + y) * p.Wd + x : -1;
         } else {
           const int g = m0 + mt * 32 + lr;
           grow[q] = (cok && g < p.M) ? g : -1;
@@ -212,7 +216,7 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][W
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q)
-        if (grow[q] >= 0) p.C[(long)grow[q] * p.ldc + gn] = v[q];
+        if (grow[q] >= 0) p.C[(long)grow[q] * p.ldc + cc] = v[q];
     }
   }
 }

@@ -40,7 +40,7 @@ __device__ __forceinline__ int mlp_k_src(int k, int hs) {
 
 // kind 0: out planes [3][Kp/16][ntap*rows][16] (sub-chunk major, see gemm_ntb.hip) of  v(tap, r, k) = W[off + tap*s_tap + r*s_row + k*s_k]
 //         * (gamma_mode = mode & 3: 1: gamma[k] | 2: gamma[r] | 0: 1);  mode >> 2: 1 = r through mlp_row_src, 2 = k through
-//         mlp_k_src (hs in s0; one tap)
+//         mlp_k_src (hs in s0; one tap); 3 / 4 = r / k in sub-pixel-major order of a conv + PixelShuffle(2)
 __device__ __forceinline__ void job_planes(const PrepEntry& e, int lb) {
   const int Kp = sr_kp(e.n2), kq = Kp >> 2;
   const long rows = (long)e.n0 * e.n1;
@@ -50,8 +50,10 @@ __device__ __forceinline__ void job_planes(const PrepEntry& e, int lb) {
   const int perm = e.mode >> 2, gm = e.mode & 3;
   int tap = row / e.n0, r = row - tap * e.n0;
   long tapoff = (long)tap * e.s0;
-  if (perm) { tap = 0; tapoff = 0; }
+  if (perm == 1 || perm == 2) { tap = 0; tapoff = 0; }
   if (perm == 1) r = mlp_row_src(r, e.s0);
+  // conv + PixelShuffle(2) (NtArgs.ps): plane row / k index sp*(n/4) + c holds torch channel c*4 + sp
+  if (perm == 3) { const int fs = e.n0 >> 2; r = (r % fs) * 4 + r / fs; }
   float v[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -59,6 +61,7 @@ __device__ __forceinline__ void job_planes(const PrepEntry& e, int lb) {
     float x = 0.f;
     if (k < e.n2 && r >= 0) {
       if (perm == 2) k = mlp_k_src(k, e.s0);
+      if (perm == 4) { const int fs = e.n2 >> 2; k = (k % fs) * 4 + k / fs; }
       if (k >= 0) {
         x = ldg_f(e.a + (long)e.off + tapoff + (long)r * e.s1 + (long)k * e.s2);
         if (gm == 1) x *= ldg_f(e.b + k);

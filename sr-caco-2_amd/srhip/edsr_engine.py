@@ -9,6 +9,7 @@ and both residual adds are conv epilogues, the ReLU mask is the epilogue of the
 data-gradient conv, pixel shuffles are index kernels.
 """
 import math
+import os
 
 import torch
 
@@ -31,6 +32,10 @@ class EDSREngine:
         self._prep = self._prep_sig = None
         self.prepared = False
         self.saved = None
+        # Upsampler stage = conv F -> 4F + PixelShuffle(2) as one kernel per direction (no [B,H,W,4F] tensor,
+        # no shuffle launches); SRHIP_FUSE_PS=0: conv + index kernel
+        self.fuse_ps = self.ws.use_bx3 and ops.ps2_fusable(self.F, 4 * self.F) and \
+            os.environ.get("SRHIP_FUSE_PS", "1") != "0"
 
     def invalidate(self):
         self.prepared = False
@@ -57,8 +62,9 @@ class EDSREngine:
                 tb = ops.PrepTable()
                 for name, conv in self._body_convs():
                     co, ci = conv.weight.shape[:2]
-                    tb.conv(conv.weight.data, ws.planes(name + ".wp", 9 * co, ci, dev))
-                    tb.conv(conv.weight.data, ws.planes(name + ".wpt", 9 * ci, co, dev), data_grad=True)
+                    ps2 = self.fuse_ps and name.startswith("up")
+                    tb.conv(conv.weight.data, ws.planes(name + ".wp", 9 * co, ci, dev), ps2=ps2)
+                    tb.conv(conv.weight.data, ws.planes(name + ".wpt", 9 * ci, co, dev), data_grad=True, ps2=ps2)
                 self._prep, self._prep_sig = tb.build(dev), sig
             self._prep.run()
         else:
@@ -103,10 +109,13 @@ class EDSREngine:
         u, h, w = rb, H, W
         ups = []
         for i in range(self.stages):
-            c = buf(f"c{i}", B, h, w, 4 * F)
-            ops.conv3x3(u, self.ws[f"up{i}.wp"], net.tail[0][2 * i].bias.data, 4 * F, out=c)
             un = buf(f"u{i}", B, 2 * h, 2 * w, F)
-            ops.pixel_shuffle(c, 2, nhwc_out=True, out=un)
+            if self.fuse_ps:
+                ops.conv3x3_ps2(u, self.ws[f"up{i}.wp"], net.tail[0][2 * i].bias.data, un)
+            else:
+                c = buf(f"c{i}", B, h, w, 4 * F)
+                ops.conv3x3(u, self.ws[f"up{i}.wp"], net.tail[0][2 * i].bias.data, 4 * F, out=c)
+                ops.pixel_shuffle(c, 2, nhwc_out=True, out=un)
             if save:
                 ups.append(u)
             u, h, w = un, 2 * h, 2 * w
@@ -142,11 +151,17 @@ class EDSREngine:
         ops.conv3x3_cin1_fwd(dy, net.tail[1].weight.data, None, F, out=du, flip=True)
         for i in reversed(range(self.stages)):
             h, w = h // 2, w // 2
-            dc = buf(f"dc{i}", B, h, w, 4 * F)
-            ops.pixel_shuffle(du, 2, nhwc_out=True, inverse=True, out=dc)
-            ops.conv3x3_wgrad(dc, sv["ups"][i], G(f"tail.0.{2 * i}.weight"), G(f"tail.0.{2 * i}.bias"))
-            du = buf(f"du{i}", B, h, w, F)
-            ops.conv3x3(dc, self.ws[f"up{i}.wpt"], None, F, out=du)
+            if self.fuse_ps:     # both gradients read the gradient of the shuffled image
+                ops.conv3x3_wgrad(du, sv["ups"][i], G(f"tail.0.{2 * i}.weight"), G(f"tail.0.{2 * i}.bias"), ps2=True)
+                dun = buf(f"du{i}", B, h, w, F)
+                ops.conv3x3_ps2_bwd_data(du, self.ws[f"up{i}.wpt"], dun)
+                du = dun
+            else:
+                dc = buf(f"dc{i}", B, h, w, 4 * F)
+                ops.pixel_shuffle(du, 2, nhwc_out=True, inverse=True, out=dc)
+                ops.conv3x3_wgrad(dc, sv["ups"][i], G(f"tail.0.{2 * i}.weight"), G(f"tail.0.{2 * i}.bias"))
+                du = buf(f"du{i}", B, h, w, F)
+                ops.conv3x3(dc, self.ws[f"up{i}.wpt"], None, F, out=du)
         drb = du                                             # grad wrt rb (= also grad wrt f0 via the skip)
         # The body's weight gradients are DEFERRED: every layer keeps its incoming gradient in a buffer
         # of its own (2*nb+1 buffers of B*H*W*F floats; sized for 288 GB of HBM) and all 2*nb+1

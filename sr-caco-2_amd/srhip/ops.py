@@ -182,18 +182,22 @@ class PrepTable:
             self._add(kind=0, a=_p(W), b=_p(gamma), out=_p(out.planes), n0=C, n1=1, n2=hp, s0=hidden // 2,
                       s1=1, s2=C, off=0, mode=8 + (2 if g else 0))
 
-    def conv(self, w, out, data_grad=False):
+    def conv(self, w, out, data_grad=False, ps2=False):
         """planes of the tap-major pack [9][Co][Ci] of a conv weight [Co,Ci,3,3], or of the
-        flipped / transposed twin [9][Ci][Co] used by the data gradient."""
+        flipped / transposed twin [9][Ci][Co] used by the data gradient.  ps2: the conv feeds a
+        PixelShuffle(2) fused into the kernel (conv3x3_ps2*): its output channels in sub-pixel-major
+        order sp*(Co/4) + c <- torch channel c*4 + sp."""
         Co, Ci = w.shape[:2]
-        assert w.is_contiguous() and tuple(w.shape[2:]) == (3, 3)
+        assert w.is_contiguous() and tuple(w.shape[2:]) == (3, 3) and (not ps2 or Co % 4 == 0)
         rows, kd = (Ci, Co) if data_grad else (Co, Ci)
         assert (out.rows, out.K) == (9 * rows, kd)
         self.keep += [w, out]
         if data_grad:   # out[t][ci][co] = w[co][ci][8 - t]
-            self._add(kind=0, a=_p(w), out=_p(out.planes), n0=Ci, n1=9, n2=Co, s0=-1, s1=9, s2=Ci * 9, off=8, mode=0)
+            self._add(kind=0, a=_p(w), out=_p(out.planes), n0=Ci, n1=9, n2=Co, s0=-1, s1=9, s2=Ci * 9, off=8,
+                      mode=16 if ps2 else 0)
         else:           # out[t][co][ci] = w[co][ci][t]
-            self._add(kind=0, a=_p(w), out=_p(out.planes), n0=Co, n1=9, n2=Ci, s0=1, s1=Ci * 9, s2=9, off=0, mode=0)
+            self._add(kind=0, a=_p(w), out=_p(out.planes), n0=Co, n1=9, n2=Ci, s0=1, s1=Ci * 9, s2=9, off=0,
+                      mode=12 if ps2 else 0)
 
     def fold_bias(self, W, b, beta, out):
         N, K = W.shape
@@ -470,17 +474,61 @@ def linear_wgrad_grouped(problems, ln_grads_zeroed=False):
     call("srhip_reduce_wgrad_grouped", ctypes.addressof(red), n, S, _st())
 
 
-def conv3x3_wgrad(dY, X, dW, db):
-    """dY NHWC [B,H,W,Cout], X NHWC [B,H,W,Cin] -> dW [Cout,Cin,3,3], db [Cout]."""
+def ps2_fusable(Cin, Cout):
+    """conv Cin -> Cout followed by PixelShuffle(2) as one kernel per direction (conv3x3_ps2*)?"""
+    return use_bx3() and Cout % 256 == 0 and Cin % 4 == 0 and Cin <= 128 and bx3_for(Cout, Cin) and bx3_nt_for(Cout, Cin)
+
+
+def conv3x3_ps2(X, Wp, bias, out, epi=0, alpha=1.0):
+    """PixelShuffle(2)(conv3x3(X) + bias) in one kernel: X NHWC [B,H,W,Cin], Wp Bx3 pack built with
+    PrepTable.conv(ps2=True) -> out NHWC [B,2H,2W,Cout/4]."""
+    _chk(X, bias, out)
+    B, H, W, Cin = X.shape
+    F = out.shape[3]
+    assert isinstance(Wp, Bx3) and Wp.rows == 9 * 4 * F and Wp.K == Cin and out.shape == (B, 2 * H, 2 * W, F)
+    args = (_p(X), X.stride(2), _p(Wp.planes), _p(bias), _p(out), out.stride(2), B, H, W, Cin, 4 * F, epi,
+            float(alpha), _st())
+    if probe.on("conv_nt"):
+        T = B * H * W
+        with probe.timed(("conv_nt", T, 4 * F, Cin, "ps2"), 18.0 * T * 4 * F * Cin, 4.0 * (T * Cin + 36 * F * Cin + T * 4 * F)):
+            call("srhip_conv3x3_ps2_bx3", *args)
+    else:
+        call("srhip_conv3x3_ps2_bx3", *args)
+    return out
+
+
+def conv3x3_ps2_bwd_data(dYup, Wpt, out):
+    """Data gradient of conv3x3_ps2 read from the gradient of its OUTPUT: dYup NHWC [B,2H,2W,F], Wpt Bx3 pack
+    built with PrepTable.conv(data_grad=True, ps2=True) -> out NHWC [B,H,W,Cin]."""
+    _chk(dYup, out)
+    B, H, W, Cin = out.shape
+    F = dYup.shape[3]
+    assert isinstance(Wpt, Bx3) and Wpt.rows == 9 * Cin and Wpt.K == 4 * F and dYup.shape == (B, 2 * H, 2 * W, F)
+    args = (_p(dYup), dYup.stride(2), _p(Wpt.planes), _p(out), out.stride(2), B, H, W, 4 * F, Cin, _st())
+    if probe.on("conv_nt"):
+        T = B * H * W
+        with probe.timed(("conv_nt", T, Cin, 4 * F, "ps2"), 18.0 * T * 4 * F * Cin, 4.0 * (T * Cin + 36 * F * Cin + T * 4 * F)):
+            call("srhip_conv3x3_ps2_bwd_data_bx3", *args)
+    else:
+        call("srhip_conv3x3_ps2_bwd_data_bx3", *args)
+    return out
+
+
+def conv3x3_wgrad(dY, X, dW, db, ps2=False):
+    """dY NHWC [B,H,W,Cout], X NHWC [B,H,W,Cin] -> dW [Cout,Cin,3,3], db [Cout].
+    ps2: dY is the gradient of the PixelShuffle(2) OUTPUT, NHWC [B,2H,2W,Cout/4] (conv3x3_ps2)."""
     _chk(dY, X, dW, db)
-    B, H, W, Cout = dY.shape
-    Cin = X.shape[3]
+    B, H, W, Cin = X.shape
+    Cout = dW.shape[0]
+    assert dY.shape == ((B, 2 * H, 2 * W, Cout // 4) if ps2 else (B, H, W, Cout))
     bx = bx3_for(Cout, Cin)
+    assert bx or not ps2, "the fused PixelShuffle weight gradient runs on the bf16x3 kernels"
     S, n = tn_plan(B * H * W, Cout, Cin, True, bx)
     part = SCRATCH.get("tn_part", n, device=dY.device)
     cs = SCRATCH.get("tn_colsum", S * Cout, device=dY.device)
     def run():
-        call("srhip_conv3x3_wgrad" + _tn_sfx(bx), _p(dY), dY.stride(2), _p(X), X.stride(2), B, H, W, Cout, Cin,
+        name = "srhip_conv3x3_ps2_wgrad_bx3" if ps2 else "srhip_conv3x3_wgrad" + _tn_sfx(bx)
+        call(name, _p(dY), dY.stride(2), _p(X), X.stride(2), B, H, W, Cout, Cin,
              _p(part), _p(cs), S, _st())
     if probe.on("conv_tn"):
         T = B * H * W

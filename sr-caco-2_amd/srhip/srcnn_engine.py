@@ -67,15 +67,22 @@ class SRCNNEngine:
         def buf(name, *shape):
             return self.bufs.get(f"{tag}.{name}", *shape, device=dev)
 
-        a0 = ops.im2col_c1(x, 5, KP1, out=buf("a0", T, KP1))
-        h1 = ops.gemm_nt(a0, ws["w1"], net.features[0].bias.data, out=buf("h1", T, C1), epi=1)
-        h2 = ops.gemm_nt(h1, ws["w2"], net.map[0].bias.data, out=buf("h2", T, C2), epi=1)
         b3 = D.get("b3p", 4, device=dev)
         b3.zero_()
         b3[:1].copy_(net.reconstruction.bias.data)
-        y4 = ops.gemm_nt(h2, ws["w3"], b3, out=buf("y4", T, 4))
         y = torch.empty(B, H, W, device=dev) if not save else buf("y", B, H, W)
-        y.view(T).copy_(y4[:, 0])
+        # the GEMM kernels address an operand with 32-bit element offsets (rows * 1024 < 2^29): inference walks
+        # the batch in groups of images that fit; a training step keeps the whole batch (the weight gradients
+        # reduce over all of it) and is limited to 2^19 pixels per rank by the same bound
+        per = max(1, ((1 << 29) - 1) // (C1 * H * W)) if not save else B
+        for b0 in range(0, B, per):
+            nb = min(per, B - b0)
+            t = nb * H * W
+            a0 = ops.im2col_c1(x[b0:b0 + nb], 5, KP1, out=buf("a0", t, KP1))
+            h1 = ops.gemm_nt(a0, ws["w1"], net.features[0].bias.data, out=buf("h1", t, C1), epi=1)
+            h2 = ops.gemm_nt(h1, ws["w2"], net.map[0].bias.data, out=buf("h2", t, C2), epi=1)
+            y4 = ops.gemm_nt(h2, ws["w3"], b3, out=buf("y4", t, 4))
+            y[b0:b0 + nb].view(t).copy_(y4[:, 0])
         if save:
             self.saved = dict(a0=a0, h1=h1, h2=h2, B=B, H=H, W=W)
         return y.view(B, 1, H, W)

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Inference sweep over the networks libsrhip runs (BASELINE.json config 5 is the reference's 16-method
+x {2,4,8} evaluation sweep, eval_all.sh): patches/s of ``model.test()`` on synthetic 512x512 HR patches,
+fp32-accurate and with ``--amp True`` (reduced-precision kernels, where the network takes them), one GPU.
+
+    python tools/eval_sweep.py [--batch 8] [--iters 20] [--out profiles/r02_eval_sweep.json]
+
+Every network is built through the same ``main.parse_input`` / ``define_model`` path as ``main.py`` /
+``eval.py``; the interpolated input the VDSR / DRRN / SRCNN family expects is produced before the timed
+region (the reference builds it in the dataset, dataset_dpsr.py:700-710)."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sr-caco-2_amd"))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+NETS = [("swinir", "SWINIR"), ("EDSR_LIIF", "EDSR_LIIF"), ("VDSR", "VDSR"), ("DRRN", "DRRN"), ("SRCNN", "SRCNN")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    import main as M
+    from dlib.models.select_model import define_model
+    rows = []
+    for net_type, method in NETS:
+        for scale in (2, 4, 8):
+            for amp in (False, True):
+                argv = ["--net_type", net_type, "--method", method, "--task", "super-resolution", "--scale", str(scale),
+                        "--n_channels", "1", "--h_size", "512", "--batch_size", str(a.batch), "--amp", str(amp)]
+                args = M.parse_input(argv)
+                torch.manual_seed(0)
+                model = define_model(args)
+                model.init_train()
+                batch = M.synth_batch(a.batch, scale, 512, model.device, 7)
+                batch["l_to_h_img"] = F.interpolate(batch["l_im"], size=(512, 512), mode="bicubic").clamp(0, 1)
+                model.feed_data(batch)
+                for _ in range(3):
+                    model.test()
+                torch.cuda.synchronize()
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
+                for _ in range(a.iters):
+                    model.test()
+                t1.record()
+                torch.cuda.synchronize()
+                ms = t0.elapsed_time(t1) / a.iters
+                out = model.E
+                assert tuple(out.shape[-2:]) == (512, 512) and torch.isfinite(out).all()
+                amp_used = bool(amp and getattr(model.netG, "amp", False) and net_type not in ("VDSR", "DRRN"))
+                rows.append({"net_type": net_type, "scale": scale, "amp_flag": amp, "reduced_precision_kernels": amp_used,
+                             "batch": a.batch, "ms_per_batch": ms, "patches_per_s": a.batch / ms * 1e3})
+                print(json.dumps(rows[-1]), flush=True)
+                del model
+                torch.cuda.empty_cache()
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump({"what": "model.test() on synthetic 512x512 HR patches, one MI355X", "rows": rows}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
