@@ -410,10 +410,19 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
   }
 }
 
+// Conv launches are one-dimensional with the block -> (slice, tile, tap) map made here: the 9 taps x i-tiles of one
+// slice read the same rows of dY and X, and the hardware deals consecutive block indices to the 8 XCDs round robin --
+// with (slice, tile, tap) on the grid axes every XCD's L2 fetched every slice for itself (rocprofv3 PMC: 2.5 GB per
+// launch against 0.29 GB algorithmic on the EDSR x8 upsampler problems, 19 GB against 2.2 GB on the x4 body batch,
+// i.e. 3.6-6 TB/s of L2 misses: the kernel's bound).  sr_xcd_block gives an XCD a contiguous run of logical indices:
+// the blocks that share a slice meet in ONE L2.  SRHIP_TN_XCD=0: the old order.
 template <int W>
-__global__ void __launch_bounds__(512, 1) k_tnb(TnArgs p) {
+__global__ void __launch_bounds__(512, 1) k_tnb(TnArgs p, int tiles, int xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  tnb_body<W>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+  if (!p.conv) { tnb_body<W>(p, blockIdx.x, blockIdx.y, 0, smem); return; }
+  const int L = xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int tap = L % 9, t2 = L / 9;
+  tnb_body<W>(p, t2 / tiles, t2 % tiles, tap, smem);
 }
 
 struct TnbGroup {
@@ -446,22 +455,26 @@ struct TnbConvBatch {
   const float* A[TNB_BATCH_MAX];
   const float* B[TNB_BATCH_MAX];
   long part_stride, colsum_stride;     // floats between consecutive problems' partial buffers
-  int n, tiles;
+  int n, tiles, xcd;
 };
 template <int W>
 __global__ void __launch_bounds__(512, 1) k_tnb_conv_batched(TnbConvBatch g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int k = blockIdx.y / g.tiles, tile = blockIdx.y - k * g.tiles;
+  // one-dimensional grid, XCD-aware (see k_tnb): logical index -> (problem, slice, tile, tap), taps fastest
+  const int L = g.xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int tap = L % 9;
+  int rr = L / 9;
+  const int tile = rr % g.tiles; rr /= g.tiles;
+  const int sl = rr % g.base.S, k = rr / g.base.S;
   TnArgs p = g.base;
   p.A = g.A[k];
   p.B = g.B[k];
   p.part = g.base.part + (long)k * g.part_stride;
   p.part_colsum = g.base.part_colsum ? g.base.part_colsum + (long)k * g.colsum_stride : nullptr;
   // taps fastest: the nine tap blocks of one (slice, problem) are dispatched together and walk the same
-  // rows of dY / X at the same pace, so eight of them are served from the Infinity Cache (with the taps
-  // in grid.z, five ran in the first round of blocks and four re-read everything from HBM in the
-  // second: EDSR x2, 134 MB per operand, 208 instead of 228 patches/s)
-  tnb_body<W>(p, blockIdx.x / 9, tile, blockIdx.x % 9, smem);
+  // rows of dY / X at the same pace (with the taps in grid.z, five ran in the first round of blocks and
+  // four re-read everything in the second: EDSR x2, 134 MB per operand, 208 instead of 228 patches/s)
+  tnb_body<W>(p, sl, tile, tap, smem);
 }
 
 int pick_tile(int n, int* w) {
@@ -551,7 +564,10 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
              "conv3x3_wgrad + PixelShuffle(2): Cout/4 = %d must be a multiple of %d (columns per lane), Cout of the tile", p.NI / 4, w);
   const int rps = sr_cdiv(p.M, p.S);
   p.rows_per_slice = (rps + TKB - 1) / TKB * TKB;
-  dim3 grid(p.S, sr_cdiv(p.NI, p.i_tile) * sr_cdiv(p.NJ, p.j_tile), p.conv ? 9 : 1);
+  const int tiles = sr_cdiv(p.NI, p.i_tile) * sr_cdiv(p.NJ, p.j_tile);
+  dim3 grid(p.S, tiles, 1);
+  if (p.conv) grid = dim3(p.S * tiles * 9, 1, 1);
+  static const int xcd = [] { const char* e = getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
   static bool attr[4] = {false, false, false, false};
 #define SR_TNB(W_)                                                                        \
   if (w == W_) {                                                                          \
@@ -559,7 +575,7 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
       if (int rc = reserve_lds(k_tnb<W_>, lds_bytes(W_), "k_tnb")) return rc;             \
       attr[W_] = true;                                                                    \
     }                                                                                     \
-    hipLaunchKernelGGL((k_tnb<W_>), grid, dim3(512), lds_bytes(W_), st, p);               \
+    hipLaunchKernelGGL((k_tnb<W_>), grid, dim3(512), lds_bytes(W_), st, p, tiles, xcd);   \
   }
   SR_TNB(1) SR_TNB(2) SR_TNB(3)
 #undef SR_TNB
@@ -608,7 +624,9 @@ int sr_conv_wgrad_batched_tnb(const TnArgs& base, const float* const* A, const f
   g.part_stride = part_stride;
   g.colsum_stride = colsum_stride;
   for (int k = 0; k < n; ++k) { g.A[k] = A[k]; g.B[k] = B[k]; }
-  dim3 grid(base.S * 9, g.tiles * n, 1);
+  static const int xcd = [] { const char* e = getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
+  g.xcd = xcd;
+  dim3 grid(base.S * 9 * g.tiles * n, 1, 1);
   static bool attr[4] = {false, false, false, false};
 #define SR_TNB_CB(W_)                                                                          \
   if (w == W_) {                                                                               \
