@@ -146,6 +146,8 @@ int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float
  *   srhip_conv3x3_ps2_bx3          Yup [B][2H][2W][F] (ldy = its pixel pitch) = PixelShuffle(2)(conv(X) + bias)
  *                                  (epi 0 | 1 relu | 6 leaky relu(alpha)); Cout = 4F
  *   srhip_conv3x3_ps2_bwd_data_bx3 dX [B][H][W][Cin] = data gradient of that conv read from dYup [B][2H][2W][F]
+ *                                  (epi 0 | 4: * (R > 0) | 7: * (R > 0 ? 1 : alpha), R [B][H][W][Cin] = the activation
+ *                                  that fed the conv)
  *   srhip_conv3x3_ps2_wgrad_bx3    partial weight gradients (as srhip_conv3x3_wgrad_bx3, torch channel order:
  *                                  srhip_reduce_conv_wgrad applies unchanged) with dY read from dYup
  * Weight planes with the conv's output channels in sub-pixel-major order sp*F + c <- torch channel c*4 + sp,
@@ -154,7 +156,8 @@ int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float
 int srhip_conv3x3_ps2_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Yup, long ldy,
                           int B, int H, int W, int Cin, int Cout, int epi, float alpha, void* stream);
 int srhip_conv3x3_ps2_bwd_data_bx3(const float* dYup, long lddy, const void* Wbt, float* dX, long ldx, int B, int H,
-                                   int W, int Cout, int Cin, void* stream);
+                                   int W, int Cout, int Cin, int epi, const float* R, long ldr, float alpha,
+                                   void* stream);
 int srhip_conv3x3_ps2_wgrad_bx3(const float* dYup, long lddy, const float* X, long ldx, int B, int H, int W,
                                 int Cout, int Cin, float* part, float* part_colsum, int S, void* stream);
 
@@ -428,6 +431,11 @@ int srhip_nonfinite_flag(const float* x, long n, int* flag, void* stream);
 int srhip_axpby(float* y, const float* x, long n, float a, float b, void* stream);
 /* g[i] = a[i] > 0 ? g[i] : 0 -- backward of a ReLU whose OUTPUT a was kept (nn.ReLU, network_vdsr.py:28). */
 int srhip_relu_mask(float* g, const float* a, long n, void* stream);
+/* g[i] = a[i] > 0 ? g[i] : alpha * g[i] -- backward of a LeakyReLU(alpha > 0) whose OUTPUT a was kept
+ * (nn.LeakyReLU(0.2), network_mslapsr.py:58,83,92). */
+int srhip_leaky_relu_mask(float* g, const float* a, long n, float alpha, void* stream);
+/* x[i] = x[i] > 0 ? x[i] : alpha * x[i] in place (nn.LeakyReLU(0.2) behind the 1-channel edge conv, network_mslapsr.py:80-83). */
+int srhip_leaky_relu(float* x, long n, float alpha, void* stream);
 /* out[0] = sum(x) (fp64 accumulation); workspace: 2048 doubles. */
 int srhip_sum(const float* x, long n, float* out, double* workspace, void* stream);
 

@@ -508,6 +508,52 @@ def g_srcnn():
     npz("g22_srcnn", **arrs)
 
 
+# ---------------------------------------------------------------- G23 MSLapSRN
+def g_mslapsrn():
+    """MSLapSRN (network_mslapsr.py:67-174) x2 / x4 / x8: output, intermediate images and the gradients of the
+    trainer's multi-scale loss (model_plain.py:277-314) from the reference class on a 2 x 1 x 12 x 10 input;
+    weights from the oracle's seeded initialiser (regenerated from the seed by the tests)."""
+    print("G23 MSLapSRN")
+    from dlib.models.network_mslapsr import MSLapSRN as RefNet
+    out = {}
+    for scale in (2, 4, 8):
+        sd = O.mslapsrn_init_state_dict(scale, seed=90 + scale)
+        net = RefNet(upscale=scale, in_chans=1)
+        assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(30 + scale)
+        x = torch.rand(2, 1, 12, 10)
+        tgt = torch.rand(2, 1, 12 * scale, 10 * scale)
+        y = net(x)
+        inter = list(net.intermediate_outs)
+        O.mslapsrn_loss(y, inter, tgt).backward()
+        sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        yo, io = O.mslapsrn_forward(sdo, x, scale)
+        O.mslapsrn_loss(yo, io, tgt).backward()
+        close(yo.detach(), y.detach(), 2e-6, f"mslapsrn x{scale} forward")
+        assert len(io) == len(inter)
+        for a, b in zip(io, inter):
+            close(a.detach(), b.detach(), 2e-6, f"mslapsrn x{scale} intermediate")
+        pre = f"x{scale}/"
+        sums = []
+        keep = ["conv1.0.weight", "laplacian_pyramid_conv1.10.bias", "laplacian_pyramid_conv2.weight",
+                "laplacian_pyramid_conv2.bias", "laplacian_pyramid_conv3.weight"]
+        if scale == 4:      # the 64 x 64 tensors in full at one scale only (fixture size); sums for the rest
+            keep += ["laplacian_pyramid_conv1.0.cl.0.weight", "laplacian_pyramid_conv1.10.weight",
+                     "laplacian_pyramid_conv4.10.weight", "laplacian_pyramid_conv4.9.cl.0.weight"]
+        for k, p in net.named_parameters():
+            close(sdo[k].grad, p.grad, 2e-6 * max(1.0, float(p.grad.abs().max())), f"mslapsrn x{scale} d{k}")
+            if k in keep:
+                out[pre + "grad/" + k] = p.grad
+            sums.append([p.grad.double().sum().item(), p.grad.double().abs().sum().item()])
+        out[pre + "x"], out[pre + "target"], out[pre + "y"] = x, tgt, y.detach()
+        for i, t in enumerate(inter):
+            out[pre + f"inter{i}"] = t.detach()
+        out[pre + "grad_sums"] = np.array(sums)
+        out[pre + "seed"] = np.array(90 + scale)
+    npz("g23_mslapsrn", **out)
+
+
 # ---------------------------------------------------------------- G19 eval.py experiment folder
 def g_eval_fixture():
     """A reference-format experiment directory + dataset + folds, and what the REFERENCE's own
@@ -1156,7 +1202,7 @@ def g_optim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
-            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn]
+            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:
         if not only or g.__name__ in only:

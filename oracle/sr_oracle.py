@@ -414,6 +414,84 @@ def vdsr_init_state_dict(in_chans: int = 1, seed: int = 0) -> SD:
     return sd
 
 
+# ----------------------------------------------------------------------------
+# MSLapSRN (dlib/models/network_mslapsr.py)
+# ----------------------------------------------------------------------------
+def mslapsrn_forward(sd: SD, x: Tensor, upscale: int) -> Tuple[Tensor, List[Tensor]]:
+    """network_mslapsr.py:134-174: conv1 + LeakyReLU(0.2); per octave: 10 x (conv + LeakyReLU), ConvTranspose2d(64, 64,
+    4, 2, 1) + LeakyReLU -> features, conv 64 -> 1 on them + ConvTranspose2d(1, 1, 4, 2, 1) of the current image ->
+    the octave's image.  Returns (last image, [images of the earlier octaves]) = (output, net.intermediate_outs)."""
+    lr = lambda t: F.leaky_relu(t, 0.2)
+    feat = lr(F.conv2d(x, sd["conv1.0.weight"], sd["conv1.0.bias"], padding=1))
+    img, outs = x, []
+    for o in range(int(math.log2(upscale))):
+        a, b, c = (f"laplacian_pyramid_conv{3 * o + k}" for k in (1, 2, 3))
+        for k in range(10):
+            feat = lr(F.conv2d(feat, sd[f"{a}.{k}.cl.0.weight"], sd[f"{a}.{k}.cl.0.bias"], padding=1))
+        feat = lr(F.conv_transpose2d(feat, sd[f"{a}.10.weight"], sd[f"{a}.10.bias"], stride=2, padding=1))
+        img = F.conv_transpose2d(img, sd[f"{b}.weight"], sd[f"{b}.bias"], stride=2, padding=1) + \
+            F.conv2d(feat, sd[f"{c}.weight"], sd[f"{c}.bias"], padding=1)
+        outs.append(img)
+    return outs[-1], outs[:-1]
+
+
+def mslapsrn_loss(out: Tensor, inter: Sequence[Tensor], target: Tensor, kind: str = "l1") -> Tensor:
+    """model_plain.py:277-314 (loss_mslaprs): the loss of the output plus the same loss of every intermediate image
+    against the bicubically resized target (align_corners=True, clamped to [0, 1]), divided by the number of images."""
+    f = loss_l1 if kind == "l1" else loss_l2
+    total = f(out, target)
+    for t in inter:
+        gt = torch.clamp(F.interpolate(target, size=t.shape[2:], mode="bicubic", align_corners=True), 0.0, 1.0)
+        total = total + f(t, gt)
+    return total / (len(inter) + 1.0)
+
+
+def mslapsrn_init_state_dict(upscale: int, seed: int = 0) -> SD:
+    """Seeded weights in the shapes / key order of the reference net: Kaiming-normal (fan_out) convs and the bilinear
+    4x4 filter on the transposed convs as in network_mslapsr.py:176-188 (a law the reference defines but does not
+    call), here with 10 % noise on the transposed-conv weights and small random biases so that every tap and every
+    bias matters in the parity fixtures."""
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+
+    def conv(name, co, ci):
+        sd[name + ".weight"] = torch.randn(co, ci, 3, 3, generator=g) * math.sqrt(2.0 / (9 * co))
+        sd[name + ".bias"] = torch.randn(co, generator=g) * 0.05
+
+    def convT(name, c):
+        k = torch.tensor([0.25, 0.75, 0.75, 0.25])
+        w = (k[:, None] * k[None, :]).expand(c, c, 4, 4) / max(1.0, c / 4.0)
+        sd[name + ".weight"] = w * (1 + 0.1 * torch.randn(c, c, 4, 4, generator=g))
+        sd[name + ".bias"] = torch.randn(c, generator=g) * 0.05
+
+    conv("conv1.0", 64, 1)
+    for o in range(int(math.log2(upscale))):
+        a, b, c = (f"laplacian_pyramid_conv{3 * o + k}" for k in (1, 2, 3))
+        for k in range(10):
+            conv(f"{a}.{k}.cl.0", 64, 64)
+        convT(f"{a}.10", 64)
+        convT(b, 1)
+        conv(c, 1, 64)
+    return sd
+
+
+def conv_transpose4x4s2_as_conv3x3(wT: Tensor) -> Tensor:
+    """ConvTranspose2d(Ci, Co, 4, stride 2, padding 1) == PixelShuffle(2) o Conv2d(Ci, 4*Co, 3, padding 1): output pixel
+    (2y + i, 2x + j) takes input pixels (y + dy, x + dx) with kernel tap (i + 1 - 2 dy, j + 1 - 2 dx) where that is
+    inside the 4x4 kernel -- 2 x 2 of the 3 x 3 taps per sub-pixel.  wT [Ci, Co, 4, 4] -> [4*Co, Ci, 3, 3] with
+    PixelShuffle's channel order co*4 + 2i + j."""
+    ci, co = wT.shape[:2]
+    w = wT.new_zeros(co, 4, ci, 3, 3)
+    for i in range(2):
+        for j in range(2):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    ky, kx = i + 1 - 2 * dy, j + 1 - 2 * dx
+                    if 0 <= ky < 4 and 0 <= kx < 4:
+                        w[:, 2 * i + j, :, dy + 1, dx + 1] = wT[:, :, ky, kx].t()
+    return w.reshape(4 * co, ci, 3, 3)
+
+
 def drrn_forward(sd: SD, x: Tensor, upscale: int, num_residual_units: int) -> Tensor:
     """network_drrn.py:22-126.  The reference's ReLUs are in place: the first ReLU of the first residual unit
     rectifies the block input itself, so the identity every unit adds is relu(conv1 output)."""

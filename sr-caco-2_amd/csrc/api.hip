@@ -226,11 +226,14 @@ int srhip_conv3x3_ps2_bx3(const float* X, long ldx, const void* Wb, const float*
   return sr_conv3x3_ntb(p, (hipStream_t)stream);
 }
 int srhip_conv3x3_ps2_bwd_data_bx3(const float* dYup, long lddy, const void* Wbt, float* dX, long ldx, int B, int H,
-                                   int W, int Cout, int Cin, void* stream) {
+                                   int W, int Cout, int Cin, int epi, const float* R, long ldr, float alpha,
+                                   void* stream) {
+  SR_REQUIRE(epi == 0 || ((epi == 4 || epi == 7) && R), "conv3x3_ps2_bwd_data_bx3: epi %d (0 | 4, 7 with R)", epi);
   NtArgs p;
   memset(&p, 0, sizeof(p));
   p.A = dYup; p.lda = lddy; p.Wb = (const unsigned short*)Wbt; p.C = dX; p.ldc = ldx;
-  p.N = Cin; p.K = Cout; p.rows_per_scale = H * W; p.alpha = 1.f; p.batch = B; p.H = H; p.Wd = W; p.ps = 2;
+  p.N = Cin; p.K = Cout; p.rows_per_scale = H * W; p.alpha = epi == 7 ? alpha : 1.f; p.batch = B; p.H = H; p.Wd = W; p.ps = 2;
+  p.epi = epi; p.R = R; p.ldr = ldr;
   return sr_conv3x3_ntb(p, (hipStream_t)stream);
 }
 int srhip_conv3x3_ps2_wgrad_bx3(const float* dYup, long lddy, const float* X, long ldx, int B, int H, int W,

@@ -449,6 +449,19 @@ __global__ void __launch_bounds__(256) k_relu_mask(float* __restrict__ g, const 
     if (!(a[i] > 0.f)) g[i] = 0.f;
 }
 
+// x = x > 0 ? x : alpha * x in place (nn.LeakyReLU after the 1-channel edge conv)
+__global__ void __launch_bounds__(256) k_leaky(float* __restrict__ x, long n, float alpha) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    x[i] = v > 0.f ? v : v * alpha;
+  }
+}
+// g *= (a > 0 ? 1 : alpha): the backward of a LeakyReLU(alpha > 0) whose output a is kept (sign(output) = sign(input))
+__global__ void __launch_bounds__(256) k_leaky_mask(float* __restrict__ g, const float* __restrict__ a, long n, float alpha) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    if (!(a[i] > 0.f)) g[i] *= alpha;
+}
+
 __global__ void __launch_bounds__(256) k_loss_l1l2(const float* __restrict__ pred, const float* __restrict__ tgt,
                                                    const float* __restrict__ wgt, float* __restrict__ grad,
                                                    double* __restrict__ part, long n, int mode, float lam,
@@ -866,6 +879,21 @@ int srhip_relu_mask(float* g, const float* a, long n, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_relu_mask, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, g, a, n);
   SR_LAUNCH_CHECK("relu_mask");
+  return 0;
+}
+
+int srhip_leaky_relu(float* x, long n, float alpha, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_leaky, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, n, alpha);
+  SR_LAUNCH_CHECK("leaky_relu");
+  return 0;
+}
+
+int srhip_leaky_relu_mask(float* g, const float* a, long n, float alpha, void* stream) {
+  if (n <= 0) return 0;
+  SR_REQUIRE(alpha > 0.f, "leaky_relu_mask: the sign of the kept output decides the slope only for alpha > 0");
+  hipLaunchKernelGGL(k_leaky_mask, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, g, a, n, alpha);
+  SR_LAUNCH_CHECK("leaky_relu_mask");
   return 0;
 }
 

@@ -36,6 +36,9 @@ def define_G(args):
     if net_type == constants.SRCNN:                 # select_network.py:207-210
         from dlib.models.network_srcnn import SRCNN as net
         return net(in_chans=opt_net[f'{nt}_in_chans'])
+    if net_type == constants.MSLAPSR:               # select_network.py:103-108
+        from dlib.models.network_mslapsr import MSLapSRN as net
+        return net(upscale=opt_net[f'{nt}_upscale'], in_chans=opt_net[f'{nt}_in_chans'])
     raise NotImplementedError(
         f"net_type {net_type!r}: only {constants.MODELS} run on libsrhip (SURVEY.md section 8f lists "
-        f"the remaining 11 reference networks as 'next')")
+        f"the remaining 10 reference networks as 'next')")

@@ -8,14 +8,17 @@ EDSR_LIIF = 'EDSR_LIIF'
 VDSR = 'VDSR'  # https://arxiv.org/pdf/1511.04587.pdf (reference constants.py:27)
 DRRN = 'DRRN'  # https://ieeexplore.ieee.org/document/8099781 (reference constants.py:29)
 SRCNN = 'SRCNN'  # https://arxiv.org/abs/1501.00092 (reference constants.py)
-MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN]
+MSLAPSR = 'MSLapSRN'  # https://arxiv.org/pdf/1710.01992.pdf (reference constants.py:47)
+MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR]
 
 SWINIR_MTH = 'SWINIR'
 EDSR_LIIF_MTH = 'EDSR_LIIF'
 VDSR_MTH = 'VDSR'
 DRRN_MTH = 'DRRN'
 SRCNN_MTH = 'SRCNN'
-NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH, DRRN: DRRN_MTH, SRCNN: SRCNN_MTH}
+MSLAPSR_MTH = 'MSLAPSR'
+NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH, DRRN: DRRN_MTH, SRCNN: SRCNN_MTH,
+                  MSLAPSR: MSLAPSR_MTH}
 
 US_PIXEL_SHUFFLE = 'pixelshuffle'
 US_PIXEL_SHUFFLE_DIRECT = 'pixelshuffledirect'

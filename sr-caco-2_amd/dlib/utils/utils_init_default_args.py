@@ -26,6 +26,8 @@ def init_net_g(netG: dict, args: dict) -> dict:
         out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels']})
     elif netG['net_type'] == constants.SRCNN:        # utils_init_default_args.py (SRCNN: in_chans only)
         out.update({f'{nt}_in_chans': args['n_channels']})
+    elif netG['net_type'] == constants.MSLAPSR:      # utils_init_default_args.py:118-125
+        out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels']})
     else:
         raise NotImplementedError(netG['net_type'])
     out[f'{nt}_init_type'] = constants.INIT_W_DEFAULT

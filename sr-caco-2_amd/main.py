@@ -120,6 +120,7 @@ def parse_input(argv=None):
                                    'resi_connection': str, 'img_range': float},
                 constants.VDSR: {},
                 constants.SRCNN: {},
+                constants.MSLAPSR: {},
                 constants.DRRN: {'num_residual_units': int},
                 constants.EDSR_LIIF: {'n_feats': int, 'n_resblocks': int, 'res_scale': float,
                                       'img_range': float}}[net_type]

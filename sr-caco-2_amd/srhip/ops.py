@@ -497,14 +497,16 @@ def conv3x3_ps2(X, Wp, bias, out, epi=0, alpha=1.0):
     return out
 
 
-def conv3x3_ps2_bwd_data(dYup, Wpt, out):
+def conv3x3_ps2_bwd_data(dYup, Wpt, out, epi=0, R=None, alpha=1.0):
     """Data gradient of conv3x3_ps2 read from the gradient of its OUTPUT: dYup NHWC [B,2H,2W,F], Wpt Bx3 pack
-    built with PrepTable.conv(data_grad=True, ps2=True) -> out NHWC [B,H,W,Cin]."""
-    _chk(dYup, out)
+    built with PrepTable.conv(data_grad=True, ps2=True) -> out NHWC [B,H,W,Cin]; epi 4 / 7: the (Leaky)ReLU mask
+    of the activation R that fed the conv."""
+    _chk(dYup, out, R)
     B, H, W, Cin = out.shape
     F = dYup.shape[3]
     assert isinstance(Wpt, Bx3) and Wpt.rows == 9 * Cin and Wpt.K == 4 * F and dYup.shape == (B, 2 * H, 2 * W, F)
-    args = (_p(dYup), dYup.stride(2), _p(Wpt.planes), _p(out), out.stride(2), B, H, W, 4 * F, Cin, _st())
+    args = (_p(dYup), dYup.stride(2), _p(Wpt.planes), _p(out), out.stride(2), B, H, W, 4 * F, Cin, epi, _p(R),
+            0 if R is None else R.stride(2), float(alpha), _st())
     if probe.on("conv_nt"):
         T = B * H * W
         with probe.timed(("conv_nt", T, Cin, 4 * F, "ps2"), 18.0 * T * 4 * F * Cin, 4.0 * (T * Cin + 36 * F * Cin + T * 4 * F)):
@@ -660,6 +662,20 @@ def relu_mask(g, a):
     """g *= (a > 0) in place (backward of a ReLU whose output a was kept)."""
     _chk(g, a)
     call("srhip_relu_mask", _p(g), _p(a), g.numel(), _st())
+    return g
+
+
+def leaky_relu_(x, alpha):
+    """x = x > 0 ? x : alpha * x in place."""
+    _chk(x)
+    call("srhip_leaky_relu", _p(x), x.numel(), float(alpha), _st())
+    return x
+
+
+def leaky_relu_mask(g, a, alpha):
+    """g *= (a > 0 ? 1 : alpha) in place (backward of a LeakyReLU whose output a was kept)."""
+    _chk(g, a)
+    call("srhip_leaky_relu_mask", _p(g), _p(a), g.numel(), float(alpha), _st())
     return g
 
 

@@ -262,6 +262,30 @@ class TrainStep:
                 raise NotImplementedError(t[0])
         return self.dy
 
+    def multiscale_loss_and_grad(self, y, inter, target):
+        """loss_mslaprs (reference model_plain.py:277-314): the loss of the output plus the same loss of every
+        intermediate image against the bicubically resized target (align_corners=True, clamped to [0, 1]; stock
+        F.interpolate, as the reference), all divided by the number of images.  L1 / L2 terms."""
+        import torch.nn.functional as F
+        n = len(inter) + 1.0
+        for t in self.loss_terms:
+            if t[0] not in ("l1", "l2"):
+                raise NotImplementedError(f"multi-scale loss (intermediate outputs) with the term {t[0]!r}: l1 / l2 only")
+        outs = [y] + list(inter)
+        tgts = [target] + [torch.clamp(F.interpolate(target, size=t.shape[2:], mode="bicubic", align_corners=True),
+                                       0.0, 1.0) for t in inter]
+        if getattr(self, "_ms", None) is None or len(self._ms[0]) != len(outs) or \
+                any(a.shape != b.shape for a, b in zip(self._ms[0], outs)):
+            self._ms = ([torch.empty_like(o) for o in outs],
+                        torch.zeros(len(outs), len(self.loss_terms), device=y.device))
+        dys, parts = self._ms
+        for j, (o, tg) in enumerate(zip(outs, tgts)):
+            for i, t in enumerate(self.loss_terms):
+                ops.loss_l1l2(o, tg.contiguous(), 0 if t[0] == "l1" else 1, t[1] / n, None, dys[j], parts[j, i:i + 1],
+                              grad_accum=i > 0)
+        self.loss_buf[1:1 + len(self.loss_terms)].copy_(parts.sum(0))
+        return dys[0], dys[1:]
+
     def step_graph(self, lr_img, hr_img):
         """The same optimisation step replayed from a hipGraph: the ~330 launches of a SwinIR step are
         captured once per (batch, shape) -- every buffer is persistent, DropPath masks are drawn on the
@@ -309,7 +333,12 @@ class TrainStep:
         if dp is None:
             dp = net.sample_drop_path(xi.shape[0], xi.device)
         y = net.engine.forward(xi, dp, save=True)
-        dy = self.loss_and_grad(y, hr_img)
+        inter = getattr(net.engine, "intermediate_outs", None)
+        d_inter = None
+        if inter:       # MSLapSRN: the trainer's multi-scale loss (model_plain.py:277-314)
+            dy, d_inter = self.multiscale_loss_and_grad(y, inter, hr_img)
+        else:
+            dy = self.loss_and_grad(y, hr_img)
         hook = None
         if self.ddp:
             self.reducer.begin()
@@ -317,7 +346,10 @@ class TrainStep:
         # ONE memset of the flat gradient buffer per step: the few gradients that are
         # accumulated with atomics (LayerNorm affine) need no per-tensor zeroing then
         self.fp.grad.zero_()
-        net.engine.backward(dy, self.fp.gviews, on_layer_done=hook, grads_zeroed=True)
+        if d_inter is not None:
+            net.engine.backward(dy, self.fp.gviews, on_layer_done=hook, grads_zeroed=True, d_inter=d_inter)
+        else:
+            net.engine.backward(dy, self.fp.gviews, on_layer_done=hook, grads_zeroed=True)
         # one device flag: non-finite loss -> the optimizer kernel skips the update
         ops.nonfinite_flag(self.loss_buf, self.flag)
         if self.ddp:

@@ -1,0 +1,112 @@
+"""MSLapSRN on libsrhip (dlib.models.network_mslapsr, srhip/mslapsrn_engine.py) against the fixture generated from
+the reference class (g23_mslapsrn.npz: output, intermediate images, gradients of the trainer's multi-scale loss) and
+against the oracle at a larger size through the fused training step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import sr_oracle as O  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GRAD_GATE = 2e-5
+
+
+def load(name):
+    z = np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiu" else z[k]) for k in z.files}
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8])
+def test_forward_intermediates_and_multiscale_gradients_vs_reference_golden(scale):
+    from dlib.models.network_mslapsr import MSLapSRN
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g23_mslapsrn").items() if k.startswith(f"x{scale}/")}
+    sd = O.mslapsrn_init_state_dict(scale, seed=int(g["seed"]))
+    net = MSLapSRN(upscale=scale, in_chans=1)
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    y = net(g["x"].cuda())
+    inter = net.intermediate_outs
+    assert len(inter) == int(np.log2(scale)) - 1
+    assert (y.detach().cpu() - g["y"]).abs().mean() <= 1e-5 and rel(y, g["y"]) < 1e-5
+    for i, t in enumerate(inter):
+        assert rel(t, g[f"inter{i}"]) < 1e-5
+    O.mslapsrn_loss(y, inter, g["target"].cuda()).backward()        # the reference's multi-scale loss on our outputs
+    sums = g["grad_sums"].numpy()
+    for i, (k, p) in enumerate(net.named_parameters()):
+        gk = p.grad.double().cpu()
+        if "grad/" + k in g:
+            assert rel(p.grad, g["grad/" + k]) <= GRAD_GATE, k
+        # every other tensor by its |gradient| sum (a LeakyReLU decision that flips under f32 rounding moves single
+        # entries: 2.6e-5 on one bias at x8, three octaves deep)
+        assert abs(gk.abs().sum().item() - sums[i][1]) <= 1e-4 * max(sums[i][1], 1e-6), (k, gk.abs().sum().item(), sums[i][1])
+    # inference form
+    net.eval()
+    with torch.no_grad():
+        ye = net(g["x"].cuda())
+    assert rel(ye, g["y"]) < 1e-5 and len(net.intermediate_outs) == len(inter)
+
+
+def test_fused_train_step_x8_vs_oracle():
+    """One fused optimisation step (forward + multi-scale L1 + backward + SGD) at 32 -> 256, x8: loss and gradients
+    equal the oracle's, and the parameters moved by -lr * gradient."""
+    from dlib.models.network_mslapsr import MSLapSRN
+    from srhip.train import TrainStep, Optimizer
+    scale = 8
+    sd = O.mslapsrn_init_state_dict(scale, seed=5)
+    net = MSLapSRN(upscale=scale, in_chans=1)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    gen = torch.Generator().manual_seed(11)
+    x, tgt = torch.rand(1, 1, 32, 32, generator=gen), torch.rand(1, 1, 256, 256, generator=gen)
+    step = TrainStep(net, [("l1", 1.0)])
+    lr = 1e-2
+    step.opt = Optimizer(step.fp, "sgd", lr=lr, momentum=0.0, nesterov=False, wd=0.0)
+    step.step(x.cuda(), tgt.cuda())
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo, io = O.mslapsrn_forward(sdo, x, scale)
+    loss = O.mslapsrn_loss(yo, io, tgt)
+    loss.backward()
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    y64, i64 = O.mslapsrn_forward(sd64, x.double(), scale)
+    O.mslapsrn_loss(y64, i64, tgt.double()).backward()
+    assert abs(step.loss_values()[0] - loss.item()) <= 2e-6 * max(1.0, abs(loss.item()))
+    worst = ("", 0.0, 0.0)
+    for k, p in net.named_parameters():
+        ref = sd64[k].grad
+        den = ref.abs().max().item() + 1e-12
+        gh = step.fp.gviews[k].detach().cpu()                # the gradient the step applied
+        e = (gh.double() - ref).abs().max().item() / den
+        e32 = (sdo[k].grad.double() - ref).abs().max().item() / den     # what float32 autograd on the CPU gets
+        if e > worst[1]:
+            worst = (k, e, e32)
+        # bias gradients are sums of 65 k signed pixels: gate against the float64 oracle, with the float32
+        # oracle's own distance from it as the yardstick
+        assert e <= max(5e-5, 3.0 * e32), (k, e, e32)
+        # and it WAS applied: w' = w - lr * g to f32 rounding of w
+        assert (p.detach().cpu() - (sd[k] - lr * gh)).abs().max() <= 1e-7 * max(1.0, sd[k].abs().max().item()), k
+    print("worst gradient vs the fp64 oracle (name, libsrhip, fp32 oracle)", worst)
+
+
+def test_registry_and_model_plain_eval():
+    import main as M
+    from dlib.models.select_model import define_model
+    args = M.parse_input(["--net_type", "MSLapSRN", "--method", "MSLAPSR", "--task", "super-resolution", "--scale", "4",
+                          "--n_channels", "1", "--h_size", "128", "--batch_size", "2"])
+    model = define_model(args)
+    model.init_train()
+    batch = M.synth_batch(2, 4, 128, model.device, 3)
+    model.feed_data(batch)
+    model.test()
+    assert tuple(model.E.shape) == (2, 1, 128, 128) and torch.isfinite(model.E).all()
+    model.optimize_parameters(0, 1)
+    assert model.check_finite() and tuple(model.E.shape) == (2, 1, 128, 128)
