@@ -410,6 +410,191 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
   }
 }
 
+// ---------------------------------------------------------------------------
+// 64-wide conv problems, THREE taps (one kernel row dy) per block.  With one tap per block a 64 x 64 tile gives a
+// consumer wave 12 MFMAs per 32-token chunk and barrier while the producers load and split 128 columns for it, and
+// every tap block splits the same dY tile again (23 % of the bf16x3 rate on the EDSR shapes).  Here the dY tile of a
+// chunk is staged ONCE for the three taps dx = -1, 0, +1 (the three shifted X tiles each get their own LDS image: a
+// token octet must be 16-byte aligned for the MFMA operand) in 16-TOKEN chunks: four operand tiles x 16 tokens = one
+// staging job per producer wave (wave k stages operand k: dY, X(-1), X(0), X(+1)), 18 MFMAs per consumer wave and
+// barrier, 48 KB of LDS -- three blocks per CU as before.  (The same with 32-token chunks -- 36 MFMAs per barrier,
+// 96 KB, ONE block per CU -- measured 4.5 % SLOWER than one tap per block: eight waves per CU do not hide the
+// producers' load latency.)  Plain operands only (no prologue, no row scale), NI and NJ multiples of 64.
+// ---------------------------------------------------------------------------
+constexpr int TK3 = 16;                         // tokens per chunk = one k step of the 32x32x16 MFMA
+__device__ __forceinline__ int unit_slot3(int col, int u) { return 2 * col + (u ^ ((col >> 3) & 1)); }
+
+template <int DBG = 0>
+__device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const int tile, const int trow,
+                                          unsigned char* smem) {
+  constexpr int BC = 64, NOP = 4;              // operand tiles per chunk: dY, X(dx = -1), X(0), X(+1)
+  constexpr int PLANE = NOP * BC * 32;         // bytes per plane per chunk buffer (two 16-byte token octets per column)
+  constexpr int BUF = 3 * PLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int wi = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;
+  const int nbj = p.NJ / BC;
+  const int bi = tile / nbj, bj = tile - bi * nbj;
+  const int i0 = bi * BC, j0 = bj * BC;
+  const int m_begin = s * p.rows_per_slice;
+  const int m_end = min(p.M, m_begin + p.rows_per_slice);
+  const int dy = trow - 1;
+  const bool do_colsum = p.part_colsum && bj == 0 && trow == 0;
+
+  struct Stage { float rv[2][8]; };            // 16 tokens x this lane's column in flight
+  const int op = wave;                         // producer wave k stages operand tile k
+  const bool isB = op != 0;
+  const int ps_f = p.NI >> 2;
+  unsigned colb = (unsigned)lane * 4u;
+  if (!isB && p.ps) {
+    const int ig = i0 + lane, sp = ig / ps_f, cc = ig - sp * ps_f;
+    colb = (unsigned)((((sp >> 1) * 2 * p.Wd + (sp & 1)) * (int)p.lda + cc) * 4);
+  }
+  const float* const P = isB ? p.B + j0 : (p.ps ? p.A : p.A + i0);      // uniform
+  const long ld = isB ? p.ldb : p.lda;
+  const int step = (!isB && p.ps) ? 2 : 1;
+  float cs = 0.f;
+
+  auto load = [&](int mc, Stage& sg) __attribute__((always_inline)) {
+    const int gm = mc + (lane & 15);             // token of this lane's per-token data
+    const bool in = gm < m_end;
+    const int x = gm % p.Wd, tq = gm / p.Wd;
+    const int y = tq % p.H, b = tq / p.H;
+    int srow = gm;
+    bool ok = in;
+    if (isB) {
+      const int yy = y + dy, xx = x + op - 2;
+      ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+      srow = (b * p.H + yy) * p.Wd + xx;
+    } else if (p.ps) {
+      srow = (b * 2 * p.H + 2 * y) * 2 * p.Wd + 2 * x;
+    }
+    const int t_row = ok ? srow : -1;
+    const int row0 = __builtin_amdgcn_readlane(t_row, 0);
+    const bool dense = __all(t_row == row0 + step * (lane & 15) && row0 >= 0);
+    if (dense) {
+      const float* q = P + (long)row0 * ld;
+      const long adv = step * ld;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        sg.rv[t >> 3][t & 7] = ColVec<1>::ldg(q, colb);
+        q += adv;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = __builtin_amdgcn_readlane(t_row, t);
+        const float* base = row >= 0 ? P + (long)row * ld : k_tnb_zero_row;
+        sg.rv[t >> 3][t & 7] = ColVec<1>::ldg(base, row >= 0 ? colb : 0u);
+      }
+    }
+  };
+  auto store = [&](unsigned char* buf, const Stage& sg) __attribute__((always_inline)) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      unsigned qh[4], qm[4], ql[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float e0 = sg.rv[o][2 * t], e1 = sg.rv[o][2 * t + 1];
+        if (do_colsum) cs += e0 + e1;              // read by the dY wave only
+        split3_pair(e0, e1, qh[t], qm[t], ql[t]);
+      }
+      const u32x4 ph = {qh[0], qh[1], qh[2], qh[3]}, pm = {qm[0], qm[1], qm[2], qm[3]},
+                  pl = {ql[0], ql[1], ql[2], ql[3]};
+      unsigned char* dst = buf + unit_slot3(op * BC + lane, o) * 16;
+      *(u32x4*)(dst) = ph;
+      *(u32x4*)(dst + PLANE) = pm;
+      *(u32x4*)(dst + 2 * PLANE) = pl;
+    }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[k][q] = 0.f;
+  const int a_off = unit_slot3(wi * 32 + r, h) * 16;
+  int b_off[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) b_off[k] = unit_slot3((1 + k) * BC + wj * 32 + r, h) * 16;
+
+  const int nch = ((m_end - m_begin + 2 * TK3 - 1) / (2 * TK3)) * 2;     // even
+  if (producer) {
+    Stage sg0, sg1;                              // chunk parity
+    load(m_begin, sg0);
+    load(m_begin + TK3, sg1);
+    store(smem, sg0);
+    load(m_begin + 2 * TK3, sg0);
+    __syncthreads();
+    for (int c = 0; c < nch; c += 2) {
+      if (DBG != 2) {
+        store(smem + BUF, sg1);                  // chunk c+1
+        load(m_begin + (c + 3) * TK3, sg1);
+      }
+      __syncthreads();
+      if (DBG != 2) {
+        store(smem, sg0);                        // chunk c+2
+        load(m_begin + (c + 4) * TK3, sg0);
+      }
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+      const unsigned char* cur = smem + (c & 1) * BUF;
+      if (DBG != 1) {
+        u32x4 fa[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fa[pl] = *(const u32x4*)(cur + pl * PLANE + a_off);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const u32x4 fb0 = *(const u32x4*)(cur + b_off[k]);
+          const u32x4 fb1 = *(const u32x4*)(cur + PLANE + b_off[k]);
+          const u32x4 fb2 = *(const u32x4*)(cur + 2 * PLANE + b_off[k]);
+          acc[k] = mfma_bf(fa[1], fb1, acc[k]);
+          acc[k] = mfma_bf(fa[0], fb2, acc[k]);
+          acc[k] = mfma_bf(fa[2], fb0, acc[k]);
+          acc[k] = mfma_bf(fa[0], fb1, acc[k]);
+          acc[k] = mfma_bf(fa[1], fb0, acc[k]);
+          acc[k] = mfma_bf(fa[0], fb0, acc[k]);
+        }
+      }
+      __syncthreads();
+    }
+    const int col = wj * 32 + r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float* out = p.part + ((long)(s * 9 + 3 * trow + k) * p.NI) * p.NJ;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int io = i0 + wi * 32 + mfma_row(q, lane);       // p.ps: kernel row sp*F + c is torch channel c*4 + sp
+        out[(long)(p.ps ? (io % ps_f) * 4 + io / ps_f : io) * p.NJ + j0 + col] = acc[k][q];
+      }
+    }
+  }
+
+  if (do_colsum) {
+    float* red = (float*)smem;                   // the chunk buffers are dead now
+    if (producer && op == 0) red[lane] = cs;
+    __syncthreads();
+    if (tid < BC) {
+      const int io = i0 + tid;
+      p.part_colsum[(long)s * p.NI + (p.ps ? (io % ps_f) * 4 + io / ps_f : io)] = red[tid];
+    }
+  }
+}
+
+template <int DBG = 0>
+__global__ void __launch_bounds__(512, 6) k_tnb3(TnArgs p, int tiles, int xcd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int L = xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int trow = L % 3, t2 = L / 3;
+  tnb_body3<DBG>(p, t2 / tiles, t2 % tiles, trow, smem);
+}
+
 // Conv launches are one-dimensional with the block -> (slice, tile, tap) map made here: the 9 taps x i-tiles of one
 // slice read the same rows of dY and X, and the hardware deals consecutive block indices to the 8 XCDs round robin --
 // with (slice, tile, tap) on the grid axes every XCD's L2 fetched every slice for itself (rocprofv3 PMC: 2.5 GB per
@@ -476,6 +661,32 @@ __global__ void __launch_bounds__(512, 1) k_tnb_conv_batched(TnbConvBatch g) {
   // four re-read everything in the second: EDSR x2, 134 MB per operand, 208 instead of 228 patches/s)
   tnb_body<W>(p, sl, tile, tap, smem);
 }
+
+template <int DBG = 0>
+__global__ void __launch_bounds__(512, 6) k_tnb3_conv_batched(TnbConvBatch g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int L = g.xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int trow = L % 3;
+  int rr = L / 3;
+  const int tile = rr % g.tiles; rr /= g.tiles;
+  const int sl = rr % g.base.S, k = rr / g.base.S;
+  TnArgs p = g.base;
+  p.A = g.A[k];
+  p.B = g.B[k];
+  p.part = g.base.part + (long)k * g.part_stride;
+  p.part_colsum = g.base.part_colsum ? g.base.part_colsum + (long)k * g.colsum_stride : nullptr;
+  tnb_body3<DBG>(p, sl, tile, trow, smem);
+}
+
+// three taps per block (tnb_body3) for this problem?  SRHIP_TN_T3=0: one tap per block
+bool tnb_t3_shape(int conv, int NI, int NJ, int w) {
+  static const int on = [] { const char* e = getenv("SRHIP_TN_T3"); return !(e && e[0] == '0'); }();
+  return on && conv && w == 1 && NI % 64 == 0 && NJ % 64 == 0;
+}
+bool tnb_t3_ok(const TnArgs& p, int w) {
+  return tnb_t3_shape(p.conv, p.NI, p.NJ, w) && !p.a_rowscale && p.b_mode == 0;
+}
+constexpr int lds_bytes3() { return 2 * 3 * 4 * 64 * 32; }
 
 int pick_tile(int n, int* w) {
   if (n % 180 == 0) { *w = 3; return 180; }
@@ -568,6 +779,16 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
   dim3 grid(p.S, tiles, 1);
   if (p.conv) grid = dim3(p.S * tiles * 9, 1, 1);
   static const int xcd = [] { const char* e = getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
+  if (tnb_t3_ok(p, w)) {       // 64-wide conv problem: three taps per block
+    static bool attr3 = false;
+    if (!attr3) {
+      if (int rc = reserve_lds(k_tnb3<0>, lds_bytes3(), "k_tnb3")) return rc;
+      attr3 = true;
+    }
+    hipLaunchKernelGGL((k_tnb3<0>), dim3(p.S * tiles * 3), dim3(512), lds_bytes3(), st, p, tiles, xcd);
+    SR_LAUNCH_CHECK("k_tnb3");
+    return 0;
+  }
   static bool attr[4] = {false, false, false, false};
 #define SR_TNB(W_)                                                                        \
   if (w == W_) {                                                                          \
@@ -586,7 +807,8 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
 int sr_conv_wgrad_batched_plan(int n, int M, int NI, int NJ, int* S, long* part_floats_per_item) {
   int tile;
   const int w = pick_w(NI, NJ, &tile);
-  const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * 9 * n;
+  const bool t3 = tnb_t3_shape(1, NI, NJ, w);             // three taps per block
+  const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * (t3 ? 3 : 9) * n;
   // Blocks in flight: 3 per CU for 64-wide tiles (49 KB of LDS each), else 1.  The slice count is chosen
   // for WHOLE rounds of blocks -- 33 problems x 9 taps x 3 slices = 891 blocks on 768 slots ran 1.16
   // rounds, i.e. the second round 16 % full (x4: 5.3 ms for what 1.93 rounds do in 3.1) -- among the
@@ -626,6 +848,16 @@ int sr_conv_wgrad_batched_tnb(const TnArgs& base, const float* const* A, const f
   for (int k = 0; k < n; ++k) { g.A[k] = A[k]; g.B[k] = B[k]; }
   static const int xcd = [] { const char* e = getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
   g.xcd = xcd;
+  if (tnb_t3_ok(g.base, w)) {  // three taps per block
+    static bool attr3 = false;
+    if (!attr3) {
+      if (int rc = reserve_lds(k_tnb3_conv_batched<0>, lds_bytes3(), "k_tnb3_conv_batched")) return rc;
+      attr3 = true;
+    }
+    hipLaunchKernelGGL((k_tnb3_conv_batched<0>), dim3(base.S * 3 * g.tiles * n), dim3(512), lds_bytes3(), st, g);
+    SR_LAUNCH_CHECK("k_tnb3_conv_batched");
+    return 0;
+  }
   dim3 grid(base.S * 9 * g.tiles * n, 1, 1);
   static bool attr[4] = {false, false, false, false};
 #define SR_TNB_CB(W_)                                                                          \
@@ -648,9 +880,11 @@ int sr_conv_wgrad_batched_tnb(const TnArgs& base, const float* const* A, const f
 int sr_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
   int tile;
   const int w = pick_w(NI, NJ, &tile);
-  const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * (conv ? 9 : 1);
+  const bool t3 = tnb_t3_shape(conv, NI, NJ, w);          // three taps per block
+  const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * (conv ? (t3 ? 3 : 9) : 1);
   static const long t1 = [] { const char* e = getenv("SRHIP_TNB_BLOCKS_W1"); return e ? atol(e) : 768L; }();
-  long s = (w == 1 ? t1 : 256) / tiles;
+  static const long t3b = [] { const char* e = getenv("SRHIP_TNB_BLOCKS_T3"); return e ? atol(e) : 768L; }();
+  long s = (t3 ? t3b : (w == 1 ? t1 : 256)) / tiles;
   const long smax = (M + 127) / 128;
   if (s > smax) s = smax;
   if (s > 256) s = 256;
