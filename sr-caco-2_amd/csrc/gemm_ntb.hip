@@ -59,6 +59,8 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
   constexpr int B_N = NPL * BN * 4;              // 16-byte slots per chunk (3 planes; AMP: the leading one)
   constexpr int B_IT = (B_N + 255) / 256;
   constexpr int A_PLANE = AROWS * PITCH, B_PLANE = BN * PITCH;
+  // 64-column conv tiles: W double-buffered in LDS, ONE barrier per (chunk, tap) iteration (k_ntb_dbw below)
+  constexpr bool DBW = CONV && WN == 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;
   unsigned char* Bs = smem + 3 * A_PLANE;
@@ -175,13 +177,14 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
       }
     }
   };
-  auto store_b = [&]() {
+  auto store_b = [&](int buf = 0) {
+    unsigned char* dstb = Bs + buf * (3 * B_PLANE);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       if (B_N % 256 == 0 || tid + it * 256 < B_N) {
         const int idx = tid + it * 256;
         const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
-        *(u32x4*)(Bs + pl * B_PLANE + (rem >> 2) * PITCH + (rem & 3) * 16) = rb[it];
+        *(u32x4*)(dstb + pl * B_PLANE + (rem >> 2) * PITCH + (rem & 3) * 16) = rb[it];
       }
     }
   };
@@ -284,15 +287,77 @@ __global__ void __launch_bounds__(256, 2) k_ntb(NtArgs p) {
     }
     tick(tk_mma);
   };
+  // 64-column conv tiles (DBW): the W chunk of iteration it+1 is stored into the OTHER LDS buffer while iteration
+  // it computes, so an iteration has ONE barrier instead of two (12-24 MFMAs per wave sat between two barriers:
+  // the loop was barrier / latency bound, 28 % of the MFMA rate inside it).  The halo tile of A stays single
+  // buffered: one extra barrier per channel chunk.  Same LDS budget class: two blocks per CU either way.
+  auto iter_dbw = [&](int it, f32x4 (&ra)[A_IT]) {
+    const int kc = it / ntap, tap = it - kc * ntap;
+    if (it + 1 < niter) store_b((it + 1) & 1);                 // W(it+1): its buffer's last reader was iteration it-1
+    if (tap == 0 && kc + 1 < nkc) load_a(kc + 1, ra);          // next channel chunk's halo: a whole chunk to land
+    {
+      const int itn = min(it + 2, niter - 1);
+      const int kcn = itn / ntap;
+      load_b(kcn, itn - kcn * ntap);
+    }
+    const unsigned char* Bc = Bs + (it & 1) * (3 * B_PLANE);
+    const int toff = ((tap / 3) * 18 + (tap % 3)) * PITCH;
+#pragma unroll
+    for (int s = 0; s < BKB / 16; ++s) {
+      u32x4 fa[WM][3], fb[WN][3];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+          fa[i][pl] = *(const u32x4*)(As + pl * A_PLANE + a_off[i] + toff + s * 32);
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+          fb[j][pl] = *(const u32x4*)(Bc + pl * B_PLANE + b_off[j] + s * 32);
+#define SR_TERM(PA, PB)                                                              \
+  _Pragma("unroll") for (int i = 0; i < WM; ++i)                                     \
+  _Pragma("unroll") for (int j = 0; j < WN; ++j)                                     \
+    acc[i][j] = mfma_bf(fa[i][PA], fb[j][PB], acc[i][j]);
+      if constexpr (AMP) {
+        SR_TERM(0, 0)
+      } else {
+        SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      }
+#undef SR_TERM
+    }
+    {
+      constexpr int NMFMA = (BKB / 16) * (AMP ? 1 : 6) * WM * WN;
+      constexpr int PER = NMFMA / B_IT > 0 ? NMFMA / B_IT : 1;
+#pragma unroll
+      for (int g = 0; g < B_IT; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);     // PER MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // then one VMEM read
+      }
+    }
+    if (tap == ntap - 1 && kc + 1 < nkc) {     // chunk boundary: every tap of this chunk has read the halo tile
+      __syncthreads();
+      store_a(ra, kc + 1);
+    }
+    __syncthreads();
+  };
   const long tk_begin = stamp ? (long)__builtin_amdgcn_s_memtime() : 0;
   load_a(0, ra0);
   load_b(0, 0);
   if (!CONV && niter > 1) load_a(1, ra1);
   tk_prev = stamp ? (long)__builtin_amdgcn_s_memtime() : 0;
   const long tk_prologue = tk_prev - tk_begin;
-  for (int it = 0; it < niter; it += 2) {
-    iter(it, ra0);
-    if (it + 1 < niter) iter(it + 1, CONV ? ra0 : ra1);
+  if (DBW && !stamp && !p.dbg) {
+    store_a(ra0, 0);
+    store_b(0);
+    if (niter > 1) load_b(0, 1);
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) iter_dbw(it, ra0);
+  } else {
+    for (int it = 0; it < niter; it += 2) {
+      iter(it, ra0);
+      if (it + 1 < niter) iter(it + 1, CONV ? ra0 : ra1);
+    }
   }
   if (stamp) {       // cycles per phase, summed over the K loop, of wave 0 of two blocks -> C[0..15] (output is lost)
     if ((blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 + 3) && blockIdx.y == 0 && tid == 0) {
@@ -326,7 +391,7 @@ template <int WM, int WN, bool CONV, bool AMP = false>
 int launch_ntb(const NtArgs& p, hipStream_t st) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int AROWS = CONV ? (BM / 16 + 2) * 18 : BM;
-  constexpr int LDS = 3 * (AROWS + BN) * PITCH;
+  constexpr int LDS = 3 * (AROWS + BN * ((CONV && WN == 1) ? 2 : 1)) * PITCH;     // DBW: two W buffers
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_ntb<WM, WN, CONV, AMP>,
