@@ -45,17 +45,19 @@ __device__ __forceinline__ f32x4 ldg_f4(const void* p) { return *(sr_gptr_f4)p; 
 
 // ---- 3-way bf16 split of f32 pairs (the operand form of the bf16x3 MFMA kernels) ----
 //   x = h + m + l, each part the bf16 rounding (RNE) of the remaining residual; the
-//   residuals are exact in f32.  Packed pairs: element 0 in the low half.  Written on
-//   2-vectors so that the subtractions compile to v_pk_add_f32.
+//   residuals are exact in f32.  Packed pairs: element 0 in the low half.
 typedef __bf16 sr_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned sr_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  const sr_f32x2 x = {x0, x1};
-  h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, sr_bf16x2));
-  const sr_f32x2 r = x - __builtin_bit_cast(sr_f32x2, sr_u32x2{h << 16, h & 0xffff0000u});
-  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sr_bf16x2));
-  const sr_f32x2 s = r - __builtin_bit_cast(sr_f32x2, sr_u32x2{m << 16, m & 0xffff0000u});
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(s, sr_bf16x2));
+  // SCALAR subtractions on purpose, and the library is built with -fno-slp-vectorize: packed f32 VALU
+  // (v_pk_add_f32 / v_pk_mul_f32) beside MFMAs is an anti-lever on this part (MI355X_MICROARCH.md, cycle table:
+  // "2 v_pk_add_f32 per gap +26 cyc vs 2 v_fma_f32"), and hipcc packs adjacent scalar adds by itself under plain -O3.
+  // Same box, whole training step: +2.4 % (SwinIR), +2.7 % (EDSR x8) against the packed form.
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(sr_f32x2{x0, x1}, sr_bf16x2));
+  const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(sr_f32x2{r0, r1}, sr_bf16x2));
+  const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(sr_f32x2{s0, s1}, sr_bf16x2));
 }
 
 // ---- XCD-aware block order ----

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256, 2) k_ntp(NtArgs p) {
     unsigned char* sa = As + (c & 1) * A_STAGE;
     unsigned char* sb = Bs + (c & 1) * B_STAGE;
     if (p.a_mode == 1) {
-      v = (v - rst.x) * rst.y;
+      v.x = (v.x - rst.x) * rst.y; v.y = (v.y - rst.x) * rst.y; v.z = (v.z - rst.x) * rst.y; v.w = (v.w - rst.x) * rst.y;   // scalar on purpose (common.h)
     } else if (p.a_mode == 2) {
       v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
     }

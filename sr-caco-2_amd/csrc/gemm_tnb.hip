@@ -247,9 +247,9 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
         if (p.a_rowscale) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const sr_f32x2 k = {bcast(sg.scale, 8 * o + 2 * t), bcast(sg.scale, 8 * o + 2 * t + 1)};
+            const float k0 = bcast(sg.scale, 8 * o + 2 * t), k1 = bcast(sg.scale, 8 * o + 2 * t + 1);
 #pragma unroll
-            for (int j = 0; j < W; ++j) x[t][j] *= k;
+            for (int j = 0; j < W; ++j) { x[t][j].x *= k0; x[t][j].y *= k1; }      // scalar on purpose (see common.h)
           }
         }
         if (do_colsum) {
@@ -261,10 +261,13 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
       } else if (p.b_mode == 1) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const sr_f32x2 mu = {bcast(sg.stats.x, 8 * o + 2 * t), bcast(sg.stats.x, 8 * o + 2 * t + 1)};
-          const sr_f32x2 rs = {bcast(sg.stats.y, 8 * o + 2 * t), bcast(sg.stats.y, 8 * o + 2 * t + 1)};
+          const float mu0 = bcast(sg.stats.x, 8 * o + 2 * t), mu1 = bcast(sg.stats.x, 8 * o + 2 * t + 1);
+          const float rs0 = bcast(sg.stats.y, 8 * o + 2 * t), rs1 = bcast(sg.stats.y, 8 * o + 2 * t + 1);
 #pragma unroll
-          for (int j = 0; j < W; ++j) x[t][j] = (x[t][j] - mu) * rs;     // zero-filled tokens carry {0, 1}
+          for (int j = 0; j < W; ++j) {             // zero-filled tokens carry {0, 1}
+            x[t][j].x = (x[t][j].x - mu0) * rs0;
+            x[t][j].y = (x[t][j].y - mu1) * rs1;
+          }
         }
       } else if (p.b_mode == 2) {
 #pragma unroll

@@ -118,7 +118,9 @@ __global__ void __launch_bounds__(256, 2) k_mlp(MlpArgs p) {
   };
   auto store1 = [&](int c, f32x4 v, const u32x4 (&rb)[B_IT]) {     // phase-1 stage c (buffer c & 1)
     unsigned char* sa = As + (c & 1) * A_STAGE;
-    if (!BWD) v = (v - rst.x) * rst.y;             // LayerNorm prologue (neutral statistics without ln_stats)
+    if (!BWD) {                                    // LayerNorm prologue (neutral statistics without ln_stats); scalar on purpose
+      v.x = (v.x - rst.x) * rst.y; v.y = (v.y - rst.x) * rst.y; v.z = (v.z - rst.x) * rst.y; v.w = (v.w - rst.x) * rst.y;
+    }
     if (c * SK + ac4 * 4 >= p.K1) v = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned h0, m0_, l0, h1, m1, l1;
     split3_pair(v.x, v.y, h0, m0_, l0);

@@ -358,8 +358,8 @@ __device__ __forceinline__ void nt_epilogue_wide_impl(const NtArgs& p, f32x16 (&
       case 1:
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         break;
-      case 2:
-        v = v * s + rv[it];
+      case 2:         // component-wise: no v_pk_fma_f32 (common.h)
+        v.x = v.x * s + rv[it].x; v.y = v.y * s + rv[it].y; v.z = v.z * s + rv[it].z; v.w = v.w * s + rv[it].w;
         break;
       case 3: {
         f32x4 gl;
@@ -420,8 +420,8 @@ __device__ __forceinline__ void nt_epilogue_wide_impl(const NtArgs& p, f32x16 (&
 #pragma unroll
     for (int k = 0; k < 4 * WN; ++k)
       if (cbase + 4 * k < nvalid) {
-        const f32x4 d = xv[k] - mean;
-        s2 += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        const float d0 = xv[k].x - mean, d1 = xv[k].y - mean, d2 = xv[k].z - mean, d3 = xv[k].w - mean;
+        s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       }
     s2 += __shfl_xor(s2, 32, 64);
     if (half == 0) red[128 + wn * 64 + wm * 32 + r] = s2;

@@ -12,7 +12,14 @@ pytestmark = pytest.mark.gpu
 import sr_oracle as O  # noqa: E402
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GRAD_GATE = 2e-5
+# Gradient gates of the tiny fixture (2 x 1 x 12 x 10 input: 240-3840 pixels per map).  A LeakyReLU decision that flips
+# under f32 rounding (an activation within rounding of 0) changes that pixel's slope from 1 to 0.2, i.e. moves the entries
+# it feeds by ~1/pixels of their size: with one build of the library conv1.10.weight at x4 sits at 1.4e-5 of the
+# reference, with another (same arithmetic, other instruction order in an unrelated kernel) at 3.7e-4 -- one pixel of 960.
+# So: tensor-wise relative L2 error <= 1e-3 here, every tensor's |gradient| sum to 1e-4, and the entry-wise gate
+# (<= max(5e-5, 3 x the fp32 oracle's own distance from fp64)) on the 256 x 256 fused-step test below, where a flipped pixel
+# is one of 65 k.
+L2_GATE = 1e-3
 
 
 def load(name):
@@ -45,7 +52,8 @@ def test_forward_intermediates_and_multiscale_gradients_vs_reference_golden(scal
     for i, (k, p) in enumerate(net.named_parameters()):
         gk = p.grad.double().cpu()
         if "grad/" + k in g:
-            assert rel(p.grad, g["grad/" + k]) <= GRAD_GATE, k
+            ref = g["grad/" + k].double()
+            assert ((gk - ref).norm() / ref.norm()).item() <= L2_GATE, k
         # every other tensor by its |gradient| sum (a LeakyReLU decision that flips under f32 rounding moves single
         # entries: 2.6e-5 on one bias at x8, three octaves deep)
         assert abs(gk.abs().sum().item() - sums[i][1]) <= 1e-4 * max(sums[i][1], 1e-6), (k, gk.abs().sum().item(), sums[i][1])
