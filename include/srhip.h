@@ -322,17 +322,22 @@ int srhip_l1_sparsity(const float* w, float* grad, float* loss_out, double* work
  * patch variance == 0]) with both variances + 1.  workspace doubles: srhip_loss_stencil_ws(B,H,W). */
 int srhip_loss_local_moments(const float* pred, const float* target, float* grad, float* loss_out, double* workspace,
                              int B, int H, int W, float lam, int grad_accum, int loss_accum, void* stream);
-/* HistogramMatch, NORM1 / NORM2 metrics (dlib/loss/main.py:690-782) over SoftHistogram(bins, 0, 1, sigma)
- * (dlib/loss/global_terms.py:17-72): lam * mean_{b,k} nrm((h_pred + 1)/sum - (h_target + 1)/sum); n = values
- * per image.  workspace floats: srhip_loss_hist_ws(B, bins). */
+/* HistogramMatch (dlib/loss/main.py:690-782) over SoftHistogram(bins, 0, 1, sigma) (dlib/loss/global_terms.py:17-72),
+ * p = (h + 1) / sum per image; n = values per image.  norm 1 | 2: lam * mean_{b,k} nrm(p_pred - p_target);
+ * 3 (KL): lam * nn.KLDivLoss(batchmean)(log p_pred, p_target); 4 (BHATTACHARYYA): lam * elb(-sum_k sqrt(p_pred p_target))
+ * with the extended log barrier of dlib/losses/elb.py:92-122 at parameter elb_t (mean over images).
+ * workspace floats: srhip_loss_hist_ws(B, bins). */
 long srhip_loss_hist_ws(int B, int bins);
 int srhip_loss_hist(const float* pred, const float* target, float* grad, float* loss_out, float* workspace, int B,
-                    long n, int bins, float sigma, int norm, float lam, int grad_accum, int loss_accum, void* stream);
-/* KDEMatch, NORM1 / NORM2 metrics (dlib/loss/main.py:785-898) over GaussianKDE(kde_bw, bins, max_color 1, 1 channel)
- * (dlib/loss/global_terms.py:75-152): lam * mean_{b,k} nrm((p_pred + 1e-4) - (p_target + 1e-4)) / bins,
- * p[k] = mean_px N(x; linspace(0,1,bins)[k], kde_bw).  workspace floats: srhip_loss_hist_ws(B, bins). */
+                    long n, int bins, float sigma, int norm, float lam, int grad_accum, int loss_accum, float elb_t,
+                    void* stream);
+/* KDEMatch (dlib/loss/main.py:785-898) over GaussianKDE(kde_bw, bins, max_color 1, 1 channel)
+ * (dlib/loss/global_terms.py:75-152), p[k] = mean_px N(x; linspace(0,1,bins)[k], kde_bw) + 1e-4.  norm 1 | 2:
+ * lam * mean_{b,k} nrm(p_pred - p_target) / bins; 4 (BHATTACHARYYA): lam * elb(-sum_k sqrt(p_pred p_target)) at
+ * parameter elb_t.  workspace floats: srhip_loss_hist_ws(B, bins). */
 int srhip_loss_kde(const float* pred, const float* target, float* grad, float* loss_out, float* workspace, int B,
-                   long n, int bins, float kde_bw, int norm, float lam, int grad_accum, int loss_accum, void* stream);
+                   long n, int bins, float kde_bw, int norm, float lam, int grad_accum, int loss_accum, float elb_t,
+                   void* stream);
 /* Local-variation terms on 1-channel images [B][H][W] (dlib/loss/main.py:328-674 with the operators of
  * dlib/loss/local_variations.py:18-141, replicate padding): op 0 image gradient (2 stencils), 1 Laplacian
  * (1), 2 local variation over a ksz x ksz window (ksz^2 - 1 stencils; ksz 3, 5 or 7).  norm 1 | 2 = the

@@ -508,6 +508,52 @@ def g_srcnn():
     npz("g22_srcnn", **arrs)
 
 
+# ---------------------------------------------------------------- G24 HistogramMatch / KDEMatch: KL and Bhattacharyya
+def g_hist_kl_bh():
+    """The remaining metrics of HistogramMatch (KL, BHATTACHARYYA) and KDEMatch (BHATTACHARYYA), dlib/loss/main.py:677-898,
+    through MasterLoss, with the barrier parameter at its initial value and after 30 schedule updates."""
+    print("G24 HistogramMatch KL / BH, KDEMatch BH")
+    from dlib.losses.elb import ELB
+    torch.manual_seed(47)
+    pred = torch.rand(2, 1, 32, 48) * 1.1 - 0.05
+    tgt = torch.round(torch.rand(2, 1, 32, 48) * 255) / 255
+    tgt[0, :, :16] = (torch.round(torch.rand(16, 48) * 40) + 3) / 255
+    out = dict(pred=pred, target=tgt)
+    cases = {"hist_kl": ("hist", 3, 1.5, 0), "hist_bh_t1": ("hist", 4, 1.0, 0), "hist_bh_t30": ("hist", 4, 2.0, 30),
+             "hist_kl_soft": ("hist", 3, 1.0, 0), "kde_bh_t1": ("kde", 4, 1.0, 0), "kde_bh_t30": ("kde", 4, 0.5, 30)}
+    for name, (kind, norm, lam, updates) in cases.items():
+        e = ELB()
+        for _ in range(updates):
+            e.update_t()
+        tval = float(e.t_lb)
+        sigma = 2e3 if name == "hist_kl_soft" else 1e5
+        norm_str = {3: ref_c.KL, 4: ref_c.BH}[norm]
+        if kind == "hist":
+            l = ref_loss.HistogramMatch(cuda_id="cpu", lambda_=lam, elb=e, color_min=0, color_max=255)
+            l.set_it(norm_str=norm_str, sigma=float(sigma))
+        else:
+            with cpu_as_cuda():
+                l = ref_loss.KDEMatch(cuda_id="cpu", lambda_=lam, elb=e, color_min=0, color_max=1)
+                l.set_it(norm_str=norm_str, kde_bw=1. / 255. ** 2, ndim=1, nbins=256)
+        m = ref_loss.MasterLoss(cuda_id="cpu")
+        m.add(l)
+        pr = pred.clone().requires_grad_(True)
+        v = m(epoch=0, y_pred=pr, y_target=tgt, trg_per_pixel_weight=None, model=None)
+        v.backward()
+        po = pred.clone().requires_grad_(True)
+        if kind == "hist":
+            vo = O.loss_histogram_match(po, tgt, lam, norm, sigma, 256, elb_t=tval)
+        else:
+            vo = O.loss_kde_match(po, tgt, lam, norm, 1. / 255. ** 2, 256, elb_t=tval)
+        vo.backward()
+        close(vo.detach(), v.detach(), 2e-6 * max(1e-9, abs(float(v))), f"{name}")
+        close(po.grad, pr.grad, 2e-6 * max(1e-12, float(pr.grad.abs().max())), f"d {name}")
+        out[f"{name}/value"], out[f"{name}/grad"] = v.detach(), pr.grad
+        out[f"{name}/cfg"] = np.array([lam, norm, sigma, tval, updates], dtype=np.float64)
+        print(f"    {name}: value {float(v):.5e}  max|grad| {float(pr.grad.abs().max()):.3e}  t {tval:.4f}")
+    npz("g24_hist_kl_bh", **out)
+
+
 # ---------------------------------------------------------------- G23 MSLapSRN
 def g_mslapsrn():
     """MSLapSRN (network_mslapsr.py:67-174) x2 / x4 / x8: output, intermediate images and the gradients of the
@@ -1202,7 +1248,7 @@ def g_optim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
-            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn]
+            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:
         if not only or g.__name__ in only:

@@ -674,13 +674,18 @@ def soft_histogram(x: Tensor, bins: int = 256, sigma: float = 1e5) -> Tensor:
 
 
 def loss_histogram_match(pred: Tensor, target: Tensor, lam: float = 1.0, norm: int = 2, sigma: float = 1e5,
-                         bins: int = 256) -> Tensor:
-    """loss/main.py:690-782, NORM1 / NORM2 metrics: histograms + 1, normalised, compared bin by bin."""
+                         bins: int = 256, elb_t: float = 1.0) -> Tensor:
+    """loss/main.py:690-782: histograms + 1, normalised; norm 1 | 2: compared bin by bin; 3: KL (nn.KLDivLoss
+    batchmean on log p, :727-729,771-773); 4: Bhattacharyya through the extended log barrier at elb_t (:775-777)."""
     b = target.shape[0]
     t = soft_histogram(target.contiguous().view(b, -1), bins, sigma) + 1.
     t = t / t.sum(dim=-1).view(-1, 1)
     p = soft_histogram(pred.contiguous().view(b, -1), bins, sigma) + 1.
     p = p / p.sum(dim=-1).view(-1, 1)
+    if norm == 3:
+        return lam * F.kl_div(p.log(), t, reduction="batchmean", log_target=False).mean()
+    if norm == 4:
+        return lam * elb(-torch.sqrt(p * t).sum(dim=1).view(-1), elb_t)
     e = p - t
     return lam * (e.abs() if norm == 1 else e * e).mean()
 
@@ -698,10 +703,13 @@ def gaussian_kde(images: Tensor, kde_bw: float, bins: int = 256) -> Tensor:
 
 
 def loss_kde_match(pred: Tensor, target: Tensor, lam: float = 1.0, norm: int = 2, kde_bw: float = 1. / 255. ** 2,
-                   bins: int = 256) -> Tensor:
-    """loss/main.py:785-898, NORM1 / NORM2 metrics: (kde + 1e-4) compared bin by bin, mean / bins."""
+                   bins: int = 256, elb_t: float = 1.0) -> Tensor:
+    """loss/main.py:785-898: (kde + 1e-4); norm 1 | 2: compared bin by bin, mean / bins; 4: Bhattacharyya through the
+    extended log barrier at elb_t (:891-892)."""
     t = gaussian_kde(target, kde_bw, bins) + 1e-4
     p = gaussian_kde(pred, kde_bw, bins) + 1e-4
+    if norm == 4:
+        return lam * elb(-torch.sqrt(p * t).sum(dim=1).view(-1), elb_t)
     e = p - t
     return lam * (e.abs() if norm == 1 else e * e).mean() / float(bins)
 

@@ -428,11 +428,14 @@ __global__ void __launch_bounds__(256) k_soft_hist(const float* __restrict__ pre
   for (int i = threadIdx.x; i < 2 * bins; i += 256) o[i] = hist[i];
 }
 
-// one block per image: histograms, the normalised difference, its loss share and dL/dh(pred)
+// one block per image: histograms, the metric's loss share and dL/dh(pred)
 // kde > 0: KDEMatch's form -- p = mean over the kde pixels + 1e-4 on both sides, no normalisation
+// kind 1 / 2: |P - Q| / (P - Q)^2 per bin;  3: KL, Q (log Q - log P) per bin (nn.KLDivLoss(batchmean)(log P, Q),
+// dlib/loss/main.py:727-729,771-773);  4: Bhattacharyya through the extended log barrier, elb(-sum_k sqrt(P Q)) per image
+// (main.py:677-687,775-777,891-892; dlib/losses/elb.py:92-122) with barrier parameter t
 __global__ void __launch_bounds__(256) k_hist_finalize(const float* __restrict__ part, float* __restrict__ dldh,
-                                                       double* __restrict__ lpart, int bins, int l1, float gs,
-                                                       float kde) {
+                                                       double* __restrict__ lpart, int bins, int kind, float gs,
+                                                       float kde, float t) {
   __shared__ float red[2][4];
   __shared__ float bc[3];
   const int b = blockIdx.x, k = threadIdx.x;
@@ -451,9 +454,29 @@ __global__ void __launch_bounds__(256) k_hist_finalize(const float* __restrict__
   const float Sp = red[0][0] + red[0][1] + red[0][2] + red[0][3], St = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   __syncthreads();
   const float P = k < bins ? (kde > 0.f ? hp : hp / Sp) : 0.f, Q = k < bins ? (kde > 0.f ? ht : ht / St) : 0.f;
-  const float e = P - Q;
-  const float dLdP = k < bins ? gs * nrm_der(e, l1) : 0.f;                 // gs = lam / (B * bins)
-  float lv = wave_sum(k < bins ? nrm_val(e, l1) : 0.f), dp = wave_sum(dLdP * P);
+  float val = 0.f, dLdP = 0.f;
+  if (kind <= 2) {
+    const float e = P - Q;
+    val = k < bins ? nrm_val(e, kind == 1) : 0.f;
+    dLdP = k < bins ? gs * nrm_der(e, kind == 1) : 0.f;                    // gs = lam / (B * bins)
+  } else if (kind == 3) {
+    val = k < bins ? Q * (logf(Q) - logf(P)) : 0.f;
+    dLdP = k < bins ? -gs * Q / P : 0.f;                                   // gs = lam / B
+  } else {
+    const float sq = k < bins ? sqrtf(P * Q) : 0.f;
+    const float ws = wave_sum(sq);
+    if ((k & 63) == 0) red[0][k >> 6] = ws;
+    __syncthreads();
+    const float z = -(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    __syncthreads();
+    const float ct = -(1.f / (t * t));
+    float psi, dpsi;
+    if (z <= ct) { psi = -(1.f / t) * logf(-z); dpsi = -1.f / (t * z); }
+    else { psi = t * z - (1.f / t) * logf(1.f / (t * t)) + (1.f / t); dpsi = t; }
+    val = k == 0 ? psi : 0.f;                                              // one value per image
+    dLdP = k < bins ? gs * dpsi * (-0.5f * sqrtf(Q / P)) : 0.f;            // gs = lam / B
+  }
+  float lv = wave_sum(val), dp = wave_sum(dLdP * P);
   if ((k & 63) == 0) { red[0][k >> 6] = lv; red[1][k >> 6] = dp; }
   __syncthreads();
   if (k == 0) {
@@ -564,10 +587,12 @@ int srhip_loss_local_moments(const float* pred, const float* target, float* grad
 long srhip_loss_hist_ws(int B, int bins) { return (long)B * HB * 2 * bins + (long)B * bins + 2L * B; }
 
 int srhip_loss_hist(const float* pred, const float* target, float* grad, float* loss_out, float* workspace, int B,
-                    long n, int bins, float sigma, int norm, float lam, int grad_accum, int loss_accum, void* stream) {
+                    long n, int bins, float sigma, int norm, float lam, int grad_accum, int loss_accum, float elb_t,
+                    void* stream) {
   SR_REQUIRE(B > 0 && n > 0 && B <= 65535, "loss_hist: empty input");
   SR_REQUIRE(bins > 0 && bins <= 256, "loss_hist: 1..256 bins (got %d)", bins);
-  SR_REQUIRE(sigma > 0.f && (norm == 1 || norm == 2), "loss_hist: sigma > 0, norm 1 or 2");
+  SR_REQUIRE(sigma > 0.f && norm >= 1 && norm <= 4, "loss_hist: sigma > 0, norm 1 | 2 | 3 (KL) | 4 (Bhattacharyya)");
+  SR_REQUIRE(norm != 4 || elb_t > 0.f, "loss_hist: the barrier parameter must be > 0");
   hipStream_t st = (hipStream_t)stream;
   // SoftHistogram(bins, min=0, max=1, sigma): delta = 1/bins as the reference's float32 tensor arithmetic sees it
   const float delta = (float)(1.0 / (double)bins), half = (float)((1.0 / (double)bins) / 2.0);
@@ -578,9 +603,9 @@ int srhip_loss_hist(const float* pred, const float* target, float* grad, float* 
   double* lpart = (double*)(dldh + (long)B * bins + (((long)B * bins) & 1));       // 8-byte aligned
   hipLaunchKernelGGL(k_soft_hist<0>, dim3(HB, B), dim3(256), 2 * bins * sizeof(float), st, pred, target, part, n, bins,
                      delta, half, sigma, rb);
-  const double cnt = (double)B * bins;
-  hipLaunchKernelGGL(k_hist_finalize, dim3(B), dim3(256), 0, st, part, dldh, lpart, bins, norm == 1,
-                     (float)((double)lam / cnt), 0.f);
+  const double cnt = norm <= 2 ? (double)B * bins : (double)B;      // KL (batchmean) and the barrier: mean over images
+  hipLaunchKernelGGL(k_hist_finalize, dim3(B), dim3(256), 0, st, part, dldh, lpart, bins, norm,
+                     (float)((double)lam / cnt), 0.f, elb_t);
   if (grad)
     hipLaunchKernelGGL(k_soft_hist_grad<0>, dim3(HB, B), dim3(256), bins * sizeof(float), st, pred, dldh, grad, n, bins,
                        delta, half, sigma, rb, grad_accum);
@@ -590,10 +615,12 @@ int srhip_loss_hist(const float* pred, const float* target, float* grad, float* 
 }
 
 int srhip_loss_kde(const float* pred, const float* target, float* grad, float* loss_out, float* workspace, int B,
-                   long n, int bins, float kde_bw, int norm, float lam, int grad_accum, int loss_accum, void* stream) {
+                   long n, int bins, float kde_bw, int norm, float lam, int grad_accum, int loss_accum, float elb_t,
+                   void* stream) {
   SR_REQUIRE(B > 0 && n > 0 && B <= 65535, "loss_kde: empty input");
   SR_REQUIRE(bins > 1 && bins <= 256, "loss_kde: 2..256 bins (got %d)", bins);
-  SR_REQUIRE(kde_bw > 0.f && (norm == 1 || norm == 2), "loss_kde: bandwidth > 0, norm 1 or 2");
+  SR_REQUIRE(kde_bw > 0.f && (norm == 1 || norm == 2 || norm == 4), "loss_kde: bandwidth > 0, norm 1, 2 or 4 (Bhattacharyya)");
+  SR_REQUIRE(norm != 4 || elb_t > 0.f, "loss_kde: the barrier parameter must be > 0");
   hipStream_t st = (hipStream_t)stream;
   // GaussianKDE(kde_bw, nbin, max_color = 1, ndim = 1): float32 constants as the reference builds them
   const float c1 = (float)pow(2.0 * 3.14159265358979323846 * (double)kde_bw, -0.5), c2 = (float)(2.0 * (double)kde_bw);
@@ -606,9 +633,9 @@ int srhip_loss_kde(const float* pred, const float* target, float* grad, float* l
   hipLaunchKernelGGL(k_soft_hist<1>, dim3(HB, B), dim3(256), 2 * bins * sizeof(float), st, pred, target, part, n, bins,
                      delta, c2, c1, rb);
   // loss = norm(pred, trg).mean() / bins  (dlib/loss/main.py:893-895)
-  const double cnt = (double)B * bins * (double)bins;
-  hipLaunchKernelGGL(k_hist_finalize, dim3(B), dim3(256), 0, st, part, dldh, lpart, bins, norm == 1,
-                     (float)((double)lam / cnt), (float)n);
+  const double cnt = norm <= 2 ? (double)B * bins * (double)bins : (double)B;
+  hipLaunchKernelGGL(k_hist_finalize, dim3(B), dim3(256), 0, st, part, dldh, lpart, bins, norm,
+                     (float)((double)lam / cnt), (float)n, elb_t);
   if (grad)
     hipLaunchKernelGGL(k_soft_hist_grad<1>, dim3(HB, B), dim3(256), bins * sizeof(float), st, pred, dldh, grad, n, bins,
                        delta, c2, c1, rb, grad_accum);

@@ -12,8 +12,8 @@ utils_config.py:279-374) Charbonnier, L2Sum, ImageGradientLoss, LaplacianFilterL
 LocalVariationLoss and their three Norm* variants are built the same way
 (dlib/loss/main.py:102-151,328-674), as are BoundedPrediction (extended log barrier,
 :189-237 + dlib/losses/elb.py), WeightsSparsityLoss (:938-959) and LocalMoments (:240-325);
-HistogramMatch and KDEMatch with their NORM1 / NORM2 metrics (:690-898); their KL / Bhattacharyya
-metrics and CrossEntropyL (it needs a segmentation head) are not (NotImplementedError on use).
+HistogramMatch and KDEMatch with all their metrics (NORM1 / NORM2 / KL / BHATTACHARYYA, :677-898);
+CrossEntropyL (it needs a segmentation head) is not (NotImplementedError on use).
 """
 import re
 
@@ -27,7 +27,7 @@ __all__ = ['MasterLoss', 'ElementaryLoss', 'L1', 'L2', 'NegativeSsim', 'L2Sum', 
            'NormLaplacianFilterLoss', 'NormLocalVariationLoss', 'BoundedPrediction', 'WeightsSparsityLoss',
            'LocalMoments', 'HistogramMatch', 'KDEMatch']
 
-KL, BH = 'KL', 'BHATTACHARYYA'      # dlib/utils/constants.py:699-700 (HistogramMatch metrics that are not built)
+KL, BH = 'KL', 'BHATTACHARYYA'      # dlib/utils/constants.py:699-700
 
 NORM1, NORM2 = '1', '2'      # dlib/utils/constants.py:696-697
 
@@ -243,9 +243,13 @@ class LocalMoments(ElementaryLoss):
         return _FusedLoss.apply(y_pred, lambda p, g, v: ops.loss_local_moments(p, t, self.lambda_, grad=g, loss_out=v))
 
 
+_HIST_NORM = {NORM1: 1, NORM2: 2, KL: 3, BH: 4}      # metric codes of srhip_loss_hist / srhip_loss_kde
+
+
 class HistogramMatch(ElementaryLoss):
-    """lambda * mean_{b,bin} nrm(p_pred - p_target), p = (soft histogram + 1) normalised, 256 bins over [0, 1],
-    sigmoid sharpness sigma (1e5); dlib/loss/main.py:690-782.  NORM1 / NORM2 metrics."""
+    """p = (soft histogram + 1) normalised, 256 bins over [0, 1], sigmoid sharpness sigma (1e5); dlib/loss/main.py:690-782.
+    NORM1 / NORM2: lambda * mean_{b,bin} nrm(p_pred - p_target); KL: lambda * KLDivLoss(batchmean)(log p_pred, p_target);
+    BHATTACHARYYA: lambda * elb(-sum_bin sqrt(p_pred p_target))."""
 
     def __init__(self, color_min=0, color_max=255, **kwargs):
         super().__init__(**kwargs)
@@ -258,8 +262,9 @@ class HistogramMatch(ElementaryLoss):
     def set_it(self, norm_str, sigma):
         assert isinstance(sigma, float) and sigma > 0., sigma
         assert isinstance(norm_str, str) and norm_str in (NORM2, NORM1, KL, BH), norm_str
-        if norm_str in (KL, BH):
-            raise NotImplementedError(f"HistogramMatch metric {norm_str}: only NORM1 / NORM2 run on libsrhip")
+        if norm_str == BH:
+            from dlib.losses.elb import ELB
+            assert isinstance(self.elb, ELB)            # main.py:732 (the dlib.losses copy)
         self.sigma, self.norm_str, self.already_set = sigma, norm_str, True
         self.nbins = len(list(range(self.color_min, self.color_max))) + 1
 
@@ -269,9 +274,10 @@ class HistogramMatch(ElementaryLoss):
             return self._zero
         assert y_target.shape == y_pred.shape, f'{y_target.shape}, {y_pred.shape}'
         t = y_target.float().contiguous()
-        norm = 1 if self.norm_str == NORM1 else 2
+        norm = _HIST_NORM[self.norm_str]
+        tb = float(self.elb.get_t()) if norm == 4 else 1.0
         return _FusedLoss.apply(y_pred, lambda p, g, v: ops.loss_hist(
-            p, t, self.lambda_, norm, self.sigma, self.nbins, grad=g, loss_out=v))
+            p, t, self.lambda_, norm, self.sigma, self.nbins, grad=g, loss_out=v, elb_t=tb))
 
 
 class KDEMatch(ElementaryLoss):
@@ -295,7 +301,8 @@ class KDEMatch(ElementaryLoss):
         assert isinstance(ndim, int) and ndim == 1, ndim
         assert isinstance(nbins, int) and nbins > 0, nbins
         if norm_str == BH:
-            raise NotImplementedError("KDEMatch metric BHATTACHARYYA: only NORM1 / NORM2 run on libsrhip")
+            from dlib.losses.elb import ELB
+            assert isinstance(self.elb, ELB)            # main.py:839 (the dlib.losses copy)
         self.kde_bw, self.norm_str, self.ndim, self.already_set = kde_bw, norm_str, ndim, True
         self.nbins = 256                              # the reference recomputes it from the colour range (:825)
 
@@ -306,9 +313,10 @@ class KDEMatch(ElementaryLoss):
         assert y_target.shape == y_pred.shape, f'{y_target.shape}, {y_pred.shape}'
         assert y_pred.ndim == 4 and y_pred.shape[1] == self.ndim
         t = y_target.float().contiguous()
-        norm = 1 if self.norm_str == NORM1 else 2
+        norm = _HIST_NORM[self.norm_str]
+        tb = float(self.elb.get_t()) if norm == 4 else 1.0
         return _FusedLoss.apply(y_pred, lambda p, g, v: ops.loss_kde(
-            p, t, self.lambda_, norm, self.kde_bw, self.nbins, grad=g, loss_out=v))
+            p, t, self.lambda_, norm, self.kde_bw, self.nbins, grad=g, loss_out=v, elb_t=tb))
 
 
 class _SparsityFn(torch.autograd.Function):
@@ -448,9 +456,9 @@ class MasterLoss(nn.Module):
             elif isinstance(l, LocalMoments):
                 out.append(("local_moments", l.lambda_))
             elif isinstance(l, KDEMatch):
-                out.append(("kde", l.lambda_, 1 if l.norm_str == NORM1 else 2, l.kde_bw, l.nbins))
+                out.append(("kde", l.lambda_, _HIST_NORM[l.norm_str], l.kde_bw, l.nbins, l.elb))
             elif isinstance(l, HistogramMatch):
-                out.append(("hist", l.lambda_, 1 if l.norm_str == NORM1 else 2, l.sigma, l.nbins))
+                out.append(("hist", l.lambda_, _HIST_NORM[l.norm_str], l.sigma, l.nbins, l.elb))
             elif isinstance(l, _LocalVariationTerm):
                 out.append((("norm_" if l.channel_norm else "") + l.kind, l.lambda_,
                             1 if l.norm_str == NORM1 else 2, l.ksz))

@@ -30,10 +30,12 @@ def define_loss(args):
         l = losses.Charbonnier(cuda_id=dev, lambda_=tr.get('charbonnier_lambda', 1.))
         l.set_eps(tr.get('charbonnier_eps', 1e-9))
         m.add(l)
+    def new_elb():                                # utils_instance.py:16,44-45 (every term gets its own deepcopy)
+        from dlib.losses.elb import ELB
+        return ELB(init_t=float(tr.get('elb_init_t', 1.)), max_t=float(tr.get('elb_max_t', 10.)),
+                   mulcoef=float(tr.get('elb_mulcoef', 1.01)))
     if tr.get('boundpred', False):
-        from dlib.losses.elb import ELB          # utils_instance.py:16,44-45
-        elb = ELB(init_t=float(tr.get('elb_init_t', 1.)), max_t=float(tr.get('elb_max_t', 10.)),
-                  mulcoef=float(tr.get('elb_mulcoef', 1.01)))
+        elb = new_elb()
         assert not tr.get('boundpred_use_residuals', False), "use_residuals is not on the hot path"
         l = losses.BoundedPrediction(cuda_id=dev, lambda_=tr.get('boundpred_lambda', 1.), elb=elb,
                                      restore_range=tr.get('boundpred_restore_range', True),
@@ -55,11 +57,12 @@ def define_loss(args):
                 l.set_it(norm_str=str(tr.get(norm_key, constants.NORM2)))
             m.add(l)
     if tr.get('hist', False):                     # utils_instance.py:168-177
-        l = losses.HistogramMatch(cuda_id=dev, lambda_=tr.get('hist_lambda', 1.), color_min=0, color_max=255)
+        l = losses.HistogramMatch(cuda_id=dev, lambda_=tr.get('hist_lambda', 1.), elb=new_elb(), color_min=0,
+                                  color_max=255)
         l.set_it(norm_str=str(tr.get('hist_metric', constants.NORM2)), sigma=float(tr.get('hist_sigma', 1e5)))
         m.add(l)
     if tr.get('kde', False):                      # utils_instance.py:180-190
-        l = losses.KDEMatch(cuda_id=dev, lambda_=tr.get('kde_lambda', 1.), color_min=0, color_max=1)
+        l = losses.KDEMatch(cuda_id=dev, lambda_=tr.get('kde_lambda', 1.), elb=new_elb(), color_min=0, color_max=1)
         l.set_it(norm_str=str(tr.get('kde_metric', constants.NORM2)), kde_bw=float(tr.get('kde_kde_bw', 1. / 255. ** 2)),
                  ndim=int(getattr(args, 'n_channels', None) or 1), nbins=int(tr.get('kde_nbins', 256)))
         m.add(l)

@@ -810,9 +810,9 @@ def loss_local_moments(pred, target, lam=1.0, grad=None, loss_out=None, grad_acc
 
 
 def loss_hist(pred, target, lam=1.0, norm=2, sigma=1e5, bins=256, grad=None, loss_out=None, grad_accum=False,
-              loss_accum=False):
-    """HistogramMatch with the NORM1 / NORM2 metrics over soft histograms of each image of the batch
-    (dlib/loss/main.py:690-782, dlib/loss/global_terms.py:17-72)."""
+              loss_accum=False, elb_t=1.0):
+    """HistogramMatch over soft histograms of each image of the batch (dlib/loss/main.py:690-782,
+    dlib/loss/global_terms.py:17-72); norm 1 | 2 | 3 (KL) | 4 (Bhattacharyya through the log barrier at elb_t)."""
     _chk(pred, target, grad, loss_out)
     B = pred.shape[0]
     n = pred.numel() // B
@@ -820,14 +820,14 @@ def loss_hist(pred, target, lam=1.0, norm=2, sigma=1e5, bins=256, grad=None, los
         loss_out = torch.empty(1, device=pred.device, dtype=torch.float32)
     ws = SCRATCH.get("hist_ws", lib.srhip_loss_hist_ws(B, bins), device=pred.device)
     call("srhip_loss_hist", _p(pred), _p(target), _p(grad), _p(loss_out), _p(ws), B, n, int(bins), float(sigma),
-         int(norm), float(lam), int(grad_accum), int(loss_accum), _st())
+         int(norm), float(lam), int(grad_accum), int(loss_accum), float(elb_t), _st())
     return loss_out
 
 
 def loss_kde(pred, target, lam=1.0, norm=2, kde_bw=1. / 255. ** 2, bins=256, grad=None, loss_out=None,
-             grad_accum=False, loss_accum=False):
-    """KDEMatch with the NORM1 / NORM2 metrics over a Gaussian KDE of each 1-channel image in [0, 1]
-    (dlib/loss/main.py:785-898, dlib/loss/global_terms.py:75-152)."""
+             grad_accum=False, loss_accum=False, elb_t=1.0):
+    """KDEMatch over a Gaussian KDE of each 1-channel image in [0, 1] (dlib/loss/main.py:785-898,
+    dlib/loss/global_terms.py:75-152); norm 1 | 2 | 4 (Bhattacharyya through the log barrier at elb_t)."""
     _chk(pred, target, grad, loss_out)
     assert pred.ndim == 3 or pred.shape[1] == 1, "KDEMatch: ndim == 1 (main.py:815)"
     B = pred.shape[0]
@@ -836,7 +836,7 @@ def loss_kde(pred, target, lam=1.0, norm=2, kde_bw=1. / 255. ** 2, bins=256, gra
         loss_out = torch.empty(1, device=pred.device, dtype=torch.float32)
     ws = SCRATCH.get("hist_ws", lib.srhip_loss_hist_ws(B, bins), device=pred.device)
     call("srhip_loss_kde", _p(pred), _p(target), _p(grad), _p(loss_out), _p(ws), B, n, int(bins), float(kde_bw),
-         int(norm), float(lam), int(grad_accum), int(loss_accum), _st())
+         int(norm), float(lam), int(grad_accum), int(loss_accum), float(elb_t), _st())
     return loss_out
 
 

@@ -248,9 +248,11 @@ class TrainStep:
                 if first:
                     self.dy.zero_()
             elif t[0] == "kde":
-                ops.loss_kde(y, target, t[1], t[2], t[3], t[4], self.dy, part, grad_accum=not first)
+                ops.loss_kde(y, target, t[1], t[2], t[3], t[4], self.dy, part, grad_accum=not first,
+                             elb_t=float(t[5].get_t()) if (t[2] == 4 and len(t) > 5) else 1.0)
             elif t[0] == "hist":
-                ops.loss_hist(y, target, t[1], t[2], t[3], t[4], self.dy, part, grad_accum=not first)
+                ops.loss_hist(y, target, t[1], t[2], t[3], t[4], self.dy, part, grad_accum=not first,
+                              elb_t=float(t[5].get_t()) if (t[2] == 4 and len(t) > 5) else 1.0)
             elif t[0] == "local_moments":
                 ops.loss_local_moments(y, target, t[1], self.dy, part, grad_accum=not first)
             elif t[0] == "l2sum":

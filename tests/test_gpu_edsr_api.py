@@ -385,8 +385,6 @@ def test_dlib_histogram_match_vs_reference_golden():
         assert abs(float(v) - float(rv)) <= 2e-5 * abs(float(rv)), (name, float(v), float(rv))
         assert (p.grad.cpu() - rg).abs().max() <= 2e-4 * float(rg.abs().max()), (name, (p.grad.cpu() - rg).abs().max())
         assert m.n_holder == list(g[name + "/names"])
-    with pytest.raises(NotImplementedError):
-        L.HistogramMatch(cuda_id=0, elb=ELB()).set_it(norm_str=L.KL, sigma=1e5)
     gen = torch.Generator().manual_seed(21)
     p = torch.rand(8, 1, 256, 256, generator=gen)
     t = torch.round(torch.rand(8, 1, 256, 256, generator=gen) ** 2 * 255) / 255
@@ -431,6 +429,43 @@ def test_dlib_kde_match_vs_reference_golden():
     vo.backward()
     assert abs(float(v) - float(vo)) <= 2e-5 * abs(float(vo)), (float(v), float(vo))
     assert (gr[:2].cpu() - po.grad).abs().max() <= 5e-4 * po.grad.abs().max()
+
+
+def test_dlib_hist_kde_kl_and_bhattacharyya_vs_reference_golden():
+    """The remaining metrics: HistogramMatch KL / BHATTACHARYYA and KDEMatch BHATTACHARYYA (dlib/loss/main.py:677-898)
+    against the reference, the barrier parameter at its initial value and after 30 schedule updates; then through the
+    fused training-step loss path."""
+    from dlib import loss as L
+    from dlib.losses.elb import ELB
+    from srhip import ops
+    g = load("g24_hist_kl_bh")
+    for name in ("hist_kl", "hist_bh_t1", "hist_bh_t30", "hist_kl_soft", "kde_bh_t1", "kde_bh_t30"):
+        lam, norm, sigma, tval, updates = [float(v) for v in g[name + "/cfg"]]
+        e = ELB()
+        for _ in range(int(updates)):
+            e.update_t()
+        assert abs(float(e.get_t()) - tval) <= 1e-6
+        norm_str = {3: L.KL, 4: L.BH}[int(norm)]
+        if name.startswith("hist"):
+            l = L.HistogramMatch(cuda_id=0, lambda_=lam, elb=e, color_min=0, color_max=255)
+            l.set_it(norm_str=norm_str, sigma=sigma)
+        else:
+            l = L.KDEMatch(cuda_id=0, lambda_=lam, elb=e, color_min=0, color_max=1)
+            l.set_it(norm_str=norm_str, kde_bw=1. / 255. ** 2, ndim=1, nbins=256)
+        m = L.MasterLoss(cuda_id=0)
+        m.add(l)
+        p = g["pred"].cuda().requires_grad_(True)
+        v = m(epoch=0, y_pred=p, y_target=g["target"].cuda(), trg_per_pixel_weight=None, model=None)
+        v.backward()
+        rv, rg = g[name + "/value"], g[name + "/grad"]
+        assert abs(float(v) - float(rv)) <= 2e-5 * abs(float(rv)), (name, float(v), float(rv))
+        assert (p.grad.cpu() - rg).abs().max() <= 2e-4 * float(rg.abs().max()), (name, (p.grad.cpu() - rg).abs().max())
+        # the same term as the fused step evaluates it (tuple from MasterLoss.terms())
+        gr = torch.empty_like(g["pred"]).cuda()
+        t = m.terms()[0]
+        f = ops.loss_hist if t[0] == "hist" else ops.loss_kde
+        v2 = f(g["pred"].cuda(), g["target"].cuda(), t[1], t[2], t[3], t[4], gr, elb_t=float(t[5].get_t()))
+        assert abs(float(v2) - float(rv)) <= 2e-5 * abs(float(rv)) and torch.equal(gr, p.grad)
 
 
 def test_optional_loss_terms_full_size_properties():
