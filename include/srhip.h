@@ -439,6 +439,10 @@ int srhip_relu_mask(float* g, const float* a, long n, void* stream);
 /* g[i] = a[i] > 0 ? g[i] : alpha * g[i] -- backward of a LeakyReLU(alpha > 0) whose OUTPUT a was kept
  * (nn.LeakyReLU(0.2), network_mslapsr.py:58,83,92). */
 int srhip_leaky_relu_mask(float* g, const float* a, long n, float alpha, void* stream);
+/* Nearest-neighbour x2 of an NHWC image, lo [B][h][w][C] -> hi [B][2h][2w][C] (adjoint = 0), and its adjoint: lo = sum of
+ * the 2 x 2 copies of hi (adjoint = 1).  F.interpolate(scale_factor=2, mode='nearest') of SwinIR's 'nearest+conv'
+ * upsampler, dlib/models/network_swinir.py:948-961.  C a multiple of 4. */
+int srhip_nearest_up2_nhwc(float* lo, float* hi, int B, int h, int w, int C, int adjoint, void* stream);
 /* x[i] = x[i] > 0 ? x[i] : alpha * x[i] in place (nn.LeakyReLU(0.2) behind the 1-channel edge conv, network_mslapsr.py:80-83). */
 int srhip_leaky_relu(float* x, long n, float alpha, void* stream);
 /* out[0] = sum(x) (fp64 accumulation); workspace: 2048 doubles. */

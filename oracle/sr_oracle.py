@@ -165,7 +165,7 @@ def _swin_block(sd: SD, pre: str, x: Tensor, hw: Tuple[int, int], ws: int,
 def swinir_forward(sd: SD, x: Tensor, cfg: dict,
                    dp_scales: Optional[Sequence[Tensor]] = None,
                    taps: Optional[dict] = None) -> Tensor:
-    """SwinIR.forward for upsampler 'pixelshuffledirect' / 'pixelshuffle'
+    """SwinIR.forward for upsampler 'pixelshuffledirect' / 'pixelshuffle' / 'nearest+conv'
     (network_swinir.py:930-970).  ``dp_scales``: per block a (2,B) tensor of
     DropPath multipliers (mask/keep_prob) for the attention and MLP branches,
     or None for eval / drop_path_rate 0.  ``taps`` collects intermediates of
@@ -224,6 +224,16 @@ def swinir_forward(sd: SD, x: Tensor, cfg: dict,
                          sd[f"upsample.{2 * i}.bias"], padding=1)
             y = pixel_shuffle(y, 2)
         y = F.conv2d(y, sd["conv_last.weight"], sd["conv_last.bias"], padding=1)
+    elif cfg["upsampler"] == "nearest_conv":  # :948-961 (x4 only, :876)
+        lr = lambda v: F.leaky_relu(v, 0.2)
+        y = F.leaky_relu(F.conv2d(f, sd["conv_before_upsample.0.weight"],
+                                  sd["conv_before_upsample.0.bias"], padding=1), 0.01)
+        y = lr(F.conv2d(F.interpolate(y, scale_factor=2, mode="nearest"), sd["conv_up1.weight"],
+                        sd["conv_up1.bias"], padding=1))
+        y = lr(F.conv2d(F.interpolate(y, scale_factor=2, mode="nearest"), sd["conv_up2.weight"],
+                        sd["conv_up2.bias"], padding=1))
+        y = F.conv2d(lr(F.conv2d(y, sd["conv_hr.weight"], sd["conv_hr.bias"], padding=1)),
+                     sd["conv_last.weight"], sd["conv_last.bias"], padding=1)
     else:
         raise NotImplementedError(cfg["upsampler"])
     y = y / cfg["img_range"] + mean
@@ -281,6 +291,11 @@ def swinir_init_state_dict(cfg: dict, seed: int = 0) -> SD:
     s = cfg["upscale"]
     if cfg["upsampler"] == "pixelshuffledirect":
         conv("upsample.0", s * s * cfg["in_chans"], c)
+    elif cfg["upsampler"] == "nearest_conv":     # network_swinir.py:874-885
+        conv("conv_before_upsample.0", 64, c)
+        for name in ("conv_up1", "conv_up2", "conv_hr"):
+            conv(name, 64, 64)
+        conv("conv_last", cfg["in_chans"], 64)
     else:
         conv("conv_before_upsample.0", 64, c)
         for i in range(int(math.log2(s))):

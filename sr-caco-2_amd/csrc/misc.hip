@@ -420,6 +420,35 @@ __global__ void __launch_bounds__(256) k_pixel_shuffle_r2_nhwc(const float* __re
     }
   }
 }
+// nearest-neighbour x2 of an NHWC image (F.interpolate(scale_factor=2, mode='nearest'), network_swinir.py:953-960) and its
+// adjoint (each low-resolution pixel receives the sum of its 2 x 2 copies).  One thread per (low-res pixel, float4 of channels).
+__global__ void __launch_bounds__(256) k_nearest_up2_nhwc(float* __restrict__ lo, float* __restrict__ hi, long npix,
+                                                          int h, int w, int C, int adjoint) {
+  const int c4n = C >> 2;
+  const long n = npix * c4n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / c4n;
+    const int c4 = (int)(i - pix * c4n);
+    const int x = (int)(pix % w);
+    const long t = pix / w;
+    const int y = (int)(t % h);
+    const long b = t / h;
+    const long W2 = 2L * w;
+    float* hp = hi + (((b * 2 * h + 2 * y) * W2 + 2 * x) * C) + 4 * c4;
+    float* lp = lo + pix * C + 4 * c4;
+    if (!adjoint) {
+      const f32x4 v = *(const f32x4*)lp;
+      *(f32x4*)hp = v; *(f32x4*)(hp + C) = v; *(f32x4*)(hp + W2 * C) = v; *(f32x4*)(hp + W2 * C + C) = v;
+    } else {
+      const f32x4 a = *(const f32x4*)hp, bq = *(const f32x4*)(hp + C), c = *(const f32x4*)(hp + W2 * C),
+                  d = *(const f32x4*)(hp + W2 * C + C);
+      f32x4 r;
+      r.x = (a.x + bq.x) + (c.x + d.x); r.y = (a.y + bq.y) + (c.y + d.y);
+      r.z = (a.z + bq.z) + (c.z + d.z); r.w = (a.w + bq.w) + (c.w + d.w);
+      *(f32x4*)lp = r;
+    }
+  }
+}
 __global__ void __launch_bounds__(256) k_pixel_unshuffle_r2_nhwc(const float* __restrict__ hi, float* __restrict__ lo,
                                                                  int h, int w, int Co) {
   const int lane = threadIdx.x & 63;
@@ -879,6 +908,16 @@ int srhip_relu_mask(float* g, const float* a, long n, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_relu_mask, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, g, a, n);
   SR_LAUNCH_CHECK("relu_mask");
+  return 0;
+}
+
+int srhip_nearest_up2_nhwc(float* lo, float* hi, int B, int h, int w, int C, int adjoint, void* stream) {
+  SR_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "nearest_up2: C must be a multiple of 4 (C=%d)", C);
+  SR_REQUIRE(lo && hi, "nearest_up2: null image");
+  const long npix = (long)B * h * w;
+  hipLaunchKernelGGL(k_nearest_up2_nhwc, dim3(ew_grid(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     lo, hi, npix, h, w, C, adjoint);
+  SR_LAUNCH_CHECK("nearest_up2");
   return 0;
 }
 

@@ -9,7 +9,7 @@ and there is no PyTorch/CPU execution path: CPU tensors raise.
 
 Supported on the HIP path: window_size 8, 1-channel input, upsamplers
 'pixelshuffledirect' (the configuration the reference trains and benchmarks,
-README.md:120-197) and 'pixelshuffle' (the registry default,
+README.md:120-197), 'nearest_conv' (x4: network_swinir.py:874-885,948-961) and 'pixelshuffle' (the registry default,
 utils_init_default_args.py:23; conv 180->64 + LeakyReLU, log2(s) x [conv 64->256 +
 PixelShuffle(2)], conv 64->1: network_swinir.py:862-868,937-942), resi_connection
 '1conv'.
@@ -141,8 +141,10 @@ class SwinIR(nn.Module):
             unsupported.append(f"window_size={window_size} (HIP path: 8)")
         if in_chans != 1:
             unsupported.append(f"in_chans={in_chans} (HIP path: 1-channel microscopy patches)")
-        if upsampler not in (constants.US_PIXEL_SHUFFLE_DIRECT, constants.US_PIXEL_SHUFFLE):
-            unsupported.append(f"upsampler={upsampler!r} (HIP path: 'pixelshuffledirect', 'pixelshuffle')")
+        if upsampler not in (constants.US_PIXEL_SHUFFLE_DIRECT, constants.US_PIXEL_SHUFFLE, constants.US_NEAREST_CONV):
+            unsupported.append(f"upsampler={upsampler!r} (HIP path: 'pixelshuffledirect', 'pixelshuffle', 'nearest_conv')")
+        if upsampler == constants.US_NEAREST_CONV:
+            assert upscale == 4, 'only support x4 now.'              # network_swinir.py:876
         if upsampler == constants.US_PIXEL_SHUFFLE and (upscale & (upscale - 1) or upscale < 2):
             unsupported.append(f"upscale={upscale} with 'pixelshuffle' (HIP path: powers of two)")
         if resi_connection != constants.R_CONNECTION_1CONV:
@@ -179,6 +181,14 @@ class SwinIR(nn.Module):
         self.conv_after_body = _conv3(embed_dim, embed_dim)
         if upsampler == constants.US_PIXEL_SHUFFLE_DIRECT:
             self.upsample = nn.ModuleList([_conv3(upscale * upscale * in_chans, embed_dim)])
+        elif upsampler == constants.US_NEAREST_CONV:   # parameter names / order of network_swinir.py:874-885
+            num_feat = 64
+            self.num_feat = num_feat
+            self.conv_before_upsample = nn.ModuleList([_conv3(num_feat, embed_dim)])
+            self.conv_up1 = _conv3(num_feat, num_feat)
+            self.conv_up2 = _conv3(num_feat, num_feat)
+            self.conv_hr = _conv3(num_feat, num_feat)
+            self.conv_last = _conv3(in_chans, num_feat)
         else:       # 'pixelshuffle': same parameter names / order as network_swinir.py:862-868
             num_feat = 64
             self.num_feat = num_feat

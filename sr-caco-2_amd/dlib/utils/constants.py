@@ -22,7 +22,7 @@ NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH, 
 
 US_PIXEL_SHUFFLE = 'pixelshuffle'
 US_PIXEL_SHUFFLE_DIRECT = 'pixelshuffledirect'
-US_NEAREST_CONV = 'nearest+conv'
+US_NEAREST_CONV = 'nearest_conv'        # reference constants.py:93
 R_CONNECTION_1CONV = '1conv'
 R_CONNECTION_3CONV = '3conv'
 

@@ -665,6 +665,15 @@ def relu_mask(g, a):
     return g
 
 
+def nearest_up2(lo, hi, adjoint=False):
+    """NHWC nearest-neighbour x2: hi [B,2h,2w,C] = each lo pixel four times; adjoint: lo = sum of the four copies."""
+    _chk(lo, hi)
+    B, h, w, C = lo.shape
+    assert hi.shape == (B, 2 * h, 2 * w, C) and lo.is_contiguous() and hi.is_contiguous()
+    call("srhip_nearest_up2_nhwc", _p(lo), _p(hi), B, h, w, C, int(bool(adjoint)), _st())
+    return lo if adjoint else hi
+
+
 def leaky_relu_(x, alpha):
     """x = x > 0 ? x : alpha * x in place."""
     _chk(x)

@@ -47,7 +47,8 @@ class SwinIREngine:
         self.scale = net.upscale
         self.blocks = list(net.swin_blocks())
         self.direct = net.upsampler == "pixelshuffledirect"
-        self.stages = 0 if self.direct else int(round(__import__("math").log2(net.upscale)))
+        self.nearest = net.upsampler == "nearest_conv"      # 2 x [nearest x2, conv, LeakyReLU], conv_hr, conv_last (x4)
+        self.stages = 0 if (self.direct or self.nearest) else int(round(__import__("math").log2(net.upscale)))
         self.layer_of_block = []
         for li, layer in enumerate(net.layers):
             for _ in layer.residual_group.blocks:
@@ -73,7 +74,8 @@ class SwinIREngine:
         for li in reversed(range(n)):
             pf = [f"layers.{li}."]
             if li == n - 1:
-                pf += ["norm.", "conv_after_body.", "conv_before_upsample.", "upsample.", "conv_last."]
+                pf += ["norm.", "conv_after_body.", "conv_before_upsample.", "upsample.", "conv_up1.", "conv_up2.",
+                       "conv_hr.", "conv_last."]
             out.append(pf)
         out.append(["conv_first.", "patch_embed."])
         return out
@@ -170,6 +172,11 @@ class SwinIREngine:
         yield "cab", net.conv_after_body
         if self.direct:
             yield "up", net.upsample[0]
+        elif self.nearest:
+            yield "cbu", net.conv_before_upsample[0]
+            yield "nup1", net.conv_up1
+            yield "nup2", net.conv_up2
+            yield "nhr", net.conv_hr
         else:
             yield "cbu", net.conv_before_upsample[0]
             for i in range(self.stages):
@@ -263,6 +270,21 @@ class SwinIREngine:
             u = buf("u", B, H, W, cu)
             ops.conv3x3(f, ws["up.wp"], net.upsample[0].bias.data, cu, out=u)
             ops.pixel_shuffle(u, r, out=y)
+        elif self.nearest:  # 'nearest_conv' (network_swinir.py:948-961)
+            nf = net.num_feat
+            u = buf("cbu", B, H, W, nf)
+            ops.conv3x3(f, ws["cbu.wp"], net.conv_before_upsample[0].bias.data, nf, out=u, epi=6, alpha=0.01)
+            n1 = ops.nearest_up2(u, buf("n1", B, 2 * H, 2 * W, nf))
+            a1 = buf("na1", B, 2 * H, 2 * W, nf)
+            ops.conv3x3(n1, ws["nup1.wp"], net.conv_up1.bias.data, nf, out=a1, epi=6, alpha=0.2)
+            n2 = ops.nearest_up2(a1, buf("n2", B, 4 * H, 4 * W, nf))
+            a2 = buf("na2", B, 4 * H, 4 * W, nf)
+            ops.conv3x3(n2, ws["nup2.wp"], net.conv_up2.bias.data, nf, out=a2, epi=6, alpha=0.2)
+            a3 = buf("na3", B, 4 * H, 4 * W, nf)
+            ops.conv3x3(a2, ws["nhr.wp"], net.conv_hr.bias.data, nf, out=a3, epi=6, alpha=0.2)
+            ops.conv3x3_cout1_fwd(a3, net.conv_last.weight.data, net.conv_last.bias.data, out=y.view(B, 4 * H, 4 * W))
+            if save:
+                sv["near"] = (u, n1, a1, n2, a2, a3)
         else:               # 'pixelshuffle' (network_swinir.py:937-942)
             nf = net.num_feat
             u = buf("cbu", B, H, W, nf)
@@ -309,6 +331,32 @@ class SwinIREngine:
             ops.pixel_shuffle(dy, r, inverse=True, out=du)
             ops.conv3x3_wgrad(du, sv["f"], G("upsample.0.weight"), G("upsample.0.bias"))
             ops.conv3x3(du, ws["up.wpt"], None, C, out=df)
+        elif self.nearest:
+            nf = net.num_feat
+            u, n1, a1, n2, a2, a3 = sv["near"]
+            h, w = 4 * H, 4 * W
+            dyv = dy.reshape(B, h, w).contiguous()
+            ops.conv3x3_cin1_wgrad(dyv, a3, G("conv_last.weight"), None, flip=True)
+            ops.sum_into(dyv, G("conv_last.bias"))
+            g3 = buf("ng3", B, h, w, nf)
+            ops.conv3x3_cin1_fwd(dyv, net.conv_last.weight.data, None, nf, out=g3, flip=True)
+            ops.leaky_relu_mask(g3, a3, 0.2)
+            ops.conv3x3_wgrad(g3, a2, G("conv_hr.weight"), G("conv_hr.bias"))
+            g2 = buf("ng2", B, h, w, nf)
+            ops.conv3x3(g3, ws["nhr.wpt"], None, nf, out=g2, epi=7, R=a2, alpha=0.2)       # * LeakyReLU'(conv_up2 output)
+            ops.conv3x3_wgrad(g2, n2, G("conv_up2.weight"), G("conv_up2.bias"))
+            ops.conv3x3(g2, ws["nup2.wpt"], None, nf, out=g3)                               # d / d(upsampled a1)
+            g1 = buf("ng1", B, 2 * H, 2 * W, nf)
+            ops.nearest_up2(g1, g3, adjoint=True)
+            ops.leaky_relu_mask(g1, a1, 0.2)
+            ops.conv3x3_wgrad(g1, n1, G("conv_up1.weight"), G("conv_up1.bias"))
+            gn = buf("ngn", B, 2 * H, 2 * W, nf)
+            ops.conv3x3(g1, ws["nup1.wpt"], None, nf, out=gn)
+            g0 = buf("ng0", B, H, W, nf)
+            ops.nearest_up2(g0, gn, adjoint=True)
+            ops.leaky_relu_mask(g0, u, 0.01)
+            ops.conv3x3_wgrad(g0, sv["f"], G("conv_before_upsample.0.weight"), G("conv_before_upsample.0.bias"))
+            ops.conv3x3(g0, ws["cbu.wpt"], None, C, out=df)
         else:
             nf, ups = net.num_feat, sv["ups"]
             h, w = H * r, W * r
