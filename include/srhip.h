@@ -169,8 +169,9 @@ int srhip_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats);
 int srhip_gemm_tn(const float* A, long lda, const float* B, long ldb, int M, int NI, int NJ,
                   const float* a_rowscale, int a_rowscale_rows, int b_mode, const float* ln_stats,
                   float* part, float* part_colsum, int S, void* stream);
-/* Up to 4 Linear weight-gradient problems over the same M rows in one launch
- * (the four Linears of a Swin block), each with its own partial buffers. */
+/* Several Linear weight-gradient problems over the same M rows in one launch, each with its own partial buffers:
+ * up to 4 (exact-f32 kernels: the four Linears of a Swin block) or up to 24 (_bx3: the 4 x depth Linears of a whole
+ * RSTB layer -- more tiles per launch need fewer reduce slices S to fill the chip). */
 typedef struct srhip_tn_problem {
   const float* A; long lda;          /* dY [M][NI] */
   const float* B; long ldb;          /* X  [M][NJ] */
@@ -206,7 +207,7 @@ int srhip_reduce_ln_linear_wgrad(const float* part, const float* colsum, int S, 
                                  float* dgamma, float* dbeta, int N, int K, int ln_grads_zeroed,
                                  void* stream);
 /* dW in torch layout [Cout][Cin][3][3]. */
-/* The slice reducers of up to four Linear problems (srhip_gemm_tn_grouped) in one launch.
+/* The slice reducers of up to 24 Linear problems (srhip_gemm_tn_grouped / _bx3) in one launch.
  * gamma == NULL: plain Linear (srhip_reduce_linear_wgrad); else the LayerNorm-folded form
  * (srhip_reduce_ln_linear_wgrad; dgamma / dbeta are accumulated with atomics: zero them first). */
 typedef struct {

@@ -193,8 +193,8 @@ int srhip_tn_group_plan_bx3(int M, int ntiles, int* S) { return sr_tn_group_plan
 int srhip_tn_group_plan(int M, int ntiles, int* S) { return sr_tn_group_plan(M, ntiles, S); }
 
 static int gemm_tn_grouped_any(bool bx, const srhip_tn_problem* probs, int nprob, int M, int S, void* stream) {
-  SR_REQUIRE(nprob >= 1 && nprob <= 4, "gemm_tn_grouped: 1..4 problems");
-  TnArgs a[4];
+  SR_REQUIRE(nprob >= 1 && nprob <= (bx ? 24 : 4), "gemm_tn_grouped: 1..%d problems", bx ? 24 : 4);
+  TnArgs a[24];
   memset(a, 0, sizeof(a));
   for (int k = 0; k < nprob; ++k) {
     const srhip_tn_problem& q = probs[k];

@@ -613,23 +613,27 @@ __global__ void __launch_bounds__(512, 1) k_tnb(TnArgs p, int tiles, int xcd) {
   tnb_body<W>(p, t2 / tiles, t2 % tiles, tap, smem);
 }
 
+// Up to TNB_GROUP_MAX Linear problems over the same rows in one launch: the four of a Swin block, or the 4 x depth of a
+// whole RSTB layer (SwinIREngine defers them to the layer's end: 48 tiles need 5 reduce slices to fill the chip instead
+// of 32 -- a sixth of the partial-sum traffic and of the reducer's work per block).  The block's problem is selected by
+// a chain of uniform conditional copies with CONSTANT indices (a runtime-indexed kernel-argument array would be copied
+// to scratch), so the body exists once.
+constexpr int TNB_GROUP_MAX = 24;
 struct TnbGroup {
-  TnArgs p[4];
-  int tile_start[5];
+  TnArgs p[TNB_GROUP_MAX];
+  int tile_start[TNB_GROUP_MAX + 1];
   int n;
 };
 template <int W, int DBG = 0>
 __global__ void __launch_bounds__(512, 1) k_tnb_grouped(TnbGroup g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = blockIdx.y;
-  int k = 0;
+  TnArgs p = g.p[0];
+  int t0 = 0;
 #pragma unroll
-  for (int i = 1; i < 4; ++i)
-    if (i < g.n && t >= g.tile_start[i]) k = i;
-  if (k == 0) tnb_body<W, DBG>(g.p[0], blockIdx.x, t - g.tile_start[0], 0, smem);
-  else if (k == 1) tnb_body<W, DBG>(g.p[1], blockIdx.x, t - g.tile_start[1], 0, smem);
-  else if (k == 2) tnb_body<W, DBG>(g.p[2], blockIdx.x, t - g.tile_start[2], 0, smem);
-  else tnb_body<W, DBG>(g.p[3], blockIdx.x, t - g.tile_start[3], 0, smem);
+  for (int i = 1; i < TNB_GROUP_MAX; ++i)
+    if (i < g.n && t >= g.tile_start[i]) { p = g.p[i]; t0 = g.tile_start[i]; }
+  tnb_body<W, DBG>(p, blockIdx.x, t - t0, 0, smem);
 }
 
 // Up to TNB_BATCH_MAX conv weight-gradient problems of ONE shape (same image geometry and channel
@@ -721,7 +725,8 @@ constexpr int lds_bytes(int w) { return 2 * 3 * 2 * 64 * w * 64; }
 }  // namespace
 
 int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
-  SR_REQUIRE(n >= 1 && n <= 4, "gemm_tn_grouped_bx3: 1..4 problems (got %d)", n);
+  SR_REQUIRE(n >= 1 && n <= TNB_GROUP_MAX, "gemm_tn_grouped_bx3: 1..%d problems (got %d)", TNB_GROUP_MAX, n);
+  static_assert(sizeof(TnbGroup) <= 4096, "kernel arguments");
   TnbGroup g;
   memset(&g, 0, sizeof(g));
   g.n = n;

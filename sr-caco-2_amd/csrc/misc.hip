@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) k_fin_ln_linear(
     atomicAdd(dbeta + k, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
   }
 }
-// The slice reducers of up to four Linear weight gradients (one Swin block) in ONE
+// The slice reducers of up to 24 Linear weight gradients (one Swin block: 4; one RSTB layer: 4 x depth) in ONE
 // launch: k_fin_ln_linear's geometry per problem; gamma == null means a plain Linear
 // (dW = G, db = dbv, no LayerNorm gradients).
 struct ReduceGroup {
@@ -157,17 +157,16 @@ struct ReduceGroup {
     const float* part; const float* colsum; const float* W; const float* gamma; const float* beta;
     float* dW; float* db; float* dgamma; float* dbeta;
     int N, K, blk0, kblocks;
-  } p[4];
+  } p[24];              // = TNB_GROUP_MAX of gemm_tnb.hip
   int n, S;
 };
 __global__ void __launch_bounds__(256) k_reduce_group(ReduceGroup g) {
   __shared__ float sd[4], sg[4][64], sb[4][64];
-  int q = 0;
-#pragma unroll
-  for (int i = 1; i < 4; ++i)
-    if (i < g.n && (int)blockIdx.x >= g.p[i].blk0) q = i;
   // select with constant indices (a runtime-indexed struct array would go to scratch)
-  const ReduceGroup::P P = q == 0 ? g.p[0] : q == 1 ? g.p[1] : q == 2 ? g.p[2] : g.p[3];
+  ReduceGroup::P P = g.p[0];
+#pragma unroll
+  for (int i = 1; i < 24; ++i)
+    if (i < g.n && (int)blockIdx.x >= g.p[i].blk0) P = g.p[i];
   const int S = g.S, N = P.N, K = P.K;
   const int lb = blockIdx.x - P.blk0;
   const int bx = lb % P.kblocks, by = lb / P.kblocks;
@@ -683,7 +682,7 @@ int srhip_reduce_ln_linear_wgrad(const float* part, const float* colsum, int S, 
 }
 
 int srhip_reduce_wgrad_grouped(const srhip_reduce_problem* probs, int nprob, int S, void* stream) {
-  SR_REQUIRE(nprob >= 1 && nprob <= 4 && S > 0, "reduce_wgrad_grouped: 1..4 problems, S > 0");
+  SR_REQUIRE(nprob >= 1 && nprob <= 24 && S > 0, "reduce_wgrad_grouped: 1..24 problems, S > 0");
   ReduceGroup g;
   memset(&g, 0, sizeof(g));
   g.n = nprob; g.S = S;

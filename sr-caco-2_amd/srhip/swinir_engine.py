@@ -385,12 +385,21 @@ class SwinIREngine:
         dt = buf("dt", T, C)
         ops.layernorm_bwd(dtn, sv["t_last"], sv["st_n"], dt, gamma=net.norm.weight.data,
                           dgamma=G("norm.weight"), dbeta=G("norm.bias"))
-        # three rotating gradient buffers: a block's incoming gradient g must stay
-        # alive until the block's grouped weight-gradient launch at its end
-        gbufs = [buf("ga", T, C), buf("gb", T, C), buf("gc", T, C)]
-        dh, dxh, da = buf("dh", T, hid), buf("dxh", T, C), buf("da", T, C)
-        gh = buf("gh", T, hid)        # gelu(h): by-product of the dgelu epilogue, operand of the fc2 weight gradient
-        dqkv = buf("dqkv", T, 3 * C)
+        # The weight gradients of ALL blocks of an RSTB layer go through ONE grouped launch + ONE reducer at the layer's
+        # end (bf16x3 kernels: up to 24 problems): 4 x depth problems = 48 tiles fill the chip with 5 reduce slices
+        # where one block's 8 tiles need 32 -- a sixth of the partial-sum traffic (33 MB written + read per block) and of
+        # the reducer's work.  Their operands therefore live until the layer's end: per block its own dh / gelu(h) /
+        # dqkv and gradient buffers (1.3 GB per layer at B = 8; sized for 288 GB of HBM).  SRHIP_WGRAD_PER_BLOCK=1 or
+        # the exact-f32 kernels: one launch per block, three rotating gradient buffers.
+        max_nb = max(len(l.residual_group.blocks) for l in net.layers)
+        defer = ws.use_bx3 and 4 * max_nb <= 24 and os.environ.get("SRHIP_WGRAD_PER_BLOCK", "0") != "1"
+        nset = max_nb if defer else 1
+        gbufs = [buf(f"g{i}", T, C) for i in range(2 * nset + 1)]
+        dhs = [buf(f"dh{i}", T, hid) for i in range(nset)]
+        ghs = [buf(f"gh{i}", T, hid) for i in range(nset)]   # gelu(h): by-product of the dgelu epilogue, operand of the fc2 weight gradient
+        dqkvs = [buf(f"dqkv{i}", T, 3 * C) for i in range(nset)]
+        dxh, da = buf("dxh", T, C), buf("da", T, C)
+        nrot = len(gbufs)
         bi = len(self.blocks)
         # bias-gradient images of all blocks (each overwritten by its attention backward: no memset)
         dbT_all = buf("dbiasT_all", len(self.blocks), max(b.num_heads for b in self.blocks), 64, 64)
@@ -404,15 +413,17 @@ class SwinIREngine:
             g = gbufs[gi]
             ops.conv3x3(dt.view(B, H, W, C), ws[f"l{li}.wpt"], None, C, out=g.view(B, H, W, C))
             nb = len(layer.residual_group.blocks)
+            pending = []                 # weight-gradient problems of the layer's blocks (deferred form)
             for j in reversed(range(nb)):
                 bi -= 1
+                dh, gh, dqkv = dhs[j % nset], ghs[j % nset], dqkvs[j % nset]
                 blk = layer.residual_group.blocks[j]
                 p = pre + f"residual_group.blocks.{j}."
                 t, st1, qkv, a, x1, st2, h = sv["blocks"][bi]
                 heads = blk.num_heads
                 s1 = None if dp is None else dp[2 * bi]
                 s2 = None if dp is None else dp[2 * bi + 1]
-                g1, gout = gbufs[(gi + 1) % 3], gbufs[(gi + 2) % 3]
+                g1, gout = gbufs[(gi + 1) % nrot], gbufs[(gi + 2) % nrot]
                 # ---- MLP branch: x2 = x1 + s2*(gelu(h) W2^T + b2)
                 if self.fuse_mlp:
                     ops.mlp_bwd(g, ws[f"{bi}.m2T"], ws[f"{bi}.m1T"], h, dh, gh, x1, st2, g1, rowscale=s2,
@@ -435,8 +446,8 @@ class SwinIREngine:
                 else:
                     ops.gemm_nt(dqkv, ws[f"{bi}.wqT"], None, out=dxh)
                     ops.layernorm_bwd(dxh, t, st1, gout, res=g1)
-                # ---- the four weight gradients of the block in ONE launch
-                ops.linear_wgrad_grouped([
+                # ---- the four weight gradients of the block: one launch per block, or collected for the layer's
+                problems = [
                     dict(dY=dqkv, X=t, dW=G(p + "attn.qkv.weight"), db=G(p + "attn.qkv.bias"), b_mode=1,
                          ln_stats=st1, ln=(blk.attn.qkv.weight.data, blk.norm1.weight.data,
                                            blk.norm1.bias.data, G(p + "norm1.weight"), G(p + "norm1.bias"))),
@@ -447,9 +458,15 @@ class SwinIREngine:
                                            blk.norm2.bias.data, G(p + "norm2.weight"), G(p + "norm2.bias"))),
                     dict(dY=g1, X=a, dW=G(p + "attn.proj.weight"), db=G(p + "attn.proj.bias"),
                          a_rowscale=s1, a_rowscale_rows=H * W),
-                ], ln_grads_zeroed=grads_zeroed)
-                gi = (gi + 2) % 3
+                ]
+                if defer:
+                    pending += problems
+                else:
+                    ops.linear_wgrad_grouped(problems, ln_grads_zeroed=grads_zeroed)
+                gi = (gi + 2) % nrot
                 g = gout
+            if pending:
+                ops.linear_wgrad_grouped(pending, ln_grads_zeroed=grads_zeroed)
             # relative-position-bias table gradients of the layer's blocks: one launch (<= 8 blocks each)
             tabs = [G(pre + f"residual_group.blocks.{j}.attn.relative_position_bias_table") for j in range(nb)]
             same = len({blk.num_heads for blk in layer.residual_group.blocks}) == 1
