@@ -449,6 +449,26 @@ int srhip_leaky_relu(float* x, long n, float alpha, void* stream);
 /* out[0] = sum(x) (fp64 accumulation); workspace: 2048 doubles. */
 int srhip_sum(const float* x, long n, float* out, double* workspace, void* stream);
 
+/* ---- BatchNorm2d over channels-last activations [T][C], T = B*H*W (nn.BatchNorm2d of MemNet's BN -> ReLU -> conv
+ * units: dlib/models/network_memnet.py:27-34,59-64,100-104,112-116).  C = 1 or a multiple of 64.
+ *   coef [4][C] = mean, rstd = 1/sqrt(var + eps), k = gamma * rstd, beta.  Training: srhip_bn_stats fills it from the
+ *   batch (biased variance) and updates running_mean / running_var in place (momentum, unbiased variance; pass NULL,
+ *   NULL to leave them alone).  Evaluation: the caller fills coef from the running statistics.
+ *   workspace: srhip_bn_workspace_bytes(T, C) bytes, caller-owned. */
+int srhip_bn_workspace_bytes(long T, int C, long* bytes);
+int srhip_bn_stats(const float* X, long T, int C, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float momentum, float eps, float* coef, void* workspace, long workspace_bytes,
+                   void* stream);
+/* Y = (X - mean) * k + beta, then ReLU if relu != 0 (nn.ReLU(True) behind every BatchNorm of the net). */
+int srhip_bn_apply(const float* X, const float* coef, float* Y, long T, int C, int relu, void* stream);
+/* Backward of Y = relu?(BN(X)) in training mode.  dz = dY * (A > 0) when A (the ReLU's output) is given, dY otherwise;
+ * dgamma = sum dz * xhat, dbeta = sum dz, ADDED to what is there if accumulate != 0 (a shared unit is applied several
+ * times per forward, network_memnet.py:69-72; either may be NULL); dX = k * (dz - mean(dz) - xhat * mean(dz * xhat)) (+ R: the skip
+ * connection of the residual unit, network_memnet.py:36-40).  dX NULL: parameter gradients only. */
+int srhip_bn_bwd(const float* dY, const float* A, const float* X, const float* coef, long T, int C, float* dX,
+                 const float* R, float* dgamma, float* dbeta, int accumulate, void* workspace, long workspace_bytes,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

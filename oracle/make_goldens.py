@@ -642,6 +642,73 @@ def g_mslapsrn():
     npz("g23_mslapsrn", **out)
 
 
+def g_memnet():
+    """MemNet (network_memnet.py:24-179) from the reference class, training mode (batch statistics, running-statistics
+    update, gradients of an L1 loss) and eval mode (running statistics), on a 2 x 1 x 6 x 5 input; two small
+    configurations (memory blocks / residual units / scale); weights from the oracle's seeded initialiser."""
+    print("G26 MemNet")
+    from dlib.models.network_memnet import MemNet as RefNet
+    out = {}
+    for tag, (scale, M, R) in {"a": (2, 2, 2), "b": (4, 3, 1)}.items():
+        sd = O.memnet_init_state_dict(M, R, 1, seed=120 + scale)
+        net = RefNet(in_chans=1, upscale=scale, num_memory_blocks=M, num_residual_blocks=R)
+        assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(40 + scale)
+        x = torch.rand(2, 1, 6, 5)
+        tgt = torch.rand(2, 1, 6 * scale, 5 * scale)
+        net.eval()
+        with torch.no_grad():
+            ye = net(x)
+        mag = max(1.0, float(ye.abs().max()))       # the net has no output normalisation: |y| ~ 7 on these inputs
+        close(O.memnet_forward(sd, x, scale, M, R, training=False), ye, 5e-6 * mag, f"memnet {tag} eval forward")
+        net.train()
+        y = net(x)
+        (y - tgt).abs().mean().backward()
+        sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+               for k, v in sd.items()}
+        stats = {}
+        yo = O.memnet_forward(sdo, x, scale, M, R, training=True, stats=stats)
+        (yo - tgt).abs().mean().backward()
+        close(yo.detach(), y.detach(), 5e-6 * mag, f"memnet {tag} train forward")
+        after = net.state_dict()
+        for k, v in stats.items():
+            if v.is_floating_point():
+                close(v, after[k], 2e-6, f"memnet {tag} {k}")
+            else:
+                assert int(v) == int(after[k]), k
+        pre = tag + "/"
+        sums = []
+        worst = 0.0
+        keep = ["feature_extractor.0.weight", "feature_extractor.0.bias", "feature_extractor.2.weight",
+                "dense_memory_blocks.0.recursive_unit.1.residual_block.3.weight",
+                "dense_memory_blocks.0.recursive_unit.1.residual_block.3.bias",
+                "dense_memory_blocks.1.gate_unit.0.weight", "dense_memory_blocks.1.gate_unit.2.weight",
+                "reconstructor.0.bias", "reconstructor.2.weight"]
+        if tag == "a":
+            keep += ["dense_memory_blocks.0.recursive_unit.0.residual_block.2.weight",
+                     "dense_memory_blocks.1.recursive_unit.1.residual_block.5.weight"]
+        for k, p_ in net.named_parameters():
+            # 30-50 ReLUs deep on a 24 x 20 image: one ReLU decision that falls differently under f32 rounding moves a
+            # gradient by a discrete step (the oracle in f64 is 1e-3 from the oracle in f32 on the 1-channel BatchNorm's
+            # bias) -- relative-L2 gate, as for the MSLapSRN fixture
+            rel = ((sdo[k].grad - p_.grad).double().norm() / p_.grad.double().norm().clamp_min(1e-30)).item()
+            assert rel < 2e-3, f"oracle != reference for memnet {tag} d{k}: relative L2 {rel:g}"
+            worst = max(worst, rel)
+            if k in keep:
+                out[pre + "grad/" + k] = p_.grad
+            sums.append([p_.grad.double().sum().item(), p_.grad.double().abs().sum().item()])
+        print(f"  ok memnet {tag} gradients: worst relative L2 oracle vs reference = {worst:.3g}")
+        for k in ("feature_extractor.0", "dense_memory_blocks.0.recursive_unit.0.residual_block.3",
+                  "dense_memory_blocks.1.gate_unit.0", "reconstructor.0"):
+            for b in ("running_mean", "running_var", "num_batches_tracked"):
+                out[pre + f"after/{k}.{b}"] = after[f"{k}.{b}"]
+        out[pre + "x"], out[pre + "target"], out[pre + "y_train"], out[pre + "y_eval"] = x, tgt, y.detach(), ye
+        out[pre + "grad_sums"] = np.array(sums)
+        out[pre + "cfg"] = np.array([scale, M, R, 120 + scale])
+    npz("g26_memnet", **out)
+
+
 # ---------------------------------------------------------------- G19 eval.py experiment folder
 def g_eval_fixture():
     """A reference-format experiment directory + dataset + folds, and what the REFERENCE's own
@@ -1290,7 +1357,7 @@ def g_optim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
-            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv]
+            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:
         if not only or g.__name__ in only:

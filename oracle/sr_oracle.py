@@ -531,6 +531,95 @@ def drrn_init_state_dict(in_chans: int = 1, seed: int = 0) -> SD:
 
 
 # ----------------------------------------------------------------------------
+# MemNet (dlib/models/network_memnet.py)
+# ----------------------------------------------------------------------------
+def batchnorm2d(sd: SD, pre: str, x: Tensor, training: bool, stats: Optional[dict] = None, eps: float = 1e-5,
+                momentum: float = 0.1) -> Tensor:
+    """nn.BatchNorm2d as the reference's nets use it (network_memnet.py:28,31,60,101,113): training mode normalises
+    with the batch mean and BIASED variance and moves the running statistics by ``momentum`` towards the batch mean /
+    UNBIASED variance (written into ``stats``, keyed like the module's buffers); eval mode uses the running ones."""
+    g, b = sd[pre + ".weight"], sd[pre + ".bias"]
+    if training:
+        mean = x.mean((0, 2, 3))
+        var = x.var((0, 2, 3), unbiased=False)
+        if stats is not None:
+            n = x.numel() / x.shape[1]
+            rm = stats.get(pre + ".running_mean", sd[pre + ".running_mean"])
+            rv = stats.get(pre + ".running_var", sd[pre + ".running_var"])
+            stats[pre + ".running_mean"] = (1 - momentum) * rm + momentum * mean.detach()
+            stats[pre + ".running_var"] = (1 - momentum) * rv + momentum * var.detach() * (n / max(n - 1.0, 1.0))
+            stats[pre + ".num_batches_tracked"] = stats.get(pre + ".num_batches_tracked",
+                                                            sd[pre + ".num_batches_tracked"]) + 1
+    else:
+        mean, var = sd[pre + ".running_mean"], sd[pre + ".running_var"]
+    sh = (1, -1, 1, 1)
+    return (x - mean.view(sh)) / torch.sqrt(var.view(sh) + eps) * g.view(sh) + b.view(sh)
+
+
+def memnet_forward(sd: SD, x: Tensor, upscale: int, num_memory_blocks: int, num_residual_blocks: int,
+                   training: bool = False, stats: Optional[dict] = None) -> Tensor:
+    """network_memnet.py:143-167: bicubic up (align_corners False, clamped); BN-ReLU-conv 1 -> 64; memory blocks; BN-ReLU-
+    conv1x1 64 -> 1; + the interpolated input.  A memory block (network_memnet.py:66-78) runs its WHOLE chain of
+    residual units ``num_residual_blocks`` times (``self.recursive_unit(out)`` is the Sequential of all of them) and keeps
+    the result of every pass as a short-term memory; the gate unit (BN-ReLU-conv1x1) reads the concatenation of those
+    and of all long-term memories (the extractor's features and every earlier block's output).  A residual unit is
+    x + conv(relu(BN(conv(relu(BN(x)))))) (:36-40).  No conv has a bias."""
+    R = num_residual_blocks
+    bn = lambda pre, t: F.relu(batchnorm2d(sd, pre, t, training, stats))
+    xi = torch.clamp(F.interpolate(x, size=(upscale * x.shape[2], upscale * x.shape[3]), mode="bicubic",
+                                   align_corners=False), 0.0, 1.0)
+    out = F.conv2d(bn("feature_extractor.0", xi), sd["feature_extractor.2.weight"], padding=1)
+    longs = [out]
+    for i in range(num_memory_blocks):
+        mb = f"dense_memory_blocks.{i}"
+        shorts = []
+        for _ in range(R):
+            for j in range(R):
+                ru = f"{mb}.recursive_unit.{j}.residual_block"
+                t = F.conv2d(bn(ru + ".0", out), sd[ru + ".2.weight"], padding=1)
+                out = F.conv2d(bn(ru + ".3", t), sd[ru + ".5.weight"], padding=1) + out
+            shorts.append(out)
+        out = F.conv2d(bn(mb + ".gate_unit.0", torch.cat(shorts + longs, 1)), sd[mb + ".gate_unit.2.weight"])
+        longs.append(out)
+    return F.conv2d(bn("reconstructor.0", out), sd["reconstructor.2.weight"]) + xi
+
+
+def memnet_init_state_dict(num_memory_blocks: int, num_residual_blocks: int, in_chans: int = 1, seed: int = 0) -> SD:
+    """Seeded weights in the shapes / key order of the reference net (network_memnet.py:100-116,172-179: Kaiming-normal
+    convs), with BatchNorm weights, biases and running statistics moved off their initial 1 / 0 / 0 / 1 so that every
+    one of them matters in the parity fixtures."""
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+
+    def bn(pre, c):
+        sd[pre + ".weight"] = 1.0 + 0.1 * torch.randn(c, generator=g)
+        sd[pre + ".bias"] = 0.05 * torch.randn(c, generator=g)
+        sd[pre + ".running_mean"] = 0.1 * torch.randn(c, generator=g)
+        sd[pre + ".running_var"] = 0.8 + 0.4 * torch.rand(c, generator=g)
+        sd[pre + ".num_batches_tracked"] = torch.tensor(3, dtype=torch.long)
+
+    def conv(name, co, ci, k):
+        sd[name] = torch.randn(co, ci, k, k, generator=g) * math.sqrt(2.0 / (ci * k * k))
+
+    bn("feature_extractor.0", in_chans)
+    conv("feature_extractor.2.weight", 64, in_chans, 3)
+    for i in range(num_memory_blocks):
+        mb = f"dense_memory_blocks.{i}"
+        for j in range(num_residual_blocks):
+            ru = f"{mb}.recursive_unit.{j}.residual_block"
+            bn(ru + ".0", 64)
+            conv(ru + ".2.weight", 64, 64, 3)
+            bn(ru + ".3", 64)
+            conv(ru + ".5.weight", 64, 64, 3)
+        gc = (num_residual_blocks + i + 1) * 64
+        bn(mb + ".gate_unit.0", gc)
+        conv(mb + ".gate_unit.2.weight", 64, gc, 1)
+    bn("reconstructor.0", 64)
+    conv("reconstructor.2.weight", in_chans, 64, 1)
+    return sd
+
+
+# ----------------------------------------------------------------------------
 # losses (dlib/loss/main.py, dlib/loss/ssim.py, dlib/loss/master.py)
 # ----------------------------------------------------------------------------
 def loss_l1(pred: Tensor, target: Tensor, lam: float = 1.0,

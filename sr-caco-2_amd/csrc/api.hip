@@ -18,7 +18,7 @@ int sr_fail(int code, const char* fmt, ...) {
 extern "C" {
 
 const char* srhip_last_error(void) { return g_err; }
-int srhip_abi_version(void) { return 9; }
+int srhip_abi_version(void) { return 10; }
 
 static int g_matmul_mode = 0;
 int srhip_set_matmul_mode(int mode) {

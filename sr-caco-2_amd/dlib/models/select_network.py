@@ -39,6 +39,11 @@ def define_G(args):
     if net_type == constants.MSLAPSR:               # select_network.py:103-108
         from dlib.models.network_mslapsr import MSLapSRN as net
         return net(upscale=opt_net[f'{nt}_upscale'], in_chans=opt_net[f'{nt}_in_chans'])
+    if net_type == constants.MEMNET:                # select_network.py:184-190
+        from dlib.models.network_memnet import MemNet as net
+        return net(in_chans=opt_net[f'{nt}_in_chans'], upscale=opt_net[f'{nt}_upscale'],
+                   num_memory_blocks=opt_net[f'{nt}_num_memory_blocks'],
+                   num_residual_blocks=opt_net[f'{nt}_num_residual_blocks'])
     raise NotImplementedError(
         f"net_type {net_type!r}: only {constants.MODELS} run on libsrhip (SURVEY.md section 8f lists "
-        f"the remaining 10 reference networks as 'next')")
+        f"the remaining 9 reference networks as 'next')")

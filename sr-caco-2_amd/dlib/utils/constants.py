@@ -9,7 +9,8 @@ VDSR = 'VDSR'  # https://arxiv.org/pdf/1511.04587.pdf (reference constants.py:27
 DRRN = 'DRRN'  # https://ieeexplore.ieee.org/document/8099781 (reference constants.py:29)
 SRCNN = 'SRCNN'  # https://arxiv.org/abs/1501.00092 (reference constants.py)
 MSLAPSR = 'MSLapSRN'  # https://arxiv.org/pdf/1710.01992.pdf (reference constants.py:47)
-MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR]
+MEMNET = 'MemNet'  # https://arxiv.org/pdf/1708.02209.pdf (reference constants.py:28)
+MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR, MEMNET]
 
 SWINIR_MTH = 'SWINIR'
 EDSR_LIIF_MTH = 'EDSR_LIIF'
@@ -17,8 +18,9 @@ VDSR_MTH = 'VDSR'
 DRRN_MTH = 'DRRN'
 SRCNN_MTH = 'SRCNN'
 MSLAPSR_MTH = 'MSLAPSR'
+MEMNET_MTH = 'MemNet'
 NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH, DRRN: DRRN_MTH, SRCNN: SRCNN_MTH,
-                  MSLAPSR: MSLAPSR_MTH}
+                  MSLAPSR: MSLAPSR_MTH, MEMNET: MEMNET_MTH}
 
 US_PIXEL_SHUFFLE = 'pixelshuffle'
 US_PIXEL_SHUFFLE_DIRECT = 'pixelshuffledirect'

@@ -28,6 +28,9 @@ def init_net_g(netG: dict, args: dict) -> dict:
         out.update({f'{nt}_in_chans': args['n_channels']})
     elif netG['net_type'] == constants.MSLAPSR:      # utils_init_default_args.py:118-125
         out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels']})
+    elif netG['net_type'] == constants.MEMNET:       # utils_init_default_args.py:220-229
+        out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'],
+                    f'{nt}_num_memory_blocks': 6, f'{nt}_num_residual_blocks': 6})
     else:
         raise NotImplementedError(netG['net_type'])
     out[f'{nt}_init_type'] = constants.INIT_W_DEFAULT

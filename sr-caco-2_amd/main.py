@@ -121,6 +121,7 @@ def parse_input(argv=None):
                 constants.VDSR: {},
                 constants.SRCNN: {},
                 constants.MSLAPSR: {},
+                constants.MEMNET: {'num_memory_blocks': int, 'num_residual_blocks': int},
                 constants.DRRN: {'num_residual_units': int},
                 constants.EDSR_LIIF: {'n_feats': int, 'n_resblocks': int, 'res_scale': float,
                                       'img_range': float}}[net_type]

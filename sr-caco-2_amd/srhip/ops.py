@@ -1022,3 +1022,49 @@ def sum_into(x, out):
     _chk(x, out)
     ws = SCRATCH.get("loss_ws", 2048, torch.float64, x.device)
     call("srhip_sum", _p(x), x.numel(), _p(out), _p(ws), _st())
+
+
+# ------------------------------------------------------------------ BatchNorm2d (channels-last)
+def _bn_ws(T, C, device):
+    nb = ctypes.c_long(0)
+    call("srhip_bn_workspace_bytes", T, C, ctypes.addressof(nb))
+    return SCRATCH.get("bn_ws", (nb.value + 7) // 8, torch.float64, device), nb.value
+
+
+def bn_stats(x, gamma, beta, coef, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """Training statistics of x [..., C] (dense, channels last) -> coef [4, C] = mean, rstd, gamma * rstd, beta;
+    running statistics updated in place when given (nn.BatchNorm2d semantics)."""
+    _chk(x, gamma, beta, coef, running_mean, running_var)
+    C = gamma.numel()
+    T = x.numel() // C
+    assert x.is_contiguous() and coef.shape == (4, C) and coef.is_contiguous()
+    ws, nb = _bn_ws(T, C, x.device)
+    call("srhip_bn_stats", _p(x), T, C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(momentum),
+         float(eps), _p(coef), _p(ws), nb, _st())
+    return coef
+
+
+def bn_apply(x, coef, out=None, relu=True):
+    """out = relu?((x - mean) * k + beta) with coef [4, C] (bn_stats, or the running statistics in eval mode)."""
+    _chk(x, coef, out)
+    C = coef.shape[1]
+    if out is None:
+        out = torch.empty_like(x)
+    assert x.is_contiguous() and out.is_contiguous() and out.shape == x.shape
+    call("srhip_bn_apply", _p(x), _p(coef), _p(out), x.numel() // C, C, int(bool(relu)), _st())
+    return out
+
+
+def bn_bwd(dy, x, coef, a=None, dx=None, res=None, dgamma=None, dbeta=None, accumulate=False):
+    """Backward of relu?(BN(x)) in training mode: dz = dy * (a > 0) if the ReLU output ``a`` is given; dgamma / dbeta are
+    written, or added to with ``accumulate``; dx (if given) = the input gradient (+ res)."""
+    _chk(dy, x, coef, a, dx, res, dgamma, dbeta)
+    C = coef.shape[1]
+    T = x.numel() // C
+    assert x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape
+    for t in (a, dx, res):
+        assert t is None or (t.is_contiguous() and t.shape == x.shape)
+    ws, nb = _bn_ws(T, C, x.device)
+    call("srhip_bn_bwd", _p(dy), _p(a), _p(x), _p(coef), T, C, _p(dx), _p(res), _p(dgamma), _p(dbeta), int(bool(accumulate)),
+         _p(ws), nb, _st())
+    return dx

@@ -3,7 +3,9 @@
 x {2,4,8} evaluation sweep, eval_all.sh): patches/s of ``model.test()`` on synthetic 512x512 HR patches,
 fp32-accurate and with ``--amp True`` (reduced-precision kernels, where the network takes them), one GPU.
 
-    python tools/eval_sweep.py [--batch 8] [--iters 20] [--out profiles/r02_eval_sweep.json]
+    python tools/eval_sweep.py [--batch 8] [--iters 20] [--nets MemNet,VDSR] [--out profiles/r02_eval_sweep.json]
+
+(--nets: only these; with --out naming an existing file their rows replace the old ones, the others stay.)
 
 Every network is built through the same ``main.parse_input`` / ``define_model`` path as ``main.py`` /
 ``eval.py``; the interpolated input the VDSR / DRRN / SRCNN family expects is produced before the timed
@@ -19,7 +21,7 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 NETS = [("swinir", "SWINIR"), ("EDSR_LIIF", "EDSR_LIIF"), ("VDSR", "VDSR"), ("DRRN", "DRRN"), ("SRCNN", "SRCNN"),
-        ("MSLapSRN", "MSLAPSR")]
+        ("MSLapSRN", "MSLAPSR"), ("MemNet", "MemNet")]
 
 
 def main():
@@ -27,11 +29,15 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--nets", default=None)
     a = ap.parse_args()
+    only = set(a.nets.split(",")) if a.nets else None
     import main as M
     from dlib.models.select_model import define_model
     rows = []
     for net_type, method in NETS:
+        if only is not None and net_type not in only:
+            continue
         for scale in (2, 4, 8):
             for amp in (False, True):
                 argv = ["--net_type", net_type, "--method", method, "--task", "super-resolution", "--scale", str(scale),
@@ -55,13 +61,16 @@ def main():
                 ms = t0.elapsed_time(t1) / a.iters
                 out = model.E
                 assert tuple(out.shape[-2:]) == (512, 512) and torch.isfinite(out).all()
-                amp_used = bool(amp and getattr(model.netG, "amp", False) and net_type not in ("VDSR", "DRRN", "MSLapSRN"))
+                amp_used = bool(amp and getattr(model.netG, "amp", False) and net_type not in ("VDSR", "DRRN", "MSLapSRN", "MemNet"))
                 rows.append({"net_type": net_type, "scale": scale, "amp_flag": amp, "reduced_precision_kernels": amp_used,
                              "batch": a.batch, "ms_per_batch": ms, "patches_per_s": a.batch / ms * 1e3})
                 print(json.dumps(rows[-1]), flush=True)
                 del model
                 torch.cuda.empty_cache()
     if a.out:
+        if only is not None and os.path.isfile(a.out):
+            old = json.load(open(a.out))["rows"]
+            rows = [r for r in old if r["net_type"] not in only] + rows
         with open(a.out, "w") as f:
             json.dump({"what": "model.test() on synthetic 512x512 HR patches, one MI355X; registry default options per network "
                                "(SwinIR: 6 x 6 blocks, embed 180); amp_flag = --amp True, reduced_precision_kernels = whether the "
