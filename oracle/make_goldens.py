@@ -472,6 +472,48 @@ def g_swinir_nearest_conv():
     npz("g25_swinir_nearest_conv", **arrs)
 
 
+def g_swinir_3conv():
+    """resi_connection '3conv' (network_swinir.py:545-552, 851-858): conv C -> C/4, LeakyReLU(0.2), conv1x1, LeakyReLU(0.2),
+    conv C/4 -> C in front of every residual connection, on the tiny trunk (embed 60 -> 15 channels): reference forward
+    (eval), dL/dx and every parameter gradient."""
+    print("G27 SwinIR tiny, resi_connection '3conv'")
+    cfg = O.swinir_config(upscale=4, in_chans=1, img_size=16, window_size=8, depths=(2, 2), embed_dim=60,
+                          num_heads=(6, 6), mlp_ratio=2, upsampler="pixelshuffledirect", resi_connection="3conv",
+                          drop_path_rate=0.0)
+    sd = perturb(O.swinir_init_state_dict(cfg, seed=66), 67)
+    net = build_ref_swinir(cfg)
+    net.load_state_dict(sd, strict=True)
+    assert list(net.state_dict().keys()) == list(sd.keys()), "key order"
+    net.eval()
+    torch.manual_seed(68)
+    x = torch.rand(2, 1, 16, 24)
+    with torch.no_grad():
+        y_eval = net(x)
+        close(O.swinir_forward(sd, x, cfg), y_eval, 2e-6, "3conv eval forward")
+    net.train()
+    for l in net.layers:
+        for b in l.residual_group.blocks:
+            b.drop_path = nn.Identity()
+    xg = x.clone().requires_grad_(True)
+    y = net(xg)
+    torch.manual_seed(69)
+    tgt = torch.rand_like(y)
+    (y - tgt).abs().mean().backward()
+    grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask") else v)
+           for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    (O.swinir_forward(sdo, xo, cfg) - tgt).abs().mean().backward()
+    close(xo.grad, xg.grad, 1e-7, "3conv dL/dx")
+    for k in grads:
+        e = (sdo[k].grad - grads[k]).abs().max().item() / (grads[k].abs().max().item() + 1e-30)
+        assert e < (1e-4 if k.endswith(".bias") else 5e-6), (k, e)
+    arrs = dict(x=x, y_eval=y_eval, target=tgt, dx=xg.grad)
+    arrs.update(sd_np(sd, "sd/"))
+    arrs.update(sd_np(grads, "grad/"))
+    npz("g27_swinir_3conv", **arrs)
+
+
 # ---------------------------------------------------------------- G21 training-crop sampler
 def g_patch_sampler():
     """PatchSampler (dataset_dpsr.py:293-507): the probabilities the reference hands to
@@ -1357,7 +1399,7 @@ def g_optim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
-            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet]
+            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:
         if not only or g.__name__ in only:

@@ -162,6 +162,16 @@ def _swin_block(sd: SD, pre: str, x: Tensor, hw: Tuple[int, int], ws: int,
     return x
 
 
+def _resi_conv(sd: SD, name: str, img: Tensor, cfg: dict) -> Tensor:
+    """The conv in front of a residual connection (network_swinir.py:543-552, 849-858): '1conv' = one 3x3 conv;
+    '3conv' = conv3x3 C -> C/4, LeakyReLU(0.2), conv1x1, LeakyReLU(0.2), conv3x3 C/4 -> C."""
+    if cfg.get("resi_connection", "1conv") == "1conv":
+        return F.conv2d(img, sd[name + ".weight"], sd[name + ".bias"], padding=1)
+    v = F.leaky_relu(F.conv2d(img, sd[name + ".0.weight"], sd[name + ".0.bias"], padding=1), 0.2)
+    v = F.leaky_relu(F.conv2d(v, sd[name + ".2.weight"], sd[name + ".2.bias"]), 0.2)
+    return F.conv2d(v, sd[name + ".4.weight"], sd[name + ".4.bias"], padding=1)
+
+
 def swinir_forward(sd: SD, x: Tensor, cfg: dict,
                    dp_scales: Optional[Sequence[Tensor]] = None,
                    taps: Optional[dict] = None) -> Tensor:
@@ -204,13 +214,11 @@ def swinir_forward(sd: SD, x: Tensor, cfg: dict,
                             taps if bi == 0 else None)
             bi += 1
         img = t.transpose(1, 2).reshape(-1, c, h, w)  # PatchUnEmbed :651-655
-        img = F.conv2d(img, sd[f"layers.{li}.conv.weight"],
-                       sd[f"layers.{li}.conv.bias"], padding=1)
+        img = _resi_conv(sd, f"layers.{li}.conv", img, cfg)
         t = img.flatten(2).transpose(1, 2) + t_in  # RSTB :562-565
     t = F.layer_norm(t, (c,), sd["norm.weight"], sd["norm.bias"])
     img = t.transpose(1, 2).reshape(-1, c, h, w)
-    f = F.conv2d(img, sd["conv_after_body.weight"], sd["conv_after_body.bias"],
-                 padding=1) + f0
+    f = _resi_conv(sd, "conv_after_body", img, cfg) + f0
     if cfg["upsampler"] == "pixelshuffledirect":  # :943-947
         y = F.conv2d(f, sd["upsample.0.weight"], sd["upsample.0.bias"],
                      padding=1)
@@ -250,10 +258,18 @@ def swinir_init_state_dict(cfg: dict, seed: int = 0) -> SD:
     hid = int(c * cfg["mlp_ratio"])
     sd: SD = {}
 
-    def conv(name, co, ci):
-        bound = 1.0 / math.sqrt(ci * 9)
-        sd[name + ".weight"] = (torch.rand(co, ci, 3, 3, generator=g) * 2 - 1) * bound
+    def conv(name, co, ci, k=3):
+        bound = 1.0 / math.sqrt(ci * k * k)
+        sd[name + ".weight"] = (torch.rand(co, ci, k, k, generator=g) * 2 - 1) * bound
         sd[name + ".bias"] = (torch.rand(co, generator=g) * 2 - 1) * bound
+
+    def resi(name):              # network_swinir.py:543-552
+        if cfg.get("resi_connection", "1conv") == "1conv":
+            conv(name, c, c)
+        else:
+            conv(name + ".0", c // 4, c)
+            conv(name + ".2", c // 4, c // 4, 1)
+            conv(name + ".4", c, c // 4)
 
     def lin(name, co, ci):
         sd[name + ".weight"] = torch.nn.init.trunc_normal_(
@@ -285,9 +301,9 @@ def swinir_init_state_dict(cfg: dict, seed: int = 0) -> SD:
             ln(p + "norm2")
             lin(p + "mlp.fc1", hid, c)
             lin(p + "mlp.fc2", c, hid)
-        conv(f"layers.{li}.conv", c, c)
+        resi(f"layers.{li}.conv")
     ln("norm")
-    conv("conv_after_body", c, c)
+    resi("conv_after_body")
     s = cfg["upscale"]
     if cfg["upsampler"] == "pixelshuffledirect":
         conv("upsample.0", s * s * cfg["in_chans"], c)
