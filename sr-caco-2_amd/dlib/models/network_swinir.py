@@ -12,7 +12,7 @@ Supported on the HIP path: window_size 8, 1-channel input, upsamplers
 README.md:120-197), 'nearest_conv' (x4: network_swinir.py:874-885,948-961) and 'pixelshuffle' (the registry default,
 utils_init_default_args.py:23; conv 180->64 + LeakyReLU, log2(s) x [conv 64->256 +
 PixelShuffle(2)], conv 64->1: network_swinir.py:862-868,937-942), resi_connection
-'1conv'.
+'1conv' and '3conv' (network_swinir.py:543-552,849-858).
 """
 import math
 
@@ -56,6 +56,24 @@ def _conv3(co, ci):
     m.weight = nn.Parameter((torch.rand(co, ci, 3, 3) * 2 - 1) * bound)
     m.bias = nn.Parameter((torch.rand(co) * 2 - 1) * bound)
     return m
+
+
+def _conv1(co, ci):
+    m = _Box()
+    bound = 1.0 / math.sqrt(ci)       # nn.Conv2d(ci, co, 1) default
+    m.weight = nn.Parameter((torch.rand(co, ci, 1, 1) * 2 - 1) * bound)
+    m.bias = nn.Parameter((torch.rand(co) * 2 - 1) * bound)
+    return m
+
+
+def _resi_conv(dim, kind):
+    """The conv in front of a residual connection (network_swinir.py:543-552, 849-858): '1conv' = Conv2d(dim, dim, 3);
+    '3conv' = Sequential(Conv2d(dim, dim/4, 3), LeakyReLU(0.2), Conv2d(dim/4, dim/4, 1), LeakyReLU(0.2),
+    Conv2d(dim/4, dim, 3)) -- parameter holders at the Sequential's indices 0, 2, 4."""
+    if kind == constants.R_CONNECTION_1CONV:
+        return _conv3(dim, dim)
+    return nn.ModuleList([_conv3(dim // 4, dim), nn.Identity(), _conv1(dim // 4, dim // 4), nn.Identity(),
+                          _conv3(dim, dim // 4)])
 
 
 def _relative_position_index(ws):
@@ -147,8 +165,8 @@ class SwinIR(nn.Module):
             assert upscale == 4, 'only support x4 now.'              # network_swinir.py:876
         if upsampler == constants.US_PIXEL_SHUFFLE and (upscale & (upscale - 1) or upscale < 2):
             unsupported.append(f"upscale={upscale} with 'pixelshuffle' (HIP path: powers of two)")
-        if resi_connection != constants.R_CONNECTION_1CONV:
-            unsupported.append(f"resi_connection={resi_connection!r} (HIP path: '1conv')")
+        if resi_connection not in (constants.R_CONNECTION_1CONV, constants.R_CONNECTION_3CONV):
+            unsupported.append(f"resi_connection={resi_connection!r} (HIP path: '1conv', '3conv')")
         if ape or not patch_norm or not qkv_bias or qk_scale is not None or drop_rate or attn_drop_rate:
             unsupported.append("ape / patch_norm=False / qkv_bias=False / qk_scale / dropout")
         if embed_dim > 256 or (embed_dim // num_heads[0]) not in (10, 16, 30, 32):
@@ -161,6 +179,7 @@ class SwinIR(nn.Module):
         self.depths, self.num_heads = list(depths), list(num_heads)
         self.window_size, self.upscale, self.img_range = window_size, upscale, img_range
         self.upsampler = upsampler
+        self.resi_connection = resi_connection
         self.mean = torch.zeros(1, 1, 1, 1)
 
         self.conv_first = _conv3(embed_dim, in_chans)
@@ -175,10 +194,10 @@ class SwinIR(nn.Module):
                 _SwinBlock(embed_dim, self.img_size, num_heads[li], window_size,
                            0 if j % 2 == 0 else window_size // 2, mlp_ratio,
                            dpr[sum(depths[:li]) + j]) for j in range(depth)])
-            rstb.conv = _conv3(embed_dim, embed_dim)
+            rstb.conv = _resi_conv(embed_dim, resi_connection)
             self.layers.append(rstb)
         self.norm = _norm(embed_dim)
-        self.conv_after_body = _conv3(embed_dim, embed_dim)
+        self.conv_after_body = _resi_conv(embed_dim, resi_connection)
         if upsampler == constants.US_PIXEL_SHUFFLE_DIRECT:
             self.upsample = nn.ModuleList([_conv3(upscale * upscale * in_chans, embed_dim)])
         elif upsampler == constants.US_NEAREST_CONV:   # parameter names / order of network_swinir.py:874-885

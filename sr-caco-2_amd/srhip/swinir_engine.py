@@ -49,6 +49,13 @@ class SwinIREngine:
         self.direct = net.upsampler == "pixelshuffledirect"
         self.nearest = net.upsampler == "nearest_conv"      # 2 x [nearest x2, conv, LeakyReLU], conv_hr, conv_last (x4)
         self.stages = 0 if (self.direct or self.nearest) else int(round(__import__("math").log2(net.upscale)))
+        # resi_connection '3conv' (network_swinir.py:545-552): conv C -> C/4, LeakyReLU(0.2), conv1x1, LeakyReLU(0.2),
+        # conv C/4 -> C.  It runs on the SAME kernels as '1conv' with the C/4 channels zero-padded to a width they take
+        # (45 -> 64 on the bf16x3 kernels, a multiple of 4 on the exact-f32 ones): padded weights / biases are 0,
+        # LeakyReLU(0) = 0, so the padded channels carry exact zeros forward and backward.
+        self.conv3 = getattr(net, "resi_connection", "1conv") == "3conv"
+        self.c4 = self.C // 4
+        self.c4p = (max(64, (self.c4 + 3) // 4 * 4) if ops.bx3_nt_for(self.C) else (self.c4 + 3) // 4 * 4)
         self.layer_of_block = []
         for li, layer in enumerate(net.layers):
             for _ in layer.residual_group.blocks:
@@ -98,6 +105,8 @@ class SwinIREngine:
         launch over a job table built once (rebuilt if a parameter moved)."""
         net, C, hid, D, ws = self.net, self.C, self.hid, self.derived, self.ws
         sig = tuple(p.data_ptr() for p in net.parameters())
+        if self.conv3:
+            self._refresh_conv3(net.conv_first.weight.device)
         if self._prep is None or sig != self._prep_sig:
             dev = net.conv_first.weight.device
             tb = ops.PrepTable()
@@ -128,12 +137,19 @@ class SwinIREngine:
                 co, ci = conv.weight.shape[:2]
                 tb.conv(conv.weight.data, ws.planes(name + ".wp", 9 * co, ci, dev))
                 tb.conv(conv.weight.data, ws.planes(name + ".wpt", 9 * ci, co, dev), data_grad=True)
+            if self.conv3:
+                P = self.c4p
+                for name, _, _ in self._rconvs():
+                    tb.linear(D.d[name + ".w1p"], ws.planes(name + ".1.w", P, P, dev))
+                    tb.linear(D.d[name + ".w1p"], ws.planes(name + ".1.wT", P, P, dev), transpose=True)
             self._prep, self._prep_sig = tb.build(dev), sig
         self._prep.run()
 
     def _prepare_f32(self):
         net, C, hid, D = self.net, self.C, self.hid, self.derived
         dev = net.conv_first.weight.device
+        if self.conv3:
+            self._refresh_conv3(dev)
         for i, b in enumerate(self.blocks):
             heads = b.num_heads
             wq = D.get(f"{i}.wq", 3 * C, C, device=dev)
@@ -164,12 +180,48 @@ class SwinIREngine:
         for name, _ in self._convs():
             ws.register(name + ".wp", D.d[name + ".wp"])
             ws.register(name + ".wpt", D.d[name + ".wpt"])
+        if self.conv3:
+            P = self.c4p
+            for name, _, _ in self._rconvs():
+                ops.transpose(D.d[name + ".w1p"], D.get(name + ".1.wT", P, P, device=dev))
+                ws.register(name + ".1.w", D.d[name + ".w1p"])
+                ws.register(name + ".1.wT", D.d[name + ".1.wT"])
+
+    def _rconvs(self):
+        """(name, module, parameter prefix) of the convs in front of the residual connections."""
+        for li, layer in enumerate(self.net.layers):
+            yield f"l{li}", layer.conv, f"layers.{li}.conv."
+        yield "cab", self.net.conv_after_body, "conv_after_body."
+
+    def _refresh_conv3(self, dev):
+        """'3conv': zero-padded copies of the three convs' parameters (read by the weight-preparation table)."""
+        D, c4, P, C = self.derived, self.c4, self.c4p, self.C
+        for name, mod, _ in self._rconvs():
+            fresh = name + ".w0p" not in D.d
+            w0, b0 = D.get(name + ".w0p", P, C, 3, 3, device=dev), D.get(name + ".b0p", P, device=dev)
+            w1, b1 = D.get(name + ".w1p", P, P, device=dev), D.get(name + ".b1p", P, device=dev)
+            w4 = D.get(name + ".w4p", C, P, 3, 3, device=dev)
+            if fresh:
+                for t in (w0, b0, w1, b1, w4):
+                    t.zero_()
+            w0[:c4].copy_(mod[0].weight.data)
+            b0[:c4].copy_(mod[0].bias.data)
+            w1[:c4, :c4].copy_(mod[2].weight.data.view(c4, c4))
+            b1[:c4].copy_(mod[2].bias.data)
+            w4[:, :c4].copy_(mod[4].weight.data)
 
     def _convs(self):
         net = self.net
-        for li, layer in enumerate(net.layers):
-            yield f"l{li}", layer.conv
-        yield "cab", net.conv_after_body
+        if self.conv3:
+            class _W:       # a 3x3 conv whose (padded) weight lives in the derived set
+                def __init__(self, w):
+                    self.weight = w
+            for name, _, _ in self._rconvs():
+                yield name + ".0", _W(self.derived.d[name + ".w0p"])
+                yield name + ".4", _W(self.derived.d[name + ".w4p"])
+        else:
+            for name, mod, _ in self._rconvs():
+                yield name, mod
         if self.direct:
             yield "up", net.upsample[0]
         elif self.nearest:
@@ -197,6 +249,19 @@ class SwinIREngine:
 
         def buf(name, *shape):
             return bufs.get(f"{tag}.{name}", *shape, device=dev)
+
+        def resi_conv(name, mod, key, src, dst, skip):
+            """dst = conv(src) + skip, the conv being '1conv' or '3conv'; returns what the backward needs."""
+            if not self.conv3:
+                ops.conv3x3(src, ws[name + ".wp"], mod.bias.data, C, out=dst, epi=2, R=skip)
+                return None
+            P = self.c4p
+            c0, c1 = buf(key + ".c0", B, H, W, P), buf(key + ".c1", B, H, W, P)
+            ops.conv3x3(src, ws[name + ".0.wp"], D.d[name + ".b0p"], P, out=c0, epi=6, alpha=0.2)
+            ops.gemm_nt(c0.view(T, P), ws[name + ".1.w"], D.d[name + ".b1p"], out=c1.view(T, P))
+            ops.leaky_relu_(c1, 0.2)
+            ops.conv3x3(c1, ws[name + ".4.wp"], mod[4].bias.data, C, out=dst, epi=2, R=skip)
+            return c0, c1
 
         f0 = buf("f0", B, H, W, C)
         ops.conv3x3_cin1_fwd(x, net.conv_first.weight.data, net.conv_first.bias.data, C, out=f0)
@@ -251,17 +316,16 @@ class SwinIREngine:
                 st1 = st_next
                 bi += 1
             tl = buf(f"L{li if save else li % 2}.out", T, C)
-            ops.conv3x3(t.view(B, H, W, C), ws[f"l{li}.wp"], layer.conv.bias.data, C,
-                        out=tl.view(B, H, W, C), epi=2, R=t_in.view(B, H, W, C))
+            rc = resi_conv(f"l{li}", layer.conv, f"L{li if save else 0}", t.view(B, H, W, C), tl.view(B, H, W, C),
+                           t_in.view(B, H, W, C))
             if save:
-                sv["layers"].append((t_in, t))
+                sv["layers"].append((t_in, t, rc))
             t = tl
         st_n = buf("st_n", T, 2)
         tn = buf("tn", T, C)
         ops.layernorm_fwd(t, st_n, tn, net.norm.weight.data, net.norm.bias.data)
         f = buf("f", B, H, W, C)
-        ops.conv3x3(tn.view(B, H, W, C), ws["cab.wp"], net.conv_after_body.bias.data, C, out=f, epi=2,
-                    R=f0)
+        sv["cab_rc"] = resi_conv("cab", net.conv_after_body, "cab", tn.view(B, H, W, C), f, f0)
         r = self.scale
         y = torch.empty(B, net.in_chans, H * r, W * r, device=dev) if not save else \
             buf("y", B, net.in_chans, H * r, W * r)
@@ -378,10 +442,34 @@ class SwinIREngine:
                     ops.conv3x3(dc, ws[f"up{i}.wpt"], None, nf, out=g)
             ops.conv3x3_wgrad(g, sv["f"], G("conv_before_upsample.0.weight"), G("conv_before_upsample.0.bias"))
             ops.conv3x3(g, ws["cbu.wpt"], None, C, out=df)
-        ops.conv3x3_wgrad(df, sv["tn"].view(B, H, W, C), G("conv_after_body.weight"),
-                          G("conv_after_body.bias"))
+        def resi_conv_bwd(name, pre, d, src, rc, dsrc):
+            """d = gradient of the conv's output; src its input; writes dsrc and the parameter gradients."""
+            if not self.conv3:
+                ops.conv3x3_wgrad(d, src, G(pre + "weight"), G(pre + "bias"))
+                ops.conv3x3(d, ws[name + ".wpt"], None, C, out=dsrc)
+                return
+            P, c4 = self.c4p, self.c4
+            c0, c1 = rc
+            dw4 = buf("rc.dw4", C, P, 3, 3)
+            ops.conv3x3_wgrad(d, c1, dw4, G(pre + "4.bias"))
+            G(pre + "4.weight").copy_(dw4[:, :c4])
+            dc1 = buf("rc.dc1", B, H, W, P)
+            ops.conv3x3(d, ws[name + ".4.wpt"], None, P, out=dc1, epi=7, R=c1, alpha=0.2)
+            dw1, db1 = buf("rc.dw1", P, P), buf("rc.db1", P)
+            ops.linear_wgrad(dc1.view(T, P), c0.view(T, P), dw1, db1)
+            G(pre + "2.weight").view(c4, c4).copy_(dw1[:c4, :c4])
+            G(pre + "2.bias").copy_(db1[:c4])
+            dc0 = buf("rc.dc0", B, H, W, P)
+            ops.gemm_nt(dc1.view(T, P), ws[name + ".1.wT"], out=dc0.view(T, P))
+            ops.leaky_relu_mask(dc0, c0, 0.2)
+            dw0, db0 = buf("rc.dw0", P, C, 3, 3), buf("rc.db0", P)
+            ops.conv3x3_wgrad(dc0, src, dw0, db0)
+            G(pre + "0.weight").copy_(dw0[:c4])
+            G(pre + "0.bias").copy_(db0[:c4])
+            ops.conv3x3(dc0, ws[name + ".0.wpt"], None, C, out=dsrc)
+
         dtn = buf("dtn", T, C)
-        ops.conv3x3(df, ws["cab.wpt"], None, C, out=dtn.view(B, H, W, C))
+        resi_conv_bwd("cab", "conv_after_body.", df, sv["tn"].view(B, H, W, C), sv["cab_rc"], dtn.view(B, H, W, C))
         dt = buf("dt", T, C)
         ops.layernorm_bwd(dtn, sv["t_last"], sv["st_n"], dt, gamma=net.norm.weight.data,
                           dgamma=G("norm.weight"), dbeta=G("norm.bias"))
@@ -405,13 +493,12 @@ class SwinIREngine:
         dbT_all = buf("dbiasT_all", len(self.blocks), max(b.num_heads for b in self.blocks), 64, 64)
         for li in reversed(range(len(net.layers))):
             layer = net.layers[li]
-            t_in, t_blocks = sv["layers"][li]
+            t_in, t_blocks, rc = sv["layers"][li]
             pre = f"layers.{li}."
-            ops.conv3x3_wgrad(dt.view(B, H, W, C), t_blocks.view(B, H, W, C), G(pre + "conv.weight"),
-                              G(pre + "conv.bias"))
             gi = 0
             g = gbufs[gi]
-            ops.conv3x3(dt.view(B, H, W, C), ws[f"l{li}.wpt"], None, C, out=g.view(B, H, W, C))
+            resi_conv_bwd(f"l{li}", pre + "conv.", dt.view(B, H, W, C), t_blocks.view(B, H, W, C), rc,
+                          g.view(B, H, W, C))
             nb = len(layer.residual_group.blocks)
             pending = []                 # weight-gradient problems of the layer's blocks (deferred form)
             for j in reversed(range(nb)):

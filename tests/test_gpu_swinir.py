@@ -264,6 +264,64 @@ def test_nearest_conv_upsampler_vs_reference_golden_and_oracle(SwinIR):
     assert worst_tab[1] <= 2e-3, worst_tab
 
 
+def test_3conv_residual_connection_vs_reference_golden_and_oracle(SwinIR):
+    """resi_connection '3conv' (network_swinir.py:545-552, 851-858): conv C -> C/4 + LeakyReLU(0.2), conv1x1 + LeakyReLU(0.2),
+    conv C/4 -> C in front of every residual connection, run on the '1conv' kernels with the C/4 channels zero-padded
+    (15 -> 16 on the exact-f32 kernels of the tiny net, 45 -> 64 on the bf16x3 kernels of the README trunk).  Tiny net
+    against the reference golden g27 (forward, dL/dx, all gradients; state_dict keys / order), README trunk against
+    the oracle."""
+    g = load("g27_swinir_3conv")
+    net = SwinIR(upscale=4, in_chans=1, img_size=16, window_size=8, depths=[2, 2], embed_dim=60,
+                 num_heads=[6, 6], mlp_ratio=2, upsampler="pixelshuffledirect", resi_connection="3conv", drop_path_rate=0.0)
+    assert list(net.state_dict().keys()) == list(sub(g, "sd/").keys())
+    net.load_state_dict(sub(g, "sd/"), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(g["x"].cuda()).cpu()
+    assert y.shape == g["y_eval"].shape and (y - g["y_eval"]).abs().max() <= 1e-5
+    net.train()
+    x = g["x"].cuda().requires_grad_(True)
+    (net(x) - g["target"].cuda()).abs().mean().backward()
+    # tensor-wise relative L2 on the tiny fixture (measured: 2.7e-6 worst; a LeakyReLU decision that flips under f32
+    # rounding would show as ~1e-4, see the nearest_conv test)
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert l2(x.grad.cpu(), g["dx"]) <= 2e-4
+    worst = ("", 0.0)
+    for k, p in net.named_parameters():
+        e = l2(p.grad.cpu(), g["grad/" + k])
+        assert e <= 2e-4, f"grad {k}: relative L2 error {e:.2e}"
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    print("3conv tiny: worst grad", worst)
+    cfg = O.swinir_config(upscale=8, resi_connection="3conv", drop_path_rate=0.0)
+    sd = O.swinir_init_state_dict(cfg, seed=9)
+    big = SwinIR(upscale=8, in_chans=1, img_size=64, window_size=8, depths=[6, 6, 6, 6], embed_dim=180,
+                 num_heads=[6, 6, 6, 6], mlp_ratio=2, upsampler="pixelshuffledirect", resi_connection="3conv",
+                 drop_path_rate=0.0)
+    assert big.engine.c4 == 45 and big.engine.c4p == 64
+    big.load_state_dict(sd, strict=True)
+    big = big.cuda().train()
+    gen = torch.Generator().manual_seed(10)
+    xb, tb = torch.rand(1, 1, 64, 64, generator=gen), torch.rand(1, 1, 512, 512, generator=gen)
+    yb = big(xb.cuda())
+    (yb - tb.cuda()).abs().mean().backward()
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask")
+               else v) for k, v in sd.items()}
+    yo = O.swinir_forward(sdo, xb, cfg)
+    (yo - tb).abs().mean().backward()
+    assert (yb.detach().cpu() - yo.detach()).abs().mean() <= 1e-5
+    worst, worst_tab = ("", 0.0), ("", 0.0)
+    for k, p in big.named_parameters():
+        ref = sdo[k].grad
+        e = (p.grad.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        if k.endswith("relative_position_bias_table"):
+            worst_tab = max(worst_tab, (k, e), key=lambda t: t[1])
+        else:
+            worst = max(worst, (k, e), key=lambda t: t[1])
+    print("3conv README trunk x8: worst grad", worst, "worst bias table", worst_tab)
+    assert worst[1] <= 2e-5, worst               # measured 1.9e-6
+    assert worst_tab[1] <= 2e-4, worst_tab       # measured 6.8e-7 (float32 summation order of 4096 signed entries)
+
+
 def test_step_graph_replays_the_eager_step_bit_for_bit(SwinIR):
     """TrainStep.step_graph (one hipGraph replay per step) against TrainStep.step (~70 launches for this net):
     20 steps from the same weights on a changing batch, SGD-Nesterov with a MyStepLR schedule that halves the rate
