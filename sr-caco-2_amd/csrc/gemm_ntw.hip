@@ -14,7 +14,7 @@
 //   * only A goes through LDS (f32 -> three bf16 planes, as before): 12 KB per 32-wide stage instead of
 //     48 KB, and a wave reads 12 fragments per 72 MFMAs instead of 24: LDS traffic per k drops to ~40 %;
 //   * one barrier per 32 k (72 MFMAs per wave) instead of two.
-// Two W register sets (stage parity): the fragments of stage c+2 are requested as soon as the MFMAs of
+// Three W register sets (stage mod 3): the fragments of stage c+3 are requested as soon as the MFMAs of
 // stage c have been issued.
 // The accumulators (16x16 tiles, column-split waves) are re-laid through LDS once per block into the
 // 32x32 / 2x2-wave layout of nt_epi.h, so every epilogue (bias, residual + DropPath, gelu', LayerNorm
@@ -44,6 +44,9 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
 // a ds_write_b128 phase (4 rows x 4 octets) each hit 16 different bank groups
 __device__ __forceinline__ int a_slot(int row, int u) { return row * 4 + (u ^ ((row >> 2) & 3)); }
 
+// DBG = true (SRHIP_NTW_DBG=bits, timing experiments only, results are wrong): 1 = W fragments always from stage 0
+// (cache-hot), 2 = no MFMAs, 4 = no epilogue, 8 = no A staging stores
+template <bool DBG>
 __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -54,6 +57,16 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
   const int nvalid = min(p.n_tile, p.N - n0);
   const int nst = (p.K + SK - 1) / SK;
   const int nsub = p.Kp / 16;                     // W planes are zero padded up to Kp (a multiple of 32)
+  // Every block walks the SAME weight planes: in lockstep all 512 blocks of a launch ask the L2 for the same few
+  // cache lines at the same moment.  Block b therefore starts its K walk at stage rot(b) and wraps around (the
+  // blocks of one XCD -- same blockIdx.x mod 8 -- get different rotations): at any moment the launch reads all
+  // stages of W.  Sums are f32 either way; only their order differs per row block (deterministic).
+  const int rot = p.k_rot ? (int)((blockIdx.x >> 3) % (unsigned)nst) : 0;
+  auto stage_of = [&](int cs) {                   // block-uniform; prefetches run up to 5 stages past the end
+    int x = cs + rot;
+    while (x >= nst) x -= nst;
+    return x;
+  };
 
   // ---- A staging: thread = 8 consecutive k of one row (two float4); rows outside the problem are clamped
   const int arow = tid >> 2, akq = tid & 3;
@@ -61,14 +74,14 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
   const char* const abase = (const char*)p.A + (long)agm * p.lda * 4;
   const float2 rst = ldg_f2(p.a_mode == 1 ? p.ln_stats + 2 * agm : k_sr_neutral);
   const int a_dst = a_slot(arow, akq) * 16;
-  auto load_a = [&](int cs, f32x4 (&v)[2]) {      // stages past the end read k = 0 of the row, never consumed
-    const int k = cs * SK + akq * 8;
+  auto load_a = [&](int cs, f32x4 (&v)[2]) {      // stages past the end wrap around, never consumed
+    const int k = stage_of(cs) * SK + akq * 8;
     v[0] = *(const f32x4*)(abase + (k < p.K ? k * 4 : 0));
     v[1] = *(const f32x4*)(abase + (k + 4 < p.K ? (k + 4) * 4 : 0));
   };
   auto store_a = [&](int cs, f32x4 (&v)[2]) {
     unsigned char* sa = smem + (cs & 1) * A_STAGE + a_dst;
-    const int k = cs * SK + akq * 8;
+    const int k = stage_of(cs) * SK + akq * 8;
     unsigned hh[4], mm[4], ll[4];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -82,24 +95,30 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
       split3_pair(x.x, x.y, hh[2 * e], mm[2 * e], ll[2 * e]);
       split3_pair(x.z, x.w, hh[2 * e + 1], mm[2 * e + 1], ll[2 * e + 1]);
     }
+    if (DBG && (p.dbg & 8)) {
+      if (hh[0] + mm[1] + ll[2] + hh[3] + mm[0] + ll[1] + hh[2] + mm[3] + ll[0] + hh[1] + mm[2] + ll[3] == 0x12345u) *(unsigned*)sa = 1u;
+      return;
+    }
     *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
     *(u32x4*)(sa + A_PLANE) = u32x4{mm[0], mm[1], mm[2], mm[3]};
     *(u32x4*)(sa + 2 * A_PLANE) = u32x4{ll[0], ll[1], ll[2], ll[3]};
   };
 
   // ---- W fragments: lane (c, g) of column tile jt reads 16 bytes (g & 1) of row n in sub-chunk 2*stage + (g >> 1);
-  //      columns past the tile's width re-read its last valid row (their results are never stored)
+  //      columns past the tile's width re-read its last valid row (their results are never stored).  The address is
+  //      a block-uniform base (stage, plane: scalar registers) + a 32-bit per-lane offset that never changes.
   const long plane_bytes = (long)p.N * p.Kp * 2;
   unsigned boff[3];
 #pragma unroll
   for (int jt = 0; jt < 3; ++jt)
-    boff[jt] = (unsigned)((n0 + min(wave * 48 + jt * 16 + c, nvalid - 1)) * 32 + (g & 1) * 16);
+    boff[jt] = (unsigned)(((g >> 1) * p.N + n0 + min(wave * 48 + jt * 16 + c, nvalid - 1)) * 32 + (g & 1) * 16);
   auto load_b = [&](int cs, u32x4 (&fb)[3][3]) {
-    const char* base = (const char*)p.Wb + (long)min(2 * cs + (g >> 1), nsub - 1) * p.N * 32;
+    const int st = (DBG && (p.dbg & 1)) ? 0 : min(stage_of(cs), nst - 1);        // stages past the end re-read the last one
+    const char* base = (const char*)p.Wb + (long)(2 * st) * p.N * 32;
 #pragma unroll
-    for (int jt = 0; jt < 3; ++jt)
+    for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
+      for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
   };
 
   f32x4 acc[4][3];
@@ -113,6 +132,13 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
 
   auto mma = [&](int cs, const u32x4 (&fb)[3][3]) {
     const unsigned char* sa = smem + (cs & 1) * A_STAGE;
+    if (DBG && (p.dbg & 2)) {            // keep the fragments alive without the matrix core
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) acc[0][j][pl] += __builtin_bit_cast(float, fb[j][pl].x ^ fb[j][pl].w);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       u32x4 fa[3];
@@ -126,29 +152,43 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
     }
   };
 
-  // register sets by stage parity
+  // A: two register sets (stage parity), loaded two stages ahead.  W: THREE fragment sets (stage mod 3), each
+  // re-requested for stage c+3 as soon as the MFMAs of stage c are issued: two stages of MFMAs (~2 us) cover the
+  // fetch -- with two sets (one stage of cover) the K loop ran at fetch latency + MFMA time per stage.
   f32x4 ra0[2], ra1[2];
-  u32x4 fb0[3][3], fb1[3][3];
+  u32x4 fb0[3][3], fb1[3][3], fb2[3][3];
   load_a(0, ra0); load_b(0, fb0);
   load_a(1, ra1); load_b(1, fb1);
+  load_b(2, fb2);
   store_a(0, ra0);
   load_a(2, ra0);
   __syncthreads();
-  for (int cs = 0; cs < nst; cs += 2) {
-    store_a(cs + 1, ra1);
-    load_a(cs + 3, ra1);
-    mma(cs, fb0);
-    load_b(cs + 2, fb0);
-    __syncthreads();
-    if (cs + 1 < nst) {                       // block-uniform
-      store_a(cs + 2, ra0);
-      load_a(cs + 4, ra0);
-      mma(cs + 1, fb1);
-      load_b(cs + 3, fb1);
-      __syncthreads();
-    }
+  // one step: stage cs is in LDS buffer cs & 1; RA = the A registers holding stage cs + 1
+#define SR_STEP(CS, RA, FB)                    \
+  store_a((CS) + 1, RA);                       \
+  load_a((CS) + 3, RA);                        \
+  mma((CS), FB);                               \
+  load_b((CS) + 3, FB);                        \
+  __syncthreads();
+  for (int cs = 0; cs < nst; cs += 6) {        // 6 = lcm(A parity, W sets); every guard is block-uniform
+    SR_STEP(cs, ra1, fb0)
+    if (cs + 1 < nst) { SR_STEP(cs + 1, ra0, fb1) }
+    if (cs + 2 < nst) { SR_STEP(cs + 2, ra1, fb2) }
+    if (cs + 3 < nst) { SR_STEP(cs + 3, ra0, fb0) }
+    if (cs + 4 < nst) { SR_STEP(cs + 4, ra1, fb1) }
+    if (cs + 5 < nst) { SR_STEP(cs + 5, ra0, fb2) }
   }
+#undef SR_STEP
 
+  if (DBG && (p.dbg & 4)) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 123456.789f) p.C[0] = sacc;
+    return;
+  }
   // ---- re-layout: 16x16 tiles of column-split waves -> 32x32 tiles of the 2 x 2 wave grid of nt_epi.h
   float* const T = (float*)smem;
 #pragma unroll
@@ -184,7 +224,15 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
 int sr_gemm_ntw(NtArgs& p, hipStream_t st) {
   static_assert(NTW_LDS >= 2 * A_STAGE && NTW_LDS >= BM * TP * 4, "LDS regions");
   dim3 grid(sr_cdiv(p.M, BM), sr_cdiv(p.N, p.n_tile));
-  hipLaunchKernelGGL(k_ntw, grid, dim3(256), NTW_LDS, st, p);
+  static const int dbg = [] { const char* e = getenv("SRHIP_NTW_DBG"); return e ? atoi(e) : 0; }();
+  static const int rot = [] { const char* e = getenv("SRHIP_NTW_ROT"); return e ? atoi(e) : 1; }();
+  p.k_rot = rot;
+  if (dbg) {
+    p.dbg = dbg;
+    hipLaunchKernelGGL(k_ntw<true>, grid, dim3(256), NTW_LDS, st, p);
+  } else {
+    hipLaunchKernelGGL(k_ntw<false>, grid, dim3(256), NTW_LDS, st, p);
+  }
   SR_LAUNCH_CHECK("k_ntw");
   return 0;
 }

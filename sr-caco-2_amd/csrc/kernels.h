@@ -35,6 +35,7 @@ struct NtArgs {
   // sub-pixel sp = 2*i + j (weight rows in that order: prep perm 3).  2: the A operand is read from the
   // shuffled image [batch][2H][2Wd][K/4] in the same order, k = sp*(K/4) + c (the data gradient of 1)
   int ps;
+  int k_rot;                  // k_ntw: rotate the K walk per block (gemm_ntw.hip)
 };
 
 struct TnArgs {

@@ -3,7 +3,7 @@ on the launching stream around every launch of the probed op classes, inside
 the timed region.  Off by default (zero overhead beyond one attribute check).
 
 Op classes ("kinds") and the kernels behind them:
-  gemm_nt    Linear forward / data gradient            k_ntp<WN> / k_ntb (gemm_ntp.hip, gemm_ntb.hip)
+  gemm_nt    Linear forward / data gradient            k_ntw / k_ntp<WN> (gemm_ntw.hip, gemm_ntp.hip)
   conv_nt    3x3 conv forward / data gradient          k_ntb<..,true> implicit GEMM (gemm_ntb.hip)
   conv_tn    3x3 conv weight gradient                  k_tnb<W> conv form (gemm_tnb.hip)
   linear_tn  Linear weight gradients (grouped launch)  k_tnb_grouped<W> (gemm_tnb.hip)
@@ -57,7 +57,7 @@ class timed:
 
 
 _KERNEL_OF_KIND = {
-    "gemm_nt": ("k_ntp", "NT GEMM (Linear forward / data gradient)"),
+    "gemm_nt": ("k_ntw|k_ntp", "NT GEMM (Linear forward / data gradient)"),
     "conv_nt": ("k_ntb", "implicit-GEMM 3x3 conv (forward / data gradient)"),
     "conv_tn": ("k_tnb", "3x3 conv weight gradient"),
     "linear_tn": ("k_tnb_grouped", "grouped Linear weight gradients"),
@@ -78,7 +78,7 @@ def _pmc_traffic(kernel_stem):
         if path and os.path.isfile(path):
             tot = n = 0.0
             for name, v in json.load(open(path)).items():
-                if kernel_stem in name:
+                if any(st in name for st in kernel_stem.split("|")):
                     tot += v["hbm_bytes_per_launch"] * v["launches"]
                     n += v["launches"]
             if n:

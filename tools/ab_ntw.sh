@@ -1,6 +1,6 @@
-set -x
-timeout 900 python -m pytest tests/test_gpu_bx3.py tests/test_gpu_kernels.py -q -x 2>&1 | tail -5
+# same-box A/B of the NT GEMM variants in the training step (bench.py): SRHIP_NTW=0 (LDS-staged W), =1 without / with the K-walk rotation
 for i in 1 2; do
-  SRHIP_NTW=0 python bench.py --steps 30 --warmup 5 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('NTW=0', d['value'], d['roofline']['avg_launch_us'])"
-  SRHIP_NTW=1 python bench.py --steps 30 --warmup 5 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('NTW=1', d['value'], d['roofline']['avg_launch_us'])"
+  for v in "SRHIP_NTW=0" "SRHIP_NTW=1 SRHIP_NTW_ROT=0" "SRHIP_NTW=1 SRHIP_NTW_ROT=1"; do
+    env $v python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', round(d['value'],1), round(d['roofline']['avg_launch_us'],2))"
+  done
 done
