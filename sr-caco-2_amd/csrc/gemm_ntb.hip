@@ -442,6 +442,9 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
 #undef SR_NTB_AMP
     }
   }
+  if constexpr (CONV) {       // 64-pixel x 192-column tiles: W fragments straight from global memory (gemm_ntw.hip); SRHIP_NTCW=0: k_ntb<1, 3>
+    if (wm == 1 && wn == 3 && p.ps == 0 && !p.dbg && !p.stagger && ntb_env("SRHIP_NTCW", 1)) return sr_conv3x3_ntcw(p, st);
+  }
 #define SR_NTB_CASE(WM_, WN_) \
   if (wm == WM_ && wn == WN_) return launch_ntb<WM_, WN_, CONV>(p, st);
   SR_NTB_CASE(1, 1) SR_NTB_CASE(1, 2) SR_NTB_CASE(1, 3)

@@ -218,7 +218,163 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
   if (p.stats_out) nt_row_stats<3>(p, acc2, lane, wm, wn, m0, nvalid, (float*)smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same idea for the 3x3 conv as implicit GEMM (64-pixel x 192-column tiles: SwinIR's 180 -> 180 convs,
+// operands / epilogues of gemm_ntb.hip's k_ntb<1, 3, true>): the halo tile of a 32-channel chunk is split once
+// into LDS (6 x 18 pixels, 80-byte pixel pitch: conflict free for the 16-lane fragment phases), and the nine
+// taps of the chunk run WITHOUT any barrier -- a tap's W fragments (rows tap*Cout + n of the tap-major pack)
+// come straight from global memory into the MFMA operand registers (three fragment sets, one per tap mod 3),
+// its A fragments are the halo tile shifted by (dy, dx).  Two barriers per channel chunk instead of one or two
+// per (chunk, tap); 18 KB of LDS reads per tap and wave-quad instead of 132 KB of W + A traffic.
+constexpr int C_PITCH = 80;                      // bytes per halo pixel and plane (32 bf16 + 16 B pad)
+constexpr int C_AROWS = 6 * 18;                  // halo pixels of a 4 x 16 tile
+constexpr int C_APLANE = C_AROWS * C_PITCH;
+constexpr int C_AN = C_AROWS * 8;                // float4 slots per chunk
+constexpr int C_AIT = (C_AN + 255) / 256;
+constexpr int NTCW_LDS = BM * TP * 4;            // the re-layout tile (> 3 halo planes)
+
+__global__ void __launch_bounds__(256, 2) k_ntcw(NtArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * p.n_tile;
+  const int nvalid = min(p.n_tile, p.N - n0);
+  int t = p.xcd_order ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;   // neighbouring tiles (shared halos) in one L2
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int img = t / p.tiles_y;
+  const int y0 = ty * 4, x0 = tx * 16;
+  const int nkc = (p.K + 31) / 32;
+
+  // ---- halo staging: thread = up to C_AIT float4 (pixel, 4 channels) of the 6 x 18 x 32-channel chunk
+  unsigned offA[C_AIT];
+  bool inA[C_AIT];
+#pragma unroll
+  for (int it = 0; it < C_AIT; ++it) {
+    const int idx = min(tid + it * 256, C_AN - 1);
+    const int row = idx >> 3, c4 = idx & 7;
+    const int hy = row / 18, hx = row - hy * 18;
+    const int y = y0 + hy - 1, x = x0 + hx - 1;
+    inA[it] = y >= 0 && y < p.H && x >= 0 && x < p.Wd;
+    const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.Wd - 1);
+    offA[it] = (unsigned)(((img * p.H + yc) * p.Wd + xc) * (int)p.lda + c4 * 4) * 4u;
+  }
+  auto load_a = [&](int kc, f32x4 (&ra)[C_AIT]) {       // K-tail lanes read k = 0 of the pixel, zeroed on store
+    const char* base = (const char*)(p.A + (long)kc * 32);
+#pragma unroll
+    for (int it = 0; it < C_AIT; ++it) {
+      const int c4 = min(tid + it * 256, C_AN - 1) & 7;
+      const bool oob = kc * 32 + c4 * 4 >= p.K;
+      ra[it] = *(const f32x4*)((oob ? (const char*)p.A : base) + (oob ? offA[it] - c4 * 16u : offA[it]));
+    }
+  };
+  auto store_a = [&](const f32x4 (&ra)[C_AIT], int kc) {
+#pragma unroll
+    for (int it = 0; it < C_AIT; ++it) {
+      if (C_AN % 256 == 0 || tid + it * 256 < C_AN) {
+        const int idx = tid + it * 256;
+        f32x4 v = ra[it];
+        if (!inA[it] || kc * 32 + (idx & 7) * 4 >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};   // outside the image / K tail: exact zeros
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pair(v.x, v.y, h0, m0_, l0);
+        split3_pair(v.z, v.w, h1, m1, l1);
+        unsigned char* dst = smem + (idx >> 3) * C_PITCH + (idx & 7) * 8;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *(u32x2*)(dst) = u32x2{h0, h1};
+        *(u32x2*)(dst + C_APLANE) = u32x2{m0_, m1};
+        *(u32x2*)(dst + 2 * C_APLANE) = u32x2{l0, l1};
+      }
+    }
+  };
+
+  // ---- W fragments of (chunk, tap): rows tap*N + n of the tap-major pack, sub-chunk 2*chunk + (g >> 1)
+  const long wrows = 9L * p.N;
+  const long plane_bytes = wrows * p.Kp * 2;
+  unsigned boff[3];
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt)
+    boff[jt] = (unsigned)(((g >> 1) * wrows + n0 + min(wave * 48 + jt * 16 + c, nvalid - 1)) * 32 + (g & 1) * 16);
+  const int niter = nkc * 9;
+  auto load_b = [&](int it, u32x4 (&fb)[3][3]) {          // iterations past the end re-read the last one
+    const int itc = min(it, niter - 1);
+    const int kc = itc / 9, tap = itc - kc * 9;
+    const char* base = (const char*)p.Wb + ((long)(2 * kc) * wrows + (long)tap * p.N) * 32;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
+  };
+
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = (i * 18 + c) * C_PITCH + 16 * g;     // image row i of the tile, pixel c, octet g
+
+  auto mma = [&](int tap, const u32x4 (&fb)[3][3]) {
+    const int toff = ((tap / 3) * 18 + (tap % 3)) * C_PITCH;                  // halo shift of the tap
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 fa[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) fa[pl] = *(const u32x4*)(smem + pl * C_APLANE + a_off[i] + toff);
+#define SR_TERM(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fa[PA], fb[j][PB], acc[i][j]);
+      SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+#undef SR_TERM
+    }
+  };
+
+  f32x4 ra[C_AIT];
+  u32x4 fb0[3][3], fb1[3][3], fb2[3][3];
+  load_a(0, ra);
+  load_b(0, fb0); load_b(1, fb1); load_b(2, fb2);
+  for (int kc = 0; kc < nkc; ++kc) {
+    if (kc) __syncthreads();                  // every tap of the previous chunk has read the halo tile
+    store_a(ra, kc);
+    __syncthreads();
+    if (kc + 1 < nkc) load_a(kc + 1, ra);     // nine taps to land
+    const int it = kc * 9;
+#pragma unroll 1
+    for (int t3 = 0; t3 < 9; t3 += 3) {
+      mma(t3, fb0);     load_b(it + t3 + 3, fb0);
+      mma(t3 + 1, fb1); load_b(it + t3 + 4, fb1);
+      mma(t3 + 2, fb2); load_b(it + t3 + 5, fb2);
+    }
+  }
+
+  // ---- re-layout into the 32x32 / 2 x 2 layout of nt_epi.h: tile row 16*y + x <-> its 32-row tile (2 image rows x 16)
+  __syncthreads();
+  float* const T = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) T[(16 * i + 4 * g + e) * TP + wave * 48 + 16 * j + c] = acc[i][j][e];
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31;
+  f32x16 acc2[1][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc2[0][j][q] = T[(wm * 32 + mfma_row(q, lane)) * TP + (wn * 3 + j) * 32 + r];
+  nt_epilogue<1, 3, true>(p, acc2, lane, wm, wn, n0, nvalid, 0, img, y0, x0);
+}
+
 }  // namespace
+
+// 64-pixel x 192-column conv tiles of the f32-accurate path (gemm_ntb.hip decides; tiles_x / tiles_y / n_tile set by the caller)
+int sr_conv3x3_ntcw(NtArgs& p, hipStream_t st) {
+  dim3 grid(p.tiles_x * p.tiles_y * p.batch, sr_cdiv(p.N, p.n_tile));
+  hipLaunchKernelGGL(k_ntcw, grid, dim3(256), NTCW_LDS, st, p);
+  SR_LAUNCH_CHECK("k_ntcw");
+  return 0;
+}
 
 // 192-column tiles of the f32-accurate path (gemm_ntp.hip decides): n_tile is set by the caller.
 int sr_gemm_ntw(NtArgs& p, hipStream_t st) {

@@ -35,11 +35,12 @@ def arm():
         Wb = ops.split_bf16x3(W)
         rs = torch.tensor([1.0, 0.0, 1.25, 2.0, 1.0, 1.0, 0.5, 1.0], device=dev)
         sets = []
+        pad = lambda n: (n + 31) // 32 * 32 if os.environ.get("MB_PAD") else n      # MB_PAD=1: 128-byte aligned row pitches
         for _ in range(NSET):
-            A = torch.randn(T, K, device=dev)
+            A = torch.randn(T, pad(K), device=dev)[:, :K]
             st = torch.stack([A.mean(1), 1 / torch.sqrt(A.var(1, unbiased=False) + 1e-5)], 1).contiguous()
-            sets.append(dict(A=A, st=st, R=torch.randn(T, N, device=dev), out=torch.empty(T, N, device=dev),
-                             so=torch.empty(T, 2, device=dev), aux=torch.empty(T, N, device=dev)))
+            sets.append(dict(A=A, st=st, R=torch.randn(T, pad(N), device=dev)[:, :N], out=torch.empty(T, pad(N), device=dev)[:, :N],
+                             so=torch.empty(T, 2, device=dev), aux=torch.empty(T, pad(N), device=dev)[:, :N]))
 
         def run(s):
             ops.gemm_nt(s["A"], Wb, b if epi != 3 else None, out=s["out"], a_mode=a_mode,
@@ -93,7 +94,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "arm":
         arm()
     else:
-        arms = [dict(SRHIP_NTW="0"), dict(SRHIP_NTW="1", SRHIP_NTW_ROT="0"), dict(SRHIP_NTW="1")] + \
+        arms = [dict(SRHIP_NTW="0"), dict(SRHIP_NTW="1"), dict(SRHIP_NTW="1", MB_PAD="1")] + \
             [dict(SRHIP_NTW="1", SRHIP_NTW_DBG=b) for b in sys.argv[1:]]
         for env in arms:
             print(env, flush=True)
