@@ -158,17 +158,19 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
   f32x4 ra0[2], ra1[2];
   u32x4 fb0[3][3], fb1[3][3], fb2[3][3];
   load_a(0, ra0); load_b(0, fb0);
-  load_a(1, ra1); load_b(1, fb1);
-  load_b(2, fb2);
+  if (nst > 1) { load_a(1, ra1); load_b(1, fb1); }
+  if (nst > 2) load_b(2, fb2);
   store_a(0, ra0);
-  load_a(2, ra0);
+  if (nst > 2) load_a(2, ra0);
   __syncthreads();
   // one step: stage cs is in LDS buffer cs & 1; RA = the A registers holding stage cs + 1
+  // (loads of stages past the end are skipped -- block-uniform branches: with 6 stages at K = 180 the three
+  // prefetches past the end were half as many W bytes again through the L1)
 #define SR_STEP(CS, RA, FB)                    \
-  store_a((CS) + 1, RA);                       \
-  load_a((CS) + 3, RA);                        \
+  if ((CS) + 1 < nst) store_a((CS) + 1, RA);   \
+  if ((CS) + 3 < nst) load_a((CS) + 3, RA);    \
   mma((CS), FB);                               \
-  load_b((CS) + 3, FB);                        \
+  if ((CS) + 3 < nst) load_b((CS) + 3, FB);    \
   __syncthreads();
   for (int cs = 0; cs < nst; cs += 6) {        // 6 = lcm(A parity, W sets); every guard is block-uniform
     SR_STEP(cs, ra1, fb0)
@@ -341,9 +343,9 @@ __global__ void __launch_bounds__(256, 2) k_ntcw(NtArgs p) {
     const int it = kc * 9;
 #pragma unroll 1
     for (int t3 = 0; t3 < 9; t3 += 3) {
-      mma(t3, fb0);     load_b(it + t3 + 3, fb0);
-      mma(t3 + 1, fb1); load_b(it + t3 + 4, fb1);
-      mma(t3 + 2, fb2); load_b(it + t3 + 5, fb2);
+      mma(t3, fb0);     if (it + t3 + 3 < niter) load_b(it + t3 + 3, fb0);
+      mma(t3 + 1, fb1); if (it + t3 + 4 < niter) load_b(it + t3 + 4, fb1);
+      mma(t3 + 2, fb2); if (it + t3 + 5 < niter) load_b(it + t3 + 5, fb2);
     }
   }
 

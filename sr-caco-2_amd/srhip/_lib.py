@@ -7,7 +7,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsrhip.so")
+# SRHIP_LIB: another build of the same library (same-box A/B of two builds, tools/ab_lib.sh)
+LIB_PATH = os.environ.get("SRHIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libsrhip.so")
 
 HEADER = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "srhip.h")
 _CT = {"p": ctypes.c_void_p, "l": ctypes.c_long, "i": ctypes.c_int,

@@ -1,12 +1,8 @@
-#!/bin/bash
-# A/B of two builds on ONE box: put the other build at sr-caco-2_amd/lib/libsrhip_old.so, then
-#   bash tools/ab_lib.sh [rounds]      (bench.py --no-roofline --no-cpu-baseline, alternating)
-L=sr-caco-2_amd/lib; n=${1:-3}
-val() { python bench.py --no-roofline --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; print(json.loads(sys.stdin.read())['value'])"; }
-cp $L/libsrhip.so $L/new.so
-for i in $(seq 1 $n); do
-  cp $L/new.so $L/libsrhip.so; a=$(val)
-  cp $L/libsrhip_old.so $L/libsrhip.so; b=$(val)
-  echo "new $a   old $b"
+# same-box A/B of two BUILDS of libsrhip in the training step: the in-tree library against sr-caco-2_amd/lib/libsrhip_base.so
+# (build the baseline from another commit, copy it there; .so files travel to the GPU box, they are not in git)
+BASE=$(pwd)/sr-caco-2_amd/lib/libsrhip_base.so
+WL=${1:-swinir_x8}
+for i in 1 2 3; do
+  SRHIP_LIB=$BASE python bench.py --workload $WL --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('base', round(d['value'],1), round(d['roofline']['avg_launch_us'],2))"
+  python bench.py --workload $WL --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('new ', round(d['value'],1), round(d['roofline']['avg_launch_us'],2))"
 done
-cp $L/new.so $L/libsrhip.so
