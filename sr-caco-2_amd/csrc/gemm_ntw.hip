@@ -368,7 +368,170 @@ __global__ void __launch_bounds__(256, 2) k_ntcw(NtArgs p) {
   nt_epilogue<1, 3, true>(p, acc2, lane, wm, wn, n0, nvalid, 0, img, y0, x0);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// ... and for the 64-column conv tiles (128 pixels x 64 columns: the 64 -> 64 body convs of EDSR / VDSR /
+// MSLapSRN / MemNet, and 64-column slices of wider outputs; operands / epilogues of k_ntb<2, 1, true>).  Waves
+// 2 x 2 as in nt_epi.h -- wave (wm, wn) owns image rows 4*wm .. 4*wm+3 (four 16-pixel row tiles) x columns
+// 32*wn .. +31 (two column tiles): the two row halves read the same W fragments (L1 hits), nothing of W goes
+// through LDS, the nine taps of a channel chunk run without a barrier, and the accumulators reach nt_epi.h's
+// layout through a wave-private LDS tile (the region of a wave is the same in both layouts).
+constexpr int D_AROWS = 10 * 18;                 // halo pixels of an 8 x 16 tile
+constexpr int D_APLANE = D_AROWS * C_PITCH;
+constexpr int D_AN = D_AROWS * 8;
+constexpr int D_AIT = (D_AN + 255) / 256;
+constexpr int D_TP = 36;                         // pitch of the wave's 64 x 32 re-layout tile (floats)
+constexpr int NTCW2_LDS = 3 * D_APLANE;          // 43200 B (> 4 waves x 64 x D_TP x 4)
+
+__global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = lane & 15, g = lane >> 4;
+  // one-dimensional grid, column block fastest: the column blocks of a pixel tile (they stage the same halo) are
+  // neighbours in time and, with the XCD-aware order, in one L2
+  int t = p.xcd_order ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int ncol = (p.N + p.n_tile - 1) / p.n_tile;
+  const int n0 = (t % ncol) * p.n_tile; t /= ncol;
+  const int nvalid = min(p.n_tile, p.N - n0);
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int img = t / p.tiles_y;
+  const int y0 = ty * 8, x0 = tx * 16;
+  const int nkc = (p.K + 31) / 32;
+
+  unsigned offA[D_AIT];
+  bool inA[D_AIT];
+#pragma unroll
+  for (int it = 0; it < D_AIT; ++it) {
+    const int idx = min(tid + it * 256, D_AN - 1);
+    const int row = idx >> 3, c4 = idx & 7;
+    const int hy = row / 18, hx = row - hy * 18;
+    const int y = y0 + hy - 1, x = x0 + hx - 1;
+    inA[it] = y >= 0 && y < p.H && x >= 0 && x < p.Wd;
+    const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.Wd - 1);
+    if (p.ps == 2) offA[it] = (unsigned)(((img * 2 * p.H + 2 * yc) * 2 * p.Wd + 2 * xc) * (int)p.lda + c4 * 4) * 4u;
+    else offA[it] = (unsigned)(((img * p.H + yc) * p.Wd + xc) * (int)p.lda + c4 * 4) * 4u;
+  }
+  auto load_a = [&](int kc, f32x4 (&ra)[D_AIT]) {
+    long koff = kc * 32;
+    if (p.ps == 2) {     // chunk kc = channels c0.. of sub-pixel sp of the shuffled image (K/4 is a multiple of 32)
+      const int fk = p.K >> 2, sp = (kc * 32) / fk, c0 = kc * 32 - sp * fk;
+      koff = ((long)(sp >> 1) * 2 * p.Wd + (sp & 1)) * p.lda + c0;
+    }
+    const char* base = (const char*)(p.A + koff);
+#pragma unroll
+    for (int it = 0; it < D_AIT; ++it) {
+      const int c4 = min(tid + it * 256, D_AN - 1) & 7;
+      const bool oob = kc * 32 + c4 * 4 >= p.K;
+      ra[it] = *(const f32x4*)((oob ? (const char*)p.A : base) + (oob ? offA[it] - c4 * 16u : offA[it]));
+    }
+  };
+  auto store_a = [&](const f32x4 (&ra)[D_AIT], int kc) {
+#pragma unroll
+    for (int it = 0; it < D_AIT; ++it) {
+      if (D_AN % 256 == 0 || tid + it * 256 < D_AN) {
+        const int idx = tid + it * 256;
+        f32x4 v = ra[it];
+        if (!inA[it] || kc * 32 + (idx & 7) * 4 >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pair(v.x, v.y, h0, m0_, l0);
+        split3_pair(v.z, v.w, h1, m1, l1);
+        unsigned char* dst = smem + (idx >> 3) * C_PITCH + (idx & 7) * 8;
+        *(u32x2*)(dst) = u32x2{h0, h1};
+        *(u32x2*)(dst + D_APLANE) = u32x2{m0_, m1};
+        *(u32x2*)(dst + 2 * D_APLANE) = u32x2{l0, l1};
+      }
+    }
+  };
+
+  const long wrows = 9L * p.N;
+  const long plane_bytes = wrows * p.Kp * 2;
+  unsigned boff[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+    boff[jt] = (unsigned)(((g >> 1) * wrows + n0 + min(wn * 32 + jt * 16 + c, nvalid - 1)) * 32 + (g & 1) * 16);
+  const int niter = nkc * 9;
+  auto load_b = [&](int it, u32x4 (&fb)[2][3]) {
+    const int kc = it / 9, tap = it - kc * 9;
+    const char* base = (const char*)p.Wb + ((long)(2 * kc) * wrows + (long)tap * p.N) * 32;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
+  };
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = ((4 * wm + i) * 18 + c) * C_PITCH + 16 * g;
+
+  auto mma = [&](int tap, const u32x4 (&fb)[2][3]) {
+    const int toff = ((tap / 3) * 18 + (tap % 3)) * C_PITCH;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 fa[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) fa[pl] = *(const u32x4*)(smem + pl * D_APLANE + a_off[i] + toff);
+#define SR_TERM(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa[PA], fb[j][PB], acc[i][j]);
+      SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+#undef SR_TERM
+    }
+  };
+
+  f32x4 ra[D_AIT];
+  u32x4 fb0[2][3], fb1[2][3], fb2[2][3];
+  load_a(0, ra);
+  load_b(0, fb0); load_b(1, fb1); load_b(2, fb2);
+  for (int kc = 0; kc < nkc; ++kc) {
+    if (kc) __syncthreads();
+    store_a(ra, kc);
+    __syncthreads();
+    if (kc + 1 < nkc) load_a(kc + 1, ra);
+    const int it = kc * 9;
+#pragma unroll 1
+    for (int t3 = 0; t3 < 9; t3 += 3) {
+      mma(t3, fb0);     if (it + t3 + 3 < niter) load_b(it + t3 + 3, fb0);
+      mma(t3 + 1, fb1); if (it + t3 + 4 < niter) load_b(it + t3 + 4, fb1);
+      mma(t3 + 2, fb2); if (it + t3 + 5 < niter) load_b(it + t3 + 5, fb2);
+    }
+  }
+
+  // ---- re-layout inside the wave: 4 x 2 tiles of 16 x 16 -> 2 x 1 tiles of 32 x 32 (tile row 16*y + x of the wave's 4 image rows)
+  __syncthreads();                                   // the halo tile is dead from here on
+  float* const T = (float*)smem + wave * (64 * D_TP);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) T[(16 * i + 4 * g + e) * D_TP + 16 * j + c] = acc[i][j][e];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the wave's own LDS writes have landed
+  const int r = lane & 31;
+  f32x16 acc2[2][1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc2[i][0][q] = T[(32 * i + mfma_row(q, lane)) * D_TP + r];
+  nt_epilogue<2, 1, true>(p, acc2, lane, wm, wn, n0, nvalid, 0, img, y0, x0);
+}
+
 }  // namespace
+
+int sr_conv3x3_ntcw2(NtArgs& p, hipStream_t st) {
+  static_assert(NTCW2_LDS >= 4 * 64 * D_TP * 4, "LDS regions");
+  dim3 grid(p.tiles_x * p.tiles_y * p.batch * sr_cdiv(p.N, p.n_tile));
+  hipLaunchKernelGGL(k_ntcw2, grid, dim3(256), NTCW2_LDS, st, p);
+  SR_LAUNCH_CHECK("k_ntcw2");
+  return 0;
+}
 
 // 64-pixel x 192-column conv tiles of the f32-accurate path (gemm_ntb.hip decides; tiles_x / tiles_y / n_tile set by the caller)
 int sr_conv3x3_ntcw(NtArgs& p, hipStream_t st) {
