@@ -446,8 +446,9 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
     if (wm == 1 && wn == 3 && p.ps == 0 && !p.dbg && !p.stagger && ntb_env("SRHIP_NTCW", 1)) return sr_conv3x3_ntcw(p, st);
     if (wm == 2 && (wn == 1 || (wn == 2 && ntb_env("SRHIP_NTCW2_WIDE", 1))) && !p.dbg && !p.stagger && ntb_env("SRHIP_NTCW2", 1)) {
       p.n_tile = 64;          // wider outputs (64 -> 256 of the upsampler): 64-column slices, column block fastest
-      return sr_conv3x3_ntcw2(p, st);
+      return sr_conv3x3_ntcw2(p, 4, st);
     }
+    if (wm == 1 && wn == 1 && !p.dbg && !p.stagger && ntb_env("SRHIP_NTCW2_SMALL", 1)) return sr_conv3x3_ntcw2(p, 2, st);
   }
 #define SR_NTB_CASE(WM_, WN_) \
   if (wm == WM_ && wn == WN_) return launch_ntb<WM_, WN_, CONV>(p, st);

@@ -375,14 +375,16 @@ __global__ void __launch_bounds__(256, 2) k_ntcw(NtArgs p) {
 // 32*wn .. +31 (two column tiles): the two row halves read the same W fragments (L1 hits), nothing of W goes
 // through LDS, the nine taps of a channel chunk run without a barrier, and the accumulators reach nt_epi.h's
 // layout through a wave-private LDS tile (the region of a wave is the same in both layouts).
-constexpr int D_AROWS = 10 * 18;                 // halo pixels of an 8 x 16 tile
-constexpr int D_APLANE = D_AROWS * C_PITCH;
-constexpr int D_AN = D_AROWS * 8;
-constexpr int D_AIT = (D_AN + 255) / 256;
-constexpr int D_TP = 36;                         // pitch of the wave's 64 x 32 re-layout tile (floats)
-constexpr int NTCW2_LDS = 3 * D_APLANE;          // 43200 B (> 4 waves x 64 x D_TP x 4)
+constexpr int D_TP = 36;                         // pitch of the wave's re-layout tile (floats)
+constexpr int ntcw2_lds(int rw) { return 3 * (2 * rw + 2) * 18 * C_PITCH; }   // 43200 / 25920 B (> 4 waves x 16 rw x D_TP x 4)
 
+// RW = image rows per wave: 4 (128-pixel tiles, k_ntb<2, 1>'s shapes) or 2 (64-pixel tiles, k_ntb<1, 1>'s: small images)
+template <int RW>
 __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
+  constexpr int D_AROWS = (2 * RW + 2) * 18;       // halo pixels of a 2 RW x 16 tile
+  constexpr int D_APLANE = D_AROWS * C_PITCH;
+  constexpr int D_AN = D_AROWS * 8;
+  constexpr int D_AIT = (D_AN + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x, lane = tid & 63;
@@ -398,7 +400,7 @@ __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
   const int tx = t % p.tiles_x; t /= p.tiles_x;
   const int ty = t % p.tiles_y;
   const int img = t / p.tiles_y;
-  const int y0 = ty * 8, x0 = tx * 16;
+  const int y0 = ty * (2 * RW), x0 = tx * 16;
   const int nkc = (p.K + 31) / 32;
 
   unsigned offA[D_AIT];
@@ -462,19 +464,19 @@ __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
       for (int jt = 0; jt < 2; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
   };
 
-  f32x4 acc[4][2];
+  f32x4 acc[RW][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RW; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int a_off[4];
+  int a_off[RW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) a_off[i] = ((4 * wm + i) * 18 + c) * C_PITCH + 16 * g;
+  for (int i = 0; i < RW; ++i) a_off[i] = ((RW * wm + i) * 18 + c) * C_PITCH + 16 * g;
 
   auto mma = [&](int tap, const u32x4 (&fb)[2][3]) {
     const int toff = ((tap / 3) * 18 + (tap % 3)) * C_PITCH;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RW; ++i) {
       u32x4 fa[3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) fa[pl] = *(const u32x4*)(smem + pl * D_APLANE + a_off[i] + toff);
@@ -505,9 +507,9 @@ __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
 
   // ---- re-layout inside the wave: 4 x 2 tiles of 16 x 16 -> 2 x 1 tiles of 32 x 32 (tile row 16*y + x of the wave's 4 image rows)
   __syncthreads();                                   // the halo tile is dead from here on
-  float* const T = (float*)smem + wave * (64 * D_TP);
+  float* const T = (float*)smem + wave * (16 * RW * D_TP);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RW; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -515,20 +517,22 @@ __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the wave's own LDS writes have landed
   const int r = lane & 31;
-  f32x16 acc2[2][1];
+  f32x16 acc2[RW / 2][1];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RW / 2; ++i)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc2[i][0][q] = T[(32 * i + mfma_row(q, lane)) * D_TP + r];
-  nt_epilogue<2, 1, true>(p, acc2, lane, wm, wn, n0, nvalid, 0, img, y0, x0);
+  nt_epilogue<RW / 2, 1, true>(p, acc2, lane, wm, wn, n0, nvalid, 0, img, y0, x0);
 }
 
 }  // namespace
 
-int sr_conv3x3_ntcw2(NtArgs& p, hipStream_t st) {
-  static_assert(NTCW2_LDS >= 4 * 64 * D_TP * 4, "LDS regions");
+// rows_per_wave 4: tiles_y counts 8-row tiles; 2: 4-row tiles (the caller's wm = 2 / 1)
+int sr_conv3x3_ntcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
+  static_assert(ntcw2_lds(4) >= 4 * 64 * D_TP * 4 && ntcw2_lds(2) >= 4 * 32 * D_TP * 4, "LDS regions");
   dim3 grid(p.tiles_x * p.tiles_y * p.batch * sr_cdiv(p.N, p.n_tile));
-  hipLaunchKernelGGL(k_ntcw2, grid, dim3(256), NTCW2_LDS, st, p);
+  if (rows_per_wave == 4) hipLaunchKernelGGL(k_ntcw2<4>, grid, dim3(256), ntcw2_lds(4), st, p);
+  else hipLaunchKernelGGL(k_ntcw2<2>, grid, dim3(256), ntcw2_lds(2), st, p);
   SR_LAUNCH_CHECK("k_ntcw2");
   return 0;
 }
