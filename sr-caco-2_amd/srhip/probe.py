@@ -58,7 +58,7 @@ class timed:
 
 _KERNEL_OF_KIND = {
     "gemm_nt": ("k_ntw|k_ntp", "NT GEMM (Linear forward / data gradient)"),
-    "conv_nt": ("k_ntb", "implicit-GEMM 3x3 conv (forward / data gradient)"),
+    "conv_nt": ("k_ntcw|k_ntb", "implicit-GEMM 3x3 conv (forward / data gradient)"),
     "conv_tn": ("k_tnb", "3x3 conv weight gradient"),
     "linear_tn": ("k_tnb_grouped", "grouped Linear weight gradients"),
     "wattn": ("k_wattn", "window attention core"),
@@ -76,13 +76,15 @@ def _pmc_traffic(kernel_stem):
                                  for r in (9, 8, 7, 6, 5, 4, 3, 2, 1)]
     for path in cands:
         if path and os.path.isfile(path):
-            tot = n = 0.0
-            for name, v in json.load(open(path)).items():
-                if any(st in name for st in kernel_stem.split("|")):
-                    tot += v["hbm_bytes_per_launch"] * v["launches"]
-                    n += v["launches"]
-            if n:
-                return tot / n, os.path.basename(path)
+            table = json.load(open(path))
+            for st in kernel_stem.split("|"):        # alternatives in order of preference: the first one that ran
+                tot = n = 0.0
+                for name, v in table.items():
+                    if st in name:
+                        tot += v["hbm_bytes_per_launch"] * v["launches"]
+                        n += v["launches"]
+                if n:
+                    return tot / n, os.path.basename(path)
     return None, None
 
 
