@@ -433,6 +433,14 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
     p.tiles_y = sr_cdiv(p.H, wm == 2 ? 8 : 4);
     p.xcd_order = ntb_env("SRHIP_CONV_XCD", 1);
   }
+  if constexpr (CONV) {       // 64-pixel x 192-column tiles: W fragments straight from global memory (gemm_ntw.hip); SRHIP_NTCW=0: k_ntb<1, 3>
+    if (wm == 1 && wn == 3 && p.ps == 0 && !p.dbg && !p.stagger && ntb_env("SRHIP_NTCW", 1)) return sr_conv3x3_ntcw(p, st);
+    if (wm == 2 && (wn == 1 || (wn == 2 && ntb_env("SRHIP_NTCW2_WIDE", 1))) && !p.dbg && !p.stagger && ntb_env("SRHIP_NTCW2", 1)) {
+      p.n_tile = 64;          // wider outputs (64 -> 256 of the upsampler): 64-column slices, column block fastest
+      return sr_conv3x3_ntcw2(p, 4, st);
+    }
+    if (wm == 1 && wn == 1 && !p.dbg && !p.stagger && ntb_env("SRHIP_NTCW2_SMALL", 1)) return sr_conv3x3_ntcw2(p, 2, st);
+  }
   if constexpr (CONV) {       // reduced-precision inference (srhip_set_matmul_mode(1)): conv kernels only here,
     if (p.amp) {              // GEMMs take gemm_ntp.hip's AMP instantiation
 #define SR_NTB_AMP(WM_, WN_) \
@@ -441,14 +449,6 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
       SR_NTB_AMP(2, 1) SR_NTB_AMP(2, 2) SR_NTB_AMP(2, 3)
 #undef SR_NTB_AMP
     }
-  }
-  if constexpr (CONV) {       // 64-pixel x 192-column tiles: W fragments straight from global memory (gemm_ntw.hip); SRHIP_NTCW=0: k_ntb<1, 3>
-    if (wm == 1 && wn == 3 && p.ps == 0 && !p.dbg && !p.stagger && ntb_env("SRHIP_NTCW", 1)) return sr_conv3x3_ntcw(p, st);
-    if (wm == 2 && (wn == 1 || (wn == 2 && ntb_env("SRHIP_NTCW2_WIDE", 1))) && !p.dbg && !p.stagger && ntb_env("SRHIP_NTCW2", 1)) {
-      p.n_tile = 64;          // wider outputs (64 -> 256 of the upsampler): 64-column slices, column block fastest
-      return sr_conv3x3_ntcw2(p, 4, st);
-    }
-    if (wm == 1 && wn == 1 && !p.dbg && !p.stagger && ntb_env("SRHIP_NTCW2_SMALL", 1)) return sr_conv3x3_ntcw2(p, 2, st);
   }
 #define SR_NTB_CASE(WM_, WN_) \
   if (wm == WM_ && wn == WN_) return launch_ntb<WM_, WN_, CONV>(p, st);

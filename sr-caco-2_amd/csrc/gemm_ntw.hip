@@ -46,8 +46,10 @@ __device__ __forceinline__ int a_slot(int row, int u) { return row * 4 + (u ^ ((
 
 // DBG = true (SRHIP_NTW_DBG=bits, timing experiments only, results are wrong): 1 = W fragments always from stage 0
 // (cache-hot), 2 = no MFMAs, 4 = no epilogue, 8 = no A staging stores
-template <bool DBG>
+// AMP = true: reduced-precision inference (one bf16 product of the leading planes; see gemm_ntb.hip)
+template <bool DBG, bool AMP = false>
 __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
+  constexpr int NPL = AMP ? 1 : 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,8 +102,10 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
       return;
     }
     *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
-    *(u32x4*)(sa + A_PLANE) = u32x4{mm[0], mm[1], mm[2], mm[3]};
-    *(u32x4*)(sa + 2 * A_PLANE) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    if (!AMP) {
+      *(u32x4*)(sa + A_PLANE) = u32x4{mm[0], mm[1], mm[2], mm[3]};
+      *(u32x4*)(sa + 2 * A_PLANE) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    }
   };
 
   // ---- W fragments: lane (c, g) of column tile jt reads 16 bytes (g & 1) of row n in sub-chunk 2*stage + (g >> 1);
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
     const int st = (DBG && (p.dbg & 1)) ? 0 : min(stage_of(cs), nst - 1);        // stages past the end re-read the last one
     const char* base = (const char*)p.Wb + (long)(2 * st) * p.N * 32;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
       for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
   };
@@ -143,11 +147,15 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
     for (int i = 0; i < 4; ++i) {
       u32x4 fa[3];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fa[pl] = *(const u32x4*)(sa + pl * A_PLANE + a_off[i]);
+      for (int pl = 0; pl < NPL; ++pl) fa[pl] = *(const u32x4*)(sa + pl * A_PLANE + a_off[i]);
       // the six cross products >= 2^-24, small terms first; term-outer: consecutive MFMAs hit different tiles
 #define SR_TERM(PA, PB) \
   _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fa[PA], fb[j][PB], acc[i][j]);
-      SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      if constexpr (AMP) {
+        SR_TERM(0, 0)
+      } else {
+        SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      }
 #undef SR_TERM
     }
   };
@@ -235,7 +243,9 @@ constexpr int C_AN = C_AROWS * 8;                // float4 slots per chunk
 constexpr int C_AIT = (C_AN + 255) / 256;
 constexpr int NTCW_LDS = BM * TP * 4;            // the re-layout tile (> 3 halo planes)
 
+template <bool AMP>
 __global__ void __launch_bounds__(256, 2) k_ntcw(NtArgs p) {
+  constexpr int NPL = AMP ? 1 : 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -284,8 +294,10 @@ __global__ void __launch_bounds__(256, 2) k_ntcw(NtArgs p) {
         unsigned char* dst = smem + (idx >> 3) * C_PITCH + (idx & 7) * 8;
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         *(u32x2*)(dst) = u32x2{h0, h1};
-        *(u32x2*)(dst + C_APLANE) = u32x2{m0_, m1};
-        *(u32x2*)(dst + 2 * C_APLANE) = u32x2{l0, l1};
+        if (!AMP) {
+          *(u32x2*)(dst + C_APLANE) = u32x2{m0_, m1};
+          *(u32x2*)(dst + 2 * C_APLANE) = u32x2{l0, l1};
+        }
       }
     }
   };
@@ -303,7 +315,7 @@ __global__ void __launch_bounds__(256, 2) k_ntcw(NtArgs p) {
     const int kc = itc / 9, tap = itc - kc * 9;
     const char* base = (const char*)p.Wb + ((long)(2 * kc) * wrows + (long)tap * p.N) * 32;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
       for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
   };
@@ -323,10 +335,14 @@ __global__ void __launch_bounds__(256, 2) k_ntcw(NtArgs p) {
     for (int i = 0; i < 4; ++i) {
       u32x4 fa[3];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fa[pl] = *(const u32x4*)(smem + pl * C_APLANE + a_off[i] + toff);
+      for (int pl = 0; pl < NPL; ++pl) fa[pl] = *(const u32x4*)(smem + pl * C_APLANE + a_off[i] + toff);
 #define SR_TERM(PA, PB) \
   _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fa[PA], fb[j][PB], acc[i][j]);
-      SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      if constexpr (AMP) {
+        SR_TERM(0, 0)
+      } else {
+        SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      }
 #undef SR_TERM
     }
   };
@@ -379,8 +395,9 @@ constexpr int D_TP = 36;                         // pitch of the wave's re-layou
 constexpr int ntcw2_lds(int rw) { return 3 * (2 * rw + 2) * 18 * C_PITCH; }   // 43200 / 25920 B (> 4 waves x 16 rw x D_TP x 4)
 
 // RW = image rows per wave: 4 (128-pixel tiles, k_ntb<2, 1>'s shapes) or 2 (64-pixel tiles, k_ntb<1, 1>'s: small images)
-template <int RW>
+template <int RW, bool AMP>
 __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
+  constexpr int NPL = AMP ? 1 : 3;
   constexpr int D_AROWS = (2 * RW + 2) * 18;       // halo pixels of a 2 RW x 16 tile
   constexpr int D_APLANE = D_AROWS * C_PITCH;
   constexpr int D_AN = D_AROWS * 8;
@@ -442,8 +459,10 @@ __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
         split3_pair(v.z, v.w, h1, m1, l1);
         unsigned char* dst = smem + (idx >> 3) * C_PITCH + (idx & 7) * 8;
         *(u32x2*)(dst) = u32x2{h0, h1};
-        *(u32x2*)(dst + D_APLANE) = u32x2{m0_, m1};
-        *(u32x2*)(dst + 2 * D_APLANE) = u32x2{l0, l1};
+        if (!AMP) {
+          *(u32x2*)(dst + D_APLANE) = u32x2{m0_, m1};
+          *(u32x2*)(dst + 2 * D_APLANE) = u32x2{l0, l1};
+        }
       }
     }
   };
@@ -459,7 +478,7 @@ __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
     const int kc = it / 9, tap = it - kc * 9;
     const char* base = (const char*)p.Wb + ((long)(2 * kc) * wrows + (long)tap * p.N) * 32;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
   };
@@ -479,29 +498,53 @@ __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
     for (int i = 0; i < RW; ++i) {
       u32x4 fa[3];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) fa[pl] = *(const u32x4*)(smem + pl * D_APLANE + a_off[i] + toff);
+      for (int pl = 0; pl < NPL; ++pl) fa[pl] = *(const u32x4*)(smem + pl * D_APLANE + a_off[i] + toff);
 #define SR_TERM(PA, PB) \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa[PA], fb[j][PB], acc[i][j]);
-      SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      if constexpr (AMP) {
+        SR_TERM(0, 0)
+      } else {
+        SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      }
 #undef SR_TERM
     }
   };
 
   f32x4 ra[D_AIT];
-  u32x4 fb0[2][3], fb1[2][3], fb2[2][3];
   load_a(0, ra);
-  load_b(0, fb0); load_b(1, fb1); load_b(2, fb2);
-  for (int kc = 0; kc < nkc; ++kc) {
-    if (kc) __syncthreads();
-    store_a(ra, kc);
-    __syncthreads();
-    if (kc + 1 < nkc) load_a(kc + 1, ra);
-    const int it = kc * 9;
+  if constexpr (AMP) {
+    // single-product form: a tap is 4 / 8 MFMAs per wave, so three taps of cover are nothing -- the fragments of a whole
+    // channel chunk (9 taps, 18 registers each) are requested one chunk ahead (set of a tap = the tap)
+    u32x4 fb[9][2][3];
+#pragma unroll
+    for (int s9 = 0; s9 < 9; ++s9)
+      if (s9 < niter) load_b(s9, fb[s9]);
+    for (int kc = 0; kc < nkc; ++kc) {
+      if (kc) __syncthreads();
+      store_a(ra, kc);
+      __syncthreads();
+      if (kc + 1 < nkc) load_a(kc + 1, ra);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        mma(tap, fb[tap]);
+        if (kc + 1 < nkc) load_b(kc * 9 + tap + 9, fb[tap]);
+      }
+    }
+  } else {
+    u32x4 fb0[2][3], fb1[2][3], fb2[2][3];
+    load_b(0, fb0); load_b(1, fb1); load_b(2, fb2);
+    for (int kc = 0; kc < nkc; ++kc) {
+      if (kc) __syncthreads();
+      store_a(ra, kc);
+      __syncthreads();
+      if (kc + 1 < nkc) load_a(kc + 1, ra);
+      const int it = kc * 9;
 #pragma unroll 1
-    for (int t3 = 0; t3 < 9; t3 += 3) {
-      mma(t3, fb0);     if (it + t3 + 3 < niter) load_b(it + t3 + 3, fb0);
-      mma(t3 + 1, fb1); if (it + t3 + 4 < niter) load_b(it + t3 + 4, fb1);
-      mma(t3 + 2, fb2); if (it + t3 + 5 < niter) load_b(it + t3 + 5, fb2);
+      for (int t3 = 0; t3 < 9; t3 += 3) {
+        mma(t3, fb0);     if (it + t3 + 3 < niter) load_b(it + t3 + 3, fb0);
+        mma(t3 + 1, fb1); if (it + t3 + 4 < niter) load_b(it + t3 + 4, fb1);
+        mma(t3 + 2, fb2); if (it + t3 + 5 < niter) load_b(it + t3 + 5, fb2);
+      }
     }
   }
 
@@ -531,8 +574,13 @@ __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
 int sr_conv3x3_ntcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
   static_assert(ntcw2_lds(4) >= 4 * 64 * D_TP * 4 && ntcw2_lds(2) >= 4 * 32 * D_TP * 4, "LDS regions");
   dim3 grid(p.tiles_x * p.tiles_y * p.batch * sr_cdiv(p.N, p.n_tile));
-  if (rows_per_wave == 4) hipLaunchKernelGGL(k_ntcw2<4>, grid, dim3(256), ntcw2_lds(4), st, p);
-  else hipLaunchKernelGGL(k_ntcw2<2>, grid, dim3(256), ntcw2_lds(2), st, p);
+  if (rows_per_wave == 4) {
+    if (p.amp) hipLaunchKernelGGL((k_ntcw2<4, true>), grid, dim3(256), ntcw2_lds(4), st, p);
+    else hipLaunchKernelGGL((k_ntcw2<4, false>), grid, dim3(256), ntcw2_lds(4), st, p);
+  } else {
+    if (p.amp) hipLaunchKernelGGL((k_ntcw2<2, true>), grid, dim3(256), ntcw2_lds(2), st, p);
+    else hipLaunchKernelGGL((k_ntcw2<2, false>), grid, dim3(256), ntcw2_lds(2), st, p);
+  }
   SR_LAUNCH_CHECK("k_ntcw2");
   return 0;
 }
@@ -540,7 +588,8 @@ int sr_conv3x3_ntcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
 // 64-pixel x 192-column conv tiles of the f32-accurate path (gemm_ntb.hip decides; tiles_x / tiles_y / n_tile set by the caller)
 int sr_conv3x3_ntcw(NtArgs& p, hipStream_t st) {
   dim3 grid(p.tiles_x * p.tiles_y * p.batch, sr_cdiv(p.N, p.n_tile));
-  hipLaunchKernelGGL(k_ntcw, grid, dim3(256), NTCW_LDS, st, p);
+  if (p.amp) hipLaunchKernelGGL(k_ntcw<true>, grid, dim3(256), NTCW_LDS, st, p);
+  else hipLaunchKernelGGL(k_ntcw<false>, grid, dim3(256), NTCW_LDS, st, p);
   SR_LAUNCH_CHECK("k_ntcw");
   return 0;
 }
@@ -552,7 +601,9 @@ int sr_gemm_ntw(NtArgs& p, hipStream_t st) {
   static const int dbg = [] { const char* e = getenv("SRHIP_NTW_DBG"); return e ? atoi(e) : 0; }();
   static const int rot = [] { const char* e = getenv("SRHIP_NTW_ROT"); return e ? atoi(e) : 1; }();
   p.k_rot = rot;
-  if (dbg) {
+  if (p.amp) {
+    hipLaunchKernelGGL((k_ntw<false, true>), grid, dim3(256), NTW_LDS, st, p);
+  } else if (dbg) {
     p.dbg = dbg;
     hipLaunchKernelGGL(k_ntw<true>, grid, dim3(256), NTW_LDS, st, p);
   } else {

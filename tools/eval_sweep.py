@@ -52,13 +52,18 @@ def main():
                 for _ in range(3):
                     model.test()
                 torch.cuda.synchronize()
-                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0.record()
-                for _ in range(a.iters):
-                    model.test()
-                t1.record()
-                torch.cuda.synchronize()
-                ms = t0.elapsed_time(t1) / a.iters
+                # median over groups of iterations: a stray host stall (these forwards are 1-2 ms of GPU work) inside ONE
+                # timed span once produced a 6x outlier for a whole configuration
+                groups = []
+                for _ in range(5):
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record()
+                    for _ in range(a.iters):
+                        model.test()
+                    t1.record()
+                    torch.cuda.synchronize()
+                    groups.append(t0.elapsed_time(t1) / a.iters)
+                ms = sorted(groups)[2]
                 out = model.E
                 assert tuple(out.shape[-2:]) == (512, 512) and torch.isfinite(out).all()
                 amp_used = bool(amp and getattr(model.netG, "amp", False) and net_type not in ("VDSR", "DRRN", "MSLapSRN", "MemNet"))
