@@ -54,8 +54,20 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * p.n_tile;
+  // One-dimensional grid: the column tiles of a row tile (they read the same A rows) are neighbours in the launch
+  // order and, with the XCD-aware order, in one L2 -- the second and third fetch of an A row is an L2 hit instead of
+  // another trip to HBM (SRHIP_NTW_GRID=0: row tile fastest, as a two-dimensional grid dealt it)
+  const int ncol = (p.N + p.n_tile - 1) / p.n_tile;
+  int bt = (int)blockIdx.x, bcol;
+  if (p.xcd_order) {
+    bt = sr_xcd_block(bt, gridDim.x);
+    bcol = bt % ncol; bt /= ncol;
+  } else {
+    const int nrow = gridDim.x / ncol;
+    bcol = bt / nrow; bt -= bcol * nrow;
+  }
+  const int m0 = bt * BM;
+  const int n0 = bcol * p.n_tile;
   const int nvalid = min(p.n_tile, p.N - n0);
   const int nst = (p.K + SK - 1) / SK;
   const int nsub = p.Kp / 16;                     // W planes are zero padded up to Kp (a multiple of 32)
@@ -63,7 +75,7 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
   // cache lines at the same moment.  Block b therefore starts its K walk at stage rot(b) and wraps around (the
   // blocks of one XCD -- same blockIdx.x mod 8 -- get different rotations): at any moment the launch reads all
   // stages of W.  Sums are f32 either way; only their order differs per row block (deterministic).
-  const int rot = p.k_rot ? (int)((blockIdx.x >> 3) % (unsigned)nst) : 0;
+  const int rot = p.k_rot ? (int)(((unsigned)bt >> 3) % (unsigned)nst) : 0;
   auto stage_of = [&](int cs) {                   // block-uniform; prefetches run up to 5 stages past the end
     int x = cs + rot;
     while (x >= nst) x -= nst;
@@ -597,7 +609,9 @@ int sr_conv3x3_ntcw(NtArgs& p, hipStream_t st) {
 // 192-column tiles of the f32-accurate path (gemm_ntp.hip decides): n_tile is set by the caller.
 int sr_gemm_ntw(NtArgs& p, hipStream_t st) {
   static_assert(NTW_LDS >= 2 * A_STAGE && NTW_LDS >= BM * TP * 4, "LDS regions");
-  dim3 grid(sr_cdiv(p.M, BM), sr_cdiv(p.N, p.n_tile));
+  dim3 grid(sr_cdiv(p.M, BM) * sr_cdiv(p.N, p.n_tile));
+  static const int gridorder = [] { const char* e = getenv("SRHIP_NTW_GRID"); return e ? atoi(e) : 1; }();
+  p.xcd_order = gridorder;
   static const int dbg = [] { const char* e = getenv("SRHIP_NTW_DBG"); return e ? atoi(e) : 0; }();
   static const int rot = [] { const char* e = getenv("SRHIP_NTW_ROT"); return e ? atoi(e) : 1; }();
   p.k_rot = rot;
