@@ -324,31 +324,46 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dyp, c
   const int lane = threadIdx.x & 63;
   const long w = blockIdx.x * 4L + (threadIdx.x >> 6);
   float ag[LN_MAXV] = {0.f, 0.f, 0.f, 0.f}, ab[LN_MAXV] = {0.f, 0.f, 0.f, 0.f};
-  for (long m = w * rows_per_wave; m < M && m < (w + 1) * rows_per_wave; ++m) {
-    const float mean = st[2 * m], rstd = st[2 * m + 1];
-    float dxh[LN_MAXV], xh[LN_MAXV];
-    float s1 = 0.f, s2 = 0.f;
+  // four rows in flight per wave: every load of the group is issued before the first reduction (one row at a time the
+  // kernel ran at the latency of 3 loads + 12 shuffles per row: 88 us for 32768 x 180, 1.1 TB/s)
+  constexpr int RU = 4;
+  const long m_end = min(M, (w + 1) * (long)rows_per_wave);
+  for (long m0 = w * rows_per_wave; m0 < m_end; m0 += RU) {
+    float dxh[RU][LN_MAXV], xh[RU][LN_MAXV], rr[RU][LN_MAXV], rstd[RU], s1[RU], s2[RU];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = lane + 64 * i;
-      dxh[i] = 0.f; xh[i] = 0.f;
-      if (c < C) {
-        const float dy = dyp[m * C + c];
-        xh[i] = (x[m * C + c] - mean) * rstd;
-        dxh[i] = g ? dy * g[c] : dy;
-        if (g) { ag[i] += dy * xh[i]; ab[i] += dy; }
-        s1 += dxh[i];
-        s2 += dxh[i] * xh[i];
+    for (int u = 0; u < RU; ++u) {
+      const long m = min(m0 + u, m_end - 1);           // rows past the end repeat the last one, never stored
+      const float mean = st[2 * m];
+      rstd[u] = st[2 * m + 1];
+      s1[u] = 0.f; s2[u] = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        dxh[u][i] = 0.f; xh[u][i] = 0.f; rr[u][i] = 0.f;
+        if (c < C) {
+          const float dy = dyp[m * C + c];
+          xh[u][i] = (x[m * C + c] - mean) * rstd[u];
+          rr[u][i] = res ? res[m * C + c] : 0.f;
+          dxh[u][i] = g ? dy * g[c] : dy;
+          if (g && m0 + u < m_end) { ag[i] += dy * xh[u][i]; ab[i] += dy; }
+          s1[u] += dxh[u][i];
+          s2[u] += dxh[u][i] * xh[u][i];
+        }
       }
     }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = lane + 64 * i;
-      if (c < C) {
-        const float d = rstd * (dxh[i] - s1 - xh[i] * s2);
-        out[m * C + c] = res ? res[m * C + c] + d : d;
+    for (int u = 0; u < RU; ++u) {
+      s1[u] = wave_sum(s1[u]) / (float)C;
+      s2[u] = wave_sum(s2[u]) / (float)C;
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      if (m0 + u < m_end) {
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+          const int c = lane + 64 * i;
+          if (c < C) out[(m0 + u) * C + c] = rr[u][i] + rstd[u] * (dxh[u][i] - s1[u] - xh[u][i] * s2[u]);
+        }
       }
     }
   }
