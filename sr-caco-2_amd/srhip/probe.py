@@ -114,7 +114,7 @@ def collect():
     traffic, src = _pmc_traffic(stem)
     out = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
            "traffic": traffic, "traffic_source": src,
-           "kernel": f"{stem}*: {what}; {arith}", "launches": n, "avg_launch_us": 1000.0 * ms / n,
+           "kernel": f"{stem.split('|')[0]}*: {what}; {arith}", "launches": n, "avg_launch_us": 1000.0 * ms / n,
            "algorithmic_gflop_per_launch": fl / n / 1e9,
            "algorithmic_mbytes_per_launch": by / n / 1e6,
            "hbm_side": {"achieved_gb_per_s_algorithmic": gbs, "frac_of_8tb_per_s": gbs / HBM_PEAK_GBS},
