@@ -1,0 +1,54 @@
+"""The LDS-staged kernels that the W-direct ones replaced by default (k_ntp<3>, k_ntb<1,3>, k_ntb<2,1>, k_ntb<1,1>) stay
+selectable (SRHIP_NTW=0, SRHIP_NTCW=0, SRHIP_NTCW2=0, SRHIP_NTCW2_SMALL=0: same-box A/Bs, tools/ab_ntw.sh / ab_ntcw.sh) --
+the switches are read once per process, so each arm runs in a child process and checks a GEMM with every epilogue family
+and three conv shapes against float64."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = textwrap.dedent('''
+    import sys
+    sys.path.insert(0, "sr-caco-2_amd")
+    import torch, torch.nn.functional as F
+    from srhip import ops
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s, scale=1.0: torch.randn(*s, generator=g) * scale
+    rel = lambda a, b: ((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max()).item()
+    # GEMM 180 x 360 with residual + row statistics, and 540 x 180 with the LayerNorm prologue
+    M = 4133
+    A, W, b, R = rnd(M, 360), rnd(180, 360, scale=0.1), rnd(180), rnd(M, 180)
+    st = torch.empty(M, 2, device="cuda")
+    y = ops.gemm_nt(A.cuda(), ops.split_bf16x3(W.cuda()), b.cuda(), epi=2, R=R.cuda(), stats_out=st)
+    ref = R.double() + F.linear(A.double(), W.double(), b.double())
+    assert rel(y, ref) < 2e-6, rel(y, ref)
+    assert rel(st[:, 0], ref.mean(1)) < 1e-5
+    A2, W2 = rnd(M, 180) * 2 + 0.3, rnd(540, 180, scale=0.1)
+    s2 = torch.stack([A2.mean(1), 1 / torch.sqrt(A2.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+    y2 = ops.gemm_nt(A2.cuda(), ops.split_bf16x3(W2.cuda()), None, a_mode=1, ln_stats=s2.cuda())
+    ref2 = F.linear((A2.double() - s2[:, :1].double()) * s2[:, 1:].double(), W2.double())
+    assert rel(y2, ref2) < 2e-6, rel(y2, ref2)
+    # convs: 180 -> 180 at 8 x 64 x 64 (64-pixel x 192-column tiles), 64 -> 64 at 8 x 128 x 128 and 2 x 24 x 40
+    for B, H, Wd, Ci, Co in ((8, 64, 64, 180, 180), (8, 128, 128, 64, 64), (2, 24, 40, 64, 64)):
+        x, w, bb = rnd(B, Ci, H, Wd), rnd(Co, Ci, 3, 3, scale=0.05), rnd(Co)
+        wp = torch.empty(9, Co, Ci, device="cuda"); wpt = torch.empty(9, Ci, Co, device="cuda")
+        ops.pack_conv_weight(w.cuda(), wp, wpt)
+        yc = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), ops.split_bf16x3(wp), bb.cuda(), Co, epi=1)
+        refc = F.relu(F.conv2d(x.double(), w.double(), bb.double(), padding=1))
+        assert rel(yc.permute(0, 3, 1, 2), refc) < 3e-6, (B, H, Wd, Ci, Co, rel(yc.permute(0, 3, 1, 2), refc))
+    print("ok")
+''')
+
+
+@pytest.mark.parametrize("env", [{}, {"SRHIP_NTW": "0"}, {"SRHIP_NTCW": "0", "SRHIP_NTCW2": "0", "SRHIP_NTCW2_SMALL": "0"},
+                                 {"SRHIP_NTW_GRID": "0", "SRHIP_NTW_ROT": "0", "SRHIP_NTCW2_WIDE": "0"}])
+def test_switchable_kernels_match_float64(env):
+    r = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-500:], r.stderr[-1500:])
