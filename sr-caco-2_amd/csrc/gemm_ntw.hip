@@ -45,7 +45,7 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
 __device__ __forceinline__ int a_slot(int row, int u) { return row * 4 + (u ^ ((row >> 2) & 3)); }
 
 // DBG = true (SRHIP_NTW_DBG=bits, timing experiments only, results are wrong): 1 = W fragments always from stage 0
-// (cache-hot), 2 = no MFMAs, 4 = no epilogue, 8 = no A staging stores
+// (cache-hot), 2 = no MFMAs, 4 = no epilogue, 8 = no A staging stores, 16 = three products instead of six
 // AMP = true: reduced-precision inference (one bf16 product of the leading planes; see gemm_ntb.hip)
 template <bool DBG, bool AMP = false>
 __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
@@ -165,6 +165,8 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
   _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fa[PA], fb[j][PB], acc[i][j]);
       if constexpr (AMP) {
         SR_TERM(0, 0)
+      } else if (DBG && (p.dbg & 16)) {      // three of the six products: what a two-plane (fp16-style) split would cost
+        SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
       } else {
         SR_TERM(1, 1) SR_TERM(0, 2) SR_TERM(2, 0) SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
       }
