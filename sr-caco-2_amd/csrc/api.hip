@@ -68,7 +68,7 @@ int srhip_split_bf16x3(const float* W, long ldw, int rows, int K, void* out, voi
 
 int srhip_prep_blocks(const srhip_prep_entry* e) {
   static_assert(sizeof(srhip_prep_entry) == sizeof(PrepEntry), "prep table layout");
-  SR_REQUIRE(e && e->kind >= 0 && e->kind <= 2, "prep_blocks: kind");
+  SR_REQUIRE(e && e->kind >= 0 && e->kind <= 3, "prep_blocks: kind");
   return sr_prep_blocks(*(const PrepEntry*)e);
 }
 

@@ -102,6 +102,59 @@ __device__ __forceinline__ void job_bias_expand(const PrepEntry& e, int lb) {
   ((float*)e.out2)[i] = ldg_f(e.a + rpi(row + 32 * a, col + 32 * b) * heads + hd);   // imgN
 }
 
+// kind 3 (experiment, SRHIP_F16X2=1): TWO fp16 planes with a power-of-two scale per ROW instead of three bf16 planes --
+//   v' = v * 2^s(row), v' = h + l, h = fp16(v'), l = fp16(v' - h);  out planes [2][Kp/16][rows][16] fp16 (same sub-chunk
+//   major layout, plane stride rows*Kp halves), then rows floats 2^-s(row) behind the two planes.  One wave per row:
+//   the row maximum decides s (max * 2^s in [8192, 16384]).  Same value definition as kind 0 (gamma modes; no perms).
+__device__ __forceinline__ void job_planes_f16(const PrepEntry& e, int lb) {
+  const int Kp = sr_kp(e.n2);
+  const int rows = e.n0;
+  const int row = lb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int gm = e.mode & 3;
+  constexpr int MAXJ = 4;                            // 4 x 256 k per row
+  float v[MAXJ][4];
+  float mx = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = j * 256 + lane * 4 + q;
+      float x = 0.f;
+      if (k < e.n2) {
+        x = ldg_f(e.a + (long)e.off + (long)row * e.s1 + (long)k * e.s2);
+        if (gm == 1) x *= ldg_f(e.b + k);
+        else if (gm == 2) x *= ldg_f(e.b + row);
+      }
+      v[j][q] = x;
+      mx = fmaxf(mx, fabsf(x));
+    }
+  }
+  mx = wave_max(mx);
+  const float sc = mx > 0.f ? exp2f(floorf(log2f(16384.f / mx))) : 1.f;
+  const long plane = (long)rows * Kp;
+  unsigned short* base = (unsigned short*)e.out;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int k0 = j * 256 + lane * 4;
+    if (k0 < Kp) {
+      unsigned short hh[4], ll[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xs = v[j][q] * sc;
+        const _Float16 h = (_Float16)xs;
+        const _Float16 l = (_Float16)(xs - (float)h);
+        hh[q] = __builtin_bit_cast(unsigned short, h);
+        ll[q] = __builtin_bit_cast(unsigned short, l);
+      }
+      unsigned short* d = base + ((long)(k0 >> 4) * rows + row) * 16 + (k0 & 15);
+      *(u32x2*)(d) = u32x2{(unsigned)hh[0] | ((unsigned)hh[1] << 16), (unsigned)hh[2] | ((unsigned)hh[3] << 16)};
+      *(u32x2*)(d + plane) = u32x2{(unsigned)ll[0] | ((unsigned)ll[1] << 16), (unsigned)ll[2] | ((unsigned)ll[3] << 16)};
+    }
+  }
+  if (lane == 0) ((float*)(base + 2 * plane))[row] = 1.0f / sc;
+}
+
 __global__ void __launch_bounds__(256) k_prep_table(const PrepEntry* __restrict__ tab, int n) {
   int lo = 0, hi = n - 1;
   while (lo < hi) {
@@ -112,6 +165,7 @@ __global__ void __launch_bounds__(256) k_prep_table(const PrepEntry* __restrict_
   const int lb = blockIdx.x - e.blk0;
   if (e.kind == 0) job_planes(e, lb);
   else if (e.kind == 1) job_fold_bias(e, lb);
+  else if (e.kind == 3) job_planes_f16(e, lb);
   else job_bias_expand(e, lb);
 }
 
@@ -121,6 +175,7 @@ int sr_prep_blocks(const PrepEntry& e) {
   if (e.kind == 0) return sr_cdiv((long)e.n0 * e.n1 * (sr_kp(e.n2) / 4), 256);
   if (e.kind == 1) return sr_cdiv(e.n0, 4);
   if (e.kind == 2) return sr_cdiv((long)e.n0 * 4096, 256);
+  if (e.kind == 3) return (e.n1 == 1 && e.n2 <= 1024 && (e.mode >> 2) == 0) ? sr_cdiv(e.n0, 4) : -1;
   return -1;
 }
 

@@ -47,6 +47,7 @@ import os as _os
 # weight-gradient (TN) side: bf16x3 from 64 channels on, once 64-wide tiles got their own plan (three blocks per
 # CU) and unequal operand widths the smaller tile class -- 64->64 at 8x128x128: 186 us (f32) vs 148 us
 BX3_MIN_CHANNELS = int(_os.environ.get("SRHIP_BX3_MIN_CH", "64"))
+F16X2 = _os.environ.get("SRHIP_F16X2", "0") not in ("", "0")      # experiment: three-product fp16 GEMM (k_nth)
 
 
 # The NT side (conv / Linear forward and data gradient) has its own threshold: at 64 -> 64 channels, B=8, 128x128
@@ -143,7 +144,10 @@ class PrepTable:
         rows, kd = (K, N) if transpose else (N, K)
         assert (out.rows, out.K) == (rows, kd)
         self.keep += [W, out, gamma]
-        self._add(kind=0, a=_p(W), b=_p(gamma), out=_p(out.planes), n0=rows, n1=1, n2=kd, s0=0,
+        # experiment SRHIP_F16X2=1: two fp16 planes + per-row power-of-two scales (prep kind 3) for the operands of the
+        # GEMMs that run on 192-column tiles (k_nth, gemm_ntw.hip) -- same routing rule as sr_gemm_ntp
+        f16 = F16X2 and (rows % 180 == 0 or (rows > 128 and rows % 128 != 0)) and kd <= 1024
+        self._add(kind=3 if f16 else 0, a=_p(W), b=_p(gamma), out=_p(out.planes), n0=rows, n1=1, n2=kd, s0=0,
                   s1=1 if transpose else K, s2=K if transpose else 1, off=0,
                   mode=0 if gamma is None else (2 if transpose else 1))
 
@@ -214,7 +218,10 @@ class PrepTable:
         blk = 0
         for i, e in enumerate(self.jobs):
             e.blk0 = blk
-            blk += lib.srhip_prep_blocks(ctypes.addressof(e))
+            nb = lib.srhip_prep_blocks(ctypes.addressof(e))
+            if nb <= 0:
+                raise SrhipError(f"srhip_prep_blocks: job {i} (kind {e.kind}) rejected: {lib.srhip_last_error().decode()}")
+            blk += nb
             arr[i] = e
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self.n, self.blocks = n, blk

@@ -52,3 +52,39 @@ def test_switchable_kernels_match_float64(env):
     r = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-500:], r.stderr[-1500:])
+
+
+F16_CHILD = textwrap.dedent('''
+    import sys
+    sys.path.insert(0, "sr-caco-2_amd")
+    import torch, torch.nn.functional as F
+    from srhip import ops
+    assert ops.F16X2
+    torch.manual_seed(0)
+    for (M, N, K, a_mode) in ((256, 180, 64, 0), (300, 180, 180, 0), (4096, 540, 180, 1), (515, 180, 360, 2), (4133, 360, 180, 0)):
+        A = (torch.randn(M, K) * 0.7 + 0.1) * torch.exp(torch.randn(M, 1) * 3)        # rows 1e-4 .. 1e4 apart
+        W = torch.randn(N, K) * 0.05 * torch.exp(torch.randn(N, 1))
+        b = torch.randn(N) * 0.0
+        out = ops.Bx3(N, K, "cuda")
+        tb = ops.PrepTable(); Wc = W.cuda().contiguous(); tb.linear(Wc, out); tb.build("cuda").run()
+        st = torch.stack([A.mean(1), 1 / torch.sqrt(A.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+        y = ops.gemm_nt(A.cuda(), out, b.cuda(), a_mode=a_mode, ln_stats=st.cuda() if a_mode == 1 else None)
+        Ad = A.double()
+        if a_mode == 1: Ad = (Ad - st[:, :1].double()) * st[:, 1:].double()
+        if a_mode == 2: Ad = F.gelu(Ad)
+        ref = F.linear(Ad, W.double(), b.double())
+        f32 = F.linear(Ad.float(), W, b).double()
+        # every ROW against itself: the per-row block exponent keeps small rows as accurate as large ones
+        e = ((y.double().cpu() - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-300)).max().item()
+        e32 = ((f32 - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-300)).max().item()
+        assert e <= max(3.0 * e32, 1e-6), (M, N, K, a_mode, e, e32)
+    print("ok")
+''')
+
+
+def test_fp16x2_three_product_gemm_is_f32_grade_per_row():
+    """Experiment SRHIP_F16X2=1 (k_nth: two fp16 planes, per-row power-of-two scales, three products): the worst ROW,
+    relative to itself, is within 3x of what a plain f32 matmul gives, on operands whose rows are 8 decades apart."""
+    r = subprocess.run([sys.executable, "-c", F16_CHILD], cwd=ROOT, env=dict(os.environ, SRHIP_F16X2="1"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
