@@ -116,6 +116,20 @@ int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bia
 int srhip_gemm_nt_bx3_lnbwd(const float* A, long lda, const void* Wb, float* out, long ldo, int M, int N, int K,
                             const float* x, long ldx, const float* stats, const float* res, long ldres,
                             void* stream);
+/* The same two contractions with the weight operand as TWO fp16 planes and a power-of-two scale per weight row
+ * (srhip_prep_table job kind 3: planes [2][Kp/16][N][16] fp16 of W[n][:] * 2^s(n), then N floats 2^-s(n)); the
+ * activation rows get their own power-of-two scale inside the kernel (a priori behind the LayerNorm prologue, else from
+ * a pass over the row), the product is h.h + h.l + l.h on the fp16 MFMA with f32 accumulation and the block exponents
+ * are undone exactly: three products instead of six, results indistinguishable from an f32 matmul (every row relative to
+ * itself; tools/split_accuracy.py, tests/test_gpu_fallback_kernels.py).  N must run on 192-column tiles (a multiple of
+ * 180, or > 128 and not a multiple of 128).  Same arguments, prologues and epilogues as the _bx3 entry points. */
+int srhip_gemm_nt_f16x2(const float* A, long lda, const void* Wh, const float* bias, float* C,
+                        long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
+                        const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha,
+                        float* aux, long ldaux, float* stats_out, void* stream);
+int srhip_gemm_nt_f16x2_lnbwd(const float* A, long lda, const void* Wh, float* out, long ldo, int M, int N, int K,
+                              const float* x, long ldx, const float* stats, const float* res, long ldres,
+                              void* stream);
 /* The MLP half of a Swin block in one kernel per direction (mlp_fused.hip): the hidden
  * activation goes from the first product's accumulators through registers and LDS into
  * the second product and never returns from HBM.

@@ -18,7 +18,7 @@ int sr_fail(int code, const char* fmt, ...) {
 extern "C" {
 
 const char* srhip_last_error(void) { return g_err; }
-int srhip_abi_version(void) { return 10; }
+int srhip_abi_version(void) { return 11; }
 
 static int g_matmul_mode = 0;
 int srhip_set_matmul_mode(int mode) {
@@ -76,7 +76,7 @@ int srhip_prep_table(const srhip_prep_entry* table_dev, int n, int total_blocks,
   return sr_prep_table((const PrepEntry*)table_dev, n, total_blocks, (hipStream_t)stream);
 }
 
-int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bias, float* C,
+static int gemm_nt_split(int wfmt, const float* A, long lda, const void* Wb, const float* bias, float* C,
                       long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
                       const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha, float* aux,
                       long ldaux, float* stats_out, void* stream) {
@@ -92,10 +92,26 @@ int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bia
   p.epi = epi; p.R = R; p.ldr = ldr; p.rowscale = rowscale; p.rows_per_scale = rows_per_scale;
   p.alpha = alpha; p.aux = aux; p.ldaux = ldaux; p.stats_out = stats_out;
   SR_REQUIRE(!aux || epi == 3, "gemm_nt_bx3: aux output is produced by epilogue 3 only");
+  p.wfmt = wfmt;
+  SR_REQUIRE(!wfmt || N % 180 == 0 || (N > 128 && N % 128 != 0), "gemm_nt_f16x2: N = %d does not run on 192-column tiles", N);
   return sr_gemm_ntb(p, (hipStream_t)stream);
 }
+int srhip_gemm_nt_bx3(const float* A, long lda, const void* Wb, const float* bias, float* C,
+                      long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
+                      const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha, float* aux,
+                      long ldaux, float* stats_out, void* stream) {
+  return gemm_nt_split(0, A, lda, Wb, bias, C, ldc, M, N, K, a_mode, ln_stats, epi, R, ldr, rowscale, rows_per_scale, alpha,
+                       aux, ldaux, stats_out, stream);
+}
+int srhip_gemm_nt_f16x2(const float* A, long lda, const void* Wh, const float* bias, float* C,
+                        long ldc, int M, int N, int K, int a_mode, const float* ln_stats, int epi,
+                        const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha, float* aux,
+                        long ldaux, float* stats_out, void* stream) {
+  return gemm_nt_split(1, A, lda, Wh, bias, C, ldc, M, N, K, a_mode, ln_stats, epi, R, ldr, rowscale, rows_per_scale, alpha,
+                       aux, ldaux, stats_out, stream);
+}
 
-int srhip_gemm_nt_bx3_lnbwd(const float* A, long lda, const void* Wb, float* out, long ldo, int M, int N, int K,
+static int gemm_nt_split_lnbwd(int wfmt, const float* A, long lda, const void* Wb, float* out, long ldo, int M, int N, int K,
                             const float* x, long ldx, const float* stats, const float* res, long ldres,
                             void* stream) {
   NtArgs p;
@@ -103,7 +119,19 @@ int srhip_gemm_nt_bx3_lnbwd(const float* A, long lda, const void* Wb, float* out
   p.A = A; p.lda = lda; p.Wb = (const unsigned short*)Wb; p.C = out; p.ldc = ldo;
   p.M = M; p.N = N; p.K = K; p.R = x; p.ldr = ldx; p.R2 = res; p.ldr2 = ldres; p.ep_stats = stats;
   p.alpha = 1.f;
+  p.wfmt = wfmt;
+  SR_REQUIRE(!wfmt || N % 180 == 0 || N > 128, "gemm_nt_f16x2_lnbwd: N = %d does not run on 192-column tiles", N);
   return sr_gemm_ntb_lnbwd(p, (hipStream_t)stream);
+}
+int srhip_gemm_nt_bx3_lnbwd(const float* A, long lda, const void* Wb, float* out, long ldo, int M, int N, int K,
+                            const float* x, long ldx, const float* stats, const float* res, long ldres,
+                            void* stream) {
+  return gemm_nt_split_lnbwd(0, A, lda, Wb, out, ldo, M, N, K, x, ldx, stats, res, ldres, stream);
+}
+int srhip_gemm_nt_f16x2_lnbwd(const float* A, long lda, const void* Wh, float* out, long ldo, int M, int N, int K,
+                              const float* x, long ldx, const float* stats, const float* res, long ldres,
+                              void* stream) {
+  return gemm_nt_split_lnbwd(1, A, lda, Wh, out, ldo, M, N, K, x, ldx, stats, res, ldres, stream);
 }
 
 int srhip_mlp_fwd_bx3(const float* x, long ldx, const float* stats, const void* W1p, const float* b1,

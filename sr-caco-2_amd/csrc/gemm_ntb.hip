@@ -508,6 +508,7 @@ int sr_gemm_ntb(NtArgs& p, hipStream_t st) {
   // K <= 192 at 180-column widths (the K = 180 Linears of a Swin block): weights resident in registers,
   // persistent blocks, only A through LDS (gemm_ntr.hip)
   p.amp = sr_matmul_mode();
+  if (p.wfmt == 1) return sr_gemm_ntp(p, st);          // two-plane fp16 operand: k_nth (gemm_ntw.hip), whatever the mode
   if (p.amp && p.epi != 5) return sr_gemm_ntp(p, st);
   if (sr_gemm_ntr_ok(p)) return sr_gemm_ntr(p, st);
   // 64-row tiles (every case but very tall problems with narrow N, which take the 128-row
@@ -528,7 +529,7 @@ int sr_gemm_ntb_lnbwd(NtArgs& p, hipStream_t st) {
   p.Kp = sr_kp(p.K);
   p.epi = 5;
   p.dbg = 0; p.stagger = 0;
-  if (ntb_env("SRHIP_NTP", 1)) return sr_gemm_ntp(p, st);
+  if (ntb_env("SRHIP_NTP", 1) || p.wfmt == 1) return sr_gemm_ntp(p, st);
   if (p.N % 180 == 0 || p.N > 128) { p.n_tile = (p.N % 180 == 0) ? 180 : 192; return launch_ntb<1, 3, false>(p, st); }
   if (p.N > 64) { p.n_tile = 128; return launch_ntb<1, 2, false>(p, st); }
   p.n_tile = 64;

@@ -215,7 +215,7 @@ int launch_ntp(const NtArgs& p, hipStream_t st) {
 int sr_gemm_ntp(NtArgs& p, hipStream_t st) {
   // 192-column tiles of the f32-accurate path: W fragments straight from global memory (gemm_ntw.hip); SRHIP_NTW=0: this file's kernel
   static const bool ntw = [] { const char* e = getenv("SRHIP_NTW"); return !(e && e[0] == '0'); }();
-  const bool w = ntw && !p.dbg;
+  const bool w = (ntw && !p.dbg) || p.wfmt == 1;
   if (p.N % 180 == 0) { p.n_tile = 180; return w ? sr_gemm_ntw(p, st) : launch_ntp<3>(p, st); }
   if (p.N <= 64) { p.n_tile = 64; return launch_ntp<1>(p, st); }
   if (p.N <= 128 || p.N % 128 == 0) { p.n_tile = 128; return launch_ntp<2>(p, st); }

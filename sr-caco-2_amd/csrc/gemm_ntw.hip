@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_nth (experiment, SRHIP_F16X2=1): the same GEMM on TWO fp16 planes per operand and THREE products
+// k_nth (weight operands of format 1, srhip_gemm_nt_f16x2): the same GEMM on TWO fp16 planes per operand and THREE products
 // (h.h + h.l + l.h on v_mfma_f32_16x16x32_f16) instead of three bf16 planes and six.  What makes two planes enough is
 // a power-of-two scale per ROW of either operand (a block exponent: exact to apply and to undo): x' = x * 2^s with
 // max|x'| in [8192, 16384], x' = h + l, h = fp16(x'), l = fp16(x' - h) carries 22 bits relative to the row's largest
@@ -258,11 +258,14 @@ constexpr int H_ASTAGE = 2 * H_APLANE;
 __device__ __forceinline__ f32x4 mfma16h(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+typedef _Float16 sr_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
-  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-  const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-  h = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-  l = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+  // packed conversions (v_cvt_pk_f16_f32, round to nearest even); the residuals are exact in f32
+  const sr_f16x2 hv = __builtin_convertvector(sr_f32x2{x0, x1}, sr_f16x2);
+  const float r0 = x0 - (float)hv.x, r1 = x1 - (float)hv.y;
+  const sr_f16x2 lv = __builtin_convertvector(sr_f32x2{r0, r1}, sr_f16x2);
+  h = __builtin_bit_cast(unsigned, hv);
+  l = __builtin_bit_cast(unsigned, lv);
 }
 
 __global__ void __launch_bounds__(256, 2) k_nth(NtArgs p) {
@@ -310,19 +313,19 @@ __global__ void __launch_bounds__(256, 2) k_nth(NtArgs p) {
 
   // ---- the row scale 2^s: a priori behind the LayerNorm prologue, else from a pass over the row
   float asc;
-  if (p.a_mode == 1) {
+  if (p.a_mode == 1 || p.stagger == -8) {       // stagger == -8: timing ablation (SRHIP_F16X2_NOPREPASS=1), no pre-pass
     asc = exp2f(floorf(log2f(16384.f * rsqrtf((float)p.K))));
   } else {
     float mx = 0.f;
-    for (int k0 = akq * 4; k0 < p.K; k0 += 16 * 8) {         // eight loads in flight (a row is 12 - 23 float4 per thread)
-      f32x4 v[8];
+    for (int k0 = akq * 4; k0 < p.K; k0 += 16 * 12) {        // twelve loads in flight: K = 180 in one batch, 360 in two
+      f32x4 v[12];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 12; ++u) {
         const int k = k0 + 16 * u;
         v[u] = *(const f32x4*)(abase + (k < p.K ? k * 4 : 0));       // past the end: k = 0 of the row again (harmless for a max)
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 12; ++u)
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));    // |gelu(x)| <= |x|
     }
     mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
@@ -806,8 +809,9 @@ int sr_gemm_ntw(NtArgs& p, hipStream_t st) {
   static const int dbg = [] { const char* e = getenv("SRHIP_NTW_DBG"); return e ? atoi(e) : 0; }();
   static const int rot = [] { const char* e = getenv("SRHIP_NTW_ROT"); return e ? atoi(e) : 1; }();
   p.k_rot = rot;
-  static const int f16x2 = [] { const char* e = getenv("SRHIP_F16X2"); return e ? atoi(e) : 0; }();
-  if (f16x2 && !p.amp) {          // experiment: the caller's planes are prep kind 3 (two fp16 planes + row scales)
+  if (p.wfmt == 1) {              // the caller's planes are prep kind 3 (two fp16 planes + row scales): also under --amp
+    static const int nopre = [] { const char* e = getenv("SRHIP_F16X2_NOPREPASS"); return e ? atoi(e) : 0; }();
+    p.stagger = nopre ? -8 : 0;   // timing ablation only: constant row scale, results can be wrong
     hipLaunchKernelGGL(k_nth, grid, dim3(256), NTW_LDS + 256, st, p);
     SR_LAUNCH_CHECK("k_nth");
     return 0;

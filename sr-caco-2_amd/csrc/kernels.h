@@ -36,6 +36,7 @@ struct NtArgs {
   // shuffled image [batch][2H][2Wd][K/4] in the same order, k = sp*(K/4) + c (the data gradient of 1)
   int ps;
   int k_rot;                  // k_ntw: rotate the K walk per block (gemm_ntw.hip)
+  int wfmt;                   // weight operand format: 0 three bf16 planes | 1 two fp16 planes + per-row 2^-s (prep kind 3; k_nth)
 };
 
 struct TnArgs {

@@ -94,17 +94,19 @@ def _tn_sfx(bx=None):
 class Bx3:
     """Weight operand pre-split into three bf16 planes [3][rows][Kp] for the bf16x3
     contractions (srhip_split_bf16x3).  rows = N (Linear) or 9*Cout (conv pack)."""
-    __slots__ = ("planes", "rows", "K")
+    __slots__ = ("planes", "rows", "K", "fmt")
 
     def __init__(self, rows, K, device):
         kp = lib.srhip_bf16x3_kp(K)
         self.planes = torch.empty(3, rows, kp, device=device, dtype=torch.int16)
         self.rows, self.K = rows, K
+        self.fmt = 0      # 0: three bf16 planes | 1: two fp16 planes + per-row 2^-s (PrepTable.linear under SRHIP_F16X2)
 
     def fill(self, W2d):
         """W2d: [rows][K] f32 view (row stride = W2d.stride(0))."""
         assert W2d.shape == (self.rows, self.K) and W2d.stride(1) == 1 and W2d.dtype == torch.float32
         call("srhip_split_bf16x3", _p(W2d), W2d.stride(0), self.rows, self.K, _p(self.planes), _st())
+        self.fmt = 0
         return self
 
 
@@ -147,6 +149,7 @@ class PrepTable:
         # experiment SRHIP_F16X2=1: two fp16 planes + per-row power-of-two scales (prep kind 3) for the operands of the
         # GEMMs that run on 192-column tiles (k_nth, gemm_ntw.hip) -- same routing rule as sr_gemm_ntp
         f16 = F16X2 and (rows % 180 == 0 or (rows > 128 and rows % 128 != 0)) and kd <= 1024
+        out.fmt = 1 if f16 else 0
         self._add(kind=3 if f16 else 0, a=_p(W), b=_p(gamma), out=_p(out.planes), n0=rows, n1=1, n2=kd, s0=0,
                   s1=1 if transpose else K, s2=K if transpose else 1, off=0,
                   mode=0 if gamma is None else (2 if transpose else 1))
@@ -268,7 +271,8 @@ def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
             a_mode, _p(ln_stats), epi, _p(R), 0 if R is None else R.stride(0), _p(rowscale),
             rows_per_scale, float(alpha), _p(aux), 0 if aux is None else aux.stride(0), _st())
     if bx:
-        name, args = "srhip_gemm_nt_bx3", (_p(A), A.stride(0), _p(W.planes)) + tail[:-1] + (_p(stats_out), tail[-1])
+        name = "srhip_gemm_nt_f16x2" if W.fmt == 1 else "srhip_gemm_nt_bx3"
+        args = (_p(A), A.stride(0), _p(W.planes)) + tail[:-1] + (_p(stats_out), tail[-1])
     else:
         assert stats_out is None, "row statistics are produced by the bx3 kernel only"
         name, args = "srhip_gemm_nt", (_p(A), A.stride(0), _p(W), W.stride(0)) + tail
@@ -288,11 +292,12 @@ def gemm_nt_lnbwd(A, W, x, stats, res, out):
     assert W.K == K and x.shape == (M, W.rows) and out.shape == (M, W.rows)
     args = (_p(A), A.stride(0), _p(W.planes), _p(out), out.stride(0), M, W.rows, K,
             _p(x), x.stride(0), _p(stats), _p(res), 0 if res is None else res.stride(0), _st())
+    name = "srhip_gemm_nt_f16x2_lnbwd" if W.fmt == 1 else "srhip_gemm_nt_bx3_lnbwd"
     if probe.on("gemm_nt"):      # same kernel as gemm_nt: belongs to the same roofline entry
         with probe.timed(("gemm_nt", M, W.rows, K), 2.0 * M * W.rows * K, 4.0 * (M * K + W.rows * K + 3 * M * W.rows)):
-            call("srhip_gemm_nt_bx3_lnbwd", *args)
+            call(name, *args)
     else:
-        call("srhip_gemm_nt_bx3_lnbwd", *args)
+        call(name, *args)
     return out
 
 
