@@ -183,6 +183,7 @@ def worker(args):
 
     from srhip import probe
     from srhip.ops import use_bx3 as ops_use_bx3
+    from srhip import ops as ops_mod
     from srhip.train import TrainStep, Optimizer
 
     torch.manual_seed(0)                      # same weights on every rank
@@ -298,7 +299,10 @@ def worker(args):
                        "global_batch": args.batch * world, "batch_per_gpu": args.batch,
                        "parallelism": f"dp{world}", "final_loss": loss, "hip_graph": bool(use_graph),
                        "eval_patches_per_s_one_gpu": eval_pps, "eval_amp_patches_per_s_one_gpu": eval_amp_pps,
-                       "matmul": ("bf16x3 split MFMA: f32 operands split into 3 bf16 parts, 6 products, "
+                       "matmul": (("Linear GEMMs: fp16x2 split MFMA (2 fp16 planes per operand under per-row power-of-two "
+                                   "scales, 3 products, f32 accumulate: f32-grade per row); convs / weight gradients: "
+                                   if getattr(ops_mod, "F16X2", False) and args.workload.startswith("swinir") else "") +
+                                  "bf16x3 split MFMA: f32 operands split into 3 bf16 parts, 6 products, "
                                   "f32 accumulate (f32-accurate)") if bx else "f32 MFMA"},
             # whole step against both rooflines: algorithmic bytes / flops x 3 (fwd + bwd) x patches/s
             "whole_step": {"hbm_frac": gbyte * 3.0 * pps / world / HBM_PEAK_GBS,

@@ -435,6 +435,189 @@ __global__ void __launch_bounds__(256, 2) k_nth(NtArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_nth2: k_nth without the pre-pass.  The block takes its A rows in PASSES of 192 k: a pass's 12 float4 per thread are
+// loaded in one go, the row maximum of the pass comes out of the registers that hold them (four threads share a row: two
+// shuffles), the row's scale is the SMALLER of the scale so far and what this pass needs (scales only go down, so nothing
+// already accumulated can overflow), the accumulators of the rows whose scale dropped are multiplied by the exact power of
+// two that separates the old scale from the new one, and the pass is split into six stage images (two planes: 48 KB, the
+// epilogue's tiles reuse the space) that the six stages read without a barrier in between.  K = 180 is one pass.
+constexpr int NTH2_LDS = NTW_LDS + 1024;         // + [64] current 2^s, [64] rescale factor of the pass, [64] 2^-s
+
+__global__ void __launch_bounds__(256, 2) k_nth2(NtArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const rscale = (float*)(smem + NTW_LDS);        // [64] rescale factor of this pass (1 or 2^-d)
+  float* const rinv = rscale + 64;                       // [64] 2^-s, final
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int ncol = (p.N + p.n_tile - 1) / p.n_tile;
+  int bt = sr_xcd_block((int)blockIdx.x, gridDim.x);
+  const int bcol = bt % ncol; bt /= ncol;
+  const int m0 = bt * BM;
+  const int n0 = bcol * p.n_tile;
+  const int nvalid = min(p.n_tile, p.N - n0);
+  const int nst = (p.K + SK - 1) / SK;
+
+  const int arow = tid >> 2, akq = tid & 3;
+  const int agm = min(m0 + arow, p.M - 1);
+  const char* const abase = (const char*)p.A + (long)agm * p.lda * 4;
+  const float2 rst = ldg_f2(p.a_mode == 1 ? p.ln_stats + 2 * agm : k_sr_neutral);
+  const int a_dst = a_slot(arow, akq) * 16;
+
+  const long plane_bytes = (long)p.N * p.Kp * 2;
+  const float* const winv_all = (const float*)((const char*)p.Wb + 2 * plane_bytes);
+  unsigned boff[3];
+  float winv[3];
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) {
+    const int col = n0 + min(wave * 48 + jt * 16 + c, nvalid - 1);
+    boff[jt] = (unsigned)(((g >> 1) * p.N + col) * 32 + (g & 1) * 16);
+    winv[jt] = winv_all[col];
+  }
+  auto load_b = [&](int cs, u32x4 (&fb)[3][2]) {
+    const char* base = (const char*)p.Wb + (long)(2 * cs) * p.N * 32;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
+  };
+  u32x4 fb0[3][2], fb1[3][2], fb2[3][2];
+  load_b(0, fb0);
+  if (nst > 1) load_b(1, fb1);
+  if (nst > 2) load_b(2, fb2);
+
+  f32x4 acc[4][3];
+  int a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = a_slot(16 * i + c, g) * 16;
+  auto mma = [&](int s6, const u32x4 (&fb)[3][2]) {
+    const unsigned char* sa = smem + s6 * H_ASTAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 fa[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * H_APLANE + a_off[i]);
+#define SR_TERM(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[i][j] = mfma16h(fa[PA], fb[j][PB], acc[i][j]);
+      SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+#undef SR_TERM
+    }
+  };
+
+  // a priori scale behind the LayerNorm prologue (|xhat| <= sqrt(K)); otherwise start from "no limit yet"
+  const float apriori = exp2f(floorf(log2f(16384.f * rsqrtf((float)p.K))));
+  float asc = p.a_mode == 1 ? apriori : 3.0e38f;          // this row's current 2^s (the same in the row's four threads)
+  const int npass = (nst + 5) / 6;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int cs0 = pass * 6;
+    if (pass) __syncthreads();                            // every wave is done with the previous pass's images
+    {
+      f32x4 ra[6][2];
+#pragma unroll
+      for (int s6 = 0; s6 < 6; ++s6) {                    // stages past the end read k = 0 of the row, zeroed below
+        const int k = (cs0 + s6) * SK + akq * 8;
+        ra[s6][0] = *(const f32x4*)(abase + (k < p.K ? k * 4 : 0));
+        ra[s6][1] = *(const f32x4*)(abase + (k + 4 < p.K ? (k + 4) * 4 : 0));
+      }
+      float mx = 0.f;
+#pragma unroll
+      for (int s6 = 0; s6 < 6; ++s6) {
+        const int k = (cs0 + s6) * SK + akq * 8;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          f32x4 x = ra[s6][e];
+          if (p.a_mode == 1) {
+            x.x = (x.x - rst.x) * rst.y; x.y = (x.y - rst.x) * rst.y; x.z = (x.z - rst.x) * rst.y; x.w = (x.w - rst.x) * rst.y;
+          } else if (p.a_mode == 2) {
+            x.x = gelu_f(x.x); x.y = gelu_f(x.y); x.z = gelu_f(x.z); x.w = gelu_f(x.w);
+          }
+          if (k + 4 * e >= p.K) x = f32x4{0.f, 0.f, 0.f, 0.f};          // K tail: exact zeros
+          ra[s6][e] = x;
+          mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
+        }
+      }
+      float old = asc;
+      if (p.a_mode != 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        const float need = mx > 0.f ? exp2f(floorf(log2f(16384.f / mx))) : 3.0e38f;
+        asc = fminf(asc, need);
+      }
+      const float use = asc > 1.0e38f ? 1.f : asc;        // an all-zero row so far: any scale
+      if (akq == 0) {
+        rscale[arow] = (old > 1.0e38f || old == asc) ? 1.f : asc / old;     // exact power of two <= 1
+        rinv[arow] = 1.0f / use;
+      }
+#pragma unroll
+      for (int s6 = 0; s6 < 6; ++s6) {
+        unsigned hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const f32x4 x = ra[s6][e];
+          split2_pair(x.x * use, x.y * use, hh[2 * e], ll[2 * e]);
+          split2_pair(x.z * use, x.w * use, hh[2 * e + 1], ll[2 * e + 1]);
+        }
+        unsigned char* sa = smem + s6 * H_ASTAGE + a_dst;
+        *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+        *(u32x4*)(sa + H_APLANE) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+      }
+    }
+    __syncthreads();
+    if (pass == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (p.a_mode != 1) {                            // rows whose scale dropped: bring what is accumulated to the new scale
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float f = rscale[16 * i + 4 * g + e];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[i][j][e] *= f;
+        }
+    }
+#define SR_STAGE(S, FB)                                              \
+    if (cs0 + (S) < nst) {                                           \
+      mma((S), FB);                                                  \
+      if (cs0 + (S) + 3 < nst) load_b(cs0 + (S) + 3, FB);            \
+    }
+    SR_STAGE(0, fb0) SR_STAGE(1, fb1) SR_STAGE(2, fb2) SR_STAGE(3, fb0) SR_STAGE(4, fb1) SR_STAGE(5, fb2)
+#undef SR_STAGE
+  }
+
+  __syncthreads();
+  float* const T = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ri = rinv[16 * i + 4 * g + e];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) T[(16 * i + 4 * g + e) * TP + wave * 48 + 16 * j + c] = acc[i][j][e] * (ri * winv[j]);
+    }
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31;
+  f32x16 acc2[1][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc2[0][j][q] = T[(wm * 32 + mfma_row(q, lane)) * TP + (wn * 3 + j) * 32 + r];
+  __syncthreads();
+  if (p.epi == 5) {
+    nt_epilogue_lnbwd<3>(p, acc2, lane, wm, wn, m0, nvalid, (float*)smem);
+    return;
+  }
+  if (p.wide_epi) {
+    nt_epilogue_wide<3>(p, acc2, lane, wave, wm, wn, n0, nvalid, m0, (float*)smem);
+    return;
+  }
+  nt_epilogue<1, 3, false>(p, acc2, lane, wm, wn, n0, nvalid, m0, 0, 0, 0);
+  if (p.stats_out) nt_row_stats<3>(p, acc2, lane, wm, wn, m0, nvalid, (float*)smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The same idea for the 3x3 conv as implicit GEMM (64-pixel x 192-column tiles: SwinIR's 180 -> 180 convs,
 // operands / epilogues of gemm_ntb.hip's k_ntb<1, 3, true>): the halo tile of a 32-channel chunk is split once
 // into LDS (6 x 18 pixels, 80-byte pixel pitch: conflict free for the 16-lane fragment phases), and the nine
@@ -812,6 +995,12 @@ int sr_gemm_ntw(NtArgs& p, hipStream_t st) {
   if (p.wfmt == 1) {              // the caller's planes are prep kind 3 (two fp16 planes + row scales): also under --amp
     static const int nopre = [] { const char* e = getenv("SRHIP_F16X2_NOPREPASS"); return e ? atoi(e) : 0; }();
     p.stagger = nopre ? -8 : 0;   // timing ablation only: constant row scale, results can be wrong
+    static const int two = [] { const char* e = getenv("SRHIP_F16X2_PASSES"); return e ? atoi(e) : 1; }();
+    if (two && !nopre) {          // 192-k passes with a running row scale: no pre-pass over A (k_nth2); 0: k_nth
+      hipLaunchKernelGGL(k_nth2, grid, dim3(256), NTH2_LDS, st, p);
+      SR_LAUNCH_CHECK("k_nth2");
+      return 0;
+    }
     hipLaunchKernelGGL(k_nth, grid, dim3(256), NTW_LDS + 256, st, p);
     SR_LAUNCH_CHECK("k_nth");
     return 0;

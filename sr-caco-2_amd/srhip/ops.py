@@ -47,7 +47,10 @@ import os as _os
 # weight-gradient (TN) side: bf16x3 from 64 channels on, once 64-wide tiles got their own plan (three blocks per
 # CU) and unequal operand widths the smaller tile class -- 64->64 at 8x128x128: 186 us (f32) vs 148 us
 BX3_MIN_CHANNELS = int(_os.environ.get("SRHIP_BX3_MIN_CH", "64"))
-F16X2 = _os.environ.get("SRHIP_F16X2", "0") not in ("", "0")      # experiment: three-product fp16 GEMM (k_nth)
+# Linear weights whose GEMMs run on 192-column tiles are prepared as TWO fp16 planes with per-row power-of-two scales and
+# multiplied with THREE products (k_nth2, gemm_ntw.hip; srhip_gemm_nt_f16x2): f32-grade per row, +6 % on the SwinIR step.
+# SRHIP_F16X2=0: three bf16 planes / six products (k_ntw) for those too.
+F16X2 = _os.environ.get("SRHIP_F16X2", "1") not in ("", "0")
 
 
 # The NT side (conv / Linear forward and data gradient) has its own threshold: at 64 -> 64 channels, B=8, 128x128
@@ -146,8 +149,8 @@ class PrepTable:
         rows, kd = (K, N) if transpose else (N, K)
         assert (out.rows, out.K) == (rows, kd)
         self.keep += [W, out, gamma]
-        # experiment SRHIP_F16X2=1: two fp16 planes + per-row power-of-two scales (prep kind 3) for the operands of the
-        # GEMMs that run on 192-column tiles (k_nth, gemm_ntw.hip) -- same routing rule as sr_gemm_ntp
+        # two fp16 planes + per-row power-of-two scales (prep kind 3) for the operands of the GEMMs that run on
+        # 192-column tiles (k_nth2, gemm_ntw.hip) -- same routing rule as sr_gemm_ntp; SRHIP_F16X2=0: bf16x3
         f16 = F16X2 and (rows % 180 == 0 or (rows > 128 and rows % 128 != 0)) and kd <= 1024
         out.fmt = 1 if f16 else 0
         self._add(kind=3 if f16 else 0, a=_p(W), b=_p(gamma), out=_p(out.planes), n0=rows, n1=1, n2=kd, s0=0,

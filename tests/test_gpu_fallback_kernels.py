@@ -46,7 +46,7 @@ CHILD = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("env", [{}, {"SRHIP_NTW": "0"}, {"SRHIP_NTCW": "0", "SRHIP_NTCW2": "0", "SRHIP_NTCW2_SMALL": "0"},
+@pytest.mark.parametrize("env", [{}, {"SRHIP_NTW": "0"}, {"SRHIP_F16X2": "0"}, {"SRHIP_NTCW": "0", "SRHIP_NTCW2": "0", "SRHIP_NTCW2_SMALL": "0"},
                                  {"SRHIP_NTW_GRID": "0", "SRHIP_NTW_ROT": "0", "SRHIP_NTCW2_WIDE": "0"}])
 def test_switchable_kernels_match_float64(env):
     r = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True,
@@ -83,8 +83,10 @@ F16_CHILD = textwrap.dedent('''
 
 
 def test_fp16x2_three_product_gemm_is_f32_grade_per_row():
-    """Experiment SRHIP_F16X2=1 (k_nth: two fp16 planes, per-row power-of-two scales, three products): the worst ROW,
-    relative to itself, is within 3x of what a plain f32 matmul gives, on operands whose rows are 8 decades apart."""
-    r = subprocess.run([sys.executable, "-c", F16_CHILD], cwd=ROOT, env=dict(os.environ, SRHIP_F16X2="1"), capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
+    """The default Linear path (k_nth2: two fp16 planes, per-row power-of-two scales, three products) and its pre-pass form
+    (k_nth, SRHIP_F16X2_PASSES=0): the worst ROW, relative to itself, is within 3x of what a plain f32 matmul gives, on
+    operands whose rows are 8 decades apart."""
+    for extra in ({}, {"SRHIP_F16X2_PASSES": "0"}):
+        r = subprocess.run([sys.executable, "-c", F16_CHILD], cwd=ROOT, env=dict(os.environ, SRHIP_F16X2="1", **extra),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (extra, r.stdout[-500:], r.stderr[-1500:])
