@@ -443,7 +443,10 @@ __global__ void __launch_bounds__(256, 2) k_nth(NtArgs p) {
 // epilogue's tiles reuse the space) that the six stages read without a barrier in between.  K = 180 is one pass.
 constexpr int NTH2_LDS = NTW_LDS + 1024;         // + [64] current 2^s, [64] rescale factor of the pass, [64] 2^-s
 
+// AMP = true (srhip_set_matmul_mode(1), inference): the leading planes only, one product
+template <bool AMP>
 __global__ void __launch_bounds__(256, 2) k_nth2(NtArgs p) {
+  constexpr int NPL = AMP ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const rscale = (float*)(smem + NTW_LDS);        // [64] rescale factor of this pass (1 or 2^-d)
   float* const rinv = rscale + 64;                       // [64] 2^-s, final
@@ -477,7 +480,7 @@ __global__ void __launch_bounds__(256, 2) k_nth2(NtArgs p) {
   auto load_b = [&](int cs, u32x4 (&fb)[3][2]) {
     const char* base = (const char*)p.Wb + (long)(2 * cs) * p.N * 32;
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
       for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
   };
@@ -496,10 +499,14 @@ __global__ void __launch_bounds__(256, 2) k_nth2(NtArgs p) {
     for (int i = 0; i < 4; ++i) {
       u32x4 fa[2];
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * H_APLANE + a_off[i]);
+      for (int pl = 0; pl < NPL; ++pl) fa[pl] = *(const u32x4*)(sa + pl * H_APLANE + a_off[i]);
 #define SR_TERM(PA, PB) \
   _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[i][j] = mfma16h(fa[PA], fb[j][PB], acc[i][j]);
-      SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      if constexpr (AMP) {
+        SR_TERM(0, 0)
+      } else {
+        SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      }
 #undef SR_TERM
     }
   };
@@ -559,7 +566,7 @@ __global__ void __launch_bounds__(256, 2) k_nth2(NtArgs p) {
         }
         unsigned char* sa = smem + s6 * H_ASTAGE + a_dst;
         *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
-        *(u32x4*)(sa + H_APLANE) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+        if (!AMP) *(u32x4*)(sa + H_APLANE) = u32x4{ll[0], ll[1], ll[2], ll[3]};
       }
     }
     __syncthreads();
@@ -997,7 +1004,8 @@ int sr_gemm_ntw(NtArgs& p, hipStream_t st) {
     p.stagger = nopre ? -8 : 0;   // timing ablation only: constant row scale, results can be wrong
     static const int two = [] { const char* e = getenv("SRHIP_F16X2_PASSES"); return e ? atoi(e) : 1; }();
     if (two && !nopre) {          // 192-k passes with a running row scale: no pre-pass over A (k_nth2); 0: k_nth
-      hipLaunchKernelGGL(k_nth2, grid, dim3(256), NTH2_LDS, st, p);
+      if (p.amp && p.epi != 5) hipLaunchKernelGGL(k_nth2<true>, grid, dim3(256), NTH2_LDS, st, p);
+      else hipLaunchKernelGGL(k_nth2<false>, grid, dim3(256), NTH2_LDS, st, p);
       SR_LAUNCH_CHECK("k_nth2");
       return 0;
     }
