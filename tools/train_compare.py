@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""100 optimisation steps of the README SwinIR (B=4) under both matmul paths from the same seed:
-loss trajectories and final parameters of the bf16x3 split-MFMA path vs the exact-f32 MFMA path."""
+"""100 optimisation steps of the README SwinIR (B=4) under the three matmul paths from the same seed: loss trajectories
+and final parameters of the default path (Linear GEMMs: two fp16 planes / three products; the rest bf16x3) and of the
+all-bf16x3 path (SRHIP_F16X2=0) against the exact-f32 MFMA path."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1:
     mode = sys.argv[1]
-    os.environ["SRHIP_MM"] = mode
+    os.environ["SRHIP_MM"] = "f32" if mode == "f32" else "bx3"
+    os.environ["SRHIP_F16X2"] = "0" if mode == "bx3_six_products" else "1"
     sys.path.insert(0, os.path.join(ROOT, "sr-caco-2_amd")); sys.path.insert(0, ROOT)
     import torch
     from dlib.models.network_swinir import SwinIR
@@ -29,12 +31,14 @@ if len(sys.argv) > 1:
     torch.save(ts.fp.flat.cpu(), f"/tmp/params_{mode}.pt")
 else:
     out = {}
-    for mode in ("f32", "bx3"):
+    for mode in ("f32", "bx3_six_products", "default"):
         r = subprocess.run([sys.executable, __file__, mode], capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         out[mode] = json.loads(line)
         print(line)
     import torch
-    a, b = torch.load("/tmp/params_f32.pt").double(), torch.load("/tmp/params_bx3.pt").double()
-    print(f"after 100 Adam steps: max |dparam| = {(a - b).abs().max().item():.3e}  rel L2 = {((a - b).norm() / a.norm()).item():.3e}")
-    print("loss |f32 - bx3| per checkpoint:", [f"{abs(x - y):.2e}" for x, y in zip(out['f32']['losses'], out['bx3']['losses'])])
+    a = torch.load("/tmp/params_f32.pt").double()
+    for mode in ("bx3_six_products", "default"):
+        b = torch.load(f"/tmp/params_{mode}.pt").double()
+        print(f"{mode}: after 100 Adam steps max |dparam| = {(a - b).abs().max().item():.3e}  rel L2 = {((a - b).norm() / a.norm()).item():.3e}")
+        print(f"  loss |f32 - {mode}| per checkpoint:", [f"{abs(x - y):.2e}" for x, y in zip(out['f32']['losses'], out[mode]['losses'])])
