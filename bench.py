@@ -301,7 +301,10 @@ def worker(args):
                        "eval_patches_per_s_one_gpu": eval_pps, "eval_amp_patches_per_s_one_gpu": eval_amp_pps,
                        "matmul": (("Linear GEMMs: fp16x2 split MFMA (2 fp16 planes per operand under per-row power-of-two "
                                    "scales, 3 products, f32 accumulate: f32-grade per row); convs / weight gradients: "
-                                   if getattr(ops_mod, "F16X2", False) and args.workload.startswith("swinir") else "") +
+                                   if getattr(ops_mod, "F16X2", False) and args.workload.startswith("swinir") else
+                                   ("64-channel 3x3 convs: fp16x2 split MFMA (2 fp16 planes, per-channel / per-halo-tile "
+                                    "power-of-two scales, 3 products: f32-grade per pixel); the rest: "
+                                    if getattr(ops_mod, "F16X2_CONV", False) and args.workload.startswith("edsr") else "")) +
                                   "bf16x3 split MFMA: f32 operands split into 3 bf16 parts, 6 products, "
                                   "f32 accumulate (f32-accurate)") if bx else "f32 MFMA"},
             # whole step against both rooflines: algorithmic bytes / flops x 3 (fwd + bwd) x patches/s

@@ -68,7 +68,7 @@ int srhip_split_bf16x3(const float* W, long ldw, int rows, int K, void* out, voi
 
 int srhip_prep_blocks(const srhip_prep_entry* e) {
   static_assert(sizeof(srhip_prep_entry) == sizeof(PrepEntry), "prep table layout");
-  SR_REQUIRE(e && e->kind >= 0 && e->kind <= 3, "prep_blocks: kind");
+  SR_REQUIRE(e && e->kind >= 0 && e->kind <= 4, "prep_blocks: kind");
   return sr_prep_blocks(*(const PrepEntry*)e);
 }
 
@@ -169,7 +169,7 @@ int srhip_mlp_bwd_bx3(const float* dy, long lddy, const void* W2Tp, const void* 
   return sr_mlp_fused(p, (hipStream_t)stream);
 }
 
-int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
+static int conv3x3_split(int wfmt, const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
                            int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                            const float* rowscale, float alpha, void* stream) {
   SR_REQUIRE(epi >= 0 && epi <= 7 && epi != 3 && epi != 5, "conv3x3_bx3: epi %d", epi);
@@ -179,7 +179,19 @@ int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float
   p.A = X; p.lda = ldx; p.Wb = (const unsigned short*)Wb; p.C = Y; p.ldc = ldy;
   p.N = Cout; p.K = Cin; p.bias = bias; p.epi = epi; p.R = R; p.ldr = ldr; p.rowscale = rowscale;
   p.rows_per_scale = H * W; p.alpha = alpha; p.batch = B; p.H = H; p.Wd = W;
+  p.wfmt = wfmt;
   return sr_conv3x3_ntb(p, (hipStream_t)stream);
+}
+int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
+                           int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
+                           const float* rowscale, float alpha, void* stream) {
+  return conv3x3_split(0, X, ldx, Wb, bias, Y, ldy, B, H, W, Cin, Cout, epi, R, ldr, rowscale, alpha, stream);
+}
+int srhip_conv3x3_nhwc_f16x2(const float* X, long ldx, const void* Wh, const float* bias, float* Y, long ldy,
+                             int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
+                             const float* rowscale, float alpha, void* stream) {
+  SR_REQUIRE(Cout <= 64 && Cin <= 256, "conv3x3_f16x2: Cout <= 64, Cin <= 256 (Cout=%d Cin=%d)", Cout, Cin);
+  return conv3x3_split(1, X, ldx, Wh, bias, Y, ldy, B, H, W, Cin, Cout, epi, R, ldr, rowscale, alpha, stream);
 }
 
 int srhip_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats) {

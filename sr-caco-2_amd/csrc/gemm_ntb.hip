@@ -433,6 +433,12 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
     p.tiles_y = sr_cdiv(p.H, wm == 2 ? 8 : 4);
     p.xcd_order = ntb_env("SRHIP_CONV_XCD", 1);
   }
+  if constexpr (CONV) {       // weight planes of format 1 (two fp16 planes, prep kind 4): 64-column tiles only
+    if (p.wfmt == 1) {
+      SR_REQUIRE(wn == 1 && p.ps == 0, "conv3x3_f16x2: Cout <= 64 and no PixelShuffle fusion (Cout=%d)", p.N);
+      return sr_conv3x3_nhcw2(p, wm == 2 ? 4 : 2, st);
+    }
+  }
   if constexpr (CONV) {       // 64-pixel x 192-column tiles: W fragments straight from global memory (gemm_ntw.hip); SRHIP_NTCW=0: k_ntb<1, 3>
     if (wm == 1 && wn == 3 && p.ps == 0 && !p.dbg && !p.stagger && ntb_env("SRHIP_NTCW", 1)) return sr_conv3x3_ntcw(p, st);
     if (wm == 2 && (wn == 1 || (wn == 2 && ntb_env("SRHIP_NTCW2_WIDE", 1))) && !p.dbg && !p.stagger && ntb_env("SRHIP_NTCW2", 1)) {

@@ -964,6 +964,199 @@ __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
   nt_epilogue<RW / 2, 1, true>(p, acc2, lane, wm, wn, n0, nvalid, 0, img, y0, x0);
 }
 
+// k_nhcw2 (experiment, SRHIP_F16X2_CONV=1; weight planes of prep kind 4): k_ntcw2 on TWO fp16 planes and three products.
+// The accumulator of an output pixel mixes nine neighbouring pixels, so the activation's block exponent is ONE power
+// of two per halo tile (all channels), kept as a running scale over the channel chunks exactly as k_nth2 does per row:
+// a chunk's tile maximum comes out of the registers that hold the chunk, the scale only goes down, and when it does
+// every accumulator of the block is multiplied by the exact power of two in between.  Emulated (tools/split_accuracy.py):
+// worst output pixel relative to itself within 1.4x of an f32 conv, also on gradient-like inputs.
+template <int RW, bool AMP>
+__global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
+  constexpr int NPL = AMP ? 1 : 2;
+  constexpr int D_AROWS = (2 * RW + 2) * 18;       // halo pixels of a 2 RW x 16 tile
+  constexpr int D_APLANE = D_AROWS * C_PITCH;
+  constexpr int D_AN = D_AROWS * 8;
+  constexpr int D_AIT = (D_AN + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = lane & 15, g = lane >> 4;
+  // one-dimensional grid, column block fastest: the column blocks of a pixel tile (they stage the same halo) are
+  // neighbours in time and, with the XCD-aware order, in one L2
+  int t = p.xcd_order ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int ncol = (p.N + p.n_tile - 1) / p.n_tile;
+  const int n0 = (t % ncol) * p.n_tile; t /= ncol;
+  const int nvalid = min(p.n_tile, p.N - n0);
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int img = t / p.tiles_y;
+  const int y0 = ty * (2 * RW), x0 = tx * 16;
+  const int nkc = (p.K + 31) / 32;
+
+  unsigned offA[D_AIT];
+  bool inA[D_AIT];
+#pragma unroll
+  for (int it = 0; it < D_AIT; ++it) {
+    const int idx = min(tid + it * 256, D_AN - 1);
+    const int row = idx >> 3, c4 = idx & 7;
+    const int hy = row / 18, hx = row - hy * 18;
+    const int y = y0 + hy - 1, x = x0 + hx - 1;
+    inA[it] = y >= 0 && y < p.H && x >= 0 && x < p.Wd;
+    const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.Wd - 1);
+    if (p.ps == 2) offA[it] = (unsigned)(((img * 2 * p.H + 2 * yc) * 2 * p.Wd + 2 * xc) * (int)p.lda + c4 * 4) * 4u;
+    else offA[it] = (unsigned)(((img * p.H + yc) * p.Wd + xc) * (int)p.lda + c4 * 4) * 4u;
+  }
+  auto load_a = [&](int kc, f32x4 (&ra)[D_AIT]) {
+    long koff = kc * 32;
+    if (p.ps == 2) {     // chunk kc = channels c0.. of sub-pixel sp of the shuffled image (K/4 is a multiple of 32)
+      const int fk = p.K >> 2, sp = (kc * 32) / fk, c0 = kc * 32 - sp * fk;
+      koff = ((long)(sp >> 1) * 2 * p.Wd + (sp & 1)) * p.lda + c0;
+    }
+    const char* base = (const char*)(p.A + koff);
+#pragma unroll
+    for (int it = 0; it < D_AIT; ++it) {
+      const int c4 = min(tid + it * 256, D_AN - 1) & 7;
+      const bool oob = kc * 32 + c4 * 4 >= p.K;
+      ra[it] = *(const f32x4*)((oob ? (const char*)p.A : base) + (oob ? offA[it] - c4 * 16u : offA[it]));
+    }
+  };
+  float* const red = (float*)(smem + 3 * D_APLANE);          // [4] wave maxima of the chunk (behind the halo planes)
+  float cur = 3.0e38f;                                       // the tile's current 2^s (block-uniform)
+  // zero what does not count, return the thread's maximum
+  auto clean_a = [&](f32x4 (&ra)[D_AIT], int kc) -> float {
+    float mx = 0.f;
+#pragma unroll
+    for (int it = 0; it < D_AIT; ++it) {
+      const int idx = tid + it * 256;
+      f32x4 v = ra[it];
+      if (!(D_AN % 256 == 0 || idx < D_AN) || !inA[it] || kc * 32 + (idx & 7) * 4 >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      ra[it] = v;
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    return mx;
+  };
+  auto store_a = [&](const f32x4 (&ra)[D_AIT], float use) {
+#pragma unroll
+    for (int it = 0; it < D_AIT; ++it) {
+      if (D_AN % 256 == 0 || tid + it * 256 < D_AN) {
+        const int idx = tid + it * 256;
+        const f32x4 v = ra[it];
+        unsigned h0, l0, h1, l1;
+        split2_pair(v.x * use, v.y * use, h0, l0);
+        split2_pair(v.z * use, v.w * use, h1, l1);
+        unsigned char* dst = smem + (idx >> 3) * C_PITCH + (idx & 7) * 8;
+        *(u32x2*)(dst) = u32x2{h0, h1};
+        if (!AMP) *(u32x2*)(dst + D_APLANE) = u32x2{l0, l1};
+      }
+    }
+  };
+
+  const long wrows = 9L * p.N;
+  const long plane_bytes = wrows * p.Kp * 2;
+  const float* const winv_all = (const float*)((const char*)p.Wb + 2 * plane_bytes);
+  unsigned boff[2];
+  float winv[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int col = n0 + min(wn * 32 + jt * 16 + c, nvalid - 1);
+    boff[jt] = (unsigned)(((g >> 1) * wrows + col) * 32 + (g & 1) * 16);
+    winv[jt] = winv_all[col];
+  }
+  const int niter = nkc * 9;
+  auto load_b = [&](int it, u32x4 (&fb)[2][2]) {
+    const int kc = it / 9, tap = it - kc * 9;
+    const char* base = (const char*)p.Wb + ((long)(2 * kc) * wrows + (long)tap * p.N) * 32;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
+  };
+
+  f32x4 acc[RW][2];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int a_off[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) a_off[i] = ((RW * wm + i) * 18 + c) * C_PITCH + 16 * g;
+
+  auto mma = [&](int tap, const u32x4 (&fb)[2][2]) {
+    const int toff = ((tap / 3) * 18 + (tap % 3)) * C_PITCH;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      u32x4 fa[2];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) fa[pl] = *(const u32x4*)(smem + pl * D_APLANE + a_off[i] + toff);
+#define SR_TERM(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma16h(fa[PA], fb[j][PB], acc[i][j]);
+      if constexpr (AMP) {
+        SR_TERM(0, 0)
+      } else {
+        SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      }
+#undef SR_TERM
+    }
+  };
+
+  f32x4 ra[D_AIT];
+  load_a(0, ra);
+  u32x4 fb0[2][2], fb1[2][2], fb2[2][2];
+  load_b(0, fb0); load_b(1, fb1); load_b(2, fb2);
+  for (int kc = 0; kc < nkc; ++kc) {
+    const float tmx = wave_max(clean_a(ra, kc));
+    if (kc) __syncthreads();                  // every tap of the previous chunk has read the halo tile (and `red`)
+    if (lane == 0) red[wave] = tmx;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float need = mx > 0.f ? exp2f(floorf(log2f(16384.f / mx))) : 3.0e38f;
+    const float old = cur;
+    cur = fminf(cur, need);
+    const float use = cur > 1.0e38f ? 1.f : cur;
+    store_a(ra, use);
+    __syncthreads();
+    if (kc + 1 < nkc) load_a(kc + 1, ra);
+    if (kc && old != cur && old < 1.0e38f) {  // the tile's scale dropped: bring the accumulators to the new one (exact)
+      const float f = cur / old;
+#pragma unroll
+      for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] *= f;
+    }
+    const int it = kc * 9;
+#pragma unroll 1
+    for (int t3 = 0; t3 < 9; t3 += 3) {
+      mma(t3, fb0);     if (it + t3 + 3 < niter) load_b(it + t3 + 3, fb0);
+      mma(t3 + 1, fb1); if (it + t3 + 4 < niter) load_b(it + t3 + 4, fb1);
+      mma(t3 + 2, fb2); if (it + t3 + 5 < niter) load_b(it + t3 + 5, fb2);
+    }
+  }
+  const float tinv = 1.0f / (cur > 1.0e38f ? 1.f : cur);
+
+  // ---- re-layout inside the wave: 4 x 2 tiles of 16 x 16 -> 2 x 1 tiles of 32 x 32 (tile row 16*y + x of the wave's 4 image rows)
+  __syncthreads();                                   // the halo tile is dead from here on
+  float* const T = (float*)smem + wave * (16 * RW * D_TP);
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) T[(16 * i + 4 * g + e) * D_TP + 16 * j + c] = acc[i][j][e] * (tinv * winv[j]);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the wave's own LDS writes have landed
+  const int r = lane & 31;
+  f32x16 acc2[RW / 2][1];
+#pragma unroll
+  for (int i = 0; i < RW / 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc2[i][0][q] = T[(32 * i + mfma_row(q, lane)) * D_TP + r];
+  nt_epilogue<RW / 2, 1, true>(p, acc2, lane, wm, wn, n0, nvalid, 0, img, y0, x0);
+}
+
 }  // namespace
 
 // rows_per_wave 4: tiles_y counts 8-row tiles; 2: 4-row tiles (the caller's wm = 2 / 1)
@@ -978,6 +1171,21 @@ int sr_conv3x3_ntcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
     else hipLaunchKernelGGL((k_ntcw2<2, false>), grid, dim3(256), ntcw2_lds(2), st, p);
   }
   SR_LAUNCH_CHECK("k_ntcw2");
+  return 0;
+}
+
+int sr_conv3x3_nhcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
+  dim3 grid(p.tiles_x * p.tiles_y * p.batch * sr_cdiv(p.N, p.n_tile));
+  const bool amp = p.amp != 0;
+  const int lds = ntcw2_lds(rows_per_wave) + 64;       // + the four wave maxima behind the (three-plane sized) halo region
+  if (rows_per_wave == 4) {
+    if (amp) hipLaunchKernelGGL((k_nhcw2<4, true>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((k_nhcw2<4, false>), grid, dim3(256), lds, st, p);
+  } else {
+    if (amp) hipLaunchKernelGGL((k_nhcw2<2, true>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((k_nhcw2<2, false>), grid, dim3(256), lds, st, p);
+  }
+  SR_LAUNCH_CHECK("k_nhcw2");
   return 0;
 }
 

@@ -155,6 +155,50 @@ __device__ __forceinline__ void job_planes_f16(const PrepEntry& e, int lb) {
   if (lane == 0) ((float*)(base + 2 * plane))[row] = 1.0f / sc;
 }
 
+// kind 4 (experiment, SRHIP_F16X2_CONV=1): the tap-major conv pack as TWO fp16 planes with a power-of-two scale per OUTPUT
+//   channel (one scale for the channel's nine tap rows: they accumulate into the same output column); planes
+//   [2][Kp/16][9*n0][16] fp16, then n0 floats 2^-s(n).  One wave per output channel; K <= 256; no perms.
+__device__ __forceinline__ void job_conv_planes_f16(const PrepEntry& e, int lb) {
+  const int Kp = sr_kp(e.n2);
+  const int n = lb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= e.n0) return;
+  float v[9][4];
+  float mx = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = lane * 4 + q;
+      float x = 0.f;
+      if (k < e.n2) x = ldg_f(e.a + (long)e.off + (long)t * e.s0 + (long)n * e.s1 + (long)k * e.s2);
+      v[t][q] = x;
+      mx = fmaxf(mx, fabsf(x));
+    }
+  mx = wave_max(mx);
+  const float sc = mx > 0.f ? exp2f(floorf(log2f(16384.f / mx))) : 1.f;
+  const long rows = 9L * e.n0, plane = rows * Kp;
+  unsigned short* base = (unsigned short*)e.out;
+  const int k0 = lane * 4;
+  if (k0 < Kp) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      unsigned short hh[4], ll[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xs = v[t][q] * sc;
+        const _Float16 h = (_Float16)xs;
+        const _Float16 l = (_Float16)(xs - (float)h);
+        hh[q] = __builtin_bit_cast(unsigned short, h);
+        ll[q] = __builtin_bit_cast(unsigned short, l);
+      }
+      unsigned short* d = base + ((long)(k0 >> 4) * rows + (long)t * e.n0 + n) * 16 + (k0 & 15);
+      *(u32x2*)(d) = u32x2{(unsigned)hh[0] | ((unsigned)hh[1] << 16), (unsigned)hh[2] | ((unsigned)hh[3] << 16)};
+      *(u32x2*)(d + plane) = u32x2{(unsigned)ll[0] | ((unsigned)ll[1] << 16), (unsigned)ll[2] | ((unsigned)ll[3] << 16)};
+    }
+  }
+  if (lane == 0) ((float*)(base + 2 * plane))[n] = 1.0f / sc;
+}
+
 __global__ void __launch_bounds__(256) k_prep_table(const PrepEntry* __restrict__ tab, int n) {
   int lo = 0, hi = n - 1;
   while (lo < hi) {
@@ -166,6 +210,7 @@ __global__ void __launch_bounds__(256) k_prep_table(const PrepEntry* __restrict_
   if (e.kind == 0) job_planes(e, lb);
   else if (e.kind == 1) job_fold_bias(e, lb);
   else if (e.kind == 3) job_planes_f16(e, lb);
+  else if (e.kind == 4) job_conv_planes_f16(e, lb);
   else job_bias_expand(e, lb);
 }
 
@@ -176,6 +221,7 @@ int sr_prep_blocks(const PrepEntry& e) {
   if (e.kind == 1) return sr_cdiv(e.n0, 4);
   if (e.kind == 2) return sr_cdiv((long)e.n0 * 4096, 256);
   if (e.kind == 3) return (e.n1 == 1 && e.n2 <= 1024 && (e.mode >> 2) == 0) ? sr_cdiv(e.n0, 4) : -1;
+  if (e.kind == 4) return (e.n1 == 9 && e.n2 <= 256 && e.mode == 0) ? sr_cdiv(e.n0, 4) : -1;
   return -1;
 }
 

@@ -51,6 +51,10 @@ BX3_MIN_CHANNELS = int(_os.environ.get("SRHIP_BX3_MIN_CH", "64"))
 # multiplied with THREE products (k_nth2, gemm_ntw.hip; srhip_gemm_nt_f16x2): f32-grade per row, +6 % on the SwinIR step.
 # SRHIP_F16X2=0: three bf16 planes / six products (k_ntw) for those too.
 F16X2 = _os.environ.get("SRHIP_F16X2", "1") not in ("", "0")
+# ... and the 3x3 convs that run on 64-column tiles (<= 64 output channels, 64..256 input channels, no PixelShuffle fusion):
+# two fp16 planes, one power-of-two scale per weight output channel and per activation halo tile, three products (k_nhcw2):
+# f32-grade per output pixel, EDSR x4 +10 %.  SRHIP_F16X2_CONV=0: bf16x3 (k_ntcw2).
+F16X2_CONV = _os.environ.get("SRHIP_F16X2_CONV", "1") not in ("", "0")
 
 
 # The NT side (conv / Linear forward and data gradient) has its own threshold: at 64 -> 64 channels, B=8, 128x128
@@ -202,11 +206,16 @@ class PrepTable:
         rows, kd = (Ci, Co) if data_grad else (Co, Ci)
         assert (out.rows, out.K) == (9 * rows, kd)
         self.keep += [w, out]
+        # two fp16 planes + per-output-channel scales (prep kind 4; SRHIP_F16X2_CONV=0: bf16x3) for the convs that run
+        # on 64-column tiles (k_nhcw2, gemm_ntw.hip): output side <= 64 channels, reduce side <= 256, no PixelShuffle
+        f16 = F16X2_CONV and not ps2 and rows <= 64 and kd <= 256 and kd >= 64
+        out.fmt = 1 if f16 else 0
+        kind = 4 if f16 else 0
         if data_grad:   # out[t][ci][co] = w[co][ci][8 - t]
-            self._add(kind=0, a=_p(w), out=_p(out.planes), n0=Ci, n1=9, n2=Co, s0=-1, s1=9, s2=Ci * 9, off=8,
+            self._add(kind=kind, a=_p(w), out=_p(out.planes), n0=Ci, n1=9, n2=Co, s0=-1, s1=9, s2=Ci * 9, off=8,
                       mode=16 if ps2 else 0)
         else:           # out[t][co][ci] = w[co][ci][t]
-            self._add(kind=0, a=_p(w), out=_p(out.planes), n0=Co, n1=9, n2=Ci, s0=1, s1=Ci * 9, s2=9, off=0,
+            self._add(kind=kind, a=_p(w), out=_p(out.planes), n0=Co, n1=9, n2=Ci, s0=1, s1=Ci * 9, s2=9, off=0,
                       mode=12 if ps2 else 0)
 
     def fold_bias(self, W, b, beta, out):
@@ -368,7 +377,7 @@ def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0
     args = (_p(X), X.stride(2), _p(Wp.planes if bx else Wp), _p(bias), _p(out), out.stride(2),
             B, H, W, Cin, Cout, epi, _p(R), 0 if R is None else R.stride(2), _p(rowscale),
             float(alpha), _st())
-    name = "srhip_conv3x3_nhwc_bx3" if bx else "srhip_conv3x3_nhwc"
+    name = ("srhip_conv3x3_nhwc_f16x2" if Wp.fmt == 1 else "srhip_conv3x3_nhwc_bx3") if bx else "srhip_conv3x3_nhwc"
     if probe.on("conv_nt"):
         T = B * H * W
         with probe.timed(("conv_nt", T, Cout, Cin), 18.0 * T * Cout * Cin,

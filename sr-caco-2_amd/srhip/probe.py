@@ -58,7 +58,7 @@ class timed:
 
 _KERNEL_OF_KIND = {
     "gemm_nt": ("k_nth|k_ntw|k_ntp", "NT GEMM (Linear forward / data gradient)"),
-    "conv_nt": ("k_ntcw|k_ntb", "implicit-GEMM 3x3 conv (forward / data gradient)"),
+    "conv_nt": ("k_nhcw|k_ntcw|k_ntb", "implicit-GEMM 3x3 conv (forward / data gradient)"),
     "conv_tn": ("k_tnb", "3x3 conv weight gradient"),
     "linear_tn": ("k_tnb_grouped", "grouped Linear weight gradients"),
     "wattn": ("k_wattn", "window attention core"),
@@ -111,6 +111,9 @@ def collect():
     bx = ops.use_bx3()
     peak = BX3_MFMA_PEAK_TFLOPS if bx else F32_MFMA_PEAK_TFLOPS
     arith = "bf16x3-split MFMA (f32-equivalent flops; peak = bf16 dense / 6)" if bx else "f32 MFMA"
+    if bx and kind == "conv_nt" and ops.F16X2_CONV:
+        arith = ("64-column convs: fp16x2-split MFMA (two fp16 planes, per-tile / per-channel power-of-two scales, three products); "
+                 "wider ones: bf16x3-split MFMA (six); f32-equivalent flops, peak quoted for six products (bf16 dense / 6)")
     if bx and kind == "gemm_nt" and ops.F16X2:      # three products on two fp16 planes: the ceiling of THIS algorithm is twice as high
         peak = 2500.0 / 3.0
         arith = ("fp16x2-split MFMA: two fp16 planes per operand under per-row power-of-two scales, three products, f32 "

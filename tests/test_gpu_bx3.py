@@ -155,6 +155,7 @@ def test_prep_table_matches_single_ops(ops, monkeypatch):
     bias_expand / split_bf16x3 applied weight by weight (bit-exact).  The bf16x3 form of the Linear planes (the fp16x2
     form the table emits by default for 192-column GEMMs is checked in tests/test_gpu_fallback_kernels.py)."""
     monkeypatch.setattr(ops, "F16X2", False)
+    monkeypatch.setattr(ops, "F16X2_CONV", False)
     N, K, heads = 540, 180, 6
     W, b, g, be = rnd(N, K, scale=0.1).cuda(), rnd(N).cuda(), (1 + 0.1 * rnd(K)).cuda(), rnd(K, scale=0.1).cuda()
     cw = rnd(64, 180, 3, 3, scale=0.05).cuda()

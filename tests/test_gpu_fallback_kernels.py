@@ -46,7 +46,7 @@ CHILD = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("env", [{}, {"SRHIP_NTW": "0"}, {"SRHIP_F16X2": "0"}, {"SRHIP_NTCW": "0", "SRHIP_NTCW2": "0", "SRHIP_NTCW2_SMALL": "0"},
+@pytest.mark.parametrize("env", [{}, {"SRHIP_NTW": "0"}, {"SRHIP_F16X2": "0", "SRHIP_F16X2_CONV": "0"}, {"SRHIP_NTCW": "0", "SRHIP_NTCW2": "0", "SRHIP_NTCW2_SMALL": "0"},
                                  {"SRHIP_NTW_GRID": "0", "SRHIP_NTW_ROT": "0", "SRHIP_NTCW2_WIDE": "0"}])
 def test_switchable_kernels_match_float64(env):
     r = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True,
@@ -90,3 +90,46 @@ def test_fp16x2_three_product_gemm_is_f32_grade_per_row():
         r = subprocess.run([sys.executable, "-c", F16_CHILD], cwd=ROOT, env=dict(os.environ, SRHIP_F16X2="1", **extra),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (extra, r.stdout[-500:], r.stderr[-1500:])
+
+
+CONV16_CHILD = textwrap.dedent('''
+    import sys
+    sys.path.insert(0, "sr-caco-2_amd")
+    import torch, torch.nn.functional as F
+    from srhip import ops
+    assert ops.F16X2_CONV
+    torch.manual_seed(0)
+    for (B, H, W, Ci, Co, kind) in ((2, 24, 40, 64, 64, "feat"), (1, 9, 7, 64, 64, "feat"), (8, 128, 128, 64, 64, "grad"),
+                                    (2, 64, 64, 128, 64, "feat"), (8, 64, 64, 64, 64, "grad")):
+        if kind == "feat":
+            x = F.relu(torch.randn(B, Ci, H, W)) * torch.exp(torch.randn(B, 1, 1, 1))
+        else:       # gradient-like: tiny, and every pixel at its own scale (e^2.5N apart inside a halo tile)
+            x = torch.randn(B, Ci, H, W) * 1e-7 * torch.exp(torch.randn(B, 1, H, W) * 2.5)
+        w = torch.randn(Co, Ci, 3, 3) * (2.0 / (9 * Ci)) ** 0.5 * torch.exp(torch.randn(Co, 1, 1, 1))
+        b = torch.randn(Co) * (0.1 if kind == "feat" else 0.0)
+        wp, wpt = ops.Bx3(9 * Co, Ci, "cuda"), ops.Bx3(9 * Ci, Co, "cuda")
+        tb = ops.PrepTable(); wc = w.cuda().contiguous(); tb.conv(wc, wp); tb.conv(wc, wpt, data_grad=True); tb.build("cuda").run()
+        assert wp.fmt == 1 and (wpt.fmt == 1) == (Ci <= 64)
+        pix = lambda t, ref: ((t - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-300)).max().item()
+        y = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, b.cuda(), Co).permute(0, 3, 1, 2).double().cpu()
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        e, e32 = pix(y, ref), pix(F.conv2d(x, w, b, padding=1).double(), ref)
+        assert e <= max(3.0 * e32, 2e-6), ("fwd", B, H, W, Ci, Co, e, e32)
+        if Ci <= 64:
+            dy = torch.randn(B, Co, H, W) * torch.exp(torch.randn(B, 1, H, W))
+            dx = ops.conv3x3(dy.permute(0, 2, 3, 1).contiguous().cuda(), wpt, None, Ci).permute(0, 3, 1, 2).double().cpu()
+            refd = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+            e, e32 = pix(dx, refd), pix(F.conv_transpose2d(dy, w, padding=1).double(), refd)
+            assert e <= max(3.0 * e32, 2e-6), ("dgrad", B, H, W, Ci, Co, e, e32)
+    print("ok")
+''')
+
+
+def test_fp16x2_three_product_conv_is_f32_grade_per_pixel():
+    """The default 64-column conv path (k_nhcw2: two fp16 planes, one power-of-two scale per weight output channel and per
+    activation halo tile as a running scale over the channel chunks, three products): the worst output PIXEL, relative to
+    itself, is within 3x of an f32 conv -- forward and data gradient, on feature-like and on gradient-like inputs whose
+    pixels are decades apart inside a tile."""
+    r = subprocess.run([sys.executable, "-c", CONV16_CHILD], cwd=ROOT, env=dict(os.environ, SRHIP_F16X2_CONV="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])

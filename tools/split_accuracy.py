@@ -51,3 +51,41 @@ report("LayerNorm output x Linear weight", A, W)
 report("gelu(h) x Linear weight (K 360)", torch.nn.functional.gelu(torch.randn(M, 360) * 2), torch.nn.init.trunc_normal_(torch.empty(180, 360), std=0.02) * 10)
 report("gradient-like (1e-7 scale) x W^T", torch.randn(M, 540) * 1e-7 * torch.exp(torch.randn(M, 1) * 2), W.t().contiguous())
 report("heavy-tailed rows (1e-3 .. 1e3)", torch.randn(M, K) * torch.exp(torch.randn(M, 1) * 3), W)
+
+
+# ---- 3x3 conv (implicit GEMM): the accumulator of an output pixel mixes nine neighbouring pixels, so the activation's block
+#      exponent cannot be per pixel -- the candidate is ONE power-of-two scale per halo tile (8 x 16 output pixels + halo, all
+#      channels), weights per output channel.  Emulated tile by tile; errors per output pixel relative to that pixel's own norm.
+def conv_report(name, x, w):
+    import torch.nn.functional as F
+    B, C, H, W = x.shape
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    f32 = F.conv2d(x, w, padding=1).double()
+    co = w.shape[0]
+    ws = torch.floor(torch.log2(16384.0 / w.abs().amax((1, 2, 3), keepdim=True)))
+    wsc = w * 2.0 ** ws
+    wh = wsc.half().float(); wl = (wsc - wh).half().float()
+    xp = F.pad(x, (1, 1, 1, 1))
+    out = torch.zeros(B, co, H, W, dtype=torch.float64)
+    for b in range(B):
+        for y0 in range(0, H, 8):
+            for x0 in range(0, W, 16):
+                t = xp[b:b + 1, :, y0:y0 + 10, x0:x0 + 18]
+                mx = t.abs().max()
+                s = torch.floor(torch.log2(16384.0 / mx)) if mx > 0 else torch.tensor(0.0)
+                ts = t * 2.0 ** s
+                th = ts.half().float(); tl = (ts - th).half().float()
+                y = F.conv2d(th, wl) + F.conv2d(tl, wh) + F.conv2d(th, wh)
+                out[b, :, y0:y0 + 8, x0:x0 + 16] = (y * 2.0 ** (-s)).double()[0] * (2.0 ** (-ws)).double().view(co, 1, 1)
+    pix = lambda y: ((y - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-300))
+    r = lambda y: ((y - ref).norm() / ref.norm()).item()
+    print(f"{name:40s} L2-rel  f32 {r(f32):.2e}  fp16x2/tile {r(out):.2e}   |  worst pixel  f32 {pix(f32).max().item():.2e}  fp16x2/tile {pix(out).max().item():.2e}"
+          f"   99.9 % pixel  f32 {pix(f32).flatten().kthvalue(int(0.999 * pix(f32).numel())).values.item():.2e}  fp16x2/tile {pix(out).flatten().kthvalue(int(0.999 * pix(out).numel())).values.item():.2e}")
+
+
+torch.manual_seed(1)
+w = torch.randn(64, 64, 3, 3) * (2.0 / (9 * 64)) ** 0.5
+feat = torch.nn.functional.relu(torch.randn(1, 64, 64, 64)) * torch.exp(torch.nn.functional.interpolate(torch.randn(1, 1, 8, 8), size=(64, 64), mode="bicubic") * 1.5)
+conv_report("conv 64->64: ReLU features, smooth gain", feat, w)
+grad = torch.randn(1, 64, 64, 64) * 1e-7 * torch.exp(torch.randn(1, 1, 64, 64) * 2.5)
+conv_report("conv 64->64: gradient-like, per-pixel e^2.5N", grad, w)
