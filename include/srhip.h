@@ -132,11 +132,17 @@ int srhip_gemm_nt_f16x2_lnbwd(const float* A, long lda, const void* Wh, float* o
                               void* stream);
 /* The 3x3 conv with its weight as two fp16 planes and a power-of-two scale per OUTPUT channel (srhip_prep_table job
  * kind 4); the activation gets ONE power-of-two scale per 8 x 16 (or 4 x 16) halo tile, kept as a running scale over the
- * channel chunks; three products.  Cout <= 64, Cin <= 256, no PixelShuffle fusion.  Experiment (SRHIP_F16X2_CONV=1 makes
- * the weight preparation emit this format); arguments as srhip_conv3x3_nhwc_bx3. */
+ * channel chunks; three products.  Cout <= 256 (64-column slices), Cin <= 256.  What the weight preparation emits by default
+ * for these shapes (SRHIP_F16X2_CONV=0: bf16x3); arguments as srhip_conv3x3_nhwc_bx3. */
 int srhip_conv3x3_nhwc_f16x2(const float* X, long ldx, const void* Wh, const float* bias, float* Y, long ldy,
                              int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                              const float* rowscale, float alpha, void* stream);
+/* srhip_conv3x3_ps2_bx3 / srhip_conv3x3_ps2_bwd_data_bx3 with the weight in that format (job kind 4, modes 12 / 16). */
+int srhip_conv3x3_ps2_f16x2(const float* X, long ldx, const void* Wh, const float* bias, float* Yup, long ldy,
+                            int B, int H, int W, int Cin, int Cout, int epi, float alpha, void* stream);
+int srhip_conv3x3_ps2_bwd_data_f16x2(const float* dYup, long lddy, const void* Wht, float* dX, long ldx, int B, int H,
+                                     int W, int Cout, int Cin, int epi, const float* R, long ldr, float alpha,
+                                     void* stream);
 /* The MLP half of a Swin block in one kernel per direction (mlp_fused.hip): the hidden
  * activation goes from the first product's accumulators through registers and LDS into
  * the second product and never returns from HBM.

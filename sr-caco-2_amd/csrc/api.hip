@@ -18,7 +18,7 @@ int sr_fail(int code, const char* fmt, ...) {
 extern "C" {
 
 const char* srhip_last_error(void) { return g_err; }
-int srhip_abi_version(void) { return 11; }
+int srhip_abi_version(void) { return 12; }
 
 static int g_matmul_mode = 0;
 int srhip_set_matmul_mode(int mode) {
@@ -190,7 +190,7 @@ int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float
 int srhip_conv3x3_nhwc_f16x2(const float* X, long ldx, const void* Wh, const float* bias, float* Y, long ldy,
                              int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                              const float* rowscale, float alpha, void* stream) {
-  SR_REQUIRE(Cout <= 64 && Cin <= 256, "conv3x3_f16x2: Cout <= 64, Cin <= 256 (Cout=%d Cin=%d)", Cout, Cin);
+  SR_REQUIRE(Cout <= 256 && Cin <= 256, "conv3x3_f16x2: Cout <= 256, Cin <= 256 (Cout=%d Cin=%d)", Cout, Cin);
   return conv3x3_split(1, X, ldx, Wh, bias, Y, ldy, B, H, W, Cin, Cout, epi, R, ldr, rowscale, alpha, stream);
 }
 
@@ -255,17 +255,17 @@ int srhip_gemm_tn_grouped_bx3(const srhip_tn_problem* probs, int nprob, int M, i
 }
 
 // conv + PixelShuffle(2) as one kernel per direction (NtArgs.ps / TnArgs.ps)
-int srhip_conv3x3_ps2_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Yup, long ldy,
+static int conv3x3_ps2_split(int wfmt, const float* X, long ldx, const void* Wb, const float* bias, float* Yup, long ldy,
                           int B, int H, int W, int Cin, int Cout, int epi, float alpha, void* stream) {
   SR_REQUIRE(epi == 0 || epi == 1 || epi == 6, "conv3x3_ps2_bx3: epi %d (0 bias | 1 relu | 6 leaky relu)", epi);
   NtArgs p;
   memset(&p, 0, sizeof(p));
   p.A = X; p.lda = ldx; p.Wb = (const unsigned short*)Wb; p.C = Yup; p.ldc = ldy;
   p.N = Cout; p.K = Cin; p.bias = bias; p.epi = epi; p.rows_per_scale = H * W; p.alpha = alpha;
-  p.batch = B; p.H = H; p.Wd = W; p.ps = 1;
+  p.batch = B; p.H = H; p.Wd = W; p.ps = 1; p.wfmt = wfmt;
   return sr_conv3x3_ntb(p, (hipStream_t)stream);
 }
-int srhip_conv3x3_ps2_bwd_data_bx3(const float* dYup, long lddy, const void* Wbt, float* dX, long ldx, int B, int H,
+static int conv3x3_ps2_bwd_data_split(int wfmt, const float* dYup, long lddy, const void* Wbt, float* dX, long ldx, int B, int H,
                                    int W, int Cout, int Cin, int epi, const float* R, long ldr, float alpha,
                                    void* stream) {
   SR_REQUIRE(epi == 0 || ((epi == 4 || epi == 7) && R), "conv3x3_ps2_bwd_data_bx3: epi %d (0 | 4, 7 with R)", epi);
@@ -273,8 +273,26 @@ int srhip_conv3x3_ps2_bwd_data_bx3(const float* dYup, long lddy, const void* Wbt
   memset(&p, 0, sizeof(p));
   p.A = dYup; p.lda = lddy; p.Wb = (const unsigned short*)Wbt; p.C = dX; p.ldc = ldx;
   p.N = Cin; p.K = Cout; p.rows_per_scale = H * W; p.alpha = epi == 7 ? alpha : 1.f; p.batch = B; p.H = H; p.Wd = W; p.ps = 2;
-  p.epi = epi; p.R = R; p.ldr = ldr;
+  p.epi = epi; p.R = R; p.ldr = ldr; p.wfmt = wfmt;
   return sr_conv3x3_ntb(p, (hipStream_t)stream);
+}
+int srhip_conv3x3_ps2_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Yup, long ldy,
+                          int B, int H, int W, int Cin, int Cout, int epi, float alpha, void* stream) {
+  return conv3x3_ps2_split(0, X, ldx, Wb, bias, Yup, ldy, B, H, W, Cin, Cout, epi, alpha, stream);
+}
+int srhip_conv3x3_ps2_f16x2(const float* X, long ldx, const void* Wh, const float* bias, float* Yup, long ldy,
+                            int B, int H, int W, int Cin, int Cout, int epi, float alpha, void* stream) {
+  return conv3x3_ps2_split(1, X, ldx, Wh, bias, Yup, ldy, B, H, W, Cin, Cout, epi, alpha, stream);
+}
+int srhip_conv3x3_ps2_bwd_data_bx3(const float* dYup, long lddy, const void* Wbt, float* dX, long ldx, int B, int H,
+                                   int W, int Cout, int Cin, int epi, const float* R, long ldr, float alpha,
+                                   void* stream) {
+  return conv3x3_ps2_bwd_data_split(0, dYup, lddy, Wbt, dX, ldx, B, H, W, Cout, Cin, epi, R, ldr, alpha, stream);
+}
+int srhip_conv3x3_ps2_bwd_data_f16x2(const float* dYup, long lddy, const void* Wht, float* dX, long ldx, int B, int H,
+                                     int W, int Cout, int Cin, int epi, const float* R, long ldr, float alpha,
+                                     void* stream) {
+  return conv3x3_ps2_bwd_data_split(1, dYup, lddy, Wht, dX, ldx, B, H, W, Cout, Cin, epi, R, ldr, alpha, stream);
 }
 int srhip_conv3x3_ps2_wgrad_bx3(const float* dYup, long lddy, const float* X, long ldx, int B, int H, int W,
                                 int Cout, int Cin, float* part, float* part_colsum, int S, void* stream) {

@@ -434,8 +434,10 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
     p.xcd_order = ntb_env("SRHIP_CONV_XCD", 1);
   }
   if constexpr (CONV) {       // weight planes of format 1 (two fp16 planes, prep kind 4): 64-column tiles only
-    if (p.wfmt == 1) {
-      SR_REQUIRE(wn == 1 && p.ps == 0, "conv3x3_f16x2: Cout <= 64 and no PixelShuffle fusion (Cout=%d)", p.N);
+    if (p.wfmt == 1) {          // 64-column slices (column block fastest) for wider outputs, as k_ntcw2
+      SR_REQUIRE(p.N <= 256 && p.K <= 256, "conv3x3_f16x2: Cout <= 256, Cin <= 256 (Cout=%d Cin=%d)", p.N, p.K);
+      p.n_tile = 64;
+      if (wm == 1 && wn != 1) p.tiles_y = sr_cdiv(p.H, 4);
       return sr_conv3x3_nhcw2(p, wm == 2 ? 4 : 2, st);
     }
   }

@@ -162,15 +162,22 @@ __device__ __forceinline__ void job_conv_planes_f16(const PrepEntry& e, int lb) 
   const int Kp = sr_kp(e.n2);
   const int n = lb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= e.n0) return;
+  // conv + PixelShuffle(2) (NtArgs.ps): plane row / k index sp*(n/4) + c holds torch channel c*4 + sp (perms 3 / 4 of kind 0)
+  const int perm = e.mode >> 2;
+  int rs = n;
+  if (perm == 3) { const int fs = e.n0 >> 2; rs = (n % fs) * 4 + n / fs; }
   float v[9][4];
   float mx = 0.f;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int k = lane * 4 + q;
+      int k = lane * 4 + q;
       float x = 0.f;
-      if (k < e.n2) x = ldg_f(e.a + (long)e.off + (long)t * e.s0 + (long)n * e.s1 + (long)k * e.s2);
+      if (k < e.n2) {
+        if (perm == 4) { const int fs = e.n2 >> 2; k = (k % fs) * 4 + k / fs; }
+        x = ldg_f(e.a + (long)e.off + (long)t * e.s0 + (long)rs * e.s1 + (long)k * e.s2);
+      }
       v[t][q] = x;
       mx = fmaxf(mx, fabsf(x));
     }
@@ -221,7 +228,7 @@ int sr_prep_blocks(const PrepEntry& e) {
   if (e.kind == 1) return sr_cdiv(e.n0, 4);
   if (e.kind == 2) return sr_cdiv((long)e.n0 * 4096, 256);
   if (e.kind == 3) return (e.n1 == 1 && e.n2 <= 1024 && (e.mode >> 2) == 0) ? sr_cdiv(e.n0, 4) : -1;
-  if (e.kind == 4) return (e.n1 == 9 && e.n2 <= 256 && e.mode == 0) ? sr_cdiv(e.n0, 4) : -1;
+  if (e.kind == 4) return (e.n1 == 9 && e.n2 <= 256 && (e.mode == 0 || e.mode == 12 || e.mode == 16)) ? sr_cdiv(e.n0, 4) : -1;
   return -1;
 }
 

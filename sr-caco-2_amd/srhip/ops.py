@@ -55,6 +55,7 @@ F16X2 = _os.environ.get("SRHIP_F16X2", "1") not in ("", "0")
 # two fp16 planes, one power-of-two scale per weight output channel and per activation halo tile, three products (k_nhcw2):
 # f32-grade per output pixel, EDSR x4 +10 %.  SRHIP_F16X2_CONV=0: bf16x3 (k_ntcw2).
 F16X2_CONV = _os.environ.get("SRHIP_F16X2_CONV", "1") not in ("", "0")
+F16X2_CONV_WIDE = _os.environ.get("SRHIP_F16X2_CONV_WIDE", "1") != "0"
 
 
 # The NT side (conv / Linear forward and data gradient) has its own threshold: at 64 -> 64 channels, B=8, 128x128
@@ -207,8 +208,10 @@ class PrepTable:
         assert (out.rows, out.K) == (9 * rows, kd)
         self.keep += [w, out]
         # two fp16 planes + per-output-channel scales (prep kind 4; SRHIP_F16X2_CONV=0: bf16x3) for the convs that run
-        # on 64-column tiles (k_nhcw2, gemm_ntw.hip): output side <= 64 channels, reduce side <= 256, no PixelShuffle
-        f16 = F16X2_CONV and not ps2 and rows <= 64 and kd <= 256 and kd >= 64
+        # on 64-column tiles / slices (k_nhcw2, gemm_ntw.hip): output side a multiple of 64 up to 256, reduce side 64 .. 256
+        f16 = F16X2_CONV and rows % 64 == 0 and rows <= 256 and 64 <= kd <= 256
+        if not F16X2_CONV_WIDE:     # SRHIP_F16X2_CONV_WIDE=0: only the 64-column convs without a fused PixelShuffle
+            f16 = f16 and rows == 64 and not ps2
         out.fmt = 1 if f16 else 0
         kind = 4 if f16 else 0
         if data_grad:   # out[t][ci][co] = w[co][ci][8 - t]
@@ -512,12 +515,13 @@ def conv3x3_ps2(X, Wp, bias, out, epi=0, alpha=1.0):
     assert isinstance(Wp, Bx3) and Wp.rows == 9 * 4 * F and Wp.K == Cin and out.shape == (B, 2 * H, 2 * W, F)
     args = (_p(X), X.stride(2), _p(Wp.planes), _p(bias), _p(out), out.stride(2), B, H, W, Cin, 4 * F, epi,
             float(alpha), _st())
+    fn = "srhip_conv3x3_ps2_f16x2" if Wp.fmt == 1 else "srhip_conv3x3_ps2_bx3"
     if probe.on("conv_nt"):
         T = B * H * W
         with probe.timed(("conv_nt", T, 4 * F, Cin, "ps2"), 18.0 * T * 4 * F * Cin, 4.0 * (T * Cin + 36 * F * Cin + T * 4 * F)):
-            call("srhip_conv3x3_ps2_bx3", *args)
+            call(fn, *args)
     else:
-        call("srhip_conv3x3_ps2_bx3", *args)
+        call(fn, *args)
     return out
 
 
@@ -531,12 +535,13 @@ def conv3x3_ps2_bwd_data(dYup, Wpt, out, epi=0, R=None, alpha=1.0):
     assert isinstance(Wpt, Bx3) and Wpt.rows == 9 * Cin and Wpt.K == 4 * F and dYup.shape == (B, 2 * H, 2 * W, F)
     args = (_p(dYup), dYup.stride(2), _p(Wpt.planes), _p(out), out.stride(2), B, H, W, 4 * F, Cin, epi, _p(R),
             0 if R is None else R.stride(2), float(alpha), _st())
+    fn = "srhip_conv3x3_ps2_bwd_data_f16x2" if Wpt.fmt == 1 else "srhip_conv3x3_ps2_bwd_data_bx3"
     if probe.on("conv_nt"):
         T = B * H * W
         with probe.timed(("conv_nt", T, Cin, 4 * F, "ps2"), 18.0 * T * 4 * F * Cin, 4.0 * (T * Cin + 36 * F * Cin + T * 4 * F)):
-            call("srhip_conv3x3_ps2_bwd_data_bx3", *args)
+            call(fn, *args)
     else:
-        call("srhip_conv3x3_ps2_bwd_data_bx3", *args)
+        call(fn, *args)
     return out
 
 

@@ -109,18 +109,41 @@ CONV16_CHILD = textwrap.dedent('''
         b = torch.randn(Co) * (0.1 if kind == "feat" else 0.0)
         wp, wpt = ops.Bx3(9 * Co, Ci, "cuda"), ops.Bx3(9 * Ci, Co, "cuda")
         tb = ops.PrepTable(); wc = w.cuda().contiguous(); tb.conv(wc, wp); tb.conv(wc, wpt, data_grad=True); tb.build("cuda").run()
-        assert wp.fmt == 1 and (wpt.fmt == 1) == (Ci <= 64)
+        assert wp.fmt == 1 and wpt.fmt == 1
         pix = lambda t, ref: ((t - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-300)).max().item()
         y = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, b.cuda(), Co).permute(0, 3, 1, 2).double().cpu()
         ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
         e, e32 = pix(y, ref), pix(F.conv2d(x, w, b, padding=1).double(), ref)
         assert e <= max(3.0 * e32, 2e-6), ("fwd", B, H, W, Ci, Co, e, e32)
-        if Ci <= 64:
+        if True:
             dy = torch.randn(B, Co, H, W) * torch.exp(torch.randn(B, 1, H, W))
             dx = ops.conv3x3(dy.permute(0, 2, 3, 1).contiguous().cuda(), wpt, None, Ci).permute(0, 3, 1, 2).double().cpu()
             refd = F.conv_transpose2d(dy.double(), w.double(), padding=1)
             e, e32 = pix(dx, refd), pix(F.conv_transpose2d(dy, w, padding=1).double(), refd)
             assert e <= max(3.0 * e32, 2e-6), ("dgrad", B, H, W, Ci, Co, e, e32)
+    # conv 64 -> 256 with the PixelShuffle(2) fused into the store, and its data gradient read from the shuffled gradient
+    for (B, H, W, Ci, Fo) in ((2, 24, 40, 64, 64), (1, 9, 7, 64, 64), (4, 128, 128, 64, 64)):
+        Co = 4 * Fo
+        x = F.relu(torch.randn(B, Ci, H, W)) * torch.exp(torch.randn(B, 1, 1, 1))
+        w = torch.randn(Co, Ci, 3, 3) * (2.0 / (9 * Ci)) ** 0.5 * torch.exp(torch.randn(Co, 1, 1, 1))
+        b = torch.randn(Co) * 0.1
+        wp, wpt = ops.Bx3(9 * Co, Ci, "cuda"), ops.Bx3(9 * Ci, Co, "cuda")
+        tb = ops.PrepTable(); wc = w.cuda().contiguous(); tb.conv(wc, wp, ps2=True); tb.conv(wc, wpt, data_grad=True, ps2=True)
+        tb.build("cuda").run()
+        assert wp.fmt == 1 and wpt.fmt == 1
+        up = torch.empty(B, 2 * H, 2 * W, Fo, device="cuda")
+        ops.conv3x3_ps2(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, b.cuda(), up)
+        ref = F.pixel_shuffle(F.conv2d(x.double(), w.double(), b.double(), padding=1), 2)
+        e = pix(up.permute(0, 3, 1, 2).double().cpu(), ref)
+        e32 = pix(F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2).double(), ref)
+        assert e <= max(3.0 * e32, 2e-6), ("ps2 fwd", B, H, W, e, e32)
+        dyu = torch.randn(B, Fo, 2 * H, 2 * W) * 1e-6 * torch.exp(torch.randn(B, 1, 2 * H, 2 * W) * 2.0)
+        dx = torch.empty(B, H, W, Ci, device="cuda")
+        ops.conv3x3_ps2_bwd_data(dyu.permute(0, 2, 3, 1).contiguous().cuda(), wpt, dx)
+        refd = F.conv_transpose2d(F.pixel_unshuffle(dyu.double(), 2), w.double(), padding=1)
+        e = pix(dx.permute(0, 3, 1, 2).double().cpu(), refd)
+        e32 = pix(F.conv_transpose2d(F.pixel_unshuffle(dyu, 2), w, padding=1).double(), refd)
+        assert e <= max(3.0 * e32, 2e-6), ("ps2 dgrad", B, H, W, e, e32)
     print("ok")
 ''')
 
