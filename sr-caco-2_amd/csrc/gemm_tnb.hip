@@ -48,6 +48,20 @@ __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 tn_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// x = h + l in fp16 (round to nearest; the residual is exact in f32), two values per call (v_cvt_pk_f16_f32)
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
+  const tn_f16x2 hv = __builtin_convertvector(f32x2{x0, x1}, tn_f16x2);
+  const float r0 = x0 - (float)hv.x, r1 = x1 - (float)hv.y;
+  const tn_f16x2 lv = __builtin_convertvector(f32x2{r0, r1}, tn_f16x2);
+  h = __builtin_bit_cast(unsigned, hv);
+  l = __builtin_bit_cast(unsigned, lv);
+}
+
 // A column holds four 16-byte units per plane (token octets 0..3 of a 32-token chunk);
 // unit (col, u) sits at slot 4*P(col) + (u ^ g(col)).  A 16-lane phase of ds_*_b128 is
 // conflict free when its 16 units differ in (P & 3, u ^ g), so that pair must be a
@@ -427,7 +441,17 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
 constexpr int TK3 = 16;                         // tokens per chunk = one k step of the 32x32x16 MFMA
 __device__ __forceinline__ int unit_slot3(int col, int u) { return 2 * col + (u ^ ((col >> 3) & 1)); }
 
-template <int DBG = 0>
+//
+// F16: the operands as TWO fp16 planes and three products (h*h + h*l + l*h on v_mfma_f32_32x32x16_f16) instead of three
+// bf16 planes and six.  fp16 has 5 exponent bits, so every operand COLUMN (a channel of dY or of X) carries a power-of-two
+// scale 2^s: the producer lane that owns the column keeps it as a running value that only goes down -- when a chunk's
+// largest |x| would pass 60000 after scaling, s drops so that the maximum lands in [8192, 16384] and the lane posts the
+// (exact, power-of-two) factor next to the chunk's planes; the consumers multiply their accumulators by factor(row) *
+// factor(column) before that chunk's MFMAs (a wave-uniform branch on four flag words; rare after the first chunks).  The
+// epilogue multiplies by 2^-s(row) * 2^-s(column).  An element far below its column's maximum keeps an ABSOLUTE error of
+// 2^-25 in scaled units = 2^-39 of the column maximum: the sum over tokens -- what a weight gradient is -- stays
+// f32-grade (error <= ~2^-22 * sum |a| |b|), which per-column scaling could not give an NT product.
+template <int DBG = 0, bool F16 = false>
 __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const int tile, const int trow,
                                           unsigned char* smem) {
   constexpr int BC = 64, NOP = 4;              // operand tiles per chunk: dY, X(dx = -1), X(0), X(+1)
@@ -460,6 +484,9 @@ __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const in
   const long ld = isB ? p.ldb : p.lda;
   const int step = (!isB && p.ps) ? 2 : 1;
   float cs = 0.f;
+  float sc = 0x1p126f;                         // F16: this lane's column scale ("unset": any non-zero chunk sets it)
+  constexpr int CTRL = 2 * PLANE;              // F16: per chunk buffer, in the place of the third plane: factors [4][64], flags [4]
+  constexpr int SINV = 2 * PLANE + 2048;       // F16: final 2^-s [4][64] (buffer 0)
 
   auto load = [&](int mc, Stage& sg) __attribute__((always_inline)) {
     const int gm = mc + (lane & 15);             // token of this lane's per-token data
@@ -496,6 +523,35 @@ __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const in
     }
   };
   auto store = [&](unsigned char* buf, const Stage& sg) __attribute__((always_inline)) {
+    if constexpr (F16) {
+      float mx = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) mx = fmaxf(mx, fabsf(sg.rv[t >> 3][t & 7]));
+      float f = 1.f;
+      if (mx * sc > 60000.f) {
+        const float ns = exp2f(fminf(floorf(log2f(16384.f / mx)), 120.f));
+        f = ns / sc;
+        sc = ns;
+      }
+      const bool ch = __any(f != 1.f);
+      float* ctrl = (float*)(buf + CTRL);
+      if (ch) ctrl[op * BC + lane] = f;
+      if (lane == 0) ((int*)(ctrl + NOP * BC))[op] = ch ? 1 : 0;
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        unsigned qh[4], ql[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float e0 = sg.rv[o][2 * t], e1 = sg.rv[o][2 * t + 1];
+          if (do_colsum) cs += e0 + e1;            // read by the dY wave only
+          split2_pair(e0 * sc, e1 * sc, qh[t], ql[t]);
+        }
+        unsigned char* dst = buf + unit_slot3(op * BC + lane, o) * 16;
+        *(u32x4*)(dst) = u32x4{qh[0], qh[1], qh[2], qh[3]};
+        *(u32x4*)(dst + PLANE) = u32x4{ql[0], ql[1], ql[2], ql[3]};
+      }
+      return;
+    }
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
       unsigned qh[4], qm[4], ql[4];
@@ -544,10 +600,43 @@ __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const in
       }
       __syncthreads();
     }
+    if constexpr (F16) {
+      ((float*)(smem + SINV))[op * BC + lane] = 1.0f / sc;
+      __syncthreads();
+    }
   } else {
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
       const unsigned char* cur = smem + (c & 1) * BUF;
+      if constexpr (F16) {
+        if (DBG != 1) {
+          const float* ctrl = (const float*)(cur + CTRL);
+          const u32x4 fl = *(const u32x4*)(ctrl + NOP * BC);
+          if (__builtin_amdgcn_readfirstlane(fl.x | fl.y | fl.z | fl.w)) {       // some column's scale dropped with this chunk: bring the sums along
+            float fa_[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) fa_[q] = fl.x ? ctrl[wi * 32 + mfma_row(q, lane)] : 1.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const unsigned on = k == 0 ? fl.y : (k == 1 ? fl.z : fl.w);
+              const float fb = on ? ctrl[(1 + k) * BC + wj * 32 + r] : 1.f;
+#pragma unroll
+              for (int q = 0; q < 16; ++q) acc[k][q] *= fa_[q] * fb;
+            }
+          }
+          const u32x4 ah = *(const u32x4*)(cur + a_off), al = *(const u32x4*)(cur + PLANE + a_off);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const u32x4 bh = *(const u32x4*)(cur + b_off[k]);
+            const u32x4 bl = *(const u32x4*)(cur + PLANE + b_off[k]);
+            acc[k] = mfma_h(al, bh, acc[k]);
+            acc[k] = mfma_h(ah, bl, acc[k]);
+            acc[k] = mfma_h(ah, bh, acc[k]);
+          }
+        }
+        __syncthreads();
+        continue;
+      }
       if (DBG != 1) {
         u32x4 fa[3];
 #pragma unroll
@@ -568,6 +657,16 @@ __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const in
       __syncthreads();
     }
     const int col = wj * 32 + r;
+    if constexpr (F16) {
+      __syncthreads();                             // the producers' final 2^-s
+      const float* sinv = (const float*)(smem + SINV);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float ib = sinv[(1 + k) * BC + col];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[k][q] *= sinv[wi * 32 + mfma_row(q, lane)] * ib;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       float* out = p.part + ((long)(s * 9 + 3 * trow + k) * p.NI) * p.NJ;
@@ -590,12 +689,12 @@ __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const in
   }
 }
 
-template <int DBG = 0>
+template <int DBG = 0, bool F16 = false>
 __global__ void __launch_bounds__(512, 6) k_tnb3(TnArgs p, int tiles, int xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int L = xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int trow = L % 3, t2 = L / 3;
-  tnb_body3<DBG>(p, t2 / tiles, t2 % tiles, trow, smem);
+  tnb_body3<DBG, F16>(p, t2 / tiles, t2 % tiles, trow, smem);
 }
 
 // Conv launches are one-dimensional with the block -> (slice, tile, tap) map made here: the 9 taps x i-tiles of one
@@ -669,7 +768,7 @@ __global__ void __launch_bounds__(512, 1) k_tnb_conv_batched(TnbConvBatch g) {
   tnb_body<W>(p, sl, tile, tap, smem);
 }
 
-template <int DBG = 0>
+template <int DBG = 0, bool F16 = false>
 __global__ void __launch_bounds__(512, 6) k_tnb3_conv_batched(TnbConvBatch g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int L = g.xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
@@ -682,7 +781,7 @@ __global__ void __launch_bounds__(512, 6) k_tnb3_conv_batched(TnbConvBatch g) {
   p.B = g.B[k];
   p.part = g.base.part + (long)k * g.part_stride;
   p.part_colsum = g.base.part_colsum ? g.base.part_colsum + (long)k * g.colsum_stride : nullptr;
-  tnb_body3<DBG>(p, sl, tile, trow, smem);
+  tnb_body3<DBG, F16>(p, sl, tile, trow, smem);
 }
 
 // three taps per block (tnb_body3) for this problem?  SRHIP_TN_T3=0: one tap per block
@@ -694,6 +793,11 @@ bool tnb_t3_ok(const TnArgs& p, int w) {
   return tnb_t3_shape(p.conv, p.NI, p.NJ, w) && !p.a_rowscale && p.b_mode == 0;
 }
 constexpr int lds_bytes3() { return 2 * 3 * 4 * 64 * 32; }
+// two fp16 planes / three products in the three-tap kernels (default); SRHIP_TN_F16X2=0: three bf16 planes / six products
+bool tnb_f16() {
+  static const int on = [] { const char* e = getenv("SRHIP_TN_F16X2"); return !(e && e[0] == '0'); }();
+  return on;
+}
 
 int pick_tile(int n, int* w) {
   if (n % 180 == 0) { *w = 3; return 180; }
@@ -793,7 +897,8 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
       if (int rc = reserve_lds(k_tnb3<0>, lds_bytes3(), "k_tnb3")) return rc;
       attr3 = true;
     }
-    hipLaunchKernelGGL((k_tnb3<0>), dim3(p.S * tiles * 3), dim3(512), lds_bytes3(), st, p, tiles, xcd);
+    if (tnb_f16()) hipLaunchKernelGGL((k_tnb3<0, true>), dim3(p.S * tiles * 3), dim3(512), lds_bytes3(), st, p, tiles, xcd);
+    else hipLaunchKernelGGL((k_tnb3<0>), dim3(p.S * tiles * 3), dim3(512), lds_bytes3(), st, p, tiles, xcd);
     SR_LAUNCH_CHECK("k_tnb3");
     return 0;
   }
@@ -862,7 +967,8 @@ int sr_conv_wgrad_batched_tnb(const TnArgs& base, const float* const* A, const f
       if (int rc = reserve_lds(k_tnb3_conv_batched<0>, lds_bytes3(), "k_tnb3_conv_batched")) return rc;
       attr3 = true;
     }
-    hipLaunchKernelGGL((k_tnb3_conv_batched<0>), dim3(base.S * 3 * g.tiles * n), dim3(512), lds_bytes3(), st, g);
+    if (tnb_f16()) hipLaunchKernelGGL((k_tnb3_conv_batched<0, true>), dim3(base.S * 3 * g.tiles * n), dim3(512), lds_bytes3(), st, g);
+    else hipLaunchKernelGGL((k_tnb3_conv_batched<0>), dim3(base.S * 3 * g.tiles * n), dim3(512), lds_bytes3(), st, g);
     SR_LAUNCH_CHECK("k_tnb3_conv_batched");
     return 0;
   }

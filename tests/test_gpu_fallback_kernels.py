@@ -156,3 +156,59 @@ def test_fp16x2_three_product_conv_is_f32_grade_per_pixel():
     r = subprocess.run([sys.executable, "-c", CONV16_CHILD], cwd=ROOT, env=dict(os.environ, SRHIP_F16X2_CONV="1"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
+
+
+TN16_CHILD = textwrap.dedent('''
+    import sys
+    sys.path.insert(0, "sr-caco-2_amd")
+    import torch, torch.nn.functional as F
+    from srhip import ops
+    torch.manual_seed(0)
+    relmax = lambda t, ref: ((t.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    for (B, H, W, Ci, Co, ps2, kind) in ((2, 24, 40, 64, 64, False, "flat"), (1, 9, 7, 64, 64, False, "flat"),
+                                         (4, 96, 96, 64, 64, False, "grad"), (2, 64, 64, 64, 256, True, "grad"),
+                                         (2, 48, 48, 128, 64, False, "rise"), (1, 40, 40, 64, 64, False, "zero")):
+        x = F.relu(torch.randn(B, Ci, H, W)) * torch.exp(torch.randn(B, 1, 1, 1))
+        dy = torch.randn(B, Co, H, W)
+        if kind == "grad":      # tiny, every pixel at its own scale, channels decades apart
+            dy = dy * 1e-7 * torch.exp(torch.randn(B, 1, H, W) * 2.5) * torch.exp(torch.randn(1, Co, 1, 1) * 3.0)
+        if kind == "rise":      # magnitudes that grow by 2^40 along the token order: the running scales must follow
+            ramp = torch.exp2(torch.linspace(-30, 10, B * H * W)).reshape(B, 1, H, W)
+            dy, x = dy * ramp, x * ramp
+        if kind == "zero":      # channels that are zero everywhere / until late
+            dy[:, :5] = 0; x[:, 7] = 0; dy[:, 9, : H // 2] = 0
+        wr = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+        br = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x.double(), wr, br, padding=1).backward(dy.double())
+        w32 = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+        F.conv2d(x, w32, None, padding=1).backward(dy)
+        dW, db = torch.empty(Co, Ci, 3, 3).cuda(), torch.empty(Co).cuda()
+        xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+        if ps2:
+            dyn = F.pixel_shuffle(dy, 2).permute(0, 2, 3, 1).contiguous().cuda()
+            ops.conv3x3_wgrad(dyn, xn, dW, db, ps2=True)
+        else:
+            ops.conv3x3_wgrad(dy.permute(0, 2, 3, 1).contiguous().cuda(), xn, dW, db)
+        # per output channel (a row of dW is one dY column: its own scale), relative to the row's largest entry
+        ref = wr.grad.reshape(Co, -1)
+        den = ref.abs().max(1, keepdim=True).values.clamp_min(1e-300)
+        e = ((dW.double().cpu().reshape(Co, -1) - ref).abs() / den).max().item()
+        e32 = ((w32.grad.double().reshape(Co, -1) - ref).abs() / den).max().item()
+        assert e <= max(3.0 * e32, 2e-6), (B, H, W, Ci, Co, ps2, kind, e, e32)
+        assert relmax(db, br.grad) < 2e-6
+        if kind == "zero":
+            assert (dW[:5] == 0).all() and (dW[:, 7] == 0).all()
+    print("ok")
+''')
+
+
+@pytest.mark.parametrize("env", [{}, {"SRHIP_TN_F16X2": "0"}])
+def test_fp16x2_three_product_conv_weight_gradient_is_f32_grade(env):
+    """The three-tap conv weight-gradient kernels (k_tnb3 / k_tnb3_conv_batched) with two fp16 planes, one running
+    power-of-two scale per operand COLUMN (channel) and three products: every row of dW, relative to its largest entry,
+    is within 3x of an f32 autograd -- on gradient-like inputs (pixels and channels decades apart), on magnitudes that
+    rise by 2^40 along the tokens (the scales must follow and the sums be rescaled) and with all-zero channels;
+    SRHIP_TN_F16X2=0 is the bf16x3 / six-product form."""
+    r = subprocess.run([sys.executable, "-c", TN16_CHILD], cwd=ROOT, env=dict(os.environ, **env),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-500:], r.stderr[-1500:])
