@@ -216,7 +216,9 @@ int srhip_conv3x3_wgrad(const float* dY, long lddy, const float* X, long ldx, in
 
 /* The three weight-gradient contractions above on the bf16 MFMA with 3-way split
  * operands (see srhip_gemm_nt_bx3): same arguments, alignment rules, slicing and
- * reducers; plan S with the _bx3 planners (one 8-wave block per CU). */
+ * reducers; plan S with the _bx3 planners (one 8-wave block per CU).  The 3x3 conv forms with Cout and Cin multiples of
+ * 64 (three taps per block) split their operands into TWO fp16 planes under a running power-of-two scale per operand
+ * column and issue three products -- same f32-grade sums; SRHIP_TN_F16X2=0 in the environment: three bf16 planes, six. */
 int srhip_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats);
 int srhip_tn_group_plan_bx3(int M, int ntiles, int* S);
 int srhip_gemm_tn_bx3(const float* A, long lda, const float* B, long ldb, int M, int NI, int NJ,
