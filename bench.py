@@ -302,8 +302,9 @@ def worker(args):
                        "matmul": (("Linear GEMMs: fp16x2 split MFMA (2 fp16 planes per operand under per-row power-of-two "
                                    "scales, 3 products, f32 accumulate: f32-grade per row); convs / weight gradients: "
                                    if getattr(ops_mod, "F16X2", False) and args.workload.startswith("swinir") else
-                                   ("64-channel 3x3 convs: fp16x2 split MFMA (2 fp16 planes, per-channel / per-halo-tile "
-                                    "power-of-two scales, 3 products: f32-grade per pixel); the rest: "
+                                   ("3x3 convs (64 .. 256 channels, fused PixelShuffle included) and their weight gradients: "
+                                    "fp16x2 split MFMA (2 fp16 planes, power-of-two scales per weight channel / halo tile / "
+                                    "operand column, 3 products: f32-grade per pixel and per dW row); anything else on the matrix core: "
                                     if getattr(ops_mod, "F16X2_CONV", False) and args.workload.startswith("edsr") else "")) +
                                   "bf16x3 split MFMA: f32 operands split into 3 bf16 parts, 6 products, "
                                   "f32 accumulate (f32-accurate)") if bx else "f32 MFMA"},
@@ -311,6 +312,8 @@ def worker(args):
             "whole_step": {"hbm_frac": gbyte * 3.0 * pps / world / HBM_PEAK_GBS,
                            "flop_frac": gflop * 3.0 * pps / world / 1000.0 / (BX3_PEAK_TFLOPS if bx else F32_MFMA_PEAK_TFLOPS),
                            "flop_frac_of_f32_mfma_peak": gflop * 3.0 * pps / world / 1000.0 / F32_MFMA_PEAK_TFLOPS,
+                           # most matrix work of the step now runs three fp16 products per f32-grade product (fp16 dense / 3)
+                           "flop_frac_of_fp16x2_peak": gflop * 3.0 * pps / world / 1000.0 / (2.0 * BX3_PEAK_TFLOPS),
                            "algorithmic_gflop_per_patch_fwd": gflop, "algorithmic_gbyte_per_patch_fwd": gbyte,
                            "per_gpu": True},
         }

@@ -190,7 +190,7 @@ int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float
 int srhip_conv3x3_nhwc_f16x2(const float* X, long ldx, const void* Wh, const float* bias, float* Y, long ldy,
                              int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                              const float* rowscale, float alpha, void* stream) {
-  SR_REQUIRE(Cout <= 256 && Cin <= 256, "conv3x3_f16x2: Cout <= 256, Cin <= 256 (Cout=%d Cin=%d)", Cout, Cin);
+  SR_REQUIRE((Cout <= 256 || Cout % 180 == 0) && Cin <= 256, "conv3x3_f16x2: Cout <= 256 or a multiple of 180, Cin <= 256 (Cout=%d Cin=%d)", Cout, Cin);
   return conv3x3_split(1, X, ldx, Wh, bias, Y, ldy, B, H, W, Cin, Cout, epi, R, ldr, rowscale, alpha, stream);
 }
 

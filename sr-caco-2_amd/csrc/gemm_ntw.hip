@@ -781,6 +781,184 @@ __global__ void __launch_bounds__(256, 2) k_ntcw(NtArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_ntcw on TWO fp16 planes and three products (the scheme of k_nhcw2 below on the 64-pixel x 192-column tile: SwinIR's
+// 180 -> 180 convs): one power-of-two scale per weight output channel (preparation job kind 4) and one per halo tile, kept
+// as a running value over the channel chunks; the block exponents are undone while the accumulators are re-laid.
+template <bool AMP>
+__global__ void __launch_bounds__(256, 2) k_nhcw(NtArgs p) {
+  constexpr int NPL = AMP ? 1 : 2;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * p.n_tile;
+  const int nvalid = min(p.n_tile, p.N - n0);
+  int t = p.xcd_order ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;   // neighbouring tiles (shared halos) in one L2
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int img = t / p.tiles_y;
+  const int y0 = ty * 4, x0 = tx * 16;
+  const int nkc = (p.K + 31) / 32;
+
+  // ---- halo staging: thread = up to C_AIT float4 (pixel, 4 channels) of the 6 x 18 x 32-channel chunk
+  unsigned offA[C_AIT];
+  bool inA[C_AIT];
+#pragma unroll
+  for (int it = 0; it < C_AIT; ++it) {
+    const int idx = min(tid + it * 256, C_AN - 1);
+    const int row = idx >> 3, c4 = idx & 7;
+    const int hy = row / 18, hx = row - hy * 18;
+    const int y = y0 + hy - 1, x = x0 + hx - 1;
+    inA[it] = y >= 0 && y < p.H && x >= 0 && x < p.Wd;
+    const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.Wd - 1);
+    offA[it] = (unsigned)(((img * p.H + yc) * p.Wd + xc) * (int)p.lda + c4 * 4) * 4u;
+  }
+  auto load_a = [&](int kc, f32x4 (&ra)[C_AIT]) {       // K-tail lanes read k = 0 of the pixel, zeroed on store
+    const char* base = (const char*)(p.A + (long)kc * 32);
+#pragma unroll
+    for (int it = 0; it < C_AIT; ++it) {
+      const int c4 = min(tid + it * 256, C_AN - 1) & 7;
+      const bool oob = kc * 32 + c4 * 4 >= p.K;
+      ra[it] = *(const f32x4*)((oob ? (const char*)p.A : base) + (oob ? offA[it] - c4 * 16u : offA[it]));
+    }
+  };
+  float* const red = (float*)(smem + 3 * C_APLANE);          // [4] wave maxima of the chunk (behind the halo planes)
+  float cur = 3.0e38f;                                       // the tile's current 2^s (block-uniform)
+  auto clean_a = [&](f32x4 (&ra)[C_AIT], int kc) -> float {  // zero what does not count, return the thread's maximum
+    float mx = 0.f;
+#pragma unroll
+    for (int it = 0; it < C_AIT; ++it) {
+      const int idx = tid + it * 256;
+      f32x4 v = ra[it];
+      if (!(C_AN % 256 == 0 || idx < C_AN) || !inA[it] || kc * 32 + (idx & 7) * 4 >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      ra[it] = v;
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    return mx;
+  };
+  auto store_a = [&](const f32x4 (&ra)[C_AIT], float use) {
+#pragma unroll
+    for (int it = 0; it < C_AIT; ++it) {
+      if (C_AN % 256 == 0 || tid + it * 256 < C_AN) {
+        const int idx = tid + it * 256;
+        const f32x4 v = ra[it];
+        unsigned h0, l0, h1, l1;
+        split2_pair(v.x * use, v.y * use, h0, l0);
+        split2_pair(v.z * use, v.w * use, h1, l1);
+        unsigned char* dst = smem + (idx >> 3) * C_PITCH + (idx & 7) * 8;
+        *(u32x2*)(dst) = u32x2{h0, h1};
+        if (!AMP) *(u32x2*)(dst + C_APLANE) = u32x2{l0, l1};
+      }
+    }
+  };
+
+  // ---- W fragments of (chunk, tap): rows tap*N + n of the tap-major pack, sub-chunk 2*chunk + (g >> 1)
+  const long wrows = 9L * p.N;
+  const long plane_bytes = wrows * p.Kp * 2;
+  const float* const winv_all = (const float*)((const char*)p.Wb + 2 * plane_bytes);     // 2^-s of the output channels
+  unsigned boff[3];
+  float winv[3];
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) {
+    const int col = n0 + min(wave * 48 + jt * 16 + c, nvalid - 1);
+    boff[jt] = (unsigned)(((g >> 1) * wrows + col) * 32 + (g & 1) * 16);
+    winv[jt] = winv_all[col];
+  }
+  const int niter = nkc * 9;
+  auto load_b = [&](int it, u32x4 (&fb)[3][2]) {          // iterations past the end re-read the last one
+    const int itc = min(it, niter - 1);
+    const int kc = itc / 9, tap = itc - kc * 9;
+    const char* base = (const char*)p.Wb + ((long)(2 * kc) * wrows + (long)tap * p.N) * 32;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+      for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
+  };
+
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = (i * 18 + c) * C_PITCH + 16 * g;     // image row i of the tile, pixel c, octet g
+
+  auto mma = [&](int tap, const u32x4 (&fb)[3][2]) {
+    const int toff = ((tap / 3) * 18 + (tap % 3)) * C_PITCH;                  // halo shift of the tap
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 fa[2];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) fa[pl] = *(const u32x4*)(smem + pl * C_APLANE + a_off[i] + toff);
+#define SR_TERM(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[i][j] = mfma16h(fa[PA], fb[j][PB], acc[i][j]);
+      if constexpr (AMP) {
+        SR_TERM(0, 0)
+      } else {
+        SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      }
+#undef SR_TERM
+    }
+  };
+
+  f32x4 ra[C_AIT];
+  u32x4 fb0[3][2], fb1[3][2], fb2[3][2];
+  load_a(0, ra);
+  load_b(0, fb0); load_b(1, fb1); load_b(2, fb2);
+  for (int kc = 0; kc < nkc; ++kc) {
+    const float tmx = wave_max(clean_a(ra, kc));
+    if (kc) __syncthreads();                  // every tap of the previous chunk has read the halo tile (and `red`)
+    if (lane == 0) red[wave] = tmx;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float need = mx > 0.f ? exp2f(floorf(log2f(16384.f / mx))) : 3.0e38f;
+    const float old = cur;
+    cur = fminf(cur, need);                   // the scale only goes down: nothing accumulated can overflow
+    const float use = cur > 1.0e38f ? 1.f : cur;
+    store_a(ra, use);
+    __syncthreads();
+    if (kc + 1 < nkc) load_a(kc + 1, ra);     // nine taps to land
+    if (kc && old != cur && old < 1.0e38f) {  // the tile's scale dropped: bring the accumulators to the new one (exact)
+      const float f = cur / old;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] *= f;
+    }
+    const int it = kc * 9;
+#pragma unroll 1
+    for (int t3 = 0; t3 < 9; t3 += 3) {
+      mma(t3, fb0);     if (it + t3 + 3 < niter) load_b(it + t3 + 3, fb0);
+      mma(t3 + 1, fb1); if (it + t3 + 4 < niter) load_b(it + t3 + 4, fb1);
+      mma(t3 + 2, fb2); if (it + t3 + 5 < niter) load_b(it + t3 + 5, fb2);
+    }
+  }
+
+  const float tinv = 1.0f / (cur > 1.0e38f ? 1.f : cur);
+  // ---- re-layout into the 32x32 / 2 x 2 layout of nt_epi.h: tile row 16*y + x <-> its 32-row tile (2 image rows x 16)
+  __syncthreads();
+  float* const T = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) T[(16 * i + 4 * g + e) * TP + wave * 48 + 16 * j + c] = acc[i][j][e] * (tinv * winv[j]);
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31;
+  f32x16 acc2[1][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc2[0][j][q] = T[(wm * 32 + mfma_row(q, lane)) * TP + (wn * 3 + j) * 32 + r];
+  nt_epilogue<1, 3, true>(p, acc2, lane, wm, wn, n0, nvalid, 0, img, y0, x0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // ... and for the 64-column conv tiles (128 pixels x 64 columns: the 64 -> 64 body convs of EDSR / VDSR /
 // MSLapSRN / MemNet, and 64-column slices of wider outputs; operands / epilogues of k_ntb<2, 1, true>).  Waves
 // 2 x 2 as in nt_epi.h -- wave (wm, wn) owns image rows 4*wm .. 4*wm+3 (four 16-pixel row tiles) x columns
@@ -1186,6 +1364,14 @@ int sr_conv3x3_nhcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
     else hipLaunchKernelGGL((k_nhcw2<2, false>), grid, dim3(256), lds, st, p);
   }
   SR_LAUNCH_CHECK("k_nhcw2");
+  return 0;
+}
+
+int sr_conv3x3_nhcw(NtArgs& p, hipStream_t st) {        // as sr_conv3x3_ntcw, weight planes of preparation job kind 4
+  dim3 grid(p.tiles_x * p.tiles_y * p.batch, sr_cdiv(p.N, p.n_tile));
+  if (p.amp) hipLaunchKernelGGL(k_nhcw<true>, grid, dim3(256), NTCW_LDS, st, p);
+  else hipLaunchKernelGGL(k_nhcw<false>, grid, dim3(256), NTCW_LDS, st, p);
+  SR_LAUNCH_CHECK("k_nhcw");
   return 0;
 }
 

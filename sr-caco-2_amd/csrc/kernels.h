@@ -96,6 +96,7 @@ int sr_gemm_ntp(NtArgs& p, hipStream_t st);
 int sr_gemm_ntw(NtArgs& p, hipStream_t st);
 int sr_conv3x3_ntcw(NtArgs& p, hipStream_t st);
 int sr_conv3x3_ntcw2(NtArgs& p, int rows_per_wave, hipStream_t st);
+int sr_conv3x3_nhcw(NtArgs& p, hipStream_t st);
 int sr_conv3x3_nhcw2(NtArgs& p, int rows_per_wave, hipStream_t st);   // the same on two fp16 planes (weight format 1)  // conv, 128- / 64-pixel x 64-column tiles, W fragments from global memory   // conv, 64-pixel x 192-column tiles, W fragments from global memory   // 192-column tiles, W fragments from global memory (gemm_ntw.hip)
 bool sr_gemm_ntr_ok(const NtArgs& p);
 int sr_gemm_ntr(NtArgs& p, hipStream_t st);

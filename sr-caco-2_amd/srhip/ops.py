@@ -56,6 +56,7 @@ F16X2 = _os.environ.get("SRHIP_F16X2", "1") not in ("", "0")
 # f32-grade per output pixel, EDSR x4 +10 %.  SRHIP_F16X2_CONV=0: bf16x3 (k_ntcw2).
 F16X2_CONV = _os.environ.get("SRHIP_F16X2_CONV", "1") not in ("", "0")
 F16X2_CONV_WIDE = _os.environ.get("SRHIP_F16X2_CONV_WIDE", "1") != "0"
+F16X2_CONV180 = _os.environ.get("SRHIP_F16X2_CONV180", "1") != "0"
 
 
 # The NT side (conv / Linear forward and data gradient) has its own threshold: at 64 -> 64 channels, B=8, 128x128
@@ -210,6 +211,8 @@ class PrepTable:
         # two fp16 planes + per-output-channel scales (prep kind 4; SRHIP_F16X2_CONV=0: bf16x3) for the convs that run
         # on 64-column tiles / slices (k_nhcw2, gemm_ntw.hip): output side a multiple of 64 up to 256, reduce side 64 .. 256
         f16 = F16X2_CONV and rows % 64 == 0 and rows <= 256 and 64 <= kd <= 256
+        if F16X2_CONV and F16X2_CONV180 and not ps2 and rows % 180 == 0 and 64 <= kd <= 256:
+            f16 = True              # SwinIR's 180-column convs: k_nhcw (64-pixel x 192-column tiles); SRHIP_F16X2_CONV180=0: k_ntcw
         if not F16X2_CONV_WIDE:     # SRHIP_F16X2_CONV_WIDE=0: only the 64-column convs without a fused PixelShuffle
             f16 = f16 and rows == 64 and not ps2
         out.fmt = 1 if f16 else 0

@@ -111,9 +111,11 @@ def collect():
     bx = ops.use_bx3()
     peak = BX3_MFMA_PEAK_TFLOPS if bx else F32_MFMA_PEAK_TFLOPS
     arith = "bf16x3-split MFMA (f32-equivalent flops; peak = bf16 dense / 6)" if bx else "f32 MFMA"
-    if bx and kind == "conv_nt" and ops.F16X2_CONV:
-        arith = ("64-column convs: fp16x2-split MFMA (two fp16 planes, per-tile / per-channel power-of-two scales, three products); "
-                 "wider ones: bf16x3-split MFMA (six); f32-equivalent flops, peak quoted for six products (bf16 dense / 6)")
+    if bx and kind == "conv_nt" and ops.F16X2_CONV:    # 64 .. 256-channel convs: three products on two fp16 planes
+        peak = 2500.0 / 3.0
+        arith = ("fp16x2-split MFMA: two fp16 planes per operand, power-of-two scales per weight output channel and per "
+                 "activation halo tile, three products, f32 accumulate (f32-equivalent flops; peak = fp16 dense / 3; frac "
+                 "against the six-product bf16x3 ceiling 416.7 in frac_of_bf16x3_peak)")
     if bx and kind == "gemm_nt" and ops.F16X2:      # three products on two fp16 planes: the ceiling of THIS algorithm is twice as high
         peak = 2500.0 / 3.0
         arith = ("fp16x2-split MFMA: two fp16 planes per operand under per-row power-of-two scales, three products, f32 "
@@ -128,7 +130,7 @@ def collect():
            "hbm_side": {"achieved_gb_per_s_algorithmic": gbs, "frac_of_8tb_per_s": gbs / HBM_PEAK_GBS},
            "share_of_probed_time": {k: v[0] / sum(x[0] for x in per_kind.values()) for k, v in per_kind.items()},
            "classes": classes}
-    if bx and kind == "gemm_nt" and ops.F16X2:
+    if bx and ((kind == "gemm_nt" and ops.F16X2) or (kind == "conv_nt" and ops.F16X2_CONV)):
         out["frac_of_bf16x3_peak"] = tf / BX3_MFMA_PEAK_TFLOPS
     if traffic:
         out["hbm_side"]["measured_gb_per_s_from_pmc_traffic"] = traffic / (ms / n * 1e-3) / 1e9

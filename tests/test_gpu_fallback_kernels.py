@@ -100,7 +100,8 @@ CONV16_CHILD = textwrap.dedent('''
     assert ops.F16X2_CONV
     torch.manual_seed(0)
     for (B, H, W, Ci, Co, kind) in ((2, 24, 40, 64, 64, "feat"), (1, 9, 7, 64, 64, "feat"), (8, 128, 128, 64, 64, "grad"),
-                                    (2, 64, 64, 128, 64, "feat"), (8, 64, 64, 64, 64, "grad")):
+                                    (2, 64, 64, 128, 64, "feat"), (8, 64, 64, 64, 64, "grad"),
+                                    (2, 64, 64, 180, 180, "feat"), (1, 9, 7, 180, 180, "grad"), (2, 40, 24, 180, 180, "grad")):
         if kind == "feat":
             x = F.relu(torch.randn(B, Ci, H, W)) * torch.exp(torch.randn(B, 1, 1, 1))
         else:       # gradient-like: tiny, and every pixel at its own scale (e^2.5N apart inside a halo tile)

@@ -411,7 +411,9 @@ for mode in ("plain", "ddp"):
     torch.cuda.synchronize()
     out[mode] = (ts.fp.flat.clone(), ts.loss_buf.clone())
 d = (out["plain"][0] - out["ddp"][0]).abs().max().item()
-assert d <= 1e-7 and torch.equal(out["plain"][1], out["ddp"][1]), d
+# LayerNorm-affine gradients are summed with float atomics: after three Adam steps a gamma next to 1.0 may sit one ulp
+# (1.19e-7) apart between two runs of the SAME path; two ulps of [1, 2) is the gate
+assert d <= 2.4e-7 and torch.equal(out["plain"][1], out["ddp"][1]), d
 # a single-bucket engine (VDSR): the bucket the engine used to announce itself must be reduced once
 v = VDSR(in_chans=1, upscale=2)
 v.load_state_dict(O.vdsr_init_state_dict(1, seed=2), strict=True)
