@@ -306,6 +306,15 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
     }
   };
 
+  auto touch = [&](const Stage& sg) __attribute__((always_inline)) {   // DBG 4: the column maxima of a stage, thrown away
+    float mx = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int j = 0; j < W; ++j) mx = fmaxf(mx, fabsf(ColVec<W>::at(sg.rv[t >> 3][t & 7], j)));
+    asm volatile("" ::"v"(mx));
+  };
+
   f32x16 acc[W][W];
 #pragma unroll
   for (int i = 0; i < W; ++i)
@@ -344,6 +353,7 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
       if (DBG != 2) store(smem + BUF, sg1);                 // chunk c+1
       const long s1 = DBG == 3 ? (long)__builtin_amdgcn_s_memtime() : 0;
       if (DBG != 2) load(m_begin + (c + 3) * TKB, sg1);
+      if (DBG == 4) touch(sg0);                  // experiment: chunk c+2 must have landed one half-iteration early
       const long s2 = DBG == 3 ? (long)__builtin_amdgcn_s_memtime() : 0;
       __syncthreads();
       const long s3 = DBG == 3 ? (long)__builtin_amdgcn_s_memtime() : 0;
@@ -351,6 +361,7 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
         store(smem, sg0);                       // chunk c+2
         load(m_begin + (c + 4) * TKB, sg0);
       }
+      if (DBG == 4) touch(sg1);
       __syncthreads();
       if (DBG == 3) { t_store += s1 - s0; t_load += s2 - s1; t_bar += s3 - s2; }
     }
@@ -867,6 +878,7 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
   if (w == 3 && dbg == 1) { hipLaunchKernelGGL((k_tnb_grouped<3, 1>), grid, dim3(512), lds_bytes(3), st, g); }
   else if (w == 3 && dbg == 2) { hipLaunchKernelGGL((k_tnb_grouped<3, 2>), grid, dim3(512), lds_bytes(3), st, g); }
+  else if (w == 3 && dbg == 4) { hipLaunchKernelGGL((k_tnb_grouped<3, 4>), grid, dim3(512), lds_bytes(3), st, g); }
   else if (w == 3 && dbg == 3) { hipLaunchKernelGGL((k_tnb_grouped<3, 3>), grid, dim3(512), lds_bytes(3), st, g); }
   else {
   SR_TNB_G(1) SR_TNB_G(2) SR_TNB_G(3)

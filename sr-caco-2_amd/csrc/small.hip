@@ -174,7 +174,7 @@ __global__ void k_conv_cin1_wgrad_fin(const float* __restrict__ part, float* __r
 // chunks of 16 channels (pixel pitch 20 floats: conflict-free ds_read_b128), the
 // weights as [tap][channel] so a thread reads 4 channels of a tap with one broadcast
 // b128: every input value is fetched from HBM once (plus the halo) instead of 9 times.
-constexpr int C1_CH = 16, C1_PIT = 20;
+constexpr int C1_CH = 16, C1_PIT = 20, C1_Q = C1_CH / 4;     // (32-channel chunks, pitch 36: 249 us against 154 -- two blocks per CU)
 __global__ void __launch_bounds__(256) k_conv_cout1_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                         int B, int H, int W, int Ci, long ldx) {
@@ -189,24 +189,46 @@ __global__ void __launch_bounds__(256) k_conv_cout1_fwd(const float* __restrict_
   }
   const int px = tid & 15, py = tid >> 4;
   float acc = 0.f;
+  // the chunk's halo values wait in registers while the previous chunk is consumed: the global loads of chunk k+1
+  // overlap the 144 FMAs per thread of chunk k (was: load -> LDS -> compute in series, 2.8 TB/s)
+  constexpr int NV = (18 * 18 * C1_Q + 255) / 256;
+  const float* src[NV];
+  bool inb[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = min(tid + k * 256, 18 * 18 * C1_Q - 1);
+    const int hp = i / C1_Q, c4 = i % C1_Q;
+    const int hy = hp / 18, hx = hp - hy * 18;
+    const int sy = ty * 16 + hy - 1, sx = tx * 16 + hx - 1;
+    inb[k] = sy >= 0 && sy < H && sx >= 0 && sx < W;
+    src[k] = x + (((long)b * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 1)) * ldx + c4 * 4;
+  }
+  f32x4 v[NV];
+  auto fetch = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c4 = min(tid + k * 256, 18 * 18 * C1_Q - 1) % C1_Q;
+      const bool ok = inb[k] && c0 + c4 * 4 < Ci;
+      v[k] = *(const f32x4*)(ok ? src[k] + c0 : x);
+      if (!ok) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  fetch(0);
   for (int c0 = 0; c0 < Ci; c0 += C1_CH) {
     __syncthreads();                                   // previous chunk consumed (and ws visible)
-    for (int i = tid; i < 18 * 18 * 4; i += 256) {
-      const int hp = i >> 2, c4 = i & 3;
-      const int hy = hp / 18, hx = hp - hy * 18;
-      const int sy = ty * 16 + hy - 1, sx = tx * 16 + hx - 1;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (sy >= 0 && sy < H && sx >= 0 && sx < W && c0 + c4 * 4 < Ci)
-        v = *(const f32x4*)(x + (((long)b * H + sy) * W + sx) * ldx + c0 + c4 * 4);
-      *(f32x4*)(xs + hp * C1_PIT + c4 * 4) = v;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = tid + k * 256;
+      if (i < 18 * 18 * C1_Q) *(f32x4*)(xs + (i / C1_Q) * C1_PIT + (i % C1_Q) * 4) = v[k];
     }
     __syncthreads();
+    if (c0 + C1_CH < Ci) fetch(c0 + C1_CH);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const float* xp = xs + ((py + t / 3) * 18 + px + t % 3) * C1_PIT;
       const float* wp = ws + t * cip + c0;
 #pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) {
+      for (int c4 = 0; c4 < C1_Q; ++c4) {
         const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
         const f32x4 wv = *(const f32x4*)(wp + c4 * 4);
         acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
