@@ -132,7 +132,7 @@ int srhip_gemm_nt_f16x2_lnbwd(const float* A, long lda, const void* Wh, float* o
                               void* stream);
 /* The 3x3 conv with its weight as two fp16 planes and a power-of-two scale per OUTPUT channel (srhip_prep_table job
  * kind 4); the activation gets ONE power-of-two scale per 8 x 16 (or 4 x 16) halo tile, kept as a running scale over the
- * channel chunks; three products.  Cout <= 256 (64-column slices), Cin <= 256.  What the weight preparation emits by default
+ * channel chunks; three products.  Cout <= 256 (64-column tiles / slices) or a multiple of 180 (192-column tiles), Cin <= 256.  What the weight preparation emits by default
  * for these shapes (SRHIP_F16X2_CONV=0: bf16x3); arguments as srhip_conv3x3_nhwc_bx3. */
 int srhip_conv3x3_nhwc_f16x2(const float* X, long ldx, const void* Wh, const float* bias, float* Y, long ldy,
                              int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
