@@ -439,6 +439,288 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
 }
 
 // ---------------------------------------------------------------------------
+// Linear problems (conv == 0) on TWO fp16 planes and three products: the scheme of tnb_body3<.., true> in the general
+// tile.  A column's scale must be ONE value for its 32-token chunk, and in tnb_body the two token halves of a column are
+// staged by different waves -- so the producer roles are re-cut here: wave = operand x COLUMN half (32 W columns), lane =
+// column W-tuple (lane & 31) x token half (lane >> 5).  The two halves of a column sit in lanes l and l ^ 32 of one
+// wave: one cross-lane exchange per column and chunk gives both the same maximum, both keep the same running
+// power-of-two scale.  Per-token scalars (DropPath scale, LayerNorm statistics) are carried by lane (token & 31) and
+// read with two v_readlane + a select.  Control block in the place of the third plane: factors [2][BC], four flag
+// words (one per producer wave); final 2^-s [2][BC] in buffer 0.
+// ---------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const int tile, unsigned char* smem) {
+  constexpr int BC = 64 * W, HC = 32 * W;
+  constexpr int PLANE = 2 * BC * 64;
+  constexpr int BUF = 3 * PLANE;
+  constexpr int CTRL = 2 * PLANE;
+  constexpr int SINV = 2 * PLANE + 4096;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int wi = wave >> 1, wj = wave & 1, r = lane & 31, h = lane >> 5;
+  const int nbj = (p.NJ + p.j_tile - 1) / p.j_tile;
+  const int bi = tile / nbj, bj = tile - bi * nbj;
+  const int i0 = bi * p.i_tile, j0 = bj * p.j_tile;
+  const int ivalid = min(p.i_tile, p.NI - i0), jvalid = min(p.j_tile, p.NJ - j0);
+  const int m_begin = s * p.rows_per_slice;
+  const int m_end = min(p.M, m_begin + p.rows_per_slice);
+  const bool do_colsum = p.part_colsum && bj == 0;
+
+  struct Stage {
+    typename ColVec<W>::T rv[2][8];
+    float scale;
+    float2 stats;
+  };
+  Stage sg0, sg1;
+  const bool isB = wave & 1;
+  const int ch = wave >> 1;                    // column half of the operand tile
+  const int lt = lane & 31, th = lane >> 5;    // column W-tuple, token half
+  const int opvalid = isB ? jvalid : ivalid;
+  const int gcol = HC * ch + W * lt;           // this lane's first column in the operand tile
+  const int colq = max(min(gcol, opvalid - W), 0);
+  const int dsh = gcol - colq;
+  const bool ragged = opvalid % W != 0;
+  const float* const opP = isB ? p.B + j0 : p.A + i0;
+  const long opLd = isB ? p.ldb : p.lda;
+  const unsigned colb = (unsigned)((16L * th * opLd + colq) * 4);
+  float cs[W], sc[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) { cs[j] = 0.f; sc[j] = 0x1p126f; }
+
+  auto load = [&](int mc, Stage& sg) __attribute__((always_inline)) {
+    const int tokl = mc + (lane & 31);          // the token whose scalars this lane carries
+    const bool interior = mc + TKB <= m_end;    // uniform
+    const bool tin = interior || tokl < m_end;
+    if (!isB) sg.scale = ldg_f((p.a_rowscale && tin) ? p.a_rowscale + tokl / p.a_rowscale_rows : k_sr_neutral + 1);
+    else sg.stats = ldg_f2((p.b_mode == 1 && tin) ? p.ln_stats + 2 * (long)tokl : k_sr_neutral);
+    const float* q = opP + (long)mc * opLd;     // uniform, advanced per token
+    if (interior) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(q, colb);
+        q += opLd;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const bool ok = mc + 16 * th + t < m_end;
+        sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(ok ? (const float*)((const char*)q + colb) : k_tnb_zero_row);
+        q += opLd;
+      }
+    }
+  };
+  auto bcast = [&](float v, int k) __attribute__((always_inline)) -> float {   // scalar of token 16 th + k of the chunk
+    const int lo = __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k);
+    const int hi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 + k);
+    return __builtin_bit_cast(float, th ? hi : lo);
+  };
+  auto store = [&](unsigned char* buf, const Stage& sg) {
+    sr_f32x2 x[2][4][W];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      if (!ragged) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < W; ++j)
+            x[o][t][j] = sr_f32x2{ColVec<W>::at(sg.rv[o][2 * t], j), ColVec<W>::at(sg.rv[o][2 * t + 1], j)};
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            float e0 = ColVec<W>::at(sg.rv[o][2 * t], W - 1), e1 = ColVec<W>::at(sg.rv[o][2 * t + 1], W - 1);
+#pragma unroll
+            for (int d = W - 2; d >= 0; --d)
+              if (j + d < W && dsh == d) {
+                e0 = ColVec<W>::at(sg.rv[o][2 * t], j + d);
+                e1 = ColVec<W>::at(sg.rv[o][2 * t + 1], j + d);
+              }
+            x[o][t][j] = sr_f32x2{e0, e1};
+          }
+      }
+      if (!isB) {
+        if (p.a_rowscale) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float k0 = bcast(sg.scale, 8 * o + 2 * t), k1 = bcast(sg.scale, 8 * o + 2 * t + 1);
+#pragma unroll
+            for (int j = 0; j < W; ++j) { x[o][t][j].x *= k0; x[o][t][j].y *= k1; }
+          }
+        }
+        if (do_colsum) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < W; ++j) cs[j] += x[o][t][j].x + x[o][t][j].y;
+        }
+      } else if (p.b_mode == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float mu0 = bcast(sg.stats.x, 8 * o + 2 * t), mu1 = bcast(sg.stats.x, 8 * o + 2 * t + 1);
+          const float rs0 = bcast(sg.stats.y, 8 * o + 2 * t), rs1 = bcast(sg.stats.y, 8 * o + 2 * t + 1);
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            x[o][t][j].x = (x[o][t][j].x - mu0) * rs0;
+            x[o][t][j].y = (x[o][t][j].y - mu1) * rs1;
+          }
+        }
+      } else if (p.b_mode == 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < W; ++j) { x[o][t][j].x = gelu_f(x[o][t][j].x); x[o][t][j].y = gelu_f(x[o][t][j].y); }
+      }
+    }
+    // the columns' maxima over the chunk's 32 tokens (this lane's 16 and lane ^ 32's), the running scales, the factors
+    float f[W];
+    bool chg = false;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      float mx = 0.f;
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mx = fmaxf(mx, fmaxf(fabsf(x[o][t][j].x), fabsf(x[o][t][j].y)));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      f[j] = 1.f;
+      if (mx * sc[j] > 60000.f) {
+        const float ns = exp2f(fminf(floorf(log2f(16384.f / mx)), 120.f));
+        f[j] = ns / sc[j];
+        sc[j] = ns;
+        chg = true;
+      }
+    }
+    const bool any = __any(chg);
+    float* ctrl = (float*)(buf + CTRL);
+    if (th == 0) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) ctrl[(isB ? BC : 0) + gcol + j] = f[j];
+    }
+    if (lane == 0) ((int*)(ctrl + 2 * BC))[wave] = any ? 1 : 0;
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        unsigned qh[4], ql[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) split2_pair(x[o][t][j].x * sc[j], x[o][t][j].y * sc[j], qh[t], ql[t]);
+        unsigned char* dst = buf + unit_slot<W>((isB ? BC : 0) + gcol + j, 2 * th + o) * 16;
+        *(u32x4*)(dst) = u32x4{qh[0], qh[1], qh[2], qh[3]};
+        *(u32x4*)(dst + PLANE) = u32x4{ql[0], ql[1], ql[2], ql[3]};
+      }
+  };
+
+  f32x16 acc[W][W];
+#pragma unroll
+  for (int i = 0; i < W; ++i)
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  int a_off[W][2], b_off[W][2];
+#pragma unroll
+  for (int i = 0; i < W; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a_off[i][ks] = unit_slot<W>((wi * W + i) * 32 + r, 2 * ks + h) * 16;
+#pragma unroll
+  for (int j = 0; j < W; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b_off[j][ks] = unit_slot<W>(BC + (wj * W + j) * 32 + r, 2 * ks + h) * 16;
+
+  const int nch = ((m_end - m_begin + 2 * TKB - 1) / (2 * TKB)) * 2;
+  if (producer) {
+    load(m_begin, sg0);
+    load(m_begin + TKB, sg1);
+    store(smem, sg0);
+    load(m_begin + 2 * TKB, sg0);
+    __syncthreads();
+    for (int c = 0; c < nch; c += 2) {
+      store(smem + BUF, sg1);
+      load(m_begin + (c + 3) * TKB, sg1);
+      __syncthreads();
+      store(smem, sg0);
+      load(m_begin + (c + 4) * TKB, sg0);
+      __syncthreads();
+    }
+    if (th == 0) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) ((float*)(smem + SINV))[(isB ? BC : 0) + gcol + j] = 1.0f / sc[j];
+    }
+    __syncthreads();
+  } else {
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+      const unsigned char* cur = smem + (c & 1) * BUF;
+      const float* ctrl = (const float*)(cur + CTRL);
+      const u32x4 fl = *(const u32x4*)(ctrl + 2 * BC);
+      if (__builtin_amdgcn_readfirstlane(fl.x | fl.y | fl.z | fl.w)) {   // some column's scale dropped with this chunk
+        float fb[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) fb[j] = ctrl[BC + (wj * W + j) * 32 + r];
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float fa = ctrl[(wi * W + i) * 32 + mfma_row(q, lane)];
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc[i][j][q] *= fa * fb[j];
+          }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 fa[W][2];
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) fa[i][pl] = *(const u32x4*)(cur + pl * PLANE + a_off[i][ks]);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          const u32x4 bh = *(const u32x4*)(cur + b_off[j][ks]);
+          const u32x4 bl = *(const u32x4*)(cur + PLANE + b_off[j][ks]);
+#pragma unroll
+          for (int i = 0; i < W; ++i) acc[i][j] = mfma_h(fa[i][1], bh, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < W; ++i) acc[i][j] = mfma_h(fa[i][0], bl, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < W; ++i) acc[i][j] = mfma_h(fa[i][0], bh, acc[i][j]);
+        }
+      }
+      __syncthreads();
+    }
+    __syncthreads();                             // the producers' final 2^-s
+    const float* sinv = (const float*)(smem + SINV);
+    float* out = p.part + ((long)s * p.NI) * p.NJ;
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const int col = (wj * W + j) * 32 + r;
+        if (col >= jvalid) continue;
+        const float ib = sinv[BC + col];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = (wi * W + i) * 32 + mfma_row(q, lane);
+          if (row < ivalid) out[(long)(i0 + row) * p.NJ + j0 + col] = acc[i][j][q] * (sinv[row] * ib);
+        }
+      }
+  }
+
+  if (do_colsum) {
+    float* red = (float*)smem;                   // [2][BC]; SINV sits behind it
+    if (producer && !isB) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) red[th * BC + gcol + j] = cs[j];
+    }
+    __syncthreads();
+    if (tid < ivalid) p.part_colsum[(long)s * p.NI + i0 + tid] = red[tid] + red[BC + tid];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // 64-wide conv problems, THREE taps (one kernel row dy) per block.  With one tap per block a 64 x 64 tile gives a
 // consumer wave 12 MFMAs per 32-token chunk and barrier while the producers load and split 128 columns for it, and
 // every tap block splits the same dY tile again (23 % of the bf16x3 rate on the EDSR shapes).  Here the dY tile of a
@@ -732,18 +1014,47 @@ constexpr int TNB_GROUP_MAX = 24;
 struct TnbGroup {
   TnArgs p[TNB_GROUP_MAX];
   int tile_start[TNB_GROUP_MAX + 1];
-  int n;
+  int n, S, xcd;
 };
+// block -> (slice, tile).  xcd: the tiles of ONE slice (they read the same token rows: the i-tiles of a problem share all
+// of X, its j-tiles all of dY) get consecutive logical indices on one XCD, i.e. run side by side on one L2; 0: the old
+// order (slice fastest: a slice's tiles are S blocks apart and meet nowhere -- 2.43 GB fetched per launch for 1.7 GB of
+// operands on the README net)
+__device__ __forceinline__ void tnb_group_block(const TnbGroup& g, int& slice, int& t) {
+  const int tiles = g.tile_start[g.n];
+  if (g.xcd) {
+    const int L = sr_xcd_block(blockIdx.x, gridDim.x);
+    t = L % tiles;
+    slice = L / tiles;
+  } else {
+    slice = blockIdx.x % g.S;
+    t = blockIdx.x / g.S;
+  }
+}
 template <int W, int DBG = 0>
 __global__ void __launch_bounds__(512, 1) k_tnb_grouped(TnbGroup g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int t = blockIdx.y;
+  int slice, t;
+  tnb_group_block(g, slice, t);
   TnArgs p = g.p[0];
   int t0 = 0;
 #pragma unroll
   for (int i = 1; i < TNB_GROUP_MAX; ++i)
     if (i < g.n && t >= g.tile_start[i]) { p = g.p[i]; t0 = g.tile_start[i]; }
-  tnb_body<W, DBG>(p, blockIdx.x, t - t0, 0, smem);
+  tnb_body<W, DBG>(p, slice, t - t0, 0, smem);
+}
+
+template <int W>
+__global__ void __launch_bounds__(512, 1) k_tnb_grouped_h(TnbGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int slice, t;
+  tnb_group_block(g, slice, t);
+  TnArgs p = g.p[0];
+  int t0 = 0;
+#pragma unroll
+  for (int i = 1; i < TNB_GROUP_MAX; ++i)
+    if (i < g.n && t >= g.tile_start[i]) { p = g.p[i]; t0 = g.tile_start[i]; }
+  tnb_body_h<W>(p, slice, t - t0, smem);
 }
 
 // Up to TNB_BATCH_MAX conv weight-gradient problems of ONE shape (same image geometry and channel
@@ -864,7 +1175,10 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
     g.p[k] = p;
   }
   g.tile_start[n] = tiles;
-  dim3 grid(probs[0].S, tiles, 1);
+  g.S = probs[0].S;
+  static const int gxcd = [] { const char* e = getenv("SRHIP_TN_GROUP_XCD"); return e ? atoi(e) : 1; }();
+  g.xcd = gxcd;
+  dim3 grid(probs[0].S * tiles, 1, 1);
   static bool attr[4] = {false, false, false, false};
 #define SR_TNB_G(W_)                                                                      \
   if (w == W_) {                                                                          \
@@ -876,6 +1190,16 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
   }
   const char* dbg_env = getenv("SRHIP_TN_DBG");
   const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  // 192-column tiles on two fp16 planes / three products (tnb_body_h); SRHIP_TN_F16X2_LINEAR=0: bf16x3 / six
+  static const int f16lin = [] { const char* e = getenv("SRHIP_TN_F16X2_LINEAR"); return e ? atoi(e) : 1; }();
+  if (w == 3 && !dbg && f16lin) {
+    static bool attr_h = false;
+    if (!attr_h) {
+      if (int rc = reserve_lds(k_tnb_grouped_h<3>, lds_bytes(3), "k_tnb_grouped_h")) return rc;
+      attr_h = true;
+    }
+    hipLaunchKernelGGL((k_tnb_grouped_h<3>), grid, dim3(512), lds_bytes(3), st, g);
+  } else
   if (w == 3 && dbg == 1) { hipLaunchKernelGGL((k_tnb_grouped<3, 1>), grid, dim3(512), lds_bytes(3), st, g); }
   else if (w == 3 && dbg == 2) { hipLaunchKernelGGL((k_tnb_grouped<3, 2>), grid, dim3(512), lds_bytes(3), st, g); }
   else if (w == 3 && dbg == 4) { hipLaunchKernelGGL((k_tnb_grouped<3, 4>), grid, dim3(512), lds_bytes(3), st, g); }

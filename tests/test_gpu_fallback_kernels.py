@@ -199,17 +199,50 @@ TN16_CHILD = textwrap.dedent('''
         assert relmax(db, br.grad) < 2e-6
         if kind == "zero":
             assert (dW[:5] == 0).all() and (dW[:, 7] == 0).all()
+    # grouped Linear weight gradients (192-column tiles, tnb_body_h): DropPath row scale on dY, plain / LayerNorm / GELU on X
+    gen = torch.Generator().manual_seed(5)
+    for (M, kind) in ((4097, "grad"), (33000, "rise"), (100, "zero")):
+        NI, NJ = 180, 360
+        dY, X = torch.randn(M, NI, generator=gen), torch.randn(M, NJ, generator=gen) * 1.5 + 0.3
+        if kind == "grad":
+            dY = dY * 1e-7 * torch.exp(torch.randn(M, 1, generator=gen) * 2.5) * torch.exp(torch.randn(1, NI, generator=gen) * 3.0)
+        if kind == "rise":
+            ramp = torch.exp2(torch.linspace(-30, 10, M)).reshape(M, 1)
+            dY, X = dY * ramp, X * ramp
+        if kind == "zero":
+            dY[:, :5] = 0; X[:, 7] = 0; dY[: M // 2, 9] = 0
+        rs = torch.rand(M // 16 + 1, generator=gen) + 0.5
+        st = torch.stack([X.mean(1), 1 / torch.sqrt(X.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+        outs = [(torch.empty(NI, NJ).cuda(), torch.empty(NI).cuda()) for _ in range(3)]
+        ops.linear_wgrad_grouped([
+            dict(dY=dY.cuda(), X=X.cuda(), dW=outs[0][0], db=outs[0][1], a_rowscale=rs.cuda(), a_rowscale_rows=16),
+            dict(dY=dY.cuda(), X=X.cuda(), dW=outs[1][0], db=outs[1][1], b_mode=1, ln_stats=st.cuda()),
+            dict(dY=dY.cuda(), X=X.cuda(), dW=outs[2][0], db=outs[2][1], b_mode=2)])
+        dYs = dY.double() * rs.double().repeat_interleave(16)[:M, None]
+        Xn = (X.double() - st[:, :1].double()) * st[:, 1:].double()
+        refs = [(dYs, X.double()), (dY.double(), Xn), (dY.double(), F.gelu(X.double()))]
+        refs32 = [((dY * rs.repeat_interleave(16)[:M, None]), X), (dY, (X - st[:, :1]) * st[:, 1:]), (dY, F.gelu(X))]
+        for (dw, db), (a, b), (a32, b32) in zip(outs, refs, refs32):
+            ref = a.t() @ b
+            den = ref.abs().max(1, keepdim=True).values.clamp_min(1e-300)
+            e = ((dw.double().cpu() - ref).abs() / den).max().item()
+            e32 = (((a32.t() @ b32).double() - ref).abs() / den).max().item()
+            assert e <= max(3.0 * e32, 2e-6), ("linear", M, kind, e, e32)
+            assert relmax(db, a.sum(0)) < 2e-6
+            if kind == "zero":
+                assert (dw[:5] == 0).all()
     print("ok")
 ''')
 
 
-@pytest.mark.parametrize("env", [{}, {"SRHIP_TN_F16X2": "0"}])
+@pytest.mark.parametrize("env", [{}, {"SRHIP_TN_F16X2": "0", "SRHIP_TN_F16X2_LINEAR": "0", "SRHIP_TN_GROUP_XCD": "0"}])
 def test_fp16x2_three_product_conv_weight_gradient_is_f32_grade(env):
     """The three-tap conv weight-gradient kernels (k_tnb3 / k_tnb3_conv_batched) with two fp16 planes, one running
     power-of-two scale per operand COLUMN (channel) and three products: every row of dW, relative to its largest entry,
     is within 3x of an f32 autograd -- on gradient-like inputs (pixels and channels decades apart), on magnitudes that
     rise by 2^40 along the tokens (the scales must follow and the sums be rescaled) and with all-zero channels;
-    SRHIP_TN_F16X2=0 is the bf16x3 / six-product form."""
+    the same for the grouped Linear weight gradients (tnb_body_h: DropPath row scale, LayerNorm and GELU prologues).
+    Second arm: the bf16x3 / six-product forms and the old block order."""
     r = subprocess.run([sys.executable, "-c", TN16_CHILD], cwd=ROOT, env=dict(os.environ, **env),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-500:], r.stderr[-1500:])
