@@ -93,6 +93,15 @@ def collect():
     mean over all its timed launches, i.e. the figure rocprofv3 --stats reports for its kernel."""
     torch.cuda.synchronize()
     from . import ops
+    # what an event pair measures with NOTHING between its records: the part of avg_launch_us that is not the kernel
+    pairs = []
+    for _ in range(64):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); b.record()
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    gaps = sorted(a.elapsed_time(b) for a, b in pairs)
+    pair_us = 1000.0 * gaps[len(gaps) // 2]
     per_kind = {}
     for key, evs in _records.items():
         ms = sum(a.elapsed_time(b) for a, b, _, _ in evs)
@@ -125,6 +134,10 @@ def collect():
     out = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
            "traffic": traffic, "traffic_source": src,
            "kernel": f"{stem.split('|')[0]}*: {what}; {arith}", "launches": n, "avg_launch_us": 1000.0 * ms / n,
+           # achieved / frac above are priced on avg_launch_us as measured (conservative); an empty event pair on this
+           # stream reads event_pair_us, so the kernel itself takes about avg_launch_us - event_pair_us -- the figure to
+           # hold against rocprofv3's average duration in profiles/
+           "event_pair_us": pair_us, "avg_launch_us_minus_event_pair": 1000.0 * ms / n - pair_us,
            "algorithmic_gflop_per_launch": fl / n / 1e9,
            "algorithmic_mbytes_per_launch": by / n / 1e6,
            "hbm_side": {"achieved_gb_per_s_algorithmic": gbs, "frac_of_8tb_per_s": gbs / HBM_PEAK_GBS},
