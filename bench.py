@@ -300,7 +300,9 @@ def worker(args):
                        "parallelism": f"dp{world}", "final_loss": loss, "hip_graph": bool(use_graph),
                        "eval_patches_per_s_one_gpu": eval_pps, "eval_amp_patches_per_s_one_gpu": eval_amp_pps,
                        "matmul": (("Linear GEMMs: fp16x2 split MFMA (2 fp16 planes per operand under per-row power-of-two "
-                                   "scales, 3 products, f32 accumulate: f32-grade per row); convs / weight gradients: "
+                                   "scales, 3 products, f32 accumulate: f32-grade per row), the 180-channel convs (scales per "
+                                   "weight channel / halo tile) and the Linear weight gradients (running scale per operand "
+                                   "column) likewise; 180-channel conv weight gradients: "
                                    if getattr(ops_mod, "F16X2", False) and args.workload.startswith("swinir") else
                                    ("3x3 convs (64 .. 256 channels, fused PixelShuffle included) and their weight gradients: "
                                     "fp16x2 split MFMA (2 fp16 planes, power-of-two scales per weight channel / halo tile / "

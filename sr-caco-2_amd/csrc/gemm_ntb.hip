@@ -433,7 +433,7 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
     p.tiles_y = sr_cdiv(p.H, wm == 2 ? 8 : 4);
     p.xcd_order = ntb_env("SRHIP_CONV_XCD", 1);
   }
-  if constexpr (CONV) {       // weight planes of format 1 (two fp16 planes, prep kind 4): 64-column tiles only
+  if constexpr (CONV) {       // weight planes of format 1 (two fp16 planes, prep kind 4): k_nhcw2 (64-column tiles / slices) or k_nhcw
     if (p.wfmt == 1) {          // 64-column slices (column block fastest) for wider outputs, as k_ntcw2
       SR_REQUIRE((p.N <= 256 || p.N % 180 == 0) && p.K <= 256, "conv3x3_f16x2: Cout <= 256 or a multiple of 180, Cin <= 256 (Cout=%d Cin=%d)", p.N, p.K);
       if (wn == 3 && p.N % 64 != 0 && p.ps == 0) {     // 180 / 192-column tiles (SwinIR): 64-pixel tiles whatever the image size

@@ -157,7 +157,7 @@ __device__ __forceinline__ void job_planes_f16(const PrepEntry& e, int lb) {
 
 // kind 4 (experiment, SRHIP_F16X2_CONV=1): the tap-major conv pack as TWO fp16 planes with a power-of-two scale per OUTPUT
 //   channel (one scale for the channel's nine tap rows: they accumulate into the same output column); planes
-//   [2][Kp/16][9*n0][16] fp16, then n0 floats 2^-s(n).  One wave per output channel; K <= 256; no perms.
+//   [2][Kp/16][9*n0][16] fp16, then n0 floats 2^-s(n).  One wave per output channel; K <= 256; perms 3 / 4 (PixelShuffle orders) as kind 0.
 __device__ __forceinline__ void job_conv_planes_f16(const PrepEntry& e, int lb) {
   const int Kp = sr_kp(e.n2);
   const int n = lb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;

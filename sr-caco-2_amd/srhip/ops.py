@@ -51,9 +51,10 @@ BX3_MIN_CHANNELS = int(_os.environ.get("SRHIP_BX3_MIN_CH", "64"))
 # multiplied with THREE products (k_nth2, gemm_ntw.hip; srhip_gemm_nt_f16x2): f32-grade per row, +6 % on the SwinIR step.
 # SRHIP_F16X2=0: three bf16 planes / six products (k_ntw) for those too.
 F16X2 = _os.environ.get("SRHIP_F16X2", "1") not in ("", "0")
-# ... and the 3x3 convs that run on 64-column tiles (<= 64 output channels, 64..256 input channels, no PixelShuffle fusion):
-# two fp16 planes, one power-of-two scale per weight output channel and per activation halo tile, three products (k_nhcw2):
-# f32-grade per output pixel, EDSR x4 +10 %.  SRHIP_F16X2_CONV=0: bf16x3 (k_ntcw2).
+# ... and the 3x3 convs with 64 / 128 / 192 / 256 (64-column tiles or slices, the PixelShuffle-fused upsampler convs included) or
+# 180 (SwinIR: 192-column tiles) output channels and 64 .. 256 input channels: two fp16 planes, one power-of-two scale per
+# weight output channel and per activation halo tile, three products (k_nhcw2 / k_nhcw): f32-grade per output pixel.
+# SRHIP_F16X2_CONV=0: bf16x3 everywhere; _WIDE=0: only the plain 64-column convs; SRHIP_F16X2_CONV180=0: SwinIR's on k_ntcw.
 F16X2_CONV = _os.environ.get("SRHIP_F16X2_CONV", "1") not in ("", "0")
 F16X2_CONV_WIDE = _os.environ.get("SRHIP_F16X2_CONV_WIDE", "1") != "0"
 F16X2_CONV180 = _os.environ.get("SRHIP_F16X2_CONV180", "1") != "0"
