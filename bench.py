@@ -52,6 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (TrainStep.step_graph; 1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the EDSR x8 / x4 / x2 lines under config.secondary")
     return ap.parse_args(argv)
 
 
@@ -92,6 +93,66 @@ def synth_batch(batch, scale, device, seed):
     hr = (torch.rand(batch, 1, 512, 512, generator=g) * 255).round() / 255
     lr = F.interpolate(hr, scale_factor=1.0 / scale, mode="bicubic").clamp(0, 1)
     return lr.to(device), hr.to(device)
+
+
+def measured_bytes_per_step(workload):
+    """HBM bytes one training step moves, summed over every kernel of the committed rocprofv3 PMC passes of this
+    workload (profiles/r0N_hbm_traffic_per_kernel_<workload>_b8.json: FETCH_SIZE x 2 + WRITE_SIZE per launch x launches,
+    tools/collect_traffic.sh), divided by the optimizer launches of that run (= its steps).  None if not collected."""
+    tag = workload.replace("swinir_x8", "swinir")
+    for r in (9, 8, 7, 6, 5, 4, 3, 2):
+        path = os.path.join(ROOT, "profiles", f"r0{r}_hbm_traffic_per_kernel_{tag}_b8.json")
+        if os.path.isfile(path):
+            table = json.load(open(path))
+            steps = sum(v["launches"] for k, v in table.items() if "k_sgd_dc" in k or "k_adam_dc" in k)
+            if steps:
+                tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in table.values())
+                return tot / steps, os.path.basename(path)
+    return None, None
+
+
+def secondary_edsr(scale, batch, dev, steps=10, warmup=3):
+    """One EDSR-baseline workload (BASELINE.json configs[1]: x4; north_star's HBM target: x8) for `steps` training
+    steps after the headline's timed region, so that its figures are driver-observed too: patches/s, whole-step
+    hbm_frac (algorithmic bytes) and the dominant kernel class's live roofline fraction."""
+    import torch
+    from srhip import probe
+    from srhip.train import TrainStep, Optimizer
+    from dlib.models.network_edsr_liif import EDSR_LIIF
+    torch.manual_seed(0)
+    net = EDSR_LIIF(scale=scale).to(dev).train()
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "adam", lr=2e-4, wd=1e-4)
+    lr_img, hr_img = synth_batch(batch, scale, dev, seed=2000 + scale)
+    for _ in range(warmup):
+        ts.step(lr_img, hr_img)
+    torch.cuda.synchronize()
+    kinds = ("conv_nt", "conv_tn")
+    probe.enable(kinds)
+    probe.active = None
+    t0 = time.perf_counter()
+    for i in range(steps):
+        probe.active = set(kinds) if i == steps // 2 else None
+        ts.step(lr_img, hr_img)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    probe.active = set(kinds)
+    roof = probe.collect()
+    probe.disable()
+    pps = batch * steps / dt
+    gflop, gbyte = WORK[f"edsr_x{scale}"]
+    out = {"patches_per_s": pps, "ms_per_step": 1000.0 * dt / steps, "steps": steps,
+           "hbm_frac": gbyte * 3.0 * pps / HBM_PEAK_GBS, "final_loss": ts.loss_values()[0]}
+    mb, src = measured_bytes_per_step(f"edsr_x{scale}")
+    if mb:
+        out["hbm_frac_measured"] = mb * (pps / batch) / 1e9 / HBM_PEAK_GBS
+        out["measured_gbyte_per_step"] = mb / 1e9
+    if roof:
+        out["dominant_kernel"] = {"kernel": roof["kernel"].split(":")[0], "frac": roof["frac"], "peak": roof["peak"],
+                                  "achieved": roof["achieved"], "unit": roof["unit"], "avg_launch_us": roof["avg_launch_us"]}
+    del ts, net
+    torch.cuda.empty_cache()
+    return out
 
 
 def physical_cores():
@@ -211,6 +272,7 @@ def worker(args):
     else:
         ts.opt = Optimizer(ts.fp, "adam", lr=2e-4, wd=1e-4)
     lr_img, hr_img = synth_batch(args.batch, scale, dev, seed=1000 + rank)
+    torch.manual_seed(1234 + rank)            # DropPath masks differ per rank (every rank of the reference draws its own)
 
     def barrier():
         if pg is not None:
@@ -241,9 +303,11 @@ def worker(args):
     dt = time.perf_counter() - t0
     probe.active = set(kinds)
     # PMC traffic of THIS workload's kernels (profiles/, collected with tools/refresh_profiles.sh)
-    tj = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_per_kernel_{args.workload.replace('swinir_x8', 'swinir')}_b8.json")
-    if os.path.isfile(tj):
-        os.environ.setdefault("SRHIP_TRAFFIC_JSON", tj)
+    for r in (9, 8, 7, 6, 5, 4, 3, 2):
+        tj = os.path.join(ROOT, "profiles", f"r0{r}_hbm_traffic_per_kernel_{args.workload.replace('swinir_x8', 'swinir')}_b8.json")
+        if os.path.isfile(tj):
+            os.environ.setdefault("SRHIP_TRAFFIC_JSON", tj)
+            break
     roof = probe.collect() if not args.no_roofline else None
     probe.disable()
     steps_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
@@ -282,6 +346,9 @@ def worker(args):
             eval_amp_pps = args.batch * 10 / (time.perf_counter() - t1)
             net.amp = False
         net.train()
+    secondary = None
+    if rank == 0 and world == 1 and args.workload == "swinir_x8" and not args.no_secondary:
+        secondary = {f"edsr_x{sc}": secondary_edsr(sc, args.batch, dev) for sc in (8, 4, 2)}
     if rank == 0:
         patches = args.batch * world * args.steps
         pps = patches / dt
@@ -293,7 +360,10 @@ def worker(args):
             "value": pps, "unit": "patches/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "timer": "HIP events, rank 0"},
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # what the matrix core computes in: f32 operands as two fp16 planes under power-of-two block exponents, three
+            # products, f32 accumulate (f32-grade results: parity gates of tests/); nothing is STORED below f32
+            "dtype": "f32 (fp16x2 split-MFMA, f32 accumulate)" if bx and getattr(ops_mod, "F16X2", False) else "f32",
             "data": "synthetic",
             "config": {"workload": f"{desc}, fwd + {args.loss} + bwd + {opt_kind}",
                        "global_batch": args.batch * world, "batch_per_gpu": args.batch,
@@ -319,6 +389,14 @@ def worker(args):
                            "algorithmic_gflop_per_patch_fwd": gflop, "algorithmic_gbyte_per_patch_fwd": gbyte,
                            "per_gpu": True},
         }
+        # hbm_frac above prices the UNFUSED-convention bytes of SURVEY 8d; this one the bytes the step really moved (PMC)
+        mb, mb_src = measured_bytes_per_step(args.workload)
+        if mb:
+            out["whole_step"]["hbm_frac_measured"] = mb * (pps / world / args.batch) / 1e9 / HBM_PEAK_GBS
+            out["whole_step"]["measured_gbyte_per_step"] = mb / 1e9
+            out["whole_step"]["measured_source"] = mb_src
+        if secondary:
+            out["config"]["secondary"] = secondary
         if roof:
             out["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:

@@ -143,26 +143,24 @@ int srhip_conv3x3_ps2_f16x2(const float* X, long ldx, const void* Wh, const floa
 int srhip_conv3x3_ps2_bwd_data_f16x2(const float* dYup, long lddy, const void* Wht, float* dX, long ldx, int B, int H,
                                      int W, int Cout, int Cin, int epi, const float* R, long ldr, float alpha,
                                      void* stream);
-/* The MLP half of a Swin block in one kernel per direction (mlp_fused.hip): the hidden
- * activation goes from the first product's accumulators through registers and LDS into
- * the second product and never returns from HBM.
+/* The MLP half of a Swin block in one kernel per direction (mlp_f16.hip): the hidden activation goes from the first
+ * product's accumulators through registers and LDS into the second product and is never read back from HBM.
  *   forward : h = LN(x) . W1^T + b1 (stats[M][2] = {mean, rstd} of x; W1 gamma-folded, b1 beta-folded),
  *             out = x + s * (gelu(h) . W2^T + b2), stats_out = {mean, rstd} of the out rows (may be NULL);
  *             h may be NULL (inference), otherwise it is what the backward reads.
  *   backward: dh = (s * dy . W2) * gelu'(h), gh = gelu(h)  (both [M][ldh], operands of the weight gradients),
  *             dx = dy + LayerNorm-backward(dh . W1)  (x, stats as in the forward).
- * Weight planes in the kernel's own order, built by srhip_prep_table entries of kind 0 with
- * mode 4 + gamma mode (rows permuted) / 8 + gamma mode (k permuted), s0 = hidden / 2:
- *   forward  W1p = rows-permuted W1*gamma [2*192][C],      W2p = k-permuted W2 [C][2*192]
- *   backward W2Tp = rows-permuted W2^T [2*192][C],         W1Tp = k-permuted (W1*gamma)^T [C][2*192]
- * C <= 192 (multiple of 4), 192 < hidden <= 384 (multiple of 8); rowscale = DropPath multipliers per sample.
+ * Operands as the Linear GEMMs take them: two fp16 planes + per-row power-of-two scales (srhip_prep_table kind 3,
+ * no permutation), three products; rowscale = DropPath multipliers per sample.  W1h = planes of W1*gamma
+ * [hidden][C], W2h = planes of W2 [C][hidden]; backward W2Th = planes of W2^T [hidden][C], W1Th = planes of
+ * (W1*gamma)^T [C][hidden].  C <= 192, hidden <= 384, both multiples of 4; row pitches multiples of 4 floats.
  * Replaces Mlp.forward + residual (dlib/models/network_swinir.py:28-45,335-337) and its autograd. */
-int srhip_mlp_fwd_bx3(const float* x, long ldx, const float* stats, const void* W1p, const float* b1,
-                      const void* W2p, const float* b2, float* h, long ldh, float* out, long ldo, int M, int C,
-                      int hidden, const float* rowscale, int rows_per_scale, float* stats_out, void* stream);
-int srhip_mlp_bwd_bx3(const float* dy, long lddy, const void* W2Tp, const void* W1Tp, const float* h, long ldh,
-                      float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
-                      int M, int C, int hidden, const float* rowscale, int rows_per_scale, void* stream);
+int srhip_mlp_fwd_f16x2(const float* x, long ldx, const float* stats, const void* W1h, const float* b1,
+                        const void* W2h, const float* b2, float* h, long ldh, float* out, long ldo, int M, int C,
+                        int hidden, const float* rowscale, int rows_per_scale, float* stats_out, void* stream);
+int srhip_mlp_bwd_f16x2(const float* dy, long lddy, const void* W2Th, const void* W1Th, const float* h, long ldh,
+                        float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
+                        int M, int C, int hidden, const float* rowscale, int rows_per_scale, void* stream);
 int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
                            int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                            const float* rowscale, float alpha, void* stream);
@@ -229,21 +227,24 @@ int srhip_conv3x3_wgrad_bx3(const float* dY, long lddy, const float* X, long ldx
                             int Cout, int Cin, float* part, float* part_colsum, int S, void* stream);
 int srhip_reduce_linear_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
                               int N, int K, void* stream);
-/* Linear fed by a folded LayerNorm: also emits dgamma / dbeta of that norm
- * (accumulated with atomics: zeroed here unless ln_grads_zeroed != 0). */
+/* Linear fed by a folded LayerNorm: also emits dgamma / dbeta of that norm.  Deterministic: the row blocks'
+ * shares go to ln_ws (srhip_ln_affine_ws(N, K) floats, caller-owned) by plain stores and a second small launch
+ * adds them in a fixed order -- no atomics, nothing to zero. */
+long srhip_ln_affine_ws(int N, int K);
 int srhip_reduce_ln_linear_wgrad(const float* part, const float* colsum, int S, const float* W,
                                  const float* gamma, const float* beta, float* dW, float* db,
-                                 float* dgamma, float* dbeta, int N, int K, int ln_grads_zeroed,
+                                 float* dgamma, float* dbeta, int N, int K, float* ln_ws,
                                  void* stream);
 /* dW in torch layout [Cout][Cin][3][3]. */
 /* The slice reducers of up to 24 Linear problems (srhip_gemm_tn_grouped / _bx3) in one launch.
  * gamma == NULL: plain Linear (srhip_reduce_linear_wgrad); else the LayerNorm-folded form
- * (srhip_reduce_ln_linear_wgrad; dgamma / dbeta are accumulated with atomics: zero them first). */
+ * (srhip_reduce_ln_linear_wgrad; ln_ws = its workspace of srhip_ln_affine_ws(N, K) floats, one per problem). */
 typedef struct {
   const float* part; const float* colsum;
   const float* W; const float* gamma; const float* beta;
   float* dW; float* db; float* dgamma; float* dbeta;
   int N, K;
+  float* ln_ws;
 } srhip_reduce_problem;
 int srhip_reduce_wgrad_grouped(const srhip_reduce_problem* probs, int nprob, int S, void* stream);
 int srhip_reduce_conv_wgrad(const float* part, const float* colsum, int S, float* dW, float* db,
@@ -263,10 +264,12 @@ int srhip_pack_conv_weight(const float* w, float* wp, float* wpt, int Co, int Ci
 int srhip_layernorm_fwd(const float* x, float* stats, float* y, const float* gamma, const float* beta,
                         long M, int C, void* stream);
 /* out = res + dx.  gamma == NULL: dy is the gradient w.r.t. the normalised
- * value; else dy is w.r.t. y and dgamma/dbeta are produced. */
+ * value; else dy is w.r.t. y and dgamma/dbeta are produced (deterministically: per-block column sums in
+ * workspace -- srhip_layernorm_bwd_ws(M, C) floats, caller-owned -- added in block order by a second launch). */
+long srhip_layernorm_bwd_ws(long M, int C);
 int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* res,
-                        const float* gamma, float* out, float* dgamma, float* dbeta, long M, int C,
-                        void* stream);
+                        const float* gamma, float* out, float* dgamma, float* dbeta, float* workspace, long M,
+                        int C, void* stream);
 
 /* ---- window attention (network_swinir.py:48-80,140-179,297-331) -------------- */
 /* table (225,heads) -> two bias images of heads*4096 floats each, stored in the order

@@ -134,39 +134,39 @@ int srhip_gemm_nt_f16x2_lnbwd(const float* A, long lda, const void* Wh, float* o
   return gemm_nt_split_lnbwd(1, A, lda, Wh, out, ldo, M, N, K, x, ldx, stats, res, ldres, stream);
 }
 
-int srhip_mlp_fwd_bx3(const float* x, long ldx, const float* stats, const void* W1p, const float* b1,
-                      const void* W2p, const float* b2, float* h, long ldh, float* out, long ldo, int M, int C,
-                      int hidden, const float* rowscale, int rows_per_scale, float* stats_out, void* stream) {
-  SR_REQUIRE(x && stats && W1p && b1 && W2p && out, "mlp_fwd_bx3: null operand");
-  SR_REQUIRE(hidden % 2 == 0, "mlp_fwd_bx3: hidden %d", hidden);
-  SR_REQUIRE(!rowscale || rows_per_scale > 0, "mlp_fwd_bx3: rows_per_scale must be > 0");
-  SR_REQUIRE(sr_matmul_mode() == 0, "mlp_fwd_bx3: f32-accurate matmul mode only");
-  MlpArgs p;
+int srhip_mlp_fwd_f16x2(const float* x, long ldx, const float* stats, const void* W1h, const float* b1,
+                        const void* W2h, const float* b2, float* h, long ldh, float* out, long ldo, int M, int C,
+                        int hidden, const float* rowscale, int rows_per_scale, float* stats_out, void* stream) {
+  SR_REQUIRE(x && stats && W1h && b1 && W2h && out, "mlp_fwd_f16x2: null operand");
+  SR_REQUIRE(!rowscale || rows_per_scale > 0, "mlp_fwd_f16x2: rows_per_scale must be > 0");
+  SR_REQUIRE(sr_matmul_mode() == 0, "mlp_fwd_f16x2: f32-accurate matmul mode only");
+  MlpF16Args p;
   memset(&p, 0, sizeof(p));
-  p.o.C = out; p.o.ldc = ldo; p.o.M = M; p.o.N = C; p.o.K = hidden; p.o.bias = b2; p.o.epi = 2;
-  p.o.R = x; p.o.ldr = ldx; p.o.rowscale = rowscale; p.o.rows_per_scale = rows_per_scale; p.o.alpha = 1.f;
-  p.o.stats_out = stats_out;
-  p.X = x; p.ldx = ldx; p.ln_stats = stats; p.K1 = C; p.hs = hidden / 2;
-  p.W1b = (const unsigned short*)W1p; p.W2b = (const unsigned short*)W2p; p.b1 = b1; p.H = h; p.ldh = h ? ldh : 4;
-  return sr_mlp_fused(p, (hipStream_t)stream);
+  p.X = x; p.ldx = ldx; p.ln_stats = stats;
+  p.W1 = (const unsigned short*)W1h; p.N1 = hidden; p.K1 = C; p.Kp1 = sr_kp(C);
+  p.W2 = (const unsigned short*)W2h; p.N2 = C; p.K2 = hidden; p.Kp2 = sr_kp(hidden);
+  p.b1 = b1; p.b2 = b2; p.H = h; p.ldh = h ? ldh : 4; p.out = out; p.ldo = ldo; p.R = x; p.ldr = ldx;
+  p.rowscale = rowscale; p.rows_per_scale = rows_per_scale; p.stats_out = stats_out;
+  p.M = M; p.C = C; p.hid = hidden;
+  return sr_mlp_f16(p, 0, (hipStream_t)stream);
 }
 
-int srhip_mlp_bwd_bx3(const float* dy, long lddy, const void* W2Tp, const void* W1Tp, const float* h, long ldh,
-                      float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
-                      int M, int C, int hidden, const float* rowscale, int rows_per_scale, void* stream) {
-  SR_REQUIRE(dy && W2Tp && W1Tp && h && dh && gh && x && stats && dx, "mlp_bwd_bx3: null operand");
-  SR_REQUIRE(hidden % 2 == 0, "mlp_bwd_bx3: hidden %d", hidden);
-  SR_REQUIRE(!rowscale || rows_per_scale > 0, "mlp_bwd_bx3: rows_per_scale must be > 0");
-  SR_REQUIRE(sr_matmul_mode() == 0, "mlp_bwd_bx3: f32-accurate matmul mode only");
-  MlpArgs p;
+int srhip_mlp_bwd_f16x2(const float* dy, long lddy, const void* W2Th, const void* W1Th, const float* h, long ldh,
+                        float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
+                        int M, int C, int hidden, const float* rowscale, int rows_per_scale, void* stream) {
+  SR_REQUIRE(dy && W2Th && W1Th && h && dh && gh && x && stats && dx, "mlp_bwd_f16x2: null operand");
+  SR_REQUIRE(!rowscale || rows_per_scale > 0, "mlp_bwd_f16x2: rows_per_scale must be > 0");
+  SR_REQUIRE(sr_matmul_mode() == 0, "mlp_bwd_f16x2: f32-accurate matmul mode only");
+  MlpF16Args p;
   memset(&p, 0, sizeof(p));
-  p.o.C = dx; p.o.ldc = lddx; p.o.M = M; p.o.N = C; p.o.K = hidden; p.o.epi = 5; p.o.alpha = 1.f;
-  p.o.R = x; p.o.ldr = ldx; p.o.R2 = dy; p.o.ldr2 = lddy; p.o.ep_stats = stats;
-  p.X = dy; p.ldx = lddy; p.K1 = C; p.hs = hidden / 2;
-  p.W1b = (const unsigned short*)W2Tp; p.W2b = (const unsigned short*)W1Tp;
-  p.H = (float*)h; p.ldh = ldh; p.dH = dh; p.GH = gh; p.rowscale1 = rowscale; p.rows_per_scale1 = rows_per_scale;
-  p.bwd = 1;
-  return sr_mlp_fused(p, (hipStream_t)stream);
+  p.X = dy; p.ldx = lddy;
+  p.W1 = (const unsigned short*)W2Th; p.N1 = hidden; p.K1 = C; p.Kp1 = sr_kp(C);
+  p.W2 = (const unsigned short*)W1Th; p.N2 = C; p.K2 = hidden; p.Kp2 = sr_kp(hidden);
+  p.H = (float*)h; p.ldh = ldh; p.dH = dh; p.GH = gh; p.out = dx; p.ldo = lddx;
+  p.R = x; p.ldr = ldx; p.R2 = dy; p.ldr2 = lddy; p.ep_stats = stats;
+  p.rowscale = rowscale; p.rows_per_scale = rows_per_scale;
+  p.M = M; p.C = C; p.hid = hidden;
+  return sr_mlp_f16(p, 1, (hipStream_t)stream);
 }
 
 static int conv3x3_split(int wfmt, const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,

@@ -19,6 +19,15 @@ int sr_fail(int code, const char* fmt, ...);
   do { hipError_t e_ = hipGetLastError(); \
        if (e_ != hipSuccess) return sr_fail(-5, "%s: %s", name, hipGetErrorString(e_)); } while (0)
 
+// Tuning and ablation switches are read from the environment only by builds made with `make EXPERIMENTS=1`
+// (-DSRHIP_EXPERIMENTS; tools/ab_*.sh load such a build through SRHIP_LIB): the shipped library takes its defaults.
+#ifdef SRHIP_EXPERIMENTS
+#include <stdlib.h>
+static inline const char* sr_getenv(const char* name) { return getenv(name); }
+#else
+static inline const char* sr_getenv(const char*) { return nullptr; }
+#endif
+
 static inline int sr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Neutral operands for optional per-row prologue data.  A conditional load whose

@@ -256,7 +256,7 @@ int launch_nt(const NtArgs& p, hipStream_t st) {
 }
 
 int nt_env(const char* name, int dflt) {
-  const char* e = getenv(name);
+  const char* e = sr_getenv(name);
   return e ? atoi(e) : dflt;
 }
 
@@ -317,7 +317,7 @@ int dispatch_nt(NtArgs& p, hipStream_t st) {
 }  // namespace
 
 static int nt_dbg() {
-  const char* e = getenv("SRHIP_NT_DBG");
+  const char* e = sr_getenv("SRHIP_NT_DBG");
   return e ? atoi(e) : 0;
 }
 

@@ -408,7 +408,7 @@ int launch_ntb(const NtArgs& p, hipStream_t st) {
 }
 
 int ntb_env(const char* name, int dflt) {
-  const char* e = getenv(name);
+  const char* e = sr_getenv(name);
   return e ? atoi(e) : dflt;
 }
 
@@ -518,11 +518,9 @@ int sr_gemm_ntb(NtArgs& p, hipStream_t st) {
   p.wide_epi = p.N % 4 == 0 && al4(p.C, p.ldc) && al4(p.R, p.ldr) && al4(p.aux, p.ldaux) &&
                ((size_t)p.C & 15) == 0 && ntb_env("SRHIP_NTB_WIDE", 1);
   // K <= 192 at 180-column widths (the K = 180 Linears of a Swin block): weights resident in registers,
-  // persistent blocks, only A through LDS (gemm_ntr.hip)
   p.amp = sr_matmul_mode();
   if (p.wfmt == 1) return sr_gemm_ntp(p, st);          // two-plane fp16 operand: k_nth (gemm_ntw.hip), whatever the mode
   if (p.amp && p.epi != 5) return sr_gemm_ntp(p, st);
-  if (sr_gemm_ntr_ok(p)) return sr_gemm_ntr(p, st);
   // 64-row tiles (every case but very tall problems with narrow N, which take the 128-row
   // tiles of this file): the 16-wide-stage kernel of gemm_ntp.hip
   {

@@ -214,7 +214,7 @@ int launch_ntp(const NtArgs& p, hipStream_t st) {
 // Caller (gemm_ntb.hip) has validated the operands and set Kp / epi / wide_epi; tile width chosen here.
 int sr_gemm_ntp(NtArgs& p, hipStream_t st) {
   // 192-column tiles of the f32-accurate path: W fragments straight from global memory (gemm_ntw.hip); SRHIP_NTW=0: this file's kernel
-  static const bool ntw = [] { const char* e = getenv("SRHIP_NTW"); return !(e && e[0] == '0'); }();
+  static const bool ntw = [] { const char* e = sr_getenv("SRHIP_NTW"); return !(e && e[0] == '0'); }();
   const bool w = (ntw && !p.dbg) || p.wfmt == 1;
   if (p.N % 180 == 0) { p.n_tile = 180; return w ? sr_gemm_ntw(p, st) : launch_ntp<3>(p, st); }
   if (p.N <= 64) { p.n_tile = 64; return launch_ntp<1>(p, st); }

@@ -243,14 +243,14 @@ __global__ void __launch_bounds__(256, 2) k_ntw(NtArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_nth (weight operands of format 1, srhip_gemm_nt_f16x2): the same GEMM on TWO fp16 planes per operand and THREE products
+// Weight operands of format 1 (srhip_gemm_nt_f16x2): the same GEMM on TWO fp16 planes per operand and THREE products
 // (h.h + h.l + l.h on v_mfma_f32_16x16x32_f16) instead of three bf16 planes and six.  What makes two planes enough is
 // a power-of-two scale per ROW of either operand (a block exponent: exact to apply and to undo): x' = x * 2^s with
 // max|x'| in [8192, 16384], x' = h + l, h = fp16(x'), l = fp16(x' - h) carries 22 bits relative to the row's largest
 // element; emulated against float64 (tools/split_accuracy.py) the results are indistinguishable from a plain f32 matmul.
 // W: planes + per-row 2^-s from the preparation kernel (prep.hip kind 3).  A: the row scale is known a priori behind the
-// LayerNorm prologue (|xhat| <= sqrt(K)), otherwise a pre-pass over the block's 64 rows finds the row maxima (one extra
-// read of the A tile).  Half the MFMAs, a third less LDS, W fetch and fragment registers than k_ntw.
+// LayerNorm prologue (|xhat| <= sqrt(K)), otherwise it is a running value over 192-k passes (k_nth2 below).  Half the
+// MFMAs, a third less LDS, W fetch and fragment registers than k_ntw.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int H_APLANE = A_PLANE;                // 64 rows x 32 k fp16
 constexpr int H_ASTAGE = 2 * H_APLANE;
@@ -268,174 +268,8 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, uns
   l = __builtin_bit_cast(unsigned, lv);
 }
 
-__global__ void __launch_bounds__(256, 2) k_nth(NtArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* const rinv = (float*)(smem + NTW_LDS);          // [64] 2^-s of the block's A rows (behind the epilogue's tiles)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, g = lane >> 4;
-  const int ncol = (p.N + p.n_tile - 1) / p.n_tile;
-  int bt = sr_xcd_block((int)blockIdx.x, gridDim.x);
-  const int bcol = bt % ncol; bt /= ncol;
-  const int m0 = bt * BM;
-  const int n0 = bcol * p.n_tile;
-  const int nvalid = min(p.n_tile, p.N - n0);
-  const int nst = (p.K + SK - 1) / SK;
-
-  const int arow = tid >> 2, akq = tid & 3;
-  const int agm = min(m0 + arow, p.M - 1);
-  const char* const abase = (const char*)p.A + (long)agm * p.lda * 4;
-  const float2 rst = ldg_f2(p.a_mode == 1 ? p.ln_stats + 2 * agm : k_sr_neutral);
-  const int a_dst = a_slot(arow, akq) * 16;
-
-  // ---- W fragments first (they do not depend on the row scale)
-  const long plane_bytes = (long)p.N * p.Kp * 2;
-  const float* const winv_all = (const float*)((const char*)p.Wb + 2 * plane_bytes);
-  unsigned boff[3];
-  float winv[3];
-#pragma unroll
-  for (int jt = 0; jt < 3; ++jt) {
-    const int col = n0 + min(wave * 48 + jt * 16 + c, nvalid - 1);
-    boff[jt] = (unsigned)(((g >> 1) * p.N + col) * 32 + (g & 1) * 16);
-    winv[jt] = winv_all[col];
-  }
-  auto load_b = [&](int cs, u32x4 (&fb)[3][2]) {
-    const char* base = (const char*)p.Wb + (long)(2 * cs) * p.N * 32;
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-      for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane_bytes + boff[jt]);
-  };
-  u32x4 fb0[3][2], fb1[3][2], fb2[3][2];
-  load_b(0, fb0);
-  if (nst > 1) load_b(1, fb1);
-  if (nst > 2) load_b(2, fb2);
-
-  // ---- the row scale 2^s: a priori behind the LayerNorm prologue, else from a pass over the row
-  float asc;
-  if (p.a_mode == 1 || p.stagger == -8) {       // stagger == -8: timing ablation (SRHIP_F16X2_NOPREPASS=1), no pre-pass
-    asc = exp2f(floorf(log2f(16384.f * rsqrtf((float)p.K))));
-  } else {
-    float mx = 0.f;
-    for (int k0 = akq * 4; k0 < p.K; k0 += 16 * 12) {        // twelve loads in flight: K = 180 in one batch, 360 in two
-      f32x4 v[12];
-#pragma unroll
-      for (int u = 0; u < 12; ++u) {
-        const int k = k0 + 16 * u;
-        v[u] = *(const f32x4*)(abase + (k < p.K ? k * 4 : 0));       // past the end: k = 0 of the row again (harmless for a max)
-      }
-#pragma unroll
-      for (int u = 0; u < 12; ++u)
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));    // |gelu(x)| <= |x|
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-    asc = mx > 0.f ? exp2f(floorf(log2f(16384.f / mx))) : 1.f;
-  }
-  if (akq == 0) rinv[arow] = 1.0f / asc;
-
-  auto load_a = [&](int cs, f32x4 (&v)[2]) {
-    const int k = cs * SK + akq * 8;
-    v[0] = *(const f32x4*)(abase + (k < p.K ? k * 4 : 0));
-    v[1] = *(const f32x4*)(abase + (k + 4 < p.K ? (k + 4) * 4 : 0));
-  };
-  auto store_a = [&](int cs, f32x4 (&v)[2]) {
-    unsigned char* sa = smem + (cs & 1) * H_ASTAGE + a_dst;
-    const int k = cs * SK + akq * 8;
-    unsigned hh[4], ll[4];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      f32x4 x = v[e];
-      if (p.a_mode == 1) {
-        x.x = (x.x - rst.x) * rst.y; x.y = (x.y - rst.x) * rst.y; x.z = (x.z - rst.x) * rst.y; x.w = (x.w - rst.x) * rst.y;
-      } else if (p.a_mode == 2) {
-        x.x = gelu_f(x.x); x.y = gelu_f(x.y); x.z = gelu_f(x.z); x.w = gelu_f(x.w);
-      }
-      if (k + 4 * e >= p.K) x = f32x4{0.f, 0.f, 0.f, 0.f};
-      split2_pair(x.x * asc, x.y * asc, hh[2 * e], ll[2 * e]);
-      split2_pair(x.z * asc, x.w * asc, hh[2 * e + 1], ll[2 * e + 1]);
-    }
-    *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
-    *(u32x4*)(sa + H_APLANE) = u32x4{ll[0], ll[1], ll[2], ll[3]};
-  };
-
-  f32x4 acc[4][3];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int a_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) a_off[i] = a_slot(16 * i + c, g) * 16;
-
-  auto mma = [&](int cs, const u32x4 (&fb)[3][2]) {
-    const unsigned char* sa = smem + (cs & 1) * H_ASTAGE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      u32x4 fa[2];
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * H_APLANE + a_off[i]);
-#define SR_TERM(PA, PB) \
-  _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[i][j] = mfma16h(fa[PA], fb[j][PB], acc[i][j]);
-      SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)          // small terms first
-#undef SR_TERM
-    }
-  };
-
-  f32x4 ra0[2], ra1[2];
-  load_a(0, ra0);
-  if (nst > 1) load_a(1, ra1);
-  store_a(0, ra0);
-  if (nst > 2) load_a(2, ra0);
-  __syncthreads();
-#define SR_STEP(CS, RA, FB)                    \
-  if ((CS) + 1 < nst) store_a((CS) + 1, RA);   \
-  if ((CS) + 3 < nst) load_a((CS) + 3, RA);    \
-  mma((CS), FB);                               \
-  if ((CS) + 3 < nst) load_b((CS) + 3, FB);    \
-  __syncthreads();
-  for (int cs = 0; cs < nst; cs += 6) {
-    SR_STEP(cs, ra1, fb0)
-    if (cs + 1 < nst) { SR_STEP(cs + 1, ra0, fb1) }
-    if (cs + 2 < nst) { SR_STEP(cs + 2, ra1, fb2) }
-    if (cs + 3 < nst) { SR_STEP(cs + 3, ra0, fb0) }
-    if (cs + 4 < nst) { SR_STEP(cs + 4, ra1, fb1) }
-    if (cs + 5 < nst) { SR_STEP(cs + 5, ra0, fb2) }
-  }
-#undef SR_STEP
-
-  // ---- undo the block exponents while re-laying the accumulators (exact: powers of two), then the epilogues of k_ntw
-  float* const T = (float*)smem;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float ri = rinv[16 * i + 4 * g + e];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) T[(16 * i + 4 * g + e) * TP + wave * 48 + 16 * j + c] = acc[i][j][e] * (ri * winv[j]);
-    }
-  __syncthreads();
-  const int wm = wave >> 1, wn = wave & 1, r = lane & 31;
-  f32x16 acc2[1][3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc2[0][j][q] = T[(wm * 32 + mfma_row(q, lane)) * TP + (wn * 3 + j) * 32 + r];
-  __syncthreads();
-  if (p.epi == 5) {
-    nt_epilogue_lnbwd<3>(p, acc2, lane, wm, wn, m0, nvalid, (float*)smem);
-    return;
-  }
-  if (p.wide_epi) {
-    nt_epilogue_wide<3>(p, acc2, lane, wave, wm, wn, n0, nvalid, m0, (float*)smem);
-    return;
-  }
-  nt_epilogue<1, 3, false>(p, acc2, lane, wm, wn, n0, nvalid, m0, 0, 0, 0);
-  if (p.stats_out) nt_row_stats<3>(p, acc2, lane, wm, wn, m0, nvalid, (float*)smem);
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// k_nth2: k_nth without the pre-pass.  The block takes its A rows in PASSES of 192 k: a pass's 12 float4 per thread are
+// k_nth2.  The block takes its A rows in PASSES of 192 k: a pass's 12 float4 per thread are
 // loaded in one go, the row maximum of the pass comes out of the registers that hold them (four threads share a row: two
 // shuffles), the row's scale is the SMALLER of the scale so far and what this pass needs (scales only go down, so nothing
 // already accumulated can overflow), the accumulators of the rows whose scale dropped are multiplied by the exact power of
@@ -547,7 +381,7 @@ __global__ void __launch_bounds__(256, 2) k_nth2(NtArgs p) {
       if (p.a_mode != 1) {
         mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-        const float need = mx > 0.f ? exp2f(floorf(log2f(16384.f / mx))) : 3.0e38f;
+        const float need = mx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / mx)), 100.f)) : 3.0e38f;
         asc = fminf(asc, need);
       }
       const float use = asc > 1.0e38f ? 1.f : asc;        // an all-zero row so far: any scale
@@ -913,7 +747,7 @@ __global__ void __launch_bounds__(256, 2) k_nhcw(NtArgs p) {
     if (lane == 0) red[wave] = tmx;
     __syncthreads();
     const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float need = mx > 0.f ? exp2f(floorf(log2f(16384.f / mx))) : 3.0e38f;
+    const float need = mx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / mx)), 100.f)) : 3.0e38f;
     const float old = cur;
     cur = fminf(cur, need);                   // the scale only goes down: nothing accumulated can overflow
     const float use = cur > 1.0e38f ? 1.f : cur;
@@ -1289,7 +1123,7 @@ __global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
     if (lane == 0) red[wave] = tmx;
     __syncthreads();
     const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float need = mx > 0.f ? exp2f(floorf(log2f(16384.f / mx))) : 3.0e38f;
+    const float need = mx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / mx)), 100.f)) : 3.0e38f;
     const float old = cur;
     cur = fminf(cur, need);
     const float use = cur > 1.0e38f ? 1.f : cur;
@@ -1388,30 +1222,26 @@ int sr_conv3x3_ntcw(NtArgs& p, hipStream_t st) {
 int sr_gemm_ntw(NtArgs& p, hipStream_t st) {
   static_assert(NTW_LDS >= 2 * A_STAGE && NTW_LDS >= BM * TP * 4, "LDS regions");
   dim3 grid(sr_cdiv(p.M, BM) * sr_cdiv(p.N, p.n_tile));
-  static const int gridorder = [] { const char* e = getenv("SRHIP_NTW_GRID"); return e ? atoi(e) : 1; }();
+  static const int gridorder = [] { const char* e = sr_getenv("SRHIP_NTW_GRID"); return e ? atoi(e) : 1; }();
   p.xcd_order = gridorder;
-  static const int dbg = [] { const char* e = getenv("SRHIP_NTW_DBG"); return e ? atoi(e) : 0; }();
-  static const int rot = [] { const char* e = getenv("SRHIP_NTW_ROT"); return e ? atoi(e) : 1; }();
+#ifdef SRHIP_EXPERIMENTS
+  static const int dbg = [] { const char* e = sr_getenv("SRHIP_NTW_DBG"); return e ? atoi(e) : 0; }();
+#endif
+  static const int rot = [] { const char* e = sr_getenv("SRHIP_NTW_ROT"); return e ? atoi(e) : 1; }();
   p.k_rot = rot;
   if (p.wfmt == 1) {              // the caller's planes are prep kind 3 (two fp16 planes + row scales): also under --amp
-    static const int nopre = [] { const char* e = getenv("SRHIP_F16X2_NOPREPASS"); return e ? atoi(e) : 0; }();
-    p.stagger = nopre ? -8 : 0;   // timing ablation only: constant row scale, results can be wrong
-    static const int two = [] { const char* e = getenv("SRHIP_F16X2_PASSES"); return e ? atoi(e) : 1; }();
-    if (two && !nopre) {          // 192-k passes with a running row scale: no pre-pass over A (k_nth2); 0: k_nth
-      if (p.amp && p.epi != 5) hipLaunchKernelGGL(k_nth2<true>, grid, dim3(256), NTH2_LDS, st, p);
-      else hipLaunchKernelGGL(k_nth2<false>, grid, dim3(256), NTH2_LDS, st, p);
-      SR_LAUNCH_CHECK("k_nth2");
-      return 0;
-    }
-    hipLaunchKernelGGL(k_nth, grid, dim3(256), NTW_LDS + 256, st, p);
-    SR_LAUNCH_CHECK("k_nth");
+    if (p.amp && p.epi != 5) hipLaunchKernelGGL(k_nth2<true>, grid, dim3(256), NTH2_LDS, st, p);
+    else hipLaunchKernelGGL(k_nth2<false>, grid, dim3(256), NTH2_LDS, st, p);
+    SR_LAUNCH_CHECK("k_nth2");
     return 0;
   }
   if (p.amp) {
     hipLaunchKernelGGL((k_ntw<false, true>), grid, dim3(256), NTW_LDS, st, p);
-  } else if (dbg) {
+#ifdef SRHIP_EXPERIMENTS
+  } else if (dbg) {               // timing ablations of the K loop (results are wrong on purpose)
     p.dbg = dbg;
     hipLaunchKernelGGL(k_ntw<true>, grid, dim3(256), NTW_LDS, st, p);
+#endif
   } else {
     hipLaunchKernelGGL(k_ntw<false>, grid, dim3(256), NTW_LDS, st, p);
   }

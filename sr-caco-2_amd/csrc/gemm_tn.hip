@@ -240,7 +240,7 @@ int sr_tn_group_plan(int M, int ntiles, int* S) { return sr_tn_group_plan_t(M, n
 int sr_tn_group_plan_t(int M, int ntiles, int dflt_target, int* S) {
   // one whole round of 512 blocks (2 blocks per CU, so one block's staging and
   // index math overlap the other's MFMAs); env SRHIP_TN_BLOCKS overrides
-  const char* e = getenv("SRHIP_TN_BLOCKS");
+  const char* e = sr_getenv("SRHIP_TN_BLOCKS");
   const long target = e ? atol(e) : dflt_target;
   long s = target / ntiles;
   if (s < 1) s = 1;

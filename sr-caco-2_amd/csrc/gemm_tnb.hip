@@ -1108,7 +1108,7 @@ __global__ void __launch_bounds__(512, 6) k_tnb3_conv_batched(TnbConvBatch g) {
 
 // three taps per block (tnb_body3) for this problem?  SRHIP_TN_T3=0: one tap per block
 bool tnb_t3_shape(int conv, int NI, int NJ, int w) {
-  static const int on = [] { const char* e = getenv("SRHIP_TN_T3"); return !(e && e[0] == '0'); }();
+  static const int on = [] { const char* e = sr_getenv("SRHIP_TN_T3"); return !(e && e[0] == '0'); }();
   return on && conv && w == 1 && NI % 64 == 0 && NJ % 64 == 0;
 }
 bool tnb_t3_ok(const TnArgs& p, int w) {
@@ -1117,7 +1117,7 @@ bool tnb_t3_ok(const TnArgs& p, int w) {
 constexpr int lds_bytes3() { return 2 * 3 * 4 * 64 * 32; }
 // two fp16 planes / three products in the three-tap kernels (default); SRHIP_TN_F16X2=0: three bf16 planes / six products
 bool tnb_f16() {
-  static const int on = [] { const char* e = getenv("SRHIP_TN_F16X2"); return !(e && e[0] == '0'); }();
+  static const int on = [] { const char* e = sr_getenv("SRHIP_TN_F16X2"); return !(e && e[0] == '0'); }();
   return on;
 }
 
@@ -1176,7 +1176,7 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
   }
   g.tile_start[n] = tiles;
   g.S = probs[0].S;
-  static const int gxcd = [] { const char* e = getenv("SRHIP_TN_GROUP_XCD"); return e ? atoi(e) : 1; }();
+  static const int gxcd = [] { const char* e = sr_getenv("SRHIP_TN_GROUP_XCD"); return e ? atoi(e) : 1; }();
   g.xcd = gxcd;
   dim3 grid(probs[0].S * tiles, 1, 1);
   static bool attr[4] = {false, false, false, false};
@@ -1188,10 +1188,14 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
     }                                                                                     \
     hipLaunchKernelGGL((k_tnb_grouped<W_>), grid, dim3(512), lds_bytes(W_), st, g);       \
   }
-  const char* dbg_env = getenv("SRHIP_TN_DBG");
-  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+#ifdef SRHIP_EXPERIMENTS
+  const char* dbg_env = sr_getenv("SRHIP_TN_DBG");
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;      // role ablations (results are wrong on purpose)
+#else
+  constexpr int dbg = 0;
+#endif
   // 192-column tiles on two fp16 planes / three products (tnb_body_h); SRHIP_TN_F16X2_LINEAR=0: bf16x3 / six
-  static const int f16lin = [] { const char* e = getenv("SRHIP_TN_F16X2_LINEAR"); return e ? atoi(e) : 1; }();
+  static const int f16lin = [] { const char* e = sr_getenv("SRHIP_TN_F16X2_LINEAR"); return e ? atoi(e) : 1; }();
   if (w == 3 && !dbg && f16lin) {
     static bool attr_h = false;
     if (!attr_h) {
@@ -1200,11 +1204,14 @@ int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st) {
     }
     hipLaunchKernelGGL((k_tnb_grouped_h<3>), grid, dim3(512), lds_bytes(3), st, g);
   } else
+#ifdef SRHIP_EXPERIMENTS
   if (w == 3 && dbg == 1) { hipLaunchKernelGGL((k_tnb_grouped<3, 1>), grid, dim3(512), lds_bytes(3), st, g); }
   else if (w == 3 && dbg == 2) { hipLaunchKernelGGL((k_tnb_grouped<3, 2>), grid, dim3(512), lds_bytes(3), st, g); }
   else if (w == 3 && dbg == 4) { hipLaunchKernelGGL((k_tnb_grouped<3, 4>), grid, dim3(512), lds_bytes(3), st, g); }
   else if (w == 3 && dbg == 3) { hipLaunchKernelGGL((k_tnb_grouped<3, 3>), grid, dim3(512), lds_bytes(3), st, g); }
-  else {
+  else
+#endif
+  {
   SR_TNB_G(1) SR_TNB_G(2) SR_TNB_G(3)
   }
 #undef SR_TNB_G
@@ -1226,7 +1233,7 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
   const int tiles = sr_cdiv(p.NI, p.i_tile) * sr_cdiv(p.NJ, p.j_tile);
   dim3 grid(p.S, tiles, 1);
   if (p.conv) grid = dim3(p.S * tiles * 9, 1, 1);
-  static const int xcd = [] { const char* e = getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
+  static const int xcd = [] { const char* e = sr_getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
   if (tnb_t3_ok(p, w)) {       // 64-wide conv problem: three taps per block
     static bool attr3 = false;
     if (!attr3) {
@@ -1295,7 +1302,7 @@ int sr_conv_wgrad_batched_tnb(const TnArgs& base, const float* const* A, const f
   g.part_stride = part_stride;
   g.colsum_stride = colsum_stride;
   for (int k = 0; k < n; ++k) { g.A[k] = A[k]; g.B[k] = B[k]; }
-  static const int xcd = [] { const char* e = getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
+  static const int xcd = [] { const char* e = sr_getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
   g.xcd = xcd;
   if (tnb_t3_ok(g.base, w)) {  // three taps per block
     static bool attr3 = false;
@@ -1332,8 +1339,8 @@ int sr_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
   const int w = pick_w(NI, NJ, &tile);
   const bool t3 = tnb_t3_shape(conv, NI, NJ, w);          // three taps per block
   const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * (conv ? (t3 ? 3 : 9) : 1);
-  static const long t1 = [] { const char* e = getenv("SRHIP_TNB_BLOCKS_W1"); return e ? atol(e) : 768L; }();
-  static const long t3b = [] { const char* e = getenv("SRHIP_TNB_BLOCKS_T3"); return e ? atol(e) : 768L; }();
+  static const long t1 = [] { const char* e = sr_getenv("SRHIP_TNB_BLOCKS_W1"); return e ? atol(e) : 768L; }();
+  static const long t3b = [] { const char* e = sr_getenv("SRHIP_TNB_BLOCKS_T3"); return e ? atol(e) : 768L; }();
   long s = (t3 ? t3b : (w == 1 ? t1 : 256)) / tiles;
   const long smax = (M + 127) / 128;
   if (s > smax) s = smax;

@@ -57,22 +57,24 @@ struct TnArgs {
                               // (lda = its pixel pitch); out rows are written in torch channel order c*4 + sp
 };
 
-// fused MLP half of a Swin block (mlp_fused.hip)
-struct MlpArgs {
-  NtArgs o;                    // output side: C, ldc, M, N (= channels), bias, epi (2 forward | 5 backward), R, R2, ep_stats, rowscale, stats_out
-  const float* X; long ldx;    // phase-1 activation rows [M][ldx]: forward x (LayerNorm prologue), backward dY
-  const float* ln_stats;       // forward: {mean, rstd}[M] of the X rows
-  int K1, Kp1;                 // channels (phase-1 reduce length) and its padded plane width
-  int hs;                      // hidden / 2
-  const unsigned short* W1b;   // phase-1 weight planes, rows in (round, half, unit) order   (prep perm 1)
-  const unsigned short* W2b;   // phase-2 weight planes, k in the accumulator-register order (prep perm 2)
-  const float* b1;             // forward: bias of the hidden layer [hidden]
-  float* H; long ldh;          // forward: pre-activation output (may be null) | backward: its input
-  float* dH; float* GH;        // backward outputs [M][ldh]: d loss / d h and gelu(h)
-  const float* rowscale1; int rows_per_scale1;   // backward: per-sample scale of dY (DropPath), null = 1
-  int bwd;
+// the MLP half of a Swin block as one kernel per direction, on the two-plane fp16 operands of the Linear GEMMs (mlp_f16.hip)
+struct MlpF16Args {
+  const float* X; long ldx;          // GEMM-1 activation rows [M][ldx]: forward x (LayerNorm prologue), backward dy
+  const float* ln_stats;             // forward: {mean, rstd}[M] of the X rows
+  const unsigned short* W1; int N1, K1, Kp1;   // GEMM-1 weight (prep kind 3): rows = hidden units, K = channels
+  const unsigned short* W2; int N2, K2, Kp2;   // GEMM-2 weight (prep kind 3): rows = channels, K = hidden units
+  const float* b1; const float* b2;  // forward biases (b1 beta-folded)
+  float* H; long ldh;                // forward: pre-activation output (may be null) | backward: its input
+  float* dH; float* GH;              // backward outputs [M][ldh]
+  float* out; long ldo;
+  const float* R; long ldr;          // forward: residual (x) | backward: x of the LayerNorm
+  const float* R2; long ldr2;        // backward: residual gradient (dy)
+  const float* ep_stats;             // backward: {mean, rstd}[M] of x
+  const float* rowscale; int rows_per_scale;   // DropPath multipliers per sample (null = 1)
+  float* stats_out;                  // forward: {mean, rstd} of the out rows (may be null)
+  int M, C, hid;
 };
-int sr_mlp_fused(MlpArgs& p, hipStream_t st);
+int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st);
 
 int sr_matmul_mode();        // 0: f32-accurate bf16x3 | 1: single bf16 product (srhip_set_matmul_mode)
 int sr_gemm_nt(NtArgs& p, hipStream_t st);
@@ -98,8 +100,6 @@ int sr_conv3x3_ntcw(NtArgs& p, hipStream_t st);
 int sr_conv3x3_ntcw2(NtArgs& p, int rows_per_wave, hipStream_t st);
 int sr_conv3x3_nhcw(NtArgs& p, hipStream_t st);
 int sr_conv3x3_nhcw2(NtArgs& p, int rows_per_wave, hipStream_t st);   // the same on two fp16 planes (weight format 1)  // conv, 128- / 64-pixel x 64-column tiles, W fragments from global memory   // conv, 64-pixel x 192-column tiles, W fragments from global memory   // 192-column tiles, W fragments from global memory (gemm_ntw.hip)
-bool sr_gemm_ntr_ok(const NtArgs& p);
-int sr_gemm_ntr(NtArgs& p, hipStream_t st);
 int sr_gemm_tn(TnArgs& p, hipStream_t st);
 int sr_gemm_tnb(TnArgs& p, hipStream_t st);
 int sr_gemm_tnb_grouped(TnArgs* probs, int n, hipStream_t st);

@@ -101,13 +101,14 @@ __global__ void k_reduce_conv_w_batched(const float* __restrict__ part, long par
 //   dW[n][k] = gamma[k]*G[n][k] + beta[k]*dbv[n];  db = dbv
 //   dgamma[k] = sum_n W[n][k]*G[n][k];  dbeta[k] = sum_n W[n][k]*dbv[n]
 // Block = 64 columns x 4 rows (one element per thread, slices unrolled by 8 so
-// the loads overlap); dgamma / dbeta are combined across row blocks with one
-// atomic per column per block (zeroed by the caller).
+// the loads overlap); the dgamma / dbeta contributions of a row block go to the workspace
+// lnws[row block][2][K] (plain stores) and k_ln_affine_finish sums them in row-block order:
+// no atomics, no memset, the same bits every run.
 __global__ void __launch_bounds__(256) k_fin_ln_linear(
     const float* __restrict__ part, const float* __restrict__ colsum, int S,
     const float* __restrict__ W, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ dW, float* __restrict__ db,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int K) {
+    float* __restrict__ lnws, int N, int K) {
   __shared__ float sd[4], sg[4][64], sb[4][64];
   const int c = threadIdx.x & 63, rr = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + c;
@@ -145,9 +146,30 @@ __global__ void __launch_bounds__(256) k_fin_ln_linear(
   sg[rr][c] = ag; sb[rr][c] = ab;
   __syncthreads();
   if (rr == 0 && k < K) {
-    atomicAdd(dgamma + k, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
-    atomicAdd(dbeta + k, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+    float* w2 = lnws + (long)blockIdx.y * 2 * K;
+    w2[k] = (sg[0][c] + sg[1][c]) + (sg[2][c] + sg[3][c]);
+    w2[K + k] = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
   }
+}
+// dgamma[k] = sum over row blocks of ws[rb][0][k], dbeta[k] = ... ws[rb][1][k], in row-block order (four
+// interleaved chains per column, combined in a fixed order)
+__device__ __forceinline__ void ln_affine_finish_one(const float* __restrict__ ws, int nrb, int K,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int idx) {
+  if (idx >= 2 * K) return;
+  const int which = idx >= K, k = idx - which * K;
+  const float* q = ws + (long)which * K + k;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int rb = 0;
+  for (; rb + 4 <= nrb; rb += 4) {
+    a0 += q[(long)(rb + 0) * 2 * K]; a1 += q[(long)(rb + 1) * 2 * K];
+    a2 += q[(long)(rb + 2) * 2 * K]; a3 += q[(long)(rb + 3) * 2 * K];
+  }
+  for (; rb < nrb; ++rb) a0 += q[(long)rb * 2 * K];
+  (which ? dbeta : dgamma)[k] = (a0 + a1) + (a2 + a3);
+}
+__global__ void __launch_bounds__(256) k_ln_affine_finish(const float* __restrict__ ws, int nrb, int K,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  ln_affine_finish_one(ws, nrb, K, dgamma, dbeta, blockIdx.x * 256 + threadIdx.x);
 }
 // The slice reducers of up to 24 Linear weight gradients (one Swin block: 4; one RSTB layer: 4 x depth) in ONE
 // launch: k_fin_ln_linear's geometry per problem; gamma == null means a plain Linear
@@ -155,8 +177,8 @@ __global__ void __launch_bounds__(256) k_fin_ln_linear(
 struct ReduceGroup {
   struct P {
     const float* part; const float* colsum; const float* W; const float* gamma; const float* beta;
-    float* dW; float* db; float* dgamma; float* dbeta;
-    int N, K, blk0, kblocks;
+    float* dW; float* db; float* dgamma; float* dbeta; float* lnws;
+    int N, K, blk0, kblocks, fblk0;
   } p[24];              // = TNB_GROUP_MAX of gemm_tnb.hip
   int n, S;
 };
@@ -208,11 +230,22 @@ __global__ void __launch_bounds__(256) k_reduce_group(ReduceGroup g) {
   if (P.gamma) {          // block-uniform
     sg[rr][c] = ag; sb[rr][c] = ab;
     __syncthreads();
-    if (rr == 0 && k < K) {
-      atomicAdd(P.dgamma + k, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
-      atomicAdd(P.dbeta + k, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+    if (rr == 0 && k < K) {     // this row block's share of dgamma / dbeta: plain stores, summed by k_ln_affine_finish_group
+      float* w2 = P.lnws + (long)by * 2 * K;
+      w2[k] = (sg[0][c] + sg[1][c]) + (sg[2][c] + sg[3][c]);
+      w2[K + k] = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
     }
   }
+}
+// second stage for the LayerNorm problems of a group: block -> problem by fblk0 (blocks of 256 threads over 2 K entries)
+__global__ void __launch_bounds__(256) k_ln_affine_finish_group(ReduceGroup g) {
+  ReduceGroup::P P = g.p[0];
+  bool found = false;
+#pragma unroll
+  for (int i = 0; i < 24; ++i)
+    if (i < g.n && g.p[i].gamma && (int)blockIdx.x >= g.p[i].fblk0) { P = g.p[i]; found = true; }
+  if (!found) return;
+  ln_affine_finish_one(P.lnws, (P.N + 3) / 4, P.K, P.dgamma, P.dbeta, ((int)blockIdx.x - P.fblk0) * 256 + threadIdx.x);
 }
 __global__ void k_reduce_colsum(const float* __restrict__ colsum, float* __restrict__ db,
                                 int N, int S) {
@@ -315,11 +348,12 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const float* __restrict__ x, flo
 // dx from the gradient w.r.t. the normalised value (dxh), with the residual
 // gradient added:  out = res + rstd*(dxh - mean(dxh) - xh*mean(dxh*xh)).
 // If g != null the incoming gradient is w.r.t. y = xh*g+b: dxh = dy*g and the
-// per-column sums dgamma += dy*xh, dbeta += dy are accumulated with atomics.
+// per-column sums dgamma = sum dy*xh, dbeta = sum dy of a BLOCK go to ws[block][2][C] (plain stores);
+// k_ln_affine_finish adds the blocks in order (deterministic: no atomics, no memset).
 __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dyp, const float* __restrict__ x,
                                                 const float* __restrict__ st, const float* __restrict__ res,
                                                 const float* __restrict__ g, float* __restrict__ out,
-                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                float* __restrict__ ws,
                                                 long M, int C, int rows_per_wave) {
   const int lane = threadIdx.x & 63;
   const long w = blockIdx.x * 4L + (threadIdx.x >> 6);
@@ -367,7 +401,7 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dyp, c
       }
     }
   }
-  if (g) {      // the block's four waves meet in LDS, then one atomic per column and block
+  if (g) {      // the block's four waves meet in LDS, then one plain store per column and block
     __shared__ float red[2][4][64 * LN_MAXV];
     const int wv = threadIdx.x >> 6;
 #pragma unroll
@@ -378,8 +412,9 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float* __restrict__ dyp, c
       for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + 64 * i;
         if (c < C) {
-          atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-          atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+          float* w2 = ws + (long)blockIdx.x * 2 * C;
+          w2[c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+          w2[C + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
         }
       }
     }
@@ -683,36 +718,41 @@ int srhip_reduce_linear_wgrad(const float* part, const float* colsum, int S, flo
 
 int srhip_reduce_ln_linear_wgrad(const float* part, const float* colsum, int S, const float* W,
                                  const float* gamma, const float* beta, float* dW, float* db,
-                                 float* dgamma, float* dbeta, int N, int K, int ln_grads_zeroed,
+                                 float* dgamma, float* dbeta, int N, int K, float* ln_ws,
                                  void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (!ln_grads_zeroed) {   // dgamma / dbeta are accumulated with atomics
-    (void)hipMemsetAsync(dgamma, 0, sizeof(float) * K, st);
-    (void)hipMemsetAsync(dbeta, 0, sizeof(float) * K, st);
-  }
+  SR_REQUIRE(ln_ws != nullptr, "reduce_ln_linear_wgrad: workspace of srhip_ln_affine_ws(N, K) floats required");
   hipLaunchKernelGGL(k_fin_ln_linear, dim3(sr_cdiv(K, 64), sr_cdiv(N, 4)), dim3(256), 0, st, part,
-                     colsum, S, W, gamma, beta, dW, db, dgamma, dbeta, N, K);
+                     colsum, S, W, gamma, beta, dW, db, ln_ws, N, K);
+  hipLaunchKernelGGL(k_ln_affine_finish, dim3(sr_cdiv(2 * K, 256)), dim3(256), 0, st, ln_ws, sr_cdiv(N, 4), K,
+                     dgamma, dbeta);
   SR_LAUNCH_CHECK("reduce_ln_linear_wgrad");
   return 0;
 }
+
+long srhip_ln_affine_ws(int N, int K) { return (long)sr_cdiv(N, 4) * 2 * K; }
 
 int srhip_reduce_wgrad_grouped(const srhip_reduce_problem* probs, int nprob, int S, void* stream) {
   SR_REQUIRE(nprob >= 1 && nprob <= 24 && S > 0, "reduce_wgrad_grouped: 1..24 problems, S > 0");
   ReduceGroup g;
   memset(&g, 0, sizeof(g));
   g.n = nprob; g.S = S;
-  int blocks = 0;
+  int blocks = 0, fblocks = 0;
   for (int i = 0; i < nprob; ++i) {
     const srhip_reduce_problem& q = probs[i];
     SR_REQUIRE(q.part && q.colsum && q.dW && q.db && q.N > 0 && q.K > 0, "reduce_wgrad_grouped: problem %d incomplete", i);
-    SR_REQUIRE(!q.gamma || (q.W && q.beta && q.dgamma && q.dbeta), "reduce_wgrad_grouped: LayerNorm problem %d incomplete", i);
+    SR_REQUIRE(!q.gamma || (q.W && q.beta && q.dgamma && q.dbeta && q.ln_ws), "reduce_wgrad_grouped: LayerNorm problem %d incomplete", i);
     ReduceGroup::P& d = g.p[i];
+    d.lnws = q.ln_ws;
+    d.fblk0 = fblocks;
+    if (q.gamma) fblocks += sr_cdiv(2 * q.K, 256);
     d.part = q.part; d.colsum = q.colsum; d.W = q.W; d.gamma = q.gamma; d.beta = q.beta;
     d.dW = q.dW; d.db = q.db; d.dgamma = q.dgamma; d.dbeta = q.dbeta; d.N = q.N; d.K = q.K;
     d.blk0 = blocks; d.kblocks = sr_cdiv(q.K, 64);
     blocks += d.kblocks * sr_cdiv(q.N, 4);
   }
   hipLaunchKernelGGL(k_reduce_group, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+  if (fblocks) hipLaunchKernelGGL(k_ln_affine_finish_group, dim3(fblocks), dim3(256), 0, (hipStream_t)stream, g);
   SR_LAUNCH_CHECK("reduce_wgrad_grouped");
   return 0;
 }
@@ -794,23 +834,25 @@ int srhip_layernorm_fwd(const float* x, float* stats, float* y, const float* gam
   return 0;
 }
 
+static inline int ln_bwd_rpw(long M) { return (int)((M + 8191) / 8192); }   // rows per wave with the affine gradients: 4 at T = 32768
+long srhip_layernorm_bwd_ws(long M, int C) {
+  const int rpw = ln_bwd_rpw(M);
+  return (long)sr_cdiv((M + rpw - 1) / rpw, 4) * 2 * C;
+}
 int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* res,
-                        const float* gamma, float* out, float* dgamma, float* dbeta, long M, int C,
-                        void* stream) {
+                        const float* gamma, float* out, float* dgamma, float* dbeta, float* workspace, long M,
+                        int C, void* stream) {
   SR_REQUIRE(C <= 64 * LN_MAXV, "layernorm: C=%d > %d unsupported", C, 64 * LN_MAXV);
-  SR_REQUIRE(!gamma || (dgamma && dbeta), "layernorm_bwd: gamma given without dgamma/dbeta");
+  SR_REQUIRE(!gamma || (dgamma && dbeta && workspace),
+             "layernorm_bwd: gamma given without dgamma / dbeta / workspace (srhip_layernorm_bwd_ws floats)");
   if (M <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  int rpw = 1;
-  if (gamma) {  // fewer, longer waves so the column atomics stay cheap
-    rpw = (int)((M + 8191) / 8192);      // 4 rows per wave at T = 32768: parallelism over atomics (reduced per block)
-    if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess ||
-        hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)
-      return sr_fail(-5, "layernorm_bwd: cannot zero dgamma / dbeta");
-  }
+  const int rpw = gamma ? ln_bwd_rpw(M) : 1;      // fewer, longer waves so that the per-block partial rows stay few
   const long waves = (M + rpw - 1) / rpw;
-  hipLaunchKernelGGL(k_ln_bwd, dim3(sr_cdiv(waves, 4)), dim3(256), 0, st, dy, x, stats, res, gamma,
-                     out, dgamma, dbeta, M, C, rpw);
+  const int blocks = sr_cdiv(waves, 4);
+  hipLaunchKernelGGL(k_ln_bwd, dim3(blocks), dim3(256), 0, st, dy, x, stats, res, gamma, out, workspace, M, C, rpw);
+  if (gamma)
+    hipLaunchKernelGGL(k_ln_affine_finish, dim3(sr_cdiv(2 * C, 256)), dim3(256), 0, st, workspace, blocks, C, dgamma, dbeta);
   SR_LAUNCH_CHECK("layernorm_bwd");
   return 0;
 }

@@ -1,0 +1,487 @@
+// The MLP half of a Swin block as ONE kernel per direction on the two-plane fp16 split MFMA (three products,
+// block exponents: the arithmetic of k_nth2, gemm_ntw.hip) -- reference Mlp.forward + the residual around it,
+// dlib/models/network_swinir.py:28-45,335-337, and their autograd:
+//
+//   forward : h = LN(x) W1f^T + b1f ,  out = x + s (gelu(h) W2^T + b2) ,  stats_out = {mean, rstd} of the out rows
+//   backward: dh = (s dy W2) * gelu'(h) ,  gh = gelu(h) ,  dx = dy + LayerNorm_backward(dh W1f; x, stats)
+//
+// Why one kernel: a launch of the Linear GEMM is launch + A fetch + K loop + epilogue IN SERIES (all 512 blocks of
+// a launch run in lockstep, one round), and the K loop is the smallest of the four.  Chained here, the hidden
+// activation never leaves the CU: one A fetch and one epilogue per direction instead of two, no read-back of h.
+//
+// How the chain works without a transposition through LDS.  GEMM 1 runs TRANSPOSED: the weight fragments take the
+// MFMA's row side and the activation fragments its column side (both operands of v_mfma_f32_16x16x32_f16 have the
+// same lane layout: index = lane & 15, k octet = lane >> 4, so swapping them is free), which leaves lane (c, g)
+// with FOUR CONSECUTIVE hidden units 16j + 4g .. + 3 of ONE token 16i + c per accumulator -- half a 16-byte
+// [token][8 k] unit of GEMM 2's A stage image (one ds_write_b64 per plane), and one 16-byte global store of h.
+// A wave owns 48 hidden units per 192-unit half (two halves: hidden <= 384) for all 64 tokens; the whole hidden
+// row of a token is in registers (of four waves) before GEMM 2 starts, so its block exponent is known up front
+// (token maximum: in-lane, two shuffles, one 1-KB LDS exchange) and needs no running rescale.  GEMM 2 is k_nth2's
+// loop: W fragments straight from global memory (planes [Kp/16][N][16], three register sets), A from the stage
+// images, six barrier-free stages per 192-k pass.  The epilogues run on the row-major re-laid tile: 16-byte
+// accesses, row statistics by four lanes per row.
+//
+// LDS: one 49-KB region serves, in turn, the x stage images, the two passes of hidden images and the output tile;
+// two blocks per CU.
+#include "common.h"
+#include "kernels.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int SK = 32;                 // k per stage
+constexpr int BM = 64;                 // tokens per block
+constexpr int APL = BM * 64;           // bytes of one plane of a stage image (64 rows x 32 fp16)
+constexpr int AST = 2 * APL;           // a stage image: two planes
+constexpr int TP = 196;                // pitch of the output tile (floats): rows 4 apart land 16 banks apart
+constexpr int R0 = BM * TP * 4;        // the shared region (>= 6 stage images)
+constexpr int MLP_LDS = R0 + (4 * 64 + 64 + 64) * 4;
+static_assert(R0 >= 6 * AST, "LDS region");
+
+__device__ __forceinline__ f32x4 mfma16h(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+typedef _Float16 sr_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
+  const sr_f16x2 hv = __builtin_convertvector(sr_f32x2{x0, x1}, sr_f16x2);
+  const float r0 = x0 - (float)hv.x, r1 = x1 - (float)hv.y;
+  const sr_f16x2 lv = __builtin_convertvector(sr_f32x2{r0, r1}, sr_f16x2);
+  h = __builtin_bit_cast(unsigned, hv);
+  l = __builtin_bit_cast(unsigned, lv);
+}
+// 16-byte unit (row, k octet u) of a stage plane (gemm_ntw.hip): conflict free for the 16-lane phases of the
+// fragment reads and of the staging writes
+__device__ __forceinline__ int a_slot(int row, int u) { return row * 4 + (u ^ ((row >> 2) & 3)); }
+
+// Phi(x), phi(x) with one exp (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7): the backward's gate, as epilogue 3
+// of nt_epi.h
+__device__ __forceinline__ void gelu_gate(float x, float& gate, float& gl) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float e1 = __expf(-0.5f * x * x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e1, x));
+  gate = cdf + x * 0.39894228040143267794f * e1;
+  gl = x * cdf;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const smax = (float*)(smem + R0);           // [4 waves][64 tokens] maxima of |A2|
+  float* const rinvx = smax + 256;                   // [64] 2^-s of the X rows (backward; forward: a constant)
+  float* const rinv2 = rinvx + 64;                   // [64] 2^-s of the hidden rows
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int m0 = sr_xcd_block((int)blockIdx.x, gridDim.x) * BM;
+  const int NH = (p.hid + 191) / 192;                // 192-unit halves of the hidden layer (1 or 2)
+  const int nst1 = p.Kp1 / SK, nst2 = p.Kp2 / SK;
+
+  // ---------------- weight fragment addressing
+  const long plane1 = (long)p.N1 * p.Kp1 * 2, plane2 = (long)p.N2 * p.Kp2 * 2;
+  const float* const winv1 = (const float*)((const char*)p.W1 + 2 * plane1);
+  const float* const winv2 = (const float*)((const char*)p.W2 + 2 * plane2);
+  unsigned boff1[2][3], boff2[3];
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int row = min(192 * hh + wave * 48 + jt * 16 + c, p.N1 - 1);
+      boff1[hh][jt] = (unsigned)(((g >> 1) * p.N1 + row) * 32 + (g & 1) * 16);
+    }
+    const int col = min(wave * 48 + jt * 16 + c, p.N2 - 1);
+    boff2[jt] = (unsigned)(((g >> 1) * p.N2 + col) * 32 + (g & 1) * 16);
+  }
+  // stage u of GEMM 1 = (half u / 6, k stage u % 6); stages past the weight's K read its last stage (the A planes are
+  // zero there, the planes finite: they add exact zeros)
+  auto load_b1 = [&](int u, u32x4 (&fb)[3][2]) {
+    const int hh = u / 6, s = min(u - 6 * hh, nst1 - 1);
+    const char* base = (const char*)p.W1 + (long)(2 * s) * p.N1 * 32;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane1 + (hh ? boff1[1][jt] : boff1[0][jt]));
+  };
+  auto load_b2 = [&](int cs, u32x4 (&fb)[3][2]) {
+    const char* base = (const char*)p.W2 + (long)(2 * min(cs, nst2 - 1)) * p.N2 * 32;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane2 + boff2[jt]);
+  };
+  u32x4 fb0[3][2], fb1[3][2], fb2[3][2];
+  load_b1(0, fb0);
+  load_b1(1, fb1);
+  load_b1(2, fb2);
+
+  // ---------------- the X rows: one pass of 192 k (K1 <= 192), split into six stage images
+  {
+    const int arow = tid >> 2, akq = tid & 3;
+    const int agm = min(m0 + arow, p.M - 1);
+    const char* const abase = (const char*)p.X + (long)agm * p.ldx * 4;
+    const float2 rst = ldg_f2(BWD ? k_sr_neutral : p.ln_stats + 2 * agm);
+    f32x4 ra[6][2];
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) {                 // past the end: k = 0 of the row, zeroed below
+      const int k = s6 * SK + akq * 8;
+      ra[s6][0] = *(const f32x4*)(abase + (k < p.K1 ? k * 4 : 0));
+      ra[s6][1] = *(const f32x4*)(abase + (k + 4 < p.K1 ? (k + 4) * 4 : 0));
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) {
+      const int k = s6 * SK + akq * 8;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        f32x4 x = ra[s6][e];
+        if (!BWD) { x.x = (x.x - rst.x) * rst.y; x.y = (x.y - rst.x) * rst.y; x.z = (x.z - rst.x) * rst.y; x.w = (x.w - rst.x) * rst.y; }
+        if (k + 4 * e >= p.K1) x = f32x4{0.f, 0.f, 0.f, 0.f};
+        ra[s6][e] = x;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
+      }
+    }
+    float asc;
+    if (BWD) {                                       // gradient rows: the block exponent comes from the row maximum
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      asc = mx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / mx)), 100.f)) : 1.f;
+    } else {                                         // behind the LayerNorm prologue |xhat| <= sqrt(K): a priori
+      asc = exp2f(floorf(log2f(16384.f * rsqrtf((float)p.K1))));
+    }
+    if (akq == 0) rinvx[arow] = 1.0f / asc;
+    const int a_dst = a_slot(arow, akq) * 16;
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) {
+      unsigned hh[4], ll[4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const f32x4 x = ra[s6][e];
+        split2_pair(x.x * asc, x.y * asc, hh[2 * e], ll[2 * e]);
+        split2_pair(x.z * asc, x.w * asc, hh[2 * e + 1], ll[2 * e + 1]);
+      }
+      unsigned char* sa = smem + s6 * AST + a_dst;
+      *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+      *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    }
+  }
+  __syncthreads();
+
+  int a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = a_slot(16 * i + c, g) * 16;
+
+  // ---------------- GEMM 1, transposed: acc1[hh][i][j] = hidden units 192 hh + 48 wave + 16 j + 4 g + e of token 16 i + c
+  f32x4 acc1[2][4][3];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc1[hh][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma1 = [&](f32x4 (&acc)[4][3], int s6, const u32x4 (&fb)[3][2]) {
+    const unsigned char* sa = smem + s6 * AST;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 fa[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off[i]);
+#define SR_TERM(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[i][j] = mfma16h(fb[j][PB], fa[PA], acc[i][j]);
+      SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)          // small terms first
+#undef SR_TERM
+    }
+  };
+#define SR_G1(U, FB)                                                   \
+  if ((U) / 6 < NH) {                                                  \
+    mma1(acc1[(U) / 6], (U) % 6, FB);                                  \
+    if ((U) + 3 < 6 * NH) load_b1((U) + 3, FB);                        \
+  }
+  SR_G1(0, fb0) SR_G1(1, fb1) SR_G1(2, fb2) SR_G1(3, fb0) SR_G1(4, fb1) SR_G1(5, fb2)
+  SR_G1(6, fb0) SR_G1(7, fb1) SR_G1(8, fb2) SR_G1(9, fb0) SR_G1(10, fb1) SR_G1(11, fb2)
+#undef SR_G1
+  // the first stages of GEMM 2's weights travel while the activation math runs (the backward's gate needs the
+  // registers: it requests them behind the math, in front of the token-maximum exchange)
+  if (!BWD) {
+    load_b2(0, fb0);
+    load_b2(1, fb1);
+    load_b2(2, fb2);
+  }
+
+  // ---------------- between the GEMMs: bias + GELU (forward) / the GELU gate (backward), in registers
+  float tmax[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    float rix[4], dps[4];
+    int gm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rix[i] = rinvx[16 * i + c];
+      gm[i] = m0 + 16 * i + c;
+      dps[i] = 1.f;
+      if (BWD && p.rowscale) dps[i] = p.rowscale[min(gm[i], p.M - 1) / p.rows_per_scale];
+    }
+    // backward: the pre-activations of (half, j) travel while (half, j - 1) is processed: four 16-byte loads in flight
+    f32x4 hcur[4], hnext[4];
+    auto load_h = [&](int hh, int j, f32x4 (&hv)[4]) {
+      const int unit0 = min(192 * hh + wave * 48 + 16 * j + 4 * g, p.hid - 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hv[i] = *(const f32x4*)(p.H + (long)min(gm[i], p.M - 1) * p.ldh + unit0);
+    };
+    if (BWD) load_h(0, 0, hcur);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      if (hh < NH) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (BWD) {
+            if (j < 2) load_h(hh, j + 1, hnext);
+            else if (hh + 1 < NH) load_h(hh + 1, 0, hnext);
+          }
+          const int unit0 = 192 * hh + wave * 48 + 16 * j + 4 * g;
+          const bool uok = unit0 < p.hid;            // hid % 4 == 0: a lane's four units are valid or not together
+          const int uc = min(unit0, p.hid - 4);
+          const f32x4 wi = *(const f32x4*)(winv1 + uc);
+          f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (!BWD) bv = *(const f32x4*)(p.b1 + uc);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            f32x4 v = acc1[hh][i][j];
+            const bool ok = uok && gm[i] < p.M;
+            if (!BWD) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = v[e] * (rix[i] * wi[e]) + bv[e];
+              if (p.H && ok) *(f32x4*)(p.H + (long)gm[i] * p.ldh + unit0) = v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = uok ? gelu_f(v[e]) : 0.f;
+            } else {
+              const f32x4 hx = hcur[i];
+              f32x4 gl;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float gate, gle;
+                gelu_gate(hx[e], gate, gle);
+                gl[e] = gle;
+                v[e] = uok ? v[e] * (rix[i] * wi[e] * dps[i]) * gate : 0.f;
+              }
+              if (ok) {
+                *(f32x4*)(p.dH + (long)gm[i] * p.ldh + unit0) = v;
+                *(f32x4*)(p.GH + (long)gm[i] * p.ldh + unit0) = gl;
+              }
+            }
+            acc1[hh][i][j] = v;
+            tmax[i] = fmaxf(fmaxf(tmax[i], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+          }
+          if (BWD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hcur[i] = hnext[i];
+          }
+        }
+      }
+    }
+  }
+  if (BWD) {
+    load_b2(0, fb0);
+    load_b2(1, fb1);
+    load_b2(2, fb2);
+  }
+  // token maxima over the whole hidden row: lanes g = 0..3 of a wave, then the four waves
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    tmax[i] = fmaxf(tmax[i], __shfl_xor(tmax[i], 16, 64));
+    tmax[i] = fmaxf(tmax[i], __shfl_xor(tmax[i], 32, 64));
+    if (g == 0) smax[wave * 64 + 16 * i + c] = tmax[i];
+  }
+  __syncthreads();                                   // also: every wave is done with the x stage images
+  float use[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = 16 * i + c;
+    const float mx = fmaxf(fmaxf(smax[t], smax[64 + t]), fmaxf(smax[128 + t], smax[192 + t]));
+    use[i] = mx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / mx)), 100.f)) : 1.f;
+    if (wave == 0 && g == 0) rinv2[t] = 1.0f / use[i];
+  }
+
+  // ---------------- GEMM 2 (k_nth2's loop): acc2[i][j] = rows 16 i + 4 g + e, columns 48 wave + 16 j + c
+  f32x4 acc2[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto stage_a2 = [&](const f32x4 (&acc)[4][3]) {   // a lane's 4 units = half an octet: one 8-byte store per plane
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int kk = wave * 48 + 16 * j + 4 * g;
+      const int s6 = kk >> 5, u = (kk & 31) >> 3, pos = kk & 7;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 v = acc[i][j];
+        unsigned h0, l0, h1, l1;
+        split2_pair(v[0] * use[i], v[1] * use[i], h0, l0);
+        split2_pair(v[2] * use[i], v[3] * use[i], h1, l1);
+        unsigned char* sa = smem + s6 * AST + a_slot(16 * i + c, u) * 16 + pos * 2;
+        *(u32x2*)(sa) = u32x2{h0, h1};
+        *(u32x2*)(sa + APL) = u32x2{l0, l1};
+      }
+    }
+  };
+  auto mma2 = [&](int s6, const u32x4 (&fb)[3][2]) {
+    const unsigned char* sa = smem + s6 * AST;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 fa[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off[i]);
+#define SR_TERM(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) acc2[i][j] = mfma16h(fa[PA], fb[j][PB], acc2[i][j]);
+      SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+#undef SR_TERM
+    }
+  };
+#define SR_G2(U, FB)                                                   \
+  {                                                                    \
+    mma2((U) % 6, FB);                                                 \
+    if ((U) + 3 < 6 * NH) load_b2((U) + 3, FB);                        \
+  }
+  stage_a2(acc1[0]);
+  __syncthreads();
+  SR_G2(0, fb0) SR_G2(1, fb1) SR_G2(2, fb2) SR_G2(3, fb0) SR_G2(4, fb1) SR_G2(5, fb2)
+  if (NH > 1) {
+    __syncthreads();                                 // every wave is done with the first pass's images
+    stage_a2(acc1[1]);
+    __syncthreads();
+    SR_G2(6, fb0) SR_G2(7, fb1) SR_G2(8, fb2) SR_G2(9, fb0) SR_G2(10, fb1) SR_G2(11, fb2)
+  }
+#undef SR_G2
+
+  // ---------------- the output tile, row-major in LDS (block exponents undone: exact powers of two)
+  __syncthreads();
+  float* const T = (float*)smem;
+  {
+    float wv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wv[j] = winv2[min(wave * 48 + 16 * j + c, p.N2 - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ri = rinv2[16 * i + 4 * g + e];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T[(16 * i + 4 * g + e) * TP + wave * 48 + 16 * j + c] = acc2[i][j][e] * (ri * wv[j]);
+      }
+  }
+  __syncthreads();
+  const int C = p.C;
+  if (!BWD) {
+    // out = x + s (acc + b2): 16-byte pieces in row-major order (a wave instruction covers 1 KB of consecutive tile bytes)
+    f32x4 rv[12];
+    int prow[12], pcol[12];
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+      const int idx = it * 256 + tid;
+      prow[it] = idx / 48;
+      pcol[it] = (idx - prow[it] * 48) * 4;
+      const int gm = m0 + prow[it];
+      const bool ok = gm < p.M && pcol[it] < C;
+      rv[it] = ok ? *(const f32x4*)(p.R + (long)gm * p.ldr + pcol[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!ok) prow[it] = -1;
+    }
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+      if (prow[it] >= 0) {
+        const int gm = m0 + prow[it];
+        float* tp = T + prow[it] * TP + pcol[it];
+        f32x4 v = *(const f32x4*)tp;
+        const f32x4 bv = p.b2 ? *(const f32x4*)(p.b2 + pcol[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float s = p.rowscale ? p.rowscale[gm / p.rows_per_scale] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] + bv[e]) * s + rv[it][e];
+        *(f32x4*)(p.out + (long)gm * p.ldo + pcol[it]) = v;
+        if (p.stats_out) *(f32x4*)tp = v;
+      }
+    }
+    if (p.stats_out) {
+      // {mean, rstd} of the out rows for the next LayerNorm (two-pass, eps 1e-5, biased variance): four lanes per row
+      __syncthreads();
+      const int row = tid >> 2, q = tid & 3;
+      f32x4 xv[12];
+      float s1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        xv[k] = *(const f32x4*)(T + row * TP + q * 48 + 4 * k);
+        if (q * 48 + 4 * k < C) s1 += (xv[k].x + xv[k].y) + (xv[k].z + xv[k].w);
+      }
+      s1 += __shfl_xor(s1, 1, 64);
+      s1 += __shfl_xor(s1, 2, 64);
+      const float mean = s1 * (1.0f / (float)C);
+      float s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 12; ++k)
+        if (q * 48 + 4 * k < C) {
+          const float d0 = xv[k].x - mean, d1 = xv[k].y - mean, d2 = xv[k].z - mean, d3 = xv[k].w - mean;
+          s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+      s2 += __shfl_xor(s2, 1, 64);
+      s2 += __shfl_xor(s2, 2, 64);
+      if (q == 0 && m0 + row < p.M)
+        *(float2*)(p.stats_out + 2 * (long)(m0 + row)) = float2{mean, rsqrtf(s2 * (1.0f / (float)C) + 1e-5f)};
+    }
+  } else {
+    // dx = dy + rstd (dxh - mean(dxh) - xhat mean(dxh xhat)),  xhat = (x - mean) rstd  (LayerNorm backward with the
+    // affine folded into W1): four lanes per row, 12 x 16 bytes each
+    const int row = tid >> 2, q = tid & 3;
+    const int gm = min(m0 + row, p.M - 1);
+    const float2 st = *(const float2*)(p.ep_stats + 2 * (long)gm);
+    f32x4 xh[12], rr[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const int col = min(q * 48 + 4 * k, C - 4);
+      xh[k] = *(const f32x4*)(p.R + (long)gm * p.ldr + col);
+      rr[k] = *(const f32x4*)(p.R2 + (long)gm * p.ldr2 + col);
+    }
+    f32x4 dv[12];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      dv[k] = *(const f32x4*)(T + row * TP + q * 48 + 4 * k);
+      const bool ok = q * 48 + 4 * k < C;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[k][e] = ok ? (xh[k][e] - st.x) * st.y : 0.f;
+        dv[k][e] = ok ? dv[k][e] : 0.f;
+        s1 += dv[k][e];
+        s2 += dv[k][e] * xh[k][e];
+      }
+    }
+    s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+    s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+    const float m1 = s1 * (1.0f / (float)C), m2 = s2 * (1.0f / (float)C);
+    if (m0 + row < p.M) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k)
+        if (q * 48 + 4 * k < C) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rr[k][e] + st.y * (dv[k][e] - m1 - xh[k][e] * m2);
+          *(f32x4*)(p.out + (long)gm * p.ldo + q * 48 + 4 * k) = o;
+        }
+    }
+  }
+}
+
+}  // namespace
+
+int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st) {
+  SR_REQUIRE(p.C % 4 == 0 && p.C >= 4 && p.C <= 192, "mlp_f16x2: C = %d (multiple of 4, <= 192)", p.C);
+  SR_REQUIRE(p.hid % 4 == 0 && p.hid >= 4 && p.hid <= 384, "mlp_f16x2: hidden = %d (multiple of 4, <= 384)", p.hid);
+  SR_REQUIRE(p.M > 0, "mlp_f16x2: M = %d", p.M);
+  SR_REQUIRE(p.ldx % 4 == 0 && p.ldo % 4 == 0 && p.ldh % 4 == 0 && p.ldr % 4 == 0 && (!bwd || p.ldr2 % 4 == 0),
+             "mlp_f16x2: row pitches must be multiples of 4 floats");
+  dim3 grid(sr_cdiv(p.M, BM));
+  if (bwd) hipLaunchKernelGGL(k_mlp_f16<true>, grid, dim3(256), MLP_LDS, st, p);
+  else hipLaunchKernelGGL(k_mlp_f16<false>, grid, dim3(256), MLP_LDS, st, p);
+  SR_LAUNCH_CHECK("k_mlp_f16");
+  return 0;
+}

@@ -131,7 +131,7 @@ __device__ __forceinline__ void job_planes_f16(const PrepEntry& e, int lb) {
     }
   }
   mx = wave_max(mx);
-  const float sc = mx > 0.f ? exp2f(floorf(log2f(16384.f / mx))) : 1.f;
+  const float sc = mx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / mx)), 100.f)) : 1.f;
   const long plane = (long)rows * Kp;
   unsigned short* base = (unsigned short*)e.out;
 #pragma unroll
@@ -182,7 +182,7 @@ __device__ __forceinline__ void job_conv_planes_f16(const PrepEntry& e, int lb) 
       mx = fmaxf(mx, fabsf(x));
     }
   mx = wave_max(mx);
-  const float sc = mx > 0.f ? exp2f(floorf(log2f(16384.f / mx))) : 1.f;
+  const float sc = mx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / mx)), 100.f)) : 1.f;
   const long rows = 9L * e.n0, plane = rows * Kp;
   unsigned short* base = (unsigned short*)e.out;
   const int k0 = lane * 4;

@@ -597,7 +597,7 @@ int srhip_bias_grad_batched(const float* dbiasT, long image_stride, float* const
 }
 
 static int wa_remap() {            // SRHIP_WA_XCD=0: plain block order (A/B switch)
-  static const int on = [] { const char* e = getenv("SRHIP_WA_XCD"); return !(e && e[0] == '0'); }();
+  static const int on = [] { const char* e = sr_getenv("SRHIP_WA_XCD"); return !(e && e[0] == '0'); }();
   return on;
 }
 

@@ -82,10 +82,8 @@ class ModelPlain:
         self.L_to_H = None if l2h is None else l2h.to(self.device, non_blocking=True)
         self.H = data['h_im'].to(self.device, non_blocking=True) if need_H else None
         w = data.get('h_per_pixel_weight', None)
-        self.h_per_pixel_weight = None if w is None else w.to(self.device)
-        if self.h_per_pixel_weight is not None:
-            raise NotImplementedError("per-pixel loss weights (--ppiw) with the fused step: use "
-                                      "dlib.loss.L1 through autograd")
+        # --ppiw (dataset_dpsr.py:925-928): consumed by the L1 term of the fused step (dlib/loss/main.py:45-76)
+        self.h_per_pixel_weight = None if w is None else w.to(self.device, non_blocking=True).float().contiguous()
 
     # ---------------------------------------------------------------- step
     def _net_input(self):
@@ -96,7 +94,7 @@ class ModelPlain:
         return self.L
 
     def optimize_parameters(self, epoch: int, current_step: int):
-        self.step_fn.step(self._net_input(), self.H)
+        self.step_fn.step(self._net_input(), self.H, weight=self.h_per_pixel_weight)
         # the engine's output buffer is persistent (overwritten by the next step) and 3-D for the
         # 1-channel conv nets: hand out a [B,1,H,W] copy, as the reference's self.E is a fresh tensor
         y = self.netG.engine.bufs.d.get("t.y")
@@ -122,12 +120,16 @@ class ModelPlain:
 
     # ---------------------------------------------------------------- eval
     def set_eval_mode(self):
+        if self.step_fn is not None:
+            self.step_fn.sync_buffers()     # distributed: every rank scores its shard with rank 0's BatchNorm statistics
         self.netG.eval()
 
     def set_train_mode(self):
         self.netG.train()
 
     def test(self):
+        if self.step_fn is not None:
+            self.step_fn.sync_buffers()
         self.netG.eval()
         with torch.no_grad():
             self.E = self.netG(self._net_input())

@@ -174,6 +174,7 @@ def main(argv=None):
     from dlib import metrics
     model = define_model(args)
     model.init_train()
+    # weights: one seed, and rank 0's replace the others' anyway (TrainStep, as DDP's constructor)
     if rank == 0:
         print(model.info_network())
     batch = synth_batch(args.batch_size, args.scale, args.h_size, model.device, 1000 + rank)
@@ -196,6 +197,9 @@ def main(argv=None):
     for step in range(1, args.max_iters + 1):
         if stream is not None:
             batch = next(stream)
+        # the reference re-seeds EVERY rank with myseed + current_step at each iteration (utils_trainer.py:359-361):
+        # DropPath masks are a function of (seed, step), identical across ranks, and a resumed run repeats them
+        torch.manual_seed((args.myseed + step) % (2 ** 32 - 1))
         model.feed_data(batch)
         model.optimize_parameters(epoch=0, current_step=step)
         model.update_learning_rate()

@@ -149,8 +149,9 @@ class PrepTable:
             setattr(e, k, v)
         self.jobs.append(e)
 
-    def linear(self, W, out, gamma=None, transpose=False):
-        """planes of W [N,K] (or W^T), optionally times gamma[k] (LayerNorm fold)."""
+    def linear(self, W, out, gamma=None, transpose=False, f16=None):
+        """planes of W [N,K] (or W^T), optionally times gamma[k] (LayerNorm fold).  f16: force (True) / forbid
+        (False) the two-plane fp16 format; None: the routing rule of the Linear GEMMs."""
         N, K = W.shape
         assert W.is_contiguous() and W.dtype == torch.float32
         rows, kd = (K, N) if transpose else (N, K)
@@ -158,46 +159,12 @@ class PrepTable:
         self.keep += [W, out, gamma]
         # two fp16 planes + per-row power-of-two scales (prep kind 3) for the operands of the GEMMs that run on
         # 192-column tiles (k_nth2, gemm_ntw.hip) -- same routing rule as sr_gemm_ntp; SRHIP_F16X2=0: bf16x3
-        f16 = F16X2 and (rows % 180 == 0 or (rows > 128 and rows % 128 != 0)) and kd <= 1024
+        if f16 is None:
+            f16 = F16X2 and (rows % 180 == 0 or (rows > 128 and rows % 128 != 0)) and kd <= 1024
         out.fmt = 1 if f16 else 0
         self._add(kind=3 if f16 else 0, a=_p(W), b=_p(gamma), out=_p(out.planes), n0=rows, n1=1, n2=kd, s0=0,
                   s1=1 if transpose else K, s2=K if transpose else 1, off=0,
                   mode=0 if gamma is None else (2 if transpose else 1))
-
-    def mlp_planes(self, W, out, hidden, which, gamma=None):
-        """Operand planes of the fused MLP kernel (srhip_mlp_fwd_bx3 / srhip_mlp_bwd_bx3) from a
-        Linear weight W, hidden units in the kernel's own order.  which:
-          'rows'   W [hidden, C]: plane rows = hidden units, k = C            (forward, first product)
-          'k'      W [C, hidden]: rows = C, k = hidden units                   (forward, second product)
-          'rowsT'  W [C, hidden] read transposed: rows = hidden units, k = C   (backward, first product)
-          'kT'     W [hidden, C] read transposed: rows = C, k = hidden units   (backward, second product)
-        gamma: LayerNorm weight folded along C ('rows', 'kT')."""
-        assert W.is_contiguous() and W.dtype == torch.float32 and hidden % 2 == 0
-        hp = mlp_hidden_padded(hidden)
-        if which in ("rows", "kT"):
-            assert W.shape[0] == hidden
-            C = W.shape[1]
-        else:
-            assert W.shape[1] == hidden and gamma is None
-            C = W.shape[0]
-        self.keep += [W, out, gamma]
-        g = gamma is not None
-        if which == "rows":
-            assert (out.rows, out.K) == (hp, C)
-            self._add(kind=0, a=_p(W), b=_p(gamma), out=_p(out.planes), n0=hp, n1=1, n2=C, s0=hidden // 2,
-                      s1=C, s2=1, off=0, mode=4 + (1 if g else 0))
-        elif which == "k":
-            assert (out.rows, out.K) == (C, hp)
-            self._add(kind=0, a=_p(W), out=_p(out.planes), n0=C, n1=1, n2=hp, s0=hidden // 2,
-                      s1=hidden, s2=1, off=0, mode=8)
-        elif which == "rowsT":
-            assert (out.rows, out.K) == (hp, C)
-            self._add(kind=0, a=_p(W), out=_p(out.planes), n0=hp, n1=1, n2=C, s0=hidden // 2,
-                      s1=1, s2=hidden, off=0, mode=4)
-        else:
-            assert which == "kT" and (out.rows, out.K) == (C, hp)
-            self._add(kind=0, a=_p(W), b=_p(gamma), out=_p(out.planes), n0=C, n1=1, n2=hp, s0=hidden // 2,
-                      s1=1, s2=C, off=0, mode=8 + (2 if g else 0))
 
     def conv(self, w, out, data_grad=False, ps2=False):
         """planes of the tap-major pack [9][Co][Ci] of a conv weight [Co,Ci,3,3], or of the
@@ -320,55 +287,53 @@ def gemm_nt_lnbwd(A, W, x, stats, res, out):
     return out
 
 
-def mlp_hidden_padded(hidden):
-    """Hidden units as the fused MLP kernel lays them out: rounds of 2 halves x 96."""
-    return -(-(hidden // 2) // 96) * 192
+def mlp_f16_fusable(C, hidden):
+    """Shapes srhip_mlp_fwd_f16x2 / srhip_mlp_bwd_f16x2 take with the weight planes PrepTable.linear builds for the
+    Linear GEMMs (format 1: two fp16 planes)."""
+    def fmt1(rows, kd):
+        return F16X2 and (rows % 180 == 0 or (rows > 128 and rows % 128 != 0)) and kd <= 1024
+    return (use_bx3() and C % 4 == 0 and 4 <= C <= 192 and hidden % 4 == 0 and 4 <= hidden <= 384
+            and fmt1(hidden, C) and fmt1(C, hidden))
 
 
-def mlp_fusable(C, hidden):
-    """Shapes srhip_mlp_fwd_bx3 / srhip_mlp_bwd_bx3 take (the README SwinIR block: 180 -> 360 -> 180)."""
-    return use_bx3() and C % 4 == 0 and C <= 192 and hidden % 8 == 0 and 192 < hidden <= 384
-
-
-def mlp_fwd(x, stats, W1p, b1, W2p, b2, out, h=None, rowscale=None, rows_per_scale=1, stats_out=None):
-    """out = x + s * (gelu(LN(x) @ W1^T + b1) @ W2^T + b2) in ONE kernel; h (optional) receives the
-    pre-activation, stats_out the {mean, rstd} of the out rows.  W1p / W2p: PrepTable.mlp_planes
-    'rows' / 'k'."""
+def mlp_fwd_f16(x, stats, W1, b1, W2, b2, out, h=None, rowscale=None, rows_per_scale=1, stats_out=None):
+    """out = x + s * (gelu(LN(x) @ W1^T + b1) @ W2^T + b2) in ONE kernel on the Linear GEMMs' own operands
+    (W1 = planes of W1*gamma [hidden, C], W2 = planes of W2 [C, hidden], both format 1); h (optional) receives the
+    pre-activation, stats_out the {mean, rstd} of the out rows."""
     _chk(x, stats, b1, b2, out, h, rowscale, stats_out)
     M, C = x.shape
     hidden = b1.shape[0]
-    assert (W1p.rows, W1p.K) == (mlp_hidden_padded(hidden), C) and (W2p.rows, W2p.K) == (C, mlp_hidden_padded(hidden))
+    assert W1.fmt == 1 and W2.fmt == 1 and (W1.rows, W1.K) == (hidden, C) and (W2.rows, W2.K) == (C, hidden)
     assert out.shape == (M, C) and (h is None or h.shape == (M, hidden))
-    args = (_p(x), x.stride(0), _p(stats), _p(W1p.planes), _p(b1), _p(W2p.planes), _p(b2), _p(h),
+    args = (_p(x), x.stride(0), _p(stats), _p(W1.planes), _p(b1), _p(W2.planes), _p(b2), _p(h),
             0 if h is None else h.stride(0), _p(out), out.stride(0), M, C, hidden, _p(rowscale), rows_per_scale,
             _p(stats_out), _st())
     if probe.on("mlp_fused"):
         with probe.timed(("mlp_fused", M, C, hidden, "fwd"), 4.0 * M * C * hidden,
                          4.0 * (M * (2 * C + (hidden if h is not None else 0)) + 2 * C * hidden)):
-            call("srhip_mlp_fwd_bx3", *args)
+            call("srhip_mlp_fwd_f16x2", *args)
     else:
-        call("srhip_mlp_fwd_bx3", *args)
+        call("srhip_mlp_fwd_f16x2", *args)
     return out
 
 
-def mlp_bwd(dy, W2Tp, W1Tp, h, dh, gh, x, stats, dx, rowscale=None, rows_per_scale=1):
-    """Data gradient of mlp_fwd in ONE kernel: dh = (s * dy @ W2) * gelu'(h), gh = gelu(h) (operands of the
-    weight gradients), dx = dy + LayerNorm_backward(dh @ W1; x, stats).  W2Tp / W1Tp: PrepTable.mlp_planes
-    'rowsT' / 'kT'."""
+def mlp_bwd_f16(dy, W2T, W1T, h, dh, gh, x, stats, dx, rowscale=None, rows_per_scale=1):
+    """Data gradient of mlp_fwd_f16 in ONE kernel: dh = (s * dy @ W2) * gelu'(h), gh = gelu(h), dx = dy +
+    LayerNorm_backward(dh @ W1f; x, stats).  W2T = planes of W2^T [hidden, C], W1T = planes of (W1*gamma)^T [C, hidden]."""
     _chk(dy, h, dh, gh, x, stats, dx, rowscale)
     M, C = dy.shape
     hidden = h.shape[1]
-    assert (W2Tp.rows, W2Tp.K) == (mlp_hidden_padded(hidden), C) and (W1Tp.rows, W1Tp.K) == (C, mlp_hidden_padded(hidden))
+    assert W2T.fmt == 1 and W1T.fmt == 1 and (W2T.rows, W2T.K) == (hidden, C) and (W1T.rows, W1T.K) == (C, hidden)
     assert dh.shape == h.shape == gh.shape and dh.stride(0) == h.stride(0) == gh.stride(0)
     assert x.shape == (M, C) and dx.shape == (M, C)
-    args = (_p(dy), dy.stride(0), _p(W2Tp.planes), _p(W1Tp.planes), _p(h), h.stride(0), _p(dh), _p(gh), _p(x),
+    args = (_p(dy), dy.stride(0), _p(W2T.planes), _p(W1T.planes), _p(h), h.stride(0), _p(dh), _p(gh), _p(x),
             x.stride(0), _p(stats), _p(dx), dx.stride(0), M, C, hidden, _p(rowscale), rows_per_scale, _st())
     if probe.on("mlp_fused"):
         with probe.timed(("mlp_fused", M, C, hidden, "bwd"), 4.0 * M * C * hidden,
                          4.0 * (M * (3 * C + 3 * hidden) + 2 * C * hidden)):
-            call("srhip_mlp_bwd_bx3", *args)
+            call("srhip_mlp_bwd_f16x2", *args)
     else:
-        call("srhip_mlp_bwd_bx3", *args)
+        call("srhip_mlp_bwd_f16x2", *args)
     return dx
 
 
@@ -436,8 +401,9 @@ def linear_wgrad(dY, X, dW, db, a_rowscale=None, a_rowscale_rows=1, b_mode=0, ln
         call("srhip_reduce_linear_wgrad", _p(part), _p(cs), S, _p(dW), _p(db), N, K, _st())
     else:
         W, gamma, beta, dgamma, dbeta = ln
+        lnws = SCRATCH.get("ln_affine_ws", lib.srhip_ln_affine_ws(N, K), device=dY.device)
         call("srhip_reduce_ln_linear_wgrad", _p(part), _p(cs), S, _p(W), _p(gamma), _p(beta),
-             _p(dW), _p(db), _p(dgamma), _p(dbeta), N, K, 0, _st())
+             _p(dW), _p(db), _p(dgamma), _p(dbeta), N, K, _p(lnws), _st())
 
 
 class _TnProblem(ctypes.Structure):   # srhip_tn_problem (include/srhip.h)
@@ -455,7 +421,7 @@ class _ReduceProblem(ctypes.Structure):   # srhip_reduce_problem (include/srhip.
                 ("N", ctypes.c_int), ("K", ctypes.c_int)]
 
 
-def linear_wgrad_grouped(problems, ln_grads_zeroed=False):
+def linear_wgrad_grouped(problems):
     """Up to 4 (exact-f32 kernels) / 24 (bf16x3) Linear weight-gradient problems over the same rows in ONE launch.
     Each problem: dict(dY, X, dW, db, a_rowscale=None, a_rowscale_rows=1, b_mode=0,
     ln_stats=None, ln=None) with the meaning of linear_wgrad()."""
@@ -493,15 +459,19 @@ def linear_wgrad_grouped(problems, ln_grads_zeroed=False):
     else:
         call("srhip_gemm_tn_grouped" + _tn_sfx(), ctypes.addressof(arr), n, M, S, _st())
     red = (_ReduceProblem * n)()
-    for r, q, (pk, ck) in zip(red, problems, views):
+    # LayerNorm-folded problems: one workspace slice each for the row blocks' dgamma / dbeta shares (deterministic
+    # two-stage sum; no atomics, nothing to zero)
+    lnsz = [lib.srhip_ln_affine_ws(q["dY"].shape[1], q["X"].shape[1]) if q.get("ln") is not None else 0 for q in problems]
+    lnws = SCRATCH.get("ln_affine_ws_g", max(1, sum(lnsz)), device=dev)
+    lo = 0
+    for r, q, (pk, ck), lsz in zip(red, problems, views, lnsz):
         r.part, r.colsum, r.dW, r.db = _p(pk), _p(ck), _p(q["dW"]), _p(q["db"])
         r.N, r.K = q["dY"].shape[1], q["X"].shape[1]
         if q.get("ln") is not None:
             W, gamma, beta, dgamma, dbeta = q["ln"]
-            if not ln_grads_zeroed:      # accumulated with atomics
-                dgamma.zero_()
-                dbeta.zero_()
             r.W, r.gamma, r.beta, r.dgamma, r.dbeta = _p(W), _p(gamma), _p(beta), _p(dgamma), _p(dbeta)
+            r.ln_ws = _p(lnws[lo:lo + lsz])
+            lo += lsz
     call("srhip_reduce_wgrad_grouped", ctypes.addressof(red), n, S, _st())
 
 
@@ -642,8 +612,11 @@ def layernorm_bwd(dy, x, stats, out, res=None, gamma=None, dgamma=None, dbeta=No
     _chk(dy, x, stats, out, res, gamma, dgamma, dbeta)
     C = x.shape[-1]
     M = x.numel() // C
+    ws = None
+    if gamma is not None:
+        ws = SCRATCH.get("ln_bwd_ws", lib.srhip_layernorm_bwd_ws(M, C), device=x.device)
     call("srhip_layernorm_bwd", _p(dy), _p(x), _p(stats), _p(res), _p(gamma), _p(out),
-         _p(dgamma), _p(dbeta), M, C, _st())
+         _p(dgamma), _p(dbeta), _p(ws), M, C, _st())
 
 
 # ------------------------------------------------------------------ attention

@@ -66,10 +66,10 @@ class SwinIREngine:
         self._prep = self._prep_sig = None
         self.prepared = False
         self.saved = None
-        # SRHIP_FUSE_MLP=1: LN -> fc1 -> GELU -> fc2 -> residual (and its data gradient) as one kernel each
-        # (mlp_fused.hip).  Parity-tested, and measured SLOWER in the training step than the separate Linear
-        # launches (413 vs 433 patches/s, same box), so it is not the default.
-        self.fuse_mlp = ops.mlp_fusable(self.C, self.hid) and os.environ.get("SRHIP_FUSE_MLP", "0") != "0"
+        # The MLP half of a block as one kernel per direction on the Linear GEMMs' own two-plane fp16 operands (mlp_f16.hip; no extra weight planes): one
+        # A fetch and one epilogue per direction instead of two, the hidden activation never read back.  SRHIP_MLP_F16=0:
+        # the separate Linear launches.
+        self.fuse_mlp_h = ops.mlp_f16_fusable(self.C, self.hid) and os.environ.get("SRHIP_MLP_F16", "1") != "0"
 
     def bucket_prefixes(self):
         """Gradient buckets in backward-completion order: one per RSTB layer (the
@@ -122,12 +122,6 @@ class SwinIREngine:
                 tb.linear(w1, ws.planes(f"{i}.w1T", C, hid, dev), gamma=g2, transpose=True)
                 tb.linear(w2, ws.planes(f"{i}.w2", C, hid, dev))
                 tb.linear(w2, ws.planes(f"{i}.w2T", hid, C, dev), transpose=True)
-                if self.fuse_mlp:      # operand planes of the fused MLP kernels (hidden units in the kernel's order)
-                    hp = ops.mlp_hidden_padded(hid)
-                    tb.mlp_planes(w1, ws.planes(f"{i}.m1", hp, C, dev), hid, "rows", gamma=g2)
-                    tb.mlp_planes(w2, ws.planes(f"{i}.m2", C, hp, dev), hid, "k")
-                    tb.mlp_planes(w2, ws.planes(f"{i}.m2T", hp, C, dev), hid, "rowsT")
-                    tb.mlp_planes(w1, ws.planes(f"{i}.m1T", C, hp, dev), hid, "kT", gamma=g2)
                 tb.fold_bias(wq, b.attn.qkv.bias.data, b.norm1.bias.data, D.get(f"{i}.bq", 3 * C, device=dev))
                 tb.fold_bias(w1, b.mlp.fc1.bias.data, b.norm2.bias.data, D.get(f"{i}.b1", hid, device=dev))
                 tb.bias_expand(b.attn.relative_position_bias_table.data,
@@ -301,10 +295,10 @@ class SwinIREngine:
                 st_next = None
                 if fuse and j + 1 < nblk:
                     st_next = buf(f"{(bi + 1) if save else (bi + 1) % 2}.st1", T, 2)
-                if self.fuse_mlp and not ops.lib.srhip_get_matmul_mode():
+                if self.fuse_mlp_h and not ops.lib.srhip_get_matmul_mode():
                     h = buf(f"{k}.h", T, hid) if save else None       # inference never reads it
-                    ops.mlp_fwd(x1, st2, ws[f"{bi}.m1"], D.d[f"{bi}.b1"], ws[f"{bi}.m2"], blk.mlp.fc2.bias.data,
-                                x2, h=h, rowscale=s2, rows_per_scale=H * W, stats_out=st_next)
+                    ops.mlp_fwd_f16(x1, st2, ws[f"{bi}.w1"], D.d[f"{bi}.b1"], ws[f"{bi}.w2"], blk.mlp.fc2.bias.data,
+                                    x2, h=h, rowscale=s2, rows_per_scale=H * W, stats_out=st_next)
                 else:
                     h = buf(f"{k}.h", T, hid)
                     ops.gemm_nt(x1, ws[f"{bi}.w1"], D.d[f"{bi}.b1"], out=h, a_mode=1, ln_stats=st2)
@@ -512,9 +506,9 @@ class SwinIREngine:
                 s2 = None if dp is None else dp[2 * bi + 1]
                 g1, gout = gbufs[(gi + 1) % nrot], gbufs[(gi + 2) % nrot]
                 # ---- MLP branch: x2 = x1 + s2*(gelu(h) W2^T + b2)
-                if self.fuse_mlp:
-                    ops.mlp_bwd(g, ws[f"{bi}.m2T"], ws[f"{bi}.m1T"], h, dh, gh, x1, st2, g1, rowscale=s2,
-                                rows_per_scale=H * W)
+                if self.fuse_mlp_h:
+                    ops.mlp_bwd_f16(g, ws[f"{bi}.w2T"], ws[f"{bi}.w1T"], h, dh, gh, x1, st2, g1, rowscale=s2,
+                                    rows_per_scale=H * W)
                 else:
                     ops.gemm_nt(g, ws[f"{bi}.w2T"], None, out=dh, epi=3, R=h, rowscale=s2,
                                 rows_per_scale=H * W, aux=gh)
@@ -549,11 +543,11 @@ class SwinIREngine:
                 if defer:
                     pending += problems
                 else:
-                    ops.linear_wgrad_grouped(problems, ln_grads_zeroed=grads_zeroed)
+                    ops.linear_wgrad_grouped(problems)
                 gi = (gi + 2) % nrot
                 g = gout
             if pending:
-                ops.linear_wgrad_grouped(pending, ln_grads_zeroed=grads_zeroed)
+                ops.linear_wgrad_grouped(pending)
             # relative-position-bias table gradients of the layer's blocks: one launch (<= 8 blocks each)
             tabs = [G(pre + f"residual_group.blocks.{j}.attn.relative_position_bias_table") for j in range(nb)]
             same = len({blk.num_heads for blk in layer.residual_group.blocks}) == 1

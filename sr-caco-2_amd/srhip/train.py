@@ -135,6 +135,29 @@ def allreduce_range(flat_grad, lo, hi, group=None, comm_stream=None):
         dist.all_reduce(flat_grad[lo:hi], group=group)
 
 
+def broadcast_replica_state(flat_params, buffers, group=None, src=0):
+    """What wrapping the network in DDP does at construction and, for the buffers, at every forward
+    (reference model_base.py:135-142: DistributedDataParallel(network, ...), default broadcast_buffers=True):
+    rank ``src``'s parameters and floating-point buffers replace every other rank's, so replicas that were
+    initialised differently -- a checkpoint loaded on the master only, another seed -- start equal.  One
+    collective for the flat parameter buffer, one for all buffers together (integer buffers -- index tables,
+    BatchNorm's num_batches_tracked -- ride as float64: exact up to 2^53)."""
+    import torch.distributed as dist
+    if flat_params is not None:
+        dist.broadcast(flat_params, src, group=group)
+    bufs = [b for b in buffers if b is not None and b.numel() > 0]
+    if not bufs:
+        return
+    allf = all(b.dtype == torch.float32 for b in bufs)
+    flat = torch.cat([b.detach().reshape(-1).to(torch.float32 if allf else torch.float64) for b in bufs])
+    dist.broadcast(flat, src, group=group)
+    o = 0
+    for b in bufs:
+        n = b.numel()
+        b.copy_(flat[o:o + n].view_as(b).to(b.dtype))
+        o += n
+
+
 class GradReducer:
     """Bucketed data-parallel gradient exchange (replaces DDP's reducer,
     model_base.py:135-142).  ``buckets``: flat [lo, hi) ranges in the order backward
@@ -212,6 +235,12 @@ class TrainStep:
         self.comm_stream = torch.cuda.Stream(device=dev) if self.ddp else None
         self.buckets = self._make_buckets() if self.ddp else []
         self.reducer = GradReducer(self.fp.grad, self.buckets, self.pg, self.comm_stream) if self.ddp else None
+        # buffers that change during training (BatchNorm running statistics: MemNet) are re-broadcast from rank 0 at
+        # every step, as DDP's broadcast_buffers does at every forward; constant ones only at construction
+        self._live_buffers = [b for k, b in net.named_buffers() if "running_" in k or "num_batches_tracked" in k]
+        if world_size > 1:
+            broadcast_replica_state(self.fp.flat, list(net.buffers()), self.pg)
+            net.weights_changed()
         if getattr(net, "img_range", 1.) != 1.:
             # SwinIR.forward divides the output by img_range (network_swinir.py:935,968); the fused
             # step feeds engine.forward's output straight to the loss
@@ -224,8 +253,16 @@ class TrainStep:
         gradient buffer."""
         return [self.fp.range_of(pf) for pf in self.net.engine.bucket_prefixes()]
 
-    def loss_and_grad(self, y, target):
-        """MasterLoss value(s) + d loss / d y through the fused loss kernels."""
+    def sync_buffers(self):
+        """rank 0's BatchNorm running statistics to every rank (DDP's broadcast_buffers, model_base.py:139): called at
+        the start of every step, and by ModelPlain before a distributed evaluation -- the last step's rank-local
+        updates must not reach the metrics."""
+        if self.world > 1 and self._live_buffers:
+            broadcast_replica_state(None, self._live_buffers, self.pg)
+
+    def loss_and_grad(self, y, target, weight=None):
+        """MasterLoss value(s) + d loss / d y through the fused loss kernels.  weight: the per-pixel weights of the
+        target (--ppiw, dataset_dpsr.py:925-928); only L1 consumes them (dlib/loss/main.py:45-76)."""
         if self.dy is None or self.dy.shape != y.shape:
             self.dy = torch.empty_like(y)
         lb = self.loss_buf
@@ -233,8 +270,8 @@ class TrainStep:
             first = i == 0
             part = lb[1 + i:2 + i]
             if t[0] in ("l1", "l2"):
-                ops.loss_l1l2(y, target, 0 if t[0] == "l1" else 1, t[1], None, self.dy, part,
-                              grad_accum=not first)
+                ops.loss_l1l2(y, target, 0 if t[0] == "l1" else 1, t[1], weight if t[0] == "l1" else None, self.dy,
+                              part, grad_accum=not first)
             elif t[0] == "ssim":
                 ops.ssim_loss(y, target, t[2], t[1], self.dy, part, grad_accum=not first)
             elif t[0] == "charbonnier":
@@ -297,6 +334,11 @@ class TrainStep:
         captures.  Results are those of step() bit for bit."""
         if self.ddp:
             raise NotImplementedError("step_graph: the RCCL bucket path is not captured; use step() under data parallelism")
+        for t in self.loss_terms:
+            # host-evaluated schedules would be frozen into the graph at capture time: the extended log barrier's t
+            # (ELB.update_t(), dlib/losses/elb.py:92-122) of BoundedPrediction and of the Bhattacharyya histogram / KDE terms
+            if t[0] == "boundpred" or (t[0] in ("hist", "kde") and len(t) > 5 and t[2] == 4):
+                raise NotImplementedError(f"step_graph: the loss term {t[0]!r} carries a host-side schedule (ELB t); use step()")
         key = (tuple(lr_img.shape), tuple(hr_img.shape))
         st = getattr(self, "_graph", None)
         if st is None or st["key"] != key:
@@ -318,35 +360,40 @@ class TrainStep:
         self.net.weights_changed()
         return self.loss_buf
 
-    def step(self, lr_img, hr_img, dp=None):
+    def step(self, lr_img, hr_img, dp=None, weight=None):
         """One optimisation step.  Returns the device tensor [total, term1, ...]
-        (no host sync here; read it when needed)."""
-        out = self._enqueue(lr_img, hr_img, dp, host_side=True)
+        (no host sync here; read it when needed).  weight: per-pixel weights of the L1 term (shape of hr_img)."""
+        out = self._enqueue(lr_img, hr_img, dp, host_side=True, weight=weight)
         self.opt.scheduler_step()
         self.net.weights_changed()
         return out
 
-    def _enqueue(self, lr_img, hr_img, dp, host_side):
+    def _enqueue(self, lr_img, hr_img, dp, host_side, weight=None):
         net = self.net
         xi, h, w = net.prepare_input(lr_img)
         assert (h, w) == tuple(xi.shape[1:]), \
             "training patches must not need padding (SwinIR: multiples of the 8x8 window)"
         self.flag.zero_()
+        self.sync_buffers()
         if dp is None:
             dp = net.sample_drop_path(xi.shape[0], xi.device)
         y = net.engine.forward(xi, dp, save=True)
         inter = getattr(net.engine, "intermediate_outs", None)
         d_inter = None
         if inter:       # MSLapSRN: the trainer's multi-scale loss (model_plain.py:277-314)
+            if weight is not None:
+                raise NotImplementedError("per-pixel weights with the multi-scale loss")
             dy, d_inter = self.multiscale_loss_and_grad(y, inter, hr_img)
         else:
-            dy = self.loss_and_grad(y, hr_img)
+            if weight is not None:
+                assert weight.shape == hr_img.shape and weight.is_contiguous(), "per-pixel weights: the target's shape"
+            dy = self.loss_and_grad(y, hr_img, weight)
         hook = None
         if self.ddp:
             self.reducer.begin()
             hook = self.reducer.bucket_done
-        # ONE memset of the flat gradient buffer per step: the few gradients that are
-        # accumulated with atomics (LayerNorm affine) need no per-tensor zeroing then
+        # every gradient kernel OVERWRITES its tensor (the LayerNorm-affine sums are two-stage and deterministic too);
+        # the memset only keeps a parameter without a gradient path (and the alignment padding) at zero
         self.fp.grad.zero_()
         if d_inter is not None:
             net.engine.backward(dy, self.fp.gviews, on_layer_done=hook, grads_zeroed=True, d_inter=d_inter)

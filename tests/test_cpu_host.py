@@ -243,7 +243,7 @@ def test_modelplain_checkpoint_protocol_signatures():
 WORKER_REDUCER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.path.join(sys.argv[1], "sr-caco-2_amd"))
-from srhip.train import FlatParams, GradReducer
+from srhip.train import FlatParams, GradReducer, broadcast_replica_state
 from dlib.utils.utils_parallel import (sync_tensor_across_gpus, sync_non_tensor_value_across_gpus,
                                        sync_dict_across_gpus, sync_metric_sums)
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -303,6 +303,53 @@ run([["2."], ["1."], ["0."]], announce=[])          # EDSR style: none announced
 run([["2."], ["1."], ["0."]], announce=[0, 1, 2])   # all announced
 run([["0.", "1.", "2."]], announce=[0])             # one bucket, announced (old VDSR / DRRN engines)
 run([["0.", "1.", "2."]], announce=[])              # one bucket, not announced
+
+# replica initialisation (model_base.py:135-142: DDP broadcasts rank 0's parameters and buffers): replicas that
+# START DIFFERENT -- another seed, BatchNorm running statistics that drifted apart, an integer step counter -- end equal,
+# and stay equal through reduced steps
+def replicas_that_start_different_end_equal():
+    torch.manual_seed(10 + rank)                            # a different initialisation on every rank
+    net = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.BatchNorm1d(4), torch.nn.Linear(4, 2))
+    with torch.no_grad():
+        net[1].running_mean.add_(rank + 1.0)
+        net[1].num_batches_tracked.add_(7 * rank + 3)
+    fp = FlatParams(net)
+    def gathered(t):
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t.contiguous())
+        return out
+    assert not torch.equal(*gathered(fp.flat))              # they do start different
+    broadcast_replica_state(fp.flat, list(net.buffers()))
+    a, b = gathered(fp.flat)
+    assert torch.equal(a, b)
+    assert torch.equal(net[0].weight.data, fp.flat[:24].view(4, 6))      # parameters are still views of the flat buffer
+    for buf in net.buffers():
+        a, b = gathered(buf.detach().to(torch.float64))
+        assert torch.equal(a, b), buf
+    assert net[1].num_batches_tracked.dtype == torch.int64 and int(net[1].num_batches_tracked) == 3   # rank 0's
+    assert float(net[1].running_mean[0]) == 1.0
+    # two reduced SGD steps on rank-local batches (BatchNorm in training mode: running statistics drift per rank),
+    # with the per-step buffer broadcast TrainStep._enqueue does -> parameters AND buffers equal afterwards
+    red = GradReducer(fp.grad, [(0, fp.total)])
+    live = [b for k, b in net.named_buffers() if "running_" in k or "num_batches_tracked" in k]
+    for step in range(2):
+        broadcast_replica_state(None, live)
+        x = torch.randn(8, 6, generator=torch.Generator().manual_seed(500 + 10 * step + rank))
+        grads = torch.autograd.grad(net(x).pow(2).mean(), list(net.parameters()))
+        for (k, _), g in zip(net.named_parameters(), grads):
+            fp.gviews[k].copy_(g)
+        red.begin()
+        red.finish()
+        fp.flat.add_(fp.grad, alpha=-0.1 / world)
+    broadcast_replica_state(None, live)                      # what distributed evaluation sees
+    a, b = gathered(fp.flat)
+    assert torch.equal(a, b)
+    for buf in net.buffers():
+        a, b = gathered(buf.detach().to(torch.float64))
+        assert torch.equal(a, b)
+
+
+replicas_that_start_different_end_equal()
 
 # eval-side collectives (utils_parallel.py:13-64 as used at utils_trainer.py:653-674)
 t = torch.tensor([float(rank + 1)], dtype=torch.float64)

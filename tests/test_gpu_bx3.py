@@ -14,15 +14,6 @@ def ops():
     return o
 
 
-@pytest.fixture(autouse=True, params=["ntp", "ntr"])
-def nt_kernel(request, monkeypatch):
-    """Every test of this file runs twice: with the production NT GEMM (gemm_ntp.hip) and with the
-    register-resident-W kernel switched on for the shapes it takes (gemm_ntr.hip, SRHIP_NTR=1: K <= 192,
-    M >= 4096, widths of 180 or <= 192 -- an experiment kept behind the switch)."""
-    monkeypatch.setenv("SRHIP_NTR", "1" if request.param == "ntr" else "0")
-    return request.param
-
-
 G = torch.Generator().manual_seed(4321)
 
 

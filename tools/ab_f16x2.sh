@@ -1,3 +1,4 @@
+#!/bin/bash
 # the two-plane fp16 / three-product kernels against the bf16x3 / six-product ones, same box:
 #   Linear GEMMs (default on, SRHIP_F16X2=0 switches it off): SwinIR parity tests with it off, then the step
 #   64-column convs (experiment, SRHIP_F16X2_CONV=1): EDSR / VDSR / MSLapSRN parity tests with it on, then the EDSR steps

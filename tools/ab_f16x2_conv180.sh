@@ -1,3 +1,4 @@
+#!/bin/bash
 # SwinIR's 180-column 3x3 convs on two fp16 planes / three products (k_nhcw) against bf16x3 / six (k_ntcw,
 # SRHIP_F16X2_CONV180=0), same box: parity tests first, then the training step
 timeout 1500 python -m pytest tests/test_gpu_swinir.py tests/test_gpu_fullsize.py tests/test_gpu_fallback_kernels.py tests/test_gpu_amp.py -q -x 2>&1 | tail -4

@@ -1,3 +1,4 @@
+#!/bin/bash
 # fp16x2 on the wider convs (64 -> 256 with the fused PixelShuffle, its data gradient, 128 / 256-column convs) against
 # bf16x3 there (SRHIP_F16X2_CONV_WIDE=0), same box: parity tests first, then the EDSR steps
 timeout 1500 python -m pytest tests/test_gpu_ps2.py tests/test_gpu_edsr_api.py tests/test_gpu_fullsize.py tests/test_gpu_fallback_kernels.py tests/test_gpu_bx3.py -q -x 2>&1 | tail -4

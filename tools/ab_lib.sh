@@ -1,3 +1,4 @@
+#!/bin/bash
 # same-box A/B of two BUILDS of libsrhip in the training step: the in-tree library against sr-caco-2_amd/lib/libsrhip_base.so
 # (build the baseline from another commit, copy it there; .so files travel to the GPU box, they are not in git)
 BASE=$(pwd)/sr-caco-2_amd/lib/libsrhip_base.so

@@ -1,3 +1,4 @@
+#!/bin/bash
 # same-box A/B of the conv variants in the training step: W fragments straight from global memory (k_ntcw: 64-pixel x 192-column
 # tiles, SwinIR; k_ntcw2: 128-pixel x 64-column tiles, EDSR and the other 64-channel nets) against W through LDS (k_ntb)
 # usage: tools/ab_ntcw.sh [workload] [NTCW|NTCW2]

@@ -1,3 +1,4 @@
+#!/bin/bash
 # same-box A/B of the Linear GEMM variants in the training step (bench.py):
 #   SRHIP_NTW=0 (k_ntp: W through LDS) | SRHIP_NTW=1 without / with the per-block rotation of the K walk (k_ntw)
 for i in 1 2 3; do

@@ -1,3 +1,4 @@
+#!/bin/bash
 # fp16x2 / three products in the three-tap conv weight-gradient kernels (default) against bf16x3 / six products
 # (SRHIP_TN_F16X2=0), same box: parity tests first, then the EDSR steps
 timeout 1500 python -m pytest tests/test_gpu_fallback_kernels.py tests/test_gpu_bx3.py tests/test_gpu_ps2.py tests/test_gpu_edsr_api.py tests/test_gpu_fullsize.py tests/test_gpu_kernels.py -q -x 2>&1 | tail -6

@@ -1,3 +1,4 @@
+#!/bin/bash
 # grouped Linear weight gradients: XCD-aware (slice, tile) order (SRHIP_TN_GROUP_XCD, default 1) x fp16x2 / three products
 # (SRHIP_TN_F16X2_LINEAR), same box: parity tests with both on, then the SwinIR step in the four arms
 SRHIP_TN_F16X2_LINEAR=1 timeout 900 python -m pytest tests/test_gpu_bx3.py tests/test_gpu_swinir.py -q -x 2>&1 | tail -3
