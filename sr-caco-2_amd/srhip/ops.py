@@ -418,7 +418,7 @@ class _ReduceProblem(ctypes.Structure):   # srhip_reduce_problem (include/srhip.
     _fields_ = [("part", ctypes.c_void_p), ("colsum", ctypes.c_void_p), ("W", ctypes.c_void_p),
                 ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("dW", ctypes.c_void_p),
                 ("db", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
-                ("N", ctypes.c_int), ("K", ctypes.c_int)]
+                ("N", ctypes.c_int), ("K", ctypes.c_int), ("ln_ws", ctypes.c_void_p)]
 
 
 def linear_wgrad_grouped(problems):

@@ -25,6 +25,28 @@ def test_library_exports_every_declared_symbol():
     assert isinstance(_lib.lib.srhip_last_error(), bytes)
 
 
+def test_ctypes_structs_mirror_the_header(tmp_path):
+    """The structs ops.py passes by address are laid out as include/srhip.h declares them: sizeof and the offset of the
+    last field, asked of the C compiler (gcc on the plain-C header) -- a field added on one side only would otherwise
+    show up as a rejected call on the GPU box."""
+    import ctypes
+    from srhip import ops
+    pairs = {"srhip_prep_entry": (ops._PrepEntry, "mode"), "srhip_tn_problem": (ops._TnProblem, "part_colsum"),
+             "srhip_reduce_problem": (ops._ReduceProblem, "ln_ws"), "srhip_conv_wgrad_item": (ops._ConvWgradItem, "db"),
+             "srhip_patch_job": (ops._PatchJob, "mode")}
+    src = tmp_path / "sizes.c"
+    body = "".join(f'  printf("{n} %zu %zu\\n", sizeof({n}), offsetof({n}, {last}));\n' for n, (_, last) in pairs.items())
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "srhip.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    for line in out.strip().splitlines():
+        name, size, off = line.split()
+        cls, last = pairs[name]
+        assert ctypes.sizeof(cls) == int(size), (name, ctypes.sizeof(cls), size)
+        assert getattr(cls, last).offset == int(off), (name, last)
+
+
 def test_plan_queries_need_no_gpu():
     from srhip import ops
     S, n = ops.tn_plan(32768, 180, 180)
