@@ -271,6 +271,27 @@ int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, con
                         const float* gamma, float* out, float* dgamma, float* dbeta, float* workspace, long M,
                         int C, void* stream);
 
+/* ---- window attention on the two-plane fp16 split MFMA (wattn2.hip) -------------- */
+/* The same contract as srhip_window_attention_fwd (network_swinir.py:48-80,153-176,297-331) with the two
+ * contractions as three fp16 products under power-of-two block exponents (q, k per token row, v per head-dim
+ * column, p a fixed 2^14; f32 accumulation): f32-grade results at a fifth of the matrix-core time, no LDS.
+ * biasF = the bias image in the kernel's accumulator order: img[head][I][J][lane][e] = table[rpi(query 16 I +
+ * (lane & 15), key 16 J + 4 (lane >> 4) + e)][head], heads*4096 floats (srhip_bias_expand_f16x2, or the `c`
+ * output of a srhip_prep_table job of kind 2; biasG -- may be NULL -- see the backward). */
+int srhip_bias_expand_f16x2(const float* table, float* biasF, float* biasG, int heads, void* stream);
+int srhip_window_attention_fwd_f16x2(const float* qkv, float* out, const float* biasF, int B, int H, int W, int C,
+                                     int heads, int shift, void* stream);
+/* Backward of the same core in ONE kernel (one wave per (window, head): query side, then key side; every operand is
+ * read in the form the matrix core takes it, nothing but the bias-gradient tile goes through LDS).  biasG = the bias
+ * image in the key side's accumulator order, img[head][J][I][lane][e] = table[rpi(query 16 I + 4 (lane >> 4) + e,
+ * key 16 J + (lane & 15))][head] (second output of srhip_bias_expand_f16x2 / `b` of a prep job of kind 2).
+ * dqkv [T][3C] is overwritten; dbiasT (may be NULL) receives the bias-gradient image in the order srhip_bias_grad
+ * reads; workspace: srhip_window_attention_bwd_f16x2_ws floats (partial tiles, summed in fp64 in a fixed order). */
+long srhip_window_attention_bwd_f16x2_ws(int B, int H, int W, int heads);
+int srhip_window_attention_bwd_f16x2(const float* qkv, const float* dout, float* dqkv, const float* biasF,
+                                     const float* biasG, float* dbiasT, float* workspace, int B, int H, int W, int C,
+                                     int heads, int shift, void* stream);
+
 /* ---- window attention (network_swinir.py:48-80,140-179,297-331) -------------- */
 /* table (225,heads) -> two bias images of heads*4096 floats each, stored in the order
  * the attention kernels read them as 32x32 MFMA accumulator tiles:

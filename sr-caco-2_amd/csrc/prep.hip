@@ -100,6 +100,12 @@ __device__ __forceinline__ void job_bias_expand(const PrepEntry& e, int lb) {
   auto rpi = [](int query, int key) { return ((query >> 3) - (key >> 3) + 7) * 15 + ((query & 7) - (key & 7) + 7); };
   ((float*)e.out)[i] = ldg_f(e.a + rpi(col + 32 * b, row + 32 * a) * heads + hd);    // imgT
   ((float*)e.out2)[i] = ldg_f(e.a + rpi(row + 32 * a, col + 32 * b) * heads + hd);   // imgN
+  if (e.c) {     // third image: the S^T accumulator order of the fp16x2 attention kernels (w2_img_index, wattn2.hip)
+    const int ee = el & 3, ln = (el >> 2) & 63, J = (el >> 8) & 3, I = el >> 10;
+    ((float*)e.c)[i] = ldg_f(e.a + rpi(16 * I + (ln & 15), 16 * J + 4 * (ln >> 4) + ee) * heads + hd);
+    // fourth image (`b`): the key side of the backward, img[J][I][lane][e] = bias(query 16 I + 4 g + e, key 16 J + c)
+    if (e.b) ((float*)e.b)[i] = ldg_f(e.a + rpi(16 * J + 4 * (ln >> 4) + ee, 16 * I + (ln & 15)) * heads + hd);
+  }
 }
 
 // kind 3 (experiment, SRHIP_F16X2=1): TWO fp16 planes with a power-of-two scale per ROW instead of three bf16 planes --

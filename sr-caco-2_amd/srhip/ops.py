@@ -197,9 +197,11 @@ class PrepTable:
         self.keep += [W, b, beta, out]
         self._add(kind=1, a=_p(W), b=_p(b), c=_p(beta), out=_p(out), n0=N, n1=K)
 
-    def bias_expand(self, table, biasT, biasN, heads):
-        self.keep += [table, biasT, biasN]
-        self._add(kind=2, a=_p(table), out=_p(biasT), out2=_p(biasN), n0=heads)
+    def bias_expand(self, table, biasT, biasN, heads, biasF=None, biasG=None):
+        """dense relative-position bias images: biasT / biasN in the 32x32 accumulator orders of wattn.hip, biasF /
+        biasG (optional, together) in the S^T / S orders of the fp16x2 attention kernels (wattn2.hip)."""
+        self.keep += [table, biasT, biasN, biasF, biasG]
+        self._add(kind=2, a=_p(table), out=_p(biasT), out2=_p(biasN), c=_p(biasF), b=_p(biasG), n0=heads)
 
     def build(self, device):
         n = len(self.jobs)
@@ -639,6 +641,42 @@ def bias_grad_batched(dbiasT_all, first, dtables):
     img = dbiasT_all[first]
     call("srhip_bias_grad_batched", _p(img), dbiasT_all.stride(0), ctypes.addressof(arr), n,
          dtables[0].shape[1], _st())
+
+
+# the attention core on two fp16 planes / three products (wattn2.hip); SRHIP_WATTN_F16=0: the exact-f32 MFMA kernels
+WATTN_F16 = _os.environ.get("SRHIP_WATTN_F16", "1") != "0"
+
+
+def wattn_f16_ok(C, heads):
+    return WATTN_F16 and use_bx3() and C % heads == 0 and C // heads in (10, 16, 30, 32) and C % 2 == 0
+
+
+def bias_expand_f16(table, biasF, biasG=None):
+    _chk(table, biasF, biasG)
+    call("srhip_bias_expand_f16x2", _p(table), _p(biasF), _p(biasG), table.shape[1], _st())
+
+
+def window_attention_bwd_f16(qkv, dout, dqkv, biasF, biasG, dbiasT, B, H, W, C, heads, shift):
+    _chk(qkv, dout, dqkv, biasF, biasG, dbiasT)
+    ws = SCRATCH.get("wattn2_ws", lib.srhip_window_attention_bwd_f16x2_ws(B, H, W, heads), device=qkv.device)
+    args = (_p(qkv), _p(dout), _p(dqkv), _p(biasF), _p(biasG), _p(dbiasT), _p(ws), B, H, W, C, heads, shift, _st())
+    if probe.on("wattn"):
+        T = B * H * W
+        with probe.timed(("wattn", "bwd", T, C), 10.0 * T * 64 * C, 4.0 * T * 7 * C):
+            call("srhip_window_attention_bwd_f16x2", *args)
+        return
+    call("srhip_window_attention_bwd_f16x2", *args)
+
+
+def window_attention_fwd_f16(qkv, out, biasF, B, H, W, C, heads, shift):
+    _chk(qkv, out, biasF)
+    args = (_p(qkv), _p(out), _p(biasF), B, H, W, C, heads, shift, _st())
+    if probe.on("wattn"):
+        T = B * H * W
+        with probe.timed(("wattn", "fwd", T, C), 4.0 * T * 64 * C, 4.0 * T * 4 * C):
+            call("srhip_window_attention_fwd_f16x2", *args)
+        return
+    call("srhip_window_attention_fwd_f16x2", *args)
 
 
 def window_attention_fwd(qkv, out, biasT, B, H, W, C, heads, shift):

@@ -126,7 +126,11 @@ class SwinIREngine:
                 tb.fold_bias(w1, b.mlp.fc1.bias.data, b.norm2.bias.data, D.get(f"{i}.b1", hid, device=dev))
                 tb.bias_expand(b.attn.relative_position_bias_table.data,
                                D.get(f"{i}.biasT", b.num_heads, 64, 64, device=dev),
-                               D.get(f"{i}.biasN", b.num_heads, 64, 64, device=dev), b.num_heads)
+                               D.get(f"{i}.biasN", b.num_heads, 64, 64, device=dev), b.num_heads,
+                               biasF=D.get(f"{i}.biasF", b.num_heads, 64, 64, device=dev)
+                               if ops.wattn_f16_ok(C, b.num_heads) else None,
+                               biasG=D.get(f"{i}.biasG", b.num_heads, 64, 64, device=dev)
+                               if ops.wattn_f16_ok(C, b.num_heads) else None)
             for name, conv in self._convs():
                 co, ci = conv.weight.shape[:2]
                 tb.conv(conv.weight.data, ws.planes(name + ".wp", 9 * co, ci, dev))
@@ -283,7 +287,10 @@ class SwinIREngine:
                 qkv = buf(f"{k}.qkv", T, 3 * C)
                 ops.gemm_nt(t, ws[f"{bi}.wq"], D.d[f"{bi}.bq"], out=qkv, a_mode=1, ln_stats=st1)
                 a = buf(f"{k}.a", T, C)
-                ops.window_attention_fwd(qkv, a, D.d[f"{bi}.biasT"], B, H, W, C, heads, blk.shift_size)
+                if ops.wattn_f16_ok(C, heads):
+                    ops.window_attention_fwd_f16(qkv, a, D.d[f"{bi}.biasF"], B, H, W, C, heads, blk.shift_size)
+                else:
+                    ops.window_attention_fwd(qkv, a, D.d[f"{bi}.biasT"], B, H, W, C, heads, blk.shift_size)
                 x1 = buf(f"{k}.x1", T, C)
                 st2 = buf(f"{k}.st2", T, 2)
                 ops.gemm_nt(a, ws[f"{bi}.wproj"], blk.attn.proj.bias.data, out=x1, epi=2, R=t,
@@ -520,8 +527,12 @@ class SwinIREngine:
                 # ---- attention branch: x1 = t + s1*(a Wp^T + bp)
                 ops.gemm_nt(g1, ws[f"{bi}.wpT"], None, out=da, epi=2, rowscale=s1, rows_per_scale=H * W)
                 dbT = dbT_all[bi, :heads]
-                ops.window_attention_bwd(qkv, da, dqkv, D.d[f"{bi}.biasT"], D.d[f"{bi}.biasN"], dbT, B, H,
-                                         W, C, heads, blk.shift_size)
+                if ops.wattn_f16_ok(C, heads):
+                    ops.window_attention_bwd_f16(qkv, da, dqkv, D.d[f"{bi}.biasF"], D.d[f"{bi}.biasG"], dbT, B, H,
+                                                 W, C, heads, blk.shift_size)
+                else:
+                    ops.window_attention_bwd(qkv, da, dqkv, D.d[f"{bi}.biasT"], D.d[f"{bi}.biasN"], dbT, B, H,
+                                             W, C, heads, blk.shift_size)
                 if ws.use_bx3:
                     ops.gemm_nt_lnbwd(dqkv, ws[f"{bi}.wqT"], t, st1, g1, gout)
                 else:

@@ -294,6 +294,68 @@ def test_window_attention(ops, B, H, W, C, heads, shift):
     check(dtable, tr.grad, 5e-5, "attention dtable")
 
 
+ATT_SHAPES = [(2, 16, 16, 180, 6, 0), (2, 16, 16, 180, 6, 4), (1, 16, 24, 60, 6, 4), (3, 24, 16, 60, 6, 0),
+              (1, 64, 64, 180, 6, 4), (1, 72, 72, 180, 6, 4), (1, 16, 24, 96, 6, 4), (2, 16, 16, 192, 6, 0),
+              (1, 24, 24, 64, 2, 4)]
+
+
+@pytest.mark.parametrize("regime", ["fresh", "saturated"])
+@pytest.mark.parametrize("B,H,W,C,heads,shift", ATT_SHAPES)
+def test_window_attention_f16x2(ops, B, H, W, C, heads, shift, regime):
+    """wattn2.hip: the attention core on two fp16 planes / three products against a float64 statement of the
+    reference's roll + partition + attention + reverse; 'saturated' = trained-like logits (q, k rows whose scales
+    are decades apart, |logits| up to ~30: one-hot-ish softmax rows next to flat ones)."""
+    T = B * H * W
+    qkv = rnd(T, 3 * C)
+    if regime == "saturated":
+        rowmag = torch.exp(rnd(T, 1) * 1.5)
+        qkv = torch.cat([qkv[:, :C] * rowmag * 3.0, qkv[:, C:2 * C] * torch.exp(rnd(T, 1)), qkv[:, 2 * C:] * torch.exp(rnd(1, C) * 2)], 1)
+    table = rnd(225, heads, scale=0.5 if regime == "fresh" else 2.0)
+    biasF, biasG = torch.empty(heads, 64, 64).cuda(), torch.empty(heads, 64, 64).cuda()
+    ops.bias_expand_f16(dev(table), biasF, biasG)
+    rpi = O.relative_position_index(8)
+    dense = table[rpi.reshape(-1)].reshape(64, 64, heads).permute(2, 0, 1)      # [head][query][key]
+    # img[head][I][J][lane][e] = bias[query 16 I + (lane & 15)][key 16 J + 4 (lane >> 4) + e]
+    I = torch.arange(4).view(4, 1, 1, 1)
+    J = torch.arange(4).view(1, 4, 1, 1)
+    lane = torch.arange(64).view(1, 1, 64, 1)
+    e = torch.arange(4).view(1, 1, 1, 4)
+    exp = dense[:, (16 * I + (lane & 15)).expand(4, 4, 64, 4), (16 * J + 4 * (lane >> 4) + e).expand(4, 4, 64, 4)]
+    assert torch.equal(biasF.cpu().reshape(heads, 4, 4, 64, 4), exp)
+    # imgG[head][J][I][lane][e] = bias[query 16 I + 4 (lane >> 4) + e][key 16 J + (lane & 15)]  (first tile index = key tile)
+    expG = dense[:, (16 * J + 4 * (lane >> 4) + e).expand(4, 4, 64, 4), (16 * I + (lane & 15)).expand(4, 4, 64, 4)]
+    assert torch.equal(biasG.cpu().reshape(heads, 4, 4, 64, 4), expG)
+    out = torch.full((T, C), float("nan")).cuda()
+    ops.window_attention_fwd_f16(dev(qkv), out, biasF, B, H, W, C, heads, shift)
+    ref64 = ref_window_attention(qkv.double(), table.double(), B, H, W, C, heads, shift)
+    ref32 = ref_window_attention(qkv, table, B, H, W, C, heads, shift)
+    # f32-grade.  A two-plane fp16 operand carries 22 significant bits against f32's 24, and these contractions are short
+    # (head dim <= 32, 64 keys): operand rounding, not accumulation, sets the error -- up to 4x an f32 computation's per
+    # operand.  Gate: within 8x of what the reference's own f32 computation is from float64 (floor 2e-6 of the largest entry).
+    e32 = (ref32.double() - ref64).abs().max().item()
+    e16 = (out.cpu().double() - ref64).abs().max().item()
+    assert e16 <= max(8.0 * e32, 2e-6 * ref64.abs().max().item()), (e16, e32)
+    check(out, ref32, 1e-5 if regime == "fresh" else 1e-4, "attention fwd f16x2")
+    # ---- backward against float64 autograd; "f32-grade" = within 8x of the f32 autograd's own distance from it (see above)
+    dout = rnd(T, C)
+    q64, t64 = qkv.double().requires_grad_(True), table.double().requires_grad_(True)
+    ref_window_attention(q64, t64, B, H, W, C, heads, shift).backward(dout.double())
+    q32, t32 = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    ref_window_attention(q32, t32, B, H, W, C, heads, shift).backward(dout)
+    dqkv = torch.full((T, 3 * C), float("nan")).cuda()
+    dbiasT = torch.full((heads, 64, 64), 123.0).cuda()      # overwritten, not accumulated into
+    ops.window_attention_bwd_f16(dev(qkv), dev(dout), dqkv, biasF, biasG, dbiasT, B, H, W, C, heads, shift)
+    dtable = torch.empty(225, heads).cuda()
+    ops.bias_grad(dbiasT, dtable)
+    for name, got, r64, r32 in (("dq", dqkv[:, :C], q64.grad[:, :C], q32.grad[:, :C]),
+                                ("dk", dqkv[:, C:2 * C], q64.grad[:, C:2 * C], q32.grad[:, C:2 * C]),
+                                ("dv", dqkv[:, 2 * C:], q64.grad[:, 2 * C:], q32.grad[:, 2 * C:]),
+                                ("dtable", dtable, t64.grad, t32.grad)):
+        e32 = (r32.double() - r64).abs().max().item()
+        e16 = (got.cpu().double() - r64).abs().max().item()
+        assert e16 <= max(8.0 * e32, 4e-6 * r64.abs().max().item()), (name, e16, e32, r64.abs().max().item())
+
+
 # ------------------------------------------------------------------ edge convs
 def test_conv_cin1_cout1(ops):
     B, H, W, Co = 2, 20, 28, 180
