@@ -271,6 +271,22 @@ int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, con
                         const float* gamma, float* out, float* dgamma, float* dbeta, float* workspace, long M,
                         int C, void* stream);
 
+/* ---- helpers of the generic conv-net engine (tape_ops.hip; DBPN / SRFBN / ProSR: SURVEY f1) ---------------- */
+/* nn.PReLU(num_parameters = 1) (dlib/models/network_dbpn.py:85-86, network_srfbn.py:38-46): y = x > 0 ? x : a x with
+ * the slope read from device memory; backward dx = g (x > 0 ? 1 : a) (dx may alias g) and dalpha (+)= sum g min(x, 0)
+ * (fp64 block partials in workspace -- 4096 doubles -- added in a fixed order: deterministic). n % 4 == 0. */
+int srhip_prelu_fwd(const float* x, const float* alpha, float* y, long n, void* stream);
+int srhip_prelu_bwd(const float* g, const float* x, const float* alpha, float* dx, float* dalpha, double* workspace,
+                    long n, int accumulate, void* stream);
+/* y[r][0:cols] = a x[r][0:cols] + b y[r][0:cols] on row-major views (channel slices of NHWC tensors: torch.cat as a
+ * view, network_dbpn.py:540-566); cols, ldy, ldx multiples of 4. */
+int srhip_axpby2d(float* y, long ldy, const float* x, long ldx, long rows, int cols, float a, float b, void* stream);
+/* nn.ReflectionPad2d(1) on NHWC (network_prosr.py:44-86): in [B][H][W][C] -> out [B][H+2][W+2][C]; adjoint != 0: its
+ * gradient, in [B][H+2][W+2][C] -> out [B][H][W][C] (a gather, deterministic).  srhip_crop1: the inverse crop
+ * [B][H+2][W+2][C] -> [B][H][W][C]; adjoint: zero-bordered placement. */
+int srhip_pad_reflect1(const float* in, float* out, int B, int H, int W, int C, int adjoint, void* stream);
+int srhip_crop1(const float* in, float* out, int B, int H, int W, int C, int adjoint, void* stream);
+
 /* ---- window attention on the two-plane fp16 split MFMA (wattn2.hip) -------------- */
 /* The same contract as srhip_window_attention_fwd (network_swinir.py:48-80,153-176,297-331) with the two
  * contractions as three fp16 products under power-of-two block exponents (q, k per token row, v per head-dim

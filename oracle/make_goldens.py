@@ -1189,6 +1189,160 @@ def g_kde():
     npz("g15_kde", **out)
 
 
+def g_dbpn():
+    print("G28 DBPN")
+    from dlib.models.network_dbpn import DBPN as RefDBPN
+    out = {}
+    # a narrow configuration (base_filter 16, feat 32, 2 passes) keeps the fixture small; every op class of the
+    # default net is in it: k6 / k8 / k12 transposed and strided convs, 1x1 compressions, PReLU, dense concatenations,
+    # weight sharing across the passes.  Weights from the oracle's seeded initialiser loaded into the reference net.
+    for scale in (2, 4, 8):
+        cfg = dict(base_filter=16, feat=32, num_stages=2)
+        sd = O.dbpn_init_state_dict(scale, 1, seed=280 + scale, bias_std=0.05, **cfg)
+        net = RefDBPN(upscale=scale, in_chans=1, **cfg)
+        ref_keys = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        assert sorted(ref_keys) == sorted((k, tuple(v.shape)) for k, v in sd.items()), "DBPN state_dict layout"
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(290 + scale)
+        x = torch.rand(2, 1, 6, 5)
+        tgt = torch.rand(2, 1, 6 * scale, 5 * scale)
+        y = net(x)
+        (y - tgt).abs().mean().backward()
+        sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        yo = O.dbpn_forward(sdo, x, scale, cfg["num_stages"])
+        (yo - tgt).abs().mean().backward()
+        close(yo.detach(), y.detach(), 1e-6, f"dbpn x{scale} forward")
+        pre = f"x{scale}/"
+        sums = []
+        for k, p in net.named_parameters():
+            close(sdo[k].grad, p.grad, 1e-6 * max(1.0, float(p.grad.abs().max())), f"dbpn x{scale} d{k}")
+            sums.append([p.grad.double().sum().item(), p.grad.double().abs().sum().item(), p.grad.double().abs().max().item()])
+            if p.grad.numel() <= 4096:
+                out[pre + "grad/" + k] = p.grad
+        out[pre + "x"], out[pre + "target"], out[pre + "y"] = x, tgt, y.detach()
+        out[pre + "grad_sums"] = np.array(sums)
+        out[pre + "grad_names"] = np.array([k for k, _ in net.named_parameters()])
+        out[pre + "seed"] = np.array(280 + scale)
+    out["state_dict_keys_default"] = np.array([k for k in RefDBPN(upscale=2, in_chans=1).state_dict().keys()])
+    npz("g28_dbpn", **out)
+
+
+def g_srfbn():
+    print("G29 SRFBN")
+    from dlib.models.network_srfbn import SRFBN as RefSRFBN
+    out = {}
+    # narrow configuration (16 features, 3 groups, 3 passes): every op class of the registry's net -- k6 / k7 / k8 / k12
+    # transposed and strided convs, dense 1x1 compressions, the feedback of the hidden state through the passes, the
+    # bilinear skip -- and the trainer's curriculum loss (mean over ALL passes' predictions, model_plain.py:202-232).
+    # FeedbackBlock.forward allocates its hidden state with .cuda() (network_srfbn.py:542): on the CPU that line is
+    # replaced by the equivalent clone for the run below.
+    import dlib.models.network_srfbn as ref_mod
+    cfg = dict(num_features=16, num_steps=3, num_groups=3)
+    for scale in (2, 3, 4, 8):
+        sd = O.srfbn_init_state_dict(scale, 1, cfg["num_features"], cfg["num_groups"], seed=300 + scale)
+        net = RefSRFBN(upscale=scale, in_chans=1, **cfg)
+        ref_keys = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        assert ref_keys == [(k, tuple(v.shape)) for k, v in sd.items()], "SRFBN state_dict layout / order"
+        net.load_state_dict(sd, strict=True)
+        zeros, torch.zeros = torch.zeros, (lambda *a, **k: _CpuZeros(zeros(*a, **k)))
+        try:
+            torch.manual_seed(310 + scale)
+            x = torch.rand(2, 1, 6, 5)
+            tgt = torch.rand(2, 1, 6 * scale, 5 * scale)
+            y = net(x)
+            outs = list(net.intermediate_outs)
+        finally:
+            torch.zeros = zeros
+        assert len(outs) == cfg["num_steps"] and outs[-1] is y
+        loss = sum((o - tgt).abs().mean() for o in outs) / len(outs)
+        loss.backward()
+        sdo = {k: (v.clone().requires_grad_(True) if not k.startswith(("sub_mean", "add_mean")) else v.clone()) for k, v in sd.items()}
+        yo = O.srfbn_forward(sdo, x, scale, cfg["num_steps"], cfg["num_groups"])
+        (sum((o - tgt).abs().mean() for o in yo) / len(yo)).backward()
+        pre = f"x{scale}/"
+        for i, (a, b) in enumerate(zip(yo, outs)):
+            close(a.detach(), b.detach(), 1e-6, f"srfbn x{scale} pass {i}")
+            out[pre + f"y{i}"] = b.detach()
+        sums, names = [], []
+        for k, p in net.named_parameters():
+            if not p.requires_grad:
+                continue
+            close(sdo[k].grad, p.grad, 1e-6 * max(1.0, float(p.grad.abs().max())), f"srfbn x{scale} d{k}")
+            sums.append([p.grad.double().sum().item(), p.grad.double().abs().sum().item(), p.grad.double().abs().max().item()])
+            names.append(k)
+            if p.grad.numel() <= 4096:
+                out[pre + "grad/" + k] = p.grad
+        out[pre + "x"], out[pre + "target"] = x, tgt
+        out[pre + "grad_sums"], out[pre + "grad_names"] = np.array(sums), np.array(names)
+        out[pre + "seed"] = np.array(300 + scale)
+    out["state_dict_keys_default"] = np.array([k for k in RefSRFBN(upscale=2, in_chans=1).state_dict().keys()])
+    npz("g29_srfbn", **out)
+
+
+class _CpuZeros:
+    """torch.zeros(...) whose .cuda() is the identity (FeedbackBlock.forward on a CPU-only box)."""
+    def __init__(self, t):
+        self.t = t
+
+    def cuda(self):
+        return self.t
+
+
+def g_prosr():
+    print("G30 ProSR")
+    from dlib.models.network_prosr import ProSR as RefProSR
+    out = {}
+    # narrow configuration (32 init features, growth 8, two / one dense blocks of 3 / 2 layers per level, a level whose
+    # features exceed max_num_feature so that final_comp exists is NOT part of the registry's nets and not built); every op
+    # class of the registry's net: reflection-padded 3x3 convs, dense concatenations, 1x1 compressions, level skips, conv +
+    # PixelShuffle + ReLU upsamplers, reconstruction on the clamped bicubic input, the multi-scale loss of the trainer.
+    for scale in (2, 4, 8):
+        n = int(math.log2(scale))
+        cfg = O.prosr_config(upscale=scale, num_init_features=32, bn_size=2, growth_rate=8,
+                             level_config=[[3, 2], [2], [2]][:n])
+        sd = O.prosr_init_state_dict(cfg, seed=320 + scale, bias_std=0.05)
+        net = RefProSR(upscale=scale, in_chans=1, residual_denseblock=True, num_init_features=32, bn_size=2, growth_rate=8,
+                       ps_woReLU=False, level_config=cfg["level_config"], level_compression=-1, res_factor=0.2,
+                       max_num_feature=312, block_compression=0.4)
+        assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()], \
+            "ProSR state_dict layout / order"
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(330 + scale)
+        x = torch.rand(2, 1, 6, 5)
+        tgt = torch.rand(2, 1, 6 * scale, 5 * scale)
+        y = net(x)
+        inter = list(net.intermediate_outs)
+        assert len(inter) == n - 1
+        loss = O.mslapsrn_loss(y, inter, tgt)            # the trainer's multi-scale loss (model_plain.py:234-275 = :277-314)
+        loss.backward()
+        sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        outs = O.prosr_forward(sdo, x, cfg)
+        O.mslapsrn_loss(outs[-1], outs[:-1], tgt).backward()
+        pre = f"x{scale}/"
+        for i, (a, b) in enumerate(zip(outs, inter + [y])):
+            close(a.detach(), b.detach(), 1e-6, f"prosr x{scale} level {i + 1}")
+            out[pre + f"y{i}"] = b.detach()
+        sums, names = [], []
+        for k, p in net.named_parameters():
+            if p.grad is None:           # init convs of the scales that were not requested
+                assert k.startswith("init_conv_") and not k.startswith(f"init_conv_{n}."), k
+                continue
+            close(sdo[k].grad, p.grad, 1e-6 * max(1.0, float(p.grad.abs().max())), f"prosr x{scale} d{k}")
+            sums.append([p.grad.double().sum().item(), p.grad.double().abs().sum().item(), p.grad.double().abs().max().item()])
+            names.append(k)
+            if p.grad.numel() <= 2048:
+                out[pre + "grad/" + k] = p.grad
+        out[pre + "x"], out[pre + "target"] = x, tgt
+        out[pre + "grad_sums"], out[pre + "grad_names"] = np.array(sums), np.array(names)
+        out[pre + "seed"] = np.array(320 + scale)
+    for scale in (2, 4, 8):
+        c = O.prosr_config(upscale=scale)
+        ref = RefProSR(upscale=scale, in_chans=1, level_config=c["level_config"])
+        out[f"state_dict_keys_default_x{scale}"] = np.array(list(ref.state_dict().keys()))
+        assert list(ref.state_dict().keys()) == list(O.prosr_init_state_dict(c).keys())
+    npz("g30_prosr", **out)
+
+
 def g_vdsr():
     print("G16 VDSR")
     from dlib.models.network_vdsr import VDSR as RefVDSR
@@ -1398,7 +1552,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_dbpn, g_srfbn, g_prosr, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

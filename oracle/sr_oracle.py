@@ -446,6 +446,285 @@ def vdsr_init_state_dict(in_chans: int = 1, seed: int = 0) -> SD:
 
 
 # ----------------------------------------------------------------------------
+# DBPN (dlib/models/network_dbpn.py)
+# ----------------------------------------------------------------------------
+_DBPN_KSP = {2: (6, 2, 2), 4: (8, 4, 2), 8: (12, 8, 2)}
+
+
+def _dbpn_conv(sd: SD, pre: str, x: Tensor, stride: int, padding: int, act: bool = True) -> Tensor:
+    """ConvBlock (network_dbpn.py:71-105, norm None): conv (+ PReLU)."""
+    y = F.conv2d(x, sd[pre + ".conv.weight"], sd[pre + ".conv.bias"], stride=stride, padding=padding)
+    return F.prelu(y, sd[pre + ".act.weight"]) if act else y
+
+
+def _dbpn_deconv(sd: SD, pre: str, x: Tensor, stride: int, padding: int) -> Tensor:
+    """DeconvBlock (:108-143): ConvTranspose2d + PReLU."""
+    y = F.conv_transpose2d(x, sd[pre + ".deconv.weight"], sd[pre + ".deconv.bias"], stride=stride, padding=padding)
+    return F.prelu(y, sd[pre + ".act.weight"])
+
+
+def _dbpn_up(sd: SD, pre: str, x: Tensor, s: int, p: int, dense: bool) -> Tensor:
+    """UpBlock / D_UpBlock (:190-205, :225-246): h0 = up(x); l0 = down(h0); h1 = up(l0 - x); h1 + h0."""
+    if dense:
+        x = _dbpn_conv(sd, pre + ".conv", x, 1, 0)
+    h0 = _dbpn_deconv(sd, pre + ".up_conv1", x, s, p)
+    l0 = _dbpn_conv(sd, pre + ".up_conv2", h0, s, p)
+    h1 = _dbpn_deconv(sd, pre + ".up_conv3", l0 - x, s, p)
+    return h1 + h0
+
+
+def _dbpn_down(sd: SD, pre: str, x: Tensor, s: int, p: int, dense: bool) -> Tensor:
+    """DownBlock / D_DownBlock (:272-287, :306-327): l0 = down(x); h0 = up(l0); l1 = down(h0 - x); l1 + l0."""
+    if dense:
+        x = _dbpn_conv(sd, pre + ".conv", x, 1, 0)
+    l0 = _dbpn_conv(sd, pre + ".down_conv1", x, s, p)
+    h0 = _dbpn_deconv(sd, pre + ".down_conv2", l0, s, p)
+    l1 = _dbpn_conv(sd, pre + ".down_conv3", h0 - x, s, p)
+    return l1 + l0
+
+
+def dbpn_forward(sd: SD, x: Tensor, upscale: int, num_stages: int = 3) -> Tensor:
+    """DBPN.forward (network_dbpn.py:532-577): the seven up / six down units are applied num_stages times with the
+    SAME weights, the pass outputs are concatenated and reconstructed by a 3x3 conv."""
+    _, s, p = _DBPN_KSP[upscale]
+    x = _dbpn_conv(sd, "feat0", x, 1, 1)
+    l = _dbpn_conv(sd, "feat1", x, 1, 0)
+    results = []
+    for _ in range(num_stages):
+        h1 = _dbpn_up(sd, "up1", l, s, p, False)
+        l1 = _dbpn_down(sd, "down1", h1, s, p, False)
+        h2 = _dbpn_up(sd, "up2", l1, s, p, False)
+        concat_h = torch.cat((h2, h1), 1)
+        l = _dbpn_down(sd, "down2", concat_h, s, p, True)
+        concat_l = torch.cat((l, l1), 1)
+        h = _dbpn_up(sd, "up3", concat_l, s, p, True)
+        for i in range(3, 7):
+            concat_h = torch.cat((h, concat_h), 1)
+            l = _dbpn_down(sd, f"down{i}", concat_h, s, p, True)
+            concat_l = torch.cat((l, concat_l), 1)
+            h = _dbpn_up(sd, f"up{i + 1}", concat_l, s, p, True)
+        results.append(h)
+    return _dbpn_conv(sd, "output_conv", torch.cat(results, 1), 1, 1, act=False)
+
+
+def dbpn_init_state_dict(upscale: int, in_chans: int = 1, base_filter: int = 64, feat: int = 256, num_stages: int = 3,
+                         seed: int = 0, bias_std: float = 0.0) -> SD:
+    """network_dbpn.py:445-530: kaiming-normal conv / deconv weights (std sqrt(2 / fan_in), fan_in = dim 1 x k x k --
+    for a ConvTranspose2d weight [Cin, Cout, k, k] torch's fan_in is Cout k k), zero biases, PReLU slopes 0.25.
+    bias_std / a jitter on the slopes (tests) make every parameter's gradient path visible."""
+    k, s, p = _DBPN_KSP[upscale]
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+
+    def conv(pre, ci, co, kk, act=True):
+        sd[pre + ".conv.weight"] = torch.randn(co, ci, kk, kk, generator=g) * math.sqrt(2.0 / (ci * kk * kk))
+        sd[pre + ".conv.bias"] = torch.randn(co, generator=g) * bias_std
+        if act:
+            sd[pre + ".act.weight"] = torch.full((1,), 0.25) + (torch.rand(1, generator=g) - 0.5) * (0.2 if bias_std else 0.0)
+
+    def deconv(pre, ci, co, kk):
+        sd[pre + ".deconv.weight"] = torch.randn(ci, co, kk, kk, generator=g) * math.sqrt(2.0 / (co * kk * kk))
+        sd[pre + ".deconv.bias"] = torch.randn(co, generator=g) * bias_std
+        sd[pre + ".act.weight"] = torch.full((1,), 0.25) + (torch.rand(1, generator=g) - 0.5) * (0.2 if bias_std else 0.0)
+
+    def up(pre, dense):
+        if dense:
+            conv(pre + ".conv", base_filter * dense, base_filter, 1)
+        deconv(pre + ".up_conv1", base_filter, base_filter, k)
+        conv(pre + ".up_conv2", base_filter, base_filter, k)
+        deconv(pre + ".up_conv3", base_filter, base_filter, k)
+
+    def down(pre, dense):
+        if dense:
+            conv(pre + ".conv", base_filter * dense, base_filter, 1)
+        conv(pre + ".down_conv1", base_filter, base_filter, k)
+        deconv(pre + ".down_conv2", base_filter, base_filter, k)
+        conv(pre + ".down_conv3", base_filter, base_filter, k)
+
+    conv("feat0", in_chans, feat, 3)
+    conv("feat1", feat, base_filter, 1)
+    up("up1", 0)
+    down("down1", 0)
+    up("up2", 0)
+    for i in range(2, 7):
+        down(f"down{i}", i)
+        up(f"up{i + 1}", i)
+    conv("output_conv", num_stages * base_filter, in_chans, 3, act=False)
+    return sd
+
+
+# ----------------------------------------------------------------------------
+# SRFBN (dlib/models/network_srfbn.py)
+# ----------------------------------------------------------------------------
+_SRFBN_KSP = {2: (6, 2, 2), 3: (7, 3, 2), 4: (8, 4, 2), 8: (12, 8, 2)}
+
+
+def srfbn_forward(sd: SD, x: Tensor, upscale: int, num_steps: int = 4, num_groups: int = 6) -> List[Tensor]:
+    """SRFBN.forward (network_srfbn.py:651-679) with FeedbackBlock.forward (:540-576): returns the predictions of all
+    num_steps passes (the last one is the network output; model_plain.py:202-232 averages the loss over all of them)."""
+    _, s, p = _SRFBN_KSP[upscale]
+
+    def cna(pre, v, stride=1, padding=0, transposed=False):
+        if transposed:
+            y = F.conv_transpose2d(v, sd[pre + ".0.weight"], sd[pre + ".0.bias"], stride=stride, padding=padding)
+        else:
+            y = F.conv2d(v, sd[pre + ".0.weight"], sd[pre + ".0.bias"], stride=stride, padding=padding)
+        return F.prelu(y, sd[pre + ".1.weight"])
+    inter = F.interpolate(x, scale_factor=upscale, mode="bilinear", align_corners=False)
+    x = cna("conv_in", x, 1, 1)
+    x = cna("feat_in", x)
+    hidden = x
+    outs = []
+    for _ in range(num_steps):
+        c = cna("block.compress_in", torch.cat((x, hidden), 1))
+        lr, hr = [c], []
+        for i in range(num_groups):
+            L = torch.cat(tuple(lr), 1)
+            if i > 0:
+                L = cna(f"block.uptranBlocks.{i - 1}", L)
+            Hh = cna(f"block.upBlocks.{i}", L, s, p, transposed=True)
+            hr.append(Hh)
+            Hc = torch.cat(tuple(hr), 1)
+            if i > 0:
+                Hc = cna(f"block.downtranBlocks.{i - 1}", Hc)
+            lr.append(cna(f"block.downBlocks.{i}", Hc, s, p))
+        hidden = cna("block.compress_out", torch.cat(tuple(lr[1:]), 1))
+        h = cna("out", hidden, s, p, transposed=True)
+        outs.append(inter + F.conv2d(h, sd["conv_out.0.weight"], sd["conv_out.0.bias"], padding=1))
+    return outs
+
+
+def srfbn_init_state_dict(upscale: int, in_chans: int = 1, num_features: int = 64, num_groups: int = 6,
+                          seed: int = 0) -> SD:
+    """Seeded weights of the reference's layout (the reference keeps torch's default initialisation; fixtures load a
+    state_dict, never compare fresh initialisations): N(0, 1 / sqrt(fan_in)) weights, small biases, PReLU slopes near 0.2;
+    the frozen MeanShift convs as network_srfbn.py:123-133."""
+    k, _, _ = _SRFBN_KSP[upscale]
+    nf = num_features
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {"sub_mean.weight": torch.eye(3).view(3, 3, 1, 1), "sub_mean.bias": -255. * torch.tensor([0.4488, 0.4371, 0.4040])}
+
+    def blk(pre, ci, co, kk, transposed=False, act=True):
+        shape = (ci, co, kk, kk) if transposed else (co, ci, kk, kk)
+        fan = (co if transposed else ci) * kk * kk
+        sd[pre + ".0.weight"] = torch.randn(*shape, generator=g) / math.sqrt(fan)
+        sd[pre + ".0.bias"] = torch.randn(co, generator=g) * 0.05
+        if act:
+            sd[pre + ".1.weight"] = torch.full((1,), 0.2) + (torch.rand(1, generator=g) - 0.5) * 0.2
+
+    blk("conv_in", in_chans, 4 * nf, 3)
+    blk("feat_in", 4 * nf, nf, 1)
+    blk("block.compress_in", 2 * nf, nf, 1)
+    for i in range(num_groups):
+        blk(f"block.upBlocks.{i}", nf, nf, k, transposed=True)
+    for i in range(num_groups):
+        blk(f"block.downBlocks.{i}", nf, nf, k)
+    for i in range(1, num_groups):
+        blk(f"block.uptranBlocks.{i - 1}", nf * (i + 1), nf, 1)
+    for i in range(1, num_groups):
+        blk(f"block.downtranBlocks.{i - 1}", nf * (i + 1), nf, 1)
+    blk("block.compress_out", num_groups * nf, nf, 1)
+    blk("out", nf, nf, k, transposed=True)
+    blk("conv_out", nf, in_chans, 3, act=False)
+    sd["add_mean.weight"] = torch.eye(3).view(3, 3, 1, 1)
+    sd["add_mean.bias"] = 255. * torch.tensor([0.4488, 0.4371, 0.4040])
+    return sd
+
+
+# ----------------------------------------------------------------------------
+# ProSR (dlib/models/network_prosr.py), residual-dense-block form
+# ----------------------------------------------------------------------------
+def prosr_config(upscale=8, in_chans=1, num_init_features=160, bn_size=4, growth_rate=40, ps_woReLU=False,
+                 level_config=None, level_compression=-1, res_factor=0.2, max_num_feature=312) -> dict:
+    if level_config is None:        # utils_init_default_args.py: hard-coded per scale
+        level_config = {2: [[8] * 9], 4: [[8] * 9, [8] * 3], 8: [[8] * 9, [8] * 3, [8]]}[upscale]
+    return dict(upscale=upscale, in_chans=in_chans, num_init_features=num_init_features, bn_size=bn_size,
+                growth_rate=growth_rate, ps_woReLU=ps_woReLU, level_config=level_config,
+                level_compression=level_compression, res_factor=res_factor, max_num_feature=max_num_feature)
+
+
+def _rconv(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """Conv2d of network_prosr.py:38-86: ReflectionPad2d(1) + 3x3 conv."""
+    return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), sd[pre + ".conv.1.weight"], sd[pre + ".conv.1.bias"])
+
+
+def prosr_forward(sd: SD, x: Tensor, cfg: dict) -> List[Tensor]:
+    """ProSR.forward (network_prosr.py:383-433) at the largest scale, no blending: the predictions of every pyramid level
+    (the last one is the output; the others are intermediate_outs)."""
+    n = int(math.log2(cfg["upscale"]))
+    feats = _rconv(sd, f"init_conv_{n}", x)
+    nf = cfg["num_init_features"]
+    outs = []
+    for i in range(n):
+        pre = f"pyramid_residual_{i + 1}"
+        v = feats
+        if i != 0:
+            v = F.conv2d(v, sd[f"{pre}.compression_{i}.conv1.weight"])
+            nf = v.shape[1]
+        for b, nl in enumerate(cfg["level_config"][i]):
+            bp = f"{pre}.residual_denseblock_{b + 1}"
+            d = v
+            for l in range(nl):
+                lp = f"{bp}.dense_block.denselayer{l + 1}"
+                a = F.relu(F.conv2d(d, sd[lp + ".conv_1.weight"], sd[lp + ".conv_1.bias"]))
+                d = torch.cat([d, _rconv(sd, lp + ".conv_2", a)], 1)
+            v = cfg["res_factor"] * F.conv2d(d, sd[bp + ".comp.conv1.weight"]) + v
+        if nf > cfg["max_num_feature"]:
+            v = F.conv2d(v, sd[f"{pre}.final_conv.final_comp.conv1.weight"])
+            nf = cfg["max_num_feature"]
+        v = _rconv(sd, f"{pre}.final_conv.final_conv", v)
+        feats = v + feats
+        feats = F.pixel_shuffle(_rconv(sd, f"{pre}_residual_upsampler.m.0", feats), 2)
+        if not cfg["ps_woReLU"]:
+            feats = F.relu(feats)
+        z = _rconv(sd, f"reconst_{i + 1}.final_conv", feats)
+        sc = 2 ** (i + 1)
+        ident = torch.clamp(F.interpolate(x, size=(sc * x.shape[2], sc * x.shape[3]), mode="bicubic",
+                                          align_corners=False), 0.0, 1.0)
+        outs.append(z + ident)
+    return outs
+
+
+def prosr_init_state_dict(cfg: dict, seed: int = 0, bias_std: float = 0.0) -> SD:
+    """Seeded weights in the reference's state_dict layout and ORDER (N(0, 1 / sqrt(fan_in)); biases zero as init_weights
+    leaves them, or small for tests)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+
+    def conv(pre, ci, co, k, bias=True):
+        sd[pre + ".weight"] = torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k)
+        if bias:
+            sd[pre + ".bias"] = torch.randn(co, generator=g) * bias_std
+
+    n = int(math.log2(cfg["upscale"]))
+    nf0 = cfg["num_init_features"]
+    for s in range(1, n + 1):
+        conv(f"init_conv_{s}.conv.1", cfg["in_chans"], nf0, 3)
+    nf = nf0
+    gr, bs = cfg["growth_rate"], cfg["bn_size"]
+    for i in range(n):
+        pre = f"pyramid_residual_{i + 1}"
+        if i != 0:
+            out_planes = nf0 if cfg["level_compression"] <= 0 else int(cfg["level_compression"] * nf)
+            conv(f"{pre}.compression_{i}.conv1", nf, out_planes, 1, bias=False)
+            nf = out_planes
+        for b, nl in enumerate(cfg["level_config"][i]):
+            bp = f"{pre}.residual_denseblock_{b + 1}"
+            for l in range(nl):
+                lp = f"{bp}.dense_block.denselayer{l + 1}"
+                conv(lp + ".conv_1", nf + l * gr, bs * gr, 1)
+                conv(lp + ".conv_2.conv.1", bs * gr, gr, 3)
+            conv(bp + ".comp.conv1", nf + nl * gr, nf, 1, bias=False)
+        if nf > cfg["max_num_feature"]:
+            conv(f"{pre}.final_conv.final_comp.conv1", nf, cfg["max_num_feature"], 1, bias=False)
+            nf = cfg["max_num_feature"]
+        conv(f"{pre}.final_conv.final_conv.conv.1", nf, nf, 3)
+        conv(f"{pre}_residual_upsampler.m.0.conv.1", nf, 4 * nf, 3)
+        conv(f"reconst_{i + 1}.final_conv.conv.1", nf, cfg["in_chans"], 3)
+    return sd
+
+
+# ----------------------------------------------------------------------------
 # MSLapSRN (dlib/models/network_mslapsr.py)
 # ----------------------------------------------------------------------------
 def mslapsrn_forward(sd: SD, x: Tensor, upscale: int) -> Tuple[Tensor, List[Tensor]]:

@@ -44,6 +44,27 @@ def define_G(args):
         return net(in_chans=opt_net[f'{nt}_in_chans'], upscale=opt_net[f'{nt}_upscale'],
                    num_memory_blocks=opt_net[f'{nt}_num_memory_blocks'],
                    num_residual_blocks=opt_net[f'{nt}_num_residual_blocks'])
+    if net_type == constants.DBPN:                  # select_network.py:139-147
+        from dlib.models.network_dbpn import DBPN as net
+        return net(upscale=opt_net[f'{nt}_upscale'], in_chans=opt_net[f'{nt}_in_chans'],
+                   base_filter=opt_net[f'{nt}_base_filter'], feat=opt_net[f'{nt}_feat'],
+                   num_stages=opt_net[f'{nt}_num_stages'])
+    if net_type == constants.SRFBN:                 # select_network.py:130-137
+        from dlib.models.network_srfbn import SRFBN as net
+        return net(upscale=opt_net[f'{nt}_upscale'], in_chans=opt_net[f'{nt}_in_chans'],
+                   num_features=opt_net[f'{nt}_num_features'], num_steps=opt_net[f'{nt}_num_steps'],
+                   num_groups=opt_net[f'{nt}_num_groups'])
+    if net_type == constants.PROSR:                 # select_network.py:110-128
+        from dlib.models.network_prosr import ProSR as net
+        upscale = opt_net[f'{nt}_upscale']
+        return net(upscale=upscale, in_chans=opt_net[f'{nt}_in_chans'],
+                   residual_denseblock=opt_net[f'{nt}_residual_denseblock'],
+                   num_init_features=opt_net[f'{nt}_num_init_features'], bn_size=opt_net[f'{nt}_bn_size'],
+                   growth_rate=opt_net[f'{nt}_growth_rate'], ps_woReLU=opt_net[f'{nt}_ps_woReLU'],
+                   level_config=opt_net[f'{nt}_level_config'][upscale],
+                   level_compression=opt_net[f'{nt}_level_compression'], res_factor=opt_net[f'{nt}_res_factor'],
+                   max_num_feature=opt_net[f'{nt}_max_num_feature'],
+                   block_compression=opt_net[f'{nt}_block_compression'])
     raise NotImplementedError(
         f"net_type {net_type!r}: only {constants.MODELS} run on libsrhip (SURVEY.md section 8f lists "
-        f"the remaining 9 reference networks as 'next')")
+        f"the remaining reference networks as 'next')")

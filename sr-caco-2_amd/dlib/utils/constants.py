@@ -10,7 +10,10 @@ DRRN = 'DRRN'  # https://ieeexplore.ieee.org/document/8099781 (reference constan
 SRCNN = 'SRCNN'  # https://arxiv.org/abs/1501.00092 (reference constants.py)
 MSLAPSR = 'MSLapSRN'  # https://arxiv.org/pdf/1710.01992.pdf (reference constants.py:47)
 MEMNET = 'MemNet'  # https://arxiv.org/pdf/1708.02209.pdf (reference constants.py:28)
-MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR, MEMNET]
+DBPN = 'DBPN'  # https://arxiv.org/pdf/1803.02735.pdf (reference constants.py:49)
+SRFBN = 'SRFBN'  # https://arxiv.org/pdf/1903.09814.pdf (reference constants.py:46)
+PROSR = 'ProSR'  # https://arxiv.org/pdf/1804.02900.pdf (reference constants.py:48)
+MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR, MEMNET, DBPN, SRFBN, PROSR]
 
 SWINIR_MTH = 'SWINIR'
 EDSR_LIIF_MTH = 'EDSR_LIIF'
@@ -19,8 +22,11 @@ DRRN_MTH = 'DRRN'
 SRCNN_MTH = 'SRCNN'
 MSLAPSR_MTH = 'MSLAPSR'
 MEMNET_MTH = 'MemNet'
+DBPN_MTH = 'DBPN'
+SRFBN_MTH = 'SRFBN'
+PROSR_MTH = 'PROSR'
 NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH, DRRN: DRRN_MTH, SRCNN: SRCNN_MTH,
-                  MSLAPSR: MSLAPSR_MTH, MEMNET: MEMNET_MTH}
+                  MSLAPSR: MSLAPSR_MTH, MEMNET: MEMNET_MTH, DBPN: DBPN_MTH, SRFBN: SRFBN_MTH, PROSR: PROSR_MTH}
 
 US_PIXEL_SHUFFLE = 'pixelshuffle'
 US_PIXEL_SHUFFLE_DIRECT = 'pixelshuffledirect'

@@ -31,6 +31,18 @@ def init_net_g(netG: dict, args: dict) -> dict:
     elif netG['net_type'] == constants.MEMNET:       # utils_init_default_args.py:220-229
         out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'],
                     f'{nt}_num_memory_blocks': 6, f'{nt}_num_residual_blocks': 6})
+    elif netG['net_type'] == constants.DBPN:         # utils_init_default_args.py:153-163
+        out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'],
+                    f'{nt}_base_filter': 64, f'{nt}_feat': 256, f'{nt}_num_stages': 3})
+    elif netG['net_type'] == constants.SRFBN:        # utils_init_default_args.py:104-112
+        out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'],
+                    f'{nt}_num_features': 64, f'{nt}_num_steps': 4, f'{nt}_num_groups': 6, f'{nt}_use_cl': True})
+    elif netG['net_type'] == constants.PROSR:        # utils_init_default_args.py:127-151 (level_config hard-coded per scale)
+        out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'],
+                    f'{nt}_residual_denseblock': True, f'{nt}_num_init_features': 160, f'{nt}_bn_size': 4,
+                    f'{nt}_growth_rate': 40, f'{nt}_ps_woReLU': False, f'{nt}_level_compression': -1,
+                    f'{nt}_res_factor': 0.2, f'{nt}_max_num_feature': 312, f'{nt}_block_compression': 0.4,
+                    f'{nt}_level_config': {2: [[8] * 9], 4: [[8] * 9, [8] * 3], 8: [[8] * 9, [8] * 3, [8]]}})
     else:
         raise NotImplementedError(netG['net_type'])
     out[f'{nt}_init_type'] = constants.INIT_W_DEFAULT

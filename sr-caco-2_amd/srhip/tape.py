@@ -1,0 +1,554 @@
+"""A small tape engine for the conv-family networks of the reference's 16-method sweep (DBPN, SRFBN,
+ProSR -- dlib/models/network_dbpn.py, network_srfbn.py, network_prosr.py).
+
+These nets are dense graphs (back-projection stages, feedback loops, dense blocks: concatenations, weight sharing
+across iterations) of a handful of operations that libsrhip already has kernels for.  Instead of a hand-sequenced
+engine per net (swinir_engine.py, edsr_engine.py ...), the network's forward is written ONCE as calls on a Tape; every
+call launches its libsrhip kernels and records a backward closure; Tape.backward replays the closures in reverse.
+No aten arithmetic: PyTorch supplies device memory, views and the index tensors that re-lay weights.
+
+How the reference's layers map onto the kernels:
+  * nn.Conv2d(k=3, s=1, p=1)                    -> the implicit-GEMM 3x3 conv (bf16x3 / fp16x2 planes from 64 channels on,
+                                                   exact-f32 MFMA below; 1-channel ends: small.hip)
+  * nn.Conv2d(k=1)                              -> the NT GEMM on the token matrix [B*H*W][C]
+  * nn.ConvTranspose2d(k=s+4, stride s, p=2)    -> conv3x3 C -> C*s*s with zero-padded sub-kernels + PixelShuffle(s):
+      out[y s + i][x s + j] = sum_{dy,dx} in[y + dy][x + dx] . Wt[:, :, i + 2 - dy s, j + 2 - dx s]
+  * nn.Conv2d(k=s+4, stride s, p=2)             -> PixelUnshuffle(s) + conv3x3 C*s*s -> C with zero-padded sub-kernels:
+      out[y][x] = sum_{dy,dx} unshuffled[y + dy][x + dx][(ci, i, j)] . W[:, ci, dy s + i + 2, dx s + j + 2]
+  * nn.PReLU() / ReLU / LeakyReLU, torch.cat, add / sub, nn.PixelShuffle, nn.ReflectionPad2d(1)
+Every tensor is NHWC.  Buffers are persistent and keyed by the position of the op on the tape, so a training step
+allocates nothing after the first one.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import call
+from .swinir_engine import _Bufs
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Var:
+    """A value on the tape: NHWC tensor `t` (1-channel images: [B, H, W]) and its gradient `g` (contiguous, same shape)."""
+    __slots__ = ("t", "g", "need", "idx")
+
+    def __init__(self, t, need=True, idx=-1):
+        self.t, self.g, self.need, self.idx = t, None, need, idx
+
+
+# --------------------------------------------------------------------------- weight re-layout maps (host, cached)
+_MAPS = {}
+
+
+def _deconv_map(s, k, p, device):
+    """ConvTranspose2d(k, stride s, padding p) as conv3x3 + PixelShuffle(s): for sub-pixel (i, j) and tap (dy, dx) the
+    source kernel element (ky, kx) = (i + p - dy s, j + p - dx s), or none.  Returns (index [s, s, 3, 3] into k*k,
+    valid [s, s, 3, 3])."""
+    key = ("deconv", s, k, p, str(device))
+    if key not in _MAPS:
+        idx = np.zeros((s, s, 3, 3), dtype=np.int64)
+        val = np.zeros((s, s, 3, 3), dtype=np.float32)
+        for i in range(s):
+            for j in range(s):
+                for dy in (-1, 0, 1):
+                    for dx in (-1, 0, 1):
+                        ky, kx = i + p - dy * s, j + p - dx * s
+                        if 0 <= ky < k and 0 <= kx < k:
+                            idx[i, j, dy + 1, dx + 1] = ky * k + kx
+                            val[i, j, dy + 1, dx + 1] = 1.0
+        assert val.sum() == k * k, "every kernel element must appear exactly once (k = s + 2 p)"
+        _MAPS[key] = (torch.from_numpy(idx).to(device), torch.from_numpy(val).to(device))
+    return _MAPS[key]
+
+
+def _down_map(s, k, p, device):
+    """Conv2d(k, stride s, padding p) as PixelUnshuffle(s) + conv3x3: (ky, kx) = (dy s + i + p, dx s + j + p)."""
+    key = ("down", s, k, p, str(device))
+    if key not in _MAPS:
+        idx = np.zeros((s, s, 3, 3), dtype=np.int64)
+        val = np.zeros((s, s, 3, 3), dtype=np.float32)
+        for i in range(s):
+            for j in range(s):
+                for dy in (-1, 0, 1):
+                    for dx in (-1, 0, 1):
+                        ky, kx = dy * s + i + p, dx * s + j + p
+                        if 0 <= ky < k and 0 <= kx < k:
+                            idx[i, j, dy + 1, dx + 1] = ky * k + kx
+                            val[i, j, dy + 1, dx + 1] = 1.0
+        assert val.sum() == k * k
+        _MAPS[key] = (torch.from_numpy(idx).to(device), torch.from_numpy(val).to(device))
+    return _MAPS[key]
+
+
+def expand_deconv(wt, s, p):
+    """ConvTranspose2d weight [Ci, Co, k, k] -> conv3x3 weight [Co*s*s, Ci, 3, 3] (PixelShuffle channel order)."""
+    Ci, Co, k, _ = wt.shape
+    idx, val = _deconv_map(s, k, p, wt.device)
+    g = wt.reshape(Ci, Co, k * k)[:, :, idx.reshape(-1)].reshape(Ci, Co, s, s, 3, 3) * val
+    return g.permute(1, 2, 3, 0, 4, 5).reshape(Co * s * s, Ci, 3, 3).contiguous()
+
+
+def collapse_deconv(dwe, Ci, Co, s, k, p):
+    """Gradient of expand_deconv: [Co*s*s, Ci, 3, 3] -> [Ci, Co, k, k] (every kernel element has exactly one image)."""
+    idx, val = _deconv_map(s, k, p, dwe.device)
+    g = dwe.reshape(Co, s, s, Ci, 3, 3).permute(3, 0, 1, 2, 4, 5).reshape(Ci, Co, -1)
+    out = torch.zeros(Ci, Co, k * k, device=dwe.device)
+    sel = val.reshape(-1) > 0
+    out[:, :, idx.reshape(-1)[sel]] = g[:, :, sel]
+    return out.reshape(Ci, Co, k, k)
+
+
+def expand_down(w, s, p):
+    """Conv2d(k, stride s) weight [Co, Ci, k, k] -> conv3x3 weight [Co, Ci*s*s, 3, 3] on the unshuffled image."""
+    Co, Ci, k, _ = w.shape
+    idx, val = _down_map(s, k, p, w.device)
+    g = w.reshape(Co, Ci, k * k)[:, :, idx.reshape(-1)].reshape(Co, Ci, s, s, 3, 3) * val
+    return g.reshape(Co, Ci * s * s, 3, 3).contiguous()
+
+
+def collapse_down(dwe, Co, Ci, s, k, p):
+    idx, val = _down_map(s, k, p, dwe.device)
+    g = dwe.reshape(Co, Ci, -1)
+    out = torch.zeros(Co, Ci, k * k, device=dwe.device)
+    sel = val.reshape(-1) > 0
+    out[:, :, idx.reshape(-1)[sel]] = g[:, :, sel]
+    return out.reshape(Co, Ci, k, k)
+
+
+# --------------------------------------------------------------------------- prepared weights
+class ConvW:
+    """Kernel-ready forms of one conv layer: `w3` the (possibly expanded) [Co, Ci, 3, 3] weight, its forward / data-
+    gradient packs (f32 [9, Co, Ci] / [9, Ci, Co], or Bx3 planes), or `w1` [Co, Ci] (+ transpose) of a 1x1 conv."""
+    __slots__ = ("kind", "s", "k", "p", "Co", "Ci", "w3", "wp", "wpt", "w1", "w1T", "bias", "use_planes")
+
+
+class WeightBank:
+    """Derived weights of every conv of a net, rebuilt after the parameters changed (TapeEngine.prepare)."""
+
+    def __init__(self):
+        self.d = {}
+        self.bufs = _Bufs()
+
+    def conv(self, key, mod_weight, bias, kind, s=1, k=3, p=1):
+        """kind: 'c3' | 'c1' | 'deconv' | 'down'."""
+        e = self.d.get(key)
+        if e is None:
+            e = self.d[key] = ConvW()
+            e.kind, e.s, e.k, e.p = kind, s, k, p
+        dev = mod_weight.device
+        w = mod_weight.data
+        if kind == "c1":
+            e.Co, e.Ci = w.shape[0], w.shape[1]
+            e.w1 = w.reshape(e.Co, e.Ci)
+            e.w1T = self.bufs.get(key + ".w1T", e.Ci, e.Co, device=dev)
+            ops.transpose(e.w1.contiguous(), e.w1T)
+            e.bias = None if bias is None else bias.data
+            e.use_planes = False
+            return e
+        if kind == "c3":
+            w3, b3 = w, (None if bias is None else bias.data)
+        elif kind == "deconv":
+            w3 = expand_deconv(w, s, p)
+            b3 = None if bias is None else bias.data.repeat_interleave(s * s).contiguous()
+        else:
+            w3 = expand_down(w, s, p)
+            b3 = None if bias is None else bias.data
+        e.w3, e.bias = w3, b3
+        e.Co, e.Ci = w3.shape[0], w3.shape[1]
+        e.use_planes = False
+        if e.Ci >= 4 and e.Co >= 4:
+            e.wp = self.bufs.get(key + ".wp", 9, e.Co, e.Ci, device=dev)
+            e.wpt = self.bufs.get(key + ".wpt", 9, e.Ci, e.Co, device=dev)
+            ops.pack_conv_weight(w3, e.wp, e.wpt)
+        return e
+
+
+# --------------------------------------------------------------------------- the tape
+class Tape:
+    def __init__(self, bufs, bank, save, device):
+        self.bufs, self.bank, self.save, self.dev = bufs, bank, save, device
+        self.n = 0
+        self.back = []          # backward closures, forward order
+        self.tag = "t" if save else "e"
+        self._gtmp = 0
+
+    # ---- buffers
+    def new(self, *shape, ring=None):
+        """Output buffer of the op at this tape position (training keeps every one; inference rotates `ring` buffers
+        per shape class so that a long net does not hold its whole activation set)."""
+        self.n += 1
+        if self.save or ring is None:
+            key = f"{self.tag}.{self.n}"
+        else:
+            self._ring = getattr(self, "_ring", {})
+            sk = tuple(shape)
+            i = self._ring.get(sk, 0)
+            self._ring[sk] = (i + 1) % ring
+            key = f"e.ring.{'x'.join(map(str, sk))}.{i}"
+        return self.bufs.get(key, *shape, device=self.dev)
+
+    def _gnew(self, v):
+        return self.bufs.get(f"g.{v.idx}", *v.t.shape, device=self.dev)
+
+    def _tmp(self, *shape):
+        self._gtmp += 1
+        return self.bufs.get(f"gtmp.{self._gtmp % 3}.{'x'.join(map(str, shape))}", *shape, device=self.dev)
+
+    def var(self, t, need=True):
+        self.n += 1
+        return Var(t, need, self.n)
+
+    def _out(self, t, need=True):
+        return Var(t, need, self.n)
+
+    def acc(self, v, producer):
+        """Add a gradient contribution to v: producer(out) writes it into a contiguous tensor of v's shape."""
+        if not v.need:
+            return
+        if v.g is None:
+            v.g = self._gnew(v)
+            producer(v.g)
+        else:
+            tmp = self._tmp(*v.t.shape)
+            producer(tmp)
+            ops.axpby(v.g, tmp, 1.0, 1.0)
+
+    # ---- parameter gradients (weight sharing: the first use overwrites, later uses add)
+    def begin_backward(self, grads):
+        self.grads, self._written = grads, set()
+
+    def gparam(self, name, producer, shape=None):
+        gt = self.grads[name]
+        if name not in self._written:
+            self._written.add(name)
+            producer(gt)
+        else:
+            tmp = self._tmp(*gt.shape)
+            producer(tmp)
+            ops.axpby(gt, tmp, 1.0, 1.0)
+
+    # ---- ops
+    def conv(self, x, key, names, act=None):
+        """x -> conv (bank entry `key`) [-> PixelShuffle / after PixelUnshuffle for the strided forms].
+        names = (weight parameter name, bias parameter name or None)."""
+        e = self.bank.d[key]
+        if e.kind == "down":
+            x = self.unshuffle(x, e.s)
+        B, H, W, Ci = x.t.shape
+        assert Ci == e.Ci, (key, x.t.shape, e.Ci)
+        T = B * H * W
+        if e.kind == "c1":
+            y = self.new(B, H, W, e.Co)
+            xin = x.t
+            ops.gemm_nt(xin.view(T, Ci) if xin.is_contiguous() else xin.as_strided((T, Ci), (xin.stride(2), 1)),
+                        e.w1, e.bias, out=y.view(T, e.Co))
+        else:
+            y = self.new(B, H, W, e.Co)
+            ops.conv3x3(x.t, e.wp, e.bias, e.Co, out=y)
+        out = self._out(y)
+        if self.save:
+            wname, bname = names
+
+            def bwd(x=x, out=out, e=e, wname=wname, bname=bname):
+                g = out.g
+                if g is None:
+                    return
+                B, H, W, Ci = x.t.shape
+                T = B * H * W
+                xin = x.t
+                if e.kind == "c1":
+                    x2 = xin.view(T, Ci) if xin.is_contiguous() else xin.as_strided((T, Ci), (xin.stride(2), 1))
+                    dW, db = self._tmp(e.Co, e.Ci), self._tmp(e.Co)
+                    ops.linear_wgrad(g.view(T, e.Co), x2, dW, db)
+                    self.gparam(wname, lambda o, dW=dW: o.view(e.Co, e.Ci).copy_(dW))
+                    if bname:
+                        self.gparam(bname, lambda o, db=db: o.copy_(db))
+                    self.acc(x, lambda o: ops.gemm_nt(g.view(T, e.Co), e.w1T, None, out=o.view(T, Ci)))
+                    return
+                dW, db = self._tmp(e.Co, e.Ci, 3, 3), self._tmp(e.Co)
+                ops.conv3x3_wgrad(g, xin, dW, db)
+                if e.kind == "c3":
+                    self.gparam(wname, lambda o, dW=dW: o.copy_(dW))
+                    if bname:
+                        self.gparam(bname, lambda o, db=db: o.copy_(db))
+                elif e.kind == "deconv":
+                    Co = e.Co // (e.s * e.s)
+                    self.gparam(wname, lambda o, dW=dW: o.copy_(collapse_deconv(dW, e.Ci, Co, e.s, e.k, e.p)))
+                    if bname:
+                        self.gparam(bname, lambda o, db=db: o.copy_(db.view(Co, e.s * e.s).sum(1)))
+                else:
+                    Cin = e.Ci // (e.s * e.s)
+                    self.gparam(wname, lambda o, dW=dW: o.copy_(collapse_down(dW, e.Co, Cin, e.s, e.k, e.p)))
+                    if bname:
+                        self.gparam(bname, lambda o, db=db: o.copy_(db))
+                self.acc(x, lambda o: ops.conv3x3(g, e.wpt, None, Ci, out=o))
+            self.back.append(bwd)
+        if e.kind == "deconv":
+            out = self.shuffle(out, e.s)
+        if act is not None:
+            out = act(out)
+        return out
+
+    def conv_in1(self, x3, weight, bias, names):
+        """first conv of a 1-channel image: x3 [B, H, W] -> [B, H, W, Co] (small.hip)."""
+        B, H, W = x3.shape
+        Co = weight.shape[0]
+        y = self.new(B, H, W, Co)
+        ops.conv3x3_cin1_fwd(x3, weight.data, None if bias is None else bias.data, Co, out=y)
+        out = self._out(y)
+        if self.save:
+            def bwd(out=out):
+                if out.g is None:
+                    return
+                dW, db = self._tmp(*weight.shape), self._tmp(Co)
+                ops.conv3x3_cin1_wgrad(x3, out.g, dW, db)
+                self.gparam(names[0], lambda o: o.copy_(dW))
+                if names[1]:
+                    self.gparam(names[1], lambda o: o.copy_(db))
+            self.back.append(bwd)
+        return out
+
+    def conv_out1(self, x, weight, bias, names):
+        """last conv to a 1-channel image: [B, H, W, Ci] -> Var of [B, H, W]."""
+        B, H, W, Ci = x.t.shape
+        y = self.new(B, H, W)
+        ops.conv3x3_cout1_fwd(x.t if x.t.is_contiguous() else x.t.contiguous(), weight.data,
+                              None if bias is None else bias.data, out=y)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out):
+                if out.g is None:
+                    return
+                dy = out.g
+                xin = x.t if x.t.is_contiguous() else x.t.contiguous()
+                dW = self._tmp(*weight.shape)
+                ops.conv3x3_cin1_wgrad(dy, xin, dW, None, flip=True)
+                self.gparam(names[0], lambda o: o.copy_(dW))
+                if names[1]:
+                    db = self._tmp(1)
+                    ops.sum_into(dy, db)
+                    self.gparam(names[1], lambda o: o.copy_(db))
+                self.acc(x, lambda o: ops.conv3x3_cin1_fwd(dy, weight.data, None, Ci, out=o, flip=True))
+            self.back.append(bwd)
+        return out
+
+    def prelu(self, x, alpha, name):
+        y = self.new(*x.t.shape)
+        xin = x.t if x.t.is_contiguous() else x.t.contiguous()
+        call("srhip_prelu_fwd", _p(xin), _p(alpha.data), _p(y), xin.numel(), _st())
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out, xin=xin):
+                if out.g is None:
+                    return
+                ws = ops.SCRATCH.get("prelu_ws", 4096, torch.float64, self.dev)
+                da = self._tmp(1)
+                dx = self._tmp(*x.t.shape)
+                call("srhip_prelu_bwd", _p(out.g), _p(xin), _p(alpha.data), _p(dx), _p(da), _p(ws), xin.numel(), 0, _st())
+                self.gparam(name, lambda o: o.copy_(da.view_as(o)))
+                self.acc(x, lambda o: o.copy_(dx))
+            self.back.append(bwd)
+        return out
+
+    def relu(self, x, slope=0.0):
+        """ReLU (slope 0) or LeakyReLU(slope): out of place (the input may feed other ops)."""
+        y = self.new(*x.t.shape)
+        y.copy_(x.t)
+        ops.leaky_relu_(y, slope)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out, y=y):
+                if out.g is None:
+                    return
+
+                def prod(o):
+                    o.copy_(out.g)
+                    if slope == 0.0:
+                        ops.relu_mask(o, y)
+                    else:
+                        ops.leaky_relu_mask(o, y, slope)
+                self.acc(x, prod)
+            self.back.append(bwd)
+        return out
+
+    def axpby(self, x, y, a=1.0, b=1.0):
+        """a x + b y (torch.add / sub, residual connections)."""
+        z = self.new(*x.t.shape)
+        z.copy_(x.t)
+        if a != 1.0:
+            ops.axpby(z, z, a, 0.0)
+        ops.axpby(z, y.t if y.t.is_contiguous() else y.t.contiguous(), b, 1.0)
+        out = self._out(z)
+        if self.save:
+            def bwd(x=x, y=y, out=out):
+                if out.g is None:
+                    return
+                self.acc(x, lambda o: (o.copy_(out.g), ops.axpby(o, o, a, 0.0) if a != 1.0 else None))
+                self.acc(y, lambda o: (o.copy_(out.g), ops.axpby(o, o, b, 0.0) if b != 1.0 else None))
+            self.back.append(bwd)
+        return out
+
+    def add_const(self, x, c):
+        """x + c for a tensor c that takes no gradient (the interpolated input of SRFBN)."""
+        z = self.new(*x.t.shape)
+        z.copy_(x.t)
+        ops.axpby(z, c, 1.0, 1.0)
+        out = self._out(z)
+        if self.save:
+            def bwd(x=x, out=out):
+                if out.g is not None:
+                    self.acc(x, lambda o: o.copy_(out.g))
+            self.back.append(bwd)
+        return out
+
+    def cat(self, vs):
+        """torch.cat(vs, channel dim): one buffer, the parts copied in by the strided axpby."""
+        B, H, W = vs[0].t.shape[:3]
+        Cs = [v.t.shape[3] for v in vs]
+        z = self.new(B, H, W, sum(Cs))
+        T = B * H * W
+        o = 0
+        for v, c in zip(vs, Cs):
+            src = v.t
+            call("srhip_axpby2d", _p(z) + 4 * o, z.stride(2), _p(src), src.stride(2), T, c, 1.0, 0.0, _st())
+            o += c
+        out = self._out(z)
+        if self.save:
+            def bwd(vs=vs, out=out):
+                if out.g is None:
+                    return
+                o = 0
+                for v, c in zip(vs, Cs):
+                    def prod(dst, o=o, c=c):
+                        call("srhip_axpby2d", _p(dst), dst.stride(2), _p(out.g) + 4 * o, out.g.stride(2), T, c, 1.0, 0.0, _st())
+                    self.acc(v, prod)
+                    o += c
+            self.back.append(bwd)
+        return out
+
+    def shuffle(self, x, r):
+        B, h, w, C = x.t.shape
+        y = self.new(B, h * r, w * r, C // (r * r))
+        ops.pixel_shuffle(x.t, r, nhwc_out=True, out=y)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out):
+                if out.g is not None:
+                    self.acc(x, lambda o: ops.pixel_shuffle(out.g, r, nhwc_out=True, inverse=True, out=o))
+            self.back.append(bwd)
+        return out
+
+    def unshuffle(self, x, r):
+        B, Hh, Ww, C = x.t.shape
+        y = self.new(B, Hh // r, Ww // r, C * r * r)
+        xin = x.t if x.t.is_contiguous() else x.t.contiguous()
+        ops.pixel_shuffle(xin, r, nhwc_out=True, inverse=True, out=y)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out):
+                if out.g is not None:
+                    self.acc(x, lambda o: ops.pixel_shuffle(out.g, r, nhwc_out=True, out=o))
+            self.back.append(bwd)
+        return out
+
+    def pad_reflect(self, x):
+        B, H, W, C = x.t.shape
+        y = self.new(B, H + 2, W + 2, C)
+        xin = x.t if x.t.is_contiguous() else x.t.contiguous()
+        call("srhip_pad_reflect1", _p(xin), _p(y), B, H, W, C, 0, _st())
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out):
+                if out.g is not None:
+                    self.acc(x, lambda o: call("srhip_pad_reflect1", _p(out.g), _p(o), B, H, W, C, 1, _st()))
+            self.back.append(bwd)
+        return out
+
+    def crop(self, x):
+        B, Hp, Wp, C = x.t.shape
+        H, W = Hp - 2, Wp - 2
+        y = self.new(B, H, W, C)
+        call("srhip_crop1", _p(x.t), _p(y), B, H, W, C, 0, _st())
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out):
+                if out.g is not None:
+                    self.acc(x, lambda o: call("srhip_crop1", _p(out.g), _p(o), B, H, W, C, 1, _st()))
+            self.back.append(bwd)
+        return out
+
+    def crop1c(self, x):
+        """crop 1 pixel per side of a 1-channel image [B, H+2, W+2] (the reflection-padded reconstruction conv): a view
+        copy, its adjoint a zero-bordered placement -- plumbing on 1-channel images, no arithmetic."""
+        B, Hp, Wp = x.t.shape
+        y = self.new(B, Hp - 2, Wp - 2)
+        y.copy_(x.t[:, 1:-1, 1:-1])
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out):
+                if out.g is None:
+                    return
+
+                def prod(o):
+                    o.zero_()
+                    o[:, 1:-1, 1:-1].copy_(out.g)
+                self.acc(x, prod)
+            self.back.append(bwd)
+        return out
+
+    def backward(self, out, dy, grads):
+        self.begin_backward(grads)
+        out.g = dy
+        for b in reversed(self.back):
+            b()
+        # a parameter the graph never reached keeps a zero gradient
+        for k, gt in grads.items():
+            if k not in self._written:
+                gt.zero_()
+
+
+class TapeEngine:
+    """Base of the engines written as a tape graph: subclasses implement bank_entries() (which convs exist, in which
+    form) and graph(tape, x3) -> output Var ([B, H, W] image)."""
+
+    def __init__(self, net):
+        self.net = net
+        self.bufs = _Bufs()
+        self.bank = WeightBank()
+        self.prepared = False
+        self.saved = None
+
+    def invalidate(self):
+        self.prepared = False
+
+    def bucket_prefixes(self):
+        return [[""]]           # one gradient bucket: every parameter
+
+    def prepare(self):
+        self.bank_entries()
+        self.prepared = True
+
+    def forward(self, x, dp=None, save=True):
+        """x [B, H, W] -> [B, 1, s H, s W]."""
+        if not self.prepared:
+            self.prepare()
+        tape = Tape(self.bufs, self.bank, save, x.device)
+        out = self.graph(tape, x)
+        if save:
+            self.saved = (tape, out)
+        B, H, W = out.t.shape
+        return out.t.view(B, 1, H, W)
+
+    def backward(self, dy, grads, need_dx=False, on_layer_done=None, grads_zeroed=False):
+        assert self.saved is not None, "backward() without a saved forward"
+        assert not need_dx, "tape engines: no gradient with respect to the input image"
+        tape, out = self.saved
+        tape.backward(out, dy.reshape(out.t.shape).contiguous(), grads)
+        return None

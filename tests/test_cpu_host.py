@@ -120,6 +120,33 @@ def test_registry_and_factories():
     assert constants.NETTYPE_METHOD[constants.SWINIR] == 'SWINIR'
 
 
+def test_tape_net_mirrors_have_the_reference_state_dict_layout():
+    """DBPN / SRFBN mirrors: the registry's default nets carry the reference's state_dict keys (SRFBN: in the
+    reference's ORDER, frozen MeanShift convs included) and the re-layout maps of the strided / transposed convs are exact."""
+    import torch.nn.functional as F
+    from dlib.models.network_dbpn import DBPN
+    from dlib.models.network_srfbn import SRFBN
+    from srhip import tape as T
+    gd = np.load(os.path.join(ROOT, "tests", "golden", "g28_dbpn.npz"))
+    gs = np.load(os.path.join(ROOT, "tests", "golden", "g29_srfbn.npz"))
+    assert sorted(DBPN(upscale=4, in_chans=1).state_dict().keys()) == sorted(str(k) for k in gd["state_dict_keys_default"])
+    assert list(SRFBN(upscale=4, in_chans=1).state_dict().keys()) == [str(k) for k in gs["state_dict_keys_default"]]
+    with pytest.raises(NotImplementedError):
+        DBPN(upscale=4, in_chans=3)
+    torch.manual_seed(0)
+    for s, k in ((2, 6), (3, 7), (4, 8), (8, 12)):
+        wt, b, x = torch.randn(3, 5, k, k), torch.randn(5), torch.randn(2, 3, 5, 6)
+        ref = F.conv_transpose2d(x, wt, b, stride=s, padding=2)
+        y = F.pixel_shuffle(F.conv2d(x, T.expand_deconv(wt, s, 2), b.repeat_interleave(s * s), padding=1), s)
+        assert (ref - y).abs().max() < 1e-4
+        w, xh = torch.randn(5, 3, k, k), torch.randn(2, 3, 5 * s, 6 * s)
+        ref = F.conv2d(xh, w, b, stride=s, padding=2)
+        y = F.conv2d(F.pixel_unshuffle(xh, s), T.expand_down(w, s, 2), b, padding=1)
+        assert (ref - y).abs().max() < 2e-4
+        d = torch.randn(5 * s * s, 3, 3, 3)          # collapse_* is the adjoint of expand_*
+        assert abs(((T.expand_deconv(wt, s, 2) * d).sum() - (wt * T.collapse_deconv(d, 3, 5, s, k, 2)).sum()).item()) < 1e-3
+
+
 def test_flat_params_and_lr_rules():
     from srhip.train import FlatParams, Optimizer
     from dlib.learning.lr_scheduler import MyStepLR

@@ -1,0 +1,209 @@
+"""DBPN and SRFBN on libsrhip (dlib.models.network_dbpn / network_srfbn: tape graphs over the libsrhip kernels,
+srhip/tape.py) against the fixtures generated from the reference classes (g28_dbpn.npz, g29_srfbn.npz: outputs and
+the gradient of every parameter) and against the oracle at the registry's default widths."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import sr_oracle as O  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# tiny fixtures (2 x 1 x 6 x 5 inputs): a PReLU decision that flips under f32 rounding moves the entries it feeds by ~1 /
+# pixels of their size, so tensors are gated by their relative L2 error and their |gradient| sums, entries at 5e-5 of the
+# tensor's largest one where no decision sits at the edge (see tests/test_gpu_mslapsrn.py for the same argument)
+L2_GATE = 1e-4
+
+
+def load(name):
+    z = np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiu" else z[k]) for k in z.files}
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def check_grads(named_grads, g):
+    names = [str(n) for n in g["grad_names"]]
+    sums = g["grad_sums"].numpy()
+    assert [k for k, _ in named_grads] == names
+    for i, (k, gk) in enumerate(named_grads):
+        gk = gk.double().cpu()
+        if gk.numel() == 1:
+            # a PReLU slope's gradient is ONE sum of signed terms over a whole feature map: it may cancel to 1e-6 of its
+            # terms, so it is held to an absolute error (1e-4 relative where it does not cancel)
+            assert abs(gk.item() - sums[i][0]) <= max(1e-4 * abs(sums[i][0]), 5e-7), (k, gk.item(), sums[i][0])
+            continue
+        if "grad/" + k in g:
+            ref = g["grad/" + k].double()
+            assert ((gk - ref).norm() / ref.norm().clamp_min(1e-30)).item() <= L2_GATE, (k, ((gk - ref).norm() / ref.norm()).item())
+        assert abs(gk.abs().sum().item() - sums[i][1]) <= 1e-4 * max(sums[i][1], 1e-6), (k, gk.abs().sum().item(), sums[i][1])
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8])
+def test_dbpn_forward_and_gradients_vs_reference_golden(scale):
+    from dlib.models.network_dbpn import DBPN
+    allg = load("g28_dbpn")
+    g = {k[len(f"x{scale}/"):]: v for k, v in allg.items() if k.startswith(f"x{scale}/")}
+    cfg = dict(base_filter=16, feat=32, num_stages=2)
+    sd = O.dbpn_init_state_dict(scale, 1, seed=int(g["seed"]), bias_std=0.05, **cfg)
+    net = DBPN(upscale=scale, in_chans=1, **cfg)
+    assert sorted((k, tuple(v.shape)) for k, v in net.state_dict().items()) == sorted((k, tuple(v.shape)) for k, v in sd.items())
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    y = net(g["x"].cuda())
+    assert (y.detach().cpu() - g["y"]).abs().mean() <= 1e-5 and rel(y, g["y"]) < 1e-5
+    (y - g["target"].cuda()).abs().mean().backward()
+    check_grads([(k, p.grad) for k, p in net.named_parameters()], g)
+    net.eval()
+    with torch.no_grad():
+        assert rel(net(g["x"].cuda()), g["y"]) < 1e-5
+    # the registry's default net has the reference's state_dict keys
+    assert sorted(DBPN(upscale=2, in_chans=1).state_dict().keys()) == sorted(str(k) for k in allg["state_dict_keys_default"])
+
+
+@pytest.mark.parametrize("scale", [2, 3, 4, 8])
+def test_srfbn_all_passes_and_curriculum_gradients_vs_reference_golden(scale):
+    from dlib.models.network_srfbn import SRFBN
+    allg = load("g29_srfbn")
+    g = {k[len(f"x{scale}/"):]: v for k, v in allg.items() if k.startswith(f"x{scale}/")}
+    cfg = dict(num_features=16, num_steps=3, num_groups=3)
+    sd = O.srfbn_init_state_dict(scale, 1, cfg["num_features"], cfg["num_groups"], seed=int(g["seed"]))
+    net = SRFBN(upscale=scale, in_chans=1, **cfg)
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    x, tgt = g["x"].cuda(), g["target"].cuda()
+    eng = net.engine
+    y = eng.forward(x[:, 0].contiguous(), None, save=True)
+    outs = eng.all_outs
+    assert len(outs) == cfg["num_steps"] and outs[-1].data_ptr() == y.data_ptr()
+    for i, o in enumerate(outs):
+        assert rel(o, g[f"y{i}"]) < 1e-5, i
+    # the trainer's curriculum loss (model_plain.py:202-232): mean over the passes of mean |out - target|
+    n = tgt.numel() * len(outs)
+    ds = [torch.sign(o - tgt) / n for o in outs]
+    grads = {k: torch.full_like(p, float("nan")) for k, p in net.named_parameters() if p.requires_grad}
+    eng.backward(ds[-1], grads, d_inter=ds[:-1])
+    check_grads([(k, grads[k]) for k, p in net.named_parameters() if p.requires_grad], g)
+    # module path (forward only hands out the last prediction, the others through intermediate_outs)
+    net.eval()
+    with torch.no_grad():
+        ye = net(x)
+    assert rel(ye, g[f"y{cfg['num_steps'] - 1}"]) < 1e-5 and len(net.intermediate_outs) == cfg["num_steps"]
+    assert [str(k) for k in allg["state_dict_keys_default"]] == list(SRFBN(upscale=2, in_chans=1).state_dict().keys())
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8])
+def test_prosr_levels_and_multiscale_gradients_vs_reference_golden(scale):
+    from dlib.models.network_prosr import ProSR
+    allg = load("g30_prosr")
+    g = {k[len(f"x{scale}/"):]: v for k, v in allg.items() if k.startswith(f"x{scale}/")}
+    n = int(np.log2(scale))
+    cfg = O.prosr_config(upscale=scale, num_init_features=32, bn_size=2, growth_rate=8, level_config=[[3, 2], [2], [2]][:n])
+    sd = O.prosr_init_state_dict(cfg, seed=int(g["seed"]), bias_std=0.05)
+    net = ProSR(upscale=scale, in_chans=1, num_init_features=32, bn_size=2, growth_rate=8, level_config=cfg["level_config"])
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    x, tgt = g["x"].cuda(), g["target"].cuda()
+    eng = net.engine
+    y = eng.forward(x[:, 0].contiguous(), None, save=True)
+    outs = list(eng.intermediate_outs) + [y]
+    assert len(outs) == n
+    for i, o in enumerate(outs):
+        assert rel(o, g[f"y{i}"]) < 1e-5, i
+    # the trainer's multi-scale loss (model_plain.py:236-275): gradients of (sum of L1 against the resized target) / levels
+    leaves = [o.detach().clone().requires_grad_(True) for o in outs]
+    O.mslapsrn_loss(leaves[-1], leaves[:-1], tgt).backward()
+    grads = {k: torch.full_like(p, float("nan")) for k, p in net.named_parameters()}
+    eng.backward(leaves[-1].grad, grads, d_inter=[l.grad for l in leaves[:-1]])
+    used = [str(k) for k in g["grad_names"]]
+    check_grads([(k, grads[k]) for k in used], g)
+    for k in grads:                 # init convs of the scales that were not requested: zero gradient
+        if k not in used:
+            assert k.startswith("init_conv_") and float(grads[k].abs().max()) == 0.0, k
+    net.eval()
+    with torch.no_grad():
+        ye = net(x)
+    assert rel(ye, g[f"y{n - 1}"]) < 1e-5 and len(net.intermediate_outs) == n - 1
+    for sc in (2, 4, 8):
+        assert list(ProSR(upscale=sc, in_chans=1, level_config=O.prosr_config(upscale=sc)["level_config"]).state_dict().keys()) \
+            == [str(k) for k in allg[f"state_dict_keys_default_x{sc}"]]
+
+
+@pytest.mark.parametrize("slopes", ["identity", "trained"])
+@pytest.mark.parametrize("net_type,scale", [("DBPN", 4), ("SRFBN", 4), ("DBPN", 8), ("SRFBN", 2)])
+def test_default_width_train_step_vs_oracle(net_type, scale, slopes):
+    """The registry's default widths (DBPN: feat 256 / base 64 / 3 passes; SRFBN: 64 features, 6 groups, 4 passes) through
+    the fused training step on a 16 x 16 patch: loss and every gradient against the oracle run in float64 (a PReLU slope's
+    gradient is one cancelling sum over whole feature maps: the fp32 oracle itself is 1e-3 off on it)."""
+    from srhip.train import TrainStep, Optimizer
+    torch.manual_seed(3)
+    x = torch.rand(2, 1, 16, 16)
+    tgt = torch.rand(2, 1, 16 * scale, 16 * scale)
+    if net_type == "DBPN":
+        from dlib.models.network_dbpn import DBPN
+        sd = O.dbpn_init_state_dict(scale, 1, seed=11, bias_std=0.02)
+        net = DBPN(upscale=scale, in_chans=1)
+        fwd = lambda s: [O.dbpn_forward(s, x, scale, 3)]
+    else:
+        from dlib.models.network_srfbn import SRFBN
+        sd = O.srfbn_init_state_dict(scale, 1, seed=12)
+        net = SRFBN(upscale=scale, in_chans=1)
+        fwd = lambda s: O.srfbn_forward(s, x, scale, 4, 6)
+    # A PReLU whose input sits within fp32 rounding of 0 takes the other slope in one of two fp32 computations; the output
+    # is continuous there but the gradient through that pixel jumps by (1 - a), i.e. one pixel enters or leaves the weight
+    # gradients upstream (measured here: single entries 4e-4 .. 8e-4 of the tensor's largest one at the default widths,
+    # identically with the exact-f32 kernels, SRHIP_MM=f32 -- the same effect tests/test_gpu_fullsize.py documents for
+    # EDSR's ReLUs).  So the entry-wise gate runs with all slopes = 1 (no jump: every conv / transposed / strided conv /
+    # concatenation / weight-sharing path at full width, 5e-5), and the trained-like slopes are held tensor-wise.
+    if slopes == "identity":
+        for k in sd:
+            if k.endswith("act.weight") or (k.endswith(".1.weight") and sd[k].numel() == 1):
+                sd[k] = torch.ones(1)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=0.0, momentum=0.0, nesterov=False, wd=0.0)        # lr 0: the gradients stay readable
+    ts.step(x.cuda(), tgt.cuda())
+    # the same step through the oracle in fp32: its own distance from the float64 run is the yardstick (deep recurrences:
+    # SRFBN back-propagates through 4 passes x 6 groups; a PReLU decision within rounding of 0 flips in either fp32 run)
+    sd32 = {k: (v.clone().requires_grad_(True) if not k.startswith(("sub_mean", "add_mean")) else v.clone()) for k, v in sd.items()}
+    o32 = (lambda s_: [O.dbpn_forward(s_, x, scale, 3)])(sd32) if net_type == "DBPN" else O.srfbn_forward(sd32, x, scale, 4, 6)
+    (sum((o - tgt).abs().mean() for o in o32) / len(o32)).backward()
+    sdo = {k: (v.double().requires_grad_(True) if not k.startswith(("sub_mean", "add_mean")) else v.double()) for k, v in sd.items()}
+    x, tgt = x.double(), tgt.double()
+    outs = fwd(sdo)
+    loss = sum((o - tgt).abs().mean() for o in outs) / len(outs)
+    loss.backward()
+    assert abs(ts.loss_values()[0] - loss.item()) <= 2e-6 * max(1.0, abs(loss.item()))
+    worst = 0.0
+    # a PReLU slope's gradient is one signed sum over whole feature maps that cancels to a small remainder: it is held to
+    # an error relative to the LARGEST slope gradient of the net (what the terms of such a sum are scaled like)
+    smax = max([abs(sdo[k].grad.item()) for k in ts.fp.names if sdo[k].grad.numel() == 1] + [0.0])
+    for k in ts.fp.names:
+        ref = sdo[k].grad
+        got = ts.fp.gviews[k].double().cpu()
+        if ref.numel() == 1:
+            assert abs(got.item() - ref.item()) <= 2e-4 * abs(ref.item()) + 1e-3 * smax, (k, got.item(), ref.item(), smax)
+            continue
+        # the library's gradient gate: entries relative to the tensor's largest one (2e-5 on the hand-sequenced engines;
+        # these graphs are 4 passes deep through shared weights, and from 64 channels on their weight gradients run on the
+        # split-MFMA TN kernels whose precision is relative to an operand COLUMN's maximum)
+        e = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+        e32 = ((sd32[k].grad.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+        el2 = ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+        worst = max(worst, e)
+        worst_l2 = max(locals().get("worst_l2", 0.0), el2)
+        if slopes == "identity":
+            assert e <= max(3.0 * e32, 5e-5), (k, e, e32, el2)
+        else:
+            assert el2 <= 2e-3, (k, e, e32, el2)
+    print(f"{net_type} x{scale}: loss {loss.item():.6f}, worst gradient error: {worst:.2e} of the tensor's largest entry, "
+          f"{worst_l2:.2e} relative L2")

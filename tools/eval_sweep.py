@@ -21,7 +21,7 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 NETS = [("swinir", "SWINIR"), ("EDSR_LIIF", "EDSR_LIIF"), ("VDSR", "VDSR"), ("DRRN", "DRRN"), ("SRCNN", "SRCNN"),
-        ("MSLapSRN", "MSLAPSR"), ("MemNet", "MemNet")]
+        ("MSLapSRN", "MSLAPSR"), ("MemNet", "MemNet"), ("DBPN", "DBPN"), ("SRFBN", "SRFBN"), ("ProSR", "PROSR")]
 
 
 def main():
@@ -66,7 +66,7 @@ def main():
                 ms = sorted(groups)[2]
                 out = model.E
                 assert tuple(out.shape[-2:]) == (512, 512) and torch.isfinite(out).all()
-                amp_used = bool(amp and getattr(model.netG, "amp", False) and net_type not in ("VDSR", "DRRN", "MSLapSRN", "MemNet"))
+                amp_used = bool(amp and getattr(model.netG, "amp", False) and net_type in ("swinir", "EDSR_LIIF", "SRCNN"))
                 rows.append({"net_type": net_type, "scale": scale, "amp_flag": amp, "reduced_precision_kernels": amp_used,
                              "batch": a.batch, "ms_per_batch": ms, "patches_per_s": a.batch / ms * 1e3})
                 print(json.dumps(rows[-1]), flush=True)
