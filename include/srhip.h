@@ -271,6 +271,15 @@ int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, con
                         const float* gamma, float* out, float* dgamma, float* dbeta, float* workspace, long M,
                         int C, void* stream);
 
+/* ---- cv2.resize(INTER_CUBIC) on 1-channel images (resize.hip): the 'l_to_h_img' tensors of the dataset --------- */
+/* dlib/datasets/dataset_dpsr.py:659-683 (_resize_low_to_scale), consumed by the SRCNN-style nets (model_plain.py:184-
+ * 195).  src / dst: B images [H][W] -> [Ho][Wo], uint8 (is_u8: OpenCV's fixed-point path) or float32.  A restatement of
+ * OpenCV's published algorithm (cv2 is absent here): PARITY UNPINNED against cv2; bit-exact / 1e-6 against
+ * oracle/cv2_cubic.py.  srhip_u8_to_unit: uint2single (utils_image.py:322-323); srhip_clip01: np.clip(x, 0, 1). */
+int srhip_resize_cubic(const void* src, void* dst, int is_u8, int B, int H, int W, int Ho, int Wo, void* stream);
+int srhip_u8_to_unit(const unsigned char* src, float* dst, long n, void* stream);
+int srhip_clip01(float* x, long n, void* stream);
+
 /* ---- helpers of the generic conv-net engine (tape_ops.hip; DBPN / SRFBN / ProSR: SURVEY f1) ---------------- */
 /* nn.PReLU(num_parameters = 1) (dlib/models/network_dbpn.py:85-86, network_srfbn.py:38-46): y = x > 0 ? x : a x with
  * the slope read from device memory; backward dx = g (x > 0 ? 1 : a) (dx may alias g) and dalpha (+)= sum g min(x, 0)

@@ -1343,6 +1343,88 @@ def g_prosr():
     npz("g30_prosr", **out)
 
 
+def _import_ref_dataset():
+    import types
+    import matplotlib.style
+    matplotlib.style.use = lambda *a, **k: None
+    sk, skf = types.ModuleType("skimage"), types.ModuleType("skimage.filters")
+    skf.threshold_otsu = None
+    sk.filters = skf
+    sys.modules.setdefault("skimage", sk)
+    sys.modules.setdefault("skimage.filters", skf)
+    import dlib.datasets.dataset_dpsr as ref_ds
+    return ref_ds
+
+
+def g_lowres():
+    """The low-resolution side of DatasetDPSR items (dataset_dpsr.py:592-645,684-744,1037-1180): outputs of the
+    reference's own functions on seeded inputs -- the fixtures of sr-caco-2_amd/dlib/datasets/lowres.py."""
+    print("G31 dataset low-resolution side")
+    ref_ds = _import_ref_dataset()
+    DS = ref_ds.DatasetDPSR
+    rng = np.random.RandomState(31)
+    out = {}
+    hr = np.clip(np.round(np.kron(rng.rand(12, 10), np.ones((8, 8))) * 40 + rng.rand(96, 80) * 6), 0, 255).astype(np.uint8)[:, :, None]
+    out["hr"] = hr
+    for sc in (2, 4, 8):
+        lo = DS.interpolate_torch(hr, scale=1. / sc, mode="bicubic", min_v=0, max_v=255)
+        out[f"interp_x{sc}"] = lo
+        out[f"sim_x{sc}"] = DS.simulate_low_res(x=np.copy(lo), seed=3 + sc, th=7., sigma=6.)
+    # per-colour weights: _build_per_color_weight reads files; its arithmetic (:614-641) on in-memory tiles
+    tiles = [np.clip(np.round(rng.gamma(1.5, 8.0, size=(40, 36))), 0, 255).astype(np.uint8) for _ in range(3)]
+    full = 1.
+    for t in tiles:
+        full = ref_ds.unnormed_histogram(t, 256, range=(0, 255))[0] + full
+    full = 256 * full / float(full.sum())
+    w = 1. / full
+    w = w / w.sum()
+    w += 1e-8
+    w = (1. - 0.1) * (w - w.min()) / (w.max() - w.min()) + 0.1
+    out["ppiw_tiles"], out["ppiw_weights"] = np.stack(tiles), w.flatten()
+
+    class _Self:
+        per_color_weight = w.flatten()
+        args = type("A", (), {"color_min": 0, "color_max": 255})()
+    x = torch.from_numpy(tiles[0][None, :16, :16].copy())
+    out["ppiw_patch_u8"], out["ppiw_patch_w"] = x, DS._get_per_pixel_weight(_Self(), x=x)
+    # LR-only augmentations: seeded numpy stream, every branch taken at least once
+    base = (rng.rand(16, 16, 1).astype(np.float32))
+    for name, fn, kw in (("blur", ref_ds.np_blur, dict(prob=1.0, area=0.4, sigma=1.3)),
+                         ("dot", ref_ds.np_prod_binary_noise, dict(prob=1.0, area=0.5, p=0.3)),
+                         ("gaus", ref_ds.np_add_gaussian_noise, dict(prob=1.0, area=0.5, std=0.05))):
+        for seed in (0, 1, 2, 3, 4, 5, 6, 7):
+            np.random.seed(1000 + seed)
+            out[f"da_{name}_{seed}"] = fn(img=np.copy(base), **kw)
+    out["da_base"] = base
+    npz("g31_lowres", **out)
+
+
+def g_patch_sampler_edt():
+    """PatchSampler 'edt' and 'edt*roi' (dataset_dpsr.py:371-457): the probabilities handed to np.random.multinomial
+    (captured) and the seeded draws."""
+    print("G32 PatchSampler edt / edt*roi")
+    ref_ds = _import_ref_dataset()
+    rng = np.random.RandomState(19)
+    out = {}
+    for name, (h, w, P, th) in {"a": (40, 52, 16, 7), "b": (33, 29, 9, 120)}.items():
+        img = np.kron(rng.rand(h // 4 + 1, w // 4 + 1), np.ones((4, 4)))[:h, :w]
+        img = np.clip(np.round(img * (30 if name != "b" else 255)), 0, 255).astype(np.uint8)
+        out[f"{name}/img"], out[f"{name}/cfg"] = img, np.array([P, th])
+        for style in (ref_c.SAMPLE_EDT, ref_c.SAMPLE_EDTXROI):
+            ref = ref_ds.PatchSampler(style, P, 256, ref_c.TH_FIX, float(th))
+            seen = []
+            real = np.random.multinomial
+            np.random.multinomial = lambda n, pvals, size=None: (seen.append(np.array(pvals)), real(n, pvals, size))[1]
+            try:
+                np.random.seed(300 + h)
+                draws = np.array([ref(img, False)[:2] for _ in range(30)])
+            finally:
+                np.random.multinomial = real
+            tag = "edt" if style == ref_c.SAMPLE_EDT else "edtxroi"
+            out[f"{name}/{tag}_pvals"], out[f"{name}/{tag}_draws"], out[f"{name}/{tag}_seed"] = seen[0], draws, np.array(300 + h)
+    npz("g32_patch_sampler_edt", **out)
+
+
 def g_vdsr():
     print("G16 VDSR")
     from dlib.models.network_vdsr import VDSR as RefVDSR
@@ -1552,7 +1634,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_dbpn, g_srfbn, g_prosr, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

@@ -125,10 +125,13 @@ def imread_gray_uint8(path: str) -> np.ndarray:
 
 
 class EvalPairs:
-    """EVAL-phase items of DatasetDPSR for sets that ship true low-resolution tiles: per index the
-    dict the evaluation loop consumes (dataset_dpsr.py:981-1005) with l_im / h_im float32 CHW in
-    [0,1] = uint8 / 255 (utils_image.py:322-323,381-382).  The cv2-bicubic 'l_to_h_img' tensors
-    (consumed by SRCNN-style nets only, model_plain.py:184-195) are not produced."""
+    """EVAL-phase items of DatasetDPSR: per index the dict the evaluation loop consumes (dataset_dpsr.py:746-838,948-1005)
+    with l_im / h_im / l_to_h_img float32 CHW in [0,1] = uint8 / 255 (utils_image.py:322-323,381-382).
+
+    True low-resolution tiles are read; where a pair has none (or --use_interpolated_low) the LR input is synthesised as
+    the reference does for CACO-2 tiles (:776-804: bicubic down-scaling of the HR tile + seeded noise in the cells'
+    region; dlib/datasets/lowres.py).  'l_to_h_img' -- the LR image brought to the HR size by cv2.resize(INTER_CUBIC),
+    what the SRCNN-style nets consume (model_plain.py:184-195) -- comes from srhip_resize_cubic on the device."""
 
     def __init__(self, args, pairs_h: dict, pairs_l: dict):
         self.args, self.pairs_h, self.pairs_l = args, pairs_h, pairs_l
@@ -141,22 +144,44 @@ class EvalPairs:
     def __len__(self):
         return len(self.im_h_ids)
 
+    def low_res_u8(self, index: int, img_h: np.ndarray, h_path: str):
+        """(LR tile uint8 HWC, its path): the true tile, or the reference's synthesis (:776-804)."""
+        from dlib.datasets import lowres
+        h_id = self.im_h_ids[index]
+        l_id = self.pairs_h[h_id]['low_path_key']
+        l_path = self.pairs_l[l_id]['abs_path'] if (self.pairs_l and l_id in self.pairs_l) else ''
+        synth = (not os.path.isfile(l_path)) or bool(getattr(self.args, 'use_interpolated_low', False))
+        if not synth:
+            return imread_gray_uint8(l_path), l_path
+        if not lowres.is_caco2(h_path):
+            raise NotImplementedError(f'{h_id}: synthesised low-resolution inputs are built for CACO-2 tiles (dataset_dpsr.py:'
+                                      f'789-799; other sets go through utils_image.imresize_np, outside this build)')
+        cmin, cmax = getattr(self.args, 'color_min', 0), getattr(self.args, 'color_max', 255)
+        lo = lowres.interpolate_torch(img_h, 1. / self.sf, getattr(self.args, 'basic_interpolation', 'bicubic'), cmin, cmax)
+        lo = np.clip(lo, a_min=cmin, a_max=cmax)
+        lo = lowres.simulate_low_res(np.copy(lo), seed=index, th=float(getattr(self.args, 'inter_low_th', 7.)),
+                                     sigma=float(getattr(self.args, 'inter_low_sigma', 6.)))
+        return lo, h_path
+
     def __getitem__(self, index: int) -> dict:
         import torch
+        from dlib.datasets import lowres
         h_id = self.im_h_ids[index]
         l_id = self.pairs_h[h_id]['low_path_key']
         h_path = self.pairs_h[h_id]['abs_path']
-        l_path = self.pairs_l[l_id]['abs_path']
-        if l_id.startswith('None_') or not os.path.isfile(l_path):
-            raise NotImplementedError(f'{l_id}: synthesised low-resolution inputs (dataset_dpsr.py:713-744, '
-                                      f'cv2 / skimage) are outside this build; ship true LR tiles')
-        img_h = imread_gray_uint8(h_path)
-        hh, ww = img_h.shape[:2]
-        img_h = img_h[:hh - hh % self.sf, :ww - ww % self.sf]            # modcrop (utils_image.py:295-306)
-        img_l = imread_gray_uint8(l_path)
+        img_h_full = imread_gray_uint8(h_path)
+        img_l, l_path = self.low_res_u8(index, img_h_full, h_path)      # the synthesis sees the un-cropped tile (:752-760)
+        hh, ww = img_h_full.shape[:2]
+        img_h = img_h_full[:hh - hh % self.sf, :ww - ww % self.sf]            # modcrop (utils_image.py:295-306)
         to_t = lambda a: torch.from_numpy(np.ascontiguousarray(np.float32(a / 255.))).permute(2, 0, 1).float()
-        return {'l_im': to_t(img_l), 'l_id': l_id, 'l_path': l_path, 'h_im': to_t(img_h), 'h_id': h_id,
-                'h_path': h_path}
+        out = {'l_im': to_t(img_l), 'l_id': l_id, 'l_path': l_path, 'h_im': to_t(img_h), 'h_id': h_id, 'h_path': h_path}
+        if torch.cuda.is_available():
+            from srhip import ops
+            lu8 = torch.from_numpy(np.array(img_l[:, :, 0], copy=True))[None].cuda()
+            up = lowres.l_to_h(lu8, img_h.shape[:2])                     # cv2.resize(img_l, (W, H), INTER_CUBIC) (:813-821,836)
+            out['l_to_h_img'] = ops.u8_to_unit(up)                       # [1, H, W] float32 on the device
+            out['l_to_h_img_aug'] = out['l_to_h_img']
+        return out
 
 
 class EvalLoader:

@@ -155,11 +155,19 @@ def parse_input(argv=None):
 
 
 def synth_batch(batch, scale, h_size, device, seed):
-    """dataset_dpsr.py:685-710 on synthetic data: H uint8-quantised, L = clamp(bicubic_down(H))."""
+    """dataset_dpsr.py:685-710 on synthetic data: H uint8-quantised, L = clamp(bicubic_down(H)); 'l_to_h_img' = the LR
+    patch brought to the HR size by cv2.resize(INTER_CUBIC) and clipped (:905-906; srhip_resize_cubic), what the
+    SRCNN-style nets consume (model_plain.py:184-195)."""
     g = torch.Generator().manual_seed(seed)
     hr = (torch.rand(batch, 1, h_size, h_size, generator=g) * 255).round() / 255
     lr = F.interpolate(hr, scale_factor=1.0 / scale, mode='bicubic').clamp(0, 1)
-    return {'l_im': lr.to(device), 'h_im': hr.to(device)}
+    out = {'l_im': lr.to(device), 'h_im': hr.to(device)}
+    if torch.device(device).type == 'cuda':
+        from srhip import ops
+        up = ops.clip01_(ops.resize_cubic(out['l_im'][:, 0].contiguous(), (h_size, h_size)))
+        out['l_to_h_img'] = up[:, None]
+        out['l_to_h_img_aug'] = out['l_to_h_img']
+    return out
 
 
 def main(argv=None):

@@ -939,6 +939,33 @@ def patch_gather(tiles, ids, y0, x0, modes, P, out=None):
     return out
 
 
+def resize_cubic(src, size_hw, out=None):
+    """cv2.resize(src, (w, h), interpolation=cv2.INTER_CUBIC) on a batch of 1-channel images [B, H, W] (uint8 or float32)
+    -> [B, h, w] of the same dtype (resize.hip; dataset_dpsr.py:659-683)."""
+    if not src.is_cuda:
+        raise SrhipError("srhip ops need CUDA/HIP tensors (no CPU fallback exists)")
+    assert src.dim() == 3 and src.is_contiguous() and src.dtype in (torch.uint8, torch.float32), (src.shape, src.dtype)
+    B, H, W = src.shape
+    Ho, Wo = int(size_hw[0]), int(size_hw[1])
+    if out is None:
+        out = torch.empty(B, Ho, Wo, device=src.device, dtype=src.dtype)
+    call("srhip_resize_cubic", _p(src), _p(out), int(src.dtype == torch.uint8), B, H, W, Ho, Wo, _st())
+    return out
+
+
+def u8_to_unit(src, out=None):
+    """uint8 -> float32 / 255 (util.uint2single)."""
+    if out is None:
+        out = torch.empty(src.shape, device=src.device, dtype=torch.float32)
+    call("srhip_u8_to_unit", _p(src), _p(out), src.numel(), _st())
+    return out
+
+
+def clip01_(x):
+    call("srhip_clip01", _p(x), x.numel(), _st())
+    return x
+
+
 def im2col_c1(x, ksize, ldo, out=None):
     """x [B,H,W] -> patch matrix [B*H*W, ldo] of a ksize x ksize / pad ksize//2 convolution (zero padded)."""
     _chk(x, out)

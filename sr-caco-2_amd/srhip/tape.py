@@ -35,6 +35,15 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
+LIMIT = (1 << 29) - 1      # the kernels' 32-bit staging offsets: a tensor operand stays below 2^29 floats per call
+
+
+def _chunks(B, per_image):
+    """batch slices [b0, b1) whose largest operand (per_image floats per image) stays under LIMIT"""
+    nb = max(1, min(B, LIMIT // max(1, per_image)))
+    return [(b0, min(B, b0 + nb)) for b0 in range(0, B, nb)]
+
+
 class Var:
     """A value on the tape: NHWC tensor `t` (1-channel images: [B, H, W]) and its gradient `g` (contiguous, same shape)."""
     __slots__ = ("t", "g", "need", "idx")
@@ -180,19 +189,15 @@ class Tape:
         self._gtmp = 0
 
     # ---- buffers
-    def new(self, *shape, ring=None):
-        """Output buffer of the op at this tape position (training keeps every one; inference rotates `ring` buffers
-        per shape class so that a long net does not hold its whole activation set)."""
+    def new(self, *shape):
+        """Output buffer of the op at this tape position.  Training keeps every one (persistent, keyed by the position: a
+        step allocates nothing after the first one); inference takes a fresh tensor from torch's caching allocator, which
+        hands the memory back as soon as the value has no consumer left -- a dense 70-layer graph at 512 x 512 would
+        otherwise hold every activation it ever made."""
         self.n += 1
-        if self.save or ring is None:
-            key = f"{self.tag}.{self.n}"
-        else:
-            self._ring = getattr(self, "_ring", {})
-            sk = tuple(shape)
-            i = self._ring.get(sk, 0)
-            self._ring[sk] = (i + 1) % ring
-            key = f"e.ring.{'x'.join(map(str, sk))}.{i}"
-        return self.bufs.get(key, *shape, device=self.dev)
+        if not self.save:
+            return torch.empty(shape, device=self.dev)
+        return self.bufs.get(f"{self.tag}.{self.n}", *shape, device=self.dev)
 
     def _gnew(self, v):
         return self.bufs.get(f"g.{v.idx}", *v.t.shape, device=self.dev)
@@ -200,6 +205,9 @@ class Tape:
     def _tmp(self, *shape):
         self._gtmp += 1
         return self.bufs.get(f"gtmp.{self._gtmp % 3}.{'x'.join(map(str, shape))}", *shape, device=self.dev)
+
+    def _tmp2(self, *shape):
+        return self.bufs.get(f"gtmp2.{'x'.join(map(str, shape))}", *shape, device=self.dev)
 
     def var(self, t, need=True):
         self.n += 1
@@ -244,14 +252,14 @@ class Tape:
         B, H, W, Ci = x.t.shape
         assert Ci == e.Ci, (key, x.t.shape, e.Ci)
         T = B * H * W
-        if e.kind == "c1":
-            y = self.new(B, H, W, e.Co)
-            xin = x.t
-            ops.gemm_nt(xin.view(T, Ci) if xin.is_contiguous() else xin.as_strided((T, Ci), (xin.stride(2), 1)),
-                        e.w1, e.bias, out=y.view(T, e.Co))
-        else:
-            y = self.new(B, H, W, e.Co)
-            ops.conv3x3(x.t, e.wp, e.bias, e.Co, out=y)
+        y = self.new(B, H, W, e.Co)
+        xin = x.t if x.t.is_contiguous() else x.t.contiguous()
+        cks = _chunks(B, H * W * max(Ci, e.Co))
+        for b0, b1 in cks:
+            if e.kind == "c1":
+                ops.gemm_nt(xin[b0:b1].view(-1, Ci), e.w1, e.bias, out=y[b0:b1].view(-1, e.Co))
+            else:
+                ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1])
         out = self._out(y)
         if self.save:
             wname, bname = names
@@ -261,19 +269,29 @@ class Tape:
                 if g is None:
                     return
                 B, H, W, Ci = x.t.shape
-                T = B * H * W
-                xin = x.t
+                xin = x.t if x.t.is_contiguous() else x.t.contiguous()
+                cks = _chunks(B, H * W * max(Ci, e.Co))
+                wshape = (e.Co, e.Ci) if e.kind == "c1" else (e.Co, e.Ci, 3, 3)
+                dW, db = self._tmp(*wshape), self._tmp(e.Co)
+                for i, (b0, b1) in enumerate(cks):          # weight gradient: summed over the batch slices
+                    dWi, dbi = (dW, db) if i == 0 else (self._tmp2(*wshape), self._tmp2(e.Co))
+                    if e.kind == "c1":
+                        ops.linear_wgrad(g[b0:b1].view(-1, e.Co), xin[b0:b1].view(-1, Ci), dWi, dbi)
+                    else:
+                        ops.conv3x3_wgrad(g[b0:b1], xin[b0:b1], dWi, dbi)
+                    if i:
+                        ops.axpby(dW, dWi, 1.0, 1.0)
+                        ops.axpby(db, dbi, 1.0, 1.0)
                 if e.kind == "c1":
-                    x2 = xin.view(T, Ci) if xin.is_contiguous() else xin.as_strided((T, Ci), (xin.stride(2), 1))
-                    dW, db = self._tmp(e.Co, e.Ci), self._tmp(e.Co)
-                    ops.linear_wgrad(g.view(T, e.Co), x2, dW, db)
                     self.gparam(wname, lambda o, dW=dW: o.view(e.Co, e.Ci).copy_(dW))
                     if bname:
                         self.gparam(bname, lambda o, db=db: o.copy_(db))
-                    self.acc(x, lambda o: ops.gemm_nt(g.view(T, e.Co), e.w1T, None, out=o.view(T, Ci)))
+
+                    def dgrad1(o):
+                        for b0, b1 in cks:
+                            ops.gemm_nt(g[b0:b1].view(-1, e.Co), e.w1T, None, out=o[b0:b1].view(-1, Ci))
+                    self.acc(x, dgrad1)
                     return
-                dW, db = self._tmp(e.Co, e.Ci, 3, 3), self._tmp(e.Co)
-                ops.conv3x3_wgrad(g, xin, dW, db)
                 if e.kind == "c3":
                     self.gparam(wname, lambda o, dW=dW: o.copy_(dW))
                     if bname:
@@ -288,7 +306,11 @@ class Tape:
                     self.gparam(wname, lambda o, dW=dW: o.copy_(collapse_down(dW, e.Co, Cin, e.s, e.k, e.p)))
                     if bname:
                         self.gparam(bname, lambda o, db=db: o.copy_(db))
-                self.acc(x, lambda o: ops.conv3x3(g, e.wpt, None, Ci, out=o))
+
+                def dgrad3(o):
+                    for b0, b1 in cks:
+                        ops.conv3x3(g[b0:b1], e.wpt, None, Ci, out=o[b0:b1])
+                self.acc(x, dgrad3)
             self.back.append(bwd)
         if e.kind == "deconv":
             out = self.shuffle(out, e.s)

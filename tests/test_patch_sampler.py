@@ -46,10 +46,32 @@ def test_host_sampler_reproduces_reference_draws():
             r0, c0 = O.roi_origin_from_uniform(img, th, P, float(uu))
             i = r0 * (img.shape[1] - P) + c0
             assert (cdf[i - 1] if i else 0.0) - 1e-12 <= uu <= cdf[i] + 1e-12
-    with pytest.raises(NotImplementedError):
-        PatchSampler(SAMPLE_ROI, 8, 256, TH_AUTO, 0.)(g["a/img"], False)
-    with pytest.raises(NotImplementedError):
-        PatchSampler("edt", 8, 256, TH_FIX, 3.)
+
+
+def test_host_sampler_edt_styles_reproduce_reference_draws_and_otsu():
+    """'edt' / 'edt*roi' (dataset_dpsr.py:371-457): the probabilities equal the ones the reference handed to
+    np.random.multinomial (captured in g32) and the seeded draws are the reference's.  'automatic_threshold': Otsu's
+    threshold restated from skimage's published algorithm (skimage is not in this image: parity unpinned) separates a
+    bimodal image where it should."""
+    from dlib.datasets.lowres import otsu_threshold
+    from dlib.datasets.dataset_dpsr import PatchSampler, SAMPLE_ROI, TH_FIX, TH_AUTO
+    g = np.load(os.path.join(G, "g32_patch_sampler_edt.npz"))
+    for name in ("a", "b"):
+        img = g[f"{name}/img"]
+        P, th = (int(v) for v in g[f"{name}/cfg"])
+        for style, tag in (("edt", "edt"), ("edt*roi", "edtxroi")):
+            s = PatchSampler(style, P, 256, TH_FIX, float(th))
+            pm = s.origin_probabilities(img, float(th))
+            assert np.array_equal(pm.reshape(-1), g[f"{name}/{tag}_pvals"])
+            np.random.seed(int(g[f"{name}/{tag}_seed"]))
+            draws = np.array([s(img, False)[:2] for _ in range(30)])
+            assert np.array_equal(draws, g[f"{name}/{tag}_draws"])
+    rng = np.random.RandomState(0)
+    img = np.where(rng.rand(64, 64) < 0.3, rng.randint(150, 200, (64, 64)), rng.randint(5, 40, (64, 64))).astype(np.uint8)
+    th = otsu_threshold(img, 256)
+    assert 39 <= th < 150          # the bin centre that closes the low mode (skimage: foreground = image > threshold)
+    r0, c0, roi = PatchSampler(SAMPLE_ROI, 8, 256, TH_AUTO, 0.)(img, True)
+    assert roi.dtype == np.uint8 and roi.mean() == (img >= th).mean() and 0 <= r0 <= 56 and 0 <= c0 <= 56
 
 
 @pytest.mark.gpu

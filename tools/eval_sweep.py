@@ -47,7 +47,6 @@ def main():
                 model = define_model(args)
                 model.init_train()
                 batch = M.synth_batch(a.batch, scale, 512, model.device, 7)
-                batch["l_to_h_img"] = F.interpolate(batch["l_im"], size=(512, 512), mode="bicubic").clamp(0, 1)
                 model.feed_data(batch)
                 for _ in range(3):
                     model.test()
