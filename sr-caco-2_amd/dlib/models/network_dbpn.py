@@ -67,7 +67,9 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, need_grad, *params):
         ctx.net = net
-        y = net.engine.forward(x, None, save=need_grad)
+        from srhip import ops
+        with ops.amp_inference(getattr(net, "amp", False) and not need_grad):       # --amp: inference only
+            y = net.engine.forward(x, None, save=need_grad)
         return y.clone() if need_grad else y
 
     @staticmethod

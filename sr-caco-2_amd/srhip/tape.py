@@ -139,11 +139,19 @@ class ConvW:
 
 
 class WeightBank:
-    """Derived weights of every conv of a net, rebuilt after the parameters changed (TapeEngine.prepare)."""
+    """Derived weights of every conv of a net, rebuilt after the parameters changed (TapeEngine.prepare).  From 64
+    channels on both sides the forward / data-gradient operands are split-MFMA planes (two fp16 planes + block exponents
+    where the kernels take them, three bf16 planes otherwise: ops.PrepTable, ONE launch for the whole net); below that,
+    f32 packs for the exact-f32 MFMA kernels."""
 
     def __init__(self):
         self.d = {}
         self.bufs = _Bufs()
+        self.ws = ops.WeightSet()
+        self._jobs, self._table, self._sig = [], None, None
+
+    def begin(self):
+        self._jobs = []
 
     def conv(self, key, mod_weight, bias, kind, s=1, k=3, p=1):
         """kind: 'c3' | 'c1' | 'deconv' | 'down'."""
@@ -155,28 +163,54 @@ class WeightBank:
         w = mod_weight.data
         if kind == "c1":
             e.Co, e.Ci = w.shape[0], w.shape[1]
-            e.w1 = w.reshape(e.Co, e.Ci)
-            e.w1T = self.bufs.get(key + ".w1T", e.Ci, e.Co, device=dev)
-            ops.transpose(e.w1.contiguous(), e.w1T)
+            e.use_planes = ops.bx3_nt_for(e.Co, e.Ci) and e.Ci % 4 == 0 and e.Co % 4 == 0
             e.bias = None if bias is None else bias.data
-            e.use_planes = False
+            w2 = w.reshape(e.Co, e.Ci)
+            if e.use_planes:
+                e.w1 = self.ws.planes(key + ".w", e.Co, e.Ci, dev)
+                e.w1T = self.ws.planes(key + ".wT", e.Ci, e.Co, dev)
+                self._jobs.append(("lin", w2, e.w1, e.w1T))
+            else:
+                e.w1 = w2
+                e.w1T = self.bufs.get(key + ".w1T", e.Ci, e.Co, device=dev)
+                ops.transpose(w2.contiguous(), e.w1T)
             return e
         if kind == "c3":
             w3, b3 = w, (None if bias is None else bias.data)
-        elif kind == "deconv":
-            w3 = expand_deconv(w, s, p)
-            b3 = None if bias is None else bias.data.repeat_interleave(s * s).contiguous()
         else:
-            w3 = expand_down(w, s, p)
-            b3 = None if bias is None else bias.data
+            ex = expand_deconv(w, s, p) if kind == "deconv" else expand_down(w, s, p)
+            w3 = self.bufs.get(key + ".w3", *ex.shape, device=dev)      # persistent: the preparation table holds its address
+            w3.copy_(ex)
+            b3 = None if bias is None else (bias.data.repeat_interleave(s * s).contiguous() if kind == "deconv" else bias.data)
         e.w3, e.bias = w3, b3
         e.Co, e.Ci = w3.shape[0], w3.shape[1]
-        e.use_planes = False
-        if e.Ci >= 4 and e.Co >= 4:
+        e.use_planes = ops.bx3_nt_for(e.Co, e.Ci) and e.Ci % 4 == 0 and e.Co % 4 == 0
+        if e.use_planes:
+            e.wp = self.ws.planes(key + ".wp", 9 * e.Co, e.Ci, dev)
+            e.wpt = self.ws.planes(key + ".wpt", 9 * e.Ci, e.Co, dev)
+            self._jobs.append(("conv", w3, e.wp, e.wpt))
+        else:
             e.wp = self.bufs.get(key + ".wp", 9, e.Co, e.Ci, device=dev)
             e.wpt = self.bufs.get(key + ".wpt", 9, e.Ci, e.Co, device=dev)
             ops.pack_conv_weight(w3, e.wp, e.wpt)
         return e
+
+    def finish(self, device):
+        """one preparation launch for every split operand of the net"""
+        if not self._jobs:
+            return
+        sig = tuple(j[1].data_ptr() for j in self._jobs)
+        if self._table is None or sig != self._sig:
+            tb = ops.PrepTable()
+            for kind, w, fwd, bwd in self._jobs:
+                if kind == "lin":
+                    tb.linear(w, fwd)
+                    tb.linear(w, bwd, transpose=True)
+                else:
+                    tb.conv(w, fwd)
+                    tb.conv(w, bwd, data_grad=True)
+            self._table, self._sig = tb.build(device), sig
+        self._table.run()
 
 
 # --------------------------------------------------------------------------- the tape
@@ -554,7 +588,9 @@ class TapeEngine:
         return [[""]]           # one gradient bucket: every parameter
 
     def prepare(self):
+        self.bank.begin()
         self.bank_entries()
+        self.bank.finish(next(self.net.parameters()).device)
         self.prepared = True
 
     def forward(self, x, dp=None, save=True):
