@@ -53,6 +53,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the EDSR x8 / x4 / x2 lines under config.secondary")
+    ap.add_argument("--train-only", action="store_true",
+                    help="profiling runs: nothing but the warm-up and the timed training steps (no evaluation figure, no "
+                         "secondary workloads, no CPU baseline), so that per-kernel statistics and PMC byte counts divide "
+                         "by the step count")
     return ap.parse_args(argv)
 
 
@@ -323,7 +327,9 @@ def worker(args):
     loss = ts.loss_values()[0]
     # secondary figure, outside the timed region: forward-only patches/s of the same net and batch
     eval_pps = eval_amp_pps = None
-    if rank == 0 and world == 1:
+    if args.train_only:
+        args.no_secondary = args.no_cpu_baseline = True
+    if rank == 0 and world == 1 and not args.train_only:
         net.eval()
         with torch.no_grad():
             for _ in range(2):

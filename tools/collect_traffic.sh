@@ -10,5 +10,5 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$ROOT/$OUT/$c" -- \
-    python3 "$ROOT/bench.py" --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > "$ROOT/$OUT/$c.log" 2>&1
+    python3 "$ROOT/bench.py" --workload $WL --steps 2 --warmup 1 --train-only --no-roofline > "$ROOT/$OUT/$c.log" 2>&1
 done
