@@ -161,6 +161,20 @@ int srhip_mlp_fwd_f16x2(const float* x, long ldx, const float* stats, const void
 int srhip_mlp_bwd_f16x2(const float* dy, long lddy, const void* W2Th, const void* W1Th, const float* h, long ldh,
                         float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
                         int M, int C, int hidden, const float* rowscale, int rows_per_scale, void* stream);
+/* The W-MSA half of a Swin block, forward, in one kernel (wmsa_f16.hip): one thread block per 8x8 window computes
+ *   qkv = LN(x) . Wqkv^T + bqkv  (stats[T][2] = {mean, rstd} of x; Wqkv gamma-folded, bqkv beta-folded),
+ *   att = softmax(q k^T / sqrt(D) + bias + shift mask) v  per head (cyclic shift 0 or 4, as srhip_window_attention_fwd_f16x2),
+ *   out = x + s * (att . Wproj^T + bproj),  stats_out = {mean, rstd} of the out rows (may be NULL).
+ * qkv [T][3C] and att [T][C] are written (the backward reads them) but read back from L2 only.  x, out: token-major
+ * [B*H*W][C], dense; out must not alias x.  Weight planes as srhip_mlp_fwd_f16x2 (prep kind 3); biasF from
+ * srhip_bias_expand_f16x2; rowscale = DropPath multipliers per sample [B] or NULL.  C <= 192 (multiple of 4),
+ * heads <= 8, head dim in {10, 16, 30, 32}, H, W multiples of 8.
+ * Replaces norm1 + roll + window_partition + WindowAttention.forward + window_reverse + roll + residual
+ * (dlib/models/network_swinir.py:288-334,153-176). */
+int srhip_wmsa_fwd_f16x2(const float* x, const float* stats, const void* Wqkvh, const float* bqkv, const void* Wprojh,
+                         const float* bproj, const float* biasF, const float* rowscale, float* qkv, float* att,
+                         float* out, float* stats_out, int B, int H, int W, int C, int heads, int shift,
+                         void* stream);
 int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
                            int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                            const float* rowscale, float alpha, void* stream);

@@ -151,6 +151,22 @@ int srhip_mlp_fwd_f16x2(const float* x, long ldx, const float* stats, const void
   return sr_mlp_f16(p, 0, (hipStream_t)stream);
 }
 
+int srhip_wmsa_fwd_f16x2(const float* x, const float* stats, const void* Wqkvh, const float* bqkv, const void* Wprojh,
+                         const float* bproj, const float* biasF, const float* rowscale, float* qkv, float* att,
+                         float* out, float* stats_out, int B, int H, int W, int C, int heads, int shift,
+                         void* stream) {
+  SR_REQUIRE(x && stats && Wqkvh && bqkv && Wprojh && biasF && qkv && att && out, "wmsa_fwd_f16x2: null operand");
+  SR_REQUIRE(out != x, "wmsa_fwd_f16x2: out must not alias x (windows read the residual while others write)");
+  SR_REQUIRE(sr_matmul_mode() == 0, "wmsa_fwd_f16x2: f32-accurate matmul mode only");
+  WmsaF16Args p;
+  memset(&p, 0, sizeof(p));
+  p.X = x; p.ln_stats = stats;
+  p.Wqkv = (const unsigned short*)Wqkvh; p.bqkv = bqkv; p.Wproj = (const unsigned short*)Wprojh; p.bproj = bproj;
+  p.biasF = biasF; p.rowscale = rowscale; p.qkv = qkv; p.att = att; p.out = out; p.stats_out = stats_out;
+  p.B = B; p.H = H; p.W = W; p.C = C; p.heads = heads; p.shift = shift;
+  return sr_wmsa_f16(p, (hipStream_t)stream);
+}
+
 int srhip_mlp_bwd_f16x2(const float* dy, long lddy, const void* W2Th, const void* W1Th, const float* h, long ldh,
                         float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
                         int M, int C, int hidden, const float* rowscale, int rows_per_scale, void* stream) {

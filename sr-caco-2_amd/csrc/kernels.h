@@ -75,6 +75,20 @@ struct MlpF16Args {
   int M, C, hid;
 };
 int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st);
+// the W-MSA half of a Swin block, forward, as one launch (wmsa_f16.hip); rows are token-major [B*H*W][..], dense
+struct WmsaF16Args {
+  const float* X;                    // block input rows [T][C] (also the residual)
+  const float* ln_stats;             // {mean, rstd}[T] of the X rows
+  const unsigned short* Wqkv; const float* bqkv;    // planes of Wqkv*gamma [3C][C] (prep kind 3), beta-folded bias
+  const unsigned short* Wproj; const float* bproj;  // planes of Wproj [C][C], bias (may be null)
+  const float* biasF;                // relative-position bias images [heads][4096] (srhip_bias_expand_f16x2)
+  const float* rowscale;             // DropPath multipliers per sample [B] (null = 1)
+  float* qkv; float* att; float* out; float* stats_out;   // [T][3C], [T][C], [T][C], [T][2] (may be null)
+  int B, H, W, C, heads, shift, Kp;
+  float scale;
+  long long* dbg;                    // experiment builds: phase timestamps
+};
+int sr_wmsa_f16(WmsaF16Args& p, hipStream_t st);
 
 int sr_matmul_mode();        // 0: f32-accurate bf16x3 | 1: single bf16 product (srhip_set_matmul_mode)
 int sr_gemm_nt(NtArgs& p, hipStream_t st);

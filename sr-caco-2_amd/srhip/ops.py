@@ -319,6 +319,34 @@ def mlp_fwd_f16(x, stats, W1, b1, W2, b2, out, h=None, rowscale=None, rows_per_s
     return out
 
 
+def wmsa_f16_fusable(C, heads):
+    """Shapes srhip_wmsa_fwd_f16x2 takes with the planes PrepTable.linear builds (format 1) and the bias images of
+    the fp16x2 attention."""
+    def fmt1(rows, kd):
+        return F16X2 and (rows % 180 == 0 or (rows > 128 and rows % 128 != 0)) and kd <= 1024
+    return (wattn_f16_ok(C, heads) and C % 4 == 0 and 4 <= C <= 192 and heads <= 8 and fmt1(3 * C, C) and fmt1(C, C))
+
+
+def wmsa_fwd_f16(x, stats, Wq, bq, Wp, bp, biasF, qkv, att, out, B, H, W, heads, shift, rowscale=None,
+                 stats_out=None):
+    """The W-MSA half of a Swin block, forward, in ONE kernel: qkv = LN(x) @ Wq^T + bq, att = window attention,
+    out = x + s * (att @ Wp^T + bp).  Wq = planes of Wqkv*gamma [3C, C], Wp = planes of Wproj [C, C] (format 1)."""
+    _chk(x, stats, bq, bp, biasF, qkv, att, out, rowscale, stats_out)
+    T, C = x.shape
+    assert T == B * H * W and Wq.fmt == 1 and Wp.fmt == 1 and (Wq.rows, Wq.K) == (3 * C, C) and (Wp.rows, Wp.K) == (C, C)
+    assert qkv.shape == (T, 3 * C) and att.shape == (T, C) and out.shape == (T, C)
+    assert rowscale is None or rowscale.numel() == B
+    args = (_p(x), _p(stats), _p(Wq.planes), _p(bq), _p(Wp.planes), _p(bp), _p(biasF), _p(rowscale), _p(qkv),
+            _p(att), _p(out), _p(stats_out), B, H, W, C, heads, shift, _st())
+    if probe.on("wmsa_fused"):
+        with probe.timed(("wmsa_fused", T, C, heads, "fwd"), 2.0 * T * C * 4 * C + 4.0 * T * 64 * C,
+                         4.0 * (T * 6 * C + 4 * C * C)):
+            call("srhip_wmsa_fwd_f16x2", *args)
+    else:
+        call("srhip_wmsa_fwd_f16x2", *args)
+    return out
+
+
 def mlp_bwd_f16(dy, W2T, W1T, h, dh, gh, x, stats, dx, rowscale=None, rows_per_scale=1):
     """Data gradient of mlp_fwd_f16 in ONE kernel: dh = (s * dy @ W2) * gelu'(h), gh = gelu(h), dx = dy +
     LayerNorm_backward(dh @ W1f; x, stats).  W2T = planes of W2^T [hidden, C], W1T = planes of (W1*gamma)^T [C, hidden]."""

@@ -70,6 +70,11 @@ class SwinIREngine:
         # A fetch and one epilogue per direction instead of two, the hidden activation never read back.  SRHIP_MLP_F16=0:
         # the separate Linear launches.
         self.fuse_mlp_h = ops.mlp_f16_fusable(self.C, self.hid) and os.environ.get("SRHIP_MLP_F16", "1") != "0"
+        # The W-MSA half, forward, as one kernel per block (wmsa_f16.hip): qkv Linear + window attention + proj Linear +
+        # residual; q, k, v and the attention output are read back from L2 by the block that wrote them.  SRHIP_WMSA_F16=0:
+        # the three separate launches.
+        self.fuse_wmsa = (all(ops.wmsa_f16_fusable(self.C, b.num_heads) for b in self.blocks)
+                          and os.environ.get("SRHIP_WMSA_F16", "1") != "0")
 
     def bucket_prefixes(self):
         """Gradient buckets in backward-completion order: one per RSTB layer (the
@@ -285,18 +290,23 @@ class SwinIREngine:
                     st1 = buf(f"{k}.st1", T, 2)
                     ops.layernorm_fwd(t, st1)
                 qkv = buf(f"{k}.qkv", T, 3 * C)
-                ops.gemm_nt(t, ws[f"{bi}.wq"], D.d[f"{bi}.bq"], out=qkv, a_mode=1, ln_stats=st1)
                 a = buf(f"{k}.a", T, C)
-                if ops.wattn_f16_ok(C, heads):
-                    ops.window_attention_fwd_f16(qkv, a, D.d[f"{bi}.biasF"], B, H, W, C, heads, blk.shift_size)
-                else:
-                    ops.window_attention_fwd(qkv, a, D.d[f"{bi}.biasT"], B, H, W, C, heads, blk.shift_size)
                 x1 = buf(f"{k}.x1", T, C)
                 st2 = buf(f"{k}.st2", T, 2)
-                ops.gemm_nt(a, ws[f"{bi}.wproj"], blk.attn.proj.bias.data, out=x1, epi=2, R=t,
-                            rowscale=s1, rows_per_scale=H * W, stats_out=st2 if fuse else None)
-                if not fuse:
-                    ops.layernorm_fwd(x1, st2)
+                if self.fuse_wmsa and fuse and not ops.lib.srhip_get_matmul_mode():
+                    ops.wmsa_fwd_f16(t, st1, ws[f"{bi}.wq"], D.d[f"{bi}.bq"], ws[f"{bi}.wproj"],
+                                     blk.attn.proj.bias.data, D.d[f"{bi}.biasF"], qkv, a, x1, B, H, W, heads,
+                                     blk.shift_size, rowscale=s1, stats_out=st2)
+                else:
+                    ops.gemm_nt(t, ws[f"{bi}.wq"], D.d[f"{bi}.bq"], out=qkv, a_mode=1, ln_stats=st1)
+                    if ops.wattn_f16_ok(C, heads):
+                        ops.window_attention_fwd_f16(qkv, a, D.d[f"{bi}.biasF"], B, H, W, C, heads, blk.shift_size)
+                    else:
+                        ops.window_attention_fwd(qkv, a, D.d[f"{bi}.biasT"], B, H, W, C, heads, blk.shift_size)
+                    ops.gemm_nt(a, ws[f"{bi}.wproj"], blk.attn.proj.bias.data, out=x1, epi=2, R=t,
+                                rowscale=s1, rows_per_scale=H * W, stats_out=st2 if fuse else None)
+                    if not fuse:
+                        ops.layernorm_fwd(x1, st2)
                 # block outputs ping-pong in eval, are kept per block in training
                 x2 = buf(f"{bi if save else bi % 2}.x2", T, C)
                 st_next = None

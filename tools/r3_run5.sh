@@ -1,4 +1,3 @@
 #!/bin/bash
-mkdir -p gpurun_out/r3e
-timeout 1500 python -m pytest tests/test_gpu_tape_nets.py -q -s > gpurun_out/r3e/test_tape.log 2>&1; echo "rc=$?" >> gpurun_out/r3e/test_tape.log
-grep "worst gradient\|AssertionError: (\|passed\|failed" gpurun_out/r3e/test_tape.log | cut -c1-250
+timeout 900 python -m pytest tests/test_gpu_swinir.py tests/test_gpu_wmsa_f16.py -x -q -m gpu 2>&1 | tail -4
+timeout 600 python bench.py --train-only 2>&1 | tail -1 | cut -c1-400

@@ -1,4 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out/r3f
-timeout 2400 python tools/eval_sweep.py --batch 8 --iters 5 --nets DBPN,SRFBN,ProSR --out gpurun_out/r3f/eval_new.json > gpurun_out/r3f/eval_new.log 2>&1; echo "rc=$?" >> gpurun_out/r3f/eval_new.log
-grep -v amdgpu.ids gpurun_out/r3f/eval_new.log | tail -25 | cut -c1-220
+timeout 900 python -m pytest tests/test_gpu_wmsa_f16.py -x -q -m gpu 2>&1 | tail -5
+timeout 300 python tools/mb_wmsa_f16.py 2>&1 | tail -7
+SRHIP_LIB=$(pwd)/sr-caco-2_amd/lib/libsrhip_exp.so timeout 300 python tools/mb_wmsa_phases.py 2>&1 | tail -12
