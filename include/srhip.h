@@ -325,11 +325,17 @@ int srhip_window_attention_fwd_f16x2(const float* qkv, float* out, const float* 
  * image in the key side's accumulator order, img[head][J][I][lane][e] = table[rpi(query 16 I + 4 (lane >> 4) + e,
  * key 16 J + (lane & 15))][head] (second output of srhip_bias_expand_f16x2 / `b` of a prep job of kind 2).
  * dqkv [T][3C] is overwritten; dbiasT (may be NULL) receives the bias-gradient image in the order srhip_bias_grad
- * reads; workspace: srhip_window_attention_bwd_f16x2_ws floats (partial tiles, summed in fp64 in a fixed order). */
+ * reads; workspace: srhip_window_attention_bwd_f16x2_ws floats (partial tiles, summed in fp64 in a fixed order;
+ * may be NULL when dbiasT is). */
 long srhip_window_attention_bwd_f16x2_ws(int B, int H, int W, int heads);
 int srhip_window_attention_bwd_f16x2(const float* qkv, const float* dout, float* dqkv, const float* biasF,
                                      const float* biasG, float* dbiasT, float* workspace, int B, int H, int W, int C,
                                      int heads, int shift, void* stream);
+/* With dbiasT NULL and a workspace the backward leaves its partial tiles there; this sums the partials of nblocks
+ * attention blocks of one geometry (workspace + i * ws_stride -> dbiasT + i * img_stride floats) in ONE launch -- the
+ * blocks of an RSTB layer share it. */
+int srhip_window_attention_dbias_reduce_f16x2(const float* workspace, long ws_stride, int nblocks, float* dbiasT,
+                                              long img_stride, int B, int H, int W, int heads, void* stream);
 
 /* ---- window attention (network_swinir.py:48-80,140-179,297-331) -------------- */
 /* table (225,heads) -> two bias images of heads*4096 floats each, stored in the order

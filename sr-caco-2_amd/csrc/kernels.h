@@ -73,6 +73,7 @@ struct MlpF16Args {
   const float* rowscale; int rows_per_scale;   // DropPath multipliers per sample (null = 1)
   float* stats_out;                  // forward: {mean, rstd} of the out rows (may be null)
   int M, C, hid;
+  long long* dbg;                    // experiment builds: phase timestamps
 };
 int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st);
 // the W-MSA half of a Swin block, forward, as one launch (wmsa_f16.hip); rows are token-major [B*H*W][..], dense

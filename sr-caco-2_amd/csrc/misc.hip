@@ -171,6 +171,33 @@ __global__ void __launch_bounds__(256) k_ln_affine_finish(const float* __restric
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
   ln_affine_finish_one(ws, nrb, K, dgamma, dbeta, blockIdx.x * 256 + threadIdx.x);
 }
+// ... for many row blocks (k_ln_bwd: up to 2048): 16 row lanes per column, four chains each, combined in a fixed order
+// (two 256-thread blocks walking 2048 rows serially took 144 us at T = 32768)
+__global__ void __launch_bounds__(1024) k_ln_affine_finish_wide(const float* __restrict__ ws, int nrb, int K,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float sm[16][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int which = idx >= K, k = idx - which * K;
+  if (idx < 2 * K) {
+    const float* q = ws + (long)which * K + k;
+    int rb = rl;
+    for (; rb + 48 < nrb; rb += 64) {
+      a0 += q[(long)(rb + 0) * 2 * K]; a1 += q[(long)(rb + 16) * 2 * K];
+      a2 += q[(long)(rb + 32) * 2 * K]; a3 += q[(long)(rb + 48) * 2 * K];
+    }
+    for (; rb < nrb; rb += 16) a0 += q[(long)rb * 2 * K];
+  }
+  sm[rl][c] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rl == 0 && idx < 2 * K) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += sm[r][c];
+    (which ? dbeta : dgamma)[k] = t;
+  }
+}
 // The slice reducers of up to 24 Linear weight gradients (one Swin block: 4; one RSTB layer: 4 x depth) in ONE
 // launch: k_fin_ln_linear's geometry per problem; gamma == null means a plain Linear
 // (dW = G, db = dbv, no LayerNorm gradients).
@@ -851,8 +878,12 @@ int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, con
   const long waves = (M + rpw - 1) / rpw;
   const int blocks = sr_cdiv(waves, 4);
   hipLaunchKernelGGL(k_ln_bwd, dim3(blocks), dim3(256), 0, st, dy, x, stats, res, gamma, out, workspace, M, C, rpw);
-  if (gamma)
-    hipLaunchKernelGGL(k_ln_affine_finish, dim3(sr_cdiv(2 * C, 256)), dim3(256), 0, st, workspace, blocks, C, dgamma, dbeta);
+  if (gamma) {
+    if (blocks >= 64)
+      hipLaunchKernelGGL(k_ln_affine_finish_wide, dim3(sr_cdiv(2 * C, 64)), dim3(1024), 0, st, workspace, blocks, C, dgamma, dbeta);
+    else
+      hipLaunchKernelGGL(k_ln_affine_finish, dim3(sr_cdiv(2 * C, 256)), dim3(256), 0, st, workspace, blocks, C, dgamma, dbeta);
+  }
   SR_LAUNCH_CHECK("layernorm_bwd");
   return 0;
 }

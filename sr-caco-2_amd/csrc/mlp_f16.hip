@@ -68,6 +68,25 @@ __device__ __forceinline__ void gelu_gate(float x, float& gate, float& gl) {
   gl = x * cdf;
 }
 
+// phase timestamps of every wave (tools/mb_mlp_phases.py): experiment builds only
+#ifdef SRHIP_EXPERIMENTS
+long long* g_mlp_dbg = nullptr;
+#define SR_TS(K) \
+  if (p.dbg && lane == 0) p.dbg[((long)blockIdx.x * 4 + wave) * 16 + (K)] = (long long)wall_clock64();
+#else
+#define SR_TS(K)
+#endif
+
+// x Phi(x) with the same Phi: the forward's activation.  erff() costs ~50 VALU instructions per element and a lane holds
+// 96 hidden units: the exact form was 18 us of a 50-us block (two waves per SIMD), this one is a third of it.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float e1 = __expf(-0.5f * x * x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  return x * (0.5f * (1.0f + copysignf(1.0f - poly * e1, x)));
+}
+
 template <bool BWD>
 __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -113,6 +132,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
 #pragma unroll
       for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane2 + boff2[jt]);
   };
+  SR_TS(0)
   u32x4 fb0[3][2], fb1[3][2], fb2[3][2];
   load_b1(0, fb0);
   load_b1(1, fb1);
@@ -168,7 +188,9 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
     }
   }
+  SR_TS(1)
   __syncthreads();
+  SR_TS(2)
 
   int a_off[4];
 #pragma unroll
@@ -203,6 +225,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
   SR_G1(0, fb0) SR_G1(1, fb1) SR_G1(2, fb2) SR_G1(3, fb0) SR_G1(4, fb1) SR_G1(5, fb2)
   SR_G1(6, fb0) SR_G1(7, fb1) SR_G1(8, fb2) SR_G1(9, fb0) SR_G1(10, fb1) SR_G1(11, fb2)
 #undef SR_G1
+  SR_TS(3)
   // the first stages of GEMM 2's weights travel while the activation math runs (the backward's gate needs the
   // registers: it requests them behind the math, in front of the token-maximum exchange)
   if (!BWD) {
@@ -255,7 +278,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
               for (int e = 0; e < 4; ++e) v[e] = v[e] * (rix[i] * wi[e]) + bv[e];
               if (p.H && ok) *(f32x4*)(p.H + (long)gm[i] * p.ldh + unit0) = v;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = uok ? gelu_f(v[e]) : 0.f;
+              for (int e = 0; e < 4; ++e) v[e] = uok ? gelu_fast(v[e]) : 0.f;
             } else {
               const f32x4 hx = hcur[i];
               f32x4 gl;
@@ -287,6 +310,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     load_b2(1, fb1);
     load_b2(2, fb2);
   }
+  SR_TS(4)
   // token maxima over the whole hidden row: lanes g = 0..3 of a wave, then the four waves
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -295,6 +319,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     if (g == 0) smax[wave * 64 + 16 * i + c] = tmax[i];
   }
   __syncthreads();                                   // also: every wave is done with the x stage images
+  SR_TS(5)
   float use[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -346,18 +371,25 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     if ((U) + 3 < 6 * NH) load_b2((U) + 3, FB);                        \
   }
   stage_a2(acc1[0]);
+  SR_TS(6)
   __syncthreads();
+  SR_TS(7)
   SR_G2(0, fb0) SR_G2(1, fb1) SR_G2(2, fb2) SR_G2(3, fb0) SR_G2(4, fb1) SR_G2(5, fb2)
+  SR_TS(8)
   if (NH > 1) {
     __syncthreads();                                 // every wave is done with the first pass's images
+    SR_TS(9)
     stage_a2(acc1[1]);
     __syncthreads();
+    SR_TS(10)
     SR_G2(6, fb0) SR_G2(7, fb1) SR_G2(8, fb2) SR_G2(9, fb0) SR_G2(10, fb1) SR_G2(11, fb2)
   }
 #undef SR_G2
+  SR_TS(11)
 
   // ---------------- the output tile, row-major in LDS (block exponents undone: exact powers of two)
   __syncthreads();
+  SR_TS(12)
   float* const T = (float*)smem;
   {
     float wv[3];
@@ -373,6 +405,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       }
   }
   __syncthreads();
+  SR_TS(13)
   const int C = p.C;
   if (!BWD) {
     // out = x + s (acc + b2): 16-byte pieces in row-major order (a wave instruction covers 1 KB of consecutive tile bytes)
@@ -469,11 +502,19 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
         }
     }
   }
+  SR_TS(14)
 }
 
 }  // namespace
 
+#ifdef SRHIP_EXPERIMENTS
+extern "C" int srhip_mlp_debug_buffer(long long* buf) { g_mlp_dbg = buf; return 0; }    // [blocks][4][16] wall-clock stamps
+#endif
+
 int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st) {
+#ifdef SRHIP_EXPERIMENTS
+  p.dbg = g_mlp_dbg;
+#endif
   SR_REQUIRE(p.C % 4 == 0 && p.C >= 4 && p.C <= 192, "mlp_f16x2: C = %d (multiple of 4, <= 192)", p.C);
   SR_REQUIRE(p.hid % 4 == 0 && p.hid >= 4 && p.hid <= 384, "mlp_f16x2: hidden = %d (multiple of 4, <= 384)", p.hid);
   SR_REQUIRE(p.M > 0, "mlp_f16x2: M = %d", p.M);

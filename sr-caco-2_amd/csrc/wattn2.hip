@@ -348,10 +348,13 @@ __global__ void __launch_bounds__(256, 2) k_wattn2_bwd(const float* __restrict__
 // partial tiles [nparts][heads][4096] (accumulator order of k_wattn2_bwd) -> the bias-gradient image in the order
 // srhip_bias_grad reads (wa_dimg_index, wattn.hip: [a][b][q][lane] of the 32x32 tiles, key = mfma_row(q, lane) + 32 a,
 // query = (lane & 31) + 32 b); fp64 sums in partial order
+// (blockIdx.y = attention block of a batched call: its partials at part + y * part_stride, its image at dimg + y * img_stride)
 __global__ void __launch_bounds__(256) k_dbias2_reduce(const float* __restrict__ part, int nparts, int heads,
-                                                       float* __restrict__ dimg) {
+                                                       float* __restrict__ dimg, long part_stride, long img_stride) {
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= heads * 4096) return;
+  part += (long)blockIdx.y * part_stride;
+  dimg += (long)blockIdx.y * img_stride;
   const int hd = o >> 12, el = o & 4095;
   const int ln = el & 63, q = (el >> 6) & 15, b = (el >> 10) & 1, a = el >> 11;
   const int key = mfma_row(q, ln) + 32 * a, query = (ln & 31) + 32 * b;
@@ -426,7 +429,8 @@ long srhip_window_attention_bwd_f16x2_ws(int B, int H, int W, int heads) {
   return (long)sr_cdiv(nwin, 4) * heads * W2_DS;        // one partial bias-gradient tile per block
 }
 
-// dbiasT (may be NULL) is overwritten with the bias-gradient image in the order srhip_bias_grad reads.
+// dbiasT (may be NULL) is overwritten with the bias-gradient image in the order srhip_bias_grad reads.  dbiasT NULL with a
+// workspace: the partial tiles are written and left for srhip_window_attention_dbias_reduce_f16x2.
 int srhip_window_attention_bwd_f16x2(const float* qkv, const float* dout, float* dqkv, const float* biasF,
                                      const float* biasG, float* dbiasT, float* workspace, int B, int H, int W, int C,
                                      int heads, int shift, void* stream) {
@@ -438,7 +442,7 @@ int srhip_window_attention_bwd_f16x2(const float* qkv, const float* dout, float*
   hipStream_t st = (hipStream_t)stream;
   constexpr int LDS = (4 * W2_DS + 4 * W2_ST) * 4;
   dim3 grid(nparts * heads), blk(256);
-  float* part = dbiasT ? workspace : nullptr;
+  float* part = workspace;
 #define SR_WA(D_)                                                                                                    \
   if (D == D_) {                                                                                                     \
     static bool attr = false;                                                                                        \
@@ -453,8 +457,20 @@ int srhip_window_attention_bwd_f16x2(const float* qkv, const float* dout, float*
   SR_WA(30) SR_WA(10) SR_WA(16) SR_WA(32)
 #undef SR_WA
   if (dbiasT)
-    hipLaunchKernelGGL(k_dbias2_reduce, dim3(sr_cdiv(heads * 4096, 256)), dim3(256), 0, st, part, nparts, heads, dbiasT);
+    hipLaunchKernelGGL(k_dbias2_reduce, dim3(sr_cdiv(heads * 4096, 256)), dim3(256), 0, st, part, nparts, heads, dbiasT, 0L, 0L);
   SR_LAUNCH_CHECK("window_attention_bwd_f16x2");
+  return 0;
+}
+
+// The bias-gradient images of nblocks attention blocks (same B, H, W, heads) from the partial tiles their backward
+// launches left at workspace + i * ws_stride, in one launch: dbiasT + i * img_stride.
+int srhip_window_attention_dbias_reduce_f16x2(const float* workspace, long ws_stride, int nblocks, float* dbiasT,
+                                              long img_stride, int B, int H, int W, int heads, void* stream) {
+  SR_REQUIRE(workspace && dbiasT && nblocks > 0 && nblocks <= 65535, "window_attention_dbias_reduce_f16x2: bad arguments");
+  const int nparts = sr_cdiv(B * (H / 8) * (W / 8), 4);
+  hipLaunchKernelGGL(k_dbias2_reduce, dim3(sr_cdiv(heads * 4096, 256), nblocks), dim3(256), 0, (hipStream_t)stream,
+                     workspace, nparts, heads, dbiasT, ws_stride, img_stride);
+  SR_LAUNCH_CHECK("window_attention_dbias_reduce_f16x2");
   return 0;
 }
 

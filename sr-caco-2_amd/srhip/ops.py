@@ -684,9 +684,28 @@ def bias_expand_f16(table, biasF, biasG=None):
     call("srhip_bias_expand_f16x2", _p(table), _p(biasF), _p(biasG), table.shape[1], _st())
 
 
-def window_attention_bwd_f16(qkv, dout, dqkv, biasF, biasG, dbiasT, B, H, W, C, heads, shift):
-    _chk(qkv, dout, dqkv, biasF, biasG, dbiasT)
-    ws = SCRATCH.get("wattn2_ws", lib.srhip_window_attention_bwd_f16x2_ws(B, H, W, heads), device=qkv.device)
+def wattn_dbias_ws(B, H, W, heads):
+    """floats of the partial bias-gradient tiles one fp16x2 attention backward leaves behind"""
+    return lib.srhip_window_attention_bwd_f16x2_ws(B, H, W, heads)
+
+
+def wattn_dbias_reduce_f16(parts, dbiasT_all, first, B, H, W, heads):
+    """The bias-gradient images of the blocks first .. first + len(parts) - 1 of dbiasT_all [nblocks, heads, 64, 64]
+    from the partial tiles parts[i] (rows of one [n, ws] buffer) their backward launches left, in ONE launch."""
+    _chk(parts, dbiasT_all)
+    assert parts.dim() == 2 and parts.stride(1) == 1 and dbiasT_all.shape[1] == heads
+    call("srhip_window_attention_dbias_reduce_f16x2", _p(parts), parts.stride(0), parts.shape[0],
+         _p(dbiasT_all[first]), dbiasT_all.stride(0), B, H, W, heads, _st())
+
+
+def window_attention_bwd_f16(qkv, dout, dqkv, biasF, biasG, dbiasT, B, H, W, C, heads, shift, parts=None):
+    """parts (a row of the buffer wattn_dbias_reduce_f16 takes): leave the partial bias-gradient tiles there instead
+    of reducing them into dbiasT (which is then not written)."""
+    _chk(qkv, dout, dqkv, biasF, biasG, dbiasT, parts)
+    if parts is not None:
+        ws, dbiasT = parts, None
+    else:
+        ws = SCRATCH.get("wattn2_ws", lib.srhip_window_attention_bwd_f16x2_ws(B, H, W, heads), device=qkv.device)
     args = (_p(qkv), _p(dout), _p(dqkv), _p(biasF), _p(biasG), _p(dbiasT), _p(ws), B, H, W, C, heads, shift, _st())
     if probe.on("wattn"):
         T = B * H * W

@@ -512,6 +512,13 @@ class SwinIREngine:
                           g.view(B, H, W, C))
             nb = len(layer.residual_group.blocks)
             pending = []                 # weight-gradient problems of the layer's blocks (deferred form)
+            # partial bias-gradient tiles of the layer's blocks: reduced by ONE launch per layer (same head count only)
+            lheads = {blk.num_heads for blk in layer.residual_group.blocks}
+            dparts = None
+            if len(lheads) == 1 and ops.wattn_f16_ok(C, next(iter(lheads))):
+                nbmax = max(len(l.residual_group.blocks) for l in net.layers)
+                dparts = buf("dbias_parts", nbmax, ops.wattn_dbias_ws(B, H, W, max(b.num_heads for b in self.blocks)))
+                dparts = dparts[:nb, :ops.wattn_dbias_ws(B, H, W, next(iter(lheads)))]
             for j in reversed(range(nb)):
                 bi -= 1
                 dh, gh, dqkv = dhs[j % nset], ghs[j % nset], dqkvs[j % nset]
@@ -539,7 +546,8 @@ class SwinIREngine:
                 dbT = dbT_all[bi, :heads]
                 if ops.wattn_f16_ok(C, heads):
                     ops.window_attention_bwd_f16(qkv, da, dqkv, D.d[f"{bi}.biasF"], D.d[f"{bi}.biasG"], dbT, B, H,
-                                                 W, C, heads, blk.shift_size)
+                                                 W, C, heads, blk.shift_size,
+                                                 parts=None if dparts is None else dparts[j])
                 else:
                     ops.window_attention_bwd(qkv, da, dqkv, D.d[f"{bi}.biasT"], D.d[f"{bi}.biasN"], dbT, B, H,
                                              W, C, heads, blk.shift_size)
@@ -571,7 +579,9 @@ class SwinIREngine:
                 ops.linear_wgrad_grouped(pending)
             # relative-position-bias table gradients of the layer's blocks: one launch (<= 8 blocks each)
             tabs = [G(pre + f"residual_group.blocks.{j}.attn.relative_position_bias_table") for j in range(nb)]
-            same = len({blk.num_heads for blk in layer.residual_group.blocks}) == 1
+            same = len(lheads) == 1
+            if dparts is not None:
+                ops.wattn_dbias_reduce_f16(dparts, dbT_all, bi, B, H, W, next(iter(lheads)))
             for j0 in range(0, nb, 8):
                 if same:
                     ops.bias_grad_batched(dbT_all, bi + j0, tabs[j0:j0 + 8])

@@ -1,3 +1,3 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_gpu_swinir.py tests/test_gpu_wmsa_f16.py -x -q -m gpu 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_swinir.py tests/test_gpu_kernels.py -x -q -m gpu 2>&1 | tail -4
 timeout 600 python bench.py --train-only 2>&1 | tail -1 | cut -c1-400
