@@ -61,7 +61,7 @@ __device__ __forceinline__ void w2_gather_cols(const float* __restrict__ base, l
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float sc = pow2_scale(mx);
-    rinv[jd] = 1.0f / sc;
+    rinv[jd] = pow2_inv(sc);
 #pragma unroll
     for (int JJ = 0; JJ < 2; ++JJ) {
       unsigned h[4], l[4];
@@ -97,15 +97,26 @@ __device__ __forceinline__ f32x4 mfma3(const u32x4& ah, const u32x4& al, const u
 // Every operand is read from global memory in the form the matrix core takes it (the re-reads of the key side hit L1 /
 // L2); nothing but the bias-gradient tile and 2 KB of row statistics goes through LDS.  The block's four dS tiles are
 // added in wave order and stored as ONE partial tile (plain stores): k_dbias2_reduce sums the partials in fp64.
+// phase timestamps of every wave (tools/mb_attn_phases.py): experiment builds only
+#ifdef SRHIP_EXPERIMENTS
+long long* g_w2_dbg = nullptr;
+#define SR_TS(K) \
+  if (dbg && lane == 0) dbg[((long)blockIdx.x * 4 + wv) * 16 + (K)] = (long long)wall_clock64();
+#else
+#define SR_TS(K)
+#endif
+
 constexpr int W2_DS = 4096;                        // floats of a dS tile
 constexpr int W2_ST = 6 * 64;                      // per wave: lse, delta, 2^-s of the Q rows (x scale), of the dO, K and V rows
 template <int D>
 __global__ void __launch_bounds__(256, 2) k_wattn2_bwd(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                       float* __restrict__ dqkv, const float* __restrict__ biasF,
                                                       const float* __restrict__ biasG, float* __restrict__ part,
-                                                      int nwin, int H, int W, int C, int heads, int shift, float scale) {
+                                                      int nwin, int H, int W, int C, int heads, int shift, float scale,
+                                                      long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) float w2s[];
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  SR_TS(0)
   float* const dsl = w2s + wv * W2_DS;
   float* const stl = w2s + 4 * W2_DS + wv * W2_ST;
   const int lb = sr_xcd_block(blockIdx.x, gridDim.x);
@@ -148,9 +159,11 @@ __global__ void __launch_bounds__(256, 2) k_wattn2_bwd(const float* __restrict__
         }
         __builtin_amdgcn_wave_barrier();
       }
+      SR_TS(1)
       u32x4 kth[2][2], ktl[2][2];
       float rkt[2];
       w2_gather_cols<D>(qb + C, C3, geo, H, W, shift, c, g, kth, ktl, rkt);
+      SR_TS(2)
       const float* bimg = biasF + (long)head * 4096;
 #pragma unroll
       for (int I = 0; I < 4; ++I) {
@@ -195,7 +208,7 @@ __global__ void __launch_bounds__(256, 2) k_wattn2_bwd(const float* __restrict__
           }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
         float dl = 0.f;
 #pragma unroll
         for (int J = 0; J < 4; ++J)
@@ -220,7 +233,7 @@ __global__ void __launch_bounds__(256, 2) k_wattn2_bwd(const float* __restrict__
         }
         dmx = fmaxf(dmx, __shfl_xor(dmx, 16, 64));
         dmx = fmaxf(dmx, __shfl_xor(dmx, 32, 64));
-        const float dsc = pow2_scale(dmx), dri = 1.0f / dsc;
+        const float dsc = pow2_scale(dmx), dri = pow2_inv(dsc);
         f32x4 O[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int JJ = 0; JJ < 2; ++JJ) {
@@ -239,6 +252,7 @@ __global__ void __launch_bounds__(256, 2) k_wattn2_bwd(const float* __restrict__
           if (d0 < D) *(float2*)(op + 16 * jd) = float2{O[jd][0] * sc4[0], O[jd][1] * sc4[1]};
           if (d0 + 2 < D) *(float2*)(op + 16 * jd + 2) = float2{O[jd][2] * sc4[2], O[jd][3] * sc4[3]};
         }
+        SR_TS(3 + I)
       }
     }
     __builtin_amdgcn_wave_barrier();      // the row statistics written by lanes g = 0 are read by every lane below
@@ -257,10 +271,12 @@ __global__ void __launch_bounds__(256, 2) k_wattn2_bwd(const float* __restrict__
 #pragma unroll
         for (int T = 0; T < 4; ++T) (void)w2_split_row(raw[T], gh[T], gl[T]);
       }
+      SR_TS(7)
       u32x4 qth[2][2], qtl[2][2], gth[2][2], gtl[2][2];
       float rqt[2], rgt[2];
       w2_gather_cols<D>(qb, C3, geo, H, W, shift, c, g, qth, qtl, rqt);
       w2_gather_cols<D>(gb, C, geo, H, W, shift, c, g, gth, gtl, rgt);
+      SR_TS(8)
       const float* bimg = biasG + (long)head * 4096;
 #pragma unroll
       for (int J = 0; J < 4; ++J) {
@@ -293,7 +309,7 @@ __global__ void __launch_bounds__(256, 2) k_wattn2_bwd(const float* __restrict__
         }
         dmx = fmaxf(dmx, __shfl_xor(dmx, 16, 64));
         dmx = fmaxf(dmx, __shfl_xor(dmx, 32, 64));
-        const float dsc = pow2_scale(dmx), dri = 1.0f / dsc;
+        const float dsc = pow2_scale(dmx), dri = pow2_inv(dsc);
         f32x4 OV[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         f32x4 OK[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -326,6 +342,7 @@ __global__ void __launch_bounds__(256, 2) k_wattn2_bwd(const float* __restrict__
             *(float2*)(op + 2 * C + 16 * jd + 2) = float2{OV[jd][2] * sv4[2], OV[jd][3] * sv4[3]};
           }
         }
+        SR_TS(9 + J)
       }
     }
   } else {
@@ -343,6 +360,7 @@ __global__ void __launch_bounds__(256, 2) k_wattn2_bwd(const float* __restrict__
       ((f32x4*)dst)[i] = o;
     }
   }
+  SR_TS(13)
 }
 
 // partial tiles [nparts][heads][4096] (accumulator order of k_wattn2_bwd) -> the bias-gradient image in the order
@@ -424,6 +442,10 @@ int srhip_window_attention_fwd_f16x2(const float* qkv, float* out, const float* 
   return 0;
 }
 
+#ifdef SRHIP_EXPERIMENTS
+int srhip_wattn2_debug_buffer(long long* buf) { g_w2_dbg = buf; return 0; }      // [blocks][4][16] wall-clock stamps
+#endif
+
 long srhip_window_attention_bwd_f16x2_ws(int B, int H, int W, int heads) {
   const int nwin = B * (H / 8) * (W / 8);
   return (long)sr_cdiv(nwin, 4) * heads * W2_DS;        // one partial bias-gradient tile per block
@@ -443,6 +465,10 @@ int srhip_window_attention_bwd_f16x2(const float* qkv, const float* dout, float*
   constexpr int LDS = (4 * W2_DS + 4 * W2_ST) * 4;
   dim3 grid(nparts * heads), blk(256);
   float* part = workspace;
+  long long* dbgp = nullptr;
+#ifdef SRHIP_EXPERIMENTS
+  dbgp = g_w2_dbg;
+#endif
 #define SR_WA(D_)                                                                                                    \
   if (D == D_) {                                                                                                     \
     static bool attr = false;                                                                                        \
@@ -452,7 +478,7 @@ int srhip_window_attention_bwd_f16x2(const float* qkv, const float* dout, float*
       attr = true;                                                                                                   \
     }                                                                                                                \
     hipLaunchKernelGGL((k_wattn2_bwd<D_>), grid, blk, LDS, st, qkv, dout, dqkv, biasF, biasG, part, nwin, H, W, C,   \
-                       heads, shift, scale);                                                                         \
+                       heads, shift, scale, dbgp);                                                                   \
   }
   SR_WA(30) SR_WA(10) SR_WA(16) SR_WA(32)
 #undef SR_WA

@@ -20,8 +20,17 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, uns
   h = __builtin_bit_cast(unsigned, hv);
   l = __builtin_bit_cast(unsigned, lv);
 }
-__device__ __forceinline__ float pow2_scale(float mx) {     // 2^s with mx * 2^s in [8192, 16384); 1 for an all-zero group
-  return mx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / mx)), 100.f)) : 1.f;
+// Power-of-two block exponent of a group whose largest magnitude is mx (>= 0): 2^s with mx * 2^s in [8192, 16384),
+// straight from the exponent field (s <= 100; an all-zero group gets 2^100: its products are exact zeros).  The
+// exp2f(floorf(log2f(16384 / mx))) form of it was ~40 VALU instructions -- 46 of them per attention backward item, a
+// third of the kernel's vector instructions.
+__device__ __forceinline__ float pow2_scale(float mx) {
+  const int e = (int)(__builtin_bit_cast(unsigned, mx) >> 23);
+  return __builtin_bit_cast(float, (unsigned)min(267 - e, 227) << 23);
+}
+// 2^-s of a power of two 2^s, exact
+__device__ __forceinline__ float pow2_inv(float sc) {
+  return __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(unsigned, sc));
 }
 
 struct W2Geom {
@@ -71,7 +80,7 @@ __device__ __forceinline__ float w2_split_row(const float (&v)[8], u32x4& hi, u3
   for (int t = 0; t < 4; ++t) split2_pair(v[2 * t] * sc, v[2 * t + 1] * sc, h[t], l[t]);
   hi = u32x4{h[0], h[1], h[2], h[3]};
   lo = u32x4{l[0], l[1], l[2], l[3]};
-  return 1.0f / sc;
+  return pow2_inv(sc);
 }
 
 // position (0..63) of slot t (0..7) of the k octet of lane group g in k step JJ (32 positions): the positions lane
@@ -152,7 +161,7 @@ __device__ __forceinline__ void w2_fwd_body(const float* qkv, float* out,
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float sc = pow2_scale(mx);
-    rvv[jd] = 1.0f / sc;
+    rvv[jd] = pow2_inv(sc);
 #pragma unroll
     for (int JJ = 0; JJ < 2; ++JJ) {
       unsigned h[4], l[4];
@@ -200,7 +209,7 @@ __device__ __forceinline__ void w2_fwd_body(const float* qkv, float* out,
       }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);
     f32x4 O[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int JJ = 0; JJ < 2; ++JJ) {

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(64 * NW * WPB, NW / 2) k_wmsa_f16(WmsaF16Args 
       mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
       asc = pow2_scale(mx);
     }
-    if (akq == 0) rinva[arow] = 1.0f / asc;
+    if (akq == 0) rinva[arow] = pow2_inv(asc);
     const int a_dst = a_slot(arow, akq) * 16;
 #pragma unroll
     for (int s6 = 0; s6 < 6; ++s6) {
