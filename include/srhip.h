@@ -161,6 +161,14 @@ int srhip_mlp_fwd_f16x2(const float* x, long ldx, const float* stats, const void
 int srhip_mlp_bwd_f16x2(const float* dy, long lddy, const void* W2Th, const void* W1Th, const float* h, long ldh,
                         float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
                         int M, int C, int hidden, const float* rowscale, int rows_per_scale, void* stream);
+/* srhip_mlp_bwd_f16x2 with a third product chained behind it in the same kernel: out3 = s3 * (dx . W3^T), the data
+ * gradient of the Linear whose output feeds this block's residual (the attention's proj: W3h = planes of Wproj^T [C][C],
+ * rowscale3 = the DropPath multipliers of the attention branch, same rows_per_scale).  dx goes from the registers that
+ * hold it into the third product's operand images: one launch, one read of dx less.  out3 [M][ld3], != dx. */
+int srhip_mlp_bwd_chain_f16x2(const float* dy, long lddy, const void* W2Th, const void* W1Th, const float* h, long ldh,
+                              float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
+                              int M, int C, int hidden, const float* rowscale, int rows_per_scale, const void* W3h,
+                              float* out3, long ld3, const float* rowscale3, void* stream);
 /* The W-MSA half of a Swin block, forward, in one kernel (wmsa_f16.hip): one thread block per 8x8 window computes
  *   qkv = LN(x) . Wqkv^T + bqkv  (stats[T][2] = {mean, rstd} of x; Wqkv gamma-folded, bqkv beta-folded),
  *   att = softmax(q k^T / sqrt(D) + bias + shift mask) v  per head (cyclic shift 0 or 4, as srhip_window_attention_fwd_f16x2),

@@ -73,6 +73,8 @@ struct MlpF16Args {
   const float* rowscale; int rows_per_scale;   // DropPath multipliers per sample (null = 1)
   float* stats_out;                  // forward: {mean, rstd} of the out rows (may be null)
   int M, C, hid;
+  // backward, optional third product: out3 = s3 * (dx . W3^T), W3 = planes [C][C] (prep kind 3)
+  const unsigned short* W3; float* out3; long ld3; const float* rowscale3;
   long long* dbg;                    // experiment builds: phase timestamps
 };
 int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st);

@@ -38,7 +38,7 @@ constexpr int APL = BM * 64;           // bytes of one plane of a stage image (6
 constexpr int AST = 2 * APL;           // a stage image: two planes
 constexpr int TP = 196;                // pitch of the output tile (floats): rows 4 apart land 16 banks apart
 constexpr int R0 = BM * TP * 4;        // the shared region (>= 6 stage images)
-constexpr int MLP_LDS = R0 + (4 * 64 + 64 + 64) * 4;
+constexpr int MLP_LDS = R0 + (4 * 64 + 64 + 64 + 64) * 4;
 static_assert(R0 >= 6 * AST, "LDS region");
 
 __device__ __forceinline__ f32x4 mfma16h(u32x4 a, u32x4 b, f32x4 c) {
@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
   float* const smax = (float*)(smem + R0);           // [4 waves][64 tokens] maxima of |A2|
   float* const rinvx = smax + 256;                   // [64] 2^-s of the X rows (backward; forward: a constant)
   float* const rinv2 = rinvx + 64;                   // [64] 2^-s of the hidden rows
+  float* const rinv3 = rinv2 + 64;                   // [64] 2^-s of the dx rows (backward with the chained product)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
@@ -491,15 +492,104 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
     s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
     const float m1 = s1 * (1.0f / (float)C), m2 = s2 * (1.0f / (float)C);
-    if (m0 + row < p.M) {
+    float omx = 0.f;
 #pragma unroll
-      for (int k = 0; k < 12; ++k)
-        if (q * 48 + 4 * k < C) {
-          f32x4 o;
+    for (int k = 0; k < 12; ++k) {
+      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q * 48 + 4 * k < C) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = rr[k][e] + st.y * (dv[k][e] - m1 - xh[k][e] * m2);
-          *(f32x4*)(p.out + (long)gm * p.ldo + q * 48 + 4 * k) = o;
+        for (int e = 0; e < 4; ++e) o[e] = rr[k][e] + st.y * (dv[k][e] - m1 - xh[k][e] * m2);
+        if (m0 + row < p.M) *(f32x4*)(p.out + (long)gm * p.ldo + q * 48 + 4 * k) = o;
+      }
+      dv[k] = o;
+      omx = fmaxf(fmaxf(omx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    }
+    if (p.W3) {
+      // ---------------- chained third product: out3 = s3 (dx . W3^T), the data gradient of the Linear in front of this
+      // block's residual (the attention's proj): dx goes from the registers that hold it into the stage images
+      u32x4 fc0[3][2], fc1[3][2], fc2[3][2];
+      const long plane3 = (long)p.C * p.Kp1 * 2;
+      const float* const winv3 = (const float*)((const char*)p.W3 + 2 * plane3);
+      auto load_b3 = [&](int cs, u32x4 (&fb)[3][2]) {
+        const char* base = (const char*)p.W3 + (long)(2 * min(cs, nst1 - 1)) * p.C * 32;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+          for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane3 + boff2[jt]);
+      };
+      load_b3(0, fc0);
+      load_b3(1, fc1);
+      load_b3(2, fc2);
+      omx = fmaxf(omx, __shfl_xor(omx, 1, 64));
+      omx = fmaxf(omx, __shfl_xor(omx, 2, 64));
+      const float sc3 = omx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / omx)), 100.f)) : 1.f;
+      __syncthreads();                               // every thread has read its part of the tile
+      if (q == 0) rinv3[row] = 1.0f / sc3;
+#pragma unroll
+      for (int k6 = 0; k6 < 6; ++k6) {               // octet 6 q + k6 of the row: columns 48 q + 8 k6 .. + 7
+        const int kk = q * 48 + 8 * k6;
+        const f32x4 a = dv[2 * k6], b = dv[2 * k6 + 1];
+        unsigned hh[4], ll[4];
+        split2_pair(a[0] * sc3, a[1] * sc3, hh[0], ll[0]);
+        split2_pair(a[2] * sc3, a[3] * sc3, hh[1], ll[1]);
+        split2_pair(b[0] * sc3, b[1] * sc3, hh[2], ll[2]);
+        split2_pair(b[2] * sc3, b[3] * sc3, hh[3], ll[3]);
+        unsigned char* sa = smem + (kk >> 5) * AST + a_slot(row, (kk & 31) >> 3) * 16;
+        *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+        *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+      }
+      __syncthreads();
+      f32x4 acc3[4][3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto mma3 = [&](int s6, const u32x4 (&fb)[3][2]) {
+        const unsigned char* sa = smem + s6 * AST;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u32x4 fa[2];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off[i]);
+#define SR_TERM(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) acc3[i][j] = mfma16h(fa[PA], fb[j][PB], acc3[i][j]);
+          SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+#undef SR_TERM
         }
+      };
+      mma3(0, fc0); load_b3(3, fc0); __builtin_amdgcn_sched_barrier(0);
+      mma3(1, fc1); load_b3(4, fc1); __builtin_amdgcn_sched_barrier(0);
+      mma3(2, fc2); load_b3(5, fc2); __builtin_amdgcn_sched_barrier(0);
+      mma3(3, fc0); __builtin_amdgcn_sched_barrier(0);
+      mma3(4, fc1); __builtin_amdgcn_sched_barrier(0);
+      mma3(5, fc2);
+      __syncthreads();                               // every wave is done with the images
+      {
+        float wv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) wv[j] = winv3[min(wave * 48 + 16 * j + c, p.C - 1)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float ri = rinv3[16 * i + 4 * g + e];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) T[(16 * i + 4 * g + e) * TP + wave * 48 + 16 * j + c] = acc3[i][j][e] * (ri * wv[j]);
+          }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 12; ++it) {
+        const int idx = it * 256 + tid, prow = idx / 48, pcol = (idx - prow * 48) * 4;
+        const int gm3 = m0 + prow;
+        if (gm3 < p.M && pcol < C) {
+          f32x4 v = *(const f32x4*)(T + prow * TP + pcol);
+          const float s3 = p.rowscale3 ? p.rowscale3[gm3 / p.rows_per_scale] : 1.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= s3;
+          *(f32x4*)(p.out3 + (long)gm3 * p.ld3 + pcol) = v;
+        }
+      }
     }
   }
   SR_TS(14)

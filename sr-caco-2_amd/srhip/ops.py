@@ -347,9 +347,11 @@ def wmsa_fwd_f16(x, stats, Wq, bq, Wp, bp, biasF, qkv, att, out, B, H, W, heads,
     return out
 
 
-def mlp_bwd_f16(dy, W2T, W1T, h, dh, gh, x, stats, dx, rowscale=None, rows_per_scale=1):
+def mlp_bwd_f16(dy, W2T, W1T, h, dh, gh, x, stats, dx, rowscale=None, rows_per_scale=1, chain=None):
     """Data gradient of mlp_fwd_f16 in ONE kernel: dh = (s * dy @ W2) * gelu'(h), gh = gelu(h), dx = dy +
-    LayerNorm_backward(dh @ W1f; x, stats).  W2T = planes of W2^T [hidden, C], W1T = planes of (W1*gamma)^T [C, hidden]."""
+    LayerNorm_backward(dh @ W1f; x, stats).  W2T = planes of W2^T [hidden, C], W1T = planes of (W1*gamma)^T [C, hidden].
+    chain = (W3, out3, rowscale3): out3 = s3 * (dx @ W3^T) behind it in the same kernel (W3 = planes [C, C], format 1:
+    the data gradient of the attention's proj Linear)."""
     _chk(dy, h, dh, gh, x, stats, dx, rowscale)
     M, C = dy.shape
     hidden = h.shape[1]
@@ -358,12 +360,20 @@ def mlp_bwd_f16(dy, W2T, W1T, h, dh, gh, x, stats, dx, rowscale=None, rows_per_s
     assert x.shape == (M, C) and dx.shape == (M, C)
     args = (_p(dy), dy.stride(0), _p(W2T.planes), _p(W1T.planes), _p(h), h.stride(0), _p(dh), _p(gh), _p(x),
             x.stride(0), _p(stats), _p(dx), dx.stride(0), M, C, hidden, _p(rowscale), rows_per_scale, _st())
+    name = "srhip_mlp_bwd_f16x2"
+    if chain is not None:
+        W3, out3, rs3 = chain
+        _chk(out3, rs3)
+        assert W3.fmt == 1 and (W3.rows, W3.K) == (C, C) and out3.shape == (M, C)
+        args = args[:-1] + (_p(W3.planes), _p(out3), out3.stride(0), _p(rs3), _st())
+        name = "srhip_mlp_bwd_chain_f16x2"
     if probe.on("mlp_fused"):
-        with probe.timed(("mlp_fused", M, C, hidden, "bwd"), 4.0 * M * C * hidden,
-                         4.0 * (M * (3 * C + 3 * hidden) + 2 * C * hidden)):
-            call("srhip_mlp_bwd_f16x2", *args)
+        with probe.timed(("mlp_fused", M, C, hidden, "bwd" if chain is None else "bwd+proj"),
+                         4.0 * M * C * hidden + (0 if chain is None else 2.0 * M * C * C),
+                         4.0 * (M * (3 * C + 3 * hidden + (C if chain is not None else 0)) + 2 * C * hidden)):
+            call(name, *args)
     else:
-        call("srhip_mlp_bwd_f16x2", *args)
+        call(name, *args)
     return dx
 
 

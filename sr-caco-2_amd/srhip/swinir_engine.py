@@ -73,6 +73,8 @@ class SwinIREngine:
         # The W-MSA half, forward, as one kernel per block (wmsa_f16.hip): qkv Linear + window attention + proj Linear +
         # residual; q, k, v and the attention output are read back from L2 by the block that wrote them.  SRHIP_WMSA_F16=0:
         # the three separate launches.
+        # The proj Linear's data gradient chained behind the fused MLP backward (SRHIP_CHAIN_PROJ=0: its own launch)
+        self.chain_proj = os.environ.get("SRHIP_CHAIN_PROJ", "1") != "0"
         self.fuse_wmsa = (all(ops.wmsa_f16_fusable(self.C, b.num_heads) for b in self.blocks)
                           and os.environ.get("SRHIP_WMSA_F16", "1") != "0")
 
@@ -530,9 +532,11 @@ class SwinIREngine:
                 s2 = None if dp is None else dp[2 * bi + 1]
                 g1, gout = gbufs[(gi + 1) % nrot], gbufs[(gi + 2) % nrot]
                 # ---- MLP branch: x2 = x1 + s2*(gelu(h) W2^T + b2)
+                chained = self.fuse_mlp_h and self.chain_proj and getattr(ws[f"{bi}.wpT"], "fmt", 0) == 1
                 if self.fuse_mlp_h:
                     ops.mlp_bwd_f16(g, ws[f"{bi}.w2T"], ws[f"{bi}.w1T"], h, dh, gh, x1, st2, g1, rowscale=s2,
-                                    rows_per_scale=H * W)
+                                    rows_per_scale=H * W,
+                                    chain=(ws[f"{bi}.wpT"], da, s1) if chained else None)
                 else:
                     ops.gemm_nt(g, ws[f"{bi}.w2T"], None, out=dh, epi=3, R=h, rowscale=s2,
                                 rows_per_scale=H * W, aux=gh)
@@ -542,7 +546,8 @@ class SwinIREngine:
                         ops.gemm_nt(dh, ws[f"{bi}.w1T"], None, out=dxh)
                         ops.layernorm_bwd(dxh, x1, st2, g1, res=g)
                 # ---- attention branch: x1 = t + s1*(a Wp^T + bp)
-                ops.gemm_nt(g1, ws[f"{bi}.wpT"], None, out=da, epi=2, rowscale=s1, rows_per_scale=H * W)
+                if not chained:
+                    ops.gemm_nt(g1, ws[f"{bi}.wpT"], None, out=da, epi=2, rowscale=s1, rows_per_scale=H * W)
                 dbT = dbT_all[bi, :heads]
                 if ops.wattn_f16_ok(C, heads):
                     ops.window_attention_bwd_f16(qkv, da, dqkv, D.d[f"{bi}.biasF"], D.d[f"{bi}.biasG"], dbT, B, H,

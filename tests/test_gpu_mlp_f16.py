@@ -106,6 +106,44 @@ def test_mlp_f16_forward_and_backward(ops, M, C, hidden, nsamp):
     assert relerr(dx, dx_ref) < 5e-6
 
 
+@pytest.mark.parametrize("M,C,hidden,nsamp", [(4096, 180, 360, 4), (1000, 180, 360, 0), (333, 96, 256, 3), (77, 64, 196, 1),
+                                              (2048, 192, 384, 2)])
+def test_mlp_f16_backward_with_chained_product(ops, M, C, hidden, nsamp):
+    """srhip_mlp_bwd_chain_f16x2: the proj Linear's data gradient out3 = s3 * (dx @ W3^T) behind the MLP backward in
+    the same kernel, against float64 and against the unchained kernel (dx, dh, gh must not change at all)."""
+    cpu, dev, P, b1f, st = _problem(ops, M, C, hidden, nsamp)
+    rps = -(-M // nsamp) if nsamp else 1
+    dy = rnd(M, C)
+    _, h_ref, dx_ref, _, _ = _reference(cpu, M, rps, dy)
+    w3 = rnd(C, C, scale=0.1)
+    s3 = torch.rand(nsamp, generator=G) + 0.5 if nsamp else None
+    P3 = ops.Bx3(C, C, "cuda")
+    tb = ops.PrepTable()
+    tb.linear(w3.cuda(), P3, f16=True)
+    tb.build("cuda").run()
+    h = h_ref.float().cuda()
+    dyd = dy.cuda()
+    out = {}
+    for chained in (False, True):
+        dh = torch.full((M, hidden), float("nan"), device="cuda")
+        gh = torch.full((M, hidden), float("nan"), device="cuda")
+        dx = torch.full((M, C), float("nan"), device="cuda")
+        o3 = torch.full((M, C), float("nan"), device="cuda")
+        ops.mlp_bwd_f16(dyd, P["w2T"], P["w1T"], h, dh, gh, dev["x"], st, dx, rowscale=dev["s"], rows_per_scale=rps,
+                        chain=(P3, o3, None if s3 is None else s3.cuda()) if chained else None)
+        out[chained] = (dh, gh, dx, o3)
+    for a, b in zip(out[False][:3], out[True][:3]):
+        assert torch.equal(a, b)
+    ref3 = dx_ref @ w3.double().t()
+    if s3 is not None:
+        ref3 = ref3 * s3.double().repeat_interleave(rps)[:M, None]
+    assert relerr(out[True][3], ref3) < 5e-6
+    # the launch it replaces
+    o3u = torch.empty(M, C, device="cuda")
+    ops.gemm_nt(out[True][2], w3.cuda(), None, out=o3u, epi=2, rowscale=None if s3 is None else s3.cuda(), rows_per_scale=rps)
+    assert relerr(out[True][3], o3u) < 2e-6
+
+
 def test_mlp_f16_rows_decades_apart(ops):
     """Block exponents are per token row: rows whose magnitudes differ by 1e8 keep f32-grade accuracy relative to
     THEMSELVES (gradient rows; the forward's LayerNorm output has an a-priori range)."""
