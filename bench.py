@@ -260,7 +260,7 @@ def worker(args):
         desc = ("SwinIR x8 README config (embed 180, depths 6+6+6+6, heads 6, window 8, mlp 2, "
                 "pixelshuffledirect), LR 1x64x64 -> HR 1x512x512")
         opt_kind = args.optimizer or "sgd"    # README.md:152-159
-        kinds = ("gemm_nt", "linear_tn", "wattn", "conv_nt", "mlp_fused")
+        kinds = ("gemm_nt", "linear_tn", "wattn", "conv_nt", "mlp_fused", "wmsa_fused")
     else:
         from dlib.models.network_edsr_liif import EDSR_LIIF
         net = EDSR_LIIF(scale=scale).to(dev).train()

@@ -62,7 +62,9 @@ _KERNEL_OF_KIND = {
     "conv_tn": ("k_tnb", "3x3 conv weight gradient"),
     "linear_tn": ("k_tnb_grouped", "grouped Linear weight gradients"),
     "wattn": ("k_wattn", "window attention core"),
-    "mlp_fused": ("k_mlp", "fused LayerNorm -> fc1 -> GELU -> fc2 -> residual (and its backward)"),
+    "mlp_fused": ("k_mlp", "fused LayerNorm -> fc1 -> GELU -> fc2 -> residual (and its backward, with the proj data "
+                           "gradient chained)"),
+    "wmsa_fused": ("k_wmsa", "fused LayerNorm -> qkv -> window attention -> proj -> residual (forward)"),
 }
 
 
@@ -125,13 +127,22 @@ def collect():
         arith = ("fp16x2-split MFMA: two fp16 planes per operand, power-of-two scales per weight output channel and per "
                  "activation halo tile, three products, f32 accumulate (f32-equivalent flops; peak = fp16 dense / 3; frac "
                  "against the six-product bf16x3 ceiling 416.7 in frac_of_bf16x3_peak)")
+    if bx and (kind in ("mlp_fused", "wmsa_fused") or (kind == "wattn" and ops.WATTN_F16)):
+        peak = 2500.0 / 3.0
+        arith = ("fp16x2-split MFMA: two fp16 planes per operand under power-of-two block exponents, three products, f32 "
+                 "accumulate (f32-equivalent flops; peak = fp16 dense / 3)")
     if bx and kind == "gemm_nt" and ops.F16X2:      # three products on two fp16 planes: the ceiling of THIS algorithm is twice as high
         peak = 2500.0 / 3.0
         arith = ("fp16x2-split MFMA: two fp16 planes per operand under per-row power-of-two scales, three products, f32 "
                  "accumulate (f32-equivalent flops; peak = fp16 dense / 3; frac against the six-product bf16x3 ceiling "
                  "416.7 in frac_of_bf16x3_peak)")
     traffic, src = _pmc_traffic(stem)
-    out = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+    # the roofline that bounds this class: time >= max(algorithmic bytes / HBM peak, algorithmic flops / MFMA peak)
+    hbm_bound = by / (HBM_PEAK_GBS * 1e9) > fl / (peak * 1e12)
+    out = {"bound": "hbm" if hbm_bound else "mfma", "achieved": gbs if hbm_bound else tf,
+           "peak": HBM_PEAK_GBS if hbm_bound else peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+           "frac": gbs / HBM_PEAK_GBS if hbm_bound else tf / peak,
+           "mfma_side": {"achieved_tflops": tf, "peak_tflops": peak, "frac": tf / peak},
            "traffic": traffic, "traffic_source": src,
            "kernel": f"{stem.split('|')[0]}*: {what}; {arith}", "launches": n, "avg_launch_us": 1000.0 * ms / n,
            # achieved / frac above are priced on avg_launch_us as measured (conservative); an empty event pair on this
