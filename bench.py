@@ -284,7 +284,7 @@ def worker(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = args.graph and world == 1 and pg is None
+    use_graph = args.graph            # data-parallel runs too: the RCCL bucket all-reduces are captured with the step
     step_fn = ts.step_graph if use_graph else ts.step
     for _ in range(max(args.warmup, 2 if use_graph else 0)):   # graph: eager step, capture, then replays
         step_fn(lr_img, hr_img)

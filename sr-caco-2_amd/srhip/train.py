@@ -327,13 +327,12 @@ class TrainStep:
 
     def step_graph(self, lr_img, hr_img):
         """The same optimisation step replayed from a hipGraph: the ~330 launches of a SwinIR step are
-        captured once per (batch, shape) -- every buffer is persistent, DropPath masks are drawn on the
+        captured once per (batch, shape), the RCCL bucket all-reduces of a data-parallel run included -- every buffer is
+        persistent, DropPath masks are drawn on the
         device by captured generator ops, the learning rate and the applied-step counter live in device
         memory -- and replayed with ONE host call per step (the eager step costs the CPU ~8 ms of launch
         calls).  The first call for a shape runs one eager step (it creates the buffers), the second
         captures.  Results are those of step() bit for bit."""
-        if self.ddp:
-            raise NotImplementedError("step_graph: the RCCL bucket path is not captured; use step() under data parallelism")
         for t in self.loss_terms:
             # host-evaluated schedules would be frozen into the graph at capture time: the extended log barrier's t
             # (ELB.update_t(), dlib/losses/elb.py:92-122) of BoundedPrediction and of the Bhattacharyya histogram / KDE terms
@@ -350,7 +349,9 @@ class TrainStep:
         if st["g"] is None:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # under data parallelism the bucketed all-reduces are captured with the step: the side stream joins the
+            # capture through the events the reducer records; thread-local error mode keeps RCCL's watchdog thread out of it
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if self.ddp else "global"):
                 self._enqueue(st["lr"], st["hr"], None, host_side=False)
             st["g"] = g
         self.opt.step_count += 1

@@ -411,6 +411,21 @@ for mode in ("plain", "ddp"):
         assert cover[0][0] == 0 and cover[-1][1] == ts.fp.total and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
     torch.cuda.synchronize()
     out[mode] = (ts.fp.flat.clone(), ts.loss_buf.clone())
+# the captured step under data parallelism: the bucket all-reduces ride in the hipGraph; same bits as the eager steps
+os.environ["SRHIP_FORCE_DDP"] = "1"
+net = SwinIR(upscale=8, in_chans=1, img_size=16, window_size=8, depths=[2, 2], embed_dim=60, num_heads=[6, 6],
+             mlp_ratio=2, upsampler="pixelshuffledirect", drop_path_rate=0.0)
+net.load_state_dict(sd0, strict=True)
+net = net.cuda().train()
+tg = TrainStep(net, [("l1", 1.0)], process_group=dist.group.WORLD, world_size=1)
+tg.opt = Optimizer(tg.fp, "adam", lr=2e-4, wd=1e-4)
+for lr_img, hr_img in batches:          # eager, capture + replay, replay
+    tg.step_graph(lr_img, hr_img)
+torch.cuda.synchronize()
+assert tg._graph["g"] is not None
+assert torch.equal(tg.fp.flat, out["ddp"][0]) and torch.equal(tg.loss_buf, out["ddp"][1]), \
+    (tg.fp.flat - out["ddp"][0]).abs().max().item()
+print("ddp graph ok")
 d = (out["plain"][0] - out["ddp"][0]).abs().max().item()
 # every reduction is deterministic (no float atomics left in the step): same seed => same replica, bit for bit
 assert d == 0.0 and torch.equal(out["plain"][0], out["ddp"][0]) and torch.equal(out["plain"][1], out["ddp"][1]), d
@@ -444,4 +459,4 @@ def test_forced_ddp_single_rank_rccl_path_matches_plain_step(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, str(script), root, str(port)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    assert p.returncode == 0 and "ddp ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+    assert p.returncode == 0 and "ddp ok" in p.stdout and "ddp graph ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]

@@ -1,2 +1,2 @@
 #!/bin/bash
-SRHIP_LIB=$(pwd)/sr-caco-2_amd/lib/libsrhip_exp.so timeout 300 python tools/mb_nt_stamps.py 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_gpu_swinir.py -x -q -m gpu -k "ddp or graph" 2>&1 | tail -25
