@@ -169,6 +169,20 @@ int srhip_mlp_bwd_chain_f16x2(const float* dy, long lddy, const void* W2Th, cons
                               float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
                               int M, int C, int hidden, const float* rowscale, int rows_per_scale, const void* W3h,
                               float* out3, long ld3, const float* rowscale3, void* stream);
+/* ... and with a product in FRONT of it as well: the MLP's incoming gradient is itself computed in the kernel,
+ *   dy = res0 + LayerNorm_backward(X0 . W0^T; x0, stats0)     (written to dy [M][lddy]: the weight gradients read it)
+ * -- the data gradient of the qkv Linear of the Swin block BEHIND this one (X0 = dqkv [M][K0], W0h = planes of
+ * (Wqkv*gamma)^T [C][K0], x0 / stats0 = that block's input rows and their {mean, rstd}, res0 = the gradient arriving
+ * at its first residual), what srhip_gemm_nt_f16x2_lnbwd computes as its own launch.  One kernel then carries the
+ * data-gradient chain from one block's attention backward to the next one's: K0 in passes of 192 under a running row
+ * exponent, the rows go from registers into the operand images of the MLP backward.  W3h may be NULL (no chained
+ * product).  dy must not alias dx or res0. */
+int srhip_mlp_bwd_front_chain_f16x2(const float* X0, long ld0, int K0, const void* W0h, const float* x0, long ldx0,
+                                    const float* stats0, const float* res0, long ldres0, float* dy, long lddy,
+                                    const void* W2Th, const void* W1Th, const float* h, long ldh, float* dh, float* gh,
+                                    const float* x, long ldx, const float* stats, float* dx, long lddx, int M, int C,
+                                    int hidden, const float* rowscale, int rows_per_scale, const void* W3h, float* out3,
+                                    long ld3, const float* rowscale3, void* stream);
 /* The W-MSA half of a Swin block, forward, in one kernel (wmsa_f16.hip): one thread block per 8x8 window computes
  *   qkv = LN(x) . Wqkv^T + bqkv  (stats[T][2] = {mean, rstd} of x; Wqkv gamma-folded, bqkv beta-folded),
  *   att = softmax(q k^T / sqrt(D) + bias + shift mask) v  per head (cyclic shift 0 or 4, as srhip_window_attention_fwd_f16x2),

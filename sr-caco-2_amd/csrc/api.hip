@@ -206,6 +206,35 @@ int srhip_mlp_bwd_chain_f16x2(const float* dy, long lddy, const void* W2Th, cons
   return sr_mlp_f16(p, 1, (hipStream_t)stream);
 }
 
+int srhip_mlp_bwd_front_chain_f16x2(const float* X0, long ld0, int K0, const void* W0h, const float* x0, long ldx0,
+                                    const float* stats0, const float* res0, long ldres0, float* dy, long lddy,
+                                    const void* W2Th, const void* W1Th, const float* h, long ldh, float* dh, float* gh,
+                                    const float* x, long ldx, const float* stats, float* dx, long lddx, int M, int C,
+                                    int hidden, const float* rowscale, int rows_per_scale, const void* W3h, float* out3,
+                                    long ld3, const float* rowscale3, void* stream) {
+  SR_REQUIRE(X0 && W0h && x0 && stats0 && res0 && dy && W2Th && W1Th && h && dh && gh && x && stats && dx,
+             "mlp_bwd_front_chain_f16x2: null operand");
+  SR_REQUIRE(K0 > 0 && K0 % 4 == 0 && ld0 % 4 == 0 && ldx0 % 4 == 0 && ldres0 % 4 == 0,
+             "mlp_bwd_front_chain_f16x2: K0 and the front pitches must be multiples of 4 floats");
+  SR_REQUIRE(!W3h || (out3 && ld3 % 4 == 0 && out3 != dx), "mlp_bwd_front_chain_f16x2: chained product needs out3 (!= dx)");
+  SR_REQUIRE((!rowscale && !rowscale3) || rows_per_scale > 0, "mlp_bwd_front_chain_f16x2: rows_per_scale must be > 0");
+  SR_REQUIRE(dy != dx && dy != res0, "mlp_bwd_front_chain_f16x2: dy must not alias dx or res0");
+  SR_REQUIRE(sr_matmul_mode() == 0, "mlp_bwd_front_chain_f16x2: f32-accurate matmul mode only");
+  MlpF16Args p;
+  memset(&p, 0, sizeof(p));
+  p.X = dy; p.ldx = lddy;
+  p.W1 = (const unsigned short*)W2Th; p.N1 = hidden; p.K1 = C; p.Kp1 = sr_kp(C);
+  p.W2 = (const unsigned short*)W1Th; p.N2 = C; p.K2 = hidden; p.Kp2 = sr_kp(hidden);
+  p.H = (float*)h; p.ldh = ldh; p.dH = dh; p.GH = gh; p.out = dx; p.ldo = lddx;
+  p.R = x; p.ldr = ldx; p.R2 = dy; p.ldr2 = lddy; p.ep_stats = stats;
+  p.rowscale = rowscale; p.rows_per_scale = rows_per_scale;
+  p.M = M; p.C = C; p.hid = hidden;
+  p.W3 = (const unsigned short*)W3h; p.out3 = out3; p.ld3 = ld3; p.rowscale3 = rowscale3;
+  p.W0 = (const unsigned short*)W0h; p.K0 = K0; p.Kp0 = sr_kp(K0); p.X0 = X0; p.ld0 = ld0;
+  p.x0 = x0; p.ldx0 = ldx0; p.stats0 = stats0; p.res0 = res0; p.ldres0 = ldres0; p.out0 = dy; p.ldo0 = lddy;
+  return sr_mlp_f16(p, 1, (hipStream_t)stream);
+}
+
 static int conv3x3_split(int wfmt, const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
                            int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                            const float* rowscale, float alpha, void* stream) {

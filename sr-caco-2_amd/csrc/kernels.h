@@ -75,6 +75,10 @@ struct MlpF16Args {
   int M, C, hid;
   // backward, optional third product: out3 = s3 * (dx . W3^T), W3 = planes [C][C] (prep kind 3)
   const unsigned short* W3; float* out3; long ld3; const float* rowscale3;
+  // backward, optional front product: the dy rows are computed here, dy = res0 + LayerNorm_backward(X0 . W0^T; x0, stats0)
+  // (W0 = planes [C][K0], prep kind 3), written to out0 and used in place of X / R2
+  const unsigned short* W0; int K0, Kp0; const float* X0; long ld0;
+  const float* x0; long ldx0; const float* stats0; const float* res0; long ldres0; float* out0; long ldo0;
   long long* dbg;                    // experiment builds: phase timestamps
 };
 int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st);

@@ -135,6 +135,213 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
   };
   SR_TS(0)
   u32x4 fb0[3][2], fb1[3][2], fb2[3][2];
+  int a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = a_slot(16 * i + c, g) * 16;
+  float* const T = (float*)smem;
+
+  // LayerNorm backward on the row-major tile in LDS (affine folded into the weight in front of it), four lanes per row,
+  // 12 x 16 bytes each:  o = res + rstd (d - mean(d) - xhat mean(d xhat)),  xhat = (x - mean) rstd.  The rows are
+  // stored and stay in the registers of the threads that computed them; returns the largest |o| of the thread's part.
+  auto ln_bwd_rows = [&](const float* xp, long ldxp, const float* stp, const float* rp, long ldrp, float* op, long ldop,
+                         f32x4 (&dv)[12]) -> float {
+    const int row = tid >> 2, q = tid & 3;
+    const int gm = min(m0 + row, p.M - 1);
+    const float2 st = *(const float2*)(stp + 2 * (long)gm);
+    f32x4 xh[12], rr[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const int col = min(q * 48 + 4 * k, p.C - 4);
+      xh[k] = *(const f32x4*)(xp + (long)gm * ldxp + col);
+      rr[k] = *(const f32x4*)(rp + (long)gm * ldrp + col);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      dv[k] = *(const f32x4*)(T + row * TP + q * 48 + 4 * k);
+      const bool ok = q * 48 + 4 * k < p.C;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[k][e] = ok ? (xh[k][e] - st.x) * st.y : 0.f;
+        dv[k][e] = ok ? dv[k][e] : 0.f;
+        s1 += dv[k][e];
+        s2 += dv[k][e] * xh[k][e];
+      }
+    }
+    s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+    s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+    const float m1 = s1 * (1.0f / (float)p.C), m2 = s2 * (1.0f / (float)p.C);
+    float omx = 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q * 48 + 4 * k < p.C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rr[k][e] + st.y * (dv[k][e] - m1 - xh[k][e] * m2);
+        if (m0 + row < p.M) *(f32x4*)(op + (long)gm * ldop + q * 48 + 4 * k) = o;
+      }
+      dv[k] = o;
+      omx = fmaxf(fmaxf(omx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    }
+    return omx;
+  };
+  // a thread's 48 row values (octets 6 q .. 6 q + 5 of its row) -> the stage images under the row's block exponent
+  // (row maximum over the row's four lanes); returns nothing, the 2^-s of the row goes to rinv_dst
+  auto rows_to_images = [&](const f32x4 (&dv)[12], float omx, float* rinv_dst) {
+    const int row = tid >> 2, q = tid & 3;
+    omx = fmaxf(omx, __shfl_xor(omx, 1, 64));
+    omx = fmaxf(omx, __shfl_xor(omx, 2, 64));
+    const float sc = omx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / omx)), 100.f)) : 1.f;
+    if (q == 0) rinv_dst[row] = 1.0f / sc;
+#pragma unroll
+    for (int k6 = 0; k6 < 6; ++k6) {                 // octet 6 q + k6 of the row: columns 48 q + 8 k6 .. + 7
+      const int kk = q * 48 + 8 * k6;
+      const f32x4 a = dv[2 * k6], b = dv[2 * k6 + 1];
+      unsigned hh[4], ll[4];
+      split2_pair(a[0] * sc, a[1] * sc, hh[0], ll[0]);
+      split2_pair(a[2] * sc, a[3] * sc, hh[1], ll[1]);
+      split2_pair(b[0] * sc, b[1] * sc, hh[2], ll[2]);
+      split2_pair(b[2] * sc, b[3] * sc, hh[3], ll[3]);
+      unsigned char* sa = smem + (kk >> 5) * AST + a_slot(row, (kk & 31) >> 3) * 16;
+      *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+      *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    }
+  };
+
+  if (BWD && p.W0) {
+    // ---------------- front product (backward, optional): the dy rows of this MLP are themselves a Linear's data
+    // gradient + LayerNorm backward -- dy = res0 + LN_bwd(X0 . W0^T; x0, stats0), the qkv Linear of the Swin block behind
+    // this one -- computed here instead of read: k_nth2's pass loop (192 k per pass, running row exponent), the
+    // LayerNorm backward on the row-major tile, and the rows go from registers into GEMM 1's stage images.
+    float* const rscale0 = smax;                     // [64] rescale factor of the pass
+    float* const rinv0 = smax + 64;                  // [64] 2^-s of the X0 rows so far
+    const int nst0 = p.Kp0 / SK;
+    const long plane0 = (long)p.C * p.Kp0 * 2;
+    const float* const winv0 = (const float*)((const char*)p.W0 + 2 * plane0);
+    auto load_b0 = [&](int cs, u32x4 (&fb)[3][2]) {
+      const char* base = (const char*)p.W0 + (long)(2 * min(cs, nst0 - 1)) * p.C * 32;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane0 + boff2[jt]);
+    };
+    load_b0(0, fb0);
+    load_b0(1, fb1);
+    load_b0(2, fb2);
+    f32x4 acc0[4][3];
+    const int arow = tid >> 2, akq = tid & 3;
+    const char* const abase = (const char*)p.X0 + (long)min(m0 + arow, p.M - 1) * p.ld0 * 4;
+    const int a_dst = a_slot(arow, akq) * 16;
+    float asc = 3.0e38f;                             // this row's current 2^s (the same in the row's four threads)
+    const int npass = (nst0 + 5) / 6;
+    for (int pass = 0; pass < npass; ++pass) {
+      const int cs0 = pass * 6;
+      if (pass) __syncthreads();                     // every wave is done with the previous pass's images
+      {
+        f32x4 ra[6][2];
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) {
+          const int k = (cs0 + s6) * SK + akq * 8;
+          ra[s6][0] = *(const f32x4*)(abase + (k < p.K0 ? k * 4 : 0));
+          ra[s6][1] = *(const f32x4*)(abase + (k + 4 < p.K0 ? (k + 4) * 4 : 0));
+        }
+        float mx = 0.f;
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) {
+          const int k = (cs0 + s6) * SK + akq * 8;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            f32x4 x = ra[s6][e];
+            if (k + 4 * e >= p.K0) x = f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[s6][e] = x;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
+          }
+        }
+        const float old = asc;
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        const float need = mx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / mx)), 100.f)) : 3.0e38f;
+        asc = fminf(asc, need);
+        const float use = asc > 1.0e38f ? 1.f : asc;
+        if (akq == 0) {
+          rscale0[arow] = (old > 1.0e38f || old == asc) ? 1.f : asc / old;
+          rinv0[arow] = 1.0f / use;
+        }
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) {
+          unsigned hh[4], ll[4];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const f32x4 x = ra[s6][e];
+            split2_pair(x.x * use, x.y * use, hh[2 * e], ll[2 * e]);
+            split2_pair(x.z * use, x.w * use, hh[2 * e + 1], ll[2 * e + 1]);
+          }
+          unsigned char* sa = smem + s6 * AST + a_dst;
+          *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+          *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+        }
+      }
+      __syncthreads();
+      if (pass == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc0[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {                                       // rows whose scale dropped: bring what is accumulated to the new scale
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float f = rscale0[16 * i + 4 * g + e];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc0[i][j][e] *= f;
+          }
+      }
+      auto mma0 = [&](int s6, const u32x4 (&fb)[3][2]) {
+        const unsigned char* sa = smem + s6 * AST;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u32x4 fa[2];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off[i]);
+#define SR_TERM(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) acc0[i][j] = mfma16h(fa[PA], fb[j][PB], acc0[i][j]);
+          SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+#undef SR_TERM
+        }
+      };
+#define SR_STAGE(S, FB)                                              \
+      if (cs0 + (S) < nst0) {                                        \
+        mma0((S), FB);                                               \
+        if (cs0 + (S) + 3 < nst0) load_b0(cs0 + (S) + 3, FB);        \
+        __builtin_amdgcn_sched_barrier(0);                           \
+      }
+      SR_STAGE(0, fb0) SR_STAGE(1, fb1) SR_STAGE(2, fb2) SR_STAGE(3, fb0) SR_STAGE(4, fb1) SR_STAGE(5, fb2)
+#undef SR_STAGE
+    }
+    __syncthreads();
+    {
+      float wv[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) wv[j] = winv0[min(wave * 48 + 16 * j + c, p.C - 1)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ri = rinv0[16 * i + 4 * g + e];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) T[(16 * i + 4 * g + e) * TP + wave * 48 + 16 * j + c] = acc0[i][j][e] * (ri * wv[j]);
+        }
+    }
+    __syncthreads();
+    f32x4 dv[12];
+    const float omx = ln_bwd_rows(p.x0, p.ldx0, p.stats0, p.res0, p.ldres0, p.out0, p.ldo0, dv);
+    __syncthreads();                                 // every thread has read its part of the tile
+    rows_to_images(dv, omx, rinvx);
+    load_b1(0, fb0);
+    load_b1(1, fb1);
+    load_b1(2, fb2);
+  } else {
   load_b1(0, fb0);
   load_b1(1, fb1);
   load_b1(2, fb2);
@@ -189,13 +396,10 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
     }
   }
+  }
   SR_TS(1)
   __syncthreads();
   SR_TS(2)
-
-  int a_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) a_off[i] = a_slot(16 * i + c, g) * 16;
 
   // ---------------- GEMM 1, transposed: acc1[hh][i][j] = hidden units 192 hh + 48 wave + 16 j + 4 g + e of token 16 i + c
   f32x4 acc1[2][4][3];
@@ -391,7 +595,6 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
   // ---------------- the output tile, row-major in LDS (block exponents undone: exact powers of two)
   __syncthreads();
   SR_TS(12)
-  float* const T = (float*)smem;
   {
     float wv[3];
 #pragma unroll
@@ -463,47 +666,9 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
         *(float2*)(p.stats_out + 2 * (long)(m0 + row)) = float2{mean, rsqrtf(s2 * (1.0f / (float)C) + 1e-5f)};
     }
   } else {
-    // dx = dy + rstd (dxh - mean(dxh) - xhat mean(dxh xhat)),  xhat = (x - mean) rstd  (LayerNorm backward with the
-    // affine folded into W1): four lanes per row, 12 x 16 bytes each
-    const int row = tid >> 2, q = tid & 3;
-    const int gm = min(m0 + row, p.M - 1);
-    const float2 st = *(const float2*)(p.ep_stats + 2 * (long)gm);
-    f32x4 xh[12], rr[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      const int col = min(q * 48 + 4 * k, C - 4);
-      xh[k] = *(const f32x4*)(p.R + (long)gm * p.ldr + col);
-      rr[k] = *(const f32x4*)(p.R2 + (long)gm * p.ldr2 + col);
-    }
+    // dx = dy + LayerNorm_backward(dxh; x, stats)  (the affine folded into W1)
     f32x4 dv[12];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      dv[k] = *(const f32x4*)(T + row * TP + q * 48 + 4 * k);
-      const bool ok = q * 48 + 4 * k < C;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        xh[k][e] = ok ? (xh[k][e] - st.x) * st.y : 0.f;
-        dv[k][e] = ok ? dv[k][e] : 0.f;
-        s1 += dv[k][e];
-        s2 += dv[k][e] * xh[k][e];
-      }
-    }
-    s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
-    s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
-    const float m1 = s1 * (1.0f / (float)C), m2 = s2 * (1.0f / (float)C);
-    float omx = 0.f;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (q * 48 + 4 * k < C) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rr[k][e] + st.y * (dv[k][e] - m1 - xh[k][e] * m2);
-        if (m0 + row < p.M) *(f32x4*)(p.out + (long)gm * p.ldo + q * 48 + 4 * k) = o;
-      }
-      dv[k] = o;
-      omx = fmaxf(fmaxf(omx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
-    }
+    float omx = ln_bwd_rows(p.R, p.ldr, p.ep_stats, p.R2, p.ldr2, p.out, p.ldo, dv);
     if (p.W3) {
       // ---------------- chained third product: out3 = s3 (dx . W3^T), the data gradient of the Linear in front of this
       // block's residual (the attention's proj): dx goes from the registers that hold it into the stage images
@@ -520,24 +685,8 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       load_b3(0, fc0);
       load_b3(1, fc1);
       load_b3(2, fc2);
-      omx = fmaxf(omx, __shfl_xor(omx, 1, 64));
-      omx = fmaxf(omx, __shfl_xor(omx, 2, 64));
-      const float sc3 = omx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / omx)), 100.f)) : 1.f;
       __syncthreads();                               // every thread has read its part of the tile
-      if (q == 0) rinv3[row] = 1.0f / sc3;
-#pragma unroll
-      for (int k6 = 0; k6 < 6; ++k6) {               // octet 6 q + k6 of the row: columns 48 q + 8 k6 .. + 7
-        const int kk = q * 48 + 8 * k6;
-        const f32x4 a = dv[2 * k6], b = dv[2 * k6 + 1];
-        unsigned hh[4], ll[4];
-        split2_pair(a[0] * sc3, a[1] * sc3, hh[0], ll[0]);
-        split2_pair(a[2] * sc3, a[3] * sc3, hh[1], ll[1]);
-        split2_pair(b[0] * sc3, b[1] * sc3, hh[2], ll[2]);
-        split2_pair(b[2] * sc3, b[3] * sc3, hh[3], ll[3]);
-        unsigned char* sa = smem + (kk >> 5) * AST + a_slot(row, (kk & 31) >> 3) * 16;
-        *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
-        *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
-      }
+      rows_to_images(dv, omx, rinv3);
       __syncthreads();
       f32x4 acc3[4][3];
 #pragma unroll

@@ -347,11 +347,13 @@ def wmsa_fwd_f16(x, stats, Wq, bq, Wp, bp, biasF, qkv, att, out, B, H, W, heads,
     return out
 
 
-def mlp_bwd_f16(dy, W2T, W1T, h, dh, gh, x, stats, dx, rowscale=None, rows_per_scale=1, chain=None):
+def mlp_bwd_f16(dy, W2T, W1T, h, dh, gh, x, stats, dx, rowscale=None, rows_per_scale=1, chain=None, front=None):
     """Data gradient of mlp_fwd_f16 in ONE kernel: dh = (s * dy @ W2) * gelu'(h), gh = gelu(h), dx = dy +
     LayerNorm_backward(dh @ W1f; x, stats).  W2T = planes of W2^T [hidden, C], W1T = planes of (W1*gamma)^T [C, hidden].
     chain = (W3, out3, rowscale3): out3 = s3 * (dx @ W3^T) behind it in the same kernel (W3 = planes [C, C], format 1:
-    the data gradient of the attention's proj Linear)."""
+    the data gradient of the attention's proj Linear).
+    front = (X0, W0, x0, stats0, res0): dy is COMPUTED in the kernel (and written): dy = res0 + LayerNorm_backward(X0 @
+    W0^T; x0, stats0) -- the qkv Linear's data gradient of the Swin block behind this one (W0 = planes [C, K0])."""
     _chk(dy, h, dh, gh, x, stats, dx, rowscale)
     M, C = dy.shape
     hidden = h.shape[1]
@@ -367,10 +369,22 @@ def mlp_bwd_f16(dy, W2T, W1T, h, dh, gh, x, stats, dx, rowscale=None, rows_per_s
         assert W3.fmt == 1 and (W3.rows, W3.K) == (C, C) and out3.shape == (M, C)
         args = args[:-1] + (_p(W3.planes), _p(out3), out3.stride(0), _p(rs3), _st())
         name = "srhip_mlp_bwd_chain_f16x2"
+    if front is not None:
+        X0, W0, x0, st0, res0 = front
+        _chk(X0, x0, st0, res0)
+        K0 = X0.shape[1]
+        assert W0.fmt == 1 and (W0.rows, W0.K) == (C, K0) and X0.shape[0] == M and x0.shape == (M, C) == res0.shape
+        if chain is None:
+            args = args[:-1] + (None, None, 0, None, _st())
+        args = (_p(X0), X0.stride(0), K0, _p(W0.planes), _p(x0), x0.stride(0), _p(st0), _p(res0), res0.stride(0)) + args
+        name = "srhip_mlp_bwd_front_chain_f16x2"
     if probe.on("mlp_fused"):
-        with probe.timed(("mlp_fused", M, C, hidden, "bwd" if chain is None else "bwd+proj"),
-                         4.0 * M * C * hidden + (0 if chain is None else 2.0 * M * C * C),
-                         4.0 * (M * (3 * C + 3 * hidden + (C if chain is not None else 0)) + 2 * C * hidden)):
+        tag = ("qkv+" if front is not None else "") + "bwd" + ("+proj" if chain is not None else "")
+        k0 = front[0].shape[1] if front is not None else 0
+        with probe.timed(("mlp_fused", M, C, hidden, tag),
+                         4.0 * M * C * hidden + (0 if chain is None else 2.0 * M * C * C) + 2.0 * M * C * k0,
+                         4.0 * (M * (3 * C + 3 * hidden + (C if chain is not None else 0) + (k0 + 2 * C if front else 0))
+                                + 2 * C * hidden)):
             call(name, *args)
     else:
         call(name, *args)

@@ -75,6 +75,8 @@ class SwinIREngine:
         # the three separate launches.
         # The proj Linear's data gradient chained behind the fused MLP backward (SRHIP_CHAIN_PROJ=0: its own launch)
         self.chain_proj = os.environ.get("SRHIP_CHAIN_PROJ", "1") != "0"
+        # ... and the qkv Linear's data gradient + LayerNorm backward of the block behind in FRONT of it (SRHIP_FRONT_QKV=0)
+        self.front_qkv = os.environ.get("SRHIP_FRONT_QKV", "1") != "0"
         self.fuse_wmsa = (all(ops.wmsa_f16_fusable(self.C, b.num_heads) for b in self.blocks)
                           and os.environ.get("SRHIP_WMSA_F16", "1") != "0")
 
@@ -514,6 +516,7 @@ class SwinIREngine:
                           g.view(B, H, W, C))
             nb = len(layer.residual_group.blocks)
             pending = []                 # weight-gradient problems of the layer's blocks (deferred form)
+            front = None                 # a block's qkv data gradient handed to the next block's fused MLP backward
             # partial bias-gradient tiles of the layer's blocks: reduced by ONE launch per layer (same head count only)
             lheads = {blk.num_heads for blk in layer.residual_group.blocks}
             dparts = None
@@ -534,9 +537,12 @@ class SwinIREngine:
                 # ---- MLP branch: x2 = x1 + s2*(gelu(h) W2^T + b2)
                 chained = self.fuse_mlp_h and self.chain_proj and getattr(ws[f"{bi}.wpT"], "fmt", 0) == 1
                 if self.fuse_mlp_h:
+                    # `front`: the qkv Linear's data gradient + LayerNorm backward of the block behind this one (its
+                    # result is this MLP's incoming gradient g) runs as the first phase of the same kernel
                     ops.mlp_bwd_f16(g, ws[f"{bi}.w2T"], ws[f"{bi}.w1T"], h, dh, gh, x1, st2, g1, rowscale=s2,
                                     rows_per_scale=H * W,
-                                    chain=(ws[f"{bi}.wpT"], da, s1) if chained else None)
+                                    chain=(ws[f"{bi}.wpT"], da, s1) if chained else None, front=front)
+                    front = None
                 else:
                     ops.gemm_nt(g, ws[f"{bi}.w2T"], None, out=dh, epi=3, R=h, rowscale=s2,
                                 rows_per_scale=H * W, aux=gh)
@@ -556,7 +562,10 @@ class SwinIREngine:
                 else:
                     ops.window_attention_bwd(qkv, da, dqkv, D.d[f"{bi}.biasT"], D.d[f"{bi}.biasN"], dbT, B, H,
                                              W, C, heads, blk.shift_size)
-                if ws.use_bx3:
+                if (ws.use_bx3 and self.fuse_mlp_h and self.front_qkv and j > 0
+                        and getattr(ws[f"{bi}.wqT"], "fmt", 0) == 1 and not ops.lib.srhip_get_matmul_mode()):
+                    front = (dqkv, ws[f"{bi}.wqT"], t, st1, g1)       # -> gout, inside the next block's MLP backward
+                elif ws.use_bx3:
                     ops.gemm_nt_lnbwd(dqkv, ws[f"{bi}.wqT"], t, st1, g1, gout)
                 else:
                     ops.gemm_nt(dqkv, ws[f"{bi}.wqT"], None, out=dxh)

@@ -144,6 +144,63 @@ def test_mlp_f16_backward_with_chained_product(ops, M, C, hidden, nsamp):
     assert relerr(out[True][3], o3u) < 2e-6
 
 
+@pytest.mark.parametrize("M,C,hidden,nsamp,chain", [(4096, 180, 360, 4, True), (1000, 180, 360, 0, True), (333, 96, 256, 3, False),
+                                                    (77, 64, 196, 1, True), (2048, 192, 384, 2, False)])
+def test_mlp_f16_backward_with_front_product(ops, M, C, hidden, nsamp, chain):
+    """srhip_mlp_bwd_front_chain_f16x2: the incoming gradient dy = res0 + LayerNorm_backward(X0 @ W0^T; x0, stats0) is
+    computed in the kernel (the qkv Linear's data gradient of the Swin block behind), against float64 and against the
+    two launches it replaces (everything behind dy must then be bit-identical: dy itself is compared to tolerance)."""
+    cpu, dev, P, b1f, st = _problem(ops, M, C, hidden, nsamp)
+    rps = -(-M // nsamp) if nsamp else 1
+    K0 = 3 * C
+    X0 = rnd(M, K0) * torch.exp(rnd(M, 1))           # rows decades apart, and the three 192-k passes differ in scale
+    X0[:, :C] *= 30.0
+    w0 = rnd(C, K0, scale=0.08)
+    x0 = rnd(M, C) * 1.3 + rnd(M, 1)
+    res0 = rnd(M, C)
+    w3 = rnd(C, C, scale=0.1)
+    s3 = torch.rand(nsamp, generator=G) + 0.5 if nsamp else None
+    P0, P3 = ops.Bx3(C, K0, "cuda"), ops.Bx3(C, C, "cuda")
+    tb = ops.PrepTable()
+    tb.linear(w0.cuda(), P0, f16=True)
+    tb.linear(w3.cuda(), P3, f16=True)
+    tb.build("cuda").run()
+    st0 = torch.empty(M, 2, device="cuda")
+    ops.layernorm_fwd(x0.cuda(), st0)
+    # float64 reference of dy
+    x0d = x0.double().requires_grad_(True)
+    xn = F.layer_norm(x0d, (C,), None, None, 1e-5)
+    xn.backward(X0.double() @ w0.double().t())
+    dy_ref = res0.double() + x0d.grad
+    _, h_ref, dx_ref, dh_ref, gh_ref = _reference(cpu, M, rps, dy_ref)
+    h = h_ref.float().cuda()
+    ch = (P3, None, None if s3 is None else s3.cuda()) if chain else None
+
+    def run(front):
+        dy = torch.full((M, C), float("nan"), device="cuda")
+        dh = torch.full((M, hidden), float("nan"), device="cuda")
+        gh = torch.full((M, hidden), float("nan"), device="cuda")
+        dx = torch.full((M, C), float("nan"), device="cuda")
+        o3 = torch.full((M, C), float("nan"), device="cuda")
+        if not front:
+            ops.gemm_nt_lnbwd(X0.cuda(), P0, x0.cuda(), st0, res0.cuda(), dy)
+        ops.mlp_bwd_f16(dy, P["w2T"], P["w1T"], h, dh, gh, dev["x"], st, dx, rowscale=dev["s"], rows_per_scale=rps,
+                        chain=(ch[0], o3, ch[2]) if chain else None,
+                        front=(X0.cuda(), P0, x0.cuda(), st0, res0.cuda()) if front else None)
+        return dy, dh, gh, dx, o3
+    fused = run(True)
+    assert relerr(fused[0], dy_ref) < 4e-6
+    assert relerr(fused[1], dh_ref) < 8e-6 and relerr(fused[2], gh_ref) < 2e-6 and relerr(fused[3], dx_ref) < 8e-6
+    if C in (180, 192):          # the stand-alone Linear kernel takes 192-column tiles only
+        sep = run(False)
+        assert relerr(fused[0], sep[0]) < 2e-6 and relerr(fused[1], sep[1]) < 4e-6 and relerr(fused[3], sep[3]) < 4e-6
+    if chain:
+        ref3 = dx_ref @ w3.double().t()
+        if s3 is not None:
+            ref3 = ref3 * s3.double().repeat_interleave(rps)[:M, None]
+        assert relerr(fused[4], ref3) < 8e-6
+
+
 def test_mlp_f16_rows_decades_apart(ops):
     """Block exponents are per token row: rows whose magnitudes differ by 1e8 keep f32-grade accuracy relative to
     THEMSELVES (gradient rows; the forward's LayerNorm output has an a-priori range)."""
