@@ -139,7 +139,6 @@ int srhip_mlp_fwd_f16x2(const float* x, long ldx, const float* stats, const void
                         int hidden, const float* rowscale, int rows_per_scale, float* stats_out, void* stream) {
   SR_REQUIRE(x && stats && W1h && b1 && W2h && out, "mlp_fwd_f16x2: null operand");
   SR_REQUIRE(!rowscale || rows_per_scale > 0, "mlp_fwd_f16x2: rows_per_scale must be > 0");
-  SR_REQUIRE(sr_matmul_mode() == 0, "mlp_fwd_f16x2: f32-accurate matmul mode only");
   MlpF16Args p;
   memset(&p, 0, sizeof(p));
   p.X = x; p.ldx = ldx; p.ln_stats = stats;
@@ -157,7 +156,6 @@ int srhip_wmsa_fwd_f16x2(const float* x, const float* stats, const void* Wqkvh, 
                          void* stream) {
   SR_REQUIRE(x && stats && Wqkvh && bqkv && Wprojh && biasF && qkv && att && out, "wmsa_fwd_f16x2: null operand");
   SR_REQUIRE(out != x, "wmsa_fwd_f16x2: out must not alias x (windows read the residual while others write)");
-  SR_REQUIRE(sr_matmul_mode() == 0, "wmsa_fwd_f16x2: f32-accurate matmul mode only");
   WmsaF16Args p;
   memset(&p, 0, sizeof(p));
   p.X = x; p.ln_stats = stats;

@@ -297,7 +297,8 @@ class SwinIREngine:
                 a = buf(f"{k}.a", T, C)
                 x1 = buf(f"{k}.x1", T, C)
                 st2 = buf(f"{k}.st2", T, 2)
-                if self.fuse_wmsa and fuse and not ops.lib.srhip_get_matmul_mode():
+                # (under --amp too: the fused kernels keep their three products -- faster than the separate one-product launches)
+                if self.fuse_wmsa and fuse:
                     ops.wmsa_fwd_f16(t, st1, ws[f"{bi}.wq"], D.d[f"{bi}.bq"], ws[f"{bi}.wproj"],
                                      blk.attn.proj.bias.data, D.d[f"{bi}.biasF"], qkv, a, x1, B, H, W, heads,
                                      blk.shift_size, rowscale=s1, stats_out=st2)
@@ -316,7 +317,7 @@ class SwinIREngine:
                 st_next = None
                 if fuse and j + 1 < nblk:
                     st_next = buf(f"{(bi + 1) if save else (bi + 1) % 2}.st1", T, 2)
-                if self.fuse_mlp_h and not ops.lib.srhip_get_matmul_mode():
+                if self.fuse_mlp_h:
                     h = buf(f"{k}.h", T, hid) if save else None       # inference never reads it
                     ops.mlp_fwd_f16(x1, st2, ws[f"{bi}.w1"], D.d[f"{bi}.b1"], ws[f"{bi}.w2"], blk.mlp.fc2.bias.data,
                                     x2, h=h, rowscale=s2, rows_per_scale=H * W, stats_out=st_next)
