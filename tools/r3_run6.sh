@@ -1,2 +1,3 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_gpu_amp.py -x -q -m gpu -s 2>&1 | grep -i "amp vs\|passed\|failed" | head
+bash tools/step_mfma_pmc.sh gpurun_out/mfma_swinir swinir_x8 2>&1 | tail -14
+bash tools/step_mfma_pmc.sh gpurun_out/mfma_edsr8 edsr_x8 2>&1 | tail -10
