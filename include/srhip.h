@@ -331,6 +331,16 @@ int srhip_axpby2d(float* y, long ldy, const float* x, long ldx, long rows, int c
  * [B][H+2][W+2][C] -> [B][H][W][C]; adjoint: zero-bordered placement. */
 int srhip_pad_reflect1(const float* in, float* out, int B, int H, int W, int C, int adjoint, void* stream);
 int srhip_crop1(const float* in, float* out, int B, int H, int W, int C, int adjoint, void* stream);
+/* The element-wise pieces of ENLCA (Efficient Non-Local Contrastive Attention, network_enlcn.py:207-366) around its dense
+ * products, token rows [T][.], in place where noted:
+ *   srhip_l2norm_rows        x[t] <- k * x[t] / max(|x[t]|_2, eps)                 (F.normalize(dim=channel) * sqrt(6), :341-342)
+ *   srhip_performer_features dash[t][j] <- ratio * (exp(dash[t][j] - |data[t]|^2 / 2) + eps)   (softmax_kernel :207-240)
+ *   srhip_enlca_finish       out[t][c] = x[t][c] + res_scale * num[t][c] / num[t][Cy]  (linear_attention :243-248 with the
+ *                            normaliser carried as column Cy of the numerator product, + the residual :364-365) */
+int srhip_l2norm_rows(float* x, long ld, long T, int C, float eps, float k, void* stream);
+int srhip_performer_features(float* dash, long ldd, const float* data, long ldx, long T, int F, int C, float ratio, float eps,
+                             void* stream);
+int srhip_enlca_finish(const float* num, long ldn, const float* x, float* out, long T, int Cy, float res_scale, void* stream);
 
 /* ---- window attention on the two-plane fp16 split MFMA (wattn2.hip) -------------- */
 /* The same contract as srhip_window_attention_fwd (network_swinir.py:48-80,153-176,297-331) with the two

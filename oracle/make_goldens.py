@@ -1356,6 +1356,36 @@ def _import_ref_dataset():
     return ref_ds
 
 
+def g_enlcn():
+    """ENLCN (network_enlcn.py): EDSR body with ENLCA blocks.  A narrow configuration (8 ResBlocks, 64 features: ENLCA at
+    body.0 and body.9, 16-dim embeddings against a 128 x 16 projection matrix) has every op class of the registry's net;
+    weights and projection matrices from the oracle's seeded initialiser loaded into the reference net.  Forward only
+    (the sweep of BASELINE config 5 evaluates it); the training-mode forward returns the same tensor (the contrastive
+    term is dropped, :434-437)."""
+    print("G33 ENLCN")
+    from dlib.models.network_enlcn import ENLCN as RefENLCN
+    out = {}
+    cfg = dict(n_resblock=8, n_feats=64)
+    for scale in (2, 4, 8):
+        sd = O.enlcn_init_state_dict(scale, 1, seed=330 + scale, **cfg)
+        net = RefENLCN(upscale=scale, in_chans=1, **cfg)
+        ref_keys = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        assert ref_keys == [(k, tuple(v.shape)) for k, v in sd.items()], "ENLCN state_dict layout / order"
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(340 + scale)
+        x = torch.rand(2, 1, 20, 24)
+        with torch.no_grad():
+            y = net.eval()(x)
+            yt = net.train()(x)
+            yo = O.enlcn_forward(sd, x, scale, cfg["n_resblock"], 0.1)
+        close(yo, y, 0.0, f"enlcn x{scale} forward")
+        close(yt, y, 0.0, f"enlcn x{scale} training-mode forward")
+        pre = f"x{scale}/"
+        out[pre + "x"], out[pre + "y"], out[pre + "seed"] = x, y, np.array(330 + scale)
+    out["state_dict_keys_default"] = np.array([k for k in RefENLCN(upscale=2, in_chans=1).state_dict().keys()])
+    npz("g33_enlcn", **out)
+
+
 def g_lowres():
     """The low-resolution side of DatasetDPSR items (dataset_dpsr.py:592-645,684-744,1037-1180): outputs of the
     reference's own functions on seeded inputs -- the fixtures of sr-caco-2_amd/dlib/datasets/lowres.py."""
@@ -1634,7 +1664,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_enlcn, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

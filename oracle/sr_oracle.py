@@ -725,6 +725,108 @@ def prosr_init_state_dict(cfg: dict, seed: int = 0, bias_std: float = 0.0) -> SD
 
 
 # ----------------------------------------------------------------------------
+# ENLCN (dlib/models/network_enlcn.py): EDSR body with Efficient Non-Local Contrastive Attention blocks
+def _enlca(sd: SD, pre: str, x: Tensor, res_scale: float) -> Tensor:
+    """ENLCA.forward in evaluation mode (network_enlcn.py:330-366; the contrastive term of training mode is dropped by
+    ENLCN.forward :434-437) with ENLA / softmax_kernel / linear_attention (:207-300): 1x1 embeddings, L2-normalised and
+    scaled by sqrt(6), positive random features exp(<x, w_j> - |x|^2 / 2) + 1e-4 against the stored projection matrix
+    (a BUFFER of the state_dict: gaussian_orthogonal_random_matrix :52-81), then linear attention."""
+    q = F.conv2d(x, sd[pre + ".conv_match1.0.weight"], sd[pre + ".conv_match1.0.bias"])
+    k = F.conv2d(x, sd[pre + ".conv_match2.0.weight"], sd[pre + ".conv_match2.0.bias"])
+    v = F.conv2d(x, sd[pre + ".conv_assembly.0.weight"], sd[pre + ".conv_assembly.0.bias"])
+    kk = math.sqrt(6)
+    k = F.normalize(k, p=2, dim=1, eps=5e-5) * kk
+    q = F.normalize(q, p=2, dim=1, eps=5e-5) * kk
+    N, C, H, W = q.shape
+    q = q.permute(0, 2, 3, 1).reshape(N, 1, H * W, C)
+    k = k.permute(0, 2, 3, 1).reshape(N, 1, H * W, C)
+    v = v.permute(0, 2, 3, 1).reshape(N, 1, H * W, -1)
+    P = sd[pre + ".attn_fn.projection_matrix"]
+    ratio = P.shape[0] ** -0.5
+    proj = P[None, None].expand(N, 1, -1, -1)
+
+    def feat(d):
+        dash = torch.einsum("...id,...jd->...ij", d, proj)
+        diag = (torch.sum(d ** 2, dim=-1) / 2.0).unsqueeze(dim=-1)
+        return ratio * (torch.exp(dash - diag) + 1e-4)
+    q, k = feat(q), feat(k)
+    d_inv = 1.0 / torch.einsum("...nd,...d->...n", q, k.sum(dim=-2))
+    context = torch.einsum("...nd,...ne->...de", k, v)
+    out = torch.einsum("...de,...nd,...n->...ne", context, q, d_inv).squeeze(1)
+    return out.permute(0, 2, 1).reshape(N, -1, H, W) * res_scale + x
+
+
+def enlcn_forward(sd: SD, x: Tensor, upscale: int, n_resblock: int = 32, res_scale: float = 0.1) -> Tensor:
+    """ENLCN.forward (network_enlcn.py:421-448): head conv; body = ENLCA, then n_resblock ResBlocks (conv-ReLU-conv,
+    x res_scale, + x: :139-160) with an ENLCA behind every eighth, then a conv; long skip; Upsampler (:163-196) + conv.
+    sub_mean / add_mean are not applied (:423,441)."""
+    x = F.conv2d(x, sd["head.0.weight"], sd["head.0.bias"], padding=1)
+    res, i = x, 0
+    res = _enlca(sd, f"body.{i}", res, res_scale); i += 1
+    for b in range(n_resblock):
+        r = F.conv2d(res, sd[f"body.{i}.body.0.weight"], sd[f"body.{i}.body.0.bias"], padding=1)
+        r = F.conv2d(F.relu(r), sd[f"body.{i}.body.2.weight"], sd[f"body.{i}.body.2.bias"], padding=1)
+        res = r * res_scale + res
+        i += 1
+        if (b + 1) % 8 == 0:
+            res = _enlca(sd, f"body.{i}", res, res_scale); i += 1
+    res = F.conv2d(res, sd[f"body.{i}.weight"], sd[f"body.{i}.bias"], padding=1) + x
+    for st in range(int(math.log2(upscale))):
+        res = F.pixel_shuffle(F.conv2d(res, sd[f"tail.0.{2 * st}.weight"], sd[f"tail.0.{2 * st}.bias"], padding=1), 2)
+    return F.conv2d(res, sd["tail.1.weight"], sd["tail.1.bias"], padding=1)
+
+
+def enlcn_init_state_dict(upscale: int, in_chans: int = 1, n_resblock: int = 32, n_feats: int = 256, seed: int = 0,
+                          bias_std: float = 0.02, w_gain: float = 1.0) -> SD:
+    """Seeded weights in the reference's state_dict layout and order (N(0, gain / sqrt(fan_in)); the frozen MeanShift convs
+    as the reference builds them :26-37; the projection matrices as gaussian_orthogonal_random_matrix builds them, from
+    this generator)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+
+    def conv(pre, ci, co, k):
+        sd[pre + ".weight"] = torch.randn(co, ci, k, k, generator=g) * (w_gain / math.sqrt(ci * k * k))
+        sd[pre + ".bias"] = torch.randn(co, generator=g) * bias_std
+
+    def shift(pre, sign):
+        sd[pre + ".weight"] = torch.eye(3).view(3, 3, 1, 1)
+        sd[pre + ".bias"] = sign * torch.tensor([0.4488, 0.4371, 0.4040])
+
+    def enlca(pre):
+        d = n_feats // 4
+        conv(pre + ".conv_match1.0", n_feats, d, 1)
+        conv(pre + ".conv_match2.0", n_feats, d, 1)
+        conv(pre + ".conv_assembly.0", n_feats, n_feats, 1)
+        blocks = []
+        for _ in range(128 // d):
+            qm, _ = torch.linalg.qr(torch.randn(d, d, generator=g))
+            blocks.append(qm.t())
+        rem = 128 - (128 // d) * d
+        if rem:
+            qm, _ = torch.linalg.qr(torch.randn(d, d, generator=g))
+            blocks.append(qm.t()[:rem])
+        mult = torch.randn(128, d, generator=g).norm(dim=1)
+        sd[pre + ".attn_fn.projection_matrix"] = torch.diag(mult) @ torch.cat(blocks)
+
+    shift("sub_mean", -1.0)
+    shift("add_mean", 1.0)
+    conv("head.0", in_chans, n_feats, 3)
+    i = 0
+    enlca(f"body.{i}"); i += 1
+    for b in range(n_resblock):
+        conv(f"body.{i}.body.0", n_feats, n_feats, 3)
+        conv(f"body.{i}.body.2", n_feats, n_feats, 3)
+        i += 1
+        if (b + 1) % 8 == 0:
+            enlca(f"body.{i}"); i += 1
+    conv(f"body.{i}", n_feats, n_feats, 3)
+    for st in range(int(math.log2(upscale))):
+        conv(f"tail.0.{2 * st}", n_feats, 4 * n_feats, 3)
+    conv("tail.1", n_feats, in_chans, 3)
+    return sd
+
+
+# ----------------------------------------------------------------------------
 # MSLapSRN (dlib/models/network_mslapsr.py)
 # ----------------------------------------------------------------------------
 def mslapsrn_forward(sd: SD, x: Tensor, upscale: int) -> Tuple[Tensor, List[Tensor]]:

@@ -127,6 +127,42 @@ __global__ void __launch_bounds__(256) k_crop1(const float* __restrict__ in, flo
   }
 }
 
+// ---- ENLCA (network_enlcn.py:207-366): the element-wise pieces around its GEMMs; one wave per row
+// F.normalize(x, p=2, dim=channel, eps) * k on token rows
+__global__ void __launch_bounds__(256) k_l2norm_rows(float* __restrict__ x, long ld, long T, int C, float eps, float k) {
+  const long t = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= T) return;
+  float* r = x + t * ld;
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) ss += r[c] * r[c];
+  const float f = k / fmaxf(sqrtf(wave_sum(ss)), eps);
+  for (int c = lane; c < C; c += 64) r[c] *= f;
+}
+// softmax_kernel :207-240: out[t][j] = ratio (exp(dash[t][j] - |data[t]|^2 / 2) + eps)
+__global__ void __launch_bounds__(256) k_performer_features(float* __restrict__ dash, long ldd, const float* __restrict__ data,
+                                                            long ldx, long T, int Fn, int C, float ratio, float eps) {
+  const long t = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= T) return;
+  const float* r = data + t * ldx;
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) ss += r[c] * r[c];
+  const float diag = wave_sum(ss) * 0.5f;
+  float* d = dash + t * ldd;
+  for (int j = lane; j < Fn; j += 64) d[j] = ratio * (expf(d[j] - diag) + eps);
+}
+// linear_attention's last step + ENLCA's residual: out = x + res_scale * num[:, :Cy] / num[:, Cy]
+__global__ void __launch_bounds__(256) k_enlca_finish(const float* __restrict__ num, long ldn, const float* __restrict__ x,
+                                                      float* __restrict__ out, long T, int Cy, float res_scale) {
+  const long t = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= T) return;
+  const float* r = num + t * ldn;
+  const float f = res_scale / r[Cy];
+  for (int c = lane; c < Cy; c += 64) out[t * Cy + c] = x[t * Cy + c] + f * r[c];
+}
+
 }  // namespace
 
 extern "C" {
@@ -171,6 +207,29 @@ int srhip_crop1(const float* in, float* out, int B, int H, int W, int C, int adj
   const long n = (long)B * (adjoint ? H + 2 : H) * (adjoint ? W + 2 : W) * (C / 4);
   hipLaunchKernelGGL(k_crop1, dim3(to_grid(n)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C / 4, adjoint);
   SR_LAUNCH_CHECK("crop1");
+  return 0;
+}
+
+int srhip_l2norm_rows(float* x, long ld, long T, int C, float eps, float k, void* stream) {
+  SR_REQUIRE(x && T > 0 && C > 0 && ld >= C, "l2norm_rows: bad arguments");
+  hipLaunchKernelGGL(k_l2norm_rows, dim3(sr_cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, T, C, eps, k);
+  SR_LAUNCH_CHECK("l2norm_rows");
+  return 0;
+}
+
+int srhip_performer_features(float* dash, long ldd, const float* data, long ldx, long T, int F, int C, float ratio, float eps,
+                             void* stream) {
+  SR_REQUIRE(dash && data && T > 0 && F > 0 && C > 0 && ldd >= F && ldx >= C, "performer_features: bad arguments");
+  hipLaunchKernelGGL(k_performer_features, dim3(sr_cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, dash, ldd, data, ldx, T, F, C,
+                     ratio, eps);
+  SR_LAUNCH_CHECK("performer_features");
+  return 0;
+}
+
+int srhip_enlca_finish(const float* num, long ldn, const float* x, float* out, long T, int Cy, float res_scale, void* stream) {
+  SR_REQUIRE(num && x && out && T > 0 && Cy > 0 && ldn > Cy, "enlca_finish: bad arguments");
+  hipLaunchKernelGGL(k_enlca_finish, dim3(sr_cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, num, ldn, x, out, T, Cy, res_scale);
+  SR_LAUNCH_CHECK("enlca_finish");
   return 0;
 }
 

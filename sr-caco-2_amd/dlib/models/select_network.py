@@ -54,6 +54,11 @@ def define_G(args):
         return net(upscale=opt_net[f'{nt}_upscale'], in_chans=opt_net[f'{nt}_in_chans'],
                    num_features=opt_net[f'{nt}_num_features'], num_steps=opt_net[f'{nt}_num_steps'],
                    num_groups=opt_net[f'{nt}_num_groups'])
+    if net_type == constants.ENLCN:                 # select_network.py:92-101 (evaluation only here)
+        from dlib.models.network_enlcn import ENLCN as net
+        return net(upscale=opt_net[f'{nt}_upscale'], n_resblock=opt_net[f'{nt}_n_resblock'],
+                   n_feats=opt_net[f'{nt}_n_feats'], res_scale=opt_net[f'{nt}_res_scale'],
+                   img_range=opt_net[f'{nt}_img_range'], in_chans=opt_net[f'{nt}_in_chans'])
     if net_type == constants.PROSR:                 # select_network.py:110-128
         from dlib.models.network_prosr import ProSR as net
         upscale = opt_net[f'{nt}_upscale']

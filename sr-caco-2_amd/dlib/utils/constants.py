@@ -13,7 +13,8 @@ MEMNET = 'MemNet'  # https://arxiv.org/pdf/1708.02209.pdf (reference constants.p
 DBPN = 'DBPN'  # https://arxiv.org/pdf/1803.02735.pdf (reference constants.py:49)
 SRFBN = 'SRFBN'  # https://arxiv.org/pdf/1903.09814.pdf (reference constants.py:46)
 PROSR = 'ProSR'  # https://arxiv.org/pdf/1804.02900.pdf (reference constants.py:48)
-MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR, MEMNET, DBPN, SRFBN, PROSR]
+ENLCN = 'ENLCN'  # https://arxiv.org/pdf/2201.03794.pdf (reference constants.py:36)
+MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR, MEMNET, DBPN, SRFBN, PROSR, ENLCN]
 
 SWINIR_MTH = 'SWINIR'
 EDSR_LIIF_MTH = 'EDSR_LIIF'
@@ -25,8 +26,10 @@ MEMNET_MTH = 'MemNet'
 DBPN_MTH = 'DBPN'
 SRFBN_MTH = 'SRFBN'
 PROSR_MTH = 'PROSR'
+ENLCN_MTH = 'ENLCN'
 NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH, DRRN: DRRN_MTH, SRCNN: SRCNN_MTH,
-                  MSLAPSR: MSLAPSR_MTH, MEMNET: MEMNET_MTH, DBPN: DBPN_MTH, SRFBN: SRFBN_MTH, PROSR: PROSR_MTH}
+                  MSLAPSR: MSLAPSR_MTH, MEMNET: MEMNET_MTH, DBPN: DBPN_MTH, SRFBN: SRFBN_MTH, PROSR: PROSR_MTH,
+                  ENLCN: ENLCN_MTH}
 
 US_PIXEL_SHUFFLE = 'pixelshuffle'
 US_PIXEL_SHUFFLE_DIRECT = 'pixelshuffledirect'

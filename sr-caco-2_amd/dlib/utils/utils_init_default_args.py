@@ -43,6 +43,9 @@ def init_net_g(netG: dict, args: dict) -> dict:
                     f'{nt}_growth_rate': 40, f'{nt}_ps_woReLU': False, f'{nt}_level_compression': -1,
                     f'{nt}_res_factor': 0.2, f'{nt}_max_num_feature': 312, f'{nt}_block_compression': 0.4,
                     f'{nt}_level_config': {2: [[8] * 9], 4: [[8] * 9, [8] * 3], 8: [[8] * 9, [8] * 3, [8]]}})
+    elif netG['net_type'] == constants.ENLCN:        # utils_init_default_args.py:74-82
+        out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'], f'{nt}_n_resblock': 32,
+                    f'{nt}_n_feats': 256, f'{nt}_res_scale': 0.1, f'{nt}_img_range': 1.0})
     else:
         raise NotImplementedError(netG['net_type'])
     out[f'{nt}_init_type'] = constants.INIT_W_DEFAULT

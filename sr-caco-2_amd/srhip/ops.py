@@ -289,6 +289,33 @@ def gemm_nt_lnbwd(A, W, x, stats, res, out):
     return out
 
 
+def l2norm_rows_(x, k=1.0, eps=5e-5):
+    """x[t] <- k * x[t] / max(|x[t]|, eps) on token rows [T, C] (F.normalize over channels, network_enlcn.py:341-342)."""
+    _chk(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    call("srhip_l2norm_rows", _p(x), x.stride(0), x.shape[0], x.shape[1], float(eps), float(k), _st())
+    return x
+
+
+def performer_features_(dash, data, eps=1e-4):
+    """dash[t][j] <- F^-1/2 (exp(dash[t][j] - |data[t]|^2 / 2) + eps), F = dash.shape[1] (softmax_kernel,
+    network_enlcn.py:207-240)."""
+    _chk(dash, data)
+    assert dash.dim() == 2 and data.dim() == 2 and dash.shape[0] == data.shape[0] and dash.stride(1) == data.stride(1) == 1
+    call("srhip_performer_features", _p(dash), dash.stride(0), _p(data), data.stride(0), dash.shape[0], dash.shape[1],
+         data.shape[1], float(dash.shape[1]) ** -0.5, float(eps), _st())
+    return dash
+
+
+def enlca_finish(num, x, out, res_scale):
+    """out = x + res_scale * num[:, :Cy] / num[:, Cy]  (x, out contiguous [T, Cy]; num [T, > Cy])."""
+    _chk(num, x, out)
+    T, Cy = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and out.shape == x.shape and num.shape[0] == T and num.shape[1] > Cy
+    call("srhip_enlca_finish", _p(num), num.stride(0), _p(x), _p(out), T, Cy, float(res_scale), _st())
+    return out
+
+
 def mlp_f16_fusable(C, hidden):
     """Shapes srhip_mlp_fwd_f16x2 / srhip_mlp_bwd_f16x2 take with the weight planes PrepTable.linear builds for the
     Linear GEMMs (format 1: two fp16 planes)."""

@@ -352,6 +352,45 @@ class Tape:
             out = act(out)
         return out
 
+    def enlca(self, x, keys, proj, res_scale):
+        """ENLCA in evaluation mode (network_enlcn.py:330-366): keys = bank entries of conv_match1 / conv_match2 /
+        conv_assembly (1x1), proj = the stored projection matrix [F, d].  Linear attention as two dense products per
+        sample, the normaliser carried as one more column of the value matrix.  Inference only (the backward raises)."""
+        e1, e2, e3 = (self.bank.d[k] for k in keys)
+        B, H, W, C = x.t.shape
+        T, L, d, Cy, Fn = B * H * W, H * W, e1.Co, e3.Co, proj.shape[0]
+        xin = x.t if x.t.is_contiguous() else x.t.contiguous()
+        x2 = xin.view(T, C)
+        dev = self.dev
+        q, k = torch.empty(T, d, device=dev), torch.empty(T, d, device=dev)
+        vext = torch.empty(T, Cy + 4, device=dev)
+        vext[:, Cy] = 1.0
+        vext[:, Cy + 1:] = 0.0
+        ops.gemm_nt(x2, e1.w1, e1.bias, out=q)
+        ops.gemm_nt(x2, e2.w1, e2.bias, out=k)
+        ops.gemm_nt(x2, e3.w1, e3.bias, out=vext[:, :Cy])
+        kk = 6.0 ** 0.5
+        ops.l2norm_rows_(q, kk)
+        ops.l2norm_rows_(k, kk)
+        pj = proj.contiguous()
+        fq = ops.performer_features_(ops.gemm_nt(q, pj), q)
+        fk = ops.performer_features_(ops.gemm_nt(k, pj), k)
+        y = self.new(B, H, W, Cy)
+        y2 = y.view(T, Cy)
+        ctx_t, colsum = torch.empty(Cy + 4, Fn, device=dev), torch.empty(Cy + 4, device=dev)
+        num = torch.empty(L, Cy + 4, device=dev)
+        for b in range(B):
+            rows = slice(b * L, (b + 1) * L)
+            ops.linear_wgrad(vext[rows], fk[rows], ctx_t, colsum)          # [v | 1]^T k' = (context | sum k')^T
+            ops.gemm_nt(fq[rows], ctx_t, None, out=num)
+            ops.enlca_finish(num, x2[rows], y2[rows], res_scale)
+        out = self._out(y)
+        if self.save:
+            def bwd():
+                raise NotImplementedError("ENLCA on libsrhip: inference only (the evaluation sweep); no backward")
+            self.back.append(bwd)
+        return out
+
     def conv_in1(self, x3, weight, bias, names):
         """first conv of a 1-channel image: x3 [B, H, W] -> [B, H, W, Co] (small.hip)."""
         B, H, W = x3.shape

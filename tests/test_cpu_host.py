@@ -120,6 +120,25 @@ def test_registry_and_factories():
     assert constants.NETTYPE_METHOD[constants.SWINIR] == 'SWINIR'
 
 
+def test_enlcn_mirror_layout_and_oracle_vs_reference_golden():
+    """ENLCN: the registry's default net carries the reference's state_dict keys in the reference's order
+    (frozen MeanShift convs and the projection-matrix buffers included); the oracle restatement reproduces the reference's
+    outputs stored in g33_enlcn.npz."""
+    from dlib.models.network_enlcn import ENLCN
+    from oracle import sr_oracle as O
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g33_enlcn.npz"))
+    assert list(ENLCN(upscale=2, in_chans=1).state_dict().keys()) == [str(k) for k in g["state_dict_keys_default"]]
+    with pytest.raises(NotImplementedError):
+        ENLCN(upscale=3, in_chans=1)
+    for scale in (2, 4, 8):
+        sd = O.enlcn_init_state_dict(scale, 1, 8, 64, seed=int(g[f"x{scale}/seed"]))
+        net = ENLCN(upscale=scale, in_chans=1, n_resblock=8, n_feats=64)
+        assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+        net.load_state_dict(sd, strict=True)
+        y = O.enlcn_forward(sd, torch.from_numpy(g[f"x{scale}/x"]), scale, 8, 0.1)
+        assert (y - torch.from_numpy(g[f"x{scale}/y"])).abs().max().item() <= 2e-6
+
+
 def test_tape_net_mirrors_have_the_reference_state_dict_layout():
     """DBPN / SRFBN mirrors: the registry's default nets carry the reference's state_dict keys (SRFBN: in the
     reference's ORDER, frozen MeanShift convs included) and the re-layout maps of the strided / transposed convs are exact."""

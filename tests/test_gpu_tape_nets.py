@@ -207,3 +207,43 @@ def test_default_width_train_step_vs_oracle(net_type, scale, slopes):
             assert el2 <= 2e-3, (k, e, e32, el2)
     print(f"{net_type} x{scale}: loss {loss.item():.6f}, worst gradient error: {worst:.2e} of the tensor's largest entry, "
           f"{worst_l2:.2e} relative L2")
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8])
+def test_enlcn_forward_vs_reference_golden(scale):
+    """ENLCN (network_enlcn.py): narrow configuration of g33_enlcn.npz -- ENLCA blocks (1x1 embeddings, L2 normalisation,
+    positive random features, linear attention with the normaliser as one more value column), ResBlocks with res_scale,
+    the F -> 4F upsampler convs as four slices -- against the reference's own output; evaluation only (backward raises)."""
+    from dlib.models.network_enlcn import ENLCN
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g33_enlcn").items() if k.startswith(f"x{scale}/")}
+    sd = O.enlcn_init_state_dict(scale, 1, 8, 64, seed=int(g["seed"]))
+    net = ENLCN(upscale=scale, in_chans=1, n_resblock=8, n_feats=64)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    x, yref = g["x"], g["y"]
+    with torch.no_grad():
+        y = net(x.cuda()).cpu()
+    assert (y - yref).abs().mean().item() <= 1e-5 and rel(y, yref) < 2e-5, rel(y, yref)
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(x.cuda()).sum().backward()
+
+
+def test_enlcn_registry_default_width_vs_oracle():
+    """The registry's net (32 ResBlocks, 256 features, five ENLCA blocks with 64-dim embeddings) at x4 on 24 x 20 inputs
+    against the oracle; and --amp within the PSNR gate."""
+    from dlib.models.network_enlcn import ENLCN
+    sd = O.enlcn_init_state_dict(4, 1, seed=5)
+    net = ENLCN(upscale=4, in_chans=1)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    gen = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 1, 24, 20, generator=gen)
+    with torch.no_grad():
+        yref = O.enlcn_forward(sd, x, 4)
+        y = net(x.cuda()).cpu()
+        net.amp = True
+        ya = net(x.cuda()).cpu()
+    assert (y - yref).abs().mean().item() <= 1e-5 and rel(y, yref) < 2e-5, rel(y, yref)
+    mse = ((ya.clamp(0, 1) - yref.clamp(0, 1)) ** 2).mean().item()        # --amp: PSNR of the amp output against the f32 one
+    assert mse < 1e-5, mse

@@ -1,3 +1,2 @@
 #!/bin/bash
-bash tools/step_mfma_pmc.sh gpurun_out/mfma_swinir swinir_x8 2>&1 | tail -14
-bash tools/step_mfma_pmc.sh gpurun_out/mfma_edsr8 edsr_x8 2>&1 | tail -10
+timeout 900 python -m pytest tests/test_gpu_tape_nets.py -x -q -m gpu -k enlcn 2>&1 | tail -25
