@@ -342,6 +342,28 @@ int srhip_performer_features(float* dash, long ldd, const float* data, long ldx,
                              void* stream);
 int srhip_enlca_finish(const float* num, long ldn, const float* x, float* out, long T, int Cy, float res_scale, void* stream);
 
+/* ---- Non-Local Sparse Attention of NLSN, evaluation forward (nlsa.hip) --------------
+ * NonLocalSparseAttention.forward, dlib/models/network_nlsn.py:131-268, token-major (channels last):
+ *   srhip_nlsa_hash_buckets   min(L // chunk + (L // chunk) % 2, 128)                                     (:193-194)
+ *   srhip_nlsa_order          hash codes = argmax over cat([r, -r]) of the rotated embedding (first maximum, :158-161;
+ *                             rotated [N*L][ld] = x_embed . rotations, columns round-major) and the tokens of every
+ *                             (sample, round) ordered by code -- ONE stable radix sort of 64-bit keys (low 20 bits =
+ *                             token), where the reference's torch.sort leaves the order of equal codes open (:199-201).
+ *                             keys_tmp, order: N * n_hashes * L entries; workspace: srhip_nlsa_sort_ws(items) bytes.
+ *   srhip_nlsa_attention      every chunk of chunk_size ordered tokens attends to itself and its two neighbouring chunks
+ *                             (keys L2-normalised, eps 5e-5; queries not), log-sum-exp scores, attention-weighted sum of
+ *                             the assembly embedding; result and score are written at the token's own position of its
+ *                             round (ret [N][n_hashes][L][Cy], score [N][n_hashes][L]: scratch), then
+ *                             out = x + res_scale * sum_h softmax_h(score) ret_h                          (:209-266).
+ *                             Ce <= 64; chunk_size such that the tile fits 160 KB of LDS (144: 135 KB). */
+int srhip_nlsa_hash_buckets(int L, int chunk_size);
+long srhip_nlsa_sort_ws(long n_items);
+int srhip_nlsa_order(const float* rotated, long ld, unsigned long long* keys_tmp, unsigned long long* order, void* workspace,
+                     long ws_bytes, int N, int L, int n_hashes, int hash_buckets, void* stream);
+int srhip_nlsa_attention(const float* x_embed, const float* y_embed, const unsigned long long* order, float* ret, float* score,
+                         const float* x, float* out, int N, int L, int Ce, int Cy, int n_hashes, int chunk_size,
+                         float res_scale, void* stream);
+
 /* ---- window attention on the two-plane fp16 split MFMA (wattn2.hip) -------------- */
 /* The same contract as srhip_window_attention_fwd (network_swinir.py:48-80,153-176,297-331) with the two
  * contractions as three fp16 products under power-of-two block exponents (q, k per token row, v per head-dim

@@ -1386,6 +1386,45 @@ def g_enlcn():
     npz("g33_enlcn", **out)
 
 
+def g_nlsn():
+    """NLSN (network_nlsn.py): EDSR body with Non-Local Sparse Attention.  Narrow configuration (8 ResBlocks, 64 features:
+    attention at body.0 and body.9, 16-dim matching embedding, 4 hash rounds, chunks of 144) on inputs with and without
+    chunk padding (L = 720: 5 chunks, 6 buckets; L = 480: padding 96, 4 buckets).  The reference draws its LSH rotations
+    from the global generator at every call and orders the codes with torch's (unstable) sort: the fixture stores the
+    rotations it drew (replayed from the same seed: evaluation mode consumes nothing else), the hash codes and the order
+    it used, and its output.  Forward only."""
+    print("G34 NLSN")
+    from dlib.models.network_nlsn import NLSN as RefNLSN
+    out = {}
+    cfg = dict(n_resblocks=8, n_feats=64)
+    for scale, hw in ((2, (24, 30)), (4, (20, 24))):
+        sd = O.nlsn_init_state_dict(scale, 1, seed=350 + scale, **cfg)
+        net = RefNLSN(upscale=scale, in_chans=1, n_hashes=4, chunk_size=144, **cfg).eval()
+        ref_keys = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        assert ref_keys == [(k, tuple(v.shape)) for k, v in sd.items()], "NLSN state_dict layout / order"
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(360 + scale)
+        x = torch.rand(2, 1, *hw)
+        with torch.no_grad():
+            torch.manual_seed(370 + scale)
+            y = net(x)
+            torch.manual_seed(370 + scale)
+            taps = []
+            yo = O.nlsn_forward(sd, x, scale, cfg["n_resblocks"], 4, 144, 0.1, taps=taps)
+            close(yo, y, 0.0, f"nlsn x{scale} forward")
+            torch.manual_seed(370 + scale)
+            rots = [torch.randn((1, cfg["n_feats"] // 4, 4, t["hash_buckets"] // 2)) for t in taps]
+            yr = O.nlsn_forward(sd, x, scale, cfg["n_resblocks"], 4, 144, 0.1, rotations=rots,
+                                indices=[t["indices"] for t in taps])
+            close(yr, y, 0.0, f"nlsn x{scale} forward with the rotations and the order replayed")
+        pre = f"x{scale}/"
+        out[pre + "x"], out[pre + "y"], out[pre + "seed"] = x, y, np.array(350 + scale)
+        for a_, (t, r) in enumerate(zip(taps, rots)):
+            out[pre + f"rot{a_}"], out[pre + f"codes{a_}"], out[pre + f"indices{a_}"] = r, t["codes"], t["indices"]
+    out["state_dict_keys_default"] = np.array([k for k in RefNLSN(upscale=2, in_chans=1).state_dict().keys()])
+    npz("g34_nlsn", **out)
+
+
 def g_lowres():
     """The low-resolution side of DatasetDPSR items (dataset_dpsr.py:592-645,684-744,1037-1180): outputs of the
     reference's own functions on seeded inputs -- the fixtures of sr-caco-2_amd/dlib/datasets/lowres.py."""
@@ -1664,7 +1703,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_enlcn, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_nlsn, g_enlcn, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

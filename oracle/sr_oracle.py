@@ -827,6 +827,146 @@ def enlcn_init_state_dict(upscale: int, in_chans: int = 1, n_resblock: int = 32,
 
 
 # ----------------------------------------------------------------------------
+# NLSN (dlib/models/network_nlsn.py): EDSR body with Non-Local Sparse Attention blocks
+def _nlsa(sd: SD, pre: str, x: Tensor, n_hashes: int, chunk_size: int, res_scale: float, rotations=None,
+          indices=None, taps=None) -> Tensor:
+    """NonLocalSparseAttention.forward (network_nlsn.py:131-268).  The reference draws the LSH rotations with torch.randn at
+    every call (:152-155) and orders the hash codes with an UNSTABLE sort (:201): both are arguments here -- rotations
+    [1, C, n_hashes, hash_buckets // 2] (None: drawn from the global generator, exactly as the reference does), indices
+    [N, n_hashes * L] (None: torch's sort, as the reference) -- so that another implementation's draw / tie order can be
+    replayed.  taps (a dict) receives the hash codes and the indices used."""
+    N, _, H, W = x.shape
+    xe = F.conv2d(x, sd[pre + ".conv_match.0.weight"], sd[pre + ".conv_match.0.bias"], padding=1)
+    ye = F.conv2d(x, sd[pre + ".conv_assembly.0.weight"], sd[pre + ".conv_assembly.0.bias"])
+    x_embed = xe.view(N, -1, H * W).contiguous().permute(0, 2, 1)
+    y_embed = ye.view(N, -1, H * W).contiguous().permute(0, 2, 1)
+    L, C = x_embed.shape[-2:]
+    Cy = y_embed.shape[-1]
+    hash_buckets = min(L // chunk_size + (L // chunk_size) % 2, 128)
+    if rotations is None:
+        rotations = torch.randn((1, C, n_hashes, hash_buckets // 2), dtype=x.dtype)
+    rot = rotations.expand(N, -1, -1, -1)
+    rotated = torch.einsum('btf,bfhi->bhti', x_embed, rot)
+    rotated = torch.cat([rotated, -rotated], dim=-1)
+    codes = torch.argmax(rotated, dim=-1)
+    offsets = torch.reshape(torch.arange(n_hashes) * hash_buckets, (1, -1, 1))
+    codes = torch.reshape(codes + offsets, (N, -1,)).detach()
+    if indices is None:
+        _, indices = codes.sort(dim=-1)
+    _, undo_sort = indices.sort(dim=-1)
+    if taps is not None:
+        taps["codes"], taps["indices"], taps["hash_buckets"] = codes, indices, hash_buckets
+    mod_indices = indices % L
+
+    def bsel(values, idx):
+        return values.gather(1, idx[:, :, None].expand(-1, -1, values.shape[-1]))
+    xs, ys = bsel(x_embed, mod_indices), bsel(y_embed, mod_indices)
+    padding = chunk_size - L % chunk_size if L % chunk_size != 0 else 0
+    xb = torch.reshape(xs, (N, n_hashes, -1, C))
+    yb = torch.reshape(ys, (N, n_hashes, -1, Cy))
+    if padding:
+        xb = torch.cat([xb, xb[:, :, -padding:, :].clone()], dim=2)
+        yb = torch.cat([yb, yb[:, :, -padding:, :].clone()], dim=2)
+    xb = torch.reshape(xb, (N, n_hashes, -1, chunk_size, C))
+    yb = torch.reshape(yb, (N, n_hashes, -1, chunk_size, Cy))
+    xm = F.normalize(xb, p=2, dim=-1, eps=5e-5)
+
+    def adj(t):
+        back = torch.cat([t[:, :, -1:, ...], t[:, :, :-1, ...]], dim=2)
+        fwd = torch.cat([t[:, :, 1:, ...], t[:, :, :1, ...]], dim=2)
+        return torch.cat([t, back, fwd], dim=3)
+    xm, yb = adj(xm), adj(yb)
+    raw = torch.einsum('bhkie,bhkje->bhkij', xb, xm)
+    bucket_score = torch.logsumexp(raw, dim=-1, keepdim=True)
+    score = torch.exp(raw - bucket_score)
+    bucket_score = torch.reshape(bucket_score, [N, n_hashes, -1])
+    ret = torch.einsum('bukij,bukje->bukie', score, yb)
+    ret = torch.reshape(ret, (N, n_hashes, -1, Cy))
+    if padding:
+        ret = ret[:, :, :-padding, :].clone()
+        bucket_score = bucket_score[:, :, :-padding].clone()
+    ret = torch.reshape(ret, (N, -1, Cy))
+    bucket_score = torch.reshape(bucket_score, (N, -1,))
+    ret = bsel(ret, undo_sort)
+    bucket_score = bucket_score.gather(1, undo_sort)
+    ret = torch.reshape(ret, (N, n_hashes, L, Cy))
+    bucket_score = torch.reshape(bucket_score, (N, n_hashes, L, 1))
+    probs = F.softmax(bucket_score, dim=1)
+    ret = torch.sum(ret * probs, dim=1)
+    return ret.permute(0, 2, 1).view(N, -1, H, W).contiguous() * res_scale + x
+
+
+def nlsn_body_layout(n_resblocks: int):
+    """(index in NLSN.body, kind) -- network_nlsn.py:326-341: an attention block first, one behind every eighth ResBlock."""
+    out, i = [(0, "nlsa")], 1
+    for b in range(n_resblocks):
+        out.append((i, "res")); i += 1
+        if (b + 1) % 8 == 0:
+            out.append((i, "nlsa")); i += 1
+    out.append((i, "conv"))
+    return out
+
+
+def nlsn_forward(sd: SD, x: Tensor, upscale: int, n_resblocks: int = 32, n_hashes: int = 4, chunk_size: int = 144,
+                 res_scale: float = 0.1, rotations=None, indices=None, taps=None) -> Tensor:
+    """NLSN.forward (network_nlsn.py:355-369); rotations / indices: one entry per attention block, in body order (None:
+    the reference's own draws / sort); taps: list that receives one dict per attention block."""
+    x = F.conv2d(x, sd["head.0.weight"], sd["head.0.bias"], padding=1)
+    res, a = x, 0
+    for i, kind in nlsn_body_layout(n_resblocks):
+        if kind == "nlsa":
+            tp = {} if taps is not None else None
+            res = _nlsa(sd, f"body.{i}", res, n_hashes, chunk_size, res_scale,
+                        None if rotations is None else rotations[a], None if indices is None else indices[a], tp)
+            if taps is not None:
+                taps.append(tp)
+            a += 1
+        elif kind == "res":
+            r = F.conv2d(res, sd[f"body.{i}.body.0.weight"], sd[f"body.{i}.body.0.bias"], padding=1)
+            r = F.conv2d(F.relu(r), sd[f"body.{i}.body.2.weight"], sd[f"body.{i}.body.2.bias"], padding=1)
+            res = r * res_scale + res
+        else:
+            res = F.conv2d(res, sd[f"body.{i}.weight"], sd[f"body.{i}.bias"], padding=1)
+    res = res + x
+    for st in range(int(math.log2(upscale))):
+        res = F.pixel_shuffle(F.conv2d(res, sd[f"tail.0.{2 * st}.weight"], sd[f"tail.0.{2 * st}.bias"], padding=1), 2)
+    return F.conv2d(res, sd["tail.1.weight"], sd["tail.1.bias"], padding=1)
+
+
+def nlsn_init_state_dict(upscale: int, in_chans: int = 1, n_resblocks: int = 32, n_feats: int = 256, seed: int = 0,
+                         bias_std: float = 0.02, w_gain: float = 1.0) -> SD:
+    """Seeded weights in the reference's state_dict layout and order (N(0, gain / sqrt(fan_in)); the frozen MeanShift
+    convs as the reference builds them :42-53)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+
+    def conv(pre, ci, co, k):
+        sd[pre + ".weight"] = torch.randn(co, ci, k, k, generator=g) * (w_gain / math.sqrt(ci * k * k))
+        sd[pre + ".bias"] = torch.randn(co, generator=g) * bias_std
+
+    def shift(pre, sign):
+        sd[pre + ".weight"] = torch.eye(3).view(3, 3, 1, 1)
+        sd[pre + ".bias"] = sign * torch.tensor([0.4488, 0.4371, 0.4040])
+
+    shift("sub_mean", -1.0)
+    shift("add_mean", 1.0)
+    conv("head.0", in_chans, n_feats, 3)
+    for i, kind in nlsn_body_layout(n_resblocks):
+        if kind == "nlsa":
+            conv(f"body.{i}.conv_match.0", n_feats, n_feats // 4, 3)
+            conv(f"body.{i}.conv_assembly.0", n_feats, n_feats, 1)
+        elif kind == "res":
+            conv(f"body.{i}.body.0", n_feats, n_feats, 3)
+            conv(f"body.{i}.body.2", n_feats, n_feats, 3)
+        else:
+            conv(f"body.{i}", n_feats, n_feats, 3)
+    for st in range(int(math.log2(upscale))):
+        conv(f"tail.0.{2 * st}", n_feats, 4 * n_feats, 3)
+    conv("tail.1", n_feats, in_chans, 3)
+    return sd
+
+
+# ----------------------------------------------------------------------------
 # MSLapSRN (dlib/models/network_mslapsr.py)
 # ----------------------------------------------------------------------------
 def mslapsrn_forward(sd: SD, x: Tensor, upscale: int) -> Tuple[Tensor, List[Tensor]]:

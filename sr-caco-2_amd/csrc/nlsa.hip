@@ -1,0 +1,219 @@
+// Non-Local Sparse Attention of NLSN, evaluation forward -- reference NonLocalSparseAttention.forward,
+// dlib/models/network_nlsn.py:131-268: locality-sensitive hashing of the matching embedding (argmax over [r, -r] of its
+// random rotations, :145-170), the tokens ordered by hash code (:199-207), attention of every 144-token chunk against
+// itself and its two neighbouring chunks with the keys L2-normalised (:224-243), and the rounds combined by a softmax over
+// their log-sum-exp scores (:258-262).
+//
+// Layout: everything stays token-major (channels last).  The order is ONE radix sort of 64-bit keys
+// (sample, round, code | token) -- stable by construction, where the reference's torch.sort leaves the order of equal
+// codes to the implementation.  The attention kernel gathers its rows through that order and writes its result and score
+// at the TOKEN's own position of its round, so the un-sort (:251-253) is free and padded rows are simply not written.
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+constexpr int TOK_BITS = 20;                 // tokens per sample < 2^20
+
+// keys of one (token, round): code = argmax over cat([r, -r]) with torch.argmax's first-maximum rule
+__global__ void __launch_bounds__(256) k_lsh_keys(const float* __restrict__ rot, long ldr, unsigned long long* __restrict__ keys,
+                                                  int N, int L, int nh, int hbh) {
+  const long idx = blockIdx.x * 256L + threadIdx.x;
+  if (idx >= (long)N * nh * L) return;
+  const int l = (int)(idx % L);
+  const int h = (int)((idx / L) % nh);
+  const int n = (int)(idx / ((long)L * nh));
+  const float* r = rot + ((long)n * L + l) * ldr + (long)h * hbh;
+  float best = r[0];
+  int code = 0;
+  for (int i = 1; i < hbh; ++i)
+    if (r[i] > best) { best = r[i]; code = i; }
+  for (int i = 0; i < hbh; ++i)
+    if (-r[i] > best) { best = -r[i]; code = hbh + i; }
+  const unsigned long long grp = ((unsigned long long)(n * nh + h) * (2 * hbh) + code);
+  keys[idx] = (grp << TOK_BITS) | (unsigned)l;
+}
+
+// One block = one chunk of one (sample, round): queries in tiles of QT rows against 3 * cs keys.
+constexpr int QT = 48;
+constexpr int CE_MAX = 64;
+constexpr int KP = CE_MAX + 1;               // key row pitch in LDS (conflict-free for lanes walking the keys)
+
+__global__ void __launch_bounds__(256) k_nlsa_attention(const float* __restrict__ xe, const float* __restrict__ ye,
+                                                        const unsigned long long* __restrict__ order, float* __restrict__ ret,
+                                                        float* __restrict__ score, int L, int Ce, int Cy, int nh, int cs,
+                                                        int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* const sq = sm;                               // [QT][Ce]
+  float* const sk = sq + QT * CE_MAX;                 // [cs][KP] one key chunk, normalised
+  float* const ss = sk + (size_t)cs * KP;             // [QT][3 cs] scores, then probabilities
+  int* const ktok = (int*)(ss + (size_t)QT * 3 * cs); // [3 cs] token of key j
+  float* const rl = (float*)(ktok + 3 * cs);          // [QT] log-sum-exp of the row
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x % nchunks;
+  const int nhh = blockIdx.x / nchunks;               // n * nh + h
+  const int n = nhh / nh;
+  const unsigned long long* ord = order + (long)nhh * L;
+  const int padding = L % cs ? cs - L % cs : 0;
+  // sorted position -> token (positions L .. L + padding - 1 repeat the last `padding` positions, :213-218)
+  auto tok_of = [&](int pos) {
+    if (pos >= L) pos -= padding;
+    return (int)(ord[pos] & ((1u << TOK_BITS) - 1));
+  };
+  const int chunks3[3] = {chunk, (chunk + nchunks - 1) % nchunks, (chunk + 1) % nchunks};      // own, back, forward (:173-176)
+  for (int j = tid; j < 3 * cs; j += 256) ktok[j] = tok_of(chunks3[j / cs] * cs + j % cs);
+  const float* xb = xe + (long)n * L * Ce;
+  const float* yb = ye + (long)n * L * Cy;
+  const int K3 = 3 * cs;
+  for (int q0 = 0; q0 < cs; q0 += QT) {
+    const int nq = min(QT, cs - q0);
+    __syncthreads();
+    for (int i = tid; i < nq * Ce; i += 256) {
+      const int r = i / Ce, e = i - r * Ce;
+      sq[r * CE_MAX + e] = xb[(long)ktok[q0 + r] * Ce + e];      // a chunk's queries are its own keys' rows, unnormalised
+    }
+    for (int kt = 0; kt < 3; ++kt) {
+      __syncthreads();
+      for (int i = tid; i < cs * Ce; i += 256) {
+        const int r = i / Ce, e = i - r * Ce;
+        sk[r * KP + e] = xb[(long)ktok[kt * cs + r] * Ce + e];
+      }
+      __syncthreads();
+      for (int r = tid; r < cs; r += 256) {                      // F.normalize(p = 2, eps = 5e-5) of the key rows (:224)
+        float s2 = 0.f;
+        for (int e = 0; e < Ce; ++e) s2 += sk[r * KP + e] * sk[r * KP + e];
+        const float f = 1.0f / fmaxf(sqrtf(s2), 5e-5f);
+        for (int e = 0; e < Ce; ++e) sk[r * KP + e] *= f;
+      }
+      __syncthreads();
+      for (int p = tid; p < nq * cs; p += 256) {
+        const int i = p / cs, j = p - i * cs;
+        float a = 0.f;
+        for (int e = 0; e < Ce; ++e) a += sq[i * CE_MAX + e] * sk[j * KP + e];
+        ss[i * K3 + kt * cs + j] = a;
+      }
+    }
+    __syncthreads();
+    // log-sum-exp of each row and the probabilities (:235-237): one wave per row
+    for (int i = tid >> 6; i < nq; i += 4) {
+      const int lane = tid & 63;
+      float mx = -3.0e38f;
+      for (int j = lane; j < K3; j += 64) mx = fmaxf(mx, ss[i * K3 + j]);
+      mx = wave_max(mx);
+      float sum = 0.f;
+      for (int j = lane; j < K3; j += 64) sum += expf(ss[i * K3 + j] - mx);
+      sum = wave_sum(sum);
+      const float lse = mx + logf(sum);
+      for (int j = lane; j < K3; j += 64) ss[i * K3 + j] = expf(ss[i * K3 + j] - lse);
+      if (lane == 0) rl[i] = lse;
+    }
+    __syncthreads();
+    // O = P . V: thread = output channel, QT row accumulators
+    for (int c = tid; c < Cy; c += 256) {
+      float acc[QT];
+#pragma unroll
+      for (int i = 0; i < QT; ++i) acc[i] = 0.f;
+      for (int j = 0; j < K3; ++j) {
+        const float v = yb[(long)ktok[j] * Cy + c];
+#pragma unroll
+        for (int i = 0; i < QT; ++i) acc[i] += ss[i * K3 + j] * v;
+      }
+#pragma unroll
+      for (int i = 0; i < QT; ++i) {
+        const int pos = chunk * cs + q0 + i;
+        if (i < nq && pos < L) ret[((long)nhh * L + ktok[q0 + i]) * Cy + c] = acc[i];
+      }
+    }
+    for (int i = tid; i < nq; i += 256) {
+      const int pos = chunk * cs + q0 + i;
+      if (pos < L) score[(long)nhh * L + ktok[q0 + i]] = rl[i];
+    }
+  }
+}
+
+// softmax over the rounds of the scores, weighted sum, residual (:256-266): one wave per token
+__global__ void __launch_bounds__(256) k_nlsa_combine(const float* __restrict__ ret, const float* __restrict__ score,
+                                                      const float* __restrict__ x, float* __restrict__ out, int N, int L,
+                                                      int Cy, int nh, float res_scale) {
+  const long t = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= (long)N * L) return;
+  const int n = (int)(t / L), l = (int)(t % L);
+  float mx = -3.0e38f;
+  for (int h = 0; h < nh; ++h) mx = fmaxf(mx, score[((long)n * nh + h) * L + l]);
+  float den = 0.f;
+  for (int h = 0; h < nh; ++h) den += expf(score[((long)n * nh + h) * L + l] - mx);
+  for (int c = lane; c < Cy; c += 64) {
+    float a = 0.f;
+    for (int h = 0; h < nh; ++h)
+      a += ret[(((long)n * nh + h) * L + l) * Cy + c] * (expf(score[((long)n * nh + h) * L + l] - mx) / den);
+    out[t * Cy + c] = a * res_scale + x[t * Cy + c];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* hash buckets of a sample with L tokens (network_nlsn.py:193-194) */
+int srhip_nlsa_hash_buckets(int L, int chunk_size) {
+  const int q = L / chunk_size;
+  const int hb = q + q % 2;
+  return hb < 128 ? hb : 128;
+}
+
+long srhip_nlsa_sort_ws(long n_items) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortKeys((void*)nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                    (int)n_items, 0, 64, (hipStream_t)0);
+  return (long)bytes;
+}
+
+/* rotated [N*L][ld] = x_embed . rotations ([.., n_hashes * hb/2] columns, round-major) -> order [N][n_hashes][L]: the
+ * tokens of every (sample, round) by hash code, ties by token index (64-bit keys, low 20 bits = token). */
+int srhip_nlsa_order(const float* rotated, long ld, unsigned long long* keys_tmp, unsigned long long* order, void* workspace,
+                     long ws_bytes, int N, int L, int n_hashes, int hash_buckets, void* stream) {
+  SR_REQUIRE(rotated && keys_tmp && order && workspace, "nlsa_order: null operand");
+  SR_REQUIRE(N > 0 && n_hashes > 0 && L > 0 && L < (1 << TOK_BITS) && hash_buckets >= 2 && hash_buckets % 2 == 0,
+             "nlsa_order: L = %d (< 2^20), hash_buckets = %d (even, >= 2)", L, hash_buckets);
+  const long items = (long)N * n_hashes * L;
+  SR_REQUIRE(items < (1L << 31), "nlsa_order: %ld items", items);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_lsh_keys, dim3(sr_cdiv(items, 256)), dim3(256), 0, st, rotated, ld, keys_tmp, N, L, n_hashes,
+                     hash_buckets / 2);
+  int grp_bits = 1;
+  while ((1L << grp_bits) < (long)N * n_hashes * hash_buckets) ++grp_bits;
+  size_t bytes = (size_t)ws_bytes;
+  if (hipcub::DeviceRadixSort::SortKeys(workspace, bytes, keys_tmp, order, (int)items, 0, TOK_BITS + grp_bits, st) != hipSuccess)
+    return sr_fail(-5, "nlsa_order: radix sort failed (workspace %ld bytes)", ws_bytes);
+  SR_LAUNCH_CHECK("nlsa_order");
+  return 0;
+}
+
+/* ret [N][n_hashes][L][Cy], score [N][n_hashes][L] (token positions) from x_embed [N*L][Ce], y_embed [N*L][Cy] and the
+ * order of srhip_nlsa_order; then out [N*L][Cy] = x + res_scale * sum_h softmax_h(score) ret_h. */
+int srhip_nlsa_attention(const float* x_embed, const float* y_embed, const unsigned long long* order, float* ret, float* score,
+                         const float* x, float* out, int N, int L, int Ce, int Cy, int n_hashes, int chunk_size,
+                         float res_scale, void* stream) {
+  SR_REQUIRE(x_embed && y_embed && order && ret && score && x && out, "nlsa_attention: null operand");
+  SR_REQUIRE(Ce > 0 && Ce <= CE_MAX && Cy > 0 && chunk_size > 0 && L >= chunk_size,
+             "nlsa_attention: Ce = %d (<= 64), chunk_size = %d (<= L = %d)", Ce, chunk_size, L);
+  const int nchunks = sr_cdiv(L, chunk_size);
+  const size_t lds = ((size_t)QT * CE_MAX + (size_t)chunk_size * KP + (size_t)QT * 3 * chunk_size + 3 * chunk_size + QT) * 4;
+  SR_REQUIRE(lds <= 160 * 1024, "nlsa_attention: chunk_size %d needs %zu bytes of LDS", chunk_size, lds);
+  hipStream_t st = (hipStream_t)stream;
+  static size_t reserved = 0;
+  if (lds > reserved) {
+    if (hipFuncSetAttribute((const void*)k_nlsa_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return sr_fail(-5, "nlsa_attention: cannot reserve %zu bytes of LDS", lds);
+    reserved = lds;
+  }
+  hipLaunchKernelGGL(k_nlsa_attention, dim3(N * n_hashes * nchunks), dim3(256), lds, st, x_embed, y_embed, order, ret, score, L,
+                     Ce, Cy, n_hashes, chunk_size, nchunks);
+  hipLaunchKernelGGL(k_nlsa_combine, dim3(sr_cdiv((long)N * L, 4)), dim3(256), 0, st, ret, score, x, out, N, L, Cy, n_hashes,
+                     res_scale);
+  SR_LAUNCH_CHECK("nlsa_attention");
+  return 0;
+}
+
+}  // extern "C"

@@ -59,6 +59,12 @@ def define_G(args):
         return net(upscale=opt_net[f'{nt}_upscale'], n_resblock=opt_net[f'{nt}_n_resblock'],
                    n_feats=opt_net[f'{nt}_n_feats'], res_scale=opt_net[f'{nt}_res_scale'],
                    img_range=opt_net[f'{nt}_img_range'], in_chans=opt_net[f'{nt}_in_chans'])
+    if net_type == constants.NLSN:                  # select_network.py:149-160 (evaluation only here)
+        from dlib.models.network_nlsn import NLSN as net
+        return net(upscale=opt_net[f'{nt}_upscale'], n_resblocks=opt_net[f'{nt}_n_resblocks'],
+                   n_feats=opt_net[f'{nt}_n_feats'], n_hashes=opt_net[f'{nt}_n_hashes'],
+                   chunk_size=opt_net[f'{nt}_chunk_size'], res_scale=opt_net[f'{nt}_res_scale'],
+                   img_range=opt_net[f'{nt}_img_range'], in_chans=opt_net[f'{nt}_in_chans'])
     if net_type == constants.PROSR:                 # select_network.py:110-128
         from dlib.models.network_prosr import ProSR as net
         upscale = opt_net[f'{nt}_upscale']

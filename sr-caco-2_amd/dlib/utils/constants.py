@@ -14,7 +14,8 @@ DBPN = 'DBPN'  # https://arxiv.org/pdf/1803.02735.pdf (reference constants.py:49
 SRFBN = 'SRFBN'  # https://arxiv.org/pdf/1903.09814.pdf (reference constants.py:46)
 PROSR = 'ProSR'  # https://arxiv.org/pdf/1804.02900.pdf (reference constants.py:48)
 ENLCN = 'ENLCN'  # https://arxiv.org/pdf/2201.03794.pdf (reference constants.py:36)
-MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR, MEMNET, DBPN, SRFBN, PROSR, ENLCN]
+NLSN = 'NLSN'  # Mei et al., CVPR 2021 (reference constants.py:38)
+MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR, MEMNET, DBPN, SRFBN, PROSR, ENLCN, NLSN]
 
 SWINIR_MTH = 'SWINIR'
 EDSR_LIIF_MTH = 'EDSR_LIIF'
@@ -27,9 +28,10 @@ DBPN_MTH = 'DBPN'
 SRFBN_MTH = 'SRFBN'
 PROSR_MTH = 'PROSR'
 ENLCN_MTH = 'ENLCN'
+NLSN_MTH = 'NLSN'
 NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH, DRRN: DRRN_MTH, SRCNN: SRCNN_MTH,
                   MSLAPSR: MSLAPSR_MTH, MEMNET: MEMNET_MTH, DBPN: DBPN_MTH, SRFBN: SRFBN_MTH, PROSR: PROSR_MTH,
-                  ENLCN: ENLCN_MTH}
+                  ENLCN: ENLCN_MTH, NLSN: NLSN_MTH}
 
 US_PIXEL_SHUFFLE = 'pixelshuffle'
 US_PIXEL_SHUFFLE_DIRECT = 'pixelshuffledirect'

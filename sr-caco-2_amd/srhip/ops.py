@@ -316,6 +316,41 @@ def enlca_finish(num, x, out, res_scale):
     return out
 
 
+def nlsa_hash_buckets(L, chunk_size):
+    return lib.srhip_nlsa_hash_buckets(int(L), int(chunk_size))
+
+
+def nlsa_order(x_embed, rotations, N, L):
+    """Token order of every (sample, hash round) of NLSN's sparse attention (network_nlsn.py:145-207): x_embed [N*L, Ce],
+    rotations [1, Ce, n_hashes, hash_buckets // 2] (what the reference draws with torch.randn at every call) -> int64
+    [N, n_hashes, L], low 20 bits = token index, ordered by hash code then token."""
+    _chk(x_embed, rotations)
+    _, Ce, nh, hbh = rotations.shape
+    rot_t = rotations[0].permute(1, 2, 0).reshape(nh * hbh, Ce).contiguous()        # [round-major column, Ce]
+    rotated = gemm_nt(x_embed, rot_t)                                               # exact-f32 MFMA
+    items = N * nh * L
+    keys = torch.empty(items, dtype=torch.int64, device=x_embed.device)
+    order = torch.empty(N, nh, L, dtype=torch.int64, device=x_embed.device)
+    wsb = lib.srhip_nlsa_sort_ws(items)
+    ws = SCRATCH.get("nlsa_sort", (wsb + 3) // 4, device=x_embed.device)
+    call("srhip_nlsa_order", _p(rotated), rotated.stride(0), keys.data_ptr(), order.data_ptr(), _p(ws), wsb, N, L, nh, 2 * hbh,
+         _st())
+    return order
+
+
+def nlsa_attention(x_embed, y_embed, order, x, out, N, L, chunk_size, res_scale):
+    """out = x + res_scale * NonLocalSparseAttention(x) given the embeddings and the token order (network_nlsn.py:209-266)."""
+    _chk(x_embed, y_embed, x, out)
+    Ce, Cy, nh = x_embed.shape[1], y_embed.shape[1], order.shape[1]
+    assert x_embed.is_contiguous() and y_embed.is_contiguous() and x.is_contiguous() and out.is_contiguous()
+    assert x.shape == (N * L, Cy) == tuple(out.shape)
+    ret = SCRATCH.get("nlsa_ret", N * nh * L * Cy, device=x.device)
+    score = SCRATCH.get("nlsa_score", N * nh * L, device=x.device)
+    call("srhip_nlsa_attention", _p(x_embed), _p(y_embed), order.data_ptr(), _p(ret), _p(score), _p(x), _p(out), N, L, Ce, Cy,
+         nh, int(chunk_size), float(res_scale), _st())
+    return out
+
+
 def mlp_f16_fusable(C, hidden):
     """Shapes srhip_mlp_fwd_f16x2 / srhip_mlp_bwd_f16x2 take with the weight planes PrepTable.linear builds for the
     Linear GEMMs (format 1: two fp16 planes)."""

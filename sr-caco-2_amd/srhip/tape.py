@@ -391,6 +391,35 @@ class Tape:
             self.back.append(bwd)
         return out
 
+    def nlsa(self, x, keys, n_hashes, chunk_size, res_scale, rotations=None, tap=None):
+        """NonLocalSparseAttention in evaluation mode (network_nlsn.py:131-268): keys = bank entries of conv_match (3x3,
+        C -> C/4) and conv_assembly (1x1).  rotations: the LSH rotations [1, C/4, n_hashes, hash_buckets // 2] (None:
+        drawn with torch.randn on the device, as the reference does at every call); tap: dict that receives the rotations
+        and the token order used.  Inference only."""
+        e1, e2 = (self.bank.d[k] for k in keys)
+        B, H, W, C = x.t.shape
+        L, T = H * W, B * H * W
+        xin = x.t if x.t.is_contiguous() else x.t.contiguous()
+        xe = torch.empty(B, H, W, e1.Co, device=self.dev)
+        ops.conv3x3(xin, e1.wp, e1.bias, e1.Co, out=xe)
+        ye = torch.empty(T, e2.Co, device=self.dev)
+        ops.gemm_nt(xin.view(T, C), e2.w1, e2.bias, out=ye)
+        hb = ops.nlsa_hash_buckets(L, chunk_size)
+        if rotations is None:
+            rotations = torch.randn(1, e1.Co, n_hashes, hb // 2, device=self.dev)
+        assert tuple(rotations.shape) == (1, e1.Co, n_hashes, hb // 2), (rotations.shape, hb)
+        order = ops.nlsa_order(xe.view(T, e1.Co), rotations, B, L)
+        if tap is not None:
+            tap["rotations"], tap["order"] = rotations, order
+        y = self.new(B, H, W, C)
+        ops.nlsa_attention(xe.view(T, e1.Co), ye, order, xin.view(T, C), y.view(T, C), B, L, chunk_size, res_scale)
+        out = self._out(y)
+        if self.save:
+            def bwd():
+                raise NotImplementedError("NonLocalSparseAttention on libsrhip: inference only; no backward")
+            self.back.append(bwd)
+        return out
+
     def conv_in1(self, x3, weight, bias, names):
         """first conv of a 1-channel image: x3 [B, H, W] -> [B, H, W, Co] (small.hip)."""
         B, H, W = x3.shape

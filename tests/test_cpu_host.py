@@ -139,6 +139,26 @@ def test_enlcn_mirror_layout_and_oracle_vs_reference_golden():
         assert (y - torch.from_numpy(g[f"x{scale}/y"])).abs().max().item() <= 2e-6
 
 
+def test_nlsn_mirror_layout_and_oracle_vs_reference_golden():
+    """NLSN: state_dict keys in the reference's order; the oracle, given the rotations the reference drew and
+    the order its sort produced (both in g34_nlsn.npz), reproduces the reference's output exactly."""
+    from dlib.models.network_nlsn import NLSN
+    from oracle import sr_oracle as O
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g34_nlsn.npz"))
+    assert list(NLSN(upscale=2, in_chans=1).state_dict().keys()) == [str(k) for k in g["state_dict_keys_default"]]
+    for scale in (2, 4):
+        sd = O.nlsn_init_state_dict(scale, 1, 8, 64, seed=int(g[f"x{scale}/seed"]))
+        net = NLSN(upscale=scale, in_chans=1, n_resblocks=8, n_feats=64)
+        assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+        rots = [torch.from_numpy(g[f"x{scale}/rot{a}"]) for a in range(2)]
+        idx = [torch.from_numpy(g[f"x{scale}/indices{a}"]) for a in range(2)]
+        taps = []
+        y = O.nlsn_forward(sd, torch.from_numpy(g[f"x{scale}/x"]), scale, 8, 4, 144, 0.1, rotations=rots, indices=idx, taps=taps)
+        assert (y - torch.from_numpy(g[f"x{scale}/y"])).abs().max().item() <= 2e-6
+        for a in range(2):
+            assert torch.equal(taps[a]["codes"], torch.from_numpy(g[f"x{scale}/codes{a}"]))
+
+
 def test_tape_net_mirrors_have_the_reference_state_dict_layout():
     """DBPN / SRFBN mirrors: the registry's default nets carry the reference's state_dict keys (SRFBN: in the
     reference's ORDER, frozen MeanShift convs included) and the re-layout maps of the strided / transposed convs are exact."""

@@ -247,3 +247,73 @@ def test_enlcn_registry_default_width_vs_oracle():
     assert (y - yref).abs().mean().item() <= 1e-5 and rel(y, yref) < 2e-5, rel(y, yref)
     mse = ((ya.clamp(0, 1) - yref.clamp(0, 1)) ** 2).mean().item()        # --amp: PSNR of the amp output against the f32 one
     assert mse < 1e-5, mse
+
+
+@pytest.mark.parametrize("scale", [2, 4])
+def test_nlsn_forward_vs_reference_golden(scale):
+    """NLSN (network_nlsn.py), narrow configuration of g34_nlsn.npz (x2: 720 tokens, 5 chunks; x4: 480 tokens, chunk
+    padding 96), fed the LSH rotations the reference drew.  (1) the hash codes agree with the reference's except where two
+    rotated components tie to rounding; (2) with the oracle replaying THIS run's token order -- the reference leaves the
+    order inside a hash bucket to torch.sort, here it is by token index -- the outputs agree to f32 rounding; (3) against
+    the reference's own output (its order) the image differs only where bucket boundaries moved."""
+    from dlib.models.network_nlsn import NLSN
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g34_nlsn").items() if k.startswith(f"x{scale}/")}
+    sd = O.nlsn_init_state_dict(scale, 1, 8, 64, seed=int(g["seed"]))
+    net = NLSN(upscale=scale, in_chans=1, n_resblocks=8, n_feats=64)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    x, yref = g["x"], g["y"]
+    rots = [g["rot0"], g["rot1"]]
+    net.engine.rotations = [r.cuda() for r in rots]
+    net.engine.taps = taps = []
+    with torch.no_grad():
+        y = net(x.cuda()).cpu()
+    N, L = x.shape[0], x.shape[2] * x.shape[3]
+    idx = []
+    for a, tp in enumerate(taps):
+        order = tp["order"].cpu()                                  # [N, n_hashes, L]: (group * buckets + code) << 20 | token
+        nh = order.shape[1]
+        tok = order & ((1 << 20) - 1)
+        hb = int(g[f"codes{a}"].max().item()) // nh + 1
+        hb += hb % 2
+        code = (order >> 20) % hb
+        for h in range(nh):                                        # ordered by code, ties by token
+            key = code[:, h] * L + tok[:, h]
+            assert bool((key[:, 1:] > key[:, :-1]).all())
+            assert torch.equal(tok[:, h].sort(dim=1)[0], torch.arange(L).expand(N, L))
+        mine = torch.empty(N, nh, L, dtype=torch.int64)
+        mine.scatter_(2, tok, code + torch.arange(nh).view(1, nh, 1) * hb)
+        agree = (mine.reshape(N, -1) == g[f"codes{a}"]).double().mean().item()
+        assert agree >= 0.995, (a, agree)
+        idx.append((tok + torch.arange(nh).view(1, nh, 1) * L).reshape(N, nh * L))
+    yo = O.nlsn_forward(sd, x, scale, 8, 4, 144, 0.1, rotations=rots, indices=idx)
+    assert (y - yo).abs().mean().item() <= 1e-5 and rel(y, yo) < 3e-5, rel(y, yo)
+    assert (y - yref).abs().mean().item() <= 2e-3, (y - yref).abs().mean().item()
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(x.cuda()).sum().backward()
+
+
+def test_nlsn_registry_default_width_vs_oracle():
+    """The registry's net (32 ResBlocks, 256 features, five attention blocks with 64-dim matching embeddings, chunks of
+    144) at x2 on 40 x 36 inputs, rotations drawn on the device, against the oracle replaying them and the order used."""
+    from dlib.models.network_nlsn import NLSN
+    sd = O.nlsn_init_state_dict(2, 1, seed=6)
+    net = NLSN(upscale=2, in_chans=1)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    gen = torch.Generator().manual_seed(10)
+    x = torch.rand(1, 1, 40, 36, generator=gen)
+    net.engine.taps = taps = []
+    with torch.no_grad():
+        y = net(x.cuda()).cpu()
+    N, L = 1, 40 * 36
+    rots = [tp["rotations"].cpu() for tp in taps]
+    idx = []
+    for tp in taps:
+        tok = tp["order"].cpu() & ((1 << 20) - 1)
+        nh = tok.shape[1]
+        idx.append((tok + torch.arange(nh).view(1, nh, 1) * L).reshape(N, nh * L))
+    with torch.no_grad():
+        yo = O.nlsn_forward(sd, x, 2, rotations=rots, indices=idx)
+    assert len(taps) == 5 and (y - yo).abs().mean().item() <= 1e-5 and rel(y, yo) < 3e-5, rel(y, yo)
