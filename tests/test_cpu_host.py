@@ -116,7 +116,7 @@ def test_registry_and_factories():
     e = init_net_g({'net_type': constants.EDSR_LIIF}, {'scale': 4, 'n_channels': 1, 'h_size': 512})
     assert define_G(A(netG=e)).n_resblocks == 16
     with pytest.raises(NotImplementedError):
-        define_G(A(netG={'net_type': 'NLSN'}))
+        define_G(A(netG={'net_type': 'GRL'}))
     assert constants.NETTYPE_METHOD[constants.SWINIR] == 'SWINIR'
 
 
