@@ -274,7 +274,7 @@ def test_main_cli_contract():
     with pytest.raises(ValueError):
         M.parse_input("--net_type swinir --method EDSR_LIIF".split())
     with pytest.raises(NotImplementedError):
-        M.parse_input("--net_type NLSN --method NLSN".split())
+        M.parse_input("--net_type GRL --method GRL".split())
     e = M.parse_input("--net_type EDSR_LIIF --method EDSR_LIIF --scale 4 --h_size 512".split())
     assert e.netG['EDSR_LIIF_n_resblocks'] == 16 and e.netG['EDSR_LIIF_upscale'] == 4
 
