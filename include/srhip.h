@@ -364,6 +364,22 @@ int srhip_nlsa_attention(const float* x_embed, const float* y_embed, const unsig
                          const float* x, float* out, int N, int L, int Ce, int Cy, int n_hashes, int chunk_size,
                          float res_scale, void* stream);
 
+/* ---- Fourier channel attention of DFCAN, evaluation forward (dfca.hip) --------------
+ * RCAB.forward, dlib/models/network_dfcan.py:39-70, channels last:
+ *   srhip_fft2_mag_pow_shift  out = fftshift2d((|fftn(x, dim=(H, W))| + eps)^gamma)  (:60-64,27-36) as a separable DFT with
+ *                             f64 accumulation; x, out [B][H][W][C]; workspace 2*B*H*W*C floats; H, W <= 256.
+ *   srhip_channel_gate        gate = sigmoid(W2 relu(W1 avgpool(feat) + b1) + b2), out = x0 + x1 * gate  (:65-70); the average
+ *                             is a two-stage fixed-order sum (workspace: srhip_channel_gate_ws doubles; gate: B*C floats).
+ *   srhip_unary               kind 0: nn.GELU() (exact erf), kind 1: sigmoid -- the activations behind DFCAN's convs
+ *                             (:44-47,98-99,108,111-113); out may alias x. */
+int srhip_fft2_mag_pow_shift(const float* x, float* out, float* workspace, int B, int H, int W, int C, float gamma, float eps,
+                             void* stream);
+long srhip_channel_gate_ws(int B, long P, int C);
+int srhip_channel_gate(const float* feat, const float* w1, const float* b1, const float* w2, const float* b2, const float* x0,
+                       const float* x1, float* out, float* gate, double* workspace, int B, long P, int C, int Cm,
+                       void* stream);
+int srhip_unary(const float* x, float* out, long n, int kind, void* stream);
+
 /* ---- window attention on the two-plane fp16 split MFMA (wattn2.hip) -------------- */
 /* The same contract as srhip_window_attention_fwd (network_swinir.py:48-80,153-176,297-331) with the two
  * contractions as three fp16 products under power-of-two block exponents (q, k per token row, v per head-dim

@@ -1425,6 +1425,30 @@ def g_nlsn():
     npz("g34_nlsn", **out)
 
 
+def g_dfcan():
+    """DFCAN (network_dfcan.py): the registry's net (it has no width options) on small inputs, even and odd sizes (the
+    quadrant swap splits at h // 2).  Forward only."""
+    print("G35 DFCAN")
+    from dlib.models.network_dfcan import DFCAN as RefDFCAN
+    out = {}
+    for scale, hw in ((2, (16, 12)), (4, (15, 12)), (8, (8, 10))):
+        sd = O.dfcan_init_state_dict(scale, 1, seed=380 + scale)
+        net = RefDFCAN(input_shape=1, upscale=scale).eval()
+        ref_keys = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        assert ref_keys == [(k, tuple(v.shape)) for k, v in sd.items()], "DFCAN state_dict layout / order"
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(390 + scale)
+        x = torch.rand(2, 1, *hw)
+        with torch.no_grad():
+            y = net(x)
+            yo = O.dfcan_forward(sd, x, scale)
+        close(yo, y, 0.0, f"dfcan x{scale} forward")
+        pre = f"x{scale}/"
+        out[pre + "x"], out[pre + "y"], out[pre + "seed"] = x, y, np.array(380 + scale)
+    out["state_dict_keys_default"] = np.array([k for k in RefDFCAN(input_shape=1, upscale=2).state_dict().keys()])
+    npz("g35_dfcan", **out)
+
+
 def g_lowres():
     """The low-resolution side of DatasetDPSR items (dataset_dpsr.py:592-645,684-744,1037-1180): outputs of the
     reference's own functions on seeded inputs -- the fixtures of sr-caco-2_amd/dlib/datasets/lowres.py."""
@@ -1703,7 +1727,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_nlsn, g_enlcn, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_dfcan, g_nlsn, g_enlcn, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

@@ -967,6 +967,69 @@ def nlsn_init_state_dict(upscale: int, in_chans: int = 1, n_resblocks: int = 32,
 
 
 # ----------------------------------------------------------------------------
+# DFCAN (dlib/models/network_dfcan.py): Fourier channel attention
+def _dfcan_fftshift2d(img: Tensor) -> Tensor:
+    """fftshift2d (network_dfcan.py:27-36): the four quadrants swapped, split at h // 2, w // 2."""
+    _, _, h, w = img.shape
+    fs11, fs12 = img[:, :, h // 2:, w // 2:], img[:, :, h // 2:, :w // 2]
+    fs21, fs22 = img[:, :, :h // 2, w // 2:], img[:, :, :h // 2, :w // 2]
+    return torch.cat([torch.cat([fs11, fs21], axis=2), torch.cat([fs12, fs22], axis=2)], axis=3)
+
+
+def _dfcan_rcab(sd: SD, pre: str, x: Tensor, gamma: float = 0.8) -> Tensor:
+    """RCAB.forward (network_dfcan.py:39-70): two conv + GELU, then the channel gate from the spectrum's magnitude:
+    |FFT2|^0.8 (+1e-8 inside the power), fftshift, conv + ReLU, global average, 64 -> 4 -> 64 with ReLU / sigmoid."""
+    x0 = x
+    x = F.gelu(F.conv2d(x, sd[pre + ".conv_gelu1.0.weight"], sd[pre + ".conv_gelu1.0.bias"], padding=1))
+    x = F.gelu(F.conv2d(x, sd[pre + ".conv_gelu2.0.weight"], sd[pre + ".conv_gelu2.0.bias"], padding=1))
+    x1 = x
+    x = torch.fft.fftn(x, dim=(2, 3))
+    x = torch.pow(torch.abs(x) + 1e-8, gamma)
+    x = _dfcan_fftshift2d(x)
+    x = F.relu(F.conv2d(x, sd[pre + ".conv_relu1.0.weight"], sd[pre + ".conv_relu1.0.bias"], padding=1))
+    x = F.adaptive_avg_pool2d(x, 1)
+    x = F.relu(F.conv2d(x, sd[pre + ".conv_relu2.0.weight"], sd[pre + ".conv_relu2.0.bias"]))
+    x = torch.sigmoid(F.conv2d(x, sd[pre + ".conv_sigmoid.0.weight"], sd[pre + ".conv_sigmoid.0.bias"]))
+    return x0 + x1 * x
+
+
+def dfcan_forward(sd: SD, x: Tensor, upscale: int) -> Tensor:
+    """DFCAN.forward (network_dfcan.py:86-116): conv + GELU; 4 residual groups of 4 RCABs; conv 64 -> 64 s^2 + GELU;
+    PixelShuffle(s); conv + sigmoid."""
+    x = F.gelu(F.conv2d(x, sd["input.0.weight"], sd["input.0.bias"], padding=1))
+    for g in range(4):
+        x0 = x
+        for r in range(4):
+            x = _dfcan_rcab(sd, f"RGs.{g}.RCABs.{r}", x)
+        x = x0 + x
+    x = F.gelu(F.conv2d(x, sd["conv_gelu.0.weight"], sd["conv_gelu.0.bias"], padding=1))
+    x = F.pixel_shuffle(x, upscale)
+    return torch.sigmoid(F.conv2d(x, sd["conv_sigmoid.0.weight"], sd["conv_sigmoid.0.bias"], padding=1))
+
+
+def dfcan_init_state_dict(upscale: int, in_chans: int = 1, seed: int = 0, bias_std: float = 0.02) -> SD:
+    """Seeded weights in the reference's state_dict layout and order (N(0, 1 / sqrt(fan_in)))."""
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+
+    def conv(pre, ci, co, k):
+        sd[pre + ".weight"] = torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k)
+        sd[pre + ".bias"] = torch.randn(co, generator=g) * bias_std
+    conv("input.0", in_chans, 64, 3)
+    for gi in range(4):
+        for r in range(4):
+            pre = f"RGs.{gi}.RCABs.{r}"
+            conv(pre + ".conv_gelu1.0", 64, 64, 3)
+            conv(pre + ".conv_gelu2.0", 64, 64, 3)
+            conv(pre + ".conv_relu1.0", 64, 64, 3)
+            conv(pre + ".conv_relu2.0", 64, 4, 1)
+            conv(pre + ".conv_sigmoid.0", 4, 64, 1)
+    conv("conv_gelu.0", 64, 64 * upscale ** 2, 3)
+    conv("conv_sigmoid.0", 64, in_chans, 3)
+    return sd
+
+
+# ----------------------------------------------------------------------------
 # MSLapSRN (dlib/models/network_mslapsr.py)
 # ----------------------------------------------------------------------------
 def mslapsrn_forward(sd: SD, x: Tensor, upscale: int) -> Tuple[Tensor, List[Tensor]]:

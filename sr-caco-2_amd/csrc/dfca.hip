@@ -1,0 +1,206 @@
+// The Fourier channel attention of DFCAN, evaluation forward -- reference RCAB.forward, dlib/models/network_dfcan.py:39-70:
+// the spectrum's magnitude |FFT2(x)|^gamma (+1e-8 inside the power, :62-63), the quadrant swap fftshift2d (:27-36), and
+// behind the conv + ReLU on it the channel gate: global average, 64 -> 4 -> 64 with ReLU / sigmoid (:65-68), out = x0 +
+// x1 * gate (:69-70).  Plus the two point-wise activations the net uses outside conv epilogues (GELU, sigmoid).
+//
+// The transform is a separable DFT on channels-last data: the channel index is the contiguous one, so a row (column)
+// transform is a small dense product with the channels as the coalesced batch dimension -- per output W (H) terms, f64
+// accumulation, twiddles from sincospi of the exactly reduced index.  LR feature maps are <= 256 x 256 here; an FFT
+// butterfly would save flops that do not matter next to the net's convs.
+#include "common.h"
+
+namespace {
+
+constexpr int DF_C = 64;      // channels per block pass (C is handled in groups of 64)
+
+// pass 1: along W.  block = (b, h) row, thread = (channel c, output v stride 4)
+__global__ void __launch_bounds__(256) k_dft_rows(const float* __restrict__ x, float2* __restrict__ T, int H, int W, int C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  double* const tw = (double*)smraw;                 // [W][2] cos, sin of 2 pi k / W
+  float* const row = (float*)(tw + 2 * W);           // [W][DF_C]
+  const int tid = threadIdx.x, c = tid & 63, v0 = tid >> 6;
+  const long bh = blockIdx.x;
+  for (int k = tid; k < W; k += 256) {
+    double s, co;
+    sincospi(2.0 * (double)k / (double)W, &s, &co);
+    tw[2 * k] = co; tw[2 * k + 1] = s;
+  }
+  for (int c0 = 0; c0 < C; c0 += DF_C) {
+    __syncthreads();
+    for (int i = tid; i < W * DF_C; i += 256) {
+      const int w = i >> 6, cc = i & 63;
+      row[i] = c0 + cc < C ? x[(bh * W + w) * C + c0 + cc] : 0.f;
+    }
+    __syncthreads();
+    if (c0 + c < C)
+      for (int v = v0; v < W; v += 4) {
+        double re = 0.0, im = 0.0;
+        int k = 0;                                     // (v * w) mod W, incrementally
+        for (int w = 0; w < W; ++w) {
+          const double xv = (double)row[w * DF_C + c];
+          re += xv * tw[2 * k];
+          im -= xv * tw[2 * k + 1];
+          k += v; if (k >= W) k -= W;
+        }
+        T[(bh * W + v) * C + c0 + c] = float2{(float)re, (float)im};
+      }
+  }
+}
+
+// pass 2: along H, then magnitude^gamma and the quadrant swap.  block = (b, v) column
+__global__ void __launch_bounds__(256) k_dft_cols_mag(const float2* __restrict__ T, float* __restrict__ out, int H, int W, int C,
+                                                      float gamma, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  double* const tw = (double*)smraw;                 // [H][2]
+  float2* const col = (float2*)(tw + 2 * H);         // [H][DF_C]
+  const int tid = threadIdx.x, c = tid & 63, u0 = tid >> 6;
+  const int b = blockIdx.x / W, v = blockIdx.x % W;
+  for (int k = tid; k < H; k += 256) {
+    double s, co;
+    sincospi(2.0 * (double)k / (double)H, &s, &co);
+    tw[2 * k] = co; tw[2 * k + 1] = s;
+  }
+  const int jv = (v - W / 2 + W) % W;                // fftshift2d: out[i][j] = img[(i + H//2) % H][(j + W//2) % W]
+  for (int c0 = 0; c0 < C; c0 += DF_C) {
+    __syncthreads();
+    for (int i = tid; i < H * DF_C; i += 256) {
+      const int h = i >> 6, cc = i & 63;
+      col[i] = c0 + cc < C ? T[(((long)b * H + h) * W + v) * C + c0 + cc] : float2{0.f, 0.f};
+    }
+    __syncthreads();
+    if (c0 + c < C)
+      for (int u = u0; u < H; u += 4) {
+        double re = 0.0, im = 0.0;
+        int k = 0;
+        for (int h = 0; h < H; ++h) {
+          const double a = (double)col[h * DF_C + c].x, bb = (double)col[h * DF_C + c].y;
+          const double co = tw[2 * k], s = tw[2 * k + 1];      // e^{-i t} = co - i s
+          re += a * co + bb * s;
+          im += bb * co - a * s;
+          k += u; if (k >= H) k -= H;
+        }
+        const float mag = (float)sqrt(re * re + im * im);
+        const int iu = (u - H / 2 + H) % H;
+        out[(((long)b * H + iu) * W + jv) * C + c0 + c] = powf(mag + eps, gamma);
+      }
+  }
+}
+
+// global average over the pixels: partial sums per (sample, pixel block), then ...
+__global__ void __launch_bounds__(256) k_pool_partial(const float* __restrict__ x, double* __restrict__ part, long P, int C,
+                                                      int nblk) {
+  __shared__ double sm[4][DF_C];
+  const int tid = threadIdx.x, c = tid & 63, r = tid >> 6;
+  const int b = blockIdx.x / nblk, pb = blockIdx.x % nblk;
+  const long p0 = (P * pb) / nblk, p1 = (P * (pb + 1)) / nblk;
+  for (int c0 = 0; c0 < C; c0 += DF_C) {
+    double a = 0.0;
+    if (c0 + c < C)
+      for (long p = p0 + r; p < p1; p += 4) a += (double)x[((long)b * P + p) * C + c0 + c];
+    sm[r][c] = a;
+    __syncthreads();
+    if (r == 0 && c0 + c < C) part[((long)b * nblk + pb) * C + c0 + c] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+    __syncthreads();
+  }
+}
+// ... the gate of one sample: mean, C -> Cm with ReLU, Cm -> C with sigmoid (1x1 convs on a 1x1 map, :66-68)
+__global__ void __launch_bounds__(256) k_gate(const double* __restrict__ part, int nblk, long P, const float* __restrict__ w1,
+                                              const float* __restrict__ b1, const float* __restrict__ w2,
+                                              const float* __restrict__ b2, float* __restrict__ gate, int C, int Cm) {
+  __shared__ float mean[256], mid[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < C) {
+    double a = 0.0;
+    for (int k = 0; k < nblk; ++k) a += part[((long)b * nblk + k) * C + tid];
+    mean[tid] = (float)(a / (double)P);
+  }
+  __syncthreads();
+  if (tid < Cm) {
+    float a = b1[tid];
+    for (int k = 0; k < C; ++k) a += w1[tid * C + k] * mean[k];
+    mid[tid] = fmaxf(a, 0.f);
+  }
+  __syncthreads();
+  if (tid < C) {
+    float a = b2[tid];
+    for (int k = 0; k < Cm; ++k) a += w2[tid * Cm + k] * mid[k];
+    gate[(long)b * C + tid] = 1.0f / (1.0f + expf(-a));
+  }
+}
+// out = x0 + x1 * gate[sample][channel]
+__global__ void __launch_bounds__(256) k_gate_apply(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                    const float* __restrict__ gate, float* __restrict__ out, long P, int C,
+                                                    long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long b = i / (P * C);
+    out[i] = x0[i] + x1[i] * gate[b * C + c];
+  }
+}
+// kind 0: exact-erf GELU (nn.GELU default); 1: sigmoid
+__global__ void __launch_bounds__(256) k_unary(const float* __restrict__ x, float* __restrict__ out, long n, int kind) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = x[i];
+    out[i] = kind == 0 ? gelu_f(v) : 1.0f / (1.0f + expf(-v));
+  }
+}
+
+inline int ew_blocks(long n) { const long g = (n + 255) / 256; return (int)(g < 8192 ? g : 8192); }
+
+}  // namespace
+
+extern "C" {
+
+/* out[b][i][j][c] = (|FFT2(x[b][.][.][c])| + eps)^gamma under fftshift2d; x, out [B][H][W][C]; workspace: 2 * B*H*W*C floats.
+ * H, W <= 256 (one row / column of 64 channels in LDS). */
+int srhip_fft2_mag_pow_shift(const float* x, float* out, float* workspace, int B, int H, int W, int C, float gamma, float eps,
+                             void* stream) {
+  SR_REQUIRE(x && out && workspace && B > 0 && H > 0 && W > 0 && C > 0, "fft2_mag_pow_shift: bad arguments");
+  SR_REQUIRE(H <= 256 && W <= 256, "fft2_mag_pow_shift: H, W <= 256 (H=%d W=%d)", H, W);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t l1 = (size_t)W * 16 + (size_t)W * DF_C * 4, l2 = (size_t)H * 16 + (size_t)H * DF_C * 8;
+  static size_t r1 = 0, r2 = 0;
+  if (l1 > r1) {
+    if (hipFuncSetAttribute((const void*)k_dft_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1) != hipSuccess)
+      return sr_fail(-5, "fft2_mag_pow_shift: cannot reserve %zu bytes of LDS", l1);
+    r1 = l1;
+  }
+  if (l2 > r2) {
+    if (hipFuncSetAttribute((const void*)k_dft_cols_mag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess)
+      return sr_fail(-5, "fft2_mag_pow_shift: cannot reserve %zu bytes of LDS", l2);
+    r2 = l2;
+  }
+  hipLaunchKernelGGL(k_dft_rows, dim3(B * H), dim3(256), l1, st, x, (float2*)workspace, H, W, C);
+  hipLaunchKernelGGL(k_dft_cols_mag, dim3(B * W), dim3(256), l2, st, (const float2*)workspace, out, H, W, C, gamma, eps);
+  SR_LAUNCH_CHECK("fft2_mag_pow_shift");
+  return 0;
+}
+
+long srhip_channel_gate_ws(int B, long P, int C) { return (long)B * (P < 4096 ? 1 : 64) * C; }   /* doubles */
+
+/* gate[b][c] = sigmoid(W2 relu(W1 mean_p(feat[b][p][.]) + b1) + b2) (W1 [Cm][C], W2 [C][Cm]); out = x0 + x1 * gate.
+ * feat, x0, x1, out: [B][P][C] contiguous; C <= 256, Cm <= 64; workspace: srhip_channel_gate_ws doubles; gate: B*C floats. */
+int srhip_channel_gate(const float* feat, const float* w1, const float* b1, const float* w2, const float* b2, const float* x0,
+                       const float* x1, float* out, float* gate, double* workspace, int B, long P, int C, int Cm,
+                       void* stream) {
+  SR_REQUIRE(feat && w1 && b1 && w2 && b2 && x0 && x1 && out && gate && workspace, "channel_gate: null operand");
+  SR_REQUIRE(B > 0 && P > 0 && C > 0 && C <= 256 && Cm > 0 && Cm <= 64, "channel_gate: C <= 256, Cm <= 64 (C=%d Cm=%d)", C, Cm);
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = P < 4096 ? 1 : 64;
+  hipLaunchKernelGGL(k_pool_partial, dim3(B * nblk), dim3(256), 0, st, feat, workspace, P, C, nblk);
+  hipLaunchKernelGGL(k_gate, dim3(B), dim3(256), 0, st, (const double*)workspace, nblk, P, w1, b1, w2, b2, gate, C, Cm);
+  const long n = (long)B * P * C;
+  hipLaunchKernelGGL(k_gate_apply, dim3(ew_blocks(n)), dim3(256), 0, st, x0, x1, gate, out, P, C, n);
+  SR_LAUNCH_CHECK("channel_gate");
+  return 0;
+}
+
+/* kind 0: nn.GELU() (exact erf); kind 1: sigmoid.  out may alias x. */
+int srhip_unary(const float* x, float* out, long n, int kind, void* stream) {
+  SR_REQUIRE(x && out && n > 0 && (kind == 0 || kind == 1), "unary: bad arguments");
+  hipLaunchKernelGGL(k_unary, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, out, n, kind);
+  SR_LAUNCH_CHECK("unary");
+  return 0;
+}
+
+}  // extern "C"

@@ -65,6 +65,9 @@ def define_G(args):
                    n_feats=opt_net[f'{nt}_n_feats'], n_hashes=opt_net[f'{nt}_n_hashes'],
                    chunk_size=opt_net[f'{nt}_chunk_size'], res_scale=opt_net[f'{nt}_res_scale'],
                    img_range=opt_net[f'{nt}_img_range'], in_chans=opt_net[f'{nt}_in_chans'])
+    if net_type == constants.DFCAN:                 # select_network.py:162-167 (evaluation only here)
+        from dlib.models.network_dfcan import DFCAN as net
+        return net(input_shape=opt_net[f'{nt}_in_chans'], upscale=opt_net[f'{nt}_upscale'])
     if net_type == constants.PROSR:                 # select_network.py:110-128
         from dlib.models.network_prosr import ProSR as net
         upscale = opt_net[f'{nt}_upscale']

@@ -50,6 +50,8 @@ def init_net_g(netG: dict, args: dict) -> dict:
         out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'], f'{nt}_n_resblocks': 32,
                     f'{nt}_n_feats': 256, f'{nt}_n_hashes': 4, f'{nt}_chunk_size': 144, f'{nt}_res_scale': 0.1,
                     f'{nt}_img_range': 1.0})
+    elif netG['net_type'] == constants.DFCAN:        # utils_init_default_args.py:194-197
+        out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels']})
     else:
         raise NotImplementedError(netG['net_type'])
     out[f'{nt}_init_type'] = constants.INIT_W_DEFAULT

@@ -125,6 +125,7 @@ def parse_input(argv=None):
                 constants.DRRN: {'num_residual_units': int},
                 constants.DBPN: {'base_filter': int, 'feat': int, 'num_stages': int},
                 constants.ENLCN: {'n_resblock': int, 'n_feats': int, 'res_scale': float},
+                constants.DFCAN: {},
                 constants.NLSN: {'n_resblocks': int, 'n_feats': int, 'n_hashes': int, 'chunk_size': int,
                                  'res_scale': float},
                 constants.SRFBN: {'num_features': int, 'num_steps': int, 'num_groups': int},

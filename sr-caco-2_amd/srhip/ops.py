@@ -351,6 +351,38 @@ def nlsa_attention(x_embed, y_embed, order, x, out, N, L, chunk_size, res_scale)
     return out
 
 
+def unary(x, out, kind):
+    """kind 'gelu' (nn.GELU(), exact erf) or 'sigmoid'; out may be x."""
+    _chk(x, out)
+    assert x.is_contiguous() and out.is_contiguous() and x.numel() == out.numel()
+    call("srhip_unary", _p(x), _p(out), x.numel(), {"gelu": 0, "sigmoid": 1}[kind], _st())
+    return out
+
+
+def fft2_mag_pow_shift(x, out, gamma=0.8, eps=1e-8):
+    """out = fftshift2d((|fftn(x, dim=(H, W))| + eps) ** gamma) on NHWC [B, H, W, C] (network_dfcan.py:27-36,60-64)."""
+    _chk(x, out)
+    B, H, W, C = x.shape
+    assert x.is_contiguous() and out.is_contiguous() and out.shape == x.shape
+    ws = SCRATCH.get("fft2_ws", 2 * x.numel(), device=x.device)
+    call("srhip_fft2_mag_pow_shift", _p(x), _p(out), _p(ws), B, H, W, C, float(gamma), float(eps), _st())
+    return out
+
+
+def channel_gate(feat, w1, b1, w2, b2, x0, x1, out):
+    """out = x0 + x1 * sigmoid(W2 relu(W1 mean_pixels(feat) + b1) + b2) per (sample, channel): the channel gate of DFCAN's
+    RCAB (network_dfcan.py:65-70).  feat, x0, x1, out NHWC [B, H, W, C]; w1 [Cm, C], w2 [C, Cm]."""
+    _chk(feat, w1, b1, w2, b2, x0, x1, out)
+    B, H, W, C = feat.shape
+    Cm = w1.shape[0]
+    assert all(t.is_contiguous() for t in (feat, w1, w2, x0, x1, out)) and w1.shape == (Cm, C) and w2.shape == (C, Cm)
+    ws = SCRATCH.get("gate_ws", lib.srhip_channel_gate_ws(B, H * W, C), torch.float64, feat.device)
+    gate = SCRATCH.get("gate_vec", B * C, device=feat.device)
+    call("srhip_channel_gate", _p(feat), _p(w1), _p(b1), _p(w2), _p(b2), _p(x0), _p(x1), _p(out), _p(gate), _p(ws), B, H * W, C,
+         Cm, _st())
+    return out
+
+
 def mlp_f16_fusable(C, hidden):
     """Shapes srhip_mlp_fwd_f16x2 / srhip_mlp_bwd_f16x2 take with the weight planes PrepTable.linear builds for the
     Linear GEMMs (format 1: two fp16 planes)."""

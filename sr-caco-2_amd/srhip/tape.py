@@ -420,6 +420,33 @@ class Tape:
             self.back.append(bwd)
         return out
 
+    def _no_backward(self, what):
+        if self.save:
+            def bwd():
+                raise NotImplementedError(f"{what} on libsrhip: inference only; no backward")
+            self.back.append(bwd)
+
+    def unary(self, x, kind):
+        """nn.GELU() / sigmoid as their own op (DFCAN: network_dfcan.py:44-47,98-99,108,111-113).  Inference only."""
+        xin = x.t if x.t.is_contiguous() else x.t.contiguous()
+        y = self.new(*x.t.shape)
+        ops.unary(xin, y, kind)
+        self._no_backward(kind)
+        return self._out(y)
+
+    def fourier_gate(self, x0, x1, key_conv, names_conv, w1, b1, w2, b2):
+        """DFCAN's Fourier channel attention (RCAB.forward, network_dfcan.py:60-70): gate = sigmoid(W2 relu(W1 avgpool(relu(
+        conv(fftshift(|FFT2(x1)|^0.8)))))), out = x0 + x1 * gate.  Inference only."""
+        a = x1.t if x1.t.is_contiguous() else x1.t.contiguous()
+        m = torch.empty_like(a)
+        ops.fft2_mag_pow_shift(a, m)
+        c = self.relu(self.conv(self.var(m, need=False), key_conv, names_conv))
+        y = self.new(*a.shape)
+        x0c = x0.t if x0.t.is_contiguous() else x0.t.contiguous()
+        ops.channel_gate(c.t, w1, b1, w2, b2, x0c, a, y)
+        self._no_backward("the Fourier channel attention")
+        return self._out(y)
+
     def conv_in1(self, x3, weight, bias, names):
         """first conv of a 1-channel image: x3 [B, H, W] -> [B, H, W, Co] (small.hip)."""
         B, H, W = x3.shape

@@ -159,6 +159,23 @@ def test_nlsn_mirror_layout_and_oracle_vs_reference_golden():
             assert torch.equal(taps[a]["codes"], torch.from_numpy(g[f"x{scale}/codes{a}"]))
 
 
+def test_dfcan_mirror_layout_and_oracle_vs_reference_golden():
+    """DFCAN: state_dict keys in the reference's order; the oracle reproduces the reference's outputs of
+    g35_dfcan.npz (even and odd image sizes: the quadrant swap splits at h // 2)."""
+    from dlib.models.network_dfcan import DFCAN
+    from oracle import sr_oracle as O
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g35_dfcan.npz"))
+    assert list(DFCAN(input_shape=1, upscale=2).state_dict().keys()) == [str(k) for k in g["state_dict_keys_default"]]
+    with pytest.raises(NotImplementedError):
+        DFCAN(input_shape=3, upscale=2)
+    for scale in (2, 4, 8):
+        sd = O.dfcan_init_state_dict(scale, 1, seed=int(g[f"x{scale}/seed"]))
+        net = DFCAN(input_shape=1, upscale=scale)
+        assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]
+        y = O.dfcan_forward(sd, torch.from_numpy(g[f"x{scale}/x"]), scale)
+        assert (y - torch.from_numpy(g[f"x{scale}/y"])).abs().max().item() <= 2e-6
+
+
 def test_tape_net_mirrors_have_the_reference_state_dict_layout():
     """DBPN / SRFBN mirrors: the registry's default nets carry the reference's state_dict keys (SRFBN: in the
     reference's ORDER, frozen MeanShift convs included) and the re-layout maps of the strided / transposed convs are exact."""

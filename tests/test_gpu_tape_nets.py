@@ -317,3 +317,35 @@ def test_nlsn_registry_default_width_vs_oracle():
     with torch.no_grad():
         yo = O.nlsn_forward(sd, x, 2, rotations=rots, indices=idx)
     assert len(taps) == 5 and (y - yo).abs().mean().item() <= 1e-5 and rel(y, yo) < 3e-5, rel(y, yo)
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8])
+def test_dfcan_forward_vs_reference_golden(scale):
+    """DFCAN (network_dfcan.py) against the reference's outputs of g35_dfcan.npz: GELU / sigmoid ops, the spectrum
+    magnitude as a separable DFT (even and odd sizes through the quadrant swap), the channel gate, the 64 -> 64 s^2
+    upsampling conv as 256-column slices."""
+    from dlib.models.network_dfcan import DFCAN
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g35_dfcan").items() if k.startswith(f"x{scale}/")}
+    sd = O.dfcan_init_state_dict(scale, 1, seed=int(g["seed"]))
+    net = DFCAN(input_shape=1, upscale=scale)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(g["x"].cuda()).cpu()
+    assert (y - g["y"]).abs().mean().item() <= 1e-5 and rel(y, g["y"]) < 2e-5, rel(y, g["y"])
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(g["x"].cuda()).sum().backward()
+
+
+def test_dfcan_spectrum_magnitude_vs_torch_fft():
+    """srhip_fft2_mag_pow_shift against torch.fft on NHWC data, sizes incl. odd and 256."""
+    from srhip import ops
+    gen = torch.Generator().manual_seed(3)
+    for (B, H, W, C) in ((2, 16, 12, 64), (1, 15, 9, 64), (1, 256, 64, 64), (1, 40, 256, 8)):
+        x = torch.randn(B, H, W, C, generator=gen)
+        out = torch.empty(B, H, W, C, device="cuda")
+        ops.fft2_mag_pow_shift(x.cuda(), out)
+        xn = x.permute(0, 3, 1, 2).double()
+        ref = O._dfcan_fftshift2d(torch.pow(torch.abs(torch.fft.fftn(xn, dim=(2, 3))) + 1e-8, 0.8)).permute(0, 2, 3, 1)
+        assert rel(out, ref) < 2e-6, ((B, H, W, C), rel(out, ref))
