@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) k_lsh_keys(const float* __restrict__ rot,
 // One block = one chunk of one (sample, round): queries in tiles of QT rows against 3 * cs keys.
 constexpr int QT = 48;
 constexpr int CE_MAX = 64;
-constexpr int KP = CE_MAX + 1;               // key row pitch in LDS (conflict-free for lanes walking the keys)
+constexpr int KP = CE_MAX + 4;               // key row pitch in LDS: 16-byte aligned rows, lanes walking the keys 4 banks apart
 
 __global__ void __launch_bounds__(256) k_nlsa_attention(const float* __restrict__ xe, const float* __restrict__ ye,
                                                         const unsigned long long* __restrict__ order, float* __restrict__ ret,
@@ -68,15 +68,15 @@ __global__ void __launch_bounds__(256) k_nlsa_attention(const float* __restrict_
   for (int q0 = 0; q0 < cs; q0 += QT) {
     const int nq = min(QT, cs - q0);
     __syncthreads();
-    for (int i = tid; i < nq * Ce; i += 256) {
-      const int r = i / Ce, e = i - r * Ce;
-      sq[r * CE_MAX + e] = xb[(long)ktok[q0 + r] * Ce + e];      // a chunk's queries are its own keys' rows, unnormalised
+    for (int i = tid; i < nq * CE_MAX; i += 256) {
+      const int r = i / CE_MAX, e = i - r * CE_MAX;
+      sq[i] = e < Ce ? xb[(long)ktok[q0 + r] * Ce + e] : 0.f;    // a chunk's queries are its own keys' rows, unnormalised
     }
     for (int kt = 0; kt < 3; ++kt) {
       __syncthreads();
-      for (int i = tid; i < cs * Ce; i += 256) {
-        const int r = i / Ce, e = i - r * Ce;
-        sk[r * KP + e] = xb[(long)ktok[kt * cs + r] * Ce + e];
+      for (int i = tid; i < cs * CE_MAX; i += 256) {
+        const int r = i / CE_MAX, e = i - r * CE_MAX;
+        sk[r * KP + e] = e < Ce ? xb[(long)ktok[kt * cs + r] * Ce + e] : 0.f;
       }
       __syncthreads();
       for (int r = tid; r < cs; r += 256) {                      // F.normalize(p = 2, eps = 5e-5) of the key rows (:224)
@@ -86,10 +86,14 @@ __global__ void __launch_bounds__(256) k_nlsa_attention(const float* __restrict_
         for (int e = 0; e < Ce; ++e) sk[r * KP + e] *= f;
       }
       __syncthreads();
+      const int Ce4 = (Ce + 3) & ~3;                              // (columns Ce .. Ce4 - 1 of both tiles are zero)
       for (int p = tid; p < nq * cs; p += 256) {
         const int i = p / cs, j = p - i * cs;
         float a = 0.f;
-        for (int e = 0; e < Ce; ++e) a += sq[i * CE_MAX + e] * sk[j * KP + e];
+        for (int e = 0; e < Ce4; e += 4) {
+          const f32x4 qv = *(const f32x4*)(sq + i * CE_MAX + e), kv = *(const f32x4*)(sk + j * KP + e);
+          a += (qv.x * kv.x + qv.y * kv.y) + (qv.z * kv.z + qv.w * kv.w);
+        }
         ss[i * K3 + kt * cs + j] = a;
       }
     }
@@ -113,7 +117,19 @@ __global__ void __launch_bounds__(256) k_nlsa_attention(const float* __restrict_
       float acc[QT];
 #pragma unroll
       for (int i = 0; i < QT; ++i) acc[i] = 0.f;
-      for (int j = 0; j < K3; ++j) {
+      int j = 0;
+      for (; j + 8 <= K3; j += 8) {                  // eight value rows in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = yb[(long)ktok[j + u] * Cy + c];
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+          const f32x4 p0 = *(const f32x4*)(ss + i * K3 + j), p1 = *(const f32x4*)(ss + i * K3 + j + 4);
+          acc[i] += (p0.x * v[0] + p0.y * v[1]) + (p0.z * v[2] + p0.w * v[3]) + (p1.x * v[4] + p1.y * v[5]) +
+                    (p1.z * v[6] + p1.w * v[7]);
+        }
+      }
+      for (; j < K3; ++j) {
         const float v = yb[(long)ktok[j] * Cy + c];
 #pragma unroll
         for (int i = 0; i < QT; ++i) acc[i] += ss[i * K3 + j] * v;
@@ -196,8 +212,8 @@ int srhip_nlsa_attention(const float* x_embed, const float* y_embed, const unsig
                          const float* x, float* out, int N, int L, int Ce, int Cy, int n_hashes, int chunk_size,
                          float res_scale, void* stream) {
   SR_REQUIRE(x_embed && y_embed && order && ret && score && x && out, "nlsa_attention: null operand");
-  SR_REQUIRE(Ce > 0 && Ce <= CE_MAX && Cy > 0 && chunk_size > 0 && L >= chunk_size,
-             "nlsa_attention: Ce = %d (<= 64), chunk_size = %d (<= L = %d)", Ce, chunk_size, L);
+  SR_REQUIRE(Ce > 0 && Ce <= CE_MAX && Cy > 0 && chunk_size > 0 && chunk_size % 4 == 0 && L >= chunk_size,
+             "nlsa_attention: Ce = %d (<= 64), chunk_size = %d (a multiple of 4, <= L = %d)", Ce, chunk_size, L);
   const int nchunks = sr_cdiv(L, chunk_size);
   const size_t lds = ((size_t)QT * CE_MAX + (size_t)chunk_size * KP + (size_t)QT * 3 * chunk_size + 3 * chunk_size + QT) * 4;
   SR_REQUIRE(lds <= 160 * 1024, "nlsa_attention: chunk_size %d needs %zu bytes of LDS", chunk_size, lds);
