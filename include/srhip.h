@@ -380,6 +380,21 @@ int srhip_channel_gate(const float* feat, const float* w1, const float* b1, cons
                        void* stream);
 int srhip_unary(const float* x, float* out, long n, int kind, void* stream);
 
+/* ---- token-branch pieces of ACT, evaluation forward (act_ops.hip) --------------
+ * dlib/models/network_act.py:468-541 on channels-last data:
+ *   srhip_unfold / srhip_fold   F.unfold(x, k, stride, padding) / F.fold(tok, (H, W), k, stride) between the feature map
+ *                               (pixels of ldx / ldo floats, C channels used) and the token matrix (rows of ldt floats,
+ *                               columns c*k*k + ky*k + kx); fold is a gather (deterministic), uncovered pixels get 0.
+ *                               unfold with k = 5, s = 1, pad = 2 is the im2col of the 5 x 5 head convs (:362-364).
+ *   srhip_layernorm_rows        nn.LayerNorm with affine over rows of any width (:115-133); y may alias x.
+ *   srhip_softmax_rows          x[r] <- softmax(scale * x[r]) in place (:173-178,212-217). */
+int srhip_unfold(const float* x, long ldx, float* tok, long ldt, int B, int H, int W, int C, int k, int s, int pad,
+                 void* stream);
+int srhip_fold(const float* tok, long ldt, float* out, long ldo, int B, int H, int W, int C, int k, int s, void* stream);
+int srhip_layernorm_rows(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, long M, int C,
+                         float eps, void* stream);
+int srhip_softmax_rows(float* x, long ld, long R, int n, float scale, void* stream);
+
 /* ---- window attention on the two-plane fp16 split MFMA (wattn2.hip) -------------- */
 /* The same contract as srhip_window_attention_fwd (network_swinir.py:48-80,153-176,297-331) with the two
  * contractions as three fp16 products under power-of-two block exponents (q, k per token row, v per head-dim

@@ -1449,6 +1449,34 @@ def g_dfcan():
     npz("g35_dfcan", **out)
 
 
+def g_act():
+    """ACT (network_act.py): a narrow configuration (16 features, 2 RCABs per group, 4 heads: 144-dim tokens) with every op
+    class of the registry's net -- 5 x 5 head convs, 3 x 3 tokens, self-attention, the cross-scale attention against
+    overlapping 6 x 6 tokens (F.fold / F.unfold), RCAN groups, fusion blocks -- on image sizes that are and are not
+    multiples of the token size.  Weights: oracle.seeded_state_dict over the reference's own layout.  Forward only."""
+    print("G36 ACT")
+    from dlib.models.network_act import ACT as RefACT
+    out = {}
+    cfg = dict(n_feats=16, n_resgroups=4, n_resblocks=2, reduction=4, n_heads=4, n_layers=8, n_fusionblocks=4)
+    for scale, hw in ((2, (12, 15)), (4, (14, 13)), (8, (9, 12))):
+        net = RefACT(upscale=scale, in_chans=1, **cfg).eval()
+        layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        sd = O.seeded_state_dict(layout, 400 + scale)
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(410 + scale)
+        x = torch.rand(2, 1, *hw)
+        with torch.no_grad():
+            y = net(x)
+            yo = O.act_forward(sd, x, scale, n_feats=16, n_resblocks=2, n_heads=4)
+        close(yo, y, 0.0, f"act x{scale} forward")
+        pre = f"x{scale}/"
+        out[pre + "x"], out[pre + "y"], out[pre + "seed"] = x, y, np.array(400 + scale)
+        out[pre + "layout_keys"] = np.array([k for k, _ in layout])
+    out["state_dict_keys_default"] = np.array([k for k in RefACT(upscale=2, in_chans=1).state_dict().keys()])
+    out["state_dict_shapes_default"] = np.array([str(tuple(v.shape)) for v in RefACT(upscale=2, in_chans=1).state_dict().values()])
+    npz("g36_act", **out)
+
+
 def g_lowres():
     """The low-resolution side of DatasetDPSR items (dataset_dpsr.py:592-645,684-744,1037-1180): outputs of the
     reference's own functions on seeded inputs -- the fixtures of sr-caco-2_amd/dlib/datasets/lowres.py."""
@@ -1727,7 +1755,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_dfcan, g_nlsn, g_enlcn, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_act, g_dfcan, g_nlsn, g_enlcn, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

@@ -1030,6 +1030,152 @@ def dfcan_init_state_dict(upscale: int, in_chans: int = 1, seed: int = 0, bias_s
 
 
 # ----------------------------------------------------------------------------
+# ACT (dlib/models/network_act.py): CNN (RCAN) branch + transformer branch with cross-scale token attention, fused
+def _act_ln(sd: SD, pre: str, x: Tensor) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[pre + ".weight"], sd[pre + ".bias"], 1e-5)
+
+
+def _act_heads(t: Tensor, h: int) -> Tensor:              # 'b n (h d) -> b h n d'
+    b, n, hd = t.shape
+    return t.reshape(b, n, h, hd // h).permute(0, 2, 1, 3)
+
+
+def _act_attend(q: Tensor, k: Tensor, v: Tensor, scale: float) -> Tensor:
+    dots = torch.einsum('bhid,bhjd->bhij', q, k) * scale
+    out = torch.einsum('bhij,bhjd->bhid', dots.softmax(dim=-1), v)
+    b, h, n, d = out.shape
+    return out.permute(0, 2, 1, 3).reshape(b, n, h * d)   # 'b h n d -> b n (h d)'
+
+
+def _act_self_attention(sd: SD, pre: str, x: Tensor, heads: int, dim_head: int) -> Tensor:
+    """PreNorm(SelfAttention) (network_act.py:115-183)"""
+    xn = _act_ln(sd, pre + ".norm", x)
+    q, k, v = F.linear(xn, sd[pre + ".fn.to_qkv.weight"]).chunk(3, dim=-1)
+    out = _act_attend(_act_heads(q, heads), _act_heads(k, heads), _act_heads(v, heads), dim_head ** -0.5)
+    return F.linear(out, sd[pre + ".fn.to_out.0.weight"], sd[pre + ".fn.to_out.0.bias"])
+
+
+def _act_cross_attention(sd: SD, pre: str, xq: Tensor, xkv: Tensor, heads: int, dim_head: int) -> Tensor:
+    """PreNorm2(CrossAttention) (network_act.py:125-227)"""
+    q = F.linear(_act_ln(sd, pre + ".norm", xq), sd[pre + ".fn.to_q.weight"])
+    k, v = F.linear(_act_ln(sd, pre + ".norm2", xkv), sd[pre + ".fn.to_kv.weight"]).chunk(2, dim=-1)
+    out = _act_attend(_act_heads(q, heads), _act_heads(k, heads), _act_heads(v, heads), dim_head ** -0.5)
+    return F.linear(out, sd[pre + ".fn.to_out.0.weight"], sd[pre + ".fn.to_out.0.bias"])
+
+
+def _act_ffn(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """PreNorm(FeedForward) (:136-148)"""
+    h = F.gelu(F.linear(_act_ln(sd, pre + ".norm", x), sd[pre + ".fn.net.0.weight"], sd[pre + ".fn.net.0.bias"]))
+    return F.linear(h, sd[pre + ".fn.net.3.weight"], sd[pre + ".fn.net.3.bias"])
+
+
+def _act_ln_mlp(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """Sequential(LayerNorm, Linear, GELU, Linear) (:396-402,416-421,450-456)"""
+    h = F.gelu(F.linear(_act_ln(sd, pre + ".0", x), sd[pre + ".1.weight"], sd[pre + ".1.bias"]))
+    return F.linear(h, sd[pre + ".3.weight"], sd[pre + ".3.bias"])
+
+
+def _act_rcab(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """RCAB (:250-277): conv, ReLU, conv, CALayer (:230-247), + x"""
+    r = F.conv2d(x, sd[pre + ".body.0.weight"], sd[pre + ".body.0.bias"], padding=1)
+    r = F.conv2d(F.relu(r), sd[pre + ".body.2.weight"], sd[pre + ".body.2.bias"], padding=1)
+    y = F.adaptive_avg_pool2d(r, 1)
+    y = F.relu(F.conv2d(y, sd[pre + ".body.3.conv_du.0.weight"], sd[pre + ".body.3.conv_du.0.bias"]))
+    y = torch.sigmoid(F.conv2d(y, sd[pre + ".body.3.conv_du.2.weight"], sd[pre + ".body.3.conv_du.2.bias"]))
+    return r * y + x
+
+
+def act_forward(sd: SD, x: Tensor, upscale: int, n_feats: int = 64, n_resblocks: int = 12, n_heads: int = 8,
+                n_fusionblocks: int = 4, token_size: int = 3, taps=None) -> Tensor:
+    """ACT.forward (network_act.py:468-541), evaluation mode (dropout 0)."""
+    h, w = x.shape[-2:]
+    ts = token_size
+    emb = n_feats * ts * ts
+    dim_head = emb // n_heads
+    x = F.conv2d(x, sd["head.0.weight"], sd["head.0.bias"], padding=1)
+    for j in (1, 2):                                       # two 5 x 5 ResBlocks (:50-76)
+        r = F.conv2d(x, sd[f"head.{j}.body.0.weight"], sd[f"head.{j}.body.0.bias"], padding=2)
+        r = F.conv2d(F.relu(r), sd[f"head.{j}.body.2.weight"], sd[f"head.{j}.body.2.bias"], padding=2)
+        x = r + x
+    identity = x
+
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+    tap("head", x)
+    tk = F.unfold(x, ts, stride=ts).permute(0, 2, 1)       # 'b d t -> b t d'
+    tk = F.linear(tk, sd["linear_encoding.weight"], sd["linear_encoding.bias"]) + tk
+    tap("enc", tk)
+    f = None
+    for i in range(n_fusionblocks):
+        tk = _act_self_attention(sd, f"mhsa_block.{i}.0", tk, n_heads, dim_head) + tk
+        tap(f"sa{i}", tk)
+        tk = _act_ffn(sd, f"mhsa_block.{i}.1", tk) + tk
+        tap(f"ffn{i}", tk)
+        ta, tb = torch.split(tk, emb // 2, -1)
+        tb = F.fold(tb.permute(0, 2, 1), (h, w), ts, stride=ts)
+        tb = F.unfold(tb, ts * 2, stride=ts).permute(0, 2, 1)
+        tb = _act_ln_mlp(sd, f"csta_block.{i}.0", tb)
+        _ta, _tb = ta, tb
+        ta = _act_cross_attention(sd, f"csta_block.{i}.1", ta, _tb, n_heads // 2, dim_head) + ta
+        tb = _act_cross_attention(sd, f"csta_block.{i}.2", tb, _ta, n_heads // 2, dim_head) + tb
+        tb = _act_ln_mlp(sd, f"csta_block.{i}.3", tb)
+        tb = F.fold(tb.permute(0, 2, 1), (h, w), ts * 2, stride=ts)
+        tb = F.unfold(tb, ts, stride=ts).permute(0, 2, 1)
+        tk = torch.cat((ta, tb), -1)
+        tk = _act_ffn(sd, f"csta_block.{i}.4", tk) + tk
+        tap(f"csta{i}", tk)
+        x0 = x                                             # ResidualGroup (:280-301)
+        for r in range(n_resblocks):
+            x = _act_rcab(sd, f"cnn_branch.{i}.body.{r}", x)
+        x = F.conv2d(x, sd[f"cnn_branch.{i}.body.{n_resblocks}.weight"], sd[f"cnn_branch.{i}.body.{n_resblocks}.bias"],
+                     padding=1) + x0
+        tap(f"cnn{i}", x)
+        tk_res, x_res = tk, x
+        tkimg = F.fold(tk.permute(0, 2, 1), (h, w), ts, stride=ts)
+        f = torch.cat((x, tkimg), 1)
+        g = f
+        for j in range(4):                                 # FB (:304-318): 1 x 1 conv, ReLU, 1 x 1 conv (no bias), + input
+            r = F.conv2d(F.relu(F.conv2d(g, sd[f"fusion_block.{i}.{j}.body.0.weight"])), sd[f"fusion_block.{i}.{j}.body.2.weight"])
+            g = r + g
+        f = f + g
+        tap(f"f{i}", f)
+        if i != n_fusionblocks - 1:
+            tkimg, x = torch.split(f, n_feats, 1)
+            tk = F.unfold(tkimg, ts, stride=ts).permute(0, 2, 1)
+            tk = _act_ln_mlp(sd, f"fusion_mlp.{i}", tk) + tk_res
+            x = F.conv2d(F.relu(F.conv2d(x, sd[f"fusion_cnn.{i}.0.weight"], sd[f"fusion_cnn.{i}.0.bias"], padding=1)),
+                         sd[f"fusion_cnn.{i}.2.weight"], sd[f"fusion_cnn.{i}.2.bias"], padding=1) + x_res
+    x = F.conv2d(f, sd["conv_last.weight"], sd["conv_last.bias"], padding=1) + identity
+    for st in range(int(math.log2(upscale))):
+        x = F.pixel_shuffle(F.conv2d(x, sd[f"tail.0.{2 * st}.weight"], sd[f"tail.0.{2 * st}.bias"], padding=1), 2)
+    return F.conv2d(x, sd["tail.1.weight"], sd["tail.1.bias"], padding=1)
+
+
+def seeded_state_dict(layout, seed: int, bias_std: float = 0.02) -> SD:
+    """Seeded weights for a (key, shape) layout taken from a module's own state_dict (ACT: 660 entries): matrices / conv
+    kernels N(0, 1 / sqrt(fan_in)), LayerNorm-like scale vectors 1 + N(0, 0.1), other vectors N(0, bias_std); the frozen
+    MeanShift convs keep the values the reference builds."""
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+    for k, shape in layout:
+        shape = tuple(int(v) for v in shape)
+        if k.startswith(("sub_mean", "add_mean")):
+            sd[k] = (torch.eye(3).view(3, 3, 1, 1) if k.endswith("weight")
+                     else (-1.0 if k.startswith("sub") else 1.0) * torch.tensor([0.4488, 0.4371, 0.4040]))
+        elif len(shape) > 1:
+            fan_in = 1
+            for v in shape[1:]:
+                fan_in *= v
+            sd[k] = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        elif k.endswith("weight"):
+            sd[k] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            sd[k] = bias_std * torch.randn(shape, generator=g)
+    return sd
+
+
+# ----------------------------------------------------------------------------
 # MSLapSRN (dlib/models/network_mslapsr.py)
 # ----------------------------------------------------------------------------
 def mslapsrn_forward(sd: SD, x: Tensor, upscale: int) -> Tuple[Tensor, List[Tensor]]:

@@ -1,0 +1,123 @@
+// Token-branch pieces of ACT, evaluation forward (reference dlib/models/network_act.py:468-541): F.unfold / F.fold between the
+// channels-last feature map and the token matrix (:475,487-492,499-503,512-514,525), LayerNorm over wide token rows (576,
+// 1152: nn.LayerNorm :115-133), the row softmax of the attention (:176,215).  The dense products around them are the
+// library's GEMMs.
+#include "common.h"
+
+namespace {
+
+// tokens[b][ty * nTx + tx][c * k * k + ky * k + kx] = x[b][ty * s + ky - pad][tx * s + kx - pad][c]  (zero outside)
+__global__ void __launch_bounds__(256) k_unfold(const float* __restrict__ x, long ldx, float* __restrict__ tok, long ldt, int B,
+                                                int H, int W, int C, int k, int s, int pad, int nTy, int nTx) {
+  const int kk = k * k;
+  const long n = (long)B * nTy * nTx * C * kk;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int d = (int)(i % ((long)C * kk));
+    const long t = i / ((long)C * kk);                      // b * nT + token
+    const int c = d / kk, kidx = d - c * kk, ky = kidx / k, kx = kidx - ky * k;
+    const int tx = (int)(t % nTx), ty = (int)((t / nTx) % nTy), b = (int)(t / ((long)nTx * nTy));
+    const int y = ty * s + ky - pad, xx = tx * s + kx - pad;
+    tok[t * ldt + d] = (y >= 0 && y < H && xx >= 0 && xx < W) ? x[(((long)b * H + y) * W + xx) * ldx + c] : 0.f;
+  }
+}
+// F.fold (pad 0): out[b][y][x][c] = sum over the tokens covering (y, x); a gather: deterministic
+__global__ void __launch_bounds__(256) k_fold(const float* __restrict__ tok, long ldt, float* __restrict__ out, long ldo, int B,
+                                              int H, int W, int C, int k, int s, int nTy, int nTx) {
+  const int kk = k * k;
+  const long n = (long)B * H * W * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long p = i / C;
+    const int xx = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+    float a = 0.f;
+    const int ty1 = min(y / s, nTy - 1), tx1 = min(xx / s, nTx - 1);
+    for (int ty = ty1; ty >= 0 && ty * s + k > y; --ty)
+      for (int tx = tx1; tx >= 0 && tx * s + k > xx; --tx)
+        a += tok[(((long)b * nTy + ty) * nTx + tx) * ldt + c * kk + (y - ty * s) * k + (xx - tx * s)];
+    out[p * ldo + c] = a;
+  }
+}
+// nn.LayerNorm over rows of any width (two passes over the row, eps inside the root, biased variance): one wave per row
+__global__ void __launch_bounds__(256) k_layernorm_rows(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy,
+                                                        const float* __restrict__ g, const float* __restrict__ bta, long M,
+                                                        int C, float eps) {
+  const long m = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const float* r = x + m * ldx;
+  float s1 = 0.f;
+  for (int c = lane; c < C; c += 64) s1 += r[c];
+  const float mean = wave_sum(s1) / (float)C;
+  float s2 = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = r[c] - mean; s2 += d * d; }
+  const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
+  float* o = y + m * ldy;
+  for (int c = lane; c < C; c += 64) o[c] = (r[c] - mean) * rstd * g[c] + bta[c];
+}
+// x[r][0:n] <- softmax(scale * x[r][0:n]): one wave per row
+__global__ void __launch_bounds__(256) k_softmax_rows(float* __restrict__ x, long ld, long R, int n, float scale) {
+  const long r = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float* p = x + r * ld;
+  float mx = -3.0e38f;
+  for (int j = lane; j < n; j += 64) mx = fmaxf(mx, p[j] * scale);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < n; j += 64) { const float e = expf(p[j] * scale - mx); p[j] = e; sum += e; }
+  const float inv = 1.0f / wave_sum(sum);
+  for (int j = lane; j < n; j += 64) p[j] *= inv;
+}
+
+inline int ew_blocks(long n) { const long g = (n + 255) / 256; return (int)(g < 16384 ? g : 16384); }
+
+}  // namespace
+
+extern "C" {
+
+/* F.unfold(x, k, stride = s, padding = pad) on channels-last data: x [B][H][W] pixels of ldx floats (C channels used) ->
+ * tok [B * nTy * nTx] rows of ldt floats, columns c * k * k + ky * k + kx (torch's channel-major order); nT. = (dim + 2 pad
+ * - k) / s + 1.  With k = 5, s = 1, pad = 2 it is the im2col of ACT's 5 x 5 head convs (network_act.py:362-364). */
+int srhip_unfold(const float* x, long ldx, float* tok, long ldt, int B, int H, int W, int C, int k, int s, int pad,
+                 void* stream) {
+  SR_REQUIRE(x && tok && B > 0 && C > 0 && k > 0 && s > 0 && pad >= 0 && H + 2 * pad >= k && W + 2 * pad >= k && ldx >= C,
+             "unfold: bad arguments");
+  const int nTy = (H + 2 * pad - k) / s + 1, nTx = (W + 2 * pad - k) / s + 1;
+  SR_REQUIRE(ldt >= (long)C * k * k, "unfold: token pitch %ld < %d", ldt, C * k * k);
+  const long n = (long)B * nTy * nTx * C * k * k;
+  hipLaunchKernelGGL(k_unfold, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, ldx, tok, ldt, B, H, W, C, k, s, pad,
+                     nTy, nTx);
+  SR_LAUNCH_CHECK("unfold");
+  return 0;
+}
+
+/* F.fold(tok, (H, W), k, stride = s): the overlap-add inverse of srhip_unfold (pad 0); pixels no token covers get 0. */
+int srhip_fold(const float* tok, long ldt, float* out, long ldo, int B, int H, int W, int C, int k, int s, void* stream) {
+  SR_REQUIRE(tok && out && B > 0 && C > 0 && k > 0 && s > 0 && H >= k && W >= k && ldo >= C && ldt >= (long)C * k * k,
+             "fold: bad arguments");
+  const int nTy = (H - k) / s + 1, nTx = (W - k) / s + 1;
+  const long n = (long)B * H * W * C;
+  hipLaunchKernelGGL(k_fold, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, tok, ldt, out, ldo, B, H, W, C, k, s, nTy, nTx);
+  SR_LAUNCH_CHECK("fold");
+  return 0;
+}
+
+/* y[m] = LayerNorm(x[m]) * gamma + beta over rows of C floats (any C; eps 1e-5 in nn.LayerNorm).  y may alias x. */
+int srhip_layernorm_rows(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, long M, int C,
+                         float eps, void* stream) {
+  SR_REQUIRE(x && y && gamma && beta && M > 0 && C > 0 && ldx >= C && ldy >= C, "layernorm_rows: bad arguments");
+  hipLaunchKernelGGL(k_layernorm_rows, dim3(sr_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gamma, beta, M, C,
+                     eps);
+  SR_LAUNCH_CHECK("layernorm_rows");
+  return 0;
+}
+
+/* x[r] <- softmax(scale * x[r]) over n columns, in place. */
+int srhip_softmax_rows(float* x, long ld, long R, int n, float scale, void* stream) {
+  SR_REQUIRE(x && R > 0 && n > 0 && ld >= n, "softmax_rows: bad arguments");
+  hipLaunchKernelGGL(k_softmax_rows, dim3(sr_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, R, n, scale);
+  SR_LAUNCH_CHECK("softmax_rows");
+  return 0;
+}
+
+}  // extern "C"

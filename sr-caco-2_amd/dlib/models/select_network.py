@@ -68,6 +68,11 @@ def define_G(args):
     if net_type == constants.DFCAN:                 # select_network.py:162-167 (evaluation only here)
         from dlib.models.network_dfcan import DFCAN as net
         return net(input_shape=opt_net[f'{nt}_in_chans'], upscale=opt_net[f'{nt}_upscale'])
+    if net_type == constants.ACT:                   # select_network.py:52-68 (evaluation only here)
+        from dlib.models.network_act import ACT as net
+        return net(**{k: opt_net[f'{nt}_{k}'] for k in ('upscale', 'in_chans', 'img_range', 'n_feats', 'n_resgroups',
+                                                        'n_resblocks', 'reduction', 'n_heads', 'n_layers', 'dropout_rate',
+                                                        'n_fusionblocks', 'token_size', 'expansion_ratio')})
     if net_type == constants.PROSR:                 # select_network.py:110-128
         from dlib.models.network_prosr import ProSR as net
         upscale = opt_net[f'{nt}_upscale']

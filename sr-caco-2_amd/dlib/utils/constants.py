@@ -16,7 +16,8 @@ PROSR = 'ProSR'  # https://arxiv.org/pdf/1804.02900.pdf (reference constants.py:
 ENLCN = 'ENLCN'  # https://arxiv.org/pdf/2201.03794.pdf (reference constants.py:36)
 NLSN = 'NLSN'  # Mei et al., CVPR 2021 (reference constants.py:38)
 DFCAN = 'DFCAN'  # https://www.nature.com/articles/s41592-020-01048-5 (reference constants.py:33)
-MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR, MEMNET, DBPN, SRFBN, PROSR, ENLCN, NLSN, DFCAN]
+ACT = 'ACT'  # https://arxiv.org/pdf/2203.07682.pdf (reference constants.py:37)
+MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR, MEMNET, DBPN, SRFBN, PROSR, ENLCN, NLSN, DFCAN, ACT]
 
 SWINIR_MTH = 'SWINIR'
 EDSR_LIIF_MTH = 'EDSR_LIIF'
@@ -31,9 +32,10 @@ PROSR_MTH = 'PROSR'
 ENLCN_MTH = 'ENLCN'
 NLSN_MTH = 'NLSN'
 DFCAN_MTH = 'DFCAN'
+ACT_MTH = 'ACT'
 NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH, DRRN: DRRN_MTH, SRCNN: SRCNN_MTH,
                   MSLAPSR: MSLAPSR_MTH, MEMNET: MEMNET_MTH, DBPN: DBPN_MTH, SRFBN: SRFBN_MTH, PROSR: PROSR_MTH,
-                  ENLCN: ENLCN_MTH, NLSN: NLSN_MTH, DFCAN: DFCAN_MTH}
+                  ENLCN: ENLCN_MTH, NLSN: NLSN_MTH, DFCAN: DFCAN_MTH, ACT: ACT_MTH}
 
 US_PIXEL_SHUFFLE = 'pixelshuffle'
 US_PIXEL_SHUFFLE_DIRECT = 'pixelshuffledirect'

@@ -1,0 +1,242 @@
+"""ACT on libsrhip, evaluation forward (reference dlib/models/network_act.py:321-541): a CNN branch (RCAN residual groups)
+and a transformer branch (3 x 3 tokens, self-attention + cross-scale attention against overlapping 6 x 6 tokens) that
+exchange features in four fusion blocks.  Written directly over the libsrhip ops: 3 x 3 convs on the split-MFMA conv
+kernels, the 5 x 5 head convs as im2col (srhip_unfold) + GEMM, Linears / 1 x 1 convs on the exact-f32 GEMM, attention per
+(sample, head) as two GEMMs around srhip_softmax_rows, F.unfold / F.fold as srhip_unfold / srhip_fold, RCAN's channel
+attention as srhip_channel_gate.  Inference only."""
+import math
+
+import torch
+
+from . import ops
+from .tape import WeightBank
+
+
+class ACTEngine:
+    def __init__(self, net):
+        self.net = net
+        self.bank = WeightBank()
+        self.prepared = False
+        self.saved = None
+        self.taps = None          # tests: dict that receives intermediate tensors (names as oracle.act_forward's taps)
+
+    def invalidate(self):
+        self.prepared = False
+
+    def bucket_prefixes(self):
+        return [[""]]
+
+    # ------------------------------------------------------------------ weights
+    def _convs3(self):
+        net = self.net
+        out = []
+        for g in range(net.n_fusionblocks):
+            rg = net.cnn_branch[g]
+            for r in range(net.n_resblocks):
+                out += [(f"cnn_branch.{g}.body.{r}.body.0", rg.body[r].body[0]), (f"cnn_branch.{g}.body.{r}.body.2", rg.body[r].body[2])]
+            out.append((f"cnn_branch.{g}.body.{net.n_resblocks}", rg.body[net.n_resblocks]))
+        for i in range(net.n_fusionblocks - 1):
+            out += [(f"fusion_cnn.{i}.0", net.fusion_cnn[i][0]), (f"fusion_cnn.{i}.2", net.fusion_cnn[i][2])]
+        out.append(("conv_last", net.conv_last))
+        return out
+
+    def prepare(self):
+        net, bank = self.net, self.bank
+        bank.begin()
+        for key, m in self._convs3():
+            bank.conv(key, m.weight, m.bias, "c3")
+        F = net.n_feats
+        for st in range(int(math.log2(net.upscale))):
+            c = net.tail[0][2 * st]
+            for j in range(4):
+                bank.conv(f"tail.0.{2 * st}.{j}", c.weight[j * F:(j + 1) * F], c.bias[j * F:(j + 1) * F], "c3")
+        bank.finish(next(net.parameters()).device)
+        self.prepared = True
+
+    # ------------------------------------------------------------------ pieces
+    def _conv3(self, key, x, out=None, relu=False):
+        e = self.bank.d[key]
+        B, H, W, _ = x.shape
+        y = torch.empty(B, H, W, e.Co, device=x.device) if out is None else out
+        ops.conv3x3(x, e.wp, e.bias, e.Co, out=y)
+        if relu:
+            ops.leaky_relu_(y, 0.0)
+        return y
+
+    @staticmethod
+    def _linear(x2, lin, out=None):
+        return ops.gemm_nt(x2, lin.weight.data, None if lin.bias is None else lin.bias.data, out=out)
+
+    @staticmethod
+    def _ln(x2, ln):
+        return ops.layernorm_rows(x2, ln.weight.data, ln.bias.data, torch.empty_like(x2))
+
+    @staticmethod
+    def _gelu_(x):
+        return ops.unary(x, x, "gelu")
+
+    def _attend(self, q, k, v, B, Tq, Tk, heads, dh, scale):
+        """q [B*Tq, heads*dh], k / v [B*Tk, heads*dh] (views with any row pitch) -> [B*Tq, heads*dh]"""
+        out = torch.empty(B * Tq, heads * dh, device=q.device)
+        Tk4 = (Tk + 3) & ~3                         # the GEMM takes contraction lengths / pitches that are multiples of 4
+        dots = torch.zeros(Tq, Tk4, device=q.device)
+        vt = torch.zeros(dh, Tk4, device=q.device)
+        for b in range(B):
+            for h in range(heads):
+                qs = q[b * Tq:(b + 1) * Tq, h * dh:(h + 1) * dh]
+                ks = k[b * Tk:(b + 1) * Tk, h * dh:(h + 1) * dh]
+                vt[:, :Tk].copy_(v[b * Tk:(b + 1) * Tk, h * dh:(h + 1) * dh].t())
+                ops.gemm_nt(qs, ks, None, out=dots[:, :Tk])
+                ops.softmax_rows_(dots[:, :Tk], scale)
+                ops.gemm_nt(dots, vt, None, out=out[b * Tq:(b + 1) * Tq, h * dh:(h + 1) * dh])
+        return out
+
+    def _self_attention(self, blk, x2, B, T):
+        net = self.net
+        qkv = ops.gemm_nt(self._ln(x2, blk.norm), blk.fn.to_qkv.weight.data)
+        inner = net.n_heads * net.dim_head
+        o = self._attend(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, T, T, net.n_heads, net.dim_head,
+                         net.dim_head ** -0.5)
+        return self._linear(o, blk.fn.to_out[0])
+
+    def _cross_attention(self, blk, xq, xkv, B, Tq, Tk):
+        net = self.net
+        heads = net.n_heads // 2
+        inner = heads * net.dim_head
+        q = ops.gemm_nt(self._ln(xq, blk.norm), blk.fn.to_q.weight.data)
+        kv = ops.gemm_nt(self._ln(xkv, blk.norm2), blk.fn.to_kv.weight.data)
+        o = self._attend(q, kv[:, :inner], kv[:, inner:], B, Tq, Tk, heads, net.dim_head, net.dim_head ** -0.5)
+        return self._linear(o, blk.fn.to_out[0])
+
+    def _ffn(self, blk, x2):                       # PreNorm(FeedForward)
+        h = self._gelu_(self._linear(self._ln(x2, blk.norm), blk.fn.net[0]))
+        return self._linear(h, blk.fn.net[3])
+
+    def _ln_mlp(self, seq, x2):                    # Sequential(LayerNorm, Linear, GELU, Linear)
+        h = self._gelu_(self._linear(self._ln(x2, seq[0]), seq[1]))
+        return self._linear(h, seq[3])
+
+    def _conv5(self, conv, x, relu):
+        """5 x 5 conv (padding 2) as im2col + GEMM"""
+        B, H, W, C = x.shape
+        cols = torch.empty(B * H * W, C * 25, device=x.device)
+        ops.unfold(x, C, 5, 1, 2, cols)
+        y = ops.gemm_nt(cols, conv.weight.data.reshape(conv.weight.shape[0], -1), conv.bias.data)
+        if relu:
+            ops.leaky_relu_(y, 0.0)
+        return y.view(B, H, W, -1)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x3, dp=None, save=False):
+        if save:
+            raise NotImplementedError("ACT on libsrhip: inference only (BASELINE config 5's evaluation sweep); no backward")
+        if not self.prepared:
+            self.prepare()
+        net = self.net
+        B, H, W = x3.shape
+        dev = x3.device
+        nf, ts, emb = net.n_feats, net.token_size, net.embedding_dim
+        x = ops.conv3x3_cin1_fwd(x3, net.head[0].weight.data, net.head[0].bias.data, nf)
+        for j in (1, 2):
+            r = self._conv5(net.head[j].body[0], x, True)
+            r = self._conv5(net.head[j].body[2], r, False)
+            ops.axpby(r, x, 1.0, 1.0)
+            x = r
+        identity = x
+
+        def tap(name, v, img=False):
+            if self.taps is not None:
+                self.taps[name] = (v.permute(0, 3, 1, 2) if img else v.view(B, -1, v.shape[-1])).detach().clone()
+        tap("head", x, True)
+        nTy, nTx = (H - ts) // ts + 1, (W - ts) // ts + 1
+        T = nTy * nTx
+        nLy, nLx = (H - 2 * ts) // ts + 1, (W - 2 * ts) // ts + 1
+        TL = nLy * nLx
+        tk = torch.empty(B * T, emb, device=dev)
+        ops.unfold(x, nf, ts, ts, 0, tk)
+        enc = self._linear(tk, net.linear_encoding)
+        ops.axpby(tk, enc, 1.0, 1.0)
+        tap("enc", tk)
+        half = emb // 2
+        ch = half // (ts * ts)
+        f = None
+        for i in range(net.n_fusionblocks):
+            ops.axpby(tk, self._self_attention(net.mhsa_block[i][0], tk, B, T), 1.0, 1.0)
+            tap(f"sa{i}", tk)
+            ops.axpby(tk, self._ffn(net.mhsa_block[i][1], tk), 1.0, 1.0)
+            tap(f"ffn{i}", tk)
+            ta = tk[:, :half].contiguous()
+            img = torch.empty(B, H, W, ch, device=dev)
+            ops.fold(tk[:, half:], ch, ts, ts, img)
+            tb = torch.empty(B * TL, ch * 4 * ts * ts, device=dev)
+            ops.unfold(img, ch, 2 * ts, ts, 0, tb)
+            cs = net.csta_block[i]
+            tb = self._ln_mlp(cs[0], tb)
+            ta_new = self._cross_attention(cs[1], ta, tb, B, T, TL)
+            tb_new = self._cross_attention(cs[2], tb, ta, B, TL, T)
+            ops.axpby(ta_new, ta, 1.0, 1.0)
+            ops.axpby(tb_new, tb, 1.0, 1.0)
+            tb = self._ln_mlp(cs[3], tb_new)
+            ops.fold(tb, ch, 2 * ts, ts, img)
+            tk = torch.empty(B * T, emb, device=dev)
+            tk[:, :half].copy_(ta_new)
+            ops.unfold(img, ch, ts, ts, 0, tk[:, half:])
+            ops.axpby(tk, self._ffn(cs[4], tk), 1.0, 1.0)
+            tap(f"csta{i}", tk)
+            # CNN branch: ResidualGroup
+            rg = net.cnn_branch[i]
+            x0 = x
+            for r in range(net.n_resblocks):
+                m = rg.body[r]
+                pre = f"cnn_branch.{i}.body.{r}.body"
+                a = self._conv3(pre + ".0", x, relu=True)
+                a = self._conv3(pre + ".2", a)
+                ca = m.body[3].conv_du
+                w1, w2 = ca[0].weight.data, ca[2].weight.data
+                y = torch.empty_like(x)
+                ops.channel_gate(a, w1.reshape(w1.shape[0], -1).contiguous(), ca[0].bias.data,
+                                 w2.reshape(w2.shape[0], -1).contiguous(), ca[2].bias.data, x, a, y)
+                x = y
+            x = self._conv3(f"cnn_branch.{i}.body.{net.n_resblocks}", x)
+            ops.axpby(x, x0, 1.0, 1.0)
+            tap(f"cnn{i}", x, True)
+            tk_res, x_res = tk, x
+            f = torch.empty(B, H, W, 2 * nf, device=dev)
+            f[..., :nf].copy_(x)
+            ops.fold(tk, nf, ts, ts, f[..., nf:])
+            f2 = f.view(B * H * W, 2 * nf)
+            g = f2
+            for j in range(4):
+                fb = net.fusion_block[i][j]
+                w0, w2 = fb.body[0].weight.data, fb.body[2].weight.data
+                r = ops.gemm_nt(g, w0.reshape(w0.shape[0], -1).contiguous())
+                ops.leaky_relu_(r, 0.0)
+                r = ops.gemm_nt(r, w2.reshape(w2.shape[0], -1).contiguous())
+                ops.axpby(r, g, 1.0, 1.0)
+                g = r
+            ops.axpby(f2, g, 1.0, 1.0)
+            tap(f"f{i}", f, True)
+            if i != net.n_fusionblocks - 1:
+                # the reference splits f = cat(x, tokens) as "x_tkn, x = torch.split(f, n_feats, 1)" (:527): the FIRST half
+                # (the CNN features) goes on as tokens, the second (the folded tokens) as the CNN branch's input
+                tk = torch.empty(B * T, emb, device=dev)
+                ops.unfold(f[..., :nf], nf, ts, ts, 0, tk)
+                tk2 = self._ln_mlp(net.fusion_mlp[i], tk)
+                ops.axpby(tk2, tk_res, 1.0, 1.0)
+                tk = tk2
+                xa = self._conv3(f"fusion_cnn.{i}.0", f[..., nf:], relu=True)
+                xa = self._conv3(f"fusion_cnn.{i}.2", xa)
+                ops.axpby(xa, x_res, 1.0, 1.0)
+                x = xa
+        x = self._conv3("conv_last", f)
+        ops.axpby(x, identity, 1.0, 1.0)
+        for st in range(int(math.log2(net.upscale))):
+            u = torch.empty(B, x.shape[1], x.shape[2], 4 * nf, device=dev)
+            for j in range(4):
+                self._conv3(f"tail.0.{2 * st}.{j}", x, out=u[..., j * nf:(j + 1) * nf])
+            x = ops.pixel_shuffle(u, 2, nhwc_out=True)
+        y = ops.conv3x3_cout1_fwd(x, net.tail[1].weight.data, net.tail[1].bias.data)
+        return y.view(B, 1, y.shape[1], y.shape[2])
+
+    def backward(self, *a, **k):
+        raise NotImplementedError("ACT on libsrhip: inference only (BASELINE config 5's evaluation sweep); no backward")

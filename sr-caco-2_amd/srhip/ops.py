@@ -383,6 +383,42 @@ def channel_gate(feat, w1, b1, w2, b2, x0, x1, out):
     return out
 
 
+def unfold(x, C, k, s, pad, out, ldx=None):
+    """F.unfold(x, k, stride=s, padding=pad) on NHWC data: x [B, H, W, >= C] (a channel-slice view is fine) -> out [B * nT,
+    >= C*k*k] (row pitch out.stride(0)), columns c*k*k + ky*k + kx."""
+    _chk(x, out)
+    B, H, W = x.shape[:3]
+    assert x.stride(3) == 1 and x.stride(1) == W * x.stride(2) and x.stride(0) == H * x.stride(1) and out.stride(1) == 1
+    call("srhip_unfold", _p(x), x.stride(2), _p(out), out.stride(0), B, H, W, C, k, s, pad, _st())
+    return out
+
+
+def fold(tok, C, k, s, out):
+    """F.fold(tok, (H, W), k, stride=s) into NHWC out [B, H, W, >= C] (a channel-slice view is fine); tok [B * nT, >= C*k*k]."""
+    _chk(tok, out)
+    B, H, W = out.shape[:3]
+    assert out.stride(3) == 1 and out.stride(1) == W * out.stride(2) and out.stride(0) == H * out.stride(1) and tok.stride(1) == 1
+    call("srhip_fold", _p(tok), tok.stride(0), _p(out), out.stride(2), B, H, W, C, k, s, _st())
+    return out
+
+
+def layernorm_rows(x, gamma, beta, out, eps=1e-5):
+    """nn.LayerNorm with affine over the rows of a 2-D view of any width; out may be x."""
+    _chk(x, gamma, beta, out)
+    assert x.dim() == 2 and out.shape == x.shape and x.stride(1) == 1 and out.stride(1) == 1
+    call("srhip_layernorm_rows", _p(x), x.stride(0), _p(out), out.stride(0), _p(gamma), _p(beta), x.shape[0], x.shape[1],
+         float(eps), _st())
+    return out
+
+
+def softmax_rows_(x, scale=1.0):
+    """x[r] <- softmax(scale * x[r]) in place, 2-D view."""
+    _chk(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    call("srhip_softmax_rows", _p(x), x.stride(0), x.shape[0], x.shape[1], float(scale), _st())
+    return x
+
+
 def mlp_f16_fusable(C, hidden):
     """Shapes srhip_mlp_fwd_f16x2 / srhip_mlp_bwd_f16x2 take with the weight planes PrepTable.linear builds for the
     Linear GEMMs (format 1: two fp16 planes)."""

@@ -176,6 +176,25 @@ def test_dfcan_mirror_layout_and_oracle_vs_reference_golden():
         assert (y - torch.from_numpy(g[f"x{scale}/y"])).abs().max().item() <= 2e-6
 
 
+def test_act_mirror_layout_and_oracle_vs_reference_golden():
+    """ACT: the 660 state_dict entries of the registry's net in the reference's order and shapes; the oracle
+    reproduces the reference's outputs of g36_act.npz (image sizes that are and are not multiples of the token size)."""
+    from dlib.models.network_act import ACT
+    from oracle import sr_oracle as O
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g36_act.npz"))
+    sd0 = ACT(upscale=2, in_chans=1).state_dict()
+    assert list(sd0.keys()) == [str(k) for k in g["state_dict_keys_default"]]
+    assert [str(tuple(v.shape)) for v in sd0.values()] == [str(k) for k in g["state_dict_shapes_default"]]
+    cfg = dict(n_feats=16, n_resgroups=4, n_resblocks=2, reduction=4, n_heads=4, n_layers=8, n_fusionblocks=4)
+    for scale in (2, 4, 8):
+        net = ACT(upscale=scale, in_chans=1, **cfg)
+        layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        assert [k for k, _ in layout] == [str(k) for k in g[f"x{scale}/layout_keys"]]
+        sd = O.seeded_state_dict(layout, int(g[f"x{scale}/seed"]))
+        y = O.act_forward(sd, torch.from_numpy(g[f"x{scale}/x"]), scale, n_feats=16, n_resblocks=2, n_heads=4)
+        assert (y - torch.from_numpy(g[f"x{scale}/y"])).abs().max().item() <= 2e-6
+
+
 def test_tape_net_mirrors_have_the_reference_state_dict_layout():
     """DBPN / SRFBN mirrors: the registry's default nets carry the reference's state_dict keys (SRFBN: in the
     reference's ORDER, frozen MeanShift convs included) and the re-layout maps of the strided / transposed convs are exact."""

@@ -349,3 +349,59 @@ def test_dfcan_spectrum_magnitude_vs_torch_fft():
         xn = x.permute(0, 3, 1, 2).double()
         ref = O._dfcan_fftshift2d(torch.pow(torch.abs(torch.fft.fftn(xn, dim=(2, 3))) + 1e-8, 0.8)).permute(0, 2, 3, 1)
         assert rel(out, ref) < 2e-6, ((B, H, W, C), rel(out, ref))
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8])
+def test_act_forward_vs_reference_golden(scale):
+    """ACT (network_act.py), narrow configuration of g36_act.npz, against the reference's own output: 5 x 5 head convs as
+    im2col + GEMM, tokens through srhip_unfold / srhip_fold (sizes that are not multiples of the token size leave uncovered
+    pixels at zero), self- and cross-scale attention per (sample, head), RCAN groups with the channel gate, fusion blocks."""
+    from dlib.models.network_act import ACT
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g36_act").items() if k.startswith(f"x{scale}/")}
+    cfg = dict(n_feats=16, n_resgroups=4, n_resblocks=2, reduction=4, n_heads=4, n_layers=8, n_fusionblocks=4)
+    net = ACT(upscale=scale, in_chans=1, **cfg)
+    sd = O.seeded_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], int(g["seed"]))
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(g["x"].cuda()).cpu()
+    # (seeded random weights drive the features to |y| ~ 40: the gates are relative to the output's largest entry)
+    assert (y - g["y"]).abs().mean().item() <= 1e-5 * g["y"].abs().max().item() and rel(y, g["y"]) < 3e-5, rel(y, g["y"])
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(g["x"].cuda()).sum().backward()
+
+
+def test_act_registry_default_width_vs_oracle():
+    """The registry's net (64 features, 12 RCABs per group, 8 heads of 72: 576-dim tokens) at x2 on a 24 x 21 input."""
+    from dlib.models.network_act import ACT
+    net = ACT(upscale=2, in_chans=1)
+    sd = O.seeded_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], 7)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    gen = torch.Generator().manual_seed(12)
+    x = torch.rand(1, 1, 24, 21, generator=gen)
+    with torch.no_grad():
+        yo = O.act_forward(sd, x, 2)
+        y = net(x.cuda()).cpu()
+    assert (y - yo).abs().mean().item() <= 1e-5 * yo.abs().max().item() and rel(y, yo) < 3e-5, rel(y, yo)
+
+
+def test_unfold_fold_vs_torch():
+    """srhip_unfold / srhip_fold against F.unfold / F.fold (channel-major token columns, overlap-add, uncovered pixels)."""
+    import torch.nn.functional as F
+    from srhip import ops
+    gen = torch.Generator().manual_seed(4)
+    for (B, H, W, C, k, s, pad) in ((2, 12, 15, 8, 3, 3, 0), (1, 14, 13, 4, 6, 3, 0), (2, 9, 10, 16, 5, 1, 2), (1, 64, 64, 32, 6, 3, 0)):
+        x = torch.randn(B, C, H, W, generator=gen)
+        ref = F.unfold(x, k, stride=s, padding=pad).permute(0, 2, 1)             # [B, T, C k k]
+        T = ref.shape[1]
+        tok = torch.empty(B * T, C * k * k, device="cuda")
+        ops.unfold(x.permute(0, 2, 3, 1).contiguous().cuda(), C, k, s, pad, tok)
+        assert torch.equal(tok.cpu().view(B, T, -1), ref)
+        if pad == 0:
+            t = torch.randn(B, T, C * k * k, generator=gen)
+            fref = F.fold(t.permute(0, 2, 1), (H, W), k, stride=s).permute(0, 2, 3, 1)
+            img = torch.empty(B, H, W, C, device="cuda")
+            ops.fold(t.view(B * T, -1).cuda(), C, k, s, img)
+            assert rel(img, fref) < 1e-6
