@@ -119,12 +119,19 @@ class ACTEngine:
     def _conv5(self, conv, x, relu):
         """5 x 5 conv (padding 2) as im2col + GEMM"""
         B, H, W, C = x.shape
-        cols = torch.empty(B * H * W, C * 25, device=x.device)
-        ops.unfold(x, C, 5, 1, 2, cols)
-        y = ops.gemm_nt(cols, conv.weight.data.reshape(conv.weight.shape[0], -1), conv.bias.data)
+        Co = conv.weight.shape[0]
+        w2 = conv.weight.data.reshape(Co, -1)
+        y = torch.empty(B, H, W, Co, device=x.device)
+        nb = max(1, min(B, (1 << 28) // (H * W * C * 25)))        # samples per im2col buffer (GEMM operands stay < 2 GiB)
+        cols = torch.empty(nb * H * W, C * 25, device=x.device)
+        for b0 in range(0, B, nb):
+            b1 = min(B, b0 + nb)
+            n = (b1 - b0) * H * W
+            ops.unfold(x[b0:b1], C, 5, 1, 2, cols[:n])
+            ops.gemm_nt(cols[:n], w2, conv.bias.data, out=y[b0:b1].view(n, Co))
         if relu:
             ops.leaky_relu_(y, 0.0)
-        return y.view(B, H, W, -1)
+        return y
 
     # ------------------------------------------------------------------ forward
     def forward(self, x3, dp=None, save=False):
