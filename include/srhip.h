@@ -368,8 +368,10 @@ int srhip_nlsa_attention(const float* x_embed, const float* y_embed, const unsig
  * RCAB.forward, dlib/models/network_dfcan.py:39-70, channels last:
  *   srhip_fft2_mag_pow_shift  out = fftshift2d((|fftn(x, dim=(H, W))| + eps)^gamma)  (:60-64,27-36) as a separable DFT with
  *                             f64 accumulation; x, out [B][H][W][C]; workspace 2*B*H*W*C floats; H, W <= 256.
- *   srhip_channel_gate        gate = sigmoid(W2 relu(W1 avgpool(feat) + b1) + b2), out = x0 + x1 * gate  (:65-70); the average
- *                             is a two-stage fixed-order sum (workspace: srhip_channel_gate_ws doubles; gate: B*C floats).
+ *   srhip_channel_gate        gate = sigmoid(W2 act(W1 avgpool(feat) + b1) + b2), out = x0 + x1 * gate  (:65-70; also RCAN's
+ *                             CALayer network_act.py:230-247 and OmniSR's SqueezeExcitation network_omni_sr.py:133-148:
+ *                             mid_act 1 = SiLU, b1 / b2 / x0 NULL); the average is a two-stage fixed-order sum
+ *                             (workspace: srhip_channel_gate_ws doubles; gate: B*C floats).
  *   srhip_unary               kind 0: nn.GELU() (exact erf), kind 1: sigmoid -- the activations behind DFCAN's convs
  *                             (:44-47,98-99,108,111-113); out may alias x. */
 int srhip_fft2_mag_pow_shift(const float* x, float* out, float* workspace, int B, int H, int W, int C, float gamma, float eps,
@@ -377,7 +379,7 @@ int srhip_fft2_mag_pow_shift(const float* x, float* out, float* workspace, int B
 long srhip_channel_gate_ws(int B, long P, int C);
 int srhip_channel_gate(const float* feat, const float* w1, const float* b1, const float* w2, const float* b2, const float* x0,
                        const float* x1, float* out, float* gate, double* workspace, int B, long P, int C, int Cm,
-                       void* stream);
+                       int mid_act, void* stream);
 int srhip_unary(const float* x, float* out, long n, int kind, void* stream);
 
 /* ---- token-branch pieces of ACT, evaluation forward (act_ops.hip) --------------
@@ -394,6 +396,27 @@ int srhip_fold(const float* tok, long ldt, float* out, long ldo, int B, int H, i
 int srhip_layernorm_rows(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, long M, int C,
                          float eps, void* stream);
 int srhip_softmax_rows(float* x, long ld, long R, int n, float scale, void* stream);
+
+/* ---- pieces of OmniSR's omni self-attention blocks, evaluation forward (omni_ops.hip) --------------
+ * dlib/models/network_omni_sr.py, channels last:
+ *   srhip_dwconv3x3          nn.Conv2d(C, C, 3, padding=1, groups=C) (:178,318,348); w [C][9], bias may be NULL
+ *   srhip_group_attention    softmax(scale q k^T + bias) v per (group of n <= 64 consecutive token rows, head) of
+ *                            qkv [groups*n][3C] (Attention.forward :258-306 on window- or grid-ordered tokens); bias
+ *                            [heads][n][n] = rel_pos_bias(rel_pos_indices) or NULL
+ *   srhip_channel_attention  Channel_Attention / Channel_Attention_grid.forward (:353-428) on qkv [B][H][W][3C]
+ *   srhip_gelu_gate          gelu(x1) * x2 of the two halves of a [T][2C] matrix (:325-326)
+ *   srhip_maxpool2d, srhip_bilinear_resize, srhip_mul_sigmoid   ESA's F.max_pool2d(7, 3), F.interpolate(bilinear,
+ *                            align_corners=False) and x * sigmoid(c4) (:104-114) */
+int srhip_dwconv3x3(const float* x, long ldx, const float* w, const float* bias, float* out, long ldo, int B, int H, int W, int C,
+                    void* stream);
+int srhip_group_attention(const float* qkv, const float* bias, float* out, long groups, int n, int C, int heads, float scale,
+                          void* stream);
+int srhip_channel_attention(const float* qkv, const float* temperature, float* out, int B, int H, int W, int C, int heads, int ps,
+                            int grid, void* stream);
+int srhip_gelu_gate(const float* x, float* out, long T, int C, void* stream);
+int srhip_maxpool2d(const float* x, float* out, int B, int H, int W, int C, int k, int s, void* stream);
+int srhip_bilinear_resize(const float* x, float* out, int B, int H, int W, int C, int Ho, int Wo, void* stream);
+int srhip_mul_sigmoid(const float* x, const float* g, float* out, long n, void* stream);
 
 /* ---- window attention on the two-plane fp16 split MFMA (wattn2.hip) -------------- */
 /* The same contract as srhip_window_attention_fwd (network_swinir.py:48-80,153-176,297-331) with the two

@@ -1477,6 +1477,35 @@ def g_act():
     npz("g36_act", **out)
 
 
+def g_omnisr():
+    """OmniSR (network_omni_sr.py): a narrow configuration (16 features, 2 groups of 1 omni block) with every op class of the
+    registry's net -- MBConv + squeeze-excitation, window and grid attention with relative-position bias, both channel
+    attentions, gated depthwise feed-forwards, ESA -- on sizes that are and are not multiples of the 8-pixel window (zero
+    padding, cropped output).  Weights: oracle.seeded_state_dict over the reference's own layout.  Forward only."""
+    print("G37 OmniSR")
+    from dlib.models.network_omni_sr import OmniSR as RefOmni
+    out = {}
+    cfg = dict(num_feat=16, res_num=2, block_num=1)
+    for scale, hw in ((2, (16, 24)), (4, (13, 18)), (8, (16, 16))):
+        net = RefOmni(input_shape=1, upscale=scale, **cfg).eval()
+        layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        sd = O.seeded_state_dict(layout, 420 + scale)
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(430 + scale)
+        x = torch.rand(2, 1, *hw)
+        with torch.no_grad():
+            y = net(x)
+            yo = O.omnisr_forward(sd, x, scale, res_num=2, block_num=1)
+        close(yo, y, 0.0, f"omnisr x{scale} forward")
+        pre = f"x{scale}/"
+        out[pre + "x"], out[pre + "y"], out[pre + "seed"] = x, y, np.array(420 + scale)
+        out[pre + "layout_keys"] = np.array([k for k, _ in layout])
+    ref = RefOmni(input_shape=1, upscale=2)
+    out["state_dict_keys_default"] = np.array([k for k in ref.state_dict().keys()])
+    out["state_dict_shapes_default"] = np.array([str(tuple(v.shape)) for v in ref.state_dict().values()])
+    npz("g37_omnisr", **out)
+
+
 def g_lowres():
     """The low-resolution side of DatasetDPSR items (dataset_dpsr.py:592-645,684-744,1037-1180): outputs of the
     reference's own functions on seeded inputs -- the fixtures of sr-caco-2_amd/dlib/datasets/lowres.py."""
@@ -1755,7 +1784,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_act, g_dfcan, g_nlsn, g_enlcn, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_omnisr, g_act, g_dfcan, g_nlsn, g_enlcn, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

@@ -1152,6 +1152,147 @@ def act_forward(sd: SD, x: Tensor, upscale: int, n_feats: int = 64, n_resblocks:
     return F.conv2d(x, sd["tail.1.weight"], sd["tail.1.bias"], padding=1)
 
 
+# ----------------------------------------------------------------------------
+# OmniSR (dlib/models/network_omni_sr.py): omni self-attention blocks (window / grid attention, spatial and channel)
+def _omni_rel_pos_indices(w: int) -> Tensor:
+    """Attention.__init__ (network_omni_sr.py:243-255)"""
+    pos = torch.arange(w)
+    grid = torch.stack(torch.meshgrid(pos, pos, indexing="ij")).reshape(2, -1).t()      # '(i j) c'
+    rel = grid[:, None, :] - grid[None, :, :] + (w - 1)
+    return (rel * torch.tensor([2 * w - 1, 1])).sum(dim=-1)
+
+
+def _omni_ln2d(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """LayerNorm2d (:27-65): over the channels of every pixel, eps 1e-6"""
+    mu = x.mean(1, keepdim=True)
+    var = (x - mu).pow(2).mean(1, keepdim=True)
+    y = (x - mu) / (var + 1e-6).sqrt()
+    return sd[pre + ".weight"].view(1, -1, 1, 1) * y + sd[pre + ".bias"].view(1, -1, 1, 1)
+
+
+def _omni_mbconv(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """MBConv(expansion 1, no downsample) wrapped in MBConvResidual (:151-189): 1x1, GELU, depthwise 3x3, GELU,
+    squeeze-excitation (mean, Linear, SiLU, Linear, sigmoid; :133-148), 1x1, + x"""
+    h = F.gelu(F.conv2d(x, sd[pre + ".fn.0.weight"], sd[pre + ".fn.0.bias"]))
+    h = F.gelu(F.conv2d(h, sd[pre + ".fn.2.weight"], sd[pre + ".fn.2.bias"], padding=1, groups=h.shape[1]))
+    g = h.mean(dim=(2, 3))
+    g = torch.sigmoid(F.linear(F.silu(F.linear(g, sd[pre + ".fn.4.gate.1.weight"])), sd[pre + ".fn.4.gate.3.weight"]))
+    h = h * g[:, :, None, None]
+    return F.conv2d(h, sd[pre + ".fn.5.weight"], sd[pre + ".fn.5.bias"]) + x
+
+
+def _omni_attention(sd: SD, pre: str, x: Tensor, w: int, pe: bool) -> Tensor:
+    """PreNormResidual(Attention) on 'b x y w1 w2 d' (:192-306): LayerNorm, qkv without bias, heads of dim / 4, scaled
+    dot product + relative-position bias, softmax, output Linear without bias, + x"""
+    b, X, Y, w1, w2, d = x.shape
+    heads = 4                                              # dim_head = channel_num // 4 (:447)
+    t = F.layer_norm(x, (d,), sd[pre + ".norm.weight"], sd[pre + ".norm.bias"], 1e-5).reshape(b * X * Y, w1 * w2, d)
+    q, k, v = F.linear(t, sd[pre + ".fn.to_qkv.weight"]).chunk(3, dim=-1)
+
+    def hd(u):                                             # 'b n (h d) -> b h n d'
+        return u.reshape(u.shape[0], u.shape[1], heads, d // heads).permute(0, 2, 1, 3)
+    q, k, v = hd(q), hd(k), hd(v)
+    q = q * (d // heads) ** -0.5
+    sim = torch.einsum('bhid,bhjd->bhij', q, k)
+    if pe:
+        bias = sd[pre + ".fn.rel_pos_bias.weight"][_omni_rel_pos_indices(w)]       # [64, 64, heads]
+        sim = sim + bias.permute(2, 0, 1)
+    out = torch.einsum('bhij,bhjd->bhid', sim.softmax(dim=-1), v)
+    out = out.permute(0, 2, 1, 3).reshape(b * X * Y, w1, w2, d)                    # 'b h (w1 w2) d -> b w1 w2 (h d)'
+    out = F.linear(out, sd[pre + ".fn.to_out.0.weight"])
+    return out.reshape(b, X, Y, w1, w2, d) + x
+
+
+def _omni_ffn(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """Conv_PreNormResidual(Gated_Conv_FeedForward) (:202-209,308-329): LayerNorm2d, 1x1 C -> 2C, depthwise 3x3,
+    gelu(x1) * x2, 1x1, + x (no biases)"""
+    h = F.conv2d(_omni_ln2d(sd, pre + ".norm", x), sd[pre + ".fn.project_in.weight"])
+    h = F.conv2d(h, sd[pre + ".fn.dwconv.weight"], padding=1, groups=h.shape[1])
+    x1, x2 = h.chunk(2, dim=1)
+    return F.conv2d(F.gelu(x1) * x2, sd[pre + ".fn.project_out.weight"]) + x
+
+
+def _omni_channel_attention(sd: SD, pre: str, x: Tensor, ps: int, grid: bool) -> Tensor:
+    """Conv_PreNormResidual(Channel_Attention / Channel_Attention_grid) (:332-428): LayerNorm2d, qkv = depthwise 3x3 of a
+    1x1, per (window, head) -- grid: per (in-window position, head) -- the d x d attention between L2-normalised channel
+    vectors, times the head's temperature, softmax, times v; 1x1; + x"""
+    from einops import rearrange
+    b, c, h, w = x.shape
+    heads = 4
+    n = _omni_ln2d(sd, pre + ".norm", x)
+    qkv = F.conv2d(n, sd[pre + ".fn.qkv.weight"])
+    qkv = F.conv2d(qkv, sd[pre + ".fn.qkv_dwconv.weight"], padding=1, groups=3 * c).chunk(3, dim=1)
+    pat = ('b (head d) (h ph) (w pw) -> b (ph pw) head d (h w)' if grid else
+           'b (head d) (h ph) (w pw) -> b (h w) head d (ph pw)')
+    q, k, v = (rearrange(t, pat, ph=ps, pw=ps, head=heads) for t in qkv)
+    q, k = F.normalize(q, dim=-1), F.normalize(k, dim=-1)
+    attn = ((q @ k.transpose(-2, -1)) * sd[pre + ".fn.temperature"]).softmax(dim=-1)
+    out = attn @ v
+    back = ('b (ph pw) head d (h w) -> b (head d) (h ph) (w pw)' if grid else
+            'b (h w) head d (ph pw) -> b (head d) (h ph) (w pw)')
+    out = rearrange(out, back, h=h // ps, w=w // ps, ph=ps, pw=ps, head=heads)
+    return F.conv2d(out, sd[pre + ".fn.project_out.weight"]) + x
+
+
+def _omni_esa(sd: SD, pre: str, x: Tensor) -> Tensor:
+    """ESA (:85-114)"""
+    c1_ = F.conv2d(x, sd[pre + ".conv1.weight"], sd[pre + ".conv1.bias"])
+    c1 = F.conv2d(c1_, sd[pre + ".conv2.weight"], sd[pre + ".conv2.bias"], stride=2)
+    v_max = F.max_pool2d(c1, kernel_size=7, stride=3)
+    c3 = F.conv2d(v_max, sd[pre + ".conv3.weight"], sd[pre + ".conv3.bias"], padding=1)
+    c3 = F.interpolate(c3, (x.size(2), x.size(3)), mode='bilinear', align_corners=False)
+    cf = F.conv2d(c1_, sd[pre + ".conv_f.weight"], sd[pre + ".conv_f.bias"])
+    c4 = F.conv2d(c3 + cf, sd[pre + ".conv4.weight"], sd[pre + ".conv4.bias"])
+    return x * torch.sigmoid(c4)
+
+
+def omnisr_forward(sd: SD, x: Tensor, upscale: int, res_num: int = 5, block_num: int = 4, window_size: int = 8,
+                   pe: bool = True, taps=None) -> Tensor:
+    """OmniSR.forward (network_omni_sr.py:577-591) with OSAG (:495-524) and OSA_Block (:430-492)."""
+    from einops import rearrange
+    H, W = x.shape[2:]
+    ws = window_size
+    x = F.pad(x, (0, (ws - W % ws) % ws, 0, (ws - H % ws) % ws), 'constant', 0)
+    residual = F.conv2d(x, sd["input.weight"], sd["input.bias"], padding=1)
+
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+    tap("input", residual)
+    out = residual
+    for g in range(res_num):
+        gin = out
+        for bk in range(block_num):
+            pre = f"residual_layer.{g}.residual_layer.{bk}.layer"
+            out = _omni_mbconv(sd, pre + ".0", out)
+            tap(f"g{g}b{bk}.mb", out)
+            t = rearrange(out, 'b d (x w1) (y w2) -> b x y w1 w2 d', w1=ws, w2=ws)
+            t = _omni_attention(sd, pre + ".2", t, ws, pe)
+            out = rearrange(t, 'b x y w1 w2 d -> b d (x w1) (y w2)')
+            tap(f"g{g}b{bk}.att1", out)
+            out = _omni_ffn(sd, pre + ".4", out)
+            tap(f"g{g}b{bk}.ffn1", out)
+            out = _omni_channel_attention(sd, pre + ".5", out, ws, False)
+            tap(f"g{g}b{bk}.ca1", out)
+            out = _omni_ffn(sd, pre + ".6", out)
+            t = rearrange(out, 'b d (w1 x) (w2 y) -> b x y w1 w2 d', w1=ws, w2=ws)
+            t = _omni_attention(sd, pre + ".8", t, ws, pe)
+            out = rearrange(t, 'b x y w1 w2 d -> b d (w1 x) (w2 y)')
+            tap(f"g{g}b{bk}.att2", out)
+            out = _omni_ffn(sd, pre + ".10", out)
+            out = _omni_channel_attention(sd, pre + ".11", out, ws, True)
+            tap(f"g{g}b{bk}.ca2", out)
+            out = _omni_ffn(sd, pre + ".12", out)
+            tap(f"g{g}b{bk}.out", out)
+        pre = f"residual_layer.{g}"
+        out = F.conv2d(out, sd[pre + f".residual_layer.{block_num}.weight"], sd[pre + f".residual_layer.{block_num}.bias"]) + gin
+        out = _omni_esa(sd, pre + ".esa", out)
+        tap(f"g{g}.esa", out)
+    out = F.conv2d(out, sd["output.weight"], sd["output.bias"], padding=1) + residual
+    out = F.pixel_shuffle(F.conv2d(out, sd["up.0.weight"], sd["up.0.bias"], padding=1), upscale)
+    return out[:, :, :H * upscale, :W * upscale]
+
+
 def seeded_state_dict(layout, seed: int, bias_std: float = 0.02) -> SD:
     """Seeded weights for a (key, shape) layout taken from a module's own state_dict (ACT: 660 entries): matrices / conv
     kernels N(0, 1 / sqrt(fan_in)), LayerNorm-like scale vectors 1 + N(0, 0.1), other vectors N(0, bias_std); the frozen

@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(256) k_pool_partial(const float* __restrict__ 
 // ... the gate of one sample: mean, C -> Cm with ReLU, Cm -> C with sigmoid (1x1 convs on a 1x1 map, :66-68)
 __global__ void __launch_bounds__(256) k_gate(const double* __restrict__ part, int nblk, long P, const float* __restrict__ w1,
                                               const float* __restrict__ b1, const float* __restrict__ w2,
-                                              const float* __restrict__ b2, float* __restrict__ gate, int C, int Cm) {
+                                              const float* __restrict__ b2, float* __restrict__ gate, int C, int Cm,
+                                              int mid_act) {
   __shared__ float mean[256], mid[64];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid < C) {
@@ -116,13 +117,13 @@ __global__ void __launch_bounds__(256) k_gate(const double* __restrict__ part, i
   }
   __syncthreads();
   if (tid < Cm) {
-    float a = b1[tid];
+    float a = b1 ? b1[tid] : 0.f;
     for (int k = 0; k < C; ++k) a += w1[tid * C + k] * mean[k];
-    mid[tid] = fmaxf(a, 0.f);
+    mid[tid] = mid_act ? a / (1.0f + expf(-a)) : fmaxf(a, 0.f);        // SiLU | ReLU
   }
   __syncthreads();
   if (tid < C) {
-    float a = b2[tid];
+    float a = b2 ? b2[tid] : 0.f;
     for (int k = 0; k < Cm; ++k) a += w2[tid * Cm + k] * mid[k];
     gate[(long)b * C + tid] = 1.0f / (1.0f + expf(-a));
   }
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(256) k_gate_apply(const float* __restrict__ x0
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     const long b = i / (P * C);
-    out[i] = x0[i] + x1[i] * gate[b * C + c];
+    out[i] = (x0 ? x0[i] : 0.f) + x1[i] * gate[b * C + c];
   }
 }
 // kind 0: exact-erf GELU (nn.GELU default); 1: sigmoid
@@ -178,17 +179,18 @@ int srhip_fft2_mag_pow_shift(const float* x, float* out, float* workspace, int B
 
 long srhip_channel_gate_ws(int B, long P, int C) { return (long)B * (P < 4096 ? 1 : 64) * C; }   /* doubles */
 
-/* gate[b][c] = sigmoid(W2 relu(W1 mean_p(feat[b][p][.]) + b1) + b2) (W1 [Cm][C], W2 [C][Cm]); out = x0 + x1 * gate.
- * feat, x0, x1, out: [B][P][C] contiguous; C <= 256, Cm <= 64; workspace: srhip_channel_gate_ws doubles; gate: B*C floats. */
+/* gate[b][c] = sigmoid(W2 act(W1 mean_p(feat[b][p][.]) + b1) + b2) (W1 [Cm][C], W2 [C][Cm]; act = ReLU (mid_act 0) or SiLU (1);
+ * b1, b2 may be NULL); out = x0 + x1 * gate (x0 may be NULL).  feat, x0, x1, out: [B][P][C] contiguous; C <= 256, Cm <= 64;
+ * workspace: srhip_channel_gate_ws doubles; gate: B*C floats. */
 int srhip_channel_gate(const float* feat, const float* w1, const float* b1, const float* w2, const float* b2, const float* x0,
                        const float* x1, float* out, float* gate, double* workspace, int B, long P, int C, int Cm,
-                       void* stream) {
-  SR_REQUIRE(feat && w1 && b1 && w2 && b2 && x0 && x1 && out && gate && workspace, "channel_gate: null operand");
+                       int mid_act, void* stream) {
+  SR_REQUIRE(feat && w1 && w2 && x1 && out && gate && workspace && (mid_act == 0 || mid_act == 1), "channel_gate: bad operand");
   SR_REQUIRE(B > 0 && P > 0 && C > 0 && C <= 256 && Cm > 0 && Cm <= 64, "channel_gate: C <= 256, Cm <= 64 (C=%d Cm=%d)", C, Cm);
   hipStream_t st = (hipStream_t)stream;
   const int nblk = P < 4096 ? 1 : 64;
   hipLaunchKernelGGL(k_pool_partial, dim3(B * nblk), dim3(256), 0, st, feat, workspace, P, C, nblk);
-  hipLaunchKernelGGL(k_gate, dim3(B), dim3(256), 0, st, (const double*)workspace, nblk, P, w1, b1, w2, b2, gate, C, Cm);
+  hipLaunchKernelGGL(k_gate, dim3(B), dim3(256), 0, st, (const double*)workspace, nblk, P, w1, b1, w2, b2, gate, C, Cm, mid_act);
   const long n = (long)B * P * C;
   hipLaunchKernelGGL(k_gate_apply, dim3(ew_blocks(n)), dim3(256), 0, st, x0, x1, gate, out, P, C, n);
   SR_LAUNCH_CHECK("channel_gate");

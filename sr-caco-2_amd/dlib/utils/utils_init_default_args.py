@@ -57,6 +57,10 @@ def init_net_g(netG: dict, args: dict) -> dict:
                     f'{nt}_img_range': 1.0, f'{nt}_n_resgroups': 4, f'{nt}_n_resblocks': 12, f'{nt}_reduction': 16,
                     f'{nt}_n_heads': 8, f'{nt}_n_layers': 8, f'{nt}_n_fusionblocks': 4, f'{nt}_dropout_rate': 0.0,
                     f'{nt}_token_size': 3, f'{nt}_expansion_ratio': 4})
+    elif netG['net_type'] == constants.OMNISR:       # utils_init_default_args.py:203-214
+        out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'], f'{nt}_num_feat': 64,
+                    f'{nt}_res_num': 5, f'{nt}_bias': True, f'{nt}_window_size': 8, f'{nt}_block_num': 4, f'{nt}_pe': True,
+                    f'{nt}_ffn_bias': True})
     else:
         raise NotImplementedError(netG['net_type'])
     out[f'{nt}_init_type'] = constants.INIT_W_DEFAULT

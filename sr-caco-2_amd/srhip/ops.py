@@ -369,17 +369,18 @@ def fft2_mag_pow_shift(x, out, gamma=0.8, eps=1e-8):
     return out
 
 
-def channel_gate(feat, w1, b1, w2, b2, x0, x1, out):
+def channel_gate(feat, w1, b1, w2, b2, x0, x1, out, mid_act="relu"):
     """out = x0 + x1 * sigmoid(W2 relu(W1 mean_pixels(feat) + b1) + b2) per (sample, channel): the channel gate of DFCAN's
     RCAB (network_dfcan.py:65-70).  feat, x0, x1, out NHWC [B, H, W, C]; w1 [Cm, C], w2 [C, Cm]."""
     _chk(feat, w1, b1, w2, b2, x0, x1, out)
     B, H, W, C = feat.shape
     Cm = w1.shape[0]
-    assert all(t.is_contiguous() for t in (feat, w1, w2, x0, x1, out)) and w1.shape == (Cm, C) and w2.shape == (C, Cm)
+    assert all(t.is_contiguous() for t in (feat, w1, w2, x1, out) + (() if x0 is None else (x0,)))
+    assert w1.shape == (Cm, C) and w2.shape == (C, Cm)
     ws = SCRATCH.get("gate_ws", lib.srhip_channel_gate_ws(B, H * W, C), torch.float64, feat.device)
     gate = SCRATCH.get("gate_vec", B * C, device=feat.device)
     call("srhip_channel_gate", _p(feat), _p(w1), _p(b1), _p(w2), _p(b2), _p(x0), _p(x1), _p(out), _p(gate), _p(ws), B, H * W, C,
-         Cm, _st())
+         Cm, {"relu": 0, "silu": 1}[mid_act], _st())
     return out
 
 
@@ -417,6 +418,63 @@ def softmax_rows_(x, scale=1.0):
     assert x.dim() == 2 and x.stride(1) == 1
     call("srhip_softmax_rows", _p(x), x.stride(0), x.shape[0], x.shape[1], float(scale), _st())
     return x
+
+
+def dwconv3x3(x, w, bias, out):
+    """nn.Conv2d(C, C, 3, padding=1, groups=C) on NHWC x / out (channel-slice views are fine); w [C, 1, 3, 3]."""
+    _chk(x, w, bias, out)
+    B, H, W, C = out.shape
+    assert x.stride(3) == 1 and out.stride(3) == 1 and w.is_contiguous() and w.numel() == 9 * C
+    call("srhip_dwconv3x3", _p(x), x.stride(2), _p(w), _p(bias), _p(out), out.stride(2), B, H, W, C, _st())
+    return out
+
+
+def group_attention(qkv, bias, out, n, heads, scale):
+    """softmax(scale q k^T + bias) v per (n consecutive rows, head): qkv [G*n, 3C] -> out [G*n, C]."""
+    _chk(qkv, bias, out)
+    C = out.shape[1]
+    assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape == (out.shape[0], 3 * C) and out.shape[0] % n == 0
+    call("srhip_group_attention", _p(qkv), _p(bias), _p(out), out.shape[0] // n, n, C, heads, float(scale), _st())
+    return out
+
+
+def channel_attention(qkv, temperature, out, heads, ps, grid):
+    _chk(qkv, temperature, out)
+    B, H, W, C = out.shape
+    assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape == (B, H, W, 3 * C)
+    call("srhip_channel_attention", _p(qkv), _p(temperature), _p(out), B, H, W, C, heads, ps, int(bool(grid)), _st())
+    return out
+
+
+def gelu_gate(x, out):
+    _chk(x, out)
+    T, C = out.shape
+    assert x.is_contiguous() and out.is_contiguous() and x.shape == (T, 2 * C)
+    call("srhip_gelu_gate", _p(x), _p(out), T, C, _st())
+    return out
+
+
+def maxpool2d(x, k, s):
+    _chk(x)
+    B, H, W, C = x.shape
+    out = torch.empty(B, (H - k) // s + 1, (W - k) // s + 1, C, device=x.device)
+    call("srhip_maxpool2d", _p(x.contiguous()), _p(out), B, H, W, C, k, s, _st())
+    return out
+
+
+def bilinear_resize(x, Ho, Wo):
+    _chk(x)
+    B, H, W, C = x.shape
+    out = torch.empty(B, Ho, Wo, C, device=x.device)
+    call("srhip_bilinear_resize", _p(x.contiguous()), _p(out), B, H, W, C, Ho, Wo, _st())
+    return out
+
+
+def mul_sigmoid(x, g, out):
+    _chk(x, g, out)
+    assert x.is_contiguous() and g.is_contiguous() and out.is_contiguous() and x.numel() == g.numel() == out.numel()
+    call("srhip_mul_sigmoid", _p(x), _p(g), _p(out), x.numel(), _st())
+    return out
 
 
 def mlp_f16_fusable(C, hidden):

@@ -195,6 +195,24 @@ def test_act_mirror_layout_and_oracle_vs_reference_golden():
         assert (y - torch.from_numpy(g[f"x{scale}/y"])).abs().max().item() <= 2e-6
 
 
+def test_omnisr_mirror_layout_and_oracle_vs_reference_golden():
+    """OmniSR: the 1066 state_dict entries of the registry's net in the reference's order and shapes; the oracle
+    reproduces the reference's outputs of g37_omnisr.npz (sizes that are and are not multiples of the window)."""
+    from dlib.models.network_omni_sr import OmniSR
+    from oracle import sr_oracle as O
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g37_omnisr.npz"))
+    sd0 = OmniSR(input_shape=1, upscale=2).state_dict()
+    assert list(sd0.keys()) == [str(k) for k in g["state_dict_keys_default"]]
+    assert [str(tuple(v.shape)) for v in sd0.values()] == [str(k) for k in g["state_dict_shapes_default"]]
+    for scale in (2, 4, 8):
+        net = OmniSR(input_shape=1, upscale=scale, num_feat=16, res_num=2, block_num=1)
+        layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        assert [k for k, _ in layout] == [str(k) for k in g[f"x{scale}/layout_keys"]]
+        sd = O.seeded_state_dict(layout, int(g[f"x{scale}/seed"]))
+        y = O.omnisr_forward(sd, torch.from_numpy(g[f"x{scale}/x"]), scale, res_num=2, block_num=1)
+        assert (y - torch.from_numpy(g[f"x{scale}/y"])).abs().max().item() <= 2e-6
+
+
 def test_tape_net_mirrors_have_the_reference_state_dict_layout():
     """DBPN / SRFBN mirrors: the registry's default nets carry the reference's state_dict keys (SRFBN: in the
     reference's ORDER, frozen MeanShift convs included) and the re-layout maps of the strided / transposed convs are exact."""

@@ -405,3 +405,38 @@ def test_unfold_fold_vs_torch():
             img = torch.empty(B, H, W, C, device="cuda")
             ops.fold(t.view(B * T, -1).cuda(), C, k, s, img)
             assert rel(img, fref) < 1e-6
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8])
+def test_omnisr_forward_vs_reference_golden(scale):
+    """OmniSR (network_omni_sr.py), narrow configuration of g37_omnisr.npz, against the reference's own output: MBConv with
+    squeeze-excitation, window and grid attention with relative-position bias, both channel attentions, gated depthwise
+    feed-forwards, ESA (stride-2 conv, 7/3 max pooling, bilinear resize); x4: a 13 x 18 input, zero-padded to the window."""
+    from dlib.models.network_omni_sr import OmniSR
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g37_omnisr").items() if k.startswith(f"x{scale}/")}
+    net = OmniSR(input_shape=1, upscale=scale, num_feat=16, res_num=2, block_num=1)
+    sd = O.seeded_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], int(g["seed"]))
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(g["x"].cuda()).cpu()
+    assert y.shape == g["y"].shape
+    assert (y - g["y"]).abs().mean().item() <= 1e-5 * max(1.0, g["y"].abs().max().item()) and rel(y, g["y"]) < 3e-5, rel(y, g["y"])
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(g["x"].cuda()).sum().backward()
+
+
+def test_omnisr_registry_default_width_vs_oracle():
+    """The registry's net (64 features, 5 groups of 4 omni blocks) at x2 on a 24 x 32 input."""
+    from dlib.models.network_omni_sr import OmniSR
+    net = OmniSR(input_shape=1, upscale=2)
+    sd = O.seeded_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], 8)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    gen = torch.Generator().manual_seed(13)
+    x = torch.rand(1, 1, 24, 32, generator=gen)
+    with torch.no_grad():
+        yo = O.omnisr_forward(sd, x, 2)
+        y = net(x.cuda()).cpu()
+    assert (y - yo).abs().mean().item() <= 1e-5 * max(1.0, yo.abs().max().item()) and rel(y, yo) < 5e-5, rel(y, yo)
