@@ -418,6 +418,27 @@ int srhip_maxpool2d(const float* x, float* out, int B, int H, int W, int C, int 
 int srhip_bilinear_resize(const float* x, float* out, int B, int H, int W, int C, int Ho, int Wo, void* stream);
 int srhip_mul_sigmoid(const float* x, const float* g, float* out, long n, void* stream);
 
+/* ---- pieces of GRL's mixed-attention blocks, evaluation forward (grl_ops.hip) ----------------------
+ * dlib/models/network_grl.py, channels last:
+ *   srhip_avgpool2d        nn.AvgPool2d(k, k) of AnchorLinear (:603-620): [B,H,W,C] -> [B,H/k,W/k,C]
+ *   srhip_cpb_bias         AffineTransform's bias (:305-311): biasT[h][j][i] = 16 sigmoid(table[index[i][j]][h]) from the CPB
+ *                          MLP's output table [entries][heads] and a relative-position index [N1][N2] (int64, as the
+ *                          module's registered buffers); key-major so a wave of queries reads consecutive words
+ *   srhip_cosine_window_attention   Attention.attn (:338-355) under AffineTransform.forward (:296-319):
+ *                          softmax(exp(min(logit_scale, log 100)) cos(q, k) + bias + mask) v per (window, head), between the
+ *                          qwh x qww windows of a [B,qH,qW,.] image and the kwh x kww windows of a [B,kH,kW,.] image that
+ *                          share a window grid -- WindowAttention.forward (:381-412: both sides the 8x8 windows of the
+ *                          rolled qkv image, shift = 4 with calculate_mask's regions :1607-1622, or 0) and the two passes of
+ *                          AnchorStripeAttention.forward (:463-514: 4x4 anchor windows against 8x8 stripes, then back).
+ *                          q / k / v / out point at the first channel of head 0, ld* = floats between pixels, head h owns
+ *                          channels [h d, (h+1) d); windows <= 64 tokens, d <= 64.  The result lands at the query token's
+ *                          own pixel: torch.roll / window_partition / window_reverse are address arithmetic. */
+int srhip_avgpool2d(const float* x, float* out, int B, int H, int W, int C, int k, void* stream);
+int srhip_cpb_bias(const float* table, const long long* index, float* biasT, int heads, int N1, int N2, int entries, void* stream);
+int srhip_cosine_window_attention(const float* q, long ldq, int qH, int qW, int qwh, int qww, const float* k, long ldk,
+                                  const float* v, long ldv, int kH, int kW, int kwh, int kww, const float* logit_scale,
+                                  const float* biasT, float* out, long ldo, int B, int heads, int d, int shift, void* stream);
+
 /* ---- window attention on the two-plane fp16 split MFMA (wattn2.hip) -------------- */
 /* The same contract as srhip_window_attention_fwd (network_swinir.py:48-80,153-176,297-331) with the two
  * contractions as three fp16 products under power-of-two block exponents (q, k per token row, v per head-dim

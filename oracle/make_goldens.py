@@ -1506,6 +1506,51 @@ def g_omnisr():
     npz("g37_omnisr", **out)
 
 
+def g_grl():
+    """GRL (network_grl.py): a narrow configuration (36 channels, two stages of two blocks: shifted / plain windows, 'H' /
+    'W' stripes) with every op class of the registry's net -- cosine window attention with the CPB-MLP bias and the shift
+    mask, anchored stripe attention (avg-pooled anchors, anchor->window then window->anchor), the conv + channel-attention
+    local branch, post-norm residuals, the pixel-shuffle tail -- on sizes that are and are not multiples of the window
+    (reflect padding, cropped output) and that are and are not the constructor's img_size (recomputed masks).  Weights:
+    oracle.grl_state_dict over the reference's own layout.  Forward only."""
+    print("G38 GRL")
+    from dlib.models.network_grl import GRL as RefGRL
+    out = {}
+    kw = dict(in_chans=1, window_size=8, mlp_ratio=2, qkv_proj_type="linear", anchor_proj_type="avgpool",
+              anchor_window_down_factor=2, out_proj_type="linear", conv_type="1conv", upsampler="pixelshuffle",
+              local_connection=True)
+    cfg = dict(depths=[2, 2], embed_dim=36, num_heads_window=[3, 3], num_heads_stripe=[3, 3])
+    for scale, hw in ((2, (16, 24)), (4, (13, 18)), (8, (16, 16))):
+        net = RefGRL(upscale=scale, img_size=16, **cfg, **kw).eval()
+        ref_sd = net.state_dict()
+        layout = [(k, tuple(v.shape)) for k, v in ref_sd.items()]
+        for k, v in O.grl_buffers((16, 16)).items():
+            assert torch.equal(v, ref_sd[k]) and v.dtype == ref_sd[k].dtype, k
+        sd = O.grl_state_dict(layout, 440 + scale, 16)
+        net.load_state_dict(sd, strict=True)
+        torch.manual_seed(450 + scale)
+        x = torch.rand(2, 1, *hw)
+        with torch.no_grad():
+            y = net(x)
+            yo = O.grl_forward(sd, x, scale, depths=(2, 2))
+        close(yo, y, 0.0, f"grl x{scale} forward")
+        pre = f"x{scale}/"
+        out[pre + "x"], out[pre + "y"], out[pre + "seed"] = x, y, np.array(440 + scale)
+        out[pre + "layout_keys"] = np.array([k for k, _ in layout])
+        out[pre + "layout_shapes"] = np.array([str(tuple(s)) for _, s in layout])
+    ref = RefGRL(upscale=2, img_size=64, depths=[4, 4, 8, 8, 8, 4, 4], embed_dim=180, num_heads_window=[3] * 7,
+                 num_heads_stripe=[3] * 7, **kw)
+    rsd = ref.state_dict()
+    for k, v in O.grl_buffers((64, 64)).items():
+        assert torch.equal(v, rsd[k]), k
+    out["state_dict_keys_default"] = np.array([k for k in rsd.keys()])
+    out["state_dict_shapes_default"] = np.array([str(tuple(v.shape)) for v in rsd.values()])
+    b = ref.set_table_index_mask((16, 24))
+    for k in ("table_sh", "index_sh_a2w", "index_sv_w2a", "mask_w", "mask_sh_a2w"):
+        out["buf_16x24/" + k] = b[k]
+    npz("g38_grl", **out)
+
+
 def g_lowres():
     """The low-resolution side of DatasetDPSR items (dataset_dpsr.py:592-645,684-744,1037-1180): outputs of the
     reference's own functions on seeded inputs -- the fixtures of sr-caco-2_amd/dlib/datasets/lowres.py."""
@@ -1784,7 +1829,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_omnisr, g_act, g_dfcan, g_nlsn, g_enlcn, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_grl, g_omnisr, g_act, g_dfcan, g_nlsn, g_enlcn, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

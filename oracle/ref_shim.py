@@ -61,3 +61,9 @@ def install():
                 r.div_(k)
             return x * r
     tl.DropPath = DropPath
+    # network_grl.py:13-14 reads two names at import: OmegaConf.create (a dict with attribute access around three
+    # constructor flags) and fairscale's checkpoint_wrapper (activation checkpointing, off in the registry's config)
+    sys.modules["omegaconf"].OmegaConf = type("OmegaConf", (), {"create": staticmethod(lambda d: types.SimpleNamespace(**d))})
+    fn = _pkg("fairscale.nn")
+    fn.checkpoint_wrapper = lambda m, **k: m
+    sys.modules["fairscale"].nn = fn

@@ -1293,6 +1293,256 @@ def omnisr_forward(sd: SD, x: Tensor, upscale: int, res_num: int = 5, block_num:
     return out[:, :, :H * upscale, :W * upscale]
 
 
+# ----------------------------------------------------------------------------
+# GRL (dlib/models/network_grl.py)
+# ----------------------------------------------------------------------------
+def _grl_partition(x: Tensor, ws) -> Tensor:
+    """window_partition (network_grl.py:512-529): (B, H, W, C) -> (B nW, wh, ww, C)"""
+    B, H, W, C = x.shape
+    x = x.view(B, H // ws[0], ws[0], W // ws[1], ws[1], C)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, ws[0], ws[1], C)
+
+
+def _grl_reverse(w: Tensor, ws, size) -> Tensor:
+    """window_reverse (network_grl.py:744-760)"""
+    H, W = size
+    B = int(w.shape[0] / (H * W / ws[0] / ws[1]))
+    x = w.view(B, H // ws[0], W // ws[1], ws[0], ws[1], -1)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H, W, -1)
+
+
+def _grl_coords(n) -> Tensor:
+    """_get_meshgrid_coords from (0, 0) (network_grl.py:1534-1539)"""
+    c = torch.stack(torch.meshgrid([torch.arange(0, n[0]), torch.arange(0, n[1])], indexing="ij"))
+    return torch.flatten(c, 1)
+
+
+def grl_relative_position_index(ws, df: int = 1, window_to_anchor: bool = True) -> Tensor:
+    """get_relative_position_index_simple (network_grl.py:1553-1577) with coords_diff_odd (:1542-1550): pairwise
+    coordinate differences between the tokens of a window and of its anchor window (sides ws // df), shifted to start at 0
+    and flattened with row stride aws[1] + ws[1] - 1."""
+    aws = [w // df for w in ws]
+    c, ca = _grl_coords(ws), _grl_coords(aws)
+    width = aws[1] + ws[1] - 1
+    if window_to_anchor:
+        a, b, off = c, ca, [w - 1 for w in aws]
+    else:
+        a, b, off = ca, c, [w - 1 for w in ws]
+    d = (a[:, :, None] - b[:, None, :]).permute(1, 2, 0).contiguous()
+    d[:, :, 0] += off[0]
+    d[:, :, 1] += off[1]
+    d[:, :, 0] *= width
+    return d.sum(-1)
+
+
+def grl_coords_table(ws, df: int = 1) -> Tensor:
+    """get_relative_coords_table_all (network_grl.py:1651-1699), pretrained sizes 0: the signed-log relative coordinates
+    the CPB MLP reads, (1, wh + awh - 1, ww + aww - 1, 2)."""
+    aws = [w // df for w in ws]
+    ts_p = [w1 - 1 - (w1 - w2) // 2 for w1, w2 in zip(ws, aws)]
+    ts_n = [-(w2 - 1) - (w1 - w2) // 2 for w1, w2 in zip(ws, aws)]
+    ch = torch.arange(ts_n[0], ts_p[0] + 1, dtype=torch.float32)
+    cw = torch.arange(ts_n[1], ts_p[1] + 1, dtype=torch.float32)
+    t = torch.stack(torch.meshgrid([ch, cw], indexing="ij")).permute(1, 2, 0).contiguous().unsqueeze(0)
+    t[:, :, :, 0] /= ts_p[0]
+    t[:, :, :, 1] /= ts_p[1]
+    t *= 8
+    return torch.sign(t) * torch.log2(torch.abs(t) + 1.0) / math.log2(8)
+
+
+def _grl_fill(res, ws, shift) -> Tensor:
+    """_fill_window (network_grl.py:1580-1604): the 3 x 3 region ids of a shifted partition, per window"""
+    m = torch.zeros((1, *res, 1))
+    cnt = 0
+    for h in (slice(0, -ws[0]), slice(-ws[0], -shift[0]), slice(-shift[0], None)):
+        for w in (slice(0, -ws[1]), slice(-ws[1], -shift[1]), slice(-shift[1], None)):
+            m[:, h, w, :] = cnt
+            cnt += 1
+    return _grl_partition(m, ws).view(-1, ws[0] * ws[1])
+
+
+def _grl_mask_fill(d: Tensor) -> Tensor:
+    return d.masked_fill(d != 0, float(-100.0)).masked_fill(d == 0, float(0.0))
+
+
+def grl_mask(res, ws, shift) -> Tensor:
+    """calculate_mask (network_grl.py:1607-1622)"""
+    m = _grl_fill(res, ws, shift)
+    return _grl_mask_fill(m.unsqueeze(1) - m.unsqueeze(2))
+
+
+def grl_mask_all(res, ws, shift, df: int = 1, window_to_anchor: bool = True) -> Tensor:
+    """calculate_mask_all (network_grl.py:1625-1648)"""
+    mw = _grl_fill(res, ws, shift)
+    ma = _grl_fill([s // df for s in res], [s // df for s in ws], [s // df for s in shift])
+    d = mw.unsqueeze(2) - ma.unsqueeze(1) if window_to_anchor else ma.unsqueeze(2) - mw.unsqueeze(1)
+    return _grl_mask_fill(d)
+
+
+def grl_buffers(x_size, window_size: int = 8, stripe_size=(8, 8), df: int = 2) -> SD:
+    """GRL.set_table_index_mask (network_grl.py:1332-1375), stripe_groups (None, None): the 13 buffers the module registers
+    (and recomputes for another input size), in registration order."""
+    ws = [window_size, window_size]
+    ss = list(stripe_size)
+    sss = [s // 2 for s in ss]                      # _get_stripe_info(.., True, ..) :322-331
+    rs = list(x_size)
+    return {
+        "table_w": grl_coords_table(ws), "table_sh": grl_coords_table(ss, df), "table_sv": grl_coords_table(ss[::-1], df),
+        "index_w": grl_relative_position_index(ws),
+        "index_sh_a2w": grl_relative_position_index(ss, df, False), "index_sh_w2a": grl_relative_position_index(ss, df, True),
+        "index_sv_a2w": grl_relative_position_index(ss[::-1], df, False),
+        "index_sv_w2a": grl_relative_position_index(ss[::-1], df, True),
+        "mask_w": grl_mask(rs, ws, [w // 2 for w in ws]),
+        "mask_sh_a2w": grl_mask_all(rs, ss, sss, df, False), "mask_sh_w2a": grl_mask_all(rs, ss, sss, df, True),
+        "mask_sv_a2w": grl_mask_all(rs, ss[::-1], sss[::-1], df, False),
+        "mask_sv_w2a": grl_mask_all(rs, ss[::-1], sss[::-1], df, True),
+    }
+
+
+def _grl_attn(sd: SD, pre: str, q: Tensor, k: Tensor, v: Tensor, table: Tensor, index: Tensor, mask: Optional[Tensor],
+              reshape: bool = True) -> Tensor:
+    """Attention.attn (network_grl.py:338-355) with AffineTransform.forward (:296-319): cosine similarity, the clamped
+    per-head logit scale, 16 sigmoid(CPB MLP(table))[index] as the bias, the shift mask, softmax, @ v."""
+    B_, _, H, hd = q.shape
+    attn = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)
+    _, nh, N1, N2 = attn.shape
+    attn = attn * torch.clamp(sd[pre + ".logit_scale"], max=math.log(1.0 / 0.01)).exp()
+    bt = F.linear(F.relu(F.linear(table, sd[pre + ".cpb_mlp.0.weight"], sd[pre + ".cpb_mlp.0.bias"])),
+                  sd[pre + ".cpb_mlp.2.weight"]).view(-1, nh)
+    bias = bt[index.view(-1)].view(N1, N2, -1).permute(2, 0, 1).contiguous()
+    attn = attn + (16 * torch.sigmoid(bias)).unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = (attn.view(B_ // nW, nW, nh, N1, N2) + mask.unsqueeze(1).unsqueeze(0)).view(-1, nh, N1, N2)
+    x = attn.softmax(-1) @ v
+    if reshape:
+        x = x.transpose(1, 2).reshape(B_, -1, H * hd)
+    return x
+
+
+def _grl_block(sd: SD, pre: str, x: Tensor, x_size, buf: SD, i: int, heads_w: int, heads_s: int, ws, ss, df: int,
+               tap=None) -> Tensor:
+    """EfficientMixAttnTransformerBlock.forward (network_grl.py:1061-1076) around MixedAttention.forward (:861-887),
+    WindowAttention.forward (:381-412), AnchorStripeAttention.forward (:463-514) without the stripe shift, CAB (:729-741),
+    Mlp (:779-785).  Block i of a stage: shifted windows on even i, 'H' stripes on even i and 'W' (transposed sizes) on
+    odd i (TransformerStage :141-143)."""
+    B, L, C = x.shape
+    H, W = x_size
+    shift = ws[0] // 2 if i % 2 == 0 else 0
+    st = "h" if i % 2 == 0 else "v"
+    ssz = list(ss) if i % 2 == 0 else list(ss)[::-1]
+    a = pre + ".attn"
+    qkv = F.linear(x, sd[a + ".qkv.body.weight"], sd[a + ".qkv.body.bias"])
+    qkv_w, qkv_s = torch.split(qkv, C * 3 // 2, dim=-1)
+    # AnchorLinear (:611-620)
+    t = F.avg_pool2d(x.transpose(1, 2).view(B, C, H, W), df, df).flatten(2).transpose(1, 2)
+    anchor = F.linear(t, sd[a + ".anchor.body.0.reduction.weight"], sd[a + ".anchor.body.0.reduction.bias"])
+    anchor = anchor.view(B, H // df, W // df, C // 2)
+    # window attention
+    q = qkv_w.view(B, H, W, -1)
+    if shift > 0:
+        q = torch.roll(q, shifts=(-shift, -shift), dims=(1, 2))
+    q = _grl_partition(q, ws).view(-1, ws[0] * ws[1], C * 3 // 2)
+    B_, N, _ = q.shape
+    q = q.reshape(B_, N, 3, heads_w, -1).permute(2, 0, 3, 1, 4)
+    xw = _grl_attn(sd, a + ".window_attn.attn_transform", q[0], q[1], q[2], buf["table_w"], buf["index_w"],
+                   buf["mask_w"] if shift > 0 else None)
+    xw = _grl_reverse(xw.view(-1, *ws, C // 2), ws, x_size)
+    if shift > 0:
+        xw = torch.roll(xw, shifts=(shift, shift), dims=(1, 2))
+    xw = xw.view(B, L, C // 2)
+    # anchored stripe attention
+    asz = [s // df for s in ssz]
+    q = _grl_partition(qkv_s.view(B, H, W, -1), ssz).view(-1, ssz[0] * ssz[1], C * 3 // 2)
+    an = _grl_partition(anchor, asz).view(-1, asz[0] * asz[1], C // 2)
+    B_, N1, _ = q.shape
+    N2 = an.shape[1]
+    q = q.reshape(B_, N1, 3, heads_s, -1).permute(2, 0, 3, 1, 4)
+    an = an.reshape(B_, N2, heads_s, -1).permute(0, 2, 1, 3)
+    xs = _grl_attn(sd, a + ".stripe_attn.attn_transform1", an, q[1], q[2], buf["table_s" + st], buf[f"index_s{st}_a2w"],
+                   None, False)
+    xs = _grl_attn(sd, a + ".stripe_attn.attn_transform2", q[0], an, xs, buf["table_s" + st], buf[f"index_s{st}_w2a"], None)
+    xs = _grl_reverse(xs.view(B_, *ssz, C // 2), ssz, x_size).view(B, H * W, C // 2)
+    att = F.linear(torch.cat([xw, xs], dim=-1), sd[a + ".proj.weight"], sd[a + ".proj.bias"])
+    if tap is not None:
+        tap(pre + ".attn", att)
+    # CAB
+    c = F.conv2d(x.transpose(1, 2).view(B, C, H, W).contiguous(), sd[pre + ".conv.cab.0.weight"], sd[pre + ".conv.cab.0.bias"],
+                 padding=1)
+    c = F.conv2d(F.gelu(c), sd[pre + ".conv.cab.2.weight"], sd[pre + ".conv.cab.2.bias"], padding=1)
+    y = F.adaptive_avg_pool2d(c, 1)
+    y = F.relu(F.conv2d(y, sd[pre + ".conv.cab.3.attention.1.weight"], sd[pre + ".conv.cab.3.attention.1.bias"]))
+    y = torch.sigmoid(F.conv2d(y, sd[pre + ".conv.cab.3.attention.3.weight"], sd[pre + ".conv.cab.3.attention.3.bias"]))
+    cab = (c * y).flatten(2).transpose(1, 2)
+    if tap is not None:
+        tap(pre + ".cab", cab)
+    x = x + 1.0 * F.layer_norm(att, (C,), sd[pre + ".norm1.weight"], sd[pre + ".norm1.bias"]) + cab
+    m = F.linear(F.gelu(F.linear(x, sd[pre + ".mlp.fc1.weight"], sd[pre + ".mlp.fc1.bias"])),
+                 sd[pre + ".mlp.fc2.weight"], sd[pre + ".mlp.fc2.bias"])
+    return x + 1.0 * F.layer_norm(m, (C,), sd[pre + ".norm2.weight"], sd[pre + ".norm2.bias"])
+
+
+def grl_forward(sd: SD, x: Tensor, upscale: int, depths: Sequence[int] = (4, 4, 8, 8, 8, 4, 4), heads_w: int = 3,
+                heads_s: int = 3, window_size: int = 8, stripe_size=(8, 8), df: int = 2, taps=None) -> Tensor:
+    """GRL.forward (network_grl.py:1462-1512), upsampler 'pixelshuffle', 1 input channel (mean 0, img_range 1), the
+    registry's options (select_network.py:70-90): linear qkv / output projections, avgpool anchors, '1conv' stage ends,
+    local connection on, no stripe shift.  Inputs are reflect-padded to a multiple of the window (:1415-1424), the output is
+    cropped.  The tables, indices and masks are those of the padded size (get_table_index_mask :1377-1398)."""
+    H0, W0 = x.shape[2:]
+    pad = max(window_size, max(stripe_size))
+    x = F.pad(x, (0, (pad - W0 % pad) % pad, 0, (pad - H0 % pad) % pad), "reflect")
+    x = (x - 0.0) * 1.0
+    ws = [window_size, window_size]
+
+    def tap(name, v):
+        if taps is not None:
+            taps[name] = v
+    f0 = F.conv2d(x, sd["conv_first.weight"], sd["conv_first.bias"], padding=1)
+    x_size = (f0.shape[2], f0.shape[3])
+    B, C = f0.shape[:2]
+    buf = grl_buffers(x_size, window_size, stripe_size, df)
+    t = F.layer_norm(f0.flatten(2).transpose(1, 2), (C,), sd["norm_start.weight"], sd["norm_start.bias"])
+    tap("start", t)
+    for s, depth in enumerate(depths):
+        res = t
+        for i in range(depth):
+            res = _grl_block(sd, f"layers.{s}.blocks.{i}", res, x_size, buf, i, heads_w, heads_s, ws, stripe_size, df, tap)
+            tap(f"layers.{s}.blocks.{i}", res)
+        res = F.conv2d(res.transpose(1, 2).view(B, C, *x_size), sd[f"layers.{s}.conv.weight"], sd[f"layers.{s}.conv.bias"],
+                       padding=1).flatten(2).transpose(1, 2)
+        t = res + t
+        tap(f"layers.{s}", t)
+    t = F.layer_norm(t, (C,), sd["norm_end.weight"], sd["norm_end.bias"]).transpose(1, 2).view(B, C, *x_size)
+    f = F.conv2d(t, sd["conv_after_body.weight"], sd["conv_after_body.bias"], padding=1) + f0
+    tap("body", f)
+    u = F.leaky_relu(F.conv2d(f, sd["conv_before_upsample.0.weight"], sd["conv_before_upsample.0.bias"], padding=1), 0.01)
+    k = 0
+    while f"upsample.up.{k}.weight" in sd:
+        u = F.pixel_shuffle(F.conv2d(u, sd[f"upsample.up.{k}.weight"], sd[f"upsample.up.{k}.bias"], padding=1), 2)
+        k += 2
+    y = F.conv2d(u, sd["conv_last.weight"], sd["conv_last.bias"], padding=1)
+    y = y / 1.0 + 0.0
+    return y[:, :, :H0 * upscale, :W0 * upscale]
+
+
+def grl_state_dict(layout, seed: int, img_size) -> SD:
+    """seeded_state_dict over GRL's layout: the 13 registered buffers keep the values the reference computes for img_size,
+    the logit scales are drawn around the reference's initial log 10 and one is pushed over the clamp at log 100."""
+    fixed = grl_buffers((img_size, img_size) if isinstance(img_size, int) else img_size)
+    sd = seeded_state_dict([kv for kv in layout if kv[0] not in fixed], seed)
+    first = True
+    for k in sd:
+        if k.endswith("logit_scale"):
+            sd[k] = sd[k] * 0.5 + math.log(10.0)
+            if first:
+                sd[k][0] = 5.0
+                first = False
+    out: SD = {}
+    for k, _ in layout:
+        out[k] = fixed[k] if k in fixed else sd[k]
+    return out
+
+
 def seeded_state_dict(layout, seed: int, bias_std: float = 0.02) -> SD:
     """Seeded weights for a (key, shape) layout taken from a module's own state_dict (ACT: 660 entries): matrices / conv
     kernels N(0, 1 / sqrt(fan_in)), LayerNorm-like scale vectors 1 + N(0, 0.1), other vectors N(0, bias_std); the frozen

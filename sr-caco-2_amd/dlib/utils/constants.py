@@ -18,7 +18,8 @@ NLSN = 'NLSN'  # Mei et al., CVPR 2021 (reference constants.py:38)
 DFCAN = 'DFCAN'  # https://www.nature.com/articles/s41592-020-01048-5 (reference constants.py:33)
 ACT = 'ACT'  # https://arxiv.org/pdf/2203.07682.pdf (reference constants.py:37)
 OMNISR = 'OmniSR'  # https://arxiv.org/pdf/2304.10244.pdf (reference constants.py:34)
-MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR, MEMNET, DBPN, SRFBN, PROSR, ENLCN, NLSN, DFCAN, ACT, OMNISR]
+GRL = 'GRL'  # https://arxiv.org/pdf/2303.00748.pdf (reference constants.py:35)
+MODELS = [SWINIR, EDSR_LIIF, VDSR, DRRN, SRCNN, MSLAPSR, MEMNET, DBPN, SRFBN, PROSR, ENLCN, NLSN, DFCAN, ACT, OMNISR, GRL]
 
 SWINIR_MTH = 'SWINIR'
 EDSR_LIIF_MTH = 'EDSR_LIIF'
@@ -35,10 +36,11 @@ NLSN_MTH = 'NLSN'
 DFCAN_MTH = 'DFCAN'
 ACT_MTH = 'ACT'
 OMNISR_MTH = 'OmniSR'
+GRL_MTH = 'GRL'
 NETTYPE_METHOD = {SWINIR: SWINIR_MTH, EDSR_LIIF: EDSR_LIIF_MTH, VDSR: VDSR_MTH, DRRN: DRRN_MTH, SRCNN: SRCNN_MTH,
                   MSLAPSR: MSLAPSR_MTH, MEMNET: MEMNET_MTH, DBPN: DBPN_MTH, SRFBN: SRFBN_MTH, PROSR: PROSR_MTH,
                   ENLCN: ENLCN_MTH, NLSN: NLSN_MTH, DFCAN: DFCAN_MTH, ACT: ACT_MTH,
-                  OMNISR: OMNISR_MTH}
+                  OMNISR: OMNISR_MTH, GRL: GRL_MTH}
 
 US_PIXEL_SHUFFLE = 'pixelshuffle'
 US_PIXEL_SHUFFLE_DIRECT = 'pixelshuffledirect'

@@ -61,6 +61,14 @@ def init_net_g(netG: dict, args: dict) -> dict:
         out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'], f'{nt}_num_feat': 64,
                     f'{nt}_res_num': 5, f'{nt}_bias': True, f'{nt}_window_size': 8, f'{nt}_block_num': 4, f'{nt}_pe': True,
                     f'{nt}_ffn_bias': True})
+    elif netG['net_type'] == constants.GRL:          # utils_init_default_args.py:166-189 ("Big")
+        out.update({f'{nt}_upscale': args['scale'], f'{nt}_in_chans': args['n_channels'],
+                    f'{nt}_img_size': args['h_size'] // args['scale'], f'{nt}_window_size': 8, f'{nt}_embed_dim': 180,
+                    f'{nt}_mlp_ratio': 2, f'{nt}_img_range': 1.0, f'{nt}_depths': [4, 4, 8, 8, 8, 4, 4],
+                    f'{nt}_num_heads_window': [3, 3, 3, 3, 3, 3, 3], f'{nt}_num_heads_stripe': [3, 3, 3, 3, 3, 3, 3],
+                    f'{nt}_upsampler': constants.US_PIXEL_SHUFFLE, f'{nt}_conv_type': '1conv', f'{nt}_out_proj_type': 'linear',
+                    f'{nt}_anchor_window_down_factor': 2, f'{nt}_qkv_proj_type': 'linear', f'{nt}_anchor_proj_type': 'avgpool',
+                    f'{nt}_local_connection': True})
     else:
         raise NotImplementedError(netG['net_type'])
     out[f'{nt}_init_type'] = constants.INIT_W_DEFAULT

@@ -126,6 +126,7 @@ def parse_input(argv=None):
                 constants.DBPN: {'base_filter': int, 'feat': int, 'num_stages': int},
                 constants.ENLCN: {'n_resblock': int, 'n_feats': int, 'res_scale': float},
                 constants.DFCAN: {},
+                constants.GRL: {'window_size': int, 'img_range': float, 'embed_dim': int, 'mlp_ratio': int},   # utils_parser.py:376-388
                 constants.OMNISR: {'num_feat': int, 'res_num': int, 'window_size': int, 'block_num': int},
                 constants.ACT: {'n_feats': int, 'n_resgroups': int, 'n_resblocks': int, 'reduction': int, 'n_heads': int,
                                 'n_layers': int, 'n_fusionblocks': int, 'token_size': int, 'expansion_ratio': int},

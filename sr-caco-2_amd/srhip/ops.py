@@ -477,6 +477,47 @@ def mul_sigmoid(x, g, out):
     return out
 
 
+def avgpool2d(x, k):
+    """nn.AvgPool2d(k, k) on NHWC [B, H, W, C] (AnchorLinear, network_grl.py:603-620)."""
+    _chk(x)
+    B, H, W, C = x.shape
+    assert x.is_contiguous()
+    out = torch.empty(B, H // k, W // k, C, device=x.device)
+    call("srhip_avgpool2d", _p(x), _p(out), B, H, W, C, k, _st())
+    return out
+
+
+def cpb_bias(table, index, heads):
+    """16 sigmoid(table[index]) as the key-major bias image [heads, N2, N1] of srhip_cosine_window_attention; table
+    [entries, heads] f32 (the CPB MLP's output), index [N1, N2] int64 (network_grl.py:305-311)."""
+    _chk(table)
+    N1, N2 = index.shape
+    assert table.is_contiguous() and table.shape[1] == heads and index.is_contiguous() and index.dtype == torch.int64
+    assert index.device == table.device
+    out = torch.empty(heads, N2, N1, device=table.device)
+    call("srhip_cpb_bias", _p(table), _p(index), _p(out), heads, N1, N2, table.shape[0], _st())
+    return out
+
+
+def cosine_window_attention(q, qwin, k, v, kwin, logit_scale, biasT, out, heads, d, shift=0):
+    """GRL's Attention.attn (network_grl.py:338-355) between the windows (qwin = (wh, ww)) of the NHWC image q [B, qH, qW, >=
+    heads*d] and the windows kwin of the NHWC images k, v [B, kH, kW, .] on the same window grid; q / k / v / out may be
+    channel-slice views of wider images (stride(3) == 1).  The result is written at the query tokens' own pixels of out."""
+    for t in (q, k, v, out):
+        assert t.dtype == torch.float32 and t.is_cuda and t.dim() == 4 and t.stride(3) == 1
+        assert t.stride(1) == t.shape[2] * t.stride(2) and t.stride(0) == t.shape[1] * t.stride(1)
+    _chk(logit_scale, biasT)
+    B, qH, qW = q.shape[:3]
+    kH, kW = k.shape[1:3]
+    assert v.shape[:3] == k.shape[:3] and out.shape[:3] == q.shape[:3] and k.shape[0] == B
+    assert biasT.shape == (heads, kwin[0] * kwin[1], qwin[0] * qwin[1]) and biasT.is_contiguous()
+    assert logit_scale.numel() == heads and logit_scale.is_contiguous()
+    call("srhip_cosine_window_attention", q.data_ptr(), q.stride(2), qH, qW, qwin[0], qwin[1], k.data_ptr(), k.stride(2),
+         v.data_ptr(), v.stride(2), kH, kW, kwin[0], kwin[1], _p(logit_scale), _p(biasT), out.data_ptr(), out.stride(2), B,
+         heads, d, int(shift), _st())
+    return out
+
+
 def mlp_f16_fusable(C, hidden):
     """Shapes srhip_mlp_fwd_f16x2 / srhip_mlp_bwd_f16x2 take with the weight planes PrepTable.linear builds for the
     Linear GEMMs (format 1: two fp16 planes)."""

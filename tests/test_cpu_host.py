@@ -116,7 +116,7 @@ def test_registry_and_factories():
     e = init_net_g({'net_type': constants.EDSR_LIIF}, {'scale': 4, 'n_channels': 1, 'h_size': 512})
     assert define_G(A(netG=e)).n_resblocks == 16
     with pytest.raises(NotImplementedError):
-        define_G(A(netG={'net_type': 'GRL'}))
+        define_G(A(netG={'net_type': 'CSRCNN'}))
     assert constants.NETTYPE_METHOD[constants.SWINIR] == 'SWINIR'
 
 
@@ -211,6 +211,41 @@ def test_omnisr_mirror_layout_and_oracle_vs_reference_golden():
         sd = O.seeded_state_dict(layout, int(g[f"x{scale}/seed"]))
         y = O.omnisr_forward(sd, torch.from_numpy(g[f"x{scale}/x"]), scale, res_num=2, block_num=1)
         assert (y - torch.from_numpy(g[f"x{scale}/y"])).abs().max().item() <= 2e-6
+
+
+def test_grl_mirror_layout_buffers_and_oracle_vs_reference_golden():
+    """GRL: the state_dict entries of the registry's net ("Big": 180 channels, 40 blocks) in the reference's
+    order and shapes, the 13 registered tables / indices / masks equal to the reference's (64 x 64 and a 16 x 24 input), and
+    the oracle reproducing the reference's outputs of g38_grl.npz (reflect-padded and recomputed-mask sizes)."""
+    from dlib.models.network_grl import GRL, table_index_mask
+    from oracle import sr_oracle as O
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g38_grl.npz"))
+    kw = dict(in_chans=1, window_size=8, mlp_ratio=2, qkv_proj_type="linear", anchor_proj_type="avgpool",
+              anchor_window_down_factor=2, out_proj_type="linear", conv_type="1conv", upsampler="pixelshuffle",
+              local_connection=True)
+    net = GRL(upscale=2, img_size=64, depths=[4, 4, 8, 8, 8, 4, 4], embed_dim=180, num_heads_window=[3] * 7,
+              num_heads_stripe=[3] * 7, **kw)
+    sd0 = net.state_dict()
+    assert list(sd0.keys()) == [str(k) for k in g["state_dict_keys_default"]]
+    assert [str(tuple(v.shape)) for v in sd0.values()] == [str(k) for k in g["state_dict_shapes_default"]]
+    for k, v in O.grl_buffers((64, 64)).items():
+        assert torch.equal(sd0[k], v) and sd0[k].dtype == v.dtype, k
+    b = table_index_mask((16, 24), (8, 8), [8, 8], 2)
+    bo = O.grl_buffers((16, 24))
+    for k in ("table_sh", "index_sh_a2w", "index_sv_w2a", "mask_w", "mask_sh_a2w"):
+        ref = torch.from_numpy(g["buf_16x24/" + k])
+        assert torch.equal(b[k], ref) and torch.equal(bo[k], ref), k
+    for scale in (2, 4, 8):
+        net = GRL(upscale=scale, img_size=16, depths=[2, 2], embed_dim=36, num_heads_window=[3, 3], num_heads_stripe=[3, 3], **kw)
+        layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        assert [k for k, _ in layout] == [str(k) for k in g[f"x{scale}/layout_keys"]]
+        assert [str(s) for _, s in layout] == [str(k) for k in g[f"x{scale}/layout_shapes"]]
+        sd = O.grl_state_dict(layout, int(g[f"x{scale}/seed"]), 16)
+        net.load_state_dict(sd, strict=True)
+        y = O.grl_forward(sd, torch.from_numpy(g[f"x{scale}/x"]), scale, depths=(2, 2))
+        assert (y - torch.from_numpy(g[f"x{scale}/y"])).abs().max().item() <= 2e-6
+    with pytest.raises(NotImplementedError):
+        GRL(upscale=2, in_chans=1, upsampler="nearest+conv")
 
 
 def test_tape_net_mirrors_have_the_reference_state_dict_layout():
@@ -328,7 +363,7 @@ def test_main_cli_contract():
     with pytest.raises(ValueError):
         M.parse_input("--net_type swinir --method EDSR_LIIF".split())
     with pytest.raises(NotImplementedError):
-        M.parse_input("--net_type GRL --method GRL".split())
+        M.parse_input("--net_type CSRCNN --method CSRCNN".split())
     e = M.parse_input("--net_type EDSR_LIIF --method EDSR_LIIF --scale 4 --h_size 512".split())
     assert e.netG['EDSR_LIIF_n_resblocks'] == 16 and e.netG['EDSR_LIIF_upscale'] == 4
 

@@ -440,3 +440,114 @@ def test_omnisr_registry_default_width_vs_oracle():
         yo = O.omnisr_forward(sd, x, 2)
         y = net(x.cuda()).cpu()
     assert (y - yo).abs().mean().item() <= 1e-5 * max(1.0, yo.abs().max().item()) and rel(y, yo) < 5e-5, rel(y, yo)
+
+
+GRL_KW = dict(in_chans=1, window_size=8, mlp_ratio=2, qkv_proj_type="linear", anchor_proj_type="avgpool",
+              anchor_window_down_factor=2, out_proj_type="linear", conv_type="1conv", upsampler="pixelshuffle",
+              local_connection=True)
+
+
+def test_cosine_window_attention_vs_float64():
+    """srhip_cosine_window_attention + srhip_cpb_bias against a float64 statement of Attention.attn under AffineTransform
+    (network_grl.py:296-319,338-355): shifted 8x8 windows (roll, partition, region mask, reverse, roll back) and the two
+    passes of the anchored stripe attention (4x4 anchor windows against 8x8 stripes), heads of 30 and of 6 channels."""
+    from srhip import ops
+    gen = torch.Generator().manual_seed(77)
+    for B, H, W, heads, d in ((2, 16, 24, 3, 30), (1, 24, 16, 3, 6), (1, 8, 8, 2, 45)):
+        C = heads * d
+        qkv = torch.randn(B, H, W, 3 * C + 8, generator=gen)
+        table = torch.randn(225, heads, generator=gen)
+        ls = torch.tensor([2.3, 5.0, 1.0][:heads])
+        buf = O.grl_buffers((H, W))
+
+        def ref(q, k, v, index, tab, mask):
+            at = torch.nn.functional.normalize(q, dim=-1) @ torch.nn.functional.normalize(k, dim=-1).transpose(-2, -1)
+            at = at * ls.double().clamp(max=np.log(100.0)).exp().view(-1, 1, 1)
+            N1, N2 = index.shape
+            at = at + 16 * torch.sigmoid(tab.double()[index.view(-1)].view(N1, N2, -1).permute(2, 0, 1))
+            if mask is not None:
+                nW = mask.shape[0]
+                at = (at.view(-1, nW, heads, N1, N2) + mask.double()[None, :, None]).view(-1, heads, N1, N2)
+            return at.softmax(-1) @ v
+        for shift in (4, 0):
+            t = qkv.double()[..., :3 * C]
+            if shift:
+                t = torch.roll(t, (-shift, -shift), (1, 2))
+            w = O._grl_partition(t, [8, 8]).view(-1, 64, 3, heads, d).permute(2, 0, 3, 1, 4)
+            o = ref(w[0], w[1], w[2], buf["index_w"], table, buf["mask_w"] if shift else None)
+            o = O._grl_reverse(o.transpose(1, 2).reshape(-1, 8, 8, C), [8, 8], (H, W))
+            if shift:
+                o = torch.roll(o, (shift, shift), (1, 2))
+            qd = qkv.cuda()
+            out = torch.full((B, H, W, C + 4), float("nan"), device="cuda")
+            bT = ops.cpb_bias(table.cuda(), buf["index_w"].cuda(), heads)
+            ops.cosine_window_attention(qd[..., :C], (8, 8), qd[..., C:2 * C], qd[..., 2 * C:3 * C], (8, 8), ls.cuda(), bT,
+                                        out[..., :C], heads, d, shift)
+            assert rel(out[..., :C], o) < 5e-6, (B, H, W, d, shift, rel(out[..., :C], o))
+            assert torch.isnan(out[..., C:]).all()
+        # anchors
+        an = torch.randn(B, H // 2, W // 2, C, generator=gen)
+        tab_s = torch.randn(121, heads, generator=gen)
+        ad = an.double()
+        a_w = O._grl_partition(ad, [4, 4]).view(-1, 16, heads, d).permute(0, 2, 1, 3)
+        w = O._grl_partition(qkv.double()[..., :3 * C], [8, 8]).view(-1, 64, 3, heads, d).permute(2, 0, 3, 1, 4)
+        x1 = ref(a_w, w[1], w[2], buf["index_sh_a2w"], tab_s, None)                  # [nW, heads, 16, d]
+        x2 = ref(w[0], a_w, x1, buf["index_sh_w2a"], tab_s, None)
+        x2 = O._grl_reverse(x2.transpose(1, 2).reshape(-1, 8, 8, C), [8, 8], (H, W))
+        qd, and_ = qkv.cuda(), an.cuda()
+        xa = torch.empty_like(and_)
+        b1 = ops.cpb_bias(tab_s.cuda(), buf["index_sh_a2w"].cuda(), heads)
+        b2 = ops.cpb_bias(tab_s.cuda(), buf["index_sh_w2a"].cuda(), heads)
+        ops.cosine_window_attention(and_, (4, 4), qd[..., C:2 * C], qd[..., 2 * C:3 * C], (8, 8), ls.cuda(), b1, xa, heads, d)
+        x1_img = O._grl_reverse(x1.transpose(1, 2).reshape(-1, 4, 4, C), [4, 4], (H // 2, W // 2))
+        assert rel(xa, x1_img) < 5e-6
+        out = torch.empty(B, H, W, C, device="cuda")
+        ops.cosine_window_attention(qd[..., :C], (8, 8), and_, xa, (4, 4), ls.cuda(), b2, out, heads, d)
+        assert rel(out, x2) < 5e-6
+    p = ops.avgpool2d(qkv.cuda().contiguous(), 2)
+    assert rel(p, torch.nn.functional.avg_pool2d(qkv.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)) < 1e-6
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8])
+def test_grl_forward_vs_reference_golden(scale):
+    """GRL (network_grl.py), narrow configuration of g38_grl.npz, against the reference's own output: shifted / plain cosine
+    window attention with the CPB-MLP bias, anchored 'H' / 'W' stripe attention, the conv + channel-attention branch (9
+    channels, zero-padded to 12), post-norm residuals, the pixel-shuffle tail; x4: a 13 x 18 input, reflect-padded; x2: a
+    16 x 24 input against masks registered for 16 x 16.  Block outputs are checked one by one against the oracle's."""
+    from dlib.models.network_grl import GRL
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g38_grl").items() if k.startswith(f"x{scale}/")}
+    net = GRL(upscale=scale, img_size=16, depths=[2, 2], embed_dim=36, num_heads_window=[3, 3], num_heads_stripe=[3, 3], **GRL_KW)
+    sd = O.grl_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], int(g["seed"]), 16)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    taps_o = {}
+    O.grl_forward(sd, g["x"], scale, depths=(2, 2), taps=taps_o)
+    net.engine.taps = {}
+    with torch.no_grad():
+        y = net(g["x"].cuda()).cpu()
+    taps = net.engine.taps
+    net.engine.taps = None
+    for k, v in taps.items():
+        if k in taps_o and taps_o[k].dim() == 3:
+            assert rel(v, taps_o[k]) < 2e-5, (k, rel(v, taps_o[k]))
+    assert y.shape == g["y"].shape
+    assert (y - g["y"]).abs().mean().item() <= 1e-5 * max(1.0, g["y"].abs().max().item()) and rel(y, g["y"]) < 3e-5, rel(y, g["y"])
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(g["x"].cuda()).sum().backward()
+
+
+def test_grl_registry_default_width_vs_oracle():
+    """The registry's width (180 channels, heads of 30, the 45 -> 48 padded local branch), two stages of two blocks, at x2 on a
+    24 x 32 input."""
+    from dlib.models.network_grl import GRL
+    net = GRL(upscale=2, img_size=64, depths=[2, 2], embed_dim=180, num_heads_window=[3, 3], num_heads_stripe=[3, 3], **GRL_KW)
+    sd = O.grl_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], 9, 64)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    gen = torch.Generator().manual_seed(14)
+    x = torch.rand(2, 1, 24, 32, generator=gen)
+    with torch.no_grad():
+        yo = O.grl_forward(sd, x, 2, depths=(2, 2))
+        y = net(x.cuda()).cpu()
+    assert (y - yo).abs().mean().item() <= 1e-5 * max(1.0, yo.abs().max().item()) and rel(y, yo) < 5e-5, rel(y, yo)

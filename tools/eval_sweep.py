@@ -21,7 +21,7 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 NETS = [("swinir", "SWINIR"), ("EDSR_LIIF", "EDSR_LIIF"), ("VDSR", "VDSR"), ("DRRN", "DRRN"), ("SRCNN", "SRCNN"),
-        ("MSLapSRN", "MSLAPSR"), ("MemNet", "MemNet"), ("DBPN", "DBPN"), ("SRFBN", "SRFBN"), ("ProSR", "PROSR"), ("ENLCN", "ENLCN"), ("NLSN", "NLSN"), ("DFCAN", "DFCAN"), ("ACT", "ACT"), ("OmniSR", "OmniSR")]
+        ("MSLapSRN", "MSLAPSR"), ("MemNet", "MemNet"), ("DBPN", "DBPN"), ("SRFBN", "SRFBN"), ("ProSR", "PROSR"), ("ENLCN", "ENLCN"), ("NLSN", "NLSN"), ("DFCAN", "DFCAN"), ("ACT", "ACT"), ("OmniSR", "OmniSR"), ("GRL", "GRL")]
 
 
 def main():
