@@ -68,66 +68,130 @@ __device__ __forceinline__ long token_pixel(const Side& s, long b, int wy, int w
   return (b * s.H + y) * s.W + x;
 }
 
-// One wave per (window, head): keys (unit length) and values in LDS, one query per lane, a running-maximum softmax over the
-// keys.  N1, N2 <= 64, head width <= DM.
+// One 256-thread block per (window, head).  Keys (unit length), values and queries (unit length times the logit scale) are
+// staged in LDS with coalesced loads; G = 256 / N1 (a power of two) neighbouring lanes share a query and walk interleaved
+// keys with a running-maximum softmax each, their partial (max, sum, accumulator) triples are merged by lane shuffles, and
+// the rows leave through LDS so that the stores are contiguous per token.  N1, N2 <= 64, head width <= DM.
 template <int DM>
-__global__ void __launch_bounds__(64) k_cos_attn(const CosAttnArgs a) {
-  __shared__ float Ks[64][DM + 1], Vs[64][DM + 1];
-  __shared__ int Rk[64];
+__global__ void __launch_bounds__(256, DM <= 32 ? 4 : 2) k_cos_attn(const CosAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ks[64][DM + 4], Vs[64][DM + 4], Qs[64][DM + 4];   // rows 16 B aligned, 4 banks apart
+  __shared__ int Rk[64], Rq[64];
+  __shared__ long Pq[64];
   const int tid = threadIdx.x, d = a.d;
   const int h = blockIdx.x % a.heads;
   long w = blockIdx.x / a.heads;
   const int wx = (int)(w % a.nwx), wy = (int)((w / a.nwx) % a.nwy);
   const long b = w / ((long)a.nwx * a.nwy);
   const int N1 = a.q.wh * a.q.ww, N2 = a.k.wh * a.k.ww;
-  for (int t = tid; t < N2 * DM; t += 64) {          // columns d .. DM-1 are zero: the dot products run over DM
-    const int j = t / DM, c = t % DM;
-    int rid;
-    const long px = token_pixel(a.k, b, wy, wx, j, a.shift, rid);
-    Ks[j][c] = c < d ? a.k.p[px * a.k.ld + h * d + c] : 0.f;
-    Vs[j][c] = c < d ? a.v[px * a.ldv + h * d + c] : 0.f;
-    if (c == 0) Rk[j] = rid;
+  {                                                  // all global loads in flight before the first LDS store
+    constexpr int IT = 64 * DM / 256;
+    float kr[IT], vr[IT], qr[IT];
+    const int c = tid % DM;
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      const int r = tid / DM + u * (256 / DM);
+      kr[u] = vr[u] = qr[u] = 0.f;
+      int rid;
+      if (r < N2) {
+        const long px = token_pixel(a.k, b, wy, wx, r, a.shift, rid);
+        if (c < d) {
+          kr[u] = a.k.p[px * a.k.ld + h * d + c];
+          vr[u] = a.v[px * a.ldv + h * d + c];
+        }
+        if (c == 0) Rk[r] = rid;
+      }
+      if (r < N1) {
+        const long px = token_pixel(a.q, b, wy, wx, r, a.shift, rid);
+        if (c < d) qr[u] = a.q.p[px * a.q.ld + h * d + c];
+        if (c == 0) { Rq[r] = rid; Pq[r] = px; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {                   // columns d .. DM-1 are zero: the dot products run over DM
+      const int r = tid / DM + u * (256 / DM);
+      Ks[r][c] = kr[u];
+      Vs[r][c] = vr[u];
+      Qs[r][c] = qr[u];
+    }
   }
   __syncthreads();
-  if (tid < N2) {                          // F.normalize(k, dim=-1): k / max(|k|, 1e-12)
+  if (tid < N2) {                                    // F.normalize(k, dim=-1): k / max(|k|, 1e-12)
     float s = 0.f;
     for (int c = 0; c < d; ++c) s += Ks[tid][c] * Ks[tid][c];
     const float r = 1.f / fmaxf(sqrtf(s), 1e-12f);
     for (int c = 0; c < d; ++c) Ks[tid][c] *= r;
+  } else if (tid >= 128 && tid - 128 < N1) {         // F.normalize(q) * clamp(logit_scale, max = log 100).exp()
+    const int i = tid - 128;
+    float s = 0.f;
+    for (int c = 0; c < d; ++c) s += Qs[i][c] * Qs[i][c];
+    const float r = expf(fminf(a.logit_scale[h], 4.605170185988092f)) / fmaxf(sqrtf(s), 1e-12f);
+    for (int c = 0; c < d; ++c) Qs[i][c] *= r;
   }
   __syncthreads();
-  if (tid >= N1) return;
-  int rq;
-  const long pq = token_pixel(a.q, b, wy, wx, tid, a.shift, rq);
+  int G = 64;
+  while (G * N1 > 256) G >>= 1;
+  const int i = tid / G, g = tid % G;
+  const bool live = i < N1;
   float q[DM], acc[DM];
-  float s = 0.f;
 #pragma unroll
   for (int c = 0; c < DM; ++c) {
-    q[c] = c < d ? a.q.p[pq * a.q.ld + h * d + c] : 0.f;
-    s += q[c] * q[c];
+    q[c] = live ? Qs[i][c] : 0.f;
     acc[c] = 0.f;
   }
-  const float r = expf(fminf(a.logit_scale[h], 4.605170185988092f)) / fmaxf(sqrtf(s), 1e-12f);   // clamp(max = log 100).exp()
-#pragma unroll
-  for (int c = 0; c < DM; ++c) q[c] *= r;
-  const float* bias = a.biasT + (long)h * N2 * N1 + tid;
   float m = -INFINITY, l = 0.f;
-  for (int j = 0; j < N2; ++j) {
-    float e = 0.f;
+  if (live) {
+    const float* bias = a.biasT + (long)h * N2 * N1 + i;
+    const int rq = Rq[i];
+    float bz[16];                                    // G >= 4, N2 <= 64: at most 16 keys per lane
 #pragma unroll
-    for (int c = 0; c < DM; ++c) e += q[c] * Ks[j][c];
-    e += bias[(long)j * N1];
-    if (a.shift > 0 && Rk[j] != rq) e += -100.f;
-    const float mn = fmaxf(m, e), cf = expf(m - mn), p = expf(e - mn);
-    l = l * cf + p;
+    for (int u = 0; u < 16; ++u) {
+      const int j = g + u * G;
+      bz[u] = j < N2 ? bias[(long)j * N1] : 0.f;
+    }
 #pragma unroll
-    for (int c = 0; c < DM; ++c) acc[c] = acc[c] * cf + p * Vs[j][c];
+    for (int u = 0; u < 16; ++u) {
+      const int j = g + u * G;
+      if (j < N2) {
+        float e = bz[u];
+#pragma unroll
+        for (int c = 0; c < DM; c += 4) {
+          const float4 kk = *reinterpret_cast<const float4*>(&Ks[j][c]);
+          e += q[c] * kk.x + q[c + 1] * kk.y + q[c + 2] * kk.z + q[c + 3] * kk.w;
+        }
+        if (a.shift > 0 && Rk[j] != rq) e += -100.f;
+        const float mn = fmaxf(m, e), cf = expf(m - mn), p = expf(e - mn);
+        l = l * cf + p;
+#pragma unroll
+        for (int c = 0; c < DM; c += 4) {
+          const float4 vv = *reinterpret_cast<const float4*>(&Vs[j][c]);
+          acc[c] = acc[c] * cf + p * vv.x;
+          acc[c + 1] = acc[c + 1] * cf + p * vv.y;
+          acc[c + 2] = acc[c + 2] * cf + p * vv.z;
+          acc[c + 3] = acc[c + 3] * cf + p * vv.w;
+        }
+        m = mn;
+      }
+    }
+  }
+  for (int o = 1; o < G; o <<= 1) {                  // the G lanes of a query are neighbours in one wave
+    const float m2 = __shfl_xor(m, o), l2 = __shfl_xor(l, o);
+    const float mn = fmaxf(m, m2);
+    const float c1 = m == -INFINITY ? 0.f : expf(m - mn), c2 = m2 == -INFINITY ? 0.f : expf(m2 - mn);
+    l = l * c1 + l2 * c2;
+#pragma unroll
+    for (int c = 0; c < DM; ++c) acc[c] = acc[c] * c1 + __shfl_xor(acc[c], o) * c2;
     m = mn;
   }
-  const float inv = 1.f / l;
+  if (live && g == 0) {                              // row i of Qs was read by this wave only
+    const float inv = 1.f / l;
 #pragma unroll
-  for (int c = 0; c < DM; ++c)
-    if (c < d) a.out[pq * a.ldo + h * d + c] = acc[c] * inv;
+    for (int c = 0; c < DM; ++c) Qs[i][c] = acc[c] * inv;
+  }
+  __syncthreads();
+  for (int t = tid; t < N1 * d; t += 256) {
+    const int r = t / d, c = t - r * d;
+    a.out[Pq[r] * a.ldo + h * d + c] = Qs[r][c];
+  }
 }
 
 }  // namespace
@@ -187,9 +251,9 @@ int srhip_cosine_window_attention(const float* q, long ldq, int qH, int qW, int 
   const long blocks = (long)B * a.nwy * a.nwx * heads;
   SR_REQUIRE(blocks < (1L << 31), "cosine_window_attention: too many windows");
   if (d <= 32)
-    hipLaunchKernelGGL(k_cos_attn<32>, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_cos_attn<32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(k_cos_attn<64>, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_cos_attn<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   SR_LAUNCH_CHECK("cosine_window_attention");
   return 0;
 }

@@ -3,7 +3,8 @@
 (average-pooled 4x4 anchors attend to the 8x8 stripe, the stripe attends back to the anchors), both cosine attentions with a
 clamped logit scale and a 16 sigmoid(CPB MLP) bias, a shared output projection, post-norm residuals, a conv + GELU + conv +
 channel-attention local branch, a GELU MLP -- each stage closed by a 3x3 conv and a skip, and a pixel-shuffle tail.  Written
-directly over the libsrhip ops: Linears on the exact-f32 GEMM (GELU as the fc2 prologue), 3x3 convs on the conv kernels (the
+directly over the libsrhip ops: Linears and 3x3 convs on the GEMM / conv kernels (bf16x3 planes from 64 channels on -- the
+kernels --amp narrows to one product -- exact f32 below; GELU as the fc2 prologue; the
 C/4 channels of the local branch zero-padded to a multiple of 4: exact), attentions / pooling / bias images in grl_ops.hip,
 the channel gate and LayerNorms of the earlier nets.  Tokens stay channels-last [B, H, W, C] throughout, so blc<->bchw,
 roll, window_partition and window_reverse are address arithmetic inside the kernels.  Inference only."""
@@ -47,8 +48,19 @@ class GRLEngine:
                 w, b = wz, bz
             wp = torch.empty(9, cop, cip, device=w.device)
             ops.pack_conv_weight(w.contiguous(), wp, None)
+            if ops.bx3_nt_for(cop, cip):                 # three bf16 planes: f32-grade, and the kernels --amp narrows
+                wp = ops.split_bf16x3(wp)
             self._w[key] = (wp, b.contiguous(), cop)
         return self._w[key]
+
+    def _lin(self, x, m, **kw):
+        """nn.Linear on the GEMM kernels (weights of 64 channels and more as bf16 planes, narrower ones exact f32)"""
+        key = ("lin", id(m))
+        if key not in self._w:
+            w = m.weight.data
+            self._w[key] = (ops.split_bf16x3(w) if ops.bx3_nt_for(*w.shape) else w, None if m.bias is None else m.bias.data)
+        w, b = self._w[key]
+        return ops.gemm_nt(x, w, b, **kw)
 
     def _conv3(self, x, conv, **kw):
         wp, b, co = self._pack(conv)
@@ -87,9 +99,8 @@ class GRLEngine:
         hw, hs = net.heads_w[s], net.heads_s[s]
         x4 = x.view(B, H, W, C)
 
-        qkv = ops.gemm_nt(x, a.qkv.body.weight.data, None if a.qkv.body.bias is None else a.qkv.body.bias.data).view(B, H, W, 3 * C)
-        red = a.anchor.body[0].reduction
-        anchor = ops.gemm_nt(ops.avgpool2d(x4, df).view(-1, C), red.weight.data, red.bias.data).view(B, H // df, W // df, half)
+        qkv = self._lin(x, a.qkv.body).view(B, H, W, 3 * C)
+        anchor = self._lin(ops.avgpool2d(x4, df).view(-1, C), a.anchor.body[0].reduction).view(B, H // df, W // df, half)
         att = torch.empty(B, H, W, C, device=x.device)
         bw, lw = self._bias_image(a.window_attn.attn_transform, net.table_w, net.index_w, hw)
         ops.cosine_window_attention(qkv[..., 0:half], ws, qkv[..., half:2 * half], qkv[..., 2 * half:3 * half], ws, lw, bw,
@@ -103,14 +114,17 @@ class GRLEngine:
         ops.cosine_window_attention(anchor, asz, qkv[..., o + half:o + 2 * half], qkv[..., o + 2 * half:o + 3 * half], ssz, l1, b1,
                                     xa, hs, half // hs, 0)
         ops.cosine_window_attention(qkv[..., o:o + half], ssz, anchor, xa, asz, l2, b2, att[..., half:], hs, half // hs, 0)
-        p = ops.gemm_nt(att.view(-1, C), a.proj.weight.data, a.proj.bias.data)
+        p = self._lin(att.view(-1, C), a.proj)
         if self.taps is not None:
             self.taps[name + ".attn"] = p.detach().clone().view(B, H * W, C)
         ops.layernorm_rows(p, blk.norm1.weight.data, blk.norm1.bias.data, p)
         ops.axpby(p, x, 1.0, 1.0)
         if net.local_connection:
             cab = blk.conv.cab
-            cm = _pad4(cab[0].weight.shape[0])
+            cm = cab[0].weight.shape[0]
+            # C/4 channels zero-padded (exact: gelu(0) = 0): to 64 where that moves both convs onto the bf16-plane kernels
+            # (45 -> 64 at the registry's width, as SwinIR's '3conv'), else to a multiple of 4 for the exact-f32 ones
+            cm = 64 if ops.bx3_nt_for(C) and 32 < cm <= 64 else _pad4(cm)
             wp1, bb1, _ = self._pack(cab[0], cout_pad=cm)
             c1 = ops.conv3x3(x4, wp1, bb1, cm)
             ops.unary(c1, c1, "gelu")
@@ -122,8 +136,8 @@ class GRLEngine:
                              p.view(B, H, W, C), c2, xn.view(B, H, W, C))
         else:
             xn = p
-        h = ops.gemm_nt(xn, blk.mlp.fc1.weight.data, blk.mlp.fc1.bias.data)
-        m = ops.gemm_nt(h, blk.mlp.fc2.weight.data, blk.mlp.fc2.bias.data, a_mode=2)
+        h = self._lin(xn, blk.mlp.fc1)
+        m = self._lin(h, blk.mlp.fc2, a_mode=2)
         ops.layernorm_rows(m, blk.norm2.weight.data, blk.norm2.bias.data, m)
         ops.axpby(m, xn, 1.0, 1.0)
         return m
