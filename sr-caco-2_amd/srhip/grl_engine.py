@@ -3,8 +3,8 @@
 (average-pooled 4x4 anchors attend to the 8x8 stripe, the stripe attends back to the anchors), both cosine attentions with a
 clamped logit scale and a 16 sigmoid(CPB MLP) bias, a shared output projection, post-norm residuals, a conv + GELU + conv +
 channel-attention local branch, a GELU MLP -- each stage closed by a 3x3 conv and a skip, and a pixel-shuffle tail.  Written
-directly over the libsrhip ops: Linears and 3x3 convs on the GEMM / conv kernels (bf16x3 planes from 64 channels on -- the
-kernels --amp narrows to one product -- exact f32 below; GELU as the fc2 prologue; the
+directly over the libsrhip ops: Linears and 3x3 convs on the GEMM / conv kernels (fp16x2 / bf16x3 planes from 64 channels on
+-- the kernels --amp narrows to one product -- exact f32 below; GELU as the fc2 prologue; the
 C/4 channels of the local branch zero-padded to a multiple of 4: exact), attentions / pooling / bias images in grl_ops.hip,
 the channel gate and LayerNorms of the earlier nets.  Tokens stay channels-last [B, H, W, C] throughout, so blc<->bchw,
 roll, window_partition and window_reverse are address arithmetic inside the kernels.  Inference only."""
@@ -34,7 +34,9 @@ class GRLEngine:
 
     # ------------------------------------------------------------------ derived weights (cached until the weights change)
     def _pack(self, conv, cin_pad=None, cout_pad=None):
-        """tap-major pack [9, Cout, Cin] of a 3x3 conv, optionally zero-padded in either channel count, and its bias"""
+        """tap-major pack [9, Cout, Cin] of a 3x3 conv, optionally zero-padded in either channel count, and its bias.  From 64
+        channels on the pack is split into planes by the weight-preparation kernel (two fp16 planes where the conv kernels
+        take them, three bf16 planes otherwise: f32-grade with three / six products, one product under --amp)."""
         key = ("conv", id(conv))
         if key not in self._w:
             w, b = conv.weight.data, conv.bias.data
@@ -46,20 +48,33 @@ class GRLEngine:
                 bz = torch.zeros(cop, device=w.device)
                 bz[:co] = b
                 w, b = wz, bz
-            wp = torch.empty(9, cop, cip, device=w.device)
-            ops.pack_conv_weight(w.contiguous(), wp, None)
-            if ops.bx3_nt_for(cop, cip):                 # three bf16 planes: f32-grade, and the kernels --amp narrows
-                wp = ops.split_bf16x3(wp)
-            self._w[key] = (wp, b.contiguous(), cop)
-        return self._w[key]
+            w = w.contiguous()
+            if ops.bx3_nt_for(cop, cip):
+                wp = ops.Bx3(9 * cop, cip, w.device)
+                tb = ops.PrepTable()
+                tb.conv(w, wp)
+                tb.build(w.device).run()
+            else:
+                wp, tb = torch.empty(9, cop, cip, device=w.device), None
+                ops.pack_conv_weight(w, wp, None)
+            self._w[key] = (wp, b.contiguous(), cop, tb)
+        return self._w[key][:3]
 
     def _lin(self, x, m, **kw):
-        """nn.Linear on the GEMM kernels (weights of 64 channels and more as bf16 planes, narrower ones exact f32)"""
+        """nn.Linear on the GEMM kernels: weights of 64 channels and more as planes (the routing rule of the Linear GEMMs:
+        two fp16 planes for the 180-multiples, three bf16 planes otherwise), narrower ones exact f32"""
         key = ("lin", id(m))
         if key not in self._w:
-            w = m.weight.data
-            self._w[key] = (ops.split_bf16x3(w) if ops.bx3_nt_for(*w.shape) else w, None if m.bias is None else m.bias.data)
-        w, b = self._w[key]
+            w = m.weight.data.contiguous()
+            tb = None
+            if ops.bx3_nt_for(*w.shape):
+                P = ops.Bx3(w.shape[0], w.shape[1], w.device)
+                tb = ops.PrepTable()
+                tb.linear(w, P)
+                tb.build(w.device).run()
+                w = P
+            self._w[key] = (w, None if m.bias is None else m.bias.data, tb)
+        w, b, _ = self._w[key]
         return ops.gemm_nt(x, w, b, **kw)
 
     def _conv3(self, x, conv, **kw):

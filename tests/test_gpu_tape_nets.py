@@ -551,3 +551,31 @@ def test_grl_registry_default_width_vs_oracle():
         yo = O.grl_forward(sd, x, 2, depths=(2, 2))
         y = net(x.cuda()).cpu()
     assert (y - yo).abs().mean().item() <= 1e-5 * max(1.0, yo.abs().max().item()) and rel(y, yo) < 5e-5, rel(y, yo)
+
+
+def test_grl_registry_net_vs_oracle_and_amp():
+    """The registry's net itself (utils_init_default_args.py:166-189: 180 channels, depths 4+4+8+8+8+4+4 = 40 blocks, 3 + 3
+    heads, anchors pooled by 2) built through define_G at x8, on 40 x 32 inputs (other than the 64 x 64 its masks were
+    registered for) against the oracle; and --amp (one bf16 product in its Linears and convs) within the PSNR gate."""
+    from types import SimpleNamespace
+    from dlib.models.select_network import define_G
+    from dlib.utils.utils_init_default_args import init_net_g
+    from dlib.utils import constants
+    opt = init_net_g({'net_type': constants.GRL}, {'scale': 8, 'n_channels': 1, 'h_size': 512})
+    net = define_G(SimpleNamespace(netG=opt))
+    assert len(net.layers) == 7 and sum(len(s.blocks) for s in net.layers) == 40 and net.input_resolution == (64, 64)
+    sd = O.grl_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], 21, 64)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    gen = torch.Generator().manual_seed(15)
+    x = torch.rand(2, 1, 40, 32, generator=gen)
+    with torch.no_grad():
+        yo = O.grl_forward(sd, x, 8)
+        y = net(x.cuda()).cpu()
+        net.amp = True
+        ya = net(x.cuda()).cpu()
+    assert y.shape == (2, 1, 320, 256)
+    assert (y - yo).abs().mean().item() <= 1e-5 * max(1.0, yo.abs().max().item()) and rel(y, yo) < 1e-4, rel(y, yo)
+    assert not torch.equal(ya, y)                                          # the reduced-precision kernels did run
+    mse = ((ya - yo) ** 2).mean().item() / max(1.0, yo.abs().max().item()) ** 2
+    assert mse < 1e-5, mse
