@@ -31,6 +31,40 @@ __global__ void __launch_bounds__(256) k_dwconv3x3(const float* __restrict__ x, 
   }
 }
 
+// the same with four channels per lane (C, ldx, ldo multiples of 4): 16-byte loads, a quarter of the index arithmetic
+__global__ void __launch_bounds__(256) k_dwconv3x3_v4(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out, long ldo, int B,
+                                                      int H, int W, int C4) {
+  const long n = (long)B * H * W * C4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const long p = i / C4;
+    const int xx = (int)(p % W), y = (int)((p / W) % H);
+    const long b = p / ((long)W * H);
+    float4 a = bias ? *reinterpret_cast<const float4*>(bias + c) : float4{0.f, 0.f, 0.f, 0.f};
+    float wr[4][9];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wr[k][t] = w[(c + k) * 9 + t];
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = y + dy, xq = xx + dx;
+        if (yy >= 0 && yy < H && xq >= 0 && xq < W) {
+          const float4 v = *reinterpret_cast<const float4*>(x + ((b * H + yy) * W + xq) * ldx + c);
+          const int t = (dy + 1) * 3 + dx + 1;
+          a.x += wr[0][t] * v.x;
+          a.y += wr[1][t] * v.y;
+          a.z += wr[2][t] * v.z;
+          a.w += wr[3][t] * v.w;
+        }
+      }
+    *reinterpret_cast<float4*>(out + p * ldo + c) = a;
+  }
+}
+
 // attention of one (group of n <= 64 tokens, head): rows of qkv [.., 3C] = q | k | v, head-major channels
 constexpr int WA_N = 64, WA_D = 32;
 __global__ void __launch_bounds__(256) k_group_attention(const float* __restrict__ qkv, const float* __restrict__ bias,
@@ -186,8 +220,13 @@ extern "C" {
 int srhip_dwconv3x3(const float* x, long ldx, const float* w, const float* bias, float* out, long ldo, int B, int H, int W, int C,
                     void* stream) {
   SR_REQUIRE(x && w && out && B > 0 && H > 0 && W > 0 && C > 0 && ldx >= C && ldo >= C, "dwconv3x3: bad arguments");
-  hipLaunchKernelGGL(k_dwconv3x3, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, out, ldo,
-                     B, H, W, C);
+  const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ((size_t)x | (size_t)out | (size_t)bias) % 16 == 0;
+  if (v4)
+    hipLaunchKernelGGL(k_dwconv3x3_v4, dim3(ew_blocks((long)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias,
+                       out, ldo, B, H, W, C / 4);
+  else
+    hipLaunchKernelGGL(k_dwconv3x3, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, out, ldo,
+                       B, H, W, C);
   SR_LAUNCH_CHECK("dwconv3x3");
   return 0;
 }
