@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
+from .planes import PlaneCache
 
 
 def _pad4(n):
@@ -25,56 +26,21 @@ class GRLEngine:
         self.saved = None
         self.taps = None
         self._w = {}
+        self.planes = PlaneCache()
 
     def invalidate(self):
         self._w = {}
+        self.planes.clear()
 
     def bucket_prefixes(self):
         return [[""]]
 
     # ------------------------------------------------------------------ derived weights (cached until the weights change)
     def _pack(self, conv, cin_pad=None, cout_pad=None):
-        """tap-major pack [9, Cout, Cin] of a 3x3 conv, optionally zero-padded in either channel count, and its bias.  From 64
-        channels on the pack is split into planes by the weight-preparation kernel (two fp16 planes where the conv kernels
-        take them, three bf16 planes otherwise: f32-grade with three / six products, one product under --amp)."""
-        key = ("conv", id(conv))
-        if key not in self._w:
-            w, b = conv.weight.data, conv.bias.data
-            co, ci = w.shape[:2]
-            cop, cip = cout_pad or co, cin_pad or ci
-            if (cop, cip) != (co, ci):
-                wz = torch.zeros(cop, cip, 3, 3, device=w.device)
-                wz[:co, :ci] = w
-                bz = torch.zeros(cop, device=w.device)
-                bz[:co] = b
-                w, b = wz, bz
-            w = w.contiguous()
-            if ops.bx3_nt_for(cop, cip):
-                wp = ops.Bx3(9 * cop, cip, w.device)
-                tb = ops.PrepTable()
-                tb.conv(w, wp)
-                tb.build(w.device).run()
-            else:
-                wp, tb = torch.empty(9, cop, cip, device=w.device), None
-                ops.pack_conv_weight(w, wp, None)
-            self._w[key] = (wp, b.contiguous(), cop, tb)
-        return self._w[key][:3]
+        return self.planes.conv(id(conv), conv.weight.data, conv.bias.data, cin_pad, cout_pad)
 
     def _lin(self, x, m, **kw):
-        """nn.Linear on the GEMM kernels: weights of 64 channels and more as planes (the routing rule of the Linear GEMMs:
-        two fp16 planes for the 180-multiples, three bf16 planes otherwise), narrower ones exact f32"""
-        key = ("lin", id(m))
-        if key not in self._w:
-            w = m.weight.data.contiguous()
-            tb = None
-            if ops.bx3_nt_for(*w.shape):
-                P = ops.Bx3(w.shape[0], w.shape[1], w.device)
-                tb = ops.PrepTable()
-                tb.linear(w, P)
-                tb.build(w.device).run()
-                w = P
-            self._w[key] = (w, None if m.bias is None else m.bias.data, tb)
-        w, b, _ = self._w[key]
+        w, b = self.planes.linear(id(m), m.weight.data, None if m.bias is None else m.bias.data)
         return ops.gemm_nt(x, w, b, **kw)
 
     def _conv3(self, x, conv, **kw):

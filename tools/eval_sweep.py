@@ -65,7 +65,7 @@ def main():
                 ms = sorted(groups)[2]
                 out = model.E
                 assert tuple(out.shape[-2:]) == (512, 512) and torch.isfinite(out).all()
-                amp_used = bool(amp and getattr(model.netG, "amp", False))     # every mirror takes --amp since round 3
+                amp_used = bool(amp and getattr(model.netG, "amp", False) and getattr(model.netG, "amp_takes_effect", True))
                 rows.append({"net_type": net_type, "scale": scale, "amp_flag": amp, "reduced_precision_kernels": amp_used,
                              "batch": a.batch, "ms_per_batch": ms, "patches_per_s": a.batch / ms * 1e3})
                 print(json.dumps(rows[-1]), flush=True)
