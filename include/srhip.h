@@ -55,6 +55,13 @@ int srhip_gemm_nt(const float* A, long lda, const float* W, long ldw, const floa
                   const float* R, long ldr, const float* rowscale, int rows_per_scale, float alpha,
                   float* aux, long ldaux, void* stream);
 
+/* zcount independent products C_z[M,N] = A_z[M,K] . W_z[N,K]^T in ONE launch of the same kernel; the bases of problem z
+ * are A + (z / zdiv) * a_z0 + (z % zdiv) * a_z1 (floats; likewise W, C): the (sample, head) slices of row-major
+ * [B*T][heads*dh] matrices.  Replaces the per-(sample, head) `q @ k^T` / `attn @ v` of SelfAttention / CrossAttention
+ * (network_act.py:151-227), einsum 'bhid,bhjd->bhij' / 'bhij,bhjd->bhid'. */
+int srhip_gemm_nt_batched(const float* A, long lda, long a_z0, long a_z1, const float* W, long ldw, long w_z0, long w_z1, float* C,
+                          long ldc, long c_z0, long c_z1, int M, int N, int K, int zcount, int zdiv, void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution, NHWC, implicit GEMM.  Wp is the tap-major
  * pack [9][Cout][Cin] from srhip_pack_conv_weight (forward) or its flipped /
  * transposed twin (data gradient).  Epilogues as srhip_gemm_nt (0,1,2,4) plus

@@ -47,6 +47,19 @@ int srhip_gemm_nt(const float* A, long lda, const float* W, long ldw, const floa
   return sr_gemm_nt(p, (hipStream_t)stream);
 }
 
+int srhip_gemm_nt_batched(const float* A, long lda, long a_z0, long a_z1, const float* W, long ldw, long w_z0, long w_z1, float* C,
+                          long ldc, long c_z0, long c_z1, int M, int N, int K, int zcount, int zdiv, void* stream) {
+  SR_REQUIRE(A && W && C && zcount > 0 && zdiv > 0 && zcount <= 65535, "gemm_nt_batched: 1 <= zcount <= 65535, zdiv > 0 (zcount=%d)", zcount);
+  SR_REQUIRE(a_z0 % 4 == 0 && a_z1 % 4 == 0 && w_z0 % 4 == 0 && w_z1 % 4 == 0, "gemm_nt_batched: operand strides must be multiples of 4 floats");
+  NtArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.alpha = 1.f; p.rows_per_scale = 1;
+  p.zcount = zcount; p.zdiv = zdiv;
+  p.zA[0] = a_z0; p.zA[1] = a_z1; p.zW[0] = w_z0; p.zW[1] = w_z1; p.zC[0] = c_z0; p.zC[1] = c_z1;
+  return sr_gemm_nt(p, (hipStream_t)stream);
+}
+
 int srhip_conv3x3_nhwc(const float* X, long ldx, const float* Wp, const float* bias, float* Y, long ldy,
                        int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                        const float* rowscale, float alpha, void* stream) {

@@ -52,6 +52,12 @@ __global__ void __launch_bounds__(256, 2) k_nt(NtArgs p) {
     y0 = ty * TROWS; x0 = tx * 16;
   } else {
     m0 = blockIdx.x * BM;
+    if (p.zcount > 1) {                            // one of a batch of GEMMs: shift the operand bases
+      const int z0 = blockIdx.z / p.zdiv, z1 = blockIdx.z - z0 * p.zdiv;
+      p.A += z0 * p.zA[0] + z1 * p.zA[1];
+      p.W += z0 * p.zW[0] + z1 * p.zW[1];
+      p.C += z0 * p.zC[0] + z1 * p.zC[1];
+    }
   }
 
   // Co-resident blocks start in lockstep and would all load, compute and store
@@ -249,7 +255,7 @@ int launch_nt(const NtArgs& p, hipStream_t st) {
   constexpr int BM = 64 * WM;
   dim3 grid;
   if (CONV) grid = dim3(p.tiles_x * p.tiles_y * p.batch, sr_cdiv(p.N, p.n_tile));
-  else grid = dim3(sr_cdiv(p.M, BM), sr_cdiv(p.N, p.n_tile));
+  else grid = dim3(sr_cdiv(p.M, BM), sr_cdiv(p.N, p.n_tile), p.zcount > 1 ? p.zcount : 1);
   hipLaunchKernelGGL((k_nt<WM, WN, BK, CONV>), grid, dim3(256), 0, st, p);
   SR_LAUNCH_CHECK("k_nt");
   return 0;

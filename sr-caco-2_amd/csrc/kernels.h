@@ -37,6 +37,10 @@ struct NtArgs {
   int ps;
   int k_rot;                  // k_ntw: rotate the K walk per block (gemm_ntw.hip)
   int wfmt;                   // weight operand format: 0 three bf16 planes | 1 two fp16 planes + per-row 2^-s (prep kind 3; k_nth)
+  // batch of independent GEMMs in one launch (exact-f32 GEMM only; blockIdx.z = problem z): operand bases move by
+  // (z / zdiv) * z?[0] + (z % zdiv) * z?[1] floats -- e.g. (sample, head) slices of a [B*T][heads*dh] matrix.  zcount <= 1: off
+  int zcount, zdiv;
+  long zA[2], zW[2], zC[2];
 };
 
 struct TnArgs {

@@ -1,8 +1,8 @@
 """ACT on libsrhip, evaluation forward (reference dlib/models/network_act.py:321-541): a CNN branch (RCAN residual groups)
 and a transformer branch (3 x 3 tokens, self-attention + cross-scale attention against overlapping 6 x 6 tokens) that
 exchange features in four fusion blocks.  Written directly over the libsrhip ops: 3 x 3 convs on the split-MFMA conv
-kernels, the 5 x 5 head convs as im2col (srhip_unfold) + GEMM, Linears / 1 x 1 convs on the exact-f32 GEMM, attention per
-(sample, head) as two GEMMs around srhip_softmax_rows, F.unfold / F.fold as srhip_unfold / srhip_fold, RCAN's channel
+kernels, the 5 x 5 head convs as im2col (srhip_unfold) + GEMM, Linears / 1 x 1 convs on the exact-f32 GEMM, the attention's
+(sample, head) products as two batched launches (srhip_gemm_nt_batched) around srhip_softmax_rows, F.unfold / F.fold as srhip_unfold / srhip_fold, RCAN's channel
 attention as srhip_channel_gate.  Inference only."""
 import math
 
@@ -76,19 +76,25 @@ class ACTEngine:
         return ops.unary(x, x, "gelu")
 
     def _attend(self, q, k, v, B, Tq, Tk, heads, dh, scale):
-        """q [B*Tq, heads*dh], k / v [B*Tk, heads*dh] (views with any row pitch) -> [B*Tq, heads*dh]"""
+        """q [B*Tq, heads*dh], k / v [B*Tk, heads*dh] (views with any row pitch) -> [B*Tq, heads*dh].  The (sample, head)
+        products run as batches of one launch each (srhip_gemm_nt_batched), a chunk of samples at a time so that the
+        attention matrices stay below 2 GiB."""
         out = torch.empty(B * Tq, heads * dh, device=q.device)
         Tk4 = (Tk + 3) & ~3                         # the GEMM takes contraction lengths / pitches that are multiples of 4
-        dots = torch.zeros(Tq, Tk4, device=q.device)
-        vt = torch.zeros(dh, Tk4, device=q.device)
-        for b in range(B):
-            for h in range(heads):
-                qs = q[b * Tq:(b + 1) * Tq, h * dh:(h + 1) * dh]
-                ks = k[b * Tk:(b + 1) * Tk, h * dh:(h + 1) * dh]
-                vt[:, :Tk].copy_(v[b * Tk:(b + 1) * Tk, h * dh:(h + 1) * dh].t())
-                ops.gemm_nt(qs, ks, None, out=dots[:, :Tk])
-                ops.softmax_rows_(dots[:, :Tk], scale)
-                ops.gemm_nt(dots, vt, None, out=out[b * Tq:(b + 1) * Tq, h * dh:(h + 1) * dh])
+        nb = max(1, min(B, (1 << 29) // (heads * Tq * Tk4)))
+        dots = torch.zeros(nb * heads, Tq, Tk4, device=q.device)      # pad columns stay 0 (softmax writes [:Tk] only)
+        vt = torch.zeros(nb * heads, dh, Tk4, device=q.device)
+        for b0 in range(0, B, nb):
+            n = min(nb, B - b0)
+            z = n * heads
+            qs, ks, vs = q[b0 * Tq:(b0 + n) * Tq], k[b0 * Tk:(b0 + n) * Tk], v[b0 * Tk:(b0 + n) * Tk]
+            vt[:z, :, :Tk].copy_(vs.reshape(n, Tk, heads, dh).permute(0, 2, 3, 1).reshape(z, dh, Tk))
+            ops.gemm_nt_batched(qs[:, :dh], (Tq * qs.stride(0), dh), ks[:, :dh], (Tk * ks.stride(0), dh),
+                                dots[0, :, :Tk], (heads * Tq * Tk4, Tq * Tk4), Tq, Tk, dh, z, heads)
+            ops.softmax_rows_(dots[:z].view(z * Tq, Tk4)[:, :Tk], scale)
+            o = out[b0 * Tq:(b0 + n) * Tq]
+            ops.gemm_nt_batched(dots[0], (heads * Tq * Tk4, Tq * Tk4), vt[0], (heads * dh * Tk4, dh * Tk4),
+                                o[:, :dh], (Tq * o.stride(0), dh), Tq, dh, Tk4, z, heads)
         return out
 
     def _self_attention(self, blk, x2, B, T):

@@ -272,6 +272,16 @@ def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
     return out
 
 
+def gemm_nt_batched(A, a_z, W, w_z, C, c_z, M, N, K, zcount, zdiv):
+    """zcount products C_z[M, N] = A_z[M, K] @ W_z[N, K]^T in one launch (exact-f32 kernel).  A / W / C: 2-D views giving the
+    base pointer and row pitch of problem 0; *_z = (stride per z // zdiv, stride per z % zdiv) in floats."""
+    _chk(A, W, C)
+    assert A.stride(-1) == 1 and W.stride(-1) == 1 and C.stride(-1) == 1
+    call("srhip_gemm_nt_batched", A.data_ptr(), A.stride(-2), a_z[0], a_z[1], W.data_ptr(), W.stride(-2), w_z[0], w_z[1],
+         C.data_ptr(), C.stride(-2), c_z[0], c_z[1], M, N, K, zcount, zdiv, _st())
+    return C
+
+
 def gemm_nt_lnbwd(A, W, x, stats, res, out):
     """out = res + LayerNorm_backward(A @ W^T; x, stats) in one kernel (W: Bx3)."""
     assert isinstance(W, Bx3)

@@ -53,6 +53,35 @@ def test_gemm_nt_bias(ops, M, N, K):
     check(out, F.linear(A, W, b), 2e-5, f"gemm_nt {M}x{N}x{K}")
 
 
+def test_gemm_nt_batched_slices(ops):
+    """srhip_gemm_nt_batched: the (sample, head) products of an attention -- 'bhid,bhjd->bhij' on head slices of row-major
+    [B*T][heads*dh] matrices and 'bhij,bhjd->bhid' back into such a matrix (network_act.py:151-227) -- in one launch each,
+    against float64; ragged token counts (441 -> pitch 444), 3 samples x 5 heads."""
+    gen = torch.Generator().manual_seed(5)
+    B, heads, dh, Tq, Tk = 3, 5, 36, 100, 441
+    Tk4 = (Tk + 3) & ~3
+    q = torch.randn(B * Tq, heads * dh + 8, generator=gen).cuda()
+    k = torch.randn(B * Tk, 2 * heads * dh, generator=gen).cuda()
+    dots = torch.zeros(B * heads, Tq, Tk4, device="cuda")
+    ops.gemm_nt_batched(q[:, :dh], (Tq * q.stride(0), dh), k[:, :dh], (Tk * k.stride(0), dh), dots[0, :, :Tk],
+                        (heads * Tq * Tk4, Tq * Tk4), Tq, Tk, dh, B * heads, heads)
+    qd = q[:, :heads * dh].double().view(B, Tq, heads, dh).permute(0, 2, 1, 3)
+    kd = k[:, :heads * dh].double().view(B, Tk, heads, dh).permute(0, 2, 1, 3)
+    ref = qd @ kd.transpose(-1, -2)
+    assert relerr(dots.view(B, heads, Tq, Tk4)[..., :Tk], ref) < 1e-6
+    assert (dots.view(B, heads, Tq, Tk4)[..., Tk:] == 0).all()
+    v = k[:, heads * dh:]
+    vt = torch.zeros(B * heads, dh, Tk4, device="cuda")
+    vt[:, :, :Tk].copy_(v.reshape(B, Tk, heads, dh).permute(0, 2, 3, 1).reshape(B * heads, dh, Tk))
+    out = torch.full((B * Tq, heads * dh + 4), float("nan"), device="cuda")
+    ops.gemm_nt_batched(dots[0], (heads * Tq * Tk4, Tq * Tk4), vt[0], (heads * dh * Tk4, dh * Tk4), out[:, :dh],
+                        (Tq * out.stride(0), dh), Tq, dh, Tk4, B * heads, heads)
+    vd = v.double().view(B, Tk, heads, dh).permute(0, 2, 1, 3)
+    ref2 = (dots.double().view(B, heads, Tq, Tk4)[..., :Tk] @ vd).permute(0, 2, 1, 3).reshape(B * Tq, heads * dh)
+    assert relerr(out[:, :heads * dh], ref2) < 1e-6
+    assert torch.isnan(out[:, heads * dh:]).all()
+
+
 def test_gemm_nt_prologues_epilogues(ops):
     M, N, K = 1024, 180, 180
     A, W, b = rnd(M, K), rnd(N, K, scale=0.1), rnd(N)
