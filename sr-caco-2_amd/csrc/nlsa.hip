@@ -147,6 +147,147 @@ __global__ void __launch_bounds__(256) k_nlsa_attention(const float* __restrict_
   }
 }
 
+// The same block on the exact-f32 matrix core (v_mfma_f32_32x32x2_f32; Cy a multiple of 32 up to 256, cs a multiple of 8, Ce a
+// multiple of 4), eight waves: 32 queries at a time; S = Q K^T as one 32 x 32 tile per wave (rows of pitch 68 = 4 * 17
+// floats: every lane half reads four consecutive features of its row with one b128 and feeds them to four MFMAs, the same k
+// permutation on both operands) with the keys' 1 / max(|k|, eps) -- computed once per block -- applied to the scores; the row
+// softmax as before; O = P V, one 32-channel tile per wave, P from LDS (pitch 4 * odd) and the value rows straight from
+// global memory in the B-operand layout (lane = channel, 128-byte segments), 32 keys (16 loads per lane) ahead.
+constexpr int MQ = 32, MP = CE_MAX + 4, MW = 8, MTH = 64 * MW;
+__global__ void __launch_bounds__(MTH) k_nlsa_attention_mfma(const float* __restrict__ xe, const float* __restrict__ ye,
+                                                             const unsigned long long* __restrict__ order,
+                                                             float* __restrict__ ret, float* __restrict__ score, int L, int Ce,
+                                                             int Cy, int nh, int cs, int nchunks, int SP) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* const sq = sm;                               // [MQ][MP]
+  float* const sk = sq + MQ * MP;                     // [cs][MP] one key chunk
+  float* const ss = sk + (size_t)cs * MP;             // [MQ][SP] scores, then probabilities
+  int* const ktok = (int*)(ss + (size_t)MQ * SP);     // [3 cs] token of key j
+  float* const kf = (float*)(ktok + 3 * cs);          // [3 cs] 1 / max(|k_j|, 5e-5)
+  float* const rl = kf + 3 * cs;                      // [MQ] log-sum-exp of the row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int chunk = blockIdx.x % nchunks;
+  const int nhh = blockIdx.x / nchunks;               // n * nh + h
+  const int n = nhh / nh;
+  const unsigned long long* ord = order + (long)nhh * L;
+  const int padding = L % cs ? cs - L % cs : 0;
+  auto tok_of = [&](int pos) {
+    if (pos >= L) pos -= padding;
+    return (int)(ord[pos] & ((1u << TOK_BITS) - 1));
+  };
+  const int chunks3[3] = {chunk, (chunk + nchunks - 1) % nchunks, (chunk + 1) % nchunks};      // own, back, forward (:173-176)
+  const float* xb = xe + (long)n * L * Ce;
+  const float* yb = ye + (long)n * L * Cy;
+  const int K3 = 3 * cs, C4 = Ce >> 2, G8 = (Ce + 7) >> 3, nct = (cs + 31) >> 5, ncy = Cy >> 5;
+  for (int j = tid; j < K3; j += MTH) {               // F.normalize(p = 2, eps = 5e-5) of the key rows (:224), as a factor
+    const int tok = tok_of(chunks3[j / cs] * cs + j % cs);
+    ktok[j] = tok;
+    const f32x4* row = (const f32x4*)(xb + (long)tok * Ce);
+    float s2 = 0.f;
+    for (int e = 0; e < C4; ++e) {
+      const f32x4 v = row[e];
+      s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    kf[j] = 1.0f / fmaxf(sqrtf(s2), 5e-5f);
+  }
+  for (int q0 = 0; q0 < cs; q0 += MQ) {
+    const int nq = min(MQ, cs - q0);
+    __syncthreads();
+    for (int i = tid; i < MQ * (CE_MAX / 4); i += MTH) {           // a chunk's queries are its own keys' rows, unnormalised
+      const int rr = i / (CE_MAX / 4), e = i - rr * (CE_MAX / 4);
+      *(f32x4*)(sq + rr * MP + 4 * e) = (rr < nq && e < C4) ? *(const f32x4*)(xb + (long)ktok[q0 + rr] * Ce + 4 * e)
+                                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int kt = 0; kt < 3; ++kt) {
+      __syncthreads();
+      for (int i = tid; i < cs * (CE_MAX / 4); i += MTH) {
+        const int rr = i / (CE_MAX / 4), e = i - rr * (CE_MAX / 4);
+        *(f32x4*)(sk + rr * MP + 4 * e) = e < C4 ? *(const f32x4*)(xb + (long)ktok[kt * cs + rr] * Ce + 4 * e)
+                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      __syncthreads();
+      for (int ct = wave; ct < nct; ct += MW) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        const float* ap = sq + r * MP + 4 * h;
+        const float* bp = sk + min(ct * 32 + r, cs - 1) * MP + 4 * h;
+        for (int g = 0; g < G8; ++g) {
+          const f32x4 fa = *(const f32x4*)(ap + g * 8), fb = *(const f32x4*)(bp + g * 8);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc = mfma32(fa[t], fb[t], acc);
+        }
+        const int col = ct * 32 + r;
+        if (col < cs) {
+          const float f = kf[kt * cs + col];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) ss[mfma_row(q, lane) * SP + kt * cs + col] = acc[q] * f;
+        }
+      }
+    }
+    __syncthreads();
+    // log-sum-exp of each row and the probabilities (:235-237): one wave per row
+    for (int i = wave; i < nq; i += MW) {
+      float mx = -3.0e38f;
+      for (int j = lane; j < K3; j += 64) mx = fmaxf(mx, ss[i * SP + j]);
+      mx = wave_max(mx);
+      float sum = 0.f;
+      for (int j = lane; j < K3; j += 64) sum += expf(ss[i * SP + j] - mx);
+      sum = wave_sum(sum);
+      const float lse = mx + logf(sum);
+      for (int j = lane; j < K3; j += 64) ss[i * SP + j] = expf(ss[i * SP + j] - lse);
+      if (lane == 0) rl[i] = lse;
+    }
+    __syncthreads();
+    // O = P . V: wave = 32 output channels
+    if (wave < ncy) {
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      const float* pp = ss + r * SP + 4 * h;
+      const float* ycol = yb + wave * 32 + r;
+      const int NG = K3 >> 3;                          // groups of 8 keys: this lane half's four, then the other's
+      float va[4][4], vb[4][4];
+      auto fetch = [&](int g0, float (&v)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int j = min((g0 + u) * 8 + 4 * h + t, K3 - 1);
+            v[u][t] = ycol[(long)ktok[j] * Cy];
+          }
+      };
+      auto run = [&](int g0, const float (&v)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (g0 + u < NG) {
+            const f32x4 fa = *(const f32x4*)(pp + (g0 + u) * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = mfma32(fa[t], v[u][t], acc);
+          }
+        }
+      };
+      fetch(0, va);
+      for (int g = 0; g < NG; g += 8) {
+        if (g + 4 < NG) fetch(g + 4, vb);
+        run(g, va);
+        if (g + 8 < NG) fetch(g + 8, va);
+        if (g + 4 < NG) run(g + 4, vb);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = mfma_row(q, lane);
+        const int pos = chunk * cs + q0 + i;
+        if (i < nq && pos < L) ret[((long)nhh * L + ktok[q0 + i]) * Cy + wave * 32 + r] = acc[q];
+      }
+    }
+    for (int i = tid; i < nq; i += MTH) {
+      const int pos = chunk * cs + q0 + i;
+      if (pos < L) score[(long)nhh * L + ktok[q0 + i]] = rl[i];
+    }
+  }
+}
+
 // softmax over the rounds of the scores, weighted sum, residual (:256-266): one wave per token
 __global__ void __launch_bounds__(256) k_nlsa_combine(const float* __restrict__ ret, const float* __restrict__ score,
                                                       const float* __restrict__ x, float* __restrict__ out, int N, int L,
@@ -215,17 +356,31 @@ int srhip_nlsa_attention(const float* x_embed, const float* y_embed, const unsig
   SR_REQUIRE(Ce > 0 && Ce <= CE_MAX && Cy > 0 && chunk_size > 0 && chunk_size % 4 == 0 && L >= chunk_size,
              "nlsa_attention: Ce = %d (<= 64), chunk_size = %d (a multiple of 4, <= L = %d)", Ce, chunk_size, L);
   const int nchunks = sr_cdiv(L, chunk_size);
-  const size_t lds = ((size_t)QT * CE_MAX + (size_t)chunk_size * KP + (size_t)QT * 3 * chunk_size + 3 * chunk_size + QT) * 4;
-  SR_REQUIRE(lds <= 160 * 1024, "nlsa_attention: chunk_size %d needs %zu bytes of LDS", chunk_size, lds);
   hipStream_t st = (hipStream_t)stream;
-  static size_t reserved = 0;
-  if (lds > reserved) {
-    if (hipFuncSetAttribute((const void*)k_nlsa_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return sr_fail(-5, "nlsa_attention: cannot reserve %zu bytes of LDS", lds);
-    reserved = lds;
+  if (Cy % 32 == 0 && Cy <= 32 * MW && chunk_size % 8 == 0 && Ce % 4 == 0) {            // the matrix-core kernel
+    const int K3 = 3 * chunk_size, SP = K3 + (12 - K3 % 8) % 8;      // pitch = 4 * odd floats
+    const size_t lds = ((size_t)MQ * MP + (size_t)chunk_size * MP + (size_t)MQ * SP + 6 * chunk_size + MQ) * 4;
+    SR_REQUIRE(lds <= 160 * 1024, "nlsa_attention: chunk_size %d needs %zu bytes of LDS", chunk_size, lds);
+    static size_t reserved_m = 0;
+    if (lds > reserved_m) {
+      if (hipFuncSetAttribute((const void*)k_nlsa_attention_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return sr_fail(-5, "nlsa_attention: cannot reserve %zu bytes of LDS", lds);
+      reserved_m = lds;
+    }
+    hipLaunchKernelGGL(k_nlsa_attention_mfma, dim3(N * n_hashes * nchunks), dim3(MTH), lds, st, x_embed, y_embed, order, ret, score,
+                       L, Ce, Cy, n_hashes, chunk_size, nchunks, SP);
+  } else {
+    const size_t lds = ((size_t)QT * CE_MAX + (size_t)chunk_size * KP + (size_t)QT * 3 * chunk_size + 3 * chunk_size + QT) * 4;
+    SR_REQUIRE(lds <= 160 * 1024, "nlsa_attention: chunk_size %d needs %zu bytes of LDS", chunk_size, lds);
+    static size_t reserved = 0;
+    if (lds > reserved) {
+      if (hipFuncSetAttribute((const void*)k_nlsa_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return sr_fail(-5, "nlsa_attention: cannot reserve %zu bytes of LDS", lds);
+      reserved = lds;
+    }
+    hipLaunchKernelGGL(k_nlsa_attention, dim3(N * n_hashes * nchunks), dim3(256), lds, st, x_embed, y_embed, order, ret, score, L,
+                       Ce, Cy, n_hashes, chunk_size, nchunks);
   }
-  hipLaunchKernelGGL(k_nlsa_attention, dim3(N * n_hashes * nchunks), dim3(256), lds, st, x_embed, y_embed, order, ret, score, L,
-                     Ce, Cy, n_hashes, chunk_size, nchunks);
   hipLaunchKernelGGL(k_nlsa_combine, dim3(sr_cdiv((long)N * L, 4)), dim3(256), 0, st, ret, score, x, out, N, L, Cy, n_hashes,
                      res_scale);
   SR_LAUNCH_CHECK("nlsa_attention");
