@@ -474,6 +474,41 @@ __global__ void k_pixel_shuffle(const float* __restrict__ in, float* __restrict_
   }
 }
 
+// Any r, channels-last on both sides (the r x r sub-kernel form of DBPN's / SRFBN's transposed convs, network_dbpn.py:107-143):
+// one low-res pixel per block pass.  Its Co*r*r values are one contiguous run and its r*r high-res pixels are runs of Co
+// channels: the [Co][r*r] -> [r*r][Co] transposition goes through LDS (row pitch r*r + 1: both sides conflict free), so
+// both global sides move whole cache lines -- the element-wise gather reached 0.8 TB/s on the 16-KB runs of r = 8.
+__global__ void __launch_bounds__(256) k_pixel_shuffle_nhwc_t(const float* __restrict__ in, float* __restrict__ out, long npix,
+                                                              int h, int w, int Co, int r, int inverse) {
+  extern __shared__ float tile[];                 // [Co][r*r + 1]
+  const int rr = r * r, P = rr + 1, n = Co * rr;
+  const long W = (long)w * r;
+  for (long pix = blockIdx.x; pix < npix; pix += gridDim.x) {
+    const int x = (int)(pix % w);
+    const long t = pix / w;
+    const int y = (int)(t % h);
+    const long b = t / h;
+    const long hi0 = ((b * h + y) * r * W + (long)x * r) * Co;      // high-res pixel (y r, x r), channel 0
+    const long lo0 = pix * n;
+    __syncthreads();
+    if (!inverse) {
+      for (int i = threadIdx.x; i < n; i += 256) tile[(i / rr) * P + i % rr] = in[lo0 + i];
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += 256) {
+        const int s = i / Co, c = i - s * Co;
+        out[hi0 + ((long)(s / r) * W + s % r) * Co + c] = tile[c * P + s];
+      }
+    } else {
+      for (int i = threadIdx.x; i < n; i += 256) {
+        const int s = i / Co, c = i - s * Co;
+        tile[c * P + s] = in[hi0 + ((long)(s / r) * W + s % r) * Co + c];
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += 256) out[lo0 + i] = tile[(i / rr) * P + i % rr];
+    }
+  }
+}
+
 // r = 2, channels-last on both sides (the EDSR upsampler stages, network_nlsn.py:108):
 // a lane moves the 4 sub-pixel values of channel c of one low-res pixel as ONE float4
 // (in[pix][4c .. 4c+3]) and four coalesced dwords (out[2y+i][2x+j][c]) -- no per-element
@@ -902,6 +937,13 @@ int srhip_pixel_shuffle(const float* in, float* out, int B, int h, int w, int Co
   }
   const long n = (long)B * h * w * Co * r * r;
   if (n == 0) return 0;
+  if (nhwc_out && r > 1 && (long)Co * (r * r + 1) * 4 <= 48 * 1024 && Co * r * r >= 256) {
+    const long npix = (long)B * h * w;
+    hipLaunchKernelGGL(k_pixel_shuffle_nhwc_t, dim3((unsigned)(npix < 65536 ? npix : 65536)), dim3(256), (size_t)Co * (r * r + 1) * 4,
+                       (hipStream_t)stream, in, out, npix, h, w, Co, r, inverse);
+    SR_LAUNCH_CHECK("pixel_shuffle_nhwc");
+    return 0;
+  }
   hipLaunchKernelGGL(k_pixel_shuffle, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, in, out,
                      B, h, w, Co, r, nhwc_out, inverse);
   SR_LAUNCH_CHECK("pixel_shuffle");

@@ -416,7 +416,8 @@ def test_conv_cin1_cout1(ops):
 
 
 # ------------------------------------------------------------------ index ops
-@pytest.mark.parametrize("r,Co,h,w", [(8, 1, 8, 8), (2, 64, 6, 10), (3, 2, 4, 4), (8, 1, 64, 64)])
+@pytest.mark.parametrize("r,Co,h,w", [(8, 1, 8, 8), (2, 64, 6, 10), (3, 2, 4, 4), (8, 1, 64, 64), (8, 64, 5, 7), (4, 32, 6, 3),
+                                      (3, 40, 4, 5), (8, 16, 9, 4)])
 def test_pixel_shuffle_bit_exact(ops, r, Co, h, w):
     B = 2
     x = torch.arange(B * Co * r * r * h * w, dtype=torch.float32).reshape(B, Co * r * r, h, w)
