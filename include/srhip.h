@@ -402,6 +402,9 @@ int srhip_unfold(const float* x, long ldx, float* tok, long ldt, int B, int H, i
 int srhip_fold(const float* tok, long ldt, float* out, long ldo, int B, int H, int W, int C, int k, int s, void* stream);
 int srhip_layernorm_rows(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, long M, int C,
                          float eps, void* stream);
+/* y = res + LayerNorm(x), rows of at most 256 values (GRL's post-norm residuals, network_grl.py:1061-1076); y may alias x / res */
+int srhip_layernorm_rows_res(const float* x, long ldx, const float* res, long ldr, float* y, long ldy, const float* gamma,
+                             const float* beta, long M, int C, float eps, void* stream);
 int srhip_softmax_rows(float* x, long ld, long R, int n, float scale, void* stream);
 
 /* ---- pieces of OmniSR's omni self-attention blocks, evaluation forward (omni_ops.hip) --------------

@@ -54,6 +54,39 @@ __global__ void __launch_bounds__(256) k_layernorm_rows(const float* __restrict_
   float* o = y + m * ldy;
   for (int c = lane; c < C; c += 64) o[c] = (r[c] - mean) * rstd * g[c] + bta[c];
 }
+// the same for rows of at most 256 values, held in registers (one read of the row), with an optional residual: y = res + LN(x)
+__global__ void __launch_bounds__(256) k_layernorm_rows_reg(const float* __restrict__ x, long ldx, const float* __restrict__ res,
+                                                            long ldr, float* __restrict__ y, long ldy, const float* __restrict__ g,
+                                                            const float* __restrict__ bta, long M, int C, float eps) {
+  const long m = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const float* r = x + m * ldx;
+  float v[4], s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane + 64 * k;
+    v[k] = c < C ? r[c] : 0.f;
+    s1 += v[k];
+  }
+  const float mean = wave_sum(s1) / (float)C;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float d = lane + 64 * k < C ? v[k] - mean : 0.f;
+    s2 += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
+  float* o = y + m * ldy;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane + 64 * k;
+    if (c < C) {
+      const float t = (v[k] - mean) * rstd * g[c] + bta[c];
+      o[c] = res ? res[m * ldr + c] + t : t;
+    }
+  }
+}
 // x[r][0:n] <- softmax(scale * x[r][0:n]): one wave per row
 __global__ void __launch_bounds__(256) k_softmax_rows(float* __restrict__ x, long ld, long R, int n, float scale) {
   const long r = blockIdx.x * 4L + (threadIdx.x >> 6);
@@ -106,9 +139,25 @@ int srhip_fold(const float* tok, long ldt, float* out, long ldo, int B, int H, i
 int srhip_layernorm_rows(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, long M, int C,
                          float eps, void* stream) {
   SR_REQUIRE(x && y && gamma && beta && M > 0 && C > 0 && ldx >= C && ldy >= C, "layernorm_rows: bad arguments");
-  hipLaunchKernelGGL(k_layernorm_rows, dim3(sr_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gamma, beta, M, C,
-                     eps);
+  if (C <= 256)
+    hipLaunchKernelGGL(k_layernorm_rows_reg, dim3(sr_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, nullptr, 0, y, ldy, gamma,
+                       beta, M, C, eps);
+  else
+    hipLaunchKernelGGL(k_layernorm_rows, dim3(sr_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gamma, beta, M, C,
+                       eps);
   SR_LAUNCH_CHECK("layernorm_rows");
+  return 0;
+}
+
+/* y = res + LayerNorm(x) over rows of at most 256 values: the post-norm residuals of GRL's blocks (network_grl.py:1061-1076);
+ * y may be x or res */
+int srhip_layernorm_rows_res(const float* x, long ldx, const float* res, long ldr, float* y, long ldy, const float* gamma,
+                             const float* beta, long M, int C, float eps, void* stream) {
+  SR_REQUIRE(x && res && y && gamma && beta && M > 0 && C > 0 && C <= 256 && ldx >= C && ldy >= C && ldr >= C,
+             "layernorm_rows_res: rows of at most 256 values (C=%d)", C);
+  hipLaunchKernelGGL(k_layernorm_rows_reg, dim3(sr_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, res, ldr, y, ldy, gamma,
+                     beta, M, C, eps);
+  SR_LAUNCH_CHECK("layernorm_rows_res");
   return 0;
 }
 

@@ -65,6 +65,15 @@ class GRLEngine:
                             tr.logit_scale.data.reshape(-1).contiguous())
         return self._w[key]
 
+    @staticmethod
+    def _ln_res(y, res, norm):
+        """y <- res + norm(y): a post-norm residual"""
+        if y.shape[1] <= 256:
+            return ops.layernorm_rows_res(y, res, norm.weight.data, norm.bias.data, y)
+        ops.layernorm_rows(y, norm.weight.data, norm.bias.data, y)
+        ops.axpby(y, res, 1.0, 1.0)
+        return y
+
     # ------------------------------------------------------------------ one block (x [T, C], channels-last tokens)
     def _block(self, blk, x, B, H, W, i, s, name):
         net = self.net
@@ -98,8 +107,7 @@ class GRLEngine:
         p = self._lin(att.view(-1, C), a.proj)
         if self.taps is not None:
             self.taps[name + ".attn"] = p.detach().clone().view(B, H * W, C)
-        ops.layernorm_rows(p, blk.norm1.weight.data, blk.norm1.bias.data, p)
-        ops.axpby(p, x, 1.0, 1.0)
+        self._ln_res(p, x, blk.norm1)
         if net.local_connection:
             cab = blk.conv.cab
             cm = cab[0].weight.shape[0]
@@ -119,8 +127,7 @@ class GRLEngine:
             xn = p
         h = self._lin(xn, blk.mlp.fc1)
         m = self._lin(h, blk.mlp.fc2, a_mode=2)
-        ops.layernorm_rows(m, blk.norm2.weight.data, blk.norm2.bias.data, m)
-        ops.axpby(m, xn, 1.0, 1.0)
+        self._ln_res(m, xn, blk.norm2)
         return m
 
     # ------------------------------------------------------------------ forward

@@ -422,6 +422,15 @@ def layernorm_rows(x, gamma, beta, out, eps=1e-5):
     return out
 
 
+def layernorm_rows_res(x, res, gamma, beta, out, eps=1e-5):
+    """out = res + nn.LayerNorm(x) over the rows of 2-D views of at most 256 columns; out may be x or res."""
+    _chk(x, res, gamma, beta, out)
+    assert x.dim() == 2 and out.shape == x.shape == res.shape and x.stride(1) == 1 and out.stride(1) == 1 and res.stride(1) == 1
+    call("srhip_layernorm_rows_res", _p(x), x.stride(0), _p(res), res.stride(0), _p(out), out.stride(0), _p(gamma), _p(beta),
+         x.shape[0], x.shape[1], float(eps), _st())
+    return out
+
+
 def softmax_rows_(x, scale=1.0):
     """x[r] <- softmax(scale * x[r]) in place, 2-D view."""
     _chk(x)
