@@ -94,6 +94,22 @@ class MemNetEngine:
             c[1].copy_(rstd)
             c[2].copy_(m.weight.data * rstd)
             c[3].copy_(m.bias.data)
+        # The BatchNorm BETWEEN a unit's two convs (residual_block.3) is affine at evaluation time and follows conv 0
+        # directly: it is folded into that conv -- w'[co] = a[co] w[co], bias'[co] = b[co] with a = gamma rstd, b = beta -
+        # mean a -- and the ReLU becomes the conv's epilogue: one pass over the feature map less per unit application.
+        tb = ops.PrepTable()
+        for i in range(self.M):
+            for j in range(self.R):
+                seq = self.net.dense_memory_blocks[i].recursive_unit[j].residual_block
+                m = seq[3]
+                a = (m.weight.data * torch.rsqrt(m.running_var.float() + m.eps)).float()
+                wf = self.derived.get(f"m{i}.u{j}.c0.wfold", CH, CH, 3, 3, device=dev)
+                wf.copy_(seq[2].weight.data * a.view(CH, 1, 1, 1))
+                bf = self.derived.get(f"m{i}.u{j}.c0.bfold", CH, device=dev)
+                bf.copy_(m.bias.data - m.running_mean * a)
+                tb.conv(wf, self.ws.planes(f"m{i}.u{j}.c0.wpf", 9 * CH, CH, dev))
+        self._fold_prep = tb.build(dev)
+        self._fold_prep.run()
         self._eval_coefs = True
 
     def interpolate(self, x):
@@ -152,8 +168,12 @@ class MemNetEngine:
                     a1, c1, a2 = buf(key + ".a1", B, H, W, CH), buf(key + ".c1", B, H, W, CH), buf(key + ".a2", B, H, W, CH)
                     nxt = buf(key + ".out" if save else f"scr.out{n % 2}", B, H, W, CH)
                     k1 = bn(u + ".0", key + ".k1", out, a1)
-                    ops.conv3x3(a1, ws[f"m{i}.u{j}.c0.wp"], None, CH, out=c1)
-                    k2 = bn(u + ".3", key + ".k2", c1, a2)
+                    if training:
+                        ops.conv3x3(a1, ws[f"m{i}.u{j}.c0.wp"], None, CH, out=c1)
+                        k2 = bn(u + ".3", key + ".k2", c1, a2)
+                    else:               # conv 0 with the BatchNorm behind it folded in, ReLU as its epilogue
+                        ops.conv3x3(a1, ws[f"m{i}.u{j}.c0.wpf"], D.d[f"m{i}.u{j}.c0.bfold"], CH, out=a2, epi=1)
+                        k2 = None
                     ops.conv3x3(a2, ws[f"m{i}.u{j}.c1.wp"], None, CH, out=nxt, epi=2, R=out)     # + the unit's input
                     if save:
                         apps.append(dict(x=out, a1=a1, c1=c1, a2=a2, k1=k1, k2=k2, j=j))
