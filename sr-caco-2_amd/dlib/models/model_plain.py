@@ -45,6 +45,7 @@ class ModelPlain:
         self.L = self.E = self.H = self.h_per_pixel_weight = self.L_to_H = None
         self._current = None
         self.step_fn = None
+        self._eval_graphs, self._weights_version = {}, 0
         self.loss_fn = None
 
     # ---------------------------------------------------------------- train setup
@@ -94,6 +95,7 @@ class ModelPlain:
         return self.L
 
     def optimize_parameters(self, epoch: int, current_step: int):
+        self._weights_version += 1
         self.step_fn.step(self._net_input(), self.H, weight=self.h_per_pixel_weight)
         # the engine's output buffer is persistent (overwritten by the next step) and 3-D for the
         # 1-channel conv nets: hand out a [B,1,H,W] copy, as the reference's self.E is a fresh tensor
@@ -132,8 +134,34 @@ class ModelPlain:
             self.step_fn.sync_buffers()
         self.netG.eval()
         with torch.no_grad():
-            self.E = self.netG(self._net_input())
+            x = self._net_input()
+            self.E = self._graph_forward(x) if self._eval_graph_on() else self.netG(x)
         self.netG.train()
+
+    # ---- the evaluation forward replayed from a hipGraph (opt-in: args.eval_graph / SRHIP_EVAL_GRAPH=1).  The small
+    # networks of the evaluation sweep are a few thousand short launches per forward: their rate is set by the host's
+    # launch calls, which a replay does not make.  One graph per (input shape, --amp, weights version): the first forward
+    # of a key runs eagerly (it creates the engine's buffers), the second is captured, later ones replay.  Any change of
+    # the weights (a training step, a checkpoint load) drops the graphs: derived weight copies are made outside them.
+    def _eval_graph_on(self):
+        return bool(getattr(self.args, 'eval_graph', False)) or os.environ.get('SRHIP_EVAL_GRAPH', '0') == '1'
+
+    def _graph_forward(self, x):
+        key = (tuple(x.shape), bool(getattr(self.netG, 'amp', False)), self._weights_version)
+        st = self._eval_graphs.get(key)
+        if st is None:
+            self._eval_graphs = {k: v for k, v in self._eval_graphs.items() if k[2] == self._weights_version}
+            self._eval_graphs[key] = {"g": None, "x": x.clone(), "y": None}
+            return self.netG(x)
+        st["x"].copy_(x)
+        if st["g"] is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["y"] = self.netG(st["x"])
+            st["g"] = g
+        st["g"].replay()
+        return st["y"].clone()
 
     def current_visuals(self, need_H=True):
         out = OrderedDict()
@@ -166,6 +194,7 @@ class ModelPlain:
         return self.save_network_path(self.netG, os.path.join(save_dir, f'G-{p_name_file}'))
 
     def load_network(self, load_path, network, strict=True, param_key='params'):
+        self._weights_version += 1
         sd = torch.load(load_path, map_location='cpu')
         if param_key in sd:
             sd = sd[param_key]

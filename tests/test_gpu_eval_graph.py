@@ -1,0 +1,47 @@
+"""ModelPlain.test() with the evaluation forward replayed from a hipGraph (--eval_graph True / SRHIP_EVAL_GRAPH=1): the same
+bits as the eager forward, for networks of each engine family; a weight change drops the graph."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sr-caco-2_amd"))
+
+CASES = [("swinir", "SWINIR", 4, ["--swinir_depths", "2+2", "--swinir_embed_dim", "60", "--swinir_num_heads", "6+6"]),
+         ("EDSR_LIIF", "EDSR_LIIF", 4, []), ("DBPN", "DBPN", 2, []), ("OmniSR", "OmniSR", 4, ["--OmniSR_res_num", "1"]),
+         ("ACT", "ACT", 2, ["--ACT_n_resblocks", "2"]), ("DFCAN", "DFCAN", 2, []), ("ENLCN", "ENLCN", 2, ["--ENLCN_n_resblock", "8"])]
+
+
+@pytest.mark.parametrize("net_type,method,scale,extra", CASES)
+def test_eval_graph_replays_the_eager_forward(net_type, method, scale, extra):
+    import main as M
+    from dlib.models.select_model import define_model
+    argv = ["--net_type", net_type, "--method", method, "--task", "super-resolution", "--scale", str(scale), "--n_channels", "1",
+            "--h_size", "96", "--batch_size", "2"] + extra
+    torch.manual_seed(0)
+    model = define_model(M.parse_input(argv + ["--eval_graph", "False"]))
+    model.init_train()
+    batch = M.synth_batch(2, scale, 96, model.device, 3)
+    model.feed_data(batch)
+    model.test()
+    ref = model.E.clone()
+    model.args.eval_graph = True
+    outs = []
+    for _ in range(3):                      # eager (creates buffers), capture + replay, replay
+        model.test()
+        outs.append(model.E.clone())
+    key = next(iter(model._eval_graphs))
+    assert model._eval_graphs[key]["g"] is not None
+    for o in outs:
+        assert torch.equal(o, ref)
+    # another input through the same graph
+    batch2 = M.synth_batch(2, scale, 96, model.device, 4)
+    model.feed_data(batch2)
+    model.test()
+    got = model.E.clone()
+    model.args.eval_graph = False
+    model.test()
+    assert torch.equal(got, model.E)

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default=None)
     ap.add_argument("--nets", default=None)
+    ap.add_argument("--graph", action="store_true", help="evaluation forwards replayed from a hipGraph (--eval_graph True)")
     a = ap.parse_args()
     only = set(a.nets.split(",")) if a.nets else None
     import main as M
@@ -41,7 +42,8 @@ def main():
         for scale in (2, 4, 8):
             for amp in (False, True):
                 argv = ["--net_type", net_type, "--method", method, "--task", "super-resolution", "--scale", str(scale),
-                        "--n_channels", "1", "--h_size", "512", "--batch_size", str(a.batch), "--amp", str(amp)]
+                        "--n_channels", "1", "--h_size", "512", "--batch_size", str(a.batch), "--amp", str(amp),
+                        "--eval_graph", str(bool(a.graph))]
                 args = M.parse_input(argv)
                 torch.manual_seed(0)
                 model = define_model(args)
