@@ -74,18 +74,33 @@ __global__ void __launch_bounds__(256) k_group_attention(const float* __restrict
   const long grp = blockIdx.x / heads;
   const int h = blockIdx.x % heads;
   const float* base = qkv + grp * n * 3L * C + h * dh;
-  for (int i = tid; i < n * dh; i += 256) {
+  for (int i = tid; i < WA_N * dh; i += 256) {            // rows n .. 63 are zero (the tiles below walk all 64)
     const int r = i / dh, e = i - r * dh;
-    sq[r][e] = base[r * 3L * C + e] * scale;
-    sk[r][e] = base[r * 3L * C + C + e];
-    sv[r][e] = base[r * 3L * C + 2 * C + e];
+    const bool in = r < n;
+    sq[r][e] = in ? base[r * 3L * C + e] * scale : 0.f;
+    sk[r][e] = in ? base[r * 3L * C + C + e] : 0.f;
+    sv[r][e] = in ? base[r * 3L * C + 2 * C + e] : 0.f;
   }
   __syncthreads();
-  for (int p = tid; p < n * n; p += 256) {
-    const int i = p / n, j = p - i * n;
-    float a = 0.f;
-    for (int e = 0; e < dh; ++e) a += sq[i][e] * sk[j][e];
-    ss[i][j] = a + (bias ? bias[((long)h * n + i) * n + j] : 0.f);
+  {                                                       // S: a 4 x 4 tile of (query, key) pairs per thread
+    const int i0 = (tid >> 4) * 4, j0 = (tid & 15) * 4;
+    float a[4][4] = {};
+    for (int e = 0; e < dh; ++e) {
+      float qv[4], kv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { qv[u] = sq[i0 + u][e]; kv[u] = sk[j0 + u][e]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a[u][v] += qv[u] * kv[v];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int i = i0 + u, j = j0 + v;
+        if (i < n && j < n) ss[i][j] = a[u][v] + (bias ? bias[((long)h * n + i) * n + j] : 0.f);
+      }
   }
   __syncthreads();
   for (int i = tid >> 2; i < n; i += 64) {               // four lanes per row
@@ -100,11 +115,17 @@ __global__ void __launch_bounds__(256) k_group_attention(const float* __restrict
     for (int j = q4; j < n; j += 4) ss[i][j] *= inv;
   }
   __syncthreads();
-  for (int p = tid; p < n * dh; p += 256) {
-    const int i = p / dh, e = p - i * dh;
-    float a = 0.f;
-    for (int j = 0; j < n; ++j) a += ss[i][j] * sv[j][e];
-    out[(grp * n + i) * (long)C + h * dh + e] = a;
+  for (int p = tid; p < (WA_N / 4) * dh; p += 256) {      // O: four rows of one channel per thread
+    const int i0 = (p / dh) * 4, e = p % dh;
+    float a[4] = {};
+    for (int j = 0; j < n; ++j) {
+      const float v = sv[j][e];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] += ss[i0 + u][j] * v;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u < n) out[(grp * n + i0 + u) * (long)C + h * dh + e] = a[u];
   }
 }
 
@@ -118,26 +139,42 @@ __device__ __forceinline__ long ca_pixel(int b, int gi, int l, int H, int W, int
   else { py = gi / ps; px = gi % ps; wy = l / nx; wx = l % nx; }
   return ((long)b * H + wy * ps + py) * W + wx * ps + px;
 }
+constexpr int CA_L = 64;
 __global__ void __launch_bounds__(256) k_channel_attention(const float* __restrict__ qkv, const float* __restrict__ temp,
                                                            float* __restrict__ out, int H, int W, int C, int heads, int ps,
                                                            int grid, int ngroups, int L) {
   __shared__ float gram[CA_D][CA_D + 1], nq[CA_D], nk[CA_D];
+  __shared__ float tq[CA_L][CA_D + 1], tk[CA_L][CA_D + 1], tv[CA_L][CA_D + 1];     // the group's q / k / v of this head
+  __shared__ long pixs[CA_L];
   const int tid = threadIdx.x;
   const int h = blockIdx.x % heads;
   const int gi = (blockIdx.x / heads) % ngroups;
   const int b = blockIdx.x / (heads * ngroups);
   const int d = C / heads;
   const int i = tid & 15, j = (tid >> 4) & 15;           // (i, j) channel pair; 256 threads = 16 x 16
-  // Gram matrix q_i . k_j and the squared norms, streaming over the L elements
   float g = 0.f, qq = 0.f, kk = 0.f;
-  if (i < d && j < d)
-    for (int l = 0; l < L; ++l) {
-      const float* px = qkv + ca_pixel(b, gi, l, H, W, ps, grid) * 3L * C + h * d;
-      const float qv = px[i], kv = px[C + j];
-      g += qv * kv;
-      if (j == 0) qq += qv * qv;
-      if (i == 0) kk += kv * kv;
+  // Gram matrix q_i . k_j and the squared norms over the L elements, CA_L of them staged at a time
+  for (int l0 = 0; l0 < L; l0 += CA_L) {
+    const int nl = min(CA_L, L - l0);
+    __syncthreads();
+    for (int t = tid; t < nl; t += 256) pixs[t] = ca_pixel(b, gi, l0 + t, H, W, ps, grid);
+    __syncthreads();
+    for (int t = tid; t < nl * d; t += 256) {
+      const int l = t / d, c = t - l * d;
+      const float* px = qkv + pixs[l] * 3L * C + h * d + c;
+      tq[l][c] = px[0];
+      tk[l][c] = px[C];
+      tv[l][c] = px[2 * C];
     }
+    __syncthreads();
+    if (i < d && j < d)
+      for (int l = 0; l < nl; ++l) {
+        const float qv = tq[l][i], kv = tk[l][j];
+        g += qv * kv;
+        qq += qv * qv;
+        kk += kv * kv;
+      }
+  }
   if (j == 0) nq[i] = qq;
   if (i == 0) nk[j] = kk;
   __syncthreads();
@@ -152,13 +189,22 @@ __global__ void __launch_bounds__(256) k_channel_attention(const float* __restri
     for (int jj = 0; jj < d; ++jj) gram[tid][jj] /= sum;
   }
   __syncthreads();
-  for (int p = tid; p < L * d; p += 256) {                 // out_i[l] = sum_j attn[i][j] v_j[l]
-    const int l = p / d, ii = p - l * d;
-    const long pix = ca_pixel(b, gi, l, H, W, ps, grid);
-    const float* v = qkv + pix * 3L * C + 2 * C + h * d;
-    float a = 0.f;
-    for (int jj = 0; jj < d; ++jj) a += gram[ii][jj] * v[jj];
-    out[pix * C + h * d + ii] = a;
+  if (L <= CA_L) {                                         // the values are still staged
+    for (int p = tid; p < L * d; p += 256) {               // out_i[l] = sum_j attn[i][j] v_j[l]
+      const int l = p / d, ii = p - l * d;
+      float a = 0.f;
+      for (int jj = 0; jj < d; ++jj) a += gram[ii][jj] * tv[l][jj];
+      out[pixs[l] * C + h * d + ii] = a;
+    }
+  } else {
+    for (int p = tid; p < L * d; p += 256) {
+      const int l = p / d, ii = p - l * d;
+      const long pix = ca_pixel(b, gi, l, H, W, ps, grid);
+      const float* v = qkv + pix * 3L * C + 2 * C + h * d;
+      float a = 0.f;
+      for (int jj = 0; jj < d; ++jj) a += gram[ii][jj] * v[jj];
+      out[pix * C + h * d + ii] = a;
+    }
   }
 }
 
