@@ -70,13 +70,15 @@ def main():
                 amp_used = bool(amp and getattr(model.netG, "amp", False) and getattr(model.netG, "amp_takes_effect", True))
                 rows.append({"net_type": net_type, "scale": scale, "amp_flag": amp, "reduced_precision_kernels": amp_used,
                              "batch": a.batch, "ms_per_batch": ms, "patches_per_s": a.batch / ms * 1e3})
+                if a.graph:
+                    rows[-1]["eval_graph"] = True
                 print(json.dumps(rows[-1]), flush=True)
                 del model
                 torch.cuda.empty_cache()
     if a.out:
         if only is not None and os.path.isfile(a.out):
             old = json.load(open(a.out))["rows"]
-            rows = [r for r in old if r["net_type"] not in only] + rows
+            rows = [r for r in old if r["net_type"] not in only or bool(r.get("eval_graph")) != bool(a.graph)] + rows
         with open(a.out, "w") as f:
             json.dump({"what": "model.test() on synthetic 512x512 HR patches, one MI355X; registry default options per network "
                                "(SwinIR: 6 x 6 blocks, embed 180); amp_flag = --amp True, reduced_precision_kernels = whether the "

@@ -17,10 +17,11 @@ def main():
     net_type, method, scale = sys.argv[1], sys.argv[2], int(sys.argv[3])
     iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
     amp = len(sys.argv) > 5 and sys.argv[5] in ("1", "amp", "True")
+    graph = len(sys.argv) > 6 and sys.argv[6] in ("1", "graph", "True")
     import main as M
     from dlib.models.select_model import define_model
     args = M.parse_input(["--net_type", net_type, "--method", method, "--task", "super-resolution", "--scale", str(scale),
-                          "--n_channels", "1", "--h_size", "512", "--batch_size", "8", "--amp", str(amp)])
+                          "--n_channels", "1", "--h_size", "512", "--batch_size", "8", "--amp", str(amp), "--eval_graph", str(graph)])
     torch.manual_seed(0)
     model = define_model(args)
     model.init_train()
