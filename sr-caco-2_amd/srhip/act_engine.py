@@ -1,7 +1,7 @@
 """ACT on libsrhip, evaluation forward (reference dlib/models/network_act.py:321-541): a CNN branch (RCAN residual groups)
 and a transformer branch (3 x 3 tokens, self-attention + cross-scale attention against overlapping 6 x 6 tokens) that
 exchange features in four fusion blocks.  Written directly over the libsrhip ops: 3 x 3 convs on the split-MFMA conv
-kernels, the 5 x 5 head convs as im2col (srhip_unfold) + GEMM, Linears / 1 x 1 convs on the exact-f32 GEMM, the attention's
+kernels, the 5 x 5 head convs as im2col (srhip_unfold) + GEMM, Linears on the split-MFMA GEMMs (weight planes: srhip/planes.py), 1 x 1 convs on the exact-f32 GEMM, the attention's
 (sample, head) products as two batched launches (srhip_gemm_nt_batched) around srhip_softmax_rows, F.unfold / F.fold as srhip_unfold / srhip_fold, RCAN's channel
 attention as srhip_channel_gate.  Inference only."""
 import math
@@ -9,6 +9,7 @@ import math
 import torch
 
 from . import ops
+from .planes import PlaneCache
 from .tape import WeightBank
 
 
@@ -16,12 +17,14 @@ class ACTEngine:
     def __init__(self, net):
         self.net = net
         self.bank = WeightBank()
+        self.planes = PlaneCache()
         self.prepared = False
         self.saved = None
         self.taps = None          # tests: dict that receives intermediate tensors (names as oracle.act_forward's taps)
 
     def invalidate(self):
         self.prepared = False
+        self.planes.clear()
 
     def bucket_prefixes(self):
         return [[""]]
@@ -63,9 +66,10 @@ class ACTEngine:
             ops.leaky_relu_(y, 0.0)
         return y
 
-    @staticmethod
-    def _linear(x2, lin, out=None):
-        return ops.gemm_nt(x2, lin.weight.data, None if lin.bias is None else lin.bias.data, out=out)
+    def _linear(self, x2, lin, out=None):
+        """nn.Linear on the GEMM kernels, the weight as planes (srhip/planes.py: f32-grade; one product under --amp)"""
+        w, b = self.planes.linear(id(lin), lin.weight.data, None if lin.bias is None else lin.bias.data)
+        return ops.gemm_nt(x2, w, b, out=out)
 
     @staticmethod
     def _ln(x2, ln):
@@ -99,7 +103,7 @@ class ACTEngine:
 
     def _self_attention(self, blk, x2, B, T):
         net = self.net
-        qkv = ops.gemm_nt(self._ln(x2, blk.norm), blk.fn.to_qkv.weight.data)
+        qkv = self._linear(self._ln(x2, blk.norm), blk.fn.to_qkv)
         inner = net.n_heads * net.dim_head
         o = self._attend(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], B, T, T, net.n_heads, net.dim_head,
                          net.dim_head ** -0.5)
@@ -109,8 +113,8 @@ class ACTEngine:
         net = self.net
         heads = net.n_heads // 2
         inner = heads * net.dim_head
-        q = ops.gemm_nt(self._ln(xq, blk.norm), blk.fn.to_q.weight.data)
-        kv = ops.gemm_nt(self._ln(xkv, blk.norm2), blk.fn.to_kv.weight.data)
+        q = self._linear(self._ln(xq, blk.norm), blk.fn.to_q)
+        kv = self._linear(self._ln(xkv, blk.norm2), blk.fn.to_kv)
         o = self._attend(q, kv[:, :inner], kv[:, inner:], B, Tq, Tk, heads, net.dim_head, net.dim_head ** -0.5)
         return self._linear(o, blk.fn.to_out[0])
 

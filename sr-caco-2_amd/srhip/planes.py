@@ -1,4 +1,4 @@
-"""Derived matmul operands of the evaluation-only engines written directly over the ops (GRL): a Linear / 1x1-conv
+"""Derived matmul operands of the evaluation-only engines written directly over the ops (GRL, ACT's Linears): a Linear / 1x1-conv
 weight or the tap-major pack of a 3x3 conv, prepared once per weight version.  From 64 channels on the operand is split into
 planes by the weight-preparation kernel (ops.PrepTable: two fp16 planes where the GEMM / conv kernels take them, three
 bf16 planes otherwise) -- f32-grade with three / six products, ONE product under --amp (ops.amp_inference); narrower

@@ -384,7 +384,12 @@ def test_act_registry_default_width_vs_oracle():
     with torch.no_grad():
         yo = O.act_forward(sd, x, 2)
         y = net(x.cuda()).cpu()
+        net.amp = True                            # --amp: one product in the 3 x 3 convs and the Linears
+        ya = net(x.cuda()).cpu()
     assert (y - yo).abs().mean().item() <= 1e-5 * yo.abs().max().item() and rel(y, yo) < 3e-5, rel(y, yo)
+    assert not torch.equal(ya, y)
+    mse = ((ya - yo) ** 2).mean().item() / max(1.0, yo.abs().max().item()) ** 2
+    assert mse < 1e-5, mse
 
 
 def test_unfold_fold_vs_torch():
