@@ -339,6 +339,7 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
   const int nch = ((m_end - m_begin + 2 * TKB - 1) / (2 * TKB)) * 2;
   // both roles execute exactly nch + 1 barriers
   if (producer) {
+    __builtin_amdgcn_s_setprio(2);                    // staging waves first: they are the critical path of a chunk
     // two chunks in flight: chunk c+1 is split and stored from one register stage
     // while the loads of chunk c+3 fill it again (c+2 sits in the other stage), so a
     // load has two chunk periods to land
@@ -448,8 +449,12 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
 // read with two v_readlane + a select.  Control block in the place of the third plane: factors [2][BC], four flag
 // words (one per producer wave); final 2^-s [2][BC] in buffer 0.
 // ---------------------------------------------------------------------------
-template <int W>
+// BM >= 0: the operand prologues fixed at compile time (b_mode = BM, the A row scale present iff AR) -- the grouped launch
+// picks the instantiation per problem (block-uniform), so the staging loop carries no mode branches; BM < 0: read from p.
+template <int W, int BM = -1, bool AR = false, bool NR = false>
 __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const int tile, unsigned char* smem) {
+  const int bmode = BM >= 0 ? BM : p.b_mode;
+  const bool arow = BM >= 0 ? AR : (p.a_rowscale != nullptr);
   constexpr int BC = 64 * W, HC = 32 * W;
   constexpr int PLANE = 2 * BC * 64;
   constexpr int BUF = 3 * PLANE;
@@ -482,7 +487,7 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
   const int gcol = HC * ch + W * lt;           // this lane's first column in the operand tile
   const int colq = max(min(gcol, opvalid - W), 0);
   const int dsh = gcol - colq;
-  const bool ragged = opvalid % W != 0;
+  const bool ragged = NR ? false : opvalid % W != 0;     // NR: every tile width of the problem is a multiple of W
   const float* const opP = isB ? p.B + j0 : p.A + i0;
   const long opLd = isB ? p.ldb : p.lda;
   const unsigned colb = (unsigned)((16L * th * opLd + colq) * 4);
@@ -494,8 +499,8 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
     const int tokl = mc + (lane & 31);          // the token whose scalars this lane carries
     const bool interior = mc + TKB <= m_end;    // uniform
     const bool tin = interior || tokl < m_end;
-    if (!isB) sg.scale = ldg_f((p.a_rowscale && tin) ? p.a_rowscale + tokl / p.a_rowscale_rows : k_sr_neutral + 1);
-    else sg.stats = ldg_f2((p.b_mode == 1 && tin) ? p.ln_stats + 2 * (long)tokl : k_sr_neutral);
+    if (!isB) sg.scale = ldg_f((arow && tin) ? p.a_rowscale + tokl / p.a_rowscale_rows : k_sr_neutral + 1);
+    else sg.stats = ldg_f2((bmode == 1 && tin) ? p.ln_stats + 2 * (long)tokl : k_sr_neutral);
     const float* q = opP + (long)mc * opLd;     // uniform, advanced per token
     if (interior) {
 #pragma unroll
@@ -543,7 +548,7 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
           }
       }
       if (!isB) {
-        if (p.a_rowscale) {
+        if (arow) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const float k0 = bcast(sg.scale, 8 * o + 2 * t), k1 = bcast(sg.scale, 8 * o + 2 * t + 1);
@@ -557,7 +562,7 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
 #pragma unroll
             for (int j = 0; j < W; ++j) cs[j] += x[o][t][j].x + x[o][t][j].y;
         }
-      } else if (p.b_mode == 1) {
+      } else if (bmode == 1) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const float mu0 = bcast(sg.stats.x, 8 * o + 2 * t), mu1 = bcast(sg.stats.x, 8 * o + 2 * t + 1);
@@ -568,7 +573,7 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
             x[o][t][j].y = (x[o][t][j].y - mu1) * rs1;
           }
         }
-      } else if (p.b_mode == 2) {
+      } else if (bmode == 2) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -633,6 +638,7 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
 
   const int nch = ((m_end - m_begin + 2 * TKB - 1) / (2 * TKB)) * 2;
   if (producer) {
+    __builtin_amdgcn_s_setprio(2);                    // the staging waves are the critical path of a chunk: issue before the MFMA waves
     load(m_begin, sg0);
     load(m_begin + TKB, sg1);
     store(smem, sg0);
@@ -875,6 +881,7 @@ __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const in
 
   const int nch = ((m_end - m_begin + 2 * TK3 - 1) / (2 * TK3)) * 2;     // even
   if (producer) {
+    __builtin_amdgcn_s_setprio(2);                    // staging waves first: they are the critical path of a chunk
     Stage sg0, sg1;                              // chunk parity
     load(m_begin, sg0);
     load(m_begin + TK3, sg1);
@@ -1054,7 +1061,10 @@ __global__ void __launch_bounds__(512, 1) k_tnb_grouped_h(TnbGroup g) {
 #pragma unroll
   for (int i = 1; i < TNB_GROUP_MAX; ++i)
     if (i < g.n && t >= g.tile_start[i]) { p = g.p[i]; t0 = g.tile_start[i]; }
-  tnb_body_h<W>(p, slice, t - t0, smem);
+  const bool even = p.NI % W == 0 && p.NJ % W == 0 && p.i_tile % W == 0 && p.j_tile % W == 0;   // no ragged W-tuples
+  if (even && p.b_mode == 1 && !p.a_rowscale) tnb_body_h<W, 1, false, true>(p, slice, t - t0, smem);     // LayerNorm-folded Linears
+  else if (even && p.b_mode == 0 && p.a_rowscale) tnb_body_h<W, 0, true, true>(p, slice, t - t0, smem); // DropPath-scaled gradients
+  else tnb_body_h<W>(p, slice, t - t0, smem);
 }
 
 // Up to TNB_BATCH_MAX conv weight-gradient problems of ONE shape (same image geometry and channel
