@@ -6,8 +6,10 @@ Kept: init_train, feed_data(dict, need_H), optimize_parameters(epoch, step),
 update_learning_rate, test, set_eval_mode / set_train_mode, current_visuals,
 current_log, save / save_best / load_network (raw ``netG.state_dict()`` with
 ``torch.save`` -- file-compatible with the reference's ``<iter>_G.pth`` /
-``G-model.pth``), save_current / load_current, loss_fn.{l_holder,n_holder,
-update_t}, attributes L, E, H, netG, save_dir.
+``G-model.pth``), save_optimizer / load_optimizer / load_optimizers
+(``<iter>_optimizerG.pth`` in torch.optim's state_dict layout), save_current /
+load_current, loss_fn.{l_holder,n_holder,update_t}, attributes L, E, H, netG,
+save_dir.
 
 Changed on purpose (same observable behaviour): one device flag replaces the
 per-step ``isfinite(...).item()`` + ~660 ``check_corruption`` host syncs
@@ -31,7 +33,10 @@ class ModelPlain:
         self.args = args
         self.opt_train = args.train if getattr(args, 'train', None) is not None else {}
         self.is_train = getattr(args, 'is_train', True)
-        self.save_dir = getattr(args, 'outd', '.')
+        # model_base.py:30: <outd_backup>/<save_dir_models>; runs without those options keep everything in outd
+        base = getattr(args, 'outd_backup', None) or getattr(args, 'outd', None) or '.'
+        sub = getattr(args, 'save_dir_models', None)
+        self.save_dir = os.path.join(base, sub) if sub else base
         dev_id = torch.cuda.current_device() if torch.cuda.is_available() else None
         if dev_id is None:
             raise RuntimeError("ModelPlain (libsrhip) needs a GPU; there is no CPU fallback")
@@ -61,6 +66,7 @@ class ModelPlain:
         self.step_fn = TrainStep(self.netG, self.loss_fn.terms(), process_group=pg, world_size=world)
         self.step_fn.opt = Optimizer(self.step_fn.fp, **optimizer_config(self.args))
         self.G_optimizer = self.step_fn.opt
+        self.load_optimizers()
         self.log_dict = OrderedDict()
 
     def load(self):
@@ -74,6 +80,32 @@ class ModelPlain:
         if path and os.path.isfile(path):
             strict = self.opt_train.get('G_param_strict', True) if hasattr(self.opt_train, 'get') else True
             self.load_network(path, self.netG, strict=strict, param_key='params')
+
+    def _reuse_optimizer(self):
+        """'G_optimizer_reuse' (utils_config.py:160, default True): optimizer state is checkpointed and resumed."""
+        return bool(self.opt_train.get('G_optimizer_reuse', True)) if hasattr(self.opt_train, 'get') else True
+
+    def load_optimizers(self):
+        """model_plain.py:88-93: args.netG['checkpoint_path_optimizerG'] (main.py points it at the newest
+        ``<iter>_optimizerG.pth``) is loaded when it exists and G_optimizer_reuse is on."""
+        netg = self.args.netG if hasattr(self.args, 'netG') else {}
+        path = netg.get('checkpoint_path_optimizerG', None) if hasattr(netg, 'get') else None
+        if path and os.path.isfile(path) and self._reuse_optimizer():
+            self.load_optimizer(path, self.G_optimizer)
+
+    @staticmethod
+    def save_optimizer(save_dir, optimizer, optimizer_label, iter_label):
+        """model_base.py:203-206: torch.save(optimizer.state_dict()) -> <iter>_<label>.pth; the dict has
+        torch.optim's layout (srhip.train.Optimizer.state_dict), so either side reads the other's file."""
+        os.makedirs(save_dir, exist_ok=True)
+        path = os.path.join(save_dir, f'{iter_label}_{optimizer_label}.pth')
+        torch.save(optimizer.state_dict(), path)
+        return path
+
+    @staticmethod
+    def load_optimizer(load_path, optimizer):
+        """model_base.py:208-211."""
+        optimizer.load_state_dict(torch.load(load_path, map_location='cpu', weights_only=False))
 
     # ---------------------------------------------------------------- data
     def feed_data(self, data, need_H=True):
@@ -121,17 +153,21 @@ class ModelPlain:
         return self.log_dict
 
     # ---------------------------------------------------------------- eval
-    def set_eval_mode(self):
+    def sync_replica_buffers(self):
+        """Distributed runs: rank 0's BatchNorm running statistics to every rank, so that each rank scores its shard
+        with the same ones.  A COLLECTIVE: the trainer calls it where every rank arrives (utils_trainer.train_valid /
+        evaluate) -- never from test() / set_eval_mode(), which the master may run alone (eval_bsize == 1,
+        utils_trainer.py:382-386)."""
         if self.step_fn is not None:
-            self.step_fn.sync_buffers()     # distributed: every rank scores its shard with rank 0's BatchNorm statistics
+            self.step_fn.sync_buffers()
+
+    def set_eval_mode(self):
         self.netG.eval()
 
     def set_train_mode(self):
         self.netG.train()
 
     def test(self):
-        if self.step_fn is not None:
-            self.step_fn.sync_buffers()
         self.netG.eval()
         with torch.no_grad():
             x = self._net_input()
@@ -180,7 +216,11 @@ class ModelPlain:
         return path
 
     def save(self, iter_label):
-        return self.save_network(self.save_dir, self.netG, 'G', iter_label)
+        """model_plain.py:95-101: <iter>_G.pth and, with G_optimizer_reuse, <iter>_optimizerG.pth."""
+        path = self.save_network(self.save_dir, self.netG, 'G', iter_label)
+        if self.step_fn is not None and self._reuse_optimizer():
+            self.save_optimizer(self.save_dir, self.G_optimizer, 'optimizerG', iter_label)
+        return path
 
     def save_network_path(self, network, path: str):
         """raw state_dict on the CPU, as model_base.py:173-181."""

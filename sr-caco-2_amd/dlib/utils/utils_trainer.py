@@ -2,8 +2,8 @@
 ``Interpolate`` -- the Bicubic baseline row of the results tables (dlib/utils/utils_trainer.py:89-167,
 used at :293,1265).  SURVEY section 8 row a18 keeps it on stock PyTorch-ROCm (``F.interpolate`` with
 ``antialias=True`` is not a kernel target); the class follows the ModelPlain-style protocol the
-evaluation loop consumes (feed_data / test / current_visuals).  The trainer loop itself is a caller of
-the hot path and out of scope."""
+evaluation loop consumes (feed_data / test / current_visuals).  Below it: the evaluation over folds
+(fast_eval / evaluate) and the training loop around the step (train_valid)."""
 import torch
 import torch.nn.functional as F
 
@@ -267,6 +267,7 @@ def evaluate(args, model, loaders: dict, tracker: dict, roi_tracker: dict, curre
         os.makedirs(d, exist_ok=True)
         model.save_current(save_dir=d)
     ddp_barrier(distributed)
+    _sync_replica_buffers(model)        # a collective: here every rank arrives; below the master may evaluate alone
     for ds_name in loaders:
         if use_best_models:
             fname = f'G-{ds_name}.pth'.replace(split, constants.VALIDSET) if args.multi_valid else 'G-model.pth'
@@ -289,3 +290,196 @@ def evaluate(args, model, loaders: dict, tracker: dict, roi_tracker: dict, curre
     model.load_current(save_dir=d)
     ddp_barrier(distributed)
     return tracker, roi_tracker
+
+
+# ==============================================================================================
+# The training loop around the step (reference dlib/utils/utils_trainer.py:170-530): epochs over the
+# rank's minibatches, validation every `checkpoint_eval` iterations with best-model selection,
+# `<iter>_G.pth` + `<iter>_optimizerG.pth` every `checkpoint_save` iterations (older ones deleted),
+# trackers pickled beside them, the test split scored with the best model at the end.  It leaves the
+# experiment folder eval.py reads.  Not reproduced: the matplotlib tracker plots and the
+# compute-cluster scratch copies (callers' tooling).
+#
+# Differences on purpose: per-iteration loss values stay on the device (one small copy per step) and
+# reach the tracker in one transfer at every validation / checkpoint / epoch end -- the reference's
+# `.item()` per term per step is a host sync per step; the three barriers per iteration
+# (:366,388,401) are dropped: the gradient all-reduce is the synchronisation point.
+# ==============================================================================================
+import math
+
+from dlib.utils.utils_tracker import update_tracker_train, is_last_perf_best_perf, save_tracker
+from dlib.utils.utils_config import clean_previous_checkpoints_except_last
+
+__all__ += ['train_valid']
+
+
+def _period(v, n_mbatchs: int, name: str) -> int:
+    """`checkpoint_eval` / `checkpoint_save`: iterations (int) or a fraction of an epoch (float < 1)
+    (utils_trainer.py:331-351)."""
+    assert v > 0, (name, v)
+    if v < 1:
+        assert isinstance(v, float), (name, type(v))
+        return max(int(v * n_mbatchs), 1)
+    assert isinstance(v, int), (name, type(v))
+    return v
+
+
+def _sync_replica_buffers(model):
+    """Rank 0's BatchNorm running statistics to every rank (what DDP's broadcast_buffers does at each forward,
+    model_base.py:139) -- a collective, so it is issued here, at points EVERY rank reaches, and never from
+    model.test() (evaluation may be master-only: utils_trainer.py:382-386)."""
+    fn = getattr(model, 'sync_replica_buffers', None)
+    if fn is not None:
+        fn()
+
+
+def _validate(args, model, valid_loaders: dict, split: str, tracker: dict, roi_tracker: dict, current_step: int,
+              current_epoch: int):
+    """utils_trainer.py:170-273: every validation set through fast_eval; when the last evaluation is the best one
+    (args.model_select_mtr, ROI-based if eval_over_roi_also_model_select) the weights go to
+    best-models/G-model.pth (multi_valid: G-<ds>.pth) with the per-image details beside them."""
+    model_is_interp = isinstance(model, Interpolate)
+    master = getattr(args, 'is_master', True)
+    for ds_name, loader in valid_loaders.items():
+        if model_is_interp:
+            ds_name = f'{ds_name}_{args.basic_interpolation}'
+        save_img_dir = join(args.outd, args.save_dir_imgs, split, ds_name)
+        os.makedirs(save_img_dir, exist_ok=True)
+        tracker, details, roi_tracker, roi_details = fast_eval(
+            model, loader, ds_name, split, tracker, roi_tracker, args, current_step, current_epoch,
+            nbr_to_plot=4, save_img_dir=save_img_dir)
+        is_last_best = is_last_perf_best_perf(tracker, roi_tracker, args.eval_over_roi_also,
+                                              args.eval_over_roi_also_model_select, split=split, ds_name=ds_name,
+                                              metric=args.model_select_mtr)
+        if not master:
+            continue
+        d = join(args.outd_backup, 'best-models')
+        os.makedirs(d, exist_ok=True)
+        if is_last_best:
+            if not model_is_interp:
+                model.save_best(d, p_name_file=f'{ds_name}.pth' if args.multi_valid else 'model.pth')
+            with open(join(d, f'details_{ds_name}.yml'), 'w') as f:
+                yaml.dump(details, f)
+            if args.eval_over_roi_also:
+                with open(join(d, f'roi_details_{ds_name}.yml'), 'w') as f:
+                    yaml.dump(roi_details, f)
+        status = write_current_perf_eval(tracker, split, ds_name, d if is_last_best else None,
+                                         f'{ds_name}.yaml' if is_last_best else None, current_step, current_epoch)
+        roi_status = None
+        if args.eval_over_roi_also:
+            roi_status = write_current_perf_eval(roi_tracker, split, ds_name, d if is_last_best else None,
+                                                 f'roi-{ds_name}.yaml' if is_last_best else None, current_step,
+                                                 current_epoch)
+        DLLogger.log(current_perf_to_str(status, roi_status, args.model_select_mtr,
+                                         bool(args.eval_over_roi_also_model_select)))
+    return tracker, roi_tracker
+
+
+class _LossLog:
+    """[total, term1, ...] of every iteration, kept on the device until someone needs numbers."""
+
+    def __init__(self):
+        self.pending, self.epoch_sum, self.n_epoch = [], None, 0
+
+    def push(self, loss_buf: torch.Tensor):
+        self.pending.append(loss_buf.detach().clone())
+
+    def drain(self, tracker: dict, names: list) -> dict:
+        if not self.pending:
+            return tracker
+        vals = torch.stack(self.pending).double().cpu()            # the one transfer
+        self.pending = []
+        vals[:, 0] = vals[:, 1:].sum(1)                            # slot 0 = MasterLoss total (master.py:46-56)
+        for row in vals.tolist():
+            tracker = update_tracker_train(tracker, n_losses=names, v_losses=row, period=constants.PR_ITER)
+        s = vals.sum(0)
+        self.epoch_sum = s if self.epoch_sum is None else self.epoch_sum + s
+        self.n_epoch += vals.shape[0]
+        return tracker
+
+    def close_epoch(self):
+        out = (self.epoch_sum / max(self.n_epoch, 1)).tolist() if self.epoch_sum is not None else None
+        self.epoch_sum, self.n_epoch = None, 0
+        return out
+
+
+def train_valid(args, model, train_loader, train_sampler, valid_loaders: dict, test_loaders: dict, tracker: dict,
+                roi_tracker: dict, current_step: int):
+    """utils_trainer.py:276-530.  ``train_loader``: a dlib.datasets.dataset_dpsr.ResidentTrainSet (``len()`` =
+    this rank's minibatches per epoch, ``.epoch(e)`` = their batch dicts under set_epoch(e) semantics; it carries its
+    own sampler, so ``train_sampler`` may be None).  ``current_step``: iterations already done (main.py: the newest
+    checkpoint's label); the loop resumes at epoch floor(current_step / len) like the reference (:287-290)."""
+    distributed = bool(getattr(args, 'distributed', False))
+    master = getattr(args, 'is_master', True)
+    n_mbatchs = len(train_loader)
+    assert n_mbatchs > 0, "the training split is smaller than one batch per rank"
+    current_epoch = math.floor(current_step / float(n_mbatchs))
+    if current_step == 0 and valid_loaders:        # the Bicubic row of the validation tracker (:292-310)
+        tracker, roi_tracker = _validate(args, Interpolate(task=args.task, scale=args.scale,
+                                                           scale_mode=args.basic_interpolation),
+                                         valid_loaders, constants.VALIDSET, tracker, roi_tracker, 0, 0)
+    max_seed = (2 ** 32) - 1
+    tr = args.train
+    n_check_eval = _period(tr['checkpoint_eval'], n_mbatchs, 'checkpoint_eval')
+    n_checkpoint_save = _period(tr['checkpoint_save'], n_mbatchs, 'checkpoint_save')
+    max_iters = getattr(args, 'max_iters', None)           # (not a reference option) stop after this many iterations
+    losses = _LossLog()
+    names = list(model.loss_fn.n_holder)
+    stop = False
+    for epoch in range(current_epoch, args.max_epochs):
+        if stop:
+            break
+        t0 = _dt.datetime.now()
+        if train_sampler is not None and distributed:
+            train_sampler.set_epoch(epoch)
+        for train_data in train_loader.epoch(epoch):
+            current_step += 1
+            # every rank re-seeds with myseed + current_step (:359-361): DropPath masks are a function of (seed, step)
+            torch.manual_seed(int((args.myseed + current_step) % max_seed))
+            model.set_train_mode()
+            model.feed_data(train_data)
+            model.optimize_parameters(epoch, current_step)
+            model.update_learning_rate()
+            losses.push(model.step_fn.loss_buf)
+            do_eval = bool(valid_loaders) and current_step % n_check_eval == 0
+            do_save = current_step % n_checkpoint_save == 0
+            if do_eval or do_save:
+                if not model.check_finite():
+                    DLLogger.log('Terminated due to error: non-finite loss')        # tools.py:55-63
+                    raise SystemExit(1)
+                tracker = losses.drain(tracker, names)
+            if do_eval:
+                _sync_replica_buffers(model)          # every rank is here; the evaluation below may be master-only
+                if (distributed and args.eval_bsize > 1) or master:
+                    tracker, roi_tracker = _validate(args, model, valid_loaders, constants.VALIDSET, tracker,
+                                                     roi_tracker, current_step, epoch)
+                ddp_barrier(distributed)
+            if do_save and master:
+                model.save(current_step)
+                clean_previous_checkpoints_except_last(model.save_dir, ['G', 'optimizerG'])
+                save_tracker(args.outd_backup, tracker=tracker, roi_tracker=roi_tracker)
+            if max_iters and current_step >= max_iters:
+                stop = True
+                break
+        tracker = losses.drain(tracker, names)
+        epoch_loss = losses.close_epoch()
+        if epoch_loss is not None:
+            tracker = update_tracker_train(tracker, n_losses=names, v_losses=epoch_loss, period=constants.PR_EPOCH)
+            DLLogger.log(f'Epoch {epoch}. Total TR loss: {epoch_loss[0]:.5f}')
+        freq = tr.get('test_epoch_freq', 50)
+        if epoch > 0 and epoch % freq == 0 and test_loaders and not stop:
+            model.flush()
+            _sync_replica_buffers(model)
+            tracker, roi_tracker = evaluate(args, model, test_loaders, tracker, roi_tracker, -1, -1,
+                                            constants.TESTSET, use_best_models=True, nbr_to_plot=30)
+        model.loss_fn.update_t()
+        DLLogger.log(f'Train epoch runtime: {_dt.datetime.now() - t0}')
+    # end of training: the test split with the best model(s) (:470-483), trackers beside the run
+    model.flush()
+    if test_loaders:
+        _sync_replica_buffers(model)
+        tracker, roi_tracker = evaluate(args, model, test_loaders, tracker, roi_tracker, -1, -1, constants.TESTSET,
+                                        use_best_models=True, nbr_to_plot=30)
+    if master:
+        save_tracker(args.outd, tracker=tracker, roi_tracker=roi_tracker)
+    return tracker, roi_tracker, current_step

@@ -12,12 +12,14 @@ Flag names, the ``--net_type`` / ``--method`` pairing check, '+'-separated lists
 and the three-stage config (defaults -> per-net defaults -> CLI overrides of
 non-None values) follow dlib/utils/utils_parser.py:291-339,900-967,1142-1143 and
 dlib/utils/utils_config.py:64-404 for the options this path uses.  The
-reference's datasets (TIFF folds, ROI patch sampling) are callers of the path and
-not reproduced: this entry trains / evaluates on
-synthetic patches of the configured shape -- ``--synthetic True`` is implied --
-through the same ModelPlain protocol the reference trainer drives
-(utils_trainer.py:353-415) and reports patches/sec plus the metric sweep of
-utils_trainer.py:961-1032.
+As the reference's main.py (:27-35) it first looks for the newest ``<iter>_G.pth`` /
+``<iter>_optimizerG.pth`` under ``<outd>/<save_dir_models>`` and resumes there (weights, optimizer state,
+iteration count).  With ``--train_dsets`` (+ ``--valid_dsets`` / ``--test_dsets``, ``--data_root``,
+``--splits_root``) it runs the reference's epoch loop (dlib/utils/utils_trainer.py:276-530: validation
+every ``--checkpoint_eval``, best-model selection, checkpoints every ``--checkpoint_save``, test split with
+the best model at the end) and leaves an experiment folder eval.py accepts.  Without folds it trains on one
+synthetic batch of the configured shape through the same ModelPlain protocol and reports patches/sec plus
+the metric sweep of utils_trainer.py:961-1032.
 """
 import argparse
 import os
@@ -50,6 +52,14 @@ def plus_list(v):
     return [int(z) for z in v.split('+')]
 
 
+def int_or_float(v):
+    """--checkpoint_eval / --checkpoint_save (utils_parser.py:205-208): iterations, or a fraction of an epoch."""
+    try:
+        return int(v)
+    except ValueError:
+        return float(v)
+
+
 class Dict2Obj(dict):
     __getattr__ = dict.get
 
@@ -68,6 +78,10 @@ def get_config(net_type):
         'train_dsets': '', 'valid_dsets': '', 'test_dsets': '', 'data_root': '', 'splits_root': 'folds',
         'sample_tr_patch': 'uniform', 'sample_tr_patch_th_style': 'fix_threshold', 'sample_tr_patch_th': 7,
         'eval_over_roi_also_ths': [4, 5, 6, 7, 8, 9, 10], 'outd': './out',
+        # experiment-folder options (utils_config.py:98-126): where checkpoints / best models / images go and how
+        # the best model is chosen
+        'save_dir_models': 'models', 'save_dir_imgs': 'imgs', 'basic_interpolation': 'bicubic',
+        'model_select_mtr': constants.PSNR_MTR, 'eval_over_roi_also_model_select': False, 'valid_n_samples': -1,
         'train': {'l1': True, 'l1_lambda': 1., 'l2': False, 'l2_lambda': 1., 'ssim': False,
                   'ssim_lambda': 1., 'ssim_window_s': 11,
                   # optional terms (utils_config.py:296-357)
@@ -92,7 +106,11 @@ def get_config(net_type):
                   'G_optimizer_momentum': 0.9, 'G_optimizer_nesterov': True, 'G_optimizer_amsgrad': False,
                   'G_scheduler_type': constants.MYSTEPLR, 'G_scheduler_step_size': 30,
                   'G_scheduler_gamma': 0.5, 'G_scheduler_min_lr': 1e-4,
-                  'G_scheduler_milestones': [250000, 400000]},
+                  'G_scheduler_milestones': [250000, 400000],
+                  # checkpoints (utils_config.py:160,185-193): optimizer state saved / resumed with the weights;
+                  # validation and checkpoint periods in iterations (int) or as a fraction of an epoch (float < 1)
+                  'G_optimizer_reuse': True, 'G_param_strict': True, 'checkpoint_eval': 5000, 'checkpoint_save': 5000,
+                  'test_epoch_freq': 50},
     }
 
 
@@ -105,15 +123,18 @@ def parse_input(argv=None):
     cfg = get_config(net_type)
     ap = argparse.ArgumentParser(description='SR-CACO-2 hot path on MI355X (libsrhip)')
     for k in ('task', 'net_type', 'method', 'dist_backend', 'cudaid', 'outd', 'train_dsets', 'valid_dsets',
-              'test_dsets', 'data_root', 'splits_root', 'sample_tr_patch', 'sample_tr_patch_th_style'):
+              'test_dsets', 'data_root', 'splits_root', 'sample_tr_patch', 'sample_tr_patch_th_style',
+              'save_dir_models', 'save_dir_imgs', 'basic_interpolation', 'model_select_mtr'):
         ap.add_argument(f'--{k}', type=str, default=None)
     for k in ('scale', 'n_channels', 'h_size', 'batch_size', 'eval_bsize', 'myseed', 'max_epochs', 'max_iters',
-              'sample_tr_patch_th'):
+              'sample_tr_patch_th', 'valid_n_samples'):
         ap.add_argument(f'--{k}', type=int, default=None)
-    for k in ('distributed', 'amp', 'eval_over_roi_also', 'eval_graph'):
+    for k in ('distributed', 'amp', 'eval_over_roi_also', 'eval_graph', 'eval_over_roi_also_model_select'):
         ap.add_argument(f'--{k}', type=str2bool, default=None)
     for k, v in cfg['train'].items():
         t = str2bool if isinstance(v, bool) else (type(v) if not isinstance(v, list) else plus_list)
+        if k in ('checkpoint_eval', 'checkpoint_save'):
+            t = int_or_float
         ap.add_argument(f'--{k}', type=t, default=None)
     nt = safe_str_var(net_type)
     net_opts = {constants.SWINIR: {'window_size': int, 'depths': plus_list, 'embed_dim': int,
@@ -179,6 +200,47 @@ def synth_batch(batch, scale, h_size, device, seed):
     return out
 
 
+def _resume_point(args):
+    """main.py:27-35 of the reference: the newest <iter>_G.pth / <iter>_optimizerG.pth under
+    <outd_backup>/<save_dir_models> become the run's starting weights / optimizer state, and the larger label its
+    iteration count.  Nothing there: iteration 0, weights from netG['init_pretrained_path'] if given."""
+    from dlib.utils.utils_config import find_last_checkpoint
+    models = os.path.join(args.outd_backup, args.save_dir_models)
+    it_g, path_g = find_last_checkpoint(models, net_type='G',
+                                        pretrained_path=args.netG.get('init_pretrained_path', '') or '')
+    args.netG['checkpoint_path_netG'] = path_g
+    it_o, path_o = find_last_checkpoint(models, net_type='optimizerG')
+    args.netG['checkpoint_path_optimizerG'] = path_o
+    return max(it_g, it_o)
+
+
+def _train_on_folds(args, model, rank, world, current_step):
+    """Real folds: the reference's epoch loop (utils_trainer.train_valid) over tiles resident in HBM."""
+    import dlib.dllogger as DLLogger
+    from dlib.utils.utils_dataloaders import get_train_set, get_all_eval_loaders
+    from dlib.utils.utils_tracker import find_last_tracker
+    from dlib.utils.utils_trainer import train_valid
+    from dlib.utils.utils_config import save_config
+    args.multi_valid = len([x for x in (args.valid_dsets or '').split(constants.SEP) if x]) > 1      # utils_parser.py:950
+    DLLogger.init_arb(log_dir=args.outd_backup, is_master=args.is_master, reset=current_step == 0)
+    if args.is_master:
+        save_config(args, args.outd_backup, 'config_model.yml')                 # what eval.py reads (utils_parser.py:1397-1401)
+    train_set = get_train_set(args, model.device, rank, world)
+    n_valid = args.valid_n_samples if args.valid_n_samples else -1
+    valid_loaders = get_all_eval_loaders(args, args.valid_dsets, n=n_valid) if args.valid_dsets else {}
+    test_loaders = get_all_eval_loaders(args, args.test_dsets, n=-1) if args.test_dsets else {}
+    tracker, roi_tracker = find_last_tracker(args.outd_backup, args)
+    t0 = time.perf_counter()
+    tracker, roi_tracker, last = train_valid(args, model, train_set, None, valid_loaders, test_loaders, tracker,
+                                             roi_tracker, current_step)
+    if args.is_master:
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        print(f'iterations {current_step + 1}..{last}: {(last - current_step) * args.batch_size * world / dt_s:.1f} '
+              f'patches/s (validation and checkpoints included)')
+        save_config(args, args.outd_backup, 'config_final.yml')
+
+
 def main(argv=None):
     args = parse_input(argv)
     rank, world = 0, 1
@@ -190,34 +252,34 @@ def main(argv=None):
         rank, world = dist.get_rank(), dist.get_world_size()
     else:
         torch.cuda.set_device(int(str(args.cudaid).split(',')[0]))
+    args.is_master = rank == 0
+    args.outd_backup = args.outd                                # utils_parser.py:1042 (no compute-cluster scratch here)
+    args.is_train = True
+    os.makedirs(os.path.join(args.outd_backup, args.save_dir_models), exist_ok=True)
+    current_step = _resume_point(args)
     torch.manual_seed(args.myseed)
     from dlib.models.select_model import define_model
     from dlib import metrics
     model = define_model(args)
-    model.init_train()
+    model.init_train()      # loads the checkpoint pair found above (model_plain.py:54-66)
     # weights: one seed, and rank 0's replace the others' anyway (TrainStep, as DDP's constructor)
     if rank == 0:
         print(model.info_network())
+        if current_step:
+            print(f'resuming at iteration {current_step}: {args.netG["checkpoint_path_netG"]}')
+    if args.train_dsets:
+        _train_on_folds(args, model, rank, world, current_step)
+        if args.distributed:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    # no folds given: the same step on one synthetic batch of the configured shape (throughput / plumbing runs)
+    from dlib.utils.utils_config import clean_previous_checkpoints_except_last
     batch = synth_batch(args.batch_size, args.scale, args.h_size, model.device, 1000 + rank)
-    stream = None
-    if args.train_dsets:      # real folds: tiles resident in HBM, crops assembled on the device (dataset_dpsr.ResidentTrainSet)
-        from dlib.utils.utils_dataloaders import get_train_set
-        train_set = get_train_set(args, model.device, rank, world)
-
-        def batches():
-            epoch = 0
-            while True:
-                n = 0
-                for b in train_set.epoch(epoch):
-                    n += 1
-                    yield b
-                assert n > 0, "the training split is smaller than one batch per rank"
-                epoch += 1
-        stream = batches()
+    n_save = args.train['checkpoint_save']
     t0, seen = time.perf_counter(), 0
-    for step in range(1, args.max_iters + 1):
-        if stream is not None:
-            batch = next(stream)
+    for step in range(current_step + 1, args.max_iters + 1):
         # the reference re-seeds EVERY rank with myseed + current_step at each iteration (utils_trainer.py:359-361):
         # DropPath masks are a function of (seed, step), identical across ranks, and a resumed run repeats them
         torch.manual_seed((args.myseed + step) % (2 ** 32 - 1))
@@ -234,6 +296,9 @@ def main(argv=None):
                 log = model.current_log()
                 print(f"iter {step:6d}  G_loss {log['G_loss']:.6f}  lr {model.current_learning_rate():.2e}  "
                       f"{seen / (time.perf_counter() - t0):8.1f} patches/s")
+        if isinstance(n_save, int) and step % n_save == 0 and rank == 0 and step != args.max_iters:
+            model.save(step)                                            # utils_trainer.py:403-411
+            clean_previous_checkpoints_except_last(model.save_dir, ['G', 'optimizerG'])
     # evaluation sweep (utils_trainer.py:961-1032): PSNR / PSNR_Y / MSE / NRMSE / SSIM, optional ROI thresholds
     from dlib.utils.utils_trainer import _forward_with_padding
     model = _forward_with_padding(batch, model, args)          # SwinIR: flipped-strip padding to the next window multiple
@@ -248,8 +313,9 @@ def main(argv=None):
             if ths:
                 msg += f'   ROI(avg over th {list(ths)}) {sw[k][:, 1:].double().mean().item():.4f}'
             print(msg)
-        os.makedirs(args.outd, exist_ok=True)
-        print('saved', model.save(args.max_iters))
+        if args.max_iters > current_step:
+            print('saved', model.save(args.max_iters))                  # <iter>_G.pth + <iter>_optimizerG.pth
+            clean_previous_checkpoints_except_last(model.save_dir, ['G', 'optimizerG'])
     if args.distributed:
         import torch.distributed as dist
         dist.barrier()

@@ -116,6 +116,89 @@ class Optimizer:
     def scheduler_step(self):
         self.sched_count += 1
 
+    # ---- checkpoints: the layout of torch.optim.{Adam,SGD}.state_dict() (what the reference's save_optimizer /
+    # load_optimizer write and read, dlib/models/model_base.py:203-211), so ``<iter>_optimizerG.pth`` files travel in
+    # both directions.  Parameter i of the one group = the i-th trainable entry of named_parameters()
+    # (utils_instance.py:216-223).  torch ignores top-level keys it does not know: 'srhip' carries what torch keeps
+    # elsewhere or not at all -- the LR rule's position (the reference rebuilds its scheduler from scratch on resume,
+    # model_plain.py:60-66, so its schedule restarts; with this key ours continues) and the applied-step count.
+    def _views(self, flat_buf):
+        fp = self.fp
+        return [flat_buf[fp.offsets[k]:fp.offsets[k] + fp.gviews[k].numel()].view_as(fp.gviews[k]) for k in fp.names]
+
+    def state_dict(self):
+        """One host sync (the applied-step counter)."""
+        n = len(self.fp.names)
+        applied = int(self.applied.item())
+        group = {'lr': self.lr, 'weight_decay': self.wd, 'maximize': False, 'foreach': None, 'differentiable': False,
+                 'fused': None, 'initial_lr': self.base_lr, 'params': list(range(n))}
+        state = {}
+        if self.kind == "adam":
+            group.update(betas=tuple(self.betas), eps=self.eps, amsgrad=False, capturable=False,
+                         decoupled_weight_decay=False)
+            if applied > 0:     # torch creates a parameter's state at its first step
+                for i, (m, v) in enumerate(zip(self._views(self.m), self._views(self.v))):
+                    state[i] = {'step': torch.tensor(float(applied)), 'exp_avg': m.detach().cpu().clone(),
+                                'exp_avg_sq': v.detach().cpu().clone()}
+        else:
+            group.update(momentum=self.momentum, dampening=0, nesterov=self.nesterov)
+            if applied > 0:
+                for i, m in enumerate(self._views(self.m)):
+                    state[i] = {'momentum_buffer': m.detach().cpu().clone()}
+        return {'state': state, 'param_groups': [group],
+                'srhip': {'kind': self.kind, 'applied': applied, 'sched_count': self.sched_count,
+                          'step_count': self.step_count, 'base_lr': self.base_lr}}
+
+    def load_state_dict(self, sd):
+        groups = sd['param_groups']
+        if len(groups) != 1:
+            raise ValueError(f"optimizer checkpoint with {len(groups)} parameter groups; this path has one")
+        g, state, n = groups[0], sd['state'], len(self.fp.names)
+        if len(g['params']) != n:
+            raise ValueError(f"optimizer checkpoint covers {len(g['params'])} parameters, the network has {n}")
+        is_adam = 'betas' in g
+        if is_adam != (self.kind == "adam"):
+            raise ValueError(f"optimizer checkpoint is {'Adam' if is_adam else 'SGD'}, the run uses {self.kind}")
+        if is_adam and g.get('amsgrad', False):
+            raise NotImplementedError("amsgrad optimizer state")
+        # hyper-parameters follow the checkpoint, as torch's load_state_dict replaces the param_groups
+        self.wd = g['weight_decay']
+        if is_adam:
+            self.betas, self.eps = tuple(g['betas']), g['eps']
+        else:
+            self.momentum, self.nesterov = g['momentum'], g['nesterov']
+        self.base_lr = g.get('initial_lr', g['lr'])
+        keys = [g['params'][i] for i in range(n)]
+        applied = 0
+        self.m.zero_()
+        if self.v is not None:
+            self.v.zero_()
+        mv, vv = self._views(self.m), (self._views(self.v) if self.v is not None else None)
+        for i, k in enumerate(keys):
+            st = state.get(k)
+            if not st:
+                continue
+            if is_adam:
+                if tuple(st['exp_avg'].shape) != tuple(mv[i].shape):
+                    raise ValueError(f"optimizer state {k}: shape {tuple(st['exp_avg'].shape)} vs parameter "
+                                     f"{self.fp.names[i]} {tuple(mv[i].shape)}")
+                mv[i].copy_(st['exp_avg'])
+                vv[i].copy_(st['exp_avg_sq'])
+                applied = max(applied, int(float(st['step'])))
+            elif st.get('momentum_buffer') is not None:
+                mv[i].copy_(st['momentum_buffer'])
+                applied = max(applied, 1)      # torch's SGD keeps no count: the buffer exists = past the first step
+        extra = sd.get('srhip')
+        if extra is not None:
+            applied = int(extra['applied'])
+            self.sched_count, self.step_count = int(extra['sched_count']), int(extra['step_count'])
+        else:
+            # a file written by torch: the reference builds a NEW scheduler on the loaded optimizer (last_epoch = -1,
+            # base_lrs = the groups' initial_lr): its learning-rate rule starts over
+            self.sched_count, self.step_count = 0, applied
+        self.applied.fill_(applied)
+        self.push_lr()
+
 
 def allreduce_range(flat_grad, lo, hi, group=None, comm_stream=None):
     """Sum-all-reduce flat_grad[lo:hi] over the data-parallel group.  On the GPU

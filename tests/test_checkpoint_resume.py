@@ -1,0 +1,409 @@
+"""optimizer checkpoints, resume, and the trainer loop that leaves an experiment folder.
+
+Reference behaviour restated: model_base.py:203-211 (save_optimizer / load_optimizer =
+torch.save / load of ``optimizer.state_dict()``), model_plain.py:88-101, main.py:27-35
+(find_last_checkpoint for 'G' and 'optimizerG', current_step = the larger label),
+utils_config.py:407-458, utils_trainer.py:276-530.
+
+CPU: the state-dict layout against torch.optim itself (both directions), the checkpoint bookkeeping,
+the master-only evaluation of a distributed run (no collective inside test()).  GPU: main.py run k
+iterations, stopped, started again in a NEW process for k more == one run of 2k iterations, bit for
+bit; a torch.optim.Adam state made by the oracle side continues on the fused optimizer; main.py over
+real folds leaves a folder eval.py evaluates."""
+import os
+import pickle
+import shutil
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "sr-caco-2_amd")
+for p in (PKG, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+FX = os.path.join(ROOT, "tests", "golden", "eval_exp")
+DS = "caco2_test_X_8_in_64_out_512_cell_CELL0"
+
+
+def _small_net():
+    torch.manual_seed(3)
+    return torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 7), torch.nn.Linear(7, 2, bias=False))
+
+
+def _torch_run(kind, steps, state=None):
+    net = _small_net()
+    opt = (torch.optim.Adam(net.parameters(), lr=2e-4, weight_decay=1e-4) if kind == "adam"
+           else torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, nesterov=True, weight_decay=1e-4))
+    if state is not None:
+        net.load_state_dict(state[0])
+        opt.load_state_dict(state[1])
+    g = torch.Generator().manual_seed(7 if state is None else 8)
+    for _ in range(steps):
+        opt.zero_grad()
+        net(torch.randn(4, 5, generator=g)).pow(2).mean().backward()
+        opt.step()
+    return net, opt
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd"])
+def test_optimizer_state_dict_is_torch_optim_layout_both_directions(kind):
+    from srhip.train import FlatParams, Optimizer
+    net, topt = _torch_run(kind, 3)
+    tsd = topt.state_dict()
+    mine_net = _small_net()
+    mine_net.load_state_dict(net.state_dict())
+    fp = FlatParams(mine_net)
+    sched = {"type": "MyStepLR", "step_size": 2, "gamma": 0.5, "min_lr": 1e-5}
+    opt = Optimizer(fp, kind, lr=2e-4 if kind == "adam" else 0.01, wd=1e-4, scheduler=sched)
+    opt.load_state_dict(tsd)                                   # torch's file -> the fused optimizer
+    assert int(opt.applied) == (3 if kind == "adam" else 1)    # torch's SGD keeps no count
+    assert opt.sched_count == 0                                # the reference rebuilds its scheduler: the rule restarts
+    views_m = opt._views(opt.m)
+    for i, p in enumerate(net.parameters()):
+        st = topt.state[p]
+        assert torch.equal(views_m[i], st["exp_avg" if kind == "adam" else "momentum_buffer"])
+        if kind == "adam":
+            assert torch.equal(opt._views(opt.v)[i], st["exp_avg_sq"])
+    sd = opt.state_dict()                                      # ... and back: torch loads ours
+    assert set(sd) == {"state", "param_groups", "srhip"}
+    assert set(sd["param_groups"][0]) >= set(tsd["param_groups"][0]) - {"initial_lr"}
+    assert sd["param_groups"][0]["params"] == tsd["param_groups"][0]["params"]
+    for i in tsd["state"]:
+        assert set(sd["state"][i]) == set(tsd["state"][i])
+        for k, v in tsd["state"][i].items():
+            assert sd["state"][i][k].dtype == v.dtype and sd["state"][i][k].shape == v.shape
+            if k != "step" or kind == "adam":
+                assert torch.equal(sd["state"][i][k], v), (i, k)
+    # a torch optimizer loaded from OUR dict continues exactly like one loaded from torch's own dict
+    a_net, _ = _torch_run(kind, 2, state=(net.state_dict(), {k: v for k, v in sd.items()}))
+    b_net, _ = _torch_run(kind, 2, state=(net.state_dict(), tsd))
+    for pa, pb in zip(a_net.parameters(), b_net.parameters()):
+        assert torch.equal(pa, pb)
+    # our own file resumes the LR rule and the counters
+    opt.sched_count, opt.step_count = 5, 5
+    opt.applied.fill_(4)
+    again = Optimizer(FlatParams(_small_net()), kind, lr=1.0, scheduler=sched)
+    again.load_state_dict(opt.state_dict())
+    assert (again.sched_count, again.step_count, int(again.applied)) == (5, 5, 4)
+    assert again.base_lr == opt.base_lr and again.lr == opt.lr == max(opt.base_lr * 0.5 ** 2, 1e-5)
+    # mismatches fail loudly
+    other = Optimizer(fp, "sgd" if kind == "adam" else "adam")
+    with pytest.raises(ValueError):
+        other.load_state_dict(tsd)
+    bad = {"state": {}, "param_groups": [dict(tsd["param_groups"][0], params=[0, 1])]}
+    with pytest.raises(ValueError):
+        opt.load_state_dict(bad)
+
+
+def test_fresh_optimizer_state_dict_has_empty_state_like_torch():
+    from srhip.train import FlatParams, Optimizer
+    opt = Optimizer(FlatParams(_small_net()), "adam")
+    sd = opt.state_dict()
+    assert sd["state"] == {} and sd["srhip"]["applied"] == 0
+    torch.optim.Adam(_small_net().parameters()).load_state_dict(sd)
+
+
+def test_find_last_checkpoint_and_cleaning(tmp_path):
+    from dlib.utils.utils_config import (find_last_checkpoint, clean_previous_checkpoints_except_last, save_config)
+    d = str(tmp_path)
+    assert find_last_checkpoint(d, "G", pretrained_path="pre.pth") == (0, "pre.pth")
+    assert find_last_checkpoint(d, "optimizerG") == (0, "")
+    for it in (5, 20, 100):
+        for lab in ("G", "optimizerG"):
+            open(os.path.join(d, f"{it}_{lab}.pth"), "w").close()
+    open(os.path.join(d, "G-model.pth"), "w").close()            # best-model naming: not a checkpoint
+    assert find_last_checkpoint(d, "G") == (100, os.path.join(d, "100_G.pth"))
+    assert find_last_checkpoint(d, "optimizerG") == (100, os.path.join(d, "100_optimizerG.pth"))
+    os.remove(os.path.join(d, "100_optimizerG.pth"))             # main.py: current_step = max of the two labels
+    assert max(find_last_checkpoint(d, "G")[0], find_last_checkpoint(d, "optimizerG")[0]) == 100
+    clean_previous_checkpoints_except_last(d, ["G", "optimizerG"])
+    assert sorted(os.listdir(d)) == ["100_G.pth", "20_optimizerG.pth", "G-model.pth"]
+    save_config({"a": (1, 2), "netG": {"x": 1.5}, "dev": torch.device("cpu")}, d, "config_model.yml")
+    with open(os.path.join(d, "config_model.yml")) as f:
+        assert yaml.safe_load(f) == {"a": [1, 2], "netG": {"x": 1.5}, "dev": "cpu"}
+
+
+def test_main_cli_checkpoint_options():
+    import main as M
+    a = M.parse_input("--net_type swinir --checkpoint_eval 0.5 --checkpoint_save 200 --G_optimizer_reuse False "
+                      "--save_dir_models ckpt".split())
+    assert a.train["checkpoint_eval"] == 0.5 and a.train["checkpoint_save"] == 200
+    assert a.train["G_optimizer_reuse"] is False and a.save_dir_models == "ckpt"
+    b = M.parse_input(["--net_type", "swinir"])
+    assert b.train["G_optimizer_reuse"] is True and b.train["checkpoint_save"] == 5000 and b.save_dir_models == "models"
+
+
+WORKER_EVAL = r'''
+import os, sys, types, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(sys.argv[1], "sr-caco-2_amd"))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+from dlib.utils import utils_trainer as UT, constants
+from dlib.utils.tools import Dict2Obj
+from dlib.utils.utils_tracker import init_tracker
+from srhip.train import broadcast_replica_state
+
+DS = "caco2_test_X_8_in_64_out_512_cell_CELL0"
+
+
+class BNModel:
+    """ModelPlain protocol around one BatchNorm buffer that differs per rank (what MemNet's running statistics
+    do after a rank-local step).  test() is NOT allowed a collective: with eval_bsize == 1 only the master runs it."""
+    def __init__(self):
+        self.running = torch.full((4,), float(rank + 1))
+        self.device = torch.device("cpu")
+        self.tested_with = []
+    def sync_replica_buffers(self):
+        broadcast_replica_state(None, [self.running])
+    def set_eval_mode(self): pass
+    def set_train_mode(self): pass
+    def feed_data(self, d, need_H=True): self.H = d["h_im"]
+    def test(self): self.tested_with.append(float(self.running[0]))
+    def current_visuals(self, need_H=True): return {"E": self.H.clone(), "H": self.H, "L": self.H}
+    def save_current(self, save_dir): pass
+    def load_current(self, save_dir): pass
+    def load_network(self, *a, **k): pass
+    netG = None
+
+
+class Loader:
+    def __init__(self): self.dataset = types.SimpleNamespace(im_h_ids_to_float={}, float_to_im_h_ids={})
+    def __iter__(self):
+        yield {"l_im": torch.rand(1, 1, 4, 4), "h_im": torch.rand(1, 1, 32, 32), "h_id": ["a"]}
+
+
+def fake_sweep(E, H, border=0, thresholds=()):
+    return {m: torch.ones(E.shape[0], 1 + len(thresholds)) for m in UT._MTRS}
+
+import dlib.metrics as MT
+MT.sweep = fake_sweep
+MT.tensor2uint82float = lambda x: x
+UT._save_prediction_png = lambda *a, **k: None
+UT._forward_with_padding = lambda data, model, args: (model.feed_data(data), model.test(), model)[2]
+class FakeInterp(BNModel):
+    def __init__(self, **k): super().__init__()
+UT.Interpolate = FakeInterp
+
+out = sys.argv[2]
+args = Dict2Obj(distributed=True, eval_bsize=1, is_master=rank == 0, outd=out, outd_backup=out, save_dir_imgs="imgs",
+                multi_valid=False, valid_dsets=DS, test_dsets=DS, basic_interpolation="bicubic", scale=8, task="super-resolution",
+                eval_over_roi_also=False, eval_over_roi_also_model_select=False, eval_over_roi_also_ths=[],
+                model_select_mtr=constants.PSNR_MTR, netG={"net_type": "memnet"})
+if rank == 0:
+    os.makedirs(os.path.join(out, "best-models"), exist_ok=True)
+    open(os.path.join(out, "best-models", "G-model.pth"), "w").close()
+dist.barrier()
+model = BNModel()
+tr, rtr = init_tracker(args), init_tracker(args)
+UT.evaluate(args, model, {DS: Loader()}, tr, rtr, -1, -1, constants.TESTSET, use_best_models=True)   # must not hang
+assert float(model.running[0]) == 1.0, model.running            # every rank holds rank 0's statistics
+assert model.tested_with == ([1.0] if rank == 0 else []), model.tested_with     # master-only evaluation
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_master_only_evaluation_of_a_batchnorm_net_does_not_hang_gloo_world2(tmp_path):
+    """ModelPlain.test() used to broadcast the BatchNorm buffers -- with eval_bsize == 1 only the master
+    evaluates (utils_trainer.py:382-386) while the others wait in a barrier: a deadlock.  The broadcast now happens
+    in evaluate() / train_valid() where every rank arrives."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker_eval.py"
+    script.write_text(WORKER_EVAL)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path / "exp")], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    try:
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o
+
+
+def test_model_plain_test_and_eval_mode_issue_no_collective():
+    import inspect
+    from dlib.models.model_plain import ModelPlain
+    for fn in (ModelPlain.test, ModelPlain.set_eval_mode):
+        assert "sync_buffers" not in inspect.getsource(fn)
+    assert "sync_buffers" in inspect.getsource(ModelPlain.sync_replica_buffers)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+SWIN_TINY = ("--task super-resolution --scale 8 --method SWINIR --net_type swinir --n_channels 1 --h_size 128 "
+             "--batch_size 2 --swinir_depths 2+2 --swinir_embed_dim 60 --swinir_num_heads 6+6 --swinir_mlp_ratio 2 "
+             "--swinir_upsampler pixelshuffledirect --l1 True --G_scheduler_type MyStepLR --G_scheduler_step_size 3 "
+             "--G_scheduler_gamma 0.5 --G_scheduler_min_lr 1e-6").split()
+
+
+def _run_main(extra, outd):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(PKG, "main.py")] + SWIN_TINY + ["--outd", outd] + extra,
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    return p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("optim", [["--G_optimizer_type", "adam", "--G_optimizer_lr", "2e-4"],
+                                   ["--G_optimizer_type", "sgd", "--G_optimizer_lr", "0.01"]])
+def test_stop_and_resume_in_a_new_process_equals_the_uninterrupted_run(tmp_path, optim):
+    """k iterations, process ends, a new process finds <k>_G.pth + <k>_optimizerG.pth (main.py:27-35) and runs k
+    more: weights AND optimizer state bit-equal to 2k uninterrupted iterations (DropPath on: masks are a function
+    of (seed, step); the LR rule decays inside the window)."""
+    k = 4
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    _run_main(optim + ["--max_iters", str(2 * k)], a)
+    _run_main(optim + ["--max_iters", str(k)], b)
+    assert sorted(os.listdir(os.path.join(b, "models"))) == [f"{k}_G.pth", f"{k}_optimizerG.pth"]
+    out = _run_main(optim + ["--max_iters", str(2 * k)], b)
+    assert f"resuming at iteration {k}" in out
+    assert sorted(os.listdir(os.path.join(b, "models"))) == [f"{2 * k}_G.pth", f"{2 * k}_optimizerG.pth"]   # older ones cleaned
+    ga, gb = (torch.load(os.path.join(d, "models", f"{2 * k}_G.pth")) for d in (a, b))
+    assert list(ga) == list(gb)
+    for key in ga:
+        assert torch.equal(ga[key], gb[key]), key
+    oa, ob = (torch.load(os.path.join(d, "models", f"{2 * k}_optimizerG.pth"), weights_only=False) for d in (a, b))
+    assert oa["srhip"] == ob["srhip"] and oa["srhip"]["applied"] == 2 * k and oa["srhip"]["sched_count"] == 2 * k
+    assert oa["param_groups"] == ob["param_groups"]
+    assert oa["param_groups"][0]["lr"] < oa["param_groups"][0]["initial_lr"]        # the rule did decay
+    for i in oa["state"]:
+        for key in oa["state"][i]:
+            assert torch.equal(oa["state"][i][key], ob["state"][i][key]), (i, key)
+    # without the optimizer file the run still resumes (weights only) but is NOT the same run: the test above is not vacuous
+    if "adam" in optim:
+        c = str(tmp_path / "c")
+        _run_main(optim + ["--max_iters", str(k)], c)
+        os.remove(os.path.join(c, "models", f"{k}_optimizerG.pth"))
+        _run_main(optim + ["--max_iters", str(2 * k)], c)
+        gc = torch.load(os.path.join(c, "models", f"{2 * k}_G.pth"))
+        assert any(not torch.equal(ga[key], gc[key]) for key in ga)
+
+
+@pytest.mark.gpu
+def test_oracle_side_adam_state_continues_on_the_fused_optimizer(tmp_path):
+    """A torch.optim.Adam.state_dict() written by the oracle side after 2 steps (the reference's
+    <iter>_optimizerG.pth) is loaded by ModelPlain.load_optimizers; 2 more fused steps == 2 more oracle steps."""
+    import sr_oracle as O
+    from dlib.utils.tools import Dict2Obj
+    from dlib.models.select_model import define_model
+    import main as M
+    cfg = O.swinir_config(upscale=8, in_chans=1, img_size=16, window_size=8, depths=(2, 2), embed_dim=60,
+                          num_heads=(6, 6), mlp_ratio=2, drop_path_rate=0.0)
+    sd0 = O.swinir_init_state_dict(cfg, seed=5)
+    names = [k for k, v in sd0.items() if v.dtype == torch.float32 and not k.endswith("attn_mask")
+             and "relative_position_index" not in k]
+    params = {k: sd0[k].clone().requires_grad_(True) for k in names}
+    full = lambda: {k: (params[k] if k in params else v) for k, v in sd0.items()}
+    topt = torch.optim.Adam([params[k] for k in names], lr=2e-4, weight_decay=1e-4)
+    gen = torch.Generator().manual_seed(12)
+    batch = {'l_im': torch.rand(2, 1, 16, 16, generator=gen), 'h_im': torch.rand(2, 1, 128, 128, generator=gen)}
+
+    def oracle_steps(n):
+        for _ in range(n):
+            topt.zero_grad()
+            O.loss_l1(O.swinir_forward(full(), batch['l_im'], cfg), batch['h_im']).backward()
+            topt.step()
+    oracle_steps(2)
+    models = tmp_path / "models"
+    models.mkdir()
+    torch.save({k: v.detach().clone() for k, v in full().items()}, str(models / "2_G.pth"))
+    torch.save(topt.state_dict(), str(models / "2_optimizerG.pth"))
+    oracle_steps(2)
+    args = M.parse_input(SWIN_TINY + ["--G_optimizer_type", "adam", "--G_optimizer_lr", "2e-4", "--G_scheduler_min_lr",
+                                      "2e-4", "--outd", str(tmp_path)])
+    args.outd_backup = args.outd
+    assert M._resume_point(args) == 2
+    model = define_model(args)
+    assert [k for k, _ in model.netG.named_parameters()] == names       # parameter i of the torch group = our i
+    model.init_train()
+    for b in model.netG.swin_blocks():
+        b.drop_prob = 0.0
+    assert int(model.G_optimizer.applied) == 2
+    for step in (3, 4):
+        model.feed_data(batch)
+        model.optimize_parameters(0, step)
+    for k, p in model.netG.named_parameters():
+        e = (p.detach().cpu() - params[k].detach()).abs().max().item()
+        assert e <= 2e-6, f"{k}: {e}"
+    # and a fresh fused optimizer (no state loaded) does NOT land there
+    os.remove(str(models / "2_optimizerG.pth"))
+    args2 = M.parse_input(SWIN_TINY + ["--G_optimizer_type", "adam", "--G_optimizer_lr", "2e-4", "--G_scheduler_min_lr",
+                                       "2e-4", "--outd", str(tmp_path)])
+    args2.outd_backup = args2.outd
+    M._resume_point(args2)
+    m2 = define_model(args2)
+    m2.init_train()
+    for b in m2.netG.swin_blocks():
+        b.drop_prob = 0.0
+    for step in (3, 4):
+        m2.feed_data(batch)
+        m2.optimize_parameters(0, step)
+    worst = max((p.detach().cpu() - params[k].detach()).abs().max().item() for k, p in m2.netG.named_parameters())
+    assert worst > 1e-5
+
+
+@pytest.mark.gpu
+def test_main_over_folds_leaves_an_experiment_folder_eval_accepts(tmp_path):
+    """main.py --train_dsets/--valid_dsets/--test_dsets: the epoch loop (utils_trainer.py:276-530) validates every
+    checkpoint_eval iterations, keeps the best model, checkpoints every checkpoint_save iterations (older ones
+    deleted), scores the test split with the best model -- and eval.py reproduces that score from the folder."""
+    outd = str(tmp_path / "exp")
+    folds = ["--train_dsets", DS, "--valid_dsets", DS, "--test_dsets", DS, "--data_root", os.path.join(FX, "data"),
+             "--splits_root", os.path.join(FX, "folds"), "--eval_bsize", "2", "--eval_over_roi_also", "True"]
+    common = [a for a in SWIN_TINY]
+    common[common.index("--h_size") + 1] = "64"
+    common[common.index("--batch_size") + 1] = "1"
+
+    def run(extra):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        p = subprocess.run([sys.executable, os.path.join(PKG, "main.py")] + common + folds + ["--outd", outd] + extra,
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+        return p.stdout
+    # 3 tiles, batch 1 -> 3 iterations per epoch; 2 epochs, validation every 2 iterations, checkpoint every 3
+    run(["--max_epochs", "2", "--checkpoint_eval", "2", "--checkpoint_save", "3", "--G_optimizer_lr", "1e-3"])
+    assert sorted(os.listdir(os.path.join(outd, "models"))) == ["6_G.pth", "6_optimizerG.pth"]
+    best = os.path.join(outd, "best-models")
+    for f in ("G-model.pth", f"details_{DS}.yml", f"{DS}.yaml", f"roi-{DS}.yaml", f"{DS}_bicubic.yaml"):
+        assert os.path.isfile(os.path.join(best, f)), f
+    for f in ("config_model.yml", "config_final.yml", "tracker.pkl", "roi_tracker.pkl", "log.txt"):
+        assert os.path.isfile(os.path.join(outd, f)), f
+    with open(os.path.join(outd, "tracker.pkl"), "rb") as f:
+        tr = pickle.load(f)
+    assert len(tr["val"][DS]["psnr"]["vals"]) == 3                              # iterations 2, 4, 6
+    assert len(tr["val"][f"{DS}_bicubic"]["psnr"]["vals"]) == 1                 # the step-0 Bicubic row
+    assert tr["val"][DS]["psnr"]["best_val"] == max(tr["val"][DS]["psnr"]["vals"])
+    assert len(tr["train"]["period_iter"]["master_loss"]["vals"]) == 6
+    assert len(tr["train"]["period_epoch"]["master_loss"]["vals"]) == 2
+    assert len(tr["test"][DS]["psnr"]["vals"]) == 1
+    test_psnr = tr["test"][DS]["psnr"]["vals"][0]
+    # a third epoch in a new process resumes at iteration 6 (epoch 2) and appends to the trackers
+    out = run(["--max_epochs", "3", "--checkpoint_eval", "2", "--checkpoint_save", "3", "--G_optimizer_lr", "1e-3"])
+    assert "resuming at iteration 6" in out
+    assert sorted(os.listdir(os.path.join(outd, "models"))) == ["9_G.pth", "9_optimizerG.pth"]
+    with open(os.path.join(outd, "tracker.pkl"), "rb") as f:
+        tr2 = pickle.load(f)
+    assert len(tr2["train"]["period_iter"]["master_loss"]["vals"]) == 9
+    assert len(tr2["val"][DS]["psnr"]["vals"]) == 4                             # + iteration 8
+    assert len(tr2["val"][f"{DS}_bicubic"]["psnr"]["vals"]) == 1                # not repeated on resume
+    # eval.py on the folder: the same best model, the same test score
+    import eval as E
+    with open(os.path.join(outd, "tracker.pkl"), "rb") as f:
+        test_psnr = pickle.load(f)["test"][DS]["psnr"]["vals"][0]
+    tr3, _ = E.evaluate_pretrained(["--cudaid", "0", "--exp_path", outd, "--data_root", os.path.join(FX, "data"),
+                                    "--splits_root", os.path.join(FX, "folds")])
+    assert abs(tr3["test"][DS]["psnr"]["vals"][0] - test_psnr) <= 1e-9
