@@ -79,6 +79,14 @@ __device__ __forceinline__ int sr_xcd_block(int B, int n) {
   return xcd * q + min(xcd, rem) + (B >> 3);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global loads and stores
+// (s_waitcnt vmcnt(0)): rows prefetched for the next tile would be waited for at the first barrier after their issue.
+__device__ __forceinline__ void sr_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ---- wave-level reductions (wave = 64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -88,279 +88,388 @@ __device__ __forceinline__ f32x4 mfma3(const u32x4& ah, const u32x4& al, const u
   return mfma16h(ah, bh, acc);
 }
 
-// Backward of the attention core, ONE kernel, one wave per (window, head); a block = four consecutive windows of one head.
-//   query side (per query tile I): S^T and dP^T = V . dO^T against all keys -> softmax row, delta = sum_k P dP,
-//     dS = P (dP - delta); dS is this lane's B operand of dQ^T = K^T . dS^T (K gathered column-form) and goes to the
-//     wave's LDS tile for the bias gradient; the row's log-sum-exp and delta are kept in LDS for the key side;
-//   key side (per key tile J): S and dP in the OTHER orientation (lane = key, registers = queries; P re-made from the
-//     log-sum-exp) are the B operands of dV^T = dO^T . P and dK^T = Q^T . dS (Q, dO gathered column-form).
-// Every operand is read from global memory in the form the matrix core takes it (the re-reads of the key side hit L1 /
-// L2); nothing but the bias-gradient tile and 2 KB of row statistics goes through LDS.  The block's four dS tiles are
-// added in wave order and stored as ONE partial tile (plain stores): k_dbias2_reduce sums the partials in fp64.
+// Backward of the attention core: a block of four waves takes FOUR consecutive windows of one head, one after the other.
+// Per window the block's 256 threads load the 64 q, k, v and dO rows of the head ONCE (8 floats per thread and tensor),
+// split them under their row exponents and leave four LDS images [64 rows][32 entries] x {hi, lo} -- one image serves
+// both operand forms:
+//   row form     (the contraction runs over the head dim)  ds_read_b128 of a row's 16-byte chunk
+//   column form  (the contraction runs over the rows)      ds_read_b64_tr_b16: the hardware's transposed read hands
+//                lane (r, g) entry 16 jd + r of the rows w2_kpos(JJ, g, 0..7); the rows' exponents cannot be factored
+//                out of such a sum, so their 2^-s go into the OTHER operand (P, dS) before that one is split
+// so nothing is gathered from global memory inside the tile loops (the gathers were 2/3 of the one-wave-per-item kernel
+// this replaces: 97 us, 300 MB of traffic for 178 MB of operands).
+//   query side  wave I: S^T and dP^T = V . dO^T of query tile I against all keys -> softmax rows, delta = sum_k P dP,
+//               dS^T: this lane's B operand of dQ^T = K^T . dS^T, and added to the block's bias-gradient tile in LDS;
+//               log-sum-exp and delta of the rows go to LDS
+//   key side    wave J: S and dP with the key on the lane (P re-made from the log-sum-exp) are the B operands of
+//               dV^T = dO^T . P and dK^T = Q^T . dS
+// Registers decide the shape (168 at three blocks per CU; a spilled address is reloaded through the same counter as the
+// row loads and serialises them): the bias comes from the head's 225-entry table in LDS (index = lane constant +
+// 30 (I - J) -+ e) and the bias-gradient sums live in LDS, which leaves room for the next window's rows to travel in
+// registers while this one is computed; the cross-lane reductions are v_permlane16/32_swap (no LDS round trip).
+// The block's dS sums leave as ONE partial tile (plain stores): k_dbias2_reduce sums the partials in fp64.
+constexpr int W2_DS = 4096;                        // floats of a dS tile
+constexpr int W3_PL = 64 * 64;                     // bytes of one plane of an image: 64 rows x 32 fp16
+constexpr int W3_IMG = 2 * W3_PL;
+constexpr int W3_WPB = 4;                          // windows per block (= the partial tiles' granularity)
+constexpr int W3_LDS = 4 * W3_IMG + (W2_DS + 256 + 4 * 64 + 2 * 64) * 4;      // images, dS sums, bias table, row data
+
+typedef short w3_s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+// 16-byte global accesses at 8-byte alignment (a head's slice of a row starts at 4 D bytes x head)
+typedef f32x4 w3_f32x4a8 __attribute__((aligned(8)));
+typedef const __attribute__((address_space(1))) w3_f32x4a8* w3_gp4;
+template <int CTRL>
+__device__ __forceinline__ float w3_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ int w3_slot(int row, int u) { return (row * 4 + (u ^ ((row >> 2) & 3))) * 16; }
+// row-form fragment of tile T of an image: lane (c, g) = row 16 T + c, entries 8 g .. 8 g + 7
+__device__ __forceinline__ void w3_rows(const unsigned char* img, int T, int c, int g, u32x4& hi, u32x4& lo) {
+  const unsigned char* p = img + w3_slot(16 * T + c, g);
+  hi = *(const u32x4*)p;
+  lo = *(const u32x4*)(p + W3_PL);
+}
+// column-form fragment (JJ, jd): lane (r, g) = entry 16 jd + r of the rows w2_kpos(JJ, g, 0..7).  Lane 4 q + p of a
+// 16-lane group supplies the address of row R0 + q, entries 16 jd + 4 p .. + 3 and receives entry 16 jd + (lane & 15)
+// of rows R0 .. R0 + 3
+__device__ __forceinline__ u32x4 w3_cols1(const unsigned char* plane, int JJ, int jd, int c, int g) {
+  const int q = c >> 2, pp = c & 3;
+  unsigned r[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 32 * JJ + 16 * h + 4 * g + q;
+    const unsigned char* a = plane + w3_slot(row, 2 * jd + (pp >> 1)) + 8 * (pp & 1);
+    const w3_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) w3_s16x4*)a);
+    const sr_u32x2 u = __builtin_bit_cast(sr_u32x2, v);
+    r[2 * h] = u.x; r[2 * h + 1] = u.y;
+  }
+  return u32x4{r[0], r[1], r[2], r[3]};
+}
+__device__ __forceinline__ void w3_cols(const unsigned char* img, int JJ, int jd, int c, int g, u32x4& hi, u32x4& lo) {
+  hi = w3_cols1(img, JJ, jd, c, g);
+  lo = w3_cols1(img + W3_PL, JJ, jd, c, g);
+}
+// reductions over the four lanes {c, c + 16, c + 32, c + 48}: v_permlane16_swap leaves rows {0, 0, 2, 2} of the value in
+// one register and rows {1, 1, 3, 3} in the other, v_permlane32_swap the lower half in one and the upper half in the other
+// (inline asm: hipcc folds the two results of __builtin_amdgcn_permlane16_swap(u, u) into one value -- it drops the max
+// and doubles the sum; s_nop 1 = the wait states it puts between a VALU write of the operands and the swap)
+__device__ __forceinline__ void w3_swap16(float v, float& a, float& b) {
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void w3_swap32(float v, float& a, float& b) {
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float w3_max4(float v) {
+  float a, b;
+  w3_swap16(v, a, b); v = fmaxf(a, b);
+  w3_swap32(v, a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ float w3_sum4(float v) {
+  float a, b;
+  w3_swap16(v, a, b); v = a + b;
+  w3_swap32(v, a, b); return a + b;
+}
+
+// four consecutive head-dim entries d0 .. d0 + 3 of one row: 16 bytes where all four exist, 8 where two do
+template <int D>
+__device__ __forceinline__ void w3_store(float* p, int d0, const f32x4& v, float sc) {
+  if (d0 + 4 <= D) *(w3_f32x4a8*)p = f32x4{v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
+  else if (d0 + 2 <= D) *(float2*)p = float2{v[0] * sc, v[1] * sc};
+}
+#ifndef W3_OCC
+#define W3_OCC 3
+#endif
 // phase timestamps of every wave (tools/mb_attn_phases.py): experiment builds only
 #ifdef SRHIP_EXPERIMENTS
-long long* g_w2_dbg = nullptr;
+__device__ long long* g_w3_dbg = nullptr;
+__device__ int g_w3_mode = 0;      // ablations (srhip_wattn2_debug_mode): 1 no arithmetic | 2 no stores | 4 no row loads
+#define W3_MODE(B) (g_w3_mode & (B))
 #define SR_TS(K) \
-  if (dbg && lane == 0) dbg[((long)blockIdx.x * 4 + wv) * 16 + (K)] = (long long)wall_clock64();
+  if (g_w3_dbg && lane == 0) g_w3_dbg[(((long)blockIdx.x * 4 + wv) * W3_WPB + wi) * 8 + (K)] = (long long)wall_clock64();
 #else
 #define SR_TS(K)
+#define W3_MODE(B) 0
 #endif
-
-constexpr int W2_DS = 4096;                        // floats of a dS tile
-constexpr int W2_ST = 6 * 64;                      // per wave: lse, delta, 2^-s of the Q rows (x scale), of the dO, K and V rows
 template <int D>
-__global__ void __launch_bounds__(256, 2) k_wattn2_bwd(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ void __launch_bounds__(256, W3_OCC) k_wattn3_bwd(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                       float* __restrict__ dqkv, const float* __restrict__ biasF,
-                                                      const float* __restrict__ biasG, float* __restrict__ part,
-                                                      int nwin, int H, int W, int C, int heads, int shift, float scale,
-                                                      long long* dbg) {
-  extern __shared__ __attribute__((aligned(16))) float w2s[];
-  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-  SR_TS(0)
-  float* const dsl = w2s + wv * W2_DS;
-  float* const stl = w2s + 4 * W2_DS + wv * W2_ST;
+                                                      float* __restrict__ part,
+                                                      int nwin, int H, int W, int C, int heads, int shift, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char w3s[];
+  unsigned char* const imQ = w3s;
+  unsigned char* const imK = w3s + W3_IMG;
+  unsigned char* const imV = w3s + 2 * W3_IMG;
+  unsigned char* const imG = w3s + 3 * W3_IMG;
+  float* const dsl = (float*)(w3s + 4 * W3_IMG);   // sum over the block's windows of the dS^T tiles (S^T accumulator order)
+  float* const tab = dsl + W2_DS;                  // the head's relative-position bias table [15][15]
+  float* const rs = tab + 256;                     // 2^-s of the rows: [0] Q (x scale), [64] K, [128] V, [192] dO
+  float* const lse = rs + 256;
+  float* const dlt = lse + 64;
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lb = sr_xcd_block(blockIdx.x, gridDim.x);
   const int head = lb % heads, wg = lb / heads;
-  const int widx = wg * 4 + wv;
-  if (widx < nwin) {
+  const int nWx = W / 8, nWy = H / 8;
+  const long C3 = 3L * C;
+  const float* const qb = qkv + head * D;
+  const float* const gb = dout + head * D;
+  float* const dqb = dqkv + head * D;
+  auto geom = [&](int widx) {
     W2Geom geo;
-    const int nWx = W / 8, nWy = H / 8;
     geo.head = head;
     geo.wx = widx % nWx;
     geo.wy = (widx / nWx) % nWy;
     geo.b = widx / (nWx * nWy);
     geo.last_row = shift > 0 && geo.wy == nWy - 1;
     geo.last_col = shift > 0 && geo.wx == nWx - 1;
-    const long C3 = 3L * C;
-    const float* qb = qkv + head * D;
-    const float* gb = dout + head * D;
-    float* dqb = dqkv + head * D;
-    int tok[4];
+    return geo;
+  };
+  // the table entry (dy + 7) * 15 + dx + 7 read back from the S^T image of the head: any (query, key) pair at that offset
+  if (tid < 225) {
+    const int dy = tid / 15 - 7, dx = tid % 15 - 7;
+    const int qy = max(dy, 0), ky = qy - dy, qx = max(dx, 0), kx = qx - dx;
+    const int query = 8 * qy + qx, key = 8 * ky + kx;
+    tab[tid] = ldg_f(biasF + (long)head * W2_DS + w2_img_index(query >> 4, key >> 4, 16 * ((key & 15) >> 2) + (query & 15)) + (key & 3));
+  }
+  // index of the bias of (query 16 I + c, key 16 J + 4 g + e) = bq + 30 (I - J) - e; of (query 16 I + 4 g + e, key 16 J + c)
+  // = bk + 30 (I - J) + e
+  const int bq = ((c >> 3) - (g >> 1) + 7) * 15 + (c & 7) - 4 * (g & 1) + 7;
+  const int bk = ((g >> 1) - (c >> 3) + 7) * 15 + 4 * (g & 1) - (c & 7) + 7;
+  // Loading role: wave wv takes rows 16 wv .. + 15 of every tensor, eight lanes per row, 16 bytes per lane (piece p =
+  // floats 4 p .. 4 p + 3 of the head's D), two instructions per tensor -- an instruction covers eight whole 4 D-byte row
+  // segments (8-16 cache lines; as 8-byte pieces, four lanes per row, it was 32 lines per instruction and four
+  // instructions per tensor: the address pipe of the CU, not HBM, set the kernel's time).  A piece with two valid floats
+  // (D = 30: p = 7) reads floats 4 p - 2 .. 4 p + 1 and keeps the upper half; an empty one reads piece 0: every load is
+  // unconditional and inside the row.
+  const int lp = lane & 7, lrow = 16 * wv + (lane >> 3);
+  constexpr int kFull = D / 4;                     // pieces with four valid floats
+  const int poff = lp < kFull ? 4 * lp : (4 * lp + 2 <= D ? 4 * lp - 2 : 0);
+  f32x4 raw[4][2];
+  auto fetch = [&](int widx) {
+    const W2Geom geo = geom(widx);
 #pragma unroll
-    for (int T = 0; T < 4; ++T) tok[T] = w2_token(geo, 16 * T + c, H, W, shift);
+    for (int i = 0; i < 2; ++i) {
+      const int tk = w2_token(geo, lrow + 8 * i, H, W, shift);
+      if (W3_MODE(4)) {
+#pragma unroll
+        for (int X = 0; X < 4; ++X)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) raw[X][i][t] = 0.01f * (float)((tk + 7 * t + 13 * X) & 63) - 0.3f;
+        continue;
+      }
+      const float* q = qb + (long)tk * C3 + poff;
+      raw[0][i] = *(w3_gp4)q;
+      raw[1][i] = *(w3_gp4)(q + C);
+      raw[2][i] = *(w3_gp4)(q + 2 * C);
+      raw[3][i] = *(w3_gp4)(gb + (long)tk * C + poff);
+    }
+  };
+  const int w0 = wg * W3_WPB;
+  fetch(w0);
+
+  for (int wi = 0; wi < W3_WPB; ++wi) {
+    const int widx = w0 + wi;
+    if (widx >= nwin) break;                       // block-uniform
+    const W2Geom geo = geom(widx);
+    SR_TS(0)
+    // ---- the window's rows -> images (row maximum over the row's eight lanes: three DPP steps)
+#pragma unroll
+    for (int X = 0; X < 4; ++X)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x4 v = raw[X][i];
+        if (lp >= kFull) v = (4 * lp + 2 <= D) ? f32x4{v[2], v[3], 0.f, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+        float mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        mx = fmaxf(mx, w3_dpp<0xB1>(mx));          // quad_perm [1, 0, 3, 2]
+        mx = fmaxf(mx, w3_dpp<0x4E>(mx));          // quad_perm [2, 3, 0, 1]
+        mx = fmaxf(mx, w3_dpp<0x141>(mx));         // row_half_mirror: lane i <-> 7 - i of its eight
+        const float sc = pow2_scale(mx);
+        unsigned h[2], l[2];
+        split2_pair(v[0] * sc, v[1] * sc, h[0], l[0]);
+        split2_pair(v[2] * sc, v[3] * sc, h[1], l[1]);
+        const int row = lrow + 8 * i;
+        unsigned char* dst = w3s + X * W3_IMG + w3_slot(row, lp >> 1) + 8 * (lp & 1);
+        *(sr_u32x2*)dst = sr_u32x2{h[0], h[1]};
+        *(sr_u32x2*)(dst + W3_PL) = sr_u32x2{l[0], l[1]};
+        if (lp == 0) rs[64 * X + row] = pow2_inv(sc) * (X == 0 ? scale : 1.f);
+      }
+    // the next window's rows travel while this one is computed (32 registers: the kernel stays under the 168 of three
+    // blocks per CU without a spill -- a spilled address is reloaded through the same counter as these loads)
+    if (widx + 1 < nwin && wi + 1 < W3_WPB) fetch(widx + 1);
+    SR_TS(1)
+    sr_lds_barrier();
+    SR_TS(2)
     const bool lane_masked = geo.last_col && (((c >> 2) & 1) != (g & 1));
 
-    // ================= query side
-    {
-      u32x4 kh[4], kl[4], vh[4], vl[4];
-      {
-        float raw[4][8], rk[4], rv[4];
-#pragma unroll
-        for (int T = 0; T < 4; ++T) w2_load_row<D>(raw[T], qb + C, C3, tok[T], g);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) rk[T] = w2_split_row(raw[T], kh[T], kl[T]);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) w2_load_row<D>(raw[T], qb + 2 * C, C3, tok[T], g);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) rv[T] = w2_split_row(raw[T], vh[T], vl[T]);
-        if (g == 0) {
-#pragma unroll
-          for (int T = 0; T < 4; ++T) { stl[256 + 16 * T + c] = rk[T]; stl[320 + 16 * T + c] = rv[T]; }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      SR_TS(1)
-      u32x4 kth[2][2], ktl[2][2];
-      float rkt[2];
-      w2_gather_cols<D>(qb + C, C3, geo, H, W, shift, c, g, kth, ktl, rkt);
-      SR_TS(2)
-      const float* bimg = biasF + (long)head * 4096;
-#pragma unroll
-      for (int I = 0; I < 4; ++I) {
-        float raw[8];
-        u32x4 qh, ql, gh, gl;
-        w2_load_row<D>(raw, qb, C3, tok[I], g);
-        const float rq = w2_split_row(raw, qh, ql);
-        w2_load_row<D>(raw, gb, C, tok[I], g);
-        const float rg = w2_split_row(raw, gh, gl);
-        if (g == 0) { stl[128 + 16 * I + c] = rq * scale; stl[192 + 16 * I + c] = rg; }
-        f32x4 S[4], P[4];
-#pragma unroll
-        for (int J = 0; J < 4; ++J) {
-          S[J] = mfma3(kh[J], kl[J], qh, ql, f32x4{0.f, 0.f, 0.f, 0.f});
-          P[J] = mfma3(vh[J], vl[J], gh, gl, f32x4{0.f, 0.f, 0.f, 0.f});      // dP^T
-        }
-        float mx = -3.0e38f;
-#pragma unroll
-        for (int J = 0; J < 4; ++J) {
-          const f32x4 bv = *(const f32x4*)(bimg + w2_img_index(I, J, lane));
-          const bool masked = lane_masked || (geo.last_row && ((I >> 1) != (J >> 1)));
-          const f32x4 rkk = *(const f32x4*)(stl + 256 + 16 * J + 4 * g), rvv = *(const f32x4*)(stl + 320 + 16 * J + 4 * g);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float sv = S[J][e] * (rq * scale * rkk[e]) + bv[e];
-            sv += masked ? -100.f : 0.f;
-            S[J][e] = sv;
-            mx = fmaxf(mx, sv);
-            P[J][e] *= rg * rvv[e];
-          }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int J = 0; J < 4; ++J)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float pe = __expf(S[J][e] - mx);
-            S[J][e] = pe;
-            sum += pe;
-          }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = __builtin_amdgcn_rcpf(sum);
-        float dl = 0.f;
-#pragma unroll
-        for (int J = 0; J < 4; ++J)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            S[J][e] *= inv;
-            dl += S[J][e] * P[J][e];
-          }
-        dl += __shfl_xor(dl, 16, 64);
-        dl += __shfl_xor(dl, 32, 64);
-        if (g == 0) { stl[16 * I + c] = mx + __logf(sum); stl[64 + 16 * I + c] = dl; }
-        float dmx = 0.f;
-#pragma unroll
-        for (int J = 0; J < 4; ++J) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float dsv = S[J][e] * (P[J][e] - dl);
-            S[J][e] = dsv;
-            dmx = fmaxf(dmx, fabsf(dsv));
-          }
-          *(f32x4*)(dsl + w2_img_index(I, J, lane)) = S[J];
-        }
-        dmx = fmaxf(dmx, __shfl_xor(dmx, 16, 64));
-        dmx = fmaxf(dmx, __shfl_xor(dmx, 32, 64));
-        const float dsc = pow2_scale(dmx), dri = pow2_inv(dsc);
-        f32x4 O[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int JJ = 0; JJ < 2; ++JJ) {
-          u32x4 dh, dlo;
-          w2_pack_pair(S[2 * JJ], S[2 * JJ + 1], dsc, dh, dlo);
-#pragma unroll
-          for (int jd = 0; jd < 2; ++jd) O[jd] = mfma3(kth[JJ][jd], ktl[JJ][jd], dh, dlo, O[jd]);
-        }
-        float* op = dqb + (long)tok[I] * C3 + 4 * g;
-#pragma unroll
-        for (int jd = 0; jd < 2; ++jd) {
-          const int d0 = 16 * jd + 4 * g;
-          float sc4[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sc4[e] = __shfl(rkt[jd], 4 * g + e, 64) * (scale * dri);     // 2^-s of column 16 jd + 4 g + e
-          if (d0 < D) *(float2*)(op + 16 * jd) = float2{O[jd][0] * sc4[0], O[jd][1] * sc4[1]};
-          if (d0 + 2 < D) *(float2*)(op + 16 * jd + 2) = float2{O[jd][2] * sc4[2], O[jd][3] * sc4[3]};
-        }
-        SR_TS(3 + I)
-      }
-    }
-    __builtin_amdgcn_wave_barrier();      // the row statistics written by lanes g = 0 are read by every lane below
-
-    // ================= key side
-    {
-      u32x4 qh[4], ql[4], gh[4], gl[4];
-      {
-        float raw[4][8];
-#pragma unroll
-        for (int T = 0; T < 4; ++T) w2_load_row<D>(raw[T], qb, C3, tok[T], g);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) (void)w2_split_row(raw[T], qh[T], ql[T]);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) w2_load_row<D>(raw[T], gb, C, tok[T], g);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) (void)w2_split_row(raw[T], gh[T], gl[T]);
-      }
-      SR_TS(7)
-      u32x4 qth[2][2], qtl[2][2], gth[2][2], gtl[2][2];
-      float rqt[2], rgt[2];
-      w2_gather_cols<D>(qb, C3, geo, H, W, shift, c, g, qth, qtl, rqt);
-      w2_gather_cols<D>(gb, C, geo, H, W, shift, c, g, gth, gtl, rgt);
-      SR_TS(8)
-      const float* bimg = biasG + (long)head * 4096;
+    // ================= query side: query tile I = wv
+    if (!W3_MODE(1)) {
+      const int I = wv;
+      u32x4 qh, ql, gh, gl;
+      w3_rows(imQ, I, c, g, qh, ql);
+      w3_rows(imG, I, c, g, gh, gl);
+      const float rq = rs[16 * I + c], rg = rs[192 + 16 * I + c];
+      f32x4 S[4], P[4];
 #pragma unroll
       for (int J = 0; J < 4; ++J) {
-        float raw[8];
         u32x4 kh, kl, vh, vl;
-        w2_load_row<D>(raw, qb + C, C3, tok[J], g);
-        const float rk = w2_split_row(raw, kh, kl);
-        w2_load_row<D>(raw, qb + 2 * C, C3, tok[J], g);
-        const float rv = w2_split_row(raw, vh, vl);
-        f32x4 S[4], P[4];      // lane (c, g): key 16 J + c against queries 16 I + 4 g + e
-        float dmx = 0.f;
+        w3_rows(imK, J, c, g, kh, kl);
+        w3_rows(imV, J, c, g, vh, vl);
+        S[J] = mfma3(kh, kl, qh, ql, f32x4{0.f, 0.f, 0.f, 0.f});
+        P[J] = mfma3(vh, vl, gh, gl, f32x4{0.f, 0.f, 0.f, 0.f});      // dP^T
+      }
+      float mx = -3.0e38f;
 #pragma unroll
-        for (int I = 0; I < 4; ++I) {
-          S[I] = mfma3(qh[I], ql[I], kh, kl, f32x4{0.f, 0.f, 0.f, 0.f});
-          P[I] = mfma3(gh[I], gl[I], vh, vl, f32x4{0.f, 0.f, 0.f, 0.f});
-          const f32x4 bv = *(const f32x4*)(bimg + w2_img_index(J, I, lane));
-          const f32x4 lse = *(const f32x4*)(stl + 16 * I + 4 * g), dl = *(const f32x4*)(stl + 64 + 16 * I + 4 * g);
-          const f32x4 rq = *(const f32x4*)(stl + 128 + 16 * I + 4 * g), rg = *(const f32x4*)(stl + 192 + 16 * I + 4 * g);
-          const bool masked = lane_masked || (geo.last_row && ((I >> 1) != (J >> 1)));
+      for (int J = 0; J < 4; ++J) {
+        const float* tb = tab + bq + 30 * (I - J);
+        const bool masked = lane_masked || (geo.last_row && ((I >> 1) != (J >> 1)));
+        const f32x4 rkk = *(const f32x4*)(rs + 64 + 16 * J + 4 * g);
+        const f32x4 rvv = *(const f32x4*)(rs + 128 + 16 * J + 4 * g);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float sv = S[I][e] * (rq[e] * rk) + bv[e];
-            sv += masked ? -100.f : 0.f;
-            const float pe = __expf(sv - lse[e]);
-            const float dsv = pe * (P[I][e] * (rg[e] * rv) - dl[e]);
-            P[I][e] = pe;
-            S[I][e] = dsv;
-            dmx = fmaxf(dmx, fabsf(dsv));
-          }
+        for (int e = 0; e < 4; ++e) {
+          float sv = S[J][e] * (rq * rkk[e]) + tb[-e];
+          sv += masked ? -100.f : 0.f;
+          S[J][e] = sv;
+          mx = fmaxf(mx, sv);
+          P[J][e] *= rg * rvv[e];
         }
-        dmx = fmaxf(dmx, __shfl_xor(dmx, 16, 64));
-        dmx = fmaxf(dmx, __shfl_xor(dmx, 32, 64));
-        const float dsc = pow2_scale(dmx), dri = pow2_inv(dsc);
-        f32x4 OV[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        f32x4 OK[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      }
+      mx = w3_max4(mx);
+      float sum = 0.f;
 #pragma unroll
-        for (int II = 0; II < 2; ++II) {
-          u32x4 ph, pl, dh, dlo;
-          w2_pack_pair(P[2 * II], P[2 * II + 1], 16384.f, ph, pl);
-          w2_pack_pair(S[2 * II], S[2 * II + 1], dsc, dh, dlo);
+      for (int J = 0; J < 4; ++J)
 #pragma unroll
-          for (int jd = 0; jd < 2; ++jd) {
-            OV[jd] = mfma3(gth[II][jd], gtl[II][jd], ph, pl, OV[jd]);
-            OK[jd] = mfma3(qth[II][jd], qtl[II][jd], dh, dlo, OK[jd]);
-          }
+        for (int e = 0; e < 4; ++e) {
+          const float pe = __expf(S[J][e] - mx);
+          S[J][e] = pe;
+          sum += pe;
         }
-        float* op = dqb + (long)tok[J] * C3 + 4 * g;
+      sum = w3_sum4(sum);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+      float dl = 0.f;
+#pragma unroll
+      for (int J = 0; J < 4; ++J)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          S[J][e] *= inv;
+          dl += S[J][e] * P[J][e];
+        }
+      dl = w3_sum4(dl);
+      if (g == 0) { lse[16 * I + c] = mx + __logf(sum); dlt[16 * I + c] = dl; }
+      float dmx = 0.f;
+#pragma unroll
+      for (int J = 0; J < 4; ++J) {
+        const f32x4 rkk = *(const f32x4*)(rs + 64 + 16 * J + 4 * g);
+        f32x4* const acc = (f32x4*)(dsl + w2_img_index(I, J, lane));
+        f32x4 ds;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ds[e] = S[J][e] * (P[J][e] - dl);
+          const float dk = ds[e] * rkk[e];           // the key row's 2^-s rides in dS: K^T below is read as stored
+          S[J][e] = dk;
+          dmx = fmaxf(dmx, fabsf(dk));
+        }
+        if (wi == 0) *acc = ds;                      // (the wave's own tiles: no other wave touches them)
+        else { const f32x4 o = *acc; *acc = f32x4{o[0] + ds[0], o[1] + ds[1], o[2] + ds[2], o[3] + ds[3]}; }
+      }
+      dmx = w3_max4(dmx);
+      const float dsc = pow2_scale(dmx), dri = pow2_inv(dsc) * scale;
+      f32x4 O[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int JJ = 0; JJ < 2; ++JJ) {
+        u32x4 dh, dlo;
+        w2_pack_pair(S[2 * JJ], S[2 * JJ + 1], dsc, dh, dlo);
 #pragma unroll
         for (int jd = 0; jd < 2; ++jd) {
-          const int d0 = 16 * jd + 4 * g;
-          float sk[4], sv4[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            sk[e] = __shfl(rqt[jd], 4 * g + e, 64) * (scale * dri);
-            sv4[e] = __shfl(rgt[jd], 4 * g + e, 64) * (1.0f / 16384.f);
-          }
-          if (d0 < D) {
-            *(float2*)(op + C + 16 * jd) = float2{OK[jd][0] * sk[0], OK[jd][1] * sk[1]};
-            *(float2*)(op + 2 * C + 16 * jd) = float2{OV[jd][0] * sv4[0], OV[jd][1] * sv4[1]};
-          }
-          if (d0 + 2 < D) {
-            *(float2*)(op + C + 16 * jd + 2) = float2{OK[jd][2] * sk[2], OK[jd][3] * sk[3]};
-            *(float2*)(op + 2 * C + 16 * jd + 2) = float2{OV[jd][2] * sv4[2], OV[jd][3] * sv4[3]};
-          }
+          u32x4 kth, ktl;
+          w3_cols(imK, JJ, jd, c, g, kth, ktl);
+          O[jd] = mfma3(kth, ktl, dh, dlo, O[jd]);
         }
-        SR_TS(9 + J)
+      }
+      float* op = dqb + (long)w2_token(geo, 16 * I + c, H, W, shift) * C3 + 4 * g;
+      if (!W3_MODE(2))
+#pragma unroll
+      for (int jd = 0; jd < 2; ++jd) w3_store<D>(op + 16 * jd, 16 * jd + 4 * g, O[jd], dri);
+    }
+    SR_TS(3)
+    sr_lds_barrier();                                // log-sum-exp and delta of every row
+    SR_TS(4)
+
+    // ================= key side: key tile J = wv
+    if (!W3_MODE(1)) {
+      const int J = wv;
+      u32x4 kh, kl, vh, vl;
+      w3_rows(imK, J, c, g, kh, kl);
+      w3_rows(imV, J, c, g, vh, vl);
+      const float rk = rs[64 + 16 * J + c], rv = rs[128 + 16 * J + c];
+      f32x4 S[4], P[4];      // lane (c, g): key 16 J + c against queries 16 I + 4 g + e
+      float dmx = 0.f, pmx = 0.f;
+#pragma unroll
+      for (int I = 0; I < 4; ++I) {
+        u32x4 qh, ql, gh, gl;
+        w3_rows(imQ, I, c, g, qh, ql);
+        w3_rows(imG, I, c, g, gh, gl);
+        S[I] = mfma3(qh, ql, kh, kl, f32x4{0.f, 0.f, 0.f, 0.f});
+        P[I] = mfma3(gh, gl, vh, vl, f32x4{0.f, 0.f, 0.f, 0.f});
+        const float* tb = tab + bk + 30 * (I - J);
+        const f32x4 ls = *(const f32x4*)(lse + 16 * I + 4 * g), dl = *(const f32x4*)(dlt + 16 * I + 4 * g);
+        const f32x4 rq = *(const f32x4*)(rs + 16 * I + 4 * g), rg = *(const f32x4*)(rs + 192 + 16 * I + 4 * g);
+        const bool masked = lane_masked || (geo.last_row && ((I >> 1) != (J >> 1)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float sv = S[I][e] * (rq[e] * rk) + tb[e];
+          sv += masked ? -100.f : 0.f;
+          const float pe = __expf(sv - ls[e]);
+          const float dsv = pe * (P[I][e] * (rg[e] * rv) - dl[e]);
+          // the query rows' 2^-s (dO's for P, q's -- times the logit scale -- for dS) ride in these operands
+          const float pf = pe * rg[e], df = dsv * rq[e];
+          P[I][e] = pf;
+          S[I][e] = df;
+          pmx = fmaxf(pmx, pf);
+          dmx = fmaxf(dmx, fabsf(df));
+        }
+      }
+      dmx = w3_max4(dmx);
+      pmx = w3_max4(pmx);
+      const float dsc = pow2_scale(dmx), dri = pow2_inv(dsc);
+      const float psc = pow2_scale(pmx), pri = pow2_inv(psc);
+      f32x4 OV[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 OK[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int II = 0; II < 2; ++II) {
+        u32x4 ph, pl, dh, dlo;
+        w2_pack_pair(P[2 * II], P[2 * II + 1], psc, ph, pl);
+        w2_pack_pair(S[2 * II], S[2 * II + 1], dsc, dh, dlo);
+#pragma unroll
+        for (int jd = 0; jd < 2; ++jd) {
+          u32x4 th, tl;
+          w3_cols(imG, II, jd, c, g, th, tl);
+          OV[jd] = mfma3(th, tl, ph, pl, OV[jd]);
+          w3_cols(imQ, II, jd, c, g, th, tl);
+          OK[jd] = mfma3(th, tl, dh, dlo, OK[jd]);
+        }
+      }
+      float* op = dqb + (long)w2_token(geo, 16 * J + c, H, W, shift) * C3 + 4 * g;
+      if (!W3_MODE(2))
+#pragma unroll
+      for (int jd = 0; jd < 2; ++jd) {
+        w3_store<D>(op + C + 16 * jd, 16 * jd + 4 * g, OK[jd], dri);
+        w3_store<D>(op + 2 * C + 16 * jd, 16 * jd + 4 * g, OV[jd], pri);
       }
     }
-  } else {
-    for (int i = lane; i < W2_DS / 4; i += 64) ((f32x4*)dsl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    SR_TS(5)
+    sr_lds_barrier();                                // the images are free for the next window
+    SR_TS(6)
   }
-  if (part) {       // the block's partial bias-gradient tile: the four waves' tiles in wave order (deterministic)
-    __syncthreads();
+  if (part) {       // the block's partial bias-gradient tile: wave I owns the tiles (I, 0..3)
     float* dst = part + ((long)wg * heads + head) * W2_DS;
-    for (int i = threadIdx.x; i < W2_DS / 4; i += 256) {
-      const f32x4 a = ((const f32x4*)w2s)[i], b = ((const f32x4*)(w2s + W2_DS))[i];
-      const f32x4 cc = ((const f32x4*)(w2s + 2 * W2_DS))[i], d = ((const f32x4*)(w2s + 3 * W2_DS))[i];
-      f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (a[e] + b[e]) + (cc[e] + d[e]);
-      ((f32x4*)dst)[i] = o;
+    for (int J = 0; J < 4; ++J) {
+      const int o = w2_img_index(wv, J, lane);
+      *(f32x4*)(dst + o) = *(const f32x4*)(dsl + o);
     }
   }
-  SR_TS(13)
 }
 
 // partial tiles [nparts][heads][4096] (accumulator order of k_wattn2_bwd) -> the bias-gradient image in the order
@@ -443,7 +552,13 @@ int srhip_window_attention_fwd_f16x2(const float* qkv, float* out, const float* 
 }
 
 #ifdef SRHIP_EXPERIMENTS
-int srhip_wattn2_debug_buffer(long long* buf) { g_w2_dbg = buf; return 0; }      // [blocks][4][16] wall-clock stamps
+// [blocks][4 waves][4 windows][8] stamps of the 100 MHz wall clock
+int srhip_wattn2_debug_buffer(long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_w3_dbg), &buf, sizeof(buf)) == hipSuccess ? 0 : -5;
+}
+int srhip_wattn2_debug_mode(int mode) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_w3_mode), &mode, sizeof(mode)) == hipSuccess ? 0 : -5;
+}
 #endif
 
 long srhip_window_attention_bwd_f16x2_ws(int B, int H, int W, int heads) {
@@ -462,24 +577,12 @@ int srhip_window_attention_bwd_f16x2(const float* qkv, const float* dout, float*
   const int nwin = B * (H / 8) * (W / 8), nparts = sr_cdiv(nwin, 4);
   const float scale = 1.0f / sqrtf((float)D);
   hipStream_t st = (hipStream_t)stream;
-  constexpr int LDS = (4 * W2_DS + 4 * W2_ST) * 4;
   dim3 grid(nparts * heads), blk(256);
   float* part = workspace;
-  long long* dbgp = nullptr;
-#ifdef SRHIP_EXPERIMENTS
-  dbgp = g_w2_dbg;
-#endif
-#define SR_WA(D_)                                                                                                    \
-  if (D == D_) {                                                                                                     \
-    static bool attr = false;                                                                                        \
-    if (!attr) {                                                                                                     \
-      if (hipFuncSetAttribute((const void*)k_wattn2_bwd<D_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) \
-        return sr_fail(-5, "window_attention_bwd_f16x2: cannot reserve %d bytes of LDS", LDS);                       \
-      attr = true;                                                                                                   \
-    }                                                                                                                \
-    hipLaunchKernelGGL((k_wattn2_bwd<D_>), grid, blk, LDS, st, qkv, dout, dqkv, biasF, biasG, part, nwin, H, W, C,   \
-                       heads, shift, scale, dbgp);                                                                   \
-  }
+#define SR_WA(D_)                                                                                                       \
+  if (D == D_)                                                                                                          \
+    hipLaunchKernelGGL((k_wattn3_bwd<D_>), grid, blk, W3_LDS, st, qkv, dout, dqkv, biasF, part, nwin, H, W, C,        \
+                       heads, shift, scale);
   SR_WA(30) SR_WA(10) SR_WA(16) SR_WA(32)
 #undef SR_WA
   if (dbiasT)

@@ -60,11 +60,16 @@ __device__ __forceinline__ int w2_token(const W2Geom& g, int pos, int H, int W, 
 template <int D>
 __device__ __forceinline__ void w2_load_row(float (&v)[8], const float* __restrict__ base, long pitch, int tok, int g) {
   const float* p = base + (long)tok * pitch + 8 * g;
+  // a pair past the head dim reads the lane's first pair instead and is zeroed afterwards: a load under a branch is
+  // waited for at the branch's join (s_waitcnt vmcnt(0)), which serialises whatever is in flight -- the address select
+  // keeps all four loads unconditional (D is even: a pair is valid or not as a whole)
+  float2 x[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) x[t] = ldg_f2(p + ((8 * g + 2 * t < D) ? 2 * t : 0));
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    float2 x = float2{0.f, 0.f};
-    if (8 * g + 2 * t < D) x = ldg_f2(p + 2 * t);            // D is even: a pair is valid or not as a whole
-    v[2 * t] = x.x; v[2 * t + 1] = x.y;
+    const bool ok = 8 * g + 2 * t < D;
+    v[2 * t] = ok ? x[t].x : 0.f; v[2 * t + 1] = ok ? x[t].y : 0.f;
   }
 }
 // ... split under the row's block exponent (row maximum over the row's four lanes); returns 2^-s
