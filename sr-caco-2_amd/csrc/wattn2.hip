@@ -115,9 +115,6 @@ constexpr int W3_WPB = 4;                          // windows per block (= the p
 constexpr int W3_LDS = 4 * W3_IMG + (W2_DS + 256 + 4 * 64 + 2 * 64) * 4;      // images, dS sums, bias table, row data
 
 typedef short w3_s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
-// 16-byte global accesses at 8-byte alignment (a head's slice of a row starts at 4 D bytes x head)
-typedef f32x4 w3_f32x4a8 __attribute__((aligned(8)));
-typedef const __attribute__((address_space(1))) w3_f32x4a8* w3_gp4;
 template <int CTRL>
 __device__ __forceinline__ float w3_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
@@ -148,35 +145,6 @@ __device__ __forceinline__ u32x4 w3_cols1(const unsigned char* plane, int JJ, in
 __device__ __forceinline__ void w3_cols(const unsigned char* img, int JJ, int jd, int c, int g, u32x4& hi, u32x4& lo) {
   hi = w3_cols1(img, JJ, jd, c, g);
   lo = w3_cols1(img + W3_PL, JJ, jd, c, g);
-}
-// reductions over the four lanes {c, c + 16, c + 32, c + 48}: v_permlane16_swap leaves rows {0, 0, 2, 2} of the value in
-// one register and rows {1, 1, 3, 3} in the other, v_permlane32_swap the lower half in one and the upper half in the other
-// (inline asm: hipcc folds the two results of __builtin_amdgcn_permlane16_swap(u, u) into one value -- it drops the max
-// and doubles the sum; s_nop 1 = the wait states it puts between a VALU write of the operands and the swap)
-__device__ __forceinline__ void w3_swap16(float v, float& a, float& b) {
-  a = v; b = v;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void w3_swap32(float v, float& a, float& b) {
-  a = v; b = v;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ float w3_max4(float v) {
-  float a, b;
-  w3_swap16(v, a, b); v = fmaxf(a, b);
-  w3_swap32(v, a, b); return fmaxf(a, b);
-}
-__device__ __forceinline__ float w3_sum4(float v) {
-  float a, b;
-  w3_swap16(v, a, b); v = a + b;
-  w3_swap32(v, a, b); return a + b;
-}
-
-// four consecutive head-dim entries d0 .. d0 + 3 of one row: 16 bytes where all four exist, 8 where two do
-template <int D>
-__device__ __forceinline__ void w3_store(float* p, int d0, const f32x4& v, float sc) {
-  if (d0 + 4 <= D) *(w3_f32x4a8*)p = f32x4{v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
-  else if (d0 + 2 <= D) *(float2*)p = float2{v[0] * sc, v[1] * sc};
 }
 #ifndef W3_OCC
 #define W3_OCC 3

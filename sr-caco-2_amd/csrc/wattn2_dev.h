@@ -33,6 +33,38 @@ __device__ __forceinline__ float pow2_inv(float sc) {
   return __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(unsigned, sc));
 }
 
+// 16-byte global accesses at 8-byte alignment (a head's slice of a row starts at 4 D bytes x head)
+typedef f32x4 w3_f32x4a8 __attribute__((aligned(8)));
+typedef const __attribute__((address_space(1))) w3_f32x4a8* w3_gp4;
+// reductions over the four lanes {c, c + 16, c + 32, c + 48}: v_permlane16_swap leaves rows {0, 0, 2, 2} of the value in
+// one register and rows {1, 1, 3, 3} in the other, v_permlane32_swap the lower half in one and the upper half in the other
+// (inline asm: hipcc folds the two results of __builtin_amdgcn_permlane16_swap(u, u) into one value -- it drops the max
+// and doubles the sum; s_nop 1 = the wait states it puts between a VALU write of the operands and the swap)
+__device__ __forceinline__ void w3_swap16(float v, float& a, float& b) {
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void w3_swap32(float v, float& a, float& b) {
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float w3_max4(float v) {
+  float a, b;
+  w3_swap16(v, a, b); v = fmaxf(a, b);
+  w3_swap32(v, a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ float w3_sum4(float v) {
+  float a, b;
+  w3_swap16(v, a, b); v = a + b;
+  w3_swap32(v, a, b); return a + b;
+}
+
+// four consecutive head-dim entries d0 .. d0 + 3 of one row: 16 bytes where all four exist, 8 where two do
+template <int D>
+__device__ __forceinline__ void w3_store(float* p, int d0, const f32x4& v, float sc) {
+  if (d0 + 4 <= D) *(w3_f32x4a8*)p = f32x4{v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
+  else if (d0 + 2 <= D) *(float2*)p = float2{v[0] * sc, v[1] * sc};
+}
 struct W2Geom {
   int head, b, wy, wx;
   bool last_row, last_col;
@@ -77,8 +109,7 @@ __device__ __forceinline__ float w2_split_row(const float (&v)[8], u32x4& hi, u3
   float mx = 0.f;
 #pragma unroll
   for (int t = 0; t < 8; ++t) mx = fmaxf(mx, fabsf(v[t]));
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  mx = w3_max4(mx);
   const float sc = pow2_scale(mx);
   unsigned h[4], l[4];
 #pragma unroll

@@ -390,6 +390,488 @@ __global__ void __launch_bounds__(64 * NW * WPB, NW / 2) k_wmsa_f16(WmsaF16Args 
   SR_TS(9)
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// 5 or 6 heads: ONE HEAD PER WAVE from the qkv GEMM to the attention output, nothing in between leaves the registers.
+// k_wmsa_f16 above gives a wave 32 qkv channels of every token, stores them, and after a barrier the attention of a head
+// gathers q, k rows (8-byte loads) and v columns (4-byte loads) back from L2 / the Infinity Cache: 17-22 us of its 72
+// and the second half of its HBM traffic (284 MB measured for 142 MB of operands).  Here wave h owns the head's D columns
+// of q, of k and of v (three 64 x 32 sub-GEMMs over the same stage images, the weight rows addressed per lane):
+//   q, k  transposed product -- lane (c, g) ends with entries 16 j + 4 g + e of token 16 i + c: after the epilogue these
+//         eight values ARE the row-form fragment of S^T = K . Q^T (the contraction runs over the head dim in any order,
+//         the same for q and k);
+//   v     plain product -- lane (c, g) ends with entry 16 j + c of tokens 16 i + 4 g + e = the V^T operand of
+//         O^T = V^T . P^T in the key order of the P registers;
+// qkv is still written (the backward reads it) but never read.  The attention output goes to global memory (backward) and,
+// split under the row's exponent (row maximum over the six waves: one LDS atomic per row and wave), straight into the
+// stage images of the proj GEMM: no re-staging pass, one barrier less.  The relative-position bias comes from the heads'
+// 225-entry tables in LDS (index = lane constant + 30 (I - J) - e).
+constexpr int TABP = 228;              // pitch of a head's bias table
+constexpr int WMSA_LDSH = R0 + (64 + 64 + 2 * 3 * 192 + 64 + 6 * TABP + 6 * 96) * 4;
+
+template <int D, int WPB>
+__global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
+  constexpr int NW = 6, NT = 64 * NW, CW = 32, NJ = 2, NIT = 3072 / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int grp = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT);
+  unsigned char* const smem = smem_all + grp * WMSA_LDSH;
+  int* const tokl = (int*)(smem + R0);               // [64] token index of window position
+  float* const rinva = (float*)(tokl + 64);          // [64] 2^-s of the a rows
+  float* const colq = rinva + 64;                    // [2][3C] column scales (2^-s of x and of the W rows) and biases of qkv
+  unsigned* const amax = (unsigned*)(colq + 2 * 3 * 192);   // [64] bits of the a rows' maxima
+  float* const tab = (float*)(amax + 64);            // [heads][TABP] relative-position bias tables
+  float* const wsc = tab + 6 * TABP;                 // [wave][96]: 2^-s of the head's 64 key rows, of its 32 V columns (x 2^-14)
+  const int tid = (int)threadIdx.x - grp * NT, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int C = p.C, N3 = 3 * C;
+  const int nst = p.Kp / SK;
+  const int nWx = p.W / 8, nWy = p.H / 8;
+  const int win = min(sr_xcd_block((int)blockIdx.x, gridDim.x) * WPB + grp, p.B * nWx * nWy - 1);
+  const W2Geom geo = w2_decode((long)win, 1, nWx, nWy, p.shift);
+  const long planeq = (long)N3 * p.Kp * 2, planep = (long)C * p.Kp * 2;
+  const float* const winvq = (const float*)((const char*)p.Wqkv + 2 * planeq);
+  const float* const winvp = (const float*)((const char*)p.Wproj + 2 * planep);
+  SR_TS(0)
+  // ---------------- phase 1: x rows of the window -> LayerNorm -> stage images (the first four waves: four lanes per row)
+  {
+    const float rix = 1.0f / exp2f(floorf(log2f(16384.f * rsqrtf((float)C))));
+    for (int n = tid; n < N3; n += NT) {
+      colq[n] = rix * winvq[n];
+      colq[N3 + n] = p.bqkv[n];
+    }
+    for (int n = tid; n < p.heads * 225; n += NT) {     // table entry (dy + 7) * 15 + dx + 7 read back from the S^T image
+      const int hd = n / 225, r = n - 225 * hd;
+      const int dy = r / 15 - 7, dx = r % 15 - 7;
+      const int qy = max(dy, 0), ky = qy - dy, qx = max(dx, 0), kx = qx - dx;
+      const int query = 8 * qy + qx, key = 8 * ky + kx;
+      tab[hd * TABP + r] = ldg_f(p.biasF + (long)hd * 4096 + w2_img_index(query >> 4, key >> 4, 16 * ((key & 15) >> 2) + (query & 15)) + (key & 3));
+    }
+    if (tid < 64) amax[tid] = 0u;
+    const int arow = (tid >> 2) & 63, akq = tid & 3;
+    const int atok = w2_token(geo, arow, p.H, p.W, p.shift);
+    if (akq == 0 && tid < 256) tokl[arow] = atok;
+    if (wave < 4) {
+      const char* const abase = (const char*)p.X + (long)atok * C * 4;
+      const float2 rst = ldg_f2(p.ln_stats + 2 * (long)atok);
+      f32x4 ra[6][2];
+#pragma unroll
+      for (int s6 = 0; s6 < 6; ++s6) {                 // past the end: k = 0 of the row, zeroed below
+        const int k = s6 * SK + akq * 8;
+        ra[s6][0] = *(const f32x4*)(abase + (k < C ? k * 4 : 0));
+        ra[s6][1] = *(const f32x4*)(abase + (k + 4 < C ? (k + 4) * 4 : 0));
+      }
+      const float asc = exp2f(floorf(log2f(16384.f * rsqrtf((float)C))));       // |xhat| <= sqrt(K): a priori
+      const int a_dst = a_slot(arow, akq) * 16;
+#pragma unroll
+      for (int s6 = 0; s6 < 6; ++s6) {
+        const int k = s6 * SK + akq * 8;
+        unsigned hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          f32x4 x = ra[s6][e];
+          x.x = (x.x - rst.x) * rst.y; x.y = (x.y - rst.x) * rst.y; x.z = (x.z - rst.x) * rst.y; x.w = (x.w - rst.x) * rst.y;
+          if (k + 4 * e >= C) x = f32x4{0.f, 0.f, 0.f, 0.f};
+          split2_pair(x.x * asc, x.y * asc, hh[2 * e], ll[2 * e]);
+          split2_pair(x.z * asc, x.w * asc, hh[2 * e + 1], ll[2 * e + 1]);
+        }
+        unsigned char* sa = smem + s6 * AST + a_dst;
+        *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+        *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+      }
+    }
+  }
+  SR_TS(1)
+  __syncthreads();
+  SR_TS(2)
+
+  // ---------------- phases 2 + 3: the head's q, k, v and its attention, in registers
+  if (wave < p.heads) {
+    const int hd = wave;
+    const int a_off0 = a_slot(c, g) * 16;            // a_slot(16 i + c, g) * 16 = a_off0 + 1024 i
+    unsigned wofs[NJ];
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) wofs[jt] = (unsigned)(((g >> 1) * N3 + D * hd + min(16 * jt + c, D - 1)) * 32 + (g & 1) * 16);
+    auto load_w = [&](int ct, int s, u32x4 (&fb)[NJ][2]) {
+      const char* base = (const char*)p.Wqkv + (long)(2 * s) * N3 * 32 + (long)ct * C * 32;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * planeq + wofs[jt]);
+    };
+    f32x4 acc[4][NJ];
+    // TR: acc[i][j] = entries 16 j + 4 g + e of token 16 i + c;  else: entry 16 j + c of tokens 16 i + 4 g + e
+    auto gemm = [&](int ct, const bool TR) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      u32x4 fA[NJ][2], fB[NJ][2];
+      auto mma = [&](int s, const u32x4 (&fb)[NJ][2]) {
+        const unsigned char* sa = smem + s * AST;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u32x4 fa[2];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off0 + 1024 * i);
+#define SR_TERM(PA, PB)                                                                      \
+  _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = TR ? mfma16h(fb[j][PB], fa[PA], acc[i][j]) \
+                                                                 : mfma16h(fa[PA], fb[j][PB], acc[i][j]);
+          SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)          // small terms first
+#undef SR_TERM
+        }
+      };
+      load_w(ct, 0, fA);
+      load_w(ct, min(1, nst - 1), fB);
+      for (int s = 0; s < nst; s += 2) {
+        mma(s, fA);
+        if (s + 2 < nst) load_w(ct, s + 2, fA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nst) {
+          mma(s + 1, fB);
+          if (s + 3 < nst) load_w(ct, s + 3, fB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    // epilogue of a transposed product: scale, bias, store, and the row-form fragments (entries past D are zero)
+    auto rows_out = [&](int ct, u32x4 (&fh)[4], u32x4 (&fl)[4], float (&rinv)[4]) {
+      float2 wi[NJ][2], bv[NJ][2];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int cc = ct * C + D * hd + min(16 * j + 4 * g + 2 * h2, D - 2);
+          wi[j][h2] = *(const float2*)(colq + cc);
+          bv[j][h2] = *(const float2*)(colq + N3 + cc);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int d0 = 16 * j + 4 * g;
+          f32x4 o;
+          o[0] = acc[i][j][0] * wi[j][0].x + bv[j][0].x; o[1] = acc[i][j][1] * wi[j][0].y + bv[j][0].y;
+          o[2] = acc[i][j][2] * wi[j][1].x + bv[j][1].x; o[3] = acc[i][j][3] * wi[j][1].y + bv[j][1].y;
+          if (d0 >= D) { o[0] = 0.f; o[1] = 0.f; }
+          if (d0 + 2 >= D) { o[2] = 0.f; o[3] = 0.f; }
+          w3_store<D>(p.qkv + (long)tokl[16 * i + c] * N3 + ct * C + D * hd + d0, d0, o, 1.0f);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * j + e] = o[e];
+        }
+        rinv[i] = w2_split_row(v, fh[i], fl[i]);
+      }
+    };
+    u32x4 qh[4], ql[4], kh[4], kl[4];
+    float rq[4], rk[4];
+    gemm(0, true);
+    rows_out(0, qh, ql, rq);
+    SR_TS(10)
+    gemm(1, true);
+    rows_out(1, kh, kl, rk);
+    SR_TS(11)
+    gemm(2, false);
+    // V: scale, bias, store (4-byte: a lane holds ONE entry of four tokens), and the V^T operand under one power-of-two
+    // scale per head-dim column
+    u32x4 vh[2][2], vl[2][2];
+    float* const rkl = wsc + 96 * hd;                // the wave's own 96 floats: written and read by this wave only
+    {
+#pragma unroll
+      for (int jd = 0; jd < 2; ++jd) {
+        const bool ok = 16 * jd + c < D;
+        const int cv = 2 * C + D * hd + min(16 * jd + c, D - 1);
+        const float wv = colq[cv], bs = colq[N3 + cv];
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = ok ? acc[i][jd][e] * wv + bs : 0.f;
+            acc[i][jd][e] = x;
+            mx = fmaxf(mx, fabsf(x));
+            if (ok) p.qkv[(long)tokl[16 * i + 4 * g + e] * N3 + cv] = x;
+          }
+        }
+        mx = w3_max4(mx);
+        const float sc = pow2_scale(mx);
+        if (g == 0) rkl[64 + 16 * jd + c] = pow2_inv(sc) * (1.0f / 16384.f);      // column 16 jd + c, times the 2^-14 of P
+#pragma unroll
+        for (int JJ = 0; JJ < 2; ++JJ) {
+          unsigned h[4], l[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {          // slots (2 t, 2 t + 1) = tokens w2_kpos(JJ, g, 2 t), + 1
+            const f32x4 a = acc[2 * JJ + (t >> 1)][jd];
+            const int e0 = 2 * (t & 1);
+            split2_pair(a[e0] * sc, a[e0 + 1] * sc, h[t], l[t]);
+          }
+          vh[JJ][jd] = u32x4{h[0], h[1], h[2], h[3]};
+          vl[JJ][jd] = u32x4{l[0], l[1], l[2], l[3]};
+        }
+      }
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int J = 0; J < 4; ++J) rkl[16 * J + c] = rk[J];                        // key 16 J + c
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    SR_TS(12)
+    const bool lane_masked = geo.last_col && (((c >> 2) & 1) != (g & 1));
+    const float* const tb0 = tab + hd * TABP + ((c >> 3) - (g >> 1) + 7) * 15 + (c & 7) - 4 * (g & 1) + 7;
+#pragma unroll
+    for (int I = 0; I < 4; ++I) {
+      f32x4 S[4];
+      const float rqs = rq[I] * p.scale;
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int J = 0; J < 4; ++J) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        a = mfma16h(kh[J], ql[I], a);
+        a = mfma16h(kl[J], qh[I], a);
+        a = mfma16h(kh[J], qh[I], a);
+        const float* tb = tb0 + 30 * (I - J);
+        const bool masked = lane_masked || (geo.last_row && ((I >> 1) != (J >> 1)));
+        const f32x4 rkk = *(const f32x4*)(rkl + 16 * J + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float sv = a[e] * (rqs * rkk[e]) + tb[-e];
+          sv += masked ? -100.f : 0.f;
+          a[e] = sv;
+          mx = fmaxf(mx, sv);
+        }
+        S[J] = a;
+      }
+      mx = w3_max4(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int J = 0; J < 4; ++J)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = __expf(S[J][e] - mx);
+          S[J][e] = pe;
+          sum += pe;
+        }
+      sum = w3_sum4(sum);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+      f32x4 O[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int JJ = 0; JJ < 2; ++JJ) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 pv = S[2 * JJ + (t >> 1)];
+          const int e0 = 2 * (t & 1);
+          split2_pair(pv[e0] * 16384.f, pv[e0 + 1] * 16384.f, h[t], l[t]);
+        }
+        const u32x4 ph = u32x4{h[0], h[1], h[2], h[3]}, pl = u32x4{l[0], l[1], l[2], l[3]};
+#pragma unroll
+        for (int jd = 0; jd < 2; ++jd) {
+          O[jd] = mfma16h(vh[JJ][jd], pl, O[jd]);
+          O[jd] = mfma16h(vl[JJ][jd], ph, O[jd]);
+          O[jd] = mfma16h(vh[JJ][jd], ph, O[jd]);
+        }
+      }
+      float am = 0.f;
+#pragma unroll
+      for (int jd = 0; jd < 2; ++jd) {
+        const int d0 = 16 * jd + 4 * g;
+        const f32x4 rvo = *(const f32x4*)(rkl + 64 + d0);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (d0 + e < D) ? O[jd][e] * (rvo[e] * inv) : 0.f;
+        w3_store<D>(p.att + (long)tokl[16 * I + c] * C + D * hd + d0, d0, o, 1.0f);
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+      }
+      am = w3_max4(am);
+      if (g == 0) atomicMax(amax + 16 * I + c, __builtin_bit_cast(unsigned, am));
+    }
+  }
+  SR_TS(3)
+  __syncthreads();                                   // every head is through its GEMMs: the stage images are free; row maxima complete
+  SR_TS(4)
+  // ---------------- the a rows, split under their exponents, into the stage images of the proj GEMM.  Each wave reads
+  // back what it stored itself (its head's columns: L2 hits) -- held in registers through the attention the 32 values
+  // per lane would put the kernel over the 168 registers of three waves per SIMD
+  if (wave < p.heads) {
+    const int hd = wave;
+    f32x4 ov[4][2];
+#pragma unroll
+    for (int I = 0; I < 4; ++I) {
+      const float* src = p.att + (long)tokl[16 * I + c] * C + D * hd + 4 * g;
+#pragma unroll
+      for (int jd = 0; jd < 2; ++jd) {
+        const int d0 = 16 * jd + 4 * g;            // a piece past D reads the lane's first piece (zeroed below)
+        const float* q = src + (d0 + 2 <= D ? 16 * jd : -4 * g);
+        ov[I][jd] = d0 + 4 <= D ? *(w3_gp4)q : f32x4{ldg_f(q), ldg_f(q + 1), 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int I = 0; I < 4; ++I) {
+      const int row = 16 * I + c;
+      const float asc = pow2_scale(__builtin_bit_cast(float, amax[row]));
+      if (hd == 0 && g == 0) rinva[row] = pow2_inv(asc);
+#pragma unroll
+      for (int jd = 0; jd < 2; ++jd) {
+        const int d0 = 16 * jd + 4 * g;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          if (d0 + 2 * h2 < D) {                       // (D is even: a pair is valid or not as a whole)
+            const int k = D * hd + d0 + 2 * h2, s6 = k >> 5, kk = k & 31;
+            unsigned hh, ll;
+            split2_pair(ov[I][jd][2 * h2] * asc, ov[I][jd][2 * h2 + 1] * asc, hh, ll);
+            unsigned char* dst = smem + s6 * AST + a_slot(row, kk >> 3) * 16 + (kk & 7) * 2;
+            *(unsigned*)dst = hh;
+            *(unsigned*)(dst + APL) = ll;
+          }
+        }
+      }
+    }
+  }
+  {
+    const int npad = (p.Kp - C) >> 1;                // channel pairs past C in the last stages: zeros
+    for (int idx = tid; idx < 64 * npad; idx += NT) {
+      const int row = idx / npad, k = C + 2 * (idx - row * npad), s6 = k >> 5, kk = k & 31;
+      unsigned char* dst = smem + s6 * AST + a_slot(row, kk >> 3) * 16 + (kk & 7) * 2;
+      *(unsigned*)dst = 0u;
+      *(unsigned*)(dst + APL) = 0u;
+    }
+  }
+  SR_TS(5)
+  // Phase 4 needs the thread's position again: derived from the thread index so that little lives through the phases above
+  int t4 = tid;
+  asm volatile("" : "+v"(t4));
+  const int lane4 = t4 & 63, c4 = lane4 & 15, g4 = lane4 >> 4;
+  unsigned boffp[NJ];
+#pragma unroll
+  for (int jt = 0; jt < NJ; ++jt) {
+    const int col = min(wave * CW + jt * 16 + c4, C - 1);
+    boffp[jt] = (unsigned)(((g4 >> 1) * C + col) * 32 + (g4 & 1) * 16);
+  }
+  u32x4 fb0[NJ][2], fb1[NJ][2], fb2[NJ][2];
+  auto load_bp = [&](int s, u32x4 (&fb)[NJ][2]) {
+    const char* base = (const char*)p.Wproj + (long)(2 * min(s, nst - 1)) * C * 32;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int jt = 0; jt < NJ; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * planep + boffp[jt]);
+  };
+  load_bp(0, fb0);
+  load_bp(1, fb1);
+  load_bp(2, fb2);
+  const int arow4 = (t4 >> 2) & 63, akq4 = t4 & 3;
+  const int atok4 = tokl[arow4];
+  const int a_off40 = a_slot(c4, g4) * 16;
+  __syncthreads();
+  SR_TS(7)
+
+  // ---------------- phase 4: proj (k_nth2's loop): acc2[i][j] = rows 16 i + 4 g + e, columns CW wave + 16 j + c
+  f32x4 acc2[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma2 = [&](int s6, const u32x4 (&fb)[NJ][2]) {
+    const unsigned char* sa = smem + s6 * AST;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 fa[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off40 + 1024 * i);
+#define SR_TERM(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc2[i][j] = mfma16h(fa[PA], fb[j][PB], acc2[i][j]);
+      SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+#undef SR_TERM
+    }
+  };
+  // the residual pieces of the row-major epilogue travel while the MFMAs run
+  f32x4 rv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = it * NT + t4, row = idx / 48, col = (idx - row * 48) * 4;
+    rv[it] = *(const f32x4*)(p.X + (long)tokl[row] * C + min(col, C - 4));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  mma2(0, fb0); load_bp(3, fb0); __builtin_amdgcn_sched_barrier(0);
+  mma2(1, fb1); load_bp(4, fb1); __builtin_amdgcn_sched_barrier(0);
+  mma2(2, fb2); load_bp(5, fb2); __builtin_amdgcn_sched_barrier(0);
+  mma2(3, fb0); __builtin_amdgcn_sched_barrier(0);
+  mma2(4, fb1); __builtin_amdgcn_sched_barrier(0);
+  mma2(5, fb2); __builtin_amdgcn_sched_barrier(0);
+  SR_TS(8)
+
+  // ---------------- the output tile, row-major in LDS (block exponents undone: exact powers of two)
+  __syncthreads();
+  float* const T = (float*)smem;
+  {
+    float wv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) wv[j] = winvp[min(wave * CW + 16 * j + c4, C - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ri = rinva[16 * i + 4 * g4 + e];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) T[(16 * i + 4 * g4 + e) * TP + wave * CW + 16 * j + c4] = acc2[i][j][e] * (ri * wv[j]);
+      }
+  }
+  __syncthreads();
+  // out = x + s (acc + bp): 16-byte pieces in row-major order
+  const float dps = p.rowscale ? p.rowscale[geo.b] : 1.f;
+  {
+    int prow[NIT], pcol[NIT], ptok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = it * NT + t4;
+      prow[it] = idx / 48;
+      pcol[it] = (idx - prow[it] * 48) * 4;
+      ptok[it] = tokl[prow[it]];
+      if (pcol[it] >= C) prow[it] = -1;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (prow[it] >= 0) {
+        float* tp = T + prow[it] * TP + pcol[it];
+        f32x4 v = *(const f32x4*)tp;
+        const f32x4 bv = p.bproj ? *(const f32x4*)(p.bproj + pcol[it]) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] + bv[e]) * dps + rv[it][e];
+        *(f32x4*)(p.out + (long)ptok[it] * C + pcol[it]) = v;
+        if (p.stats_out) *(f32x4*)tp = v;
+      }
+    }
+  }
+  if (p.stats_out) {
+    // {mean, rstd} of the out rows for the next LayerNorm (two-pass, eps 1e-5, biased variance): four lanes per row
+    __syncthreads();
+    if (wave >= 4) return;
+    const int row = arow4, q = akq4;
+    f32x4 xv[12];
+    float s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      xv[k] = *(const f32x4*)(T + row * TP + q * 48 + 4 * k);
+      if (q * 48 + 4 * k < C) s1 += (xv[k].x + xv[k].y) + (xv[k].z + xv[k].w);
+    }
+    s1 += __shfl_xor(s1, 1, 64);
+    s1 += __shfl_xor(s1, 2, 64);
+    const float mean = s1 * (1.0f / (float)C);
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+      if (q * 48 + 4 * k < C) {
+        const float d0 = xv[k].x - mean, d1 = xv[k].y - mean, d2 = xv[k].z - mean, d3 = xv[k].w - mean;
+        s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    s2 += __shfl_xor(s2, 1, 64);
+    s2 += __shfl_xor(s2, 2, 64);
+    if (q == 0) *(float2*)(p.stats_out + 2 * (long)atok4) = float2{mean, rsqrtf(s2 * (1.0f / (float)C) + 1e-5f)};
+  }
+  SR_TS(9)
+}
+
 }  // namespace
 
 #ifdef SRHIP_EXPERIMENTS
@@ -419,12 +901,12 @@ int sr_wmsa_f16(WmsaF16Args& p, hipStream_t st) {
     if (six) {                                                                                                 \
       static bool attr = false;                                                                                \
       if (!attr) {                                                                                             \
-        if (hipFuncSetAttribute((const void*)k_wmsa_f16<D_, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                2 * WMSA_LDS) != hipSuccess)                                                   \
-          return sr_fail(-5, "wmsa_f16x2: cannot reserve %d bytes of LDS", 2 * WMSA_LDS);                      \
+        if (hipFuncSetAttribute((const void*)k_wmsa_f16h<D_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                2 * WMSA_LDSH) != hipSuccess)                                                  \
+          return sr_fail(-5, "wmsa_f16x2: cannot reserve %d bytes of LDS", 2 * WMSA_LDSH);                     \
         attr = true;                                                                                           \
       }                                                                                                        \
-      hipLaunchKernelGGL((k_wmsa_f16<D_, 6, 2>), dim3(sr_cdiv(nwin, 2)), dim3(768), 2 * WMSA_LDS, st, p);      \
+      hipLaunchKernelGGL((k_wmsa_f16h<D_, 2>), dim3(sr_cdiv(nwin, 2)), dim3(768), 2 * WMSA_LDSH, st, p);       \
     } else {                                                                                                   \
       hipLaunchKernelGGL((k_wmsa_f16<D_, 4, 1>), dim3(nwin), dim3(256), WMSA_LDS, st, p);                      \
     }                                                                                                          \
