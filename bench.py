@@ -159,6 +159,124 @@ def secondary_edsr(scale, batch, dev, steps=10, warmup=3):
     return out
 
 
+
+EVAL_NETS = [("swinir", "SWINIR"), ("EDSR_LIIF", "EDSR_LIIF"), ("VDSR", "VDSR"), ("DRRN", "DRRN"), ("SRCNN", "SRCNN"),
+             ("MSLapSRN", "MSLAPSR"), ("MemNet", "MemNet"), ("DBPN", "DBPN"), ("SRFBN", "SRFBN"), ("ProSR", "PROSR"),
+             ("ENLCN", "ENLCN"), ("NLSN", "NLSN"), ("DFCAN", "DFCAN"), ("ACT", "ACT"), ("OmniSR", "OmniSR"), ("GRL", "GRL")]
+
+
+def secondary_exact_f32(batch, dev, steps=5, warmup=2):
+    """The headline workload on the EXACT-f32 matrix path (SRHIP_MM=f32: v_mfma_f32_32x32x2_f32, no operand split) for a
+    few steps: what the fp16x2 split (22 significant bits per operand, three products) buys over IEEE f32 products."""
+    import torch
+    from srhip.train import TrainStep, Optimizer
+    from dlib.models.network_swinir import SwinIR
+    old = os.environ.get("SRHIP_MM")
+    os.environ["SRHIP_MM"] = "f32"
+    try:
+        torch.manual_seed(0)
+        net = SwinIR(upscale=8, in_chans=1, img_size=64, window_size=8, depths=[6, 6, 6, 6], embed_dim=180,
+                     num_heads=[6, 6, 6, 6], mlp_ratio=2, upsampler="pixelshuffledirect").to(dev).train()
+        ts = TrainStep(net, [("l1", 1.0)])
+        ts.opt = Optimizer(ts.fp, "sgd", lr=0.01, momentum=0.9, nesterov=True, wd=0.0)
+        lr_img, hr_img = synth_batch(batch, 8, dev, seed=1000)
+        torch.manual_seed(1234)
+        for _ in range(warmup):
+            ts.step(lr_img, hr_img)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ts.step(lr_img, hr_img)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out = {"patches_per_s": batch * steps / dt, "ms_per_step": 1000.0 * dt / steps, "steps": steps,
+               "final_loss": ts.loss_values()[0], "matmul": "exact f32 MFMA (v_mfma_f32_32x32x2_f32), f32 operands"}
+        del ts, net
+        torch.cuda.empty_cache()
+        return out
+    finally:
+        if old is None:
+            os.environ.pop("SRHIP_MM", None)
+        else:
+            os.environ["SRHIP_MM"] = old
+
+
+def torch_rocm_baseline(batch, dev, steps=5, warmup=2):
+    """The same step through the vendor-library path on the SAME GPU: the oracle's module (plain PyTorch ops: aten /
+    rocBLAS / MIOpen kernels, fp32, autograd) on cuda, same batch, same L1 loss, SGD-Nesterov by torch.optim.  The
+    checker is timed here as a baseline, never shipped (oracle/ header)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sr_oracle as O
+    cfg = O.swinir_config(drop_path_rate=0.0)
+    sd = {k: v.to(dev) for k, v in O.swinir_init_state_dict(cfg, seed=0).items()}
+    params = []
+    for k, v in sd.items():
+        if v.dtype == torch.float32 and not k.endswith("attn_mask"):
+            v.requires_grad_(True)
+            params.append(v)
+    opt = torch.optim.SGD(params, lr=0.01, momentum=0.9, nesterov=True)
+    lr_img, hr_img = synth_batch(batch, 8, dev, seed=1000)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        O.loss_l1(O.swinir_forward(sd, lr_img, cfg), hr_img).backward()
+        opt.step()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"value": batch * steps / dt, "unit": "patches/s", "ms_per_step": 1000.0 * dt / steps, "steps": steps,
+           "what": "oracle SwinIR x8 README module on cuda: stock PyTorch-ROCm kernels (aten elementwise, rocBLAS/hipBLASLt "
+                   "GEMMs, MIOpen convs), fp32, autograd + torch.optim.SGD(nesterov); DropPath off; same B, same GPU",
+           "torch": torch.__version__}
+    del sd, params, opt
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary_eval_x8(batch, iters=3):
+    """BASELINE.json config 5 at x8: model.test() patches/s of every registry network, fp32-accurate kernels and with
+    --amp True (reduced-precision kernels where the network takes them), a few iterations each."""
+    import torch
+    import main as M
+    from dlib.models.select_model import define_model
+    rows = {}
+    for net_type, method in EVAL_NETS:
+        row = {}
+        for amp in (False, True):
+            argv = ["--net_type", net_type, "--method", method, "--task", "super-resolution", "--scale", "8",
+                    "--n_channels", "1", "--h_size", "512", "--batch_size", str(batch), "--amp", str(amp),
+                    "--outd", os.path.join(ROOT, "gpurun_out", "bench_eval")]
+            args = M.parse_input(argv)
+            torch.manual_seed(0)
+            model = define_model(args)
+            model.netG.eval()
+            data = M.synth_batch(batch, 8, 512, model.device, 7)
+            model.feed_data(data)
+            model.test()                                   # weight preparation, buffers
+            model.test()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                model.test()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert tuple(model.E.shape[-2:]) == (512, 512) and bool(torch.isfinite(model.E).all())
+            row["amp_patches_per_s" if amp else "patches_per_s"] = batch * iters / dt
+            if amp:
+                row["reduced_precision_kernels"] = bool(getattr(model.netG, "amp", False)
+                                                        and getattr(model.netG, "amp_takes_effect", True))
+            del model
+            torch.cuda.empty_cache()
+        rows[net_type] = row
+    return {"batch": batch, "iters": iters, "nets": rows}
+
+
 def physical_cores():
     """sockets x cores per socket from lscpu (hardware threads are reported separately)."""
     try:
@@ -286,9 +404,12 @@ def worker(args):
 
     use_graph = args.graph            # data-parallel runs too: the RCCL bucket all-reduces are captured with the step
     step_fn = ts.step_graph if use_graph else ts.step
+    gpu_legs = {}                     # wall seconds of every leg that keeps the GPU busy (synchronize-bracketed)
+    t_leg = time.perf_counter()
     for _ in range(max(args.warmup, 2 if use_graph else 0)):   # graph: eager step, capture, then replays
         step_fn(lr_img, hr_img)
     barrier()
+    gpu_legs["warmup"] = time.perf_counter() - t_leg
     if use_graph:
         args.no_roofline = True          # per-launch HIP events cannot be recorded inside a replayed graph
     if not args.no_roofline:
@@ -305,6 +426,7 @@ def worker(args):
     marks[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
+    gpu_legs["timed_steps"] = dt
     probe.active = set(kinds)
     # PMC traffic of THIS workload's kernels (profiles/, collected with tools/refresh_profiles.sh)
     for r in (9, 8, 7, 6, 5, 4, 3, 2):
@@ -330,6 +452,7 @@ def worker(args):
     if args.train_only:
         args.no_secondary = args.no_cpu_baseline = True
     if rank == 0 and world == 1 and not args.train_only:
+        t_leg = time.perf_counter()
         net.eval()
         with torch.no_grad():
             for _ in range(2):
@@ -352,9 +475,26 @@ def worker(args):
             eval_amp_pps = args.batch * 10 / (time.perf_counter() - t1)
             net.amp = False
         net.train()
+        gpu_legs["eval_forward"] = time.perf_counter() - t_leg
     secondary = None
+    torch_base = None
     if rank == 0 and world == 1 and args.workload == "swinir_x8" and not args.no_secondary:
+        t_leg = time.perf_counter()
         secondary = {f"edsr_x{sc}": secondary_edsr(sc, args.batch, dev) for sc in (8, 4, 2)}
+        gpu_legs["secondary_edsr"] = time.perf_counter() - t_leg
+        # the training state of the headline run is not needed any more: its buffers make room for the legs below
+        del ts
+        net.engine.bufs.d.clear()
+        torch.cuda.empty_cache()
+        t_leg = time.perf_counter()
+        secondary["swinir_x8_exact_f32"] = secondary_exact_f32(args.batch, dev)
+        gpu_legs["secondary_exact_f32"] = time.perf_counter() - t_leg
+        t_leg = time.perf_counter()
+        secondary["eval_x8"] = secondary_eval_x8(args.batch)
+        gpu_legs["secondary_eval_x8"] = time.perf_counter() - t_leg
+        t_leg = time.perf_counter()
+        torch_base = torch_rocm_baseline(args.batch, dev)
+        gpu_legs["torch_rocm_baseline"] = time.perf_counter() - t_leg
     if rank == 0:
         patches = args.batch * world * args.steps
         pps = patches / dt
@@ -405,6 +545,11 @@ def worker(args):
             out["config"]["secondary"] = secondary
         if roof:
             out["roofline"] = roof
+        if torch_base:
+            out["torch_rocm_baseline"] = torch_base
+        # how much of this run was GPU work (the timed region is a fraction of a second; the CPU baseline is most of the rest)
+        out["gpu_seconds_total"] = sum(gpu_legs.values())
+        out["gpu_seconds"] = gpu_legs
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, opt_kind)
         print(json.dumps(out), flush=True)

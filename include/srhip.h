@@ -28,6 +28,9 @@ extern "C" {
 
 const char* srhip_last_error(void);
 int srhip_abi_version(void);
+/* 1 in a build made with `make EXPERIMENTS=1` (tuning / ablation switches of the C side are read from the environment, phase
+   stamps compiled in), 0 in the shipped library, which takes its defaults and reads no environment. */
+int srhip_experiments_enabled(void);
 /* Arithmetic of the bf16x3 contractions (srhip_gemm_nt_bx3, srhip_conv3x3_nhwc_bx3), process-wide:
  *   0 (default)  f32-accurate: six bf16 products of the three-way split operands
  *   1            reduced precision for INFERENCE: one bf16 product of the leading planes, f32

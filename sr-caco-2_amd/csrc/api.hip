@@ -18,7 +18,14 @@ int sr_fail(int code, const char* fmt, ...) {
 extern "C" {
 
 const char* srhip_last_error(void) { return g_err; }
-int srhip_abi_version(void) { return 12; }
+int srhip_abi_version(void) { return 13; }
+int srhip_experiments_enabled(void) {
+#ifdef SRHIP_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 static int g_matmul_mode = 0;
 int srhip_set_matmul_mode(int mode) {

@@ -39,18 +39,19 @@ def interpolate_torch(x: np.ndarray, scale: float, mode: str = 'bicubic', min_v:
 
 def simulate_low_res(x: np.ndarray, seed: int, th: float, sigma: float, min_v: float = 0.0, max_v: float = 255.) -> np.ndarray:
     """dataset_dpsr.py:713-744: Gaussian noise N(v, sigma) on the pixels >= th (the cells), seeded per image index with the
-    reference's set_seed (utils_reproducibility.py:89-115: torch, numpy and random all take the seed)."""
-    import random
+    reference's set_seed (utils_reproducibility.py:89-115)."""
     assert sigma >= 0.0 and isinstance(sigma, float) and th >= 0 and isinstance(th, float)
     assert isinstance(x, np.ndarray) and x.ndim == 3 and x.shape[-1] in (1, 3)
     v = torch.from_numpy(x).float()
     roi = (v >= th).float()
-    torch.manual_seed(seed)
-    np.random.seed(seed)
-    random.seed(seed)
-    if torch.cuda.is_available():
-        torch.cuda.manual_seed_all(seed)
-    new_low = torch.normal(mean=v, std=sigma)
+    # The reference runs this inside a DataLoader worker and re-seeds the worker's GLOBAL generators (torch, numpy, random)
+    # with the item index; here the call happens in the main process (resident sets are built up front), where that would
+    # leave every rank's numpy / random streams at the last tile's index and perturb whatever is drawn next (patch
+    # samplers, LR augmentations, DropPath).  The only draw below is torch.normal: a private generator seeded with the
+    # index yields the very stream the re-seeded default generator would (golden g31), and touches nothing global.
+    gen = torch.Generator()
+    gen.manual_seed(seed)
+    new_low = torch.normal(mean=v, std=sigma, generator=gen)
     new_low = torch.clamp(new_low, 0.0, 255.)
     new_low = new_low * roi + (1 - roi) * v
     new_low = torch.clamp(new_low, min=min_v, max=max_v)

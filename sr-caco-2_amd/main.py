@@ -226,6 +226,12 @@ def _train_on_folds(args, model, rank, world, current_step):
     if args.is_master:
         save_config(args, args.outd_backup, 'config_model.yml')                 # what eval.py reads (utils_parser.py:1397-1401)
     train_set = get_train_set(args, model.device, rank, world)
+    # host-side draws of the input pipeline (edt / Otsu patch samplers, --da_* augmentations: numpy / random): one stream per
+    # rank, as the reference's DataLoader workers have
+    import random
+    import numpy as np
+    np.random.seed((int(args.myseed or 0) + rank) % (2 ** 32 - 1))
+    random.seed(int(args.myseed or 0) + rank)
     n_valid = args.valid_n_samples if args.valid_n_samples else -1
     valid_loaders = get_all_eval_loaders(args, args.valid_dsets, n=n_valid) if args.valid_dsets else {}
     test_loaders = get_all_eval_loaders(args, args.test_dsets, n=-1) if args.test_dsets else {}

@@ -254,10 +254,15 @@ class GradReducer:
         self.grad, self.buckets, self.group, self.comm_stream = flat_grad, list(buckets), group, comm_stream
         self.done = [True] * len(self.buckets)
         self.log = []                       # bucket indices in the order they were reduced (tests)
+        # trace = True: HIP events around every bucket (tests / profiles: does bucket i's all-reduce run beside the
+        # backward kernels of the layers after it?).  events[i] = (announced on the compute stream, all-reduce start
+        # and end on the side stream)
+        self.trace, self.events = False, {}
 
     def begin(self):
         self.done = [False] * len(self.buckets)
         self.log = []
+        self.events = {}
 
     def bucket_done(self, i):
         if self.done[i]:
@@ -265,6 +270,17 @@ class GradReducer:
         self.done[i] = True
         self.log.append(i)
         lo, hi = self.buckets[i]
+        if self.trace and self.comm_stream is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev[0])
+            ev[1].record(self.comm_stream)
+            with torch.cuda.stream(self.comm_stream):
+                import torch.distributed as dist
+                dist.all_reduce(self.grad[lo:hi], group=self.group)
+            ev[2].record(self.comm_stream)
+            self.events[i] = ev
+            return
         allreduce_range(self.grad, lo, hi, self.group, self.comm_stream)
 
     def reduce_flag(self, flag):

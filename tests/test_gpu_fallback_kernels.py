@@ -13,6 +13,25 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# Switches read by the C side (common.h: sr_getenv) are live only in an experiments build (make EXPERIMENTS=1 ->
+# sr-caco-2_amd/lib/libsrhip_exp.so, built by __graft_entry__.build()); the shipped library ignores them.  An arm that sets
+# one runs on that build (SRHIP_LIB) and its child asserts that the build really reads them; Python-side switches
+# (srhip/ops.py, the engines) work with either library.
+C_SIDE = {"SRHIP_NTW", "SRHIP_NTW_GRID", "SRHIP_NTW_ROT", "SRHIP_TN_F16X2", "SRHIP_TN_F16X2_LINEAR", "SRHIP_TN_GROUP_XCD",
+          "SRHIP_TN_T3", "SRHIP_TN_XCD", "SRHIP_WA_XCD", "SRHIP_TN_BLOCKS", "SRHIP_WMSA_NW"}
+EXP_LIB = os.path.join(ROOT, "sr-caco-2_amd", "lib", "libsrhip_exp.so")
+ASSERT_EXP = "from srhip import ops as _o\nassert _o.lib.srhip_experiments_enabled() == 1, 'the loaded library ignores C-side switches'\n"
+
+
+def child_env(env):
+    """(environment, code prefix) of an arm's child process."""
+    if not (set(env) & C_SIDE):
+        return dict(os.environ, **env), ""
+    if not os.path.isfile(EXP_LIB):
+        pytest.skip(f"{sorted(set(env) & C_SIDE)} are read by an experiments build only and {EXP_LIB} is absent "
+                    "(make -C sr-caco-2_amd/csrc EXPERIMENTS=1 OUT=../lib/libsrhip_exp.so OBJDIR=../lib/obj_exp)")
+    return dict(os.environ, SRHIP_LIB=EXP_LIB, **env), "import sys\nsys.path.insert(0, 'sr-caco-2_amd')\n" + ASSERT_EXP
+
 CHILD = textwrap.dedent('''
     import sys
     sys.path.insert(0, "sr-caco-2_amd")
@@ -49,7 +68,8 @@ CHILD = textwrap.dedent('''
 @pytest.mark.parametrize("env", [{}, {"SRHIP_NTW": "0"}, {"SRHIP_F16X2": "0", "SRHIP_F16X2_CONV": "0"}, {"SRHIP_NTCW": "0", "SRHIP_NTCW2": "0", "SRHIP_NTCW2_SMALL": "0"},
                                  {"SRHIP_NTW_GRID": "0", "SRHIP_NTW_ROT": "0", "SRHIP_NTCW2_WIDE": "0"}])
 def test_switchable_kernels_match_float64(env):
-    r = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True,
+    cenv, pre = child_env(env)
+    r = subprocess.run([sys.executable, "-c", pre + CHILD], cwd=ROOT, env=cenv, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-500:], r.stderr[-1500:])
 
@@ -243,6 +263,7 @@ def test_fp16x2_three_product_conv_weight_gradient_is_f32_grade(env):
     rise by 2^40 along the tokens (the scales must follow and the sums be rescaled) and with all-zero channels;
     the same for the grouped Linear weight gradients (tnb_body_h: DropPath row scale, LayerNorm and GELU prologues).
     Second arm: the bf16x3 / six-product forms and the old block order."""
-    r = subprocess.run([sys.executable, "-c", TN16_CHILD], cwd=ROOT, env=dict(os.environ, **env),
+    cenv, pre = child_env(env)
+    r = subprocess.run([sys.executable, "-c", pre + TN16_CHILD], cwd=ROOT, env=cenv,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-500:], r.stderr[-1500:])

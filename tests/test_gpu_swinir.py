@@ -460,3 +460,97 @@ def test_forced_ddp_single_rank_rccl_path_matches_plain_step(tmp_path):
     p = subprocess.run([sys.executable, str(script), root, str(port)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert p.returncode == 0 and "ddp ok" in p.stdout and "ddp graph ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+DDP_README_WORKER = r'''
+import json, os, sys, torch, torch.distributed as dist
+root = sys.argv[1]
+for p in (os.path.join(root, "sr-caco-2_amd"), os.path.join(root, "oracle"), root):
+    sys.path.insert(0, p)
+os.environ["SRHIP_FORCE_DDP"] = "1"
+from dlib.models.network_swinir import SwinIR
+from srhip.train import TrainStep, Optimizer
+import bench
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+torch.manual_seed(0)
+net = SwinIR(upscale=8, in_chans=1, img_size=64, window_size=8, depths=[6, 6, 6, 6], embed_dim=180,
+             num_heads=[6, 6, 6, 6], mlp_ratio=2, upsampler="pixelshuffledirect").cuda().train()
+ts = TrainStep(net, [("l1", 1.0)], process_group=dist.group.WORLD, world_size=1)
+ts.opt = Optimizer(ts.fp, "sgd", lr=0.01, momentum=0.9, nesterov=True, wd=0.0)
+assert ts.ddp and len(ts.buckets) == 5
+lr_img, hr_img = bench.synth_batch(8, 8, "cuda", seed=1000)
+for _ in range(3):
+    ts.step(lr_img, hr_img)
+torch.cuda.synchronize()
+ts.reducer.trace = True
+# compute-stream marks: step start, backward end (recorded by the hook of the LAST bucket's announce = finish())
+t_start, t_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t_start.record()
+ts.step(lr_img, hr_img)
+t_end.record()
+torch.cuda.synchronize()
+ev = ts.reducer.events
+assert sorted(ev) == [0, 1, 2, 3, 4] and ts.reducer.log == [0, 1, 2, 3, 4], ts.reducer.log
+rows = []
+for i in range(5):
+    lo, hi = ts.buckets[i]
+    rows.append({"bucket": i, "mbytes": (hi - lo) * 4 / 1e6,
+                 "announced_ms": t_start.elapsed_time(ev[i][0]), "allreduce_start_ms": t_start.elapsed_time(ev[i][1]),
+                 "allreduce_end_ms": t_start.elapsed_time(ev[i][2])})
+step_ms = t_start.elapsed_time(t_end)
+out = {"what": "README SwinIR x8, B = 8, one rank (SRHIP_FORCE_DDP=1, RCCL group of one): per bucket, when the engine "
+               "announced it on the compute stream and when its all-reduce started / ended on the side stream, ms after the "
+               "step's first kernel; the step's last kernel (optimizer) ended at step_ms",
+       "step_ms": step_ms, "total_mbytes": sum(r["mbytes"] for r in rows), "buckets": rows}
+os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(root, "gpurun_out", "r04_ddp_overlap.json"), "w"), indent=1)
+# the schedule: buckets in backward-completion order, each all-reduce enqueued (and, with one rank, finished) while
+# backward kernels of the layers behind it are still to come -- i.e. before the NEXT bucket is even announced, and all but
+# the last one long before the step's end
+for a, b in zip(rows, rows[1:]):
+    assert a["announced_ms"] < b["announced_ms"], (a, b)
+    assert a["allreduce_start_ms"] <= b["announced_ms"] + 0.05, (a, b)       # started before the next layer's backward ended
+    assert a["allreduce_end_ms"] <= b["announced_ms"] + 0.5, (a, b)
+assert rows[0]["announced_ms"] < 0.6 * step_ms and rows[3]["allreduce_end_ms"] < step_ms
+assert abs(out["total_mbytes"] - 31.5) < 0.2, out["total_mbytes"]
+dist.destroy_process_group()
+print("ddp readme ok", json.dumps(out["buckets"]))
+'''
+
+
+def test_forced_ddp_at_readme_size_overlaps_buckets_with_backward(tmp_path):
+    """Config 4's schedule at its real size on the one GPU there is: README SwinIR x8, B = 8, SRHIP_FORCE_DDP=1 (RCCL
+    group of one): five buckets (31.5 MB) in backward-completion order on the side stream, bucket i's all-reduce under
+    way before layer i - 1's backward has ended (HIP events on both streams; gpurun_out/r04_ddp_overlap.json)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "ddp_readme_worker.py"
+    script.write_text(DDP_README_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, str(script), root, str(port)], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0 and "ddp readme ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_bench_self_launch_one_rank_rccl_path(tmp_path):
+    """`python bench.py --gpus 1` with SRHIP_FORCE_DDP=1: the worker initialises RCCL, takes the bucketed path for every
+    step of the README workload and prints the contract's JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(SRHIP_FORCE_DDP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                        "--train-only"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and d["value"] > 100 and d["config"]["parallelism"] == "dp1"
