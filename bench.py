@@ -100,9 +100,10 @@ def synth_batch(batch, scale, device, seed):
 
 
 def measured_bytes_per_step(workload):
-    """HBM bytes one training step moves, summed over every kernel of the committed rocprofv3 PMC passes of this
-    workload (profiles/r0N_hbm_traffic_per_kernel_<workload>_b8.json: FETCH_SIZE x 2 + WRITE_SIZE per launch x launches,
-    tools/collect_traffic.sh), divided by the optimizer launches of that run (= its steps).  None if not collected."""
+    """HBM bytes one training step moved in the COMMITTED rocprofv3 PMC passes of this workload (newest
+    profiles/r0N_hbm_traffic_per_kernel_<workload>_b8.json: FETCH_SIZE x 2 + WRITE_SIZE per launch x launches,
+    tools/collect_traffic.sh), divided by the optimizer launches of that run (= its steps).  Not counters of the run being
+    reported: the keys that use it say 'from_committed_pmc' and name the file.  None if not collected."""
     tag = workload.replace("swinir_x8", "swinir")
     for r in (9, 8, 7, 6, 5, 4, 3, 2):
         path = os.path.join(ROOT, "profiles", f"r0{r}_hbm_traffic_per_kernel_{tag}_b8.json")
@@ -149,8 +150,9 @@ def secondary_edsr(scale, batch, dev, steps=10, warmup=3):
            "hbm_frac": gbyte * 3.0 * pps / HBM_PEAK_GBS, "final_loss": ts.loss_values()[0]}
     mb, src = measured_bytes_per_step(f"edsr_x{scale}")
     if mb:
-        out["hbm_frac_measured"] = mb * (pps / batch) / 1e9 / HBM_PEAK_GBS
-        out["measured_gbyte_per_step"] = mb / 1e9
+        out["hbm_frac_from_committed_pmc"] = mb * (pps / batch) / 1e9 / HBM_PEAK_GBS
+        out["committed_pmc_gbyte_per_step"] = mb / 1e9
+        out["committed_pmc_source"] = src
     if roof:
         out["dominant_kernel"] = {"kernel": roof["kernel"].split(":")[0], "frac": roof["frac"], "peak": roof["peak"],
                                   "achieved": roof["achieved"], "unit": roof["unit"], "avg_launch_us": roof["avg_launch_us"]}
@@ -535,12 +537,13 @@ def worker(args):
                            "algorithmic_gflop_per_patch_fwd": gflop, "algorithmic_gbyte_per_patch_fwd": gbyte,
                            "per_gpu": True},
         }
-        # hbm_frac above prices the UNFUSED-convention bytes of SURVEY 8d; this one the bytes the step really moved (PMC)
+        # hbm_frac above prices the UNFUSED-convention bytes of SURVEY 8d; this one the bytes a step moved in the committed PMC passes
+        # (profiles/, named in committed_pmc_source: stale after a kernel change until tools/refresh_profiles.sh is run again)
         mb, mb_src = measured_bytes_per_step(args.workload)
         if mb:
-            out["whole_step"]["hbm_frac_measured"] = mb * (pps / world / args.batch) / 1e9 / HBM_PEAK_GBS
-            out["whole_step"]["measured_gbyte_per_step"] = mb / 1e9
-            out["whole_step"]["measured_source"] = mb_src
+            out["whole_step"]["hbm_frac_from_committed_pmc"] = mb * (pps / world / args.batch) / 1e9 / HBM_PEAK_GBS
+            out["whole_step"]["committed_pmc_gbyte_per_step"] = mb / 1e9
+            out["whole_step"]["committed_pmc_source"] = mb_src
         if secondary:
             out["config"]["secondary"] = secondary
         if roof:

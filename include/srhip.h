@@ -31,12 +31,14 @@ int srhip_abi_version(void);
 /* 1 in a build made with `make EXPERIMENTS=1` (tuning / ablation switches of the C side are read from the environment, phase
    stamps compiled in), 0 in the shipped library, which takes its defaults and reads no environment. */
 int srhip_experiments_enabled(void);
-/* Arithmetic of the bf16x3 contractions (srhip_gemm_nt_bx3, srhip_conv3x3_nhwc_bx3), process-wide:
+/* Arithmetic of the split-MFMA contractions (srhip_gemm_nt_bx3, srhip_conv3x3_nhwc_bx3), per calling THREAD (thread-local;
+ * an entry point reads it when it enqueues its kernels, so it is a property of the call, not of the stream or the process):
  *   0 (default)  f32-accurate: six bf16 products of the three-way split operands
  *   1            reduced precision for INFERENCE: one bf16 product of the leading planes, f32
  *                accumulation -- the role of the reference's --amp autocast at evaluation time
  *                (model_plain.py:322-327, eval_all.sh); outputs differ from mode 0 at the 1e-3
- *                relative level (gate: PSNR within 0.01 dB).  Training always runs mode 0. */
+ *                relative level (gate: PSNR within 0.01 dB).  Training always runs mode 0.
+ * Re-entrant across threads and streams; a thread that wants both modes brackets the calls (net.amp does). */
 int srhip_set_matmul_mode(int mode);
 int srhip_get_matmul_mode(void);
 

@@ -379,13 +379,17 @@ def edsr_config(upscale=4, in_chans=1, n_feats=64, n_resblocks=16,
                 n_resblocks=n_resblocks, res_scale=res_scale)
 
 
-def edsr_forward(sd: SD, x: Tensor, cfg: dict) -> Tensor:
+def edsr_forward(sd: SD, x: Tensor, cfg: dict, relu_masks=None) -> Tensor:
+    """relu_masks (tests only): per ResBlock a {0, 1} tensor that REPLACES the ReLU's own decision -- the ReLU becomes
+    pre * mask.  A gradient check against another computation of the same net is then not confused by pixels whose
+    pre-activation lies within rounding of zero (one flipped decision moves a weight-gradient entry by a whole pixel's
+    contribution): both sides differentiate the same piecewise-linear function."""
     nb = cfg["n_resblocks"]
     f0 = F.conv2d(x, sd["head.0.weight"], sd["head.0.bias"], padding=1)
     r = f0
     for k in range(nb):  # ResBlock: conv-ReLU-conv, *res_scale, +x  (:89-93)
-        y = F.relu(F.conv2d(r, sd[f"body.{k}.body.0.weight"],
-                            sd[f"body.{k}.body.0.bias"], padding=1))
+        y = F.conv2d(r, sd[f"body.{k}.body.0.weight"], sd[f"body.{k}.body.0.bias"], padding=1)
+        y = F.relu(y) if relu_masks is None else y * relu_masks[k].to(y.dtype)
         y = F.conv2d(y, sd[f"body.{k}.body.2.weight"],
                      sd[f"body.{k}.body.2.bias"], padding=1)
         r = y * cfg["res_scale"] + r

@@ -27,7 +27,9 @@ int srhip_experiments_enabled(void) {
 #endif
 }
 
-static int g_matmul_mode = 0;
+// per THREAD: a call reads it when it enqueues its kernels (the launch arguments carry the choice), so two host threads
+// driving two streams cannot flip each other's mode, and within a thread calls are sequential
+static thread_local int g_matmul_mode = 0;
 int srhip_set_matmul_mode(int mode) {
   if (mode != 0 && mode != 1) return sr_fail(-22, "set_matmul_mode: mode %d (0 = f32-accurate bf16x3, 1 = single bf16 product)", mode);
   g_matmul_mode = mode;

@@ -98,9 +98,9 @@ def test_edsr_full_size_train_step_vs_oracle(scale, loss):
     y = net.engine.bufs.d["t.y"].detach().reshape(1, 1, 512, 512).cpu()
     grads = {k: v.clone() for k, v in ts.fp.gviews.items()}
 
-    def oracle(dtype):
+    def oracle(dtype, masks=None):
         sd = {k: v.to(dtype).clone().requires_grad_(True) for k, v in sd0.items()}
-        yo = O.edsr_forward(sd, lr_img.to(dtype), cfg)
+        yo = O.edsr_forward(sd, lr_img.to(dtype), cfg, relu_masks=masks)
         tot, _ = O.master_loss(yo, hr_img.to(dtype), terms)
         tot.backward()
         return sd, yo.detach(), tot
@@ -119,13 +119,12 @@ def test_edsr_full_size_train_step_vs_oracle(scale, loss):
     assert y.shape == (1, 1, 512, 512)
     assert mae <= 1e-5 and gap <= 0.01
     assert abs(lv[0] - tot.item()) <= 1e-5 * max(1.0, abs(tot.item()))
-    # Gradient gates for a ReLU net.  Tensor-wise relative L2 error against the exact (fp64) gradients
-    # <= GRAD_GATE.  Largest single entry: a ReLU whose pre-activation lies within fp32 rounding of zero
-    # switches on in one computation and off in the other -- ONE pixel of the 4096 .. 65536 of the body's
-    # feature maps then enters or leaves a weight-gradient sum (measured: 1.3e-4 at 64x64, 1.1e-4 at 128x128,
-    # 1.9e-5 at 256x256, while the tensor-wise error stays at 1e-6; the reference's own fp32 result shows the
-    # same against fp64 whenever it has such a pixel: 4.1e-5 at x4) -- so the entry-wise gate allows two such
-    # pixels: 2 / (LR pixels per image); tensor-wise the same pixels show as a few 1e-5 (gate 1e-4).
+    # Gradient gates for a ReLU net.  A ReLU whose pre-activation lies within fp32 rounding of zero switches on in
+    # one computation and off in the other -- ONE pixel of the 4096 .. 65536 of the body's feature maps then enters
+    # or leaves a weight-gradient sum (measured: 1.3e-4 at 64x64; the reference's own fp32 result shows the same
+    # against fp64 whenever it has such a pixel: 4.1e-5 at x4).  Against the free-running fp64 oracle only the
+    # tensor-wise relative L2 error is gated (1e-4; such pixels show as a few 1e-5); every ENTRY is gated below
+    # against an fp64 oracle run under the HIP run's own ReLU decisions.
     kl, el = worst_l2(grads, {k: v.grad for k, v in sd64.items()})
     # evidence for the mechanism: ReLU masks of the HIP run against an fp64 recomputation of the same
     # pre-activations from the HIP run's own block inputs
@@ -138,9 +137,15 @@ def test_edsr_full_size_train_step_vs_oracle(scale, loss):
         flips += int(((pre > 0) != (a.permute(0, 3, 1, 2).cpu() > 0)).sum())
     print(f"  worst tensor-wise relative L2 error vs fp64: {kl} {el:.2e}; ReLU decisions that differ from an fp64 "
           f"recomputation in blocks 5, 11, 12: {flips} of {3 * 64 * (512 // scale) ** 2}")
-    npix = (512 // scale) ** 2
     assert el <= 1e-4, (kl, el)
-    assert e64 <= max(GRAD_GATE, 3.0 * eo, 2.0 / npix), (k64, e64, eo)
+    # ENTRY-wise: against an fp64 oracle that takes the HIP run's own ReLU decisions (the saved activations' signs) --
+    # the same piecewise-linear function on both sides, so no entry is excused: GRAD_GATE (2e-5) on every one
+    masks = [(net.engine.saved["blocks"][kb][1].permute(0, 3, 1, 2).cpu() > 0) for kb in range(cfg["n_resblocks"])]
+    sdm, ym, _ = oracle(torch.float64, masks)
+    km, em = worst_grad(grads, {k: v.grad.float() for k, v in sdm.items()})
+    print(f"  worst grad entry vs the fp64 oracle under the HIP run's ReLU decisions: {km} {em:.2e}; its output differs from "
+          f"the free-running fp64 oracle's by {(ym.float() - y).abs().max().item():.1e} (HIP) ")
+    assert em <= GRAD_GATE, (km, em)
     # Adam's first update is lr * g / (|g| + eps): where a gradient entry is ~0 its SIGN decides a full
     # +-lr step, so the update is checked from the HIP gradients themselves (the gradients are gated above)
     worst = 0.0

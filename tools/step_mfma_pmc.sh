@@ -7,7 +7,7 @@ ROOT=$(pwd)
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d "$ROOT/$OUT/sq" -- \
-  python3 "$ROOT/bench.py" --workload $WL --steps 4 --warmup 2 --no-cpu-baseline --no-roofline > "$ROOT/$OUT/bench.log" 2>&1 || true
+  python3 "$ROOT/bench.py" --workload $WL --steps 4 --warmup 2 --train-only --no-roofline > "$ROOT/$OUT/bench.log" 2>&1 || true
 cd "$ROOT"
 python3 - "$OUT" <<'P'
 import csv, glob, json, re, sys, collections
