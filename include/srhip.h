@@ -199,7 +199,9 @@ int srhip_mlp_bwd_front_chain_f16x2(const float* X0, long ld0, int K0, const voi
  *   qkv = LN(x) . Wqkv^T + bqkv  (stats[T][2] = {mean, rstd} of x; Wqkv gamma-folded, bqkv beta-folded),
  *   att = softmax(q k^T / sqrt(D) + bias + shift mask) v  per head (cyclic shift 0 or 4, as srhip_window_attention_fwd_f16x2),
  *   out = x + s * (att . Wproj^T + bproj),  stats_out = {mean, rstd} of the out rows (may be NULL).
- * qkv [T][3C] and att [T][C] are written (the backward reads them) but read back from L2 only.  x, out: token-major
+ * qkv [T][3C] and att [T][C] are written for the backward.  With 5 or 6 heads a wave owns one head from the qkv GEMM to the
+ * attention output: q, k, v never leave its registers, qkv is only written and may be NULL (inference); other head counts
+ * read their qkv rows back from L2 after a barrier.  x, out: token-major
  * [B*H*W][C], dense; out must not alias x.  Weight planes as srhip_mlp_fwd_f16x2 (prep kind 3); biasF from
  * srhip_bias_expand_f16x2; rowscale = DropPath multipliers per sample [B] or NULL.  C <= 192 (multiple of 4),
  * heads <= 8, head dim in {10, 16, 30, 32}, H, W multiples of 8.

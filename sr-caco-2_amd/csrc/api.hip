@@ -176,7 +176,7 @@ int srhip_wmsa_fwd_f16x2(const float* x, const float* stats, const void* Wqkvh, 
                          const float* bproj, const float* biasF, const float* rowscale, float* qkv, float* att,
                          float* out, float* stats_out, int B, int H, int W, int C, int heads, int shift,
                          void* stream) {
-  SR_REQUIRE(x && stats && Wqkvh && bqkv && Wprojh && biasF && qkv && att && out, "wmsa_fwd_f16x2: null operand");
+  SR_REQUIRE(x && stats && Wqkvh && bqkv && Wprojh && biasF && att && out, "wmsa_fwd_f16x2: null operand");
   SR_REQUIRE(out != x, "wmsa_fwd_f16x2: out must not alias x (windows read the residual while others write)");
   WmsaF16Args p;
   memset(&p, 0, sizeof(p));

@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
           o[2] = acc[i][j][2] * wi[j][1].x + bv[j][1].x; o[3] = acc[i][j][3] * wi[j][1].y + bv[j][1].y;
           if (d0 >= D) { o[0] = 0.f; o[1] = 0.f; }
           if (d0 + 2 >= D) { o[2] = 0.f; o[3] = 0.f; }
-          w3_store<D>(p.qkv + (long)tokl[16 * i + c] * N3 + ct * C + D * hd + d0, d0, o, 1.0f);
+          if (p.qkv) w3_store<D>(p.qkv + (long)tokl[16 * i + c] * N3 + ct * C + D * hd + d0, d0, o, 1.0f);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[4 * j + e] = o[e];
         }
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
             const float x = ok ? acc[i][jd][e] * wv + bs : 0.f;
             acc[i][jd][e] = x;
             mx = fmaxf(mx, fabsf(x));
-            if (ok) p.qkv[(long)tokl[16 * i + 4 * g + e] * N3 + cv] = x;
+            if (ok && p.qkv) p.qkv[(long)tokl[16 * i + 4 * g + e] * N3 + cv] = x;
           }
         }
         mx = w3_max4(mx);
@@ -888,6 +888,8 @@ int sr_wmsa_f16(WmsaF16Args& p, hipStream_t st) {
   SR_REQUIRE((long)p.B * p.H * p.W < (1L << 31), "wmsa_f16x2: more than 2^31 tokens");
   const int D = p.C / p.heads;
   SR_REQUIRE(D == 30 || D == 10 || D == 16 || D == 32, "wmsa_f16x2: head dim %d not built", D);
+  SR_REQUIRE(p.qkv || p.heads == 5 || p.heads == 6,
+             "wmsa_f16x2: qkv may be omitted (inference) only with 5 or 6 heads: the four-wave kernel reads it back");
   p.Kp = sr_kp(p.C);
 #ifdef SRHIP_EXPERIMENTS
   p.dbg = g_wmsa_dbg;

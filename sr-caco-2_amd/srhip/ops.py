@@ -582,7 +582,8 @@ def wmsa_fwd_f16(x, stats, Wq, bq, Wp, bp, biasF, qkv, att, out, B, H, W, heads,
     _chk(x, stats, bq, bp, biasF, qkv, att, out, rowscale, stats_out)
     T, C = x.shape
     assert T == B * H * W and Wq.fmt == 1 and Wp.fmt == 1 and (Wq.rows, Wq.K) == (3 * C, C) and (Wp.rows, Wp.K) == (C, C)
-    assert qkv.shape == (T, 3 * C) and att.shape == (T, C) and out.shape == (T, C)
+    assert (qkv is None and heads in (5, 6)) or qkv.shape == (T, 3 * C)      # None (inference): q, k, v stay in registers
+    assert att.shape == (T, C) and out.shape == (T, C)
     assert rowscale is None or rowscale.numel() == B
     args = (_p(x), _p(stats), _p(Wq.planes), _p(bq), _p(Wp.planes), _p(bp), _p(biasF), _p(rowscale), _p(qkv),
             _p(att), _p(out), _p(stats_out), B, H, W, C, heads, shift, _st())

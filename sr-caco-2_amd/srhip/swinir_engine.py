@@ -293,7 +293,9 @@ class SwinIREngine:
                 if st1 is None:
                     st1 = buf(f"{k}.st1", T, 2)
                     ops.layernorm_fwd(t, st1)
-                qkv = buf(f"{k}.qkv", T, 3 * C)
+                # inference with 5 / 6 heads: the fused kernel keeps q, k, v in registers and writes no qkv at all
+                no_qkv = (not save) and self.fuse_wmsa and fuse and heads in (5, 6)
+                qkv = None if no_qkv else buf(f"{k}.qkv", T, 3 * C)
                 a = buf(f"{k}.a", T, C)
                 x1 = buf(f"{k}.x1", T, C)
                 st2 = buf(f"{k}.st2", T, 2)

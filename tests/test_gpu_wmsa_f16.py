@@ -105,6 +105,10 @@ def test_wmsa_f16_forward(ops, B, H, W, C, heads, shift, drop):
     out2 = torch.empty_like(out)
     ops.wmsa_fwd_f16(d["x"], st, Pq, bqf, Pp, d["bp"], biasF, qkv, att, out2, B, H, W, heads, shift, rowscale=sd)
     assert torch.equal(out2, out)
+    if heads in (5, 6):      # inference form: q, k, v stay in the registers of the head's wave, no qkv is written
+        out3, att3 = torch.empty_like(out), torch.empty_like(att)
+        ops.wmsa_fwd_f16(d["x"], st, Pq, bqf, Pp, d["bp"], biasF, None, att3, out3, B, H, W, heads, shift, rowscale=sd)
+        assert torch.equal(out3, out) and torch.equal(att3, att)
 
     # the three launches it replaces
     if ops.wattn_f16_ok(C, heads):
