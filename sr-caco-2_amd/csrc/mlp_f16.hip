@@ -112,8 +112,11 @@ __device__ __forceinline__ void gelu_gate2(sr_f32x2 x, sr_f32x2& gate, sr_f32x2&
   gl = x * cdf;
 }
 
-template <bool BWD>
+// AMP (forward only; srhip_set_matmul_mode(1): inference under --amp): ONE product of the leading fp16 planes -- no lo
+// planes are staged, loaded or multiplied: a third of the matrix-core work, half of the stage-image and weight traffic
+template <bool BWD, bool AMP = false>
 __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
+  constexpr int NPL = AMP ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const smax = (float*)(smem + R0);           // [4 waves][64 tokens] maxima of |A2|
   float* const rinvx = smax + 256;                   // [64] 2^-s of the X rows (backward; forward: a constant)
@@ -147,14 +150,14 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     const int hh = u / 6, s = min(u - 6 * hh, nst1 - 1);
     const char* base = (const char*)p.W1 + (long)(2 * s) * p.N1 * 32;
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
       for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane1 + (hh ? boff1[1][jt] : boff1[0][jt]));
   };
   auto load_b2 = [&](int cs, u32x4 (&fb)[3][2]) {
     const char* base = (const char*)p.W2 + (long)(2 * min(cs, nst2 - 1)) * p.N2 * 32;
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
       for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane2 + boff2[jt]);
   };
@@ -418,7 +421,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       }
       unsigned char* sa = smem + s6 * AST + a_dst;
       *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
-      *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+      if (!AMP) *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
     }
   }
   }
@@ -440,10 +443,14 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     for (int i = 0; i < 4; ++i) {
       u32x4 fa[2];
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off[i]);
+      for (int pl = 0; pl < NPL; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off[i]);
 #define SR_TERM(PA, PB) \
   _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[i][j] = mfma16h(fb[j][PB], fa[PA], acc[i][j]);
-      SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)          // small terms first
+      if constexpr (AMP) {
+        SR_TERM(0, 0)
+      } else {
+        SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)          // small terms first
+      }
 #undef SR_TERM
     }
   };
@@ -582,7 +589,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
         split2_pair(v[2] * use[i], v[3] * use[i], h1, l1);
         unsigned char* sa = smem + s6 * AST + a_slot(16 * i + c, u) * 16 + pos * 2;
         *(u32x2*)(sa) = u32x2{h0, h1};
-        *(u32x2*)(sa + APL) = u32x2{l0, l1};
+        if (!AMP) *(u32x2*)(sa + APL) = u32x2{l0, l1};
       }
     }
   };
@@ -592,10 +599,14 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     for (int i = 0; i < 4; ++i) {
       u32x4 fa[2];
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off[i]);
+      for (int pl = 0; pl < NPL; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off[i]);
 #define SR_TERM(PA, PB) \
   _Pragma("unroll") for (int j = 0; j < 3; ++j) acc2[i][j] = mfma16h(fa[PA], fb[j][PB], acc2[i][j]);
-      SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      if constexpr (AMP) {
+        SR_TERM(0, 0)
+      } else {
+        SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      }
 #undef SR_TERM
     }
   };
@@ -790,6 +801,7 @@ int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st) {
              "mlp_f16x2: row pitches must be multiples of 4 floats");
   dim3 grid(sr_cdiv(p.M, BM));
   if (bwd) hipLaunchKernelGGL(k_mlp_f16<true>, grid, dim3(256), MLP_LDS, st, p);
+  else if (sr_matmul_mode() == 1) hipLaunchKernelGGL((k_mlp_f16<false, true>), grid, dim3(256), MLP_LDS, st, p);     // inference under --amp
   else hipLaunchKernelGGL(k_mlp_f16<false>, grid, dim3(256), MLP_LDS, st, p);
   SR_LAUNCH_CHECK("k_mlp_f16");
   return 0;

@@ -409,8 +409,11 @@ __global__ void __launch_bounds__(64 * NW * WPB, NW / 2) k_wmsa_f16(WmsaF16Args 
 constexpr int TABP = 228;              // pitch of a head's bias table
 constexpr int WMSA_LDSH = R0 + (64 + 64 + 2 * 3 * 192 + 64 + 6 * TABP + 6 * 96) * 4;
 
-template <int D, int WPB>
+// AMP (srhip_set_matmul_mode(1): inference under --amp): one product of the leading fp16 planes everywhere -- no lo plane is
+// staged, loaded or multiplied
+template <int D, int WPB, bool AMP = false>
 __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
+  constexpr int NPL = AMP ? 1 : 2;
   constexpr int NW = 6, NT = 64 * NW, CW = 32, NJ = 2, NIT = 3072 / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int grp = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT);
@@ -477,7 +480,7 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
         }
         unsigned char* sa = smem + s6 * AST + a_dst;
         *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
-        *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+        if (!AMP) *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
       }
     }
   }
@@ -495,7 +498,7 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
     auto load_w = [&](int ct, int s, u32x4 (&fb)[NJ][2]) {
       const char* base = (const char*)p.Wqkv + (long)(2 * s) * N3 * 32 + (long)ct * C * 32;
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
+      for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * planeq + wofs[jt]);
     };
@@ -513,11 +516,15 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
         for (int i = 0; i < 4; ++i) {
           u32x4 fa[2];
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off0 + 1024 * i);
+          for (int pl = 0; pl < NPL; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off0 + 1024 * i);
 #define SR_TERM(PA, PB)                                                                      \
   _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = TR ? mfma16h(fb[j][PB], fa[PA], acc[i][j]) \
                                                                  : mfma16h(fa[PA], fb[j][PB], acc[i][j]);
-          SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)          // small terms first
+          if constexpr (AMP) {
+            SR_TERM(0, 0)
+          } else {
+            SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)          // small terms first
+          }
 #undef SR_TERM
         }
       };
@@ -628,8 +635,10 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
 #pragma unroll
       for (int J = 0; J < 4; ++J) {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-        a = mfma16h(kh[J], ql[I], a);
-        a = mfma16h(kl[J], qh[I], a);
+        if (!AMP) {
+          a = mfma16h(kh[J], ql[I], a);
+          a = mfma16h(kl[J], qh[I], a);
+        }
         a = mfma16h(kh[J], qh[I], a);
         const float* tb = tb0 + 30 * (I - J);
         const bool masked = lane_masked || (geo.last_row && ((I >> 1) != (J >> 1)));
@@ -668,8 +677,10 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
         const u32x4 ph = u32x4{h[0], h[1], h[2], h[3]}, pl = u32x4{l[0], l[1], l[2], l[3]};
 #pragma unroll
         for (int jd = 0; jd < 2; ++jd) {
-          O[jd] = mfma16h(vh[JJ][jd], pl, O[jd]);
-          O[jd] = mfma16h(vl[JJ][jd], ph, O[jd]);
+          if (!AMP) {
+            O[jd] = mfma16h(vh[JJ][jd], pl, O[jd]);
+            O[jd] = mfma16h(vl[JJ][jd], ph, O[jd]);
+          }
           O[jd] = mfma16h(vh[JJ][jd], ph, O[jd]);
         }
       }
@@ -723,7 +734,7 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
             split2_pair(ov[I][jd][2 * h2] * asc, ov[I][jd][2 * h2 + 1] * asc, hh, ll);
             unsigned char* dst = smem + s6 * AST + a_slot(row, kk >> 3) * 16 + (kk & 7) * 2;
             *(unsigned*)dst = hh;
-            *(unsigned*)(dst + APL) = ll;
+            if (!AMP) *(unsigned*)(dst + APL) = ll;
           }
         }
       }
@@ -735,7 +746,7 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
       const int row = idx / npad, k = C + 2 * (idx - row * npad), s6 = k >> 5, kk = k & 31;
       unsigned char* dst = smem + s6 * AST + a_slot(row, kk >> 3) * 16 + (kk & 7) * 2;
       *(unsigned*)dst = 0u;
-      *(unsigned*)(dst + APL) = 0u;
+      if (!AMP) *(unsigned*)(dst + APL) = 0u;
     }
   }
   SR_TS(5)
@@ -753,7 +764,7 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
   auto load_bp = [&](int s, u32x4 (&fb)[NJ][2]) {
     const char* base = (const char*)p.Wproj + (long)(2 * min(s, nst - 1)) * C * 32;
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
       for (int jt = 0; jt < NJ; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * planep + boffp[jt]);
   };
@@ -778,10 +789,14 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
     for (int i = 0; i < 4; ++i) {
       u32x4 fa[2];
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off40 + 1024 * i);
+      for (int pl = 0; pl < NPL; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off40 + 1024 * i);
 #define SR_TERM(PA, PB) \
   _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc2[i][j] = mfma16h(fa[PA], fb[j][PB], acc2[i][j]);
-      SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      if constexpr (AMP) {
+        SR_TERM(0, 0)
+      } else {
+        SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+      }
 #undef SR_TERM
     }
   };
@@ -897,6 +912,7 @@ int sr_wmsa_f16(WmsaF16Args& p, hipStream_t st) {
   p.scale = 1.0f / sqrtf((float)D);
   const int nwin = p.B * (p.H / 8) * (p.W / 8);
   bool six = p.heads == 5 || p.heads == 6;
+  const bool amp = sr_matmul_mode() == 1;          // inference under --amp (5 / 6 heads: one product of the leading planes)
   if (const char* e = sr_getenv("SRHIP_WMSA_NW")) six = six && e[0] == '6';      // experiment builds only
 #define SR_WA(D_)                                                                                              \
   if (D == D_) {                                                                                               \
@@ -904,11 +920,14 @@ int sr_wmsa_f16(WmsaF16Args& p, hipStream_t st) {
       static bool attr = false;                                                                                \
       if (!attr) {                                                                                             \
         if (hipFuncSetAttribute((const void*)k_wmsa_f16h<D_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                2 * WMSA_LDSH) != hipSuccess ||                                                \
+            hipFuncSetAttribute((const void*)k_wmsa_f16h<D_, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 2 * WMSA_LDSH) != hipSuccess)                                                  \
           return sr_fail(-5, "wmsa_f16x2: cannot reserve %d bytes of LDS", 2 * WMSA_LDSH);                     \
         attr = true;                                                                                           \
       }                                                                                                        \
-      hipLaunchKernelGGL((k_wmsa_f16h<D_, 2>), dim3(sr_cdiv(nwin, 2)), dim3(768), 2 * WMSA_LDSH, st, p);       \
+      if (amp) hipLaunchKernelGGL((k_wmsa_f16h<D_, 2, true>), dim3(sr_cdiv(nwin, 2)), dim3(768), 2 * WMSA_LDSH, st, p); \
+      else hipLaunchKernelGGL((k_wmsa_f16h<D_, 2>), dim3(sr_cdiv(nwin, 2)), dim3(768), 2 * WMSA_LDSH, st, p);  \
     } else {                                                                                                   \
       hipLaunchKernelGGL((k_wmsa_f16<D_, 4, 1>), dim3(nwin), dim3(256), WMSA_LDS, st, p);                      \
     }                                                                                                          \
