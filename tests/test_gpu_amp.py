@@ -160,3 +160,54 @@ def test_amp_flag_leaves_training_untouched():
         y.abs().mean().backward()
         outs.append((y.detach().clone(), net.body[0].body[0].weight.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+REGISTRY_AMP = [("DBPN", "DBPN"), ("SRFBN", "SRFBN"), ("ProSR", "PROSR"), ("NLSN", "NLSN"), ("DFCAN", "DFCAN"),
+                ("SRCNN", "SRCNN"), ("ENLCN", "ENLCN"), ("ACT", "ACT"), ("GRL", "GRL"), ("OmniSR", "OmniSR")]
+
+
+@pytest.mark.parametrize("scale", [2, 4, 8])
+@pytest.mark.parametrize("net_type,method", REGISTRY_AMP)
+def test_amp_inference_psnr_gate_registry_nets(net_type, method, scale):
+    """Config 5's gate for the rest of the registry, every scale: ``--amp True`` against the f32-accurate forward of the
+    SAME weights through the CLI's construction path (main.parse_input / define_model / model.test()): PSNR against the
+    target within 0.01 dB.  NLSN draws its LSH rotations per forward: both forwards run from one seed."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "sr-caco-2_amd"))
+    import main as M
+    from dlib.models.select_model import define_model
+    argv = ["--net_type", net_type, "--method", method, "--task", "super-resolution", "--scale", str(scale),
+            "--n_channels", "1", "--h_size", "256", "--batch_size", "1", "--outd", "/tmp/srhip_amp_gate"]
+    outs = {}
+    sd = None
+    batch = None
+    for amp in (False, True):
+        args = M.parse_input(argv + ["--amp", str(amp)])
+        torch.manual_seed(0)
+        model = define_model(args)
+        if sd is None:
+            sd = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
+            batch = M.synth_batch(1, scale, 256, model.device, 21)
+        else:
+            model.netG.load_state_dict(sd, strict=True)
+            model.netG.weights_changed()
+        model.netG.eval()
+        model.feed_data(batch)
+        torch.manual_seed(5)
+        model.test()
+        outs[amp] = model.E.detach().float().cpu().clone()
+        took = bool(getattr(model.netG, "amp", False) and getattr(model.netG, "amp_takes_effect", True))
+        del model
+        torch.cuda.empty_cache()
+    hr = batch["h_im"].cpu()
+    assert torch.isfinite(outs[False]).all() and torch.isfinite(outs[True]).all()
+    # freshly initialised weights can leave the image range (DBPN x2: |y| up to 6): PSNR clamps to [0, 1], so both outputs
+    # are brought back into range by the SAME factor first (the gate stays a statement about relative precision)
+    rng = max(1.0, outs[False].abs().max().item())
+    outs = {k: v / rng for k, v in outs.items()}
+    gap = (psnr(outs[False], hr, scale) - psnr(outs[True], hr, scale)).abs().max().item()
+    mae = (outs[False] - outs[True]).abs().mean().item()
+    print(f"{net_type} x{scale}: amp vs fp32 MAE {mae:.2e} (|y| max {outs[False].abs().max().item():.2f}), PSNR gap {gap:.5f} dB, "
+          f"reduced-precision kernels taken: {took}")
+    assert gap <= 0.01, (net_type, scale, gap)
