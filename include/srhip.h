@@ -355,6 +355,18 @@ int srhip_l2norm_rows(float* x, long ld, long T, int C, float eps, float k, void
 int srhip_performer_features(float* dash, long ldd, const float* data, long ldx, long T, int F, int C, float ratio, float eps,
                              void* stream);
 int srhip_enlca_finish(const float* num, long ldn, const float* x, float* out, long T, int Cy, float res_scale, void* stream);
+/* Their autograd (ENLCA trains through the reference's one step, model_plain.py:318-396; the dense products in between are
+ * srhip_gemm_nt* / srhip_linear_wgrad*):
+ *   srhip_l2norm_rows_train      as srhip_l2norm_rows, also factors[t] = k / max(|x[t]|, eps)
+ *   srhip_l2norm_rows_bwd        dy[t] <- f (dy[t] - y[t] (y[t] . dy[t]) / k^2)  (f dy[t] where the norm was clamped), in place
+ *   srhip_performer_features_bwd g <- g (f - ratio eps): the gradient with respect to dash, in place (n = elements, % 4 == 0)
+ *   srhip_enlca_finish_bwd       dnum[t][c] = s dout[t][c] (c < Cy), dnum[t][Cy] = -sum_c s dout[t][c] num[t][c] / num[t][Cy],
+ *                                s = res_scale / num[t][Cy]; columns past Cy zero */
+int srhip_l2norm_rows_train(float* x, long ld, long T, int C, float eps, float k, float* factors, void* stream);
+int srhip_l2norm_rows_bwd(float* dy, long ldd, const float* y, long ldy, const float* factors, long T, int C, float eps, float k,
+                          void* stream);
+int srhip_performer_features_bwd(float* g, const float* f, long n, float ratio_eps, void* stream);
+int srhip_enlca_finish_bwd(const float* dout, const float* num, long ldn, float* dnum, long T, int Cy, float res_scale, void* stream);
 
 /* ---- Non-Local Sparse Attention of NLSN, evaluation forward (nlsa.hip) --------------
  * NonLocalSparseAttention.forward, dlib/models/network_nlsn.py:131-268, token-major (channels last):

@@ -1386,6 +1386,49 @@ def g_enlcn():
     npz("g33_enlcn", **out)
 
 
+def g_enlcn_grad():
+    """ENLCN training step of the reference (model_plain.py:318-396 drives every registry net through the same step):
+    the narrow configuration of g33 in TRAINING mode, L1 loss against a random target, autograd -> the gradient of every
+    parameter.  (ENLCA's contrastive term is computed by the reference in training mode and dropped, :434-437: it reaches
+    no gradient.)  The oracle's own autograd must reproduce them."""
+    print("G39 ENLCN gradients")
+    from dlib.models.network_enlcn import ENLCN as RefENLCN
+    out = {}
+    cfg = dict(n_resblock=8, n_feats=64)
+    for scale in (2,):
+        sd = O.enlcn_init_state_dict(scale, 1, seed=390 + scale, **cfg)
+        net = RefENLCN(upscale=scale, in_chans=1, **cfg)
+        net.load_state_dict(sd, strict=True)
+        net.train()
+        torch.manual_seed(395 + scale)
+        x = torch.rand(2, 1, 16, 24)
+        tgt = torch.rand(2, 1, 16 * scale, 24 * scale)
+        y = net(x)
+        loss = (y - tgt).abs().mean()
+        loss.backward()
+        sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 else v) for k, v in sd.items()}
+        yo = O.enlcn_forward(sdo, x, scale, cfg["n_resblock"], 0.1)
+        (yo - tgt).abs().mean().backward()
+        close(yo, y, 0.0, f"enlcn x{scale} training forward")
+        pre = f"x{scale}/"
+        out[pre + "x"], out[pre + "tgt"], out[pre + "y"], out[pre + "loss"] = x, tgt, y, loss.detach()
+        out[pre + "seed"] = np.array(390 + scale)
+        n = 0
+        for k, p_ in net.named_parameters():
+            if not p_.requires_grad:
+                continue
+            assert p_.grad is not None, k
+            g_o = sdo[k].grad
+            assert g_o is not None, k
+            close(g_o, p_.grad, 1e-7 * max(1.0, p_.grad.abs().max().item()), f"enlcn x{scale} grad {k}") if n < 3 else None
+            err = (g_o - p_.grad).abs().max().item()
+            assert err <= 1e-6 * max(1e-3, p_.grad.abs().max().item()), (k, err)
+            out[pre + "grad/" + k] = p_.grad
+            n += 1
+        print(f"  {n} parameter gradients, oracle autograd == reference autograd")
+    npz("g39_enlcn_grad", **out)
+
+
 def g_nlsn():
     """NLSN (network_nlsn.py): EDSR body with Non-Local Sparse Attention.  Narrow configuration (8 ResBlocks, 64 features:
     attention at body.0 and body.9, 16-dim matching embedding, 4 hash rounds, chunks of 144) on inputs with and without
@@ -1829,7 +1872,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_grl, g_omnisr, g_act, g_dfcan, g_nlsn, g_enlcn, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_grl, g_omnisr, g_act, g_dfcan, g_nlsn, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(256) k_crop1(const float* __restrict__ in, flo
 
 // ---- ENLCA (network_enlcn.py:207-366): the element-wise pieces around its GEMMs; one wave per row
 // F.normalize(x, p=2, dim=channel, eps) * k on token rows
-__global__ void __launch_bounds__(256) k_l2norm_rows(float* __restrict__ x, long ld, long T, int C, float eps, float k) {
+__global__ void __launch_bounds__(256) k_l2norm_rows(float* __restrict__ x, long ld, long T, int C, float eps, float k,
+                                                     float* __restrict__ fac) {
   const long t = blockIdx.x * 4L + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (t >= T) return;
@@ -138,6 +139,53 @@ __global__ void __launch_bounds__(256) k_l2norm_rows(float* __restrict__ x, long
   for (int c = lane; c < C; c += 64) ss += r[c] * r[c];
   const float f = k / fmaxf(sqrtf(wave_sum(ss)), eps);
   for (int c = lane; c < C; c += 64) r[c] *= f;
+  if (fac && lane == 0) fac[t] = f;               // training: the row's factor k / max(|x|, eps) for the backward
+}
+// backward of y = f x, f = k / max(|x|, eps):  dx = f (dy - y (y . dy) / k^2)  (|x| >= eps: the projection off the radial
+// direction);  dx = f dy where the norm was clamped (f = k / eps).  In place on dy.
+__global__ void __launch_bounds__(256) k_l2norm_rows_bwd(float* __restrict__ dy, long ldd, const float* __restrict__ y, long ldy,
+                                                         const float* __restrict__ fac, long T, int C, float eps, float k) {
+  const long t = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= T) return;
+  float* d = dy + t * ldd;
+  const float* r = y + t * ldy;
+  const float f = fac[t];
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) dot += r[c] * d[c];
+  dot = wave_sum(dot);
+  const float s = (f < k / eps) ? dot / (k * k) : 0.f;
+  for (int c = lane; c < C; c += 64) d[c] = f * (d[c] - r[c] * s);
+}
+// backward of f = ratio (exp(dash - diag) + eps) with respect to dash: g (f - ratio eps), in place on g.  (The diag = |data|^2 / 2
+// path is a gradient along data itself: the L2 normalisation in front of it projects exactly that direction out.)
+__global__ void __launch_bounds__(256) k_performer_features_bwd(float* __restrict__ g, const float* __restrict__ f, long n, float c) {
+  const long i = (blockIdx.x * 256L + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 gv = *(const f32x4*)(g + i);
+  const f32x4 fv = *(const f32x4*)(f + i);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) gv[e] *= fv[e] - c;
+  *(f32x4*)(g + i) = gv;
+}
+// backward of out = x + res_scale num[:, :Cy] / num[:, Cy] with respect to num (the residual path is dout itself):
+//   dnum[:, c] = s dout[c], s = res_scale / den;  dnum[:, Cy] = -sum_c s dout[c] num[c] / den;  dnum[:, Cy + 1 ..] = 0
+__global__ void __launch_bounds__(256) k_enlca_finish_bwd(const float* __restrict__ dout, const float* __restrict__ num, long ldn,
+                                                          float* __restrict__ dnum, long T, int Cy, float res_scale) {
+  const long t = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= T) return;
+  const float* r = num + t * ldn;
+  float* o = dnum + t * ldn;
+  const float den = r[Cy], s = res_scale / den;
+  float acc = 0.f;
+  for (int c = lane; c < Cy; c += 64) {
+    const float d = s * dout[t * Cy + c];
+    o[c] = d;
+    acc += d * r[c];
+  }
+  acc = wave_sum(acc);
+  for (int c = Cy + lane; c < (int)ldn; c += 64) o[c] = c == Cy ? -acc / den : 0.f;
 }
 // softmax_kernel :207-240: out[t][j] = ratio (exp(dash[t][j] - |data[t]|^2 / 2) + eps)
 __global__ void __launch_bounds__(256) k_performer_features(float* __restrict__ dash, long ldd, const float* __restrict__ data,
@@ -212,8 +260,37 @@ int srhip_crop1(const float* in, float* out, int B, int H, int W, int C, int adj
 
 int srhip_l2norm_rows(float* x, long ld, long T, int C, float eps, float k, void* stream) {
   SR_REQUIRE(x && T > 0 && C > 0 && ld >= C, "l2norm_rows: bad arguments");
-  hipLaunchKernelGGL(k_l2norm_rows, dim3(sr_cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, T, C, eps, k);
+  hipLaunchKernelGGL(k_l2norm_rows, dim3(sr_cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, T, C, eps, k, (float*)nullptr);
   SR_LAUNCH_CHECK("l2norm_rows");
+  return 0;
+}
+
+int srhip_l2norm_rows_train(float* x, long ld, long T, int C, float eps, float k, float* factors, void* stream) {
+  SR_REQUIRE(x && factors && T > 0 && C > 0 && ld >= C && eps > 0.f, "l2norm_rows_train: bad arguments");
+  hipLaunchKernelGGL(k_l2norm_rows, dim3(sr_cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, T, C, eps, k, factors);
+  SR_LAUNCH_CHECK("l2norm_rows_train");
+  return 0;
+}
+
+int srhip_l2norm_rows_bwd(float* dy, long ldd, const float* y, long ldy, const float* factors, long T, int C, float eps, float k,
+                          void* stream) {
+  SR_REQUIRE(dy && y && factors && T > 0 && C > 0 && ldd >= C && ldy >= C && eps > 0.f, "l2norm_rows_bwd: bad arguments");
+  hipLaunchKernelGGL(k_l2norm_rows_bwd, dim3(sr_cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, dy, ldd, y, ldy, factors, T, C, eps, k);
+  SR_LAUNCH_CHECK("l2norm_rows_bwd");
+  return 0;
+}
+
+int srhip_performer_features_bwd(float* g, const float* f, long n, float ratio_eps, void* stream) {
+  SR_REQUIRE(g && f && n > 0 && n % 4 == 0, "performer_features_bwd: n = %ld (positive multiple of 4)", n);
+  hipLaunchKernelGGL(k_performer_features_bwd, dim3(sr_cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, g, f, n, ratio_eps);
+  SR_LAUNCH_CHECK("performer_features_bwd");
+  return 0;
+}
+
+int srhip_enlca_finish_bwd(const float* dout, const float* num, long ldn, float* dnum, long T, int Cy, float res_scale, void* stream) {
+  SR_REQUIRE(dout && num && dnum && T > 0 && Cy > 0 && ldn > Cy, "enlca_finish_bwd: bad arguments");
+  hipLaunchKernelGGL(k_enlca_finish_bwd, dim3(sr_cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, dout, num, ldn, dnum, T, Cy, res_scale);
+  SR_LAUNCH_CHECK("enlca_finish_bwd");
   return 0;
 }
 

@@ -3,8 +3,8 @@ constructor, ``forward((B,1,h,w) in [0,1]) -> (B,1,s*h,s*w)`` and the reference'
 (``sub_mean.* / add_mean.*`` -- the frozen MeanShift convs, built but not applied :423,441 --, ``head.0.*``,
 ``body.{i}.conv_match1.0.* ... body.{i}.attn_fn.projection_matrix`` for the ENLCA blocks, ``body.{i}.body.{0,2}.*`` for
 the ResBlocks, ``tail.0.{0,2,4}.*``, ``tail.1.*``): released weights load with strict=True.  The compute is
-``srhip.enlcn_engine.ENLCNEngine`` (tape graph over the libsrhip kernels).  Evaluation only: ENLCA's backward is not built
-(``backward`` raises); 1-channel inputs; GPU only."""
+``srhip.enlcn_engine.ENLCNEngine`` (tape graph over the libsrhip kernels): evaluation and training (ENLCA's autograd:
+srhip.tape.Tape.enlca; gradients pinned against the reference's, tests/golden/g39_enlcn_grad.npz); 1-channel inputs; GPU only."""
 import math
 
 import torch

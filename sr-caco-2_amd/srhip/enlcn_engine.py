@@ -1,7 +1,8 @@
 """ENLCN as a tape graph (reference dlib/models/network_enlcn.py:369-448): head conv; body = ENLCA, n_resblock ResBlocks
 (conv-ReLU-conv, x res_scale, + x) with an ENLCA behind every eighth, a conv; long skip; Upsampler (conv F -> 4F +
 PixelShuffle(2) per factor of two) and the output conv.  The F -> 4F convs run as four 3x3 convs of F output channels
-(the conv kernels take up to 256 output columns) written side by side.  Inference only: ENLCA has no backward here."""
+(the conv kernels take up to 256 output columns) written side by side, their gradients into the matching rows of the
+parameter's.  Trains through the tape's derived backward (ENLCA: Tape.enlca)."""
 import math
 
 from .tape import TapeEngine
@@ -57,10 +58,8 @@ class ENLCNEngine(TapeEngine):
                 res = t.conv(res, f"body.{i}", (f"body.{i}.weight", f"body.{i}.bias"))
         res = t.axpby(res, x, 1.0, 1.0)
         for st in range(int(math.log2(net.upscale))):
-            names = (f"tail.0.{2 * st}.weight", f"tail.0.{2 * st}.bias")
-            res = t.shuffle(t.cat([t.conv(res, f"tail.0.{2 * st}.{j}", names) for j in range(4)]), 2)
+            F = net.n_feats
+            res = t.shuffle(t.cat([t.conv(res, f"tail.0.{2 * st}.{j}", (f"tail.0.{2 * st}.weight", f"tail.0.{2 * st}.bias",
+                                                                       (j * F, (j + 1) * F))) for j in range(4)]), 2)
         return t.conv_out1(res, net.tail[1].weight, net.tail[1].bias, ("tail.1.weight", "tail.1.bias"))
 
-    def backward(self, *a, **k):
-        raise NotImplementedError("ENLCN on libsrhip: inference only (BASELINE config 5's evaluation sweep); training it "
-                                  "needs the backward of ENLCA, which is not built")

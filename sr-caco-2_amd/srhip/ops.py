@@ -307,6 +307,39 @@ def l2norm_rows_(x, k=1.0, eps=5e-5):
     return x
 
 
+def l2norm_rows_train_(x, factors, k=1.0, eps=5e-5):
+    """l2norm_rows_ that also leaves factors[t] = k / max(|x[t]|, eps) for l2norm_rows_bwd_."""
+    _chk(x, factors)
+    assert x.dim() == 2 and x.stride(1) == 1 and factors.numel() == x.shape[0]
+    call("srhip_l2norm_rows_train", _p(x), x.stride(0), x.shape[0], x.shape[1], float(eps), float(k), _p(factors), _st())
+    return x
+
+
+def l2norm_rows_bwd_(dy, y, factors, k=1.0, eps=5e-5):
+    """dy <- the gradient with respect to the un-normalised rows (y = the normalised rows, factors from the forward)."""
+    _chk(dy, y, factors)
+    assert dy.shape == y.shape and dy.stride(1) == y.stride(1) == 1
+    call("srhip_l2norm_rows_bwd", _p(dy), dy.stride(0), _p(y), y.stride(0), _p(factors), dy.shape[0], dy.shape[1], float(eps),
+         float(k), _st())
+    return dy
+
+
+def performer_features_bwd_(g, f, eps=1e-4):
+    """g <- g * (f - F^-1/2 eps): gradient of performer_features_ with respect to its `dash` argument."""
+    _chk(g, f)
+    assert g.shape == f.shape and g.is_contiguous() and f.is_contiguous() and g.numel() % 4 == 0
+    call("srhip_performer_features_bwd", _p(g), _p(f), g.numel(), float(f.shape[1]) ** -0.5 * float(eps), _st())
+    return g
+
+
+def enlca_finish_bwd(dout, num, dnum, res_scale):
+    _chk(dout, num, dnum)
+    T, Cy = dout.shape
+    assert dout.is_contiguous() and num.shape == dnum.shape and num.is_contiguous() and dnum.is_contiguous() and num.shape[1] > Cy
+    call("srhip_enlca_finish_bwd", _p(dout), _p(num), num.stride(0), _p(dnum), T, Cy, float(res_scale), _st())
+    return dnum
+
+
 def performer_features_(dash, data, eps=1e-4):
     """dash[t][j] <- F^-1/2 (exp(dash[t][j] - |data[t]|^2 / 2) + eps), F = dash.shape[1] (softmax_kernel,
     network_enlcn.py:207-240)."""

@@ -266,10 +266,17 @@ class Tape:
     def begin_backward(self, grads):
         self.grads, self._written = grads, set()
 
-    def gparam(self, name, producer, shape=None):
+    def gparam(self, name, producer, shape=None, rows=None):
+        """rows = (lo, hi): the producer fills rows lo .. hi - 1 of the parameter's gradient (a conv run as slices of its
+        output channels: ENLCN's F -> 4F upsampler convs)."""
         gt = self.grads[name]
-        if name not in self._written:
+        key = name
+        if rows is not None:
+            gt = gt[rows[0]:rows[1]]
+            key = (name, rows[0])
             self._written.add(name)
+        if key not in self._written:
+            self._written.add(key)
             producer(gt)
         else:
             tmp = self._tmp(*gt.shape)
@@ -296,9 +303,10 @@ class Tape:
                 ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1])
         out = self._out(y)
         if self.save:
-            wname, bname = names
+            wname, bname = names[0], names[1]
+            rows = names[2] if len(names) > 2 else None          # this conv = output channels rows[0] .. rows[1] - 1 of the parameter
 
-            def bwd(x=x, out=out, e=e, wname=wname, bname=bname):
+            def bwd(x=x, out=out, e=e, wname=wname, bname=bname, rows=rows):
                 g = out.g
                 if g is None:
                     return
@@ -327,9 +335,9 @@ class Tape:
                     self.acc(x, dgrad1)
                     return
                 if e.kind == "c3":
-                    self.gparam(wname, lambda o, dW=dW: o.copy_(dW))
+                    self.gparam(wname, lambda o, dW=dW: o.copy_(dW), rows=rows)
                     if bname:
-                        self.gparam(bname, lambda o, db=db: o.copy_(db))
+                        self.gparam(bname, lambda o, db=db: o.copy_(db), rows=rows)
                 elif e.kind == "deconv":
                     Co = e.Co // (e.s * e.s)
                     self.gparam(wname, lambda o, dW=dW: o.copy_(collapse_deconv(dW, e.Ci, Co, e.s, e.k, e.p)))
@@ -353,9 +361,12 @@ class Tape:
         return out
 
     def enlca(self, x, keys, proj, res_scale):
-        """ENLCA in evaluation mode (network_enlcn.py:330-366): keys = bank entries of conv_match1 / conv_match2 /
+        """ENLCA (network_enlcn.py:330-366): keys = bank entries (= parameter name prefixes) of conv_match1 / conv_match2 /
         conv_assembly (1x1), proj = the stored projection matrix [F, d].  Linear attention as two dense products per
-        sample, the normaliser carried as one more column of the value matrix.  Inference only (the backward raises)."""
+        sample, the normaliser carried as one more column of the value matrix.  Training: the intermediates stay (embeddings,
+        normalisation factors, feature maps, per-sample context and numerator) and the backward runs the same products
+        transposed around three small elementwise kernels (srhip_enlca_finish_bwd, srhip_performer_features_bwd,
+        srhip_l2norm_rows_bwd); the contrastive term the reference computes in training mode is dropped by it (:434-437)."""
         e1, e2, e3 = (self.bank.d[k] for k in keys)
         B, H, W, C = x.t.shape
         T, L, d, Cy, Fn = B * H * W, H * W, e1.Co, e3.Co, proj.shape[0]
@@ -370,24 +381,73 @@ class Tape:
         ops.gemm_nt(x2, e2.w1, e2.bias, out=k)
         ops.gemm_nt(x2, e3.w1, e3.bias, out=vext[:, :Cy])
         kk = 6.0 ** 0.5
-        ops.l2norm_rows_(q, kk)
-        ops.l2norm_rows_(k, kk)
+        facq = fack = None
+        if self.save:
+            facq, fack = torch.empty(T, device=dev), torch.empty(T, device=dev)
+            ops.l2norm_rows_train_(q, facq, kk)
+            ops.l2norm_rows_train_(k, fack, kk)
+        else:
+            ops.l2norm_rows_(q, kk)
+            ops.l2norm_rows_(k, kk)
         pj = proj.contiguous()
         fq = ops.performer_features_(ops.gemm_nt(q, pj), q)
         fk = ops.performer_features_(ops.gemm_nt(k, pj), k)
         y = self.new(B, H, W, Cy)
         y2 = y.view(T, Cy)
-        ctx_t, colsum = torch.empty(Cy + 4, Fn, device=dev), torch.empty(Cy + 4, device=dev)
-        num = torch.empty(L, Cy + 4, device=dev)
+        colsum = torch.empty(Cy + 4, device=dev)
+        # inference: one context / numerator buffer serves every sample; training keeps them per sample
+        ctx_all = torch.empty(B if self.save else 1, Cy + 4, Fn, device=dev)
+        num_all = torch.empty(T if self.save else L, Cy + 4, device=dev)
         for b in range(B):
             rows = slice(b * L, (b + 1) * L)
+            ctx_t = ctx_all[b if self.save else 0]
+            num = num_all[rows] if self.save else num_all
             ops.linear_wgrad(vext[rows], fk[rows], ctx_t, colsum)          # [v | 1]^T k' = (context | sum k')^T
             ops.gemm_nt(fq[rows], ctx_t, None, out=num)
             ops.enlca_finish(num, x2[rows], y2[rows], res_scale)
         out = self._out(y)
         if self.save:
-            def bwd():
-                raise NotImplementedError("ENLCA on libsrhip: inference only (the evaluation sweep); no backward")
+            def bwd(x=x, out=out):
+                g = out.g
+                if g is None:
+                    return
+                g2 = (g if g.is_contiguous() else g.contiguous()).view(T, Cy)
+                dnum = torch.empty(T, Cy + 4, device=dev)
+                ops.enlca_finish_bwd(g2, num_all, dnum, res_scale)
+                dfq, dfk = torch.empty(T, Fn, device=dev), torch.empty(T, Fn, device=dev)
+                dvext = torch.empty(T, Cy + 4, device=dev)
+                dctx_t, junk = torch.empty(Cy + 4, Fn, device=dev), torch.empty(Cy + 4, device=dev)
+                for b in range(B):
+                    rows = slice(b * L, (b + 1) * L)
+                    ctx_t = ctx_all[b]
+                    # num = fq ctx_t^T, ctx_t = vext^T fk
+                    ops.gemm_nt(dnum[rows], ctx_t.t().contiguous(), None, out=dfq[rows])          # dfq = dnum ctx_t
+                    ops.linear_wgrad(dnum[rows], fq[rows], dctx_t, junk)                          # dctx_t = dnum^T fq
+                    ops.gemm_nt(fk[rows], dctx_t, None, out=dvext[rows])                          # dvext = fk dctx_t^T
+                    ops.gemm_nt(vext[rows], dctx_t.t().contiguous(), None, out=dfk[rows])         # dfk = vext dctx_t
+                ops.performer_features_bwd_(dfq, fq)                                              # -> d dash
+                ops.performer_features_bwd_(dfk, fk)
+                pjT = pj.t().contiguous()
+                dq, dk = ops.gemm_nt(dfq, pjT), ops.gemm_nt(dfk, pjT)                             # dash = data P^T
+                ops.l2norm_rows_bwd_(dq, q, facq, kk)
+                ops.l2norm_rows_bwd_(dk, k, fack, kk)
+                dv = dvext[:, :Cy].contiguous()
+                for e, dY, key in ((e1, dq, keys[0]), (e2, dk, keys[1]), (e3, dv, keys[2])):
+                    dW, db = torch.empty(e.Co, e.Ci, device=dev), torch.empty(e.Co, device=dev)
+                    ops.linear_wgrad(dY, x2, dW, db)
+                    self.gparam(key + ".0.weight", lambda o, dW=dW, e=e: o.view(e.Co, e.Ci).copy_(dW))
+                    self.gparam(key + ".0.bias", lambda o, db=db: o.copy_(db))
+
+                def dgrad(o):                       # d x = dq0 Wq + dk0 Wk + dv Wv + the residual's dout
+                    o2 = o.view(T, C)
+                    tmp = torch.empty(T, C, device=dev)
+                    ops.gemm_nt(dq, e1.w1T, None, out=o2)
+                    ops.gemm_nt(dk, e2.w1T, None, out=tmp)
+                    ops.axpby(o2, tmp, 1.0, 1.0)
+                    ops.gemm_nt(dv, e3.w1T, None, out=tmp)
+                    ops.axpby(o2, tmp, 1.0, 1.0)
+                    ops.axpby(o2, g2, 1.0, 1.0)
+                self.acc(x, dgrad)
             self.back.append(bwd)
         return out
 

@@ -224,9 +224,60 @@ def test_enlcn_forward_vs_reference_golden(scale):
     with torch.no_grad():
         y = net(x.cuda()).cpu()
     assert (y - yref).abs().mean().item() <= 1e-5 and rel(y, yref) < 2e-5, rel(y, yref)
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(x.cuda()).sum().backward()
+
+
+def test_enlcn_training_step_gradients_vs_reference_golden():
+    """ENLCN trains: forward in training mode, L1 loss, every parameter gradient of the narrow
+    configuration against the REFERENCE's own autograd (g39_enlcn_grad.npz: written by oracle/make_goldens.py::g_enlcn_grad
+    from the imported reference net, the oracle's autograd asserted equal) -- ENLCA's backward (1x1 embeddings, L2
+    normalisation, positive random features, linear attention with the normaliser column), ResBlocks, the F -> 4F upsampler
+    convs run as four output slices (gradients into the matching rows).  Gate: the library's 2e-5 of a tensor's largest
+    entry; ReLU decisions within rounding of zero are excused as in tests/test_gpu_fullsize.py by a 3x-the-fp32-oracle arm."""
+    from dlib.models.network_enlcn import ENLCN
+    from srhip.train import TrainStep, Optimizer
+    scale = 2
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g39_enlcn_grad").items() if k.startswith(f"x{scale}/")}
+    sd = O.enlcn_init_state_dict(scale, 1, 8, 64, seed=int(g["seed"]))
+    net = ENLCN(upscale=scale, in_chans=1, n_resblock=8, n_feats=64)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=0.0, momentum=0.0, nesterov=False, wd=0.0)        # lr 0: the gradients stay readable
+    x, tgt = g["x"], g["tgt"]
+    ts.step(x.cuda(), tgt.cuda())
+    assert abs(ts.loss_values()[0] - float(g["loss"])) <= 2e-6
+    # yardstick for ReLU flips: the fp32 oracle's own distance from an fp64 run
+    sd64 = {k: (v.double().requires_grad_(True) if v.dtype == torch.float32 and not k.startswith(("sub_mean", "add_mean"))
+                else v) for k, v in sd.items()}
+    (O.enlcn_forward(sd64, x.double(), scale, 8, 0.1) - tgt.double()).abs().mean().backward()
+    worst, n = 0.0, 0
+    for k in ts.fp.names:
+        ref = g["grad/" + k].double()
+        got = ts.fp.gviews[k].double().cpu()
+        den = ref.abs().max().clamp_min(1e-30)
+        e = ((got - ref).abs().max() / den).item()
+        e32 = ((ref - sd64[k].grad).abs().max() / den).item()          # the reference's fp32 autograd vs fp64
+        worst = max(worst, e)
+        n += 1
+        assert e <= max(2e-5, 3.0 * e32), (k, e, e32)
+    assert n == 52
+    print(f"ENLCN x{scale} training step: loss {ts.loss_values()[0]:.6f}, worst gradient error {worst:.2e} of a tensor's largest entry")
+
+
+def test_main_cli_trains_enlcn(tmp_path):
+    """`main.py --net_type ENLCN --max_iters 20`: the registry net through ModelPlain's step, loss finite and falling."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "sr-caco-2_amd", "main.py"), "--net_type", "ENLCN", "--method", "ENLCN",
+                        "--task", "super-resolution", "--scale", "4", "--n_channels", "1", "--h_size", "128", "--batch_size", "2",
+                        "--max_iters", "20", "--G_optimizer_lr", "1e-4", "--ENLCN_n_resblock", "8", "--ENLCN_n_feats", "64",
+                        "--outd", str(tmp_path)], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    losses = [float(l.split("G_loss")[1].split()[0]) for l in p.stdout.splitlines() if "G_loss" in l]
+    assert len(losses) == 2 and all(np.isfinite(losses)) and losses[1] < losses[0], losses
+    assert os.path.isfile(os.path.join(str(tmp_path), "models", "20_G.pth"))
 
 
 def test_enlcn_registry_default_width_vs_oracle():
