@@ -982,6 +982,14 @@ __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
 // a chunk's tile maximum comes out of the registers that hold the chunk, the scale only goes down, and when it does
 // every accumulator of the block is multiplied by the exact power of two in between.  Emulated (tools/split_accuracy.py):
 // worst output pixel relative to itself within 1.4x of an f32 conv, also on gradient-like inputs.
+// phase timestamps of every wave of k_nhcw2 (tools/mb_conv64_phases.py): experiment builds only
+#ifdef SRHIP_EXPERIMENTS
+__device__ long long* g_nhcw2_dbg = nullptr;
+#define SR_TSC(K) \
+  if (g_nhcw2_dbg && lane == 0) g_nhcw2_dbg[((long)blockIdx.x * 4 + wave) * 16 + (K)] = (long long)wall_clock64();
+#else
+#define SR_TSC(K)
+#endif
 template <int RW, bool AMP>
 __global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
   constexpr int NPL = AMP ? 1 : 2;
@@ -1006,6 +1014,7 @@ __global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
   const int img = t / p.tiles_y;
   const int y0 = ty * (2 * RW), x0 = tx * 16;
   const int nkc = (p.K + 31) / 32;
+  SR_TSC(0)
 
   unsigned offA[D_AIT];
   bool inA[D_AIT];
@@ -1117,11 +1126,13 @@ __global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
   load_a(0, ra);
   u32x4 fb0[2][2], fb1[2][2], fb2[2][2];
   load_b(0, fb0); load_b(1, fb1); load_b(2, fb2);
+  SR_TSC(1)
   for (int kc = 0; kc < nkc; ++kc) {
     const float tmx = wave_max(clean_a(ra, kc));
     if (kc) __syncthreads();                  // every tap of the previous chunk has read the halo tile (and `red`)
     if (lane == 0) red[wave] = tmx;
     __syncthreads();
+    if (kc < 2) { SR_TSC(2 + 4 * kc) }
     const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float need = mx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / mx)), 100.f)) : 3.0e38f;
     const float old = cur;
@@ -1129,6 +1140,7 @@ __global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
     const float use = cur > 1.0e38f ? 1.f : cur;
     store_a(ra, use);
     __syncthreads();
+    if (kc < 2) { SR_TSC(3 + 4 * kc) }
     if (kc + 1 < nkc) load_a(kc + 1, ra);
     if (kc && old != cur && old < 1.0e38f) {  // the tile's scale dropped: bring the accumulators to the new one (exact)
       const float f = cur / old;
@@ -1146,11 +1158,13 @@ __global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
       mma(t3 + 1, fb1); if (it + t3 + 4 < niter) load_b(it + t3 + 4, fb1);
       mma(t3 + 2, fb2); if (it + t3 + 5 < niter) load_b(it + t3 + 5, fb2);
     }
+    if (kc < 2) { SR_TSC(4 + 4 * kc) }
   }
   const float tinv = 1.0f / (cur > 1.0e38f ? 1.f : cur);
 
   // ---- re-layout inside the wave: 4 x 2 tiles of 16 x 16 -> 2 x 1 tiles of 32 x 32 (tile row 16*y + x of the wave's 4 image rows)
   __syncthreads();                                   // the halo tile is dead from here on
+  SR_TSC(10)
   float* const T = (float*)smem + wave * (16 * RW * D_TP);
 #pragma unroll
   for (int i = 0; i < RW; ++i)
@@ -1166,10 +1180,19 @@ __global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
   for (int i = 0; i < RW / 2; ++i)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc2[i][0][q] = T[(32 * i + mfma_row(q, lane)) * D_TP + r];
+  SR_TSC(11)
   nt_epilogue<RW / 2, 1, true>(p, acc2, lane, wm, wn, n0, nvalid, 0, img, y0, x0);
+  SR_TSC(12)
 }
 
 }  // namespace
+
+#ifdef SRHIP_EXPERIMENTS
+// [blocks][4 waves][16] stamps of the 100 MHz wall clock
+extern "C" int srhip_nhcw2_debug_buffer(long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_nhcw2_dbg), &buf, sizeof(buf)) == hipSuccess ? 0 : -5;
+}
+#endif
 
 // rows_per_wave 4: tiles_y counts 8-row tiles; 2: 4-row tiles (the caller's wm = 2 / 1)
 int sr_conv3x3_ntcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
