@@ -425,6 +425,14 @@ int srhip_layernorm_rows(const float* x, long ldx, float* y, long ldy, const flo
 int srhip_layernorm_rows_res(const float* x, long ldx, const float* res, long ldr, float* y, long ldy, const float* gamma,
                              const float* beta, long M, int C, float eps, void* stream);
 int srhip_softmax_rows(float* x, long ld, long R, int n, float scale, void* stream);
+/* Row softmax for training paths (NLSN's chunk attention, network_nlsn.py:236-243, through autograd):
+ *   srhip_softmax_rows_lse   as srhip_softmax_rows, also lse[r] = log sum_j exp(scale x[r][j])   (the bucket score :238)
+ *   srhip_softmax_rows_bwd   dP[r][j] <- P[r][j] (dP[r][j] - sum_k P[r][k] dP[r][k] + dlse[r]) in place: the gradient with
+ *                            respect to the logits of P = softmax and of lse (dlse may be NULL)
+ *   srhip_rowdot             out[r] = sum_c a[r][c] b[r][c] */
+int srhip_softmax_rows_lse(float* x, long ld, long R, int n, float scale, float* lse, void* stream);
+int srhip_softmax_rows_bwd(const float* P, float* dP, long ld, long R, int n, const float* dlse, void* stream);
+int srhip_rowdot(const float* a, long lda, const float* b, long ldb, float* out, long R, int n, void* stream);
 
 /* ---- pieces of OmniSR's omni self-attention blocks, evaluation forward (omni_ops.hip) --------------
  * dlib/models/network_omni_sr.py, channels last:

@@ -1468,6 +1468,61 @@ def g_nlsn():
     npz("g34_nlsn", **out)
 
 
+def g_nlsn_grad():
+    """NLSN training step of the reference: the narrow configuration of g34 at x4 (L = 480: chunk padding 96) in TRAINING
+    mode, L1 loss against a random target, autograd -> the gradient of every parameter.  The fixture also stores the LSH
+    rotations the reference drew and the token order its sort produced (through the oracle's taps under the same seed; the
+    oracle's forward and autograd must reproduce the reference's exactly), so that a run fed the same rotations AND order
+    is comparable entry by entry."""
+    print("G40 NLSN gradients")
+    from dlib.models.network_nlsn import NLSN as RefNLSN
+    out = {}
+    cfg = dict(n_resblocks=8, n_feats=64)
+    for scale, hw in ((4, (20, 24)),):
+        sd = O.nlsn_init_state_dict(scale, 1, seed=450 + scale, **cfg)
+        net = RefNLSN(upscale=scale, in_chans=1, n_hashes=4, chunk_size=144, **cfg)
+        net.load_state_dict(sd, strict=True)
+        net.train()
+        torch.manual_seed(455 + scale)
+        x = torch.rand(2, 1, *hw)
+        tgt = torch.rand(2, 1, hw[0] * scale, hw[1] * scale)
+        torch.manual_seed(460 + scale)
+        y = net(x)
+        loss = (y - tgt).abs().mean()
+        loss.backward()
+        sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.startswith(("sub_mean", "add_mean"))
+                   else v) for k, v in sd.items()}
+        torch.manual_seed(460 + scale)
+        taps = []
+        yo = O.nlsn_forward(sdo, x, scale, cfg["n_resblocks"], 4, 144, 0.1, taps=taps)
+        close(yo, y, 0.0, f"nlsn x{scale} training forward")
+        (yo - tgt).abs().mean().backward()
+        torch.manual_seed(460 + scale)
+        rots = [torch.randn((1, cfg["n_feats"] // 4, 4, t["hash_buckets"] // 2)) for t in taps]
+        with torch.no_grad():
+            yr = O.nlsn_forward(sd, x, scale, cfg["n_resblocks"], 4, 144, 0.1, rotations=rots,
+                                indices=[t["indices"] for t in taps])
+        close(yr, y, 0.0, f"nlsn x{scale} training forward with the rotations and the order replayed")
+        pre = f"x{scale}/"
+        out[pre + "x"], out[pre + "tgt"], out[pre + "y"], out[pre + "loss"] = x, tgt, y.detach(), loss.detach()
+        out[pre + "seed"] = np.array(450 + scale)
+        for a_, (t, r) in enumerate(zip(taps, rots)):
+            out[pre + f"rot{a_}"], out[pre + f"indices{a_}"] = r, t["indices"].to(torch.int32)
+        n = 0
+        for k, p_ in net.named_parameters():
+            if not p_.requires_grad:
+                continue
+            assert p_.grad is not None, k
+            g_o = sdo[k].grad
+            assert g_o is not None, k
+            err = (g_o - p_.grad).abs().max().item()
+            assert err <= 1e-6 * max(1e-3, p_.grad.abs().max().item()), (k, err)
+            out[pre + "grad/" + k] = p_.grad
+            n += 1
+        print(f"  {n} parameter gradients, oracle autograd == reference autograd")
+    npz("g40_nlsn_grad", **out)
+
+
 def g_dfcan():
     """DFCAN (network_dfcan.py): the registry's net (it has no width options) on small inputs, even and odd sizes (the
     quadrant swap splits at h // 2).  Forward only."""
@@ -1872,7 +1927,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_grl, g_omnisr, g_act, g_dfcan, g_nlsn, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_grl, g_omnisr, g_act, g_dfcan, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

@@ -102,6 +102,50 @@ __global__ void __launch_bounds__(256) k_softmax_rows(float* __restrict__ x, lon
   for (int j = lane; j < n; j += 64) p[j] *= inv;
 }
 
+// the same, also leaving lse[r] = log sum exp(scale * x[r]) (a training forward keeps it: NLSN's bucket score)
+__global__ void __launch_bounds__(256) k_softmax_rows_lse(float* __restrict__ x, long ld, long R, int n, float scale,
+                                                          float* __restrict__ lse) {
+  const long r = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float* p = x + r * ld;
+  float mx = -3.0e38f;
+  for (int j = lane; j < n; j += 64) mx = fmaxf(mx, p[j] * scale);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < n; j += 64) { const float e = expf(p[j] * scale - mx); p[j] = e; sum += e; }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int j = lane; j < n; j += 64) p[j] *= inv;
+  if (lane == 0) lse[r] = mx + logf(sum);
+}
+// backward of P = softmax(s) (and of lse = log sum exp s, whose gradient is P itself), in place on dP:
+//   ds[r][j] = P[r][j] (dP[r][j] - sum_k P[r][k] dP[r][k] + dlse[r])        (dlse may be NULL)
+__global__ void __launch_bounds__(256) k_softmax_rows_bwd(const float* __restrict__ P, float* __restrict__ dP, long ld, long R,
+                                                          int n, const float* __restrict__ dlse) {
+  const long r = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* p = P + r * ld;
+  float* d = dP + r * ld;
+  float dot = 0.f;
+  for (int j = lane; j < n; j += 64) dot += p[j] * d[j];
+  dot = wave_sum(dot);
+  const float add = (dlse ? dlse[r] : 0.f) - dot;
+  for (int j = lane; j < n; j += 64) d[j] = p[j] * (d[j] + add);
+}
+// out[r] = sum_c a[r][c] b[r][c]
+__global__ void __launch_bounds__(256) k_rowdot(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                float* __restrict__ out, long R, int n) {
+  const long r = blockIdx.x * 4L + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float s = 0.f;
+  for (int j = lane; j < n; j += 64) s += a[r * lda + j] * b[r * ldb + j];
+  s = wave_sum(s);
+  if (lane == 0) out[r] = s;
+}
+
 inline int ew_blocks(long n) { const long g = (n + 255) / 256; return (int)(g < 16384 ? g : 16384); }
 
 }  // namespace
@@ -166,6 +210,27 @@ int srhip_softmax_rows(float* x, long ld, long R, int n, float scale, void* stre
   SR_REQUIRE(x && R > 0 && n > 0 && ld >= n, "softmax_rows: bad arguments");
   hipLaunchKernelGGL(k_softmax_rows, dim3(sr_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, R, n, scale);
   SR_LAUNCH_CHECK("softmax_rows");
+  return 0;
+}
+
+int srhip_softmax_rows_lse(float* x, long ld, long R, int n, float scale, float* lse, void* stream) {
+  SR_REQUIRE(x && lse && R > 0 && n > 0 && ld >= n, "softmax_rows_lse: bad arguments");
+  hipLaunchKernelGGL(k_softmax_rows_lse, dim3(sr_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, R, n, scale, lse);
+  SR_LAUNCH_CHECK("softmax_rows_lse");
+  return 0;
+}
+
+int srhip_softmax_rows_bwd(const float* P, float* dP, long ld, long R, int n, const float* dlse, void* stream) {
+  SR_REQUIRE(P && dP && R > 0 && n > 0 && ld >= n, "softmax_rows_bwd: bad arguments");
+  hipLaunchKernelGGL(k_softmax_rows_bwd, dim3(sr_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, P, dP, ld, R, n, dlse);
+  SR_LAUNCH_CHECK("softmax_rows_bwd");
+  return 0;
+}
+
+int srhip_rowdot(const float* a, long lda, const float* b, long ldb, float* out, long R, int n, void* stream) {
+  SR_REQUIRE(a && b && out && R > 0 && n > 0 && lda >= n && ldb >= n, "rowdot: bad arguments");
+  hipLaunchKernelGGL(k_rowdot, dim3(sr_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, R, n);
+  SR_LAUNCH_CHECK("rowdot");
   return 0;
 }
 

@@ -5,7 +5,7 @@ conv_assembly.0.*`` for the attention blocks, ``body.{i}.body.{0,2}.*`` for the 
 ``tail.1.*``): released weights load with strict=True.  The compute is ``srhip.nlsn_engine.NLSNEngine``.  As in the
 reference, the LSH rotations are drawn anew at every forward (:152-155), so two forwards of the same input differ at the
 level the hashing decides; the token order inside a hash bucket is by token index here (the reference leaves it to
-torch.sort).  Evaluation only (``backward`` raises); 1-channel inputs; at least chunk_size pixels per image; GPU only."""
+torch.sort).  Trains (srhip.tape.Tape.nlsa: the attention core differentiated in chunk-major dense form); 1-channel inputs; at least chunk_size pixels per image; GPU only."""
 import math
 
 import torch

@@ -1,6 +1,7 @@
 """NLSN as a tape graph (reference dlib/models/network_nlsn.py:296-369): head conv; body = NonLocalSparseAttention, then
 n_resblocks ResBlocks (conv-ReLU-conv, x res_scale, + x) with an attention block behind every eighth, a conv; long skip;
-Upsampler (conv F -> 4F as four F-column convs + PixelShuffle(2) per factor of two) and the output conv.  Inference only."""
+Upsampler (conv F -> 4F as four F-column convs + PixelShuffle(2) per factor of two) and the output conv.  Trains through the
+tape's derived backward (the sparse attention: Tape.nlsa)."""
 import math
 
 from .tape import TapeEngine
@@ -19,6 +20,7 @@ def body_layout(n_resblocks):
 class NLSNEngine(TapeEngine):
     rotations = None          # tests: one LSH rotation tensor per attention block (None: drawn per call, as the reference)
     taps = None               # tests: list that receives {"rotations", "order"} per attention block
+    orders = None             # tests: one token order per attention block (replays another implementation's sort)
 
     def bank_entries(self):
         net, bank = self.net, self.bank
@@ -50,7 +52,8 @@ class NLSNEngine(TapeEngine):
                     tap = {}
                     self.taps.append(tap)
                 res = t.nlsa(res, (f"body.{i}.conv_match", f"body.{i}.conv_assembly"), net.n_hashes, net.chunk_size, rs,
-                             None if self.rotations is None else self.rotations[a], tap)
+                             None if self.rotations is None else self.rotations[a], tap,
+                             None if self.orders is None else self.orders[a])
                 a += 1
             elif kind == "res":
                 r = t.conv(res, f"body.{i}.0", (f"body.{i}.body.0.weight", f"body.{i}.body.0.bias"))
@@ -60,10 +63,8 @@ class NLSNEngine(TapeEngine):
                 res = t.conv(res, f"body.{i}", (f"body.{i}.weight", f"body.{i}.bias"))
         res = t.axpby(res, x, 1.0, 1.0)
         for st in range(int(math.log2(net.upscale))):
-            names = (f"tail.0.{2 * st}.weight", f"tail.0.{2 * st}.bias")
-            res = t.shuffle(t.cat([t.conv(res, f"tail.0.{2 * st}.{j}", names) for j in range(4)]), 2)
+            F = net.n_feats
+            res = t.shuffle(t.cat([t.conv(res, f"tail.0.{2 * st}.{j}", (f"tail.0.{2 * st}.weight", f"tail.0.{2 * st}.bias",
+                                                                       (j * F, (j + 1) * F))) for j in range(4)]), 2)
         return t.conv_out1(res, net.tail[1].weight, net.tail[1].bias, ("tail.1.weight", "tail.1.bias"))
 
-    def backward(self, *a, **k):
-        raise NotImplementedError("NLSN on libsrhip: inference only (BASELINE config 5's evaluation sweep); the backward of "
-                                  "the sparse attention is not built")

@@ -381,16 +381,24 @@ def nlsa_order(x_embed, rotations, N, L):
     return order
 
 
-def nlsa_attention(x_embed, y_embed, order, x, out, N, L, chunk_size, res_scale):
-    """out = x + res_scale * NonLocalSparseAttention(x) given the embeddings and the token order (network_nlsn.py:209-266)."""
+def nlsa_attention(x_embed, y_embed, order, x, out, N, L, chunk_size, res_scale, keep=False):
+    """out = x + res_scale * NonLocalSparseAttention(x) given the embeddings and the token order (network_nlsn.py:209-266).
+    keep (training): the per-round results ret [N, nh, L, Cy] and bucket scores [N, nh, L] (token positions) are fresh
+    tensors, returned for the backward; else they live in the shared scratch."""
     _chk(x_embed, y_embed, x, out)
     Ce, Cy, nh = x_embed.shape[1], y_embed.shape[1], order.shape[1]
     assert x_embed.is_contiguous() and y_embed.is_contiguous() and x.is_contiguous() and out.is_contiguous()
     assert x.shape == (N * L, Cy) == tuple(out.shape)
-    ret = SCRATCH.get("nlsa_ret", N * nh * L * Cy, device=x.device)
-    score = SCRATCH.get("nlsa_score", N * nh * L, device=x.device)
+    if keep:
+        ret = torch.empty(N * nh * L * Cy, device=x.device)
+        score = torch.empty(N * nh * L, device=x.device)
+    else:
+        ret = SCRATCH.get("nlsa_ret", N * nh * L * Cy, device=x.device)
+        score = SCRATCH.get("nlsa_score", N * nh * L, device=x.device)
     call("srhip_nlsa_attention", _p(x_embed), _p(y_embed), order.data_ptr(), _p(ret), _p(score), _p(x), _p(out), N, L, Ce, Cy,
          nh, int(chunk_size), float(res_scale), _st())
+    if keep:
+        return out, ret[:N * nh * L * Cy].view(N, nh, L, Cy), score[:N * nh * L].view(N, nh, L)
     return out
 
 
@@ -461,6 +469,31 @@ def layernorm_rows_res(x, res, gamma, beta, out, eps=1e-5):
     assert x.dim() == 2 and out.shape == x.shape == res.shape and x.stride(1) == 1 and out.stride(1) == 1 and res.stride(1) == 1
     call("srhip_layernorm_rows_res", _p(x), x.stride(0), _p(res), res.stride(0), _p(out), out.stride(0), _p(gamma), _p(beta),
          x.shape[0], x.shape[1], float(eps), _st())
+    return out
+
+
+def softmax_rows_lse_(x, lse, scale=1.0):
+    """softmax_rows_ that also leaves lse[r] = log sum exp(scale * x[r])."""
+    _chk(x, lse)
+    assert x.dim() == 2 and x.stride(1) == 1 and lse.numel() == x.shape[0]
+    call("srhip_softmax_rows_lse", _p(x), x.stride(0), x.shape[0], x.shape[1], float(scale), _p(lse), _st())
+    return x
+
+
+def softmax_rows_bwd_(P, dP, dlse=None):
+    """dP <- P * (dP - rowsum(P * dP) + dlse[:, None]): gradient with respect to the logits (and through lse)."""
+    _chk(P, dP, dlse)
+    assert P.shape == dP.shape and P.dim() == 2 and P.stride(1) == 1 and dP.stride(1) == 1 and P.stride(0) == dP.stride(0)
+    call("srhip_softmax_rows_bwd", _p(P), _p(dP), P.stride(0), P.shape[0], P.shape[1], _p(dlse), _st())
+    return dP
+
+
+def rowdot(a, b, out=None):
+    _chk(a, b, out)
+    assert a.shape == b.shape and a.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = torch.empty(a.shape[0], device=a.device)
+    call("srhip_rowdot", _p(a), a.stride(0), _p(b), b.stride(0), _p(out), a.shape[0], a.shape[1], _st())
     return out
 
 

@@ -451,33 +451,115 @@ class Tape:
             self.back.append(bwd)
         return out
 
-    def nlsa(self, x, keys, n_hashes, chunk_size, res_scale, rotations=None, tap=None):
-        """NonLocalSparseAttention in evaluation mode (network_nlsn.py:131-268): keys = bank entries of conv_match (3x3,
-        C -> C/4) and conv_assembly (1x1).  rotations: the LSH rotations [1, C/4, n_hashes, hash_buckets // 2] (None:
+    def nlsa(self, x, keys, n_hashes, chunk_size, res_scale, rotations=None, tap=None, order=None):
+        """NonLocalSparseAttention (network_nlsn.py:131-268): keys = bank entries (= parameter name prefixes) of conv_match
+        (3x3, C -> C/4) and conv_assembly (1x1).  rotations: the LSH rotations [1, C/4, n_hashes, hash_buckets // 2] (None:
         drawn with torch.randn on the device, as the reference does at every call); tap: dict that receives the rotations
-        and the token order used.  Inference only."""
+        and the token order used; order (tests): int64 [B, n_hashes, L], token index in the low 20 bits, used instead of the
+        sort's result -- replays the order another implementation's sort produced, ties included.
+        Forward: the fused kernels of nlsa.hip (hash, one radix sort, chunk attention written to token positions, rounds
+        combined).  Backward (training): the embeddings are ordinary tape convs; the attention core is differentiated in
+        chunk-major dense form -- rows gathered by the saved order (hash codes are constants of the step, as .detach() makes
+        them in the reference, :171), P = softmax(xb xm^T) recomputed, then dP = dret yb^T, d logits = P (dP - sum P dP +
+        d lse), dxb, dxm (through the keys' L2 normalisation), dyb as batched exact-f32 GEMMs (srhip_gemm_nt_batched) and
+        scattered back to the tokens (padded rows are duplicates whose outputs the forward drops: zero gradient in)."""
         e1, e2 = (self.bank.d[k] for k in keys)
         B, H, W, C = x.t.shape
         L, T = H * W, B * H * W
-        xin = x.t if x.t.is_contiguous() else x.t.contiguous()
-        xe = torch.empty(B, H, W, e1.Co, device=self.dev)
-        ops.conv3x3(xin, e1.wp, e1.bias, e1.Co, out=xe)
-        ye = torch.empty(T, e2.Co, device=self.dev)
-        ops.gemm_nt(xin.view(T, C), e2.w1, e2.bias, out=ye)
+        if self.save:
+            xe_v = self.conv(x, keys[0], (keys[0] + ".0.weight", keys[0] + ".0.bias"))
+            ye_v = self.conv(x, keys[1], (keys[1] + ".0.weight", keys[1] + ".0.bias"))
+            xe, ye = xe_v.t, ye_v.t.view(T, e2.Co)
+            xin = x.t if x.t.is_contiguous() else x.t.contiguous()
+        else:
+            xin = x.t if x.t.is_contiguous() else x.t.contiguous()
+            xe = torch.empty(B, H, W, e1.Co, device=self.dev)
+            ops.conv3x3(xin, e1.wp, e1.bias, e1.Co, out=xe)
+            ye = torch.empty(T, e2.Co, device=self.dev)
+            ops.gemm_nt(xin.view(T, C), e2.w1, e2.bias, out=ye)
         hb = ops.nlsa_hash_buckets(L, chunk_size)
         if rotations is None:
             rotations = torch.randn(1, e1.Co, n_hashes, hb // 2, device=self.dev)
         assert tuple(rotations.shape) == (1, e1.Co, n_hashes, hb // 2), (rotations.shape, hb)
-        order = ops.nlsa_order(xe.view(T, e1.Co), rotations, B, L)
+        if order is None:
+            order = ops.nlsa_order(xe.view(T, e1.Co), rotations, B, L)
+        else:
+            assert tuple(order.shape) == (B, n_hashes, L) and order.dtype == torch.int64 and order.is_contiguous()
         if tap is not None:
             tap["rotations"], tap["order"] = rotations, order
         y = self.new(B, H, W, C)
-        ops.nlsa_attention(xe.view(T, e1.Co), ye, order, xin.view(T, C), y.view(T, C), B, L, chunk_size, res_scale)
+        if not self.save:
+            ops.nlsa_attention(xe.view(T, e1.Co), ye, order, xin.view(T, C), y.view(T, C), B, L, chunk_size, res_scale)
+            return self._out(y)
+        _, ret, score = ops.nlsa_attention(xe.view(T, e1.Co), ye, order, xin.view(T, C), y.view(T, C), B, L, chunk_size,
+                                           res_scale, keep=True)
         out = self._out(y)
-        if self.save:
-            def bwd():
-                raise NotImplementedError("NonLocalSparseAttention on libsrhip: inference only; no backward")
-            self.back.append(bwd)
+        dev, cs, nh, Ce, Cy = self.dev, int(chunk_size), int(n_hashes), e1.Co, e2.Co
+
+        def bwd(x=x, out=out, xe_v=xe_v, ye_v=ye_v):
+            g = out.g
+            if g is None:
+                return
+            g2 = (g if g.is_contiguous() else g.contiguous()).view(B, L, Cy)
+            # ---- the rounds' softmax combination (:258-262), token order
+            probs = torch.softmax(score, dim=1)                                              # [B, nh, L]
+            gx = g2.view(B, 1, L, Cy).expand(B, nh, L, Cy).contiguous()
+            a = ops.rowdot(ret.reshape(-1, Cy), gx.view(-1, Cy)).view(B, nh, L) * res_scale  # d out / d probs
+            dlse = probs * (a - (probs * a).sum(1, keepdim=True))
+            dret = gx.mul_((probs * res_scale).unsqueeze(-1))                                # [B, nh, L, Cy]
+            # ---- chunk-major index maps from the saved order (positions past L repeat the last `padding` positions, :213-218)
+            tok = order & ((1 << 20) - 1)                                                    # [B, nh, L] int64
+            padding = (cs - L % cs) % cs
+            tokp = torch.cat([tok, tok[:, :, L - padding:]], 2) if padding else tok
+            Lp = L + padding
+            nch = Lp // cs
+            NB = B * nh * nch
+            qtok = tokp.view(B, nh, nch, cs)
+            ktok = torch.cat([qtok, qtok.roll(1, 2), qtok.roll(-1, 2)], 3)                   # own, previous, next chunk (:224-231)
+            base = (torch.arange(B, device=dev) * L).view(B, 1, 1, 1)
+            qflat, kflat = (qtok + base).reshape(-1), (ktok + base).reshape(-1)
+            rbase = (torch.arange(B * nh, device=dev) * L).view(B, nh, 1, 1)
+            rflat = (qtok + rbase).reshape(-1)                                               # row of (sample, round, token)
+            xe2, ye2 = xe.view(T, Ce), ye
+            xb = xe2.index_select(0, qflat)                                                  # [NB cs, Ce] queries (un-normalised)
+            xm = xe2.index_select(0, kflat)                                                  # [NB 3cs, Ce] keys
+            fac = torch.empty(xm.shape[0], device=dev)
+            ops.l2norm_rows_train_(xm, fac, 1.0)                                             # F.normalize(eps 5e-5) (:222)
+            yb = ye2.index_select(0, kflat)                                                  # [NB 3cs, Cy] values
+            dret_s = dret.view(-1, Cy).index_select(0, rflat)
+            dlse_s = dlse.reshape(-1).index_select(0, rflat)
+            if padding:                                                                      # padded rows: outputs dropped (:246-249)
+                dret_s.view(B, nh, Lp, Cy)[:, :, L:] = 0.0
+                dlse_s.view(B, nh, Lp)[:, :, L:] = 0.0
+            del dret, gx
+            K3 = 3 * cs
+            P = torch.empty(NB * cs, K3, device=dev)
+            ops.gemm_nt_batched(xb[:cs], (cs * Ce, 0), xm[:K3], (K3 * Ce, 0), P[:cs], (cs * K3, 0), cs, K3, Ce, NB, 1)
+            junk = torch.empty(NB * cs, device=dev)
+            ops.softmax_rows_lse_(P, junk)                                                   # P = exp(raw - lse) (:236-240)
+            dP = torch.empty(NB * cs, K3, device=dev)
+            ops.gemm_nt_batched(dret_s[:cs], (cs * Cy, 0), yb[:K3], (K3 * Cy, 0), dP[:cs], (cs * K3, 0), cs, K3, Cy, NB, 1)
+            ops.softmax_rows_bwd_(P, dP, dlse_s)                                             # -> d raw
+            t3 = lambda m, r, c_: m.view(NB, r, c_).transpose(1, 2).contiguous()
+            xmT, xbT, drawT, PT, dretT = t3(xm, K3, Ce), t3(xb, cs, Ce), t3(dP, cs, K3), t3(P, cs, K3), t3(dret_s, cs, Cy)
+            dxb = torch.empty(NB * cs, Ce, device=dev)
+            ops.gemm_nt_batched(dP[:cs], (cs * K3, 0), xmT.view(-1, K3)[:Ce], (Ce * K3, 0), dxb[:cs], (cs * Ce, 0), cs, Ce, K3, NB, 1)
+            dxm = torch.empty(NB * K3, Ce, device=dev)
+            ops.gemm_nt_batched(drawT.view(-1, cs)[:K3], (K3 * cs, 0), xbT.view(-1, cs)[:Ce], (Ce * cs, 0), dxm[:K3], (K3 * Ce, 0),
+                                K3, Ce, cs, NB, 1)
+            dyb = torch.empty(NB * K3, Cy, device=dev)
+            ops.gemm_nt_batched(PT.view(-1, cs)[:K3], (K3 * cs, 0), dretT.view(-1, cs)[:Cy], (Cy * cs, 0), dyb[:K3], (K3 * Cy, 0),
+                                K3, Cy, cs, NB, 1)
+            ops.l2norm_rows_bwd_(dxm, xm, fac, 1.0)                                          # keys' normalisation
+            dxe = torch.zeros(T, Ce, device=dev)
+            dxe.index_add_(0, qflat, dxb)
+            dxe.index_add_(0, kflat, dxm)
+            dye = torch.zeros(T, Cy, device=dev)
+            dye.index_add_(0, kflat, dyb)
+            self.acc(xe_v, lambda o: o.view(T, Ce).copy_(dxe))
+            self.acc(ye_v, lambda o: o.view(T, Cy).copy_(dye))
+            self.acc(x, lambda o: o.view(B, L, Cy).copy_(g2))                                # the residual (:266)
+        self.back.append(bwd)
         return out
 
     def _no_backward(self, what):

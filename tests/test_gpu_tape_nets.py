@@ -340,9 +340,84 @@ def test_nlsn_forward_vs_reference_golden(scale):
     yo = O.nlsn_forward(sd, x, scale, 8, 4, 144, 0.1, rotations=rots, indices=idx)
     assert (y - yo).abs().mean().item() <= 1e-5 and rel(y, yo) < 3e-5, rel(y, yo)
     assert (y - yref).abs().mean().item() <= 2e-3, (y - yref).abs().mean().item()
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(x.cuda()).sum().backward()
+
+
+def test_nlsn_training_step_gradients_vs_reference_golden():
+    """NLSN trains: forward in training mode, L1 loss, every parameter gradient of the narrow x4
+    configuration (L = 480, chunk padding 96) against the REFERENCE's own autograd (g40_nlsn_grad.npz: written by
+    oracle/make_goldens.py::g_nlsn_grad from the imported reference net, the oracle's autograd asserted equal), fed the LSH
+    rotations the reference drew AND the token order its sort produced (the order inside a hash bucket is the sort
+    implementation's; with it replayed the two runs are the same function).  Then, order computed here (own sort): the
+    gradients against the oracle's fp64 autograd replaying THIS run's order.  Gate: the library's 2e-5 of a tensor's largest
+    entry, ReLU decisions within rounding of zero excused by the 3x-the-fp32-reference arm."""
+    from dlib.models.network_nlsn import NLSN
+    from srhip.train import TrainStep, Optimizer
+    scale = 4
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g40_nlsn_grad").items() if k.startswith(f"x{scale}/")}
+    sd = O.nlsn_init_state_dict(scale, 1, 8, 64, seed=int(g["seed"]))
+    net = NLSN(upscale=scale, in_chans=1, n_resblocks=8, n_feats=64)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    x, tgt = g["x"], g["tgt"]
+    N, L, nh = x.shape[0], x.shape[2] * x.shape[3], 4
+    rots = [g["rot0"], g["rot1"]]
+    ref_idx = [g["indices0"].long(), g["indices1"].long()]
+    net.engine.rotations = [r.cuda() for r in rots]
+
+    def sd64():
+        return {k: (v.double().requires_grad_(True) if v.dtype == torch.float32 and not k.startswith(("sub_mean", "add_mean"))
+                    else v) for k, v in sd.items()}
+
+    def check(ts, ref_of, s64, what):
+        worst, n = 0.0, 0
+        for k in ts.fp.names:
+            ref = ref_of(k).double()
+            got = ts.fp.gviews[k].double().cpu()
+            den = ref.abs().max().clamp_min(1e-30)
+            e = ((got - ref).abs().max() / den).item()
+            e32 = 0.0 if s64 is None else ((ref - s64[k].grad).abs().max() / den).item()
+            worst, n = max(worst, e), n + 1
+            assert e <= max(2e-5, 3.0 * e32), (what, k, e, e32)
+        assert n == 50
+        print(f"NLSN x{scale} training step ({what}): loss {ts.loss_values()[0]:.6f}, worst gradient error {worst:.2e}")
+
+    # (1) the reference's order replayed
+    net.engine.orders = [(i % L).view(N, nh, L).contiguous().cuda() for i in ref_idx]
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=0.0, momentum=0.0, nesterov=False, wd=0.0)        # lr 0: the gradients stay readable
+    ts.step(x.cuda(), tgt.cuda())
+    assert abs(ts.loss_values()[0] - float(g["loss"])) <= 2e-6
+    s64 = sd64()
+    (O.nlsn_forward(s64, x.double(), scale, 8, 4, 144, 0.1, rotations=[r.double() for r in rots], indices=ref_idx)
+     - tgt.double()).abs().mean().backward()
+    check(ts, lambda k: g["grad/" + k], s64, "reference order")
+    # (2) this library's own sort
+    net.engine.orders = None
+    net.engine.taps = taps = []
+    ts.step(x.cuda(), tgt.cuda())
+    idx = [((tp["order"].cpu() & ((1 << 20) - 1)) + torch.arange(nh).view(1, nh, 1) * L).reshape(N, nh * L) for tp in taps]
+    assert len(idx) == 2
+    s64 = sd64()
+    (O.nlsn_forward(s64, x.double(), scale, 8, 4, 144, 0.1, rotations=[r.double() for r in rots], indices=idx)
+     - tgt.double()).abs().mean().backward()
+    check(ts, lambda k: s64[k].grad, None, "own order")
+
+
+def test_main_cli_trains_nlsn(tmp_path):
+    """`main.py --net_type NLSN --max_iters 20`: the registry net through ModelPlain's step (rotations drawn per call on the
+    device), loss finite and falling."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "sr-caco-2_amd", "main.py"), "--net_type", "NLSN", "--method", "NLSN",
+                        "--task", "super-resolution", "--scale", "4", "--n_channels", "1", "--h_size", "128", "--batch_size", "2",
+                        "--max_iters", "20", "--G_optimizer_lr", "1e-4", "--NLSN_n_resblocks", "8", "--NLSN_n_feats", "64",
+                        "--outd", str(tmp_path)], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    losses = [float(l.split("G_loss")[1].split()[0]) for l in p.stdout.splitlines() if "G_loss" in l]
+    assert len(losses) == 2 and all(np.isfinite(losses)) and losses[1] < losses[0], losses
+    assert os.path.isfile(os.path.join(str(tmp_path), "models", "20_G.pth"))
 
 
 def test_nlsn_registry_default_width_vs_oracle():
