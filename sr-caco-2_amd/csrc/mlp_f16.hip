@@ -72,7 +72,7 @@ __device__ __forceinline__ void gelu_gate(float x, float& gate, float& gl) {
 #ifdef SRHIP_EXPERIMENTS
 long long* g_mlp_dbg = nullptr;
 #define SR_TS(K) \
-  if (p.dbg && lane == 0) p.dbg[((long)blockIdx.x * 4 + wave) * 16 + (K)] = (long long)wall_clock64();
+  if (p.dbg && lane == 0) p.dbg[((long)blockIdx.x * 4 + wave) * 24 + (K)] = (long long)wall_clock64();
 #else
 #define SR_TS(K)
 #endif
@@ -161,6 +161,12 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
 #pragma unroll
       for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane2 + boff2[jt]);
   };
+#ifdef SRHIP_EXPERIMENTS
+  if (p.stagger > 0 && (blockIdx.x & 1)) {           // experiment: every second block starts late (phases of the two halves interleave)
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < p.stagger) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   SR_TS(0)
   u32x4 fb0[3][2], fb1[3][2], fb2[3][2];
   int a_off[4];
@@ -347,6 +353,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       SR_STAGE(0, fb0) SR_STAGE(1, fb1) SR_STAGE(2, fb2) SR_STAGE(3, fb0) SR_STAGE(4, fb1) SR_STAGE(5, fb2)
 #undef SR_STAGE
     }
+    SR_TS(15)
     __syncthreads();
     {
       float wv[3];
@@ -362,8 +369,10 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
         }
     }
     __syncthreads();
+    SR_TS(16)
     f32x4 dv[12];
     const float omx = ln_bwd_rows(p.x0, p.ldx0, p.stats0, p.res0, p.ldres0, p.out0, p.ldo0, dv);
+    SR_TS(17)
     __syncthreads();                                 // every thread has read its part of the tile
     rows_to_images(dv, omx, rinvx);
     load_b1(0, fb0);
@@ -709,6 +718,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     // dx = dy + LayerNorm_backward(dxh; x, stats)  (the affine folded into W1)
     f32x4 dv[12];
     float omx = ln_bwd_rows(p.R, p.ldr, p.ep_stats, p.R2, p.ldr2, p.out, p.ldo, dv);
+    SR_TS(18)
     if (p.W3) {
       // ---------------- chained third product: out3 = s3 (dx . W3^T), the data gradient of the Linear in front of this
       // block's residual (the attention's proj): dx goes from the registers that hold it into the stage images
@@ -728,6 +738,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       __syncthreads();                               // every thread has read its part of the tile
       rows_to_images(dv, omx, rinv3);
       __syncthreads();
+      SR_TS(19)
       f32x4 acc3[4][3];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -752,6 +763,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       mma3(3, fc0); __builtin_amdgcn_sched_barrier(0);
       mma3(4, fc1); __builtin_amdgcn_sched_barrier(0);
       mma3(5, fc2);
+      SR_TS(20)
       __syncthreads();                               // every wave is done with the images
       {
         float wv[3];
@@ -767,6 +779,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
           }
       }
       __syncthreads();
+      SR_TS(21)
 #pragma unroll
       for (int it = 0; it < 12; ++it) {
         const int idx = it * 256 + tid, prow = idx / 48, pcol = (idx - prow * 48) * 4;
@@ -787,12 +800,13 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
 }  // namespace
 
 #ifdef SRHIP_EXPERIMENTS
-extern "C" int srhip_mlp_debug_buffer(long long* buf) { g_mlp_dbg = buf; return 0; }    // [blocks][4][16] wall-clock stamps
+extern "C" int srhip_mlp_debug_buffer(long long* buf) { g_mlp_dbg = buf; return 0; }    // [blocks][4][24] wall-clock stamps
 #endif
 
 int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st) {
 #ifdef SRHIP_EXPERIMENTS
   p.dbg = g_mlp_dbg;
+  { const char* e = sr_getenv("SRHIP_MLP_STAGGER"); p.stagger = e ? atoi(e) : 0; }      // 10-ns units
 #endif
   SR_REQUIRE(p.C % 4 == 0 && p.C >= 4 && p.C <= 192, "mlp_f16x2: C = %d (multiple of 4, <= 192)", p.C);
   SR_REQUIRE(p.hid % 4 == 0 && p.hid >= 4 && p.hid <= 384, "mlp_f16x2: hidden = %d (multiple of 4, <= 384)", p.hid);
