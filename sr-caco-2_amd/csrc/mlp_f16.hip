@@ -316,6 +316,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
         }
       }
       __syncthreads();
+      if (pass == 0) { SR_TS(22) }
       if (pass == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -352,6 +353,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       }
       SR_STAGE(0, fb0) SR_STAGE(1, fb1) SR_STAGE(2, fb2) SR_STAGE(3, fb0) SR_STAGE(4, fb1) SR_STAGE(5, fb2)
 #undef SR_STAGE
+      if (pass == 0) { SR_TS(23) }
     }
     SR_TS(15)
     __syncthreads();

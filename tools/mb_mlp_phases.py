@@ -47,11 +47,11 @@ def bwd_full(): ops.mlp_bwd_f16(dy, P["w2T"], P["w1T"], h, dh, gh, x, st, dx, ch
 # slot -> name, in time order per direction
 ORDER = {"forward": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14],
          "backward": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18, 14],
-         "backward qkv+ +proj": [0, 15, 16, 17, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19, 20, 21, 14]}
+         "backward qkv+ +proj": [0, 22, 23, 15, 16, 17, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19, 20, 21, 14]}
 NAMES = {0: "start", 1: "x staged", 2: "barrier", 3: "gemm1 done", 4: "activation done", 5: "max+barrier", 6: "h pass 1 staged",
          7: "barrier", 8: "gemm2 pass 1", 9: "barrier", 10: "h pass 2 staged+barrier", 11: "gemm2 pass 2", 12: "barrier",
          13: "T laid+barrier", 14: "end", 15: "front gemm (3 passes)", 16: "front T laid+barriers", 17: "front LN bwd rows",
-         18: "LN bwd rows", 19: "dx images+barriers", 20: "gemm3", 21: "T laid+barriers"}
+         18: "LN bwd rows", 22: "front pass 0 rows staged", 23: "front pass 0 products", 19: "dx images+barriers", 20: "gemm3", 21: "T laid+barriers"}
 for name, f in (("forward", fwd), ("backward", bwd), ("backward qkv+ +proj", bwd_full)):
     for _ in range(3):
         f()
