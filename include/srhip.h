@@ -144,11 +144,23 @@ int srhip_gemm_nt_f16x2_lnbwd(const float* A, long lda, const void* Wh, float* o
                               void* stream);
 /* The 3x3 conv with its weight as two fp16 planes and a power-of-two scale per OUTPUT channel (srhip_prep_table job
  * kind 4); the activation gets ONE power-of-two scale per 8 x 16 (or 4 x 16) halo tile, kept as a running scale over the
- * channel chunks; three products.  Cout <= 256 (64-column tiles / slices) or a multiple of 180 (192-column tiles), Cin <= 256.  What the weight preparation emits by default
+ * channel chunks; three products.  Cout <= 4096 (64-column tiles / slices) or a multiple of 180 (192-column tiles), Cin <= 4096.  What the weight preparation emits by default
  * for these shapes (SRHIP_F16X2_CONV=0: bf16x3); arguments as srhip_conv3x3_nhwc_bx3. */
 int srhip_conv3x3_nhwc_f16x2(const float* X, long ldx, const void* Wh, const float* bias, float* Y, long ldy,
                              int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                              const float* rowscale, float alpha, void* stream);
+/* The split-operand conv (wfmt 0: srhip_conv3x3_nhwc_bx3's weight, 1: srhip_conv3x3_nhwc_f16x2's) with what the plain CNNs of
+ * the evaluation sweep put around it folded into its prologue / epilogue (one pass over the feature map less per fold):
+ *   in_bn_coef [4][Cin] = running mean, 1/sqrt(var+eps), gamma/sqrt(var+eps), beta: evaluation-mode BatchNorm2d + ReLU on
+ *          the INPUT (zero padding applied to the activation), MemNet's BN-ReLU-conv (network_memnet.py:27-34); the
+ *          expression of srhip_bn_apply; wfmt 1, Cout a multiple of 64, <= 4096
+ *   epi 8: relu(R + s*(acc+bias))                    DRRN's residual unit (network_drrn.py:58-62)
+ *   epi 9: prelu(acc+bias), slope = *slope (device)  DBPN's ConvBlock / DeconvBlock activation (network_dbpn.py:16-60)
+ *   epi 10: prelu(acc+bias) + alpha * R              ... and the projection units' l0 - x / h1 + h0 (:93-99,128-134) */
+int srhip_conv3x3_nhwc_split_ex(int wfmt, const float* X, long ldx, const void* Wp, const float* bias, float* Y, long ldy,
+                                int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
+                                const float* rowscale, float alpha, const float* in_bn_coef, const float* slope,
+                                void* stream);
 /* srhip_conv3x3_ps2_bx3 / srhip_conv3x3_ps2_bwd_data_bx3 with the weight in that format (job kind 4, modes 12 / 16). */
 int srhip_conv3x3_ps2_f16x2(const float* X, long ldx, const void* Wh, const float* bias, float* Yup, long ldy,
                             int B, int H, int W, int Cin, int Cout, int epi, float alpha, void* stream);

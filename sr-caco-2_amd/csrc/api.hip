@@ -257,11 +257,16 @@ int srhip_mlp_bwd_front_chain_f16x2(const float* X0, long ld0, int K0, const voi
 
 static int conv3x3_split(int wfmt, const float* X, long ldx, const void* Wb, const float* bias, float* Y, long ldy,
                            int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
-                           const float* rowscale, float alpha, void* stream) {
-  SR_REQUIRE(epi >= 0 && epi <= 7 && epi != 3 && epi != 5, "conv3x3_bx3: epi %d", epi);
-  SR_REQUIRE((epi != 4 && epi != 7) || R, "conv3x3_bx3: mask epilogue %d needs R", epi);
+                           const float* rowscale, float alpha, void* stream, const float* in_bn_coef = nullptr,
+                           const float* slope = nullptr) {
+  SR_REQUIRE(epi >= 0 && epi <= 10 && epi != 3 && epi != 5, "conv3x3_bx3: epi %d", epi);
+  SR_REQUIRE((epi != 4 && epi != 7 && epi != 8 && epi != 10) || R, "conv3x3_bx3: epilogue %d needs R", epi);
+  SR_REQUIRE((epi != 9 && epi != 10) || (slope && !rowscale), "conv3x3_bx3: epilogue %d takes the PReLU slope (and no row scale)", epi);
+  SR_REQUIRE(!in_bn_coef || (wfmt == 1 && Cout <= 4096 && Cout % 64 == 0 && Cin % 4 == 0),
+             "conv3x3: the BatchNorm-ReLU input prologue runs on the 64-column fp16x2 kernel (Cout = %d a multiple of 64, <= 4096)", Cout);
   NtArgs p;
   memset(&p, 0, sizeof(p));
+  p.pro_coef = in_bn_coef; p.slope = slope;
   p.A = X; p.lda = ldx; p.Wb = (const unsigned short*)Wb; p.C = Y; p.ldc = ldy;
   p.N = Cout; p.K = Cin; p.bias = bias; p.epi = epi; p.R = R; p.ldr = ldr; p.rowscale = rowscale;
   p.rows_per_scale = H * W; p.alpha = alpha; p.batch = B; p.H = H; p.Wd = W;
@@ -276,8 +281,17 @@ int srhip_conv3x3_nhwc_bx3(const float* X, long ldx, const void* Wb, const float
 int srhip_conv3x3_nhwc_f16x2(const float* X, long ldx, const void* Wh, const float* bias, float* Y, long ldy,
                              int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                              const float* rowscale, float alpha, void* stream) {
-  SR_REQUIRE((Cout <= 256 || Cout % 180 == 0) && Cin <= 256, "conv3x3_f16x2: Cout <= 256 or a multiple of 180, Cin <= 256 (Cout=%d Cin=%d)", Cout, Cin);
+  SR_REQUIRE((Cout <= 4096 || Cout % 180 == 0) && Cin <= 4096, "conv3x3_f16x2: Cout <= 4096 or a multiple of 180, Cin <= 4096 (Cout=%d Cin=%d)", Cout, Cin);
   return conv3x3_split(1, X, ldx, Wh, bias, Y, ldy, B, H, W, Cin, Cout, epi, R, ldr, rowscale, alpha, stream);
+}
+
+int srhip_conv3x3_nhwc_split_ex(int wfmt, const float* X, long ldx, const void* Wp, const float* bias, float* Y, long ldy,
+                                int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
+                                const float* rowscale, float alpha, const float* in_bn_coef, const float* slope,
+                                void* stream) {
+  SR_REQUIRE(wfmt == 0 || wfmt == 1, "conv3x3_split_ex: weight format %d (0 three bf16 planes, 1 two fp16 planes)", wfmt);
+  SR_REQUIRE(wfmt == 0 || ((Cout <= 4096 || Cout % 180 == 0) && Cin <= 4096), "conv3x3_f16x2: Cout <= 4096 or a multiple of 180, Cin <= 4096 (Cout=%d Cin=%d)", Cout, Cin);
+  return conv3x3_split(wfmt, X, ldx, Wp, bias, Y, ldy, B, H, W, Cin, Cout, epi, R, ldr, rowscale, alpha, stream, in_bn_coef, slope);
 }
 
 int srhip_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats) {

@@ -435,7 +435,7 @@ int dispatch_ntb(NtArgs& p, hipStream_t st) {
   }
   if constexpr (CONV) {       // weight planes of format 1 (two fp16 planes, prep kind 4): k_nhcw2 (64-column tiles / slices) or k_nhcw
     if (p.wfmt == 1) {          // 64-column slices (column block fastest) for wider outputs, as k_ntcw2
-      SR_REQUIRE((p.N <= 256 || p.N % 180 == 0) && p.K <= 256, "conv3x3_f16x2: Cout <= 256 or a multiple of 180, Cin <= 256 (Cout=%d Cin=%d)", p.N, p.K);
+      SR_REQUIRE((p.N <= 4096 || p.N % 180 == 0) && p.K <= 4096, "conv3x3_f16x2: Cout <= 4096 or a multiple of 180, Cin <= 4096 (Cout=%d Cin=%d)", p.N, p.K);
       if (wn == 3 && p.N % 64 != 0 && p.ps == 0) {     // 180 / 192-column tiles (SwinIR): 64-pixel tiles whatever the image size
         p.tiles_y = sr_cdiv(p.H, 4);
         return sr_conv3x3_nhcw(p, st);

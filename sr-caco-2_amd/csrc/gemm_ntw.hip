@@ -1029,6 +1029,10 @@ __global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
     if (p.ps == 2) offA[it] = (unsigned)(((img * 2 * p.H + 2 * yc) * 2 * p.Wd + 2 * xc) * (int)p.lda + c4 * 4) * 4u;
     else offA[it] = (unsigned)(((img * p.H + yc) * p.Wd + xc) * (int)p.lda + c4 * 4) * 4u;
   }
+  // input prologue (evaluation-mode BatchNorm + ReLU in front of the conv, network_memnet.py:27-34): relu((x - mean) k +
+  // beta) per channel, applied to the halo tile on its way into the stage images -- the zero padding is of the
+  // ACTIVATION, so it is applied before the out-of-image pixels are zeroed.  Same expression as k_bn_apply (bn.hip).
+  f32x4 pro_mean = {0.f, 0.f, 0.f, 0.f}, pro_k = {1.f, 1.f, 1.f, 1.f}, pro_beta = {0.f, 0.f, 0.f, 0.f};
   auto load_a = [&](int kc, f32x4 (&ra)[D_AIT]) {
     long koff = kc * 32;
     if (p.ps == 2) {     // chunk kc = channels c0.. of sub-pixel sp of the shuffled image (K/4 is a multiple of 32)
@@ -1042,6 +1046,12 @@ __global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
       const bool oob = kc * 32 + c4 * 4 >= p.K;
       ra[it] = *(const f32x4*)((oob ? (const char*)p.A : base) + (oob ? offA[it] - c4 * 16u : offA[it]));
     }
+    if (p.pro_coef) {    // the thread's four channels of the chunk (256 % 8 == 0: the same in every iteration)
+      const int ch = min(kc * 32 + (tid & 7) * 4, p.K - 4);
+      pro_mean = ldg_f4(p.pro_coef + ch);
+      pro_k = ldg_f4(p.pro_coef + 2 * p.K + ch);
+      pro_beta = ldg_f4(p.pro_coef + 3 * p.K + ch);
+    }
   };
   float* const red = (float*)(smem + 3 * D_APLANE);          // [4] wave maxima of the chunk (behind the halo planes)
   float cur = 3.0e38f;                                       // the tile's current 2^s (block-uniform)
@@ -1052,6 +1062,10 @@ __global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
     for (int it = 0; it < D_AIT; ++it) {
       const int idx = tid + it * 256;
       f32x4 v = ra[it];
+      if (p.pro_coef) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - pro_mean[e]) * pro_k[e] + pro_beta[e], 0.f);
+      }
       if (!(D_AN % 256 == 0 || idx < D_AN) || !inA[it] || kc * 32 + (idx & 7) * 4 >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};
       ra[it] = v;
       mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));

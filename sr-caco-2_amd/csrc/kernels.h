@@ -16,6 +16,9 @@ struct NtArgs {
   int a_mode;                 // 0 plain | 1 (x-mean)*rstd from ln_stats | 2 gelu(x)
   const float* ln_stats;      // [M][2] = mean, rstd
   int epi;                    // 0 +bias | 1 relu | 2 R + s*(acc+bias) | 3 s*acc*gelu'(R) | 4 acc*(R>0) | 6 leaky relu(alpha) | 7 acc*(R>0 ? 1 : alpha)
+                              // | 8 relu(R + s*(acc+bias)) | 9 prelu(acc+bias; *slope) | 10 prelu(acc+bias; *slope) + alpha*R
+  const float* slope;         // epi 9 / 10: the PReLU's one learnable slope, on the device
+  const float* pro_coef;      // conv (k_nhcw2): BatchNorm (evaluation) + ReLU on the INPUT, coef [4][K] = mean, rstd, gamma*rstd, beta
   const float* R; long ldr;
   float* aux; long ldaux;     // epi 3: optional second output gelu(R)
   // epi 5 (LayerNorm backward, bx3 GEMM only): R = x, R2 = residual gradient, ep_stats = {mean, rstd}[M]

@@ -91,7 +91,9 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][W
   // The epilogue mode is block-uniform: switch OUTSIDE the element loops, and
   // batch the 16 loads of a tile ahead of the math (one wait per tile, not one
   // per element).
-  const bool needR = p.R != nullptr && p.epi >= 2;
+  const bool needR = p.R != nullptr && p.epi >= 2 && p.epi != 9;
+  const float slope = (p.epi == 9 || p.epi == 10) ? ldg_f(p.slope) : 0.f;
+  if (p.epi == 9 || p.epi == 10) blk_s = 1.f;       // alpha is the residual's factor there
   // pass 1: ALL residual / gate loads of the wave (WM x WN tiles x 16) are issued
   // before any of them is used: the epilogue is latency bound otherwise (every block
   // of the launch reaches it at the same moment)
@@ -210,6 +212,18 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][W
         case 7:            // its backward: R = the activation's OUTPUT (same sign as its input)
 #pragma unroll
           for (int q = 0; q < 16; ++q) v[q] = rv[q] > 0.f ? v[q] : v[q] * p.alpha;
+          break;
+        case 8:            // residual, then ReLU (DRRN's unit, network_drrn.py:58-62)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = fmaxf(v[q] * blk_s + rv[q], 0.f);
+          break;
+        case 9:            // PReLU, one slope (network_dbpn.py ConvBlock / DeconvBlock activation)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = v[q] > 0.f ? v[q] : slope * v[q];
+          break;
+        case 10:           // PReLU, then + alpha * R (the projection units' l0 - x / h1 + h0)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = (v[q] > 0.f ? v[q] : slope * v[q]) + p.alpha * rv[q];
           break;
         default:
           break;

@@ -163,7 +163,7 @@ __device__ __forceinline__ void job_planes_f16(const PrepEntry& e, int lb) {
 
 // kind 4 (experiment, SRHIP_F16X2_CONV=1): the tap-major conv pack as TWO fp16 planes with a power-of-two scale per OUTPUT
 //   channel (one scale for the channel's nine tap rows: they accumulate into the same output column); planes
-//   [2][Kp/16][9*n0][16] fp16, then n0 floats 2^-s(n).  One wave per output channel; K <= 256; perms 3 / 4 (PixelShuffle orders) as kind 0.
+//   [2][Kp/16][9*n0][16] fp16, then n0 floats 2^-s(n).  One wave per output channel, 256 k per pass; K <= 4096; perms 3 / 4 (PixelShuffle orders) as kind 0.
 __device__ __forceinline__ void job_conv_planes_f16(const PrepEntry& e, int lb) {
   const int Kp = sr_kp(e.n2);
   const int n = lb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -172,41 +172,51 @@ __device__ __forceinline__ void job_conv_planes_f16(const PrepEntry& e, int lb) 
   const int perm = e.mode >> 2;
   int rs = n;
   if (perm == 3) { const int fs = e.n0 >> 2; rs = (n % fs) * 4 + n / fs; }
+  // 256 k per pass of the wave (K <= 256: one pass, the values stay in registers between the maximum and the split)
+  const int nch = (Kp + 255) >> 8;
   float v[9][4];
-  float mx = 0.f;
+  auto load_chunk = [&](int ch) -> float {
+    float m = 0.f;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int k = lane * 4 + q;
-      float x = 0.f;
-      if (k < e.n2) {
-        if (perm == 4) { const int fs = e.n2 >> 2; k = (k % fs) * 4 + k / fs; }
-        x = ldg_f(e.a + (long)e.off + (long)t * e.s0 + (long)rs * e.s1 + (long)k * e.s2);
+      for (int q = 0; q < 4; ++q) {
+        int k = ch * 256 + lane * 4 + q;
+        float x = 0.f;
+        if (k < e.n2) {
+          if (perm == 4) { const int fs = e.n2 >> 2; k = (k % fs) * 4 + k / fs; }
+          x = ldg_f(e.a + (long)e.off + (long)t * e.s0 + (long)rs * e.s1 + (long)k * e.s2);
+        }
+        v[t][q] = x;
+        m = fmaxf(m, fabsf(x));
       }
-      v[t][q] = x;
-      mx = fmaxf(mx, fabsf(x));
-    }
+    return m;
+  };
+  float mx = 0.f;
+  for (int ch = 0; ch < nch; ++ch) mx = fmaxf(mx, load_chunk(ch));
   mx = wave_max(mx);
   const float sc = mx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / mx)), 100.f)) : 1.f;
   const long rows = 9L * e.n0, plane = rows * Kp;
   unsigned short* base = (unsigned short*)e.out;
-  const int k0 = lane * 4;
-  if (k0 < Kp) {
+  for (int ch = 0; ch < nch; ++ch) {
+    if (nch > 1) load_chunk(ch);
+    const int k0 = ch * 256 + lane * 4;
+    if (k0 < Kp) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      unsigned short hh[4], ll[4];
+      for (int t = 0; t < 9; ++t) {
+        unsigned short hh[4], ll[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float xs = v[t][q] * sc;
-        const _Float16 h = (_Float16)xs;
-        const _Float16 l = (_Float16)(xs - (float)h);
-        hh[q] = __builtin_bit_cast(unsigned short, h);
-        ll[q] = __builtin_bit_cast(unsigned short, l);
+        for (int q = 0; q < 4; ++q) {
+          const float xs = v[t][q] * sc;
+          const _Float16 h = (_Float16)xs;
+          const _Float16 l = (_Float16)(xs - (float)h);
+          hh[q] = __builtin_bit_cast(unsigned short, h);
+          ll[q] = __builtin_bit_cast(unsigned short, l);
+        }
+        unsigned short* d = base + ((long)(k0 >> 4) * rows + (long)t * e.n0 + n) * 16 + (k0 & 15);
+        *(u32x2*)(d) = u32x2{(unsigned)hh[0] | ((unsigned)hh[1] << 16), (unsigned)hh[2] | ((unsigned)hh[3] << 16)};
+        *(u32x2*)(d + plane) = u32x2{(unsigned)ll[0] | ((unsigned)ll[1] << 16), (unsigned)ll[2] | ((unsigned)ll[3] << 16)};
       }
-      unsigned short* d = base + ((long)(k0 >> 4) * rows + (long)t * e.n0 + n) * 16 + (k0 & 15);
-      *(u32x2*)(d) = u32x2{(unsigned)hh[0] | ((unsigned)hh[1] << 16), (unsigned)hh[2] | ((unsigned)hh[3] << 16)};
-      *(u32x2*)(d + plane) = u32x2{(unsigned)ll[0] | ((unsigned)ll[1] << 16), (unsigned)ll[2] | ((unsigned)ll[3] << 16)};
     }
   }
   if (lane == 0) ((float*)(base + 2 * plane))[n] = 1.0f / sc;
@@ -234,7 +244,7 @@ int sr_prep_blocks(const PrepEntry& e) {
   if (e.kind == 1) return sr_cdiv(e.n0, 4);
   if (e.kind == 2) return sr_cdiv((long)e.n0 * 4096, 256);
   if (e.kind == 3) return (e.n1 == 1 && e.n2 <= 1024 && (e.mode >> 2) == 0) ? sr_cdiv(e.n0, 4) : -1;
-  if (e.kind == 4) return (e.n1 == 9 && e.n2 <= 256 && (e.mode == 0 || e.mode == 12 || e.mode == 16)) ? sr_cdiv(e.n0, 4) : -1;
+  if (e.kind == 4) return (e.n1 == 9 && e.n2 <= 4096 && (e.mode == 0 || e.mode == 12 || e.mode == 16)) ? sr_cdiv(e.n0, 4) : -1;
   return -1;
 }
 

@@ -35,15 +35,14 @@ class DBPNEngine(TapeEngine):
                        act=lambda v: t.prelu(v, blk.conv.act.weight, name + ".conv.act.weight"))
         subs = ("up_conv1", "up_conv2", "up_conv3") if up else ("down_conv1", "down_conv2", "down_conv3")
 
-        def run(sub, v, is_deconv):
+        def run(sub, v, is_deconv, add=None):
             m = getattr(blk, sub)
             inner = "deconv" if is_deconv else "conv"
             return t.conv(v, f"{name}.{sub}", (f"{name}.{sub}.{inner}.weight", f"{name}.{sub}.{inner}.bias"),
-                          act=lambda u: t.prelu(u, m.act.weight, f"{name}.{sub}.act.weight"))
+                          prelu=(m.act.weight, f"{name}.{sub}.act.weight"), add=add)
         a0 = run(subs[0], x, up)
-        b0 = run(subs[1], a0, not up)
-        a1 = run(subs[2], t.axpby(b0, x, 1.0, -1.0), up)
-        return t.axpby(a1, a0, 1.0, 1.0)
+        d0 = run(subs[1], a0, not up, add=(x, -1.0))         # l0 - x  (h0 - x)
+        return run(subs[2], d0, up, add=(a0, 1.0))           # h1 + h0  (l1 + l0)
 
     def graph(self, t, x3):
         net = self.net

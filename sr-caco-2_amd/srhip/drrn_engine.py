@@ -10,8 +10,8 @@ the ReLU in front of conv1 acts on an input that is already in [0, 1]:
     x0 = relu(conv1(xi));  r_0 = x0;  a_k = relu(conv_a(r_k));  r_{k+1} = relu(conv_b(a_k) + x0);
     y  = conv2(r_U) + xi
 
-Launches: the 1-channel edge conv with a fused ReLU, 2U bf16x3 implicit-GEMM convs (ReLU / residual
-epilogues; the residual unit's ReLU is one in-place pass), the 128->1 edge conv.  The weight gradients of the
+Launches: the 1-channel edge conv with a fused ReLU, 2U split-operand implicit-GEMM convs (epilogues: ReLU /
+residual + ReLU, srhip_conv3x3_nhwc_split_ex epi 8), the 128->1 edge conv.  The weight gradients of the
 shared convs are summed over the U applications.
 """
 import torch
@@ -92,8 +92,11 @@ class DRRNEngine:
             a = buf(f"a{k if save else 0}", B, H, W, CH)
             ops.conv3x3(r, self.ws["wa.wp"], None, CH, out=a, epi=1)
             rn = buf(f"r{k + 1 if save else 1 + k % 2}", B, H, W, CH)
-            ops.conv3x3(a, self.ws["wb.wp"], None, CH, out=rn, epi=2, R=x0)
-            ops.relu_mask(rn, rn)                            # r_{k+1} = relu(conv_b(a_k) + x0), in place
+            if self.ws.use_bx3:                              # r_{k+1} = relu(conv_b(a_k) + x0): residual + ReLU as the epilogue
+                ops.conv3x3(a, self.ws["wb.wp"], None, CH, out=rn, epi=8, R=x0)
+            else:
+                ops.conv3x3(a, self.ws["wb.wp"], None, CH, out=rn, epi=2, R=x0)
+                ops.relu_mask(rn, rn)
             if save:
                 rs.append(r)
                 as_.append(a)

@@ -10,8 +10,10 @@ BN-ReLU-conv1x1.  A residual unit is x + conv(relu(BN(conv(relu(BN(x)))))); no c
 On the device (NHWC, T = B*H*W pixels):
   BatchNorm      training: srhip_bn_stats (batch statistics -> coefficients, running statistics updated in place, in the
                  order of application, as the reference's sequential calls do) + srhip_bn_apply (ReLU fused);
-                 evaluation: coefficients from the running statistics, srhip_bn_apply only
-  3x3 convs      the bf16x3 implicit-GEMM conv; the unit's skip connection is its epilogue (epi 2)
+                 evaluation: coefficients from the running statistics; a residual unit's two BatchNorms ride in its
+                 first conv (the one in front as the BN-ReLU input prologue of srhip_conv3x3_nhwc_split_ex, the one behind
+                 folded into the weight), srhip_bn_apply only for the gate and the two ends
+  3x3 convs      the split-operand implicit-GEMM conv; the unit's skip connection is its epilogue (epi 2)
   gate 1x1 conv  the bf16x3 NT GEMM on the [T, gate_channels] concatenation (in row chunks below 2 GiB)
   1-channel ends the edge-conv kernels (the 64 -> 1 1x1 conv as a 3x3 with only its centre tap set)
   backward       ReLU masks ride in the data-gradient convs / GEMM (epi 4); srhip_bn_bwd = one reduction + one apply
@@ -167,13 +169,21 @@ class MemNetEngine:
                     key = f"m{i}.r{r}.u{j}" if save else "scr"
                     a1, c1, a2 = buf(key + ".a1", B, H, W, CH), buf(key + ".c1", B, H, W, CH), buf(key + ".a2", B, H, W, CH)
                     nxt = buf(key + ".out" if save else f"scr.out{n % 2}", B, H, W, CH)
-                    k1 = bn(u + ".0", key + ".k1", out, a1)
                     if training:
+                        k1 = bn(u + ".0", key + ".k1", out, a1)
                         ops.conv3x3(a1, ws[f"m{i}.u{j}.c0.wp"], None, CH, out=c1)
                         k2 = bn(u + ".3", key + ".k2", c1, a2)
-                    else:               # conv 0 with the BatchNorm behind it folded in, ReLU as its epilogue
-                        ops.conv3x3(a1, ws[f"m{i}.u{j}.c0.wpf"], D.d[f"m{i}.u{j}.c0.bfold"], CH, out=a2, epi=1)
-                        k2 = None
+                    else:
+                        # conv 0 with the BatchNorm behind it folded into its weight (ReLU: its epilogue) and the BatchNorm-
+                        # ReLU in front of it applied to the halo tile as it is staged (srhip_conv3x3_nhwc_split_ex): the
+                        # unit is two launches and no pass over the feature map besides them
+                        wpf = ws[f"m{i}.u{j}.c0.wpf"]
+                        k1 = k2 = None
+                        if wpf.fmt == 1:
+                            ops.conv3x3(out, wpf, D.d[f"m{i}.u{j}.c0.bfold"], CH, out=a2, epi=1, in_bn=D.d["coef." + u + ".0"])
+                        else:
+                            bn(u + ".0", key + ".k1", out, a1)
+                            ops.conv3x3(a1, wpf, D.d[f"m{i}.u{j}.c0.bfold"], CH, out=a2, epi=1)
                     ops.conv3x3(a2, ws[f"m{i}.u{j}.c1.wp"], None, CH, out=nxt, epi=2, R=out)     # + the unit's input
                     if save:
                         apps.append(dict(x=out, a1=a1, c1=c1, a2=a2, k1=k1, k2=k2, j=j))

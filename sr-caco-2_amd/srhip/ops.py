@@ -58,6 +58,8 @@ F16X2 = _os.environ.get("SRHIP_F16X2", "1") not in ("", "0")
 F16X2_CONV = _os.environ.get("SRHIP_F16X2_CONV", "1") not in ("", "0")
 F16X2_CONV_WIDE = _os.environ.get("SRHIP_F16X2_CONV_WIDE", "1") != "0"
 F16X2_CONV180 = _os.environ.get("SRHIP_F16X2_CONV180", "1") != "0"
+# widest output / reduce side that takes the fp16x2 conv (DBPN / SRFBN's stride-8 transposed convs are 64 -> 4096 and back)
+F16X2_CONV_MAX = int(_os.environ.get("SRHIP_F16X2_CONV_MAX", "4096"))
 
 
 # The NT side (conv / Linear forward and data gradient) has its own threshold: at 64 -> 64 channels, B=8, 128x128
@@ -178,7 +180,7 @@ class PrepTable:
         self.keep += [w, out]
         # two fp16 planes + per-output-channel scales (prep kind 4; SRHIP_F16X2_CONV=0: bf16x3) for the convs that run
         # on 64-column tiles / slices (k_nhcw2, gemm_ntw.hip): output side a multiple of 64 up to 256, reduce side 64 .. 256
-        f16 = F16X2_CONV and rows % 64 == 0 and rows <= 256 and 64 <= kd <= 256
+        f16 = F16X2_CONV and rows % 64 == 0 and rows <= F16X2_CONV_MAX and 64 <= kd <= F16X2_CONV_MAX
         if F16X2_CONV and F16X2_CONV180 and not ps2 and rows % 180 == 0 and 64 <= kd <= 256:
             f16 = True              # SwinIR's 180-column convs: k_nhcw (64-pixel x 192-column tiles); SRHIP_F16X2_CONV180=0: k_ntcw
         if not F16X2_CONV_WIDE:     # SRHIP_F16X2_CONV_WIDE=0: only the 64-column convs without a fused PixelShuffle
@@ -706,10 +708,12 @@ def mlp_bwd_f16(dy, W2T, W1T, h, dh, gh, x, stats, dx, rowscale=None, rows_per_s
     return dx
 
 
-def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0):
-    """X NHWC [B,H,W,Cin], Wp packed [9,Cout,Cin] (f32 tensor or Bx3) -> [B,H,W,Cout]."""
+def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0, in_bn=None, slope=None):
+    """X NHWC [B,H,W,Cin], Wp packed [9,Cout,Cin] (f32 tensor or Bx3) -> [B,H,W,Cout].
+    in_bn (coef [4, Cin] of srhip_bn_apply; fp16x2 weight planes) / slope (PReLU's one-element parameter) / epi 8-10: the
+    folds of srhip_conv3x3_nhwc_split_ex."""
     bx = isinstance(Wp, Bx3)
-    _chk(X, None if bx else Wp, bias, out, R, rowscale)
+    _chk(X, None if bx else Wp, bias, out, R, rowscale, in_bn, slope)
     B, H, W, Cin = X.shape
     if out is None:
         out = torch.empty(B, H, W, Cout, device=X.device, dtype=torch.float32)
@@ -719,6 +723,11 @@ def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0
             B, H, W, Cin, Cout, epi, _p(R), 0 if R is None else R.stride(2), _p(rowscale),
             float(alpha), _st())
     name = ("srhip_conv3x3_nhwc_f16x2" if Wp.fmt == 1 else "srhip_conv3x3_nhwc_bx3") if bx else "srhip_conv3x3_nhwc"
+    if in_bn is not None or slope is not None or epi >= 8:
+        assert bx, "conv3x3: prologue / epilogues 8-10 run on the split-operand kernels"
+        assert in_bn is None or (Wp.fmt == 1 and tuple(in_bn.shape) == (4, Cin) and in_bn.is_contiguous())
+        name = "srhip_conv3x3_nhwc_split_ex"
+        args = (int(Wp.fmt),) + args[:-1] + (_p(in_bn), _p(slope), _st())
     if probe.on("conv_nt"):
         T = B * H * W
         with probe.timed(("conv_nt", T, Cout, Cin), 18.0 * T * Cout * Cin,

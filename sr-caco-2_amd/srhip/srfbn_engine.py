@@ -37,8 +37,7 @@ class SRFBNEngine(TapeEngine):
         def cna(v, key, pre):
             """conv + PReLU of Sequential `pre` (parameters pre.0.weight / pre.0.bias / pre.1.weight)."""
             mod = net.get_submodule(pre)
-            return t.conv(v, key, (pre + ".0.weight", pre + ".0.bias"),
-                          act=lambda u: t.prelu(u, mod[1].weight, pre + ".1.weight"))
+            return t.conv(v, key, (pre + ".0.weight", pre + ".0.bias"), prelu=(mod[1].weight, pre + ".1.weight"))
         x = t.conv_in1(x3, net.conv_in[0].weight, net.conv_in[0].bias, ("conv_in.0.weight", "conv_in.0.bias"))
         x = t.prelu(x, net.conv_in[1].weight, "conv_in.1.weight")
         x = cna(x, "feat_in", "feat_in")

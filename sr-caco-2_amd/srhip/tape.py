@@ -284,9 +284,12 @@ class Tape:
             ops.axpby(gt, tmp, 1.0, 1.0)
 
     # ---- ops
-    def conv(self, x, key, names, act=None):
+    def conv(self, x, key, names, act=None, prelu=None, add=None):
         """x -> conv (bank entry `key`) [-> PixelShuffle / after PixelUnshuffle for the strided forms].
-        names = (weight parameter name, bias parameter name or None)."""
+        names = (weight parameter name, bias parameter name or None).
+        prelu = (slope parameter, its name), add = (Var, factor): out = prelu(conv(x)) + factor * Var (DBPN's projection
+        units).  In evaluation mode both ride in the 3x3 conv's epilogue (srhip_conv3x3_nhwc_split_ex epi 9 / 10; the
+        addend of a transposed conv is added behind its PixelShuffle); with the tape recording they are the ordinary ops."""
         e = self.bank.d[key]
         if e.kind == "down":
             x = self.unshuffle(x, e.s)
@@ -296,9 +299,19 @@ class Tape:
         y = self.new(B, H, W, e.Co)
         xin = x.t if x.t.is_contiguous() else x.t.contiguous()
         cks = _chunks(B, H * W * max(Ci, e.Co))
+        fuse = prelu is not None and not self.save and e.kind != "c1" and e.use_planes
+        fuse_add = fuse and add is not None and e.kind != "deconv"
+        radd = None
+        if fuse_add:
+            radd = add[0].t if add[0].t.is_contiguous() else add[0].t.contiguous()
         for b0, b1 in cks:
             if e.kind == "c1":
                 ops.gemm_nt(xin[b0:b1].view(-1, Ci), e.w1, e.bias, out=y[b0:b1].view(-1, e.Co))
+            elif fuse_add:
+                ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1], epi=10, R=radd[b0:b1], alpha=float(add[1]),
+                            slope=prelu[0].data)
+            elif fuse:
+                ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1], epi=9, slope=prelu[0].data)
             else:
                 ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1])
         out = self._out(y)
@@ -358,6 +371,10 @@ class Tape:
             out = self.shuffle(out, e.s)
         if act is not None:
             out = act(out)
+        if prelu is not None and not fuse:
+            out = self.prelu(out, prelu[0], prelu[1])
+        if add is not None and not fuse_add:
+            out = self.axpby(out, add[0], 1.0, float(add[1]))
         return out
 
     def enlca(self, x, keys, proj, res_scale):
