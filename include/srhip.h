@@ -561,6 +561,10 @@ int srhip_conv3x3_cout1_fwd(const float* x, long ldx, const float* w, const floa
  * inverse=1 runs the mapping backwards (gradient). */
 int srhip_pixel_shuffle(const float* in, float* out, int B, int h, int w, int Co, int r,
                         int nhwc_out, int inverse, void* stream);
+/* out NHWC [B][h*r][w*r][Co] = PixelShuffle(in) + fac * add (add laid out as out): the addend behind a transposed conv run as
+ * conv3x3 + PixelShuffle (DBPN's projection units, network_dbpn.py:93-99,128-134).  Co*(r*r+1)*4 <= 48 KB, Co*r*r >= 256. */
+int srhip_pixel_shuffle_add(const float* in, float* out, int B, int h, int w, int Co, int r, const float* add, float fac,
+                            void* stream);
 
 /* ---- losses (dlib/loss/main.py:45-99; MasterLoss dlib/loss/master.py:46-56) -- */
 /* mode 0: lam*mean(|pred-target| * weight?) ; mode 1: lam*mean((pred-target)^2).

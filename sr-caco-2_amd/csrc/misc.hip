@@ -478,8 +478,11 @@ __global__ void k_pixel_shuffle(const float* __restrict__ in, float* __restrict_
 // one low-res pixel per block pass.  Its Co*r*r values are one contiguous run and its r*r high-res pixels are runs of Co
 // channels: the [Co][r*r] -> [r*r][Co] transposition goes through LDS (row pitch r*r + 1: both sides conflict free), so
 // both global sides move whole cache lines -- the element-wise gather reached 0.8 TB/s on the 16-KB runs of r = 8.
+// add (forward only): out = shuffled + fac * add, add laid out as out (a projection unit's h1 + h0 / h0 - x behind a
+// transposed conv, network_dbpn.py:93-99,128-134).
 __global__ void __launch_bounds__(256) k_pixel_shuffle_nhwc_t(const float* __restrict__ in, float* __restrict__ out, long npix,
-                                                              int h, int w, int Co, int r, int inverse) {
+                                                              int h, int w, int Co, int r, int inverse,
+                                                              const float* __restrict__ add, float fac) {
   extern __shared__ float tile[];                 // [Co][r*r + 1]
   const int rr = r * r, P = rr + 1, n = Co * rr;
   const long W = (long)w * r;
@@ -496,7 +499,8 @@ __global__ void __launch_bounds__(256) k_pixel_shuffle_nhwc_t(const float* __res
       __syncthreads();
       for (int i = threadIdx.x; i < n; i += 256) {
         const int s = i / Co, c = i - s * Co;
-        out[hi0 + ((long)(s / r) * W + s % r) * Co + c] = tile[c * P + s];
+        const long o = hi0 + ((long)(s / r) * W + s % r) * Co + c;
+        out[o] = add ? tile[c * P + s] + fac * add[o] : tile[c * P + s];
       }
     } else {
       for (int i = threadIdx.x; i < n; i += 256) {
@@ -923,10 +927,21 @@ int srhip_layernorm_bwd(const float* dy, const float* x, const float* stats, con
   return 0;
 }
 
+static int pixel_shuffle_any(const float* in, float* out, int B, int h, int w, int Co, int r, int nhwc_out, int inverse,
+                             const float* add, float fac, void* stream);
 int srhip_pixel_shuffle(const float* in, float* out, int B, int h, int w, int Co, int r,
                         int nhwc_out, int inverse, void* stream) {
+  return pixel_shuffle_any(in, out, B, h, w, Co, r, nhwc_out, inverse, nullptr, 0.f, stream);
+}
+int srhip_pixel_shuffle_add(const float* in, float* out, int B, int h, int w, int Co, int r, const float* add, float fac,
+                            void* stream) {
+  SR_REQUIRE(add, "pixel_shuffle_add: null addend");
+  return pixel_shuffle_any(in, out, B, h, w, Co, r, 1, 0, add, fac, stream);
+}
+static int pixel_shuffle_any(const float* in, float* out, int B, int h, int w, int Co, int r, int nhwc_out, int inverse,
+                             const float* add, float fac, void* stream) {
   SR_REQUIRE(r >= 1 && Co >= 1, "pixel_shuffle: bad r/Co");
-  if (r == 2 && nhwc_out && (long)B * h < 65536 && ((size_t)in & 15) == 0 && ((size_t)out & 15) == 0) {
+  if (!add && r == 2 && nhwc_out && (long)B * h < 65536 && ((size_t)in & 15) == 0 && ((size_t)out & 15) == 0) {
     // fast path: in = low-res side [B][h][w][4*Co], out = high-res side [B][2h][2w][Co]
     // (inverse: `in` is the high-res side, `out` the low-res one)
     dim3 grid(sr_cdiv((long)w * sr_cdiv(Co, 64), 4) < 64 ? sr_cdiv((long)w * sr_cdiv(Co, 64), 4) : 64, B * h);
@@ -940,10 +955,11 @@ int srhip_pixel_shuffle(const float* in, float* out, int B, int h, int w, int Co
   if (nhwc_out && r > 1 && (long)Co * (r * r + 1) * 4 <= 48 * 1024 && Co * r * r >= 256) {
     const long npix = (long)B * h * w;
     hipLaunchKernelGGL(k_pixel_shuffle_nhwc_t, dim3((unsigned)(npix < 65536 ? npix : 65536)), dim3(256), (size_t)Co * (r * r + 1) * 4,
-                       (hipStream_t)stream, in, out, npix, h, w, Co, r, inverse);
+                       (hipStream_t)stream, in, out, npix, h, w, Co, r, inverse, add, fac);
     SR_LAUNCH_CHECK("pixel_shuffle_nhwc");
     return 0;
   }
+  SR_REQUIRE(!add, "pixel_shuffle_add: runs on the channels-last transposing kernel (Co (r r + 1) * 4 <= 48 KB, Co r r >= 256; Co=%d r=%d)", Co, r);
   hipLaunchKernelGGL(k_pixel_shuffle, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, in, out,
                      B, h, w, Co, r, nhwc_out, inverse);
   SR_LAUNCH_CHECK("pixel_shuffle");

@@ -1159,10 +1159,23 @@ def conv3x3_cout1_fwd(x, w, bias, out=None):
 
 
 # ------------------------------------------------------------------ pixel shuffle
-def pixel_shuffle(x, r, nhwc_out=False, inverse=False, out=None):
+def pixel_shuffle_add_ok(Co, r):
+    """shapes srhip_pixel_shuffle_add takes"""
+    return r > 1 and Co * (r * r + 1) * 4 <= 48 * 1024 and Co * r * r >= 256
+
+
+def pixel_shuffle(x, r, nhwc_out=False, inverse=False, out=None, add=None, fac=1.0):
     """forward: x NHWC [B,h,w,Co*r*r] -> NCHW [B,Co,h*r,w*r] (or NHWC).  inverse:
-    x is the high-res side and the NHWC low-res tensor is returned."""
-    _chk(x, out)
+    x is the high-res side and the NHWC low-res tensor is returned.  add (NHWC forward only): out = shuffled + fac * add."""
+    _chk(x, out, add)
+    if add is not None:
+        B, h, w, C = x.shape
+        Co = C // (r * r)
+        assert nhwc_out and not inverse and add.is_contiguous() and tuple(add.shape) == (B, h * r, w * r, Co)
+        if out is None:
+            out = torch.empty(B, h * r, w * r, Co, device=x.device, dtype=torch.float32)
+        call("srhip_pixel_shuffle_add", _p(x), _p(out), B, h, w, Co, r, _p(add), float(fac), _st())
+        return out
     if not inverse:
         B, h, w, C = x.shape
         Co = C // (r * r)

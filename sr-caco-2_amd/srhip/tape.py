@@ -368,6 +368,12 @@ class Tape:
                 self.acc(x, dgrad3)
             self.back.append(bwd)
         if e.kind == "deconv":
+            if fuse and add is not None and ops.pixel_shuffle_add_ok(e.Co // (e.s * e.s), e.s):
+                # evaluation: the addend of a transposed conv goes in with its PixelShuffle
+                yh = self.new(B, H * e.s, W * e.s, e.Co // (e.s * e.s))
+                ra = add[0].t if add[0].t.is_contiguous() else add[0].t.contiguous()
+                ops.pixel_shuffle(out.t, e.s, nhwc_out=True, out=yh, add=ra, fac=float(add[1]))
+                return self._out(yh)
             out = self.shuffle(out, e.s)
         if act is not None:
             out = act(out)

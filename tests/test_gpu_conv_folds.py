@@ -89,3 +89,19 @@ def test_entry_point_rejects_what_it_cannot_run():
         ops.conv3x3(x, wp, b, 64, epi=8)                       # no addend
     with pytest.raises(RuntimeError):
         ops.conv3x3(x, wp, b, 64, epi=10, slope=slope)         # no addend
+
+
+@pytest.mark.parametrize("Co,r", [(64, 8), (64, 4), (64, 2), (16, 8)])
+def test_pixel_shuffle_with_addend(Co, r):
+    from srhip import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 5, 7, Co * r * r, generator=g).cuda()
+    a = torch.randn(2, 5 * r, 7 * r, Co, generator=g).cuda()
+    ref = F.pixel_shuffle(x.permute(0, 3, 1, 2), r).permute(0, 2, 3, 1)
+    if not ops.pixel_shuffle_add_ok(Co, r):
+        with pytest.raises(RuntimeError):
+            ops.pixel_shuffle(x, r, nhwc_out=True, add=a, fac=-1.0)
+        return
+    for fac in (1.0, -1.0):
+        y = ops.pixel_shuffle(x, r, nhwc_out=True, add=a, fac=fac)
+        assert torch.equal(y, ref + fac * a) or (y - (ref + fac * a)).abs().max().item() <= 1e-6
