@@ -266,8 +266,9 @@ def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
     else:
         assert stats_out is None, "row statistics are produced by the bx3 kernel only"
         name, args = "srhip_gemm_nt", (_p(A), A.stride(0), _p(W), W.stride(0)) + tail
-    if probe.on("gemm_nt"):
-        with probe.timed(("gemm_nt", M, N, K), 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)):
+    kind = "gemm_nt" if bx else "gemm_nt_f32"
+    if probe.on(kind):
+        with probe.timed((kind, M, N, K), 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)):
             call(name, *args)
     else:
         call(name, *args)
@@ -279,8 +280,13 @@ def gemm_nt_batched(A, a_z, W, w_z, C, c_z, M, N, K, zcount, zdiv):
     base pointer and row pitch of problem 0; *_z = (stride per z // zdiv, stride per z % zdiv) in floats."""
     _chk(A, W, C)
     assert A.stride(-1) == 1 and W.stride(-1) == 1 and C.stride(-1) == 1
-    call("srhip_gemm_nt_batched", A.data_ptr(), A.stride(-2), a_z[0], a_z[1], W.data_ptr(), W.stride(-2), w_z[0], w_z[1],
-         C.data_ptr(), C.stride(-2), c_z[0], c_z[1], M, N, K, zcount, zdiv, _st())
+    args = (A.data_ptr(), A.stride(-2), a_z[0], a_z[1], W.data_ptr(), W.stride(-2), w_z[0], w_z[1],
+            C.data_ptr(), C.stride(-2), c_z[0], c_z[1], M, N, K, zcount, zdiv, _st())
+    if probe.on("gemm_batched"):
+        with probe.timed(("gemm_batched", M, N, K, zcount), 2.0 * M * N * K * zcount, 4.0 * zcount * (M * K + N * K + M * N)):
+            call("srhip_gemm_nt_batched", *args)
+    else:
+        call("srhip_gemm_nt_batched", *args)
     return C
 
 
@@ -397,8 +403,15 @@ def nlsa_attention(x_embed, y_embed, order, x, out, N, L, chunk_size, res_scale,
     else:
         ret = SCRATCH.get("nlsa_ret", N * nh * L * Cy, device=x.device)
         score = SCRATCH.get("nlsa_score", N * nh * L, device=x.device)
-    call("srhip_nlsa_attention", _p(x_embed), _p(y_embed), order.data_ptr(), _p(ret), _p(score), _p(x), _p(out), N, L, Ce, Cy,
-         nh, int(chunk_size), float(res_scale), _st())
+    args = (_p(x_embed), _p(y_embed), order.data_ptr(), _p(ret), _p(score), _p(x), _p(out), N, L, Ce, Cy,
+            nh, int(chunk_size), float(res_scale), _st())
+    if probe.on("nlsa"):
+        Lp = -(-L // chunk_size) * chunk_size       # every (padded) token against its own and the two neighbouring chunks
+        with probe.timed(("nlsa", N, L, Ce, Cy, nh), 2.0 * N * nh * Lp * 3 * chunk_size * (Ce + Cy),
+                         4.0 * N * L * (nh * (Ce + Cy) * 4 + nh * (Cy + 1) * 2 + 2 * Cy)):
+            call("srhip_nlsa_attention", *args)
+    else:
+        call("srhip_nlsa_attention", *args)
     if keep:
         return out, ret[:N * nh * L * Cy].view(N, nh, L, Cy), score[:N * nh * L].view(N, nh, L)
     return out
@@ -599,9 +612,16 @@ def cosine_window_attention(q, qwin, k, v, kwin, logit_scale, biasT, out, heads,
     assert v.shape[:3] == k.shape[:3] and out.shape[:3] == q.shape[:3] and k.shape[0] == B
     assert biasT.shape == (heads, kwin[0] * kwin[1], qwin[0] * qwin[1]) and biasT.is_contiguous()
     assert logit_scale.numel() == heads and logit_scale.is_contiguous()
-    call("srhip_cosine_window_attention", q.data_ptr(), q.stride(2), qH, qW, qwin[0], qwin[1], k.data_ptr(), k.stride(2),
-         v.data_ptr(), v.stride(2), kH, kW, kwin[0], kwin[1], _p(logit_scale), _p(biasT), out.data_ptr(), out.stride(2), B,
-         heads, d, int(shift), _st())
+    args = (q.data_ptr(), q.stride(2), qH, qW, qwin[0], qwin[1], k.data_ptr(), k.stride(2),
+            v.data_ptr(), v.stride(2), kH, kW, kwin[0], kwin[1], _p(logit_scale), _p(biasT), out.data_ptr(), out.stride(2), B,
+            heads, d, int(shift), _st())
+    if probe.on("grl_attn"):
+        nq, nk = qwin[0] * qwin[1], kwin[0] * kwin[1]
+        with probe.timed(("grl_attn", qH, qW, nq, nk, heads, d), 4.0 * B * qH * qW * nk * heads * d,
+                         4.0 * B * heads * d * (2 * qH * qW + 2 * kH * kW)):
+            call("srhip_cosine_window_attention", *args)
+    else:
+        call("srhip_cosine_window_attention", *args)
     return out
 
 
@@ -728,9 +748,10 @@ def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0
         assert in_bn is None or (Wp.fmt == 1 and tuple(in_bn.shape) == (4, Cin) and in_bn.is_contiguous())
         name = "srhip_conv3x3_nhwc_split_ex"
         args = (int(Wp.fmt),) + args[:-1] + (_p(in_bn), _p(slope), _st())
-    if probe.on("conv_nt"):
+    kind = "conv_nt" if bx else "conv_nt_f32"
+    if probe.on(kind):
         T = B * H * W
-        with probe.timed(("conv_nt", T, Cout, Cin), 18.0 * T * Cout * Cin,
+        with probe.timed((kind, T, Cout, Cin), 18.0 * T * Cout * Cin,
                          4.0 * (T * Cin + 9 * Cin * Cout + T * Cout * (2 if R is not None else 1))):
             call(name, *args)
     else:

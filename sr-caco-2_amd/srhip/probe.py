@@ -65,7 +65,15 @@ _KERNEL_OF_KIND = {
     "mlp_fused": ("k_mlp", "fused LayerNorm -> fc1 -> GELU -> fc2 -> residual (and its backward, with the proj data "
                            "gradient chained)"),
     "wmsa_fused": ("k_wmsa", "fused LayerNorm -> qkv -> window attention -> proj -> residual (forward)"),
+    # the evaluation sweep's other classes (tools/eval_sweep.py): exact-f32 arithmetic, priced against the f32 peak
+    "gemm_nt_f32": ("k_nt<", "NT GEMM, exact f32 (v_mfma_f32_32x32x2_f32)"),
+    "conv_nt_f32": ("k_nt<", "implicit-GEMM 3x3 conv, exact f32"),
+    "gemm_batched": ("k_nt<", "batched NT GEMM, exact f32: every (sample, head) product of a layer in one launch"),
+    "nlsa": ("k_nlsa_attention", "NLSN chunk attention on the exact-f32 matrix core"),
+    "grl_attn": ("k_cosine_window_attention", "GRL cosine window / anchor-stripe attention (vector ALU, f32)"),
 }
+_F32_KINDS = ("gemm_nt_f32", "conv_nt_f32", "gemm_batched", "nlsa", "grl_attn")
+ALL_KINDS = tuple(_KERNEL_OF_KIND)
 
 
 def _pmc_traffic(kernel_stem):
@@ -119,7 +127,7 @@ def collect():
     stem, what = _KERNEL_OF_KIND.get(kind, (kind, kind))
     tf = fl / (ms * 1e-3) / 1e12
     gbs = by / (ms * 1e-3) / 1e9
-    bx = ops.use_bx3()
+    bx = ops.use_bx3() and kind not in _F32_KINDS
     peak = BX3_MFMA_PEAK_TFLOPS if bx else F32_MFMA_PEAK_TFLOPS
     arith = "bf16x3-split MFMA (f32-equivalent flops; peak = bf16 dense / 6)" if bx else "f32 MFMA"
     if bx and kind == "conv_nt" and ops.F16X2_CONV:    # 64 .. 256-channel convs: three products on two fp16 planes
@@ -152,6 +160,7 @@ def collect():
            "algorithmic_gflop_per_launch": fl / n / 1e9,
            "algorithmic_mbytes_per_launch": by / n / 1e6,
            "hbm_side": {"achieved_gb_per_s_algorithmic": gbs, "frac_of_8tb_per_s": gbs / HBM_PEAK_GBS},
+           "probed_ms": {k: v[0] for k, v in per_kind.items()},
            "share_of_probed_time": {k: v[0] / sum(x[0] for x in per_kind.values()) for k, v in per_kind.items()},
            "classes": classes}
     if bx and ((kind == "gemm_nt" and ops.F16X2) or (kind == "conv_nt" and ops.F16X2_CONV)):

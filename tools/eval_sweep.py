@@ -24,6 +24,29 @@ NETS = [("swinir", "SWINIR"), ("EDSR_LIIF", "EDSR_LIIF"), ("VDSR", "VDSR"), ("DR
         ("MSLapSRN", "MSLAPSR"), ("MemNet", "MemNet"), ("DBPN", "DBPN"), ("SRFBN", "SRFBN"), ("ProSR", "PROSR"), ("ENLCN", "ENLCN"), ("NLSN", "NLSN"), ("DFCAN", "DFCAN"), ("ACT", "ACT"), ("OmniSR", "OmniSR"), ("GRL", "GRL")]
 
 
+def roofline_of(model, forward_ms, amp_used):
+    """One more forward with HIP events around every launch of the op classes srhip.probe knows (ALGORITHMIC flops / bytes per
+    launch): the class with the largest summed time, its achieved rate against the ceiling of its arithmetic, and how much of
+    the forward it is.  The events serialise nothing but add ~10 us per launch: shares are of the UNPROBED forward time."""
+    from srhip import probe
+    probe.enable(probe.ALL_KINDS)
+    model.test()
+    r = probe.collect()
+    probe.disable()
+    if r is None:
+        return {"kernel": None, "note": "no launch of a probed op class (srhip.probe) in this forward"}
+    tot = sum(r["probed_ms"].values())
+    dom = max(r["probed_ms"].values())
+    out = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us",
+                              "algorithmic_gflop_per_launch", "algorithmic_mbytes_per_launch")}
+    if amp_used:      # the single-product kernels: the ceiling of THAT arithmetic is the dense 16-bit peak
+        out["note_amp"] = "reduced-precision forward: one 16-bit product per multiply; frac is against the three-product ceiling"
+    out["mfma_frac"], out["hbm_frac"] = r["mfma_side"]["frac"], r["hbm_side"]["frac_of_8tb_per_s"]
+    out["share_of_forward"] = min(1.0, dom / forward_ms)
+    out["probed_share_of_forward"] = min(1.0, tot / forward_ms)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
@@ -70,6 +93,7 @@ def main():
                 amp_used = bool(amp and getattr(model.netG, "amp", False) and getattr(model.netG, "amp_takes_effect", True))
                 rows.append({"net_type": net_type, "scale": scale, "amp_flag": amp, "reduced_precision_kernels": amp_used,
                              "batch": a.batch, "ms_per_batch": ms, "patches_per_s": a.batch / ms * 1e3})
+                rows[-1]["roofline"] = roofline_of(model, ms, amp_used)
                 if a.graph:
                     rows[-1]["eval_graph"] = True
                 print(json.dumps(rows[-1]), flush=True)
