@@ -71,10 +71,28 @@ class DRRNEngine:
         out = F.interpolate(x, size=(s * x.shape[2], s * x.shape[3]), mode='bicubic', align_corners=False)
         return torch.clamp(out, min=0.0, max=1.0)[:, 0].contiguous()
 
+    def forward_h16(self, x):
+        """--amp evaluation on fp16 storage (conv_h16.hip): the same launches with float16 feature maps, one fp16 product."""
+        net, U = self.net, self.U
+        xi = self.interpolate(x[:, None])
+        B, H, W = xi.shape
+
+        def buf(name):
+            return self.bufs.get("h." + name, B, H, W, CH, device=x.device, dtype=torch.float16)
+        x0 = ops.conv3x3_cin1_h16(xi, net.conv1[1].weight.data, None, CH, out=buf("x0"), relu=True)
+        r = x0
+        for k in range(U):
+            a = ops.conv3x3_h16(r, self.ws["wa.wp"], None, CH, out=buf("a"), epi=1)
+            r = ops.conv3x3_h16(a, self.ws["wb.wp"], None, CH, out=buf(f"r{k % 2}"), epi=8, R=x0)
+        y = ops.conv3x3_cout1_h16(r, net.conv2[1].weight.data, None, add=xi)
+        return y.view(B, 1, H, W)
+
     def forward(self, x, dp=None, save=True):
         """x [B,H,W] (LR) -> [B,1,s*H,s*W]."""
         if not self.prepared:
             self.prepare()
+        if not save and ops.h16_eval() and self.ws.use_bx3 and self.ws["wa.wp"].fmt == 1:
+            return self.forward_h16(x)
         net, U = self.net, self.U
         xi = self.interpolate(x[:, None])
         B, H, W = xi.shape

@@ -77,10 +77,40 @@ class EDSREngine:
         self.prepared = True
 
     # ------------------------------------------------------------------ forward
+    def _h16_ok(self):
+        return (self.ws.use_bx3 and self.fuse_ps and self.F % 64 == 0
+                and all(self.ws[n + ".wp"].fmt == 1 for n, _ in self._body_convs()))
+
+    def forward_h16(self, x):
+        """--amp evaluation on fp16 storage (conv_h16.hip): the same launches with float16 feature maps, one fp16 product;
+        the upsampler's conv stores through its PixelShuffle(2)."""
+        net, F = self.net, self.F
+        B, H, W = x.shape
+        dev = x.device
+
+        def buf(name, *shape):
+            return self.bufs.get("h." + name, *shape, device=dev, dtype=torch.float16)
+        f0 = ops.conv3x3_cin1_h16(x, net.head[0].weight.data, net.head[0].bias.data, F, out=buf("f0", B, H, W, F))
+        r, rs = f0, float(net.res_scale)
+        for k in range(self.nb):
+            a = ops.conv3x3_h16(r, self.ws[f"b{k}.0.wp"], net.body[k].body[0].bias.data, F, out=buf("a", B, H, W, F), epi=1)
+            r = ops.conv3x3_h16(a, self.ws[f"b{k}.2.wp"], net.body[k].body[2].bias.data, F, out=buf(f"r{k % 2}", B, H, W, F),
+                                epi=2, R=r, alpha=rs)
+        u = ops.conv3x3_h16(r, self.ws["bend.wp"], net.body[self.nb].bias.data, F, out=buf("rb", B, H, W, F), epi=2, R=f0)
+        h, w = H, W
+        for i in range(self.stages):
+            u = ops.conv3x3_h16(u, self.ws[f"up{i}.wp"], net.tail[0][2 * i].bias.data, 4 * F, out=buf(f"u{i}", B, 2 * h, 2 * w, F),
+                                ps2=True)
+            h, w = 2 * h, 2 * w
+        y = ops.conv3x3_cout1_h16(u, net.tail[1].weight.data, net.tail[1].bias.data)
+        return y.view(B, 1, h, w)
+
     def forward(self, x, dp=None, save=True):
         """x [B,H,W] -> [B,1,s*H,s*W]."""
         if not self.prepared:
             self.prepare()
+        if not save and ops.h16_eval() and self._h16_ok():
+            return self.forward_h16(x)
         net, F, D = self.net, self.F, self.derived
         B, H, W = x.shape
         dev = x.device

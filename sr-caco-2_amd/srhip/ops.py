@@ -83,6 +83,16 @@ def set_matmul_mode(mode):
     call("srhip_set_matmul_mode", int(mode))
 
 
+# --amp at evaluation time: the plain conv family (VDSR, DRRN, EDSR) runs on fp16 STORAGE (conv_h16.hip: activations fp16 in
+# HBM, one fp16 product); SRHIP_H16_EVAL=0: the f32-storage single-product kernels, as every other net
+H16_EVAL = _os.environ.get("SRHIP_H16_EVAL", "1") != "0"
+
+
+def h16_eval():
+    """inside ``amp_inference(True)`` with the fp16-storage path enabled"""
+    return H16_EVAL and lib.srhip_get_matmul_mode() == 1
+
+
 class amp_inference:
     """``with ops.amp_inference(on):`` -- reduced-precision matmuls / convs inside the block (the role of
     torch.cuda.amp.autocast at evaluation time in the reference, model_plain.py:322-327)."""
@@ -756,6 +766,51 @@ def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0
             call(name, *args)
     else:
         call(name, *args)
+    return out
+
+
+def _ph(t):
+    """pointer of an fp16 CUDA tensor (or None)"""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float16:
+        raise SrhipError("fp16-storage ops take float16 CUDA/HIP tensors")
+    return t.data_ptr()
+
+
+def conv3x3_h16(X, Wp, bias, Cout, out=None, epi=0, R=None, alpha=1.0, ps2=False):
+    """fp16-storage 3x3 conv (srhip_conv3x3_nhwc_h16): X NHWC float16 [B,H,W,Cin], Wp = the fp16x2 weight planes (Bx3 fmt 1;
+    ps2: built with PrepTable.conv(ps2=True)) -> float16 [B,H,W,Cout] (ps2: [B,2H,2W,Cout/4])."""
+    assert isinstance(Wp, Bx3) and Wp.fmt == 1, "conv3x3_h16: fp16x2 weight planes"
+    B, H, W, Cin = X.shape
+    assert Wp.rows == 9 * Cout and Wp.K == Cin and X.stride(3) == 1 and X.stride(1) == W * X.stride(2)
+    if out is None:
+        out = torch.empty((B, 2 * H, 2 * W, Cout // 4) if ps2 else (B, H, W, Cout), device=X.device, dtype=torch.float16)
+    _chk(bias)
+    call("srhip_conv3x3_nhwc_h16", _ph(X), X.stride(2), _p(Wp.planes), _p(bias), _ph(out), out.stride(2), B, H, W, Cin, Cout,
+         int(epi), _ph(R), 0 if R is None else R.stride(2), float(alpha), int(bool(ps2)), _st())
+    return out
+
+
+def conv3x3_cin1_h16(x, w, bias, Co, out=None, relu=False):
+    """f32 image [B,H,W] -> float16 features [B,H,W,Co] (w [Co,1,3,3] f32)."""
+    _chk(x, w, bias)
+    B, H, W = x.shape
+    assert x.is_contiguous() and w.is_contiguous() and tuple(w.shape) == (Co, 1, 3, 3)
+    if out is None:
+        out = torch.empty(B, H, W, Co, device=x.device, dtype=torch.float16)
+    call("srhip_conv3x3_cin1_h16", _p(x), _p(w), _p(bias), _ph(out), out.stride(2), B, H, W, Co, int(bool(relu)), _st())
+    return out
+
+
+def conv3x3_cout1_h16(x, w, bias, add=None, out=None):
+    """float16 features [B,H,W,Ci] -> f32 image [B,H,W] (w [1,Ci,3,3] f32), + bias + the f32 image `add`."""
+    _chk(w, bias, add, out)
+    B, H, W, Ci = x.shape
+    assert x.stride(3) == 1 and w.is_contiguous() and tuple(w.shape) == (1, Ci, 3, 3) and (add is None or add.is_contiguous())
+    if out is None:
+        out = torch.empty(B, H, W, device=x.device, dtype=torch.float32)
+    call("srhip_conv3x3_cout1_h16", _ph(x), x.stride(2), _p(w), _p(bias), _p(add), _p(out), B, H, W, Ci, _st())
     return out
 
 

@@ -62,10 +62,26 @@ class VDSREngine:
         out = F.interpolate(x, size=(s * x.shape[2], s * x.shape[3]), mode='bicubic', align_corners=False)
         return torch.clamp(out, min=0.0, max=1.0)[:, 0].contiguous()
 
+    def forward_h16(self, x):
+        """--amp evaluation on fp16 storage (conv_h16.hip): the same launches with float16 feature maps, one fp16 product."""
+        net = self.net
+        xi = self.interpolate(x[:, None])
+        B, H, W = xi.shape
+        a = self.bufs.get("h.a0", B, H, W, CH, device=x.device, dtype=torch.float16)
+        ops.conv3x3_cin1_h16(xi, net.conv1[0].weight.data, None, CH, out=a, relu=True)
+        for k in range(self.nt):
+            an = self.bufs.get(f"h.a{1 + k % 2}", B, H, W, CH, device=x.device, dtype=torch.float16)
+            ops.conv3x3_h16(a, self.ws[f"t{k}.wp"], None, CH, out=an, epi=1)
+            a = an
+        y = ops.conv3x3_cout1_h16(a, net.conv2.weight.data, None, add=xi)       # + the interpolated input
+        return y.view(B, 1, H, W)
+
     def forward(self, x, dp=None, save=True):
         """x [B,H,W] (LR) -> [B,1,s*H,s*W]."""
         if not self.prepared:
             self.prepare()
+        if not save and ops.h16_eval() and self.ws.use_bx3 and self.ws["t0.wp"].fmt == 1:
+            return self.forward_h16(x)
         net = self.net
         xi = self.interpolate(x[:, None])
         B, H, W = xi.shape

@@ -1,0 +1,80 @@
+"""fp16-storage convs of the evaluation path (conv_h16.hip, include/srhip.h srhip_conv3x3_nhwc_h16 / _cin1_h16 / _cout1_h16)
+against float64 aten on the SAME rounded operands: the fp16 activations as they are, the weight as the leading fp16 plane under
+its per-output-channel power-of-two scale (emulated here), so that what remains is the f32 accumulation order and the final
+rounding of the result to fp16 (2^-11 relative)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _w_hi(w):
+    """the leading fp16 plane of srhip_prep_table job kind 4: one power-of-two scale per output channel"""
+    mx = w.abs().flatten(1).max(1)[0].clamp_min(1e-30)
+    sc = torch.exp2(torch.floor(torch.log2(16384.0 / mx))).view(-1, 1, 1, 1)
+    return ((w * sc).half().double() / sc.double())
+
+
+def _planes(w, ps2=False):
+    from srhip import ops
+    Co, Ci = w.shape[:2]
+    wp = ops.Bx3(9 * Co, Ci, "cuda")
+    tb = ops.PrepTable()
+    tb.conv(w, wp, ps2=ps2)
+    tb.build("cuda").run()
+    assert wp.fmt == 1
+    return wp
+
+
+def _check(y, ref):
+    y, ref = y.double(), ref.double()
+    tol = 2.0 ** -10 * ref.abs() + 2e-4 * ref.abs().max()
+    bad = ((y - ref).abs() > tol).sum().item()
+    assert bad == 0, (bad, ((y - ref).abs() / ref.abs().max()).max().item())
+
+
+@pytest.mark.parametrize("Cin,Cout,hw,B", [(64, 64, (21, 19), 2), (64, 64, (64, 64), 8), (128, 128, (9, 33), 1), (64, 256, (16, 16), 3),
+                                           (256, 64, (12, 20), 1)])
+def test_conv3x3_h16_epilogues(Cin, Cout, hw, B):
+    from srhip import ops
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, hw[0], hw[1], Cin, generator=g).cuda().half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).cuda()
+    b = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    r = torch.randn(B, hw[0], hw[1], Cout, generator=g).cuda().half()
+    wp = _planes(w)
+    pre = F.conv2d(x.double().permute(0, 3, 1, 2), _w_hi(w), None, padding=1).permute(0, 2, 3, 1)
+    _check(ops.conv3x3_h16(x, wp, None, Cout), pre)
+    _check(ops.conv3x3_h16(x, wp, b, Cout, epi=1), torch.relu(pre + b.double()))
+    _check(ops.conv3x3_h16(x, wp, b, Cout, epi=2, R=r, alpha=0.1), r.double() + 0.1 * (pre + b.double()))
+    _check(ops.conv3x3_h16(x, wp, None, Cout, epi=8, R=r), torch.relu(r.double() + pre))
+
+
+@pytest.mark.parametrize("hw,B", [((16, 16), 2), ((13, 21), 1)])
+def test_conv3x3_h16_pixelshuffle2(hw, B):
+    from srhip import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, hw[0], hw[1], 64, generator=g).cuda().half()
+    w = (torch.randn(256, 64, 3, 3, generator=g) / 24.0).cuda()
+    b = (torch.randn(256, generator=g) * 0.1).cuda()
+    wp = _planes(w, ps2=True)
+    pre = F.conv2d(x.double().permute(0, 3, 1, 2), _w_hi(w), b.double(), padding=1)
+    ref = F.pixel_shuffle(pre, 2).permute(0, 2, 3, 1)
+    _check(ops.conv3x3_h16(x, wp, b, 256, ps2=True), ref)
+
+
+def test_edge_convs_h16():
+    from srhip import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 19, 23, generator=g).cuda()
+    w1 = (torch.randn(64, 1, 3, 3, generator=g) / 3.0).cuda()
+    b1 = (torch.randn(64, generator=g) * 0.1).cuda()
+    f = ops.conv3x3_cin1_h16(x, w1, b1, 64, relu=True)
+    ref = torch.relu(F.conv2d(x.double()[:, None], w1.double(), b1.double(), padding=1)).permute(0, 2, 3, 1)
+    _check(f, ref)
+    w2 = (torch.randn(1, 64, 3, 3, generator=g) / 24.0).cuda()
+    b2 = torch.tensor([0.05], device="cuda")
+    y = ops.conv3x3_cout1_h16(f, w2, b2, add=x)
+    ref2 = F.conv2d(f.double().permute(0, 3, 1, 2), w2.double(), b2.double(), padding=1)[:, 0] + x.double()
+    assert ((y.double() - ref2).abs().max() / ref2.abs().max()).item() < 1e-5
