@@ -162,7 +162,8 @@ def test_amp_flag_leaves_training_untouched():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-REGISTRY_AMP = [("DBPN", "DBPN"), ("SRFBN", "SRFBN"), ("ProSR", "PROSR"), ("NLSN", "NLSN"), ("DFCAN", "DFCAN"),
+REGISTRY_AMP = [("VDSR", "VDSR"), ("DRRN", "DRRN"), ("EDSR_LIIF", "EDSR_LIIF"),       # fp16 STORAGE under --amp (conv_h16.hip)
+                ("MSLapSRN", "MSLAPSR"), ("DBPN", "DBPN"), ("SRFBN", "SRFBN"), ("ProSR", "PROSR"), ("NLSN", "NLSN"), ("DFCAN", "DFCAN"),
                 ("SRCNN", "SRCNN"), ("ENLCN", "ENLCN"), ("ACT", "ACT"), ("GRL", "GRL"), ("OmniSR", "OmniSR")]
 
 
