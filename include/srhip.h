@@ -164,18 +164,23 @@ int srhip_conv3x3_nhwc_split_ex(int wfmt, const float* X, long ldx, const void* 
 /* ---- fp16-STORAGE inference of the plain conv family (--amp at evaluation time; eval_all.sh's sweep, select_network.py:52-210):
  * activations NHWC fp16 in HBM, the weight = the leading fp16 plane of the srhip_conv3x3_nhwc_f16x2 operand (job kind 4; ps2:
  * mode 12), ONE fp16 MFMA product, f32 accumulate, fp16 out.  Cin a multiple of 32, Cout of 64 (ps2: of 256), pitches multiples
- * of 8 halves.  epi 0 +bias | 1 relu | 2 R + alpha*(acc+bias) | 8 relu(R + alpha*(acc+bias)) (R fp16, laid out as Y).
+ * of 8 halves.  epi 0 +bias | 1 relu | 2 R + alpha*(acc+bias) | 6 leaky relu(alpha) | 8 relu(R + alpha*(acc+bias)) (R fp16, laid
+ * out as Y).  in_bn_coef [4][Cin] (may be NULL): evaluation-mode BatchNorm + ReLU on the input, as srhip_conv3x3_nhwc_split_ex.
+ * center_only: the weight is a 1x1 conv held in the centre tap of a 3x3 (the other taps are not multiplied).
  * ps2: the result goes through PixelShuffle(2) into Y [B][2H][2W][Cout/4] (network_nlsn.py:100-118).  Replaces
  * nn.Conv2d + ReLU / ResBlock of network_vdsr.py:24-60, network_drrn.py:22-62, network_nlsn.py:72-128 under torch.autocast-like
  * reduced precision (the reference has no such mode: the PSNR gate of tests/test_gpu_amp.py is the contract). */
 int srhip_conv3x3_nhwc_h16(const void* X, long ldx, const void* Wh, const float* bias, void* Y, long ldy, int B, int H, int W,
-                           int Cin, int Cout, int epi, const void* R, long ldr, float alpha, int ps2, void* stream);
-/* the 1 -> Cout conv at the head: f32 image [B][H][W] in, fp16 features out (w [Cout][1][3][3] f32, optional ReLU) */
+                           int Cin, int Cout, int epi, const void* R, long ldr, float alpha, int ps2, const float* in_bn_coef,
+                           int center_only, void* stream);
+/* the 1 -> Cout conv at the head: f32 image [B][H][W] in, fp16 features out (w [Cout][1][3][3] f32; act 0 none | 1 ReLU | 2
+ * LeakyReLU(alpha)) */
 int srhip_conv3x3_cin1_h16(const float* x, const float* w, const float* bias, void* y, long ldy, int B, int H, int W, int Co,
-                           int relu, void* stream);
-/* the Cin -> 1 conv at the tail: fp16 features in, f32 image [B][H][W] out, + bias + the f32 image `add` (may be NULL) */
-int srhip_conv3x3_cout1_h16(const void* x, long ldx, const float* w, const float* bias, const float* add, float* y, int B, int H,
-                            int W, int Ci, void* stream);
+                           int act, float alpha, void* stream);
+/* the Cin -> 1 conv at the tail: fp16 features in (optionally through BatchNorm-ReLU, in_bn_coef [4][Cin]), f32 image
+ * [B][H][W] out, + bias + the f32 image `add` (may be NULL) */
+int srhip_conv3x3_cout1_h16(const void* x, long ldx, const float* w, const float* bias, const float* add, const float* in_bn_coef,
+                            float* y, int B, int H, int W, int Ci, void* stream);
 /* srhip_conv3x3_ps2_bx3 / srhip_conv3x3_ps2_bwd_data_bx3 with the weight in that format (job kind 4, modes 12 / 16). */
 int srhip_conv3x3_ps2_f16x2(const float* X, long ldx, const void* Wh, const float* bias, float* Yup, long ldy,
                             int B, int H, int W, int Cin, int Cout, int epi, float alpha, void* stream);

@@ -295,21 +295,24 @@ int srhip_conv3x3_nhwc_split_ex(int wfmt, const float* X, long ldx, const void* 
 }
 
 int srhip_conv3x3_nhwc_h16(const void* X, long ldx, const void* Wh, const float* bias, void* Y, long ldy, int B, int H, int W,
-                           int Cin, int Cout, int epi, const void* R, long ldr, float alpha, int ps2, void* stream) {
+                           int Cin, int Cout, int epi, const void* R, long ldr, float alpha, int ps2, const float* in_bn_coef,
+                           int center_only, void* stream) {
   ConvH16Args p;
   memset(&p, 0, sizeof(p));
+  p.in_bn = in_bn_coef; p.center_only = center_only;
   p.X = (const _Float16*)X; p.ldx = ldx; p.Wb = (const unsigned short*)Wh; p.bias = bias; p.Y = (_Float16*)Y; p.ldy = ldy;
   p.R = (const _Float16*)R; p.ldr = ldr; p.epi = epi; p.alpha = alpha; p.B = B; p.H = H; p.Wd = W; p.K = Cin; p.N = Cout;
   p.ps = ps2 ? 1 : 0;
   return sr_conv3x3_h16(p, (hipStream_t)stream);
 }
 int srhip_conv3x3_cin1_h16(const float* x, const float* w, const float* bias, void* y, long ldy, int B, int H, int W, int Co,
-                           int relu, void* stream) {
-  return sr_conv_cin1_h16(x, w, bias, y, ldy, B, H, W, Co, relu, (hipStream_t)stream);
+                           int act, float alpha, void* stream) {
+  SR_REQUIRE(act >= 0 && act <= 2, "conv3x3_cin1_h16: act %d (0 none, 1 relu, 2 leaky relu)", act);
+  return sr_conv_cin1_h16(x, w, bias, y, ldy, B, H, W, Co, act, alpha, (hipStream_t)stream);
 }
-int srhip_conv3x3_cout1_h16(const void* x, long ldx, const float* w, const float* bias, const float* add, float* y, int B, int H,
-                            int W, int Ci, void* stream) {
-  return sr_conv_cout1_h16(x, ldx, w, bias, add, y, B, H, W, Ci, (hipStream_t)stream);
+int srhip_conv3x3_cout1_h16(const void* x, long ldx, const float* w, const float* bias, const float* add, const float* in_bn_coef,
+                            float* y, int B, int H, int W, int Ci, void* stream) {
+  return sr_conv_cout1_h16(x, ldx, w, bias, add, in_bn_coef, y, B, H, W, Ci, (hipStream_t)stream);
 }
 
 int srhip_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats) {

@@ -7,9 +7,10 @@
 //
 //   k_conv3x3_h16   3x3 conv, stride 1, zero padding, Cin a multiple of 32, Cout a multiple of 64: 2 RW x 16 pixel tiles x
 //                   64-column slices (the shapes and wave layout of k_nhcw2, gemm_ntw.hip); the nine taps of a 32-channel
-//                   chunk run without a barrier on weight fragments requested a chunk ahead; epilogues bias / ReLU /
-//                   residual / residual + ReLU on the row-major re-laid tile (16-byte accesses), optionally stored through
-//                   PixelShuffle(2) (the EDSR upsampler, network_nlsn.py:100-118)
+//                   chunk run without a barrier on weight fragments requested a chunk ahead; optional BatchNorm-ReLU input
+//                   prologue (MemNet); epilogues bias / ReLU / LeakyReLU / residual / residual + ReLU on the row-major
+//                   re-laid tile (16-byte accesses), optionally stored through PixelShuffle(2) (the EDSR upsampler,
+//                   network_nlsn.py:100-118); a 1x1 conv runs as the centre tap alone
 //   k_cin1_h16      the 1 -> Cout conv at the head (f32 image in, fp16 features out; network_vdsr.py:57-60)
 //   k_cout1_h16     the Cin -> 1 conv at the tail (fp16 features in, f32 image out, + the interpolated input)
 #include "common.h"
@@ -64,17 +65,37 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_h16(ConvH16Args p) {
     const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.Wd - 1);
     offA[it] = (unsigned)((((long)img * p.H + yc) * p.Wd + xc) * p.ldx + c8 * 8) * 2u;
   }
+  // input prologue (MemNet's BN-ReLU-conv, network_memnet.py:27-34): relu((x - mean) k + beta) on the thread's eight
+  // channels of the chunk (256 % 4 == 0: the same group in every iteration), before the padding zeros go in
+  f32x4 bm[2], bk[2], bb[2];
   auto load_a = [&](int kc, u32x4 (&ra)[AIT]) {
     const char* base = (const char*)p.X + (long)kc * 64;
 #pragma unroll
     for (int it = 0; it < AIT; ++it) ra[it] = *(const u32x4*)(base + offA[it]);
+    if (p.in_bn) {
+      const int ch = kc * 32 + (tid & 3) * 8;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        bm[h2] = ldg_f4(p.in_bn + ch + 4 * h2);
+        bk[h2] = ldg_f4(p.in_bn + 2 * p.K + ch + 4 * h2);
+        bb[h2] = ldg_f4(p.in_bn + 3 * p.K + ch + 4 * h2);
+      }
+    }
   };
   auto store_a = [&](const u32x4 (&ra)[AIT]) {
 #pragma unroll
     for (int it = 0; it < AIT; ++it) {
       if (AN % 256 == 0 || tid + it * 256 < AN) {
         const int idx = tid + it * 256;
-        *(u32x4*)(smem + (idx >> 2) * HP + (idx & 3) * 16) = inA[it] ? ra[it] : u32x4{0u, 0u, 0u, 0u};
+        u32x4 v = ra[it];
+        if (p.in_bn) {
+          h16x8 hv = __builtin_bit_cast(h16x8, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            hv[e] = (_Float16)fmaxf(((float)hv[e] - bm[e >> 2][e & 3]) * bk[e >> 2][e & 3] + bb[e >> 2][e & 3], 0.f);
+          v = __builtin_bit_cast(u32x4, hv);
+        }
+        *(u32x4*)(smem + (idx >> 2) * HP + (idx & 3) * 16) = inA[it] ? v : u32x4{0u, 0u, 0u, 0u};
       }
     }
   };
@@ -99,8 +120,10 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_h16(ConvH16Args p) {
   u32x4 ra[AIT];
   load_a(0, ra);
   u32x4 fb[9][2];
+  const bool one = p.center_only != 0;            // block-uniform
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) load_b(0, tap, fb[tap]);
+  for (int tap = 0; tap < 9; ++tap)
+    if (!one || tap == 4) load_b(0, tap, fb[tap]);
   for (int kc = 0; kc < nkc; ++kc) {
     if (kc) __syncthreads();                      // every tap of the previous chunk has read the halo tile
     store_a(ra);
@@ -108,6 +131,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_h16(ConvH16Args p) {
     if (kc + 1 < nkc) load_a(kc + 1, ra);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
+      if (one && tap != 4) continue;
       const int toff = ((tap / 3) * 18 + (tap % 3)) * HP;
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
@@ -165,6 +189,10 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_h16(ConvH16Args p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
+    if (p.epi == 6) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+    }
     h16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
@@ -178,10 +206,10 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_h16(ConvH16Args p) {
   }
 }
 
-// 1 -> Co conv (f32 image in, fp16 features out), optional ReLU.  A thread owns 8 output channels of one pixel.
+// 1 -> Co conv (f32 image in, fp16 features out), act 0 none | 1 ReLU | 2 LeakyReLU(alpha).  A thread owns 8 output channels of one pixel.
 __global__ void __launch_bounds__(256) k_cin1_h16(const float* __restrict__ x, const float* __restrict__ w,
                                                   const float* __restrict__ bias, _Float16* __restrict__ y, long ldy, int B,
-                                                  int H, int W, int Co, int relu) {
+                                                  int H, int W, int Co, int act, float alpha) {
   extern __shared__ float wl[];                  // [9][Co] + [Co]
   for (int i = threadIdx.x; i < 9 * Co; i += 256) wl[(i % 9) * Co + i / 9] = w[i];
   for (int i = threadIdx.x; i < Co; i += 256) wl[9 * Co + i] = bias ? bias[i] : 0.f;
@@ -208,7 +236,7 @@ __global__ void __launch_bounds__(256) k_cin1_h16(const float* __restrict__ x, c
     }
     h16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (_Float16)(relu ? fmaxf(v[e], 0.f) : v[e]);
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)(act == 1 ? fmaxf(v[e], 0.f) : (act == 2 && v[e] < 0.f ? v[e] * alpha : v[e]));
     *(h16x8*)(y + pix * ldy + gq * 8) = o;
   }
 }
@@ -217,9 +245,13 @@ __global__ void __launch_bounds__(256) k_cin1_h16(const float* __restrict__ x, c
 // eighth of the channels (16-byte loads), summed with three shuffles.
 __global__ void __launch_bounds__(256) k_cout1_h16(const _Float16* __restrict__ x, long ldx, const float* __restrict__ w,
                                                    const float* __restrict__ bias, const float* __restrict__ add,
-                                                   float* __restrict__ y, int B, int H, int W, int Ci) {
-  extern __shared__ float wl[];                  // [9][Ci]
+                                                   const float* __restrict__ in_bn, float* __restrict__ y, int B, int H, int W,
+                                                   int Ci) {
+  extern __shared__ float wl[];                  // [9][Ci] weights, [3][Ci] BatchNorm mean / k / beta of the input prologue
+  float* const cf = wl + 9 * Ci;
   for (int i = threadIdx.x; i < 9 * Ci; i += 256) wl[(i % 9) * Ci + i / 9] = w[i];
+  if (in_bn)
+    for (int i = threadIdx.x; i < Ci; i += 256) { cf[i] = in_bn[i]; cf[Ci + i] = in_bn[2 * Ci + i]; cf[2 * Ci + i] = in_bn[3 * Ci + i]; }
   __syncthreads();
   const long n = (long)B * H * W;
   const int sub = threadIdx.x & 7;
@@ -238,7 +270,11 @@ __global__ void __launch_bounds__(256) k_cout1_h16(const _Float16* __restrict__ 
       for (int c0 = sub * 8; c0 < Ci; c0 += 64) {
         const h16x8 xv = *(const h16x8*)(row + c0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += (float)xv[e] * wl[t * Ci + c0 + e];
+        for (int e = 0; e < 8; ++e) {
+          float xe = (float)xv[e];
+          if (in_bn) xe = fmaxf((xe - cf[c0 + e]) * cf[Ci + c0 + e] + cf[2 * Ci + c0 + e], 0.f);
+          s += xe * wl[t * Ci + c0 + e];
+        }
       }
     }
     s += __shfl_xor(s, 1, 64);
@@ -255,7 +291,8 @@ int sr_conv3x3_h16(ConvH16Args& p, hipStream_t st) {
   SR_REQUIRE(p.K % 32 == 0 && p.K >= 32 && p.K <= 4096 && p.N % 64 == 0 && p.N <= 4096,
              "conv3x3_h16: Cin = %d (a multiple of 32), Cout = %d (a multiple of 64), both <= 4096", p.K, p.N);
   SR_REQUIRE(p.ldx % 8 == 0 && p.ldy % 8 == 0 && (!p.R || p.ldr % 8 == 0), "conv3x3_h16: pixel pitches must be multiples of 8 halves");
-  SR_REQUIRE(p.epi == 0 || p.epi == 1 || ((p.epi == 2 || p.epi == 8) && p.R), "conv3x3_h16: epilogue %d (0, 1, 2 / 8 with R)", p.epi);
+  SR_REQUIRE(p.epi == 0 || p.epi == 1 || p.epi == 6 || ((p.epi == 2 || p.epi == 8) && p.R),
+             "conv3x3_h16: epilogue %d (0, 1, 6, 2 / 8 with R)", p.epi);
   SR_REQUIRE(!p.ps || (p.N % 256 == 0 && !p.R), "conv3x3_h16 + PixelShuffle(2): Cout %% 256 == 0 and no residual (Cout=%d)", p.N);
   SR_REQUIRE(p.B > 0 && p.H > 0 && p.Wd > 0, "conv3x3_h16: empty image");
   SR_REQUIRE((long)p.B * p.H * p.Wd * p.ldx < (1L << 31), "conv3x3_h16: input larger than 4 GiB (32-bit staging offsets)");
@@ -272,26 +309,26 @@ int sr_conv3x3_h16(ConvH16Args& p, hipStream_t st) {
   return 0;
 }
 
-int sr_conv_cin1_h16(const float* x, const float* w, const float* bias, void* y, long ldy, int B, int H, int W, int Co, int relu,
-                     hipStream_t st) {
+int sr_conv_cin1_h16(const float* x, const float* w, const float* bias, void* y, long ldy, int B, int H, int W, int Co, int act,
+                     float alpha, hipStream_t st) {
   SR_REQUIRE(x && w && y, "conv_cin1_h16: null operand");
   SR_REQUIRE(Co % 8 == 0 && Co <= 1024 && ldy % 8 == 0, "conv_cin1_h16: Cout = %d (a multiple of 8, <= 1024)", Co);
   const long n = (long)B * H * W * (Co / 8);
   if (n <= 0) return 0;
   const int grid = (int)(n / 256 + 1 < 8192 ? n / 256 + 1 : 8192);
-  hipLaunchKernelGGL(k_cin1_h16, dim3(grid), dim3(256), (size_t)10 * Co * 4, st, x, w, bias, (_Float16*)y, ldy, B, H, W, Co, relu);
+  hipLaunchKernelGGL(k_cin1_h16, dim3(grid), dim3(256), (size_t)10 * Co * 4, st, x, w, bias, (_Float16*)y, ldy, B, H, W, Co, act, alpha);
   SR_LAUNCH_CHECK("k_cin1_h16");
   return 0;
 }
 
-int sr_conv_cout1_h16(const void* x, long ldx, const float* w, const float* bias, const float* add, float* y, int B, int H, int W,
-                      int Ci, hipStream_t st) {
+int sr_conv_cout1_h16(const void* x, long ldx, const float* w, const float* bias, const float* add, const float* in_bn, float* y,
+                      int B, int H, int W, int Ci, hipStream_t st) {
   SR_REQUIRE(x && w && y, "conv_cout1_h16: null operand");
   SR_REQUIRE(Ci % 64 == 0 && Ci <= 1024 && ldx % 8 == 0, "conv_cout1_h16: Cin = %d (a multiple of 64, <= 1024)", Ci);
   const long n = (long)B * H * W;
   if (n <= 0) return 0;
   const int grid = (int)(n / 32 + 1 < 16384 ? n / 32 + 1 : 16384);
-  hipLaunchKernelGGL(k_cout1_h16, dim3(grid), dim3(256), (size_t)9 * Ci * 4, st, (const _Float16*)x, ldx, w, bias, add, y, B, H, W, Ci);
+  hipLaunchKernelGGL(k_cout1_h16, dim3(grid), dim3(256), (size_t)12 * Ci * 4, st, (const _Float16*)x, ldx, w, bias, add, in_bn, y, B, H, W, Ci);
   SR_LAUNCH_CHECK("k_cout1_h16");
   return 0;
 }

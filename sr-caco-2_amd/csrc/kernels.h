@@ -54,16 +54,18 @@ struct ConvH16Args {
   const float* bias;                 // [N] (torch order) or null
   _Float16* Y; long ldy;             // NHWC fp16 [B][H][Wd][ldy] (ps: [B][2H][2Wd][ldy], N / 4 channels)
   const _Float16* R; long ldr;       // residual operand of epilogues 2 / 8
-  int epi;                           // 0 +bias | 1 relu | 2 R + alpha*(acc+bias) | 8 relu(R + alpha*(acc+bias))
+  int epi;                           // 0 +bias | 1 relu | 2 R + alpha*(acc+bias) | 6 leaky relu(alpha) | 8 relu(R + alpha*(acc+bias))
   float alpha;
+  const float* in_bn;                // [4][K] = mean, rstd, gamma*rstd, beta: evaluation-mode BatchNorm + ReLU on the input
+  int center_only;                   // 1: only the centre tap is non-zero (a 1x1 conv held as a 3x3 weight)
   int B, H, Wd, K, N, ps;
   int tiles_x, tiles_y;              // set by the dispatcher
 };
 int sr_conv3x3_h16(ConvH16Args& p, hipStream_t st);
-int sr_conv_cin1_h16(const float* x, const float* w, const float* bias, void* y, long ldy, int B, int H, int W, int Co, int relu,
-                     hipStream_t st);
-int sr_conv_cout1_h16(const void* x, long ldx, const float* w, const float* bias, const float* add, float* y, int B, int H, int W,
-                      int Ci, hipStream_t st);
+int sr_conv_cin1_h16(const float* x, const float* w, const float* bias, void* y, long ldy, int B, int H, int W, int Co, int act,
+                     float alpha, hipStream_t st);
+int sr_conv_cout1_h16(const void* x, long ldx, const float* w, const float* bias, const float* add, const float* in_bn, float* y,
+                      int B, int H, int W, int Ci, hipStream_t st);
 
 struct TnArgs {
   // out[i][j] = sum_m pa(A)[m][i] * pb(B)[m'][j]   (m' = m, or the tap-shifted pixel)

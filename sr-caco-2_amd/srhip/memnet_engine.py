@@ -49,6 +49,8 @@ class MemNetEngine:
     def invalidate(self):
         self.prepared = False
         self._eval_coefs = False
+        self._h16_ready = False
+        self._h16_overflow = False
 
     def bucket_prefixes(self):
         """0.3-3 M parameters: one gradient bucket."""
@@ -120,6 +122,59 @@ class MemNetEngine:
         out = F.interpolate(x, size=(s * x.shape[2], s * x.shape[3]), mode='bicubic', align_corners=False)
         return torch.clamp(out, min=0.0, max=1.0)[:, 0].contiguous()
 
+    def _prepare_h16(self, dev):
+        """the gate units' 1x1 convs as the centre tap of 3x3 weights, in the fp16x2 conv operand format (conv_h16.hip)"""
+        tb = ops.PrepTable()
+        for i in range(self.M):
+            gc = self._gc(i)
+            w3 = self.derived.get(f"m{i}.gw3", CH, gc, 3, 3, device=dev)
+            w3.zero_()
+            w3[:, :, 1, 1].copy_(self.net.dense_memory_blocks[i].gate_unit[2].weight.data.view(CH, gc))
+            tb.conv(w3, self.ws.planes(f"m{i}.gw3p", 9 * CH, gc, dev))
+        tb.build(dev).run()
+        self._h16_ready = True
+
+    def forward_h16(self, x):
+        """--amp evaluation on fp16 storage (conv_h16.hip): float16 feature maps, one fp16 product; every BatchNorm-ReLU is
+        the input prologue of the conv behind it (the gate's 1x1 conv runs as the centre tap of a 3x3 operand)."""
+        net, D, ws, R = self.net, self.derived, self.ws, self.R
+        xi = self.interpolate(x[:, None])
+        B, H, W = xi.shape
+        dev = x.device
+        if not self._eval_coefs:
+            self._prepare_eval_coefs(dev)
+        if not getattr(self, "_h16_ready", False):
+            self._prepare_h16(dev)
+
+        def buf(name, *shape):
+            return self.bufs.get("h." + name, *shape, device=dev, dtype=torch.float16)
+        a0 = self.bufs.get("h.a0", B, H, W, device=dev)
+        ops.bn_apply(xi.view(-1, 1), D.d["coef.feature_extractor.0"], a0.view(-1, 1), relu=True)
+        f0 = ops.conv3x3_cin1_h16(a0, net.feature_extractor[2].weight.data, None, CH, out=buf("f0", B, H, W, CH))
+        longs, out, n = [f0], f0, 0
+        for i in range(self.M):
+            gc = self._gc(i)
+            cat = buf(f"cat{i}", B, H, W, gc)
+            for r in range(R):
+                for j in range(R):
+                    u = self._unit(i, j)
+                    a2 = ops.conv3x3_h16(out, ws[f"m{i}.u{j}.c0.wpf"], D.d[f"m{i}.u{j}.c0.bfold"], CH, out=buf("a2", B, H, W, CH),
+                                         epi=1, in_bn=D.d["coef." + u + ".0"])
+                    out = ops.conv3x3_h16(a2, ws[f"m{i}.u{j}.c1.wp"], None, CH, out=buf(f"o{n % 2}", B, H, W, CH), epi=2, R=out)
+                    n += 1
+                cat[..., r * CH:(r + 1) * CH].copy_(out)
+            for k, t in enumerate(longs):
+                cat[..., (R + k) * CH:(R + k + 1) * CH].copy_(t)
+            gate = ops.conv3x3_h16(cat, ws[f"m{i}.gw3p"], None, CH, out=buf(f"gate{i}", B, H, W, CH),
+                                   in_bn=D.d[f"coef.dense_memory_blocks.{i}.gate_unit.0"], center_only=True)
+            longs.append(gate)
+            out = gate
+        y = ops.conv3x3_cout1_h16(out, D.d["rec.w3"], None, add=xi, in_bn=D.d["coef.reconstructor.0"])
+        return y.view(B, 1, H, W)
+
+    def _h16_ok(self):
+        return all(self.ws[f"m{i}.u{j}.c{c}.wp"].fmt == 1 for i in range(self.M) for j in range(self.R) for c in (0, 1))
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, dp=None, save=True):
         """x [B,h,w] (LR) -> [B,1,s*h,s*w].  BatchNorm follows ``net.training``: batch statistics (and the running-
@@ -129,6 +184,14 @@ class MemNetEngine:
         net, D, ws, R = self.net, self.derived, self.ws, self.R
         training = bool(net.training)
         assert not (save and not training), "MemNet (libsrhip): gradients in eval mode (frozen BatchNorm) are not built"
+        if not save and not training and ops.h16_eval() and self._h16_ok() and not getattr(self, "_h16_overflow", False):
+            # MemNet's memory blocks add 36 residual units per block without a normalisation in between: with untrained
+            # statistics the feature maps leave fp16's range (65504).  One finiteness check of the output image per forward
+            # (a 200-ms forward: the host round trip is noise); on overflow this net stays on f32 storage.
+            y = self.forward_h16(x)
+            if bool(torch.isfinite(y).all()):
+                return y
+            self._h16_overflow = True
         xi = self.interpolate(x[:, None])
         B, H, W = xi.shape
         T = B * H * W

@@ -106,11 +106,46 @@ class MSLapSRNEngine:
         self._prep.run()
         self.prepared = True
 
+    def forward_h16(self, x):
+        """--amp evaluation on fp16 storage (conv_h16.hip): the feature branch on float16 maps, one fp16 product; the
+        1-channel image branch stays f32."""
+        net, D, ws = self.net, self.derived, self.ws
+        B, h, w = x.shape
+        dev = x.device
+
+        def buf(name, *shape):
+            return self.bufs.get("h." + name, *shape, device=dev, dtype=torch.float16)
+        feat = ops.conv3x3_cin1_h16(x, net.conv1[0].weight.data, net.conv1[0].bias.data, CH, out=buf("f0", B, h, w, CH), leaky=SLOPE)
+        img, outs = x, []
+        for o in range(self.octaves):
+            a, _, c = self._mods(o)
+            for k in range(10):
+                feat = ops.conv3x3_h16(feat, ws[f"o{o}.c{k}.wp"], a[k].cl[0].bias.data, CH, out=buf(f"o{o}.a{k % 2}", B, h, w, CH),
+                                       epi=6, alpha=SLOPE)
+            up = ops.conv3x3_h16(feat, ws[f"o{o}.up.wp"], D.d[f"o{o}.bc"], 4 * CH, out=buf(f"o{o}.up", B, 2 * h, 2 * w, CH), epi=6,
+                                 alpha=SLOPE, ps2=True)
+            c4 = self.bufs.get(f"h.o{o}.c4", B, h, w, 4, device=dev)
+            ops.conv3x3_cin1_fwd(img, D.d[f"o{o}.w4"], D.d[f"o{o}.b4"], 4, out=c4)
+            base = self.bufs.get(f"h.o{o}.base", B, 1, 2 * h, 2 * w, device=dev)
+            ops.pixel_shuffle(c4, 2, out=base)
+            out = torch.empty(B, 2 * h, 2 * w, device=dev)
+            ops.conv3x3_cout1_h16(up, c.weight.data, c.bias.data, add=base.view(B, 2 * h, 2 * w), out=out)
+            outs.append(out.view(B, 1, 2 * h, 2 * w))
+            feat, img, h, w = up, out, 2 * h, 2 * w
+        self.intermediate_outs = outs[:-1]
+        return outs[-1]
+
+    def _h16_ok(self):
+        return all(self.ws[f"o{o}.c{k}.wp"].fmt == 1 for o in range(self.octaves) for k in range(10)) and \
+            all(self.ws[f"o{o}.up.wp"].fmt == 1 for o in range(self.octaves))
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, dp=None, save=True):
         """x [B,H,W] (LR) -> [B,1,s*H,s*W]; the images of the earlier octaves in self.intermediate_outs."""
         if not self.prepared:
             self.prepare()
+        if not save and ops.h16_eval() and self._h16_ok():
+            return self.forward_h16(x)
         net, D, ws = self.net, self.derived, self.ws
         B, h, w = x.shape
         dev = x.device

@@ -778,7 +778,7 @@ def _ph(t):
     return t.data_ptr()
 
 
-def conv3x3_h16(X, Wp, bias, Cout, out=None, epi=0, R=None, alpha=1.0, ps2=False):
+def conv3x3_h16(X, Wp, bias, Cout, out=None, epi=0, R=None, alpha=1.0, ps2=False, in_bn=None, center_only=False):
     """fp16-storage 3x3 conv (srhip_conv3x3_nhwc_h16): X NHWC float16 [B,H,W,Cin], Wp = the fp16x2 weight planes (Bx3 fmt 1;
     ps2: built with PrepTable.conv(ps2=True)) -> float16 [B,H,W,Cout] (ps2: [B,2H,2W,Cout/4])."""
     assert isinstance(Wp, Bx3) and Wp.fmt == 1, "conv3x3_h16: fp16x2 weight planes"
@@ -786,31 +786,34 @@ def conv3x3_h16(X, Wp, bias, Cout, out=None, epi=0, R=None, alpha=1.0, ps2=False
     assert Wp.rows == 9 * Cout and Wp.K == Cin and X.stride(3) == 1 and X.stride(1) == W * X.stride(2)
     if out is None:
         out = torch.empty((B, 2 * H, 2 * W, Cout // 4) if ps2 else (B, H, W, Cout), device=X.device, dtype=torch.float16)
-    _chk(bias)
+    _chk(bias, in_bn)
+    assert in_bn is None or (tuple(in_bn.shape) == (4, Cin) and in_bn.is_contiguous())
     call("srhip_conv3x3_nhwc_h16", _ph(X), X.stride(2), _p(Wp.planes), _p(bias), _ph(out), out.stride(2), B, H, W, Cin, Cout,
-         int(epi), _ph(R), 0 if R is None else R.stride(2), float(alpha), int(bool(ps2)), _st())
+         int(epi), _ph(R), 0 if R is None else R.stride(2), float(alpha), int(bool(ps2)), _p(in_bn), int(bool(center_only)), _st())
     return out
 
 
-def conv3x3_cin1_h16(x, w, bias, Co, out=None, relu=False):
-    """f32 image [B,H,W] -> float16 features [B,H,W,Co] (w [Co,1,3,3] f32)."""
+def conv3x3_cin1_h16(x, w, bias, Co, out=None, relu=False, leaky=None):
+    """f32 image [B,H,W] -> float16 features [B,H,W,Co] (w [Co,1,3,3] f32); relu / leaky = slope: the activation behind it."""
     _chk(x, w, bias)
     B, H, W = x.shape
     assert x.is_contiguous() and w.is_contiguous() and tuple(w.shape) == (Co, 1, 3, 3)
     if out is None:
         out = torch.empty(B, H, W, Co, device=x.device, dtype=torch.float16)
-    call("srhip_conv3x3_cin1_h16", _p(x), _p(w), _p(bias), _ph(out), out.stride(2), B, H, W, Co, int(bool(relu)), _st())
+    call("srhip_conv3x3_cin1_h16", _p(x), _p(w), _p(bias), _ph(out), out.stride(2), B, H, W, Co,
+         2 if leaky is not None else int(bool(relu)), float(leaky or 0.0), _st())
     return out
 
 
-def conv3x3_cout1_h16(x, w, bias, add=None, out=None):
-    """float16 features [B,H,W,Ci] -> f32 image [B,H,W] (w [1,Ci,3,3] f32), + bias + the f32 image `add`."""
-    _chk(w, bias, add, out)
+def conv3x3_cout1_h16(x, w, bias, add=None, out=None, in_bn=None):
+    """float16 features [B,H,W,Ci] (through BatchNorm-ReLU if in_bn [4, Ci] is given) -> f32 image [B,H,W] (w [1,Ci,3,3] f32),
+    + bias + the f32 image `add`."""
+    _chk(w, bias, add, out, in_bn)
     B, H, W, Ci = x.shape
     assert x.stride(3) == 1 and w.is_contiguous() and tuple(w.shape) == (1, Ci, 3, 3) and (add is None or add.is_contiguous())
     if out is None:
         out = torch.empty(B, H, W, device=x.device, dtype=torch.float32)
-    call("srhip_conv3x3_cout1_h16", _ph(x), x.stride(2), _p(w), _p(bias), _p(add), _p(out), B, H, W, Ci, _st())
+    call("srhip_conv3x3_cout1_h16", _ph(x), x.stride(2), _p(w), _p(bias), _p(add), _p(in_bn), _p(out), B, H, W, Ci, _st())
     return out
 
 

@@ -78,3 +78,40 @@ def test_edge_convs_h16():
     y = ops.conv3x3_cout1_h16(f, w2, b2, add=x)
     ref2 = F.conv2d(f.double().permute(0, 3, 1, 2), w2.double(), b2.double(), padding=1)[:, 0] + x.double()
     assert ((y.double() - ref2).abs().max() / ref2.abs().max()).item() < 1e-5
+
+
+def test_conv3x3_h16_bn_prologue_leaky_and_1x1():
+    from srhip import ops
+    g = torch.Generator().manual_seed(21)
+    B, H, W, Cin, Cout = 2, 18, 20, 128, 64
+    x = torch.randn(B, H, W, Cin, generator=g).cuda().half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).cuda()
+    b = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    wp = _planes(w)
+    mean, var = torch.randn(Cin, generator=g) * 0.3, torch.rand(Cin, generator=g) + 0.5
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+    rstd = torch.rsqrt(var + 1e-5)
+    coef = torch.stack([mean, rstd, gamma * rstd, beta]).cuda().contiguous()
+    # the prologue's activation is rounded to fp16 before the product, as a separate fp16 BatchNorm-ReLU pass would
+    act = torch.relu((x.float() - coef[0]) * coef[2] + coef[3]).half()
+    pre = F.conv2d(act.double().permute(0, 3, 1, 2), _w_hi(w), b.double(), padding=1).permute(0, 2, 3, 1)
+    _check(ops.conv3x3_h16(x, wp, b, Cout, in_bn=coef), pre)
+    # LeakyReLU epilogue
+    pre0 = F.conv2d(x.double().permute(0, 3, 1, 2), _w_hi(w), b.double(), padding=1).permute(0, 2, 3, 1)
+    _check(ops.conv3x3_h16(x, wp, b, Cout, epi=6, alpha=0.2), F.leaky_relu(pre0, 0.2))
+    # a 1x1 conv held in the centre tap
+    w1 = torch.zeros(Cout, Cin, 3, 3, device="cuda")
+    w1[:, :, 1, 1] = torch.randn(Cout, Cin, generator=g).cuda() / Cin ** 0.5
+    wp1 = _planes(w1)
+    ref1 = F.conv2d(act.double().permute(0, 3, 1, 2), _w_hi(w1), None, padding=1).permute(0, 2, 3, 1)
+    _check(ops.conv3x3_h16(x, wp1, None, Cout, in_bn=coef, center_only=True), ref1)
+    # tail conv with the prologue; head conv with LeakyReLU
+    w2 = (torch.randn(1, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).cuda()
+    y = ops.conv3x3_cout1_h16(x, w2, None, in_bn=coef)
+    act32 = torch.relu((x.double() - coef[0].double()) * coef[2].double() + coef[3].double())
+    ref2 = F.conv2d(act32.permute(0, 3, 1, 2), w2.double(), None, padding=1)[:, 0]
+    assert ((y.double() - ref2).abs().max() / ref2.abs().max()).item() < 1e-5
+    img = torch.rand(2, 11, 13, generator=g).cuda()
+    wh = (torch.randn(64, 1, 3, 3, generator=g) / 3.0).cuda()
+    f = ops.conv3x3_cin1_h16(img, wh, None, 64, leaky=0.2)
+    _check(f, F.leaky_relu(F.conv2d(img.double()[:, None], wh.double(), None, padding=1), 0.2).permute(0, 2, 3, 1))

@@ -73,6 +73,16 @@ def main():
                 model.init_train()
                 batch = M.synth_batch(a.batch, scale, 512, model.device, 7)
                 model.feed_data(batch)
+                if net_type == "MemNet":
+                    # its BatchNorms need running statistics: with the initial (0, 1) every forward grows by orders of
+                    # magnitude per memory block (and leaves fp16's range under --amp).  A few training-mode forwards on a
+                    # small crop, as tests/test_gpu_amp.py does
+                    model.netG.train()
+                    with torch.no_grad():
+                        crop = model.L[:2, :, :32, :32].contiguous()
+                        for _ in range(30):
+                            model.netG(crop)
+                    model.netG.eval()
                 for _ in range(3):
                     model.test()
                 torch.cuda.synchronize()
