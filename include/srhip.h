@@ -439,6 +439,8 @@ int srhip_channel_gate(const float* feat, const float* w1, const float* b1, cons
                        const float* x1, float* out, float* gate, double* workspace, int B, long P, int C, int Cm,
                        int mid_act, void* stream);
 int srhip_unary(const float* x, float* out, long n, int kind, void* stream);
+/* its backward: dx = g * f'; kind 0 (GELU): xy = the op's input, kind 1 (sigmoid): xy = its output */
+int srhip_unary_bwd(const float* xy, const float* g, float* dx, long n, int kind, void* stream);
 
 /* ---- token-branch pieces of ACT, evaluation forward (act_ops.hip) --------------
  * dlib/models/network_act.py:468-541 on channels-last data:

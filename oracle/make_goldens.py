@@ -1547,6 +1547,48 @@ def g_dfcan():
     npz("g35_dfcan", **out)
 
 
+def g_dfcan_grad():
+    """DFCAN training step of the reference: the registry's net at x2 on a small input in TRAINING mode, L1 loss against a
+    random target, autograd -> the gradient of every parameter (through torch.fft.fftn / abs / pow / the quadrant swap and
+    the channel gate).  The oracle's own autograd must reproduce them."""
+    print("G41 DFCAN gradients")
+    from dlib.models.network_dfcan import DFCAN as RefDFCAN
+    out = {}
+    for scale, hw in ((2, (16, 12)),):
+        sd = O.dfcan_init_state_dict(scale, 1, seed=480 + scale)
+        net = RefDFCAN(input_shape=1, upscale=scale)
+        net.load_state_dict(sd, strict=True)
+        net.train()
+        torch.manual_seed(485 + scale)
+        x = torch.rand(2, 1, *hw)
+        tgt = torch.rand(2, 1, hw[0] * scale, hw[1] * scale)
+        y = net(x)
+        loss = (y - tgt).abs().mean()
+        loss.backward()
+        sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 else v) for k, v in sd.items()}
+        yo = O.dfcan_forward(sdo, x, scale)
+        (yo - tgt).abs().mean().backward()
+        close(yo, y, 0.0, f"dfcan x{scale} training forward")
+        pre = f"x{scale}/"
+        out[pre + "x"], out[pre + "tgt"], out[pre + "y"], out[pre + "loss"] = x, tgt, y.detach(), loss.detach()
+        out[pre + "seed"] = np.array(480 + scale)
+        n = 0
+        for k, p_ in net.named_parameters():
+            assert p_.grad is not None, k
+            g_o = sdo[k].grad
+            assert g_o is not None, k
+            err = (g_o - p_.grad).abs().max().item()
+            assert err <= 1e-6 * max(1e-3, p_.grad.abs().max().item()), (k, err)
+            if p_.grad.numel() <= 8192:
+                out[pre + "grad/" + k] = p_.grad
+            else:       # the 48 64 x 64 x 3 x 3 weights: two output channels in full + the tensor's sum and sum of magnitudes
+                out[pre + "gslice/" + k] = p_.grad[:2].clone()
+                out[pre + "gsum/" + k] = torch.stack([p_.grad.double().sum(), p_.grad.double().abs().sum(), p_.grad.double().abs().max()])
+            n += 1
+        print(f"  {n} parameter gradients, oracle autograd == reference autograd")
+    npz("g41_dfcan_grad", **out)
+
+
 def g_act():
     """ACT (network_act.py): a narrow configuration (16 features, 2 RCABs per group, 4 heads: 144-dim tokens) with every op
     class of the registry's net -- 5 x 5 head convs, 3 x 3 tokens, self-attention, the cross-scale attention against
@@ -1927,7 +1969,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_grl, g_omnisr, g_act, g_dfcan, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_grl, g_omnisr, g_act, g_dfcan, g_dfcan_grad, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

@@ -146,6 +146,15 @@ __global__ void __launch_bounds__(256) k_unary(const float* __restrict__ x, floa
   }
 }
 
+// backward of k_unary: gelu from its INPUT x (exact erf derivative), sigmoid from its OUTPUT y
+__global__ void __launch_bounds__(256) k_unary_bwd(const float* __restrict__ xy, const float* __restrict__ g, float* __restrict__ dx,
+                                                   long n, int kind) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = xy[i];
+    dx[i] = g[i] * (kind == 0 ? dgelu_f(v) : v * (1.0f - v));
+  }
+}
+
 inline int ew_blocks(long n) { const long g = (n + 255) / 256; return (int)(g < 8192 ? g : 8192); }
 
 }  // namespace
@@ -202,6 +211,14 @@ int srhip_unary(const float* x, float* out, long n, int kind, void* stream) {
   SR_REQUIRE(x && out && n > 0 && (kind == 0 || kind == 1), "unary: bad arguments");
   hipLaunchKernelGGL(k_unary, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, out, n, kind);
   SR_LAUNCH_CHECK("unary");
+  return 0;
+}
+
+/* dx = g * f'(.) for srhip_unary's functions: kind 0 (GELU) takes the op's INPUT in xy, kind 1 (sigmoid) its OUTPUT.  dx may be g. */
+int srhip_unary_bwd(const float* xy, const float* g, float* dx, long n, int kind, void* stream) {
+  SR_REQUIRE(xy && g && dx && n > 0 && (kind == 0 || kind == 1), "unary_bwd: bad arguments");
+  hipLaunchKernelGGL(k_unary_bwd, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, xy, g, dx, n, kind);
+  SR_LAUNCH_CHECK("unary_bwd");
   return 0;
 }
 

@@ -2,7 +2,7 @@
 (``input_shape`` = input channels, ``upscale``), ``forward((B,1,h,w) in [0,1]) -> (B,1,s*h,s*w)`` (the last op is a
 sigmoid) and the reference's state_dict keys, shapes and order (``input.0.*``, ``RGs.{g}.RCABs.{r}.conv_gelu1.0.* ...
 conv_sigmoid.0.*``, ``conv_gelu.0.*``, ``conv_sigmoid.0.*``).  The compute is ``srhip.dfcan_engine.DFCANEngine``: the
-spectrum's magnitude as a separable DFT with f64 accumulation.  Evaluation only (``backward`` raises); 1-channel inputs;
+spectrum's magnitude as a separable DFT with f64 accumulation.  Trains (srhip.tape.Tape.fourier_gate: the spectrum magnitude differentiated through stock torch.fft); 1-channel inputs;
 LR images up to 256 x 256; GPU only."""
 import torch.nn as nn
 

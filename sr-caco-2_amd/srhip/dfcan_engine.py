@@ -1,6 +1,6 @@
 """DFCAN as a tape graph (reference dlib/models/network_dfcan.py:86-116): conv + GELU; four residual groups of four RCABs
 (two conv + GELU, the Fourier channel attention, skip); conv 64 -> 64 s^2 + GELU as 256-column slices; PixelShuffle(s);
-conv + sigmoid.  Inference only."""
+conv + sigmoid.  Trains through the tape's derived backward (Tape.fourier_gate: the spectrum magnitude through stock torch.fft)."""
 from .tape import TapeEngine
 
 
@@ -35,15 +35,15 @@ class DFCANEngine(TapeEngine):
                 w1, w2 = m.conv_relu2[0].weight, m.conv_sigmoid[0].weight
                 x = t.fourier_gate(x, b, f"{pre}.conv_relu1", (f"{pre}.conv_relu1.0.weight", f"{pre}.conv_relu1.0.bias"),
                                    w1.data.reshape(w1.shape[0], w1.shape[1]).contiguous(), m.conv_relu2[0].bias.data,
-                                   w2.data.reshape(w2.shape[0], w2.shape[1]).contiguous(), m.conv_sigmoid[0].bias.data)
+                                   w2.data.reshape(w2.shape[0], w2.shape[1]).contiguous(), m.conv_sigmoid[0].bias.data,
+                                   names_gate=(f"{pre}.conv_relu2.0.weight", f"{pre}.conv_relu2.0.bias",
+                                               f"{pre}.conv_sigmoid.0.weight", f"{pre}.conv_sigmoid.0.bias"))
             x = t.axpby(x, x0, 1.0, 1.0)
-        names = ("conv_gelu.0.weight", "conv_gelu.0.bias")
-        parts = [t.conv(x, f"conv_gelu.{j}", names) for j in range(self.nslices)]
+        wsl = net.conv_gelu[0].weight.shape[0] // self.nslices
+        parts = [t.conv(x, f"conv_gelu.{j}", ("conv_gelu.0.weight", "conv_gelu.0.bias", (j * wsl, (j + 1) * wsl)))
+                 for j in range(self.nslices)]
         u = t.unary(t.cat(parts) if len(parts) > 1 else parts[0], "gelu")
         u = t.shuffle(u, net.upscale)
         y = t.conv_out1(u, net.conv_sigmoid[0].weight, net.conv_sigmoid[0].bias, ("conv_sigmoid.0.weight", "conv_sigmoid.0.bias"))
         return t.unary(y, "sigmoid")
 
-    def backward(self, *a, **k):
-        raise NotImplementedError("DFCAN on libsrhip: inference only (BASELINE config 5's evaluation sweep); the backward of "
-                                  "the Fourier channel attention is not built")

@@ -435,6 +435,14 @@ def unary(x, out, kind):
     return out
 
 
+def unary_bwd(xy, g, out, kind):
+    """out = g * f'(.): kind 'gelu' takes the op's input, 'sigmoid' its output."""
+    _chk(xy, g, out)
+    assert xy.is_contiguous() and g.is_contiguous() and out.is_contiguous() and xy.numel() == g.numel() == out.numel()
+    call("srhip_unary_bwd", _p(xy), _p(g), _p(out), xy.numel(), {"gelu": 0, "sigmoid": 1}[kind], _st())
+    return out
+
+
 def fft2_mag_pow_shift(x, out, gamma=0.8, eps=1e-8):
     """out = fftshift2d((|fftn(x, dim=(H, W))| + eps) ** gamma) on NHWC [B, H, W, C] (network_dfcan.py:27-36,60-64)."""
     _chk(x, out)

@@ -592,25 +592,72 @@ class Tape:
             self.back.append(bwd)
 
     def unary(self, x, kind):
-        """nn.GELU() / sigmoid as their own op (DFCAN: network_dfcan.py:44-47,98-99,108,111-113).  Inference only."""
+        """nn.GELU() / sigmoid as their own op (DFCAN: network_dfcan.py:44-47,98-99,108,111-113)."""
         xin = x.t if x.t.is_contiguous() else x.t.contiguous()
         y = self.new(*x.t.shape)
         ops.unary(xin, y, kind)
-        self._no_backward(kind)
-        return self._out(y)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out, xin=xin, y=y):
+                if out.g is None:
+                    return
+                g = out.g if out.g.is_contiguous() else out.g.contiguous()
+                self.acc(x, lambda o: ops.unary_bwd(xin if kind == "gelu" else y, g, o, kind))
+            self.back.append(bwd)
+        return out
 
-    def fourier_gate(self, x0, x1, key_conv, names_conv, w1, b1, w2, b2):
+    def fourier_gate(self, x0, x1, key_conv, names_conv, w1, b1, w2, b2, names_gate=None, gamma=0.8, eps=1e-8):
         """DFCAN's Fourier channel attention (RCAB.forward, network_dfcan.py:60-70): gate = sigmoid(W2 relu(W1 avgpool(relu(
-        conv(fftshift(|FFT2(x1)|^0.8)))))), out = x0 + x1 * gate.  Inference only."""
+        conv(fftshift(|FFT2(x1)|^0.8)))))), out = x0 + x1 * gate.  names_gate = parameter names of (W1, b1, W2, b2).
+        Backward (training): the gate's two tiny Linears by hand on [B, C] tensors; the spectrum magnitude through stock
+        torch.fft -- with F = FFT2(x1) and G the incoming gradient un-shifted and times gamma (|F| + eps)^(gamma - 1) / |F|,
+        d x1 = Re(unnormalised IFFT2(G F)) -- registered in front of the conv so that it runs behind the conv's backward."""
         a = x1.t if x1.t.is_contiguous() else x1.t.contiguous()
+        B, H, W, C = a.shape
         m = torch.empty_like(a)
-        ops.fft2_mag_pow_shift(a, m)
-        c = self.relu(self.conv(self.var(m, need=False), key_conv, names_conv))
+        ops.fft2_mag_pow_shift(a, m, gamma, eps)
+        mv = self.var(m, need=self.save)
+        if self.save:
+            def spec_bwd(x1=x1, mv=mv, a=a):
+                if mv.g is None:
+                    return
+                Fq = torch.fft.fftn(a, dim=(1, 2))
+                mag = Fq.abs()
+                g0 = torch.roll(mv.g, shifts=(H // 2, W // 2), dims=(1, 2))        # through fftshift2d (:27-36)
+                G = g0 * gamma * (mag + eps).pow(gamma - 1.0) / mag.clamp_min(1e-30)
+                G = torch.where(mag > 0, G, torch.zeros_like(G))
+                dx = torch.fft.ifftn(G * Fq, dim=(1, 2), norm="forward").real.contiguous()
+                self.acc(x1, lambda o: o.copy_(dx))
+            self.back.append(spec_bwd)
+        c = self.relu(self.conv(mv, key_conv, names_conv))
         y = self.new(*a.shape)
         x0c = x0.t if x0.t.is_contiguous() else x0.t.contiguous()
         ops.channel_gate(c.t, w1, b1, w2, b2, x0c, a, y)
-        self._no_backward("the Fourier channel attention")
-        return self._out(y)
+        out = self._out(y)
+        if self.save:
+            assert names_gate is not None
+            gate = ops.SCRATCH.get("gate_vec", B * C, device=a.device)[:B * C].view(B, C).clone()
+            pool = c.t.mean((1, 2))
+
+            def gate_bwd(x0=x0, x1=x1, c=c, out=out, a=a, gate=gate, pool=pool):
+                g = out.g
+                if g is None:
+                    return
+                self.acc(x0, lambda o: o.copy_(g))
+                self.acc(x1, lambda o: torch.mul(g, gate.view(B, 1, 1, C), out=o))
+                dgate = (g * a).sum((1, 2))
+                z1 = pool @ w1.t() + b1
+                r1 = torch.relu(z1)
+                dz2 = dgate * gate * (1.0 - gate)
+                dz1 = (dz2 @ w2) * (z1 > 0)
+                self.gparam(names_gate[2], lambda o: o.view(w2.shape).copy_(dz2.t() @ r1))
+                self.gparam(names_gate[3], lambda o: o.copy_(dz2.sum(0)))
+                self.gparam(names_gate[0], lambda o: o.view(w1.shape).copy_(dz1.t() @ pool))
+                self.gparam(names_gate[1], lambda o: o.copy_(dz1.sum(0)))
+                dpool = (dz1 @ w1) / float(H * W)
+                self.acc(c, lambda o: o.copy_(dpool.view(B, 1, 1, C).expand(B, H, W, C)))
+            self.back.append(gate_bwd)
+        return out
 
     def conv_in1(self, x3, weight, bias, names):
         """first conv of a 1-channel image: x3 [B, H, W] -> [B, H, W, Co] (small.hip)."""

@@ -459,9 +459,6 @@ def test_dfcan_forward_vs_reference_golden(scale):
     with torch.no_grad():
         y = net(g["x"].cuda()).cpu()
     assert (y - g["y"]).abs().mean().item() <= 1e-5 and rel(y, g["y"]) < 2e-5, rel(y, g["y"])
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(g["x"].cuda()).sum().backward()
 
 
 def test_dfcan_spectrum_magnitude_vs_torch_fft():
@@ -710,3 +707,63 @@ def test_grl_registry_net_vs_oracle_and_amp():
     assert not torch.equal(ya, y)                                          # the reduced-precision kernels did run
     mse = ((ya - yo) ** 2).mean().item() / max(1.0, yo.abs().max().item()) ** 2
     assert mse < 1e-5, mse
+
+
+def test_dfcan_training_step_gradients_vs_reference_golden():
+    """DFCAN trains: forward in training mode, L1 loss, every parameter gradient of the registry's net at
+    x2 against the REFERENCE's own autograd (g41_dfcan_grad.npz, oracle/make_goldens.py::g_dfcan_grad; the 64 x 64 x 3 x 3
+    weights as two output channels in full + the tensor's sum / sum of magnitudes) -- the GELU / sigmoid backward, the channel
+    gate's two Linears, and the spectrum magnitude (|FFT2|^0.8 under the quadrant swap) through stock torch.fft.  Gate 2e-5 of
+    a tensor's largest entry; ReLU decisions within rounding of zero excused by the 3x-the-fp32-oracle arm."""
+    from dlib.models.network_dfcan import DFCAN
+    from srhip.train import TrainStep, Optimizer
+    scale = 2
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g41_dfcan_grad").items() if k.startswith(f"x{scale}/")}
+    sd = O.dfcan_init_state_dict(scale, 1, seed=int(g["seed"]))
+    net = DFCAN(input_shape=1, upscale=scale)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=0.0, momentum=0.0, nesterov=False, wd=0.0)
+    x, tgt = g["x"], g["tgt"]
+    ts.step(x.cuda(), tgt.cuda())
+    assert abs(ts.loss_values()[0] - float(g["loss"])) <= 2e-6
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    (O.dfcan_forward(sd64, x.double(), scale) - tgt.double()).abs().mean().backward()
+    worst, n = 0.0, 0
+    for k in ts.fp.names:
+        got = ts.fp.gviews[k].double().cpu()
+        r64 = sd64[k].grad
+        if "grad/" + k in g:
+            ref = g["grad/" + k].double()
+            den = ref.abs().max().clamp_min(1e-30)
+            e = ((got - ref).abs().max() / den).item()
+            e32 = ((ref - r64).abs().max() / den).item()
+        else:
+            ref, sums = g["gslice/" + k].double(), g["gsum/" + k].double()
+            den = sums[2].clamp_min(1e-30)
+            e = ((got[:2] - ref).abs().max() / den).item()
+            e32 = ((ref - r64[:2]).abs().max() / den).item()
+            assert abs(got.sum().item() - sums[0].item()) <= 1e-4 * sums[1].item(), k
+            assert abs(got.abs().sum().item() - sums[1].item()) <= 1e-4 * sums[1].item(), k
+            # and the whole tensor against the fp64 oracle (the slice pins the oracle to the reference)
+            e = max(e, ((got - r64).abs().max() / den).item() - e32)
+        worst, n = max(worst, e), n + 1
+        assert e <= max(2e-5, 3.0 * e32), (k, e, e32)
+    assert n == 166
+    print(f"DFCAN x{scale} training step: loss {ts.loss_values()[0]:.6f}, worst gradient error {worst:.2e} of a tensor's largest entry")
+
+
+def test_main_cli_trains_dfcan(tmp_path):
+    """`main.py --net_type DFCAN --max_iters 20`: the registry net through ModelPlain's step, loss finite and falling."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "sr-caco-2_amd", "main.py"), "--net_type", "DFCAN", "--method", "DFCAN",
+                        "--task", "super-resolution", "--scale", "4", "--n_channels", "1", "--h_size", "128", "--batch_size", "2",
+                        "--max_iters", "20", "--G_optimizer_lr", "1e-4", "--outd", str(tmp_path)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    losses = [float(l.split("G_loss")[1].split()[0]) for l in p.stdout.splitlines() if "G_loss" in l]
+    assert len(losses) == 2 and all(np.isfinite(losses)) and losses[1] < losses[0], losses
