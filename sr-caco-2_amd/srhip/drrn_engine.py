@@ -92,6 +92,7 @@ class DRRNEngine:
         if not self.prepared:
             self.prepare()
         if not save and ops.h16_eval() and self.ws.use_bx3 and self.ws["wa.wp"].fmt == 1:
+            self.last_eval_path = "fp16 storage"
             return self.forward_h16(x)
         net, U = self.net, self.U
         xi = self.interpolate(x[:, None])

@@ -110,6 +110,7 @@ class EDSREngine:
         if not self.prepared:
             self.prepare()
         if not save and ops.h16_eval() and self._h16_ok():
+            self.last_eval_path = "fp16 storage"
             return self.forward_h16(x)
         net, F, D = self.net, self.F, self.derived
         B, H, W = x.shape

@@ -190,6 +190,7 @@ class MemNetEngine:
             # (a 200-ms forward: the host round trip is noise); on overflow this net stays on f32 storage.
             y = self.forward_h16(x)
             if bool(torch.isfinite(y).all()):
+                self.last_eval_path = "fp16 storage"
                 return y
             self._h16_overflow = True
         xi = self.interpolate(x[:, None])

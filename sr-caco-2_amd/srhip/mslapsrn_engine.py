@@ -145,6 +145,7 @@ class MSLapSRNEngine:
         if not self.prepared:
             self.prepare()
         if not save and ops.h16_eval() and self._h16_ok():
+            self.last_eval_path = "fp16 storage"
             return self.forward_h16(x)
         net, D, ws = self.net, self.derived, self.ws
         B, h, w = x.shape

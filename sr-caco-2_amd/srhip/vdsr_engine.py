@@ -81,6 +81,7 @@ class VDSREngine:
         if not self.prepared:
             self.prepare()
         if not save and ops.h16_eval() and self.ws.use_bx3 and self.ws["t0.wp"].fmt == 1:
+            self.last_eval_path = "fp16 storage"
             return self.forward_h16(x)
         net = self.net
         xi = self.interpolate(x[:, None])
