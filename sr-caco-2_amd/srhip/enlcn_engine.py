@@ -51,9 +51,8 @@ class ENLCNEngine(TapeEngine):
                 res = t.enlca(res, [f"body.{i}.{s}" for s in ("conv_match1", "conv_match2", "conv_assembly")],
                               m.attn_fn.projection_matrix, rs)
             elif kind == "res":
-                r = t.conv(res, f"body.{i}.0", (f"body.{i}.body.0.weight", f"body.{i}.body.0.bias"))
-                r = t.conv(t.relu(r), f"body.{i}.2", (f"body.{i}.body.2.weight", f"body.{i}.body.2.bias"))
-                res = t.axpby(r, res, rs, 1.0)
+                r = t.conv(res, f"body.{i}.0", (f"body.{i}.body.0.weight", f"body.{i}.body.0.bias"), relu=True)
+                res = t.conv(r, f"body.{i}.2", (f"body.{i}.body.2.weight", f"body.{i}.body.2.bias"), res=(res, rs))
             else:
                 res = t.conv(res, f"body.{i}", (f"body.{i}.weight", f"body.{i}.bias"))
         res = t.axpby(res, x, 1.0, 1.0)

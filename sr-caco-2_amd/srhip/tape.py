@@ -284,9 +284,12 @@ class Tape:
             ops.axpby(gt, tmp, 1.0, 1.0)
 
     # ---- ops
-    def conv(self, x, key, names, act=None, prelu=None, add=None):
+    def conv(self, x, key, names, act=None, prelu=None, add=None, relu=False, res=None):
         """x -> conv (bank entry `key`) [-> PixelShuffle / after PixelUnshuffle for the strided forms].
         names = (weight parameter name, bias parameter name or None).
+        relu / res = (Var, factor) (plain 3x3 convs): out = relu(conv(x)) / out = Var + factor * conv(x) as the conv's
+        epilogue in both modes (the ResBlock of the EDSR-body nets, network_nlsn.py:72-98: two launches instead of six); the
+        backward masks / scales the incoming gradient in place before the conv's own.
         prelu = (slope parameter, its name), add = (Var, factor): out = prelu(conv(x)) + factor * Var (DBPN's projection
         units).  In evaluation mode both ride in the 3x3 conv's epilogue (srhip_conv3x3_nhwc_split_ex epi 9 / 10; the
         addend of a transposed conv is added behind its PixelShuffle); with the tape recording they are the ordinary ops."""
@@ -304,9 +307,17 @@ class Tape:
         radd = None
         if fuse_add:
             radd = add[0].t if add[0].t.is_contiguous() else add[0].t.contiguous()
+        assert not (relu or res is not None) or (e.kind == "c3" and prelu is None and add is None and act is None and not (relu and res))
+        rres = None
+        if res is not None:
+            rres = res[0].t if res[0].t.is_contiguous() else res[0].t.contiguous()
         for b0, b1 in cks:
             if e.kind == "c1":
                 ops.gemm_nt(xin[b0:b1].view(-1, Ci), e.w1, e.bias, out=y[b0:b1].view(-1, e.Co))
+            elif relu:
+                ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1], epi=1)
+            elif res is not None:
+                ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1], epi=2, R=rres[b0:b1], alpha=float(res[1]))
             elif fuse_add:
                 ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1], epi=10, R=radd[b0:b1], alpha=float(add[1]),
                             slope=prelu[0].data)
@@ -323,6 +334,12 @@ class Tape:
                 g = out.g
                 if g is None:
                     return
+                if relu:                                     # out = relu(conv): the gradient where the output is positive
+                    ops.relu_mask(g, out.t)
+                if res is not None:                          # out = R + f conv: R takes g, the conv f g
+                    self.acc(res[0], lambda o: o.copy_(g))
+                    if float(res[1]) != 1.0:
+                        ops.axpby(g, g, float(res[1]), 0.0)
                 B, H, W, Ci = x.t.shape
                 xin = x.t if x.t.is_contiguous() else x.t.contiguous()
                 cks = _chunks(B, H * W * max(Ci, e.Co))
