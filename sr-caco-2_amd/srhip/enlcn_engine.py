@@ -40,6 +40,18 @@ class ENLCNEngine(TapeEngine):
             for j in range(4):
                 bank.conv(f"tail.0.{2 * st}.{j}", c.weight[j * F:(j + 1) * F], c.bias[j * F:(j + 1) * F], "c3")
 
+    def _h16_ok(self):
+        F = self.net.n_feats
+        return F % 64 == 0 and F <= 1024 and all(e.use_planes and e.wp.fmt == 1 for k, e in self.bank.d.items() if e.kind == "c3")
+
+    def forward_h16(self, x):
+        net = self.net
+
+        def attention(t, v, i):
+            return t.enlca(v, [f"body.{i}.{s}" for s in ("conv_match1", "conv_match2", "conv_assembly")],
+                           net.body[i].attn_fn.projection_matrix, net.res_scale)
+        return self.edsr_body_h16(x, self._body(), attention)
+
     def graph(self, t, x3):
         net = self.net
         rs = net.res_scale

@@ -40,6 +40,27 @@ class NLSNEngine(TapeEngine):
             for j in range(4):
                 bank.conv(f"tail.0.{2 * st}.{j}", c.weight[j * F:(j + 1) * F], c.bias[j * F:(j + 1) * F], "c3")
 
+    def _h16_ok(self):
+        F = self.net.n_feats
+        return F % 64 == 0 and F <= 1024 and all(e.use_planes and e.wp.fmt == 1 for k, e in self.bank.d.items() if e.kind == "c3")
+
+    def forward_h16(self, x):
+        net = self.net
+        state = {"a": 0}
+
+        def attention(t, v, i):
+            a = state["a"]
+            state["a"] += 1
+            tap = None
+            if self.taps is not None:
+                tap = {}
+                self.taps.append(tap)
+            return t.nlsa(v, (f"body.{i}.conv_match", f"body.{i}.conv_assembly"), net.n_hashes, net.chunk_size, net.res_scale,
+                          None if self.rotations is None else self.rotations[a], tap,
+                          None if self.orders is None else self.orders[a])
+        layout = [(i, "nlsa" if k == "nlsa" else k) for i, k in body_layout(net.n_resblocks)]
+        return self.edsr_body_h16(x, layout, attention)
+
     def graph(self, t, x3):
         net = self.net
         rs = net.res_scale

@@ -19,6 +19,8 @@ How the reference's layers map onto the kernels:
 Every tensor is NHWC.  Buffers are persistent and keyed by the position of the op on the tape, so a training step
 allocates nothing after the first one.
 """
+import math
+
 import numpy as np
 import torch
 
@@ -907,6 +909,7 @@ class TapeEngine:
 
     def invalidate(self):
         self.prepared = False
+        self._h16_ready = False
 
     def bucket_prefixes(self):
         return [[""]]           # one gradient bucket: every parameter
@@ -921,12 +924,55 @@ class TapeEngine:
         """x [B, H, W] -> [B, 1, s H, s W]."""
         if not self.prepared:
             self.prepare()
+        if not save and ops.h16_eval() and hasattr(self, "forward_h16") and self._h16_ok():
+            self.last_eval_path = "fp16 storage (attention blocks f32)"
+            return self.forward_h16(x)
         tape = Tape(self.bufs, self.bank, save, x.device)
         out = self.graph(tape, x)
         if save:
             self.saved = (tape, out)
         B, H, W = out.t.shape
         return out.t.view(B, 1, H, W)
+
+    def edsr_body_h16(self, x, layout, attention):
+        """--amp evaluation of the EDSR-body nets (ENLCN, NLSN) on fp16 storage (conv_h16.hip): head conv, ResBlocks (two
+        launches each: ReLU / residual as epilogues), the body's last conv with the long skip as its epilogue, the F -> 4F
+        upsampler convs stored through their PixelShuffle(2), the output conv -- float16 feature maps, one fp16 product.
+        The attention blocks (attention(tape, Var f32, body index) -> Var) run on f32 copies of their input, as under
+        f32-storage --amp."""
+        net, bank = self.net, self.bank
+        F, rs = net.n_feats, float(net.res_scale)
+        dev = x.device
+        if not getattr(self, "_h16_ready", False):        # the upsampler convs whole, in sub-pixel-major column order
+            tb = ops.PrepTable()
+            self._h16_up = []
+            for st in range(int(math.log2(net.upscale))):
+                c = net.tail[0][2 * st]
+                wp = ops.Bx3(9 * 4 * F, F, dev)
+                tb.conv(c.weight.data, wp, ps2=True)
+                self._h16_up.append((wp, c.bias.data))
+            if self._h16_up:
+                tb.build(dev).run()
+            self._h16_ready = all(wp.fmt == 1 for wp, _ in self._h16_up)
+            assert self._h16_ready, "edsr_body_h16: the upsampler conv does not take the fp16x2 operand format"
+        t = Tape(self.bufs, bank, False, dev)
+        h = ops.conv3x3_cin1_h16(x, net.head[0].weight.data, net.head[0].bias.data, F)
+        res = h
+        for i, kind in layout:
+            if kind == "res":
+                e0, e2 = bank.d[f"body.{i}.0"], bank.d[f"body.{i}.2"]
+                a = ops.conv3x3_h16(res, e0.wp, e0.bias, F, epi=1)
+                res = ops.conv3x3_h16(a, e2.wp, e2.bias, F, epi=2, R=res, alpha=rs)
+            elif kind == "conv":
+                e = bank.d[f"body.{i}"]
+                res = ops.conv3x3_h16(res, e.wp, e.bias, F, epi=2, R=h)          # + the long skip
+            else:
+                res = attention(t, t.var(res.float(), need=False), i).t.half()
+        for wp, b in self._h16_up:
+            res = ops.conv3x3_h16(res, wp, b, 4 * F, ps2=True)
+        y = ops.conv3x3_cout1_h16(res, net.tail[1].weight.data, net.tail[1].bias.data)
+        B, H, W = y.shape
+        return y.view(B, 1, H, W)
 
     def backward(self, dy, grads, need_dx=False, on_layer_done=None, grads_zeroed=False):
         assert self.saved is not None, "backward() without a saved forward"
