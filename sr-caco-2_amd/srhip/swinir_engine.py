@@ -103,6 +103,7 @@ class SwinIREngine:
     def prepare(self):
         """Derived weight copies (folded LayerNorm, transposes, conv packs, dense
         bias images).  Must be re-run whenever parameters change."""
+        self.prepared_tail = False
         if self.ws.use_bx3:
             self._prepare_bx3()
         else:
@@ -241,6 +242,26 @@ class SwinIREngine:
             for i in range(self.stages):
                 yield f"up{i}", net.upsample[2 * i]
 
+    def _eval_tail_ok(self):
+        nf = self.net.num_feat
+        return (self.ws.use_bx3 and not self.direct and not self.nearest and self.stages > 0 and self.net.in_chans == 1
+                and (self.scale & (self.scale - 1)) == 0
+                and nf % 64 == 0 and ops.ps2_fusable(nf, 4 * nf) and ops.F16X2_CONV and ops.F16X2_CONV_WIDE)
+
+    def _eval_tail_planes(self, dev):
+        """the 'pixelshuffle' upsampler's convs in sub-pixel-major column order (PrepTable.conv(ps2=True)): evaluation only"""
+        if getattr(self, "_tail_planes", None) is None or not self.prepared_tail:
+            tb = ops.PrepTable()
+            nf = self.net.num_feat
+            self._tail_planes = []
+            for i in range(self.stages):
+                wp = ops.Bx3(9 * 4 * nf, nf, dev)
+                tb.conv(self.net.upsample[2 * i].weight.data, wp, ps2=True)
+                self._tail_planes.append(wp)
+            tb.build(dev).run()
+            self.prepared_tail = True
+        return self._tail_planes
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, dp=None, save=True):
         """x: [B,H,W] fp32 cuda, H and W multiples of 8 -> [B,1,s*H,s*W].
@@ -367,6 +388,27 @@ class SwinIREngine:
             ops.conv3x3_cout1_fwd(a3, net.conv_last.weight.data, net.conv_last.bias.data, out=y.view(B, 4 * H, 4 * W))
             if save:
                 sv["near"] = (u, n1, a1, n2, a2, a3)
+        elif not save and self._eval_tail_ok():
+            # evaluation: the upsampler's convs store through their PixelShuffle(2) (no separate shuffle pass); under --amp on
+            # fp16 storage (conv_h16.hip: the 64-channel maps at up to 256 x 256 are what the tail's time goes into)
+            nf = net.num_feat
+            u = buf("cbu", B, H, W, nf)
+            ops.conv3x3(f, ws["cbu.wp"], net.conv_before_upsample[0].bias.data, nf, out=u, epi=6, alpha=0.01)
+            ups_w = self._eval_tail_planes(dev)
+            h, w = H, W
+            if ops.h16_eval():
+                u = u.half()
+                for i in range(self.stages):
+                    u = ops.conv3x3_h16(u, ups_w[i], net.upsample[2 * i].bias.data, 4 * nf,
+                                        out=bufs.get(f"h.upu{i}", B, 2 * h, 2 * w, nf, device=dev, dtype=torch.float16), ps2=True)
+                    h, w = 2 * h, 2 * w
+                ops.conv3x3_cout1_h16(u, net.conv_last.weight.data, net.conv_last.bias.data, out=y.view(B, h, w))
+            else:
+                for i in range(self.stages):
+                    un = buf(f"upu{i}", B, 2 * h, 2 * w, nf)
+                    ops.conv3x3_ps2(u, ups_w[i], net.upsample[2 * i].bias.data, un)
+                    u, h, w = un, 2 * h, 2 * w
+                ops.conv3x3_cout1_fwd(u, net.conv_last.weight.data, net.conv_last.bias.data, out=y.view(B, h, w))
         else:               # 'pixelshuffle' (network_swinir.py:937-942)
             nf = net.num_feat
             u = buf("cbu", B, H, W, nf)
