@@ -10,7 +10,9 @@
 //                   chunk run without a barrier on weight fragments requested a chunk ahead; optional BatchNorm-ReLU input
 //                   prologue (MemNet); epilogues bias / ReLU / LeakyReLU / residual / residual + ReLU on the row-major
 //                   re-laid tile (16-byte accesses), optionally stored through PixelShuffle(2) (the EDSR upsampler,
-//                   network_nlsn.py:100-118); a 1x1 conv runs as the centre tap alone
+//                   network_nlsn.py:100-118)
+//   k_conv1x1_h16   a 1x1 conv held as the centre tap of a 3x3 operand (MemNet's gate units, SRCNN's layers): no halo,
+//                   three 32-channel chunks per stage
 //   k_cin1_h16      the 1 -> Cout conv at the head (f32 image in, fp16 features out; network_vdsr.py:57-60)
 //   k_cout1_h16     the Cin -> 1 conv at the tail (fp16 features in, f32 image out, + the interpolated input)
 #include "common.h"
@@ -28,122 +30,17 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
 }
 
-constexpr int h16_lds(int rw) {
-  const int halo = (2 * rw + 2) * 18 * HP, tile = 2 * rw * 16 * TPF * 4;
-  return halo > tile ? halo : tile;
+constexpr int h16_lds(int rw) {       // the halo tile of a chunk | three chunks of the tile's own pixels (1x1) | the f32 output tile
+  const int halo = (2 * rw + 2) * 18 * HP, one = 3 * 2 * rw * 16 * HP, tile = 2 * rw * 16 * TPF * 4;
+  return (halo > tile ? halo : tile) > one ? (halo > tile ? halo : tile) : one;
 }
 
+// The accumulators of a 2 RW x 16 pixel x 64 column tile (acc[i][j][e] = pixel 16 (RW wm + i) + 4 g + e, column 32 wn + 16 j + c)
+// -> row-major in LDS -> bias / activation / residual on 8-column groups -> fp16 stores of 16 bytes.
 template <int RW>
-__global__ void __launch_bounds__(256, 2) k_conv3x3_h16(ConvH16Args p) {
-  constexpr int AROWS = (2 * RW + 2) * 18;       // halo pixels of a 2 RW x 16 tile
-  constexpr int AN = AROWS * 4;                  // 16-byte slots per chunk (8 channels each)
-  constexpr int AIT = (AN + 255) / 256;
+__device__ __forceinline__ void h16_epilogue(const ConvH16Args& p, const f32x4 (&acc)[RW][2], unsigned char* smem, int tid, int wm,
+                                             int wn, int c, int g, int n0, int img, int y0, int x0) {
   constexpr int NPX = 2 * RW * 16;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int c = lane & 15, g = lane >> 4;
-  int t = sr_xcd_block((int)blockIdx.x, gridDim.x);
-  const int ncol = p.N >> 6;
-  const int n0 = (t % ncol) * 64; t /= ncol;
-  const int tx = t % p.tiles_x; t /= p.tiles_x;
-  const int ty = t % p.tiles_y;
-  const int img = t / p.tiles_y;
-  const int y0 = ty * (2 * RW), x0 = tx * 16;
-  const int nkc = p.K >> 5;
-
-  unsigned offA[AIT];
-  bool inA[AIT];
-#pragma unroll
-  for (int it = 0; it < AIT; ++it) {
-    const int idx = min(tid + it * 256, AN - 1);
-    const int row = idx >> 2, c8 = idx & 3;
-    const int hy = row / 18, hx = row - hy * 18;
-    const int y = y0 + hy - 1, x = x0 + hx - 1;
-    inA[it] = y >= 0 && y < p.H && x >= 0 && x < p.Wd && (AN % 256 == 0 || tid + it * 256 < AN);
-    const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.Wd - 1);
-    offA[it] = (unsigned)((((long)img * p.H + yc) * p.Wd + xc) * p.ldx + c8 * 8) * 2u;
-  }
-  // input prologue (MemNet's BN-ReLU-conv, network_memnet.py:27-34): relu((x - mean) k + beta) on the thread's eight
-  // channels of the chunk (256 % 4 == 0: the same group in every iteration), before the padding zeros go in
-  f32x4 bm[2], bk[2], bb[2];
-  auto load_a = [&](int kc, u32x4 (&ra)[AIT]) {
-    const char* base = (const char*)p.X + (long)kc * 64;
-#pragma unroll
-    for (int it = 0; it < AIT; ++it) ra[it] = *(const u32x4*)(base + offA[it]);
-    if (p.in_bn) {
-      const int ch = kc * 32 + (tid & 3) * 8;
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        bm[h2] = ldg_f4(p.in_bn + ch + 4 * h2);
-        bk[h2] = ldg_f4(p.in_bn + 2 * p.K + ch + 4 * h2);
-        bb[h2] = ldg_f4(p.in_bn + 3 * p.K + ch + 4 * h2);
-      }
-    }
-  };
-  auto store_a = [&](const u32x4 (&ra)[AIT]) {
-#pragma unroll
-    for (int it = 0; it < AIT; ++it) {
-      if (AN % 256 == 0 || tid + it * 256 < AN) {
-        const int idx = tid + it * 256;
-        u32x4 v = ra[it];
-        if (p.in_bn) {
-          h16x8 hv = __builtin_bit_cast(h16x8, v);
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            hv[e] = (_Float16)fmaxf(((float)hv[e] - bm[e >> 2][e & 3]) * bk[e >> 2][e & 3] + bb[e >> 2][e & 3], 0.f);
-          v = __builtin_bit_cast(u32x4, hv);
-        }
-        *(u32x4*)(smem + (idx >> 2) * HP + (idx & 3) * 16) = inA[it] ? v : u32x4{0u, 0u, 0u, 0u};
-      }
-    }
-  };
-  const long wrows = 9L * p.N;
-  unsigned boff[2];
-#pragma unroll
-  for (int jt = 0; jt < 2; ++jt) boff[jt] = (unsigned)(((g >> 1) * wrows + n0 + wn * 32 + jt * 16 + c) * 32 + (g & 1) * 16);
-  auto load_b = [&](int kc, int tap, u32x4 (&fb)[2]) {
-    const char* base = (const char*)p.Wb + ((long)(2 * kc) * wrows + (long)tap * p.N) * 32;
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) fb[jt] = *(const u32x4*)(base + boff[jt]);
-  };
-  f32x4 acc[RW][2];
-#pragma unroll
-  for (int i = 0; i < RW; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int a_off[RW];
-#pragma unroll
-  for (int i = 0; i < RW; ++i) a_off[i] = ((RW * wm + i) * 18 + c) * HP + 16 * g;
-
-  u32x4 ra[AIT];
-  load_a(0, ra);
-  u32x4 fb[9][2];
-  const bool one = p.center_only != 0;            // block-uniform
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-    if (!one || tap == 4) load_b(0, tap, fb[tap]);
-  for (int kc = 0; kc < nkc; ++kc) {
-    if (kc) __syncthreads();                      // every tap of the previous chunk has read the halo tile
-    store_a(ra);
-    __syncthreads();
-    if (kc + 1 < nkc) load_a(kc + 1, ra);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      if (one && tap != 4) continue;
-      const int toff = ((tap / 3) * 18 + (tap % 3)) * HP;
-#pragma unroll
-      for (int i = 0; i < RW; ++i) {
-        const u32x4 fa = *(const u32x4*)(smem + a_off[i] + toff);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa, fb[tap][j], acc[i][j]);
-      }
-      if (kc + 1 < nkc) load_b(kc + 1, tap, fb[tap]);
-    }
-  }
-
-  // ---- the tile row-major in LDS (pixel 16 * (tile row) + x, 64 columns), then 16-byte epilogue accesses
   __syncthreads();                                // the halo tile is dead from here on
   float* const T = (float*)smem;
 #pragma unroll
@@ -204,6 +101,228 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_h16(ConvH16Args p) {
       *(h16x8*)(p.Y + pix * p.ldy + col) = o;
     }
   }
+}
+
+template <int RW>
+__global__ void __launch_bounds__(256, 2) k_conv3x3_h16(ConvH16Args p) {
+  constexpr int AROWS = (2 * RW + 2) * 18;       // halo pixels of a 2 RW x 16 tile
+  constexpr int AN = AROWS * 4;                  // 16-byte slots per chunk (8 channels each)
+  constexpr int AIT = (AN + 255) / 256;
+  constexpr int NPX = 2 * RW * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = lane & 15, g = lane >> 4;
+  int t = sr_xcd_block((int)blockIdx.x, gridDim.x);
+  const int ncol = p.N >> 6;
+  const int n0 = (t % ncol) * 64; t /= ncol;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int img = t / p.tiles_y;
+  const int y0 = ty * (2 * RW), x0 = tx * 16;
+  const int nkc = p.K >> 5;
+
+  unsigned offA[AIT];
+  bool inA[AIT];
+#pragma unroll
+  for (int it = 0; it < AIT; ++it) {
+    const int idx = min(tid + it * 256, AN - 1);
+    const int row = idx >> 2, c8 = idx & 3;
+    const int hy = row / 18, hx = row - hy * 18;
+    const int y = y0 + hy - 1, x = x0 + hx - 1;
+    inA[it] = y >= 0 && y < p.H && x >= 0 && x < p.Wd && (AN % 256 == 0 || tid + it * 256 < AN);
+    const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.Wd - 1);
+    offA[it] = (unsigned)((((long)img * p.H + yc) * p.Wd + xc) * p.ldx + c8 * 8) * 2u;
+  }
+  // input prologue (MemNet's BN-ReLU-conv, network_memnet.py:27-34): relu((x - mean) k + beta) on the thread's eight
+  // channels of the chunk (256 % 4 == 0: the same group in every iteration), before the padding zeros go in
+  f32x4 bm[2], bk[2], bb[2];
+  auto load_a = [&](int kc, u32x4 (&ra)[AIT]) {
+    const char* base = (const char*)p.X + (long)kc * 64;
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) ra[it] = inA[it] ? *(const u32x4*)(base + offA[it]) : u32x4{0u, 0u, 0u, 0u};
+    if (p.in_bn) {
+      const int ch = kc * 32 + (tid & 3) * 8;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        bm[h2] = ldg_f4(p.in_bn + ch + 4 * h2);
+        bk[h2] = ldg_f4(p.in_bn + 2 * p.K + ch + 4 * h2);
+        bb[h2] = ldg_f4(p.in_bn + 3 * p.K + ch + 4 * h2);
+      }
+    }
+  };
+  auto store_a = [&](const u32x4 (&ra)[AIT]) {
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+      if (AN % 256 == 0 || tid + it * 256 < AN) {
+        const int idx = tid + it * 256;
+        u32x4 v = ra[it];
+        if (p.in_bn) {
+          h16x8 hv = __builtin_bit_cast(h16x8, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            hv[e] = (_Float16)fmaxf(((float)hv[e] - bm[e >> 2][e & 3]) * bk[e >> 2][e & 3] + bb[e >> 2][e & 3], 0.f);
+          v = __builtin_bit_cast(u32x4, hv);
+        }
+        *(u32x4*)(smem + (idx >> 2) * HP + (idx & 3) * 16) = inA[it] ? v : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  const long wrows = 9L * p.N;
+  unsigned boff[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) boff[jt] = (unsigned)(((g >> 1) * wrows + n0 + wn * 32 + jt * 16 + c) * 32 + (g & 1) * 16);
+  auto load_b = [&](int kc, int tap, u32x4 (&fb)[2]) {
+    const char* base = (const char*)p.Wb + ((long)(2 * kc) * wrows + (long)tap * p.N) * 32;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) fb[jt] = *(const u32x4*)(base + boff[jt]);
+  };
+  f32x4 acc[RW][2];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int a_off[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) a_off[i] = ((RW * wm + i) * 18 + c) * HP + 16 * g;
+
+  u32x4 ra[AIT];
+  load_a(0, ra);
+  u32x4 fb[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) load_b(0, tap, fb[tap]);
+  for (int kc = 0; kc < nkc; ++kc) {
+    if (kc) __syncthreads();                      // every tap of the previous chunk has read the halo tile
+    store_a(ra);
+    __syncthreads();
+    if (kc + 1 < nkc) load_a(kc + 1, ra);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = ((tap / 3) * 18 + (tap % 3)) * HP;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const u32x4 fa = *(const u32x4*)(smem + a_off[i] + toff);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa, fb[tap][j], acc[i][j]);
+      }
+      if (kc + 1 < nkc) load_b(kc + 1, tap, fb[tap]);
+    }
+  }
+
+  h16_epilogue<RW>(p, acc, smem, tid, wm, wn, c, g, n0, img, y0, x0);
+}
+
+// 1x1 conv (the weight's centre tap): no halo, so a stage is THREE 32-channel chunks of the tile's own pixels (one pair of
+// barriers per 96 channels instead of per 32: at one tap a chunk is 8 MFMAs per wave, the barriers were the loop).
+template <int RW>
+__global__ void __launch_bounds__(256, 2) k_conv1x1_h16(ConvH16Args p) {
+  constexpr int NPX = 2 * RW * 16;
+  constexpr int CPS = 3;                         // chunks per stage
+  constexpr int AN = NPX * 4;                    // 16-byte slots per chunk
+  constexpr int AIT = AN / 256;                  // 2 (RW = 4) or 1 (RW = 2)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = lane & 15, g = lane >> 4;
+  int t = sr_xcd_block((int)blockIdx.x, gridDim.x);
+  const int ncol = p.N >> 6;
+  const int n0 = (t % ncol) * 64; t /= ncol;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int img = t / p.tiles_y;
+  const int y0 = ty * (2 * RW), x0 = tx * 16;
+  const int nkc = p.K >> 5;
+  unsigned offA[AIT];
+  bool inA[AIT];
+#pragma unroll
+  for (int it = 0; it < AIT; ++it) {
+    const int idx = tid + it * 256;
+    const int px = idx >> 2, c8 = idx & 3;
+    const int y = y0 + (px >> 4), x = x0 + (px & 15);
+    inA[it] = y < p.H && x < p.Wd;
+    offA[it] = (unsigned)((((long)img * p.H + min(y, p.H - 1)) * p.Wd + min(x, p.Wd - 1)) * p.ldx + c8 * 8) * 2u;
+  }
+  f32x4 bm[CPS][2], bk[CPS][2], bb[CPS][2];
+  auto load_a = [&](int kc0, u32x4 (&ra)[CPS][AIT]) {
+#pragma unroll
+    for (int q = 0; q < CPS; ++q) {
+      const int kc = min(kc0 + q, nkc - 1);
+      const char* base = (const char*)p.X + (long)kc * 64;
+#pragma unroll
+      for (int it = 0; it < AIT; ++it) ra[q][it] = inA[it] ? *(const u32x4*)(base + offA[it]) : u32x4{0u, 0u, 0u, 0u};
+      if (p.in_bn) {
+        const int ch = kc * 32 + (tid & 3) * 8;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          bm[q][h2] = ldg_f4(p.in_bn + ch + 4 * h2);
+          bk[q][h2] = ldg_f4(p.in_bn + 2 * p.K + ch + 4 * h2);
+          bb[q][h2] = ldg_f4(p.in_bn + 3 * p.K + ch + 4 * h2);
+        }
+      }
+    }
+  };
+  auto store_a = [&](const u32x4 (&ra)[CPS][AIT]) {
+#pragma unroll
+    for (int q = 0; q < CPS; ++q)
+#pragma unroll
+      for (int it = 0; it < AIT; ++it) {
+        const int idx = tid + it * 256;
+        u32x4 v = ra[q][it];
+        if (p.in_bn) {
+          h16x8 hv = __builtin_bit_cast(h16x8, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            hv[e] = (_Float16)fmaxf(((float)hv[e] - bm[q][e >> 2][e & 3]) * bk[q][e >> 2][e & 3] + bb[q][e >> 2][e & 3], 0.f);
+          v = inA[it] ? __builtin_bit_cast(u32x4, hv) : u32x4{0u, 0u, 0u, 0u};
+        }
+        *(u32x4*)(smem + q * NPX * HP + (idx >> 2) * HP + (idx & 3) * 16) = v;
+      }
+  };
+  const long wrows = 9L * p.N;
+  unsigned boff[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) boff[jt] = (unsigned)(((g >> 1) * wrows + 4L * p.N + n0 + wn * 32 + jt * 16 + c) * 32 + (g & 1) * 16);
+  auto load_b = [&](int kc0, u32x4 (&fb)[CPS][2]) {
+#pragma unroll
+    for (int q = 0; q < CPS; ++q) {
+      const char* base = (const char*)p.Wb + (long)(2 * min(kc0 + q, nkc - 1)) * wrows * 32;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) fb[q][jt] = *(const u32x4*)(base + boff[jt]);
+    }
+  };
+  f32x4 acc[RW][2];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int a_off[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) a_off[i] = ((RW * wm + i) * 16 + c) * HP + 16 * g;
+  u32x4 ra[CPS][AIT];
+  u32x4 fb[CPS][2];
+  load_a(0, ra);
+  load_b(0, fb);
+  for (int kc0 = 0; kc0 < nkc; kc0 += CPS) {
+    if (kc0) __syncthreads();
+    store_a(ra);
+    __syncthreads();
+    if (kc0 + CPS < nkc) load_a(kc0 + CPS, ra);
+#pragma unroll
+    for (int q = 0; q < CPS; ++q) {
+      if (kc0 + q < nkc) {                          // block-uniform
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+          const u32x4 fa = *(const u32x4*)(smem + q * NPX * HP + a_off[i]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa, fb[q][j], acc[i][j]);
+        }
+      }
+    }
+    if (kc0 + CPS < nkc) load_b(kc0 + CPS, fb);
+  }
+  h16_epilogue<RW>(p, acc, smem, tid, wm, wn, c, g, n0, img, y0, x0);
 }
 
 // 1 -> Co conv (f32 image in, fp16 features out), act 0 none | 1 ReLU | 2 LeakyReLU(alpha).  A thread owns 8 output channels of one pixel.
@@ -303,7 +422,10 @@ int sr_conv3x3_h16(ConvH16Args& p, hipStream_t st) {
   p.tiles_x = sr_cdiv(p.Wd, 16);
   p.tiles_y = sr_cdiv(p.H, 2 * rw);
   dim3 grid((unsigned)((long)p.tiles_x * p.tiles_y * p.B * (p.N / 64)));
-  if (rw == 4) hipLaunchKernelGGL(k_conv3x3_h16<4>, grid, dim3(256), h16_lds(4), st, p);
+  if (p.center_only) {
+    if (rw == 4) hipLaunchKernelGGL(k_conv1x1_h16<4>, grid, dim3(256), h16_lds(4), st, p);
+    else hipLaunchKernelGGL(k_conv1x1_h16<2>, grid, dim3(256), h16_lds(2), st, p);
+  } else if (rw == 4) hipLaunchKernelGGL(k_conv3x3_h16<4>, grid, dim3(256), h16_lds(4), st, p);
   else hipLaunchKernelGGL(k_conv3x3_h16<2>, grid, dim3(256), h16_lds(2), st, p);
   SR_LAUNCH_CHECK("k_conv3x3_h16");
   return 0;

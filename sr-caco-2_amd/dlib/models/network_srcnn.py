@@ -26,7 +26,10 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, need_grad, *params):
         ctx.net = net
-        y = net.engine.forward(x, None, save=need_grad)
+        # --amp (inference only; training stays f32-accurate): fp16 storage of the 1024-channel feature map, one product
+        from srhip import ops
+        with ops.amp_inference(getattr(net, "amp", False) and not need_grad):
+            y = net.engine.forward(x, None, save=need_grad)
         return y.clone() if need_grad else y
 
     @staticmethod

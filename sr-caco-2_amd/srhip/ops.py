@@ -178,7 +178,7 @@ class PrepTable:
                   s1=1 if transpose else K, s2=K if transpose else 1, off=0,
                   mode=0 if gamma is None else (2 if transpose else 1))
 
-    def conv(self, w, out, data_grad=False, ps2=False):
+    def conv(self, w, out, data_grad=False, ps2=False, force_f16=False):
         """planes of the tap-major pack [9][Co][Ci] of a conv weight [Co,Ci,3,3], or of the
         flipped / transposed twin [9][Ci][Co] used by the data gradient.  ps2: the conv feeds a
         PixelShuffle(2) fused into the kernel (conv3x3_ps2*): its output channels in sub-pixel-major
@@ -195,6 +195,9 @@ class PrepTable:
             f16 = True              # SwinIR's 180-column convs: k_nhcw (64-pixel x 192-column tiles); SRHIP_F16X2_CONV180=0: k_ntcw
         if not F16X2_CONV_WIDE:     # SRHIP_F16X2_CONV_WIDE=0: only the 64-column convs without a fused PixelShuffle
             f16 = f16 and rows == 64 and not ps2
+        if force_f16:               # operands of the fp16-storage kernels (conv_h16.hip) whatever the f32-grade kernel would take
+            assert rows % 64 == 0 and kd % 32 == 0 and rows <= 4096 and kd <= 4096
+            f16 = True
         out.fmt = 1 if f16 else 0
         kind = 4 if f16 else 0
         if data_grad:   # out[t][ci][co] = w[co][ci][8 - t]
