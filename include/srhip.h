@@ -156,7 +156,8 @@ int srhip_conv3x3_nhwc_f16x2(const float* X, long ldx, const void* Wh, const flo
  *          expression of srhip_bn_apply; wfmt 1, Cout a multiple of 64, <= 4096
  *   epi 8: relu(R + s*(acc+bias))                    DRRN's residual unit (network_drrn.py:58-62)
  *   epi 9: prelu(acc+bias), slope = *slope (device)  DBPN's ConvBlock / DeconvBlock activation (network_dbpn.py:16-60)
- *   epi 10: prelu(acc+bias) + alpha * R              ... and the projection units' l0 - x / h1 + h0 (:93-99,128-134) */
+ *   epi 10: prelu(acc+bias) + alpha * R              ... and the projection units' l0 - x / h1 + h0 (:93-99,128-134)
+ *   epi 11: gelu(acc+bias), exact erf                DFCAN's conv + nn.GELU() (network_dfcan.py:44-47,98-99) */
 int srhip_conv3x3_nhwc_split_ex(int wfmt, const float* X, long ldx, const void* Wp, const float* bias, float* Y, long ldy,
                                 int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                                 const float* rowscale, float alpha, const float* in_bn_coef, const float* slope,

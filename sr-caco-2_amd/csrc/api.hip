@@ -259,7 +259,7 @@ static int conv3x3_split(int wfmt, const float* X, long ldx, const void* Wb, con
                            int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                            const float* rowscale, float alpha, void* stream, const float* in_bn_coef = nullptr,
                            const float* slope = nullptr) {
-  SR_REQUIRE(epi >= 0 && epi <= 10 && epi != 3 && epi != 5, "conv3x3_bx3: epi %d", epi);
+  SR_REQUIRE(epi >= 0 && epi <= 11 && epi != 3 && epi != 5, "conv3x3_bx3: epi %d", epi);
   SR_REQUIRE((epi != 4 && epi != 7 && epi != 8 && epi != 10) || R, "conv3x3_bx3: epilogue %d needs R", epi);
   SR_REQUIRE((epi != 9 && epi != 10) || (slope && !rowscale), "conv3x3_bx3: epilogue %d takes the PReLU slope (and no row scale)", epi);
   SR_REQUIRE(!in_bn_coef || (wfmt == 1 && Cout <= 4096 && Cout % 64 == 0 && Cin % 4 == 0),

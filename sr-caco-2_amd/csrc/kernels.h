@@ -17,6 +17,7 @@ struct NtArgs {
   const float* ln_stats;      // [M][2] = mean, rstd
   int epi;                    // 0 +bias | 1 relu | 2 R + s*(acc+bias) | 3 s*acc*gelu'(R) | 4 acc*(R>0) | 6 leaky relu(alpha) | 7 acc*(R>0 ? 1 : alpha)
                               // | 8 relu(R + s*(acc+bias)) | 9 prelu(acc+bias; *slope) | 10 prelu(acc+bias; *slope) + alpha*R
+                              // | 11 gelu(acc+bias) (exact erf)
   const float* slope;         // epi 9 / 10: the PReLU's one learnable slope, on the device
   const float* pro_coef;      // conv (k_nhcw2): BatchNorm (evaluation) + ReLU on the INPUT, coef [4][K] = mean, rstd, gamma*rstd, beta
   const float* R; long ldr;

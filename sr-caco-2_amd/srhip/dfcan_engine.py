@@ -30,8 +30,8 @@ class DFCANEngine(TapeEngine):
             for r in range(4):
                 m = net.RGs[g].RCABs[r]
                 pre = f"RGs.{g}.RCABs.{r}"
-                a = t.unary(t.conv(x, f"{pre}.conv_gelu1", (f"{pre}.conv_gelu1.0.weight", f"{pre}.conv_gelu1.0.bias")), "gelu")
-                b = t.unary(t.conv(a, f"{pre}.conv_gelu2", (f"{pre}.conv_gelu2.0.weight", f"{pre}.conv_gelu2.0.bias")), "gelu")
+                a = t.conv(x, f"{pre}.conv_gelu1", (f"{pre}.conv_gelu1.0.weight", f"{pre}.conv_gelu1.0.bias"), gelu=True)
+                b = t.conv(a, f"{pre}.conv_gelu2", (f"{pre}.conv_gelu2.0.weight", f"{pre}.conv_gelu2.0.bias"), gelu=True)
                 w1, w2 = m.conv_relu2[0].weight, m.conv_sigmoid[0].weight
                 x = t.fourier_gate(x, b, f"{pre}.conv_relu1", (f"{pre}.conv_relu1.0.weight", f"{pre}.conv_relu1.0.bias"),
                                    w1.data.reshape(w1.shape[0], w1.shape[1]).contiguous(), m.conv_relu2[0].bias.data,

@@ -764,7 +764,7 @@ def conv3x3(X, Wp, bias, Cout, out=None, epi=0, R=None, rowscale=None, alpha=1.0
             B, H, W, Cin, Cout, epi, _p(R), 0 if R is None else R.stride(2), _p(rowscale),
             float(alpha), _st())
     name = ("srhip_conv3x3_nhwc_f16x2" if Wp.fmt == 1 else "srhip_conv3x3_nhwc_bx3") if bx else "srhip_conv3x3_nhwc"
-    if in_bn is not None or slope is not None or epi >= 8:
+    if in_bn is not None or slope is not None or epi >= 8:     # epi 8-11
         assert bx, "conv3x3: prologue / epilogues 8-10 run on the split-operand kernels"
         assert in_bn is None or (Wp.fmt == 1 and tuple(in_bn.shape) == (4, Cin) and in_bn.is_contiguous())
         name = "srhip_conv3x3_nhwc_split_ex"

@@ -286,12 +286,14 @@ class Tape:
             ops.axpby(gt, tmp, 1.0, 1.0)
 
     # ---- ops
-    def conv(self, x, key, names, act=None, prelu=None, add=None, relu=False, res=None):
+    def conv(self, x, key, names, act=None, prelu=None, add=None, relu=False, res=None, gelu=False):
         """x -> conv (bank entry `key`) [-> PixelShuffle / after PixelUnshuffle for the strided forms].
         names = (weight parameter name, bias parameter name or None).
         relu / res = (Var, factor) (plain 3x3 convs): out = relu(conv(x)) / out = Var + factor * conv(x) as the conv's
         epilogue in both modes (the ResBlock of the EDSR-body nets, network_nlsn.py:72-98: two launches instead of six); the
         backward masks / scales the incoming gradient in place before the conv's own.
+        gelu: nn.GELU() behind the conv -- its epilogue in evaluation mode (epi 11), the separate op with the tape recording
+        (the backward needs the pre-activation).
         prelu = (slope parameter, its name), add = (Var, factor): out = prelu(conv(x)) + factor * Var (DBPN's projection
         units).  In evaluation mode both ride in the 3x3 conv's epilogue (srhip_conv3x3_nhwc_split_ex epi 9 / 10; the
         addend of a transposed conv is added behind its PixelShuffle); with the tape recording they are the ordinary ops."""
@@ -318,6 +320,8 @@ class Tape:
                 ops.gemm_nt(xin[b0:b1].view(-1, Ci), e.w1, e.bias, out=y[b0:b1].view(-1, e.Co))
             elif relu:
                 ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1], epi=1)
+            elif gelu and not self.save and e.kind == "c3" and e.use_planes:
+                ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1], epi=11)
             elif res is not None:
                 ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1], epi=2, R=rres[b0:b1], alpha=float(res[1]))
             elif fuse_add:
@@ -396,6 +400,8 @@ class Tape:
             out = self.shuffle(out, e.s)
         if act is not None:
             out = act(out)
+        if gelu and not (not self.save and e.kind == "c3" and e.use_planes):
+            out = self.unary(out, "gelu")
         if prelu is not None and not fuse:
             out = self.prelu(out, prelu[0], prelu[1])
         if add is not None and not fuse_add:
