@@ -124,6 +124,7 @@ struct WmsaF16Args {
   int B, H, W, C, heads, shift, Kp;
   float scale;
   long long* dbg;                    // experiment builds: phase timestamps
+  int stagger;                       // experiment builds: start delay of a block's second window (10-ns units)
 };
 int sr_wmsa_f16(WmsaF16Args& p, hipStream_t st);
 

@@ -435,6 +435,12 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
   const long planeq = (long)N3 * p.Kp * 2, planep = (long)C * p.Kp * 2;
   const float* const winvq = (const float*)((const char*)p.Wqkv + 2 * planeq);
   const float* const winvp = (const float*)((const char*)p.Wproj + 2 * planep);
+#ifdef SRHIP_EXPERIMENTS
+  if (p.stagger > 0 && grp == 1) {                   // experiment: the block's second window starts late
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < p.stagger) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   SR_TS(0)
   // ---------------- phase 1: x rows of the window -> LayerNorm -> stage images (the first four waves: four lanes per row)
   {
@@ -908,6 +914,7 @@ int sr_wmsa_f16(WmsaF16Args& p, hipStream_t st) {
   p.Kp = sr_kp(p.C);
 #ifdef SRHIP_EXPERIMENTS
   p.dbg = g_wmsa_dbg;
+  { const char* e = sr_getenv("SRHIP_WMSA_STAGGER"); p.stagger = e ? atoi(e) : 0; }
 #endif
   p.scale = 1.0f / sqrtf((float)D);
   const int nwin = p.B * (p.H / 8) * (p.W / 8);
