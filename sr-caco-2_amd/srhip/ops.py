@@ -65,7 +65,9 @@ F16X2_CONV_MAX = int(_os.environ.get("SRHIP_F16X2_CONV_MAX", "4096"))
 # The NT side (conv / Linear forward and data gradient) has its own threshold: at 64 -> 64 channels, B=8, 128x128
 # (tools/mb_conv64.py) the conv goes 108.8 -> 65.5 us on the bf16x3 kernel; the weight-gradient side only caught
 # up (186 -> 148 us) after its plan for 64-wide tiles changed -- with the plan of the wide tiles it was slower (212 us).
-BX3_MIN_CHANNELS_NT = int(_os.environ.get("SRHIP_BX3_MIN_CH_NT", "64"))
+# Round 4: 32 -- ProSR's DenseNet convs (40- / 80-channel growth) ran on the exact-f32 kernel under 64: same box, x8 / x4 / x2
+# evaluation 64.7 -> 53.8 / 112.8 -> 90.1 / 173.1 -> 135.3 ms per batch on the split kernels; 16 changes nothing further.
+BX3_MIN_CHANNELS_NT = int(_os.environ.get("SRHIP_BX3_MIN_CH_NT", "32"))
 
 
 def bx3_nt_for(*channels):
