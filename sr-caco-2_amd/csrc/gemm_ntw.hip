@@ -976,6 +976,96 @@ __global__ void __launch_bounds__(256, 2) k_ntcw2(NtArgs p) {
   nt_epilogue<RW / 2, 1, true>(p, acc2, lane, wm, wn, n0, nvalid, 0, img, y0, x0);
 }
 
+// 16-byte epilogue of the 64-column conv kernels (k_nhcw2): the 2 RW x 16 pixel x 64 column tile row-major in LDS (pitch
+// W_TP), a thread owns 8 consecutive columns of a pixel per pass -- the residual / mask operand comes as two 16-byte loads,
+// the result leaves as two 16-byte stores.  The generic nt_epilogue moves single floats (a lane holds one column of 16 rows):
+// 4.3 us of a 23-us block on 256 x 256 images.  Same arithmetic per element, in the same order (nt_epi.h); needs N % 8 == 0
+// and 16-byte aligned C / R rows (the dispatcher decides: NtArgs.wide_epi).
+constexpr int W_TP = 68;
+template <int RW>
+__device__ __forceinline__ void nhcw2_epilogue_wide(const NtArgs& p, const float* T, int tid, int n0, int nvalid, int img, int y0,
+                                                    int x0) {
+  constexpr int NPX = 2 * RW * 16;
+  float blk_s = p.alpha;
+  if (p.rowscale) blk_s *= p.rowscale[img];
+  const bool prelu = p.epi == 9 || p.epi == 10;
+  const float slope = prelu ? ldg_f(p.slope) : 0.f;
+  if (prelu) blk_s = 1.f;
+  const bool needR = p.R != nullptr && p.epi >= 2 && p.epi != 9 && p.epi != 11;
+  const bool shuf = p.ps == 1;
+  const int fs = p.N >> 2;
+#pragma unroll
+  for (int it = 0; it < (NPX * 8) / 256; ++it) {
+    const int idx = tid + it * 256;
+    const int px = idx >> 3, c8 = (idx & 7) * 8;
+    const int y = y0 + (px >> 4), x = x0 + (px & 15);
+    if (y >= p.H || x >= p.Wd || c8 >= nvalid) continue;
+    const int gn = n0 + c8;
+    const int sp = shuf ? gn / fs : 0, cc = shuf ? gn - sp * fs : gn;
+    const long grow = ((long)img * p.H + y) * p.Wd + x;
+    f32x4 v0 = *(const f32x4*)(T + px * W_TP + c8), v1 = *(const f32x4*)(T + px * W_TP + c8 + 4);
+    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
+    if (needR) { r0 = ldg_f4(p.R + grow * p.ldr + gn); r1 = ldg_f4(p.R + grow * p.ldr + gn + 4); }
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    const float rv[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+    if (p.bias) {
+      if (shuf) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += p.bias[(cc + e) * 4 + sp];
+      } else {
+        const f32x4 b0 = ldg_f4(p.bias + gn), b1 = ldg_f4(p.bias + gn + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+      }
+    }
+    switch (p.epi) {
+      case 1:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        break;
+      case 2:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * blk_s + rv[e];
+        break;
+      case 4:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rv[e] > 0.f ? v[e] : 0.f;
+        break;
+      case 6:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.alpha;
+        break;
+      case 7:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rv[e] > 0.f ? v[e] : v[e] * p.alpha;
+        break;
+      case 8:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * blk_s + rv[e], 0.f);
+        break;
+      case 9:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+        break;
+      case 10:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] > 0.f ? v[e] : slope * v[e]) + p.alpha * rv[e];
+        break;
+      case 11:
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        break;
+      default:
+        break;
+    }
+    float* dst;
+    if (shuf) dst = p.C + (((long)img * 2 * p.H + 2 * y + (sp >> 1)) * (2 * p.Wd) + 2 * x + (sp & 1)) * p.ldc + cc;
+    else dst = p.C + grow * p.ldc + gn;
+    *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+    *(f32x4*)(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+}
+
 // k_nhcw2 (experiment, SRHIP_F16X2_CONV=1; weight planes of prep kind 4): k_ntcw2 on TWO fp16 planes and three products.
 // The accumulator of an output pixel mixes nine neighbouring pixels, so the activation's block exponent is ONE power
 // of two per halo tile (all channels), kept as a running scale over the channel chunks exactly as k_nth2 does per row:
@@ -991,7 +1081,12 @@ __device__ long long* g_nhcw2_dbg = nullptr;
 #define SR_TSC(K)
 #endif
 template <int RW, bool AMP>
-__global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
+// three blocks per CU (166 VGPRs at RW = 4, no spill; 43 KB of LDS each): same box, against two -- the 64 -> 64 conv at 8 x 256 x 256
+// 152.4 -> 142.4 us, EDSR x8 training step 4.72 -> 4.65 ms, VDSR / DRRN evaluation 9.23 -> 8.75 / 88.8 -> 81.8 ms per batch
+#ifndef SR_NHCW2_OCC
+#define SR_NHCW2_OCC 3
+#endif
+__global__ void __launch_bounds__(256, SR_NHCW2_OCC) k_nhcw2(NtArgs p) {
   constexpr int NPL = AMP ? 1 : 2;
   constexpr int D_AROWS = (2 * RW + 2) * 18;       // halo pixels of a 2 RW x 16 tile
   constexpr int D_APLANE = D_AROWS * C_PITCH;
@@ -1176,6 +1271,23 @@ __global__ void __launch_bounds__(256, 2) k_nhcw2(NtArgs p) {
   }
   const float tinv = 1.0f / (cur > 1.0e38f ? 1.f : cur);
 
+  if (p.wide_epi) {                                  // block-uniform (set by the dispatcher): 16-byte epilogue accesses
+    __syncthreads();                                 // the halo tile is dead from here on
+    SR_TSC(10)
+    float* const Tw = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          Tw[(16 * (RW * wm + i) + 4 * g + e) * W_TP + 32 * wn + 16 * j + c] = acc[i][j][e] * (tinv * winv[j]);
+    __syncthreads();
+    SR_TSC(11)
+    nhcw2_epilogue_wide<RW>(p, Tw, tid, n0, nvalid, img, y0, x0);
+    SR_TSC(12)
+    return;
+  }
   // ---- re-layout inside the wave: 4 x 2 tiles of 16 x 16 -> 2 x 1 tiles of 32 x 32 (tile row 16*y + x of the wave's 4 image rows)
   __syncthreads();                                   // the halo tile is dead from here on
   SR_TSC(10)
@@ -1224,6 +1336,12 @@ int sr_conv3x3_ntcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
 }
 
 int sr_conv3x3_nhcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
+  static_assert(ntcw2_lds(4) >= 128 * W_TP * 4 && ntcw2_lds(2) >= 64 * W_TP * 4, "LDS: the row-major output tile");
+  {
+    const auto al4 = [](const void* q, long ld) { return !q || (((size_t)q & 15) == 0 && ld % 4 == 0); };
+    p.wide_epi = p.N % 8 == 0 && al4(p.C, p.ldc) && al4(p.R, p.ldr) && al4(p.bias, 4) && (p.ps != 1 || (p.N >> 2) % 8 == 0) &&
+                 sr_getenv("SRHIP_NHCW2_WIDE_OFF") == nullptr;
+  }
   dim3 grid(p.tiles_x * p.tiles_y * p.batch * sr_cdiv(p.N, p.n_tile));
   const bool amp = p.amp != 0;
   const int lds = ntcw2_lds(rows_per_wave) + 64;       // + the four wave maxima behind the (three-plane sized) halo region
