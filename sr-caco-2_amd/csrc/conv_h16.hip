@@ -104,7 +104,7 @@ __device__ __forceinline__ void h16_epilogue(const ConvH16Args& p, const f32x4 (
 }
 
 template <int RW>
-__global__ void __launch_bounds__(256, 2) k_conv3x3_h16(ConvH16Args p) {
+__global__ void __launch_bounds__(256, 3) k_conv3x3_h16(ConvH16Args p) {
   constexpr int AROWS = (2 * RW + 2) * 18;       // halo pixels of a 2 RW x 16 tile
   constexpr int AN = AROWS * 4;                  // 16-byte slots per chunk (8 channels each)
   constexpr int AIT = (AN + 255) / 256;
@@ -142,7 +142,9 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_h16(ConvH16Args p) {
     const char* base = (const char*)p.X + (long)kc * 64;
 #pragma unroll
     for (int it = 0; it < AIT; ++it) ra[it] = inA[it] ? *(const u32x4*)(base + offA[it]) : u32x4{0u, 0u, 0u, 0u};
-    if (p.in_bn) {
+  };
+  auto store_a = [&](const u32x4 (&ra)[AIT], int kc) {
+    if (p.in_bn) {                                // (L1 / L2 hits: every block reads the same 3 x 32 floats per chunk)
       const int ch = kc * 32 + (tid & 3) * 8;
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
@@ -151,8 +153,6 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_h16(ConvH16Args p) {
         bb[h2] = ldg_f4(p.in_bn + 3 * p.K + ch + 4 * h2);
       }
     }
-  };
-  auto store_a = [&](const u32x4 (&ra)[AIT]) {
 #pragma unroll
     for (int it = 0; it < AIT; ++it) {
       if (AN % 256 == 0 || tid + it * 256 < AN) {
@@ -189,24 +189,32 @@ __global__ void __launch_bounds__(256, 2) k_conv3x3_h16(ConvH16Args p) {
 
   u32x4 ra[AIT];
   load_a(0, ra);
-  u32x4 fb[9][2];
+  // weight fragments three taps ahead, in three register sets (a whole chunk ahead took 72 registers: two blocks per CU;
+  // with 24 the kernel fits three)
+  u32x4 fb0[2], fb1[2], fb2[2];
+  const int niter = nkc * 9;
+  auto load_it = [&](int it, u32x4 (&fb)[2]) { load_b(it / 9, it % 9, fb); };
+  auto mma = [&](int tap, const u32x4 (&fb)[2]) {
+    const int toff = ((tap / 3) * 18 + (tap % 3)) * HP;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) load_b(0, tap, fb[tap]);
+    for (int i = 0; i < RW; ++i) {
+      const u32x4 fa = *(const u32x4*)(smem + a_off[i] + toff);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa, fb[j], acc[i][j]);
+    }
+  };
+  load_it(0, fb0); load_it(1, fb1); load_it(2, fb2);
   for (int kc = 0; kc < nkc; ++kc) {
     if (kc) __syncthreads();                      // every tap of the previous chunk has read the halo tile
-    store_a(ra);
+    store_a(ra, kc);
     __syncthreads();
     if (kc + 1 < nkc) load_a(kc + 1, ra);
+    const int it = kc * 9;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int toff = ((tap / 3) * 18 + (tap % 3)) * HP;
-#pragma unroll
-      for (int i = 0; i < RW; ++i) {
-        const u32x4 fa = *(const u32x4*)(smem + a_off[i] + toff);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa, fb[tap][j], acc[i][j]);
-      }
-      if (kc + 1 < nkc) load_b(kc + 1, tap, fb[tap]);
+    for (int t3 = 0; t3 < 9; t3 += 3) {
+      mma(t3, fb0);     if (it + t3 + 3 < niter) load_it(it + t3 + 3, fb0);
+      mma(t3 + 1, fb1); if (it + t3 + 4 < niter) load_it(it + t3 + 4, fb1);
+      mma(t3 + 2, fb2); if (it + t3 + 5 < niter) load_it(it + t3 + 5, fb2);
     }
   }
 
