@@ -262,6 +262,8 @@ static int conv3x3_split(int wfmt, const float* X, long ldx, const void* Wb, con
   SR_REQUIRE(epi >= 0 && epi <= 11 && epi != 3 && epi != 5, "conv3x3_bx3: epi %d", epi);
   SR_REQUIRE((epi != 4 && epi != 7 && epi != 8 && epi != 10) || R, "conv3x3_bx3: epilogue %d needs R", epi);
   SR_REQUIRE((epi != 9 && epi != 10) || (slope && !rowscale), "conv3x3_bx3: epilogue %d takes the PReLU slope (and no row scale)", epi);
+  SR_REQUIRE(epi != 11 || (wfmt == 1 && Cout <= 4096 && Cout % 64 == 0 && Cin <= 4096),
+             "conv3x3: the GELU epilogue runs on the 64-column fp16x2 kernel (Cout = %d a multiple of 64)", Cout);
   SR_REQUIRE(!in_bn_coef || (wfmt == 1 && Cout <= 4096 && Cout % 64 == 0 && Cin % 4 == 0),
              "conv3x3: the BatchNorm-ReLU input prologue runs on the 64-column fp16x2 kernel (Cout = %d a multiple of 64, <= 4096)", Cout);
   NtArgs p;

@@ -1342,6 +1342,7 @@ int sr_conv3x3_nhcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
     p.wide_epi = p.N % 8 == 0 && al4(p.C, p.ldc) && al4(p.R, p.ldr) && al4(p.bias, 4) && (p.ps != 1 || (p.N >> 2) % 8 == 0) &&
                  sr_getenv("SRHIP_NHCW2_WIDE_OFF") == nullptr;
   }
+  SR_REQUIRE(p.epi != 11 || p.wide_epi, "conv3x3: the GELU epilogue needs Cout %% 8 == 0 and 16-byte aligned rows (Cout=%d)", p.N);
   dim3 grid(p.tiles_x * p.tiles_y * p.batch * sr_cdiv(p.N, p.n_tile));
   const bool amp = p.amp != 0;
   const int lds = ntcw2_lds(rows_per_wave) + 64;       // + the four wave maxima behind the (three-plane sized) halo region

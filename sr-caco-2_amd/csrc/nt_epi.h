@@ -221,10 +221,8 @@ __device__ __forceinline__ void nt_epilogue(const NtArgs& p, f32x16 (&acc)[WM][W
 #pragma unroll
           for (int q = 0; q < 16; ++q) v[q] = v[q] > 0.f ? v[q] : slope * v[q];
           break;
-        case 11:           // nn.GELU(), exact erf (network_dfcan.py:44-47)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) v[q] = gelu_f(v[q]);
-          break;
+        // (epilogue 11, nn.GELU(), lives in the 64-column conv kernel's own 16-byte epilogue only -- gemm_ntw.hip: erff in this
+        // shared one put 448 bytes of scratch into the widest exact-f32 tiles)
         case 10:           // PReLU, then + alpha * R (the projection units' l0 - x / h1 + h0)
 #pragma unroll
           for (int q = 0; q < 16; ++q) v[q] = (v[q] > 0.f ? v[q] : slope * v[q]) + p.alpha * rv[q];

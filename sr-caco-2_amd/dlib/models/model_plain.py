@@ -180,13 +180,20 @@ class ModelPlain:
     # of a key runs eagerly (it creates the engine's buffers), the second is captured, later ones replay.  Any change of
     # the weights (a training step, a checkpoint load) drops the graphs: derived weight copies are made outside them.
     def _eval_graph_on(self):
-        return bool(getattr(self.args, 'eval_graph', False)) or os.environ.get('SRHIP_EVAL_GRAPH', '0') == '1'
+        env = os.environ.get('SRHIP_EVAL_GRAPH', '')
+        if env == '0':
+            return False
+        # a network whose forward is launch-bound at the sweep's sizes asks for the replay itself (OmniSR: ~1100 launches,
+        # 16 ms of kernels in 20 ms of forward)
+        return bool(getattr(self.args, 'eval_graph', False)) or env == '1' or bool(getattr(self.netG, 'eval_graph_default', False))
 
     def _graph_forward(self, x):
         key = (tuple(x.shape), bool(getattr(self.netG, 'amp', False)), self._weights_version)
         st = self._eval_graphs.get(key)
         if st is None:
             self._eval_graphs = {k: v for k, v in self._eval_graphs.items() if k[2] == self._weights_version}
+            if len(self._eval_graphs) >= 8:        # many input shapes (whole images of a test set): no more graphs, eager
+                return self.netG(x)
             self._eval_graphs[key] = {"g": None, "x": x.clone(), "y": None}
             return self.netG(x)
         st["x"].copy_(x)

@@ -113,6 +113,7 @@ class _OSAG(nn.Module):                                           # :495-524
 
 class OmniSR(TapeNet):
     amp_takes_effect = False      # every contraction of this net runs on the exact-f32 kernels: --amp changes nothing
+    eval_graph_default = True     # ModelPlain.test() replays the evaluation forward from a hipGraph (SRHIP_EVAL_GRAPH=0: eager)
     def __init__(self, input_shape: int = 3, upscale: int = 2, num_feat: int = 64, res_num: int = 5, bias: bool = True,
                  window_size: int = 8, block_num: int = 4, pe: bool = True, ffn_bias: bool = True):
         super().__init__()

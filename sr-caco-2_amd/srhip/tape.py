@@ -320,7 +320,7 @@ class Tape:
                 ops.gemm_nt(xin[b0:b1].view(-1, Ci), e.w1, e.bias, out=y[b0:b1].view(-1, e.Co))
             elif relu:
                 ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1], epi=1)
-            elif gelu and not self.save and e.kind == "c3" and e.use_planes:
+            elif gelu and not self.save and e.kind == "c3" and e.use_planes and e.wp.fmt == 1 and e.Co % 64 == 0:
                 ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1], epi=11)
             elif res is not None:
                 ops.conv3x3(xin[b0:b1], e.wp, e.bias, e.Co, out=y[b0:b1], epi=2, R=rres[b0:b1], alpha=float(res[1]))
@@ -400,7 +400,7 @@ class Tape:
             out = self.shuffle(out, e.s)
         if act is not None:
             out = act(out)
-        if gelu and not (not self.save and e.kind == "c3" and e.use_planes):
+        if gelu and not (not self.save and e.kind == "c3" and e.use_planes and e.wp.fmt == 1 and e.Co % 64 == 0):
             out = self.unary(out, "gelu")
         if prelu is not None and not fuse:
             out = self.prelu(out, prelu[0], prelu[1])
