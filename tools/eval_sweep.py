@@ -30,7 +30,15 @@ def roofline_of(model, forward_ms, amp_used):
     the forward it is.  The events serialise nothing but add ~10 us per launch: shares are of the UNPROBED forward time."""
     from srhip import probe
     probe.enable(probe.ALL_KINDS)
-    model.test()
+    prev = os.environ.get("SRHIP_EVAL_GRAPH")
+    os.environ["SRHIP_EVAL_GRAPH"] = "0"          # the probed forward runs eagerly (a graph replay makes no Python-side launches)
+    try:
+        model.test()
+    finally:
+        if prev is None:
+            os.environ.pop("SRHIP_EVAL_GRAPH", None)
+        else:
+            os.environ["SRHIP_EVAL_GRAPH"] = prev
     r = probe.collect()
     probe.disable()
     if r is None:
