@@ -333,6 +333,133 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_h16(ConvH16Args p) {
   h16_epilogue<RW>(p, acc, smem, tid, wm, wn, c, g, n0, img, y0, x0);
 }
 
+// SRCNN under --amp, all three layers in ONE kernel (network_srcnn.py:23-69: features 5x5 1 -> 1024 + ReLU as its 32-wide patch
+// matrix, map 1x1 1024 -> 128 + ReLU, reconstruction 1x1 128 -> 1): a block owns 128 pixels and walks the 1024 hidden channels
+// in 16 chunks of 64 -- layer 1 of a chunk TRANSPOSED (weights on the MFMA's row side, so that a lane ends with four consecutive
+// hidden units of one pixel: half an 8-k unit of layer 2's A operand, one 8-byte LDS write), bias + ReLU + fp16 in registers,
+// layer 2 accumulating over the chunks from a double-buffered stage image; the 128-wide result meets its 128 -> 1 dot product
+// in the epilogue.  The 1024-channel map (8.6 GB at B = 8, 512 x 512 in f32, written and read back by the layer-wise path)
+// never exists.  Weights: the centre taps of the fp16x2 conv operands srhip_prep_table builds (leading plane).
+struct SrcnnH16Args {
+  const _Float16* A0;                // [T][32] patch matrix (25 taps + 7 zeros)
+  const unsigned short* W1; long plane1; const float* b1;     // planes of [1024][32] at tap 4 of a [9*1024] row set
+  const unsigned short* W2; long plane2; const float* b2;     // planes of [128][1024] at tap 4 of a [9*128] row set
+  const float* w3; const float* b3;  // [128], [1]
+  float* y;                          // [T]
+  long T;
+};
+constexpr int SC_N1 = 1024, SC_N2 = 128, SC_NPX = 128;
+constexpr int SC_LDS = SC_NPX * HP + 2 * 2 * SC_NPX * HP + 2 * SC_NPX * 4;      // A0 image + two h1 images (2 sub-chunks each) + row sums
+
+__global__ void __launch_bounds__(256, 3) k_srcnn_h16(SrcnnH16Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const a0img = smem;
+  unsigned char* const h1img = smem + SC_NPX * HP;                 // [buf][sub][px][HP]
+  float* const rsum = (float*)(h1img + 4 * SC_NPX * HP);           // [2 column halves][128 pixels]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = lane & 15, g = lane >> 4;
+  const long t0 = (long)blockIdx.x * SC_NPX;
+  // ---- the block's 128 rows of the patch matrix: 512 16-byte slots
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + it * 256, px = idx >> 2, c8 = idx & 3;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (t0 + px < p.T) v = *(const u32x4*)((const char*)p.A0 + ((t0 + px) * 32 + c8 * 8) * 2);
+    *(u32x4*)(a0img + px * HP + c8 * 16) = v;
+  }
+  const float* const winv1 = (const float*)((const char*)p.W1 + 2 * p.plane1);
+  const float* const winv2 = (const float*)((const char*)p.W2 + 2 * p.plane2);
+  const long wrows1 = 9L * SC_N1, wrows2 = 9L * SC_N2;
+  // layer 1, transposed: A = weight rows (hidden units 64 hc + 32 wn + 16 j + c), B = pixel rows 16 (4 wm + i) + c
+  auto load_w1 = [&](int hc, u32x4 (&f)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      f[j] = *(const u32x4*)((const char*)p.W1 + ((long)(g >> 1) * wrows1 + 4L * SC_N1 + 64 * hc + 32 * wn + 16 * j + c) * 32 + (g & 1) * 16);
+  };
+  // layer 2: B = weight rows (outputs 64 wn + 16 j2 + c), k = hidden units 64 hc + 32 s + 8 g ..
+  auto load_w2 = [&](int hc, u32x4 (&f)[2][4]) {
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        f[sb][j] = *(const u32x4*)((const char*)p.W2 + ((long)(4 * hc + 2 * sb + (g >> 1)) * wrows2 + 4L * SC_N2 + 64 * wn + 16 * j + c) * 32 + (g & 1) * 16);
+  };
+  f32x4 acc2[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 fw1[2], fw2[2][4];
+  load_w1(0, fw1);
+  load_w2(0, fw2);
+  __syncthreads();
+  for (int hc = 0; hc < SC_N1 / 64; ++hc) {
+    unsigned char* const img = h1img + (hc & 1) * 2 * SC_NPX * HP;
+    // ---- layer 1 of the chunk, one 16-pixel row tile at a time: acc1[j][e] = hidden unit 64 hc + 32 wn + 16 j + 4 g + e of
+    // pixel 16 (4 wm + i) + c
+    f32x4 wi[2], bi[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int u0 = 64 * hc + 32 * wn + 16 * j + 4 * g;
+      wi[j] = ldg_f4(winv1 + u0);
+      bi[j] = ldg_f4(p.b1 + u0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4 fa0 = *(const u32x4*)(a0img + (16 * (4 * wm + i) + c) * HP + 16 * g);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f32x4 a1 = mfma16(fw1[j], fa0, f32x4{0.f, 0.f, 0.f, 0.f});
+        _Float16 h4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h4[e] = (_Float16)fmaxf(a1[e] * wi[j][e] + bi[j][e], 0.f);
+        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+        // sub-chunk wn (k = 32 wn + ..), k offset 16 j + 4 g inside it: 8 bytes
+        *(h16x4*)(img + wn * SC_NPX * HP + (16 * (4 * wm + i) + c) * HP + (16 * j + 4 * g) * 2) = h16x4{h4[0], h4[1], h4[2], h4[3]};
+      }
+    }
+    if (hc + 1 < SC_N1 / 64) load_w1(hc + 1, fw1);
+    __syncthreads();                                  // the chunk's image is complete (the other buffer is free to be rewritten)
+    // ---- layer 2 over the chunk's 64 hidden units
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 fa = *(const u32x4*)(img + sb * SC_NPX * HP + (16 * (4 * wm + i) + c) * HP + 16 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[i][j] = mfma16(fa, fw2[sb][j], acc2[i][j]);
+      }
+    if (hc + 1 < SC_N1 / 64) load_w2(hc + 1, fw2);
+  }
+  // ---- layer 2's epilogue and layer 3: y = sum_c relu(acc2 * winv2 + b2)[c] * w3[c] + b3
+  float part[4][4];                                   // [i][e]: pixel 16 (4 wm + i) + 4 g + e, over this lane's four columns
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[i][e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = 64 * wn + 16 * j + c;
+    const float wv = winv2[col], bv = p.b2[col], w3 = p.w3[col];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part[i][e] += fmaxf(acc2[i][j][e] * wv + bv, 0.f) * w3;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = part[i][e];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      if (c == 0) rsum[wn * SC_NPX + 16 * (4 * wm + i) + 4 * g + e] = v;
+    }
+  __syncthreads();
+  if (tid < SC_NPX && t0 + tid < p.T) p.y[t0 + tid] = rsum[tid] + rsum[SC_NPX + tid] + p.b3[0];
+}
+
 // 1 -> Co conv (f32 image in, fp16 features out), act 0 none | 1 ReLU | 2 LeakyReLU(alpha).  A thread owns 8 output channels of one pixel.
 __global__ void __launch_bounds__(256) k_cin1_h16(const float* __restrict__ x, const float* __restrict__ w,
                                                   const float* __restrict__ bias, _Float16* __restrict__ y, long ldy, int B,
@@ -460,5 +587,16 @@ int sr_conv_cout1_h16(const void* x, long ldx, const float* w, const float* bias
   const int grid = (int)(n / 32 + 1 < 16384 ? n / 32 + 1 : 16384);
   hipLaunchKernelGGL(k_cout1_h16, dim3(grid), dim3(256), (size_t)12 * Ci * 4, st, (const _Float16*)x, ldx, w, bias, add, in_bn, y, B, H, W, Ci);
   SR_LAUNCH_CHECK("k_cout1_h16");
+  return 0;
+}
+
+int sr_srcnn_h16(const void* a0, const void* W1h, const float* b1, const void* W2h, const float* b2, const float* w3, const float* b3,
+                 float* y, long T, hipStream_t st) {
+  SR_REQUIRE(a0 && W1h && b1 && W2h && b2 && w3 && b3 && y && T > 0, "srcnn_h16: null operand");
+  SrcnnH16Args p;
+  p.A0 = (const _Float16*)a0; p.W1 = (const unsigned short*)W1h; p.plane1 = 9L * SC_N1 * 32 * 2; p.b1 = b1;
+  p.W2 = (const unsigned short*)W2h; p.plane2 = 9L * SC_N2 * 1024 * 2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.y = y; p.T = T;
+  hipLaunchKernelGGL(k_srcnn_h16, dim3((unsigned)((T + SC_NPX - 1) / SC_NPX)), dim3(256), SC_LDS, st, p);
+  SR_LAUNCH_CHECK("k_srcnn_h16");
   return 0;
 }

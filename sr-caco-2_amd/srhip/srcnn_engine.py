@@ -77,26 +77,20 @@ class SRCNNEngine:
         return self._h16_ready
 
     def forward_h16(self, x):
-        """--amp evaluation on fp16 storage: the 1024-channel feature map (8.6 GB at B = 8, 512 x 512 in f32: the forward is
-        its write and read-back) lives in HBM as float16; the 1x1 layers are centre-tap launches of the fp16-storage conv
-        (no halo fetched), one fp16 product."""
+        """--amp evaluation: the three layers in ONE kernel (srhip_srcnn_fwd_h16, conv_h16.hip) -- the 1024-channel feature map
+        (8.6 GB at B = 8, 512 x 512 in f32: the layer-wise forward is its write and read-back) is walked in 64-channel chunks
+        through LDS and never reaches HBM; fp16 products, f32 accumulate."""
         net, D = self.net, self.derived
         B, H, W = x.shape
         dev = x.device
+        T = B * H * W
         y = torch.empty(B, H, W, device=dev)
-        per = max(1, ((1 << 30) - 1) // (C1 * H * W))
-        for b0 in range(0, B, per):
-            nb = min(per, B - b0)
-            t = nb * H * W
-            a0 = ops.im2col_c1(x[b0:b0 + nb], 5, KP1, out=self.bufs.get("h.a0", t, KP1, device=dev))
-            a16 = self.bufs.get("h.a16", nb, H, W, 32, device=dev, dtype=torch.float16)
-            a16.view(t, 32)[:, :KP1].copy_(a0)
-            a16.view(t, 32)[:, KP1:].zero_()
-            h1 = ops.conv3x3_h16(a16, self._h16_w1, net.features[0].bias.data, C1, epi=1, center_only=True,
-                                 out=self.bufs.get("h.h1", nb, H, W, C1, device=dev, dtype=torch.float16))
-            h2 = ops.conv3x3_h16(h1, self._h16_w2, net.map[0].bias.data, C2, epi=1, center_only=True,
-                                 out=self.bufs.get("h.h2", nb, H, W, C2, device=dev, dtype=torch.float16))
-            ops.conv3x3_cout1_h16(h2, D.d["h.w3"], net.reconstruction.bias.data, out=y[b0:b0 + nb])
+        a0 = ops.im2col_c1(x, 5, KP1, out=self.bufs.get("h.a0", T, KP1, device=dev))
+        a16 = self.bufs.get("h.a16", T, 32, device=dev, dtype=torch.float16)
+        a16[:, :KP1].copy_(a0)
+        a16[:, KP1:].zero_()
+        ops.srcnn_fwd_h16(a16, self._h16_w1, net.features[0].bias.data, self._h16_w2, net.map[0].bias.data,
+                          net.reconstruction.weight.data.view(C2), net.reconstruction.bias.data, y.view(T))
         return y.view(B, 1, H, W)
 
     def forward(self, x, dp=None, save=True):

@@ -115,3 +115,33 @@ def test_conv3x3_h16_bn_prologue_leaky_and_1x1():
     wh = (torch.randn(64, 1, 3, 3, generator=g) / 3.0).cuda()
     f = ops.conv3x3_cin1_h16(img, wh, None, 64, leaky=0.2)
     _check(f, F.leaky_relu(F.conv2d(img.double()[:, None], wh.double(), None, padding=1), 0.2).permute(0, 2, 3, 1))
+
+
+def test_srcnn_fused_forward_h16():
+    """srhip_srcnn_fwd_h16 against float64 on the same rounded operands (fp16 patches, leading fp16 weight planes, the
+    1024-channel map rounded to fp16 behind its ReLU as the kernel does)."""
+    from srhip import ops
+    g = torch.Generator().manual_seed(31)
+    T = 128 * 37 + 5
+    a = torch.zeros(T, 32)
+    a[:, :25] = torch.rand(T, 25, generator=g)
+    a16 = a.cuda().half()
+    w1 = torch.zeros(1024, 32, 3, 3, device="cuda")
+    w1[:, :25, 1, 1] = (torch.randn(1024, 25, generator=g) * 0.2).cuda()
+    w2 = torch.zeros(128, 1024, 3, 3, device="cuda")
+    w2[:, :, 1, 1] = (torch.randn(128, 1024, generator=g) / 32.0).cuda()
+    b1, b2 = (torch.randn(1024, generator=g) * 0.1).cuda(), (torch.randn(128, generator=g) * 0.1).cuda()
+    w3, b3 = (torch.randn(128, generator=g) * 0.1).cuda(), torch.tensor([0.03], device="cuda")
+    p1, p2 = ops.Bx3(9 * 1024, 32, "cuda"), ops.Bx3(9 * 128, 1024, "cuda")
+    tb = ops.PrepTable()
+    tb.conv(w1, p1, force_f16=True)
+    tb.conv(w2, p2, force_f16=True)
+    tb.build("cuda").run()
+    y = torch.empty(T, device="cuda")
+    ops.srcnn_fwd_h16(a16, p1, b1, p2, b2, w3, b3, y)
+    W1, W2 = _w_hi(w1)[:, :, 1, 1], _w_hi(w2)[:, :, 1, 1]
+    h1 = torch.relu(a16.double() @ W1.t() + b1.double()).half().double()
+    h2 = torch.relu(h1 @ W2.t() + b2.double())
+    ref = h2 @ w3.double() + b3.double()
+    err = ((y.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-4, err
