@@ -340,10 +340,9 @@ class TrainStep:
         if world_size > 1:
             broadcast_replica_state(self.fp.flat, list(net.buffers()), self.pg)
             net.weights_changed()
-        if getattr(net, "img_range", 1.) != 1.:
-            # SwinIR.forward divides the output by img_range (network_swinir.py:935,968); the fused
-            # step feeds engine.forward's output straight to the loss
-            raise NotImplementedError("fused training step: img_range != 1 is not supported")
+        # SwinIR.forward multiplies the input by img_range and divides the output by it (network_swinir.py:935,968; the mean
+        # is zero for one channel): prepare_input does the first, the step scales y before the loss and dy behind it
+        self.inv_range = 1.0 / float(getattr(net, "img_range", 1.) or 1.)
         self.dy = None
 
     def _make_buckets(self):
@@ -478,6 +477,8 @@ class TrainStep:
         if dp is None:
             dp = net.sample_drop_path(xi.shape[0], xi.device)
         y = net.engine.forward(xi, dp, save=True)
+        if self.inv_range != 1.0:
+            ops.axpby(y, y, self.inv_range, 0.0)
         inter = getattr(net.engine, "intermediate_outs", None)
         d_inter = None
         if inter:       # MSLapSRN: the trainer's multi-scale loss (model_plain.py:277-314)
@@ -492,6 +493,8 @@ class TrainStep:
         if self.ddp:
             self.reducer.begin()
             hook = self.reducer.bucket_done
+        if self.inv_range != 1.0:
+            ops.axpby(dy, dy, self.inv_range, 0.0)
         # every gradient kernel OVERWRITES its tensor (the LayerNorm-affine sums are two-stage and deterministic too);
         # the memset only keeps a parameter without a gradient path (and the alignment padding) at zero
         self.fp.grad.zero_()

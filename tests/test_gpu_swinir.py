@@ -554,3 +554,27 @@ def test_bench_self_launch_one_rank_rccl_path(tmp_path):
     line = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and d["value"] > 100 and d["config"]["parallelism"] == "dp1"
+
+
+def test_fused_step_with_img_range():
+    """img_range != 1 (network_swinir.py:935,968: input x img_range, output / img_range) in the fused training step: the
+    gradients of TrainStep equal those of the module path (net(x) + torch autograd around the same kernels)."""
+    from dlib.models.network_swinir import SwinIR
+    from srhip.train import TrainStep, Optimizer
+    torch.manual_seed(3)
+    kw = dict(upscale=2, in_chans=1, img_size=16, window_size=8, depths=[2], embed_dim=60, num_heads=[6], mlp_ratio=2,
+              upsampler="pixelshuffledirect", img_range=4.0, drop_path_rate=0.0)
+    net = SwinIR(**kw).cuda().train()
+    x = torch.rand(2, 1, 16, 16, device="cuda")
+    tgt = torch.rand(2, 1, 32, 32, device="cuda")
+    y = net(x)
+    (y - tgt).abs().mean().backward()
+    ref = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    loss_ref = (y - tgt).abs().mean().item()
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=0.0, momentum=0.0, nesterov=False, wd=0.0)
+    ts.step(x, tgt)
+    assert abs(ts.loss_values()[0] - loss_ref) <= 1e-6
+    for k in ts.fp.names:
+        a, b = ts.fp.gviews[k], ref[k]
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), k
