@@ -183,11 +183,11 @@ int srhip_conv3x3_cin1_h16(const float* x, const float* w, const float* bias, vo
 int srhip_conv3x3_cout1_h16(const void* x, long ldx, const float* w, const float* bias, const float* add, const float* in_bn_coef,
                             float* y, int B, int H, int W, int Ci, void* stream);
 /* SRCNN's evaluation forward under --amp in ONE kernel (network_srcnn.py:23-69; fp16 products, f32 accumulate): patches [T][32]
- * fp16 = the 5x5 patch matrix (25 taps + 7 zero columns), W1h / W2h = the fp16x2 conv operands (job kind 4) of the layers held as
+ * fp16 = the 5x5 patch matrix (25 taps + 7 zero columns) -- or NULL: built inside from image [B][H][W] f32 (T = B*H*W) --, W1h / W2h = the fp16x2 conv operands (job kind 4) of the layers held as
  * centre taps of 3x3 weights ([1024][32] and [128][1024]), w3 [128], b3 [1] f32 -> y [T] f32.  The 1024-channel feature map is
  * never written: a block walks it in 64-channel chunks through LDS. */
-int srhip_srcnn_fwd_h16(const void* patches, const void* W1h, const float* b1, const void* W2h, const float* b2, const float* w3,
-                        const float* b3, float* y, long T, void* stream);
+int srhip_srcnn_fwd_h16(const void* patches, const float* image, int B, int H, int W, const void* W1h, const float* b1,
+                        const void* W2h, const float* b2, const float* w3, const float* b3, float* y, long T, void* stream);
 /* srhip_conv3x3_ps2_bx3 / srhip_conv3x3_ps2_bwd_data_bx3 with the weight in that format (job kind 4, modes 12 / 16). */
 int srhip_conv3x3_ps2_f16x2(const float* X, long ldx, const void* Wh, const float* bias, float* Yup, long ldy,
                             int B, int H, int W, int Cin, int Cout, int epi, float alpha, void* stream);

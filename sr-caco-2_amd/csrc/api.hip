@@ -317,9 +317,9 @@ int srhip_conv3x3_cout1_h16(const void* x, long ldx, const float* w, const float
   return sr_conv_cout1_h16(x, ldx, w, bias, add, in_bn_coef, y, B, H, W, Ci, (hipStream_t)stream);
 }
 
-int srhip_srcnn_fwd_h16(const void* patches, const void* W1h, const float* b1, const void* W2h, const float* b2, const float* w3,
-                        const float* b3, float* y, long T, void* stream) {
-  return sr_srcnn_h16(patches, W1h, b1, W2h, b2, w3, b3, y, T, (hipStream_t)stream);
+int srhip_srcnn_fwd_h16(const void* patches, const float* image, int B, int H, int W, const void* W1h, const float* b1,
+                        const void* W2h, const float* b2, const float* w3, const float* b3, float* y, long T, void* stream) {
+  return sr_srcnn_h16(patches, image, B, H, W, W1h, b1, W2h, b2, w3, b3, y, T, (hipStream_t)stream);
 }
 
 int srhip_tn_plan(int M, int NI, int NJ, int conv, int* S, long* part_floats) {

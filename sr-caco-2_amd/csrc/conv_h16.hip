@@ -341,7 +341,8 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_h16(ConvH16Args p) {
 // in the epilogue.  The 1024-channel map (8.6 GB at B = 8, 512 x 512 in f32, written and read back by the layer-wise path)
 // never exists.  Weights: the centre taps of the fp16x2 conv operands srhip_prep_table builds (leading plane).
 struct SrcnnH16Args {
-  const _Float16* A0;                // [T][32] patch matrix (25 taps + 7 zeros)
+  const _Float16* A0;                // [T][32] patch matrix (25 taps + 7 zeros), or null: built here from the image
+  const float* img; int B, H, W;     // the f32 image [B][H][W] (A0 == null)
   const unsigned short* W1; long plane1; const float* b1;     // planes of [1024][32] at tap 4 of a [9*1024] row set
   const unsigned short* W2; long plane2; const float* b2;     // planes of [128][1024] at tap 4 of a [9*128] row set
   const float* w3; const float* b3;  // [128], [1]
@@ -362,12 +363,36 @@ __global__ void __launch_bounds__(256, 3) k_srcnn_h16(SrcnnH16Args p) {
   const int c = lane & 15, g = lane >> 4;
   const long t0 = (long)blockIdx.x * SC_NPX;
   // ---- the block's 128 rows of the patch matrix: 512 16-byte slots
+  if (p.A0) {
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int idx = tid + it * 256, px = idx >> 2, c8 = idx & 3;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (t0 + px < p.T) v = *(const u32x4*)((const char*)p.A0 + ((t0 + px) * 32 + c8 * 8) * 2);
-    *(u32x4*)(a0img + px * HP + c8 * 16) = v;
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 256, px = idx >> 2, c8 = idx & 3;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (t0 + px < p.T) v = *(const u32x4*)((const char*)p.A0 + ((t0 + px) * 32 + c8 * 8) * 2);
+      *(u32x4*)(a0img + px * HP + c8 * 16) = v;
+    }
+  } else {
+    // ... built from the image: column j = tap (j / 5, j % 5) of the 5 x 5 neighbourhood, zero outside the image
+    // (srhip_im2col_c1's matrix, data.hip); a thread = (pixel, taps 16 half .. + 15)
+    const int px = tid >> 1, hf = tid & 1;
+    const long t = t0 + px;
+    h16x8 v0, v1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v0[e] = (_Float16)0.f; v1[e] = (_Float16)0.f; }
+    if (t < p.T) {
+      const int xx = (int)(t % p.W), yy = (int)((t / p.W) % p.H);
+      const float* ib = p.img + (t / ((long)p.W * p.H)) * p.H * p.W;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int j = 16 * hf + e;
+        float v = 0.f;
+        const int sy = yy + j / 5 - 2, sx = xx + j % 5 - 2;
+        if (j < 25 && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) v = ib[(long)sy * p.W + sx];
+        if (e < 8) v0[e] = (_Float16)v; else v1[e - 8] = (_Float16)v;
+      }
+    }
+    *(h16x8*)(a0img + px * HP + hf * 32) = v0;
+    *(h16x8*)(a0img + px * HP + hf * 32 + 16) = v1;
   }
   const float* const winv1 = (const float*)((const char*)p.W1 + 2 * p.plane1);
   const float* const winv2 = (const float*)((const char*)p.W2 + 2 * p.plane2);
@@ -503,7 +528,14 @@ __global__ void __launch_bounds__(256) k_cout1_h16(const _Float16* __restrict__ 
                                                    int Ci) {
   extern __shared__ float wl[];                  // [9][Ci] weights, [3][Ci] BatchNorm mean / k / beta of the input prologue
   float* const cf = wl + 9 * Ci;
+  typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+  h16x2* const wh = (h16x2*)(cf + 3 * Ci);       // [9][Ci / 2] the weights as fp16 pairs (no prologue: v_dot2_f32_f16)
   for (int i = threadIdx.x; i < 9 * Ci; i += 256) wl[(i % 9) * Ci + i / 9] = w[i];
+  if (!in_bn)
+    for (int i = threadIdx.x; i < 9 * Ci / 2; i += 256) {
+      const int t = i / (Ci / 2), c2 = i - t * (Ci / 2);
+      wh[i] = h16x2{(_Float16)w[(2 * c2) * 9 + t], (_Float16)w[(2 * c2 + 1) * 9 + t]};
+    }
   if (in_bn)
     for (int i = threadIdx.x; i < Ci; i += 256) { cf[i] = in_bn[i]; cf[Ci + i] = in_bn[2 * Ci + i]; cf[2 * Ci + i] = in_bn[3 * Ci + i]; }
   __syncthreads();
@@ -523,11 +555,16 @@ __global__ void __launch_bounds__(256) k_cout1_h16(const _Float16* __restrict__ 
       const _Float16* row = x + ((b * H + sy) * W + sx) * ldx;
       for (int c0 = sub * 8; c0 < Ci; c0 += 64) {
         const h16x8 xv = *(const h16x8*)(row + c0);
+        if (in_bn) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float xe = (float)xv[e];
-          if (in_bn) xe = fmaxf((xe - cf[c0 + e]) * cf[Ci + c0 + e] + cf[2 * Ci + c0 + e], 0.f);
-          s += xe * wl[t * Ci + c0 + e];
+          for (int e = 0; e < 8; ++e) {
+            const float xe = fmaxf(((float)xv[e] - cf[c0 + e]) * cf[Ci + c0 + e] + cf[2 * Ci + c0 + e], 0.f);
+            s += xe * wl[t * Ci + c0 + e];
+          }
+        } else {                                 // four packed dot products (fp16 pairs, f32 accumulate) per 16 bytes
+          const h16x2* wp = wh + t * (Ci / 2) + (c0 >> 1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_fdot2(h16x2{xv[2 * e], xv[2 * e + 1]}, wp[e], s, false);
         }
       }
     }
@@ -585,16 +622,17 @@ int sr_conv_cout1_h16(const void* x, long ldx, const float* w, const float* bias
   const long n = (long)B * H * W;
   if (n <= 0) return 0;
   const int grid = (int)(n / 32 + 1 < 16384 ? n / 32 + 1 : 16384);
-  hipLaunchKernelGGL(k_cout1_h16, dim3(grid), dim3(256), (size_t)12 * Ci * 4, st, (const _Float16*)x, ldx, w, bias, add, in_bn, y, B, H, W, Ci);
+  hipLaunchKernelGGL(k_cout1_h16, dim3(grid), dim3(256), (size_t)12 * Ci * 4 + (size_t)9 * Ci * 2, st, (const _Float16*)x, ldx, w, bias, add, in_bn, y, B, H, W, Ci);
   SR_LAUNCH_CHECK("k_cout1_h16");
   return 0;
 }
 
-int sr_srcnn_h16(const void* a0, const void* W1h, const float* b1, const void* W2h, const float* b2, const float* w3, const float* b3,
-                 float* y, long T, hipStream_t st) {
-  SR_REQUIRE(a0 && W1h && b1 && W2h && b2 && w3 && b3 && y && T > 0, "srcnn_h16: null operand");
+int sr_srcnn_h16(const void* a0, const float* img, int B, int H, int W, const void* W1h, const float* b1, const void* W2h,
+                 const float* b2, const float* w3, const float* b3, float* y, long T, hipStream_t st) {
+  SR_REQUIRE((a0 || img) && W1h && b1 && W2h && b2 && w3 && b3 && y && T > 0, "srcnn_h16: null operand");
+  SR_REQUIRE(a0 || (B > 0 && H > 0 && W > 0 && (long)B * H * W == T), "srcnn_h16: image %d x %d x %d for %ld pixels", B, H, W, T);
   SrcnnH16Args p;
-  p.A0 = (const _Float16*)a0; p.W1 = (const unsigned short*)W1h; p.plane1 = 9L * SC_N1 * 32 * 2; p.b1 = b1;
+  p.A0 = (const _Float16*)a0; p.img = img; p.B = B; p.H = H; p.W = W; p.W1 = (const unsigned short*)W1h; p.plane1 = 9L * SC_N1 * 32 * 2; p.b1 = b1;
   p.W2 = (const unsigned short*)W2h; p.plane2 = 9L * SC_N2 * 1024 * 2; p.b2 = b2; p.w3 = w3; p.b3 = b3; p.y = y; p.T = T;
   hipLaunchKernelGGL(k_srcnn_h16, dim3((unsigned)((T + SC_NPX - 1) / SC_NPX)), dim3(256), SC_LDS, st, p);
   SR_LAUNCH_CHECK("k_srcnn_h16");

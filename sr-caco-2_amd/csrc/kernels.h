@@ -65,8 +65,8 @@ struct ConvH16Args {
 int sr_conv3x3_h16(ConvH16Args& p, hipStream_t st);
 int sr_conv_cin1_h16(const float* x, const float* w, const float* bias, void* y, long ldy, int B, int H, int W, int Co, int act,
                      float alpha, hipStream_t st);
-int sr_srcnn_h16(const void* a0, const void* W1h, const float* b1, const void* W2h, const float* b2, const float* w3, const float* b3,
-                 float* y, long T, hipStream_t st);
+int sr_srcnn_h16(const void* a0, const float* img, int B, int H, int W, const void* W1h, const float* b1, const void* W2h,
+                 const float* b2, const float* w3, const float* b3, float* y, long T, hipStream_t st);
 int sr_conv_cout1_h16(const void* x, long ldx, const float* w, const float* bias, const float* add, const float* in_bn, float* y,
                       int B, int H, int W, int Ci, hipStream_t st);
 

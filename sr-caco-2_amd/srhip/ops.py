@@ -830,14 +830,23 @@ def conv3x3_cout1_h16(x, w, bias, add=None, out=None, in_bn=None):
     return out
 
 
-def srcnn_fwd_h16(patches, W1p, b1, W2p, b2, w3, b3, out):
-    """SRCNN's three layers in one launch (srhip_srcnn_fwd_h16): patches [T, 32] float16, W1p / W2p = centre-tap fp16x2 conv
-    operands of [1024, 32] / [128, 1024], w3 [128], b3 [1] -> out [T] f32."""
-    _chk(b1, b2, w3, b3, out)
-    T = patches.shape[0]
-    assert patches.is_contiguous() and tuple(patches.shape) == (T, 32) and W1p.fmt == 1 and W2p.fmt == 1
-    assert (W1p.rows, W1p.K) == (9 * 1024, 32) and (W2p.rows, W2p.K) == (9 * 128, 1024) and w3.numel() == 128 and out.numel() == T
-    call("srhip_srcnn_fwd_h16", _ph(patches), _p(W1p.planes), _p(b1), _p(W2p.planes), _p(b2), _p(w3), _p(b3), _p(out), T, _st())
+def srcnn_fwd_h16(patches, W1p, b1, W2p, b2, w3, b3, out, image=None):
+    """SRCNN's three layers in one launch (srhip_srcnn_fwd_h16): patches [T, 32] float16 (or None with image [B, H, W] f32: the
+    patch matrix is built inside), W1p / W2p = centre-tap fp16x2 conv operands of [1024, 32] / [128, 1024], w3 [128], b3 [1]
+    -> out [T] f32."""
+    _chk(b1, b2, w3, b3, out, image)
+    assert W1p.fmt == 1 and W2p.fmt == 1 and (W1p.rows, W1p.K) == (9 * 1024, 32) and (W2p.rows, W2p.K) == (9 * 128, 1024)
+    if image is not None:
+        assert patches is None and image.is_contiguous() and image.dim() == 3
+        B, H, W = image.shape
+        T = B * H * W
+    else:
+        T = patches.shape[0]
+        B = H = W = 0
+        assert patches.is_contiguous() and tuple(patches.shape) == (T, 32)
+    assert w3.numel() == 128 and out.numel() == T
+    call("srhip_srcnn_fwd_h16", _ph(patches), _p(image), B, H, W, _p(W1p.planes), _p(b1), _p(W2p.planes), _p(b2), _p(w3), _p(b3),
+         _p(out), T, _st())
     return out
 
 

@@ -85,12 +85,9 @@ class SRCNNEngine:
         dev = x.device
         T = B * H * W
         y = torch.empty(B, H, W, device=dev)
-        a0 = ops.im2col_c1(x, 5, KP1, out=self.bufs.get("h.a0", T, KP1, device=dev))
-        a16 = self.bufs.get("h.a16", T, 32, device=dev, dtype=torch.float16)
-        a16[:, :KP1].copy_(a0)
-        a16[:, KP1:].zero_()
-        ops.srcnn_fwd_h16(a16, self._h16_w1, net.features[0].bias.data, self._h16_w2, net.map[0].bias.data,
-                          net.reconstruction.weight.data.view(C2), net.reconstruction.bias.data, y.view(T))
+        ops.srcnn_fwd_h16(None, self._h16_w1, net.features[0].bias.data, self._h16_w2, net.map[0].bias.data,
+                          net.reconstruction.weight.data.view(C2), net.reconstruction.bias.data, y.view(T),
+                          image=x if x.is_contiguous() else x.contiguous())
         return y.view(B, 1, H, W)
 
     def forward(self, x, dp=None, save=True):

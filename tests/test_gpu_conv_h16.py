@@ -76,7 +76,8 @@ def test_edge_convs_h16():
     w2 = (torch.randn(1, 64, 3, 3, generator=g) / 24.0).cuda()
     b2 = torch.tensor([0.05], device="cuda")
     y = ops.conv3x3_cout1_h16(f, w2, b2, add=x)
-    ref2 = F.conv2d(f.double().permute(0, 3, 1, 2), w2.double(), b2.double(), padding=1)[:, 0] + x.double()
+    # (the tail conv multiplies fp16 pairs -- v_dot2_f32_f16, f32 accumulate --: its weights are rounded to fp16 too)
+    ref2 = F.conv2d(f.double().permute(0, 3, 1, 2), w2.half().double(), b2.double(), padding=1)[:, 0] + x.double()
     assert ((y.double() - ref2).abs().max() / ref2.abs().max()).item() < 1e-5
 
 
@@ -145,3 +146,12 @@ def test_srcnn_fused_forward_h16():
     ref = h2 @ w3.double() + b3.double()
     err = ((y.double() - ref).abs().max() / ref.abs().max()).item()
     assert err < 2e-4, err
+    # the patch matrix built inside the kernel from the image == srhip_im2col_c1's (rounded to fp16)
+    img = torch.rand(3, 21, 37, generator=g).cuda()
+    a0 = ops.im2col_c1(img, 5, 28)
+    a16b = torch.zeros(a0.shape[0], 32, device="cuda", dtype=torch.float16)
+    a16b[:, :28] = a0
+    y1, y2 = torch.empty(a0.shape[0], device="cuda"), torch.empty(a0.shape[0], device="cuda")
+    ops.srcnn_fwd_h16(a16b, p1, b1, p2, b2, w3, b3, y1)
+    ops.srcnn_fwd_h16(None, p1, b1, p2, b2, w3, b3, y2, image=img)
+    assert torch.equal(y1, y2)
