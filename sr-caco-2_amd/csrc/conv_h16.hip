@@ -30,8 +30,8 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
 }
 
-constexpr int h16_lds(int rw) {       // the halo tile of a chunk | three chunks of the tile's own pixels (1x1) | the f32 output tile
-  const int halo = (2 * rw + 2) * 18 * HP, one = 3 * 2 * rw * 16 * HP, tile = 2 * rw * 16 * TPF * 4;
+constexpr int h16_lds(int rw) {       // two halo tiles (chunks alternate) | three chunks of the tile's own pixels (1x1) | the f32 output tile
+  const int halo = 2 * (2 * rw + 2) * 18 * HP, one = 3 * 2 * rw * 16 * HP, tile = 2 * rw * 16 * TPF * 4;
   return (halo > tile ? halo : tile) > one ? (halo > tile ? halo : tile) : one;
 }
 
@@ -143,7 +143,9 @@ __global__ void __launch_bounds__(256, 3) k_conv3x3_h16(ConvH16Args p) {
 #pragma unroll
     for (int it = 0; it < AIT; ++it) ra[it] = inA[it] ? *(const u32x4*)(base + offA[it]) : u32x4{0u, 0u, 0u, 0u};
   };
+  constexpr int IMG = AROWS * HP;                 // one chunk's halo image; two of them, used alternately
   auto store_a = [&](const u32x4 (&ra)[AIT], int kc) {
+    unsigned char* const img_w = smem + (kc & 1) * IMG;
     if (p.in_bn) {                                // (L1 / L2 hits: every block reads the same 3 x 32 floats per chunk)
       const int ch = kc * 32 + (tid & 3) * 8;
 #pragma unroll
@@ -165,7 +167,7 @@ __global__ void __launch_bounds__(256, 3) k_conv3x3_h16(ConvH16Args p) {
             hv[e] = (_Float16)fmaxf(((float)hv[e] - bm[e >> 2][e & 3]) * bk[e >> 2][e & 3] + bb[e >> 2][e & 3], 0.f);
           v = __builtin_bit_cast(u32x4, hv);
         }
-        *(u32x4*)(smem + (idx >> 2) * HP + (idx & 3) * 16) = inA[it] ? v : u32x4{0u, 0u, 0u, 0u};
+        *(u32x4*)(img_w + (idx >> 2) * HP + (idx & 3) * 16) = inA[it] ? v : u32x4{0u, 0u, 0u, 0u};
       }
     }
   };
@@ -194,27 +196,29 @@ __global__ void __launch_bounds__(256, 3) k_conv3x3_h16(ConvH16Args p) {
   u32x4 fb0[2], fb1[2], fb2[2];
   const int niter = nkc * 9;
   auto load_it = [&](int it, u32x4 (&fb)[2]) { load_b(it / 9, it % 9, fb); };
-  auto mma = [&](int tap, const u32x4 (&fb)[2]) {
+  auto mma = [&](const unsigned char* img_r, int tap, const u32x4 (&fb)[2]) {
     const int toff = ((tap / 3) * 18 + (tap % 3)) * HP;
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-      const u32x4 fa = *(const u32x4*)(smem + a_off[i] + toff);
+      const u32x4 fa = *(const u32x4*)(img_r + a_off[i] + toff);
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa, fb[j], acc[i][j]);
     }
   };
   load_it(0, fb0); load_it(1, fb1); load_it(2, fb2);
   for (int kc = 0; kc < nkc; ++kc) {
-    if (kc) __syncthreads();                      // every tap of the previous chunk has read the halo tile
+    // ONE barrier per chunk: chunk kc goes into image kc & 1 while slower waves may still read the other one (whoever
+    // writes image kc & 1 has passed barrier kc - 1, which every wave reaches behind its taps of chunk kc - 2)
     store_a(ra, kc);
     __syncthreads();
     if (kc + 1 < nkc) load_a(kc + 1, ra);
+    const unsigned char* const img_r = smem + (kc & 1) * IMG;
     const int it = kc * 9;
 #pragma unroll
     for (int t3 = 0; t3 < 9; t3 += 3) {
-      mma(t3, fb0);     if (it + t3 + 3 < niter) load_it(it + t3 + 3, fb0);
-      mma(t3 + 1, fb1); if (it + t3 + 4 < niter) load_it(it + t3 + 4, fb1);
-      mma(t3 + 2, fb2); if (it + t3 + 5 < niter) load_it(it + t3 + 5, fb2);
+      mma(img_r, t3, fb0);     if (it + t3 + 3 < niter) load_it(it + t3 + 3, fb0);
+      mma(img_r, t3 + 1, fb1); if (it + t3 + 4 < niter) load_it(it + t3 + 4, fb1);
+      mma(img_r, t3 + 2, fb2); if (it + t3 + 5 < niter) load_it(it + t3 + 5, fb2);
     }
   }
 
