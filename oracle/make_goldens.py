@@ -195,7 +195,7 @@ def build_ref_swinir(cfg):
                   img_range=cfg["img_range"], depths=cfg["depths"],
                   embed_dim=cfg["embed_dim"], num_heads=cfg["num_heads"],
                   mlp_ratio=cfg["mlp_ratio"], upsampler=cfg["upsampler"],
-                  resi_connection=cfg["resi_connection"])
+                  resi_connection=cfg["resi_connection"], ape=cfg.get("ape", False))
 
 
 def perturb(sd, seed):
@@ -512,6 +512,64 @@ def g_swinir_3conv():
     arrs.update(sd_np(sd, "sd/"))
     arrs.update(sd_np(grads, "grad/"))
     npz("g27_swinir_3conv", **arrs)
+
+
+def _swinir_grad_golden(tag, name, cfg, x, seeds):
+    """Reference eval forward, dL/dx and every parameter gradient (drop-path off) for one SwinIR configuration; the
+    oracle is held to the same numbers."""
+    sd = perturb(O.swinir_init_state_dict(cfg, seed=seeds[0]), seeds[1])
+    net = build_ref_swinir(cfg)
+    net.load_state_dict(sd, strict=True)
+    assert list(net.state_dict().keys()) == list(sd.keys()), "key order"
+    net.eval()
+    with torch.no_grad():
+        y_eval = net(x)
+        close(O.swinir_forward(sd, x, cfg), y_eval, 2e-6, tag + " eval forward")
+    net.train()
+    for l in net.layers:
+        for b in l.residual_group.blocks:
+            b.drop_path = nn.Identity()
+    xg = x.clone().requires_grad_(True)
+    y = net(xg)
+    torch.manual_seed(seeds[2])
+    tgt = torch.rand_like(y)
+    (y - tgt).abs().mean().backward()
+    grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask") else v)
+           for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    (O.swinir_forward(sdo, xo, cfg) - tgt).abs().mean().backward()
+    close(xo.grad, xg.grad, 1e-7, tag + " dL/dx")
+    for k in grads:
+        e = (sdo[k].grad - grads[k]).abs().max().item() / (grads[k].abs().max().item() + 1e-30)
+        assert e < (1e-4 if k.endswith(".bias") else 5e-6), (k, e)
+    arrs = dict(x=x, y_eval=y_eval, target=tgt, dx=xg.grad)
+    arrs.update(sd_np(sd, "sd/"))
+    arrs.update(sd_np(grads, "grad/"))
+    npz(name, **arrs)
+
+
+def g_swinir_ape():
+    """ape=True (network_swinir.py:812-815, 918-919): a learned [1, img_size^2, C] table added to the tokens after
+    patch_embed; the input has to be img_size x img_size."""
+    print("G42 SwinIR tiny, absolute position embedding")
+    cfg = O.swinir_config(upscale=2, in_chans=1, img_size=16, window_size=8, depths=(2, 2), embed_dim=60,
+                          num_heads=(6, 6), mlp_ratio=2, upsampler="pixelshuffledirect", drop_path_rate=0.0, ape=True)
+    torch.manual_seed(72)
+    _swinir_grad_golden("ape", "g42_swinir_ape", cfg, torch.rand(2, 1, 16, 16), (70, 71, 73))
+
+
+def g_swinir_rgb():
+    """in_chans=3 (network_swinir.py:722-727, 934-935, 968): the RGB mean subtracted before / added after the network,
+    img_range 2; 'pixelshuffledirect' (conv C -> 3 s^2) and 'pixelshuffle' (conv_last 64 -> 3) tails, one RSTB of two
+    blocks each."""
+    print("G43/G44 SwinIR tiny, three image channels")
+    for name, ups, seeds in (("g43_swinir_rgb_direct", "pixelshuffledirect", (74, 75, 76)),
+                             ("g44_swinir_rgb_pixelshuffle", "pixelshuffle", (77, 78, 79))):
+        cfg = O.swinir_config(upscale=2, in_chans=3, img_size=16, window_size=8, depths=(2,), embed_dim=60,
+                              num_heads=(6,), mlp_ratio=2, upsampler=ups, drop_path_rate=0.0, img_range=2.0)
+        torch.manual_seed(seeds[0] + 100)
+        _swinir_grad_golden("rgb " + ups, name, cfg, torch.rand(2, 3, 16, 24), seeds)
 
 
 # ---------------------------------------------------------------- G21 training-crop sampler
@@ -1970,7 +2028,7 @@ def g_optim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = [g_grl, g_omnisr, g_act, g_dfcan, g_dfcan_grad, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
-            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv]
+            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv, g_swinir_ape, g_swinir_rgb]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:
         if not only or g.__name__ in only:

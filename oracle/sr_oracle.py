@@ -86,9 +86,9 @@ def swinir_config(upscale=8, in_chans=1, img_size=64, window_size=8,
                   img_range=1.0, depths=(6, 6, 6, 6), embed_dim=180,
                   num_heads=(6, 6, 6, 6), mlp_ratio=2,
                   upsampler="pixelshuffledirect", resi_connection="1conv",
-                  drop_path_rate=0.1) -> dict:
+                  drop_path_rate=0.1, ape=False) -> dict:
     """README.md:120-197 configuration by default."""
-    return dict(upscale=upscale, in_chans=in_chans, img_size=img_size,
+    return dict(ape=ape, upscale=upscale, in_chans=in_chans, img_size=img_size,
                 window_size=window_size, img_range=img_range,
                 depths=list(depths), embed_dim=embed_dim,
                 num_heads=list(num_heads), mlp_ratio=mlp_ratio,
@@ -198,6 +198,8 @@ def swinir_forward(sd: SD, x: Tensor, cfg: dict,
     t = f0.flatten(2).transpose(1, 2)  # PatchEmbed :610-614
     t = F.layer_norm(t, (c,), sd["patch_embed.norm.weight"],
                      sd["patch_embed.norm.bias"])
+    if cfg.get("ape", False):    # network_swinir.py:918-919 (the input has to be img_size x img_size)
+        t = t + sd["absolute_pos_embed"]
     bi = 0
     for li, depth in enumerate(cfg["depths"]):
         t_in = t
@@ -280,9 +282,12 @@ def swinir_init_state_dict(cfg: dict, seed: int = 0) -> SD:
         sd[name + ".weight"] = torch.ones(c)
         sd[name + ".bias"] = torch.zeros(c)
 
+    size = cfg["img_size"]
+    if cfg.get("ape", False):    # network_swinir.py:812-815; a module's own parameters precede its children's
+        sd["absolute_pos_embed"] = torch.nn.init.trunc_normal_(
+            torch.empty(1, size * size, c), std=0.02, generator=g)
     conv("conv_first", c, cfg["in_chans"])
     ln("patch_embed.norm")
-    size = cfg["img_size"]
     wsb = min(ws, size) if size <= ws else ws
     for li, depth in enumerate(cfg["depths"]):
         heads = cfg["num_heads"][li]

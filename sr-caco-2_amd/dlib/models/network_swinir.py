@@ -157,8 +157,8 @@ class SwinIR(nn.Module):
         unsupported = []
         if window_size != 8:
             unsupported.append(f"window_size={window_size} (HIP path: 8)")
-        if in_chans != 1:
-            unsupported.append(f"in_chans={in_chans} (HIP path: 1-channel microscopy patches)")
+        if not 1 <= in_chans <= 4:
+            unsupported.append(f"in_chans={in_chans} (HIP path: 1 to 4 image channels)")
         if upsampler not in (constants.US_PIXEL_SHUFFLE_DIRECT, constants.US_PIXEL_SHUFFLE, constants.US_NEAREST_CONV):
             unsupported.append(f"upsampler={upsampler!r} (HIP path: 'pixelshuffledirect', 'pixelshuffle', 'nearest_conv')")
         if upsampler == constants.US_NEAREST_CONV:
@@ -167,8 +167,8 @@ class SwinIR(nn.Module):
             unsupported.append(f"upscale={upscale} with 'pixelshuffle' (HIP path: powers of two)")
         if resi_connection not in (constants.R_CONNECTION_1CONV, constants.R_CONNECTION_3CONV):
             unsupported.append(f"resi_connection={resi_connection!r} (HIP path: '1conv', '3conv')")
-        if ape or not patch_norm or not qkv_bias or qk_scale is not None or drop_rate or attn_drop_rate:
-            unsupported.append("ape / patch_norm=False / qkv_bias=False / qk_scale / dropout")
+        if not patch_norm or not qkv_bias or qk_scale is not None or drop_rate or attn_drop_rate:
+            unsupported.append("patch_norm=False / qkv_bias=False / qk_scale / dropout")
         if embed_dim > 256 or (embed_dim // num_heads[0]) not in (10, 16, 30, 32):
             unsupported.append(f"embed_dim={embed_dim} / heads={num_heads}")
         if unsupported:
@@ -180,7 +180,14 @@ class SwinIR(nn.Module):
         self.window_size, self.upscale, self.img_range = window_size, upscale, img_range
         self.upsampler = upsampler
         self.resi_connection = resi_connection
-        self.mean = torch.zeros(1, 1, 1, 1)
+        if in_chans == 3:       # network_swinir.py:722-727
+            self.mean = torch.Tensor((0.4488, 0.4371, 0.4040)).view(1, 3, 1, 1)
+        else:
+            self.mean = torch.zeros(1, 1, 1, 1)
+        self.ape = bool(ape)
+        if self.ape:    # network_swinir.py:812-815 (patch_size 1: one row per pixel of an img_size patch)
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, self.img_size[0] * self.img_size[1], embed_dim))
+            nn.init.trunc_normal_(self.absolute_pos_embed, std=.02)
 
         self.conv_first = _conv3(embed_dim, in_chans)
         self.patch_embed = _Box()
@@ -274,8 +281,9 @@ class SwinIR(nn.Module):
 
     # -- forward -------------------------------------------------------------
     def prepare_input(self, x):
-        """check_image_size (network_swinir.py:908-913): reflect-pad to a multiple
-        of the window; (x-mean)*img_range is the identity for 1 channel."""
+        """check_image_size (network_swinir.py:908-913): reflect-pad to a multiple of the window; (x - mean) * img_range
+        (:934-935; the mean is zero unless in_chans == 3).  in_chans 1: [B, H, W]; otherwise NHWC with the channels
+        zero-padded to 4 (what the engine's conv_first takes)."""
         if not x.is_cuda:
             raise RuntimeError("SwinIR (libsrhip) runs on the GPU only: move the model and the "
                                "input to cuda; there is no CPU fallback")
@@ -285,9 +293,13 @@ class SwinIR(nn.Module):
         ph, pw = (ws - h % ws) % ws, (ws - w % ws) % ws
         if ph or pw:
             x = F.pad(x, (0, pw, 0, ph), 'reflect')
+        if self.in_chans == 3:
+            x = x - self.mean.to(x)
         if self.img_range != 1.:
             x = x * self.img_range
-        return x.float().contiguous()[:, 0], h, w
+        if self.in_chans == 1:
+            return x.float().contiguous()[:, 0], h, w
+        return F.pad(x.float().permute(0, 2, 3, 1), (0, 4 - self.in_chans)).contiguous(), h, w
 
     def forward(self, x, dp=None):
         xi, h, w = self.prepare_input(x)
@@ -295,11 +307,15 @@ class SwinIR(nn.Module):
             dp = self.sample_drop_path(x.shape[0], x.device)
         if xi.shape[1] <= self.window_size or xi.shape[2] <= self.window_size:
             raise NotImplementedError("inputs must be larger than one 8x8 window")
+        if self.ape and tuple(xi.shape[1:3]) != self.img_size:   # the reference's broadcast fails the same way (:919)
+            raise RuntimeError(f"ape=True: the input has to be img_size {self.img_size}, got {tuple(xi.shape[1:3])}")
         params = [p for _, p in self.named_parameters()]
         need_grad = torch.is_grad_enabled() and (xi.requires_grad or any(p.requires_grad for p in params))
         refresh_if_params_changed(self, params)   # stock torch.optim wrote the weights?
         y = _NetFn.apply(xi, self, dp, need_grad, *params)
         if self.img_range != 1.:
             y = y / self.img_range
+        if self.in_chans == 3:
+            y = y + self.mean.to(y)
         s = self.upscale
         return y[:, :, :h * s, :w * s]

@@ -39,12 +39,17 @@ class _Bufs:
         self.d.clear()
 
 
+def net_dev(net):
+    return net.conv_first.weight.device
+
+
 class SwinIREngine:
     def __init__(self, net):
         self.net = net
         self.C = net.embed_dim
         self.hid = int(net.embed_dim * net.mlp_ratio)
         self.scale = net.upscale
+        self.ci = net.in_chans          # 1: the single-channel edge kernels; otherwise _prepare_edges
         self.blocks = list(net.swin_blocks())
         self.direct = net.upsampler == "pixelshuffledirect"
         self.nearest = net.upsampler == "nearest_conv"      # 2 x [nearest x2, conv, LeakyReLU], conv_hr, conv_last (x4)
@@ -108,7 +113,28 @@ class SwinIREngine:
             self._prepare_bx3()
         else:
             self._prepare_f32()
+        if self.ci != 1:
+            self._prepare_edges(net_dev(self.net))
         self.prepared = True
+
+    def _prepare_edges(self, dev):
+        """in_chans != 1 (RGB, network_swinir.py:722-727): conv_first and conv_last run on the exact-f32 3x3 conv kernel
+        with the image channels zero-padded to 4 (its Cin granularity); the padded weights are zero, so the padded channel
+        carries nothing forward or backward."""
+        net, C, D, ci = self.net, self.C, self.derived, self.ci
+        w4 = D.get("first.w4", C, 4, 3, 3, device=dev)
+        w4.zero_()
+        w4[:, :ci].copy_(net.conv_first.weight.data)
+        ops.pack_conv_weight(w4, D.get("first.wp", 9, C, 4, device=dev), D.get("first.wpt", 9, 4, C, device=dev))
+        if not self.direct:
+            nf = net.num_feat
+            w4 = D.get("last.w4", 4, nf, 3, 3, device=dev)
+            b4 = D.get("last.b4", 4, device=dev)
+            w4.zero_()
+            b4.zero_()
+            w4[:ci].copy_(net.conv_last.weight.data)
+            b4[:ci].copy_(net.conv_last.bias.data)
+            ops.pack_conv_weight(w4, D.get("last.wp", 9, 4, nf, device=dev), D.get("last.wpt", 9, nf, 4, device=dev))
 
     def _prepare_bx3(self):
         """bf16x3 planes of every matmul operand + folded biases + bias images, by ONE
@@ -264,12 +290,13 @@ class SwinIREngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, dp=None, save=True):
-        """x: [B,H,W] fp32 cuda, H and W multiples of 8 -> [B,1,s*H,s*W].
-        dp: None or a [2*nblocks, B] tensor of DropPath multipliers."""
+        """x: [B,H,W] fp32 cuda (in_chans 1) or NHWC [B,H,W,4] (in_chans 2..4, zero-padded), H and W multiples of 8
+        -> [B,in_chans,s*H,s*W].  dp: None or a [2*nblocks, B] tensor of DropPath multipliers."""
         if not self.prepared:
             self.prepare()
         net, C, hid, D, ws = self.net, self.C, self.hid, self.derived, self.ws
-        B, H, W = x.shape
+        B, H, W = x.shape[:3]
+        assert x.dim() == (3 if self.ci == 1 else 4) and (self.ci == 1 or x.shape[3] == 4), x.shape
         T = B * H * W
         dev = x.device
         bufs = self.bufs
@@ -292,11 +319,18 @@ class SwinIREngine:
             return c0, c1
 
         f0 = buf("f0", B, H, W, C)
-        ops.conv3x3_cin1_fwd(x, net.conv_first.weight.data, net.conv_first.bias.data, C, out=f0)
+        if self.ci == 1:
+            ops.conv3x3_cin1_fwd(x, net.conv_first.weight.data, net.conv_first.bias.data, C, out=f0)
+        else:
+            ops.conv3x3(x, D.d["first.wp"], net.conv_first.bias.data, C, out=f0)
         st_pe = buf("st_pe", T, 2)
         t = buf("t0", T, C)
         ops.layernorm_fwd(f0.view(T, C), st_pe, t, net.patch_embed.norm.weight.data,
                           net.patch_embed.norm.bias.data)
+        if net.ape:     # network_swinir.py:918-919: one [H*W, C] table, the same for every patch of the batch
+            pos = net.absolute_pos_embed.data.view(H * W, C)
+            for b in range(B):
+                ops.axpby(t[b * H * W:(b + 1) * H * W], pos, 1.0, 1.0)
         sv = {"x": x, "f0": f0, "st_pe": st_pe, "blocks": [], "layers": [], "B": B, "H": H, "W": W,
               "dp": dp}
         bi = 0
@@ -368,6 +402,13 @@ class SwinIREngine:
         r = self.scale
         y = torch.empty(B, net.in_chans, H * r, W * r, device=dev) if not save else \
             buf("y", B, net.in_chans, H * r, W * r)
+        def conv_last(src, h, w):
+            if self.ci == 1:
+                ops.conv3x3_cout1_fwd(src, net.conv_last.weight.data, net.conv_last.bias.data, out=y.view(B, h, w))
+                return
+            o4 = ops.conv3x3(src, D.d["last.wp"], D.d["last.b4"], 4, out=buf("last.o4", B, h, w, 4))
+            y.copy_(o4[..., :self.ci].permute(0, 3, 1, 2))      # NHWC (padded to 4) -> NCHW: data movement
+
         if self.direct:     # conv 180 -> s*s, PixelShuffle(s) (network_swinir.py:943-947)
             cu = r * r * net.in_chans
             u = buf("u", B, H, W, cu)
@@ -385,7 +426,7 @@ class SwinIREngine:
             ops.conv3x3(n2, ws["nup2.wp"], net.conv_up2.bias.data, nf, out=a2, epi=6, alpha=0.2)
             a3 = buf("na3", B, 4 * H, 4 * W, nf)
             ops.conv3x3(a2, ws["nhr.wp"], net.conv_hr.bias.data, nf, out=a3, epi=6, alpha=0.2)
-            ops.conv3x3_cout1_fwd(a3, net.conv_last.weight.data, net.conv_last.bias.data, out=y.view(B, 4 * H, 4 * W))
+            conv_last(a3, 4 * H, 4 * W)
             if save:
                 sv["near"] = (u, n1, a1, n2, a2, a3)
         elif not save and self._eval_tail_ok():
@@ -421,7 +462,7 @@ class SwinIREngine:
                 ops.pixel_shuffle(c, 2, nhwc_out=True, out=u)
                 h, w = 2 * h, 2 * w
                 ups.append(u)
-            ops.conv3x3_cout1_fwd(u, net.conv_last.weight.data, net.conv_last.bias.data, out=y.view(B, h, w))
+            conv_last(u, h, w)
             if save:
                 sv["ups"] = ups
         if save:
@@ -431,8 +472,8 @@ class SwinIREngine:
 
     # ------------------------------------------------------------------ backward
     def backward(self, dy, grads, need_dx=False, on_layer_done=None, grads_zeroed=False):
-        """dy: [B,1,s*H,s*W]; grads: dict name -> tensor to receive the parameter
-        gradient (overwritten).  Returns d loss / d x [B,H,W] if need_dx."""
+        """dy: [B,in_chans,s*H,s*W]; grads: dict name -> tensor to receive the parameter
+        gradient (overwritten).  Returns d loss / d x in the layout forward() took if need_dx."""
         sv = self.saved
         assert sv is not None, "backward() without a saved forward"
         net, C, hid, D, ws = self.net, self.C, self.hid, self.derived, self.ws
@@ -449,6 +490,23 @@ class SwinIREngine:
         def G(name):
             return grads[name]
 
+        def conv_last_bwd(src, h, w, gsrc):
+            """conv_last: parameter gradients, and gsrc = d loss / d src"""
+            if self.ci == 1:    # 64 -> 1: the 1-channel kernels with the roles of x / dy swapped and flipped taps
+                dyv = dy.reshape(B, h, w).contiguous()
+                ops.conv3x3_cin1_wgrad(dyv, src, G("conv_last.weight"), None, flip=True)
+                ops.sum_into(dyv, G("conv_last.bias"))
+                ops.conv3x3_cin1_fwd(dyv, net.conv_last.weight.data, None, net.num_feat, out=gsrc, flip=True)
+                return
+            g4 = buf("last.g4", B, h, w, 4)         # NCHW -> NHWC padded to 4 channels: data movement
+            g4.zero_()
+            g4[..., :self.ci].copy_(dy.permute(0, 2, 3, 1))
+            dw4, db4 = buf("last.dw4", 4, net.num_feat, 3, 3), buf("last.db4", 4)
+            ops.conv3x3_wgrad(g4, src, dw4, db4)
+            G("conv_last.weight").copy_(dw4[:self.ci])
+            G("conv_last.bias").copy_(db4[:self.ci])
+            ops.conv3x3(g4, D.d["last.wpt"], None, net.num_feat, out=gsrc)
+
         df = buf("df", B, H, W, C)
         if self.direct:
             du = buf("du", B, H, W, cu)
@@ -459,11 +517,8 @@ class SwinIREngine:
             nf = net.num_feat
             u, n1, a1, n2, a2, a3 = sv["near"]
             h, w = 4 * H, 4 * W
-            dyv = dy.reshape(B, h, w).contiguous()
-            ops.conv3x3_cin1_wgrad(dyv, a3, G("conv_last.weight"), None, flip=True)
-            ops.sum_into(dyv, G("conv_last.bias"))
             g3 = buf("ng3", B, h, w, nf)
-            ops.conv3x3_cin1_fwd(dyv, net.conv_last.weight.data, None, nf, out=g3, flip=True)
+            conv_last_bwd(a3, h, w, g3)
             ops.leaky_relu_mask(g3, a3, 0.2)
             ops.conv3x3_wgrad(g3, a2, G("conv_hr.weight"), G("conv_hr.bias"))
             g2 = buf("ng2", B, h, w, nf)
@@ -484,12 +539,8 @@ class SwinIREngine:
         else:
             nf, ups = net.num_feat, sv["ups"]
             h, w = H * r, W * r
-            dyv = dy.reshape(B, h, w).contiguous()
-            # conv_last 64 -> 1: the 1-channel kernels with the roles of x / dy swapped and flipped taps
-            ops.conv3x3_cin1_wgrad(dyv, ups[-1], G("conv_last.weight"), None, flip=True)
-            ops.sum_into(dyv, G("conv_last.bias"))
             g = buf(f"dupu{self.stages}", B, h, w, nf)
-            ops.conv3x3_cin1_fwd(dyv, net.conv_last.weight.data, None, nf, out=g, flip=True)
+            conv_last_bwd(ups[-1], h, w, g)
             for i in reversed(range(self.stages)):
                 h, w = h // 2, w // 2
                 dc = buf(f"dupc{i}", B, h, w, 4 * nf)
@@ -651,10 +702,22 @@ class SwinIREngine:
             if on_layer_done is not None:   # this layer's gradients are enqueued
                 on_layer_done(len(net.layers) - 1 - li)
         # patch_embed.norm and the conv_after_body skip (f = conv(..) + f0)
+        if net.ape:     # d table = sum over the batch of the token gradient
+            dpos = G("absolute_pos_embed").view(H * W, C)
+            dpos.copy_(dt[:H * W])
+            for b in range(1, B):
+                ops.axpby(dpos, dt[b * H * W:(b + 1) * H * W], 1.0, 1.0)
         df0 = buf("df0", T, C)
         ops.layernorm_bwd(dt, sv["f0"].view(T, C), sv["st_pe"], df0, res=df.view(T, C),
                           gamma=net.patch_embed.norm.weight.data, dgamma=G("patch_embed.norm.weight"),
                           dbeta=G("patch_embed.norm.bias"))
+        if self.ci != 1:
+            dw4 = buf("first.dw4", C, 4, 3, 3)
+            ops.conv3x3_wgrad(df0.view(B, H, W, C), sv["x"], dw4, G("conv_first.bias"))
+            G("conv_first.weight").copy_(dw4[:, :self.ci])
+            if need_dx:     # in the layout of the input: NHWC, 4 channels (the padded one receives an exact zero)
+                return ops.conv3x3(df0.view(B, H, W, C), D.d["first.wpt"], None, 4)
+            return None
         ops.conv3x3_cin1_wgrad(sv["x"], df0.view(B, H, W, C), G("conv_first.weight"),
                                G("conv_first.bias"))
         if need_dx:

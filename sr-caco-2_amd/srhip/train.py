@@ -343,6 +343,7 @@ class TrainStep:
         # SwinIR.forward multiplies the input by img_range and divides the output by it (network_swinir.py:935,968; the mean
         # is zero for one channel): prepare_input does the first, the step scales y before the loss and dy behind it
         self.inv_range = 1.0 / float(getattr(net, "img_range", 1.) or 1.)
+        self._mean_img = None
         self.dy = None
 
     def _make_buckets(self):
@@ -470,14 +471,20 @@ class TrainStep:
     def _enqueue(self, lr_img, hr_img, dp, host_side, weight=None):
         net = self.net
         xi, h, w = net.prepare_input(lr_img)
-        assert (h, w) == tuple(xi.shape[1:]), \
+        assert (h, w) == tuple(xi.shape[1:3]), \
             "training patches must not need padding (SwinIR: multiples of the 8x8 window)"
         self.flag.zero_()
         self.sync_buffers()
         if dp is None:
             dp = net.sample_drop_path(xi.shape[0], xi.device)
         y = net.engine.forward(xi, dp, save=True)
-        if self.inv_range != 1.0:
+        mean = getattr(net, "mean", None)
+        if torch.is_tensor(mean) and bool((mean != 0).any()):
+            # y / img_range + mean (network_swinir.py:968; RGB only): the mean as an image, one launch with the scale
+            if self._mean_img is None or self._mean_img.shape != y.shape:
+                self._mean_img = mean.to(y).expand_as(y).contiguous()
+            ops.axpby(y, self._mean_img, 1.0, self.inv_range)
+        elif self.inv_range != 1.0:
             ops.axpby(y, y, self.inv_range, 0.0)
         inter = getattr(net.engine, "intermediate_outs", None)
         d_inter = None

@@ -322,6 +322,73 @@ def test_3conv_residual_connection_vs_reference_golden_and_oracle(SwinIR):
     assert worst_tab[1] <= 2e-4, worst_tab       # measured 6.8e-7 (float32 summation order of 4096 signed entries)
 
 
+def test_absolute_position_embedding_vs_reference_golden(SwinIR):
+    """ape=True (network_swinir.py:812-815, 918-919): the learned [1, img_size^2, C] table added to the tokens after
+    patch_embed.norm, its gradient the batch sum of the token gradient.  Reference golden g42: state_dict keys / order
+    (the table comes first), eval forward, dL/dx, every gradient; an input that is not img_size x img_size fails as
+    the reference's broadcast does."""
+    g = load("g42_swinir_ape")
+    net = SwinIR(upscale=2, in_chans=1, img_size=16, window_size=8, depths=[2, 2], embed_dim=60,
+                 num_heads=[6, 6], mlp_ratio=2, upsampler="pixelshuffledirect", drop_path_rate=0.0, ape=True)
+    assert list(net.state_dict().keys()) == list(sub(g, "sd/").keys())
+    assert "absolute_pos_embed" in net.no_weight_decay()
+    net.load_state_dict(sub(g, "sd/"), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(g["x"].cuda()).cpu()
+        with pytest.raises(RuntimeError):
+            net(torch.rand(1, 1, 16, 24).cuda())
+    assert y.shape == g["y_eval"].shape and (y - g["y_eval"]).abs().max() <= 1e-5
+    net.train()
+    x = g["x"].cuda().requires_grad_(True)
+    (net(x) - g["target"].cuda()).abs().mean().backward()
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert l2(x.grad.cpu(), g["dx"]) <= 2e-4
+    worst = ("", 0.0)
+    for k, p in net.named_parameters():
+        e = l2(p.grad.cpu(), g["grad/" + k])
+        assert e <= 2e-4, f"grad {k}: relative L2 error {e:.2e}"
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    print("ape tiny: worst grad", worst, "table", l2(net.absolute_pos_embed.grad.cpu(), g["grad/absolute_pos_embed"]))
+
+
+@pytest.mark.parametrize("name,ups", [("g43_swinir_rgb_direct", "pixelshuffledirect"),
+                                      ("g44_swinir_rgb_pixelshuffle", "pixelshuffle")])
+def test_three_image_channels_vs_reference_golden(SwinIR, name, ups):
+    """in_chans=3 (network_swinir.py:722-727, 934-935, 968): the RGB mean and img_range around the network, conv_first 3 -> C
+    and conv_last 64 -> 3 on the exact-f32 conv kernel with the image channels zero-padded to 4.  Reference goldens
+    g43 / g44: keys / order, eval forward, dL/dx, every gradient; the fused training step (srhip/train.py) lands on the
+    same gradients."""
+    from srhip.train import TrainStep
+    g = load(name)
+    net = SwinIR(upscale=2, in_chans=3, img_size=16, window_size=8, depths=[2], embed_dim=60, num_heads=[6], mlp_ratio=2,
+                 upsampler=ups, drop_path_rate=0.0, img_range=2.0)
+    assert list(net.state_dict().keys()) == list(sub(g, "sd/").keys())
+    net.load_state_dict(sub(g, "sd/"), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(g["x"].cuda()).cpu()
+    assert y.shape == g["y_eval"].shape and (y - g["y_eval"]).abs().max() <= 1e-5
+    net.train()
+    x = g["x"].cuda().requires_grad_(True)
+    (net(x) - g["target"].cuda()).abs().mean().backward()
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert l2(x.grad.cpu(), g["dx"]) <= 2e-4
+    worst = ("", 0.0)
+    for k, p in net.named_parameters():
+        e = l2(p.grad.cpu(), g["grad/" + k])
+        assert e <= 2e-4, f"grad {k}: relative L2 error {e:.2e}"
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    print(name, "worst grad", worst)
+    # the fused step: loss and gradients of the same batch
+    step = TrainStep(net, [("l1", 1.0)], dict(kind="adam", lr=0.0))
+    loss = step.loss_and_grads_only(g["x"].cuda(), g["target"].cuda()) if hasattr(step, "loss_and_grads_only") else None
+    if loss is not None:
+        ref = (g["y_train"] - g["target"]).abs().mean().item() if "y_train" in g else None
+        for k, v in step.named_grads():
+            assert l2(v.cpu(), g["grad/" + k]) <= 2e-4, k
+
+
 def test_step_graph_replays_the_eager_step_bit_for_bit(SwinIR):
     """TrainStep.step_graph (one hipGraph replay per step) against TrainStep.step (~70 launches for this net):
     20 steps from the same weights on a changing batch, SGD-Nesterov with a MyStepLR schedule that halves the rate
