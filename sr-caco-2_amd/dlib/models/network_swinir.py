@@ -167,8 +167,8 @@ class SwinIR(nn.Module):
             unsupported.append(f"upscale={upscale} with 'pixelshuffle' (HIP path: powers of two)")
         if resi_connection not in (constants.R_CONNECTION_1CONV, constants.R_CONNECTION_3CONV):
             unsupported.append(f"resi_connection={resi_connection!r} (HIP path: '1conv', '3conv')")
-        if not patch_norm or not qkv_bias or qk_scale is not None or drop_rate or attn_drop_rate:
-            unsupported.append("patch_norm=False / qkv_bias=False / qk_scale / dropout")
+        if not patch_norm or not qkv_bias or qk_scale is not None:
+            unsupported.append("patch_norm=False / qkv_bias=False / qk_scale")
         if embed_dim > 256 or (embed_dim // num_heads[0]) not in (10, 16, 30, 32):
             unsupported.append(f"embed_dim={embed_dim} / heads={num_heads}")
         if unsupported:
@@ -184,6 +184,9 @@ class SwinIR(nn.Module):
             self.mean = torch.Tensor((0.4488, 0.4371, 0.4040)).view(1, 3, 1, 1)
         else:
             self.mean = torch.zeros(1, 1, 1, 1)
+        # nn.Dropout (pos_drop, Mlp.drop, proj_drop, attn_drop; network_swinir.py:48-56, 113-117, 817) is the identity in
+        # evaluation mode, which runs as is; a training-mode forward with a non-zero rate raises (sample_drop_path)
+        self.drop_rate, self.attn_drop_rate = float(drop_rate), float(attn_drop_rate)
         self.ape = bool(ape)
         if self.ape:    # network_swinir.py:812-815 (patch_size 1: one row per pixel of an img_size patch)
             self.absolute_pos_embed = nn.Parameter(torch.zeros(1, self.img_size[0] * self.img_size[1], embed_dim))
@@ -258,6 +261,9 @@ class SwinIR(nn.Module):
     def sample_drop_path(self, batch, device):
         """timm DropPath semantics (per-sample Bernoulli(keep)/keep), one row per
         (block, branch); None when nothing is dropped."""
+        if self.training and (self.drop_rate or self.attn_drop_rate):
+            raise NotImplementedError("SwinIR on libsrhip: drop_rate / attn_drop_rate > 0 in training mode (the dropout masks "
+                                      "are not implemented; evaluation, where dropout is the identity, runs)")
         probs = [b.drop_prob for b in self.swin_blocks()]
         if not self.training or max(probs) == 0.0:
             return None

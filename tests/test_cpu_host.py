@@ -73,7 +73,21 @@ def test_cpu_tensors_fail_loudly():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         metrics.mbatch_gpu_calculate_psnr(torch.rand(1, 1, 32, 32), torch.rand(1, 1, 32, 32))
     with pytest.raises(NotImplementedError):
-        SwinIR(upscale=4, in_chans=3, img_size=64, window_size=8, upsampler="pixelshuffle")
+        SwinIR(upscale=4, in_chans=1, img_size=64, window_size=7, upsampler="pixelshuffle")
+    # dropout rates: accepted (evaluation is the identity), a training-mode forward refuses
+    nd = SwinIR(upscale=2, in_chans=1, img_size=16, window_size=8, depths=[2], embed_dim=60, num_heads=[6], mlp_ratio=2,
+                upsampler="pixelshuffledirect", drop_rate=0.1, attn_drop_rate=0.1)
+    assert nd.eval().sample_drop_path(2, "cpu") is None
+    with pytest.raises(NotImplementedError, match="drop_rate"):
+        nd.train().sample_drop_path(2, "cpu")
+    # RGB and the absolute position embedding: the reference's parameter names, order and shapes (goldens g42 / g44)
+    for name, kw in (("g42_swinir_ape", dict(in_chans=1, depths=[2, 2], num_heads=[6, 6], upsampler="pixelshuffledirect", ape=True)),
+                     ("g44_swinir_rgb_pixelshuffle", dict(in_chans=3, depths=[2], num_heads=[6], upsampler="pixelshuffle", img_range=2.0))):
+        z = np.load(os.path.join(G, name + ".npz"))
+        ref = {k[3:]: z[k].shape for k in z.files if k.startswith("sd/")}
+        net = SwinIR(upscale=2, img_size=16, window_size=8, embed_dim=60, mlp_ratio=2, **kw)
+        assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == list(ref.items())
+    assert torch.equal(net.mean.flatten(), torch.tensor([0.4488, 0.4371, 0.4040]))
 
 
 def test_state_dict_layouts_match_reference():

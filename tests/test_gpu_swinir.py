@@ -380,13 +380,44 @@ def test_three_image_channels_vs_reference_golden(SwinIR, name, ups):
         assert e <= 2e-4, f"grad {k}: relative L2 error {e:.2e}"
         worst = max(worst, (k, e), key=lambda t: t[1])
     print(name, "worst grad", worst)
-    # the fused step: loss and gradients of the same batch
-    step = TrainStep(net, [("l1", 1.0)], dict(kind="adam", lr=0.0))
-    loss = step.loss_and_grads_only(g["x"].cuda(), g["target"].cuda()) if hasattr(step, "loss_and_grads_only") else None
-    if loss is not None:
-        ref = (g["y_train"] - g["target"]).abs().mean().item() if "y_train" in g else None
-        for k, v in step.named_grads():
-            assert l2(v.cpu(), g["grad/" + k]) <= 2e-4, k
+    # the fused step (y / img_range + mean in front of the loss): loss and gradients of the same batch
+    from srhip.train import Optimizer
+    net.load_state_dict(sub(g, "sd/"), strict=True)
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=1e-12, momentum=0.0, nesterov=False, wd=0.0)
+    ts.step(g["x"].cuda(), g["target"].cuda())
+    torch.cuda.synchronize()
+    ref_loss = (g["y_eval"] - g["target"]).abs().mean().item()
+    assert abs(ts.loss_buf[1].item() - ref_loss) <= 1e-5 * max(1.0, ref_loss), (ts.loss_buf, ref_loss)      # [total, terms...]
+    for k, _ in net.named_parameters():
+        assert l2(ts.fp.gviews[k].cpu(), g["grad/" + k]) <= 2e-4, k
+
+
+def test_three_image_channels_nearest_conv_vs_oracle(SwinIR):
+    """in_chans=3 with the 'nearest_conv' tail (x4): forward and every gradient against the oracle's autograd (the oracle
+    is pinned to the reference on this tail by g25 and on RGB by g43 / g44)."""
+    cfg = O.swinir_config(upscale=4, in_chans=3, img_size=16, window_size=8, depths=(2,), embed_dim=60, num_heads=(6,),
+                          mlp_ratio=2, upsampler="nearest_conv", drop_path_rate=0.0)
+    sd = O.swinir_init_state_dict(cfg, seed=91)
+    net = SwinIR(upscale=4, in_chans=3, img_size=16, window_size=8, depths=[2], embed_dim=60, num_heads=[6], mlp_ratio=2,
+                 upsampler="nearest_conv", drop_path_rate=0.0)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    gen = torch.Generator().manual_seed(92)
+    x, t = torch.rand(2, 3, 16, 16, generator=gen), torch.rand(2, 3, 64, 64, generator=gen)
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg)
+    (y - t.cuda()).abs().mean().backward()
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask") else v)
+           for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = O.swinir_forward(sdo, xo, cfg)
+    (yo - t).abs().mean().backward()
+    assert (y.detach().cpu() - yo.detach()).abs().max() <= 1e-5
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert l2(xg.grad.cpu(), xo.grad) <= 2e-4
+    for k, p in net.named_parameters():
+        assert l2(p.grad.cpu(), sdo[k].grad) <= 2e-4, k
 
 
 def test_step_graph_replays_the_eager_step_bit_for_bit(SwinIR):
