@@ -462,6 +462,11 @@ int srhip_unfold(const float* x, long ldx, float* tok, long ldt, int B, int H, i
 int srhip_fold(const float* tok, long ldt, float* out, long ldo, int B, int H, int W, int C, int k, int s, void* stream);
 int srhip_layernorm_rows(const float* x, long ldx, float* y, long ldy, const float* gamma, const float* beta, long M, int C,
                          float eps, void* stream);
+/* Backward of srhip_layernorm_rows (nn.LayerNorm's autograd, network_act.py:115-133 in training): dx,
+ * dgamma[C], dbeta[C]; rows of at most 2048 values; ws: srhip_layernorm_rows_bwd_ws(M, C) floats; deterministic. */
+long srhip_layernorm_rows_bwd_ws(long M, int C);
+int srhip_layernorm_rows_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma, float* dx, long lddx,
+                             float* dgamma, float* dbeta, float* ws, long M, int C, float eps, void* stream);
 /* y = res + LayerNorm(x), rows of at most 256 values (GRL's post-norm residuals, network_grl.py:1061-1076); y may alias x / res */
 int srhip_layernorm_rows_res(const float* x, long ldx, const float* res, long ldr, float* y, long ldy, const float* gamma,
                              const float* beta, long M, int C, float eps, void* stream);

@@ -1498,7 +1498,7 @@ def g_nlsn():
     from dlib.models.network_nlsn import NLSN as RefNLSN
     out = {}
     cfg = dict(n_resblocks=8, n_feats=64)
-    for scale, hw in ((2, (24, 30)), (4, (20, 24))):
+    for scale, hw in ((2, (24, 30)), (4, (20, 24)), (8, (18, 20))):
         sd = O.nlsn_init_state_dict(scale, 1, seed=350 + scale, **cfg)
         net = RefNLSN(upscale=scale, in_chans=1, n_hashes=4, chunk_size=144, **cfg).eval()
         ref_keys = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
@@ -1673,6 +1673,57 @@ def g_act():
     out["state_dict_keys_default"] = np.array([k for k in RefACT(upscale=2, in_chans=1).state_dict().keys()])
     out["state_dict_shapes_default"] = np.array([str(tuple(v.shape)) for v in RefACT(upscale=2, in_chans=1).state_dict().values()])
     npz("g36_act", **out)
+
+
+def g_act_grad():
+    """ACT training step of the reference: the narrow configuration of g36 at x2 on a 12 x 15 input (15 = 5 tokens of 3; the
+    last row / column of 6 x 6 tokens overlaps) in TRAINING mode, L1 loss against a random target, autograd -> the gradient of
+    every parameter the forward reaches (self- and cross-scale attention, F.fold / F.unfold, LayerNorm over 144 / 288 / 72
+    columns, GELU, the 5 x 5 head convs, RCAN's channel attention, the fusion blocks).  The oracle's own autograd must
+    reproduce them.  Tensors above 8192 entries: two rows in full + sum / sum of magnitudes / largest magnitude."""
+    print("G45 ACT gradients")
+    from dlib.models.network_act import ACT as RefACT
+    out = {}
+    cfg = dict(n_feats=16, n_resgroups=4, n_resblocks=2, reduction=4, n_heads=4, n_layers=8, n_fusionblocks=4)
+    for scale, hw in ((2, (12, 15)),):
+        net = RefACT(upscale=scale, in_chans=1, **cfg)
+        layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        sd = O.seeded_state_dict(layout, 500 + scale)
+        net.load_state_dict(sd, strict=True)
+        net.train()
+        torch.manual_seed(505 + scale)
+        x = torch.rand(2, 1, *hw)
+        tgt = torch.rand(2, 1, hw[0] * scale, hw[1] * scale)
+        y = net(x)
+        loss = (y - tgt).abs().mean()
+        loss.backward()
+        trainable = {k for k, p_ in net.named_parameters() if p_.requires_grad}
+        sdo = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+        yo = O.act_forward(sdo, x, scale, n_feats=16, n_resblocks=2, n_heads=4)
+        (yo - tgt).abs().mean().backward()
+        close(yo, y, 0.0, f"act x{scale} training forward")
+        pre = f"x{scale}/"
+        out[pre + "x"], out[pre + "tgt"], out[pre + "y"], out[pre + "loss"] = x, tgt, y.detach(), loss.detach()
+        out[pre + "seed"] = np.array(500 + scale)
+        n = unused = 0
+        for k, p_ in net.named_parameters():
+            if p_.grad is None:             # frozen MeanShift convs; blocks past n_fusionblocks
+                assert sdo[k].grad is None or float(sdo[k].grad.abs().max()) == 0.0, k
+                unused += 1
+                continue
+            g_o = sdo[k].grad
+            assert g_o is not None, k
+            err = (g_o - p_.grad).abs().max().item()
+            assert err <= 1e-6 * max(1e-3, p_.grad.abs().max().item()), (k, err)
+            if p_.grad.numel() <= 8192:
+                out[pre + "grad/" + k] = p_.grad
+            else:
+                out[pre + "gslice/" + k] = p_.grad[:2].clone()
+                out[pre + "gsum/" + k] = torch.stack([p_.grad.double().sum(), p_.grad.double().abs().sum(), p_.grad.double().abs().max()])
+            n += 1
+        out[pre + "n_grads"] = np.array(n)
+        print(f"  {n} parameter gradients ({unused} parameters the forward does not reach), oracle autograd == reference autograd")
+    npz("g45_act_grad", **out)
 
 
 def g_omnisr():
@@ -2027,7 +2078,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_grl, g_omnisr, g_act, g_dfcan, g_dfcan_grad, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_grl, g_omnisr, g_act, g_act_grad, g_dfcan, g_dfcan_grad, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv, g_swinir_ape, g_swinir_rgb]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

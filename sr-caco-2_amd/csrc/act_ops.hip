@@ -54,6 +54,56 @@ __global__ void __launch_bounds__(256) k_layernorm_rows(const float* __restrict_
   float* o = y + m * ldy;
   for (int c = lane; c < C; c += 64) o[c] = (r[c] - mean) * rstd * g[c] + bta[c];
 }
+// backward of nn.LayerNorm over rows of any width (the token branch of ACT in training): with xhat = (x - mean) rstd and
+// u = dy gamma, dx = rstd (u - mean(u) - xhat mean(u xhat)); a wave owns rows m, m + 4 nblk, ...; its sums of dy xhat / dy per
+// column live in its own LDS slice (one lane per column: no atomics, a fixed order), the block's four slices are added into
+// part[block][2][C] and k_ln_rows_bwd_reduce adds the blocks in order
+__global__ void __launch_bounds__(256) k_layernorm_rows_bwd(const float* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                            long ldx, const float* __restrict__ g, float* __restrict__ dx,
+                                                            long lddx, float* __restrict__ part, long M, int C, float eps) {
+  extern __shared__ float acc[];                   // [4 waves][2][C]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* const ag = acc + (long)wave * 2 * C;
+  float* const ab = ag + C;
+  for (int c = lane; c < C; c += 64) { ag[c] = 0.f; ab[c] = 0.f; }
+  for (long m = blockIdx.x * 4L + wave; m < M; m += gridDim.x * 4L) {
+    const float* r = x + m * ldx;
+    const float* d = dy + m * lddy;
+    float s1 = 0.f;
+    for (int c = lane; c < C; c += 64) s1 += r[c];
+    const float mean = wave_sum(s1) / (float)C;
+    float s2 = 0.f;
+    for (int c = lane; c < C; c += 64) { const float t = r[c] - mean; s2 += t * t; }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
+    float su = 0.f, sx = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (r[c] - mean) * rstd, u = d[c] * g[c];
+      su += u;
+      sx += u * xh;
+      ag[c] += d[c] * xh;
+      ab[c] += d[c];
+    }
+    const float mu = wave_sum(su) / (float)C, mx = wave_sum(sx) / (float)C;
+    float* o = dx + m * lddx;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (r[c] - mean) * rstd;
+      o[c] = rstd * (d[c] * g[c] - mu - xh * mx);
+    }
+  }
+  __syncthreads();
+  float* const pb = part + (long)blockIdx.x * 2 * C;
+  for (int c = threadIdx.x; c < 2 * C; c += 256)
+    pb[c] = (acc[c] + acc[2 * C + c]) + (acc[4 * C + c] + acc[6 * C + c]);
+}
+__global__ void __launch_bounds__(256) k_ln_rows_bwd_reduce(const float* __restrict__ part, int nblk, int C,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * C) return;
+  float a = 0.f;
+  for (int b = 0; b < nblk; ++b) a += part[(long)b * 2 * C + c];
+  if (c < C) dgamma[c] = a;
+  else dbeta[c - C] = a;
+}
 // the same for rows of at most 256 values, held in registers (one read of the row), with an optional residual: y = res + LN(x)
 __global__ void __launch_bounds__(256) k_layernorm_rows_reg(const float* __restrict__ x, long ldx, const float* __restrict__ res,
                                                             long ldr, float* __restrict__ y, long ldy, const float* __restrict__ g,
@@ -190,6 +240,23 @@ int srhip_layernorm_rows(const float* x, long ldx, float* y, long ldy, const flo
     hipLaunchKernelGGL(k_layernorm_rows, dim3(sr_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gamma, beta, M, C,
                        eps);
   SR_LAUNCH_CHECK("layernorm_rows");
+  return 0;
+}
+
+static int ln_rows_bwd_blocks(long M) { return (int)(sr_cdiv(M, 4) < 512 ? sr_cdiv(M, 4) : 512); }
+/* floats of workspace srhip_layernorm_rows_bwd takes */
+long srhip_layernorm_rows_bwd_ws(long M, int C) { return M > 0 && C > 0 ? (long)ln_rows_bwd_blocks(M) * 2 * C : 0; }
+/* Backward of srhip_layernorm_rows: dx, dgamma[C], dbeta[C]; rows of at most 2048 values; deterministic. */
+int srhip_layernorm_rows_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma, float* dx, long lddx,
+                             float* dgamma, float* dbeta, float* ws, long M, int C, float eps, void* stream) {
+  SR_REQUIRE(dy && x && gamma && dx && dgamma && dbeta && ws && M > 0 && C > 0 && C <= 2048 && lddy >= C && ldx >= C && lddx >= C,
+             "layernorm_rows_bwd: bad arguments (rows of at most 2048 values; C=%d)", C);
+  const int nblk = ln_rows_bwd_blocks(M);
+  hipLaunchKernelGGL(k_layernorm_rows_bwd, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), (hipStream_t)stream, dy, lddy, x,
+                     ldx, gamma, dx, lddx, ws, M, C, eps);
+  SR_LAUNCH_CHECK("layernorm_rows_bwd");
+  hipLaunchKernelGGL(k_ln_rows_bwd_reduce, dim3(sr_cdiv(2 * C, 256)), dim3(256), 0, (hipStream_t)stream, ws, nblk, C, dgamma, dbeta);
+  SR_LAUNCH_CHECK("layernorm_rows_bwd_reduce");
   return 0;
 }
 

@@ -54,21 +54,21 @@ def define_G(args):
         return net(upscale=opt_net[f'{nt}_upscale'], in_chans=opt_net[f'{nt}_in_chans'],
                    num_features=opt_net[f'{nt}_num_features'], num_steps=opt_net[f'{nt}_num_steps'],
                    num_groups=opt_net[f'{nt}_num_groups'])
-    if net_type == constants.ENLCN:                 # select_network.py:92-101 (evaluation only here)
+    if net_type == constants.ENLCN:                 # select_network.py:92-101
         from dlib.models.network_enlcn import ENLCN as net
         return net(upscale=opt_net[f'{nt}_upscale'], n_resblock=opt_net[f'{nt}_n_resblock'],
                    n_feats=opt_net[f'{nt}_n_feats'], res_scale=opt_net[f'{nt}_res_scale'],
                    img_range=opt_net[f'{nt}_img_range'], in_chans=opt_net[f'{nt}_in_chans'])
-    if net_type == constants.NLSN:                  # select_network.py:149-160 (evaluation only here)
+    if net_type == constants.NLSN:                  # select_network.py:149-160
         from dlib.models.network_nlsn import NLSN as net
         return net(upscale=opt_net[f'{nt}_upscale'], n_resblocks=opt_net[f'{nt}_n_resblocks'],
                    n_feats=opt_net[f'{nt}_n_feats'], n_hashes=opt_net[f'{nt}_n_hashes'],
                    chunk_size=opt_net[f'{nt}_chunk_size'], res_scale=opt_net[f'{nt}_res_scale'],
                    img_range=opt_net[f'{nt}_img_range'], in_chans=opt_net[f'{nt}_in_chans'])
-    if net_type == constants.DFCAN:                 # select_network.py:162-167 (evaluation only here)
+    if net_type == constants.DFCAN:                 # select_network.py:162-167
         from dlib.models.network_dfcan import DFCAN as net
         return net(input_shape=opt_net[f'{nt}_in_chans'], upscale=opt_net[f'{nt}_upscale'])
-    if net_type == constants.ACT:                   # select_network.py:52-68 (evaluation only here)
+    if net_type == constants.ACT:                   # select_network.py:52-68
         from dlib.models.network_act import ACT as net
         return net(**{k: opt_net[f'{nt}_{k}'] for k in ('upscale', 'in_chans', 'img_range', 'n_feats', 'n_resgroups',
                                                         'n_resblocks', 'reduction', 'n_heads', 'n_layers', 'dropout_rate',

@@ -1,16 +1,19 @@
-"""ACT on libsrhip, evaluation forward (reference dlib/models/network_act.py:321-541): a CNN branch (RCAN residual groups)
+"""ACT on libsrhip (reference dlib/models/network_act.py:321-541): a CNN branch (RCAN residual groups)
 and a transformer branch (3 x 3 tokens, self-attention + cross-scale attention against overlapping 6 x 6 tokens) that
 exchange features in four fusion blocks.  Written directly over the libsrhip ops: 3 x 3 convs on the split-MFMA conv
 kernels, the 5 x 5 head convs as im2col (srhip_unfold) + GEMM, Linears on the split-MFMA GEMMs (weight planes: srhip/planes.py), 1 x 1 convs on the exact-f32 GEMM, the attention's
 (sample, head) products as two batched launches (srhip_gemm_nt_batched) around srhip_softmax_rows, F.unfold / F.fold as srhip_unfold / srhip_fold, RCAN's channel
-attention as srhip_channel_gate.  Inference only."""
+attention as srhip_channel_gate.  Training (save=True) runs the same graph on the tape of srhip/tape.py (_forward_tape): the
+backward of every op is derived there from kernels of this library (the attention products transposed, F.fold / F.unfold as
+each other's adjoints, srhip_layernorm_rows_bwd, srhip_softmax_rows_bwd)."""
 import math
 
 import torch
 
 from . import ops
 from .planes import PlaneCache
-from .tape import WeightBank
+from .swinir_engine import _Bufs
+from .tape import Tape, WeightBank
 
 
 class ACTEngine:
@@ -18,6 +21,7 @@ class ACTEngine:
         self.net = net
         self.bank = WeightBank()
         self.planes = PlaneCache()
+        self.bufs = _Bufs()
         self.prepared = False
         self.saved = None
         self.taps = None          # tests: dict that receives intermediate tensors (names as oracle.act_forward's taps)
@@ -145,10 +149,10 @@ class ACTEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x3, dp=None, save=False):
-        if save:
-            raise NotImplementedError("ACT on libsrhip: inference only (BASELINE config 5's evaluation sweep); no backward")
         if not self.prepared:
             self.prepare()
+        if save:
+            return self._forward_tape(x3)
         net = self.net
         B, H, W = x3.shape
         dev = x3.device
@@ -255,5 +259,140 @@ class ACTEngine:
         y = ops.conv3x3_cout1_fwd(x, net.tail[1].weight.data, net.tail[1].bias.data)
         return y.view(B, 1, y.shape[1], y.shape[2])
 
-    def backward(self, *a, **k):
-        raise NotImplementedError("ACT on libsrhip: inference only (BASELINE config 5's evaluation sweep); no backward")
+    # ------------------------------------------------------------------ training: the same graph on the tape
+    def _forward_tape(self, x3):
+        """forward() op for op with the tape recording (srhip/tape.py): 3 x 3 convs on the bank's planes, everything on
+        token rows (Linears, 1 x 1 convs, the attention products) on the exact-f32 GEMMs."""
+        net = self.net
+        t = Tape(self.bufs, self.bank, True, x3.device)
+        nm = {id(p): k for k, p in net.named_parameters()}
+        N = lambda p: nm[id(p)]
+        B, H, W = x3.shape
+        nf, ts, emb = net.n_feats, net.token_size, net.embedding_dim
+        half = emb // 2
+        ch = half // (ts * ts)
+        nTy, nTx = (H - ts) // ts + 1, (W - ts) // ts + 1
+        T = nTy * nTx
+        TL = ((H - 2 * ts) // ts + 1) * ((W - 2 * ts) // ts + 1)
+
+        def lin(x, m):
+            return t.linear(x, m.weight, m.bias, N(m.weight), None if m.bias is None else N(m.bias))
+
+        def ln(x, m):
+            return t.layernorm_rows(x, m, N(m.weight), N(m.bias))
+
+        def c3(x, key, mod, **kw):
+            return t.conv(x, key, (N(mod.weight), N(mod.bias)), **kw)
+
+        def self_attention(blk, x):
+            qkv = lin(ln(x, blk.norm), blk.fn.to_qkv)
+            inner = net.n_heads * net.dim_head
+            o = t.attend(t.cols(qkv, 0, inner), t.cols(qkv, inner, 2 * inner), t.cols(qkv, 2 * inner, 3 * inner), B, T, T,
+                         net.n_heads, net.dim_head, net.dim_head ** -0.5)
+            return lin(o, blk.fn.to_out[0])
+
+        def cross_attention(blk, xq, xkv, Tq, Tk):
+            heads = net.n_heads // 2
+            inner = heads * net.dim_head
+            q = lin(ln(xq, blk.norm), blk.fn.to_q)
+            kv = lin(ln(xkv, blk.norm2), blk.fn.to_kv)
+            o = t.attend(q, t.cols(kv, 0, inner), t.cols(kv, inner, 2 * inner), B, Tq, Tk, heads, net.dim_head, net.dim_head ** -0.5)
+            return lin(o, blk.fn.to_out[0])
+
+        def ffn(blk, x):
+            return lin(t.unary(lin(ln(x, blk.norm), blk.fn.net[0]), "gelu"), blk.fn.net[3])
+
+        def ln_mlp(seq, x):
+            return lin(t.unary(lin(ln(x, seq[0]), seq[1]), "gelu"), seq[3])
+
+        xv = t.conv_in1(x3, net.head[0].weight, net.head[0].bias, (N(net.head[0].weight), N(net.head[0].bias)))
+        for j in (1, 2):
+            b0, b2 = net.head[j].body[0], net.head[j].body[2]
+            r = t.conv_im2col(xv, b0.weight, b0.bias, N(b0.weight), N(b0.bias), 5, relu=True)
+            r = t.conv_im2col(r, b2.weight, b2.bias, N(b2.weight), N(b2.bias), 5)
+            xv = t.axpby(r, xv)
+        identity = xv
+        tk = t.unfold(xv, ts, ts)
+        tk = t.axpby(tk, lin(tk, net.linear_encoding))
+        f = None
+        for i in range(net.n_fusionblocks):
+            tk = t.axpby(tk, self_attention(net.mhsa_block[i][0], tk))
+            tk = t.axpby(tk, ffn(net.mhsa_block[i][1], tk))
+            ta = t.cols(tk, 0, half)
+            img = t.fold(t.cols(tk, half, emb), ch, ts, ts, B, H, W)
+            tb = t.unfold(img, 2 * ts, ts)
+            cs = net.csta_block[i]
+            tb = ln_mlp(cs[0], tb)
+            ta_new = t.axpby(cross_attention(cs[1], ta, tb, T, TL), ta)
+            tb_new = t.axpby(cross_attention(cs[2], tb, ta, TL, T), tb)
+            tb = ln_mlp(cs[3], tb_new)
+            img = t.fold(tb, ch, 2 * ts, ts, B, H, W)
+            tk = t.cat_cols([ta_new, t.unfold(img, ts, ts)])
+            tk = t.axpby(tk, ffn(cs[4], tk))
+            rg = net.cnn_branch[i]
+            x0 = xv
+            for r in range(net.n_resblocks):
+                m = rg.body[r]
+                pre = f"cnn_branch.{i}.body.{r}.body"
+                a = c3(xv, pre + ".0", m.body[0], relu=True)
+                a = c3(a, pre + ".2", m.body[2])
+                ca = m.body[3].conv_du
+                xv = t.rcan_gate(a, xv, ca[0].weight, ca[0].bias, ca[2].weight, ca[2].bias,
+                                 (N(ca[0].weight), N(ca[0].bias), N(ca[2].weight), N(ca[2].bias)))
+            last = rg.body[net.n_resblocks]
+            xv = c3(xv, f"cnn_branch.{i}.body.{net.n_resblocks}", last, res=(x0, 1.0))
+            tk_res, x_res = tk, xv
+            f = t.cat_cols([xv, t.fold(tk, nf, ts, ts, B, H, W)])
+            f2, f_img = self._rows_of(t, f, B * H * W, 2 * nf)
+            g = f2
+            for j in range(4):
+                fb = net.fusion_block[i][j]
+                r = t.relu(t.linear(g, fb.body[0].weight, None, N(fb.body[0].weight)))
+                g = t.axpby(t.linear(r, fb.body[2].weight, None, N(fb.body[2].weight)), g)
+            f2 = t.axpby(f2, g)
+            f = self._map_of(t, f2, B, H, W, 2 * nf)
+            if i != net.n_fusionblocks - 1:
+                # "x_tkn, x = torch.split(f, n_feats, 1)" (:527): the CNN half goes on as tokens, the token half as the map
+                tk = t.unfold(t.cols(f, 0, nf), ts, ts)
+                tk = t.axpby(ln_mlp(net.fusion_mlp[i], tk), tk_res)
+                fc = net.fusion_cnn[i]
+                xa = c3(t.cols(f, nf, 2 * nf), f"fusion_cnn.{i}.0", fc[0], relu=True)
+                xv = c3(xa, f"fusion_cnn.{i}.2", fc[2], res=(x_res, 1.0))
+        xv = c3(f, "conv_last", net.conv_last, res=(identity, 1.0))
+        F = nf
+        for st in range(int(math.log2(net.upscale))):
+            c = net.tail[0][2 * st]
+            parts = [t.conv(xv, f"tail.0.{2 * st}.{j}", (N(c.weight), N(c.bias), (j * F, (j + 1) * F))) for j in range(4)]
+            xv = t.shuffle(t.cat_cols(parts), 2)
+        out = t.conv_out1(xv, net.tail[1].weight, net.tail[1].bias, (N(net.tail[1].weight), N(net.tail[1].bias)))
+        self.saved = (t, out)
+        Bo, Ho, Wo = out.t.shape
+        return out.t.view(Bo, 1, Ho, Wo)
+
+    @staticmethod
+    def _rows_of(t, v, M, C):
+        """an NHWC map as token rows [M, C] (a reshape: the gradient flows through a view of the same shape change)"""
+        r = t.var(v.t.reshape(M, C))
+        if t.save:
+            def bwd(v=v, r=r):
+                if r.g is not None:
+                    t.acc(v, lambda o: o.copy_(r.g.view(o.shape)))
+            t.back.append(bwd)
+        return r, v
+
+    @staticmethod
+    def _map_of(t, r, B, H, W, C):
+        m = t.var(r.t.view(B, H, W, C))
+        if t.save:
+            def bwd(r=r, m=m):
+                if m.g is not None:
+                    t.acc(r, lambda o: o.copy_(m.g.reshape(o.shape)))
+            t.back.append(bwd)
+        return m
+
+    def backward(self, dy, grads, need_dx=False, on_layer_done=None, grads_zeroed=False):
+        assert self.saved is not None, "backward() without a saved forward"
+        assert not need_dx, "ACT: no gradient with respect to the input image"
+        tape, out = self.saved
+        tape.backward(out, dy.reshape(out.t.shape).contiguous(), grads)
+        return None

@@ -501,6 +501,17 @@ def layernorm_rows(x, gamma, beta, out, eps=1e-5):
     return out
 
 
+def layernorm_rows_bwd(dy, x, gamma, dx, dgamma, dbeta, eps=1e-5):
+    """backward of layernorm_rows: dx [M, C], dgamma [C], dbeta [C] from dy / x (2-D views, rows of at most 2048 values)."""
+    _chk(dy, x, gamma, dx, dgamma, dbeta)
+    assert x.dim() == 2 and dy.shape == x.shape == dx.shape and x.stride(1) == 1 and dy.stride(1) == 1 and dx.stride(1) == 1
+    M, C = x.shape
+    ws = SCRATCH.get("ln_rows_bwd_ws", lib.srhip_layernorm_rows_bwd_ws(M, C), device=x.device)
+    call("srhip_layernorm_rows_bwd", _p(dy), dy.stride(0), _p(x), x.stride(0), _p(gamma), _p(dx), dx.stride(0), _p(dgamma),
+         _p(dbeta), _p(ws), M, C, float(eps), _st())
+    return dx
+
+
 def layernorm_rows_res(x, res, gamma, beta, out, eps=1e-5):
     """out = res + nn.LayerNorm(x) over the rows of 2-D views of at most 256 columns; out may be x or res."""
     _chk(x, res, gamma, beta, out)

@@ -684,6 +684,248 @@ class Tape:
             self.back.append(gate_bwd)
         return out
 
+    # ---- ops on token matrices and their maps to / from feature maps (ACT's transformer branch in training)
+    @staticmethod
+    def _c(t):
+        return t if t.is_contiguous() else t.contiguous()
+
+    def linear(self, x, weight, bias, wname, bname=None):
+        """nn.Linear / a 1x1 conv on rows: x [M, K] -> [M, N] on the exact-f32 GEMM; weight [N, K(, 1, 1)]."""
+        w = weight.data.reshape(weight.shape[0], -1)
+        N, K = w.shape
+        xin = self._c(x.t)
+        M = xin.shape[0]
+        assert xin.shape == (M, K), (wname, xin.shape, w.shape)
+        y = self.new(M, N)
+        ops.gemm_nt(xin, w, None if bias is None else bias.data, out=y)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out, xin=xin, w=w):
+                if out.g is None:
+                    return
+                g = self._c(out.g)
+                dW, db = self._tmp(N, K), self._tmp(N)
+                ops.linear_wgrad(g, xin, dW, db)
+                self.gparam(wname, lambda o: o.view(N, K).copy_(dW))
+                if bname:
+                    self.gparam(bname, lambda o: o.copy_(db))
+                if x.need:
+                    wT = w.t().contiguous()
+                    self.acc(x, lambda o: ops.gemm_nt(g, wT, None, out=o))
+            self.back.append(bwd)
+        return out
+
+    def layernorm_rows(self, x, ln, gname, bname):
+        """nn.LayerNorm over the rows of x [M, C] (any C up to 2048)."""
+        xin = self._c(x.t)
+        y = self.new(*xin.shape)
+        ops.layernorm_rows(xin, ln.weight.data, ln.bias.data, y, eps=ln.eps)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out, xin=xin):
+                if out.g is None:
+                    return
+                C = xin.shape[1]
+                dx, dg, db = self._tmp(*xin.shape), self._tmp(C), self._tmp2(C)
+                ops.layernorm_rows_bwd(self._c(out.g), xin, ln.weight.data, dx, dg, db, eps=ln.eps)
+                self.gparam(gname, lambda o: o.copy_(dg))
+                self.gparam(bname, lambda o: o.copy_(db))
+                self.acc(x, lambda o: o.copy_(dx))
+            self.back.append(bwd)
+        return out
+
+    def cols(self, x, lo, hi):
+        """x[..., lo:hi] as its own tensor (torch.split / chunk on the last dim): a copy; the adjoint places the gradient."""
+        y = self.new(*x.t.shape[:-1], hi - lo)
+        y.copy_(x.t[..., lo:hi])
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out):
+                if out.g is None:
+                    return
+
+                def prod(o):
+                    o.zero_()
+                    o[..., lo:hi].copy_(out.g)
+                self.acc(x, prod)
+            self.back.append(bwd)
+        return out
+
+    def cat_cols(self, vs):
+        """torch.cat(vs, dim=-1) of tensors of any rank: copies; the adjoint slices."""
+        Cs = [v.t.shape[-1] for v in vs]
+        z = self.new(*vs[0].t.shape[:-1], sum(Cs))
+        o = 0
+        for v, c in zip(vs, Cs):
+            z[..., o:o + c].copy_(v.t)
+            o += c
+        out = self._out(z)
+        if self.save:
+            def bwd(vs=vs, out=out):
+                if out.g is None:
+                    return
+                o = 0
+                for v, c in zip(vs, Cs):
+                    self.acc(v, lambda dst, o=o, c=c: dst.copy_(out.g[..., o:o + c]))
+                    o += c
+            self.back.append(bwd)
+        return out
+
+    def unfold(self, x, k, s):
+        """F.unfold(x, k, stride=s) of an NHWC map -> token rows [B * nT, C k k]; its adjoint is F.fold."""
+        xin = self._c(x.t)
+        B, H, W, C = xin.shape
+        nT = ((H - k) // s + 1) * ((W - k) // s + 1)
+        y = self.new(B * nT, C * k * k)
+        ops.unfold(xin, C, k, s, 0, y)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out):
+                if out.g is not None:
+                    self.acc(x, lambda o: ops.fold(self._c(out.g), C, k, s, o))
+            self.back.append(bwd)
+        return out
+
+    def fold(self, tok, C, k, s, B, H, W):
+        """F.fold(tok, (H, W), k, stride=s) -> NHWC [B, H, W, C] (overlaps add); its adjoint is F.unfold."""
+        tin = self._c(tok.t)
+        y = self.new(B, H, W, C)
+        ops.fold(tin, C, k, s, y)
+        out = self._out(y)
+        if self.save:
+            def bwd(tok=tok, out=out):
+                if out.g is not None:
+                    self.acc(tok, lambda o: ops.unfold(self._c(out.g), C, k, s, 0, o))
+            self.back.append(bwd)
+        return out
+
+    def conv_im2col(self, x, weight, bias, wname, bname, k, relu=False):
+        """k x k conv (padding k // 2) as im2col + GEMM (ACT's 5 x 5 head convs, network_act.py:362-364).  Backward: the
+        weight gradient from the re-made patch matrix, the data gradient as the same conv of the gradient with the flipped,
+        transposed kernel."""
+        xin = self._c(x.t)
+        B, H, W, C = xin.shape
+        Co = weight.shape[0]
+        T = B * H * W
+        assert T * C * k * k < (1 << 29), "conv_im2col: the patch matrix of this batch passes 2 GiB"
+        colsb = self._tmp2(T, C * k * k)
+        ops.unfold(xin, C, k, 1, k // 2, colsb)
+        y = self.new(B, H, W, Co)
+        ops.gemm_nt(colsb, weight.data.reshape(Co, -1), bias.data, out=y.view(T, Co))
+        if relu:
+            ops.leaky_relu_(y, 0.0)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out, xin=xin, y=y):
+                if out.g is None:
+                    return
+                g = self._c(out.g)
+                if relu:
+                    ops.relu_mask(g, y)
+                colsb = self._tmp2(T, C * k * k)
+                ops.unfold(xin, C, k, 1, k // 2, colsb)
+                dW, db = self._tmp(Co, C * k * k), self._tmp(Co)
+                ops.linear_wgrad(g.view(T, Co), colsb, dW, db)
+                self.gparam(wname, lambda o: o.view(Co, C * k * k).copy_(dW))
+                self.gparam(bname, lambda o: o.copy_(db))
+                if x.need:
+                    wt = weight.data.flip(2, 3).permute(1, 0, 2, 3).reshape(C, Co * k * k).contiguous()
+                    gcols = self._tmp2(T, Co * k * k)
+                    ops.unfold(g, Co, k, 1, k // 2, gcols)
+                    self.acc(x, lambda o: ops.gemm_nt(gcols, wt, None, out=o.view(T, C)))
+            self.back.append(bwd)
+        return out
+
+    def attend(self, q, k, v, B, Tq, Tk, heads, dh, scale):
+        """softmax(scale q k^T) v per (sample, head): q [B Tq, heads dh], k / v [B Tk, heads dh] -> [B Tq, heads dh]; the
+        (sample, head) products as batched launches of the exact-f32 GEMM around the row softmax, operands re-laid per head
+        (copies), contraction lengths zero-padded to multiples of 4.  Backward: dP = dO v^T, the softmax's row gradient,
+        dq = dS k, dk = dS^T q, dv = P^T dO -- four more batched launches on transposed copies."""
+        Z = B * heads
+        Tk4, Tq4 = (Tk + 3) & ~3, (Tq + 3) & ~3
+        assert Z * Tq * Tk4 < (1 << 29), "attend: the attention matrices of this batch pass 2 GiB"
+        dev = self.dev
+
+        def heads_of(t, T):                                   # [B T, heads dh] -> [Z, T, dh]
+            return t.reshape(B, T, heads, dh).permute(0, 2, 1, 3).reshape(Z, T, dh).contiguous()
+
+        def padT(t, T, T4):                                   # [Z, T, n] -> [Z, n, T4], zero-padded transposes
+            o = torch.zeros(Z, t.shape[2], T4, device=dev)
+            o[:, :, :T].copy_(t.transpose(1, 2))
+            return o
+
+        def bmm(A, W, C, M, N, K):                            # C_z[M, N] = A_z[M, K] W_z[N, K]^T, contiguous [Z, ., .] views
+            ops.gemm_nt_batched(A[0], (A.stride(0), 0), W[0], (W.stride(0), 0), C[0], (C.stride(0), 0), M, N, K, Z, 1)
+
+        qh, kh, vh = heads_of(q.t, Tq), heads_of(k.t, Tk), heads_of(v.t, Tk)
+        P = (self.new(Z, Tq, Tk4) if self.save else torch.empty(Z, Tq, Tk4, device=dev))
+        P.zero_()
+        bmm(qh, kh, P[:, :, :Tk], Tq, Tk, dh)
+        ops.softmax_rows_(P.view(Z * Tq, Tk4)[:, :Tk], scale)
+        oh = torch.empty(Z, Tq, dh, device=dev)
+        bmm(P, padT(vh, Tk, Tk4), oh, Tq, dh, Tk4)
+        y = self.new(B * Tq, heads * dh)
+        y.view(B, Tq, heads, dh).copy_(oh.view(B, heads, Tq, dh).permute(0, 2, 1, 3))
+        out = self._out(y)
+        if self.save:
+            def bwd(q=q, k=k, v=v, out=out, P=P):
+                if out.g is None:
+                    return
+                qh, kh, vh = heads_of(q.t, Tq), heads_of(k.t, Tk), heads_of(v.t, Tk)     # re-laid again: not kept
+                gh = heads_of(self._c(out.g), Tq)
+                dS = torch.zeros(Z, Tq, Tk4, device=dev)
+                bmm(gh, vh, dS[:, :, :Tk], Tq, Tk, dh)
+                ops.softmax_rows_bwd_(P.view(Z * Tq, Tk4)[:, :Tk], dS.view(Z * Tq, Tk4)[:, :Tk])
+                ops.axpby(dS, dS, float(scale), 0.0)
+
+                def back_to_rows(th, T):                      # [Z, T, dh] -> [B T, heads dh]
+                    return lambda o: o.view(B, T, heads, dh).copy_(th.view(B, heads, T, dh).permute(0, 2, 1, 3))
+                dq = torch.empty(Z, Tq, dh, device=dev)
+                bmm(dS, padT(kh, Tk, Tk4), dq, Tq, dh, Tk4)
+                self.acc(q, back_to_rows(dq, Tq))
+                dST = padT(dS[:, :, :Tk], Tq, Tq4)            # [Z, Tk, Tq4]
+                dk = torch.empty(Z, Tk, dh, device=dev)
+                bmm(dST, padT(qh, Tq, Tq4), dk, Tk, dh, Tq4)
+                self.acc(k, back_to_rows(dk, Tk))
+                PT = padT(P[:, :, :Tk], Tq, Tq4)
+                dv = torch.empty(Z, Tk, dh, device=dev)
+                bmm(PT, padT(gh, Tq, Tq4), dv, Tk, dh, Tq4)
+                self.acc(v, back_to_rows(dv, Tk))
+            self.back.append(bwd)
+        return out
+
+    def rcan_gate(self, a, x, w1, b1, w2, b2, names):
+        """RCAN's channel attention with the block's skip (network_act.py:230-277): out = x + a * sigmoid(W2 relu(W1 mean(a) + b1)
+        + b2).  names = parameter names of (W1, b1, W2, b2); the two tiny Linears' backward by hand on [B, C] tensors."""
+        ain, xin = self._c(a.t), self._c(x.t)
+        B, H, W, C = ain.shape
+        w1m, w2m = w1.data.reshape(w1.shape[0], -1).contiguous(), w2.data.reshape(w2.shape[0], -1).contiguous()
+        y = self.new(B, H, W, C)
+        ops.channel_gate(ain, w1m, b1.data, w2m, b2.data, xin, ain, y)
+        out = self._out(y)
+        if self.save:
+            gate = ops.SCRATCH.get("gate_vec", B * C, device=ain.device)[:B * C].view(B, C).clone()
+            pool = ain.mean((1, 2))
+
+            def bwd(a=a, x=x, out=out, gate=gate, pool=pool):
+                g = out.g
+                if g is None:
+                    return
+                self.acc(x, lambda o: o.copy_(g))
+                dgate = (g * ain).sum((1, 2))
+                z1 = pool @ w1m.t() + b1.data
+                r1 = torch.relu(z1)
+                dz2 = dgate * gate * (1.0 - gate)
+                dz1 = (dz2 @ w2m) * (z1 > 0)
+                self.gparam(names[2], lambda o: o.view(w2m.shape).copy_(dz2.t() @ r1))
+                self.gparam(names[3], lambda o: o.copy_(dz2.sum(0)))
+                self.gparam(names[0], lambda o: o.view(w1m.shape).copy_(dz1.t() @ pool))
+                self.gparam(names[1], lambda o: o.copy_(dz1.sum(0)))
+                dpool = (dz1 @ w1m) / float(H * W)
+                self.acc(a, lambda o: torch.addcmul(dpool.view(B, 1, 1, C).expand(B, H, W, C), g, gate.view(B, 1, 1, C), out=o))
+            self.back.append(bwd)
+        return out
+
     def conv_in1(self, x3, weight, bias, names):
         """first conv of a 1-channel image: x3 [B, H, W] -> [B, H, W, Co] (small.hip)."""
         B, H, W = x3.shape

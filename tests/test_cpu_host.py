@@ -160,7 +160,7 @@ def test_nlsn_mirror_layout_and_oracle_vs_reference_golden():
     from oracle import sr_oracle as O
     g = np.load(os.path.join(ROOT, "tests", "golden", "g34_nlsn.npz"))
     assert list(NLSN(upscale=2, in_chans=1).state_dict().keys()) == [str(k) for k in g["state_dict_keys_default"]]
-    for scale in (2, 4):
+    for scale in (2, 4, 8):
         sd = O.nlsn_init_state_dict(scale, 1, 8, 64, seed=int(g[f"x{scale}/seed"]))
         net = NLSN(upscale=scale, in_chans=1, n_resblocks=8, n_feats=64)
         assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]

@@ -1,0 +1,50 @@
+"""Host logic of the ACT training tape (srhip/act_engine.py::_forward_tape + the token-matrix ops of srhip/tape.py) with torch
+stand-ins for the kernels (tests/emul_ops.py): the graph wiring, every backward closure's accumulation and the parameter names
+against the REFERENCE's autograd (tests/golden/g45_act_grad.npz).  The same comparison with the real kernels:
+tests/test_gpu_tape_nets.py::test_act_training_step_gradients_vs_reference_golden."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sr-caco-2_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_act_tape_wiring_against_reference_gradients(monkeypatch):
+    import emul_ops
+    import sr_oracle as O
+    from dlib.models.network_act import ACT
+    emul_ops.install(monkeypatch)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g45_act_grad.npz"))
+    g = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("x2/")}
+    net = ACT(upscale=2, in_chans=1, n_feats=16, n_resgroups=4, n_resblocks=2, reduction=4, n_heads=4, n_layers=8, n_fusionblocks=4)
+    layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    net.load_state_dict(O.seeded_state_dict(layout, int(g["seed"])), strict=True)
+    net.train()
+    x, tgt = g["x"], g["tgt"]
+    eng = net.engine
+    y = eng.forward(x[:, 0].contiguous(), None, save=True)
+    assert (y - g["y"]).abs().max().item() <= 2e-5 * g["y"].abs().max().item()
+    dy = torch.sign(y - tgt) / y.numel()
+    grads = {k: torch.full_like(p, float("nan")) for k, p in net.named_parameters()}
+    eng.backward(dy, grads)
+    n = 0
+    for k, got in grads.items():
+        if "grad/" + k in g:
+            ref = g["grad/" + k]
+            e = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+        elif "gslice/" + k in g:
+            ref, sums = g["gslice/" + k], g["gsum/" + k]
+            e = ((got[:2] - ref).abs().max() / sums[2].float().clamp_min(1e-30)).item()
+            assert abs(got.double().sum().item() - sums[0].item()) <= 1e-4 * sums[1].item(), k
+            assert abs(got.double().abs().sum().item() - sums[1].item()) <= 1e-4 * sums[1].item(), k
+        else:                                   # a parameter the forward does not reach
+            assert float(got.abs().max()) == 0.0, k
+            continue
+        assert e <= 2e-4, (k, e)
+        n += 1
+    assert n == int(g["n_grads"])

@@ -300,10 +300,10 @@ def test_enlcn_registry_default_width_vs_oracle():
     assert mse < 1e-5, mse
 
 
-@pytest.mark.parametrize("scale", [2, 4])
+@pytest.mark.parametrize("scale", [2, 4, 8])
 def test_nlsn_forward_vs_reference_golden(scale):
     """NLSN (network_nlsn.py), narrow configuration of g34_nlsn.npz (x2: 720 tokens, 5 chunks; x4: 480 tokens, chunk
-    padding 96), fed the LSH rotations the reference drew.  (1) the hash codes agree with the reference's except where two
+    padding 96; x8: 360 tokens, padding 72, three PixelShuffle(2) stages), fed the LSH rotations the reference drew.  (1) the hash codes agree with the reference's except where two
     rotated components tie to rounding; (2) with the oracle replaying THIS run's token order -- the reference leaves the
     order inside a hash bucket to torch.sort, here it is by token index -- the outputs agree to f32 rounding; (3) against
     the reference's own output (its order) the image differs only where bucket boundaries moved."""
@@ -490,9 +490,102 @@ def test_act_forward_vs_reference_golden(scale):
         y = net(g["x"].cuda()).cpu()
     # (seeded random weights drive the features to |y| ~ 40: the gates are relative to the output's largest entry)
     assert (y - g["y"]).abs().mean().item() <= 1e-5 * g["y"].abs().max().item() and rel(y, g["y"]) < 3e-5, rel(y, g["y"])
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(g["x"].cuda()).sum().backward()
+    net.train()                             # the training forward (the tape graph) computes the same image
+    yt = net(g["x"].cuda()).detach().cpu()
+    assert rel(yt, g["y"]) < 3e-5, rel(yt, g["y"])
+
+
+@pytest.mark.parametrize("M,C", [(40, 72), (37, 144), (4100, 1152), (9, 2048)])
+def test_layernorm_rows_backward_kernel(M, C):
+    """srhip_layernorm_rows_bwd against float64 autograd of F.layer_norm: dx, dgamma, dbeta; rows beyond one pass of the grid
+    (M = 4100 > 4 x 512 blocks), widths up to the 2048 limit; twice the same bits (fixed summation order)."""
+    from srhip import ops
+    gen = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=gen) * 2 + 0.5).cuda()
+    dy = torch.randn(M, C, generator=gen).cuda()
+    gamma, beta = (torch.rand(C, generator=gen) + 0.5).cuda(), torch.randn(C, generator=gen).cuda()
+    y = ops.layernorm_rows(x, gamma, beta, torch.empty_like(x))
+    outs = []
+    for _ in range(2):
+        dx, dg, db = torch.empty_like(x), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        ops.layernorm_rows_bwd(dy, x, gamma, dx, dg, db)
+        outs.append((dx.clone(), dg.clone(), db.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    x64, g64, b64 = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y64 = torch.nn.functional.layer_norm(x64, (C,), g64, b64, 1e-5)
+    assert (y.double() - y64).abs().max().item() <= 1e-5
+    rx, rg, rb = torch.autograd.grad(y64, (x64, g64, b64), dy.double())
+    for got, ref in zip(outs[0], (rx, rg, rb)):
+        assert ((got.double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6
+    with pytest.raises(RuntimeError):
+        ops.layernorm_rows_bwd(torch.zeros(4, 2052, device="cuda"), torch.zeros(4, 2052, device="cuda"), torch.ones(2052, device="cuda"),
+                               torch.zeros(4, 2052, device="cuda"), torch.zeros(2052, device="cuda"), torch.zeros(2052, device="cuda"))
+
+
+def test_act_training_step_gradients_vs_reference_golden():
+    """ACT trains: forward in training mode, L1 loss, every parameter gradient of the narrow x2
+    configuration against the REFERENCE's own autograd (g45_act_grad.npz, oracle/make_goldens.py::g_act_grad; tensors above
+    8192 entries as two rows in full + the tensor's sum / sum of magnitudes, and the whole tensor against the oracle's fp64
+    autograd) -- the attention products and the row softmax backward, F.fold / F.unfold as each other's adjoints, LayerNorm
+    over 144 / 288 / 72 columns (srhip_layernorm_rows_bwd), GELU, the 5 x 5 head convs, RCAN's channel gate, the fusion
+    blocks.  Gate 2e-5 of a tensor's largest entry; ReLU decisions within rounding of zero excused by the
+    3x-the-fp32-oracle arm.  The same wiring with torch stand-ins for the kernels: tests/test_cpu_tape_logic.py."""
+    from dlib.models.network_act import ACT
+    from srhip.train import TrainStep, Optimizer
+    scale = 2
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g45_act_grad").items() if k.startswith(f"x{scale}/")}
+    kw = dict(n_feats=16, n_resblocks=2, n_heads=4)
+    net = ACT(upscale=scale, in_chans=1, n_resgroups=4, reduction=4, n_layers=8, n_fusionblocks=4, **kw)
+    sd = O.seeded_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], int(g["seed"]))
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=0.0, momentum=0.0, nesterov=False, wd=0.0)
+    x, tgt = g["x"], g["tgt"]
+    ts.step(x.cuda(), tgt.cuda())
+    assert abs(ts.loss_values()[0] - float(g["loss"])) <= 2e-5 * max(1.0, float(g["loss"]))
+    trainable = {k for k, p in net.named_parameters() if p.requires_grad}
+    sd64 = {k: (v.double().requires_grad_(True) if k in trainable else v.double()) for k, v in sd.items()}
+    (O.act_forward(sd64, x.double(), scale, **kw) - tgt.double()).abs().mean().backward()
+    worst, n = ("", 0.0), 0
+    for k in ts.fp.names:
+        got = ts.fp.gviews[k].double().cpu()
+        r64 = sd64[k].grad
+        if "grad/" + k in g:
+            ref = g["grad/" + k].double()
+            den = ref.abs().max().clamp_min(1e-30)
+            e = ((got - ref).abs().max() / den).item()
+            e32 = ((ref - r64).abs().max() / den).item()
+        elif "gslice/" + k in g:
+            ref, sums = g["gslice/" + k].double(), g["gsum/" + k].double()
+            den = sums[2].clamp_min(1e-30)
+            e = ((got[:2] - ref).abs().max() / den).item()
+            e32 = ((ref - r64[:2]).abs().max() / den).item()
+            assert abs(got.sum().item() - sums[0].item()) <= 1e-4 * sums[1].item(), k
+            assert abs(got.abs().sum().item() - sums[1].item()) <= 1e-4 * sums[1].item(), k
+            e = max(e, ((got - r64).abs().max() / den).item() - e32)
+        else:                                   # blocks past n_fusionblocks: the forward does not reach them
+            assert float(got.abs().max()) == 0.0, k
+            continue
+        worst, n = max(worst, (k, e), key=lambda t: t[1]), n + 1
+        assert e <= max(2e-5, 3.0 * e32), (k, e, e32)
+    assert n == int(g["n_grads"])
+    print(f"ACT x{scale} training step: loss {ts.loss_values()[0]:.6f}, worst gradient error {worst[1]:.2e} ({worst[0]}) of a tensor's largest entry")
+
+
+def test_main_cli_trains_act(tmp_path):
+    """`main.py --net_type ACT --max_iters 20`: the registry net through ModelPlain's step, loss finite and falling."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "sr-caco-2_amd", "main.py"), "--net_type", "ACT", "--method", "ACT",
+                        "--task", "super-resolution", "--scale", "4", "--n_channels", "1", "--h_size", "96", "--batch_size", "2",
+                        "--max_iters", "20", "--G_optimizer_lr", "1e-4", "--outd", str(tmp_path)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    losses = [float(l.split("G_loss")[1].split()[0]) for l in p.stdout.splitlines() if "G_loss" in l]
+    assert len(losses) == 2 and all(np.isfinite(losses)) and losses[1] < losses[0], losses
 
 
 def test_act_registry_default_width_vs_oracle():
