@@ -195,7 +195,8 @@ def build_ref_swinir(cfg):
                   img_range=cfg["img_range"], depths=cfg["depths"],
                   embed_dim=cfg["embed_dim"], num_heads=cfg["num_heads"],
                   mlp_ratio=cfg["mlp_ratio"], upsampler=cfg["upsampler"],
-                  resi_connection=cfg["resi_connection"], ape=cfg.get("ape", False))
+                  resi_connection=cfg["resi_connection"], ape=cfg.get("ape", False),
+                  patch_norm=cfg.get("patch_norm", True), qkv_bias=cfg.get("qkv_bias", True))
 
 
 def perturb(sd, seed):
@@ -570,6 +571,16 @@ def g_swinir_rgb():
                               num_heads=(6,), mlp_ratio=2, upsampler=ups, drop_path_rate=0.0, img_range=2.0)
         torch.manual_seed(seeds[0] + 100)
         _swinir_grad_golden("rgb " + ups, name, cfg, torch.rand(2, 3, 16, 24), seeds)
+
+
+def g_swinir_plain_embed():
+    """patch_norm=False and qkv_bias=False (network_swinir.py:799-803, 104): no LayerNorm behind conv_first, no bias in the
+    qkv Linear -- neither has parameters in the state_dict."""
+    print("G46 SwinIR tiny, patch_norm=False, qkv_bias=False")
+    cfg = O.swinir_config(upscale=2, in_chans=1, img_size=16, window_size=8, depths=(2,), embed_dim=60, num_heads=(6,),
+                          mlp_ratio=2, upsampler="pixelshuffledirect", drop_path_rate=0.0, patch_norm=False, qkv_bias=False)
+    torch.manual_seed(180)
+    _swinir_grad_golden("plain embed", "g46_swinir_plain_embed", cfg, torch.rand(2, 1, 16, 24), (181, 182, 183))
 
 
 # ---------------------------------------------------------------- G21 training-crop sampler
@@ -2079,7 +2090,7 @@ def g_optim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = [g_grl, g_omnisr, g_act, g_act_grad, g_dfcan, g_dfcan_grad, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
-            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv, g_swinir_ape, g_swinir_rgb]
+            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv, g_swinir_ape, g_swinir_rgb, g_swinir_plain_embed]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:
         if not only or g.__name__ in only:

@@ -86,9 +86,9 @@ def swinir_config(upscale=8, in_chans=1, img_size=64, window_size=8,
                   img_range=1.0, depths=(6, 6, 6, 6), embed_dim=180,
                   num_heads=(6, 6, 6, 6), mlp_ratio=2,
                   upsampler="pixelshuffledirect", resi_connection="1conv",
-                  drop_path_rate=0.1, ape=False) -> dict:
+                  drop_path_rate=0.1, ape=False, patch_norm=True, qkv_bias=True) -> dict:
     """README.md:120-197 configuration by default."""
-    return dict(ape=ape, upscale=upscale, in_chans=in_chans, img_size=img_size,
+    return dict(ape=ape, patch_norm=patch_norm, qkv_bias=qkv_bias, upscale=upscale, in_chans=in_chans, img_size=img_size,
                 window_size=window_size, img_range=img_range,
                 depths=list(depths), embed_dim=embed_dim,
                 num_heads=list(num_heads), mlp_ratio=mlp_ratio,
@@ -107,7 +107,7 @@ def _wmsa(sd: SD, pre: str, xw: Tensor, heads: int, mask: Optional[Tensor],
     """WindowAttention.forward, network_swinir.py:140-179."""
     nb, n, c = xw.shape
     d = c // heads
-    qkv = F.linear(xw, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"])
+    qkv = F.linear(xw, sd[pre + "qkv.weight"], sd.get(pre + "qkv.bias"))   # qkv_bias=False: no such key (:104)
     if taps is not None:
         taps.setdefault("qkv", qkv.detach().clone())
     qkv = qkv.reshape(nb, n, 3, heads, d).permute(2, 0, 3, 1, 4)
@@ -196,8 +196,9 @@ def swinir_forward(sd: SD, x: Tensor, cfg: dict,
 
     f0 = F.conv2d(x, sd["conv_first.weight"], sd["conv_first.bias"], padding=1)
     t = f0.flatten(2).transpose(1, 2)  # PatchEmbed :610-614
-    t = F.layer_norm(t, (c,), sd["patch_embed.norm.weight"],
-                     sd["patch_embed.norm.bias"])
+    if "patch_embed.norm.weight" in sd:      # patch_norm=True (:611-612)
+        t = F.layer_norm(t, (c,), sd["patch_embed.norm.weight"],
+                         sd["patch_embed.norm.bias"])
     if cfg.get("ape", False):    # network_swinir.py:918-919 (the input has to be img_size x img_size)
         t = t + sd["absolute_pos_embed"]
     bi = 0
@@ -287,7 +288,8 @@ def swinir_init_state_dict(cfg: dict, seed: int = 0) -> SD:
         sd["absolute_pos_embed"] = torch.nn.init.trunc_normal_(
             torch.empty(1, size * size, c), std=0.02, generator=g)
     conv("conv_first", c, cfg["in_chans"])
-    ln("patch_embed.norm")
+    if cfg.get("patch_norm", True):
+        ln("patch_embed.norm")
     wsb = min(ws, size) if size <= ws else ws
     for li, depth in enumerate(cfg["depths"]):
         heads = cfg["num_heads"][li]
@@ -302,6 +304,8 @@ def swinir_init_state_dict(cfg: dict, seed: int = 0) -> SD:
                     torch.empty((2 * wsb - 1) ** 2, heads), std=0.02, generator=g)
             sd[p + "attn.relative_position_index"] = relative_position_index(wsb)
             lin(p + "attn.qkv", 3 * c, c)
+            if not cfg.get("qkv_bias", True):
+                del sd[p + "attn.qkv.bias"]
             lin(p + "attn.proj", c, c)
             ln(p + "norm2")
             lin(p + "mlp.fc1", hid, c)

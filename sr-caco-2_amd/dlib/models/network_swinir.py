@@ -36,10 +36,10 @@ def _trunc_normal_(t, std=.02):
     return nn.init.trunc_normal_(t, mean=0., std=std, a=-2., b=2.)
 
 
-def _linear(out_f, in_f):
+def _linear(out_f, in_f, bias=True):
     m = _Box()
     m.weight = nn.Parameter(_trunc_normal_(torch.empty(out_f, in_f)))
-    m.bias = nn.Parameter(torch.zeros(out_f))
+    m.bias = nn.Parameter(torch.zeros(out_f)) if bias else None
     return m
 
 
@@ -98,7 +98,7 @@ def _shift_mask(h, w, ws, shift):
 
 class _SwinBlock(_Box):
     def __init__(self, dim, input_resolution, num_heads, window_size, shift_size, mlp_ratio,
-                 drop_path):
+                 drop_path, qkv_bias=True):
         super().__init__()
         self.dim, self.num_heads = dim, num_heads
         self.window_size, self.shift_size = window_size, shift_size
@@ -115,7 +115,7 @@ class _SwinBlock(_Box):
         attn.relative_position_bias_table = nn.Parameter(
             _trunc_normal_(torch.empty((2 * wsb - 1) ** 2, num_heads)))
         attn.register_buffer("relative_position_index", _relative_position_index(wsb))
-        attn.qkv = _linear(3 * dim, dim)
+        attn.qkv = _linear(3 * dim, dim, bias=qkv_bias)
         attn.proj = _linear(dim, dim)
         self.attn = attn
         self.norm2 = _norm(dim)
@@ -167,8 +167,8 @@ class SwinIR(nn.Module):
             unsupported.append(f"upscale={upscale} with 'pixelshuffle' (HIP path: powers of two)")
         if resi_connection not in (constants.R_CONNECTION_1CONV, constants.R_CONNECTION_3CONV):
             unsupported.append(f"resi_connection={resi_connection!r} (HIP path: '1conv', '3conv')")
-        if not patch_norm or not qkv_bias or qk_scale is not None:
-            unsupported.append("patch_norm=False / qkv_bias=False / qk_scale")
+        if qk_scale is not None:
+            unsupported.append("qk_scale (HIP path: head_dim ** -0.5)")
         if embed_dim > 256 or (embed_dim // num_heads[0]) not in (10, 16, 30, 32):
             unsupported.append(f"embed_dim={embed_dim} / heads={num_heads}")
         if unsupported:
@@ -194,7 +194,9 @@ class SwinIR(nn.Module):
 
         self.conv_first = _conv3(embed_dim, in_chans)
         self.patch_embed = _Box()
-        self.patch_embed.norm = _norm(embed_dim)
+        self.patch_norm = bool(patch_norm)
+        if self.patch_norm:                     # network_swinir.py:799-803: no norm -> no parameters in patch_embed
+            self.patch_embed.norm = _norm(embed_dim)
         dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
         self.layers = nn.ModuleList()
         for li, depth in enumerate(depths):
@@ -203,7 +205,7 @@ class SwinIR(nn.Module):
             rstb.residual_group.blocks = nn.ModuleList([
                 _SwinBlock(embed_dim, self.img_size, num_heads[li], window_size,
                            0 if j % 2 == 0 else window_size // 2, mlp_ratio,
-                           dpr[sum(depths[:li]) + j]) for j in range(depth)])
+                           dpr[sum(depths[:li]) + j], qkv_bias=qkv_bias) for j in range(depth)])
             rstb.conv = _resi_conv(embed_dim, resi_connection)
             self.layers.append(rstb)
         self.norm = _norm(embed_dim)

@@ -85,6 +85,14 @@ class SwinIREngine:
         self.fuse_wmsa = (all(ops.wmsa_f16_fusable(self.C, b.num_heads) for b in self.blocks)
                           and os.environ.get("SRHIP_WMSA_F16", "1") != "0")
 
+    def _qkv_bias(self, blk):
+        """the qkv Linear's bias, or zeros when the net was built with qkv_bias=False (network_swinir.py:104)"""
+        if blk.attn.qkv.bias is not None:
+            return blk.attn.qkv.bias.data
+        z = self.derived.get("zero.bq", 3 * self.C, device=blk.attn.qkv.weight.device)
+        z.zero_()
+        return z
+
     def bucket_prefixes(self):
         """Gradient buckets in backward-completion order: one per RSTB layer (the
         tail -- norm / conv_after_body / upsample -- rides with the last layer), the
@@ -158,7 +166,7 @@ class SwinIREngine:
                 tb.linear(w1, ws.planes(f"{i}.w1T", C, hid, dev), gamma=g2, transpose=True)
                 tb.linear(w2, ws.planes(f"{i}.w2", C, hid, dev))
                 tb.linear(w2, ws.planes(f"{i}.w2T", hid, C, dev), transpose=True)
-                tb.fold_bias(wq, b.attn.qkv.bias.data, b.norm1.bias.data, D.get(f"{i}.bq", 3 * C, device=dev))
+                tb.fold_bias(wq, self._qkv_bias(b), b.norm1.bias.data, D.get(f"{i}.bq", 3 * C, device=dev))
                 tb.fold_bias(w1, b.mlp.fc1.bias.data, b.norm2.bias.data, D.get(f"{i}.b1", hid, device=dev))
                 tb.bias_expand(b.attn.relative_position_bias_table.data,
                                D.get(f"{i}.biasT", b.num_heads, 64, 64, device=dev),
@@ -188,7 +196,7 @@ class SwinIREngine:
             heads = b.num_heads
             wq = D.get(f"{i}.wq", 3 * C, C, device=dev)
             bq = D.get(f"{i}.bq", 3 * C, device=dev)
-            ops.fold_layernorm(b.attn.qkv.weight.data, b.attn.qkv.bias.data, b.norm1.weight.data,
+            ops.fold_layernorm(b.attn.qkv.weight.data, self._qkv_bias(b), b.norm1.weight.data,
                                b.norm1.bias.data, wq, bq)
             ops.transpose(wq, D.get(f"{i}.wqT", C, 3 * C, device=dev))
             ops.transpose(b.attn.proj.weight.data, D.get(f"{i}.wpT", C, C, device=dev))
@@ -325,8 +333,11 @@ class SwinIREngine:
             ops.conv3x3(x, D.d["first.wp"], net.conv_first.bias.data, C, out=f0)
         st_pe = buf("st_pe", T, 2)
         t = buf("t0", T, C)
-        ops.layernorm_fwd(f0.view(T, C), st_pe, t, net.patch_embed.norm.weight.data,
-                          net.patch_embed.norm.bias.data)
+        if net.patch_norm:
+            ops.layernorm_fwd(f0.view(T, C), st_pe, t, net.patch_embed.norm.weight.data,
+                              net.patch_embed.norm.bias.data)
+        else:           # patch_norm=False: the tokens are conv_first's output (a copy: the blocks and `ape` write t)
+            t.copy_(f0.view(T, C))
         if net.ape:     # network_swinir.py:918-919: one [H*W, C] table, the same for every patch of the batch
             pos = net.absolute_pos_embed.data.view(H * W, C)
             for b in range(B):
@@ -668,7 +679,8 @@ class SwinIREngine:
                     ops.layernorm_bwd(dxh, t, st1, gout, res=g1)
                 # ---- the four weight gradients of the block: one launch per block, or collected for the layer's
                 problems = [
-                    dict(dY=dqkv, X=t, dW=G(p + "attn.qkv.weight"), db=G(p + "attn.qkv.bias"), b_mode=1,
+                    dict(dY=dqkv, X=t, dW=G(p + "attn.qkv.weight"),
+                         db=G(p + "attn.qkv.bias") if blk.attn.qkv.bias is not None else buf("dbq.unused", 3 * C), b_mode=1,
                          ln_stats=st1, ln=(blk.attn.qkv.weight.data, blk.norm1.weight.data,
                                            blk.norm1.bias.data, G(p + "norm1.weight"), G(p + "norm1.bias"))),
                     dict(dY=g, X=gh, dW=G(p + "mlp.fc2.weight"), db=G(p + "mlp.fc2.bias"), a_rowscale=s2,
@@ -708,9 +720,13 @@ class SwinIREngine:
             for b in range(1, B):
                 ops.axpby(dpos, dt[b * H * W:(b + 1) * H * W], 1.0, 1.0)
         df0 = buf("df0", T, C)
-        ops.layernorm_bwd(dt, sv["f0"].view(T, C), sv["st_pe"], df0, res=df.view(T, C),
-                          gamma=net.patch_embed.norm.weight.data, dgamma=G("patch_embed.norm.weight"),
-                          dbeta=G("patch_embed.norm.bias"))
+        if net.patch_norm:
+            ops.layernorm_bwd(dt, sv["f0"].view(T, C), sv["st_pe"], df0, res=df.view(T, C),
+                              gamma=net.patch_embed.norm.weight.data, dgamma=G("patch_embed.norm.weight"),
+                              dbeta=G("patch_embed.norm.bias"))
+        else:
+            df0.copy_(dt)
+            ops.axpby(df0, df.view(T, C), 1.0, 1.0)
         if self.ci != 1:
             dw4 = buf("first.dw4", C, 4, 3, 3)
             ops.conv3x3_wgrad(df0.view(B, H, W, C), sv["x"], dw4, G("conv_first.bias"))

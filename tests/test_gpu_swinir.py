@@ -420,6 +420,34 @@ def test_three_image_channels_nearest_conv_vs_oracle(SwinIR):
         assert l2(p.grad.cpu(), sdo[k].grad) <= 2e-4, k
 
 
+def test_without_patch_norm_and_qkv_bias_vs_reference_golden(SwinIR):
+    """patch_norm=False, qkv_bias=False (network_swinir.py:799-803, 104): the tokens are conv_first's output, the folded qkv
+    bias is W beta alone.  Reference golden g46: keys / order (no patch_embed.*, no attn.qkv.bias), eval forward, dL/dx, every
+    gradient through the autograd path and through the fused step."""
+    from srhip.train import TrainStep, Optimizer
+    g = load("g46_swinir_plain_embed")
+    net = SwinIR(upscale=2, in_chans=1, img_size=16, window_size=8, depths=[2], embed_dim=60, num_heads=[6], mlp_ratio=2,
+                 upsampler="pixelshuffledirect", drop_path_rate=0.0, patch_norm=False, qkv_bias=False)
+    assert list(net.state_dict().keys()) == list(sub(g, "sd/").keys())
+    net.load_state_dict(sub(g, "sd/"), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        y = net(g["x"].cuda()).cpu()
+    assert y.shape == g["y_eval"].shape and (y - g["y_eval"]).abs().max() <= 1e-5
+    net.train()
+    x = g["x"].cuda().requires_grad_(True)
+    (net(x) - g["target"].cuda()).abs().mean().backward()
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert l2(x.grad.cpu(), g["dx"]) <= 2e-4
+    for k, p in net.named_parameters():
+        assert l2(p.grad.cpu(), g["grad/" + k]) <= 2e-4, k
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=1e-12, momentum=0.0, nesterov=False, wd=0.0)
+    ts.step(g["x"].cuda(), g["target"].cuda())
+    for k, _ in net.named_parameters():
+        assert l2(ts.fp.gviews[k].cpu(), g["grad/" + k]) <= 2e-4, k
+
+
 def test_step_graph_replays_the_eager_step_bit_for_bit(SwinIR):
     """TrainStep.step_graph (one hipGraph replay per step) against TrainStep.step (~70 launches for this net):
     20 steps from the same weights on a changing batch, SGD-Nesterov with a MyStepLR schedule that halves the rate
