@@ -500,6 +500,14 @@ int srhip_gelu_gate(const float* x, float* out, long T, int C, void* stream);
 int srhip_maxpool2d(const float* x, float* out, int B, int H, int W, int C, int k, int s, void* stream);
 int srhip_bilinear_resize(const float* x, float* out, int B, int H, int W, int C, int Ho, int Wo, void* stream);
 int srhip_mul_sigmoid(const float* x, const float* g, float* out, long n, void* stream);
+/* Pieces the backward of OmniSR's training graph is composed from (srhip/omnisr_engine.py::_forward_tape; autograd of
+ * network_omni_sr.py:85-114,243-306): srhip_mul out = a * b; srhip_add_periodic x[i] += v[i % period] (the relative-position
+ * bias of every window, :291-294) and its adjoint srhip_sum_periodic out[j] = sum_k x[k period + j] (fixed order);
+ * srhip_maxpool2d_bwd the gradient of srhip_maxpool2d as a gather (first maximum of a window, as torch). */
+int srhip_mul(const float* a, const float* b, float* out, long n, void* stream);
+int srhip_add_periodic(float* x, const float* v, long n, long period, void* stream);
+int srhip_sum_periodic(const float* x, float* out, long n, long period, void* stream);
+int srhip_maxpool2d_bwd(const float* x, const float* g, float* dx, int B, int H, int W, int C, int k, int s, void* stream);
 
 /* ---- pieces of GRL's mixed-attention blocks, evaluation forward (grl_ops.hip) ----------------------
  * dlib/models/network_grl.py, channels last:

@@ -1766,6 +1766,50 @@ def g_omnisr():
     npz("g37_omnisr", **out)
 
 
+def g_omnisr_grad():
+    """OmniSR training step of the reference: the narrow configuration of g37 at x2 on a 16 x 32 input (2 x 4 windows: the grid
+    attention's 8 tokens) in TRAINING mode, L1 loss against a random target, autograd -> the gradient of every parameter
+    (MBConv + squeeze-excitation, window / grid attention with the relative-position bias table, both channel attentions with
+    their temperatures, the gated depthwise feed-forwards, ESA's strided conv / max pooling / bilinear resize).  The oracle's
+    own autograd must reproduce them."""
+    print("G47 OmniSR gradients")
+    from dlib.models.network_omni_sr import OmniSR as RefOmni
+    out = {}
+    cfg = dict(num_feat=16, res_num=2, block_num=1)
+    for scale, hw in ((2, (16, 32)),):
+        net = RefOmni(input_shape=1, upscale=scale, **cfg)
+        layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        sd = O.seeded_state_dict(layout, 520 + scale)
+        net.load_state_dict(sd, strict=True)
+        net.train()
+        torch.manual_seed(525 + scale)
+        x = torch.rand(2, 1, *hw)
+        tgt = torch.rand(2, 1, hw[0] * scale, hw[1] * scale)
+        y = net(x)
+        loss = (y - tgt).abs().mean()
+        loss.backward()
+        trainable = {k for k, p_ in net.named_parameters() if p_.requires_grad}
+        sdo = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+        yo = O.omnisr_forward(sdo, x, scale, res_num=2, block_num=1)
+        (yo - tgt).abs().mean().backward()
+        close(yo, y, 0.0, f"omnisr x{scale} training forward")
+        pre = f"x{scale}/"
+        out[pre + "x"], out[pre + "tgt"], out[pre + "y"], out[pre + "loss"] = x, tgt, y.detach(), loss.detach()
+        out[pre + "seed"] = np.array(520 + scale)
+        n = 0
+        for k, p_ in net.named_parameters():
+            assert p_.grad is not None, k
+            g_o = sdo[k].grad
+            assert g_o is not None, k
+            err = (g_o - p_.grad).abs().max().item()
+            assert err <= 1e-6 * max(1e-3, p_.grad.abs().max().item()), (k, err)
+            out[pre + "grad/" + k] = p_.grad
+            n += 1
+        out[pre + "n_grads"] = np.array(n)
+        print(f"  {n} parameter gradients, oracle autograd == reference autograd")
+    npz("g47_omnisr_grad", **out)
+
+
 def g_grl():
     """GRL (network_grl.py): a narrow configuration (36 channels, two stages of two blocks: shifted / plain windows, 'H' /
     'W' stripes) with every op class of the registry's net -- cosine window attention with the CPB-MLP bias and the shift
@@ -2089,7 +2133,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_grl, g_omnisr, g_act, g_act_grad, g_dfcan, g_dfcan_grad, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_grl, g_omnisr, g_omnisr_grad, g_act, g_act_grad, g_dfcan, g_dfcan_grad, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv, g_swinir_ape, g_swinir_rgb, g_swinir_plain_embed]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

@@ -258,6 +258,47 @@ __global__ void __launch_bounds__(256) k_mul_sigmoid(const float* __restrict__ x
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = x[i] / (1.0f + expf(-g[i]));
 }
 
+// ---- pieces of the training path (srhip/omnisr_engine.py::_forward_tape): element-wise product, a periodic addend (the
+// relative-position bias of every window) and its adjoint (the sum over the periods), max pooling's gradient
+__global__ void __launch_bounds__(256) k_mul(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] * b[i];
+}
+__global__ void __launch_bounds__(256) k_add_periodic(float* __restrict__ x, const float* __restrict__ v, long n, long period) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] += v[i % period];
+}
+// out[j] = sum over k of x[k * period + j]: one thread per j, k ascending (a fixed order)
+__global__ void __launch_bounds__(256) k_sum_periodic(const float* __restrict__ x, float* __restrict__ out, long count, long period) {
+  const long j = blockIdx.x * 256L + threadIdx.x;
+  if (j >= period) return;
+  float a = 0.f;
+  for (long k = 0; k < count; ++k) a += x[k * period + j];
+  out[j] = a;
+}
+// gradient of k_maxpool as a gather: an input pixel takes the gradient of every window whose first maximum it is
+__global__ void __launch_bounds__(256) k_maxpool_bwd(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ dx,
+                                                     int B, int H, int W, int C, int k, int s, int Ho, int Wo) {
+  const long n = (long)B * H * W * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long p = i / C;
+    const int xx = (int)(p % W), y = (int)((p / W) % H);
+    const long b = p / ((long)W * H);
+    float a = 0.f;
+    for (int yo = min(y / s, Ho - 1); yo >= 0 && yo * s + k > y; --yo)
+      for (int xo = min(xx / s, Wo - 1); xo >= 0 && xo * s + k > xx; --xo) {
+        float m = -3.0e38f;
+        int am = -1;
+        for (int dy = 0; dy < k; ++dy)
+          for (int dxx = 0; dxx < k; ++dxx) {
+            const float v = x[((b * H + yo * s + dy) * W + xo * s + dxx) * C + c];
+            if (v > m) { m = v; am = dy * k + dxx; }
+          }
+        if (am == (y - yo * s) * k + (xx - xo * s)) a += g[((b * Ho + yo) * Wo + xo) * C + c];
+      }
+    dx[i] = a;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -336,6 +377,38 @@ int srhip_mul_sigmoid(const float* x, const float* g, float* out, long n, void* 
   SR_REQUIRE(x && g && out && n > 0, "mul_sigmoid: bad arguments");
   hipLaunchKernelGGL(k_mul_sigmoid, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, g, out, n);
   SR_LAUNCH_CHECK("mul_sigmoid");
+  return 0;
+}
+
+/* ---- training path of OmniSR (the tape graph): small pieces its backward is composed from ---- */
+/* out = a * b element-wise; out may alias a or b */
+int srhip_mul(const float* a, const float* b, float* out, long n, void* stream) {
+  SR_REQUIRE(a && b && out && n > 0, "mul: bad arguments");
+  hipLaunchKernelGGL(k_mul, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  SR_LAUNCH_CHECK("mul");
+  return 0;
+}
+/* x[i] += v[i % period]: the relative-position bias [heads][n][n] added to the logits of every window (network_omni_sr.py:291-294) */
+int srhip_add_periodic(float* x, const float* v, long n, long period, void* stream) {
+  SR_REQUIRE(x && v && n > 0 && period > 0 && n % period == 0, "add_periodic: n must be a multiple of the period");
+  hipLaunchKernelGGL(k_add_periodic, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, v, n, period);
+  SR_LAUNCH_CHECK("add_periodic");
+  return 0;
+}
+/* out[j] = sum_k x[k * period + j], k < n / period: the adjoint of srhip_add_periodic (the bias gradient); fixed order */
+int srhip_sum_periodic(const float* x, float* out, long n, long period, void* stream) {
+  SR_REQUIRE(x && out && n > 0 && period > 0 && n % period == 0, "sum_periodic: n must be a multiple of the period");
+  hipLaunchKernelGGL(k_sum_periodic, dim3(sr_cdiv(period, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n / period, period);
+  SR_LAUNCH_CHECK("sum_periodic");
+  return 0;
+}
+/* gradient of srhip_maxpool2d: dx [B][H][W][C] from x and g [B][Ho][Wo][C] (a gather: deterministic) */
+int srhip_maxpool2d_bwd(const float* x, const float* g, float* dx, int B, int H, int W, int C, int k, int s, void* stream) {
+  SR_REQUIRE(x && g && dx && B > 0 && C > 0 && k > 0 && s > 0 && H >= k && W >= k, "maxpool2d_bwd: bad arguments");
+  const int Ho = (H - k) / s + 1, Wo = (W - k) / s + 1;
+  hipLaunchKernelGGL(k_maxpool_bwd, dim3(ew_blocks((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, g, dx, B, H, W, C, k,
+                     s, Ho, Wo);
+  SR_LAUNCH_CHECK("maxpool2d_bwd");
   return 0;
 }
 

@@ -2,7 +2,7 @@
 constructor, ``forward((B,1,h,w) in [0,1]) -> (B,1,s*h,s*w)`` (inputs zero-padded to multiples of the window, the output
 cropped) and the reference's state_dict keys, shapes and order (``residual_layer.{g}.residual_layer.{b}.layer.{0,2,4,5,6,8,
 10,11,12}.*``, ``residual_layer.{g}.residual_layer.{n}``, ``residual_layer.{g}.esa.*``, ``input``, ``output``, ``up.0``).
-The compute is ``srhip.omnisr_engine.OmniSREngine``.  Evaluation only (training raises); 1-channel inputs; GPU only."""
+The compute is ``srhip.omnisr_engine.OmniSREngine``.  Training through the tape graph of the engine (window-multiple patches); 1-channel inputs; GPU only."""
 import torch
 import torch.nn as nn
 

@@ -73,7 +73,7 @@ def define_G(args):
         return net(**{k: opt_net[f'{nt}_{k}'] for k in ('upscale', 'in_chans', 'img_range', 'n_feats', 'n_resgroups',
                                                         'n_resblocks', 'reduction', 'n_heads', 'n_layers', 'dropout_rate',
                                                         'n_fusionblocks', 'token_size', 'expansion_ratio')})
-    if net_type == constants.OMNISR:                # select_network.py:169-181 (evaluation only here)
+    if net_type == constants.OMNISR:                # select_network.py:169-181
         from dlib.models.network_omni_sr import OmniSR as net
         return net(input_shape=opt_net[f'{nt}_in_chans'], upscale=opt_net[f'{nt}_upscale'],
                    num_feat=opt_net[f'{nt}_num_feat'], res_num=opt_net[f'{nt}_res_num'], bias=opt_net[f'{nt}_bias'],

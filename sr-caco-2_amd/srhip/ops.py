@@ -611,6 +611,41 @@ def mul_sigmoid(x, g, out):
     return out
 
 
+def mul(a, b, out=None):
+    """out = a * b element-wise (same shapes, dense)."""
+    _chk(a, b, out)
+    if out is None:
+        out = torch.empty_like(a)
+    assert a.is_contiguous() and b.is_contiguous() and out.is_contiguous() and a.numel() == b.numel() == out.numel()
+    call("srhip_mul", _p(a), _p(b), _p(out), a.numel(), _st())
+    return out
+
+
+def add_periodic(x, v):
+    """x.view(-1)[i] += v.view(-1)[i % v.numel()] (x dense, its size a multiple of v's)."""
+    _chk(x, v)
+    assert x.is_contiguous() and v.is_contiguous()
+    call("srhip_add_periodic", _p(x), _p(v), x.numel(), v.numel(), _st())
+    return x
+
+
+def sum_periodic(x, out):
+    """out.view(-1)[j] = sum_k x.view(-1)[k * out.numel() + j]."""
+    _chk(x, out)
+    assert x.is_contiguous() and out.is_contiguous()
+    call("srhip_sum_periodic", _p(x), _p(out), x.numel(), out.numel(), _st())
+    return out
+
+
+def maxpool2d_bwd(x, g, k, s):
+    _chk(x, g)
+    B, H, W, C = x.shape
+    assert x.is_contiguous() and g.is_contiguous() and tuple(g.shape) == (B, (H - k) // s + 1, (W - k) // s + 1, C)
+    dx = torch.empty_like(x)
+    call("srhip_maxpool2d_bwd", _p(x), _p(g), _p(dx), B, H, W, C, k, s, _st())
+    return dx
+
+
 def avgpool2d(x, k):
     """nn.AvgPool2d(k, k) on NHWC [B, H, W, C] (AnchorLinear, network_grl.py:603-620)."""
     _chk(x)

@@ -715,11 +715,12 @@ class Tape:
             self.back.append(bwd)
         return out
 
-    def layernorm_rows(self, x, ln, gname, bname):
-        """nn.LayerNorm over the rows of x [M, C] (any C up to 2048)."""
+    def layernorm_rows(self, x, ln, gname, bname, eps=None):
+        """nn.LayerNorm over the rows of x [M, C] (any C up to 2048); eps: the module's unless given."""
         xin = self._c(x.t)
         y = self.new(*xin.shape)
-        ops.layernorm_rows(xin, ln.weight.data, ln.bias.data, y, eps=ln.eps)
+        eps = float(ln.eps if eps is None else eps)
+        ops.layernorm_rows(xin, ln.weight.data, ln.bias.data, y, eps=eps)
         out = self._out(y)
         if self.save:
             def bwd(x=x, out=out, xin=xin):
@@ -727,7 +728,7 @@ class Tape:
                     return
                 C = xin.shape[1]
                 dx, dg, db = self._tmp(*xin.shape), self._tmp(C), self._tmp2(C)
-                ops.layernorm_rows_bwd(self._c(out.g), xin, ln.weight.data, dx, dg, db, eps=ln.eps)
+                ops.layernorm_rows_bwd(self._c(out.g), xin, ln.weight.data, dx, dg, db, eps=eps)
                 self.gparam(gname, lambda o: o.copy_(dg))
                 self.gparam(bname, lambda o: o.copy_(db))
                 self.acc(x, lambda o: o.copy_(dx))
@@ -836,11 +837,13 @@ class Tape:
             self.back.append(bwd)
         return out
 
-    def attend(self, q, k, v, B, Tq, Tk, heads, dh, scale):
+    def attend(self, q, k, v, B, Tq, Tk, heads, dh, scale, bias=None, on_dbias=None):
         """softmax(scale q k^T) v per (sample, head): q [B Tq, heads dh], k / v [B Tk, heads dh] -> [B Tq, heads dh]; the
         (sample, head) products as batched launches of the exact-f32 GEMM around the row softmax, operands re-laid per head
         (copies), contraction lengths zero-padded to multiples of 4.  Backward: dP = dO v^T, the softmax's row gradient,
-        dq = dS k, dk = dS^T q, dv = P^T dO -- four more batched launches on transposed copies."""
+        dq = dS k, dk = dS^T q, dv = P^T dO -- four more batched launches on transposed copies.
+        bias [heads, Tq, Tk]: added to the scaled logits of every sample (OmniSR's relative-position bias); on_dbias(d) receives
+        its gradient (the sum over the samples)."""
         Z = B * heads
         Tk4, Tq4 = (Tk + 3) & ~3, (Tq + 3) & ~3
         assert Z * Tq * Tk4 < (1 << 29), "attend: the attention matrices of this batch pass 2 GiB"
@@ -861,7 +864,14 @@ class Tape:
         P = (self.new(Z, Tq, Tk4) if self.save else torch.empty(Z, Tq, Tk4, device=dev))
         P.zero_()
         bmm(qh, kh, P[:, :, :Tk], Tq, Tk, dh)
-        ops.softmax_rows_(P.view(Z * Tq, Tk4)[:, :Tk], scale)
+        if bias is None:
+            ops.softmax_rows_(P.view(Z * Tq, Tk4)[:, :Tk], scale)
+        else:
+            bpad = torch.zeros(heads, Tq, Tk4, device=dev)
+            bpad[:, :, :Tk].copy_(bias)
+            ops.axpby(P, P, float(scale), 0.0)
+            ops.add_periodic(P, bpad)
+            ops.softmax_rows_(P.view(Z * Tq, Tk4)[:, :Tk], 1.0)
         oh = torch.empty(Z, Tq, dh, device=dev)
         bmm(P, padT(vh, Tk, Tk4), oh, Tq, dh, Tk4)
         y = self.new(B * Tq, heads * dh)
@@ -876,6 +886,10 @@ class Tape:
                 dS = torch.zeros(Z, Tq, Tk4, device=dev)
                 bmm(gh, vh, dS[:, :, :Tk], Tq, Tk, dh)
                 ops.softmax_rows_bwd_(P.view(Z * Tq, Tk4)[:, :Tk], dS.view(Z * Tq, Tk4)[:, :Tk])
+                if bias is not None and on_dbias is not None:
+                    db = torch.empty(heads, Tq, Tk4, device=dev)
+                    ops.sum_periodic(dS, db)
+                    on_dbias(db[:, :, :Tk])
                 ops.axpby(dS, dS, float(scale), 0.0)
 
                 def back_to_rows(th, T):                      # [Z, T, dh] -> [B T, heads dh]
@@ -923,6 +937,252 @@ class Tape:
                 self.gparam(names[1], lambda o: o.copy_(dz1.sum(0)))
                 dpool = (dz1 @ w1m) / float(H * W)
                 self.acc(a, lambda o: torch.addcmul(dpool.view(B, 1, 1, C).expand(B, H, W, C), g, gate.view(B, 1, 1, C), out=o))
+            self.back.append(bwd)
+        return out
+
+    # ---- more ops of this kind (OmniSR's training graph)
+    def reshape(self, x, *shape):
+        """the same storage under another shape (rows <-> NHWC map)"""
+        r = self.var(self._c(x.t).view(*shape))
+        if self.save:
+            def bwd(x=x, r=r):
+                if r.g is not None:
+                    self.acc(x, lambda o: o.copy_(r.g.reshape(o.shape)))
+            self.back.append(bwd)
+        return r
+
+    def relayout(self, x, fwd, inv, pad_last=None):
+        """y = fwd(x) made dense, fwd a chain of view ops (reshape / permute) and inv its inverse: window / grid partitions.
+        pad_last: the last dimension zero-padded to this width (a contraction length the GEMMs take); inv sees the unpadded part."""
+        v = fwd(x.t)
+        n = v.shape[-1]
+        if pad_last is None or pad_last == n:
+            y = self.new(*v.shape)
+            y.copy_(v)
+        else:
+            y = self.new(*v.shape[:-1], pad_last)
+            y.zero_()
+            y[..., :n].copy_(v)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out):
+                if out.g is not None:
+                    self.acc(x, lambda o: o.copy_(inv(out.g[..., :n])))
+            self.back.append(bwd)
+        return out
+
+    def dwconv(self, x, weight, bias, wname, bname=None):
+        """nn.Conv2d(C, C, 3, padding=1, groups=C).  Backward: the data gradient is the same conv with flipped taps; the weight
+        gradient dW[c][tap] = sum_p g[p][c] x[p + tap][c] is the block diagonal of g^T @ unfold(x) (one GEMM; the other blocks
+        are dropped)."""
+        xin = self._c(x.t)
+        B, H, W, C = xin.shape
+        y = self.new(B, H, W, C)
+        ops.dwconv3x3(xin, weight.data, None if bias is None else bias.data, y)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out, xin=xin):
+                if out.g is None:
+                    return
+                g = self._c(out.g)
+                T = B * H * W
+                colsb = self._tmp2(T, 9 * C)
+                ops.unfold(xin, C, 3, 1, 1, colsb)
+                full, db = self._tmp(C, 9 * C), self._tmp(C)
+                ops.linear_wgrad(g.view(T, C), colsb, full, db)
+                ar = torch.arange(C, device=full.device)
+                self.gparam(wname, lambda o: o.view(C, 9).copy_(full.view(C, C, 9)[ar, ar]))
+                if bname:
+                    self.gparam(bname, lambda o: o.copy_(db))
+                wf = weight.data.flip(2, 3).contiguous()
+                self.acc(x, lambda o: ops.dwconv3x3(g, wf, None, o))
+            self.back.append(bwd)
+        return out
+
+    def se_gate(self, d, w1, w2, names):
+        """squeeze-excitation of MBConv (network_omni_sr.py:133-148): out = d * sigmoid(W2 silu(W1 mean(d))), no biases; the two
+        tiny Linears' backward by hand on [B, C] tensors."""
+        din = self._c(d.t)
+        B, H, W, C = din.shape
+        w1m, w2m = w1.data, w2.data
+        y = self.new(B, H, W, C)
+        ops.channel_gate(din, w1m, None, w2m, None, None, din, y, mid_act="silu")
+        out = self._out(y)
+        if self.save:
+            gate = ops.SCRATCH.get("gate_vec", B * C, device=din.device)[:B * C].view(B, C).clone()
+            pool = din.mean((1, 2))
+
+            def bwd(d=d, out=out, gate=gate, pool=pool):
+                g = out.g
+                if g is None:
+                    return
+                dgate = (g * din).sum((1, 2))
+                z1 = pool @ w1m.t()
+                sg = torch.sigmoid(z1)
+                r1 = z1 * sg
+                dz2 = dgate * gate * (1.0 - gate)
+                dz1 = (dz2 @ w2m) * (sg * (1.0 + z1 * (1.0 - sg)))
+                self.gparam(names[1], lambda o: o.view(w2m.shape).copy_(dz2.t() @ r1))
+                self.gparam(names[0], lambda o: o.view(w1m.shape).copy_(dz1.t() @ pool))
+                dpool = (dz1 @ w1m) / float(H * W)
+                self.acc(d, lambda o: torch.addcmul(dpool.view(B, 1, 1, C).expand(B, H, W, C), g, gate.view(B, 1, 1, C), out=o))
+            self.back.append(bwd)
+        return out
+
+    def gelu_gate(self, x):
+        """gelu(x1) * x2 for the two channel halves of x [.., 2C] (Gated_Conv_FeedForward, network_omni_sr.py:324-327)."""
+        xin = self._c(x.t)
+        C2 = xin.shape[-1]
+        C = C2 // 2
+        T = xin.numel() // C2
+        y = self.new(*xin.shape[:-1], C)
+        ops.gelu_gate(xin.view(T, C2), y.view(T, C))
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out, xin=xin):
+                if out.g is None:
+                    return
+                g = self._c(out.g).view(T, C)
+                x1, x2 = xin.view(T, C2)[:, :C].contiguous(), xin.view(T, C2)[:, C:].contiguous()
+                ga = ops.unary(x1, torch.empty_like(x1), "gelu")
+                d2 = ops.mul(g, ga)
+                d1 = ops.unary_bwd(x1, ops.mul(g, x2), torch.empty_like(x1), "gelu")
+
+                def prod(o):
+                    ov = o.view(T, C2)
+                    ov[:, :C].copy_(d1)
+                    ov[:, C:].copy_(d2)
+                self.acc(x, prod)
+            self.back.append(bwd)
+        return out
+
+    def mul_sigmoid(self, x, c):
+        """x * sigmoid(c) (ESA, network_omni_sr.py:113-114)."""
+        xin, cin = self._c(x.t), self._c(c.t)
+        y = self.new(*xin.shape)
+        ops.mul_sigmoid(xin, cin, y)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, c=c, out=out):
+                if out.g is None:
+                    return
+                g = self._c(out.g)
+                self.acc(x, lambda o: ops.mul_sigmoid(g, cin, o))
+                sg = ops.unary(cin, torch.empty_like(cin), "sigmoid")
+                self.acc(c, lambda o: ops.unary_bwd(sg, ops.mul(g, xin), o, "sigmoid"))
+            self.back.append(bwd)
+        return out
+
+    def normalize_rows(self, x, eps=1e-12):
+        """F.normalize(x, dim=-1) on rows [M, n]: x / max(|x|, eps); dx = (g - y (y . g)) / max(|x|, eps)."""
+        xin = self._c(x.t)
+        M, n = xin.shape
+        inv = 1.0 / ops.rowdot(xin, xin).sqrt().clamp_min(eps)             # [M]: per-row scalars
+        invE = inv.view(M, 1).expand(M, n).contiguous()
+        y = self.new(M, n)
+        ops.mul(xin, invE, y)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out, y=y, invE=invE, inv=inv):
+                if out.g is None:
+                    return
+                g = self._c(out.g)
+                coef = (ops.rowdot(y, g) * inv).view(M, 1).expand(M, n).contiguous()
+
+                def prod(o):
+                    ops.mul(g, invE, o)
+                    ops.axpby(o, ops.mul(y, coef), -1.0, 1.0)
+                self.acc(x, prod)
+            self.back.append(bwd)
+        return out
+
+    def scale_rows(self, x, s_rows, on_grad):
+        """y[r] = s_rows[r] * x[r] (the head's temperature on the channel attention's query rows); on_grad receives
+        d s_rows [M] = rowdot(g, x)."""
+        xin = self._c(x.t)
+        M, n = xin.shape
+        sE = s_rows.view(M, 1).expand(M, n).contiguous()
+        y = self.new(M, n)
+        ops.mul(xin, sE, y)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out, sE=sE):
+                if out.g is None:
+                    return
+                g = self._c(out.g)
+                on_grad(ops.rowdot(g, xin))
+                self.acc(x, lambda o: ops.mul(g, sE, o))
+            self.back.append(bwd)
+        return out
+
+    def conv_patches(self, x, weight, bias, wname, bname, k, s):
+        """k x k conv, stride s, no padding, as F.unfold + GEMM (ESA's conv2, network_omni_sr.py:96,106).  Backward: weight
+        gradient from the patch matrix, data gradient = F.fold of g W (the overlap-add adjoint)."""
+        xin = self._c(x.t)
+        B, H, W, C = xin.shape
+        Co = weight.shape[0]
+        Ho, Wo = (H - k) // s + 1, (W - k) // s + 1
+        T = B * Ho * Wo
+        w2 = weight.data.reshape(Co, -1)
+        colsb = self._tmp2(T, C * k * k)
+        ops.unfold(xin, C, k, s, 0, colsb)
+        y = self.new(B, Ho, Wo, Co)
+        ops.gemm_nt(colsb, w2, bias.data, out=y.view(T, Co))
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out, xin=xin):
+                if out.g is None:
+                    return
+                g = self._c(out.g).view(T, Co)
+                colsb = self._tmp2(T, C * k * k)
+                ops.unfold(xin, C, k, s, 0, colsb)
+                dW, db = self._tmp(Co, C * k * k), self._tmp(Co)
+                ops.linear_wgrad(g, colsb, dW, db)
+                self.gparam(wname, lambda o: o.view(Co, C * k * k).copy_(dW))
+                self.gparam(bname, lambda o: o.copy_(db))
+                dcols = ops.gemm_nt(g, w2.t().contiguous(), None)
+                self.acc(x, lambda o: ops.fold(dcols, C, k, s, o))
+            self.back.append(bwd)
+        return out
+
+    def maxpool(self, x, k, s):
+        xin = self._c(x.t)
+        y = ops.maxpool2d(xin, k, s)
+        self.n += 1
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out, xin=xin):
+                if out.g is not None:
+                    self.acc(x, lambda o: o.copy_(ops.maxpool2d_bwd(xin, self._c(out.g), k, s)))
+            self.back.append(bwd)
+        return out
+
+    def bilinear(self, x, Ho, Wo):
+        """F.interpolate(bilinear, align_corners=False) to (Ho, Wo).  The map is separable and linear: its adjoint runs as two
+        GEMMs against the (tiny, zero-padded) interpolation matrices A_h [Ho, H], A_w [Wo, W]."""
+        xin = self._c(x.t)
+        B, H, W, C = xin.shape
+        y = ops.bilinear_resize(xin, Ho, Wo)
+        self.n += 1
+        out = self._out(y)
+        if self.save:
+            def interp(n_in, n_out):                  # A^T zero-padded to a multiple of 4 rows: [n_in4, n_out]
+                eye = torch.eye(n_in, device=xin.device).view(1, n_in, n_in, 1)
+                a = torch.nn.functional.interpolate(eye, size=(n_out, 1), mode="bilinear", align_corners=False)[0, :, :, 0]
+                at = torch.zeros((n_in + 3) & ~3, n_out, device=xin.device)
+                at[:n_in].copy_(a)
+                return at
+
+            def bwd(x=x, out=out):
+                if out.g is None:
+                    return
+                g = self._c(out.g)                                              # [B, Ho, Wo, C]
+                ah, aw = interp(H, Ho), interp(W, Wo)
+                r1 = g.permute(0, 2, 3, 1).reshape(B * Wo * C, Ho).contiguous()   # rows (b, x, c), columns y
+                t1 = ops.gemm_nt(r1, ah, None)[:, :H]                             # [(b, x, c), i]
+                r2 = t1.reshape(B, Wo, C, H).permute(0, 3, 2, 1).reshape(B * H * C, Wo).contiguous()   # rows (b, i, c), columns x
+                t2 = ops.gemm_nt(r2, aw, None)[:, :W]                             # [(b, i, c), j]
+                self.acc(x, lambda o: o.copy_(t2.reshape(B, H, C, W).permute(0, 1, 3, 2)))
             self.back.append(bwd)
         return out
 

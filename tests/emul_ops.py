@@ -164,7 +164,8 @@ SCRATCH = _Scratch()
 def channel_gate(feat, w1, b1, w2, b2, x0, x1, out, mid_act="relu"):
     B, H, W, C = feat.shape
     pool = feat.mean((1, 2))
-    z = torch.relu(pool @ w1.t() + (0 if b1 is None else b1))
+    z = pool @ w1.t() + (0 if b1 is None else b1)
+    z = torch.relu(z) if mid_act == "relu" else F.silu(z)
     gate = torch.sigmoid(z @ w2.t() + (0 if b2 is None else b2))
     SCRATCH.get("gate_vec", B * C)[:B * C].copy_(gate.reshape(-1))
     out.copy_((0 if x0 is None else x0) + x1 * gate.view(B, 1, 1, C))
@@ -220,7 +221,64 @@ def pixel_shuffle(x, r, nhwc_out=False, inverse=False, out=None, add=None, fac=1
     return out
 
 
-NAMES = ["pack_conv_weight", "conv3x3", "conv3x3_wgrad", "gemm_nt", "linear_wgrad", "gemm_nt_batched", "softmax_rows_",
+def dwconv3x3(x, w, bias, out):
+    C = out.shape[3]
+    out.copy_(_nhwc(F.conv2d(_nchw(x[..., :C]), w.reshape(C, 1, 3, 3), bias, padding=1, groups=C)))
+    return out
+
+
+def gelu_gate(x, out):
+    C = out.shape[1]
+    out.copy_(F.gelu(x[:, :C]) * x[:, C:])
+    return out
+
+
+def mul_sigmoid(x, g, out):
+    out.copy_((x * torch.sigmoid(g)).reshape(out.shape))
+    return out
+
+
+def mul(a, b, out=None):
+    if out is None:
+        return a * b
+    out.copy_(a * b)
+    return out
+
+
+def rowdot(a, b, out=None):
+    r = (a * b).sum(1)
+    if out is None:
+        return r
+    out.copy_(r)
+    return out
+
+
+def add_periodic(x, v):
+    x.view(-1, v.numel()).add_(v.reshape(1, -1))
+    return x
+
+
+def sum_periodic(x, out):
+    out.copy_(x.reshape(-1, out.numel()).sum(0).reshape(out.shape))
+    return out
+
+
+def maxpool2d(x, k, s):
+    return _nhwc(F.max_pool2d(_nchw(x), k, s)).contiguous()
+
+
+def maxpool2d_bwd(x, g, k, s):
+    xx = x.detach().clone().requires_grad_(True)
+    return torch.autograd.grad(_nhwc(F.max_pool2d(_nchw(xx), k, s)), xx, g)[0].contiguous()
+
+
+def bilinear_resize(x, Ho, Wo):
+    return _nhwc(F.interpolate(_nchw(x), (Ho, Wo), mode="bilinear", align_corners=False)).contiguous()
+
+
+NAMES = ["dwconv3x3", "gelu_gate", "mul_sigmoid", "mul", "rowdot", "add_periodic", "sum_periodic", "maxpool2d", "maxpool2d_bwd",
+         "bilinear_resize",
+         "pack_conv_weight", "conv3x3", "conv3x3_wgrad", "gemm_nt", "linear_wgrad", "gemm_nt_batched", "softmax_rows_",
          "softmax_rows_bwd_", "layernorm_rows", "layernorm_rows_bwd", "unfold", "fold", "axpby", "leaky_relu_", "relu_mask",
          "unary", "unary_bwd", "channel_gate", "conv3x3_cin1_fwd", "conv3x3_cin1_wgrad", "conv3x3_cout1_fwd", "sum_into",
          "pixel_shuffle", "SCRATCH"]

@@ -48,3 +48,32 @@ def test_act_tape_wiring_against_reference_gradients(monkeypatch):
         assert e <= 2e-4, (k, e)
         n += 1
     assert n == int(g["n_grads"])
+
+
+def test_omnisr_tape_wiring_against_reference_gradients(monkeypatch):
+    """srhip/omnisr_engine.py::_forward_tape: window / grid attention with the bias table, both channel attentions, MBConv,
+    the gated feed-forwards, ESA -- against tests/golden/g47_omnisr_grad.npz."""
+    import emul_ops
+    import sr_oracle as O
+    from dlib.models.network_omni_sr import OmniSR
+    emul_ops.install(monkeypatch)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g47_omnisr_grad.npz"))
+    g = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("x2/")}
+    net = OmniSR(input_shape=1, upscale=2, num_feat=16, res_num=2, block_num=1)
+    layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    net.load_state_dict(O.seeded_state_dict(layout, int(g["seed"])), strict=True)
+    net.train()
+    x, tgt = g["x"], g["tgt"]
+    eng = net.engine
+    y = eng.forward(x[:, 0].contiguous(), None, save=True)
+    assert (y - g["y"]).abs().max().item() <= 2e-5 * g["y"].abs().max().item()
+    dy = torch.sign(y - tgt) / y.numel()
+    grads = {k: torch.full_like(p, float("nan")) for k, p in net.named_parameters()}
+    eng.backward(dy, grads)
+    n = 0
+    for k, got in grads.items():
+        ref = g["grad/" + k]
+        e = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+        assert e <= 2e-4, (k, e)
+        n += 1
+    assert n == int(g["n_grads"])

@@ -643,9 +643,81 @@ def test_omnisr_forward_vs_reference_golden(scale):
         y = net(g["x"].cuda()).cpu()
     assert y.shape == g["y"].shape
     assert (y - g["y"]).abs().mean().item() <= 1e-5 * max(1.0, g["y"].abs().max().item()) and rel(y, g["y"]) < 3e-5, rel(y, g["y"])
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(g["x"].cuda()).sum().backward()
+    if scale != 4:                          # the training forward (the tape graph; window-multiple inputs) computes the same image
+        net.train()
+        yt = net(g["x"].cuda()).detach().cpu()
+        assert rel(yt, g["y"]) < 3e-5, rel(yt, g["y"])
+
+
+def test_omnisr_backward_pieces():
+    """srhip_mul, srhip_add_periodic / srhip_sum_periodic (adjoint pair), srhip_maxpool2d_bwd against torch."""
+    from srhip import ops
+    gen = torch.Generator().manual_seed(5)
+    a, b = torch.randn(3, 37, 5, generator=gen).cuda(), torch.randn(3, 37, 5, generator=gen).cuda()
+    assert torch.equal(ops.mul(a, b), a * b)
+    x, v = torch.randn(7, 4, 6, 8, generator=gen).cuda(), torch.randn(4, 6, 8, generator=gen).cuda()
+    ref = x + v
+    assert torch.equal(ops.add_periodic(x.clone(), v), ref)
+    s = ops.sum_periodic(x, torch.empty_like(v))
+    assert (s - x.sum(0)).abs().max().item() <= 1e-5 and torch.equal(s, ops.sum_periodic(x, torch.empty_like(v)))
+    for (H, W, k, st) in ((15, 31, 7, 3), (7, 7, 7, 3), (9, 12, 3, 2)):
+        xi = torch.randn(2, H, W, 5, generator=gen).cuda()
+        xr = xi.clone().requires_grad_(True)
+        yr = torch.nn.functional.max_pool2d(xr.permute(0, 3, 1, 2), k, st).permute(0, 2, 3, 1)
+        gr = torch.randn(yr.shape, generator=gen).cuda()
+        (dref,) = torch.autograd.grad(yr, xr, gr)
+        assert torch.equal(ops.maxpool2d(xi, k, st), yr.detach().contiguous())
+        assert (ops.maxpool2d_bwd(xi, gr.contiguous(), k, st) - dref).abs().max().item() <= 1e-6
+
+
+def test_omnisr_training_step_gradients_vs_reference_golden():
+    """OmniSR trains: forward in training mode, L1 loss, every parameter gradient of the narrow x2
+    configuration against the REFERENCE's own autograd (g47_omnisr_grad.npz, oracle/make_goldens.py::g_omnisr_grad) -- window
+    and grid attention as batched GEMMs around the row softmax with the relative-position bias table's gradient, both channel
+    attentions on L2-normalised rows with their temperatures, the depthwise convs' weight gradient as the block diagonal of
+    one GEMM, squeeze-excitation, the gated feed-forwards, ESA's strided conv / max pooling / bilinear resize.  Gate 2e-5 of a
+    tensor's largest entry or 3x the fp32 oracle's own distance from fp64.  The same wiring with torch stand-ins for the
+    kernels: tests/test_cpu_tape_logic.py."""
+    from dlib.models.network_omni_sr import OmniSR
+    from srhip.train import TrainStep, Optimizer
+    scale = 2
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g47_omnisr_grad").items() if k.startswith(f"x{scale}/")}
+    net = OmniSR(input_shape=1, upscale=scale, num_feat=16, res_num=2, block_num=1)
+    sd = O.seeded_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], int(g["seed"]))
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=0.0, momentum=0.0, nesterov=False, wd=0.0)
+    x, tgt = g["x"], g["tgt"]
+    ts.step(x.cuda(), tgt.cuda())
+    assert abs(ts.loss_values()[0] - float(g["loss"])) <= 2e-5 * max(1.0, float(g["loss"]))
+    trainable = {k for k, p in net.named_parameters() if p.requires_grad}
+    sd64 = {k: (v.double().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+    (O.omnisr_forward(sd64, x.double(), scale, res_num=2, block_num=1) - tgt.double()).abs().mean().backward()
+    worst, n = ("", 0.0), 0
+    for k in ts.fp.names:
+        got, ref, r64 = ts.fp.gviews[k].double().cpu(), g["grad/" + k].double(), sd64[k].grad
+        den = ref.abs().max().clamp_min(1e-30)
+        e, e32 = ((got - ref).abs().max() / den).item(), ((ref - r64).abs().max() / den).item()
+        worst, n = max(worst, (k, e), key=lambda t: t[1]), n + 1
+        assert e <= max(2e-5, 3.0 * e32), (k, e, e32)
+    assert n == int(g["n_grads"])
+    print(f"OmniSR x{scale} training step: loss {ts.loss_values()[0]:.6f}, worst gradient error {worst[1]:.2e} ({worst[0]})")
+
+
+def test_main_cli_trains_omnisr(tmp_path):
+    """`main.py --net_type OmniSR --max_iters 20`: the registry net through ModelPlain's step, loss finite and falling."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "sr-caco-2_amd", "main.py"), "--net_type", "OmniSR", "--method", "OmniSR",
+                        "--task", "super-resolution", "--scale", "4", "--n_channels", "1", "--h_size", "128", "--batch_size", "2",
+                        "--max_iters", "20", "--G_optimizer_lr", "1e-4", "--outd", str(tmp_path)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    losses = [float(l.split("G_loss")[1].split()[0]) for l in p.stdout.splitlines() if "G_loss" in l]
+    assert len(losses) == 2 and all(np.isfinite(losses)) and losses[1] < losses[0], losses
 
 
 def test_omnisr_registry_default_width_vs_oracle():
