@@ -2,7 +2,7 @@
 ``forward((B,1,h,w) in [0,1]) -> (B,1,s*h,s*w)`` and the reference's state_dict keys, shapes and order (``sub_mean / add_mean``,
 ``head.{0,1,2}``, ``linear_encoding``, ``mhsa_block.{i}.{0,1}``, ``csta_block.{i}.{0..4}``, ``cnn_branch.{g}.body.{r}`` and the
 unused ``cnn_branch.4`` conv, ``fusion_block / fusion_mlp / fusion_cnn``, ``conv_last``, ``tail``): released weights load with
-strict=True.  The compute is ``srhip.act_engine.ACTEngine``.  Evaluation only (training raises); 1-channel inputs; images of
+strict=True.  The compute is ``srhip.act_engine.ACTEngine``.  Training through the tape graph of the engine; 1-channel inputs; images of
 at least 6 x 6 pixels; GPU only."""
 import math
 
