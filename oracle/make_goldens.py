@@ -1810,6 +1810,56 @@ def g_omnisr_grad():
     npz("g47_omnisr_grad", **out)
 
 
+def g_grl_grad():
+    """GRL training step of the reference: the narrow configuration of g38 at x2 on a 16 x 24 input in TRAINING mode (drop
+    path off), L1 loss against a random target, autograd -> the gradient of every parameter (cosine window / anchored stripe
+    attention with the logit scales -- one over the clamp -- and the CPB MLPs, the conv + channel-attention local branch,
+    post-norm residuals).  The oracle's own autograd must reproduce them."""
+    print("G48 GRL gradients")
+    from dlib.models.network_grl import GRL as RefGRL
+    out = {}
+    kw = dict(in_chans=1, window_size=8, mlp_ratio=2, qkv_proj_type="linear", anchor_proj_type="avgpool",
+              anchor_window_down_factor=2, out_proj_type="linear", conv_type="1conv", upsampler="pixelshuffle",
+              local_connection=True, drop_path_rate=0.0)
+    cfg = dict(depths=[2, 2], embed_dim=36, num_heads_window=[3, 3], num_heads_stripe=[3, 3])
+    for scale, hw in ((2, (16, 24)),):
+        net = RefGRL(upscale=scale, img_size=16, **cfg, **kw)
+        layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        sd = O.grl_state_dict(layout, 540 + scale, 16)
+        net.load_state_dict(sd, strict=True)
+        net.train()
+        torch.manual_seed(545 + scale)
+        x = torch.rand(2, 1, *hw)
+        tgt = torch.rand(2, 1, hw[0] * scale, hw[1] * scale)
+        y = net(x)
+        loss = (y - tgt).abs().mean()
+        loss.backward()
+        trainable = {k for k, p_ in net.named_parameters() if p_.requires_grad}
+        sdo = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+        yo = O.grl_forward(sdo, x, scale, depths=(2, 2))
+        (yo - tgt).abs().mean().backward()
+        close(yo, y, 0.0, f"grl x{scale} training forward")
+        pre = f"x{scale}/"
+        out[pre + "x"], out[pre + "tgt"], out[pre + "y"], out[pre + "loss"] = x, tgt, y.detach(), loss.detach()
+        out[pre + "seed"] = np.array(540 + scale)
+        n = 0
+        for k, p_ in net.named_parameters():
+            assert p_.grad is not None, k
+            g_o = sdo[k].grad
+            assert g_o is not None, k
+            err = (g_o - p_.grad).abs().max().item()
+            assert err <= 1e-5 * max(1e-3, p_.grad.abs().max().item()), (k, err)      # (sums of ~1e-6 terms in another order)
+            if p_.grad.numel() <= 8192:
+                out[pre + "grad/" + k] = p_.grad
+            else:
+                out[pre + "gslice/" + k] = p_.grad[:2].clone()
+                out[pre + "gsum/" + k] = torch.stack([p_.grad.double().sum(), p_.grad.double().abs().sum(), p_.grad.double().abs().max()])
+            n += 1
+        out[pre + "n_grads"] = np.array(n)
+        print(f"  {n} parameter gradients, oracle autograd == reference autograd")
+    npz("g48_grl_grad", **out)
+
+
 def g_grl():
     """GRL (network_grl.py): a narrow configuration (36 channels, two stages of two blocks: shifted / plain windows, 'H' /
     'W' stripes) with every op class of the registry's net -- cosine window attention with the CPB-MLP bias and the shift
@@ -2133,7 +2183,7 @@ def g_optim():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_grl, g_omnisr, g_omnisr_grad, g_act, g_act_grad, g_dfcan, g_dfcan_grad, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_grl, g_grl_grad, g_omnisr, g_omnisr_grad, g_act, g_act_grad, g_dfcan, g_dfcan_grad, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv, g_swinir_ape, g_swinir_rgb, g_swinir_plain_embed]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

@@ -6,7 +6,7 @@ attn_transform, stripe_attn.attn_transform{1,2}, proj}, norm1, conv.cab.{0,2,3.a
 ``layers.{i}.conv``, ``norm_end``, ``conv_after_body``, ``conv_before_upsample.0``, ``upsample.up.{0,2,..}``, ``conv_last``.
 Built for the options the registry passes: linear qkv / output projections, average-pooled anchors, '1conv' stage ends, the
 pixel-shuffle upsampler, the local (conv + channel attention) branch on or off, no stripe shift.  The compute is
-``srhip.grl_engine.GRLEngine``.  Evaluation only (training raises); 1-channel inputs; GPU only."""
+``srhip.grl_engine.GRLEngine``.  Training through the tape graph of the engine (window-multiple patches); 1-channel inputs; GPU only."""
 import math
 
 import torch

@@ -79,7 +79,7 @@ def define_G(args):
                    num_feat=opt_net[f'{nt}_num_feat'], res_num=opt_net[f'{nt}_res_num'], bias=opt_net[f'{nt}_bias'],
                    window_size=opt_net[f'{nt}_window_size'], block_num=opt_net[f'{nt}_block_num'], pe=opt_net[f'{nt}_pe'],
                    ffn_bias=opt_net[f'{nt}_ffn_bias'])
-    if net_type == constants.GRL:                   # select_network.py:70-90 (evaluation only here)
+    if net_type == constants.GRL:                   # select_network.py:70-90
         from dlib.models.network_grl import GRL as net
         return net(**{k: opt_net[f'{nt}_{k}'] for k in ('upscale', 'in_chans', 'img_size', 'window_size', 'img_range', 'depths',
                                                         'embed_dim', 'num_heads_window', 'num_heads_stripe', 'mlp_ratio',

@@ -1,4 +1,4 @@
-"""GRL on libsrhip, evaluation forward (reference dlib/models/network_grl.py:1462-1512): stages of mixed-attention blocks
+"""GRL on libsrhip (reference dlib/models/network_grl.py:1462-1512): stages of mixed-attention blocks
 (:1061-1076) -- one qkv Linear whose halves feed an 8x8 (shifted) window attention and an anchored stripe attention
 (average-pooled 4x4 anchors attend to the 8x8 stripe, the stripe attends back to the anchors), both cosine attentions with a
 clamped logit scale and a 16 sigmoid(CPB MLP) bias, a shared output projection, post-norm residuals, a conv + GELU + conv +
@@ -7,12 +7,14 @@ directly over the libsrhip ops: Linears and 3x3 convs on the GEMM / conv kernels
 -- the kernels --amp narrows to one product -- exact f32 below; GELU as the fc2 prologue; the
 C/4 channels of the local branch zero-padded to a multiple of 4: exact), attentions / pooling / bias images in grl_ops.hip,
 the channel gate and LayerNorms of the earlier nets.  Tokens stay channels-last [B, H, W, C] throughout, so blc<->bchw,
-roll, window_partition and window_reverse are address arithmetic inside the kernels.  Inference only."""
+roll, window_partition and window_reverse are address arithmetic inside the kernels.  Training (save=True) runs the graph on the tape of srhip/tape.py (_forward_tape)."""
 import torch
 import torch.nn.functional as F
 
 from . import ops
 from .planes import PlaneCache
+from .swinir_engine import _Bufs
+from .tape import Tape, WeightBank
 
 
 def _pad4(n):
@@ -27,10 +29,14 @@ class GRLEngine:
         self.taps = None
         self._w = {}
         self.planes = PlaneCache()
+        self.bufs = _Bufs()
+        self.bank = WeightBank()
+        self._bank_ready = False
 
     def invalidate(self):
         self._w = {}
         self.planes.clear()
+        self._bank_ready = False
 
     def bucket_prefixes(self):
         return [[""]]
@@ -133,7 +139,7 @@ class GRLEngine:
     # ------------------------------------------------------------------ forward
     def forward(self, x3, dp=None, save=False):
         if save:
-            raise NotImplementedError("GRL on libsrhip: inference only (BASELINE config 5's evaluation sweep); no backward")
+            return self._forward_tape(x3)
         net = self.net
         B, H0, W0 = x3.shape
         p = net.pad_size
@@ -174,5 +180,179 @@ class GRLEngine:
             u = ops.pixel_shuffle(self._conv3(u, conv), 2, nhwc_out=True)
         return ops.conv3x3_cout1_fwd(u, net.conv_last.weight.data, net.conv_last.bias.data)
 
-    def backward(self, *a, **k):
-        raise NotImplementedError("GRL on libsrhip: inference only (BASELINE config 5's evaluation sweep); no backward")
+    # ------------------------------------------------------------------ training: the same graph on the tape
+    def _forward_tape(self, x3):
+        """forward() with the tape recording (srhip/tape.py).  Every attention runs on rows per (window, head) -- L2-normalised
+        queries / keys, the clamped logit scale on the query rows, 16 sigmoid(CPB MLP)[index] (+ the shift mask) as a
+        periodic addend, batched GEMMs around the row softmax; roll / window partition / reverse are the relayout copies
+        around them; the C/4-channel convs of the local branch as im2col + GEMM; the CPB MLPs (a [225, 2] table through 512
+        units) by hand."""
+        import math
+        from dlib.models.network_grl import table_index_mask
+        net = self.net
+        B, H, W = x3.shape
+        C, df, ws = net.embed_dim, net.df, list(net.window_size)
+        half = C // 2
+        if H % net.pad_size or W % net.pad_size:
+            raise NotImplementedError("GRL on libsrhip: training patches have to be multiples of the window / stripe size")
+        dev = x3.device
+        if not self._bank_ready:
+            self.bank.begin()
+            for si, stage in enumerate(net.layers):
+                self.bank.conv(f"layers.{si}.conv", stage.conv.weight, stage.conv.bias, "c3")
+            self.bank.conv("conv_after_body", net.conv_after_body.weight, net.conv_after_body.bias, "c3")
+            self.bank.conv("conv_before_upsample.0", net.conv_before_upsample[0].weight, net.conv_before_upsample[0].bias, "c3")
+            for k, conv in enumerate(list(net.upsample.up)[0::2]):
+                self.bank.conv(f"upsample.up.{2 * k}", conv.weight, conv.bias, "c3")
+            self.bank.finish(dev)
+            self._bank_ready = True
+        t = Tape(self.bufs, self.bank, True, dev)
+        nm = {id(p): k for k, p in net.named_parameters()}
+        N = lambda p: None if p is None else nm[id(p)]
+        T = B * H * W
+        mask_w = table_index_mask((H, W), net.window_size, net.stripe_size, df)["mask_w"].to(dev)      # [nW, 64, 64]
+
+        def lin(x, m):
+            return t.linear(x, m.weight, m.bias, N(m.weight), N(m.bias))
+
+        def ln(x, m):
+            return t.layernorm_rows(x, m, N(m.weight), N(m.bias))
+
+        def per_head(m, Hm, Wm, wsz, heads, shift, pad):
+            """NHWC map [B, Hm, Wm, heads dh] -> rows [(b, window, head, token), dh (zero-padded to `pad`)] and back"""
+            dh = m.t.shape[3] // heads
+            ny, nx = Hm // wsz[0], Wm // wsz[1]
+
+            def fwd(v):
+                if shift:
+                    v = torch.roll(v, shifts=(-shift, -shift), dims=(1, 2))
+                return v.reshape(B, ny, wsz[0], nx, wsz[1], heads, dh).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, dh)
+
+            def inv(u):
+                v = u.reshape(B, ny, nx, heads, wsz[0], wsz[1], dh).permute(0, 1, 4, 2, 5, 3, 6).reshape(B, Hm, Wm, heads * dh)
+                return torch.roll(v, shifts=(shift, shift), dims=(1, 2)) if shift else v
+            return t.relayout(m, fwd, inv, pad_last=pad), fwd, inv
+
+        def cosine_attention(tr, qr, kr, vr, nWin, heads, Tq, Tk, table, index, mask):
+            """qr / kr / vr: per-head rows; returns per-head rows [(b, window, head, Tq), dh4]"""
+            lam = tr.logit_scale
+            sc = torch.clamp(lam.data.reshape(-1), max=math.log(100.0)).exp()                        # [heads]
+            s_rows = sc.view(1, heads, 1).expand(B * nWin, heads, Tq).reshape(-1).contiguous()
+
+            def on_scale(ds):
+                d = ds.view(B * nWin, heads, Tq).sum((0, 2)) * sc * (lam.data.reshape(-1) < math.log(100.0))
+                t.gparam(N(lam), lambda o: o.view(-1).copy_(d))
+            # the CPB MLP over the relative-coordinates table (AffineTransform :296-319), by hand: [n, 2] -> 512 -> heads
+            w0, b0, w2 = tr.cpb_mlp[0].weight, tr.cpb_mlp[0].bias, tr.cpb_mlp[2].weight
+            tab = table.reshape(-1, 2).to(dev)
+            pre = tab @ w0.data.t() + b0.data
+            h1 = torch.relu(pre)
+            sg = torch.sigmoid(h1 @ w2.data.t())                                                     # [n, heads]
+            idx = index.reshape(-1).to(dev)
+            bias = (16.0 * sg)[idx].view(Tq, Tk, heads).permute(2, 0, 1)                             # [heads, Tq, Tk]
+            if mask is None:
+                addend = bias.contiguous()
+            else:
+                addend = (bias.unsqueeze(0) + mask.unsqueeze(1)).reshape(-1, Tq, Tk).contiguous()    # [(window, head), Tq, Tk]
+
+            def on_dbias(d):
+                db = d.reshape(-1, heads, Tq, Tk).sum(0)                                             # [heads, Tq, Tk]
+                dsg = torch.zeros_like(sg).index_add_(0, idx, db.permute(1, 2, 0).reshape(-1, heads)) * 16.0
+                dz = dsg * sg * (1.0 - sg)
+                t.gparam(N(w2), lambda o: o.copy_(dz.t() @ h1))
+                dh1 = (dz @ w2.data) * (pre > 0)
+                t.gparam(N(w0), lambda o: o.copy_(dh1.t() @ tab))
+                t.gparam(N(b0), lambda o: o.copy_(dh1.sum(0)))
+            qs = t.scale_rows(t.normalize_rows(qr), s_rows, on_scale)
+            return t.attend(qs, t.normalize_rows(kr), vr, B * nWin * heads, Tq, Tk, 1, qr.t.shape[1], 1.0, bias=addend,
+                            on_dbias=on_dbias)
+
+        def avgpool(xmap):
+            """nn.AvgPool2d(df): the df x df patches (F.unfold) against a constant averaging row"""
+            Cc = xmap.t.shape[3]
+            u = t.unfold(xmap, df, df)                                                                # [B nT, Cc df df]
+            wavg = torch.zeros(4, df * df, device=dev)
+            wavg[0] = 1.0 / (df * df)
+            r = t.linear(t.reshape(u, -1, df * df), wavg, None, None)
+            return t.reshape(t.cols(r, 0, 1), B, H // df, W // df, Cc)
+
+        def block(blk, x, i, si, name):
+            a = blk.attn
+            hw, hs = net.heads_w[si], net.heads_s[si]
+            ssz = list(net.stripe_size) if i % 2 == 0 else list(net.stripe_size)[::-1]
+            asz = [v // df for v in ssz]
+            sfx = "h" if i % 2 == 0 else "v"
+            shift = ws[0] // 2 if i % 2 == 0 else 0
+            xmap = t.reshape(x, B, H, W, C)
+            qkv = lin(x, a.qkv.body)
+            anchor = t.reshape(lin(t.reshape(avgpool(xmap), -1, C), a.anchor.body[0].reduction), B, H // df, W // df, half)
+
+            def part(j):
+                return t.reshape(t.cols(qkv, j * half, (j + 1) * half), B, H, W, half)
+            # window attention
+            dw4 = (half // hw + 3) & ~3
+            nW = (H // ws[0]) * (W // ws[1])
+            q, fwd_w, inv_w = per_head(part(0), H, W, ws, hw, shift, dw4)
+            k, _, _ = per_head(part(1), H, W, ws, hw, shift, dw4)
+            v, _, _ = per_head(part(2), H, W, ws, hw, shift, dw4)
+            tr = a.window_attn.attn_transform
+            ow = cosine_attention(tr, q, k, v, nW, hw, ws[0] * ws[1], ws[0] * ws[1], net.table_w, net.index_w,
+                                  mask_w if shift else None)
+            dhw = half // hw
+            xw = t.relayout(ow, lambda u: inv_w(u[..., :dhw]), lambda g: F.pad(fwd_w(g), (0, dw4 - dhw)))
+            # anchored stripe attention
+            ds4 = (half // hs + 3) & ~3
+            dhs = half // hs
+            nS = (H // ssz[0]) * (W // ssz[1])
+            q, fwd_s, inv_s = per_head(part(3), H, W, ssz, hs, 0, ds4)
+            k, _, _ = per_head(part(4), H, W, ssz, hs, 0, ds4)
+            v, _, _ = per_head(part(5), H, W, ssz, hs, 0, ds4)
+            an, _, _ = per_head(anchor, H // df, W // df, asz, hs, 0, ds4)
+            Ta, Ts = asz[0] * asz[1], ssz[0] * ssz[1]
+            st = a.stripe_attn
+            xa = cosine_attention(st.attn_transform1, an, k, v, nS, hs, Ta, Ts, getattr(net, "table_s" + sfx),
+                                  getattr(net, f"index_s{sfx}_a2w"), None)
+            os_ = cosine_attention(st.attn_transform2, q, an, xa, nS, hs, Ts, Ta, getattr(net, "table_s" + sfx),
+                                   getattr(net, f"index_s{sfx}_w2a"), None)
+            xs = t.relayout(os_, lambda u: inv_s(u[..., :dhs]), lambda g: F.pad(fwd_s(g), (0, ds4 - dhs)))
+            return xw, xs, xmap, a
+
+        f0 = t.conv_in1(x3, net.conv_first.weight, net.conv_first.bias, (N(net.conv_first.weight), N(net.conv_first.bias)))
+        tk = ln(t.reshape(f0, T, C), net.norm_start)
+        for si, stage in enumerate(net.layers):
+            res = tk
+            for i, blk in enumerate(stage.blocks):
+                xw, xs, xmap, a = block(blk, res, i, si, f"layers.{si}.blocks.{i}")
+                att = t.cat_cols([t.reshape(xw, T, half), t.reshape(xs, T, half)])
+                p = t.axpby(ln(lin(att, a.proj), blk.norm1), res)
+                if net.local_connection:
+                    cab = blk.conv.cab
+                    c1 = t.unary(t.conv_im2col(xmap, cab[0].weight, cab[0].bias, N(cab[0].weight), N(cab[0].bias), 3), "gelu")
+                    c2 = t.conv_im2col(c1, cab[2].weight, cab[2].bias, N(cab[2].weight), N(cab[2].bias), 3)
+                    ca = cab[3].attention
+                    xn = t.reshape(t.rcan_gate(c2, t.reshape(p, B, H, W, C), ca[1].weight, ca[1].bias, ca[3].weight, ca[3].bias,
+                                               (N(ca[1].weight), N(ca[1].bias), N(ca[3].weight), N(ca[3].bias))), T, C)
+                else:
+                    xn = p
+                m = lin(t.unary(lin(xn, blk.mlp.fc1), "gelu"), blk.mlp.fc2)
+                res = t.axpby(ln(m, blk.norm2), xn)
+            tk = t.reshape(t.conv(t.reshape(res, B, H, W, C), f"layers.{si}.conv", (N(stage.conv.weight), N(stage.conv.bias)),
+                                  res=(t.reshape(tk, B, H, W, C), 1.0)), T, C)
+        tk = ln(tk, net.norm_end)
+        f = t.conv(t.reshape(tk, B, H, W, C), "conv_after_body", (N(net.conv_after_body.weight), N(net.conv_after_body.bias)),
+                   res=(f0, 1.0))
+        cb = net.conv_before_upsample[0]
+        u = t.relu(t.conv(f, "conv_before_upsample.0", (N(cb.weight), N(cb.bias))), 0.01)
+        for k, conv in enumerate(list(net.upsample.up)[0::2]):
+            u = t.shuffle(t.conv(u, f"upsample.up.{2 * k}", (N(conv.weight), N(conv.bias))), 2)
+        y = t.conv_out1(u, net.conv_last.weight, net.conv_last.bias, (N(net.conv_last.weight), N(net.conv_last.bias)))
+        self.saved = (t, y)
+        Bo, Ho, Wo = y.t.shape
+        return y.t.view(Bo, 1, Ho, Wo)
+
+    def backward(self, dy, grads, need_dx=False, on_layer_done=None, grads_zeroed=False):
+        assert self.saved is not None, "backward() without a saved forward"
+        assert not need_dx, "GRL: no gradient with respect to the input image"
+        tape, out = self.saved
+        tape.backward(out, dy.reshape(out.t.shape).contiguous(), grads)
+        return None

@@ -704,13 +704,17 @@ class Tape:
                 if out.g is None:
                     return
                 g = self._c(out.g)
-                dW, db = self._tmp(N, K), self._tmp(N)
-                ops.linear_wgrad(g, xin, dW, db)
-                self.gparam(wname, lambda o: o.view(N, K).copy_(dW))
-                if bname:
-                    self.gparam(bname, lambda o: o.copy_(db))
+                N4 = (N + 3) & ~3
+                if N4 != N:                  # the contraction of the data gradient runs over N: zero columns up to a multiple of 4
+                    g = torch.nn.functional.pad(g, (0, N4 - N))
+                if wname is not None:        # (None: a constant matrix, e.g. the averaging weights of a pooling)
+                    dW, db = self._tmp(N4, K), self._tmp(N4)
+                    ops.linear_wgrad(g, xin, dW, db)
+                    self.gparam(wname, lambda o: o.view(N, K).copy_(dW[:N]))
+                    if bname:
+                        self.gparam(bname, lambda o: o.copy_(db[:N]))
                 if x.need:
-                    wT = w.t().contiguous()
+                    wT = torch.nn.functional.pad(w.t(), (0, N4 - N)).contiguous()
                     self.acc(x, lambda o: ops.gemm_nt(g, wT, None, out=o))
             self.back.append(bwd)
         return out
@@ -801,18 +805,28 @@ class Tape:
         return out
 
     def conv_im2col(self, x, weight, bias, wname, bname, k, relu=False):
-        """k x k conv (padding k // 2) as im2col + GEMM (ACT's 5 x 5 head convs, network_act.py:362-364).  Backward: the
-        weight gradient from the re-made patch matrix, the data gradient as the same conv of the gradient with the flipped,
-        transposed kernel."""
+        """k x k conv (padding k // 2) as im2col + GEMM (ACT's 5 x 5 head convs, network_act.py:362-364; GRL's C/4-channel
+        convs).  Backward: the weight gradient from the re-made patch matrix, the data gradient as the same conv of the
+        gradient with the flipped, transposed kernel.  Contraction lengths that are not multiples of 4 are zero-padded."""
         xin = self._c(x.t)
         B, H, W, C = xin.shape
         Co = weight.shape[0]
         T = B * H * W
-        assert T * C * k * k < (1 << 29), "conv_im2col: the patch matrix of this batch passes 2 GiB"
-        colsb = self._tmp2(T, C * k * k)
-        ops.unfold(xin, C, k, 1, k // 2, colsb)
+        K, Kg = C * k * k, Co * k * k
+        K4, Kg4 = (K + 3) & ~3, (Kg + 3) & ~3
+        assert T * max(K4, Kg4) < (1 << 29), "conv_im2col: the patch matrix of this batch passes 2 GiB"
+
+        def patches(src, Cs, Kp):
+            cb = self._tmp2(T, Kp)
+            if Kp != Cs * k * k:
+                cb.zero_()
+            ops.unfold(src, Cs, k, 1, k // 2, cb)
+            return cb
+
+        def padded(w2, Kp):
+            return w2 if w2.shape[1] == Kp else torch.nn.functional.pad(w2, (0, Kp - w2.shape[1])).contiguous()
         y = self.new(B, H, W, Co)
-        ops.gemm_nt(colsb, weight.data.reshape(Co, -1), bias.data, out=y.view(T, Co))
+        ops.gemm_nt(patches(xin, C, K4), padded(weight.data.reshape(Co, K), K4), bias.data, out=y.view(T, Co))
         if relu:
             ops.leaky_relu_(y, 0.0)
         out = self._out(y)
@@ -823,16 +837,15 @@ class Tape:
                 g = self._c(out.g)
                 if relu:
                     ops.relu_mask(g, y)
-                colsb = self._tmp2(T, C * k * k)
-                ops.unfold(xin, C, k, 1, k // 2, colsb)
-                dW, db = self._tmp(Co, C * k * k), self._tmp(Co)
-                ops.linear_wgrad(g.view(T, Co), colsb, dW, db)
-                self.gparam(wname, lambda o: o.view(Co, C * k * k).copy_(dW))
-                self.gparam(bname, lambda o: o.copy_(db))
+                Co4 = (Co + 3) & ~3
+                g2 = g.view(T, Co) if Co4 == Co else torch.nn.functional.pad(g.view(T, Co), (0, Co4 - Co))
+                dW, db = self._tmp(Co4, K4), self._tmp(Co4)
+                ops.linear_wgrad(g2, patches(xin, C, K4), dW, db)
+                self.gparam(wname, lambda o: o.view(Co, K).copy_(dW[:Co, :K]))
+                self.gparam(bname, lambda o: o.copy_(db[:Co]))
                 if x.need:
-                    wt = weight.data.flip(2, 3).permute(1, 0, 2, 3).reshape(C, Co * k * k).contiguous()
-                    gcols = self._tmp2(T, Co * k * k)
-                    ops.unfold(g, Co, k, 1, k // 2, gcols)
+                    wt = padded(weight.data.flip(2, 3).permute(1, 0, 2, 3).reshape(C, Kg), Kg4)
+                    gcols = patches(g, Co, Kg4)
                     self.acc(x, lambda o: ops.gemm_nt(gcols, wt, None, out=o.view(T, C)))
             self.back.append(bwd)
         return out
@@ -842,8 +855,9 @@ class Tape:
         (sample, head) products as batched launches of the exact-f32 GEMM around the row softmax, operands re-laid per head
         (copies), contraction lengths zero-padded to multiples of 4.  Backward: dP = dO v^T, the softmax's row gradient,
         dq = dS k, dk = dS^T q, dv = P^T dO -- four more batched launches on transposed copies.
-        bias [heads, Tq, Tk]: added to the scaled logits of every sample (OmniSR's relative-position bias); on_dbias(d) receives
-        its gradient (the sum over the samples)."""
+        bias [R, Tq, Tk], R a multiple of heads dividing B heads (heads: one image per sample, OmniSR's relative-position bias;
+        nW heads with heads = 1 rows per head: GRL's bias + shift mask per window): added to the scaled logits periodically;
+        on_dbias(d [R, Tq, Tk]) receives its gradient (the sum over the periods)."""
         Z = B * heads
         Tk4, Tq4 = (Tk + 3) & ~3, (Tq + 3) & ~3
         assert Z * Tq * Tk4 < (1 << 29), "attend: the attention matrices of this batch pass 2 GiB"
@@ -867,7 +881,9 @@ class Tape:
         if bias is None:
             ops.softmax_rows_(P.view(Z * Tq, Tk4)[:, :Tk], scale)
         else:
-            bpad = torch.zeros(heads, Tq, Tk4, device=dev)
+            R = bias.shape[0]
+            assert Z % R == 0, (Z, R)
+            bpad = torch.zeros(R, Tq, Tk4, device=dev)
             bpad[:, :, :Tk].copy_(bias)
             ops.axpby(P, P, float(scale), 0.0)
             ops.add_periodic(P, bpad)
@@ -887,7 +903,7 @@ class Tape:
                 bmm(gh, vh, dS[:, :, :Tk], Tq, Tk, dh)
                 ops.softmax_rows_bwd_(P.view(Z * Tq, Tk4)[:, :Tk], dS.view(Z * Tq, Tk4)[:, :Tk])
                 if bias is not None and on_dbias is not None:
-                    db = torch.empty(heads, Tq, Tk4, device=dev)
+                    db = torch.empty(bias.shape[0], Tq, Tk4, device=dev)
                     ops.sum_periodic(dS, db)
                     on_dbias(db[:, :, :Tk])
                 ops.axpby(dS, dS, float(scale), 0.0)

@@ -133,6 +133,10 @@ def relu_mask(g, y):
     g.mul_((y > 0).to(g.dtype))
 
 
+def leaky_relu_mask(g, y, slope):
+    g.mul_(torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope)))
+
+
 def unary(x, y, kind):
     y.copy_(F.gelu(x) if kind == "gelu" else torch.sigmoid(x))
     return y
@@ -276,7 +280,7 @@ def bilinear_resize(x, Ho, Wo):
     return _nhwc(F.interpolate(_nchw(x), (Ho, Wo), mode="bilinear", align_corners=False)).contiguous()
 
 
-NAMES = ["dwconv3x3", "gelu_gate", "mul_sigmoid", "mul", "rowdot", "add_periodic", "sum_periodic", "maxpool2d", "maxpool2d_bwd",
+NAMES = ["leaky_relu_mask", "dwconv3x3", "gelu_gate", "mul_sigmoid", "mul", "rowdot", "add_periodic", "sum_periodic", "maxpool2d", "maxpool2d_bwd",
          "bilinear_resize",
          "pack_conv_weight", "conv3x3", "conv3x3_wgrad", "gemm_nt", "linear_wgrad", "gemm_nt_batched", "softmax_rows_",
          "softmax_rows_bwd_", "layernorm_rows", "layernorm_rows_bwd", "unfold", "fold", "axpby", "leaky_relu_", "relu_mask",

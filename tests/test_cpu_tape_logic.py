@@ -77,3 +77,40 @@ def test_omnisr_tape_wiring_against_reference_gradients(monkeypatch):
         assert e <= 2e-4, (k, e)
         n += 1
     assert n == int(g["n_grads"])
+
+
+def test_grl_tape_wiring_against_reference_gradients(monkeypatch):
+    """srhip/grl_engine.py::_forward_tape: cosine window attention (shifted: bias + mask per window), the anchored stripe
+    attention both ways, logit scales (one over the clamp), the CPB MLPs, the local conv branch -- against
+    tests/golden/g48_grl_grad.npz."""
+    import emul_ops
+    import sr_oracle as O
+    from dlib.models.network_grl import GRL
+    emul_ops.install(monkeypatch)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g48_grl_grad.npz"))
+    g = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("x2/")}
+    net = GRL(upscale=2, img_size=16, in_chans=1, window_size=8, mlp_ratio=2, qkv_proj_type="linear", anchor_proj_type="avgpool",
+              anchor_window_down_factor=2, out_proj_type="linear", conv_type="1conv", upsampler="pixelshuffle",
+              local_connection=True, depths=[2, 2], embed_dim=36, num_heads_window=[3, 3], num_heads_stripe=[3, 3])
+    layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    net.load_state_dict(O.grl_state_dict(layout, int(g["seed"]), 16), strict=True)
+    net.train()
+    x, tgt = g["x"], g["tgt"]
+    eng = net.engine
+    y = eng.forward(x[:, 0].contiguous(), None, save=True)
+    assert (y - g["y"]).abs().max().item() <= 2e-5 * g["y"].abs().max().item()
+    dy = torch.sign(y - tgt) / y.numel()
+    grads = {k: torch.full_like(p, float("nan")) for k, p in net.named_parameters()}
+    eng.backward(dy, grads)
+    n = 0
+    for k, got in grads.items():
+        if "grad/" + k in g:
+            ref = g["grad/" + k]
+            e = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+        else:
+            ref, sums = g["gslice/" + k], g["gsum/" + k]
+            e = ((got[:2] - ref).abs().max() / sums[2].float().clamp_min(1e-30)).item()
+            assert abs(got.double().sum().item() - sums[0].item()) <= 1e-4 * sums[1].item(), k
+        assert e <= (2e-3 if k.endswith("logit_scale") else 2e-4), (k, e)
+        n += 1
+    assert n == int(g["n_grads"])

@@ -825,9 +825,69 @@ def test_grl_forward_vs_reference_golden(scale):
             assert rel(v, taps_o[k]) < 2e-5, (k, rel(v, taps_o[k]))
     assert y.shape == g["y"].shape
     assert (y - g["y"]).abs().mean().item() <= 1e-5 * max(1.0, g["y"].abs().max().item()) and rel(y, g["y"]) < 3e-5, rel(y, g["y"])
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(g["x"].cuda()).sum().backward()
+    if scale != 4:                          # the training forward (the tape graph; window-multiple inputs) computes the same image
+        net.train()
+        yt = net(g["x"].cuda()).detach().cpu()
+        assert rel(yt, g["y"]) < 3e-5, rel(yt, g["y"])
+
+
+def test_grl_training_step_gradients_vs_reference_golden():
+    """GRL trains: forward in training mode, L1 loss, every parameter gradient of the narrow x2
+    configuration against the REFERENCE's own autograd (g48_grl_grad.npz, oracle/make_goldens.py::g_grl_grad) -- cosine window
+    attention under the shift (bias + mask per window as a periodic addend), the anchored stripe attention both ways, the
+    logit scales (one over the clamp: zero gradient), the CPB MLPs by hand, the C/4-channel convs as im2col + GEMM, the
+    post-norm residuals.  Gate 2e-5 of a tensor's largest entry or 3x the fp32 oracle's own distance from fp64 (the logit
+    scales: sums of ~1e-6 terms, 2e-3).  The same wiring with torch stand-ins for the kernels: tests/test_cpu_tape_logic.py."""
+    from dlib.models.network_grl import GRL
+    from srhip.train import TrainStep, Optimizer
+    scale = 2
+    g = {k[len(f"x{scale}/"):]: v for k, v in load("g48_grl_grad").items() if k.startswith(f"x{scale}/")}
+    net = GRL(upscale=scale, img_size=16, in_chans=1, window_size=8, mlp_ratio=2, qkv_proj_type="linear",
+              anchor_proj_type="avgpool", anchor_window_down_factor=2, out_proj_type="linear", conv_type="1conv",
+              upsampler="pixelshuffle", local_connection=True, depths=[2, 2], embed_dim=36, num_heads_window=[3, 3],
+              num_heads_stripe=[3, 3])
+    sd = O.grl_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], int(g["seed"]), 16)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=0.0, momentum=0.0, nesterov=False, wd=0.0)
+    x, tgt = g["x"], g["tgt"]
+    ts.step(x.cuda(), tgt.cuda())
+    assert abs(ts.loss_values()[0] - float(g["loss"])) <= 2e-5 * max(1.0, float(g["loss"]))
+    trainable = {k for k, p in net.named_parameters() if p.requires_grad}
+    sd64 = {k: (v.double().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+    (O.grl_forward(sd64, x.double(), scale, depths=(2, 2)) - tgt.double()).abs().mean().backward()
+    worst, n = ("", 0.0), 0
+    for k in ts.fp.names:
+        got, r64 = ts.fp.gviews[k].double().cpu(), sd64[k].grad
+        if "grad/" + k in g:
+            ref = g["grad/" + k].double()
+            den = ref.abs().max().clamp_min(1e-30)
+            e, e32 = ((got - ref).abs().max() / den).item(), ((ref - r64).abs().max() / den).item()
+        else:
+            ref, sums = g["gslice/" + k].double(), g["gsum/" + k].double()
+            den = sums[2].clamp_min(1e-30)
+            e, e32 = ((got[:2] - ref).abs().max() / den).item(), ((ref - r64[:2]).abs().max() / den).item()
+            e = max(e, ((got - r64).abs().max() / den).item() - e32)
+        worst, n = max(worst, (k, e), key=lambda t: t[1]), n + 1
+        assert e <= max(2e-3 if k.endswith("logit_scale") else 2e-5, 3.0 * e32), (k, e, e32)
+    assert n == int(g["n_grads"])
+    print(f"GRL x{scale} training step: loss {ts.loss_values()[0]:.6f}, worst gradient error {worst[1]:.2e} ({worst[0]})")
+
+
+def test_main_cli_trains_grl(tmp_path):
+    """`main.py --net_type GRL --max_iters 20`: the registry net (40 blocks) through ModelPlain's step, loss finite and falling."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "sr-caco-2_amd", "main.py"), "--net_type", "GRL", "--method", "GRL",
+                        "--task", "super-resolution", "--scale", "4", "--n_channels", "1", "--h_size", "128", "--batch_size", "2",
+                        "--max_iters", "20", "--G_optimizer_lr", "1e-4", "--outd", str(tmp_path)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    losses = [float(l.split("G_loss")[1].split()[0]) for l in p.stdout.splitlines() if "G_loss" in l]
+    assert len(losses) == 2 and all(np.isfinite(losses)) and losses[1] < losses[0], losses
 
 
 def test_grl_registry_default_width_vs_oracle():
