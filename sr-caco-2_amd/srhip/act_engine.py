@@ -343,14 +343,14 @@ class ACTEngine:
             xv = c3(xv, f"cnn_branch.{i}.body.{net.n_resblocks}", last, res=(x0, 1.0))
             tk_res, x_res = tk, xv
             f = t.cat_cols([xv, t.fold(tk, nf, ts, ts, B, H, W)])
-            f2, f_img = self._rows_of(t, f, B * H * W, 2 * nf)
+            f2 = t.reshape(f, B * H * W, 2 * nf)
             g = f2
             for j in range(4):
                 fb = net.fusion_block[i][j]
                 r = t.relu(t.linear(g, fb.body[0].weight, None, N(fb.body[0].weight)))
                 g = t.axpby(t.linear(r, fb.body[2].weight, None, N(fb.body[2].weight)), g)
             f2 = t.axpby(f2, g)
-            f = self._map_of(t, f2, B, H, W, 2 * nf)
+            f = t.reshape(f2, B, H, W, 2 * nf)
             if i != net.n_fusionblocks - 1:
                 # "x_tkn, x = torch.split(f, n_feats, 1)" (:527): the CNN half goes on as tokens, the token half as the map
                 tk = t.unfold(t.cols(f, 0, nf), ts, ts)
@@ -368,27 +368,6 @@ class ACTEngine:
         self.saved = (t, out)
         Bo, Ho, Wo = out.t.shape
         return out.t.view(Bo, 1, Ho, Wo)
-
-    @staticmethod
-    def _rows_of(t, v, M, C):
-        """an NHWC map as token rows [M, C] (a reshape: the gradient flows through a view of the same shape change)"""
-        r = t.var(v.t.reshape(M, C))
-        if t.save:
-            def bwd(v=v, r=r):
-                if r.g is not None:
-                    t.acc(v, lambda o: o.copy_(r.g.view(o.shape)))
-            t.back.append(bwd)
-        return r, v
-
-    @staticmethod
-    def _map_of(t, r, B, H, W, C):
-        m = t.var(r.t.view(B, H, W, C))
-        if t.save:
-            def bwd(r=r, m=m):
-                if m.g is not None:
-                    t.acc(r, lambda o: o.copy_(m.g.reshape(o.shape)))
-            t.back.append(bwd)
-        return m
 
     def backward(self, dy, grads, need_dx=False, on_layer_done=None, grads_zeroed=False):
         assert self.saved is not None, "backward() without a saved forward"

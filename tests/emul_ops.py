@@ -1,4 +1,5 @@
-"""Test infrastructure: torch (CPU) stand-ins for the libsrhip entry points the tape of srhip/act_engine.py calls, so that the
+"""Test infrastructure: torch (CPU) stand-ins for the libsrhip entry points the training tapes of srhip/act_engine.py,
+omnisr_engine.py and grl_engine.py call, so that the
 HOST logic of the tape -- which op feeds which, what each backward closure accumulates where, parameter names -- can be checked
 on a machine without a GPU against the reference's gradients (tests/test_cpu_tape_logic.py).  Nothing here is the product: the
 kernels themselves are tested on the GPU (tests/test_gpu_*.py), and the package has no CPU path (srhip.ops raises on CPU
