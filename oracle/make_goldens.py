@@ -196,7 +196,7 @@ def build_ref_swinir(cfg):
                   embed_dim=cfg["embed_dim"], num_heads=cfg["num_heads"],
                   mlp_ratio=cfg["mlp_ratio"], upsampler=cfg["upsampler"],
                   resi_connection=cfg["resi_connection"], ape=cfg.get("ape", False),
-                  patch_norm=cfg.get("patch_norm", True), qkv_bias=cfg.get("qkv_bias", True))
+                  patch_norm=cfg.get("patch_norm", True), qkv_bias=cfg.get("qkv_bias", True), qk_scale=cfg.get("qk_scale"))
 
 
 def perturb(sd, seed):
@@ -581,6 +581,16 @@ def g_swinir_plain_embed():
                           mlp_ratio=2, upsampler="pixelshuffledirect", drop_path_rate=0.0, patch_norm=False, qkv_bias=False)
     torch.manual_seed(180)
     _swinir_grad_golden("plain embed", "g46_swinir_plain_embed", cfg, torch.rand(2, 1, 16, 24), (181, 182, 183))
+
+
+def g_swinir_window4():
+    """window_size=4 with qk_scale=0.3 (network_swinir.py:102, 232-236): 16-token windows, shift 2 in the odd blocks, heads of
+    10 channels; the 'pixelshuffle' tail.  The HIP path runs such nets on its general tape graph (srhip/swinir_tape_engine.py)."""
+    print("G49 SwinIR tiny, window 4, qk_scale")
+    cfg = O.swinir_config(upscale=2, in_chans=1, img_size=16, window_size=4, depths=(2, 2), embed_dim=60, num_heads=(6, 6),
+                          mlp_ratio=2, upsampler="pixelshuffle", drop_path_rate=0.0, qk_scale=0.3, ape=True)
+    torch.manual_seed(190)
+    _swinir_grad_golden("window 4", "g49_swinir_window4", cfg, torch.rand(2, 1, 16, 16), (191, 192, 193))
 
 
 # ---------------------------------------------------------------- G21 training-crop sampler
@@ -2184,7 +2194,7 @@ def g_optim():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gens = [g_grl, g_grl_grad, g_omnisr, g_omnisr_grad, g_act, g_act_grad, g_dfcan, g_dfcan_grad, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
-            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv, g_swinir_ape, g_swinir_rgb, g_swinir_plain_embed]
+            g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv, g_swinir_ape, g_swinir_rgb, g_swinir_plain_embed, g_swinir_window4]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:
         if not only or g.__name__ in only:

@@ -86,9 +86,9 @@ def swinir_config(upscale=8, in_chans=1, img_size=64, window_size=8,
                   img_range=1.0, depths=(6, 6, 6, 6), embed_dim=180,
                   num_heads=(6, 6, 6, 6), mlp_ratio=2,
                   upsampler="pixelshuffledirect", resi_connection="1conv",
-                  drop_path_rate=0.1, ape=False, patch_norm=True, qkv_bias=True) -> dict:
+                  drop_path_rate=0.1, ape=False, patch_norm=True, qkv_bias=True, qk_scale=None) -> dict:
     """README.md:120-197 configuration by default."""
-    return dict(ape=ape, patch_norm=patch_norm, qkv_bias=qkv_bias, upscale=upscale, in_chans=in_chans, img_size=img_size,
+    return dict(ape=ape, patch_norm=patch_norm, qkv_bias=qkv_bias, qk_scale=qk_scale, upscale=upscale, in_chans=in_chans, img_size=img_size,
                 window_size=window_size, img_range=img_range,
                 depths=list(depths), embed_dim=embed_dim,
                 num_heads=list(num_heads), mlp_ratio=mlp_ratio,
@@ -103,7 +103,7 @@ def swinir_drop_path_rates(cfg: dict) -> List[float]:
 
 
 def _wmsa(sd: SD, pre: str, xw: Tensor, heads: int, mask: Optional[Tensor],
-          rpi: Tensor, taps: Optional[dict]) -> Tensor:
+          rpi: Tensor, taps: Optional[dict], qk_scale: Optional[float] = None) -> Tensor:
     """WindowAttention.forward, network_swinir.py:140-179."""
     nb, n, c = xw.shape
     d = c // heads
@@ -111,7 +111,7 @@ def _wmsa(sd: SD, pre: str, xw: Tensor, heads: int, mask: Optional[Tensor],
     if taps is not None:
         taps.setdefault("qkv", qkv.detach().clone())
     qkv = qkv.reshape(nb, n, 3, heads, d).permute(2, 0, 3, 1, 4)
-    q, k, v = qkv[0] * (d ** -0.5), qkv[1], qkv[2]
+    q, k, v = qkv[0] * (qk_scale or d ** -0.5), qkv[1], qkv[2]        # :102 (scale = qk_scale or head_dim ** -0.5)
     att = q @ k.transpose(-2, -1)
     bias = sd[pre + "relative_position_bias_table"][rpi.reshape(-1)]
     att = att + bias.reshape(n, n, heads).permute(2, 0, 1)[None]
@@ -128,7 +128,7 @@ def _wmsa(sd: SD, pre: str, xw: Tensor, heads: int, mask: Optional[Tensor],
 
 def _swin_block(sd: SD, pre: str, x: Tensor, hw: Tuple[int, int], ws: int,
                 shift: int, heads: int, dp_scale: Optional[Tensor],
-                rpi: Tensor, taps: Optional[dict]) -> Tensor:
+                rpi: Tensor, taps: Optional[dict], qk_scale: Optional[float] = None) -> Tensor:
     """SwinTransformerBlock.forward, network_swinir.py:287-337."""
     h, w = hw
     b, l, c = x.shape
@@ -142,7 +142,7 @@ def _swin_block(sd: SD, pre: str, x: Tensor, hw: Tuple[int, int], ws: int,
     else:
         mask = None
     yw = window_partition(y, ws).reshape(-1, ws * ws, c)
-    yw = _wmsa(sd, pre + "attn.", yw, heads, mask, rpi, taps)
+    yw = _wmsa(sd, pre + "attn.", yw, heads, mask, rpi, taps, qk_scale)
     y = window_reverse(yw.reshape(-1, ws, ws, c), ws, h, w)
     if shift:
         y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
@@ -214,7 +214,7 @@ def swinir_forward(sd: SD, x: Tensor, cfg: dict,
                             (h, w), wsj, shift, cfg["num_heads"][li],
                             None if dp_scales is None else dp_scales[bi],
                             rpi if wsj == ws else relative_position_index(wsj),
-                            taps if bi == 0 else None)
+                            taps if bi == 0 else None, cfg.get("qk_scale"))
             bi += 1
         img = t.transpose(1, 2).reshape(-1, c, h, w)  # PatchUnEmbed :651-655
         img = _resi_conv(sd, f"layers.{li}.conv", img, cfg)
@@ -1420,13 +1420,14 @@ def _grl_attn(sd: SD, pre: str, q: Tensor, k: Tensor, v: Tensor, table: Tensor, 
     attn = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)
     _, nh, N1, N2 = attn.shape
     attn = attn * torch.clamp(sd[pre + ".logit_scale"], max=math.log(1.0 / 0.01)).exp()
+    table = table.to(q.dtype)                     # (the float64 runs of the tests)
     bt = F.linear(F.relu(F.linear(table, sd[pre + ".cpb_mlp.0.weight"], sd[pre + ".cpb_mlp.0.bias"])),
                   sd[pre + ".cpb_mlp.2.weight"]).view(-1, nh)
     bias = bt[index.view(-1)].view(N1, N2, -1).permute(2, 0, 1).contiguous()
     attn = attn + (16 * torch.sigmoid(bias)).unsqueeze(0)
     if mask is not None:
         nW = mask.shape[0]
-        attn = (attn.view(B_ // nW, nW, nh, N1, N2) + mask.unsqueeze(1).unsqueeze(0)).view(-1, nh, N1, N2)
+        attn = (attn.view(B_ // nW, nW, nh, N1, N2) + mask.to(attn.dtype).unsqueeze(1).unsqueeze(0)).view(-1, nh, N1, N2)
     x = attn.softmax(-1) @ v
     if reshape:
         x = x.transpose(1, 2).reshape(B_, -1, H * hd)
