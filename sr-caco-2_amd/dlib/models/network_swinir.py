@@ -155,10 +155,14 @@ class SwinIR(nn.Module):
                  upsampler='', resi_connection=constants.R_CONNECTION_1CONV, **kwargs):
         super().__init__()
         unsupported = []
-        if window_size != 8:
-            unsupported.append(f"window_size={window_size} (HIP path: 8)")
+        # window_size != 8 or a given qk_scale: the general tape graph (srhip/swinir_tape_engine.py); otherwise the fused engine
+        self.use_tape = window_size != 8 or qk_scale is not None
+        self.qk_scale = qk_scale
         if not 1 <= in_chans <= 4:
             unsupported.append(f"in_chans={in_chans} (HIP path: 1 to 4 image channels)")
+        if self.use_tape and (in_chans != 1 or resi_connection != constants.R_CONNECTION_1CONV):
+            unsupported.append("window_size != 8 / qk_scale with in_chans != 1 or resi_connection '3conv' (the tape graph takes "
+                               "1-channel images and '1conv')")
         if upsampler not in (constants.US_PIXEL_SHUFFLE_DIRECT, constants.US_PIXEL_SHUFFLE, constants.US_NEAREST_CONV):
             unsupported.append(f"upsampler={upsampler!r} (HIP path: 'pixelshuffledirect', 'pixelshuffle', 'nearest_conv')")
         if upsampler == constants.US_NEAREST_CONV:
@@ -167,10 +171,10 @@ class SwinIR(nn.Module):
             unsupported.append(f"upscale={upscale} with 'pixelshuffle' (HIP path: powers of two)")
         if resi_connection not in (constants.R_CONNECTION_1CONV, constants.R_CONNECTION_3CONV):
             unsupported.append(f"resi_connection={resi_connection!r} (HIP path: '1conv', '3conv')")
-        if qk_scale is not None:
-            unsupported.append("qk_scale (HIP path: head_dim ** -0.5)")
-        if embed_dim > 256 or (embed_dim // num_heads[0]) not in (10, 16, 30, 32):
+        if not self.use_tape and (embed_dim > 256 or (embed_dim // num_heads[0]) not in (10, 16, 30, 32)):
             unsupported.append(f"embed_dim={embed_dim} / heads={num_heads}")
+        if self.use_tape and (embed_dim % 4 or any(embed_dim % h for h in num_heads)):
+            unsupported.append(f"embed_dim={embed_dim} / heads={num_heads} (a multiple of 4, divisible by the heads)")
         if unsupported:
             raise NotImplementedError("SwinIR on libsrhip does not support: " + "; ".join(unsupported))
         size = img_size if isinstance(img_size, (tuple, list)) else (img_size, img_size)
@@ -240,8 +244,12 @@ class SwinIR(nn.Module):
     @property
     def engine(self):
         if self._engine is None:
-            from srhip.swinir_engine import SwinIREngine
-            self._engine = SwinIREngine(self)
+            if self.use_tape:
+                from srhip.swinir_tape_engine import SwinIRTapeEngine
+                self._engine = SwinIRTapeEngine(self)
+            else:
+                from srhip.swinir_engine import SwinIREngine
+                self._engine = SwinIREngine(self)
         return self._engine
 
     def _apply(self, fn, *a, **k):   # .cuda() / .to(): parameter storage moves
@@ -314,7 +322,7 @@ class SwinIR(nn.Module):
         if dp is None:
             dp = self.sample_drop_path(x.shape[0], x.device)
         if xi.shape[1] <= self.window_size or xi.shape[2] <= self.window_size:
-            raise NotImplementedError("inputs must be larger than one 8x8 window")
+            raise NotImplementedError("inputs must be larger than one window")
         if self.ape and tuple(xi.shape[1:3]) != self.img_size:   # the reference's broadcast fails the same way (:919)
             raise RuntimeError(f"ape=True: the input has to be img_size {self.img_size}, got {tuple(xi.shape[1:3])}")
         params = [p for _, p in self.named_parameters()]

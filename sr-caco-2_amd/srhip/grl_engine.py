@@ -219,19 +219,7 @@ class GRLEngine:
             return t.layernorm_rows(x, m, N(m.weight), N(m.bias))
 
         def per_head(m, Hm, Wm, wsz, heads, shift, pad):
-            """NHWC map [B, Hm, Wm, heads dh] -> rows [(b, window, head, token), dh (zero-padded to `pad`)] and back"""
-            dh = m.t.shape[3] // heads
-            ny, nx = Hm // wsz[0], Wm // wsz[1]
-
-            def fwd(v):
-                if shift:
-                    v = torch.roll(v, shifts=(-shift, -shift), dims=(1, 2))
-                return v.reshape(B, ny, wsz[0], nx, wsz[1], heads, dh).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, dh)
-
-            def inv(u):
-                v = u.reshape(B, ny, nx, heads, wsz[0], wsz[1], dh).permute(0, 1, 4, 2, 5, 3, 6).reshape(B, Hm, Wm, heads * dh)
-                return torch.roll(v, shifts=(shift, shift), dims=(1, 2)) if shift else v
-            return t.relayout(m, fwd, inv, pad_last=pad), fwd, inv
+            return t.window_heads(m, wsz, heads, shift, pad)
 
         def cosine_attention(tr, qr, kr, vr, nWin, heads, Tq, Tk, table, index, mask):
             """qr / kr / vr: per-head rows; returns per-head rows [(b, window, head, Tq), dh4]"""
@@ -299,7 +287,7 @@ class GRLEngine:
             ow = cosine_attention(tr, q, k, v, nW, hw, ws[0] * ws[1], ws[0] * ws[1], net.table_w, net.index_w,
                                   mask_w if shift else None)
             dhw = half // hw
-            xw = t.relayout(ow, lambda u: inv_w(u[..., :dhw]), lambda g: F.pad(fwd_w(g), (0, dw4 - dhw)))
+            xw = t.heads_windows(ow, fwd_w, inv_w, dhw, dw4)
             # anchored stripe attention
             ds4 = (half // hs + 3) & ~3
             dhs = half // hs
@@ -314,7 +302,7 @@ class GRLEngine:
                                   getattr(net, f"index_s{sfx}_a2w"), None)
             os_ = cosine_attention(st.attn_transform2, q, an, xa, nS, hs, Ts, Ta, getattr(net, "table_s" + sfx),
                                    getattr(net, f"index_s{sfx}_w2a"), None)
-            xs = t.relayout(os_, lambda u: inv_s(u[..., :dhs]), lambda g: F.pad(fwd_s(g), (0, ds4 - dhs)))
+            xs = t.heads_windows(os_, fwd_s, inv_s, dhs, ds4)
             return xw, xs, xmap, a
 
         f0 = t.conv_in1(x3, net.conv_first.weight, net.conv_first.bias, (N(net.conv_first.weight), N(net.conv_first.bias)))

@@ -1202,6 +1202,58 @@ class Tape:
             self.back.append(bwd)
         return out
 
+    def window_heads(self, m, wsz, heads, shift=0, pad=None):
+        """NHWC map [B, Hm, Wm, heads dh] -> rows [(b, window, head, token), dh (zero-padded to `pad`)]: roll by -shift,
+        window partition, one row block per head.  Returns (Var, fwd, inv): the view chains both ways (inv on unpadded rows)."""
+        B, Hm, Wm, Ch = m.t.shape
+        dh = Ch // heads
+        ny, nx = Hm // wsz[0], Wm // wsz[1]
+
+        def fwd(v):
+            if shift:
+                v = torch.roll(v, shifts=(-shift, -shift), dims=(1, 2))
+            return v.reshape(B, ny, wsz[0], nx, wsz[1], heads, dh).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, dh)
+
+        def inv(u):
+            v = u.reshape(B, ny, nx, heads, wsz[0], wsz[1], dh).permute(0, 1, 4, 2, 5, 3, 6).reshape(B, Hm, Wm, heads * dh)
+            return torch.roll(v, shifts=(shift, shift), dims=(1, 2)) if shift else v
+        return self.relayout(m, fwd, inv, pad_last=pad), fwd, inv
+
+    def heads_windows(self, rows, fwd, inv, dh, pad):
+        """the way back from window_heads' row form (rows [.., pad], the first dh columns used) to the NHWC map"""
+        return self.relayout(rows, lambda u: inv(u[..., :dh]), lambda g: torch.nn.functional.pad(fwd(g), (0, pad - dh)))
+
+    def add_rows_param(self, x, param, name):
+        """x [B L, C] + param [1, L, C] for every sample (SwinIR's absolute position embedding, network_swinir.py:918-919);
+        the parameter's gradient is the sum over the samples."""
+        y = self.new(*x.t.shape)
+        y.copy_(x.t)
+        ops.add_periodic(y, param.data.reshape(-1).contiguous())
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out):
+                if out.g is None:
+                    return
+                g = self._c(out.g)
+                self.gparam(name, lambda o: ops.sum_periodic(g, o))
+                self.acc(x, lambda o: o.copy_(g))
+            self.back.append(bwd)
+        return out
+
+    def nearest_up2(self, x):
+        """F.interpolate(scale_factor=2, mode='nearest') on an NHWC map; the adjoint adds the four copies."""
+        xin = self._c(x.t)
+        B, h, w, C = xin.shape
+        y = self.new(B, 2 * h, 2 * w, C)
+        ops.nearest_up2(xin, y)
+        out = self._out(y)
+        if self.save:
+            def bwd(x=x, out=out):
+                if out.g is not None:
+                    self.acc(x, lambda o: ops.nearest_up2(o, self._c(out.g), adjoint=True))
+            self.back.append(bwd)
+        return out
+
     def conv_in1(self, x3, weight, bias, names):
         """first conv of a 1-channel image: x3 [B, H, W] -> [B, H, W, Co] (small.hip)."""
         B, H, W = x3.shape

@@ -138,6 +138,15 @@ def leaky_relu_mask(g, y, slope):
     g.mul_(torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope)))
 
 
+def nearest_up2(lo, hi, adjoint=False):
+    B, h, w, C = lo.shape
+    if adjoint:
+        lo.copy_(hi.reshape(B, h, 2, w, 2, C).sum((2, 4)))
+        return lo
+    hi.copy_(lo.repeat_interleave(2, 1).repeat_interleave(2, 2))
+    return hi
+
+
 def unary(x, y, kind):
     y.copy_(F.gelu(x) if kind == "gelu" else torch.sigmoid(x))
     return y
@@ -281,7 +290,7 @@ def bilinear_resize(x, Ho, Wo):
     return _nhwc(F.interpolate(_nchw(x), (Ho, Wo), mode="bilinear", align_corners=False)).contiguous()
 
 
-NAMES = ["leaky_relu_mask", "dwconv3x3", "gelu_gate", "mul_sigmoid", "mul", "rowdot", "add_periodic", "sum_periodic", "maxpool2d", "maxpool2d_bwd",
+NAMES = ["nearest_up2", "leaky_relu_mask", "dwconv3x3", "gelu_gate", "mul_sigmoid", "mul", "rowdot", "add_periodic", "sum_periodic", "maxpool2d", "maxpool2d_bwd",
          "bilinear_resize",
          "pack_conv_weight", "conv3x3", "conv3x3_wgrad", "gemm_nt", "linear_wgrad", "gemm_nt_batched", "softmax_rows_",
          "softmax_rows_bwd_", "layernorm_rows", "layernorm_rows_bwd", "unfold", "fold", "axpby", "leaky_relu_", "relu_mask",

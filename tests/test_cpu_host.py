@@ -72,8 +72,10 @@ def test_cpu_tensors_fail_loudly():
         loss.L1(cuda_id="cpu")(epoch=0, y_pred=torch.rand(1, 1, 8, 8), y_target=torch.rand(1, 1, 8, 8))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         metrics.mbatch_gpu_calculate_psnr(torch.rand(1, 1, 32, 32), torch.rand(1, 1, 32, 32))
-    with pytest.raises(NotImplementedError):
-        SwinIR(upscale=4, in_chans=1, img_size=64, window_size=7, upsampler="pixelshuffle")
+    with pytest.raises(NotImplementedError):                    # the general-window tape graph takes 1-channel images
+        SwinIR(upscale=4, in_chans=3, img_size=64, window_size=7, upsampler="pixelshuffle")
+    assert SwinIR(upscale=4, in_chans=1, img_size=64, window_size=4, upsampler="pixelshuffle", embed_dim=60, depths=[2],
+                  num_heads=[6]).use_tape
     # dropout rates: accepted (evaluation is the identity), a training-mode forward refuses
     nd = SwinIR(upscale=2, in_chans=1, img_size=16, window_size=8, depths=[2], embed_dim=60, num_heads=[6], mlp_ratio=2,
                 upsampler="pixelshuffledirect", drop_rate=0.1, attn_drop_rate=0.1)

@@ -114,3 +114,31 @@ def test_grl_tape_wiring_against_reference_gradients(monkeypatch):
         assert e <= (2e-3 if k.endswith("logit_scale") else 2e-4), (k, e)
         n += 1
     assert n == int(g["n_grads"])
+
+
+def test_swinir_general_window_tape_wiring_against_reference_gradients(monkeypatch):
+    """srhip/swinir_tape_engine.py (window_size 4, qk_scale 0.3, ape, shifted odd blocks, 'pixelshuffle' tail) against
+    tests/golden/g49_swinir_window4.npz: state_dict layout, eval forward, every parameter gradient."""
+    import emul_ops
+    from dlib.models.network_swinir import SwinIR
+    emul_ops.install(monkeypatch)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g49_swinir_window4.npz"))
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    net = SwinIR(upscale=2, in_chans=1, img_size=16, window_size=4, depths=[2, 2], embed_dim=60, num_heads=[6, 6], mlp_ratio=2,
+                 upsampler="pixelshuffle", drop_path_rate=0.0, qk_scale=0.3, ape=True)
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd/")}
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    eng = net.engine
+    assert type(eng).__name__ == "SwinIRTapeEngine"
+    x = g["x"][:, 0].contiguous()
+    y_eval = eng.forward(x, None, save=False)
+    assert (y_eval - g["y_eval"]).abs().max().item() <= 2e-5
+    y = eng.forward(x, None, save=True)
+    dy = torch.sign(y - g["target"]) / y.numel()
+    grads = {k: torch.full_like(p, float("nan")) for k, p in net.named_parameters()}
+    eng.backward(dy, grads)
+    for k, got in grads.items():
+        ref = g["grad/" + k]
+        e = ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+        assert e <= 2e-4, (k, e)

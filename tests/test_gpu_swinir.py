@@ -448,6 +448,44 @@ def test_without_patch_norm_and_qkv_bias_vs_reference_golden(SwinIR):
         assert l2(ts.fp.gviews[k].cpu(), g["grad/" + k]) <= 2e-4, k
 
 
+def test_general_window_and_qk_scale_on_the_tape_graph_vs_reference_golden(SwinIR):
+    """window_size=4, qk_scale=0.3 (network_swinir.py:102, 232-236), ape, shifted odd blocks, 'pixelshuffle' tail: the general
+    tape graph (srhip/swinir_tape_engine.py; the fused engine owns 8 x 8 windows).  Reference golden g49: keys / order, eval
+    forward, every gradient through the autograd path and through the fused step; DropPath multipliers scale the branches."""
+    from srhip.train import TrainStep, Optimizer
+    g = load("g49_swinir_window4")
+    net = SwinIR(upscale=2, in_chans=1, img_size=16, window_size=4, depths=[2, 2], embed_dim=60, num_heads=[6, 6], mlp_ratio=2,
+                 upsampler="pixelshuffle", drop_path_rate=0.0, qk_scale=0.3, ape=True)
+    assert list(net.state_dict().keys()) == list(sub(g, "sd/").keys())
+    net.load_state_dict(sub(g, "sd/"), strict=True)
+    net = net.cuda().eval()
+    assert type(net.engine).__name__ == "SwinIRTapeEngine"
+    with torch.no_grad():
+        y = net(g["x"].cuda()).cpu()
+    assert y.shape == g["y_eval"].shape and (y - g["y_eval"]).abs().max() <= 1e-5
+    net.train()
+    (net(g["x"].cuda()) - g["target"].cuda()).abs().mean().backward()
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    worst = ("", 0.0)
+    for k, p in net.named_parameters():
+        e = l2(p.grad.cpu(), g["grad/" + k])
+        assert e <= 2e-4, f"grad {k}: relative L2 error {e:.2e}"
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    print("window 4 / qk_scale: worst grad", worst)
+    ts = TrainStep(net, [("l1", 1.0)])
+    ts.opt = Optimizer(ts.fp, "sgd", lr=1e-12, momentum=0.0, nesterov=False, wd=0.0)
+    ts.step(g["x"].cuda(), g["target"].cuda())
+    for k, _ in net.named_parameters():
+        assert l2(ts.fp.gviews[k].cpu(), g["grad/" + k]) <= 2e-4, k
+    # DropPath multipliers: zeros on every branch leave the blocks as identities
+    dp0 = torch.zeros(8, 2, device="cuda")
+    with torch.no_grad():
+        xi, _, _ = net.prepare_input(g["x"].cuda())
+        y0 = net.engine.forward(xi, dp0, save=False)
+        y1 = net.engine.forward(xi, torch.ones(8, 2, device="cuda"), save=False)
+    assert not torch.equal(y0, y1) and (y1.cpu() - g["y_eval"]).abs().max() <= 1e-5
+
+
 def test_step_graph_replays_the_eager_step_bit_for_bit(SwinIR):
     """TrainStep.step_graph (one hipGraph replay per step) against TrainStep.step (~70 launches for this net):
     20 steps from the same weights on a changing batch, SGD-Nesterov with a MyStepLR schedule that halves the rate
