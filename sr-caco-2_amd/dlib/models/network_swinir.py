@@ -160,9 +160,6 @@ class SwinIR(nn.Module):
         self.qk_scale = qk_scale
         if not 1 <= in_chans <= 4:
             unsupported.append(f"in_chans={in_chans} (HIP path: 1 to 4 image channels)")
-        if self.use_tape and (in_chans != 1 or resi_connection != constants.R_CONNECTION_1CONV):
-            unsupported.append("window_size != 8 / qk_scale with in_chans != 1 or resi_connection '3conv' (the tape graph takes "
-                               "1-channel images and '1conv')")
         if upsampler not in (constants.US_PIXEL_SHUFFLE_DIRECT, constants.US_PIXEL_SHUFFLE, constants.US_NEAREST_CONV):
             unsupported.append(f"upsampler={upsampler!r} (HIP path: 'pixelshuffledirect', 'pixelshuffle', 'nearest_conv')")
         if upsampler == constants.US_NEAREST_CONV:

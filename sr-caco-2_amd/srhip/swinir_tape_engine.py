@@ -3,7 +3,8 @@ any window_size, qk_scale -- on the general tape graph (srhip/tape.py).  Referen
 :140-179 (WindowAttention), :907-970 (forward).  Every window attention runs on rows per (window, head): batched GEMMs around
 the row softmax, the relative-position bias (+ the shift mask per window) as a periodic addend, its table's gradient gathered
 back through the index; roll / window partition / reverse are the relayout copies around it; Linears on the exact-f32 GEMM,
-3 x 3 convs on the conv kernels.  Slower than the fused engine by design (nothing is fused); the same kernels' parity."""
+3 x 3 convs on the conv kernels (the image-channel convs of RGB nets and the '3conv' residual convs as im2col GEMMs).
+Slower than the fused engine by design (nothing is fused); the same kernels' parity."""
 import math
 
 import torch
@@ -15,9 +16,6 @@ from .tape import Tape, WeightBank
 
 class SwinIRTapeEngine:
     def __init__(self, net):
-        if net.in_chans != 1:
-            raise NotImplementedError("SwinIR on libsrhip: window_size != 8 / qk_scale run on the tape graph, which takes "
-                                      "1-channel images")
         self.net = net
         self.bufs = _Bufs()
         self.bank = WeightBank()
@@ -57,12 +55,14 @@ class SwinIRTapeEngine:
         self.prepared = True
 
     def forward(self, x, dp=None, save=True):
-        """x [B, H, W] (multiples of the window) -> [B, 1, s H, s W]; dp: None or [2 nblocks, B] DropPath multipliers."""
+        """x [B, H, W] (1 channel) or NHWC [B, H, W, 4] (in_chans 2..4 zero-padded, as SwinIR.prepare_input hands it over), H and
+        W multiples of the window -> [B, in_chans, s H, s W]; dp: None or [2 nblocks, B] DropPath multipliers."""
         from dlib.models.network_swinir import _shift_mask
         if not self.prepared:
             self.prepare()
         net = self.net
-        B, H, W = x.shape
+        B, H, W = x.shape[:3]
+        ci = net.in_chans
         C, L = net.embed_dim, H * W
         T = B * L
         dev = x.device
@@ -83,7 +83,20 @@ class SwinIRTapeEngine:
             """the conv in front of a residual connection ('1conv' | '3conv', :543-552) + skip"""
             if getattr(net, "resi_connection", "1conv") == "1conv":
                 return c3(v, key, m, res=(skip, 1.0))
-            raise NotImplementedError("SwinIR (tape graph): resi_connection '3conv' runs on the fused engine only (window 8)")
+            # '3conv': conv C -> C/4, LeakyReLU(0.2), 1x1, LeakyReLU(0.2), conv C/4 -> C as im2col GEMMs (any channel count)
+            c0 = t.relu(t.conv_im2col(v, m[0].weight, m[0].bias, N(m[0].weight), N(m[0].bias), 3), 0.2)
+            c1 = t.relu(t.conv_im2col(c0, m[2].weight, m[2].bias, N(m[2].weight), N(m[2].bias), 1), 0.2)
+            return t.axpby(t.conv_im2col(c1, m[4].weight, m[4].bias, N(m[4].weight), N(m[4].bias), 3), skip)
+
+        def to_image(v):
+            """NHWC [B, h, w, ci] -> the output layout [B, ci, h, w]"""
+            return t.relayout(v, lambda u: u.permute(0, 3, 1, 2), lambda g: g.permute(0, 2, 3, 1))
+
+        def last_conv(u):
+            m = net.conv_last
+            if ci == 1:
+                return t.conv_out1(u, m.weight, m.bias, (N(m.weight), N(m.bias)))
+            return to_image(t.conv_im2col(u, m.weight, m.bias, N(m.weight), N(m.bias), 3))
 
         def drop_path(v, k):
             if dp is None:
@@ -125,7 +138,11 @@ class SwinIRTapeEngine:
             m = lin(t.unary(lin(ln(x1, blk.norm2), blk.mlp.fc1), "gelu"), blk.mlp.fc2)
             return t.axpby(drop_path(m, 2 * bi + 1), x1)
 
-        f0 = t.conv_in1(x, net.conv_first.weight, net.conv_first.bias, (N(net.conv_first.weight), N(net.conv_first.bias)))
+        cf = net.conv_first
+        if ci == 1:
+            f0 = t.conv_in1(x, cf.weight, cf.bias, (N(cf.weight), N(cf.bias)))
+        else:
+            f0 = t.conv_im2col(t.var(x[..., :ci].contiguous(), need=False), cf.weight, cf.bias, N(cf.weight), N(cf.bias), 3)
         tk = t.reshape(f0, T, C)
         if net.patch_norm:
             tk = ln(tk, net.patch_embed.norm)
@@ -142,21 +159,21 @@ class SwinIRTapeEngine:
         f = resi(t.reshape(tk, B, H, W, C), "conv_after_body", net.conv_after_body, f0)
         s = net.upscale
         if net.upsampler == "pixelshuffledirect":
-            y = t.reshape(t.shuffle(c3(f, "upsample.0", net.upsample[0]), s), B, H * s, W * s)
+            y = t.shuffle(c3(f, "upsample.0", net.upsample[0]), s)
+            y = t.reshape(y, B, H * s, W * s) if ci == 1 else to_image(y)
         elif net.upsampler == "nearest_conv":
             u = t.relu(c3(f, "conv_before_upsample.0", net.conv_before_upsample[0]), 0.01)
             u = t.relu(c3(t.nearest_up2(u), "conv_up1", net.conv_up1), 0.2)
             u = t.relu(c3(t.nearest_up2(u), "conv_up2", net.conv_up2), 0.2)
-            u = t.relu(c3(u, "conv_hr", net.conv_hr), 0.2)
-            y = t.conv_out1(u, net.conv_last.weight, net.conv_last.bias, (N(net.conv_last.weight), N(net.conv_last.bias)))
+            y = last_conv(t.relu(c3(u, "conv_hr", net.conv_hr), 0.2))
         else:
             u = t.relu(c3(f, "conv_before_upsample.0", net.conv_before_upsample[0]), 0.01)
             for i in range(int(round(math.log2(s)))):
                 u = t.shuffle(c3(u, f"upsample.{2 * i}", net.upsample[2 * i]), 2)
-            y = t.conv_out1(u, net.conv_last.weight, net.conv_last.bias, (N(net.conv_last.weight), N(net.conv_last.bias)))
+            y = last_conv(u)
         if save:
             self.saved = (t, y)
-        return y.t.view(B, 1, H * s, W * s)
+        return y.t.reshape(B, ci, H * s, W * s)
 
     def backward(self, dy, grads, need_dx=False, on_layer_done=None, grads_zeroed=False):
         assert self.saved is not None, "backward() without a saved forward"

@@ -72,8 +72,10 @@ def test_cpu_tensors_fail_loudly():
         loss.L1(cuda_id="cpu")(epoch=0, y_pred=torch.rand(1, 1, 8, 8), y_target=torch.rand(1, 1, 8, 8))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         metrics.mbatch_gpu_calculate_psnr(torch.rand(1, 1, 32, 32), torch.rand(1, 1, 32, 32))
-    with pytest.raises(NotImplementedError):                    # the general-window tape graph takes 1-channel images
-        SwinIR(upscale=4, in_chans=3, img_size=64, window_size=7, upsampler="pixelshuffle")
+    with pytest.raises(NotImplementedError):                    # heads have to divide the embedding (a multiple of 4)
+        SwinIR(upscale=4, in_chans=1, img_size=64, window_size=7, upsampler="pixelshuffle", embed_dim=90, num_heads=[4], depths=[2])
+    with pytest.raises(NotImplementedError):
+        SwinIR(upscale=4, in_chans=5, img_size=64, window_size=8, upsampler="pixelshuffle")
     assert SwinIR(upscale=4, in_chans=1, img_size=64, window_size=4, upsampler="pixelshuffle", embed_dim=60, depths=[2],
                   num_heads=[6]).use_tape
     # dropout rates: accepted (evaluation is the identity), a training-mode forward refuses

@@ -142,3 +142,42 @@ def test_swinir_general_window_tape_wiring_against_reference_gradients(monkeypat
         ref = g["grad/" + k]
         e = ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
         assert e <= 2e-4, (k, e)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("g43_swinir_rgb_direct", dict(upscale=2, in_chans=3, depths=[2], num_heads=[6], upsampler="pixelshuffledirect", img_range=2.0)),
+    ("g44_swinir_rgb_pixelshuffle", dict(upscale=2, in_chans=3, depths=[2], num_heads=[6], upsampler="pixelshuffle", img_range=2.0)),
+    ("g27_swinir_3conv", dict(upscale=4, in_chans=1, depths=[2, 2], num_heads=[6, 6], upsampler="pixelshuffledirect",
+                              resi_connection="3conv")),
+])
+def test_swinir_tape_engine_rgb_and_3conv_against_reference_gradients(monkeypatch, name, kw):
+    """The general tape graph on configurations the fused engine also runs (8 x 8 windows): RGB input / output convs and the
+    '3conv' residual convs as im2col GEMMs -- reference goldens g43 / g44 / g27."""
+    import emul_ops
+    import torch.nn.functional as F
+    from dlib.models.network_swinir import SwinIR
+    from srhip.swinir_tape_engine import SwinIRTapeEngine
+    emul_ops.install(monkeypatch)
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    g = {k: torch.from_numpy(z[k]) for k in z.files}
+    net = SwinIR(img_size=16, window_size=8, embed_dim=60, mlp_ratio=2, drop_path_rate=0.0, **kw)
+    net.load_state_dict({k[3:]: v for k, v in g.items() if k.startswith("sd/")}, strict=True)
+    eng = SwinIRTapeEngine(net)
+    x, rng, ci = g["x"], float(kw.get("img_range", 1.0)), kw["in_chans"]
+    if ci == 1:
+        xi, mean = x[:, 0].contiguous(), 0.0
+    else:
+        mean = net.mean
+        xi = F.pad(((x - mean) * rng).permute(0, 2, 3, 1), (0, 4 - ci)).contiguous()
+    y = eng.forward(xi, None, save=True) / rng + mean
+    assert (y - g["y_eval"]).abs().max().item() <= 2e-5
+    dy = torch.sign(y - g["target"]) / y.numel() / rng
+    grads = {k: torch.full_like(p, float("nan")) for k, p in net.named_parameters()}
+    eng.backward(dy.contiguous(), grads)
+    for k, got in grads.items():
+        ref = g["grad/" + k]
+        e = ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+        assert e <= 2e-4, (k, e)

@@ -486,6 +486,35 @@ def test_general_window_and_qk_scale_on_the_tape_graph_vs_reference_golden(SwinI
     assert not torch.equal(y0, y1) and (y1.cpu() - g["y_eval"]).abs().max() <= 1e-5
 
 
+def test_tape_graph_rgb_3conv_nearest_conv_window4_vs_oracle(SwinIR):
+    """Everything the fused engine does not take at once -- window 4, qk_scale, RGB, '3conv', 'nearest_conv' x4, no patch norm,
+    no qkv bias -- on the general tape graph against the oracle's autograd (the oracle is pinned to the reference on each of
+    these by g25, g27, g43, g44, g46, g49)."""
+    cfg = O.swinir_config(upscale=4, in_chans=3, img_size=16, window_size=4, depths=(2,), embed_dim=60, num_heads=(6,), mlp_ratio=2,
+                          upsampler="nearest_conv", resi_connection="3conv", drop_path_rate=0.0, qk_scale=0.25, patch_norm=False,
+                          qkv_bias=False, img_range=2.0)
+    sd = O.swinir_init_state_dict(cfg, seed=95)
+    net = SwinIR(upscale=4, in_chans=3, img_size=16, window_size=4, depths=[2], embed_dim=60, num_heads=[6], mlp_ratio=2,
+                 upsampler="nearest_conv", resi_connection="3conv", drop_path_rate=0.0, qk_scale=0.25, patch_norm=False,
+                 qkv_bias=False, img_range=2.0)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    assert type(net.engine).__name__ == "SwinIRTapeEngine"
+    gen = torch.Generator().manual_seed(96)
+    x, tg = torch.rand(2, 3, 16, 20, generator=gen), torch.rand(2, 3, 64, 80, generator=gen)
+    y = net(x.cuda())
+    (y - tg.cuda()).abs().mean().backward()
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask") else v)
+           for k, v in sd.items()}
+    yo = O.swinir_forward(sdo, x, cfg)
+    (yo - tg).abs().mean().backward()
+    assert (y.detach().cpu() - yo.detach()).abs().max() <= 1e-5
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    for k, p in net.named_parameters():
+        assert l2(p.grad.cpu(), sdo[k].grad) <= 2e-4, k
+
+
 def test_step_graph_replays_the_eager_step_bit_for_bit(SwinIR):
     """TrainStep.step_graph (one hipGraph replay per step) against TrainStep.step (~70 launches for this net):
     20 steps from the same weights on a changing batch, SGD-Nesterov with a MyStepLR schedule that halves the rate
