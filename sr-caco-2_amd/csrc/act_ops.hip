@@ -95,14 +95,21 @@ __global__ void __launch_bounds__(256) k_layernorm_rows_bwd(const float* __restr
   for (int c = threadIdx.x; c < 2 * C; c += 256)
     pb[c] = (acc[c] + acc[2 * C + c]) + (acc[4 * C + c] + acc[6 * C + c]);
 }
+// 64 columns per block; the four waves each add every fourth block's partial, then wave 0 adds the four sums in order
 __global__ void __launch_bounds__(256) k_ln_rows_bwd_reduce(const float* __restrict__ part, int nblk, int C,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= 2 * C) return;
+  __shared__ float acc[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   float a = 0.f;
-  for (int b = 0; b < nblk; ++b) a += part[(long)b * 2 * C + c];
-  if (c < C) dgamma[c] = a;
-  else dbeta[c - C] = a;
+  if (c < 2 * C)
+    for (int b = q; b < nblk; b += 4) a += part[(long)b * 2 * C + c];
+  acc[q][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (q == 0 && c < 2 * C) {
+    a = (acc[0][threadIdx.x] + acc[1][threadIdx.x]) + (acc[2][threadIdx.x] + acc[3][threadIdx.x]);
+    if (c < C) dgamma[c] = a;
+    else dbeta[c - C] = a;
+  }
 }
 // the same for rows of at most 256 values, held in registers (one read of the row), with an optional residual: y = res + LN(x)
 __global__ void __launch_bounds__(256) k_layernorm_rows_reg(const float* __restrict__ x, long ldx, const float* __restrict__ res,
@@ -255,7 +262,7 @@ int srhip_layernorm_rows_bwd(const float* dy, long lddy, const float* x, long ld
   hipLaunchKernelGGL(k_layernorm_rows_bwd, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), (hipStream_t)stream, dy, lddy, x,
                      ldx, gamma, dx, lddx, ws, M, C, eps);
   SR_LAUNCH_CHECK("layernorm_rows_bwd");
-  hipLaunchKernelGGL(k_ln_rows_bwd_reduce, dim3(sr_cdiv(2 * C, 256)), dim3(256), 0, (hipStream_t)stream, ws, nblk, C, dgamma, dbeta);
+  hipLaunchKernelGGL(k_ln_rows_bwd_reduce, dim3(sr_cdiv(2 * C, 64)), dim3(256), 0, (hipStream_t)stream, ws, nblk, C, dgamma, dbeta);
   SR_LAUNCH_CHECK("layernorm_rows_bwd_reduce");
   return 0;
 }

@@ -28,6 +28,7 @@ class GRLEngine:
         self.saved = None
         self.taps = None
         self._w = {}
+        self._consts = {}                 # input-size constants (shift masks): survive invalidate()
         self.planes = PlaneCache()
         self.bufs = _Bufs()
         self.bank = WeightBank()
@@ -210,7 +211,10 @@ class GRLEngine:
         nm = {id(p): k for k, p in net.named_parameters()}
         N = lambda p: None if p is None else nm[id(p)]
         T = B * H * W
-        mask_w = table_index_mask((H, W), net.window_size, net.stripe_size, df)["mask_w"].to(dev)      # [nW, 64, 64]
+        key = ("mask_w", H, W)
+        if key not in self._consts:         # made once per input size (a host-built table: not inside a graph capture)
+            self._consts[key] = table_index_mask((H, W), net.window_size, net.stripe_size, df)["mask_w"].to(dev)
+        mask_w = self._consts[key]                                                                      # [nW, 64, 64]
 
         def lin(x, m):
             return t.linear(x, m.weight, m.bias, N(m.weight), N(m.bias))

@@ -21,6 +21,7 @@ class SwinIRTapeEngine:
         self.bank = WeightBank()
         self.prepared = False
         self.saved = None
+        self._masks = {}
 
     def invalidate(self):
         self.prepared = False
@@ -120,7 +121,10 @@ class SwinIRTapeEngine:
             idx = blk.attn.relative_position_index.reshape(-1).to(dev)
             bias = tab.data[idx].view(n, n, heads).permute(2, 0, 1)                         # [heads, n, n]
             if shift:
-                mask = _shift_mask(H, W, ws, shift).to(dev)                                  # [nW, n, n]
+                key = (H, W, ws, shift)
+                if key not in self._masks:  # made once per input size (host-built: not inside a graph capture)
+                    self._masks[key] = _shift_mask(H, W, ws, shift).to(dev)
+                mask = self._masks[key]                                                      # [nW, n, n]
                 addend = (bias.unsqueeze(0) + mask.unsqueeze(1)).reshape(-1, n, n).contiguous()
             else:
                 addend = bias.contiguous()

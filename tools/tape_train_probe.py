@@ -1,6 +1,6 @@
 """Training step of a registry tape net (ACT | OmniSR | GRL | ...) at the README batch: B = 8, 64 x 64 -> 512 x 512, L1 + SGD;
 prints ms per step, the loss before / after, peak memory.
-usage: python tools/tape_train_probe.py [ACT|OmniSR|GRL] [scale] [batch]"""
+usage: python tools/tape_train_probe.py [ACT|OmniSR|GRL] [scale] [batch] [graph]     (graph: TrainStep.step_graph, one hipGraph replay per step)"""
 import os
 import sys
 import time
@@ -14,6 +14,7 @@ from srhip.train import TrainStep  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "ACT"
 scale = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+graph = len(sys.argv) > 4 and sys.argv[4] == "graph"
 torch.manual_seed(0)
 if name == "ACT":
     from dlib.models.network_act import ACT
@@ -33,13 +34,14 @@ net = net.cuda().train()
 ts = TrainStep(net, [("l1", 1.0)])
 x, t = torch.rand(B, 1, 64, 64).cuda(), torch.rand(B, 1, 64 * scale, 64 * scale).cuda()
 losses = []
-for i in range(5):
-    if i == 2:
+n_warm = 4 if graph else 2
+for i in range(n_warm + 3):
+    if i == n_warm:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-    ts.step(x, t)
+    (ts.step_graph if graph else ts.step)(x, t)
     losses.append(ts.loss_values()[0])
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / 3 * 1e3
-print(f"{name} x{scale} B={B}: {ms:.1f} ms per training step = {B / ms * 1e3:.1f} patches/s; loss {losses[0]:.5f} -> {losses[-1]:.5f}; "
+print(f"{name} x{scale} B={B}{' (step_graph)' if graph else ''}: {ms:.1f} ms per training step = {B / ms * 1e3:.1f} patches/s; loss {losses[0]:.5f} -> {losses[-1]:.5f}; "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
