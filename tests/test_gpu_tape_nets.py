@@ -875,6 +875,39 @@ def test_grl_training_step_gradients_vs_reference_golden():
     print(f"GRL x{scale} training step: loss {ts.loss_values()[0]:.6f}, worst gradient error {worst[1]:.2e} ({worst[0]})")
 
 
+def test_tape_training_steps_replay_from_a_hipgraph():
+    """TrainStep.step_graph on the tape graphs written this round (OmniSR: window / grid / channel attention, index_add_ of the
+    bias table; GRL: shift masks cached per input size): five steps from the same weights, eager against replayed -- the same
+    loss trajectory (the bias tables' gradients go through atomics: 1e-5 relative)."""
+    from dlib.models.network_omni_sr import OmniSR
+    from dlib.models.network_grl import GRL
+    from srhip.train import TrainStep, Optimizer
+    gen = torch.Generator().manual_seed(3)
+    x, tg = torch.rand(2, 1, 16, 32, generator=gen).cuda(), torch.rand(2, 1, 32, 64, generator=gen).cuda()
+
+    def make(kind):
+        torch.manual_seed(11)
+        if kind == "omnisr":
+            return OmniSR(input_shape=1, upscale=2, num_feat=16, res_num=2, block_num=1)
+        return GRL(upscale=2, img_size=16, in_chans=1, window_size=8, mlp_ratio=2, qkv_proj_type="linear", anchor_proj_type="avgpool",
+                   anchor_window_down_factor=2, out_proj_type="linear", conv_type="1conv", upsampler="pixelshuffle",
+                   local_connection=True, depths=[2, 2], embed_dim=36, num_heads_window=[3, 3], num_heads_stripe=[3, 3])
+    for kind in ("omnisr", "grl"):
+        runs = []
+        for mode in ("eager", "graph"):
+            net = make(kind).cuda().train()
+            ts = TrainStep(net, [("l1", 1.0)])
+            ts.opt = Optimizer(ts.fp, "sgd", lr=0.01, momentum=0.9, nesterov=True, wd=0.0)
+            losses = []
+            for _ in range(5):
+                (ts.step if mode == "eager" else ts.step_graph)(x, tg)
+                losses.append(ts.loss_values()[0])
+            runs.append(losses)
+        assert runs[0][-1] < runs[0][0], (kind, runs[0])
+        for a, b in zip(*runs):
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (kind, runs)
+
+
 def test_main_cli_trains_grl(tmp_path):
     """`main.py --net_type GRL --max_iters 20`: the registry net (40 blocks) through ModelPlain's step, loss finite and falling."""
     import subprocess
