@@ -215,6 +215,9 @@ class GRL(TapeNet):
         self.df = anchor_window_down_factor
         self.heads_w, self.heads_s = list(num_heads_window), list(num_heads_stripe)
         self.local_connection = bool(local_connection)
+        # stochastic depth (network_grl.py:1262, 1012, 1058-1066): rate i of linspace(0, drop_path_rate, sum(depths)) on both
+        # residual branches of block i, timm's DropPath (per-sample Bernoulli(keep) / keep) in training mode
+        self.drop_probs = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
         self.pad_size = max(window_size, max(self.stripe_size))
         half = embed_dim // 2
         ok = (embed_dim % 4 == 0 and embed_dim >= 18 and window_size ** 2 <= 64 and self.stripe_size[0] * self.stripe_size[1] <= 64
@@ -240,6 +243,16 @@ class GRL(TapeNet):
                 nn.init.trunc_normal_(m.weight, std=0.02)
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
+
+    def sample_drop_path(self, batch, device):
+        """[2 nblocks, B] DropPath multipliers (one row per residual branch), None when nothing is dropped"""
+        if not self.training or max(self.drop_probs) == 0.0:
+            return None
+        cache = getattr(self, "_dp_keep", None)
+        if cache is None or cache.device != torch.device(device):
+            cache = self._dp_keep = 1.0 - torch.tensor(self.drop_probs, device=device).repeat_interleave(2)
+        mask = torch.bernoulli(cache[:, None].expand(-1, batch))
+        return (mask / cache[:, None]).contiguous()
 
     def _make_engine(self):
         from srhip.grl_engine import GRLEngine

@@ -140,7 +140,9 @@ class GRLEngine:
     # ------------------------------------------------------------------ forward
     def forward(self, x3, dp=None, save=False):
         if save:
-            return self._forward_tape(x3)
+            if dp is None:          # the autograd path (TrainStep draws the multipliers itself)
+                dp = self.net.sample_drop_path(x3.shape[0], x3.device)
+            return self._forward_tape(x3, dp)
         net = self.net
         B, H0, W0 = x3.shape
         p = net.pad_size
@@ -182,7 +184,7 @@ class GRLEngine:
         return ops.conv3x3_cout1_fwd(u, net.conv_last.weight.data, net.conv_last.bias.data)
 
     # ------------------------------------------------------------------ training: the same graph on the tape
-    def _forward_tape(self, x3):
+    def _forward_tape(self, x3, dp=None):
         """forward() with the tape recording (srhip/tape.py).  Every attention runs on rows per (window, head) -- L2-normalised
         queries / keys, the clamped logit scale on the query rows, 16 sigmoid(CPB MLP)[index] (+ the shift mask) as a
         periodic addend, batched GEMMs around the row softmax; roll / window partition / reverse are the relayout copies
@@ -259,6 +261,12 @@ class GRLEngine:
             return t.attend(qs, t.normalize_rows(kr), vr, B * nWin * heads, Tq, Tk, 1, qr.t.shape[1], 1.0, bias=addend,
                             on_dbias=on_dbias)
 
+        def drop(v, k):
+            """timm DropPath with the multipliers of branch k (network_grl.py:1058-1066)"""
+            if dp is None:
+                return v
+            return t.scale_rows(v, dp[k].repeat_interleave(H * W).contiguous(), lambda d: None)
+
         def avgpool(xmap):
             """nn.AvgPool2d(df): the df x df patches (F.unfold) against a constant averaging row"""
             Cc = xmap.t.shape[3]
@@ -311,12 +319,13 @@ class GRLEngine:
 
         f0 = t.conv_in1(x3, net.conv_first.weight, net.conv_first.bias, (N(net.conv_first.weight), N(net.conv_first.bias)))
         tk = ln(t.reshape(f0, T, C), net.norm_start)
+        bi = 0
         for si, stage in enumerate(net.layers):
             res = tk
             for i, blk in enumerate(stage.blocks):
                 xw, xs, xmap, a = block(blk, res, i, si, f"layers.{si}.blocks.{i}")
                 att = t.cat_cols([t.reshape(xw, T, half), t.reshape(xs, T, half)])
-                p = t.axpby(ln(lin(att, a.proj), blk.norm1), res)
+                p = t.axpby(drop(ln(lin(att, a.proj), blk.norm1), 2 * bi), res)
                 if net.local_connection:
                     cab = blk.conv.cab
                     c1 = t.unary(t.conv_im2col(xmap, cab[0].weight, cab[0].bias, N(cab[0].weight), N(cab[0].bias), 3), "gelu")
@@ -327,7 +336,8 @@ class GRLEngine:
                 else:
                     xn = p
                 m = lin(t.unary(lin(xn, blk.mlp.fc1), "gelu"), blk.mlp.fc2)
-                res = t.axpby(ln(m, blk.norm2), xn)
+                res = t.axpby(drop(ln(m, blk.norm2), 2 * bi + 1), xn)
+                bi += 1
             tk = t.reshape(t.conv(t.reshape(res, B, H, W, C), f"layers.{si}.conv", (N(stage.conv.weight), N(stage.conv.bias)),
                                   res=(t.reshape(tk, B, H, W, C), 1.0)), T, C)
         tk = ln(tk, net.norm_end)

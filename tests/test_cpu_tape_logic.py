@@ -91,7 +91,8 @@ def test_grl_tape_wiring_against_reference_gradients(monkeypatch):
     g = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("x2/")}
     net = GRL(upscale=2, img_size=16, in_chans=1, window_size=8, mlp_ratio=2, qkv_proj_type="linear", anchor_proj_type="avgpool",
               anchor_window_down_factor=2, out_proj_type="linear", conv_type="1conv", upsampler="pixelshuffle",
-              local_connection=True, depths=[2, 2], embed_dim=36, num_heads_window=[3, 3], num_heads_stripe=[3, 3])
+              local_connection=True, depths=[2, 2], embed_dim=36, num_heads_window=[3, 3], num_heads_stripe=[3, 3],
+              drop_path_rate=0.0)
     layout = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
     net.load_state_dict(O.grl_state_dict(layout, int(g["seed"]), 16), strict=True)
     net.train()
@@ -114,6 +115,14 @@ def test_grl_tape_wiring_against_reference_gradients(monkeypatch):
         assert e <= (2e-3 if k.endswith("logit_scale") else 2e-4), (k, e)
         n += 1
     assert n == int(g["n_grads"])
+    # stochastic depth (network_grl.py:1058-1066): multipliers of one leave the image as it is, zeros drop both branches
+    x3 = x[:, 0].contiguous()
+    y1 = eng._forward_tape(x3, torch.ones(8, 2)).clone()          # (the tape's buffers are persistent: clone what is kept)
+    y0 = eng._forward_tape(x3, torch.zeros(8, 2)).clone()
+    assert torch.allclose(y1, g["y"], atol=2e-5 * g["y"].abs().max().item()) and (y0 - y1).abs().max().item() > 1e-3
+    net.drop_probs = [0.0, 0.1, 0.2, 0.3]
+    dp = net.sample_drop_path(2, "cpu")
+    assert dp.shape == (8, 2) and set(dp[:2].flatten().tolist()) == {1.0} and net.eval().sample_drop_path(2, "cpu") is None
 
 
 def test_swinir_general_window_tape_wiring_against_reference_gradients(monkeypatch):

@@ -845,7 +845,7 @@ def test_grl_training_step_gradients_vs_reference_golden():
     net = GRL(upscale=scale, img_size=16, in_chans=1, window_size=8, mlp_ratio=2, qkv_proj_type="linear",
               anchor_proj_type="avgpool", anchor_window_down_factor=2, out_proj_type="linear", conv_type="1conv",
               upsampler="pixelshuffle", local_connection=True, depths=[2, 2], embed_dim=36, num_heads_window=[3, 3],
-              num_heads_stripe=[3, 3])
+              num_heads_stripe=[3, 3], drop_path_rate=0.0)
     sd = O.grl_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], int(g["seed"]), 16)
     net.load_state_dict(sd, strict=True)
     net = net.cuda().train()
@@ -891,7 +891,8 @@ def test_tape_training_steps_replay_from_a_hipgraph():
             return OmniSR(input_shape=1, upscale=2, num_feat=16, res_num=2, block_num=1)
         return GRL(upscale=2, img_size=16, in_chans=1, window_size=8, mlp_ratio=2, qkv_proj_type="linear", anchor_proj_type="avgpool",
                    anchor_window_down_factor=2, out_proj_type="linear", conv_type="1conv", upsampler="pixelshuffle",
-                   local_connection=True, depths=[2, 2], embed_dim=36, num_heads_window=[3, 3], num_heads_stripe=[3, 3])
+                   local_connection=True, depths=[2, 2], embed_dim=36, num_heads_window=[3, 3], num_heads_stripe=[3, 3],
+              drop_path_rate=0.0)
     for kind in ("omnisr", "grl"):
         runs = []
         for mode in ("eager", "graph"):
