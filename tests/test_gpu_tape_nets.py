@@ -809,7 +809,8 @@ def test_grl_forward_vs_reference_golden(scale):
     16 x 24 input against masks registered for 16 x 16.  Block outputs are checked one by one against the oracle's."""
     from dlib.models.network_grl import GRL
     g = {k[len(f"x{scale}/"):]: v for k, v in load("g38_grl").items() if k.startswith(f"x{scale}/")}
-    net = GRL(upscale=scale, img_size=16, depths=[2, 2], embed_dim=36, num_heads_window=[3, 3], num_heads_stripe=[3, 3], **GRL_KW)
+    net = GRL(upscale=scale, img_size=16, depths=[2, 2], embed_dim=36, num_heads_window=[3, 3], num_heads_stripe=[3, 3],
+              drop_path_rate=0.0, **GRL_KW)          # (0: the training-mode forward below is compared with the evaluation image)
     sd = O.grl_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], int(g["seed"]), 16)
     net.load_state_dict(sd, strict=True)
     net = net.cuda().eval()
