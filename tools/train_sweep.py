@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Training sweep over the sixteen registry networks: one MI355X, B = 8 synthetic 512 x 512 HR patches (x8: 64 x 64 LR), the
+registry's default options, ModelPlain.optimize_parameters (forward + L1 + backward + Adam) -- ms per step, patches/s and the
+loss before / after the timed steps.
+
+    python tools/train_sweep.py [--batch 8] [--scale 8] [--steps 4] [--nets GRL,ACT] [--out profiles/r04_train_sweep.json]
+
+Every network is built through the same ``main.parse_input`` / ``define_model`` path as ``main.py``."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sr-caco-2_amd"))
+import torch  # noqa: E402
+
+NETS = [("swinir", "SWINIR"), ("EDSR_LIIF", "EDSR_LIIF"), ("VDSR", "VDSR"), ("DRRN", "DRRN"), ("SRCNN", "SRCNN"),
+        ("MSLapSRN", "MSLAPSR"), ("MemNet", "MemNet"), ("DBPN", "DBPN"), ("SRFBN", "SRFBN"), ("ProSR", "PROSR"), ("ENLCN", "ENLCN"),
+        ("NLSN", "NLSN"), ("DFCAN", "DFCAN"), ("ACT", "ACT"), ("OmniSR", "OmniSR"), ("GRL", "GRL")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--scale", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--nets", default=None)
+    a = ap.parse_args()
+    only = set(a.nets.split(",")) if a.nets else None
+    import main as M
+    from dlib.models.select_model import define_model
+    rows = []
+    for net_type, method in NETS:
+        if only is not None and net_type not in only:
+            continue
+        argv = ["--net_type", net_type, "--method", method, "--task", "super-resolution", "--scale", str(a.scale), "--n_channels", "1",
+                "--h_size", "512", "--batch_size", str(a.batch), "--G_optimizer_lr", "1e-4"]
+        args = M.parse_input(argv)
+        torch.manual_seed(0)
+        row = {"net_type": net_type, "scale": a.scale, "batch": a.batch}
+        try:
+            model = define_model(args)
+            model.init_train()
+            model.feed_data(M.synth_batch(a.batch, a.scale, 512, model.device, 7))
+            for k in range(2):
+                model.optimize_parameters(0, k)
+            first = model.current_log()["G_loss"]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(a.steps):
+                model.optimize_parameters(0, 2 + k)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / a.steps * 1e3
+            last = model.current_log()["G_loss"]
+            row.update(ms_per_step=ms, patches_per_s=a.batch / ms * 1e3, loss_after_2_steps=float(first), loss_at_end=float(last),
+                       finite=bool(model.check_finite()), peak_memory_gib=torch.cuda.max_memory_allocated() / 2 ** 30)
+            del model
+        except Exception as e:      # a sweep row, not a gate: the tests are the gate
+            row["error"] = f"{type(e).__name__}: {e}"[:300]
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        rows.append(row)
+        print(json.dumps(row), flush=True)
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump({"what": "ModelPlain.optimize_parameters (forward + L1 + backward + Adam, eager) on synthetic 512x512 HR patches, "
+                               "one MI355X; registry default options per network", "rows": rows}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
