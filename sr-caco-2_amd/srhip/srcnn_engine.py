@@ -26,6 +26,7 @@ class SRCNNEngine:
         self._prep = self._prep_sig = None
         self.prepared = False
         self.saved = None
+        self.rows_max = ((1 << 29) - 1) // C1      # rows of a 1024-wide operand one GEMM call addresses (32-bit element offsets)
 
     def invalidate(self):
         self.prepared = False
@@ -110,20 +111,23 @@ class SRCNNEngine:
         b3.zero_()
         b3[:1].copy_(net.reconstruction.bias.data)
         y = torch.empty(B, H, W, device=dev) if not save else buf("y", B, H, W)
-        # the GEMM kernels address an operand with 32-bit element offsets (rows * 1024 < 2^29): inference walks
-        # the batch in groups of images that fit; a training step keeps the whole batch (the weight gradients
-        # reduce over all of it) and is limited to 2^19 pixels per rank by the same bound
-        per = max(1, ((1 << 29) - 1) // (C1 * H * W)) if not save else B
+        # the GEMM kernels address an operand with 32-bit element offsets (rows * 1024 < 2^29): the batch is walked in groups
+        # of images that fit (self.rows_max rows per call); a training step keeps every group's activations in whole-batch
+        # buffers and its backward walks the same groups, adding their weight gradients
+        per = max(1, self.rows_max // (H * W))
+        if save:
+            a0w, h1w, h2w = buf("a0", T, KP1), buf("h1", T, C1), buf("h2", T, C2)
         for b0 in range(0, B, per):
             nb = min(per, B - b0)
             t = nb * H * W
-            a0 = ops.im2col_c1(x[b0:b0 + nb], 5, KP1, out=buf("a0", t, KP1))
-            h1 = ops.gemm_nt(a0, ws["w1"], net.features[0].bias.data, out=buf("h1", t, C1), epi=1)
-            h2 = ops.gemm_nt(h1, ws["w2"], net.map[0].bias.data, out=buf("h2", t, C2), epi=1)
+            r0 = b0 * H * W
+            a0 = ops.im2col_c1(x[b0:b0 + nb], 5, KP1, out=a0w[r0:r0 + t] if save else buf("a0", t, KP1))
+            h1 = ops.gemm_nt(a0, ws["w1"], net.features[0].bias.data, out=h1w[r0:r0 + t] if save else buf("h1", t, C1), epi=1)
+            h2 = ops.gemm_nt(h1, ws["w2"], net.map[0].bias.data, out=h2w[r0:r0 + t] if save else buf("h2", t, C2), epi=1)
             y4 = ops.gemm_nt(h2, ws["w3"], b3, out=buf("y4", t, 4))
             y[b0:b0 + nb].view(t).copy_(y4[:, 0])
         if save:
-            self.saved = dict(a0=a0, h1=h1, h2=h2, B=B, H=H, W=W)
+            self.saved = dict(a0=a0w, h1=h1w, h2=h2w, B=B, H=H, W=W, per=per)
         return y.view(B, 1, H, W)
 
     def backward(self, dy, grads, need_dx=False, on_layer_done=None, grads_zeroed=False):
@@ -143,13 +147,26 @@ class SRCNNEngine:
         dy4[:, 0].copy_(dy.reshape(T))
         dw3, db3 = buf("dw3", 4, C2), buf("db3", 4)
         dw1 = buf("dw1", C1, KP1)
-        dh2 = ops.gemm_nt(dy4, ws["w3T"], None, out=buf("dh2", T, C2), epi=4, R=sv["h2"])     # * (h2 > 0)
-        dh1 = ops.gemm_nt(dh2, ws["w2T"], None, out=buf("dh1", T, C1), epi=4, R=sv["h1"])     # * (h1 > 0)
-        ops.linear_wgrad_grouped([
-            dict(dY=dy4, X=sv["h2"], dW=dw3, db=db3),
-            dict(dY=dh2, X=sv["h1"], dW=grads["map.0.weight"].view(C2, C1), db=grads["map.0.bias"]),
-            dict(dY=dh1, X=sv["a0"], dW=dw1, db=grads["features.0.bias"]),
-        ])
+        step = sv["per"] * H * W
+        for r0 in range(0, T, step):
+            r1 = min(T, r0 + step)
+            first = r0 == 0
+            dh2 = ops.gemm_nt(dy4[r0:r1], ws["w3T"], None, out=buf("dh2", r1 - r0, C2), epi=4, R=sv["h2"][r0:r1])     # * (h2 > 0)
+            dh1 = ops.gemm_nt(dh2, ws["w2T"], None, out=buf("dh1", r1 - r0, C1), epi=4, R=sv["h1"][r0:r1])            # * (h1 > 0)
+            # the first group writes the gradients, the others add theirs
+            tw3, tb3, tw1 = (dw3, db3, dw1) if first else (buf("dw3.t", 4, C2), buf("db3.t", 4), buf("dw1.t", C1, KP1))
+            tw2 = grads["map.0.weight"].view(C2, C1) if first else buf("dw2.t", C2, C1)
+            tb2 = grads["map.0.bias"] if first else buf("db2.t", C2)
+            tb1 = grads["features.0.bias"] if first else buf("db1.t", C1)
+            ops.linear_wgrad_grouped([
+                dict(dY=dy4[r0:r1], X=sv["h2"][r0:r1], dW=tw3, db=tb3),
+                dict(dY=dh2, X=sv["h1"][r0:r1], dW=tw2, db=tb2),
+                dict(dY=dh1, X=sv["a0"][r0:r1], dW=tw1, db=tb1),
+            ])
+            if not first:
+                for dst, src in ((dw3, tw3), (db3, tb3), (dw1, tw1), (grads["map.0.weight"].view(C2, C1), tw2),
+                                 (grads["map.0.bias"], tb2), (grads["features.0.bias"], tb1)):
+                    ops.axpby(dst, src, 1.0, 1.0)
         grads["reconstruction.weight"].view(1, C2).copy_(dw3[:1])
         grads["reconstruction.bias"].copy_(db3[:1])
         grads["features.0.weight"].view(C1, 25).copy_(dw1[:, :25])

@@ -193,6 +193,33 @@ def test_srcnn_fwd_bwd_vs_reference_golden_and_full_size_step():
             assert (p.detach().cpu() - sdo[k].detach()).abs().max() <= 2e-6, k
 
 
+def test_srcnn_training_step_walks_the_batch_in_groups():
+    """A training batch larger than one GEMM call addresses (rows x 1024 < 2^29: B = 8 of 512 x 512 is four groups) is walked in
+    groups of images, forward and backward, the weight gradients added up: with the limit forced down (three groups of one
+    40 x 40 image) the gradients are those of the ungrouped step."""
+    from dlib.models.network_srcnn import SRCNN
+    from srhip.train import TrainStep, Optimizer
+    gen = torch.Generator().manual_seed(70)
+    x, tgt = torch.rand(3, 1, 40, 40, generator=gen).cuda(), torch.rand(3, 1, 40, 40, generator=gen).cuda()
+    sd = O.srcnn_init_state_dict(1, seed=71, bias_std=0.05)
+    got = []
+    for rows_max in (None, 1600):
+        net = SRCNN(in_chans=1)
+        net.load_state_dict(sd, strict=True)
+        net = net.cuda().train()
+        if rows_max is not None:
+            net.engine.rows_max = rows_max
+        ts = TrainStep(net, [("l1", 1.0)])
+        ts.opt = Optimizer(ts.fp, "sgd", lr=0.0, momentum=0.0, nesterov=False, wd=0.0)
+        ts.step(x, tgt)
+        got.append((ts.loss_values()[0], {k: ts.fp.gviews[k].clone() for k in ts.fp.names}))
+        assert net.engine.saved["per"] == (3 if rows_max is None else 1)
+    assert abs(got[0][0] - got[1][0]) <= 1e-7
+    for k in got[0][1]:
+        a, b = got[0][1][k], got[1][1][k]
+        assert ((a - b).abs().max() / a.abs().max().clamp_min(1e-30)).item() <= 2e-6, k
+
+
 def test_vdsr_full_size_forward_and_train_step():
     """VDSR at the benchmark patch (1 x 64 x 64 -> 512 x 512): forward against the oracle (MAE <= 1e-5, PSNR
     within 0.01 dB) and one fused optimisation step against the oracle's autograd + SGD-Nesterov step."""

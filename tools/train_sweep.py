@@ -5,7 +5,8 @@ loss before / after the timed steps.
 
     python tools/train_sweep.py [--batch 8] [--scale 8] [--steps 4] [--nets GRL,ACT] [--out profiles/r04_train_sweep.json]
 
-Every network is built through the same ``main.parse_input`` / ``define_model`` path as ``main.py``."""
+Every network is built through the same ``main.parse_input`` / ``define_model`` path as ``main.py``; each one runs in its own
+process (a tape net keeps every activation of its step in persistent buffers: tens of GiB that die with the process)."""
 import argparse
 import json
 import os
@@ -14,8 +15,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sr-caco-2_amd"))
-import torch  # noqa: E402
-
 NETS = [("swinir", "SWINIR"), ("EDSR_LIIF", "EDSR_LIIF"), ("VDSR", "VDSR"), ("DRRN", "DRRN"), ("SRCNN", "SRCNN"),
         ("MSLapSRN", "MSLAPSR"), ("MemNet", "MemNet"), ("DBPN", "DBPN"), ("SRFBN", "SRFBN"), ("ProSR", "PROSR"), ("ENLCN", "ENLCN"),
         ("NLSN", "NLSN"), ("DFCAN", "DFCAN"), ("ACT", "ACT"), ("OmniSR", "OmniSR"), ("GRL", "GRL")]
@@ -28,8 +27,32 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--out", default=None)
     ap.add_argument("--nets", default=None)
+    ap.add_argument("--child", action="store_true", help="(internal) run the named nets in this process")
     a = ap.parse_args()
     only = set(a.nets.split(",")) if a.nets else None
+    if not a.child:             # the parent never touches the GPU: one child process per network
+        import subprocess
+        rows = []
+        for net_type, _ in NETS:
+            if only is not None and net_type not in only:
+                continue
+            cmd = [sys.executable, os.path.abspath(__file__), "--child", "--nets", net_type, "--batch", str(a.batch), "--scale",
+                   str(a.scale), "--steps", str(a.steps)]
+            try:
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+                row = json.loads(line[-1]) if line else {"net_type": net_type, "error": (p.stderr or "no output")[-300:]}
+            except subprocess.TimeoutExpired:
+                row = {"net_type": net_type, "error": "timeout"}
+            rows.append(row)
+            print(json.dumps(row), flush=True)
+            if a.out:           # rewritten after every row: a sweep cut short keeps what it measured
+                with open(a.out, "w") as f:
+                    json.dump({"what": "ModelPlain.optimize_parameters (forward + L1 + backward + Adam, eager: host launch time included) on "
+                               "synthetic 512x512 HR patches, one MI355X; registry default options per network; one process "
+                               "per network", "rows": rows}, f, indent=1)
+        return
+    import torch
     import main as M
     from dlib.models.select_model import define_model
     rows = []
@@ -64,10 +87,6 @@ def main():
         torch.cuda.reset_peak_memory_stats()
         rows.append(row)
         print(json.dumps(row), flush=True)
-    if a.out:
-        with open(a.out, "w") as f:
-            json.dump({"what": "ModelPlain.optimize_parameters (forward + L1 + backward + Adam, eager) on synthetic 512x512 HR patches, "
-                               "one MI355X; registry default options per network", "rows": rows}, f, indent=1)
 
 
 if __name__ == "__main__":
