@@ -213,7 +213,7 @@ def test_srcnn_training_step_walks_the_batch_in_groups():
         ts.opt = Optimizer(ts.fp, "sgd", lr=0.0, momentum=0.0, nesterov=False, wd=0.0)
         ts.step(x, tgt)
         got.append((ts.loss_values()[0], {k: ts.fp.gviews[k].clone() for k in ts.fp.names}))
-        assert net.engine.saved["per"] == (3 if rows_max is None else 1)
+        assert (net.engine.saved["per"] >= 3) if rows_max is None else (net.engine.saved["per"] == 1)      # images per group
     assert abs(got[0][0] - got[1][0]) <= 1e-7
     for k in got[0][1]:
         a, b = got[0][1][k], got[1][1][k]
