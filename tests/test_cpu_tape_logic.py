@@ -190,3 +190,33 @@ def test_swinir_tape_engine_rgb_and_3conv_against_reference_gradients(monkeypatc
         ref = g["grad/" + k]
         e = ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
         assert e <= 2e-4, (k, e)
+
+
+def test_swinir_tape_engine_droppath_multipliers_against_the_oracle(monkeypatch):
+    """DropPath on the general tape graph (row 2 i of the multipliers on block i's attention branch, 2 i + 1 on its MLP branch,
+    network_swinir.py:334-335): forward and gradients against the oracle run with the same per-sample multipliers."""
+    import emul_ops
+    import sr_oracle as O
+    from dlib.models.network_swinir import SwinIR
+    emul_ops.install(monkeypatch)
+    cfg = O.swinir_config(upscale=2, in_chans=1, img_size=16, window_size=4, depths=(2, 2), embed_dim=60, num_heads=(6, 6),
+                          mlp_ratio=2, upsampler="pixelshuffledirect", drop_path_rate=0.2, qk_scale=None)
+    sd = O.swinir_init_state_dict(cfg, seed=5)
+    net = SwinIR(upscale=2, in_chans=1, img_size=16, window_size=4, depths=[2, 2], embed_dim=60, num_heads=[6, 6], mlp_ratio=2,
+                 upsampler="pixelshuffledirect", drop_path_rate=0.2)
+    net.load_state_dict(sd, strict=True)
+    gen = torch.Generator().manual_seed(6)
+    x, tgt = torch.rand(3, 1, 16, 16, generator=gen), torch.rand(3, 1, 32, 32, generator=gen)
+    dp = torch.tensor([[0.0, 1.25, 1.25], [1.25, 1.25, 0.0], [1.0, 1.0, 1.0], [1.25, 0.0, 1.25],
+                       [1.5, 1.5, 0.0], [0.0, 1.5, 1.5], [2.0, 0.0, 0.0], [1.0, 1.0, 1.0]])
+    eng = net.engine
+    y = eng.forward(x[:, 0].contiguous(), dp, save=True)
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask") else v) for k, v in sd.items()}
+    yo = O.swinir_forward(sdo, x, cfg, dp_scales=dp.view(4, 2, 3))
+    assert (y - yo.detach()).abs().max().item() <= 2e-5
+    (yo - tgt).abs().mean().backward()
+    grads = {k: torch.full_like(p, float("nan")) for k, p in net.named_parameters()}
+    eng.backward((torch.sign(y - tgt) / y.numel()).contiguous(), grads)
+    for k, got in grads.items():
+        ref = sdo[k].grad
+        assert ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item() <= 2e-4, k
