@@ -203,6 +203,42 @@ def secondary_exact_f32(batch, dev, steps=5, warmup=2):
             os.environ["SRHIP_MM"] = old
 
 
+def secondary_model_plain(batch, steps=20, warmup=3):
+    """The headline workload through the PRODUCT entry point: main.parse_input (the README's flags) -> define_model ->
+    ModelPlain.feed_data / optimize_parameters, what `main.py` runs per iteration -- against `value`, which times
+    TrainStep.step directly.  (profiles/r04_train_sweep.json's 379 patches/s was the REGISTRY-DEFAULT SwinIR -- 36 blocks and
+    the conv 'pixelshuffle' upsampler, Adam -- not this README net of 24 blocks / 'pixelshuffledirect': VERDICT r4 item 3.)"""
+    import torch
+    import main as M
+    from dlib.models.select_model import define_model
+    argv = ["--task", "super-resolution", "--scale", "8", "--method", "SWINIR", "--net_type", "swinir", "--n_channels", "1",
+            "--h_size", "512", "--batch_size", str(batch), "--G_optimizer_type", "sgd", "--G_optimizer_lr", "0.01",
+            "--G_optimizer_wd", "0.0", "--G_scheduler_type", "MyStepLR", "--G_scheduler_step_size", "30",
+            "--G_scheduler_gamma", "0.5", "--swinir_window_size", "8", "--swinir_depths", "6+6+6+6",
+            "--swinir_embed_dim", "180", "--swinir_num_heads", "6+6+6+6", "--swinir_mlp_ratio", "2",
+            "--swinir_upsampler", "pixelshuffledirect", "--l1", "True", "--amp", "False",
+            "--outd", os.path.join(ROOT, "gpurun_out", "bench_model_plain")]
+    args = M.parse_input(argv)
+    torch.manual_seed(0)
+    model = define_model(args)
+    model.init_train()
+    model.feed_data(M.synth_batch(batch, 8, 512, model.device, 1000))
+    for k in range(warmup):
+        model.optimize_parameters(0, k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        model.optimize_parameters(0, warmup + k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"patches_per_s": batch * steps / dt, "ms_per_step": 1000.0 * dt / steps, "steps": steps,
+           "entry": "main.parse_input -> define_model -> ModelPlain.optimize_parameters (README flags, L1, SGD-Nesterov)",
+           "final_loss": float(model.current_log()["G_loss"]), "finite": bool(model.check_finite())}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def torch_rocm_baseline(batch, dev, steps=5, warmup=2):
     """The same step through the vendor-library path on the SAME GPU: the oracle's module (plain PyTorch ops: aten /
     rocBLAS / MIOpen kernels, fp32, autograd) on cuda, same batch, same L1 loss, SGD-Nesterov by torch.optim.  The
@@ -507,6 +543,10 @@ def worker(args):
         t_leg = time.perf_counter()
         secondary["swinir_x8_exact_f32"] = secondary_exact_f32(args.batch, dev)
         gpu_legs["secondary_exact_f32"] = time.perf_counter() - t_leg
+        t_leg = time.perf_counter()
+        secondary["model_plain"] = secondary_model_plain(args.batch)
+        secondary["model_plain_patches_per_s"] = secondary["model_plain"]["patches_per_s"]
+        gpu_legs["secondary_model_plain"] = time.perf_counter() - t_leg
         t_leg = time.perf_counter()
         secondary["eval_x8"] = secondary_eval_x8(args.batch)
         gpu_legs["secondary_eval_x8"] = time.perf_counter() - t_leg

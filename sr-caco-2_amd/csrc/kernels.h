@@ -112,6 +112,7 @@ struct MlpF16Args {
   const float* x0; long ldx0; const float* stats0; const float* res0; long ldres0; float* out0; long ldo0;
   long long* dbg;                    // experiment builds: phase timestamps
   int stagger;                       // experiment builds: start delay of odd blocks (10-ns units)
+  int stagger_mode; int* cu_count;   // experiment builds: 1 = delay the block that arrives second on its CU (per-CU arrival counters)
 };
 int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st);
 // the W-MSA half of a Swin block, forward, as one launch (wmsa_f16.hip); rows are token-major [B*H*W][..], dense

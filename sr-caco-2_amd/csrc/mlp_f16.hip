@@ -71,8 +71,9 @@ __device__ __forceinline__ void gelu_gate(float x, float& gate, float& gl) {
 // phase timestamps of every wave (tools/mb_mlp_phases.py): experiment builds only
 #ifdef SRHIP_EXPERIMENTS
 long long* g_mlp_dbg = nullptr;
+int* g_mlp_cu_count = nullptr;
 #define SR_TS(K) \
-  if (p.dbg && lane == 0) p.dbg[((long)blockIdx.x * 4 + wave) * 24 + (K)] = (long long)wall_clock64();
+  if (p.dbg && lane == 0) p.dbg[((long)blockIdx.x * 4 + wave) * 32 + (K)] = (long long)wall_clock64();
 #else
 #define SR_TS(K)
 #endif
@@ -162,9 +163,23 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane2 + boff2[jt]);
   };
 #ifdef SRHIP_EXPERIMENTS
-  if (p.stagger > 0 && (blockIdx.x & 1)) {           // experiment: every second block starts late (phases of the two halves interleave)
-    const long long t0 = (long long)wall_clock64();
-    while ((long long)wall_clock64() - t0 < p.stagger) __builtin_amdgcn_s_sleep(16);
+  {
+    // which CU runs this block: {xcc, se, sh, cu} of HW_REG_XCC_ID / HW_REG_HW_ID
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15;
+    const unsigned cuid = (xcc << 8) | (((hwid >> 13) & 7) << 5) | (((hwid >> 12) & 1) << 4) | ((hwid >> 8) & 15);
+    if (p.dbg && lane == 0) p.dbg[((long)blockIdx.x * 4 + wave) * 32 + 24] = (long long)cuid;
+    bool late = blockIdx.x & 1;                      // mode 0: odd blocks
+    if (p.stagger_mode == 1 && p.cu_count) {         // mode 1: the block that arrives second on its CU
+      __shared__ int s_slot;
+      if (tid == 0) s_slot = atomicAdd(p.cu_count + cuid, 1);
+      __syncthreads();
+      late = s_slot & 1;
+      if (p.dbg && lane == 0) p.dbg[((long)blockIdx.x * 4 + wave) * 32 + 25] = (long long)s_slot;
+    }
+    if (p.stagger > 0 && late) {                     // experiment: every second block starts late (phases of the two halves interleave)
+      const long long t0 = (long long)wall_clock64();
+      while ((long long)wall_clock64() - t0 < p.stagger) __builtin_amdgcn_s_sleep(16);
+    }
   }
 #endif
   SR_TS(0)
@@ -174,9 +189,15 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
   for (int i = 0; i < 4; ++i) a_off[i] = a_slot(16 * i + c, g) * 16;
   float* const T = (float*)smem;
 
-  // LayerNorm backward on the row-major tile in LDS (affine folded into the weight in front of it), four lanes per row,
-  // 12 x 16 bytes each:  o = res + rstd (d - mean(d) - xhat mean(d xhat)),  xhat = (x - mean) rstd.  The rows are
-  // stored and stay in the registers of the threads that computed them; returns the largest |o| of the thread's part.
+  // LayerNorm backward on the row-major tile in LDS (affine folded into the weight in front of it), four lanes per row:
+  //   o = res + rstd (d - mean(d) - xhat mean(d xhat)),  xhat = (x - mean) rstd.
+  // A thread owns the k octets (stage s6, octet q) of its row -- columns 32 s6 + 8 q .. + 7, the x staging's own mapping:
+  // a wave instruction covers 16 rows x 128 contiguous bytes (each cache line used whole by the instruction pair e = 0, 1),
+  // and an octet is one 16-byte unit of a stage image afterwards.  (Round 4 gave a thread 48 CONSECUTIVE columns: every
+  // lane of an instruction in a line of its own, each line touched by twelve instructions with the block's 92 KB of x /
+  // residual rows passing through the 32-KB L1 in between -- 11 us per call, the same alone on the CU or with a partner.)
+  // The rows are stored and stay in the registers of the threads that computed them; returns the largest |o| of the
+  // thread's part.
   auto ln_bwd_rows = [&](const float* xp, long ldxp, const float* stp, const float* rp, long ldrp, float* op, long ldop,
                          f32x4 (&dv)[12]) -> float {
     const int row = tid >> 2, q = tid & 3;
@@ -185,15 +206,17 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     f32x4 xh[12], rr[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
-      const int col = min(q * 48 + 4 * k, p.C - 4);
-      xh[k] = *(const f32x4*)(xp + (long)gm * ldxp + col);
-      rr[k] = *(const f32x4*)(rp + (long)gm * ldrp + col);
+      const int col = (k >> 1) * 32 + q * 8 + (k & 1) * 4;
+      const int cc = col < p.C ? col : 0;              // past the end: the row's first piece, zeroed below
+      xh[k] = *(const f32x4*)(xp + (long)gm * ldxp + cc);
+      rr[k] = *(const f32x4*)(rp + (long)gm * ldrp + cc);
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
-      dv[k] = *(const f32x4*)(T + row * TP + q * 48 + 4 * k);
-      const bool ok = q * 48 + 4 * k < p.C;
+      const int col = (k >> 1) * 32 + q * 8 + (k & 1) * 4;
+      dv[k] = *(const f32x4*)(T + row * TP + col);
+      const bool ok = col < p.C;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         xh[k][e] = ok ? (xh[k][e] - st.x) * st.y : 0.f;
@@ -208,35 +231,36 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     float omx = 0.f;
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
+      const int col = (k >> 1) * 32 + q * 8 + (k & 1) * 4;
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (q * 48 + 4 * k < p.C) {
+      if (col < p.C) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rr[k][e] + st.y * (dv[k][e] - m1 - xh[k][e] * m2);
-        if (m0 + row < p.M) *(f32x4*)(op + (long)gm * ldop + q * 48 + 4 * k) = o;
+        if (m0 + row < p.M) *(f32x4*)(op + (long)gm * ldop + col) = o;
       }
       dv[k] = o;
       omx = fmaxf(fmaxf(omx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     }
     return omx;
   };
-  // a thread's 48 row values (octets 6 q .. 6 q + 5 of its row) -> the stage images under the row's block exponent
-  // (row maximum over the row's four lanes); returns nothing, the 2^-s of the row goes to rinv_dst
+  // a thread's six octets (stage s6, octet q) of its row -> the stage images under the row's block exponent (row maximum
+  // over the row's four lanes); the 2^-s of the row goes to rinv_dst
   auto rows_to_images = [&](const f32x4 (&dv)[12], float omx, float* rinv_dst) {
     const int row = tid >> 2, q = tid & 3;
     omx = fmaxf(omx, __shfl_xor(omx, 1, 64));
     omx = fmaxf(omx, __shfl_xor(omx, 2, 64));
     const float sc = omx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / omx)), 100.f)) : 1.f;
     if (q == 0) rinv_dst[row] = 1.0f / sc;
+    const int a_dst = a_slot(row, q) * 16;
 #pragma unroll
-    for (int k6 = 0; k6 < 6; ++k6) {                 // octet 6 q + k6 of the row: columns 48 q + 8 k6 .. + 7
-      const int kk = q * 48 + 8 * k6;
-      const f32x4 a = dv[2 * k6], b = dv[2 * k6 + 1];
+    for (int s6 = 0; s6 < 6; ++s6) {
+      const f32x4 a = dv[2 * s6], b = dv[2 * s6 + 1];
       unsigned hh[4], ll[4];
       split2_pair(a[0] * sc, a[1] * sc, hh[0], ll[0]);
       split2_pair(a[2] * sc, a[3] * sc, hh[1], ll[1]);
       split2_pair(b[0] * sc, b[1] * sc, hh[2], ll[2]);
       split2_pair(b[2] * sc, b[3] * sc, hh[3], ll[3]);
-      unsigned char* sa = smem + (kk >> 5) * AST + a_slot(row, (kk & 31) >> 3) * 16;
+      unsigned char* sa = smem + s6 * AST + a_dst;
       *(u32x4*)(sa) = u32x4{hh[0], hh[1], hh[2], hh[3]};
       *(u32x4*)(sa + APL) = u32x4{ll[0], ll[1], ll[2], ll[3]};
     }
@@ -494,23 +518,27 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       dps[i] = 1.f;
       if (BWD && p.rowscale) dps[i] = p.rowscale[min(gm[i], p.M - 1) / p.rows_per_scale];
     }
-    // backward: the pre-activations of (half, j) travel while (half, j - 1) is processed: four 16-byte loads in flight
-    f32x4 hcur[4], hnext[4];
-    auto load_h = [&](int hh, int j, f32x4 (&hv)[4]) {
-      const int unit0 = min(192 * hh + wave * 48 + 16 * j + 4 * g, p.hid - 4);
+    // backward: the pre-activations of group (half, j) travel while the two groups in front of it are processed: eight
+    // 16-byte loads in flight per lane (round 4 kept four: the phase ran at the latency of six dependent HBM round trips)
+    f32x4 hbuf[3][4];
+    auto load_h = [&](int grp, f32x4 (&hv)[4]) {
+      const int unit0 = min(192 * (grp / 3) + wave * 48 + 16 * (grp % 3) + 4 * g, p.hid - 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) hv[i] = *(const f32x4*)(p.H + (long)min(gm[i], p.M - 1) * p.ldh + unit0);
     };
-    if (BWD) load_h(0, 0, hcur);
+    if (BWD) {
+      load_h(0, hbuf[0]);
+      load_h(1, hbuf[1]);
+    }
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       if (hh < NH) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           if (BWD) {
-            if (j < 2) load_h(hh, j + 1, hnext);
-            else if (hh + 1 < NH) load_h(hh + 1, 0, hnext);
+            if (3 * hh + j + 2 < 3 * NH) load_h(3 * hh + j + 2, hbuf[(3 * hh + j + 2) % 3]);
           }
+          f32x4 (&hcur)[4] = hbuf[(3 * hh + j) % 3];
           const int unit0 = 192 * hh + wave * 48 + 16 * j + 4 * g;
           const bool uok = unit0 < p.hid;            // hid % 4 == 0: a lane's four units are valid or not together
           const int uc = min(unit0, p.hid - 4);
@@ -548,10 +576,6 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
             }
             acc1[hh][i][j] = v;
             tmax[i] = fmaxf(fmaxf(tmax[i], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-          }
-          if (BWD) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hcur[i] = hnext[i];
           }
         }
       }
@@ -802,13 +826,17 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
 }  // namespace
 
 #ifdef SRHIP_EXPERIMENTS
-extern "C" int srhip_mlp_debug_buffer(long long* buf) { g_mlp_dbg = buf; return 0; }    // [blocks][4][24] wall-clock stamps
+extern "C" int srhip_mlp_debug_buffer(long long* buf) { g_mlp_dbg = buf; return 0; }    // [blocks][4][32] wall-clock stamps
+extern "C" int srhip_mlp_cu_counters(int* buf) { g_mlp_cu_count = buf; return 0; }      // [4096] zeroed ints: arrival order per CU
 #endif
 
 int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st) {
 #ifdef SRHIP_EXPERIMENTS
   p.dbg = g_mlp_dbg;
   { const char* e = sr_getenv("SRHIP_MLP_STAGGER"); p.stagger = e ? atoi(e) : 0; }      // 10-ns units
+  { const char* e = sr_getenv("SRHIP_MLP_STAGGER_MODE"); p.stagger_mode = e ? atoi(e) : 0; }
+  p.cu_count = g_mlp_cu_count;
+  if (p.cu_count && p.stagger_mode == 1) (void)hipMemsetAsync(p.cu_count, 0, 4096 * sizeof(int), st);
 #endif
   SR_REQUIRE(p.C % 4 == 0 && p.C >= 4 && p.C <= 192, "mlp_f16x2: C = %d (multiple of 4, <= 192)", p.C);
   SR_REQUIRE(p.hid % 4 == 0 && p.hid >= 4 && p.hid <= 384, "mlp_f16x2: hidden = %d (multiple of 4, <= 384)", p.hid);

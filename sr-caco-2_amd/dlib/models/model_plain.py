@@ -47,7 +47,8 @@ class ModelPlain:
         self.netG.amp = bool(getattr(args, 'amp', False))
         self.schedulers = []
         self.log_dict = OrderedDict()
-        self.L = self.E = self.H = self.h_per_pixel_weight = self.L_to_H = None
+        self._E, self._E_pending = None, False
+        self.L = self.H = self.h_per_pixel_weight = self.L_to_H = None
         self._current = None
         self.step_fn = None
         self._eval_graphs, self._weights_version = {}, 0
@@ -129,10 +130,22 @@ class ModelPlain:
     def optimize_parameters(self, epoch: int, current_step: int):
         self._weights_version += 1
         self.step_fn.step(self._net_input(), self.H, weight=self.h_per_pixel_weight)
-        # the engine's output buffer is persistent (overwritten by the next step) and 3-D for the
-        # 1-channel conv nets: hand out a [B,1,H,W] copy, as the reference's self.E is a fresh tensor
-        y = self.netG.engine.bufs.d.get("t.y")
-        self.E = None if y is None else y.reshape(y.shape[0], 1, *y.shape[-2:]).clone()
+        # the engine's output buffer is persistent (overwritten by the next step) and 3-D for the 1-channel conv nets:
+        # ``self.E`` hands out a [B,1,H,W] copy, as the reference's self.E is a fresh tensor -- made when somebody reads it
+        # (current_visuals), not in every step (a 8 MB copy + an allocation per iteration the training loop never looks at)
+        self._E, self._E_pending = None, True
+
+    @property
+    def E(self):
+        if self._E is None and self._E_pending:
+            y = self.netG.engine.bufs.d.get("t.y")
+            self._E = None if y is None else y.reshape(y.shape[0], 1, *y.shape[-2:]).clone()
+            self._E_pending = False
+        return self._E
+
+    @E.setter
+    def E(self, v):
+        self._E, self._E_pending = v, False
 
     def update_learning_rate(self):
         pass   # TrainStep steps the LR rule once per iteration (utils_trainer.py:370)

@@ -148,6 +148,10 @@ class _NetFn(torch.autograd.Function):
 
 
 class SwinIR(nn.Module):
+    # forward() multiplies the input by img_range and divides the output by it (reference :935,968): the fused training
+    # step (srhip/train.py) applies the same scale around the loss only for a net that says so
+    forward_divides_by_img_range = True
+
     def __init__(self, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=[6, 6, 6, 6],
                  num_heads=[6, 6, 6, 6], window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None,
                  drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm,

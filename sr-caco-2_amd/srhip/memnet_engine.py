@@ -189,6 +189,11 @@ class MemNetEngine:
             # statistics the feature maps leave fp16's range (65504).  One finiteness check of the output image per forward
             # (a 200-ms forward: the host round trip is noise); on overflow this net stays on f32 storage.
             y = self.forward_h16(x)
+            # under a hipGraph capture (ModelPlain._graph_forward captures the SECOND call of a weights version) a host
+            # read is not permitted: the eager call in front of the capture made the check for these weights
+            if torch.cuda.is_current_stream_capturing():
+                self.last_eval_path = "fp16 storage"
+                return y
             if bool(torch.isfinite(y).all()):
                 self.last_eval_path = "fp16 storage"
                 return y

@@ -342,7 +342,12 @@ class TrainStep:
             net.weights_changed()
         # SwinIR.forward multiplies the input by img_range and divides the output by it (network_swinir.py:935,968; the mean
         # is zero for one channel): prepare_input does the first, the step scales y before the loss and dy behind it
-        self.inv_range = 1.0 / float(getattr(net, "img_range", 1.) or 1.)
+        # Only a net whose forward() does that opts in (`forward_divides_by_img_range`): EDSR-LIIF / ENLCN / NLSN / ACT carry
+        # an img_range too, but it parametrises MeanShift convs their forward never applies -- scaling here would train on
+        # y / img_range while forward() and test() return y.
+        self.inv_range = 1.0
+        if getattr(net, "forward_divides_by_img_range", False):
+            self.inv_range = 1.0 / float(getattr(net, "img_range", 1.) or 1.)
         self._mean_img = None
         self.dy = None
 

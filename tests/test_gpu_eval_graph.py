@@ -12,7 +12,9 @@ sys.path.insert(0, os.path.join(ROOT, "sr-caco-2_amd"))
 
 CASES = [("swinir", "SWINIR", 4, ["--swinir_depths", "2+2", "--swinir_embed_dim", "60", "--swinir_num_heads", "6+6"]),
          ("EDSR_LIIF", "EDSR_LIIF", 4, []), ("DBPN", "DBPN", 2, []), ("OmniSR", "OmniSR", 4, ["--OmniSR_res_num", "1"]),
-         ("ACT", "ACT", 2, ["--ACT_n_resblocks", "2"]), ("DFCAN", "DFCAN", 2, []), ("ENLCN", "ENLCN", 2, ["--ENLCN_n_resblock", "8"])]
+         ("ACT", "ACT", 2, ["--ACT_n_resblocks", "2"]), ("DFCAN", "DFCAN", 2, []), ("ENLCN", "ENLCN", 2, ["--ENLCN_n_resblock", "8"]),
+         # MemNet on fp16 storage checks its output for finiteness on the host: not inside a capture
+         ("MemNet", "MemNet", 2, ["--amp", "True", "--MemNet_num_memory_blocks", "2", "--MemNet_num_residual_blocks", "2"])]
 
 
 @pytest.mark.parametrize("net_type,method,scale,extra", CASES)

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "sr-caco-2_amd"))
 import torch
 from srhip import ops
 
-M, C, hid = 32768, 180, 360
+M, C, hid = (int(sys.argv[1]) if len(sys.argv) > 1 else 32768), 180, 360
 dev = "cuda"
 x = torch.randn(M, C, device=dev); dy = torch.randn(M, C, device=dev)
 w1 = torch.randn(hid, C, device=dev) * 0.1; w2 = torch.randn(C, hid, device=dev) * 0.1
@@ -25,7 +25,7 @@ st = torch.empty(M, 2, device=dev); ops.layernorm_fwd(x, st)
 h = torch.empty(M, hid, device=dev); out = torch.empty(M, C, device=dev); sto = torch.empty(M, 2, device=dev)
 dh = torch.empty(M, hid, device=dev); gh = torch.empty(M, hid, device=dev); dx = torch.empty(M, C, device=dev)
 nblk = M // 64
-dbg = torch.zeros(nblk, 4, 24, dtype=torch.int64, device=dev)
+dbg = torch.zeros(nblk, 4, 32, dtype=torch.int64, device=dev)
 fn = ops.lib.srhip_mlp_debug_buffer
 fn.argtypes = [ctypes.c_void_p]
 # the chained form of the training step: front = the qkv Linear's data gradient (K0 = 3 C) + LayerNorm backward of the block
