@@ -441,6 +441,11 @@ int srhip_nlsa_attention(const float* x_embed, const float* y_embed, const unsig
  *                             (:44-47,98-99,108,111-113); out may alias x. */
 int srhip_fft2_mag_pow_shift(const float* x, float* out, float* workspace, int B, int H, int W, int C, float gamma, float eps,
                              void* stream);
+/* its backward (training, Tape.fourier_gate; the reference differentiates torch.fft through autograd, network_dfcan.py:60-64):
+ * dx = Re(unnormalised IFFT2(G . FFT2(x))), G = unshifted g . gamma (|F| + eps)^(gamma - 1) / |F| (0 where |F| = 0), as four
+ * separable DFT passes with f64 accumulation; x, g, dx [B][H][W][C]; workspace 2*B*H*W*C floats; H, W <= 256. */
+int srhip_fft2_mag_pow_shift_bwd(const float* x, const float* g, float* dx, float* workspace, int B, int H, int W, int C,
+                                 float gamma, float eps, void* stream);
 long srhip_channel_gate_ws(int B, long P, int C);
 int srhip_channel_gate(const float* feat, const float* w1, const float* b1, const float* w2, const float* b2, const float* x0,
                        const float* x1, float* out, float* gate, double* workspace, int B, long P, int C, int Cm,

@@ -101,6 +101,138 @@ __global__ void __launch_bounds__(256) k_dft_cols_mag(const float2* __restrict__
   }
 }
 
+// ---- backward of the spectrum magnitude (training; round 5: replaces the torch.fft calls of Tape.fourier_gate).  With
+// F = FFT2(x) (unnormalised) and g the gradient of out = fftshift2d((|F| + eps)^gamma):
+//     G[u][v] = g[iu][jv] gamma (|F| + eps)^(gamma - 1) / |F|   (0 where |F| = 0),   dx = Re( sum_uv G F e^{+i theta} )
+// since d|F| / dx[h][w] = Re(F e^{+i theta}) / |F|, theta = 2 pi (u h / H + v w / W): an inverse DFT (no 1 / N) of Z = G F.
+// Pass 1 is the forward's k_dft_rows; pass 2 below forms Z in place of T (a block owns its (b, v) column: loaded to LDS
+// whole before anything is written); pass 3 the inverse transform along H, in place again; pass 4 the inverse along W,
+// real part only.  Same structure as the forward passes: four channels per thread, f64 accumulation, ascending sums.
+__global__ void __launch_bounds__(256) k_dft_cols_gz(float2* __restrict__ T, const float* __restrict__ g, int H, int W, int C,
+                                                     float gamma, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  double* const tw = (double*)smraw;                 // [H][2]
+  float2* const col = (float2*)(tw + 2 * H);         // [H][DF_C]
+  const int tid = threadIdx.x, c = (tid & 15) * 4, u0 = tid >> 4;
+  const int b = blockIdx.x / W, v = blockIdx.x % W;
+  for (int k = tid; k < H; k += 256) {
+    double s, co;
+    sincospi(2.0 * (double)k / (double)H, &s, &co);
+    tw[2 * k] = co; tw[2 * k + 1] = s;
+  }
+  const int jv = (v - W / 2 + W) % W;
+  for (int c0 = 0; c0 < C; c0 += DF_C) {
+    __syncthreads();
+    for (int i = tid; i < H * DF_C; i += 256) {
+      const int h = i >> 6, cc = i & 63;
+      col[i] = c0 + cc < C ? T[(((long)b * H + h) * W + v) * C + c0 + cc] : float2{0.f, 0.f};
+    }
+    __syncthreads();
+    for (int u = u0; u < H; u += 16) {
+      double re[4] = {0.0, 0.0, 0.0, 0.0}, im[4] = {0.0, 0.0, 0.0, 0.0};
+      int k = 0;
+      for (int h = 0; h < H; ++h) {
+        const f32x4 p0 = *(const f32x4*)(col + h * DF_C + c), p1 = *(const f32x4*)(col + h * DF_C + c + 2);
+        const double co = tw[2 * k], s = tw[2 * k + 1];        // e^{-i t} = co - i s
+        const double a[4] = {(double)p0[0], (double)p0[2], (double)p1[0], (double)p1[2]};
+        const double bb[4] = {(double)p0[1], (double)p0[3], (double)p1[1], (double)p1[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          re[e] += a[e] * co + bb[e] * s;
+          im[e] += bb[e] * co - a[e] * s;
+        }
+        k += u; if (k >= H) k -= H;
+      }
+      const int iu = (u - H / 2 + H) % H;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + c + e < C) {
+          const float mag = (float)sqrt(re[e] * re[e] + im[e] * im[e]);
+          const float g0 = g[(((long)b * H + iu) * W + jv) * C + c0 + c + e];
+          const float G = mag > 0.f ? g0 * gamma * powf(mag + eps, gamma - 1.0f) / fmaxf(mag, 1e-30f) : 0.f;
+          T[(((long)b * H + u) * W + v) * C + c0 + c + e] = float2{G * (float)re[e], G * (float)im[e]};
+        }
+    }
+  }
+}
+// pass 3: Y[h] = sum_u Z[u] e^{+2 pi i u h / H} along H, in place (block = (b, v) column)
+__global__ void __launch_bounds__(256) k_idft_cols(float2* __restrict__ T, int H, int W, int C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  double* const tw = (double*)smraw;
+  float2* const col = (float2*)(tw + 2 * H);
+  const int tid = threadIdx.x, c = (tid & 15) * 4, h0 = tid >> 4;
+  const int b = blockIdx.x / W, v = blockIdx.x % W;
+  for (int k = tid; k < H; k += 256) {
+    double s, co;
+    sincospi(2.0 * (double)k / (double)H, &s, &co);
+    tw[2 * k] = co; tw[2 * k + 1] = s;
+  }
+  for (int c0 = 0; c0 < C; c0 += DF_C) {
+    __syncthreads();
+    for (int i = tid; i < H * DF_C; i += 256) {
+      const int u = i >> 6, cc = i & 63;
+      col[i] = c0 + cc < C ? T[(((long)b * H + u) * W + v) * C + c0 + cc] : float2{0.f, 0.f};
+    }
+    __syncthreads();
+    for (int h = h0; h < H; h += 16) {
+      double re[4] = {0.0, 0.0, 0.0, 0.0}, im[4] = {0.0, 0.0, 0.0, 0.0};
+      int k = 0;
+      for (int u = 0; u < H; ++u) {
+        const f32x4 p0 = *(const f32x4*)(col + u * DF_C + c), p1 = *(const f32x4*)(col + u * DF_C + c + 2);
+        const double co = tw[2 * k], s = tw[2 * k + 1];        // e^{+i t} = co + i s
+        const double a[4] = {(double)p0[0], (double)p0[2], (double)p1[0], (double)p1[2]};
+        const double bb[4] = {(double)p0[1], (double)p0[3], (double)p1[1], (double)p1[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          re[e] += a[e] * co - bb[e] * s;
+          im[e] += bb[e] * co + a[e] * s;
+        }
+        k += h; if (k >= H) k -= H;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + c + e < C) T[(((long)b * H + h) * W + v) * C + c0 + c + e] = float2{(float)re[e], (float)im[e]};
+    }
+  }
+}
+// pass 4: dx[w] = Re sum_v Y[v] e^{+2 pi i v w / W} along W (block = (b, h) row)
+__global__ void __launch_bounds__(256) k_idft_rows_real(const float2* __restrict__ T, float* __restrict__ dx, int H, int W, int C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  double* const tw = (double*)smraw;                 // [W][2]
+  float2* const row = (float2*)(tw + 2 * W);         // [W][DF_C]
+  const int tid = threadIdx.x, c = (tid & 15) * 4, w0 = tid >> 4;
+  const long bh = blockIdx.x;
+  for (int k = tid; k < W; k += 256) {
+    double s, co;
+    sincospi(2.0 * (double)k / (double)W, &s, &co);
+    tw[2 * k] = co; tw[2 * k + 1] = s;
+  }
+  for (int c0 = 0; c0 < C; c0 += DF_C) {
+    __syncthreads();
+    for (int i = tid; i < W * DF_C; i += 256) {
+      const int v = i >> 6, cc = i & 63;
+      row[i] = c0 + cc < C ? T[(bh * W + v) * C + c0 + cc] : float2{0.f, 0.f};
+    }
+    __syncthreads();
+    for (int w = w0; w < W; w += 16) {
+      double re[4] = {0.0, 0.0, 0.0, 0.0};
+      int k = 0;
+      for (int v = 0; v < W; ++v) {
+        const f32x4 p0 = *(const f32x4*)(row + v * DF_C + c), p1 = *(const f32x4*)(row + v * DF_C + c + 2);
+        const double co = tw[2 * k], s = tw[2 * k + 1];
+        re[0] += (double)p0[0] * co - (double)p0[1] * s;
+        re[1] += (double)p0[2] * co - (double)p0[3] * s;
+        re[2] += (double)p1[0] * co - (double)p1[1] * s;
+        re[3] += (double)p1[2] * co - (double)p1[3] * s;
+        k += w; if (k >= W) k -= W;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + c + e < C) dx[(bh * W + w) * C + c0 + c + e] = (float)re[e];
+    }
+  }
+}
+
 // global average over the pixels: partial sums per (sample, pixel block), then ...
 __global__ void __launch_bounds__(256) k_pool_partial(const float* __restrict__ x, double* __restrict__ part, long P, int C,
                                                       int nblk) {
@@ -198,6 +330,40 @@ int srhip_fft2_mag_pow_shift(const float* x, float* out, float* workspace, int B
   hipLaunchKernelGGL(k_dft_rows, dim3(B * H), dim3(256), l1, st, x, (float2*)workspace, H, W, C);
   hipLaunchKernelGGL(k_dft_cols_mag, dim3(B * W), dim3(256), l2, st, (const float2*)workspace, out, H, W, C, gamma, eps);
   SR_LAUNCH_CHECK("fft2_mag_pow_shift");
+  return 0;
+}
+
+/* dx = d loss / d x of srhip_fft2_mag_pow_shift given g = d loss / d out (same shapes; workspace 2*B*H*W*C floats). */
+int srhip_fft2_mag_pow_shift_bwd(const float* x, const float* g, float* dx, float* workspace, int B, int H, int W, int C,
+                                 float gamma, float eps, void* stream) {
+  SR_REQUIRE(x && g && dx && workspace && B > 0 && H > 0 && W > 0 && C > 0, "fft2_mag_pow_shift_bwd: bad arguments");
+  SR_REQUIRE(H <= 256 && W <= 256, "fft2_mag_pow_shift_bwd: H, W <= 256 (H=%d W=%d)", H, W);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t l1 = (size_t)W * 16 + (size_t)W * DF_C * 4, l2 = (size_t)H * 16 + (size_t)H * DF_C * 8;
+  const size_t l4 = (size_t)W * 16 + (size_t)W * DF_C * 8;
+  static size_t r1 = 0, r2 = 0, r4 = 0;
+  if (l1 > r1) {
+    if (hipFuncSetAttribute((const void*)k_dft_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1) != hipSuccess)
+      return sr_fail(-5, "fft2_mag_pow_shift_bwd: cannot reserve %zu bytes of LDS", l1);
+    r1 = l1;
+  }
+  if (l2 > r2) {
+    if (hipFuncSetAttribute((const void*)k_dft_cols_gz, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_idft_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess)
+      return sr_fail(-5, "fft2_mag_pow_shift_bwd: cannot reserve %zu bytes of LDS", l2);
+    r2 = l2;
+  }
+  if (l4 > r4) {
+    if (hipFuncSetAttribute((const void*)k_idft_rows_real, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4) != hipSuccess)
+      return sr_fail(-5, "fft2_mag_pow_shift_bwd: cannot reserve %zu bytes of LDS", l4);
+    r4 = l4;
+  }
+  float2* const T = (float2*)workspace;
+  hipLaunchKernelGGL(k_dft_rows, dim3(B * H), dim3(256), l1, st, x, T, H, W, C);
+  hipLaunchKernelGGL(k_dft_cols_gz, dim3(B * W), dim3(256), l2, st, T, g, H, W, C, gamma, eps);
+  hipLaunchKernelGGL(k_idft_cols, dim3(B * W), dim3(256), l2, st, T, H, W, C);
+  hipLaunchKernelGGL(k_idft_rows_real, dim3(B * H), dim3(256), l4, st, (const float2*)T, dx, H, W, C);
+  SR_LAUNCH_CHECK("fft2_mag_pow_shift_bwd");
   return 0;
 }
 

@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     const unsigned cuid = (xcc << 8) | (((hwid >> 13) & 7) << 5) | (((hwid >> 12) & 1) << 4) | ((hwid >> 8) & 15);
     if (p.dbg && lane == 0) p.dbg[((long)blockIdx.x * 4 + wave) * 32 + 24] = (long long)cuid;
     bool late = blockIdx.x & 1;                      // mode 0: odd blocks
+    if (p.stagger_mode == 2) late = blockIdx.x >= gridDim.x / 2;     // mode 2: the upper half of the grid (blocks b and b + 256 share a CU at 512 blocks)
     if (p.stagger_mode == 1 && p.cu_count) {         // mode 1: the block that arrives second on its CU
       __shared__ int s_slot;
       if (tid == 0) s_slot = atomicAdd(p.cu_count + cuid, 1);
@@ -823,6 +824,385 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
   SR_TS(14)
 }
 
+
+// =====================================================================================================================
+// Round 5: the same forward with the memory side and the matrix side in DIFFERENT waves.
+//
+// What round 4's stamps could not show and a one-block-per-CU run did (tools/mb_mlp_stagger.py): a 64-token block ALONE on
+// its CU takes 32 us of the 42 us two co-resident blocks take -- the kernel is a chain of dependent phases, each waiting
+// for its own loads, and its partner block only shares that wait.  Putting the partner in another phase by a start delay
+// gains 3 % (the chain is as long as before).  What shortens the chain: all eight matrix waves of the CU on ONE tile (each
+// phase half as long), and the row traffic -- x rows in, LayerNorm, the split into stage images; the residual, out rows
+// and row statistics out -- in four waves of their own that work on the OTHER tile of the CU meanwhile.  Their loads and
+// stores never sit in front of a weight fragment in a matrix wave's in-order memory counter.
+//
+// One block per CU: 12 waves (three per SIMD, 168 registers), two 64-token tiles.  G = waves 0..7, R = waves 8..11.  A
+// static schedule of slots, one LDS-only barrier between slots, the same barrier count on every path (no flags, no spins):
+//
+//   slot   G (matrix waves)                                       R (row waves)
+//    0     W1 fragments requested                                 x rows (t0) -> LN -> images A   (raw rows stay in registers)
+//    1     GEMM 1 (t0, images A), bias + GELU, h rows out, maxima x rows (t1) -> images B
+//    2     hidden rows -> images: half 0 -> C, half 1 -> A
+//    3     GEMM 2 (t0): waves 0..3 over half 0 (C), 4..7 over half 1 (A)
+//    4     partial output tiles -> C, A
+//    5     GEMM 1 (t1, images B), ...                             out rows (t0) = x + s (C + A + b2), row statistics
+//    6..8  as 2..4 for t1
+//    9                                                            out rows (t1)
+//
+// GEMM 1: wave (hh, w) owns hidden units 192 hh + 48 w .. + 47 of all 64 tokens (what wave w of k_mlp_f16 held in acc1[hh]:
+// the same accumulators, the same h bits).  GEMM 2 is split over K between the two wave quartets (a wave's fragments are
+// used for four row tiles: no weight byte is requested twice by the CU); the two partial tiles meet in the row waves.
+constexpr int GR_NT = 768;
+constexpr int GR_SMALL = (8 * 64 + 2 * 64 + 64) * 4;          // smax [8][64], rinvx [2][64], rinv2 [64]
+constexpr int GR_LDS = 3 * R0 + GR_SMALL;
+static_assert(GR_LDS <= 160 * 1024, "LDS of one CU");
+
+#ifdef SRHIP_EXPERIMENTS
+#define GR_TS(K) \
+  if (p.dbg && lane == 0) p.dbg[((long)blockIdx.x * 12 + wave) * 32 + (K)] = (long long)wall_clock64();
+#else
+#define GR_TS(K)
+#endif
+
+__global__ void __launch_bounds__(GR_NT, 3) k_mlp_gr_fwd(MlpF16Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const RA = smem;
+  unsigned char* const RB = smem + R0;
+  unsigned char* const RC = smem + 2 * R0;
+  float* const smax = (float*)(smem + 3 * R0);       // [8 waves][64 tokens] maxima of |gelu(h)|
+  float* const rinvx = smax + 8 * 64;                // [2 tiles][64] 2^-s of the LN(x) rows
+  float* const rinv2 = rinvx + 2 * 64;               // [64] 2^-s of the hidden rows
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool isG = wave < 8;
+  const int c = lane & 15, g = lane >> 4;
+  const int ntiles = (p.M + BM - 1) / BM;
+  const int tile0 = 2 * sr_xcd_block((int)blockIdx.x, gridDim.x);
+  const int nt = min(2, ntiles - tile0);             // tiles of this block (>= 1)
+  const int nst1 = p.Kp1 / SK, nst2 = p.Kp2 / SK;
+  const int C = p.C;
+  GR_TS(0)
+
+  // ------------------------------------------------------------------ matrix-wave state
+  const int hh = (wave >> 2) & 1, w4 = wave & 3;     // G: hidden half and 48-wide slice
+  const long plane1 = (long)p.N1 * p.Kp1 * 2, plane2 = (long)p.N2 * p.Kp2 * 2;
+  const float* const winv1 = (const float*)((const char*)p.W1 + 2 * plane1);
+  const float* const winv2 = (const float*)((const char*)p.W2 + 2 * plane2);
+  unsigned boff1[3], boff2[3];
+  int a_off[4];
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) {
+    const int row = min(192 * hh + w4 * 48 + jt * 16 + c, p.N1 - 1);
+    boff1[jt] = (unsigned)(((g >> 1) * p.N1 + row) * 32 + (g & 1) * 16);
+    const int col = min(w4 * 48 + jt * 16 + c, p.N2 - 1);
+    boff2[jt] = (unsigned)(((g >> 1) * p.N2 + col) * 32 + (g & 1) * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = a_slot(16 * i + c, g) * 16;
+  auto load_b1 = [&](int s6, u32x4 (&fb)[3][2]) {
+    const char* base = (const char*)p.W1 + (long)(2 * min(s6, nst1 - 1)) * p.N1 * 32;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane1 + boff1[jt]);
+  };
+  auto load_b2 = [&](int s6, u32x4 (&fb)[3][2]) {     // stage 6 hh + s6 of the hidden contraction
+    const char* base = (const char*)p.W2 + (long)(2 * min(6 * hh + s6, nst2 - 1)) * p.N2 * 32;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane2 + boff2[jt]);
+  };
+  u32x4 fb0[3][2], fb1[3][2];                         // two weight register sets (168 registers per wave): stage s in set s & 1
+  f32x4 acc[4][3];                                   // GEMM 1: units 192 hh + 48 w4 + 16 j + 4 g + e of token 16 i + c;
+                                                     // GEMM 2: rows 16 i + 4 g + e, columns 48 w4 + 16 j + c
+  float use[4];
+  // A fragments from `img`, weights on the ROW side (transposed product)
+  auto mma_t = [&](const unsigned char* img, int s6, const u32x4 (&fb)[3][2]) {
+    const unsigned char* sa = img + s6 * AST;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 fa[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off[i]);
+#define SR_TERM(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[i][j] = mfma16h(fb[j][PB], fa[PA], acc[i][j]);
+      SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+#undef SR_TERM
+    }
+  };
+  auto mma_n = [&](const unsigned char* img, int s6, const u32x4 (&fb)[3][2]) {
+    const unsigned char* sa = img + s6 * AST;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 fa[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) fa[pl] = *(const u32x4*)(sa + pl * APL + a_off[i]);
+#define SR_TERM(PA, PB) \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[i][j] = mfma16h(fa[PA], fb[j][PB], acc[i][j]);
+      SR_TERM(0, 1) SR_TERM(1, 0) SR_TERM(0, 0)
+#undef SR_TERM
+    }
+  };
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // slot 1 / 5: GEMM 1 of tile t over the x images, bias + GELU in registers, h rows out, token maxima
+  auto g_gemm1_act = [&](int t, const unsigned char* img) {
+    const int m0 = (tile0 + t) * BM;
+    zero_acc();
+    mma_t(img, 0, fb0); load_b1(2, fb0); __builtin_amdgcn_sched_barrier(0);
+    mma_t(img, 1, fb1); load_b1(3, fb1); __builtin_amdgcn_sched_barrier(0);
+    mma_t(img, 2, fb0); load_b1(4, fb0); __builtin_amdgcn_sched_barrier(0);
+    mma_t(img, 3, fb1); load_b1(5, fb1); __builtin_amdgcn_sched_barrier(0);
+    mma_t(img, 4, fb0); __builtin_amdgcn_sched_barrier(0);
+    mma_t(img, 5, fb1);
+    float tmax[4] = {0.f, 0.f, 0.f, 0.f};
+    float rix[4];
+    int gm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rix[i] = rinvx[64 * t + 16 * i + c];
+      gm[i] = m0 + 16 * i + c;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int unit0 = 192 * hh + w4 * 48 + 16 * j + 4 * g;
+      const bool uok = unit0 < p.hid;                  // hid % 4 == 0: a lane's four units are valid or not together
+      const int uc = min(unit0, p.hid - 4);
+      const f32x4 wi = *(const f32x4*)(winv1 + uc);
+      const f32x4 bv = *(const f32x4*)(p.b1 + uc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = acc[i][j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * (rix[i] * wi[e]) + bv[e];
+        if (p.H && uok && gm[i] < p.M) *(f32x4*)(p.H + (long)gm[i] * p.ldh + unit0) = v;
+        const sr_f32x2 g0 = gelu_fast2(sr_f32x2{v[0], v[1]}), g1 = gelu_fast2(sr_f32x2{v[2], v[3]});
+        v = uok ? f32x4{g0.x, g0.y, g1.x, g1.y} : f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[i][j] = v;
+        tmax[i] = fmaxf(fmaxf(tmax[i], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      }
+    }
+    // GEMM 2's first weight stages travel through the barrier and the staging slot behind it (requested here, not in front
+    // of the activation math: 72 registers the math needs)
+    __builtin_amdgcn_sched_barrier(0);
+    load_b2(0, fb0);
+    load_b2(1, fb1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tmax[i] = fmaxf(tmax[i], __shfl_xor(tmax[i], 16, 64));
+      tmax[i] = fmaxf(tmax[i], __shfl_xor(tmax[i], 32, 64));
+      if (g == 0) smax[wave * 64 + 16 * i + c] = tmax[i];
+    }
+  };
+  // slot 2 / 6: the hidden rows under their block exponent (token maximum over the eight waves) -> images of half hh
+  auto g_stage_a2 = [&](unsigned char* img) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = 16 * i + c;
+      float mx = fmaxf(fmaxf(smax[t], smax[64 + t]), fmaxf(smax[128 + t], smax[192 + t]));
+      mx = fmaxf(mx, fmaxf(fmaxf(smax[256 + t], smax[320 + t]), fmaxf(smax[384 + t], smax[448 + t])));
+      use[i] = mx > 0.f ? exp2f(fminf(floorf(log2f(16384.f / mx)), 100.f)) : 1.f;
+      if (wave == 0 && g == 0) rinv2[t] = 1.0f / use[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int kk = w4 * 48 + 16 * j + 4 * g;
+      const int s6 = kk >> 5, u = (kk & 31) >> 3, pos = kk & 7;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 v = acc[i][j];
+        unsigned h0, l0, h1, l1;
+        split2_pair(v[0] * use[i], v[1] * use[i], h0, l0);
+        split2_pair(v[2] * use[i], v[3] * use[i], h1, l1);
+        unsigned char* sa = img + s6 * AST + a_slot(16 * i + c, u) * 16 + pos * 2;
+        *(u32x2*)(sa) = u32x2{h0, h1};
+        *(u32x2*)(sa + APL) = u32x2{l0, l1};
+      }
+    }
+  };
+  // slot 3 / 7: this quartet's half of GEMM 2 (six stages of its own images); then the next tile's W1 stages are requested
+  auto g_gemm2 = [&](const unsigned char* img) {
+    zero_acc();
+    mma_n(img, 0, fb0); load_b2(2, fb0); __builtin_amdgcn_sched_barrier(0);
+    mma_n(img, 1, fb1); load_b2(3, fb1); __builtin_amdgcn_sched_barrier(0);
+    mma_n(img, 2, fb0); load_b2(4, fb0); __builtin_amdgcn_sched_barrier(0);
+    mma_n(img, 3, fb1); load_b2(5, fb1); __builtin_amdgcn_sched_barrier(0);
+    mma_n(img, 4, fb0); __builtin_amdgcn_sched_barrier(0);
+    mma_n(img, 5, fb1);
+  };
+  // slot 4 / 8: the partial output tile, row-major (block exponents undone: exact powers of two)
+  auto g_tile_out = [&](unsigned char* img, bool more) {
+    float* const T = (float*)img;
+    float wv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wv[j] = winv2[min(w4 * 48 + 16 * j + c, p.N2 - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ri = rinv2[16 * i + 4 * g + e];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T[(16 * i + 4 * g + e) * TP + w4 * 48 + 16 * j + c] = acc[i][j][e] * (ri * wv[j]);
+      }
+    if (more) {                                      // the next tile's first W1 stages travel through the barrier
+      __builtin_amdgcn_sched_barrier(0);
+      load_b1(0, fb0);
+      load_b1(1, fb1);
+    }
+  };
+
+  // ------------------------------------------------------------------ row-wave state
+  const int rtid = tid - 512, rrow = (rtid >> 2) & 63, rq = rtid & 3;
+  f32x4 xr0[6][2], xr1[6][2];                        // the raw x rows of the two tiles: the residual of the epilogue
+  // slot 0 / 1: x rows of tile t -> LayerNorm -> split -> stage images (one pass of 192 k)
+  auto r_stage = [&](int t, unsigned char* img, f32x4 (&xr)[6][2]) {
+    const int m0 = (tile0 + t) * BM;
+    const int agm = min(m0 + rrow, p.M - 1);
+    const char* const abase = (const char*)p.X + (long)agm * p.ldx * 4;
+    const float2 rst = ldg_f2(p.ln_stats + 2 * agm);
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) {                 // past the end: k = 0 of the row, zeroed below
+      const int k = s6 * SK + rq * 8;
+      xr[s6][0] = *(const f32x4*)(abase + (k < p.K1 ? k * 4 : 0));
+      xr[s6][1] = *(const f32x4*)(abase + (k + 4 < p.K1 ? (k + 4) * 4 : 0));
+    }
+    const float asc = exp2f(floorf(log2f(16384.f * rsqrtf((float)p.K1))));      // |xhat| <= sqrt(K): a priori
+    if (rq == 0) rinvx[64 * t + rrow] = 1.0f / asc;
+    const int a_dst = a_slot(rrow, rq) * 16;
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) {
+      const int k = s6 * SK + rq * 8;
+      unsigned hv[4], lv[4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        f32x4 x = xr[s6][e];
+        x.x = (x.x - rst.x) * rst.y; x.y = (x.y - rst.x) * rst.y; x.z = (x.z - rst.x) * rst.y; x.w = (x.w - rst.x) * rst.y;
+        if (k + 4 * e >= p.K1) x = f32x4{0.f, 0.f, 0.f, 0.f};
+        split2_pair(x.x * asc, x.y * asc, hv[2 * e], lv[2 * e]);
+        split2_pair(x.z * asc, x.w * asc, hv[2 * e + 1], lv[2 * e + 1]);
+      }
+      unsigned char* sa = img + s6 * AST + a_dst;
+      *(u32x4*)(sa) = u32x4{hv[0], hv[1], hv[2], hv[3]};
+      *(u32x4*)(sa + APL) = u32x4{lv[0], lv[1], lv[2], lv[3]};
+    }
+  };
+  // slot 5 / 9: out = x + s (T0 + T1 + b2) and the {mean, rstd} of the out rows (two-pass, eps 1e-5, biased variance): a
+  // thread owns the octets (stage s6, octet rq) of its row, as it loaded them
+  auto r_epilogue = [&](int t, const unsigned char* i0, const unsigned char* i1, f32x4 (&xr)[6][2]) {
+    const int m0 = (tile0 + t) * BM;
+    const int gm = m0 + rrow;
+    const bool rok = gm < p.M;
+    const float* const T0 = (const float*)i0;
+    const float* const T1 = (const float*)i1;
+    const float s = p.rowscale ? p.rowscale[min(gm, p.M - 1) / p.rows_per_scale] : 1.f;
+    float s1 = 0.f;                                  // (the out row replaces the x row in the thread's registers)
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int col = s6 * SK + rq * 8 + 4 * e;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < C) {
+          const f32x4 a = *(const f32x4*)(T0 + rrow * TP + col), b = *(const f32x4*)(T1 + rrow * TP + col);
+          const f32x4 bv = p.b2 ? *(const f32x4*)(p.b2 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = ((a[q] + b[q]) + bv[q]) * s + xr[s6][e][q];
+          if (rok) *(f32x4*)(p.out + (long)gm * p.ldo + col) = v;
+          s1 += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        xr[s6][e] = v;
+      }
+    if (p.stats_out) {
+      s1 += __shfl_xor(s1, 1, 64);
+      s1 += __shfl_xor(s1, 2, 64);
+      const float mean = s1 * (1.0f / (float)C);
+      float s2 = 0.f;
+#pragma unroll
+      for (int s6 = 0; s6 < 6; ++s6)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          if (s6 * SK + rq * 8 + 4 * e < C) {
+            const f32x4 v = xr[s6][e];
+            const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+            s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          }
+      s2 += __shfl_xor(s2, 1, 64);
+      s2 += __shfl_xor(s2, 2, 64);
+      if (rq == 0 && rok) *(float2*)(p.stats_out + 2 * (long)gm) = float2{mean, rsqrtf(s2 * (1.0f / (float)C) + 1e-5f)};
+    }
+  };
+
+  // ------------------------------------------------------------------ the schedule: one straight-line program per role
+  // (a role's registers are live only inside its own branch), the same number of barriers on both
+  const bool two = nt > 1;
+  if (isG) {
+    load_b1(0, fb0);                                 // slot 0
+    load_b1(1, fb1);
+    GR_TS(1)
+    sr_lds_barrier();
+    GR_TS(2)
+    g_gemm1_act(0, RA);                              // slot 1
+    GR_TS(3)
+    sr_lds_barrier();
+    GR_TS(4)
+    g_stage_a2(hh ? RA : RC);                        // slot 2
+    GR_TS(5)
+    sr_lds_barrier();
+    GR_TS(6)
+    g_gemm2(hh ? RA : RC);                           // slot 3
+    GR_TS(7)
+    sr_lds_barrier();
+    GR_TS(8)
+    g_tile_out(hh ? RA : RC, two);                   // slot 4
+    GR_TS(9)
+    sr_lds_barrier();
+    GR_TS(10)
+    if (!two) return;
+    g_gemm1_act(1, RB);                              // slot 5
+    GR_TS(11)
+    sr_lds_barrier();
+    GR_TS(12)
+    g_stage_a2(hh ? RA : RC);                        // slot 6
+    GR_TS(13)
+    sr_lds_barrier();
+    GR_TS(14)
+    g_gemm2(hh ? RA : RC);                           // slot 7
+    GR_TS(15)
+    sr_lds_barrier();
+    GR_TS(16)
+    g_tile_out(hh ? RA : RC, false);                 // slot 8
+    GR_TS(17)
+    sr_lds_barrier();
+  } else {
+    r_stage(0, RA, xr0);                             // slot 0
+    GR_TS(1)
+    sr_lds_barrier();
+    GR_TS(2)
+    if (two) r_stage(1, RB, xr1);                    // slot 1
+    GR_TS(3)
+    sr_lds_barrier();
+    sr_lds_barrier();                                // slots 2, 3, 4: nothing for the row waves
+    sr_lds_barrier();
+    sr_lds_barrier();
+    GR_TS(10)
+    r_epilogue(0, RC, RA, xr0);                      // slot 5
+    GR_TS(11)
+    if (!two) return;
+    sr_lds_barrier();
+    sr_lds_barrier();                                // slots 6, 7, 8
+    sr_lds_barrier();
+    sr_lds_barrier();
+    GR_TS(18)
+    r_epilogue(1, RC, RA, xr1);                      // slot 9
+    GR_TS(19)
+  }
+}
+
 }  // namespace
 
 #ifdef SRHIP_EXPERIMENTS
@@ -844,6 +1224,19 @@ int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st) {
   SR_REQUIRE(p.ldx % 4 == 0 && p.ldo % 4 == 0 && p.ldh % 4 == 0 && p.ldr % 4 == 0 && (!bwd || p.ldr2 % 4 == 0),
              "mlp_f16x2: row pitches must be multiples of 4 floats");
   dim3 grid(sr_cdiv(p.M, BM));
+  // two hidden halves, f32-grade: the producer / consumer form (one block per CU, two tiles each)
+  static int gr_on = -1;
+  if (gr_on < 0) {
+    const char* e = sr_getenv("SRHIP_MLP_GR");
+    gr_on = e ? atoi(e) : 0;        // measured (profiles/r05_mlp_structure_experiments.txt): 76.7 us against 57.4 -- off
+    if (gr_on && hipFuncSetAttribute((const void*)k_mlp_gr_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, GR_LDS) != hipSuccess)
+      return sr_fail(-5, "mlp_f16x2: cannot reserve %d bytes of LDS", GR_LDS);
+  }
+  if (!bwd && gr_on && sr_matmul_mode() != 1 && p.hid > 192) {
+    hipLaunchKernelGGL(k_mlp_gr_fwd, dim3(sr_cdiv(sr_cdiv(p.M, BM), 2)), dim3(GR_NT), GR_LDS, st, p);
+    SR_LAUNCH_CHECK("k_mlp_gr_fwd");
+    return 0;
+  }
   if (bwd) hipLaunchKernelGGL(k_mlp_f16<true>, grid, dim3(256), MLP_LDS, st, p);
   else if (sr_matmul_mode() == 1) hipLaunchKernelGGL((k_mlp_f16<false, true>), grid, dim3(256), MLP_LDS, st, p);     // inference under --amp
   else hipLaunchKernelGGL(k_mlp_f16<false>, grid, dim3(256), MLP_LDS, st, p);

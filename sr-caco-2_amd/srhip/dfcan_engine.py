@@ -1,6 +1,6 @@
 """DFCAN as a tape graph (reference dlib/models/network_dfcan.py:86-116): conv + GELU; four residual groups of four RCABs
 (two conv + GELU, the Fourier channel attention, skip); conv 64 -> 64 s^2 + GELU as 256-column slices; PixelShuffle(s);
-conv + sigmoid.  Trains through the tape's derived backward (Tape.fourier_gate: the spectrum magnitude through stock torch.fft)."""
+conv + sigmoid.  Trains through the tape's derived backward (Tape.fourier_gate: the spectrum magnitude through the in-tree DFT passes, dfca.hip)."""
 from .tape import TapeEngine
 
 

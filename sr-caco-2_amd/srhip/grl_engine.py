@@ -239,9 +239,9 @@ class GRLEngine:
             # the CPB MLP over the relative-coordinates table (AffineTransform :296-319), by hand: [n, 2] -> 512 -> heads
             w0, b0, w2 = tr.cpb_mlp[0].weight, tr.cpb_mlp[0].bias, tr.cpb_mlp[2].weight
             tab = table.reshape(-1, 2).to(dev)
-            pre = tab @ w0.data.t() + b0.data
+            pre = ops.mm(tab, w0.data, tb=True, bias=b0.data)
             h1 = torch.relu(pre)
-            sg = torch.sigmoid(h1 @ w2.data.t())                                                     # [n, heads]
+            sg = torch.sigmoid(ops.mm(h1, w2.data, tb=True))                                                     # [n, heads]
             idx = index.reshape(-1).to(dev)
             bias = (16.0 * sg)[idx].view(Tq, Tk, heads).permute(2, 0, 1)                             # [heads, Tq, Tk]
             if mask is None:
@@ -253,9 +253,9 @@ class GRLEngine:
                 db = d.reshape(-1, heads, Tq, Tk).sum(0)                                             # [heads, Tq, Tk]
                 dsg = torch.zeros_like(sg).index_add_(0, idx, db.permute(1, 2, 0).reshape(-1, heads)) * 16.0
                 dz = dsg * sg * (1.0 - sg)
-                t.gparam(N(w2), lambda o: o.copy_(dz.t() @ h1))
-                dh1 = (dz @ w2.data) * (pre > 0)
-                t.gparam(N(w0), lambda o: o.copy_(dh1.t() @ tab))
+                t.gparam(N(w2), lambda o: o.copy_(ops.mm(dz, h1, ta=True)))
+                dh1 = ops.mm(dz, w2.data) * (pre > 0)
+                t.gparam(N(w0), lambda o: o.copy_(ops.mm(dh1, tab, ta=True)))
                 t.gparam(N(b0), lambda o: o.copy_(dh1.sum(0)))
             qs = t.scale_rows(t.normalize_rows(qr), s_rows, on_scale)
             return t.attend(qs, t.normalize_rows(kr), vr, B * nWin * heads, Tq, Tk, 1, qr.t.shape[1], 1.0, bias=addend,

@@ -290,6 +290,22 @@ def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
     return out
 
 
+def mm(a, b, ta=False, tb=False, bias=None):
+    """op(a) . op(b) (+ bias) for the SMALL dense products of the tape nets (squeeze-excitation gates, continuous-position-
+    bias MLPs: a few rows each) on the library's own exact-f32 MFMA kernel (srhip_gemm_nt) instead of aten's `@`
+    (rocBLAS): op(a) [M, K] and op(b)^T [N, K] are made contiguous, K zero-padded to a multiple of 4."""
+    A = a.t() if ta else a
+    W = b if tb else b.t()               # srhip_gemm_nt takes W [N, K] and computes A W^T
+    K = A.shape[1]
+    assert W.shape[1] == K, (A.shape, W.shape)
+    if K % 4:
+        K4 = (K + 3) // 4 * 4
+        Ap = A.new_zeros(A.shape[0], K4); Ap[:, :K] = A
+        Wp = W.new_zeros(W.shape[0], K4); Wp[:, :K] = W
+        A, W = Ap, Wp
+    return gemm_nt(A.contiguous().float(), W.contiguous().float(), None if bias is None else bias.contiguous())
+
+
 def gemm_nt_batched(A, a_z, W, w_z, C, c_z, M, N, K, zcount, zdiv):
     """zcount products C_z[M, N] = A_z[M, K] @ W_z[N, K]^T in one launch (exact-f32 kernel).  A / W / C: 2-D views giving the
     base pointer and row pitch of problem 0; *_z = (stride per z // zdiv, stride per z % zdiv) in floats."""
@@ -456,6 +472,17 @@ def fft2_mag_pow_shift(x, out, gamma=0.8, eps=1e-8):
     ws = SCRATCH.get("fft2_ws", 2 * x.numel(), device=x.device)
     call("srhip_fft2_mag_pow_shift", _p(x), _p(out), _p(ws), B, H, W, C, float(gamma), float(eps), _st())
     return out
+
+
+def fft2_mag_pow_shift_bwd(x, g, dx, gamma=0.8, eps=1e-8):
+    """dx = gradient of fft2_mag_pow_shift at x for the output gradient g (NHWC, contiguous): the in-tree separable DFT, four
+    passes (forward rows, forward columns with G . F formed in place, inverse columns, inverse rows' real part)."""
+    _chk(x, g, dx)
+    B, H, W, C = x.shape
+    assert x.is_contiguous() and g.is_contiguous() and dx.is_contiguous() and g.shape == x.shape == dx.shape
+    ws = SCRATCH.get("fft2_ws", 2 * x.numel(), device=x.device)
+    call("srhip_fft2_mag_pow_shift_bwd", _p(x), _p(g), _p(dx), _p(ws), B, H, W, C, float(gamma), float(eps), _st())
+    return dx
 
 
 def channel_gate(feat, w1, b1, w2, b2, x0, x1, out, mid_act="relu"):

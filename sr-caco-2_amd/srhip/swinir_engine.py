@@ -107,7 +107,30 @@ class SwinIREngine:
                        "conv_hr.", "conv_last."]
             out.append(pf)
         out.append(["conv_first.", "patch_embed."])
+        groups = self.layer0_bucket_groups()
+        if groups is not None and n > 1:
+            # Layer 0 is the LAST layer of backward: as one bucket (7.5 MB of the README net) it is announced 0.2 ms before
+            # the step ends and its all-reduce is the one exchange a multi-GPU run cannot hide.  Split: the
+            # upper blocks (+ the layer's conv), the middle blocks, and block 0 with the head -- each a contiguous range
+            # of the flat buffer (named_parameters order: conv_first, patch_embed, layers.0.residual_group.blocks.0..,
+            # layers.0.conv) announced as soon as ITS weight gradients are enqueued; the last bucket is 1.3 MB.
+            first, middle, last = groups
+            out = out[:n - 1]
+            out.append([f"layers.0.residual_group.blocks.{j}." for j in first] + ["layers.0.conv."])
+            if middle:
+                out.append([f"layers.0.residual_group.blocks.{j}." for j in middle])
+            out.append(["conv_first.", "patch_embed.", "absolute_pos_embed"]
+                       + [f"layers.0.residual_group.blocks.{j}." for j in last])
         return out
+
+    def layer0_bucket_groups(self):
+        """(first, middle, last) block indices of layer 0's gradient buckets under data parallelism, or None (one bucket).
+        SRHIP_DDP_SPLIT0=0 keeps the layer whole."""
+        nb = len(self.net.layers[0].residual_group.blocks)
+        if nb < 2 or os.environ.get("SRHIP_DDP_SPLIT0", "1") == "0":
+            return None
+        lo = max(1, nb // 2)
+        return list(range(lo, nb)), list(range(1, lo)), [0]
 
     # ------------------------------------------------------------------ weights
     def invalidate(self):
@@ -482,6 +505,22 @@ class SwinIREngine:
         return y
 
     # ------------------------------------------------------------------ backward
+    def _bias_table_grads(self, layer, pre, dparts, dbT_all, bi0, j_lo, j_hi, lheads, B, H, W, G):
+        """Relative-position-bias table gradients of the layer's blocks [j_lo, j_hi) (bi0 = global index of block 0 of
+        the layer): the partial tiles of the attention backward reduced, then one batched launch per <= 8 blocks."""
+        if j_hi <= j_lo:
+            return
+        tabs = [G(pre + f"residual_group.blocks.{j}.attn.relative_position_bias_table") for j in range(j_lo, j_hi)]
+        same = len(lheads) == 1
+        if dparts is not None:
+            ops.wattn_dbias_reduce_f16(dparts[j_lo:j_hi], dbT_all, bi0 + j_lo, B, H, W, next(iter(lheads)))
+        for j0 in range(0, j_hi - j_lo, 8):
+            if same:
+                ops.bias_grad_batched(dbT_all, bi0 + j_lo + j0, tabs[j0:j0 + 8])
+            else:
+                for j in range(j_lo + j0, min(j_hi, j_lo + j0 + 8)):
+                    ops.bias_grad(dbT_all[bi0 + j, :layer.residual_group.blocks[j].num_heads], tabs[j - j_lo])
+
     def backward(self, dy, grads, need_dx=False, on_layer_done=None, grads_zeroed=False):
         """dy: [B,in_chans,s*H,s*W]; grads: dict name -> tensor to receive the parameter
         gradient (overwritten).  Returns d loss / d x in the layout forward() took if need_dx."""
@@ -622,6 +661,16 @@ class SwinIREngine:
             resi_conv_bwd(f"l{li}", pre + "conv.", dt.view(B, H, W, C), t_blocks.view(B, H, W, C), rc,
                           g.view(B, H, W, C))
             nb = len(layer.residual_group.blocks)
+            # data-parallel runs: layer 0 announces its gradients in up to three buckets (bucket_prefixes); `cuts` maps
+            # the block index at which a group is complete to the bucket to announce there
+            cuts = {}
+            if li == 0 and on_layer_done is not None and len(net.layers) > 1 and defer:
+                grp = self.layer0_bucket_groups()
+                if grp is not None:
+                    cuts[grp[0][0]] = len(net.layers) - 1
+                    if grp[1]:
+                        cuts[grp[1][0]] = len(net.layers)
+            flushed_hi = nb              # blocks [flushed_hi, nb) have their weight / bias-table gradients enqueued
             pending = []                 # weight-gradient problems of the layer's blocks (deferred form)
             front = None                 # a block's qkv data gradient handed to the next block's fused MLP backward
             # partial bias-gradient tiles of the layer's blocks: reduced by ONE launch per layer (same head count only)
@@ -697,21 +746,18 @@ class SwinIREngine:
                     ops.linear_wgrad_grouped(problems)
                 gi = (gi + 2) % nrot
                 g = gout
+                if j in cuts:            # blocks [j, flushed_hi) are complete: their gradients now, their bucket announced
+                    ops.linear_wgrad_grouped(pending)
+                    pending = []
+                    self._bias_table_grads(layer, pre, dparts, dbT_all, bi - j, j, flushed_hi, lheads, B, H, W, G)
+                    flushed_hi = j
+                    on_layer_done(cuts[j])
             if pending:
                 ops.linear_wgrad_grouped(pending)
             # relative-position-bias table gradients of the layer's blocks: one launch (<= 8 blocks each)
-            tabs = [G(pre + f"residual_group.blocks.{j}.attn.relative_position_bias_table") for j in range(nb)]
-            same = len(lheads) == 1
-            if dparts is not None:
-                ops.wattn_dbias_reduce_f16(dparts, dbT_all, bi, B, H, W, next(iter(lheads)))
-            for j0 in range(0, nb, 8):
-                if same:
-                    ops.bias_grad_batched(dbT_all, bi + j0, tabs[j0:j0 + 8])
-                else:
-                    for j in range(j0, min(nb, j0 + 8)):
-                        ops.bias_grad(dbT_all[bi + j, :layer.residual_group.blocks[j].num_heads], tabs[j])
+            self._bias_table_grads(layer, pre, dparts, dbT_all, bi, 0, flushed_hi, lheads, B, H, W, G)
             ops.axpby(dt, g, 1.0, 1.0)   # RSTB skip: t_out = conv(blocks(t_in)) + t_in
-            if on_layer_done is not None:   # this layer's gradients are enqueued
+            if on_layer_done is not None and not cuts:   # this layer's gradients are enqueued
                 on_layer_done(len(net.layers) - 1 - li)
         # patch_embed.norm and the conv_after_body skip (f = conv(..) + f0)
         if net.ape:     # d table = sum over the batch of the token gradient

@@ -634,9 +634,10 @@ class Tape:
     def fourier_gate(self, x0, x1, key_conv, names_conv, w1, b1, w2, b2, names_gate=None, gamma=0.8, eps=1e-8):
         """DFCAN's Fourier channel attention (RCAB.forward, network_dfcan.py:60-70): gate = sigmoid(W2 relu(W1 avgpool(relu(
         conv(fftshift(|FFT2(x1)|^0.8)))))), out = x0 + x1 * gate.  names_gate = parameter names of (W1, b1, W2, b2).
-        Backward (training): the gate's two tiny Linears by hand on [B, C] tensors; the spectrum magnitude through stock
-        torch.fft -- with F = FFT2(x1) and G the incoming gradient un-shifted and times gamma (|F| + eps)^(gamma - 1) / |F|,
-        d x1 = Re(unnormalised IFFT2(G F)) -- registered in front of the conv so that it runs behind the conv's backward."""
+        Backward (training): the gate's two tiny Linears by hand on [B, C] tensors (ops.mm: the library's exact-f32 GEMM); the
+        spectrum magnitude through the in-tree DFT passes (srhip_fft2_mag_pow_shift_bwd) -- with F = FFT2(x1) and G the
+        incoming gradient un-shifted and times gamma (|F| + eps)^(gamma - 1) / |F|, d x1 = Re(unnormalised IFFT2(G F)) --
+        registered in front of the conv so that it runs behind the conv's backward."""
         a = x1.t if x1.t.is_contiguous() else x1.t.contiguous()
         B, H, W, C = a.shape
         m = torch.empty_like(a)
@@ -646,13 +647,8 @@ class Tape:
             def spec_bwd(x1=x1, mv=mv, a=a):
                 if mv.g is None:
                     return
-                Fq = torch.fft.fftn(a, dim=(1, 2))
-                mag = Fq.abs()
-                g0 = torch.roll(mv.g, shifts=(H // 2, W // 2), dims=(1, 2))        # through fftshift2d (:27-36)
-                G = g0 * gamma * (mag + eps).pow(gamma - 1.0) / mag.clamp_min(1e-30)
-                G = torch.where(mag > 0, G, torch.zeros_like(G))
-                dx = torch.fft.ifftn(G * Fq, dim=(1, 2), norm="forward").real.contiguous()
-                self.acc(x1, lambda o: o.copy_(dx))
+                gm = mv.g if mv.g.is_contiguous() else mv.g.contiguous()
+                self.acc(x1, lambda o: ops.fft2_mag_pow_shift_bwd(a, gm, o, gamma, eps))
             self.back.append(spec_bwd)
         c = self.relu(self.conv(mv, key_conv, names_conv))
         y = self.new(*a.shape)
@@ -671,15 +667,15 @@ class Tape:
                 self.acc(x0, lambda o: o.copy_(g))
                 self.acc(x1, lambda o: torch.mul(g, gate.view(B, 1, 1, C), out=o))
                 dgate = (g * a).sum((1, 2))
-                z1 = pool @ w1.t() + b1
+                z1 = ops.mm(pool, w1, tb=True, bias=b1)
                 r1 = torch.relu(z1)
                 dz2 = dgate * gate * (1.0 - gate)
-                dz1 = (dz2 @ w2) * (z1 > 0)
-                self.gparam(names_gate[2], lambda o: o.view(w2.shape).copy_(dz2.t() @ r1))
+                dz1 = ops.mm(dz2, w2) * (z1 > 0)
+                self.gparam(names_gate[2], lambda o: o.view(w2.shape).copy_(ops.mm(dz2, r1, ta=True)))
                 self.gparam(names_gate[3], lambda o: o.copy_(dz2.sum(0)))
-                self.gparam(names_gate[0], lambda o: o.view(w1.shape).copy_(dz1.t() @ pool))
+                self.gparam(names_gate[0], lambda o: o.view(w1.shape).copy_(ops.mm(dz1, pool, ta=True)))
                 self.gparam(names_gate[1], lambda o: o.copy_(dz1.sum(0)))
-                dpool = (dz1 @ w1) / float(H * W)
+                dpool = ops.mm(dz1, w1) / float(H * W)
                 self.acc(c, lambda o: o.copy_(dpool.view(B, 1, 1, C).expand(B, H, W, C)))
             self.back.append(gate_bwd)
         return out
@@ -943,15 +939,15 @@ class Tape:
                     return
                 self.acc(x, lambda o: o.copy_(g))
                 dgate = (g * ain).sum((1, 2))
-                z1 = pool @ w1m.t() + b1.data
+                z1 = ops.mm(pool, w1m, tb=True, bias=b1.data)
                 r1 = torch.relu(z1)
                 dz2 = dgate * gate * (1.0 - gate)
-                dz1 = (dz2 @ w2m) * (z1 > 0)
-                self.gparam(names[2], lambda o: o.view(w2m.shape).copy_(dz2.t() @ r1))
+                dz1 = ops.mm(dz2, w2m) * (z1 > 0)
+                self.gparam(names[2], lambda o: o.view(w2m.shape).copy_(ops.mm(dz2, r1, ta=True)))
                 self.gparam(names[3], lambda o: o.copy_(dz2.sum(0)))
-                self.gparam(names[0], lambda o: o.view(w1m.shape).copy_(dz1.t() @ pool))
+                self.gparam(names[0], lambda o: o.view(w1m.shape).copy_(ops.mm(dz1, pool, ta=True)))
                 self.gparam(names[1], lambda o: o.copy_(dz1.sum(0)))
-                dpool = (dz1 @ w1m) / float(H * W)
+                dpool = ops.mm(dz1, w1m) / float(H * W)
                 self.acc(a, lambda o: torch.addcmul(dpool.view(B, 1, 1, C).expand(B, H, W, C), g, gate.view(B, 1, 1, C), out=o))
             self.back.append(bwd)
         return out
@@ -989,7 +985,7 @@ class Tape:
 
     def dwconv(self, x, weight, bias, wname, bname=None):
         """nn.Conv2d(C, C, 3, padding=1, groups=C).  Backward: the data gradient is the same conv with flipped taps; the weight
-        gradient dW[c][tap] = sum_p g[p][c] x[p + tap][c] is the block diagonal of g^T @ unfold(x) (one GEMM; the other blocks
+        gradient dW[c][tap] = sum_p g[p][c] x[p + tap][c] is the block diagonal of g^T . unfold(x) (one GEMM; the other blocks
         are dropped)."""
         xin = self._c(x.t)
         B, H, W, C = xin.shape
@@ -1033,14 +1029,14 @@ class Tape:
                 if g is None:
                     return
                 dgate = (g * din).sum((1, 2))
-                z1 = pool @ w1m.t()
+                z1 = ops.mm(pool, w1m, tb=True)
                 sg = torch.sigmoid(z1)
                 r1 = z1 * sg
                 dz2 = dgate * gate * (1.0 - gate)
-                dz1 = (dz2 @ w2m) * (sg * (1.0 + z1 * (1.0 - sg)))
-                self.gparam(names[1], lambda o: o.view(w2m.shape).copy_(dz2.t() @ r1))
-                self.gparam(names[0], lambda o: o.view(w1m.shape).copy_(dz1.t() @ pool))
-                dpool = (dz1 @ w1m) / float(H * W)
+                dz1 = ops.mm(dz2, w2m) * (sg * (1.0 + z1 * (1.0 - sg)))
+                self.gparam(names[1], lambda o: o.view(w2m.shape).copy_(ops.mm(dz2, r1, ta=True)))
+                self.gparam(names[0], lambda o: o.view(w1m.shape).copy_(ops.mm(dz1, pool, ta=True)))
+                dpool = ops.mm(dz1, w1m) / float(H * W)
                 self.acc(d, lambda o: torch.addcmul(dpool.view(B, 1, 1, C).expand(B, H, W, C), g, gate.view(B, 1, 1, C), out=o))
             self.back.append(bwd)
         return out

@@ -620,8 +620,11 @@ assert torch.equal(tg.fp.flat, out["ddp"][0]) and torch.equal(tg.loss_buf, out["
     (tg.fp.flat - out["ddp"][0]).abs().max().item()
 print("ddp graph ok")
 d = (out["plain"][0] - out["ddp"][0]).abs().max().item()
-# every reduction is deterministic (no float atomics left in the step): same seed => same replica, bit for bit
-assert d == 0.0 and torch.equal(out["plain"][0], out["ddp"][0]) and torch.equal(out["plain"][1], out["ddp"][1]), d
+# every reduction is deterministic (no float atomics left in the step).  Round 5: under data parallelism layer 0's Linear
+# weight gradients leave in two or three grouped launches instead of one (their buckets are announced early), i.e. with
+# another slice count: the same sums in another order -- the replicas of a run are still bit-identical to each other
+# (and the captured step to the eager one, above); against the single-process step: rounding only
+assert d <= 1e-6 * out["plain"][0].abs().max().item() and torch.allclose(out["plain"][1], out["ddp"][1], rtol=1e-6), d
 # a single-bucket engine (VDSR): the bucket the engine used to announce itself must be reduced once
 v = VDSR(in_chans=1, upscale=2)
 v.load_state_dict(O.vdsr_init_state_dict(1, seed=2), strict=True)
@@ -672,7 +675,7 @@ net = SwinIR(upscale=8, in_chans=1, img_size=64, window_size=8, depths=[6, 6, 6,
              num_heads=[6, 6, 6, 6], mlp_ratio=2, upsampler="pixelshuffledirect").cuda().train()
 ts = TrainStep(net, [("l1", 1.0)], process_group=dist.group.WORLD, world_size=1)
 ts.opt = Optimizer(ts.fp, "sgd", lr=0.01, momentum=0.9, nesterov=True, wd=0.0)
-assert ts.ddp and len(ts.buckets) == 5
+assert ts.ddp and len(ts.buckets) == 6      # layers 3, 2, 1; layer 0 in three (blocks 3-5 + conv, 1-2, 0 + head)
 lr_img, hr_img = bench.synth_batch(8, 8, "cuda", seed=1000)
 for _ in range(3):
     ts.step(lr_img, hr_img)
@@ -685,9 +688,9 @@ ts.step(lr_img, hr_img)
 t_end.record()
 torch.cuda.synchronize()
 ev = ts.reducer.events
-assert sorted(ev) == [0, 1, 2, 3, 4] and ts.reducer.log == [0, 1, 2, 3, 4], ts.reducer.log
+assert sorted(ev) == list(range(6)) and ts.reducer.log == list(range(6)), ts.reducer.log
 rows = []
-for i in range(5):
+for i in range(6):
     lo, hi = ts.buckets[i]
     rows.append({"bucket": i, "mbytes": (hi - lo) * 4 / 1e6,
                  "announced_ms": t_start.elapsed_time(ev[i][0]), "allreduce_start_ms": t_start.elapsed_time(ev[i][1]),
@@ -698,7 +701,7 @@ out = {"what": "README SwinIR x8, B = 8, one rank (SRHIP_FORCE_DDP=1, RCCL group
                "step's first kernel; the step's last kernel (optimizer) ended at step_ms",
        "step_ms": step_ms, "total_mbytes": sum(r["mbytes"] for r in rows), "buckets": rows}
 os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(root, "gpurun_out", "r04_ddp_overlap.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(root, "gpurun_out", "r05_ddp_overlap.json"), "w"), indent=1)
 # the schedule: buckets in backward-completion order, each all-reduce enqueued (and, with one rank, finished) while
 # backward kernels of the layers behind it are still to come -- i.e. before the NEXT bucket is even announced, and all but
 # the last one long before the step's end
@@ -706,8 +709,14 @@ for a, b in zip(rows, rows[1:]):
     assert a["announced_ms"] < b["announced_ms"], (a, b)
     assert a["allreduce_start_ms"] <= b["announced_ms"] + 0.05, (a, b)       # started before the next layer's backward ended
     assert a["allreduce_end_ms"] <= b["announced_ms"] + 0.5, (a, b)
-assert rows[0]["announced_ms"] < 0.6 * step_ms and rows[3]["allreduce_end_ms"] < step_ms
+assert rows[0]["announced_ms"] < 0.6 * step_ms and rows[4]["allreduce_end_ms"] < step_ms
 assert abs(out["total_mbytes"] - 31.5) < 0.2, out["total_mbytes"]
+# round 5: layer 0 in three buckets -- the one exchange a multi-GPU run cannot hide is the last bucket: block 0 + the head
+assert rows[5]["mbytes"] <= 2.0, rows[5]
+assert rows[3]["announced_ms"] <= step_ms - 0.8, (rows[3], step_ms)     # blocks 3-5 of layer 0: a millisecond before the end
+# the ranges tile the flat gradient buffer exactly once
+cover = sorted(ts.buckets)
+assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:])) and cover[-1][1] == ts.fp.grad.numel()
 dist.destroy_process_group()
 print("ddp readme ok", json.dumps(out["buckets"]))
 '''
@@ -715,8 +724,9 @@ print("ddp readme ok", json.dumps(out["buckets"]))
 
 def test_forced_ddp_at_readme_size_overlaps_buckets_with_backward(tmp_path):
     """Config 4's schedule at its real size on the one GPU there is: README SwinIR x8, B = 8, SRHIP_FORCE_DDP=1 (RCCL
-    group of one): five buckets (31.5 MB) in backward-completion order on the side stream, bucket i's all-reduce under
-    way before layer i - 1's backward has ended (HIP events on both streams; gpurun_out/r04_ddp_overlap.json)."""
+    group of one): six buckets (31.5 MB; layer 0 in three, the last one 1.3 MB) in backward-completion order on the side
+    stream, bucket i's all-reduce under way before the next bucket's backward has ended (HIP events on both streams;
+    gpurun_out/r05_ddp_overlap.json)."""
     import socket
     import subprocess
     import sys
