@@ -103,12 +103,16 @@ def measured_bytes_per_step(workload):
     """HBM bytes one training step moved in the COMMITTED rocprofv3 PMC passes of this workload (newest
     profiles/r0N_hbm_traffic_per_kernel_<workload>_b8.json: FETCH_SIZE x 2 + WRITE_SIZE per launch x launches,
     tools/collect_traffic.sh), divided by the optimizer launches of that run (= its steps).  Not counters of the run being
-    reported: the keys that use it say 'from_committed_pmc' and name the file.  None if not collected."""
+    reported: the keys that use it say 'from_committed_pmc' and name the file.  None if not collected, or if the profile
+    was collected from other kernel sources than the ones this library was built from (its `_meta.csrc_sha16`)."""
     tag = workload.replace("swinir_x8", "swinir")
     for r in (9, 8, 7, 6, 5, 4, 3, 2):
         path = os.path.join(ROOT, "profiles", f"r0{r}_hbm_traffic_per_kernel_{tag}_b8.json")
         if os.path.isfile(path):
             table = json.load(open(path))
+            from srhip.probe import csrc_hash
+            if table.pop("_meta", {}).get("csrc_sha16") != csrc_hash():
+                return None, None       # the newest profile belongs to another build of the kernels: no figure (VERDICT r4)
             steps = sum(v["launches"] for k, v in table.items() if "k_sgd_dc" in k or "k_adam_dc" in k)
             if steps:
                 tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in table.values())

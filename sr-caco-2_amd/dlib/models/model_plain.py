@@ -211,6 +211,10 @@ class ModelPlain:
             return self.netG(x)
         st["x"].copy_(x)
         if st["g"] is None:
+            # one eager forward in THIS mode first: what an engine prepares lazily per mode (MemNet's evaluation-time
+            # BatchNorm folds are dropped by every train() call; its fp16-storage range check reads the output on the host)
+            # must not happen inside the capture -- a host copy or read there is an error
+            self.netG(st["x"])
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

@@ -3,12 +3,14 @@ on the launching stream around every launch of the probed op classes, inside
 the timed region.  Off by default (zero overhead beyond one attribute check).
 
 Op classes ("kinds") and the kernels behind them:
-  gemm_nt    Linear forward / data gradient            k_ntw / k_ntp<WN> (gemm_ntw.hip, gemm_ntp.hip)
-  conv_nt    3x3 conv forward / data gradient          k_ntb<..,true> implicit GEMM (gemm_ntb.hip)
-  conv_tn    3x3 conv weight gradient                  k_tnb<W> conv form (gemm_tnb.hip)
-  linear_tn  Linear weight gradients (grouped launch)  k_tnb_grouped<W> (gemm_tnb.hip)
-  wattn      window attention forward / backward       k_wattn_* (wattn.hip)
-  mlp_fused  fused LN->fc1->GELU->fc2 (+ its backward) k_mlp_* (mlp_fused.hip)
+  gemm_nt     Linear forward / data gradient            k_nth2 / k_ntw (gemm_ntw.hip; fp16x2 / bf16x3 planes), k_nt* exact f32
+  conv_nt     3x3 conv forward / data gradient          k_nhcw / k_nhcw2<..> implicit GEMM (gemm_ntw.hip), k_ntb (gemm_ntb.hip)
+  conv_tn     3x3 conv weight gradient                  k_tnb<W> / k_tnb3 conv forms (gemm_tnb.hip)
+  linear_tn   Linear weight gradients (grouped launch)  k_tnb_grouped_h<W> (gemm_tnb.hip)
+  wattn       window attention core, backward           k_wattn3_bwd (wattn2.hip); exact f32: k_wattn_* (wattn.hip)
+  wmsa_fused  norm1 + qkv + attention + proj, forward   k_wmsa_f16h (wmsa_f16.hip)
+  mlp_fused   LN -> fc1 -> GELU -> fc2 (+ its backward,  k_mlp_f16<bwd> (mlp_f16.hip)
+              qkv / proj data gradients chained)
 Every record carries the launch's ALGORITHMIC flops and bytes (SURVEY 8d
 convention: operands read once, result written once, fp32)."""
 import json
@@ -17,8 +19,9 @@ import os
 import torch
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
-# bf16x3 path: every f32 product costs 6 bf16 products on v_mfma_f32_32x32x16_bf16
-# (dense bf16 peak 2.5 PFLOP/s, MI355X_MICROARCH.md) -> ceiling in f32-equivalent flops
+# bf16x3 path (the fallback split): every f32 product costs 6 bf16 products on v_mfma_f32_32x32x16_bf16 (dense 16-bit peak
+# 2.5 PFLOP/s, MI355X_MICROARCH.md) -> ceiling in f32-equivalent flops.  The fp16x2 path of the hot kernels costs 3 products
+# (v_mfma_f32_16x16x32_f16, same dense peak): its ceiling is twice this one (bench.py: flop_frac_of_fp16x2_peak).
 BX3_MFMA_PEAK_TFLOPS = 2500.0 / 6.0
 HBM_PEAK_GBS = 8000.0
 active = None           # None | set of kinds being timed in the current step
@@ -34,6 +37,19 @@ def enable(kinds):
 def disable():
     global active
     active = None
+
+
+def csrc_hash():
+    """sha256 (16 hex digits) over the kernel sources the library is built from (csrc/*.hip, *.h, Makefile): ties a
+    committed PMC profile to the build it measured."""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def on(kind):
@@ -87,10 +103,14 @@ def _pmc_traffic(kernel_stem):
     for path in cands:
         if path and os.path.isfile(path):
             table = json.load(open(path))
+            # counters of ANOTHER build of the kernels say nothing about this run: a profile is used only if it was
+            # collected from the kernel sources this library was built from (tools/parse_traffic.py records their hash)
+            if table.get("_meta", {}).get("csrc_sha16") != csrc_hash():
+                continue
             for st in kernel_stem.split("|"):        # alternatives in order of preference: the first one that ran
                 tot = n = 0.0
                 for name, v in table.items():
-                    if st in name:
+                    if name != "_meta" and st in name:
                         tot += v["hbm_bytes_per_launch"] * v["launches"]
                         n += v["launches"]
                 if n:

@@ -23,6 +23,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), name
     assert _lib.lib.srhip_abi_version() >= 3
     assert isinstance(_lib.lib.srhip_last_error(), bytes)
+    # the entry-point count README.md / DESIGN.md quote is the header's (the docs lagged the header)
+    import re
+    for doc in ("README.md", "DESIGN.md"):
+        m = re.search(r'(\d+) `extern "C"` entry points', open(os.path.join(ROOT, doc)).read())
+        assert m and int(m.group(1)) == len(protos), (doc, m and m.group(1), len(protos))
 
 
 def test_ctypes_structs_mirror_the_header(tmp_path):

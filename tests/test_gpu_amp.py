@@ -185,8 +185,10 @@ REGISTRY_AMP = [("VDSR", "VDSR"), ("DRRN", "DRRN"), ("EDSR_LIIF", "EDSR_LIIF"), 
 @pytest.mark.parametrize("net_type,method", REGISTRY_AMP)
 def test_amp_inference_psnr_gate_registry_nets(net_type, method, scale):
     """Config 5's gate for the rest of the registry, every scale: ``--amp True`` against the f32-accurate forward of the
-    SAME weights through the CLI's construction path (main.parse_input / define_model / model.test()): PSNR against the
-    target within 0.01 dB.  NLSN draws its LSH rotations per forward: both forwards run from one seed."""
+    SAME weights through the CLI's construction path (main.parse_input / define_model / model.test()): PSNR against a
+    target 30 dB from the f32 output within 0.01 dB, and the mean absolute difference of the two outputs bounded (1e-3 of
+    the image range, 6e-3 of the output's mean deviation).  NLSN draws its LSH rotations per forward: both forwards run
+    from one seed."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "sr-caco-2_amd"))
@@ -215,14 +217,26 @@ def test_amp_inference_psnr_gate_registry_nets(net_type, method, scale):
         took = bool(getattr(model.netG, "amp", False) and getattr(model.netG, "amp_takes_effect", True))
         del model
         torch.cuda.empty_cache()
-    hr = batch["h_im"].cpu()
     assert torch.isfinite(outs[False]).all() and torch.isfinite(outs[True]).all()
-    # freshly initialised weights can leave the image range (DBPN x2: |y| up to 6): PSNR clamps to [0, 1], so both outputs
-    # are brought back into range by the SAME factor first (the gate stays a statement about relative precision)
-    rng = max(1.0, outs[False].abs().max().item())
-    outs = {k: v / rng for k, v in outs.items()}
-    gap = (psnr(outs[False], hr, scale) - psnr(outs[True], hr, scale)).abs().max().item()
-    mae = (outs[False] - outs[True]).abs().mean().item()
-    print(f"{net_type} x{scale}: amp vs fp32 MAE {mae:.2e} (|y| max {outs[False].abs().max().item():.2f}), PSNR gap {gap:.5f} dB, "
-          f"reduced-precision kernels taken: {took}")
+    # Round 5: the gate in the regime a trained net works in.  Freshly initialised weights give an output
+    # that has nothing to do with the batch's target -- a PSNR of 5-10 dB hardly moves with the output's relative error, so
+    # "within 0.01 dB of the f32 forward" said little.  Here the f32 output itself defines the image: both outputs go through
+    # the SAME affine map that puts the f32 output's 1 % .. 99 % range on [0.1, 0.9], and the target is that image plus
+    # Gaussian noise at 30 dB, quantised to 8 bits like a stored target: PSNR(f32 output, target) = 30 dB, and an error
+    # e (rms, image units) of the --amp output costs 10 log10(1 + e^2 / sigma^2) dB -- 0.01 dB at e = 1.5e-3 of the range.
+    y32, yamp = outs[False].double(), outs[True].double()
+    lo, hi = torch.quantile(y32.flatten()[:1 << 22], 0.01), torch.quantile(y32.flatten()[:1 << 22], 0.99)
+    a = 0.8 / max((hi - lo).item(), 1e-12)
+    n32, namp = ((y32 - lo) * a + 0.1).float(), ((yamp - lo) * a + 0.1).float()
+    g = torch.Generator().manual_seed(77)
+    sigma = 10.0 ** (-30.0 / 20.0)
+    target = ((n32 + sigma * torch.randn(n32.shape, generator=g)).clamp(0, 1) * 255).round() / 255
+    p32, pamp = psnr(n32.clamp(0, 1), target, scale), psnr(namp.clamp(0, 1), target, scale)
+    gap = (p32 - pamp).abs().max().item()
+    mae = (n32 - namp).abs().mean().item()                       # in units of the image range
+    rel = ((y32 - yamp).abs().mean() / (y32 - y32.mean()).abs().mean().clamp_min(1e-30)).item()
+    print(f"{net_type} x{scale}: f32 output at {p32.mean().item():.2f} dB of its noisy 8-bit target; amp vs fp32: PSNR gap {gap:.5f} dB, "
+          f"MAE {mae:.2e} of the range, relative MAE {rel:.2e}; reduced-precision kernels taken: {took}")
+    assert p32.min().item() >= 25.0, (net_type, scale, p32)
     assert gap <= 0.01, (net_type, scale, gap)
+    assert mae <= 1.0e-3 and rel <= 6.0e-3, (net_type, scale, mae, rel)

@@ -28,7 +28,14 @@ for k, e in res.items():
     write = e["WRITE_SIZE"][0] / e["WRITE_SIZE"][1] * 1024
     summary[k] = {"launches": e["FETCH_SIZE"][1], "fetch_bytes_per_launch_x2": fetch,
                   "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write}
-json.dump(summary, open(out, "w"), indent=1)
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sr-caco-2_amd"))
+try:                     # which build these counters belong to (bench.py uses a profile only for the same kernel sources)
+    from srhip.probe import csrc_hash
+    meta = {"csrc_sha16": csrc_hash()}
+except Exception as e:   # noqa: BLE001
+    meta = {"csrc_sha16": None, "error": str(e)}
+json.dump(dict(summary, _meta=meta), open(out, "w"), indent=1)
 for k, v in sorted(summary.items(), key=lambda t: -t[1]["hbm_bytes_per_launch"] * t[1]["launches"])[:12]:
     print(f"{k[:70]:70s} n={v['launches']:5d} fetch*2={v['fetch_bytes_per_launch_x2']/1e6:8.1f}MB "
           f"write={v['write_bytes_per_launch']/1e6:8.1f}MB")
