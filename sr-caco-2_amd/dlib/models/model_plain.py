@@ -127,9 +127,38 @@ class ModelPlain:
             return self.L_to_H
         return self.L
 
+    def _train_graph_on(self):
+        """The training step replayed from a hipGraph (TrainStep.step_graph: bit for bit the eager step; one host call
+        instead of hundreds to thousands of launches -- GRL's step is ~16 k launches and host-bound when eager).  Default
+        for the engines that say so (`train_graph_default`: the fused SwinIR / EDSR engines and the tape nets);
+        `--train_graph True / False` or SRHIP_TRAIN_GRAPH=1 / 0 force it either way.  A loss term with a host-side schedule
+        (ELB t) or a capture that fails falls back to the eager step for the rest of the run."""
+        if getattr(self, "_train_graph_failed", False):
+            return False
+        env = os.environ.get("SRHIP_TRAIN_GRAPH", "")
+        if env in ("0", "1"):
+            return env == "1"
+        arg = getattr(self.args, "train_graph", None)
+        if arg is not None:
+            return bool(arg)
+        return bool(getattr(getattr(self.netG, "engine", None), "train_graph_default", False))
+
     def optimize_parameters(self, epoch: int, current_step: int):
         self._weights_version += 1
-        self.step_fn.step(self._net_input(), self.H, weight=self.h_per_pixel_weight)
+        done = False
+        if self._train_graph_on():
+            try:
+                self.step_fn.step_graph(self._net_input(), self.H, weight=self.h_per_pixel_weight)
+                done = True
+            except NotImplementedError:       # a host-scheduled loss term: eager from here on
+                self._train_graph_failed = True
+            except RuntimeError as e:         # a capture the engine does not survive (a host read, an unsupported call)
+                self._train_graph_failed = True
+                self.step_fn._graph = None
+                print(f"[libsrhip] training-step capture failed ({str(e).splitlines()[0][:120]}): eager steps from here on",
+                      flush=True)
+        if not done:
+            self.step_fn.step(self._net_input(), self.H, weight=self.h_per_pixel_weight)
         # the engine's output buffer is persistent (overwritten by the next step) and 3-D for the 1-channel conv nets:
         # ``self.E`` hands out a [B,1,H,W] copy, as the reference's self.E is a fresh tensor -- made when somebody reads it
         # (current_visuals), not in every step (a 8 MB copy + an allocation per iteration the training loop never looks at)

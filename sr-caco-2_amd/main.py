@@ -74,6 +74,7 @@ def get_config(net_type):
         'scale': 2, 'n_channels': 1, 'h_size': 96, 'batch_size': 8, 'eval_bsize': 8, 'myseed': 0,
         'distributed': False, 'dist_backend': constants.GLOO, 'cudaid': '0', 'amp': False,
         'eval_graph': False,     # (not a reference option) evaluation forwards replayed from a hipGraph: ModelPlain.test()
+        'train_graph': None,     # (not a reference option) training step replayed from a hipGraph: None = the engine's default
         'max_epochs': 1, 'max_iters': 50, 'eval_over_roi_also': False,
         'train_dsets': '', 'valid_dsets': '', 'test_dsets': '', 'data_root': '', 'splits_root': 'folds',
         'sample_tr_patch': 'uniform', 'sample_tr_patch_th_style': 'fix_threshold', 'sample_tr_patch_th': 7,
@@ -129,7 +130,7 @@ def parse_input(argv=None):
     for k in ('scale', 'n_channels', 'h_size', 'batch_size', 'eval_bsize', 'myseed', 'max_epochs', 'max_iters',
               'sample_tr_patch_th', 'valid_n_samples'):
         ap.add_argument(f'--{k}', type=int, default=None)
-    for k in ('distributed', 'amp', 'eval_over_roi_also', 'eval_graph', 'eval_over_roi_also_model_select'):
+    for k in ('distributed', 'amp', 'eval_over_roi_also', 'eval_graph', 'train_graph', 'eval_over_roi_also_model_select'):
         ap.add_argument(f'--{k}', type=str2bool, default=None)
     for k, v in cfg['train'].items():
         t = str2bool if isinstance(v, bool) else (type(v) if not isinstance(v, list) else plus_list)

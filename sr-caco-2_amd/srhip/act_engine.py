@@ -17,6 +17,8 @@ from .tape import Tape, WeightBank
 
 
 class ACTEngine:
+    train_graph_default = True      # ModelPlain replays the training step from a hipGraph (TrainStep.step_graph)
+
     def __init__(self, net):
         self.net = net
         self.bank = WeightBank()

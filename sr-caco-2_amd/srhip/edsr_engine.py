@@ -18,6 +18,8 @@ from .swinir_engine import _Bufs
 
 
 class EDSREngine:
+    train_graph_default = True      # ModelPlain replays the training step from a hipGraph (TrainStep.step_graph)
+
     def __init__(self, net):
         self.net = net
         self.F = net.n_feats

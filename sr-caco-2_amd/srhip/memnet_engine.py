@@ -232,12 +232,19 @@ class MemNetEngine:
             cat = buf(f"m{i}.cat", B, H, W, gc)
             apps = []
             n = 0
+            pass_in = []                 # training: the input of every pass over the unit chain (what the backward keeps)
             for r in range(R):
+                pass_in.append(out)
                 for j in range(R):
                     u = self._unit(i, j)
-                    key = f"m{i}.r{r}.u{j}" if save else "scr"
-                    a1, c1, a2 = buf(key + ".a1", B, H, W, CH), buf(key + ".c1", B, H, W, CH), buf(key + ".a2", B, H, W, CH)
-                    nxt = buf(key + ".out" if save else f"scr.out{n % 2}", B, H, W, CH)
+                    # Round 5: a training forward keeps per unit application only the BatchNorm coefficients (and per pass its
+                    # result, the next pass's input); a1 / c1 / a2 and the units' outputs inside a pass go through scratch
+                    # buffers and are RECOMPUTED in the backward, one pass at a time, from the pass input and those
+                    # coefficients (the same kernels on the same inputs: the same bits).  Keeping all four maps of all 36
+                    # applications of all 6 blocks was 464 GB at the README batch (B = 8, 512 x 512): beyond the GPU.
+                    key = f"m{i}.r{r}.u{j}"
+                    a1, c1, a2 = buf("scr.a1", B, H, W, CH), buf("scr.c1", B, H, W, CH), buf("scr.a2", B, H, W, CH)
+                    nxt = buf(f"m{i}.r{r}.out" if (save and j == R - 1) else f"scr.out{n % 2}", B, H, W, CH)
                     if training:
                         k1 = bn(u + ".0", key + ".k1", out, a1)
                         ops.conv3x3(a1, ws[f"m{i}.u{j}.c0.wp"], None, CH, out=c1)
@@ -255,20 +262,20 @@ class MemNetEngine:
                             ops.conv3x3(a1, wpf, D.d[f"m{i}.u{j}.c0.bfold"], CH, out=a2, epi=1)
                     ops.conv3x3(a2, ws[f"m{i}.u{j}.c1.wp"], None, CH, out=nxt, epi=2, R=out)     # + the unit's input
                     if save:
-                        apps.append(dict(x=out, a1=a1, c1=c1, a2=a2, k1=k1, k2=k2, j=j))
+                        apps.append(dict(k1=k1, k2=k2, j=j))
                     out = nxt
                     n += 1
                 cat[..., r * CH:(r + 1) * CH].copy_(out)                                       # short-term memory r
             for k, t in enumerate(longs):
                 cat[..., (R + k) * CH:(R + k + 1) * CH].copy_(t)                               # long-term memories
-            ag = buf(f"m{i}.ag", T, gc)
+            ag = buf("scr.ag", T * self._gc(self.M - 1))[:T * gc].view(T, gc)
             kg = bn(f"dense_memory_blocks.{i}.gate_unit.0", f"m{i}.kg", cat.view(T, gc), ag)
             gate = buf(f"m{i}.gate", B, H, W, CH)
             rows = max(1, GEMM_BYTES_MAX // (4 * gc))
             for r0 in range(0, T, rows):
                 ops.gemm_nt(ag[r0:r0 + rows], ws[f"m{i}.gw"], out=gate.view(T, CH)[r0:r0 + rows])
             if save:
-                sv_blocks.append(dict(apps=apps, cat=cat, ag=ag, kg=kg))
+                sv_blocks.append(dict(apps=apps, cat=cat, kg=kg, pass_in=pass_in))        # (ag is recomputed from cat and kg)
             longs.append(gate)
             out = gate
         ar = buf("ar", B, H, W, CH)
@@ -324,40 +331,60 @@ class MemNetEngine:
             gc = self._gc(i)
             mbn = f"dense_memory_blocks.{i}"
             g_gate = g_long[i + 1].view(T, CH)
-            # ---- gate unit: gate = relu(BN(cat)) @ Wg^T
-            ops.linear_wgrad(g_gate, sb["ag"], grads[mbn + ".gate_unit.2.weight"].view(CH, gc), None)
-            dzg = buf(f"dzg{i}", T, gc)
-            ops.gemm_nt(g_gate, ws[f"m{i}.gwt"], out=dzg, epi=4, R=sb["ag"])                    # * (ag > 0)
-            g_cat = buf(f"gcat{i}", B, H, W, gc)
+            # ---- gate unit: gate = relu(BN(cat)) @ Wg^T  (relu(BN(cat)) recomputed from the saved coefficients)
+            gcmax = self._gc(self.M - 1)         # one allocation at the widest block's size, views for the others
+            ag = buf("ag", T * gcmax)[:T * gc].view(T, gc)
+            ops.bn_apply(sb["cat"].view(T, gc), sb["kg"], ag, relu=True)
+            ops.linear_wgrad(g_gate, ag, grads[mbn + ".gate_unit.2.weight"].view(CH, gc), None)
+            dzg = buf("dzg", T * gcmax)[:T * gc].view(T, gc)
+            ops.gemm_nt(g_gate, ws[f"m{i}.gwt"], out=dzg, epi=4, R=ag)                          # * (ag > 0)
+            g_cat = buf("gcat", T * gcmax)[:T * gc].view(B, H, W, gc)
             bn_bwd(mbn + ".gate_unit.0", dzg, sb["cat"].view(T, gc), sb["kg"], dx=g_cat.view(T, gc))
             for k in range(i + 1):
                 add_long(k, g_cat[..., (R + k) * CH:(R + k + 1) * CH])
             # ---- the R passes over the chain of R residual units, last pass first
-            items, g = [], None
+            g = None
             dwt = buf("dwt", R * R * 2, CH, CH, 3, 3)
             n = R * R
             for r in reversed(range(R)):
-                gs = buf(f"gs{r}", B, H, W, CH)                                                # d / d(pass r's result)
+                gs = buf(f"gs{r % 2}", B, H, W, CH)                                            # d / d(pass r's result)
                 gs.copy_(g_cat[..., r * CH:(r + 1) * CH])
                 if g is not None:
                     gs.add_(g)
                 g = gs
+                # the pass's unit chain again, forward, from its saved input and BatchNorm coefficients (per-unit buffers,
+                # shared by every pass of every block: 4 R maps)
+                x = sb["pass_in"][r]
+                rec = []
+                for j in range(R):
+                    ap = sb["apps"][r * R + j]
+                    a1, c1 = buf(f"rc.a1.{j}", B, H, W, CH), buf(f"rc.c1.{j}", B, H, W, CH)
+                    a2 = buf(f"rc.a2.{j}", B, H, W, CH)
+                    ops.bn_apply(x, ap["k1"], a1, relu=True)
+                    ops.conv3x3(a1, ws[f"m{i}.u{j}.c0.wp"], None, CH, out=c1)
+                    ops.bn_apply(c1, ap["k2"], a2, relu=True)
+                    rec.append(dict(x=x, a1=a1, c1=c1, a2=a2, k1=ap["k1"], k2=ap["k2"]))
+                    if j < R - 1:
+                        nxt = buf(f"rc.x.{j + 1}", B, H, W, CH)
+                        ops.conv3x3(a2, ws[f"m{i}.u{j}.c1.wp"], None, CH, out=nxt, epi=2, R=x)
+                        x = nxt
+                items = []
                 for j in reversed(range(R)):
                     n -= 1
-                    ap = sb["apps"][n]
+                    ap = rec[j]
                     u = self._unit(i, j)
                     items.append((g, ap["a2"], dwt[2 * n + 1], None))
                     dz2 = buf("dz", B, H, W, CH)
                     ops.conv3x3(g, ws[f"m{i}.u{j}.c1.wpt"], None, CH, out=dz2, epi=4, R=ap["a2"])
-                    dc1 = buf(f"dc{n}", B, H, W, CH)
+                    dc1 = buf(f"dc{j}", B, H, W, CH)
                     bn_bwd(u + ".3", dz2, ap["c1"], ap["k2"], dx=dc1)
                     items.append((dc1, ap["a1"], dwt[2 * n], None))
                     dz1 = buf("dz", B, H, W, CH)
                     ops.conv3x3(dc1, ws[f"m{i}.u{j}.c0.wpt"], None, CH, out=dz1, epi=4, R=ap["a1"])
-                    gx = buf(f"gx{n}", B, H, W, CH)
+                    gx = buf(f"gx{j}", B, H, W, CH)
                     bn_bwd(u + ".0", dz1, ap["x"], ap["k1"], dx=gx, res=g)                     # + the skip connection
                     g = gx
-            ops.conv3x3_wgrad_batched(items)
+                ops.conv3x3_wgrad_batched(items)     # the pass's twelve weight gradients (its operands die with the pass)
             dwv = dwt.view(R, R, 2, CH, CH, 3, 3)
             for j in range(R):
                 u = self._unit(i, j)

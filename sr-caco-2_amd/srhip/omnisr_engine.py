@@ -22,6 +22,8 @@ def _b(m):
 
 
 class OmniSREngine:
+    train_graph_default = True      # ModelPlain replays the training step from a hipGraph (TrainStep.step_graph)
+
     def __init__(self, net):
         self.net = net
         self.prepared = True

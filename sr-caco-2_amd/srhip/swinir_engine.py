@@ -44,6 +44,8 @@ def net_dev(net):
 
 
 class SwinIREngine:
+    train_graph_default = True      # ModelPlain replays the training step from a hipGraph (TrainStep.step_graph)
+
     def __init__(self, net):
         self.net = net
         self.C = net.embed_dim

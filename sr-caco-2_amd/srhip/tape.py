@@ -16,8 +16,9 @@ How the reference's layers map onto the kernels:
   * nn.Conv2d(k=s+4, stride s, p=2)             -> PixelUnshuffle(s) + conv3x3 C*s*s -> C with zero-padded sub-kernels:
       out[y][x] = sum_{dy,dx} unshuffled[y + dy][x + dx][(ci, i, j)] . W[:, ci, dy s + i + 2, dx s + j + 2]
   * nn.PReLU() / ReLU / LeakyReLU, torch.cat, add / sub, nn.PixelShuffle, nn.ReflectionPad2d(1)
-Every tensor is NHWC.  Buffers are persistent and keyed by the position of the op on the tape, so a training step
-allocates nothing after the first one.
+Every tensor is NHWC.  Training buffers come from a pool keyed by shape with liveness (_Pool): a value's activation and
+gradient return to it when the op that produced the value has run its backward; the request sequence repeats every step, so a
+training step allocates nothing after the first one.
 """
 import math
 
@@ -47,11 +48,61 @@ def _chunks(B, per_image):
 
 
 class Var:
-    """A value on the tape: NHWC tensor `t` (1-channel images: [B, H, W]) and its gradient `g` (contiguous, same shape)."""
-    __slots__ = ("t", "g", "need", "idx")
+    """A value on the tape: NHWC tensor `t` (1-channel images: [B, H, W]) and its gradient `g` (contiguous, same shape).
+    `gpool`: g was taken from the tape's buffer pool (and goes back there once the op that produced the value has run its
+    backward)."""
+    __slots__ = ("t", "g", "need", "idx", "gpool")
 
     def __init__(self, t, need=True, idx=-1):
-        self.t, self.g, self.need, self.idx = t, None, need, idx
+        self.t, self.g, self.need, self.idx, self.gpool = t, None, need, idx, False
+
+
+class _Pool:
+    """Training buffers of a tape net, by shape, with liveness (round 5).  Round 4 kept one persistent
+    buffer per tape position and one gradient buffer per value for the whole step: every activation AND every gradient of
+    the graph at once (SRFBN 234 GiB at the README batch, DBPN beyond 288).  A value's activation and gradient are dead as
+    soon as the op that PRODUCED it has run its backward closure -- its consumers come later on the tape, so their
+    closures have already run -- and go back to the pool there; gradient buffers of the ops in front are then served from
+    the activations just released.  The peak is the forward's activations plus a handful of gradients.  The sequence of
+    requests is the same in every step, so every request gets the same tensor again: nothing is allocated after the first
+    step and a captured step (TrainStep.step_graph) stays valid."""
+
+    def __init__(self):
+        self.all, self.free = {}, {}
+
+    def reset(self):
+        """every buffer free again (a new forward; whatever a forward without a backward left marked as taken included)"""
+        self.free = {k: list(v) for k, v in self.all.items()}
+
+    def take(self, shape, device):
+        key = tuple(shape)
+        fl = self.free.get(key)
+        if fl:
+            return fl.pop()
+        t = torch.empty(key, device=device)
+        self.all.setdefault(key, []).append(t)
+        self.free.setdefault(key, [])
+        return t
+
+    def give(self, t):
+        self.free[tuple(t.shape)].append(t)
+
+    def nbytes(self):
+        return sum(4 * t.numel() for v in self.all.values() for t in v)
+
+
+class _BackList(list):
+    """The tape's backward closures.  append() also records which values and buffers were created since the previous
+    append: they belong to the op whose closure this is, and are released when it has run."""
+
+    def __init__(self, tape):
+        super().__init__()
+        self.tape = tape
+
+    def append(self, fn):
+        t = self.tape
+        super().append((fn, t._recent_vars, t._recent_bufs))
+        t._recent_vars, t._recent_bufs = [], []
 
 
 # --------------------------------------------------------------------------- weight re-layout maps (host, cached)
@@ -220,9 +271,16 @@ class Tape:
     def __init__(self, bufs, bank, save, device):
         self.bufs, self.bank, self.save, self.dev = bufs, bank, save, device
         self.n = 0
-        self.back = []          # backward closures, forward order
+        self._recent_vars, self._recent_bufs = [], []
+        self.back = _BackList(self)          # (backward closure, values, buffers of its op), forward order
         self.tag = "t" if save else "e"
         self._gtmp = 0
+        self.pool = None
+        if save:
+            if getattr(bufs, "pool", None) is None:
+                bufs.pool = _Pool()
+            self.pool = bufs.pool
+            self.pool.reset()
 
     # ---- buffers
     def new(self, *shape):
@@ -233,10 +291,13 @@ class Tape:
         self.n += 1
         if not self.save:
             return torch.empty(shape, device=self.dev)
-        return self.bufs.get(f"{self.tag}.{self.n}", *shape, device=self.dev)
+        t = self.pool.take(shape, self.dev)
+        self._recent_bufs.append(t)
+        return t
 
     def _gnew(self, v):
-        return self.bufs.get(f"g.{v.idx}", *v.t.shape, device=self.dev)
+        v.gpool = True
+        return self.pool.take(v.t.shape, self.dev)
 
     def _tmp(self, *shape):
         self._gtmp += 1
@@ -247,10 +308,16 @@ class Tape:
 
     def var(self, t, need=True):
         self.n += 1
-        return Var(t, need, self.n)
+        v = Var(t, need, self.n)
+        if self.save:           # (an evaluation tape must not hold references: torch's allocator frees what has no reader left)
+            self._recent_vars.append(v)
+        return v
 
     def _out(self, t, need=True):
-        return Var(t, need, self.n)
+        v = Var(t, need, self.n)
+        if self.save:
+            self._recent_vars.append(v)
+        return v
 
     def acc(self, v, producer):
         """Add a gradient contribution to v: producer(out) writes it into a contiguous tensor of v's shape."""
@@ -1460,8 +1527,16 @@ class Tape:
     def backward(self, out, dy, grads):
         self.begin_backward(grads)
         out.g = dy
-        for b in reversed(self.back):
-            b()
+        for fn, vars_, bufs_ in reversed(self.back):
+            fn()
+            # the op's values have no reader left (their consumers' closures ran before this one): gradient and activation
+            # buffers back to the pool
+            for v in vars_:
+                if v.gpool and v.g is not None:
+                    self.pool.give(v.g)
+                v.g, v.gpool = None, False
+            for b in bufs_:
+                self.pool.give(b)
         # a parameter the graph never reached keeps a zero gradient
         for k, gt in grads.items():
             if k not in self._written:
@@ -1471,6 +1546,7 @@ class Tape:
 class TapeEngine:
     """Base of the engines written as a tape graph: subclasses implement bank_entries() (which convs exist, in which
     form) and graph(tape, x3) -> output Var ([B, H, W] image)."""
+    train_graph_default = True      # ModelPlain replays the training step from a hipGraph (TrainStep.step_graph)
 
     def __init__(self, net):
         self.net = net

@@ -429,7 +429,7 @@ class TrainStep:
         self.loss_buf[1:1 + len(self.loss_terms)].copy_(parts.sum(0))
         return dys[0], dys[1:]
 
-    def step_graph(self, lr_img, hr_img):
+    def step_graph(self, lr_img, hr_img, weight=None):
         """The same optimisation step replayed from a hipGraph: the ~330 launches of a SwinIR step are
         captured once per (batch, shape), the RCCL bucket all-reduces of a data-parallel run included -- every buffer is
         persistent, DropPath masks are drawn on the
@@ -442,21 +442,24 @@ class TrainStep:
             # (ELB.update_t(), dlib/losses/elb.py:92-122) of BoundedPrediction and of the Bhattacharyya histogram / KDE terms
             if t[0] == "boundpred" or (t[0] in ("hist", "kde") and len(t) > 5 and t[2] == 4):
                 raise NotImplementedError(f"step_graph: the loss term {t[0]!r} carries a host-side schedule (ELB t); use step()")
-        key = (tuple(lr_img.shape), tuple(hr_img.shape))
+        key = (tuple(lr_img.shape), tuple(hr_img.shape), weight is not None)
         st = getattr(self, "_graph", None)
         if st is None or st["key"] != key:
-            out = self.step(lr_img, hr_img)               # eager: allocates every buffer of this shape
-            self._graph = {"key": key, "g": None, "lr": lr_img.clone(), "hr": hr_img.clone()}
+            out = self.step(lr_img, hr_img, weight=weight)    # eager: allocates every buffer of this shape
+            self._graph = {"key": key, "g": None, "lr": lr_img.clone(), "hr": hr_img.clone(),
+                           "w": None if weight is None else weight.clone()}
             return out
         st["lr"].copy_(lr_img)
         st["hr"].copy_(hr_img)
+        if weight is not None:
+            st["w"].copy_(weight)
         if st["g"] is None:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             # under data parallelism the bucketed all-reduces are captured with the step: the side stream joins the
             # capture through the events the reducer records; thread-local error mode keeps RCCL's watchdog thread out of it
             with torch.cuda.graph(g, capture_error_mode="thread_local" if self.ddp else "global"):
-                self._enqueue(st["lr"], st["hr"], None, host_side=False)
+                self._enqueue(st["lr"], st["hr"], None, host_side=False, weight=st["w"])
             st["g"] = g
         self.opt.step_count += 1
         self.opt.push_lr()
