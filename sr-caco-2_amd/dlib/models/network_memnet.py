@@ -122,7 +122,14 @@ class MemNet(nn.Module):
         need_grad = self.training and torch.is_grad_enabled() and any(p.requires_grad for p in params)
         refresh_if_params_changed(self, params)   # stock torch.optim wrote the weights?
         if not self.training:
-            self.engine._eval_coefs = False       # the running statistics are buffers: re-read them (80 tiny copies)
+            # the running statistics are buffers: re-read them (80 tiny copies + one preparation launch) when something wrote
+            # them since the last evaluation forward -- a training forward of the engine (it drops the flag itself: its
+            # kernels write through raw pointers) or torch (load_state_dict, .copy_: the tensors' version counters).  Not in
+            # every call: a host copy is not permitted inside a hipGraph capture (ModelPlain --eval_graph).
+            sig = tuple(b._version for b in self.buffers())
+            if sig != getattr(self, "_bn_buffer_versions", None):
+                self._bn_buffer_versions = sig
+                self.engine._eval_coefs = False
             gc_max = (len(self.dense_memory_blocks) + self.dense_memory_blocks[0].num_residual_blocks) * 64
             per = xi.shape[1] * xi.shape[2] * self.upscale ** 2 * gc_max
             # the widest gate concatenation of the batch must stay below 2^31 elements (32-bit staging offsets of the conv /

@@ -184,6 +184,8 @@ class MemNetEngine:
         net, D, ws, R = self.net, self.derived, self.ws, self.R
         training = bool(net.training)
         assert not (save and not training), "MemNet (libsrhip): gradients in eval mode (frozen BatchNorm) are not built"
+        if training:
+            self._eval_coefs = False        # this forward updates the running statistics: the evaluation-time folds are stale
         if not save and not training and ops.h16_eval() and self._h16_ok() and not getattr(self, "_h16_overflow", False):
             # MemNet's memory blocks add 36 residual units per block without a normalisation in between: with untrained
             # statistics the feature maps leave fp16's range (65504).  One finiteness check of the output image per forward
