@@ -33,6 +33,9 @@ class EDSREngine:
         self.ws.use_bx3 = ops.bx3_nt_for(self.F)
         self._prep = self._prep_sig = None
         self.prepared = False
+        # weight gradients on a side stream beside the data-gradient chain (backward); SRHIP_EDSR_SIDE_WGRAD=0: one stream
+        self.side_wgrad = os.environ.get("SRHIP_EDSR_SIDE_WGRAD", "1") != "0"
+        self.wstream = None
         self.saved = None
         # Upsampler stage = conv F -> 4F + PixelShuffle(2) as one kernel per direction (no [B,H,W,4F] tensor,
         # no shuffle launches); SRHIP_FUSE_PS=0: conv + index kernel
@@ -173,11 +176,34 @@ class EDSREngine:
         def G(name):
             return grads[name]
 
+        # Round 5: the WEIGHT gradients run on a side stream beside the data-gradient chain.  The chain is what the next
+        # kernel waits for -- 2 nb + 2 launches of one block per CU, each ~16 us of latency for 3 us of matrix work at the
+        # x8 patch size (64 x 64 LR pixels) -- and no weight gradient is on it: each needs only its layer's incoming gradient
+        # and saved input, both complete when the chain has passed the layer.  side(fn): everything enqueued so far is fn's
+        # input (one event), fn's launches go to the side stream; the streams join at the end (and inside a captured step:
+        # a fork / join of the graph).  All weight-gradient launches share that one stream, so their scratch buffers
+        # (ops.SCRATCH: partial sums) are used strictly one launch after the other, as before.
+        main = torch.cuda.current_stream()
+        batched = ops.bx3_for(F, F) and self.nb > 0          # (the deferred form: every layer's operands in buffers of their own)
+        use_side = self.side_wgrad and dev.type == "cuda" and batched
+        if use_side and self.wstream is None:
+            self.wstream = torch.cuda.Stream(device=dev)
+
+        def side(fn):
+            if not use_side:
+                fn()
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.wstream.wait_event(ev)
+            with torch.cuda.stream(self.wstream):
+                fn()
+
         s = net.scale
         dy = dy.reshape(B, H * s, W * s).contiguous()
         # tail conv F->1: weight grad = 1-channel wgrad kernel with the roles of
         # x / dy swapped and flipped taps; data grad = 1-channel fwd kernel, flipped
-        ops.conv3x3_cin1_wgrad(dy, sv["u_last"], G("tail.1.weight"), None, flip=True)
+        side(lambda: ops.conv3x3_cin1_wgrad(dy, sv["u_last"], G("tail.1.weight"), None, flip=True))
         ops.sum_into(dy, G("tail.1.bias"))
         h, w = H * s, W * s
         du = buf(f"du{self.stages}", B, h, w, F)
@@ -185,14 +211,16 @@ class EDSREngine:
         for i in reversed(range(self.stages)):
             h, w = h // 2, w // 2
             if self.fuse_ps:     # both gradients read the gradient of the shuffled image
-                ops.conv3x3_wgrad(du, sv["ups"][i], G(f"tail.0.{2 * i}.weight"), G(f"tail.0.{2 * i}.bias"), ps2=True)
+                side(lambda du=du, i=i: ops.conv3x3_wgrad(du, sv["ups"][i], G(f"tail.0.{2 * i}.weight"),
+                                                          G(f"tail.0.{2 * i}.bias"), ps2=True))
                 dun = buf(f"du{i}", B, h, w, F)
                 ops.conv3x3_ps2_bwd_data(du, self.ws[f"up{i}.wpt"], dun)
                 du = dun
             else:
                 dc = buf(f"dc{i}", B, h, w, 4 * F)
                 ops.pixel_shuffle(du, 2, nhwc_out=True, inverse=True, out=dc)
-                ops.conv3x3_wgrad(dc, sv["ups"][i], G(f"tail.0.{2 * i}.weight"), G(f"tail.0.{2 * i}.bias"))
+                side(lambda dc=dc, i=i: ops.conv3x3_wgrad(dc, sv["ups"][i], G(f"tail.0.{2 * i}.weight"),
+                                                          G(f"tail.0.{2 * i}.bias")))
                 du = buf(f"du{i}", B, h, w, F)
                 ops.conv3x3(dc, self.ws[f"up{i}.wpt"], None, F, out=du)
         drb = du                                             # grad wrt rb (= also grad wrt f0 via the skip)
@@ -202,14 +230,25 @@ class EDSREngine:
         # data-gradient chain.  Alone, a 64 -> 64 problem at 64x64x8 pixels is 2.4 GFLOP: it was cut in
         # ~85 reduce slices to fill the chip and paid a 12.5 MB partial buffer + a reducer per layer
         # (rocprofv3, EDSR x8: 36 x (96 + 24) us of a 9.6 ms step).
-        batched = ops.bx3_for(F, F) and self.nb > 0
         wg = []                                              # (dY, X, dW, db)
+
+        # (with the side stream the batch leaves in groups of >= `grp` problems as the chain passes them: each group runs
+        # beside the rest of the chain; without it: one launch at the end, as in round 2)
+        grp = max(8, (2 * self.nb + 1 + 3) // 4) if use_side else 1 << 30
+
+        def flush():
+            if wg:
+                items = list(wg)
+                wg.clear()
+                side(lambda: ops.conv3x3_wgrad_batched(items))
 
         def wgrad(dY, X, wname, bname):
             if batched:
                 wg.append((dY, X, G(wname), G(bname)))
+                if len(wg) >= grp:
+                    flush()
             else:
-                ops.conv3x3_wgrad(dY, X, G(wname), G(bname))
+                side(lambda: ops.conv3x3_wgrad(dY, X, G(wname), G(bname)))
 
         wgrad(drb, sv["r_last"], f"body.{self.nb}.weight", f"body.{self.nb}.bias")
         if batched:
@@ -234,13 +273,15 @@ class EDSREngine:
             ops.conv3x3(da, self.ws[f"b{k}.0.wpt"], None, F, out=other, epi=2, R=g)  # + skip gradient
             g = other
         if batched:
-            ops.conv3x3_wgrad_batched(wg)
+            flush()
+        ops.axpby(g, drb, 1.0, 1.0)                          # long skip: rb = conv(body) + f0
+        side(lambda: ops.conv3x3_cin1_wgrad(sv["x"], g, G("head.0.weight"), G("head.0.bias")))
+        if use_side:
+            main.wait_stream(self.wstream)                   # every weight gradient is in before anything reads them
         if rs != 1.0:                # d(conv2 weights) = rs * (g (x) a): g was used unscaled above
             for k in range(self.nb):
                 for nm in (f"body.{k}.body.2.weight", f"body.{k}.body.2.bias"):
                     ops.axpby(G(nm), G(nm), 0.0, rs)
-        ops.axpby(g, drb, 1.0, 1.0)                          # long skip: rb = conv(body) + f0
-        ops.conv3x3_cin1_wgrad(sv["x"], g, G("head.0.weight"), G("head.0.bias"))
         if need_dx:
             wflip = net.head[0].weight.data.flip(2, 3).reshape(1, F, 3, 3).contiguous()
             return ops.conv3x3_cout1_fwd(g, wflip, None)

@@ -212,6 +212,9 @@ class MemNetEngine:
         def buf(name, *shape):
             return self.bufs.get(f"{tag}.{name}", *shape, device=dev)
 
+        def scr(key):
+            return self.bufs.get(key, B, H, W, CH, device=dev)
+
         def bn(pre, key, src, dst):
             m = self.bn[pre]
             if training:
@@ -245,8 +248,9 @@ class MemNetEngine:
                     # coefficients (the same kernels on the same inputs: the same bits).  Keeping all four maps of all 36
                     # applications of all 6 blocks was 464 GB at the README batch (B = 8, 512 x 512): beyond the GPU.
                     key = f"m{i}.r{r}.u{j}"
-                    a1, c1, a2 = buf("scr.a1", B, H, W, CH), buf("scr.c1", B, H, W, CH), buf("scr.a2", B, H, W, CH)
-                    nxt = buf(f"m{i}.r{r}.out" if (save and j == R - 1) else f"scr.out{n % 2}", B, H, W, CH)
+                    # (the scratch maps are the backward's recompute buffers: dead when the forward ends, rewritten there)
+                    a1, c1, a2 = scr("g.rc.a1.0"), scr("g.rc.c1.0"), scr("g.rc.a2.0")
+                    nxt = buf(f"m{i}.r{r}.out", B, H, W, CH) if (save and j == R - 1) else scr(f"g.rc.x.{1 + n % 2}")
                     if training:
                         k1 = bn(u + ".0", key + ".k1", out, a1)
                         ops.conv3x3(a1, ws[f"m{i}.u{j}.c0.wp"], None, CH, out=c1)
@@ -270,7 +274,7 @@ class MemNetEngine:
                 cat[..., r * CH:(r + 1) * CH].copy_(out)                                       # short-term memory r
             for k, t in enumerate(longs):
                 cat[..., (R + k) * CH:(R + k + 1) * CH].copy_(t)                               # long-term memories
-            ag = buf("scr.ag", T * self._gc(self.M - 1))[:T * gc].view(T, gc)
+            ag = self.bufs.get("g.ag", T * self._gc(self.M - 1), device=dev)[:T * gc].view(T, gc)     # (the backward's buffer)
             kg = bn(f"dense_memory_blocks.{i}.gate_unit.0", f"m{i}.kg", cat.view(T, gc), ag)
             gate = buf(f"m{i}.gate", B, H, W, CH)
             rows = max(1, GEMM_BYTES_MAX // (4 * gc))
