@@ -33,8 +33,11 @@ class EDSREngine:
         self.ws.use_bx3 = ops.bx3_nt_for(self.F)
         self._prep = self._prep_sig = None
         self.prepared = False
-        # weight gradients on a side stream beside the data-gradient chain (backward); SRHIP_EDSR_SIDE_WGRAD=0: one stream
-        self.side_wgrad = os.environ.get("SRHIP_EDSR_SIDE_WGRAD", "1") != "0"
+        # weight gradients on a side stream beside the data-gradient chain (backward): SRHIP_EDSR_SIDE_WGRAD=1.  Measured
+        # (round 5, EDSR x8, B = 8, same box, two rounds): 1715.2 / 1715.0 patches/s on one stream, 1687.3 / 1671.7 with the
+        # side stream -- the chain's one-block-per-CU launches do not leave the weight-gradient blocks room they could use
+        # (both slow down); off.
+        self.side_wgrad = os.environ.get("SRHIP_EDSR_SIDE_WGRAD", "0") == "1"
         self.wstream = None
         self.saved = None
         # Upsampler stage = conv F -> 4F + PixelShuffle(2) as one kernel per direction (no [B,H,W,4F] tensor,
@@ -176,7 +179,7 @@ class EDSREngine:
         def G(name):
             return grads[name]
 
-        # Round 5: the WEIGHT gradients run on a side stream beside the data-gradient chain.  The chain is what the next
+        # Round 5 experiment (off by default, see __init__): the WEIGHT gradients on a side stream beside the data-gradient chain.  The chain is what the next
         # kernel waits for -- 2 nb + 2 launches of one block per CU, each ~16 us of latency for 3 us of matrix work at the
         # x8 patch size (64 x 64 LR pixels) -- and no weight gradient is on it: each needs only its layer's incoming gradient
         # and saved input, both complete when the chain has passed the layer.  side(fn): everything enqueued so far is fn's
