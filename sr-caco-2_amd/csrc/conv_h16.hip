@@ -37,11 +37,12 @@ constexpr int h16_lds(int rw) {       // two halo tiles (chunks alternate) | thr
 
 // The accumulators of a 2 RW x 16 pixel x 64 column tile (acc[i][j][e] = pixel 16 (RW wm + i) + 4 g + e, column 32 wn + 16 j + c)
 // -> row-major in LDS -> bias / activation / residual on 8-column groups -> fp16 stores of 16 bytes.
-template <int RW>
+template <int RW, bool LDS_ONLY = false>
 __device__ __forceinline__ void h16_epilogue(const ConvH16Args& p, const f32x4 (&acc)[RW][2], unsigned char* smem, int tid, int wm,
                                              int wn, int c, int g, int n0, int img, int y0, int x0) {
   constexpr int NPX = 2 * RW * 16;
-  __syncthreads();                                // the halo tile is dead from here on
+  // (LDS_ONLY: the persistent kernel has the next tile's halo loads in flight here; __syncthreads() would wait for them)
+  if (LDS_ONLY) sr_lds_barrier(); else __syncthreads();     // the halo tile is dead from here on
   float* const T = (float*)smem;
 #pragma unroll
   for (int i = 0; i < RW; ++i)
@@ -49,7 +50,7 @@ __device__ __forceinline__ void h16_epilogue(const ConvH16Args& p, const f32x4 (
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) T[(16 * (RW * wm + i) + 4 * g + e) * TPF + 32 * wn + 16 * j + c] = acc[i][j][e];
-  __syncthreads();
+  if (LDS_ONLY) sr_lds_barrier(); else __syncthreads();
   const float* const winv = (const float*)((const char*)p.Wb + 2 * p.plane_bytes);
   // thread -> (pixel, 8-column group): NPX * 8 items
 #pragma unroll
@@ -223,6 +224,164 @@ __global__ void __launch_bounds__(256, 3) k_conv3x3_h16(ConvH16Args p) {
   }
 
   h16_epilogue<RW>(p, acc, smem, tid, wm, wn, c, g, n0, img, y0, x0);
+}
+
+// The same conv as a PERSISTENT kernel for the launches that are many rounds of blocks (round 5).  A
+// 64 -> 64 layer on 512 x 512 x 8 pixels is 16,384 tiles of 144 MFMAs per wave -- 1.1 us of matrix work each behind three
+// dependent memory round trips (the first halo chunk, the weight fragments, the residual): with three blocks per CU the
+// launch ran at a block's latency, 215 us against ~65 us of either floor.  Here a block walks tiles (grid = 3 blocks per CU,
+// tiles b, b + G, ...: the same XCD-aware order, G a multiple of 8) and, when the last tap of a tile has been issued,
+// the stream of (tile, chunk) stages simply runs on: behind the last chunk's barrier the NEXT tile's first halo chunk is
+// requested, behind its last taps the next tile's first weight fragments; they travel during the epilogue (LDS-only
+// barriers: nothing waits for them) and the next tile starts from registers.  Same arithmetic, same order per output.
+template <bool BN>
+__global__ void __launch_bounds__(256, 3) k_conv3x3_h16p(ConvH16Args p, int ntiles) {
+  constexpr int RW = 4;
+  constexpr int AROWS = (2 * RW + 2) * 18;
+  constexpr int AN = AROWS * 4;
+  constexpr int AIT = (AN + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = lane & 15, g = lane >> 4;
+  const int ncol = p.N >> 6;
+  const int nkc = p.K >> 5;
+  const long wrows = 9L * p.N;
+  constexpr int IMG = AROWS * HP;
+  struct Geo { int n0, img, y0, x0; unsigned offA[AIT]; unsigned in; };
+  auto geom = [&](int tl, Geo& q) {
+    int t = sr_xcd_block(tl, ntiles);
+    q.n0 = (t % ncol) * 64; t /= ncol;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    q.img = t / p.tiles_y;
+    q.y0 = ty * (2 * RW); q.x0 = tx * 16;
+    q.in = 0u;
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+      const int idx = min(tid + it * 256, AN - 1);
+      const int row = idx >> 2, c8 = idx & 3;
+      const int hy = row / 18, hx = row - hy * 18;
+      const int y = q.y0 + hy - 1, x = q.x0 + hx - 1;
+      if (y >= 0 && y < p.H && x >= 0 && x < p.Wd && (AN % 256 == 0 || tid + it * 256 < AN)) q.in |= 1u << it;
+      const int yc = min(max(y, 0), p.H - 1), xc = min(max(x, 0), p.Wd - 1);
+      q.offA[it] = (unsigned)((((long)q.img * p.H + yc) * p.Wd + xc) * p.ldx + c8 * 8) * 2u;
+    }
+  };
+  auto load_a = [&](const Geo& q, int kc, u32x4 (&ra)[AIT]) {
+    const char* base = (const char*)p.X + (long)kc * 64;
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) ra[it] = ((q.in >> it) & 1u) ? *(const u32x4*)(base + q.offA[it]) : u32x4{0u, 0u, 0u, 0u};
+  };
+  f32x4 bm[2], bk[2], bb[2];
+  auto store_a = [&](const u32x4 (&ra)[AIT], int kc, unsigned in) {
+    unsigned char* const img_w = smem + (kc & 1) * IMG;
+    if (BN) {
+      const int ch = kc * 32 + (tid & 3) * 8;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        bm[h2] = ldg_f4(p.in_bn + ch + 4 * h2);
+        bk[h2] = ldg_f4(p.in_bn + 2 * p.K + ch + 4 * h2);
+        bb[h2] = ldg_f4(p.in_bn + 3 * p.K + ch + 4 * h2);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+      if (AN % 256 == 0 || tid + it * 256 < AN) {
+        const int idx = tid + it * 256;
+        u32x4 v = ra[it];
+        if (BN) {
+          h16x8 hv = __builtin_bit_cast(h16x8, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            hv[e] = (_Float16)fmaxf(((float)hv[e] - bm[e >> 2][e & 3]) * bk[e >> 2][e & 3] + bb[e >> 2][e & 3], 0.f);
+          v = __builtin_bit_cast(u32x4, hv);
+        }
+        *(u32x4*)(img_w + (idx >> 2) * HP + (idx & 3) * 16) = ((in >> it) & 1u) ? v : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  unsigned boff[2];
+  auto set_boff = [&](int n0) {
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) boff[jt] = (unsigned)(((g >> 1) * wrows + n0 + wn * 32 + jt * 16 + c) * 32 + (g & 1) * 16);
+  };
+  auto load_b = [&](int kc, int tap, u32x4 (&fb)[2]) {
+    const char* base = (const char*)p.Wb + ((long)(2 * kc) * wrows + (long)tap * p.N) * 32;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) fb[jt] = *(const u32x4*)(base + boff[jt]);
+  };
+  f32x4 acc[RW][2];
+  int a_off[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) a_off[i] = ((RW * wm + i) * 18 + c) * HP + 16 * g;
+  auto mma = [&](const unsigned char* img_r, int tap, const u32x4 (&fb)[2]) {
+    const int toff = ((tap / 3) * 18 + (tap % 3)) * HP;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const u32x4 fa = *(const u32x4*)(img_r + a_off[i] + toff);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa, fb[j], acc[i][j]);
+    }
+  };
+  const int niter = nkc * 9;
+  auto load_it = [&](int it, u32x4 (&fb)[2]) { load_b(it / 9, it % 9, fb); };
+
+  Geo gc, gn;
+  int tl = blockIdx.x;
+  geom(tl, gc);
+  gn = gc;
+  set_boff(gc.n0);
+  unsigned boffn[2] = {boff[0], boff[1]};            // the NEXT tile's weight-fragment offsets (its column slice may differ)
+  u32x4 ra[AIT];
+  u32x4 fb0[2], fb1[2], fb2[2];
+  load_it(0, fb0); load_it(1, fb1); load_it(2, fb2);
+  load_a(gc, 0, ra);
+  for (;;) {
+    const int tn = tl + (int)gridDim.x;
+    const bool more = tn < ntiles;
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < nkc; ++kc) {
+      store_a(ra, kc, gc.in);
+      sr_lds_barrier();                            // ONE barrier per chunk (as k_conv3x3_h16), LDS only: prefetches stay in flight
+      const bool last = kc + 1 == nkc;
+      if (!last) load_a(gc, kc + 1, ra);
+      else if (more) {                             // the stream of chunks runs on into the next tile: its first halo chunk now,
+        geom(tn, gn);                              // its first weight fragments behind this chunk's last taps
+        load_a(gn, 0, ra);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+          boffn[jt] = (unsigned)(((g >> 1) * wrows + gn.n0 + wn * 32 + jt * 16 + c) * 32 + (g & 1) * 16);
+      }
+      const unsigned char* const img_r = smem + (kc & 1) * IMG;
+      const int it = kc * 9;
+      // fragments of tap it + 3 ..: this tile's while there are any, then taps 0, 1, 2 of the next tile
+      auto next_frag = [&](int nx, u32x4 (&fb)[2]) {
+        if (nx < niter) load_it(nx, fb);
+        else if (more) {
+          const char* base = (const char*)p.Wb + (long)(nx - niter) * p.N * 32;
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) fb[jt] = *(const u32x4*)(base + boffn[jt]);
+        }
+      };
+#pragma unroll
+      for (int t3 = 0; t3 < 9; t3 += 3) {
+        mma(img_r, t3, fb0);     next_frag(it + t3 + 3, fb0);
+        mma(img_r, t3 + 1, fb1); next_frag(it + t3 + 4, fb1);
+        mma(img_r, t3 + 2, fb2); next_frag(it + t3 + 5, fb2);
+      }
+    }
+    h16_epilogue<RW, true>(p, acc, smem, tid, wm, wn, c, g, gc.n0, gc.img, gc.y0, gc.x0);
+    if (!more) break;
+    gc = gn;
+    boff[0] = boffn[0]; boff[1] = boffn[1];
+    tl = tn;
+    sr_lds_barrier();                              // every thread has read its part of the output tile: the images may be written
+  }
 }
 
 // 1x1 conv (the weight's centre tap): no halo, so a stage is THREE 32-channel chunks of the tile's own pixels (one pair of
@@ -601,8 +760,16 @@ int sr_conv3x3_h16(ConvH16Args& p, hipStream_t st) {
   if (p.center_only) {
     if (rw == 4) hipLaunchKernelGGL(k_conv1x1_h16<4>, grid, dim3(256), h16_lds(4), st, p);
     else hipLaunchKernelGGL(k_conv1x1_h16<2>, grid, dim3(256), h16_lds(2), st, p);
-  } else if (rw == 4) hipLaunchKernelGGL(k_conv3x3_h16<4>, grid, dim3(256), h16_lds(4), st, p);
-  else hipLaunchKernelGGL(k_conv3x3_h16<2>, grid, dim3(256), h16_lds(2), st, p);
+  } else if (rw == 4) {
+    // more than four rounds of blocks: the persistent form (768 blocks = three per CU, a multiple of 8 for the XCD order)
+    static const int pers = [] { const char* e = sr_getenv("SRHIP_H16_PERSISTENT"); return e ? atoi(e) : 1; }();
+    const long ntiles = (long)grid.x;
+    if (pers && ntiles >= 4 * 768 && ntiles < (1L << 30)) {
+      if (p.in_bn) hipLaunchKernelGGL(k_conv3x3_h16p<true>, dim3(768), dim3(256), h16_lds(4), st, p, (int)ntiles);
+      else hipLaunchKernelGGL(k_conv3x3_h16p<false>, dim3(768), dim3(256), h16_lds(4), st, p, (int)ntiles);
+    }
+    else hipLaunchKernelGGL(k_conv3x3_h16<4>, grid, dim3(256), h16_lds(4), st, p);
+  } else hipLaunchKernelGGL(k_conv3x3_h16<2>, grid, dim3(256), h16_lds(2), st, p);
   SR_LAUNCH_CHECK("k_conv3x3_h16");
   return 0;
 }
