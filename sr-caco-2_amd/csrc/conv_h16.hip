@@ -761,8 +761,12 @@ int sr_conv3x3_h16(ConvH16Args& p, hipStream_t st) {
     if (rw == 4) hipLaunchKernelGGL(k_conv1x1_h16<4>, grid, dim3(256), h16_lds(4), st, p);
     else hipLaunchKernelGGL(k_conv1x1_h16<2>, grid, dim3(256), h16_lds(2), st, p);
   } else if (rw == 4) {
-    // more than four rounds of blocks: the persistent form (768 blocks = three per CU, a multiple of 8 for the XCD order)
-    static const int pers = [] { const char* e = sr_getenv("SRHIP_H16_PERSISTENT"); return e ? atoi(e) : 1; }();
+    // more than four rounds of blocks: the persistent form (768 blocks = three per CU, a multiple of 8 for the XCD order) --
+    // an experiment, OFF: measured 3-5 % SLOWER than the one-tile blocks (VDSR --amp 1921 -> 1836 patches/s, DRRN 212 -> 205,
+    // MemNet 65.2 -> 62.7).  The launch is not waiting for its first halo chunk: per 128-pixel tile the four waves pull
+    // 147 KB of weight fragments through the CU's 64-B/clk vector-memory path (70 us of a 215-us VDSR layer), read 290 KB of
+    // A fragments from LDS and issue 1.1 us of MFMAs -- three throughput limits of the same size that overlap only partly.
+    static const int pers = [] { const char* e = sr_getenv("SRHIP_H16_PERSISTENT"); return e ? atoi(e) : 0; }();
     const long ntiles = (long)grid.x;
     if (pers && ntiles >= 4 * 768 && ntiles < (1L << 30)) {
       if (p.in_bn) hipLaunchKernelGGL(k_conv3x3_h16p<true>, dim3(768), dim3(256), h16_lds(4), st, p, (int)ntiles);
