@@ -461,6 +461,11 @@ def train_valid(args, model, train_loader, train_sampler, valid_loaders: dict, t
             if max_iters and current_step >= max_iters:
                 stop = True
                 break
+        # (one host sync per epoch) a non-finite loss since the last checkpoint boundary must not reach the tracker / the
+        # epoch mean: the reference terminates at the first one (tools.py:55-63)
+        if not model.check_finite():
+            DLLogger.log('Terminated due to error: non-finite loss')
+            raise SystemExit(1)
         tracker = losses.drain(tracker, names)
         epoch_loss = losses.close_epoch()
         if epoch_loss is not None:

@@ -207,6 +207,28 @@ def _resume_point(args):
     iteration count.  Nothing there: iteration 0, weights from netG['init_pretrained_path'] if given."""
     from dlib.utils.utils_config import find_last_checkpoint
     models = os.path.join(args.outd_backup, args.save_dir_models)
+    # The reference's parser gives every experiment a folder of its own; here --outd defaults to a shared './out'.  A folder
+    # whose saved configuration (config_model.yml, written by a run over folds) names ANOTHER network is not this run's to
+    # resume: say so instead of failing in load_state_dict or silently training zero iterations (ADVICE r4).
+    cfg_path = os.path.join(args.outd_backup, 'config_model.yml')
+    if os.path.isfile(cfg_path):
+        import yaml
+        try:
+            old = yaml.safe_load(open(cfg_path)) or {}
+        except Exception:                       # python-tagged values the safe loader refuses: compare the text
+            old = {}
+            txt = open(cfg_path).read()
+            for key in ('net_type', 'scale'):
+                import re
+                m = re.search(rf'^{key}:\s*(\S+)', txt, re.M)
+                if m:
+                    old[key] = m.group(1)
+        if 'net_type' not in old and isinstance(old.get('netG'), dict) and 'net_type' in old['netG']:
+            old['net_type'] = old['netG']['net_type']           # (the reference's own files keep it under netG)
+        for key in ('net_type', 'scale'):
+            if key in old and str(old[key]) != str(getattr(args, key)):
+                raise SystemExit(f"--outd {args.outd_backup} holds an experiment with {key} = {old[key]} (config_model.yml); this "
+                                 f"run asks for {getattr(args, key)}: give it a folder of its own (--outd)")
     it_g, path_g = find_last_checkpoint(models, net_type='G',
                                         pretrained_path=args.netG.get('init_pretrained_path', '') or '')
     args.netG['checkpoint_path_netG'] = path_g
@@ -273,7 +295,9 @@ def main(argv=None):
     if rank == 0:
         print(model.info_network())
         if current_step:
-            print(f'resuming at iteration {current_step}: {args.netG["checkpoint_path_netG"]}')
+            print(f'[libsrhip] RESUMING at iteration {current_step} from {args.netG["checkpoint_path_netG"]} '
+                  f'(newest checkpoint under {os.path.join(args.outd_backup, args.save_dir_models)}; --outd selects the folder)',
+                  flush=True)
     if args.train_dsets:
         _train_on_folds(args, model, rank, world, current_step)
         if args.distributed:

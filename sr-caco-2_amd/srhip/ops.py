@@ -586,7 +586,11 @@ def dwconv3x3(x, w, bias, out):
     _chk(x, w, bias, out)
     B, H, W, C = out.shape
     assert x.stride(3) == 1 and out.stride(3) == 1 and w.is_contiguous() and w.numel() == 9 * C
-    call("srhip_dwconv3x3", _p(x), x.stride(2), _p(w), _p(bias), _p(out), out.stride(2), B, H, W, C, _st())
+    if probe.on("omni_ops"):
+        with probe.timed(("omni_ops", "dwconv3x3", B * H * W, C), 18.0 * B * H * W * C, 8.0 * B * H * W * C):
+            call("srhip_dwconv3x3", _p(x), x.stride(2), _p(w), _p(bias), _p(out), out.stride(2), B, H, W, C, _st())
+    else:
+        call("srhip_dwconv3x3", _p(x), x.stride(2), _p(w), _p(bias), _p(out), out.stride(2), B, H, W, C, _st())
     return out
 
 
@@ -595,7 +599,12 @@ def group_attention(qkv, bias, out, n, heads, scale):
     _chk(qkv, bias, out)
     C = out.shape[1]
     assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape == (out.shape[0], 3 * C) and out.shape[0] % n == 0
-    call("srhip_group_attention", _p(qkv), _p(bias), _p(out), out.shape[0] // n, n, C, heads, float(scale), _st())
+    if probe.on("omni_ops"):
+        T = out.shape[0]
+        with probe.timed(("omni_ops", "group_attention", T, C, n), 4.0 * T * n * C, 16.0 * T * C):
+            call("srhip_group_attention", _p(qkv), _p(bias), _p(out), out.shape[0] // n, n, C, heads, float(scale), _st())
+    else:
+        call("srhip_group_attention", _p(qkv), _p(bias), _p(out), out.shape[0] // n, n, C, heads, float(scale), _st())
     return out
 
 
@@ -603,7 +612,12 @@ def channel_attention(qkv, temperature, out, heads, ps, grid):
     _chk(qkv, temperature, out)
     B, H, W, C = out.shape
     assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape == (B, H, W, 3 * C)
-    call("srhip_channel_attention", _p(qkv), _p(temperature), _p(out), B, H, W, C, heads, ps, int(bool(grid)), _st())
+    if probe.on("omni_ops"):
+        T = B * H * W
+        with probe.timed(("omni_ops", "channel_attention", T, C, ps), 4.0 * T * C * (C // heads), 16.0 * T * C):
+            call("srhip_channel_attention", _p(qkv), _p(temperature), _p(out), B, H, W, C, heads, ps, int(bool(grid)), _st())
+    else:
+        call("srhip_channel_attention", _p(qkv), _p(temperature), _p(out), B, H, W, C, heads, ps, int(bool(grid)), _st())
     return out
 
 
@@ -874,8 +888,17 @@ def conv3x3_h16(X, Wp, bias, Cout, out=None, epi=0, R=None, alpha=1.0, ps2=False
         out = torch.empty((B, 2 * H, 2 * W, Cout // 4) if ps2 else (B, H, W, Cout), device=X.device, dtype=torch.float16)
     _chk(bias, in_bn)
     assert in_bn is None or (tuple(in_bn.shape) == (4, Cin) and in_bn.is_contiguous())
-    call("srhip_conv3x3_nhwc_h16", _ph(X), X.stride(2), _p(Wp.planes), _p(bias), _ph(out), out.stride(2), B, H, W, Cin, Cout,
-         int(epi), _ph(R), 0 if R is None else R.stride(2), float(alpha), int(bool(ps2)), _p(in_bn), int(bool(center_only)), _st())
+    def run():
+        call("srhip_conv3x3_nhwc_h16", _ph(X), X.stride(2), _p(Wp.planes), _p(bias), _ph(out), out.stride(2), B, H, W, Cin, Cout,
+             int(epi), _ph(R), 0 if R is None else R.stride(2), float(alpha), int(bool(ps2)), _p(in_bn), int(bool(center_only)), _st())
+    if probe.on("conv_h16"):
+        T = B * H * W
+        taps = 1 if center_only else 9
+        with probe.timed(("conv_h16", T, Cout, Cin, taps), 2.0 * taps * T * Cout * Cin,
+                         2.0 * (T * Cin + T * Cout + (T * Cout if R is not None else 0)) + 2.0 * taps * Cin * Cout):
+            run()
+    else:
+        run()
     return out
 
 
@@ -918,8 +941,14 @@ def srcnn_fwd_h16(patches, W1p, b1, W2p, b2, w3, b3, out, image=None):
         B = H = W = 0
         assert patches.is_contiguous() and tuple(patches.shape) == (T, 32)
     assert w3.numel() == 128 and out.numel() == T
-    call("srhip_srcnn_fwd_h16", _ph(patches), _p(image), B, H, W, _p(W1p.planes), _p(b1), _p(W2p.planes), _p(b2), _p(w3), _p(b3),
-         _p(out), T, _st())
+    def run():
+        call("srhip_srcnn_fwd_h16", _ph(patches), _p(image), B, H, W, _p(W1p.planes), _p(b1), _p(W2p.planes), _p(b2), _p(w3), _p(b3),
+             _p(out), T, _st())
+    if probe.on("conv_h16"):        # 25 -> 1024 -> 128 -> 1 per pixel; the image in and out (the hidden maps never exist)
+        with probe.timed(("conv_h16", "srcnn", T), 2.0 * T * (32 * 1024 + 1024 * 128 + 128), 8.0 * T + 2.0 * (32 * 1024 + 1024 * 128)):
+            run()
+    else:
+        run()
     return out
 
 

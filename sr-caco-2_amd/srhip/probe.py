@@ -87,8 +87,15 @@ _KERNEL_OF_KIND = {
     "gemm_batched": ("k_nt<", "batched NT GEMM, exact f32: every (sample, head) product of a layer in one launch"),
     "nlsa": ("k_nlsa_attention", "NLSN chunk attention on the exact-f32 matrix core"),
     "grl_attn": ("k_cosine_window_attention", "GRL cosine window / anchor-stripe attention (vector ALU, f32)"),
+    # fp16 STORAGE (--amp evaluation, conv_h16.hip): one fp16 product per multiply, fp16 maps: priced against the dense
+    # 16-bit matrix peak and 2-byte elements
+    "conv_h16": ("k_conv3x3_h16|k_conv1x1_h16|k_srcnn_h16", "3x3 / 1x1 conv on fp16 storage (one v_mfma_f32_16x16x32_f16 product, "
+                                                              "f32 accumulate), SRCNN's three layers in one launch"),
+    # OmniSR's own kernels (omni_ops.hip): depthwise convs, window / grid attention, channel attention -- vector ALU, f32
+    "omni_ops": ("k_dwconv3x3|k_group_attention|k_channel_attention", "OmniSR depthwise 3x3 convs, 64-token window / grid attention, "
+                                                                    "channel attention (vector ALU, f32)"),
 }
-_F32_KINDS = ("gemm_nt_f32", "conv_nt_f32", "gemm_batched", "nlsa", "grl_attn")
+_F32_KINDS = ("gemm_nt_f32", "conv_nt_f32", "gemm_batched", "nlsa", "grl_attn", "omni_ops")
 ALL_KINDS = tuple(_KERNEL_OF_KIND)
 
 
@@ -159,6 +166,9 @@ def collect():
         peak = 2500.0 / 3.0
         arith = ("fp16x2-split MFMA: two fp16 planes per operand under power-of-two block exponents, three products, f32 "
                  "accumulate (f32-equivalent flops; peak = fp16 dense / 3)")
+    if kind == "conv_h16":
+        peak = 2500.0
+        arith = "fp16 MFMA, one product per multiply on fp16 storage (peak = fp16 dense)"
     if bx and kind == "gemm_nt" and ops.F16X2:      # three products on two fp16 planes: the ceiling of THIS algorithm is twice as high
         peak = 2500.0 / 3.0
         arith = ("fp16x2-split MFMA: two fp16 planes per operand under per-row power-of-two scales, three products, f32 "

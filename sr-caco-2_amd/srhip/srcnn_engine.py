@@ -124,7 +124,7 @@ class SRCNNEngine:
             a0 = ops.im2col_c1(x[b0:b0 + nb], 5, KP1, out=a0w[r0:r0 + t] if save else buf("a0", t, KP1))
             h1 = ops.gemm_nt(a0, ws["w1"], net.features[0].bias.data, out=h1w[r0:r0 + t] if save else buf("h1", t, C1), epi=1)
             h2 = ops.gemm_nt(h1, ws["w2"], net.map[0].bias.data, out=h2w[r0:r0 + t] if save else buf("h2", t, C2), epi=1)
-            y4 = ops.gemm_nt(h2, ws["w3"], b3, out=buf("y4", t, 4))
+            y4 = ops.gemm_nt(h2, ws["w3"], b3, out=buf("y4", min(per, B) * H * W, 4)[:t])
             y[b0:b0 + nb].view(t).copy_(y4[:, 0])
         if save:
             self.saved = dict(a0=a0w, h1=h1w, h2=h2w, B=B, H=H, W=W, per=per)
@@ -151,8 +151,10 @@ class SRCNNEngine:
         for r0 in range(0, T, step):
             r1 = min(T, r0 + step)
             first = r0 == 0
-            dh2 = ops.gemm_nt(dy4[r0:r1], ws["w3T"], None, out=buf("dh2", r1 - r0, C2), epi=4, R=sv["h2"][r0:r1])     # * (h2 > 0)
-            dh1 = ops.gemm_nt(dh2, ws["w2T"], None, out=buf("dh1", r1 - r0, C1), epi=4, R=sv["h1"][r0:r1])            # * (h1 > 0)
+            # (scratch at the FULL group size, sliced for a smaller last group: a changing shape would reallocate 2 GiB twice
+            # per step -- no allocation in the steady state, capturable)
+            dh2 = ops.gemm_nt(dy4[r0:r1], ws["w3T"], None, out=buf("dh2", min(step, T), C2)[:r1 - r0], epi=4, R=sv["h2"][r0:r1])   # * (h2 > 0)
+            dh1 = ops.gemm_nt(dh2, ws["w2T"], None, out=buf("dh1", min(step, T), C1)[:r1 - r0], epi=4, R=sv["h1"][r0:r1])          # * (h1 > 0)
             # the first group writes the gradients, the others add theirs
             tw3, tb3, tw1 = (dw3, db3, dw1) if first else (buf("dw3.t", 4, C2), buf("db3.t", 4), buf("dw1.t", C1, KP1))
             tw2 = grads["map.0.weight"].view(C2, C1) if first else buf("dw2.t", C2, C1)
