@@ -270,7 +270,7 @@ def test_stop_and_resume_in_a_new_process_equals_the_uninterrupted_run(tmp_path,
     _run_main(optim + ["--max_iters", str(k)], b)
     assert sorted(os.listdir(os.path.join(b, "models"))) == [f"{k}_G.pth", f"{k}_optimizerG.pth"]
     out = _run_main(optim + ["--max_iters", str(2 * k)], b)
-    assert f"resuming at iteration {k}" in out
+    assert f"RESUMING at iteration {k}" in out
     assert sorted(os.listdir(os.path.join(b, "models"))) == [f"{2 * k}_G.pth", f"{2 * k}_optimizerG.pth"]   # older ones cleaned
     ga, gb = (torch.load(os.path.join(d, "models", f"{2 * k}_G.pth")) for d in (a, b))
     assert list(ga) == list(gb)
@@ -393,7 +393,7 @@ def test_main_over_folds_leaves_an_experiment_folder_eval_accepts(tmp_path):
     test_psnr = tr["test"][DS]["psnr"]["vals"][0]
     # a third epoch in a new process resumes at iteration 6 (epoch 2) and appends to the trackers
     out = run(["--max_epochs", "3", "--checkpoint_eval", "2", "--checkpoint_save", "3", "--G_optimizer_lr", "1e-3"])
-    assert "resuming at iteration 6" in out
+    assert "RESUMING at iteration 6" in out
     assert sorted(os.listdir(os.path.join(outd, "models"))) == ["9_G.pth", "9_optimizerG.pth"]
     with open(os.path.join(outd, "tracker.pkl"), "rb") as f:
         tr2 = pickle.load(f)
