@@ -1989,7 +1989,7 @@ def g_vdsr():
     from dlib.models.network_vdsr import VDSR as RefVDSR
     out = {}
     keep = ("conv1.0.weight", "trunk.0.conv.weight", "trunk.17.conv.weight", "conv2.weight")
-    for scale in (2, 4):
+    for scale in (2, 4, 8):        # x8 since round 5 (the x8 case was oracle-vs-HIP only)
         # weights from the oracle's seeded initialiser (the reference's own N(0, sqrt(2/(9 Cout))) law) loaded
         # into the reference net: the fixture stays small (no 0.67 M-parameter tensors)
         sd = O.vdsr_init_state_dict(1, seed=60 + scale)
@@ -2022,7 +2022,7 @@ def g_drrn():
     print("G17 DRRN")
     from dlib.models.network_drrn import DRRN as RefDRRN
     out = {}
-    for scale, units in ((2, 3), (4, 25)):
+    for scale, units in ((2, 3), (4, 25), (8, 9)):       # x8 since round 5
         sd = O.drrn_init_state_dict(1, seed=70 + scale)
         net = RefDRRN(in_chans=1, upscale=scale, num_residual_units=units)
         assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in sd.items()]

@@ -80,7 +80,7 @@ def test_edsr_full_size_forward_vs_reference_golden():
     assert (ps(y) - ps(yo)).abs().max() <= 0.01
 
 
-@pytest.mark.parametrize("scale", [2, 4])
+@pytest.mark.parametrize("scale", [2, 4, 8])
 def test_vdsr_fwd_bwd_vs_reference_golden(scale):
     """SURVEY f1, first of the plain CNNs: VDSR (network_vdsr.py) on the libsrhip conv kernels -- forward and
     every weight gradient against the reference's outputs; registry and state_dict contract."""
@@ -113,7 +113,7 @@ def test_vdsr_fwd_bwd_vs_reference_golden(scale):
         net(g[pre + "x"])
 
 
-@pytest.mark.parametrize("scale", [2, 4])
+@pytest.mark.parametrize("scale", [2, 4, 8])
 def test_drrn_fwd_bwd_vs_reference_golden(scale):
     """DRRN (network_drrn.py; shared-weight recursive block, 3 and 25 units) -- forward and the four
     weight gradients (the shared ones summed over the applications) against the reference."""
