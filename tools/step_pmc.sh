@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 IFS='+' read -ra GRP <<< "$GROUPS_"
 for g in "${GRP[@]}"; do
-  rocprofv3 --kernel-trace --pmc $g --output-format csv -d "$ROOT/$OUT/p$i" -- \
+  rocprofv3 --kernel-trace --pmc $g --output-format csv -d "$ROOT/$OUT/pass$i" -- \
     python3 "$ROOT/bench.py" --workload $WL --steps 3 --warmup 2 --train-only --no-roofline > "$ROOT/$OUT/bench$i.log" 2>&1 || true
   i=$((i+1))
 done
@@ -18,7 +18,7 @@ python3 - "$OUT" <<'P'
 import csv, glob, json, re, sys, collections
 d = sys.argv[1]
 out = collections.defaultdict(dict)
-for pdir in sorted(glob.glob(f"{d}/p*")):
+for pdir in sorted(glob.glob(f"{d}/pass*")):
     cc = glob.glob(f"{pdir}/**/*counter_collection.csv", recursive=True)
     kt = glob.glob(f"{pdir}/**/*kernel_trace.csv", recursive=True)
     if not cc or not kt:
@@ -44,4 +44,4 @@ for k, v in rows:
     print(f"{k[:44]:44s} n={v.get('launches', 0):4d} {v.get('avg_us_under_pmc', 0):8.1f} us  " +
           "  ".join(f"{c}={x:.3g}" for c, x in v.items() if c not in ("launches", "avg_us_under_pmc")))
 P
-rm -rf "$OUT"/p*
+rm -rf "$OUT"/pass*
