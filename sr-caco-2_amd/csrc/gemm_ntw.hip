@@ -1080,13 +1080,20 @@ __device__ long long* g_nhcw2_dbg = nullptr;
 #else
 #define SR_TSC(K)
 #endif
-template <int RW, bool AMP>
-// three blocks per CU (166 VGPRs at RW = 4, no spill; 43 KB of LDS each): same box, against two -- the 64 -> 64 conv at 8 x 256 x 256
-// 152.4 -> 142.4 us, EDSR x8 training step 4.72 -> 4.65 ms, VDSR / DRRN evaluation 9.23 -> 8.75 / 88.8 -> 81.8 ms per batch
 #ifndef SR_NHCW2_OCC
 #define SR_NHCW2_OCC 3
 #endif
-__global__ void __launch_bounds__(256, SR_NHCW2_OCC) k_nhcw2(NtArgs p) {
+template <bool DEEP_> struct Nhcw2Ring { static constexpr int SETS = DEEP_ ? 9 : 3, OCC = DEEP_ ? 2 : SR_NHCW2_OCC; };
+template <int RW, bool AMP, bool DEEP = false>
+// three blocks per CU (166 VGPRs at RW = 4, no spill; 43 KB of LDS each): same box, against two -- the 64 -> 64 conv at 8 x 256 x 256
+// 152.4 -> 142.4 us, EDSR x8 training step 4.72 -> 4.65 ms, VDSR / DRRN evaluation 9.23 -> 8.75 / 88.8 -> 81.8 ms per batch
+// DEEP (RW = 2, at most two blocks per CU: the launches of a few hundred blocks -- EDSR x8's body convs at 8 x 64 x 64 are 512 blocks, two per
+// CU) runs at the latency of its own chain, not at a rate: tools/mb_conv64_phases.py, round 5 -- 16.2 us per block, of which the
+// 18 taps take 6.8 us for 1.6 us of MFMA issue: every tap waits for its weight fragments, requested three taps (0.27 us of
+// matrix time) ahead of an L2 that all 512 blocks ask for the same lines at the same moment (~1.1 us).  Two blocks per CU
+// leave 256 registers: there the ring is NINE register sets -- a whole 32-channel chunk ahead; the fragments of chunk k + 1
+// travel while chunk k's taps and the staging of chunk k + 1 run.
+__global__ void __launch_bounds__(256, Nhcw2Ring<DEEP>::OCC) k_nhcw2(NtArgs p) {
   constexpr int NPL = AMP ? 1 : 2;
   constexpr int D_AROWS = (2 * RW + 2) * 18;       // halo pixels of a 2 RW x 16 tile
   constexpr int D_APLANE = D_AROWS * C_PITCH;
@@ -1233,8 +1240,11 @@ __global__ void __launch_bounds__(256, SR_NHCW2_OCC) k_nhcw2(NtArgs p) {
 
   f32x4 ra[D_AIT];
   load_a(0, ra);
-  u32x4 fb0[2][2], fb1[2][2], fb2[2][2];
-  load_b(0, fb0); load_b(1, fb1); load_b(2, fb2);
+  constexpr int NSETS = Nhcw2Ring<DEEP>::SETS;
+  u32x4 fbr[NSETS][2][2];
+#pragma unroll
+  for (int q = 0; q < NSETS; ++q)
+    if (q < niter) load_b(q, fbr[q]);
   SR_TSC(1)
   for (int kc = 0; kc < nkc; ++kc) {
     const float tmx = wave_max(clean_a(ra, kc));
@@ -1261,11 +1271,19 @@ __global__ void __launch_bounds__(256, SR_NHCW2_OCC) k_nhcw2(NtArgs p) {
           for (int e = 0; e < 4; ++e) acc[i][j][e] *= f;
     }
     const int it = kc * 9;
+    if constexpr (NSETS == 9) {                // the ring holds a chunk: tap t in set t, refilled with the next chunk's tap t
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        mma(t, fbr[t]);
+        if (it + t + 9 < niter) load_b(it + t + 9, fbr[t]);
+      }
+    } else {
 #pragma unroll 1
-    for (int t3 = 0; t3 < 9; t3 += 3) {
-      mma(t3, fb0);     if (it + t3 + 3 < niter) load_b(it + t3 + 3, fb0);
-      mma(t3 + 1, fb1); if (it + t3 + 4 < niter) load_b(it + t3 + 4, fb1);
-      mma(t3 + 2, fb2); if (it + t3 + 5 < niter) load_b(it + t3 + 5, fb2);
+      for (int t3 = 0; t3 < 9; t3 += 3) {
+        mma(t3, fbr[0]);     if (it + t3 + 3 < niter) load_b(it + t3 + 3, fbr[0]);
+        mma(t3 + 1, fbr[1]); if (it + t3 + 4 < niter) load_b(it + t3 + 4, fbr[1]);
+        mma(t3 + 2, fbr[2]); if (it + t3 + 5 < niter) load_b(it + t3 + 5, fbr[2]);
+      }
     }
     if (kc < 2) { SR_TSC(4 + 4 * kc) }
   }
@@ -1349,6 +1367,8 @@ int sr_conv3x3_nhcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
   if (rows_per_wave == 4) {
     if (amp) hipLaunchKernelGGL((k_nhcw2<4, true>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((k_nhcw2<4, false>), grid, dim3(256), lds, st, p);
+  } else if (!amp && grid.x <= 512 && !sr_getenv("SRHIP_NHCW2_DEEP_OFF")) {   // at most two blocks per CU: the whole-chunk weight ring
+    hipLaunchKernelGGL((k_nhcw2<2, false, true>), grid, dim3(256), lds, st, p);
   } else {
     if (amp) hipLaunchKernelGGL((k_nhcw2<2, true>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((k_nhcw2<2, false>), grid, dim3(256), lds, st, p);
