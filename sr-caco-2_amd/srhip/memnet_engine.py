@@ -337,7 +337,7 @@ class MemNetEngine:
             gc = self._gc(i)
             mbn = f"dense_memory_blocks.{i}"
             g_gate = g_long[i + 1].view(T, CH)
-            # ---- gate unit: gate = relu(BN(cat)) @ Wg^T  (relu(BN(cat)) recomputed from the saved coefficients)
+            # ---- gate unit: gate = relu(BN(cat)) . Wg^T  (relu(BN(cat)) recomputed from the saved coefficients)
             gcmax = self._gc(self.M - 1)         # one allocation at the widest block's size, views for the others
             ag = buf("ag", T * gcmax)[:T * gc].view(T, gc)
             ops.bn_apply(sb["cat"].view(T, gc), sb["kg"], ag, relu=True)

@@ -263,7 +263,7 @@ class WeightSet:
 
 def gemm_nt(A, W, bias=None, out=None, a_mode=0, ln_stats=None, epi=0, R=None,
             rowscale=None, rows_per_scale=1, alpha=1.0, aux=None, stats_out=None):
-    """out[M,N] = epi(pro(A)[M,K] @ W[N,K]^T + bias).  W: f32 tensor (exact-f32
+    """out[M,N] = epi(pro(A)[M,K] . W[N,K]^T + bias).  W: f32 tensor (exact-f32
     MFMA) or Bx3 (3-way bf16 split MFMA)."""
     bx = isinstance(W, Bx3)
     _chk(A, None if bx else W, bias, out, ln_stats, R, rowscale, aux)
@@ -307,7 +307,7 @@ def mm(a, b, ta=False, tb=False, bias=None):
 
 
 def gemm_nt_batched(A, a_z, W, w_z, C, c_z, M, N, K, zcount, zdiv):
-    """zcount products C_z[M, N] = A_z[M, K] @ W_z[N, K]^T in one launch (exact-f32 kernel).  A / W / C: 2-D views giving the
+    """zcount products C_z[M, N] = A_z[M, K] . W_z[N, K]^T in one launch (exact-f32 kernel).  A / W / C: 2-D views giving the
     base pointer and row pitch of problem 0; *_z = (stride per z // zdiv, stride per z % zdiv) in floats."""
     _chk(A, W, C)
     assert A.stride(-1) == 1 and W.stride(-1) == 1 and C.stride(-1) == 1
@@ -322,7 +322,7 @@ def gemm_nt_batched(A, a_z, W, w_z, C, c_z, M, N, K, zcount, zdiv):
 
 
 def gemm_nt_lnbwd(A, W, x, stats, res, out):
-    """out = res + LayerNorm_backward(A @ W^T; x, stats) in one kernel (W: Bx3)."""
+    """out = res + LayerNorm_backward(A . W^T; x, stats) in one kernel (W: Bx3)."""
     assert isinstance(W, Bx3)
     _chk(A, x, stats, res, out)
     M, K = A.shape
@@ -745,7 +745,7 @@ def mlp_f16_fusable(C, hidden):
 
 
 def mlp_fwd_f16(x, stats, W1, b1, W2, b2, out, h=None, rowscale=None, rows_per_scale=1, stats_out=None):
-    """out = x + s * (gelu(LN(x) @ W1^T + b1) @ W2^T + b2) in ONE kernel on the Linear GEMMs' own operands
+    """out = x + s * (gelu(LN(x) . W1^T + b1) . W2^T + b2) in ONE kernel on the Linear GEMMs' own operands
     (W1 = planes of W1*gamma [hidden, C], W2 = planes of W2 [C, hidden], both format 1); h (optional) receives the
     pre-activation, stats_out the {mean, rstd} of the out rows."""
     _chk(x, stats, b1, b2, out, h, rowscale, stats_out)
@@ -775,8 +775,8 @@ def wmsa_f16_fusable(C, heads):
 
 def wmsa_fwd_f16(x, stats, Wq, bq, Wp, bp, biasF, qkv, att, out, B, H, W, heads, shift, rowscale=None,
                  stats_out=None):
-    """The W-MSA half of a Swin block, forward, in ONE kernel: qkv = LN(x) @ Wq^T + bq, att = window attention,
-    out = x + s * (att @ Wp^T + bp).  Wq = planes of Wqkv*gamma [3C, C], Wp = planes of Wproj [C, C] (format 1)."""
+    """The W-MSA half of a Swin block, forward, in ONE kernel: qkv = LN(x) . Wq^T + bq, att = window attention,
+    out = x + s * (att . Wp^T + bp).  Wq = planes of Wqkv*gamma [3C, C], Wp = planes of Wproj [C, C] (format 1)."""
     _chk(x, stats, bq, bp, biasF, qkv, att, out, rowscale, stats_out)
     T, C = x.shape
     assert T == B * H * W and Wq.fmt == 1 and Wp.fmt == 1 and (Wq.rows, Wq.K) == (3 * C, C) and (Wp.rows, Wp.K) == (C, C)
@@ -795,9 +795,9 @@ def wmsa_fwd_f16(x, stats, Wq, bq, Wp, bp, biasF, qkv, att, out, B, H, W, heads,
 
 
 def mlp_bwd_f16(dy, W2T, W1T, h, dh, gh, x, stats, dx, rowscale=None, rows_per_scale=1, chain=None, front=None):
-    """Data gradient of mlp_fwd_f16 in ONE kernel: dh = (s * dy @ W2) * gelu'(h), gh = gelu(h), dx = dy +
-    LayerNorm_backward(dh @ W1f; x, stats).  W2T = planes of W2^T [hidden, C], W1T = planes of (W1*gamma)^T [C, hidden].
-    chain = (W3, out3, rowscale3): out3 = s3 * (dx @ W3^T) behind it in the same kernel (W3 = planes [C, C], format 1:
+    """Data gradient of mlp_fwd_f16 in ONE kernel: dh = (s * dy . W2) * gelu'(h), gh = gelu(h), dx = dy +
+    LayerNorm_backward(dh . W1f; x, stats).  W2T = planes of W2^T [hidden, C], W1T = planes of (W1*gamma)^T [C, hidden].
+    chain = (W3, out3, rowscale3): out3 = s3 * (dx . W3^T) behind it in the same kernel (W3 = planes [C, C], format 1:
     the data gradient of the attention's proj Linear).
     front = (X0, W0, x0, stats0, res0): dy is COMPUTED in the kernel (and written): dy = res0 + LayerNorm_backward(X0 @
     W0^T; x0, stats0) -- the qkv Linear's data gradient of the Swin block behind this one (W0 = planes [C, K0])."""
@@ -979,7 +979,7 @@ SCRATCH = Scratch()
 
 def linear_wgrad(dY, X, dW, db, a_rowscale=None, a_rowscale_rows=1, b_mode=0, ln_stats=None,
                  ln=None):
-    """dW[N,K] = dY[M,N]^T @ pro(X)[M,K]; db = colsum(dY).  ``ln`` =
+    """dW[N,K] = dY[M,N]^T . pro(X)[M,K]; db = colsum(dY).  ``ln`` =
     (W, gamma, beta, dgamma, dbeta) finishes a LayerNorm-folded Linear."""
     _chk(dY, X, dW, db, a_rowscale, ln_stats)
     M, N = dY.shape
