@@ -196,9 +196,13 @@ __global__ void __launch_bounds__(256, 3) k_conv3x3_h16(ConvH16Args p) {
   // with 24 the kernel fits three)
   u32x4 fb0[2], fb1[2], fb2[2];
   const int niter = nkc * 9;
-  auto load_it = [&](int it, u32x4 (&fb)[2]) { load_b(it / 9, it % 9, fb); };
+  // every block walks the nine taps from another start (weight lines spread over the L2: gemm_ntw.hip, round 5)
+  const int rot9 = (int)(((unsigned)blockIdx.x >> 3) % 9u);
+  auto tr9 = [&](int tap) { const int x = tap + rot9; return x >= 9 ? x - 9 : x; };
+  auto load_it = [&](int it, u32x4 (&fb)[2]) { load_b(it / 9, tr9(it % 9), fb); };
   auto mma = [&](const unsigned char* img_r, int tap, const u32x4 (&fb)[2]) {
-    const int toff = ((tap / 3) * 18 + (tap % 3)) * HP;
+    const int tp = tr9(tap), ty3 = (tp * 11) >> 5;          // tp / 3 for tp < 9
+    const int toff = (ty3 * 18 + (tp - 3 * ty3)) * HP;
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const u32x4 fa = *(const u32x4*)(img_r + a_off[i] + toff);

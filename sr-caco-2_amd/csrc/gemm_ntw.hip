@@ -700,9 +700,13 @@ __global__ void __launch_bounds__(256, 2) k_nhcw(NtArgs p) {
     winv[jt] = winv_all[col];
   }
   const int niter = nkc * 9;
+  // every block walks the nine taps from another start (blocks of one XCD -- same blockIdx.x mod 8 -- get different ones):
+  // in lockstep the whole launch would ask the L2 for the same tap's weight lines at the same moment (k_ntw, k_mlp_f16)
+  const int rot9 = p.k_rot ? (int)(((unsigned)blockIdx.x >> 3) % 9u) : 0;
+  auto tr9 = [&](int tap) { const int x = tap + rot9; return x >= 9 ? x - 9 : x; };
   auto load_b = [&](int it, u32x4 (&fb)[3][2]) {          // iterations past the end re-read the last one
     const int itc = min(it, niter - 1);
-    const int kc = itc / 9, tap = itc - kc * 9;
+    const int kc = itc / 9, tap = tr9(itc - kc * 9);
     const char* base = (const char*)p.Wb + ((long)(2 * kc) * wrows + (long)tap * p.N) * 32;
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl)
@@ -720,7 +724,8 @@ __global__ void __launch_bounds__(256, 2) k_nhcw(NtArgs p) {
   for (int i = 0; i < 4; ++i) a_off[i] = (i * 18 + c) * C_PITCH + 16 * g;     // image row i of the tile, pixel c, octet g
 
   auto mma = [&](int tap, const u32x4 (&fb)[3][2]) {
-    const int toff = ((tap / 3) * 18 + (tap % 3)) * C_PITCH;                  // halo shift of the tap
+    const int tp = tr9(tap), ty3 = (tp * 11) >> 5;                            // tp / 3 for tp < 9
+    const int toff = (ty3 * 18 + (tp - 3 * ty3)) * C_PITCH;                      // halo shift of the tap
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       u32x4 fa[2];
@@ -1202,8 +1207,12 @@ __global__ void __launch_bounds__(256, Nhcw2Ring<DEEP>::OCC) k_nhcw2(NtArgs p) {
     winv[jt] = winv_all[col];
   }
   const int niter = nkc * 9;
+  // every block walks the nine taps from another start (blocks of one XCD -- same blockIdx.x mod 8 -- get different ones):
+  // in lockstep the whole launch would ask the L2 for the same tap's weight lines at the same moment (k_ntw, k_mlp_f16)
+  const int rot9 = p.k_rot ? (int)(((unsigned)blockIdx.x >> 3) % 9u) : 0;
+  auto tr9 = [&](int tap) { const int x = tap + rot9; return x >= 9 ? x - 9 : x; };
   auto load_b = [&](int it, u32x4 (&fb)[2][2]) {
-    const int kc = it / 9, tap = it - kc * 9;
+    const int kc = it / 9, tap = tr9(it - kc * 9);
     const char* base = (const char*)p.Wb + ((long)(2 * kc) * wrows + (long)tap * p.N) * 32;
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl)
@@ -1221,7 +1230,8 @@ __global__ void __launch_bounds__(256, Nhcw2Ring<DEEP>::OCC) k_nhcw2(NtArgs p) {
   for (int i = 0; i < RW; ++i) a_off[i] = ((RW * wm + i) * 18 + c) * C_PITCH + 16 * g;
 
   auto mma = [&](int tap, const u32x4 (&fb)[2][2]) {
-    const int toff = ((tap / 3) * 18 + (tap % 3)) * C_PITCH;
+    const int tp = tr9(tap), ty3 = (tp * 11) >> 5;                            // tp / 3 for tp < 9
+    const int toff = (ty3 * 18 + (tp - 3 * ty3)) * C_PITCH;
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       u32x4 fa[2];
@@ -1362,6 +1372,7 @@ int sr_conv3x3_nhcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
   }
   SR_REQUIRE(p.epi != 11 || p.wide_epi, "conv3x3: the GELU epilogue needs Cout %% 8 == 0 and 16-byte aligned rows (Cout=%d)", p.N);
   dim3 grid(p.tiles_x * p.tiles_y * p.batch * sr_cdiv(p.N, p.n_tile));
+  { static const int crot = [] { const char* e = sr_getenv("SRHIP_CONV_ROT"); return e ? atoi(e) : 1; }(); p.k_rot = crot; }
   const bool amp = p.amp != 0;
   const int lds = ntcw2_lds(rows_per_wave) + 64;       // + the four wave maxima behind the (three-plane sized) halo region
   if (rows_per_wave == 4) {
@@ -1379,6 +1390,7 @@ int sr_conv3x3_nhcw2(NtArgs& p, int rows_per_wave, hipStream_t st) {
 
 int sr_conv3x3_nhcw(NtArgs& p, hipStream_t st) {        // as sr_conv3x3_ntcw, weight planes of preparation job kind 4
   dim3 grid(p.tiles_x * p.tiles_y * p.batch, sr_cdiv(p.N, p.n_tile));
+  { static const int crot = [] { const char* e = sr_getenv("SRHIP_CONV_ROT"); return e ? atoi(e) : 1; }(); p.k_rot = crot; }
   if (p.amp) hipLaunchKernelGGL(k_nhcw<true>, grid, dim3(256), NTCW_LDS, st, p);
   else hipLaunchKernelGGL(k_nhcw<false>, grid, dim3(256), NTCW_LDS, st, p);
   SR_LAUNCH_CHECK("k_nhcw");

@@ -110,6 +110,7 @@ struct MlpF16Args {
   // (W0 = planes [C][K0], prep kind 3), written to out0 and used in place of X / R2
   const unsigned short* W0; int K0, Kp0; const float* X0; long ld0;
   const float* x0; long ldx0; const float* stats0; const float* res0; long ldres0; float* out0; long ldo0;
+  int k_rot;                         // 1: every block starts its six-stage K walks at another stage (set by the dispatcher)
   long long* dbg;                    // experiment builds: phase timestamps
   int stagger;                       // experiment builds: start delay of odd blocks (10-ns units)
   int stagger_mode; int* cu_count;   // experiment builds: 1 = delay the block that arrives second on its CU (per-CU arrival counters)
@@ -126,6 +127,7 @@ struct WmsaF16Args {
   float* qkv; float* att; float* out; float* stats_out;   // [T][3C], [T][C], [T][C], [T][2] (may be null)
   int B, H, W, C, heads, shift, Kp;
   float scale;
+  int k_rot;                         // 1: every block starts its K walks at another stage (set by the dispatcher)
   long long* dbg;                    // experiment builds: phase timestamps
   int stagger;                       // experiment builds: start delay of a block's second window (10-ns units)
 };

@@ -129,6 +129,12 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
   const int m0 = sr_xcd_block((int)blockIdx.x, gridDim.x) * BM;
   const int NH = (p.hid + 191) / 192;                // 192-unit halves of the hidden layer (1 or 2)
   const int nst1 = p.Kp1 / SK, nst2 = p.Kp2 / SK;
+  // Every block walks the SAME weight planes; in lockstep all 64 blocks of an XCD ask its L2 for the same few lines at the
+  // same moment.  As k_ntw (gemm_ntw.hip), block b starts every six-stage K walk at stage rot(b) and wraps around (the blocks
+  // of one XCD -- same blockIdx.x mod 8 -- get different rotations): the stage images of a pass are all in LDS before its
+  // products start, so any order serves; sums are f32 either way, only their order differs per row block (deterministic).
+  const int rot = p.k_rot ? (int)(((unsigned)blockIdx.x >> 3) % 6u) : 0;
+  auto rs6 = [&](int s6) { const int x = s6 + rot; return x >= 6 ? x - 6 : x; };      // s6 in 0 .. 5
 
   // ---------------- weight fragment addressing
   const long plane1 = (long)p.N1 * p.Kp1 * 2, plane2 = (long)p.N2 * p.Kp2 * 2;
@@ -148,7 +154,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
   // stage u of GEMM 1 = (half u / 6, k stage u % 6); stages past the weight's K read its last stage (the A planes are
   // zero there, the planes finite: they add exact zeros)
   auto load_b1 = [&](int u, u32x4 (&fb)[3][2]) {
-    const int hh = u / 6, s = min(u - 6 * hh, nst1 - 1);
+    const int hh = u / 6, s = min(rs6(u - 6 * hh), nst1 - 1);
     const char* base = (const char*)p.W1 + (long)(2 * s) * p.N1 * 32;
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl)
@@ -156,7 +162,8 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       for (int jt = 0; jt < 3; ++jt) fb[jt][pl] = *(const u32x4*)(base + pl * plane1 + (hh ? boff1[1][jt] : boff1[0][jt]));
   };
   auto load_b2 = [&](int cs, u32x4 (&fb)[3][2]) {
-    const char* base = (const char*)p.W2 + (long)(2 * min(cs, nst2 - 1)) * p.N2 * 32;
+    const int pass6 = (cs / 6) * 6;
+    const char* base = (const char*)p.W2 + (long)(2 * min(pass6 + rs6(cs - pass6), nst2 - 1)) * p.N2 * 32;
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
@@ -278,7 +285,10 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     const long plane0 = (long)p.C * p.Kp0 * 2;
     const float* const winv0 = (const float*)((const char*)p.W0 + 2 * plane0);
     auto load_b0 = [&](int cs, u32x4 (&fb)[3][2]) {
-      const char* base = (const char*)p.W0 + (long)(2 * min(cs, nst0 - 1)) * p.C * 32;
+      const int pass6 = (cs / 6) * 6, np = min(6, nst0 - pass6);        // a pass of the front product: 6 stages, the last one fewer
+      int x = cs - pass6 + (np > 0 ? rot % np : 0);
+      if (x >= np) x -= np;
+      const char* base = (const char*)p.W0 + (long)(2 * min(pass6 + x, nst0 - 1)) * p.C * 32;
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
@@ -357,8 +367,11 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
             for (int j = 0; j < 3; ++j) acc0[i][j][e] *= f;
           }
       }
+      const int np0 = min(6, nst0 - cs0), rot0 = rot % np0;
       auto mma0 = [&](int s6, const u32x4 (&fb)[3][2]) {
-        const unsigned char* sa = smem + s6 * AST;
+        int x6 = s6 + rot0;
+        if (x6 >= np0) x6 -= np0;
+        const unsigned char* sa = smem + x6 * AST;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           u32x4 fa[2];
@@ -474,7 +487,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc1[hh][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto mma1 = [&](f32x4 (&acc)[4][3], int s6, const u32x4 (&fb)[3][2]) {
-    const unsigned char* sa = smem + s6 * AST;
+    const unsigned char* sa = smem + rs6(s6) * AST;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       u32x4 fa[2];
@@ -630,7 +643,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
     }
   };
   auto mma2 = [&](int s6, const u32x4 (&fb)[3][2]) {
-    const unsigned char* sa = smem + s6 * AST;
+    const unsigned char* sa = smem + rs6(s6) * AST;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       u32x4 fa[2];
@@ -753,7 +766,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
       const long plane3 = (long)p.C * p.Kp1 * 2;
       const float* const winv3 = (const float*)((const char*)p.W3 + 2 * plane3);
       auto load_b3 = [&](int cs, u32x4 (&fb)[3][2]) {
-        const char* base = (const char*)p.W3 + (long)(2 * min(cs, nst1 - 1)) * p.C * 32;
+        const char* base = (const char*)p.W3 + (long)(2 * min(rs6(cs), nst1 - 1)) * p.C * 32;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
@@ -772,7 +785,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       auto mma3 = [&](int s6, const u32x4 (&fb)[3][2]) {
-        const unsigned char* sa = smem + s6 * AST;
+        const unsigned char* sa = smem + rs6(s6) * AST;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           u32x4 fa[2];
@@ -1223,6 +1236,8 @@ int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st) {
   SR_REQUIRE(p.M > 0, "mlp_f16x2: M = %d", p.M);
   SR_REQUIRE(p.ldx % 4 == 0 && p.ldo % 4 == 0 && p.ldh % 4 == 0 && p.ldr % 4 == 0 && (!bwd || p.ldr2 % 4 == 0),
              "mlp_f16x2: row pitches must be multiples of 4 floats");
+  static const int krot = [] { const char* e = sr_getenv("SRHIP_MLP_ROT"); return e ? atoi(e) : 1; }();
+  p.k_rot = krot;
   dim3 grid(sr_cdiv(p.M, BM));
   // two hidden halves, f32-grade: the producer / consumer form (one block per CU, two tiles each)
   static int gr_on = -1;

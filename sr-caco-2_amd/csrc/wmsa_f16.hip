@@ -429,6 +429,11 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
   const int c = lane & 15, g = lane >> 4;
   const int C = p.C, N3 = 3 * C;
   const int nst = p.Kp / SK;
+  // as k_ntw / k_mlp_f16: every block starts its K walks at another stage (blocks of one XCD -- same blockIdx.x mod 8 -- get
+  // different rotations), so that the launch does not ask an L2 for the same weight lines at the same moment; the stage
+  // images are complete before a product starts; f32 sums in another order per block (deterministic)
+  const int rot = p.k_rot ? (int)(((unsigned)blockIdx.x >> 3) % (unsigned)nst) : 0;
+  auto rst = [&](int s) { const int x = s + rot; return s >= nst ? s : (x >= nst ? x - nst : x); };   // stages past the weight's K (zero images) stay
   const int nWx = p.W / 8, nWy = p.H / 8;
   const int win = min(sr_xcd_block((int)blockIdx.x, gridDim.x) * WPB + grp, p.B * nWx * nWy - 1);
   const W2Geom geo = w2_decode((long)win, 1, nWx, nWy, p.shift);
@@ -502,7 +507,7 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
 #pragma unroll
     for (int jt = 0; jt < NJ; ++jt) wofs[jt] = (unsigned)(((g >> 1) * N3 + D * hd + min(16 * jt + c, D - 1)) * 32 + (g & 1) * 16);
     auto load_w = [&](int ct, int s, u32x4 (&fb)[NJ][2]) {
-      const char* base = (const char*)p.Wqkv + (long)(2 * s) * N3 * 32 + (long)ct * C * 32;
+      const char* base = (const char*)p.Wqkv + (long)(2 * rst(s)) * N3 * 32 + (long)ct * C * 32;
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
@@ -517,7 +522,7 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       u32x4 fA[NJ][2], fB[NJ][2];
       auto mma = [&](int s, const u32x4 (&fb)[NJ][2]) {
-        const unsigned char* sa = smem + s * AST;
+        const unsigned char* sa = smem + rst(s) * AST;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           u32x4 fa[2];
@@ -768,7 +773,7 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
   }
   u32x4 fb0[NJ][2], fb1[NJ][2], fb2[NJ][2];
   auto load_bp = [&](int s, u32x4 (&fb)[NJ][2]) {
-    const char* base = (const char*)p.Wproj + (long)(2 * min(s, nst - 1)) * C * 32;
+    const char* base = (const char*)p.Wproj + (long)(2 * rst(min(s, nst - 1))) * C * 32;
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
@@ -790,7 +795,7 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto mma2 = [&](int s6, const u32x4 (&fb)[NJ][2]) {
-    const unsigned char* sa = smem + s6 * AST;
+    const unsigned char* sa = smem + rst(s6) * AST;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       u32x4 fa[2];
@@ -917,6 +922,7 @@ int sr_wmsa_f16(WmsaF16Args& p, hipStream_t st) {
   { const char* e = sr_getenv("SRHIP_WMSA_STAGGER"); p.stagger = e ? atoi(e) : 0; }
 #endif
   p.scale = 1.0f / sqrtf((float)D);
+  { static const int krot = [] { const char* e = sr_getenv("SRHIP_WMSA_ROT"); return e ? atoi(e) : 1; }(); p.k_rot = krot; }
   const int nwin = p.B * (p.H / 8) * (p.W / 8);
   bool six = p.heads == 5 || p.heads == 6;
   const bool amp = sr_matmul_mode() == 1;          // inference under --amp (5 / 6 heads: one product of the leading planes)

@@ -57,7 +57,10 @@ def test_conv_pixelshuffle_fused_forward_backward(ops, B, H, W, Cin, Fo):
     c = ops.conv3x3(xn, wp0, bc, Co)
     y0 = torch.empty_like(y)
     ops.pixel_shuffle(c, 2, nhwc_out=True, out=y0)
-    assert torch.equal(y, y0)                     # same products in the same order, stored elsewhere
+    # the same products, stored elsewhere -- in the same order until round 5; since then a block starts its nine-tap walk at a
+    # tap that depends on its index in the launch (weight lines spread over the L2, gemm_ntw.hip), and the two launches number
+    # their blocks differently: rounding-level difference
+    assert (y - y0).abs().max().item() <= 2e-6 * y0.abs().max().item()
     # relu epilogue rides along
     yr = torch.empty_like(y)
     ops.conv3x3_ps2(xn, wp, bc, yr, epi=1)
