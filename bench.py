@@ -49,7 +49,9 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=8, help="patches per GPU (README --batch_size 8)")
     ap.add_argument("--loss", default="l1", choices=["l1", "l2ssim"])
     ap.add_argument("--optimizer", default=None, choices=["sgd", "adam"])
-    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (TrainStep.step_graph; 1 GPU)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (TrainStep.step_graph) also under data "
+                    "parallelism; on ONE GPU that is the default since round 5 (what ModelPlain.optimize_parameters does)")
+    ap.add_argument("--no-graph", action="store_true", help="eager steps only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the EDSR x8 / x4 / x2 lines under config.secondary")
@@ -460,16 +462,28 @@ def worker(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = args.graph            # data-parallel runs too: the RCCL bucket all-reduces are captured with the step
-    step_fn = ts.step_graph if use_graph else ts.step
+    # The step replayed from a hipGraph (bit for bit the eager step; one host call instead of ~330 launches): the default on
+    # one GPU since round 5 -- the product entry point (ModelPlain.optimize_parameters) does the same; --graph asks for it
+    # under data parallelism too (the RCCL bucket all-reduces are captured with the step), --no-graph for eager steps.  The
+    # one step in twenty that carries the roofline's per-launch HIP events runs eagerly (events cannot be recorded inside a
+    # replay); a capture that fails falls back to eager steps for the whole run.
+    use_graph = (args.graph or world == 1) and not args.no_graph
     gpu_legs = {}                     # wall seconds of every leg that keeps the GPU busy (synchronize-bracketed)
     t_leg = time.perf_counter()
-    for _ in range(max(args.warmup, 2 if use_graph else 0)):   # graph: eager step, capture, then replays
-        step_fn(lr_img, hr_img)
+    if use_graph:
+        try:
+            for _ in range(max(args.warmup, 3)):             # eager step, capture, then replays
+                ts.step_graph(lr_img, hr_img)
+        except Exception as e:        # noqa: BLE001  (capture not possible here: say so and time eager steps)
+            print(f"[bench] hipGraph capture failed ({str(e).splitlines()[0][:160]}): eager steps", file=sys.stderr, flush=True)
+            ts._graph = None
+            use_graph = False
+    if not use_graph:
+        for _ in range(args.warmup):
+            ts.step(lr_img, hr_img)
+    step_fn = ts.step_graph if use_graph else ts.step
     barrier()
     gpu_legs["warmup"] = time.perf_counter() - t_leg
-    if use_graph:
-        args.no_roofline = True          # per-launch HIP events cannot be recorded inside a replayed graph
     if not args.no_roofline:
         probe.enable(kinds)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -478,9 +492,10 @@ def worker(args):
         # HIP events around every launch of the probed op classes in ONE of every twenty steps (an
         # event pair is two barrier packets: a probed step runs ~18 % slower, so probing all of
         # them would cost the headline number), taken mid-run
-        probe.active = set(kinds) if (not args.no_roofline and i % 20 == 10 % max(args.steps, 1)) else None
+        probed = not args.no_roofline and i % 20 == 10 % max(args.steps, 1)
+        probe.active = set(kinds) if probed else None
         marks[i].record()
-        step_fn(lr_img, hr_img)
+        (ts.step if probed else step_fn)(lr_img, hr_img)
     marks[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
