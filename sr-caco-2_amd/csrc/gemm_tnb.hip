@@ -517,11 +517,29 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
       }
     }
   };
+  // The same for a chunk that lies entirely inside the slice, WITHOUT a branch around any load: the compiler's s_waitcnt
+  // placement keeps the order of the loads in flight only along straight-line code -- behind a join (interior / ragged,
+  // operand A / B) it assumed every stage register could have been loaded last, and each store() began with vmcnt(1):
+  // it waited for the loads issued just before the barrier, the two-stage prefetch never overlapped anything.  The main
+  // loop and its preheader use this form only; the generic one serves the last chunks of a slice.
+  auto load_i = [&](int mc, Stage& sg) __attribute__((always_inline)) {
+    const int tokl = mc + (lane & 31);
+    if (BM < 0 || AR) sg.scale = ldg_f((!isB && arow) ? p.a_rowscale + tokl / p.a_rowscale_rows : k_sr_neutral + 1);
+    if (BM < 0 || BM == 1) sg.stats = ldg_f2((isB && bmode == 1) ? p.ln_stats + 2 * (long)tokl : k_sr_neutral);
+    const float* q = opP + (long)mc * opLd;     // uniform, advanced per token
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(q, colb);
+      q += opLd;
+    }
+  };
   auto bcast = [&](float v, int k) __attribute__((always_inline)) -> float {   // scalar of token 16 th + k of the chunk
     const int lo = __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k);
     const int hi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 + k);
     return __builtin_bit_cast(float, th ? hi : lo);
   };
+  // (Experiment, dropped: the next chunk's loads issued in the MIDDLE of store(), right after the values have left the stage
+  // registers -- 525 -> 548-561 us per launch on the README net, as the same move in tnb_body / tnb_body3: 1-2.5 % of the step.)
   auto store = [&](unsigned char* buf, const Stage& sg) {
     sr_f32x2 x[2][4][W];
 #pragma unroll
@@ -639,12 +657,30 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
   const int nch = ((m_end - m_begin + 2 * TKB - 1) / (2 * TKB)) * 2;
   if (producer) {
     __builtin_amdgcn_s_setprio(2);                    // the staging waves are the critical path of a chunk: issue before the MFMA waves
-    load(m_begin, sg0);
-    load(m_begin + TKB, sg1);
-    store(smem, sg0);
-    load(m_begin + 2 * TKB, sg0);
-    __syncthreads();
-    for (int c = 0; c < nch; c += 2) {
+    const int n_int = (m_end - m_begin) / TKB;     // chunks that lie entirely inside the slice
+    int c = 0;
+    if (n_int >= 5) {                              // (uniform) straight-line loads from the first one on
+      load_i(m_begin, sg0);
+      load_i(m_begin + TKB, sg1);
+      store(smem, sg0);
+      load_i(m_begin + 2 * TKB, sg0);
+      __syncthreads();
+      for (; c + 4 < n_int; c += 2) {              // the loads of chunks c + 3, c + 4: interior
+        store(smem + BUF, sg1);
+        load_i(m_begin + (c + 3) * TKB, sg1);
+        __syncthreads();
+        store(smem, sg0);
+        load_i(m_begin + (c + 4) * TKB, sg0);
+        __syncthreads();
+      }
+    } else {
+      load(m_begin, sg0);
+      load(m_begin + TKB, sg1);
+      store(smem, sg0);
+      load(m_begin + 2 * TKB, sg0);
+      __syncthreads();
+    }
+    for (; c < nch; c += 2) {
       store(smem + BUF, sg1);
       load(m_begin + (c + 3) * TKB, sg1);
       __syncthreads();

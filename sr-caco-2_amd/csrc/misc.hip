@@ -209,8 +209,11 @@ struct ReduceGroup {
   } p[24];              // = TNB_GROUP_MAX of gemm_tnb.hip
   int n, S;
 };
+// a block: RG_ROWS rows x 64 columns of one problem (four rows per pass); the 24-way problem select from the kernel
+// arguments is paid once per 1024 elements (at 4 rows per block it cost more than the sums)
+constexpr int RG_ROWS = 16;
 __global__ void __launch_bounds__(256) k_reduce_group(ReduceGroup g) {
-  __shared__ float sd[4], sg[4][64], sb[4][64];
+  __shared__ float sd[RG_ROWS], sg[4][64], sb[4][64];
   // select with constant indices (a runtime-indexed struct array would go to scratch)
   ReduceGroup::P P = g.p[0];
 #pragma unroll
@@ -221,37 +224,49 @@ __global__ void __launch_bounds__(256) k_reduce_group(ReduceGroup g) {
   const int bx = lb % P.kblocks, by = lb / P.kblocks;
   const int c = threadIdx.x & 63, rr = threadIdx.x >> 6;
   const int k = bx * 64 + c;
-  const int n = by * 4 + rr;
-  if (c == 0) {   // one lane per row sums that row's bias-gradient slices
+  if (threadIdx.x < RG_ROWS) {   // one lane per row sums that row's bias-gradient slices
+    const int n = by * RG_ROWS + threadIdx.x;
     float d = 0.f;
     if (n < N)
       for (int s = 0; s < S; ++s) d += P.colsum[(long)s * N + n];
-    sd[rr] = d;
+    sd[threadIdx.x] = d;
     if (n < N && bx == 0) P.db[n] = d;
   }
   __syncthreads();
   float ag = 0.f, ab = 0.f;
-  if (k < K && n < N) {
-    const long sl = (long)N * K;
-    const float* pp = P.part + (long)n * K + k;
-    float G = 0.f;
-    int s = 0;
-    for (; s + 8 <= S; s += 8) {
-      float v[8];
+  const long sl = (long)N * K;
+  const float gk = (P.gamma && k < K) ? P.gamma[k] : 0.f, bk = (P.gamma && k < K) ? P.beta[k] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = pp[(s + u) * sl];
+  for (int pass = 0; pass < RG_ROWS / 4; ++pass) {
+    const int n = by * RG_ROWS + pass * 4 + rr;
+    if (k < K && n < N) {
+      const float* pp = P.part + (long)n * K + k;
+      float G = 0.f;
+      int s = 0;
+      for (; s + 8 <= S; s += 8) {
+        float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) G += v[u];
-    }
-    for (; s < S; ++s) G += pp[s * sl];
-    if (P.gamma) {
-      const float d = sd[rr];
-      const float w = P.W[(long)n * K + k];
-      P.dW[(long)n * K + k] = P.gamma[k] * G + P.beta[k] * d;
-      ag = w * G;
-      ab = w * d;
-    } else {
-      P.dW[(long)n * K + k] = G;
+        for (int u = 0; u < 8; ++u) v[u] = pp[(s + u) * sl];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) G += v[u];
+      }
+      for (; s + 4 <= S; s += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = pp[(s + u) * sl];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) G += v[u];
+      }
+      for (; s < S; ++s) G += pp[s * sl];
+      if (P.gamma) {
+        const float d = sd[pass * 4 + rr];
+        const float w = P.W[(long)n * K + k];
+        P.dW[(long)n * K + k] = gk * G + bk * d;
+        ag += w * G;
+        ab += w * d;
+      } else {
+        P.dW[(long)n * K + k] = G;
+      }
     }
   }
   if (P.gamma) {          // block-uniform
@@ -272,7 +287,7 @@ __global__ void __launch_bounds__(256) k_ln_affine_finish_group(ReduceGroup g) {
   for (int i = 0; i < 24; ++i)
     if (i < g.n && g.p[i].gamma && (int)blockIdx.x >= g.p[i].fblk0) { P = g.p[i]; found = true; }
   if (!found) return;
-  ln_affine_finish_one(P.lnws, (P.N + 3) / 4, P.K, P.dgamma, P.dbeta, ((int)blockIdx.x - P.fblk0) * 256 + threadIdx.x);
+  ln_affine_finish_one(P.lnws, (P.N + RG_ROWS - 1) / RG_ROWS, P.K, P.dgamma, P.dbeta, ((int)blockIdx.x - P.fblk0) * 256 + threadIdx.x);
 }
 __global__ void k_reduce_colsum(const float* __restrict__ colsum, float* __restrict__ db,
                                 int N, int S) {
@@ -815,7 +830,7 @@ int srhip_reduce_wgrad_grouped(const srhip_reduce_problem* probs, int nprob, int
     d.part = q.part; d.colsum = q.colsum; d.W = q.W; d.gamma = q.gamma; d.beta = q.beta;
     d.dW = q.dW; d.db = q.db; d.dgamma = q.dgamma; d.dbeta = q.dbeta; d.N = q.N; d.K = q.K;
     d.blk0 = blocks; d.kblocks = sr_cdiv(q.K, 64);
-    blocks += d.kblocks * sr_cdiv(q.N, 4);
+    blocks += d.kblocks * sr_cdiv(q.N, RG_ROWS);
   }
   hipLaunchKernelGGL(k_reduce_group, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
   if (fblocks) hipLaunchKernelGGL(k_ln_affine_finish_group, dim3(fblocks), dim3(256), 0, (hipStream_t)stream, g);

@@ -116,6 +116,18 @@ __device__ __forceinline__ void job_planes_f16(const PrepEntry& e, int lb) {
   const int Kp = sr_kp(e.n2);
   const int rows = e.n0;
   const int row = lb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // a transposed source (s2 != 1: the block's four rows are four CONSECUTIVE floats of every source line): the block
+  // gathers its 4 x n2 values through LDS with 16 bytes of each line per 4 lanes, instead of 64 lines per load
+  // instruction and wave (the texture path, one line per clock, was the bound: 39 us for SwinIR's 96 transposed jobs)
+  __shared__ float tile[4][1024 + 4];
+  const bool staged = e.s2 != 1 && e.s1 == 1;        // block-uniform
+  if (staged) {
+    const int r = threadIdx.x & 3, row_r = lb * 4 + r;
+    if (row_r < rows)
+      for (int k = threadIdx.x >> 2; k < e.n2; k += 64)
+        tile[r][k] = ldg_f(e.a + (long)e.off + (long)row_r + (long)k * e.s2);
+    __syncthreads();
+  }
   if (row >= rows) return;
   const int gm = e.mode & 3;
   constexpr int MAXJ = 4;                            // 4 x 256 k per row
@@ -128,7 +140,7 @@ __device__ __forceinline__ void job_planes_f16(const PrepEntry& e, int lb) {
       const int k = j * 256 + lane * 4 + q;
       float x = 0.f;
       if (k < e.n2) {
-        x = ldg_f(e.a + (long)e.off + (long)row * e.s1 + (long)k * e.s2);
+        x = staged ? tile[threadIdx.x >> 6][k] : ldg_f(e.a + (long)e.off + (long)row * e.s1 + (long)k * e.s2);
         if (gm == 1) x *= ldg_f(e.b + k);
         else if (gm == 2) x *= ldg_f(e.b + row);
       }
@@ -223,11 +235,18 @@ __device__ __forceinline__ void job_conv_planes_f16(const PrepEntry& e, int lb) 
 }
 
 __global__ void __launch_bounds__(256) k_prep_table(const PrepEntry* __restrict__ tab, int n) {
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  // block -> job: the number of jobs that start at or before this block (blk0 ascending), counted by the whole block with
+  // independent loads -- ONE memory round trip where a binary search over the table chained log2(n) of them (the search
+  // was most of a block's lifetime: 33 us for the 96 forward Linear jobs of SwinIR, whose data moves in 10)
+  __shared__ int s_cnt[4];
+  int cnt = 0;
+  for (int i = threadIdx.x; i < n + (int)threadIdx.x; i += 256) {       // trip count uniform over the wave
+    const bool in = i < n && tab[i].blk0 <= (int)blockIdx.x;
+    cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
   }
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  const int lo = __builtin_amdgcn_readfirstlane((s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3])) - 1;
   const PrepEntry e = tab[lo];
   const int lb = blockIdx.x - e.blk0;
   if (e.kind == 0) job_planes(e, lb);

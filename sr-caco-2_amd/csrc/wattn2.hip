@@ -446,23 +446,35 @@ __global__ void __launch_bounds__(256, W3_OCC) k_wattn3_bwd(const float* __restr
 // (blockIdx.y = attention block of a batched call: its partials at part + y * part_stride, its image at dimg + y * img_stride)
 __global__ void __launch_bounds__(256) k_dbias2_reduce(const float* __restrict__ part, int nparts, int heads,
                                                        float* __restrict__ dimg, long part_stride, long img_stride) {
-  const int o = blockIdx.x * 256 + threadIdx.x;
-  if (o >= heads * 4096) return;
+  // block = (head, a, b, q >> 2): 64 lanes x the 4 registers q & 3, which are 4 CONSECUTIVE floats of a partial tile
+  // (key & 3 == q & 3): one 16-byte load per partial; the partials dealt to the block's 4 waves, joined through LDS
+  __shared__ double sm[4][64][4];
+  const int ln = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int hd = blockIdx.x >> 4, a = (blockIdx.x >> 3) & 1, b = (blockIdx.x >> 2) & 1, qh = blockIdx.x & 3;
   part += (long)blockIdx.y * part_stride;
   dimg += (long)blockIdx.y * img_stride;
-  const int hd = o >> 12, el = o & 4095;
-  const int ln = el & 63, q = (el >> 6) & 15, b = (el >> 10) & 1, a = el >> 11;
-  const int key = mfma_row(q, ln) + 32 * a, query = (ln & 31) + 32 * b;
-  const int mine = w2_img_index(query >> 4, key >> 4, 16 * ((key >> 2) & 3) + (query & 15)) + (key & 3);
+  const int key = mfma_row(4 * qh, ln) + 32 * a, query = (ln & 31) + 32 * b;
+  const int mine = w2_img_index(query >> 4, key >> 4, 16 * ((key >> 2) & 3) + (query & 15));
   const float* p = part + (long)hd * W2_DS + mine;
+  const long ps = (long)heads * W2_DS;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int i = 0;
-  for (; i + 4 <= nparts; i += 4) {
-    s0 += (double)p[(long)(i + 0) * heads * W2_DS]; s1 += (double)p[(long)(i + 1) * heads * W2_DS];
-    s2 += (double)p[(long)(i + 2) * heads * W2_DS]; s3 += (double)p[(long)(i + 3) * heads * W2_DS];
+  int i = pg;
+  for (; i + 28 < nparts; i += 32) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(p + (long)(i + 4 * u) * ps);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s0 += (double)v[u][0]; s1 += (double)v[u][1]; s2 += (double)v[u][2]; s3 += (double)v[u][3]; }
   }
-  for (; i < nparts; ++i) s0 += (double)p[(long)i * heads * W2_DS];
-  dimg[o] = (float)((s0 + s1) + (s2 + s3));
+  for (; i < nparts; i += 4) {
+    const f32x4 v = *(const f32x4*)(p + (long)i * ps);
+    s0 += (double)v[0]; s1 += (double)v[1]; s2 += (double)v[2]; s3 += (double)v[3];
+  }
+  sm[pg][ln][0] = s0; sm[pg][ln][1] = s1; sm[pg][ln][2] = s2; sm[pg][ln][3] = s3;
+  __syncthreads();
+  // wave pg writes register q = 4 qh + pg of the 64 lanes: one 256-byte row of the image
+  const double t = (sm[0][ln][pg] + sm[1][ln][pg]) + (sm[2][ln][pg] + sm[3][ln][pg]);
+  dimg[(long)hd * 4096 + ((a * 2 + b) * 16 + 4 * qh + pg) * 64 + ln] = (float)t;
 }
 
 // bias table (225, heads) -> images in the accumulator orders of k_wattn2_*:
@@ -554,7 +566,7 @@ int srhip_window_attention_bwd_f16x2(const float* qkv, const float* dout, float*
   SR_WA(30) SR_WA(10) SR_WA(16) SR_WA(32)
 #undef SR_WA
   if (dbiasT)
-    hipLaunchKernelGGL(k_dbias2_reduce, dim3(sr_cdiv(heads * 4096, 256)), dim3(256), 0, st, part, nparts, heads, dbiasT, 0L, 0L);
+    hipLaunchKernelGGL(k_dbias2_reduce, dim3(heads * 16), dim3(256), 0, st, part, nparts, heads, dbiasT, 0L, 0L);
   SR_LAUNCH_CHECK("window_attention_bwd_f16x2");
   return 0;
 }
@@ -565,7 +577,7 @@ int srhip_window_attention_dbias_reduce_f16x2(const float* workspace, long ws_st
                                               long img_stride, int B, int H, int W, int heads, void* stream) {
   SR_REQUIRE(workspace && dbiasT && nblocks > 0 && nblocks <= 65535, "window_attention_dbias_reduce_f16x2: bad arguments");
   const int nparts = sr_cdiv(B * (H / 8) * (W / 8), 4);
-  hipLaunchKernelGGL(k_dbias2_reduce, dim3(sr_cdiv(heads * 4096, 256), nblocks), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_dbias2_reduce, dim3(heads * 16, nblocks), dim3(256), 0, (hipStream_t)stream,
                      workspace, nparts, heads, dbiasT, ws_stride, img_stride);
   SR_LAUNCH_CHECK("window_attention_dbias_reduce_f16x2");
   return 0;
