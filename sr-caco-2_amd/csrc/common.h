@@ -35,7 +35,7 @@ static inline int sr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // branch join (s_waitcnt vmcnt(0) in the middle of a prefetch); selecting the
 // ADDRESS instead keeps the load unconditional and the prefetch asynchronous.
 //   [0..1] = {mean 0, rstd 1}   [2..3] = {0, 0}   [1] = scale 1
-__device__ const float k_sr_neutral[4] = {0.f, 1.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) const float k_sr_neutral[4] = {0.f, 1.f, 0.f, 0.f};
 
 // Loads through a pointer the compiler cannot prove global (a select between a
 // kernel-argument pointer and a __device__ constant, a pointer read from a struct

@@ -538,8 +538,14 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
     const int hi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 + k);
     return __builtin_bit_cast(float, th ? hi : lo);
   };
-  // (Experiment, dropped: the next chunk's loads issued in the MIDDLE of store(), right after the values have left the stage
-  // registers -- 525 -> 548-561 us per launch on the README net, as the same move in tnb_body / tnb_body3: 1-2.5 % of the step.)
+  // (Experiments, dropped.  The next chunk's loads issued in the MIDDLE of store(), right after the values have left the stage
+  // registers, so that they fly under 1.6 store() periods: with the exact waits of load_i 460-473 -> 536-540 us per launch on
+  // the README net -- the data then returns into the register file while the producer is busiest; issued at the end of
+  // store() it returns while the wave sits at the barrier.  The same move in tnb_body / tnb_body3: 1-2.5 % of the step lost.
+  // THREE register stages over the two LDS buffers (a load gets almost three chunk periods): the LayerNorm instantiation
+  // needs more than the 256 registers two waves per SIMD leave -- 169 spills, and scratch traffic shares vmcnt with the
+  // prefetch.  The launch WITHOUT any operand prologue (no LayerNorm / DropPath arithmetic: wrong results, same accesses):
+  // 465 us against 465 -- the staging arithmetic is not the bound, the reads are (1.74 GB per launch at 3.7-3.9 TB/s).)
   auto store = [&](unsigned char* buf, const Stage& sg) {
     sr_f32x2 x[2][4][W];
 #pragma unroll
