@@ -42,6 +42,27 @@ __global__ void k_reduce_slices(const float* __restrict__ part, float* __restric
 }
 // conv: part [S][9][Co][Ci] -> dW torch layout [Co][Ci][3][3]
 // (the bias gradient, sum_s colsum[s][co], rides in the last block)
+// dw[cc][tap] = sum over the S slices of part[s][tap][cc] (cc = co * Ci + ci).  Threads walk the partial sums in THEIR
+// order -- consecutive lanes read consecutive floats of a slice, four slices in flight; the transposition to the torch
+// weight layout happens on the write, 1 / S of the traffic.  (Walking dw's order instead made neighbouring lanes read nine
+// different tap planes: 13 us for the 33 MB of a 180 x 180 conv at 28 slices.)
+__device__ __forceinline__ void reduce_conv_slices(const float* __restrict__ part, float* __restrict__ dw, int Co, int Ci,
+                                                   int S, int main_blocks) {
+  const long cc_n = (long)Co * Ci, n = cc_n * 9;
+  for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < n; j += (long)main_blocks * blockDim.x) {
+    const int tap = (int)(j / cc_n);
+    const long cc = j - tap * cc_n;
+    const float* q = part + j;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 4 <= S; s += 4) {
+      a0 += q[(long)(s + 0) * n]; a1 += q[(long)(s + 1) * n];
+      a2 += q[(long)(s + 2) * n]; a3 += q[(long)(s + 3) * n];
+    }
+    for (; s < S; ++s) a0 += q[(long)s * n];
+    dw[cc * 9 + tap] = (a0 + a1) + (a2 + a3);
+  }
+}
 __global__ void k_reduce_conv_w(const float* __restrict__ part, float* __restrict__ dw,
                                 int Co, int Ci, int S, const float* __restrict__ colsum,
                                 float* __restrict__ db, int main_blocks) {
@@ -53,15 +74,7 @@ __global__ void k_reduce_conv_w(const float* __restrict__ part, float* __restric
     }
     return;
   }
-  const long n = (long)Co * Ci * 9;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
-       i += (long)main_blocks * blockDim.x) {
-    const int tap = i % 9;
-    const long cc = i / 9;  // co*Ci + ci
-    float a = 0.f;
-    for (int s = 0; s < S; ++s) a += part[((long)s * 9 + tap) * Co * Ci + cc];
-    dw[i] = a;
-  }
+  reduce_conv_slices(part, dw, Co, Ci, S, main_blocks);
 }
 // the same for n problems of one shape (blockIdx.y = problem; partial buffers part_stride /
 // colsum_stride floats apart)
@@ -86,15 +99,7 @@ __global__ void k_reduce_conv_w_batched(const float* __restrict__ part, long par
     }
     return;
   }
-  const long n = (long)Co * Ci * 9;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
-       i += (long)main_blocks * blockDim.x) {
-    const int tap = i % 9;
-    const long cc = i / 9;
-    float a = 0.f;
-    for (int s = 0; s < S; ++s) a += part[((long)s * 9 + tap) * Co * Ci + cc];
-    dw[i] = a;
-  }
+  reduce_conv_slices(part, dw, Co, Ci, S, main_blocks);
 }
 // Linear fed by a folded LayerNorm (W_f = W*gamma, b_f = b + W.beta):
 //   G = sum_s part, dbv = sum_s colsum
