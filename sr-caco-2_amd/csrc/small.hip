@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) k_conv_cin1_fwd(const float* __restrict__
     }
   }
 }
-// part[wave][co][10]: dw[co][t] = sum_p dy[p][co]*x[p+t] (t<9), db[co] (t=9)
+// part[block][co][10]: dw[co][t] = sum_p dy[p][co]*x[p+t] (t<9), db[co] (t=9)
 __global__ void __launch_bounds__(256) k_conv_cin1_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                          float* __restrict__ part, int B, int H, int W, int Co,
                                                          long lddy) {
@@ -144,16 +144,28 @@ __global__ void __launch_bounds__(256) k_conv_cin1_wgrad(const float* __restrict
       gp += (long)PF * lddy;
     }
   }
+  // the block's four waves join their sums in LDS (wave after wave: the same bits every run) and leave ONE partial row:
+  // the finisher, whose reads are a gather (one line per value), walks a quarter of the rows
+  __shared__ float red[64 * CO_PER_LANE * 10];
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
 #pragma unroll
-  for (int i = 0; i < CO_PER_LANE; ++i) {
-    const int co = lane + 64 * i;
-    if (co < Co) {
+      for (int i = 0; i < CO_PER_LANE; ++i) {
+        const int co = lane + 64 * i;
+        if (co < Co) {
 #pragma unroll
-      for (int t = 0; t < 10; ++t) part[(wave * Co + co) * 10 + t] = acc[i][t];
+          for (int t = 0; t < 10; ++t) {
+            const float v = (w ? red[co * 10 + t] : 0.f) + acc[i][t];
+            if (w < 3) red[co * 10 + t] = v;
+            else part[((long)blockIdx.x * Co + co) * 10 + t] = v;
+          }
+        }
+      }
     }
+    if (w < 3) __syncthreads();
   }
 }
-// dw[co][t] = sum_waves part (flip: written to 8-t), db[co]; one wave per output
+// dw[co][t] = sum_blocks part (flip: written to 8-t), db[co]; one wave per output
 __global__ void k_conv_cin1_wgrad_fin(const float* __restrict__ part, float* __restrict__ dw,
                                       float* __restrict__ db, int Co, int nwave, int flip) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -363,7 +375,7 @@ int srhip_conv3x3_cin1_fwd(const float* x, const float* w, const float* bias, fl
   return 0;
 }
 
-long srhip_conv3x3_cin1_wgrad_ws(int Co) { return 8192L * Co * 10; }  // floats: [waves][Co][10]
+long srhip_conv3x3_cin1_wgrad_ws(int Co) { return 8192L * Co * 10; }  // floats: [blocks][Co][10] (2048 blocks at most: a bound)
 
 int srhip_conv3x3_cin1_wgrad(const float* x, const float* dy, long lddy, float* dw, float* db,
                              float* workspace, int B, int H, int W, int Co, int flip, void* stream) {
@@ -376,7 +388,7 @@ int srhip_conv3x3_cin1_wgrad(const float* x, const float* dy, long lddy, float* 
   hipLaunchKernelGGL(k_conv_cin1_wgrad, dim3(blocks), dim3(256), 0, st, x, dy, workspace, B, H, W, Co,
                      lddy);
   hipLaunchKernelGGL(k_conv_cin1_wgrad_fin, dim3(sr_cdiv(Co * 10, 4)), dim3(256), 0, st, workspace,
-                     dw, db, Co, blocks * 4, flip);
+                     dw, db, Co, blocks, flip);
   SR_LAUNCH_CHECK("conv_cin1_wgrad");
   return 0;
 }
