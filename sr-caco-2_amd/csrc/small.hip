@@ -182,73 +182,92 @@ __global__ void k_conv_cin1_wgrad_fin(const float* __restrict__ part, float* __r
 }
 // Cout = 1: y[p] = b + sum_t sum_ci x[p+t][ci] * w[ci][t]   (x NHWC, Ci <= 256, Ci % 4 == 0)
 // tail conv of the EDSR wiring, network_nlsn.py:347-350.
-// Block = 16 x 16 output pixels, one per thread.  The 18 x 18 halo goes through LDS in
-// chunks of 16 channels (pixel pitch 20 floats: conflict-free ds_read_b128), the
-// weights as [tap][channel] so a thread reads 4 channels of a tap with one broadcast
-// b128: every input value is fetched from HBM once (plus the halo) instead of 9 times.
-constexpr int C1_CH = 16, C1_PIT = 20, C1_Q = C1_CH / 4;     // (32-channel chunks, pitch 36: 249 us against 154 -- two blocks per CU)
-__global__ void __launch_bounds__(256) k_conv_cout1_fwd(const float* __restrict__ x, const float* __restrict__ w,
+// Block = 128 threads, 16 x 32 output pixels, FOUR per thread (a vertical strip of 4).  The 34 x 18 halo goes through LDS in
+// chunks of 16 channels (pixel pitch 20 floats: conflict-free ds_read_b128; 8-channel chunks fetch half sectors: 327 us),
+// the weights straight from the kernel argument with uniform addresses (scalar loads into SGPRs, no LDS, no VGPRs): every
+// input value is fetched from HBM once (plus the halo).  A strip reads 6 rows x 3 columns of halo vectors and 9 weight
+// vectors per 4 channels -- 27 LDS reads for 4 pixels; with one pixel per thread (18 per pixel) the LDS carried 9.7 GB
+// for the 537 MB of an 8 x 512 x 512 x 64 input and bounded the kernel (182 us, 2.9 TB/s).
+constexpr int C1_CH = 16, C1_PIT = 20, C1_Q = C1_CH / 4;
+constexpr int C1_TW = 16, C1_TH = 32, C1_HC = C1_TW + 2, C1_HR = C1_TH + 2;
+__global__ void __launch_bounds__(128, 2) k_conv_cout1_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                         int B, int H, int W, int Ci, long ldx) {
-  __shared__ __attribute__((aligned(16))) float xs[18 * 18 * C1_PIT];
-  __shared__ __attribute__((aligned(16))) float ws[9 * 64 * CO_PER_LANE];     // [tap][Ci padded to 16]
+  __shared__ __attribute__((aligned(16))) float xs[C1_HR * C1_HC * C1_PIT];
   const int tid = threadIdx.x;
   const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
-  const int cip = (Ci + C1_CH - 1) / C1_CH * C1_CH;
-  for (int i = tid; i < 9 * cip; i += 256) {
-    const int t = i / cip, c = i - t * cip;
-    ws[i] = c < Ci ? w[c * 9 + t] : 0.f;
-  }
-  const int px = tid & 15, py = tid >> 4;
-  float acc = 0.f;
+  const int px = tid & 15, pr = tid >> 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   // the chunk's halo values wait in registers while the previous chunk is consumed: the global loads of chunk k+1
-  // overlap the 144 FMAs per thread of chunk k (was: load -> LDS -> compute in series, 2.8 TB/s)
-  constexpr int NV = (18 * 18 * C1_Q + 255) / 256;
-  const float* src[NV];
-  bool inb[NV];
+  // overlap the FMAs of chunk k
+  constexpr int NI = C1_HR * C1_HC * C1_Q;
+  constexpr int NV = (NI + 127) / 128;
+  unsigned src[NV];                  // offsets from x in 16-byte units (ldx % 4 == 0)
+  unsigned inb = 0;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int i = min(tid + k * 256, 18 * 18 * C1_Q - 1);
+    const int i = min(tid + k * 128, NI - 1);
     const int hp = i / C1_Q, c4 = i % C1_Q;
-    const int hy = hp / 18, hx = hp - hy * 18;
-    const int sy = ty * 16 + hy - 1, sx = tx * 16 + hx - 1;
-    inb[k] = sy >= 0 && sy < H && sx >= 0 && sx < W;
-    src[k] = x + (((long)b * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 1)) * ldx + c4 * 4;
+    const int hy = hp / C1_HC, hx = hp - hy * C1_HC;
+    const int sy = ty * C1_TH + hy - 1, sx = tx * C1_TW + hx - 1;
+    if (sy >= 0 && sy < H && sx >= 0 && sx < W) inb |= 1u << k;
+    src[k] = (unsigned)(((((long)b * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 1)) * ldx + c4 * 4) >> 2);
   }
   f32x4 v[NV];
   auto fetch = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      const int c4 = min(tid + k * 256, 18 * 18 * C1_Q - 1) % C1_Q;
-      const bool ok = inb[k] && c0 + c4 * 4 < Ci;
-      v[k] = *(const f32x4*)(ok ? src[k] + c0 : x);
+      const int c4 = min(tid + k * 128, NI - 1) % C1_Q;
+      const bool ok = ((inb >> k) & 1u) && c0 + c4 * 4 < Ci;
+      v[k] = *(const f32x4*)(ok ? x + (long)src[k] * 4 + c0 : x);
       if (!ok) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   fetch(0);
   for (int c0 = 0; c0 < Ci; c0 += C1_CH) {
-    __syncthreads();                                   // previous chunk consumed (and ws visible)
+    __syncthreads();                                   // previous chunk consumed
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      const int i = tid + k * 256;
-      if (i < 18 * 18 * C1_Q) *(f32x4*)(xs + (i / C1_Q) * C1_PIT + (i % C1_Q) * 4) = v[k];
+      const int i = tid + k * 128;
+      if (i < NI) *(f32x4*)(xs + (i / C1_Q) * C1_PIT + (i % C1_Q) * 4) = v[k];
     }
     __syncthreads();
     if (c0 + C1_CH < Ci) fetch(c0 + C1_CH);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float* xp = xs + ((py + t / 3) * 18 + px + t % 3) * C1_PIT;
-      const float* wp = ws + t * cip + c0;
+    for (int c4 = 0; c4 < C1_Q; ++c4) {
+      if (c0 + c4 * 4 >= Ci) break;                   // (uniform) Ci % 4 == 0
+      float wq[9][4];                                  // uniform: w[ci][tap] of the four channels
 #pragma unroll
-      for (int c4 = 0; c4 < C1_Q; ++c4) {
-        const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
-        const f32x4 wv = *(const f32x4*)(wp + c4 * 4);
-        acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wq[t][j] = w[(long)(c0 + c4 * 4 + j) * 9 + t];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {                    // halo row 4 pr + r feeds the strip's pixels p = r - 2 .. r
+        f32x4 xv[3];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          xv[dx] = *(const f32x4*)(xs + ((4 * pr + r) * C1_HC + px + dx) * C1_PIT + c4 * 4);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int tyy = r - p;
+          if (tyy >= 0 && tyy < 3) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const float* wt = wq[tyy * 3 + dx];
+              acc[p] += xv[dx].x * wt[0] + xv[dx].y * wt[1] + xv[dx].z * wt[2] + xv[dx].w * wt[3];
+            }
+          }
+        }
       }
     }
   }
-  const int oy = ty * 16 + py, ox = tx * 16 + px;
-  if (oy < H && ox < W) y[((long)b * H + oy) * W + ox] = acc + (bias ? bias[0] : 0.f);
+  const int ox = tx * C1_TW + px;
+  const float bb = bias ? bias[0] : 0.f;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int oy = ty * C1_TH + 4 * pr + p;
+    if (oy < H && ox < W) y[((long)b * H + oy) * W + ox] = acc[p] + bb;
+  }
 }
 
 // ----------------------------------------------------------------------------
@@ -397,8 +416,9 @@ int srhip_conv3x3_cout1_fwd(const float* x, long ldx, const float* w, const floa
                             int H, int W, int Ci, void* stream) {
   SR_REQUIRE(Ci <= 64 * CO_PER_LANE, "conv_cout1: Cin=%d > %d", Ci, 64 * CO_PER_LANE);
   SR_REQUIRE(Ci % 4 == 0 && ldx % 4 == 0, "conv_cout1: Cin and ldx must be multiples of 4 (Cin=%d)", Ci);
+  SR_REQUIRE((long)B * H * W * ldx < (1L << 34), "conv_cout1: input beyond 64 GB (32-bit offsets in 16-byte units)");
   if ((long)B * H * W <= 0) return 0;
-  hipLaunchKernelGGL(k_conv_cout1_fwd, dim3(sr_cdiv(W, 16), sr_cdiv(H, 16), B), dim3(256), 0,
+  hipLaunchKernelGGL(k_conv_cout1_fwd, dim3(sr_cdiv(W, C1_TW), sr_cdiv(H, C1_TH), B), dim3(128), 0,
                      (hipStream_t)stream, x, w, bias, y, B, H, W, Ci, ldx);
   SR_LAUNCH_CHECK("conv_cout1_fwd");
   return 0;
