@@ -48,7 +48,7 @@ def main():
             print(json.dumps(row), flush=True)
             if a.out:           # rewritten after every row: a sweep cut short keeps what it measured
                 with open(a.out, "w") as f:
-                    json.dump({"what": "ModelPlain.optimize_parameters (forward + L1 + backward + Adam, eager: host launch time included) on "
+                    json.dump({"what": "ModelPlain.optimize_parameters (forward + L1 + backward + Adam, the product's default: one hipGraph replay per step where the engine offers it, eager otherwise) on "
                                "synthetic 512x512 HR patches, one MI355X; registry default options per network; one process "
                                "per network", "rows": rows}, f, indent=1)
         return
