@@ -451,8 +451,13 @@ __device__ __forceinline__ void tnb_body(const TnArgs& p, const int s, const int
 // ---------------------------------------------------------------------------
 // BM >= 0: the operand prologues fixed at compile time (b_mode = BM, the A row scale present iff AR) -- the grouped launch
 // picks the instantiation per problem (block-uniform), so the staging loop carries no mode branches; BM < 0: read from p.
-template <int W, int BM = -1, bool AR = false, bool NR = false>
-__device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const int tile, unsigned char* smem) {
+// CONV: the 3x3 conv weight gradient of tap `tap` (B rows are the tap-shifted pixels of a [batch][H][Wd] image, zero outside;
+// plain operands: BM = 0, no row scale, no PixelShuffle form; both operands below 4 GB: 32-bit row offsets).  A chunk's
+// source rows differ between the lane halves, so its loads take a per-lane row offset: lane (token & 31) works out the
+// token's source row (-1: none), a load reads it back with two v_readlane + a select, clamps it and store() zeroes the
+// tokens that had none -- no branch around a load anywhere, one form for interior and ragged chunks.
+template <int W, int BM = -1, bool AR = false, bool NR = false, bool CONV = false>
+__device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const int tile, unsigned char* smem, const int tap = 0) {
   const int bmode = BM >= 0 ? BM : p.b_mode;
   const bool arow = BM >= 0 ? AR : (p.a_rowscale != nullptr);
   constexpr int BC = 64 * W, HC = 32 * W;
@@ -472,12 +477,14 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
   const int ivalid = min(p.i_tile, p.NI - i0), jvalid = min(p.j_tile, p.NJ - j0);
   const int m_begin = s * p.rows_per_slice;
   const int m_end = min(p.M, m_begin + p.rows_per_slice);
-  const bool do_colsum = p.part_colsum && bj == 0;
+  const bool do_colsum = p.part_colsum && bj == 0 && tap == 0;
+  const int cdy = CONV ? tap / 3 - 1 : 0, cdx = CONV ? tap % 3 - 1 : 0;
 
   struct Stage {
     typename ColVec<W>::T rv[2][8];
     float scale;
     float2 stats;
+    int trow;                 // CONV: source row of token (lane & 31) of the chunk, -1 = none (outside the image / the slice)
   };
   Stage sg0, sg1;
   const bool isB = wave & 1;
@@ -495,6 +502,27 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
 #pragma unroll
   for (int j = 0; j < W; ++j) { cs[j] = 0.f; sc[j] = 0x1p126f; }
 
+  auto bcast_i = [&](int v, int k) __attribute__((always_inline)) -> int {       // value of token 16 th + k of the chunk
+    const int lo = __builtin_amdgcn_readlane(v, k), hi = __builtin_amdgcn_readlane(v, 16 + k);
+    return th ? hi : lo;
+  };
+  const unsigned ld4 = (unsigned)opLd * 4u, colb0 = (unsigned)colq * 4u;
+  auto load_c = [&](int mc, Stage& sg) __attribute__((always_inline)) {
+    const int gm = mc + (lane & 31);
+    bool ok = gm < m_end;
+    int srow = gm;
+    const int x = gm % p.Wd, tq = gm / p.Wd;
+    const int y = tq % p.H, bq = tq / p.H;
+    const int yy = y + (isB ? cdy : 0), xx = x + (isB ? cdx : 0);
+    ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+    srow = (bq * p.H + yy) * p.Wd + xx;
+    sg.trow = ok ? srow : -1;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int row = max(bcast_i(sg.trow, t), 0);
+      sg.rv[t >> 3][t & 7] = ColVec<W>::ldg(opP, (unsigned)row * ld4 + colb0);
+    }
+  };
   auto load = [&](int mc, Stage& sg) __attribute__((always_inline)) {
     const int tokl = mc + (lane & 31);          // the token whose scalars this lane carries
     const bool interior = mc + TKB <= m_end;    // uniform
@@ -570,6 +598,17 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
               }
             x[o][t][j] = sr_f32x2{e0, e1};
           }
+      }
+      if (CONV) {             // tokens without a source row (outside the image or the slice) count as zeros
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool ok0 = bcast_i(sg.trow, 8 * o + 2 * t) >= 0, ok1 = bcast_i(sg.trow, 8 * o + 2 * t + 1) >= 0;
+#pragma unroll
+          for (int j = 0; j < W; ++j) {
+            x[o][t][j].x = ok0 ? x[o][t][j].x : 0.f;
+            x[o][t][j].y = ok1 ? x[o][t][j].y : 0.f;
+          }
+        }
       }
       if (!isB) {
         if (arow) {
@@ -665,7 +704,21 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
     __builtin_amdgcn_s_setprio(2);                    // the staging waves are the critical path of a chunk: issue before the MFMA waves
     const int n_int = (m_end - m_begin) / TKB;     // chunks that lie entirely inside the slice
     int c = 0;
-    if (n_int >= 5) {                              // (uniform) straight-line loads from the first one on
+    if constexpr (CONV) {
+      load_c(m_begin, sg0);
+      load_c(m_begin + TKB, sg1);
+      store(smem, sg0);
+      load_c(m_begin + 2 * TKB, sg0);
+      __syncthreads();
+      for (; c < nch; c += 2) {
+        store(smem + BUF, sg1);
+        load_c(m_begin + (c + 3) * TKB, sg1);
+        __syncthreads();
+        store(smem, sg0);
+        load_c(m_begin + (c + 4) * TKB, sg0);
+        __syncthreads();
+      }
+    } else if (n_int >= 5) {                              // (uniform) straight-line loads from the first one on
       load_i(m_begin, sg0);
       load_i(m_begin + TKB, sg1);
       store(smem, sg0);
@@ -741,7 +794,7 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
     }
     __syncthreads();                             // the producers' final 2^-s
     const float* sinv = (const float*)(smem + SINV);
-    float* out = p.part + ((long)s * p.NI) * p.NJ;
+    float* out = p.part + ((long)(s * (CONV ? 9 : 1) + tap) * p.NI) * p.NJ;
 #pragma unroll
     for (int i = 0; i < W; ++i)
 #pragma unroll
@@ -1054,6 +1107,18 @@ __global__ void __launch_bounds__(512, 1) k_tnb(TnArgs p, int tiles, int xcd) {
   tnb_body<W>(p, t2 / tiles, t2 % tiles, tap, smem);
 }
 
+// 3x3 conv weight gradient on 192-column tiles, two fp16 planes / three products (tnb_body_h<.., CONV>): SwinIR's 180-channel
+// convs.  Same block -> (slice, tile, tap) map as k_tnb.
+template <int W>
+__global__ void __launch_bounds__(512, 1) k_tnb_hc(TnArgs p, int tiles, int xcd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int L = xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int tap = L % 9, t2 = L / 9;
+  const bool even = p.NI % W == 0 && p.NJ % W == 0 && p.i_tile % W == 0 && p.j_tile % W == 0;
+  if (even) tnb_body_h<W, 0, false, true, true>(p, t2 / tiles, t2 % tiles, smem, tap);
+  else tnb_body_h<W, 0, false, false, true>(p, t2 / tiles, t2 % tiles, smem, tap);
+}
+
 // Up to TNB_GROUP_MAX Linear problems over the same rows in one launch: the four of a Swin block, or the 4 x depth of a
 // whole RSTB layer (SwinIREngine defers them to the layer's end: 48 tiles need 5 reduce slices to fill the chip instead
 // of 32 -- a sixth of the partial-sum traffic and of the reducer's work per block).  The block's problem is selected by
@@ -1295,6 +1360,19 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
     if (tnb_f16()) hipLaunchKernelGGL((k_tnb3<0, true>), dim3(p.S * tiles * 3), dim3(512), lds_bytes3(), st, p, tiles, xcd);
     else hipLaunchKernelGGL((k_tnb3<0>), dim3(p.S * tiles * 3), dim3(512), lds_bytes3(), st, p, tiles, xcd);
     SR_LAUNCH_CHECK("k_tnb3");
+    return 0;
+  }
+  // 192-column conv problems with plain operands: two fp16 planes / three products (k_tnb_hc); SRHIP_TN_F16X2_CONV3=0: six bf16
+  static const int f16c3 = [] { const char* e = sr_getenv("SRHIP_TN_F16X2_CONV3"); return e ? atoi(e) : 1; }();
+  if (p.conv && w == 3 && f16c3 && tnb_f16() && !p.ps && p.b_mode == 0 && !p.a_rowscale &&
+      (long)p.M * p.lda < (1L << 30) && (long)p.batch * p.H * p.Wd * p.ldb < (1L << 30)) {
+    static bool attr_hc = false;
+    if (!attr_hc) {
+      if (int rc = reserve_lds(k_tnb_hc<3>, lds_bytes(3), "k_tnb_hc")) return rc;
+      attr_hc = true;
+    }
+    hipLaunchKernelGGL((k_tnb_hc<3>), grid, dim3(512), lds_bytes(3), st, p, tiles, xcd);
+    SR_LAUNCH_CHECK("k_tnb_hc");
     return 0;
   }
   static bool attr[4] = {false, false, false, false};
