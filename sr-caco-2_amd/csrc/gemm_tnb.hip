@@ -704,7 +704,7 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
     __builtin_amdgcn_s_setprio(2);                    // the staging waves are the critical path of a chunk: issue before the MFMA waves
     const int n_int = (m_end - m_begin) / TKB;     // chunks that lie entirely inside the slice
     int c = 0;
-    if constexpr (CONV) {
+    if constexpr (CONV) {        // (three register stages fit here -- 224 registers -- and measured 95.0 / 95.8 us against 92.8 / 93.1)
       load_c(m_begin, sg0);
       load_c(m_begin + TKB, sg1);
       store(smem, sg0);
