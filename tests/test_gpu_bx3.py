@@ -214,9 +214,12 @@ def test_gemm_row_stats(ops, M, N, K):
     assert (st - st2).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize("B,H,W,Ci,Co", [(1, 12, 20, 128, 128), (2, 9, 7, 128, 192), (1, 16, 16, 256, 128), (3, 8, 8, 180, 180)])
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(1, 12, 20, 128, 128), (2, 9, 7, 128, 192), (1, 16, 16, 256, 128), (3, 8, 8, 180, 180),
+                                         # 192-column tiles on two fp16 planes (k_tnb_hc): ragged column tuples (184, 200 are not
+                                         # multiples of 3), rows that are no multiple of the chunk, several slices and tiles
+                                         (2, 9, 7, 180, 184), (1, 13, 11, 200, 192), (1, 40, 56, 180, 180), (2, 24, 24, 384, 180)])
 def test_conv_wgrad_bx3_borders_and_tails(ops, B, H, W, Ci, Co):
-    """bf16x3 conv weight gradient on images whose rows are not multiples of the 32-token chunk
+    """conv weight gradient (bf16x3 / fp16x2 bodies) on images whose rows are not multiples of the 32-token chunk
     (border taps, partial last chunk, ragged slices) against float64 autograd."""
     x, w, dy = rnd(B, Ci, H, W), rnd(Co, Ci, 3, 3, scale=0.05), rnd(B, Co, H, W)
     wr = w.double().clone().requires_grad_(True)
