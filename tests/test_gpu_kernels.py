@@ -415,6 +415,16 @@ def test_conv_cin1_cout1(ops):
     check(dwt, wr2.grad, 2e-5, "cout1 dW")
 
 
+@pytest.mark.parametrize("B,H,W,Ci", [(1, 40, 50, 4), (2, 33, 17, 60), (1, 70, 36, 180), (1, 32, 16, 256)])
+def test_conv_cout1_channel_counts(ops, B, H, W, Ci):
+    """Cout = 1 tail conv (four output pixels per thread, 16-channel chunks): channel counts that are not multiples of
+    the chunk, images that are not multiples of the 16 x 32 tile, against float64."""
+    xt, wt, bt = rnd(B, Ci, H, W), rnd(1, Ci, 3, 3, scale=0.1), rnd(1)
+    yt = ops.conv3x3_cout1_fwd(dev(xt.permute(0, 2, 3, 1)), dev(wt), dev(bt))
+    ref = F.conv2d(xt.double(), wt.double(), bt.double(), padding=1)[:, 0]
+    assert (yt.cpu().double() - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item()) * (1 + Ci / 64)
+
+
 # ------------------------------------------------------------------ index ops
 @pytest.mark.parametrize("r,Co,h,w", [(8, 1, 8, 8), (2, 64, 6, 10), (3, 2, 4, 4), (8, 1, 64, 64), (8, 64, 5, 7), (4, 32, 6, 3),
                                       (3, 40, 4, 5), (8, 16, 9, 4)])
