@@ -1107,8 +1107,8 @@ __global__ void __launch_bounds__(512, 1) k_tnb(TnArgs p, int tiles, int xcd) {
   tnb_body<W>(p, t2 / tiles, t2 % tiles, tap, smem);
 }
 
-// 3x3 conv weight gradient on 192-column tiles, two fp16 planes / three products (tnb_body_h<.., CONV>): SwinIR's 180-channel
-// convs.  Same block -> (slice, tile, tap) map as k_tnb.
+// 3x3 conv weight gradient on 64 W-column tiles, two fp16 planes / three products (tnb_body_h<.., CONV>): SwinIR's 180-channel
+// convs (W = 3), DRRN's 128-channel ones (W = 2).  Same block -> (slice, tile, tap) map as k_tnb.
 template <int W>
 __global__ void __launch_bounds__(512, 1) k_tnb_hc(TnArgs p, int tiles, int xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1362,16 +1362,24 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
     SR_LAUNCH_CHECK("k_tnb3");
     return 0;
   }
-  // 192-column conv problems with plain operands: two fp16 planes / three products (k_tnb_hc); SRHIP_TN_F16X2_CONV3=0: six bf16
+  // single conv problems with plain operands on 128- and 192-column tiles: two fp16
+  // planes / three products (k_tnb_hc); SRHIP_TN_F16X2_CONV3=0: six bf16
   static const int f16c3 = [] { const char* e = sr_getenv("SRHIP_TN_F16X2_CONV3"); return e ? atoi(e) : 1; }();
-  if (p.conv && w == 3 && f16c3 && tnb_f16() && !p.ps && p.b_mode == 0 && !p.a_rowscale &&
+  // (64-column tiles stay on k_tnb<1>: SwinIR's 180 -> 64 conv 78 us there, 97 us on this body -- the per-lane row offsets
+  // weigh more where a lane stages one column)
+  if (p.conv && w >= 2 && f16c3 && tnb_f16() && !p.ps && p.b_mode == 0 && !p.a_rowscale &&
       (long)p.M * p.lda < (1L << 30) && (long)p.batch * p.H * p.Wd * p.ldb < (1L << 30)) {
-    static bool attr_hc = false;
-    if (!attr_hc) {
-      if (int rc = reserve_lds(k_tnb_hc<3>, lds_bytes(3), "k_tnb_hc")) return rc;
-      attr_hc = true;
+    static bool attr_hc[4] = {false, false, false, false};
+#define SR_TNB_HC(W_)                                                                       \
+    if (w == W_) {                                                                          \
+      if (!attr_hc[W_]) {                                                                   \
+        if (int rc = reserve_lds(k_tnb_hc<W_>, lds_bytes(W_), "k_tnb_hc")) return rc;       \
+        attr_hc[W_] = true;                                                                 \
+      }                                                                                     \
+      hipLaunchKernelGGL((k_tnb_hc<W_>), grid, dim3(512), lds_bytes(W_), st, p, tiles, xcd); \
     }
-    hipLaunchKernelGGL((k_tnb_hc<3>), grid, dim3(512), lds_bytes(3), st, p, tiles, xcd);
+    SR_TNB_HC(2) SR_TNB_HC(3)
+#undef SR_TNB_HC
     SR_LAUNCH_CHECK("k_tnb_hc");
     return 0;
   }
