@@ -25,6 +25,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the prototypes between this push and the pop at the end of the file are its
+ * only dynamic symbols. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 const char* srhip_last_error(void);
 int srhip_abi_version(void);
@@ -758,6 +763,19 @@ int srhip_adam_step_dc(float* p, const float* g, float* m, float* v, long n, con
 int srhip_sgd_step_dc(float* p, const float* g, float* buf, long n, const int* counter, float lr,
                       float momentum, float wd, int nesterov, float gscale, const int* skip_flag,
                       const float* lr_dev, void* stream);
+/* Gradient clipping by the global L2 norm over the flat gradient -- torch.nn.utils.clip_grad_norm_(parameters, max_norm,
+ * norm_type=2) of the step (model_plain.py:350-361, G_optimizer_clipgrad > 0).  g holds the SUM over ranks after the
+ * all-reduce; the norm is taken of g * gscale (gscale = 1 / world_size: what DDP's averaged gradients give).  norm_coef[0] =
+ * that norm, norm_coef[1] = min(1, max_norm / (norm + 1e-6)) (NaN if the norm is: torch's clamp); g *= norm_coef[1].  Two-stage
+ * fixed-order reduction in double: deterministic, capturable in a hipGraph, no host sync.  workspace:
+ * srhip_grad_norm_clip_ws() bytes, 8-byte aligned. */
+long srhip_grad_norm_clip_ws(void);
+int srhip_grad_norm_clip(float* g, long n, float gscale, float max_norm, float* norm_coef, void* workspace,
+                         long workspace_bytes, void* stream);
+/* Exponential moving average of the weights, ModelBase.update_E (model_base.py:213-219; E_decay > 0, model_plain.py:393-394):
+ * e = e * decay + p * (1 - decay) over the flat parameter buffer.  Skipped on the device when *skip_flag != 0 (the
+ * reference returns from the step before update_E on a non-finite loss, model_plain.py:344-346). */
+int srhip_ema_update(float* e, const float* p, long n, float decay, const int* skip_flag, void* stream);
 /* flag[0] |= any(!isfinite(x)): one device flag instead of the reference's
  * per-tensor host syncs (dlib/utils/tools.py:28-63, model_plain.py:344). */
 int srhip_nonfinite_flag(const float* x, long n, int* flag, void* stream);
@@ -796,6 +814,9 @@ int srhip_bn_bwd(const float* dY, const float* A, const float* X, const float* c
                  const float* R, float* dgamma, float* dbeta, int accumulate, void* workspace, long workspace_bytes,
                  void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

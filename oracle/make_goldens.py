@@ -2191,9 +2191,74 @@ def g_optim():
     npz("g8_optim", **out)
 
 
+# ---------------------------------------------------------------- G50 clipped step + netE
+def g_clip_ema():
+    """The two remaining pieces of ModelPlain.optimize_parameters (model_plain.py:350-361,393-394): clip_grad_norm_ in front
+    of the optimizer and ModelBase.update_E behind it -- the reference's own calls on a three-tensor parameter list, three
+    steps, one of them under the threshold (coefficient 1)."""
+    print("G50 clip_grad_norm_ step + update_E")
+    from dlib.models.model_base import ModelBase          # the reference's update_E
+
+    class _Holder:                                        # what update_E touches of a ModelBase: netG, netE, get_bare_model
+        def get_bare_model(self, net):
+            return net
+
+    torch.manual_seed(50)
+    shapes = [(257,), (16, 9), (5,)]
+    p0 = [torch.randn(*s) for s in shapes]
+    scales = (1.0, 0.02, 3.0)                             # step 2's norm falls under max_norm: no clipping there
+    gs = [[torch.randn(*s) * sc for s in shapes] for sc in scales]
+    max_norm, decay = 1.5, 0.9
+    out = dict(max_norm=np.array(max_norm), decay=np.array(decay))
+    for i, t in enumerate(p0):
+        out[f"p0/{i}"] = t
+    for name in ("adam", "sgd"):
+        netG = nn.ParameterList([nn.Parameter(t.clone()) for t in p0])
+        netE = nn.ParameterList([nn.Parameter(t.clone()) for t in p0])
+        h = _Holder()
+        h.netG, h.netE = netG, netE
+        ModelBase.update_E(h, 0)                          # model_plain.py:82-84: netE starts as a copy
+        if name == "adam":
+            opt = torch.optim.Adam(list(netG), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+        else:
+            opt = torch.optim.SGD(list(netG), lr=0.01, momentum=0.9, nesterov=True, weight_decay=0.0)
+        po = [t.clone() for t in p0]
+        eo = [t.clone() for t in p0]
+        m = [torch.zeros_like(t) for t in p0]
+        v = [torch.zeros_like(t) for t in p0]
+        norms = []
+        for step in range(3):
+            for p, g in zip(netG, gs[step]):
+                p.grad = g.clone()
+            total = torch.nn.utils.clip_grad_norm_(list(netG), max_norm=max_norm, norm_type=2)
+            opt.step()
+            ModelBase.update_E(h, decay)
+            go = [g.clone() for g in gs[step]]
+            tot_o, coef_o = O.clip_grad_norm(go, max_norm)
+            close(tot_o, total, 1e-6, f"{name} total norm step {step + 1}")
+            for j in range(len(po)):
+                if name == "adam":
+                    O.adam_step(po[j], go[j], m[j], v[j], step + 1, 2e-4, wd=1e-4)
+                else:
+                    O.sgd_nesterov_step(po[j], go[j], m[j], step == 0, 0.01)
+            O.ema_update(eo, po, decay)
+            norms.append(float(total))
+            for j in range(len(po)):
+                close(po[j], netG[j].detach(), 2e-7, f"{name} clipped step {step + 1} tensor {j}")
+                close(eo[j], netE[j].detach(), 2e-7, f"{name} netE step {step + 1} tensor {j}")
+                out[f"{name}/p/{step}/{j}"] = netG[j].detach().clone()
+                out[f"{name}/e/{step}/{j}"] = netE[j].detach().clone()
+        out[f"{name}/norms"] = np.array(norms)
+        assert norms[1] < max_norm < norms[0], norms
+    for step in range(3):
+        for j in range(len(shapes)):
+            out[f"g/{step}/{j}"] = gs[step][j]
+    npz("g50_clip_ema", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gens = [g_grl, g_grl_grad, g_omnisr, g_omnisr_grad, g_act, g_act_grad, g_dfcan, g_dfcan_grad, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
+    gens = [g_clip_ema, g_grl, g_grl_grad, g_omnisr, g_omnisr_grad, g_act, g_act_grad, g_dfcan, g_dfcan_grad, g_nlsn, g_nlsn_grad, g_enlcn, g_enlcn_grad, g_dbpn, g_srfbn, g_prosr, g_lowres, g_patch_sampler_edt, g_index, g_edsr, g_edsr_full, g_swinir_tiny, g_swinir_readme, g_losses, g_losses_extra, g_losses_elb, g_local_moments, g_hist, g_kde, g_vdsr, g_drrn, g_interpolate, g_patches,
             g_metrics, g_optim, g_trained_like, g_eval_fixture, g_swinir_pixelshuffle, g_patch_sampler, g_srcnn, g_mslapsrn, g_hist_kl_bh, g_swinir_nearest_conv, g_memnet, g_swinir_3conv, g_swinir_ape, g_swinir_rgb, g_swinir_plain_embed, g_swinir_window4]
     only = set(sys.argv[1:])          # e.g. `python oracle/make_goldens.py g_losses_extra`
     for g in gens:

@@ -2195,6 +2195,23 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
     p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
 
 
+def clip_grad_norm(grads, max_norm: float):
+    """torch.nn.utils.clip_grad_norm_(parameters, max_norm, norm_type=2) as the step calls it (model_plain.py:350-361,
+    G_optimizer_clipgrad > 0): total = ||(||g_1||, ..., ||g_n||)||_2, coef = min(1, max_norm / (total + 1e-6)), every
+    gradient scaled in place.  Returns (total, coef)."""
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g, 2) for g in grads]), 2)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return total, coef
+
+
+def ema_update(e_params, g_params, decay: float) -> None:
+    """ModelBase.update_E (model_base.py:213-219): e = e * decay + g * (1 - decay) per parameter, in place."""
+    for e, g in zip(e_params, g_params):
+        e.mul_(decay).add_(g, alpha=1 - decay)
+
+
 def sgd_nesterov_step(p: Tensor, g: Tensor, buf: Tensor, first: bool, lr: float,
                       momentum=0.9, wd=0.0, nesterov=True) -> None:
     """torch.optim.SGD with momentum (dampening 0), in place."""

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include "../../include/srhip.h"   // every entry point is defined against its public prototype (and takes its default visibility from it)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -24,8 +25,12 @@ int sr_fail(int code, const char* fmt, ...);
 #ifdef SRHIP_EXPERIMENTS
 #include <stdlib.h>
 static inline const char* sr_getenv(const char* name) { return getenv(name); }
+// the library is built with -fvisibility=hidden: include/srhip.h's prototypes are the only exports (the header pushes default
+// visibility around them).  The stamp / ablation hooks of tools/mb_*_phases.py are exported by the experiments build only.
+#define SR_DEBUG_EXPORT extern "C" __attribute__((visibility("default")))
 #else
 static inline const char* sr_getenv(const char*) { return nullptr; }
+#define SR_DEBUG_EXPORT extern "C"
 #endif
 
 static inline int sr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1343,7 +1343,7 @@ __global__ void __launch_bounds__(256, Nhcw2Ring<DEEP>::OCC) k_nhcw2(NtArgs p) {
 
 #ifdef SRHIP_EXPERIMENTS
 // [blocks][4 waves][16] stamps of the 100 MHz wall clock
-extern "C" int srhip_nhcw2_debug_buffer(long long* buf) {
+SR_DEBUG_EXPORT int srhip_nhcw2_debug_buffer(long long* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_nhcw2_dbg), &buf, sizeof(buf)) == hipSuccess ? 0 : -5;
 }
 #endif

@@ -764,6 +764,51 @@ __global__ void k_sgd_dc(float* __restrict__ p, const float* __restrict__ g, flo
     p[i] = pi - lr * d;
   }
 }
+// ---- gradient clipping by the global L2 norm (torch.nn.utils.clip_grad_norm_, model_plain.py:350-361) --------------------
+// Two-stage fixed-order reduction (no float atomics: a replayed or data-parallel step clips bit for bit like the eager one):
+// block b sums the squares of ITS slice of the flat gradient in double, one block joins the GC_BLOCKS partials in order,
+// writes norm = gscale * sqrt(sum) and coef = min(1, max_norm / (norm + 1e-6)) (a NaN norm gives a NaN coefficient, as
+// torch's clamp does), and a third launch scales the gradient by the device-resident coefficient.
+constexpr int GC_BLOCKS = 1024;
+__global__ void __launch_bounds__(256) k_sumsq_partials(const float* __restrict__ g, long n, double* __restrict__ part) {
+  __shared__ double sh[4];
+  const long per = ((n + GC_BLOCKS - 1) / GC_BLOCKS + 3) / 4 * 4;
+  const long lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double a = 0.0;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) { const double v = g[i]; a += v * v; }
+  a = wave_sum_d(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void __launch_bounds__(GC_BLOCKS) k_clip_coef(const double* __restrict__ part, float gscale, float max_norm,
+                                                         float* __restrict__ out) {
+  __shared__ double sh[GC_BLOCKS / 64];
+  double a = wave_sum_d(part[threadIdx.x]);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < GC_BLOCKS / 64; ++i) t += sh[i];
+    const float norm = (float)(sqrt(t) * (double)gscale);
+    const float c = max_norm / (norm + 1e-6f);
+    out[0] = norm;
+    out[1] = c < 1.f ? c : (c != c ? c : 1.f);
+  }
+}
+__global__ void k_scale_dev(float* __restrict__ g, long n, const float* __restrict__ coef) {
+  const float c = *coef;
+  if (c == 1.f) return;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] *= c;
+}
+// exponential moving average of the weights (ModelBase.update_E, model_base.py:213-219): e = e * decay + p * (1 - decay);
+// skipped with the optimizer update on a non-finite loss (optimize_parameters returns before update_E, model_plain.py:344-346)
+__global__ void k_ema(float* __restrict__ e, const float* __restrict__ p, long n, float decay, float alpha,
+                      const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    e[i] = __fadd_rn(__fmul_rn(e[i], decay), __fmul_rn(p[i], alpha));
+}
 // finite check: flag[0] |= any(!isfinite(x))
 __global__ void k_nonfinite(const float* __restrict__ x, long n, int* __restrict__ flag) {
   int bad = 0;
@@ -1059,6 +1104,33 @@ int srhip_sgd_step_dc(float* p, const float* g, float* buf, long n, const int* c
   hipLaunchKernelGGL(k_sgd_dc, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, counter,
                      lr, momentum, wd, nesterov, gscale, skip_flag, lr_dev);
   SR_LAUNCH_CHECK("sgd_step_dc");
+  return 0;
+}
+
+long srhip_grad_norm_clip_ws(void) { return (long)GC_BLOCKS * 8; }
+
+int srhip_grad_norm_clip(float* g, long n, float gscale, float max_norm, float* norm_coef, void* workspace,
+                         long workspace_bytes, void* stream) {
+  if (n <= 0) return 0;
+  SR_REQUIRE(g && norm_coef && workspace, "grad_norm_clip: null operand");
+  SR_REQUIRE(workspace_bytes >= (long)GC_BLOCKS * 8 && ((uintptr_t)workspace & 7) == 0,
+             "grad_norm_clip: workspace of %ld bytes, 8-byte aligned (srhip_grad_norm_clip_ws)", (long)GC_BLOCKS * 8);
+  SR_REQUIRE(max_norm > 0.f, "grad_norm_clip: max_norm = %g must be positive", (double)max_norm);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_sumsq_partials, dim3(GC_BLOCKS), dim3(256), 0, st, g, n, (double*)workspace);
+  hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(GC_BLOCKS), 0, st, (const double*)workspace, gscale, max_norm, norm_coef);
+  hipLaunchKernelGGL(k_scale_dev, dim3(ew_grid(n)), dim3(256), 0, st, g, n, norm_coef + 1);
+  SR_LAUNCH_CHECK("grad_norm_clip");
+  return 0;
+}
+
+int srhip_ema_update(float* e, const float* p, long n, float decay, const int* skip_flag, void* stream) {
+  if (n <= 0) return 0;
+  SR_REQUIRE(e && p, "ema_update: null operand");
+  SR_REQUIRE(decay >= 0.f && decay <= 1.f, "ema_update: decay = %g outside [0, 1]", (double)decay);
+  hipLaunchKernelGGL(k_ema, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, e, p, n, decay,
+                     (float)(1.0 - (double)decay), skip_flag);
+  SR_LAUNCH_CHECK("ema_update");
   return 0;
 }
 

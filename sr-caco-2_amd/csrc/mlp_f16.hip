@@ -1219,8 +1219,8 @@ __global__ void __launch_bounds__(GR_NT, 3) k_mlp_gr_fwd(MlpF16Args p) {
 }  // namespace
 
 #ifdef SRHIP_EXPERIMENTS
-extern "C" int srhip_mlp_debug_buffer(long long* buf) { g_mlp_dbg = buf; return 0; }    // [blocks][4][32] wall-clock stamps
-extern "C" int srhip_mlp_cu_counters(int* buf) { g_mlp_cu_count = buf; return 0; }      // [4096] zeroed ints: arrival order per CU
+SR_DEBUG_EXPORT int srhip_mlp_debug_buffer(long long* buf) { g_mlp_dbg = buf; return 0; }    // [blocks][4][32] wall-clock stamps
+SR_DEBUG_EXPORT int srhip_mlp_cu_counters(int* buf) { g_mlp_cu_count = buf; return 0; }      // [4096] zeroed ints: arrival order per CU
 #endif
 
 int sr_mlp_f16(MlpF16Args& p, int bwd, hipStream_t st) {

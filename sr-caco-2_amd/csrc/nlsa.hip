@@ -4,12 +4,11 @@
 // itself and its two neighbouring chunks with the keys L2-normalised (:224-243), and the rounds combined by a softmax over
 // their log-sum-exp scores (:258-262).
 //
-// Layout: everything stays token-major (channels last).  The order is ONE radix sort of 64-bit keys
-// (sample, round, code | token) -- stable by construction, where the reference's torch.sort leaves the order of equal
-// codes to the implementation.  The attention kernel gathers its rows through that order and writes its result and score
+// Layout: everything stays token-major (channels last).  The order is ONE stable counting sort per (sample, round) of the
+// 64-bit keys (sample, round, code | token) by their hash code (<= 128 buckets: k_bucket_order, in-tree -- no sort library),
+// where the reference's torch.sort leaves the order of equal codes to the implementation.  The attention kernel gathers its rows through that order and writes its result and score
 // at the TOKEN's own position of its round, so the un-sort (:251-253) is free and padded rows are simply not written.
 #include "common.h"
-#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -32,6 +31,64 @@ __global__ void __launch_bounds__(256) k_lsh_keys(const float* __restrict__ rot,
     if (-r[i] > best) { best = -r[i]; code = hbh + i; }
   const unsigned long long grp = ((unsigned long long)(n * nh + h) * (2 * hbh) + code);
   keys[idx] = (grp << TOK_BITS) | (unsigned)l;
+}
+
+// Stable counting sort of the L keys of one (sample, round) by hash code: one block per group.  Histogram (integer LDS
+// atomics), exclusive scan, then the tokens in tiles of 1024 in their own order: a token's slot = start of its code + tokens
+// of that code in earlier tiles + in earlier waves of this tile + in lower lanes of its wave (ballot per distinct code).
+constexpr int BO_T = 1024, BO_W = BO_T / 64, BO_HB = 128;
+__global__ void __launch_bounds__(BO_T) k_bucket_order(const unsigned long long* __restrict__ keys,
+                                                        unsigned long long* __restrict__ order, int L, int hb) {
+  __shared__ int base[BO_HB];
+  __shared__ int wcnt[BO_W][BO_HB];
+  const int g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const unsigned long long* k = keys + (long)g * L;
+  unsigned long long* o = order + (long)g * L;
+  const unsigned long long grp0 = (unsigned long long)g * hb;
+  if (tid < BO_HB) base[tid] = 0;
+  for (int i = tid; i < BO_W * BO_HB; i += BO_T) (&wcnt[0][0])[i] = 0;
+  __syncthreads();
+  for (int l = tid; l < L; l += BO_T) atomicAdd(&base[(int)((k[l] >> TOK_BITS) - grp0)], 1);
+  __syncthreads();
+  if (wave == 0) {                 // exclusive scan of <= 128 counts: two per lane
+    const int a = base[2 * lane], b = base[2 * lane + 1];
+    int s = a + b;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(s, d);
+      if (lane >= d) s += t;
+    }
+    base[2 * lane] = s - a - b;
+    base[2 * lane + 1] = s - b;
+  }
+  __syncthreads();
+  for (int l0 = 0; l0 < L; l0 += BO_T) {
+    const int l = l0 + tid;
+    const bool live = l < L;
+    const unsigned long long key = live ? k[l] : 0ull;
+    const int code = live ? (int)((key >> TOK_BITS) - grp0) : -1;
+    int rank = 0;
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+      const int c0 = __shfl(code, __ffsll((long long)todo) - 1);
+      const unsigned long long same = __ballot(code == c0);
+      if (code == c0) rank = __popcll(same & ((1ull << lane) - 1ull));
+      if (lane == 0) wcnt[wave][c0] = __popcll(same);
+      todo &= ~same;
+    }
+    __syncthreads();
+    if (live) {
+      int before = base[code];
+      for (int w = 0; w < wave; ++w) before += wcnt[w][code];
+      o[before + rank] = key;
+    }
+    __syncthreads();
+    if (tid < BO_HB) {
+      int t = 0;
+      for (int w = 0; w < BO_W; ++w) { t += wcnt[w][tid]; wcnt[w][tid] = 0; }
+      base[tid] += t;
+    }
+    __syncthreads();
+  }
 }
 
 // One block = one chunk of one (sample, round): queries in tiles of QT rows against 3 * cs keys.
@@ -319,30 +376,24 @@ int srhip_nlsa_hash_buckets(int L, int chunk_size) {
   return hb < 128 ? hb : 128;
 }
 
-long srhip_nlsa_sort_ws(long n_items) {
-  size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortKeys((void*)nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                    (int)n_items, 0, 64, (hipStream_t)0);
-  return (long)bytes;
-}
+/* the in-tree counting sort keeps its histograms in LDS: no global workspace (the query stays in the ABI; callers may pass
+ * any non-NULL pointer) */
+long srhip_nlsa_sort_ws(long n_items) { (void)n_items; return 16; }
 
 /* rotated [N*L][ld] = x_embed . rotations ([.., n_hashes * hb/2] columns, round-major) -> order [N][n_hashes][L]: the
  * tokens of every (sample, round) by hash code, ties by token index (64-bit keys, low 20 bits = token). */
 int srhip_nlsa_order(const float* rotated, long ld, unsigned long long* keys_tmp, unsigned long long* order, void* workspace,
                      long ws_bytes, int N, int L, int n_hashes, int hash_buckets, void* stream) {
   SR_REQUIRE(rotated && keys_tmp && order && workspace, "nlsa_order: null operand");
-  SR_REQUIRE(N > 0 && n_hashes > 0 && L > 0 && L < (1 << TOK_BITS) && hash_buckets >= 2 && hash_buckets % 2 == 0,
-             "nlsa_order: L = %d (< 2^20), hash_buckets = %d (even, >= 2)", L, hash_buckets);
+  SR_REQUIRE(N > 0 && n_hashes > 0 && L > 0 && L < (1 << TOK_BITS) && hash_buckets >= 2 && hash_buckets % 2 == 0 &&
+             hash_buckets <= BO_HB, "nlsa_order: L = %d (< 2^20), hash_buckets = %d (even, 2 ... 128)", L, hash_buckets);
   const long items = (long)N * n_hashes * L;
   SR_REQUIRE(items < (1L << 31), "nlsa_order: %ld items", items);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_lsh_keys, dim3(sr_cdiv(items, 256)), dim3(256), 0, st, rotated, ld, keys_tmp, N, L, n_hashes,
                      hash_buckets / 2);
-  int grp_bits = 1;
-  while ((1L << grp_bits) < (long)N * n_hashes * hash_buckets) ++grp_bits;
-  size_t bytes = (size_t)ws_bytes;
-  if (hipcub::DeviceRadixSort::SortKeys(workspace, bytes, keys_tmp, order, (int)items, 0, TOK_BITS + grp_bits, st) != hipSuccess)
-    return sr_fail(-5, "nlsa_order: radix sort failed (workspace %ld bytes)", ws_bytes);
+  (void)ws_bytes;
+  hipLaunchKernelGGL(k_bucket_order, dim3(N * n_hashes), dim3(BO_T), 0, st, keys_tmp, order, L, hash_buckets);
   SR_LAUNCH_CHECK("nlsa_order");
   return 0;
 }

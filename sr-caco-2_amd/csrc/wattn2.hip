@@ -533,10 +533,10 @@ int srhip_window_attention_fwd_f16x2(const float* qkv, float* out, const float* 
 
 #ifdef SRHIP_EXPERIMENTS
 // [blocks][4 waves][4 windows][8] stamps of the 100 MHz wall clock
-int srhip_wattn2_debug_buffer(long long* buf) {
+__attribute__((visibility("default"))) int srhip_wattn2_debug_buffer(long long* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_w3_dbg), &buf, sizeof(buf)) == hipSuccess ? 0 : -5;
 }
-int srhip_wattn2_debug_mode(int mode) {
+__attribute__((visibility("default"))) int srhip_wattn2_debug_mode(int mode) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_w3_mode), &mode, sizeof(mode)) == hipSuccess ? 0 : -5;
 }
 #endif

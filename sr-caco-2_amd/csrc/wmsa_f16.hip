@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(64 * 6 * WPB, 3) k_wmsa_f16h(WmsaF16Args p) {
 }  // namespace
 
 #ifdef SRHIP_EXPERIMENTS
-extern "C" int srhip_wmsa_debug_buffer(long long* buf) { g_wmsa_dbg = buf; return 0; }   // [blocks][waves][16] stamps of the 100 MHz wall clock
+SR_DEBUG_EXPORT int srhip_wmsa_debug_buffer(long long* buf) { g_wmsa_dbg = buf; return 0; }   // [blocks][waves][16] stamps of the 100 MHz wall clock
 #endif
 
 int sr_wmsa_f16(WmsaF16Args& p, hipStream_t st) {

@@ -11,6 +11,12 @@ current_log, save / save_best / load_network (raw ``netG.state_dict()`` with
 load_current, loss_fn.{l_holder,n_holder,update_t}, attributes L, E, H, netG,
 save_dir.
 
+Gradient clipping (``G_optimizer_clipgrad``, model_plain.py:350-361) and the moving-average network netE
+(``E_decay``, :46-47,77-86,393-394; ``<iter>_E.pth``, ``E-current_model.pth``, ``E-<best>``) run inside the fused
+step (srhip_grad_norm_clip, srhip_ema_update).  Options of the reference's step that change its numbers and are
+NOT implemented raise instead of being ignored: ``--amp True`` in training (autocast + GradScaler, :322-327,348,363),
+``G_regularizer_orthstep / clipstep`` (:365-387).
+
 Changed on purpose (same observable behaviour): one device flag replaces the
 per-step ``isfinite(...).item()`` + ~660 ``check_corruption`` host syncs
 (model_plain.py:344,396; tools.py:55-63): a non-finite loss skips the update on
@@ -42,9 +48,14 @@ class ModelPlain:
             raise RuntimeError("ModelPlain (libsrhip) needs a GPU; there is no CPU fallback")
         self.device = torch.device(f'cuda:{dev_id}')
         self.netG = define_G(args).to(self.device)
-        # --amp: the reference trains and evaluates under autocast (model_plain.py:322-327); here training stays
-        # f32-accurate (parity gate) and evaluation takes the single-product bf16 kernels
+        # --amp: the reference trains and evaluates under autocast (model_plain.py:322-327); here evaluation takes the
+        # reduced-precision kernels and a TRAINING step under --amp raises (optimize_parameters): it is not implemented, and
+        # training f32-grade under a flag that asks for something else would be a silent change of the run
         self.netG.amp = bool(getattr(args, 'amp', False))
+        for k in ('G_regularizer_orthstep', 'G_regularizer_clipstep'):
+            if float(self._opt(k, 0.0) or 0.0) > 0:
+                raise NotImplementedError(f"{k} > 0 (model_plain.py:365-387: orthogonal / clipping weight regularizers) is not "
+                                          f"implemented on this path")
         self.schedulers = []
         self.log_dict = OrderedDict()
         self._E, self._E_pending = None, False
@@ -53,6 +64,17 @@ class ModelPlain:
         self.step_fn = None
         self._eval_graphs, self._weights_version = {}, 0
         self.loss_fn = None
+
+    def _opt(self, key, default=None):
+        t = self.opt_train
+        if hasattr(t, 'get'):
+            v = t.get(key, None)
+            return default if v is None else v
+        return default
+
+    @property
+    def E_decay(self):
+        return float(self._opt('E_decay', 0.0) or 0.0)
 
     # ---------------------------------------------------------------- train setup
     def init_train(self):
@@ -64,11 +86,26 @@ class ModelPlain:
         if getattr(self.args, 'distributed', False):
             import torch.distributed as dist
             world, pg = dist.get_world_size(), dist.group.WORLD
-        self.step_fn = TrainStep(self.netG, self.loss_fn.terms(), process_group=pg, world_size=world)
+        self.step_fn = TrainStep(self.netG, self.loss_fn.terms(), process_group=pg, world_size=world,
+                                 clipgrad=float(self._opt('G_optimizer_clipgrad', 0.0) or 0.0), ema_decay=self.E_decay)
         self.step_fn.opt = Optimizer(self.step_fn.fp, **optimizer_config(self.args))
         self.G_optimizer = self.step_fn.opt
         self.load_optimizers()
+        self.load_E()
         self.log_dict = OrderedDict()
+
+    def load_E(self):
+        """model_plain.py:75-86: with E_decay > 0, netE comes from args.netG['checkpoint_path_netE'] if that file exists
+        (key 'params_ema' or a raw state_dict), else it starts as a copy of netG (update_E(0); TrainStep did that)."""
+        if self.E_decay <= 0 or self.step_fn is None:
+            return
+        netg = self.args.netG if hasattr(self.args, 'netG') else {}
+        path = netg.get('checkpoint_path_netE', None) if hasattr(netg, 'get') else None
+        if path and os.path.isfile(path):
+            sd = torch.load(path, map_location='cpu')
+            if 'params_ema' in sd:
+                sd = sd['params_ema']
+            self.step_fn.load_ema_state_dict(sd, strict=bool(self._opt('E_param_strict', True)))
 
     def load(self):
         """model_plain.py:68-73: weights from args.netG['checkpoint_path_netG'] if that file exists
@@ -143,7 +180,30 @@ class ModelPlain:
             return bool(arg)
         return bool(getattr(getattr(self.netG, "engine", None), "train_graph_default", False))
 
+    def _capture_failed(self, why):
+        """A capture the engine does not survive: eager steps for the rest of the run.  Host-side state an aborted capture
+        consumed is put back (the tape nets' liveness pool, what the engine saved for a backward that never ran); under
+        data parallelism EVERY rank must take the same path (a rank replaying bucket all-reduces against ranks enqueueing
+        them eagerly still matches call for call, but say so)."""
+        self._train_graph_failed = True
+        self.step_fn._graph = None
+        eng = getattr(self.netG, 'engine', None)
+        pool = getattr(getattr(eng, 'bufs', None), 'pool', None)
+        if pool is not None and hasattr(pool, 'reset'):
+            pool.reset()
+        if getattr(eng, 'saved', None) is not None:
+            eng.saved = None
+        rank = ''
+        if getattr(self.args, 'distributed', False):
+            import torch.distributed as dist
+            rank = f' [rank {dist.get_rank()}]'
+        print(f"[libsrhip]{rank} training-step capture failed ({why}): eager steps from here on", flush=True)
+
     def optimize_parameters(self, epoch: int, current_step: int):
+        if getattr(self.netG, 'amp', False):
+            raise NotImplementedError("--amp True in training (torch.cuda.amp autocast + GradScaler, model_plain.py:322-327,"
+                                      "348,363) is not implemented on this path: the step is f32-grade only; --amp selects the "
+                                      "reduced-precision kernels for evaluation (model.test / eval.py)")
         self._weights_version += 1
         done = False
         if self._train_graph_on():
@@ -152,11 +212,8 @@ class ModelPlain:
                 done = True
             except NotImplementedError:       # a host-scheduled loss term: eager from here on
                 self._train_graph_failed = True
-            except RuntimeError as e:         # a capture the engine does not survive (a host read, an unsupported call)
-                self._train_graph_failed = True
-                self.step_fn._graph = None
-                print(f"[libsrhip] training-step capture failed ({str(e).splitlines()[0][:120]}): eager steps from here on",
-                      flush=True)
+            except Exception as e:            # a capture the engine does not survive (a host read, an assert, an unsupported call)
+                self._capture_failed(f"{type(e).__name__}: {str(e).splitlines()[0][:120] if str(e) else ''}")
         if not done:
             self.step_fn.step(self._net_input(), self.H, weight=self.h_per_pixel_weight)
         # the engine's output buffer is persistent (overwritten by the next step) and 3-D for the 1-channel conv nets:
@@ -238,6 +295,9 @@ class ModelPlain:
                 return self.netG(x)
             self._eval_graphs[key] = {"g": None, "x": x.clone(), "y": None}
             return self.netG(x)
+        from srhip import ops as _ops
+        if st["g"] is not None and st.get("gen") != _ops.realloc_generation():
+            st["g"], st["y"] = None, None          # a persistent buffer was replaced since the capture: re-capture
         st["x"].copy_(x)
         if st["g"] is None:
             # one eager forward in THIS mode first: what an engine prepares lazily per mode (MemNet's evaluation-time
@@ -249,6 +309,7 @@ class ModelPlain:
             with torch.cuda.graph(g):
                 st["y"] = self.netG(st["x"])
             st["g"] = g
+            st["gen"] = _ops.realloc_generation()
         st["g"].replay()
         return st["y"].clone()
 
@@ -271,6 +332,9 @@ class ModelPlain:
     def save(self, iter_label):
         """model_plain.py:95-101: <iter>_G.pth and, with G_optimizer_reuse, <iter>_optimizerG.pth."""
         path = self.save_network(self.save_dir, self.netG, 'G', iter_label)
+        if self.E_decay > 0 and self.step_fn is not None:                       # <iter>_E.pth (model_plain.py:97-98)
+            os.makedirs(self.save_dir, exist_ok=True)
+            torch.save(self.step_fn.ema_state_dict(), os.path.join(self.save_dir, f'{iter_label}_E.pth'))
         if self.step_fn is not None and self._reuse_optimizer():
             self.save_optimizer(self.save_dir, self.G_optimizer, 'optimizerG', iter_label)
         return path
@@ -284,6 +348,8 @@ class ModelPlain:
         """model_plain.py:131-137 (called as save_best(_dir, p_name_file='model.pth'),
         utils_trainer.py:230): writes <save_dir>/G-<p_name_file>."""
         os.makedirs(save_dir, exist_ok=True)
+        if self.E_decay > 0 and self.step_fn is not None:                       # E-<name> beside G-<name> (model_plain.py:136-139)
+            torch.save(self.step_fn.ema_state_dict(), os.path.join(save_dir, f'E-{p_name_file}'))
         return self.save_network_path(self.netG, os.path.join(save_dir, f'G-{p_name_file}'))
 
     def load_network(self, load_path, network, strict=True, param_key='params'):
@@ -303,6 +369,8 @@ class ModelPlain:
     def save_current(self, save_dir: str):
         """model_plain.py:103-110 (utils_trainer.py:1208): <save_dir>/G-current_model.pth."""
         os.makedirs(save_dir, exist_ok=True)
+        if self.E_decay > 0 and self.step_fn is not None:
+            torch.save(self.step_fn.ema_state_dict(), os.path.join(save_dir, 'E-current_model.pth'))
         return self.save_network_path(self.netG, os.path.join(save_dir, 'G-current_model.pth'))
 
     def load_current(self, save_dir: str):
@@ -310,6 +378,10 @@ class ModelPlain:
         path = os.path.join(save_dir, 'G-current_model.pth')
         if os.path.isfile(path):
             self.load_network(path, self.netG, strict=True, param_key='params')
+        path_e = os.path.join(save_dir, 'E-current_model.pth')
+        if self.E_decay > 0 and self.step_fn is not None and os.path.isfile(path_e):
+            sd = torch.load(path_e, map_location='cpu')
+            self.step_fn.load_ema_state_dict(sd.get('params_ema', sd), strict=True)
 
     def flush(self):
         self.L = self.E = self.H = None

@@ -456,7 +456,7 @@ def train_valid(args, model, train_loader, train_sampler, valid_loaders: dict, t
                 ddp_barrier(distributed)
             if do_save and master:
                 model.save(current_step)
-                clean_previous_checkpoints_except_last(model.save_dir, ['G', 'optimizerG'])
+                clean_previous_checkpoints_except_last(model.save_dir, ['G', 'optimizerG'] + (['E'] if model.E_decay > 0 else []))
                 save_tracker(args.outd_backup, tracker=tracker, roi_tracker=roi_tracker)
             if max_iters and current_step >= max_iters:
                 stop = True

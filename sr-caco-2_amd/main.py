@@ -11,7 +11,14 @@
 Flag names, the ``--net_type`` / ``--method`` pairing check, '+'-separated lists
 and the three-stage config (defaults -> per-net defaults -> CLI overrides of
 non-None values) follow dlib/utils/utils_parser.py:291-339,900-967,1142-1143 and
-dlib/utils/utils_config.py:64-404 for the options this path uses.  The
+dlib/utils/utils_config.py:64-404 for the options this path uses.
+
+Every flag of the reference's parser is known here (utils_parser.py:33-880) and falls into one of three classes:
+implemented; accepted without effect because it only names folders / logging / launcher plumbing (IGNORED_FLAGS);
+or -- a flag that changes the numbers of a run and is not implemented on this path -- accepted only at the
+reference's default and an error otherwise (DEFAULT_ONLY_FLAGS).  A flag nobody knows is an error, as in the
+reference (argparse's ``parse_args``; a key missing from the config raises ValueError, utils_parser.py:900-923).
+
 As the reference's main.py (:27-35) it first looks for the newest ``<iter>_G.pth`` /
 ``<iter>_optimizerG.pth`` under ``<outd>/<save_dir_models>`` and resumes there (weights, optimizer state,
 iteration count).  With ``--train_dsets`` (+ ``--valid_dsets`` / ``--test_dsets``, ``--data_root``,
@@ -78,6 +85,13 @@ def get_config(net_type):
         'max_epochs': 1, 'max_iters': 50, 'eval_over_roi_also': False,
         'train_dsets': '', 'valid_dsets': '', 'test_dsets': '', 'data_root': '', 'splits_root': 'folds',
         'sample_tr_patch': 'uniform', 'sample_tr_patch_th_style': 'fix_threshold', 'sample_tr_patch_th': 7,
+        # input pipeline (utils_config.py:130-138,215-233,260-262; dlib/datasets/dataset_dpsr.py, lowres.py)
+        'use_interpolated_low': False, 'inter_low_th': 7., 'inter_low_sigma': 6.,
+        'ppiw': False, 'ppiw_min_per_col_w': 0.001,
+        'da_blur': False, 'da_blur_prob': 0.5, 'da_blur_area': 0.3, 'da_blur_sigma': 1.,
+        'da_dot_bin_noise': False, 'da_dot_bin_noise_prob': 0.5, 'da_dot_bin_noise_area': 0.3, 'da_dot_bin_noise_p': 0.5,
+        'da_add_gaus_noise': False, 'da_add_gaus_noise_prob': 0.5, 'da_add_gaus_noise_area': 0.3,
+        'da_add_gaus_noise_std': 0.03,
         'eval_over_roi_also_ths': [4, 5, 6, 7, 8, 9, 10], 'outd': './out',
         # experiment-folder options (utils_config.py:98-126): where checkpoints / best models / images go and how
         # the best model is chosen
@@ -104,7 +118,9 @@ def get_config(net_type):
                   'norm_loc_var_type': constants.NORM2,
                   'G_optimizer_type': constants.ADAM, 'G_optimizer_lr': 2e-4, 'G_optimizer_wd': 1e-4,
                   'G_optimizer_beta1': 0.9, 'G_optimizer_beta2': 0.999, 'G_optimizer_eps_adam': 1e-8,
-                  'G_optimizer_momentum': 0.9, 'G_optimizer_nesterov': True, 'G_optimizer_amsgrad': False,
+                  'G_optimizer_momentum': 0.9, 'G_optimizer_nesterov': True,
+                  # clip_grad_norm_ in front of the optimizer and the moving-average network netE (utils_config.py:153,159,183)
+                  'G_optimizer_clipgrad': 0.0, 'E_decay': 0.0, 'E_param_strict': True,
                   'G_scheduler_type': constants.MYSTEPLR, 'G_scheduler_step_size': 30,
                   'G_scheduler_gamma': 0.5, 'G_scheduler_min_lr': 1e-4,
                   'G_scheduler_milestones': [250000, 400000],
@@ -115,6 +131,28 @@ def get_config(net_type):
     }
 
 
+# reference flags that select folders, logging, plotting or launcher plumbing: accepted, no effect on the numbers of a run
+IGNORED_FLAGS = {'debug_subfolder': str, 'exp_id': str, 'verbose': str2bool, 'fd_exp': str, 'num_workers': int,
+                 'plot_epoch_freq': int, 'synch_scratch_epoch_freq': int, 'local_rank': int, 'local_world_size': int,
+                 'init_method': str, 'world_size': int, 'is_train': str2bool,
+                 'amp_eval': str2bool,      # consumed by the WSOL inference code only (inference_wsol.py:246), not by this task
+                 'test_epoch_freq': int}
+# reference flags that change what a run computes and are NOT implemented here: only the reference's default passes
+# (utils_config.py:64-404), anything else is an error -- never a silently different run
+DEFAULT_ONLY_FLAGS = {
+    'G_regularizer_orthstep': (float, 0.0), 'G_regularizer_clipstep': (float, 0.0),        # model_plain.py:365-387
+    'G_optimizer_amsgrad': (str2bool, False),
+    'reconstruct_type': (str, 'low_res'), 'reconstruct_input': (str, 'fake'),
+    'net_task': (str, 'regression'), 'ce': (str2bool, False), 'ce_lambda': (float, None),
+    'augment': (str2bool, False), 'augment_nbr_steps': (int, None), 'augment_use_roi': (str2bool, None),
+    'train_n': (float, 1.0),
+}
+_RESIDUAL_TERMS = ('l1', 'l2', 'l2sum', 'charbonnier', 'boundpred', 'local_moments', 'img_grad', 'norm_img_grad', 'laplace',
+                   'norm_laplace', 'loc_var', 'norm_loc_var')
+for _t in _RESIDUAL_TERMS:                                  # <term>_use_residuals (dlib/loss/core.py): the image path only
+    DEFAULT_ONLY_FLAGS[f'{_t}_use_residuals'] = (str2bool, False)
+
+
 def parse_input(argv=None):
     pre = argparse.ArgumentParser(add_help=False)
     pre.add_argument('--net_type', type=str, default=constants.SWINIR)
@@ -122,7 +160,8 @@ def parse_input(argv=None):
     if net_type not in constants.MODELS:
         raise NotImplementedError(f'--net_type {net_type}: libsrhip runs {constants.MODELS}')
     cfg = get_config(net_type)
-    ap = argparse.ArgumentParser(description='SR-CACO-2 hot path on MI355X (libsrhip)')
+    ap = argparse.ArgumentParser(description='SR-CACO-2 hot path on MI355X (libsrhip)',
+                                 usage='main.py --net_type <net> --method <METHOD> [flags of the reference parser; -h lists them]')
     for k in ('task', 'net_type', 'method', 'dist_backend', 'cudaid', 'outd', 'train_dsets', 'valid_dsets',
               'test_dsets', 'data_root', 'splits_root', 'sample_tr_patch', 'sample_tr_patch_th_style',
               'save_dir_models', 'save_dir_imgs', 'basic_interpolation', 'model_select_mtr'):
@@ -130,8 +169,19 @@ def parse_input(argv=None):
     for k in ('scale', 'n_channels', 'h_size', 'batch_size', 'eval_bsize', 'myseed', 'max_epochs', 'max_iters',
               'sample_tr_patch_th', 'valid_n_samples'):
         ap.add_argument(f'--{k}', type=int, default=None)
-    for k in ('distributed', 'amp', 'eval_over_roi_also', 'eval_graph', 'train_graph', 'eval_over_roi_also_model_select'):
+    for k in ('distributed', 'amp', 'eval_over_roi_also', 'eval_graph', 'train_graph', 'eval_over_roi_also_model_select',
+              'use_interpolated_low', 'ppiw', 'da_blur', 'da_dot_bin_noise', 'da_add_gaus_noise'):
         ap.add_argument(f'--{k}', type=str2bool, default=None)
+    for k in ('inter_low_th', 'inter_low_sigma', 'ppiw_min_per_col_w', 'da_blur_prob', 'da_blur_area', 'da_blur_sigma',
+              'da_dot_bin_noise_prob', 'da_dot_bin_noise_area', 'da_dot_bin_noise_p', 'da_add_gaus_noise_prob',
+              'da_add_gaus_noise_area', 'da_add_gaus_noise_std'):
+        ap.add_argument(f'--{k}', type=float, default=None)
+    ap.add_argument('--init_pretrained_path', type=str, default=None)        # netG['init_pretrained_path'] (utils_config.py:146)
+    for k, t in IGNORED_FLAGS.items():
+        if k not in cfg['train']:
+            ap.add_argument(f'--{k}', type=t, default=None)
+    for k, (t, _) in DEFAULT_ONLY_FLAGS.items():
+        ap.add_argument(f'--{k}', type=t, default=None)
     for k, v in cfg['train'].items():
         t = str2bool if isinstance(v, bool) else (type(v) if not isinstance(v, list) else plus_list)
         if k in ('checkpoint_eval', 'checkpoint_save'):
@@ -162,12 +212,27 @@ def parse_input(argv=None):
                                       'img_range': float}}[net_type]
     for k, t in net_opts.items():
         ap.add_argument(f'--{nt}_{k}', type=t, default=None)
+    # <net>_init_type / _init_bn_type / _init_gain (select_network.py:285-289): the registry default 'default' keeps each
+    # module's own initialisation, which is what define_G does here; another initialiser is not implemented
+    init_defaults = {'init_type': (str, constants.INIT_W_DEFAULT), 'init_bn_type': (str, constants.INIT_BN_CONSTANT),
+                     'init_gain': (float, 1.0)}
+    for k, (t, _) in init_defaults.items():
+        ap.add_argument(f'--{nt}_{k}', type=t, default=None)
     ns, unknown = ap.parse_known_args(argv)
-    if unknown:   # the reference has ~300 flags; the ones for callers of the path are accepted and ignored
-        print(f'[main] ignoring flags outside the hot path: {unknown[::2]}', file=sys.stderr)
+    if unknown:
+        # the reference's parser is argparse.parse_args(): an unknown flag ends the run (and a key missing from the config
+        # raises ValueError, utils_parser.py:900-923) -- it is never skipped
+        ap.error(f"unrecognized arguments: {' '.join(unknown)} (not a flag of the reference's parser, or of a network other "
+                 f"than --net_type {net_type})")
+    for k, (_, dflt) in list(DEFAULT_ONLY_FLAGS.items()) + [(f'{nt}_{k}', v) for k, v in init_defaults.items()]:
+        v = getattr(ns, k)
+        if v is not None and dflt is not None and v != dflt:
+            ap.error(f"--{k} {v}: this option changes what the run computes and is not implemented on this path "
+                     f"(only the reference's default {dflt!r} is accepted)")
     # any non-None CLI value overrides the top-level / nested key (utils_parser.py:900-923)
+    skip = set(IGNORED_FLAGS) | set(DEFAULT_ONLY_FLAGS) | {f'{nt}_{k}' for k in init_defaults} | {'init_pretrained_path'}
     for k, v in vars(ns).items():
-        if v is None:
+        if v is None or (k in skip and k not in cfg['train']):
             continue
         if k in cfg['train']:
             cfg['train'][k] = v
@@ -178,6 +243,8 @@ def parse_input(argv=None):
                          f"({constants.NETTYPE_METHOD[net_type]})")
     # --amp True: evaluation (model.test / eval.py) runs the reduced-precision kernels; training stays fp32-accurate
     cfg['netG'] = init_net_g({'net_type': net_type}, cfg)
+    if ns.init_pretrained_path is not None:
+        cfg['netG']['init_pretrained_path'] = ns.init_pretrained_path
     for k in net_opts:
         v = getattr(ns, f'{nt}_{k}')
         if v is not None:
@@ -234,6 +301,11 @@ def _resume_point(args):
     args.netG['checkpoint_path_netG'] = path_g
     it_o, path_o = find_last_checkpoint(models, net_type='optimizerG')
     args.netG['checkpoint_path_optimizerG'] = path_o
+    if float(args.train.get('E_decay', 0.0) or 0.0) > 0:
+        # the reference leaves netE's resume as a todo (main.py:32; checkpoint_path_netE stays ''): a resumed run would restart
+        # its moving average from the current weights.  Here the newest <iter>_E.pth continues it.
+        _, path_e = find_last_checkpoint(models, net_type='E')
+        args.netG['checkpoint_path_netE'] = path_e
     return max(it_g, it_o)
 
 
@@ -329,7 +401,7 @@ def main(argv=None):
                       f"{seen / (time.perf_counter() - t0):8.1f} patches/s")
         if isinstance(n_save, int) and step % n_save == 0 and rank == 0 and step != args.max_iters:
             model.save(step)                                            # utils_trainer.py:403-411
-            clean_previous_checkpoints_except_last(model.save_dir, ['G', 'optimizerG'])
+            clean_previous_checkpoints_except_last(model.save_dir, ['G', 'optimizerG'] + (['E'] if model.E_decay > 0 else []))
     # evaluation sweep (utils_trainer.py:961-1032): PSNR / PSNR_Y / MSE / NRMSE / SSIM, optional ROI thresholds
     from dlib.utils.utils_trainer import _forward_with_padding
     model = _forward_with_padding(batch, model, args)          # SwinIR: flipped-strip padding to the next window multiple
@@ -346,7 +418,7 @@ def main(argv=None):
             print(msg)
         if args.max_iters > current_step:
             print('saved', model.save(args.max_iters))                  # <iter>_G.pth + <iter>_optimizerG.pth
-            clean_previous_checkpoints_except_last(model.save_dir, ['G', 'optimizerG'])
+            clean_previous_checkpoints_except_last(model.save_dir, ['G', 'optimizerG'] + (['E'] if model.E_decay > 0 else []))
     if args.distributed:
         import torch.distributed as dist
         dist.barrier()

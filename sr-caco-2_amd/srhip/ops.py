@@ -959,6 +959,21 @@ def tn_plan(M, NI, NJ, conv=False, bx=None):
     return S.value, n.value
 
 
+# Generation of the persistent buffers: bumped whenever a named buffer is REPLACED (a scratch buffer grown, an engine buffer
+# re-made for another shape) -- the old tensor goes back to torch's caching allocator while a captured hipGraph may still hold
+# its address.  TrainStep.step_graph / ModelPlain's evaluation graphs record it at capture and re-capture when it has moved
+# (a validation forward on a larger image between two replays grew 'fft2_ws' / 'nlsa_sort' under a captured step).
+_REALLOC_GEN = [0]
+
+
+def realloc_generation():
+    return _REALLOC_GEN[0]
+
+
+def note_realloc():
+    _REALLOC_GEN[0] += 1
+
+
 class Scratch:
     """Grow-only device scratch buffers keyed by name (caller-owned workspace of
     the C-ABI; reused across calls so the hot loop never allocates)."""
@@ -969,6 +984,8 @@ class Scratch:
     def get(self, name, n, dtype=torch.float32, device="cuda"):
         b = self.bufs.get(name)
         if b is None or b.numel() < n or b.dtype != dtype:
+            if b is not None:
+                note_realloc()
             b = torch.empty(max(int(n), 1), device=device, dtype=dtype)
             self.bufs[name] = b
         return b
@@ -1698,6 +1715,23 @@ def sgd_step_dc(p, g, buf, counter, lr, momentum=0.9, wd=0.0, nesterov=True, gsc
     _chk(p, g, buf, counter, skip_flag, lr_dev)
     call("srhip_sgd_step_dc", _p(p), _p(g), _p(buf), p.numel(), _p(counter), float(lr), float(momentum),
          float(wd), int(nesterov), float(gscale), _p(skip_flag), _p(lr_dev), _st())
+
+
+def grad_norm_clip(g, gscale, max_norm, norm_coef):
+    """clip_grad_norm_(max_norm, 2) over the flat gradient (model_plain.py:350-361): norm_coef[0] = ||g * gscale||_2,
+    norm_coef[1] = min(1, max_norm / (norm + 1e-6)), g *= norm_coef[1].  Device-resident, deterministic, capturable."""
+    _chk(g, norm_coef)
+    assert norm_coef.numel() >= 2 and norm_coef.dtype == torch.float32
+    wsb = lib.srhip_grad_norm_clip_ws()
+    ws = SCRATCH.get("clip_ws", wsb // 8, torch.float64, g.device)
+    call("srhip_grad_norm_clip", _p(g), g.numel(), float(gscale), float(max_norm), _p(norm_coef), _p(ws), wsb, _st())
+
+
+def ema_update(e, p, decay, skip_flag=None):
+    """e = e * decay + p * (1 - decay) (ModelBase.update_E, model_base.py:213-219); skipped on the device if *skip_flag."""
+    _chk(e, p, skip_flag)
+    assert e.numel() == p.numel()
+    call("srhip_ema_update", _p(e), _p(p), e.numel(), float(decay), _p(skip_flag), _st())
 
 
 def nonfinite_flag(x, flag):

@@ -31,11 +31,15 @@ class _Bufs:
     def get(self, key, *shape, device="cuda", dtype=torch.float32):
         t = self.d.get(key)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            if t is not None:
+                ops.note_realloc()      # a replaced buffer is freed: captured graphs holding its address must be re-made
             t = torch.empty(shape, device=device, dtype=dtype)
             self.d[key] = t
         return t
 
     def clear(self):
+        if self.d:
+            ops.note_realloc()
         self.d.clear()
 
 

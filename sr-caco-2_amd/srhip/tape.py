@@ -69,13 +69,25 @@ class _Pool:
 
     def __init__(self):
         self.all, self.free = {}, {}
+        self.used = set()
 
     def reset(self):
-        """every buffer free again (a new forward; whatever a forward without a backward left marked as taken included)"""
+        """every buffer free again (a new forward; whatever a forward without a backward left marked as taken included).
+        Shapes the LAST step never asked for (a ragged last batch, another patch size) are released here instead of staying
+        resident beside the current set -- SRFBN / DBPN sit near the HBM capacity at the README batch; a captured
+        step that held them is re-made (ops.note_realloc)."""
+        if self.used:
+            stale = [k for k in self.all if k not in self.used]
+            if stale:
+                for k in stale:
+                    del self.all[k]
+                ops.note_realloc()
+        self.used = set()
         self.free = {k: list(v) for k, v in self.all.items()}
 
     def take(self, shape, device):
         key = tuple(shape)
+        self.used.add(key)
         fl = self.free.get(key)
         if fl:
             return fl.pop()

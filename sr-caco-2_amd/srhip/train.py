@@ -312,7 +312,11 @@ class TrainStep:
     dlib/loss/master.py:46-56)."""
 
     def __init__(self, net, loss_terms=(("l1", 1.0),), optimizer=None, process_group=None,
-                 world_size=1):
+                 world_size=1, clipgrad=0.0, ema_decay=0.0):
+        """clipgrad > 0: torch.nn.utils.clip_grad_norm_(max_norm=clipgrad, norm_type=2) of the (averaged) gradient in front of
+        the optimizer (G_optimizer_clipgrad, model_plain.py:350-361).  ema_decay > 0: an exponential moving average of the
+        weights is kept in `self.ema_flat` (layout of fp.flat) and updated behind every applied step (E_decay, netE:
+        model_plain.py:46-47,393-394, model_base.py:213-219)."""
         self.net = net
         self.fp = FlatParams(net)
         net.weights_changed()
@@ -350,6 +354,37 @@ class TrainStep:
             self.inv_range = 1.0 / float(getattr(net, "img_range", 1.) or 1.)
         self._mean_img = None
         self.dy = None
+        self.clipgrad = float(clipgrad or 0.0)
+        # [global L2 norm of the last step's gradient (before clipping), the coefficient it was scaled by]
+        self.clip_state = torch.zeros(2, device=dev) if self.clipgrad > 0 else None
+        self.ema_decay = float(ema_decay or 0.0)
+        # update_E(0) at construction = a copy of the weights (model_plain.py:82-84); a checkpoint replaces it (ModelPlain.load)
+        self.ema_flat = self.fp.flat.clone() if self.ema_decay > 0 else None
+
+    def ema_state_dict(self):
+        """state_dict of the reference's netE (a second define_G instance whose PARAMETERS follow the moving average; its
+        buffers are never touched by update_E and stay what the constructor made: here the network's own constants)."""
+        from collections import OrderedDict
+        assert self.ema_flat is not None, "E_decay == 0: there is no netE"
+        fp = self.fp
+        out = OrderedDict()
+        for k, v in self.net.state_dict().items():
+            if k in fp.offsets:
+                o = fp.offsets[k]
+                out[k] = self.ema_flat[o:o + v.numel()].view_as(v).detach().cpu().clone()
+            else:
+                out[k] = v.detach().cpu().clone()
+        return out
+
+    def load_ema_state_dict(self, sd, strict=True):
+        fp = self.fp
+        missing = [k for k in fp.names if k not in sd]
+        if missing and strict:
+            raise KeyError(f"netE checkpoint misses {missing[:4]} ... ({len(missing)} parameters)")
+        for k in fp.names:
+            if k in sd:
+                o, n = fp.offsets[k], fp.gviews[k].numel()
+                self.ema_flat[o:o + n].copy_(sd[k].reshape(-1))
 
     def _make_buckets(self):
         """Gradient buckets in the order backward completes them (the engine names
@@ -444,6 +479,10 @@ class TrainStep:
                 raise NotImplementedError(f"step_graph: the loss term {t[0]!r} carries a host-side schedule (ELB t); use step()")
         key = (tuple(lr_img.shape), tuple(hr_img.shape), weight is not None)
         st = getattr(self, "_graph", None)
+        if st is not None and st["g"] is not None and st.get("gen") != ops.realloc_generation():
+            # a persistent buffer was replaced since the capture (an evaluation forward on a larger image grew a scratch
+            # buffer, another batch shape re-made an engine buffer): the graph holds freed addresses -- eager step, re-capture
+            st = self._graph = None
         if st is None or st["key"] != key:
             out = self.step(lr_img, hr_img, weight=weight)    # eager: allocates every buffer of this shape
             self._graph = {"key": key, "g": None, "lr": lr_img.clone(), "hr": hr_img.clone(),
@@ -461,6 +500,7 @@ class TrainStep:
             with torch.cuda.graph(g, capture_error_mode="thread_local" if self.ddp else "global"):
                 self._enqueue(st["lr"], st["hr"], None, host_side=False, weight=st["w"])
             st["g"] = g
+            st["gen"] = ops.realloc_generation()
         self.opt.step_count += 1
         self.opt.push_lr()
         st["g"].replay()
@@ -525,7 +565,11 @@ class TrainStep:
             if t[0] == "w_sparsity":         # x world because the optimizer divides the all-reduced sum by it
                 ops.l1_sparsity(self.fp.flat, t[1] * self.world, self.fp.grad, self._sink)
         torch.maximum(self.sticky, self.flag, out=self.sticky)
+        if self.clipgrad > 0:                # on the averaged gradient, as the reference clips behind DDP's all-reduce
+            ops.grad_norm_clip(self.fp.grad, 1.0 / self.world, self.clipgrad, self.clip_state)
         self.opt.step(gscale=1.0 / self.world, skip_flag=self.flag, host_side=host_side)
+        if self.ema_flat is not None:
+            ops.ema_update(self.ema_flat, self.fp.flat, self.ema_decay, self.flag)
         return self.loss_buf
 
     def loss_values(self):

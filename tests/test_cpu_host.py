@@ -28,6 +28,12 @@ def test_library_exports_every_declared_symbol():
     for doc in ("README.md", "DESIGN.md"):
         m = re.search(r'(\d+) `extern "C"` entry points', open(os.path.join(ROOT, doc)).read())
         assert m and int(m.group(1)) == len(protos), (doc, m and m.group(1), len(protos))
+    # the C-ABI is the ONLY thing the shipped library exports (built with -fvisibility=hidden; VERDICT r5: ~50 mangled C++
+    # symbols leaked): nm -D's defined functions == the header's prototypes, nothing else
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    funcs = sorted(line.split()[-1] for line in out.splitlines() if len(line.split()) == 3 and line.split()[1] in "TtWw")
+    if os.path.basename(_lib.LIB_PATH) == "libsrhip.so":
+        assert funcs == sorted(protos), (sorted(set(funcs) ^ set(protos)))
 
 
 def test_ctypes_structs_mirror_the_header(tmp_path):
@@ -389,6 +395,71 @@ def test_main_cli_contract():
         M.parse_input("--net_type CSRCNN --method CSRCNN".split())
     e = M.parse_input("--net_type EDSR_LIIF --method EDSR_LIIF --scale 4 --h_size 512".split())
     assert e.netG['EDSR_LIIF_n_resblocks'] == 16 and e.netG['EDSR_LIIF_upscale'] == 4
+
+
+def test_main_cli_says_no_instead_of_ignoring(capsys):
+    """VERDICT r5 item 4 (reference: argparse.parse_args + 'key not found' ValueError, utils_parser.py:884,900-923): a flag
+    that changes what a run computes is implemented, or an error -- never skipped.  Flags that only name folders / logging /
+    launcher plumbing pass without effect; implemented ones land in the configuration."""
+    sys.path.insert(0, os.path.join(ROOT, "sr-caco-2_amd"))
+    import main as M
+    base = "--net_type swinir --method SWINIR --scale 8".split()
+    a = M.parse_input(base + "--G_optimizer_clipgrad 1.0 --E_decay 0.999 --E_param_strict False --ppiw True --da_blur True "
+                             "--da_blur_sigma 2.0 --use_interpolated_low True --inter_low_sigma 5.0 --exp_id run7 --verbose True "
+                             "--num_workers 4 --local_rank 0 --swinir_init_type init_w_default --G_regularizer_orthstep 0 "
+                             "--l1_use_residuals False --init_pretrained_path /x/y.pth".split())
+    assert a.train['G_optimizer_clipgrad'] == 1.0 and a.train['E_decay'] == 0.999 and a.train['E_param_strict'] is False
+    assert a.ppiw is True and a.da_blur is True and a.da_blur_sigma == 2.0 and a.da_blur_prob == 0.5
+    assert a.use_interpolated_low is True and a.inter_low_sigma == 5.0 and a.inter_low_th == 7.0
+    assert a.netG['init_pretrained_path'] == '/x/y.pth'
+    for bad in ("--G_regularizer_orthstep 1", "--G_regularizer_clipstep 2", "--G_optimizer_amsgrad True",
+                "--swinir_init_type init_w_normal", "--swinir_init_gain 0.2", "--l1_use_residuals True", "--ce True",
+                "--augment True", "--reconstruct_type high_res", "--train_n 0.5", "--no_such_flag 1",
+                "--EDSR_LIIF_n_feats 32"):          # (another network's option)
+        with pytest.raises(SystemExit) as ei:
+            M.parse_input(base + bad.split())
+        assert ei.value.code == 2, bad
+        assert bad.split()[0] in capsys.readouterr().err
+    # the same through the command line: a non-zero exit before anything touches a GPU
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "sr-caco-2_amd", "main.py")] + base + ["--G_regularizer_orthstep", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "G_regularizer_orthstep" in r.stderr
+    # every flag of the reference's parser is known to this one (names as of utils_parser.py:33-880; per-net options apart)
+    ref_flags = ("cudaid myseed debug_subfolder task reconstruct_type reconstruct_input method is_train n_channels train_dsets "
+                 "valid_dsets test_dsets h_size valid_n_samples scale train_n batch_size eval_bsize num_workers exp_id verbose "
+                 "fd_exp save_dir_models save_dir_imgs init_pretrained_path basic_interpolation use_interpolated_low inter_low_th "
+                 "inter_low_sigma E_decay G_optimizer_type G_optimizer_lr G_optimizer_wd G_optimizer_clipgrad G_optimizer_reuse "
+                 "G_optimizer_momentum G_optimizer_nesterov G_optimizer_beta1 G_optimizer_beta2 G_optimizer_eps_adam "
+                 "G_optimizer_amsgrad G_scheduler_type G_scheduler_gamma G_scheduler_min_lr G_scheduler_step_size "
+                 "G_regularizer_orthstep G_regularizer_clipstep G_param_strict E_param_strict checkpoint_eval checkpoint_save "
+                 "test_epoch_freq plot_epoch_freq synch_scratch_epoch_freq max_epochs ppiw ppiw_min_per_col_w sample_tr_patch "
+                 "sample_tr_patch_th_style sample_tr_patch_th w_sparsity w_sparsity_lambda net_type net_task elb_init_t elb_max_t "
+                 "elb_mulcoef l1 l1_use_residuals l1_lambda l2 l2_use_residuals l2_lambda l2sum l2sum_use_residuals l2sum_lambda "
+                 "ssim ssim_lambda ssim_window_s charbonnier charbonnier_use_residuals charbonnier_lambda charbonnier_eps boundpred "
+                 "boundpred_use_residuals boundpred_lambda boundpred_eps boundpred_restore_range local_moments "
+                 "local_moments_use_residuals local_moments_lambda local_moments_ksz img_grad img_grad_use_residuals img_grad_lambda "
+                 "img_grad_norm norm_img_grad norm_img_grad_use_residuals norm_img_grad_lambda norm_img_grad_type laplace "
+                 "laplace_use_residuals laplace_lambda laplace_norm norm_laplace norm_laplace_use_residuals norm_laplace_lambda "
+                 "norm_laplace_type loc_var loc_var_ksz loc_var_use_residuals loc_var_lambda loc_var_norm norm_loc_var "
+                 "norm_loc_var_ksz norm_loc_var_use_residuals norm_loc_var_lambda norm_loc_var_type hist hist_lambda hist_sigma "
+                 "hist_metric kde kde_lambda kde_nbins kde_kde_bw kde_metric ce ce_lambda amp amp_eval distributed local_rank "
+                 "local_world_size init_method dist_backend world_size model_select_mtr augment augment_nbr_steps augment_use_roi "
+                 "eval_over_roi_also eval_over_roi_also_model_select da_blur da_blur_prob da_blur_area da_blur_sigma da_dot_bin_noise "
+                 "da_dot_bin_noise_prob da_dot_bin_noise_area da_dot_bin_noise_p da_add_gaus_noise da_add_gaus_noise_prob "
+                 "da_add_gaus_noise_area da_add_gaus_noise_std").split()
+    import argparse
+    known = set()
+    orig = argparse.ArgumentParser.add_argument
+
+    def spy(self, *names, **kw):
+        known.update(n[2:] for n in names if n.startswith('--'))
+        return orig(self, *names, **kw)
+    argparse.ArgumentParser.add_argument = spy
+    try:
+        M.parse_input(base)
+    finally:
+        argparse.ArgumentParser.add_argument = orig
+    assert not [f for f in ref_flags if f not in known], [f for f in ref_flags if f not in known]
 
 
 def test_sharded_sampler_matches_torch_distributed_sampler():

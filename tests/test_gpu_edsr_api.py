@@ -687,6 +687,109 @@ def test_model_plain_steps_match_oracle_training(tmp_path, opt):
     assert torch.equal(model.current_visuals()['E'], e1)
 
 
+@pytest.mark.parametrize("opt,graph", [("adam", False), ("sgd", True)])
+def test_model_plain_clipgrad_and_ema_match_oracle_training(tmp_path, opt, graph):
+    """G_optimizer_clipgrad + E_decay through the fused step (VERDICT r5 item 4; model_plain.py:350-361,393-394): three steps
+    == the oracle's autograd + clip_grad_norm (pinned against torch's / the reference's calls by g50) + optimizer + update_E,
+    parameter for parameter, eager and replayed from a hipGraph; <iter>_E.pth is netE's state_dict and resumes."""
+    from dlib.models.select_model import define_model
+    args = tiny_args(opt)
+    args['outd'] = str(tmp_path)
+    args['train_graph'] = graph
+    max_norm, decay = 0.05 if opt == "adam" else 0.4, 0.9
+    args['train'].update({'G_optimizer_clipgrad': max_norm, 'E_decay': decay})
+    model = define_model(args)
+    cfg = O.swinir_config(upscale=8, in_chans=1, img_size=16, window_size=8, depths=(2, 2), embed_dim=60,
+                          num_heads=(6, 6), mlp_ratio=2, drop_path_rate=0.0)
+    sd0 = O.swinir_init_state_dict(cfg, seed=9)
+    model.netG.load_state_dict(sd0, strict=True)
+    for b in model.netG.swin_blocks():
+        b.drop_prob = 0.0
+    model.init_train()
+    gen = torch.Generator().manual_seed(12)
+    batch = {'l_im': torch.rand(2, 1, 16, 16, generator=gen), 'h_im': torch.rand(2, 1, 128, 128, generator=gen)}
+    sdo = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and not k.endswith("attn_mask")
+               else v) for k, v in sd0.items()}
+    names = [k for k, v in sdo.items() if v.requires_grad]
+    st = {k: (torch.zeros_like(sdo[k]), torch.zeros_like(sdo[k])) for k in names}
+    ema = {k: sdo[k].detach().clone() for k in names}
+    clipped = []
+    for step in range(3):
+        model.feed_data(batch)
+        model.optimize_parameters(epoch=0, current_step=step)
+        lo = O.loss_l1(O.swinir_forward(sdo, batch['l_im'], cfg), batch['h_im'])
+        for k in names:
+            sdo[k].grad = None
+        lo.backward()
+        with torch.no_grad():
+            total, coef = O.clip_grad_norm([sdo[k].grad for k in names], max_norm)
+            clipped.append(float(coef) < 1.0)
+            norm_dev, coef_dev = model.step_fn.clip_state.tolist()
+            assert abs(norm_dev - float(total)) <= 2e-5 * float(total), (norm_dev, float(total))
+            assert abs(coef_dev - float(coef)) <= 2e-5
+            for k in names:
+                if opt == "adam":
+                    O.adam_step(sdo[k], sdo[k].grad, st[k][0], st[k][1], step + 1, 2e-4, wd=1e-4)
+                else:
+                    O.sgd_nesterov_step(sdo[k], sdo[k].grad, st[k][0], step == 0, 0.01)
+            O.ema_update([ema[k] for k in names], [sdo[k] for k in names], decay)
+    assert any(clipped), "the test's max_norm never clipped"
+    for k, p in model.netG.named_parameters():
+        e = (p.detach().cpu() - sdo[k].detach()).abs().max().item()
+        assert e <= 2e-6, f"{k}: {e}"
+    esd = model.step_fn.ema_state_dict()
+    assert list(esd.keys()) == list(sd0.keys())
+    for k in names:
+        e = (esd[k] - ema[k]).abs().max().item()
+        assert e <= 2e-6, f"netE {k}: {e}"
+    assert torch.equal(esd["layers.0.residual_group.blocks.0.attn.relative_position_index"],
+                       sd0["layers.0.residual_group.blocks.0.attn.relative_position_index"])
+    # <iter>_E.pth beside <iter>_G.pth, E-current_model.pth / E-model.pth; a new model resumes the average from it
+    model.save(3)
+    raw = torch.load(os.path.join(model.save_dir, "3_E.pth"))
+    assert list(raw.keys()) == list(sd0.keys()) and all(torch.equal(raw[k], esd[k]) for k in raw)
+    model.save_current(str(tmp_path / "cur"))
+    model.save_best(str(tmp_path / "best"), "model.pth")
+    assert os.path.isfile(tmp_path / "cur" / "E-current_model.pth") and os.path.isfile(tmp_path / "best" / "E-model.pth")
+    args2 = tiny_args(opt)
+    args2['outd'] = str(tmp_path)
+    args2['train'].update({'G_optimizer_clipgrad': max_norm, 'E_decay': decay})
+    args2['netG']['checkpoint_path_netE'] = os.path.join(model.save_dir, "3_E.pth")
+    m2 = define_model(args2)
+    m2.init_train()
+    e2 = m2.step_fn.ema_state_dict()
+    assert all(torch.equal(e2[k], esd[k]) for k in names)
+    # without E_decay there is no netE and no E file; clipgrad 0 leaves the step unclipped (clip_state absent)
+    args3 = tiny_args(opt)
+    args3['outd'] = str(tmp_path / "plain")
+    m3 = define_model(args3)
+    m3.init_train()
+    assert m3.step_fn.ema_flat is None and m3.step_fn.clip_state is None
+    m3.save(1)
+    assert not os.path.isfile(os.path.join(m3.save_dir, "1_E.pth"))
+
+
+def test_model_plain_refuses_what_it_does_not_implement(tmp_path):
+    """--amp True in training, G_regularizer_*: NotImplementedError, never a silently different run (VERDICT r5 weak #3)."""
+    from dlib.models.select_model import define_model
+    args = tiny_args("adam")
+    args['outd'] = str(tmp_path)
+    args['amp'] = True
+    model = define_model(args)
+    model.init_train()
+    model.feed_data({'l_im': torch.rand(2, 1, 16, 16), 'h_im': torch.rand(2, 1, 128, 128)})
+    with pytest.raises(NotImplementedError, match="amp"):
+        model.optimize_parameters(0, 0)
+    model.test()                                   # evaluation under --amp stays available
+    assert model.current_visuals()['E'].shape == (2, 1, 128, 128)
+    for k in ("G_regularizer_orthstep", "G_regularizer_clipstep"):
+        a = tiny_args("adam")
+        a['outd'] = str(tmp_path)
+        a['train'][k] = 10
+        with pytest.raises(NotImplementedError, match=k):
+            define_model(a)
+
+
 def test_model_plain_step_with_optional_loss_terms(tmp_path):
     """MasterLoss = Charbonnier + 0.5 * LocalVariation(5, NORM1) + 2 * NormImageGradient(NORM2) through the
     fused step (config keys of utils_config.py:301-357): loss values and the updated parameters against the

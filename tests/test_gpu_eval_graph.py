@@ -55,3 +55,52 @@ def test_eval_graph_replays_the_eager_forward(net_type, method, scale, extra):
     model.test()
     os.environ.pop("SRHIP_EVAL_GRAPH", None)
     assert torch.equal(got, model.E)
+
+
+@pytest.mark.parametrize("net_type,method,extra", [("DFCAN", "DFCAN", []), ("NLSN", "NLSN", ["--NLSN_n_resblocks", "4", "--NLSN_n_feats", "64"]),
+                                                   ("swinir", "SWINIR", ["--swinir_depths", "2+2", "--swinir_embed_dim", "60",
+                                                                         "--swinir_num_heads", "6+6"])])
+def test_captured_training_step_survives_a_larger_validation_forward(net_type, method, extra):
+    """the captured training step holds raw addresses of grow-only scratch buffers ('fft2_ws', 'gate_ws':
+    DFCAN; 'nlsa_sort', 'nlsa_ret': NLSN) and of the engines' named buffers; a validation forward on a LARGER image between
+    two replays re-allocates them.  The buffers carry a generation count now: the step notices, runs eagerly once and
+    re-captures.  Train (graph) -> test() on a larger image -> train again == the same sequence with eager steps."""
+    import main as M
+    from dlib.models.select_model import define_model
+    from srhip import ops
+    argv = ["--net_type", net_type, "--method", method, "--task", "super-resolution", "--scale", "2", "--n_channels", "1",
+            "--h_size", "64", "--batch_size", "2", "--G_optimizer_type", "sgd", "--G_optimizer_lr", "0.01"] + extra
+    results = []
+    for graph in (True, False):
+        torch.manual_seed(0)
+        model = define_model(M.parse_input(argv + ["--train_graph", str(graph)]))
+        model.init_train()
+        for b in getattr(model.netG, "swin_blocks", lambda: [])():
+            b.drop_prob = 0.0
+        small = M.synth_batch(2, 2, 64, model.device, 3)
+        big = M.synth_batch(2, 2, 192, model.device, 5)
+        outs = []
+        for it in range(3):                  # eager (buffers), capture + replay, replay
+            torch.manual_seed(100 + it)      # NLSN draws its LSH rotations from the global generator
+            model.feed_data(small)
+            model.optimize_parameters(0, it)
+        if graph:
+            assert model.step_fn._graph is not None and model.step_fn._graph["g"] is not None
+            gen0 = ops.realloc_generation()
+        torch.manual_seed(7)
+        model.feed_data(big)
+        model.test()                         # grows the scratch buffers / re-makes the engine's evaluation buffers
+        outs.append(model.E.clone())
+        if graph:
+            assert ops.realloc_generation() != gen0, "the larger forward replaced no buffer: the test does not test"
+        for it in range(3, 6):
+            torch.manual_seed(100 + it)
+            model.feed_data(small)
+            model.optimize_parameters(0, it)
+        torch.cuda.synchronize()
+        assert model.check_finite()
+        if graph:
+            assert model.step_fn._graph["g"] is not None         # re-captured
+        results.append((outs[0], model.step_fn.fp.flat.clone()))
+    assert torch.equal(results[0][0], results[1][0])
+    assert torch.equal(results[0][1], results[1][1]), (results[0][1] - results[1][1]).abs().max().item()

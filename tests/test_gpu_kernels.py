@@ -528,6 +528,82 @@ def test_optimizers(ops):
     assert flag.item() == 1
 
 
+def test_grad_norm_clip_and_ema_kernels(ops):
+    """srhip_grad_norm_clip / srhip_ema_update against the reference's own calls (tests/golden/g50_clip_ema.npz: torch's
+    clip_grad_norm_ -> optimizer.step() -> ModelBase.update_E, model_plain.py:350-361,393-394) on the flat layout of the
+    training step (tensors padded to 16 bytes), then at the README net's size against the oracle; NaN norms propagate as
+    torch's clamp does; a set skip flag leaves netE alone; world-size scaling of the norm."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g50_clip_ema.npz"))
+    max_norm, decay = float(g["max_norm"]), float(g["decay"])
+    shapes = [g[f"p0/{j}"].shape for j in range(3)]
+    offs, off = [], 0
+    for sh in shapes:
+        offs.append(off)
+        off += (int(np.prod(sh)) + 3) // 4 * 4
+
+    def flat(prefix):
+        f = torch.zeros(off)
+        for j, sh in enumerate(shapes):
+            f[offs[j]:offs[j] + int(np.prod(sh))] = torch.from_numpy(g[f"{prefix}/{j}"]).reshape(-1)
+        return f
+    for name in ("adam", "sgd"):
+        p, e = dev(flat("p0")), dev(flat("p0"))
+        m, v = torch.zeros(off).cuda(), torch.zeros(off).cuda()
+        nc = torch.zeros(2).cuda()
+        for step in range(3):
+            gr = dev(flat(f"g/{step}"))
+            ops.grad_norm_clip(gr, 1.0, max_norm, nc)
+            ref_norm = float(g[f"{name}/norms"][step])
+            assert abs(nc[0].item() - ref_norm) <= 2e-6 * ref_norm
+            assert (nc[1].item() == 1.0) == (ref_norm + 1e-6 <= max_norm)
+            if name == "adam":
+                ops.adam_step(p, gr, m, v, step + 1, 2e-4, wd=1e-4)
+            else:
+                ops.sgd_step(p, gr, m, 0.01, first=(step == 0))
+            ops.ema_update(e, p, decay)
+            assert (p.cpu() - flat(f"{name}/p/{step}")).abs().max() < 5e-7, (name, step)
+            assert (e.cpu() - flat(f"{name}/e/{step}")).abs().max() < 5e-7, (name, step)
+    n = 7865884 + 36                                         # the README SwinIR's flat gradient
+    gr = rnd(n) * 1e-3
+    go = [gr.clone()]
+    total, coef = O.clip_grad_norm(go, 0.5)
+    d = dev(gr)
+    nc = torch.zeros(2).cuda()
+    ops.grad_norm_clip(d, 1.0, 0.5, nc)
+    assert abs(nc[0].item() - float(total)) <= 2e-6 * float(total) and abs(nc[1].item() - float(coef)) <= 1e-6
+    assert (d.cpu() - go[0]).abs().max() <= 1e-6 * go[0].abs().max()
+    d2 = dev(gr * 4)                                          # the SUM of four ranks' gradients: norm of g / 4
+    ops.grad_norm_clip(d2, 0.25, 0.5, nc)
+    assert abs(nc[0].item() - float(total)) <= 2e-6 * float(total)
+    assert (d2.cpu() * 0.25 - go[0]).abs().max() <= 1e-6 * go[0].abs().max()
+    a1, a2 = dev(gr), dev(gr)                                 # bit-identical from run to run (fixed-order reduction)
+    n1, n2 = torch.zeros(2).cuda(), torch.zeros(2).cuda()
+    ops.grad_norm_clip(a1, 1.0, 0.5, n1)
+    ops.grad_norm_clip(a2, 1.0, 0.5, n2)
+    assert torch.equal(a1, a2) and torch.equal(n1, n2)
+    bad = gr.clone()
+    bad[12345] = float("nan")
+    db = dev(bad)
+    ops.grad_norm_clip(db, 1.0, 0.5, nc)
+    assert math.isnan(nc[0].item()) and math.isnan(nc[1].item()) and torch.isnan(db).all()     # clip_grad_norm_'s behaviour
+    e0 = rnd(1000)
+    e, p = dev(e0), dev(rnd(1000))
+    flag = torch.ones(1, dtype=torch.int32).cuda()
+    ops.ema_update(e, p, 0.999, flag)
+    assert torch.equal(e.cpu(), e0)
+    flag.zero_()
+    ops.ema_update(e, p, 0.999, flag)
+    eo = [e0.clone()]
+    O.ema_update(eo, [p.cpu()], 0.999)
+    assert (e.cpu() - eo[0]).abs().max() <= 1e-7
+    ops.ema_update(e, p, 0.0)                                 # update_E(0): a copy (model_plain.py:82-84)
+    assert torch.equal(e, p)
+    with pytest.raises(RuntimeError):
+        ops.grad_norm_clip(dev(gr), 1.0, 0.0, nc)             # max_norm must be positive
+
+
 def test_errors_are_loud(ops):
     with pytest.raises(RuntimeError):
         ops.gemm_nt(torch.zeros(4, 6).cuda(), torch.zeros(4, 6).cuda())       # K % 4 != 0

@@ -588,6 +588,41 @@ def test_step_graph_replays_the_eager_step_bit_for_bit(SwinIR):
     assert host_ms < 2.0 and torch.isfinite(ts.loss_buf).all()
 
 
+def test_step_graph_with_droppath_follows_the_per_step_seed(SwinIR):
+    """ModelPlain replays the step from a hipGraph by default and the trainer re-seeds every rank with
+    myseed + current_step before each iteration (utils_trainer.py:359-361, main.py): the captured torch.bernoulli of
+    sample_drop_path must draw from the CURRENT seed at every replay, not from the capture-time one.  drop_path_rate 0.5
+    on the tiny net (so that masks differ between steps with near certainty), re-seeded before every step: graph and eager
+    trajectories are bit-identical, and consecutive steps do not repeat a mask."""
+    from srhip.train import TrainStep, Optimizer
+    cfg = O.swinir_config(upscale=8, in_chans=1, img_size=16, window_size=8, depths=(2, 2), embed_dim=60,
+                          num_heads=(6, 6), mlp_ratio=2, drop_path_rate=0.5)
+    sd0 = O.trained_like_(O.swinir_init_state_dict(cfg, seed=91), 92, lin_scale=3.0)
+    gen = torch.Generator().manual_seed(93)
+    batch = (torch.rand(4, 1, 16, 16, generator=gen).cuda(), torch.rand(4, 1, 128, 128, generator=gen).cuda())
+    runs = []
+    for mode in ("eager", "graph"):
+        net = tiny(SwinIR, dpr=0.5)
+        net.load_state_dict(sd0, strict=True)
+        net = net.cuda().train()
+        assert max(b.drop_prob for b in net.swin_blocks()) == 0.5
+        ts = TrainStep(net, [("l1", 1.0)])
+        ts.opt = Optimizer(ts.fp, "sgd", lr=0.01, momentum=0.9, nesterov=True, wd=0.0)
+        losses = []
+        for it in range(8):
+            torch.manual_seed(1000 + it)                     # the trainer's per-iteration seed
+            (ts.step if mode == "eager" else ts.step_graph)(*batch)
+            losses.append(ts.loss_buf.clone())
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses).cpu(), ts.fp.flat.clone().cpu()))
+    assert torch.equal(runs[0][0], runs[1][0]), (runs[0][0][:, 0] - runs[1][0][:, 0]).abs().max()
+    assert torch.equal(runs[0][1], runs[1][1])
+    # the same batch every step: a repeated mask would repeat the loss up to the (small) weight change; masks that differ
+    # move it by far more -- at least one consecutive pair must differ visibly in the replayed run
+    l = runs[1][0][:, 0]
+    assert (l[1:] - l[:-1]).abs().max() > 1e-3 * l.abs().max(), l
+
+
 DDP_WORKER = r'''
 import os, sys, socket, torch, torch.distributed as dist
 root = sys.argv[1]
