@@ -17,8 +17,9 @@ optimizer on one synthetic batch of 8 patches per GPU:
 
 Rank 0 prints ONE JSON line.  ``value`` = patches of all ranks / wall time of exactly K steps between
 barrier + synchronize pairs (max over ranks); ``step_ms`` = median / p10 / p90 of the per-step durations
-from HIP events recorded on the compute stream; ``roofline`` = the dominant kernel class timed live with
-HIP events inside the timed region (one of every twenty steps); ``cpu_baseline`` = the oracle (PyTorch-fp32
+from HIP events recorded on the compute stream; ``roofline`` = the dominant KERNEL (largest summed launch time) timed
+live with HIP events around every launch of three eager steps run right BEHIND the timed region (events cannot be recorded
+inside a hipGraph replay and an event pair slows a step: the timed K steps carry none); ``cpu_baseline`` = the oracle (PyTorch-fp32
 CPU restatement, validated against the reference) timed on the host cores on a bounded sample, B=1 and B=8.
 """
 import argparse
@@ -52,6 +53,9 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (TrainStep.step_graph) also under data "
                     "parallelism; on ONE GPU that is the default since round 5 (what ModelPlain.optimize_parameters does)")
     ap.add_argument("--no-graph", action="store_true", help="eager steps only")
+    ap.add_argument("--droppath-per-rank", action="store_true", help="every rank draws its own DropPath masks; default: all "
+                    "ranks draw the same ones, as the reference's trainer seeds every rank with myseed + current_step "
+                    "(utils_trainer.py:359-361)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the EDSR x8 / x4 / x2 lines under config.secondary")
@@ -454,7 +458,9 @@ def worker(args):
     else:
         ts.opt = Optimizer(ts.fp, "adam", lr=2e-4, wd=1e-4)
     lr_img, hr_img = synth_batch(args.batch, scale, dev, seed=1000 + rank)
-    torch.manual_seed(1234 + rank)            # DropPath masks differ per rank (every rank of the reference draws its own)
+    # DropPath masks: the reference re-seeds EVERY rank with myseed + current_step (utils_trainer.py:359-361), i.e. the same
+    # masks on all ranks; --droppath-per-rank gives each rank its own stream
+    torch.manual_seed(1234 + (rank if args.droppath_per_rank else 0))
 
     def barrier():
         if pg is not None:
@@ -464,9 +470,9 @@ def worker(args):
 
     # The step replayed from a hipGraph (bit for bit the eager step; one host call instead of ~330 launches): the default on
     # one GPU since round 5 -- the product entry point (ModelPlain.optimize_parameters) does the same; --graph asks for it
-    # under data parallelism too (the RCCL bucket all-reduces are captured with the step), --no-graph for eager steps.  The
-    # one step in twenty that carries the roofline's per-launch HIP events runs eagerly (events cannot be recorded inside a
-    # replay); a capture that fails falls back to eager steps for the whole run.
+    # under data parallelism too (the RCCL bucket all-reduces are captured with the step), --no-graph for eager steps.  A
+    # capture that fails falls back to eager steps for the whole run.  The steps that carry the roofline's per-launch HIP
+    # events run eagerly BEHIND the timed region (round 6; VERDICT r5 item 5: one of them used to sit inside it).
     use_graph = (args.graph or world == 1) and not args.no_graph
     gpu_legs = {}                     # wall seconds of every leg that keeps the GPU busy (synchronize-bracketed)
     t_leg = time.perf_counter()
@@ -484,23 +490,37 @@ def worker(args):
     step_fn = ts.step_graph if use_graph else ts.step
     barrier()
     gpu_legs["warmup"] = time.perf_counter() - t_leg
-    if not args.no_roofline:
-        probe.enable(kinds)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        # HIP events around every launch of the probed op classes in ONE of every twenty steps (an
-        # event pair is two barrier packets: a probed step runs ~18 % slower, so probing all of
-        # them would cost the headline number), taken mid-run
-        probed = not args.no_roofline and i % 20 == 10 % max(args.steps, 1)
-        probe.active = set(kinds) if probed else None
+    for i in range(args.steps):               # the timed region: exactly K steps of the step function, nothing else
         marks[i].record()
-        (ts.step if probed else step_fn)(lr_img, hr_img)
+        step_fn(lr_img, hr_img)
     marks[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
     gpu_legs["timed_steps"] = dt
-    probe.active = set(kinds)
+    # behind the timed region: the same step eagerly (what the earlier rounds' headline timed; ADVICE r5: both methodologies
+    # in the line), then three eager steps with HIP events around every launch of the probed op classes (an event pair is two
+    # barrier packets: a probed step runs ~18 % slower)
+    eager_pps = None
+    if use_graph and not args.no_roofline:
+        t_leg = time.perf_counter()
+        n_eager = min(10, args.steps)
+        ts.step(lr_img, hr_img)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_eager):
+            ts.step(lr_img, hr_img)
+        barrier()
+        eager_pps = args.batch * world * n_eager / (time.perf_counter() - t1)
+        gpu_legs["eager_steps"] = time.perf_counter() - t_leg
+    if not args.no_roofline:
+        t_leg = time.perf_counter()
+        probe.enable(kinds)
+        for _ in range(3):
+            ts.step(lr_img, hr_img)
+        barrier()
+        gpu_legs["probed_steps"] = time.perf_counter() - t_leg
     # PMC traffic of THIS workload's kernels (profiles/, collected with tools/refresh_profiles.sh)
     for r in (9, 8, 7, 6, 5, 4, 3, 2):
         tj = os.path.join(ROOT, "profiles", f"r0{r}_hbm_traffic_per_kernel_{args.workload.replace('swinir_x8', 'swinir')}_b8.json")
@@ -591,6 +611,10 @@ def worker(args):
             "config": {"workload": f"{desc}, fwd + {args.loss} + bwd + {opt_kind}",
                        "global_batch": args.batch * world, "batch_per_gpu": args.batch,
                        "parallelism": f"dp{world}", "final_loss": loss, "hip_graph": bool(use_graph),
+                       # `value` is measured on step_fn: graph replay when hip_graph is true; the same K-step protocol on eager
+                       # steps (the methodology of rounds 1-4) beside it
+                       "eager_patches_per_s": eager_pps,
+                       "droppath_masks": "per rank" if args.droppath_per_rank else "same on every rank (reference seeding)",
                        "eval_patches_per_s_one_gpu": eval_pps, "eval_amp_patches_per_s_one_gpu": eval_amp_pps,
                        "matmul": (("Linear GEMMs: fp16x2 split MFMA (2 fp16 planes per operand under per-row power-of-two "
                                    "scales, 3 products, f32 accumulate: f32-grade per row), the 180-channel convs (scales per "

@@ -167,6 +167,22 @@ int srhip_conv3x3_nhwc_split_ex(int wfmt, const float* X, long ldx, const void* 
                                 int B, int H, int W, int Cin, int Cout, int epi, const float* R, long ldr,
                                 const float* rowscale, float alpha, const float* in_bn_coef, const float* slope,
                                 void* stream);
+/* One EDSR ResBlock (64 -> 64 -> 64 channels) per launch (resblock.hip) -- ResBlock.forward,
+ * dlib/models/network_nlsn.py:72-93 (conv -> ReLU -> conv, .mul(res_scale), += x) and its data gradient:
+ *   forward :  a  = relu(conv3x3(x; W1) + b1)  [B][H][W][lda]   (saved: the weight gradients and the backward read it)
+ *              out = x + res_scale * (conv3x3(a; W2) + b2)
+ *   backward:  da = res_scale * conv3x3(g; W2^T) * (a > 0)      (the first conv's weight gradient reads it)
+ *              dx = g + conv3x3(da; W1^T)
+ * The second conv runs from LDS on the first one's tile (+ a one-pixel ring, recomputed per tile): one launch, one halo
+ * fetch, no read-back of a / da.  W*h: fp16x2 conv operands of srhip_prep_table kind 4 for 64 -> 64 channels (the
+ * backward takes the data-gradient forms: flipped taps, transposed channels -- what srhip_conv3x3_nhwc_f16x2 takes for
+ * the same job).  Arithmetic of srhip_conv3x3_nhwc_f16x2: two fp16 planes, three products, f32 accumulate; the mid tile
+ * under one power-of-two exponent of its own.  out / a must not alias x (dx / da: g). */
+int srhip_resblock64_fwd_f16x2(const float* x, long ldx, const void* W1h, const float* b1, const void* W2h, const float* b2,
+                               float res_scale, float* a, long lda, float* out, long ldout, int B, int H, int W, void* stream);
+int srhip_resblock64_bwd_f16x2(const float* g, long ldg, const void* W2Th, const void* W1Th, const float* a, long lda,
+                               float res_scale, float* da, long ldda, float* dx, long lddx, int B, int H, int W, void* stream);
+
 /* ---- fp16-STORAGE inference of the plain conv family (--amp at evaluation time; eval_all.sh's sweep, select_network.py:52-210):
  * activations NHWC fp16 in HBM, the weight = the leading fp16 plane of the srhip_conv3x3_nhwc_f16x2 operand (job kind 4; ps2:
  * mode 12), ONE fp16 MFMA product, f32 accumulate, fp16 out.  Cin a multiple of 32, Cout of 64 (ps2: of 256), pitches multiples
@@ -205,7 +221,9 @@ int srhip_conv3x3_ps2_bwd_data_f16x2(const float* dYup, long lddy, const void* W
  *             out = x + s * (gelu(h) . W2^T + b2), stats_out = {mean, rstd} of the out rows (may be NULL);
  *             h may be NULL (inference), otherwise it is what the backward reads.
  *   backward: dh = (s * dy . W2) * gelu'(h), gh = gelu(h)  (both [M][ldh], operands of the weight gradients),
- *             dx = dy + LayerNorm-backward(dh . W1)  (x, stats as in the forward).
+ *             dx = dy + LayerNorm-backward(dh . W1)  (x, stats as in the forward).  gh may be NULL: the fc2 weight
+ *             gradient then takes h itself with b_mode 2 (srhip_tn_problem: gelu applied in the operand prologue, the
+ *             same x Phi(x) bit for bit) -- 4 * M * hidden bytes less written per block.
  * Operands as the Linear GEMMs take them: two fp16 planes + per-row power-of-two scales (srhip_prep_table kind 3,
  * no permutation), three products; rowscale = DropPath multipliers per sample.  W1h = planes of W1*gamma
  * [hidden][C], W2h = planes of W2 [C][hidden]; backward W2Th = planes of W2^T [hidden][C], W1Th = planes of
@@ -776,6 +794,29 @@ int srhip_grad_norm_clip(float* g, long n, float gscale, float max_norm, float* 
  * e = e * decay + p * (1 - decay) over the flat parameter buffer.  Skipped on the device when *skip_flag != 0 (the
  * reference returns from the step before update_E on a non-finite loss, model_plain.py:344-346). */
 int srhip_ema_update(float* e, const float* p, long n, float decay, const int* skip_flag, void* stream);
+/* ---- data-parallel gradient exchange (comm.hip): what DistributedDataParallel's reducer does for the reference
+ * (dlib/models/model_base.py:135-142), for a caller that is not PyTorch.  One process per GPU; one communicator per process
+ * (RCCL over xGMI; resolved with dlopen at the first call -- the copy PyTorch bundles if the process has one, else ROCm's
+ * librccl.so.1; never loaded by a process that does not call these).
+ *   srhip_allreduce_unique_id   one rank (by convention 0) fills 128 bytes; the caller carries them to every rank (file /
+ *                               socket / MPI -- its own rendezvous)
+ *   srhip_allreduce_init        every rank, on its CURRENT device (hipSetDevice first): *comm = an opaque handle
+ *   srhip_allreduce_bucket_async  in-place SUM over the ranks of buf[0 .. n) (a contiguous range of the flat gradient, in
+ *                               backward-completion order), enqueued on comm_stream BEHIND everything enqueued on
+ *                               compute_stream so far (one event); returns at once.  The optimizer divides by the world
+ *                               size (gscale of srhip_adam_step / srhip_sgd_step).
+ *   srhip_allreduce_flag_async  the same with MAX over one int: the step's non-finite flag (srhip_nonfinite_flag), so that
+ *                               every rank skips the same update
+ *   srhip_allreduce_wait        compute_stream waits for every exchange enqueued on comm_stream so far (in front of the
+ *                               optimizer launch); nothing blocks the host
+ *   srhip_allreduce_destroy
+ * All calls of one communicator come from one thread, in the same order on every rank (RCCL's rule). */
+int srhip_allreduce_unique_id(void* id128);
+int srhip_allreduce_init(const void* id128, int rank, int world_size, void** comm);
+int srhip_allreduce_bucket_async(void* comm, float* buf, long n, void* compute_stream, void* comm_stream);
+int srhip_allreduce_flag_async(void* comm, int* flag, void* compute_stream, void* comm_stream);
+int srhip_allreduce_wait(void* comm, void* comm_stream, void* compute_stream);
+int srhip_allreduce_destroy(void* comm);
 /* flag[0] |= any(!isfinite(x)): one device flag instead of the reference's
  * per-tensor host syncs (dlib/utils/tools.py:28-63, model_plain.py:344). */
 int srhip_nonfinite_flag(const float* x, long n, int* flag, void* stream);

@@ -190,7 +190,7 @@ int srhip_wmsa_fwd_f16x2(const float* x, const float* stats, const void* Wqkvh, 
 int srhip_mlp_bwd_f16x2(const float* dy, long lddy, const void* W2Th, const void* W1Th, const float* h, long ldh,
                         float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
                         int M, int C, int hidden, const float* rowscale, int rows_per_scale, void* stream) {
-  SR_REQUIRE(dy && W2Th && W1Th && h && dh && gh && x && stats && dx, "mlp_bwd_f16x2: null operand");
+  SR_REQUIRE(dy && W2Th && W1Th && h && dh && x && stats && dx, "mlp_bwd_f16x2: null operand");
   SR_REQUIRE(!rowscale || rows_per_scale > 0, "mlp_bwd_f16x2: rows_per_scale must be > 0");
   SR_REQUIRE(sr_matmul_mode() == 0, "mlp_bwd_f16x2: f32-accurate matmul mode only");
   MlpF16Args p;
@@ -209,7 +209,7 @@ int srhip_mlp_bwd_chain_f16x2(const float* dy, long lddy, const void* W2Th, cons
                               float* dh, float* gh, const float* x, long ldx, const float* stats, float* dx, long lddx,
                               int M, int C, int hidden, const float* rowscale, int rows_per_scale, const void* W3h,
                               float* out3, long ld3, const float* rowscale3, void* stream) {
-  SR_REQUIRE(dy && W2Th && W1Th && h && dh && gh && x && stats && dx && W3h && out3, "mlp_bwd_chain_f16x2: null operand");
+  SR_REQUIRE(dy && W2Th && W1Th && h && dh && x && stats && dx && W3h && out3, "mlp_bwd_chain_f16x2: null operand");
   SR_REQUIRE((!rowscale && !rowscale3) || rows_per_scale > 0, "mlp_bwd_chain_f16x2: rows_per_scale must be > 0");
   SR_REQUIRE(ld3 % 4 == 0 && out3 != dx, "mlp_bwd_chain_f16x2: out3 pitch must be a multiple of 4 floats, out3 != dx");
   SR_REQUIRE(sr_matmul_mode() == 0, "mlp_bwd_chain_f16x2: f32-accurate matmul mode only");
@@ -232,7 +232,7 @@ int srhip_mlp_bwd_front_chain_f16x2(const float* X0, long ld0, int K0, const voi
                                     const float* x, long ldx, const float* stats, float* dx, long lddx, int M, int C,
                                     int hidden, const float* rowscale, int rows_per_scale, const void* W3h, float* out3,
                                     long ld3, const float* rowscale3, void* stream) {
-  SR_REQUIRE(X0 && W0h && x0 && stats0 && res0 && dy && W2Th && W1Th && h && dh && gh && x && stats && dx,
+  SR_REQUIRE(X0 && W0h && x0 && stats0 && res0 && dy && W2Th && W1Th && h && dh && x && stats && dx,
              "mlp_bwd_front_chain_f16x2: null operand");
   SR_REQUIRE(K0 > 0 && K0 % 4 == 0 && ld0 % 4 == 0 && ldx0 % 4 == 0 && ldres0 % 4 == 0,
              "mlp_bwd_front_chain_f16x2: K0 and the front pitches must be multiples of 4 floats");
@@ -294,6 +294,35 @@ int srhip_conv3x3_nhwc_split_ex(int wfmt, const float* X, long ldx, const void* 
   SR_REQUIRE(wfmt == 0 || wfmt == 1, "conv3x3_split_ex: weight format %d (0 three bf16 planes, 1 two fp16 planes)", wfmt);
   SR_REQUIRE(wfmt == 0 || ((Cout <= 4096 || Cout % 180 == 0) && Cin <= 4096), "conv3x3_f16x2: Cout <= 4096 or a multiple of 180, Cin <= 4096 (Cout=%d Cin=%d)", Cout, Cin);
   return conv3x3_split(wfmt, X, ldx, Wp, bias, Y, ldy, B, H, W, Cin, Cout, epi, R, ldr, rowscale, alpha, stream, in_bn_coef, slope);
+}
+
+int srhip_resblock64_fwd_f16x2(const float* x, long ldx, const void* W1h, const float* b1, const void* W2h, const float* b2,
+                               float res_scale, float* a, long lda, float* out, long ldout, int B, int H, int W, void* stream) {
+  SR_REQUIRE(x && W1h && b1 && W2h && b2 && a && out, "resblock64_fwd: null operand");
+  SR_REQUIRE(ldx % 4 == 0 && lda % 4 == 0 && ldout % 4 == 0 && ldx >= 64 && lda >= 64 && ldout >= 64,
+             "resblock64_fwd: pixel pitches must be multiples of 4 floats, >= 64");
+  SR_REQUIRE(out != x && a != x, "resblock64_fwd: out / a must not alias x (neighbouring tiles read its halo)");
+  SR_REQUIRE((long)B * H * W * ldx < (1L << 30), "resblock64_fwd: input beyond 4 GB");
+  SR_REQUIRE(sr_matmul_mode() == 0, "resblock64_fwd: f32-accurate matmul mode only");
+  ResBlockArgs p;
+  memset(&p, 0, sizeof(p));
+  p.X = x; p.ldx = ldx; p.W1 = W1h; p.W2 = W2h; p.b1 = b1; p.b2 = b2; p.Mid = a; p.ldmid = lda; p.Out = out; p.ldout = ldout;
+  p.rs = res_scale; p.batch = B; p.H = H; p.Wd = W;
+  return sr_resblock64(p, 0, (hipStream_t)stream);
+}
+int srhip_resblock64_bwd_f16x2(const float* g, long ldg, const void* W2Th, const void* W1Th, const float* a, long lda,
+                               float res_scale, float* da, long ldda, float* dx, long lddx, int B, int H, int W, void* stream) {
+  SR_REQUIRE(g && W2Th && W1Th && a && da && dx, "resblock64_bwd: null operand");
+  SR_REQUIRE(ldg % 4 == 0 && lda % 4 == 0 && ldda % 4 == 0 && lddx % 4 == 0 && ldg >= 64 && lda >= 64 && ldda >= 64 && lddx >= 64,
+             "resblock64_bwd: pixel pitches must be multiples of 4 floats, >= 64");
+  SR_REQUIRE(dx != g && da != g && da != a, "resblock64_bwd: dx / da must not alias g, da must not alias a");
+  SR_REQUIRE((long)B * H * W * ldg < (1L << 30), "resblock64_bwd: input beyond 4 GB");
+  SR_REQUIRE(sr_matmul_mode() == 0, "resblock64_bwd: f32-accurate matmul mode only");
+  ResBlockArgs p;
+  memset(&p, 0, sizeof(p));
+  p.X = g; p.ldx = ldg; p.W1 = W2Th; p.W2 = W1Th; p.Mask = a; p.ldmask = lda; p.Mid = da; p.ldmid = ldda; p.Out = dx; p.ldout = lddx;
+  p.rs = res_scale; p.batch = B; p.H = H; p.Wd = W;
+  return sr_resblock64(p, 1, (hipStream_t)stream);
 }
 
 int srhip_conv3x3_nhwc_h16(const void* X, long ldx, const void* Wh, const float* bias, void* Y, long ldy, int B, int H, int W,

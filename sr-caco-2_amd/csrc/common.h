@@ -33,6 +33,15 @@ static inline const char* sr_getenv(const char*) { return nullptr; }
 #define SR_DEBUG_EXPORT extern "C"
 #endif
 
+// Stores of tensors nobody reads again before they have left every cache (saved activations of a training step: h, dh,
+// gelu(h), qkv): with -DSRHIP_NT they carry the `nt` (streaming) hint, so that they do not push the rows a kernel re-reads
+// (residual rows, its own attention output) out of the L2.  A build variant (make EXTRA=-DSRHIP_NT=1): measured, see DESIGN.
+#ifdef SRHIP_NT
+#define SR_ST_STREAM(PTR, VAL) __builtin_nontemporal_store((VAL), (PTR))
+#else
+#define SR_ST_STREAM(PTR, VAL) (*(PTR) = (VAL))
+#endif
+
 static inline int sr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Neutral operands for optional per-row prologue data.  A conditional load whose
@@ -127,6 +136,28 @@ __device__ __forceinline__ float dgelu_f(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
   return cdf + x * pdf;
+}
+
+// x Phi(x) on PAIRS with one exp per element (Abramowitz & Stegun 7.1.26, |Phi error| <= 1.5e-7): the activation of the fused
+// MLP kernels (mlp_f16.hip) and of the weight-gradient prologue that recomputes gelu(h) from the saved pre-activation
+// (gemm_tnb.hip, b_mode 2) -- one definition, so both see the same bits.
+// The same two functions on PAIRS (v_pk_mul / v_pk_fma / v_pk_add_f32: two lanes' worth of f32 arithmetic per issue slot).
+// The activation phase runs no MFMA and is bound by vector issue (96 hidden units per lane x ~17 instructions): packed,
+// the non-transcendental part is half the slots.  (Beside MFMAs packed f32 is an anti-lever -- the library is built with
+// -fno-slp-vectorize for that -- so the packing is explicit and only here.)
+__device__ __forceinline__ sr_f32x2 gelu_poly2(sr_f32x2 x, sr_f32x2& e1) {
+  const sr_f32x2 ax = sr_f32x2{fabsf(x.x), fabsf(x.y)};
+  const sr_f32x2 q = (x * x) * (-0.5f * 1.44269504088896340736f);        // exp(-x^2 / 2) = 2^q
+  e1 = sr_f32x2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+  const sr_f32x2 d = ax * (0.3275911f * 0.70710678118654752440f) + 1.0f;
+  const sr_f32x2 t = sr_f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const sr_f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const sr_f32x2 om = 1.0f - poly * e1;
+  return sr_f32x2{copysignf(om.x, x.x), copysignf(om.y, x.y)} * 0.5f + 0.5f;        // Phi(x)
+}
+__device__ __forceinline__ sr_f32x2 gelu_fast2(sr_f32x2 x) {
+  sr_f32x2 e1;
+  return x * gelu_poly2(x, e1);
 }
 
 // 32x32x2 f32 MFMA: exact f32 fma chain (MI355X_MICROARCH "Matrix cores").

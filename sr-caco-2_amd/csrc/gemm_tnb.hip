@@ -640,7 +640,7 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int j = 0; j < W; ++j) { x[o][t][j].x = gelu_f(x[o][t][j].x); x[o][t][j].y = gelu_f(x[o][t][j].y); }
+          for (int j = 0; j < W; ++j) x[o][t][j] = gelu_fast2(x[o][t][j]);     // the MLP forward's own x Phi(x), packed
       }
     }
     // the columns' maxima over the chunk's 32 tokens (this lane's 16 and lane ^ 32's), the running scales, the factors
@@ -984,12 +984,12 @@ __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const in
     load(m_begin + 2 * TK3, sg0);
     __syncthreads();
     for (int c = 0; c < nch; c += 2) {
-      if (DBG != 2) {
+      if (DBG != 2 && DBG != 5) {
         store(smem + BUF, sg1);                  // chunk c+1
         load(m_begin + (c + 3) * TK3, sg1);
       }
       __syncthreads();
-      if (DBG != 2) {
+      if (DBG != 2 && DBG != 5) {
         store(smem, sg0);                        // chunk c+2
         load(m_begin + (c + 4) * TK3, sg0);
       }
@@ -1001,6 +1001,11 @@ __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const in
     }
   } else {
     __syncthreads();
+    u32x4 g5[8];
+    if (DBG == 5) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g5[q] = *(const u32x4*)(smem + q * 1024 + lane * 16);
+    }
     for (int c = 0; c < nch; ++c) {
       const unsigned char* cur = smem + (c & 1) * BUF;
       if constexpr (F16) {
@@ -1019,11 +1024,13 @@ __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const in
               for (int q = 0; q < 16; ++q) acc[k][q] *= fa_[q] * fb;
             }
           }
-          const u32x4 ah = *(const u32x4*)(cur + a_off), al = *(const u32x4*)(cur + PLANE + a_off);
+          // DBG 5 (experiments): no fragment reads -- the operands are whatever the registers of `g5` hold (read once in front
+          // of the loop): what remains per chunk is the flag word, nine MFMAs and the barrier
+          const u32x4 ah = DBG == 5 ? g5[0] : *(const u32x4*)(cur + a_off), al = DBG == 5 ? g5[1] : *(const u32x4*)(cur + PLANE + a_off);
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            const u32x4 bh = *(const u32x4*)(cur + b_off[k]);
-            const u32x4 bl = *(const u32x4*)(cur + PLANE + b_off[k]);
+            const u32x4 bh = DBG == 5 ? g5[2 + k] : *(const u32x4*)(cur + b_off[k]);
+            const u32x4 bl = DBG == 5 ? g5[5 + k] : *(const u32x4*)(cur + PLANE + b_off[k]);
             acc[k] = mfma_h(al, bh, acc[k]);
             acc[k] = mfma_h(ah, bl, acc[k]);
             acc[k] = mfma_h(ah, bh, acc[k]);
@@ -1171,6 +1178,7 @@ __global__ void __launch_bounds__(512, 1) k_tnb_grouped_h(TnbGroup g) {
   const bool even = p.NI % W == 0 && p.NJ % W == 0 && p.i_tile % W == 0 && p.j_tile % W == 0;   // no ragged W-tuples
   if (even && p.b_mode == 1 && !p.a_rowscale) tnb_body_h<W, 1, false, true>(p, slice, t - t0, smem);     // LayerNorm-folded Linears
   else if (even && p.b_mode == 0 && p.a_rowscale) tnb_body_h<W, 0, true, true>(p, slice, t - t0, smem); // DropPath-scaled gradients
+  else if (even && p.b_mode == 2 && p.a_rowscale) tnb_body_h<W, 2, true, true>(p, slice, t - t0, smem); // fc2: gelu(h) recomputed
   else tnb_body_h<W>(p, slice, t - t0, smem);
 }
 
@@ -1357,6 +1365,15 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
       if (int rc = reserve_lds(k_tnb3<0>, lds_bytes3(), "k_tnb3")) return rc;
       attr3 = true;
     }
+#ifdef SRHIP_EXPERIMENTS
+    {   // role ablations (wrong results on purpose; tools/mb_tnb3.py): 1 = consumers skip their MFMAs, 2 = producers neither load nor store
+      const char* e = sr_getenv("SRHIP_TN_DBG");
+      const int dbg = e ? atoi(e) : 0;
+      if (dbg == 1 && tnb_f16()) { hipLaunchKernelGGL((k_tnb3<1, true>), dim3(p.S * tiles * 3), dim3(512), lds_bytes3(), st, p, tiles, xcd); return 0; }
+      if (dbg == 2 && tnb_f16()) { hipLaunchKernelGGL((k_tnb3<2, true>), dim3(p.S * tiles * 3), dim3(512), lds_bytes3(), st, p, tiles, xcd); return 0; }
+      if (dbg == 5 && tnb_f16()) { hipLaunchKernelGGL((k_tnb3<5, true>), dim3(p.S * tiles * 3), dim3(512), lds_bytes3(), st, p, tiles, xcd); return 0; }
+    }
+#endif
     if (tnb_f16()) hipLaunchKernelGGL((k_tnb3<0, true>), dim3(p.S * tiles * 3), dim3(512), lds_bytes3(), st, p, tiles, xcd);
     else hipLaunchKernelGGL((k_tnb3<0>), dim3(p.S * tiles * 3), dim3(512), lds_bytes3(), st, p, tiles, xcd);
     SR_LAUNCH_CHECK("k_tnb3");

@@ -47,6 +47,19 @@ struct NtArgs {
   long zA[2], zW[2], zC[2];
 };
 
+// one EDSR ResBlock (64 channels) per launch, forward or data gradient (resblock.hip)
+struct ResBlockArgs {
+  const float* X; long ldx;            // stage-1 input, NHWC [batch][H][Wd][ldx]: x (forward) / the incoming gradient g (backward)
+  const void* W1; const void* W2;      // fp16x2 conv operands (prep kind 4) of the first / second conv of the launch
+  const float* b1; const float* b2;    // forward: the convs' biases; backward: unused
+  const float* Mask; long ldmask;      // backward: the saved activation a (ReLU mask of stage 1)
+  float* Mid; long ldmid;              // stage-1 result: a (forward) / da (backward)
+  float* Out; long ldout;              // x + rs (conv(a) + b2)  /  g + conv(da)
+  float rs;
+  int batch, H, Wd, tiles_x, tiles_y, k_rot;
+};
+int sr_resblock64(ResBlockArgs& p, int bwd, hipStream_t st);
+
 // fp16-storage conv of the evaluation path (conv_h16.hip)
 struct ConvH16Args {
   const _Float16* X; long ldx;       // NHWC fp16 [B][H][Wd][ldx]

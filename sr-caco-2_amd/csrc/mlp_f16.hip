@@ -88,24 +88,9 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return x * (0.5f * (1.0f + copysignf(1.0f - poly * e1, x)));
 }
 
-// The same two functions on PAIRS (v_pk_mul / v_pk_fma / v_pk_add_f32: two lanes' worth of f32 arithmetic per issue slot).
-// The activation phase runs no MFMA and is bound by vector issue (96 hidden units per lane x ~17 instructions): packed,
-// the non-transcendental part is half the slots.  (Beside MFMAs packed f32 is an anti-lever -- the library is built with
-// -fno-slp-vectorize for that -- so the packing is explicit and only here.)
-__device__ __forceinline__ sr_f32x2 gelu_poly2(sr_f32x2 x, sr_f32x2& e1) {
-  const sr_f32x2 ax = sr_f32x2{fabsf(x.x), fabsf(x.y)};
-  const sr_f32x2 q = (x * x) * (-0.5f * 1.44269504088896340736f);        // exp(-x^2 / 2) = 2^q
-  e1 = sr_f32x2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
-  const sr_f32x2 d = ax * (0.3275911f * 0.70710678118654752440f) + 1.0f;
-  const sr_f32x2 t = sr_f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-  const sr_f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const sr_f32x2 om = 1.0f - poly * e1;
-  return sr_f32x2{copysignf(om.x, x.x), copysignf(om.y, x.y)} * 0.5f + 0.5f;        // Phi(x)
-}
-__device__ __forceinline__ sr_f32x2 gelu_fast2(sr_f32x2 x) {
-  sr_f32x2 e1;
-  return x * gelu_poly2(x, e1);
-}
+// gelu_poly2 / gelu_fast2 (the same two functions on PAIRS of f32: v_pk_mul / v_pk_fma / v_pk_add_f32) live in common.h --
+// the grouped weight-gradient launch applies the SAME x Phi(x) to the saved pre-activations in its operand prologue, so the
+// backward no longer stores gelu(h).
 __device__ __forceinline__ void gelu_gate2(sr_f32x2 x, sr_f32x2& gate, sr_f32x2& gl) {
   sr_f32x2 e1;
   const sr_f32x2 cdf = gelu_poly2(x, e1);
@@ -566,7 +551,7 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
             if (!BWD) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = v[e] * (rix[i] * wi[e]) + bv[e];
-              if (p.H && ok) *(f32x4*)(p.H + (long)gm[i] * p.ldh + unit0) = v;
+              if (p.H && ok) SR_ST_STREAM((f32x4*)(p.H + (long)gm[i] * p.ldh + unit0), v);
               {
                 const sr_f32x2 g0 = gelu_fast2(sr_f32x2{v[0], v[1]}), g1 = gelu_fast2(sr_f32x2{v[2], v[3]});
                 v = uok ? f32x4{g0.x, g0.y, g1.x, g1.y} : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -584,8 +569,8 @@ __global__ void __launch_bounds__(256, 2) k_mlp_f16(MlpF16Args p) {
                 for (int e = 0; e < 4; ++e) v[e] = uok ? v[e] * (rix[i] * wi[e] * dps[i]) * gt[e] : 0.f;
               }
               if (ok) {
-                *(f32x4*)(p.dH + (long)gm[i] * p.ldh + unit0) = v;
-                *(f32x4*)(p.GH + (long)gm[i] * p.ldh + unit0) = gl;
+                SR_ST_STREAM((f32x4*)(p.dH + (long)gm[i] * p.ldh + unit0), v);
+                if (p.GH) SR_ST_STREAM((f32x4*)(p.GH + (long)gm[i] * p.ldh + unit0), gl);     // NULL: the weight gradient recomputes it from h
               }
             }
             acc1[hh][i][j] = v;

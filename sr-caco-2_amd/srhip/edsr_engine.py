@@ -44,6 +44,10 @@ class EDSREngine:
         # no shuffle launches); SRHIP_FUSE_PS=0: conv + index kernel
         self.fuse_ps = self.ws.use_bx3 and ops.ps2_fusable(self.F, 4 * self.F) and \
             os.environ.get("SRHIP_FUSE_PS", "1") != "0"
+        # One launch per ResBlock and direction (resblock.hip: conv -> ReLU -> conv -> + skip from LDS, round 6) instead of two:
+        # SRHIP_FUSE_RESBLOCK=0 keeps the two conv launches.  64-feature nets on the fp16x2 conv operands only.
+        self.fuse_rb = self.ws.use_bx3 and ops.resblock64_fusable(self.F) and \
+            os.environ.get("SRHIP_FUSE_RESBLOCK", "1") != "0"
 
     def invalidate(self):
         self.prepared = False
@@ -133,13 +137,19 @@ class EDSREngine:
         r = f0
         blocks = []
         rs = float(net.res_scale)
+        fuse_rb = self.fuse_rb and not ops.lib.srhip_get_matmul_mode() and \
+            ops.resblock64_fusable(F, self.ws["b0.0.wp"] if self.nb else None)
         for k in range(self.nb):
             kk = k if save else k % 2
             a = buf(f"a{kk if save else 0}", B, H, W, F)
-            ops.conv3x3(r, self.ws[f"b{k}.0.wp"], net.body[k].body[0].bias.data, F, out=a, epi=1)
             rn = buf(f"r{kk}", B, H, W, F)
-            ops.conv3x3(a, self.ws[f"b{k}.2.wp"], net.body[k].body[2].bias.data, F, out=rn, epi=2, R=r,
-                        alpha=rs)
+            if fuse_rb:
+                ops.resblock64_fwd(r, self.ws[f"b{k}.0.wp"], net.body[k].body[0].bias.data, self.ws[f"b{k}.2.wp"],
+                                   net.body[k].body[2].bias.data, rs, a, rn)
+            else:
+                ops.conv3x3(r, self.ws[f"b{k}.0.wp"], net.body[k].body[0].bias.data, F, out=a, epi=1)
+                ops.conv3x3(a, self.ws[f"b{k}.2.wp"], net.body[k].body[2].bias.data, F, out=rn, epi=2, R=r,
+                            alpha=rs)
             if save:
                 blocks.append((r, a))
             r = rn
@@ -262,6 +272,8 @@ class EDSREngine:
             gs = [ga if (self.nb - k) % 2 == 0 else gb for k in range(self.nb + 1)]
             das = [da1] * self.nb
         g = gs[self.nb]
+        fuse_rb = self.fuse_rb and not ops.lib.srhip_get_matmul_mode() and \
+            ops.resblock64_fusable(F, self.ws["b0.0.wpt"] if self.nb else None) and batched
         ops.conv3x3(drb, self.ws["bend.wpt"], None, F, out=g)
         for k in reversed(range(self.nb)):
             r_in, a = sv["blocks"][k]
@@ -269,6 +281,11 @@ class EDSREngine:
             other, da = gs[k], das[k]
             # r_out = rs*(conv2(a)+b2) + r_in ;  a = relu(conv1(r_in)+b1)
             wgrad(g, a, p + "2.weight", p + "2.bias")
+            if fuse_rb:          # both data gradients of the block in one launch (da leaves for the weight gradient)
+                ops.resblock64_bwd(g, self.ws[f"b{k}.2.wpt"], self.ws[f"b{k}.0.wpt"], a, rs, da, other)
+                wgrad(da, r_in, p + "0.weight", p + "0.bias")
+                g = other
+                continue
             ops.conv3x3(g, self.ws[f"b{k}.2.wpt"], None, F, out=da, epi=4, R=a)     # * (a > 0)
             if rs != 1.0:
                 ops.axpby(da, da, 0.0, rs)

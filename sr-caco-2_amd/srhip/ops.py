@@ -758,7 +758,8 @@ def mlp_fwd_f16(x, stats, W1, b1, W2, b2, out, h=None, rowscale=None, rows_per_s
             _p(stats_out), _st())
     if probe.on("mlp_fused"):
         with probe.timed(("mlp_fused", M, C, hidden, "fwd"), 4.0 * M * C * hidden,
-                         4.0 * (M * (2 * C + (hidden if h is not None else 0)) + 2 * C * hidden)):
+                         4.0 * (M * (2 * C + (hidden if h is not None else 0)) + 2 * C * hidden),
+                         kernel="k_mlp_f16<false", lb_bytes=4.0 * (M * 2 * C + 2 * C * hidden)):
             call("srhip_mlp_fwd_f16x2", *args)
     else:
         call("srhip_mlp_fwd_f16x2", *args)
@@ -787,7 +788,8 @@ def wmsa_fwd_f16(x, stats, Wq, bq, Wp, bp, biasF, qkv, att, out, B, H, W, heads,
             _p(att), _p(out), _p(stats_out), B, H, W, C, heads, shift, _st())
     if probe.on("wmsa_fused"):
         with probe.timed(("wmsa_fused", T, C, heads, "fwd"), 2.0 * T * C * 4 * C + 4.0 * T * 64 * C,
-                         4.0 * (T * 6 * C + 4 * C * C)):
+                         4.0 * (T * ((6 if qkv is not None else 3) * C) + 4 * C * C),
+                         kernel="k_wmsa_f16h", lb_bytes=4.0 * (T * 2 * C + 4 * C * C)):
             call("srhip_wmsa_fwd_f16x2", *args)
     else:
         call("srhip_wmsa_fwd_f16x2", *args)
@@ -805,7 +807,9 @@ def mlp_bwd_f16(dy, W2T, W1T, h, dh, gh, x, stats, dx, rowscale=None, rows_per_s
     M, C = dy.shape
     hidden = h.shape[1]
     assert W2T.fmt == 1 and W1T.fmt == 1 and (W2T.rows, W2T.K) == (hidden, C) and (W1T.rows, W1T.K) == (C, hidden)
-    assert dh.shape == h.shape == gh.shape and dh.stride(0) == h.stride(0) == gh.stride(0)
+    # gh None: gelu(h) is not stored -- the fc2 weight gradient reads h with b_mode=2 (linear_wgrad_grouped)
+    assert dh.shape == h.shape and dh.stride(0) == h.stride(0)
+    assert gh is None or (gh.shape == h.shape and gh.stride(0) == h.stride(0))
     assert x.shape == (M, C) and dx.shape == (M, C)
     args = (_p(dy), dy.stride(0), _p(W2T.planes), _p(W1T.planes), _p(h), h.stride(0), _p(dh), _p(gh), _p(x),
             x.stride(0), _p(stats), _p(dx), dx.stride(0), M, C, hidden, _p(rowscale), rows_per_scale, _st())
@@ -830,8 +834,12 @@ def mlp_bwd_f16(dy, W2T, W1T, h, dh, gh, x, stats, dx, rowscale=None, rows_per_s
         k0 = front[0].shape[1] if front is not None else 0
         with probe.timed(("mlp_fused", M, C, hidden, tag),
                          4.0 * M * C * hidden + (0 if chain is None else 2.0 * M * C * C) + 2.0 * M * C * k0,
-                         4.0 * (M * (3 * C + 3 * hidden + (C if chain is not None else 0) + (k0 + 2 * C if front else 0))
-                                + 2 * C * hidden)):
+                         4.0 * (M * (3 * C + (3 if gh is not None else 2) * hidden + (C if chain is not None else 0)
+                                     + (k0 + 2 * C if front else 0)) + 2 * C * hidden),
+                         kernel="k_mlp_f16<true",
+                         # fused bound: incoming / outgoing gradients, the block's saved input rows, weights -- not h / dh / gelu(h)
+                         lb_bytes=4.0 * (M * (3 * C + (C if chain is not None else 0) + (k0 + 2 * C if front else 0))
+                                         + 2 * C * hidden + (C * C if chain is not None else 0) + C * k0)):
             call(name, *args)
     else:
         call(name, *args)
@@ -1087,6 +1095,51 @@ def linear_wgrad_grouped(problems):
 def ps2_fusable(Cin, Cout):
     """conv Cin -> Cout followed by PixelShuffle(2) as one kernel per direction (conv3x3_ps2*)?"""
     return use_bx3() and Cout % 256 == 0 and Cin % 4 == 0 and Cin <= 128 and bx3_for(Cout, Cin) and bx3_nt_for(Cout, Cin)
+
+
+def resblock64_fusable(F, Wp=None):
+    """The one-launch ResBlock kernels (resblock.hip) take 64 -> 64 -> 64 channels on fp16x2 conv operands."""
+    return F == 64 and F16X2_CONV and (Wp is None or (isinstance(Wp, Bx3) and Wp.fmt == 1))
+
+
+def resblock64_fwd(x, W1, b1, W2, b2, res_scale, a, out):
+    """a = relu(conv3x3(x; W1) + b1), out = x + res_scale * (conv3x3(a; W2) + b2) in ONE kernel (ResBlock.forward,
+    network_nlsn.py:72-93).  x, a, out NHWC [B,H,W,64]; W1 / W2: fp16x2 conv operands (PrepTable.conv)."""
+    _chk(x, b1, b2, a, out)
+    B, H, W, C = x.shape
+    assert C == 64 and a.shape == x.shape == out.shape and x.stride(3) == 1 and x.stride(1) == W * x.stride(2)
+    assert all(isinstance(w, Bx3) and w.fmt == 1 and (w.rows, w.K) == (9 * 64, 64) for w in (W1, W2))
+    def run():
+        call("srhip_resblock64_fwd_f16x2", _p(x), x.stride(2), _p(W1.planes), _p(b1), _p(W2.planes), _p(b2), float(res_scale),
+             _p(a), a.stride(2), _p(out), out.stride(2), B, H, W, _st())
+    if probe.on("conv_nt"):
+        T = B * H * W
+        with probe.timed(("conv_nt", T, 64, 64, "resblock fwd"), 2 * 18.0 * T * 64 * 64, 4.0 * (3 * T * 64 + 2 * 9 * 64 * 64),
+                         kernel="k_resblock64<false"):
+            run()
+    else:
+        run()
+    return out
+
+
+def resblock64_bwd(g, W2T, W1T, a, res_scale, da, dx):
+    """da = res_scale * conv3x3(g; W2^T) * (a > 0), dx = g + conv3x3(da; W1^T) in ONE kernel: the data gradient of
+    resblock64_fwd.  W2T / W1T: the data-gradient conv operands (PrepTable.conv(data_grad=True))."""
+    _chk(g, a, da, dx)
+    B, H, W, C = g.shape
+    assert C == 64 and a.shape == g.shape == da.shape == dx.shape and g.stride(3) == 1 and g.stride(1) == W * g.stride(2)
+    assert all(isinstance(w, Bx3) and w.fmt == 1 and (w.rows, w.K) == (9 * 64, 64) for w in (W2T, W1T))
+    def run():
+        call("srhip_resblock64_bwd_f16x2", _p(g), g.stride(2), _p(W2T.planes), _p(W1T.planes), _p(a), a.stride(2),
+             float(res_scale), _p(da), da.stride(2), _p(dx), dx.stride(2), B, H, W, _st())
+    if probe.on("conv_nt"):
+        T = B * H * W
+        with probe.timed(("conv_nt", T, 64, 64, "resblock bwd"), 2 * 18.0 * T * 64 * 64, 4.0 * (4 * T * 64 + 2 * 9 * 64 * 64),
+                         kernel="k_resblock64<true"):
+            run()
+    else:
+        run()
+    return dx
 
 
 def conv3x3_ps2(X, Wp, bias, out, epi=0, alpha=1.0):

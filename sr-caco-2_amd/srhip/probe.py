@@ -26,6 +26,7 @@ BX3_MFMA_PEAK_TFLOPS = 2500.0 / 6.0
 HBM_PEAK_GBS = 8000.0
 active = None           # None | set of kinds being timed in the current step
 _records = {}
+_meta = {}              # key -> (kernel name stem | None, fused-lower-bound bytes per launch)
 
 
 def enable(kinds):
@@ -59,8 +60,12 @@ def on(kind):
 class timed:
     """with probe.timed(("gemm_nt", M, N, K), flops, bytes): launch..."""
 
-    def __init__(self, key, flops, nbytes=0.0):
+    def __init__(self, key, flops, nbytes=0.0, kernel=None, lb_bytes=None):
+        """kernel: name stem of THE kernel behind this launch (rocprofv3 / PMC tables are keyed by kernel name);
+        lb_bytes: SURVEY 8d's fused lower bound for the launch -- only the op's inputs, outputs and weights touch HBM,
+        no saved intermediate -- beside nbytes, the operand bytes this launch is designed to move."""
         self.key, self.flops, self.nbytes = key, flops, nbytes
+        _meta[key] = (kernel, nbytes if lb_bytes is None else lb_bytes)
 
     def __enter__(self):
         self.a = torch.cuda.Event(enable_timing=True)
@@ -125,9 +130,32 @@ def _pmc_traffic(kernel_stem):
     return None, None
 
 
+def _pmc_mfma_busy(kernel_stem):
+    """MFMA-busy share (SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)) of the kernels whose name contains
+    kernel_stem, from the committed, hash-matched profiles/r0N_mfma_busy_per_kernel_<workload>_b8.json (tools/step_mfma_pmc.sh).
+    None if not collected for THIS build of the kernels."""
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    want = os.environ.get("SRHIP_TRAFFIC_JSON")
+    if not want:
+        return None, None
+    path = want.replace("hbm_traffic_per_kernel", "mfma_busy_per_kernel")
+    if not os.path.isfile(path):
+        return None, None
+    table = json.load(open(path))
+    if table.get("_meta", {}).get("csrc_sha16") != csrc_hash():
+        return None, None
+    tot = n = 0.0
+    for name, v in table.items():
+        if name != "_meta" and kernel_stem in name and "mfma_busy_frac_at_2.4GHz" in v:
+            tot += v["mfma_busy_frac_at_2.4GHz"] * v["launches"]
+            n += v["launches"]
+    return (tot / n, os.path.basename(path)) if n else (None, None)
+
+
 def collect():
-    """Dominant op class (largest summed launch time) -> roofline dict.  avg_launch_us is the
-    mean over all its timed launches, i.e. the figure rocprofv3 --stats reports for its kernel."""
+    """Dominant KERNEL -- the (op class, instantiation, shape) key with the largest summed launch time -> roofline dict
+    (round 6; the class sum rides along under `class_*`).  avg_launch_us is the mean over its timed launches, i.e. the figure
+    rocprofv3 --stats reports for that kernel."""
     torch.cuda.synchronize()
     from . import ops
     # what an event pair measures with NOTHING between its records: the part of avg_launch_us that is not the kernel
@@ -150,8 +178,16 @@ def collect():
         g[4][" ".join(str(v) for v in key[1:])] = {"launches": len(evs), "avg_us": 1000.0 * ms / len(evs)}
     if not per_kind:
         return None
-    kind, (ms, fl, by, n, classes) = max(per_kind.items(), key=lambda kv: kv[1][0])
+    # the dominant kernel: one key = one kernel instantiation at one shape
+    per_key = {key: (sum(a.elapsed_time(b) for a, b, _, _ in evs), sum(e[2] for e in evs), sum(e[3] for e in evs), len(evs))
+               for key, evs in _records.items()}
+    dom_key, (ms, fl, by, n) = max(per_key.items(), key=lambda kv: kv[1][0])
+    kind = dom_key[0]
+    class_ms, class_fl, class_by, class_n, classes = per_kind[kind]
     stem, what = _KERNEL_OF_KIND.get(kind, (kind, kind))
+    kname, lb_per_launch = _meta.get(dom_key, (None, by / n))
+    if kname:
+        stem = kname
     tf = fl / (ms * 1e-3) / 1e12
     gbs = by / (ms * 1e-3) / 1e9
     bx = ops.use_bx3() and kind not in _F32_KINDS
@@ -182,7 +218,8 @@ def collect():
            "frac": gbs / HBM_PEAK_GBS if hbm_bound else tf / peak,
            "mfma_side": {"achieved_tflops": tf, "peak_tflops": peak, "frac": tf / peak},
            "traffic": traffic, "traffic_source": src,
-           "kernel": f"{stem.split('|')[0]}*: {what}; {arith}", "launches": n, "avg_launch_us": 1000.0 * ms / n,
+           "kernel": f"{stem.split('|')[0]}*: {what}; {arith}", "kernel_key": " ".join(str(v) for v in dom_key),
+           "launches": n, "avg_launch_us": 1000.0 * ms / n,
            # achieved / frac above are priced on avg_launch_us as measured (conservative); an empty event pair on this
            # stream reads event_pair_us, so the kernel itself takes about avg_launch_us - event_pair_us -- the figure to
            # hold against rocprofv3's average duration in profiles/
@@ -190,6 +227,13 @@ def collect():
            "algorithmic_gflop_per_launch": fl / n / 1e9,
            "algorithmic_mbytes_per_launch": by / n / 1e6,
            "hbm_side": {"achieved_gb_per_s_algorithmic": gbs, "frac_of_8tb_per_s": gbs / HBM_PEAK_GBS},
+           # two accountings of the same launch: `frac` prices the operand bytes the kernel is DESIGNED to
+           # move (saved activations of a training step included); this one SURVEY 8d's fused lower bound (inputs, outputs,
+           # weights only) -- against the same binding roof
+           "fused_lower_bound_mbytes_per_launch": lb_per_launch / 1e6,
+           "frac_vs_fused_lower_bound": max(lb_per_launch / (HBM_PEAK_GBS * 1e9), fl / n / (peak * 1e12)) / (ms / n * 1e-3),
+           "class": {"kind": kind, "launches": class_n, "summed_ms": class_ms,
+                     "frac": max(class_by / (HBM_PEAK_GBS * 1e9), class_fl / (peak * 1e12)) / (class_ms * 1e-3)},
            "probed_ms": {k: v[0] for k, v in per_kind.items()},
            "share_of_probed_time": {k: v[0] / sum(x[0] for x in per_kind.values()) for k, v in per_kind.items()},
            "classes": classes}
@@ -197,4 +241,8 @@ def collect():
         out["frac_of_bf16x3_peak"] = tf / BX3_MFMA_PEAK_TFLOPS
     if traffic:
         out["hbm_side"]["measured_gb_per_s_from_pmc_traffic"] = traffic / (ms / n * 1e-3) / 1e9
+        out["traffic_over_charged_bytes"] = traffic / (by / n)
+    busy, busy_src = _pmc_mfma_busy(stem.split("|")[0])
+    out["mfma_busy"] = busy                      # None unless profiles/ holds a pass over THIS build of the kernels
+    out["mfma_busy_source"] = busy_src
     return out

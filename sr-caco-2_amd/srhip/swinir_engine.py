@@ -651,7 +651,14 @@ class SwinIREngine:
         nset = max_nb if defer else 1
         gbufs = [buf(f"g{i}", T, C) for i in range(2 * nset + 1)]
         dhs = [buf(f"dh{i}", T, hid) for i in range(nset)]
-        ghs = [buf(f"gh{i}", T, hid) for i in range(nset)]   # gelu(h): by-product of the dgelu epilogue, operand of the fc2 weight gradient
+        # gelu(h), operand of the fc2 weight gradient: by-product of the dgelu epilogue.  SRHIP_RECOMPUTE_GH=1 (round 6, VERDICT
+        # r5 item 1a): the fused backward does NOT store it (47 MB per block less written at B = 8) and the grouped weight-gradient
+        # launch recomputes it from the saved h in its operand prologue (b_mode 2, the forward's own packed x Phi(x)).  Measured
+        # on the README step, same box, two rounds each: the MLP backward 127 -> 112 us per launch (-0.35 ms per step), the
+        # grouped launch +160 us each (the GELU sits on the two B-operand staging waves of the fc2 tiles, the launch is ONE
+        # round of 240 blocks and ends with its slowest block): 689 against 708 patches/s -- a loss, so it stays opt-in.
+        recompute_gh = (self.fuse_mlp_h and ws.use_bx3 and ops.F16X2 and os.environ.get("SRHIP_RECOMPUTE_GH", "0") == "1")
+        ghs = [None if recompute_gh else buf(f"gh{i}", T, hid) for i in range(nset)]
         dqkvs = [buf(f"dqkv{i}", T, 3 * C) for i in range(nset)]
         dxh, da = buf("dxh", T, C), buf("da", T, C)
         nrot = len(gbufs)
@@ -738,8 +745,8 @@ class SwinIREngine:
                          db=G(p + "attn.qkv.bias") if blk.attn.qkv.bias is not None else buf("dbq.unused", 3 * C), b_mode=1,
                          ln_stats=st1, ln=(blk.attn.qkv.weight.data, blk.norm1.weight.data,
                                            blk.norm1.bias.data, G(p + "norm1.weight"), G(p + "norm1.bias"))),
-                    dict(dY=g, X=gh, dW=G(p + "mlp.fc2.weight"), db=G(p + "mlp.fc2.bias"), a_rowscale=s2,
-                         a_rowscale_rows=H * W),
+                    dict(dY=g, X=h if gh is None else gh, b_mode=2 if gh is None else 0, dW=G(p + "mlp.fc2.weight"),
+                         db=G(p + "mlp.fc2.bias"), a_rowscale=s2, a_rowscale_rows=H * W),
                     dict(dY=dh, X=x1, dW=G(p + "mlp.fc1.weight"), db=G(p + "mlp.fc1.bias"), b_mode=1,
                          ln_stats=st2, ln=(blk.mlp.fc1.weight.data, blk.norm2.weight.data,
                                            blk.norm2.bias.data, G(p + "norm2.weight"), G(p + "norm2.bias"))),

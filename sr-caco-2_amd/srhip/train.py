@@ -305,6 +305,81 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
 
+class RcclComm:
+    """The C-ABI's own communicator (srhip_allreduce_*, csrc/comm.hip: RCCL resolved with dlopen) -- the exchange a caller
+    without PyTorch uses.  One per process, on the current device."""
+
+    def __init__(self, rank, world, id_bytes):
+        import ctypes
+        assert len(id_bytes) == 128
+        self._id = ctypes.create_string_buffer(bytes(id_bytes), 128)
+        h = ctypes.c_void_p(0)
+        ops.call("srhip_allreduce_init", ctypes.addressof(self._id), int(rank), int(world), ctypes.addressof(h))
+        self.h, self.rank, self.world = h.value, rank, world
+
+    @staticmethod
+    def unique_id():
+        import ctypes
+        buf = ctypes.create_string_buffer(128)
+        ops.call("srhip_allreduce_unique_id", ctypes.addressof(buf))
+        return buf.raw
+
+    def bucket(self, t, compute_stream, comm_stream):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        ops.call("srhip_allreduce_bucket_async", self.h, t.data_ptr(), t.numel(), compute_stream.cuda_stream,
+                 comm_stream.cuda_stream)
+
+    def flag(self, t, compute_stream, comm_stream):
+        assert t.is_cuda and t.dtype == torch.int32 and t.numel() == 1
+        ops.call("srhip_allreduce_flag_async", self.h, t.data_ptr(), compute_stream.cuda_stream, comm_stream.cuda_stream)
+
+    def wait(self, comm_stream, compute_stream):
+        ops.call("srhip_allreduce_wait", self.h, comm_stream.cuda_stream, compute_stream.cuda_stream)
+
+    def close(self):
+        if self.h:
+            ops.call("srhip_allreduce_destroy", self.h)
+            self.h = None
+
+
+class CabiGradReducer(GradReducer):
+    """GradReducer on the C-ABI communicator (SRHIP_COMM=cabi): same buckets, same order, same side stream; the collectives
+    are enqueued by srhip_allreduce_bucket_async instead of torch.distributed.all_reduce."""
+
+    def __init__(self, flat_grad, buckets, comm, comm_stream):
+        super().__init__(flat_grad, buckets, None, comm_stream)
+        self.comm = comm
+
+    def bucket_done(self, i):
+        if self.done[i]:
+            return
+        self.done[i] = True
+        self.log.append(i)
+        lo, hi = self.buckets[i]
+        self.comm.bucket(self.grad[lo:hi], torch.cuda.current_stream(), self.comm_stream)
+
+    def reduce_flag(self, flag):
+        self.comm.flag(flag, torch.cuda.current_stream(), self.comm_stream)
+
+    def finish(self, flag=None):
+        for i in range(len(self.buckets)):
+            self.bucket_done(i)
+        if flag is not None:
+            self.reduce_flag(flag)
+        self.comm.wait(self.comm_stream, torch.cuda.current_stream())
+
+
+def open_cabi_comm(world, group=None):
+    """One RcclComm per process: rank 0 makes the id, torch.distributed (when there is more than one rank) carries it."""
+    rank = 0
+    idb = [RcclComm.unique_id()]
+    if world > 1:
+        import torch.distributed as dist
+        rank = dist.get_rank(group)
+        dist.broadcast_object_list(idb, src=0, group=group)
+    return RcclComm(rank, world, idb[0])
+
+
 class TrainStep:
     """loss_terms: sequence of ('l1', lam) | ('l2', lam) | ('ssim', lam, window) |
     ('charbonnier', lam, eps) | ('l2sum', lam) | ('grad'|'laplace'|'lv'|'norm_grad'|
@@ -337,7 +412,14 @@ class TrainStep:
         self.sticky = torch.zeros(1, dtype=torch.int32, device=dev)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.ddp else None
         self.buckets = self._make_buckets() if self.ddp else []
-        self.reducer = GradReducer(self.fp.grad, self.buckets, self.pg, self.comm_stream) if self.ddp else None
+        # SRHIP_COMM=cabi: the gradient exchange through the C-ABI's own RCCL communicator (srhip_allreduce_*: what a caller
+        # without PyTorch uses) instead of torch.distributed's -- same buckets, same order, same side stream
+        self.comm = None
+        if self.ddp and os.environ.get("SRHIP_COMM", "torch") == "cabi":
+            self.comm = open_cabi_comm(world_size, self.pg)
+            self.reducer = CabiGradReducer(self.fp.grad, self.buckets, self.comm, self.comm_stream)
+        else:
+            self.reducer = GradReducer(self.fp.grad, self.buckets, self.pg, self.comm_stream) if self.ddp else None
         # buffers that change during training (BatchNorm running statistics: MemNet) are re-broadcast from rank 0 at
         # every step, as DDP's broadcast_buffers does at every forward; constant ones only at construction
         self._live_buffers = [b for k, b in net.named_buffers() if "running_" in k or "num_batches_tracked" in k]

@@ -91,7 +91,8 @@ def test_captured_training_step_survives_a_larger_validation_forward(net_type, m
         model.feed_data(big)
         model.test()                         # grows the scratch buffers / re-makes the engine's evaluation buffers
         outs.append(model.E.clone())
-        if graph:
+        if graph and net_type != "NLSN":      # (NLSN's sort scratch is a fixed 16 bytes since the in-tree counting sort: its
+            # larger forward may replace nothing -- then there is nothing to invalidate and the replays must simply stay right)
             assert ops.realloc_generation() != gen0, "the larger forward replaced no buffer: the test does not test"
         for it in range(3, 6):
             torch.manual_seed(100 + it)
@@ -102,5 +103,11 @@ def test_captured_training_step_survives_a_larger_validation_forward(net_type, m
         if graph:
             assert model.step_fn._graph["g"] is not None         # re-captured
         results.append((outs[0], model.step_fn.fp.flat.clone()))
+    if net_type == "NLSN":
+        # NLSN's backward scatters with index_add_ (float atomics: two eager runs differ in the last bits too): a replay on
+        # freed scratch memory shows up as garbage, not as rounding
+        assert torch.allclose(results[0][0], results[1][0], rtol=1e-3, atol=1e-4)
+        assert torch.allclose(results[0][1], results[1][1], rtol=1e-3, atol=1e-5), (results[0][1] - results[1][1]).abs().max().item()
+        return
     assert torch.equal(results[0][0], results[1][0])
     assert torch.equal(results[0][1], results[1][1]), (results[0][1] - results[1][1]).abs().max().item()

@@ -177,6 +177,56 @@ def test_conv3x3_epilogues(ops):
     check(y.permute(0, 3, 1, 2), F.conv2d(x, w, None, padding=1) * (R > 0), 2e-5, "conv relu-mask")
 
 
+@pytest.mark.parametrize("B,H,W,rs", [(2, 16, 24, 1.0), (1, 9, 21, 0.1), (3, 4, 16, 1.0), (8, 64, 64, 1.0), (1, 130, 70, 0.5)])
+def test_resblock64_one_launch_fwd_and_bwd(ops, B, H, W, rs):
+    """srhip_resblock64_{fwd,bwd}_f16x2 (one launch per EDSR ResBlock and direction, round 6) against torch on the CPU --
+    ResBlock.forward of the reference (network_nlsn.py:72-93) and its autograd: a, out; da, dx.  Sizes that are not multiples
+    of the 4 x 16 tile, one-tile images, the x8 training shape, res_scale != 1; bias and ReLU decisions at the image border
+    (the ring of mid pixels OUTSIDE the image must be zeros, not conv values: checked by the border rows of `out`)."""
+    if not ops.resblock64_fusable(64):
+        pytest.skip("fp16x2 conv operands are off")
+    C = 64
+    x = rnd(B, C, H, W)
+    w1, w2 = rnd(C, C, 3, 3, scale=0.05), rnd(C, C, 3, 3, scale=0.05)
+    b1, b2 = rnd(C, scale=0.3), rnd(C, scale=0.3)
+    planes = {k: ops.Bx3(9 * C, C, "cuda") for k in ("w1", "w2", "w1t", "w2t")}
+    w1d, w2d = dev(w1), dev(w2)
+    tb = ops.PrepTable()
+    tb.conv(w1d, planes["w1"])
+    tb.conv(w2d, planes["w2"])
+    tb.conv(w1d, planes["w1t"], data_grad=True)
+    tb.conv(w2d, planes["w2t"], data_grad=True)
+    tb.build("cuda").run()
+    assert all(v.fmt == 1 for v in planes.values())
+    xh = dev(x.permute(0, 2, 3, 1))
+    a, out = torch.empty_like(xh), torch.empty_like(xh)
+    ops.resblock64_fwd(xh, planes["w1"], dev(b1), planes["w2"], dev(b2), rs, a, out)
+    xr = x.clone().requires_grad_(True)
+    ar = F.relu(F.conv2d(xr, w1, b1, padding=1))
+    outr = xr + rs * F.conv2d(ar, w2, b2, padding=1)
+    check(a.permute(0, 3, 1, 2), ar, 2e-5, "resblock a")
+    check(out.permute(0, 3, 1, 2), outr, 2e-5, "resblock out")
+    # the unfused launches give the same numbers to rounding (their own halo-tile exponents differ from the mid tile's)
+    wp1, wp2 = planes["w1"], planes["w2"]
+    a_u = ops.conv3x3(xh, wp1, dev(b1), C, epi=1)
+    out_u = ops.conv3x3(a_u, wp2, dev(b2), C, epi=2, R=xh, alpha=rs)
+    check(out, out_u, 1e-5, "resblock vs two launches")
+    # backward: g -> da (gradient wrt the first conv's output, ReLU mask applied), dx
+    g = rnd(B, C, H, W)
+    gh = dev(g.permute(0, 2, 3, 1))
+    da, dx = torch.empty_like(xh), torch.empty_like(xh)
+    # ReLU decisions of the DEVICE activation (pixels within rounding of zero may fall on the other side on the CPU)
+    a_dev = a.permute(0, 3, 1, 2).cpu()
+    mask = (a_dev > 0).float()
+    ops.resblock64_bwd(gh, planes["w2t"], planes["w1t"], a, rs, da, dx)
+    dar = rs * F.conv_transpose2d(g, w2, padding=1) * mask
+    dxr = g + F.conv_transpose2d(dar, w1, padding=1)
+    check(da.permute(0, 3, 1, 2), dar, 2e-5, "resblock da")
+    check(dx.permute(0, 3, 1, 2), dxr, 2e-5, "resblock dx")
+    with pytest.raises(RuntimeError):
+        ops.resblock64_fwd(xh, planes["w1"], dev(b1), planes["w2"], dev(b2), rs, a, xh)      # out aliases x
+
+
 # ------------------------------------------------------------------ gemm_tn
 @pytest.mark.parametrize("M,NI,NJ", [(5000, 180, 180), (4096, 540, 180), (3000, 360, 180),
                                      (2500, 180, 360), (700, 60, 60), (1234, 64, 256),
@@ -572,12 +622,18 @@ def test_grad_norm_clip_and_ema_kernels(ops):
     d = dev(gr)
     nc = torch.zeros(2).cuda()
     ops.grad_norm_clip(d, 1.0, 0.5, nc)
-    assert abs(nc[0].item() - float(total)) <= 2e-6 * float(total) and abs(nc[1].item() - float(coef)) <= 1e-6
-    assert (d.cpu() - go[0]).abs().max() <= 1e-6 * go[0].abs().max()
+    # the kernel sums the squares in double; torch's own f32 vector_norm over ONE 7.9 M-element tensor carries ~2e-4 of
+    # accumulation error (the reference clips 330 smaller tensors: norm of norms).  Gate against the f64 norm; the f32
+    # restatement only has to agree to ITS accuracy
+    total64 = float(gr.double().norm())
+    coef64 = min(1.0, 0.5 / (total64 + 1e-6))
+    assert abs(nc[0].item() - total64) <= 2e-6 * total64 and abs(nc[1].item() - coef64) <= 1e-6
+    assert abs(nc[0].item() - float(total)) <= 1e-3 * float(total)
+    assert (d.cpu() - gr * coef64).abs().max() <= 1e-6 * gr.abs().max()
     d2 = dev(gr * 4)                                          # the SUM of four ranks' gradients: norm of g / 4
     ops.grad_norm_clip(d2, 0.25, 0.5, nc)
-    assert abs(nc[0].item() - float(total)) <= 2e-6 * float(total)
-    assert (d2.cpu() * 0.25 - go[0]).abs().max() <= 1e-6 * go[0].abs().max()
+    assert abs(nc[0].item() - total64) <= 2e-6 * total64
+    assert (d2.cpu() * 0.25 - gr * coef64).abs().max() <= 1e-6 * gr.abs().max()
     a1, a2 = dev(gr), dev(gr)                                 # bit-identical from run to run (fixed-order reduction)
     n1, n2 = torch.zeros(2).cuda(), torch.zeros(2).cuda()
     ops.grad_norm_clip(a1, 1.0, 0.5, n1)

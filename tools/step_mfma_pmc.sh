@@ -29,7 +29,21 @@ for k, (c, t, n) in acc.items():
     if c <= 0: continue
     out[k] = {"launches": n, "avg_us_under_pmc": t / n / 1e3, "mfma_busy_cycles_per_launch": c / n,
               "mfma_busy_frac_at_2.4GHz": c / (t * 1e-9 * 2.4e9 * 1024.0)}
-json.dump(out, open(f"{d}/mfma_busy_per_kernel.json", "w"), indent=1)
+sys.path.insert(0, "sr-caco-2_amd")
+try:                      # tie the table to the kernel sources it measured (bench.py reads it only when they match the loaded build)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("probe_hash", "sr-caco-2_amd/srhip/probe.py")
+    src = open("sr-caco-2_amd/srhip/probe.py").read()
+    import hashlib, os
+    h = hashlib.sha256()
+    cd = "sr-caco-2_amd/csrc"
+    for f in sorted(os.listdir(cd)):
+        if f.endswith((".hip", ".h")) or f == "Makefile":
+            h.update(f.encode()); h.update(open(os.path.join(cd, f), "rb").read())
+    meta = {"csrc_sha16": h.hexdigest()[:16]}
+except Exception as e:
+    meta = {"csrc_sha16": None, "error": str(e)}
+json.dump(dict(out, _meta=meta), open(f"{d}/mfma_busy_per_kernel.json", "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["avg_us_under_pmc"] * kv[1]["launches"])[:12]:
     print(f"{k[:50]:50s} n={v['launches']:5d} avg {v['avg_us_under_pmc']:8.1f} us  MFMA-busy >= {100 * v['mfma_busy_frac_at_2.4GHz']:.1f} %")
 P
