@@ -10,7 +10,6 @@
 // would each claim the same GPUs), else librccl.so.1 of the ROCm installation.  A process that never calls
 // srhip_allreduce_* never loads it.
 #include <dlfcn.h>
-#include <mutex>
 #include <new>
 #include <rccl/rccl.h>
 #include "common.h"
@@ -27,7 +26,6 @@ struct RcclApi {
   const char* error = nullptr;
 };
 RcclApi g_api;
-std::once_flag g_once;
 
 void load_rccl() {
   static const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
@@ -49,7 +47,8 @@ void load_rccl() {
 }
 
 int need_rccl(const char* who) {
-  std::call_once(g_once, load_rccl);
+  static const bool once = (load_rccl(), true);       // thread-safe one-time initialisation (C++11 local static)
+  (void)once;
   if (g_api.error) return sr_fail(-38, "%s: %s", who, g_api.error);
   return 0;
 }

@@ -833,6 +833,7 @@ __device__ __forceinline__ void tnb_body_h(const TnArgs& p, const int s, const i
 // producers' load latency.)  Plain operands only (no prologue, no row scale), NI and NJ multiples of 64.
 // ---------------------------------------------------------------------------
 constexpr int TK3 = 16;                         // tokens per chunk = one k step of the 32x32x16 MFMA
+#define SR_TNB3_OCC 6                           // waves per SIMD: three 8-wave blocks per CU
 __device__ __forceinline__ int unit_slot3(int col, int u) { return 2 * col + (u ^ ((col >> 3) & 1)); }
 
 //
@@ -974,6 +975,10 @@ __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const in
 #pragma unroll
   for (int k = 0; k < 3; ++k) b_off[k] = unit_slot3((1 + k) * BC + wj * 32 + r, h) * 16;
 
+  // (Round 6, measured and dropped: THREE register stages -- a chunk's rows requested three chunk periods ahead.  The role
+  // ablations say the staging path is the longer pole (tools/mb_tnb3.py at 8 x 256 x 256, 64 -> 256 channels: all 960 us | no
+  // MFMAs 739 | no staging 538), but the third stage does not fit: 127 spilled registers at the 80 of three blocks per CU, 50
+  // at the 128 of two -- scratch traffic shares vmcnt with the prefetch: EDSR x8 1,810 -> 1,143 patches/s.)
   const int nch = ((m_end - m_begin + 2 * TK3 - 1) / (2 * TK3)) * 2;     // even
   if (producer) {
     __builtin_amdgcn_s_setprio(2);                    // staging waves first: they are the critical path of a chunk
@@ -1092,7 +1097,7 @@ __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const in
 }
 
 template <int DBG = 0, bool F16 = false>
-__global__ void __launch_bounds__(512, 6) k_tnb3(TnArgs p, int tiles, int xcd) {
+__global__ void __launch_bounds__(512, SR_TNB3_OCC) k_tnb3(TnArgs p, int tiles, int xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int L = xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int trow = L % 3, t2 = L / 3;
@@ -1216,7 +1221,7 @@ __global__ void __launch_bounds__(512, 1) k_tnb_conv_batched(TnbConvBatch g) {
 }
 
 template <int DBG = 0, bool F16 = false>
-__global__ void __launch_bounds__(512, 6) k_tnb3_conv_batched(TnbConvBatch g) {
+__global__ void __launch_bounds__(512, SR_TNB3_OCC) k_tnb3_conv_batched(TnbConvBatch g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int L = g.xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int trow = L % 3;
@@ -1424,7 +1429,7 @@ int sr_conv_wgrad_batched_plan(int n, int M, int NI, int NJ, int* S, long* part_
   // for WHOLE rounds of blocks -- 33 problems x 9 taps x 3 slices = 891 blocks on 768 slots ran 1.16
   // rounds, i.e. the second round 16 % full (x4: 5.3 ms for what 1.93 rounds do in 3.1) -- among the
   // counts that leave a slice at least 1024 rows; ties go to fewer slices (less partial traffic).
-  const long slots = w == 1 ? 768 : 256;
+  const long slots = w == 1 ? 128L * SR_TNB3_OCC : 256;
   long best = 1;
   double best_eff = 0.0;
   for (long s = 1; s <= 64; ++s) {

@@ -48,6 +48,9 @@ class EDSREngine:
         # SRHIP_FUSE_RESBLOCK=0 keeps the two conv launches.  64-feature nets on the fp16x2 conv operands only.
         self.fuse_rb = self.ws.use_bx3 and ops.resblock64_fusable(self.F) and \
             os.environ.get("SRHIP_FUSE_RESBLOCK", "1") != "0"
+        # ... where a conv launch is latency-bound: the fused kernel recomputes the first conv on a one-pixel ring around its
+        # 4 x 16 tile (108 mid pixels for 64), which a launch that fills the chip many times over pays in matrix-core time
+        self.fuse_rb_maxpix = int(os.environ.get("SRHIP_FUSE_RESBLOCK_MAXPIX", str(8 * 64 * 64)))
 
     def invalidate(self):
         self.prepared = False
@@ -137,7 +140,7 @@ class EDSREngine:
         r = f0
         blocks = []
         rs = float(net.res_scale)
-        fuse_rb = self.fuse_rb and not ops.lib.srhip_get_matmul_mode() and \
+        fuse_rb = self.fuse_rb and not ops.lib.srhip_get_matmul_mode() and B * H * W <= self.fuse_rb_maxpix and \
             ops.resblock64_fusable(F, self.ws["b0.0.wp"] if self.nb else None)
         for k in range(self.nb):
             kk = k if save else k % 2
@@ -272,7 +275,7 @@ class EDSREngine:
             gs = [ga if (self.nb - k) % 2 == 0 else gb for k in range(self.nb + 1)]
             das = [da1] * self.nb
         g = gs[self.nb]
-        fuse_rb = self.fuse_rb and not ops.lib.srhip_get_matmul_mode() and \
+        fuse_rb = self.fuse_rb and not ops.lib.srhip_get_matmul_mode() and B * H * W <= self.fuse_rb_maxpix and \
             ops.resblock64_fusable(F, self.ws["b0.0.wpt"] if self.nb else None) and batched
         ops.conv3x3(drb, self.ws["bend.wpt"], None, F, out=g)
         for k in reversed(range(self.nb)):
