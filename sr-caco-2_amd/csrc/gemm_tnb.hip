@@ -1096,6 +1096,288 @@ __device__ __forceinline__ void tnb_body3(const TnArgs& p, const int s, const in
   }
 }
 
+// ---------------------------------------------------------------------------
+// 64-wide conv problems, ALL NINE taps per block (round 6; two fp16 planes / three products only).
+//
+// What the three-tap form costs (role ablations, tools/mb_tnb3.py, 8 x 256 x 256 pixels, 64 -> 256 channels: everything
+// 960 us | consumers without their MFMAs 739 | producers without loads and stores 538 -- against 186 us of matrix time):
+//   * staging: a tap row's block stages dY and three shifted X tiles for its three taps -- twelve operand tiles per chunk
+//     position for the nine taps, every one split (VALU) and written to LDS, and the staging waves run at the latency of their
+//     own loads (two chunks ahead, 85 registers per wave with three blocks per CU: no room for a third stage);
+//   * LDS: a consumer wave reads 8 KB of fragments for nine MFMAs.
+// Here a tap (dy, dx) pairs the dY tile shifted by -dx ALONG its row with the X tile of row y + dy:
+//     dW[dy, dx][co][ci] = sum_q dY[q - (0, dx)][co] * X[q + (dy, 0)][ci]          (q = p + (0, dx))
+// -- SIX operand tiles per chunk (dY for dx = -1, 0, +1; X for dy = -1, 0, +1; the X tiles are plain rows: aligned, always
+// dense) feed all nine taps: half the loads, splits and LDS writes per MFMA.  One block per CU, 14 waves: six staging waves
+// (one operand tile each, THREE register stages: a chunk's rows are requested three chunk periods ahead) and eight matrix
+// waves = 2 x 2 quadrants of the 64 x 64 tile x two tap groups (taps 0-4 / 5-8: 15 + 12 MFMAs per SIMD and chunk, the same
+// on all four SIMDs); a matrix wave reads ten fragments (three dY shifts, two X rows; 10 KB) for 15 / 12 MFMAs.  Partial
+// sums leave in the layout of the three-tap form ([slice][tap][NI][NJ]): same reducers.
+// ---------------------------------------------------------------------------
+constexpr int T9_OPS = 6;
+constexpr int T9_PLANE = T9_OPS * 64 * 32;        // bytes per plane and chunk buffer
+constexpr int T9_CTRL = 2 * T9_PLANE;             // factors [6][64] floats, then the six flag words (+ 2 pad)
+constexpr int T9_BUF = 2 * T9_PLANE + 2048;
+constexpr int T9_SINV = 2 * T9_BUF;               // final 2^-s [6][64]
+constexpr int T9_LDS = 2 * T9_BUF + 2048;
+constexpr int T9_THREADS = 14 * 64;
+
+// DBG (experiments build, SRHIP_TN_DBG; results are wrong on purpose): 1 = no MFMAs | 2 = staging waves neither load nor store
+// | 6 = matrix waves read no fragments (one register quad stands in for all of them) | 7 = 2 + 6 | 8 = 7 without any barrier
+// in the chunk loops | 9 = 7 with the staging waves gone (they return at once: barriers among the eight matrix waves only)
+template <int H2, int DBG = 0>
+__device__ __forceinline__ void tnb9_consume(const TnArgs& p, const int s, const int i0, const int j0, const int nch,
+                                             unsigned char* smem, const int wi, const int wj, const int lane) {
+  // tap t = 5 H2 + u: (dy index, dx index) = (t / 3, t % 3)
+  constexpr int NU = H2 ? 4 : 5;
+  constexpr int DY0 = H2 ? 1 : 0;                  // the two X rows this wave reads: DY0, DY0 + 1
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[u][q] = 0.f;
+  int a_off[3], b_off[2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) a_off[d] = unit_slot3(d * 64 + wi * 32 + r, h) * 16;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) b_off[d] = unit_slot3((3 + DY0 + d) * 64 + wj * 32 + r, h) * 16;
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    const unsigned char* cur = smem + (c & 1) * T9_BUF;
+    const float* ctrl = (const float*)(cur + T9_CTRL);
+    const u32x4 f0 = *(const u32x4*)(ctrl + T9_OPS * 64);
+    const sr_u32x2 f1 = *(const sr_u32x2*)(ctrl + T9_OPS * 64 + 4);
+    if (__builtin_amdgcn_readfirstlane(f0.x | f0.y | f0.z | f0.w | f1.x | f1.y)) {   // some column's scale dropped with this chunk
+      const unsigned fl[6] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y};
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        constexpr int T0 = 5 * H2;
+        const int t = T0 + u, dyi = t / 3, dxi = t - 3 * dyi;
+        if (fl[dxi] | fl[3 + dyi]) {
+          const float fb = fl[3 + dyi] ? ctrl[(3 + dyi) * 64 + wj * 32 + r] : 1.f;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[u][q] *= (fl[dxi] ? ctrl[dxi * 64 + wi * 32 + mfma_row(q, lane)] : 1.f) * fb;
+        }
+      }
+    }
+    // All ten fragments first, then the three product terms as three PASSES over the wave's units: an accumulator is touched
+    // again only NU MFMAs later.  (Term by term per unit -- three MFMAs in a row into the same accumulator -- the matrix waves
+    // alone, without staging and without fragment reads, ran 695 of the launch's 794 us: a dependent 32x32x16 MFMA waits out
+    // the whole latency of the one in front of it.)
+    u32x4 ah[3], al[3], bh[2], bl[2];
+    const u32x4 dummy = u32x4{(unsigned)lane, 0x3c003c00u, 0x3c003c00u, (unsigned)c};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      bh[d] = (DBG >= 6) ? dummy : *(const u32x4*)(cur + b_off[d]);
+      bl[d] = (DBG >= 6) ? dummy : *(const u32x4*)(cur + T9_PLANE + b_off[d]);
+    }
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      ah[dx] = (DBG >= 6) ? dummy : *(const u32x4*)(cur + a_off[dx]);
+      al[dx] = (DBG >= 6) ? dummy : *(const u32x4*)(cur + T9_PLANE + a_off[dx]);
+    }
+    if (DBG != 1) {
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int t = 5 * H2 + u, dyi = t / 3, dxi = t - 3 * dyi;
+          if (DBG == 10) {            // (experiment: the bf16 form of the same MFMA shape on the same registers, no barriers)
+            acc[u] = mfma_bf(term == 0 ? al[dxi] : ah[dxi], term == 1 ? bl[dyi - DY0] : bh[dyi - DY0], acc[u]);
+          } else if (term == 0) acc[u] = mfma_h(al[dxi], bh[dyi - DY0], acc[u]);
+          else if (term == 1) acc[u] = mfma_h(ah[dxi], bl[dyi - DY0], acc[u]);
+          else acc[u] = mfma_h(ah[dxi], bh[dyi - DY0], acc[u]);
+        }
+      }
+    }
+    if (DBG != 8 && DBG != 10) __syncthreads();
+  }
+  if (DBG != 9) __syncthreads();                   // the staging waves' final 2^-s
+  const float* sinv = (const float*)(smem + T9_SINV);
+  const int col = wj * 32 + r;
+  const int ps_f = p.NI >> 2;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int t = 5 * H2 + u, dyi = t / 3, dxi = t - 3 * dyi;
+    const float ib = sinv[(3 + dyi) * 64 + col];
+    float* out = p.part + ((long)(s * 9 + t) * p.NI) * p.NJ;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int io = i0 + wi * 32 + mfma_row(q, lane);         // p.ps: kernel row sp*F + c is torch channel c*4 + sp
+      out[(long)(p.ps ? (io % ps_f) * 4 + io / ps_f : io) * p.NJ + j0 + col] = acc[u][q] * (sinv[dxi * 64 + wi * 32 + mfma_row(q, lane)] * ib);
+    }
+  }
+}
+
+template <int DBG = 0>
+__device__ __forceinline__ void tnb_body9(const TnArgs& p, const int s, const int tile, unsigned char* smem) {
+  constexpr int BC = 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 8;
+  const int nbj = p.NJ / BC;
+  const int bi = tile / nbj, bj = tile - bi * nbj;
+  const int i0 = bi * BC, j0 = bj * BC;
+  const int m_begin = s * p.rows_per_slice;
+  const int m_end = min(p.M, m_begin + p.rows_per_slice);
+  const int nch = ((m_end - m_begin + 3 * TK3 - 1) / (3 * TK3)) * 3;      // a multiple of 3: three register stages
+  if (!producer) {
+    const int q4 = wave & 3;
+    if (wave < 4) tnb9_consume<0, DBG>(p, s, i0, j0, nch, smem, q4 >> 1, q4 & 1, lane);
+    else tnb9_consume<1, DBG>(p, s, i0, j0, nch, smem, q4 >> 1, q4 & 1, lane);
+    if (p.part_colsum && bj == 0) __syncthreads();            // the column sums' exchange below
+    return;
+  }
+  if (DBG == 9) return;
+  // ---------------- staging wave `op`: 0..2 = dY shifted by dx = op - 1 along the row, 3..5 = X of row y + (op - 4)
+  const int op = wave - 8;
+  const bool isB = op >= 3;
+  const int sh = isB ? op - 4 : op - 1;
+  const bool do_colsum = p.part_colsum && bj == 0 && op == 1;
+  struct Stage { float rv[2][8]; };
+  const int ps_f = p.NI >> 2;
+  unsigned colb = (unsigned)lane * 4u;
+  if (!isB && p.ps) {
+    const int ig = i0 + lane, sp = ig / ps_f, cc = ig - sp * ps_f;
+    colb = (unsigned)((((sp >> 1) * 2 * p.Wd + (sp & 1)) * (int)p.lda + cc) * 4);
+  }
+  const float* const P = isB ? p.B + j0 : (p.ps ? p.A : p.A + i0);      // uniform
+  const long ld = isB ? p.ldb : p.lda;
+  const int step = (!isB && p.ps) ? 2 : 1;
+  float cs = 0.f;
+  float sc = 0x1p126f;
+  // The chunks are loaded in order, 16 tokens apart: lane (token & 15) carries its token's (x, y, image) and steps it --
+  // three integer divisions per chunk otherwise (a third of the staging wave's instructions).
+  int cx, cy, cb;
+  {
+    const int gm0 = m_begin + (lane & 15);
+    cx = gm0 % p.Wd;
+    const int tq = gm0 / p.Wd;
+    cy = tq % p.H;
+    cb = tq / p.H;
+  }
+  // last pixel row a dense chunk may start its 16th token on (PixelShuffle form: a lane's column offset reaches up to one
+  // shuffled row + one pixel further)
+  const int last_row = (!isB && p.ps) ? p.batch * p.H * p.Wd * 4 - 1 - (2 * p.Wd + 1) : p.batch * p.H * p.Wd - 1;
+  auto load = [&](int mc, Stage& sg) __attribute__((always_inline)) {
+    const int gm = mc + (lane & 15);
+    const int x = cx, y = cy, b = cb;
+    cx += 16;
+    while (cx >= p.Wd) { cx -= p.Wd; if (++cy == p.H) { cy = 0; ++cb; } }
+    bool ok = gm < m_end;
+    int srow;
+    if (isB) {
+      const int yy = y + sh;
+      ok = ok && yy >= 0 && yy < p.H;
+      srow = (b * p.H + yy) * p.Wd + x;
+    } else {
+      const int xx = x - sh;
+      ok = ok && xx >= 0 && xx < p.Wd;
+      srow = p.ps ? (b * 2 * p.H + 2 * y) * 2 * p.Wd + 2 * xx : (b * p.H + y) * p.Wd + xx;
+    }
+    // Dense form: the valid tokens of the chunk sit on ONE arithmetic row sequence base + step t -- then all sixteen rows
+    // are read from it (a token without a source -- the pixel before a row's first, the row above the image -- reads its
+    // neighbour's row instead, in bounds) and the invalid ones are zeroed afterwards: no per-token address, no branch
+    // around a load.  Anything else (a chunk across an image's last row with dy = +1, the operand's first / last rows) takes
+    // the per-token form.
+    const int cand = srow - step * (lane & 15);
+    int base = ok ? cand : -2147483647 - 1;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) base = max(base, __shfl_xor(base, o, 64));
+    const unsigned okmask = (unsigned)__ballot(ok) & 0xffffu;
+    const bool dense = okmask != 0u && __all(!ok || cand == base) && __builtin_amdgcn_readfirstlane(base) >= 0 &&
+                       __builtin_amdgcn_readfirstlane(base) + 15 * step <= last_row;
+    if (dense) {
+      const float* q = P + (long)__builtin_amdgcn_readfirstlane(base) * ld;
+      const long adv = step * ld;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float v = ColVec<1>::ldg(q, colb);
+        sg.rv[t >> 3][t & 7] = v;
+        q += adv;
+      }
+      if (okmask != 0xffffu) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          if (!((okmask >> t) & 1u)) sg.rv[t >> 3][t & 7] = 0.f;
+      }
+    } else {
+      const int t_row = ok ? srow : -1;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = __builtin_amdgcn_readlane(t_row, t);
+        const float* base_p = row >= 0 ? P + (long)row * ld : k_tnb_zero_row;
+        sg.rv[t >> 3][t & 7] = ColVec<1>::ldg(base_p, row >= 0 ? colb : 0u);
+      }
+    }
+  };
+  auto store = [&](unsigned char* buf, const Stage& sg) __attribute__((always_inline)) {
+    float mx = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) mx = fmaxf(mx, fabsf(sg.rv[t >> 3][t & 7]));
+    float f = 1.f;
+    if (mx * sc > 60000.f) {
+      const float ns = exp2f(fminf(floorf(log2f(16384.f / mx)), 120.f));
+      f = ns / sc;
+      sc = ns;
+    }
+    const bool ch = __any(f != 1.f);
+    float* ctrl = (float*)(buf + T9_CTRL);
+    if (ch) ctrl[op * BC + lane] = f;
+    if (lane == 0) ((int*)(ctrl + T9_OPS * BC))[op] = ch ? 1 : 0;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      unsigned qh[4], ql[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float e0 = sg.rv[o][2 * t], e1 = sg.rv[o][2 * t + 1];
+        if (do_colsum) cs += e0 + e1;
+        split2_pair(e0 * sc, e1 * sc, qh[t], ql[t]);
+      }
+      unsigned char* dst = buf + unit_slot3(op * BC + lane, o) * 16;
+      *(u32x4*)(dst) = u32x4{qh[0], qh[1], qh[2], qh[3]};
+      *(u32x4*)(dst + T9_PLANE) = u32x4{ql[0], ql[1], ql[2], ql[3]};
+    }
+  };
+  __builtin_amdgcn_s_setprio(2);
+  Stage sa, sb, sc3;
+  load(m_begin, sa);
+  load(m_begin + TK3, sb);
+  load(m_begin + 2 * TK3, sc3);
+  if (lane == 0 && op == 0) { int* fw = (int*)(smem + T9_CTRL) + T9_OPS * BC; fw[6] = 0; fw[7] = 0; fw = (int*)(smem + T9_BUF + T9_CTRL) + T9_OPS * BC; fw[6] = 0; fw[7] = 0; }
+  store(smem, sa);
+  load(m_begin + 3 * TK3, sa);
+  __syncthreads();
+  // chunk c + K + 1 goes to buffer (c + K + 1) & 1 from the stage that holds it; that stage then takes chunk c + K + 4
+#define SR_T9STEP(K_, ST_)                                                                                   \
+  if (DBG != 2 && DBG < 7) { store(smem + (((c + (K_) + 1) & 1) ? T9_BUF : 0), ST_); load(m_begin + (c + (K_) + 4) * TK3, ST_); } \
+  if (DBG != 8 && DBG != 10) __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < nch; c += 3) {
+    SR_T9STEP(0, sb) SR_T9STEP(1, sc3) SR_T9STEP(2, sa)
+  }
+#undef SR_T9STEP
+  ((float*)(smem + T9_SINV))[op * BC + lane] = 1.0f / sc;
+  __syncthreads();
+  if (p.part_colsum && bj == 0) {
+    float* red = (float*)smem;                   // the chunk buffers are dead: every matrix wave is past its last chunk
+    if (op == 1) red[lane] = cs;
+    __syncthreads();
+    if (op == 2) {
+      const int io = i0 + lane;
+      p.part_colsum[(long)s * p.NI + (p.ps ? (io % ps_f) * 4 + io / ps_f : io)] = red[lane];
+    }
+  }
+}
+
+template <int DBG = 0>
+__global__ void __launch_bounds__(T9_THREADS) k_tnb9(TnArgs p, int tiles, int xcd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int L = xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  tnb_body9<DBG>(p, L / tiles, L % tiles, smem);
+}
+
 template <int DBG = 0, bool F16 = false>
 __global__ void __launch_bounds__(512, SR_TNB3_OCC) k_tnb3(TnArgs p, int tiles, int xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1236,6 +1518,20 @@ __global__ void __launch_bounds__(512, SR_TNB3_OCC) k_tnb3_conv_batched(TnbConvB
   tnb_body3<DBG, F16>(p, sl, tile, trow, smem);
 }
 
+__global__ void __launch_bounds__(T9_THREADS) k_tnb9_conv_batched(TnbConvBatch g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int L = g.xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  int rr = L;
+  const int tile = rr % g.tiles; rr /= g.tiles;
+  const int sl = rr % g.base.S, k = rr / g.base.S;
+  TnArgs p = g.base;
+  p.A = g.A[k];
+  p.B = g.B[k];
+  p.part = g.base.part + (long)k * g.part_stride;
+  p.part_colsum = g.base.part_colsum ? g.base.part_colsum + (long)k * g.colsum_stride : nullptr;
+  tnb_body9<0>(p, sl, tile, smem);
+}
+
 // three taps per block (tnb_body3) for this problem?  SRHIP_TN_T3=0: one tap per block
 bool tnb_t3_shape(int conv, int NI, int NJ, int w) {
   static const int on = [] { const char* e = sr_getenv("SRHIP_TN_T3"); return !(e && e[0] == '0'); }();
@@ -1245,6 +1541,16 @@ bool tnb_t3_ok(const TnArgs& p, int w) {
   return tnb_t3_shape(p.conv, p.NI, p.NJ, w) && !p.a_rowscale && p.b_mode == 0;
 }
 constexpr int lds_bytes3() { return 2 * 3 * 4 * 64 * 32; }
+// all nine taps per block (tnb_body9: two fp16 planes only)?  SRHIP_TN_T9=0 (experiments build): the three-tap form
+bool tnb_t9_shape(int conv, int NI, int NJ, int w) {
+#ifdef SR_TN_T9_OFF
+  return false;                                    // build variant for the same-box A/B (make EXTRA=-DSR_TN_T9_OFF)
+#endif
+  static const int on = [] { const char* e = sr_getenv("SRHIP_TN_T9"); return !(e && e[0] == '0'); }();
+  static const int f16 = [] { const char* e = sr_getenv("SRHIP_TN_F16X2"); return !(e && e[0] == '0'); }();
+  return on && f16 && tnb_t3_shape(conv, NI, NJ, w);
+}
+bool tnb_t9_ok(const TnArgs& p, int w) { return tnb_t9_shape(p.conv, p.NI, p.NJ, w) && tnb_t3_ok(p, w); }
 // two fp16 planes / three products in the three-tap kernels (default); SRHIP_TN_F16X2=0: three bf16 planes / six products
 bool tnb_f16() {
   static const int on = [] { const char* e = sr_getenv("SRHIP_TN_F16X2"); return !(e && e[0] == '0'); }();
@@ -1364,6 +1670,25 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
   dim3 grid(p.S, tiles, 1);
   if (p.conv) grid = dim3(p.S * tiles * 9, 1, 1);
   static const int xcd = [] { const char* e = sr_getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
+  if (tnb_t9_ok(p, w)) {       // 64-wide conv problem: all nine taps per block, one block per CU
+    static bool attr9 = false;
+    if (!attr9) {
+      if (int rc = reserve_lds(k_tnb9<0>, T9_LDS, "k_tnb9")) return rc;
+      attr9 = true;
+    }
+#ifdef SRHIP_EXPERIMENTS
+    {
+      const char* e = sr_getenv("SRHIP_TN_DBG");
+      const int dbg = e ? atoi(e) : 0;
+#define SR_T9DBG(D_) if (dbg == D_) { reserve_lds(k_tnb9<D_>, T9_LDS, "k_tnb9"); hipLaunchKernelGGL(k_tnb9<D_>, dim3(p.S * tiles), dim3(T9_THREADS), T9_LDS, st, p, tiles, xcd); return 0; }
+      SR_T9DBG(1) SR_T9DBG(2) SR_T9DBG(6) SR_T9DBG(7) SR_T9DBG(8) SR_T9DBG(9) SR_T9DBG(10)
+#undef SR_T9DBG
+    }
+#endif
+    hipLaunchKernelGGL(k_tnb9<0>, dim3(p.S * tiles), dim3(T9_THREADS), T9_LDS, st, p, tiles, xcd);
+    SR_LAUNCH_CHECK("k_tnb9");
+    return 0;
+  }
   if (tnb_t3_ok(p, w)) {       // 64-wide conv problem: three taps per block
     static bool attr3 = false;
     if (!attr3) {
@@ -1424,12 +1749,13 @@ int sr_conv_wgrad_batched_plan(int n, int M, int NI, int NJ, int* S, long* part_
   int tile;
   const int w = pick_w(NI, NJ, &tile);
   const bool t3 = tnb_t3_shape(1, NI, NJ, w);             // three taps per block
-  const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * (t3 ? 3 : 9) * n;
+  const bool t9 = tnb_t9_shape(1, NI, NJ, w);             // nine: one block per (tile, slice), one block per CU
+  const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * (t9 ? 1 : (t3 ? 3 : 9)) * n;
   // Blocks in flight: 3 per CU for 64-wide tiles (49 KB of LDS each), else 1.  The slice count is chosen
   // for WHOLE rounds of blocks -- 33 problems x 9 taps x 3 slices = 891 blocks on 768 slots ran 1.16
   // rounds, i.e. the second round 16 % full (x4: 5.3 ms for what 1.93 rounds do in 3.1) -- among the
   // counts that leave a slice at least 1024 rows; ties go to fewer slices (less partial traffic).
-  const long slots = w == 1 ? 128L * SR_TNB3_OCC : 256;
+  const long slots = t9 ? 256 : (w == 1 ? 128L * SR_TNB3_OCC : 256);
   long best = 1;
   double best_eff = 0.0;
   for (long s = 1; s <= 64; ++s) {
@@ -1464,6 +1790,16 @@ int sr_conv_wgrad_batched_tnb(const TnArgs& base, const float* const* A, const f
   for (int k = 0; k < n; ++k) { g.A[k] = A[k]; g.B[k] = B[k]; }
   static const int xcd = [] { const char* e = sr_getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
   g.xcd = xcd;
+  if (tnb_t9_ok(g.base, w)) {  // all nine taps per block
+    static bool attr9 = false;
+    if (!attr9) {
+      if (int rc = reserve_lds(k_tnb9_conv_batched, T9_LDS, "k_tnb9_conv_batched")) return rc;
+      attr9 = true;
+    }
+    hipLaunchKernelGGL(k_tnb9_conv_batched, dim3(base.S * g.tiles * n), dim3(T9_THREADS), T9_LDS, st, g);
+    SR_LAUNCH_CHECK("k_tnb9_conv_batched");
+    return 0;
+  }
   if (tnb_t3_ok(g.base, w)) {  // three taps per block
     static bool attr3 = false;
     if (!attr3) {
@@ -1498,10 +1834,11 @@ int sr_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
   int tile;
   const int w = pick_w(NI, NJ, &tile);
   const bool t3 = tnb_t3_shape(conv, NI, NJ, w);          // three taps per block
-  const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * (conv ? (t3 ? 3 : 9) : 1);
+  const bool t9 = tnb_t9_shape(conv, NI, NJ, w);          // nine taps per block, one block per CU
+  const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * (conv ? (t9 ? 1 : (t3 ? 3 : 9)) : 1);
   static const long t1 = [] { const char* e = sr_getenv("SRHIP_TNB_BLOCKS_W1"); return e ? atol(e) : 768L; }();
   static const long t3b = [] { const char* e = sr_getenv("SRHIP_TNB_BLOCKS_T3"); return e ? atol(e) : 768L; }();
-  long s = (t3 ? t3b : (w == 1 ? t1 : 256)) / tiles;
+  long s = (t9 ? 256 : (t3 ? t3b : (w == 1 ? t1 : 256))) / tiles;
   const long smax = (M + 127) / 128;
   if (s > smax) s = smax;
   if (s > 256) s = 256;

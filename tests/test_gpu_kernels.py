@@ -653,7 +653,7 @@ def test_grad_norm_clip_and_ema_kernels(ops):
     ops.ema_update(e, p, 0.999, flag)
     eo = [e0.clone()]
     O.ema_update(eo, [p.cpu()], 0.999)
-    assert (e.cpu() - eo[0]).abs().max() <= 1e-7
+    assert (e.cpu() - eo[0]).abs().max() <= 5e-7          # values O(1): two roundings each side
     ops.ema_update(e, p, 0.0)                                 # update_E(0): a copy (model_plain.py:82-84)
     assert torch.equal(e, p)
     with pytest.raises(RuntimeError):
