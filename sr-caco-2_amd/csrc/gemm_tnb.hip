@@ -1143,6 +1143,8 @@ __device__ __forceinline__ void tnb9_consume(const TnArgs& p, const int s, const
 #pragma unroll
   for (int d = 0; d < 2; ++d) b_off[d] = unit_slot3((3 + DY0 + d) * 64 + wj * 32 + r, h) * 16;
   __syncthreads();
+  long long ts0 = 0, ts1 = 0;
+  if (DBG == 3) ts0 = (long long)wall_clock64();
   for (int c = 0; c < nch; ++c) {
     const unsigned char* cur = smem + (c & 1) * T9_BUF;
     const float* ctrl = (const float*)(cur + T9_CTRL);
@@ -1193,6 +1195,7 @@ __device__ __forceinline__ void tnb9_consume(const TnArgs& p, const int s, const
     }
     if (DBG != 8 && DBG != 10) __syncthreads();
   }
+  if (DBG == 3) ts1 = (long long)wall_clock64();
   if (DBG != 9) __syncthreads();                   // the staging waves' final 2^-s
   const float* sinv = (const float*)(smem + T9_SINV);
   const int col = wj * 32 + r;
@@ -1206,6 +1209,13 @@ __device__ __forceinline__ void tnb9_consume(const TnArgs& p, const int s, const
     for (int q = 0; q < 16; ++q) {
       const int io = i0 + wi * 32 + mfma_row(q, lane);         // p.ps: kernel row sp*F + c is torch channel c*4 + sp
       out[(long)(p.ps ? (io % ps_f) * 4 + io / ps_f : io) * p.NJ + j0 + col] = acc[u][q] * (sinv[dxi * 64 + wi * 32 + mfma_row(q, lane)] * ib);
+    }
+  }
+  if (DBG == 3 && lane == 0 && p.part_colsum) {      // stamps (10-ns units) of block 0 .. 3's matrix waves: loop start, loop end, done
+    const long long ts2 = (long long)wall_clock64();
+    if (blockIdx.x < 4) {
+      long long* d = (long long*)p.part_colsum + ((long)blockIdx.x * 8 + (H2 * 4 + wi * 2 + wj)) * 4;
+      d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = nch;
     }
   }
 }
@@ -1681,7 +1691,7 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
       const char* e = sr_getenv("SRHIP_TN_DBG");
       const int dbg = e ? atoi(e) : 0;
 #define SR_T9DBG(D_) if (dbg == D_) { reserve_lds(k_tnb9<D_>, T9_LDS, "k_tnb9"); hipLaunchKernelGGL(k_tnb9<D_>, dim3(p.S * tiles), dim3(T9_THREADS), T9_LDS, st, p, tiles, xcd); return 0; }
-      SR_T9DBG(1) SR_T9DBG(2) SR_T9DBG(6) SR_T9DBG(7) SR_T9DBG(8) SR_T9DBG(9) SR_T9DBG(10)
+      SR_T9DBG(1) SR_T9DBG(2) SR_T9DBG(6) SR_T9DBG(7) SR_T9DBG(3) SR_T9DBG(8) SR_T9DBG(9) SR_T9DBG(10)
 #undef SR_T9DBG
     }
 #endif

@@ -134,10 +134,12 @@ __global__ void __launch_bounds__(256) k_conv_cin1_wgrad(const float* __restrict
           }
 #pragma unroll
           for (int i = 0; i < CO_PER_LANE; ++i) {
-            const float g = gq[u][i];
+            if (64 * i < Co) {           // (wave-uniform: a 64-channel tensor skips three quarters of these FMAs)
+              const float g = gq[u][i];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[i][t] += g * xv[t / 3][t % 3];
-            acc[i][9] += g;
+              for (int t = 0; t < 9; ++t) acc[i][t] += g * xv[t / 3][t % 3];
+              acc[i][9] += g;
+            }
           }
         }
       }
@@ -213,6 +215,8 @@ __global__ void __launch_bounds__(128, 2) k_conv_cout1_fwd(const float* __restri
     if (sy >= 0 && sy < H && sx >= 0 && sx < W) inb |= 1u << k;
     src[k] = (unsigned)(((((long)b * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 1)) * ldx + c4 * 4) >> 2);
   }
+  // (Round 6, measured and dropped: TWO chunks in flight, with __syncthreads() or with LDS-only barriers around the store --
+  // 252 registers, 267 us against 163 on EDSR's 537-MB tail input.)
   f32x4 v[NV];
   auto fetch = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
