@@ -619,7 +619,7 @@ def test_step_graph_with_droppath_follows_the_per_step_seed(SwinIR):
     assert torch.equal(runs[0][1], runs[1][1])
     # the same batch every step: a repeated mask would repeat the loss up to the (small) weight change; masks that differ
     # move it by far more -- at least one consecutive pair must differ visibly in the replayed run
-    l = runs[1][0][:, 0]
+    l = runs[1][0][:, 1]                                  # (loss_buf = [total (host-side), term 1, ...])
     assert (l[1:] - l[:-1]).abs().max() > 1e-3 * l.abs().max(), l
 
 
