@@ -921,3 +921,34 @@ def test_fused_step_with_img_range():
     for k in ts.fp.names:
         a, b = ts.fp.gviews[k], ref[k]
         assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), k
+
+
+def test_recompute_gelu_in_the_weight_gradient_matches_the_stored_form(SwinIR):
+    """SRHIP_RECOMPUTE_GH=1 (round 6; opt-in because it measured slower): the fused MLP backward does not
+    store gelu(h), the grouped weight-gradient launch recomputes it from the saved h in its operand prologue (b_mode 2, the
+    forward's own packed x Phi(x), instantiation tnb_body_h<3, 2, true, true> with DropPath row scales / the generic one
+    without).  Every parameter gradient of the tiny net and of a README-width net equals the stored form's to rounding."""
+    from srhip.train import TrainStep, Optimizer
+    for kw, dpr in ((dict(depths=[2, 2], embed_dim=60, num_heads=[6, 6]), 0.0), (dict(depths=[2], embed_dim=180, num_heads=[6]), 0.3)):
+        torch.manual_seed(5)
+        grads = {}
+        for mode in ("0", "1"):
+            os.environ["SRHIP_RECOMPUTE_GH"] = mode
+            try:
+                torch.manual_seed(11)
+                net = SwinIR(upscale=8, in_chans=1, img_size=16, window_size=8, mlp_ratio=2, upsampler="pixelshuffledirect",
+                             drop_path_rate=dpr, **kw).cuda().train()
+                ts = TrainStep(net, [("l1", 1.0)])
+                ts.opt = Optimizer(ts.fp, "sgd", lr=0.0, momentum=0.0, nesterov=False, wd=0.0)
+                gen = torch.Generator().manual_seed(3)
+                lr_img, hr_img = torch.rand(2, 1, 16, 16, generator=gen).cuda(), torch.rand(2, 1, 128, 128, generator=gen).cuda()
+                torch.manual_seed(77)                      # the same DropPath masks in both runs
+                ts.step(lr_img, hr_img)
+                torch.cuda.synchronize()
+                grads[mode] = {k: ts.fp.gviews[k].clone() for k in ts.fp.names}
+            finally:
+                os.environ.pop("SRHIP_RECOMPUTE_GH", None)
+        for k in grads["0"]:
+            a, b = grads["1"][k], grads["0"][k]
+            assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-12), k
+        assert any("fc2.weight" in k for k in grads["0"])
