@@ -612,9 +612,9 @@ class SwinIREngine:
         def resi_conv_bwd(name, pre, d, src, rc, dsrc):
             """d = gradient of the conv's output; src its input; writes dsrc and the parameter gradients."""
             if not self.conv3:
-                ops.conv3x3_wgrad(d, src, G(pre + "weight"), G(pre + "bias"))
+                ev = side(lambda: ops.conv3x3_wgrad(d, src, G(pre + "weight"), G(pre + "bias")))
                 ops.conv3x3(d, ws[name + ".wpt"], None, C, out=dsrc)
-                return
+                return ev
             P, c4 = self.c4p, self.c4
             c0, c1 = rc
             dw4 = buf("rc.dw4", C, P, 3, 3)
@@ -635,11 +635,6 @@ class SwinIREngine:
             G(pre + "0.bias").copy_(db0[:c4])
             ops.conv3x3(dc0, ws[name + ".0.wpt"], None, C, out=dsrc)
 
-        dtn = buf("dtn", T, C)
-        resi_conv_bwd("cab", "conv_after_body.", df, sv["tn"].view(B, H, W, C), sv["cab_rc"], dtn.view(B, H, W, C))
-        dt = buf("dt", T, C)
-        ops.layernorm_bwd(dtn, sv["t_last"], sv["st_n"], dt, gamma=net.norm.weight.data,
-                          dgamma=G("norm.weight"), dbeta=G("norm.bias"))
         # The weight gradients of ALL blocks of an RSTB layer go through ONE grouped launch + ONE reducer at the layer's
         # end (bf16x3 kernels: up to 24 problems): 4 x depth problems = 48 tiles fill the chip with 5 reduce slices
         # where one block's 8 tiles need 32 -- a sixth of the partial-sum traffic (33 MB written + read per block) and of
@@ -649,8 +644,40 @@ class SwinIREngine:
         max_nb = max(len(l.residual_group.blocks) for l in net.layers)
         defer = ws.use_bx3 and 4 * max_nb <= 24 and os.environ.get("SRHIP_WGRAD_PER_BLOCK", "0") != "1"
         nset = max_nb if defer else 1
-        gbufs = [buf(f"g{i}", T, C) for i in range(2 * nset + 1)]
-        dhs = [buf(f"dh{i}", T, hid) for i in range(nset)]
+        # SRHIP_SWIN_SIDE_WGRAD=1 (round 6 experiment): a layer's grouped weight-gradient launch, its reducers, the bias-table
+        # reductions and the RSTB conv's weight gradient go to a SIDE stream and run beside the next layer's data-gradient
+        # chain (no weight gradient is on that chain).  Their operands then outlive the layer: two sets of the per-layer
+        # buffers, by layer parity (+1.3 GB).
+        side_on = defer and dev.type == "cuda" and os.environ.get("SRHIP_SWIN_SIDE_WGRAD", "1") == "1"
+        if side_on and getattr(self, "wstream", None) is None:
+            self.wstream = torch.cuda.Stream(device=dev)
+        main_stream = torch.cuda.current_stream() if dev.type == "cuda" else None
+
+        side_done = []       # one event per finished layer on the side stream
+
+        def side(fn):
+            if not side_on:
+                fn()
+                return None
+            ev = torch.cuda.Event()
+            ev.record(main_stream)
+            self.wstream.wait_event(ev)
+            with torch.cuda.stream(self.wstream):
+                fn()
+                done = torch.cuda.Event()
+                done.record(self.wstream)
+            return done
+
+        dtn = buf("dtn", T, C)
+        resi_conv_bwd("cab", "conv_after_body.", df, sv["tn"].view(B, H, W, C), sv["cab_rc"], dtn.view(B, H, W, C))
+        dt = buf("dt", T, C)
+        ops.layernorm_bwd(dtn, sv["t_last"], sv["st_n"], dt, gamma=net.norm.weight.data,
+                          dgamma=G("norm.weight"), dbeta=G("norm.bias"))
+        def layer_bufs(par):
+            sfx = f".p{par}" if side_on else ""
+            return ([buf(f"g{i}{sfx}", T, C) for i in range(2 * nset + 1)], [buf(f"dh{i}{sfx}", T, hid) for i in range(nset)],
+                    [buf(f"dqkv{i}{sfx}", T, 3 * C) for i in range(nset)], sfx)
+        gbufs, dhs, dqkvs, sfx = layer_bufs(0)
         # gelu(h), operand of the fc2 weight gradient: by-product of the dgelu epilogue.  SRHIP_RECOMPUTE_GH=1 (round 6, VERDICT
         # r5 item 1a): the fused backward does NOT store it (47 MB per block less written at B = 8) and the grouped weight-gradient
         # launch recomputes it from the saved h in its operand prologue (b_mode 2, the forward's own packed x Phi(x)).  Measured
@@ -659,7 +686,7 @@ class SwinIREngine:
         # round of 240 blocks and ends with its slowest block): 689 against 708 patches/s -- a loss, so it stays opt-in.
         recompute_gh = (self.fuse_mlp_h and ws.use_bx3 and ops.F16X2 and os.environ.get("SRHIP_RECOMPUTE_GH", "0") == "1")
         ghs = [None if recompute_gh else buf(f"gh{i}", T, hid) for i in range(nset)]
-        dqkvs = [buf(f"dqkv{i}", T, 3 * C) for i in range(nset)]
+        ghs2 = [None if recompute_gh else buf(f"gh{i}.p1", T, hid) for i in range(nset)] if side_on else ghs
         dxh, da = buf("dxh", T, C), buf("da", T, C)
         nrot = len(gbufs)
         bi = len(self.blocks)
@@ -669,10 +696,15 @@ class SwinIREngine:
             layer = net.layers[li]
             t_in, t_blocks, rc = sv["layers"][li]
             pre = f"layers.{li}."
+            if side_on:        # this layer's set: the other one may still be read by the layer behind it on the side stream
+                gbufs, dhs, dqkvs, sfx = layer_bufs(li & 1)
+                if len(side_done) >= 2:          # ... and the layer two back, which had THIS set, has to be through with it
+                    main_stream.wait_event(side_done[-2])
+            ghs_l = ghs2 if (side_on and (li & 1)) else ghs
             gi = 0
             g = gbufs[gi]
-            resi_conv_bwd(f"l{li}", pre + "conv.", dt.view(B, H, W, C), t_blocks.view(B, H, W, C), rc,
-                          g.view(B, H, W, C))
+            conv_done = resi_conv_bwd(f"l{li}", pre + "conv.", dt.view(B, H, W, C), t_blocks.view(B, H, W, C), rc,
+                                      g.view(B, H, W, C))
             nb = len(layer.residual_group.blocks)
             # data-parallel runs: layer 0 announces its gradients in up to three buckets (bucket_prefixes); `cuts` maps
             # the block index at which a group is complete to the bucket to announce there
@@ -691,11 +723,12 @@ class SwinIREngine:
             dparts = None
             if len(lheads) == 1 and ops.wattn_f16_ok(C, next(iter(lheads))):
                 nbmax = max(len(l.residual_group.blocks) for l in net.layers)
-                dparts = buf("dbias_parts", nbmax, ops.wattn_dbias_ws(B, H, W, max(b.num_heads for b in self.blocks)))
+                dparts = buf("dbias_parts" + (f".p{li & 1}" if side_on else ""), nbmax,
+                             ops.wattn_dbias_ws(B, H, W, max(b.num_heads for b in self.blocks)))
                 dparts = dparts[:nb, :ops.wattn_dbias_ws(B, H, W, next(iter(lheads)))]
             for j in reversed(range(nb)):
                 bi -= 1
-                dh, gh, dqkv = dhs[j % nset], ghs[j % nset], dqkvs[j % nset]
+                dh, gh, dqkv = dhs[j % nset], ghs_l[j % nset], dqkvs[j % nset]
                 blk = layer.residual_group.blocks[j]
                 p = pre + f"residual_group.blocks.{j}."
                 t, st1, qkv, a, x1, st2, h = sv["blocks"][bi]
@@ -760,18 +793,27 @@ class SwinIREngine:
                 gi = (gi + 2) % nrot
                 g = gout
                 if j in cuts:            # blocks [j, flushed_hi) are complete: their gradients now, their bucket announced
-                    ops.linear_wgrad_grouped(pending)
+                    def cut_end(pending=pending, flushed_hi=flushed_hi, j=j, bi=bi):
+                        ops.linear_wgrad_grouped(pending)
+                        self._bias_table_grads(layer, pre, dparts, dbT_all, bi - j, j, flushed_hi, lheads, B, H, W, G)
+                        on_layer_done(cuts[j])       # on the side stream: the bucket's all-reduce is ordered behind it
+                    side(cut_end)
                     pending = []
-                    self._bias_table_grads(layer, pre, dparts, dbT_all, bi - j, j, flushed_hi, lheads, B, H, W, G)
                     flushed_hi = j
-                    on_layer_done(cuts[j])
-            if pending:
-                ops.linear_wgrad_grouped(pending)
-            # relative-position-bias table gradients of the layer's blocks: one launch (<= 8 blocks each)
-            self._bias_table_grads(layer, pre, dparts, dbT_all, bi, 0, flushed_hi, lheads, B, H, W, G)
+            def layer_end(pending=pending, layer=layer, pre=pre, dparts=dparts, bi=bi, flushed_hi=flushed_hi, lheads=lheads, li=li,
+                          cuts=cuts):
+                if pending:
+                    ops.linear_wgrad_grouped(pending)
+                # relative-position-bias table gradients of the layer's blocks: one launch (<= 8 blocks each)
+                self._bias_table_grads(layer, pre, dparts, dbT_all, bi, 0, flushed_hi, lheads, B, H, W, G)
+                if on_layer_done is not None and not cuts:   # this layer's gradients are enqueued (all of them on this stream)
+                    on_layer_done(len(net.layers) - 1 - li)
+            side_done.append(side(layer_end))
+            if conv_done is not None:            # the side stream's conv weight gradient reads dt
+                main_stream.wait_event(conv_done)
             ops.axpby(dt, g, 1.0, 1.0)   # RSTB skip: t_out = conv(blocks(t_in)) + t_in
-            if on_layer_done is not None and not cuts:   # this layer's gradients are enqueued
-                on_layer_done(len(net.layers) - 1 - li)
+        if side_on:
+            main_stream.wait_stream(self.wstream)            # every weight gradient is in before anything reads them
         # patch_embed.norm and the conv_after_body skip (f = conv(..) + f0)
         if net.ape:     # d table = sum over the batch of the token gradient
             dpos = G("absolute_pos_embed").view(H * W, C)

@@ -952,3 +952,34 @@ def test_recompute_gelu_in_the_weight_gradient_matches_the_stored_form(SwinIR):
             a, b = grads["1"][k], grads["0"][k]
             assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-12), k
         assert any("fc2.weight" in k for k in grads["0"])
+
+
+def test_side_stream_weight_gradients_match_the_in_order_form(SwinIR):
+    """SRHIP_SWIN_SIDE_WGRAD=1 (round 6 experiment, opt-in): each RSTB layer's grouped weight-gradient launch, its reducers
+    and the bias-table reductions run on a side stream beside the next layer's data-gradient chain, the per-layer operand
+    buffers double by layer parity.  Four layers (so a buffer set is reused two layers on), eager and under graph replay:
+    every parameter gradient is bit-identical to the in-order form's (same kernels, same fixed-order reductions)."""
+    from srhip.train import TrainStep, Optimizer
+    grads = {}
+    for mode in ("0", "1", "1g"):
+        os.environ["SRHIP_SWIN_SIDE_WGRAD"] = mode[0]
+        try:
+            torch.manual_seed(11)
+            net = SwinIR(upscale=8, in_chans=1, img_size=16, window_size=8, mlp_ratio=2, upsampler="pixelshuffledirect",
+                         drop_path_rate=0.0, depths=[2, 2, 2, 2], embed_dim=60, num_heads=[6, 6, 6, 6]).cuda().train()
+            ts = TrainStep(net, [("l1", 1.0)])
+            ts.opt = Optimizer(ts.fp, "sgd", lr=0.0, momentum=0.0, nesterov=False, wd=0.0)
+            gen = torch.Generator().manual_seed(3)
+            lr_img, hr_img = torch.rand(2, 1, 16, 16, generator=gen).cuda(), torch.rand(2, 1, 128, 128, generator=gen).cuda()
+            if mode == "1g":
+                for _ in range(3):
+                    ts.step_graph(lr_img, hr_img)
+            else:
+                ts.step(lr_img, hr_img)
+            torch.cuda.synchronize()
+            grads[mode] = {k: ts.fp.gviews[k].clone() for k in ts.fp.names}
+        finally:
+            os.environ.pop("SRHIP_SWIN_SIDE_WGRAD", None)
+    for mode in ("1", "1g"):
+        for k in grads["0"]:
+            assert torch.equal(grads[mode][k], grads["0"][k]), (mode, k)
