@@ -1388,6 +1388,304 @@ __global__ void __launch_bounds__(T9_THREADS) k_tnb9(TnArgs p, int tiles, int xc
   tnb_body9<DBG>(p, L / tiles, L % tiles, smem);
 }
 
+// ---------------------------------------------------------------------------
+// The STRIP form of the nine-tap block (round 6, third form; images whose width is a multiple of 64).
+//
+// What the token-order form above still pays (role ablations, 8 x 256 x 256, 64 -> 256, same box: everything 786 us | matrix
+// waves alone 362 | only TWO of the six staging waves working 702 | only ONE 656): a staging wave needs ~1.2 us for the ~350
+// instructions of its 16-token chunk (load addresses, dense-chunk test, maxima, split, LDS writes), the block waits for it at
+// every chunk's barrier, and there are SIX tiles per chunk because the +-1 shifts of dY and the +-1 rows of X are staged as
+// copies.  Here a block walks a 64-pixel-wide STRIP of the image downwards, one pixel row (four 16-token chunks) per barrier:
+//   * X row y + 1 is staged ONCE and stays in a four-row ring: it is the dy = +1 operand of row y, dy = 0 of y + 1 and
+//     dy = -1 of y + 2;
+//   * dY row y is staged ONCE with a one-pixel halo on either side (the neighbour strip's pixel, zero at the image's edge);
+//     the matrix waves build the dx = +-1 operands in registers: a lane's k-octet plus the neighbour octet's edge token,
+//     funnel-shifted by 16 bits (v_alignbit_b32, 16 per chunk and wave);
+// -- 130 tokens staged per 64 tokens of product instead of 384, by FOUR staging waves (one per SIMD) that work on 32 / 33
+// tokens per barrier with one row-address computation (no per-token coordinates: a strip's rows are arithmetic sequences of
+// the flattened (image, y) row index, in the PixelShuffle form too), one row ahead.  Rows outside the
+// image (dy = -1 above the first row, +1 below the last): the matrix waves leave those taps out for that row.  A lane gets its
+// octet's neighbour tokens from a small per-octet edge array (first | last token, one dword per column: conflict-free, where
+// the octets' own dwords 32 bytes apart would be read four lanes to a bank); the halo pixels are that array's outer entries.
+// 108 KB of LDS (two dY rows, four X rows); sixteen waves, one block per CU: per SIMD one staging wave and the three matrix
+// waves of one 32 x 32 quadrant, one tap ROW each (nine MFMAs per chunk from two X and two dY fragment reads; 48 accumulator
+// registers, so the compiler can keep several chunks' reads in flight inside the 128 of a 16-wave block).  Exponents as
+// in tnb_body9 (fixed per block from the first row, the true maxima checked at the end, one retry); the two waves that stage
+// halves of the same columns agree on them through LDS.  Slices are row ranges of one strip (S >= the strip count).
+// ---------------------------------------------------------------------------
+constexpr int S9_SUB = 64 * 32;                   // bytes per chunk sub-buffer and plane: 64 columns x two octets x 16 B
+constexpr int S9_DYPL = 4 * S9_SUB;               // a dY row, one plane
+constexpr int S9_EDGE = 10 * 256;                 // .. and its octets' edge tokens, one plane: [octet -1 .. 8][64 columns] dwords
+constexpr int S9_DYE = 2 * S9_DYPL;               // (first token | last token << 16); octets -1 and 8 are the halo pixels
+constexpr int S9_DYROW = 2 * S9_DYPL + 2 * S9_EDGE;
+constexpr int S9_XPL = 4 * S9_SUB;
+constexpr int S9_XROW = 2 * S9_XPL;
+constexpr int S9_X0 = 2 * S9_DYROW;               // the X ring (four rows) behind the two dY rows
+constexpr int S9_MISC = S9_X0 + 4 * S9_XROW;
+constexpr int S9_SINV = S9_MISC;                  // [2][64]: 2^-s of the dY / X columns
+constexpr int S9_MAX = S9_MISC + 512;             // [4][64]: the staging waves' column maxima
+constexpr int S9_CS = S9_MISC + 1536;             // [2][64]: column sums of the two dY halves
+constexpr int S9_RETRY = S9_MISC + 2048;
+constexpr int S9_LDS = S9_MISC + 2304;
+constexpr int S9_THREADS = 16 * 64;
+static_assert(S9_LDS <= 160 * 1024, "LDS of one CU");
+
+// matrix wave of tap row DYI (dy = DYI - 1; taps 3 DYI + dx index) and quadrant (wi, wj) of the 64 x 64 tile
+template <int DYI, int DBG = 0>
+__device__ __forceinline__ void tnb9s_consume(const TnArgs& p, const int s, const int i0, const int j0, const int r0, const int r1,
+                                              const int nsteps, unsigned char* smem, const int wi, const int wj, const int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc[3];
+  const int a_self = unit_slot3(wi * 32 + r, h) * 16;                     // + c * S9_SUB: the lane's octet 2 c + h of chunk c
+  const int a_edge = S9_DYE + h * 256 + (wi * 32 + r) * 4;                // + c * 512: edge tokens of octet 2 c + h - 1, + 512: 2 c + h + 1
+  const int b_self = unit_slot3(wj * 32 + r, h) * 16;
+  {
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[u][q] = 0.f;
+    __syncthreads();                                 // (the staging waves' maxima)
+    __syncthreads();                                 // rows r0 - 1 .. r0 + 1 of X and r0 of dY are in place
+    int y = r0 % p.H;
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k) {
+      const int row = r0 + k;
+      // the wave's X row lies outside the image (dy = -1 above the first row, +1 below the last): nothing to add
+      const bool inside = DYI == 1 || (DYI == 0 ? y > 0 : y < p.H - 1);
+      if (row < r1 && inside) {
+        const unsigned char* dyb = smem + (row & 1) * S9_DYROW;
+        const unsigned char* xb = smem + S9_X0 + ((row + DYI - 1 + 4) & 3) * S9_XROW + b_self;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const u32x4 dummy = u32x4{(unsigned)lane, 0x3c003c00u, 0x3c003c00u, (unsigned)c};
+          const u32x4 bh = (DBG >= 6) ? dummy : *(const u32x4*)(xb + c * S9_SUB);
+          const u32x4 bl = (DBG >= 6) ? dummy : *(const u32x4*)(xb + S9_XPL + c * S9_SUB);
+          u32x4 a[2][3];                             // [plane][dx index]: dx index 2 (dx = +1) pairs token q with dY[q - 1], 0 with dY[q + 1]
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            const u32x4 d = (DBG >= 6) ? dummy : *(const u32x4*)(dyb + pl * S9_DYPL + a_self + c * S9_SUB);
+            const unsigned pv = (DBG >= 6) ? 0u : *(const unsigned*)(dyb + pl * S9_EDGE + a_edge + c * 512);         // last token: high half
+            const unsigned nx = (DBG >= 6) ? 0u : *(const unsigned*)(dyb + pl * S9_EDGE + a_edge + c * 512 + 512);   // first token: low half
+            a[pl][1] = d;
+            a[pl][2] = u32x4{__builtin_amdgcn_alignbit(d.x, pv, 16), __builtin_amdgcn_alignbit(d.y, d.x, 16),
+                             __builtin_amdgcn_alignbit(d.z, d.y, 16), __builtin_amdgcn_alignbit(d.w, d.z, 16)};
+            a[pl][0] = u32x4{__builtin_amdgcn_alignbit(d.y, d.x, 16), __builtin_amdgcn_alignbit(d.z, d.y, 16),
+                             __builtin_amdgcn_alignbit(d.w, d.z, 16), __builtin_amdgcn_alignbit(nx, d.w, 16)};
+          }
+          if (DBG != 1) {
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+#pragma unroll
+              for (int u = 0; u < 3; ++u) {
+                if (term == 0) acc[u] = mfma_h(a[1][u], bh, acc[u]);
+                else if (term == 1) acc[u] = mfma_h(a[0][u], bl, acc[u]);
+                else acc[u] = mfma_h(a[0][u], bh, acc[u]);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      y = (y + 1 == p.H) ? 0 : y + 1;
+    }
+    __syncthreads();                                 // the staging waves' 2^-s
+  }
+  const float* sinv = (const float*)(smem + S9_SINV);
+  const int col = wj * 32 + r;
+  const int ps_f = p.NI >> 2;
+  const float ib = sinv[64 + col];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    float* out = p.part + ((long)(s * 9 + 3 * DYI + u) * p.NI) * p.NJ;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int il = wi * 32 + mfma_row(q, lane), io = i0 + il;   // p.ps: kernel row sp*F + c is torch channel c*4 + sp
+      out[(long)(p.ps ? (io % ps_f) * 4 + io / ps_f : io) * p.NJ + j0 + col] = acc[u][q] * (sinv[il] * ib);
+    }
+  }
+}
+
+// words per block behind the partial sums (S9_AUX floats each): [0] = 1 if some column's exponent did not hold in pass 0,
+// [64 ..): the four staging waves' column maxima
+constexpr int S9_AUX = 64 + 4 * 64;
+
+template <int DBG = 0>
+__device__ __forceinline__ void tnb_body9s(const TnArgs& p, const int s, const int tile, const int tiles, const int pass,
+                                           unsigned char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  float* const aux = p.part + (long)p.S * 9 * p.NI * p.NJ + (long)(s * tiles + tile) * S9_AUX;
+  // pass 1 (one resident block per CU walks the block list, right behind pass 0): only the blocks whose exponents did not
+  // hold run again, with exact ones
+  if (pass && !__builtin_amdgcn_readfirstlane(*(const int*)aux)) return;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nbj = p.NJ / 64;
+  const int bi = tile / nbj, bj = tile - bi * nbj;
+  const int i0 = bi * 64, j0 = bj * 64;
+  // slice -> (strip, row range of the flattened (image, y) index)
+  // strip k owns the slices [k S / nstrips, (k + 1) S / nstrips): at least one each (S >= nstrips)
+  const int nstrips = p.Wd >> 6;
+  int strip = 0;
+  while ((strip + 1) * p.S / nstrips <= s) ++strip;
+  const int s_first = strip * p.S / nstrips, sps = (strip + 1) * p.S / nstrips - s_first;
+  const int ss = s - s_first;
+  const int RT = p.batch * p.H;
+  const int rps = (RT + sps - 1) / sps;
+  const int r0 = min(RT, ss * rps), r1 = min(RT, r0 + rps);
+  const int nsteps = r1 - r0;
+  const int x0 = strip * 64;
+  const bool colsum = p.part_colsum && bj == 0;
+  if (wave < 12) {              // waves q, q + 4, q + 8 (one SIMD): quadrant q of the tile, tap rows dy = -1, 0, +1
+    const int q4 = wave & 3;
+    if (wave < 4) tnb9s_consume<0, DBG>(p, s, i0, j0, r0, r1, nsteps, smem, q4 >> 1, q4 & 1, lane);
+    else if (wave < 8) tnb9s_consume<1, DBG>(p, s, i0, j0, r0, r1, nsteps, smem, q4 >> 1, q4 & 1, lane);
+    else tnb9s_consume<2, DBG>(p, s, i0, j0, r0, r1, nsteps, smem, q4 >> 1, q4 & 1, lane);
+    if (colsum) __syncthreads();
+    return;
+  }
+  // ---------------- staging wave sw: 0 / 1 = dY tokens [-1, 32) / [32, 65) of the strip's row, 2 / 3 = X tokens [0, 32) / [32, 64)
+  const int sw = wave - 12;
+  const bool isB = sw >= 2;
+  const int half = sw & 1;
+  struct Stage { float v[32]; float halo; };
+  const int ps_f = p.NI >> 2;
+  unsigned colb = (unsigned)lane * 4u;
+  if (!isB && p.ps) {
+    const int ig = i0 + lane, sp = ig / ps_f, cc = ig - sp * ps_f;
+    colb = (unsigned)((((sp >> 1) * 2 * p.Wd + (sp & 1)) * (int)p.lda + cc) * 4);
+  }
+  const bool psA = !isB && p.ps;
+  const float* const P = isB ? p.B + j0 : (p.ps ? p.A : p.A + i0);      // uniform
+  const long ld = isB ? p.ldb : p.lda;
+  const long adv = psA ? 2 * ld : ld;              // floats between consecutive tokens of a row
+  const int last_need = isB ? min(RT - 1, r1) : r1 - 1;      // last row of the operand this slice reads
+  const int hx = half ? x0 + 64 : x0 - 1;          // the dY waves' halo pixel
+  const bool halo_ok = !isB && hx >= 0 && hx < p.Wd;
+  float cs = 0.f, sc = 1.f, mxrun = 0.f;
+  auto pick = [](float m) __attribute__((always_inline)) { return exp2f(fminf(fmaxf(4.f - floorf(log2f(m)), -120.f), 120.f)); };
+  auto load = [&](int rr, Stage& g) __attribute__((always_inline)) {
+    if (rr >= 0 && rr <= last_need) {              // uniform
+      const long tok = psA ? 4L * rr * p.Wd : (long)rr * p.Wd;            // the row's first pixel
+      const float* q = P + (tok + (psA ? 2 : 1) * (x0 + 32 * half)) * ld;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        g.v[t] = ColVec<1>::ldg(q, colb);
+        q += adv;
+      }
+      g.halo = halo_ok ? ColVec<1>::ldg(P + (tok + (psA ? 2 : 1) * hx) * ld, colb) : 0.f;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 32; ++t) g.v[t] = 0.f;
+      g.halo = 0.f;
+    }
+  };
+  auto stage_max = [&](const Stage& g) __attribute__((always_inline)) {
+    float m = fabsf(g.halo);
+#pragma unroll
+    for (int t = 0; t < 32; ++t) m = fmaxf(m, fabsf(g.v[t]));
+    return m;
+  };
+  // row rr of the operand -> its ring buffer; planes PL apart; this wave's octets 4 half .. 4 half + 3
+  auto store = [&](int rr, const Stage& g) __attribute__((always_inline)) {
+    mxrun = fmaxf(mxrun, stage_max(g));
+    unsigned char* rb = isB ? smem + S9_X0 + ((rr + 4) & 3) * S9_XROW : smem + (rr & 1) * S9_DYROW;
+    const int PL = isB ? S9_XPL : S9_DYPL;
+    unsigned* const edge = (unsigned*)(smem + (rr & 1) * S9_DYROW + S9_DYE) + (1 + 4 * half) * 64 + lane;   // (dY) octet 4 half
+    rb += 2 * half * S9_SUB;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      unsigned qh[4], ql[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float e0 = g.v[8 * o + 2 * t], e1 = g.v[8 * o + 2 * t + 1];
+        if (!isB) cs += e0 + e1;
+        split2_pair(e0 * sc, e1 * sc, qh[t], ql[t]);
+      }
+      unsigned char* dst = rb + (o >> 1) * S9_SUB + unit_slot3(lane, o & 1) * 16;
+      *(u32x4*)(dst) = u32x4{qh[0], qh[1], qh[2], qh[3]};
+      *(u32x4*)(dst + PL) = u32x4{ql[0], ql[1], ql[2], ql[3]};
+      if (!isB) {                                  // the octet's edge tokens: first | last << 16
+        edge[o * 64] = (qh[0] & 0xffffu) | (qh[3] & 0xffff0000u);
+        edge[o * 64 + S9_EDGE / 4] = (ql[0] & 0xffffu) | (ql[3] & 0xffff0000u);
+      }
+    }
+    if (!isB) {                                    // halo pixel: the last token of octet -1 / the first of octet 8
+      unsigned hh, hl;
+      split2_pair(g.halo * sc, 0.f, hh, hl);
+      unsigned* const e = (unsigned*)(smem + (rr & 1) * S9_DYROW + S9_DYE) + (half ? 9 * 64 : 0) + lane;
+      e[0] = half ? (hh & 0xffffu) : (hh << 16);
+      e[S9_EDGE / 4] = half ? (hl & 0xffffu) : (hl << 16);
+    }
+  };
+  // (No s_setprio here: staging first -- the token-order form's choice -- 601 us, matrix waves first 591, none 580.)
+
+  const int lead = isB ? 2 : 1;                    // step k stores row r0 + k + lead
+  float* mxs = (float*)(smem + S9_MAX);
+  Stage g0;                      // ONE register stage (a second one spills at the 128 registers of a 16-wave block): a row's
+                                 // requests leave behind the previous row's stores and have the rest of the step to arrive
+  {
+    load(r0, g0);
+    mxs[sw * 64 + lane] = pass ? aux[64 + sw * 64 + lane] : stage_max(g0);
+    if (lane == 0 && sw == 0) *(volatile int*)(smem + S9_RETRY) = 0;
+    __syncthreads();
+    {
+      const float m2 = fmaxf(mxs[sw * 64 + lane], mxs[(sw ^ 1) * 64 + lane]);      // both halves of the column
+      float mw = m2;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+      const float m = (m2 > 0.f || pass) ? m2 : mw;          // pass 0: a column without a nonzero yet takes the tile's
+      sc = m > 0.f ? pick(m) : 1.f;
+    }
+    store(r0, g0);
+    if (isB) {
+      load(r0 - 1, g0);
+      store(r0 - 1, g0);
+      load(r0 + 1, g0);
+      store(r0 + 1, g0);
+    }
+    load(r0 + lead, g0);
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k) {
+      if (DBG != 2 && DBG < 7) { store(r0 + k + lead, g0); load(r0 + k + lead + 1, g0); }
+      __syncthreads();
+    }
+    if (half == 0) ((float*)(smem + S9_SINV))[(isB ? 64 : 0) + lane] = 1.0f / sc;
+    if (!pass) {
+      aux[64 + sw * 64 + lane] = mxrun;            // pass 1 takes both halves' maxima from here
+      const float top = mxrun * sc;
+      if (__any(top > 60000.f || (mxrun > 0.f && top < 0.5f)) && lane == 0) *(volatile int*)(smem + S9_RETRY) = 1;
+    }
+    if (colsum && !isB) ((float*)(smem + S9_CS))[half * 64 + lane] = cs;
+    __syncthreads();
+    if (!pass && sw == 0 && lane == 0) *(int*)aux = *(volatile const int*)(smem + S9_RETRY);
+  }
+  if (colsum) {
+    __syncthreads();
+    if (sw == 0) {
+      const float* c2 = (const float*)(smem + S9_CS);
+      const int io = i0 + lane;
+      p.part_colsum[(long)s * p.NI + (p.ps ? (io % ps_f) * 4 + io / ps_f : io)] = c2[lane] + c2[64 + lane];
+    }
+  }
+}
+
+// PASS 0: one block per (slice, tile).  PASS 1 (its own instantiation: the loop around the body costs the first pass registers):
+// at most one resident block per CU walks the block list and runs the flagged ones again.
+template <int DBG = 0, int PASS = 0>
+__global__ void __launch_bounds__(S9_THREADS) k_tnb9s(TnArgs p, int tiles, int xcd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (PASS) {
+#pragma unroll 1
+    for (int L = blockIdx.x; L < p.S * tiles; L += gridDim.x) {
+      tnb_body9s<DBG>(p, L / tiles, L % tiles, tiles, 1, smem);
+      __syncthreads();
+    }
+    return;
+  }
+  const int L = xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  tnb_body9s<DBG>(p, L / tiles, L % tiles, tiles, 0, smem);
+}
+
 template <int DBG = 0, bool F16 = false>
 __global__ void __launch_bounds__(512, SR_TNB3_OCC) k_tnb3(TnArgs p, int tiles, int xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1542,6 +1840,31 @@ __global__ void __launch_bounds__(T9_THREADS) k_tnb9_conv_batched(TnbConvBatch g
   tnb_body9<0>(p, sl, tile, smem);
 }
 
+template <int PASS>
+__global__ void __launch_bounds__(S9_THREADS) k_tnb9s_conv_batched(TnbConvBatch g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  auto one = [&](int L) __attribute__((always_inline)) {
+    int rr = L;
+    const int tile = rr % g.tiles; rr /= g.tiles;
+    const int sl = rr % g.base.S, k = rr / g.base.S;
+    TnArgs p = g.base;
+    p.A = g.A[k];
+    p.B = g.B[k];
+    p.part = g.base.part + (long)k * g.part_stride;
+    p.part_colsum = g.base.part_colsum ? g.base.part_colsum + (long)k * g.colsum_stride : nullptr;
+    tnb_body9s<0>(p, sl, tile, g.tiles, PASS, smem);
+  };
+  if (PASS) {                  // a resident grid walks the block list (see k_tnb9s)
+#pragma unroll 1
+    for (int L = blockIdx.x; L < g.base.S * g.tiles * g.n; L += gridDim.x) {
+      one(L);
+      __syncthreads();
+    }
+    return;
+  }
+  one(g.xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x);
+}
+
 // three taps per block (tnb_body3) for this problem?  SRHIP_TN_T3=0: one tap per block
 bool tnb_t3_shape(int conv, int NI, int NJ, int w) {
   static const int on = [] { const char* e = sr_getenv("SRHIP_TN_T3"); return !(e && e[0] == '0'); }();
@@ -1561,6 +1884,16 @@ bool tnb_t9_shape(int conv, int NI, int NJ, int w) {
   return on && f16 && tnb_t3_shape(conv, NI, NJ, w);
 }
 bool tnb_t9_ok(const TnArgs& p, int w) { return tnb_t9_shape(p.conv, p.NI, p.NJ, w) && tnb_t3_ok(p, w); }
+// the strip form of it (tnb_body9s): image width a multiple of 64, at least one slice per strip, four rows per slice.  SRHIP_TN_T9S=0
+// (experiments build): the token-order form
+bool tnb_t9s_ok(const TnArgs& p, int w) {
+#ifdef SR_TN_T9S_OFF
+  return false;                                    // build variant for the same-box A/B (make EXTRA=-DSR_TN_T9S_OFF)
+#endif
+  static const int on = [] { const char* e = sr_getenv("SRHIP_TN_T9S"); return !(e && e[0] == '0'); }();
+  return on && tnb_t9_ok(p, w) && p.Wd % 64 == 0 && p.S >= p.Wd / 64 &&
+         (long)p.batch * p.H * (p.Wd / 64) >= 4L * p.S;      // a slice of fewer than four rows stages more halo rows than rows
+}
 // two fp16 planes / three products in the three-tap kernels (default); SRHIP_TN_F16X2=0: three bf16 planes / six products
 bool tnb_f16() {
   static const int on = [] { const char* e = sr_getenv("SRHIP_TN_F16X2"); return !(e && e[0] == '0'); }();
@@ -1680,6 +2013,27 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
   dim3 grid(p.S, tiles, 1);
   if (p.conv) grid = dim3(p.S * tiles * 9, 1, 1);
   static const int xcd = [] { const char* e = sr_getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
+  if (tnb_t9s_ok(p, w)) {      // 64-wide conv problem, image width a multiple of 64: nine taps per block, strip walk
+    static bool attr9s = false;
+    if (!attr9s) {
+      if (int rc = reserve_lds(k_tnb9s<0, 0>, S9_LDS, "k_tnb9s")) return rc;
+      if (int rc = reserve_lds(k_tnb9s<0, 1>, S9_LDS, "k_tnb9s")) return rc;
+      attr9s = true;
+    }
+#ifdef SRHIP_EXPERIMENTS
+    {
+      const char* e = sr_getenv("SRHIP_TN_DBG");
+      const int dbg = e ? atoi(e) : 0;
+#define SR_T9DBG(D_) if (dbg == D_) { reserve_lds(k_tnb9s<D_>, S9_LDS, "k_tnb9s"); hipLaunchKernelGGL(k_tnb9s<D_>, dim3(p.S * tiles), dim3(S9_THREADS), S9_LDS, st, p, tiles, xcd); return 0; }
+      SR_T9DBG(1) SR_T9DBG(2) SR_T9DBG(6) SR_T9DBG(7)
+#undef SR_T9DBG
+    }
+#endif
+    hipLaunchKernelGGL((k_tnb9s<0, 0>), dim3(p.S * tiles), dim3(S9_THREADS), S9_LDS, st, p, tiles, xcd);
+    hipLaunchKernelGGL((k_tnb9s<0, 1>), dim3(min(p.S * tiles, 256)), dim3(S9_THREADS), S9_LDS, st, p, tiles, xcd);
+    SR_LAUNCH_CHECK("k_tnb9s");
+    return 0;
+  }
   if (tnb_t9_ok(p, w)) {       // 64-wide conv problem: all nine taps per block, one block per CU
     static bool attr9 = false;
     if (!attr9) {
@@ -1691,7 +2045,7 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
       const char* e = sr_getenv("SRHIP_TN_DBG");
       const int dbg = e ? atoi(e) : 0;
 #define SR_T9DBG(D_) if (dbg == D_) { reserve_lds(k_tnb9<D_>, T9_LDS, "k_tnb9"); hipLaunchKernelGGL(k_tnb9<D_>, dim3(p.S * tiles), dim3(T9_THREADS), T9_LDS, st, p, tiles, xcd); return 0; }
-      SR_T9DBG(1) SR_T9DBG(2) SR_T9DBG(6) SR_T9DBG(7) SR_T9DBG(3) SR_T9DBG(8) SR_T9DBG(9) SR_T9DBG(10)
+      SR_T9DBG(1) SR_T9DBG(2) SR_T9DBG(6) SR_T9DBG(7) SR_T9DBG(3) SR_T9DBG(8) SR_T9DBG(9) SR_T9DBG(10) SR_T9DBG(4) SR_T9DBG(5)
 #undef SR_T9DBG
     }
 #endif
@@ -1775,7 +2129,7 @@ int sr_conv_wgrad_batched_plan(int n, int M, int NI, int NJ, int* S, long* part_
     if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
   }
   *S = (int)best;
-  *part_floats_per_item = best * 9 * (long)NI * NJ;
+  *part_floats_per_item = best * 9 * (long)NI * NJ + (t9 ? best * (tiles / n) * S9_AUX : 0);      // + the strip form's per-block words
   return 0;
 }
 
@@ -1800,6 +2154,18 @@ int sr_conv_wgrad_batched_tnb(const TnArgs& base, const float* const* A, const f
   for (int k = 0; k < n; ++k) { g.A[k] = A[k]; g.B[k] = B[k]; }
   static const int xcd = [] { const char* e = sr_getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
   g.xcd = xcd;
+  if (tnb_t9s_ok(g.base, w)) { // all nine taps per block, strip walk
+    static bool attr9s = false;
+    if (!attr9s) {
+      if (int rc = reserve_lds(k_tnb9s_conv_batched<0>, S9_LDS, "k_tnb9s_conv_batched")) return rc;
+      if (int rc = reserve_lds(k_tnb9s_conv_batched<1>, S9_LDS, "k_tnb9s_conv_batched")) return rc;
+      attr9s = true;
+    }
+    hipLaunchKernelGGL(k_tnb9s_conv_batched<0>, dim3(base.S * g.tiles * n), dim3(S9_THREADS), S9_LDS, st, g);
+    hipLaunchKernelGGL(k_tnb9s_conv_batched<1>, dim3(min(base.S * g.tiles * n, 256)), dim3(S9_THREADS), S9_LDS, st, g);
+    SR_LAUNCH_CHECK("k_tnb9s_conv_batched");
+    return 0;
+  }
   if (tnb_t9_ok(g.base, w)) {  // all nine taps per block
     static bool attr9 = false;
     if (!attr9) {
@@ -1855,5 +2221,6 @@ int sr_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
   if (s < 1) s = 1;
   *S = (int)s;
   *part_floats = s * (conv ? 9 : 1) * (long)NI * NJ;
+  if (t9) *part_floats += s * tiles * S9_AUX;              // the strip form's per-block words (tnb_body9s)
   return 0;
 }

@@ -265,3 +265,64 @@ def test_conv_wgrad_batched_matches_float64(ops, n, B, H, W, C):
     ops.conv3x3_wgrad_batched(items)
     for (_, _, dw, db), (rw, rb) in zip(items, refs):
         assert relerr(dw, rw) < 2e-6 and relerr(db, rb) < 2e-6
+
+
+def _conv_wgrad_ref(x, dy):
+    Co, Ci = dy.shape[1], x.shape[1]
+    wr = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    br = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wr, br, padding=1).backward(dy.double())
+    return wr.grad, br.grad
+
+
+def _row_relerr(dW, ref):
+    """largest error of a dW row (one output channel) relative to that row's largest entry"""
+    a, b = dW.detach().double().cpu().flatten(1), ref.flatten(1)
+    return ((a - b).abs().amax(1) / b.abs().amax(1).clamp_min(1e-300)).max().item()
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,ps2", [(1, 5, 64, 64, 64, False), (2, 7, 128, 64, 64, False), (3, 4, 64, 64, 256, True),
+                                              (1, 9, 192, 64, 256, True), (2, 33, 64, 64, 128, False), (1, 3, 256, 128, 64, False)])
+def test_conv_wgrad_strip_form(ops, B, H, W, Ci, Co, ps2):
+    """The strip form of the nine-tap conv weight gradient (k_tnb9s: image width a multiple of 64; dY staged once per row with
+    a one-pixel halo and shifted in registers, X rows kept in a ring): several strips (the halo comes from the neighbour
+    strip), image borders inside a slice's row range (batch > 1), slices of one or two rows, the PixelShuffle form -- every
+    row of dW against float64 autograd."""
+    x, dy = rnd(B, Ci, H, W), rnd(B, Co, H, W)
+    rw, rb = _conv_wgrad_ref(x, dy)
+    dW, db = torch.full((Co, Ci, 3, 3), 7.0).cuda(), torch.full((Co,), 7.0).cuda()
+    dyn = dy.permute(0, 2, 3, 1).contiguous()
+    if ps2:       # the gradient of the PixelShuffle(2) output: [B, 2H, 2W, Co/4], channel c*4 + (2i + j) at pixel (2y+i, 2x+j)
+        dyn = F.pixel_shuffle(dy, 2).permute(0, 2, 3, 1).contiguous()
+    ops.conv3x3_wgrad(dyn.cuda(), x.permute(0, 2, 3, 1).contiguous().cuda(), dW, db, ps2=ps2)
+    assert _row_relerr(dW, rw) < 2e-6 and relerr(db, rb) < 2e-6
+
+
+def test_conv_wgrad_strip_form_exponents_are_checked(ops):
+    """The block fixes a column's power-of-two scale from its first row and checks the column's true maximum at the end:
+    (a) a channel that is zero in the first rows and 1e-4 of the others later, (b) pixels 1e6 times larger than the first
+    row's further down, (c) a channel 1e-6 of the others throughout, (d) all-zero channels -- every row of dW, relative to
+    its own largest entry, stays at f32 grade (the block runs a second time with exact scales where the first guess fails)."""
+    B, H, W, C = 1, 40, 64, 64
+    x, dy = rnd(B, C, H, W), rnd(B, C, H, W)
+    x[:, 3, :6] = 0
+    x[:, 3, 6:] *= 1e-4
+    dy[:, 5, :6] = 0
+    dy[:, 5, 6:] *= 1e-4
+    dy[:, :, 25:] *= 1e6
+    x[:, 9] *= 1e-6
+    dy[:, 11] *= 1e-6
+    x[:, 20] = 0
+    dy[:, 21] = 0
+    rw, rb = _conv_wgrad_ref(x, dy)
+    dW, db = torch.empty(C, C, 3, 3).cuda(), torch.empty(C).cuda()
+    ops.conv3x3_wgrad(dy.permute(0, 2, 3, 1).contiguous().cuda(), x.permute(0, 2, 3, 1).contiguous().cuda(), dW, db)
+    # rows: relative to the row's largest entry; the all-zero dY channel's row is exactly zero
+    assert dW[21].abs().max().item() == 0 and dW[:, 20].abs().max().item() == 0
+    keep = [i for i in range(C) if i != 21]
+    assert _row_relerr(dW[keep], rw[keep]) < 3e-6
+    # columns (input channels) too: the small X channels against their own scale
+    a, b = dW.detach().double().cpu().permute(1, 0, 2, 3).flatten(1), rw.permute(1, 0, 2, 3).flatten(1)
+    keepc = [j for j in range(C) if j != 20]
+    assert ((a[keepc] - b[keepc]).abs().amax(1) / b[keepc].abs().amax(1)).max().item() < 3e-6
+    assert relerr(db, rb) < 2e-6

@@ -31,6 +31,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         out.append(f"{B}x{H}x{W} {Cin}->{Cout}{' ps2' if ps2 else ''}: {us:8.1f} us/launch (+reducer)  {3 * gf / us:6.1f} TF/s fp16-equivalent")
     print(f"SRHIP_TN_DBG={os.environ.get('SRHIP_TN_DBG', '0')}: " + " | ".join(out))
 else:
-    for dbg in ("8", "10"):
+    for dbg in ("0", "1", "2"):
         env = dict(os.environ, SRHIP_TN_DBG=dbg)
         subprocess.run([sys.executable, os.path.abspath(__file__), "--one"], env=env, check=False)
