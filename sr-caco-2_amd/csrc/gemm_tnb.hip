@@ -1513,7 +1513,7 @@ template <int DBG = 0>
 __device__ __forceinline__ void tnb_body9s(const TnArgs& p, const int s, const int tile, const int tiles, const int pass,
                                            unsigned char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
-  float* const aux = p.part + (long)p.S * 9 * p.NI * p.NJ + (long)(s * tiles + tile) * S9_AUX;
+  float* const aux = p.aux + (long)(s * tiles + tile) * S9_AUX;
   // pass 1 (one resident block per CU walks the block list, right behind pass 0): only the blocks whose exponents did not
   // hold run again, with exact ones
   if (pass && !__builtin_amdgcn_readfirstlane(*(const int*)aux)) return;
@@ -1852,6 +1852,7 @@ __global__ void __launch_bounds__(S9_THREADS) k_tnb9s_conv_batched(TnbConvBatch 
     p.B = g.B[k];
     p.part = g.base.part + (long)k * g.part_stride;
     p.part_colsum = g.base.part_colsum ? g.base.part_colsum + (long)k * g.colsum_stride : nullptr;
+    p.aux = g.base.aux + (long)k * g.base.S * g.tiles * S9_AUX;
     tnb_body9s<0>(p, sl, tile, g.tiles, PASS, smem);
   };
   if (PASS) {                  // a resident grid walks the block list (see k_tnb9s)
@@ -2014,6 +2015,7 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
   if (p.conv) grid = dim3(p.S * tiles * 9, 1, 1);
   static const int xcd = [] { const char* e = sr_getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
   if (tnb_t9s_ok(p, w)) {      // 64-wide conv problem, image width a multiple of 64: nine taps per block, strip walk
+    p.aux = p.part + (long)p.S * 9 * p.NI * p.NJ;          // (sr_tn_plan_bx3 sized the workspace for it)
     static bool attr9s = false;
     if (!attr9s) {
       if (int rc = reserve_lds(k_tnb9s<0, 0>, S9_LDS, "k_tnb9s")) return rc;
@@ -2155,6 +2157,7 @@ int sr_conv_wgrad_batched_tnb(const TnArgs& base, const float* const* A, const f
   static const int xcd = [] { const char* e = sr_getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
   g.xcd = xcd;
   if (tnb_t9s_ok(g.base, w)) { // all nine taps per block, strip walk
+    g.base.aux = base.part + (long)n * part_stride;        // behind the n problems' partial sums (the plan sized it)
     static bool attr9s = false;
     if (!attr9s) {
       if (int rc = reserve_lds(k_tnb9s_conv_batched<0>, S9_LDS, "k_tnb9s_conv_batched")) return rc;

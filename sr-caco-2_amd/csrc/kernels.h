@@ -99,6 +99,7 @@ struct TnArgs {
   int i_tile, j_tile, rows_per_slice;   // set by the dispatcher
   int ps;                     // conv: A is the shuffled gradient image [batch][2H][2Wd][NI/4] of a conv + PixelShuffle(2)
                               // (lda = its pixel pitch); out rows are written in torch channel order c*4 + sp
+  float* aux;                 // set by the dispatcher: per-block words of the strip form (behind ALL partial sums of the call)
 };
 
 // the MLP half of a Swin block as one kernel per direction, on the two-plane fp16 operands of the Linear GEMMs (mlp_f16.hip)

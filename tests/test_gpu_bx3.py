@@ -326,3 +326,25 @@ def test_conv_wgrad_strip_form_exponents_are_checked(ops):
     keepc = [j for j in range(C) if j != 20]
     assert ((a[keepc] - b[keepc]).abs().amax(1) / b[keepc].abs().amax(1)).max().item() < 3e-6
     assert relerr(db, rb) < 2e-6
+
+
+def test_conv_wgrad_batched_strip_form_second_pass(ops):
+    """The batched launch on 64-wide images (strip form) with items whose exponents do not hold in the first pass (pixels that
+    grow by 1e6 down the image, a channel far below the others): the flagged blocks run again in the second pass, every item's
+    partial sums stay its own (the per-block words sit behind ALL items' partial sums), every row of dW at f32 grade."""
+    n, B, H, W, C = 5, 2, 24, 64, 64
+    items, refs = [], []
+    for k in range(n):
+        x, dy = rnd(B, C, H, W), rnd(B, C, H, W)
+        if k % 2 == 1:
+            dy[:, :, 10:] *= 1e6
+            x[:, 7, :4] = 0
+            x[:, 7, 4:] *= 1e-5
+        refs.append(_conv_wgrad_ref(x, dy))
+        items.append((dy.permute(0, 2, 3, 1).contiguous().cuda(), x.permute(0, 2, 3, 1).contiguous().cuda(),
+                      torch.full((C, C, 3, 3), 7.0).cuda(), torch.full((C,), 7.0).cuda()))
+    ops.conv3x3_wgrad_batched(items)
+    for (_, _, dw, db), (rw, rb) in zip(items, refs):
+        assert _row_relerr(dw, rw) < 3e-6 and relerr(db, rb) < 2e-6
+        a, b = dw.detach().double().cpu().permute(1, 0, 2, 3).flatten(1), rw.permute(1, 0, 2, 3).flatten(1)
+        assert ((a - b).abs().amax(1) / b.abs().amax(1)).max().item() < 3e-6
