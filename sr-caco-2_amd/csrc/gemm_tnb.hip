@@ -1409,9 +1409,22 @@ __global__ void __launch_bounds__(T9_THREADS) k_tnb9(TnArgs p, int tiles, int xc
 // the octets' own dwords 32 bytes apart would be read four lanes to a bank); the halo pixels are that array's outer entries.
 // 108 KB of LDS (two dY rows, four X rows); sixteen waves, one block per CU: per SIMD one staging wave and the three matrix
 // waves of one 32 x 32 quadrant, one tap ROW each (nine MFMAs per chunk from two X and two dY fragment reads; 48 accumulator
-// registers, so the compiler can keep several chunks' reads in flight inside the 128 of a 16-wave block).  Exponents as
-// in tnb_body9 (fixed per block from the first row, the true maxima checked at the end, one retry); the two waves that stage
-// halves of the same columns agree on them through LDS.  Slices are row ranges of one strip (S >= the strip count).
+// registers, so the compiler can keep several chunks' reads in flight inside the 128 of a 16-wave block).
+// Slices are row ranges of one strip (S >= the strip count).
+//
+// EXPONENTS.  A column's two planes hold x * sc, sc a power of two FIXED before the block's first row and never changed
+// while it runs: the matrix waves carry no per-chunk state.  (The running exponents of the token-order form cost its matrix
+// waves six flag words per chunk turned into a scalar -- v_readfirstlane -- for an almost-never-taken branch: a VALU -> SGPR
+// transfer behind MFMAs waits until the wave's matrix instructions have drained, the pipe idles once per chunk: its
+// MFMA-only loop runs 635 us with the check and 244 without.)  fp16 leaves room for a guess: the column's largest magnitude
+// of the block's first row (but at least 2^-8 of the tile's) is put into [16, 32) -- a later pixel may be 2,000 x larger
+// before the high plane overflows, and the pair resolves 2^-25 absolute, 2^-29 of that first maximum (f32 itself: 2^-24
+// relative).  The two waves that stage
+// halves of the same columns agree on it through LDS.  The staging waves track every column's TRUE maximum as they go; a
+// block whose guess did not hold (some column's maximum x sc outside [1/8, 60000]) says so in a word behind the call's
+// partial sums and leaves its maxima there, and a SECOND PASS (k_tnb9s<.., 1>: the same grid, unflagged blocks leave at
+// once) runs exactly those blocks again with exact exponents and overwrites their partial sums.  (The second run as a loop
+// inside the kernel cost the first pass its registers: 111 -> 128 + scratch, 102 -> 141 us on a 8 x 128 x 128 problem.)
 // ---------------------------------------------------------------------------
 constexpr int S9_SUB = 64 * 32;                   // bytes per chunk sub-buffer and plane: 64 columns x two octets x 16 B
 constexpr int S9_DYPL = 4 * S9_SUB;               // a dY row, one plane
@@ -1514,8 +1527,7 @@ __device__ __forceinline__ void tnb_body9s(const TnArgs& p, const int s, const i
                                            unsigned char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   float* const aux = p.aux + (long)(s * tiles + tile) * S9_AUX;
-  // pass 1 (one resident block per CU walks the block list, right behind pass 0): only the blocks whose exponents did not
-  // hold run again, with exact ones
+  // pass 1 (the same grid right behind pass 0): only the blocks whose exponents did not hold run again, with exact ones
   if (pass && !__builtin_amdgcn_readfirstlane(*(const int*)aux)) return;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nbj = p.NJ / 64;
@@ -1632,8 +1644,13 @@ __device__ __forceinline__ void tnb_body9s(const TnArgs& p, const int s, const i
       float mw = m2;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
-      const float m = (m2 > 0.f || pass) ? m2 : mw;          // pass 0: a column without a nonzero yet takes the tile's
-      sc = m > 0.f ? pick(m) : 1.f;
+      // pass 0: the first row says little about a SPARSE column (a ReLU channel: 6 % of EDSR's body columns stay zero
+      // throughout, others show one barely positive pixel in the first row and ordinary ones later), so no column is taken
+      // for more than 2^8 below the tile's maximum on that evidence: what follows may be 100 x larger than the tile's
+      // first row or 10^4 x smaller.  (The column's own first-row maximum alone -- the tile's for an all-zero one -- ran
+      // nearly every block of EDSR's body convs twice; and ONE flagged block costs the second pass a whole block's time.)
+      if (pass) sc = m2 > 0.f ? pick(m2) : 1.f;
+      else { const float m = fmaxf(m2, mw * 0x1p-8f); sc = m > 0.f ? pick(m) : 1.f; }
     }
     store(r0, g0);
     if (isB) {
@@ -1653,7 +1670,7 @@ __device__ __forceinline__ void tnb_body9s(const TnArgs& p, const int s, const i
     if (!pass) {
       aux[64 + sw * 64 + lane] = mxrun;            // pass 1 takes both halves' maxima from here
       const float top = mxrun * sc;
-      if (__any(top > 60000.f || (mxrun > 0.f && top < 0.5f)) && lane == 0) *(volatile int*)(smem + S9_RETRY) = 1;
+      if (__any(top > 60000.f || (mxrun > 0.f && top < 0.125f)) && lane == 0) *(volatile int*)(smem + S9_RETRY) = 1;
     }
     if (colsum && !isB) ((float*)(smem + S9_CS))[half * 64 + lane] = cs;
     __syncthreads();
@@ -1669,21 +1686,13 @@ __device__ __forceinline__ void tnb_body9s(const TnArgs& p, const int s, const i
   }
 }
 
-// PASS 0: one block per (slice, tile).  PASS 1 (its own instantiation: the loop around the body costs the first pass registers):
-// at most one resident block per CU walks the block list and runs the flagged ones again.
+// PASS 0: one block per (slice, tile).  PASS 1: the same grid again; a block whose flag is clear leaves at once (6 us for a
+// launch without a flagged block), the others run with exact exponents.
 template <int DBG = 0, int PASS = 0>
 __global__ void __launch_bounds__(S9_THREADS) k_tnb9s(TnArgs p, int tiles, int xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (PASS) {
-#pragma unroll 1
-    for (int L = blockIdx.x; L < p.S * tiles; L += gridDim.x) {
-      tnb_body9s<DBG>(p, L / tiles, L % tiles, tiles, 1, smem);
-      __syncthreads();
-    }
-    return;
-  }
   const int L = xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  tnb_body9s<DBG>(p, L / tiles, L % tiles, tiles, 0, smem);
+  tnb_body9s<DBG>(p, L / tiles, L % tiles, tiles, PASS, smem);
 }
 
 template <int DBG = 0, bool F16 = false>
@@ -1855,14 +1864,6 @@ __global__ void __launch_bounds__(S9_THREADS) k_tnb9s_conv_batched(TnbConvBatch 
     p.aux = g.base.aux + (long)k * g.base.S * g.tiles * S9_AUX;
     tnb_body9s<0>(p, sl, tile, g.tiles, PASS, smem);
   };
-  if (PASS) {                  // a resident grid walks the block list (see k_tnb9s)
-#pragma unroll 1
-    for (int L = blockIdx.x; L < g.base.S * g.tiles * g.n; L += gridDim.x) {
-      one(L);
-      __syncthreads();
-    }
-    return;
-  }
   one(g.xcd ? sr_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x);
 }
 
@@ -2032,7 +2033,7 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
     }
 #endif
     hipLaunchKernelGGL((k_tnb9s<0, 0>), dim3(p.S * tiles), dim3(S9_THREADS), S9_LDS, st, p, tiles, xcd);
-    hipLaunchKernelGGL((k_tnb9s<0, 1>), dim3(min(p.S * tiles, 256)), dim3(S9_THREADS), S9_LDS, st, p, tiles, xcd);
+    hipLaunchKernelGGL((k_tnb9s<0, 1>), dim3(p.S * tiles), dim3(S9_THREADS), S9_LDS, st, p, tiles, xcd);
     SR_LAUNCH_CHECK("k_tnb9s");
     return 0;
   }
@@ -2165,7 +2166,7 @@ int sr_conv_wgrad_batched_tnb(const TnArgs& base, const float* const* A, const f
       attr9s = true;
     }
     hipLaunchKernelGGL(k_tnb9s_conv_batched<0>, dim3(base.S * g.tiles * n), dim3(S9_THREADS), S9_LDS, st, g);
-    hipLaunchKernelGGL(k_tnb9s_conv_batched<1>, dim3(min(base.S * g.tiles * n, 256)), dim3(S9_THREADS), S9_LDS, st, g);
+    hipLaunchKernelGGL(k_tnb9s_conv_batched<1>, dim3(base.S * g.tiles * n), dim3(S9_THREADS), S9_LDS, st, g);
     SR_LAUNCH_CHECK("k_tnb9s_conv_batched");
     return 0;
   }
