@@ -514,7 +514,22 @@ def worker(args):
         barrier()
         eager_pps = args.batch * world * n_eager / (time.perf_counter() - t1)
         gpu_legs["eager_steps"] = time.perf_counter() - t_leg
+    # From here on the launches are IN ORDER on one stream (SwinIR: SRHIP_SWIN_SIDE_WGRAD=0 -- the timed steps ran a layer's
+    # weight gradients on a side stream beside the next layer's chain, round 6): a kernel that shares the chip with another
+    # stream's launch has no duration of its own, and the roofline below is a statement about ONE kernel.  The profiles under
+    # profiles/ are taken the same way (tools/refresh_profiles.sh exports the switch).
+    side_default = os.environ.get("SRHIP_SWIN_SIDE_WGRAD", "1") == "1" and args.workload == "swinir_x8"
+    eager_in_order_pps = None
     if not args.no_roofline:
+        os.environ["SRHIP_SWIN_SIDE_WGRAD"] = "0"
+        if use_graph and side_default:
+            ts.step(lr_img, hr_img)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n_eager):
+                ts.step(lr_img, hr_img)
+            barrier()
+            eager_in_order_pps = args.batch * world * n_eager / (time.perf_counter() - t1)
         t_leg = time.perf_counter()
         probe.enable(kinds)
         for _ in range(3):
@@ -614,6 +629,11 @@ def worker(args):
                        # `value` is measured on step_fn: graph replay when hip_graph is true; the same K-step protocol on eager
                        # steps (the methodology of rounds 1-4) beside it
                        "eager_patches_per_s": eager_pps,
+                       # SwinIR: the timed steps run each RSTB layer's weight gradients on a side stream; the same eager steps
+                       # with every launch in order on one stream -- the mode the roofline's per-launch durations (and the
+                       # profiles under profiles/) are taken in
+                       "side_stream_weight_gradients": bool(side_default),
+                       "eager_in_order_patches_per_s": eager_in_order_pps,
                        "droppath_masks": "per rank" if args.droppath_per_rank else "same on every rank (reference seeding)",
                        "eval_patches_per_s_one_gpu": eval_pps, "eval_amp_patches_per_s_one_gpu": eval_amp_pps,
                        "matmul": (("Linear GEMMs: fp16x2 split MFMA (2 fp16 planes per operand under per-row power-of-two "

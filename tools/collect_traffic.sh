@@ -8,6 +8,7 @@ WL=${2:-swinir_x8}
 ROOT=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export SRHIP_SWIN_SIDE_WGRAD=0     # launches in order on one stream: per-kernel counters are attributable (see refresh_profiles.sh)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$ROOT/$OUT/$c" -- \
     python3 "$ROOT/bench.py" --workload $WL --steps 2 --warmup 1 --train-only --no-roofline > "$ROOT/$OUT/$c.log" 2>&1

@@ -8,6 +8,10 @@ OUT=${2:-gpurun_out/prof_$WL}
 ROOT=$(pwd)
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+# per-kernel figures are taken with every launch IN ORDER on one stream (SwinIR: a layer's weight gradients otherwise run on a
+# side stream beside the next layer's chain, and kernels that share the chip have no duration of their own); bench.py probes
+# its roofline the same way
+export SRHIP_SWIN_SIDE_WGRAD=0
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/run" -- python3 "$ROOT/bench.py" --workload $WL --train-only > "$ROOT/$OUT/bench.json" 2> "$ROOT/$OUT/bench.err" || true
 cd "$ROOT"
 python3 tools/prof_summary.py "$OUT/run" 30 > "$OUT/rocprofv3_stats.txt"

@@ -6,6 +6,7 @@ OUT=${1:-gpurun_out/mfma_pmc}; WL=${2:-swinir_x8}
 ROOT=$(pwd)
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export SRHIP_SWIN_SIDE_WGRAD=0     # launches in order on one stream: per-kernel counters are attributable (see refresh_profiles.sh)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d "$ROOT/$OUT/sq" -- \
   python3 "$ROOT/bench.py" --workload $WL --steps 4 --warmup 2 --train-only --no-roofline > "$ROOT/$OUT/bench.log" 2>&1 || true
 cd "$ROOT"
