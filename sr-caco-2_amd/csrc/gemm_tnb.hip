@@ -1513,7 +1513,8 @@ __device__ __forceinline__ void tnb9s_consume(const TnArgs& p, const int s, cons
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int il = wi * 32 + mfma_row(q, lane), io = i0 + il;   // p.ps: kernel row sp*F + c is torch channel c*4 + sp
-      out[(long)(p.ps ? (io % ps_f) * 4 + io / ps_f : io) * p.NJ + j0 + col] = acc[u][q] * (sinv[il] * ib);
+      if (io < p.NI && j0 + col < p.NJ)
+        out[(long)(p.ps ? (io % ps_f) * 4 + io / ps_f : io) * p.NJ + j0 + col] = acc[u][q] * (sinv[il] * ib);
     }
   }
 }
@@ -1530,8 +1531,8 @@ __device__ __forceinline__ void tnb_body9s(const TnArgs& p, const int s, const i
   // pass 1 (the same grid right behind pass 0): only the blocks whose exponents did not hold run again, with exact ones
   if (pass && !__builtin_amdgcn_readfirstlane(*(const int*)aux)) return;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nbj = p.NJ / 64;
-  const int bi = tile / nbj, bj = tile - bi * nbj;
+  const int nbj = (p.NJ + 63) / 64;                // channel counts that are no multiple of 64: the last tile's columns beyond
+  const int bi = tile / nbj, bj = tile - bi * nbj; // NI / NJ are zeros in the planes and are not written
   const int i0 = bi * 64, j0 = bj * 64;
   // slice -> (strip, row range of the flattened (image, y) index)
   // strip k owns the slices [k S / nstrips, (k + 1) S / nstrips): at least one each (S >= nstrips)
@@ -1566,6 +1567,7 @@ __device__ __forceinline__ void tnb_body9s(const TnArgs& p, const int s, const i
     colb = (unsigned)((((sp >> 1) * 2 * p.Wd + (sp & 1)) * (int)p.lda + cc) * 4);
   }
   const bool psA = !isB && p.ps;
+  const bool lane_ok = isB ? j0 + lane < p.NJ : i0 + lane < p.NI;       // the lane's column exists
   const float* const P = isB ? p.B + j0 : (p.ps ? p.A : p.A + i0);      // uniform
   const long ld = isB ? p.ldb : p.lda;
   const long adv = psA ? 2 * ld : ld;              // floats between consecutive tokens of a row
@@ -1580,10 +1582,10 @@ __device__ __forceinline__ void tnb_body9s(const TnArgs& p, const int s, const i
       const float* q = P + (tok + (psA ? 2 : 1) * (x0 + 32 * half)) * ld;
 #pragma unroll
       for (int t = 0; t < 32; ++t) {
-        g.v[t] = ColVec<1>::ldg(q, colb);
+        g.v[t] = lane_ok ? ColVec<1>::ldg(q, colb) : 0.f;
         q += adv;
       }
-      g.halo = halo_ok ? ColVec<1>::ldg(P + (tok + (psA ? 2 : 1) * hx) * ld, colb) : 0.f;
+      g.halo = (halo_ok && lane_ok) ? ColVec<1>::ldg(P + (tok + (psA ? 2 : 1) * hx) * ld, colb) : 0.f;
     } else {
 #pragma unroll
       for (int t = 0; t < 32; ++t) g.v[t] = 0.f;
@@ -1678,7 +1680,7 @@ __device__ __forceinline__ void tnb_body9s(const TnArgs& p, const int s, const i
   }
   if (colsum) {
     __syncthreads();
-    if (sw == 0) {
+    if (sw == 0 && lane_ok) {
       const float* c2 = (const float*)(smem + S9_CS);
       const int io = i0 + lane;
       p.part_colsum[(long)s * p.NI + (p.ps ? (io % ps_f) * 4 + io / ps_f : io)] = c2[lane] + c2[64 + lane];
@@ -1886,16 +1888,6 @@ bool tnb_t9_shape(int conv, int NI, int NJ, int w) {
   return on && f16 && tnb_t3_shape(conv, NI, NJ, w);
 }
 bool tnb_t9_ok(const TnArgs& p, int w) { return tnb_t9_shape(p.conv, p.NI, p.NJ, w) && tnb_t3_ok(p, w); }
-// the strip form of it (tnb_body9s): image width a multiple of 64, at least one slice per strip, four rows per slice.  SRHIP_TN_T9S=0
-// (experiments build): the token-order form
-bool tnb_t9s_ok(const TnArgs& p, int w) {
-#ifdef SR_TN_T9S_OFF
-  return false;                                    // build variant for the same-box A/B (make EXTRA=-DSR_TN_T9S_OFF)
-#endif
-  static const int on = [] { const char* e = sr_getenv("SRHIP_TN_T9S"); return !(e && e[0] == '0'); }();
-  return on && tnb_t9_ok(p, w) && p.Wd % 64 == 0 && p.S >= p.Wd / 64 &&
-         (long)p.batch * p.H * (p.Wd / 64) >= 4L * p.S;      // a slice of fewer than four rows stages more halo rows than rows
-}
 // two fp16 planes / three products in the three-tap kernels (default); SRHIP_TN_F16X2=0: three bf16 planes / six products
 bool tnb_f16() {
   static const int on = [] { const char* e = sr_getenv("SRHIP_TN_F16X2"); return !(e && e[0] == '0'); }();
@@ -1918,6 +1910,28 @@ int pick_w(int NI, int NJ, int* tile) {
   *tile = wi == wj ? ti : (w == 3 ? 192 : 64 * w);        // equal classes keep 180-wide tiles for 180 / 360 / 540
   if (wi == wj && ti != tj) *tile = 64 * w;
   return w;
+}
+
+// The strip form of the nine-tap block (tnb_body9s): image width a multiple of 64, at least one slice per strip, four rows per
+// slice.  Channel counts: every conv of at least 64 channels on either side, in 64-column tiles -- the last one partly empty
+// where a count is no multiple of 64.  Against the one-tap-per-block kernels of the wider tiles (launch + reducer, 8 x 64 x 64,
+// same box): 180 -> 180 114 -> 90 us, 180 -> 64 107 -> 66, 128 -> 128 85 -> 60 (8 x 128 x 128: 262 -> 142), 256 -> 256
+// 247 -> 137, 192 -> 192 107 -> 90, 96 -> 96 75 -> 57.  SRHIP_TN_T9S=0 / SRHIP_TN_T9S_RAGGED=0 (experiments build): off /
+// multiples of 64 only.
+bool tnb_t9s_shape(int conv, int NI, int NJ) {
+#ifdef SR_TN_T9S_OFF
+  return false;                                    // build variant for the same-box A/B (make EXTRA=-DSR_TN_T9S_OFF)
+#endif
+  static const int on = [] { const char* e = sr_getenv("SRHIP_TN_T9S"); return !(e && e[0] == '0'); }();
+  static const int ragged = [] { const char* e = sr_getenv("SRHIP_TN_T9S_RAGGED"); return e ? atoi(e) : 1; }();
+  if (!on || !tnb_f16() || !conv) return false;
+  int t;
+  if (tnb_t9_shape(conv, NI, NJ, pick_w(NI, NJ, &t))) return true;
+  return ragged && NI >= 64 && NJ >= 64;
+}
+bool tnb_t9s_ok(const TnArgs& p) {
+  return tnb_t9s_shape(p.conv, p.NI, p.NJ) && !p.a_rowscale && p.b_mode == 0 && p.Wd % 64 == 0 && p.S >= p.Wd / 64 &&
+         (long)p.batch * p.H * (p.Wd / 64) >= 4L * p.S;      // a slice of fewer than four rows stages more halo rows than rows
 }
 
 template <typename K>
@@ -2011,11 +2025,13 @@ int sr_gemm_tnb(TnArgs& p, hipStream_t st) {
              "conv3x3_wgrad + PixelShuffle(2): Cout/4 = %d must be a multiple of %d (columns per lane), Cout of the tile", p.NI / 4, w);
   const int rps = sr_cdiv(p.M, p.S);
   p.rows_per_slice = (rps + TKB - 1) / TKB * TKB;
-  const int tiles = sr_cdiv(p.NI, p.i_tile) * sr_cdiv(p.NJ, p.j_tile);
+  int tiles = sr_cdiv(p.NI, p.i_tile) * sr_cdiv(p.NJ, p.j_tile);
   dim3 grid(p.S, tiles, 1);
   if (p.conv) grid = dim3(p.S * tiles * 9, 1, 1);
   static const int xcd = [] { const char* e = sr_getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
-  if (tnb_t9s_ok(p, w)) {      // 64-wide conv problem, image width a multiple of 64: nine taps per block, strip walk
+  if (tnb_t9s_ok(p) && (!p.ps || p.NI % 64 == 0)) {      // nine taps per block, strip walk, 64-column tiles
+    p.i_tile = p.j_tile = 64;
+    tiles = sr_cdiv(p.NI, 64) * sr_cdiv(p.NJ, 64);
     p.aux = p.part + (long)p.S * 9 * p.NI * p.NJ;          // (sr_tn_plan_bx3 sized the workspace for it)
     static bool attr9s = false;
     if (!attr9s) {
@@ -2116,7 +2132,9 @@ int sr_conv_wgrad_batched_plan(int n, int M, int NI, int NJ, int* S, long* part_
   int tile;
   const int w = pick_w(NI, NJ, &tile);
   const bool t3 = tnb_t3_shape(1, NI, NJ, w);             // three taps per block
-  const bool t9 = tnb_t9_shape(1, NI, NJ, w);             // nine: one block per (tile, slice), one block per CU
+  const bool t9s = tnb_t9s_shape(1, NI, NJ);
+  const bool t9 = t9s || tnb_t9_shape(1, NI, NJ, w);      // nine: one block per (tile, slice), one block per CU
+  if (t9s) tile = 64;
   const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * (t9 ? 1 : (t3 ? 3 : 9)) * n;
   // Blocks in flight: 3 per CU for 64-wide tiles (49 KB of LDS each), else 1.  The slice count is chosen
   // for WHOLE rounds of blocks -- 33 problems x 9 taps x 3 slices = 891 blocks on 768 slots ran 1.16
@@ -2157,7 +2175,9 @@ int sr_conv_wgrad_batched_tnb(const TnArgs& base, const float* const* A, const f
   for (int k = 0; k < n; ++k) { g.A[k] = A[k]; g.B[k] = B[k]; }
   static const int xcd = [] { const char* e = sr_getenv("SRHIP_TN_XCD"); return !(e && e[0] == '0'); }();
   g.xcd = xcd;
-  if (tnb_t9s_ok(g.base, w)) { // all nine taps per block, strip walk
+  if (tnb_t9s_ok(g.base)) {    // all nine taps per block, strip walk
+    g.base.i_tile = g.base.j_tile = 64;
+    g.tiles = sr_cdiv(base.NI, 64) * sr_cdiv(base.NJ, 64);
     g.base.aux = base.part + (long)n * part_stride;        // behind the n problems' partial sums (the plan sized it)
     static bool attr9s = false;
     if (!attr9s) {
@@ -2214,7 +2234,9 @@ int sr_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats) {
   int tile;
   const int w = pick_w(NI, NJ, &tile);
   const bool t3 = tnb_t3_shape(conv, NI, NJ, w);          // three taps per block
-  const bool t9 = tnb_t9_shape(conv, NI, NJ, w);          // nine taps per block, one block per CU
+  const bool t9s = tnb_t9s_shape(conv, NI, NJ);           // nine taps per block in 64-column tiles, one block per CU
+  const bool t9 = t9s || tnb_t9_shape(conv, NI, NJ, w);   // (the slice count of a shape is the strip form's also where an image
+  if (t9s) tile = 64;                                     //  width sends the call to another kernel: the plan does not see it)
   const long tiles = (long)sr_cdiv(NI, tile) * sr_cdiv(NJ, tile) * (conv ? (t9 ? 1 : (t3 ? 3 : 9)) : 1);
   static const long t1 = [] { const char* e = sr_getenv("SRHIP_TNB_BLOCKS_W1"); return e ? atol(e) : 768L; }();
   static const long t3b = [] { const char* e = sr_getenv("SRHIP_TNB_BLOCKS_T3"); return e ? atol(e) : 768L; }();

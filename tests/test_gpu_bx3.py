@@ -282,7 +282,11 @@ def _row_relerr(dW, ref):
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co,ps2", [(1, 5, 64, 64, 64, False), (2, 7, 128, 64, 64, False), (3, 4, 64, 64, 256, True),
-                                              (1, 9, 192, 64, 256, True), (2, 33, 64, 64, 128, False), (1, 3, 256, 128, 64, False)])
+                                              (1, 9, 192, 64, 256, True), (2, 33, 64, 64, 128, False), (1, 3, 256, 128, 64, False),
+                                              # channel counts that are no multiple of 64 (SwinIR's convs): the last 64-column
+                                              # tile is partly empty
+                                              (2, 6, 64, 180, 180, False), (1, 5, 128, 180, 64, False), (2, 4, 64, 64, 180, False),
+                                              (1, 8, 64, 128, 96, False), (1, 4, 64, 100, 256, True), (2, 5, 128, 68, 72, False)])
 def test_conv_wgrad_strip_form(ops, B, H, W, Ci, Co, ps2):
     """The strip form of the nine-tap conv weight gradient (k_tnb9s: image width a multiple of 64; dY staged once per row with
     a one-pixel halo and shifted in registers, X rows kept in a ring): several strips (the halo comes from the neighbour
