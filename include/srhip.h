@@ -328,7 +328,11 @@ int srhip_conv3x3_wgrad(const float* dY, long lddy, const float* X, long ldx, in
  * operands (see srhip_gemm_nt_bx3): same arguments, alignment rules, slicing and
  * reducers; plan S with the _bx3 planners (one 8-wave block per CU).  The 3x3 conv forms with Cout and Cin multiples of
  * 64 (three taps per block) split their operands into TWO fp16 planes under a running power-of-two scale per operand
- * column and issue three products -- same f32-grade sums; SRHIP_TN_F16X2=0 in the environment: three bf16 planes, six. */
+ * column and issue three products -- same f32-grade sums; SRHIP_TN_F16X2=0 in the environment: three bf16 planes, six.
+ * Round 6: 3x3 conv problems of at least 64 channels on either side, on images whose width is a multiple of 64, run in the
+ * strip form (all nine taps per block, power-of-two scales fixed per block, a second pass for the blocks whose guess did not
+ * hold); part_floats of the conv plan is the partial sums [S][9][NI][NJ] PLUS that kernel's per-block words behind them --
+ * allocate what the plan says, the reducers read the first S*9*NI*NJ floats. */
 int srhip_tn_plan_bx3(int M, int NI, int NJ, int conv, int* S, long* part_floats);
 int srhip_tn_group_plan_bx3(int M, int ntiles, int* S);
 int srhip_gemm_tn_bx3(const float* A, long lda, const float* B, long ldb, int M, int NI, int NJ,
@@ -750,7 +754,8 @@ int srhip_metrics_ssim(const float* E, const float* Hh, int B, int H, int W, int
  * EDSR-style stack (network_nlsn.py:72-93,325-345 backward) -- in one contraction launch plus one
  * reducer launch: item k: dW_k[Cout][Cin][3][3] = sum_px dY_k (x) shifted X_k, db_k = sum_px dY_k.
  * items is a HOST array; part / part_colsum hold n * part_floats_per_item and n * S * Cout floats
- * (srhip_conv3x3_wgrad_batched_plan).  bf16x3 split MFMA (f32-accurate). */
+ * (srhip_conv3x3_wgrad_batched_plan; item k's partial sums start at part + k * S*9*Cout*Cin, the strip-form kernel's
+ * per-block words of all items sit behind the n-th item's).  fp16x2 / bf16x3 split MFMA (f32-accurate). */
 typedef struct { const float* dY; const float* X; float* dW; float* db; } srhip_conv_wgrad_item;
 int srhip_conv3x3_wgrad_batched_plan(int n, int B, int H, int W, int Cout, int Cin, int* S,
                                      long* part_floats_per_item);

@@ -63,7 +63,8 @@ def test_plan_queries_need_no_gpu():
     S, n = ops.tn_plan(32768, 180, 180)
     assert S >= 1 and n == S * 180 * 180
     S9, n9 = ops.tn_plan(32768, 180, 180, conv=True)
-    assert n9 == S9 * 9 * 180 * 180
+    # the nine taps' partial sums + the strip-form kernel's per-block words (320 floats for each of the 3 x 3 64-column tiles)
+    assert n9 == S9 * 9 * 180 * 180 + S9 * 9 * 320
 
 
 def test_cpu_tensors_fail_loudly():
