@@ -1501,7 +1501,8 @@ __device__ __forceinline__ void tnb9s_consume(const TnArgs& p, const int s, cons
       __syncthreads();
       y = (y + 1 == p.H) ? 0 : y + 1;
     }
-    __syncthreads();                                 // the staging waves' 2^-s
+    __syncthreads();                                 // the staging waves' 2^-s and maxima
+    __syncthreads();                                 // (their verdict on the exponents)
   }
   const float* sinv = (const float*)(smem + S9_SINV);
   const int col = wj * 32 + r;
@@ -1520,7 +1521,7 @@ __device__ __forceinline__ void tnb9s_consume(const TnArgs& p, const int s, cons
 }
 
 // words per block behind the partial sums (S9_AUX floats each): [0] = 1 if some column's exponent did not hold in pass 0,
-// [64 ..): the four staging waves' column maxima
+// [1 .. 4] = why, per staging wave (1: a column overflowed, 2: one fell below the resolution), [64 ..): their column maxima
 constexpr int S9_AUX = 64 + 4 * 64;
 
 template <int DBG = 0>
@@ -1669,12 +1670,19 @@ __device__ __forceinline__ void tnb_body9s(const TnArgs& p, const int s, const i
       __syncthreads();
     }
     if (half == 0) ((float*)(smem + S9_SINV))[(isB ? 64 : 0) + lane] = 1.0f / sc;
-    if (!pass) {
-      aux[64 + sw * 64 + lane] = mxrun;            // pass 1 takes both halves' maxima from here
-      const float top = mxrun * sc;
-      if (__any(top > 60000.f || (mxrun > 0.f && top < 0.125f)) && lane == 0) *(volatile int*)(smem + S9_RETRY) = 1;
-    }
+    mxs[sw * 64 + lane] = mxrun;
     if (colsum && !isB) ((float*)(smem + S9_CS))[half * 64 + lane] = cs;
+    __syncthreads();
+    if (!pass) {
+      // did the guess hold?  By the column's maximum over BOTH halves of the strip's rows (a half whose own pixels are all
+      // tiny is below the column's resolution rightly)
+      aux[64 + sw * 64 + lane] = mxrun;            // pass 1 takes both halves' maxima from here
+      const float mcol = fmaxf(mxrun, mxs[(sw ^ 1) * 64 + lane]);
+      const float top = mcol * sc;
+      const bool over = __any(top > 60000.f), under = __any(mcol > 0.f && top < 0.125f);
+      if ((over || under) && lane == 0) *(volatile int*)(smem + S9_RETRY) = 1;
+      if (lane == 0) ((int*)aux)[1 + sw] = (over ? 1 : 0) | (under ? 2 : 0);      // (for tools/t9s_retry_stats.py: which wave, why)
+    }
     __syncthreads();
     if (!pass && sw == 0 && lane == 0) *(int*)aux = *(volatile const int*)(smem + S9_RETRY);
   }

@@ -40,3 +40,15 @@ for name, m in (("dY", dy), ("X", x)):
           " < 1e-2:", int(((rel < 1e-2) & (m > 0)).sum()), "of", m.numel())
     print("   per item (flagged slices / zero cols / cols < 1e-2 of tile max):",
           [(int((flags[k] != 0).sum()), int((m[k] == 0).sum()), int(((rel[k] < 1e-2) & (m[k] > 0)).sum())) for k in range(n)])
+# details of the flagged blocks: every column's maximum relative to the tile's
+for k in range(n):
+    for sl in range(S):
+        if flags[k, sl] != 0:
+            print(f"item {k} slice {sl}: why (staging waves dY lo / dY hi / X lo / X hi; 1 = overflow, 2 = below resolution):",
+                  aux[k, sl, 1:5].view(torch.int32).tolist())
+            for name, m in (("dY", dy[k, sl]), ("X", x[k, sl])):
+                t = m.max().item()
+                srt = torch.sort(m)[0]
+                nz = srt[srt > 0]
+                print(f"item {k} slice {sl} {name}: tile max {t:.3e}, zero cols {int((m == 0).sum())}, smallest nonzero / tile max "
+                      f"{(nz[0] / t).item():.2e} {(nz[1] / t).item():.2e} {(nz[2] / t).item():.2e}, largest {(srt[-1] / t).item():.2f} {(srt[-2] / t).item():.2f}")
