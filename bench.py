@@ -518,7 +518,8 @@ def worker(args):
     # weight gradients on a side stream beside the next layer's chain, round 6): a kernel that shares the chip with another
     # stream's launch has no duration of its own, and the roofline below is a statement about ONE kernel.  The profiles under
     # profiles/ are taken the same way (tools/refresh_profiles.sh exports the switch).
-    side_default = os.environ.get("SRHIP_SWIN_SIDE_WGRAD", "1") == "1" and args.workload == "swinir_x8"
+    side_env = os.environ.get("SRHIP_SWIN_SIDE_WGRAD")
+    side_default = (side_env or "1") == "1" and args.workload == "swinir_x8"
     eager_in_order_pps = None
     if not args.no_roofline:
         os.environ["SRHIP_SWIN_SIDE_WGRAD"] = "0"
@@ -544,6 +545,11 @@ def worker(args):
             break
     roof = probe.collect() if not args.no_roofline else None
     probe.disable()
+    if not args.no_roofline:                 # what follows (config.secondary) runs the product's default again
+        if side_env is None:
+            os.environ.pop("SRHIP_SWIN_SIDE_WGRAD", None)
+        else:
+            os.environ["SRHIP_SWIN_SIDE_WGRAD"] = side_env
     steps_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
 
     def pct(q):
